@@ -1,0 +1,163 @@
+/*
+ * mi355x_kernels.h -- C ABI of the MI355X (gfx950 / CDNA4) kernel library
+ * (libmi355x_kernels.so) behind the PETSc HIPMI355X Vec/Mat implementations.
+ *
+ * Plain C: raw device pointers, sizes, an opaque handle that owns one HIP
+ * stream.  No PETSc types, no torch types.  Every function returns 0 on
+ * success or a non-zero hipError_t value (mi355x_error_string() decodes it);
+ * nothing throws, nothing exits.  PetscScalar = double, PetscInt = int32
+ * (reference: include/petscsys.h:188, include/petscmath.h:198).
+ *
+ * Each entry cites the reference CPU routine it replaces (path relative to
+ * the PETSc tree, erdc/petsc-dev 3.3.0-dev).  Floating-point contract: all
+ * kernels are compiled with -ffp-contract=off, i.e. a*b+c is a rounded
+ * multiply followed by a rounded add, exactly what the reference's C loops
+ * do when built without FMA.  Element-wise kernels and the row-sequential
+ * SpMV paths therefore reproduce the reference bit for bit; reductions use
+ * a fixed tree (run-to-run reproducible) and agree to a stated tolerance.
+ */
+#ifndef MI355X_KERNELS_H
+#define MI355X_KERNELS_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mi355x_handle_s    *mi355x_handle_t;    /* one HIP stream + reduction workspace */
+typedef struct mi355x_event_s     *mi355x_event_t;     /* hipEvent_t */
+typedef struct mi355x_spmv_plan_s *mi355x_spmv_plan_t; /* row-block partition of one CSR matrix */
+typedef struct mi355x_bsr_plan_s  *mi355x_bsr_plan_t;
+
+/* ---- runtime --------------------------------------------------------- */
+const char *mi355x_error_string(int err);
+int  mi355x_device_count(int *count);
+int  mi355x_set_device(int dev);
+int  mi355x_get_device(int *dev);
+int  mi355x_device_name(char *buf, size_t len);
+int  mi355x_device_synchronize(void);
+
+int  mi355x_handle_create(mi355x_handle_t *h);
+int  mi355x_handle_destroy(mi355x_handle_t h);
+int  mi355x_handle_synchronize(mi355x_handle_t h);
+void *mi355x_handle_stream(mi355x_handle_t h);           /* the raw hipStream_t */
+/* pinned, device-visible scratch of >= 64 doubles owned by the handle
+ * (reduction results are written here by the device, read by the host
+ * after mi355x_handle_synchronize) */
+double *mi355x_handle_host_scratch(mi355x_handle_t h);
+double *mi355x_handle_device_scratch(mi355x_handle_t h);  /* >= 64 doubles in HBM */
+
+int  mi355x_malloc(void **dptr, size_t bytes);
+int  mi355x_free(void *dptr);
+int  mi355x_host_malloc(void **hptr, size_t bytes);      /* pinned + device-mapped */
+int  mi355x_host_free(void *hptr);
+int  mi355x_memcpy_h2d(mi355x_handle_t h, void *dst, const void *src, size_t bytes); /* async on h */
+int  mi355x_memcpy_d2h(mi355x_handle_t h, void *dst, const void *src, size_t bytes); /* async on h */
+int  mi355x_memcpy_d2d(mi355x_handle_t h, void *dst, const void *src, size_t bytes); /* async on h */
+int  mi355x_memset(mi355x_handle_t h, void *dst, int byte, size_t bytes);
+
+int  mi355x_event_create(mi355x_event_t *e);
+int  mi355x_event_destroy(mi355x_event_t e);
+int  mi355x_event_record(mi355x_event_t e, mi355x_handle_t h);
+int  mi355x_event_synchronize(mi355x_event_t e);
+int  mi355x_event_elapsed_ms(mi355x_event_t start, mi355x_event_t stop, float *ms);
+int  mi355x_handle_wait_event(mi355x_handle_t h, mi355x_event_t e);  /* hipStreamWaitEvent */
+
+/* ---- Vec element-wise kernels (24-32 B/element, HBM-bound) ------------ */
+/* VecSet_Seq          src/vec/vec/impls/seq/dvec2.c:722      x[i] = alpha */
+int mi355x_vec_set(mi355x_handle_t h, size_t n, double alpha, double *x);
+/* VecCopy_Seq         src/vec/vec/impls/seq/bvec2.c:464      y = x */
+int mi355x_vec_copy(mi355x_handle_t h, size_t n, const double *x, double *y);
+/* VecScale_Seq        src/vec/vec/impls/seq/bvec1.c:183      x *= alpha (dscal) */
+int mi355x_vec_scale(mi355x_handle_t h, size_t n, double alpha, double *x);
+/* VecSwap_Seq         src/vec/vec/impls/seq/bvec2.c:519 */
+int mi355x_vec_swap(mi355x_handle_t h, size_t n, double *x, double *y);
+/* VecAXPY_Seq         src/vec/vec/impls/seq/bvec1.c:244      y += alpha x (daxpy) */
+int mi355x_vec_axpy(mi355x_handle_t h, size_t n, double alpha, const double *x, double *y);
+/* VecAYPX_Seq         src/vec/vec/impls/seq/dvec2.c:971      y = x + alpha y */
+int mi355x_vec_aypx(mi355x_handle_t h, size_t n, double alpha, const double *x, double *y);
+/* VecAXPBY_Seq        src/vec/vec/impls/seq/bvec1.c:320      y = alpha x + beta y */
+int mi355x_vec_axpby(mi355x_handle_t h, size_t n, double alpha, double beta, const double *x, double *y);
+/* VecWAXPY_Seq        src/vec/vec/impls/seq/dvec2.c:1082     w = y + alpha x */
+int mi355x_vec_waxpy(mi355x_handle_t h, size_t n, double alpha, const double *x, const double *y, double *w);
+/* VecAXPBYPCZ_Seq     src/vec/vec/impls/seq/bvec1.c:418      z = alpha x + beta y + gamma z */
+int mi355x_vec_axpbypcz(mi355x_handle_t h, size_t n, double alpha, double beta, double gamma,
+                        const double *x, const double *y, double *z);
+/* VecPointwiseMult_Seq   src/vec/vec/impls/seq/bvec2.c:234   w = x .* y (w may alias x or y) */
+int mi355x_vec_pointwise_mult(mi355x_handle_t h, size_t n, const double *x, const double *y, double *w);
+/* VecPointwiseDivide_Seq src/vec/vec/impls/seq/bvec2.c:298   w = x ./ y */
+int mi355x_vec_pointwise_divide(mi355x_handle_t h, size_t n, const double *x, const double *y, double *w);
+/* VecReciprocal_Default  src/vec/vec/utils/vinv.c            x[i] = 1/x[i] where x[i] != 0 */
+int mi355x_vec_reciprocal(mi355x_handle_t h, size_t n, double *x);
+/* PCSetUp_Jacobi host loop  src/ksp/pc/impls/jacobi/jacobi.c:182-190  d = (d==0) ? 1 : 1/d, done on device */
+int mi355x_vec_jacobi_invert(mi355x_handle_t h, size_t n, double *d, int *nzero_dev);
+/* VecMAXPY_Seq        src/vec/vec/impls/seq/dvec2.c:836      x += sum_j alpha[j] y_j ; grouping
+ * (nv%4 first, then fours) and left-to-right product sums follow petscaxpy.h:101-110.
+ * y: host array of nv device pointers; alpha: host array. */
+int mi355x_vec_maxpy(mi355x_handle_t h, size_t n, int nv, const double *alpha, const double *const *y, double *x);
+
+/* ---- Vec reductions (8-16 B/element) ---------------------------------- */
+/* Results are written to `out` (device-accessible: HBM or pinned host memory) when the
+ * kernel completes on the handle's stream; the caller synchronises.  Two-level
+ * fixed-shape tree: per-lane strided partial -> wavefront shuffle -> LDS -> per-block
+ * partial -> last-arriving block sums the per-block partials in block order. */
+/* VecDot_Seq/VecTDot_Seq  src/vec/vec/impls/seq/bvec1.c:57,122   out[0] = sum x_i y_i */
+int mi355x_vec_dot(mi355x_handle_t h, size_t n, const double *x, const double *y, double *out);
+/* VecNorm_Seq         src/vec/vec/impls/seq/bvec2.c:605
+ * type 0: NORM_1 -> out[0]=sum|x|; 1: NORM_2 -> out[0]=sum x^2 (caller takes sqrt, as pvec2.c:62 does);
+ * 3: NORM_INFINITY -> out[0]=max|x| (NaN propagates, bvec2.c:628-630); 4: NORM_1_AND_2 -> out[0]=sum|x|, out[1]=sum x^2 */
+int mi355x_vec_norm(mi355x_handle_t h, size_t n, int type, const double *x, double *out);
+/* VecDotNorm2 (BiCGStab)  src/vec/vec/utils/vinv.c:1200   out[0] = sum s_i t_i, out[1] = sum t_i^2 */
+int mi355x_vec_dotnorm2(mi355x_handle_t h, size_t n, const double *s, const double *t, double *out);
+/* VecMDot_Seq         src/vec/vec/impls/seq/dvec2.c:146     out[j] = sum_i x_i y_j,i , j<nv ; x read once per 8 y's */
+int mi355x_vec_mdot(mi355x_handle_t h, size_t n, int nv, const double *x, const double *const *y, double *out);
+/* VecSum / VecMax helpers are not on the Krylov path and are not provided. */
+
+/* ---- CSR SpMV (MatMult_SeqAIJ family) --------------------------------- */
+/* Analysis: partitions rows into row blocks (<= MI355X_SPMV_BLOCK_NNZ nonzeros staged
+ * through LDS per workgroup).  ai_host is the host copy of the row pointer (m+1 ints).
+ * If rows_host != NULL the matrix is in compressed-row form (reference:
+ * src/mat/utils/compressedrow.c:28): ai_host has nrows+1 entries and rows_host[k]
+ * is the output row of compressed row k (device copy kept in the plan). */
+int mi355x_spmv_plan_create(mi355x_handle_t h, int nrows, const int *ai_host, const int *rows_host,
+                            mi355x_spmv_plan_t *plan);
+int mi355x_spmv_plan_destroy(mi355x_spmv_plan_t plan);
+int mi355x_spmv_plan_info(mi355x_spmv_plan_t plan, int *nblocks, int *nlong, size_t *workspace_bytes);
+/* MatMult_SeqAIJ      src/mat/impls/aij/seq/aij.c:1225 (loop 1269-1277, macro aij.h:383-386)
+ *   y[r] = sum_k a[k] x[j[k]], products summed in k order starting from 0.0 */
+int mi355x_spmv_csr(mi355x_handle_t h, mi355x_spmv_plan_t plan, const int *ai, const int *aj,
+                    const double *aa, const double *x, double *y);
+/* MatMultAdd_SeqAIJ   src/mat/impls/aij/seq/aij.c:1291   z[r] = y[r] + sum_k ... (sum starts from y[r]);
+ * z may alias y.  With a compressed-row plan only the listed rows are touched (z must alias y
+ * or already hold y, as aij.c:1314-1316 arranges). */
+int mi355x_spmv_csr_add(mi355x_handle_t h, mi355x_spmv_plan_t plan, const int *ai, const int *aj,
+                        const double *aa, const double *x, const double *y, double *z);
+/* MatMultTranspose[Add]_SeqAIJ  src/mat/impls/aij/seq/aij.c:1078-1135 is served by the same two
+ * kernels applied to an explicit transpose whose rows list contributions in increasing
+ * original-row order (the order the reference's scatter loop adds them in). */
+
+/* MatGetDiagonal_SeqAIJ  src/mat/impls/aij/seq/aij.c:1040   d[r] = A[r,r] or 0 */
+int mi355x_csr_get_diagonal(mi355x_handle_t h, int m, const int *ai, const int *aj, const double *aa, double *d);
+
+/* ---- BCSR SpMV (MatMult_SeqBAIJ_3/_4/_N) ------------------------------- */
+/* src/mat/impls/baij/seq/baij2.c:331 (bs=3), :387 (bs=4), :981 (N); blocks column-major */
+int mi355x_spmv_bsr(mi355x_handle_t h, int mbs, int bs, const int *ai, const int *aj,
+                    const double *aa, const double *x, double *y);
+
+/* ---- halo pack / unpack (VecScatter) ---------------------------------- */
+/* Pack_1    src/vec/vec/utils/vpscat.c:493   buf[k] = x[idx[k]] */
+int mi355x_pack(mi355x_handle_t h, size_t n, const int *idx, const double *x, double *buf);
+/* UnPack_1  src/vec/vec/utils/vpscat.c:503   INSERT: y[idx[k]] = buf[k]; ADD: y[idx[k]] += buf[k]
+ * (idx == NULL means contiguous: y[k]).  ADD requires idx entries to be distinct within one call. */
+int mi355x_unpack_insert(mi355x_handle_t h, size_t n, const int *idx, const double *buf, double *y);
+int mi355x_unpack_add(mi355x_handle_t h, size_t n, const int *idx, const double *buf, double *y);
+
+/* ---- measurement ------------------------------------------------------- */
+/* STREAM-style copy (pattern: src/benchmarks/streams/CUDAVersion.cu) for the achievable-bandwidth line */
+int mi355x_stream_triad(mi355x_handle_t h, size_t n, double alpha, const double *b, const double *c, double *a);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

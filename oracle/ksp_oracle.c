@@ -1,0 +1,415 @@
+/*
+ * ksp_oracle.c -- TEST INFRASTRUCTURE (see oracle.h).  Sequential restatement of the reference's
+ * KSPSolve for CG, GMRES(m) and BiCGStab with none / Jacobi / block-Jacobi preconditioning, built on
+ * the orc_* Vec and SeqAIJ restatements (left preconditioning, preconditioned residual norm,
+ * KSPDefaultConverged -- the defaults the reference's golden outputs were produced with).
+ */
+#include "oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* KSPConvergedReason values, include/petscksp.h */
+#define R_ITERATING 0
+#define R_CONVERGED_RTOL 2
+#define R_CONVERGED_ATOL 3
+#define R_CONVERGED_ITS 4
+#define R_DIVERGED_NULL (-2)
+#define R_DIVERGED_ITS (-3)
+#define R_DIVERGED_DTOL (-4)
+#define R_DIVERGED_BREAKDOWN (-5)
+#define R_DIVERGED_INDEFINITE_PC (-8)
+#define R_DIVERGED_NAN (-9)
+#define R_DIVERGED_INDEFINITE_MAT (-10)
+
+typedef struct solver_s {
+  int ksp_type, pc_type;
+  double rtol, abstol, dtol;
+  int max_it, restart, refine_always, guess_nonzero;
+  int n;
+  const int *ai, *aj;
+  const double *aa;
+  double *idiag;              /* Jacobi: 1/diag (0 -> 1), PCSetUp_Jacobi jacobi.c:170-190 */
+  int nblocks;
+  const int *blk;
+  struct solver_s *sub;       /* block Jacobi sub-solvers */
+  int **sbi, **sbj; double **sba;
+  /* convergence state (KSPDefaultConverged, iterativ.c:702) */
+  double rnorm0, ttol;
+  int its, reason;
+  double *hist; int hist_cap, nhist;
+} solver;
+
+void orc_ksp_default_opts(orc_ksp_opts *o) {
+  memset(o, 0, sizeof(*o));
+  o->ksp_type = ORC_KSP_GMRES; o->pc_type = ORC_PC_NONE;
+  o->rtol = 1e-5; o->abstol = 1e-50; o->dtol = 1e4; o->max_it = 10000;   /* itcreate.c:662-666 */
+  o->restart = 30;                                                        /* gmresimpl.h GMRES_DEFAULT_MAXK */
+  o->sub_ksp_type = ORC_KSP_PREONLY; o->sub_pc_type = ORC_PC_JACOBI;
+  o->sub_rtol = 1e-5; o->sub_abstol = 1e-50; o->sub_dtol = 1e4; o->sub_max_it = 10000;
+}
+
+static void monitor(solver *s, double r) { if (s->hist && s->nhist < s->hist_cap) s->hist[s->nhist] = r; s->nhist++; }
+
+static int solve(solver *s, const double *b, double *x);
+
+/* ---- PC ---- */
+static void pc_setup(solver *s) {
+  if (s->pc_type == ORC_PC_JACOBI) {
+    s->idiag = (double *)malloc(sizeof(double) * (size_t)s->n);
+    orc_csr_get_diagonal(s->n, s->ai, s->aj, s->aa, s->idiag);   /* MatGetDiagonal */
+    orc_vec_reciprocal((size_t)s->n, s->idiag);                   /* VecReciprocal */
+    for (int i = 0; i < s->n; i++) if (s->idiag[i] == 0.0) s->idiag[i] = 1.0;
+  } else if (s->pc_type == ORC_PC_BJACOBI) {
+    /* PCSetUp_BJacobi_*: sub-KSP on each diagonal block (bjacobi.c:858-923; MatGetSubMatrices of
+     * the contiguous diagonal blocks) */
+    s->sub = (solver *)calloc((size_t)s->nblocks, sizeof(solver));
+    s->sbi = (int **)calloc((size_t)s->nblocks, sizeof(int *));
+    s->sbj = (int **)calloc((size_t)s->nblocks, sizeof(int *));
+    s->sba = (double **)calloc((size_t)s->nblocks, sizeof(double *));
+    for (int k = 0; k < s->nblocks; k++) {
+      int lo = s->blk[k], hi = s->blk[k + 1], m = hi - lo, nz = 0;
+      for (int r = lo; r < hi; r++)
+        for (int q = s->ai[r]; q < s->ai[r + 1]; q++) if (s->aj[q] >= lo && s->aj[q] < hi) nz++;
+      int *bi = (int *)malloc(sizeof(int) * (size_t)(m + 1));
+      int *bj = (int *)malloc(sizeof(int) * (size_t)(nz > 0 ? nz : 1));
+      double *ba = (double *)malloc(sizeof(double) * (size_t)(nz > 0 ? nz : 1));
+      nz = 0; bi[0] = 0;
+      for (int r = lo; r < hi; r++) {
+        for (int q = s->ai[r]; q < s->ai[r + 1]; q++)
+          if (s->aj[q] >= lo && s->aj[q] < hi) { bj[nz] = s->aj[q] - lo; ba[nz++] = s->aa[q]; }
+        bi[r - lo + 1] = nz;
+      }
+      s->sbi[k] = bi; s->sbj[k] = bj; s->sba[k] = ba;
+      solver *t = &s->sub[k];
+      t->n = m; t->ai = bi; t->aj = bj; t->aa = ba;
+      pc_setup(t);
+    }
+  }
+}
+
+static void pc_free(solver *s) {
+  free(s->idiag); s->idiag = NULL;
+  if (s->sub) {
+    for (int k = 0; k < s->nblocks; k++) { pc_free(&s->sub[k]); free(s->sbi[k]); free(s->sbj[k]); free(s->sba[k]); }
+    free(s->sub); free(s->sbi); free(s->sbj); free(s->sba);
+    s->sub = NULL;
+  }
+}
+
+/* PCApply: PCApply_Jacobi jacobi.c:266 (VecPointwiseMult(y,x,diag)); PCApply_None (VecCopy);
+ * PCApply_BJacobi_Singleblock/Multiblock bjacobi.c:738,1140 (sub-KSPSolve per block, zero guess) */
+static void pc_apply(solver *s, const double *x, double *y) {
+  if (s->pc_type == ORC_PC_NONE) orc_vec_copy((size_t)s->n, x, y);
+  else if (s->pc_type == ORC_PC_JACOBI) orc_vec_pointwise_mult((size_t)s->n, x, s->idiag, y);
+  else {
+    for (int k = 0; k < s->nblocks; k++) {
+      solver *t = &s->sub[k];
+      t->hist = NULL; t->nhist = 0; t->hist_cap = 0;
+      solve(t, x + s->blk[k], y + s->blk[k]);
+    }
+  }
+}
+
+static void mat_mult(solver *s, const double *x, double *y) { orc_spmv_csr(s->n, s->ai, s->aj, s->aa, x, y); }
+/* KSP_PCApplyBAorAB, PC_LEFT branch of PCApplyBAorAB precon.c:620-622 */
+static void pc_apply_BA(solver *s, const double *x, double *y, double *w) { mat_mult(s, x, w); pc_apply(s, w, y); }
+
+/* KSPDefaultConverged, src/ksp/ksp/interface/iterativ.c:702-780 (preconditioned norm, left PC) */
+static void converged(solver *s, int n, double rnorm, const double *b) {
+  s->reason = R_ITERATING;
+  if (!n) {
+    if (s->guess_nonzero) {
+      double *z = (double *)malloc(sizeof(double) * (size_t)s->n), snorm;
+      pc_apply(s, b, z);
+      orc_vec_norm((size_t)s->n, 1, z, &snorm);
+      free(z);
+      if (!snorm) snorm = rnorm;
+      s->rnorm0 = snorm;
+    } else s->rnorm0 = rnorm;
+    s->ttol = fmax(s->rtol * s->rnorm0, s->abstol);
+  }
+  /* chknorm == -1 (itcreate.c:668) so the test is always made */
+  if (isnan(rnorm) || isinf(rnorm)) s->reason = R_DIVERGED_NAN;
+  else if (rnorm <= s->ttol) s->reason = (rnorm < s->abstol) ? R_CONVERGED_ATOL : R_CONVERGED_RTOL;
+  else if (rnorm >= s->dtol * s->rnorm0) s->reason = R_DIVERGED_DTOL;
+}
+
+/* KSPInitialResidual, src/ksp/ksp/interface/itres.c:39-73 (PC_LEFT) */
+static void initial_residual(solver *s, const double *x, double *vt1, double *vt2, double *vres, const double *b) {
+  size_t n = (size_t)s->n;
+  if (s->guess_nonzero) {
+    mat_mult(s, x, vt1);
+    orc_vec_copy(n, b, vt2);
+    orc_vec_axpy(n, -1.0, vt1, vt2);
+    pc_apply(s, vt2, vres);
+  } else {
+    orc_vec_copy(n, b, vt2);
+    pc_apply(s, b, vres);
+  }
+}
+
+/* ---- KSPSolve_CG, src/ksp/ksp/impls/cg/cg.c:92-286 (KSP_NORM_PRECONDITIONED, no single reduction) ---- */
+static void solve_cg(solver *s, const double *B, double *X) {
+  size_t n = (size_t)s->n;
+  double *R = (double *)malloc(3 * n * sizeof(double)), *Z = R + n, *P = Z + n, *W = Z;
+  double dpi = 0.0, a = 1.0, beta, betaold = 1.0, b, dpiold, dp = 0.0;
+  int i;
+  s->its = 0;
+  if (s->guess_nonzero) { mat_mult(s, X, R); orc_vec_aypx(n, -1.0, B, R); }
+  else orc_vec_copy(n, B, R);
+  pc_apply(s, R, Z);
+  orc_vec_norm(n, 1, Z, &dp);
+  monitor(s, dp);
+  converged(s, 0, dp, B);
+  if (s->reason) { free(R); return; }
+  beta = orc_vec_dot(n, Z, R);
+  i = 0;
+  do {
+    s->its = i + 1;
+    if (beta == 0.0) { s->reason = R_CONVERGED_ATOL; break; }
+    else if (i > 0 && beta * betaold < 0.0) { s->reason = R_DIVERGED_INDEFINITE_PC; break; }
+    if (!i) { orc_vec_copy(n, Z, P); b = 0.0; }
+    else { b = beta / betaold; orc_vec_aypx(n, b, Z, P); }
+    dpiold = dpi;
+    mat_mult(s, P, W);
+    dpi = orc_vec_dot(n, P, W);
+    betaold = beta;
+    if (dpi == 0.0 || (i > 0 && dpi * dpiold <= 0.0)) { s->reason = R_DIVERGED_INDEFINITE_MAT; break; }
+    a = beta / dpi;
+    orc_vec_axpy(n, a, P, X);
+    orc_vec_axpy(n, -a, W, R);
+    pc_apply(s, R, Z);
+    orc_vec_norm(n, 1, Z, &dp);
+    monitor(s, dp);
+    converged(s, i + 1, dp, B);
+    if (s->reason) break;
+    beta = orc_vec_dot(n, Z, R);
+    i++;
+  } while (i < s->max_it);
+  if (i >= s->max_it) s->reason = R_DIVERGED_ITS;
+  free(R);
+}
+
+/* ---- KSPSolve_GMRES, src/ksp/ksp/impls/gmres/gmres.c:118-409 + borthog2.c:35-119 ---- */
+typedef struct {
+  int max_k;
+  double *hh, *hes, *grs, *cc, *ss, *lhh, *nrs;
+  double *temp, *temp_matop, **vv;
+} gm;
+#define HH(a, b) (g->hh + (size_t)(b) * (g->max_k + 2) + (a))
+#define HES(a, b) (g->hes + (size_t)(b) * (g->max_k + 1) + (a))
+
+static double normalize(size_t n, double *x) {   /* VecNormalize rvector.c:299 */
+  double nrm;
+  orc_vec_norm(n, 1, x, &nrm);
+  if (nrm != 0.0 && nrm != 1.0) orc_vec_scale(n, 1.0 / nrm, x);
+  return nrm;
+}
+
+static void gmres_build_soln(solver *s, gm *g, double *X, int it) {   /* gmres.c:309-354 */
+  size_t n = (size_t)s->n;
+  if (it < 0) return;
+  if (*HH(it, it) != 0.0) g->nrs[it] = g->grs[it] / *HH(it, it);
+  else { s->reason = R_DIVERGED_BREAKDOWN; return; }
+  for (int ii = 1; ii <= it; ii++) {
+    int k = it - ii;
+    double tt = g->grs[k];
+    for (int j = k + 1; j <= it; j++) tt = tt - *HH(k, j) * g->nrs[j];
+    if (*HH(k, k) == 0.0) { s->reason = R_DIVERGED_BREAKDOWN; return; }
+    g->nrs[k] = tt / *HH(k, k);
+  }
+  orc_vec_set(n, 0.0, g->temp);
+  orc_vec_maxpy(n, it + 1, g->nrs, (const double *const *)g->vv, g->temp);
+  orc_vec_axpy(n, 1.0, g->temp, X);
+}
+
+static void gmres_orthog(solver *s, gm *g, int it) {   /* borthog2.c:35-119 */
+  size_t n = (size_t)s->n;
+  double *hh = HH(0, it), *hes = HES(0, it), *lhh = g->lhh;
+  int passes = s->refine_always ? 2 : 1;
+  for (int j = 0; j <= it; j++) { hh[j] = 0.0; hes[j] = 0.0; }
+  for (int p = 0; p < passes; p++) {
+    orc_vec_mdot(n, it + 1, g->vv[it + 1], (const double *const *)g->vv, lhh);
+    for (int j = 0; j <= it; j++) lhh[j] = -lhh[j];
+    orc_vec_maxpy(n, it + 1, lhh, (const double *const *)g->vv, g->vv[it + 1]);
+    for (int j = 0; j <= it; j++) { hh[j] -= lhh[j]; hes[j] -= lhh[j]; }
+  }
+}
+
+static void gmres_update_hessenberg(solver *s, gm *g, int it, int hapend, double *res) {   /* gmres.c:360-409 */
+  double *hh = HH(0, it), *cc = g->cc, *ss = g->ss, tt;
+  for (int j = 1; j <= it; j++) {
+    tt = *hh;
+    *hh = *cc * tt + *ss * *(hh + 1);
+    hh++;
+    *hh = *cc++ * *hh - (*ss++ * tt);
+  }
+  if (!hapend) {
+    tt = sqrt(*hh * *hh + *(hh + 1) * *(hh + 1));
+    if (tt == 0.0) { s->reason = R_DIVERGED_NULL; return; }
+    *cc = *hh / tt;
+    *ss = *(hh + 1) / tt;
+    g->grs[it + 1] = -(*ss * g->grs[it]);
+    g->grs[it] = *cc * g->grs[it];
+    *hh = *cc * *hh + *ss * *(hh + 1);
+    *res = fabs(g->grs[it + 1]);
+  } else *res = 0.0;
+}
+
+static int gmres_cycle(solver *s, gm *g, const double *B, double *X) {   /* gmres.c:118-209 */
+  size_t n = (size_t)s->n;
+  double res_norm, res, hapbnd, tt;
+  int it = 0, hapend = 0;
+  res_norm = normalize(n, g->vv[0]);
+  res = res_norm;
+  g->grs[0] = res_norm;
+  monitor(s, res);
+  if (!res) { s->reason = R_CONVERGED_ATOL; return 0; }
+  converged(s, s->its, res, B);
+  while (!s->reason && it < g->max_k && s->its < s->max_it) {
+    if (it) monitor(s, res);
+    pc_apply_BA(s, g->vv[it], g->vv[it + 1], g->temp_matop);
+    gmres_orthog(s, g, it);
+    tt = normalize(n, g->vv[it + 1]);
+    *HH(it + 1, it) = tt;
+    *HES(it + 1, it) = tt;
+    hapbnd = fabs(tt / g->grs[it]);
+    if (hapbnd > 1e-30) hapbnd = 1e-30;     /* haptol, gmres.c KSPCreate_GMRES */
+    if (tt < hapbnd) hapend = 1;
+    gmres_update_hessenberg(s, g, it, hapend, &res);
+    it++;
+    s->its++;
+    if (s->reason) break;
+    converged(s, s->its, res, B);
+    if (hapend) break;
+  }
+  if (it && (s->reason || s->its >= s->max_it)) monitor(s, res);
+  gmres_build_soln(s, g, X, it - 1);
+  return it;
+}
+
+static void solve_gmres(solver *s, const double *B, double *X) {   /* gmres.c:213-243 */
+  size_t n = (size_t)s->n;
+  gm G, *g = &G;
+  int k = s->restart, itcount = 0, guess = s->guess_nonzero;
+  g->max_k = k;
+  g->hh = (double *)calloc((size_t)(k + 2) * (k + 1), sizeof(double));
+  g->hes = (double *)calloc((size_t)(k + 1) * (k + 1), sizeof(double));
+  g->grs = (double *)calloc((size_t)k + 2, sizeof(double));
+  g->cc = (double *)calloc((size_t)k + 1, sizeof(double));
+  g->ss = (double *)calloc((size_t)k + 1, sizeof(double));
+  g->lhh = (double *)calloc((size_t)k + 2, sizeof(double));
+  g->nrs = (double *)calloc((size_t)k + 2, sizeof(double));
+  g->vv = (double **)calloc((size_t)k + 2, sizeof(double *));
+  double *store = (double *)calloc((size_t)(k + 4) * n + 1, sizeof(double));
+  g->temp = store; g->temp_matop = store + n;
+  for (int j = 0; j < k + 2; j++) g->vv[j] = store + (size_t)(j + 2) * n;
+  s->its = 0;
+  s->reason = R_ITERATING;
+  while (!s->reason) {
+    initial_residual(s, X, g->temp, g->temp_matop, g->vv[0], B);
+    itcount += gmres_cycle(s, g, B, X);
+    if (itcount >= s->max_it) { if (!s->reason) s->reason = R_DIVERGED_ITS; break; }
+    s->guess_nonzero = 1;
+  }
+  s->guess_nonzero = guess;
+  free(g->hh); free(g->hes); free(g->grs); free(g->cc); free(g->ss); free(g->lhh); free(g->nrs); free(g->vv); free(store);
+}
+
+/* ---- KSPSolve_BCGS, src/ksp/ksp/impls/bcgs/bcgs.c:43-160 (PC_LEFT) ---- */
+static void solve_bcgs(solver *s, const double *B, double *X) {
+  size_t n = (size_t)s->n;
+  double *R = (double *)calloc(6 * n + 1, sizeof(double)), *RP = R + n, *V = RP + n, *T = V + n, *S = T + n, *P = S + n;
+  double rho, rhoold, alpha, beta, omega, omegaold, d1, d2, dp = 0.0;
+  int i;
+  initial_residual(s, X, V, T, R, B);
+  orc_vec_norm(n, 1, R, &dp);
+  s->its = 0;
+  monitor(s, dp);
+  converged(s, 0, dp, B);
+  if (s->reason) { free(R); return; }
+  orc_vec_copy(n, R, RP);
+  rhoold = 1.0; alpha = 1.0; omegaold = 1.0;
+  orc_vec_set(n, 0.0, P);
+  orc_vec_set(n, 0.0, V);
+  i = 0;
+  do {
+    rho = orc_vec_dot(n, R, RP);
+    beta = (rho / rhoold) * (alpha / omegaold);
+    orc_vec_axpbypcz(n, 1.0, -omegaold * beta, beta, R, V, P);
+    pc_apply_BA(s, P, V, T);
+    d1 = orc_vec_dot(n, V, RP);
+    if (d1 == 0.0) { s->reason = R_DIVERGED_BREAKDOWN; break; }   /* reference raises PETSC_ERR_PLIB */
+    alpha = rho / d1;
+    orc_vec_waxpy(n, -alpha, V, R, S);
+    pc_apply_BA(s, S, T, R);
+    orc_vec_dotnorm2(n, S, T, &d1, &d2);
+    if (d2 == 0.0) {
+      d1 = orc_vec_dot(n, S, S);
+      if (d1 != 0.0) { s->reason = R_DIVERGED_BREAKDOWN; break; }
+      orc_vec_axpy(n, alpha, P, X);
+      s->its++;
+      s->reason = R_CONVERGED_RTOL;
+      monitor(s, 0.0);
+      break;
+    }
+    omega = d1 / d2;
+    orc_vec_axpbypcz(n, alpha, omega, 1.0, P, S, X);
+    orc_vec_waxpy(n, -omega, T, S, R);
+    orc_vec_norm(n, 1, R, &dp);
+    rhoold = rho; omegaold = omega;
+    s->its++;
+    monitor(s, dp);
+    converged(s, i + 1, dp, B);
+    if (s->reason) break;
+    if (rho == 0.0) { s->reason = R_DIVERGED_BREAKDOWN; break; }
+    i++;
+  } while (i < s->max_it);
+  if (i >= s->max_it) s->reason = R_DIVERGED_ITS;
+  free(R);
+}
+
+/* KSPSolve, src/ksp/ksp/interface/itfunc.c:335: zero the guess unless told otherwise, then the type's solve;
+ * KSPSolve_PREONLY (impls/preonly/preonly.c): x = PC(b), CONVERGED_ITS */
+static int solve(solver *s, const double *b, double *x) {
+  if (!s->guess_nonzero) orc_vec_set((size_t)s->n, 0.0, x);
+  s->reason = R_ITERATING; s->its = 0;
+  switch (s->ksp_type) {
+  case ORC_KSP_CG: solve_cg(s, b, x); break;
+  case ORC_KSP_GMRES: solve_gmres(s, b, x); break;
+  case ORC_KSP_BCGS: solve_bcgs(s, b, x); break;
+  case ORC_KSP_PREONLY: pc_apply(s, b, x); s->its = 1; s->reason = R_CONVERGED_ITS; break;
+  default: return 1;
+  }
+  return 0;
+}
+
+int orc_ksp_solve(const orc_ksp_opts *o, int n, const int *ai, const int *aj, const double *aa, const double *b,
+                  double *x, double *hist, int hist_cap, int *nhist, int *its, int *reason) {
+  solver S;
+  memset(&S, 0, sizeof(S));
+  S.ksp_type = o->ksp_type; S.pc_type = o->pc_type;
+  S.rtol = o->rtol; S.abstol = o->abstol; S.dtol = o->dtol; S.max_it = o->max_it;
+  S.restart = o->restart; S.refine_always = o->refine_always; S.guess_nonzero = o->guess_nonzero;
+  S.n = n; S.ai = ai; S.aj = aj; S.aa = aa;
+  S.nblocks = o->nblocks; S.blk = o->blk;
+  S.hist = hist; S.hist_cap = hist_cap; S.nhist = 0;
+  pc_setup(&S);
+  if (S.pc_type == ORC_PC_BJACOBI) {
+    for (int k = 0; k < S.nblocks; k++) {
+      solver *t = &S.sub[k];
+      pc_free(t);   /* sub PC type is set below, redo its set-up */
+      t->ksp_type = o->sub_ksp_type; t->pc_type = o->sub_pc_type;
+      t->rtol = o->sub_rtol; t->abstol = o->sub_abstol; t->dtol = o->sub_dtol; t->max_it = o->sub_max_it;
+      t->restart = o->restart; t->refine_always = 0;
+      pc_setup(t);
+    }
+  }
+  int rc = solve(&S, b, x);
+  if (nhist) *nhist = S.nhist;
+  if (its) *its = S.its;
+  if (reason) *reason = S.reason;
+  pc_free(&S);
+  return rc;
+}

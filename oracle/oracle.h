@@ -1,0 +1,106 @@
+/*
+ * oracle.h -- CPU restatement of the reference's Krylov hot path (erdc/petsc-dev, PETSc 3.3.0-dev).
+ *
+ * TEST INFRASTRUCTURE ONLY.  This library is the checker: it may be imported, linked or
+ * executed by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, and by
+ * nothing else.  The product (petsc-dev_amd/) never calls into it and has no CPU fallback.
+ *
+ * Every function is a plain-C, single-thread restatement of one reference routine (cited
+ * file:line, relative to the PETSc tree) operating on raw arrays: same loop order, same
+ * special cases, products and sums in the same order.  Built with -O2 -ffp-contract=off:
+ * a*b+c is a rounded multiply followed by a rounded add, as in a reference build for
+ * baseline x86-64 (no FMA).  BLAS-1 calls of the reference (ddot_/daxpy_/dscal_/dasum_,
+ * include/petscblaslapack_uscore.h) are restated with netlib reference-BLAS semantics
+ * (strictly left-to-right accumulation).
+ *
+ * Pinning: the reference cannot be built under this round's rules (its headers need the
+ * configure-generated petscconf.h; config/BuildSystem is an un-vendored submodule), so the
+ * oracle is pinned by the reference's own golden outputs, committed under tests/golden/
+ * (tests/test_oracle_golden.py): src/mat/examples/tests/output/ex5_{11_A,11_B,21,23}.out,
+ * src/ksp/ksp/examples/{tests/output/ex3_1,ex3_2,ex4_1, tutorials/output/ex2_bjacobi*,ex2f_1,
+ * ex5_1,ex5_2,ex9_1}.out -- see DESIGN.md section 3.
+ */
+#ifndef ORACLE_H
+#define ORACLE_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- Vec (src/vec/vec/impls/seq) ---- */
+void   orc_vec_set(size_t n, double alpha, double *x);                                   /* dvec2.c:722 */
+void   orc_vec_copy(size_t n, const double *x, double *y);                               /* bvec2.c:464 */
+void   orc_vec_scale(size_t n, double alpha, double *x);                                 /* bvec1.c:183 */
+void   orc_vec_swap(size_t n, double *x, double *y);                                     /* bvec2.c:519 */
+void   orc_vec_axpy(size_t n, double alpha, const double *x, double *y);                 /* bvec1.c:244 */
+void   orc_vec_aypx(size_t n, double alpha, const double *x, double *y);                 /* dvec2.c:971 */
+void   orc_vec_axpby(size_t n, double alpha, double beta, const double *x, double *y);   /* bvec1.c:320 */
+void   orc_vec_waxpy(size_t n, double alpha, const double *x, const double *y, double *w); /* dvec2.c:1082 */
+void   orc_vec_axpbypcz(size_t n, double alpha, double beta, double gamma, const double *x, const double *y, double *z); /* bvec1.c:418 */
+void   orc_vec_pointwise_mult(size_t n, const double *x, const double *y, double *w);    /* bvec2.c:234 */
+void   orc_vec_pointwise_divide(size_t n, const double *x, const double *y, double *w);  /* bvec2.c:298 */
+void   orc_vec_reciprocal(size_t n, double *x);                                          /* vinv.c VecReciprocal_Default */
+void   orc_vec_maxpy(size_t n, int nv, const double *alpha, const double *const *y, double *x); /* dvec2.c:836 */
+double orc_vec_dot(size_t n, const double *x, const double *y);                          /* bvec1.c:57,122 */
+void   orc_vec_mdot(size_t n, int nv, const double *x, const double *const *y, double *z); /* dvec2.c:146 */
+/* type: 0 NORM_1, 1 NORM_2, 2 FROBENIUS, 3 INFINITY, 4 NORM_1_AND_2 (out[0],out[1]) */
+void   orc_vec_norm(size_t n, int type, const double *x, double *out);                   /* bvec2.c:605 */
+void   orc_vec_dotnorm2(size_t n, const double *s, const double *t, double *dp, double *nm); /* vinv.c:1200 */
+
+/* ---- SeqAIJ (src/mat/impls/aij/seq/aij.c) ---- */
+void orc_spmv_csr(int m, const int *ai, const int *aj, const double *aa, const double *x, double *y);           /* :1225 */
+void orc_spmv_csr_add(int m, const int *ai, const int *aj, const double *aa, const double *x, const double *y, double *z); /* :1291 */
+void orc_spmv_csr_transpose(int m, int n, const int *ai, const int *aj, const double *aa, const double *x, double *y);     /* :1124 */
+void orc_spmv_csr_transpose_add(int m, int n, const int *ai, const int *aj, const double *aa, const double *x, const double *z, double *y); /* :1078 */
+void orc_csr_get_diagonal(int m, const int *ai, const int *aj, const double *aa, double *d);                    /* :1040 */
+/* explicit transpose, rows of A^T listing contributions in increasing original-row order */
+void orc_csr_transpose(int m, int n, const int *ai, const int *aj, const double *aa, int *ti, int *tj, double *ta);
+/* ---- SeqBAIJ (src/mat/impls/baij/seq/baij2.c:331,387,981) ---- */
+void orc_spmv_bsr(int mbs, int bs, const int *ai, const int *aj, const double *aa, const double *x, double *y);
+
+/* ---- MPIAIJ set-up, integer work (bit-exact) ---- */
+/* Split rank `rank`'s rows [rstart,rend) of a global CSR (sorted columns) into the diagonal block
+ * (local column indices) and off-diagonal block (global columns, then compacted through garray):
+ * MatSetValues_MPIAIJ column test src/mat/impls/aij/mpi/mpiaij.c:517-560, MatSetUpMultiply_MPIAIJ
+ * mmaij.c:9-161.  Caller allocates: ad_i,bo_i [mloc+1]; ad_j,ad_a,bo_j,bo_a [nnz of the row range];
+ * garray [nnz bound].  Returns ec (number of ghost columns). */
+int orc_mpiaij_split(int rstart, int rend, int cstart, int cend, const int *ai, const int *aj, const double *aa,
+                     int *ad_i, int *ad_j, double *ad_a, int *bo_i, int *bo_j, double *bo_a, int *garray);
+/* VecScatterCreate_PtoS (src/vec/vec/utils/vpscat.c:1730-1924) for the MPIAIJ pattern
+ * (from = garray, to = stride 0..ec-1), evaluated for rank `rank` given every rank's garray.
+ * ranges[size+1] = column ownership.  Outputs (caller allocates generously):
+ *  recv side ("from"): nrecv procs, rprocs[], rstarts[nrecv+1], rindices[] (slots in lvec)
+ *  send side ("to"):   nsend procs, sprocs[], sstarts[nsend+1], sindices[] (local x indices)
+ *  local part: nlocal, lto[] (local x idx), lfrom[] (lvec slot). */
+void orc_scatter_create(int size, int rank, const int *ranges, const int *const *garrays, const int *ecs,
+                        int *nrecv, int *rprocs, int *rstarts, int *rindices,
+                        int *nsend, int *sprocs, int *sstarts, int *sindices,
+                        int *nlocal, int *lto, int *lfrom);
+
+/* ---- KSP (src/ksp/ksp/impls/{cg/cg.c:92, gmres/gmres.c:118-409 + borthog2.c:35, bcgs/bcgs.c:43}) ---- */
+enum { ORC_KSP_CG = 0, ORC_KSP_GMRES = 1, ORC_KSP_BCGS = 2, ORC_KSP_PREONLY = 3 };
+enum { ORC_PC_NONE = 0, ORC_PC_JACOBI = 1, ORC_PC_BJACOBI = 2 };
+typedef struct {
+  int ksp_type, pc_type;
+  double rtol, abstol, dtol;
+  int max_it;
+  int restart;            /* GMRES(m) */
+  int refine_always;      /* -ksp_gmres_cgs_refinement_type refine_always */
+  int guess_nonzero;
+  /* block Jacobi: nblocks contiguous blocks with boundaries blk[0..nblocks]; sub-solver */
+  int nblocks;
+  const int *blk;
+  int sub_ksp_type, sub_pc_type;
+  double sub_rtol, sub_abstol, sub_dtol;
+  int sub_max_it;
+} orc_ksp_opts;
+void orc_ksp_default_opts(orc_ksp_opts *o);
+/* Solves A x = b.  hist[0..] receives the residual norms the monitor would print (hist_cap entries
+ * at most); returns iteration count in *its, KSPConvergedReason in *reason. */
+int orc_ksp_solve(const orc_ksp_opts *o, int n, const int *ai, const int *aj, const double *aa, const double *b,
+                  double *x, double *hist, int hist_cap, int *nhist, int *its, int *reason);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

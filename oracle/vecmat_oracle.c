@@ -1,0 +1,248 @@
+/*
+ * vecmat_oracle.c -- TEST INFRASTRUCTURE (see oracle.h).  Plain-C restatement of the
+ * reference's sequential Vec and SeqAIJ/SeqBAIJ kernels.  Build: gcc -O2 -ffp-contract=off.
+ */
+#include "oracle.h"
+#include <math.h>
+#include <string.h>
+#include <stdlib.h>
+
+/* ------------------------------------------------------------------ Vec */
+
+/* VecSet_Seq, src/vec/vec/impls/seq/dvec2.c:722 */
+void orc_vec_set(size_t n, double alpha, double *x) {
+  for (size_t i = 0; i < n; i++) x[i] = alpha;
+}
+
+/* VecCopy_Seq, src/vec/vec/impls/seq/bvec2.c:464 (memcpy when x != y) */
+void orc_vec_copy(size_t n, const double *x, double *y) {
+  if (x != y) memmove(y, x, n * sizeof(double));
+}
+
+/* VecScale_Seq, src/vec/vec/impls/seq/bvec1.c:183: alpha==0 -> VecSet, alpha==1 -> nothing, else dscal */
+void orc_vec_scale(size_t n, double alpha, double *x) {
+  if (alpha == 0.0) orc_vec_set(n, 0.0, x);
+  else if (alpha != 1.0)
+    for (size_t i = 0; i < n; i++) x[i] = alpha * x[i];
+}
+
+/* VecSwap_Seq, src/vec/vec/impls/seq/bvec2.c:519 (dswap) */
+void orc_vec_swap(size_t n, double *x, double *y) {
+  if (x == y) return;
+  for (size_t i = 0; i < n; i++) { double t = x[i]; x[i] = y[i]; y[i] = t; }
+}
+
+/* VecAXPY_Seq, src/vec/vec/impls/seq/bvec1.c:244: skipped for alpha==0, else daxpy (dy = dy + da*dx) */
+void orc_vec_axpy(size_t n, double alpha, const double *x, double *y) {
+  if (alpha == 0.0) return;
+  for (size_t i = 0; i < n; i++) y[i] = y[i] + alpha * x[i];
+}
+
+/* VecAYPX_Seq, src/vec/vec/impls/seq/dvec2.c:971-1014 */
+void orc_vec_aypx(size_t n, double alpha, const double *x, double *y) {
+  if (alpha == 0.0) orc_vec_copy(n, x, y);
+  else if (alpha == 1.0) orc_vec_axpy(n, alpha, x, y);
+  else if (alpha == -1.0) { for (size_t i = 0; i < n; i++) y[i] = x[i] - y[i]; }
+  else { for (size_t i = 0; i < n; i++) y[i] = x[i] + alpha * y[i]; }
+}
+
+/* VecAXPBY_Seq, src/vec/vec/impls/seq/bvec1.c:320-358 */
+void orc_vec_axpby(size_t n, double alpha, double beta, const double *x, double *y) {
+  if (alpha == 0.0) orc_vec_scale(n, beta, y);
+  else if (beta == 1.0) orc_vec_axpy(n, alpha, x, y);
+  else if (alpha == 1.0) orc_vec_aypx(n, beta, x, y);
+  else if (beta == 0.0) { for (size_t i = 0; i < n; i++) y[i] = alpha * x[i]; }
+  else { for (size_t i = 0; i < n; i++) y[i] = alpha * x[i] + beta * y[i]; }
+}
+
+/* VecWAXPY_Seq, src/vec/vec/impls/seq/dvec2.c:1082-1115 */
+void orc_vec_waxpy(size_t n, double alpha, const double *x, const double *y, double *w) {
+  if (alpha == 1.0) { for (size_t i = 0; i < n; i++) w[i] = y[i] + x[i]; }
+  else if (alpha == -1.0) { for (size_t i = 0; i < n; i++) w[i] = y[i] - x[i]; }
+  else if (alpha == 0.0) { memmove(w, y, n * sizeof(double)); }
+  else { for (size_t i = 0; i < n; i++) w[i] = y[i] + alpha * x[i]; }
+}
+
+/* VecAXPBYPCZ_Seq, src/vec/vec/impls/seq/bvec1.c:418-455 (the non-threadcomm variant) */
+void orc_vec_axpbypcz(size_t n, double alpha, double beta, double gamma, const double *x, const double *y, double *z) {
+  if (alpha == 1.0) { for (size_t i = 0; i < n; i++) z[i] = x[i] + beta * y[i] + gamma * z[i]; }
+  else if (gamma == 1.0) { for (size_t i = 0; i < n; i++) z[i] = alpha * x[i] + beta * y[i] + z[i]; }
+  else if (gamma == 0.0) { for (size_t i = 0; i < n; i++) z[i] = alpha * x[i] + beta * y[i]; }
+  else { for (size_t i = 0; i < n; i++) z[i] = alpha * x[i] + beta * y[i] + gamma * z[i]; }
+}
+
+/* VecPointwiseMult_Seq, src/vec/vec/impls/seq/bvec2.c:234-260 (aliasing cases give the same values) */
+void orc_vec_pointwise_mult(size_t n, const double *x, const double *y, double *w) {
+  for (size_t i = 0; i < n; i++) w[i] = x[i] * y[i];
+}
+
+/* VecPointwiseDivide_Seq, src/vec/vec/impls/seq/bvec2.c:298 */
+void orc_vec_pointwise_divide(size_t n, const double *x, const double *y, double *w) {
+  for (size_t i = 0; i < n; i++) w[i] = x[i] / y[i];
+}
+
+/* VecReciprocal_Default, src/vec/vec/utils/vinv.c: x[i] = 1/x[i] where x[i] != 0 */
+void orc_vec_reciprocal(size_t n, double *x) {
+  for (size_t i = 0; i < n; i++) if (x[i] != 0.0) x[i] = 1.0 / x[i];
+}
+
+/* VecMAXPY_Seq, src/vec/vec/impls/seq/dvec2.c:836-904 with PetscAXPY/2/3/4 of
+ * include/petsc-private/petscaxpy.h:101-110: the first nv%4 vectors in one sweep, then fours. */
+void orc_vec_maxpy(size_t n, int nv, const double *alpha, const double *const *y, double *x) {
+  int rem = nv & 3, j;
+  size_t i;
+  switch (rem) {
+  case 3: for (i = 0; i < n; i++) x[i] += alpha[0] * y[0][i] + alpha[1] * y[1][i] + alpha[2] * y[2][i]; break;
+  case 2: for (i = 0; i < n; i++) x[i] += alpha[0] * y[0][i] + alpha[1] * y[1][i]; break;
+  case 1: for (i = 0; i < n; i++) x[i] += alpha[0] * y[0][i]; break;
+  }
+  for (j = rem; j < nv; j += 4) {
+    const double a0 = alpha[j], a1 = alpha[j + 1], a2 = alpha[j + 2], a3 = alpha[j + 3];
+    const double *y0 = y[j], *y1 = y[j + 1], *y2 = y[j + 2], *y3 = y[j + 3];
+    for (i = 0; i < n; i++) x[i] += a0 * y0[i] + a1 * y1[i] + a2 * y2[i] + a3 * y3[i];
+  }
+}
+
+/* VecDot_Seq/VecTDot_Seq, src/vec/vec/impls/seq/bvec1.c:57,122: ddot_, netlib order (left to right) */
+double orc_vec_dot(size_t n, const double *x, const double *y) {
+  double s = 0.0;
+  for (size_t i = 0; i < n; i++) s = s + x[i] * y[i];
+  return s;
+}
+
+/* One column of VecMDot_Seq, src/vec/vec/impls/seq/dvec2.c:146-342: the n%4 leading elements are
+ * consumed highest index first (switch fall-through :168-183), then fours with
+ * sum += x0*y0 + x1*y1 + x2*y2 + x3*y3.  The 4-vectors-at-a-time grouping does not change any
+ * individual sum. */
+static double mdot_one(size_t n, const double *x, const double *y) {
+  double sum = 0.0;
+  size_t rem = n & 3, j = n;
+  switch (rem) {
+  case 3: sum += x[2] * y[2]; /* fall through */
+  case 2: sum += x[1] * y[1]; /* fall through */
+  case 1: sum += x[0] * y[0]; /* fall through */
+  case 0: x += rem; y += rem; j -= rem; break;
+  }
+  while (j > 0) {
+    sum += x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
+    x += 4; y += 4; j -= 4;
+  }
+  return sum;
+}
+void orc_vec_mdot(size_t n, int nv, const double *x, const double *const *y, double *z) {
+  for (int j = 0; j < nv; j++) z[j] = mdot_one(n, x, y[j]);
+}
+
+/* VecNorm_Seq, src/vec/vec/impls/seq/bvec2.c:605-642 */
+void orc_vec_norm(size_t n, int type, const double *x, double *out) {
+  size_t i;
+  if (type == 1 || type == 2) {
+    out[0] = sqrt(orc_vec_dot(n, x, x));
+  } else if (type == 3) {
+    double max = 0.0, tmp;
+    for (i = 0; i < n; i++) {
+      if ((tmp = fabs(x[i])) > max) max = tmp;
+      if (tmp != tmp) { max = tmp; break; }
+    }
+    out[0] = max;
+  } else if (type == 0) {
+    double s = 0.0;
+    for (i = 0; i < n; i++) s = s + fabs(x[i]);   /* dasum */
+    out[0] = s;
+  } else if (type == 4) {
+    orc_vec_norm(n, 0, x, out);
+    orc_vec_norm(n, 1, x, out + 1);
+  }
+}
+
+/* VecDotNorm2 default branch, src/vec/vec/utils/vinv.c:1222-1234 */
+void orc_vec_dotnorm2(size_t n, const double *s, const double *t, double *dp, double *nm) {
+  double dpx = 0.0, nmx = 0.0;
+  for (size_t i = 0; i < n; i++) { dpx += s[i] * t[i]; nmx += t[i] * t[i]; }
+  *dp = dpx; *nm = nmx;
+}
+
+/* ------------------------------------------------------------------ SeqAIJ */
+
+/* MatMult_SeqAIJ, src/mat/impls/aij/seq/aij.c:1269-1277 with PetscSparseDensePlusDot aij.h:383-386 */
+void orc_spmv_csr(int m, const int *ai, const int *aj, const double *aa, const double *x, double *y) {
+  for (int i = 0; i < m; i++) {
+    double sum = 0.0;
+    for (int k = ai[i]; k < ai[i + 1]; k++) sum += aa[k] * x[aj[k]];
+    y[i] = sum;
+  }
+}
+
+/* MatMultAdd_SeqAIJ, src/mat/impls/aij/seq/aij.c:1334-1341 */
+void orc_spmv_csr_add(int m, const int *ai, const int *aj, const double *aa, const double *x, const double *y, double *z) {
+  for (int i = 0; i < m; i++) {
+    double sum = y[i];
+    for (int k = ai[i]; k < ai[i + 1]; k++) sum += aa[k] * x[aj[k]];
+    z[i] = sum;
+  }
+}
+
+/* MatMultTransposeAdd_SeqAIJ, src/mat/impls/aij/seq/aij.c:1078-1119: y = z; y[j[k]] += x[i]*a[k] */
+void orc_spmv_csr_transpose_add(int m, int n, const int *ai, const int *aj, const double *aa, const double *x,
+                                const double *z, double *y) {
+  if (z != y) memmove(y, z, (size_t)n * sizeof(double));
+  for (int i = 0; i < m; i++) {
+    const double alpha = x[i];
+    for (int k = ai[i]; k < ai[i + 1]; k++) y[aj[k]] += alpha * aa[k];
+  }
+}
+
+/* MatMultTranspose_SeqAIJ, src/mat/impls/aij/seq/aij.c:1124-1133: VecSet(y,0) then the Add form */
+void orc_spmv_csr_transpose(int m, int n, const int *ai, const int *aj, const double *aa, const double *x, double *y) {
+  for (int j = 0; j < n; j++) y[j] = 0.0;
+  orc_spmv_csr_transpose_add(m, n, ai, aj, aa, x, y, y);
+}
+
+/* MatGetDiagonal_SeqAIJ, src/mat/impls/aij/seq/aij.c:1040-1073: linear search of each row, 0 if absent */
+void orc_csr_get_diagonal(int m, const int *ai, const int *aj, const double *aa, double *d) {
+  for (int i = 0; i < m; i++) {
+    d[i] = 0.0;
+    for (int k = ai[i]; k < ai[i + 1]; k++) if (aj[k] == i) { d[i] = aa[k]; break; }
+  }
+}
+
+/* Counting-sort transpose; stable, so row c of A^T lists (r, a_rc) in increasing r. */
+void orc_csr_transpose(int m, int n, const int *ai, const int *aj, const double *aa, int *ti, int *tj, double *ta) {
+  int nz = ai[m];
+  for (int j = 0; j <= n; j++) ti[j] = 0;
+  for (int k = 0; k < nz; k++) ti[aj[k] + 1]++;
+  for (int j = 0; j < n; j++) ti[j + 1] += ti[j];
+  int *next = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+  for (int j = 0; j < n; j++) next[j] = ti[j];
+  for (int i = 0; i < m; i++)
+    for (int k = ai[i]; k < ai[i + 1]; k++) {
+      int p = next[aj[k]]++;
+      tj[p] = i;
+      ta[p] = aa[k];
+    }
+  free(next);
+}
+
+/* ------------------------------------------------------------------ SeqBAIJ */
+
+/* MatMult_SeqBAIJ_3/_4/_N, src/mat/impls/baij/seq/baij2.c:331-383, 387-436, 981-1032: per block
+ * row, bs running sums; each block (column-major) adds sum_r += v[r] x0 + v[r+bs] x1 + ... as one
+ * left-to-right expression (bs = 3, 4 spelled out in the reference; _N uses a dgemv-like loop,
+ * restated here in the same column order). */
+void orc_spmv_bsr(int mbs, int bs, const int *ai, const int *aj, const double *aa, const double *x, double *y) {
+  const int bs2 = bs * bs;
+  double sum[16];
+  for (int i = 0; i < mbs; i++) {
+    for (int r = 0; r < bs; r++) sum[r] = 0.0;
+    for (int k = ai[i]; k < ai[i + 1]; k++) {
+      const double *v = aa + (size_t)k * bs2;
+      const double *xb = x + (size_t)aj[k] * bs;
+      for (int r = 0; r < bs; r++) {
+        double t = v[r] * xb[0];
+        for (int c = 1; c < bs; c++) t = t + v[r + c * bs] * xb[c];
+        sum[r] += t;
+      }
+    }
+    for (int r = 0; r < bs; r++) y[(size_t)i * bs + r] = sum[r];
+  }
+}

@@ -1,0 +1,27 @@
+"""In-tree builds (make + hipcc/gcc).  No JIT cache: the .so files travel with the tree."""
+import os
+import subprocess
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+
+
+def kernels_lib_path():
+    return os.path.join(PKG, "csrc", "libmi355x_kernels.so")
+
+
+def host_lib_path():
+    return os.path.join(PKG, "host", "libpetschipmi355x.so")
+
+
+def _make(directory, jobs=8):
+    subprocess.run(["make", "-j%d" % jobs, "-C", directory], check=True)
+
+
+def build_all(oracle=True):
+    """Compile every HIP extension for gfx950, the C host library and (test infrastructure) the oracle."""
+    os.environ.setdefault("PYTORCH_ROCM_ARCH", "gfx950")
+    _make(os.path.join(PKG, "csrc"))
+    _make(os.path.join(PKG, "host"))
+    if oracle:
+        _make(os.path.join(ROOT, "oracle"))

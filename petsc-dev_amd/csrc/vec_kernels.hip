@@ -1,0 +1,489 @@
+// Vec BLAS-1 kernels for gfx950.  All of them are HBM-bound streams: 16-byte
+// (double2) loads/stores per lane, grid capped at 2048 workgroups (256 CUs x 8
+// resident 256-thread workgroups) with a grid-stride loop, two independent
+// double2 iterations in flight per lane.  Compiled with -ffp-contract=off so
+// a*x+y is a rounded multiply then a rounded add, as in the reference's C loops
+// (src/vec/vec/impls/seq/{bvec1,bvec2,dvec2}.c).
+#include "common.hpp"
+
+// ------------------------------------------------------------------------
+// element-wise map:  out[i] = op(a[i], b[i], c[i])   (inputs may alias out)
+// ------------------------------------------------------------------------
+template <int NIN, class Op>
+__global__ __launch_bounds__(MI355X_BLOCK) void map_kernel(Op op, const double *a, const double *b, const double *c,
+                                                          double *out, size_t n, int vec_ok) {
+  const size_t tid = (size_t)blockIdx.x * MI355X_BLOCK + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * MI355X_BLOCK;
+  if (vec_ok) {
+    const size_t n2 = n >> 1;
+    const double2 *a2 = reinterpret_cast<const double2 *>(a);
+    const double2 *b2 = reinterpret_cast<const double2 *>(b);
+    const double2 *c2 = reinterpret_cast<const double2 *>(c);
+    double2 *o2 = reinterpret_cast<double2 *>(out);
+    size_t i = tid;
+    for (; i + stride < n2; i += 2 * stride) {
+      double2 av0 = {0, 0}, bv0 = {0, 0}, cv0 = {0, 0}, av1 = {0, 0}, bv1 = {0, 0}, cv1 = {0, 0};
+      if (NIN >= 1) { av0 = a2[i]; av1 = a2[i + stride]; }
+      if (NIN >= 2) { bv0 = b2[i]; bv1 = b2[i + stride]; }
+      if (NIN >= 3) { cv0 = c2[i]; cv1 = c2[i + stride]; }
+      double2 r0, r1;
+      r0.x = op(av0.x, bv0.x, cv0.x); r0.y = op(av0.y, bv0.y, cv0.y);
+      r1.x = op(av1.x, bv1.x, cv1.x); r1.y = op(av1.y, bv1.y, cv1.y);
+      o2[i] = r0;
+      o2[i + stride] = r1;
+    }
+    if (i < n2) {
+      double2 av = {0, 0}, bv = {0, 0}, cv = {0, 0};
+      if (NIN >= 1) av = a2[i];
+      if (NIN >= 2) bv = b2[i];
+      if (NIN >= 3) cv = c2[i];
+      double2 r;
+      r.x = op(av.x, bv.x, cv.x); r.y = op(av.y, bv.y, cv.y);
+      o2[i] = r;
+    }
+    if ((n & 1) && tid == 0) {
+      const size_t k = n - 1;
+      out[k] = op(NIN >= 1 ? a[k] : 0.0, NIN >= 2 ? b[k] : 0.0, NIN >= 3 ? c[k] : 0.0);
+    }
+  } else {
+    for (size_t i = tid; i < n; i += stride)
+      out[i] = op(NIN >= 1 ? a[i] : 0.0, NIN >= 2 ? b[i] : 0.0, NIN >= 3 ? c[i] : 0.0);
+  }
+}
+
+template <int NIN, class Op>
+static int launch_map(mi355x_handle_t h, Op op, const double *a, const double *b, const double *c, double *out, size_t n) {
+  if (n == 0) return 0;
+  int vec_ok = mi355x_aligned16(out) && (NIN < 1 || mi355x_aligned16(a)) && (NIN < 2 || mi355x_aligned16(b)) &&
+               (NIN < 3 || mi355x_aligned16(c));
+  int grid = mi355x_grid_for(n, 4);
+  hipLaunchKernelGGL((map_kernel<NIN, Op>), dim3(grid), dim3(MI355X_BLOCK), 0, h->stream, op, a, b, c, out, n, vec_ok);
+  MI355X_LAUNCH_CHECK();
+  return 0;
+}
+
+struct OpSet      { double al; __device__ double operator()(double, double, double) const { return al; } };
+struct OpCopy     { __device__ double operator()(double x, double, double) const { return x; } };
+struct OpScale    { double al; __device__ double operator()(double x, double, double) const { return al * x; } };
+struct OpAxpy     { double al; __device__ double operator()(double x, double y, double) const { return y + al * x; } };
+struct OpAypx     { double al; __device__ double operator()(double x, double y, double) const { return x + al * y; } };
+struct OpXmY      { __device__ double operator()(double x, double y, double) const { return x - y; } };
+struct OpYmX      { __device__ double operator()(double x, double y, double) const { return y - x; } };
+struct OpXpY      { __device__ double operator()(double x, double y, double) const { return y + x; } };
+struct OpAxpby    { double al, be; __device__ double operator()(double x, double y, double) const { return al * x + be * y; } };
+struct OpMul      { __device__ double operator()(double x, double y, double) const { return x * y; } };
+struct OpDiv      { __device__ double operator()(double x, double y, double) const { return x / y; } };
+struct OpRecip    { __device__ double operator()(double x, double, double) const { return x != 0.0 ? 1.0 / x : x; } };
+struct OpJacInv   { __device__ double operator()(double x, double, double) const { return x == 0.0 ? 1.0 : 1.0 / x; } };
+// z = al x + be y + ga z with the reference's four variants (bvec1.c:430-449)
+struct OpAxpbypczA1 { double be, ga; __device__ double operator()(double x, double y, double z) const { return x + be * y + ga * z; } };
+struct OpAxpbypczG1 { double al, be; __device__ double operator()(double x, double y, double z) const { return al * x + be * y + z; } };
+struct OpAxpbypczG0 { double al, be; __device__ double operator()(double x, double y, double) const { return al * x + be * y; } };
+struct OpAxpbypcz   { double al, be, ga; __device__ double operator()(double x, double y, double z) const { return al * x + be * y + ga * z; } };
+struct OpTriad    { double al; __device__ double operator()(double b, double c, double) const { return b + al * c; } };
+
+// swap needs two outputs
+__global__ __launch_bounds__(MI355X_BLOCK) void swap_kernel(double *x, double *y, size_t n) {
+  const size_t stride = (size_t)gridDim.x * MI355X_BLOCK;
+  for (size_t i = (size_t)blockIdx.x * MI355X_BLOCK + threadIdx.x; i < n; i += stride) {
+    double t = x[i];
+    x[i] = y[i];
+    y[i] = t;
+  }
+}
+
+// ------------------------------------------------------------------------
+// MAXPY: x += (a0 y0 + .. ) [group 0, G0 vectors] ; x += (..) [group 1, G1 vectors]
+// groups and left-to-right sums as petscaxpy.h:101-110 / dvec2.c:853-900
+// ------------------------------------------------------------------------
+struct MaxpyArgs {
+  const double *y[8];
+  double a[8];
+};
+
+template <int G>
+__device__ __forceinline__ double group_sum(const double *a, const double *v) {
+  double s = a[0] * v[0];
+#pragma unroll
+  for (int j = 1; j < G; ++j) s = s + a[j] * v[j];
+  return s;
+}
+
+template <int G0, int G1>
+__global__ __launch_bounds__(MI355X_BLOCK) void maxpy_kernel(MaxpyArgs args, double *x, size_t n, int vec_ok) {
+  const size_t tid = (size_t)blockIdx.x * MI355X_BLOCK + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * MI355X_BLOCK;
+  constexpr int NV = G0 + G1;
+  if (vec_ok) {
+    const size_t n2 = n >> 1;
+    double2 *x2 = reinterpret_cast<double2 *>(x);
+    for (size_t i = tid; i < n2; i += stride) {
+      double2 yv[NV];
+#pragma unroll
+      for (int j = 0; j < NV; ++j) yv[j] = reinterpret_cast<const double2 *>(args.y[j])[i];
+      double2 xv = x2[i];
+      double lo[NV], hi[NV];
+#pragma unroll
+      for (int j = 0; j < NV; ++j) { lo[j] = yv[j].x; hi[j] = yv[j].y; }
+      xv.x = xv.x + group_sum<G0>(args.a, lo);
+      xv.y = xv.y + group_sum<G0>(args.a, hi);
+      if (G1 > 0) {
+        xv.x = xv.x + group_sum<(G1 > 0 ? G1 : 1)>(args.a + G0, lo + G0);
+        xv.y = xv.y + group_sum<(G1 > 0 ? G1 : 1)>(args.a + G0, hi + G0);
+      }
+      x2[i] = xv;
+    }
+    if ((n & 1) && tid == 0) {
+      const size_t k = n - 1;
+      double v[NV];
+#pragma unroll
+      for (int j = 0; j < NV; ++j) v[j] = args.y[j][k];
+      double xv = x[k] + group_sum<G0>(args.a, v);
+      if (G1 > 0) xv = xv + group_sum<(G1 > 0 ? G1 : 1)>(args.a + G0, v + G0);
+      x[k] = xv;
+    }
+  } else {
+    for (size_t k = tid; k < n; k += stride) {
+      double v[NV];
+#pragma unroll
+      for (int j = 0; j < NV; ++j) v[j] = args.y[j][k];
+      double xv = x[k] + group_sum<G0>(args.a, v);
+      if (G1 > 0) xv = xv + group_sum<(G1 > 0 ? G1 : 1)>(args.a + G0, v + G0);
+      x[k] = xv;
+    }
+  }
+}
+
+template <int G0, int G1>
+static int launch_maxpy(mi355x_handle_t h, const MaxpyArgs &args, double *x, size_t n, int vec_ok) {
+  int grid = mi355x_grid_for(n, 2);
+  hipLaunchKernelGGL((maxpy_kernel<G0, G1>), dim3(grid), dim3(MI355X_BLOCK), 0, h->stream, args, x, n, vec_ok);
+  MI355X_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------
+// reductions: single launch, fixed tree, last-arriving workgroup finishes
+// ------------------------------------------------------------------------
+enum { RED_SUM = 0, RED_MAX = 1 };
+
+template <int NOUT, int MODE>
+__device__ __forceinline__ void block_reduce_store(double (&acc)[NOUT], double *dst /* NOUT doubles */, double (*lds)[NOUT]) {
+  const int lane = threadIdx.x & (MI355X_WAVE - 1);
+  const int wave = threadIdx.x / MI355X_WAVE;
+#pragma unroll
+  for (int j = 0; j < NOUT; ++j) {
+    double v = (MODE == RED_MAX) ? wave_max(acc[j]) : wave_sum(acc[j]);
+    if (lane == 0) lds[wave][j] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < NOUT) {
+    double s = lds[0][threadIdx.x];
+#pragma unroll
+    for (int w = 1; w < MI355X_BLOCK / MI355X_WAVE; ++w)
+      s = (MODE == RED_MAX) ? nanmax(s, lds[w][threadIdx.x]) : s + lds[w][threadIdx.x];
+    dst[threadIdx.x] = s;
+  }
+}
+
+// F::accum(i2 or i, acc): adds element contributions
+template <int NOUT, int MODE, class F>
+__global__ __launch_bounds__(MI355X_BLOCK) void reduce_kernel(F f, size_t n, int vec_ok, double *partials,
+                                                             unsigned int *ticket, double *out) {
+  __shared__ double lds[MI355X_BLOCK / MI355X_WAVE][NOUT];
+  __shared__ int is_last;
+  const size_t tid = (size_t)blockIdx.x * MI355X_BLOCK + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * MI355X_BLOCK;
+  double acc[NOUT];
+#pragma unroll
+  for (int j = 0; j < NOUT; ++j) acc[j] = 0.0;
+  if (vec_ok) {
+    const size_t n2 = n >> 1;
+    for (size_t i = tid; i < n2; i += stride) f.accum2(i, acc);
+    if ((n & 1) && tid == 0) f.accum1(n - 1, acc);
+  } else {
+    for (size_t i = tid; i < n; i += stride) f.accum1(i, acc);
+  }
+  if (gridDim.x == 1) {  // single workgroup: no hand-off needed
+    block_reduce_store<NOUT, MODE>(acc, out, lds);
+    return;
+  }
+  block_reduce_store<NOUT, MODE>(acc, partials + (size_t)blockIdx.x * NOUT, lds);
+  // Publish this workgroup's partials, then take a ticket (agent-scope release ->
+  // counter; the storing lanes and lane 0 are all in wavefront 0).
+  if (threadIdx.x < MI355X_WAVE) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int last = (t == gridDim.x - 1);
+      if (last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      is_last = last;
+    }
+  }
+  __syncthreads();
+  if (!is_last) return;
+  // last-arriving workgroup: sum the per-workgroup partials in workgroup order
+#pragma unroll
+  for (int j = 0; j < NOUT; ++j) acc[j] = 0.0;
+  for (unsigned int b = threadIdx.x; b < gridDim.x; b += MI355X_BLOCK) {
+#pragma unroll
+    for (int j = 0; j < NOUT; ++j) {
+      double v = __hip_atomic_load(partials + (size_t)b * NOUT + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      acc[j] = (MODE == RED_MAX) ? nanmax(acc[j], v) : acc[j] + v;
+    }
+  }
+  __syncthreads();
+  block_reduce_store<NOUT, MODE>(acc, out, lds);
+  if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int NOUT, int MODE, class F>
+static int launch_reduce(mi355x_handle_t h, F f, size_t n, int vec_ok, double *out) {
+  int grid = mi355x_grid_for(n, 8);
+  hipLaunchKernelGGL((reduce_kernel<NOUT, MODE, F>), dim3(grid), dim3(MI355X_BLOCK), 0, h->stream, f, n, vec_ok,
+                     h->partials, h->ticket, out);
+  MI355X_LAUNCH_CHECK();
+  return 0;
+}
+
+struct DotF {
+  const double *x, *y;
+  __device__ void accum1(size_t i, double (&a)[1]) const { a[0] += x[i] * y[i]; }
+  __device__ void accum2(size_t i, double (&a)[1]) const {
+    double2 xv = reinterpret_cast<const double2 *>(x)[i], yv = reinterpret_cast<const double2 *>(y)[i];
+    a[0] += xv.x * yv.x;
+    a[0] += xv.y * yv.y;
+  }
+};
+struct SumSqF {
+  const double *x;
+  __device__ void accum1(size_t i, double (&a)[1]) const { a[0] += x[i] * x[i]; }
+  __device__ void accum2(size_t i, double (&a)[1]) const {
+    double2 xv = reinterpret_cast<const double2 *>(x)[i];
+    a[0] += xv.x * xv.x;
+    a[0] += xv.y * xv.y;
+  }
+};
+struct SumAbsF {
+  const double *x;
+  __device__ void accum1(size_t i, double (&a)[1]) const { a[0] += fabs(x[i]); }
+  __device__ void accum2(size_t i, double (&a)[1]) const {
+    double2 xv = reinterpret_cast<const double2 *>(x)[i];
+    a[0] += fabs(xv.x);
+    a[0] += fabs(xv.y);
+  }
+};
+struct MaxAbsF {
+  const double *x;
+  __device__ void accum1(size_t i, double (&a)[1]) const { a[0] = nanmax(a[0], fabs(x[i])); }
+  __device__ void accum2(size_t i, double (&a)[1]) const {
+    double2 xv = reinterpret_cast<const double2 *>(x)[i];
+    a[0] = nanmax(a[0], fabs(xv.x));
+    a[0] = nanmax(a[0], fabs(xv.y));
+  }
+};
+struct Norm12F {
+  const double *x;
+  __device__ void accum1(size_t i, double (&a)[2]) const { a[0] += fabs(x[i]); a[1] += x[i] * x[i]; }
+  __device__ void accum2(size_t i, double (&a)[2]) const {
+    double2 xv = reinterpret_cast<const double2 *>(x)[i];
+    a[0] += fabs(xv.x); a[1] += xv.x * xv.x;
+    a[0] += fabs(xv.y); a[1] += xv.y * xv.y;
+  }
+};
+struct DotNorm2F {
+  const double *s, *t;
+  __device__ void accum1(size_t i, double (&a)[2]) const { a[0] += s[i] * t[i]; a[1] += t[i] * t[i]; }
+  __device__ void accum2(size_t i, double (&a)[2]) const {
+    double2 sv = reinterpret_cast<const double2 *>(s)[i], tv = reinterpret_cast<const double2 *>(t)[i];
+    a[0] += sv.x * tv.x; a[1] += tv.x * tv.x;
+    a[0] += sv.y * tv.y; a[1] += tv.y * tv.y;
+  }
+};
+template <int NV>
+struct MDotF {
+  const double *x;
+  const double *y[NV];
+  __device__ void accum1(size_t i, double (&a)[NV]) const {
+    double xv = x[i];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) a[j] += xv * y[j][i];
+  }
+  __device__ void accum2(size_t i, double (&a)[NV]) const {
+    double2 xv = reinterpret_cast<const double2 *>(x)[i];
+    double2 yv[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) yv[j] = reinterpret_cast<const double2 *>(y[j])[i];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      a[j] += xv.x * yv[j].x;
+      a[j] += xv.y * yv[j].y;
+    }
+  }
+};
+
+template <int NV>
+static int launch_mdot(mi355x_handle_t h, size_t n, const double *x, const double *const *y, double *out) {
+  MDotF<NV> f;
+  f.x = x;
+  int vec_ok = mi355x_aligned16(x);
+  for (int j = 0; j < NV; ++j) {
+    f.y[j] = y[j];
+    vec_ok = vec_ok && mi355x_aligned16(y[j]);
+  }
+  return launch_reduce<NV, RED_SUM>(h, f, n, vec_ok, out);
+}
+
+extern "C" {
+
+int mi355x_vec_set(mi355x_handle_t h, size_t n, double alpha, double *x) {
+  return launch_map<0>(h, OpSet{alpha}, nullptr, nullptr, nullptr, x, n);
+}
+int mi355x_vec_copy(mi355x_handle_t h, size_t n, const double *x, double *y) {
+  if (x == y) return 0;
+  return launch_map<1>(h, OpCopy{}, x, nullptr, nullptr, y, n);
+}
+int mi355x_vec_scale(mi355x_handle_t h, size_t n, double alpha, double *x) {
+  // VecScale_Seq (bvec1.c:183): alpha==0 -> set 0, alpha==1 -> nothing, else dscal
+  if (alpha == 0.0) return mi355x_vec_set(h, n, 0.0, x);
+  if (alpha == 1.0) return 0;
+  return launch_map<1>(h, OpScale{alpha}, x, nullptr, nullptr, x, n);
+}
+int mi355x_vec_swap(mi355x_handle_t h, size_t n, double *x, double *y) {
+  if (x == y || n == 0) return 0;
+  hipLaunchKernelGGL(swap_kernel, dim3(mi355x_grid_for(n, 4)), dim3(MI355X_BLOCK), 0, h->stream, x, y, n);
+  MI355X_LAUNCH_CHECK();
+  return 0;
+}
+int mi355x_vec_axpy(mi355x_handle_t h, size_t n, double alpha, const double *x, double *y) {
+  if (alpha == 0.0) return 0;  // bvec1.c:253
+  return launch_map<2>(h, OpAxpy{alpha}, x, y, nullptr, y, n);
+}
+int mi355x_vec_aypx(mi355x_handle_t h, size_t n, double alpha, const double *x, double *y) {
+  // dvec2.c:980-1009
+  if (alpha == 0.0) return mi355x_vec_copy(h, n, x, y);
+  if (alpha == 1.0) return mi355x_vec_axpy(h, n, 1.0, x, y);
+  if (alpha == -1.0) return launch_map<2>(h, OpXmY{}, x, y, nullptr, y, n);
+  return launch_map<2>(h, OpAypx{alpha}, x, y, nullptr, y, n);
+}
+int mi355x_vec_axpby(mi355x_handle_t h, size_t n, double alpha, double beta, const double *x, double *y) {
+  // bvec1.c:329-356
+  if (alpha == 0.0) return mi355x_vec_scale(h, n, beta, y);
+  if (beta == 1.0) return mi355x_vec_axpy(h, n, alpha, x, y);
+  if (alpha == 1.0) return mi355x_vec_aypx(h, n, beta, x, y);
+  if (beta == 0.0) return launch_map<1>(h, OpScale{alpha}, x, nullptr, nullptr, y, n);
+  return launch_map<2>(h, OpAxpby{alpha, beta}, x, y, nullptr, y, n);
+}
+int mi355x_vec_waxpy(mi355x_handle_t h, size_t n, double alpha, const double *x, const double *y, double *w) {
+  // dvec2.c:1094-1109
+  if (alpha == 1.0) return launch_map<2>(h, OpXpY{}, x, y, nullptr, w, n);
+  if (alpha == -1.0) return launch_map<2>(h, OpYmX{}, x, y, nullptr, w, n);
+  if (alpha == 0.0) return mi355x_vec_copy(h, n, y, w);
+  return launch_map<2>(h, OpAxpy{alpha}, x, y, nullptr, w, n);
+}
+int mi355x_vec_axpbypcz(mi355x_handle_t h, size_t n, double alpha, double beta, double gamma, const double *x,
+                        const double *y, double *z) {
+  if (alpha == 1.0) return launch_map<3>(h, OpAxpbypczA1{beta, gamma}, x, y, z, z, n);
+  if (gamma == 1.0) return launch_map<3>(h, OpAxpbypczG1{alpha, beta}, x, y, z, z, n);
+  if (gamma == 0.0) return launch_map<2>(h, OpAxpbypczG0{alpha, beta}, x, y, nullptr, z, n);
+  return launch_map<3>(h, OpAxpbypcz{alpha, beta, gamma}, x, y, z, z, n);
+}
+int mi355x_vec_pointwise_mult(mi355x_handle_t h, size_t n, const double *x, const double *y, double *w) {
+  return launch_map<2>(h, OpMul{}, x, y, nullptr, w, n);
+}
+int mi355x_vec_pointwise_divide(mi355x_handle_t h, size_t n, const double *x, const double *y, double *w) {
+  return launch_map<2>(h, OpDiv{}, x, y, nullptr, w, n);
+}
+int mi355x_vec_reciprocal(mi355x_handle_t h, size_t n, double *x) {
+  return launch_map<1>(h, OpRecip{}, x, nullptr, nullptr, x, n);
+}
+int mi355x_vec_jacobi_invert(mi355x_handle_t h, size_t n, double *d, int *nzero_dev) {
+  (void)nzero_dev;
+  return launch_map<1>(h, OpJacInv{}, d, nullptr, nullptr, d, n);
+}
+int mi355x_stream_triad(mi355x_handle_t h, size_t n, double alpha, const double *b, const double *c, double *a) {
+  return launch_map<2>(h, OpTriad{alpha}, b, c, nullptr, a, n);
+}
+
+int mi355x_vec_maxpy(mi355x_handle_t h, size_t n, int nv, const double *alpha, const double *const *y, double *x) {
+  if (nv <= 0 || n == 0) return 0;
+  int pos = 0;
+  int rem = nv & 3;
+  while (pos < nv) {
+    MaxpyArgs args;
+    int g0, g1;
+    if (pos == 0 && rem) {
+      g0 = rem;
+      g1 = (nv - rem >= 4) ? 4 : 0;
+    } else {
+      g0 = 4;
+      g1 = (nv - pos - 4 >= 4) ? 4 : 0;
+    }
+    int cnt = g0 + g1;
+    int vec_ok = mi355x_aligned16(x);
+    for (int j = 0; j < 8; ++j) {
+      args.y[j] = (j < cnt) ? y[pos + j] : nullptr;
+      args.a[j] = (j < cnt) ? alpha[pos + j] : 0.0;
+      if (j < cnt) vec_ok = vec_ok && mi355x_aligned16(y[pos + j]);
+    }
+    int rc = 0;
+    switch (g0 * 10 + g1) {
+      case 10: rc = launch_maxpy<1, 0>(h, args, x, n, vec_ok); break;
+      case 20: rc = launch_maxpy<2, 0>(h, args, x, n, vec_ok); break;
+      case 30: rc = launch_maxpy<3, 0>(h, args, x, n, vec_ok); break;
+      case 40: rc = launch_maxpy<4, 0>(h, args, x, n, vec_ok); break;
+      case 14: rc = launch_maxpy<1, 4>(h, args, x, n, vec_ok); break;
+      case 24: rc = launch_maxpy<2, 4>(h, args, x, n, vec_ok); break;
+      case 34: rc = launch_maxpy<3, 4>(h, args, x, n, vec_ok); break;
+      case 44: rc = launch_maxpy<4, 4>(h, args, x, n, vec_ok); break;
+      default: return (int)hipErrorInvalidValue;
+    }
+    if (rc) return rc;
+    pos += cnt;
+  }
+  return 0;
+}
+
+int mi355x_vec_dot(mi355x_handle_t h, size_t n, const double *x, const double *y, double *out) {
+  DotF f{x, y};
+  return launch_reduce<1, RED_SUM>(h, f, n, mi355x_aligned16(x) && mi355x_aligned16(y), out);
+}
+int mi355x_vec_norm(mi355x_handle_t h, size_t n, int type, const double *x, double *out) {
+  int v = mi355x_aligned16(x);
+  switch (type) {
+    case 0: return launch_reduce<1, RED_SUM>(h, SumAbsF{x}, n, v, out);
+    case 1:
+    case 2: return launch_reduce<1, RED_SUM>(h, SumSqF{x}, n, v, out);
+    case 3: return launch_reduce<1, RED_MAX>(h, MaxAbsF{x}, n, v, out);
+    case 4: return launch_reduce<2, RED_SUM>(h, Norm12F{x}, n, v, out);
+    default: return (int)hipErrorInvalidValue;
+  }
+}
+int mi355x_vec_dotnorm2(mi355x_handle_t h, size_t n, const double *s, const double *t, double *out) {
+  DotNorm2F f{s, t};
+  return launch_reduce<2, RED_SUM>(h, f, n, mi355x_aligned16(s) && mi355x_aligned16(t), out);
+}
+int mi355x_vec_mdot(mi355x_handle_t h, size_t n, int nv, const double *x, const double *const *y, double *out) {
+  int pos = 0;
+  while (pos < nv) {
+    int left = nv - pos;
+    int rc;
+    if (left >= 8)      { rc = launch_mdot<8>(h, n, x, y + pos, out + pos); pos += 8; }
+    else if (left == 7) { rc = launch_mdot<7>(h, n, x, y + pos, out + pos); pos += 7; }
+    else if (left == 6) { rc = launch_mdot<6>(h, n, x, y + pos, out + pos); pos += 6; }
+    else if (left == 5) { rc = launch_mdot<5>(h, n, x, y + pos, out + pos); pos += 5; }
+    else if (left == 4) { rc = launch_mdot<4>(h, n, x, y + pos, out + pos); pos += 4; }
+    else if (left == 3) { rc = launch_mdot<3>(h, n, x, y + pos, out + pos); pos += 3; }
+    else if (left == 2) { rc = launch_mdot<2>(h, n, x, y + pos, out + pos); pos += 2; }
+    else                { rc = launch_mdot<1>(h, n, x, y + pos, out + pos); pos += 1; }
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+}  // extern "C"

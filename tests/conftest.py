@@ -1,0 +1,23 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def built():
+    """Make sure the in-tree libraries exist (built by __graft_entry__.build())."""
+    import petsc_dev_amd as pda
+    if not (os.path.exists(pda.kernels_lib_path()) and os.path.exists(pda.host_lib_path())
+            and os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so"))):
+        pda.build_all()
+    return pda

@@ -1,0 +1,228 @@
+"""ctypes/numpy front end of oracle/liboracle.so (the CPU restatement; test infrastructure only)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_path = os.path.join(ROOT, "oracle", "liboracle.so")
+_lib = None
+
+pd = C.POINTER(C.c_double)
+pi = C.POINTER(C.c_int)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_path):
+            import subprocess
+            subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True)
+        _lib = C.CDLL(_path)
+        _lib.orc_vec_dot.restype = C.c_double
+        _lib.orc_gen_p7.restype = C.c_long
+        _lib.orc_gen_p7.argtypes = [C.c_int, C.c_int, C.c_int, C.c_long, C.c_long, C.c_void_p, C.c_void_p, C.c_void_p]
+    return _lib
+
+
+def D(a):
+    assert a.dtype == np.float64 and a.flags.c_contiguous
+    return a.ctypes.data_as(pd)
+
+
+def I(a):
+    assert a.dtype == np.int32 and a.flags.c_contiguous
+    return a.ctypes.data_as(pi)
+
+
+def ptrs(vecs):
+    arr = (pd * len(vecs))(*[D(v) for v in vecs])
+    return arr
+
+
+def f64(x):
+    return C.c_double(float(x))
+
+
+def n_(a):
+    return C.c_size_t(a.size)
+
+
+# ---- Vec ----
+def vec_set(x, alpha): lib().orc_vec_set(n_(x), f64(alpha), D(x))
+def vec_copy(x, y): lib().orc_vec_copy(n_(x), D(x), D(y))
+def vec_scale(x, alpha): lib().orc_vec_scale(n_(x), f64(alpha), D(x))
+def vec_swap(x, y): lib().orc_vec_swap(n_(x), D(x), D(y))
+def vec_axpy(y, alpha, x): lib().orc_vec_axpy(n_(x), f64(alpha), D(x), D(y))
+def vec_aypx(y, alpha, x): lib().orc_vec_aypx(n_(x), f64(alpha), D(x), D(y))
+def vec_axpby(y, alpha, beta, x): lib().orc_vec_axpby(n_(x), f64(alpha), f64(beta), D(x), D(y))
+def vec_waxpy(w, alpha, x, y): lib().orc_vec_waxpy(n_(x), f64(alpha), D(x), D(y), D(w))
+def vec_axpbypcz(z, a, b, g, x, y): lib().orc_vec_axpbypcz(n_(x), f64(a), f64(b), f64(g), D(x), D(y), D(z))
+def vec_pointwise_mult(w, x, y): lib().orc_vec_pointwise_mult(n_(x), D(x), D(y), D(w))
+def vec_pointwise_divide(w, x, y): lib().orc_vec_pointwise_divide(n_(x), D(x), D(y), D(w))
+def vec_reciprocal(x): lib().orc_vec_reciprocal(n_(x), D(x))
+
+
+def vec_maxpy(x, alpha, ys):
+    alpha = np.ascontiguousarray(alpha, dtype=np.float64)
+    lib().orc_vec_maxpy(n_(x), C.c_int(len(ys)), D(alpha), ptrs(ys), D(x))
+
+
+def vec_dot(x, y):
+    return lib().orc_vec_dot(n_(x), D(x), D(y))
+
+
+def vec_mdot(x, ys):
+    z = np.zeros(len(ys))
+    lib().orc_vec_mdot(n_(x), C.c_int(len(ys)), D(x), ptrs(ys), D(z))
+    return z
+
+
+def vec_norm(x, ntype):
+    out = np.zeros(2)
+    lib().orc_vec_norm(n_(x), C.c_int(ntype), D(x), D(out))
+    return out if ntype == 4 else out[0]
+
+
+def vec_dotnorm2(s, t):
+    dp = C.c_double()
+    nm = C.c_double()
+    lib().orc_vec_dotnorm2(n_(s), D(s), D(t), C.byref(dp), C.byref(nm))
+    return dp.value, nm.value
+
+
+# ---- Mat ----
+def spmv(ai, aj, aa, x):
+    m = ai.size - 1
+    y = np.zeros(m)
+    lib().orc_spmv_csr(C.c_int(m), I(ai), I(aj), D(aa), D(x), D(y))
+    return y
+
+
+def spmv_add(ai, aj, aa, x, y):
+    m = ai.size - 1
+    z = np.zeros(m)
+    lib().orc_spmv_csr_add(C.c_int(m), I(ai), I(aj), D(aa), D(x), D(y), D(z))
+    return z
+
+
+def spmv_t(ai, aj, aa, x, n):
+    m = ai.size - 1
+    y = np.zeros(n)
+    lib().orc_spmv_csr_transpose(C.c_int(m), C.c_int(n), I(ai), I(aj), D(aa), D(x), D(y))
+    return y
+
+
+def spmv_t_add(ai, aj, aa, x, z, n):
+    m = ai.size - 1
+    y = np.zeros(n)
+    lib().orc_spmv_csr_transpose_add(C.c_int(m), C.c_int(n), I(ai), I(aj), D(aa), D(x), D(z), D(y))
+    return y
+
+
+def get_diagonal(ai, aj, aa):
+    m = ai.size - 1
+    d = np.zeros(m)
+    lib().orc_csr_get_diagonal(C.c_int(m), I(ai), I(aj), D(aa), D(d))
+    return d
+
+
+def csr_transpose(ai, aj, aa, n):
+    m = ai.size - 1
+    ti = np.zeros(n + 1, dtype=np.int32)
+    tj = np.zeros(max(aj.size, 1), dtype=np.int32)
+    ta = np.zeros(max(aj.size, 1))
+    lib().orc_csr_transpose(C.c_int(m), C.c_int(n), I(ai), I(aj), D(aa), I(ti), I(tj), D(ta))
+    return ti, tj[:aj.size], ta[:aj.size]
+
+
+def spmv_bsr(bs, ai, aj, aa, x):
+    mbs = ai.size - 1
+    y = np.zeros(mbs * bs)
+    lib().orc_spmv_bsr(C.c_int(mbs), C.c_int(bs), I(ai), I(aj), D(aa), D(x), D(y))
+    return y
+
+
+def gen_p7(nx, ny, nz, rstart=0, rend=None):
+    if rend is None:
+        rend = nx * ny * nz
+    m = rend - rstart
+    nnz = lib().orc_gen_p7(nx, ny, nz, rstart, rend, None, None, None)
+    ai = np.zeros(m + 1, dtype=np.int32)
+    aj = np.zeros(nnz, dtype=np.int32)
+    aa = np.zeros(nnz)
+    lib().orc_gen_p7(nx, ny, nz, rstart, rend, ai.ctypes.data, aj.ctypes.data, aa.ctypes.data)
+    return ai, aj, aa
+
+
+# ---- MPIAIJ set-up ----
+def mpiaij_split(rstart, rend, cstart, cend, ai, aj, aa):
+    mloc = rend - rstart
+    nz = int(ai[rend] - ai[rstart])
+    ad_i = np.zeros(mloc + 1, dtype=np.int32); bo_i = np.zeros(mloc + 1, dtype=np.int32)
+    ad_j = np.zeros(max(nz, 1), dtype=np.int32); bo_j = np.zeros(max(nz, 1), dtype=np.int32)
+    ad_a = np.zeros(max(nz, 1)); bo_a = np.zeros(max(nz, 1))
+    garray = np.zeros(max(nz, 1), dtype=np.int32)
+    ec = lib().orc_mpiaij_split(rstart, rend, cstart, cend, I(ai), I(aj), D(aa), I(ad_i), I(ad_j), D(ad_a),
+                                I(bo_i), I(bo_j), D(bo_a), I(garray))
+    na, nb = int(ad_i[-1]), int(bo_i[-1])
+    return dict(ad_i=ad_i, ad_j=ad_j[:na].copy(), ad_a=ad_a[:na].copy(), bo_i=bo_i, bo_j=bo_j[:nb].copy(),
+                bo_a=bo_a[:nb].copy(), garray=garray[:ec].copy())
+
+
+def scatter_create(size, rank, ranges, garrays):
+    ranges = np.ascontiguousarray(ranges, dtype=np.int32)
+    ecs = np.array([g.size for g in garrays], dtype=np.int32)
+    gs = [np.ascontiguousarray(g, dtype=np.int32) if g.size else np.zeros(1, dtype=np.int32) for g in garrays]
+    gp = (pi * size)(*[I(g) for g in gs])
+    tot = int(ecs.sum()) + 1
+    rprocs = np.zeros(size + 1, dtype=np.int32); rstarts = np.zeros(size + 2, dtype=np.int32)
+    rind = np.zeros(tot, dtype=np.int32)
+    sprocs = np.zeros(size + 1, dtype=np.int32); sstarts = np.zeros(size + 2, dtype=np.int32)
+    sind = np.zeros(tot, dtype=np.int32)
+    lto = np.zeros(tot, dtype=np.int32); lfrom = np.zeros(tot, dtype=np.int32)
+    nr = C.c_int(); ns = C.c_int(); nl = C.c_int()
+    lib().orc_scatter_create(size, rank, I(ranges), gp, I(ecs), C.byref(nr), I(rprocs), I(rstarts), I(rind),
+                             C.byref(ns), I(sprocs), I(sstarts), I(sind), C.byref(nl), I(lto), I(lfrom))
+    nr, ns, nl = nr.value, ns.value, nl.value
+    return dict(rprocs=rprocs[:nr].copy(), rstarts=rstarts[:nr + 1].copy(), rindices=rind[:rstarts[nr]].copy(),
+                sprocs=sprocs[:ns].copy(), sstarts=sstarts[:ns + 1].copy(), sindices=sind[:sstarts[ns]].copy(),
+                lto=lto[:nl].copy(), lfrom=lfrom[:nl].copy())
+
+
+# ---- KSP ----
+class KspOpts(C.Structure):
+    _fields_ = [("ksp_type", C.c_int), ("pc_type", C.c_int), ("rtol", C.c_double), ("abstol", C.c_double),
+                ("dtol", C.c_double), ("max_it", C.c_int), ("restart", C.c_int), ("refine_always", C.c_int),
+                ("guess_nonzero", C.c_int), ("nblocks", C.c_int), ("blk", pi), ("sub_ksp_type", C.c_int),
+                ("sub_pc_type", C.c_int), ("sub_rtol", C.c_double), ("sub_abstol", C.c_double),
+                ("sub_dtol", C.c_double), ("sub_max_it", C.c_int)]
+
+
+KSP = dict(cg=0, gmres=1, bcgs=2, preonly=3)
+PC = dict(none=0, jacobi=1, bjacobi=2)
+
+
+def ksp_solve(ai, aj, aa, b, ksp="gmres", pc="none", x0=None, blocks=None, sub_ksp="preonly", sub_pc="jacobi", **kw):
+    o = KspOpts()
+    lib().orc_ksp_default_opts(C.byref(o))
+    o.ksp_type = KSP[ksp]; o.pc_type = PC[pc]
+    o.sub_ksp_type = KSP[sub_ksp]; o.sub_pc_type = PC[sub_pc]
+    for k, v in kw.items():
+        setattr(o, k, v)
+    n = ai.size - 1
+    x = np.zeros(n) if x0 is None else np.array(x0, dtype=np.float64)
+    if x0 is not None:
+        o.guess_nonzero = 1
+    blk = None
+    if blocks is not None:
+        blk = np.ascontiguousarray(blocks, dtype=np.int32)
+        o.nblocks = blk.size - 1
+        o.blk = I(blk)
+    cap = 20000
+    hist = np.zeros(cap)
+    nh = C.c_int(); its = C.c_int(); reason = C.c_int()
+    rc = lib().orc_ksp_solve(C.byref(o), C.c_int(n), I(ai), I(aj), D(aa), D(b), D(x), D(hist), C.c_int(cap),
+                             C.byref(nh), C.byref(its), C.byref(reason))
+    assert rc == 0
+    return x, hist[:min(nh.value, cap)].copy(), its.value, reason.value

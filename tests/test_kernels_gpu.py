@@ -1,0 +1,330 @@
+"""Parity of every HIP kernel against the oracle, through the C ABI (include/mi355x_kernels.h).
+
+Element-wise kernels, MAXPY and the row-sequential SpMV paths must be BIT-EXACT; reductions use a
+fixed tree and are checked to |err| <= 1e-13 * sum|terms| (stated tolerance, fp64)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import orc
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [0, 1, 2, 3, 63, 64, 65, 255, 1000, 4097, 65536 + 3, 1_000_001]
+
+
+@pytest.fixture(scope="module")
+def dev(built):
+    from gpu import Dev
+    d = Dev()
+    yield d
+    d.free_all()
+
+
+def rnd(n, seed):
+    return np.random.default_rng(seed).standard_normal(n)
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint64)
+
+
+def assert_bitexact(a, b):
+    assert a.shape == b.shape
+    assert np.array_equal(bits(a), bits(b)), "max abs diff %g" % (np.max(np.abs(a - b)) if a.size else 0)
+
+
+@pytest.mark.parametrize("n", SIZES)
+def test_elementwise_bitexact(dev, n):
+    k = dev.k
+    x, y, z = rnd(n, 1), rnd(n, 2), rnd(n, 3)
+    dx, dy, dz = dev.put(x), dev.put(y), dev.put(z)
+    dw = dev.alloc(8 * max(n, 2))
+
+    def reset():
+        for p, a in ((dx, x), (dy, y), (dz, z)):
+            if n:
+                dev.chk(k.mi355x_memcpy_h2d(dev.h, p, a.ctypes.data, a.nbytes))
+
+    for alpha in (0.0, 1.0, -1.0, 0.37):
+        reset(); dev.chk(k.mi355x_vec_axpy(dev.h, n, alpha, dx, dy))
+        r = y.copy(); orc.vec_axpy(r, alpha, x); assert_bitexact(dev.get(dy, n), r)
+        reset(); dev.chk(k.mi355x_vec_aypx(dev.h, n, alpha, dx, dy))
+        r = y.copy(); orc.vec_aypx(r, alpha, x); assert_bitexact(dev.get(dy, n), r)
+        reset(); dev.chk(k.mi355x_vec_waxpy(dev.h, n, alpha, dx, dy, dw))
+        r = np.zeros(n); orc.vec_waxpy(r, alpha, x, y); assert_bitexact(dev.get(dw, n), r)
+        reset(); dev.chk(k.mi355x_vec_scale(dev.h, n, alpha, dx))
+        r = x.copy(); orc.vec_scale(r, alpha); assert_bitexact(dev.get(dx, n), r)
+        for beta in (0.0, 1.0, -2.5):
+            reset(); dev.chk(k.mi355x_vec_axpby(dev.h, n, alpha, beta, dx, dy))
+            r = y.copy(); orc.vec_axpby(r, alpha, beta, x); assert_bitexact(dev.get(dy, n), r)
+            for gamma in (0.0, 1.0, 0.5):
+                reset(); dev.chk(k.mi355x_vec_axpbypcz(dev.h, n, alpha, beta, gamma, dx, dy, dz))
+                r = z.copy(); orc.vec_axpbypcz(r, alpha, beta, gamma, x, y); assert_bitexact(dev.get(dz, n), r)
+    reset(); dev.chk(k.mi355x_vec_pointwise_mult(dev.h, n, dx, dy, dw))
+    r = np.zeros(n); orc.vec_pointwise_mult(r, x, y); assert_bitexact(dev.get(dw, n), r)
+    # aliasing cases of VecPointwiseMult_Seq (w==x, w==y)
+    reset(); dev.chk(k.mi355x_vec_pointwise_mult(dev.h, n, dx, dy, dx)); assert_bitexact(dev.get(dx, n), r)
+    reset(); dev.chk(k.mi355x_vec_pointwise_mult(dev.h, n, dx, dy, dy)); assert_bitexact(dev.get(dy, n), r)
+    reset(); dev.chk(k.mi355x_vec_pointwise_divide(dev.h, n, dx, dy, dw))
+    r = np.zeros(n); orc.vec_pointwise_divide(r, x, y); assert_bitexact(dev.get(dw, n), r)
+    reset(); dev.chk(k.mi355x_vec_set(dev.h, n, 3.25, dw)); assert_bitexact(dev.get(dw, n), np.full(n, 3.25))
+    reset(); dev.chk(k.mi355x_vec_copy(dev.h, n, dx, dw)); assert_bitexact(dev.get(dw, n), x)
+    reset(); dev.chk(k.mi355x_vec_swap(dev.h, n, dx, dy))
+    assert_bitexact(dev.get(dx, n), y); assert_bitexact(dev.get(dy, n), x)
+    xz = x.copy(); xz[::7] = 0.0
+    if n:
+        dev.chk(k.mi355x_memcpy_h2d(dev.h, dx, xz.ctypes.data, xz.nbytes))
+    dev.chk(k.mi355x_vec_reciprocal(dev.h, n, dx))
+    r = xz.copy(); orc.vec_reciprocal(r); assert_bitexact(dev.get(dx, n), r)
+    for p in (dx, dy, dz, dw):
+        dev.free(p)
+
+
+def test_unaligned_views(dev):
+    """Vectors that start 8 bytes off a 16-byte boundary take the scalar path; same bits."""
+    k = dev.k
+    n = 10001
+    x, y = rnd(n + 1, 4), rnd(n + 1, 5)
+    dx, dy = dev.put(x), dev.put(y)
+    ox, oy = C.c_void_p(dx.value + 8), C.c_void_p(dy.value + 8)
+    dev.chk(k.mi355x_vec_axpy(dev.h, n, 0.7, ox, oy))
+    r = y[1:].copy(); orc.vec_axpy(r, 0.7, x[1:].copy())
+    assert_bitexact(dev.get(oy, n), r)
+    dev.chk(k.mi355x_vec_dot(dev.h, n, ox, oy, dev.host_scratch()))
+    got = dev.scalar_out()[0]
+    ref = orc.vec_dot(x[1:].copy(), r)
+    assert abs(got - ref) <= 1e-13 * np.sum(np.abs(x[1:] * r))
+    dev.free(dx); dev.free(dy)
+
+
+@pytest.mark.parametrize("n", SIZES)
+@pytest.mark.parametrize("nv", [1, 2, 3, 4, 5, 7, 8, 9, 12, 30, 31])
+def test_maxpy_bitexact(dev, n, nv):
+    if n > 70000 and nv not in (3, 30):
+        pytest.skip("large size covered for nv=3,30")
+    k = dev.k
+    x = rnd(n, 10)
+    ys = [rnd(n, 100 + j) for j in range(nv)]
+    alpha = rnd(nv, 11)
+    dx = dev.put(x)
+    dys = [dev.put(v) for v in ys]
+    tab = dev.ptr_table(dys)
+    dev.chk(k.mi355x_vec_maxpy(dev.h, n, nv, alpha.ctypes.data_as(C.POINTER(C.c_double)), tab, dx))
+    r = x.copy(); orc.vec_maxpy(r, alpha, ys)
+    assert_bitexact(dev.get(dx, n), r)
+    dev.free(dx)
+    for p in dys:
+        dev.free(p)
+
+
+@pytest.mark.parametrize("n", SIZES)
+def test_reductions(dev, n):
+    k = dev.k
+    x, y = rnd(n, 20), rnd(n, 21)
+    dx, dy = dev.put(x), dev.put(y)
+    out = dev.host_scratch()
+    tol = 1e-13
+    dev.chk(k.mi355x_vec_dot(dev.h, n, dx, dy, out))
+    got = dev.scalar_out()[0]
+    assert abs(got - orc.vec_dot(x, y)) <= tol * np.sum(np.abs(x * y)) + 0.0
+    # run-to-run reproducible (fixed tree)
+    dev.chk(k.mi355x_vec_dot(dev.h, n, dx, dy, out))
+    assert dev.scalar_out()[0] == got
+    dev.chk(k.mi355x_vec_norm(dev.h, n, 1, dx, out))
+    assert abs(np.sqrt(dev.scalar_out()[0]) - orc.vec_norm(x, 1)) <= tol * max(np.linalg.norm(x), 1e-300) * 4
+    dev.chk(k.mi355x_vec_norm(dev.h, n, 0, dx, out))
+    assert abs(dev.scalar_out()[0] - orc.vec_norm(x, 0)) <= tol * np.sum(np.abs(x))
+    dev.chk(k.mi355x_vec_norm(dev.h, n, 3, dx, out))
+    assert dev.scalar_out()[0] == orc.vec_norm(x, 3)  # max is exact
+    dev.chk(k.mi355x_vec_norm(dev.h, n, 4, dx, out))
+    g = dev.scalar_out(2)
+    r = orc.vec_norm(x, 4)
+    assert abs(g[0] - r[0]) <= tol * np.sum(np.abs(x)) and abs(np.sqrt(g[1]) - r[1]) <= 4 * tol * max(r[1], 1e-300)
+    dev.chk(k.mi355x_vec_dotnorm2(dev.h, n, dx, dy, out))
+    g = dev.scalar_out(2)
+    dp, nm = orc.vec_dotnorm2(x, y)
+    assert abs(g[0] - dp) <= tol * np.sum(np.abs(x * y)) and abs(g[1] - nm) <= tol * np.sum(y * y)
+    dev.free(dx); dev.free(dy)
+
+
+def test_norm_inf_nan(dev):
+    k = dev.k
+    x = rnd(5000, 30)
+    x[1234] = np.nan
+    dx = dev.put(x)
+    dev.chk(k.mi355x_vec_norm(dev.h, x.size, 3, dx, dev.host_scratch()))
+    assert np.isnan(dev.scalar_out()[0]) and np.isnan(orc.vec_norm(x, 3))
+    dev.free(dx)
+
+
+@pytest.mark.parametrize("n", [0, 1, 5, 1000, 65537, 300_001])
+@pytest.mark.parametrize("nv", [1, 2, 3, 5, 8, 9, 17, 31])
+def test_mdot(dev, n, nv):
+    k = dev.k
+    x = rnd(n, 40)
+    ys = [rnd(n, 200 + j) for j in range(nv)]
+    dx = dev.put(x)
+    dys = [dev.put(v) for v in ys]
+    dev.chk(k.mi355x_vec_mdot(dev.h, n, nv, dx, dev.ptr_table(dys), dev.host_scratch()))
+    got = dev.scalar_out(nv)
+    ref = orc.vec_mdot(x, ys)
+    for j in range(nv):
+        assert abs(got[j] - ref[j]) <= 1e-13 * np.sum(np.abs(x * ys[j]))
+    dev.free(dx)
+    for p in dys:
+        dev.free(p)
+
+
+# ---------------------------------------------------------------- SpMV
+def upload_csr(dev, ai, aj, aa):
+    return dev.put(ai), dev.put(aj if aj.size else np.zeros(1, np.int32)), dev.put(aa if aa.size else np.zeros(1))
+
+
+def make_plan(dev, ai, rows=None):
+    plan = C.c_void_p()
+    rp = rows.ctypes.data if rows is not None else None
+    dev.chk(dev.k.mi355x_spmv_plan_create(dev.h, ai.size - 1, ai.ctypes.data, rp, C.byref(plan)))
+    return plan
+
+
+def random_csr(m, n, rowlen, seed, sort=True):
+    rng = np.random.default_rng(seed)
+    lens = rowlen(rng, m).astype(np.int64)
+    lens = np.minimum(lens, n)
+    ai = np.zeros(m + 1, dtype=np.int32)
+    ai[1:] = np.cumsum(lens)
+    aj = np.empty(int(ai[-1]), dtype=np.int32)
+    for r in range(m):
+        c = rng.choice(n, size=int(lens[r]), replace=False)
+        aj[ai[r]:ai[r + 1]] = np.sort(c) if sort else c
+    aa = rng.standard_normal(aj.size)
+    return ai, aj, aa
+
+
+def run_spmv(dev, ai, aj, aa, x, y0=None, rows=None):
+    k = dev.k
+    dai, daj, daa = upload_csr(dev, ai, aj, aa)
+    dx = dev.put(x)
+    plan = make_plan(dev, ai, rows)
+    if y0 is None:
+        m_out = ai.size - 1
+        dy = dev.put(np.full(m_out, 7.0))
+        dev.chk(k.mi355x_spmv_csr(dev.h, plan, dai, daj, daa, dx, dy))
+    else:
+        m_out = y0.size
+        dy = dev.put(y0)
+        dev.chk(k.mi355x_spmv_csr_add(dev.h, plan, dai, daj, daa, dx, dy, dy))
+    y = dev.get(dy, m_out)
+    dev.chk(k.mi355x_spmv_plan_destroy(plan))
+    for p in (dai, daj, daa, dx, dy):
+        dev.free(p)
+    return y
+
+
+@pytest.mark.parametrize("dims", [(5, 4, 3), (16, 16, 16), (33, 17, 9), (64, 64, 40)])
+def test_spmv_p7_bitexact(dev, dims):
+    ai, aj, aa = orc.gen_p7(*dims)
+    n = ai.size - 1
+    x = np.sin(0.37 * np.arange(n)) + 1.0
+    assert_bitexact(run_spmv(dev, ai, aj, aa, x), orc.spmv(ai, aj, aa, x))
+    y0 = rnd(n, 50)
+    assert_bitexact(run_spmv(dev, ai, aj, aa, x, y0=y0), orc.spmv_add(ai, aj, aa, x, y0))
+
+
+def test_spmv_short_rows_bitexact(dev):
+    """rows of 0..16 nonzeros incl. empty rows, rectangular: one lane per row, reference summation order"""
+    ai, aj, aa = random_csr(3001, 2000, lambda rng, m: rng.integers(0, 17, m), 60)
+    x = rnd(2000, 61)
+    assert_bitexact(run_spmv(dev, ai, aj, aa, x), orc.spmv(ai, aj, aa, x))
+
+
+def test_spmv_irregular(dev):
+    """log-normal row lengths (SURVEY 8d config 4 stand-in, scaled down) + a few rows longer than the LDS stage"""
+    def rl(rng, m):
+        l = np.clip(np.exp(rng.normal(np.log(60), 0.6, m)), 3, 400)
+        l[::97] = 3000  # > 2048: whole-workgroup path
+        l[5] = 0
+        return l
+    ai, aj, aa = random_csr(1500, 6000, rl, 62)
+    x = rnd(6000, 63)
+    got = run_spmv(dev, ai, aj, aa, x)
+    ref = orc.spmv(ai, aj, aa, x)
+    scale = np.zeros(ai.size - 1)
+    np.add.at(scale, np.repeat(np.arange(ai.size - 1), np.diff(ai)), np.abs(aa * x[aj]))
+    assert np.all(np.abs(got - ref) <= 1e-12 * np.maximum(scale, 1e-300))  # BASELINE.md tolerance
+    y0 = rnd(ai.size - 1, 64)
+    got = run_spmv(dev, ai, aj, aa, x, y0=y0)
+    ref = orc.spmv_add(ai, aj, aa, x, y0)
+    assert np.all(np.abs(got - ref) <= 1e-12 * np.maximum(scale + np.abs(y0), 1e-300))
+
+
+def test_spmv_compressed_rows(dev):
+    """off-diagonal-block shape: most rows empty; compressed-row plan touches only listed rows"""
+    m, n = 5000, 700
+    rng = np.random.default_rng(70)
+    rows = np.sort(rng.choice(m, size=300, replace=False)).astype(np.int32)
+    cai, aj, aa = random_csr(300, n, lambda r, mm: r.integers(1, 4, mm), 71)
+    x = rnd(n, 72)
+    y0 = rnd(m, 73)
+    got = run_spmv(dev, cai, aj, aa, x, y0=y0, rows=rows)
+    # oracle on the uncompressed matrix
+    ai = np.zeros(m + 1, dtype=np.int32)
+    ai[rows + 1] = np.diff(cai)
+    ai = np.cumsum(ai).astype(np.int32)
+    assert_bitexact(got, orc.spmv_add(ai, aj, aa, x, y0))
+
+
+def test_spmv_transpose_via_explicit_transpose(dev):
+    ai, aj, aa = random_csr(700, 900, lambda rng, m: rng.integers(0, 12, m), 80)
+    x = rnd(700, 81)
+    ti, tj, ta = orc.csr_transpose(ai, aj, aa, 900)
+    assert_bitexact(run_spmv(dev, ti, tj, ta, x), orc.spmv_t(ai, aj, aa, x, 900))
+    z = rnd(900, 82)
+    assert_bitexact(run_spmv(dev, ti, tj, ta, x, y0=z), orc.spmv_t_add(ai, aj, aa, x, z, 900))
+
+
+def test_get_diagonal(dev):
+    ai, aj, aa = random_csr(2000, 2000, lambda rng, m: rng.integers(0, 9, m), 90)
+    dai, daj, daa = upload_csr(dev, ai, aj, aa)
+    dd = dev.alloc(8 * 2000)
+    dev.chk(dev.k.mi355x_csr_get_diagonal(dev.h, 2000, dai, daj, daa, dd))
+    assert_bitexact(dev.get(dd, 2000), orc.get_diagonal(ai, aj, aa))
+
+
+@pytest.mark.parametrize("bs", [1, 2, 3, 4, 5])
+def test_spmv_bsr(dev, bs):
+    mbs, nbs = 400, 500
+    ai, aj, _ = random_csr(mbs, nbs, lambda rng, m: rng.integers(0, 30, m), 95 + bs)
+    aa = rnd(aj.size * bs * bs, 96)
+    x = rnd(nbs * bs, 97)
+    dai, daj, daa = upload_csr(dev, ai, aj, aa)
+    dx = dev.put(x)
+    dy = dev.alloc(8 * mbs * bs)
+    dev.chk(dev.k.mi355x_spmv_bsr(dev.h, mbs, bs, dai, daj, daa, dx, dy))
+    got = dev.get(dy, mbs * bs)
+    ref = orc.spmv_bsr(bs, ai, aj, aa, x)
+    assert np.allclose(got, ref, rtol=0, atol=1e-12 * 30 * bs * 10)
+
+
+def test_pack_unpack(dev):
+    k = dev.k
+    n = 50000
+    x = rnd(n, 110)
+    idx = np.random.default_rng(111).permutation(n)[:20000].astype(np.int32)
+    dx, didx = dev.put(x), dev.put(idx)
+    dbuf = dev.alloc(8 * idx.size)
+    dev.chk(k.mi355x_pack(dev.h, idx.size, didx, dx, dbuf))
+    assert_bitexact(dev.get(dbuf, idx.size), x[idx])
+    y = rnd(n, 112)
+    dy = dev.put(y)
+    dev.chk(k.mi355x_unpack_add(dev.h, idx.size, didx, dbuf, dy))
+    r = y.copy(); r[idx] = r[idx] + x[idx]
+    assert_bitexact(dev.get(dy, n), r)
+    dev.chk(k.mi355x_unpack_insert(dev.h, idx.size, didx, dbuf, dy))
+    r[idx] = x[idx]
+    assert_bitexact(dev.get(dy, n), r)
+    dev.chk(k.mi355x_unpack_insert(dev.h, 100, None, dbuf, dy))
+    r[:100] = x[idx][:100]
+    assert_bitexact(dev.get(dy, n), r)
