@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""bench.py -- KSP CG + Jacobi on the 3-D 7-point Poisson operator, 256^3 rows per GPU
+(BASELINE.json configs[1] at N=1; configs[2] = 512^3 in 8 z-slabs at N=8; weak scaling in between).
+
+A step = one CG iteration of the reference's KSPSolve_CG op sequence over the HIPMI355X Vec/Mat types:
+1 SpMV (MatMult_SeqAIJ / MatMult_MPIAIJ with RCCL halo), 1 Jacobi apply, 2 dots, 1 norm, 2 axpy, 1 aypx.
+value = iterations/s x global unknowns (aggregates over ranks under weak scaling); ksp_its_per_sec and
+spmv_gbps carry BASELINE.json's two quantities as absolute numbers.  roofline: the SpMV kernel, timed
+with HIP events on the compute stream inside the timed solve.  cpu_baseline: the oracle's C
+restatement of the same solve on one host core, bounded sample (rank 0, N=1 only).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--n", type=int, default=256, help="grid points per side per GPU (rows per GPU = n^3)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-its", type=int, default=20)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+    import numpy as np
+    dist = None
+    if world > 1:
+        import torch  # noqa: F401  (device runtime first, then our libraries bind to the same one)
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+    import petsc_dev_amd as pda  # noqa: F401
+    from petsc_dev_amd import petsc as P
+    L = P.lib()
+    if world > 1:
+        from petsc_dev_amd import dist as PD
+        comm = PD.torch_comm(device_comm=True)
+    else:
+        comm = L.COMM_SELF
+
+    n = args.n
+    nx, ny, nz = n, n, n * world            # z-slabs: rank r owns planes [r*n, (r+1)*n)
+    mloc = n ** 3
+    rs, re_ = rank * mloc, (rank + 1) * mloc
+    t0 = time.time()
+    ai, aj, aa = P.gen_poisson7(nx, ny, nz, rs, re_)
+    if world > 1:
+        A = P.Mat.from_csr_mpi(ai, aj, aa, mloc, mloc * world, mloc * world, comm=comm)
+    else:
+        A = P.Mat.from_csr(ai, aj, aa, comm=comm)
+    nnz_loc = int(aj.size)
+    u = P.Vec.create(mloc, N=mloc * world, comm=comm)
+    L.VecSet(u.h, 1.0)
+    b, x = u.duplicate(), u.duplicate()
+    A.mult(u, b)                                         # b = A * 1
+    setup_s = time.time() - t0
+
+    ksp = P.KSP(comm=comm)
+    ksp.set_operators(A)
+    ksp.set_type("cg")
+    ksp.set_pc_type("jacobi")
+
+    # the dominant kernel: SpMV of the (diagonal block of the) matrix
+    if world > 1:
+        Ad = C.c_void_p()
+        L.MatMPIAIJGetSeqAIJ(A.h, C.byref(Ad), None, None)
+        m_, i_, j_, a_ = C.c_int(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        L.MatSeqAIJGetArrays(Ad, C.byref(m_), C.byref(i_), C.byref(j_), C.byref(a_))
+        nnz_k = int(np.ctypeslib.as_array(C.cast(i_, C.POINTER(C.c_int)), (mloc + 1,))[mloc])
+        timed = Ad
+    else:
+        nnz_k = nnz_loc
+        timed = A.h
+    spmv_bytes = 12 * nnz_k + 4 * (mloc + 1) + 8 * mloc + 8 * mloc
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    k = pda.load_kernels()
+    # warm-up: W untimed iterations (also uploads the matrix, builds the Jacobi diagonal)
+    ksp.set_tolerances(rtol=0.0, abstol=1e-300, dtol=1e300, max_it=max(args.warmup, 1))
+    ksp.solve(b, x)
+    k.mi355x_device_synchronize()
+    L.MatHIPMI355XSetTiming(timed, 1)
+    ksp.set_tolerances(rtol=0.0, abstol=1e-300, dtol=1e300, max_it=args.steps)
+    barrier()
+    k.mi355x_device_synchronize()
+    t0 = time.perf_counter()
+    ksp.solve(b, x)
+    k.mi355x_device_synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    its = ksp.its
+    nl, tms = C.c_int(), C.c_double()
+    L.MatHIPMI355XGetTiming(timed, C.byref(nl), C.byref(tms))
+    L.MatHIPMI355XSetTiming(timed, 0)
+    if dist is not None:
+        import torch
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0])
+        s = torch.tensor([tms.value / max(nl.value, 1)], dtype=torch.float64)
+        dist.all_reduce(s, op=dist.ReduceOp.MAX)
+        spmv_ms = float(s[0])
+    else:
+        spmv_ms = tms.value / max(nl.value, 1)
+    assert its == args.steps, "solver stopped after %d of %d iterations (reason %d)" % (its, args.steps, ksp.reason)
+
+    its_per_s = args.steps / dt
+    unknowns = mloc * world
+    value = its_per_s * unknowns / 1e6
+    spmv_gbps_one = spmv_bytes / (spmv_ms * 1e-3) / 1e9
+    cg_bytes = spmv_bytes + 136 * mloc                                   # unfused CG+Jacobi op sequence
+    out = {
+        "metric": "KSP CG+Jacobi iterations/s x unknowns (3-D 7-pt Poisson, %d^3 rows per GPU); ksp_its_per_sec and spmv_gbps are BASELINE.json's two quantities" % n,
+        "value": round(value, 3), "unit": "Mdof-it/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "3D 7-pt Poisson P7(%d,%d,%d) = %d rows, %s, KSPCG + PCJACOBI, b = A*1, x0 = 0, exactly K iterations"
+                   % (nx, ny, nz, unknowns, "MatSeqAIJ on 1 GPU" if world == 1 else "MatMPIAIJ in %d z-slabs, RCCL halo" % world),
+                   "rows_per_gpu": mloc, "nnz_per_gpu": nnz_loc, "parallelism": "row-block dp%d" % world},
+        "ksp_its_per_sec": round(its_per_s, 2),
+        "spmv_gbps": round(spmv_gbps_one * world, 1),
+        "ksp_gbps": round(cg_bytes * its_per_s * world / 1e9, 1),
+        "ksp_hbm_frac": round(cg_bytes * its_per_s / 8e12, 4),
+        "roofline": {"bound": "hbm", "kernel": "spmv_csr_rowblock_kernel", "achieved": round(spmv_gbps_one, 1), "peak": 8000.0,
+                     "unit": "GB/s", "frac": round(spmv_gbps_one / 8000.0, 4), "traffic": None,
+                     "algorithmic_bytes_per_launch": spmv_bytes, "avg_launch_ms": round(spmv_ms, 5), "launches_timed": nl.value},
+        "setup_s": round(setup_s, 2),
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import orc
+        # the same workload, bounded sample: the first cpu_its iterations of the same solve on one host core
+        bref = orc.spmv(ai, aj, aa, np.ones(mloc))
+        t0 = time.perf_counter()
+        _, _, cits, _ = orc.ksp_solve(ai, aj, aa, bref, ksp="cg", pc="jacobi", rtol=0.0, abstol=1e-300, dtol=1e300, max_it=args.cpu_its)
+        cdt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": round(cits / cdt * unknowns / 1e6, 3), "unit": "Mdof-it/s", "cores": 1, "kind": "port",
+                               "its_per_sec": round(cits / cdt, 4),
+                               "sample": "first %d CG+Jacobi iterations of the same P7(%d) solve by the oracle (C restatement of the reference CPU path, gcc -O2, 1 thread)" % (cits, n)}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,95 @@
+"""Launcher glue for more than one rank (one process per GPU, started by torch.distributed.run).
+
+torch.distributed (gloo) is plumbing only: it carries the host-side set-up collectives the reference
+does with MPI (layout all-gather, ghost-column lists) and distributes the RCCL unique id.  The data
+path -- halo exchange and scalar all-reduces on device buffers -- is RCCL over xGMI called from C
+(include/mi355x_comm.h), never through Python."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import petsc as P
+
+_AG = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p)
+_AR = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int)
+_BAR = C.CFUNCTYPE(C.c_int, C.c_void_p)
+_keep = []
+
+
+def make_comm(rank, size, allgather_bytes, allreduce_array, barrier):
+    """Build a PetscComm from three Python callables:
+       allgather_bytes(bytes) -> list of `size` bytes objects; allreduce_array(np.ndarray, op) -> np.ndarray; barrier()."""
+    L = P.lib()
+
+    def ag(ctx, sendbuf, nbytes, recvbuf):
+        try:
+            parts = allgather_bytes(C.string_at(sendbuf, nbytes))
+            C.memmove(recvbuf, b"".join(parts), nbytes * size)
+            return 0
+        except Exception as e:  # pragma: no cover
+            print("allgather callback failed:", e, flush=True)
+            return 1
+
+    def ar(ctx, buf, count, is_double, op):
+        try:
+            dt = np.float64 if is_double else np.int32
+            a = np.frombuffer(C.string_at(buf, count * np.dtype(dt).itemsize), dtype=dt).copy()
+            r = np.ascontiguousarray(allreduce_array(a, op), dtype=dt)
+            C.memmove(buf, r.ctypes.data, r.nbytes)
+            return 0
+        except Exception as e:  # pragma: no cover
+            print("allreduce callback failed:", e, flush=True)
+            return 1
+
+    def bar(ctx):
+        barrier()
+        return 0
+
+    cbs = (_AG(ag), _AR(ar), _BAR(bar))
+    _keep.append(cbs)
+    comm = C.c_void_p()
+    L.PetscCommCreate(rank, size, None, C.cast(cbs[0], C.c_void_p), C.cast(cbs[1], C.c_void_p), C.cast(cbs[2], C.c_void_p), C.byref(comm))
+    return comm
+
+
+def torch_comm(device_comm=True):
+    """PetscComm over the default torch.distributed (gloo) group; optionally attaches an RCCL communicator."""
+    import torch
+    import torch.distributed as dist
+    rank, size = dist.get_rank(), dist.get_world_size()
+    ops = {0: dist.ReduceOp.SUM, 1: dist.ReduceOp.MAX, 2: dist.ReduceOp.MIN}
+
+    def allgather_bytes(b):
+        t = torch.frombuffer(bytearray(b), dtype=torch.uint8)
+        outs = [torch.empty_like(t) for _ in range(size)]
+        dist.all_gather(outs, t)
+        return [bytes(o.numpy().tobytes()) for o in outs]
+
+    def allreduce_array(a, op):
+        t = torch.from_numpy(a.astype(np.float64 if a.dtype == np.float64 else np.int64))
+        dist.all_reduce(t, op=ops[op])
+        return t.numpy().astype(a.dtype)
+
+    comm = make_comm(rank, size, allgather_bytes, allreduce_array, dist.barrier)
+    L = P.lib()
+    L.PetscCommSetWorld(comm)
+    if device_comm and size > 1:
+        k = P.load_kernels()
+        uid = C.create_string_buffer(128)
+        if rank == 0:
+            rc = k.mi355x_comm_get_unique_id(uid)
+            if rc:
+                raise RuntimeError("ncclGetUniqueId failed: %s" % k.mi355x_comm_error_string(rc).decode())
+        obj = [uid.raw]
+        dist.broadcast_object_list(obj, src=0)
+        dev = int(os.environ.get("LOCAL_RANK", "0"))
+        rc = k.mi355x_set_device(dev)
+        if rc:
+            raise RuntimeError("hipSetDevice(%d) failed: %s" % (dev, k.mi355x_error_string(rc).decode()))
+        dcomm = C.c_void_p()
+        rc = k.mi355x_comm_init_rank(C.byref(dcomm), size, rank, obj[0])
+        if rc:
+            raise RuntimeError("ncclCommInitRank failed: %s" % k.mi355x_comm_error_string(rc).decode())
+        L.PetscCommSetDeviceComm(comm, dcomm)
+    return comm

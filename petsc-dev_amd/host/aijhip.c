@@ -1,0 +1,448 @@
+/* MATSEQAIJHIPMI355X (and MATSEQBAIJHIPMI355X): host CSR container for assembly (the part of
+ * Mat_SeqAIJ the path needs: src/mat/impls/aij/seq/aij.h:10-39,99-115; MatSetValues_SeqAIJ aij.c:~330,
+ * MatAssemblyEnd_SeqAIJ aij.c:~860) plus the device mirror and the ops the reference's GPU subclass
+ * overrides (MatCreate_SeqAIJCUSP, src/mat/impls/aij/seq/seqcusp/aijcusp.cu:657-681): mult, multadd,
+ * multtranspose[add], getdiagonal, assemblyend, getvecs, destroy. */
+#include "petscimpl.h"
+
+#define SA(A) ((Mat_SeqAIJ *)(A)->data)
+#define SD(A) ((Mat_SeqAIJHIP *)(A)->spptr)
+#define CHUNKSIZE 15   /* aij.h: rows grow by this many slots when preallocation is exceeded */
+
+/* ---------------------------------------------------------------- host container */
+static PetscErrorCode seqaij_prealloc(Mat A, PetscInt nz, const PetscInt *nnz) {
+  PetscErrorCode ierr;
+  Mat_SeqAIJ *a = SA(A);
+  PetscInt m = a->m;
+  if (nz == PETSC_DEFAULT || nz == PETSC_DECIDE) nz = 5;   /* aij.c MatSeqAIJSetPreallocation_SeqAIJ */
+  if (nz < 0) SETERRQ(A->comm, PETSC_ERR_ARG_OUTOFRANGE, "nz cannot be less than 0: value %d", nz);
+  free(a->i); free(a->j); free(a->a); free(a->ilen); free(a->imax);
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)(m + 1), &a->i);CHKERRQ(ierr);
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)PetscMax(m, 1), &a->ilen);CHKERRQ(ierr);
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)PetscMax(m, 1), &a->imax);CHKERRQ(ierr);
+  a->i[0] = 0;
+  for (PetscInt r = 0; r < m; r++) {
+    PetscInt c = nnz ? nnz[r] : nz;
+    if (c < 0) SETERRQ(A->comm, PETSC_ERR_ARG_OUTOFRANGE, "nnz cannot be less than 0: local row %d value %d", r, c);
+    a->imax[r] = c; a->ilen[r] = 0; a->i[r + 1] = a->i[r] + c;
+  }
+  a->maxnz = a->i[m];
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)PetscMax(a->maxnz, 1), &a->j);CHKERRQ(ierr);
+  ierr = PetscMalloc(sizeof(PetscScalar) * (size_t)PetscMax(a->maxnz, 1), &a->a);CHKERRQ(ierr);
+  a->nz = 0; a->compact = PETSC_FALSE;
+  A->preallocated = PETSC_TRUE;
+  return 0;
+}
+
+/* grow row r by CHUNKSIZE slots (MatSeqXAIJReallocateAIJ, aij.h) */
+static PetscErrorCode seqaij_grow(Mat_SeqAIJ *a, PetscInt r) {
+  PetscErrorCode ierr;
+  PetscInt m = a->m, add = CHUNKSIZE, newmax = a->i[m] + add;
+  PetscInt *nj; PetscScalar *na;
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)newmax, &nj);CHKERRQ(ierr);
+  ierr = PetscMalloc(sizeof(PetscScalar) * (size_t)newmax, &na);CHKERRQ(ierr);
+  PetscInt upto = a->i[r] + a->ilen[r];
+  memcpy(nj, a->j, sizeof(PetscInt) * (size_t)upto);
+  memcpy(na, a->a, sizeof(PetscScalar) * (size_t)upto);
+  PetscInt tail = a->i[m] - a->i[r + 1];
+  memcpy(nj + a->i[r + 1] + add, a->j + a->i[r + 1], sizeof(PetscInt) * (size_t)tail);
+  memcpy(na + a->i[r + 1] + add, a->a + a->i[r + 1], sizeof(PetscScalar) * (size_t)tail);
+  for (PetscInt q = r + 1; q <= m; q++) a->i[q] += add;
+  a->imax[r] += add;
+  free(a->j); free(a->a);
+  a->j = nj; a->a = na; a->maxnz = newmax;
+  return 0;
+}
+
+/* one entry of MatSetValues_SeqAIJ: sorted insertion into the row, INSERT or ADD on a hit */
+static PetscErrorCode seqaij_set(Mat_SeqAIJ *a, PetscInt r, PetscInt c, PetscScalar v, InsertMode mode, PetscBool *newnz) {
+  PetscErrorCode ierr;
+  PetscInt *rp = a->j + a->i[r], n = a->ilen[r], lo = 0, hi = n;
+  PetscScalar *ap = a->a + a->i[r];
+  while (hi - lo > 5) { PetscInt t = (lo + hi) / 2; if (rp[t] > c) hi = t; else lo = t; }
+  PetscInt k;
+  for (k = lo; k < n; k++) {
+    if (rp[k] > c) break;
+    if (rp[k] == c) { if (mode == ADD_VALUES) ap[k] += v; else ap[k] = v; return 0; }
+  }
+  if (a->compact && n >= a->imax[r]) { /* packed rows have no slack */ }
+  if (n >= a->imax[r]) {
+    ierr = seqaij_grow(a, r);CHKERRQ(ierr);
+    rp = a->j + a->i[r]; ap = a->a + a->i[r];
+  }
+  for (PetscInt q = n - 1; q >= k; q--) { rp[q + 1] = rp[q]; ap[q + 1] = ap[q]; }
+  rp[k] = c; ap[k] = v;
+  a->ilen[r] = n + 1;
+  a->nz++;
+  if (newnz) *newnz = PETSC_TRUE;
+  return 0;
+}
+
+/* MatAssemblyEnd_SeqAIJ (aij.c:~860-930): squeeze out the unused slots of every row */
+static PetscErrorCode seqaij_compact(Mat_SeqAIJ *a) {
+  PetscInt m = a->m, shift = 0;
+  a->nonzerorows = 0;
+  for (PetscInt r = 0; r < m; r++) {
+    PetscInt start = a->i[r], n = a->ilen[r];
+    if (shift) {
+      memmove(a->j + start - shift, a->j + start, sizeof(PetscInt) * (size_t)n);
+      memmove(a->a + start - shift, a->a + start, sizeof(PetscScalar) * (size_t)n);
+    }
+    PetscInt slack = a->imax[r] - n;
+    a->i[r] = start - shift;
+    shift += slack;
+    a->imax[r] = n;
+    a->nonzerorows += (n > 0);
+  }
+  a->i[m] -= shift;
+  a->nz = a->i[m];
+  a->compact = PETSC_TRUE;
+  return 0;
+}
+
+/* ---------------------------------------------------------------- device mirror */
+static PetscErrorCode device_free(Mat A) {
+  Mat_SeqAIJHIP *d = SD(A);
+  if (!d) return 0;
+  if (d->d_i) mi355x_free(d->d_i);
+  if (d->d_j) mi355x_free(d->d_j);
+  if (d->d_a) mi355x_free(d->d_a);
+  if (d->plan) mi355x_spmv_plan_destroy(d->plan);
+  if (d->t_i) mi355x_free(d->t_i);
+  if (d->t_j) mi355x_free(d->t_j);
+  if (d->t_a) mi355x_free(d->t_a);
+  if (d->t_plan) mi355x_spmv_plan_destroy(d->t_plan);
+  memset(d, 0, sizeof(*d));
+  d->uploaded_state = -1; d->t_state = -1;
+  return 0;
+}
+
+/* MatCUSPCopyToGPU (aijcusp.cu:126-253): H2D of i, j, a when the host copy is newer.  Unlike the
+ * reference, a value-only change (same pattern) re-sends only `a`. */
+PetscErrorCode MatSeqAIJHIPUpload(Mat A) {
+  PetscErrorCode ierr;
+  Mat_SeqAIJ *a = SA(A);
+  Mat_SeqAIJHIP *d = SD(A);
+  PetscDeviceCtx *dc;
+  if (d->uploaded_state == A->state && d->d_a) return 0;
+  ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
+  if (!a->compact) SETERRQ(A->comm, PETSC_ERR_ARG_WRONGSTATE, "matrix must be assembled before it is sent to the GPU");
+  PetscBool same_pattern = (PetscBool)(d->d_a && d->plan && d->cprow_n == -2 - a->nz);   /* see below */
+  if (!same_pattern) {
+    PetscBool keepcprow = d->cprow;
+    device_free(A);
+    d->cprow = keepcprow;
+    PetscInt m = a->m, nrows = m;
+    const PetscInt *ip = a->i; PetscInt *ci = NULL, *ridx = NULL;
+    /* compressed rows when >= 60% of the rows are empty (Mat_CheckCompressedRow ratio, compressedrow.c:28;
+     * the reference forces it off for B, mpiaij.c:705, because its CPU loop gains little -- on the GPU the
+     * off-diagonal block is >99% empty rows and visiting them costs a full pass over y) */
+    PetscBool use_cprow = PETSC_FALSE;
+    if (d->cprow && m > 0 && (double)(m - a->nonzerorows) > 0.6 * m) {
+      use_cprow = PETSC_TRUE;
+      nrows = a->nonzerorows;
+      ierr = PetscMalloc(sizeof(PetscInt) * (size_t)(nrows + 1), &ci);CHKERRQ(ierr);
+      ierr = PetscMalloc(sizeof(PetscInt) * (size_t)PetscMax(nrows, 1), &ridx);CHKERRQ(ierr);
+      PetscInt k = 0; ci[0] = 0;
+      for (PetscInt r = 0; r < m; r++) if (a->i[r + 1] > a->i[r]) { ridx[k] = r; ci[++k] = a->i[r + 1]; }
+      ip = ci;
+    }
+    CHKHIP(mi355x_malloc((void **)&d->d_i, sizeof(PetscInt) * (size_t)(nrows + 1)));
+    CHKHIP(mi355x_malloc((void **)&d->d_j, sizeof(PetscInt) * (size_t)PetscMax(a->nz, 1)));
+    CHKHIP(mi355x_malloc((void **)&d->d_a, sizeof(PetscScalar) * (size_t)PetscMax(a->nz, 1)));
+    CHKHIP(mi355x_memcpy_h2d(dc->h, d->d_i, ip, sizeof(PetscInt) * (size_t)(nrows + 1)));
+    CHKHIP(mi355x_memcpy_h2d(dc->h, d->d_j, a->j, sizeof(PetscInt) * (size_t)a->nz));
+    if (a->bs <= 1) CHKHIP(mi355x_spmv_plan_create(dc->h, nrows, ip, use_cprow ? ridx : NULL, &d->plan));
+    CHKHIP(mi355x_handle_synchronize(dc->h));
+    free(ci); free(ridx);
+    d->cprow_n = -2 - a->nz;   /* remembers the pattern size this mirror was built for */
+    if (!use_cprow) d->cprow = PETSC_FALSE;
+  }
+  size_t vals = (size_t)a->nz * (size_t)(a->bs > 1 ? a->bs * a->bs : 1);
+  if (a->bs > 1 && !same_pattern) { mi355x_free(d->d_a); CHKHIP(mi355x_malloc((void **)&d->d_a, sizeof(PetscScalar) * PetscMax(vals, 1))); }
+  CHKHIP(mi355x_memcpy_h2d(dc->h, d->d_a, a->a, sizeof(PetscScalar) * vals));
+  CHKHIP(mi355x_handle_synchronize(dc->h));
+  d->uploaded_state = A->state;
+  return 0;
+}
+
+PetscErrorCode MatSeqAIJHIPSetCompressedRow(Mat A, PetscBool flg) { SD(A)->cprow = flg; SD(A)->uploaded_state = -1; SD(A)->cprow_n = 0; return 0; }
+
+/* explicit transpose, contributions of each output row in increasing original-row order (the order
+ * MatMultTransposeAdd_SeqAIJ's scatter loop adds them in, aij.c:1100-1112) */
+static PetscErrorCode upload_transpose(Mat A) {
+  PetscErrorCode ierr;
+  Mat_SeqAIJ *a = SA(A);
+  Mat_SeqAIJHIP *d = SD(A);
+  PetscDeviceCtx *dc;
+  if (d->t_state == A->state && d->t_a) return 0;
+  ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
+  PetscInt m = a->m, n = a->n, nz = a->nz;
+  PetscInt *ti, *tj, *next; PetscScalar *ta;
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)(n + 1), &ti);CHKERRQ(ierr);
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)PetscMax(nz, 1), &tj);CHKERRQ(ierr);
+  ierr = PetscMalloc(sizeof(PetscScalar) * (size_t)PetscMax(nz, 1), &ta);CHKERRQ(ierr);
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)PetscMax(n, 1), &next);CHKERRQ(ierr);
+  memset(ti, 0, sizeof(PetscInt) * (size_t)(n + 1));
+  for (PetscInt k = 0; k < nz; k++) ti[a->j[k] + 1]++;
+  for (PetscInt c = 0; c < n; c++) ti[c + 1] += ti[c];
+  for (PetscInt c = 0; c < n; c++) next[c] = ti[c];
+  for (PetscInt r = 0; r < m; r++)
+    for (PetscInt k = a->i[r]; k < a->i[r + 1]; k++) { PetscInt p = next[a->j[k]]++; tj[p] = r; ta[p] = a->a[k]; }
+  if (d->t_i) { mi355x_free(d->t_i); mi355x_free(d->t_j); mi355x_free(d->t_a); mi355x_spmv_plan_destroy(d->t_plan); d->t_plan = NULL; }
+  CHKHIP(mi355x_malloc((void **)&d->t_i, sizeof(PetscInt) * (size_t)(n + 1)));
+  CHKHIP(mi355x_malloc((void **)&d->t_j, sizeof(PetscInt) * (size_t)PetscMax(nz, 1)));
+  CHKHIP(mi355x_malloc((void **)&d->t_a, sizeof(PetscScalar) * (size_t)PetscMax(nz, 1)));
+  CHKHIP(mi355x_memcpy_h2d(dc->h, d->t_i, ti, sizeof(PetscInt) * (size_t)(n + 1)));
+  CHKHIP(mi355x_memcpy_h2d(dc->h, d->t_j, tj, sizeof(PetscInt) * (size_t)nz));
+  CHKHIP(mi355x_memcpy_h2d(dc->h, d->t_a, ta, sizeof(PetscScalar) * (size_t)nz));
+  CHKHIP(mi355x_spmv_plan_create(dc->h, n, ti, NULL, &d->t_plan));
+  CHKHIP(mi355x_handle_synchronize(dc->h));
+  free(ti); free(tj); free(ta); free(next);
+  d->t_state = A->state;
+  return 0;
+}
+
+/* ---------------------------------------------------------------- ops */
+static PetscErrorCode MatSetUp_SeqAIJHIP(Mat A) { return seqaij_prealloc(A, PETSC_DEFAULT, NULL); }
+
+static PetscErrorCode MatSetValues_SeqAIJHIP(Mat A, PetscInt m, const PetscInt im[], PetscInt n, const PetscInt in[], const PetscScalar v[], InsertMode is) {
+  PetscErrorCode ierr;
+  Mat_SeqAIJ *a = SA(A);
+  for (PetscInt k = 0; k < m; k++) {
+    PetscInt row = im[k];
+    if (row < 0) continue;
+    if (row >= a->m) SETERRQ(A->comm, PETSC_ERR_ARG_OUTOFRANGE, "Row too large: row %d max %d", row, a->m - 1);
+    for (PetscInt l = 0; l < n; l++) {
+      if (in[l] < 0) continue;
+      if (in[l] >= a->n) SETERRQ(A->comm, PETSC_ERR_ARG_OUTOFRANGE, "Column too large: col %d max %d", in[l], a->n - 1);
+      ierr = seqaij_set(a, row, in[l], v[k * n + l], is, NULL);CHKERRQ(ierr);   /* row-oriented values, aij.c roworiented */
+    }
+  }
+  return 0;
+}
+
+static PetscErrorCode MatAssemblyEnd_SeqAIJHIP(Mat A, MatAssemblyType mode) {
+  if (mode == MAT_FLUSH_ASSEMBLY) return 0;
+  /* (the reference re-installs ops->mult here because the inode check may have replaced it,
+   *  aijcusp.cu:462-466; this container has no inode variant) */
+  return seqaij_compact(SA(A));
+}
+
+static PetscErrorCode MatMult_SeqAIJHIP(Mat A, Vec xx, Vec yy) {   /* MatMult_SeqAIJCUSP aijcusp.cu:349 */
+  PetscErrorCode ierr;
+  Mat_SeqAIJ *a = SA(A); Mat_SeqAIJHIP *d = SD(A);
+  const PetscScalar *x; PetscScalar *y; PetscDeviceCtx *dc;
+  ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
+  ierr = MatSeqAIJHIPUpload(A);CHKERRQ(ierr);
+  ierr = VecHIPGetRead(xx, &x);CHKERRQ(ierr);
+  ierr = VecHIPGetWrite(yy, &y);CHKERRQ(ierr);
+  ierr = MatTimingBegin(A, dc->h);CHKERRQ(ierr);
+  if (a->bs > 1) CHKHIP(mi355x_spmv_bsr(dc->h, a->m, a->bs, d->d_i, d->d_j, d->d_a, x, y));
+  else {
+    if (d->cprow) CHKHIP(mi355x_vec_set(dc->h, (size_t)a->m, 0.0, y));   /* rows without entries */
+    CHKHIP(mi355x_spmv_csr(dc->h, d->plan, d->d_i, d->d_j, d->d_a, x, y));
+  }
+  ierr = MatTimingEnd(A, dc->h);CHKERRQ(ierr);
+  ierr = VecHIPRestoreWrite(yy);CHKERRQ(ierr);
+  if (a->bs > 1) { ierr = PetscLogFlops(2.0 * a->bs * a->bs * a->nz - (double)a->bs * a->nonzerorows);CHKERRQ(ierr); }
+  else { ierr = PetscLogFlops(2.0 * a->nz - a->nonzerorows);CHKERRQ(ierr); }   /* aij.c:1281 */
+  return 0;
+}
+
+static PetscErrorCode MatMultAdd_SeqAIJHIP(Mat A, Vec xx, Vec yy, Vec zz) {   /* MatMultAdd_SeqAIJCUSP aijcusp.cu:405 */
+  PetscErrorCode ierr;
+  Mat_SeqAIJ *a = SA(A); Mat_SeqAIJHIP *d = SD(A);
+  const PetscScalar *x, *y; PetscScalar *z; PetscDeviceCtx *dc;
+  if (a->bs > 1) SETERRQ(A->comm, PETSC_ERR_SUP, "MatMultAdd for the BAIJ type is outside the ported path");
+  ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
+  ierr = MatSeqAIJHIPUpload(A);CHKERRQ(ierr);
+  ierr = VecHIPGetRead(xx, &x);CHKERRQ(ierr);
+  if (zz == yy) { ierr = VecHIPGetReadWrite(zz, &z);CHKERRQ(ierr); y = z; }
+  else {
+    ierr = VecHIPGetRead(yy, &y);CHKERRQ(ierr);
+    ierr = VecHIPGetWrite(zz, &z);CHKERRQ(ierr);
+    if (d->cprow) { CHKHIP(mi355x_vec_copy(dc->h, (size_t)a->m, y, z)); y = z; }   /* aij.c:1314-1316 */
+  }
+  ierr = MatTimingBegin(A, dc->h);CHKERRQ(ierr);
+  CHKHIP(mi355x_spmv_csr_add(dc->h, d->plan, d->d_i, d->d_j, d->d_a, x, y, z));
+  ierr = MatTimingEnd(A, dc->h);CHKERRQ(ierr);
+  ierr = VecHIPRestoreWrite(zz);CHKERRQ(ierr);
+  ierr = PetscLogFlops(2.0 * a->nz);CHKERRQ(ierr);
+  return 0;
+}
+
+static PetscErrorCode MatMultTransposeAdd_SeqAIJHIP(Mat A, Vec xx, Vec zz, Vec yy) {   /* aij.c:1078: yy = zz + A^T xx */
+  PetscErrorCode ierr;
+  Mat_SeqAIJ *a = SA(A); Mat_SeqAIJHIP *d = SD(A);
+  const PetscScalar *x, *z; PetscScalar *y; PetscDeviceCtx *dc;
+  if (a->bs > 1) SETERRQ(A->comm, PETSC_ERR_SUP, "MatMultTranspose for the BAIJ type is outside the ported path");
+  ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
+  ierr = upload_transpose(A);CHKERRQ(ierr);
+  ierr = VecHIPGetRead(xx, &x);CHKERRQ(ierr);
+  if (zz == yy) { ierr = VecHIPGetReadWrite(yy, &y);CHKERRQ(ierr); z = y; }
+  else { ierr = VecHIPGetRead(zz, &z);CHKERRQ(ierr); ierr = VecHIPGetWrite(yy, &y);CHKERRQ(ierr); }
+  CHKHIP(mi355x_spmv_csr_add(dc->h, d->t_plan, d->t_i, d->t_j, d->t_a, x, z, y));
+  ierr = VecHIPRestoreWrite(yy);CHKERRQ(ierr);
+  ierr = PetscLogFlops(2.0 * a->nz);CHKERRQ(ierr);
+  return 0;
+}
+static PetscErrorCode MatMultTranspose_SeqAIJHIP(Mat A, Vec xx, Vec yy) {   /* aij.c:1124: VecSet(yy,0); Add */
+  PetscErrorCode ierr;
+  Mat_SeqAIJ *a = SA(A); Mat_SeqAIJHIP *d = SD(A);
+  const PetscScalar *x; PetscScalar *y; PetscDeviceCtx *dc;
+  if (a->bs > 1) SETERRQ(A->comm, PETSC_ERR_SUP, "MatMultTranspose for the BAIJ type is outside the ported path");
+  ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
+  ierr = upload_transpose(A);CHKERRQ(ierr);
+  ierr = VecHIPGetRead(xx, &x);CHKERRQ(ierr);
+  ierr = VecHIPGetWrite(yy, &y);CHKERRQ(ierr);
+  /* 0 + p1 + p2 ... == p1 + p2 ... bit for bit, so the plain product kernel serves */
+  CHKHIP(mi355x_spmv_csr(dc->h, d->t_plan, d->t_i, d->t_j, d->t_a, x, y));
+  ierr = VecHIPRestoreWrite(yy);CHKERRQ(ierr);
+  ierr = PetscLogFlops(2.0 * a->nz);CHKERRQ(ierr);
+  return 0;
+}
+
+static PetscErrorCode MatGetDiagonal_SeqAIJHIP(Mat A, Vec v) {   /* aij.c:1040 */
+  PetscErrorCode ierr;
+  Mat_SeqAIJ *a = SA(A); Mat_SeqAIJHIP *d = SD(A);
+  PetscScalar *dv; PetscDeviceCtx *dc;
+  if (v->map->n != a->m) SETERRQ(A->comm, PETSC_ERR_ARG_SIZ, "Nonconforming matrix and vector");
+  if (a->bs > 1 || d->cprow) {   /* host route for the rarely used shapes */
+    PetscScalar *h;
+    ierr = VecGetArray(v, &h);CHKERRQ(ierr);
+    if (a->bs > 1) {
+      PetscInt bs = a->bs, mbs = a->m / bs;
+      for (PetscInt r = 0; r < a->m; r++) h[r] = 0.0;
+      for (PetscInt br = 0; br < mbs; br++) for (PetscInt k = a->i[br]; k < a->i[br + 1]; k++) if (a->j[k] == br)
+        for (PetscInt q = 0; q < bs; q++) h[br * bs + q] = a->a[(size_t)k * bs * bs + q * bs + q];
+    } else {
+      for (PetscInt r = 0; r < a->m; r++) { h[r] = 0.0; for (PetscInt k = a->i[r]; k < a->i[r + 1]; k++) if (a->j[k] == r) { h[r] = a->a[k]; break; } }
+    }
+    return VecRestoreArray(v, &h);
+  }
+  ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
+  ierr = MatSeqAIJHIPUpload(A);CHKERRQ(ierr);
+  ierr = VecHIPGetWrite(v, &dv);CHKERRQ(ierr);
+  CHKHIP(mi355x_csr_get_diagonal(dc->h, a->m, d->d_i, d->d_j, d->d_a, dv));
+  return VecHIPRestoreWrite(v);
+}
+
+static PetscErrorCode MatScale_SeqAIJHIP(Mat A, PetscScalar alpha) {   /* MatScale_SeqAIJ: dscal on a->a */
+  Mat_SeqAIJ *a = SA(A);
+  size_t vals = (size_t)a->nz * (size_t)(a->bs > 1 ? a->bs * a->bs : 1);
+  for (size_t k = 0; k < vals; k++) a->a[k] = alpha * a->a[k];
+  return PetscLogFlops((PetscLogDouble)vals);
+}
+static PetscErrorCode MatZeroEntries_SeqAIJHIP(Mat A) {
+  Mat_SeqAIJ *a = SA(A);
+  size_t vals = (size_t)(a->compact ? a->nz : a->maxnz) * (size_t)(a->bs > 1 ? a->bs * a->bs : 1);
+  memset(a->a, 0, sizeof(PetscScalar) * vals);
+  return 0;
+}
+
+static PetscErrorCode MatGetVecs_HIP(Mat A, Vec *right, Vec *left) {   /* MatGetVecs_SeqAIJCUSP aijcusp.cu:324-345 */
+  PetscErrorCode ierr;
+  if (right) {
+    ierr = VecCreate(A->comm, right);CHKERRQ(ierr);
+    ierr = VecSetSizes(*right, A->cmap->n, A->cmap->N);CHKERRQ(ierr);
+    ierr = VecSetType(*right, VECHIPMI355X);CHKERRQ(ierr);
+  }
+  if (left) {
+    ierr = VecCreate(A->comm, left);CHKERRQ(ierr);
+    ierr = VecSetSizes(*left, A->rmap->n, A->rmap->N);CHKERRQ(ierr);
+    ierr = VecSetType(*left, VECHIPMI355X);CHKERRQ(ierr);
+  }
+  return 0;
+}
+PetscErrorCode MatGetVecs_HIPMI355X(Mat A, Vec *right, Vec *left) { return MatGetVecs_HIP(A, right, left); }
+
+static PetscErrorCode MatDestroy_SeqAIJHIP(Mat A) {   /* free the mirror and zero spptr first, aijcusp.cu:584-586 */
+  Mat_SeqAIJ *a = SA(A);
+  if (SD(A)) { device_free(A); free(A->spptr); A->spptr = NULL; }
+  if (a) { free(a->i); free(a->j); free(a->a); free(a->ilen); free(a->imax); free(a); A->data = NULL; }
+  return 0;
+}
+
+static PetscErrorCode create_common(Mat B, const char *tname, PetscInt bs) {
+  PetscErrorCode ierr;
+  Mat_SeqAIJ *a; Mat_SeqAIJHIP *d;
+  if (B->comm->size > 1) SETERRQ(B->comm, PETSC_ERR_ARG_WRONG, "Comm must be of size 1");
+  ierr = PetscMalloc(sizeof(*a), &a);CHKERRQ(ierr);
+  memset(a, 0, sizeof(*a));
+  ierr = PetscMalloc(sizeof(*d), &d);CHKERRQ(ierr);
+  memset(d, 0, sizeof(*d));
+  d->uploaded_state = -1; d->t_state = -1;
+  a->m = B->rmap->n; a->n = B->cmap->n; a->bs = bs;
+  B->data = a; B->spptr = d;
+  snprintf(B->type_name, sizeof(B->type_name), "%s", tname);
+  MatOps *o = B->ops;
+  o->setvalues = MatSetValues_SeqAIJHIP; o->mult = MatMult_SeqAIJHIP; o->multadd = MatMultAdd_SeqAIJHIP;
+  o->multtranspose = MatMultTranspose_SeqAIJHIP; o->multtransposeadd = MatMultTransposeAdd_SeqAIJHIP;
+  o->getdiagonal = MatGetDiagonal_SeqAIJHIP; o->assemblyend = MatAssemblyEnd_SeqAIJHIP; o->zeroentries = MatZeroEntries_SeqAIJHIP;
+  o->setup = MatSetUp_SeqAIJHIP; o->scale = MatScale_SeqAIJHIP; o->destroy = MatDestroy_SeqAIJHIP; o->getvecs = MatGetVecs_HIP;
+  return 0;
+}
+PetscErrorCode MatCreate_SeqAIJHIPMI355X(Mat B) { return create_common(B, MATSEQAIJHIPMI355X, 1); }
+PetscErrorCode MatCreate_SeqBAIJHIPMI355X(Mat B) { return create_common(B, MATSEQBAIJHIPMI355X, 0); }
+
+PetscErrorCode MatSeqAIJSetPreallocation(Mat A, PetscInt nz, const PetscInt nnz[]) {
+  /* a no-op for other types, like the composed "MatSeqAIJSetPreallocation_C" lookup (aij.c:3908) */
+  if (!A || strcmp(A->type_name, MATSEQAIJHIPMI355X)) return 0;
+  return seqaij_prealloc(A, nz, nnz);
+}
+
+/* MatCreateSeqAIJWithArrays (aij.c): the arrays are copied (the reference aliases them) */
+static PetscErrorCode adopt_csr(Mat B, PetscInt nrows, PetscInt bs, const PetscInt *i, const PetscInt *j, const PetscScalar *a) {
+  PetscErrorCode ierr;
+  Mat_SeqAIJ *s = SA(B);
+  PetscInt nz = i[nrows];
+  size_t vals = (size_t)nz * (size_t)(bs > 1 ? bs * bs : 1);
+  if (i[0] != 0) SETERRQ(B->comm, PETSC_ERR_ARG_OUTOFRANGE, "i (row indices) must start with 0");
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)(nrows + 1), &s->i);CHKERRQ(ierr);
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)PetscMax(nz, 1), &s->j);CHKERRQ(ierr);
+  ierr = PetscMalloc(sizeof(PetscScalar) * PetscMax(vals, 1), &s->a);CHKERRQ(ierr);
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)PetscMax(nrows, 1), &s->ilen);CHKERRQ(ierr);
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)PetscMax(nrows, 1), &s->imax);CHKERRQ(ierr);
+  memcpy(s->i, i, sizeof(PetscInt) * (size_t)(nrows + 1));
+  memcpy(s->j, j, sizeof(PetscInt) * (size_t)nz);
+  memcpy(s->a, a, sizeof(PetscScalar) * vals);
+  s->nonzerorows = 0;
+  for (PetscInt r = 0; r < nrows; r++) {
+    s->ilen[r] = s->imax[r] = i[r + 1] - i[r];
+    if (s->ilen[r] < 0) SETERRQ(B->comm, PETSC_ERR_ARG_OUTOFRANGE, "Negative row length in i (row indices) row = %d length = %d", r, s->ilen[r]);
+    s->nonzerorows += (s->ilen[r] > 0);
+  }
+  s->nz = s->maxnz = nz; s->compact = PETSC_TRUE;
+  if (bs > 1) { s->m = nrows; s->bs = bs; }
+  B->preallocated = PETSC_TRUE; B->assembled = PETSC_TRUE; B->was_assembled = PETSC_TRUE; B->state++;
+  return 0;
+}
+PetscErrorCode MatCreateSeqAIJWithArrays(MPI_Comm comm, PetscInt m, PetscInt n, PetscInt i[], PetscInt j[], PetscScalar a[], Mat *mat) {
+  PetscErrorCode ierr;
+  ierr = MatCreate(comm, mat);CHKERRQ(ierr);
+  ierr = MatSetSizes(*mat, m, n, m, n);CHKERRQ(ierr);
+  ierr = MatSetType(*mat, MATSEQAIJHIPMI355X);CHKERRQ(ierr);
+  ierr = adopt_csr(*mat, m, 1, i, j, a);CHKERRQ(ierr);
+  return 0;
+}
+/* MatCreateSeqBAIJWithArrays (src/mat/impls/baij/seq/baij.c): m, n are point sizes; i, j index blocks */
+PetscErrorCode MatCreateSeqBAIJWithArrays(MPI_Comm comm, PetscInt bs, PetscInt m, PetscInt n, PetscInt i[], PetscInt j[], PetscScalar a[], Mat *mat) {
+  PetscErrorCode ierr;
+  if (bs < 1 || m % bs || n % bs) SETERRQ(comm, PETSC_ERR_ARG_SIZ, "block size %d must divide the local sizes %d, %d", bs, m, n);
+  ierr = MatCreate(comm, mat);CHKERRQ(ierr);
+  ierr = MatSetSizes(*mat, m, n, m, n);CHKERRQ(ierr);
+  ierr = MatSetType(*mat, MATSEQBAIJHIPMI355X);CHKERRQ(ierr);
+  ierr = adopt_csr(*mat, m / bs, bs, i, j, a);CHKERRQ(ierr);
+  if (bs == 1) SA(*mat)->bs = 1;
+  return 0;
+}
+PetscErrorCode MatSeqAIJGetArrays(Mat A, PetscInt *m, const PetscInt **i, const PetscInt **j, const PetscScalar **a) {
+  if (!A || !A->data || (strcmp(A->type_name, MATSEQAIJHIPMI355X) && strcmp(A->type_name, MATSEQBAIJHIPMI355X))) SETERRQ(0, PETSC_ERR_ARG_WRONG, "not a SeqAIJHIPMI355X matrix");
+  Mat_SeqAIJ *s = SA(A);
+  if (m) *m = s->m;
+  if (i) *i = s->i;
+  if (j) *j = s->j;
+  if (a) *a = s->a;
+  return 0;
+}

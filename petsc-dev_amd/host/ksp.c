@@ -1,0 +1,247 @@
+/* KSP driver: the host-side control flow the reference runs unchanged over any Vec/Mat type
+ * (src/ksp/ksp/interface/itfunc.c:175,335; itcreate.c:640-700; iterativ.c:702,911-986; itres.c:39;
+ * macros include/petsc-private/kspimpl.h:181-188).  Only host scalars live here; every vector
+ * operation dispatches through the Vec/Mat function tables to the HIP kernels. */
+#include "petscimpl.h"
+
+#define KSPValid(k) do { if (!(k)) SETERRQ(0, PETSC_ERR_ARG_NULL, "Null KSP"); } while (0)
+
+PetscErrorCode KSPCreate(MPI_Comm comm, KSP *inksp) {   /* itcreate.c:640-700 */
+  PetscErrorCode ierr;
+  KSP ksp;
+  ierr = PetscMalloc(sizeof(*ksp), &ksp);CHKERRQ(ierr);
+  memset(ksp, 0, sizeof(*ksp));
+  ksp->comm = comm;
+  ksp->max_it = 10000; ksp->pc_side = PC_SIDE_DEFAULT; ksp->rtol = 1.e-5; ksp->abstol = 1.e-50; ksp->divtol = 1.e4;
+  ksp->chknorm = -1; ksp->normtype = KSP_NORM_DEFAULT; ksp->rnorm = 0.0; ksp->its = 0; ksp->guess_zero = PETSC_TRUE;
+  ksp->reason = KSP_CONVERGED_ITERATING;
+  *inksp = ksp;
+  return 0;
+}
+
+static struct { const char *name; PetscErrorCode (*fn)(KSP); } ksp_types[] = {
+  {KSPCG, KSPCreate_CG}, {KSPGMRES, KSPCreate_GMRES}, {KSPBCGS, KSPCreate_BCGS}, {KSPPREONLY, KSPCreate_PREONLY}, {NULL, NULL}};
+
+PetscErrorCode KSPSetType(KSP ksp, KSPType type) {
+  PetscErrorCode ierr;
+  KSPValid(ksp);
+  if (!strcmp(ksp->type_name, type)) return 0;
+  for (int i = 0; ksp_types[i].name; i++) {
+    if (!strcmp(ksp_types[i].name, type)) {
+      if (ksp->ops->destroy) { ierr = (*ksp->ops->destroy)(ksp);CHKERRQ(ierr); }
+      if (ksp->work) { ierr = VecDestroyVecs(ksp->nwork, &ksp->work);CHKERRQ(ierr); ksp->nwork = 0; }
+      memset(ksp->ops, 0, sizeof(ksp->ops));
+      ksp->data = NULL; ksp->setupcalled = 0;
+      ierr = (*ksp_types[i].fn)(ksp);CHKERRQ(ierr);
+      snprintf(ksp->type_name, sizeof(ksp->type_name), "%s", type);
+      return 0;
+    }
+  }
+  SETERRQ(ksp->comm, PETSC_ERR_ARG_UNKNOWN_TYPE, "Unable to find requested KSP type %s", type);
+}
+PetscErrorCode KSPGetType(KSP ksp, KSPType *type) { KSPValid(ksp); *type = ksp->type_name; return 0; }
+PetscErrorCode KSPGetPC(KSP ksp, PC *pc) {
+  KSPValid(ksp);
+  if (!ksp->pc) { PetscErrorCode ierr = PCCreate(ksp->comm, &ksp->pc);CHKERRQ(ierr); snprintf(ksp->pc->prefix, sizeof(ksp->pc->prefix), "%s", ksp->prefix); }
+  *pc = ksp->pc;
+  return 0;
+}
+PetscErrorCode KSPSetOperators(KSP ksp, Mat Amat, Mat Pmat, MatStructure flag) {
+  PetscErrorCode ierr; PC pc;
+  ierr = KSPGetPC(ksp, &pc);CHKERRQ(ierr);
+  ierr = PCSetOperators(pc, Amat, Pmat, flag);CHKERRQ(ierr);
+  if (ksp->setupcalled > 1) ksp->setupcalled = 1;   /* so that next solve call will call PCSetUp() on new matrix */
+  return 0;
+}
+PetscErrorCode KSPSetTolerances(KSP ksp, PetscReal rtol, PetscReal abstol, PetscReal dtol, PetscInt maxits) {   /* itfunc.c */
+  KSPValid(ksp);
+  if (rtol != PETSC_DEFAULT) { if (rtol < 0.0 || 1.0 <= rtol) SETERRQ(ksp->comm, PETSC_ERR_ARG_OUTOFRANGE, "Relative tolerance %g must be non-negative and less than 1.0", rtol); ksp->rtol = rtol; }
+  if (abstol != PETSC_DEFAULT) { if (abstol < 0.0) SETERRQ(ksp->comm, PETSC_ERR_ARG_OUTOFRANGE, "Absolute tolerance %g must be non-negative", abstol); ksp->abstol = abstol; }
+  if (dtol != PETSC_DEFAULT) { if (dtol < 0.0) SETERRQ(ksp->comm, PETSC_ERR_ARG_OUTOFRANGE, "Divergence tolerance %g must be larger than 1.0", dtol); ksp->divtol = dtol; }
+  if (maxits != PETSC_DEFAULT) { if (maxits < 0) SETERRQ(ksp->comm, PETSC_ERR_ARG_OUTOFRANGE, "Maximum number of iterations %d must be non-negative", maxits); ksp->max_it = maxits; }
+  return 0;
+}
+PetscErrorCode KSPSetInitialGuessNonzero(KSP ksp, PetscBool flg) { KSPValid(ksp); ksp->guess_zero = (PetscBool)!flg; return 0; }
+PetscErrorCode KSPSetNormType(KSP ksp, KSPNormType t) { KSPValid(ksp); ksp->normtype = t; return 0; }
+PetscErrorCode KSPSetOptionsPrefix(KSP ksp, const char prefix[]) {
+  KSPValid(ksp);
+  snprintf(ksp->prefix, sizeof(ksp->prefix), "%s", prefix ? prefix : "");
+  if (ksp->pc) snprintf(ksp->pc->prefix, sizeof(ksp->pc->prefix), "%s", ksp->prefix);
+  return 0;
+}
+PetscErrorCode KSPSetFromOptions(KSP ksp) {   /* itcl.c KSPSetFromOptions, the options the golden tests use */
+  PetscErrorCode ierr; char t[64]; PetscBool set; PetscReal r; PetscInt iv; PC pc;
+  KSPValid(ksp);
+  ierr = KSPGetPC(ksp, &pc);CHKERRQ(ierr);
+  ierr = PCSetFromOptions(pc);CHKERRQ(ierr);
+  ierr = PetscOptionsGetString(ksp->prefix, "-ksp_type", t, sizeof(t), &set);CHKERRQ(ierr);
+  if (set) { ierr = KSPSetType(ksp, t);CHKERRQ(ierr); }
+  else if (!ksp->type_name[0]) { ierr = KSPSetType(ksp, KSPGMRES);CHKERRQ(ierr); }   /* default, itcl.c */
+  ierr = PetscOptionsGetInt(ksp->prefix, "-ksp_max_it", &iv, &set);CHKERRQ(ierr); if (set) ksp->max_it = iv;
+  ierr = PetscOptionsGetReal(ksp->prefix, "-ksp_rtol", &r, &set);CHKERRQ(ierr); if (set) ksp->rtol = r;
+  ierr = PetscOptionsGetReal(ksp->prefix, "-ksp_atol", &r, &set);CHKERRQ(ierr); if (set) ksp->abstol = r;
+  ierr = PetscOptionsGetReal(ksp->prefix, "-ksp_divtol", &r, &set);CHKERRQ(ierr); if (set) ksp->divtol = r;
+  ierr = PetscOptionsGetString(ksp->prefix, "-ksp_initial_guess_nonzero", t, sizeof(t), &set);CHKERRQ(ierr); if (set) ksp->guess_zero = PETSC_FALSE;
+  if (ksp->ops->setfromoptions) { ierr = (*ksp->ops->setfromoptions)(ksp);CHKERRQ(ierr); }
+  return 0;
+}
+
+/* KSPDefaultGetWork / KSPGetVecs, iterativ.c:911-986: work vectors duplicate vec_sol (inherit its type) */
+PetscErrorCode KSPDefaultGetWork(KSP ksp, PetscInt nw) {
+  PetscErrorCode ierr;
+  if (ksp->work) { ierr = VecDestroyVecs(ksp->nwork, &ksp->work);CHKERRQ(ierr); }
+  ksp->nwork = nw;
+  if (ksp->vec_sol) { ierr = VecDuplicateVecs(ksp->vec_sol, nw, &ksp->work);CHKERRQ(ierr); }
+  else {
+    Vec r;
+    ierr = MatGetVecs(ksp->pc->mat, &r, NULL);CHKERRQ(ierr);
+    ierr = VecDuplicateVecs(r, nw, &ksp->work);CHKERRQ(ierr);
+    ierr = VecDestroy(&r);CHKERRQ(ierr);
+  }
+  return 0;
+}
+
+PetscErrorCode KSPSetUp(KSP ksp) {   /* itfunc.c:175 */
+  PetscErrorCode ierr;
+  KSPValid(ksp);
+  if (!ksp->type_name[0]) { ierr = KSPSetType(ksp, KSPGMRES);CHKERRQ(ierr); }
+  if (ksp->setupcalled == 2) return 0;
+  if (!ksp->pc || !ksp->pc->mat) SETERRQ(ksp->comm, PETSC_ERR_ARG_WRONGSTATE, "Matrix must be set first");
+  if (!ksp->setupcalled) { ierr = (*ksp->ops->setup)(ksp);CHKERRQ(ierr); }
+  /* norm type / side defaults (KSPSetUpNorms_Private): preconditioned norm, left PC for the three methods */
+  if (ksp->normtype == KSP_NORM_DEFAULT) ksp->normtype = strcmp(ksp->type_name, KSPPREONLY) ? KSP_NORM_PRECONDITIONED : KSP_NORM_NONE;
+  if (ksp->pc_side == PC_SIDE_DEFAULT) ksp->pc_side = PC_LEFT;
+  if (ksp->normtype != KSP_NORM_PRECONDITIONED && ksp->normtype != KSP_NORM_NONE)
+    SETERRQ(ksp->comm, PETSC_ERR_SUP, "only the (default) preconditioned residual norm is on the ported path");
+  ierr = PCSetUp(ksp->pc);CHKERRQ(ierr);
+  ksp->setupcalled = 2;
+  return 0;
+}
+
+PetscErrorCode KSPSolve(KSP ksp, Vec b, Vec x) {   /* itfunc.c:335 */
+  PetscErrorCode ierr;
+  KSPValid(ksp);
+  if (b == x) SETERRQ(ksp->comm, PETSC_ERR_SUP, "in-place solve (b == x) is outside the ported path");
+  ksp->vec_rhs = b; ksp->vec_sol = x;
+  ierr = KSPSetUp(ksp);CHKERRQ(ierr);
+  if (ksp->guess_zero) { ierr = VecSet(ksp->vec_sol, 0.0);CHKERRQ(ierr); }
+  if (ksp->res_hist_reset) ksp->res_hist_len = 0;
+  ksp->reason = KSP_CONVERGED_ITERATING;
+  ierr = (*ksp->ops->solve)(ksp);CHKERRQ(ierr);
+  if (!ksp->reason) SETERRQ(ksp->comm, PETSC_ERR_PLIB, "Internal error, solver returned without setting converged reason");
+  return 0;
+}
+PetscErrorCode KSPGetIterationNumber(KSP ksp, PetscInt *its) { KSPValid(ksp); *its = ksp->its; return 0; }
+PetscErrorCode KSPGetResidualNorm(KSP ksp, PetscReal *r) { KSPValid(ksp); *r = ksp->rnorm; return 0; }
+PetscErrorCode KSPGetConvergedReason(KSP ksp, KSPConvergedReason *reason) { KSPValid(ksp); *reason = ksp->reason; return 0; }
+PetscErrorCode KSPSetResidualHistory(KSP ksp, PetscReal a[], PetscInt na, PetscBool reset) {
+  PetscErrorCode ierr;
+  KSPValid(ksp);
+  free(ksp->res_hist_alloc); ksp->res_hist_alloc = NULL;
+  if (na != PETSC_DECIDE && na != PETSC_DEFAULT && a) { ksp->res_hist = a; ksp->res_hist_max = na; }
+  else {
+    if (na == PETSC_DECIDE || na == PETSC_DEFAULT) na = 10000;
+    ierr = PetscMalloc(sizeof(PetscReal) * (size_t)na, &ksp->res_hist_alloc);CHKERRQ(ierr);
+    ksp->res_hist = ksp->res_hist_alloc; ksp->res_hist_max = na;
+  }
+  ksp->res_hist_len = 0; ksp->res_hist_reset = reset;
+  return 0;
+}
+PetscErrorCode KSPGetResidualHistory(KSP ksp, PetscReal *a[], PetscInt *na) { KSPValid(ksp); if (a) *a = ksp->res_hist; if (na) *na = ksp->res_hist_len; return 0; }
+PetscErrorCode KSPLogResidualHistory(KSP ksp, PetscReal norm) {   /* kspimpl.h KSPLogResidualHistory */
+  if (ksp->res_hist && ksp->res_hist_max > ksp->res_hist_len) ksp->res_hist[ksp->res_hist_len++] = norm;
+  return 0;
+}
+PetscErrorCode KSPMonitorSet(KSP ksp, PetscErrorCode (*monitor)(KSP, PetscInt, PetscReal, void *), void *mctx, PetscErrorCode (*destroy)(void **)) {
+  KSPValid(ksp); (void)destroy;
+  ksp->monitor = monitor; ksp->mctx = mctx;
+  return 0;
+}
+PetscErrorCode KSPMonitor(KSP ksp, PetscInt it, PetscReal rnorm) {
+  if (ksp->monitor) { PetscErrorCode ierr = (*ksp->monitor)(ksp, it, rnorm, ksp->mctx);CHKERRQ(ierr); }
+  return 0;
+}
+PetscErrorCode KSPDestroy(KSP *pksp) {
+  PetscErrorCode ierr;
+  KSP ksp = *pksp;
+  if (!ksp) return 0;
+  if (ksp->ops->destroy) { ierr = (*ksp->ops->destroy)(ksp);CHKERRQ(ierr); }
+  if (ksp->work) { ierr = VecDestroyVecs(ksp->nwork, &ksp->work);CHKERRQ(ierr); }
+  ierr = PCDestroy(&ksp->pc);CHKERRQ(ierr);
+  free(ksp->res_hist_alloc);
+  free(ksp); *pksp = NULL;
+  return 0;
+}
+
+/* kspimpl.h:181-188 */
+PetscErrorCode KSP_MatMult(KSP ksp, Mat A, Vec x, Vec y) { (void)ksp; return MatMult(A, x, y); }
+PetscErrorCode KSP_PCApply(KSP ksp, Vec x, Vec y) { return PCApply(ksp->pc, x, y); }
+/* PCApplyBAorAB, src/ksp/pc/interface/precon.c:553-640 (no diagonal scaling) */
+PetscErrorCode KSP_PCApplyBAorAB(KSP ksp, Vec x, Vec y, Vec w) {
+  PetscErrorCode ierr;
+  if (x == y) SETERRQ(ksp->comm, PETSC_ERR_ARG_IDN, "x and y must be different vectors");
+  if (ksp->pc_side == PC_RIGHT) { ierr = PCApply(ksp->pc, x, w);CHKERRQ(ierr); ierr = MatMult(ksp->pc->mat, w, y);CHKERRQ(ierr); }
+  else if (ksp->pc_side == PC_LEFT) { ierr = MatMult(ksp->pc->mat, x, w);CHKERRQ(ierr); ierr = PCApply(ksp->pc, w, y);CHKERRQ(ierr); }
+  else SETERRQ(ksp->comm, PETSC_ERR_SUP, "symmetric preconditioning is outside the ported path");
+  return 0;
+}
+
+/* KSPInitialResidual, itres.c:39-73 */
+PetscErrorCode KSPInitialResidual(KSP ksp, Vec vsoln, Vec vt1, Vec vt2, Vec vres, Vec vb) {
+  PetscErrorCode ierr;
+  Mat Amat = ksp->pc->mat;
+  if (!ksp->guess_zero) {
+    ierr = KSP_MatMult(ksp, Amat, vsoln, vt1);CHKERRQ(ierr);
+    ierr = VecCopy(vb, vt2);CHKERRQ(ierr);
+    ierr = VecAXPY(vt2, -1.0, vt1);CHKERRQ(ierr);
+    if (ksp->pc_side == PC_RIGHT) { ierr = VecCopy(vt2, vres);CHKERRQ(ierr); }
+    else { ierr = KSP_PCApply(ksp, vt2, vres);CHKERRQ(ierr); }
+  } else {
+    ierr = VecCopy(vb, vt2);CHKERRQ(ierr);
+    if (ksp->pc_side == PC_RIGHT) { ierr = VecCopy(vb, vres);CHKERRQ(ierr); }
+    else if (ksp->pc_side == PC_LEFT) { ierr = KSP_PCApply(ksp, vb, vres);CHKERRQ(ierr); }
+    else SETERRQ(ksp->comm, PETSC_ERR_SUP, "Invalid preconditioning side %d", (int)ksp->pc_side);
+  }
+  return 0;
+}
+
+/* KSPDefaultConverged, iterativ.c:702-783 */
+PetscErrorCode KSPDefaultConverged(KSP ksp, PetscInt n, PetscReal rnorm, KSPConvergedReason *reason) {
+  PetscErrorCode ierr;
+  *reason = KSP_CONVERGED_ITERATING;
+  if (ksp->normtype == KSP_NORM_NONE) SETERRQ(ksp->comm, PETSC_ERR_ARG_WRONGSTATE, "Use KSPSkipConverged() with KSPNormType of KSP_NORM_NONE");
+  if (!n) {
+    if (!ksp->guess_zero) {
+      PetscReal snorm;
+      if (ksp->normtype == KSP_NORM_UNPRECONDITIONED || ksp->pc_side == PC_RIGHT) { ierr = VecNorm(ksp->vec_rhs, NORM_2, &snorm);CHKERRQ(ierr); }
+      else {
+        Vec z;
+        ierr = VecDuplicate(ksp->vec_rhs, &z);CHKERRQ(ierr);
+        ierr = KSP_PCApply(ksp, ksp->vec_rhs, z);CHKERRQ(ierr);
+        ierr = VecNorm(z, NORM_2, &snorm);CHKERRQ(ierr);
+        ierr = VecDestroy(&z);CHKERRQ(ierr);
+      }
+      if (!snorm) snorm = rnorm;   /* zero RHS and nonzero guess */
+      ksp->rnorm0 = snorm;
+    } else ksp->rnorm0 = rnorm;
+    ksp->ttol = PetscMax(ksp->rtol * ksp->rnorm0, ksp->abstol);
+  }
+  if (n <= ksp->chknorm) return 0;
+  if (PetscIsInfOrNanScalar(rnorm)) *reason = KSP_DIVERGED_NAN;
+  else if (rnorm <= ksp->ttol) *reason = (rnorm < ksp->abstol) ? KSP_CONVERGED_ATOL : KSP_CONVERGED_RTOL;
+  else if (rnorm >= ksp->divtol * ksp->rnorm0) *reason = KSP_DIVERGED_DTOL;
+  return 0;
+}
+
+/* KSPPREONLY, src/ksp/ksp/impls/preonly/preonly.c: x = PC(b) */
+static PetscErrorCode KSPSetUp_PREONLY(KSP ksp) { (void)ksp; return 0; }
+static PetscErrorCode KSPSolve_PREONLY(KSP ksp) {
+  PetscErrorCode ierr;
+  if (!ksp->guess_zero) SETERRQ(ksp->comm, PETSC_ERR_USER, "Running KSP of preonly doesn't make sense with nonzero initial guess\nyou probably want a KSP type of Richardson");
+  ksp->its = 0;
+  ierr = KSP_PCApply(ksp, ksp->vec_rhs, ksp->vec_sol);CHKERRQ(ierr);
+  ksp->its = 1;
+  ksp->reason = KSP_CONVERGED_ITS;
+  return 0;
+}
+PetscErrorCode KSPCreate_PREONLY(KSP ksp) { ksp->ops->setup = KSPSetUp_PREONLY; ksp->ops->solve = KSPSolve_PREONLY; return 0; }

@@ -1,0 +1,217 @@
+/* Mat: public wrappers (size/state checks, dispatch through mat->ops -- src/mat/interface/matrix.c)
+ * and the string-keyed type registry (src/mat/interface/matreg.c:42-82,137-180). */
+#include "petscimpl.h"
+
+#define MAXTYPES 16
+static struct { char name[32]; MatCreateFn fn; } mat_types[MAXTYPES];
+static int n_mat_types = 0;
+
+PetscErrorCode MatRegister(const char *name, MatCreateFn fn) {
+  for (int i = 0; i < n_mat_types; i++) if (!strcmp(mat_types[i].name, name)) { mat_types[i].fn = fn; return 0; }
+  if (n_mat_types >= MAXTYPES) SETERRQ(0, PETSC_ERR_PLIB, "Mat type table full");
+  snprintf(mat_types[n_mat_types].name, 32, "%s", name);
+  mat_types[n_mat_types++].fn = fn;
+  return 0;
+}
+
+#define MatValid(A, arg) do { if (!(A)) SETERRQ(0, PETSC_ERR_ARG_NULL, "Null Object: Parameter # %d", arg); } while (0)
+#define MatTypeSet(A, arg) do { MatValid(A, arg); if (!(A)->data) SETERRQ((A)->comm, PETSC_ERR_ARG_TYPENOTSET, "Mat type not set: Parameter # %d", arg); } while (0)
+#define MatAssembled(A) do { if (!(A)->assembled) SETERRQ((A)->comm, PETSC_ERR_ARG_WRONGSTATE, "Not for unassembled matrix"); } while (0)
+
+PetscErrorCode MatCreate(MPI_Comm comm, Mat *A) {
+  Mat B;
+  PetscErrorCode ierr = PetscMalloc(sizeof(*B), &B);CHKERRQ(ierr);
+  memset(B, 0, sizeof(*B));
+  B->comm = comm;
+  B->m_req = B->n_req = B->M_req = B->N_req = -1;
+  *A = B;
+  return 0;
+}
+PetscErrorCode MatSetSizes(Mat A, PetscInt m, PetscInt n, PetscInt M, PetscInt N) {
+  MatValid(A, 1);
+  if (M > 0 && m > M) SETERRQ(A->comm, PETSC_ERR_ARG_INCOMP, "Local row size %d cannot be larger than global row size %d", m, M);
+  if (N > 0 && n > N) SETERRQ(A->comm, PETSC_ERR_ARG_INCOMP, "Local column size %d cannot be larger than global column size %d", n, N);
+  A->m_req = m; A->n_req = n; A->M_req = M; A->N_req = N;
+  return 0;
+}
+PetscErrorCode MatSetType(Mat A, MatType type) {
+  PetscErrorCode ierr;
+  MatValid(A, 1);
+  if (!strcmp(A->type_name, type)) return 0;
+  for (int i = 0; i < n_mat_types; i++) {
+    if (!strcmp(mat_types[i].name, type)) {
+      if (A->ops->destroy) { ierr = (*A->ops->destroy)(A);CHKERRQ(ierr); }   /* matreg.c:68-71 */
+      memset(A->ops, 0, sizeof(A->ops));
+      A->data = NULL; A->spptr = NULL;
+      if (!A->rmap) {
+        if (A->m_req == -1 && A->M_req == -1) SETERRQ(A->comm, PETSC_ERR_ORDER, "Must call MatSetSizes() before MatSetType()");
+        ierr = PetscLayoutCreateSetUp(A->comm, A->m_req, A->M_req, &A->rmap);CHKERRQ(ierr);
+        ierr = PetscLayoutCreateSetUp(A->comm, A->n_req, A->N_req, &A->cmap);CHKERRQ(ierr);
+      }
+      ierr = (*mat_types[i].fn)(A);CHKERRQ(ierr);
+      return 0;
+    }
+  }
+  SETERRQ(A->comm, PETSC_ERR_ARG_UNKNOWN_TYPE, "Unknown Mat type given: %s", type);
+}
+PetscErrorCode MatSetFromOptions(Mat A) {
+  char t[64];
+  PetscBool set;
+  PetscErrorCode ierr = PetscOptionsGetString(NULL, "-mat_type", t, sizeof(t), &set);CHKERRQ(ierr);
+  if (!set) snprintf(t, sizeof(t), "%s", MATAIJHIPMI355X);
+  if (!strcmp(t, "aij")) snprintf(t, sizeof(t), "%s", MATAIJHIPMI355X);
+  else if (!strcmp(t, "seqaij")) snprintf(t, sizeof(t), "%s", MATSEQAIJHIPMI355X);
+  else if (!strcmp(t, "mpiaij")) snprintf(t, sizeof(t), "%s", MATMPIAIJHIPMI355X);
+  return MatSetType(A, t);
+}
+PetscErrorCode MatGetType(Mat A, MatType *type) { MatValid(A, 1); *type = A->type_name; return 0; }
+PetscErrorCode MatSetUp(Mat A) {
+  MatTypeSet(A, 1);
+  if (!A->preallocated && A->ops->setup) { PetscErrorCode ierr = (*A->ops->setup)(A);CHKERRQ(ierr); }
+  return 0;
+}
+PetscErrorCode MatSetValues(Mat A, PetscInt m, const PetscInt idxm[], PetscInt n, const PetscInt idxn[], const PetscScalar v[], InsertMode addv) {
+  PetscErrorCode ierr;
+  MatTypeSet(A, 1);
+  if (!m || !n) return 0;
+  if (!A->preallocated) { ierr = MatSetUp(A);CHKERRQ(ierr); }
+  ierr = (*A->ops->setvalues)(A, m, idxm, n, idxn, v, addv);CHKERRQ(ierr);
+  A->assembled = PETSC_FALSE;   /* matrix.c:1083 */
+  return 0;
+}
+PetscErrorCode MatAssemblyBegin(Mat A, MatAssemblyType type) {
+  MatTypeSet(A, 1);
+  if (A->ops->assemblybegin) { PetscErrorCode ierr = (*A->ops->assemblybegin)(A, type);CHKERRQ(ierr); }
+  return 0;
+}
+PetscErrorCode MatAssemblyEnd(Mat A, MatAssemblyType type) {   /* matrix.c:4881 */
+  PetscErrorCode ierr;
+  MatTypeSet(A, 1);
+  if (!A->preallocated) { ierr = MatSetUp(A);CHKERRQ(ierr); }
+  if (A->ops->assemblyend) { ierr = (*A->ops->assemblyend)(A, type);CHKERRQ(ierr); }
+  if (type == MAT_FINAL_ASSEMBLY) { A->assembled = PETSC_TRUE; A->was_assembled = PETSC_TRUE; }
+  A->state++;
+  return 0;
+}
+PetscErrorCode MatDestroy(Mat *A) {
+  PetscErrorCode ierr;
+  if (!*A) return 0;
+  if ((*A)->ops->destroy) { ierr = (*(*A)->ops->destroy)(*A);CHKERRQ(ierr); }
+  ierr = PetscLayoutDestroy(&(*A)->rmap);CHKERRQ(ierr);
+  ierr = PetscLayoutDestroy(&(*A)->cmap);CHKERRQ(ierr);
+  if ((*A)->time_ev) { for (PetscInt k = 0; k < 2 * (*A)->time_cap; k++) mi355x_event_destroy((*A)->time_ev[k]); free((*A)->time_ev); }
+  free(*A); *A = NULL;
+  return 0;
+}
+PetscErrorCode MatGetSize(Mat A, PetscInt *M, PetscInt *N) { MatValid(A, 1); if (M) *M = A->rmap->N; if (N) *N = A->cmap->N; return 0; }
+PetscErrorCode MatGetLocalSize(Mat A, PetscInt *m, PetscInt *n) { MatValid(A, 1); if (m) *m = A->rmap->n; if (n) *n = A->cmap->n; return 0; }
+PetscErrorCode MatGetOwnershipRange(Mat A, PetscInt *rs, PetscInt *re) { MatValid(A, 1); if (rs) *rs = A->rmap->rstart; if (re) *re = A->rmap->rend; return 0; }
+
+PetscErrorCode MatGetVecs(Mat A, Vec *right, Vec *left) {   /* matrix.c:8009-8037 */
+  MatTypeSet(A, 1);
+  PetscErrorCode ierr = (*A->ops->getvecs)(A, right, left);CHKERRQ(ierr);
+  return 0;
+}
+
+PetscErrorCode MatMult(Mat A, Vec x, Vec y) {   /* matrix.c:2132-2158 */
+  PetscErrorCode ierr;
+  MatTypeSet(A, 1); MatAssembled(A);
+  if (x == y) SETERRQ(A->comm, PETSC_ERR_ARG_IDN, "x and y must be different vectors");
+  if (A->cmap->N != x->map->N) SETERRQ(A->comm, PETSC_ERR_ARG_SIZ, "Mat mat,Vec x: global dim %d %d", A->cmap->N, x->map->N);
+  if (A->rmap->N != y->map->N) SETERRQ(A->comm, PETSC_ERR_ARG_SIZ, "Mat mat,Vec y: global dim %d %d", A->rmap->N, y->map->N);
+  if (A->rmap->n != y->map->n) SETERRQ(A->comm, PETSC_ERR_ARG_SIZ, "Mat mat,Vec y: local dim %d %d", A->rmap->n, y->map->n);
+  if (!A->ops->mult) SETERRQ(A->comm, PETSC_ERR_SUP, "This matrix type does not have a multiply defined");
+  ierr = (*A->ops->mult)(A, x, y);CHKERRQ(ierr);
+  PetscObjectStateIncrease(y);
+  return 0;
+}
+PetscErrorCode MatMultAdd(Mat A, Vec v1, Vec v2, Vec v3) {   /* matrix.c:2304 */
+  PetscErrorCode ierr;
+  MatTypeSet(A, 1); MatAssembled(A);
+  if (A->cmap->N != v1->map->N) SETERRQ(A->comm, PETSC_ERR_ARG_SIZ, "Mat mat,Vec v1: global dim %d %d", A->cmap->N, v1->map->N);
+  if (A->rmap->n != v3->map->n) SETERRQ(A->comm, PETSC_ERR_ARG_SIZ, "Mat mat,Vec v3: local dim %d %d", A->rmap->n, v3->map->n);
+  if (A->rmap->n != v2->map->n) SETERRQ(A->comm, PETSC_ERR_ARG_SIZ, "Mat mat,Vec v2: local dim %d %d", A->rmap->n, v2->map->n);
+  if (v1 == v3) SETERRQ(A->comm, PETSC_ERR_ARG_IDN, "v1 and v3 must be different vectors");
+  ierr = (*A->ops->multadd)(A, v1, v2, v3);CHKERRQ(ierr);
+  PetscObjectStateIncrease(v3);
+  return 0;
+}
+PetscErrorCode MatMultTranspose(Mat A, Vec x, Vec y) {   /* matrix.c:2187 */
+  PetscErrorCode ierr;
+  MatTypeSet(A, 1); MatAssembled(A);
+  if (x == y) SETERRQ(A->comm, PETSC_ERR_ARG_IDN, "x and y must be different vectors");
+  if (A->rmap->N != x->map->N) SETERRQ(A->comm, PETSC_ERR_ARG_SIZ, "Mat mat,Vec x: global dim %d %d", A->rmap->N, x->map->N);
+  if (A->cmap->N != y->map->N) SETERRQ(A->comm, PETSC_ERR_ARG_SIZ, "Mat mat,Vec y: global dim %d %d", A->cmap->N, y->map->N);
+  if (!A->ops->multtranspose) SETERRQ(A->comm, PETSC_ERR_SUP, "This matrix type does not have a multiply tranpose defined");
+  ierr = (*A->ops->multtranspose)(A, x, y);CHKERRQ(ierr);
+  PetscObjectStateIncrease(y);
+  return 0;
+}
+PetscErrorCode MatMultTransposeAdd(Mat A, Vec v1, Vec v2, Vec v3) {
+  PetscErrorCode ierr;
+  MatTypeSet(A, 1); MatAssembled(A);
+  if (v1 == v3) SETERRQ(A->comm, PETSC_ERR_ARG_IDN, "v1 and v3 must be different vectors");
+  if (A->rmap->N != v1->map->N) SETERRQ(A->comm, PETSC_ERR_ARG_SIZ, "Mat mat,Vec v1: global dim %d %d", A->rmap->N, v1->map->N);
+  if (A->cmap->N != v2->map->N) SETERRQ(A->comm, PETSC_ERR_ARG_SIZ, "Mat mat,Vec v2: global dim %d %d", A->cmap->N, v2->map->N);
+  if (A->cmap->N != v3->map->N) SETERRQ(A->comm, PETSC_ERR_ARG_SIZ, "Mat mat,Vec v3: global dim %d %d", A->cmap->N, v3->map->N);
+  if (!A->ops->multtransposeadd) SETERRQ(A->comm, PETSC_ERR_SUP, "Mat type %s", A->type_name);
+  ierr = (*A->ops->multtransposeadd)(A, v1, v2, v3);CHKERRQ(ierr);
+  PetscObjectStateIncrease(v3);
+  return 0;
+}
+PetscErrorCode MatGetDiagonal(Mat A, Vec d) {   /* matrix.c:4080 */
+  PetscErrorCode ierr;
+  MatTypeSet(A, 1); MatAssembled(A);
+  if (!A->ops->getdiagonal) SETERRQ(A->comm, PETSC_ERR_SUP, "Mat type %s", A->type_name);
+  ierr = (*A->ops->getdiagonal)(A, d);CHKERRQ(ierr);
+  PetscObjectStateIncrease(d);
+  return 0;
+}
+PetscErrorCode MatScale(Mat A, PetscScalar a) {
+  PetscErrorCode ierr;
+  MatTypeSet(A, 1); MatAssembled(A);
+  if (!A->ops->scale) SETERRQ(A->comm, PETSC_ERR_SUP, "Mat type %s", A->type_name);
+  if (a != 1.0) { ierr = (*A->ops->scale)(A, a);CHKERRQ(ierr); A->state++; }
+  return 0;
+}
+PetscErrorCode MatZeroEntries(Mat A) {
+  PetscErrorCode ierr;
+  MatTypeSet(A, 1);
+  if (!A->ops->zeroentries) SETERRQ(A->comm, PETSC_ERR_SUP, "Mat type %s", A->type_name);
+  ierr = (*A->ops->zeroentries)(A);CHKERRQ(ierr);
+  A->state++;
+  return 0;
+}
+
+/* ---- per-launch device timing used by bench.py (hipEvent pairs on the compute stream) ---- */
+PetscErrorCode MatHIPMI355XSetTiming(Mat A, PetscBool on) {
+  MatValid(A, 1);
+  A->timing = on; A->time_n = 0; A->time_ms = 0.0;
+  if (on && !A->time_ev) {
+    A->time_cap = 4096;
+    PetscErrorCode ierr = PetscMalloc(sizeof(mi355x_event_t) * 2 * (size_t)A->time_cap, &A->time_ev);CHKERRQ(ierr);
+    for (PetscInt k = 0; k < 2 * A->time_cap; k++) CHKHIP(mi355x_event_create(&A->time_ev[k]));
+  }
+  return 0;
+}
+PetscErrorCode MatTimingBegin(Mat A, mi355x_handle_t h) {
+  if (A->timing && A->time_n < A->time_cap) CHKHIP(mi355x_event_record(A->time_ev[2 * A->time_n], h));
+  return 0;
+}
+PetscErrorCode MatTimingEnd(Mat A, mi355x_handle_t h) {
+  if (A->timing && A->time_n < A->time_cap) { CHKHIP(mi355x_event_record(A->time_ev[2 * A->time_n + 1], h)); A->time_n++; }
+  return 0;
+}
+PetscErrorCode MatHIPMI355XGetTiming(Mat A, PetscInt *nlaunches, PetscLogDouble *total_ms) {
+  MatValid(A, 1);
+  double tot = 0.0;
+  for (PetscInt k = 0; k < A->time_n; k++) {
+    float ms = 0.f;
+    CHKHIP(mi355x_event_synchronize(A->time_ev[2 * k + 1]));
+    CHKHIP(mi355x_event_elapsed_ms(A->time_ev[2 * k], A->time_ev[2 * k + 1], &ms));
+    tot += ms;
+  }
+  if (nlaunches) *nlaunches = A->time_n;
+  if (total_ms) *total_ms = tot;
+  return 0;
+}

@@ -1,0 +1,263 @@
+/* MATMPIAIJHIPMI355X: row-block distributed CSR.  Mat_MPIAIJ layout and MatMult choreography of
+ * src/mat/impls/aij/mpi/mpiaij.c:1102-1238 and mmaij.c:9-161; the GPU subclass role of
+ * src/mat/impls/aij/mpi/mpicusp/mpiaijcusp.cu:85-112,204-235.  A (diagonal block, local columns)
+ * and B (off-diagonal block, columns compacted through garray) are MATSEQAIJHIPMI355X. */
+#include "petscimpl.h"
+
+#define MA(A) ((Mat_MPIAIJ *)(A)->data)
+extern PetscErrorCode MatGetVecs_HIPMI355X(Mat A, Vec *right, Vec *left);
+
+static PetscErrorCode make_block(Mat parent, PetscInt m, PetscInt n, Mat *blk) {
+  PetscErrorCode ierr;
+  (void)parent;
+  ierr = MatCreate(PETSC_COMM_SELF, blk);CHKERRQ(ierr);
+  ierr = MatSetSizes(*blk, m, n, m, n);CHKERRQ(ierr);
+  ierr = MatSetType(*blk, MATSEQAIJHIPMI355X);CHKERRQ(ierr);
+  return 0;
+}
+
+PetscErrorCode MatMPIAIJSetPreallocation(Mat A, PetscInt d_nz, const PetscInt d_nnz[], PetscInt o_nz, const PetscInt o_nnz[]) {
+  PetscErrorCode ierr;
+  if (!A || strcmp(A->type_name, MATMPIAIJHIPMI355X)) return 0;   /* composed-function no-op for other types */
+  Mat_MPIAIJ *a = MA(A);
+  if (d_nz == PETSC_DEFAULT || d_nz == PETSC_DECIDE) d_nz = 5;     /* mpiaij.c MatMPIAIJSetPreallocation_MPIAIJ */
+  if (o_nz == PETSC_DEFAULT || o_nz == PETSC_DECIDE) o_nz = 2;
+  if (!a->A) {
+    ierr = make_block(A, A->rmap->n, A->cmap->n, &a->A);CHKERRQ(ierr);
+    ierr = make_block(A, A->rmap->n, A->cmap->N, &a->B);CHKERRQ(ierr);
+  }
+  ierr = MatSeqAIJSetPreallocation(a->A, d_nz, d_nnz);CHKERRQ(ierr);
+  ierr = MatSeqAIJSetPreallocation(a->B, o_nz, o_nnz);CHKERRQ(ierr);
+  A->preallocated = PETSC_TRUE;
+  return 0;
+}
+static PetscErrorCode MatSetUp_MPIAIJHIP(Mat A) { return MatMPIAIJSetPreallocation(A, PETSC_DEFAULT, NULL, PETSC_DEFAULT, NULL); }
+
+static int cmp_int(const void *a, const void *b) { PetscInt x = *(const PetscInt *)a, y = *(const PetscInt *)b; return (x > y) - (x < y); }
+
+/* MatSetValues_MPIAIJ, mpiaij.c:517-560: locally owned rows only (the reference stashes the rest) */
+static PetscErrorCode MatSetValues_MPIAIJHIP(Mat A, PetscInt m, const PetscInt im[], PetscInt n, const PetscInt in[], const PetscScalar v[], InsertMode addv) {
+  PetscErrorCode ierr;
+  Mat_MPIAIJ *a = MA(A);
+  for (PetscInt i = 0; i < m; i++) {
+    if (im[i] < 0) continue;
+    if (im[i] < a->rstart || im[i] >= a->rend) SETERRQ(A->comm, PETSC_ERR_SUP, "row %d is not owned by this process [%d,%d): off-process MatSetValues is outside the ported path", im[i], a->rstart, a->rend);
+    PetscInt row = im[i] - a->rstart;
+    for (PetscInt j = 0; j < n; j++) {
+      PetscInt col = in[j];
+      if (col < 0) continue;
+      if (col >= A->cmap->N) SETERRQ(A->comm, PETSC_ERR_ARG_OUTOFRANGE, "Column too large: col %d max %d", col, A->cmap->N - 1);
+      if (col >= a->cstart && col < a->cend) {
+        PetscInt lc = col - a->cstart;
+        ierr = MatSetValues(a->A, 1, &row, 1, &lc, &v[i * n + j], addv);CHKERRQ(ierr);
+      } else {
+        PetscInt bc = col;
+        if (a->garray) {   /* assembled before: B's columns are compacted (colmap lookup, mpiaij.c:540-550) */
+          PetscInt *p = (PetscInt *)bsearch(&col, a->garray, (size_t)a->ec, sizeof(PetscInt), cmp_int);
+          if (!p) SETERRQ(A->comm, PETSC_ERR_SUP, "new off-diagonal column %d after assembly (MatDisAssemble_MPIAIJ, mmaij.c:170) is outside the ported path", col);
+          bc = (PetscInt)(p - a->garray);
+        }
+        ierr = MatSetValues(a->B, 1, &row, 1, &bc, &v[i * n + j], addv);CHKERRQ(ierr);
+      }
+    }
+  }
+  return 0;
+}
+
+/* MatSetUpMultiply_MPIAIJ, mmaij.c:9-161 */
+PetscErrorCode MatSetUpMultiply_MPIAIJ(Mat mat) {
+  PetscErrorCode ierr;
+  Mat_MPIAIJ *aij = MA(mat);
+  Mat_SeqAIJ *B = (Mat_SeqAIJ *)aij->B->data;
+  PetscInt nzB = B->nz, ec = 0, *garray, *tmp;
+  /* garray = sorted distinct global columns of B (mmaij.c:27-50) */
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)PetscMax(nzB, 1), &tmp);CHKERRQ(ierr);
+  memcpy(tmp, B->j, sizeof(PetscInt) * (size_t)nzB);
+  qsort(tmp, (size_t)nzB, sizeof(PetscInt), cmp_int);
+  for (PetscInt k = 0; k < nzB; k++) if (k == 0 || tmp[k] != tmp[k - 1]) tmp[ec++] = tmp[k];
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)(ec + 1), &garray);CHKERRQ(ierr);
+  memcpy(garray, tmp, sizeof(PetscInt) * (size_t)ec);
+  free(tmp);
+  /* compact out the extra columns in B (mmaij.c:56-63) */
+  for (PetscInt k = 0; k < nzB; k++) {
+    PetscInt *p = (PetscInt *)bsearch(&B->j[k], garray, (size_t)ec, sizeof(PetscInt), cmp_int);
+    B->j[k] = (PetscInt)(p - garray);
+  }
+  B->n = ec;
+  ierr = PetscLayoutDestroy(&aij->B->cmap);CHKERRQ(ierr);
+  ierr = PetscLayoutCreateSetUp(PETSC_COMM_SELF, ec, ec, &aij->B->cmap);CHKERRQ(ierr);
+  aij->B->state++;
+  /* local vector that is used to scatter into (mmaij.c:102) */
+  ierr = VecCreateSeqHIPMI355X(PETSC_COMM_SELF, ec, &aij->lvec);CHKERRQ(ierr);
+  /* generate the scatter context (mmaij.c:131-148) */
+  ierr = VecScatterCreate_PtoS_MPIAIJ(mat->comm, mat->cmap, ec, garray, &aij->Mvctx);CHKERRQ(ierr);
+  aij->garray = garray; aij->ec = ec;
+  ierr = MatSeqAIJHIPSetCompressedRow(aij->B, PETSC_TRUE);CHKERRQ(ierr);
+  return 0;
+}
+
+static PetscErrorCode MatAssemblyEnd_MPIAIJHIP(Mat A, MatAssemblyType mode) {   /* mpiaij.c:650-720 */
+  PetscErrorCode ierr;
+  Mat_MPIAIJ *a = MA(A);
+  if (mode == MAT_FLUSH_ASSEMBLY) return 0;
+  ierr = MatAssemblyBegin(a->A, mode);CHKERRQ(ierr);
+  ierr = MatAssemblyEnd(a->A, mode);CHKERRQ(ierr);
+  ierr = MatAssemblyBegin(a->B, mode);CHKERRQ(ierr);
+  ierr = MatAssemblyEnd(a->B, mode);CHKERRQ(ierr);
+  if (!a->garray) { ierr = MatSetUpMultiply_MPIAIJ(A);CHKERRQ(ierr); }   /* mpiaij.c:701-703 */
+  return 0;
+}
+
+static PetscErrorCode MatMult_MPIAIJHIP(Mat A, Vec xx, Vec yy) {   /* mpiaij.c:1102-1116 */
+  PetscErrorCode ierr;
+  Mat_MPIAIJ *a = MA(A);
+  if (xx->map->n != A->cmap->n) SETERRQ(A->comm, PETSC_ERR_ARG_SIZ, "Incompatible partition of A (%d) and xx (%d)", A->cmap->n, xx->map->n);
+  ierr = VecScatterBegin(a->Mvctx, xx, a->lvec, INSERT_VALUES, SCATTER_FORWARD);CHKERRQ(ierr);   /* halo stream */
+  ierr = (*a->A->ops->mult)(a->A, xx, yy);CHKERRQ(ierr);                                         /* compute stream, overlaps */
+  ierr = VecScatterEnd(a->Mvctx, xx, a->lvec, INSERT_VALUES, SCATTER_FORWARD);CHKERRQ(ierr);
+  ierr = (*a->B->ops->multadd)(a->B, a->lvec, yy, yy);CHKERRQ(ierr);
+  return 0;
+}
+static PetscErrorCode MatMultAdd_MPIAIJHIP(Mat A, Vec xx, Vec yy, Vec zz) {   /* mpiaij.c:1132-1143 */
+  PetscErrorCode ierr;
+  Mat_MPIAIJ *a = MA(A);
+  ierr = VecScatterBegin(a->Mvctx, xx, a->lvec, INSERT_VALUES, SCATTER_FORWARD);CHKERRQ(ierr);
+  ierr = (*a->A->ops->multadd)(a->A, xx, yy, zz);CHKERRQ(ierr);
+  ierr = VecScatterEnd(a->Mvctx, xx, a->lvec, INSERT_VALUES, SCATTER_FORWARD);CHKERRQ(ierr);
+  ierr = (*a->B->ops->multadd)(a->B, a->lvec, zz, zz);CHKERRQ(ierr);
+  return 0;
+}
+static PetscErrorCode MatMultTranspose_MPIAIJHIP(Mat A, Vec xx, Vec yy) {   /* mpiaij.c:1147-1174, !merged branch */
+  PetscErrorCode ierr;
+  Mat_MPIAIJ *a = MA(A);
+  ierr = (*a->B->ops->multtranspose)(a->B, xx, a->lvec);CHKERRQ(ierr);
+  ierr = VecScatterBegin(a->Mvctx, a->lvec, yy, ADD_VALUES, SCATTER_REVERSE);CHKERRQ(ierr);
+  ierr = (*a->A->ops->multtranspose)(a->A, xx, yy);CHKERRQ(ierr);
+  ierr = VecScatterEnd(a->Mvctx, a->lvec, yy, ADD_VALUES, SCATTER_REVERSE);CHKERRQ(ierr);
+  return 0;
+}
+static PetscErrorCode MatMultTransposeAdd_MPIAIJHIP(Mat A, Vec xx, Vec yy, Vec zz) {   /* mpiaij.c:1223-1238 */
+  PetscErrorCode ierr;
+  Mat_MPIAIJ *a = MA(A);
+  ierr = (*a->B->ops->multtranspose)(a->B, xx, a->lvec);CHKERRQ(ierr);
+  ierr = VecScatterBegin(a->Mvctx, a->lvec, zz, ADD_VALUES, SCATTER_REVERSE);CHKERRQ(ierr);
+  ierr = (*a->A->ops->multtransposeadd)(a->A, xx, yy, zz);CHKERRQ(ierr);
+  ierr = VecScatterEnd(a->Mvctx, a->lvec, zz, ADD_VALUES, SCATTER_REVERSE);CHKERRQ(ierr);
+  return 0;
+}
+static PetscErrorCode MatGetDiagonal_MPIAIJHIP(Mat A, Vec v) {   /* mpiaij.c:1246-1256 */
+  if (A->rmap->N != A->cmap->N) SETERRQ(A->comm, PETSC_ERR_SUP, "Supports only square matrix where A->A is diag block");
+  if (A->rmap->rstart != A->cmap->rstart || A->rmap->rend != A->cmap->rend) SETERRQ(A->comm, PETSC_ERR_ARG_SIZ, "row partition must equal col partition");
+  return (*MA(A)->A->ops->getdiagonal)(MA(A)->A, v);
+}
+static PetscErrorCode MatScale_MPIAIJHIP(Mat A, PetscScalar aa) {
+  PetscErrorCode ierr;
+  ierr = MatScale(MA(A)->A, aa);CHKERRQ(ierr);
+  ierr = MatScale(MA(A)->B, aa);CHKERRQ(ierr);
+  return 0;
+}
+static PetscErrorCode MatZeroEntries_MPIAIJHIP(Mat A) {
+  PetscErrorCode ierr;
+  ierr = MatZeroEntries(MA(A)->A);CHKERRQ(ierr);
+  ierr = MatZeroEntries(MA(A)->B);CHKERRQ(ierr);
+  return 0;
+}
+static PetscErrorCode MatDestroy_MPIAIJHIP(Mat A) {
+  PetscErrorCode ierr;
+  Mat_MPIAIJ *a = MA(A);
+  if (!a) return 0;
+  ierr = MatDestroy(&a->A);CHKERRQ(ierr);
+  ierr = MatDestroy(&a->B);CHKERRQ(ierr);
+  ierr = VecDestroy(&a->lvec);CHKERRQ(ierr);
+  ierr = VecScatterDestroy(&a->Mvctx);CHKERRQ(ierr);
+  free(a->garray);
+  free(a); A->data = NULL;
+  return 0;
+}
+
+PetscErrorCode MatCreate_MPIAIJHIPMI355X(Mat B) {   /* MatCreate_MPIAIJCUSP, mpiaijcusp.cu:204-235 */
+  PetscErrorCode ierr;
+  Mat_MPIAIJ *a;
+  ierr = PetscMalloc(sizeof(*a), &a);CHKERRQ(ierr);
+  memset(a, 0, sizeof(*a));
+  a->rstart = B->rmap->rstart; a->rend = B->rmap->rend; a->cstart = B->cmap->rstart; a->cend = B->cmap->rend;
+  B->data = a;
+  snprintf(B->type_name, sizeof(B->type_name), "%s", MATMPIAIJHIPMI355X);
+  MatOps *o = B->ops;
+  o->setvalues = MatSetValues_MPIAIJHIP; o->mult = MatMult_MPIAIJHIP; o->multadd = MatMultAdd_MPIAIJHIP;
+  o->multtranspose = MatMultTranspose_MPIAIJHIP; o->multtransposeadd = MatMultTransposeAdd_MPIAIJHIP;
+  o->getdiagonal = MatGetDiagonal_MPIAIJHIP; o->assemblyend = MatAssemblyEnd_MPIAIJHIP; o->zeroentries = MatZeroEntries_MPIAIJHIP;
+  o->setup = MatSetUp_MPIAIJHIP; o->scale = MatScale_MPIAIJHIP; o->destroy = MatDestroy_MPIAIJHIP; o->getvecs = MatGetVecs_HIPMI355X;
+  return 0;
+}
+/* base name "aijhipmi355x" -> seq or mpi by communicator size (MatRegisterBaseName, matreg.c:161-180) */
+PetscErrorCode MatCreate_AIJHIPMI355X(Mat B) {
+  return (B->comm->size == 1) ? MatCreate_SeqAIJHIPMI355X(B) : MatCreate_MPIAIJHIPMI355X(B);
+}
+
+/* MatCreateMPIAIJWithArrays (mpiaij.c; via MatMPIAIJSetPreallocationCSR): i/j/a hold this rank's rows with
+ * global, ascending column indices.  The split is the column test of MatSetValues_MPIAIJ done in bulk. */
+PetscErrorCode MatCreateMPIAIJWithArrays(MPI_Comm comm, PetscInt m, PetscInt n, PetscInt M, PetscInt N, const PetscInt i[], const PetscInt j[], const PetscScalar a[], Mat *mat) {
+  PetscErrorCode ierr;
+  Mat A;
+  if (i[0]) SETERRQ(comm, PETSC_ERR_ARG_OUTOFRANGE, "i (row indices) must start with 0");
+  if (m < 0) SETERRQ(comm, PETSC_ERR_ARG_OUTOFRANGE, "local number of rows (m) cannot be PETSC_DECIDE, or negative");
+  ierr = MatCreate(comm, &A);CHKERRQ(ierr);
+  ierr = MatSetSizes(A, m, n, M, N);CHKERRQ(ierr);
+  ierr = MatSetType(A, MATMPIAIJHIPMI355X);CHKERRQ(ierr);
+  Mat_MPIAIJ *aij = MA(A);
+  PetscInt cs = aij->cstart, ce = aij->cend, nd = 0, no = 0;
+  for (PetscInt k = 0; k < i[m]; k++) { if (j[k] >= cs && j[k] < ce) nd++; else no++; }
+  PetscInt *di, *dj, *oi, *oj; PetscScalar *da, *oa;
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)(m + 1), &di);CHKERRQ(ierr);
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)(m + 1), &oi);CHKERRQ(ierr);
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)PetscMax(nd, 1), &dj);CHKERRQ(ierr);
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)PetscMax(no, 1), &oj);CHKERRQ(ierr);
+  ierr = PetscMalloc(sizeof(PetscScalar) * (size_t)PetscMax(nd, 1), &da);CHKERRQ(ierr);
+  ierr = PetscMalloc(sizeof(PetscScalar) * (size_t)PetscMax(no, 1), &oa);CHKERRQ(ierr);
+  nd = no = 0; di[0] = oi[0] = 0;
+  for (PetscInt r = 0; r < m; r++) {
+    for (PetscInt k = i[r]; k < i[r + 1]; k++) {
+      if (j[k] < 0 || j[k] >= A->cmap->N) SETERRQ(comm, PETSC_ERR_ARG_OUTOFRANGE, "Column %d out of range [0,%d) in row %d", j[k], A->cmap->N, r);
+      if (k > i[r] && j[k] <= j[k - 1]) SETERRQ(comm, PETSC_ERR_ARG_WRONG, "columns of row %d must be ascending and distinct", r);
+      if (j[k] >= cs && j[k] < ce) { dj[nd] = j[k] - cs; da[nd++] = a[k]; }
+      else { oj[no] = j[k]; oa[no++] = a[k]; }
+    }
+    di[r + 1] = nd; oi[r + 1] = no;
+  }
+  ierr = MatCreateSeqAIJWithArrays(PETSC_COMM_SELF, m, A->cmap->n, di, dj, da, &aij->A);CHKERRQ(ierr);
+  ierr = MatCreateSeqAIJWithArrays(PETSC_COMM_SELF, m, A->cmap->N, oi, oj, oa, &aij->B);CHKERRQ(ierr);
+  free(di); free(dj); free(da); free(oi); free(oj); free(oa);
+  A->preallocated = PETSC_TRUE;
+  ierr = MatSetUpMultiply_MPIAIJ(A);CHKERRQ(ierr);
+  A->assembled = PETSC_TRUE; A->was_assembled = PETSC_TRUE; A->state++;
+  *mat = A;
+  return 0;
+}
+
+PetscErrorCode MatMPIAIJGetSeqAIJ(Mat A, Mat *Ad, Mat *Ao, const PetscInt **garray) {   /* mpiaij.c MatMPIAIJGetSeqAIJ */
+  if (!A || strcmp(A->type_name, MATMPIAIJHIPMI355X)) SETERRQ(0, PETSC_ERR_ARG_WRONG, "not an MPIAIJHIPMI355X matrix");
+  if (Ad) *Ad = MA(A)->A;
+  if (Ao) *Ao = MA(A)->B;
+  if (garray) *garray = MA(A)->garray;
+  return 0;
+}
+PetscErrorCode MatMPIAIJGetScatter(Mat A, VecScatter *ctx, Vec *lvec, PetscInt *ec) {
+  if (!A || strcmp(A->type_name, MATMPIAIJHIPMI355X)) SETERRQ(0, PETSC_ERR_ARG_WRONG, "not an MPIAIJHIPMI355X matrix");
+  if (ctx) *ctx = MA(A)->Mvctx;
+  if (lvec) *lvec = MA(A)->lvec;
+  if (ec) *ec = MA(A)->ec;
+  return 0;
+}
+
+PetscErrorCode PetscHIPMI355XRegisterAll(void) {
+  PetscErrorCode ierr;
+  ierr = VecRegister(VECSEQHIPMI355X, VecCreate_SeqHIPMI355X);CHKERRQ(ierr);
+  ierr = VecRegister(VECMPIHIPMI355X, VecCreate_MPIHIPMI355X);CHKERRQ(ierr);
+  ierr = VecRegister(VECHIPMI355X, VecCreate_HIPMI355X);CHKERRQ(ierr);
+  ierr = MatRegister(MATSEQAIJHIPMI355X, MatCreate_SeqAIJHIPMI355X);CHKERRQ(ierr);
+  ierr = MatRegister(MATMPIAIJHIPMI355X, MatCreate_MPIAIJHIPMI355X);CHKERRQ(ierr);
+  ierr = MatRegister(MATAIJHIPMI355X, MatCreate_AIJHIPMI355X);CHKERRQ(ierr);
+  ierr = MatRegister(MATSEQBAIJHIPMI355X, MatCreate_SeqBAIJHIPMI355X);CHKERRQ(ierr);
+  return 0;
+}

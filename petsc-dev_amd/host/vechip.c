@@ -1,0 +1,379 @@
+/* VECSEQHIPMI355X / VECMPIHIPMI355X: vectors resident in HBM.  The role of
+ * src/vec/vec/impls/seq/seqcusp/veccusp.cu and src/vec/vec/impls/mpi/mpicusp/mpicusp.cu in the
+ * reference (ops tables veccusp.cu:1915-1941, mpicusp.cu:193-217), written against the C ABI of
+ * mi355x_kernels.h.  Coherence: a host mirror exists only after the first host access; flags as in
+ * cuspvecimpl.h:95-150.  Reductions: device two-level tree -> (RCCL all-reduce when the
+ * communicator has more than one rank, replacing MPI_Allreduce of pbvec.c:16,30 / pvec2.c:20,62-80)
+ * -> pinned host scalar -> one stream synchronise. */
+#include "petscimpl.h"
+
+#define VH(v) ((Vec_HIPMI355X *)(v)->data)
+
+static PetscErrorCode dev_alloc(Vec v) {
+  Vec_HIPMI355X *s = VH(v);
+  if (!s->dev) {
+    PetscDeviceCtx *dc;
+    PetscErrorCode ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
+    CHKHIP(mi355x_malloc((void **)&s->dev, sizeof(PetscScalar) * (size_t)PetscMax(v->map->n, 2)));
+    if (s->valid == VALID_NONE) {   /* new vectors are zero, as VecCreate_Seq's PetscMemzero */
+      CHKHIP(mi355x_memset(dc->h, s->dev, 0, sizeof(PetscScalar) * (size_t)v->map->n));
+      s->valid = VALID_DEVICE;
+    }
+  }
+  return 0;
+}
+static PetscErrorCode host_alloc(Vec v) {
+  Vec_HIPMI355X *s = VH(v);
+  if (!s->host) {
+    PetscErrorCode ierr = PetscMalloc(sizeof(PetscScalar) * (size_t)PetscMax(v->map->n, 1), &s->host);CHKERRQ(ierr);
+    s->host_owned = 1;
+    if (s->valid == VALID_NONE) { memset(s->host, 0, sizeof(PetscScalar) * (size_t)v->map->n); s->valid = VALID_HOST; }
+  }
+  return 0;
+}
+static PetscErrorCode to_device(Vec v) {   /* VecCUSPCopyToGPU, veccusp.cu:109 */
+  Vec_HIPMI355X *s = VH(v);
+  PetscErrorCode ierr = dev_alloc(v);CHKERRQ(ierr);
+  if (s->valid == VALID_HOST) {
+    PetscDeviceCtx *dc;
+    ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
+    CHKHIP(mi355x_memcpy_h2d(dc->h, s->dev, s->host, sizeof(PetscScalar) * (size_t)v->map->n));
+    CHKHIP(mi355x_handle_synchronize(dc->h));   /* the host buffer is pageable */
+    s->valid = VALID_BOTH;
+  }
+  return 0;
+}
+static PetscErrorCode to_host(Vec v) {   /* VecCUSPCopyFromGPU, veccusp.cu:173 */
+  Vec_HIPMI355X *s = VH(v);
+  PetscErrorCode ierr = host_alloc(v);CHKERRQ(ierr);
+  if (s->valid == VALID_DEVICE) {
+    PetscDeviceCtx *dc;
+    ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
+    CHKHIP(mi355x_memcpy_d2h(dc->h, s->host, s->dev, sizeof(PetscScalar) * (size_t)v->map->n));
+    CHKHIP(mi355x_handle_synchronize(dc->h));
+    s->valid = VALID_BOTH;
+  }
+  return 0;
+}
+
+PetscErrorCode VecHIPGetRead(Vec v, const PetscScalar **d) {
+  PetscErrorCode ierr = to_device(v);CHKERRQ(ierr);
+  *d = VH(v)->dev;
+  return 0;
+}
+PetscErrorCode VecHIPGetWrite(Vec v, PetscScalar **d) {
+  PetscErrorCode ierr = dev_alloc(v);CHKERRQ(ierr);
+  *d = VH(v)->dev;
+  return 0;
+}
+PetscErrorCode VecHIPGetReadWrite(Vec v, PetscScalar **d) {
+  PetscErrorCode ierr = to_device(v);CHKERRQ(ierr);
+  *d = VH(v)->dev;
+  return 0;
+}
+PetscErrorCode VecHIPRestoreWrite(Vec v) { VH(v)->valid = VALID_DEVICE; return 0; }
+
+static int is_hip(Vec v) { return v && v->data && strstr(v->type_name, "hipmi355x") != NULL; }
+#define CheckHIP(v) do { if (!is_hip(v)) SETERRQ((v)->comm, PETSC_ERR_ARG_NOTSAMETYPE, "vector of type %s mixed with a HIPMI355X vector", (v)->type_name); } while (0)
+
+PetscErrorCode VecHIPMI355XGetArray(Vec v, PetscScalar **d) { CheckHIP(v); return VecHIPGetReadWrite(v, d); }
+PetscErrorCode VecHIPMI355XRestoreArray(Vec v, PetscScalar **d) { if (d) *d = NULL; VecHIPRestoreWrite(v); PetscObjectStateIncrease(v); return 0; }
+PetscErrorCode VecHIPMI355XGetArrayRead(Vec v, const PetscScalar **d) { CheckHIP(v); return VecHIPGetRead(v, d); }
+
+/* ---- host access ---- */
+static PetscErrorCode VecGetArray_HIP(Vec v, PetscScalar **a) {
+  PetscErrorCode ierr = to_host(v);CHKERRQ(ierr);
+  *a = VH(v)->host;
+  return 0;
+}
+static PetscErrorCode VecRestoreArray_HIP(Vec v, PetscScalar **a) { if (a) *a = NULL; VH(v)->valid = VALID_HOST; return 0; }
+static PetscErrorCode VecGetArrayRead_HIP(Vec v, const PetscScalar **a) {
+  PetscErrorCode ierr = to_host(v);CHKERRQ(ierr);
+  *a = VH(v)->host;
+  return 0;
+}
+/* VecPlaceArray_SeqCUSP (veccusp.cu): adopt a host array; the device copy is refreshed on next use */
+static PetscErrorCode VecPlaceArray_HIP(Vec v, const PetscScalar *a) {
+  Vec_HIPMI355X *s = VH(v);
+  if (s->placed_save) SETERRQ(v->comm, PETSC_ERR_ARG_WRONGSTATE, "VecPlaceArray() was already called on this vector, without a call to VecResetArray()");
+  PetscErrorCode ierr = to_host(v);CHKERRQ(ierr);
+  s->placed_save = s->host;
+  s->host = (PetscScalar *)a;
+  s->valid = VALID_HOST;
+  return 0;
+}
+static PetscErrorCode VecResetArray_HIP(Vec v) {
+  Vec_HIPMI355X *s = VH(v);
+  if (!s->placed_save) return 0;
+  s->host = s->placed_save;
+  s->placed_save = NULL;
+  s->valid = VALID_HOST;
+  return 0;
+}
+static PetscErrorCode VecSetValues_HIP(Vec v, PetscInt ni, const PetscInt ix[], const PetscScalar y[], InsertMode mode) {
+  PetscScalar *a;
+  PetscErrorCode ierr = VecGetArray_HIP(v, &a);CHKERRQ(ierr);
+  for (PetscInt k = 0; k < ni; k++) {
+    if (ix[k] < 0) continue;
+    if (ix[k] < v->map->rstart || ix[k] >= v->map->rend) SETERRQ(v->comm, PETSC_ERR_SUP, "off-process VecSetValues (index %d outside [%d,%d)) is outside the ported path", ix[k], v->map->rstart, v->map->rend);
+    if (mode == INSERT_VALUES) a[ix[k] - v->map->rstart] = y[k];
+    else a[ix[k] - v->map->rstart] += y[k];
+  }
+  return VecRestoreArray_HIP(v, NULL);
+}
+
+/* ---- element-wise ops ---- */
+#define DEVCTX PetscDeviceCtx *dc; ierr = PetscDeviceGet(&dc);CHKERRQ(ierr)
+#define N_(v) ((size_t)(v)->map->n)
+
+static PetscErrorCode VecSet_HIP(Vec x, PetscScalar alpha) {
+  PetscErrorCode ierr; PetscScalar *d; DEVCTX;
+  ierr = VecHIPGetWrite(x, &d);CHKERRQ(ierr);
+  CHKHIP(mi355x_vec_set(dc->h, N_(x), alpha, d));
+  return VecHIPRestoreWrite(x);
+}
+static PetscErrorCode VecCopy_HIP(Vec x, Vec y) {
+  PetscErrorCode ierr; const PetscScalar *dx; PetscScalar *dy; DEVCTX;
+  CheckHIP(y);
+  ierr = VecHIPGetRead(x, &dx);CHKERRQ(ierr);
+  ierr = VecHIPGetWrite(y, &dy);CHKERRQ(ierr);
+  CHKHIP(mi355x_vec_copy(dc->h, N_(x), dx, dy));
+  return VecHIPRestoreWrite(y);
+}
+static PetscErrorCode VecSwap_HIP(Vec x, Vec y) {
+  PetscErrorCode ierr; PetscScalar *dx, *dy; DEVCTX;
+  CheckHIP(y);
+  ierr = VecHIPGetReadWrite(x, &dx);CHKERRQ(ierr);
+  ierr = VecHIPGetReadWrite(y, &dy);CHKERRQ(ierr);
+  CHKHIP(mi355x_vec_swap(dc->h, N_(x), dx, dy));
+  VecHIPRestoreWrite(x);
+  return VecHIPRestoreWrite(y);
+}
+static PetscErrorCode VecScale_HIP(Vec x, PetscScalar alpha) {
+  PetscErrorCode ierr; PetscScalar *d; DEVCTX;
+  ierr = VecHIPGetReadWrite(x, &d);CHKERRQ(ierr);
+  CHKHIP(mi355x_vec_scale(dc->h, N_(x), alpha, d));
+  ierr = PetscLogFlops((PetscLogDouble)x->map->n);CHKERRQ(ierr);
+  return VecHIPRestoreWrite(x);
+}
+static PetscErrorCode VecAXPY_HIP(Vec y, PetscScalar alpha, Vec x) {
+  PetscErrorCode ierr; const PetscScalar *dx; PetscScalar *dy; DEVCTX;
+  CheckHIP(x);
+  if (alpha == 0.0) return 0;
+  ierr = VecHIPGetRead(x, &dx);CHKERRQ(ierr);
+  ierr = VecHIPGetReadWrite(y, &dy);CHKERRQ(ierr);
+  CHKHIP(mi355x_vec_axpy(dc->h, N_(y), alpha, dx, dy));
+  ierr = PetscLogFlops(2.0 * y->map->n);CHKERRQ(ierr);
+  return VecHIPRestoreWrite(y);
+}
+static PetscErrorCode VecAYPX_HIP(Vec y, PetscScalar alpha, Vec x) {
+  PetscErrorCode ierr; const PetscScalar *dx; PetscScalar *dy; DEVCTX;
+  CheckHIP(x);
+  ierr = VecHIPGetRead(x, &dx);CHKERRQ(ierr);
+  ierr = VecHIPGetReadWrite(y, &dy);CHKERRQ(ierr);
+  CHKHIP(mi355x_vec_aypx(dc->h, N_(y), alpha, dx, dy));
+  ierr = PetscLogFlops(2.0 * y->map->n);CHKERRQ(ierr);
+  return VecHIPRestoreWrite(y);
+}
+static PetscErrorCode VecAXPBY_HIP(Vec y, PetscScalar alpha, PetscScalar beta, Vec x) {
+  PetscErrorCode ierr; const PetscScalar *dx; PetscScalar *dy; DEVCTX;
+  CheckHIP(x);
+  ierr = VecHIPGetRead(x, &dx);CHKERRQ(ierr);
+  ierr = VecHIPGetReadWrite(y, &dy);CHKERRQ(ierr);
+  CHKHIP(mi355x_vec_axpby(dc->h, N_(y), alpha, beta, dx, dy));
+  ierr = PetscLogFlops(3.0 * y->map->n);CHKERRQ(ierr);
+  return VecHIPRestoreWrite(y);
+}
+static PetscErrorCode VecWAXPY_HIP(Vec w, PetscScalar alpha, Vec x, Vec y) {
+  PetscErrorCode ierr; const PetscScalar *dx, *dy; PetscScalar *dw; DEVCTX;
+  CheckHIP(x); CheckHIP(y);
+  ierr = VecHIPGetRead(x, &dx);CHKERRQ(ierr);
+  ierr = VecHIPGetRead(y, &dy);CHKERRQ(ierr);
+  ierr = VecHIPGetWrite(w, &dw);CHKERRQ(ierr);
+  CHKHIP(mi355x_vec_waxpy(dc->h, N_(w), alpha, dx, dy, dw));
+  ierr = PetscLogFlops(2.0 * w->map->n);CHKERRQ(ierr);
+  return VecHIPRestoreWrite(w);
+}
+static PetscErrorCode VecAXPBYPCZ_HIP(Vec z, PetscScalar alpha, PetscScalar beta, PetscScalar gamma, Vec x, Vec y) {
+  PetscErrorCode ierr; const PetscScalar *dx, *dy; PetscScalar *dz; DEVCTX;
+  CheckHIP(x); CheckHIP(y);
+  ierr = VecHIPGetRead(x, &dx);CHKERRQ(ierr);
+  ierr = VecHIPGetRead(y, &dy);CHKERRQ(ierr);
+  ierr = VecHIPGetReadWrite(z, &dz);CHKERRQ(ierr);
+  CHKHIP(mi355x_vec_axpbypcz(dc->h, N_(z), alpha, beta, gamma, dx, dy, dz));
+  ierr = PetscLogFlops(5.0 * z->map->n);CHKERRQ(ierr);
+  return VecHIPRestoreWrite(z);
+}
+static PetscErrorCode VecPointwiseMult_HIP(Vec w, Vec x, Vec y) {
+  PetscErrorCode ierr; const PetscScalar *dx, *dy; PetscScalar *dw; DEVCTX;
+  CheckHIP(x); CheckHIP(y);
+  ierr = VecHIPGetRead(x, &dx);CHKERRQ(ierr);
+  ierr = VecHIPGetRead(y, &dy);CHKERRQ(ierr);
+  if (w == x || w == y) { ierr = VecHIPGetReadWrite(w, &dw);CHKERRQ(ierr); }
+  else { ierr = VecHIPGetWrite(w, &dw);CHKERRQ(ierr); }
+  CHKHIP(mi355x_vec_pointwise_mult(dc->h, N_(w), dx, dy, dw));
+  ierr = PetscLogFlops((PetscLogDouble)w->map->n);CHKERRQ(ierr);
+  return VecHIPRestoreWrite(w);
+}
+static PetscErrorCode VecPointwiseDivide_HIP(Vec w, Vec x, Vec y) {
+  PetscErrorCode ierr; const PetscScalar *dx, *dy; PetscScalar *dw; DEVCTX;
+  CheckHIP(x); CheckHIP(y);
+  ierr = VecHIPGetRead(x, &dx);CHKERRQ(ierr);
+  ierr = VecHIPGetRead(y, &dy);CHKERRQ(ierr);
+  if (w == x || w == y) { ierr = VecHIPGetReadWrite(w, &dw);CHKERRQ(ierr); }
+  else { ierr = VecHIPGetWrite(w, &dw);CHKERRQ(ierr); }
+  CHKHIP(mi355x_vec_pointwise_divide(dc->h, N_(w), dx, dy, dw));
+  ierr = PetscLogFlops((PetscLogDouble)w->map->n);CHKERRQ(ierr);
+  return VecHIPRestoreWrite(w);
+}
+static PetscErrorCode VecReciprocal_HIP(Vec x) {
+  PetscErrorCode ierr; PetscScalar *d; DEVCTX;
+  ierr = VecHIPGetReadWrite(x, &d);CHKERRQ(ierr);
+  CHKHIP(mi355x_vec_reciprocal(dc->h, N_(x), d));
+  return VecHIPRestoreWrite(x);
+}
+static PetscErrorCode VecMAXPY_HIP(Vec y, PetscInt nv, const PetscScalar *alpha, Vec *x) {
+  PetscErrorCode ierr; PetscScalar *dy; DEVCTX;
+  const double **tab;
+  ierr = PetscMalloc(sizeof(double *) * (size_t)nv, &tab);CHKERRQ(ierr);
+  for (PetscInt j = 0; j < nv; j++) { CheckHIP(x[j]); ierr = VecHIPGetRead(x[j], &tab[j]);CHKERRQ(ierr); }
+  ierr = VecHIPGetReadWrite(y, &dy);CHKERRQ(ierr);
+  CHKHIP(mi355x_vec_maxpy(dc->h, N_(y), nv, alpha, tab, dy));
+  free(tab);
+  ierr = PetscLogFlops(nv * 2.0 * y->map->n);CHKERRQ(ierr);
+  return VecHIPRestoreWrite(y);
+}
+
+/* ---- reductions ---- */
+/* finish: `count` partial results are being written by the kernel just launched.  One rank: they
+ * land in the pinned scratch.  Several ranks: they land in HBM scratch, are all-reduced in place
+ * over RCCL on the same stream, copied to the pinned scratch, and only then do we synchronise. */
+static PetscErrorCode reduce_target(Vec x, PetscDeviceCtx *dc, double **out) {
+  *out = (x->comm->size > 1) ? mi355x_handle_device_scratch(dc->h) : mi355x_handle_host_scratch(dc->h);
+  return 0;
+}
+static PetscErrorCode reduce_finish(Vec x, PetscDeviceCtx *dc, int count, int is_max, PetscScalar *result) {
+  double *hs = mi355x_handle_host_scratch(dc->h);
+  if (x->comm->size > 1) {
+    double *ds = mi355x_handle_device_scratch(dc->h);
+    if (!x->comm->dcomm) SETERRQ(x->comm, PETSC_ERR_ORDER, "parallel HIPMI355X vectors need PetscCommSetDeviceComm() (RCCL) before reductions");
+    if (is_max) CHKHIP(mi355x_comm_allreduce_max(x->comm->dcomm, dc->h, ds, (size_t)count));
+    else CHKHIP(mi355x_comm_allreduce_sum(x->comm->dcomm, dc->h, ds, (size_t)count));
+    CHKHIP(mi355x_memcpy_d2h(dc->h, hs, ds, sizeof(double) * (size_t)count));
+  }
+  CHKHIP(mi355x_handle_synchronize(dc->h));
+  for (int j = 0; j < count; j++) result[j] = hs[j];
+  return 0;
+}
+
+static PetscErrorCode VecDot_HIP(Vec x, Vec y, PetscScalar *val) {
+  PetscErrorCode ierr; const PetscScalar *dx, *dy; double *out; DEVCTX;
+  CheckHIP(y);
+  ierr = VecHIPGetRead(x, &dx);CHKERRQ(ierr);
+  ierr = VecHIPGetRead(y, &dy);CHKERRQ(ierr);
+  ierr = reduce_target(x, dc, &out);CHKERRQ(ierr);
+  CHKHIP(mi355x_vec_dot(dc->h, N_(x), dx, dy, out));
+  ierr = reduce_finish(x, dc, 1, 0, val);CHKERRQ(ierr);
+  if (x->map->n > 0) { ierr = PetscLogFlops(2.0 * x->map->n - 1);CHKERRQ(ierr); }
+  return 0;
+}
+static PetscErrorCode VecMDot_HIP(Vec x, PetscInt nv, const Vec y[], PetscScalar *val) {
+  PetscErrorCode ierr; const PetscScalar *dx; double *out; DEVCTX;
+  const double *tab[32];
+  ierr = VecHIPGetRead(x, &dx);CHKERRQ(ierr);
+  for (PetscInt pos = 0; pos < nv; pos += 32) {   /* pvec2.c:12-17 uses a 128-entry stack buffer; ours is the 64-double scratch */
+    PetscInt cnt = PetscMin(32, nv - pos);
+    for (PetscInt j = 0; j < cnt; j++) { CheckHIP(y[pos + j]); ierr = VecHIPGetRead(y[pos + j], &tab[j]);CHKERRQ(ierr); }
+    ierr = reduce_target(x, dc, &out);CHKERRQ(ierr);
+    CHKHIP(mi355x_vec_mdot(dc->h, N_(x), cnt, dx, tab, out));
+    ierr = reduce_finish(x, dc, cnt, 0, val + pos);CHKERRQ(ierr);
+  }
+  ierr = PetscLogFlops(PetscMax(nv * (2.0 * x->map->n - 1), 0.0));CHKERRQ(ierr);
+  return 0;
+}
+static PetscErrorCode VecNorm_HIP(Vec x, NormType type, PetscReal *val) {
+  PetscErrorCode ierr; const PetscScalar *dx; double *out; PetscScalar r[2]; DEVCTX;
+  ierr = VecHIPGetRead(x, &dx);CHKERRQ(ierr);
+  ierr = reduce_target(x, dc, &out);CHKERRQ(ierr);
+  CHKHIP(mi355x_vec_norm(dc->h, N_(x), (int)type, dx, out));
+  if (type == NORM_1_AND_2) {
+    ierr = reduce_finish(x, dc, 2, 0, r);CHKERRQ(ierr);
+    val[0] = r[0]; val[1] = PetscSqrtReal(r[1]);           /* pvec2.c:80-82 */
+  } else if (type == NORM_INFINITY) {
+    ierr = reduce_finish(x, dc, 1, 1, r);CHKERRQ(ierr);    /* MPIU_MAX, pvec2.c:74 */
+    *val = r[0];
+  } else {
+    ierr = reduce_finish(x, dc, 1, 0, r);CHKERRQ(ierr);
+    *val = (type == NORM_1) ? r[0] : PetscSqrtReal(r[0]);  /* pvec2.c:62-64: reduce the square, then sqrt */
+  }
+  if (type != NORM_INFINITY) { ierr = PetscLogFlops(PetscMax(2.0 * x->map->n - 1, 0.0));CHKERRQ(ierr); }
+  return 0;
+}
+static PetscErrorCode VecDotNorm2_HIP(Vec s, Vec t, PetscScalar *dp, PetscScalar *nm) {
+  PetscErrorCode ierr; const PetscScalar *ds_, *dt; double *out; PetscScalar r[2]; DEVCTX;
+  CheckHIP(t);
+  ierr = VecHIPGetRead(s, &ds_);CHKERRQ(ierr);
+  ierr = VecHIPGetRead(t, &dt);CHKERRQ(ierr);
+  ierr = reduce_target(s, dc, &out);CHKERRQ(ierr);
+  CHKHIP(mi355x_vec_dotnorm2(dc->h, N_(s), ds_, dt, out));
+  ierr = reduce_finish(s, dc, 2, 0, r);CHKERRQ(ierr);
+  *dp = r[0]; *nm = r[1];
+  ierr = PetscLogFlops(4.0 * s->map->n);CHKERRQ(ierr);
+  return 0;
+}
+
+static PetscErrorCode VecDestroy_HIP(Vec v) {
+  Vec_HIPMI355X *s = VH(v);
+  if (!s) return 0;
+  if (s->placed_save) { s->host = s->placed_save; s->placed_save = NULL; }
+  if (s->dev) mi355x_free(s->dev);
+  if (s->host && s->host_owned) free(s->host);
+  free(s);
+  v->data = NULL;
+  return 0;
+}
+
+static PetscErrorCode VecDuplicate_HIP(Vec v, Vec *newv) {
+  PetscErrorCode ierr;
+  Vec w;
+  ierr = VecCreate(v->comm, &w);CHKERRQ(ierr);
+  ierr = PetscLayoutReference(v->map, &w->map);CHKERRQ(ierr);
+  ierr = (*v->ops->create)(w);CHKERRQ(ierr);
+  *newv = w;
+  return 0;
+}
+
+static PetscErrorCode VecCreate_HIP_common(Vec v, const char *tname, VecCreateFn self) {
+  PetscErrorCode ierr;
+  Vec_HIPMI355X *s;
+  ierr = PetscMalloc(sizeof(*s), &s);CHKERRQ(ierr);
+  memset(s, 0, sizeof(*s));
+  v->data = s;
+  snprintf(v->type_name, sizeof(v->type_name), "%s", tname);
+  VecOps *o = v->ops;
+  o->duplicate = VecDuplicate_HIP; o->dot = VecDot_HIP; o->tdot = VecDot_HIP; o->mdot = VecMDot_HIP; o->mtdot = VecMDot_HIP;
+  o->norm = VecNorm_HIP; o->scale = VecScale_HIP; o->copy = VecCopy_HIP; o->set = VecSet_HIP; o->swap = VecSwap_HIP;
+  o->axpy = VecAXPY_HIP; o->axpby = VecAXPBY_HIP; o->maxpy = VecMAXPY_HIP; o->aypx = VecAYPX_HIP; o->waxpy = VecWAXPY_HIP;
+  o->axpbypcz = VecAXPBYPCZ_HIP; o->pointwisemult = VecPointwiseMult_HIP; o->pointwisedivide = VecPointwiseDivide_HIP;
+  o->setvalues = VecSetValues_HIP; o->getarray = VecGetArray_HIP; o->restorearray = VecRestoreArray_HIP;
+  o->getarrayread = VecGetArrayRead_HIP; o->placearray = VecPlaceArray_HIP; o->resetarray = VecResetArray_HIP;
+  o->destroy = VecDestroy_HIP; o->reciprocal = VecReciprocal_HIP; o->dotnorm2 = VecDotNorm2_HIP; o->create = self;
+  return 0;
+}
+
+PetscErrorCode VecCreate_SeqHIPMI355X(Vec v) {
+  if (v->comm->size > 1) SETERRQ(v->comm, PETSC_ERR_ARG_WRONG, "Cannot create VECSEQHIPMI355X on more than one process");
+  return VecCreate_HIP_common(v, VECSEQHIPMI355X, VecCreate_SeqHIPMI355X);
+}
+PetscErrorCode VecCreate_MPIHIPMI355X(Vec v) { return VecCreate_HIP_common(v, VECMPIHIPMI355X, VecCreate_MPIHIPMI355X); }
+/* size dispatch, as VecCreate_CUSP mpicusp.cu:232-246 */
+PetscErrorCode VecCreate_HIPMI355X(Vec v) {
+  return (v->comm->size == 1) ? VecCreate_SeqHIPMI355X(v) : VecCreate_MPIHIPMI355X(v);
+}
+PetscErrorCode VecCreateSeqHIPMI355X(MPI_Comm comm, PetscInt n, Vec *v) {
+  PetscErrorCode ierr;
+  ierr = VecCreate(comm, v);CHKERRQ(ierr);
+  ierr = VecSetSizes(*v, n, n);CHKERRQ(ierr);
+  ierr = VecSetType(*v, VECSEQHIPMI355X);CHKERRQ(ierr);
+  return 0;
+}

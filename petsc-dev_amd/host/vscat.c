@@ -1,0 +1,249 @@
+/* VecScatter, parallel -> sequential "general" form: the halo exchange of MatMult_MPIAIJ.
+ * Set-up restates VecScatterCreate_PtoS (src/vec/vec/utils/vpscat.c:1730-1924) with the index-list
+ * exchange done by one all-gather of every rank's request list instead of Isend/Irecv pairs (same
+ * resulting to/from lists, bit for bit).  Begin/End replace VecScatterBegin_1/End_1
+ * (vpscat.h:14-233: pack, persistent MPI_Start, MPI_Waitany, unpack) by
+ *     device pack kernel -> RCCL grouped send/recv over xGMI on the halo stream -> device unpack,
+ * ordered against the compute stream with two HIP events so the diagonal-block SpMV overlaps it. */
+#include "petscimpl.h"
+
+static int owner_of(int size, const PetscInt *range, PetscInt idx) {   /* vpscat.c:1762-1772 */
+  for (int j = 0; j < size; j++) if (idx < range[j + 1]) return j;
+  return -1;
+}
+
+static PetscBool is_contiguous(const PetscInt *idx, PetscInt n) {
+  for (PetscInt k = 1; k < n; k++) if (idx[k] != idx[0] + k) return PETSC_FALSE;
+  return PETSC_TRUE;
+}
+
+PetscErrorCode VecScatterCreate_PtoS_MPIAIJ(MPI_Comm comm, PetscLayout *xmap, PetscInt ec, const PetscInt *garray, VecScatter *out) {
+  PetscErrorCode ierr;
+  VecScatter ctx;
+  int size = comm->size, rank = comm->rank;
+  PetscInt *ecs, maxec = 0, *all = NULL;
+  ierr = PetscMalloc(sizeof(*ctx), &ctx);CHKERRQ(ierr);
+  memset(ctx, 0, sizeof(*ctx));
+  ctx->comm = comm;
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)size, &ecs);CHKERRQ(ierr);
+  if (size > 1) {
+    if (comm->allgather(comm->ctx, &ec, (int)sizeof(PetscInt), ecs)) SETERRQ(comm, PETSC_ERR_LIB, "allgather failed");
+  } else ecs[0] = ec;
+  for (int p = 0; p < size; p++) maxec = PetscMax(maxec, ecs[p]);
+  if (size > 1 && maxec > 0) {
+    PetscInt *mine;
+    ierr = PetscMalloc(sizeof(PetscInt) * (size_t)maxec, &mine);CHKERRQ(ierr);
+    memset(mine, 0, sizeof(PetscInt) * (size_t)maxec);
+    memcpy(mine, garray, sizeof(PetscInt) * (size_t)ec);
+    ierr = PetscMalloc(sizeof(PetscInt) * (size_t)maxec * (size_t)size, &all);CHKERRQ(ierr);
+    if (comm->allgather(comm->ctx, mine, (int)(sizeof(PetscInt) * (size_t)maxec), all)) SETERRQ(comm, PETSC_ERR_LIB, "allgather failed");
+    free(mine);
+  }
+  /* ---- "from" (receive) side: owners ascending, slots in order of appearance (vpscat.c:1871-1885) ---- */
+  VecScatterSide *from = &ctx->from, *to = &ctx->to;
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)(size + 1), &from->procs);CHKERRQ(ierr);
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)(size + 2), &from->starts);CHKERRQ(ierr);
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)PetscMax(ec, 1), &from->indices);CHKERRQ(ierr);
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)PetscMax(ec, 1), &from->local_slots);CHKERRQ(ierr);
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)PetscMax(ec, 1), &to->local_slots);CHKERRQ(ierr);
+  PetscInt cnt = 0;
+  from->n = 0; from->starts[0] = 0;
+  for (int p = 0; p < size; p++) {
+    if (p == rank) continue;
+    PetscBool have = PETSC_FALSE;
+    for (PetscInt i = 0; i < ec; i++) {
+      int o = owner_of(size, xmap->range, garray[i]);
+      if (o < 0) SETERRQ(comm, PETSC_ERR_PLIB, "ith %d block entry %d not owned by any process, upper bound %d", i, garray[i], xmap->range[size]);
+      if (o == p) { from->indices[cnt++] = i; have = PETSC_TRUE; }
+    }
+    if (have) { from->procs[from->n++] = p; from->starts[from->n] = cnt; }
+  }
+  /* local part (vpscat.c:1897-1910) */
+  PetscInt nl = 0;
+  for (PetscInt i = 0; i < ec; i++)
+    if (garray[i] >= xmap->range[rank] && garray[i] < xmap->range[rank + 1]) { to->local_slots[nl] = garray[i] - xmap->range[rank]; from->local_slots[nl++] = i; }
+  from->local_n = to->local_n = nl;
+  /* ---- "to" (send) side: requesting ranks ascending, their order of request (vpscat.c:1782,1846-1856) ---- */
+  PetscInt total = 0;
+  for (int q = 0; q < size; q++) if (q != rank) total += ecs[q];
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)(size + 1), &to->procs);CHKERRQ(ierr);
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)(size + 2), &to->starts);CHKERRQ(ierr);
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)PetscMax(total, 1), &to->indices);CHKERRQ(ierr);
+  cnt = 0; to->n = 0; to->starts[0] = 0;
+  for (int q = 0; q < size; q++) {
+    if (q == rank) continue;
+    PetscBool have = PETSC_FALSE;
+    const PetscInt *gq = all + (size_t)q * (size_t)maxec;
+    for (PetscInt i = 0; i < ecs[q]; i++)
+      if (gq[i] >= xmap->range[rank] && gq[i] < xmap->range[rank + 1]) { to->indices[cnt++] = gq[i] - xmap->range[rank]; have = PETSC_TRUE; }
+    if (have) { to->procs[to->n++] = q; to->starts[to->n] = cnt; }
+  }
+  free(all); free(ecs);
+  /* contiguity (the to->contiq / from->contiq special case, vpscat.c:1951-1960), here per side */
+  from->contiq = PETSC_TRUE;
+  for (PetscInt i = 0; i < from->n; i++) if (!is_contiguous(from->indices + from->starts[i], from->starts[i + 1] - from->starts[i])) from->contiq = PETSC_FALSE;
+  to->contiq = PETSC_TRUE;
+  for (PetscInt i = 0; i < to->n; i++) if (!is_contiguous(to->indices + to->starts[i], to->starts[i + 1] - to->starts[i])) to->contiq = PETSC_FALSE;
+  *out = ctx;
+  return 0;
+}
+
+PetscErrorCode VecScatterGetLists(VecScatter ctx, PetscInt *nrecv, const PetscInt **rprocs, const PetscInt **rstarts, const PetscInt **rindices,
+                                  PetscInt *nsend, const PetscInt **sprocs, const PetscInt **sstarts, const PetscInt **sindices,
+                                  PetscInt *nlocal, const PetscInt **lto, const PetscInt **lfrom) {
+  if (!ctx) SETERRQ(0, PETSC_ERR_ARG_NULL, "Null VecScatter");
+  *nrecv = ctx->from.n; *rprocs = ctx->from.procs; *rstarts = ctx->from.starts; *rindices = ctx->from.indices;
+  *nsend = ctx->to.n; *sprocs = ctx->to.procs; *sstarts = ctx->to.starts; *sindices = ctx->to.indices;
+  *nlocal = ctx->to.local_n; *lto = ctx->to.local_slots; *lfrom = ctx->from.local_slots;
+  return 0;
+}
+
+/* one-time index upload (VecScatterInitializeForGPU, src/vec/vec/utils/veccusp/vscatcusp.c:29-112) */
+static PetscErrorCode scatter_device_setup(VecScatter ctx, PetscDeviceCtx *dc) {
+  if (ctx->device_ready) return 0;
+  VecScatterSide *s[2] = {&ctx->to, &ctx->from};
+  for (int k = 0; k < 2; k++) {
+    PetscInt tot = s[k]->starts[s[k]->n];
+    if (tot > 0) {
+      CHKHIP(mi355x_malloc((void **)&s[k]->d_indices, sizeof(PetscInt) * (size_t)tot));
+      CHKHIP(mi355x_memcpy_h2d(dc->h, s[k]->d_indices, s[k]->indices, sizeof(PetscInt) * (size_t)tot));
+      CHKHIP(mi355x_malloc((void **)&s[k]->d_values, sizeof(PetscScalar) * (size_t)tot));
+    }
+    if (s[k]->local_n > 0) {
+      CHKHIP(mi355x_malloc((void **)&s[k]->d_local_slots, sizeof(PetscInt) * (size_t)s[k]->local_n));
+      CHKHIP(mi355x_memcpy_h2d(dc->h, s[k]->d_local_slots, s[k]->local_slots, sizeof(PetscInt) * (size_t)s[k]->local_n));
+    }
+  }
+  CHKHIP(mi355x_handle_synchronize(dc->h));
+  CHKHIP(mi355x_event_create(&ctx->ev_packed));
+  CHKHIP(mi355x_event_create(&ctx->ev_done));
+  ctx->device_ready = 1;
+  return 0;
+}
+
+/* FORWARD/INSERT: x (parallel) -> y (= lvec, sequential).  REVERSE/ADD: x (= lvec) -> y (parallel), +=. */
+PetscErrorCode VecScatterBegin(VecScatter ctx, Vec x, Vec y, InsertMode addv, ScatterMode mode) {
+  PetscErrorCode ierr;
+  PetscDeviceCtx *dc;
+  if (!ctx) SETERRQ(0, PETSC_ERR_ARG_NULL, "Null VecScatter");
+  if (ctx->inuse) SETERRQ(ctx->comm, PETSC_ERR_ARG_WRONGSTATE, " Scatter ctx already in use");   /* vscat.c:1637 */
+  if (!((mode == SCATTER_FORWARD && addv == INSERT_VALUES) || (mode == SCATTER_REVERSE && addv == ADD_VALUES)))
+    SETERRQ(ctx->comm, PETSC_ERR_SUP, "only FORWARD/INSERT and REVERSE/ADD (the MatMult[Transpose]_MPIAIJ uses) are ported");
+  ctx->inuse = PETSC_TRUE;
+  if (ctx->to.n == 0 && ctx->from.n == 0 && ctx->to.local_n == 0) return 0;
+  ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
+  ierr = scatter_device_setup(ctx, dc);CHKERRQ(ierr);
+  if ((ctx->to.n || ctx->from.n) && !ctx->comm->dcomm) SETERRQ(ctx->comm, PETSC_ERR_ORDER, "parallel scatter needs PetscCommSetDeviceComm() (RCCL)");
+  mi355x_comm_t rc = ctx->comm->dcomm;
+  VecScatterSide *to = &ctx->to, *from = &ctx->from;
+  if (mode == SCATTER_FORWARD) {
+    const PetscScalar *dx; PetscScalar *dy;
+    ierr = VecHIPGetRead(x, &dx);CHKERRQ(ierr);
+    ierr = VecHIPGetReadWrite(y, &dy);CHKERRQ(ierr);
+    /* the halo stream starts after everything already queued on the compute stream (x is final) */
+    CHKHIP(mi355x_event_record(ctx->ev_packed, dc->h));
+    CHKHIP(mi355x_handle_wait_event(dc->hcomm, ctx->ev_packed));
+    PetscInt nsend = to->starts[to->n];
+    if (nsend && !to->contiq) CHKHIP(mi355x_pack(dc->hcomm, (size_t)nsend, to->d_indices, dx, to->d_values));   /* Pack_1 */
+    if (to->n || from->n) {
+      CHKHIP(mi355x_comm_group_start());
+      for (PetscInt i = 0; i < from->n; i++) {
+        PetscInt s = from->starts[i], c = from->starts[i + 1] - s;
+        PetscScalar *dst = from->contiq ? dy + from->indices[s] : from->d_values + s;
+        CHKHIP(mi355x_comm_recv(rc, dc->hcomm, dst, (size_t)c, from->procs[i]));
+      }
+      for (PetscInt i = 0; i < to->n; i++) {
+        PetscInt s = to->starts[i], c = to->starts[i + 1] - s;
+        const PetscScalar *src = to->contiq ? dx + to->indices[s] : to->d_values + s;
+        CHKHIP(mi355x_comm_send(rc, dc->hcomm, src, (size_t)c, to->procs[i]));
+      }
+      CHKHIP(mi355x_comm_group_end());
+    }
+    if (from->n && !from->contiq) CHKHIP(mi355x_unpack_insert(dc->hcomm, (size_t)from->starts[from->n], from->d_indices, from->d_values, dy));   /* UnPack_1 */
+    if (to->local_n) {   /* Scatter_1, vpscat.c:538 */
+      PetscScalar *tmp = mi355x_handle_device_scratch(dc->hcomm);
+      for (PetscInt o = 0; o < to->local_n; o += 64) {
+        PetscInt c = PetscMin(64, to->local_n - o);
+        CHKHIP(mi355x_pack(dc->hcomm, (size_t)c, to->d_local_slots + o, dx, tmp));
+        CHKHIP(mi355x_unpack_insert(dc->hcomm, (size_t)c, from->d_local_slots + o, tmp, dy));
+      }
+    }
+    CHKHIP(mi355x_event_record(ctx->ev_done, dc->hcomm));
+  } else {
+    const PetscScalar *dx; PetscScalar *dy;
+    ierr = VecHIPGetRead(x, &dx);CHKERRQ(ierr);
+    ierr = VecHIPGetReadWrite(y, &dy);CHKERRQ(ierr);
+    CHKHIP(mi355x_event_record(ctx->ev_packed, dc->h));
+    CHKHIP(mi355x_handle_wait_event(dc->hcomm, ctx->ev_packed));
+    PetscInt nback = from->starts[from->n];
+    if (nback && !from->contiq) CHKHIP(mi355x_pack(dc->hcomm, (size_t)nback, from->d_indices, dx, from->d_values));
+    if (to->n || from->n) {
+      CHKHIP(mi355x_comm_group_start());
+      for (PetscInt i = 0; i < to->n; i++) {
+        PetscInt s = to->starts[i], c = to->starts[i + 1] - s;
+        CHKHIP(mi355x_comm_recv(rc, dc->hcomm, to->d_values + s, (size_t)c, to->procs[i]));
+      }
+      for (PetscInt i = 0; i < from->n; i++) {
+        PetscInt s = from->starts[i], c = from->starts[i + 1] - s;
+        const PetscScalar *src = from->contiq ? dx + from->indices[s] : from->d_values + s;
+        CHKHIP(mi355x_comm_send(rc, dc->hcomm, src, (size_t)c, from->procs[i]));
+      }
+      CHKHIP(mi355x_comm_group_end());
+    }
+    CHKHIP(mi355x_event_record(ctx->ev_done, dc->hcomm));
+  }
+  return 0;
+}
+
+PetscErrorCode VecScatterEnd(VecScatter ctx, Vec x, Vec y, InsertMode addv, ScatterMode mode) {
+  PetscErrorCode ierr;
+  PetscDeviceCtx *dc;
+  if (!ctx) SETERRQ(0, PETSC_ERR_ARG_NULL, "Null VecScatter");
+  ctx->inuse = PETSC_FALSE;
+  if (ctx->to.n == 0 && ctx->from.n == 0 && ctx->to.local_n == 0) return 0;
+  ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
+  /* the compute stream resumes after the halo stream's work (replaces MPI_Waitany, vpscat.h:210) */
+  CHKHIP(mi355x_handle_wait_event(dc->h, ctx->ev_done));
+  if (mode == SCATTER_REVERSE) {
+    /* y[idx] += received, one neighbour after the other in rank order: the additions happen here,
+     * after the local transpose product, as mpiaij.c:1162-1164 assumes; the order is fixed (the
+     * reference's is arrival order unless -vecscatter_reproduce, vpscat.h:206-208) */
+    PetscScalar *dy;
+    VecScatterSide *to = &ctx->to, *from = &ctx->from;
+    ierr = VecHIPGetReadWrite(y, &dy);CHKERRQ(ierr);
+    for (PetscInt i = 0; i < to->n; i++) {
+      PetscInt s = to->starts[i], c = to->starts[i + 1] - s;
+      CHKHIP(mi355x_unpack_add(dc->h, (size_t)c, to->d_indices + s, to->d_values + s, dy));
+    }
+    if (to->local_n) {
+      const PetscScalar *dx;
+      PetscScalar *tmp = mi355x_handle_device_scratch(dc->h);
+      ierr = VecHIPGetRead(x, &dx);CHKERRQ(ierr);
+      for (PetscInt o = 0; o < to->local_n; o += 64) {
+        PetscInt c = PetscMin(64, to->local_n - o);
+        CHKHIP(mi355x_pack(dc->h, (size_t)c, from->d_local_slots + o, dx, tmp));
+        CHKHIP(mi355x_unpack_add(dc->h, (size_t)c, to->d_local_slots + o, tmp, dy));
+      }
+    }
+  }
+  ierr = VecHIPRestoreWrite(y);CHKERRQ(ierr);
+  PetscObjectStateIncrease(y);
+  return 0;
+}
+
+PetscErrorCode VecScatterDestroy(VecScatter *pctx) {
+  VecScatter ctx = *pctx;
+  if (!ctx) return 0;
+  VecScatterSide *s[2] = {&ctx->to, &ctx->from};
+  for (int k = 0; k < 2; k++) {
+    free(s[k]->procs); free(s[k]->starts); free(s[k]->indices); free(s[k]->local_slots);
+    if (s[k]->d_indices) mi355x_free(s[k]->d_indices);
+    if (s[k]->d_values) mi355x_free(s[k]->d_values);
+    if (s[k]->d_local_slots) mi355x_free(s[k]->d_local_slots);
+  }
+  if (ctx->ev_packed) mi355x_event_destroy(ctx->ev_packed);
+  if (ctx->ev_done) mi355x_event_destroy(ctx->ev_done);
+  free(ctx);
+  *pctx = NULL;
+  return 0;
+}

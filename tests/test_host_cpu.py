@@ -1,0 +1,239 @@
+"""CPU-side checks (no GPU): both C-ABI libraries load and export every symbol their headers declare;
+host set-up logic (assembly, MPIAIJ split, garray, VecScatter index lists -- integer work, bit-exact
+against the oracle); the product fails loudly without a device."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared(header):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    names = set(re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\(", txt))
+    return {n for n in names if re.match(r"(mi355x_|Petsc|Vec|Mat|KSP|PC|MPI_Comm_)", n) and not n.endswith("Fn") and n != "PetscErrorCode"}
+
+
+def test_kernel_library_exports(built):
+    lib = C.CDLL(built.kernels_lib_path())
+    for h in ("mi355x_kernels.h", "mi355x_comm.h"):
+        names = declared(h)
+        assert len(names) > 10
+        for n in sorted(names):
+            assert hasattr(lib, n), "%s declared in %s but not exported" % (n, h)
+
+
+def test_host_library_exports(built):
+    built.load_kernels()
+    lib = C.CDLL(built.host_lib_path())
+    names = declared("petschipmi355x.h")
+    assert len(names) > 100
+    for n in sorted(names):
+        assert hasattr(lib, n), "%s declared in petschipmi355x.h but not exported" % n
+
+
+def test_no_cpu_fallback(built):
+    """Without a GPU every compute entry point must fail with PETSC_ERR_LIB, not silently compute."""
+    k = built.load_kernels()
+    n = C.c_int()
+    k.mi355x_device_count(C.byref(n))
+    if n.value > 0:
+        pytest.skip("a GPU is present")
+    from petsc_dev_amd import petsc as P
+    v = P.Vec.create(10, comm=P.lib().COMM_SELF)
+    with pytest.raises(P.PetscError) as e:
+        P.lib().VecSet(v.h, 1.0)
+    assert e.value.code == 76 and "no gfx950 device" in str(e.value)
+
+
+def lap2d(m, n):
+    import scipy.sparse as sp
+    N = m * n
+    I = np.arange(N); i = I // n; j = I - i * n
+    rows, cols, vals = [I], [I], [4.0 * np.ones(N)]
+    for mask, off in ((i > 0, -n), (i < m - 1, n), (j > 0, -1), (j < n - 1, 1)):
+        r = I[mask]; rows.append(r); cols.append(r + off); vals.append(-np.ones(r.size))
+    A = sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(N, N))
+    A.sort_indices()
+    return A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(np.float64)
+
+
+def seq_arrays(P, A):
+    m = C.c_int(); pi_, pj, pa = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    P.lib().MatSeqAIJGetArrays(A, C.byref(m), C.byref(pi_), C.byref(pj), C.byref(pa))
+    m = m.value
+    ai = np.ctypeslib.as_array(C.cast(pi_, C.POINTER(C.c_int)), (m + 1,)).copy()
+    nz = int(ai[-1])
+    aj = np.ctypeslib.as_array(C.cast(pj, C.POINTER(C.c_int)), (max(nz, 1),))[:nz].copy()
+    aa = np.ctypeslib.as_array(C.cast(pa, C.POINTER(C.c_double)), (max(nz, 1),))[:nz].copy()
+    return ai, aj, aa
+
+
+def test_matsetvalues_assembly_matches_csr(built):
+    """ex2.c:96-103 style assembly through MatSetValues (unsorted insertion order, preallocation 2 then growth)"""
+    from petsc_dev_amd import petsc as P
+    L = P.lib()
+    m, n = 9, 7
+    ai, aj, aa = lap2d(m, n)
+    A = C.c_void_p()
+    L.MatCreate(L.COMM_SELF, C.byref(A))
+    L.MatSetSizes(A, m * n, m * n, m * n, m * n)
+    L.MatSetType(A, b"seqaijhipmi355x")
+    L.MatSeqAIJSetPreallocation(A, 2, None)   # too small on purpose: rows must grow
+
+    def one(v, t):
+        return (t * 1)(v)
+    for Ii in range(m * n):
+        i, j = divmod(Ii, n)
+        for cond, J in ((i > 0, Ii - n), (i < m - 1, Ii + n), (j > 0, Ii - 1), (j < n - 1, Ii + 1)):
+            if cond:
+                L.MatSetValues(A, 1, one(Ii, C.c_int), 1, one(J, C.c_int), one(-1.0, C.c_double), P.INSERT_VALUES)
+        L.MatSetValues(A, 1, one(Ii, C.c_int), 1, one(Ii, C.c_int), one(3.0, C.c_double), P.INSERT_VALUES)
+        L.MatSetValues(A, 1, one(Ii, C.c_int), 1, one(Ii, C.c_int), one(1.0, C.c_double), P.ADD_VALUES)
+    L.MatAssemblyBegin(A, P.MAT_FINAL_ASSEMBLY)
+    L.MatAssemblyEnd(A, P.MAT_FINAL_ASSEMBLY)
+    gi, gj, ga = seq_arrays(P, A)
+    assert np.array_equal(gi, ai) and np.array_equal(gj, aj) and np.array_equal(ga, aa)
+    L.MatDestroy(C.byref(A))
+
+
+def scatter_lists(P, ctx):
+    L = P.lib()
+    nr, ns, nl = C.c_int(), C.c_int(), C.c_int()
+    p = [C.c_void_p() for _ in range(8)]
+    L.VecScatterGetLists(ctx, C.byref(nr), C.byref(p[0]), C.byref(p[1]), C.byref(p[2]), C.byref(ns), C.byref(p[3]),
+                         C.byref(p[4]), C.byref(p[5]), C.byref(nl), C.byref(p[6]), C.byref(p[7]))
+
+    def arr(ptr, n):
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_int)), (max(n, 1),))[:n].copy()
+    nr, ns, nl = nr.value, ns.value, nl.value
+    rstarts = arr(p[1], nr + 1); sstarts = arr(p[4], ns + 1)
+    return dict(rprocs=arr(p[0], nr), rstarts=rstarts, rindices=arr(p[2], int(rstarts[nr])),
+                sprocs=arr(p[3], ns), sstarts=sstarts, sindices=arr(p[5], int(sstarts[ns])),
+                lto=arr(p[6], nl), lfrom=arr(p[7], nl))
+
+
+def mpiaij_pieces(P, A):
+    L = P.lib()
+    Ad, Ao, g = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    L.MatMPIAIJGetSeqAIJ(A, C.byref(Ad), C.byref(Ao), C.byref(g))
+    ctx, lvec, ec = C.c_void_p(), C.c_void_p(), C.c_int()
+    L.MatMPIAIJGetScatter(A, C.byref(ctx), C.byref(lvec), C.byref(ec))
+    garray = np.ctypeslib.as_array(C.cast(g, C.POINTER(C.c_int)), (max(ec.value, 1),))[:ec.value].copy()
+    return seq_arrays(P, Ad), seq_arrays(P, Ao), garray, scatter_lists(P, ctx)
+
+
+def build_local(P, comm, ai, aj, aa, rs, re_, N, via_setvalues=False):
+    L = P.lib()
+    li = (ai[rs:re_ + 1] - ai[rs]).astype(np.int32)
+    lj = aj[ai[rs]:ai[re_]].copy(); la = aa[ai[rs]:ai[re_]].copy()
+    if not via_setvalues:
+        return P.Mat.from_csr_mpi(li, lj, la, re_ - rs, N, N, comm=comm)
+    A = P.Mat()
+    L.MatCreate(comm, C.byref(A.h))
+    L.MatSetSizes(A.h, re_ - rs, re_ - rs, N, N)
+    L.MatSetType(A.h, b"aijhipmi355x" if True else b"")
+    L.MatMPIAIJSetPreallocation(A.h, 3, None, 1, None)
+    L.MatSeqAIJSetPreallocation(A.h, 3, None)
+    for r in range(rs, re_):
+        cols = aj[ai[r]:ai[r + 1]][::-1].copy()   # reversed insertion order
+        vals = aa[ai[r]:ai[r + 1]][::-1].copy()
+        L.MatSetValues(A.h, 1, (C.c_int * 1)(r), cols.size, cols.ctypes.data_as(C.c_void_p), vals.ctypes.data_as(C.c_void_p), P.INSERT_VALUES)
+    L.MatAssemblyBegin(A.h, P.MAT_FINAL_ASSEMBLY)
+    L.MatAssemblyEnd(A.h, P.MAT_FINAL_ASSEMBLY)
+    return A
+
+
+def check_against_oracle(size, got, ai, aj, aa, ranges):
+    ref = [orc.mpiaij_split(int(ranges[r]), int(ranges[r + 1]), int(ranges[r]), int(ranges[r + 1]), ai, aj, aa) for r in range(size)]
+    garrays = [r["garray"] for r in ref]
+    for r in range(size):
+        (di, dj, da), (oi, oj, oa), garray, lists = got[r]
+        assert np.array_equal(di, ref[r]["ad_i"]) and np.array_equal(dj, ref[r]["ad_j"]) and np.array_equal(da, ref[r]["ad_a"])
+        assert np.array_equal(oi, ref[r]["bo_i"]) and np.array_equal(oj, ref[r]["bo_j"]) and np.array_equal(oa, ref[r]["bo_a"])
+        assert np.array_equal(garray, ref[r]["garray"])
+        sc = orc.scatter_create(size, r, ranges, garrays)
+        for key in sc:
+            assert np.array_equal(lists[key], sc[key]), (r, key, lists[key], sc[key])
+
+
+def check_mpiaij_setup(P, size, ai, aj, aa, ranges, via_setvalues=False):
+    """every rank builds its MPIAIJ piece; all integer outputs must equal the oracle's, bit for bit"""
+    from fakempi import FakeWorld
+    N = ai.size - 1
+
+    def work(rank, comm):
+        A = build_local(P, comm, ai, aj, aa, int(ranges[rank]), int(ranges[rank + 1]), N, via_setvalues)
+        out = mpiaij_pieces(P, A.h)
+        A.destroy()
+        return out
+
+    got = FakeWorld(size).run(work)
+    check_against_oracle(size, got, ai, aj, aa, ranges)
+    return got
+
+
+@pytest.mark.parametrize("size", [1, 2, 3, 8])
+def test_mpiaij_setup_p7_slabs(built, size):
+    """3-D 7-pt operator in z-slabs (SURVEY 8d config 3 shape): <= 2 neighbours, contiguous planes"""
+    from petsc_dev_amd import petsc as P
+    nx, ny, nz = 6, 5, 16
+    ai, aj, aa = orc.gen_p7(nx, ny, nz)
+    ranges = np.array([nx * ny * ((nz * r) // size) for r in range(size + 1)], dtype=np.int32)
+    got = check_mpiaij_setup(P, size, ai, aj, aa, ranges)
+    if size > 1:
+        lists = got[1][3]
+        assert lists["rprocs"].tolist() == ([0, 2] if size > 2 else [0])
+        # halo of a rank: one plane to and from each z-neighbour
+        assert all(c == nx * ny for c in np.diff(lists["sstarts"]))
+
+
+@pytest.mark.parametrize("size", [2, 3, 5])
+def test_mpiaij_setup_irregular(built, size):
+    """random pattern, uneven PETSC_DECIDE-like ownership, via MatSetValues with reversed insertion order"""
+    from petsc_dev_amd import petsc as P
+    import scipy.sparse as sp
+    N = 97
+    A = sp.random(N, N, density=0.08, random_state=7, format="csr") + sp.eye(N, format="csr")
+    A = sp.csr_matrix(A); A.sort_indices()
+    ai, aj, aa = A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(np.float64)
+    ranges = np.array([0] + list(np.cumsum([N // size + (N % size > r) for r in range(size)])), dtype=np.int32)
+    check_mpiaij_setup(P, size, ai, aj, aa, ranges, via_setvalues=True)
+
+
+def test_ex5_np3_layout(built):
+    """src/mat/examples/tests/ex5.c on 3 ranks (golden ex5_23.out): 8x8 dense rows, PETSC_DECIDE split 3/3/2"""
+    from petsc_dev_amd import petsc as P
+    m = 8
+    dense = np.array([[10 * (i + 1) + j + 1 for j in range(m)] for i in range(m)], dtype=np.float64)
+    ai = np.arange(0, m * m + 1, m, dtype=np.int32); aj = np.tile(np.arange(m, dtype=np.int32), m); aa = dense.ravel().copy()
+    ranges = np.array([0, 3, 6, 8], dtype=np.int32)
+    got = check_mpiaij_setup(P, 3, ai, aj, aa, ranges)
+    assert got[0][2].tolist() == [3, 4, 5, 6, 7]
+
+
+def test_options_and_types(built):
+    from petsc_dev_amd import petsc as P
+    L = P.lib()
+    L.PetscOptionsClear()
+    L.PetscOptionsInsertString(b"-ksp_type cg -pc_type jacobi -ksp_rtol 1e-7 -ksp_max_it 33 -mat_type aij -vec_type standard")
+    v = C.c_void_p()
+    L.VecCreate(L.COMM_SELF, C.byref(v)); L.VecSetSizes(v, 5, 5); L.VecSetFromOptions(v)
+    t = C.c_char_p(); L.VecGetType(v, C.byref(t)); assert t.value == b"seqhipmi355x"
+    A = C.c_void_p()
+    L.MatCreate(L.COMM_SELF, C.byref(A)); L.MatSetSizes(A, 5, 5, 5, 5); L.MatSetFromOptions(A)
+    L.MatGetType(A, C.byref(t)); assert t.value == b"seqaijhipmi355x"
+    with pytest.raises(P.PetscError) as e:
+        L.MatSetType(A, b"nosuchtype")
+    assert e.value.code == 86
+    with pytest.raises(P.PetscError) as e:
+        L.VecSetType(v, b"nosuchtype")
+    assert e.value.code == 86
+    L.PetscOptionsClear()
+    L.VecDestroy(C.byref(v)); L.MatDestroy(C.byref(A))

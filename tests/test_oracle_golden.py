@@ -1,0 +1,131 @@
+"""Pins the oracle (oracle/*.c) to the reference's OWN golden outputs (tests/golden/, copied data files of
+src/mat/examples/tests/output and src/ksp/ksp/examples/{tests,tutorials}/output) and to the reference run
+recorded in SURVEY.md 8(c)/(d).  Residual norms are compared as the 6-significant-digit text
+-ksp_monitor_short prints."""
+import os
+
+import numpy as np
+
+import orc
+import problems as pb
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def fmt(v):
+    return np.array([float("%g" % x) for x in v])
+
+
+def test_ex5_seqaij_rectA():
+    """ex5 -mat_type seqaij -rectA (makefile:754) vs output/ex5_11_A.out: MatMult, MatMultTranspose, MatGetDiagonal"""
+    ai, aj, aa, m, n = pb.ex5_mat(8, rect=2)
+    gold = pb.parse_vecview(os.path.join(G, "ex5_11_A.out"))
+    y = np.arange(n, dtype=np.float64)
+    assert np.array_equal(fmt(orc.spmv(ai, aj, aa, y)), gold[0])
+    x = np.arange(m, dtype=np.float64)
+    assert np.array_equal(fmt(orc.spmv_t(ai, aj, aa, x, n)), gold[1])
+    assert np.array_equal(fmt(orc.get_diagonal(ai, aj, aa)), gold[-1])
+    # the example's self-checks: MatMultAdd == MatMult + z, MatMultTransposeAdd == MatMultTranspose + u (norm <= 1e-8)
+    z = 100.0 * (np.arange(m) + 1)
+    assert np.linalg.norm(orc.spmv(ai, aj, aa, y) + z - orc.spmv_add(ai, aj, aa, y, z)) <= 1e-8
+    u = 100.0 * np.arange(n)
+    assert np.linalg.norm(orc.spmv_t(ai, aj, aa, x, n) + u - orc.spmv_t_add(ai, aj, aa, x, u, n)) <= 1e-8
+
+
+def test_ex5_mpiaij():
+    """ex5 -mat_type mpiaij on 1 and 3 ranks (makefile:775, runex5_2) vs ex5_21.out / ex5_23.out: the distributed
+    product assembled from diagonal + off-diagonal blocks through garray and the scatter lists"""
+    ai, aj, aa, m, n = pb.ex5_mat(8)
+    y = np.arange(n, dtype=np.float64)
+    x = np.arange(m, dtype=np.float64)
+    for size, name in ((1, "ex5_21.out"), (3, "ex5_23.out")):
+        gold = pb.parse_vecview(os.path.join(G, name))
+        ranges = np.array([0] + list(np.cumsum([m // size + (m % size > r) for r in range(size)])), dtype=np.int32)
+        pieces = [orc.mpiaij_split(int(ranges[r]), int(ranges[r + 1]), int(ranges[r]), int(ranges[r + 1]), ai, aj, aa) for r in range(size)]
+        garrays = [p["garray"] for p in pieces]
+        out = np.zeros(m); outT = np.zeros(n)
+        for r, p in enumerate(pieces):
+            sc = orc.scatter_create(size, r, ranges, garrays)
+            lvec = np.zeros(p["garray"].size)
+            # forward scatter: what each owner sends lands in the listed lvec slots (MatMult_MPIAIJ, mpiaij.c:1111-1114)
+            for q, proc in enumerate(sc["rprocs"]):
+                slots = sc["rindices"][sc["rstarts"][q]:sc["rstarts"][q + 1]]
+                owner = orc.scatter_create(size, int(proc), ranges, garrays)
+                k = list(owner["sprocs"]).index(r)
+                src = owner["sindices"][owner["sstarts"][k]:owner["sstarts"][k + 1]] + ranges[proc]
+                lvec[slots] = y[src]
+            yl = y[ranges[r]:ranges[r + 1]]
+            d = orc.spmv(p["ad_i"], p["ad_j"], p["ad_a"], yl)
+            out[ranges[r]:ranges[r + 1]] = orc.spmv_add(p["bo_i"], p["bo_j"], p["bo_a"], lvec, d) if lvec.size else d
+            # transpose: local part + reverse scatter ADD of B^T x (MatMultTranspose_MPIAIJ, mpiaij.c:1147-1174)
+            xl = x[ranges[r]:ranges[r + 1]]
+            outT[ranges[r]:ranges[r + 1]] += orc.spmv_t(p["ad_i"], p["ad_j"], p["ad_a"], xl, int(ranges[r + 1] - ranges[r]))
+            if lvec.size:
+                outT[p["garray"]] += orc.spmv_t(p["bo_i"], p["bo_j"], p["bo_a"], xl, lvec.size)
+        assert np.array_equal(fmt(out), gold[0])
+        assert np.array_equal(fmt(outT), gold[1])
+        assert np.array_equal(fmt(orc.get_diagonal(ai, aj, aa)), gold[-1])
+
+
+def test_config1_cg_jacobi_reference_run():
+    """the compiled reference gave, for ex2 -m 100 -n 100 -ksp_type cg -pc_type jacobi,
+    160 iterations, 'Norm of error 5.70785e-05', residuals 5.04975 2.54845 1.81892 1.67695 ... 4.47805e-06"""
+    ai, aj, aa = pb.lap2d(100, 100)
+    u = np.ones(10000)
+    b = orc.spmv(ai, aj, aa, u)
+    x, h, its, reason = orc.ksp_solve(ai, aj, aa, b, ksp="cg", pc="jacobi", rtol=1e-2 / (101 * 101), abstol=1e-50)
+    assert its == 160 and reason == 2
+    assert ["%g" % v for v in h[:4]] == ["5.04975", "2.54845", "1.81892", "1.67695"] and "%g" % h[-1] == "4.47805e-06"
+    assert "%g" % np.linalg.norm(x - u) == "5.70785e-05"
+
+
+def test_ksp_tests_ex3_gmres_jacobi_nonzero_guess():
+    """src/ksp/ksp/examples/tests/ex3.c -pc_type jacobi -m 5 -ksp_gmres_cgs_refinement_type refine_always
+    (makefile:187,192) vs output/ex3_1.out, ex3_2.out: GMRES(30), Jacobi, non-zero initial guess"""
+    (ai, aj, aa), b, u0, ustar = pb.ex3_fem(5)
+    for name in ("ex3_1.out", "ex3_2.out"):
+        gold = pb.parse_monitor(os.path.join(G, "ksp_tests", name))[0]
+        x, h, its, reason = orc.ksp_solve(ai, aj, aa, b, ksp="gmres", pc="jacobi", x0=u0, refine_always=1)
+        pb.check_monitor(h, gold)
+        assert np.linalg.norm(x - ustar) <= 1e-12   # the example prints nothing when the error is below 1e-14/h
+
+
+def test_tutorial_ex2f_gmres_jacobi():
+    """src/ksp/ksp/examples/tutorials/ex2f.F (m = n = 3) -pc_type jacobi refine_always (makefile:406) vs ex2f_1.out"""
+    ai, aj, aa = pb.lap2d(3, 3)
+    b = orc.spmv(ai, aj, aa, np.ones(9))
+    gold = pb.parse_monitor(os.path.join(G, "ksp_tutorials", "ex2f_1.out"))[0]
+    x, h, its, reason = orc.ksp_solve(ai, aj, aa, b, ksp="gmres", pc="jacobi", refine_always=1)
+    pb.check_monitor(h, gold)
+    assert its == 3 and np.linalg.norm(x - 1.0) < 1e-12
+
+
+def test_tutorial_ex2_block_jacobi():
+    """ex2 (m=8, n=7) on 4 ranks, -pc_type bjacobi -sub_pc_type jacobi -sub_ksp_type gmres (makefile:350,360):
+    ex2_bjacobi.out (one block spanning the ranks) and ex2_bjacobi_3.out (one 14-row block per rank)"""
+    ai, aj, aa = pb.lap2d(8, 7)
+    u = np.ones(56)
+    b = orc.spmv(ai, aj, aa, u)
+    rtol = 1e-2 / (9 * 8)
+    for name, blocks, err, nits in (("ex2_bjacobi.out", [0, 56], "2.10144e-06", 1), ("ex2_bjacobi_3.out", [0, 14, 28, 42, 56], "0.000404746", 7)):
+        gold = pb.parse_monitor(os.path.join(G, "ksp_tutorials", name))[0]
+        x, h, its, reason = orc.ksp_solve(ai, aj, aa, b, ksp="gmres", pc="bjacobi", blocks=blocks, sub_ksp="gmres", sub_pc="jacobi",
+                                          rtol=rtol, abstol=1e-50)
+        pb.check_monitor(h, gold)
+        assert its == nits and "%g" % np.linalg.norm(x - u) == err
+
+
+def test_tutorial_ex9_gmres_and_bcgs_jacobi():
+    """src/ksp/ksp/examples/tutorials/ex9.c -t 2 -pc_type jacobi -ksp_type gmres refine_always -s2_ksp_type bcgs
+    -s2_pc_type jacobi (makefile:438-439) vs ex9_1.out: system 1 at t=0 (GMRES) and system 2 at t=0,1 (BiCGStab)"""
+    solves = pb.parse_monitor(os.path.join(G, "ksp_tutorials", "ex9_1.out"))
+    (ai, aj, aa), u = pb.ex9_system(1, 0)
+    b = orc.spmv(ai, aj, aa, u)
+    x, h, its, reason = orc.ksp_solve(ai, aj, aa, b, ksp="gmres", pc="jacobi", refine_always=1)
+    pb.check_monitor(h, solves[0])
+    for t, gold in ((0, solves[1]), (1, solves[3])):
+        (ai, aj, aa), u = pb.ex9_system(2, t)
+        b = orc.spmv(ai, aj, aa, u)
+        x, h, its, reason = orc.ksp_solve(ai, aj, aa, b, ksp="bcgs", pc="jacobi")
+        pb.check_monitor(h, gold)
+        assert np.linalg.norm(x - u) < 1e-4   # CheckError tolerance of the example
