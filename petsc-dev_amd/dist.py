@@ -83,7 +83,9 @@ def torch_comm(device_comm=True):
                 raise RuntimeError("ncclGetUniqueId failed: %s" % k.mi355x_comm_error_string(rc).decode())
         obj = [uid.raw]
         dist.broadcast_object_list(obj, src=0)
-        dev = int(os.environ.get("LOCAL_RANK", "0"))
+        ndev = C.c_int()
+        k.mi355x_device_count(C.byref(ndev))
+        dev = int(os.environ.get("LOCAL_RANK", "0")) % max(ndev.value, 1)
         rc = k.mi355x_set_device(dev)
         if rc:
             raise RuntimeError("hipSetDevice(%d) failed: %s" % (dev, k.mi355x_error_string(rc).decode()))

@@ -170,6 +170,7 @@ static PetscErrorCode PCApply_BJacobi(PC pc, Vec x, Vec y) {
   ierr = KSPSolve(bj->ksp, bj->x, bj->y);CHKERRQ(ierr);
   bx->dev = sx; bx->valid = vx; by->dev = sy; by->valid = vy;
   ierr = VecHIPRestoreWrite(y);CHKERRQ(ierr);
+  PetscObjectStateIncrease(y);   /* y changed through the alias: cached norms are stale (VecRestoreArray does this in bjacobi.c:758) */
   return 0;
 }
 static PetscErrorCode PCDestroy_BJacobi(PC pc) {

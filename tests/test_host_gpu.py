@@ -1,0 +1,312 @@
+"""GPU parity of the host library (Vec/Mat/KSP/PC objects over the HIP kernels) against the oracle and the
+reference's golden outputs.  These read like the reference's own example tests: build the objects through
+the PETSc-named API, run the op, compare.
+
+Tolerances (fp64): element-wise ops, MAXPY, SpMV/SpMV-add/transpose: bit-exact.  Reductions:
+|err| <= 1e-13 * sum|terms|.  Krylov residual histories: equal to 6 significant digits -- the text
+-ksp_monitor_short prints -- with identical iteration counts for the golden cases, and relative 1e-6 /
+iteration count +-1 for the long CG case (BASELINE.md tolerances)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import orc
+import problems as pb
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def P(built):
+    from petsc_dev_amd import petsc as P
+    P.lib()
+    return P
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint64)
+
+
+def rnd(n, seed):
+    return np.random.default_rng(seed).standard_normal(n)
+
+
+def V(P, a):
+    return P.Vec.from_array(a, comm=P.lib().COMM_SELF)
+
+
+def test_vec_ops_through_function_table(P):
+    L = P.lib()
+    n = 100003
+    x, y, z = rnd(n, 1), rnd(n, 2), rnd(n, 3)
+    vx, vy, vz = V(P, x), V(P, y), V(P, z)
+    t = C.c_char_p(); L.VecGetType(vx.h, C.byref(t)); assert t.value == b"seqhipmi355x"
+    L.VecAXPY(vy.h, 0.3, vx.h); r = y.copy(); orc.vec_axpy(r, 0.3, x); assert np.array_equal(bits(vy.array()), bits(r)); y = r
+    L.VecAYPX(vy.h, -1.7, vx.h); orc.vec_aypx(r, -1.7, x); assert np.array_equal(bits(vy.array()), bits(r))
+    L.VecWAXPY(vz.h, 2.5, vx.h, vy.h); w = np.zeros(n); orc.vec_waxpy(w, 2.5, x, r); assert np.array_equal(bits(vz.array()), bits(w))
+    L.VecAXPBYPCZ(vz.h, 0.5, -0.25, 1.0, vx.h, vy.h); orc.vec_axpbypcz(w, 0.5, -0.25, 1.0, x, r); assert np.array_equal(bits(vz.array()), bits(w))
+    L.VecPointwiseMult(vz.h, vx.h, vy.h); orc.vec_pointwise_mult(w, x, r); assert np.array_equal(bits(vz.array()), bits(w))
+    # reductions + norm cache (rvector.c:205-224): second call is served from the cache, a write invalidates it
+    n2 = vx.norm(P.NORM_2)
+    assert abs(n2 - orc.vec_norm(x, 1)) <= 1e-13 * n2 * 4
+    assert vx.norm(P.NORM_2) == n2
+    L.VecScale(vx.h, 2.0)
+    assert vx.norm(P.NORM_2) == 2.0 * n2            # VecScale rescales the cached norm (rvector.c:476)
+    L.VecAXPY(vx.h, 1.0, vy.h)
+    x2 = 2.0 * x; orc.vec_axpy(x2, 1.0, r)
+    assert abs(vx.norm(P.NORM_2) - orc.vec_norm(x2, 1)) <= 1e-12 * orc.vec_norm(x2, 1)
+    assert abs(vx.dot(vy) - orc.vec_dot(x2, r)) <= 1e-13 * np.sum(np.abs(x2 * r))
+    assert vx.norm(P.NORM_INFINITY) == np.max(np.abs(x2))
+    n1, n2b = vx.norm(P.NORM_1_AND_2)
+    assert abs(n1 - np.sum(np.abs(x2))) <= 1e-13 * n1 and abs(n2b - np.linalg.norm(x2)) <= 1e-12 * n2b
+    dp, nm = C.c_double(), C.c_double()
+    L.VecDotNorm2(vx.h, vy.h, C.byref(dp), C.byref(nm))
+    rdp, rnm = orc.vec_dotnorm2(x2, r)
+    assert abs(dp.value - rdp) <= 1e-13 * np.sum(np.abs(x2 * r)) and abs(nm.value - rnm) <= 1e-13 * rnm
+    # VecSet caches the norms of a constant vector
+    L.VecSet(vz.h, -3.0)
+    assert vz.norm(P.NORM_INFINITY) == 3.0 and vz.norm(P.NORM_1) == 3.0 * n
+    # error behaviour of the wrappers
+    with pytest.raises(P.PetscError) as e:
+        L.VecAXPY(vx.h, 1.0, vx.h)
+    assert e.value.code == 61
+    small = V(P, np.ones(5))
+    with pytest.raises(P.PetscError) as e:
+        L.VecAXPY(vx.h, 1.0, small.h)
+    assert e.value.code == 75
+
+
+def test_vec_mdot_maxpy_and_host_access(P):
+    L = P.lib()
+    n, nv = 50001, 13
+    x = rnd(n, 5)
+    ys = [rnd(n, 10 + j) for j in range(nv)]
+    vx = V(P, x)
+    vys = [V(P, a) for a in ys]
+    tab = P.vec_table(vys)
+    out = np.zeros(nv)
+    L.VecMDot(vx.h, nv, tab, out.ctypes.data_as(C.c_void_p))
+    ref = orc.vec_mdot(x, ys)
+    for j in range(nv):
+        assert abs(out[j] - ref[j]) <= 1e-13 * np.sum(np.abs(x * ys[j]))
+    al = rnd(nv, 6)
+    L.VecMAXPY(vx.h, nv, al.ctypes.data_as(C.c_void_p), tab)
+    r = x.copy(); orc.vec_maxpy(r, al, ys)
+    assert np.array_equal(bits(vx.array()), bits(r))
+    # host write access through VecGetArray/VecRestoreArray marks the device copy stale (coherence flags)
+    p = C.c_void_p()
+    L.VecGetArray(vx.h, C.byref(p))
+    arr = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_double)), (n,))
+    arr[:] = 2.0
+    L.VecRestoreArray(vx.h, C.byref(p))
+    assert vx.norm(P.NORM_1) == 2.0 * n
+    # VecPlaceArray / VecResetArray (used by PCBJACOBI in the reference)
+    other = np.full(n, 0.5)
+    L.VecPlaceArray(vx.h, other.ctypes.data_as(C.c_void_p))
+    assert vx.norm(P.NORM_1) == 0.5 * n
+    L.VecResetArray(vx.h)
+    assert vx.norm(P.NORM_1) == 2.0 * n
+
+
+@pytest.mark.parametrize("name,rect,mtype", [("ex5_11_A.out", 2, "seq"), ("ex5_21.out", 0, "mpi")])
+def test_mat_ex5_golden(P, name, rect, mtype):
+    """src/mat/examples/tests/ex5.c: MatMult, MatMultAdd, MatMultTranspose, MatMultTransposeAdd, MatGetDiagonal,
+    MatScale on seqaij (-rectA) and mpiaij (np=1); printed vectors must equal the golden files"""
+    L = P.lib()
+    ai, aj, aa, m, n = pb.ex5_mat(8, rect=rect, alpha=1.0)
+    if mtype == "seq":
+        A = P.Mat.from_csr(ai, aj, aa, ncols=n)
+    else:
+        A = P.Mat.from_csr_mpi(ai, aj, aa, n, m, n, comm=L.COMM_SELF)
+    L.MatScale(A.h, 0.1)
+    gold = pb.parse_vecview(os.path.join(G, name))
+    fmt = lambda v: np.array([float("%g" % t) for t in v])  # noqa: E731
+    y = V(P, np.arange(n, dtype=np.float64)); x = V(P, np.zeros(m)); z = V(P, 100.0 * (np.arange(m) + 1)); w = V(P, np.zeros(m))
+    u = V(P, 100.0 * np.arange(n)); s = V(P, np.zeros(n))
+    L.MatMult(A.h, y.h, x.h)
+    assert np.array_equal(fmt(x.array()), gold[0])
+    L.MatMultAdd(A.h, y.h, z.h, w.h)
+    L.VecAXPY(x.h, 1.0, z.h); L.VecAXPY(x.h, -1.0, w.h)
+    assert x.norm() <= 1e-8                         # the example's own check
+    x.set_array(np.arange(m, dtype=np.float64))
+    L.MatMultTranspose(A.h, x.h, y.h)
+    assert np.array_equal(fmt(y.array()), gold[1])
+    L.MatMultTransposeAdd(A.h, x.h, u.h, s.h)
+    L.VecAXPY(y.h, 1.0, u.h); L.VecAXPY(y.h, -1.0, s.h)
+    assert y.norm() <= 1e-8
+    if rect == 0:
+        L.MatGetDiagonal(A.h, x.h)
+        assert np.array_equal(fmt(x.array()), gold[-1])
+    # bit-exact against the oracle too
+    ai2, aj2, aa2, _, _ = pb.ex5_mat(8, rect=rect, alpha=1.0)
+    aa2 = 0.1 * aa2
+    yy = np.arange(n, dtype=np.float64)
+    y.set_array(yy)
+    L.MatMult(A.h, y.h, w.h)
+    assert np.array_equal(bits(w.array()), bits(orc.spmv(ai2, aj2, aa2, yy)))
+
+
+def test_mat_p7_and_transpose_bitexact(P):
+    L = P.lib()
+    ai, aj, aa = P.gen_poisson7(20, 17, 13)
+    n = ai.size - 1
+    aa = aa * (1.0 + 0.01 * np.sin(np.arange(aa.size)))     # make the transpose non-trivial
+    A = P.Mat.from_csr(ai, aj, aa)
+    x = np.sin(0.37 * np.arange(n)) + 1.0
+    vx, vy, vz = V(P, x), V(P, np.zeros(n)), V(P, rnd(n, 3))
+    L.MatMult(A.h, vx.h, vy.h)
+    assert np.array_equal(bits(vy.array()), bits(orc.spmv(ai, aj, aa, x)))
+    L.MatMultTranspose(A.h, vx.h, vy.h)
+    assert np.array_equal(bits(vy.array()), bits(orc.spmv_t(ai, aj, aa, x, n)))
+    z = vz.array()
+    L.MatMultTransposeAdd(A.h, vx.h, vz.h, vy.h)
+    assert np.array_equal(bits(vy.array()), bits(orc.spmv_t_add(ai, aj, aa, x, z, n)))
+    L.MatMultAdd(A.h, vx.h, vz.h, vz.h)            # in place
+    assert np.array_equal(bits(vz.array()), bits(orc.spmv_add(ai, aj, aa, x, z)))
+    # value-only update: MatScale bumps the state, only `a` is re-sent
+    L.MatScale(A.h, -2.0)
+    L.MatMult(A.h, vx.h, vy.h)
+    assert np.array_equal(bits(vy.array()), bits(orc.spmv(ai, aj, -2.0 * aa, x)))
+    fl = C.c_double(); L.PetscGetFlops(C.byref(fl)); assert fl.value > 0
+
+
+def test_baij_matmult(P):
+    L = P.lib()
+    rng = np.random.default_rng(4)
+    mbs, bs = 300, 3
+    import scipy.sparse as sp
+    S = sp.random(mbs, mbs, density=0.05, random_state=5, format="csr") + sp.eye(mbs, format="csr")
+    S = sp.csr_matrix(S); S.sort_indices()
+    bi, bj = S.indptr.astype(np.int32), S.indices.astype(np.int32)
+    ba = rng.standard_normal(bj.size * bs * bs)
+    A = P.Mat.from_bsr(bs, bi, bj, ba)
+    x = rnd(mbs * bs, 6)
+    vx, vy = V(P, x), V(P, np.zeros(mbs * bs))
+    L.MatMult(A.h, vx.h, vy.h)
+    ref = orc.spmv_bsr(bs, bi, bj, ba, x)
+    assert np.allclose(vy.array(), ref, rtol=0, atol=1e-12 * 50)
+
+
+def solve(P, ai, aj, aa, b, ksp, pc, x0=None, opts="", **tol):
+    L = P.lib()
+    A = P.Mat.from_csr(ai, aj, aa)
+    vb = V(P, b)
+    vx = V(P, np.zeros(b.size) if x0 is None else x0)
+    k = P.KSP(comm=L.COMM_SELF)
+    k.set_operators(A)
+    L.PetscOptionsClear()
+    L.PetscOptionsInsertString(("-ksp_type %s -pc_type %s %s" % (ksp, pc, opts)).encode())
+    if tol:
+        k.set_tolerances(**tol)
+    k.set_from_options()
+    if x0 is not None:
+        L.KSPSetInitialGuessNonzero(k.h, 1)
+    k.record_history()
+    k.solve(vb, vx)
+    L.PetscOptionsClear()
+    return vx.array(), k.history(), k.its, k.reason
+
+
+def test_ksp_config1_cg_jacobi(P):
+    """BASELINE.json configs[0]: ex2 -m 100 -n 100 -ksp_type cg -pc_type jacobi -> 160 its, error 5.70785e-05"""
+    ai, aj, aa = pb.lap2d(100, 100)
+    u = np.ones(10000)
+    b = orc.spmv(ai, aj, aa, u)
+    x, h, its, reason = solve(P, ai, aj, aa, b, "cg", "jacobi", rtol=1e-2 / (101 * 101), abstol=1e-50)
+    xr, hr, itsr, rr = orc.ksp_solve(ai, aj, aa, b, ksp="cg", pc="jacobi", rtol=1e-2 / (101 * 101), abstol=1e-50)
+    assert abs(its - itsr) <= 1 and reason == rr == 2
+    k = min(len(h), len(hr))
+    assert np.allclose(h[:k], hr[:k], rtol=1e-6, atol=0)
+    assert ["%g" % v for v in h[:4]] == ["5.04975", "2.54845", "1.81892", "1.67695"]
+    assert "%.5g" % np.linalg.norm(x - u) == "5.7078e-05" or "%.5g" % np.linalg.norm(x - u) == "5.7079e-05"
+
+
+def test_ksp_golden_ex3_ex2f_ex9(P):
+    (ai, aj, aa), b, u0, ustar = pb.ex3_fem(5)
+    gold = pb.parse_monitor(os.path.join(G, "ksp_tests", "ex3_1.out"))[0]
+    x, h, its, reason = solve(P, ai, aj, aa, b, "gmres", "jacobi", x0=u0, opts="-ksp_gmres_cgs_refinement_type refine_always")
+    pb.check_monitor(h, gold)
+    assert np.linalg.norm(x - ustar) <= 1e-12
+    ai, aj, aa = pb.lap2d(3, 3)
+    b = orc.spmv(ai, aj, aa, np.ones(9))
+    gold = pb.parse_monitor(os.path.join(G, "ksp_tutorials", "ex2f_1.out"))[0]
+    x, h, its, reason = solve(P, ai, aj, aa, b, "gmres", "jacobi", opts="-ksp_gmres_cgs_refinement_type refine_always")
+    pb.check_monitor(h, gold)
+    solves = pb.parse_monitor(os.path.join(G, "ksp_tutorials", "ex9_1.out"))
+    (ai, aj, aa), u = pb.ex9_system(1, 0)
+    x, h, its, reason = solve(P, ai, aj, aa, orc.spmv(ai, aj, aa, u), "gmres", "jacobi", opts="-ksp_gmres_cgs_refinement_type refine_always")
+    pb.check_monitor(h, solves[0])
+    for t, g in ((0, solves[1]), (1, solves[3])):
+        (ai, aj, aa), u = pb.ex9_system(2, t)
+        x, h, its, reason = solve(P, ai, aj, aa, orc.spmv(ai, aj, aa, u), "bcgs", "jacobi")
+        pb.check_monitor(h, g)
+        assert np.linalg.norm(x - u) < 1e-4
+
+
+def test_ksp_bjacobi_single_block_golden(P):
+    """ex2_bjacobi.out: one block, sub-KSP GMRES + Jacobi (-sub_ksp_type gmres -sub_pc_type jacobi); device-side aliasing
+    of the work vectors instead of the reference's host VecPlaceArray round trip"""
+    ai, aj, aa = pb.lap2d(8, 7)
+    u = np.ones(56)
+    b = orc.spmv(ai, aj, aa, u)
+    gold = pb.parse_monitor(os.path.join(G, "ksp_tutorials", "ex2_bjacobi.out"))[0]
+    x, h, its, reason = solve(P, ai, aj, aa, b, "gmres", "bjacobi", opts="-pc_bjacobi_blocks 1 -sub_pc_type jacobi -sub_ksp_type gmres",
+                              rtol=1e-2 / 72, abstol=1e-50)
+    pb.check_monitor(h, gold)
+    assert its == 1 and "%.5g" % np.linalg.norm(x - u) in ("2.1014e-06", "2.1015e-06")
+
+
+@pytest.mark.parametrize("ksp", ["cg", "gmres", "bcgs"])
+@pytest.mark.parametrize("pc", ["none", "jacobi", "bjacobi"])
+def test_ksp_vs_oracle_p7(P, ksp, pc):
+    """every solver x preconditioner of the north star on a 3-D 7-pt operator with varying coefficients"""
+    ai, aj, aa = P.gen_poisson7(12, 11, 10)
+    n = ai.size - 1
+    d = 1.0 + 0.5 * np.sin(np.arange(n))           # symmetric diagonal scaling keeps it SPD
+    rows = np.repeat(np.arange(n), np.diff(ai))
+    aa = aa * d[rows] * d[aj]
+    b = orc.spmv(ai, aj, aa, np.cos(0.1 * np.arange(n)))
+    kw = dict(rtol=1e-8)
+    x, h, its, reason = solve(P, ai, aj, aa, b, ksp, pc, opts="-ksp_gmres_restart 20", **kw)
+    okw = dict(blocks=[0, n], sub_ksp="preonly", sub_pc="jacobi") if pc == "bjacobi" else {}
+    xr, hr, itsr, rr = orc.ksp_solve(ai, aj, aa, b, ksp=ksp, pc=pc, rtol=1e-8, restart=20, **okw)
+    k = min(len(h), len(hr))
+    if ksp == "bcgs":
+        # BiCGStab's recurrences amplify the last-bit differences of the dot products: histories agree tightly
+        # while the residual is still large, later only in order of magnitude; the solutions agree
+        early = hr[:k] > 1e-3 * hr[0]
+        assert np.allclose(h[:k][early], hr[:k][early], rtol=1e-6, atol=0)
+        assert reason == rr and abs(its - itsr) <= max(3, itsr // 5)
+    else:
+        assert reason == rr and abs(its - itsr) <= 1
+        assert np.allclose(h[:k], hr[:k], rtol=1e-6, atol=1e-14 * hr[0])
+    assert np.linalg.norm(x - xr) <= 1e-6 * np.linalg.norm(xr)
+
+
+def test_p7_full_size_properties(P):
+    """BASELINE.json configs[1] at full size (P7(256): 16.8M rows) through size-independent properties:
+    A*1 is the boundary indicator pattern (row sums), linearity A(ax+by) = aAx + bAy, symmetry <Ax,y> = <x,Ay>."""
+    L = P.lib()
+    n = 256
+    ai, aj, aa = P.gen_poisson7(n, n, n)
+    A = P.Mat.from_csr(ai, aj, aa)
+    N = n ** 3
+    one = P.Vec.create(N, comm=L.COMM_SELF); L.VecSet(one.h, 1.0)
+    r = one.duplicate()
+    A.mult(one, r)
+    rs = r.array()
+    expect = 6.0 - np.diff(ai) + 1.0                  # 6 - (#neighbours) ; row has 1 + #neighbours entries
+    assert np.array_equal(rs, expect)
+    del rs, expect
+    x = P.Vec.from_array(np.sin(0.37 * np.arange(N)) + 1.0, comm=L.COMM_SELF)
+    y = P.Vec.from_array(np.cos(0.11 * np.arange(N)), comm=L.COMM_SELF)
+    ax, ay, w, aw = x.duplicate(), x.duplicate(), x.duplicate(), x.duplicate()
+    A.mult(x, ax); A.mult(y, ay)
+    L.VecWAXPY(w.h, 2.5, x.h, y.h)                    # w = y + 2.5 x
+    A.mult(w, aw)
+    L.VecAXPY(aw.h, -2.5, ax.h); L.VecAXPY(aw.h, -1.0, ay.h)
+    assert aw.norm() <= 1e-12 * ax.norm()
+    assert abs(ax.dot(y) - x.dot(ay)) <= 1e-12 * ax.norm() * y.norm()

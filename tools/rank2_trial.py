@@ -1,0 +1,57 @@
+"""Development aid: run the N>1 path (MatMPIAIJ + RCCL halo + RCCL all-reduce) with world ranks that may share
+one GPU, and compare every rank's result with the sequential oracle."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    import torch  # noqa: F401
+    import torch.distributed as dist
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    import petsc_dev_amd as pda  # noqa: F401
+    from petsc_dev_amd import petsc as P
+    from petsc_dev_amd import dist as PD
+    import orc
+    L = P.lib()
+    comm = PD.torch_comm(device_comm=True)
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+    nx, ny, nz = n, n, n * world
+    mloc = n ** 3
+    ai, aj, aa = P.gen_poisson7(nx, ny, nz, rank * mloc, (rank + 1) * mloc)
+    A = P.Mat.from_csr_mpi(ai, aj, aa, mloc, mloc * world, mloc * world, comm=comm)
+    gi, gj, ga = orc.gen_p7(nx, ny, nz)
+    N = mloc * world
+    xg = np.sin(0.37 * np.arange(N)) + 1.0
+    x = P.Vec.from_array(xg[rank * mloc:(rank + 1) * mloc], comm=comm, N=N)
+    y = x.duplicate()
+    A.mult(x, y)
+    ref = orc.spmv(gi, gj, ga, xg)[rank * mloc:(rank + 1) * mloc]
+    ok1 = np.array_equal(y.array().view(np.uint64), ref.view(np.uint64))
+    L.MatMultTranspose(A.h, x.h, y.h)
+    reft = orc.spmv_t(gi, gj, ga, xg, N)[rank * mloc:(rank + 1) * mloc]
+    ok2 = np.allclose(y.array(), reft, rtol=1e-13, atol=1e-13)
+    nrm = x.norm()
+    ok3 = abs(nrm - np.linalg.norm(xg)) <= 1e-12 * nrm
+    b = x.duplicate(); u = x.duplicate(); L.VecSet(u.h, 1.0); A.mult(u, b)
+    k = P.KSP(comm=comm); k.set_operators(A); k.set_type("cg"); k.set_pc_type("jacobi"); k.set_tolerances(rtol=1e-8); k.record_history()
+    sol = x.duplicate()
+    k.solve(b, sol)
+    xr, hr, itsr, rr = orc.ksp_solve(gi, gj, ga, orc.spmv(gi, gj, ga, np.ones(N)), ksp="cg", pc="jacobi", rtol=1e-8)
+    h = k.history()
+    ok4 = abs(k.its - itsr) <= 1 and np.allclose(h[:min(len(h), len(hr))], hr[:min(len(h), len(hr))], rtol=1e-6)
+    print("rank %d/%d: MatMult bitexact=%s MatMultTranspose=%s norm=%s CG its=%d (oracle %d) hist=%s" % (rank, world, ok1, ok2, ok3, k.its, itsr, ok4), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    if not (ok1 and ok2 and ok3 and ok4):
+        sys.exit(1)
+
+
+if __name__ == "__main__":
+    main()
