@@ -148,6 +148,8 @@ struct _p_VecScatter {
   PetscBool inuse;            /* guard, vscat.c:1637 */
   mi355x_event_t ev_packed, ev_done;
   int device_ready;
+  /* every rank's request list (kept from set-up) for the host-staged transport */
+  PetscInt *all_garray, *ecs, *xrange, maxec, ec, nlocal_x, max_nlocal_x, rstart_x;
 };
 PetscErrorCode VecScatterCreate_PtoS_MPIAIJ(MPI_Comm comm, PetscLayout *xmap, PetscInt ec, const PetscInt *garray, VecScatter *ctx);
 

@@ -249,14 +249,21 @@ static PetscErrorCode VecMAXPY_HIP(Vec y, PetscInt nv, const PetscScalar *alpha,
  * land in the pinned scratch.  Several ranks: they land in HBM scratch, are all-reduced in place
  * over RCCL on the same stream, copied to the pinned scratch, and only then do we synchronise. */
 static PetscErrorCode reduce_target(Vec x, PetscDeviceCtx *dc, double **out) {
-  *out = (x->comm->size > 1) ? mi355x_handle_device_scratch(dc->h) : mi355x_handle_host_scratch(dc->h);
+  *out = (x->comm->size > 1 && x->comm->dcomm) ? mi355x_handle_device_scratch(dc->h) : mi355x_handle_host_scratch(dc->h);
   return 0;
 }
 static PetscErrorCode reduce_finish(Vec x, PetscDeviceCtx *dc, int count, int is_max, PetscScalar *result) {
   double *hs = mi355x_handle_host_scratch(dc->h);
+  if (x->comm->size > 1 && !x->comm->dcomm) {
+    /* host-staged transport (no RCCL communicator attached): the reference's own arrangement, a device
+     * reduction followed by a host all-reduce (mpicusp.cu:32-113); used by the shared-GPU rehearsal tests */
+    CHKHIP(mi355x_handle_synchronize(dc->h));
+    for (int j = 0; j < count; j++) result[j] = hs[j];
+    if (x->comm->allreduce(x->comm->ctx, result, count, 1, is_max ? 1 : 0)) SETERRQ(x->comm, PETSC_ERR_LIB, "allreduce failed");
+    return 0;
+  }
   if (x->comm->size > 1) {
     double *ds = mi355x_handle_device_scratch(dc->h);
-    if (!x->comm->dcomm) SETERRQ(x->comm, PETSC_ERR_ORDER, "parallel HIPMI355X vectors need PetscCommSetDeviceComm() (RCCL) before reductions");
     if (is_max) CHKHIP(mi355x_comm_allreduce_max(x->comm->dcomm, dc->h, ds, (size_t)count));
     else CHKHIP(mi355x_comm_allreduce_sum(x->comm->dcomm, dc->h, ds, (size_t)count));
     CHKHIP(mi355x_memcpy_d2h(dc->h, hs, ds, sizeof(double) * (size_t)count));

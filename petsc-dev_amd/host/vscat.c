@@ -78,7 +78,11 @@ PetscErrorCode VecScatterCreate_PtoS_MPIAIJ(MPI_Comm comm, PetscLayout *xmap, Pe
       if (gq[i] >= xmap->range[rank] && gq[i] < xmap->range[rank + 1]) { to->indices[cnt++] = gq[i] - xmap->range[rank]; have = PETSC_TRUE; }
     if (have) { to->procs[to->n++] = q; to->starts[to->n] = cnt; }
   }
-  free(all); free(ecs);
+  ctx->all_garray = all; ctx->ecs = ecs; ctx->maxec = maxec; ctx->ec = ec;
+  ctx->nlocal_x = xmap->n; ctx->rstart_x = xmap->rstart; ctx->max_nlocal_x = 0;
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)(size + 1), &ctx->xrange);CHKERRQ(ierr);
+  memcpy(ctx->xrange, xmap->range, sizeof(PetscInt) * (size_t)(size + 1));
+  for (int p = 0; p < size; p++) ctx->max_nlocal_x = PetscMax(ctx->max_nlocal_x, xmap->range[p + 1] - xmap->range[p]);
   /* contiguity (the to->contiq / from->contiq special case, vpscat.c:1951-1960), here per side */
   from->contiq = PETSC_TRUE;
   for (PetscInt i = 0; i < from->n; i++) if (!is_contiguous(from->indices + from->starts[i], from->starts[i + 1] - from->starts[i])) from->contiq = PETSC_FALSE;
@@ -121,6 +125,56 @@ static PetscErrorCode scatter_device_setup(VecScatter ctx, PetscDeviceCtx *dc) {
   return 0;
 }
 
+/* Host-staged transport, used only when the communicator has no RCCL communicator attached (several ranks
+ * sharing one GPU in the rehearsal tests): device -> host, one all-gather, host -> device, the arrangement
+ * of the reference's CUSP path (vpscat.h:56-61,226-230).  Same results as the RCCL path, including the
+ * order of the reverse-mode additions (owner by owner in rank order, request order within an owner). */
+static PetscErrorCode staged_forward(VecScatter ctx, PetscDeviceCtx *dc, const PetscScalar *dx, PetscScalar *dy) {
+  PetscErrorCode ierr;
+  MPI_Comm comm = ctx->comm;
+  size_t mx = (size_t)ctx->max_nlocal_x;
+  PetscScalar *mine, *all, *lv;
+  ierr = PetscMalloc(sizeof(PetscScalar) * PetscMax(mx, 1), &mine);CHKERRQ(ierr);
+  ierr = PetscMalloc(sizeof(PetscScalar) * PetscMax(mx, 1) * (size_t)comm->size, &all);CHKERRQ(ierr);
+  ierr = PetscMalloc(sizeof(PetscScalar) * (size_t)PetscMax(ctx->ec, 1), &lv);CHKERRQ(ierr);
+  memset(mine, 0, sizeof(PetscScalar) * PetscMax(mx, 1));
+  CHKHIP(mi355x_memcpy_d2h(dc->h, mine, dx, sizeof(PetscScalar) * (size_t)ctx->nlocal_x));
+  CHKHIP(mi355x_handle_synchronize(dc->h));
+  if (comm->allgather(comm->ctx, mine, (int)(sizeof(PetscScalar) * mx), all)) SETERRQ(comm, PETSC_ERR_LIB, "allgather failed");
+  const PetscInt *g = ctx->all_garray + (size_t)comm->rank * (size_t)ctx->maxec;
+  for (PetscInt i = 0; i < ctx->ec; i++) {
+    int p = owner_of(comm->size, ctx->xrange, g[i]);
+    lv[i] = all[(size_t)p * mx + (size_t)(g[i] - ctx->xrange[p])];
+  }
+  CHKHIP(mi355x_memcpy_h2d(dc->h, dy, lv, sizeof(PetscScalar) * (size_t)ctx->ec));
+  CHKHIP(mi355x_handle_synchronize(dc->h));
+  free(mine); free(all); free(lv);
+  return 0;
+}
+static PetscErrorCode staged_reverse(VecScatter ctx, PetscDeviceCtx *dc, const PetscScalar *dx, PetscScalar *dy) {
+  PetscErrorCode ierr;
+  MPI_Comm comm = ctx->comm;
+  size_t me = (size_t)PetscMax(ctx->maxec, 1);
+  PetscScalar *mine, *all, *y;
+  ierr = PetscMalloc(sizeof(PetscScalar) * me, &mine);CHKERRQ(ierr);
+  ierr = PetscMalloc(sizeof(PetscScalar) * me * (size_t)comm->size, &all);CHKERRQ(ierr);
+  ierr = PetscMalloc(sizeof(PetscScalar) * (size_t)PetscMax(ctx->nlocal_x, 1), &y);CHKERRQ(ierr);
+  memset(mine, 0, sizeof(PetscScalar) * me);
+  CHKHIP(mi355x_memcpy_d2h(dc->h, mine, dx, sizeof(PetscScalar) * (size_t)ctx->ec));
+  CHKHIP(mi355x_memcpy_d2h(dc->h, y, dy, sizeof(PetscScalar) * (size_t)ctx->nlocal_x));
+  CHKHIP(mi355x_handle_synchronize(dc->h));
+  if (comm->allgather(comm->ctx, mine, (int)(sizeof(PetscScalar) * me), all)) SETERRQ(comm, PETSC_ERR_LIB, "allgather failed");
+  PetscInt lo = ctx->rstart_x, hi = ctx->rstart_x + ctx->nlocal_x;
+  for (int q = 0; q < comm->size; q++) {
+    const PetscInt *gq = ctx->all_garray + (size_t)q * (size_t)ctx->maxec;
+    for (PetscInt i = 0; i < ctx->ecs[q]; i++) if (gq[i] >= lo && gq[i] < hi) y[gq[i] - lo] = y[gq[i] - lo] + all[(size_t)q * me + (size_t)i];
+  }
+  CHKHIP(mi355x_memcpy_h2d(dc->h, dy, y, sizeof(PetscScalar) * (size_t)ctx->nlocal_x));
+  CHKHIP(mi355x_handle_synchronize(dc->h));
+  free(mine); free(all); free(y);
+  return 0;
+}
+
 /* FORWARD/INSERT: x (parallel) -> y (= lvec, sequential).  REVERSE/ADD: x (= lvec) -> y (parallel), +=. */
 PetscErrorCode VecScatterBegin(VecScatter ctx, Vec x, Vec y, InsertMode addv, ScatterMode mode) {
   PetscErrorCode ierr;
@@ -133,7 +187,7 @@ PetscErrorCode VecScatterBegin(VecScatter ctx, Vec x, Vec y, InsertMode addv, Sc
   if (ctx->to.n == 0 && ctx->from.n == 0 && ctx->to.local_n == 0) return 0;
   ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
   ierr = scatter_device_setup(ctx, dc);CHKERRQ(ierr);
-  if ((ctx->to.n || ctx->from.n) && !ctx->comm->dcomm) SETERRQ(ctx->comm, PETSC_ERR_ORDER, "parallel scatter needs PetscCommSetDeviceComm() (RCCL)");
+  if (ctx->comm->size > 1 && !ctx->comm->dcomm) return 0;   /* host-staged transport: everything happens in End (collective) */
   mi355x_comm_t rc = ctx->comm->dcomm;
   VecScatterSide *to = &ctx->to, *from = &ctx->from;
   if (mode == SCATTER_FORWARD) {
@@ -200,8 +254,19 @@ PetscErrorCode VecScatterEnd(VecScatter ctx, Vec x, Vec y, InsertMode addv, Scat
   PetscDeviceCtx *dc;
   if (!ctx) SETERRQ(0, PETSC_ERR_ARG_NULL, "Null VecScatter");
   ctx->inuse = PETSC_FALSE;
-  if (ctx->to.n == 0 && ctx->from.n == 0 && ctx->to.local_n == 0) return 0;
+  if (ctx->comm->size == 1 && ctx->to.local_n == 0) return 0;
   ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
+  if (ctx->comm->size > 1 && !ctx->comm->dcomm) {   /* collective: every rank takes part, neighbours or not */
+    const PetscScalar *dx; PetscScalar *dy;
+    ierr = VecHIPGetRead(x, &dx);CHKERRQ(ierr);
+    ierr = VecHIPGetReadWrite(y, &dy);CHKERRQ(ierr);
+    if (mode == SCATTER_FORWARD) { ierr = staged_forward(ctx, dc, dx, dy);CHKERRQ(ierr); }
+    else { ierr = staged_reverse(ctx, dc, dx, dy);CHKERRQ(ierr); }
+    ierr = VecHIPRestoreWrite(y);CHKERRQ(ierr);
+    PetscObjectStateIncrease(y);
+    return 0;
+  }
+  if (ctx->to.n == 0 && ctx->from.n == 0 && ctx->to.local_n == 0) return 0;
   /* the compute stream resumes after the halo stream's work (replaces MPI_Waitany, vpscat.h:210) */
   CHKHIP(mi355x_handle_wait_event(dc->h, ctx->ev_done));
   if (mode == SCATTER_REVERSE) {
@@ -243,6 +308,7 @@ PetscErrorCode VecScatterDestroy(VecScatter *pctx) {
   }
   if (ctx->ev_packed) mi355x_event_destroy(ctx->ev_packed);
   if (ctx->ev_done) mi355x_event_destroy(ctx->ev_done);
+  free(ctx->all_garray); free(ctx->ecs); free(ctx->xrange);
   free(ctx);
   *pctx = NULL;
   return 0;

@@ -1,0 +1,25 @@
+"""The N>1 path end to end on ONE GPU: two processes (torch.distributed.run, gloo) share the card, so RCCL
+cannot be used (it rejects two ranks on one device) and the host-staged transport carries the halo and the
+reductions.  Everything else -- MatCreateMPIAIJWithArrays, diagonal/off-diagonal SpMV, compressed-row
+off-diagonal block, MatMultTranspose with reverse/ADD scatter, parallel dots and norms, KSPCG over MPI vectors --
+is the code the 8-GPU run executes.  Results are compared with the sequential oracle on every rank."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_mpiaij_two_ranks_one_gpu(built, nranks):
+    env = dict(os.environ, MI355X_STAGED="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks),
+           "--master-addr", "127.0.0.1", "--master-port", str(29520 + nranks), os.path.join(ROOT, "tools", "rank2_trial.py"), "12"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0, out[-3000:]
+    for k in range(nranks):
+        assert "rank %d/%d: MatMult bitexact=True MatMultTranspose=True norm=True" % (k, nranks) in out, out[-3000:]

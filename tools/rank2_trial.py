@@ -20,7 +20,8 @@ def main():
     from petsc_dev_amd import dist as PD
     import orc
     L = P.lib()
-    comm = PD.torch_comm(device_comm=True)
+    staged = os.environ.get("MI355X_STAGED", "0") == "1"   # several ranks on one GPU: RCCL refuses, use the host-staged transport
+    comm = PD.torch_comm(device_comm=not staged)
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 16
     nx, ny, nz = n, n, n * world
     mloc = n ** 3
@@ -32,7 +33,10 @@ def main():
     x = P.Vec.from_array(xg[rank * mloc:(rank + 1) * mloc], comm=comm, N=N)
     y = x.duplicate()
     A.mult(x, y)
-    ref = orc.spmv(gi, gj, ga, xg)[rank * mloc:(rank + 1) * mloc]
+    # MatMult_MPIAIJ order (mpiaij.c:1111-1114): diagonal block first, then += off-diagonal block * ghost values
+    pc = orc.mpiaij_split(rank * mloc, (rank + 1) * mloc, rank * mloc, (rank + 1) * mloc, gi, gj, ga)
+    ref = orc.spmv(pc["ad_i"], pc["ad_j"], pc["ad_a"], xg[rank * mloc:(rank + 1) * mloc])
+    ref = orc.spmv_add(pc["bo_i"], pc["bo_j"], pc["bo_a"], xg[pc["garray"]].copy(), ref)
     ok1 = np.array_equal(y.array().view(np.uint64), ref.view(np.uint64))
     L.MatMultTranspose(A.h, x.h, y.h)
     reft = orc.spmv_t(gi, gj, ga, xg, N)[rank * mloc:(rank + 1) * mloc]
