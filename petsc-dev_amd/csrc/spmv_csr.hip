@@ -18,7 +18,8 @@
 #include "common.hpp"
 #include <vector>
 
-#define SPMV_BLOCK_NNZ 2048
+#define SPMV_BLOCK_NNZ 2048   // LDS stage (doubles)
+#define SPMV_BLOCK_CAP 2046   // nonzeros per row block: any alignment of the first pair still fits 4 pairs per lane
 #define SPMV_BLOCK_ROWS 256
 #define SPMV_LONG_FLAG 0x40000000
 
@@ -30,13 +31,13 @@ struct mi355x_spmv_plan_s {
   int nblocks;     // row blocks
   int nlong;       // of which single long rows
   int chunk;       // ceil(nblocks / NXCD)
-  int *d_rowblk;   // nblocks+1 row boundaries
+  int2 *d_rowblk;  // nblocks+1 entries {first row, first nonzero}
   int *d_rows;     // compressed-row output indices or NULL
 };
 
 template <bool ADD, bool CPROW, bool VEC>
 __global__ __launch_bounds__(MI355X_BLOCK) void spmv_csr_rowblock_kernel(
-    const int *__restrict__ rowblk, int nblocks, int chunk, const int *__restrict__ ai, const int *__restrict__ aj,
+    const int2 *__restrict__ rowblk, int nblocks, int chunk, const int *__restrict__ ai, const int *__restrict__ aj,
     const double *__restrict__ aa, const double *__restrict__ x, const double *yin, double *yout,
     const int *__restrict__ rows) {
   __shared__ double prod[SPMV_BLOCK_NNZ];
@@ -48,15 +49,15 @@ __global__ __launch_bounds__(MI355X_BLOCK) void spmv_csr_rowblock_kernel(
   const int lb = xcd * chunk + slot;
   if (slot >= chunk || lb >= nblocks) return;
 
-  const int r0 = rowblk[lb];
-  const int r1 = rowblk[lb + 1];
-  const int k0 = ai[r0];
-  const int k1 = ai[r1];
+  // {first row, first nonzero} of this row block and of the next: one round trip, no dependent chain
+  const int2 b0 = rowblk[lb];
+  const int2 b1 = rowblk[lb + 1];
+  const int r0 = b0.x, r1 = b1.x, k0 = b0.y, k1 = b1.y;
   const int nnz = k1 - k0;
   const int nrows = r1 - r0;
   const int tid = threadIdx.x;
 
-  if (nnz > SPMV_BLOCK_NNZ) {
+  if (nnz > SPMV_BLOCK_CAP) {
     // one long row: strided partial sums, then a fixed tree
     double s = 0.0;
     for (int k = k0 + tid; k < k1; k += MI355X_BLOCK) {
@@ -77,19 +78,52 @@ __global__ __launch_bounds__(MI355X_BLOCK) void spmv_csr_rowblock_kernel(
     return;
   }
 
+  // lanes per row: largest power of two with nrows*tpr <= 256, at most one wavefront; short rows
+  // (the stencil case) get one lane per row and the reference's summation order
+  int tpr = 1;
+  while (tpr < MI355X_WAVE && nrows * (tpr * 2) <= MI355X_BLOCK) tpr *= 2;
+  if (nnz <= 16 * nrows) tpr = 1;
+
+  // row extents for the summation phase are requested now, so their latency overlaps the stream below
+  int rs = 0, re = 0, orow = 0;
+  double ysum = 0.0;
+  if (tpr == 1 && tid < nrows) {
+    rs = ai[r0 + tid];
+    re = ai[r0 + tid + 1];
+    orow = CPROW ? rows[r0 + tid] : r0 + tid;
+    if (ADD) ysum = yin[orow];
+  }
+
   // ---- stream the block's nonzeros: product -> LDS -----------------------
   if (VEC) {
+    // all loads of this lane are issued before any is consumed: 4 x (16 B val + 8 B col) in flight per lane
+    constexpr int PAIRS = SPMV_BLOCK_NNZ / (2 * MI355X_BLOCK);
     const int ka = k0 & ~1;  // 16-byte aligned start for val, 8-byte for col
-    for (int k = ka + 2 * tid; k < k1; k += 2 * MI355X_BLOCK) {
-      if (k >= k0 && k + 1 < k1) {
-        v2d v = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(aa + k));
-        v2i c = __builtin_nontemporal_load(reinterpret_cast<const v2i *>(aj + k));
-        double x0 = x[c.x];
-        double x1 = x[c.y];
-        prod[k - k0] = v.x * x0;
-        prod[k - k0 + 1] = v.y * x1;
-      } else {
-        if (k >= k0) prod[k - k0] = __builtin_nontemporal_load(aa + k) * x[__builtin_nontemporal_load(aj + k)];
+    v2d v[PAIRS];
+    v2i c[PAIRS];
+    bool full[PAIRS];
+#pragma unroll
+    for (int p = 0; p < PAIRS; ++p) {
+      const int k = ka + 2 * tid + p * 2 * MI355X_BLOCK;
+      full[p] = (k >= k0) && (k + 1 < k1);
+      if (full[p]) {
+        v[p] = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(aa + k));
+        c[p] = __builtin_nontemporal_load(reinterpret_cast<const v2i *>(aj + k));
+      }
+    }
+    double xa[PAIRS], xb[PAIRS];
+#pragma unroll
+    for (int p = 0; p < PAIRS; ++p) {
+      if (full[p]) { xa[p] = x[c[p].x]; xb[p] = x[c[p].y]; }
+    }
+#pragma unroll
+    for (int p = 0; p < PAIRS; ++p) {
+      const int k = ka + 2 * tid + p * 2 * MI355X_BLOCK;
+      if (full[p]) {
+        prod[k - k0] = v[p].x * xa[p];
+        prod[k - k0 + 1] = v[p].y * xb[p];
+      } else {  // a pair cut by the block boundary (at most two per block)
+        if (k >= k0 && k < k1) prod[k - k0] = __builtin_nontemporal_load(aa + k) * x[__builtin_nontemporal_load(aj + k)];
         if (k + 1 >= k0 && k + 1 < k1)
           prod[k + 1 - k0] = __builtin_nontemporal_load(aa + k + 1) * x[__builtin_nontemporal_load(aj + k + 1)];
       }
@@ -101,35 +135,26 @@ __global__ __launch_bounds__(MI355X_BLOCK) void spmv_csr_rowblock_kernel(
   __syncthreads();
 
   // ---- per-row sums out of LDS -------------------------------------------
-  // lanes per row: largest power of two with nrows*tpr <= 256, at most one wavefront
-  int tpr = 1;
-  while (tpr < MI355X_WAVE && nrows * (tpr * 2) <= MI355X_BLOCK) tpr *= 2;
-  if (nnz <= 16 * nrows) tpr = 1;  // short rows: one lane per row, reference summation order
-
   if (tpr == 1) {
-    for (int r = tid; r < nrows; r += MI355X_BLOCK) {
-      const int row = r0 + r;
-      const int s = ai[row] - k0;
-      const int e = ai[row + 1] - k0;
-      const int orow = CPROW ? rows[row] : row;
-      double sum = ADD ? yin[orow] : 0.0;
-      for (int k = s; k < e; ++k) sum += prod[k];
+    if (tid < nrows) {
+      double sum = ADD ? ysum : 0.0;
+      for (int k = rs - k0; k < re - k0; ++k) sum += prod[k];
       yout[orow] = sum;
     }
   } else {
     const int r = tid / tpr;
     const int sub = tid & (tpr - 1);
     double sum = 0.0;
-    int orow = 0;
+    int orow2 = 0;
     if (r < nrows) {
       const int row = r0 + r;
       const int s = ai[row] - k0;
       const int e = ai[row + 1] - k0;
-      orow = CPROW ? rows[row] : row;
+      orow2 = CPROW ? rows[row] : row;
       for (int k = s + sub; k < e; k += tpr) sum += prod[k];
     }
     for (int off = tpr >> 1; off > 0; off >>= 1) sum += __shfl_down(sum, off, MI355X_WAVE);
-    if (r < nrows && sub == 0) yout[orow] = ADD ? (yin[orow] + sum) : sum;
+    if (r < nrows && sub == 0) yout[orow2] = ADD ? (yin[orow2] + sum) : sum;
   }
 }
 
@@ -171,16 +196,16 @@ int mi355x_spmv_plan_create(mi355x_handle_t h, int nrows, const int *ai_host, co
   p->d_rowblk = nullptr;
   p->d_rows = nullptr;
   p->nlong = 0;
-  std::vector<int> rb;
+  std::vector<int2> rb;
   rb.reserve((size_t)nrows / 128 + 2);
-  rb.push_back(0);
+  rb.push_back(make_int2(0, ai_host[0]));
   int r = 0;
   while (r < nrows) {
     const int start = r;
     int nnz = 0;
     while (r < nrows && (r - start) < SPMV_BLOCK_ROWS) {
       const int len = ai_host[r + 1] - ai_host[r];
-      if (nnz + len > SPMV_BLOCK_NNZ) break;
+      if (nnz + len > SPMV_BLOCK_CAP) break;
       nnz += len;
       ++r;
     }
@@ -188,12 +213,12 @@ int mi355x_spmv_plan_create(mi355x_handle_t h, int nrows, const int *ai_host, co
       ++r;
       p->nlong++;
     }
-    rb.push_back(r);
+    rb.push_back(make_int2(r, ai_host[r]));
   }
   p->nblocks = (int)rb.size() - 1;
   p->chunk = (p->nblocks + MI355X_NXCD - 1) / MI355X_NXCD;
-  MI355X_TRY(hipMalloc((void **)&p->d_rowblk, sizeof(int) * rb.size()));
-  MI355X_TRY(hipMemcpyAsync(p->d_rowblk, rb.data(), sizeof(int) * rb.size(), hipMemcpyHostToDevice, h->stream));
+  MI355X_TRY(hipMalloc((void **)&p->d_rowblk, sizeof(int2) * rb.size()));
+  MI355X_TRY(hipMemcpyAsync(p->d_rowblk, rb.data(), sizeof(int2) * rb.size(), hipMemcpyHostToDevice, h->stream));
   if (rows_host) {
     MI355X_TRY(hipMalloc((void **)&p->d_rows, sizeof(int) * (size_t)(nrows > 0 ? nrows : 1)));
     MI355X_TRY(hipMemcpyAsync(p->d_rows, rows_host, sizeof(int) * (size_t)nrows, hipMemcpyHostToDevice, h->stream));
@@ -214,7 +239,7 @@ int mi355x_spmv_plan_destroy(mi355x_spmv_plan_t p) {
 int mi355x_spmv_plan_info(mi355x_spmv_plan_t p, int *nblocks, int *nlong, size_t *workspace_bytes) {
   if (nblocks) *nblocks = p->nblocks;
   if (nlong) *nlong = p->nlong;
-  if (workspace_bytes) *workspace_bytes = sizeof(int) * ((size_t)p->nblocks + 1 + (p->d_rows ? (size_t)p->nrows : 0));
+  if (workspace_bytes) *workspace_bytes = sizeof(int) * (2 * ((size_t)p->nblocks + 1) + (p->d_rows ? (size_t)p->nrows : 0));
   return 0;
 }
 

@@ -167,7 +167,7 @@ static int launch_maxpy(mi355x_handle_t h, const MaxpyArgs &args, double *x, siz
 // ------------------------------------------------------------------------
 enum { RED_SUM = 0, RED_MAX = 1 };
 
-template <int NOUT, int MODE>
+template <int NOUT, int MODE, bool PUBLISH = false>
 __device__ __forceinline__ void block_reduce_store(double (&acc)[NOUT], double *dst /* NOUT doubles */, double (*lds)[NOUT]) {
   const int lane = threadIdx.x & (MI355X_WAVE - 1);
   const int wave = threadIdx.x / MI355X_WAVE;
@@ -182,7 +182,10 @@ __device__ __forceinline__ void block_reduce_store(double (&acc)[NOUT], double *
 #pragma unroll
     for (int w = 1; w < MI355X_BLOCK / MI355X_WAVE; ++w)
       s = (MODE == RED_MAX) ? nanmax(s, lds[w][threadIdx.x]) : s + lds[w][threadIdx.x];
-    dst[threadIdx.x] = s;
+    // a partial that another workgroup will read is stored write-through (sc1): it reaches the memory side
+    // without an L2 write-back fence per workgroup
+    if (PUBLISH) __hip_atomic_store(dst + threadIdx.x, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else dst[threadIdx.x] = s;
   }
 }
 
@@ -199,7 +202,7 @@ __global__ __launch_bounds__(MI355X_BLOCK) void reduce_kernel(F f, size_t n, int
   for (int j = 0; j < NOUT; ++j) acc[j] = 0.0;
   if (vec_ok) {
     const size_t n2 = n >> 1;
-    for (size_t i = tid; i < n2; i += stride) f.accum2(i, acc);
+    f.template sweep<NOUT>(tid, stride, n2, acc);
     if ((n & 1) && tid == 0) f.accum1(n - 1, acc);
   } else {
     for (size_t i = tid; i < n; i += stride) f.accum1(i, acc);
@@ -208,14 +211,13 @@ __global__ __launch_bounds__(MI355X_BLOCK) void reduce_kernel(F f, size_t n, int
     block_reduce_store<NOUT, MODE>(acc, out, lds);
     return;
   }
-  block_reduce_store<NOUT, MODE>(acc, partials + (size_t)blockIdx.x * NOUT, lds);
-  // Publish this workgroup's partials, then take a ticket (agent-scope release ->
-  // counter; the storing lanes and lane 0 are all in wavefront 0).
+  block_reduce_store<NOUT, MODE, true>(acc, partials + (size_t)blockIdx.x * NOUT, lds);
+  // Publish: the partials were stored write-through by lanes of wavefront 0; once those stores have left
+  // (vmcnt(0)) lane 0 takes a ticket.  The workgroup that draws the last ticket acquires (invalidates its
+  // CU's L1) and reads every partial with sc1 loads.
   if (threadIdx.x < MI355X_WAVE) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (threadIdx.x == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       int last = (t == gridDim.x - 1);
       if (last) {
@@ -244,15 +246,33 @@ __global__ __launch_bounds__(MI355X_BLOCK) void reduce_kernel(F f, size_t n, int
 
 template <int NOUT, int MODE, class F>
 static int launch_reduce(mi355x_handle_t h, F f, size_t n, int vec_ok, double *out) {
-  int grid = mi355x_grid_for(n, 8);
+  int grid = mi355x_grid_for(n, 16);
+  if (grid > 1024) grid = 1024;   // 4 workgroups per CU; the last one sums <= 1024 partials
   hipLaunchKernelGGL((reduce_kernel<NOUT, MODE, F>), dim3(grid), dim3(MI355X_BLOCK), 0, h->stream, f, n, vec_ok,
                      h->partials, h->ticket, out);
   MI355X_LAUNCH_CHECK();
   return 0;
 }
 
+// default sweep: 4 grid-stride iterations' loads issued together, consumed in order
+#define DEFAULT_SWEEP()                                                                              \
+  template <int NOUT_>                                                                               \
+  __device__ __forceinline__ void sweep(size_t tid, size_t stride, size_t n2, double (&a)[NOUT_]) const { \
+    size_t i = tid;                                                                                  \
+    for (; i + 3 * stride < n2; i += 4 * stride) accum2x4(i, stride, a);                             \
+    for (; i < n2; i += stride) accum2(i, a);                                                        \
+  }
+
 struct DotF {
   const double *x, *y;
+  DEFAULT_SWEEP()
+  __device__ void accum2x4(size_t i, size_t st, double (&a)[1]) const {
+    const double2 *x2 = reinterpret_cast<const double2 *>(x), *y2 = reinterpret_cast<const double2 *>(y);
+    double2 xv0 = x2[i], xv1 = x2[i + st], xv2 = x2[i + 2 * st], xv3 = x2[i + 3 * st];
+    double2 yv0 = y2[i], yv1 = y2[i + st], yv2 = y2[i + 2 * st], yv3 = y2[i + 3 * st];
+    a[0] += xv0.x * yv0.x; a[0] += xv0.y * yv0.y; a[0] += xv1.x * yv1.x; a[0] += xv1.y * yv1.y;
+    a[0] += xv2.x * yv2.x; a[0] += xv2.y * yv2.y; a[0] += xv3.x * yv3.x; a[0] += xv3.y * yv3.y;
+  }
   __device__ void accum1(size_t i, double (&a)[1]) const { a[0] += x[i] * y[i]; }
   __device__ void accum2(size_t i, double (&a)[1]) const {
     double2 xv = reinterpret_cast<const double2 *>(x)[i], yv = reinterpret_cast<const double2 *>(y)[i];
@@ -262,6 +282,13 @@ struct DotF {
 };
 struct SumSqF {
   const double *x;
+  DEFAULT_SWEEP()
+  __device__ void accum2x4(size_t i, size_t st, double (&a)[1]) const {
+    const double2 *x2 = reinterpret_cast<const double2 *>(x);
+    double2 v0 = x2[i], v1 = x2[i + st], v2 = x2[i + 2 * st], v3 = x2[i + 3 * st];
+    a[0] += v0.x * v0.x; a[0] += v0.y * v0.y; a[0] += v1.x * v1.x; a[0] += v1.y * v1.y;
+    a[0] += v2.x * v2.x; a[0] += v2.y * v2.y; a[0] += v3.x * v3.x; a[0] += v3.y * v3.y;
+  }
   __device__ void accum1(size_t i, double (&a)[1]) const { a[0] += x[i] * x[i]; }
   __device__ void accum2(size_t i, double (&a)[1]) const {
     double2 xv = reinterpret_cast<const double2 *>(x)[i];
@@ -271,6 +298,8 @@ struct SumSqF {
 };
 struct SumAbsF {
   const double *x;
+  DEFAULT_SWEEP()
+  __device__ void accum2x4(size_t i, size_t st, double (&a)[1]) const { accum2(i, a); accum2(i + st, a); accum2(i + 2 * st, a); accum2(i + 3 * st, a); }
   __device__ void accum1(size_t i, double (&a)[1]) const { a[0] += fabs(x[i]); }
   __device__ void accum2(size_t i, double (&a)[1]) const {
     double2 xv = reinterpret_cast<const double2 *>(x)[i];
@@ -280,6 +309,8 @@ struct SumAbsF {
 };
 struct MaxAbsF {
   const double *x;
+  DEFAULT_SWEEP()
+  __device__ void accum2x4(size_t i, size_t st, double (&a)[1]) const { accum2(i, a); accum2(i + st, a); accum2(i + 2 * st, a); accum2(i + 3 * st, a); }
   __device__ void accum1(size_t i, double (&a)[1]) const { a[0] = nanmax(a[0], fabs(x[i])); }
   __device__ void accum2(size_t i, double (&a)[1]) const {
     double2 xv = reinterpret_cast<const double2 *>(x)[i];
@@ -289,6 +320,8 @@ struct MaxAbsF {
 };
 struct Norm12F {
   const double *x;
+  DEFAULT_SWEEP()
+  __device__ void accum2x4(size_t i, size_t st, double (&a)[2]) const { accum2(i, a); accum2(i + st, a); accum2(i + 2 * st, a); accum2(i + 3 * st, a); }
   __device__ void accum1(size_t i, double (&a)[2]) const { a[0] += fabs(x[i]); a[1] += x[i] * x[i]; }
   __device__ void accum2(size_t i, double (&a)[2]) const {
     double2 xv = reinterpret_cast<const double2 *>(x)[i];
@@ -298,6 +331,8 @@ struct Norm12F {
 };
 struct DotNorm2F {
   const double *s, *t;
+  DEFAULT_SWEEP()
+  __device__ void accum2x4(size_t i, size_t st, double (&a)[2]) const { accum2(i, a); accum2(i + st, a); accum2(i + 2 * st, a); accum2(i + 3 * st, a); }
   __device__ void accum1(size_t i, double (&a)[2]) const { a[0] += s[i] * t[i]; a[1] += t[i] * t[i]; }
   __device__ void accum2(size_t i, double (&a)[2]) const {
     double2 sv = reinterpret_cast<const double2 *>(s)[i], tv = reinterpret_cast<const double2 *>(t)[i];
@@ -309,6 +344,12 @@ template <int NV>
 struct MDotF {
   const double *x;
   const double *y[NV];
+  template <int NOUT_>
+  __device__ __forceinline__ void sweep(size_t tid, size_t stride, size_t n2, double (&a)[NOUT_]) const {
+    size_t i = tid;
+    if (NV <= 4) for (; i + stride < n2; i += 2 * stride) { accum2(i, a); accum2(i + stride, a); }
+    for (; i < n2; i += stride) accum2(i, a);
+  }
   __device__ void accum1(size_t i, double (&a)[NV]) const {
     double xv = x[i];
 #pragma unroll
