@@ -53,6 +53,9 @@ void orc_spmv_csr_add(int m, const int *ai, const int *aj, const double *aa, con
 void orc_spmv_csr_transpose(int m, int n, const int *ai, const int *aj, const double *aa, const double *x, double *y);     /* :1124 */
 void orc_spmv_csr_transpose_add(int m, int n, const int *ai, const int *aj, const double *aa, const double *x, const double *z, double *y); /* :1078 */
 void orc_csr_get_diagonal(int m, const int *ai, const int *aj, const double *aa, double *d);                    /* :1040 */
+/* inode variant (src/mat/impls/aij/seq/inode.c:392-578 mult, :3964-4034 detection) */
+int  orc_check_inode(int m, const int *ai, const int *aj, int limit, int *ns);
+void orc_spmv_csr_inode(int m, const int *ai, const int *aj, const double *aa, const double *x, double *y);
 /* explicit transpose, rows of A^T listing contributions in increasing original-row order */
 void orc_csr_transpose(int m, int n, const int *ai, const int *aj, const double *aa, int *ti, int *tj, double *ta);
 /* ---- SeqBAIJ (src/mat/impls/baij/seq/baij2.c:331,387,981) ---- */

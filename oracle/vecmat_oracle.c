@@ -246,3 +246,43 @@ void orc_spmv_bsr(int mbs, int bs, const int *ai, const int *aj, const double *a
     for (int r = 0; r < bs; r++) y[(size_t)i * bs + r] = sum[r];
   }
 }
+
+/* ------------------------------------------------------------------ SeqAIJ, inode variant */
+
+/* Mat_CheckInode, src/mat/impls/aij/seq/inode.c:3964-4034: consecutive rows with identical column
+ * pattern are grouped, at most `limit` (default 5) rows per node.  ns[] receives the node sizes.
+ * Returns the node count, or 0 when the reference would NOT switch to the inode routines
+ * (node_count > 0.8 m). */
+int orc_check_inode(int m, const int *ai, const int *aj, int limit, int *ns) {
+  int i = 0, node_count = 0;
+  const int *idx = aj;
+  while (i < m) {
+    int nzx = ai[i + 1] - ai[i], j, blk = 1;
+    const int *idy = idx;
+    for (j = i + 1; j < m && blk < limit; ++j, ++blk) {
+      int nzy = ai[j + 1] - ai[j];
+      if (nzy != nzx) break;
+      idy += nzx;
+      if (memcmp(idx, idy, (size_t)nzx * sizeof(int))) break;
+    }
+    ns[node_count++] = blk;
+    idx += (size_t)blk * nzx;
+    i = j;
+  }
+  if (!m || node_count > .8 * m) return 0;
+  return node_count;
+}
+
+/* MatMult_SeqAIJ_Inode, src/mat/impls/aij/seq/inode.c:392-578: whatever the node size (cases 1..5), every
+ * row's sum is built two products at a time, sum += v[0]*x0 + v[1]*x1, with a single trailing product
+ * when the row length is odd -- a different rounding from MatMult_SeqAIJ's one-at-a-time loop. */
+void orc_spmv_csr_inode(int m, const int *ai, const int *aj, const double *aa, const double *x, double *y) {
+  for (int i = 0; i < m; i++) {
+    const int s = ai[i], sz = ai[i + 1] - ai[i];
+    double sum = 0.0;
+    int n;
+    for (n = 0; n < sz - 1; n += 2) sum += aa[s + n] * x[aj[s + n]] + aa[s + n + 1] * x[aj[s + n + 1]];
+    if (n == sz - 1) sum += aa[s + n] * x[aj[s + n]];
+    y[i] = sum;
+  }
+}

@@ -7,7 +7,8 @@ ROOT = os.path.dirname(PKG)
 
 
 def kernels_lib_path():
-    return os.path.join(PKG, "csrc", "libmi355x_kernels.so")
+    # MI355X_KERNELS_LIB selects an alternative build of the same C ABI (tuning experiments)
+    return os.environ.get("MI355X_KERNELS_LIB") or os.path.join(PKG, "csrc", "libmi355x_kernels.so")
 
 
 def host_lib_path():

@@ -18,9 +18,24 @@
 #include "common.hpp"
 #include <vector>
 
-#define SPMV_BLOCK_NNZ 2048   // LDS stage (doubles)
-#define SPMV_BLOCK_CAP 2046   // nonzeros per row block: any alignment of the first pair still fits 4 pairs per lane
-#define SPMV_BLOCK_ROWS 256
+// tuning knobs (the defaults are the measured best on MI355X for the 7-point operator)
+#ifndef SPMV_THREADS
+#define SPMV_THREADS 256
+#endif
+#ifndef SPMV_NT
+#define SPMV_NT 1            // non-temporal loads for the val/col streams
+#endif
+#ifndef SPMV_REMAP
+#define SPMV_REMAP 0         // 1 = each XCD walks a contiguous eighth of the row blocks (measured slower)
+#endif
+#define SPMV_BLOCK_NNZ (8 * SPMV_THREADS)     // LDS stage (doubles): 4 pairs per lane
+#define SPMV_BLOCK_CAP (SPMV_BLOCK_NNZ - 2)   // nonzeros per row block: any alignment of the first pair still fits
+#define SPMV_BLOCK_ROWS SPMV_THREADS
+#if SPMV_NT
+#define SPMV_LOAD(p) __builtin_nontemporal_load(p)
+#else
+#define SPMV_LOAD(p) (*(p))
+#endif
 #define SPMV_LONG_FLAG 0x40000000
 
 typedef double v2d __attribute__((ext_vector_type(2)));
@@ -36,18 +51,23 @@ struct mi355x_spmv_plan_s {
 };
 
 template <bool ADD, bool CPROW, bool VEC>
-__global__ __launch_bounds__(MI355X_BLOCK) void spmv_csr_rowblock_kernel(
+__global__ __launch_bounds__(SPMV_THREADS) void spmv_csr_rowblock_kernel(
     const int2 *__restrict__ rowblk, int nblocks, int chunk, const int *__restrict__ ai, const int *__restrict__ aj,
     const double *__restrict__ aa, const double *__restrict__ x, const double *yin, double *yout,
     const int *__restrict__ rows) {
   __shared__ double prod[SPMV_BLOCK_NNZ];
-  __shared__ double wsum[MI355X_BLOCK / MI355X_WAVE];
+  __shared__ double wsum[SPMV_THREADS / MI355X_WAVE];
 
   // XCD-aware remap: workgroups b, b+8, b+16.. share an XCD; give them consecutive row blocks
+#if SPMV_REMAP
   const int xcd = blockIdx.x % MI355X_NXCD;
   const int slot = blockIdx.x / MI355X_NXCD;
   const int lb = xcd * chunk + slot;
   if (slot >= chunk || lb >= nblocks) return;
+#else
+  const int lb = blockIdx.x;
+  if (lb >= nblocks) return;
+#endif
 
   // {first row, first nonzero} of this row block and of the next: one round trip, no dependent chain
   const int2 b0 = rowblk[lb];
@@ -60,9 +80,9 @@ __global__ __launch_bounds__(MI355X_BLOCK) void spmv_csr_rowblock_kernel(
   if (nnz > SPMV_BLOCK_CAP) {
     // one long row: strided partial sums, then a fixed tree
     double s = 0.0;
-    for (int k = k0 + tid; k < k1; k += MI355X_BLOCK) {
-      double v = __builtin_nontemporal_load(aa + k);
-      int c = __builtin_nontemporal_load(aj + k);
+    for (int k = k0 + tid; k < k1; k += SPMV_THREADS) {
+      double v = SPMV_LOAD(aa + k);
+      int c = SPMV_LOAD(aj + k);
       s += v * x[c];
     }
     s = wave_sum(s);
@@ -71,7 +91,7 @@ __global__ __launch_bounds__(MI355X_BLOCK) void spmv_csr_rowblock_kernel(
     if (tid == 0) {
       double t = wsum[0];
 #pragma unroll
-      for (int w = 1; w < MI355X_BLOCK / MI355X_WAVE; ++w) t += wsum[w];
+      for (int w = 1; w < SPMV_THREADS / MI355X_WAVE; ++w) t += wsum[w];
       const int orow = CPROW ? rows[r0] : r0;
       yout[orow] = ADD ? (yin[orow] + t) : t;
     }
@@ -81,7 +101,7 @@ __global__ __launch_bounds__(MI355X_BLOCK) void spmv_csr_rowblock_kernel(
   // lanes per row: largest power of two with nrows*tpr <= 256, at most one wavefront; short rows
   // (the stencil case) get one lane per row and the reference's summation order
   int tpr = 1;
-  while (tpr < MI355X_WAVE && nrows * (tpr * 2) <= MI355X_BLOCK) tpr *= 2;
+  while (tpr < MI355X_WAVE && nrows * (tpr * 2) <= SPMV_THREADS) tpr *= 2;
   if (nnz <= 16 * nrows) tpr = 1;
 
   // row extents for the summation phase are requested now, so their latency overlaps the stream below
@@ -97,18 +117,18 @@ __global__ __launch_bounds__(MI355X_BLOCK) void spmv_csr_rowblock_kernel(
   // ---- stream the block's nonzeros: product -> LDS -----------------------
   if (VEC) {
     // all loads of this lane are issued before any is consumed: 4 x (16 B val + 8 B col) in flight per lane
-    constexpr int PAIRS = SPMV_BLOCK_NNZ / (2 * MI355X_BLOCK);
+    constexpr int PAIRS = SPMV_BLOCK_NNZ / (2 * SPMV_THREADS);
     const int ka = k0 & ~1;  // 16-byte aligned start for val, 8-byte for col
     v2d v[PAIRS];
     v2i c[PAIRS];
     bool full[PAIRS];
 #pragma unroll
     for (int p = 0; p < PAIRS; ++p) {
-      const int k = ka + 2 * tid + p * 2 * MI355X_BLOCK;
+      const int k = ka + 2 * tid + p * 2 * SPMV_THREADS;
       full[p] = (k >= k0) && (k + 1 < k1);
       if (full[p]) {
-        v[p] = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(aa + k));
-        c[p] = __builtin_nontemporal_load(reinterpret_cast<const v2i *>(aj + k));
+        v[p] = SPMV_LOAD(reinterpret_cast<const v2d *>(aa + k));
+        c[p] = SPMV_LOAD(reinterpret_cast<const v2i *>(aj + k));
       }
     }
     double xa[PAIRS], xb[PAIRS];
@@ -118,19 +138,19 @@ __global__ __launch_bounds__(MI355X_BLOCK) void spmv_csr_rowblock_kernel(
     }
 #pragma unroll
     for (int p = 0; p < PAIRS; ++p) {
-      const int k = ka + 2 * tid + p * 2 * MI355X_BLOCK;
+      const int k = ka + 2 * tid + p * 2 * SPMV_THREADS;
       if (full[p]) {
         prod[k - k0] = v[p].x * xa[p];
         prod[k - k0 + 1] = v[p].y * xb[p];
       } else {  // a pair cut by the block boundary (at most two per block)
-        if (k >= k0 && k < k1) prod[k - k0] = __builtin_nontemporal_load(aa + k) * x[__builtin_nontemporal_load(aj + k)];
+        if (k >= k0 && k < k1) prod[k - k0] = SPMV_LOAD(aa + k) * x[SPMV_LOAD(aj + k)];
         if (k + 1 >= k0 && k + 1 < k1)
-          prod[k + 1 - k0] = __builtin_nontemporal_load(aa + k + 1) * x[__builtin_nontemporal_load(aj + k + 1)];
+          prod[k + 1 - k0] = SPMV_LOAD(aa + k + 1) * x[SPMV_LOAD(aj + k + 1)];
       }
     }
   } else {
-    for (int k = k0 + tid; k < k1; k += MI355X_BLOCK)
-      prod[k - k0] = __builtin_nontemporal_load(aa + k) * x[__builtin_nontemporal_load(aj + k)];
+    for (int k = k0 + tid; k < k1; k += SPMV_THREADS)
+      prod[k - k0] = SPMV_LOAD(aa + k) * x[SPMV_LOAD(aj + k)];
   }
   __syncthreads();
 
@@ -176,7 +196,7 @@ static int launch_spmv(mi355x_handle_t h, mi355x_spmv_plan_t p, const int *ai, c
   if (p->nblocks == 0) return 0;
   const bool vec = mi355x_aligned16(aa) && ((((uintptr_t)aj) & 7u) == 0);
   const bool cprow = p->d_rows != nullptr;
-  dim3 grid(p->chunk * MI355X_NXCD), block(MI355X_BLOCK);
+  dim3 grid(p->chunk * MI355X_NXCD), block(SPMV_THREADS);
 #define SPMV_GO(C, V)                                                                                               \
   hipLaunchKernelGGL((spmv_csr_rowblock_kernel<ADD, C, V>), grid, block, 0, h->stream, p->d_rowblk, p->nblocks,    \
                      p->chunk, ai, aj, aa, x, yin, yout, p->d_rows)

@@ -99,6 +99,20 @@ def spmv(ai, aj, aa, x):
     return y
 
 
+def check_inode(ai, aj, limit=5):
+    m = ai.size - 1
+    ns = np.zeros(m + 1, dtype=np.int32)
+    nc = lib().orc_check_inode(C.c_int(m), I(ai), I(aj), C.c_int(limit), I(ns))
+    return nc, ns[:nc].copy()
+
+
+def spmv_inode(ai, aj, aa, x):
+    m = ai.size - 1
+    y = np.zeros(m)
+    lib().orc_spmv_csr_inode(C.c_int(m), I(ai), I(aj), D(aa), D(x), D(y))
+    return y
+
+
 def spmv_add(ai, aj, aa, x, y):
     m = ai.size - 1
     z = np.zeros(m)

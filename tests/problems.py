@@ -114,3 +114,34 @@ def parse_vecview(path):
             except ValueError:
                 cur = None
     return [np.array(v) for v in vecs if v]
+
+
+def elasticity_like(nx, ny, nz, dof=3, seed=3):
+    """A 3-dof-per-node operator stored point-wise (AIJ): 27-point node stencil, dense dof x dof coupling -- the
+    shape of src/ksp/ksp/examples/tutorials/ex56.c's matrix (rows of one node share their column pattern, so the
+    reference switches to its inode routines: 'found N/3 nodes, limit used is 5').  Returns point CSR and the
+    equivalent block CSR (blocks column-major as in baij.h)."""
+    rng = np.random.default_rng(seed)
+    nn = nx * ny * nz
+    bi = [0]; bj = []
+    for k in range(nz):
+        for j in range(ny):
+            for i in range(nx):
+                for dk in (-1, 0, 1):
+                    for dj in (-1, 0, 1):
+                        for di in (-1, 0, 1):
+                            ii, jj, kk = i + di, j + dj, k + dk
+                            if 0 <= ii < nx and 0 <= jj < ny and 0 <= kk < nz:
+                                bj.append(ii + nx * (jj + ny * kk))
+                bi.append(len(bj))
+    bi = np.array(bi, dtype=np.int32); bj = np.array(bj, dtype=np.int32)
+    blocks = rng.standard_normal((bj.size, dof, dof))          # blocks[b][r][c]
+    ba = np.ascontiguousarray(blocks.transpose(0, 2, 1)).ravel()   # column-major per block
+    ai = [0]; aj = []; aa = []
+    for node in range(nn):
+        for r in range(dof):
+            for b in range(bi[node], bi[node + 1]):
+                for c in range(dof):
+                    aj.append(bj[b] * dof + c); aa.append(blocks[b, r, c])
+            ai.append(len(aj))
+    return (np.array(ai, dtype=np.int32), np.array(aj, dtype=np.int32), np.array(aa)), (bi, bj, ba)

@@ -190,6 +190,29 @@ def test_baij_matmult(P):
     assert np.allclose(vy.array(), ref, rtol=0, atol=1e-12 * 50)
 
 
+def test_elasticity_aij_vs_inode_and_baij(P):
+    """the same 3-dof operator as point AIJ (reference: inode routines) and as BAIJ bs=3
+    (MatMult_SeqBAIJ_3).  The HIP AIJ path equals the plain row loop bit for bit and the inode variant to 1e-12
+    (scaled per row); the BCSR kernel agrees with MatMult_SeqBAIJ_3's order to the same tolerance."""
+    L = P.lib()
+    (ai, aj, aa), (bi, bj, ba) = pb.elasticity_like(9, 8, 7)
+    m = ai.size - 1
+    x = rnd(m, 11)
+    scale = np.zeros(m); np.add.at(scale, np.repeat(np.arange(m), np.diff(ai)), np.abs(aa * x[aj]))
+    A = P.Mat.from_csr(ai, aj, aa)
+    vx, vy = V(P, x), V(P, np.zeros(m))
+    L.MatMult(A.h, vx.h, vy.h)
+    y = vy.array()
+    # rows of 24..81 nonzeros use several lanes per row + a shuffle tree: tolerance, not bit-exactness
+    assert np.all(np.abs(y - orc.spmv(ai, aj, aa, x)) <= 1e-12 * scale)
+    assert np.all(np.abs(y - orc.spmv_inode(ai, aj, aa, x)) <= 1e-12 * scale)
+    B = P.Mat.from_bsr(3, bi, bj, ba)
+    L.MatMult(B.h, vx.h, vy.h)
+    yb = vy.array()
+    assert np.all(np.abs(yb - orc.spmv_bsr(3, bi, bj, ba, x)) <= 1e-12 * scale)
+    assert np.all(np.abs(yb - y) <= 1e-12 * scale)
+
+
 def solve(P, ai, aj, aa, b, ksp, pc, x0=None, opts="", **tol):
     L = P.lib()
     A = P.Mat.from_csr(ai, aj, aa)

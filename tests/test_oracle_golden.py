@@ -129,3 +129,18 @@ def test_tutorial_ex9_gmres_and_bcgs_jacobi():
         x, h, its, reason = orc.ksp_solve(ai, aj, aa, b, ksp="bcgs", pc="jacobi")
         pb.check_monitor(h, gold)
         assert np.linalg.norm(x - u) < 1e-4   # CheckError tolerance of the example
+
+
+def test_inode_detection_and_variant():
+    """a 3-dof operator stored as AIJ makes the reference switch to MatMult_SeqAIJ_Inode
+    ('found m/3 nodes, limit used is 5'); the scalar 7-point operator does not ('not using I-node routines')."""
+    (ai, aj, aa), _ = pb.elasticity_like(4, 3, 3)
+    m = ai.size - 1
+    nc, ns = orc.check_inode(ai, aj)
+    assert nc == m // 3 and np.all(ns == 3)
+    pi_, pj, pa = orc.gen_p7(8, 8, 8)
+    assert orc.check_inode(pi_, pj)[0] == 0
+    x = np.random.default_rng(1).standard_normal(m)
+    y0, y1 = orc.spmv(ai, aj, aa, x), orc.spmv_inode(ai, aj, aa, x)
+    scale = np.zeros(m); np.add.at(scale, np.repeat(np.arange(m), np.diff(ai)), np.abs(aa * x[aj]))
+    assert np.all(np.abs(y0 - y1) <= 1e-13 * scale) and not np.array_equal(y0, y1)   # same product, different rounding
