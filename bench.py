@@ -143,6 +143,24 @@ def main():
         "setup_s": round(setup_s, 2),
     }
 
+    # HBM traffic of the same kernel from the committed rocprofv3 PMC passes of this command (separate
+    # FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE x2 on gfx950, calibration in profiles/r01_fetch_calibration.md)
+    try:
+        import csv
+        fs = ws = None
+        with open(os.path.join(ROOT, "profiles", "r01_bench_pmc_summary.csv")) as f:
+            for row in csv.DictReader(f):
+                if "spmv_csr_rowblock_kernel<false, false, true>" in row["kernel"]:
+                    if row["counter"] == "FETCH_SIZE":
+                        fs = float(row["avg_value_KB"])
+                    elif row["counter"] == "WRITE_SIZE":
+                        ws = float(row["avg_value_KB"])
+        if fs is not None and ws is not None and n == 256 and world == 1:
+            out["roofline"]["traffic"] = int((2.0 * fs + ws) * 1024)
+            out["roofline"]["traffic_source"] = "profiles/r01_bench_pmc_summary.csv (rocprofv3 --pmc, separate passes; bytes per launch)"
+    except Exception:
+        pass
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import orc
         # the same workload, bounded sample: the first cpu_its iterations of the same solve on one host core

@@ -143,7 +143,11 @@ int mi355x_csr_get_diagonal(mi355x_handle_t h, int m, const int *ai, const int *
 /* ---- BCSR SpMV (MatMult_SeqBAIJ_3/_4/_N) ------------------------------- */
 /* src/mat/impls/baij/seq/baij2.c:331 (bs=3), :387 (bs=4), :981 (N); blocks column-major */
 int mi355x_spmv_bsr(mi355x_handle_t h, int mbs, int bs, const int *ai, const int *aj,
-                    const double *aa, const double *x, double *y);
+                    const double *aa, const double *x, double *y);          /* one wavefront per block row, no analysis */
+/* row-block streaming variant: `plan` = mi355x_spmv_plan_create over the block-row pointer multiplied by bs*bs
+ * (it then partitions by VALUES); aligned 16-byte loads need aa 16-byte aligned */
+int mi355x_spmv_bsr_planned(mi355x_handle_t h, mi355x_spmv_plan_t plan, int bs, const int *ai, const int *aj,
+                            const double *aa, const double *x, double *y);
 
 /* ---- halo pack / unpack (VecScatter) ---------------------------------- */
 /* Pack_1    src/vec/vec/utils/vpscat.c:493   buf[k] = x[idx[k]] */

@@ -21,8 +21,10 @@ __global__ __launch_bounds__(MI355X_BLOCK) void unpack_kernel(size_t n, const in
 
 // One wavefront per block row.  The block row's values (nb*bs*bs doubles, blocks stored
 // column-major as in baij.h) are read as one contiguous, fully coalesced stream; element e
-// belongs to block e/(bs*bs), column (e%(bs*bs))/bs, row e%bs.  Each lane keeps bs
-// accumulators; a shuffle tree finishes the bs row sums.
+// belongs to block e/(bs*bs), column (e%(bs*bs))/bs, row e%bs.  Each lane requests its first
+// four elements (value, block column, x entry) before consuming any, so a wavefront keeps
+// 2 KB of values in flight instead of 512 B; bs accumulators per lane; a shuffle tree
+// finishes the bs row sums.
 template <int BS>
 __global__ __launch_bounds__(MI355X_BLOCK) void bsr_wave_kernel(int mbs, const int *__restrict__ ai,
                                                                const int *__restrict__ aj,
@@ -32,12 +34,39 @@ __global__ __launch_bounds__(MI355X_BLOCK) void bsr_wave_kernel(int mbs, const i
   const int brow = (blockIdx.x * MI355X_BLOCK + threadIdx.x) / MI355X_WAVE;
   if (brow >= mbs) return;
   constexpr int BS2 = BS * BS;
-  const long b0 = ai[brow], b1 = ai[brow + 1];
-  const long e0 = b0 * BS2, e1 = b1 * BS2;
+  constexpr int UNR = 4;
+  const long e0 = (long)ai[brow] * BS2, e1 = (long)ai[brow + 1] * BS2;
   double acc[BS];
 #pragma unroll
   for (int r = 0; r < BS; ++r) acc[r] = 0.0;
-  for (long e = e0 + lane; e < e1; e += MI355X_WAVE) {
+
+  double av[UNR], xv[UNR];
+  int bc[UNR], qq[UNR];
+  bool ok[UNR];
+#pragma unroll
+  for (int t = 0; t < UNR; ++t) {
+    const long e = e0 + lane + (long)t * MI355X_WAVE;
+    ok[t] = e < e1;
+    if (ok[t]) {
+      const long blk = e / BS2;
+      qq[t] = (int)(e - blk * BS2);
+      av[t] = __builtin_nontemporal_load(aa + e);
+      bc[t] = aj[blk];
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < UNR; ++t)
+    if (ok[t]) xv[t] = x[(long)bc[t] * BS + qq[t] / BS];
+#pragma unroll
+  for (int t = 0; t < UNR; ++t) {
+    if (ok[t]) {
+      const int r = qq[t] % BS;
+      const double p = av[t] * xv[t];
+#pragma unroll
+      for (int rr = 0; rr < BS; ++rr) acc[rr] += (rr == r) ? p : 0.0;
+    }
+  }
+  for (long e = e0 + lane + (long)UNR * MI355X_WAVE; e < e1; e += MI355X_WAVE) {   // block rows beyond 256/bs^2 blocks
     const long blk = e / BS2;
     const int q = (int)(e - blk * BS2);
     const int c = q / BS;

@@ -178,6 +178,98 @@ __global__ __launch_bounds__(SPMV_THREADS) void spmv_csr_rowblock_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// BCSR (MatMult_SeqBAIJ_3/_4/_N, reference src/mat/impls/baij/seq/baij2.c:331-436,981) with the same
+// row-block streaming structure: the plan is built over the block-row pointer scaled by bs*bs (so it
+// counts values), a workgroup streams <= 2046 values of consecutive block rows with 16-byte loads,
+// looks the block column up once per value (e / bs^2), multiplies by x[col*bs + c] and parks the
+// products in LDS; point row (br, r) then owns the LDS entries s + bs*j + r, j < nblocks*bs
+// (blocks are column-major, baij.h:13-30) and is summed by 1..64 lanes + a shuffle tree.
+template <int BS>
+__global__ __launch_bounds__(SPMV_THREADS) void bsr_rowblock_kernel(const int2 *__restrict__ rowblk, int nblocks,
+                                                                   const int *__restrict__ ai, const int *__restrict__ aj,
+                                                                   const double *__restrict__ aa,
+                                                                   const double *__restrict__ x, double *__restrict__ y) {
+  __shared__ double prod[SPMV_BLOCK_NNZ];
+  constexpr int BS2 = BS * BS;
+  const int lb = blockIdx.x;
+  if (lb >= nblocks) return;
+  const int2 b0 = rowblk[lb];
+  const int2 b1 = rowblk[lb + 1];
+  const int r0 = b0.x, r1 = b1.x, k0 = b0.y, k1 = b1.y;   // block rows [r0,r1), values [k0,k1)
+  const int tid = threadIdx.x;
+  const int nv = (r1 - r0) * BS;                           // point rows of this workgroup
+  if (k1 - k0 > SPMV_BLOCK_CAP) {
+    // one block row wider than the LDS stage: strided partial sums per point row, tree at the end
+    double acc[BS];
+#pragma unroll
+    for (int r = 0; r < BS; ++r) acc[r] = 0.0;
+    for (int e = k0 + tid; e < k1; e += SPMV_THREADS) {
+      const int blk = e / BS2, q = e - blk * BS2, c = q / BS, r = q - c * BS;
+      const double p = SPMV_LOAD(aa + e) * x[(long)aj[blk] * BS + c];
+#pragma unroll
+      for (int rr = 0; rr < BS; ++rr) acc[rr] += (rr == r) ? p : 0.0;
+    }
+    __shared__ double part[SPMV_THREADS / MI355X_WAVE][BS];
+#pragma unroll
+    for (int r = 0; r < BS; ++r) { double v = wave_sum(acc[r]); if ((tid & 63) == 0) part[tid / 64][r] = v; }
+    __syncthreads();
+    if (tid < BS) { double t = part[0][tid]; for (int w = 1; w < SPMV_THREADS / MI355X_WAVE; ++w) t += part[w][tid]; y[(long)r0 * BS + tid] = t; }
+    return;
+  }
+  int tpr = 1;
+  while (tpr < MI355X_WAVE && nv * (tpr * 2) <= SPMV_THREADS) tpr *= 2;
+  // extents of this lane's point row, requested before the stream
+  const int v = tid / tpr, sub = tid & (tpr - 1);
+  int s = 0, cnt = 0, rr_ = 0, br = 0;
+  if (v < nv) {
+    br = r0 + v / BS;
+    rr_ = v - (v / BS) * BS;
+    const int a0 = ai[br], a1 = ai[br + 1];
+    s = a0 * BS2 - k0;
+    cnt = (a1 - a0) * BS;
+  }
+  constexpr int PAIRS = SPMV_BLOCK_NNZ / (2 * SPMV_THREADS);
+  const int ka = k0 & ~1;
+  v2d vv[PAIRS];
+  int c0[PAIRS], c1[PAIRS];
+  bool full[PAIRS];
+#pragma unroll
+  for (int p = 0; p < PAIRS; ++p) {
+    const int k = ka + 2 * tid + p * 2 * SPMV_THREADS;
+    full[p] = (k >= k0) && (k + 1 < k1);
+    if (full[p]) {
+      vv[p] = SPMV_LOAD(reinterpret_cast<const v2d *>(aa + k));
+      const int blk0 = k / BS2, blk1 = (k + 1) / BS2;
+      c0[p] = aj[blk0] * BS + (k - blk0 * BS2) / BS;
+      c1[p] = aj[blk1] * BS + (k + 1 - blk1 * BS2) / BS;
+    }
+  }
+  double xa[PAIRS], xb[PAIRS];
+#pragma unroll
+  for (int p = 0; p < PAIRS; ++p)
+    if (full[p]) { xa[p] = x[c0[p]]; xb[p] = x[c1[p]]; }
+#pragma unroll
+  for (int p = 0; p < PAIRS; ++p) {
+    const int k = ka + 2 * tid + p * 2 * SPMV_THREADS;
+    if (full[p]) {
+      prod[k - k0] = vv[p].x * xa[p];
+      prod[k - k0 + 1] = vv[p].y * xb[p];
+    } else {
+      for (int e = k; e <= k + 1; ++e)
+        if (e >= k0 && e < k1) {
+          const int blk = e / BS2;
+          prod[e - k0] = SPMV_LOAD(aa + e) * x[(long)aj[blk] * BS + (e - blk * BS2) / BS];
+        }
+    }
+  }
+  __syncthreads();
+  double sum = 0.0;
+  for (int j = sub; j < cnt; j += tpr) sum += prod[s + BS * j + rr_];
+  for (int off = tpr >> 1; off > 0; off >>= 1) sum += __shfl_down(sum, off, MI355X_WAVE);
+  if (v < nv && sub == 0) y[(long)br * BS + rr_] = sum;
+}
+
 __global__ __launch_bounds__(MI355X_BLOCK) void csr_diag_kernel(int m, const int *__restrict__ ai,
                                                                const int *__restrict__ aj,
                                                                const double *__restrict__ aa, double *d) {
@@ -271,6 +363,26 @@ int mi355x_spmv_csr(mi355x_handle_t h, mi355x_spmv_plan_t plan, const int *ai, c
 int mi355x_spmv_csr_add(mi355x_handle_t h, mi355x_spmv_plan_t plan, const int *ai, const int *aj, const double *aa,
                         const double *x, const double *y, double *z) {
   return launch_spmv<true>(h, plan, ai, aj, aa, x, y, z);
+}
+
+int mi355x_spmv_bsr_planned(mi355x_handle_t h, mi355x_spmv_plan_t p, int bs, const int *ai, const int *aj,
+                            const double *aa, const double *x, double *y) {
+  if (p->nblocks == 0) return 0;
+  dim3 grid(p->nblocks), block(SPMV_THREADS);
+#define BSR_GO(B) hipLaunchKernelGGL((bsr_rowblock_kernel<B>), grid, block, 0, h->stream, p->d_rowblk, p->nblocks, ai, aj, aa, x, y)
+  switch (bs) {
+    case 2: BSR_GO(2); break;
+    case 3: BSR_GO(3); break;
+    case 4: BSR_GO(4); break;
+    case 5: BSR_GO(5); break;
+    case 6: BSR_GO(6); break;
+    case 7: BSR_GO(7); break;
+    case 8: BSR_GO(8); break;
+    default: return (int)hipErrorInvalidValue;
+  }
+#undef BSR_GO
+  MI355X_LAUNCH_CHECK();
+  return 0;
 }
 
 int mi355x_csr_get_diagonal(mi355x_handle_t h, int m, const int *ai, const int *aj, const double *aa, double *d) {

@@ -153,6 +153,14 @@ PetscErrorCode MatSeqAIJHIPUpload(Mat A) {
     CHKHIP(mi355x_memcpy_h2d(dc->h, d->d_i, ip, sizeof(PetscInt) * (size_t)(nrows + 1)));
     CHKHIP(mi355x_memcpy_h2d(dc->h, d->d_j, a->j, sizeof(PetscInt) * (size_t)a->nz));
     if (a->bs <= 1) CHKHIP(mi355x_spmv_plan_create(dc->h, nrows, ip, use_cprow ? ridx : NULL, &d->plan));
+    else {   /* BAIJ: the plan partitions the VALUE stream, i.e. the block-row pointer scaled by bs*bs */
+      PetscInt *sc, bs2 = a->bs * a->bs;
+      if ((double)a->nz * bs2 > 2147483000.0) SETERRQ(A->comm, PETSC_ERR_ARG_OUTOFRANGE, "BAIJ matrix too large for 32-bit value offsets");
+      ierr = PetscMalloc(sizeof(PetscInt) * (size_t)(nrows + 1), &sc);CHKERRQ(ierr);
+      for (PetscInt r = 0; r <= nrows; r++) sc[r] = a->i[r] * bs2;
+      CHKHIP(mi355x_spmv_plan_create(dc->h, nrows, sc, NULL, &d->plan));
+      free(sc);
+    }
     CHKHIP(mi355x_handle_synchronize(dc->h));
     free(ci); free(ridx);
     d->cprow_n = -2 - a->nz;   /* remembers the pattern size this mirror was built for */
@@ -238,7 +246,7 @@ static PetscErrorCode MatMult_SeqAIJHIP(Mat A, Vec xx, Vec yy) {   /* MatMult_Se
   ierr = VecHIPGetRead(xx, &x);CHKERRQ(ierr);
   ierr = VecHIPGetWrite(yy, &y);CHKERRQ(ierr);
   ierr = MatTimingBegin(A, dc->h);CHKERRQ(ierr);
-  if (a->bs > 1) CHKHIP(mi355x_spmv_bsr(dc->h, a->m, a->bs, d->d_i, d->d_j, d->d_a, x, y));
+  if (a->bs > 1) CHKHIP(mi355x_spmv_bsr_planned(dc->h, d->plan, a->bs, d->d_i, d->d_j, d->d_a, x, y));
   else {
     if (d->cprow) CHKHIP(mi355x_vec_set(dc->h, (size_t)a->m, 0.0, y));   /* rows without entries */
     CHKHIP(mi355x_spmv_csr(dc->h, d->plan, d->d_i, d->d_j, d->d_a, x, y));

@@ -306,6 +306,25 @@ def test_spmv_bsr(dev, bs):
     got = dev.get(dy, mbs * bs)
     ref = orc.spmv_bsr(bs, ai, aj, aa, x)
     assert np.allclose(got, ref, rtol=0, atol=1e-12 * 30 * bs * 10)
+    if bs > 1:   # row-block streaming variant, plan over the value stream
+        sc = (ai.astype(np.int64) * bs * bs).astype(np.int32)
+        plan = make_plan(dev, sc)
+        dev.chk(dev.k.mi355x_vec_set(dev.h, mbs * bs, 7.0, dy))
+        dev.chk(dev.k.mi355x_spmv_bsr_planned(dev.h, plan, bs, dai, daj, daa, dx, dy))
+        assert np.allclose(dev.get(dy, mbs * bs), ref, rtol=0, atol=1e-12 * 30 * bs * 10)
+
+
+def test_spmv_bsr_wide_block_row(dev):
+    """a block row wider than the LDS stage (> 2046 values) takes the whole-workgroup path"""
+    bs, mbs, nbs = 3, 40, 600
+    ai, aj, _ = random_csr(mbs, nbs, lambda rng, m: np.where(np.arange(m) % 7 == 3, 300, rng.integers(0, 20, m)), 123)
+    aa = rnd(aj.size * bs * bs, 124)
+    x = rnd(nbs * bs, 125)
+    dai, daj, daa = upload_csr(dev, ai, aj, aa)
+    dx = dev.put(x); dy = dev.alloc(8 * mbs * bs)
+    plan = make_plan(dev, (ai.astype(np.int64) * bs * bs).astype(np.int32))
+    dev.chk(dev.k.mi355x_spmv_bsr_planned(dev.h, plan, bs, dai, daj, daa, dx, dy))
+    assert np.allclose(dev.get(dy, mbs * bs), orc.spmv_bsr(bs, ai, aj, aa, x), rtol=0, atol=1e-10)
 
 
 def test_pack_unpack(dev):
