@@ -117,6 +117,11 @@ typedef int (*PetscCommAllgatherFn)(void *ctx, const void *sendbuf, int nbytes, 
 typedef int (*PetscCommAllreduceFn)(void *ctx, void *buf, int count, int is_double, int op /*0 sum,1 max,2 min*/);
 typedef int (*PetscCommBarrierFn)(void *ctx);
 PetscErrorCode PetscCommCreate(int rank, int size, void *ctx, PetscCommAllgatherFn, PetscCommAllreduceFn, PetscCommBarrierFn, MPI_Comm *comm);
+/* optional host-staged neighbour exchange (used only when no RCCL communicator is attached, e.g. several ranks
+ * sharing one GPU): post every receive and send of one halo exchange, return when all have completed */
+typedef int (*PetscCommExchangeFn)(void *ctx, int nsend, const int *speers, void *const *sbufs, const int *sbytes,
+                                   int nrecv, const int *rpeers, void *const *rbufs, const int *rbytes);
+PetscErrorCode PetscCommSetExchange(MPI_Comm comm, PetscCommExchangeFn fn);
 PetscErrorCode PetscCommSetWorld(MPI_Comm comm);
 /* attach the RCCL communicator (mi355x_comm.h) used for device-side halo exchange and reductions */
 PetscErrorCode PetscCommSetDeviceComm(MPI_Comm comm, void *mi355x_comm);

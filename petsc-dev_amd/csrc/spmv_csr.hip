@@ -28,9 +28,18 @@
 #ifndef SPMV_REMAP
 #define SPMV_REMAP 0         // 1 = each XCD walks a contiguous eighth of the row blocks (measured slower)
 #endif
-#define SPMV_BLOCK_NNZ (8 * SPMV_THREADS)     // LDS stage (doubles): 4 pairs per lane
+#ifndef SPMV_CH
+#define SPMV_CH 32
+#endif
+#ifndef SPMV_RPT
+#define SPMV_RPT 1           // rows per lane in the one-lane-per-row summation (block = RPT*THREADS rows)
+#endif
+#ifndef SPMV_MINWAVES
+#define SPMV_MINWAVES 1      // __launch_bounds__ second argument (waves per SIMD the register allocator must allow)
+#endif
+#define SPMV_BLOCK_NNZ (8 * SPMV_THREADS * SPMV_RPT)   // LDS stage (doubles): 4*RPT pairs per lane
 #define SPMV_BLOCK_CAP (SPMV_BLOCK_NNZ - 2)   // nonzeros per row block: any alignment of the first pair still fits
-#define SPMV_BLOCK_ROWS SPMV_THREADS
+#define SPMV_BLOCK_ROWS (SPMV_THREADS * SPMV_RPT)
 #if SPMV_NT
 #define SPMV_LOAD(p) __builtin_nontemporal_load(p)
 #else
@@ -51,7 +60,7 @@ struct mi355x_spmv_plan_s {
 };
 
 template <bool ADD, bool CPROW, bool VEC>
-__global__ __launch_bounds__(SPMV_THREADS) void spmv_csr_rowblock_kernel(
+__global__ __launch_bounds__(SPMV_THREADS, SPMV_MINWAVES) void spmv_csr_rowblock_kernel(
     const int2 *__restrict__ rowblk, int nblocks, int chunk, const int *__restrict__ ai, const int *__restrict__ aj,
     const double *__restrict__ aa, const double *__restrict__ x, const double *yin, double *yout,
     const int *__restrict__ rows) {
@@ -59,11 +68,18 @@ __global__ __launch_bounds__(SPMV_THREADS) void spmv_csr_rowblock_kernel(
   __shared__ double wsum[SPMV_THREADS / MI355X_WAVE];
 
   // XCD-aware remap: workgroups b, b+8, b+16.. share an XCD; give them consecutive row blocks
-#if SPMV_REMAP
+#if SPMV_REMAP == 1
   const int xcd = blockIdx.x % MI355X_NXCD;
   const int slot = blockIdx.x / MI355X_NXCD;
   const int lb = xcd * chunk + slot;
   if (slot >= chunk || lb >= nblocks) return;
+#elif SPMV_REMAP == 2
+  // interleaved: XCD x owns runs of SPMV_CH consecutive row blocks, runs dealt round-robin over the XCDs, so all
+  // XCDs stream one window of 8*SPMV_CH blocks while each re-uses its own x lines
+  const int xcd = blockIdx.x % MI355X_NXCD;
+  const int slot = blockIdx.x / MI355X_NXCD;
+  const int lb = ((slot / SPMV_CH) * MI355X_NXCD + xcd) * SPMV_CH + (slot % SPMV_CH);
+  if (lb >= nblocks) return;
 #else
   const int lb = blockIdx.x;
   if (lb >= nblocks) return;
@@ -102,16 +118,22 @@ __global__ __launch_bounds__(SPMV_THREADS) void spmv_csr_rowblock_kernel(
   // (the stencil case) get one lane per row and the reference's summation order
   int tpr = 1;
   while (tpr < MI355X_WAVE && nrows * (tpr * 2) <= SPMV_THREADS) tpr *= 2;
-  if (nnz <= 16 * nrows) tpr = 1;
+  if (nnz <= 16 * nrows || nrows > SPMV_THREADS) tpr = 1;
 
   // row extents for the summation phase are requested now, so their latency overlaps the stream below
-  int rs = 0, re = 0, orow = 0;
-  double ysum = 0.0;
-  if (tpr == 1 && tid < nrows) {
-    rs = ai[r0 + tid];
-    re = ai[r0 + tid + 1];
-    orow = CPROW ? rows[r0 + tid] : r0 + tid;
-    if (ADD) ysum = yin[orow];
+  int rs[SPMV_RPT], re[SPMV_RPT], orow[SPMV_RPT];
+  double ysum[SPMV_RPT];
+#pragma unroll
+  for (int q = 0; q < SPMV_RPT; ++q) {
+    const int r = tid + q * SPMV_THREADS;
+    rs[q] = re[q] = orow[q] = 0;
+    ysum[q] = 0.0;
+    if (tpr == 1 && r < nrows) {
+      rs[q] = ai[r0 + r];
+      re[q] = ai[r0 + r + 1];
+      orow[q] = CPROW ? rows[r0 + r] : r0 + r;
+      if (ADD) ysum[q] = yin[orow[q]];
+    }
   }
 
   // ---- stream the block's nonzeros: product -> LDS -----------------------
@@ -156,10 +178,13 @@ __global__ __launch_bounds__(SPMV_THREADS) void spmv_csr_rowblock_kernel(
 
   // ---- per-row sums out of LDS -------------------------------------------
   if (tpr == 1) {
-    if (tid < nrows) {
-      double sum = ADD ? ysum : 0.0;
-      for (int k = rs - k0; k < re - k0; ++k) sum += prod[k];
-      yout[orow] = sum;
+#pragma unroll
+    for (int q = 0; q < SPMV_RPT; ++q) {
+      if (tid + q * SPMV_THREADS < nrows) {
+        double sum = ADD ? ysum[q] : 0.0;
+        for (int k = rs[q] - k0; k < re[q] - k0; ++k) sum += prod[k];
+        yout[orow[q]] = sum;
+      }
     }
   } else {
     const int r = tid / tpr;
@@ -288,7 +313,12 @@ static int launch_spmv(mi355x_handle_t h, mi355x_spmv_plan_t p, const int *ai, c
   if (p->nblocks == 0) return 0;
   const bool vec = mi355x_aligned16(aa) && ((((uintptr_t)aj) & 7u) == 0);
   const bool cprow = p->d_rows != nullptr;
+  #if SPMV_REMAP == 2
+  const int per = MI355X_NXCD * SPMV_CH;
+  dim3 grid(((p->nblocks + per - 1) / per) * per), block(SPMV_THREADS);
+#else
   dim3 grid(p->chunk * MI355X_NXCD), block(SPMV_THREADS);
+#endif
 #define SPMV_GO(C, V)                                                                                               \
   hipLaunchKernelGGL((spmv_csr_rowblock_kernel<ADD, C, V>), grid, block, 0, h->stream, p->d_rowblk, p->nblocks,    \
                      p->chunk, ai, aj, aa, x, yin, yout, p->d_rows)

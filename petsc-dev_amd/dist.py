@@ -14,12 +14,15 @@ from . import petsc as P
 _AG = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p)
 _AR = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int)
 _BAR = C.CFUNCTYPE(C.c_int, C.c_void_p)
+_EXC = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.POINTER(C.c_int),
+                   C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.POINTER(C.c_int))
 _keep = []
 
 
-def make_comm(rank, size, allgather_bytes, allreduce_array, barrier):
-    """Build a PetscComm from three Python callables:
-       allgather_bytes(bytes) -> list of `size` bytes objects; allreduce_array(np.ndarray, op) -> np.ndarray; barrier()."""
+def make_comm(rank, size, allgather_bytes, allreduce_array, barrier, exchange=None):
+    """Build a PetscComm from Python callables:
+       allgather_bytes(bytes) -> list of `size` bytes objects; allreduce_array(np.ndarray, op) -> np.ndarray; barrier();
+       exchange(sends=[(peer, bytes)], recvs=[(peer, nbytes)]) -> list of bytes, one per recv (host-staged halo, optional)."""
     L = P.lib()
 
     def ag(ctx, sendbuf, nbytes, recvbuf):
@@ -46,10 +49,24 @@ def make_comm(rank, size, allgather_bytes, allreduce_array, barrier):
         barrier()
         return 0
 
-    cbs = (_AG(ag), _AR(ar), _BAR(bar))
+    def exc(ctx, ns, speers, sbufs, sbytes, nr, rpeers, rbufs, rbytes):
+        try:
+            sends = [(speers[i], C.string_at(sbufs[i], sbytes[i])) for i in range(ns)]
+            recvs = [(rpeers[i], rbytes[i]) for i in range(nr)]
+            got = exchange(sends, recvs)
+            for i in range(nr):
+                C.memmove(rbufs[i], got[i], rbytes[i])
+            return 0
+        except Exception as e:  # pragma: no cover
+            print("exchange callback failed:", e, flush=True)
+            return 1
+
+    cbs = (_AG(ag), _AR(ar), _BAR(bar), _EXC(exc))
     _keep.append(cbs)
     comm = C.c_void_p()
     L.PetscCommCreate(rank, size, None, C.cast(cbs[0], C.c_void_p), C.cast(cbs[1], C.c_void_p), C.cast(cbs[2], C.c_void_p), C.byref(comm))
+    if exchange is not None:
+        L.PetscCommSetExchange(comm, C.cast(cbs[3], C.c_void_p))
     return comm
 
 
@@ -71,7 +88,17 @@ def torch_comm(device_comm=True):
         dist.all_reduce(t, op=ops[op])
         return t.numpy().astype(a.dtype)
 
-    comm = make_comm(rank, size, allgather_bytes, allreduce_array, dist.barrier)
+    def exchange(sends, recvs):
+        bufs = [torch.empty(nb, dtype=torch.uint8) for _, nb in recvs]
+        ops = [dist.P2POp(dist.irecv, b, peer) for b, (peer, _) in zip(bufs, recvs)]
+        keep = [torch.frombuffer(bytearray(data), dtype=torch.uint8) for _, data in sends]
+        ops += [dist.P2POp(dist.isend, t, peer) for t, (peer, _) in zip(keep, sends)]
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        return [bytes(b.numpy().tobytes()) for b in bufs]
+
+    comm = make_comm(rank, size, allgather_bytes, allreduce_array, dist.barrier, exchange=exchange)
     L = P.lib()
     L.PetscCommSetWorld(comm)
     if device_comm and size > 1:

@@ -37,6 +37,7 @@ struct _p_PetscComm {
   PetscCommAllgatherFn allgather;
   PetscCommAllreduceFn allreduce;
   PetscCommBarrierFn barrier;
+  PetscCommExchangeFn exchange;
   mi355x_comm_t dcomm;     /* RCCL communicator for device buffers */
 };
 
@@ -149,7 +150,7 @@ struct _p_VecScatter {
   mi355x_event_t ev_packed, ev_done;
   int device_ready;
   /* every rank's request list (kept from set-up) for the host-staged transport */
-  PetscInt *all_garray, *ecs, *xrange, maxec, ec, nlocal_x, max_nlocal_x, rstart_x;
+  PetscScalar *h_send, *h_recv;   /* host staging buffers of the host-staged transport */
 };
 PetscErrorCode VecScatterCreate_PtoS_MPIAIJ(MPI_Comm comm, PetscLayout *xmap, PetscInt ec, const PetscInt *garray, VecScatter *ctx);
 

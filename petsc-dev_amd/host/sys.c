@@ -35,7 +35,7 @@ PetscErrorCode PetscGetFlops(PetscLogDouble *f) { *f = total_flops; return 0; }
 const char *PetscHIPMI355XVersion(void) { return "petsc-hipmi355x 0.1 (gfx950)"; }
 
 /* ---------------------------------------------------------------- communicator */
-static struct _p_PetscComm comm_self = {0, 1, NULL, NULL, NULL, NULL, NULL};
+static struct _p_PetscComm comm_self = {0, 1, NULL, NULL, NULL, NULL, NULL, NULL};
 MPI_Comm PETSC_COMM_SELF = &comm_self;
 MPI_Comm PETSC_COMM_WORLD = &comm_self;
 
@@ -45,10 +45,11 @@ PetscErrorCode PetscCommCreate(int rank, int size, void *ctx, PetscCommAllgather
   struct _p_PetscComm *c;
   if (size > 1 && (!ag || !ar)) SETERRQ(0, PETSC_ERR_ARG_NULL, "a communicator of size %d needs allgather and allreduce callbacks", size);
   ierr = PetscMalloc(sizeof(*c), &c);CHKERRQ(ierr);
-  c->rank = rank; c->size = size; c->ctx = ctx; c->allgather = ag; c->allreduce = ar; c->barrier = bar; c->dcomm = NULL;
+  c->rank = rank; c->size = size; c->ctx = ctx; c->allgather = ag; c->allreduce = ar; c->barrier = bar; c->exchange = NULL; c->dcomm = NULL;
   *comm = c;
   return 0;
 }
+PetscErrorCode PetscCommSetExchange(MPI_Comm comm, PetscCommExchangeFn fn) { comm->exchange = fn; return 0; }
 PetscErrorCode PetscCommSetWorld(MPI_Comm comm) { PETSC_COMM_WORLD = comm ? comm : &comm_self; return 0; }
 PetscErrorCode PetscCommSetDeviceComm(MPI_Comm comm, void *dcomm) { comm->dcomm = (mi355x_comm_t)dcomm; return 0; }
 PetscErrorCode PetscCommDestroy(MPI_Comm *comm) {

@@ -78,11 +78,7 @@ PetscErrorCode VecScatterCreate_PtoS_MPIAIJ(MPI_Comm comm, PetscLayout *xmap, Pe
       if (gq[i] >= xmap->range[rank] && gq[i] < xmap->range[rank + 1]) { to->indices[cnt++] = gq[i] - xmap->range[rank]; have = PETSC_TRUE; }
     if (have) { to->procs[to->n++] = q; to->starts[to->n] = cnt; }
   }
-  ctx->all_garray = all; ctx->ecs = ecs; ctx->maxec = maxec; ctx->ec = ec;
-  ctx->nlocal_x = xmap->n; ctx->rstart_x = xmap->rstart; ctx->max_nlocal_x = 0;
-  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)(size + 1), &ctx->xrange);CHKERRQ(ierr);
-  memcpy(ctx->xrange, xmap->range, sizeof(PetscInt) * (size_t)(size + 1));
-  for (int p = 0; p < size; p++) ctx->max_nlocal_x = PetscMax(ctx->max_nlocal_x, xmap->range[p + 1] - xmap->range[p]);
+  free(all); free(ecs);
   /* contiguity (the to->contiq / from->contiq special case, vpscat.c:1951-1960), here per side */
   from->contiq = PETSC_TRUE;
   for (PetscInt i = 0; i < from->n; i++) if (!is_contiguous(from->indices + from->starts[i], from->starts[i + 1] - from->starts[i])) from->contiq = PETSC_FALSE;
@@ -125,53 +121,42 @@ static PetscErrorCode scatter_device_setup(VecScatter ctx, PetscDeviceCtx *dc) {
   return 0;
 }
 
-/* Host-staged transport, used only when the communicator has no RCCL communicator attached (several ranks
- * sharing one GPU in the rehearsal tests): device -> host, one all-gather, host -> device, the arrangement
- * of the reference's CUSP path (vpscat.h:56-61,226-230).  Same results as the RCCL path, including the
- * order of the reverse-mode additions (owner by owner in rank order, request order within an owner). */
-static PetscErrorCode staged_forward(VecScatter ctx, PetscDeviceCtx *dc, const PetscScalar *dx, PetscScalar *dy) {
+/* One neighbour exchange: receives into rdst[i], sends from ssrc[i] (device pointers).  RCCL: one grouped
+ * ncclRecv/ncclSend on the halo stream.  Without an RCCL communicator (several ranks sharing one GPU in the
+ * rehearsal tests) the same buffers travel device -> host -> launcher-supplied exchange -> host -> device, the
+ * arrangement of the reference's own CUSP path (vpscat.h:56-61,226-230); everything around the transport --
+ * pack, contiguity shortcuts, offsets, unpack order -- is shared. */
+static PetscErrorCode neighbour_exchange(VecScatter ctx, PetscDeviceCtx *dc, PetscInt nr, const PetscInt *rprocs, PetscScalar *const *rdst, const PetscInt *rcnt,
+                                         PetscInt ns, const PetscInt *sprocs, const PetscScalar *const *ssrc, const PetscInt *scnt) {
   PetscErrorCode ierr;
   MPI_Comm comm = ctx->comm;
-  size_t mx = (size_t)ctx->max_nlocal_x;
-  PetscScalar *mine, *all, *lv;
-  ierr = PetscMalloc(sizeof(PetscScalar) * PetscMax(mx, 1), &mine);CHKERRQ(ierr);
-  ierr = PetscMalloc(sizeof(PetscScalar) * PetscMax(mx, 1) * (size_t)comm->size, &all);CHKERRQ(ierr);
-  ierr = PetscMalloc(sizeof(PetscScalar) * (size_t)PetscMax(ctx->ec, 1), &lv);CHKERRQ(ierr);
-  memset(mine, 0, sizeof(PetscScalar) * PetscMax(mx, 1));
-  CHKHIP(mi355x_memcpy_d2h(dc->h, mine, dx, sizeof(PetscScalar) * (size_t)ctx->nlocal_x));
-  CHKHIP(mi355x_handle_synchronize(dc->h));
-  if (comm->allgather(comm->ctx, mine, (int)(sizeof(PetscScalar) * mx), all)) SETERRQ(comm, PETSC_ERR_LIB, "allgather failed");
-  const PetscInt *g = ctx->all_garray + (size_t)comm->rank * (size_t)ctx->maxec;
-  for (PetscInt i = 0; i < ctx->ec; i++) {
-    int p = owner_of(comm->size, ctx->xrange, g[i]);
-    lv[i] = all[(size_t)p * mx + (size_t)(g[i] - ctx->xrange[p])];
+  if (comm->dcomm) {
+    CHKHIP(mi355x_comm_group_start());
+    for (PetscInt i = 0; i < nr; i++) CHKHIP(mi355x_comm_recv(comm->dcomm, dc->hcomm, rdst[i], (size_t)rcnt[i], rprocs[i]));
+    for (PetscInt i = 0; i < ns; i++) CHKHIP(mi355x_comm_send(comm->dcomm, dc->hcomm, ssrc[i], (size_t)scnt[i], sprocs[i]));
+    CHKHIP(mi355x_comm_group_end());
+    return 0;
   }
-  CHKHIP(mi355x_memcpy_h2d(dc->h, dy, lv, sizeof(PetscScalar) * (size_t)ctx->ec));
-  CHKHIP(mi355x_handle_synchronize(dc->h));
-  free(mine); free(all); free(lv);
-  return 0;
-}
-static PetscErrorCode staged_reverse(VecScatter ctx, PetscDeviceCtx *dc, const PetscScalar *dx, PetscScalar *dy) {
-  PetscErrorCode ierr;
-  MPI_Comm comm = ctx->comm;
-  size_t me = (size_t)PetscMax(ctx->maxec, 1);
-  PetscScalar *mine, *all, *y;
-  ierr = PetscMalloc(sizeof(PetscScalar) * me, &mine);CHKERRQ(ierr);
-  ierr = PetscMalloc(sizeof(PetscScalar) * me * (size_t)comm->size, &all);CHKERRQ(ierr);
-  ierr = PetscMalloc(sizeof(PetscScalar) * (size_t)PetscMax(ctx->nlocal_x, 1), &y);CHKERRQ(ierr);
-  memset(mine, 0, sizeof(PetscScalar) * me);
-  CHKHIP(mi355x_memcpy_d2h(dc->h, mine, dx, sizeof(PetscScalar) * (size_t)ctx->ec));
-  CHKHIP(mi355x_memcpy_d2h(dc->h, y, dy, sizeof(PetscScalar) * (size_t)ctx->nlocal_x));
-  CHKHIP(mi355x_handle_synchronize(dc->h));
-  if (comm->allgather(comm->ctx, mine, (int)(sizeof(PetscScalar) * me), all)) SETERRQ(comm, PETSC_ERR_LIB, "allgather failed");
-  PetscInt lo = ctx->rstart_x, hi = ctx->rstart_x + ctx->nlocal_x;
-  for (int q = 0; q < comm->size; q++) {
-    const PetscInt *gq = ctx->all_garray + (size_t)q * (size_t)ctx->maxec;
-    for (PetscInt i = 0; i < ctx->ecs[q]; i++) if (gq[i] >= lo && gq[i] < hi) y[gq[i] - lo] = y[gq[i] - lo] + all[(size_t)q * me + (size_t)i];
+  if (!comm->exchange) SETERRQ(comm, PETSC_ERR_ORDER, "parallel scatter needs PetscCommSetDeviceComm() (RCCL) or PetscCommSetExchange() (host-staged)");
+  size_t stot = 0, rtot = 0;
+  for (PetscInt i = 0; i < ns; i++) stot += (size_t)scnt[i];
+  for (PetscInt i = 0; i < nr; i++) rtot += (size_t)rcnt[i];
+  if (!ctx->h_send) { ierr = PetscMalloc(sizeof(PetscScalar) * PetscMax((size_t)ctx->to.starts[ctx->to.n] + (size_t)ctx->from.starts[ctx->from.n], 1), &ctx->h_send);CHKERRQ(ierr); }
+  if (!ctx->h_recv) { ierr = PetscMalloc(sizeof(PetscScalar) * PetscMax((size_t)ctx->to.starts[ctx->to.n] + (size_t)ctx->from.starts[ctx->from.n], 1), &ctx->h_recv);CHKERRQ(ierr); }
+  void *sb[64], *rb[64]; int sp[64], rp[64], sbytes[64], rbytes[64];
+  if (ns > 64 || nr > 64) SETERRQ(comm, PETSC_ERR_SUP, "host-staged transport supports at most 64 neighbours");
+  size_t off = 0;
+  for (PetscInt i = 0; i < ns; i++) {
+    CHKHIP(mi355x_memcpy_d2h(dc->hcomm, ctx->h_send + off, ssrc[i], sizeof(PetscScalar) * (size_t)scnt[i]));
+    sb[i] = ctx->h_send + off; sp[i] = sprocs[i]; sbytes[i] = (int)(sizeof(PetscScalar) * (size_t)scnt[i]);
+    off += (size_t)scnt[i];
   }
-  CHKHIP(mi355x_memcpy_h2d(dc->h, dy, y, sizeof(PetscScalar) * (size_t)ctx->nlocal_x));
-  CHKHIP(mi355x_handle_synchronize(dc->h));
-  free(mine); free(all); free(y);
+  off = 0;
+  for (PetscInt i = 0; i < nr; i++) { rb[i] = ctx->h_recv + off; rp[i] = rprocs[i]; rbytes[i] = (int)(sizeof(PetscScalar) * (size_t)rcnt[i]); off += (size_t)rcnt[i]; }
+  CHKHIP(mi355x_handle_synchronize(dc->hcomm));
+  if (comm->exchange(comm->ctx, (int)ns, sp, sb, sbytes, (int)nr, rp, rb, rbytes)) SETERRQ(comm, PETSC_ERR_LIB, "host exchange failed");
+  for (PetscInt i = 0; i < nr; i++) CHKHIP(mi355x_memcpy_h2d(dc->hcomm, rdst[i], rb[i], (size_t)rbytes[i]));
+  CHKHIP(mi355x_handle_synchronize(dc->hcomm));   /* the staging buffer is pageable and reused */
   return 0;
 }
 
@@ -187,8 +172,8 @@ PetscErrorCode VecScatterBegin(VecScatter ctx, Vec x, Vec y, InsertMode addv, Sc
   if (ctx->to.n == 0 && ctx->from.n == 0 && ctx->to.local_n == 0) return 0;
   ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
   ierr = scatter_device_setup(ctx, dc);CHKERRQ(ierr);
-  if (ctx->comm->size > 1 && !ctx->comm->dcomm) return 0;   /* host-staged transport: everything happens in End (collective) */
-  mi355x_comm_t rc = ctx->comm->dcomm;
+  PetscScalar *rdst[64]; const PetscScalar *ssrc[64]; PetscInt rcnt[64], scnt[64];
+  if (ctx->to.n > 64 || ctx->from.n > 64) SETERRQ(ctx->comm, PETSC_ERR_SUP, "more than 64 neighbours");
   VecScatterSide *to = &ctx->to, *from = &ctx->from;
   if (mode == SCATTER_FORWARD) {
     const PetscScalar *dx; PetscScalar *dy;
@@ -200,18 +185,17 @@ PetscErrorCode VecScatterBegin(VecScatter ctx, Vec x, Vec y, InsertMode addv, Sc
     PetscInt nsend = to->starts[to->n];
     if (nsend && !to->contiq) CHKHIP(mi355x_pack(dc->hcomm, (size_t)nsend, to->d_indices, dx, to->d_values));   /* Pack_1 */
     if (to->n || from->n) {
-      CHKHIP(mi355x_comm_group_start());
       for (PetscInt i = 0; i < from->n; i++) {
-        PetscInt s = from->starts[i], c = from->starts[i + 1] - s;
-        PetscScalar *dst = from->contiq ? dy + from->indices[s] : from->d_values + s;
-        CHKHIP(mi355x_comm_recv(rc, dc->hcomm, dst, (size_t)c, from->procs[i]));
+        PetscInt s = from->starts[i];
+        rcnt[i] = from->starts[i + 1] - s;
+        rdst[i] = from->contiq ? dy + from->indices[s] : from->d_values + s;
       }
       for (PetscInt i = 0; i < to->n; i++) {
-        PetscInt s = to->starts[i], c = to->starts[i + 1] - s;
-        const PetscScalar *src = to->contiq ? dx + to->indices[s] : to->d_values + s;
-        CHKHIP(mi355x_comm_send(rc, dc->hcomm, src, (size_t)c, to->procs[i]));
+        PetscInt s = to->starts[i];
+        scnt[i] = to->starts[i + 1] - s;
+        ssrc[i] = to->contiq ? dx + to->indices[s] : to->d_values + s;
       }
-      CHKHIP(mi355x_comm_group_end());
+      ierr = neighbour_exchange(ctx, dc, from->n, from->procs, rdst, rcnt, to->n, to->procs, ssrc, scnt);CHKERRQ(ierr);
     }
     if (from->n && !from->contiq) CHKHIP(mi355x_unpack_insert(dc->hcomm, (size_t)from->starts[from->n], from->d_indices, from->d_values, dy));   /* UnPack_1 */
     if (to->local_n) {   /* Scatter_1, vpscat.c:538 */
@@ -232,17 +216,17 @@ PetscErrorCode VecScatterBegin(VecScatter ctx, Vec x, Vec y, InsertMode addv, Sc
     PetscInt nback = from->starts[from->n];
     if (nback && !from->contiq) CHKHIP(mi355x_pack(dc->hcomm, (size_t)nback, from->d_indices, dx, from->d_values));
     if (to->n || from->n) {
-      CHKHIP(mi355x_comm_group_start());
       for (PetscInt i = 0; i < to->n; i++) {
-        PetscInt s = to->starts[i], c = to->starts[i + 1] - s;
-        CHKHIP(mi355x_comm_recv(rc, dc->hcomm, to->d_values + s, (size_t)c, to->procs[i]));
+        PetscInt s = to->starts[i];
+        rcnt[i] = to->starts[i + 1] - s;
+        rdst[i] = to->d_values + s;
       }
       for (PetscInt i = 0; i < from->n; i++) {
-        PetscInt s = from->starts[i], c = from->starts[i + 1] - s;
-        const PetscScalar *src = from->contiq ? dx + from->indices[s] : from->d_values + s;
-        CHKHIP(mi355x_comm_send(rc, dc->hcomm, src, (size_t)c, from->procs[i]));
+        PetscInt s = from->starts[i];
+        scnt[i] = from->starts[i + 1] - s;
+        ssrc[i] = from->contiq ? dx + from->indices[s] : from->d_values + s;
       }
-      CHKHIP(mi355x_comm_group_end());
+      ierr = neighbour_exchange(ctx, dc, to->n, to->procs, rdst, rcnt, from->n, from->procs, ssrc, scnt);CHKERRQ(ierr);
     }
     CHKHIP(mi355x_event_record(ctx->ev_done, dc->hcomm));
   }
@@ -254,19 +238,8 @@ PetscErrorCode VecScatterEnd(VecScatter ctx, Vec x, Vec y, InsertMode addv, Scat
   PetscDeviceCtx *dc;
   if (!ctx) SETERRQ(0, PETSC_ERR_ARG_NULL, "Null VecScatter");
   ctx->inuse = PETSC_FALSE;
-  if (ctx->comm->size == 1 && ctx->to.local_n == 0) return 0;
-  ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
-  if (ctx->comm->size > 1 && !ctx->comm->dcomm) {   /* collective: every rank takes part, neighbours or not */
-    const PetscScalar *dx; PetscScalar *dy;
-    ierr = VecHIPGetRead(x, &dx);CHKERRQ(ierr);
-    ierr = VecHIPGetReadWrite(y, &dy);CHKERRQ(ierr);
-    if (mode == SCATTER_FORWARD) { ierr = staged_forward(ctx, dc, dx, dy);CHKERRQ(ierr); }
-    else { ierr = staged_reverse(ctx, dc, dx, dy);CHKERRQ(ierr); }
-    ierr = VecHIPRestoreWrite(y);CHKERRQ(ierr);
-    PetscObjectStateIncrease(y);
-    return 0;
-  }
   if (ctx->to.n == 0 && ctx->from.n == 0 && ctx->to.local_n == 0) return 0;
+  ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
   /* the compute stream resumes after the halo stream's work (replaces MPI_Waitany, vpscat.h:210) */
   CHKHIP(mi355x_handle_wait_event(dc->h, ctx->ev_done));
   if (mode == SCATTER_REVERSE) {
@@ -308,7 +281,7 @@ PetscErrorCode VecScatterDestroy(VecScatter *pctx) {
   }
   if (ctx->ev_packed) mi355x_event_destroy(ctx->ev_packed);
   if (ctx->ev_done) mi355x_event_destroy(ctx->ev_done);
-  free(ctx->all_garray); free(ctx->ecs); free(ctx->xrange);
+  free(ctx->h_send); free(ctx->h_recv);
   free(ctx);
   *pctx = NULL;
   return 0;

@@ -12,6 +12,7 @@ class FakeWorld:
         self.size = size
         self.barrier = threading.Barrier(size)
         self.slots = [None] * size
+        self.boxes = {}
 
     def comm_for(self, rank):
         def allgather_bytes(b):
@@ -26,7 +27,22 @@ class FakeWorld:
             arrs = np.stack([np.frombuffer(p, dtype=a.dtype) for p in parts])
             return {0: arrs.sum(0), 1: arrs.max(0), 2: arrs.min(0)}[op].astype(a.dtype)
 
-        return D.make_comm(rank, self.size, allgather_bytes, allreduce_array, lambda: self.barrier.wait())
+        def exchange(sends, recvs):
+            import queue
+            for peer, data in sends:
+                self.boxes.setdefault((rank, peer), queue.Queue()).put(data)
+            out = []
+            for peer, nb in recvs:
+                while True:
+                    q = self.boxes.get((peer, rank))
+                    if q is not None:
+                        break
+                    import time
+                    time.sleep(0.0005)
+                out.append(q.get(timeout=60))
+            return out
+
+        return D.make_comm(rank, self.size, allgather_bytes, allreduce_array, lambda: self.barrier.wait(), exchange=exchange)
 
     def run(self, fn):
         """fn(rank, comm) on every rank; returns the list of results; re-raises the first failure"""

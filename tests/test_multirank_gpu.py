@@ -1,6 +1,8 @@
 """The N>1 path end to end on ONE GPU: two processes (torch.distributed.run, gloo) share the card, so RCCL
-cannot be used (it rejects two ranks on one device) and the host-staged transport carries the halo and the
-reductions.  Everything else -- MatCreateMPIAIJWithArrays, diagonal/off-diagonal SpMV, compressed-row
+cannot be used (it rejects two ranks on one device) and the host-staged transport (device -> host -> gloo
+isend/irecv -> host -> device in place of ncclSend/ncclRecv; host all-reduce in place of ncclAllReduce) carries
+the halo and the reductions.  Pack/unpack kernels, contiguity shortcuts, offsets and the unpack order are the
+RCCL path's own.  Everything else -- MatCreateMPIAIJWithArrays, diagonal/off-diagonal SpMV, compressed-row
 off-diagonal block, MatMultTranspose with reverse/ADD scatter, parallel dots and norms, KSPCG over MPI vectors --
 is the code the 8-GPU run executes.  Results are compared with the sequential oracle on every rank."""
 import os
@@ -23,3 +25,4 @@ def test_mpiaij_two_ranks_one_gpu(built, nranks):
     assert r.returncode == 0, out[-3000:]
     for k in range(nranks):
         assert "rank %d/%d: MatMult bitexact=True MatMultTranspose=True norm=True" % (k, nranks) in out, out[-3000:]
+        assert "rank %d/%d: irregular MatMult bitexact=True MatMultTranspose bitexact=True" % (k, nranks) in out, out[-3000:]

@@ -50,6 +50,39 @@ def main():
     xr, hr, itsr, rr = orc.ksp_solve(gi, gj, ga, orc.spmv(gi, gj, ga, np.ones(N)), ksp="cg", pc="jacobi", rtol=1e-8)
     h = k.history()
     ok4 = abs(k.its - itsr) <= 1 and np.allclose(h[:min(len(h), len(hr))], hr[:min(len(h), len(hr))], rtol=1e-6)
+    # ---- irregular pattern, uneven ownership: non-contiguous halo indices (device pack / unpack kernels), several
+    # neighbours, reverse-mode additions in rank order -- bit-exact against the MPIAIJ-ordered oracle emulation
+    import scipy.sparse as sp
+    NI = 2003
+    S = sp.random(NI, NI, density=0.01, random_state=11, format="csr") + sp.eye(NI, format="csr")
+    S = sp.csr_matrix(S); S.sort_indices()
+    si, sj, sa = S.indptr.astype(np.int32), S.indices.astype(np.int32), S.data.astype(np.float64)
+    rng_ = np.array([0] + list(np.cumsum([NI // world + (NI % world > r) for r in range(world)])), dtype=np.int32)
+    rs, re_ = int(rng_[rank]), int(rng_[rank + 1])
+    li = (si[rs:re_ + 1] - si[rs]).astype(np.int32)
+    B = P.Mat.from_csr_mpi(li, sj[si[rs]:si[re_]].copy(), sa[si[rs]:si[re_]].copy(), re_ - rs, NI, NI, comm=comm)
+    xi = np.cos(0.3 * np.arange(NI)) + 0.1
+    vx = P.Vec.from_array(xi[rs:re_], comm=comm, N=NI)
+    vy = vx.duplicate()
+    B.mult(vx, vy)
+    pcs = [orc.mpiaij_split(int(rng_[q]), int(rng_[q + 1]), int(rng_[q]), int(rng_[q + 1]), si, sj, sa) for q in range(world)]
+    me = pcs[rank]
+    ref = orc.spmv(me["ad_i"], me["ad_j"], me["ad_a"], xi[rs:re_].copy())
+    if me["garray"].size:
+        ref = orc.spmv_add(me["bo_i"], me["bo_j"], me["bo_a"], xi[me["garray"]].copy(), ref)
+    ok5 = np.array_equal(vy.array().view(np.uint64), ref.view(np.uint64))
+    L.MatMultTranspose(B.h, vx.h, vy.h)
+    reft = orc.spmv_t(me["ad_i"], me["ad_j"], me["ad_a"], xi[rs:re_].copy(), re_ - rs)
+    for q in range(world):
+        if q == rank or not pcs[q]["garray"].size:
+            continue
+        lv = orc.spmv_t(pcs[q]["bo_i"], pcs[q]["bo_j"], pcs[q]["bo_a"], xi[rng_[q]:rng_[q + 1]].copy(), pcs[q]["garray"].size)
+        for i_, g in enumerate(pcs[q]["garray"]):
+            if rs <= g < re_:
+                reft[g - rs] = reft[g - rs] + lv[i_]
+    ok6 = np.array_equal(vy.array().view(np.uint64), reft.view(np.uint64))
+    print("rank %d/%d: irregular MatMult bitexact=%s MatMultTranspose bitexact=%s" % (rank, world, ok5, ok6), flush=True)
+    ok1 = ok1 and ok5 and ok6
     print("rank %d/%d: MatMult bitexact=%s MatMultTranspose=%s norm=%s CG its=%d (oracle %d) hist=%s" % (rank, world, ok1, ok2, ok3, k.its, itsr, ok4), flush=True)
     dist.barrier()
     dist.destroy_process_group()
