@@ -149,9 +149,11 @@ struct _p_VecScatter {
   PetscBool inuse;            /* guard, vscat.c:1637 */
   mi355x_event_t ev_packed, ev_done;
   int device_ready;
+  int ready_marked;           /* ev_packed already recorded by VecScatterMarkReady */
   /* every rank's request list (kept from set-up) for the host-staged transport */
   PetscScalar *h_send, *h_recv;   /* host staging buffers of the host-staged transport */
 };
+PetscErrorCode VecScatterMarkReady(VecScatter ctx, Vec x);
 PetscErrorCode VecScatterCreate_PtoS_MPIAIJ(MPI_Comm comm, PetscLayout *xmap, PetscInt ec, const PetscInt *garray, VecScatter *ctx);
 
 /* ---- Mat ---- */

@@ -160,6 +160,22 @@ static PetscErrorCode neighbour_exchange(VecScatter ctx, PetscDeviceCtx *dc, Pet
   return 0;
 }
 
+/* Records "the source vector is final" on the compute stream NOW, so that the caller may queue independent work
+ * (the diagonal-block SpMV) on the compute stream before VecScatterBegin spends host time enqueueing the RCCL
+ * operations: the halo stream still only waits for what preceded this point. */
+PetscErrorCode VecScatterMarkReady(VecScatter ctx, Vec x) {
+  PetscErrorCode ierr;
+  PetscDeviceCtx *dc;
+  const PetscScalar *dx;
+  if (!ctx || (ctx->to.n == 0 && ctx->from.n == 0 && ctx->to.local_n == 0)) return 0;
+  ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
+  ierr = VecHIPGetRead(x, &dx);CHKERRQ(ierr);   /* a host-side x is uploaded before the mark, not after it */
+  ierr = scatter_device_setup(ctx, dc);CHKERRQ(ierr);
+  CHKHIP(mi355x_event_record(ctx->ev_packed, dc->h));
+  ctx->ready_marked = 1;
+  return 0;
+}
+
 /* FORWARD/INSERT: x (parallel) -> y (= lvec, sequential).  REVERSE/ADD: x (= lvec) -> y (parallel), +=. */
 PetscErrorCode VecScatterBegin(VecScatter ctx, Vec x, Vec y, InsertMode addv, ScatterMode mode) {
   PetscErrorCode ierr;
@@ -179,8 +195,9 @@ PetscErrorCode VecScatterBegin(VecScatter ctx, Vec x, Vec y, InsertMode addv, Sc
     const PetscScalar *dx; PetscScalar *dy;
     ierr = VecHIPGetRead(x, &dx);CHKERRQ(ierr);
     ierr = VecHIPGetReadWrite(y, &dy);CHKERRQ(ierr);
-    /* the halo stream starts after everything already queued on the compute stream (x is final) */
-    CHKHIP(mi355x_event_record(ctx->ev_packed, dc->h));
+    /* the halo stream starts after everything queued on the compute stream when x became final */
+    if (!ctx->ready_marked) CHKHIP(mi355x_event_record(ctx->ev_packed, dc->h));
+    ctx->ready_marked = 0;
     CHKHIP(mi355x_handle_wait_event(dc->hcomm, ctx->ev_packed));
     PetscInt nsend = to->starts[to->n];
     if (nsend && !to->contiq) CHKHIP(mi355x_pack(dc->hcomm, (size_t)nsend, to->d_indices, dx, to->d_values));   /* Pack_1 */
