@@ -28,7 +28,6 @@ extern "C" {
 typedef struct mi355x_handle_s    *mi355x_handle_t;    /* one HIP stream + reduction workspace */
 typedef struct mi355x_event_s     *mi355x_event_t;     /* hipEvent_t */
 typedef struct mi355x_spmv_plan_s *mi355x_spmv_plan_t; /* row-block partition of one CSR matrix */
-typedef struct mi355x_bsr_plan_s  *mi355x_bsr_plan_t;
 
 /* ---- runtime --------------------------------------------------------- */
 const char *mi355x_error_string(int err);

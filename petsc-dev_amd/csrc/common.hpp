@@ -30,7 +30,6 @@ struct mi355x_handle_s {
   unsigned int *ticket;       // arrival counter for the single-launch reductions
   double *host_scratch;       // pinned + mapped, MI355X_SCRATCH_DOUBLES
   double *dev_scratch;        // HBM, MI355X_SCRATCH_DOUBLES
-  void *argbuf;               // device staging for pointer tables (MDot/MAXPY use kernel args instead)
 };
 
 struct mi355x_event_s {

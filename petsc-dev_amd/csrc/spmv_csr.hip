@@ -45,7 +45,6 @@
 #else
 #define SPMV_LOAD(p) (*(p))
 #endif
-#define SPMV_LONG_FLAG 0x40000000
 
 typedef double v2d __attribute__((ext_vector_type(2)));
 typedef int v2i __attribute__((ext_vector_type(2)));

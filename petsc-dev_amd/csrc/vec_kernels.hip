@@ -1,7 +1,7 @@
 // Vec BLAS-1 kernels for gfx950.  All of them are HBM-bound streams: 16-byte
-// (double2) loads/stores per lane, grid capped at 2048 workgroups (256 CUs x 8
-// resident 256-thread workgroups) with a grid-stride loop, two independent
-// double2 iterations in flight per lane.  Compiled with -ffp-contract=off so
+// (double2) loads/stores per lane and a grid-stride loop; element-wise kernels run
+// <= 2048 workgroups (256 CUs x 8 resident 256-thread workgroups) with two double2
+// iterations in flight per lane, reductions <= 1024 workgroups with four.  Compiled with -ffp-contract=off so
 // a*x+y is a rounded multiply then a rounded add, as in the reference's C loops
 // (src/vec/vec/impls/seq/{bvec1,bvec2,dvec2}.c).
 #include "common.hpp"

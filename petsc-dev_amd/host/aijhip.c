@@ -65,7 +65,6 @@ static PetscErrorCode seqaij_set(Mat_SeqAIJ *a, PetscInt r, PetscInt c, PetscSca
     if (rp[k] > c) break;
     if (rp[k] == c) { if (mode == ADD_VALUES) ap[k] += v; else ap[k] = v; return 0; }
   }
-  if (a->compact && n >= a->imax[r]) { /* packed rows have no slack */ }
   if (n >= a->imax[r]) {
     ierr = seqaij_grow(a, r);CHKERRQ(ierr);
     rp = a->j + a->i[r]; ap = a->a + a->i[r];
@@ -113,7 +112,7 @@ static PetscErrorCode device_free(Mat A) {
   if (d->t_a) mi355x_free(d->t_a);
   if (d->t_plan) mi355x_spmv_plan_destroy(d->t_plan);
   memset(d, 0, sizeof(*d));
-  d->uploaded_state = -1; d->t_state = -1;
+  d->uploaded_state = -1; d->t_state = -1; d->pattern_nz = -1;
   return 0;
 }
 
@@ -127,7 +126,7 @@ PetscErrorCode MatSeqAIJHIPUpload(Mat A) {
   if (d->uploaded_state == A->state && d->d_a) return 0;
   ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
   if (!a->compact) SETERRQ(A->comm, PETSC_ERR_ARG_WRONGSTATE, "matrix must be assembled before it is sent to the GPU");
-  PetscBool same_pattern = (PetscBool)(d->d_a && d->plan && d->cprow_n == -2 - a->nz);   /* see below */
+  PetscBool same_pattern = (PetscBool)(d->d_a && d->plan && d->pattern_nz == a->nz);   /* entries are never removed: same nz == same pattern */
   if (!same_pattern) {
     PetscBool keepcprow = d->cprow;
     device_free(A);
@@ -163,7 +162,7 @@ PetscErrorCode MatSeqAIJHIPUpload(Mat A) {
     }
     CHKHIP(mi355x_handle_synchronize(dc->h));
     free(ci); free(ridx);
-    d->cprow_n = -2 - a->nz;   /* remembers the pattern size this mirror was built for */
+    d->pattern_nz = a->nz;
     if (!use_cprow) d->cprow = PETSC_FALSE;
   }
   size_t vals = (size_t)a->nz * (size_t)(a->bs > 1 ? a->bs * a->bs : 1);
@@ -174,7 +173,7 @@ PetscErrorCode MatSeqAIJHIPUpload(Mat A) {
   return 0;
 }
 
-PetscErrorCode MatSeqAIJHIPSetCompressedRow(Mat A, PetscBool flg) { SD(A)->cprow = flg; SD(A)->uploaded_state = -1; SD(A)->cprow_n = 0; return 0; }
+PetscErrorCode MatSeqAIJHIPSetCompressedRow(Mat A, PetscBool flg) { SD(A)->cprow = flg; SD(A)->uploaded_state = -1; SD(A)->pattern_nz = -1; return 0; }
 
 /* explicit transpose, contributions of each output row in increasing original-row order (the order
  * MatMultTransposeAdd_SeqAIJ's scatter loop adds them in, aij.c:1100-1112) */
@@ -380,7 +379,7 @@ static PetscErrorCode create_common(Mat B, const char *tname, PetscInt bs) {
   memset(a, 0, sizeof(*a));
   ierr = PetscMalloc(sizeof(*d), &d);CHKERRQ(ierr);
   memset(d, 0, sizeof(*d));
-  d->uploaded_state = -1; d->t_state = -1;
+  d->uploaded_state = -1; d->t_state = -1; d->pattern_nz = -1;
   a->m = B->rmap->n; a->n = B->cmap->n; a->bs = bs;
   B->data = a; B->spptr = d;
   snprintf(B->type_name, sizeof(B->type_name), "%s", tname);

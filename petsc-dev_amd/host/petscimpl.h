@@ -208,8 +208,8 @@ typedef struct {
   mi355x_spmv_plan_t plan;
   int uploaded_state;        /* Mat state at last upload (compare state instead of valid_GPU_matrix) */
   /* compressed-row form for mostly-empty blocks (src/mat/utils/compressedrow.c:28) */
-  PetscBool cprow;
-  PetscInt cprow_n;
+  PetscBool cprow;            /* compressed-row form requested (off-diagonal block) */
+  PetscInt pattern_nz;        /* nz of the pattern the mirror was built for (-1: none) */
   /* cached explicit transpose for MatMultTranspose */
   PetscInt *t_i, *t_j; PetscScalar *t_a; mi355x_spmv_plan_t t_plan; int t_state;
 } Mat_SeqAIJHIP;

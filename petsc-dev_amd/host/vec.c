@@ -31,8 +31,6 @@ PetscErrorCode VecCreate(MPI_Comm comm, Vec *vec) {
   return 0;
 }
 
-/* sizes are recorded in a provisional layout; PetscLayoutSetUp happens at type set (as VecSetType does) */
-typedef struct { PetscInt n, N; } PendingSizes;
 PetscErrorCode VecSetSizes(Vec v, PetscInt n, PetscInt N) {
   PetscErrorCode ierr;
   VecValid(v, 1);
