@@ -122,6 +122,11 @@ int mi355x_vec_mdot(mi355x_handle_t h, size_t n, int nv, const double *x, const 
 int mi355x_spmv_plan_create(mi355x_handle_t h, int nrows, const int *ai_host, const int *rows_host,
                             mi355x_spmv_plan_t *plan);
 int mi355x_spmv_plan_destroy(mi355x_spmv_plan_t plan);
+/* Optional second analysis step (not for compressed-row plans): if the matrix uses <= 256 distinct offsets
+ * (col - row) -- stencil operators -- one byte per nonzero is stored next to the CSR arrays and the SpMV
+ * kernels stream val + 1 B instead of val + 4 B col.  Same arithmetic, same bits; no-op otherwise. */
+int mi355x_spmv_plan_compress_indices(mi355x_handle_t h, mi355x_spmv_plan_t plan, const int *ai_host, const int *aj_host);
+int mi355x_spmv_plan_is_compressed(mi355x_spmv_plan_t plan, int *ntab);
 int mi355x_spmv_plan_info(mi355x_spmv_plan_t plan, int *nblocks, int *nlong, size_t *workspace_bytes);
 /* MatMult_SeqAIJ      src/mat/impls/aij/seq/aij.c:1225 (loop 1269-1277, macro aij.h:383-386)
  *   y[r] = sum_k a[k] x[j[k]], products summed in k order starting from 0.0 */

@@ -60,6 +60,8 @@ KERNEL_API = {
     "mi355x_vec_mdot": [vp, sz, i32, vp, C.POINTER(vp), vp],
     "mi355x_spmv_plan_create": [vp, i32, vp, vp, C.POINTER(vp)],
     "mi355x_spmv_plan_destroy": [vp],
+    "mi355x_spmv_plan_compress_indices": [vp, vp, vp, vp],
+    "mi355x_spmv_plan_is_compressed": [vp, pi32],
     "mi355x_spmv_plan_info": [vp, pi32, pi32, C.POINTER(sz)],
     "mi355x_spmv_csr": [vp, vp, vp, vp, vp, vp, vp],
     "mi355x_spmv_csr_add": [vp, vp, vp, vp, vp, vp, vp, vp],

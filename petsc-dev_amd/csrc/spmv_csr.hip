@@ -56,6 +56,10 @@ struct mi355x_spmv_plan_s {
   int chunk;       // ceil(nblocks / NXCD)
   int2 *d_rowblk;  // nblocks+1 entries {first row, first nonzero}
   int *d_rows;     // compressed-row output indices or NULL
+  // offset-dictionary index compression (col = row + table[idx8]); NULL when the matrix has > 256 distinct offsets
+  unsigned char *d_idx8;
+  int *d_offtab;
+  int ntab;
 };
 
 template <bool ADD, bool CPROW, bool VEC>
@@ -203,6 +207,112 @@ __global__ __launch_bounds__(SPMV_THREADS, SPMV_MINWAVES) void spmv_csr_rowblock
 }
 
 // ---------------------------------------------------------------------------------------------
+// Index-compressed variant.  A matrix whose entries use at most 256 distinct offsets (col - row) -- every
+// stencil operator: 7 for the 3-D Poisson matrix, 135 for 3-dof 27-point elasticity -- gets, at analysis time,
+// one byte per nonzero (the position of its offset in a table) next to the unchanged CSR arrays.  The kernel
+// streams val (8 B) + idx8 (1 B) instead of val + col (12 B): 25 % fewer matrix bytes.  The row of each nonzero,
+// which the offset needs, comes from an LDS marker array written by the lanes that own the rows (they hold the
+// row extents anyway).  Arithmetic and summation order are those of the plain kernel: same bits.
+template <bool ADD>
+__global__ __launch_bounds__(SPMV_THREADS, SPMV_MINWAVES) void spmv_csr_rowblock_idx8_kernel(
+    const int2 *__restrict__ rowblk, int nblocks, const int *__restrict__ ai, const unsigned char *__restrict__ idx8,
+    const int *__restrict__ offtab_g, int ntab, const double *__restrict__ aa, const double *__restrict__ x,
+    const double *yin, double *yout) {
+  __shared__ double prod[SPMV_BLOCK_NNZ];
+  __shared__ unsigned char rowof[SPMV_BLOCK_NNZ];
+  __shared__ int offtab[256];
+  __shared__ double wsum[SPMV_THREADS / MI355X_WAVE];
+  const int lb = blockIdx.x;
+  if (lb >= nblocks) return;
+  const int2 b0 = rowblk[lb];
+  const int2 b1 = rowblk[lb + 1];
+  const int r0 = b0.x, r1 = b1.x, k0 = b0.y, k1 = b1.y;
+  const int nnz = k1 - k0;
+  const int nrows = r1 - r0;
+  const int tid = threadIdx.x;
+  if (tid < ntab) offtab[tid] = offtab_g[tid];
+
+  if (nnz > SPMV_BLOCK_CAP) {   // one long row: every entry belongs to row r0
+    __syncthreads();
+    double s = 0.0;
+    for (int k = k0 + tid; k < k1; k += SPMV_THREADS) s += SPMV_LOAD(aa + k) * x[r0 + offtab[SPMV_LOAD(idx8 + k)]];
+    s = wave_sum(s);
+    if ((tid & (MI355X_WAVE - 1)) == 0) wsum[tid / MI355X_WAVE] = s;
+    __syncthreads();
+    if (tid == 0) {
+      double t = wsum[0];
+#pragma unroll
+      for (int w = 1; w < SPMV_THREADS / MI355X_WAVE; ++w) t += wsum[w];
+      yout[r0] = ADD ? (yin[r0] + t) : t;
+    }
+    return;
+  }
+
+  int tpr = 1;
+  while (tpr < MI355X_WAVE && nrows * (tpr * 2) <= SPMV_THREADS) tpr *= 2;
+  if (nnz <= 16 * nrows) tpr = 1;
+  const int r = tid / tpr, sub = tid & (tpr - 1);
+  int rs = 0, re = 0;
+  double ysum = 0.0;
+  if (r < nrows) {
+    rs = ai[r0 + r] - k0;
+    re = ai[r0 + r + 1] - k0;
+    if (ADD && sub == 0) ysum = yin[r0 + r];
+  }
+  // this lane's slice of the value / index streams, requested before anything is consumed
+  constexpr int PAIRS = SPMV_BLOCK_NNZ / (2 * SPMV_THREADS);
+  const int ka = k0 & ~1;
+  v2d v[PAIRS];
+  unsigned short ix[PAIRS];
+  bool full[PAIRS];
+#pragma unroll
+  for (int p = 0; p < PAIRS; ++p) {
+    const int k = ka + 2 * tid + p * 2 * SPMV_THREADS;
+    full[p] = (k >= k0) && (k + 1 < k1);
+    if (full[p]) {
+      v[p] = SPMV_LOAD(reinterpret_cast<const v2d *>(aa + k));
+      ix[p] = SPMV_LOAD(reinterpret_cast<const unsigned short *>(idx8 + k));
+    }
+  }
+  // row markers: the lanes of row r tag its nonzeros
+  for (int k = rs + sub; k < re; k += tpr) rowof[k] = (unsigned char)r;
+  __syncthreads();
+  double xa[PAIRS], xb[PAIRS];
+#pragma unroll
+  for (int p = 0; p < PAIRS; ++p) {
+    if (full[p]) {
+      const int k = ka + 2 * tid + p * 2 * SPMV_THREADS - k0;
+      xa[p] = x[r0 + rowof[k] + offtab[ix[p] & 0xff]];
+      xb[p] = x[r0 + rowof[k + 1] + offtab[ix[p] >> 8]];
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < PAIRS; ++p) {
+    const int k = ka + 2 * tid + p * 2 * SPMV_THREADS;
+    if (full[p]) {
+      prod[k - k0] = v[p].x * xa[p];
+      prod[k - k0 + 1] = v[p].y * xb[p];
+    } else {
+      for (int e = k; e <= k + 1; ++e)
+        if (e >= k0 && e < k1) prod[e - k0] = SPMV_LOAD(aa + e) * x[r0 + rowof[e - k0] + offtab[SPMV_LOAD(idx8 + e)]];
+    }
+  }
+  __syncthreads();
+  if (tpr == 1) {
+    if (r < nrows) {
+      double sum = ADD ? ysum : 0.0;
+      for (int k = rs; k < re; ++k) sum += prod[k];
+      yout[r0 + r] = sum;
+    }
+  } else {
+    double sum = 0.0;
+    if (r < nrows) for (int k = rs + sub; k < re; k += tpr) sum += prod[k];
+    for (int off = tpr >> 1; off > 0; off >>= 1) sum += __shfl_down(sum, off, MI355X_WAVE);
+    if (r < nrows && sub == 0) yout[r0 + r] = ADD ? (ysum + sum) : sum;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // BCSR (MatMult_SeqBAIJ_3/_4/_N, reference src/mat/impls/baij/seq/baij2.c:331-436,981) with the same
 // row-block streaming structure: the plan is built over the block-row pointer scaled by bs*bs (so it
 // counts values), a workgroup streams <= 2046 values of consecutive block rows with 16-byte loads,
@@ -312,6 +422,12 @@ static int launch_spmv(mi355x_handle_t h, mi355x_spmv_plan_t p, const int *ai, c
   if (p->nblocks == 0) return 0;
   const bool vec = mi355x_aligned16(aa) && ((((uintptr_t)aj) & 7u) == 0);
   const bool cprow = p->d_rows != nullptr;
+  if (p->d_idx8 && !cprow && mi355x_aligned16(aa)) {
+    hipLaunchKernelGGL((spmv_csr_rowblock_idx8_kernel<ADD>), dim3(p->nblocks), dim3(SPMV_THREADS), 0, h->stream, p->d_rowblk,
+                       p->nblocks, ai, p->d_idx8, p->d_offtab, p->ntab, aa, x, yin, yout);
+    MI355X_LAUNCH_CHECK();
+    return 0;
+  }
   #if SPMV_REMAP == 2
   const int per = MI355X_NXCD * SPMV_CH;
   dim3 grid(((p->nblocks + per - 1) / per) * per), block(SPMV_THREADS);
@@ -336,6 +452,9 @@ int mi355x_spmv_plan_create(mi355x_handle_t h, int nrows, const int *ai_host, co
   p->nrows = nrows;
   p->d_rowblk = nullptr;
   p->d_rows = nullptr;
+  p->d_idx8 = nullptr;
+  p->d_offtab = nullptr;
+  p->ntab = 0;
   p->nlong = 0;
   std::vector<int2> rb;
   rb.reserve((size_t)nrows / 128 + 2);
@@ -369,11 +488,55 @@ int mi355x_spmv_plan_create(mi355x_handle_t h, int nrows, const int *ai_host, co
   return 0;
 }
 
+// Offset-dictionary analysis: idx8[k] = position of (aj[k] - row) in a table of <= 256 distinct offsets.
+// Returns 0 and leaves the plan uncompressed when the matrix has more distinct offsets.
+int mi355x_spmv_plan_compress_indices(mi355x_handle_t h, mi355x_spmv_plan_t p, const int *ai_host, const int *aj_host) {
+  if (!p || p->d_rows || p->d_idx8 || p->nrows == 0) return 0;
+  if (SPMV_BLOCK_ROWS > 256) return 0;   // row markers are bytes
+  const int m = p->nrows;
+  const long nnz = ai_host[m];
+  std::vector<unsigned char> idx((size_t)(nnz > 0 ? nnz : 1));
+  int tab[256];
+  int ntab = 0;
+  // small open-addressing map offset -> slot (offsets of a stencil matrix repeat row after row, so the
+  // previous row's slots are tried first)
+  int last = 0;
+  for (int r = 0; r < m; ++r) {
+    for (int k = ai_host[r]; k < ai_host[r + 1]; ++k) {
+      const int off = aj_host[k] - r;
+      int slot = -1;
+      if (ntab && tab[last] == off) slot = last;
+      else for (int t = 0; t < ntab; ++t) if (tab[t] == off) { slot = t; break; }
+      if (slot < 0) {
+        if (ntab == 256) return 0;   // too many distinct offsets: keep plain CSR
+        tab[ntab] = off;
+        slot = ntab++;
+      }
+      idx[(size_t)k] = (unsigned char)slot;
+      last = (slot + 1 < ntab) ? slot + 1 : 0;
+    }
+  }
+  MI355X_TRY(hipMalloc((void **)&p->d_idx8, (size_t)(nnz > 0 ? nnz : 1) + 16));
+  MI355X_TRY(hipMalloc((void **)&p->d_offtab, sizeof(int) * 256));
+  MI355X_TRY(hipMemcpyAsync(p->d_idx8, idx.data(), (size_t)nnz, hipMemcpyHostToDevice, h->stream));
+  MI355X_TRY(hipMemcpyAsync(p->d_offtab, tab, sizeof(int) * (size_t)ntab, hipMemcpyHostToDevice, h->stream));
+  MI355X_TRY(hipStreamSynchronize(h->stream));
+  p->ntab = ntab;
+  return 0;
+}
+
 int mi355x_spmv_plan_destroy(mi355x_spmv_plan_t p) {
   if (!p) return 0;
   hipFree(p->d_rowblk);
+  if (p->d_idx8) hipFree(p->d_idx8);
+  if (p->d_offtab) hipFree(p->d_offtab);
   if (p->d_rows) hipFree(p->d_rows);
   delete p;
+  return 0;
+}
+
+int mi355x_spmv_plan_is_compressed(mi355x_spmv_plan_t p, int *ntab) {
+  if (ntab) *ntab = p->d_idx8 ? p->ntab : 0;
   return 0;
 }
 

@@ -151,7 +151,14 @@ PetscErrorCode MatSeqAIJHIPUpload(Mat A) {
     CHKHIP(mi355x_malloc((void **)&d->d_a, sizeof(PetscScalar) * (size_t)PetscMax(a->nz, 1)));
     CHKHIP(mi355x_memcpy_h2d(dc->h, d->d_i, ip, sizeof(PetscInt) * (size_t)(nrows + 1)));
     CHKHIP(mi355x_memcpy_h2d(dc->h, d->d_j, a->j, sizeof(PetscInt) * (size_t)a->nz));
-    if (a->bs <= 1) CHKHIP(mi355x_spmv_plan_create(dc->h, nrows, ip, use_cprow ? ridx : NULL, &d->plan));
+    if (a->bs <= 1) {
+      PetscInt ic = 1; PetscBool set;
+      CHKHIP(mi355x_spmv_plan_create(dc->h, nrows, ip, use_cprow ? ridx : NULL, &d->plan));
+      /* -mat_hipmi355x_index_compression <0|1> (default 1): one byte per nonzero instead of a 4-byte column index
+       * when the matrix uses <= 256 distinct (col - row) offsets; plain CSR otherwise */
+      ierr = PetscOptionsGetInt(NULL, "-mat_hipmi355x_index_compression", &ic, &set);CHKERRQ(ierr);
+      if (ic && !use_cprow) CHKHIP(mi355x_spmv_plan_compress_indices(dc->h, d->plan, a->i, a->j));
+    }
     else {   /* BAIJ: the plan partitions the VALUE stream, i.e. the block-row pointer scaled by bs*bs */
       PetscInt *sc, bs2 = a->bs * a->bs;
       if ((double)a->nz * bs2 > 2147483000.0) SETERRQ(A->comm, PETSC_ERR_ARG_OUTOFRANGE, "BAIJ matrix too large for 32-bit value offsets");

@@ -203,11 +203,16 @@ def random_csr(m, n, rowlen, seed, sort=True):
     return ai, aj, aa
 
 
-def run_spmv(dev, ai, aj, aa, x, y0=None, rows=None):
+def run_spmv(dev, ai, aj, aa, x, y0=None, rows=None, compress=False):
     k = dev.k
     dai, daj, daa = upload_csr(dev, ai, aj, aa)
     dx = dev.put(x)
     plan = make_plan(dev, ai, rows)
+    if compress:
+        dev.chk(k.mi355x_spmv_plan_compress_indices(dev.h, plan, ai.ctypes.data, aj.ctypes.data))
+        nt = C.c_int()
+        k.mi355x_spmv_plan_is_compressed(plan, C.byref(nt))
+        run_spmv.last_ntab = nt.value
     if y0 is None:
         m_out = ai.size - 1
         dy = dev.put(np.full(m_out, 7.0))
@@ -231,6 +236,58 @@ def test_spmv_p7_bitexact(dev, dims):
     assert_bitexact(run_spmv(dev, ai, aj, aa, x), orc.spmv(ai, aj, aa, x))
     y0 = rnd(n, 50)
     assert_bitexact(run_spmv(dev, ai, aj, aa, x, y0=y0), orc.spmv_add(ai, aj, aa, x, y0))
+
+
+@pytest.mark.parametrize("dims", [(5, 4, 3), (33, 17, 9), (64, 64, 40)])
+def test_spmv_index_compression_bitexact(dev, dims):
+    """offset-dictionary index compression (col = row + table[idx8]): same bits as the plain kernel and the oracle"""
+    ai, aj, aa = orc.gen_p7(*dims)
+    aa = aa * (1.0 + 0.01 * np.cos(np.arange(aa.size)))
+    n = ai.size - 1
+    x = np.sin(0.37 * np.arange(n)) + 1.0
+    got = run_spmv(dev, ai, aj, aa, x, compress=True)
+    assert run_spmv.last_ntab == 7
+    assert_bitexact(got, orc.spmv(ai, aj, aa, x))
+    y0 = rnd(n, 51)
+    assert_bitexact(run_spmv(dev, ai, aj, aa, x, y0=y0, compress=True), orc.spmv_add(ai, aj, aa, x, y0))
+
+
+def test_spmv_index_compression_other_shapes(dev):
+    """banded matrix with long rows (several lanes per row, 81 offsets), a dense row longer than the LDS stage, and a
+    random matrix with > 256 distinct offsets (analysis declines, plain CSR is used)"""
+    n = 3000
+    rows_ = []
+    for r in range(n):
+        c = np.arange(max(0, r - 40), min(n, r + 41))
+        rows_.append(c)
+    lens = np.array([c.size for c in rows_])
+    ai = np.concatenate(([0], np.cumsum(lens))).astype(np.int32)
+    aj = np.concatenate(rows_).astype(np.int32)
+    aa = rnd(aj.size, 52)
+    x = rnd(n, 53)
+    got = run_spmv(dev, ai, aj, aa, x, compress=True)
+    assert run_spmv.last_ntab == 81
+    scale = np.zeros(n); np.add.at(scale, np.repeat(np.arange(n), lens), np.abs(aa * x[aj]))
+    assert np.all(np.abs(got - orc.spmv(ai, aj, aa, x)) <= 1e-12 * scale)
+    # one dense row of 2500 entries in an otherwise diagonal matrix: 2500 offsets > 256 -> declined
+    ai2 = np.concatenate(([0], np.cumsum(np.where(np.arange(n) == 7, 2500, 1)))).astype(np.int32)
+    aj2 = np.concatenate([np.arange(2500) if r == 7 else np.array([r]) for r in range(n)]).astype(np.int32)
+    aa2 = rnd(aj2.size, 54)
+    got = run_spmv(dev, ai2, aj2, aa2, x, compress=True)
+    assert run_spmv.last_ntab == 0
+    sc2 = np.zeros(n); np.add.at(sc2, np.repeat(np.arange(n), np.diff(ai2)), np.abs(aa2 * x[aj2]))
+    assert np.all(np.abs(got - orc.spmv(ai2, aj2, aa2, x)) <= 1e-12 * sc2)
+    # Toeplitz-like long row: row 0 holds columns 0..2499 and every row r holds r..r+199 (200 offsets <= 256), so the
+    # compressed kernel's whole-workgroup path runs for row 0
+    n3 = 2600
+    cols3 = [np.arange(0, 2500)] + [np.arange(r, min(n3, r + 200)) for r in range(1, n3)]
+    ai3 = np.concatenate(([0], np.cumsum([c.size for c in cols3]))).astype(np.int32)
+    aj3 = np.concatenate(cols3).astype(np.int32)
+    aa3 = rnd(aj3.size, 55); x3 = rnd(n3, 56)
+    got = run_spmv(dev, ai3, aj3, aa3, x3, compress=True)
+    assert run_spmv.last_ntab == 0    # 2500 offsets in row 0
+    sc3 = np.zeros(n3); np.add.at(sc3, np.repeat(np.arange(n3), np.diff(ai3)), np.abs(aa3 * x3[aj3]))
+    assert np.all(np.abs(got - orc.spmv(ai3, aj3, aa3, x3)) <= 1e-12 * sc3)
 
 
 def test_spmv_short_rows_bitexact(dev):
