@@ -81,6 +81,8 @@ typedef struct _p_Mat        *Mat;
 typedef struct _p_VecScatter *VecScatter;
 typedef struct _p_KSP        *KSP;
 typedef struct _p_PC         *PC;
+typedef struct _p_PetscViewer *PetscViewer;
+typedef enum { FILE_MODE_READ, FILE_MODE_WRITE } PetscFileMode;
 typedef const char *VecType;
 typedef const char *MatType;
 typedef const char *KSPType;
@@ -228,6 +230,14 @@ PetscErrorCode MatMPIAIJGetScatter(Mat A, VecScatter *ctx, Vec *lvec, PetscInt *
 /* per-MatMult device timing (HIP events on the compute stream around the SpMV launches) for bench.py */
 PetscErrorCode MatHIPMI355XSetTiming(Mat A, PetscBool on);
 PetscErrorCode MatHIPMI355XGetTiming(Mat A, PetscInt *nlaunches, PetscLogDouble *total_ms);
+
+/* ---- binary IO (PETSc binary format, big-endian; src/mat/impls/aij/seq/aij.c:4093-4157, src/vec/vec/utils/vecio.c) ---- */
+PetscErrorCode PetscViewerBinaryOpen(MPI_Comm comm, const char name[], PetscFileMode mode, PetscViewer *viewer);
+PetscErrorCode PetscViewerDestroy(PetscViewer *viewer);
+PetscErrorCode MatLoad(Mat A, PetscViewer viewer);     /* AIJ types, sequential and parallel (each rank reads its rows) */
+PetscErrorCode MatView(Mat A, PetscViewer viewer);     /* sequential AIJ */
+PetscErrorCode VecLoad(Vec v, PetscViewer viewer);
+PetscErrorCode VecView(Vec v, PetscViewer viewer);     /* sequential */
 
 /* example-driver support: bulk assembly of the 3-D 7-point Poisson operator (rows [rstart,rend), global
  * ascending columns); the 3-D analogue of src/ksp/ksp/examples/tutorials/ex2.c:96-103 */

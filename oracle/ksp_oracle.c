@@ -25,7 +25,7 @@
 typedef struct solver_s {
   int ksp_type, pc_type;
   double rtol, abstol, dtol;
-  int max_it, restart, refine_always, guess_nonzero;
+  int max_it, restart, refine_always, guess_nonzero, cg_single;
   int n;
   const int *ai, *aj;
   const double *aa;
@@ -149,11 +149,12 @@ static void initial_residual(solver *s, const double *x, double *vt1, double *vt
   }
 }
 
-/* ---- KSPSolve_CG, src/ksp/ksp/impls/cg/cg.c:92-286 (KSP_NORM_PRECONDITIONED, no single reduction) ---- */
+/* ---- KSPSolve_CG, src/ksp/ksp/impls/cg/cg.c:92-286 (KSP_NORM_PRECONDITIONED; -ksp_cg_single_reduction optional) ---- */
 static void solve_cg(solver *s, const double *B, double *X) {
   size_t n = (size_t)s->n;
-  double *R = (double *)malloc(3 * n * sizeof(double)), *Z = R + n, *P = Z + n, *W = Z;
-  double dpi = 0.0, a = 1.0, beta, betaold = 1.0, b, dpiold, dp = 0.0;
+  const int single = s->cg_single;
+  double *R = (double *)malloc(5 * n * sizeof(double)), *Z = R + n, *P = Z + n, *S = P + n, *W = single ? S + n : Z;
+  double dpi = 0.0, a = 1.0, beta, betaold = 1.0, b, dpiold, dp = 0.0, delta = 0.0;
   int i;
   s->its = 0;
   if (s->guess_nonzero) { mat_mult(s, X, R); orc_vec_aypx(n, -1.0, B, R); }
@@ -163,6 +164,7 @@ static void solve_cg(solver *s, const double *B, double *X) {
   monitor(s, dp);
   converged(s, 0, dp, B);
   if (s->reason) { free(R); return; }
+  if (single) { mat_mult(s, Z, S); delta = orc_vec_dot(n, Z, S); }
   beta = orc_vec_dot(n, Z, R);
   i = 0;
   do {
@@ -172,19 +174,21 @@ static void solve_cg(solver *s, const double *B, double *X) {
     if (!i) { orc_vec_copy(n, Z, P); b = 0.0; }
     else { b = beta / betaold; orc_vec_aypx(n, b, Z, P); }
     dpiold = dpi;
-    mat_mult(s, P, W);
-    dpi = orc_vec_dot(n, P, W);
+    if (!single || !i) { mat_mult(s, P, W); dpi = orc_vec_dot(n, P, W); }
+    else { orc_vec_aypx(n, beta / betaold, S, W); dpi = delta - beta * beta * dpiold / (betaold * betaold); }
     betaold = beta;
     if (dpi == 0.0 || (i > 0 && dpi * dpiold <= 0.0)) { s->reason = R_DIVERGED_INDEFINITE_MAT; break; }
     a = beta / dpi;
     orc_vec_axpy(n, a, P, X);
     orc_vec_axpy(n, -a, W, R);
     pc_apply(s, R, Z);
+    if (single) mat_mult(s, Z, S);
     orc_vec_norm(n, 1, Z, &dp);
     monitor(s, dp);
     converged(s, i + 1, dp, B);
     if (s->reason) break;
-    beta = orc_vec_dot(n, Z, R);
+    if (single) { const double *vv[2] = {S, R}; double t2[2]; orc_vec_mdot(n, 2, Z, vv, t2); delta = t2[0]; beta = t2[1]; }
+    else beta = orc_vec_dot(n, Z, R);
     i++;
   } while (i < s->max_it);
   if (i >= s->max_it) s->reason = R_DIVERGED_ITS;
@@ -391,7 +395,7 @@ int orc_ksp_solve(const orc_ksp_opts *o, int n, const int *ai, const int *aj, co
   memset(&S, 0, sizeof(S));
   S.ksp_type = o->ksp_type; S.pc_type = o->pc_type;
   S.rtol = o->rtol; S.abstol = o->abstol; S.dtol = o->dtol; S.max_it = o->max_it;
-  S.restart = o->restart; S.refine_always = o->refine_always; S.guess_nonzero = o->guess_nonzero;
+  S.restart = o->restart; S.refine_always = o->refine_always; S.guess_nonzero = o->guess_nonzero; S.cg_single = o->cg_single;
   S.n = n; S.ai = ai; S.aj = aj; S.aa = aa;
   S.nblocks = o->nblocks; S.blk = o->blk;
   S.hist = hist; S.hist_cap = hist_cap; S.nhist = 0;

@@ -432,6 +432,7 @@ static PetscErrorCode adopt_csr(Mat B, PetscInt nrows, PetscInt bs, const PetscI
   B->preallocated = PETSC_TRUE; B->assembled = PETSC_TRUE; B->was_assembled = PETSC_TRUE; B->state++;
   return 0;
 }
+PetscErrorCode MatSeqAIJSetCSR_Private(Mat B, PetscInt m, const PetscInt *i, const PetscInt *j, const PetscScalar *a) { return adopt_csr(B, m, 1, i, j, a); }
 PetscErrorCode MatCreateSeqAIJWithArrays(MPI_Comm comm, PetscInt m, PetscInt n, PetscInt i[], PetscInt j[], PetscScalar a[], Mat *mat) {
   PetscErrorCode ierr;
   ierr = MatCreate(comm, mat);CHKERRQ(ierr);

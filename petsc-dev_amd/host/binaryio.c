@@ -1,0 +1,141 @@
+/* PETSc binary format (big-endian on disk): MatLoad / MatView for AIJ and VecLoad / VecView, SURVEY 8f.2.
+ * Layout (src/mat/impls/aij/seq/aij.c:4093-4157, include/petscmat.h:136, include/petscvec.h:113):
+ *   Mat: int32 {MAT_FILE_CLASSID = 1211216, M, N, nz}, int32 rowlens[M], int32 cols[nz], float64 vals[nz]
+ *   Vec: int32 {VEC_FILE_CLASSID = 1211214, n}, float64 vals[n]
+ * Parallel MatLoad (MatLoad_MPIAIJ, mpiaij.c:3416): here every rank reads the header and the row lengths and then
+ * seeks to its own rows (the reference has rank 0 read and send). */
+#include "petscimpl.h"
+#include <stdint.h>
+
+#define MAT_FILE_CLASSID 1211216
+#define VEC_FILE_CLASSID 1211214
+
+struct _p_PetscViewer { MPI_Comm comm; FILE *f; int mode; };
+
+static uint32_t bswap32(uint32_t v) { return (v >> 24) | ((v >> 8) & 0xff00u) | ((v << 8) & 0xff0000u) | (v << 24); }
+static uint64_t bswap64(uint64_t v) { return ((uint64_t)bswap32((uint32_t)v) << 32) | bswap32((uint32_t)(v >> 32)); }
+static int little_endian(void) { const uint16_t one = 1; return *(const unsigned char *)&one; }
+
+static PetscErrorCode read_ints(FILE *f, PetscInt *p, size_t n) {
+  if (fread(p, sizeof(PetscInt), n, f) != n) SETERRQ(0, 66 /* PETSC_ERR_FILE_READ */, "Read past end of file");
+  if (little_endian()) for (size_t k = 0; k < n; k++) p[k] = (PetscInt)bswap32((uint32_t)p[k]);
+  return 0;
+}
+static PetscErrorCode read_scalars(FILE *f, PetscScalar *p, size_t n) {
+  if (fread(p, sizeof(PetscScalar), n, f) != n) SETERRQ(0, 66, "Read past end of file");
+  if (little_endian()) { uint64_t *q = (uint64_t *)p; for (size_t k = 0; k < n; k++) q[k] = bswap64(q[k]); }
+  return 0;
+}
+static PetscErrorCode write_ints(FILE *f, const PetscInt *p, size_t n) {
+  for (size_t k = 0; k < n; k++) { uint32_t v = little_endian() ? bswap32((uint32_t)p[k]) : (uint32_t)p[k]; if (fwrite(&v, 4, 1, f) != 1) SETERRQ(0, 67, "write failed"); }
+  return 0;
+}
+static PetscErrorCode write_scalars(FILE *f, const PetscScalar *p, size_t n) {
+  for (size_t k = 0; k < n; k++) { uint64_t v; memcpy(&v, &p[k], 8); if (little_endian()) v = bswap64(v); if (fwrite(&v, 8, 1, f) != 1) SETERRQ(0, 67, "write failed"); }
+  return 0;
+}
+
+PetscErrorCode PetscViewerBinaryOpen(MPI_Comm comm, const char name[], PetscFileMode mode, PetscViewer *viewer) {
+  PetscViewer v;
+  PetscErrorCode ierr = PetscMalloc(sizeof(*v), &v);CHKERRQ(ierr);
+  v->comm = comm; v->mode = (int)mode;
+  v->f = fopen(name, mode == FILE_MODE_READ ? "rb" : "wb");
+  if (!v->f) { free(v); SETERRQ(comm, 65 /* PETSC_ERR_FILE_OPEN */, "Cannot open file %s", name); }
+  *viewer = v;
+  return 0;
+}
+PetscErrorCode PetscViewerDestroy(PetscViewer *viewer) {
+  if (*viewer) { if ((*viewer)->f) fclose((*viewer)->f); free(*viewer); *viewer = NULL; }
+  return 0;
+}
+
+extern PetscErrorCode MatSeqAIJSetCSR_Private(Mat, PetscInt, const PetscInt *, const PetscInt *, const PetscScalar *);
+extern PetscErrorCode MatMPIAIJSetCSR_Private(Mat, PetscInt, const PetscInt *, const PetscInt *, const PetscScalar *);
+
+PetscErrorCode MatLoad(Mat A, PetscViewer viewer) {
+  PetscErrorCode ierr;
+  PetscInt header[4], M, N, *rowlens, *li, *lj; PetscScalar *la;
+  if (!A || !viewer) SETERRQ(0, PETSC_ERR_ARG_NULL, "Null argument");
+  if (viewer->mode != FILE_MODE_READ) SETERRQ(A->comm, PETSC_ERR_ARG_WRONG, "viewer not opened for reading");
+  long base = ftell(viewer->f);
+  ierr = read_ints(viewer->f, header, 4);CHKERRQ(ierr);
+  if (header[0] != MAT_FILE_CLASSID) SETERRQ(A->comm, 79 /* PETSC_ERR_FILE_UNEXPECTED */, "not matrix object");
+  M = header[1]; N = header[2];
+  if (header[3] < 0) SETERRQ(A->comm, 79, "Matrix stored in special format on disk, cannot load as SeqAIJ");
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)PetscMax(M, 1), &rowlens);CHKERRQ(ierr);
+  ierr = read_ints(viewer->f, rowlens, (size_t)M);CHKERRQ(ierr);
+  if (!A->type_name[0]) {
+    if (A->m_req == -1 && A->M_req == -1) { ierr = MatSetSizes(A, PETSC_DECIDE, PETSC_DECIDE, M, N);CHKERRQ(ierr); }
+    ierr = MatSetType(A, MATAIJHIPMI355X);CHKERRQ(ierr);
+  }
+  if (A->rmap->N != M || A->cmap->N != N) SETERRQ(A->comm, 79, "Matrix in file of different length (%d,%d) than the input matrix (%d,%d)", M, N, A->rmap->N, A->cmap->N);
+  PetscInt rs = A->rmap->rstart, re = A->rmap->rend, m = re - rs;
+  long before = 0, mine = 0;
+  for (PetscInt r = 0; r < rs; r++) before += rowlens[r];
+  for (PetscInt r = rs; r < re; r++) mine += rowlens[r];
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)(m + 1), &li);CHKERRQ(ierr);
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)PetscMax(mine, 1), &lj);CHKERRQ(ierr);
+  ierr = PetscMalloc(sizeof(PetscScalar) * (size_t)PetscMax(mine, 1), &la);CHKERRQ(ierr);
+  li[0] = 0;
+  for (PetscInt r = 0; r < m; r++) li[r + 1] = li[r] + rowlens[rs + r];
+  long cols0 = base + 16 + 4L * M, vals0 = cols0 + 4L * header[3];
+  fseek(viewer->f, cols0 + 4L * before, SEEK_SET);
+  ierr = read_ints(viewer->f, lj, (size_t)mine);CHKERRQ(ierr);
+  fseek(viewer->f, vals0 + 8L * before, SEEK_SET);
+  ierr = read_scalars(viewer->f, la, (size_t)mine);CHKERRQ(ierr);
+  fseek(viewer->f, vals0 + 8L * header[3], SEEK_SET);   /* leave the file positioned after the matrix */
+  if (!strcmp(A->type_name, MATSEQAIJHIPMI355X)) { ierr = MatSeqAIJSetCSR_Private(A, m, li, lj, la);CHKERRQ(ierr); }
+  else if (!strcmp(A->type_name, MATMPIAIJHIPMI355X)) { ierr = MatMPIAIJSetCSR_Private(A, m, li, lj, la);CHKERRQ(ierr); }
+  else SETERRQ(A->comm, PETSC_ERR_SUP, "MatLoad for type %s", A->type_name);
+  free(rowlens); free(li); free(lj); free(la);
+  return 0;
+}
+
+PetscErrorCode MatView(Mat A, PetscViewer viewer) {
+  PetscErrorCode ierr;
+  if (!A || !viewer) SETERRQ(0, PETSC_ERR_ARG_NULL, "Null argument");
+  if (strcmp(A->type_name, MATSEQAIJHIPMI355X)) SETERRQ(A->comm, PETSC_ERR_SUP, "binary MatView is ported for the sequential AIJ type only");
+  PetscInt m; const PetscInt *ai, *aj; const PetscScalar *aa;
+  ierr = MatSeqAIJGetArrays(A, &m, &ai, &aj, &aa);CHKERRQ(ierr);
+  PetscInt header[4] = {MAT_FILE_CLASSID, m, A->cmap->N, ai[m]}, *rl;
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)PetscMax(m, 1), &rl);CHKERRQ(ierr);
+  for (PetscInt r = 0; r < m; r++) rl[r] = ai[r + 1] - ai[r];
+  ierr = write_ints(viewer->f, header, 4);CHKERRQ(ierr);
+  ierr = write_ints(viewer->f, rl, (size_t)m);CHKERRQ(ierr);
+  ierr = write_ints(viewer->f, aj, (size_t)ai[m]);CHKERRQ(ierr);
+  ierr = write_scalars(viewer->f, aa, (size_t)ai[m]);CHKERRQ(ierr);
+  free(rl);
+  return 0;
+}
+
+PetscErrorCode VecLoad(Vec v, PetscViewer viewer) {   /* src/vec/vec/utils/vecio.c */
+  PetscErrorCode ierr;
+  PetscInt header[2];
+  if (!v || !viewer) SETERRQ(0, PETSC_ERR_ARG_NULL, "Null argument");
+  long base = ftell(viewer->f);
+  ierr = read_ints(viewer->f, header, 2);CHKERRQ(ierr);
+  if (header[0] != VEC_FILE_CLASSID) SETERRQ(v->comm, 79, "Not vector next in file");
+  if (!v->map) { ierr = VecSetSizes(v, PETSC_DECIDE, header[1]);CHKERRQ(ierr); }
+  if (!v->type_name[0]) { ierr = VecSetType(v, VECHIPMI355X);CHKERRQ(ierr); }
+  if (v->map->N != header[1]) SETERRQ(v->comm, 79, "Vector in file different length (%d) then input vector (%d)", header[1], v->map->N);
+  PetscScalar *a;
+  ierr = VecGetArray(v, &a);CHKERRQ(ierr);
+  fseek(viewer->f, base + 8 + 8L * v->map->rstart, SEEK_SET);
+  ierr = read_scalars(viewer->f, a, (size_t)v->map->n);CHKERRQ(ierr);
+  ierr = VecRestoreArray(v, &a);CHKERRQ(ierr);
+  fseek(viewer->f, base + 8 + 8L * header[1], SEEK_SET);
+  return 0;
+}
+
+PetscErrorCode VecView(Vec v, PetscViewer viewer) {
+  PetscErrorCode ierr;
+  if (!v || !viewer) SETERRQ(0, PETSC_ERR_ARG_NULL, "Null argument");
+  if (v->comm->size > 1) SETERRQ(v->comm, PETSC_ERR_SUP, "binary VecView is ported for sequential vectors only");
+  PetscInt header[2] = {VEC_FILE_CLASSID, v->map->N};
+  const PetscScalar *a;
+  ierr = write_ints(viewer->f, header, 2);CHKERRQ(ierr);
+  ierr = VecGetArrayRead(v, &a);CHKERRQ(ierr);
+  ierr = write_scalars(viewer->f, a, (size_t)v->map->n);CHKERRQ(ierr);
+  ierr = VecRestoreArrayRead(v, &a);CHKERRQ(ierr);
+  return 0;
+}

@@ -8,14 +8,26 @@
 #include "petscimpl.h"
 
 /* ================================================================== CG */
-static PetscErrorCode KSPSetUp_CG(KSP ksp) { return KSPDefaultGetWork(ksp, 3); }   /* cg.c:50-80 (no eigenvalue work) */
+typedef struct { PetscBool singlereduction; } KSP_CG;   /* cgimpl.h */
+static PetscErrorCode KSPSetUp_CG(KSP ksp) {   /* cg.c:50-80 (no eigenvalue work): 3 work vectors, 5 with -ksp_cg_single_reduction */
+  return KSPDefaultGetWork(ksp, ((KSP_CG *)ksp->data)->singlereduction ? 5 : 3);
+}
+static PetscErrorCode KSPSetFromOptions_CG(KSP ksp) {   /* cg.c:330-345 */
+  char t[16]; PetscBool set;
+  PetscErrorCode ierr = PetscOptionsGetString(ksp->prefix, "-ksp_cg_single_reduction", t, sizeof(t), &set);CHKERRQ(ierr);
+  if (set) ((KSP_CG *)ksp->data)->singlereduction = (PetscBool)(strcmp(t, "0") && strcmp(t, "false"));
+  return 0;
+}
+static PetscErrorCode KSPDestroy_CG(KSP ksp) { free(ksp->data); ksp->data = NULL; return 0; }
 
 static PetscErrorCode KSPSolve_CG(KSP ksp) {
   PetscErrorCode ierr;
   PetscInt i;
-  PetscScalar dpi = 0.0, a = 1.0, beta, betaold = 1.0, b = 0, dpiold;
+  PetscScalar dpi = 0.0, a = 1.0, beta, betaold = 1.0, b = 0, dpiold, delta = 0.0;
   PetscReal dp = 0.0;
-  Vec X = ksp->vec_sol, B = ksp->vec_rhs, R = ksp->work[0], Z = ksp->work[1], P = ksp->work[2], W = Z;
+  const PetscBool single = ((KSP_CG *)ksp->data)->singlereduction;
+  Vec X = ksp->vec_sol, B = ksp->vec_rhs, R = ksp->work[0], Z = ksp->work[1], P = ksp->work[2];
+  Vec S = single ? ksp->work[3] : NULL, W = single ? ksp->work[4] : Z;   /* cg.c:116-122 */
   Mat Amat = ksp->pc->mat;
 
   ksp->its = 0;
@@ -30,6 +42,10 @@ static PetscErrorCode KSPSolve_CG(KSP ksp) {
   ksp->rnorm = dp;
   ierr = KSPDefaultConverged(ksp, 0, dp, &ksp->reason);CHKERRQ(ierr);
   if (ksp->reason) return 0;
+  if (single) {                                                   /* cg.c:166-169 */
+    ierr = KSP_MatMult(ksp, Amat, Z, S);CHKERRQ(ierr);
+    ierr = VecTDot(Z, S, &delta);CHKERRQ(ierr);
+  }
   ierr = VecTDot(Z, R, &beta);CHKERRQ(ierr);                     /* beta <- z'*r */
   if (PetscIsInfOrNanScalar(beta)) SETERRQ(ksp->comm, PETSC_ERR_FP, "Infinite or not-a-number generated in dot product");
 
@@ -41,8 +57,13 @@ static PetscErrorCode KSPSolve_CG(KSP ksp) {
     if (!i) { ierr = VecCopy(Z, P);CHKERRQ(ierr); b = 0.0; }     /* p <- z */
     else { b = beta / betaold; ierr = VecAYPX(P, b, Z);CHKERRQ(ierr); }   /* p <- z + b*p */
     dpiold = dpi;
-    ierr = KSP_MatMult(ksp, Amat, P, W);CHKERRQ(ierr);           /* w <- Ap */
-    ierr = VecTDot(P, W, &dpi);CHKERRQ(ierr);                    /* dpi <- p'w */
+    if (!single || !i) {
+      ierr = KSP_MatMult(ksp, Amat, P, W);CHKERRQ(ierr);         /* w <- Ap */
+      ierr = VecTDot(P, W, &dpi);CHKERRQ(ierr);                  /* dpi <- p'w */
+    } else {                                                      /* cg.c:200-203: recurrences instead of a product and a dot */
+      ierr = VecAYPX(W, beta / betaold, S);CHKERRQ(ierr);        /* w <- Ap */
+      dpi = delta - beta * beta * dpiold / (betaold * betaold);  /* dpi <- p'w */
+    }
     betaold = beta;
     if (PetscIsInfOrNanScalar(dpi)) SETERRQ(ksp->comm, PETSC_ERR_FP, "Infinite or not-a-number generated in dot product");
     if ((dpi == 0.0) || ((i > 0) && (dpi * dpiold <= 0.0))) { ksp->reason = KSP_DIVERGED_INDEFINITE_MAT; break; }
@@ -50,20 +71,33 @@ static PetscErrorCode KSPSolve_CG(KSP ksp) {
     ierr = VecAXPY(X, a, P);CHKERRQ(ierr);                       /* x <- x + ap */
     ierr = VecAXPY(R, -a, W);CHKERRQ(ierr);                      /* r <- r - aw */
     ierr = KSP_PCApply(ksp, R, Z);CHKERRQ(ierr);                 /* z <- Br */
+    if (single) { ierr = KSP_MatMult(ksp, Amat, Z, S);CHKERRQ(ierr); }   /* cg.c:217-219 */
     ierr = VecNorm(Z, NORM_2, &dp);CHKERRQ(ierr);
     ksp->rnorm = dp;
     KSPLogResidualHistory(ksp, dp);
     ierr = KSPMonitor(ksp, i + 1, dp);CHKERRQ(ierr);
     ierr = KSPDefaultConverged(ksp, i + 1, dp, &ksp->reason);CHKERRQ(ierr);
     if (ksp->reason) break;
-    ierr = VecTDot(Z, R, &beta);CHKERRQ(ierr);                   /* beta <- z'*r */
+    if (single) {                                                 /* cg.c:263-270: one VecMDot(2) = one reduction for delta and beta */
+      PetscScalar tmp[2]; Vec vecs[2];
+      vecs[0] = S; vecs[1] = R;
+      ierr = VecMDot(Z, 2, vecs, tmp);CHKERRQ(ierr);
+      delta = tmp[0]; beta = tmp[1];
+    } else { ierr = VecTDot(Z, R, &beta);CHKERRQ(ierr); }        /* beta <- z'*r */
     if (PetscIsInfOrNanScalar(beta)) SETERRQ(ksp->comm, PETSC_ERR_FP, "Infinite or not-a-number generated in dot product");
     i++;
   } while (i < ksp->max_it);
   if (i >= ksp->max_it) ksp->reason = KSP_DIVERGED_ITS;
   return 0;
 }
-PetscErrorCode KSPCreate_CG(KSP ksp) { ksp->ops->setup = KSPSetUp_CG; ksp->ops->solve = KSPSolve_CG; return 0; }
+PetscErrorCode KSPCreate_CG(KSP ksp) {
+  KSP_CG *cg;
+  PetscErrorCode ierr = PetscMalloc(sizeof(*cg), &cg);CHKERRQ(ierr);
+  cg->singlereduction = PETSC_FALSE;
+  ksp->data = cg;
+  ksp->ops->setup = KSPSetUp_CG; ksp->ops->solve = KSPSolve_CG; ksp->ops->setfromoptions = KSPSetFromOptions_CG; ksp->ops->destroy = KSPDestroy_CG;
+  return 0;
+}
 
 /* ================================================================== GMRES(m) */
 typedef struct {

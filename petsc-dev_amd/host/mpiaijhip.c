@@ -200,6 +200,7 @@ PetscErrorCode MatCreate_AIJHIPMI355X(Mat B) {
 
 /* MatCreateMPIAIJWithArrays (mpiaij.c; via MatMPIAIJSetPreallocationCSR): i/j/a hold this rank's rows with
  * global, ascending column indices.  The split is the column test of MatSetValues_MPIAIJ done in bulk. */
+PetscErrorCode MatMPIAIJSetCSR_Private(Mat A, PetscInt m, const PetscInt i[], const PetscInt j[], const PetscScalar a[]);
 PetscErrorCode MatCreateMPIAIJWithArrays(MPI_Comm comm, PetscInt m, PetscInt n, PetscInt M, PetscInt N, const PetscInt i[], const PetscInt j[], const PetscScalar a[], Mat *mat) {
   PetscErrorCode ierr;
   Mat A;
@@ -208,6 +209,16 @@ PetscErrorCode MatCreateMPIAIJWithArrays(MPI_Comm comm, PetscInt m, PetscInt n, 
   ierr = MatCreate(comm, &A);CHKERRQ(ierr);
   ierr = MatSetSizes(A, m, n, M, N);CHKERRQ(ierr);
   ierr = MatSetType(A, MATMPIAIJHIPMI355X);CHKERRQ(ierr);
+  ierr = MatMPIAIJSetCSR_Private(A, m, i, j, a);CHKERRQ(ierr);
+  *mat = A;
+  return 0;
+}
+
+/* fills an (empty) MATMPIAIJHIPMI355X from this rank's rows in CSR form (MatMPIAIJSetPreallocationCSR, mpiaij.c) */
+PetscErrorCode MatMPIAIJSetCSR_Private(Mat A, PetscInt m, const PetscInt i[], const PetscInt j[], const PetscScalar a[]) {
+  PetscErrorCode ierr;
+  MPI_Comm comm = A->comm;
+  if (m != A->rmap->n) SETERRQ(comm, PETSC_ERR_ARG_SIZ, "local row count %d does not match the layout %d", m, A->rmap->n);
   Mat_MPIAIJ *aij = MA(A);
   PetscInt cs = aij->cstart, ce = aij->cend, nd = 0, no = 0;
   for (PetscInt k = 0; k < i[m]; k++) { if (j[k] >= cs && j[k] < ce) nd++; else no++; }
@@ -234,7 +245,6 @@ PetscErrorCode MatCreateMPIAIJWithArrays(MPI_Comm comm, PetscInt m, PetscInt n, 
   A->preallocated = PETSC_TRUE;
   ierr = MatSetUpMultiply_MPIAIJ(A);CHKERRQ(ierr);
   A->assembled = PETSC_TRUE; A->was_assembled = PETSC_TRUE; A->state++;
-  *mat = A;
   return 0;
 }
 

@@ -247,6 +247,21 @@ def test_ksp_config1_cg_jacobi(P):
     assert "%.5g" % np.linalg.norm(x - u) == "5.7078e-05" or "%.5g" % np.linalg.norm(x - u) == "5.7079e-05"
 
 
+def test_ksp_cg_single_reduction(P):
+    """-ksp_cg_single_reduction (cg.c:116-122,200-203,263-270): two reductions per iteration instead of
+    three (VecMDot(2) for delta and beta), A*p by recurrence; same op sequence as the oracle's restatement"""
+    ai, aj, aa = pb.lap2d(40, 37)
+    n = ai.size - 1
+    b = orc.spmv(ai, aj, aa, np.ones(n))
+    x, h, its, reason = solve(P, ai, aj, aa, b, "cg", "jacobi", opts="-ksp_cg_single_reduction 1", rtol=1e-8)
+    xr, hr, itsr, rr = orc.ksp_solve(ai, aj, aa, b, ksp="cg", pc="jacobi", rtol=1e-8, cg_single=1)
+    x0, h0, its0, _ = orc.ksp_solve(ai, aj, aa, b, ksp="cg", pc="jacobi", rtol=1e-8)
+    assert reason == rr == 2 and abs(its - itsr) <= 1 and abs(itsr - its0) <= 2
+    k = min(len(h), len(hr))
+    assert np.allclose(h[:k], hr[:k], rtol=1e-6, atol=0)
+    assert np.linalg.norm(x - 1.0) < 1e-6
+
+
 def test_ksp_golden_ex3_ex2f_ex9(P):
     (ai, aj, aa), b, u0, ustar = pb.ex3_fem(5)
     gold = pb.parse_monitor(os.path.join(G, "ksp_tests", "ex3_1.out"))[0]
