@@ -153,6 +153,15 @@ int mi355x_spmv_bsr(mi355x_handle_t h, int mbs, int bs, const int *ai, const int
 int mi355x_spmv_bsr_planned(mi355x_handle_t h, mi355x_spmv_plan_t plan, int bs, const int *ai, const int *aj,
                             const double *aa, const double *x, double *y);
 
+/* ---- ILU(0) triangular solves ---------------------------- */
+/* MatSolve_SeqAIJ_NaturalOrdering  src/mat/impls/aij/seq/aijfact.c:3126-3172 on the factor layout of :1628-1700,
+ * one launch per dependency level; `rows` lists the rows of the level (device array).  Lower: x[i] = b[i] - L(i,:)x
+ * (b may alias x); upper: x[i] = (x[i] - U(i,:)x) * inverted diagonal. */
+int mi355x_ilu0_lower_level(mi355x_handle_t h, int nrows, const int *rows, const int *bi, const int *bj,
+                            const double *ba, const double *b, double *x);
+int mi355x_ilu0_upper_level(mi355x_handle_t h, int nrows, const int *rows, const int *bj, const double *ba,
+                            const int *bdiag, double *x);
+
 /* ---- halo pack / unpack (VecScatter) ---------------------------------- */
 /* Pack_1    src/vec/vec/utils/vpscat.c:493   buf[k] = x[idx[k]] */
 int mi355x_pack(mi355x_handle_t h, size_t n, const int *idx, const double *x, double *buf);

@@ -102,6 +102,7 @@ typedef const char *PCType;
 #define PCNONE     "none"
 #define PCJACOBI   "jacobi"
 #define PCBJACOBI  "bjacobi"
+#define PCILU      "ilu"       /* ILU(0), natural ordering, sequential AIJ */
 
 /* ---- Sys ----------------------------------------------------------------------------------- */
 extern MPI_Comm PETSC_COMM_SELF, PETSC_COMM_WORLD;
@@ -252,6 +253,7 @@ PetscErrorCode PCSetUp(PC pc);
 PetscErrorCode PCApply(PC pc, Vec x, Vec y);
 PetscErrorCode PCSetFromOptions(PC pc);
 PetscErrorCode PCDestroy(PC *pc);
+PetscErrorCode PCILUGetLevels_HIPMI355X(PC pc, PetscInt *nlevL, PetscInt *nlevU);   /* launches per triangular solve */
 PetscErrorCode PCBJacobiGetSubKSP(PC pc, PetscInt *n_local, PetscInt *first_local, KSP **ksp);
 
 /* ---- KSP (include/petscksp.h) ---------------------------------------------------------------- */

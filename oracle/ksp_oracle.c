@@ -30,6 +30,7 @@ typedef struct solver_s {
   const int *ai, *aj;
   const double *aa;
   double *idiag;              /* Jacobi: 1/diag (0 -> 1), PCSetUp_Jacobi jacobi.c:170-190 */
+  int *fi, *fj, *fdiag; double *fa;   /* ILU(0) factors in the reference's L / reversed-U layout */
   int nblocks;
   const int *blk;
   struct solver_s *sub;       /* block Jacobi sub-solvers */
@@ -53,9 +54,89 @@ static void monitor(solver *s, double r) { if (s->hist && s->nhist < s->hist_cap
 
 static int solve(solver *s, const double *b, double *x);
 
+/* ---- ILU(0), natural ordering: src/mat/impls/aij/seq/aijfact.c ---- */
+/* MatILUFactorSymbolic_SeqAIJ_ilu0 (:1628-1700): L rows forward (columns < i), then the U rows stored from the
+ * last row backwards, each followed by its diagonal slot; bdiag[i] = position of the (inverted) diagonal. */
+int orc_ilu0_factor(int n, const int *ai, const int *aj, const double *aa, int *bi, int *bj, int *bdiag, double *ba) {
+  int k = 0;
+  int *adiag = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+  for (int i = 0; i < n; i++) {
+    adiag[i] = -1;
+    for (int q = ai[i]; q < ai[i + 1]; q++) if (aj[q] == i) { adiag[i] = q; break; }
+    if (adiag[i] < 0) { free(adiag); return 1; }   /* "Matrix is missing diagonal entry" */
+  }
+  bi[0] = 0;
+  for (int i = 0; i < n; i++) {
+    int nz = adiag[i] - ai[i];
+    bi[i + 1] = bi[i] + nz;
+    for (int j = 0; j < nz; j++) bj[k++] = aj[ai[i] + j];
+  }
+  bdiag[n] = bi[n] - 1;
+  for (int i = n - 1; i >= 0; i--) {
+    int nz = ai[i + 1] - adiag[i] - 1;
+    for (int j = 0; j < nz; j++) bj[k++] = aj[adiag[i] + 1 + j];
+    bj[k++] = i;
+    bdiag[i] = bdiag[i + 1] + nz + 1;
+  }
+  /* MatLUFactorNumeric_SeqAIJ (:461-620), identity permutations, no shift needed */
+  double *rtmp = (double *)calloc((size_t)n + 1, sizeof(double));
+  for (int i = 0; i < n; i++) {
+    int nz = bi[i + 1] - bi[i];
+    const int *bjtmp = bj + bi[i];
+    for (int j = 0; j < nz; j++) rtmp[bjtmp[j]] = 0.0;
+    nz = bdiag[i] - bdiag[i + 1];
+    bjtmp = bj + bdiag[i + 1] + 1;
+    for (int j = 0; j < nz; j++) rtmp[bjtmp[j]] = 0.0;
+    for (int q = ai[i]; q < ai[i + 1]; q++) rtmp[aj[q]] = aa[q];
+    const int nzL = bi[i + 1] - bi[i];
+    for (int kk = 0; kk < nzL; kk++) {
+      const int row = bj[bi[i] + kk];
+      double *pc = rtmp + row;
+      if (*pc != 0.0) {
+        const double multiplier = *pc * ba[bdiag[row]];
+        *pc = multiplier;
+        const int *pj = bj + bdiag[row + 1] + 1;
+        const double *pv = ba + bdiag[row + 1] + 1;
+        const int nzu = bdiag[row] - bdiag[row + 1] - 1;
+        for (int j = 0; j < nzu; j++) rtmp[pj[j]] -= multiplier * pv[j];
+      }
+    }
+    for (int j = 0; j < nzL; j++) ba[bi[i] + j] = rtmp[bj[bi[i] + j]];
+    nz = bdiag[i] - bdiag[i + 1] - 1;
+    for (int j = 0; j < nz; j++) ba[bdiag[i + 1] + 1 + j] = rtmp[bj[bdiag[i + 1] + 1 + j]];
+    ba[bdiag[i]] = 1.0 / rtmp[i];   /* inverted diagonal */
+  }
+  free(rtmp); free(adiag);
+  return 0;
+}
+
+/* MatSolve_SeqAIJ_NaturalOrdering (:3126-3172) with PetscSparseDenseMinusDot (aij.h:337-339) */
+void orc_ilu0_solve(int n, const int *bi, const int *bj, const int *bdiag, const double *ba, const double *b, double *x) {
+  if (!n) return;
+  x[0] = b[0];
+  for (int i = 1; i < n; i++) {
+    double sum = b[i];
+    for (int q = bi[i]; q < bi[i + 1]; q++) sum -= ba[q] * x[bj[q]];
+    x[i] = sum;
+  }
+  for (int i = n - 1; i >= 0; i--) {
+    const int s0 = bdiag[i + 1] + 1, nz = bdiag[i] - bdiag[i + 1] - 1;
+    double sum = x[i];
+    for (int q = 0; q < nz; q++) sum -= ba[s0 + q] * x[bj[s0 + q]];
+    x[i] = sum * ba[s0 + nz];
+  }
+}
+
 /* ---- PC ---- */
 static void pc_setup(solver *s) {
-  if (s->pc_type == ORC_PC_JACOBI) {
+  if (s->pc_type == ORC_PC_ILU) {
+    int nz = s->ai[s->n];
+    s->fi = (int *)malloc(sizeof(int) * (size_t)(s->n + 1));
+    s->fj = (int *)malloc(sizeof(int) * (size_t)(nz + 1));
+    s->fdiag = (int *)malloc(sizeof(int) * (size_t)(s->n + 1));
+    s->fa = (double *)calloc((size_t)nz + 1, sizeof(double));
+    orc_ilu0_factor(s->n, s->ai, s->aj, s->aa, s->fi, s->fj, s->fdiag, s->fa);
+  } else if (s->pc_type == ORC_PC_JACOBI) {
     s->idiag = (double *)malloc(sizeof(double) * (size_t)s->n);
     orc_csr_get_diagonal(s->n, s->ai, s->aj, s->aa, s->idiag);   /* MatGetDiagonal */
     orc_vec_reciprocal((size_t)s->n, s->idiag);                   /* VecReciprocal */
@@ -90,6 +171,7 @@ static void pc_setup(solver *s) {
 
 static void pc_free(solver *s) {
   free(s->idiag); s->idiag = NULL;
+  free(s->fi); free(s->fj); free(s->fdiag); free(s->fa); s->fi = s->fj = s->fdiag = NULL; s->fa = NULL;
   if (s->sub) {
     for (int k = 0; k < s->nblocks; k++) { pc_free(&s->sub[k]); free(s->sbi[k]); free(s->sbj[k]); free(s->sba[k]); }
     free(s->sub); free(s->sbi); free(s->sbj); free(s->sba);
@@ -102,6 +184,7 @@ static void pc_free(solver *s) {
 static void pc_apply(solver *s, const double *x, double *y) {
   if (s->pc_type == ORC_PC_NONE) orc_vec_copy((size_t)s->n, x, y);
   else if (s->pc_type == ORC_PC_JACOBI) orc_vec_pointwise_mult((size_t)s->n, x, s->idiag, y);
+  else if (s->pc_type == ORC_PC_ILU) orc_ilu0_solve(s->n, s->fi, s->fj, s->fdiag, s->fa, x, y);   /* PCApply_ILU -> MatSolve */
   else {
     for (int k = 0; k < s->nblocks; k++) {
       solver *t = &s->sub[k];

@@ -1,0 +1,194 @@
+/* PCILU with zero fill on a sequential AIJ block: the reference's default preconditioner on one rank
+ * and its default sub-preconditioner under PCBJACOBI (src/ksp/pc/interface/precon.c:14-53).
+ *   set-up : MatILUFactorSymbolic_SeqAIJ_ilu0 + MatLUFactorNumeric_SeqAIJ (src/mat/impls/aij/seq/aijfact.c:1628, :461),
+ *            natural ordering, on the HOST copy of the matrix -- as the reference's own GPU back end does
+ *            (src/mat/impls/aij/seq/seqcusparse/aijcusparse.cu:192-445 factors on the CPU and solves on the GPU);
+ *            then a dependency-level analysis of L and U and one upload.
+ *   apply  : MatSolve_SeqAIJ_NaturalOrdering (aijfact.c:3126) as level-scheduled device kernels, one launch per level. */
+#include "petscimpl.h"
+
+typedef struct {
+  PetscInt n, nz;
+  PetscInt *bi, *bj, *bdiag; PetscScalar *ba;            /* host factors */
+  PetscInt *d_bi, *d_bj, *d_bdiag; PetscScalar *d_ba;    /* device copies */
+  PetscInt nlevL, nlevU, *levptrL, *levptrU;             /* level pointers (host) */
+  PetscInt *d_rowsL, *d_rowsU;                           /* rows ordered by level (device) */
+  int factored_state;
+} PC_ILU;
+
+static PetscErrorCode ilu_free(PC_ILU *f) {
+  free(f->bi); free(f->bj); free(f->bdiag); free(f->ba); free(f->levptrL); free(f->levptrU);
+  if (f->d_bi) mi355x_free(f->d_bi);
+  if (f->d_bj) mi355x_free(f->d_bj);
+  if (f->d_bdiag) mi355x_free(f->d_bdiag);
+  if (f->d_ba) mi355x_free(f->d_ba);
+  if (f->d_rowsL) mi355x_free(f->d_rowsL);
+  if (f->d_rowsU) mi355x_free(f->d_rowsU);
+  memset(f, 0, sizeof(*f));
+  f->factored_state = -1;
+  return 0;
+}
+
+/* rows sorted by dependency level (stable: ascending row inside a level) */
+static PetscErrorCode level_order(PetscInt n, const PetscInt *lev, PetscInt nlev, PetscInt **ptr_out, PetscInt **rows_out) {
+  PetscErrorCode ierr;
+  PetscInt *ptr, *rows, *next;
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)(nlev + 1), &ptr);CHKERRQ(ierr);
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)PetscMax(n, 1), &rows);CHKERRQ(ierr);
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)(nlev + 1), &next);CHKERRQ(ierr);
+  memset(ptr, 0, sizeof(PetscInt) * (size_t)(nlev + 1));
+  for (PetscInt i = 0; i < n; i++) ptr[lev[i] + 1]++;
+  for (PetscInt l = 0; l < nlev; l++) ptr[l + 1] += ptr[l];
+  memcpy(next, ptr, sizeof(PetscInt) * (size_t)(nlev + 1));
+  for (PetscInt i = 0; i < n; i++) rows[next[lev[i]]++] = i;
+  free(next);
+  *ptr_out = ptr; *rows_out = rows;
+  return 0;
+}
+
+static PetscErrorCode PCSetUp_ILU(PC pc) {
+  PetscErrorCode ierr;
+  PC_ILU *f = (PC_ILU *)pc->data;
+  Mat A = pc->pmat;
+  PetscInt n; const PetscInt *ai, *aj; const PetscScalar *aa;
+  PetscDeviceCtx *dc;
+  if (strcmp(A->type_name, MATSEQAIJHIPMI355X)) SETERRQ(pc->comm, PETSC_ERR_SUP, "PCILU needs a sequential AIJ matrix (use -pc_type bjacobi -sub_pc_type ilu in parallel); got %s", A->type_name);
+  if (f->factored_state == A->state && f->d_ba) return 0;
+  ierr = MatSeqAIJGetArrays(A, &n, &ai, &aj, &aa);CHKERRQ(ierr);
+  if (A->rmap->n != A->cmap->n) SETERRQ(pc->comm, PETSC_ERR_ARG_WRONG, "Must be square matrix, rows %d columns %d", A->rmap->n, A->cmap->n);
+  ierr = ilu_free(f);CHKERRQ(ierr);
+  f->n = n; f->nz = ai[n];
+  PetscInt *adiag;
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)PetscMax(n, 1), &adiag);CHKERRQ(ierr);
+  for (PetscInt i = 0; i < n; i++) {
+    adiag[i] = -1;
+    for (PetscInt q = ai[i]; q < ai[i + 1]; q++) if (aj[q] == i) { adiag[i] = q; break; }
+    if (adiag[i] < 0) SETERRQ(pc->comm, PETSC_ERR_ARG_WRONGSTATE, "Matrix is missing diagonal entry %d", i);
+  }
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)(n + 1), &f->bi);CHKERRQ(ierr);
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)(f->nz + 1), &f->bj);CHKERRQ(ierr);
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)(n + 1), &f->bdiag);CHKERRQ(ierr);
+  ierr = PetscMalloc(sizeof(PetscScalar) * (size_t)(f->nz + 1), &f->ba);CHKERRQ(ierr);
+  memset(f->ba, 0, sizeof(PetscScalar) * (size_t)(f->nz + 1));
+  /* symbolic: the pattern of A, L part forward, U part from the last row backwards (aijfact.c:1660-1685) */
+  PetscInt k = 0, *bi = f->bi, *bj = f->bj, *bdiag = f->bdiag; PetscScalar *ba = f->ba;
+  bi[0] = 0;
+  for (PetscInt i = 0; i < n; i++) {
+    PetscInt nzl = adiag[i] - ai[i];
+    bi[i + 1] = bi[i] + nzl;
+    for (PetscInt j = 0; j < nzl; j++) bj[k++] = aj[ai[i] + j];
+  }
+  bdiag[n] = bi[n] - 1;
+  for (PetscInt i = n - 1; i >= 0; i--) {
+    PetscInt nzu = ai[i + 1] - adiag[i] - 1;
+    for (PetscInt j = 0; j < nzu; j++) bj[k++] = aj[adiag[i] + 1 + j];
+    bj[k++] = i;
+    bdiag[i] = bdiag[i + 1] + nzu + 1;
+  }
+  /* numeric (aijfact.c:505-570): row by row with a dense work row; pivots are stored inverted */
+  PetscScalar *rtmp;
+  ierr = PetscMalloc(sizeof(PetscScalar) * (size_t)(n + 1), &rtmp);CHKERRQ(ierr);
+  const PetscReal zeropivot = 100.0 * 2.220446049250313e-16;   /* ilu.c:389 */
+  for (PetscInt i = 0; i < n; i++) {
+    PetscInt nzl = bi[i + 1] - bi[i], nzu = bdiag[i] - bdiag[i + 1];
+    PetscReal rs = 0.0;
+    for (PetscInt j = 0; j < nzl; j++) rtmp[bj[bi[i] + j]] = 0.0;
+    for (PetscInt j = 0; j < nzu; j++) rtmp[bj[bdiag[i + 1] + 1 + j]] = 0.0;
+    for (PetscInt q = ai[i]; q < ai[i + 1]; q++) rtmp[aj[q]] = aa[q];
+    for (PetscInt kk = 0; kk < nzl; kk++) {
+      const PetscInt row = bj[bi[i] + kk];
+      PetscScalar *pc_ = rtmp + row;
+      if (*pc_ != 0.0) {
+        const PetscScalar multiplier = *pc_ * ba[bdiag[row]];
+        *pc_ = multiplier;
+        const PetscInt *pj = bj + bdiag[row + 1] + 1;
+        const PetscScalar *pv = ba + bdiag[row + 1] + 1;
+        const PetscInt nz = bdiag[row] - bdiag[row + 1] - 1;
+        for (PetscInt j = 0; j < nz; j++) rtmp[pj[j]] -= multiplier * pv[j];
+      }
+    }
+    for (PetscInt j = 0; j < nzl; j++) { ba[bi[i] + j] = rtmp[bj[bi[i] + j]]; rs += PetscAbsScalar(ba[bi[i] + j]); }
+    for (PetscInt j = 0; j < nzu - 1; j++) { ba[bdiag[i + 1] + 1 + j] = rtmp[bj[bdiag[i + 1] + 1 + j]]; rs += PetscAbsScalar(ba[bdiag[i + 1] + 1 + j]); }
+    /* MatPivotCheck: the reference would shift (MAT_SHIFT_NONZERO); a shift-free factorisation is what is ported */
+    if (PetscAbsScalar(rtmp[i]) <= zeropivot * rs) { free(rtmp); free(adiag); SETERRQ(pc->comm, 71 /* PETSC_ERR_MAT_LU_ZRPVT */, "Zero pivot row %d value %g tolerance %g * rs %g (pivot shifting is outside the ported path)", i, PetscAbsScalar(rtmp[i]), zeropivot, rs); }
+    ba[bdiag[i]] = 1.0 / rtmp[i];
+  }
+  free(rtmp); free(adiag);
+  /* dependency levels: a row may start once the rows it references are done */
+  PetscInt *lev, *rowsL, *rowsU;
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)PetscMax(n, 1), &lev);CHKERRQ(ierr);
+  f->nlevL = 0;
+  for (PetscInt i = 0; i < n; i++) {
+    PetscInt l = 0;
+    for (PetscInt q = bi[i]; q < bi[i + 1]; q++) l = PetscMax(l, lev[bj[q]] + 1);
+    lev[i] = l; f->nlevL = PetscMax(f->nlevL, l + 1);
+  }
+  ierr = level_order(n, lev, f->nlevL, &f->levptrL, &rowsL);CHKERRQ(ierr);
+  f->nlevU = 0;
+  for (PetscInt i = n - 1; i >= 0; i--) {
+    PetscInt l = 0, s0 = bdiag[i + 1] + 1, nz = bdiag[i] - bdiag[i + 1] - 1;
+    for (PetscInt q = 0; q < nz; q++) l = PetscMax(l, lev[bj[s0 + q]] + 1);
+    lev[i] = l; f->nlevU = PetscMax(f->nlevU, l + 1);
+  }
+  ierr = level_order(n, lev, f->nlevU, &f->levptrU, &rowsU);CHKERRQ(ierr);
+  free(lev);
+  ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
+  CHKHIP(mi355x_malloc((void **)&f->d_bi, sizeof(PetscInt) * (size_t)(n + 1)));
+  CHKHIP(mi355x_malloc((void **)&f->d_bj, sizeof(PetscInt) * (size_t)(f->nz + 1)));
+  CHKHIP(mi355x_malloc((void **)&f->d_bdiag, sizeof(PetscInt) * (size_t)(n + 1)));
+  CHKHIP(mi355x_malloc((void **)&f->d_ba, sizeof(PetscScalar) * (size_t)(f->nz + 1)));
+  CHKHIP(mi355x_malloc((void **)&f->d_rowsL, sizeof(PetscInt) * (size_t)PetscMax(n, 1)));
+  CHKHIP(mi355x_malloc((void **)&f->d_rowsU, sizeof(PetscInt) * (size_t)PetscMax(n, 1)));
+  CHKHIP(mi355x_memcpy_h2d(dc->h, f->d_bi, bi, sizeof(PetscInt) * (size_t)(n + 1)));
+  CHKHIP(mi355x_memcpy_h2d(dc->h, f->d_bj, bj, sizeof(PetscInt) * (size_t)(f->nz + 1)));
+  CHKHIP(mi355x_memcpy_h2d(dc->h, f->d_bdiag, bdiag, sizeof(PetscInt) * (size_t)(n + 1)));
+  CHKHIP(mi355x_memcpy_h2d(dc->h, f->d_ba, ba, sizeof(PetscScalar) * (size_t)(f->nz + 1)));
+  CHKHIP(mi355x_memcpy_h2d(dc->h, f->d_rowsL, rowsL, sizeof(PetscInt) * (size_t)n));
+  CHKHIP(mi355x_memcpy_h2d(dc->h, f->d_rowsU, rowsU, sizeof(PetscInt) * (size_t)n));
+  CHKHIP(mi355x_handle_synchronize(dc->h));
+  free(rowsL); free(rowsU);
+  f->factored_state = A->state;
+  return 0;
+}
+
+static PetscErrorCode PCApply_ILU(PC pc, Vec x, Vec y) {   /* PCApply_ILU -> MatSolve(fact, x, y) */
+  PetscErrorCode ierr;
+  PC_ILU *f = (PC_ILU *)pc->data;
+  const PetscScalar *db; PetscScalar *dx; PetscDeviceCtx *dc;
+  ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
+  ierr = VecHIPGetRead(x, &db);CHKERRQ(ierr);
+  ierr = VecHIPGetWrite(y, &dx);CHKERRQ(ierr);
+  for (PetscInt l = 0; l < f->nlevL; l++)
+    CHKHIP(mi355x_ilu0_lower_level(dc->h, f->levptrL[l + 1] - f->levptrL[l], f->d_rowsL + f->levptrL[l], f->d_bi, f->d_bj, f->d_ba, db, dx));
+  for (PetscInt l = 0; l < f->nlevU; l++)
+    CHKHIP(mi355x_ilu0_upper_level(dc->h, f->levptrU[l + 1] - f->levptrU[l], f->d_rowsU + f->levptrU[l], f->d_bj, f->d_ba, f->d_bdiag, dx));
+  ierr = VecHIPRestoreWrite(y);CHKERRQ(ierr);
+  PetscObjectStateIncrease(y);
+  ierr = PetscLogFlops(2.0 * f->nz - f->n);CHKERRQ(ierr);
+  return 0;
+}
+
+static PetscErrorCode PCDestroy_ILU(PC pc) {
+  PC_ILU *f = (PC_ILU *)pc->data;
+  if (f) { ilu_free(f); free(f); pc->data = NULL; }
+  return 0;
+}
+
+PetscErrorCode PCCreate_ILU(PC pc) {
+  PC_ILU *f;
+  PetscErrorCode ierr = PetscMalloc(sizeof(*f), &f);CHKERRQ(ierr);
+  memset(f, 0, sizeof(*f));
+  f->factored_state = -1;
+  pc->data = f;
+  pc->ops->setup = PCSetUp_ILU; pc->ops->apply = PCApply_ILU; pc->ops->destroy = PCDestroy_ILU;
+  return 0;
+}
+
+/* levels of the two triangular solves (for tests / DESIGN.md) */
+PetscErrorCode PCILUGetLevels_HIPMI355X(PC pc, PetscInt *nlevL, PetscInt *nlevU) {
+  if (strcmp(pc->type_name, "ilu")) SETERRQ(pc->comm, PETSC_ERR_ARG_WRONG, "not a PCILU");
+  PC_ILU *f = (PC_ILU *)pc->data;
+  if (nlevL) *nlevL = f->nlevL;
+  if (nlevU) *nlevU = f->nlevU;
+  return 0;
+}

@@ -12,7 +12,7 @@ PetscErrorCode PCCreate(MPI_Comm comm, PC *newpc) {
   return 0;
 }
 static struct { const char *name; PetscErrorCode (*fn)(PC); } pc_types[] = {
-  {PCNONE, PCCreate_None}, {PCJACOBI, PCCreate_Jacobi}, {PCBJACOBI, PCCreate_BJacobi}, {NULL, NULL}};
+  {PCNONE, PCCreate_None}, {PCJACOBI, PCCreate_Jacobi}, {PCBJACOBI, PCCreate_BJacobi}, {PCILU, PCCreate_ILU}, {NULL, NULL}};
 
 PetscErrorCode PCSetType(PC pc, PCType type) {
   PetscErrorCode ierr;
@@ -28,7 +28,7 @@ PetscErrorCode PCSetType(PC pc, PCType type) {
       return 0;
     }
   }
-  SETERRQ(pc->comm, PETSC_ERR_ARG_UNKNOWN_TYPE, "Unable to find requested PC type %s (ported: none, jacobi, bjacobi)", type);
+  SETERRQ(pc->comm, PETSC_ERR_ARG_UNKNOWN_TYPE, "Unable to find requested PC type %s (ported: none, jacobi, bjacobi, ilu)", type);
 }
 PetscErrorCode PCGetType(PC pc, PCType *type) { *type = pc->type_name; return 0; }
 PetscErrorCode PCSetOperators(PC pc, Mat Amat, Mat Pmat, MatStructure flag) {
@@ -51,9 +51,10 @@ PetscErrorCode PCSetUp(PC pc) {   /* precon.c:~800 */
   if (pc->setupcalled > 1) return 0;
   if (!pc->mat) SETERRQ(pc->comm, PETSC_ERR_ARG_WRONGSTATE, "Matrix must be set first");
   if (!pc->type_name[0]) {
-    /* PCGetDefaultType_Private (precon.c:14-53) picks ILU / block Jacobi+ILU; factorisations are a
-     * "next" row, so the default here is (block) Jacobi with a Jacobi sub-solve */
-    ierr = PCSetType(pc, pc->comm->size == 1 ? PCJACOBI : PCBJACOBI);CHKERRQ(ierr);
+    /* PCGetDefaultType_Private (precon.c:14-53): ILU on one process (when the matrix can be factored, i.e.
+     * sequential AIJ here), block Jacobi on several */
+    if (pc->comm->size > 1) { ierr = PCSetType(pc, PCBJACOBI);CHKERRQ(ierr); }
+    else { ierr = PCSetType(pc, !strcmp(pc->pmat->type_name, MATSEQAIJHIPMI355X) ? PCILU : PCJACOBI);CHKERRQ(ierr); }
   }
   if (pc->ops->setup) { ierr = (*pc->ops->setup)(pc);CHKERRQ(ierr); }
   pc->setupcalled = 2;
@@ -143,8 +144,8 @@ static PetscErrorCode PCSetUp_BJacobi(PC pc) {   /* PCSetUp_BJacobi_Singleblock,
     snprintf(prefix, sizeof(prefix), "%ssub_", pc->prefix);
     ierr = KSPSetOptionsPrefix(bj->ksp, prefix);CHKERRQ(ierr);
     ierr = KSPGetPC(bj->ksp, &subpc);CHKERRQ(ierr);
-    /* reference default sub-PC is ILU(0) (precon.c:14-53), a "next" row; Jacobi keeps the sub-solve on the device */
-    ierr = PCSetType(subpc, PCJACOBI);CHKERRQ(ierr);
+    /* the sub-PC defaults to ILU(0) like the reference's (precon.c:14-53, PCSetUp of the sub-KSP) */
+    ierr = PCSetType(subpc, PCILU);CHKERRQ(ierr);
     ierr = VecCreateSeqHIPMI355X(PETSC_COMM_SELF, bj->block->rmap->n, &bj->x);CHKERRQ(ierr);
     ierr = VecCreateSeqHIPMI355X(PETSC_COMM_SELF, bj->block->rmap->n, &bj->y);CHKERRQ(ierr);
   }

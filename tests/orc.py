@@ -204,6 +204,23 @@ def scatter_create(size, rank, ranges, garrays):
                 lto=lto[:nl].copy(), lfrom=lfrom[:nl].copy())
 
 
+def ilu0_factor(ai, aj, aa):
+    n = ai.size - 1
+    nz = int(ai[-1])
+    bi = np.zeros(n + 1, dtype=np.int32); bj = np.zeros(nz + 1, dtype=np.int32)
+    bd = np.zeros(n + 1, dtype=np.int32); ba = np.zeros(nz + 1)
+    rc = lib().orc_ilu0_factor(C.c_int(n), I(ai), I(aj), D(aa), I(bi), I(bj), I(bd), D(ba))
+    assert rc == 0
+    return bi, bj, bd, ba
+
+
+def ilu0_solve(f, b):
+    bi, bj, bd, ba = f
+    x = np.zeros(b.size)
+    lib().orc_ilu0_solve(C.c_int(b.size), I(bi), I(bj), I(bd), D(ba), D(b), D(x))
+    return x
+
+
 # ---- KSP ----
 class KspOpts(C.Structure):
     _fields_ = [("ksp_type", C.c_int), ("pc_type", C.c_int), ("rtol", C.c_double), ("abstol", C.c_double),
@@ -214,7 +231,7 @@ class KspOpts(C.Structure):
 
 
 KSP = dict(cg=0, gmres=1, bcgs=2, preonly=3)
-PC = dict(none=0, jacobi=1, bjacobi=2)
+PC = dict(none=0, jacobi=1, bjacobi=2, ilu=3)
 
 
 def ksp_solve(ai, aj, aa, b, ksp="gmres", pc="none", x0=None, blocks=None, sub_ksp="preonly", sub_pc="jacobi", **kw):

@@ -284,6 +284,41 @@ def test_ksp_golden_ex3_ex2f_ex9(P):
         assert np.linalg.norm(x - u) < 1e-4
 
 
+def test_ilu0_apply_bitexact_and_golden(P):
+    """PCILU (ILU(0), natural ordering).  The level-scheduled device solve reproduces
+    MatSolve_SeqAIJ_NaturalOrdering bit for bit (one lane per row, products subtracted in column order), and with NO
+    -pc_type option a one-rank solve picks ILU like the reference: ex2 -m 5 -n 5 refine_always == ex2_1.out."""
+    L = P.lib()
+    for ai, aj, aa in (pb.lap2d(9, 7), P.gen_poisson7(7, 6, 5)):
+        n = ai.size - 1
+        aa = aa * (1.0 + 0.05 * np.sin(np.arange(aa.size)))
+        A = P.Mat.from_csr(ai, aj, aa)
+        pc = C.c_void_p()
+        k = P.KSP(comm=L.COMM_SELF); k.set_operators(A); L.KSPGetPC(k.h, C.byref(pc)); L.PCSetType(pc, b"ilu")
+        bvec = rnd(n, 77)
+        vb, vx = V(P, bvec), V(P, np.zeros(n))
+        L.raw("PCSetUp")(pc); L.raw("PCApply")(pc, vb.h, vx.h)
+        ref = orc.ilu0_solve(orc.ilu0_factor(ai, aj, aa), bvec)
+        assert np.array_equal(bits(vx.array()), bits(ref))
+        nl, nu = C.c_int(), C.c_int()
+        L.PCILUGetLevels_HIPMI355X(pc, C.byref(nl), C.byref(nu))
+        assert nl.value == nu.value and nl.value > 1
+    ai, aj, aa = pb.lap2d(5, 5)
+    u = np.ones(25)
+    b = orc.spmv(ai, aj, aa, u)
+    gold = pb.parse_monitor(os.path.join(G, "ksp_tutorials", "ex2_1.out"))[0]
+    A = P.Mat.from_csr(ai, aj, aa)
+    k = P.KSP(comm=L.COMM_SELF); k.set_operators(A)
+    L.PetscOptionsClear(); L.PetscOptionsInsertString(b"-ksp_gmres_cgs_refinement_type refine_always")
+    k.set_tolerances(rtol=1e-2 / 36, abstol=1e-50)
+    k.set_from_options(); k.record_history()
+    vb, vx = V(P, b), V(P, np.zeros(25))
+    k.solve(vb, vx)
+    L.PetscOptionsClear()
+    pb.check_monitor(k.history(), gold)
+    assert k.its == 4 and "%.5g" % np.linalg.norm(vx.array() - u) in ("0.0003927", "0.00039270")
+
+
 def test_ksp_bjacobi_single_block_golden(P):
     """ex2_bjacobi.out: one block, sub-KSP GMRES + Jacobi (-sub_ksp_type gmres -sub_pc_type jacobi); device-side aliasing
     of the work vectors instead of the reference's host VecPlaceArray round trip"""
@@ -298,7 +333,7 @@ def test_ksp_bjacobi_single_block_golden(P):
 
 
 @pytest.mark.parametrize("ksp", ["cg", "gmres", "bcgs"])
-@pytest.mark.parametrize("pc", ["none", "jacobi", "bjacobi"])
+@pytest.mark.parametrize("pc", ["none", "jacobi", "bjacobi", "ilu"])
 def test_ksp_vs_oracle_p7(P, ksp, pc):
     """every solver x preconditioner of the north star on a 3-D 7-pt operator with varying coefficients"""
     ai, aj, aa = P.gen_poisson7(12, 11, 10)
@@ -309,7 +344,7 @@ def test_ksp_vs_oracle_p7(P, ksp, pc):
     b = orc.spmv(ai, aj, aa, np.cos(0.1 * np.arange(n)))
     kw = dict(rtol=1e-8)
     x, h, its, reason = solve(P, ai, aj, aa, b, ksp, pc, opts="-ksp_gmres_restart 20", **kw)
-    okw = dict(blocks=[0, n], sub_ksp="preonly", sub_pc="jacobi") if pc == "bjacobi" else {}
+    okw = dict(blocks=[0, n], sub_ksp="preonly", sub_pc="ilu") if pc == "bjacobi" else {}   # default sub-PC = ILU(0)
     xr, hr, itsr, rr = orc.ksp_solve(ai, aj, aa, b, ksp=ksp, pc=pc, rtol=1e-8, restart=20, **okw)
     k = min(len(h), len(hr))
     if ksp == "bcgs":

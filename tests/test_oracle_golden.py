@@ -144,3 +144,23 @@ def test_inode_detection_and_variant():
     y0, y1 = orc.spmv(ai, aj, aa, x), orc.spmv_inode(ai, aj, aa, x)
     scale = np.zeros(m); np.add.at(scale, np.repeat(np.arange(m), np.diff(ai)), np.abs(aa * x[aj]))
     assert np.all(np.abs(y0 - y1) <= 1e-13 * scale) and not np.array_equal(y0, y1)   # same product, different rounding
+
+
+def test_tutorial_ex2_gmres_ilu0():
+    """ex2 -m 5 -n 5 refine_always with the reference's DEFAULT preconditioners (makefile:317-326):
+    ex2_1.out = 1 rank, GMRES + ILU(0); ex2_2.out = 2 ranks, GMRES + block Jacobi with ILU(0) on each
+    diagonal block (13 + 12 rows).  Pins MatILUFactorSymbolic_ilu0 / MatLUFactorNumeric / MatSolve."""
+    ai, aj, aa = pb.lap2d(5, 5)
+    u = np.ones(25)
+    b = orc.spmv(ai, aj, aa, u)
+    os.makedirs(os.path.join(G, "ksp_tutorials"), exist_ok=True)
+    rtol = 1e-2 / 36
+    gold = pb.parse_monitor(os.path.join(G, "ksp_tutorials", "ex2_1.out"))[0]
+    x, h, its, reason = orc.ksp_solve(ai, aj, aa, b, ksp="gmres", pc="ilu", refine_always=1, rtol=rtol, abstol=1e-50)
+    pb.check_monitor(h, gold)
+    assert its == 4 and "%g" % np.linalg.norm(x - u) == "0.000392701"
+    gold = pb.parse_monitor(os.path.join(G, "ksp_tutorials", "ex2_2.out"))[0]
+    x, h, its, reason = orc.ksp_solve(ai, aj, aa, b, ksp="gmres", pc="bjacobi", blocks=[0, 13, 25], sub_ksp="preonly", sub_pc="ilu",
+                                      refine_always=1, rtol=rtol, abstol=1e-50)
+    pb.check_monitor(h, gold)
+    assert its == 7 and "%g" % np.linalg.norm(x - u) == "0.000292349"

@@ -83,6 +83,29 @@ def main():
     ok6 = np.array_equal(vy.array().view(np.uint64), reft.view(np.uint64))
     print("rank %d/%d: irregular MatMult bitexact=%s MatMultTranspose bitexact=%s" % (rank, world, ok5, ok6), flush=True)
     ok1 = ok1 and ok5 and ok6
+    # ---- reference golden on 2 ranks: ex2 -m 5 -n 5 -ksp_gmres_cgs_refinement_type refine_always with NO pc option =
+    # GMRES + block Jacobi + ILU(0) per rank (13 + 12 rows) == src/ksp/ksp/examples/tutorials/output/ex2_2.out
+    if world == 2:
+        import problems as pb
+        gi2, gj2, ga2 = pb.lap2d(5, 5)
+        split = [0, 13, 25]
+        r0_, r1_ = split[rank], split[rank + 1]
+        li2 = (gi2[r0_:r1_ + 1] - gi2[r0_]).astype(np.int32)
+        E = P.Mat.from_csr_mpi(li2, gj2[gi2[r0_]:gi2[r1_]].copy(), ga2[gi2[r0_]:gi2[r1_]].copy(), r1_ - r0_, 25, 25, comm=comm)
+        ue = P.Vec.create(r1_ - r0_, N=25, comm=comm); L.VecSet(ue.h, 1.0)
+        be, xe = ue.duplicate(), ue.duplicate()
+        E.mult(ue, be)
+        ke = P.KSP(comm=comm); ke.set_operators(E)
+        L.PetscOptionsClear(); L.PetscOptionsInsertString(b"-ksp_gmres_cgs_refinement_type refine_always")
+        ke.set_tolerances(rtol=1e-2 / 36, abstol=1e-50); ke.set_from_options(); ke.record_history()
+        ke.solve(be, xe)
+        L.PetscOptionsClear()
+        gold = pb.parse_monitor(os.path.join(ROOT, "tests", "golden", "ksp_tutorials", "ex2_2.out"))[0]
+        pb.check_monitor(ke.history(), gold)
+        L.VecAXPY(xe.h, -1.0, ue.h)
+        okg = ke.its == 7 and "%.5g" % xe.norm() in ("0.00029235", "0.00029234")
+        print("rank %d/%d: golden ex2_2.out (GMRES + bjacobi + ILU(0), 2 ranks) its=%d ok=%s" % (rank, world, ke.its, okg), flush=True)
+        ok1 = ok1 and okg
     print("rank %d/%d: MatMult bitexact=%s MatMultTranspose=%s norm=%s CG its=%d (oracle %d) hist=%s" % (rank, world, ok1, ok2, ok3, k.its, itsr, ok4), flush=True)
     dist.barrier()
     dist.destroy_process_group()
