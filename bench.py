@@ -150,13 +150,14 @@ def main():
         fs = ws = None
         with open(os.path.join(ROOT, "profiles", "r01_bench_pmc_summary.csv")) as f:
             for row in csv.DictReader(f):
-                if "spmv_csr_rowblock_kernel<false, false, true>" in row["kernel"]:
+                if "spmv_csr_rowblock" in row["kernel"] and "<true" not in row["kernel"]:   # the y = A x instantiation
                     if row["counter"] == "FETCH_SIZE":
                         fs = float(row["avg_value_KB"])
                     elif row["counter"] == "WRITE_SIZE":
                         ws = float(row["avg_value_KB"])
         if fs is not None and ws is not None and n == 256 and world == 1:
             out["roofline"]["traffic"] = int((2.0 * fs + ws) * 1024)
+            out["roofline"]["kernel"] = "spmv_csr_rowblock_idx8_kernel (CSR + 1-byte offset-dictionary column indices; 'achieved' uses the CSR algorithmic bytes, 'traffic' is what the kernel actually moved)"
             out["roofline"]["traffic_source"] = "profiles/r01_bench_pmc_summary.csv (rocprofv3 --pmc, separate passes; bytes per launch)"
     except Exception:
         pass
