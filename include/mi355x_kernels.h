@@ -40,6 +40,9 @@ int  mi355x_device_synchronize(void);
 int  mi355x_handle_create(mi355x_handle_t *h);
 int  mi355x_handle_destroy(mi355x_handle_t h);
 int  mi355x_handle_synchronize(mi355x_handle_t h);
+/* wait for the last reduction written to the handle's pinned scratch (polls a completion word the kernel stores
+ * after the result; bounded, falls back to a stream synchronise) */
+int  mi355x_handle_wait_result(mi355x_handle_t h);
 void *mi355x_handle_stream(mi355x_handle_t h);           /* the raw hipStream_t */
 /* pinned, device-visible scratch of >= 64 doubles owned by the handle
  * (reduction results are written here by the device, read by the host

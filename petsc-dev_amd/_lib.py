@@ -23,6 +23,7 @@ KERNEL_API = {
     "mi355x_handle_create": [C.POINTER(vp)],
     "mi355x_handle_destroy": [vp],
     "mi355x_handle_synchronize": [vp],
+    "mi355x_handle_wait_result": [vp],
     "mi355x_handle_stream": [vp],
     "mi355x_handle_host_scratch": [vp],
     "mi355x_handle_device_scratch": [vp],

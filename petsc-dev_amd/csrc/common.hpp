@@ -30,6 +30,8 @@ struct mi355x_handle_s {
   unsigned int *ticket;       // arrival counter for the single-launch reductions
   double *host_scratch;       // pinned + mapped, MI355X_SCRATCH_DOUBLES
   double *dev_scratch;        // HBM, MI355X_SCRATCH_DOUBLES
+  unsigned long long seq;     // sequence number of the last reduction whose result goes to host_scratch
+  volatile unsigned long long *host_seq;  // pinned word the finishing workgroup stores that number to (after the result)
 };
 
 struct mi355x_event_s {

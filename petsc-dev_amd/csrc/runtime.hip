@@ -30,10 +30,13 @@ int mi355x_handle_create(mi355x_handle_t *out) {
   MI355X_TRY(hipMalloc((void **)&h->partials, sizeof(double) * MI355X_MAX_GRID * MI355X_MAX_RED));
   MI355X_TRY(hipMalloc((void **)&h->ticket, 256));
   MI355X_TRY(hipMemset(h->ticket, 0, 256));
-  MI355X_TRY(hipHostMalloc((void **)&h->host_scratch, sizeof(double) * MI355X_SCRATCH_DOUBLES, hipHostMallocMapped));
+  // +1 slot: the completion sequence word that lets the host poll instead of synchronising the stream
+  MI355X_TRY(hipHostMalloc((void **)&h->host_scratch, sizeof(double) * (MI355X_SCRATCH_DOUBLES + 8), hipHostMallocMapped | hipHostMallocCoherent));
   MI355X_TRY(hipMalloc((void **)&h->dev_scratch, sizeof(double) * MI355X_SCRATCH_DOUBLES));
   MI355X_TRY(hipMemset(h->dev_scratch, 0, sizeof(double) * MI355X_SCRATCH_DOUBLES));
-  memset(h->host_scratch, 0, sizeof(double) * MI355X_SCRATCH_DOUBLES);
+  memset(h->host_scratch, 0, sizeof(double) * (MI355X_SCRATCH_DOUBLES + 8));
+  h->host_seq = reinterpret_cast<volatile unsigned long long *>(h->host_scratch + MI355X_SCRATCH_DOUBLES);
+  h->seq = 0;
   MI355X_TRY(hipDeviceSynchronize());
   *out = h;
   return 0;
@@ -50,6 +53,19 @@ int mi355x_handle_destroy(mi355x_handle_t h) {
   return 0;
 }
 int mi355x_handle_synchronize(mi355x_handle_t h) { MI355X_TRY(hipStreamSynchronize(h->stream)); return 0; }
+
+// Wait for the most recent reduction that targeted the handle's pinned scratch: the finishing workgroup stores the
+// result and then the sequence number (system-scope release), so the host can poll a cache line instead of paying
+// a stream synchronisation.  Bounded: after ~2 ms of polling it falls back to hipStreamSynchronize.
+int mi355x_handle_wait_result(mi355x_handle_t h) {
+  const unsigned long long want = h->seq;
+  for (long spin = 0; spin < 2000000; ++spin) {
+    if (*h->host_seq == want) { __sync_synchronize(); return 0; }
+    __builtin_ia32_pause();
+  }
+  MI355X_TRY(hipStreamSynchronize(h->stream));
+  return 0;
+}
 void *mi355x_handle_stream(mi355x_handle_t h) { return (void *)h->stream; }
 double *mi355x_handle_host_scratch(mi355x_handle_t h) { return h->host_scratch; }
 double *mi355x_handle_device_scratch(mi355x_handle_t h) { return h->dev_scratch; }

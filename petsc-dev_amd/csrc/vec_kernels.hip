@@ -189,10 +189,20 @@ __device__ __forceinline__ void block_reduce_store(double (&acc)[NOUT], double *
   }
 }
 
+// After the result has been stored: make it visible to the host, then store the completion number the host polls.
+__device__ __forceinline__ void publish_to_host(unsigned long long *host_seq, unsigned long long seq) {
+  __syncthreads();                       // the result stores of lanes < NOUT are done
+  if (host_seq && threadIdx.x == 0) {
+    __threadfence_system();
+    __hip_atomic_store(host_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 // F::accum(i2 or i, acc): adds element contributions
 template <int NOUT, int MODE, class F>
 __global__ __launch_bounds__(MI355X_BLOCK) void reduce_kernel(F f, size_t n, int vec_ok, double *partials,
-                                                             unsigned int *ticket, double *out) {
+                                                             unsigned int *ticket, double *out,
+                                                             unsigned long long *host_seq, unsigned long long seq) {
   __shared__ double lds[MI355X_BLOCK / MI355X_WAVE][NOUT];
   __shared__ int is_last;
   const size_t tid = (size_t)blockIdx.x * MI355X_BLOCK + threadIdx.x;
@@ -209,6 +219,7 @@ __global__ __launch_bounds__(MI355X_BLOCK) void reduce_kernel(F f, size_t n, int
   }
   if (gridDim.x == 1) {  // single workgroup: no hand-off needed
     block_reduce_store<NOUT, MODE>(acc, out, lds);
+    publish_to_host(host_seq, seq);
     return;
   }
   block_reduce_store<NOUT, MODE, true>(acc, partials + (size_t)blockIdx.x * NOUT, lds);
@@ -242,14 +253,21 @@ __global__ __launch_bounds__(MI355X_BLOCK) void reduce_kernel(F f, size_t n, int
   __syncthreads();
   block_reduce_store<NOUT, MODE>(acc, out, lds);
   if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  publish_to_host(host_seq, seq);
 }
 
 template <int NOUT, int MODE, class F>
 static int launch_reduce(mi355x_handle_t h, F f, size_t n, int vec_ok, double *out) {
   int grid = mi355x_grid_for(n, 16);
   if (grid > 1024) grid = 1024;   // 4 workgroups per CU; the last one sums <= 1024 partials
+  // a result that goes to the handle's pinned scratch is followed by a completion number (mi355x_handle_wait_result)
+  unsigned long long *hs = nullptr, seq = 0;
+  if (out >= h->host_scratch && out < h->host_scratch + MI355X_SCRATCH_DOUBLES) {
+    hs = const_cast<unsigned long long *>(h->host_seq);
+    seq = ++h->seq;
+  }
   hipLaunchKernelGGL((reduce_kernel<NOUT, MODE, F>), dim3(grid), dim3(MI355X_BLOCK), 0, h->stream, f, n, vec_ok,
-                     h->partials, h->ticket, out);
+                     h->partials, h->ticket, out, hs, seq);
   MI355X_LAUNCH_CHECK();
   return 0;
 }

@@ -268,8 +268,12 @@ static PetscErrorCode reduce_finish(Vec x, PetscDeviceCtx *dc, int count, int is
     else CHKHIP(mi355x_comm_allreduce_sum(x->comm->dcomm, dc->h, ds, (size_t)count));
     /* device -> pinned host by a tiny kernel on the same stream (lower latency than a DMA copy of 8..256 bytes) */
     CHKHIP(mi355x_vec_copy(dc->h, (size_t)count, ds, hs));
+    CHKHIP(mi355x_handle_synchronize(dc->h));
+  } else {
+    /* one rank: the reduction kernel wrote the result and then a completion number to pinned memory; polling that
+     * word is cheaper than a stream synchronisation and lets the next launches go out at once */
+    CHKHIP(mi355x_handle_wait_result(dc->h));
   }
-  CHKHIP(mi355x_handle_synchronize(dc->h));
   for (int j = 0; j < count; j++) result[j] = hs[j];
   return 0;
 }
