@@ -66,6 +66,12 @@ int  mi355x_event_synchronize(mi355x_event_t e);
 int  mi355x_event_elapsed_ms(mi355x_event_t start, mi355x_event_t stop, float *ms);
 int  mi355x_handle_wait_event(mi355x_handle_t h, mi355x_event_t e);  /* hipStreamWaitEvent */
 
+/* hipGraph capture of whatever is enqueued on the handle between begin and end; replay with one call */
+int  mi355x_graph_capture_begin(mi355x_handle_t h);
+int  mi355x_graph_capture_end(mi355x_handle_t h, void **graph_exec);
+int  mi355x_graph_launch(mi355x_handle_t h, void *graph_exec);
+int  mi355x_graph_destroy(void *graph_exec);
+
 /* ---- Vec element-wise kernels (24-32 B/element, HBM-bound) ------------ */
 /* VecSet_Seq          src/vec/vec/impls/seq/dvec2.c:722      x[i] = alpha */
 int mi355x_vec_set(mi355x_handle_t h, size_t n, double alpha, double *x);

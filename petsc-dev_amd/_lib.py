@@ -27,6 +27,10 @@ KERNEL_API = {
     "mi355x_handle_stream": [vp],
     "mi355x_handle_host_scratch": [vp],
     "mi355x_handle_device_scratch": [vp],
+    "mi355x_graph_capture_begin": [vp],
+    "mi355x_graph_capture_end": [vp, C.POINTER(vp)],
+    "mi355x_graph_launch": [vp, vp],
+    "mi355x_graph_destroy": [vp],
     "mi355x_malloc": [C.POINTER(vp), sz],
     "mi355x_free": [vp],
     "mi355x_host_malloc": [C.POINTER(vp), sz],

@@ -126,4 +126,29 @@ int mi355x_handle_wait_event(mi355x_handle_t h, mi355x_event_t e) {
   return 0;
 }
 
+// ---- hipGraph capture of a launch-bound sequence on the handle's stream (e.g. the ~1500 level kernels of one
+// ILU(0) application): capture once, replay with one call.
+int mi355x_graph_capture_begin(mi355x_handle_t h) {
+  MI355X_TRY(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+  return 0;
+}
+int mi355x_graph_capture_end(mi355x_handle_t h, void **exec_out) {
+  hipGraph_t g = nullptr;
+  hipGraphExec_t e = nullptr;
+  MI355X_TRY(hipStreamEndCapture(h->stream, &g));
+  hipError_t rc = hipGraphInstantiate(&e, g, nullptr, nullptr, 0);
+  hipGraphDestroy(g);
+  if (rc != hipSuccess) return (int)rc;
+  *exec_out = (void *)e;
+  return 0;
+}
+int mi355x_graph_launch(mi355x_handle_t h, void *exec) {
+  MI355X_TRY(hipGraphLaunch((hipGraphExec_t)exec, h->stream));
+  return 0;
+}
+int mi355x_graph_destroy(void *exec) {
+  if (exec) MI355X_TRY(hipGraphExecDestroy((hipGraphExec_t)exec));
+  return 0;
+}
+
 }  // extern "C"

@@ -13,6 +13,9 @@ typedef struct {
   PetscInt *d_bi, *d_bj, *d_bdiag; PetscScalar *d_ba;    /* device copies */
   PetscInt nlevL, nlevU, *levptrL, *levptrU;             /* level pointers (host) */
   PetscInt *d_rowsL, *d_rowsU;                           /* rows ordered by level (device) */
+  PetscScalar *d_work;                                   /* fixed in-place buffer the captured graph works on */
+  void *graph;                                           /* hipGraphExec of the nlevL + nlevU level launches */
+  int graph_tried;
   int factored_state;
 } PC_ILU;
 
@@ -24,6 +27,8 @@ static PetscErrorCode ilu_free(PC_ILU *f) {
   if (f->d_ba) mi355x_free(f->d_ba);
   if (f->d_rowsL) mi355x_free(f->d_rowsL);
   if (f->d_rowsU) mi355x_free(f->d_rowsU);
+  if (f->d_work) mi355x_free(f->d_work);
+  if (f->graph) mi355x_graph_destroy(f->graph);
   memset(f, 0, sizeof(*f));
   f->factored_state = -1;
   return 0;
@@ -158,10 +163,32 @@ static PetscErrorCode PCApply_ILU(PC pc, Vec x, Vec y) {   /* PCApply_ILU -> Mat
   ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
   ierr = VecHIPGetRead(x, &db);CHKERRQ(ierr);
   ierr = VecHIPGetWrite(y, &dx);CHKERRQ(ierr);
-  for (PetscInt l = 0; l < f->nlevL; l++)
-    CHKHIP(mi355x_ilu0_lower_level(dc->h, f->levptrL[l + 1] - f->levptrL[l], f->d_rowsL + f->levptrL[l], f->d_bi, f->d_bj, f->d_ba, db, dx));
-  for (PetscInt l = 0; l < f->nlevU; l++)
-    CHKHIP(mi355x_ilu0_upper_level(dc->h, f->levptrU[l + 1] - f->levptrU[l], f->d_rowsU + f->levptrU[l], f->d_bj, f->d_ba, f->d_bdiag, dx));
+  /* The level launches are a launch-bound inner loop (766 + 766 kernels for P7(256)): with more than a handful of
+   * levels they are captured once into a hipGraph that works in place on a fixed buffer and replayed per
+   * application (copy in, one graph launch, copy out).  Same kernels, same order, same bits. */
+  if (!f->graph_tried && f->nlevL + f->nlevU > 16) {
+    f->graph_tried = 1;
+    if (!mi355x_malloc((void **)&f->d_work, sizeof(PetscScalar) * (size_t)PetscMax(f->n, 1)) && !mi355x_graph_capture_begin(dc->h)) {
+      int bad = 0;
+      for (PetscInt l = 0; l < f->nlevL && !bad; l++)
+        bad = mi355x_ilu0_lower_level(dc->h, f->levptrL[l + 1] - f->levptrL[l], f->d_rowsL + f->levptrL[l], f->d_bi, f->d_bj, f->d_ba, f->d_work, f->d_work);
+      for (PetscInt l = 0; l < f->nlevU && !bad; l++)
+        bad = mi355x_ilu0_upper_level(dc->h, f->levptrU[l + 1] - f->levptrU[l], f->d_rowsU + f->levptrU[l], f->d_bj, f->d_ba, f->d_bdiag, f->d_work);
+      void *g = NULL;
+      if (mi355x_graph_capture_end(dc->h, &g) || bad) g = NULL;   /* capture failed: stay with plain launches */
+      f->graph = g;
+    }
+  }
+  if (f->graph) {
+    CHKHIP(mi355x_vec_copy(dc->h, (size_t)f->n, db, f->d_work));
+    CHKHIP(mi355x_graph_launch(dc->h, f->graph));
+    CHKHIP(mi355x_vec_copy(dc->h, (size_t)f->n, f->d_work, dx));
+  } else {
+    for (PetscInt l = 0; l < f->nlevL; l++)
+      CHKHIP(mi355x_ilu0_lower_level(dc->h, f->levptrL[l + 1] - f->levptrL[l], f->d_rowsL + f->levptrL[l], f->d_bi, f->d_bj, f->d_ba, db, dx));
+    for (PetscInt l = 0; l < f->nlevU; l++)
+      CHKHIP(mi355x_ilu0_upper_level(dc->h, f->levptrU[l + 1] - f->levptrU[l], f->d_rowsU + f->levptrU[l], f->d_bj, f->d_ba, f->d_bdiag, dx));
+  }
   ierr = VecHIPRestoreWrite(y);CHKERRQ(ierr);
   PetscObjectStateIncrease(y);
   ierr = PetscLogFlops(2.0 * f->nz - f->n);CHKERRQ(ierr);
