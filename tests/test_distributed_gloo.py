@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.parametrize("world", [2, 4])
 def test_mpiaij_setup_gloo(built, world):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
-           "--master-addr", "127.0.0.1", "--master-port", str(29540 + world), os.path.join(ROOT, "tools", "gloo_setup_check.py")]
+           "--master-addr", "127.0.0.1", "--master-port", str(29540 + world), os.path.join(ROOT, "tests", "tools", "gloo_setup_check.py")]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, OMP_NUM_THREADS="1"))
     out = r.stdout + r.stderr
     assert r.returncode == 0, out[-3000:]

@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_mpiaij_two_ranks_one_gpu(built, nranks):
     env = dict(os.environ, MI355X_STAGED="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks),
-           "--master-addr", "127.0.0.1", "--master-port", str(29520 + nranks), os.path.join(ROOT, "tools", "rank2_trial.py"), "12"]
+           "--master-addr", "127.0.0.1", "--master-port", str(29520 + nranks), os.path.join(ROOT, "tests", "tools", "rank2_trial.py"), "12"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     out = r.stdout + r.stderr
     assert r.returncode == 0, out[-3000:]
