@@ -137,6 +137,7 @@ def main():
         "spmv_gbps": round(spmv_gbps_one * world, 1),
         "ksp_gbps": round(cg_bytes * its_per_s * world / 1e9, 1),
         "ksp_hbm_frac": round(cg_bytes * its_per_s / 8e12, 4),
+        "ksp_gbps_basis": "SURVEY 8(d) algorithmic bytes of the reference's op-by-op iteration (SpMV + 17 vector passes); the fused CG update moves 13 passes",
         "roofline": {"bound": "hbm", "kernel": "spmv_csr_rowblock_kernel", "achieved": round(spmv_gbps_one, 1), "peak": 8000.0,
                      "unit": "GB/s", "frac": round(spmv_gbps_one / 8000.0, 4), "traffic": None,
                      "algorithmic_bytes_per_launch": spmv_bytes, "avg_launch_ms": round(spmv_ms, 5), "launches_timed": nl.value},

@@ -118,6 +118,11 @@ int mi355x_vec_dot(mi355x_handle_t h, size_t n, const double *x, const double *y
 int mi355x_vec_norm(mi355x_handle_t h, size_t n, int type, const double *x, double *out);
 /* VecDotNorm2 (BiCGStab)  src/vec/vec/utils/vinv.c:1200   out[0] = sum s_i t_i, out[1] = sum t_i^2 */
 int mi355x_vec_dotnorm2(mi355x_handle_t h, size_t n, const double *s, const double *t, double *out);
+/* Fused CG update, one sweep for cg.c:206-232 + PCApply_Jacobi (jacobi.c:266-277):
+ * x += a p; r += (-a) w; z = r .* d; out[0] = sum z*z, out[1] = sum z*r.  Same bits as
+ * mi355x_vec_axpy x2, mi355x_vec_pointwise_mult, mi355x_vec_norm(2), mi355x_vec_dot in sequence. */
+int mi355x_vec_cg_update(mi355x_handle_t h, size_t n, double a, const double *p, const double *w, const double *d,
+                         double *x, double *r, double *z, double *out);
 /* VecMDot_Seq         src/vec/vec/impls/seq/dvec2.c:146     out[j] = sum_i x_i y_j,i , j<nv ; x read once per 8 y's */
 int mi355x_vec_mdot(mi355x_handle_t h, size_t n, int nv, const double *x, const double *const *y, double *out);
 /* VecSum / VecMax helpers are not on the Krylov path and are not provided. */

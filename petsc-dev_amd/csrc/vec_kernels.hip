@@ -358,6 +358,50 @@ struct DotNorm2F {
     a[0] += sv.y * tv.y; a[1] += tv.y * tv.y;
   }
 };
+// One CG update sweep (KSPSolve_CG cg.c:206-232 with PCApply_Jacobi jacobi.c:266-277 in between):
+//   x += a p ; r += (-a) w ; z = r .* d ; out = { sum z*z , sum z*r }
+// Element-wise arithmetic is that of the separate kernels (OpAxpy, OpAxpy, OpMul) and each lane meets its elements in
+// the same order as SumSqF / DotF do under launch_reduce, so x, r, z and both sums carry the same bits as the five
+// separate launches; HBM passes drop from 12 to 8.
+struct CGUpdateF {
+  double a, ma;
+  const double *p, *w, *d;
+  double *x, *r, *z;
+  template <int NOUT_>
+  __device__ __forceinline__ void sweep(size_t tid, size_t stride, size_t n2, double (&acc)[NOUT_]) const {
+    size_t i = tid;
+    for (; i + stride < n2; i += 2 * stride) {
+      const double2 *p2 = reinterpret_cast<const double2 *>(p), *w2 = reinterpret_cast<const double2 *>(w);
+      const double2 *d2 = reinterpret_cast<const double2 *>(d);
+      double2 *x2 = reinterpret_cast<double2 *>(x), *r2 = reinterpret_cast<double2 *>(r), *z2 = reinterpret_cast<double2 *>(z);
+      double2 pv0 = p2[i], pv1 = p2[i + stride], wv0 = w2[i], wv1 = w2[i + stride], dv0 = d2[i], dv1 = d2[i + stride];
+      double2 xv0 = x2[i], xv1 = x2[i + stride], rv0 = r2[i], rv1 = r2[i + stride], zv0, zv1;
+      step(pv0.x, wv0.x, dv0.x, xv0.x, rv0.x, zv0.x, acc); step(pv0.y, wv0.y, dv0.y, xv0.y, rv0.y, zv0.y, acc);
+      step(pv1.x, wv1.x, dv1.x, xv1.x, rv1.x, zv1.x, acc); step(pv1.y, wv1.y, dv1.y, xv1.y, rv1.y, zv1.y, acc);
+      x2[i] = xv0; r2[i] = rv0; z2[i] = zv0;
+      x2[i + stride] = xv1; r2[i + stride] = rv1; z2[i + stride] = zv1;
+    }
+    for (; i < n2; i += stride) {
+      double2 pv = reinterpret_cast<const double2 *>(p)[i], wv = reinterpret_cast<const double2 *>(w)[i];
+      double2 dv = reinterpret_cast<const double2 *>(d)[i];
+      double2 xv = reinterpret_cast<double2 *>(x)[i], rv = reinterpret_cast<double2 *>(r)[i], zv;
+      step(pv.x, wv.x, dv.x, xv.x, rv.x, zv.x, acc); step(pv.y, wv.y, dv.y, xv.y, rv.y, zv.y, acc);
+      reinterpret_cast<double2 *>(x)[i] = xv; reinterpret_cast<double2 *>(r)[i] = rv; reinterpret_cast<double2 *>(z)[i] = zv;
+    }
+  }
+  __device__ __forceinline__ void step(double pv, double wv, double dv, double &xv, double &rv, double &zv, double (&acc)[2]) const {
+    xv = xv + a * pv;
+    rv = rv + ma * wv;
+    zv = rv * dv;
+    acc[0] += zv * zv;
+    acc[1] += zv * rv;
+  }
+  __device__ void accum1(size_t i, double (&acc)[2]) const {
+    double xv = x[i], rv = r[i], zv;
+    step(p[i], w[i], d[i], xv, rv, zv, acc);
+    x[i] = xv; r[i] = rv; z[i] = zv;
+  }
+};
 template <int NV>
 struct MDotF {
   const double *x;
@@ -526,6 +570,13 @@ int mi355x_vec_norm(mi355x_handle_t h, size_t n, int type, const double *x, doub
 int mi355x_vec_dotnorm2(mi355x_handle_t h, size_t n, const double *s, const double *t, double *out) {
   DotNorm2F f{s, t};
   return launch_reduce<2, RED_SUM>(h, f, n, mi355x_aligned16(s) && mi355x_aligned16(t), out);
+}
+int mi355x_vec_cg_update(mi355x_handle_t h, size_t n, double a, const double *p, const double *w, const double *d,
+                         double *x, double *r, double *z, double *out) {
+  CGUpdateF f{a, -a, p, w, d, x, r, z};
+  int v = mi355x_aligned16(p) && mi355x_aligned16(w) && mi355x_aligned16(d) && mi355x_aligned16(x) && mi355x_aligned16(r) &&
+          mi355x_aligned16(z);
+  return launch_reduce<2, RED_SUM>(h, f, n, v, out);
 }
 int mi355x_vec_mdot(mi355x_handle_t h, size_t n, int nv, const double *x, const double *const *y, double *out) {
   int pos = 0;

@@ -8,7 +8,7 @@
 #include "petscimpl.h"
 
 /* ================================================================== CG */
-typedef struct { PetscBool singlereduction; } KSP_CG;   /* cgimpl.h */
+typedef struct { PetscBool singlereduction; PetscBool fused; } KSP_CG;   /* cgimpl.h; fused: see KSPSolve_CG */
 static PetscErrorCode KSPSetUp_CG(KSP ksp) {   /* cg.c:50-80 (no eigenvalue work): 3 work vectors, 5 with -ksp_cg_single_reduction */
   return KSPDefaultGetWork(ksp, ((KSP_CG *)ksp->data)->singlereduction ? 5 : 3);
 }
@@ -16,6 +16,8 @@ static PetscErrorCode KSPSetFromOptions_CG(KSP ksp) {   /* cg.c:330-345 */
   char t[16]; PetscBool set;
   PetscErrorCode ierr = PetscOptionsGetString(ksp->prefix, "-ksp_cg_single_reduction", t, sizeof(t), &set);CHKERRQ(ierr);
   if (set) ((KSP_CG *)ksp->data)->singlereduction = (PetscBool)(strcmp(t, "0") && strcmp(t, "false"));
+  ierr = PetscOptionsGetString(ksp->prefix, "-ksp_cg_fused", t, sizeof(t), &set);CHKERRQ(ierr);
+  if (set) ((KSP_CG *)ksp->data)->fused = (PetscBool)(strcmp(t, "0") && strcmp(t, "false"));
   return 0;
 }
 static PetscErrorCode KSPDestroy_CG(KSP ksp) { free(ksp->data); ksp->data = NULL; return 0; }
@@ -29,6 +31,12 @@ static PetscErrorCode KSPSolve_CG(KSP ksp) {
   Vec X = ksp->vec_sol, B = ksp->vec_rhs, R = ksp->work[0], Z = ksp->work[1], P = ksp->work[2];
   Vec S = single ? ksp->work[3] : NULL, W = single ? ksp->work[4] : Z;   /* cg.c:116-122 */
   Mat Amat = ksp->pc->mat;
+  /* Fused forms (default on, -ksp_cg_fused 0 turns them off; iterates and history are bit-identical either way):
+   * with PCJACOBI the two AXPYs, the PCApply, the norm and the dot of cg.c:206-232 are one sweep
+   * (VecCGUpdate_HIPMI355X); with any other PC the norm and the dot share one VecDotNorm2 reduction. */
+  const PetscBool fused = (PetscBool)(((KSP_CG *)ksp->data)->fused && !single);
+  Vec D = NULL;
+  if (fused) { ierr = PCJacobiGetInverseDiagonal_Private(ksp->pc, &D);CHKERRQ(ierr); }
 
   ksp->its = 0;
   if (!ksp->guess_zero) {
@@ -68,11 +76,18 @@ static PetscErrorCode KSPSolve_CG(KSP ksp) {
     if (PetscIsInfOrNanScalar(dpi)) SETERRQ(ksp->comm, PETSC_ERR_FP, "Infinite or not-a-number generated in dot product");
     if ((dpi == 0.0) || ((i > 0) && (dpi * dpiold <= 0.0))) { ksp->reason = KSP_DIVERGED_INDEFINITE_MAT; break; }
     a = beta / dpi;
-    ierr = VecAXPY(X, a, P);CHKERRQ(ierr);                       /* x <- x + ap */
-    ierr = VecAXPY(R, -a, W);CHKERRQ(ierr);                      /* r <- r - aw */
-    ierr = KSP_PCApply(ksp, R, Z);CHKERRQ(ierr);                 /* z <- Br */
-    if (single) { ierr = KSP_MatMult(ksp, Amat, Z, S);CHKERRQ(ierr); }   /* cg.c:217-219 */
-    ierr = VecNorm(Z, NORM_2, &dp);CHKERRQ(ierr);
+    PetscBool have_beta = PETSC_FALSE;
+    PetscScalar zz, zr;
+    if (fused && D) { ierr = VecCGUpdate_HIPMI355X(X, R, Z, P, W, D, a, &zz, &zr, &have_beta);CHKERRQ(ierr); }
+    if (!have_beta) {
+      ierr = VecAXPY(X, a, P);CHKERRQ(ierr);                     /* x <- x + ap */
+      ierr = VecAXPY(R, -a, W);CHKERRQ(ierr);                    /* r <- r - aw */
+      ierr = KSP_PCApply(ksp, R, Z);CHKERRQ(ierr);               /* z <- Br */
+      if (single) { ierr = KSP_MatMult(ksp, Amat, Z, S);CHKERRQ(ierr); }   /* cg.c:217-219 */
+      if (fused) { PetscReal n2; ierr = VecDotNorm2(R, Z, &zr, &n2);CHKERRQ(ierr); zz = n2; have_beta = PETSC_TRUE; }
+    }
+    if (have_beta) dp = PetscSqrtReal(zz);                        /* the square is reduced, then rooted (pvec2.c:62-64) */
+    else { ierr = VecNorm(Z, NORM_2, &dp);CHKERRQ(ierr); }
     ksp->rnorm = dp;
     KSPLogResidualHistory(ksp, dp);
     ierr = KSPMonitor(ksp, i + 1, dp);CHKERRQ(ierr);
@@ -83,7 +98,8 @@ static PetscErrorCode KSPSolve_CG(KSP ksp) {
       vecs[0] = S; vecs[1] = R;
       ierr = VecMDot(Z, 2, vecs, tmp);CHKERRQ(ierr);
       delta = tmp[0]; beta = tmp[1];
-    } else { ierr = VecTDot(Z, R, &beta);CHKERRQ(ierr); }        /* beta <- z'*r */
+    } else if (have_beta) beta = zr;
+    else { ierr = VecTDot(Z, R, &beta);CHKERRQ(ierr); }          /* beta <- z'*r */
     if (PetscIsInfOrNanScalar(beta)) SETERRQ(ksp->comm, PETSC_ERR_FP, "Infinite or not-a-number generated in dot product");
     i++;
   } while (i < ksp->max_it);
@@ -94,6 +110,7 @@ PetscErrorCode KSPCreate_CG(KSP ksp) {
   KSP_CG *cg;
   PetscErrorCode ierr = PetscMalloc(sizeof(*cg), &cg);CHKERRQ(ierr);
   cg->singlereduction = PETSC_FALSE;
+  cg->fused = PETSC_TRUE;
   ksp->data = cg;
   ksp->ops->setup = KSPSetUp_CG; ksp->ops->solve = KSPSolve_CG; ksp->ops->setfromoptions = KSPSetFromOptions_CG; ksp->ops->destroy = KSPDestroy_CG;
   return 0;

@@ -105,6 +105,15 @@ static PetscErrorCode PCApply_Jacobi(PC pc, Vec x, Vec y) {   /* jacobi.c:266-27
   PC_Jacobi *jac = (PC_Jacobi *)pc->data;
   return VecPointwiseMult(y, x, jac->diag);
 }
+/* for the fused CG update (krylov.c): the vector PCApply_Jacobi multiplies by, or NULL when pc is another type */
+PetscErrorCode PCJacobiGetInverseDiagonal_Private(PC pc, Vec *d) {
+  PetscErrorCode ierr;
+  *d = NULL;
+  if (!pc || pc->ops->apply != PCApply_Jacobi) return 0;
+  if (pc->setupcalled < 2) { ierr = PCSetUp(pc);CHKERRQ(ierr); }
+  *d = ((PC_Jacobi *)pc->data)->diag;
+  return 0;
+}
 static PetscErrorCode PCDestroy_Jacobi(PC pc) {
   PC_Jacobi *jac = (PC_Jacobi *)pc->data;
   if (jac) { PetscErrorCode ierr = VecDestroy(&jac->diag);CHKERRQ(ierr); free(jac); pc->data = NULL; }

@@ -132,6 +132,8 @@ PetscErrorCode VecHIPGetRead(Vec v, const PetscScalar **d);
 PetscErrorCode VecHIPGetWrite(Vec v, PetscScalar **d);       /* contents will be overwritten */
 PetscErrorCode VecHIPGetReadWrite(Vec v, PetscScalar **d);
 PetscErrorCode VecHIPRestoreWrite(Vec v);                    /* device newer; state++ */
+PetscErrorCode VecCGUpdate_HIPMI355X(Vec x, Vec r, Vec z, Vec p, Vec w, Vec d, PetscScalar a, PetscScalar *zz, PetscScalar *zr, PetscBool *done);
+PetscErrorCode PCJacobiGetInverseDiagonal_Private(PC pc, Vec *d);   /* NULL unless pc is a set-up PCJACOBI */
 
 /* ---- VecScatter (VecScatter_MPI_General, include/petsc-private/vecimpl.h:509-555) ---- */
 typedef struct {

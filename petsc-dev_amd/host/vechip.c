@@ -334,6 +334,34 @@ static PetscErrorCode VecDotNorm2_HIP(Vec s, Vec t, PetscScalar *dp, PetscScalar
   return 0;
 }
 
+/* Fused CG update for HIPMI355X vectors (KSPSolve_CG cg.c:206-232 with a Jacobi PCApply in the middle):
+ * x += a p; r -= a w; z = r .* d; *zz = z'z, *zr = z'r in one sweep and one reduction (one all-reduce of two
+ * doubles on several ranks instead of two of one).  Results carry the bits of the separate VecAXPY, VecAXPY,
+ * VecPointwiseMult, VecNorm, VecTDot calls.  Returns *done = PETSC_FALSE (and does nothing) when an operand is
+ * not a HIPMI355X vector, so the caller keeps the unfused sequence. */
+PetscErrorCode VecCGUpdate_HIPMI355X(Vec x, Vec r, Vec z, Vec p, Vec w, Vec d, PetscScalar a, PetscScalar *zz, PetscScalar *zr, PetscBool *done) {
+  PetscErrorCode ierr; const PetscScalar *dp_, *dw, *dd; PetscScalar *dx, *dr, *dz; double *out; PetscScalar res[2]; DEVCTX;
+  *done = PETSC_FALSE;
+  if (!is_hip(x) || !is_hip(r) || !is_hip(z) || !is_hip(p) || !is_hip(w) || !is_hip(d) || a == 0.0) return 0;
+  if (x->map->n != r->map->n || x->map->n != z->map->n || x->map->n != p->map->n || x->map->n != w->map->n || x->map->n != d->map->n) return 0;
+  if (x == r || x == z || r == z || z == p || z == d) return 0;   /* z may be w (cg.c:122 keeps A*p in Z) */
+  ierr = VecHIPGetRead(p, &dp_);CHKERRQ(ierr);
+  ierr = VecHIPGetRead(w, &dw);CHKERRQ(ierr);
+  ierr = VecHIPGetRead(d, &dd);CHKERRQ(ierr);
+  ierr = VecHIPGetReadWrite(x, &dx);CHKERRQ(ierr);
+  ierr = VecHIPGetReadWrite(r, &dr);CHKERRQ(ierr);
+  ierr = VecHIPGetWrite(z, &dz);CHKERRQ(ierr);
+  ierr = reduce_target(x, dc, &out);CHKERRQ(ierr);
+  CHKHIP(mi355x_vec_cg_update(dc->h, N_(x), a, dp_, dw, dd, dx, dr, dz, out));
+  VecHIPRestoreWrite(x); VecHIPRestoreWrite(r); VecHIPRestoreWrite(z);
+  PetscObjectStateIncrease(x); PetscObjectStateIncrease(r); PetscObjectStateIncrease(z);
+  ierr = reduce_finish(x, dc, 2, 0, res);CHKERRQ(ierr);
+  *zz = res[0]; *zr = res[1];
+  ierr = PetscLogFlops(9.0 * x->map->n);CHKERRQ(ierr);   /* 2n + 2n + n + 2n + 2n */
+  *done = PETSC_TRUE;
+  return 0;
+}
+
 static PetscErrorCode VecDestroy_HIP(Vec v) {
   Vec_HIPMI355X *s = VH(v);
   if (!s) return 0;

@@ -247,6 +247,21 @@ def test_ksp_config1_cg_jacobi(P):
     assert "%.5g" % np.linalg.norm(x - u) == "5.7078e-05" or "%.5g" % np.linalg.norm(x - u) == "5.7079e-05"
 
 
+@pytest.mark.parametrize("pc", ["jacobi", "none", "ilu"])
+def test_ksp_cg_fused_forms_are_bit_identical(P, pc):
+    """KSPSolve_CG's fused forms (default): with PCJACOBI one sweep does both AXPYs, the PCApply, the norm and the
+    dot; otherwise norm and dot share one VecDotNorm2.  -ksp_cg_fused 0 runs the reference's op-by-op sequence
+    (cg.c:206-232): iterates and the whole residual history must carry the same bits."""
+    ai, aj, aa = pb.lap2d(41, 37)
+    n = ai.size - 1
+    b = orc.spmv(ai, aj, aa, np.cos(0.3 * np.arange(n)))
+    xf, hf, itsf, rf = solve(P, ai, aj, aa, b, "cg", pc, rtol=1e-9)
+    xu, hu, itsu, ru = solve(P, ai, aj, aa, b, "cg", pc, opts="-ksp_cg_fused 0", rtol=1e-9)
+    assert itsf == itsu and rf == ru == 2 and itsf > 20
+    assert np.array_equal(bits(hf), bits(hu))
+    assert np.array_equal(bits(xf), bits(xu))
+
+
 def test_ksp_cg_single_reduction(P):
     """-ksp_cg_single_reduction (cg.c:116-122,200-203,263-270): two reductions per iteration instead of
     three (VecMDot(2) for delta and beta), A*p by recurrence; same op sequence as the oracle's restatement"""
@@ -289,7 +304,8 @@ def test_ilu0_apply_bitexact_and_golden(P):
     MatSolve_SeqAIJ_NaturalOrdering bit for bit (one lane per row, products subtracted in column order), and with NO
     -pc_type option a one-rank solve picks ILU like the reference: ex2 -m 5 -n 5 refine_always == ex2_1.out."""
     L = P.lib()
-    for ai, aj, aa in (pb.lap2d(9, 7), P.gen_poisson7(7, 6, 5)):
+    # the third case has 31 + 31 levels: above 16 the level launches run as a captured hipGraph (same bits)
+    for ai, aj, aa in (pb.lap2d(9, 7), P.gen_poisson7(7, 6, 5), P.gen_poisson7(12, 11, 10)):
         n = ai.size - 1
         aa = aa * (1.0 + 0.05 * np.sin(np.arange(aa.size)))
         A = P.Mat.from_csr(ai, aj, aa)
@@ -299,6 +315,8 @@ def test_ilu0_apply_bitexact_and_golden(P):
         vb, vx = V(P, bvec), V(P, np.zeros(n))
         L.raw("PCSetUp")(pc); L.raw("PCApply")(pc, vb.h, vx.h)
         ref = orc.ilu0_solve(orc.ilu0_factor(ai, aj, aa), bvec)
+        assert np.array_equal(bits(vx.array()), bits(ref))
+        L.raw("PCApply")(pc, vb.h, vx.h)            # replay
         assert np.array_equal(bits(vx.array()), bits(ref))
         nl, nu = C.c_int(), C.c_int()
         L.PCILUGetLevels_HIPMI355X(pc, C.byref(nl), C.byref(nu))

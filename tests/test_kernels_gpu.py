@@ -404,3 +404,39 @@ def test_pack_unpack(dev):
     dev.chk(k.mi355x_unpack_insert(dev.h, 100, None, dbuf, dy))
     r[:100] = x[idx][:100]
     assert_bitexact(dev.get(dy, n), r)
+
+
+@pytest.mark.parametrize("n", SIZES)
+def test_cg_update_matches_separate_kernels_bitwise(dev, n):
+    """mi355x_vec_cg_update (x += a p; r -= a w; z = r.*d; z'z, z'r in one sweep) must leave exactly the bits of the
+    five separate launches it replaces (axpy, axpy, pointwise mult, norm, dot), vectors AND reduction results, and
+    the vectors must equal the oracle's element-wise loops."""
+    k = dev.k
+    a = 0.731
+    p, w, d, x, r = rnd(n, 11), rnd(n, 12), 1.0 / (2.0 + rnd(n, 13) ** 2), rnd(n, 14), rnd(n, 15)
+    dp, dw, dd = dev.put(p), dev.put(w), dev.put(d)
+    x1, r1, z1 = dev.put(x), dev.put(r), dev.alloc(8 * max(n, 2))
+    x2, r2, z2 = dev.put(x), dev.put(r), dev.alloc(8 * max(n, 2))
+    hs = dev.host_scratch()
+    dev.chk(k.mi355x_vec_axpy(dev.h, n, a, dp, x1))
+    dev.chk(k.mi355x_vec_axpy(dev.h, n, -a, dw, r1))
+    dev.chk(k.mi355x_vec_pointwise_mult(dev.h, n, r1, dd, z1))
+    dev.chk(k.mi355x_vec_norm(dev.h, n, 2, z1, hs)); zz = dev.scalar_out(1)[0]
+    dev.chk(k.mi355x_vec_dot(dev.h, n, z1, r1, hs)); zr = dev.scalar_out(1)[0]
+    dev.chk(k.mi355x_vec_cg_update(dev.h, n, a, dp, dw, dd, x2, r2, z2, hs))
+    out = dev.scalar_out(2)
+    for u, v in ((x1, x2), (r1, r2), (z1, z2)):
+        assert_bitexact(dev.get(u, n), dev.get(v, n))
+    assert_bitexact(np.array([zz, zr]), out)
+    xo, ro = x.copy(), r.copy()
+    orc.vec_axpy(xo, a, p); orc.vec_axpy(ro, -a, w)
+    zo = np.zeros(n); orc.vec_pointwise_mult(zo, ro, d)
+    assert_bitexact(dev.get(x2, n), xo); assert_bitexact(dev.get(r2, n), ro); assert_bitexact(dev.get(z2, n), zo)
+    # z aliasing w, as KSPSolve_CG uses it (cg.c:122: W = Z)
+    dev.chk(k.mi355x_memcpy_h2d(dev.h, x2, x.ctypes.data, x.nbytes)) if n else None
+    dev.chk(k.mi355x_memcpy_h2d(dev.h, r2, r.ctypes.data, r.nbytes)) if n else None
+    dev.chk(k.mi355x_vec_cg_update(dev.h, n, a, dp, dw, dd, x2, r2, dw, hs))
+    assert_bitexact(dev.scalar_out(2), out)
+    assert_bitexact(dev.get(dw, n), zo); assert_bitexact(dev.get(r2, n), ro); assert_bitexact(dev.get(x2, n), xo)
+    for q in (dp, dw, dd, x1, r1, z1, x2, r2, z2):
+        dev.free(q)
