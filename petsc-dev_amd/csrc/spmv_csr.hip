@@ -17,6 +17,7 @@
 //     that XCD's own 4 MiB L2 instead of being fetched into all eight.
 #include "common.hpp"
 #include <vector>
+#include <stdlib.h>
 
 // tuning knobs (the defaults are the measured best on MI355X for the 7-point operator)
 #ifndef SPMV_THREADS
@@ -36,6 +37,9 @@
 #endif
 #ifndef SPMV_MINWAVES
 #define SPMV_MINWAVES 1      // __launch_bounds__ second argument (waves per SIMD the register allocator must allow)
+#endif
+#ifndef SPMV_PIPE_DEFAULT
+#define SPMV_PIPE_DEFAULT 0  // workgroups per CU of the pipelined idx8 kernel (0 = one workgroup per row block); env MI355X_SPMV_PIPE overrides
 #endif
 #define SPMV_BLOCK_NNZ (8 * SPMV_THREADS * SPMV_RPT)   // LDS stage (doubles): 4*RPT pairs per lane
 #define SPMV_BLOCK_CAP (SPMV_BLOCK_NNZ - 2)   // nonzeros per row block: any alignment of the first pair still fits
@@ -60,6 +64,7 @@ struct mi355x_spmv_plan_s {
   unsigned char *d_idx8;
   int *d_offtab;
   int ntab;
+  int pipe_grid;   // > 0: workgroups of the pipelined idx8 kernel (multiple of 8); 0: one workgroup per row block
 };
 
 template <bool ADD, bool CPROW, bool VEC>
@@ -213,6 +218,11 @@ __global__ __launch_bounds__(SPMV_THREADS, SPMV_MINWAVES) void spmv_csr_rowblock
 // streams val (8 B) + idx8 (1 B) instead of val + col (12 B): 25 % fewer matrix bytes.  The row of each nonzero,
 // which the offset needs, comes from an LDS marker array written by the lanes that own the rows (they hold the
 // row extents anyway).  Arithmetic and summation order are those of the plain kernel: same bits.
+// Branch-free addressing: every lane issues all of its loads unconditionally -- a lane whose pair lies outside the
+// block re-reads the block's first pair (same address as lane 0: merged by the coalescer), a pair cut by the block
+// boundary is loaded whole (an aligned 16-byte access cannot leave the page its first half lies in) and the element
+// outside the block is simply not written to LDS.  With no control flow between the loads the compiler keeps all of
+// them in flight behind a single s_waitcnt; the earlier predicated form serialised them pair by pair.
 template <bool ADD>
 __global__ __launch_bounds__(SPMV_THREADS, SPMV_MINWAVES) void spmv_csr_rowblock_idx8_kernel(
     const int2 *__restrict__ rowblk, int nblocks, const int *__restrict__ ai, const unsigned char *__restrict__ idx8,
@@ -222,6 +232,7 @@ __global__ __launch_bounds__(SPMV_THREADS, SPMV_MINWAVES) void spmv_csr_rowblock
   __shared__ unsigned char rowof[SPMV_BLOCK_NNZ];
   __shared__ int offtab[256];
   __shared__ double wsum[SPMV_THREADS / MI355X_WAVE];
+  static_assert(SPMV_THREADS >= 256, "the offset table is staged by the first 256 lanes");
 #if SPMV_REMAP == 2
   const int xcd = blockIdx.x % MI355X_NXCD;
   const int slot = blockIdx.x / MI355X_NXCD;
@@ -236,9 +247,11 @@ __global__ __launch_bounds__(SPMV_THREADS, SPMV_MINWAVES) void spmv_csr_rowblock
   const int nnz = k1 - k0;
   const int nrows = r1 - r0;
   const int tid = threadIdx.x;
-  if (tid < ntab) offtab[tid] = offtab_g[tid];
+  const int tabv = offtab_g[tid & 255];   // 256 initialised entries (zeros past ntab)
+  (void)ntab;
 
   if (nnz > SPMV_BLOCK_CAP) {   // one long row: every entry belongs to row r0
+    if (tid < 256) offtab[tid] = tabv;
     __syncthreads();
     double s = 0.0;
     for (int k = k0 + tid; k < k1; k += SPMV_THREADS) s += SPMV_LOAD(aa + k) * x[r0 + offtab[SPMV_LOAD(idx8 + k)]];
@@ -253,61 +266,69 @@ __global__ __launch_bounds__(SPMV_THREADS, SPMV_MINWAVES) void spmv_csr_rowblock
     }
     return;
   }
+  if (nnz == 0) {               // only empty rows
+    if (tid < nrows) yout[r0 + tid] = ADD ? yin[r0 + tid] : 0.0;
+    return;
+  }
 
   int tpr = 1;
   while (tpr < MI355X_WAVE && nrows * (tpr * 2) <= SPMV_THREADS) tpr *= 2;
   if (nnz <= 16 * nrows) tpr = 1;
   const int r = tid / tpr, sub = tid & (tpr - 1);
-  int rs = 0, re = 0;
+  const int rc = r < nrows ? r : nrows - 1;
+  const int a0 = ai[r0 + rc], a1 = ai[r0 + rc + 1];
   double ysum = 0.0;
-  if (r < nrows) {
-    rs = ai[r0 + r] - k0;
-    re = ai[r0 + r + 1] - k0;
-    if (ADD && sub == 0) ysum = yin[r0 + r];
-  }
-  // this lane's slice of the value / index streams, requested before anything is consumed
+  if (ADD) ysum = yin[r0 + rc];
+  // this lane's slice of the value / index streams
   constexpr int PAIRS = SPMV_BLOCK_NNZ / (2 * SPMV_THREADS);
   const int ka = k0 & ~1;
   v2d v[PAIRS];
-  unsigned short ix[PAIRS];
-  bool full[PAIRS];
+  unsigned int ix[PAIRS];
 #pragma unroll
   for (int p = 0; p < PAIRS; ++p) {
     const int k = ka + 2 * tid + p * 2 * SPMV_THREADS;
-    full[p] = (k >= k0) && (k + 1 < k1);
-    if (full[p]) {
-      v[p] = SPMV_LOAD(reinterpret_cast<const v2d *>(aa + k));
-      ix[p] = SPMV_LOAD(reinterpret_cast<const unsigned short *>(idx8 + k));
-    }
+    const int kk = (k < k1) ? k : ka;
+    v[p] = SPMV_LOAD(reinterpret_cast<const v2d *>(aa + kk));
+    ix[p] = SPMV_LOAD(reinterpret_cast<const unsigned short *>(idx8 + kk));
   }
+  const int rs = r < nrows ? a0 - k0 : 0, re = r < nrows ? a1 - k0 : 0;
   // row markers: the lanes of row r tag its nonzeros
   for (int k = rs + sub; k < re; k += tpr) rowof[k] = (unsigned char)r;
+  if (tid < 256) offtab[tid] = tabv;
   __syncthreads();
   double xa[PAIRS], xb[PAIRS];
 #pragma unroll
   for (int p = 0; p < PAIRS; ++p) {
-    if (full[p]) {
-      const int k = ka + 2 * tid + p * 2 * SPMV_THREADS - k0;
-      xa[p] = x[r0 + rowof[k] + offtab[ix[p] & 0xff]];
-      xb[p] = x[r0 + rowof[k + 1] + offtab[ix[p] >> 8]];
-    }
+    const int k = ka + 2 * tid + p * 2 * SPMV_THREADS;
+    const bool in = k < k1;                       // the pair touches the block
+    const bool v0 = in && k >= k0, v1 = in && (k + 1 < k1);
+    const int kk = in ? k : ka;
+    // element to address x with when the slot's own element lies outside the block: the pair's other element,
+    // or (idle lane, pair = the block's first) element k0
+    const int s0 = v0 ? 0 : (in ? 1 : (k0 & 1));
+    const int s1 = v1 ? 1 : (in ? 0 : (k0 & 1));
+    xa[p] = x[r0 + rowof[kk + s0 - k0] + offtab[(ix[p] >> (8 * s0)) & 0xff]];
+    xb[p] = x[r0 + rowof[kk + s1 - k0] + offtab[(ix[p] >> (8 * s1)) & 0xff]];
   }
 #pragma unroll
   for (int p = 0; p < PAIRS; ++p) {
     const int k = ka + 2 * tid + p * 2 * SPMV_THREADS;
-    if (full[p]) {
-      prod[k - k0] = v[p].x * xa[p];
-      prod[k - k0 + 1] = v[p].y * xb[p];
-    } else {
-      for (int e = k; e <= k + 1; ++e)
-        if (e >= k0 && e < k1) prod[e - k0] = SPMV_LOAD(aa + e) * x[r0 + rowof[e - k0] + offtab[SPMV_LOAD(idx8 + e)]];
-    }
+    const double pa = v[p].x * xa[p], pb = v[p].y * xb[p];
+    // products of elements outside the block go to the stage's last slot, which no block uses (nnz <= CAP)
+    prod[(k >= k0 && k < k1) ? k - k0 : SPMV_BLOCK_NNZ - 1] = pa;
+    prod[(k + 1 < k1) ? k + 1 - k0 : SPMV_BLOCK_NNZ - 1] = pb;
   }
   __syncthreads();
   if (tpr == 1) {
     if (r < nrows) {
       double sum = ADD ? ysum : 0.0;
-      for (int k = rs; k < re; ++k) sum += prod[k];
+      for (int k = rs; k < re; k += 8) {          // 8 LDS reads in flight; added in column order
+        double t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = prod[(k + j < re) ? k + j : re - 1];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const double u = sum + t[j]; sum = (k + j < re) ? u : sum; }
+      }
       yout[r0 + r] = sum;
     }
   } else {
@@ -316,6 +337,170 @@ __global__ __launch_bounds__(SPMV_THREADS, SPMV_MINWAVES) void spmv_csr_rowblock
     for (int off = tpr >> 1; off > 0; off >>= 1) sum += __shfl_down(sum, off, MI355X_WAVE);
     if (r < nrows && sub == 0) yout[r0 + r] = ADD ? (ysum + sum) : sum;
   }
+}
+
+__device__ __forceinline__ int pipe_tpr(int nrows) {   // lanes per row of a block with few, long rows (as in the plain kernel)
+  int tpr = 1;
+  while (tpr < MI355X_WAVE && nrows * (tpr * 2) <= SPMV_THREADS) tpr *= 2;
+  return tpr;
+}
+template <bool ADD>
+__global__ __launch_bounds__(SPMV_THREADS) void spmv_csr_idx8_pipe_kernel(
+    const int2 *__restrict__ rowblk, int nblocks, const int *__restrict__ ai, const unsigned char *__restrict__ idx8,
+    const int *__restrict__ offtab_g, int ntab, const double *__restrict__ aa, const double *__restrict__ x,
+    const double *yin, double *yout) {
+  __shared__ double prod[SPMV_BLOCK_NNZ];
+  __shared__ unsigned char rowof[SPMV_BLOCK_NNZ];
+  __shared__ int offtab[256];
+  __shared__ double wsum[SPMV_THREADS / MI355X_WAVE];
+  constexpr int PAIRS = SPMV_BLOCK_NNZ / (2 * SPMV_THREADS);
+  const int tid = threadIdx.x;
+  const int xcd = blockIdx.x % MI355X_NXCD;
+  const int nwalk = gridDim.x / MI355X_NXCD;          // walkers per XCD
+  int q = blockIdx.x / MI355X_NXCD;                   // position in this XCD's sequence of row blocks
+#define PIPE_TPR(nr_, nz_) (((nz_) <= 16 * (nr_)) ? 1 : pipe_tpr(nr_))
+#define PIPE_LB(q_) ((((q_) / SPMV_CH) * MI355X_NXCD + xcd) * SPMV_CH + ((q_) % SPMV_CH))
+  int lb = PIPE_LB(q);
+  if (lb >= nblocks) return;
+  if (tid < ntab) offtab[tid] = offtab_g[tid];
+
+  int2 b0 = rowblk[lb], b1 = rowblk[lb + 1];
+  v2d v[PAIRS];
+  unsigned short ix[PAIRS];
+  int rs = 0, re = 0;
+  double ysum = 0.0;
+  // prologue: the first block's slices
+  {
+    const int k0 = b0.y, k1 = b1.y, nr = b1.x - b0.x;
+    if (k1 - k0 <= SPMV_BLOCK_CAP) {
+      const int tp = PIPE_TPR(nr, k1 - k0), rr = tid / tp;
+      if (rr < nr) {
+        rs = ai[b0.x + rr] - k0;
+        re = ai[b0.x + rr + 1] - k0;
+        if (ADD && (tid & (tp - 1)) == 0) ysum = yin[b0.x + rr];
+      }
+      const int ka = k0 & ~1;
+#pragma unroll
+      for (int p = 0; p < PAIRS; ++p) {
+        const int k = ka + 2 * tid + p * 2 * SPMV_THREADS;
+        if (k >= k0 && k + 1 < k1) {
+          v[p] = SPMV_LOAD(reinterpret_cast<const v2d *>(aa + k));
+          ix[p] = SPMV_LOAD(reinterpret_cast<const unsigned short *>(idx8 + k));
+        }
+      }
+    }
+  }
+
+  for (;;) {
+    const int r0 = b0.x, r1 = b1.x, k0 = b0.y, k1 = b1.y;
+    const int nnz = k1 - k0, nrows = r1 - r0;
+    const int qn = q + nwalk;
+    const int lbn = PIPE_LB(qn);
+    const bool have_next = lbn < nblocks;
+    int2 nb0 = b0, nb1 = b1;
+    if (have_next) { nb0 = rowblk[lbn]; nb1 = rowblk[lbn + 1]; }
+    const int nk0 = nb0.y, nk1 = nb1.y, nnr = nb1.x - nb0.x;
+    const bool next_short = have_next && (nk1 - nk0 <= SPMV_BLOCK_CAP);
+    v2d vn[PAIRS];
+    unsigned short ixn[PAIRS];
+    int nrs = 0, nre = 0;
+    double nysum = 0.0;
+
+    if (nnz > SPMV_BLOCK_CAP) {   // one long row: every entry belongs to row r0 (nothing was prefetched for it)
+      __syncthreads();
+      double s = 0.0;
+      for (int k = k0 + tid; k < k1; k += SPMV_THREADS) s += SPMV_LOAD(aa + k) * x[r0 + offtab[SPMV_LOAD(idx8 + k)]];
+      s = wave_sum(s);
+      if ((tid & (MI355X_WAVE - 1)) == 0) wsum[tid / MI355X_WAVE] = s;
+      __syncthreads();
+      if (tid == 0) {
+        double t = wsum[0];
+#pragma unroll
+        for (int w = 1; w < SPMV_THREADS / MI355X_WAVE; ++w) t += wsum[w];
+        yout[r0] = ADD ? (yin[r0] + t) : t;
+      }
+      if (next_short) {
+        const int tp = PIPE_TPR(nnr, nk1 - nk0), rr = tid / tp;
+        if (rr < nnr) {
+          nrs = ai[nb0.x + rr] - nk0;
+          nre = ai[nb0.x + rr + 1] - nk0;
+          if (ADD && (tid & (tp - 1)) == 0) nysum = yin[nb0.x + rr];
+        }
+        const int nka = nk0 & ~1;
+#pragma unroll
+        for (int p = 0; p < PAIRS; ++p) {
+          const int k = nka + 2 * tid + p * 2 * SPMV_THREADS;
+          if (k >= nk0 && k + 1 < nk1) {
+            vn[p] = SPMV_LOAD(reinterpret_cast<const v2d *>(aa + k));
+            ixn[p] = SPMV_LOAD(reinterpret_cast<const unsigned short *>(idx8 + k));
+          }
+        }
+      }
+    } else {
+      // row markers: the lanes of row r tag its nonzeros
+      const int tpr = PIPE_TPR(nrows, nnz), r = tid / tpr, sub = tid & (tpr - 1);
+      for (int k = rs + sub; k < re; k += tpr) rowof[k] = (unsigned char)r;
+      __syncthreads();
+      const int ka = k0 & ~1;
+      double xa[PAIRS], xb[PAIRS];
+#pragma unroll
+      for (int p = 0; p < PAIRS; ++p) {
+        const int k = ka + 2 * tid + p * 2 * SPMV_THREADS;
+        if (k >= k0 && k + 1 < k1) {
+          xa[p] = x[r0 + rowof[k - k0] + offtab[ix[p] & 0xff]];
+          xb[p] = x[r0 + rowof[k - k0 + 1] + offtab[ix[p] >> 8]];
+        }
+      }
+      // prefetch the next block behind the gathers
+      if (next_short) {
+        const int tp = PIPE_TPR(nnr, nk1 - nk0), rr = tid / tp;
+        if (rr < nnr) {
+          nrs = ai[nb0.x + rr] - nk0;
+          nre = ai[nb0.x + rr + 1] - nk0;
+          if (ADD && (tid & (tp - 1)) == 0) nysum = yin[nb0.x + rr];
+        }
+        const int nka = nk0 & ~1;
+#pragma unroll
+        for (int p = 0; p < PAIRS; ++p) {
+          const int k = nka + 2 * tid + p * 2 * SPMV_THREADS;
+          if (k >= nk0 && k + 1 < nk1) {
+            vn[p] = SPMV_LOAD(reinterpret_cast<const v2d *>(aa + k));
+            ixn[p] = SPMV_LOAD(reinterpret_cast<const unsigned short *>(idx8 + k));
+          }
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < PAIRS; ++p) {
+        const int k = ka + 2 * tid + p * 2 * SPMV_THREADS;
+        if (k >= k0 && k + 1 < k1) {
+          prod[k - k0] = v[p].x * xa[p];
+          prod[k - k0 + 1] = v[p].y * xb[p];
+        } else {
+          for (int e = k; e <= k + 1; ++e)
+            if (e >= k0 && e < k1) prod[e - k0] = SPMV_LOAD(aa + e) * x[r0 + rowof[e - k0] + offtab[SPMV_LOAD(idx8 + e)]];
+        }
+      }
+      __syncthreads();
+      if (tpr == 1) {
+        if (r < nrows) {
+          double sum = ADD ? ysum : 0.0;
+          for (int k = rs; k < re; ++k) sum += prod[k];
+          yout[r0 + r] = sum;
+        }
+      } else {
+        double sum = 0.0;
+        if (r < nrows) for (int k = rs + sub; k < re; k += tpr) sum += prod[k];
+        for (int off = tpr >> 1; off > 0; off >>= 1) sum += __shfl_down(sum, off, MI355X_WAVE);
+        if (r < nrows && sub == 0) yout[r0 + r] = ADD ? (ysum + sum) : sum;
+      }
+    }
+    if (!have_next) break;
+    q = qn; b0 = nb0; b1 = nb1; rs = nrs; re = nre; ysum = nysum;
+#pragma unroll
+    for (int p = 0; p < PAIRS; ++p) { v[p] = vn[p]; ix[p] = ixn[p]; }
+  }
+#undef PIPE_LB
+#undef PIPE_TPR
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -435,6 +620,10 @@ static int launch_spmv(mi355x_handle_t h, mi355x_spmv_plan_t p, const int *ai, c
 #else
     const int g8 = p->nblocks;
 #endif
+    if (p->pipe_grid > 0 && p->pipe_grid < p->nblocks)
+      hipLaunchKernelGGL((spmv_csr_idx8_pipe_kernel<ADD>), dim3(p->pipe_grid), dim3(SPMV_THREADS), 0, h->stream, p->d_rowblk,
+                         p->nblocks, ai, p->d_idx8, p->d_offtab, p->ntab, aa, x, yin, yout);
+    else
     hipLaunchKernelGGL((spmv_csr_rowblock_idx8_kernel<ADD>), dim3(g8), dim3(SPMV_THREADS), 0, h->stream, p->d_rowblk,
                        p->nblocks, ai, p->d_idx8, p->d_offtab, p->ntab, aa, x, yin, yout);
     MI355X_LAUNCH_CHECK();
@@ -468,6 +657,7 @@ int mi355x_spmv_plan_create(mi355x_handle_t h, int nrows, const int *ai_host, co
   p->d_offtab = nullptr;
   p->ntab = 0;
   p->nlong = 0;
+  p->pipe_grid = 0;
   std::vector<int2> rb;
   rb.reserve((size_t)nrows / 128 + 2);
   rb.push_back(make_int2(0, ai_host[0]));
@@ -530,10 +720,19 @@ int mi355x_spmv_plan_compress_indices(mi355x_handle_t h, mi355x_spmv_plan_t p, c
   }
   MI355X_TRY(hipMalloc((void **)&p->d_idx8, (size_t)(nnz > 0 ? nnz : 1) + 16));
   MI355X_TRY(hipMalloc((void **)&p->d_offtab, sizeof(int) * 256));
+  MI355X_TRY(hipMemsetAsync(p->d_offtab, 0, sizeof(int) * 256, h->stream));
   MI355X_TRY(hipMemcpyAsync(p->d_idx8, idx.data(), (size_t)nnz, hipMemcpyHostToDevice, h->stream));
   MI355X_TRY(hipMemcpyAsync(p->d_offtab, tab, sizeof(int) * (size_t)ntab, hipMemcpyHostToDevice, h->stream));
   MI355X_TRY(hipStreamSynchronize(h->stream));
   p->ntab = ntab;
+  // pipelined walkers: MI355X_SPMV_PIPE workgroups per CU (0 = one workgroup per row block)
+  {
+    int wg_per_cu = SPMV_PIPE_DEFAULT;
+    if (const char *e = getenv("MI355X_SPMV_PIPE")) wg_per_cu = atoi(e);
+    int dev = 0, ncu = 256;
+    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (wg_per_cu > 0 && ncu >= MI355X_NXCD) p->pipe_grid = (ncu / MI355X_NXCD) * MI355X_NXCD * wg_per_cu;
+  }
   return 0;
 }
 
