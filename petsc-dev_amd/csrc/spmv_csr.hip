@@ -32,18 +32,12 @@
 #ifndef SPMV_CH
 #define SPMV_CH 32
 #endif
-#ifndef SPMV_RPT
-#define SPMV_RPT 1           // rows per lane in the one-lane-per-row summation (block = RPT*THREADS rows)
-#endif
 #ifndef SPMV_MINWAVES
 #define SPMV_MINWAVES 1      // __launch_bounds__ second argument (waves per SIMD the register allocator must allow)
 #endif
-#ifndef SPMV_PIPE_DEFAULT
-#define SPMV_PIPE_DEFAULT 0  // workgroups per CU of the pipelined idx8 kernel (0 = one workgroup per row block); env MI355X_SPMV_PIPE overrides
-#endif
-#define SPMV_BLOCK_NNZ (8 * SPMV_THREADS * SPMV_RPT)   // LDS stage (doubles): 4*RPT pairs per lane
+#define SPMV_BLOCK_NNZ (8 * SPMV_THREADS)   // LDS stage (doubles): 4 pairs per lane
 #define SPMV_BLOCK_CAP (SPMV_BLOCK_NNZ - 2)   // nonzeros per row block: any alignment of the first pair still fits
-#define SPMV_BLOCK_ROWS (SPMV_THREADS * SPMV_RPT)
+#define SPMV_BLOCK_ROWS SPMV_THREADS
 #if SPMV_NT
 #define SPMV_LOAD(p) __builtin_nontemporal_load(p)
 #else
@@ -64,7 +58,6 @@ struct mi355x_spmv_plan_s {
   unsigned char *d_idx8;
   int *d_offtab;
   int ntab;
-  int pipe_grid;   // > 0: workgroups of the pipelined idx8 kernel (multiple of 8); 0: one workgroup per row block
 };
 
 template <bool ADD, bool CPROW, bool VEC>
@@ -121,62 +114,62 @@ __global__ __launch_bounds__(SPMV_THREADS, SPMV_MINWAVES) void spmv_csr_rowblock
     }
     return;
   }
+  if (nnz == 0) {   // only empty rows
+    if (tid < nrows) {
+      const int orow = CPROW ? rows[r0 + tid] : r0 + tid;
+      yout[orow] = ADD ? yin[orow] : 0.0;
+    }
+    return;
+  }
 
   // lanes per row: largest power of two with nrows*tpr <= 256, at most one wavefront; short rows
   // (the stencil case) get one lane per row and the reference's summation order
   int tpr = 1;
   while (tpr < MI355X_WAVE && nrows * (tpr * 2) <= SPMV_THREADS) tpr *= 2;
-  if (nnz <= 16 * nrows || nrows > SPMV_THREADS) tpr = 1;
+  if (nnz <= 16 * nrows) tpr = 1;
 
-  // row extents for the summation phase are requested now, so their latency overlaps the stream below
-  int rs[SPMV_RPT], re[SPMV_RPT], orow[SPMV_RPT];
-  double ysum[SPMV_RPT];
-#pragma unroll
-  for (int q = 0; q < SPMV_RPT; ++q) {
-    const int r = tid + q * SPMV_THREADS;
-    rs[q] = re[q] = orow[q] = 0;
-    ysum[q] = 0.0;
-    if (tpr == 1 && r < nrows) {
-      rs[q] = ai[r0 + r];
-      re[q] = ai[r0 + r + 1];
-      orow[q] = CPROW ? rows[r0 + r] : r0 + r;
-      if (ADD) ysum[q] = yin[orow[q]];
-    }
-  }
+  // Every load below is unconditional (see the idx8 kernel further down for why): lanes past the last row re-read
+  // the last row's extent, lanes past the last pair re-read the block's first pair.
+  const int r = tid / tpr, sub = tid & (tpr - 1);
+  const int rc = r < nrows ? r : nrows - 1;
+  const int a0 = ai[r0 + rc], a1 = ai[r0 + rc + 1];
+  const int orow = CPROW ? rows[r0 + rc] : r0 + rc;
+  double ysum = 0.0;
+  if (ADD) ysum = yin[orow];
 
   // ---- stream the block's nonzeros: product -> LDS -----------------------
   if (VEC) {
-    // all loads of this lane are issued before any is consumed: 4 x (16 B val + 8 B col) in flight per lane
     constexpr int PAIRS = SPMV_BLOCK_NNZ / (2 * SPMV_THREADS);
     const int ka = k0 & ~1;  // 16-byte aligned start for val, 8-byte for col
     v2d v[PAIRS];
     v2i c[PAIRS];
-    bool full[PAIRS];
 #pragma unroll
     for (int p = 0; p < PAIRS; ++p) {
       const int k = ka + 2 * tid + p * 2 * SPMV_THREADS;
-      full[p] = (k >= k0) && (k + 1 < k1);
-      if (full[p]) {
-        v[p] = SPMV_LOAD(reinterpret_cast<const v2d *>(aa + k));
-        c[p] = SPMV_LOAD(reinterpret_cast<const v2i *>(aj + k));
-      }
+      const int kk = (k < k1) ? k : ka;
+      v[p] = SPMV_LOAD(reinterpret_cast<const v2d *>(aa + kk));
+      c[p] = SPMV_LOAD(reinterpret_cast<const v2i *>(aj + kk));
     }
     double xa[PAIRS], xb[PAIRS];
 #pragma unroll
     for (int p = 0; p < PAIRS; ++p) {
-      if (full[p]) { xa[p] = x[c[p].x]; xb[p] = x[c[p].y]; }
+      const int k = ka + 2 * tid + p * 2 * SPMV_THREADS;
+      const bool in = k < k1;
+      const bool v0 = in && k >= k0, v1 = in && (k + 1 < k1);
+      // a slot whose own element lies outside the block gathers with the column of the pair's other element, an
+      // idle lane (it holds the block's first pair) with that of element k0: always a column of this block
+      const int s0 = v0 ? 0 : (in ? 1 : (k0 & 1));
+      const int s1 = v1 ? 1 : (in ? 0 : (k0 & 1));
+      xa[p] = x[s0 ? c[p].y : c[p].x];
+      xb[p] = x[s1 ? c[p].y : c[p].x];
     }
 #pragma unroll
     for (int p = 0; p < PAIRS; ++p) {
       const int k = ka + 2 * tid + p * 2 * SPMV_THREADS;
-      if (full[p]) {
-        prod[k - k0] = v[p].x * xa[p];
-        prod[k - k0 + 1] = v[p].y * xb[p];
-      } else {  // a pair cut by the block boundary (at most two per block)
-        if (k >= k0 && k < k1) prod[k - k0] = SPMV_LOAD(aa + k) * x[SPMV_LOAD(aj + k)];
-        if (k + 1 >= k0 && k + 1 < k1)
-          prod[k + 1 - k0] = SPMV_LOAD(aa + k + 1) * x[SPMV_LOAD(aj + k + 1)];
-      }
+      const double pa = v[p].x * xa[p], pb = v[p].y * xb[p];
+      // products of elements outside the block go to the stage's last slot, which no block uses (nnz <= CAP)
+      prod[(k >= k0 && k < k1) ? k - k0 : SPMV_BLOCK_NNZ - 1] = pa;
+      prod[(k + 1 < k1) ? k + 1 - k0 : SPMV_BLOCK_NNZ - 1] = pb;
     }
   } else {
     for (int k = k0 + tid; k < k1; k += SPMV_THREADS)
@@ -185,29 +178,24 @@ __global__ __launch_bounds__(SPMV_THREADS, SPMV_MINWAVES) void spmv_csr_rowblock
   __syncthreads();
 
   // ---- per-row sums out of LDS -------------------------------------------
+  const int rs = r < nrows ? a0 - k0 : 0, re = r < nrows ? a1 - k0 : 0;
   if (tpr == 1) {
+    if (r < nrows) {
+      double sum = ADD ? ysum : 0.0;
+      for (int k = rs; k < re; k += 8) {          // 8 LDS reads in flight; added in column order
+        double t[8];
 #pragma unroll
-    for (int q = 0; q < SPMV_RPT; ++q) {
-      if (tid + q * SPMV_THREADS < nrows) {
-        double sum = ADD ? ysum[q] : 0.0;
-        for (int k = rs[q] - k0; k < re[q] - k0; ++k) sum += prod[k];
-        yout[orow[q]] = sum;
+        for (int j = 0; j < 8; ++j) t[j] = prod[(k + j < re) ? k + j : re - 1];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const double u = sum + t[j]; sum = (k + j < re) ? u : sum; }
       }
+      yout[orow] = sum;
     }
   } else {
-    const int r = tid / tpr;
-    const int sub = tid & (tpr - 1);
     double sum = 0.0;
-    int orow2 = 0;
-    if (r < nrows) {
-      const int row = r0 + r;
-      const int s = ai[row] - k0;
-      const int e = ai[row + 1] - k0;
-      orow2 = CPROW ? rows[row] : row;
-      for (int k = s + sub; k < e; k += tpr) sum += prod[k];
-    }
+    if (r < nrows) for (int k = rs + sub; k < re; k += tpr) sum += prod[k];
     for (int off = tpr >> 1; off > 0; off >>= 1) sum += __shfl_down(sum, off, MI355X_WAVE);
-    if (r < nrows && sub == 0) yout[orow2] = ADD ? (yin[orow2] + sum) : sum;
+    if (r < nrows && sub == 0) yout[orow] = ADD ? (ysum + sum) : sum;
   }
 }
 
@@ -339,170 +327,6 @@ __global__ __launch_bounds__(SPMV_THREADS, SPMV_MINWAVES) void spmv_csr_rowblock
   }
 }
 
-__device__ __forceinline__ int pipe_tpr(int nrows) {   // lanes per row of a block with few, long rows (as in the plain kernel)
-  int tpr = 1;
-  while (tpr < MI355X_WAVE && nrows * (tpr * 2) <= SPMV_THREADS) tpr *= 2;
-  return tpr;
-}
-template <bool ADD>
-__global__ __launch_bounds__(SPMV_THREADS) void spmv_csr_idx8_pipe_kernel(
-    const int2 *__restrict__ rowblk, int nblocks, const int *__restrict__ ai, const unsigned char *__restrict__ idx8,
-    const int *__restrict__ offtab_g, int ntab, const double *__restrict__ aa, const double *__restrict__ x,
-    const double *yin, double *yout) {
-  __shared__ double prod[SPMV_BLOCK_NNZ];
-  __shared__ unsigned char rowof[SPMV_BLOCK_NNZ];
-  __shared__ int offtab[256];
-  __shared__ double wsum[SPMV_THREADS / MI355X_WAVE];
-  constexpr int PAIRS = SPMV_BLOCK_NNZ / (2 * SPMV_THREADS);
-  const int tid = threadIdx.x;
-  const int xcd = blockIdx.x % MI355X_NXCD;
-  const int nwalk = gridDim.x / MI355X_NXCD;          // walkers per XCD
-  int q = blockIdx.x / MI355X_NXCD;                   // position in this XCD's sequence of row blocks
-#define PIPE_TPR(nr_, nz_) (((nz_) <= 16 * (nr_)) ? 1 : pipe_tpr(nr_))
-#define PIPE_LB(q_) ((((q_) / SPMV_CH) * MI355X_NXCD + xcd) * SPMV_CH + ((q_) % SPMV_CH))
-  int lb = PIPE_LB(q);
-  if (lb >= nblocks) return;
-  if (tid < ntab) offtab[tid] = offtab_g[tid];
-
-  int2 b0 = rowblk[lb], b1 = rowblk[lb + 1];
-  v2d v[PAIRS];
-  unsigned short ix[PAIRS];
-  int rs = 0, re = 0;
-  double ysum = 0.0;
-  // prologue: the first block's slices
-  {
-    const int k0 = b0.y, k1 = b1.y, nr = b1.x - b0.x;
-    if (k1 - k0 <= SPMV_BLOCK_CAP) {
-      const int tp = PIPE_TPR(nr, k1 - k0), rr = tid / tp;
-      if (rr < nr) {
-        rs = ai[b0.x + rr] - k0;
-        re = ai[b0.x + rr + 1] - k0;
-        if (ADD && (tid & (tp - 1)) == 0) ysum = yin[b0.x + rr];
-      }
-      const int ka = k0 & ~1;
-#pragma unroll
-      for (int p = 0; p < PAIRS; ++p) {
-        const int k = ka + 2 * tid + p * 2 * SPMV_THREADS;
-        if (k >= k0 && k + 1 < k1) {
-          v[p] = SPMV_LOAD(reinterpret_cast<const v2d *>(aa + k));
-          ix[p] = SPMV_LOAD(reinterpret_cast<const unsigned short *>(idx8 + k));
-        }
-      }
-    }
-  }
-
-  for (;;) {
-    const int r0 = b0.x, r1 = b1.x, k0 = b0.y, k1 = b1.y;
-    const int nnz = k1 - k0, nrows = r1 - r0;
-    const int qn = q + nwalk;
-    const int lbn = PIPE_LB(qn);
-    const bool have_next = lbn < nblocks;
-    int2 nb0 = b0, nb1 = b1;
-    if (have_next) { nb0 = rowblk[lbn]; nb1 = rowblk[lbn + 1]; }
-    const int nk0 = nb0.y, nk1 = nb1.y, nnr = nb1.x - nb0.x;
-    const bool next_short = have_next && (nk1 - nk0 <= SPMV_BLOCK_CAP);
-    v2d vn[PAIRS];
-    unsigned short ixn[PAIRS];
-    int nrs = 0, nre = 0;
-    double nysum = 0.0;
-
-    if (nnz > SPMV_BLOCK_CAP) {   // one long row: every entry belongs to row r0 (nothing was prefetched for it)
-      __syncthreads();
-      double s = 0.0;
-      for (int k = k0 + tid; k < k1; k += SPMV_THREADS) s += SPMV_LOAD(aa + k) * x[r0 + offtab[SPMV_LOAD(idx8 + k)]];
-      s = wave_sum(s);
-      if ((tid & (MI355X_WAVE - 1)) == 0) wsum[tid / MI355X_WAVE] = s;
-      __syncthreads();
-      if (tid == 0) {
-        double t = wsum[0];
-#pragma unroll
-        for (int w = 1; w < SPMV_THREADS / MI355X_WAVE; ++w) t += wsum[w];
-        yout[r0] = ADD ? (yin[r0] + t) : t;
-      }
-      if (next_short) {
-        const int tp = PIPE_TPR(nnr, nk1 - nk0), rr = tid / tp;
-        if (rr < nnr) {
-          nrs = ai[nb0.x + rr] - nk0;
-          nre = ai[nb0.x + rr + 1] - nk0;
-          if (ADD && (tid & (tp - 1)) == 0) nysum = yin[nb0.x + rr];
-        }
-        const int nka = nk0 & ~1;
-#pragma unroll
-        for (int p = 0; p < PAIRS; ++p) {
-          const int k = nka + 2 * tid + p * 2 * SPMV_THREADS;
-          if (k >= nk0 && k + 1 < nk1) {
-            vn[p] = SPMV_LOAD(reinterpret_cast<const v2d *>(aa + k));
-            ixn[p] = SPMV_LOAD(reinterpret_cast<const unsigned short *>(idx8 + k));
-          }
-        }
-      }
-    } else {
-      // row markers: the lanes of row r tag its nonzeros
-      const int tpr = PIPE_TPR(nrows, nnz), r = tid / tpr, sub = tid & (tpr - 1);
-      for (int k = rs + sub; k < re; k += tpr) rowof[k] = (unsigned char)r;
-      __syncthreads();
-      const int ka = k0 & ~1;
-      double xa[PAIRS], xb[PAIRS];
-#pragma unroll
-      for (int p = 0; p < PAIRS; ++p) {
-        const int k = ka + 2 * tid + p * 2 * SPMV_THREADS;
-        if (k >= k0 && k + 1 < k1) {
-          xa[p] = x[r0 + rowof[k - k0] + offtab[ix[p] & 0xff]];
-          xb[p] = x[r0 + rowof[k - k0 + 1] + offtab[ix[p] >> 8]];
-        }
-      }
-      // prefetch the next block behind the gathers
-      if (next_short) {
-        const int tp = PIPE_TPR(nnr, nk1 - nk0), rr = tid / tp;
-        if (rr < nnr) {
-          nrs = ai[nb0.x + rr] - nk0;
-          nre = ai[nb0.x + rr + 1] - nk0;
-          if (ADD && (tid & (tp - 1)) == 0) nysum = yin[nb0.x + rr];
-        }
-        const int nka = nk0 & ~1;
-#pragma unroll
-        for (int p = 0; p < PAIRS; ++p) {
-          const int k = nka + 2 * tid + p * 2 * SPMV_THREADS;
-          if (k >= nk0 && k + 1 < nk1) {
-            vn[p] = SPMV_LOAD(reinterpret_cast<const v2d *>(aa + k));
-            ixn[p] = SPMV_LOAD(reinterpret_cast<const unsigned short *>(idx8 + k));
-          }
-        }
-      }
-#pragma unroll
-      for (int p = 0; p < PAIRS; ++p) {
-        const int k = ka + 2 * tid + p * 2 * SPMV_THREADS;
-        if (k >= k0 && k + 1 < k1) {
-          prod[k - k0] = v[p].x * xa[p];
-          prod[k - k0 + 1] = v[p].y * xb[p];
-        } else {
-          for (int e = k; e <= k + 1; ++e)
-            if (e >= k0 && e < k1) prod[e - k0] = SPMV_LOAD(aa + e) * x[r0 + rowof[e - k0] + offtab[SPMV_LOAD(idx8 + e)]];
-        }
-      }
-      __syncthreads();
-      if (tpr == 1) {
-        if (r < nrows) {
-          double sum = ADD ? ysum : 0.0;
-          for (int k = rs; k < re; ++k) sum += prod[k];
-          yout[r0 + r] = sum;
-        }
-      } else {
-        double sum = 0.0;
-        if (r < nrows) for (int k = rs + sub; k < re; k += tpr) sum += prod[k];
-        for (int off = tpr >> 1; off > 0; off >>= 1) sum += __shfl_down(sum, off, MI355X_WAVE);
-        if (r < nrows && sub == 0) yout[r0 + r] = ADD ? (ysum + sum) : sum;
-      }
-    }
-    if (!have_next) break;
-    q = qn; b0 = nb0; b1 = nb1; rs = nrs; re = nre; ysum = nysum;
-#pragma unroll
-    for (int p = 0; p < PAIRS; ++p) { v[p] = vn[p]; ix[p] = ixn[p]; }
-  }
-#undef PIPE_LB
-#undef PIPE_TPR
-}
-
 // ---------------------------------------------------------------------------------------------
 // BCSR (MatMult_SeqBAIJ_3/_4/_N, reference src/mat/impls/baij/seq/baij2.c:331-436,981) with the same
 // row-block streaming structure: the plan is built over the block-row pointer scaled by bs*bs (so it
@@ -542,53 +366,54 @@ __global__ __launch_bounds__(SPMV_THREADS) void bsr_rowblock_kernel(const int2 *
     if (tid < BS) { double t = part[0][tid]; for (int w = 1; w < SPMV_THREADS / MI355X_WAVE; ++w) t += part[w][tid]; y[(long)r0 * BS + tid] = t; }
     return;
   }
+  if (k1 == k0) {   // only empty block rows
+    if (tid < nv) y[(long)r0 * BS + tid] = 0.0;
+    return;
+  }
   int tpr = 1;
   while (tpr < MI355X_WAVE && nv * (tpr * 2) <= SPMV_THREADS) tpr *= 2;
-  // extents of this lane's point row, requested before the stream
+  // extents of this lane's point row, requested before the stream; all loads unconditional (see the idx8 kernel)
   const int v = tid / tpr, sub = tid & (tpr - 1);
-  int s = 0, cnt = 0, rr_ = 0, br = 0;
-  if (v < nv) {
-    br = r0 + v / BS;
-    rr_ = v - (v / BS) * BS;
-    const int a0 = ai[br], a1 = ai[br + 1];
-    s = a0 * BS2 - k0;
-    cnt = (a1 - a0) * BS;
-  }
+  const int vc = v < nv ? v : nv - 1;
+  const int br = r0 + vc / BS;
+  const int rr_ = vc - (vc / BS) * BS;
+  const int a0 = ai[br], a1 = ai[br + 1];
   constexpr int PAIRS = SPMV_BLOCK_NNZ / (2 * SPMV_THREADS);
   const int ka = k0 & ~1;
   v2d vv[PAIRS];
-  int c0[PAIRS], c1[PAIRS];
-  bool full[PAIRS];
+  int j0[PAIRS], j1[PAIRS], cc0[PAIRS], cc1[PAIRS];
 #pragma unroll
   for (int p = 0; p < PAIRS; ++p) {
     const int k = ka + 2 * tid + p * 2 * SPMV_THREADS;
-    full[p] = (k >= k0) && (k + 1 < k1);
-    if (full[p]) {
-      vv[p] = SPMV_LOAD(reinterpret_cast<const v2d *>(aa + k));
-      const int blk0 = k / BS2, blk1 = (k + 1) / BS2;
-      c0[p] = aj[blk0] * BS + (k - blk0 * BS2) / BS;
-      c1[p] = aj[blk1] * BS + (k + 1 - blk1 * BS2) / BS;
-    }
+    const bool in = k < k1;
+    const bool v0 = in && k >= k0, v1 = in && (k + 1 < k1);
+    const int kk = in ? k : ka;
+    vv[p] = SPMV_LOAD(reinterpret_cast<const v2d *>(aa + kk));
+    // value index each slot takes its block column from: its own, or a neighbour inside the block
+    const int f0 = kk + (v0 ? 0 : (in ? 1 : (k0 & 1)));
+    const int f1 = kk + (v1 ? 1 : (in ? 0 : (k0 & 1)));
+    const int blk0 = f0 / BS2, blk1 = f1 / BS2;
+    j0[p] = aj[blk0];
+    j1[p] = aj[blk1];
+    cc0[p] = (f0 - blk0 * BS2) / BS;
+    cc1[p] = (f1 - blk1 * BS2) / BS;
   }
   double xa[PAIRS], xb[PAIRS];
 #pragma unroll
-  for (int p = 0; p < PAIRS; ++p)
-    if (full[p]) { xa[p] = x[c0[p]]; xb[p] = x[c1[p]]; }
+  for (int p = 0; p < PAIRS; ++p) {
+    xa[p] = x[(long)j0[p] * BS + cc0[p]];
+    xb[p] = x[(long)j1[p] * BS + cc1[p]];
+  }
 #pragma unroll
   for (int p = 0; p < PAIRS; ++p) {
     const int k = ka + 2 * tid + p * 2 * SPMV_THREADS;
-    if (full[p]) {
-      prod[k - k0] = vv[p].x * xa[p];
-      prod[k - k0 + 1] = vv[p].y * xb[p];
-    } else {
-      for (int e = k; e <= k + 1; ++e)
-        if (e >= k0 && e < k1) {
-          const int blk = e / BS2;
-          prod[e - k0] = SPMV_LOAD(aa + e) * x[(long)aj[blk] * BS + (e - blk * BS2) / BS];
-        }
-    }
+    const double pa = vv[p].x * xa[p], pb = vv[p].y * xb[p];
+    prod[(k >= k0 && k < k1) ? k - k0 : SPMV_BLOCK_NNZ - 1] = pa;
+    prod[(k + 1 < k1) ? k + 1 - k0 : SPMV_BLOCK_NNZ - 1] = pb;
   }
   __syncthreads();
+  const int s = a0 * BS2 - k0;
+  const int cnt = v < nv ? (a1 - a0) * BS : 0;
   double sum = 0.0;
   for (int j = sub; j < cnt; j += tpr) sum += prod[s + BS * j + rr_];
   for (int off = tpr >> 1; off > 0; off >>= 1) sum += __shfl_down(sum, off, MI355X_WAVE);
@@ -620,10 +445,6 @@ static int launch_spmv(mi355x_handle_t h, mi355x_spmv_plan_t p, const int *ai, c
 #else
     const int g8 = p->nblocks;
 #endif
-    if (p->pipe_grid > 0 && p->pipe_grid < p->nblocks)
-      hipLaunchKernelGGL((spmv_csr_idx8_pipe_kernel<ADD>), dim3(p->pipe_grid), dim3(SPMV_THREADS), 0, h->stream, p->d_rowblk,
-                         p->nblocks, ai, p->d_idx8, p->d_offtab, p->ntab, aa, x, yin, yout);
-    else
     hipLaunchKernelGGL((spmv_csr_rowblock_idx8_kernel<ADD>), dim3(g8), dim3(SPMV_THREADS), 0, h->stream, p->d_rowblk,
                        p->nblocks, ai, p->d_idx8, p->d_offtab, p->ntab, aa, x, yin, yout);
     MI355X_LAUNCH_CHECK();
@@ -657,7 +478,6 @@ int mi355x_spmv_plan_create(mi355x_handle_t h, int nrows, const int *ai_host, co
   p->d_offtab = nullptr;
   p->ntab = 0;
   p->nlong = 0;
-  p->pipe_grid = 0;
   std::vector<int2> rb;
   rb.reserve((size_t)nrows / 128 + 2);
   rb.push_back(make_int2(0, ai_host[0]));
@@ -725,14 +545,6 @@ int mi355x_spmv_plan_compress_indices(mi355x_handle_t h, mi355x_spmv_plan_t p, c
   MI355X_TRY(hipMemcpyAsync(p->d_offtab, tab, sizeof(int) * (size_t)ntab, hipMemcpyHostToDevice, h->stream));
   MI355X_TRY(hipStreamSynchronize(h->stream));
   p->ntab = ntab;
-  // pipelined walkers: MI355X_SPMV_PIPE workgroups per CU (0 = one workgroup per row block)
-  {
-    int wg_per_cu = SPMV_PIPE_DEFAULT;
-    if (const char *e = getenv("MI355X_SPMV_PIPE")) wg_per_cu = atoi(e);
-    int dev = 0, ncu = 256;
-    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-    if (wg_per_cu > 0 && ncu >= MI355X_NXCD) p->pipe_grid = (ncu / MI355X_NXCD) * MI355X_NXCD * wg_per_cu;
-  }
   return 0;
 }
 
