@@ -123,6 +123,12 @@ int mi355x_vec_dotnorm2(mi355x_handle_t h, size_t n, const double *s, const doub
  * mi355x_vec_axpy x2, mi355x_vec_pointwise_mult, mi355x_vec_norm(2), mi355x_vec_dot in sequence. */
 int mi355x_vec_cg_update(mi355x_handle_t h, size_t n, double a, const double *p, const double *w, const double *d,
                          double *x, double *r, double *z, double *out);
+/* The same sweep with the step length formed on the device: a = beta / *dpi_dev (dpi = p'w left in device memory by
+ * mi355x_vec_dot, all-reduced there on several ranks).  The break-down tests of cg.c:196-199 (dpi NaN/Inf, dpi == 0,
+ * check_sign && dpi*dpiold <= 0) are evaluated in the kernel: if one fires, x, r, z are left untouched.
+ * out[0] = sum z*z, out[1] = sum z*r, out[2] = dpi (for the host's own copy of those tests). */
+int mi355x_vec_cg_update_dev(mi355x_handle_t h, size_t n, double beta, const double *dpi_dev, double dpiold, int check_sign,
+                             const double *p, const double *w, const double *d, double *x, double *r, double *z, double *out);
 /* VecMDot_Seq         src/vec/vec/impls/seq/dvec2.c:146     out[j] = sum_i x_i y_j,i , j<nv ; x read once per 8 y's */
 int mi355x_vec_mdot(mi355x_handle_t h, size_t n, int nv, const double *x, const double *const *y, double *out);
 /* VecSum / VecMax helpers are not on the Krylov path and are not provided. */

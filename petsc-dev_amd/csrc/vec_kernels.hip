@@ -198,6 +198,9 @@ __device__ __forceinline__ void publish_to_host(unsigned long long *host_seq, un
   }
 }
 
+// functors that need a once-per-lane hook before the sweep specialise this
+template <class F> struct has_prologue { static constexpr bool value = false; };
+
 // F::accum(i2 or i, acc): adds element contributions
 template <int NOUT, int MODE, class F>
 __global__ __launch_bounds__(MI355X_BLOCK) void reduce_kernel(F f, size_t n, int vec_ok, double *partials,
@@ -210,6 +213,7 @@ __global__ __launch_bounds__(MI355X_BLOCK) void reduce_kernel(F f, size_t n, int
   double acc[NOUT];
 #pragma unroll
   for (int j = 0; j < NOUT; ++j) acc[j] = 0.0;
+  if constexpr (has_prologue<F>::value) f.prologue(tid, acc);
   if (vec_ok) {
     const size_t n2 = n >> 1;
     f.template sweep<NOUT>(tid, stride, n2, acc);
@@ -402,6 +406,68 @@ struct CGUpdateF {
     x[i] = xv; r[i] = rv; z[i] = zv;
   }
 };
+// The same sweep with the step length computed on the device: a = beta / dpi where dpi = p'w is still in device memory
+// (the VecTDot kernel, all-reduced in place over RCCL on several ranks, wrote it there), so the host does not have to
+// wait for the dot before it can launch the update -- one host synchronisation per CG iteration instead of two.
+// KSPSolve_CG's break-down tests on dpi (cg.c:196-199) are evaluated here too: when one fires nothing is modified, and
+// the host, which receives dpi in out[2], takes the reference's exit with x, r, z untouched.  out[2] carries dpi
+// through the reduction tree unchanged (lane 0 of workgroup 0 contributes it, every other lane +0.0).
+struct CGUpdateDevF {
+  double beta, dpiold;
+  int check_sign;
+  const double *dpi_ptr;
+  const double *p, *w, *d;
+  double *x, *r, *z;
+  __device__ __forceinline__ bool scalars(double &a) const {
+    const double dpi = *dpi_ptr;
+    const bool bad = !(dpi == dpi) || fabs(dpi) == __builtin_huge_val() || dpi == 0.0 || (check_sign && dpi * dpiold <= 0.0);
+    a = bad ? 0.0 : beta / dpi;
+    return !bad;
+  }
+  __device__ __forceinline__ void prologue(size_t tid, double (&acc)[3]) const {
+    if (tid == 0) acc[2] = *dpi_ptr;
+  }
+  __device__ __forceinline__ void step(double a, double pv, double wv, double dv, double &xv, double &rv, double &zv, double (&acc)[3]) const {
+    if (a != 0.0) {            // VecAXPY leaves y alone for alpha == 0 (bvec1.c:253)
+      xv = xv + a * pv;
+      rv = rv + (-a) * wv;
+    }
+    zv = rv * dv;
+    acc[0] += zv * zv;
+    acc[1] += zv * rv;
+  }
+  template <int NOUT_>
+  __device__ __forceinline__ void sweep(size_t tid, size_t stride, size_t n2, double (&acc)[NOUT_]) const {
+    double a;
+    if (!scalars(a)) return;
+    const double2 *p2 = reinterpret_cast<const double2 *>(p), *w2 = reinterpret_cast<const double2 *>(w);
+    const double2 *d2 = reinterpret_cast<const double2 *>(d);
+    double2 *x2 = reinterpret_cast<double2 *>(x), *r2 = reinterpret_cast<double2 *>(r), *z2 = reinterpret_cast<double2 *>(z);
+    size_t i = tid;
+    for (; i + stride < n2; i += 2 * stride) {
+      double2 pv0 = p2[i], pv1 = p2[i + stride], wv0 = w2[i], wv1 = w2[i + stride], dv0 = d2[i], dv1 = d2[i + stride];
+      double2 xv0 = x2[i], xv1 = x2[i + stride], rv0 = r2[i], rv1 = r2[i + stride], zv0, zv1;
+      step(a, pv0.x, wv0.x, dv0.x, xv0.x, rv0.x, zv0.x, acc); step(a, pv0.y, wv0.y, dv0.y, xv0.y, rv0.y, zv0.y, acc);
+      step(a, pv1.x, wv1.x, dv1.x, xv1.x, rv1.x, zv1.x, acc); step(a, pv1.y, wv1.y, dv1.y, xv1.y, rv1.y, zv1.y, acc);
+      x2[i] = xv0; r2[i] = rv0; z2[i] = zv0;
+      x2[i + stride] = xv1; r2[i + stride] = rv1; z2[i + stride] = zv1;
+    }
+    for (; i < n2; i += stride) {
+      double2 pv = p2[i], wv = w2[i], dv = d2[i], xv = x2[i], rv = r2[i], zv;
+      step(a, pv.x, wv.x, dv.x, xv.x, rv.x, zv.x, acc); step(a, pv.y, wv.y, dv.y, xv.y, rv.y, zv.y, acc);
+      x2[i] = xv; r2[i] = rv; z2[i] = zv;
+    }
+  }
+  __device__ void accum1(size_t i, double (&acc)[3]) const {
+    double a;
+    if (!scalars(a)) return;
+    double xv = x[i], rv = r[i], zv;
+    step(a, p[i], w[i], d[i], xv, rv, zv, acc);
+    x[i] = xv; r[i] = rv; z[i] = zv;
+  }
+};
+template <> struct has_prologue<CGUpdateDevF> { static constexpr bool value = true; };
+
 template <int NV>
 struct MDotF {
   const double *x;
@@ -577,6 +643,13 @@ int mi355x_vec_cg_update(mi355x_handle_t h, size_t n, double a, const double *p,
   int v = mi355x_aligned16(p) && mi355x_aligned16(w) && mi355x_aligned16(d) && mi355x_aligned16(x) && mi355x_aligned16(r) &&
           mi355x_aligned16(z);
   return launch_reduce<2, RED_SUM>(h, f, n, v, out);
+}
+int mi355x_vec_cg_update_dev(mi355x_handle_t h, size_t n, double beta, const double *dpi_dev, double dpiold, int check_sign,
+                             const double *p, const double *w, const double *d, double *x, double *r, double *z, double *out) {
+  CGUpdateDevF f{beta, dpiold, check_sign, dpi_dev, p, w, d, x, r, z};
+  int v = mi355x_aligned16(p) && mi355x_aligned16(w) && mi355x_aligned16(d) && mi355x_aligned16(x) && mi355x_aligned16(r) &&
+          mi355x_aligned16(z);
+  return launch_reduce<3, RED_SUM>(h, f, n, v, out);
 }
 int mi355x_vec_mdot(mi355x_handle_t h, size_t n, int nv, const double *x, const double *const *y, double *out) {
   int pos = 0;

@@ -8,7 +8,7 @@
 #include "petscimpl.h"
 
 /* ================================================================== CG */
-typedef struct { PetscBool singlereduction; PetscBool fused; } KSP_CG;   /* cgimpl.h; fused: see KSPSolve_CG */
+typedef struct { PetscBool singlereduction; PetscInt fused; } KSP_CG;   /* cgimpl.h; fused: 0/1/2, see KSPSolve_CG */
 static PetscErrorCode KSPSetUp_CG(KSP ksp) {   /* cg.c:50-80 (no eigenvalue work): 3 work vectors, 5 with -ksp_cg_single_reduction */
   return KSPDefaultGetWork(ksp, ((KSP_CG *)ksp->data)->singlereduction ? 5 : 3);
 }
@@ -17,7 +17,7 @@ static PetscErrorCode KSPSetFromOptions_CG(KSP ksp) {   /* cg.c:330-345 */
   PetscErrorCode ierr = PetscOptionsGetString(ksp->prefix, "-ksp_cg_single_reduction", t, sizeof(t), &set);CHKERRQ(ierr);
   if (set) ((KSP_CG *)ksp->data)->singlereduction = (PetscBool)(strcmp(t, "0") && strcmp(t, "false"));
   ierr = PetscOptionsGetString(ksp->prefix, "-ksp_cg_fused", t, sizeof(t), &set);CHKERRQ(ierr);
-  if (set) ((KSP_CG *)ksp->data)->fused = (PetscBool)(strcmp(t, "0") && strcmp(t, "false"));
+  if (set) ((KSP_CG *)ksp->data)->fused = (!strcmp(t, "0") || !strcmp(t, "false")) ? 0 : ((!strcmp(t, "1") || !strcmp(t, "true")) ? 1 : 2);
   return 0;
 }
 static PetscErrorCode KSPDestroy_CG(KSP ksp) { free(ksp->data); ksp->data = NULL; return 0; }
@@ -31,12 +31,21 @@ static PetscErrorCode KSPSolve_CG(KSP ksp) {
   Vec X = ksp->vec_sol, B = ksp->vec_rhs, R = ksp->work[0], Z = ksp->work[1], P = ksp->work[2];
   Vec S = single ? ksp->work[3] : NULL, W = single ? ksp->work[4] : Z;   /* cg.c:116-122 */
   Mat Amat = ksp->pc->mat;
-  /* Fused forms (default on, -ksp_cg_fused 0 turns them off; iterates and history are bit-identical either way):
-   * with PCJACOBI the two AXPYs, the PCApply, the norm and the dot of cg.c:206-232 are one sweep
-   * (VecCGUpdate_HIPMI355X); with any other PC the norm and the dot share one VecDotNorm2 reduction. */
-  const PetscBool fused = (PetscBool)(((KSP_CG *)ksp->data)->fused && !single);
+  /* Fused forms, -ksp_cg_fused <0|1|2> (default 2); iterates and history carry the same bits at every level:
+   *  1: with PCJACOBI the two AXPYs, the PCApply, the norm and the dot of cg.c:206-232 are one sweep
+   *     (VecCGUpdate_HIPMI355X); with any other PC the norm and the dot share one VecDotNorm2 reduction;
+   *  2: as 1, and with PCJACOBI dpi = p'w stays on the device, where the update forms a = beta/dpi itself: one host
+   *     synchronisation per iteration instead of two (VecTDotBegin_HIPMI355X / VecCGUpdateDev_HIPMI355X);
+   *  0: the reference's op-by-op sequence. */
+  const PetscInt flevel = single ? 0 : ((KSP_CG *)ksp->data)->fused;
+  const PetscBool fused = (PetscBool)(flevel > 0);
   Vec D = NULL;
-  if (fused) { ierr = PCJacobiGetInverseDiagonal_Private(ksp->pc, &D);CHKERRQ(ierr); }
+  PetscBool devscalar = PETSC_FALSE;
+  if (fused) {
+    ierr = PCJacobiGetInverseDiagonal_Private(ksp->pc, &D);CHKERRQ(ierr);
+    if (D) { PetscBool ok; ierr = VecCGUpdateCheck_HIPMI355X(X, R, Z, P, W, D, &ok);CHKERRQ(ierr); if (!ok) D = NULL; }
+    devscalar = (PetscBool)(D && flevel > 1);
+  }
 
   ksp->its = 0;
   if (!ksp->guess_zero) {
@@ -65,20 +74,28 @@ static PetscErrorCode KSPSolve_CG(KSP ksp) {
     if (!i) { ierr = VecCopy(Z, P);CHKERRQ(ierr); b = 0.0; }     /* p <- z */
     else { b = beta / betaold; ierr = VecAYPX(P, b, Z);CHKERRQ(ierr); }   /* p <- z + b*p */
     dpiold = dpi;
+    PetscBool dpi_on_device = PETSC_FALSE;
     if (!single || !i) {
       ierr = KSP_MatMult(ksp, Amat, P, W);CHKERRQ(ierr);         /* w <- Ap */
-      ierr = VecTDot(P, W, &dpi);CHKERRQ(ierr);                  /* dpi <- p'w */
+      if (devscalar) { ierr = VecTDotBegin_HIPMI355X(P, W, &dpi_on_device);CHKERRQ(ierr); }
+      if (!dpi_on_device) { ierr = VecTDot(P, W, &dpi);CHKERRQ(ierr); }   /* dpi <- p'w */
     } else {                                                      /* cg.c:200-203: recurrences instead of a product and a dot */
       ierr = VecAYPX(W, beta / betaold, S);CHKERRQ(ierr);        /* w <- Ap */
       dpi = delta - beta * beta * dpiold / (betaold * betaold);  /* dpi <- p'w */
     }
     betaold = beta;
+    PetscBool have_beta = PETSC_FALSE;
+    PetscScalar zz = 0.0, zr = 0.0;
+    if (dpi_on_device) {
+      /* the update kernel applies the tests below to dpi itself and touches nothing if one fires; dpi comes back
+       * with the two sums, and the host takes the same exits */
+      ierr = VecCGUpdateDev_HIPMI355X(X, R, Z, P, W, D, beta, dpiold, (PetscBool)(i > 0), &zz, &zr, &dpi);CHKERRQ(ierr);
+      have_beta = PETSC_TRUE;
+    }
     if (PetscIsInfOrNanScalar(dpi)) SETERRQ(ksp->comm, PETSC_ERR_FP, "Infinite or not-a-number generated in dot product");
     if ((dpi == 0.0) || ((i > 0) && (dpi * dpiold <= 0.0))) { ksp->reason = KSP_DIVERGED_INDEFINITE_MAT; break; }
     a = beta / dpi;
-    PetscBool have_beta = PETSC_FALSE;
-    PetscScalar zz, zr;
-    if (fused && D) { ierr = VecCGUpdate_HIPMI355X(X, R, Z, P, W, D, a, &zz, &zr, &have_beta);CHKERRQ(ierr); }
+    if (!have_beta && fused && D) { ierr = VecCGUpdate_HIPMI355X(X, R, Z, P, W, D, a, &zz, &zr, &have_beta);CHKERRQ(ierr); }
     if (!have_beta) {
       ierr = VecAXPY(X, a, P);CHKERRQ(ierr);                     /* x <- x + ap */
       ierr = VecAXPY(R, -a, W);CHKERRQ(ierr);                    /* r <- r - aw */
@@ -110,7 +127,7 @@ PetscErrorCode KSPCreate_CG(KSP ksp) {
   KSP_CG *cg;
   PetscErrorCode ierr = PetscMalloc(sizeof(*cg), &cg);CHKERRQ(ierr);
   cg->singlereduction = PETSC_FALSE;
-  cg->fused = PETSC_TRUE;
+  cg->fused = 2;
   ksp->data = cg;
   ksp->ops->setup = KSPSetUp_CG; ksp->ops->solve = KSPSolve_CG; ksp->ops->setfromoptions = KSPSetFromOptions_CG; ksp->ops->destroy = KSPDestroy_CG;
   return 0;

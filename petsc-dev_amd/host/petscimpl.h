@@ -133,6 +133,9 @@ PetscErrorCode VecHIPGetWrite(Vec v, PetscScalar **d);       /* contents will be
 PetscErrorCode VecHIPGetReadWrite(Vec v, PetscScalar **d);
 PetscErrorCode VecHIPRestoreWrite(Vec v);                    /* device newer; state++ */
 PetscErrorCode VecCGUpdate_HIPMI355X(Vec x, Vec r, Vec z, Vec p, Vec w, Vec d, PetscScalar a, PetscScalar *zz, PetscScalar *zr, PetscBool *done);
+PetscErrorCode VecCGUpdateCheck_HIPMI355X(Vec x, Vec r, Vec z, Vec p, Vec w, Vec d, PetscBool *ok);
+PetscErrorCode VecTDotBegin_HIPMI355X(Vec x, Vec y, PetscBool *ok);   /* result stays on the device; pairs with VecCGUpdateDev */
+PetscErrorCode VecCGUpdateDev_HIPMI355X(Vec x, Vec r, Vec z, Vec p, Vec w, Vec d, PetscScalar beta, PetscScalar dpiold, PetscBool check_sign, PetscScalar *zz, PetscScalar *zr, PetscScalar *dpi);
 PetscErrorCode PCJacobiGetInverseDiagonal_Private(PC pc, Vec *d);   /* NULL unless pc is a set-up PCJACOBI */
 
 /* ---- VecScatter (VecScatter_MPI_General, include/petsc-private/vecimpl.h:509-555) ---- */

@@ -248,24 +248,30 @@ static PetscErrorCode VecMAXPY_HIP(Vec y, PetscInt nv, const PetscScalar *alpha,
 /* finish: `count` partial results are being written by the kernel just launched.  One rank: they
  * land in the pinned scratch.  Several ranks: they land in HBM scratch, are all-reduced in place
  * over RCCL on the same stream, copied to the pinned scratch, and only then do we synchronise. */
+/* A communicator with an RCCL communicator attached reduces on the device (also a one-rank one: the tests use that
+ * to run this path on a single GPU); several ranks without one use the host-staged transport. */
+#define DEVICE_COLLECTIVES(x) ((x)->comm->dcomm != NULL)
+#define HOST_STAGED(x) ((x)->comm->size > 1 && !(x)->comm->dcomm)
 static PetscErrorCode reduce_target(Vec x, PetscDeviceCtx *dc, double **out) {
-  *out = (x->comm->size > 1 && x->comm->dcomm) ? mi355x_handle_device_scratch(dc->h) : mi355x_handle_host_scratch(dc->h);
+  *out = DEVICE_COLLECTIVES(x) ? mi355x_handle_device_scratch(dc->h) : mi355x_handle_host_scratch(dc->h);
   return 0;
 }
-static PetscErrorCode reduce_finish(Vec x, PetscDeviceCtx *dc, int count, int is_max, PetscScalar *result) {
+/* count values were reduced on this rank into the target; the first nsum of them are summed (or max-ed) over the
+ * ranks, the rest are carried along as they are */
+static PetscErrorCode reduce_finish2(Vec x, PetscDeviceCtx *dc, int nsum, int count, int is_max, PetscScalar *result) {
   double *hs = mi355x_handle_host_scratch(dc->h);
-  if (x->comm->size > 1 && !x->comm->dcomm) {
+  if (HOST_STAGED(x)) {
     /* host-staged transport (no RCCL communicator attached): the reference's own arrangement, a device
      * reduction followed by a host all-reduce (mpicusp.cu:32-113); used by the shared-GPU rehearsal tests */
     CHKHIP(mi355x_handle_synchronize(dc->h));
     for (int j = 0; j < count; j++) result[j] = hs[j];
-    if (x->comm->allreduce(x->comm->ctx, result, count, 1, is_max ? 1 : 0)) SETERRQ(x->comm, PETSC_ERR_LIB, "allreduce failed");
+    if (x->comm->allreduce(x->comm->ctx, result, nsum, 1, is_max ? 1 : 0)) SETERRQ(x->comm, PETSC_ERR_LIB, "allreduce failed");
     return 0;
   }
-  if (x->comm->size > 1) {
+  if (DEVICE_COLLECTIVES(x)) {
     double *ds = mi355x_handle_device_scratch(dc->h);
-    if (is_max) CHKHIP(mi355x_comm_allreduce_max(x->comm->dcomm, dc->h, ds, (size_t)count));
-    else CHKHIP(mi355x_comm_allreduce_sum(x->comm->dcomm, dc->h, ds, (size_t)count));
+    if (is_max) CHKHIP(mi355x_comm_allreduce_max(x->comm->dcomm, dc->h, ds, (size_t)nsum));
+    else CHKHIP(mi355x_comm_allreduce_sum(x->comm->dcomm, dc->h, ds, (size_t)nsum));
     /* device -> pinned host by a tiny kernel on the same stream (lower latency than a DMA copy of 8..256 bytes) */
     CHKHIP(mi355x_vec_copy(dc->h, (size_t)count, ds, hs));
     CHKHIP(mi355x_handle_synchronize(dc->h));
@@ -276,6 +282,9 @@ static PetscErrorCode reduce_finish(Vec x, PetscDeviceCtx *dc, int count, int is
   }
   for (int j = 0; j < count; j++) result[j] = hs[j];
   return 0;
+}
+static PetscErrorCode reduce_finish(Vec x, PetscDeviceCtx *dc, int count, int is_max, PetscScalar *result) {
+  return reduce_finish2(x, dc, count, count, is_max, result);
 }
 
 static PetscErrorCode VecDot_HIP(Vec x, Vec y, PetscScalar *val) {
@@ -342,9 +351,9 @@ static PetscErrorCode VecDotNorm2_HIP(Vec s, Vec t, PetscScalar *dp, PetscScalar
 PetscErrorCode VecCGUpdate_HIPMI355X(Vec x, Vec r, Vec z, Vec p, Vec w, Vec d, PetscScalar a, PetscScalar *zz, PetscScalar *zr, PetscBool *done) {
   PetscErrorCode ierr; const PetscScalar *dp_, *dw, *dd; PetscScalar *dx, *dr, *dz; double *out; PetscScalar res[2]; DEVCTX;
   *done = PETSC_FALSE;
-  if (!is_hip(x) || !is_hip(r) || !is_hip(z) || !is_hip(p) || !is_hip(w) || !is_hip(d) || a == 0.0) return 0;
-  if (x->map->n != r->map->n || x->map->n != z->map->n || x->map->n != p->map->n || x->map->n != w->map->n || x->map->n != d->map->n) return 0;
-  if (x == r || x == z || r == z || z == p || z == d) return 0;   /* z may be w (cg.c:122 keeps A*p in Z) */
+  ierr = VecCGUpdateCheck_HIPMI355X(x, r, z, p, w, d, done);CHKERRQ(ierr);
+  if (!*done || a == 0.0) { *done = PETSC_FALSE; return 0; }
+  *done = PETSC_FALSE;
   ierr = VecHIPGetRead(p, &dp_);CHKERRQ(ierr);
   ierr = VecHIPGetRead(w, &dw);CHKERRQ(ierr);
   ierr = VecHIPGetRead(d, &dd);CHKERRQ(ierr);
@@ -359,6 +368,54 @@ PetscErrorCode VecCGUpdate_HIPMI355X(Vec x, Vec r, Vec z, Vec p, Vec w, Vec d, P
   *zz = res[0]; *zr = res[1];
   ierr = PetscLogFlops(9.0 * x->map->n);CHKERRQ(ierr);   /* 2n + 2n + n + 2n + 2n */
   *done = PETSC_TRUE;
+  return 0;
+}
+
+/* Split form for KSPSolve_CG with device-resident scalars.  VecTDotBegin leaves p'w in slot DPI_SLOT of the
+ * device scratch (all-reduced in place over RCCL when the communicator has one) without any host synchronisation;
+ * VecCGUpdateDev then forms a = beta/dpi on the device, does the fused update and returns z'z, z'r and dpi with the
+ * one synchronisation of the iteration.  Not available with the host-staged transport (*ok = PETSC_FALSE). */
+#define DPI_SLOT 8
+PetscErrorCode VecTDotBegin_HIPMI355X(Vec x, Vec y, PetscBool *ok) {
+  PetscErrorCode ierr; const PetscScalar *dx, *dy; double *ds; DEVCTX;
+  *ok = PETSC_FALSE;
+  if (!is_hip(x) || !is_hip(y) || HOST_STAGED(x) || x->map->n != y->map->n) return 0;
+  ierr = VecHIPGetRead(x, &dx);CHKERRQ(ierr);
+  ierr = VecHIPGetRead(y, &dy);CHKERRQ(ierr);
+  ds = mi355x_handle_device_scratch(dc->h) + DPI_SLOT;
+  CHKHIP(mi355x_vec_dot(dc->h, N_(x), dx, dy, ds));
+  if (DEVICE_COLLECTIVES(x)) CHKHIP(mi355x_comm_allreduce_sum(x->comm->dcomm, dc->h, ds, 1));
+  if (x->map->n > 0) { ierr = PetscLogFlops(2.0 * x->map->n - 1);CHKERRQ(ierr); }
+  *ok = PETSC_TRUE;
+  return 0;
+}
+PetscErrorCode VecCGUpdateDev_HIPMI355X(Vec x, Vec r, Vec z, Vec p, Vec w, Vec d, PetscScalar beta, PetscScalar dpiold, PetscBool check_sign,
+                                        PetscScalar *zz, PetscScalar *zr, PetscScalar *dpi) {
+  PetscErrorCode ierr; const PetscScalar *dp_, *dw, *dd; PetscScalar *dx, *dr, *dz; double *out; PetscScalar res[3]; DEVCTX;
+  ierr = VecHIPGetRead(p, &dp_);CHKERRQ(ierr);
+  ierr = VecHIPGetRead(w, &dw);CHKERRQ(ierr);
+  ierr = VecHIPGetRead(d, &dd);CHKERRQ(ierr);
+  ierr = VecHIPGetReadWrite(x, &dx);CHKERRQ(ierr);
+  ierr = VecHIPGetReadWrite(r, &dr);CHKERRQ(ierr);
+  if (z == w) { ierr = VecHIPGetReadWrite(z, &dz);CHKERRQ(ierr); }   /* left as it is when the update is refused */
+  else { ierr = VecHIPGetWrite(z, &dz);CHKERRQ(ierr); }
+  ierr = reduce_target(x, dc, &out);CHKERRQ(ierr);
+  CHKHIP(mi355x_vec_cg_update_dev(dc->h, N_(x), beta, mi355x_handle_device_scratch(dc->h) + DPI_SLOT, dpiold, (int)check_sign,
+                                  dp_, dw, dd, dx, dr, dz, out));
+  VecHIPRestoreWrite(x); VecHIPRestoreWrite(r); VecHIPRestoreWrite(z);
+  PetscObjectStateIncrease(x); PetscObjectStateIncrease(r); PetscObjectStateIncrease(z);
+  ierr = reduce_finish2(x, dc, 2, 3, 0, res);CHKERRQ(ierr);
+  *zz = res[0]; *zr = res[1]; *dpi = res[2];
+  ierr = PetscLogFlops(9.0 * x->map->n);CHKERRQ(ierr);
+  return 0;
+}
+/* can the six vectors of a CG iteration take the fused update at all (types, sizes, aliasing)? */
+PetscErrorCode VecCGUpdateCheck_HIPMI355X(Vec x, Vec r, Vec z, Vec p, Vec w, Vec d, PetscBool *ok) {
+  *ok = PETSC_FALSE;
+  if (!is_hip(x) || !is_hip(r) || !is_hip(z) || !is_hip(p) || !is_hip(w) || !is_hip(d)) return 0;
+  if (x->map->n != r->map->n || x->map->n != z->map->n || x->map->n != p->map->n || x->map->n != w->map->n || x->map->n != d->map->n) return 0;
+  if (x == r || x == z || r == z || z == p || z == d) return 0;   /* z may be w (cg.c:122 keeps A*p in Z) */
+  *ok = PETSC_TRUE;
   return 0;
 }
 

@@ -213,12 +213,13 @@ def test_elasticity_aij_vs_inode_and_baij(P):
     assert np.all(np.abs(yb - y) <= 1e-12 * scale)
 
 
-def solve(P, ai, aj, aa, b, ksp, pc, x0=None, opts="", **tol):
+def solve(P, ai, aj, aa, b, ksp, pc, x0=None, opts="", comm=None, **tol):
     L = P.lib()
-    A = P.Mat.from_csr(ai, aj, aa)
-    vb = V(P, b)
-    vx = V(P, np.zeros(b.size) if x0 is None else x0)
-    k = P.KSP(comm=L.COMM_SELF)
+    comm = comm or L.COMM_SELF
+    A = P.Mat.from_csr(ai, aj, aa, comm=comm)
+    vb = P.Vec.from_array(b, comm=comm)
+    vx = P.Vec.from_array(np.zeros(b.size) if x0 is None else x0, comm=comm)
+    k = P.KSP(comm=comm)
     k.set_operators(A)
     L.PetscOptionsClear()
     L.PetscOptionsInsertString(("-ksp_type %s -pc_type %s %s" % (ksp, pc, opts)).encode())
@@ -249,17 +250,78 @@ def test_ksp_config1_cg_jacobi(P):
 
 @pytest.mark.parametrize("pc", ["jacobi", "none", "ilu"])
 def test_ksp_cg_fused_forms_are_bit_identical(P, pc):
-    """KSPSolve_CG's fused forms (default): with PCJACOBI one sweep does both AXPYs, the PCApply, the norm and the
-    dot; otherwise norm and dot share one VecDotNorm2.  -ksp_cg_fused 0 runs the reference's op-by-op sequence
-    (cg.c:206-232): iterates and the whole residual history must carry the same bits."""
+    """KSPSolve_CG's fused forms: level 1 -- with PCJACOBI one sweep does both AXPYs, the PCApply, the norm and the
+    dot, otherwise norm and dot share one VecDotNorm2; level 2 (default) -- additionally p'w stays on the device and
+    the sweep forms a = beta/dpi itself.  -ksp_cg_fused 0 runs the reference's op-by-op sequence (cg.c:206-232):
+    iterates and the whole residual history must carry the same bits at every level."""
     ai, aj, aa = pb.lap2d(41, 37)
     n = ai.size - 1
     b = orc.spmv(ai, aj, aa, np.cos(0.3 * np.arange(n)))
-    xf, hf, itsf, rf = solve(P, ai, aj, aa, b, "cg", pc, rtol=1e-9)
     xu, hu, itsu, ru = solve(P, ai, aj, aa, b, "cg", pc, opts="-ksp_cg_fused 0", rtol=1e-9)
-    assert itsf == itsu and rf == ru == 2 and itsf > 20
-    assert np.array_equal(bits(hf), bits(hu))
-    assert np.array_equal(bits(xf), bits(xu))
+    assert ru == 2 and itsu > 20
+    for level in ("1", "2", None):
+        xf, hf, itsf, rf = solve(P, ai, aj, aa, b, "cg", pc, opts=("-ksp_cg_fused " + level) if level else "", rtol=1e-9)
+        assert itsf == itsu and rf == ru
+        assert np.array_equal(bits(hf), bits(hu))
+        assert np.array_equal(bits(xf), bits(xu))
+
+
+def test_ksp_cg_indefinite_exits_match_at_every_fusion_level(P):
+    """A sign change of p'Ap is KSP_DIVERGED_INDEFINITE_MAT (cg.c:198) and leaves x at the previous iterate; with the
+    device-resident scalar the update kernel itself has to refuse the step.  Same iteration, same x bits at all levels."""
+    ai, aj, aa = pb.lap2d(12, 11)
+    n = ai.size - 1
+    aa = aa.copy()
+    for row in (5, 40, 77):                       # negative diagonal entries: indefinite, Jacobi PC indefinite too
+        k = ai[row] + int(np.where(aj[ai[row]:ai[row + 1]] == row)[0][0])
+        aa[k] = -3.0
+    b = np.cos(0.7 * np.arange(n))
+    res = {}
+    for level in ("0", "1", "2"):
+        for pc in ("none", "jacobi"):
+            x, h, its, reason = solve(P, ai, aj, aa, b, "cg", pc, opts="-ksp_cg_fused " + level, rtol=1e-12, max_it=200)
+            res[level, pc] = (bits(x).copy(), bits(h).copy(), its, reason)
+    for pc in ("none", "jacobi"):
+        assert res["0", pc][3] in (-8, -10)       # KSP_DIVERGED_INDEFINITE_PC / _MAT
+        for level in ("1", "2"):
+            assert res[level, pc][2:] == res["0", pc][2:]
+            assert np.array_equal(res[level, pc][0], res["0", pc][0]) and np.array_equal(res[level, pc][1], res["0", pc][1])
+    assert any(res["0", pc][3] == -10 for pc in ("none", "jacobi")), "no case exercised the INDEFINITE_MAT exit"
+
+
+def test_device_collectives_on_a_one_rank_rccl_communicator(P):
+    """The several-GPU reduction path (result in HBM scratch -> RCCL all-reduce in place on the compute stream -> copy
+    kernel to pinned memory -> one stream synchronisation; device-resident p'w for CG) run on ONE GPU by attaching a
+    one-rank RCCL communicator to a one-rank PetscComm.  Everything must equal the plain one-rank path bit for bit."""
+    import ctypes as C
+    import importlib
+    PD = importlib.import_module("petsc-dev_amd.dist")
+    L = P.lib()
+    k = P.load_kernels()
+    comm = PD.make_comm(0, 1, lambda b_: [b_], lambda a, op: a, lambda: None)
+    uid = C.create_string_buffer(128)
+    assert k.mi355x_comm_get_unique_id(uid) == 0
+    dcomm = C.c_void_p()
+    rc = k.mi355x_comm_init_rank(C.byref(dcomm), 1, 0, uid.raw)
+    assert rc == 0, k.mi355x_comm_error_string(rc).decode()
+    L.PetscCommSetDeviceComm(comm, dcomm)
+    try:
+        ai, aj, aa = pb.lap2d(33, 29)
+        n = ai.size - 1
+        b = orc.spmv(ai, aj, aa, np.cos(0.3 * np.arange(n)))
+        x = V(P, rnd(n, 5)); y = V(P, rnd(n, 6))
+        xc = P.Vec.from_array(x.array(), comm=comm); yc = P.Vec.from_array(y.array(), comm=comm)
+        for nt in (0, 1, 2, 3):
+            assert x.norm(nt) == xc.norm(nt)
+        assert x.dot(y) == xc.dot(yc)
+        for ksp, pc in (("cg", "jacobi"), ("cg", "none"), ("gmres", "jacobi"), ("bcgs", "jacobi")):
+            ref = solve(P, ai, aj, aa, b, ksp, pc, rtol=1e-9)
+            got = solve(P, ai, aj, aa, b, ksp, pc, rtol=1e-9, comm=comm)
+            assert got[2:] == ref[2:]
+            assert np.array_equal(bits(got[1]), bits(ref[1])) and np.array_equal(bits(got[0]), bits(ref[0]))
+    finally:
+        L.PetscCommSetDeviceComm(comm, None)
+        k.mi355x_comm_destroy(dcomm)
 
 
 def test_ksp_cg_single_reduction(P):

@@ -440,3 +440,40 @@ def test_cg_update_matches_separate_kernels_bitwise(dev, n):
     assert_bitexact(dev.get(dw, n), zo); assert_bitexact(dev.get(r2, n), ro); assert_bitexact(dev.get(x2, n), xo)
     for q in (dp, dw, dd, x1, r1, z1, x2, r2, z2):
         dev.free(q)
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 255, 4097, 1_000_001])
+def test_cg_update_dev_scalar_form(dev, n):
+    """mi355x_vec_cg_update_dev: a = beta / dpi formed on the device from a device-resident dpi.  Same bits as the
+    host-scalar form (IEEE division on both sides); dpi comes back in out[2]; when a break-down test of cg.c:196-199
+    fires (dpi NaN/Inf/0, or a sign change against dpiold) the vectors are left untouched."""
+    k = dev.k
+    beta, dpi = 0.83, 1.37
+    a = beta / dpi
+    p, w, d, x, r = rnd(n, 21), rnd(n, 22), 1.0 / (2.0 + rnd(n, 23) ** 2), rnd(n, 24), rnd(n, 25)
+    dp, dw, dd = dev.put(p), dev.put(w), dev.put(d)
+    x1, r1, z1 = dev.put(x), dev.put(r), dev.alloc(8 * max(n, 2))
+    x2, r2, z2 = dev.put(x), dev.put(r), dev.alloc(8 * max(n, 2))
+    ddpi = dev.put(np.array([dpi, 0.0]))
+    hs = dev.host_scratch()
+    dev.chk(k.mi355x_vec_cg_update(dev.h, n, a, dp, dw, dd, x1, r1, z1, hs)); ref = dev.scalar_out(2)
+    dev.chk(k.mi355x_vec_cg_update_dev(dev.h, n, beta, ddpi, 0.5, 1, dp, dw, dd, x2, r2, z2, hs)); out = dev.scalar_out(3)
+    assert_bitexact(out[:2], ref)
+    assert out[2] == dpi
+    for u, v in ((x1, x2), (r1, r2), (z1, z2)):
+        assert_bitexact(dev.get(u, n), dev.get(v, n))
+    # refused updates: nothing is written
+    xb, rb, zb = dev.get(x2, n), dev.get(r2, n), dev.get(z2, n)
+    for bad, dpiold, chk in ((0.0, 1.0, 0), (np.nan, 1.0, 0), (np.inf, 1.0, 0), (-1.0, 2.0, 1), (1.0, -2.0, 1)):
+        dev.chk(k.mi355x_memcpy_h2d(dev.h, ddpi, np.array([bad]).ctypes.data, 8)); dev.sync()
+        dev.chk(k.mi355x_vec_cg_update_dev(dev.h, n, beta, ddpi, dpiold, chk, dp, dw, dd, x2, r2, z2, hs)); out = dev.scalar_out(3)
+        assert (np.isnan(out[2]) and np.isnan(bad)) or out[2] == bad
+        assert out[0] == 0.0 and out[1] == 0.0
+        assert_bitexact(dev.get(x2, n), xb); assert_bitexact(dev.get(r2, n), rb); assert_bitexact(dev.get(z2, n), zb)
+    # a sign change is only a break-down when the caller asks for the test (first iteration: check_sign = 0)
+    dev.chk(k.mi355x_memcpy_h2d(dev.h, ddpi, np.array([-1.0]).ctypes.data, 8)); dev.sync()
+    dev.chk(k.mi355x_vec_cg_update_dev(dev.h, n, beta, ddpi, 2.0, 0, dp, dw, dd, x2, r2, z2, hs)); out = dev.scalar_out(3)
+    if n:
+        assert not np.array_equal(dev.get(x2, n), xb)
+    for q in (dp, dw, dd, x1, r1, z1, x2, r2, z2, ddpi):
+        dev.free(q)
