@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--n", type=int, default=256, help="grid points per side per GPU (rows per GPU = n^3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-its", type=int, default=20)
+    ap.add_argument("--ksp-opts", default="", help="extra options-database string (development: e.g. '-ksp_cg_fused 2')")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -71,6 +72,9 @@ def main():
     ksp.set_operators(A)
     ksp.set_type("cg")
     ksp.set_pc_type("jacobi")
+    if args.ksp_opts:
+        L.PetscOptionsInsertString(args.ksp_opts.encode())
+        ksp.set_from_options()
 
     # the dominant kernel: SpMV of the (diagonal block of the) matrix
     if world > 1:

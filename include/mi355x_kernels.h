@@ -43,6 +43,9 @@ int  mi355x_handle_synchronize(mi355x_handle_t h);
 /* wait for the last reduction written to the handle's pinned scratch (polls a completion word the kernel stores
  * after the result; bounded, falls back to a stream synchronise) */
 int  mi355x_handle_wait_result(mi355x_handle_t h);
+/* queue a copy of count (<= 64) doubles from device memory to the pinned scratch followed by the completion number:
+ * mi355x_handle_wait_result then returns as soon as THAT point of the stream is reached, whatever was queued behind it */
+int  mi355x_handle_publish(mi355x_handle_t h, const double *src_dev, int count);
 void *mi355x_handle_stream(mi355x_handle_t h);           /* the raw hipStream_t */
 /* pinned, device-visible scratch of >= 64 doubles owned by the handle
  * (reduction results are written here by the device, read by the host
@@ -118,6 +121,9 @@ int mi355x_vec_dot(mi355x_handle_t h, size_t n, const double *x, const double *y
 int mi355x_vec_norm(mi355x_handle_t h, size_t n, int type, const double *x, double *out);
 /* VecDotNorm2 (BiCGStab)  src/vec/vec/utils/vinv.c:1200   out[0] = sum s_i t_i, out[1] = sum t_i^2 */
 int mi355x_vec_dotnorm2(mi355x_handle_t h, size_t n, const double *s, const double *t, double *out);
+/* VecAYPX with the scalar's numerator on the device: y = x + (*num_dev / den) y (alpha == 0 -> copy, dvec2.c:980).
+ * KSPSolve_CG's p = z + (beta_new/beta_old) p when beta_new has not reached the host yet. */
+int mi355x_vec_aypx_dev(mi355x_handle_t h, size_t n, const double *num_dev, double den, const double *x, double *y);
 /* Fused CG update, one sweep for cg.c:206-232 + PCApply_Jacobi (jacobi.c:266-277):
  * x += a p; r += (-a) w; z = r .* d; out[0] = sum z*z, out[1] = sum z*r.  Same bits as
  * mi355x_vec_axpy x2, mi355x_vec_pointwise_mult, mi355x_vec_norm(2), mi355x_vec_dot in sequence. */
@@ -126,9 +132,12 @@ int mi355x_vec_cg_update(mi355x_handle_t h, size_t n, double a, const double *p,
 /* The same sweep with the step length formed on the device: a = beta / *dpi_dev (dpi = p'w left in device memory by
  * mi355x_vec_dot, all-reduced there on several ranks).  The break-down tests of cg.c:196-199 (dpi NaN/Inf, dpi == 0,
  * check_sign && dpi*dpiold <= 0) are evaluated in the kernel: if one fires, x, r, z are left untouched.
- * out[0] = sum z*z, out[1] = sum z*r, out[2] = dpi (for the host's own copy of those tests). */
+ * out[0] = sum z*z, out[1] = sum z*r, out[2] = dpi (for the host's own copy of those tests).  also_to_host != 0 with a
+ * device `out`: the three values are stored to the first pinned scratch slots as well, followed by the completion
+ * number (mi355x_handle_wait_result) -- the result serves a later kernel and the host without a second launch. */
 int mi355x_vec_cg_update_dev(mi355x_handle_t h, size_t n, double beta, const double *dpi_dev, double dpiold, int check_sign,
-                             const double *p, const double *w, const double *d, double *x, double *r, double *z, double *out);
+                             const double *p, const double *w, const double *d, double *x, double *r, double *z, double *out,
+                             int also_to_host);
 /* VecMDot_Seq         src/vec/vec/impls/seq/dvec2.c:146     out[j] = sum_i x_i y_j,i , j<nv ; x read once per 8 y's */
 int mi355x_vec_mdot(mi355x_handle_t h, size_t n, int nv, const double *x, const double *const *y, double *out);
 /* VecSum / VecMax helpers are not on the Krylov path and are not provided. */

@@ -198,13 +198,52 @@ __device__ __forceinline__ void publish_to_host(unsigned long long *host_seq, un
   }
 }
 
+// y = x + (num/den) y with the scalar's numerator still in device memory (KSPSolve_CG: b = beta_new/beta_old, beta_new
+// being the z'r the previous kernel on the stream has just reduced).  VecAYPX_Seq's special case alpha == 0 -> copy
+// (dvec2.c:980) is kept; alpha == +-1 need no special form (x + 1*y and x + (-1)*y are the bits of x + y and x - y).
+__global__ __launch_bounds__(MI355X_BLOCK) void aypx_dev_kernel(const double *num, double den, const double *x, double *y, size_t n, int vec_ok) {
+  const double alpha = *num / den;
+  const bool copy = (alpha == 0.0);
+  const size_t tid = (size_t)blockIdx.x * MI355X_BLOCK + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * MI355X_BLOCK;
+  if (vec_ok) {
+    const size_t n2 = n >> 1;
+    const double2 *x2 = reinterpret_cast<const double2 *>(x);
+    double2 *y2 = reinterpret_cast<double2 *>(y);
+    size_t i = tid;
+    for (; i + stride < n2; i += 2 * stride) {
+      double2 xv0 = x2[i], xv1 = x2[i + stride], yv0 = y2[i], yv1 = y2[i + stride], r0, r1;
+      r0.x = copy ? xv0.x : xv0.x + alpha * yv0.x; r0.y = copy ? xv0.y : xv0.y + alpha * yv0.y;
+      r1.x = copy ? xv1.x : xv1.x + alpha * yv1.x; r1.y = copy ? xv1.y : xv1.y + alpha * yv1.y;
+      y2[i] = r0;
+      y2[i + stride] = r1;
+    }
+    if (i < n2) {
+      double2 xv = x2[i], yv = y2[i], r;
+      r.x = copy ? xv.x : xv.x + alpha * yv.x; r.y = copy ? xv.y : xv.y + alpha * yv.y;
+      y2[i] = r;
+    }
+    if ((n & 1) && tid == 0) y[n - 1] = copy ? x[n - 1] : x[n - 1] + alpha * y[n - 1];
+  } else {
+    for (size_t i = tid; i < n; i += stride) y[i] = copy ? x[i] : x[i] + alpha * y[i];
+  }
+}
+
+// copy <= 64 doubles from device memory to the handle's pinned scratch, then store the completion number the host
+// polls (mi355x_handle_wait_result): how a result that had to stay on the device first (RCCL all-reduce, a later kernel
+// reading it) reaches the host without a stream synchronisation
+__global__ void publish_kernel(const double *src, double *host_dst, int count, unsigned long long *host_seq, unsigned long long seq) {
+  if ((int)threadIdx.x < count) host_dst[threadIdx.x] = src[threadIdx.x];
+  publish_to_host(host_seq, seq);
+}
+
 // functors that need a once-per-lane hook before the sweep specialise this
 template <class F> struct has_prologue { static constexpr bool value = false; };
 
 // F::accum(i2 or i, acc): adds element contributions
 template <int NOUT, int MODE, class F>
 __global__ __launch_bounds__(MI355X_BLOCK) void reduce_kernel(F f, size_t n, int vec_ok, double *partials,
-                                                             unsigned int *ticket, double *out,
+                                                             unsigned int *ticket, double *out, double *host_copy,
                                                              unsigned long long *host_seq, unsigned long long seq) {
   __shared__ double lds[MI355X_BLOCK / MI355X_WAVE][NOUT];
   __shared__ int is_last;
@@ -223,6 +262,7 @@ __global__ __launch_bounds__(MI355X_BLOCK) void reduce_kernel(F f, size_t n, int
   }
   if (gridDim.x == 1) {  // single workgroup: no hand-off needed
     block_reduce_store<NOUT, MODE>(acc, out, lds);
+    if (host_copy) { __syncthreads(); if (threadIdx.x < NOUT) host_copy[threadIdx.x] = out[threadIdx.x]; }
     publish_to_host(host_seq, seq);
     return;
   }
@@ -257,21 +297,28 @@ __global__ __launch_bounds__(MI355X_BLOCK) void reduce_kernel(F f, size_t n, int
   __syncthreads();
   block_reduce_store<NOUT, MODE>(acc, out, lds);
   if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // a result that stays on the device for the next kernel can be handed to the host as well (same lanes that stored it)
+  if (host_copy) { __syncthreads(); if (threadIdx.x < NOUT) host_copy[threadIdx.x] = out[threadIdx.x]; }
   publish_to_host(host_seq, seq);
 }
 
 template <int NOUT, int MODE, class F>
-static int launch_reduce(mi355x_handle_t h, F f, size_t n, int vec_ok, double *out) {
+static int launch_reduce(mi355x_handle_t h, F f, size_t n, int vec_ok, double *out, bool also_to_host = false) {
   int grid = mi355x_grid_for(n, 16);
   if (grid > 1024) grid = 1024;   // 4 workgroups per CU; the last one sums <= 1024 partials
   // a result that goes to the handle's pinned scratch is followed by a completion number (mi355x_handle_wait_result)
   unsigned long long *hs = nullptr, seq = 0;
+  double *host_copy = nullptr;
   if (out >= h->host_scratch && out < h->host_scratch + MI355X_SCRATCH_DOUBLES) {
     hs = const_cast<unsigned long long *>(h->host_seq);
     seq = ++h->seq;
+  } else if (also_to_host) {   // result to `out` (device) AND to the first NOUT pinned slots, then the completion number
+    hs = const_cast<unsigned long long *>(h->host_seq);
+    seq = ++h->seq;
+    host_copy = h->host_scratch;
   }
   hipLaunchKernelGGL((reduce_kernel<NOUT, MODE, F>), dim3(grid), dim3(MI355X_BLOCK), 0, h->stream, f, n, vec_ok,
-                     h->partials, h->ticket, out, hs, seq);
+                     h->partials, h->ticket, out, host_copy, hs, seq);
   MI355X_LAUNCH_CHECK();
   return 0;
 }
@@ -540,6 +587,21 @@ int mi355x_vec_aypx(mi355x_handle_t h, size_t n, double alpha, const double *x, 
   if (alpha == -1.0) return launch_map<2>(h, OpXmY{}, x, y, nullptr, y, n);
   return launch_map<2>(h, OpAypx{alpha}, x, y, nullptr, y, n);
 }
+int mi355x_vec_aypx_dev(mi355x_handle_t h, size_t n, const double *num_dev, double den, const double *x, double *y) {
+  if (n == 0) return 0;
+  int vec_ok = mi355x_aligned16(x) && mi355x_aligned16(y);
+  hipLaunchKernelGGL(aypx_dev_kernel, dim3(mi355x_grid_for(n, 4)), dim3(MI355X_BLOCK), 0, h->stream, num_dev, den, x, y, n, vec_ok);
+  MI355X_LAUNCH_CHECK();
+  return 0;
+}
+int mi355x_handle_publish(mi355x_handle_t h, const double *src_dev, int count) {
+  if (count < 0 || count > MI355X_SCRATCH_DOUBLES) return (int)hipErrorInvalidValue;
+  const unsigned long long seq = ++h->seq;
+  hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(MI355X_WAVE), 0, h->stream, src_dev, h->host_scratch, count,
+                     const_cast<unsigned long long *>(h->host_seq), seq);
+  MI355X_LAUNCH_CHECK();
+  return 0;
+}
 int mi355x_vec_axpby(mi355x_handle_t h, size_t n, double alpha, double beta, const double *x, double *y) {
   // bvec1.c:329-356
   if (alpha == 0.0) return mi355x_vec_scale(h, n, beta, y);
@@ -645,11 +707,12 @@ int mi355x_vec_cg_update(mi355x_handle_t h, size_t n, double a, const double *p,
   return launch_reduce<2, RED_SUM>(h, f, n, v, out);
 }
 int mi355x_vec_cg_update_dev(mi355x_handle_t h, size_t n, double beta, const double *dpi_dev, double dpiold, int check_sign,
-                             const double *p, const double *w, const double *d, double *x, double *r, double *z, double *out) {
+                             const double *p, const double *w, const double *d, double *x, double *r, double *z, double *out,
+                             int also_to_host) {
   CGUpdateDevF f{beta, dpiold, check_sign, dpi_dev, p, w, d, x, r, z};
   int v = mi355x_aligned16(p) && mi355x_aligned16(w) && mi355x_aligned16(d) && mi355x_aligned16(x) && mi355x_aligned16(r) &&
           mi355x_aligned16(z);
-  return launch_reduce<3, RED_SUM>(h, f, n, v, out);
+  return launch_reduce<3, RED_SUM>(h, f, n, v, out, also_to_host != 0);
 }
 int mi355x_vec_mdot(mi355x_handle_t h, size_t n, int nv, const double *x, const double *const *y, double *out) {
   int pos = 0;

@@ -17,7 +17,7 @@ static PetscErrorCode KSPSetFromOptions_CG(KSP ksp) {   /* cg.c:330-345 */
   PetscErrorCode ierr = PetscOptionsGetString(ksp->prefix, "-ksp_cg_single_reduction", t, sizeof(t), &set);CHKERRQ(ierr);
   if (set) ((KSP_CG *)ksp->data)->singlereduction = (PetscBool)(strcmp(t, "0") && strcmp(t, "false"));
   ierr = PetscOptionsGetString(ksp->prefix, "-ksp_cg_fused", t, sizeof(t), &set);CHKERRQ(ierr);
-  if (set) ((KSP_CG *)ksp->data)->fused = (!strcmp(t, "0") || !strcmp(t, "false")) ? 0 : ((!strcmp(t, "1") || !strcmp(t, "true")) ? 1 : 2);
+  if (set) ((KSP_CG *)ksp->data)->fused = (!strcmp(t, "0") || !strcmp(t, "false")) ? 0 : ((!strcmp(t, "1") || !strcmp(t, "true")) ? 1 : (!strcmp(t, "2") ? 2 : 3));
   return 0;
 }
 static PetscErrorCode KSPDestroy_CG(KSP ksp) { free(ksp->data); ksp->data = NULL; return 0; }
@@ -31,16 +31,21 @@ static PetscErrorCode KSPSolve_CG(KSP ksp) {
   Vec X = ksp->vec_sol, B = ksp->vec_rhs, R = ksp->work[0], Z = ksp->work[1], P = ksp->work[2];
   Vec S = single ? ksp->work[3] : NULL, W = single ? ksp->work[4] : Z;   /* cg.c:116-122 */
   Mat Amat = ksp->pc->mat;
-  /* Fused forms, -ksp_cg_fused <0|1|2> (default 2); iterates and history carry the same bits at every level:
+  /* Fused forms, -ksp_cg_fused <0|1|2|3> (default 3); iterates and history carry the same bits at every level:
    *  1: with PCJACOBI the two AXPYs, the PCApply, the norm and the dot of cg.c:206-232 are one sweep
    *     (VecCGUpdate_HIPMI355X); with any other PC the norm and the dot share one VecDotNorm2 reduction;
    *  2: as 1, and with PCJACOBI dpi = p'w stays on the device, where the update forms a = beta/dpi itself: one host
    *     synchronisation per iteration instead of two (VecTDotBegin_HIPMI355X / VecCGUpdateDev_HIPMI355X);
+   *  3: as 2, and while the host waits for the sums of iteration i (its convergence test) the device already runs
+   *     the front half of iteration i+1 -- p = z + b p with b = beta_new/beta formed on the device
+   *     (VecAYPXDev_HIPMI355X), w = A p, p'w -- so the host round trip is off the device's critical path.  If the
+   *     test then ends the solve, only the work vectors P and Z(=W) have been touched; not done for the last
+   *     permitted iteration, nor when the residual is within 10x of its target;
    *  0: the reference's op-by-op sequence. */
   const PetscInt flevel = single ? 0 : ((KSP_CG *)ksp->data)->fused;
   const PetscBool fused = (PetscBool)(flevel > 0);
   Vec D = NULL;
-  PetscBool devscalar = PETSC_FALSE;
+  PetscBool devscalar = PETSC_FALSE, front_queued = PETSC_FALSE;
   if (fused) {
     ierr = PCJacobiGetInverseDiagonal_Private(ksp->pc, &D);CHKERRQ(ierr);
     if (D) { PetscBool ok; ierr = VecCGUpdateCheck_HIPMI355X(X, R, Z, P, W, D, &ok);CHKERRQ(ierr); if (!ok) D = NULL; }
@@ -71,17 +76,24 @@ static PetscErrorCode KSPSolve_CG(KSP ksp) {
     ksp->its = i + 1;
     if (beta == 0.0) { ksp->reason = KSP_CONVERGED_ATOL; break; }
     else if ((i > 0) && (beta * betaold < 0.0)) { ksp->reason = KSP_DIVERGED_INDEFINITE_PC; break; }
-    if (!i) { ierr = VecCopy(Z, P);CHKERRQ(ierr); b = 0.0; }     /* p <- z */
-    else { b = beta / betaold; ierr = VecAYPX(P, b, Z);CHKERRQ(ierr); }   /* p <- z + b*p */
-    dpiold = dpi;
     PetscBool dpi_on_device = PETSC_FALSE;
-    if (!single || !i) {
-      ierr = KSP_MatMult(ksp, Amat, P, W);CHKERRQ(ierr);         /* w <- Ap */
-      if (devscalar) { ierr = VecTDotBegin_HIPMI355X(P, W, &dpi_on_device);CHKERRQ(ierr); }
-      if (!dpi_on_device) { ierr = VecTDot(P, W, &dpi);CHKERRQ(ierr); }   /* dpi <- p'w */
-    } else {                                                      /* cg.c:200-203: recurrences instead of a product and a dot */
-      ierr = VecAYPX(W, beta / betaold, S);CHKERRQ(ierr);        /* w <- Ap */
-      dpi = delta - beta * beta * dpiold / (betaold * betaold);  /* dpi <- p'w */
+    if (front_queued) {          /* p, w = A p and p'w of this iteration were queued behind the previous update */
+      b = beta / betaold;
+      dpiold = dpi;
+      dpi_on_device = PETSC_TRUE;
+      front_queued = PETSC_FALSE;
+    } else {
+      if (!i) { ierr = VecCopy(Z, P);CHKERRQ(ierr); b = 0.0; }     /* p <- z */
+      else { b = beta / betaold; ierr = VecAYPX(P, b, Z);CHKERRQ(ierr); }   /* p <- z + b*p */
+      dpiold = dpi;
+      if (!single || !i) {
+        ierr = KSP_MatMult(ksp, Amat, P, W);CHKERRQ(ierr);         /* w <- Ap */
+        if (devscalar) { ierr = VecTDotBegin_HIPMI355X(P, W, &dpi_on_device);CHKERRQ(ierr); }
+        if (!dpi_on_device) { ierr = VecTDot(P, W, &dpi);CHKERRQ(ierr); }   /* dpi <- p'w */
+      } else {                                                      /* cg.c:200-203: recurrences instead of a product and a dot */
+        ierr = VecAYPX(W, beta / betaold, S);CHKERRQ(ierr);        /* w <- Ap */
+        dpi = delta - beta * beta * dpiold / (betaold * betaold);  /* dpi <- p'w */
+      }
     }
     betaold = beta;
     PetscBool have_beta = PETSC_FALSE;
@@ -89,7 +101,17 @@ static PetscErrorCode KSPSolve_CG(KSP ksp) {
     if (dpi_on_device) {
       /* the update kernel applies the tests below to dpi itself and touches nothing if one fires; dpi comes back
        * with the two sums, and the host takes the same exits */
-      ierr = VecCGUpdateDev_HIPMI355X(X, R, Z, P, W, D, beta, dpiold, (PetscBool)(i > 0), &zz, &zr, &dpi);CHKERRQ(ierr);
+      ierr = VecCGUpdateDevBegin_HIPMI355X(X, R, Z, P, W, D, beta, dpiold, (PetscBool)(i > 0));CHKERRQ(ierr);
+      if (flevel > 2 && i + 1 < ksp->max_it && dp > 10.0 * ksp->ttol) {
+        /* front half of iteration i+1 (beta of this iteration is its betaold) */
+        PetscBool ok;
+        ierr = VecAYPXDev_HIPMI355X(P, beta, Z);CHKERRQ(ierr);
+        ierr = KSP_MatMult(ksp, Amat, P, W);CHKERRQ(ierr);
+        ierr = VecTDotBegin_HIPMI355X(P, W, &ok);CHKERRQ(ierr);
+        if (!ok) SETERRQ(ksp->comm, PETSC_ERR_PLIB, "split dot refused after it had been accepted");
+        front_queued = PETSC_TRUE;
+      }
+      ierr = VecCGUpdateDevEnd_HIPMI355X(X, &zz, &zr, &dpi);CHKERRQ(ierr);
       have_beta = PETSC_TRUE;
     }
     if (PetscIsInfOrNanScalar(dpi)) SETERRQ(ksp->comm, PETSC_ERR_FP, "Infinite or not-a-number generated in dot product");
@@ -127,7 +149,7 @@ PetscErrorCode KSPCreate_CG(KSP ksp) {
   KSP_CG *cg;
   PetscErrorCode ierr = PetscMalloc(sizeof(*cg), &cg);CHKERRQ(ierr);
   cg->singlereduction = PETSC_FALSE;
-  cg->fused = 2;
+  cg->fused = 3;
   ksp->data = cg;
   ksp->ops->setup = KSPSetUp_CG; ksp->ops->solve = KSPSolve_CG; ksp->ops->setfromoptions = KSPSetFromOptions_CG; ksp->ops->destroy = KSPDestroy_CG;
   return 0;

@@ -135,7 +135,9 @@ PetscErrorCode VecHIPRestoreWrite(Vec v);                    /* device newer; st
 PetscErrorCode VecCGUpdate_HIPMI355X(Vec x, Vec r, Vec z, Vec p, Vec w, Vec d, PetscScalar a, PetscScalar *zz, PetscScalar *zr, PetscBool *done);
 PetscErrorCode VecCGUpdateCheck_HIPMI355X(Vec x, Vec r, Vec z, Vec p, Vec w, Vec d, PetscBool *ok);
 PetscErrorCode VecTDotBegin_HIPMI355X(Vec x, Vec y, PetscBool *ok);   /* result stays on the device; pairs with VecCGUpdateDev */
-PetscErrorCode VecCGUpdateDev_HIPMI355X(Vec x, Vec r, Vec z, Vec p, Vec w, Vec d, PetscScalar beta, PetscScalar dpiold, PetscBool check_sign, PetscScalar *zz, PetscScalar *zr, PetscScalar *dpi);
+PetscErrorCode VecCGUpdateDevBegin_HIPMI355X(Vec x, Vec r, Vec z, Vec p, Vec w, Vec d, PetscScalar beta, PetscScalar dpiold, PetscBool check_sign);
+PetscErrorCode VecCGUpdateDevEnd_HIPMI355X(Vec x, PetscScalar *zz, PetscScalar *zr, PetscScalar *dpi);
+PetscErrorCode VecAYPXDev_HIPMI355X(Vec p, PetscScalar den, Vec z);   /* p = z + (z'r on the device / den) p */
 PetscErrorCode PCJacobiGetInverseDiagonal_Private(PC pc, Vec *d);   /* NULL unless pc is a set-up PCJACOBI */
 
 /* ---- VecScatter (VecScatter_MPI_General, include/petsc-private/vecimpl.h:509-555) ---- */

@@ -272,9 +272,10 @@ static PetscErrorCode reduce_finish2(Vec x, PetscDeviceCtx *dc, int nsum, int co
     double *ds = mi355x_handle_device_scratch(dc->h);
     if (is_max) CHKHIP(mi355x_comm_allreduce_max(x->comm->dcomm, dc->h, ds, (size_t)nsum));
     else CHKHIP(mi355x_comm_allreduce_sum(x->comm->dcomm, dc->h, ds, (size_t)nsum));
-    /* device -> pinned host by a tiny kernel on the same stream (lower latency than a DMA copy of 8..256 bytes) */
-    CHKHIP(mi355x_vec_copy(dc->h, (size_t)count, ds, hs));
-    CHKHIP(mi355x_handle_synchronize(dc->h));
+    /* device -> pinned host by a tiny kernel on the same stream that also stores the completion number the host
+     * polls: no stream synchronisation, and kernels queued behind it do not delay the result */
+    CHKHIP(mi355x_handle_publish(dc->h, ds, count));
+    CHKHIP(mi355x_handle_wait_result(dc->h));
   } else {
     /* one rank: the reduction kernel wrote the result and then a completion number to pinned memory; polling that
      * word is cheaper than a stream synchronisation and lets the next launches go out at once */
@@ -389,9 +390,11 @@ PetscErrorCode VecTDotBegin_HIPMI355X(Vec x, Vec y, PetscBool *ok) {
   *ok = PETSC_TRUE;
   return 0;
 }
-PetscErrorCode VecCGUpdateDev_HIPMI355X(Vec x, Vec r, Vec z, Vec p, Vec w, Vec d, PetscScalar beta, PetscScalar dpiold, PetscBool check_sign,
-                                        PetscScalar *zz, PetscScalar *zr, PetscScalar *dpi) {
-  PetscErrorCode ierr; const PetscScalar *dp_, *dw, *dd; PetscScalar *dx, *dr, *dz; double *out; PetscScalar res[3]; DEVCTX;
+/* Begin queues the sweep (results go to device scratch slots 0..2, all-reduced there when the communicator has an
+ * RCCL communicator, then published to pinned memory); End waits for exactly that point of the stream, so the caller
+ * may queue more work in between (KSPSolve_CG queues the next iteration's AYPX, MatMult and dot there). */
+PetscErrorCode VecCGUpdateDevBegin_HIPMI355X(Vec x, Vec r, Vec z, Vec p, Vec w, Vec d, PetscScalar beta, PetscScalar dpiold, PetscBool check_sign) {
+  PetscErrorCode ierr; const PetscScalar *dp_, *dw, *dd; PetscScalar *dx, *dr, *dz; double *ds; DEVCTX;
   ierr = VecHIPGetRead(p, &dp_);CHKERRQ(ierr);
   ierr = VecHIPGetRead(w, &dw);CHKERRQ(ierr);
   ierr = VecHIPGetRead(d, &dd);CHKERRQ(ierr);
@@ -399,14 +402,37 @@ PetscErrorCode VecCGUpdateDev_HIPMI355X(Vec x, Vec r, Vec z, Vec p, Vec w, Vec d
   ierr = VecHIPGetReadWrite(r, &dr);CHKERRQ(ierr);
   if (z == w) { ierr = VecHIPGetReadWrite(z, &dz);CHKERRQ(ierr); }   /* left as it is when the update is refused */
   else { ierr = VecHIPGetWrite(z, &dz);CHKERRQ(ierr); }
-  ierr = reduce_target(x, dc, &out);CHKERRQ(ierr);
-  CHKHIP(mi355x_vec_cg_update_dev(dc->h, N_(x), beta, mi355x_handle_device_scratch(dc->h) + DPI_SLOT, dpiold, (int)check_sign,
-                                  dp_, dw, dd, dx, dr, dz, out));
+  ds = mi355x_handle_device_scratch(dc->h);
+  /* one rank: the finishing workgroup hands the sums to the host itself; several: all-reduce first, then publish */
+  CHKHIP(mi355x_vec_cg_update_dev(dc->h, N_(x), beta, ds + DPI_SLOT, dpiold, (int)check_sign, dp_, dw, dd, dx, dr, dz, ds,
+                                  DEVICE_COLLECTIVES(x) ? 0 : 1));
   VecHIPRestoreWrite(x); VecHIPRestoreWrite(r); VecHIPRestoreWrite(z);
   PetscObjectStateIncrease(x); PetscObjectStateIncrease(r); PetscObjectStateIncrease(z);
-  ierr = reduce_finish2(x, dc, 2, 3, 0, res);CHKERRQ(ierr);
-  *zz = res[0]; *zr = res[1]; *dpi = res[2];
+  if (DEVICE_COLLECTIVES(x)) {
+    CHKHIP(mi355x_comm_allreduce_sum(x->comm->dcomm, dc->h, ds, 2));
+    CHKHIP(mi355x_handle_publish(dc->h, ds, 3));
+  }
   ierr = PetscLogFlops(9.0 * x->map->n);CHKERRQ(ierr);
+  return 0;
+}
+PetscErrorCode VecCGUpdateDevEnd_HIPMI355X(Vec x, PetscScalar *zz, PetscScalar *zr, PetscScalar *dpi) {
+  PetscErrorCode ierr; DEVCTX;
+  (void)x;
+  CHKHIP(mi355x_handle_wait_result(dc->h));
+  const double *hs = mi355x_handle_host_scratch(dc->h);
+  *zz = hs[0]; *zr = hs[1]; *dpi = hs[2];
+  return 0;
+}
+/* p = z + (zr/den) p with zr = the z'r the last VecCGUpdateDevBegin left in device scratch slot 1 (VecAYPX(P,b,Z) of
+ * cg.c:187 with b = beta_new/beta_old formed on the device) */
+PetscErrorCode VecAYPXDev_HIPMI355X(Vec p, PetscScalar den, Vec z) {
+  PetscErrorCode ierr; const PetscScalar *dz; PetscScalar *dp_; DEVCTX;
+  ierr = VecHIPGetRead(z, &dz);CHKERRQ(ierr);
+  ierr = VecHIPGetReadWrite(p, &dp_);CHKERRQ(ierr);
+  CHKHIP(mi355x_vec_aypx_dev(dc->h, N_(p), mi355x_handle_device_scratch(dc->h) + 1, den, dz, dp_));
+  VecHIPRestoreWrite(p);
+  PetscObjectStateIncrease(p);
+  ierr = PetscLogFlops(2.0 * p->map->n);CHKERRQ(ierr);
   return 0;
 }
 /* can the six vectors of a CG iteration take the fused update at all (types, sizes, aliasing)? */

@@ -259,7 +259,7 @@ def test_ksp_cg_fused_forms_are_bit_identical(P, pc):
     b = orc.spmv(ai, aj, aa, np.cos(0.3 * np.arange(n)))
     xu, hu, itsu, ru = solve(P, ai, aj, aa, b, "cg", pc, opts="-ksp_cg_fused 0", rtol=1e-9)
     assert ru == 2 and itsu > 20
-    for level in ("1", "2", None):
+    for level in ("1", "2", "3", None):
         xf, hf, itsf, rf = solve(P, ai, aj, aa, b, "cg", pc, opts=("-ksp_cg_fused " + level) if level else "", rtol=1e-9)
         assert itsf == itsu and rf == ru
         assert np.array_equal(bits(hf), bits(hu))
@@ -277,13 +277,13 @@ def test_ksp_cg_indefinite_exits_match_at_every_fusion_level(P):
         aa[k] = -3.0
     b = np.cos(0.7 * np.arange(n))
     res = {}
-    for level in ("0", "1", "2"):
+    for level in ("0", "1", "2", "3"):
         for pc in ("none", "jacobi"):
             x, h, its, reason = solve(P, ai, aj, aa, b, "cg", pc, opts="-ksp_cg_fused " + level, rtol=1e-12, max_it=200)
             res[level, pc] = (bits(x).copy(), bits(h).copy(), its, reason)
     for pc in ("none", "jacobi"):
         assert res["0", pc][3] in (-8, -10)       # KSP_DIVERGED_INDEFINITE_PC / _MAT
-        for level in ("1", "2"):
+        for level in ("1", "2", "3"):
             assert res[level, pc][2:] == res["0", pc][2:]
             assert np.array_equal(res[level, pc][0], res["0", pc][0]) and np.array_equal(res[level, pc][1], res["0", pc][1])
     assert any(res["0", pc][3] == -10 for pc in ("none", "jacobi")), "no case exercised the INDEFINITE_MAT exit"
