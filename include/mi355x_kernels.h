@@ -161,6 +161,13 @@ int mi355x_spmv_plan_info(mi355x_spmv_plan_t plan, int *nblocks, int *nlong, siz
  *   y[r] = sum_k a[k] x[j[k]], products summed in k order starting from 0.0 */
 int mi355x_spmv_csr(mi355x_handle_t h, mi355x_spmv_plan_t plan, const int *ai, const int *aj,
                     const double *aa, const double *x, double *y);
+/* y = A x and sum_r x_r y_r from ONE pass over the matrix (KSPSolve_CG: w = A p, dpi = p'w; cg.c:190-191): the SpMV
+ * leaves one value per row block in the plan, mi355x_spmv_dot_finish adds them in block order into out[0] (device-
+ * accessible).  Square matrices with an index-compressed plan only: mi355x_spmv_csr_dot returns hipErrorNotSupported
+ * (801) otherwise and does nothing.  y carries the bits of mi355x_spmv_csr; the dot uses a fixed tree. */
+int mi355x_spmv_csr_dot(mi355x_handle_t h, mi355x_spmv_plan_t plan, const int *ai, const int *aj, const double *aa,
+                        const double *x, double *y);
+int mi355x_spmv_dot_finish(mi355x_handle_t h, mi355x_spmv_plan_t plan, double *out);
 /* MatMultAdd_SeqAIJ   src/mat/impls/aij/seq/aij.c:1291   z[r] = y[r] + sum_k ... (sum starts from y[r]);
  * z may alias y.  With a compressed-row plan only the listed rows are touched (z must alias y
  * or already hold y, as aij.c:1314-1316 arranges). */

@@ -74,6 +74,8 @@ KERNEL_API = {
     "mi355x_spmv_plan_info": [vp, pi32, pi32, C.POINTER(sz)],
     "mi355x_spmv_csr": [vp, vp, vp, vp, vp, vp, vp],
     "mi355x_spmv_csr_add": [vp, vp, vp, vp, vp, vp, vp, vp],
+    "mi355x_spmv_csr_dot": [vp, vp, vp, vp, vp, vp, vp],
+    "mi355x_spmv_dot_finish": [vp, vp, vp],
     "mi355x_csr_get_diagonal": [vp, i32, vp, vp, vp, vp],
     "mi355x_spmv_bsr": [vp, i32, i32, vp, vp, vp, vp, vp],
     "mi355x_spmv_bsr_planned": [vp, vp, i32, vp, vp, vp, vp, vp],

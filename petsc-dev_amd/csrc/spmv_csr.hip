@@ -58,6 +58,7 @@ struct mi355x_spmv_plan_s {
   unsigned char *d_idx8;
   int *d_offtab;
   int ntab;
+  double *d_dotpart;   // per-row-block x'y values of mi355x_spmv_csr_dot (allocated on first use)
 };
 
 template <bool ADD, bool CPROW, bool VEC>
@@ -211,16 +212,17 @@ __global__ __launch_bounds__(SPMV_THREADS, SPMV_MINWAVES) void spmv_csr_rowblock
 // boundary is loaded whole (an aligned 16-byte access cannot leave the page its first half lies in) and the element
 // outside the block is simply not written to LDS.  With no control flow between the loads the compiler keeps all of
 // them in flight behind a single s_waitcnt; the earlier predicated form serialised them pair by pair.
-template <bool ADD>
+template <bool ADD, bool DOT>
 __global__ __launch_bounds__(SPMV_THREADS, SPMV_MINWAVES) void spmv_csr_rowblock_idx8_kernel(
     const int2 *__restrict__ rowblk, int nblocks, const int *__restrict__ ai, const unsigned char *__restrict__ idx8,
     const int *__restrict__ offtab_g, int ntab, const double *__restrict__ aa, const double *__restrict__ x,
-    const double *yin, double *yout) {
+    const double *yin, double *yout, double *__restrict__ dotpart) {
   __shared__ double prod[SPMV_BLOCK_NNZ];
   __shared__ unsigned char rowof[SPMV_BLOCK_NNZ];
   __shared__ int offtab[256];
   __shared__ double wsum[SPMV_THREADS / MI355X_WAVE];
   static_assert(SPMV_THREADS >= 256, "the offset table is staged by the first 256 lanes");
+  static_assert(!(DOT && ADD), "the x'y by-product is provided for y = A x only");
 #if SPMV_REMAP == 2
   const int xcd = blockIdx.x % MI355X_NXCD;
   const int slot = blockIdx.x / MI355X_NXCD;
@@ -250,12 +252,15 @@ __global__ __launch_bounds__(SPMV_THREADS, SPMV_MINWAVES) void spmv_csr_rowblock
       double t = wsum[0];
 #pragma unroll
       for (int w = 1; w < SPMV_THREADS / MI355X_WAVE; ++w) t += wsum[w];
-      yout[r0] = ADD ? (yin[r0] + t) : t;
+      const double yv = ADD ? (yin[r0] + t) : t;
+      yout[r0] = yv;
+      if (DOT) dotpart[lb] = yv * x[r0];
     }
     return;
   }
   if (nnz == 0) {               // only empty rows
     if (tid < nrows) yout[r0 + tid] = ADD ? yin[r0 + tid] : 0.0;
+    if (DOT && tid == 0) dotpart[lb] = 0.0;
     return;
   }
 
@@ -267,6 +272,8 @@ __global__ __launch_bounds__(SPMV_THREADS, SPMV_MINWAVES) void spmv_csr_rowblock
   const int a0 = ai[r0 + rc], a1 = ai[r0 + rc + 1];
   double ysum = 0.0;
   if (ADD) ysum = yin[r0 + rc];
+  double xrow = 0.0;
+  if (DOT) xrow = x[r0 + rc];   // square matrix: x entry of this lane's row, for the x'y by-product
   // this lane's slice of the value / index streams
   constexpr int PAIRS = SPMV_BLOCK_NNZ / (2 * SPMV_THREADS);
   const int ka = k0 & ~1;
@@ -307,6 +314,7 @@ __global__ __launch_bounds__(SPMV_THREADS, SPMV_MINWAVES) void spmv_csr_rowblock
     prod[(k + 1 < k1) ? k + 1 - k0 : SPMV_BLOCK_NNZ - 1] = pb;
   }
   __syncthreads();
+  double yval = 0.0;             // this lane's row result (lanes without a row: 0)
   if (tpr == 1) {
     if (r < nrows) {
       double sum = ADD ? ysum : 0.0;
@@ -318,12 +326,27 @@ __global__ __launch_bounds__(SPMV_THREADS, SPMV_MINWAVES) void spmv_csr_rowblock
         for (int j = 0; j < 8; ++j) { const double u = sum + t[j]; sum = (k + j < re) ? u : sum; }
       }
       yout[r0 + r] = sum;
+      yval = sum;
     }
   } else {
     double sum = 0.0;
     if (r < nrows) for (int k = rs + sub; k < re; k += tpr) sum += prod[k];
     for (int off = tpr >> 1; off > 0; off >>= 1) sum += __shfl_down(sum, off, MI355X_WAVE);
-    if (r < nrows && sub == 0) yout[r0 + r] = ADD ? (ysum + sum) : sum;
+    if (r < nrows && sub == 0) { yval = ADD ? (ysum + sum) : sum; yout[r0 + r] = yval; }
+  }
+  if (DOT) {
+    // x'y by-product: this block's sum of x_r y_r in a fixed order (lanes -> wavefront tree -> 4 wavefronts in order);
+    // mi355x_spmv_csr_dot sums the per-block values in block order afterwards
+    const bool mine = (r < nrows) && (sub == 0);
+    double c = wave_sum(mine ? yval * xrow : 0.0);
+    if ((tid & (MI355X_WAVE - 1)) == 0) wsum[tid / MI355X_WAVE] = c;
+    __syncthreads();
+    if (tid == 0) {
+      double t = wsum[0];
+#pragma unroll
+      for (int w = 1; w < SPMV_THREADS / MI355X_WAVE; ++w) t += wsum[w];
+      dotpart[lb] = t;
+    }
   }
 }
 
@@ -420,6 +443,22 @@ __global__ __launch_bounds__(SPMV_THREADS) void bsr_rowblock_kernel(const int2 *
   if (v < nv && sub == 0) y[(long)br * BS + rr_] = sum;
 }
 
+// sum of the per-row-block x'y values in block order: 1024 lanes stride over them, fixed tree
+__global__ __launch_bounds__(1024) void dot_partials_kernel(const double *__restrict__ part, int n, double *out) {
+  __shared__ double lds[1024 / MI355X_WAVE];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 1024) s += part[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & (MI355X_WAVE - 1)) == 0) lds[threadIdx.x / MI355X_WAVE] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = lds[0];
+#pragma unroll
+    for (int w = 1; w < 1024 / MI355X_WAVE; ++w) t += lds[w];
+    out[0] = t;
+  }
+}
+
 __global__ __launch_bounds__(MI355X_BLOCK) void csr_diag_kernel(int m, const int *__restrict__ ai,
                                                                const int *__restrict__ aj,
                                                                const double *__restrict__ aa, double *d) {
@@ -445,8 +484,8 @@ static int launch_spmv(mi355x_handle_t h, mi355x_spmv_plan_t p, const int *ai, c
 #else
     const int g8 = p->nblocks;
 #endif
-    hipLaunchKernelGGL((spmv_csr_rowblock_idx8_kernel<ADD>), dim3(g8), dim3(SPMV_THREADS), 0, h->stream, p->d_rowblk,
-                       p->nblocks, ai, p->d_idx8, p->d_offtab, p->ntab, aa, x, yin, yout);
+    hipLaunchKernelGGL((spmv_csr_rowblock_idx8_kernel<ADD, false>), dim3(g8), dim3(SPMV_THREADS), 0, h->stream, p->d_rowblk,
+                       p->nblocks, ai, p->d_idx8, p->d_offtab, p->ntab, aa, x, yin, yout, (double *)nullptr);
     MI355X_LAUNCH_CHECK();
     return 0;
   }
@@ -478,6 +517,7 @@ int mi355x_spmv_plan_create(mi355x_handle_t h, int nrows, const int *ai_host, co
   p->d_offtab = nullptr;
   p->ntab = 0;
   p->nlong = 0;
+  p->d_dotpart = nullptr;
   std::vector<int2> rb;
   rb.reserve((size_t)nrows / 128 + 2);
   rb.push_back(make_int2(0, ai_host[0]));
@@ -554,6 +594,7 @@ int mi355x_spmv_plan_destroy(mi355x_spmv_plan_t p) {
   if (p->d_idx8) hipFree(p->d_idx8);
   if (p->d_offtab) hipFree(p->d_offtab);
   if (p->d_rows) hipFree(p->d_rows);
+  if (p->d_dotpart) hipFree(p->d_dotpart);
   delete p;
   return 0;
 }
@@ -573,6 +614,34 @@ int mi355x_spmv_plan_info(mi355x_spmv_plan_t p, int *nblocks, int *nlong, size_t
 int mi355x_spmv_csr(mi355x_handle_t h, mi355x_spmv_plan_t plan, const int *ai, const int *aj, const double *aa,
                     const double *x, double *y) {
   return launch_spmv<false>(h, plan, ai, aj, aa, x, nullptr, y);
+}
+
+// y = A x and x'y from one pass over the matrix (KSPSolve_CG's w = A p, dpi = p'w): every row block leaves its sum of
+// x_r y_r in the plan; mi355x_spmv_dot_finish adds them in block order (a second, tiny launch).  Needs the
+// index-compressed plan and a square matrix; hipErrorNotSupported otherwise (the caller then uses mi355x_spmv_csr +
+// mi355x_vec_dot).
+int mi355x_spmv_csr_dot(mi355x_handle_t h, mi355x_spmv_plan_t p, const int *ai, const int *aj, const double *aa,
+                        const double *x, double *y) {
+  (void)aj;
+  if (!p->d_idx8 || p->d_rows || !mi355x_aligned16(aa)) return (int)hipErrorNotSupported;
+  if (p->nblocks == 0) return 0;
+  if (!p->d_dotpart) MI355X_TRY(hipMalloc((void **)&p->d_dotpart, sizeof(double) * (size_t)p->nblocks));
+#if SPMV_REMAP == 2
+  const int per8 = MI355X_NXCD * SPMV_CH;
+  const int g8 = ((p->nblocks + per8 - 1) / per8) * per8;
+#else
+  const int g8 = p->nblocks;
+#endif
+  hipLaunchKernelGGL((spmv_csr_rowblock_idx8_kernel<false, true>), dim3(g8), dim3(SPMV_THREADS), 0, h->stream, p->d_rowblk,
+                     p->nblocks, ai, p->d_idx8, p->d_offtab, p->ntab, aa, x, (const double *)nullptr, y, p->d_dotpart);
+  MI355X_LAUNCH_CHECK();
+  return 0;
+}
+int mi355x_spmv_dot_finish(mi355x_handle_t h, mi355x_spmv_plan_t p, double *out) {
+  if (p->nblocks == 0 || !p->d_dotpart) { MI355X_TRY(hipMemsetAsync(out, 0, sizeof(double), h->stream)); return 0; }
+  hipLaunchKernelGGL(dot_partials_kernel, dim3(1), dim3(1024), 0, h->stream, p->d_dotpart, p->nblocks, out);
+  MI355X_LAUNCH_CHECK();
+  return 0;
 }
 
 int mi355x_spmv_csr_add(mi355x_handle_t h, mi355x_spmv_plan_t plan, const int *ai, const int *aj, const double *aa,

@@ -264,6 +264,39 @@ static PetscErrorCode MatMult_SeqAIJHIP(Mat A, Vec xx, Vec yy) {   /* MatMult_Se
   return 0;
 }
 
+/* w = A p with dpi = p'w as a by-product of the same pass (KSPSolve_CG cg.c:190-191); dpi is left in the device
+ * scratch slot the fused CG update reads (all-reduced there when the vectors' communicator has an RCCL communicator).
+ * *ok = PETSC_FALSE and nothing done unless A is a square, sequential, index-compressed AIJ matrix of this type. */
+PetscErrorCode MatMultTDotBegin_HIPMI355X(Mat A, Vec xx, Vec yy, PetscBool *ok) {
+  PetscErrorCode ierr;
+  *ok = PETSC_FALSE;
+  if (!A || A->ops->mult != MatMult_SeqAIJHIP) return 0;
+  Mat_SeqAIJ *a = SA(A); Mat_SeqAIJHIP *d = SD(A);
+  const PetscScalar *x; PetscScalar *y; PetscDeviceCtx *dc; int ntab = 0;
+  if (a->bs > 1 || d->cprow || a->m != a->n || xx == yy) return 0;
+  if (xx->map->n != a->n || yy->map->n != a->m || (xx->comm->size > 1 && !xx->comm->dcomm)) return 0;
+  ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
+  ierr = MatSeqAIJHIPUpload(A);CHKERRQ(ierr);
+  if (!d->plan) return 0;
+  CHKHIP(mi355x_spmv_plan_is_compressed(d->plan, &ntab));
+  if (!ntab) return 0;
+  ierr = VecHIPGetRead(xx, &x);CHKERRQ(ierr);
+  ierr = VecHIPGetWrite(yy, &y);CHKERRQ(ierr);
+  ierr = MatTimingBegin(A, dc->h);CHKERRQ(ierr);
+  int rc = mi355x_spmv_csr_dot(dc->h, d->plan, d->d_i, d->d_j, d->d_a, x, y);
+  if (rc == 801) return 0;   /* hipErrorNotSupported: nothing was launched */
+  CHKHIP(rc);
+  ierr = MatTimingEnd(A, dc->h);CHKERRQ(ierr);
+  double *slot = mi355x_handle_device_scratch(dc->h) + PETSC_HIP_DPI_SLOT;
+  CHKHIP(mi355x_spmv_dot_finish(dc->h, d->plan, slot));
+  if (xx->comm->dcomm) CHKHIP(mi355x_comm_allreduce_sum(xx->comm->dcomm, dc->h, slot, 1));
+  ierr = VecHIPRestoreWrite(yy);CHKERRQ(ierr);
+  PetscObjectStateIncrease(yy);
+  ierr = PetscLogFlops(2.0 * a->nz - a->nonzerorows + 2.0 * a->m - 1);CHKERRQ(ierr);
+  *ok = PETSC_TRUE;
+  return 0;
+}
+
 static PetscErrorCode MatMultAdd_SeqAIJHIP(Mat A, Vec xx, Vec yy, Vec zz) {   /* MatMultAdd_SeqAIJCUSP aijcusp.cu:405 */
   PetscErrorCode ierr;
   Mat_SeqAIJ *a = SA(A); Mat_SeqAIJHIP *d = SD(A);

@@ -17,7 +17,7 @@ static PetscErrorCode KSPSetFromOptions_CG(KSP ksp) {   /* cg.c:330-345 */
   PetscErrorCode ierr = PetscOptionsGetString(ksp->prefix, "-ksp_cg_single_reduction", t, sizeof(t), &set);CHKERRQ(ierr);
   if (set) ((KSP_CG *)ksp->data)->singlereduction = (PetscBool)(strcmp(t, "0") && strcmp(t, "false"));
   ierr = PetscOptionsGetString(ksp->prefix, "-ksp_cg_fused", t, sizeof(t), &set);CHKERRQ(ierr);
-  if (set) ((KSP_CG *)ksp->data)->fused = (!strcmp(t, "0") || !strcmp(t, "false")) ? 0 : ((!strcmp(t, "1") || !strcmp(t, "true")) ? 1 : (!strcmp(t, "2") ? 2 : 3));
+  if (set) ((KSP_CG *)ksp->data)->fused = (!strcmp(t, "0") || !strcmp(t, "false")) ? 0 : ((!strcmp(t, "1") || !strcmp(t, "true")) ? 1 : (!strcmp(t, "2") ? 2 : (!strcmp(t, "4") ? 4 : 3)));
   return 0;
 }
 static PetscErrorCode KSPDestroy_CG(KSP ksp) { free(ksp->data); ksp->data = NULL; return 0; }
@@ -31,7 +31,7 @@ static PetscErrorCode KSPSolve_CG(KSP ksp) {
   Vec X = ksp->vec_sol, B = ksp->vec_rhs, R = ksp->work[0], Z = ksp->work[1], P = ksp->work[2];
   Vec S = single ? ksp->work[3] : NULL, W = single ? ksp->work[4] : Z;   /* cg.c:116-122 */
   Mat Amat = ksp->pc->mat;
-  /* Fused forms, -ksp_cg_fused <0|1|2|3> (default 3); iterates and history carry the same bits at every level:
+  /* Fused forms, -ksp_cg_fused <0|1|2|3|4> (default 3); iterates and history carry the same bits at every level:
    *  1: with PCJACOBI the two AXPYs, the PCApply, the norm and the dot of cg.c:206-232 are one sweep
    *     (VecCGUpdate_HIPMI355X); with any other PC the norm and the dot share one VecDotNorm2 reduction;
    *  2: as 1, and with PCJACOBI dpi = p'w stays on the device, where the update forms a = beta/dpi itself: one host
@@ -41,6 +41,10 @@ static PetscErrorCode KSPSolve_CG(KSP ksp) {
    *     (VecAYPXDev_HIPMI355X), w = A p, p'w -- so the host round trip is off the device's critical path.  If the
    *     test then ends the solve, only the work vectors P and Z(=W) have been touched; not done for the last
    *     permitted iteration, nor when the residual is within 10x of its target;
+   *  4: as 3, and on one rank p'w is a by-product of the SpMV pass itself (MatMultTDotBegin_HIPMI355X: the separate
+   *     16n-byte dot pass disappears).  Its summation tree differs from VecTDot's, so iterates agree with the other
+   *     levels to rounding (1e-15 relative per step), not bit for bit; measured gain 1-2 % (the separate dot reads p
+   *     and the just-written w largely out of the Infinity Cache), so it is an option, not the default;
    *  0: the reference's op-by-op sequence. */
   const PetscInt flevel = single ? 0 : ((KSP_CG *)ksp->data)->fused;
   const PetscBool fused = (PetscBool)(flevel > 0);
@@ -87,9 +91,12 @@ static PetscErrorCode KSPSolve_CG(KSP ksp) {
       else { b = beta / betaold; ierr = VecAYPX(P, b, Z);CHKERRQ(ierr); }   /* p <- z + b*p */
       dpiold = dpi;
       if (!single || !i) {
-        ierr = KSP_MatMult(ksp, Amat, P, W);CHKERRQ(ierr);         /* w <- Ap */
-        if (devscalar) { ierr = VecTDotBegin_HIPMI355X(P, W, &dpi_on_device);CHKERRQ(ierr); }
-        if (!dpi_on_device) { ierr = VecTDot(P, W, &dpi);CHKERRQ(ierr); }   /* dpi <- p'w */
+        if (devscalar && flevel > 3) { ierr = MatMultTDotBegin_HIPMI355X(Amat, P, W, &dpi_on_device);CHKERRQ(ierr); }   /* both at once */
+        if (!dpi_on_device) {
+          ierr = KSP_MatMult(ksp, Amat, P, W);CHKERRQ(ierr);       /* w <- Ap */
+          if (devscalar) { ierr = VecTDotBegin_HIPMI355X(P, W, &dpi_on_device);CHKERRQ(ierr); }
+          if (!dpi_on_device) { ierr = VecTDot(P, W, &dpi);CHKERRQ(ierr); }   /* dpi <- p'w */
+        }
       } else {                                                      /* cg.c:200-203: recurrences instead of a product and a dot */
         ierr = VecAYPX(W, beta / betaold, S);CHKERRQ(ierr);        /* w <- Ap */
         dpi = delta - beta * beta * dpiold / (betaold * betaold);  /* dpi <- p'w */
@@ -104,11 +111,14 @@ static PetscErrorCode KSPSolve_CG(KSP ksp) {
       ierr = VecCGUpdateDevBegin_HIPMI355X(X, R, Z, P, W, D, beta, dpiold, (PetscBool)(i > 0));CHKERRQ(ierr);
       if (flevel > 2 && i + 1 < ksp->max_it && dp > 10.0 * ksp->ttol) {
         /* front half of iteration i+1 (beta of this iteration is its betaold) */
-        PetscBool ok;
+        PetscBool ok = PETSC_FALSE;
         ierr = VecAYPXDev_HIPMI355X(P, beta, Z);CHKERRQ(ierr);
-        ierr = KSP_MatMult(ksp, Amat, P, W);CHKERRQ(ierr);
-        ierr = VecTDotBegin_HIPMI355X(P, W, &ok);CHKERRQ(ierr);
-        if (!ok) SETERRQ(ksp->comm, PETSC_ERR_PLIB, "split dot refused after it had been accepted");
+        if (flevel > 3) { ierr = MatMultTDotBegin_HIPMI355X(Amat, P, W, &ok);CHKERRQ(ierr); }
+        if (!ok) {
+          ierr = KSP_MatMult(ksp, Amat, P, W);CHKERRQ(ierr);
+          ierr = VecTDotBegin_HIPMI355X(P, W, &ok);CHKERRQ(ierr);
+          if (!ok) SETERRQ(ksp->comm, PETSC_ERR_PLIB, "split dot refused after it had been accepted");
+        }
         front_queued = PETSC_TRUE;
       }
       ierr = VecCGUpdateDevEnd_HIPMI355X(X, &zz, &zr, &dpi);CHKERRQ(ierr);

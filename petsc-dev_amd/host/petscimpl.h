@@ -137,6 +137,8 @@ PetscErrorCode VecCGUpdateCheck_HIPMI355X(Vec x, Vec r, Vec z, Vec p, Vec w, Vec
 PetscErrorCode VecTDotBegin_HIPMI355X(Vec x, Vec y, PetscBool *ok);   /* result stays on the device; pairs with VecCGUpdateDev */
 PetscErrorCode VecCGUpdateDevBegin_HIPMI355X(Vec x, Vec r, Vec z, Vec p, Vec w, Vec d, PetscScalar beta, PetscScalar dpiold, PetscBool check_sign);
 PetscErrorCode VecCGUpdateDevEnd_HIPMI355X(Vec x, PetscScalar *zz, PetscScalar *zr, PetscScalar *dpi);
+#define PETSC_HIP_DPI_SLOT 8   /* device scratch slot holding p'w between the dot (or the SpMV by-product) and the CG update */
+PetscErrorCode MatMultTDotBegin_HIPMI355X(Mat A, Vec x, Vec y, PetscBool *ok);   /* y = A x, x'y left on the device */
 PetscErrorCode VecAYPXDev_HIPMI355X(Vec p, PetscScalar den, Vec z);   /* p = z + (z'r on the device / den) p */
 PetscErrorCode PCJacobiGetInverseDiagonal_Private(PC pc, Vec *d);   /* NULL unless pc is a set-up PCJACOBI */
 

@@ -376,7 +376,7 @@ PetscErrorCode VecCGUpdate_HIPMI355X(Vec x, Vec r, Vec z, Vec p, Vec w, Vec d, P
  * device scratch (all-reduced in place over RCCL when the communicator has one) without any host synchronisation;
  * VecCGUpdateDev then forms a = beta/dpi on the device, does the fused update and returns z'z, z'r and dpi with the
  * one synchronisation of the iteration.  Not available with the host-staged transport (*ok = PETSC_FALSE). */
-#define DPI_SLOT 8
+#define DPI_SLOT PETSC_HIP_DPI_SLOT
 PetscErrorCode VecTDotBegin_HIPMI355X(Vec x, Vec y, PetscBool *ok) {
   PetscErrorCode ierr; const PetscScalar *dx, *dy; double *ds; DEVCTX;
   *ok = PETSC_FALSE;

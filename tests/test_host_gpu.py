@@ -259,11 +259,20 @@ def test_ksp_cg_fused_forms_are_bit_identical(P, pc):
     b = orc.spmv(ai, aj, aa, np.cos(0.3 * np.arange(n)))
     xu, hu, itsu, ru = solve(P, ai, aj, aa, b, "cg", pc, opts="-ksp_cg_fused 0", rtol=1e-9)
     assert ru == 2 and itsu > 20
-    for level in ("1", "2", "3", None):
-        xf, hf, itsf, rf = solve(P, ai, aj, aa, b, "cg", pc, opts=("-ksp_cg_fused " + level) if level else "", rtol=1e-9)
+    for level in ("1", "2", "3"):
+        xf, hf, itsf, rf = solve(P, ai, aj, aa, b, "cg", pc, opts="-ksp_cg_fused " + level, rtol=1e-9)
         assert itsf == itsu and rf == ru
         assert np.array_equal(bits(hf), bits(hu))
         assert np.array_equal(bits(xf), bits(xu))
+    xd, hd, itsd, rd = solve(P, ai, aj, aa, b, "cg", pc, rtol=1e-9)            # default = level 3
+    assert itsd == itsu and np.array_equal(bits(hd), bits(hu)) and np.array_equal(bits(xd), bits(xu))
+    # level 4: p'w is a by-product of the SpMV pass, summed in another order -> agreement to rounding
+    for level in ("4",):
+        xf, hf, itsf, rf = solve(P, ai, aj, aa, b, "cg", pc, opts="-ksp_cg_fused " + level, rtol=1e-9)
+        assert abs(itsf - itsu) <= 1 and rf == ru
+        k_ = min(len(hf), len(hu))
+        assert np.allclose(hf[:k_], hu[:k_], rtol=1e-9, atol=0)
+        assert np.linalg.norm(xf - xu) <= 1e-9 * np.linalg.norm(xu)
 
 
 def test_ksp_cg_indefinite_exits_match_at_every_fusion_level(P):
@@ -277,7 +286,7 @@ def test_ksp_cg_indefinite_exits_match_at_every_fusion_level(P):
         aa[k] = -3.0
     b = np.cos(0.7 * np.arange(n))
     res = {}
-    for level in ("0", "1", "2", "3"):
+    for level in ("0", "1", "2", "3", "4"):
         for pc in ("none", "jacobi"):
             x, h, its, reason = solve(P, ai, aj, aa, b, "cg", pc, opts="-ksp_cg_fused " + level, rtol=1e-12, max_it=200)
             res[level, pc] = (bits(x).copy(), bits(h).copy(), its, reason)
@@ -286,6 +295,9 @@ def test_ksp_cg_indefinite_exits_match_at_every_fusion_level(P):
         for level in ("1", "2", "3"):
             assert res[level, pc][2:] == res["0", pc][2:]
             assert np.array_equal(res[level, pc][0], res["0", pc][0]) and np.array_equal(res[level, pc][1], res["0", pc][1])
+        assert res["4", pc][2:] == res["0", pc][2:]          # same exit at the same iteration; x to rounding
+        x4, x0 = res["4", pc][0].view(np.float64), res["0", pc][0].view(np.float64)
+        assert np.linalg.norm(x4 - x0) <= 1e-9 * max(np.linalg.norm(x0), 1e-300)
     assert any(res["0", pc][3] == -10 for pc in ("none", "jacobi")), "no case exercised the INDEFINITE_MAT exit"
 
 

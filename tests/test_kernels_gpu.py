@@ -290,6 +290,49 @@ def test_spmv_index_compression_other_shapes(dev):
     assert np.all(np.abs(got - orc.spmv(ai3, aj3, aa3, x3)) <= 1e-12 * sc3)
 
 
+def test_spmv_with_dot_byproduct(dev):
+    """mi355x_spmv_csr_dot + mi355x_spmv_dot_finish: y carries the bits of mi355x_spmv_csr, and x'y (one value per row
+    block, summed in block order) equals the oracle's dot to 1e-13 * sum|x_r y_r|.  Shapes: P7 (one lane per row),
+    banded long rows with every 7th row empty, 200-entry rows (several lanes per row, ten rows per block); an
+    uncompressed plan must be refused (801) without launching anything."""
+    k = dev.k
+    cases = []
+    ai, aj, aa = orc.gen_p7(33, 17, 9)
+    cases.append((ai, aj, aa * (1.0 + 0.01 * np.cos(np.arange(aa.size)))))
+    n = 3000
+    rows_ = [np.arange(max(0, r - 40), min(n, r + 41)) if r % 7 else np.arange(0) for r in range(n)]   # every 7th row empty
+    cases.append((np.concatenate(([0], np.cumsum([c.size for c in rows_]))).astype(np.int32), np.concatenate(rows_).astype(np.int32), None))
+    n3 = 2600
+    cols3 = [np.arange(r, min(n3, r + 200)) for r in range(n3)]
+    cases.append((np.concatenate(([0], np.cumsum([c.size for c in cols3]))).astype(np.int32), np.concatenate(cols3).astype(np.int32), None))
+    for ci, (ai, aj, aa) in enumerate(cases):
+        if aa is None:
+            aa = rnd(aj.size, 70 + ci)
+        m = ai.size - 1
+        x = rnd(m, 80 + ci)
+        dai, daj, daa = upload_csr(dev, ai, aj, aa)
+        dx = dev.put(x); dy = dev.put(np.full(m, 7.0)); dy2 = dev.put(np.full(m, 9.0)); dout = dev.alloc(64)
+        plan = make_plan(dev, ai, None)
+        rc = k.mi355x_spmv_csr_dot(dev.h, plan, dai, daj, daa, dx, dy)
+        assert rc == 801                                              # no index compression yet: refused
+        dev.chk(k.mi355x_spmv_plan_compress_indices(dev.h, plan, ai.ctypes.data, aj.ctypes.data))
+        nt = C.c_int(); k.mi355x_spmv_plan_is_compressed(plan, C.byref(nt))
+        if nt.value == 0:
+            assert k.mi355x_spmv_csr_dot(dev.h, plan, dai, daj, daa, dx, dy) == 801
+        else:
+            dev.chk(k.mi355x_spmv_csr_dot(dev.h, plan, dai, daj, daa, dx, dy))
+            dev.chk(k.mi355x_spmv_dot_finish(dev.h, plan, dout))
+            dev.chk(k.mi355x_spmv_csr(dev.h, plan, dai, daj, daa, dx, dy2))
+            y, y2 = dev.get(dy, m), dev.get(dy2, m)
+            assert_bitexact(y, y2)
+            got = dev.get(dout, 1)[0]
+            assert abs(got - orc.vec_dot(x, y)) <= 1e-13 * np.sum(np.abs(x * y)), (ci, got)
+        dev.chk(k.mi355x_spmv_plan_destroy(plan))
+        for q in (dai, daj, daa, dx, dy, dy2, dout):
+            dev.free(q)
+        assert ci != 0 or nt.value == 7
+
+
 def test_spmv_short_rows_bitexact(dev):
     """rows of 0..16 nonzeros incl. empty rows, rectangular: one lane per row, reference summation order"""
     ai, aj, aa = random_csr(3001, 2000, lambda rng, m: rng.integers(0, 17, m), 60)
