@@ -138,7 +138,7 @@ int mi355x_vec_cg_update(mi355x_handle_t h, size_t n, double a, const double *p,
 int mi355x_vec_cg_update_dev(mi355x_handle_t h, size_t n, double beta, const double *dpi_dev, double dpiold, int check_sign,
                              const double *p, const double *w, const double *d, double *x, double *r, double *z, double *out,
                              int also_to_host);
-/* VecMDot_Seq         src/vec/vec/impls/seq/dvec2.c:146     out[j] = sum_i x_i y_j,i , j<nv ; x read once per 8 y's */
+/* VecMDot_Seq         src/vec/vec/impls/seq/dvec2.c:146     out[j] = sum_i x_i y_j,i , j<nv ; x read once per 16 y's */
 int mi355x_vec_mdot(mi355x_handle_t h, size_t n, int nv, const double *x, const double *const *y, double *out);
 /* VecSum / VecMax helpers are not on the Krylov path and are not provided. */
 

@@ -97,8 +97,8 @@ __global__ __launch_bounds__(MI355X_BLOCK) void swap_kernel(double *x, double *y
 // groups and left-to-right sums as petscaxpy.h:101-110 / dvec2.c:853-900
 // ------------------------------------------------------------------------
 struct MaxpyArgs {
-  const double *y[8];
-  double a[8];
+  const double *y[16];
+  double a[16];
 };
 
 template <int G>
@@ -109,11 +109,21 @@ __device__ __forceinline__ double group_sum(const double *a, const double *v) {
   return s;
 }
 
-template <int G0, int G1>
+// x += group 0 (G0 = 1..4 vectors), then NG4 groups of four, each group summed left to right and added to x in turn:
+// the association of petscaxpy.h:101-110.  Up to 16 vectors per sweep, so x is read and written once per 16.
+template <int G0, int NG4>
+__device__ __forceinline__ double maxpy_elem(double xv, const double *a, const double *v) {
+  xv = xv + group_sum<G0>(a, v);
+#pragma unroll
+  for (int g = 0; g < NG4; ++g) xv = xv + group_sum<4>(a + G0 + 4 * g, v + G0 + 4 * g);
+  return xv;
+}
+
+template <int G0, int NG4>
 __global__ __launch_bounds__(MI355X_BLOCK) void maxpy_kernel(MaxpyArgs args, double *x, size_t n, int vec_ok) {
   const size_t tid = (size_t)blockIdx.x * MI355X_BLOCK + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * MI355X_BLOCK;
-  constexpr int NV = G0 + G1;
+  constexpr int NV = G0 + 4 * NG4;
   if (vec_ok) {
     const size_t n2 = n >> 1;
     double2 *x2 = reinterpret_cast<double2 *>(x);
@@ -125,12 +135,8 @@ __global__ __launch_bounds__(MI355X_BLOCK) void maxpy_kernel(MaxpyArgs args, dou
       double lo[NV], hi[NV];
 #pragma unroll
       for (int j = 0; j < NV; ++j) { lo[j] = yv[j].x; hi[j] = yv[j].y; }
-      xv.x = xv.x + group_sum<G0>(args.a, lo);
-      xv.y = xv.y + group_sum<G0>(args.a, hi);
-      if (G1 > 0) {
-        xv.x = xv.x + group_sum<(G1 > 0 ? G1 : 1)>(args.a + G0, lo + G0);
-        xv.y = xv.y + group_sum<(G1 > 0 ? G1 : 1)>(args.a + G0, hi + G0);
-      }
+      xv.x = maxpy_elem<G0, NG4>(xv.x, args.a, lo);
+      xv.y = maxpy_elem<G0, NG4>(xv.y, args.a, hi);
       x2[i] = xv;
     }
     if ((n & 1) && tid == 0) {
@@ -138,26 +144,22 @@ __global__ __launch_bounds__(MI355X_BLOCK) void maxpy_kernel(MaxpyArgs args, dou
       double v[NV];
 #pragma unroll
       for (int j = 0; j < NV; ++j) v[j] = args.y[j][k];
-      double xv = x[k] + group_sum<G0>(args.a, v);
-      if (G1 > 0) xv = xv + group_sum<(G1 > 0 ? G1 : 1)>(args.a + G0, v + G0);
-      x[k] = xv;
+      x[k] = maxpy_elem<G0, NG4>(x[k], args.a, v);
     }
   } else {
     for (size_t k = tid; k < n; k += stride) {
       double v[NV];
 #pragma unroll
       for (int j = 0; j < NV; ++j) v[j] = args.y[j][k];
-      double xv = x[k] + group_sum<G0>(args.a, v);
-      if (G1 > 0) xv = xv + group_sum<(G1 > 0 ? G1 : 1)>(args.a + G0, v + G0);
-      x[k] = xv;
+      x[k] = maxpy_elem<G0, NG4>(x[k], args.a, v);
     }
   }
 }
 
-template <int G0, int G1>
+template <int G0, int NG4>
 static int launch_maxpy(mi355x_handle_t h, const MaxpyArgs &args, double *x, size_t n, int vec_ok) {
   int grid = mi355x_grid_for(n, 2);
-  hipLaunchKernelGGL((maxpy_kernel<G0, G1>), dim3(grid), dim3(MI355X_BLOCK), 0, h->stream, args, x, n, vec_ok);
+  hipLaunchKernelGGL((maxpy_kernel<G0, NG4>), dim3(grid), dim3(MI355X_BLOCK), 0, h->stream, args, x, n, vec_ok);
   MI355X_LAUNCH_CHECK();
   return 0;
 }
@@ -644,36 +646,31 @@ int mi355x_stream_triad(mi355x_handle_t h, size_t n, double alpha, const double 
 int mi355x_vec_maxpy(mi355x_handle_t h, size_t n, int nv, const double *alpha, const double *const *y, double *x) {
   if (nv <= 0 || n == 0) return 0;
   int pos = 0;
-  int rem = nv & 3;
+  const int rem = nv & 3;
   while (pos < nv) {
     MaxpyArgs args;
-    int g0, g1;
-    if (pos == 0 && rem) {
-      g0 = rem;
-      g1 = (nv - rem >= 4) ? 4 : 0;
-    } else {
-      g0 = 4;
-      g1 = (nv - pos - 4 >= 4) ? 4 : 0;
-    }
-    int cnt = g0 + g1;
+    // first group: the remainder nv % 4 if there is one (dvec2.c:853-877 handles it first), else four; then up to
+    // three more groups of four in the same sweep
+    const int g0 = (pos == 0 && rem) ? rem : 4;
+    int ng4 = (nv - pos - g0) / 4;
+    if (ng4 > 3) ng4 = 3;
+    const int cnt = g0 + 4 * ng4;
     int vec_ok = mi355x_aligned16(x);
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < 16; ++j) {
       args.y[j] = (j < cnt) ? y[pos + j] : nullptr;
       args.a[j] = (j < cnt) ? alpha[pos + j] : 0.0;
       if (j < cnt) vec_ok = vec_ok && mi355x_aligned16(y[pos + j]);
     }
     int rc = 0;
-    switch (g0 * 10 + g1) {
-      case 10: rc = launch_maxpy<1, 0>(h, args, x, n, vec_ok); break;
-      case 20: rc = launch_maxpy<2, 0>(h, args, x, n, vec_ok); break;
-      case 30: rc = launch_maxpy<3, 0>(h, args, x, n, vec_ok); break;
-      case 40: rc = launch_maxpy<4, 0>(h, args, x, n, vec_ok); break;
-      case 14: rc = launch_maxpy<1, 4>(h, args, x, n, vec_ok); break;
-      case 24: rc = launch_maxpy<2, 4>(h, args, x, n, vec_ok); break;
-      case 34: rc = launch_maxpy<3, 4>(h, args, x, n, vec_ok); break;
-      case 44: rc = launch_maxpy<4, 4>(h, args, x, n, vec_ok); break;
+#define MAXPY_CASE(G, N4) case (G) * 10 + (N4): rc = launch_maxpy<G, N4>(h, args, x, n, vec_ok); break
+    switch (g0 * 10 + ng4) {
+      MAXPY_CASE(1, 0); MAXPY_CASE(1, 1); MAXPY_CASE(1, 2); MAXPY_CASE(1, 3);
+      MAXPY_CASE(2, 0); MAXPY_CASE(2, 1); MAXPY_CASE(2, 2); MAXPY_CASE(2, 3);
+      MAXPY_CASE(3, 0); MAXPY_CASE(3, 1); MAXPY_CASE(3, 2); MAXPY_CASE(3, 3);
+      MAXPY_CASE(4, 0); MAXPY_CASE(4, 1); MAXPY_CASE(4, 2); MAXPY_CASE(4, 3);
       default: return (int)hipErrorInvalidValue;
     }
+#undef MAXPY_CASE
     if (rc) return rc;
     pos += cnt;
   }
@@ -716,18 +713,20 @@ int mi355x_vec_cg_update_dev(mi355x_handle_t h, size_t n, double beta, const dou
 }
 int mi355x_vec_mdot(mi355x_handle_t h, size_t n, int nv, const double *x, const double *const *y, double *out) {
   int pos = 0;
-  while (pos < nv) {
+  while (pos < nv) {   // up to 16 vectors per pass over x
     int left = nv - pos;
+    int cnt = left > 16 ? 16 : left;
+    if (left > 16 && left < 24) cnt = (left + 1) / 2;   // two passes of similar width instead of 16 + a few
     int rc;
-    if (left >= 8)      { rc = launch_mdot<8>(h, n, x, y + pos, out + pos); pos += 8; }
-    else if (left == 7) { rc = launch_mdot<7>(h, n, x, y + pos, out + pos); pos += 7; }
-    else if (left == 6) { rc = launch_mdot<6>(h, n, x, y + pos, out + pos); pos += 6; }
-    else if (left == 5) { rc = launch_mdot<5>(h, n, x, y + pos, out + pos); pos += 5; }
-    else if (left == 4) { rc = launch_mdot<4>(h, n, x, y + pos, out + pos); pos += 4; }
-    else if (left == 3) { rc = launch_mdot<3>(h, n, x, y + pos, out + pos); pos += 3; }
-    else if (left == 2) { rc = launch_mdot<2>(h, n, x, y + pos, out + pos); pos += 2; }
-    else                { rc = launch_mdot<1>(h, n, x, y + pos, out + pos); pos += 1; }
+    switch (cnt) {
+#define MDOT_CASE(N) case N: rc = launch_mdot<N>(h, n, x, y + pos, out + pos); break
+      MDOT_CASE(1); MDOT_CASE(2); MDOT_CASE(3); MDOT_CASE(4); MDOT_CASE(5); MDOT_CASE(6); MDOT_CASE(7); MDOT_CASE(8);
+      MDOT_CASE(9); MDOT_CASE(10); MDOT_CASE(11); MDOT_CASE(12); MDOT_CASE(13); MDOT_CASE(14); MDOT_CASE(15); MDOT_CASE(16);
+#undef MDOT_CASE
+      default: return (int)hipErrorInvalidValue;
+    }
     if (rc) return rc;
+    pos += cnt;
   }
   return 0;
 }
