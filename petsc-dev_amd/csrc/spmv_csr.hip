@@ -363,6 +363,7 @@ __global__ __launch_bounds__(SPMV_THREADS) void bsr_rowblock_kernel(const int2 *
                                                                    const double *__restrict__ aa,
                                                                    const double *__restrict__ x, double *__restrict__ y) {
   __shared__ double prod[SPMV_BLOCK_NNZ];
+  __shared__ int ajs[SPMV_BLOCK_NNZ / 4 + 1];   // block columns of the row block (bs >= 2: at most NNZ/4 blocks)
   constexpr int BS2 = BS * BS;
   const int lb = blockIdx.x;
   if (lb >= nblocks) return;
@@ -401,31 +402,33 @@ __global__ __launch_bounds__(SPMV_THREADS) void bsr_rowblock_kernel(const int2 *
   const int br = r0 + vc / BS;
   const int rr_ = vc - (vc / BS) * BS;
   const int a0 = ai[br], a1 = ai[br + 1];
+  // block columns of this row block: one coalesced load into LDS instead of a global gather per value (a block's bs^2
+  // values share one entry); k0 is a multiple of bs^2 because row blocks start at block-row boundaries
+  const int kb0 = k0 / BS2, nblk = (k1 - k0) / BS2;
+  for (int b = tid; b < nblk; b += SPMV_THREADS) ajs[b] = aj[kb0 + b];
   constexpr int PAIRS = SPMV_BLOCK_NNZ / (2 * SPMV_THREADS);
   const int ka = k0 & ~1;
   v2d vv[PAIRS];
-  int j0[PAIRS], j1[PAIRS], cc0[PAIRS], cc1[PAIRS];
+#pragma unroll
+  for (int p = 0; p < PAIRS; ++p) {
+    const int k = ka + 2 * tid + p * 2 * SPMV_THREADS;
+    const int kk = (k < k1) ? k : ka;
+    vv[p] = SPMV_LOAD(reinterpret_cast<const v2d *>(aa + kk));
+  }
+  __syncthreads();
+  double xa[PAIRS], xb[PAIRS];
 #pragma unroll
   for (int p = 0; p < PAIRS; ++p) {
     const int k = ka + 2 * tid + p * 2 * SPMV_THREADS;
     const bool in = k < k1;
     const bool v0 = in && k >= k0, v1 = in && (k + 1 < k1);
     const int kk = in ? k : ka;
-    vv[p] = SPMV_LOAD(reinterpret_cast<const v2d *>(aa + kk));
     // value index each slot takes its block column from: its own, or a neighbour inside the block
-    const int f0 = kk + (v0 ? 0 : (in ? 1 : (k0 & 1)));
-    const int f1 = kk + (v1 ? 1 : (in ? 0 : (k0 & 1)));
+    const int f0 = kk + (v0 ? 0 : (in ? 1 : (k0 & 1))) - k0;
+    const int f1 = kk + (v1 ? 1 : (in ? 0 : (k0 & 1))) - k0;
     const int blk0 = f0 / BS2, blk1 = f1 / BS2;
-    j0[p] = aj[blk0];
-    j1[p] = aj[blk1];
-    cc0[p] = (f0 - blk0 * BS2) / BS;
-    cc1[p] = (f1 - blk1 * BS2) / BS;
-  }
-  double xa[PAIRS], xb[PAIRS];
-#pragma unroll
-  for (int p = 0; p < PAIRS; ++p) {
-    xa[p] = x[(long)j0[p] * BS + cc0[p]];
-    xb[p] = x[(long)j1[p] * BS + cc1[p]];
+    xa[p] = x[(long)ajs[blk0] * BS + (f0 - blk0 * BS2) / BS];
+    xb[p] = x[(long)ajs[blk1] * BS + (f1 - blk1 * BS2) / BS];
   }
 #pragma unroll
   for (int p = 0; p < PAIRS; ++p) {
