@@ -355,7 +355,7 @@ static PetscErrorCode gmres_cycle(PetscInt *itcount, KSP ksp) {
 static PetscErrorCode KSPSolve_GMRES(KSP ksp) {   /* gmres.c:213-243 */
   PetscErrorCode ierr;
   KSP_GMRES *g = GM;
-  PetscInt its, itcount = 0;
+  PetscInt its = 0, itcount = 0;
   PetscBool guess_zero = ksp->guess_zero;
   ksp->its = 0;
   ksp->reason = KSP_CONVERGED_ITERATING;

@@ -217,8 +217,7 @@ PetscErrorCode MatCreateMPIAIJWithArrays(MPI_Comm comm, PetscInt m, PetscInt n, 
 /* fills an (empty) MATMPIAIJHIPMI355X from this rank's rows in CSR form (MatMPIAIJSetPreallocationCSR, mpiaij.c) */
 PetscErrorCode MatMPIAIJSetCSR_Private(Mat A, PetscInt m, const PetscInt i[], const PetscInt j[], const PetscScalar a[]) {
   PetscErrorCode ierr;
-  MPI_Comm comm = A->comm;
-  if (m != A->rmap->n) SETERRQ(comm, PETSC_ERR_ARG_SIZ, "local row count %d does not match the layout %d", m, A->rmap->n);
+  if (m != A->rmap->n) SETERRQ(A->comm, PETSC_ERR_ARG_SIZ, "local row count %d does not match the layout %d", m, A->rmap->n);
   Mat_MPIAIJ *aij = MA(A);
   PetscInt cs = aij->cstart, ce = aij->cend, nd = 0, no = 0;
   for (PetscInt k = 0; k < i[m]; k++) { if (j[k] >= cs && j[k] < ce) nd++; else no++; }

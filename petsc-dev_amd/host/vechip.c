@@ -111,7 +111,7 @@ static PetscErrorCode VecResetArray_HIP(Vec v) {
   return 0;
 }
 static PetscErrorCode VecSetValues_HIP(Vec v, PetscInt ni, const PetscInt ix[], const PetscScalar y[], InsertMode mode) {
-  PetscScalar *a;
+  PetscScalar *a = NULL;
   PetscErrorCode ierr = VecGetArray_HIP(v, &a);CHKERRQ(ierr);
   for (PetscInt k = 0; k < ni; k++) {
     if (ix[k] < 0) continue;

@@ -475,3 +475,40 @@ def test_p7_full_size_properties(P):
     L.VecAXPY(aw.h, -2.5, ax.h); L.VecAXPY(aw.h, -1.0, ay.h)
     assert aw.norm() <= 1e-12 * ax.norm()
     assert abs(ax.dot(y) - x.dot(ay)) <= 1e-12 * ax.norm() * y.norm()
+
+
+def test_cg_jacobi_full_size_properties(P):
+    """KSPCG + PCJACOBI at BASELINE.json's full size (P7(256)) through size-independent properties: the solve of
+    A x = A*1 converges to the vector of ones, the reported (preconditioned) residual norm equals the recomputed
+    ||D^-1 (b - A x)|| to 1e-6, and the fused default and the op-by-op sequence (-ksp_cg_fused 0) produce the same
+    iteration count, the same history bits and the same x bits at this size too."""
+    L = P.lib()
+    n = 256
+    ai, aj, aa = P.gen_poisson7(n, n, n)
+    A = P.Mat.from_csr(ai, aj, aa)
+    N = n ** 3
+    one = P.Vec.create(N, comm=L.COMM_SELF); L.VecSet(one.h, 1.0)
+    b = one.duplicate(); A.mult(one, b)
+    outs = []
+    for opts in ("", "-ksp_cg_fused 0"):
+        x = one.duplicate(); L.VecSet(x.h, 0.0)
+        k = P.KSP(comm=L.COMM_SELF)
+        k.set_operators(A)
+        L.PetscOptionsClear(); L.PetscOptionsInsertString(("-ksp_type cg -pc_type jacobi " + opts).encode())
+        k.set_tolerances(rtol=1e-8, max_it=5000)
+        k.set_from_options()
+        k.record_history()
+        k.solve(b, x)
+        L.PetscOptionsClear()
+        outs.append((k.its, k.reason, k.history().copy(), x))
+    (its, reason, h, x), (its0, reason0, h0, x0) = outs
+    assert reason == reason0 == 2 and its == its0 and 200 < its < 2000
+    assert np.array_equal(bits(h), bits(h0))
+    xa = x.array()
+    assert np.array_equal(bits(xa), bits(x0.array()))
+    assert np.max(np.abs(xa - 1.0)) < 1e-4
+    del xa
+    # recomputed preconditioned residual: diag(A) = 6 everywhere
+    r = one.duplicate(); A.mult(x, r)
+    L.VecAYPX(r.h, -1.0, b.h)                          # r = b - A x
+    assert abs(r.norm() / 6.0 - h[-1]) <= 1e-6 * h[0]
