@@ -177,9 +177,26 @@ def main():
         t0 = time.perf_counter()
         _, _, cits, _ = orc.ksp_solve(ai, aj, aa, bref, ksp="cg", pc="jacobi", rtol=0.0, abstol=1e-300, dtol=1e300, max_it=args.cpu_its)
         cdt = time.perf_counter() - t0
-        out["cpu_baseline"] = {"value": round(cits / cdt * unknowns / 1e6, 3), "unit": "Mdof-it/s", "cores": 1, "kind": "port",
-                               "its_per_sec": round(cits / cdt, 4),
-                               "sample": "first %d CG+Jacobi iterations of the same P7(%d) solve by the oracle (C restatement of the reference CPU path, gcc -O2, 1 thread)" % (cits, n)}
+        # all the host cores this job may use, one thread per block of rows (the reference's one-MPI-rank-per-core
+        # arrangement inside one process, oracle/cpu_baseline_mt.c)
+        try:
+            cores = len(os.sched_getaffinity(0))
+        except AttributeError:
+            cores = os.cpu_count() or 1
+        try:                                             # a container's CPU share (cgroup v2 quota), if there is one
+            quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+            if quota != "max":
+                cores = max(1, min(cores, int(int(quota) / int(period))))
+        except Exception:
+            pass
+        cores = min(cores, 16)                           # the GPU box's CPU share for one GPU
+        mt_its = max(args.cpu_its, 3 * args.cpu_its)
+        mdt, _, _ = orc.cg_jacobi_mt(ai, aj, aa, bref, mt_its, cores)
+        out["cpu_baseline"] = {"value": round(mt_its / mdt * unknowns / 1e6, 3), "unit": "Mdof-it/s", "cores": cores, "kind": "port",
+                               "its_per_sec": round(mt_its / mdt, 4), "its_per_sec_1core": round(cits / cdt, 4),
+                               "sample": "first %d CG+Jacobi iterations of the same P7(%d) solve on %d host threads (one per block of rows, the "
+                                         "reference's rank-per-core arrangement in one process; C restatement of the reference CPU path, gcc -O2); "
+                                         "its_per_sec_1core: first %d iterations by the sequential oracle on one core" % (mt_its, n, cores, cits)}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -110,4 +110,10 @@ int orc_ksp_solve(const orc_ksp_opts *o, int n, const int *ai, const int *aj, co
 #ifdef __cplusplus
 }
 #endif
+/* cpu_baseline_mt.c: CG + Jacobi with one thread per "rank" (row blocks, per-thread partial sums added in rank order),
+ * the arrangement of the reference's MPI run inside one process; `its` iterations from x = 0; returns the seconds they
+ * took, x and the last preconditioned residual norm.  Timing aid for bench.py's cpu_baseline. */
+double orc_cg_jacobi_mt(int n, const int *ai, const int *aj, const double *aa, const double *b, int its, int nthreads,
+                        double *x, double *rnorm_out);
+
 #endif

@@ -257,3 +257,18 @@ def ksp_solve(ai, aj, aa, b, ksp="gmres", pc="none", x0=None, blocks=None, sub_k
                              C.byref(nh), C.byref(its), C.byref(reason))
     assert rc == 0
     return x, hist[:min(nh.value, cap)].copy(), its.value, reason.value
+
+
+def cg_jacobi_mt(ai, aj, aa, b, its, nthreads):
+    """CG + Jacobi, `its` iterations from x = 0, one thread per block of rows (oracle/cpu_baseline_mt.c): the CPU
+    baseline's timed loop.  Returns (seconds, x, last preconditioned residual norm)."""
+    L = lib()
+    L.orc_cg_jacobi_mt.restype = C.c_double
+    n = ai.size - 1
+    x = np.zeros(n)
+    rn = C.c_double()
+    ai = np.ascontiguousarray(ai, dtype=np.int32); aj = np.ascontiguousarray(aj, dtype=np.int32)
+    aa = np.ascontiguousarray(aa, dtype=np.float64); b = np.ascontiguousarray(b, dtype=np.float64)
+    t = L.orc_cg_jacobi_mt(C.c_int(n), ai.ctypes.data_as(C.c_void_p), aj.ctypes.data_as(C.c_void_p), aa.ctypes.data_as(C.c_void_p),
+                           b.ctypes.data_as(C.c_void_p), C.c_int(its), C.c_int(nthreads), x.ctypes.data_as(C.c_void_p), C.byref(rn))
+    return t, x, rn.value

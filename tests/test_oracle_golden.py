@@ -164,3 +164,20 @@ def test_tutorial_ex2_gmres_ilu0():
                                       refine_always=1, rtol=rtol, abstol=1e-50)
     pb.check_monitor(h, gold)
     assert its == 7 and "%g" % np.linalg.norm(x - u) == "0.000292349"
+
+
+def test_threaded_cpu_baseline_matches_the_sequential_oracle():
+    """bench.py's cpu_baseline loop (one thread per block of rows, partial sums added in rank order -- the reference's
+    MPI arrangement inside one process) computes the same CG + Jacobi iterates as the sequential oracle, to the
+    rounding of the re-associated dot products"""
+    import problems as pb
+    ai, aj, aa = pb.lap2d(30, 23)
+    n = ai.size - 1
+    b = orc.spmv(ai, aj, aa, np.ones(n))
+    xs, hs, its, _ = orc.ksp_solve(ai, aj, aa, b, ksp="cg", pc="jacobi", rtol=0.0, abstol=1e-300, dtol=1e300, max_it=25)
+    assert its == 25
+    for nt in (1, 3, 8):
+        t, x, rn = orc.cg_jacobi_mt(ai, aj, aa, b, 25, nt)
+        assert t >= 0.0
+        assert np.linalg.norm(x - xs) <= 1e-12 * np.linalg.norm(xs)
+        assert abs(rn - hs[25]) <= 1e-10 * hs[0]
