@@ -427,7 +427,8 @@ struct CGUpdateF {
       const double2 *p2 = reinterpret_cast<const double2 *>(p), *w2 = reinterpret_cast<const double2 *>(w);
       const double2 *d2 = reinterpret_cast<const double2 *>(d);
       double2 *x2 = reinterpret_cast<double2 *>(x), *r2 = reinterpret_cast<double2 *>(r), *z2 = reinterpret_cast<double2 *>(z);
-      double2 pv0 = p2[i], pv1 = p2[i + stride], wv0 = w2[i], wv1 = w2[i + stride], dv0 = d2[i], dv1 = d2[i + stride];
+      const double2 one2 = {1.0, 1.0};
+      double2 pv0 = p2[i], pv1 = p2[i + stride], wv0 = w2[i], wv1 = w2[i + stride], dv0 = d ? d2[i] : one2, dv1 = d ? d2[i + stride] : one2;
       double2 xv0 = x2[i], xv1 = x2[i + stride], rv0 = r2[i], rv1 = r2[i + stride], zv0, zv1;
       step(pv0.x, wv0.x, dv0.x, xv0.x, rv0.x, zv0.x, acc); step(pv0.y, wv0.y, dv0.y, xv0.y, rv0.y, zv0.y, acc);
       step(pv1.x, wv1.x, dv1.x, xv1.x, rv1.x, zv1.x, acc); step(pv1.y, wv1.y, dv1.y, xv1.y, rv1.y, zv1.y, acc);
@@ -435,8 +436,9 @@ struct CGUpdateF {
       x2[i + stride] = xv1; r2[i + stride] = rv1; z2[i + stride] = zv1;
     }
     for (; i < n2; i += stride) {
+      const double2 one2 = {1.0, 1.0};
       double2 pv = reinterpret_cast<const double2 *>(p)[i], wv = reinterpret_cast<const double2 *>(w)[i];
-      double2 dv = reinterpret_cast<const double2 *>(d)[i];
+      double2 dv = d ? reinterpret_cast<const double2 *>(d)[i] : one2;
       double2 xv = reinterpret_cast<double2 *>(x)[i], rv = reinterpret_cast<double2 *>(r)[i], zv;
       step(pv.x, wv.x, dv.x, xv.x, rv.x, zv.x, acc); step(pv.y, wv.y, dv.y, xv.y, rv.y, zv.y, acc);
       reinterpret_cast<double2 *>(x)[i] = xv; reinterpret_cast<double2 *>(r)[i] = rv; reinterpret_cast<double2 *>(z)[i] = zv;
@@ -451,7 +453,7 @@ struct CGUpdateF {
   }
   __device__ void accum1(size_t i, double (&acc)[2]) const {
     double xv = x[i], rv = r[i], zv;
-    step(p[i], w[i], d[i], xv, rv, zv, acc);
+    step(p[i], w[i], d ? d[i] : 1.0, xv, rv, zv, acc);
     x[i] = xv; r[i] = rv; z[i] = zv;
   }
 };
@@ -491,10 +493,11 @@ struct CGUpdateDevF {
     if (!scalars(a)) return;
     const double2 *p2 = reinterpret_cast<const double2 *>(p), *w2 = reinterpret_cast<const double2 *>(w);
     const double2 *d2 = reinterpret_cast<const double2 *>(d);
+    const double2 one2 = {1.0, 1.0};
     double2 *x2 = reinterpret_cast<double2 *>(x), *r2 = reinterpret_cast<double2 *>(r), *z2 = reinterpret_cast<double2 *>(z);
     size_t i = tid;
     for (; i + stride < n2; i += 2 * stride) {
-      double2 pv0 = p2[i], pv1 = p2[i + stride], wv0 = w2[i], wv1 = w2[i + stride], dv0 = d2[i], dv1 = d2[i + stride];
+      double2 pv0 = p2[i], pv1 = p2[i + stride], wv0 = w2[i], wv1 = w2[i + stride], dv0 = d ? d2[i] : one2, dv1 = d ? d2[i + stride] : one2;
       double2 xv0 = x2[i], xv1 = x2[i + stride], rv0 = r2[i], rv1 = r2[i + stride], zv0, zv1;
       step(a, pv0.x, wv0.x, dv0.x, xv0.x, rv0.x, zv0.x, acc); step(a, pv0.y, wv0.y, dv0.y, xv0.y, rv0.y, zv0.y, acc);
       step(a, pv1.x, wv1.x, dv1.x, xv1.x, rv1.x, zv1.x, acc); step(a, pv1.y, wv1.y, dv1.y, xv1.y, rv1.y, zv1.y, acc);
@@ -502,7 +505,7 @@ struct CGUpdateDevF {
       x2[i + stride] = xv1; r2[i + stride] = rv1; z2[i + stride] = zv1;
     }
     for (; i < n2; i += stride) {
-      double2 pv = p2[i], wv = w2[i], dv = d2[i], xv = x2[i], rv = r2[i], zv;
+      double2 pv = p2[i], wv = w2[i], dv = d ? d2[i] : one2, xv = x2[i], rv = r2[i], zv;
       step(a, pv.x, wv.x, dv.x, xv.x, rv.x, zv.x, acc); step(a, pv.y, wv.y, dv.y, xv.y, rv.y, zv.y, acc);
       x2[i] = xv; r2[i] = rv; z2[i] = zv;
     }
@@ -511,7 +514,7 @@ struct CGUpdateDevF {
     double a;
     if (!scalars(a)) return;
     double xv = x[i], rv = r[i], zv;
-    step(a, p[i], w[i], d[i], xv, rv, zv, acc);
+    step(a, p[i], w[i], d ? d[i] : 1.0, xv, rv, zv, acc);
     x[i] = xv; r[i] = rv; z[i] = zv;
   }
 };
@@ -700,7 +703,7 @@ int mi355x_vec_cg_update(mi355x_handle_t h, size_t n, double a, const double *p,
                          double *x, double *r, double *z, double *out) {
   CGUpdateF f{a, -a, p, w, d, x, r, z};
   int v = mi355x_aligned16(p) && mi355x_aligned16(w) && mi355x_aligned16(d) && mi355x_aligned16(x) && mi355x_aligned16(r) &&
-          mi355x_aligned16(z);
+          mi355x_aligned16(z);   /* d == NULL (identity preconditioner) counts as aligned */
   return launch_reduce<2, RED_SUM>(h, f, n, v, out);
 }
 int mi355x_vec_cg_update_dev(mi355x_handle_t h, size_t n, double beta, const double *dpi_dev, double dpiold, int check_sign,
@@ -708,7 +711,7 @@ int mi355x_vec_cg_update_dev(mi355x_handle_t h, size_t n, double beta, const dou
                              int also_to_host) {
   CGUpdateDevF f{beta, dpiold, check_sign, dpi_dev, p, w, d, x, r, z};
   int v = mi355x_aligned16(p) && mi355x_aligned16(w) && mi355x_aligned16(d) && mi355x_aligned16(x) && mi355x_aligned16(r) &&
-          mi355x_aligned16(z);
+          mi355x_aligned16(z);   /* d == NULL (identity preconditioner) counts as aligned */
   return launch_reduce<3, RED_SUM>(h, f, n, v, out, also_to_host != 0);
 }
 int mi355x_vec_mdot(mi355x_handle_t h, size_t n, int nv, const double *x, const double *const *y, double *out) {

@@ -32,7 +32,7 @@ static PetscErrorCode KSPSolve_CG(KSP ksp) {
   Vec S = single ? ksp->work[3] : NULL, W = single ? ksp->work[4] : Z;   /* cg.c:116-122 */
   Mat Amat = ksp->pc->mat;
   /* Fused forms, -ksp_cg_fused <0|1|2|3|4> (default 3); iterates and history carry the same bits at every level:
-   *  1: with PCJACOBI the two AXPYs, the PCApply, the norm and the dot of cg.c:206-232 are one sweep
+   *  1: with PCJACOBI (or PCNONE) the two AXPYs, the PCApply, the norm and the dot of cg.c:206-232 are one sweep
    *     (VecCGUpdate_HIPMI355X); with any other PC the norm and the dot share one VecDotNorm2 reduction;
    *  2: as 1, and with PCJACOBI dpi = p'w stays on the device, where the update forms a = beta/dpi itself: one host
    *     synchronisation per iteration instead of two (VecTDotBegin_HIPMI355X / VecCGUpdateDev_HIPMI355X);
@@ -49,11 +49,11 @@ static PetscErrorCode KSPSolve_CG(KSP ksp) {
   const PetscInt flevel = single ? 0 : ((KSP_CG *)ksp->data)->fused;
   const PetscBool fused = (PetscBool)(flevel > 0);
   Vec D = NULL;
-  PetscBool devscalar = PETSC_FALSE, front_queued = PETSC_FALSE;
+  PetscBool devscalar = PETSC_FALSE, front_queued = PETSC_FALSE, fusedpc = PETSC_FALSE;   /* fusedpc: PCJACOBI (D) or PCNONE (D == NULL, z = r) */
   if (fused) {
     ierr = PCJacobiGetInverseDiagonal_Private(ksp->pc, &D);CHKERRQ(ierr);
-    if (D) { PetscBool ok; ierr = VecCGUpdateCheck_HIPMI355X(X, R, Z, P, W, D, &ok);CHKERRQ(ierr); if (!ok) D = NULL; }
-    devscalar = (PetscBool)(D && flevel > 1);
+    if (D || PCIsNone_Private(ksp->pc)) { ierr = VecCGUpdateCheck_HIPMI355X(X, R, Z, P, W, D, &fusedpc);CHKERRQ(ierr); }
+    devscalar = (PetscBool)(fusedpc && flevel > 1);
   }
 
   ksp->its = 0;
@@ -127,7 +127,7 @@ static PetscErrorCode KSPSolve_CG(KSP ksp) {
     if (PetscIsInfOrNanScalar(dpi)) SETERRQ(ksp->comm, PETSC_ERR_FP, "Infinite or not-a-number generated in dot product");
     if ((dpi == 0.0) || ((i > 0) && (dpi * dpiold <= 0.0))) { ksp->reason = KSP_DIVERGED_INDEFINITE_MAT; break; }
     a = beta / dpi;
-    if (!have_beta && fused && D) { ierr = VecCGUpdate_HIPMI355X(X, R, Z, P, W, D, a, &zz, &zr, &have_beta);CHKERRQ(ierr); }
+    if (!have_beta && fusedpc) { ierr = VecCGUpdate_HIPMI355X(X, R, Z, P, W, D, a, &zz, &zr, &have_beta);CHKERRQ(ierr); }
     if (!have_beta) {
       ierr = VecAXPY(X, a, P);CHKERRQ(ierr);                     /* x <- x + ap */
       ierr = VecAXPY(R, -a, W);CHKERRQ(ierr);                    /* r <- r - aw */

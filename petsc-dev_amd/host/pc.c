@@ -114,6 +114,7 @@ PetscErrorCode PCJacobiGetInverseDiagonal_Private(PC pc, Vec *d) {
   *d = ((PC_Jacobi *)pc->data)->diag;
   return 0;
 }
+PetscBool PCIsNone_Private(PC pc) { return (PetscBool)(pc && pc->ops->apply == PCApply_None); }
 static PetscErrorCode PCDestroy_Jacobi(PC pc) {
   PC_Jacobi *jac = (PC_Jacobi *)pc->data;
   if (jac) { PetscErrorCode ierr = VecDestroy(&jac->diag);CHKERRQ(ierr); free(jac); pc->data = NULL; }

@@ -357,7 +357,8 @@ PetscErrorCode VecCGUpdate_HIPMI355X(Vec x, Vec r, Vec z, Vec p, Vec w, Vec d, P
   *done = PETSC_FALSE;
   ierr = VecHIPGetRead(p, &dp_);CHKERRQ(ierr);
   ierr = VecHIPGetRead(w, &dw);CHKERRQ(ierr);
-  ierr = VecHIPGetRead(d, &dd);CHKERRQ(ierr);
+  dd = NULL;
+  if (d) { ierr = VecHIPGetRead(d, &dd);CHKERRQ(ierr); }
   ierr = VecHIPGetReadWrite(x, &dx);CHKERRQ(ierr);
   ierr = VecHIPGetReadWrite(r, &dr);CHKERRQ(ierr);
   ierr = VecHIPGetWrite(z, &dz);CHKERRQ(ierr);
@@ -397,7 +398,8 @@ PetscErrorCode VecCGUpdateDevBegin_HIPMI355X(Vec x, Vec r, Vec z, Vec p, Vec w, 
   PetscErrorCode ierr; const PetscScalar *dp_, *dw, *dd; PetscScalar *dx, *dr, *dz; double *ds; DEVCTX;
   ierr = VecHIPGetRead(p, &dp_);CHKERRQ(ierr);
   ierr = VecHIPGetRead(w, &dw);CHKERRQ(ierr);
-  ierr = VecHIPGetRead(d, &dd);CHKERRQ(ierr);
+  dd = NULL;
+  if (d) { ierr = VecHIPGetRead(d, &dd);CHKERRQ(ierr); }
   ierr = VecHIPGetReadWrite(x, &dx);CHKERRQ(ierr);
   ierr = VecHIPGetReadWrite(r, &dr);CHKERRQ(ierr);
   if (z == w) { ierr = VecHIPGetReadWrite(z, &dz);CHKERRQ(ierr); }   /* left as it is when the update is refused */
@@ -438,8 +440,9 @@ PetscErrorCode VecAYPXDev_HIPMI355X(Vec p, PetscScalar den, Vec z) {
 /* can the six vectors of a CG iteration take the fused update at all (types, sizes, aliasing)? */
 PetscErrorCode VecCGUpdateCheck_HIPMI355X(Vec x, Vec r, Vec z, Vec p, Vec w, Vec d, PetscBool *ok) {
   *ok = PETSC_FALSE;
-  if (!is_hip(x) || !is_hip(r) || !is_hip(z) || !is_hip(p) || !is_hip(w) || !is_hip(d)) return 0;
-  if (x->map->n != r->map->n || x->map->n != z->map->n || x->map->n != p->map->n || x->map->n != w->map->n || x->map->n != d->map->n) return 0;
+  /* d == NULL: identity preconditioner (PCNONE), z = r */
+  if (!is_hip(x) || !is_hip(r) || !is_hip(z) || !is_hip(p) || !is_hip(w) || (d && !is_hip(d))) return 0;
+  if (x->map->n != r->map->n || x->map->n != z->map->n || x->map->n != p->map->n || x->map->n != w->map->n || (d && x->map->n != d->map->n)) return 0;
   if (x == r || x == z || r == z || z == p || z == d) return 0;   /* z may be w (cg.c:122 keeps A*p in Z) */
   *ok = PETSC_TRUE;
   return 0;
