@@ -138,6 +138,14 @@ int mi355x_vec_cg_update(mi355x_handle_t h, size_t n, double a, const double *p,
 int mi355x_vec_cg_update_dev(mi355x_handle_t h, size_t n, double beta, const double *dpi_dev, double dpiold, int check_sign,
                              const double *p, const double *w, const double *d, double *x, double *r, double *z, double *out,
                              int also_to_host);
+/* Fused forms for KSPSolve_BCGS (src/ksp/ksp/impls/bcgs/bcgs.c:43-160); same bits as the calls they replace.
+ * pmult_dot:      w = x .* d (PCApply_Jacobi jacobi.c:266; d == NULL: identity), out[0] = sum w*y       (bcgs.c:108-109)
+ * pmult_dotnorm2: w = x .* d,                       out[0] = sum s*w, out[1] = sum w*w               (bcgs.c:116-117)
+ * bcgs_update:    x = alpha p + omega s + x ; r = s - omega t ; out[0] = sum r*r, out[1] = sum r*rp  (bcgs.c:134-136,103) */
+int mi355x_vec_pmult_dot(mi355x_handle_t h, size_t n, const double *x, const double *d, const double *y, double *w, double *out);
+int mi355x_vec_pmult_dotnorm2(mi355x_handle_t h, size_t n, const double *x, const double *d, const double *s, double *w, double *out);
+int mi355x_vec_bcgs_update(mi355x_handle_t h, size_t n, double alpha, double omega, const double *p, const double *s, const double *t,
+                           const double *rp, double *x, double *r, double *out);
 /* VecMDot_Seq         src/vec/vec/impls/seq/dvec2.c:146     out[j] = sum_i x_i y_j,i , j<nv ; x read once per 16 y's */
 int mi355x_vec_mdot(mi355x_handle_t h, size_t n, int nv, const double *x, const double *const *y, double *out);
 /* VecSum / VecMax helpers are not on the Krylov path and are not provided. */

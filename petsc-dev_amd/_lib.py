@@ -65,6 +65,9 @@ KERNEL_API = {
     "mi355x_vec_mdot": [vp, sz, i32, vp, C.POINTER(vp), vp],
     "mi355x_vec_cg_update": [vp, sz, dbl, vp, vp, vp, vp, vp, vp, vp],
     "mi355x_vec_aypx_dev": [vp, sz, vp, dbl, vp, vp],
+    "mi355x_vec_pmult_dot": [vp, sz, vp, vp, vp, vp, vp],
+    "mi355x_vec_pmult_dotnorm2": [vp, sz, vp, vp, vp, vp, vp],
+    "mi355x_vec_bcgs_update": [vp, sz, dbl, dbl, vp, vp, vp, vp, vp, vp, vp],
     "mi355x_handle_publish": [vp, vp, i32],
     "mi355x_vec_cg_update_dev": [vp, sz, dbl, vp, dbl, i32, vp, vp, vp, vp, vp, vp, vp, i32],
     "mi355x_spmv_plan_create": [vp, i32, vp, vp, C.POINTER(vp)],

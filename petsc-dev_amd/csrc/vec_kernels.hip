@@ -520,6 +520,80 @@ struct CGUpdateDevF {
 };
 template <> struct has_prologue<CGUpdateDevF> { static constexpr bool value = true; };
 
+// ---- fused forms for KSPSolve_BCGS (bcgs.c:43-160); each keeps the element-wise arithmetic of the calls it replaces and
+// the per-lane summation order of DotF / DotNorm2F / SumSqF under launch_reduce, so results carry the same bits.
+// w = x .* d (PCApply_Jacobi; d == NULL: identity, PCNONE's copy) and Sum w*y (VecDot(w, y)): 4 passes instead of 5.
+struct PMultDotF {
+  const double *x, *d, *y;
+  double *w;
+  DEFAULT_SWEEP()
+  __device__ void accum2x4(size_t i, size_t st, double (&a)[1]) const { accum2(i, a); accum2(i + st, a); accum2(i + 2 * st, a); accum2(i + 3 * st, a); }
+  __device__ void accum1(size_t i, double (&a)[1]) const {
+    const double wv = x[i] * (d ? d[i] : 1.0);
+    w[i] = wv;
+    a[0] += wv * y[i];
+  }
+  __device__ void accum2(size_t i, double (&a)[1]) const {
+    const double2 one2 = {1.0, 1.0};
+    double2 xv = reinterpret_cast<const double2 *>(x)[i], dv = d ? reinterpret_cast<const double2 *>(d)[i] : one2;
+    double2 yv = reinterpret_cast<const double2 *>(y)[i], wv;
+    wv.x = xv.x * dv.x; wv.y = xv.y * dv.y;
+    reinterpret_cast<double2 *>(w)[i] = wv;
+    a[0] += wv.x * yv.x;
+    a[0] += wv.y * yv.y;
+  }
+};
+// w = x .* d and VecDotNorm2(s, w): Sum s*w, Sum w*w
+struct PMultDotNorm2F {
+  const double *x, *d, *s;
+  double *w;
+  DEFAULT_SWEEP()
+  __device__ void accum2x4(size_t i, size_t st, double (&a)[2]) const { accum2(i, a); accum2(i + st, a); accum2(i + 2 * st, a); accum2(i + 3 * st, a); }
+  __device__ void accum1(size_t i, double (&a)[2]) const {
+    const double wv = x[i] * (d ? d[i] : 1.0);
+    w[i] = wv;
+    a[0] += s[i] * wv; a[1] += wv * wv;
+  }
+  __device__ void accum2(size_t i, double (&a)[2]) const {
+    const double2 one2 = {1.0, 1.0};
+    double2 xv = reinterpret_cast<const double2 *>(x)[i], dv = d ? reinterpret_cast<const double2 *>(d)[i] : one2;
+    double2 sv = reinterpret_cast<const double2 *>(s)[i], wv;
+    wv.x = xv.x * dv.x; wv.y = xv.y * dv.y;
+    reinterpret_cast<double2 *>(w)[i] = wv;
+    a[0] += sv.x * wv.x; a[1] += wv.x * wv.x;
+    a[0] += sv.y * wv.y; a[1] += wv.y * wv.y;
+  }
+};
+// x = alpha p + omega s + x (VecAXPBYPCZ, gamma == 1 form, bvec1.c:436), r = s + (-omega) t (VecWAXPY, dvec2.c:1094),
+// Sum r*r (VecNorm), Sum r*rp (next iteration's VecDot(R,RP)): 7 passes instead of 10, one reduction instead of two
+struct BcgsUpdateF {
+  double alpha, omega, momega;
+  const double *p, *s, *t, *rp;
+  double *x, *r;
+  DEFAULT_SWEEP()
+  __device__ void accum2x4(size_t i, size_t st, double (&a)[2]) const { accum2(i, a); accum2(i + st, a); accum2(i + 2 * st, a); accum2(i + 3 * st, a); }
+  __device__ __forceinline__ void one(double pv, double sv, double tv, double rpv, double &xv, double &rv, double (&a)[2]) const {
+    xv = alpha * pv + omega * sv + xv;
+    rv = (momega == 0.0) ? sv : sv + momega * tv;      // VecWAXPY copies for alpha == 0
+    a[0] += rv * rv;
+    a[1] += rv * rpv;
+  }
+  __device__ void accum1(size_t i, double (&a)[2]) const {
+    double xv = x[i], rv;
+    one(p[i], s[i], t[i], rp[i], xv, rv, a);
+    x[i] = xv; r[i] = rv;
+  }
+  __device__ void accum2(size_t i, double (&a)[2]) const {
+    double2 pv = reinterpret_cast<const double2 *>(p)[i], sv = reinterpret_cast<const double2 *>(s)[i];
+    double2 tv = reinterpret_cast<const double2 *>(t)[i], qv = reinterpret_cast<const double2 *>(rp)[i];
+    double2 xv = reinterpret_cast<double2 *>(x)[i], rv;
+    one(pv.x, sv.x, tv.x, qv.x, xv.x, rv.x, a);
+    one(pv.y, sv.y, tv.y, qv.y, xv.y, rv.y, a);
+    reinterpret_cast<double2 *>(x)[i] = xv;
+    reinterpret_cast<double2 *>(r)[i] = rv;
+  }
+};
+
 template <int NV>
 struct MDotF {
   const double *x;
@@ -713,6 +787,20 @@ int mi355x_vec_cg_update_dev(mi355x_handle_t h, size_t n, double beta, const dou
   int v = mi355x_aligned16(p) && mi355x_aligned16(w) && mi355x_aligned16(d) && mi355x_aligned16(x) && mi355x_aligned16(r) &&
           mi355x_aligned16(z);   /* d == NULL (identity preconditioner) counts as aligned */
   return launch_reduce<3, RED_SUM>(h, f, n, v, out, also_to_host != 0);
+}
+int mi355x_vec_pmult_dot(mi355x_handle_t h, size_t n, const double *x, const double *d, const double *y, double *w, double *out) {
+  PMultDotF f{x, d, y, w};
+  return launch_reduce<1, RED_SUM>(h, f, n, mi355x_aligned16(x) && mi355x_aligned16(d) && mi355x_aligned16(y) && mi355x_aligned16(w), out);
+}
+int mi355x_vec_pmult_dotnorm2(mi355x_handle_t h, size_t n, const double *x, const double *d, const double *s, double *w, double *out) {
+  PMultDotNorm2F f{x, d, s, w};
+  return launch_reduce<2, RED_SUM>(h, f, n, mi355x_aligned16(x) && mi355x_aligned16(d) && mi355x_aligned16(s) && mi355x_aligned16(w), out);
+}
+int mi355x_vec_bcgs_update(mi355x_handle_t h, size_t n, double alpha, double omega, const double *p, const double *s, const double *t,
+                           const double *rp, double *x, double *r, double *out) {
+  BcgsUpdateF f{alpha, omega, -omega, p, s, t, rp, x, r};
+  int v = mi355x_aligned16(p) && mi355x_aligned16(s) && mi355x_aligned16(t) && mi355x_aligned16(rp) && mi355x_aligned16(x) && mi355x_aligned16(r);
+  return launch_reduce<2, RED_SUM>(h, f, n, v, out);
 }
 int mi355x_vec_mdot(mi355x_handle_t h, size_t n, int nv, const double *x, const double *const *y, double *out) {
   int pos = 0;

@@ -391,14 +391,26 @@ PetscErrorCode KSPCreate_GMRES(KSP ksp) {   /* gmres.c KSPCreate_GMRES: restart 
 /* ================================================================== BiCGStab */
 static PetscErrorCode KSPSetUp_BCGS(KSP ksp) { return KSPDefaultGetWork(ksp, 6); }   /* bcgs.c:13 */
 
+/* -ksp_bcgs_fused <bool> (default true): with left PCJACOBI / PCNONE the PCApply is fused with the dot(s) that follow it
+ * and the x/r update with the norm and the NEXT iteration's rho (VecPMultDot, VecPMultDotNorm2, VecBCGSUpdate in
+ * vechip.c): 22 vector passes and 3 reductions per iteration instead of 27 and 4, identical bits. */
 static PetscErrorCode KSPSolve_BCGS(KSP ksp) {
   PetscErrorCode ierr;
   PetscInt i;
-  PetscScalar rho, rhoold, alpha, beta, omega, omegaold, d1;
+  PetscScalar rho = 0.0, rhoold, alpha, beta, omega, omegaold, d1;
   PetscReal dp = 0.0, d2;
   Vec X = ksp->vec_sol, B = ksp->vec_rhs, R = ksp->work[0], RP = ksp->work[1], V = ksp->work[2], T = ksp->work[3], S = ksp->work[4], P = ksp->work[5];
+  Mat Amat = ksp->pc->mat;
+  Vec D = NULL;
+  PetscBool fusedpc = PETSC_FALSE, have_rho = PETSC_FALSE, done;
+  char t_[16]; PetscBool set;
 
   if (ksp->pc_side == PC_RIGHT) SETERRQ(ksp->comm, PETSC_ERR_SUP, "right-preconditioned BiCGStab is outside the ported path");
+  ierr = PetscOptionsGetString(ksp->prefix, "-ksp_bcgs_fused", t_, sizeof(t_), &set);CHKERRQ(ierr);
+  if (!set || (strcmp(t_, "0") && strcmp(t_, "false"))) {
+    ierr = PCJacobiGetInverseDiagonal_Private(ksp->pc, &D);CHKERRQ(ierr);
+    fusedpc = (PetscBool)(D != NULL || PCIsNone_Private(ksp->pc));
+  }
   ierr = KSPInitialResidual(ksp, X, V, T, R, B);CHKERRQ(ierr);   /* initial preconditioned residual */
   ierr = VecNorm(R, NORM_2, &dp);CHKERRQ(ierr);
   ksp->its = 0;
@@ -413,16 +425,27 @@ static PetscErrorCode KSPSolve_BCGS(KSP ksp) {
   ierr = VecSet(V, 0.0);CHKERRQ(ierr);
   i = 0;
   do {
-    ierr = VecDot(R, RP, &rho);CHKERRQ(ierr);                    /* rho <- (r,rp) */
+    if (!have_rho) { ierr = VecDot(R, RP, &rho);CHKERRQ(ierr); }  /* rho <- (r,rp) */
+    have_rho = PETSC_FALSE;
     beta = (rho / rhoold) * (alpha / omegaold);
     ierr = VecAXPBYPCZ(P, 1.0, -omegaold * beta, beta, R, V);CHKERRQ(ierr);   /* p <- r - omega*beta*v + beta*p */
-    ierr = KSP_PCApplyBAorAB(ksp, P, V, T);CHKERRQ(ierr);        /* v <- K p */
-    ierr = VecDot(V, RP, &d1);CHKERRQ(ierr);
+    done = PETSC_FALSE;
+    if (fusedpc) {                                               /* v <- K p and (v,rp) */
+      ierr = KSP_MatMult(ksp, Amat, P, T);CHKERRQ(ierr);
+      ierr = VecPMultDot_HIPMI355X(V, T, D, RP, &d1, &done);CHKERRQ(ierr);
+      if (!done) { ierr = KSP_PCApply(ksp, T, V);CHKERRQ(ierr); }
+    } else { ierr = KSP_PCApplyBAorAB(ksp, P, V, T);CHKERRQ(ierr); }
+    if (!done) { ierr = VecDot(V, RP, &d1);CHKERRQ(ierr); }
     if (d1 == 0.0) SETERRQ(ksp->comm, PETSC_ERR_PLIB, "Divide by zero");
     alpha = rho / d1;
     ierr = VecWAXPY(S, -alpha, V, R);CHKERRQ(ierr);              /* s <- r - a v */
-    ierr = KSP_PCApplyBAorAB(ksp, S, T, R);CHKERRQ(ierr);        /* t <- K s */
-    ierr = VecDotNorm2(S, T, &d1, &d2);CHKERRQ(ierr);
+    done = PETSC_FALSE;
+    if (fusedpc) {                                               /* t <- K s and (s,t), (t,t) */
+      ierr = KSP_MatMult(ksp, Amat, S, R);CHKERRQ(ierr);
+      ierr = VecPMultDotNorm2_HIPMI355X(T, R, D, S, &d1, &d2, &done);CHKERRQ(ierr);
+      if (!done) { ierr = KSP_PCApply(ksp, R, T);CHKERRQ(ierr); }
+    } else { ierr = KSP_PCApplyBAorAB(ksp, S, T, R);CHKERRQ(ierr); }
+    if (!done) { ierr = VecDotNorm2(S, T, &d1, &d2);CHKERRQ(ierr); }
     if (d2 == 0.0) {
       /* t is 0: if s is 0 too, alpha p may be the solution */
       ierr = VecDot(S, S, &d1);CHKERRQ(ierr);
@@ -436,17 +459,26 @@ static PetscErrorCode KSPSolve_BCGS(KSP ksp) {
       break;
     }
     omega = d1 / d2;                                             /* w <- (t's)/(t't) */
-    ierr = VecAXPBYPCZ(X, alpha, omega, 1.0, P, S);CHKERRQ(ierr);/* x <- alpha*p + omega*s + x */
-    ierr = VecWAXPY(R, -omega, T, S);CHKERRQ(ierr);              /* r <- s - w t */
-    ierr = VecNorm(R, NORM_2, &dp);CHKERRQ(ierr);
-    rhoold = rho; omegaold = omega;
+    done = PETSC_FALSE;
+    if (fusedpc) {                                               /* x, r, (r,r) and the next (r,rp) in one sweep */
+      PetscScalar rr, rhonext;
+      ierr = VecBCGSUpdate_HIPMI355X(X, R, P, S, T, RP, alpha, omega, &rr, &rhonext, &done);CHKERRQ(ierr);
+      if (done) { dp = PetscSqrtReal(rr); rhoold = rho; rho = rhonext; have_rho = PETSC_TRUE; }
+    }
+    if (!done) {
+      ierr = VecAXPBYPCZ(X, alpha, omega, 1.0, P, S);CHKERRQ(ierr);/* x <- alpha*p + omega*s + x */
+      ierr = VecWAXPY(R, -omega, T, S);CHKERRQ(ierr);            /* r <- s - w t */
+      ierr = VecNorm(R, NORM_2, &dp);CHKERRQ(ierr);
+      rhoold = rho;
+    }
+    omegaold = omega;
     ksp->its++;
     ksp->rnorm = dp;
     KSPLogResidualHistory(ksp, dp);
     ierr = KSPMonitor(ksp, i + 1, dp);CHKERRQ(ierr);
     ierr = KSPDefaultConverged(ksp, i + 1, dp, &ksp->reason);CHKERRQ(ierr);
     if (ksp->reason) break;
-    if (rho == 0.0) { ksp->reason = KSP_DIVERGED_BREAKDOWN; break; }
+    if ((have_rho ? rhoold : rho) == 0.0) { ksp->reason = KSP_DIVERGED_BREAKDOWN; break; }   /* bcgs.c:146: the rho this iteration used */
     i++;
   } while (i < ksp->max_it);
   if (i >= ksp->max_it) ksp->reason = KSP_DIVERGED_ITS;

@@ -448,6 +448,68 @@ PetscErrorCode VecCGUpdateCheck_HIPMI355X(Vec x, Vec r, Vec z, Vec p, Vec w, Vec
   return 0;
 }
 
+/* Fused forms for KSPSolve_BCGS (krylov.c); *done = PETSC_FALSE and nothing touched unless every operand is a
+ * HIPMI355X vector of the same local size.  d == NULL stands for the identity preconditioner. */
+static int all_hip_same_size(Vec a, Vec b, Vec c, Vec d, Vec e, Vec f) {
+  Vec v[6] = {a, b, c, d, e, f};
+  for (int i = 0; i < 6; i++) if (v[i] && (!is_hip(v[i]) || v[i]->map->n != a->map->n)) return 0;
+  return 1;
+}
+PetscErrorCode VecPMultDot_HIPMI355X(Vec w, Vec x, Vec d, Vec y, PetscScalar *val, PetscBool *done) {   /* w = x.*d ; val = (w,y) */
+  PetscErrorCode ierr; const PetscScalar *dx, *dd = NULL, *dy; PetscScalar *dw; double *out; DEVCTX;
+  *done = PETSC_FALSE;
+  if (!all_hip_same_size(w, x, y, d, NULL, NULL) || w == x || w == y || w == d) return 0;
+  ierr = VecHIPGetRead(x, &dx);CHKERRQ(ierr);
+  if (d) { ierr = VecHIPGetRead(d, &dd);CHKERRQ(ierr); }
+  ierr = VecHIPGetRead(y, &dy);CHKERRQ(ierr);
+  ierr = VecHIPGetWrite(w, &dw);CHKERRQ(ierr);
+  ierr = reduce_target(w, dc, &out);CHKERRQ(ierr);
+  CHKHIP(mi355x_vec_pmult_dot(dc->h, N_(w), dx, dd, dy, dw, out));
+  VecHIPRestoreWrite(w); PetscObjectStateIncrease(w);
+  ierr = reduce_finish(w, dc, 1, 0, val);CHKERRQ(ierr);
+  ierr = PetscLogFlops(3.0 * w->map->n);CHKERRQ(ierr);
+  *done = PETSC_TRUE;
+  return 0;
+}
+PetscErrorCode VecPMultDotNorm2_HIPMI355X(Vec w, Vec x, Vec d, Vec s_, PetscScalar *dp, PetscReal *nm, PetscBool *done) {   /* w = x.*d ; (s,w), (w,w) */
+  PetscErrorCode ierr; const PetscScalar *dx, *dd = NULL, *dsv; PetscScalar *dw; double *out; PetscScalar res[2]; DEVCTX;
+  *done = PETSC_FALSE;
+  if (!all_hip_same_size(w, x, s_, d, NULL, NULL) || w == x || w == s_ || w == d) return 0;
+  ierr = VecHIPGetRead(x, &dx);CHKERRQ(ierr);
+  if (d) { ierr = VecHIPGetRead(d, &dd);CHKERRQ(ierr); }
+  ierr = VecHIPGetRead(s_, &dsv);CHKERRQ(ierr);
+  ierr = VecHIPGetWrite(w, &dw);CHKERRQ(ierr);
+  ierr = reduce_target(w, dc, &out);CHKERRQ(ierr);
+  CHKHIP(mi355x_vec_pmult_dotnorm2(dc->h, N_(w), dx, dd, dsv, dw, out));
+  VecHIPRestoreWrite(w); PetscObjectStateIncrease(w);
+  ierr = reduce_finish(w, dc, 2, 0, res);CHKERRQ(ierr);
+  *dp = res[0]; *nm = res[1];
+  ierr = PetscLogFlops(5.0 * w->map->n);CHKERRQ(ierr);
+  *done = PETSC_TRUE;
+  return 0;
+}
+/* x = alpha p + omega s + x ; r = s - omega t ; *rr = (r,r) ; *rho = (r,rp) */
+PetscErrorCode VecBCGSUpdate_HIPMI355X(Vec x, Vec r, Vec p, Vec s_, Vec t, Vec rp, PetscScalar alpha, PetscScalar omega, PetscScalar *rr, PetscScalar *rho, PetscBool *done) {
+  PetscErrorCode ierr; const PetscScalar *dp_, *dsv, *dt, *drp; PetscScalar *dx, *dr; double *out; PetscScalar res[2]; DEVCTX;
+  *done = PETSC_FALSE;
+  if (!all_hip_same_size(x, r, p, s_, t, rp) || x == r || x == p || x == s_ || x == t || x == rp || r == p || r == s_ || r == t || r == rp) return 0;
+  ierr = VecHIPGetRead(p, &dp_);CHKERRQ(ierr);
+  ierr = VecHIPGetRead(s_, &dsv);CHKERRQ(ierr);
+  ierr = VecHIPGetRead(t, &dt);CHKERRQ(ierr);
+  ierr = VecHIPGetRead(rp, &drp);CHKERRQ(ierr);
+  ierr = VecHIPGetReadWrite(x, &dx);CHKERRQ(ierr);
+  ierr = VecHIPGetWrite(r, &dr);CHKERRQ(ierr);
+  ierr = reduce_target(x, dc, &out);CHKERRQ(ierr);
+  CHKHIP(mi355x_vec_bcgs_update(dc->h, N_(x), alpha, omega, dp_, dsv, dt, drp, dx, dr, out));
+  VecHIPRestoreWrite(x); VecHIPRestoreWrite(r);
+  PetscObjectStateIncrease(x); PetscObjectStateIncrease(r);
+  ierr = reduce_finish(x, dc, 2, 0, res);CHKERRQ(ierr);
+  *rr = res[0]; *rho = res[1];
+  ierr = PetscLogFlops(10.0 * x->map->n);CHKERRQ(ierr);
+  *done = PETSC_TRUE;
+  return 0;
+}
+
 static PetscErrorCode VecDestroy_HIP(Vec v) {
   Vec_HIPMI355X *s = VH(v);
   if (!s) return 0;

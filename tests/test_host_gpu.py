@@ -336,6 +336,24 @@ def test_device_collectives_on_a_one_rank_rccl_communicator(P):
         k.mi355x_comm_destroy(dcomm)
 
 
+@pytest.mark.parametrize("pc", ["jacobi", "none", "ilu"])
+def test_ksp_bcgs_fused_forms_are_bit_identical(P, pc):
+    """KSPSolve_BCGS with the PCApply fused into the dots that follow it and the x/r update fused with the norm and the
+    next rho (default) against the reference's op-by-op sequence (-ksp_bcgs_fused 0, bcgs.c:98-150): same iteration
+    count, same history bits, same x bits (nonsymmetric operator so that the two-sided recurrences matter)."""
+    ai, aj, aa = pb.lap2d(37, 33)
+    n = ai.size - 1
+    aa = aa * (1.0 + 0.3 * np.sin(np.arange(aa.size)))        # nonsymmetric values on the symmetric pattern
+    rows = np.repeat(np.arange(n), np.diff(ai))
+    aa[aj == rows] = 5.0                                      # keep it diagonally dominant
+    b = np.cos(0.3 * np.arange(n))
+    xu, hu, itsu, ru = solve(P, ai, aj, aa, b, "bcgs", pc, opts="-ksp_bcgs_fused 0", rtol=1e-9)
+    xf, hf, itsf, rf = solve(P, ai, aj, aa, b, "bcgs", pc, rtol=1e-9)
+    assert ru == 2 and itsu >= 4 and itsf == itsu and rf == ru
+    assert np.array_equal(bits(hf), bits(hu))
+    assert np.array_equal(bits(xf), bits(xu))
+
+
 def test_ksp_cg_single_reduction(P):
     """-ksp_cg_single_reduction (cg.c:116-122,200-203,263-270): two reductions per iteration instead of
     three (VecMDot(2) for delta and beta), A*p by recurrence; same op sequence as the oracle's restatement"""

@@ -539,3 +539,42 @@ def test_cg_update_dev_scalar_form(dev, n):
     assert_bitexact(np.ctypeslib.as_array((C.c_double * 3).from_address(addr)).copy(), polled)
     for q in (dp, dw, dd, x1, r1, z1, x2, r2, z2, ddpi, dres):
         dev.free(q)
+
+
+@pytest.mark.parametrize("n", [0, 1, 3, 255, 4097, 1_000_001])
+def test_bcgs_fused_kernels_match_separate_kernels_bitwise(dev, n):
+    """mi355x_vec_pmult_dot / pmult_dotnorm2 / bcgs_update against the separate launches they replace
+    (pointwise mult + dot; pointwise mult + dotnorm2; axpbypcz + waxpy + norm + dot): vectors and sums bit for bit,
+    including the identity preconditioner (d = NULL) and alpha = 1 / omega = 0, 1, -1 special forms."""
+    k = dev.k
+    x, d, y, s_ = rnd(n, 31), 1.0 / (2.0 + rnd(n, 32) ** 2), rnd(n, 33), rnd(n, 34)
+    dx, dd, dy, ds = dev.put(x), dev.put(d), dev.put(y), dev.put(s_)
+    w1, w2 = dev.alloc(8 * max(n, 2)), dev.alloc(8 * max(n, 2))
+    hs = dev.host_scratch()
+    for dptr in (dd, None):
+        if dptr is None:
+            dev.chk(k.mi355x_vec_copy(dev.h, n, dx, w1))
+        else:
+            dev.chk(k.mi355x_vec_pointwise_mult(dev.h, n, dx, dptr, w1))
+        dev.chk(k.mi355x_vec_dot(dev.h, n, w1, dy, hs)); ref = dev.scalar_out(1)
+        dev.chk(k.mi355x_vec_pmult_dot(dev.h, n, dx, dptr, dy, w2, hs)); got = dev.scalar_out(1)
+        assert_bitexact(got, ref); assert_bitexact(dev.get(w2, n), dev.get(w1, n))
+        dev.chk(k.mi355x_vec_dotnorm2(dev.h, n, ds, w1, hs)); ref = dev.scalar_out(2)
+        dev.chk(k.mi355x_vec_pmult_dotnorm2(dev.h, n, dx, dptr, ds, w2, hs)); got = dev.scalar_out(2)
+        assert_bitexact(got, ref); assert_bitexact(dev.get(w2, n), dev.get(w1, n))
+    p, t, rp, xx = rnd(n, 35), rnd(n, 36), rnd(n, 37), rnd(n, 38)
+    dp, dt, drp = dev.put(p), dev.put(t), dev.put(rp)
+    x1, x2, r1, r2 = dev.put(xx), dev.put(xx), dev.alloc(8 * max(n, 2)), dev.alloc(8 * max(n, 2))
+    for alpha, omega in ((0.37, -1.21), (1.0, 0.5), (0.2, 1.0), (0.2, -1.0), (0.3, 0.0)):
+        for q in (x1, x2):
+            if n:
+                dev.chk(k.mi355x_memcpy_h2d(dev.h, q, xx.ctypes.data, xx.nbytes))
+        dev.chk(k.mi355x_vec_axpbypcz(dev.h, n, alpha, omega, 1.0, dp, ds, x1))
+        dev.chk(k.mi355x_vec_waxpy(dev.h, n, -omega, dt, ds, r1))
+        dev.chk(k.mi355x_vec_norm(dev.h, n, 2, r1, hs)); rr = dev.scalar_out(1)[0]
+        dev.chk(k.mi355x_vec_dot(dev.h, n, r1, drp, hs)); rho = dev.scalar_out(1)[0]
+        dev.chk(k.mi355x_vec_bcgs_update(dev.h, n, alpha, omega, dp, ds, dt, drp, x2, r2, hs)); got = dev.scalar_out(2)
+        assert_bitexact(got, np.array([rr, rho]))
+        assert_bitexact(dev.get(x2, n), dev.get(x1, n)); assert_bitexact(dev.get(r2, n), dev.get(r1, n))
+    for q in (dx, dd, dy, ds, w1, w2, dp, dt, drp, x1, x2, r1, r2):
+        dev.free(q)
