@@ -2,19 +2,22 @@
 // reference src/mat/impls/aij/seq/aij.c:1225-1358).
 //
 // "Row-block streaming" layout of the work (HBM-bound, AI = 0.125 flop/B):
-//   * host analysis cuts the rows into row blocks of <= 256 rows and <= 2048 nonzeros;
+//   * host analysis cuts the rows into row blocks of <= 256 rows and <= 2046 nonzeros;
 //   * one 256-thread workgroup per row block streams that block's val/col_idx slice with
 //     fully coalesced 16-byte (val) / 8-byte (col) non-temporal loads, gathers x through
 //     L1/L2 (x is the only reused operand, so val/col are kept out of the cache with `nt`),
-//     multiplies, and parks the products in LDS;
+//     multiplies, and parks the products in LDS.  All loads are issued unconditionally and
+//     ahead of their use (clamped addresses instead of predication, see the idx8 kernel);
 //   * after one barrier each row is summed from LDS: one lane per row, products added in
 //     column order starting from 0.0 (or y[r]) -- the exact order of PetscSparseDensePlusDot
 //     (aij.h:383-386), so the result is bit-identical to the reference's non-FMA C loop.
 //     Row blocks with few, long rows use 2..64 lanes per row and a shuffle tree instead;
-//   * a row longer than 2048 nonzeros gets a whole workgroup (strided partial sums + tree);
-//   * blockIdx is remapped so that each XCD walks one contiguous eighth of the row blocks:
-//     the x entries a 7-point row needs (r, r+-1, r+-N, r+-N^2) are then re-used out of
-//     that XCD's own 4 MiB L2 instead of being fetched into all eight.
+//   * a row longer than 2046 nonzeros gets a whole workgroup (strided partial sums + tree);
+//   * blockIdx is remapped so that runs of SPMV_CH consecutive row blocks are dealt round-robin
+//     to the 8 XCDs: all XCDs stream one window of the matrix while the x entries a 7-point
+//     row needs (r, r+-1, r+-N, r+-N^2) are re-used out of one XCD's own 4 MiB L2;
+//   * variants: offset-dictionary index compression (1 byte per nonzero instead of 4), an
+//     x'y by-product for CG, and the BCSR form of the same structure.
 #include "common.hpp"
 #include <vector>
 #include <stdlib.h>
