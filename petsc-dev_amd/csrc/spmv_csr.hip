@@ -447,6 +447,16 @@ __global__ __launch_bounds__(SPMV_THREADS) void bsr_rowblock_kernel(const int2 *
   for (int j = sub; j < cnt; j += tpr) sum += prod[s + BS * j + rr_];
   for (int off = tpr >> 1; off > 0; off >>= 1) sum += __shfl_down(sum, off, MI355X_WAVE);
   if (v < nv && sub == 0) y[(long)br * BS + rr_] = sum;
+  // block rows with very few blocks: the row block can hold more point rows than the workgroup has lanes
+  // (<= 256 block rows x bs); the remaining ones are summed the same way, one lane per point row (tpr is 1 here)
+  for (int v2 = tid + SPMV_THREADS; v2 < nv; v2 += SPMV_THREADS) {
+    const int br2 = r0 + v2 / BS, rr2 = v2 - (v2 / BS) * BS;
+    const int b0_ = ai[br2], b1_ = ai[br2 + 1];
+    const int s2 = b0_ * BS2 - k0, cnt2 = (b1_ - b0_) * BS;
+    double sum2 = 0.0;
+    for (int j = 0; j < cnt2; ++j) sum2 += prod[s2 + BS * j + rr2];
+    y[(long)br2 * BS + rr2] = sum2;
+  }
 }
 
 // sum of the per-row-block x'y values in block order: 1024 lanes stride over them, fixed tree

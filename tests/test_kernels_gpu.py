@@ -427,6 +427,30 @@ def test_spmv_bsr_wide_block_row(dev):
     assert np.allclose(dev.get(dy, mbs * bs), orc.spmv_bsr(bs, ai, aj, aa, x), rtol=0, atol=1e-10)
 
 
+@pytest.mark.parametrize("bs", [2, 3, 5, 8])
+def test_spmv_bsr_few_blocks_per_row(dev, bs):
+    """block rows with 0, 1 or 2 blocks: a row block of <= 256 block rows then holds more point rows (<= 256*bs) than
+    the workgroup has lanes -- every one of them must still be written (block-diagonal BAIJ is the extreme case)"""
+    mbs = 1500
+    rng = np.random.default_rng(200 + bs)
+    cnt = rng.integers(0, 3, mbs); cnt[::5] = 1
+    ai = np.concatenate(([0], np.cumsum(cnt))).astype(np.int32)
+    aj = np.concatenate([np.sort(rng.choice(mbs, c, replace=False)) for c in cnt]).astype(np.int32)
+    aa = rnd(aj.size * bs * bs, 201)
+    x = rnd(mbs * bs, 202)
+    dai, daj, daa = upload_csr(dev, ai, aj, aa)
+    dx = dev.put(x); dy = dev.put(np.full(mbs * bs, 7.0))
+    plan = make_plan(dev, (ai.astype(np.int64) * bs * bs).astype(np.int32))
+    dev.chk(dev.k.mi355x_spmv_bsr_planned(dev.h, plan, bs, dai, daj, daa, dx, dy))
+    ref = orc.spmv_bsr(bs, ai, aj, aa, x)
+    got = dev.get(dy, mbs * bs)
+    assert np.allclose(got, ref, rtol=0, atol=1e-12 * 2 * bs * 10)   # baij2.c groups a block's products before adding
+    assert not np.any(got == 7.0)                        # every point row written
+    dev.chk(dev.k.mi355x_spmv_plan_destroy(plan))
+    for q in (dai, daj, daa, dx, dy):
+        dev.free(q)
+
+
 def test_pack_unpack(dev):
     k = dev.k
     n = 50000
