@@ -123,6 +123,44 @@ def main():
         ksp.record_history()
         ksp.solve(b, u)
         print("IRR converged: its=%d reason=%d final=%g error=%g" % (ksp.its, ksp.reason, ksp.rnorm, np.linalg.norm(u.array() - 1.0)), flush=True)
+    elif which == "aij27":
+        # the same elasticity shape stored as plain AIJ (81 nonzeros per row, 135 distinct offsets -> idx8 applies)
+        nn = int(sys.argv[2]) if len(sys.argv) > 2 else 96
+        bs = 3
+        bi, bj, ba = gen_baij27(nn)
+        mbs = bi.size - 1
+        cnt = np.diff(bi)
+        ai = np.concatenate(([0], np.cumsum(np.repeat(cnt * bs, bs)))).astype(np.int64)
+        assert ai[-1] < 2 ** 31
+        # row (br, r): for each block j of block row br, columns bj*3 + 0..2; values ba[blk*9 + c*3 + r] (column-major blocks)
+        blk_row = np.repeat(np.arange(mbs), cnt)
+        aj = np.empty(bj.size * 9, dtype=np.int32); aa = np.empty(bj.size * 9)
+        start = np.repeat(bi[:-1].astype(np.int64), cnt)           # first block of the block row, per block
+        pos_in_row = np.arange(bj.size) - start
+        for r in range(bs):
+            base = ai[blk_row * bs + r] + pos_in_row * bs
+            for c in range(bs):
+                aj[base + c] = bj * bs + c
+                aa[base + c] = ba[np.arange(bj.size) * 9 + c * 3 + r]
+        ai = ai.astype(np.int32)
+        m = mbs * bs
+        print("AIJ27: m=%d nnz=%d (%.1f/row)" % (m, aj.size, aj.size / m), flush=True)
+        A = P.Mat.from_csr(ai, aj, aa)
+        x = P.Vec.from_array(np.sin(0.1 * np.arange(m)), comm=L.COMM_SELF)
+        y = x.duplicate()
+        A.mult(x, y)
+        B = 12 * aj.size + 4 * (m + 1) + 16 * m
+        L.MatHIPMI355XSetTiming(A.h, 1)
+        for _ in range(20):
+            A.mult(x, y)
+        nl, tms = C.c_int(), C.c_double()
+        L.MatHIPMI355XGetTiming(A.h, C.byref(nl), C.byref(tms))
+        t = tms.value / nl.value * 1e-3
+        print("AIJ (elasticity shape) spmv: %.3f ms  %.1f GB/s CSR-algorithmic (%.3f of 8 TB/s)" % (t * 1e3, B / t / 1e9, B / t / 8e12), flush=True)
+        Ab = P.Mat.from_bsr(bs, bi, bj, ba)
+        yb = x.duplicate(); Ab.mult(x, yb)
+        ya, ybb = y.array(), yb.array()
+        print("  max |AIJ - BAIJ| = %g (scale %g)" % (np.max(np.abs(ya - ybb)), np.max(np.abs(ya))), flush=True)
     else:
         nn = int(sys.argv[2]) if len(sys.argv) > 2 else 128
         t0 = time.time()
