@@ -1,0 +1,149 @@
+"""Seeded random shapes through the SpMV kernels (plain CSR, index-compressed, add form, x'y by-product, BCSR) against
+the oracle: row-length mixes that put row-block boundaries at odd/even offsets, empty rows and empty row blocks,
+single-row and single-entry matrices, rows that span the LDS stage, banded patterns that compress and random ones that
+do not.  Short rows (<= 16 per row on average in a block) must match bit for bit, the others to 1e-12 * sum|a x|."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev(built):
+    from gpu import Dev
+    d = Dev()
+    yield d
+    d.free_all()
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint64)
+
+
+def make_case(seed):
+    rng = np.random.default_rng(1000 + seed)
+    kind = seed % 8
+    m = int(rng.integers(1, 6000))
+    n = m if kind in (0, 1, 2, 3) else int(rng.integers(1, 6000))
+    if kind == 0:      # banded, few offsets: compresses
+        offs = np.unique(rng.integers(-40, 41, int(rng.integers(1, 12))))
+        rows = [np.array([c for c in r + offs if 0 <= c < n and rng.random() < 0.9], dtype=np.int64) for r in range(m)]
+    elif kind == 1:    # stencil-like with empty stretches
+        offs = np.array([-37, -1, 0, 1, 37])
+        rows = [np.array([c for c in r + offs if 0 <= c < n]) if (r // 300) % 3 else np.zeros(0, np.int64) for r in range(m)]
+    elif kind == 2:    # long banded rows (several lanes per row)
+        w = int(rng.integers(30, 120))
+        rows = [np.arange(max(0, r - w), min(n, r + w + 1)) for r in range(m)]
+    elif kind == 3:    # a few rows longer than the LDS stage inside short ones
+        big = set(rng.integers(0, m, 3).tolist())
+        rows = [np.sort(rng.choice(n, size=min(n, 2500 if r in big else int(rng.integers(0, 9))), replace=False)) for r in range(m)]
+    elif kind == 4:    # short random rows, rectangular
+        rows = [np.sort(rng.choice(n, size=min(n, int(rng.integers(0, 17))), replace=False)) for r in range(m)]
+    elif kind == 5:    # log-normal row lengths
+        lens = np.clip(np.exp(rng.normal(2.5, 1.0, m)).astype(int), 0, min(n, 400))
+        rows = [np.sort(rng.choice(n, size=int(l), replace=False)) for l in lens]
+    elif kind == 6:    # one entry per row / one row
+        if rng.random() < 0.5:
+            rows = [np.array([int(rng.integers(0, n))]) for _ in range(m)]
+        else:
+            m = 1
+            rows = [np.sort(rng.choice(n, size=min(n, int(rng.integers(1, 3000))), replace=False))]
+    else:              # exactly-full row blocks: row lengths that tile the 2046-entry stage
+        L = int(rng.choice([2, 3, 6, 11, 31, 62, 93, 186]))
+        rows = [np.sort(rng.choice(n, size=min(n, L), replace=False)) for _ in range(m)]
+    lens = np.array([r.size for r in rows])
+    ai = np.concatenate(([0], np.cumsum(lens))).astype(np.int32)
+    aj = (np.concatenate(rows) if lens.sum() else np.zeros(0)).astype(np.int32)
+    aa = rng.standard_normal(aj.size)
+    x = rng.standard_normal(n)
+    return ai, aj, aa, x, m, n
+
+
+def check(got, ref, ai, aj, aa, x, what):
+    m = ai.size - 1
+    lens = np.diff(ai)
+    scale = np.zeros(m)
+    if aj.size:
+        np.add.at(scale, np.repeat(np.arange(m), lens), np.abs(aa * x[aj]))
+    assert np.all(np.abs(got - ref) <= 1e-12 * scale + 0.0), what
+    # rows in blocks of short rows are summed by one lane in column order: most of them bit for bit
+    short = lens <= 8
+    if short.all():
+        assert np.array_equal(bits(got), bits(ref)), what + " (short rows: bit-exact)"
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_spmv_random_shapes(dev, seed):
+    k = dev.k
+    ai, aj, aa, x, m, n = make_case(seed)
+    dai = dev.put(ai); daj = dev.put(aj if aj.size else np.zeros(2, np.int32)); daa = dev.put(aa if aa.size else np.zeros(2))
+    dx = dev.put(x)
+    y0 = np.random.default_rng(seed).standard_normal(m)
+    ref = orc.spmv(ai, aj, aa, x)
+    refadd = orc.spmv_add(ai, aj, aa, x, y0)
+    for compress in (False, True):
+        plan = C.c_void_p()
+        dev.chk(k.mi355x_spmv_plan_create(dev.h, m, ai.ctypes.data, None, C.byref(plan)))
+        nt = C.c_int(0)
+        if compress:
+            dev.chk(k.mi355x_spmv_plan_compress_indices(dev.h, plan, ai.ctypes.data, (aj if aj.size else np.zeros(2, np.int32)).ctypes.data))
+            k.mi355x_spmv_plan_is_compressed(plan, C.byref(nt))
+        dy = dev.put(np.full(m, 7.0))
+        dev.chk(k.mi355x_spmv_csr(dev.h, plan, dai, daj, daa, dx, dy))
+        got = dev.get(dy, m)
+        check(got, ref, ai, aj, aa, x, "seed %d compress %d ntab %d" % (seed, compress, nt.value))
+        dz = dev.put(y0)
+        dev.chk(k.mi355x_spmv_csr_add(dev.h, plan, dai, daj, daa, dx, dz, dz))
+        check(dev.get(dz, m), refadd, ai, aj, aa, x, "add seed %d compress %d" % (seed, compress))
+        if compress and nt.value and m == n:
+            dev.chk(k.mi355x_vec_set(dev.h, m, 7.0, dy))
+            dout = dev.alloc(64)
+            dev.chk(k.mi355x_spmv_csr_dot(dev.h, plan, dai, daj, daa, dx, dy))
+            dev.chk(k.mi355x_spmv_dot_finish(dev.h, plan, dout))
+            y2 = dev.get(dy, m)
+            assert np.array_equal(bits(y2), bits(got))
+            d = dev.get(dout, 1)[0]
+            assert abs(d - float(np.dot(x[:m], y2))) <= 1e-12 * float(np.sum(np.abs(x[:m] * y2))) + 1e-300
+            dev.free(dout)
+        dev.chk(k.mi355x_spmv_plan_destroy(plan))
+        dev.free(dy); dev.free(dz)
+    for q in (dai, daj, daa, dx):
+        dev.free(q)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_bsr_random_shapes(dev, seed):
+    k = dev.k
+    rng = np.random.default_rng(3000 + seed)
+    bs = int(rng.integers(2, 9))
+    mbs = int(rng.integers(1, 1200)); nbs = int(rng.integers(1, 1200))
+    maxb = [1, 3, 10, 40, 300][seed % 5]
+    cnt = np.minimum(rng.integers(0, maxb + 1, mbs), nbs)
+    if seed % 5 == 4:
+        cnt[:] = np.minimum(rng.integers(0, 4, mbs), nbs); cnt[int(rng.integers(0, mbs))] = min(nbs, 300)   # one block row wider than the stage
+    ai = np.concatenate(([0], np.cumsum(cnt))).astype(np.int32)
+    aj = (np.concatenate([np.sort(rng.choice(nbs, int(c), replace=False)) for c in cnt]) if cnt.sum() else np.zeros(0)).astype(np.int32)
+    aa = rng.standard_normal(aj.size * bs * bs)
+    x = rng.standard_normal(nbs * bs)
+    dai = dev.put(ai); daj = dev.put(aj if aj.size else np.zeros(2, np.int32)); daa = dev.put(aa if aa.size else np.zeros(2))
+    dx = dev.put(x); dy = dev.put(np.full(mbs * bs, 7.0))
+    plan = C.c_void_p()
+    sc = (ai.astype(np.int64) * bs * bs).astype(np.int32)
+    dev.chk(k.mi355x_spmv_plan_create(dev.h, mbs, sc.ctypes.data, None, C.byref(plan)))
+    dev.chk(k.mi355x_spmv_bsr_planned(dev.h, plan, bs, dai, daj, daa, dx, dy))
+    got = dev.get(dy, mbs * bs)
+    ref = orc.spmv_bsr(bs, ai, aj, aa, x)
+    scale = np.zeros(mbs * bs)
+    if aj.size:
+        blocks = aa.reshape(-1, bs, bs)                       # column-major blocks: [blk][c][r]
+        xb = x.reshape(nbs, bs)[aj]                           # [blk][c]
+        contrib = np.abs(blocks * xb[:, :, None]).sum(1)      # [blk][r]
+        np.add.at(scale.reshape(mbs, bs), np.repeat(np.arange(mbs), cnt), contrib)
+    assert np.all(np.abs(got - ref) <= 1e-12 * scale), "bsr seed %d bs %d" % (seed, bs)
+    dev.chk(k.mi355x_spmv_plan_destroy(plan))
+    for q in (dai, daj, daa, dx, dy):
+        dev.free(q)
