@@ -147,3 +147,66 @@ def test_bsr_random_shapes(dev, seed):
     dev.chk(k.mi355x_spmv_plan_destroy(plan))
     for q in (dai, daj, daa, dx, dy):
         dev.free(q)
+
+
+@pytest.fixture(scope="module")
+def P(built):
+    import importlib
+    return importlib.import_module("petsc-dev_amd.petsc")
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_ksp_random_small_systems(P, seed):
+    """every solver x preconditioner of the path on small random diagonally dominant systems (sizes 1..700, also
+    n = 1 and n = 2, symmetric for CG) against the oracle: same convergence reason, iteration count within +-1
+    (BiCGStab: +-max(2, 20 %)), histories to 1e-6 while the residual is above 1e-4 of its start, same solution."""
+    rng = np.random.default_rng(5000 + seed)
+    ksp = ["cg", "gmres", "bcgs"][seed % 3]
+    pc = ["none", "jacobi", "bjacobi", "ilu"][(seed // 3) % 4]
+    n = [1, 2, 3, 17, 64, 257, 700][seed % 7]
+    dens = min(n, int(rng.integers(1, 9)))
+    rows = [np.unique(np.concatenate(([r], rng.choice(n, size=dens, replace=False)))) for r in range(n)]
+    if ksp == "cg":     # symmetric pattern and values
+        import scipy.sparse as sp
+        A = sp.lil_matrix((n, n))
+        for r in range(n):
+            for c in rows[r]:
+                v = rng.standard_normal()
+                A[r, c] = v; A[c, r] = v
+        A = sp.csr_matrix(A)
+        A.setdiag(np.abs(A).sum(1).A1 + 1.0 + rng.random(n))
+        A.sort_indices()
+        ai, aj, aa = A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(np.float64)
+    else:
+        lens = np.array([r.size for r in rows])
+        ai = np.concatenate(([0], np.cumsum(lens))).astype(np.int32)
+        aj = np.concatenate(rows).astype(np.int32)
+        aa = rng.standard_normal(aj.size)
+        rr = np.repeat(np.arange(n), lens)
+        rowabs = np.zeros(n); np.add.at(rowabs, rr, np.abs(aa))
+        aa[aj == rr] = rowabs + 1.0 + rng.random(n)
+    xs = rng.standard_normal(n)
+    b = orc.spmv(ai, aj, aa, xs)
+    L = P.lib()
+    Am = P.Mat.from_csr(ai, aj, aa)
+    vb = P.Vec.from_array(b, comm=L.COMM_SELF); vx = P.Vec.from_array(np.zeros(n), comm=L.COMM_SELF)
+    k = P.KSP(comm=L.COMM_SELF)
+    k.set_operators(Am)
+    L.PetscOptionsClear()
+    L.PetscOptionsInsertString(("-ksp_type %s -pc_type %s -ksp_gmres_restart 12" % (ksp, pc)).encode())
+    k.set_tolerances(rtol=1e-9, max_it=400)
+    k.set_from_options()
+    k.record_history()
+    k.solve(vb, vx)
+    L.PetscOptionsClear()
+    x, h, its, reason = vx.array(), k.history(), k.its, k.reason
+    okw = dict(blocks=[0, n], sub_ksp="preonly", sub_pc="ilu") if pc == "bjacobi" else {}
+    xr, hr, itsr, rr_ = orc.ksp_solve(ai, aj, aa, b, ksp=ksp, pc=pc, rtol=1e-9, max_it=400, restart=12, **okw)
+    assert reason == rr_, (ksp, pc, n, reason, rr_)
+    tol_its = max(2, itsr // 5) if ksp == "bcgs" else 1
+    assert abs(its - itsr) <= tol_its, (ksp, pc, n, its, itsr)
+    kk = min(len(h), len(hr))
+    early = hr[:kk] > 1e-4 * hr[0]
+    assert np.allclose(h[:kk][early], hr[:kk][early], rtol=1e-6, atol=0)
+    assert np.linalg.norm(x - xr) <= 1e-6 * max(np.linalg.norm(xr), 1e-300)
+    assert np.linalg.norm(x - xs) <= 1e-6 * max(np.linalg.norm(xs), 1e-300)
