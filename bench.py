@@ -26,7 +26,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--n", type=int, default=256, help="grid points per side per GPU (rows per GPU = n^3)")
+    ap.add_argument("--grid-n", dest="n", type=int, default=256, help="grid points per side per GPU (rows per GPU = n^3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-its", type=int, default=20)
     ap.add_argument("--ksp-opts", default="", help="extra options-database string (development: e.g. '-ksp_cg_fused 2')")
@@ -47,7 +47,8 @@ def main():
     L = P.lib()
     if world > 1:
         from petsc_dev_amd import dist as PD
-        comm = PD.torch_comm(device_comm=True)
+        # MI355X_STAGED=1: rehearsal of the N>1 flow with several ranks on ONE GPU (RCCL refuses that): host-staged transport
+        comm = PD.torch_comm(device_comm=os.environ.get("MI355X_STAGED", "0") != "1")
     else:
         comm = L.COMM_SELF
 
@@ -131,6 +132,10 @@ def main():
         return
     spmv_gbps_one = spmv_bytes / (spmv_ms * 1e-3) / 1e9
     cg_bytes = spmv_bytes + 136 * mloc                                   # unfused CG+Jacobi op sequence
+    noff = C.c_int(0)
+    L.MatHIPMI355XGetIndexCompression(timed, C.byref(noff))
+    kernel_name = ("spmv_csr_rowblock_idx8_kernel (CSR + 1-byte offset-dictionary column indices, %d offsets; 'achieved' uses the CSR algorithmic bytes)" % noff.value) if noff.value else "spmv_csr_rowblock_kernel"
+    staged = world > 1 and os.environ.get("MI355X_STAGED", "0") == "1"
     out = {
         "metric": "KSP CG+Jacobi iterations/s x unknowns (3-D 7-pt Poisson, %d^3 rows per GPU); ksp_its_per_sec and spmv_gbps are BASELINE.json's two quantities" % n,
         "value": round(value, 3), "unit": "Mdof-it/s",
@@ -138,14 +143,14 @@ def main():
         "ms_per_step": round(dt / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "3D 7-pt Poisson P7(%d,%d,%d) = %d rows, %s, KSPCG + PCJACOBI, b = A*1, x0 = 0, exactly K iterations"
-                   % (nx, ny, nz, unknowns, "MatSeqAIJ on 1 GPU" if world == 1 else "MatMPIAIJ in %d z-slabs, RCCL halo" % world),
+                   % (nx, ny, nz, unknowns, "MatSeqAIJ on 1 GPU" if world == 1 else "MatMPIAIJ in %d z-slabs, %s" % (world, "HOST-STAGED halo and reductions (one-GPU rehearsal, not a measurement)" if staged else "RCCL halo")),
                    "rows_per_gpu": mloc, "nnz_per_gpu": nnz_loc, "parallelism": "row-block dp%d" % world},
         "ksp_its_per_sec": round(its_per_s, 2),
         "spmv_gbps": round(spmv_gbps_one * world, 1),
         "ksp_gbps": round(cg_bytes * its_per_s * world / 1e9, 1),
         "ksp_hbm_frac": round(cg_bytes * its_per_s / 8e12, 4),
         "ksp_gbps_basis": "SURVEY 8(d) algorithmic bytes of the reference's op-by-op iteration (SpMV + 17 vector passes); the fused CG update moves 13 passes",
-        "roofline": {"bound": "hbm", "kernel": "spmv_csr_rowblock_kernel", "achieved": round(spmv_gbps_one, 1), "peak": 8000.0,
+        "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": round(spmv_gbps_one, 1), "peak": 8000.0,
                      "unit": "GB/s", "frac": round(spmv_gbps_one / 8000.0, 4), "traffic": None,
                      "algorithmic_bytes_per_launch": spmv_bytes, "avg_launch_ms": round(spmv_ms, 5), "launches_timed": nl.value},
         "setup_s": round(setup_s, 2),
@@ -165,7 +170,7 @@ def main():
                         ws = float(row["avg_value_KB"])
         if fs is not None and ws is not None and n == 256 and world == 1:
             out["roofline"]["traffic"] = int((2.0 * fs + ws) * 1024)
-            out["roofline"]["kernel"] = "spmv_csr_rowblock_idx8_kernel (CSR + 1-byte offset-dictionary column indices; 'achieved' uses the CSR algorithmic bytes, 'traffic' is what the kernel actually moved)"
+            out["roofline"]["kernel"] = kernel_name.replace("'achieved' uses the CSR algorithmic bytes", "'achieved' uses the CSR algorithmic bytes, 'traffic' is what the kernel actually moved")
             out["roofline"]["traffic_source"] = "profiles/r01_bench_pmc_summary.csv (rocprofv3 --pmc, separate passes; bytes per launch)"
     except Exception:
         pass

@@ -264,6 +264,24 @@ static PetscErrorCode MatMult_SeqAIJHIP(Mat A, Vec xx, Vec yy) {   /* MatMult_Se
   return 0;
 }
 
+/* number of distinct (col - row) offsets of the index-compressed SpMV plan, 0 when the matrix streams plain 4-byte
+ * column indices (bench.py labels its roofline kernel with it; an MPIAIJ matrix answers for its diagonal block) */
+PetscErrorCode MatHIPMI355XGetIndexCompression(Mat A, PetscInt *noffsets) {
+  PetscErrorCode ierr; int ntab = 0;
+  *noffsets = 0;
+  if (!A) return 0;
+  if (A->ops->mult != MatMult_SeqAIJHIP) {
+    Mat Ad = NULL;
+    if (!strcmp(A->type_name, MATMPIAIJHIPMI355X)) { ierr = MatMPIAIJGetSeqAIJ(A, &Ad, NULL, NULL);CHKERRQ(ierr); }
+    if (!Ad || Ad->ops->mult != MatMult_SeqAIJHIP) return 0;
+    A = Ad;
+  }
+  ierr = MatSeqAIJHIPUpload(A);CHKERRQ(ierr);
+  if (SD(A)->plan && SA(A)->bs <= 1) CHKHIP(mi355x_spmv_plan_is_compressed(SD(A)->plan, &ntab));
+  *noffsets = ntab;
+  return 0;
+}
+
 /* w = A p with dpi = p'w as a by-product of the same pass (KSPSolve_CG cg.c:190-191); dpi is left in the device
  * scratch slot the fused CG update reads (all-reduced there when the vectors' communicator has an RCCL communicator).
  * *ok = PETSC_FALSE and nothing done unless A is a square, sequential, index-compressed AIJ matrix of this type. */

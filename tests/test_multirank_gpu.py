@@ -28,3 +28,20 @@ def test_mpiaij_two_ranks_one_gpu(built, nranks):
         assert "rank %d/%d: irregular MatMult bitexact=True MatMultTranspose bitexact=True" % (k, nranks) in out, out[-3000:]
         if nranks == 2:   # the reference's own 2-rank golden, default preconditioner (block Jacobi + ILU(0))
             assert "rank %d/2: golden ex2_2.out (GMRES + bjacobi + ILU(0), 2 ranks) its=7 ok=True" % k in out, out[-3000:]
+
+
+def test_bench_two_ranks_rehearsal(built):
+    """bench.py's N>1 flow (torch.distributed.run launch, z-slab MatMPIAIJ, max-over-ranks timing, one JSON line from
+    rank 0) rehearsed with two ranks on the one GPU through the host-staged transport (MI355X_STAGED=1)."""
+    import json
+    env = dict(os.environ, MI355X_STAGED="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--grid-n", "40"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["warmup"] == 2 and d["scaling"] == "weak"
+    assert d["config"]["rows_per_gpu"] == 40 ** 3 and d["value"] > 0 and d["roofline"]["avg_launch_ms"] > 0
+    assert "idx8" in d["roofline"]["kernel"]
