@@ -125,15 +125,15 @@ int mi355x_vec_dotnorm2(mi355x_handle_t h, size_t n, const double *s, const doub
  * KSPSolve_CG's p = z + (beta_new/beta_old) p when beta_new has not reached the host yet. */
 int mi355x_vec_aypx_dev(mi355x_handle_t h, size_t n, const double *num_dev, double den, const double *x, double *y);
 /* Fused CG update, one sweep for cg.c:206-232 + PCApply_Jacobi (jacobi.c:266-277):
- * x += a p; r += (-a) w; z = r .* d; out[0] = sum z*z, out[1] = sum z*r.  Same bits as
- * mi355x_vec_axpy x2, mi355x_vec_pointwise_mult, mi355x_vec_norm(2), mi355x_vec_dot in sequence. */
+ * x += a p; r += (-a) w; z = r .* d (d == NULL: z = r); out[0] = sum z*z, out[1] = sum z*r, out[2] = sum r*r.  Same
+ * bits as mi355x_vec_axpy x2, mi355x_vec_pointwise_mult, mi355x_vec_norm(2) of z / of r, mi355x_vec_dot in sequence. */
 int mi355x_vec_cg_update(mi355x_handle_t h, size_t n, double a, const double *p, const double *w, const double *d,
                          double *x, double *r, double *z, double *out);
 /* The same sweep with the step length formed on the device: a = beta / *dpi_dev (dpi = p'w left in device memory by
  * mi355x_vec_dot, all-reduced there on several ranks).  The break-down tests of cg.c:196-199 (dpi NaN/Inf, dpi == 0,
  * check_sign && dpi*dpiold <= 0) are evaluated in the kernel: if one fires, x, r, z are left untouched.
- * out[0] = sum z*z, out[1] = sum z*r, out[2] = dpi (for the host's own copy of those tests).  also_to_host != 0 with a
- * device `out`: the three values are stored to the first pinned scratch slots as well, followed by the completion
+ * out[0] = sum z*z, out[1] = sum z*r, out[2] = sum r*r, out[3] = dpi (for the host's own copy of those tests).
+ * also_to_host != 0 with a device `out`: the four values are stored to the first pinned scratch slots as well, followed by the completion
  * number (mi355x_handle_wait_result) -- the result serves a later kernel and the host without a second launch. */
 int mi355x_vec_cg_update_dev(mi355x_handle_t h, size_t n, double beta, const double *dpi_dev, double dpiold, int check_sign,
                              const double *p, const double *w, const double *d, double *x, double *r, double *z, double *out,

@@ -26,6 +26,7 @@ typedef struct solver_s {
   int ksp_type, pc_type;
   double rtol, abstol, dtol;
   int max_it, restart, refine_always, guess_nonzero, cg_single;
+  int norm_type;   /* KSPNormType: 0 none, 1 preconditioned (default), 2 unpreconditioned, 3 natural (petscksp.h) */
   int n;
   const int *ai, *aj;
   const double *aa;
@@ -46,6 +47,7 @@ void orc_ksp_default_opts(orc_ksp_opts *o) {
   o->ksp_type = ORC_KSP_GMRES; o->pc_type = ORC_PC_NONE;
   o->rtol = 1e-5; o->abstol = 1e-50; o->dtol = 1e4; o->max_it = 10000;   /* itcreate.c:662-666 */
   o->restart = 30;                                                        /* gmresimpl.h GMRES_DEFAULT_MAXK */
+  o->norm_type = 1;                                                       /* KSP_NORM_PRECONDITIONED (left PC default) */
   o->sub_ksp_type = ORC_KSP_PREONLY; o->sub_pc_type = ORC_PC_JACOBI;
   o->sub_rtol = 1e-5; o->sub_abstol = 1e-50; o->sub_dtol = 1e4; o->sub_max_it = 10000;
 }
@@ -198,15 +200,23 @@ static void mat_mult(solver *s, const double *x, double *y) { orc_spmv_csr(s->n,
 /* KSP_PCApplyBAorAB, PC_LEFT branch of PCApplyBAorAB precon.c:620-622 */
 static void pc_apply_BA(solver *s, const double *x, double *y, double *w) { mat_mult(s, x, w); pc_apply(s, w, y); }
 
-/* KSPDefaultConverged, src/ksp/ksp/interface/iterativ.c:702-780 (preconditioned norm, left PC) */
+/* KSPDefaultConverged, src/ksp/ksp/interface/iterativ.c:702-780 (left PC; the norm of the right-hand side for a
+ * nonzero guess follows the norm type, :718-737); KSP_NORM_NONE installs KSPSkipConverged (itcreate.c:228-229,
+ * iterativ.c:536-544) */
 static void converged(solver *s, int n, double rnorm, const double *b) {
   s->reason = R_ITERATING;
+  if (s->norm_type == 0) { if (n >= s->max_it) s->reason = R_CONVERGED_ITS; return; }
   if (!n) {
     if (s->guess_nonzero) {
-      double *z = (double *)malloc(sizeof(double) * (size_t)s->n), snorm;
-      pc_apply(s, b, z);
-      orc_vec_norm((size_t)s->n, 1, z, &snorm);
-      free(z);
+      double snorm = 0.0;
+      if (s->norm_type == 2) orc_vec_norm((size_t)s->n, 1, b, &snorm);
+      else {
+        double *z = (double *)malloc(sizeof(double) * (size_t)s->n);
+        pc_apply(s, b, z);
+        if (s->norm_type == 1) orc_vec_norm((size_t)s->n, 1, z, &snorm);
+        else snorm = sqrt(fabs(orc_vec_dot((size_t)s->n, b, z)));
+        free(z);
+      }
       if (!snorm) snorm = rnorm;
       s->rnorm0 = snorm;
     } else s->rnorm0 = rnorm;
@@ -232,23 +242,32 @@ static void initial_residual(solver *s, const double *x, double *vt1, double *vt
   }
 }
 
-/* ---- KSPSolve_CG, src/ksp/ksp/impls/cg/cg.c:92-286 (KSP_NORM_PRECONDITIONED; -ksp_cg_single_reduction optional) ---- */
+/* ---- KSPSolve_CG, src/ksp/ksp/impls/cg/cg.c:92-286 (all four norm types :136-161,233-260; -ksp_cg_single_reduction) ---- */
 static void solve_cg(solver *s, const double *B, double *X) {
   size_t n = (size_t)s->n;
-  const int single = s->cg_single;
+  const int single = s->cg_single, nt = s->norm_type;
   double *R = (double *)malloc(5 * n * sizeof(double)), *Z = R + n, *P = Z + n, *S = P + n, *W = single ? S + n : Z;
-  double dpi = 0.0, a = 1.0, beta, betaold = 1.0, b, dpiold, dp = 0.0, delta = 0.0;
+  double dpi = 0.0, a = 1.0, beta = 0.0, betaold = 1.0, b, dpiold, dp = 0.0, delta = 0.0;
   int i;
   s->its = 0;
   if (s->guess_nonzero) { mat_mult(s, X, R); orc_vec_aypx(n, -1.0, B, R); }
   else orc_vec_copy(n, B, R);
-  pc_apply(s, R, Z);
-  orc_vec_norm(n, 1, Z, &dp);
+  if (nt == 1) { pc_apply(s, R, Z); orc_vec_norm(n, 1, Z, &dp); }
+  else if (nt == 2) orc_vec_norm(n, 1, R, &dp);
+  else if (nt == 3) {
+    pc_apply(s, R, Z);
+    if (single) { mat_mult(s, Z, S); delta = orc_vec_dot(n, Z, S); }
+    beta = orc_vec_dot(n, Z, R);
+    dp = sqrt(fabs(beta));
+  } else dp = 0.0;
   monitor(s, dp);
   converged(s, 0, dp, B);
   if (s->reason) { free(R); return; }
-  if (single) { mat_mult(s, Z, S); delta = orc_vec_dot(n, Z, S); }
-  beta = orc_vec_dot(n, Z, R);
+  if (nt != 1 && nt != 3) pc_apply(s, R, Z);
+  if (nt != 3) {
+    if (single) { mat_mult(s, Z, S); delta = orc_vec_dot(n, Z, S); }
+    beta = orc_vec_dot(n, Z, R);
+  }
   i = 0;
   do {
     s->its = i + 1;
@@ -264,17 +283,25 @@ static void solve_cg(solver *s, const double *B, double *X) {
     a = beta / dpi;
     orc_vec_axpy(n, a, P, X);
     orc_vec_axpy(n, -a, W, R);
-    pc_apply(s, R, Z);
-    if (single) mat_mult(s, Z, S);
-    orc_vec_norm(n, 1, Z, &dp);
+    if (nt == 1) { pc_apply(s, R, Z); if (single) mat_mult(s, Z, S); orc_vec_norm(n, 1, Z, &dp); }
+    else if (nt == 2) orc_vec_norm(n, 1, R, &dp);
+    else if (nt == 3) {
+      pc_apply(s, R, Z);
+      if (single) { const double *vv[2] = {S, R}; double t2[2]; mat_mult(s, Z, S); orc_vec_mdot(n, 2, Z, vv, t2); delta = t2[0]; beta = t2[1]; }
+      else beta = orc_vec_dot(n, Z, R);
+      dp = sqrt(fabs(beta));
+    } else dp = 0.0;
     monitor(s, dp);
     converged(s, i + 1, dp, B);
     if (s->reason) break;
-    if (single) { const double *vv[2] = {S, R}; double t2[2]; orc_vec_mdot(n, 2, Z, vv, t2); delta = t2[0]; beta = t2[1]; }
-    else beta = orc_vec_dot(n, Z, R);
+    if (nt != 1 && nt != 3) { pc_apply(s, R, Z); if (single) mat_mult(s, Z, S); }
+    if (nt != 3) {
+      if (single) { const double *vv[2] = {S, R}; double t2[2]; orc_vec_mdot(n, 2, Z, vv, t2); delta = t2[0]; beta = t2[1]; }
+      else beta = orc_vec_dot(n, Z, R);
+    }
     i++;
   } while (i < s->max_it);
-  if (i >= s->max_it) s->reason = R_DIVERGED_ITS;
+  if (i >= s->max_it && !(nt == 0 && s->reason)) s->reason = R_DIVERGED_ITS;
   free(R);
 }
 
@@ -478,7 +505,7 @@ int orc_ksp_solve(const orc_ksp_opts *o, int n, const int *ai, const int *aj, co
   memset(&S, 0, sizeof(S));
   S.ksp_type = o->ksp_type; S.pc_type = o->pc_type;
   S.rtol = o->rtol; S.abstol = o->abstol; S.dtol = o->dtol; S.max_it = o->max_it;
-  S.restart = o->restart; S.refine_always = o->refine_always; S.guess_nonzero = o->guess_nonzero; S.cg_single = o->cg_single;
+  S.restart = o->restart; S.refine_always = o->refine_always; S.guess_nonzero = o->guess_nonzero; S.cg_single = o->cg_single; S.norm_type = o->norm_type;
   S.n = n; S.ai = ai; S.aj = aj; S.aa = aa;
   S.nblocks = o->nblocks; S.blk = o->blk;
   S.hist = hist; S.hist_cap = hist_cap; S.nhist = 0;
@@ -487,7 +514,7 @@ int orc_ksp_solve(const orc_ksp_opts *o, int n, const int *ai, const int *aj, co
     for (int k = 0; k < S.nblocks; k++) {
       solver *t = &S.sub[k];
       pc_free(t);   /* sub PC type is set below, redo its set-up */
-      t->ksp_type = o->sub_ksp_type; t->pc_type = o->sub_pc_type;
+      t->ksp_type = o->sub_ksp_type; t->pc_type = o->sub_pc_type; t->norm_type = 1;
       t->rtol = o->sub_rtol; t->abstol = o->sub_abstol; t->dtol = o->sub_dtol; t->max_it = o->sub_max_it;
       t->restart = o->restart; t->refine_always = 0;
       pc_setup(t);

@@ -100,6 +100,7 @@ typedef struct {
   double sub_rtol, sub_abstol, sub_dtol;
   int sub_max_it;
   int cg_single;          /* -ksp_cg_single_reduction (cg.c:116-122,200-203,263-270) */
+  int norm_type;          /* KSPNormType for CG (cg.c:136-161): 0 none, 1 preconditioned (default), 2 unpreconditioned, 3 natural */
 } orc_ksp_opts;
 void orc_ksp_default_opts(orc_ksp_opts *o);
 /* Solves A x = b.  hist[0..] receives the residual norms the monitor would print (hist_cap entries

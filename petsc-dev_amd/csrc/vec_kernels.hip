@@ -412,7 +412,7 @@ struct DotNorm2F {
   }
 };
 // One CG update sweep (KSPSolve_CG cg.c:206-232 with PCApply_Jacobi jacobi.c:266-277 in between):
-//   x += a p ; r += (-a) w ; z = r .* d ; out = { sum z*z , sum z*r }
+//   x += a p ; r += (-a) w ; z = r .* d ; out = { sum z*z , sum z*r , sum r*r }
 // Element-wise arithmetic is that of the separate kernels (OpAxpy, OpAxpy, OpMul) and each lane meets its elements in
 // the same order as SumSqF / DotF do under launch_reduce, so x, r, z and both sums carry the same bits as the five
 // separate launches; HBM passes drop from 12 to 8.
@@ -444,14 +444,15 @@ struct CGUpdateF {
       reinterpret_cast<double2 *>(x)[i] = xv; reinterpret_cast<double2 *>(r)[i] = rv; reinterpret_cast<double2 *>(z)[i] = zv;
     }
   }
-  __device__ __forceinline__ void step(double pv, double wv, double dv, double &xv, double &rv, double &zv, double (&acc)[2]) const {
+  __device__ __forceinline__ void step(double pv, double wv, double dv, double &xv, double &rv, double &zv, double (&acc)[3]) const {
     xv = xv + a * pv;
     rv = rv + ma * wv;
     zv = rv * dv;
     acc[0] += zv * zv;
     acc[1] += zv * rv;
+    acc[2] += rv * rv;         // VecNorm(R) for KSP_NORM_UNPRECONDITIONED (cg.c:246)
   }
-  __device__ void accum1(size_t i, double (&acc)[2]) const {
+  __device__ void accum1(size_t i, double (&acc)[3]) const {
     double xv = x[i], rv = r[i], zv;
     step(p[i], w[i], d ? d[i] : 1.0, xv, rv, zv, acc);
     x[i] = xv; r[i] = rv; z[i] = zv;
@@ -461,7 +462,7 @@ struct CGUpdateF {
 // (the VecTDot kernel, all-reduced in place over RCCL on several ranks, wrote it there), so the host does not have to
 // wait for the dot before it can launch the update -- one host synchronisation per CG iteration instead of two.
 // KSPSolve_CG's break-down tests on dpi (cg.c:196-199) are evaluated here too: when one fires nothing is modified, and
-// the host, which receives dpi in out[2], takes the reference's exit with x, r, z untouched.  out[2] carries dpi
+// the host, which receives dpi in out[3], takes the reference's exit with x, r, z untouched.  out[3] carries dpi
 // through the reduction tree unchanged (lane 0 of workgroup 0 contributes it, every other lane +0.0).
 struct CGUpdateDevF {
   double beta, dpiold;
@@ -475,10 +476,10 @@ struct CGUpdateDevF {
     a = bad ? 0.0 : beta / dpi;
     return !bad;
   }
-  __device__ __forceinline__ void prologue(size_t tid, double (&acc)[3]) const {
-    if (tid == 0) acc[2] = *dpi_ptr;
+  __device__ __forceinline__ void prologue(size_t tid, double (&acc)[4]) const {
+    if (tid == 0) acc[3] = *dpi_ptr;
   }
-  __device__ __forceinline__ void step(double a, double pv, double wv, double dv, double &xv, double &rv, double &zv, double (&acc)[3]) const {
+  __device__ __forceinline__ void step(double a, double pv, double wv, double dv, double &xv, double &rv, double &zv, double (&acc)[4]) const {
     if (a != 0.0) {            // VecAXPY leaves y alone for alpha == 0 (bvec1.c:253)
       xv = xv + a * pv;
       rv = rv + (-a) * wv;
@@ -486,6 +487,7 @@ struct CGUpdateDevF {
     zv = rv * dv;
     acc[0] += zv * zv;
     acc[1] += zv * rv;
+    acc[2] += rv * rv;
   }
   template <int NOUT_>
   __device__ __forceinline__ void sweep(size_t tid, size_t stride, size_t n2, double (&acc)[NOUT_]) const {
@@ -510,7 +512,7 @@ struct CGUpdateDevF {
       x2[i] = xv; r2[i] = rv; z2[i] = zv;
     }
   }
-  __device__ void accum1(size_t i, double (&acc)[3]) const {
+  __device__ void accum1(size_t i, double (&acc)[4]) const {
     double a;
     if (!scalars(a)) return;
     double xv = x[i], rv = r[i], zv;
@@ -778,7 +780,7 @@ int mi355x_vec_cg_update(mi355x_handle_t h, size_t n, double a, const double *p,
   CGUpdateF f{a, -a, p, w, d, x, r, z};
   int v = mi355x_aligned16(p) && mi355x_aligned16(w) && mi355x_aligned16(d) && mi355x_aligned16(x) && mi355x_aligned16(r) &&
           mi355x_aligned16(z);   /* d == NULL (identity preconditioner) counts as aligned */
-  return launch_reduce<2, RED_SUM>(h, f, n, v, out);
+  return launch_reduce<3, RED_SUM>(h, f, n, v, out);
 }
 int mi355x_vec_cg_update_dev(mi355x_handle_t h, size_t n, double beta, const double *dpi_dev, double dpiold, int check_sign,
                              const double *p, const double *w, const double *d, double *x, double *r, double *z, double *out,
@@ -786,7 +788,7 @@ int mi355x_vec_cg_update_dev(mi355x_handle_t h, size_t n, double beta, const dou
   CGUpdateDevF f{beta, dpiold, check_sign, dpi_dev, p, w, d, x, r, z};
   int v = mi355x_aligned16(p) && mi355x_aligned16(w) && mi355x_aligned16(d) && mi355x_aligned16(x) && mi355x_aligned16(r) &&
           mi355x_aligned16(z);   /* d == NULL (identity preconditioner) counts as aligned */
-  return launch_reduce<3, RED_SUM>(h, f, n, v, out, also_to_host != 0);
+  return launch_reduce<4, RED_SUM>(h, f, n, v, out, also_to_host != 0);
 }
 int mi355x_vec_pmult_dot(mi355x_handle_t h, size_t n, const double *x, const double *d, const double *y, double *w, double *out) {
   PMultDotF f{x, d, y, w};

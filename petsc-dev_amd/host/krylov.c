@@ -56,24 +56,44 @@ static PetscErrorCode KSPSolve_CG(KSP ksp) {
     devscalar = (PetscBool)(fusedpc && flevel > 1);
   }
 
+  const KSPNormType nt = ksp->normtype;   /* cg.c:136-161,233-260: which norm the convergence test sees */
   ksp->its = 0;
   if (!ksp->guess_zero) {
     ierr = KSP_MatMult(ksp, Amat, X, R);CHKERRQ(ierr);            /* r <- b - Ax */
     ierr = VecAYPX(R, -1.0, B);CHKERRQ(ierr);
   } else { ierr = VecCopy(B, R);CHKERRQ(ierr); }                 /* r <- b (x is 0) */
-  ierr = KSP_PCApply(ksp, R, Z);CHKERRQ(ierr);                   /* z <- Br */
-  ierr = VecNorm(Z, NORM_2, &dp);CHKERRQ(ierr);
+  switch (nt) {
+  case KSP_NORM_PRECONDITIONED:
+    ierr = KSP_PCApply(ksp, R, Z);CHKERRQ(ierr);                 /* z <- Br */
+    ierr = VecNorm(Z, NORM_2, &dp);CHKERRQ(ierr);
+    break;
+  case KSP_NORM_UNPRECONDITIONED:
+    ierr = VecNorm(R, NORM_2, &dp);CHKERRQ(ierr);
+    break;
+  case KSP_NORM_NATURAL:
+    ierr = KSP_PCApply(ksp, R, Z);CHKERRQ(ierr);
+    if (single) { ierr = KSP_MatMult(ksp, Amat, Z, S);CHKERRQ(ierr); ierr = VecTDot(Z, S, &delta);CHKERRQ(ierr); }
+    ierr = VecTDot(Z, R, &beta);CHKERRQ(ierr);
+    if (PetscIsInfOrNanScalar(beta)) SETERRQ(ksp->comm, PETSC_ERR_FP, "Infinite or not-a-number generated in dot product");
+    dp = PetscSqrtReal(PetscAbsScalar(beta));
+    break;
+  case KSP_NORM_NONE: dp = 0.0; break;
+  default: SETERRQ(ksp->comm, PETSC_ERR_SUP, "norm type %d", (int)nt);
+  }
   KSPLogResidualHistory(ksp, dp);
   ierr = KSPMonitor(ksp, 0, dp);CHKERRQ(ierr);
   ksp->rnorm = dp;
   ierr = KSPDefaultConverged(ksp, 0, dp, &ksp->reason);CHKERRQ(ierr);
   if (ksp->reason) return 0;
-  if (single) {                                                   /* cg.c:166-169 */
-    ierr = KSP_MatMult(ksp, Amat, Z, S);CHKERRQ(ierr);
-    ierr = VecTDot(Z, S, &delta);CHKERRQ(ierr);
+  if (nt != KSP_NORM_PRECONDITIONED && nt != KSP_NORM_NATURAL) { ierr = KSP_PCApply(ksp, R, Z);CHKERRQ(ierr); }
+  if (nt != KSP_NORM_NATURAL) {
+    if (single) {                                                 /* cg.c:166-169 */
+      ierr = KSP_MatMult(ksp, Amat, Z, S);CHKERRQ(ierr);
+      ierr = VecTDot(Z, S, &delta);CHKERRQ(ierr);
+    }
+    ierr = VecTDot(Z, R, &beta);CHKERRQ(ierr);                   /* beta <- z'*r */
+    if (PetscIsInfOrNanScalar(beta)) SETERRQ(ksp->comm, PETSC_ERR_FP, "Infinite or not-a-number generated in dot product");
   }
-  ierr = VecTDot(Z, R, &beta);CHKERRQ(ierr);                     /* beta <- z'*r */
-  if (PetscIsInfOrNanScalar(beta)) SETERRQ(ksp->comm, PETSC_ERR_FP, "Infinite or not-a-number generated in dot product");
 
   i = 0;
   do {
@@ -103,13 +123,13 @@ static PetscErrorCode KSPSolve_CG(KSP ksp) {
       }
     }
     betaold = beta;
-    PetscBool have_beta = PETSC_FALSE;
-    PetscScalar zz = 0.0, zr = 0.0;
+    PetscBool have_sums = PETSC_FALSE;                             /* z, z'z, z'r, r'r all produced by one fused sweep */
+    PetscScalar zz = 0.0, zr = 0.0, rr = 0.0;
     if (dpi_on_device) {
       /* the update kernel applies the tests below to dpi itself and touches nothing if one fires; dpi comes back
-       * with the two sums, and the host takes the same exits */
+       * with the sums, and the host takes the same exits */
       ierr = VecCGUpdateDevBegin_HIPMI355X(X, R, Z, P, W, D, beta, dpiold, (PetscBool)(i > 0));CHKERRQ(ierr);
-      if (flevel > 2 && i + 1 < ksp->max_it && dp > 10.0 * ksp->ttol) {
+      if (flevel > 2 && i + 1 < ksp->max_it && (nt == KSP_NORM_NONE || dp > 10.0 * ksp->ttol)) {
         /* front half of iteration i+1 (beta of this iteration is its betaold) */
         PetscBool ok = PETSC_FALSE;
         ierr = VecAYPXDev_HIPMI355X(P, beta, Z);CHKERRQ(ierr);
@@ -121,34 +141,65 @@ static PetscErrorCode KSPSolve_CG(KSP ksp) {
         }
         front_queued = PETSC_TRUE;
       }
-      ierr = VecCGUpdateDevEnd_HIPMI355X(X, &zz, &zr, &dpi);CHKERRQ(ierr);
-      have_beta = PETSC_TRUE;
+      ierr = VecCGUpdateDevEnd_HIPMI355X(X, &zz, &zr, &rr, &dpi);CHKERRQ(ierr);
+      have_sums = PETSC_TRUE;
     }
     if (PetscIsInfOrNanScalar(dpi)) SETERRQ(ksp->comm, PETSC_ERR_FP, "Infinite or not-a-number generated in dot product");
     if ((dpi == 0.0) || ((i > 0) && (dpi * dpiold <= 0.0))) { ksp->reason = KSP_DIVERGED_INDEFINITE_MAT; break; }
     a = beta / dpi;
-    if (!have_beta && fusedpc) { ierr = VecCGUpdate_HIPMI355X(X, R, Z, P, W, D, a, &zz, &zr, &have_beta);CHKERRQ(ierr); }
-    if (!have_beta) {
+    if (!have_sums && fusedpc) { ierr = VecCGUpdate_HIPMI355X(X, R, Z, P, W, D, a, &zz, &zr, &rr, &have_sums);CHKERRQ(ierr); }
+    if (have_sums) {
+      /* z = B r is already there whatever the norm type (the reference applies the PC before or after the test,
+       * cg.c:233-268: same z either way), and so is the next beta */
+      if (nt == KSP_NORM_PRECONDITIONED) dp = PetscSqrtReal(zz);   /* the square is reduced, then rooted (pvec2.c:62-64) */
+      else if (nt == KSP_NORM_UNPRECONDITIONED) dp = PetscSqrtReal(rr);
+      else if (nt == KSP_NORM_NATURAL) {
+        if (PetscIsInfOrNanScalar(zr)) SETERRQ(ksp->comm, PETSC_ERR_FP, "Infinite or not-a-number generated in dot product");
+        dp = PetscSqrtReal(PetscAbsScalar(zr));
+      } else dp = 0.0;
+    } else {
       ierr = VecAXPY(X, a, P);CHKERRQ(ierr);                     /* x <- x + ap */
       ierr = VecAXPY(R, -a, W);CHKERRQ(ierr);                    /* r <- r - aw */
-      ierr = KSP_PCApply(ksp, R, Z);CHKERRQ(ierr);               /* z <- Br */
-      if (single) { ierr = KSP_MatMult(ksp, Amat, Z, S);CHKERRQ(ierr); }   /* cg.c:217-219 */
-      if (fused) { PetscReal n2; ierr = VecDotNorm2(R, Z, &zr, &n2);CHKERRQ(ierr); zz = n2; have_beta = PETSC_TRUE; }
+      if (nt == KSP_NORM_PRECONDITIONED) {
+        ierr = KSP_PCApply(ksp, R, Z);CHKERRQ(ierr);             /* z <- Br */
+        if (single) { ierr = KSP_MatMult(ksp, Amat, Z, S);CHKERRQ(ierr); }   /* cg.c:217-219 */
+        if (fused) { PetscReal n2; ierr = VecDotNorm2(R, Z, &zr, &n2);CHKERRQ(ierr); dp = PetscSqrtReal(n2); have_sums = PETSC_TRUE; }   /* norm and next beta share a reduction */
+        else { ierr = VecNorm(Z, NORM_2, &dp);CHKERRQ(ierr); }
+      } else if (nt == KSP_NORM_UNPRECONDITIONED) {
+        ierr = VecNorm(R, NORM_2, &dp);CHKERRQ(ierr);
+      } else if (nt == KSP_NORM_NATURAL) {
+        ierr = KSP_PCApply(ksp, R, Z);CHKERRQ(ierr);
+        if (single) {
+          PetscScalar tmp[2]; Vec vecs[2];
+          vecs[0] = S; vecs[1] = R;
+          ierr = KSP_MatMult(ksp, Amat, Z, S);CHKERRQ(ierr);
+          ierr = VecMDot(Z, 2, vecs, tmp);CHKERRQ(ierr);
+          delta = tmp[0]; beta = tmp[1];
+        } else { ierr = VecTDot(Z, R, &beta);CHKERRQ(ierr); }
+        if (PetscIsInfOrNanScalar(beta)) SETERRQ(ksp->comm, PETSC_ERR_FP, "Infinite or not-a-number generated in dot product");
+        dp = PetscSqrtReal(PetscAbsScalar(beta));
+      } else dp = 0.0;
     }
-    if (have_beta) dp = PetscSqrtReal(zz);                        /* the square is reduced, then rooted (pvec2.c:62-64) */
-    else { ierr = VecNorm(Z, NORM_2, &dp);CHKERRQ(ierr); }
     ksp->rnorm = dp;
     KSPLogResidualHistory(ksp, dp);
     ierr = KSPMonitor(ksp, i + 1, dp);CHKERRQ(ierr);
     ierr = KSPDefaultConverged(ksp, i + 1, dp, &ksp->reason);CHKERRQ(ierr);
     if (ksp->reason) break;
-    if (single) {                                                 /* cg.c:263-270: one VecMDot(2) = one reduction for delta and beta */
-      PetscScalar tmp[2]; Vec vecs[2];
-      vecs[0] = S; vecs[1] = R;
-      ierr = VecMDot(Z, 2, vecs, tmp);CHKERRQ(ierr);
-      delta = tmp[0]; beta = tmp[1];
-    } else if (have_beta) beta = zr;
-    else { ierr = VecTDot(Z, R, &beta);CHKERRQ(ierr); }          /* beta <- z'*r */
+    if (have_sums) beta = zr;                                      /* beta <- z'*r, from the fused sweep */
+    else {
+      if (nt != KSP_NORM_PRECONDITIONED && nt != KSP_NORM_NATURAL) {
+        ierr = KSP_PCApply(ksp, R, Z);CHKERRQ(ierr);             /* z <- Br */
+        if (single) { ierr = KSP_MatMult(ksp, Amat, Z, S);CHKERRQ(ierr); }
+      }
+      if (nt != KSP_NORM_NATURAL) {
+        if (single) {                                             /* cg.c:263-270: one VecMDot(2) = one reduction for delta and beta */
+          PetscScalar tmp[2]; Vec vecs[2];
+          vecs[0] = S; vecs[1] = R;
+          ierr = VecMDot(Z, 2, vecs, tmp);CHKERRQ(ierr);
+          delta = tmp[0]; beta = tmp[1];
+        } else { ierr = VecTDot(Z, R, &beta);CHKERRQ(ierr); }    /* beta <- z'*r */
+      }
+    }
     if (PetscIsInfOrNanScalar(beta)) SETERRQ(ksp->comm, PETSC_ERR_FP, "Infinite or not-a-number generated in dot product");
     i++;
   } while (i < ksp->max_it);

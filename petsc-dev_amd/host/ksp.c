@@ -82,6 +82,15 @@ PetscErrorCode KSPSetFromOptions(KSP ksp) {   /* itcl.c KSPSetFromOptions, the o
   ierr = PetscOptionsGetReal(ksp->prefix, "-ksp_atol", &r, &set);CHKERRQ(ierr); if (set) ksp->abstol = r;
   ierr = PetscOptionsGetReal(ksp->prefix, "-ksp_divtol", &r, &set);CHKERRQ(ierr); if (set) ksp->divtol = r;
   ierr = PetscOptionsGetString(ksp->prefix, "-ksp_initial_guess_nonzero", t, sizeof(t), &set);CHKERRQ(ierr); if (set) ksp->guess_zero = PETSC_FALSE;
+  ierr = PetscOptionsGetString(ksp->prefix, "-ksp_norm_type", t, sizeof(t), &set);CHKERRQ(ierr);   /* itcl.c: KSPNormTypes[] */
+  if (set) {
+    if (!strcmp(t, "none")) ksp->normtype = KSP_NORM_NONE;
+    else if (!strcmp(t, "preconditioned")) ksp->normtype = KSP_NORM_PRECONDITIONED;
+    else if (!strcmp(t, "unpreconditioned")) ksp->normtype = KSP_NORM_UNPRECONDITIONED;
+    else if (!strcmp(t, "natural")) ksp->normtype = KSP_NORM_NATURAL;
+    else SETERRQ(ksp->comm, PETSC_ERR_ARG_UNKNOWN_TYPE, "Unknown norm type %s", t);
+    ksp->setupcalled = ksp->setupcalled == 2 ? 1 : ksp->setupcalled;   /* have KSPSetUp look at the combination again */
+  }
   if (ksp->ops->setfromoptions) { ierr = (*ksp->ops->setfromoptions)(ksp);CHKERRQ(ierr); }
   return 0;
 }
@@ -111,8 +120,11 @@ PetscErrorCode KSPSetUp(KSP ksp) {   /* itfunc.c:175 */
   /* norm type / side defaults (KSPSetUpNorms_Private): preconditioned norm, left PC for the three methods */
   if (ksp->normtype == KSP_NORM_DEFAULT) ksp->normtype = strcmp(ksp->type_name, KSPPREONLY) ? KSP_NORM_PRECONDITIONED : KSP_NORM_NONE;
   if (ksp->pc_side == PC_SIDE_DEFAULT) ksp->pc_side = PC_LEFT;
-  if (ksp->normtype != KSP_NORM_PRECONDITIONED && ksp->normtype != KSP_NORM_NONE)
-    SETERRQ(ksp->comm, PETSC_ERR_SUP, "only the (default) preconditioned residual norm is on the ported path");
+  /* KSPSetNormType (itcreate.c:196-205): every norm with KSPCG; the others here run the preconditioned norm */
+  if (ksp->normtype != KSP_NORM_PRECONDITIONED && ksp->normtype != KSP_NORM_NONE && strcmp(ksp->type_name, KSPCG))
+    SETERRQ(ksp->comm, PETSC_ERR_SUP, "KSP %s: only the preconditioned residual norm is on the ported path (unpreconditioned/natural: KSPCG)", ksp->type_name);
+  if (ksp->normtype == KSP_NORM_NONE && strcmp(ksp->type_name, KSPCG) && strcmp(ksp->type_name, KSPPREONLY))
+    SETERRQ(ksp->comm, PETSC_ERR_SUP, "KSP %s with KSP_NORM_NONE is outside the ported path", ksp->type_name);
   ierr = PCSetUp(ksp->pc);CHKERRQ(ierr);
   ksp->setupcalled = 2;
   return 0;
@@ -205,20 +217,22 @@ PetscErrorCode KSPInitialResidual(KSP ksp, Vec vsoln, Vec vt1, Vec vt2, Vec vres
   return 0;
 }
 
-/* KSPDefaultConverged, iterativ.c:702-783 */
+/* KSPDefaultConverged, iterativ.c:702-783; with KSP_NORM_NONE the test installed by KSPSetNormType is
+ * KSPSkipConverged (itcreate.c:228-229, iterativ.c:536-544): iterate until max_it, then KSP_CONVERGED_ITS */
 PetscErrorCode KSPDefaultConverged(KSP ksp, PetscInt n, PetscReal rnorm, KSPConvergedReason *reason) {
   PetscErrorCode ierr;
   *reason = KSP_CONVERGED_ITERATING;
-  if (ksp->normtype == KSP_NORM_NONE) SETERRQ(ksp->comm, PETSC_ERR_ARG_WRONGSTATE, "Use KSPSkipConverged() with KSPNormType of KSP_NORM_NONE");
+  if (ksp->normtype == KSP_NORM_NONE) { if (n >= ksp->max_it) *reason = KSP_CONVERGED_ITS; return 0; }
   if (!n) {
     if (!ksp->guess_zero) {
-      PetscReal snorm;
+      PetscReal snorm = 0.0;
       if (ksp->normtype == KSP_NORM_UNPRECONDITIONED || ksp->pc_side == PC_RIGHT) { ierr = VecNorm(ksp->vec_rhs, NORM_2, &snorm);CHKERRQ(ierr); }
       else {
         Vec z;
         ierr = VecDuplicate(ksp->vec_rhs, &z);CHKERRQ(ierr);
         ierr = KSP_PCApply(ksp, ksp->vec_rhs, z);CHKERRQ(ierr);
-        ierr = VecNorm(z, NORM_2, &snorm);CHKERRQ(ierr);
+        if (ksp->normtype == KSP_NORM_NATURAL) { PetscScalar nrm; ierr = VecDot(ksp->vec_rhs, z, &nrm);CHKERRQ(ierr); snorm = PetscSqrtReal(PetscAbsScalar(nrm)); }
+        else { ierr = VecNorm(z, NORM_2, &snorm);CHKERRQ(ierr); }
         ierr = VecDestroy(&z);CHKERRQ(ierr);
       }
       if (!snorm) snorm = rnorm;   /* zero RHS and nonzero guess */

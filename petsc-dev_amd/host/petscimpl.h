@@ -132,11 +132,11 @@ PetscErrorCode VecHIPGetRead(Vec v, const PetscScalar **d);
 PetscErrorCode VecHIPGetWrite(Vec v, PetscScalar **d);       /* contents will be overwritten */
 PetscErrorCode VecHIPGetReadWrite(Vec v, PetscScalar **d);
 PetscErrorCode VecHIPRestoreWrite(Vec v);                    /* device newer; state++ */
-PetscErrorCode VecCGUpdate_HIPMI355X(Vec x, Vec r, Vec z, Vec p, Vec w, Vec d, PetscScalar a, PetscScalar *zz, PetscScalar *zr, PetscBool *done);
+PetscErrorCode VecCGUpdate_HIPMI355X(Vec x, Vec r, Vec z, Vec p, Vec w, Vec d, PetscScalar a, PetscScalar *zz, PetscScalar *zr, PetscScalar *rr, PetscBool *done);
 PetscErrorCode VecCGUpdateCheck_HIPMI355X(Vec x, Vec r, Vec z, Vec p, Vec w, Vec d, PetscBool *ok);
 PetscErrorCode VecTDotBegin_HIPMI355X(Vec x, Vec y, PetscBool *ok);   /* result stays on the device; pairs with VecCGUpdateDev */
 PetscErrorCode VecCGUpdateDevBegin_HIPMI355X(Vec x, Vec r, Vec z, Vec p, Vec w, Vec d, PetscScalar beta, PetscScalar dpiold, PetscBool check_sign);
-PetscErrorCode VecCGUpdateDevEnd_HIPMI355X(Vec x, PetscScalar *zz, PetscScalar *zr, PetscScalar *dpi);
+PetscErrorCode VecCGUpdateDevEnd_HIPMI355X(Vec x, PetscScalar *zz, PetscScalar *zr, PetscScalar *rr, PetscScalar *dpi);
 #define PETSC_HIP_DPI_SLOT 8   /* device scratch slot holding p'w between the dot (or the SpMV by-product) and the CG update */
 PetscErrorCode MatMultTDotBegin_HIPMI355X(Mat A, Vec x, Vec y, PetscBool *ok);   /* y = A x, x'y left on the device */
 PetscErrorCode VecAYPXDev_HIPMI355X(Vec p, PetscScalar den, Vec z);   /* p = z + (z'r on the device / den) p */

@@ -349,8 +349,8 @@ static PetscErrorCode VecDotNorm2_HIP(Vec s, Vec t, PetscScalar *dp, PetscScalar
  * doubles on several ranks instead of two of one).  Results carry the bits of the separate VecAXPY, VecAXPY,
  * VecPointwiseMult, VecNorm, VecTDot calls.  Returns *done = PETSC_FALSE (and does nothing) when an operand is
  * not a HIPMI355X vector, so the caller keeps the unfused sequence. */
-PetscErrorCode VecCGUpdate_HIPMI355X(Vec x, Vec r, Vec z, Vec p, Vec w, Vec d, PetscScalar a, PetscScalar *zz, PetscScalar *zr, PetscBool *done) {
-  PetscErrorCode ierr; const PetscScalar *dp_, *dw, *dd; PetscScalar *dx, *dr, *dz; double *out; PetscScalar res[2]; DEVCTX;
+PetscErrorCode VecCGUpdate_HIPMI355X(Vec x, Vec r, Vec z, Vec p, Vec w, Vec d, PetscScalar a, PetscScalar *zz, PetscScalar *zr, PetscScalar *rr, PetscBool *done) {
+  PetscErrorCode ierr; const PetscScalar *dp_, *dw, *dd; PetscScalar *dx, *dr, *dz; double *out; PetscScalar res[3]; DEVCTX;
   *done = PETSC_FALSE;
   ierr = VecCGUpdateCheck_HIPMI355X(x, r, z, p, w, d, done);CHKERRQ(ierr);
   if (!*done || a == 0.0) { *done = PETSC_FALSE; return 0; }
@@ -366,8 +366,8 @@ PetscErrorCode VecCGUpdate_HIPMI355X(Vec x, Vec r, Vec z, Vec p, Vec w, Vec d, P
   CHKHIP(mi355x_vec_cg_update(dc->h, N_(x), a, dp_, dw, dd, dx, dr, dz, out));
   VecHIPRestoreWrite(x); VecHIPRestoreWrite(r); VecHIPRestoreWrite(z);
   PetscObjectStateIncrease(x); PetscObjectStateIncrease(r); PetscObjectStateIncrease(z);
-  ierr = reduce_finish(x, dc, 2, 0, res);CHKERRQ(ierr);
-  *zz = res[0]; *zr = res[1];
+  ierr = reduce_finish(x, dc, 3, 0, res);CHKERRQ(ierr);
+  *zz = res[0]; *zr = res[1]; *rr = res[2];
   ierr = PetscLogFlops(9.0 * x->map->n);CHKERRQ(ierr);   /* 2n + 2n + n + 2n + 2n */
   *done = PETSC_TRUE;
   return 0;
@@ -411,18 +411,18 @@ PetscErrorCode VecCGUpdateDevBegin_HIPMI355X(Vec x, Vec r, Vec z, Vec p, Vec w, 
   VecHIPRestoreWrite(x); VecHIPRestoreWrite(r); VecHIPRestoreWrite(z);
   PetscObjectStateIncrease(x); PetscObjectStateIncrease(r); PetscObjectStateIncrease(z);
   if (DEVICE_COLLECTIVES(x)) {
-    CHKHIP(mi355x_comm_allreduce_sum(x->comm->dcomm, dc->h, ds, 2));
-    CHKHIP(mi355x_handle_publish(dc->h, ds, 3));
+    CHKHIP(mi355x_comm_allreduce_sum(x->comm->dcomm, dc->h, ds, 3));
+    CHKHIP(mi355x_handle_publish(dc->h, ds, 4));
   }
   ierr = PetscLogFlops(9.0 * x->map->n);CHKERRQ(ierr);
   return 0;
 }
-PetscErrorCode VecCGUpdateDevEnd_HIPMI355X(Vec x, PetscScalar *zz, PetscScalar *zr, PetscScalar *dpi) {
+PetscErrorCode VecCGUpdateDevEnd_HIPMI355X(Vec x, PetscScalar *zz, PetscScalar *zr, PetscScalar *rr, PetscScalar *dpi) {
   PetscErrorCode ierr; DEVCTX;
   (void)x;
   CHKHIP(mi355x_handle_wait_result(dc->h));
   const double *hs = mi355x_handle_host_scratch(dc->h);
-  *zz = hs[0]; *zr = hs[1]; *dpi = hs[2];
+  *zz = hs[0]; *zr = hs[1]; *rr = hs[2]; *dpi = hs[3];
   return 0;
 }
 /* p = z + (zr/den) p with zr = the z'r the last VecCGUpdateDevBegin left in device scratch slot 1 (VecAYPX(P,b,Z) of

@@ -360,6 +360,35 @@ def test_ksp_bcgs_fused_forms_are_bit_identical(P, pc):
     assert np.array_equal(bits(xf), bits(xu))
 
 
+@pytest.mark.parametrize("norm", ["preconditioned", "unpreconditioned", "natural", "none"])
+@pytest.mark.parametrize("pc", ["jacobi", "ilu"])
+def test_ksp_cg_norm_types(P, norm, pc):
+    """KSPSolve_CG's four norm types (cg.c:136-161,233-260; -ksp_norm_type): the history against the oracle's
+    restatement, and the fused default against the op-by-op sequence bit for bit (the fused sweep also returns r'r,
+    so every norm comes out of the same reduction).  KSP_NORM_NONE runs to max_it and ends KSP_CONVERGED_ITS (4)."""
+    ai, aj, aa = pb.lap2d(33, 29)
+    n = ai.size - 1
+    d = 1.0 + 0.5 * np.sin(np.arange(n))
+    rows = np.repeat(np.arange(n), np.diff(ai))
+    aa = aa * d[rows] * d[aj]
+    b = orc.spmv(ai, aj, aa, np.cos(0.3 * np.arange(n)))
+    kw = dict(rtol=1e-8, max_it=37 if norm == "none" else 500)
+    o = "-ksp_norm_type " + norm
+    xf, hf, itsf, rf = solve(P, ai, aj, aa, b, "cg", pc, opts=o, **kw)
+    xu, hu, itsu, ru = solve(P, ai, aj, aa, b, "cg", pc, opts=o + " -ksp_cg_fused 0", **kw)
+    nt = dict(none=0, preconditioned=1, unpreconditioned=2, natural=3)[norm]
+    xr, hr, itsr, rr = orc.ksp_solve(ai, aj, aa, b, ksp="cg", pc=pc, norm_type=nt, **kw)
+    assert itsf == itsu and rf == ru and np.array_equal(bits(hf), bits(hu)) and np.array_equal(bits(xf), bits(xu))
+    assert rf == rr and abs(itsf - itsr) <= 1
+    if norm == "none":
+        assert rf == 4 and itsf == 37 and np.all(hf[:38] == 0.0)
+    else:
+        assert rf == 2
+        k = min(len(hf), len(hr))
+        assert np.allclose(hf[:k], hr[:k], rtol=1e-6, atol=1e-14 * hr[0])
+    assert np.linalg.norm(xf - xr) <= 1e-6 * np.linalg.norm(xr)
+
+
 def test_ksp_cg_single_reduction(P):
     """-ksp_cg_single_reduction (cg.c:116-122,200-203,263-270): two reductions per iteration instead of
     three (VecMDot(2) for delta and beta), A*p by recurrence; same op sequence as the oracle's restatement"""

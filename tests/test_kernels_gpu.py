@@ -490,11 +490,12 @@ def test_cg_update_matches_separate_kernels_bitwise(dev, n):
     dev.chk(k.mi355x_vec_pointwise_mult(dev.h, n, r1, dd, z1))
     dev.chk(k.mi355x_vec_norm(dev.h, n, 2, z1, hs)); zz = dev.scalar_out(1)[0]
     dev.chk(k.mi355x_vec_dot(dev.h, n, z1, r1, hs)); zr = dev.scalar_out(1)[0]
+    dev.chk(k.mi355x_vec_norm(dev.h, n, 2, r1, hs)); rr = dev.scalar_out(1)[0]
     dev.chk(k.mi355x_vec_cg_update(dev.h, n, a, dp, dw, dd, x2, r2, z2, hs))
-    out = dev.scalar_out(2)
+    out = dev.scalar_out(3)
     for u, v in ((x1, x2), (r1, r2), (z1, z2)):
         assert_bitexact(dev.get(u, n), dev.get(v, n))
-    assert_bitexact(np.array([zz, zr]), out)
+    assert_bitexact(np.array([zz, zr, rr]), out)
     xo, ro = x.copy(), r.copy()
     orc.vec_axpy(xo, a, p); orc.vec_axpy(ro, -a, w)
     zo = np.zeros(n); orc.vec_pointwise_mult(zo, ro, d)
@@ -503,7 +504,7 @@ def test_cg_update_matches_separate_kernels_bitwise(dev, n):
     dev.chk(k.mi355x_memcpy_h2d(dev.h, x2, x.ctypes.data, x.nbytes)) if n else None
     dev.chk(k.mi355x_memcpy_h2d(dev.h, r2, r.ctypes.data, r.nbytes)) if n else None
     dev.chk(k.mi355x_vec_cg_update(dev.h, n, a, dp, dw, dd, x2, r2, dw, hs))
-    assert_bitexact(dev.scalar_out(2), out)
+    assert_bitexact(dev.scalar_out(3), out)
     assert_bitexact(dev.get(dw, n), zo); assert_bitexact(dev.get(r2, n), ro); assert_bitexact(dev.get(x2, n), xo)
     for q in (dp, dw, dd, x1, r1, z1, x2, r2, z2):
         dev.free(q)
@@ -523,23 +524,23 @@ def test_cg_update_dev_scalar_form(dev, n):
     x2, r2, z2 = dev.put(x), dev.put(r), dev.alloc(8 * max(n, 2))
     ddpi = dev.put(np.array([dpi, 0.0]))
     hs = dev.host_scratch()
-    dev.chk(k.mi355x_vec_cg_update(dev.h, n, a, dp, dw, dd, x1, r1, z1, hs)); ref = dev.scalar_out(2)
-    dev.chk(k.mi355x_vec_cg_update_dev(dev.h, n, beta, ddpi, 0.5, 1, dp, dw, dd, x2, r2, z2, hs, 0)); out = dev.scalar_out(3)
-    assert_bitexact(out[:2], ref)
-    assert out[2] == dpi
+    dev.chk(k.mi355x_vec_cg_update(dev.h, n, a, dp, dw, dd, x1, r1, z1, hs)); ref = dev.scalar_out(3)
+    dev.chk(k.mi355x_vec_cg_update_dev(dev.h, n, beta, ddpi, 0.5, 1, dp, dw, dd, x2, r2, z2, hs, 0)); out = dev.scalar_out(4)
+    assert_bitexact(out[:3], ref)
+    assert out[3] == dpi
     for u, v in ((x1, x2), (r1, r2), (z1, z2)):
         assert_bitexact(dev.get(u, n), dev.get(v, n))
     # refused updates: nothing is written
     xb, rb, zb = dev.get(x2, n), dev.get(r2, n), dev.get(z2, n)
     for bad, dpiold, chk in ((0.0, 1.0, 0), (np.nan, 1.0, 0), (np.inf, 1.0, 0), (-1.0, 2.0, 1), (1.0, -2.0, 1)):
         dev.chk(k.mi355x_memcpy_h2d(dev.h, ddpi, np.array([bad]).ctypes.data, 8)); dev.sync()
-        dev.chk(k.mi355x_vec_cg_update_dev(dev.h, n, beta, ddpi, dpiold, chk, dp, dw, dd, x2, r2, z2, hs, 0)); out = dev.scalar_out(3)
-        assert (np.isnan(out[2]) and np.isnan(bad)) or out[2] == bad
-        assert out[0] == 0.0 and out[1] == 0.0
+        dev.chk(k.mi355x_vec_cg_update_dev(dev.h, n, beta, ddpi, dpiold, chk, dp, dw, dd, x2, r2, z2, hs, 0)); out = dev.scalar_out(4)
+        assert (np.isnan(out[3]) and np.isnan(bad)) or out[3] == bad
+        assert out[0] == 0.0 and out[1] == 0.0 and out[2] == 0.0
         assert_bitexact(dev.get(x2, n), xb); assert_bitexact(dev.get(r2, n), rb); assert_bitexact(dev.get(z2, n), zb)
     # a sign change is only a break-down when the caller asks for the test (first iteration: check_sign = 0)
     dev.chk(k.mi355x_memcpy_h2d(dev.h, ddpi, np.array([-1.0]).ctypes.data, 8)); dev.sync()
-    dev.chk(k.mi355x_vec_cg_update_dev(dev.h, n, beta, ddpi, 2.0, 0, dp, dw, dd, x2, r2, z2, hs, 0)); out = dev.scalar_out(3)
+    dev.chk(k.mi355x_vec_cg_update_dev(dev.h, n, beta, ddpi, 2.0, 0, dp, dw, dd, x2, r2, z2, hs, 0)); out = dev.scalar_out(4)
     if n:
         assert not np.array_equal(dev.get(x2, n), xb)
     # result kept on the device AND handed to the host by the same launch; then p = z + (z'r / den) p on the device
@@ -551,16 +552,16 @@ def test_cg_update_dev_scalar_form(dev, n):
     dev.chk(k.mi355x_vec_cg_update_dev(dev.h, n, beta, ddpi, 0.5, 1, dp, dw, dd, x2, r2, z2, dres, 1))
     dev.chk(k.mi355x_handle_wait_result(dev.h))
     addr = k.mi355x_handle_host_scratch(dev.h)
-    polled = np.ctypeslib.as_array((C.c_double * 3).from_address(addr)).copy()
-    assert_bitexact(polled[:2], ref); assert polled[2] == dpi
-    assert_bitexact(dev.get(dres, 3), polled)
+    polled = np.ctypeslib.as_array((C.c_double * 4).from_address(addr)).copy()
+    assert_bitexact(polled[:3], ref); assert polled[3] == dpi
+    assert_bitexact(dev.get(dres, 4), polled)
     den = 0.77
     dev.chk(k.mi355x_vec_aypx_dev(dev.h, n, C.c_void_p(dres.value + 8), den, z2, dp))       # p <- z + (zr/den) p
     pref = p.copy(); orc.vec_aypx(pref, polled[1] / den, dev.get(z2, n))
     assert_bitexact(dev.get(dp, n), pref)
     # publish: device values -> pinned scratch + completion number
-    dev.chk(k.mi355x_handle_publish(dev.h, dres, 3)); dev.chk(k.mi355x_handle_wait_result(dev.h))
-    assert_bitexact(np.ctypeslib.as_array((C.c_double * 3).from_address(addr)).copy(), polled)
+    dev.chk(k.mi355x_handle_publish(dev.h, dres, 4)); dev.chk(k.mi355x_handle_wait_result(dev.h))
+    assert_bitexact(np.ctypeslib.as_array((C.c_double * 4).from_address(addr)).copy(), polled)
     for q in (dp, dw, dd, x1, r1, z1, x2, r2, z2, ddpi, dres):
         dev.free(q)
 
