@@ -79,6 +79,53 @@ def test_vec_ops_through_function_table(P):
     assert e.value.code == 75
 
 
+def test_vec_tutorial_ex1_golden(P):
+    """src/vec/vec/examples/tutorials/ex1.c replayed on HIPMI355X vectors (n = 20): VecSet, Dot, MDot, Scale, Copy, AXPY,
+    AYPX, Swap, WAXPY, PointwiseMult, PointwiseDivide, MAXPY and the norms in between, printed as the example prints
+    them and compared with the reference's output/ex1_1.out (the VecMax/VecMin lines are not on the ported path)."""
+    import ctypes as C
+    L = P.lib()
+    n = 20
+    small = 1e-10                                      # PETSC_SMALL
+    x = P.Vec.create(n, comm=L.COMM_SELF)
+    y, w = x.duplicate(), x.duplicate()
+    z = [x.duplicate() for _ in range(3)]
+    L.VecSet(x.h, 1.0); L.VecSet(y.h, 2.0)
+    for k, v in enumerate((1.0, 2.0, 3.0)):
+        L.VecSet(z[k].h, v)
+    assert x.dot(y) == 2.0 * n
+    tab = (C.c_void_p * 3)(*[v.h.value for v in z])
+    dots = (C.c_double * 3)()
+    L.VecMDot(x.h, 3, tab, dots)
+    assert list(dots) == [1.0 * n, 2.0 * n, 3.0 * n]
+    out = ["Vector length %d" % n, "All other values should be near zero"]
+
+    def chk(name, vec, expect):
+        v = vec.norm() - expect * np.sqrt(float(n))
+        if -small < v < small:
+            v = 0.0
+        return "%s %g" % (name, v)
+    L.VecScale(x.h, 2.0); out.append(chk("VecScale", x, 2.0))
+    L.VecCopy(x.h, w.h); out.append(chk("VecCopy ", w, 2.0))
+    L.VecAXPY(y.h, 3.0, x.h); out.append(chk("VecAXPY", y, 8.0))
+    L.VecAYPX(y.h, 2.0, x.h); out.append(chk("VecAYPX", y, 18.0))
+    L.VecSwap(x.h, y.h); out.append(chk("VecSwap ", y, 2.0)); out.append(chk("VecSwap ", x, 18.0))
+    L.VecWAXPY(w.h, 2.0, x.h, y.h); out.append(chk("VecWAXPY", w, 38.0))
+    L.VecPointwiseMult(w.h, y.h, x.h); out.append(chk("VecPointwiseMult", w, 36.0))
+    L.VecPointwiseDivide(w.h, x.h, y.h); out.append(chk("VecPointwiseDivide", w, 9.0))
+    al = (C.c_double * 3)(1.0, 3.0, 2.0)
+    L.VecSet(x.h, 1.0)
+    L.VecMAXPY(x.h, 3, al, tab)
+    vs = []
+    for k, e in enumerate((1.0, 2.0, 3.0)):
+        v = z[k].norm() - e * np.sqrt(float(n))
+        vs.append(0.0 if -small < v < small else v)
+    out.append("VecMAXPY %g %g %g " % tuple(vs))
+    assert np.array_equal(x.array(), np.full(n, 1.0 + 1.0 + 6.0 + 6.0))
+    gold = [l.rstrip("\n") for l in open(os.path.join(G, "vec_tutorials", "ex1_1.out")) if not l.startswith(("VecMax", "VecMin"))]
+    assert [l.rstrip() for l in out] == [l.rstrip() for l in gold]
+
+
 def test_vec_mdot_maxpy_and_host_access(P):
     L = P.lib()
     n, nv = 50001, 13
