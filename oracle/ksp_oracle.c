@@ -438,7 +438,7 @@ static void solve_bcgs(solver *s, const double *B, double *X) {
   double rho, rhoold, alpha, beta, omega, omegaold, d1, d2, dp = 0.0;
   int i;
   initial_residual(s, X, V, T, R, B);
-  orc_vec_norm(n, 1, R, &dp);
+  if (s->norm_type != 0) orc_vec_norm(n, 1, R, &dp);   /* bcgs.c:76: no norm with KSP_NORM_NONE */
   s->its = 0;
   monitor(s, dp);
   converged(s, 0, dp, B);
@@ -471,7 +471,7 @@ static void solve_bcgs(solver *s, const double *B, double *X) {
     omega = d1 / d2;
     orc_vec_axpbypcz(n, alpha, omega, 1.0, P, S, X);
     orc_vec_waxpy(n, -omega, T, S, R);
-    orc_vec_norm(n, 1, R, &dp);
+    if (s->norm_type != 0) orc_vec_norm(n, 1, R, &dp);   /* bcgs.c:131 */
     rhoold = rho; omegaold = omega;
     s->its++;
     monitor(s, dp);

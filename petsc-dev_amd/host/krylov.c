@@ -462,8 +462,9 @@ static PetscErrorCode KSPSolve_BCGS(KSP ksp) {
     ierr = PCJacobiGetInverseDiagonal_Private(ksp->pc, &D);CHKERRQ(ierr);
     fusedpc = (PetscBool)(D != NULL || PCIsNone_Private(ksp->pc));
   }
+  const PetscBool nonorm = (PetscBool)(ksp->normtype == KSP_NORM_NONE);   /* bcgs.c:76,131: smoother use, no norms, KSPSkipConverged */
   ierr = KSPInitialResidual(ksp, X, V, T, R, B);CHKERRQ(ierr);   /* initial preconditioned residual */
-  ierr = VecNorm(R, NORM_2, &dp);CHKERRQ(ierr);
+  if (!nonorm) { ierr = VecNorm(R, NORM_2, &dp);CHKERRQ(ierr); }
   ksp->its = 0;
   ksp->rnorm = dp;
   KSPLogResidualHistory(ksp, dp);
@@ -514,12 +515,12 @@ static PetscErrorCode KSPSolve_BCGS(KSP ksp) {
     if (fusedpc) {                                               /* x, r, (r,r) and the next (r,rp) in one sweep */
       PetscScalar rr, rhonext;
       ierr = VecBCGSUpdate_HIPMI355X(X, R, P, S, T, RP, alpha, omega, &rr, &rhonext, &done);CHKERRQ(ierr);
-      if (done) { dp = PetscSqrtReal(rr); rhoold = rho; rho = rhonext; have_rho = PETSC_TRUE; }
+      if (done) { dp = nonorm ? 0.0 : PetscSqrtReal(rr); rhoold = rho; rho = rhonext; have_rho = PETSC_TRUE; }
     }
     if (!done) {
       ierr = VecAXPBYPCZ(X, alpha, omega, 1.0, P, S);CHKERRQ(ierr);/* x <- alpha*p + omega*s + x */
       ierr = VecWAXPY(R, -omega, T, S);CHKERRQ(ierr);            /* r <- s - w t */
-      ierr = VecNorm(R, NORM_2, &dp);CHKERRQ(ierr);
+      if (!nonorm) { ierr = VecNorm(R, NORM_2, &dp);CHKERRQ(ierr); }
       rhoold = rho;
     }
     omegaold = omega;

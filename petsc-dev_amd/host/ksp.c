@@ -123,7 +123,7 @@ PetscErrorCode KSPSetUp(KSP ksp) {   /* itfunc.c:175 */
   /* KSPSetNormType (itcreate.c:196-205): every norm with KSPCG; the others here run the preconditioned norm */
   if (ksp->normtype != KSP_NORM_PRECONDITIONED && ksp->normtype != KSP_NORM_NONE && strcmp(ksp->type_name, KSPCG))
     SETERRQ(ksp->comm, PETSC_ERR_SUP, "KSP %s: only the preconditioned residual norm is on the ported path (unpreconditioned/natural: KSPCG)", ksp->type_name);
-  if (ksp->normtype == KSP_NORM_NONE && strcmp(ksp->type_name, KSPCG) && strcmp(ksp->type_name, KSPPREONLY))
+  if (ksp->normtype == KSP_NORM_NONE && strcmp(ksp->type_name, KSPCG) && strcmp(ksp->type_name, KSPBCGS) && strcmp(ksp->type_name, KSPPREONLY))
     SETERRQ(ksp->comm, PETSC_ERR_SUP, "KSP %s with KSP_NORM_NONE is outside the ported path", ksp->type_name);
   ierr = PCSetUp(ksp->pc);CHKERRQ(ierr);
   ksp->setupcalled = 2;

@@ -436,6 +436,20 @@ def test_ksp_cg_norm_types(P, norm, pc):
     assert np.linalg.norm(xf - xr) <= 1e-6 * np.linalg.norm(xr)
 
 
+def test_ksp_bcgs_as_smoother_without_norms(P):
+    """-ksp_norm_type none with BiCGStab (bcgs.c:76,131: no VecNorm, KSPSkipConverged): exactly max_it iterations,
+    KSP_CONVERGED_ITS, zero history, and the iterate of the normal run after the same number of iterations"""
+    ai, aj, aa = pb.lap2d(21, 19)
+    n = ai.size - 1
+    b = np.cos(0.3 * np.arange(n))
+    x0, h0, its0, r0 = solve(P, ai, aj, aa, b, "bcgs", "jacobi", opts="-ksp_norm_type none", max_it=6)
+    xr, hr, itsr, rr = orc.ksp_solve(ai, aj, aa, b, ksp="bcgs", pc="jacobi", norm_type=0, max_it=6)
+    x1, h1, its1, r1 = solve(P, ai, aj, aa, b, "bcgs", "jacobi", rtol=1e-30, max_it=6)
+    assert (its0, r0) == (6, 4) and (itsr, rr) == (6, 4) and np.all(h0[:7] == 0.0)
+    assert np.array_equal(bits(x0), bits(x1))
+    assert np.linalg.norm(x0 - xr) <= 1e-10 * np.linalg.norm(xr)
+
+
 def test_ksp_cg_single_reduction(P):
     """-ksp_cg_single_reduction (cg.c:116-122,200-203,263-270): two reductions per iteration instead of
     three (VecMDot(2) for delta and beta), A*p by recurrence; same op sequence as the oracle's restatement"""
