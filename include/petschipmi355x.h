@@ -266,6 +266,7 @@ PetscErrorCode KSPGetPC(KSP ksp, PC *pc);
 PetscErrorCode KSPSetTolerances(KSP ksp, PetscReal rtol, PetscReal abstol, PetscReal dtol, PetscInt maxits);
 PetscErrorCode KSPSetInitialGuessNonzero(KSP ksp, PetscBool flg);
 PetscErrorCode KSPSetNormType(KSP ksp, KSPNormType normtype);
+PetscErrorCode KSPSetPCSide(KSP ksp, PCSide side);   /* -ksp_pc_side <left|right>; right: KSPGMRES only */
 PetscErrorCode KSPSetOptionsPrefix(KSP ksp, const char prefix[]);
 PetscErrorCode KSPSetFromOptions(KSP ksp);   /* -ksp_type -ksp_rtol -ksp_atol -ksp_max_it -ksp_gmres_restart -ksp_gmres_cgs_refinement_type -pc_type -sub_* */
 PetscErrorCode KSPGMRESSetRestart(KSP ksp, PetscInt restart);

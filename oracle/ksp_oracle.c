@@ -27,6 +27,7 @@ typedef struct solver_s {
   double rtol, abstol, dtol;
   int max_it, restart, refine_always, guess_nonzero, cg_single;
   int norm_type;   /* KSPNormType: 0 none, 1 preconditioned (default), 2 unpreconditioned, 3 natural (petscksp.h) */
+  int pc_right;    /* PC_RIGHT (GMRES only): A B y = b, x = B y; the norm is then the unpreconditioned one */
   int n;
   const int *ai, *aj;
   const double *aa;
@@ -198,7 +199,10 @@ static void pc_apply(solver *s, const double *x, double *y) {
 
 static void mat_mult(solver *s, const double *x, double *y) { orc_spmv_csr(s->n, s->ai, s->aj, s->aa, x, y); }
 /* KSP_PCApplyBAorAB, PC_LEFT branch of PCApplyBAorAB precon.c:620-622 */
-static void pc_apply_BA(solver *s, const double *x, double *y, double *w) { mat_mult(s, x, w); pc_apply(s, w, y); }
+static void pc_apply_BA(solver *s, const double *x, double *y, double *w) {
+  if (s->pc_right) { pc_apply(s, x, w); mat_mult(s, w, y); }   /* PC_RIGHT branch, precon.c:617-619 */
+  else { mat_mult(s, x, w); pc_apply(s, w, y); }
+}
 
 /* KSPDefaultConverged, src/ksp/ksp/interface/iterativ.c:702-780 (left PC; the norm of the right-hand side for a
  * nonzero guess follows the norm type, :718-737); KSP_NORM_NONE installs KSPSkipConverged (itcreate.c:228-229,
@@ -209,7 +213,7 @@ static void converged(solver *s, int n, double rnorm, const double *b) {
   if (!n) {
     if (s->guess_nonzero) {
       double snorm = 0.0;
-      if (s->norm_type == 2) orc_vec_norm((size_t)s->n, 1, b, &snorm);
+      if (s->norm_type == 2 || s->pc_right) orc_vec_norm((size_t)s->n, 1, b, &snorm);
       else {
         double *z = (double *)malloc(sizeof(double) * (size_t)s->n);
         pc_apply(s, b, z);
@@ -228,17 +232,19 @@ static void converged(solver *s, int n, double rnorm, const double *b) {
   else if (rnorm >= s->dtol * s->rnorm0) s->reason = R_DIVERGED_DTOL;
 }
 
-/* KSPInitialResidual, src/ksp/ksp/interface/itres.c:39-73 (PC_LEFT) */
+/* KSPInitialResidual, src/ksp/ksp/interface/itres.c:39-73 (PC_LEFT: B(b - A x); PC_RIGHT: b - A x) */
 static void initial_residual(solver *s, const double *x, double *vt1, double *vt2, double *vres, const double *b) {
   size_t n = (size_t)s->n;
   if (s->guess_nonzero) {
     mat_mult(s, x, vt1);
     orc_vec_copy(n, b, vt2);
     orc_vec_axpy(n, -1.0, vt1, vt2);
-    pc_apply(s, vt2, vres);
+    if (s->pc_right) orc_vec_copy(n, vt2, vres);
+    else pc_apply(s, vt2, vres);
   } else {
     orc_vec_copy(n, b, vt2);
-    pc_apply(s, b, vres);
+    if (s->pc_right) orc_vec_copy(n, b, vres);
+    else pc_apply(s, b, vres);
   }
 }
 
@@ -335,6 +341,7 @@ static void gmres_build_soln(solver *s, gm *g, double *X, int it) {   /* gmres.c
   }
   orc_vec_set(n, 0.0, g->temp);
   orc_vec_maxpy(n, it + 1, g->nrs, (const double *const *)g->vv, g->temp);
+  if (s->pc_right) { pc_apply(s, g->temp, g->temp_matop); orc_vec_copy(n, g->temp_matop, g->temp); }   /* KSPUnwindPreconditioner */
   orc_vec_axpy(n, 1.0, g->temp, X);
 }
 
@@ -505,7 +512,7 @@ int orc_ksp_solve(const orc_ksp_opts *o, int n, const int *ai, const int *aj, co
   memset(&S, 0, sizeof(S));
   S.ksp_type = o->ksp_type; S.pc_type = o->pc_type;
   S.rtol = o->rtol; S.abstol = o->abstol; S.dtol = o->dtol; S.max_it = o->max_it;
-  S.restart = o->restart; S.refine_always = o->refine_always; S.guess_nonzero = o->guess_nonzero; S.cg_single = o->cg_single; S.norm_type = o->norm_type;
+  S.restart = o->restart; S.refine_always = o->refine_always; S.guess_nonzero = o->guess_nonzero; S.cg_single = o->cg_single; S.norm_type = o->norm_type; S.pc_right = (o->pc_right && o->ksp_type == ORC_KSP_GMRES);
   S.n = n; S.ai = ai; S.aj = aj; S.aa = aa;
   S.nblocks = o->nblocks; S.blk = o->blk;
   S.hist = hist; S.hist_cap = hist_cap; S.nhist = 0;

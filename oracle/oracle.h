@@ -101,6 +101,7 @@ typedef struct {
   int sub_max_it;
   int cg_single;          /* -ksp_cg_single_reduction (cg.c:116-122,200-203,263-270) */
   int norm_type;          /* KSPNormType for CG (cg.c:136-161): 0 none, 1 preconditioned (default), 2 unpreconditioned, 3 natural */
+  int pc_right;           /* -ksp_pc_side right (GMRES): KSPInitialResidual itres.c:55-64, PCApplyBAorAB precon.c:617, gmres.c:343-346 */
 } orc_ksp_opts;
 void orc_ksp_default_opts(orc_ksp_opts *o);
 /* Solves A x = b.  hist[0..] receives the residual norms the monitor would print (hist_cap entries

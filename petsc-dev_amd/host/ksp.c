@@ -63,6 +63,13 @@ PetscErrorCode KSPSetTolerances(KSP ksp, PetscReal rtol, PetscReal abstol, Petsc
 }
 PetscErrorCode KSPSetInitialGuessNonzero(KSP ksp, PetscBool flg) { KSPValid(ksp); ksp->guess_zero = (PetscBool)!flg; return 0; }
 PetscErrorCode KSPSetNormType(KSP ksp, KSPNormType t) { KSPValid(ksp); ksp->normtype = t; return 0; }
+PetscErrorCode KSPSetPCSide(KSP ksp, PCSide side) {   /* itcreate.c KSPSetPCSide */
+  KSPValid(ksp);
+  if (side != PC_LEFT && side != PC_RIGHT) SETERRQ(ksp->comm, PETSC_ERR_SUP, "only left and right preconditioning are on the ported path");
+  ksp->pc_side = side;
+  if (ksp->setupcalled == 2) ksp->setupcalled = 1;
+  return 0;
+}
 PetscErrorCode KSPSetOptionsPrefix(KSP ksp, const char prefix[]) {
   KSPValid(ksp);
   snprintf(ksp->prefix, sizeof(ksp->prefix), "%s", prefix ? prefix : "");
@@ -82,6 +89,12 @@ PetscErrorCode KSPSetFromOptions(KSP ksp) {   /* itcl.c KSPSetFromOptions, the o
   ierr = PetscOptionsGetReal(ksp->prefix, "-ksp_atol", &r, &set);CHKERRQ(ierr); if (set) ksp->abstol = r;
   ierr = PetscOptionsGetReal(ksp->prefix, "-ksp_divtol", &r, &set);CHKERRQ(ierr); if (set) ksp->divtol = r;
   ierr = PetscOptionsGetString(ksp->prefix, "-ksp_initial_guess_nonzero", t, sizeof(t), &set);CHKERRQ(ierr); if (set) ksp->guess_zero = PETSC_FALSE;
+  ierr = PetscOptionsGetString(ksp->prefix, "-ksp_pc_side", t, sizeof(t), &set);CHKERRQ(ierr);
+  if (set) {
+    if (!strcmp(t, "left")) { ierr = KSPSetPCSide(ksp, PC_LEFT);CHKERRQ(ierr); }
+    else if (!strcmp(t, "right")) { ierr = KSPSetPCSide(ksp, PC_RIGHT);CHKERRQ(ierr); }
+    else SETERRQ(ksp->comm, PETSC_ERR_ARG_UNKNOWN_TYPE, "Unknown preconditioning side %s", t);
+  }
   ierr = PetscOptionsGetString(ksp->prefix, "-ksp_norm_type", t, sizeof(t), &set);CHKERRQ(ierr);   /* itcl.c: KSPNormTypes[] */
   if (set) {
     if (!strcmp(t, "none")) ksp->normtype = KSP_NORM_NONE;
@@ -117,14 +130,23 @@ PetscErrorCode KSPSetUp(KSP ksp) {   /* itfunc.c:175 */
   if (ksp->setupcalled == 2) return 0;
   if (!ksp->pc || !ksp->pc->mat) SETERRQ(ksp->comm, PETSC_ERR_ARG_WRONGSTATE, "Matrix must be set first");
   if (!ksp->setupcalled) { ierr = (*ksp->ops->setup)(ksp);CHKERRQ(ierr); }
-  /* norm type / side defaults (KSPSetUpNorms_Private): preconditioned norm, left PC for the three methods */
-  if (ksp->normtype == KSP_NORM_DEFAULT) ksp->normtype = strcmp(ksp->type_name, KSPPREONLY) ? KSP_NORM_PRECONDITIONED : KSP_NORM_NONE;
+  /* norm type / side defaults (KSPSetUpNorms_Private, itcreate.c): left PC + preconditioned norm; right PC (GMRES
+   * only here) goes with the unpreconditioned norm, which is what its recurrence produces */
   if (ksp->pc_side == PC_SIDE_DEFAULT) ksp->pc_side = PC_LEFT;
-  /* KSPSetNormType (itcreate.c:196-205): every norm with KSPCG; the others here run the preconditioned norm */
-  if (ksp->normtype != KSP_NORM_PRECONDITIONED && ksp->normtype != KSP_NORM_NONE && strcmp(ksp->type_name, KSPCG))
-    SETERRQ(ksp->comm, PETSC_ERR_SUP, "KSP %s: only the preconditioned residual norm is on the ported path (unpreconditioned/natural: KSPCG)", ksp->type_name);
-  if (ksp->normtype == KSP_NORM_NONE && strcmp(ksp->type_name, KSPCG) && strcmp(ksp->type_name, KSPBCGS) && strcmp(ksp->type_name, KSPPREONLY))
-    SETERRQ(ksp->comm, PETSC_ERR_SUP, "KSP %s with KSP_NORM_NONE is outside the ported path", ksp->type_name);
+  if (ksp->pc_side == PC_RIGHT && strcmp(ksp->type_name, KSPGMRES))
+    SETERRQ(ksp->comm, PETSC_ERR_SUP, "KSP %s with right preconditioning is outside the ported path (KSPGMRES has it)", ksp->type_name);
+  if (ksp->normtype == KSP_NORM_DEFAULT)
+    ksp->normtype = !strcmp(ksp->type_name, KSPPREONLY) ? KSP_NORM_NONE : (ksp->pc_side == PC_RIGHT ? KSP_NORM_UNPRECONDITIONED : KSP_NORM_PRECONDITIONED);
+  if (!strcmp(ksp->type_name, KSPGMRES)) {
+    if (ksp->normtype != (ksp->pc_side == PC_RIGHT ? KSP_NORM_UNPRECONDITIONED : KSP_NORM_PRECONDITIONED))
+      SETERRQ(ksp->comm, PETSC_ERR_SUP, "KSPGMRES: the norm follows the side (left: preconditioned, right: unpreconditioned)");
+  } else {
+    /* KSPSetNormType (itcreate.c:196-205): every norm with KSPCG; BiCGStab: preconditioned or none */
+    if (ksp->normtype != KSP_NORM_PRECONDITIONED && ksp->normtype != KSP_NORM_NONE && strcmp(ksp->type_name, KSPCG))
+      SETERRQ(ksp->comm, PETSC_ERR_SUP, "KSP %s: only the preconditioned residual norm is on the ported path (unpreconditioned/natural: KSPCG)", ksp->type_name);
+    if (ksp->normtype == KSP_NORM_NONE && strcmp(ksp->type_name, KSPCG) && strcmp(ksp->type_name, KSPBCGS) && strcmp(ksp->type_name, KSPPREONLY))
+      SETERRQ(ksp->comm, PETSC_ERR_SUP, "KSP %s with KSP_NORM_NONE is outside the ported path", ksp->type_name);
+  }
   ierr = PCSetUp(ksp->pc);CHKERRQ(ierr);
   ksp->setupcalled = 2;
   return 0;

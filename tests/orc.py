@@ -227,7 +227,7 @@ class KspOpts(C.Structure):
                 ("dtol", C.c_double), ("max_it", C.c_int), ("restart", C.c_int), ("refine_always", C.c_int),
                 ("guess_nonzero", C.c_int), ("nblocks", C.c_int), ("blk", pi), ("sub_ksp_type", C.c_int),
                 ("sub_pc_type", C.c_int), ("sub_rtol", C.c_double), ("sub_abstol", C.c_double),
-                ("sub_dtol", C.c_double), ("sub_max_it", C.c_int), ("cg_single", C.c_int), ("norm_type", C.c_int)]
+                ("sub_dtol", C.c_double), ("sub_max_it", C.c_int), ("cg_single", C.c_int), ("norm_type", C.c_int), ("pc_right", C.c_int)]
 
 
 KSP = dict(cg=0, gmres=1, bcgs=2, preonly=3)

@@ -450,6 +450,34 @@ def test_ksp_bcgs_as_smoother_without_norms(P):
     assert np.linalg.norm(x0 - xr) <= 1e-10 * np.linalg.norm(xr)
 
 
+@pytest.mark.parametrize("pc", ["jacobi", "ilu", "bjacobi"])
+def test_ksp_gmres_right_preconditioning(P, pc):
+    """-ksp_pc_side right with KSPGMRES (KSPInitialResidual itres.c:55-64, PCApplyBAorAB precon.c:617, the unwinding in
+    KSPGMRESBuildSoln gmres.c:343-346): the monitored norm is the TRUE residual norm; history and solution against the
+    oracle's restatement, with a restart inside the solve and a nonzero initial guess."""
+    ai, aj, aa = pb.lap2d(23, 19)
+    n = ai.size - 1
+    aa = aa * (1.0 + 0.3 * np.sin(np.arange(aa.size)))
+    rows = np.repeat(np.arange(n), np.diff(ai))
+    aa[aj == rows] = 5.0 + np.cos(np.arange(n))
+    xs = np.cos(0.3 * np.arange(n))
+    b = orc.spmv(ai, aj, aa, xs)
+    x0 = 0.1 * np.sin(np.arange(n))
+    x, h, its, reason = solve(P, ai, aj, aa, b, "gmres", pc, x0=x0, opts="-ksp_pc_side right -ksp_gmres_restart 7", rtol=1e-9)
+    okw = dict(blocks=[0, n], sub_ksp="preonly", sub_pc="ilu") if pc == "bjacobi" else {}
+    xr, hr, itsr, rr = orc.ksp_solve(ai, aj, aa, b, ksp="gmres", pc=pc, x0=x0, pc_right=1, restart=7, rtol=1e-9, **okw)
+    assert reason == rr == 2 and abs(its - itsr) <= 1 and its > 7
+    k = min(len(h), len(hr))
+    assert np.allclose(h[:k], hr[:k], rtol=1e-6, atol=1e-14 * hr[0])
+    assert np.linalg.norm(x - xr) <= 1e-7 * np.linalg.norm(xr)
+    # the first monitored value is the true residual norm of the initial guess
+    assert abs(h[0] - np.linalg.norm(b - orc.spmv(ai, aj, aa, x0))) <= 1e-12 * np.linalg.norm(b)
+    # right preconditioning is refused where it is not ported
+    with pytest.raises(P.PetscError):
+        solve(P, ai, aj, aa, b, "cg", pc, opts="-ksp_pc_side right", rtol=1e-9)
+    P.lib().PetscOptionsClear()
+
+
 def test_ksp_cg_single_reduction(P):
     """-ksp_cg_single_reduction (cg.c:116-122,200-203,263-270): two reductions per iteration instead of
     three (VecMDot(2) for delta and beta), A*p by recurrence; same op sequence as the oracle's restatement"""
