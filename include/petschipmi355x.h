@@ -279,6 +279,9 @@ PetscErrorCode KSPGetConvergedReason(KSP ksp, KSPConvergedReason *reason);
 PetscErrorCode KSPSetResidualHistory(KSP ksp, PetscReal a[], PetscInt na, PetscBool reset);
 PetscErrorCode KSPGetResidualHistory(KSP ksp, PetscReal *a[], PetscInt *na);
 /* the residual norms KSPMonitor would be called with (what -ksp_monitor_short prints) */
+/* -ksp_monitor / -ksp_monitor_short (iterativ.c:178,484): the reference's text, on rank 0 */
+PetscErrorCode KSPMonitorDefault(KSP ksp, PetscInt n, PetscReal rnorm, void *dummy);
+PetscErrorCode KSPMonitorDefaultShort(KSP ksp, PetscInt n, PetscReal rnorm, void *dummy);
 PetscErrorCode KSPMonitorSet(KSP ksp, PetscErrorCode (*monitor)(KSP, PetscInt, PetscReal, void *), void *mctx, PetscErrorCode (*destroy)(void **));
 PetscErrorCode KSPDestroy(KSP *ksp);
 

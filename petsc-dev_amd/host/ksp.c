@@ -3,6 +3,8 @@
  * macros include/petsc-private/kspimpl.h:181-188).  Only host scalars live here; every vector
  * operation dispatches through the Vec/Mat function tables to the HIP kernels. */
 #include "petscimpl.h"
+#include <stdio.h>
+static const char *ksp_reason_name(KSPConvergedReason r);
 
 #define KSPValid(k) do { if (!(k)) SETERRQ(0, PETSC_ERR_ARG_NULL, "Null KSP"); } while (0)
 
@@ -89,6 +91,12 @@ PetscErrorCode KSPSetFromOptions(KSP ksp) {   /* itcl.c KSPSetFromOptions, the o
   ierr = PetscOptionsGetReal(ksp->prefix, "-ksp_atol", &r, &set);CHKERRQ(ierr); if (set) ksp->abstol = r;
   ierr = PetscOptionsGetReal(ksp->prefix, "-ksp_divtol", &r, &set);CHKERRQ(ierr); if (set) ksp->divtol = r;
   ierr = PetscOptionsGetString(ksp->prefix, "-ksp_initial_guess_nonzero", t, sizeof(t), &set);CHKERRQ(ierr); if (set) ksp->guess_zero = PETSC_FALSE;
+  ierr = PetscOptionsGetString(ksp->prefix, "-ksp_monitor", t, sizeof(t), &set);CHKERRQ(ierr);
+  if (set) { ierr = KSPMonitorSet(ksp, KSPMonitorDefault, NULL, NULL);CHKERRQ(ierr); }
+  ierr = PetscOptionsGetString(ksp->prefix, "-ksp_monitor_short", t, sizeof(t), &set);CHKERRQ(ierr);
+  if (set) { ierr = KSPMonitorSet(ksp, KSPMonitorDefaultShort, NULL, NULL);CHKERRQ(ierr); }
+  ierr = PetscOptionsGetString(ksp->prefix, "-ksp_converged_reason", t, sizeof(t), &set);CHKERRQ(ierr);
+  if (set) ksp->printreason = PETSC_TRUE;
   ierr = PetscOptionsGetString(ksp->prefix, "-ksp_pc_side", t, sizeof(t), &set);CHKERRQ(ierr);
   if (set) {
     if (!strcmp(t, "left")) { ierr = KSPSetPCSide(ksp, PC_LEFT);CHKERRQ(ierr); }
@@ -163,6 +171,11 @@ PetscErrorCode KSPSolve(KSP ksp, Vec b, Vec x) {   /* itfunc.c:335 */
   ksp->reason = KSP_CONVERGED_ITERATING;
   ierr = (*ksp->ops->solve)(ksp);CHKERRQ(ierr);
   if (!ksp->reason) SETERRQ(ksp->comm, PETSC_ERR_PLIB, "Internal error, solver returned without setting converged reason");
+  if (ksp->printreason && !ksp->comm->rank) {   /* -ksp_converged_reason, itfunc.c:662-668 */
+    if (ksp->reason > 0) printf("Linear solve converged due to %s iterations %d\n", ksp_reason_name(ksp->reason), (int)ksp->its);
+    else printf("Linear solve did not converge due to %s iterations %d\n", ksp_reason_name(ksp->reason), (int)ksp->its);
+    fflush(stdout);
+  }
   return 0;
 }
 PetscErrorCode KSPGetIterationNumber(KSP ksp, PetscInt *its) { KSPValid(ksp); *its = ksp->its; return 0; }
@@ -190,6 +203,34 @@ PetscErrorCode KSPMonitorSet(KSP ksp, PetscErrorCode (*monitor)(KSP, PetscInt, P
   KSPValid(ksp); (void)destroy;
   ksp->monitor = monitor; ksp->mctx = mctx;
   return 0;
+}
+/* KSPMonitorDefault / KSPMonitorDefaultShort, iterativ.c:178-195,484-503: what -ksp_monitor / -ksp_monitor_short print
+ * (rank 0 of the KSP's communicator; a prefixed, i.e. inner, solver announces itself at iteration 0) */
+PetscErrorCode KSPMonitorDefault(KSP ksp, PetscInt n, PetscReal rnorm, void *dummy) {
+  (void)dummy;
+  if (ksp->comm->rank) return 0;
+  if (n == 0 && ksp->prefix[0]) printf("  Residual norms for %s solve.\n", ksp->prefix);
+  printf("%3d KSP Residual norm %14.12e \n", (int)n, (double)rnorm);
+  fflush(stdout);
+  return 0;
+}
+PetscErrorCode KSPMonitorDefaultShort(KSP ksp, PetscInt its, PetscReal fnorm, void *dummy) {
+  (void)dummy;
+  if (ksp->comm->rank) return 0;
+  if (its == 0 && ksp->prefix[0]) printf("  Residual norms for %s solve.\n", ksp->prefix);
+  if (fnorm > 1.e-9) printf("%3d KSP Residual norm %g \n", (int)its, (double)fnorm);
+  else if (fnorm > 1.e-11) printf("%3d KSP Residual norm %5.3e \n", (int)its, (double)fnorm);
+  else printf("%3d KSP Residual norm < 1.e-11\n", (int)its);
+  fflush(stdout);
+  return 0;
+}
+static const char *ksp_reason_name(KSPConvergedReason r) {   /* KSPConvergedReasons[], dlregisksp.c:98-104 */
+  static const char *const shifted[] = {"DIVERGED_INDEFINITE_MAT", "DIVERGED_NAN", "DIVERGED_INDEFINITE_PC", "DIVERGED_NONSYMMETRIC",
+    "DIVERGED_BREAKDOWN_BICG", "DIVERGED_BREAKDOWN", "DIVERGED_DTOL", "DIVERGED_ITS", "DIVERGED_NULL", "", "CONVERGED_ITERATING",
+    "CONVERGED_RTOL_NORMAL", "CONVERGED_RTOL", "CONVERGED_ATOL", "CONVERGED_ITS", "CONVERGED_CG_NEG_CURVE", "CONVERGED_CG_CONSTRAINED",
+    "CONVERGED_STEP_LENGTH", "CONVERGED_HAPPY_BREAKDOWN", "CONVERGED_ATOL_NORMAL"};
+  int k = (int)r + 10;
+  return (k >= 0 && k < (int)(sizeof(shifted) / sizeof(shifted[0]))) ? shifted[k] : "UNKNOWN";
 }
 PetscErrorCode KSPMonitor(KSP ksp, PetscInt it, PetscReal rnorm) {
   if (ksp->monitor) { PetscErrorCode ierr = (*ksp->monitor)(ksp, it, rnorm, ksp->mctx);CHKERRQ(ierr); }

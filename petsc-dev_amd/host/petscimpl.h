@@ -288,6 +288,7 @@ struct _p_KSP {
   int setupcalled;
   PetscReal *res_hist; PetscInt res_hist_len, res_hist_max; PetscBool res_hist_reset; PetscReal *res_hist_alloc;
   PetscErrorCode (*monitor)(KSP, PetscInt, PetscReal, void *); void *mctx;
+  PetscBool printreason;   /* -ksp_converged_reason */
   void *data;
 };
 PetscErrorCode KSPDefaultConverged(KSP ksp, PetscInt n, PetscReal rnorm, KSPConvergedReason *reason);

@@ -478,6 +478,33 @@ def test_ksp_gmres_right_preconditioning(P, pc):
     P.lib().PetscOptionsClear()
 
 
+def test_monitor_text_is_the_reference_output(P, capfd):
+    """-ksp_monitor_short / -ksp_converged_reason print the reference's own text (KSPMonitorDefaultShort iterativ.c:484,
+    itfunc.c:662): the stdout of `ex2 -m 5 -n 5 -ksp_monitor_short -ksp_gmres_cgs_refinement_type refine_always`
+    replayed here must equal the monitor lines of output/ex2_1.out character for character, and CG + Jacobi on ex2's
+    100 x 100 grid must print config 1's first residuals."""
+    ai, aj, aa = pb.lap2d(5, 5)
+    u = np.ones(25)
+    b = orc.spmv(ai, aj, aa, u)
+    capfd.readouterr()
+    x, h, its, reason = solve(P, ai, aj, aa, b, "gmres", "ilu", opts="-ksp_monitor_short -ksp_converged_reason -ksp_gmres_cgs_refinement_type refine_always",
+                              rtol=1e-2 / 36, abstol=1e-50)
+    out = capfd.readouterr().out.splitlines()
+    gold = open(os.path.join(G, "ksp_tutorials", "ex2_1.out")).read().splitlines()
+    assert out[:5] == gold[:5]
+    assert out[5] == "Linear solve converged due to CONVERGED_RTOL iterations 4"
+    assert "Norm of error %g iterations %d" % (np.linalg.norm(x - u), its) == gold[5]
+    ai, aj, aa = pb.lap2d(100, 100)
+    b = orc.spmv(ai, aj, aa, np.ones(10000))
+    solve(P, ai, aj, aa, b, "cg", "jacobi", opts="-ksp_monitor_short", rtol=1e-2 / (101 * 101), abstol=1e-50)
+    out = capfd.readouterr().out.splitlines()
+    assert out[:4] == ["  0 KSP Residual norm 5.04975 ", "  1 KSP Residual norm 2.54845 ", "  2 KSP Residual norm 1.81892 ", "  3 KSP Residual norm 1.67695 "]
+    assert out[160] == "160 KSP Residual norm 4.47805e-06 " and len(out) == 161
+    solve(P, ai, aj, aa, b, "cg", "jacobi", opts="-ksp_monitor", rtol=1e-2 / (101 * 101), abstol=1e-50, max_it=1)
+    out = capfd.readouterr().out.splitlines()
+    assert out[0].startswith("  0 KSP Residual norm 5.04975") and out[0].endswith("e+00 ") and len(out[0]) == len("  0 KSP Residual norm 5.049752469181e+00 ")
+
+
 def test_ksp_cg_single_reduction(P):
     """-ksp_cg_single_reduction (cg.c:116-122,200-203,263-270): two reductions per iteration instead of
     three (VecMDot(2) for delta and beta), A*p by recurrence; same op sequence as the oracle's restatement"""
