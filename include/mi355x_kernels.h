@@ -36,6 +36,7 @@ int  mi355x_set_device(int dev);
 int  mi355x_get_device(int *dev);
 int  mi355x_device_name(char *buf, size_t len);
 int  mi355x_device_synchronize(void);
+int  mi355x_mem_info(size_t *free_bytes, size_t *total_bytes);   /* hipMemGetInfo of the current device */
 
 int  mi355x_handle_create(mi355x_handle_t *h);
 int  mi355x_handle_destroy(mi355x_handle_t h);

@@ -20,6 +20,7 @@ KERNEL_API = {
     "mi355x_get_device": [pi32],
     "mi355x_device_name": [C.c_char_p, sz],
     "mi355x_device_synchronize": [],
+    "mi355x_mem_info": [C.POINTER(sz), C.POINTER(sz)],
     "mi355x_handle_create": [C.POINTER(vp)],
     "mi355x_handle_destroy": [vp],
     "mi355x_handle_synchronize": [vp],

@@ -22,6 +22,7 @@ int mi355x_device_name(char *buf, size_t len) {
   return 0;
 }
 int mi355x_device_synchronize(void) { MI355X_TRY(hipDeviceSynchronize()); return 0; }
+int mi355x_mem_info(size_t *free_bytes, size_t *total_bytes) { MI355X_TRY(hipMemGetInfo(free_bytes, total_bytes)); return 0; }
 
 int mi355x_handle_create(mi355x_handle_t *out) {
   mi355x_handle_s *h = new mi355x_handle_s();

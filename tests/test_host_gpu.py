@@ -681,3 +681,45 @@ def test_cg_jacobi_full_size_properties(P):
     r = one.duplicate(); A.mult(x, r)
     L.VecAYPX(r.h, -1.0, b.h)                          # r = b - A x
     assert abs(r.norm() / 6.0 - h[-1]) <= 1e-6 * h[0]
+
+
+def test_no_device_memory_leak_over_object_lifetimes(P):
+    """create / solve / destroy cycles of every object kind on the path (Seq and MPI matrices, BAIJ, KSP with each PC
+    incl. ILU's hipGraph and the transpose cache) must give the device memory back: hipMemGetInfo after 30 cycles
+    equals the value after the first few (allocator pools settle in the warm-up cycles)."""
+    import ctypes as C
+    import gc
+    L = P.lib()
+    k = P.load_kernels()
+
+    def free_bytes():
+        f, t = C.c_size_t(), C.c_size_t()
+        assert k.mi355x_mem_info(C.byref(f), C.byref(t)) == 0
+        return f.value
+
+    ai, aj, aa = P.gen_poisson7(24, 20, 16)
+    n = ai.size - 1
+    b = np.cos(0.3 * np.arange(n))
+
+    def cycle(i):
+        for ksp, pc in (("cg", "jacobi"), ("gmres", "ilu"), ("bcgs", "bjacobi"), ("cg", "none")):
+            solve(P, ai, aj, aa, b, ksp, pc, rtol=1e-6, mpi=(i % 2 == 1 and pc != "ilu"))   # PCILU wants a sequential matrix, as in the reference
+        A = P.Mat.from_csr(ai, aj, aa)
+        x = P.Vec.from_array(b, comm=L.COMM_SELF); y = x.duplicate()
+        L.MatMultTranspose(A.h, x.h, y.h)
+        bi = np.arange(0, 201, dtype=np.int32); bj = np.arange(200, dtype=np.int32)
+        Ab = P.Mat.from_bsr(3, bi, bj, np.ones(200 * 9))
+        xb = P.Vec.from_array(np.ones(600), comm=L.COMM_SELF); yb = xb.duplicate()
+        Ab.mult(xb, yb)
+        for o in (A, x, y, Ab, xb, yb):
+            o.destroy()
+        gc.collect()
+        k.mi355x_device_synchronize()
+
+    for i in range(4):
+        cycle(i)
+    base = free_bytes()
+    for i in range(30):
+        cycle(i)
+    after = free_bytes()
+    assert after >= base - (1 << 20), "device memory shrank by %d bytes over 30 object life cycles" % (base - after)
