@@ -12,7 +12,8 @@ def kernels_lib_path():
 
 
 def host_lib_path():
-    return os.path.join(PKG, "host", "libpetschipmi355x.so")
+    # PETSC_HIPMI355X_HOST_LIB selects an alternative build of the host library (e.g. an AddressSanitizer build for the CPU tests)
+    return os.environ.get("PETSC_HIPMI355X_HOST_LIB") or os.path.join(PKG, "host", "libpetschipmi355x.so")
 
 
 def _make(directory, jobs=8):
