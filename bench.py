@@ -135,7 +135,7 @@ def main():
     noff = C.c_int(0)
     L.MatHIPMI355XGetIndexCompression(timed, C.byref(noff))
     kernel_name = ("spmv_csr_rowblock_idx8_kernel (CSR + 1-byte offset-dictionary column indices, %d offsets; 'achieved' uses the CSR algorithmic bytes)" % noff.value) if noff.value else "spmv_csr_rowblock_kernel"
-    staged = world > 1 and os.environ.get("MI355X_STAGED", "0") == "1"
+    staged = world > 1 and PD.last_transport != "rccl"
     out = {
         "metric": "KSP CG+Jacobi iterations/s x unknowns (3-D 7-pt Poisson, %d^3 rows per GPU); ksp_its_per_sec and spmv_gbps are BASELINE.json's two quantities" % n,
         "value": round(value, 3), "unit": "Mdof-it/s",

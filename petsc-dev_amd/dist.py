@@ -6,6 +6,7 @@ path -- halo exchange and scalar all-reduces on device buffers -- is RCCL over x
 (include/mi355x_comm.h), never through Python."""
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -70,6 +71,42 @@ def make_comm(rank, size, allgather_bytes, allreduce_array, barrier, exchange=No
     return comm
 
 
+last_transport = "single"   # what the last torch_comm() call ended up with: "single", "rccl" or "host-staged"
+
+
+def _rccl_self_test(k, dcomm, rank, size):
+    """One all-reduce and one ring send/recv on a fresh communicator, checked on the host; returns "" or what failed."""
+    h = C.c_void_p()
+    if k.mi355x_handle_create(C.byref(h)):
+        return "handle"
+    buf = C.c_void_p()
+    try:
+        if k.mi355x_malloc(C.byref(buf), 64):
+            return "malloc"
+        v = np.array([1.0 + rank, -1.0, 0.0, 0.0])
+        k.mi355x_memcpy_h2d(h, buf, v.ctypes.data, v.nbytes)
+        rc = k.mi355x_comm_allreduce_sum(dcomm, h, buf, 1)
+        if rc:
+            return "ncclAllReduce: %s" % k.mi355x_comm_error_string(rc).decode()
+        nxt, prv = (rank + 1) % size, (rank - 1) % size
+        rc = k.mi355x_comm_group_start()
+        rc = rc or k.mi355x_comm_recv(dcomm, h, C.c_void_p(buf.value + 16), 1, prv)
+        rc = rc or k.mi355x_comm_send(dcomm, h, C.c_void_p(buf.value + 8), 1, nxt)
+        rc2 = k.mi355x_comm_group_end()
+        if rc or rc2:
+            return "ncclSend/Recv: %s" % k.mi355x_comm_error_string(rc or rc2).decode()
+        k.mi355x_memcpy_d2h(h, v.ctypes.data, buf, v.nbytes)
+        if k.mi355x_handle_synchronize(h):
+            return "stream synchronise after the self test"
+        if v[0] != size * (size + 1) / 2.0 or v[2] != -1.0:
+            return "self test values %r" % (v.tolist(),)
+        return ""
+    finally:
+        if buf:
+            k.mi355x_free(buf)
+        k.mi355x_handle_destroy(h)
+
+
 def torch_comm(device_comm=True):
     """PetscComm over the default torch.distributed (gloo) group; optionally attaches an RCCL communicator."""
     import torch
@@ -118,7 +155,27 @@ def torch_comm(device_comm=True):
             raise RuntimeError("hipSetDevice(%d) failed: %s" % (dev, k.mi355x_error_string(rc).decode()))
         dcomm = C.c_void_p()
         rc = k.mi355x_comm_init_rank(C.byref(dcomm), size, rank, obj[0])
-        if rc:
-            raise RuntimeError("ncclCommInitRank failed: %s" % k.mi355x_comm_error_string(rc).decode())
-        L.PetscCommSetDeviceComm(comm, dcomm)
+        why = "" if rc == 0 else "ncclCommInitRank: %s" % k.mi355x_comm_error_string(rc).decode()
+        if rc == 0:
+            why = _rccl_self_test(k, dcomm, rank, size)
+        # every rank must take the same transport: agree over gloo
+        ok = torch.tensor([0 if why else 1], dtype=torch.int32)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok[0]) == 1:
+            L.PetscCommSetDeviceComm(comm, dcomm)
+            transport = "rccl"
+        else:
+            # LOUD: the halo and the reductions then travel device -> host -> gloo -> host -> device (the reference's own
+            # CUSP arrangement); still the GPU compute path, but not the transport this library is built for
+            print("[petsc-hipmi355x] rank %d: RCCL communicator unusable (%s); ALL ranks fall back to the host-staged transport"
+                  % (rank, why or "another rank failed"), file=sys.stderr, flush=True)
+            if rc == 0:
+                k.mi355x_comm_destroy(dcomm)
+            transport = "host-staged"
+    elif size > 1:
+        transport = "host-staged"
+    else:
+        transport = "single"
+    global last_transport
+    last_transport = transport
     return comm

@@ -366,6 +366,9 @@ def test_device_collectives_on_a_one_rank_rccl_communicator(P):
     assert rc == 0, k.mi355x_comm_error_string(rc).decode()
     L.PetscCommSetDeviceComm(comm, dcomm)
     try:
+        # the launcher's self test: one all-reduce and one grouped ncclSend/ncclRecv (to itself on one rank) through the
+        # C wrappers of include/mi355x_comm.h
+        assert PD._rccl_self_test(k, dcomm, 0, 1) == ""
         ai, aj, aa = pb.lap2d(33, 29)
         n = ai.size - 1
         b = orc.spmv(ai, aj, aa, np.cos(0.3 * np.arange(n)))
