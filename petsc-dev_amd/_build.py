@@ -27,3 +27,5 @@ def build_all(oracle=True):
     _make(os.path.join(PKG, "host"))
     if oracle:
         _make(os.path.join(ROOT, "oracle"))
+    if os.path.isdir(os.path.join(ROOT, "examples")):
+        _make(os.path.join(ROOT, "examples"))      # standalone C user programs on the host library

@@ -726,3 +726,26 @@ def test_no_device_memory_leak_over_object_lifetimes(P):
         cycle(i)
     after = free_bytes()
     assert after >= base - (1 << 20), "device memory shrank by %d bytes over 30 object life cycles" % (base - after)
+
+
+def test_standalone_c_program_reproduces_the_tutorial_outputs(built):
+    """examples/poisson2d.c -- plain C on the PETSc-named API, MatSetValues assembly, options from the command line, no
+    Python in the loop -- run as the reference's makefile runs its ex2 tutorial: the complete stdout must equal
+    output/ex2_1.out (default GMRES + ILU(0) on one rank), and BASELINE.json's configs[0] must give 160 iterations."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(G), "..", "examples", "poisson2d")
+    exe = os.path.abspath(exe)
+    assert os.path.exists(exe), "examples/poisson2d was not built (python -c 'import __graft_entry__ as g; g.build()')"
+    r = subprocess.run([exe, "-m", "5", "-n", "5", "-ksp_monitor_short", "-ksp_gmres_cgs_refinement_type", "refine_always"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout == open(os.path.join(G, "ksp_tutorials", "ex2_1.out")).read()
+    r = subprocess.run([exe, "-m", "100", "-n", "100", "-ksp_type", "cg", "-pc_type", "jacobi", "-ksp_converged_reason"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = r.stdout.splitlines()
+    assert lines[0] == "Linear solve converged due to CONVERGED_RTOL iterations 160"
+    assert lines[1].startswith("Norm of error 5.7078") and lines[1].endswith("iterations 160")
+    # an unknown type is an error message and a non-zero exit, not a crash
+    r = subprocess.run([exe, "-ksp_type", "nosuchmethod"], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "nosuchmethod" in r.stderr
