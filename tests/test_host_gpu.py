@@ -740,6 +740,11 @@ def test_standalone_c_program_reproduces_the_tutorial_outputs(built):
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout == open(os.path.join(G, "ksp_tutorials", "ex2_1.out")).read()
+    # ex2_bjacobi.out (makefile:350: 4 ranks, ONE block spanning them = the whole matrix; same arithmetic on one rank)
+    r = subprocess.run([exe, "-pc_type", "bjacobi", "-pc_bjacobi_blocks", "1", "-ksp_monitor_short", "-sub_pc_type", "jacobi", "-sub_ksp_type", "gmres"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout == open(os.path.join(G, "ksp_tutorials", "ex2_bjacobi.out")).read()
     r = subprocess.run([exe, "-m", "100", "-n", "100", "-ksp_type", "cg", "-pc_type", "jacobi", "-ksp_converged_reason"],
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
