@@ -186,6 +186,8 @@ int mi355x_spmv_csr_add(mi355x_handle_t h, mi355x_spmv_plan_t plan, const int *a
  * kernels applied to an explicit transpose whose rows list contributions in increasing
  * original-row order (the order the reference's scatter loop adds them in). */
 
+/* MatDiagonalScale_SeqAIJ  src/mat/impls/aij/seq/aij.c:2055   a[k] = (a[k] * l[row]) * r[col]; l or r may be NULL */
+int mi355x_csr_diagonal_scale(mi355x_handle_t h, int m, const int *ai, const int *aj, double *aa, const double *l, const double *r);
 /* MatGetDiagonal_SeqAIJ  src/mat/impls/aij/seq/aij.c:1040   d[r] = A[r,r] or 0 */
 int mi355x_csr_get_diagonal(mi355x_handle_t h, int m, const int *ai, const int *aj, const double *aa, double *d);
 

@@ -224,6 +224,7 @@ PetscErrorCode MatMultTransposeAdd(Mat A, Vec x, Vec y, Vec z);
 PetscErrorCode MatGetDiagonal(Mat A, Vec d);
 PetscErrorCode MatScale(Mat A, PetscScalar a);
 PetscErrorCode MatZeroEntries(Mat A);
+PetscErrorCode MatDiagonalScale(Mat A, Vec l, Vec r);   /* A <- diag(l) A diag(r); l or r may be NULL (aij.c:2055, mpiaij.c:2183) */
 /* introspection for parity tests: host CSR of a SeqAIJ block; MPIAIJ pieces (Mat_MPIAIJ, mpiaij.h:35-77) */
 PetscErrorCode MatSeqAIJGetArrays(Mat A, PetscInt *m, const PetscInt **i, const PetscInt **j, const PetscScalar **a);
 PetscErrorCode MatMPIAIJGetSeqAIJ(Mat A, Mat *Ad, Mat *Ao, const PetscInt **garray);
@@ -231,6 +232,7 @@ PetscErrorCode MatMPIAIJGetScatter(Mat A, VecScatter *ctx, Vec *lvec, PetscInt *
 /* per-MatMult device timing (HIP events on the compute stream around the SpMV launches) for bench.py */
 PetscErrorCode MatHIPMI355XSetTiming(Mat A, PetscBool on);
 PetscErrorCode MatHIPMI355XGetTiming(Mat A, PetscInt *nlaunches, PetscLogDouble *total_ms);
+PetscErrorCode MatHIPMI355XGetUploadCount(Mat A, PetscInt *n);   /* value uploads host -> device of a sequential matrix so far */
 PetscErrorCode MatHIPMI355XGetIndexCompression(Mat A, PetscInt *noffsets);   /* 0: plain CSR indices; else #offsets of the 1-byte dictionary */
 
 /* ---- binary IO (PETSc binary format, big-endian; src/mat/impls/aij/seq/aij.c:4093-4157, src/vec/vec/utils/vecio.c) ---- */

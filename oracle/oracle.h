@@ -52,6 +52,7 @@ void orc_spmv_csr(int m, const int *ai, const int *aj, const double *aa, const d
 void orc_spmv_csr_add(int m, const int *ai, const int *aj, const double *aa, const double *x, const double *y, double *z); /* :1291 */
 void orc_spmv_csr_transpose(int m, int n, const int *ai, const int *aj, const double *aa, const double *x, double *y);     /* :1124 */
 void orc_spmv_csr_transpose_add(int m, int n, const int *ai, const int *aj, const double *aa, const double *x, const double *z, double *y); /* :1078 */
+void orc_csr_diagonal_scale(int m, const int *ai, const int *aj, double *aa, const double *l, const double *r);                 /* :2055 */
 void orc_csr_get_diagonal(int m, const int *ai, const int *aj, const double *aa, double *d);                    /* :1040 */
 /* inode variant (src/mat/impls/aij/seq/inode.c:392-578 mult, :3964-4034 detection) */
 int  orc_check_inode(int m, const int *ai, const int *aj, int limit, int *ns);

@@ -199,6 +199,11 @@ void orc_spmv_csr_transpose(int m, int n, const int *ai, const int *aj, const do
 }
 
 /* MatGetDiagonal_SeqAIJ, src/mat/impls/aij/seq/aij.c:1040-1073: linear search of each row, 0 if absent */
+/* MatDiagonalScale_SeqAIJ, aij.c:2055-2092: the left pass over all entries, then the right pass; either may be NULL */
+void orc_csr_diagonal_scale(int m, const int *ai, const int *aj, double *aa, const double *l, const double *r) {
+  if (l) for (int i = 0; i < m; i++) for (int k = ai[i]; k < ai[i + 1]; k++) aa[k] *= l[i];
+  if (r) for (int k = 0; k < ai[m]; k++) aa[k] *= r[aj[k]];
+}
 void orc_csr_get_diagonal(int m, const int *ai, const int *aj, const double *aa, double *d) {
   for (int i = 0; i < m; i++) {
     d[i] = 0.0;

@@ -475,6 +475,20 @@ __global__ __launch_bounds__(1024) void dot_partials_kernel(const double *__rest
   }
 }
 
+// MatDiagonalScale_SeqAIJ (aij.c:2055-2092): a[k] = (a[k] * l[row]) * r[col]; either vector may be absent.  One lane per row.
+__global__ __launch_bounds__(MI355X_BLOCK) void csr_diagscale_kernel(int m, const int *__restrict__ ai, const int *__restrict__ aj,
+                                                                    double *aa, const double *__restrict__ l, const double *__restrict__ r) {
+  const int row = blockIdx.x * MI355X_BLOCK + threadIdx.x;
+  if (row >= m) return;
+  const double lv = l ? l[row] : 1.0;
+  for (int k = ai[row]; k < ai[row + 1]; ++k) {
+    double v = aa[k];
+    if (l) v = v * lv;
+    if (r) v = v * r[aj[k]];
+    aa[k] = v;
+  }
+}
+
 __global__ __launch_bounds__(MI355X_BLOCK) void csr_diag_kernel(int m, const int *__restrict__ ai,
                                                                const int *__restrict__ aj,
                                                                const double *__restrict__ aa, double *d) {
@@ -681,6 +695,13 @@ int mi355x_spmv_bsr_planned(mi355x_handle_t h, mi355x_spmv_plan_t p, int bs, con
     default: return (int)hipErrorInvalidValue;
   }
 #undef BSR_GO
+  MI355X_LAUNCH_CHECK();
+  return 0;
+}
+
+int mi355x_csr_diagonal_scale(mi355x_handle_t h, int m, const int *ai, const int *aj, double *aa, const double *l, const double *r) {
+  if (m <= 0 || (!l && !r)) return 0;
+  hipLaunchKernelGGL(csr_diagscale_kernel, dim3((m + MI355X_BLOCK - 1) / MI355X_BLOCK), dim3(MI355X_BLOCK), 0, h->stream, m, ai, aj, aa, l, r);
   MI355X_LAUNCH_CHECK();
   return 0;
 }

@@ -176,6 +176,7 @@ PetscErrorCode MatSeqAIJHIPUpload(Mat A) {
   if (a->bs > 1 && !same_pattern) { mi355x_free(d->d_a); CHKHIP(mi355x_malloc((void **)&d->d_a, sizeof(PetscScalar) * PetscMax(vals, 1))); }
   CHKHIP(mi355x_memcpy_h2d(dc->h, d->d_a, a->a, sizeof(PetscScalar) * vals));
   CHKHIP(mi355x_handle_synchronize(dc->h));
+  d->n_uploads++;
   d->uploaded_state = A->state;
   return 0;
 }
@@ -264,6 +265,14 @@ static PetscErrorCode MatMult_SeqAIJHIP(Mat A, Vec xx, Vec yy) {   /* MatMult_Se
   return 0;
 }
 
+/* how many times the values of a sequential matrix of this type have crossed to the device (tests: value updates with an
+ * unchanged pattern must not add to it) */
+PetscErrorCode MatHIPMI355XGetUploadCount(Mat A, PetscInt *n) {
+  *n = 0;
+  if (!A || A->ops->mult != MatMult_SeqAIJHIP) SETERRQ(A ? A->comm : 0, PETSC_ERR_ARG_WRONG, "sequential HIPMI355X matrix expected");
+  *n = SD(A)->n_uploads;
+  return 0;
+}
 /* number of distinct (col - row) offsets of the index-compressed SpMV plan, 0 when the matrix streams plain 4-byte
  * column indices (bench.py labels its roofline kernel with it; an MPIAIJ matrix answers for its diagonal block) */
 PetscErrorCode MatHIPMI355XGetIndexCompression(Mat A, PetscInt *noffsets) {
@@ -393,16 +402,75 @@ static PetscErrorCode MatGetDiagonal_SeqAIJHIP(Mat A, Vec v) {   /* aij.c:1040 *
   return VecHIPRestoreWrite(v);
 }
 
+/* Value updates with an unchanged pattern: the host copy and the device copy are updated side by side, so
+ * the next MatMult finds the device values current and nothing crosses PCIe (the reference's GPU back end re-sent the
+ * whole matrix after every such call, aijcusp.cu:138-152).  The wrappers in mat.c bump the object state AFTER the op:
+ * the device copy is stamped with that future state.  The cached transpose is dropped. */
+static PetscBool device_values_current(Mat A) {
+  Mat_SeqAIJHIP *d = SD(A);
+  return (PetscBool)(d->d_a && d->uploaded_state == A->state && SA(A)->bs <= 1);
+}
 static PetscErrorCode MatScale_SeqAIJHIP(Mat A, PetscScalar alpha) {   /* MatScale_SeqAIJ: dscal on a->a */
-  Mat_SeqAIJ *a = SA(A);
+  PetscErrorCode ierr;
+  Mat_SeqAIJ *a = SA(A); Mat_SeqAIJHIP *d = SD(A);
   size_t vals = (size_t)a->nz * (size_t)(a->bs > 1 ? a->bs * a->bs : 1);
+  const PetscBool on_device = (PetscBool)(device_values_current(A) && alpha != 0.0);   /* alpha == 0: signs of zero, take the upload */
   for (size_t k = 0; k < vals; k++) a->a[k] = alpha * a->a[k];
+  if (on_device) {
+    PetscDeviceCtx *dc;
+    ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
+    CHKHIP(mi355x_vec_scale(dc->h, vals, alpha, d->d_a));
+    d->uploaded_state = A->state + 1;
+    d->t_state = -1;
+  }
   return PetscLogFlops((PetscLogDouble)vals);
 }
 static PetscErrorCode MatZeroEntries_SeqAIJHIP(Mat A) {
-  Mat_SeqAIJ *a = SA(A);
+  PetscErrorCode ierr;
+  Mat_SeqAIJ *a = SA(A); Mat_SeqAIJHIP *d = SD(A);
   size_t vals = (size_t)(a->compact ? a->nz : a->maxnz) * (size_t)(a->bs > 1 ? a->bs * a->bs : 1);
+  const PetscBool on_device = (PetscBool)(device_values_current(A) && a->compact);
   memset(a->a, 0, sizeof(PetscScalar) * vals);
+  if (on_device) {
+    PetscDeviceCtx *dc;
+    ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
+    CHKHIP(mi355x_memset(dc->h, d->d_a, 0, sizeof(PetscScalar) * vals));
+    d->uploaded_state = A->state + 1;
+    d->t_state = -1;
+  }
+  return 0;
+}
+/* MatDiagonalScale_SeqAIJ, aij.c:2055-2092: left scaling pass, then right scaling pass ((a*l)*r) */
+static PetscErrorCode MatDiagonalScale_SeqAIJHIP(Mat A, Vec ll, Vec rr) {
+  PetscErrorCode ierr;
+  Mat_SeqAIJ *a = SA(A); Mat_SeqAIJHIP *d = SD(A);
+  const PetscScalar *l = NULL, *r = NULL;
+  if (a->bs > 1) SETERRQ(A->comm, PETSC_ERR_SUP, "MatDiagonalScale for the BAIJ type is outside the ported path");
+  if (!a->compact) SETERRQ(A->comm, PETSC_ERR_ARG_WRONGSTATE, "matrix must be assembled");
+  if (ll && ll->map->n != a->m) SETERRQ(A->comm, PETSC_ERR_ARG_SIZ, "Left scaling vector wrong length");
+  if (rr && rr->map->n != a->n) SETERRQ(A->comm, PETSC_ERR_ARG_SIZ, "Right scaling vector wrong length");
+  const PetscBool on_device = (PetscBool)(device_values_current(A) && !d->cprow);
+  if (on_device) {   /* device pointers first: fetching the host arrays below must not be what makes them stale */
+    const PetscScalar *dl = NULL, *dr = NULL; PetscDeviceCtx *dc;
+    ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
+    if (ll) { ierr = VecHIPGetRead(ll, &dl);CHKERRQ(ierr); }
+    if (rr) { ierr = VecHIPGetRead(rr, &dr);CHKERRQ(ierr); }
+    CHKHIP(mi355x_csr_diagonal_scale(dc->h, a->m, d->d_i, d->d_j, d->d_a, dl, dr));
+    d->uploaded_state = A->state + 1;
+    d->t_state = -1;
+  }
+  if (ll) {
+    ierr = VecGetArrayRead(ll, &l);CHKERRQ(ierr);
+    for (PetscInt i = 0; i < a->m; i++) for (PetscInt k = a->i[i]; k < a->i[i + 1]; k++) a->a[k] *= l[i];
+    ierr = VecRestoreArrayRead(ll, &l);CHKERRQ(ierr);
+    ierr = PetscLogFlops((PetscLogDouble)a->nz);CHKERRQ(ierr);
+  }
+  if (rr) {
+    ierr = VecGetArrayRead(rr, &r);CHKERRQ(ierr);
+    for (PetscInt k = 0; k < a->nz; k++) a->a[k] *= r[a->j[k]];
+    ierr = VecRestoreArrayRead(rr, &r);CHKERRQ(ierr);
+    ierr = PetscLogFlops((PetscLogDouble)a->nz);CHKERRQ(ierr);
+  }
   return 0;
 }
 
@@ -445,7 +513,7 @@ static PetscErrorCode create_common(Mat B, const char *tname, PetscInt bs) {
   o->setvalues = MatSetValues_SeqAIJHIP; o->mult = MatMult_SeqAIJHIP; o->multadd = MatMultAdd_SeqAIJHIP;
   o->multtranspose = MatMultTranspose_SeqAIJHIP; o->multtransposeadd = MatMultTransposeAdd_SeqAIJHIP;
   o->getdiagonal = MatGetDiagonal_SeqAIJHIP; o->assemblyend = MatAssemblyEnd_SeqAIJHIP; o->zeroentries = MatZeroEntries_SeqAIJHIP;
-  o->setup = MatSetUp_SeqAIJHIP; o->scale = MatScale_SeqAIJHIP; o->destroy = MatDestroy_SeqAIJHIP; o->getvecs = MatGetVecs_HIP;
+  o->setup = MatSetUp_SeqAIJHIP; o->scale = MatScale_SeqAIJHIP; o->diagonalscale = MatDiagonalScale_SeqAIJHIP; o->destroy = MatDestroy_SeqAIJHIP; o->getvecs = MatGetVecs_HIP;
   return 0;
 }
 PetscErrorCode MatCreate_SeqAIJHIPMI355X(Mat B) { return create_common(B, MATSEQAIJHIPMI355X, 1); }

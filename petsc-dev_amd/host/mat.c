@@ -174,6 +174,15 @@ PetscErrorCode MatScale(Mat A, PetscScalar a) {
   if (a != 1.0) { ierr = (*A->ops->scale)(A, a);CHKERRQ(ierr); A->state++; }
   return 0;
 }
+PetscErrorCode MatDiagonalScale(Mat A, Vec l, Vec r) {   /* matrix.c MatDiagonalScale: A <- diag(l) A diag(r), either may be NULL */
+  PetscErrorCode ierr;
+  MatTypeSet(A, 1); MatAssembled(A);
+  if (!A->ops->diagonalscale) SETERRQ(A->comm, PETSC_ERR_SUP, "Mat type %s", A->type_name);
+  if (!l && !r) return 0;
+  ierr = (*A->ops->diagonalscale)(A, l, r);CHKERRQ(ierr);
+  A->state++;
+  return 0;
+}
 PetscErrorCode MatZeroEntries(Mat A) {
   PetscErrorCode ierr;
   MatTypeSet(A, 1);

@@ -159,6 +159,25 @@ static PetscErrorCode MatScale_MPIAIJHIP(Mat A, PetscScalar aa) {
   ierr = MatScale(MA(A)->B, aa);CHKERRQ(ierr);
   return 0;
 }
+/* MatDiagonalScale_MPIAIJ, mpiaij.c:2183-2213: the right vector's ghost values come through the MatMult scatter */
+static PetscErrorCode MatDiagonalScale_MPIAIJHIP(Mat A, Vec ll, Vec rr) {
+  PetscErrorCode ierr;
+  Mat_MPIAIJ *aij = MA(A);
+  if (rr) {
+    if (rr->map->n != A->cmap->n) SETERRQ(A->comm, PETSC_ERR_ARG_SIZ, "right vector non-conforming local size");
+    ierr = VecScatterBegin(aij->Mvctx, rr, aij->lvec, INSERT_VALUES, SCATTER_FORWARD);CHKERRQ(ierr);
+  }
+  if (ll) {
+    if (ll->map->n != A->rmap->n) SETERRQ(A->comm, PETSC_ERR_ARG_SIZ, "left vector non-conforming local size");
+    ierr = MatDiagonalScale(aij->B, ll, NULL);CHKERRQ(ierr);
+  }
+  ierr = MatDiagonalScale(aij->A, ll, rr);CHKERRQ(ierr);
+  if (rr) {
+    ierr = VecScatterEnd(aij->Mvctx, rr, aij->lvec, INSERT_VALUES, SCATTER_FORWARD);CHKERRQ(ierr);
+    ierr = MatDiagonalScale(aij->B, NULL, aij->lvec);CHKERRQ(ierr);
+  }
+  return 0;
+}
 static PetscErrorCode MatZeroEntries_MPIAIJHIP(Mat A) {
   PetscErrorCode ierr;
   ierr = MatZeroEntries(MA(A)->A);CHKERRQ(ierr);
@@ -190,7 +209,7 @@ PetscErrorCode MatCreate_MPIAIJHIPMI355X(Mat B) {   /* MatCreate_MPIAIJCUSP, mpi
   o->setvalues = MatSetValues_MPIAIJHIP; o->mult = MatMult_MPIAIJHIP; o->multadd = MatMultAdd_MPIAIJHIP;
   o->multtranspose = MatMultTranspose_MPIAIJHIP; o->multtransposeadd = MatMultTransposeAdd_MPIAIJHIP;
   o->getdiagonal = MatGetDiagonal_MPIAIJHIP; o->assemblyend = MatAssemblyEnd_MPIAIJHIP; o->zeroentries = MatZeroEntries_MPIAIJHIP;
-  o->setup = MatSetUp_MPIAIJHIP; o->scale = MatScale_MPIAIJHIP; o->destroy = MatDestroy_MPIAIJHIP; o->getvecs = MatGetVecs_HIPMI355X;
+  o->setup = MatSetUp_MPIAIJHIP; o->scale = MatScale_MPIAIJHIP; o->diagonalscale = MatDiagonalScale_MPIAIJHIP; o->destroy = MatDestroy_MPIAIJHIP; o->getvecs = MatGetVecs_HIPMI355X;
   return 0;
 }
 /* base name "aijhipmi355x" -> seq or mpi by communicator size (MatRegisterBaseName, matreg.c:161-180) */

@@ -182,6 +182,7 @@ typedef struct _MatOps {
   PetscErrorCode (*zeroentries)(Mat);                    /* slot 23 */
   PetscErrorCode (*setup)(Mat);
   PetscErrorCode (*scale)(Mat, PetscScalar);
+  PetscErrorCode (*diagonalscale)(Mat, Vec, Vec);        /* slot 18 */
   PetscErrorCode (*destroy)(Mat);                        /* slot 60 */
   PetscErrorCode (*getvecs)(Mat, Vec *, Vec *);          /* slot 88 */
 } MatOps;
@@ -225,6 +226,7 @@ typedef struct {
   PetscInt pattern_nz;        /* nz of the pattern the mirror was built for (-1: none) */
   /* cached explicit transpose for MatMultTranspose */
   PetscInt *t_i, *t_j; PetscScalar *t_a; mi355x_spmv_plan_t t_plan; int t_state;
+  PetscInt n_uploads;        /* value uploads so far */
 } Mat_SeqAIJHIP;
 
 /* Mat_MPIAIJ, src/mat/impls/aij/mpi/mpiaij.h:35-77 */

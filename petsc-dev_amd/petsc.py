@@ -41,12 +41,12 @@ _SIG = {
     "MatCreateSeqBAIJWithArrays": [vp, i32, i32, i32, vp, vp, vp, P(vp)],
     "MatDestroy": [P(vp)], "MatGetSize": [vp, P(i32), P(i32)], "MatGetLocalSize": [vp, P(i32), P(i32)],
     "MatGetOwnershipRange": [vp, P(i32), P(i32)], "MatGetVecs": [vp, P(vp), P(vp)],
-    "MatMult": [vp, vp, vp], "MatMultAdd": [vp, vp, vp, vp], "MatMultTranspose": [vp, vp, vp],
+    "MatDiagonalScale": [vp, vp, vp], "MatMult": [vp, vp, vp], "MatMultAdd": [vp, vp, vp, vp], "MatMultTranspose": [vp, vp, vp],
     "MatMultTransposeAdd": [vp, vp, vp, vp], "MatGetDiagonal": [vp, vp], "MatScale": [vp, dbl], "MatZeroEntries": [vp],
     "MatSeqAIJGetArrays": [vp, P(i32), P(vp), P(vp), P(vp)], "MatMPIAIJGetSeqAIJ": [vp, P(vp), P(vp), P(vp)],
     "MatMPIAIJGetScatter": [vp, P(vp), P(vp), P(i32)],
     "MatHIPMI355XSetTiming": [vp, i32], "MatHIPMI355XGetTiming": [vp, P(i32), P(dbl)],
-    "MatHIPMI355XGetIndexCompression": [vp, P(i32)],
+    "MatHIPMI355XGetIndexCompression": [vp, P(i32)], "MatHIPMI355XGetUploadCount": [vp, P(i32)],
     "PetscHIPMI355XGenPoisson7": [i32, i32, i32, C.c_long, C.c_long, vp, vp, vp, P(C.c_long)],
     "PetscViewerBinaryOpen": [vp, C.c_char_p, i32, P(vp)], "PetscViewerDestroy": [P(vp)],
     "MatLoad": [vp, vp], "MatView": [vp, vp], "VecLoad": [vp, vp], "VecView": [vp, vp],

@@ -134,6 +134,13 @@ def spmv_t_add(ai, aj, aa, x, z, n):
     return y
 
 
+def diagonal_scale(ai, aj, aa, l=None, r=None):
+    """returns the values of diag(l) A diag(r)"""
+    out = np.array(aa, dtype=np.float64)
+    lib().orc_csr_diagonal_scale(C.c_int(ai.size - 1), I(ai), I(aj), D(out), D(l) if l is not None else None, D(r) if r is not None else None)
+    return out
+
+
 def get_diagonal(ai, aj, aa):
     m = ai.size - 1
     d = np.zeros(m)

@@ -754,3 +754,43 @@ def test_standalone_c_program_reproduces_the_tutorial_outputs(built):
     # an unknown type is an error message and a non-zero exit, not a crash
     r = subprocess.run([exe, "-ksp_type", "nosuchmethod"], capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "nosuchmethod" in r.stderr
+
+
+def test_value_updates_on_the_device_copy(P):
+    """MatScale / MatDiagonalScale / MatZeroEntries after the matrix has been used on the device: host and
+    device copies are updated side by side (no re-upload), results bit-identical to the oracle's loops (aij.c:2055:
+    left pass then right pass) and to the route through a fresh upload; the cached transpose follows."""
+    L = P.lib()
+    ai, aj, aa = pb.lap2d(23, 19)
+    n = ai.size - 1
+    aa = aa * (1.0 + 0.3 * np.sin(np.arange(aa.size)))
+    l, r = 1.0 + 0.5 * np.cos(np.arange(n)), 2.0 + np.sin(0.7 * np.arange(n))
+    x = np.cos(0.3 * np.arange(n))
+    vx = V(P, x); vy = V(P, np.zeros(n)); vl, vr = V(P, l), V(P, r)
+    for used_first in (True, False):                      # device-side update / host update + upload
+        A = P.Mat.from_csr(ai, aj, aa)
+        if used_first:
+            A.mult(vx, vy); L.MatMultTranspose(A.h, vx.h, vy.h)       # uploads A and builds the transpose cache
+        L.MatDiagonalScale(A.h, vl.h, vr.h)
+        ref = orc.diagonal_scale(ai, aj, aa, l, r)
+        A.mult(vx, vy)
+        assert np.array_equal(bits(vy.array()), bits(orc.spmv(ai, aj, ref, x)))
+        L.MatMultTranspose(A.h, vx.h, vy.h)
+        assert np.allclose(vy.array(), orc.spmv_t(ai, aj, ref, x, n), rtol=0, atol=1e-12)
+        L.MatDiagonalScale(A.h, None, vr.h)
+        ref = orc.diagonal_scale(ai, aj, ref, None, r)
+        L.MatDiagonalScale(A.h, vl.h, None)
+        ref = orc.diagonal_scale(ai, aj, ref, l, None)
+        L.MatScale(A.h, -0.37)
+        ref = -0.37 * ref
+        A.mult(vx, vy)
+        assert np.array_equal(bits(vy.array()), bits(orc.spmv(ai, aj, ref, x)))
+        d = vx.duplicate(); L.MatGetDiagonal(A.h, d.h)
+        assert np.array_equal(bits(d.array()), bits(orc.get_diagonal(ai, aj, ref)))
+        L.MatZeroEntries(A.h)
+        A.mult(vx, vy)
+        assert np.all(vy.array() == 0.0)
+        nup = C.c_int()
+        L.MatHIPMI355XGetUploadCount(A.h, C.byref(nup))
+        assert nup.value == 1, "values crossed PCIe %d times" % nup.value   # used_first: only the first use; else: one upload after the first update
+        A.destroy()
