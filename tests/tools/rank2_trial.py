@@ -82,6 +82,21 @@ def main():
                 reft[g - rs] = reft[g - rs] + lv[i_]
     ok6 = np.array_equal(vy.array().view(np.uint64), reft.view(np.uint64))
     print("rank %d/%d: irregular MatMult bitexact=%s MatMultTranspose bitexact=%s" % (rank, world, ok5, ok6), flush=True)
+    # MatDiagonalScale_MPIAIJ (mpiaij.c:2183): left vector by rows, right vector's ghost values through the MatMult
+    # scatter; the device copies of both blocks are updated in place.  Then MatScale.  Against the scaled oracle pieces.
+    lg = 1.0 + 0.5 * np.cos(np.arange(NI)); rg = 2.0 + np.sin(0.7 * np.arange(NI))
+    vl = P.Vec.from_array(lg[rs:re_], comm=comm, N=NI); vr = P.Vec.from_array(rg[rs:re_], comm=comm, N=NI)
+    L.MatDiagonalScale(B.h, vl.h, vr.h)
+    L.MatScale(B.h, -0.37)
+    B.mult(vx, vy)
+    ad = -0.37 * orc.diagonal_scale(me["ad_i"], me["ad_j"], me["ad_a"], lg[rs:re_].copy(), rg[rs:re_].copy())
+    ref = orc.spmv(me["ad_i"], me["ad_j"], ad, xi[rs:re_].copy())
+    if me["garray"].size:
+        bo = orc.diagonal_scale(me["bo_i"], me["bo_j"], me["bo_a"], lg[rs:re_].copy(), None)
+        bo = -0.37 * orc.diagonal_scale(me["bo_i"], me["bo_j"], bo, None, rg[me["garray"]].copy())
+        ref = orc.spmv_add(me["bo_i"], me["bo_j"], bo, xi[me["garray"]].copy(), ref)
+    ok7 = np.array_equal(vy.array().view(np.uint64), ref.view(np.uint64))
+    print("rank %d/%d: MatDiagonalScale + MatScale then MatMult bitexact=%s" % (rank, world, ok7), flush=True)
     ok1 = ok1 and ok5 and ok6
     # ---- reference golden on 2 ranks: ex2 -m 5 -n 5 -ksp_gmres_cgs_refinement_type refine_always with NO pc option =
     # GMRES + block Jacobi + ILU(0) per rank (13 + 12 rows) == src/ksp/ksp/examples/tutorials/output/ex2_2.out
