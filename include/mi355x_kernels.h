@@ -186,6 +186,10 @@ int mi355x_spmv_csr_add(mi355x_handle_t h, mi355x_spmv_plan_t plan, const int *a
  * kernels applied to an explicit transpose whose rows list contributions in increasing
  * original-row order (the order the reference's scatter loop adds them in). */
 
+/* MatSetValuesBatch with an unchanged pattern (src/mat/interface/matrix.c:1698; GPU analogue aijAssemble.cu:157):
+ * aa[segslot[s]] += v[order[k]] for k in [segptr[s], segptr[s+1]) in that order, s < nseg.  The map is built on the host
+ * once per connectivity; contributions are added in the order of the reference's loop of MatSetValues(ADD_VALUES). */
+int mi355x_csr_assemble(mi355x_handle_t h, int nseg, const int *segptr, const int *segslot, const int *order, const double *v, double *aa);
 /* MatDiagonalScale_SeqAIJ  src/mat/impls/aij/seq/aij.c:2055   a[k] = (a[k] * l[row]) * r[col]; l or r may be NULL */
 int mi355x_csr_diagonal_scale(mi355x_handle_t h, int m, const int *ai, const int *aj, double *aa, const double *l, const double *r);
 /* MatGetDiagonal_SeqAIJ  src/mat/impls/aij/seq/aij.c:1040   d[r] = A[r,r] or 0 */

@@ -205,6 +205,7 @@ PetscErrorCode MatSetUp(Mat A);
 PetscErrorCode MatSeqAIJSetPreallocation(Mat A, PetscInt nz, const PetscInt nnz[]);
 PetscErrorCode MatMPIAIJSetPreallocation(Mat A, PetscInt d_nz, const PetscInt d_nnz[], PetscInt o_nz, const PetscInt o_nnz[]);
 PetscErrorCode MatSetValues(Mat A, PetscInt m, const PetscInt idxm[], PetscInt n, const PetscInt idxn[], const PetscScalar v[], InsertMode addv);
+PetscErrorCode MatSetValuesBatch(Mat A, PetscInt nb, PetscInt bs, PetscInt rows[], const PetscScalar v[]);   /* matrix.c:1698; device-side value assembly when the pattern is unchanged */
 PetscErrorCode MatAssemblyBegin(Mat A, MatAssemblyType type);
 PetscErrorCode MatAssemblyEnd(Mat A, MatAssemblyType type);
 /* bulk creation from CSR (MatCreateSeqAIJWithArrays src/mat/impls/aij/seq/aij.c, MatCreateMPIAIJWithArrays

@@ -82,6 +82,7 @@ KERNEL_API = {
     "mi355x_spmv_dot_finish": [vp, vp, vp],
     "mi355x_csr_get_diagonal": [vp, i32, vp, vp, vp, vp],
     "mi355x_csr_diagonal_scale": [vp, i32, vp, vp, vp, vp, vp],
+    "mi355x_csr_assemble": [vp, i32, vp, vp, vp, vp, vp],
     "mi355x_spmv_bsr": [vp, i32, i32, vp, vp, vp, vp, vp],
     "mi355x_spmv_bsr_planned": [vp, vp, i32, vp, vp, vp, vp, vp],
     "mi355x_ilu0_lower_level": [vp, i32, vp, vp, vp, vp, vp, vp],

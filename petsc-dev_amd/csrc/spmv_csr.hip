@@ -475,6 +475,20 @@ __global__ __launch_bounds__(1024) void dot_partials_kernel(const double *__rest
   }
 }
 
+// Value assembly through a precomputed map (MatSetValuesBatch with an unchanged pattern): nonzero `segslot[s]` receives
+// the contributions v[order[k]], k in [segptr[s], segptr[s+1]), added to its current value one after the other in the
+// order the reference's loop of MatSetValues(ADD_VALUES) would add them (matrix.c:1715-1718) -- one lane per nonzero,
+// no atomics, same bits as the host loop.
+__global__ __launch_bounds__(MI355X_BLOCK) void csr_assemble_kernel(int nseg, const int *__restrict__ segptr, const int *__restrict__ segslot,
+                                                                   const int *__restrict__ order, const double *__restrict__ v, double *aa) {
+  const int s = blockIdx.x * MI355X_BLOCK + threadIdx.x;
+  if (s >= nseg) return;
+  const int slot = segslot[s];
+  double sum = aa[slot];
+  for (int k = segptr[s]; k < segptr[s + 1]; ++k) sum += v[order[k]];
+  aa[slot] = sum;
+}
+
 // MatDiagonalScale_SeqAIJ (aij.c:2055-2092): a[k] = (a[k] * l[row]) * r[col]; either vector may be absent.  One lane per row.
 __global__ __launch_bounds__(MI355X_BLOCK) void csr_diagscale_kernel(int m, const int *__restrict__ ai, const int *__restrict__ aj,
                                                                     double *aa, const double *__restrict__ l, const double *__restrict__ r) {
@@ -695,6 +709,13 @@ int mi355x_spmv_bsr_planned(mi355x_handle_t h, mi355x_spmv_plan_t p, int bs, con
     default: return (int)hipErrorInvalidValue;
   }
 #undef BSR_GO
+  MI355X_LAUNCH_CHECK();
+  return 0;
+}
+
+int mi355x_csr_assemble(mi355x_handle_t h, int nseg, const int *segptr, const int *segslot, const int *order, const double *v, double *aa) {
+  if (nseg <= 0) return 0;
+  hipLaunchKernelGGL(csr_assemble_kernel, dim3((nseg + MI355X_BLOCK - 1) / MI355X_BLOCK), dim3(MI355X_BLOCK), 0, h->stream, nseg, segptr, segslot, order, v, aa);
   MI355X_LAUNCH_CHECK();
   return 0;
 }

@@ -111,8 +111,14 @@ static PetscErrorCode device_free(Mat A) {
   if (d->t_j) mi355x_free(d->t_j);
   if (d->t_a) mi355x_free(d->t_a);
   if (d->t_plan) mi355x_spmv_plan_destroy(d->t_plan);
+  if (d->bm_order) mi355x_free(d->bm_order);
+  if (d->bm_segptr) mi355x_free(d->bm_segptr);
+  if (d->bm_segslot) mi355x_free(d->bm_segslot);
+  if (d->bm_v) mi355x_free(d->bm_v);
+  const PetscInt nup = d->n_uploads;
   memset(d, 0, sizeof(*d));
   d->uploaded_state = -1; d->t_state = -1; d->pattern_nz = -1;
+  d->n_uploads = nup;
   return 0;
 }
 
@@ -234,6 +240,110 @@ static PetscErrorCode MatSetValues_SeqAIJHIP(Mat A, PetscInt m, const PetscInt i
       ierr = seqaij_set(a, row, in[l], v[k * n + l], is, NULL);CHKERRQ(ierr);   /* row-oriented values, aij.c roworiented */
     }
   }
+  return 0;
+}
+
+/* MatSetValuesBatch (matrix.c:1698; the reference's GPU version aijAssemble.cu:157 sorts and reduces a COO list on every
+ * call): nb square blocks of bs x bs values, rows[] = their row = column indices, ADD_VALUES.  With an assembled matrix
+ * whose pattern already holds every (row, col) pair -- the re-assembly of a time step or Newton iteration -- the values
+ * are assembled ON THE DEVICE through a map built once per connectivity: contributions grouped by nonzero, kept in call
+ * order, one lane per nonzero adds them one after the other (mi355x_csr_assemble), so the result carries the bits of the
+ * reference's loop of MatSetValues.  The host copy is refreshed from the device afterwards.  Anything else (first
+ * assembly, new nonzeros, BAIJ) takes that loop itself. */
+static unsigned long long fnv1a(const void *p, size_t nbytes) {
+  const unsigned char *c = (const unsigned char *)p; unsigned long long h = 1469598103934665603ULL;
+  for (size_t k = 0; k < nbytes; k++) { h ^= c[k]; h *= 1099511628211ULL; }
+  return h;
+}
+static PetscErrorCode batch_map_build(Mat A, PetscInt nb, PetscInt bs, const PetscInt rows[], PetscBool *ok) {
+  PetscErrorCode ierr;
+  Mat_SeqAIJ *a = SA(A); Mat_SeqAIJHIP *d = SD(A);
+  PetscDeviceCtx *dc;
+  const size_t T = (size_t)nb * (size_t)bs * (size_t)bs;
+  PetscInt *slot = NULL, *count = NULL, *order = NULL, *segptr = NULL, *segslot = NULL;
+  *ok = PETSC_FALSE;
+  if (T == 0 || T > 2147483000UL) return 0;
+  ierr = PetscMalloc(sizeof(PetscInt) * T, &slot);CHKERRQ(ierr);
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)(a->nz + 1), &count);CHKERRQ(ierr);
+  memset(count, 0, sizeof(PetscInt) * (size_t)(a->nz + 1));
+  size_t used = 0;
+  for (PetscInt b = 0; b < nb; b++) {
+    const PetscInt *rb = rows + (size_t)b * bs;
+    for (PetscInt i = 0; i < bs; i++) {
+      const PetscInt row = rb[i];
+      if (row >= a->m) { free(slot); free(count); SETERRQ(A->comm, PETSC_ERR_ARG_OUTOFRANGE, "Row too large: row %d max %d", row, a->m - 1); }
+      for (PetscInt j = 0; j < bs; j++) {
+        const size_t t = ((size_t)b * bs + i) * bs + j;
+        const PetscInt col = rb[j];
+        slot[t] = -1;
+        if (row < 0 || col < 0) continue;                     /* MatSetValues ignores negative indices */
+        if (col >= a->n) { free(slot); free(count); SETERRQ(A->comm, PETSC_ERR_ARG_OUTOFRANGE, "Column too large: col %d max %d", col, a->n - 1); }
+        PetscInt k = a->i[row];
+        for (; k < a->i[row + 1]; k++) if (a->j[k] == col) break;
+        if (k == a->i[row + 1]) { free(slot); free(count); return 0; }   /* a new nonzero: not a pure value re-assembly */
+        slot[t] = k; count[k + 1]++; used++;
+      }
+    }
+  }
+  /* counting sort by nonzero, stable in t: the order of the reference's loop */
+  PetscInt nseg = 0;
+  for (PetscInt k = 0; k < a->nz; k++) if (count[k + 1]) nseg++;
+  ierr = PetscMalloc(sizeof(PetscInt) * PetscMax(used, 1), &order);CHKERRQ(ierr);
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)(nseg + 1), &segptr);CHKERRQ(ierr);
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)PetscMax(nseg, 1), &segslot);CHKERRQ(ierr);
+  { PetscInt s = 0, run = 0;
+    for (PetscInt k = 0; k < a->nz; k++) { const PetscInt c = count[k + 1]; count[k + 1] = run; if (c) { segptr[s] = run; segslot[s] = k; s++; } run += c; }
+    segptr[nseg] = run; }
+  for (size_t t = 0; t < T; t++) if (slot[t] >= 0) order[count[slot[t] + 1]++] = (PetscInt)t;
+  ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
+  if (d->bm_order) mi355x_free(d->bm_order);
+  if (d->bm_segptr) mi355x_free(d->bm_segptr);
+  if (d->bm_segslot) mi355x_free(d->bm_segslot);
+  d->bm_order = d->bm_segptr = d->bm_segslot = NULL;
+  CHKHIP(mi355x_malloc((void **)&d->bm_order, sizeof(PetscInt) * PetscMax(used, 1)));
+  CHKHIP(mi355x_malloc((void **)&d->bm_segptr, sizeof(PetscInt) * (size_t)(nseg + 1)));
+  CHKHIP(mi355x_malloc((void **)&d->bm_segslot, sizeof(PetscInt) * (size_t)PetscMax(nseg, 1)));
+  CHKHIP(mi355x_memcpy_h2d(dc->h, d->bm_order, order, sizeof(PetscInt) * used));
+  CHKHIP(mi355x_memcpy_h2d(dc->h, d->bm_segptr, segptr, sizeof(PetscInt) * (size_t)(nseg + 1)));
+  CHKHIP(mi355x_memcpy_h2d(dc->h, d->bm_segslot, segslot, sizeof(PetscInt) * (size_t)nseg));
+  CHKHIP(mi355x_handle_synchronize(dc->h));
+  free(slot); free(count); free(order); free(segptr); free(segslot);
+  d->bm_nb = nb; d->bm_bs = bs; d->bm_nseg = nseg; d->bm_T = T;
+  d->bm_hash = fnv1a(rows, sizeof(PetscInt) * (size_t)nb * (size_t)bs);
+  *ok = PETSC_TRUE;
+  return 0;
+}
+static PetscErrorCode MatSetValuesBatch_SeqAIJHIP(Mat A, PetscInt nb, PetscInt bs, PetscInt rows[], const PetscScalar v[]) {
+  PetscErrorCode ierr;
+  Mat_SeqAIJ *a = SA(A); Mat_SeqAIJHIP *d = SD(A);
+  PetscBool ok = PETSC_FALSE;
+  if (a->bs <= 1 && a->compact && A->assembled && nb > 0 && bs > 0 && !d->cprow) {
+    ierr = MatSeqAIJHIPUpload(A);CHKERRQ(ierr);               /* device values current before they are added to */
+    ok = (PetscBool)(d->bm_order && d->bm_nb == nb && d->bm_bs == bs && d->pattern_nz == a->nz &&
+                     d->bm_hash == fnv1a(rows, sizeof(PetscInt) * (size_t)nb * (size_t)bs));
+    if (!ok) { ierr = batch_map_build(A, nb, bs, rows, &ok);CHKERRQ(ierr); }
+  }
+  if (!ok) {                                                   /* the reference's default (matrix.c:1715-1718) */
+    for (PetscInt b = 0; b < nb; b++) { ierr = MatSetValues(A, bs, &rows[(size_t)b * bs], bs, &rows[(size_t)b * bs], &v[(size_t)b * bs * bs], ADD_VALUES);CHKERRQ(ierr); }
+    return 0;
+  }
+  PetscDeviceCtx *dc;
+  ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
+  if (d->bm_vcap < d->bm_T) {
+    if (d->bm_v) mi355x_free(d->bm_v);
+    d->bm_v = NULL;
+    CHKHIP(mi355x_malloc((void **)&d->bm_v, sizeof(PetscScalar) * d->bm_T));
+    d->bm_vcap = d->bm_T;
+  }
+  CHKHIP(mi355x_memcpy_h2d(dc->h, d->bm_v, v, sizeof(PetscScalar) * d->bm_T));
+  CHKHIP(mi355x_csr_assemble(dc->h, d->bm_nseg, d->bm_segptr, d->bm_segslot, d->bm_order, d->bm_v, d->d_a));
+  CHKHIP(mi355x_memcpy_d2h(dc->h, a->a, d->d_a, sizeof(PetscScalar) * (size_t)a->nz));   /* host mirror follows */
+  CHKHIP(mi355x_handle_synchronize(dc->h));                    /* v and a->a are pageable host memory */
+  /* MatSetValuesBatch's wrapper leaves the state alone and the MatAssemblyEnd that has to follow bumps it once: the
+   * device copy is stamped with that state, so the assembly does not trigger an upload */
+  d->uploaded_state = A->state + 1;
+  d->t_state = -1;
+  ierr = PetscLogFlops((PetscLogDouble)d->bm_T);CHKERRQ(ierr);
   return 0;
 }
 
@@ -513,7 +623,7 @@ static PetscErrorCode create_common(Mat B, const char *tname, PetscInt bs) {
   o->setvalues = MatSetValues_SeqAIJHIP; o->mult = MatMult_SeqAIJHIP; o->multadd = MatMultAdd_SeqAIJHIP;
   o->multtranspose = MatMultTranspose_SeqAIJHIP; o->multtransposeadd = MatMultTransposeAdd_SeqAIJHIP;
   o->getdiagonal = MatGetDiagonal_SeqAIJHIP; o->assemblyend = MatAssemblyEnd_SeqAIJHIP; o->zeroentries = MatZeroEntries_SeqAIJHIP;
-  o->setup = MatSetUp_SeqAIJHIP; o->scale = MatScale_SeqAIJHIP; o->diagonalscale = MatDiagonalScale_SeqAIJHIP; o->destroy = MatDestroy_SeqAIJHIP; o->getvecs = MatGetVecs_HIP;
+  o->setup = MatSetUp_SeqAIJHIP; o->scale = MatScale_SeqAIJHIP; o->diagonalscale = MatDiagonalScale_SeqAIJHIP; o->setvaluesbatch = MatSetValuesBatch_SeqAIJHIP; o->destroy = MatDestroy_SeqAIJHIP; o->getvecs = MatGetVecs_HIP;
   return 0;
 }
 PetscErrorCode MatCreate_SeqAIJHIPMI355X(Mat B) { return create_common(B, MATSEQAIJHIPMI355X, 1); }

@@ -79,6 +79,21 @@ PetscErrorCode MatSetValues(Mat A, PetscInt m, const PetscInt idxm[], PetscInt n
   A->assembled = PETSC_FALSE;   /* matrix.c:1083 */
   return 0;
 }
+/* MatSetValuesBatch, matrix.c:1698-1722: nb square blocks of bs x bs values (row-major), rows[b*bs .. b*bs+bs) their
+ * row and column indices, ADD_VALUES; MatAssemblyBegin/End must follow as after MatSetValues */
+PetscErrorCode MatSetValuesBatch(Mat A, PetscInt nb, PetscInt bs, PetscInt rows[], const PetscScalar v[]) {
+  PetscErrorCode ierr;
+  MatTypeSet(A, 1);
+  if (nb <= 0 || bs <= 0) return 0;
+  if (!rows || !v) SETERRQ(A->comm, PETSC_ERR_ARG_NULL, "Null array");
+  if (!A->preallocated) { ierr = MatSetUp(A);CHKERRQ(ierr); }
+  if (A->ops->setvaluesbatch) { ierr = (*A->ops->setvaluesbatch)(A, nb, bs, rows, v);CHKERRQ(ierr); }
+  else {
+    for (PetscInt b = 0; b < nb; b++) { ierr = MatSetValues(A, bs, &rows[(size_t)b * bs], bs, &rows[(size_t)b * bs], &v[(size_t)b * bs * bs], ADD_VALUES);CHKERRQ(ierr); }
+  }
+  A->assembled = PETSC_FALSE;
+  return 0;
+}
 PetscErrorCode MatAssemblyBegin(Mat A, MatAssemblyType type) {
   MatTypeSet(A, 1);
   if (A->ops->assemblybegin) { PetscErrorCode ierr = (*A->ops->assemblybegin)(A, type);CHKERRQ(ierr); }

@@ -183,6 +183,7 @@ typedef struct _MatOps {
   PetscErrorCode (*setup)(Mat);
   PetscErrorCode (*scale)(Mat, PetscScalar);
   PetscErrorCode (*diagonalscale)(Mat, Vec, Vec);        /* slot 18 */
+  PetscErrorCode (*setvaluesbatch)(Mat, PetscInt, PetscInt, PetscInt[], const PetscScalar[]);
   PetscErrorCode (*destroy)(Mat);                        /* slot 60 */
   PetscErrorCode (*getvecs)(Mat, Vec *, Vec *);          /* slot 88 */
 } MatOps;
@@ -227,6 +228,10 @@ typedef struct {
   /* cached explicit transpose for MatMultTranspose */
   PetscInt *t_i, *t_j; PetscScalar *t_a; mi355x_spmv_plan_t t_plan; int t_state;
   PetscInt n_uploads;        /* value uploads so far */
+  /* MatSetValuesBatch map for one connectivity (rows array): contributions grouped by nonzero, in call order */
+  PetscInt bm_nb, bm_bs, bm_nseg; unsigned long long bm_hash; size_t bm_T, bm_vcap;
+  PetscInt *bm_order, *bm_segptr, *bm_segslot;   /* device */
+  PetscScalar *bm_v;                             /* device staging of the element values */
 } Mat_SeqAIJHIP;
 
 /* Mat_MPIAIJ, src/mat/impls/aij/mpi/mpiaij.h:35-77 */

@@ -41,7 +41,7 @@ _SIG = {
     "MatCreateSeqBAIJWithArrays": [vp, i32, i32, i32, vp, vp, vp, P(vp)],
     "MatDestroy": [P(vp)], "MatGetSize": [vp, P(i32), P(i32)], "MatGetLocalSize": [vp, P(i32), P(i32)],
     "MatGetOwnershipRange": [vp, P(i32), P(i32)], "MatGetVecs": [vp, P(vp), P(vp)],
-    "MatDiagonalScale": [vp, vp, vp], "MatMult": [vp, vp, vp], "MatMultAdd": [vp, vp, vp, vp], "MatMultTranspose": [vp, vp, vp],
+    "MatDiagonalScale": [vp, vp, vp], "MatSetValuesBatch": [vp, i32, i32, vp, vp], "MatMult": [vp, vp, vp], "MatMultAdd": [vp, vp, vp, vp], "MatMultTranspose": [vp, vp, vp],
     "MatMultTransposeAdd": [vp, vp, vp, vp], "MatGetDiagonal": [vp, vp], "MatScale": [vp, dbl], "MatZeroEntries": [vp],
     "MatSeqAIJGetArrays": [vp, P(i32), P(vp), P(vp), P(vp)], "MatMPIAIJGetSeqAIJ": [vp, P(vp), P(vp), P(vp)],
     "MatMPIAIJGetScatter": [vp, P(vp), P(vp), P(i32)],

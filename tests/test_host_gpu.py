@@ -794,3 +794,57 @@ def test_value_updates_on_the_device_copy(P):
         L.MatHIPMI355XGetUploadCount(A.h, C.byref(nup))
         assert nup.value == 1, "values crossed PCIe %d times" % nup.value   # used_first: only the first use; else: one upload after the first update
         A.destroy()
+
+
+def test_setvaluesbatch_device_assembly(P):
+    """MatSetValuesBatch (matrix.c:1698): first assembly goes through the reference's loop of MatSetValues; every later
+    one with the same connectivity is a device-side value assembly through the cached map -- bit-identical to the
+    loop (contributions added per nonzero in call order, also with repeated and negative indices inside a block),
+    host mirror refreshed, and no upload of the matrix in between."""
+    L = P.lib()
+    rng = np.random.default_rng(42)
+    nn, nb, bs = 900, 2500, 4
+    rows = rng.integers(0, nn, (nb, bs)).astype(np.int32)
+    rows[::7, 1] = rows[::7, 0]                            # a repeated index inside a block
+    rows[::11, 2] = -1                                     # a negative index: ignored
+    v1 = rng.standard_normal((nb, bs, bs)); v2 = rng.standard_normal((nb, bs, bs))
+
+    def new_mat():
+        A = P.Mat(); L.MatCreate(L.COMM_SELF, C.byref(A.h))
+        L.MatSetSizes(A.h, nn, nn, nn, nn); L.MatSetType(A.h, b"seqaijhipmi355x"); L.MatSetUp(A.h)
+        return A
+
+    def batch(A, v):
+        L.MatSetValuesBatch(A.h, nb, bs, rows.ctypes.data_as(C.c_void_p), np.ascontiguousarray(v).ctypes.data_as(C.c_void_p))
+        L.MatAssemblyBegin(A.h, 0); L.MatAssemblyEnd(A.h, 0)
+
+    def values(A):
+        m = C.c_int(); pi, pj, pa = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        L.MatSeqAIJGetArrays(A.h, C.byref(m), C.byref(pi), C.byref(pj), C.byref(pa))
+        ai = np.ctypeslib.as_array((C.c_int * (m.value + 1)).from_address(pi.value)).copy()
+        return ai, np.ctypeslib.as_array((C.c_double * int(ai[-1])).from_address(pa.value)).copy()
+
+    A = new_mat(); batch(A, v1)                            # loop route (nothing assembled yet)
+    x = P.Vec.from_array(np.cos(0.3 * np.arange(nn)), comm=L.COMM_SELF); y = x.duplicate()
+    A.mult(x, y)                                           # first (and only) upload
+    batch(A, v2)                                           # device route: A += second set
+    ai, a_dev = values(A)
+    A.mult(x, y); y_dev = y.array()
+    nup = C.c_int(); L.MatHIPMI355XGetUploadCount(A.h, C.byref(nup))
+    assert nup.value == 1
+    L.PetscOptionsClear()
+    B = new_mat(); batch(B, v1)
+    for b in range(nb):                                    # the reference's default: one MatSetValues per block
+        r = rows[b].ctypes.data_as(C.c_void_p)
+        L.MatSetValues(B.h, bs, r, bs, r, np.ascontiguousarray(v2[b]).ctypes.data_as(C.c_void_p), 2)
+    L.MatAssemblyBegin(B.h, 0); L.MatAssemblyEnd(B.h, 0)
+    bi, b_ref = values(B)
+    assert np.array_equal(ai, bi) and np.array_equal(bits(a_dev), bits(b_ref))
+    B.mult(x, y)
+    assert np.array_equal(bits(y_dev), bits(y.array()))
+    # zero and re-assemble on the device: the map is reused
+    L.MatZeroEntries(A.h); batch(A, v2)
+    C_ = new_mat(); batch(C_, v2)
+    assert np.array_equal(bits(values(A)[1]), bits(values(C_)[1]))
+    L.MatHIPMI355XGetUploadCount(A.h, C.byref(nup))
+    assert nup.value == 1
