@@ -18,6 +18,7 @@ def built():
     """Make sure the in-tree libraries exist (built by __graft_entry__.build())."""
     import petsc_dev_amd as pda
     if not (os.path.exists(pda.kernels_lib_path()) and os.path.exists(pda.host_lib_path())
-            and os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so"))):
+            and os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so"))
+            and os.path.exists(os.path.join(ROOT, "examples", "poisson2d"))):
         pda.build_all()
     return pda
