@@ -508,6 +508,22 @@ def test_monitor_text_is_the_reference_output(P, capfd):
     assert out[0].startswith("  0 KSP Residual norm 5.04975") and out[0].endswith("e+00 ") and len(out[0]) == len("  0 KSP Residual norm 5.049752469181e+00 ")
 
 
+@pytest.mark.parametrize("norm", ["natural", "unpreconditioned"])
+def test_ksp_cg_single_reduction_with_other_norms(P, norm):
+    """-ksp_cg_single_reduction combined with the natural / unpreconditioned norm (cg.c:141-147,247-270): against the
+    oracle's restatement of the same branches"""
+    ai, aj, aa = pb.lap2d(31, 27)
+    n = ai.size - 1
+    b = orc.spmv(ai, aj, aa, np.cos(0.2 * np.arange(n)))
+    nt = dict(unpreconditioned=2, natural=3)[norm]
+    x, h, its, reason = solve(P, ai, aj, aa, b, "cg", "jacobi", opts="-ksp_cg_single_reduction 1 -ksp_norm_type " + norm, rtol=1e-8)
+    xr, hr, itsr, rr = orc.ksp_solve(ai, aj, aa, b, ksp="cg", pc="jacobi", rtol=1e-8, cg_single=1, norm_type=nt)
+    assert reason == rr == 2 and abs(its - itsr) <= 1
+    k = min(len(h), len(hr))
+    assert np.allclose(h[:k], hr[:k], rtol=1e-6, atol=1e-14 * hr[0])
+    assert np.linalg.norm(x - xr) <= 1e-6 * np.linalg.norm(xr)
+
+
 def test_ksp_cg_single_reduction(P):
     """-ksp_cg_single_reduction (cg.c:116-122,200-203,263-270): two reductions per iteration instead of
     three (VecMDot(2) for delta and beta), A*p by recurrence; same op sequence as the oracle's restatement"""
