@@ -437,6 +437,15 @@ def test_ksp_cg_norm_types(P, norm, pc):
         k = min(len(hf), len(hr))
         assert np.allclose(hf[:k], hr[:k], rtol=1e-6, atol=1e-14 * hr[0])
     assert np.linalg.norm(xf - xr) <= 1e-6 * np.linalg.norm(xr)
+    if norm != "none":
+        # nonzero initial guess: the relative tolerance is then measured against the norm of the right-hand side in
+        # the selected norm (KSPDefaultConverged, iterativ.c:718-737)
+        x0 = 0.3 * np.sin(np.arange(n))
+        xg, hg, itsg, rg = solve(P, ai, aj, aa, b, "cg", pc, x0=x0, opts=o, **kw)
+        xo, ho, itso, ro = orc.ksp_solve(ai, aj, aa, b, ksp="cg", pc=pc, x0=x0, norm_type=nt, **kw)
+        assert rg == ro == 2 and abs(itsg - itso) <= 1
+        k = min(len(hg), len(ho))
+        assert np.allclose(hg[:k], ho[:k], rtol=1e-6, atol=1e-14 * ho[0])
 
 
 def test_ksp_bcgs_as_smoother_without_norms(P):
