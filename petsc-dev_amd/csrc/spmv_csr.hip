@@ -224,7 +224,7 @@ __global__ __launch_bounds__(SPMV_THREADS, SPMV_MINWAVES) void spmv_csr_rowblock
   __shared__ unsigned char rowof[SPMV_BLOCK_NNZ];
   __shared__ int offtab[256];
   __shared__ double wsum[SPMV_THREADS / MI355X_WAVE];
-  static_assert(SPMV_THREADS >= 256, "the offset table is staged by the first 256 lanes");
+  static_assert(SPMV_THREADS == 256 || SPMV_THREADS == 128 || SPMV_THREADS == 512, "the offset table is staged 256 / SPMV_THREADS entries per lane");
   static_assert(!(DOT && ADD), "the x'y by-product is provided for y = A x only");
 #if SPMV_REMAP == 2
   const int xcd = blockIdx.x % MI355X_NXCD;
@@ -241,10 +241,12 @@ __global__ __launch_bounds__(SPMV_THREADS, SPMV_MINWAVES) void spmv_csr_rowblock
   const int nrows = r1 - r0;
   const int tid = threadIdx.x;
   const int tabv = offtab_g[tid & 255];   // 256 initialised entries (zeros past ntab)
+  const int tabv2 = (SPMV_THREADS < 256) ? offtab_g[(tid + SPMV_THREADS) & 255] : 0;
   (void)ntab;
 
   if (nnz > SPMV_BLOCK_CAP) {   // one long row: every entry belongs to row r0
     if (tid < 256) offtab[tid] = tabv;
+    if (SPMV_THREADS < 256) offtab[tid + SPMV_THREADS] = tabv2;
     __syncthreads();
     double s = 0.0;
     for (int k = k0 + tid; k < k1; k += SPMV_THREADS) s += SPMV_LOAD(aa + k) * x[r0 + offtab[SPMV_LOAD(idx8 + k)]];
@@ -293,6 +295,7 @@ __global__ __launch_bounds__(SPMV_THREADS, SPMV_MINWAVES) void spmv_csr_rowblock
   // row markers: the lanes of row r tag its nonzeros
   for (int k = rs + sub; k < re; k += tpr) rowof[k] = (unsigned char)r;
   if (tid < 256) offtab[tid] = tabv;
+  if (SPMV_THREADS < 256) offtab[tid + SPMV_THREADS] = tabv2;
   __syncthreads();
   double xa[PAIRS], xb[PAIRS];
 #pragma unroll
