@@ -210,3 +210,32 @@ def test_ksp_random_small_systems(P, seed):
     assert np.allclose(h[:kk][early], hr[:kk][early], rtol=1e-6, atol=0)
     assert np.linalg.norm(x - xr) <= 1e-6 * max(np.linalg.norm(xr), 1e-300)
     assert np.linalg.norm(x - xs) <= 1e-6 * max(np.linalg.norm(xs), 1e-300)
+
+
+@pytest.mark.parametrize("ksp,pc", [("cg", "jacobi"), ("gmres", "bjacobi"), ("bcgs", "jacobi"), ("gmres", "ilu")])
+def test_repeated_solves_are_bitwise_reproducible(P, ksp, pc):
+    """fixed reduction trees, ticketed hand-off, no floating-point atomics: five solves of the same system (new KSP and
+    vectors each time, 0.6 M unknowns so that every kernel runs many workgroups per CU) give the same history bits and
+    the same solution bits"""
+    L = P.lib()
+    ai, aj, aa = P.gen_poisson7(96, 80, 80)
+    n = ai.size - 1
+    aa = aa * (1.0 + 0.05 * np.cos(np.arange(aa.size)))
+    b = np.cos(0.01 * np.arange(n))
+    A = P.Mat.from_csr(ai, aj, aa)
+    ref = None
+    for rep in range(5):
+        vb = P.Vec.from_array(b, comm=L.COMM_SELF); vx = P.Vec.from_array(np.zeros(n), comm=L.COMM_SELF)
+        k = P.KSP(comm=L.COMM_SELF)
+        k.set_operators(A)
+        L.PetscOptionsClear()
+        L.PetscOptionsInsertString(("-ksp_type %s -pc_type %s -ksp_gmres_restart 10" % (ksp, pc)).encode())
+        k.set_tolerances(rtol=1e-6, max_it=60)
+        k.set_from_options(); k.record_history()
+        k.solve(vb, vx)
+        L.PetscOptionsClear()
+        got = (k.its, k.reason, bits(k.history()).copy(), bits(vx.array()).copy())
+        if ref is None:
+            ref = got
+        else:
+            assert got[:2] == ref[:2] and np.array_equal(got[2], ref[2]) and np.array_equal(got[3], ref[3]), "run %d differs" % rep
