@@ -47,6 +47,7 @@ int  mi355x_handle_wait_result(mi355x_handle_t h);
 /* queue a copy of count (<= 64) doubles from device memory to the pinned scratch followed by the completion number:
  * mi355x_handle_wait_result then returns as soon as THAT point of the stream is reached, whatever was queued behind it */
 int  mi355x_handle_publish(mi355x_handle_t h, const double *src_dev, int count);
+int  mi355x_handle_publish_at(mi355x_handle_t h, const double *src_dev, int count, int dst_offset);   /* into host_scratch[dst_offset ..) */
 void *mi355x_handle_stream(mi355x_handle_t h);           /* the raw hipStream_t */
 /* pinned, device-visible scratch of >= 64 doubles owned by the handle
  * (reduction results are written here by the device, read by the host

@@ -99,6 +99,7 @@ typedef const char *PCType;
 #define KSPGMRES   "gmres"
 #define KSPBCGS    "bcgs"
 #define KSPPREONLY "preonly"
+#define KSPGROPPCG "groppcg"   /* Gropp's overlapped CG (src/ksp/ksp/impls/cg/groppcg/groppcg.c), SURVEY 8f.4 */
 #define PCNONE     "none"
 #define PCJACOBI   "jacobi"
 #define PCBJACOBI  "bjacobi"
@@ -185,6 +186,12 @@ PetscErrorCode VecMTDot(Vec x, PetscInt nv, const Vec y[], PetscScalar val[]);
 PetscErrorCode VecNorm(Vec x, NormType type, PetscReal *val);
 PetscErrorCode VecNormalize(Vec x, PetscReal *val);
 PetscErrorCode VecDotNorm2(Vec s, Vec t, PetscScalar *dp, PetscReal *nm);
+/* split-phase reductions (src/vec/vec/utils/comb.c:402-721); the all-reduce runs on the halo stream between Begin and End */
+PetscErrorCode VecDotBegin(Vec x, Vec y, PetscScalar *result);
+PetscErrorCode VecDotEnd(Vec x, Vec y, PetscScalar *result);
+PetscErrorCode VecNormBegin(Vec x, NormType type, PetscReal *result);   /* NORM_2 */
+PetscErrorCode VecNormEnd(Vec x, NormType type, PetscReal *result);
+PetscErrorCode PetscCommSplitReductionBegin(MPI_Comm comm);
 
 /* ---- VecScatter (parallel -> sequential general, the MPIAIJ halo) ----------------------------- */
 PetscErrorCode VecScatterBegin(VecScatter ctx, Vec x, Vec y, InsertMode addv, ScatterMode mode);

@@ -311,6 +311,55 @@ static void solve_cg(solver *s, const double *B, double *X) {
   free(R);
 }
 
+/* ---- KSPSolve_GROPPCG, src/ksp/ksp/impls/cg/groppcg/groppcg.c:40-175 (split-phase reductions are immediate here) ---- */
+static void solve_groppcg(solver *sv, const double *B, double *X) {
+  size_t n = (size_t)sv->n;
+  const int nt = sv->norm_type;
+  double *r = (double *)malloc(6 * n * sizeof(double)), *p = r + n, *s = p + n, *S = s + n, *z = S + n, *Z = z + n;
+  double alpha, beta, gamma, gammaNew, t, dp = 0.0;
+  int i;
+  sv->its = 0;
+  if (sv->guess_nonzero) { mat_mult(sv, X, r); orc_vec_aypx(n, -1.0, B, r); }
+  else orc_vec_copy(n, B, r);
+  pc_apply(sv, r, z);
+  orc_vec_copy(n, z, p);
+  gamma = orc_vec_dot(n, r, z);
+  mat_mult(sv, p, s);
+  if (nt == 1) orc_vec_norm(n, 1, z, &dp);
+  else if (nt == 2) orc_vec_norm(n, 1, r, &dp);
+  else if (nt == 3) dp = sqrt(fabs(gamma));
+  else dp = 0.0;
+  monitor(sv, dp);
+  converged(sv, 0, dp, B);
+  if (sv->reason) { free(r); return; }
+  i = 0;
+  do {
+    sv->its = i + 1;
+    i++;
+    t = orc_vec_dot(n, p, s);
+    pc_apply(sv, s, S);
+    alpha = gamma / t;
+    orc_vec_axpy(n, alpha, p, X);
+    orc_vec_axpy(n, -alpha, s, r);
+    orc_vec_axpy(n, -alpha, S, z);
+    if (nt == 2) orc_vec_norm(n, 1, r, &dp);
+    else if (nt == 1) orc_vec_norm(n, 1, z, &dp);
+    gammaNew = orc_vec_dot(n, r, z);
+    mat_mult(sv, z, Z);
+    if (nt == 3) dp = sqrt(fabs(gammaNew));
+    else if (nt == 0) dp = 0.0;
+    monitor(sv, dp);
+    converged(sv, i, dp, B);
+    if (sv->reason) break;
+    beta = gammaNew / gamma;
+    gamma = gammaNew;
+    orc_vec_aypx(n, beta, z, p);
+    orc_vec_aypx(n, beta, Z, s);
+  } while (i < sv->max_it);
+  if (i >= sv->max_it && !sv->reason) sv->reason = R_DIVERGED_ITS;
+  free(r);
+}
+
 /* ---- KSPSolve_GMRES, src/ksp/ksp/impls/gmres/gmres.c:118-409 + borthog2.c:35-119 ---- */
 typedef struct {
   int max_k;
@@ -498,6 +547,7 @@ static int solve(solver *s, const double *b, double *x) {
   s->reason = R_ITERATING; s->its = 0;
   switch (s->ksp_type) {
   case ORC_KSP_CG: solve_cg(s, b, x); break;
+  case ORC_KSP_GROPPCG: solve_groppcg(s, b, x); break;
   case ORC_KSP_GMRES: solve_gmres(s, b, x); break;
   case ORC_KSP_BCGS: solve_bcgs(s, b, x); break;
   case ORC_KSP_PREONLY: pc_apply(s, b, x); s->its = 1; s->reason = R_CONVERGED_ITS; break;

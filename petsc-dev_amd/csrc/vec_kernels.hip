@@ -675,14 +675,15 @@ int mi355x_vec_aypx_dev(mi355x_handle_t h, size_t n, const double *num_dev, doub
   MI355X_LAUNCH_CHECK();
   return 0;
 }
-int mi355x_handle_publish(mi355x_handle_t h, const double *src_dev, int count) {
-  if (count < 0 || count > MI355X_SCRATCH_DOUBLES) return (int)hipErrorInvalidValue;
+int mi355x_handle_publish_at(mi355x_handle_t h, const double *src_dev, int count, int dst_offset) {
+  if (count < 0 || dst_offset < 0 || dst_offset + count > MI355X_SCRATCH_DOUBLES) return (int)hipErrorInvalidValue;
   const unsigned long long seq = ++h->seq;
-  hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(MI355X_WAVE), 0, h->stream, src_dev, h->host_scratch, count,
+  hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(MI355X_WAVE), 0, h->stream, src_dev, h->host_scratch + dst_offset, count,
                      const_cast<unsigned long long *>(h->host_seq), seq);
   MI355X_LAUNCH_CHECK();
   return 0;
 }
+int mi355x_handle_publish(mi355x_handle_t h, const double *src_dev, int count) { return mi355x_handle_publish_at(h, src_dev, count, 0); }
 int mi355x_vec_axpby(mi355x_handle_t h, size_t n, double alpha, double beta, const double *x, double *y) {
   // bvec1.c:329-356
   if (alpha == 0.0) return mi355x_vec_scale(h, n, beta, y);

@@ -216,6 +216,88 @@ PetscErrorCode KSPCreate_CG(KSP ksp) {
   return 0;
 }
 
+/* ================================================================== GROPPCG
+ * Gropp's variant of CG (src/ksp/ksp/impls/cg/groppcg/groppcg.c:40-175): the same Krylov space, two
+ * reductions per iteration, each overlapped with work that does not need its result -- (p,s) with the preconditioner
+ * application, {norm, (r,z)} with the matrix product.  The reductions are split-phase (VecDotBegin/End,
+ * PetscCommSplitReductionBegin): on several GPUs the all-reduce travels on the halo stream while the compute stream
+ * runs the overlapped kernel.  Six work vectors, all four norm types. */
+static PetscErrorCode KSPSetUp_GROPPCG(KSP ksp) { return KSPDefaultGetWork(ksp, 6); }
+static PetscErrorCode KSPSolve_GROPPCG(KSP ksp) {
+  PetscErrorCode ierr;
+  PetscInt i;
+  PetscScalar alpha, beta = 0.0, gamma, gammaNew, t;
+  PetscReal dp = 0.0;
+  Vec x = ksp->vec_sol, b = ksp->vec_rhs, r = ksp->work[0], p = ksp->work[1], s = ksp->work[2], S = ksp->work[3], z = ksp->work[4], Z = ksp->work[5];
+  Mat Amat = ksp->pc->mat;
+  const KSPNormType nt = ksp->normtype;
+
+  ksp->its = 0;
+  if (!ksp->guess_zero) {
+    ierr = KSP_MatMult(ksp, Amat, x, r);CHKERRQ(ierr);           /* r <- b - Ax */
+    ierr = VecAYPX(r, -1.0, b);CHKERRQ(ierr);
+  } else { ierr = VecCopy(b, r);CHKERRQ(ierr); }
+  ierr = KSP_PCApply(ksp, r, z);CHKERRQ(ierr);                   /* z <- Br */
+  ierr = VecCopy(z, p);CHKERRQ(ierr);                            /* p <- z */
+  ierr = VecDotBegin(r, z, &gamma);CHKERRQ(ierr);                /* gamma <- z'r, overlapped with s <- Ap */
+  ierr = PetscCommSplitReductionBegin(r->comm);CHKERRQ(ierr);
+  ierr = KSP_MatMult(ksp, Amat, p, s);CHKERRQ(ierr);
+  ierr = VecDotEnd(r, z, &gamma);CHKERRQ(ierr);
+  switch (nt) {
+  case KSP_NORM_PRECONDITIONED: ierr = VecNorm(z, NORM_2, &dp);CHKERRQ(ierr); break;
+  case KSP_NORM_UNPRECONDITIONED: ierr = VecNorm(r, NORM_2, &dp);CHKERRQ(ierr); break;
+  case KSP_NORM_NATURAL:
+    if (PetscIsInfOrNanScalar(gamma)) SETERRQ(ksp->comm, PETSC_ERR_FP, "Infinite or not-a-number generated in dot product");
+    dp = PetscSqrtReal(PetscAbsScalar(gamma));
+    break;
+  case KSP_NORM_NONE: dp = 0.0; break;
+  default: SETERRQ(ksp->comm, PETSC_ERR_SUP, "norm type %d", (int)nt);
+  }
+  KSPLogResidualHistory(ksp, dp);
+  ierr = KSPMonitor(ksp, 0, dp);CHKERRQ(ierr);
+  ksp->rnorm = dp;
+  ierr = KSPDefaultConverged(ksp, 0, dp, &ksp->reason);CHKERRQ(ierr);
+  if (ksp->reason) return 0;
+
+  i = 0;
+  do {
+    ksp->its = i + 1;
+    i++;
+    ierr = VecDotBegin(p, s, &t);CHKERRQ(ierr);                  /* t <- p's, overlapped with S <- Bs */
+    ierr = PetscCommSplitReductionBegin(p->comm);CHKERRQ(ierr);
+    ierr = KSP_PCApply(ksp, s, S);CHKERRQ(ierr);
+    ierr = VecDotEnd(p, s, &t);CHKERRQ(ierr);
+    alpha = gamma / t;
+    ierr = VecAXPY(x, alpha, p);CHKERRQ(ierr);                   /* x <- x + alpha p */
+    ierr = VecAXPY(r, -alpha, s);CHKERRQ(ierr);                  /* r <- r - alpha s */
+    ierr = VecAXPY(z, -alpha, S);CHKERRQ(ierr);                  /* z <- z - alpha S */
+    if (nt == KSP_NORM_UNPRECONDITIONED) { ierr = VecNormBegin(r, NORM_2, &dp);CHKERRQ(ierr); }
+    else if (nt == KSP_NORM_PRECONDITIONED) { ierr = VecNormBegin(z, NORM_2, &dp);CHKERRQ(ierr); }
+    ierr = VecDotBegin(r, z, &gammaNew);CHKERRQ(ierr);           /* overlapped with Z <- Az */
+    ierr = PetscCommSplitReductionBegin(r->comm);CHKERRQ(ierr);
+    ierr = KSP_MatMult(ksp, Amat, z, Z);CHKERRQ(ierr);
+    if (nt == KSP_NORM_UNPRECONDITIONED) { ierr = VecNormEnd(r, NORM_2, &dp);CHKERRQ(ierr); }
+    else if (nt == KSP_NORM_PRECONDITIONED) { ierr = VecNormEnd(z, NORM_2, &dp);CHKERRQ(ierr); }
+    ierr = VecDotEnd(r, z, &gammaNew);CHKERRQ(ierr);
+    if (nt == KSP_NORM_NATURAL) {
+      if (PetscIsInfOrNanScalar(gammaNew)) SETERRQ(ksp->comm, PETSC_ERR_FP, "Infinite or not-a-number generated in dot product");
+      dp = PetscSqrtReal(PetscAbsScalar(gammaNew));
+    } else if (nt == KSP_NORM_NONE) dp = 0.0;
+    ksp->rnorm = dp;
+    KSPLogResidualHistory(ksp, dp);
+    ierr = KSPMonitor(ksp, i, dp);CHKERRQ(ierr);
+    ierr = KSPDefaultConverged(ksp, i, dp, &ksp->reason);CHKERRQ(ierr);
+    if (ksp->reason) break;
+    beta = gammaNew / gamma;
+    gamma = gammaNew;
+    ierr = VecAYPX(p, beta, z);CHKERRQ(ierr);                    /* p <- z + beta p */
+    ierr = VecAYPX(s, beta, Z);CHKERRQ(ierr);                    /* s <- Z + beta s */
+  } while (i < ksp->max_it);
+  if (i >= ksp->max_it && !ksp->reason) ksp->reason = KSP_DIVERGED_ITS;
+  return 0;
+}
+PetscErrorCode KSPCreate_GROPPCG(KSP ksp) { ksp->ops->setup = KSPSetUp_GROPPCG; ksp->ops->solve = KSPSolve_GROPPCG; return 0; }
+
 /* ================================================================== GMRES(m) */
 typedef struct {
   PetscInt max_k;

@@ -510,6 +510,104 @@ PetscErrorCode VecBCGSUpdate_HIPMI355X(Vec x, Vec r, Vec p, Vec s_, Vec t, Vec r
   return 0;
 }
 
+/* ---- split-phase reductions (src/vec/vec/utils/comb.c:402-721: VecDotBegin/End, VecNormBegin/End,
+ * PetscCommSplitReductionBegin).  Begin launches the device reduction into the next slot of the device scratch (no
+ * host involvement); PetscCommSplitReductionBegin starts what brings the queued results to the host -- one RCCL
+ * all-reduce of all slots ON THE HALO STREAM (it overlaps the kernels the caller queues on the compute stream
+ * meanwhile, the point of KSPGROPPCG) followed by the publish kernel there; on one rank just the publish kernel on the
+ * compute stream, ahead of the caller's next kernels -- and the first End polls the completion number. */
+#define SR_SLOT0 48      /* device scratch slots of the pending results (ordinary reductions use <= 32 from slot 0) */
+#define SR_HOST0 48      /* where they land in the pinned scratch: clear of what ordinary reductions (<= 32 values) use meanwhile */
+#define SR_MAX 8
+static struct { int n, started, fetched; int kind[SR_MAX]; PetscScalar val[SR_MAX]; Vec owner; mi355x_event_t ev; } sr;
+static PetscErrorCode sr_queue(Vec x, int kind, const PetscScalar *dx, const PetscScalar *dy) {
+  PetscErrorCode ierr; DEVCTX;
+  if (sr.started) SETERRQ(x->comm, PETSC_ERR_ORDER, "Called VecxxxBegin() in a different order or number of times than VecxxxEnd(): a split reduction is still pending");
+  if (sr.n >= SR_MAX) SETERRQ(x->comm, PETSC_ERR_SUP, "at most %d reductions per split phase", SR_MAX);
+  double *slot = HOST_STAGED(x) ? mi355x_handle_host_scratch(dc->h) + SR_HOST0 + sr.n : mi355x_handle_device_scratch(dc->h) + SR_SLOT0 + sr.n;
+  if (kind == 0) CHKHIP(mi355x_vec_dot(dc->h, N_(x), dx, dy, slot));
+  else CHKHIP(mi355x_vec_norm(dc->h, N_(x), 1, dx, slot));
+  sr.kind[sr.n++] = kind; sr.owner = x;
+  return 0;
+}
+PetscErrorCode VecDotBegin(Vec x, Vec y, PetscScalar *result) {
+  PetscErrorCode ierr; const PetscScalar *dx, *dy;
+  (void)result;
+  CheckHIP(x); CheckHIP(y);
+  if (x->map->n != y->map->n) SETERRQ(x->comm, PETSC_ERR_ARG_INCOMP, "Incompatible vector local lengths");
+  ierr = VecHIPGetRead(x, &dx);CHKERRQ(ierr);
+  ierr = VecHIPGetRead(y, &dy);CHKERRQ(ierr);
+  ierr = sr_queue(x, 0, dx, dy);CHKERRQ(ierr);
+  if (x->map->n > 0) { ierr = PetscLogFlops(2.0 * x->map->n - 1);CHKERRQ(ierr); }
+  return 0;
+}
+PetscErrorCode VecNormBegin(Vec x, NormType type, PetscReal *result) {
+  PetscErrorCode ierr; const PetscScalar *dx;
+  (void)result;
+  CheckHIP(x);
+  if (type != NORM_2) SETERRQ(x->comm, PETSC_ERR_SUP, "split-phase norms: NORM_2 only");
+  ierr = VecHIPGetRead(x, &dx);CHKERRQ(ierr);
+  ierr = sr_queue(x, 1, dx, NULL);CHKERRQ(ierr);
+  ierr = PetscLogFlops(PetscMax(2.0 * x->map->n - 1, 0.0));CHKERRQ(ierr);
+  return 0;
+}
+PetscErrorCode PetscCommSplitReductionBegin(MPI_Comm comm) {
+  PetscErrorCode ierr; DEVCTX;
+  (void)comm;
+  if (!sr.n || sr.started) return 0;
+  Vec x = sr.owner;
+  sr.started = 1; sr.fetched = 0;
+  if (HOST_STAGED(x)) return 0;                                   /* host all-reduce at the first End */
+  double *ds = mi355x_handle_device_scratch(dc->h) + SR_SLOT0;
+  if (DEVICE_COLLECTIVES(x)) {
+    if (!sr.ev) CHKHIP(mi355x_event_create(&sr.ev));
+    CHKHIP(mi355x_event_record(sr.ev, dc->h));                    /* the reductions queued so far */
+    CHKHIP(mi355x_handle_wait_event(dc->hcomm, sr.ev));
+    CHKHIP(mi355x_comm_allreduce_sum(x->comm->dcomm, dc->hcomm, ds, (size_t)sr.n));
+    CHKHIP(mi355x_handle_publish_at(dc->hcomm, ds, sr.n, SR_HOST0));   /* lands in the HALO handle's pinned scratch */
+  } else {
+    CHKHIP(mi355x_handle_publish_at(dc->h, ds, sr.n, SR_HOST0));
+  }
+  return 0;
+}
+static PetscErrorCode sr_fetch(Vec x) {
+  PetscErrorCode ierr; DEVCTX;
+  if (!sr.n) SETERRQ(x->comm, PETSC_ERR_ORDER, "VecxxxEnd() without a matching VecxxxBegin()");
+  if (!sr.started) { ierr = PetscCommSplitReductionBegin(x->comm);CHKERRQ(ierr); }
+  if (sr.fetched == 0) {
+    Vec o = sr.owner;
+    if (HOST_STAGED(o)) {
+      CHKHIP(mi355x_handle_synchronize(dc->h));
+      const double *hs = mi355x_handle_host_scratch(dc->h) + SR_HOST0;
+      for (int j = 0; j < sr.n; j++) sr.val[j] = hs[j];
+      if (o->comm->allreduce(o->comm->ctx, sr.val, sr.n, 1, 0)) SETERRQ(o->comm, PETSC_ERR_LIB, "allreduce failed");
+    } else {
+      mi355x_handle_t hh = DEVICE_COLLECTIVES(o) ? dc->hcomm : dc->h;
+      CHKHIP(mi355x_handle_wait_result(hh));
+      const double *hs = mi355x_handle_host_scratch(hh) + SR_HOST0;
+      for (int j = 0; j < sr.n; j++) sr.val[j] = hs[j];
+      /* the slots may be rewritten by the next phase only after the all-reduce that read them has finished */
+      if (DEVICE_COLLECTIVES(o)) { CHKHIP(mi355x_event_record(sr.ev, dc->hcomm)); CHKHIP(mi355x_handle_wait_event(dc->h, sr.ev)); }
+    }
+  }
+  return 0;
+}
+static PetscErrorCode sr_take(Vec x, int kind, PetscScalar *out) {
+  PetscErrorCode ierr = sr_fetch(x);CHKERRQ(ierr);
+  if (sr.fetched >= sr.n || sr.kind[sr.fetched] != kind) SETERRQ(x->comm, PETSC_ERR_ORDER, "Called VecxxxEnd() in a different order or number of times than VecxxxBegin()");
+  *out = sr.val[sr.fetched++];
+  if (sr.fetched == sr.n) { sr.n = 0; sr.started = 0; sr.fetched = 0; sr.owner = NULL; }
+  return 0;
+}
+PetscErrorCode VecDotEnd(Vec x, Vec y, PetscScalar *result) { (void)y; return sr_take(x, 0, result); }
+PetscErrorCode VecNormEnd(Vec x, NormType type, PetscReal *result) {
+  PetscScalar v;
+  (void)type;
+  PetscErrorCode ierr = sr_take(x, 1, &v);CHKERRQ(ierr);
+  *result = PetscSqrtReal(v);                                     /* squares reduced, then rooted (comb.c / pvec2.c:62) */
+  return 0;
+}
+
 static PetscErrorCode VecDestroy_HIP(Vec v) {
   Vec_HIPMI355X *s = VH(v);
   if (!s) return 0;

@@ -27,7 +27,7 @@ _SIG = {
     "VecSet": [vp, dbl], "VecCopy": [vp, vp], "VecSwap": [vp, vp], "VecScale": [vp, dbl], "VecAXPY": [vp, dbl, vp],
     "VecAYPX": [vp, dbl, vp], "VecAXPBY": [vp, dbl, dbl, vp], "VecWAXPY": [vp, dbl, vp, vp],
     "VecAXPBYPCZ": [vp, dbl, dbl, dbl, vp, vp], "VecMAXPY": [vp, i32, vp, vp], "VecPointwiseMult": [vp, vp, vp],
-    "VecPointwiseDivide": [vp, vp, vp], "VecReciprocal": [vp], "VecDot": [vp, vp, P(dbl)], "VecTDot": [vp, vp, P(dbl)],
+    "VecPointwiseDivide": [vp, vp, vp], "VecReciprocal": [vp], "VecDot": [vp, vp, P(dbl)], "VecDotBegin": [vp, vp, P(dbl)], "VecDotEnd": [vp, vp, P(dbl)], "VecNormBegin": [vp, i32, P(dbl)], "VecNormEnd": [vp, i32, P(dbl)], "PetscCommSplitReductionBegin": [vp], "VecTDot": [vp, vp, P(dbl)],
     "VecMDot": [vp, i32, vp, vp], "VecMTDot": [vp, i32, vp, vp], "VecNorm": [vp, i32, P(dbl)], "VecNormalize": [vp, P(dbl)],
     "VecDotNorm2": [vp, vp, P(dbl), P(dbl)],
     "VecScatterBegin": [vp, vp, vp, i32, i32], "VecScatterEnd": [vp, vp, vp, i32, i32],

@@ -237,7 +237,7 @@ class KspOpts(C.Structure):
                 ("sub_dtol", C.c_double), ("sub_max_it", C.c_int), ("cg_single", C.c_int), ("norm_type", C.c_int), ("pc_right", C.c_int)]
 
 
-KSP = dict(cg=0, gmres=1, bcgs=2, preonly=3)
+KSP = dict(cg=0, gmres=1, bcgs=2, preonly=3, groppcg=4)
 PC = dict(none=0, jacobi=1, bjacobi=2, ilu=3)
 
 

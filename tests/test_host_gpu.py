@@ -377,7 +377,8 @@ def test_device_collectives_on_a_one_rank_rccl_communicator(P):
         for nt in (0, 1, 2, 3):
             assert x.norm(nt) == xc.norm(nt)
         assert x.dot(y) == xc.dot(yc)
-        for ksp, pc in (("cg", "jacobi"), ("cg", "none"), ("gmres", "jacobi"), ("bcgs", "jacobi")):
+        # groppcg: its split-phase all-reduce travels on the HALO stream and is published from the halo handle
+        for ksp, pc in (("cg", "jacobi"), ("cg", "none"), ("gmres", "jacobi"), ("bcgs", "jacobi"), ("groppcg", "jacobi"), ("groppcg", "bjacobi")):
             ref = solve(P, ai, aj, aa, b, ksp, pc, rtol=1e-9)
             got = solve(P, ai, aj, aa, b, ksp, pc, rtol=1e-9, comm=comm)
             assert got[2:] == ref[2:]
@@ -531,6 +532,42 @@ def test_ksp_cg_single_reduction_with_other_norms(P, norm):
     k = min(len(h), len(hr))
     assert np.allclose(h[:k], hr[:k], rtol=1e-6, atol=1e-14 * hr[0])
     assert np.linalg.norm(x - xr) <= 1e-6 * np.linalg.norm(xr)
+
+
+@pytest.mark.parametrize("norm", ["preconditioned", "unpreconditioned", "natural", "none"])
+def test_ksp_groppcg(P, norm):
+    """KSPGROPPCG (groppcg.c:40-175) on split-phase reductions (VecDotBegin/End, VecNormBegin/End,
+    PetscCommSplitReductionBegin): history against the oracle's restatement for every norm type, same solution as
+    KSPCG, and the split-reduction calls refuse a wrong Begin/End order as comb.c does."""
+    ai, aj, aa = pb.lap2d(37, 31)
+    n = ai.size - 1
+    d = 1.0 + 0.5 * np.sin(np.arange(n))
+    rows = np.repeat(np.arange(n), np.diff(ai))
+    aa = aa * d[rows] * d[aj]
+    b = orc.spmv(ai, aj, aa, np.cos(0.3 * np.arange(n)))
+    nt = dict(none=0, preconditioned=1, unpreconditioned=2, natural=3)[norm]
+    kw = dict(rtol=1e-8, max_it=41 if norm == "none" else 500)
+    for pc in ("jacobi", "bjacobi"):
+        x, h, its, reason = solve(P, ai, aj, aa, b, "groppcg", pc, opts="-ksp_norm_type " + norm, **kw)
+        okw = dict(blocks=[0, n], sub_ksp="preonly", sub_pc="ilu") if pc == "bjacobi" else {}
+        xr, hr, itsr, rr = orc.ksp_solve(ai, aj, aa, b, ksp="groppcg", pc=pc, norm_type=nt, **kw, **okw)
+        assert reason == rr and abs(its - itsr) <= 1
+        k = min(len(h), len(hr))
+        assert np.allclose(h[:k], hr[:k], rtol=1e-6, atol=1e-14 * max(hr[0], 1e-300))
+        assert np.linalg.norm(x - xr) <= 1e-6 * np.linalg.norm(xr)
+        if norm == "preconditioned":
+            xc, hc, itsc, rc = solve(P, ai, aj, aa, b, "cg", pc, **kw)
+            assert np.linalg.norm(x - xc) <= 1e-6 * np.linalg.norm(xc) and abs(its - itsc) <= 2
+    # Begin/End discipline
+    L = P.lib()
+    u, v = V(P, rnd(100, 1)), V(P, rnd(100, 2))
+    r1, r2 = C.c_double(), C.c_double()
+    L.VecDotBegin(u.h, v.h, C.byref(r1)); L.VecNormBegin(u.h, 1, C.byref(r2))
+    L.PetscCommSplitReductionBegin(L.COMM_SELF)
+    with pytest.raises(P.PetscError):
+        L.VecNormEnd(u.h, 1, C.byref(r2))                  # the dot was begun first
+    L.VecDotEnd(u.h, v.h, C.byref(r1)); L.VecNormEnd(u.h, 1, C.byref(r2))
+    assert r1.value == u.dot(v) and r2.value == u.norm()
 
 
 def test_ksp_cg_single_reduction(P):

@@ -50,6 +50,13 @@ def main():
     xr, hr, itsr, rr = orc.ksp_solve(gi, gj, ga, orc.spmv(gi, gj, ga, np.ones(N)), ksp="cg", pc="jacobi", rtol=1e-8)
     h = k.history()
     ok4 = abs(k.its - itsr) <= 1 and np.allclose(h[:min(len(h), len(hr))], hr[:min(len(h), len(hr))], rtol=1e-6)
+    # Gropp's CG over the same operator: split-phase reductions across the ranks (staged: host all-reduce at the End)
+    kg = P.KSP(comm=comm); kg.set_operators(A); kg.set_type("groppcg"); kg.set_pc_type("jacobi"); kg.set_tolerances(rtol=1e-8); kg.record_history()
+    L.VecSet(sol.h, 0.0)
+    kg.solve(b, sol)
+    xg_, hg, itsg, rg = orc.ksp_solve(gi, gj, ga, orc.spmv(gi, gj, ga, np.ones(N)), ksp="groppcg", pc="jacobi", rtol=1e-8)
+    hh = kg.history()
+    ok4 = ok4 and abs(kg.its - itsg) <= 1 and np.allclose(hh[:min(len(hh), len(hg))], hg[:min(len(hh), len(hg))], rtol=1e-6)
     # ---- irregular pattern, uneven ownership: non-contiguous halo indices (device pack / unpack kernels), several
     # neighbours, reverse-mode additions in rank order -- bit-exact against the MPIAIJ-ordered oracle emulation
     import scipy.sparse as sp

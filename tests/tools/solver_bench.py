@@ -21,7 +21,7 @@ def main():
     u = P.Vec.create(N, comm=L.COMM_SELF); L.VecSet(u.h, 1.0)
     b, x = u.duplicate(), u.duplicate()
     A.mult(u, b)
-    for ksp_t, pc_t in (("cg", "jacobi"), ("gmres", "jacobi"), ("bcgs", "jacobi"), ("cg", "none"), ("gmres", "none")):
+    for ksp_t, pc_t in (("cg", "jacobi"), ("groppcg", "jacobi"), ("gmres", "jacobi"), ("bcgs", "jacobi"), ("cg", "none"), ("gmres", "none")):
         ksp = P.KSP(comm=L.COMM_SELF)
         ksp.set_operators(A)
         L.PetscOptionsClear()
@@ -36,7 +36,7 @@ def main():
         ksp.solve(b, x)
         k.mi355x_device_synchronize()
         dt = time.perf_counter() - t0
-        print("%-6s + %-7s: %4d its  %8.3f ms/it  %8.1f it/s  (reason %d)" % (ksp_t, pc_t, ksp.its, dt / max(ksp.its, 1) * 1e3, ksp.its / dt, ksp.reason), flush=True)
+        print("%-7s + %-7s: %4d its  %8.3f ms/it  %8.1f it/s  (reason %d)" % (ksp_t, pc_t, ksp.its, dt / max(ksp.its, 1) * 1e3, ksp.its / dt, ksp.reason), flush=True)
         L.PetscOptionsClear()
 
 
