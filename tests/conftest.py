@@ -19,6 +19,7 @@ def built():
     import petsc_dev_amd as pda
     if not (os.path.exists(pda.kernels_lib_path()) and os.path.exists(pda.host_lib_path())
             and os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so"))
-            and os.path.exists(os.path.join(ROOT, "examples", "poisson2d"))):
+            and os.path.exists(os.path.join(ROOT, "examples", "poisson2d"))
+            and os.path.exists(os.path.join(ROOT, "examples", "mm2petsc"))):
         pda.build_all()
     return pda

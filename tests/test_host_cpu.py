@@ -304,3 +304,36 @@ def test_matload_parallel(built, size):
         return out
     got = FakeWorld(size).run(work)
     check_against_oracle(size, got, ai, aj, aa, ranges)
+
+
+def test_matrixmarket_converter(built, tmp_path):
+    """examples/mm2petsc (the reference's converter is the example ex72.c): MatrixMarket coordinate files --
+    real general, real symmetric (lower triangle stored), pattern symmetric -- become PETSc binary files that MatLoad
+    reads back as exactly the matrix scipy reads from the same .mtx.  Host-only, no GPU."""
+    import subprocess
+    import scipy.io
+    import scipy.sparse as sp
+    from petsc_dev_amd import petsc as P
+    L = P.lib()
+    exe = os.path.join(ROOT, "examples", "mm2petsc")
+    assert os.path.exists(exe), "examples/mm2petsc was not built"
+    rng = np.random.default_rng(7)
+    G = sp.random(37, 29, density=0.15, random_state=3, format="coo")
+    S = sp.random(41, 41, density=0.1, random_state=4, format="csr"); S = sp.coo_matrix(sp.tril(S + S.T + sp.eye(41)))
+    cases = {"general.mtx": (G, None), "symmetric.mtx": (S, "symmetric")}
+    for name, (m, symm) in cases.items():
+        scipy.io.mmwrite(str(tmp_path / name), m, symmetry=symm or "general")
+    with open(tmp_path / "pattern.mtx", "w") as f:          # pattern symmetric, with comment lines
+        f.write("%%MatrixMarket matrix coordinate pattern symmetric\n% a comment\n%\n5 5 6\n1 1\n2 1\n3 3\n5 2\n5 5\n4 4\n")
+    for name in ("general.mtx", "symmetric.mtx", "pattern.mtx"):
+        src, dst = str(tmp_path / name), str(tmp_path / (name + ".petsc"))
+        r = subprocess.run([exe, "-fin", src, "-fout", dst], capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0, r.stdout + r.stderr
+        ref = sp.csr_matrix(scipy.io.mmread(src)); ref.sort_indices()
+        viewer = C.c_void_p(); A = C.c_void_p()
+        L.PetscViewerBinaryOpen(L.COMM_SELF, dst.encode(), 0, C.byref(viewer))
+        L.MatCreate(L.COMM_SELF, C.byref(A)); L.MatLoad(A, viewer)
+        ai, aj, aa = seq_arrays(P, A)
+        assert np.array_equal(ai, ref.indptr) and np.array_equal(aj, ref.indices) and np.array_equal(aa, ref.data), name
+    r = subprocess.run([exe, "-fin", str(tmp_path / "missing.mtx"), "-fout", "x"], capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0
