@@ -65,8 +65,8 @@ PetscErrorCode MatLoad(Mat A, PetscViewer viewer) {
   ierr = PetscMalloc(sizeof(PetscInt) * (size_t)PetscMax(M, 1), &rowlens);CHKERRQ(ierr);
   ierr = read_ints(viewer->f, rowlens, (size_t)M);CHKERRQ(ierr);
   if (!A->type_name[0]) {
-    if (A->m_req == -1 && A->M_req == -1) { ierr = MatSetSizes(A, PETSC_DECIDE, PETSC_DECIDE, M, N);CHKERRQ(ierr); }
-    ierr = MatSetType(A, MATAIJHIPMI355X);CHKERRQ(ierr);
+    if (A->m_req == -1 && A->M_req == -1) { ierr = MatSetSizes(A, PETSC_DECIDE, PETSC_DECIDE, M, N);CHKERRQ(ierr); }   /* applies a type chosen earlier */
+    if (!A->type_name[0]) { ierr = MatSetType(A, MATAIJHIPMI355X);CHKERRQ(ierr); }
   }
   if (A->rmap->N != M || A->cmap->N != N) SETERRQ(A->comm, 79, "Matrix in file of different length (%d,%d) than the input matrix (%d,%d)", M, N, A->rmap->N, A->cmap->N);
   PetscInt rs = A->rmap->rstart, re = A->rmap->rend, m = re - rs;

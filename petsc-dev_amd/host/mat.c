@@ -32,6 +32,12 @@ PetscErrorCode MatSetSizes(Mat A, PetscInt m, PetscInt n, PetscInt M, PetscInt N
   if (M > 0 && m > M) SETERRQ(A->comm, PETSC_ERR_ARG_INCOMP, "Local row size %d cannot be larger than global row size %d", m, M);
   if (N > 0 && n > N) SETERRQ(A->comm, PETSC_ERR_ARG_INCOMP, "Local column size %d cannot be larger than global column size %d", n, N);
   A->m_req = m; A->n_req = n; A->M_req = M; A->N_req = N;
+  if (A->pending_type[0] && !A->type_name[0]) {   /* the type was chosen first: its constructor can run now */
+    char t[32];
+    snprintf(t, sizeof(t), "%s", A->pending_type);
+    A->pending_type[0] = 0;
+    return MatSetType(A, t);
+  }
   return 0;
 }
 PetscErrorCode MatSetType(Mat A, MatType type) {
@@ -44,7 +50,10 @@ PetscErrorCode MatSetType(Mat A, MatType type) {
       memset(A->ops, 0, sizeof(A->ops));
       A->data = NULL; A->spptr = NULL;
       if (!A->rmap) {
-        if (A->m_req == -1 && A->M_req == -1) SETERRQ(A->comm, PETSC_ERR_ORDER, "Must call MatSetSizes() before MatSetType()");
+        if (A->m_req == -1 && A->M_req == -1) {   /* sizes not known yet (e.g. MatSetType, then MatLoad): remember the choice */
+          snprintf(A->pending_type, sizeof(A->pending_type), "%s", type);
+          return 0;
+        }
         ierr = PetscLayoutCreateSetUp(A->comm, A->m_req, A->M_req, &A->rmap);CHKERRQ(ierr);
         ierr = PetscLayoutCreateSetUp(A->comm, A->n_req, A->N_req, &A->cmap);CHKERRQ(ierr);
       }

@@ -191,6 +191,7 @@ typedef struct _MatOps {
 struct _p_Mat {
   MPI_Comm comm;
   char type_name[32];
+  char pending_type[32];      /* MatSetType() before the sizes are known (allowed, matreg.c): applied by MatSetSizes()/MatLoad() */
   MatOps ops[1];
   PetscLayout *rmap, *cmap;
   PetscInt m_req, n_req, M_req, N_req;   /* MatSetSizes arguments */

@@ -20,6 +20,7 @@ def built():
     if not (os.path.exists(pda.kernels_lib_path()) and os.path.exists(pda.host_lib_path())
             and os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so"))
             and os.path.exists(os.path.join(ROOT, "examples", "poisson2d"))
-            and os.path.exists(os.path.join(ROOT, "examples", "mm2petsc"))):
+            and os.path.exists(os.path.join(ROOT, "examples", "mm2petsc"))
+            and os.path.exists(os.path.join(ROOT, "examples", "loadsolve"))):
         pda.build_all()
     return pda
