@@ -163,9 +163,10 @@ def main():
         print("  max |AIJ - BAIJ| = %g (scale %g)" % (np.max(np.abs(ya - ybb)), np.max(np.abs(ya))), flush=True)
     else:
         nn = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+        bs = int(sys.argv[3]) if len(sys.argv) > 3 else 3      # 4: the 3-dof blocks zero-padded to 4x4 (BASELINE configs[4])
         t0 = time.time()
-        bi, bj, ba = gen_baij27(nn)
-        mbs, bs = bi.size - 1, 3
+        bi, bj, ba = gen_baij27(nn, bs=bs)
+        mbs = bi.size - 1
         print("BAIJ27: mbs=%d nnzb=%d generated in %.1fs" % (mbs, bj.size, time.time() - t0), flush=True)
         A = P.Mat.from_bsr(bs, bi, bj, ba)
         x = P.Vec.from_array(np.sin(0.1 * np.arange(mbs * bs)), comm=L.COMM_SELF)
@@ -178,7 +179,7 @@ def main():
         nl, tms = C.c_int(), C.c_double()
         L.MatHIPMI355XGetTiming(A.h, C.byref(nl), C.byref(tms))
         t = tms.value / nl.value * 1e-3
-        print("BAIJ bs=3 spmv: %.3f ms  %.1f GB/s algorithmic (%.3f of 8 TB/s)" % (t * 1e3, B / t / 1e9, B / t / 8e12), flush=True)
+        print("BAIJ bs=%d spmv: %.3f ms  %.1f GB/s algorithmic (%.3f of 8 TB/s)" % (bs, t * 1e3, B / t / 1e9, B / t / 8e12), flush=True)
         if nn <= 32:
             import orc
             ref = orc.spmv_bsr(bs, bi, bj, ba, np.sin(0.1 * np.arange(mbs * bs)))
