@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--grid-n", dest="n", type=int, default=256, help="grid points per side per GPU (rows per GPU = n^3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-its", type=int, default=20)
+    ap.add_argument("--wide-planes", action="store_true", help="development: (2n)x(2n)x(n/4) rows per GPU instead of n^3 (N=8 is then the cube P7(2n))")
     ap.add_argument("--ksp-opts", default="", help="extra options-database string (development: e.g. '-ksp_cg_fused 2')")
     args = ap.parse_args()
 
@@ -54,7 +55,11 @@ def main():
 
     n = args.n
     nx, ny, nz = n, n, n * world            # z-slabs: rank r owns planes [r*n, (r+1)*n)
-    mloc = n ** 3
+    if args.wide_planes or (world == 8 and n == 256):
+        # same rows per GPU, planes twice as wide: (2n) x (2n) x (n/4) per rank.  On 8 GPUs that is the cube P7(512) =
+        # BASELINE.json configs[2] exactly (2 MiB halo per neighbour); measured cost of the wider planes on one GPU: +3 %
+        nx, ny, nz = 2 * n, 2 * n, (n // 4) * world
+    mloc = nx * ny * (nz // world)
     rs, re_ = rank * mloc, (rank + 1) * mloc
     t0 = time.time()
     ai, aj, aa = P.gen_poisson7(nx, ny, nz, rs, re_)

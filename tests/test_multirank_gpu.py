@@ -31,13 +31,16 @@ def test_mpiaij_two_ranks_one_gpu(built, nranks):
             assert "rank %d/2: golden ex2_2.out (GMRES + bjacobi + ILU(0), 2 ranks) its=7 ok=True" % k in out, out[-3000:]
 
 
-def test_bench_two_ranks_rehearsal(built):
+@pytest.mark.parametrize("wide", [False, True])
+def test_bench_two_ranks_rehearsal(built, wide):
     """bench.py's N>1 flow (torch.distributed.run launch, z-slab MatMPIAIJ, max-over-ranks timing, one JSON line from
     rank 0) rehearsed with two ranks on the one GPU through the host-staged transport (MI355X_STAGED=1)."""
     import json
     env = dict(os.environ, MI355X_STAGED="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--grid-n", "40"]
+           "--master-port", "29534" if wide else "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--grid-n", "40"]
+    if wide:                      # the slab shape bench.py uses on 8 GPUs (planes twice as wide, a quarter as many per rank)
+        cmd.append("--wide-planes")
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -46,3 +49,4 @@ def test_bench_two_ranks_rehearsal(built):
     assert d["n_gpus"] == 2 and d["steps"] == 6 and d["warmup"] == 2 and d["scaling"] == "weak"
     assert d["config"]["rows_per_gpu"] == 40 ** 3 and d["value"] > 0 and d["roofline"]["avg_launch_ms"] > 0
     assert "idx8" in d["roofline"]["kernel"]
+    assert ("P7(80,80,20)" if wide else "P7(40,40,80)") in d["config"]["workload"]
