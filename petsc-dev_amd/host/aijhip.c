@@ -230,6 +230,9 @@ static PetscErrorCode MatSetUp_SeqAIJHIP(Mat A) { return seqaij_prealloc(A, PETS
 static PetscErrorCode MatSetValues_SeqAIJHIP(Mat A, PetscInt m, const PetscInt im[], PetscInt n, const PetscInt in[], const PetscScalar v[], InsertMode is) {
   PetscErrorCode ierr;
   Mat_SeqAIJ *a = SA(A);
+  /* a host-side insertion: whatever the device-side updates stamped (MatSetValuesBatch, MatScale, ... look one state
+   * bump ahead), the device copy is stale from here on */
+  SD(A)->uploaded_state = -1;
   for (PetscInt k = 0; k < m; k++) {
     PetscInt row = im[k];
     if (row < 0) continue;

@@ -929,3 +929,69 @@ def test_standalone_load_and_solve(built):
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "Residual norm < 1.e-6 |b| (reason 2)" in r.stdout
+
+
+@pytest.mark.parametrize("pc", ["jacobi", "ilu", "bjacobi"])
+def test_time_step_loop_with_device_side_value_updates(P, pc):
+    """A time-step / Newton-style loop: the same Mat and KSP are re-used while the values change on the device
+    (MatZeroEntries + MatSetValuesBatch re-assembly, MatDiagonalScale, MatScale), KSPSetOperators announces each change
+    and the preconditioner is rebuilt from the updated values (Jacobi from the device copy, ILU(0) from the refreshed
+    host mirror), with ordinary host-side MatSetValues mixed in between (they must invalidate what the device-side
+    updates stamped).  Every step must give the bits of a solve with a freshly built matrix and solver."""
+    L = P.lib()
+    rng = np.random.default_rng(9)
+    nn, ne, bs = 400, 1400, 3
+    rows = np.stack([rng.choice(nn, bs, replace=False) for _ in range(ne)]).astype(np.int32)
+    def elems(seed):
+        r = np.random.default_rng(seed)
+        k = r.standard_normal((ne, bs, bs)); k = 0.2 * (k + k.transpose(0, 2, 1))
+        k[:, np.arange(bs), np.arange(bs)] = 2.0 + r.random((ne, bs))          # dominant diagonals
+        return np.ascontiguousarray(k)
+
+    def build(v, l=None, r=None, scale=None):
+        A = P.Mat(); L.MatCreate(L.COMM_SELF, C.byref(A.h))
+        L.MatSetSizes(A.h, nn, nn, nn, nn); L.MatSetType(A.h, b"seqaijhipmi355x"); L.MatSetUp(A.h)
+        L.MatSetValuesBatch(A.h, ne, bs, rows.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p))
+        ident = np.arange(nn, dtype=np.int32); ones = np.ones(nn)
+        for i in range(nn):                                                          # every row gets a diagonal entry
+            L.MatSetValues(A.h, 1, ident[i:i + 1].ctypes.data_as(C.c_void_p), 1, ident[i:i + 1].ctypes.data_as(C.c_void_p), ones[i:i + 1].ctypes.data_as(C.c_void_p), 2)
+        L.MatAssemblyBegin(A.h, 0); L.MatAssemblyEnd(A.h, 0)
+        if l is not None:
+            L.MatDiagonalScale(A.h, l.h, r.h)
+        if scale is not None:
+            L.MatScale(A.h, scale)
+        return A
+
+    def solve_with(k, A, b):
+        x = b.duplicate(); L.VecSet(x.h, 0.0)
+        k.set_operators(A)
+        k.solve(b, x)
+        return bits(x.array()).copy(), k.its, k.reason
+
+    def new_ksp():
+        k = P.KSP(comm=L.COMM_SELF)
+        L.PetscOptionsClear(); L.PetscOptionsInsertString(("-ksp_type gmres -pc_type %s" % pc).encode())
+        k.set_tolerances(rtol=1e-10); k.set_from_options(); L.PetscOptionsClear()
+        return k
+
+    b = P.Vec.from_array(np.cos(0.3 * np.arange(nn)), comm=L.COMM_SELF)
+    dl = 1.0 + 0.3 * np.cos(np.arange(nn)); vl = P.Vec.from_array(dl, comm=L.COMM_SELF)
+    A = build(elems(0))
+    k = new_ksp()
+    got = [solve_with(k, A, b)]
+    ident = np.arange(nn, dtype=np.int32); ones = np.ones(nn)
+    for step in (1, 2):
+        L.MatZeroEntries(A.h)                                                        # device + host, no upload
+        v = elems(step)
+        L.MatSetValuesBatch(A.h, ne, bs, rows.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p))   # device-side assembly
+        for i in range(nn):
+            L.MatSetValues(A.h, 1, ident[i:i + 1].ctypes.data_as(C.c_void_p), 1, ident[i:i + 1].ctypes.data_as(C.c_void_p), ones[i:i + 1].ctypes.data_as(C.c_void_p), 2)
+        L.MatAssemblyBegin(A.h, 0); L.MatAssemblyEnd(A.h, 0)
+        L.MatDiagonalScale(A.h, vl.h, vl.h)
+        L.MatScale(A.h, 1.5)
+        got.append(solve_with(k, A, b))
+    ref = [solve_with(new_ksp(), build(elems(0)), b)]
+    for step in (1, 2):
+        ref.append(solve_with(new_ksp(), build(elems(step), vl, vl, 1.5), b))
+    for g, r_ in zip(got, ref):
+        assert g[1:] == r_[1:] and g[2] == 2 and np.array_equal(g[0], r_[0])
