@@ -995,3 +995,55 @@ def test_time_step_loop_with_device_side_value_updates(P, pc):
         ref.append(solve_with(new_ksp(), build(elems(step), vl, vl, 1.5), b))
     for g, r_ in zip(got, ref):
         assert g[1:] == r_[1:] and g[2] == 2 and np.array_equal(g[0], r_[0])
+
+
+def test_pattern_change_after_device_use(P):
+    """new nonzeros inserted after the matrix has been used on the device (and after a device-side batch assembly has
+    cached its map): plan, index dictionary, transpose cache and batch map are rebuilt; MatMult / MatMultTranspose equal
+    the oracle on the new matrix, and a batch assembly on the new pattern equals the loop of MatSetValues."""
+    L = P.lib()
+    ai, aj, aa = pb.lap2d(17, 13)
+    n = ai.size - 1
+    A = P.Mat(); L.MatCreate(L.COMM_SELF, C.byref(A.h))
+    L.MatSetSizes(A.h, n, n, n, n); L.MatSetType(A.h, b"seqaijhipmi355x"); L.MatSetUp(A.h)
+    for r in range(n):
+        cols = aj[ai[r]:ai[r + 1]].copy(); vals = aa[ai[r]:ai[r + 1]].copy()
+        rr = np.array([r], dtype=np.int32)
+        L.MatSetValues(A.h, 1, rr.ctypes.data_as(C.c_void_p), cols.size, cols.ctypes.data_as(C.c_void_p), vals.ctypes.data_as(C.c_void_p), 1)
+    L.MatAssemblyBegin(A.h, 0); L.MatAssemblyEnd(A.h, 0)
+    x = np.cos(0.3 * np.arange(n)); vx = V(P, x); vy = V(P, np.zeros(n))
+    A.mult(vx, vy); L.MatMultTranspose(A.h, vx.h, vy.h)
+    rows = np.array([[0, 1], [5, 6]], dtype=np.int32); v = np.arange(8.0).reshape(2, 2, 2)
+    L.MatSetValuesBatch(A.h, 2, 2, rows.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p))      # builds and caches a map
+    L.MatAssemblyBegin(A.h, 0); L.MatAssemblyEnd(A.h, 0)
+    import scipy.sparse as sp
+    S = sp.csr_matrix((aa, aj, ai), shape=(n, n)).tolil()
+    for b_ in range(2):
+        for i in range(2):
+            for j in range(2):
+                S[rows[b_, i], rows[b_, j]] += v[b_, i, j]
+    # three entries that are not in the pattern yet, far from the diagonal
+    new = [(3, n - 2, 2.5), (n - 1, 0, -1.25), (40, 100, 0.5)]
+    for r, c, val in new:
+        rr, cc, vv = np.array([r], np.int32), np.array([c], np.int32), np.array([val])
+        L.MatSetValues(A.h, 1, rr.ctypes.data_as(C.c_void_p), 1, cc.ctypes.data_as(C.c_void_p), vv.ctypes.data_as(C.c_void_p), 2)
+        S[r, c] += val
+    L.MatAssemblyBegin(A.h, 0); L.MatAssemblyEnd(A.h, 0)
+    S = sp.csr_matrix(S); S.sort_indices()
+    si, sj, sa = S.indptr.astype(np.int32), S.indices.astype(np.int32), S.data.astype(np.float64)
+    A.mult(vx, vy)
+    assert np.array_equal(bits(vy.array()), bits(orc.spmv(si, sj, sa, x)))
+    L.MatMultTranspose(A.h, vx.h, vy.h)
+    assert np.allclose(vy.array(), orc.spmv_t(si, sj, sa, x, n), rtol=0, atol=1e-12)
+    # batch assembly on the NEW pattern, touching one of the new entries
+    rows2 = np.array([[3, n - 2], [5, 6]], dtype=np.int32)
+    L.MatSetValuesBatch(A.h, 2, 2, rows2.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p))
+    L.MatAssemblyBegin(A.h, 0); L.MatAssemblyEnd(A.h, 0)
+    S = S.tolil()
+    for b_ in range(2):
+        for i in range(2):
+            for j in range(2):
+                S[rows2[b_, i], rows2[b_, j]] += v[b_, i, j]
+    S = sp.csr_matrix(S); S.sort_indices()
+    A.mult(vx, vy)
+    assert np.allclose(vy.array(), orc.spmv(S.indptr.astype(np.int32), S.indices.astype(np.int32), S.data.astype(np.float64), x), rtol=0, atol=1e-13)
