@@ -40,7 +40,8 @@ int mi355x_comm_init_rank(mi355x_comm_t *out, int nranks, int rank, const char i
   mi355x_comm_s *c = new mi355x_comm_s();
   c->rank = rank;
   c->nranks = nranks;
-  NCCL_TRY(ncclCommInitRank(&c->comm, nranks, uid, rank));
+  ncclResult_t r = ncclCommInitRank(&c->comm, nranks, uid, rank);
+  if (r != ncclSuccess) { delete c; *out = nullptr; return 100000 + (int)r; }
   *out = c;
   return 0;
 }
