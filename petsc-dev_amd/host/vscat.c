@@ -131,10 +131,13 @@ static PetscErrorCode neighbour_exchange(VecScatter ctx, PetscDeviceCtx *dc, Pet
   PetscErrorCode ierr;
   MPI_Comm comm = ctx->comm;
   if (comm->dcomm) {
+    int rc = 0, rc_end;
     CHKHIP(mi355x_comm_group_start());
-    for (PetscInt i = 0; i < nr; i++) CHKHIP(mi355x_comm_recv(comm->dcomm, dc->hcomm, rdst[i], (size_t)rcnt[i], rprocs[i]));
-    for (PetscInt i = 0; i < ns; i++) CHKHIP(mi355x_comm_send(comm->dcomm, dc->hcomm, ssrc[i], (size_t)scnt[i], sprocs[i]));
-    CHKHIP(mi355x_comm_group_end());
+    for (PetscInt i = 0; i < nr && !rc; i++) rc = mi355x_comm_recv(comm->dcomm, dc->hcomm, rdst[i], (size_t)rcnt[i], rprocs[i]);
+    for (PetscInt i = 0; i < ns && !rc; i++) rc = mi355x_comm_send(comm->dcomm, dc->hcomm, ssrc[i], (size_t)scnt[i], sprocs[i]);
+    rc_end = mi355x_comm_group_end();                       /* always closed, also after a failed post */
+    CHKHIP(rc);
+    CHKHIP(rc_end);
     return 0;
   }
   if (!comm->exchange) SETERRQ(comm, PETSC_ERR_ORDER, "parallel scatter needs PetscCommSetDeviceComm() (RCCL) or PetscCommSetExchange() (host-staged)");
