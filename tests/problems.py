@@ -19,6 +19,25 @@ def lap2d(m, n):
     return csr(sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(N, N)))
 
 
+def tridiag(n=10):
+    """src/ksp/pc/examples/tests/ex2.c:33-47: tridiagonal (-1, 2, -1), n = 10, seqaij"""
+    A = sp.diags([-np.ones(n - 1), 2.0 * np.ones(n), -np.ones(n - 1)], [-1, 0, 1])
+    return csr(A)
+
+
+def ex5_tutorial(size=1, second=False, m=3):
+    """src/ksp/ksp/examples/tutorials/ex5.c on `size` ranks: n = 2*size, 5-point operator with diagonal 4 (first
+    system) or 6 (second system, re-assembled into the same pattern); exact solution u[i] = local index + 100*rank
+    over PETSC_DECIDE ownership"""
+    n = 2 * size
+    ai, aj, aa = lap2d(m, n)
+    if second:
+        aa = np.where(aa == 4.0, 6.0, aa)
+    N = m * n
+    u = np.concatenate([np.arange(N // size + (N % size > r), dtype=np.float64) + 100.0 * r for r in range(size)])
+    return (ai, aj, aa), u
+
+
 def ex5_mat(m=8, rect=0, alpha=0.1):
     """src/mat/examples/tests/ex5.c: dense m x n with C[i,j] = 10(i+1)+j+1, then MatScale(alpha) (a[k] = alpha*a[k])"""
     n = m + rect
@@ -145,3 +164,102 @@ def elasticity_like(nx, ny, nz, dof=3, seed=3):
                     aj.append(bj[b] * dof + c); aa.append(blocks[b, r, c])
             ai.append(len(aj))
     return (np.array(ai, dtype=np.int32), np.array(aj, dtype=np.int32), np.array(aa)), (bi, bj, ba)
+
+
+def gen_irr(n=1564794, mean=73.0, seed=12345):
+    """SURVEY 8(d) config 4 stand-in 'IRR': log-normal row lengths clipped to [3,400], columns banded +-50 000 with
+    20 % uniform long-range entries, diagonally dominant values.  (A random pattern: no FEM matrix looks like this;
+    gen_fem3 below is the structured stand-in.)"""
+    rng = np.random.default_rng(seed)
+    lens = np.clip(np.exp(rng.normal(np.log(mean) - 0.18, 0.6, n)), 3, 400).astype(np.int64)
+    tot = int(lens.sum())
+    rows = np.repeat(np.arange(n, dtype=np.int64), lens)
+    band = min(50000, max(1, n // 4))
+    off = rng.integers(-band, band + 1, tot)
+    far = rng.random(tot) < 0.2
+    cols = np.where(far, rng.integers(0, n, tot), np.clip(rows + off, 0, n - 1))
+    first = np.concatenate(([0], np.cumsum(lens)[:-1]))
+    cols[first] = rows[first]                       # make sure the diagonal is present
+    key = np.unique(rows * n + cols)                # sorts by (row, col) and removes duplicates
+    rows = key // n
+    cols = (key - rows * n).astype(np.int32)
+    ai = np.zeros(n + 1, dtype=np.int64)
+    np.add.at(ai, rows + 1, 1)
+    ai = np.cumsum(ai).astype(np.int32)
+    aa = -rng.random(cols.size)
+    rsum = np.zeros(n)
+    np.add.at(rsum, rows, -aa)
+    diag = cols == rows.astype(np.int32)
+    aa[diag] = rsum[rows[diag]] + 1.0               # strictly diagonally dominant
+    return ai, cols, aa
+
+
+def fem3_blocks(ex=130, ey=130, ez=67, seed=7, rcm=True):
+    """Node graph of an unstructured-looking hexahedral mesh: an ex x ey x ez element box with a central bore and
+    eight bolt holes cut out (the shape of SuiteSparse Flan_1565, a steel flange of hexahedral elements), nodes
+    renumbered by reverse Cuthill-McKee.  Returns the block CSR pattern (bi, bj): node a is coupled to node b when
+    they share an element (27 neighbours in the interior, fewer on the surfaces and around the holes)."""
+    from scipy.sparse.csgraph import reverse_cuthill_mckee
+    cx, cy = (np.indices((ex, ey)) + 0.5)
+    cx = cx / ex - 0.5; cy = cy / ey - 0.5
+    rad = np.hypot(cx, cy)
+    keep2 = (rad > 0.18) & (rad < 0.5)               # annulus: bore in the middle, round outer rim
+    for t in range(8):
+        ang = 2 * np.pi * (t + 0.5) / 8
+        keep2 &= np.hypot(cx - 0.36 * np.cos(ang), cy - 0.36 * np.sin(ang)) > 0.05
+    keep = np.repeat(keep2[:, :, None], ez, axis=2)
+    keep[:, :, ez // 2:] &= (rad < 0.32)[:, :, None]   # the hub is taller than the flange plate
+    e_i, e_j, e_k = np.nonzero(keep)
+    nxn, nyn = ex + 1, ey + 1
+    corner = []
+    for dk in (0, 1):
+        for dj in (0, 1):
+            for di in (0, 1):
+                corner.append((e_i + di) + nxn * ((e_j + dj) + nyn * (e_k + dk)))
+    corner = np.stack(corner, 1)                     # elements x 8 grid-node ids
+    used, inv = np.unique(corner.ravel(), return_inverse=True)
+    nn = used.size
+    ne = corner.shape[0]
+    E = sp.csr_matrix((np.ones(ne * 8, dtype=np.int8), (np.repeat(np.arange(ne), 8), inv)), shape=(ne, nn))
+    G = (E.T @ E).tocsr()
+    G.data[:] = 1
+    if rcm:
+        perm = reverse_cuthill_mckee(G, symmetric_mode=True)
+        G = G[perm][:, perm].tocsr()
+    G.sort_indices()
+    return G.indptr.astype(np.int32), G.indices.astype(np.int32)
+
+
+def expand_blocks(bi, bj, blocks):
+    """Point CSR (rows of a node interleaved: row 3*node + r) of a block matrix; blocks[b][r][c]."""
+    dof = blocks.shape[1]
+    nb = bi.size - 1
+    cnt = np.diff(bi).astype(np.int64)
+    ai = np.concatenate(([0], np.cumsum(np.repeat(cnt * dof, dof))))
+    assert ai[-1] < 2 ** 31
+    blk_row = np.repeat(np.arange(nb, dtype=np.int64), cnt)
+    pos = np.arange(bj.size, dtype=np.int64) - np.repeat(bi[:-1].astype(np.int64), cnt)
+    aj = np.empty(bj.size * dof * dof, dtype=np.int32)
+    aa = np.empty(bj.size * dof * dof)
+    for r in range(dof):
+        base = ai[blk_row * dof + r] + pos * dof
+        for c in range(dof):
+            aj[base + c] = bj * dof + c
+            aa[base + c] = blocks[:, r, c]
+    return ai.astype(np.int32), aj, aa
+
+
+def gen_fem3(ex=130, ey=130, ez=67, dof=3, seed=7, rcm=True):
+    """Unstructured-FEM-like stand-in for BASELINE configs[3] (Flan_1565: 1 564 794 rows, 3 dof per node, hexahedra):
+    the fem3_blocks mesh with a dense dof x dof coupling per node pair, stored point-wise (AIJ).  Symmetric pattern,
+    strictly diagonally dominant values.  Defaults give ~1.57 M rows, ~76 nonzeros per row."""
+    bi, bj = fem3_blocks(ex, ey, ez, seed, rcm)
+    rng = np.random.default_rng(seed)
+    blocks = -rng.random((bj.size, dof, dof))
+    ai, aj, aa = expand_blocks(bi, bj, blocks)
+    rows = np.repeat(np.arange(ai.size - 1, dtype=np.int64), np.diff(ai))
+    rsum = np.zeros(ai.size - 1)
+    np.add.at(rsum, rows, -aa)
+    diag = aj == rows.astype(np.int32)
+    aa[diag] = rsum[rows[diag]] + 1.0
+    return ai, aj, aa

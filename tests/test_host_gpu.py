@@ -158,7 +158,7 @@ def test_vec_mdot_maxpy_and_host_access(P):
     assert vx.norm(P.NORM_1) == 2.0 * n
 
 
-@pytest.mark.parametrize("name,rect,mtype", [("ex5_11_A.out", 2, "seq"), ("ex5_21.out", 0, "mpi")])
+@pytest.mark.parametrize("name,rect,mtype", [("ex5_11_A.out", 2, "seq"), ("ex5_11_B.out", -2, "seq"), ("ex5_21.out", 0, "mpi")])
 def test_mat_ex5_golden(P, name, rect, mtype):
     """src/mat/examples/tests/ex5.c: MatMult, MatMultAdd, MatMultTranspose, MatMultTransposeAdd, MatGetDiagonal,
     MatScale on seqaij (-rectA) and mpiaij (np=1); printed vectors must equal the golden files"""
@@ -583,6 +583,52 @@ def test_ksp_cg_single_reduction(P):
     k = min(len(h), len(hr))
     assert np.allclose(h[:k], hr[:k], rtol=1e-6, atol=0)
     assert np.linalg.norm(x - 1.0) < 1e-6
+
+
+@pytest.mark.parametrize("fused", [0, 1, 3])
+def test_ksp_cg_pc_tests_ex2_golden(P, fused):
+    """src/ksp/pc/examples/tests/ex2.c -ksp_type cg -ksp_monitor_short vs output/ex2_1.out (the reference's own CG
+    golden: tridiagonal n = 10, PCNONE, 5 iterations) on the HIP path, op-by-op and fused forms"""
+    ai, aj, aa = pb.tridiag(10)
+    b = orc.spmv(ai, aj, aa, np.ones(10))
+    gold = pb.parse_monitor(os.path.join(G, "pc_tests", "ex2_1.out"))[0]
+    x, h, its, reason = solve(P, ai, aj, aa, b, "cg", "none", opts="-ksp_cg_fused %d" % fused)
+    pb.check_monitor(h, gold)
+    assert its == 5 and reason == 2 and np.linalg.norm(x - 1.0) <= 1e-14
+
+
+def test_ksp_golden_ex4_and_ex5_two_systems(P):
+    """ksp/examples/tests/ex4.c (ex4_1.out) and tutorials/ex5.c (ex5_1.out: two solves with ONE KSP, the second after
+    MatZeroEntries + re-assembly of new values into the same pattern -- the device copy is refreshed, not rebuilt)"""
+    L = P.lib()
+    (ai, aj, aa), b, u0, ustar = pb.ex3_fem(5)
+    gold = pb.parse_monitor(os.path.join(G, "ksp_tests", "ex4_1.out"))[0]
+    x, h, its, reason = solve(P, ai, aj, aa, b, "gmres", "jacobi", x0=u0, opts="-ksp_gmres_cgs_refinement_type refine_always")
+    pb.check_monitor(h, gold)
+    solves = pb.parse_monitor(os.path.join(G, "ksp_tutorials", "ex5_1.out"))
+    (ai, aj, aa), u = pb.ex5_tutorial(1, False)
+    A = P.Mat.from_csr(ai, aj, aa)
+    vu = V(P, u); vb = vu.duplicate(); vx = vu.duplicate()
+    k = P.KSP(comm=L.COMM_SELF)
+    k.set_operators(A)
+    L.PetscOptionsClear()
+    L.PetscOptionsInsertString(b"-ksp_type gmres -pc_type jacobi -ksp_gmres_cgs_refinement_type refine_always")
+    k.set_from_options()
+    L.PetscOptionsClear()
+    for second in (False, True):
+        if second:
+            (ai2, aj2, aa2), _ = pb.ex5_tutorial(1, True)
+            L.MatZeroEntries(A.h)
+            rows = np.repeat(np.arange(ai2.size - 1, dtype=np.int32), np.diff(ai2))
+            for r, c, v in zip(rows, aj2, aa2):     # the example's loop of MatSetValues(ADD_VALUES)
+                L.MatSetValues(A.h, 1, C.byref(C.c_int(int(r))), 1, C.byref(C.c_int(int(c))), C.byref(C.c_double(float(v))), P.ADD_VALUES)
+            L.MatAssemblyBegin(A.h, P.MAT_FINAL_ASSEMBLY); L.MatAssemblyEnd(A.h, P.MAT_FINAL_ASSEMBLY)
+            k.set_operators(A)
+        A.mult(vu, vb)
+        k.record_history()
+        k.solve(vb, vx)
+        pb.check_monitor(k.history(), solves[1 if second else 0])
+        assert np.linalg.norm(vx.array() - u) < 1e-4 * np.linalg.norm(u)
 
 
 def test_ksp_golden_ex3_ex2f_ex9(P):

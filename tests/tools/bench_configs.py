@@ -17,29 +17,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def gen_irr(n=1564794, mean=73.0, seed=12345):
-    rng = np.random.default_rng(seed)
-    lens = np.clip(np.exp(rng.normal(np.log(mean) - 0.18, 0.6, n)), 3, 400).astype(np.int64)
-    tot = int(lens.sum())
-    rows = np.repeat(np.arange(n, dtype=np.int64), lens)
-    off = rng.integers(-50000, 50001, tot)
-    far = rng.random(tot) < 0.2
-    cols = np.where(far, rng.integers(0, n, tot), np.clip(rows + off, 0, n - 1))
-    first = np.concatenate(([0], np.cumsum(lens)[:-1]))
-    cols[first] = rows[first]                       # make sure the diagonal is present
-    key = rows * n + cols
-    key = np.unique(key)                            # sorts by (row, col) and removes duplicates
-    rows = key // n
-    cols = (key - rows * n).astype(np.int32)
-    ai = np.zeros(n + 1, dtype=np.int64)
-    np.add.at(ai, rows + 1, 1)
-    ai = np.cumsum(ai).astype(np.int32)
-    aa = -rng.random(cols.size)
-    rsum = np.zeros(n)
-    np.add.at(rsum, rows, -aa)
-    diag = cols == rows.astype(np.int32)
-    aa[diag] = rsum[rows[diag]] + 1.0               # strictly diagonally dominant
-    return ai, cols, aa
+from problems import gen_irr  # noqa: E402
 
 
 def gen_baij27(nn=128, bs=3, seed=5):
