@@ -166,9 +166,23 @@ int mi355x_spmv_plan_destroy(mi355x_spmv_plan_t plan);
  * kernels stream val + 1 B instead of val + 4 B col.  Same arithmetic, same bits; no-op otherwise. */
 int mi355x_spmv_plan_compress_indices(mi355x_handle_t h, mi355x_spmv_plan_t plan, const int *ai_host, const int *aj_host);
 int mi355x_spmv_plan_is_compressed(mi355x_spmv_plan_t plan, int *ntab);
+/* Optional analysis step for matrices with repeated row patterns (finite elements with several dof per node): the
+ * MI355X form of the reference's inodes.  ns[nnodes] are the node sizes Mat_CheckInode finds (src/mat/impls/aij/seq/
+ * inode.c:3981-3998: consecutive rows with identical column lists, <= limit rows per node).  Each group's column list is
+ * stored once and the SpMV streams val + (4 / rows-per-group) B instead of val + 4 B per nonzero; `a` stays the CSR
+ * array.  No-op (returns 0, plan unchanged) when it would not pay or the plan is compressed-row / index-compressed. */
+int mi355x_spmv_plan_group_rows(mi355x_handle_t h, mi355x_spmv_plan_t plan, const int *ai_host, const int *aj_host,
+                                int nnodes, const int *ns);
+/* Row sums two products at a time, sum += a0 x0 + a1 x1 (MatMult_SeqAIJ_Inode / MatMultAdd_SeqAIJ_Inode, inode.c:430-440,
+ * 619-631), instead of one at a time (MatMult_SeqAIJ, aij.h:383-386): set when the reference would run its inode
+ * routines on this matrix, so that the result carries ITS rounding.  Applies to the one-lane-per-row paths. */
+int mi355x_spmv_plan_set_pairsum(mi355x_spmv_plan_t plan, int on);
+int mi355x_spmv_plan_group_info(mi355x_spmv_plan_t plan, int *ngroups, long *nshared_indices, int *pairsum);
 int mi355x_spmv_plan_info(mi355x_spmv_plan_t plan, int *nblocks, int *nlong, size_t *workspace_bytes);
 /* MatMult_SeqAIJ      src/mat/impls/aij/seq/aij.c:1225 (loop 1269-1277, macro aij.h:383-386)
- *   y[r] = sum_k a[k] x[j[k]], products summed in k order starting from 0.0 */
+ *   y[r] = sum_k a[k] x[j[k]], products summed in k order starting from 0.0
+ * aa and aj must be allocated with 16 bytes of slack past their last element (mi355x_malloc of nz elements + 16 B):
+ * the kernels read aligned pairs, and the pair holding the last element may extend one element past it. */
 int mi355x_spmv_csr(mi355x_handle_t h, mi355x_spmv_plan_t plan, const int *ai, const int *aj,
                     const double *aa, const double *x, double *y);
 /* y = A x and sum_r x_r y_r from ONE pass over the matrix (KSPSolve_CG: w = A p, dpi = p'w; cg.c:190-191): the SpMV

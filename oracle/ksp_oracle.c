@@ -29,6 +29,7 @@ typedef struct solver_s {
   int norm_type;   /* KSPNormType: 0 none, 1 preconditioned (default), 2 unpreconditioned, 3 natural (petscksp.h) */
   int pc_right;    /* PC_RIGHT (GMRES only): A B y = b, x = B y; the norm is then the unpreconditioned one */
   int n;
+  int inode;       /* -1: not checked yet; 1: Mat_CheckInode keeps the inode routines for this matrix; 0: plain */
   const int *ai, *aj;
   const double *aa;
   double *idiag;              /* Jacobi: 1/diag (0 -> 1), PCSetUp_Jacobi jacobi.c:170-190 */
@@ -166,7 +167,7 @@ static void pc_setup(solver *s) {
       }
       s->sbi[k] = bi; s->sbj[k] = bj; s->sba[k] = ba;
       solver *t = &s->sub[k];
-      t->n = m; t->ai = bi; t->aj = bj; t->aa = ba;
+      t->n = m; t->ai = bi; t->aj = bj; t->aa = ba; t->inode = -1;
       pc_setup(t);
     }
   }
@@ -197,7 +198,17 @@ static void pc_apply(solver *s, const double *x, double *y) {
   }
 }
 
-static void mat_mult(solver *s, const double *x, double *y) { orc_spmv_csr(s->n, s->ai, s->aj, s->aa, x, y); }
+/* MatMult as MATSEQAIJ dispatches it: MatMult_SeqAIJ_Inode once Mat_CheckInode has kept the inode routines (checked on
+ * first use, as MatAssemblyEnd_SeqAIJ_Inode does once per pattern), MatMult_SeqAIJ otherwise */
+static void mat_mult(solver *s, const double *x, double *y) {
+  if (s->inode < 0) {
+    int *ns = (int *)malloc(sizeof(int) * (size_t)(s->n + 1));
+    s->inode = orc_check_inode(s->n, s->ai, s->aj, 5, ns) > 0;
+    free(ns);
+  }
+  if (s->inode) orc_spmv_csr_inode(s->n, s->ai, s->aj, s->aa, x, y);
+  else orc_spmv_csr(s->n, s->ai, s->aj, s->aa, x, y);
+}
 /* KSP_PCApplyBAorAB, PC_LEFT branch of PCApplyBAorAB precon.c:620-622 */
 static void pc_apply_BA(solver *s, const double *x, double *y, double *w) {
   if (s->pc_right) { pc_apply(s, x, w); mat_mult(s, w, y); }   /* PC_RIGHT branch, precon.c:617-619 */
@@ -563,7 +574,7 @@ int orc_ksp_solve(const orc_ksp_opts *o, int n, const int *ai, const int *aj, co
   S.ksp_type = o->ksp_type; S.pc_type = o->pc_type;
   S.rtol = o->rtol; S.abstol = o->abstol; S.dtol = o->dtol; S.max_it = o->max_it;
   S.restart = o->restart; S.refine_always = o->refine_always; S.guess_nonzero = o->guess_nonzero; S.cg_single = o->cg_single; S.norm_type = o->norm_type; S.pc_right = (o->pc_right && o->ksp_type == ORC_KSP_GMRES);
-  S.n = n; S.ai = ai; S.aj = aj; S.aa = aa;
+  S.n = n; S.ai = ai; S.aj = aj; S.aa = aa; S.inode = -1;
   S.nblocks = o->nblocks; S.blk = o->blk;
   S.hist = hist; S.hist_cap = hist_cap; S.nhist = 0;
   pc_setup(&S);

@@ -57,6 +57,8 @@ void orc_csr_get_diagonal(int m, const int *ai, const int *aj, const double *aa,
 /* inode variant (src/mat/impls/aij/seq/inode.c:392-578 mult, :3964-4034 detection) */
 int  orc_check_inode(int m, const int *ai, const int *aj, int limit, int *ns);
 void orc_spmv_csr_inode(int m, const int *ai, const int *aj, const double *aa, const double *x, double *y);
+void orc_spmv_csr_inode_add(int m, const int *ai, const int *aj, const double *aa, const double *x, const double *z, double *y);
+int  orc_matmult_seqaij(int m, const int *ai, const int *aj, const double *aa, const double *x, const double *z, double *y, int *ns_work);
 /* explicit transpose, rows of A^T listing contributions in increasing original-row order */
 void orc_csr_transpose(int m, int n, const int *ai, const int *aj, const double *aa, int *ti, int *tj, double *ta);
 /* ---- SeqBAIJ (src/mat/impls/baij/seq/baij2.c:331,387,981) ---- */

@@ -291,3 +291,22 @@ void orc_spmv_csr_inode(int m, const int *ai, const int *aj, const double *aa, c
     y[i] = sum;
   }
 }
+/* MatMultAdd_SeqAIJ_Inode, inode.c:583-760: the same loops with every row's sum started from z[row] */
+void orc_spmv_csr_inode_add(int m, const int *ai, const int *aj, const double *aa, const double *x, const double *z, double *y) {
+  for (int i = 0; i < m; i++) {
+    const int s = ai[i], sz = ai[i + 1] - ai[i];
+    double sum = z[i];
+    int n;
+    for (n = 0; n < sz - 1; n += 2) sum += aa[s + n] * x[aj[s + n]] + aa[s + n + 1] * x[aj[s + n + 1]];
+    if (n == sz - 1) sum += aa[s + n] * x[aj[s + n]];
+    y[i] = sum;
+  }
+}
+/* What MatMult / MatMultAdd dispatch to for a MATSEQAIJ matrix (inode.use defaults to true, inode2.c:85-99): the inode
+ * routines when Mat_CheckInode keeps them (node_count <= 0.8 m), the plain ones otherwise.  z == NULL: MatMult. */
+int orc_matmult_seqaij(int m, const int *ai, const int *aj, const double *aa, const double *x, const double *z, double *y, int *ns_work) {
+  const int nodes = orc_check_inode(m, ai, aj, 5, ns_work);
+  if (nodes) { if (z) orc_spmv_csr_inode_add(m, ai, aj, aa, x, z, y); else orc_spmv_csr_inode(m, ai, aj, aa, x, y); }
+  else       { if (z) orc_spmv_csr_add(m, ai, aj, aa, x, z, y); else orc_spmv_csr(m, ai, aj, aa, x, y); }
+  return nodes;
+}

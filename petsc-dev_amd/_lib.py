@@ -76,6 +76,9 @@ KERNEL_API = {
     "mi355x_spmv_plan_destroy": [vp],
     "mi355x_spmv_plan_compress_indices": [vp, vp, vp, vp],
     "mi355x_spmv_plan_is_compressed": [vp, pi32],
+    "mi355x_spmv_plan_group_rows": [vp, vp, vp, vp, i32, vp],
+    "mi355x_spmv_plan_set_pairsum": [vp, i32],
+    "mi355x_spmv_plan_group_info": [vp, pi32, C.POINTER(C.c_long), pi32],
     "mi355x_spmv_plan_info": [vp, pi32, pi32, C.POINTER(sz)],
     "mi355x_spmv_csr": [vp, vp, vp, vp, vp, vp, vp],
     "mi355x_spmv_csr_add": [vp, vp, vp, vp, vp, vp, vp, vp],

@@ -38,6 +38,10 @@
 #ifndef SPMV_MINWAVES
 #define SPMV_MINWAVES 1      // __launch_bounds__ second argument (waves per SIMD the register allocator must allow)
 #endif
+#ifndef SPMV_SEQ_AVG
+#define SPMV_SEQ_AVG 16      // row blocks with <= this many nonzeros per row on average: one lane per row, reference summation order
+#endif
+#define SPMV_GJ_CAP 960      // grouped-row kernel: shared column indices per row block (LDS sized for 7 workgroups per CU)
 #define SPMV_BLOCK_NNZ (8 * SPMV_THREADS)   // LDS stage (doubles): 4 pairs per lane
 #define SPMV_BLOCK_CAP (SPMV_BLOCK_NNZ - 2)   // nonzeros per row block: any alignment of the first pair still fits
 #define SPMV_BLOCK_ROWS SPMV_THREADS
@@ -62,13 +66,52 @@ struct mi355x_spmv_plan_s {
   int *d_offtab;
   int ntab;
   double *d_dotpart;   // per-row-block x'y values of mi355x_spmv_csr_dot (allocated on first use)
+  // rows summed the way MatMult_SeqAIJ_Inode does (two products at a time, inode.c:392-578): set when the reference's
+  // Mat_CheckInode would switch this matrix to its inode routines
+  int pairsum;
+  // grouped rows (the MI355X form of the reference's inodes): consecutive rows with one column pattern share ONE
+  // stored column list; d_rowblk4 = {first row, first nonzero, first shared column index, 0} per row block
+  int4 *d_rowblk4;
+  int *d_goff;         // per row: where its group's column list starts in d_gj
+  int *d_gj;           // the groups' column lists, one after the other
+  int ngroups;
+  long ngj;
 };
+
+// One lane's row sum out of the LDS product stage, 8 reads in flight.  pairsum == 0: products added one at a time in
+// column order (PetscSparseDensePlusDot, aij.h:383-386).  pairsum != 0: two at a time, sum += p[n] + p[n+1], odd
+// tail alone (MatMult_SeqAIJ_Inode / MatMultAdd_SeqAIJ_Inode, inode.c:430-440,619-631).
+__device__ __forceinline__ double row_sum_lds(const double *prod, int rs, int re, double sum, int pairsum) {
+  if (!pairsum) {
+    for (int k = rs; k < re; k += 8) {
+      double t[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) t[j] = prod[(k + j < re) ? k + j : re - 1];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const double u = sum + t[j]; sum = (k + j < re) ? u : sum; }
+    }
+  } else {
+    for (int k = rs; k < re; k += 8) {       // rs + multiples of 8: pairs stay aligned with the row start
+      double t[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) t[j] = prod[(k + j < re) ? k + j : re - 1];
+#pragma unroll
+      for (int j = 0; j < 8; j += 2) {
+        const double pr = t[j] + t[j + 1];
+        const double inc = (k + j + 1 < re) ? pr : t[j];
+        const double u = sum + inc;
+        sum = (k + j < re) ? u : sum;
+      }
+    }
+  }
+  return sum;
+}
 
 template <bool ADD, bool CPROW, bool VEC>
 __global__ __launch_bounds__(SPMV_THREADS, SPMV_MINWAVES) void spmv_csr_rowblock_kernel(
     const int2 *__restrict__ rowblk, int nblocks, int chunk, const int *__restrict__ ai, const int *__restrict__ aj,
     const double *__restrict__ aa, const double *__restrict__ x, const double *yin, double *yout,
-    const int *__restrict__ rows) {
+    const int *__restrict__ rows, int pairsum) {
   __shared__ double prod[SPMV_BLOCK_NNZ];
   __shared__ double wsum[SPMV_THREADS / MI355X_WAVE];
 
@@ -130,7 +173,7 @@ __global__ __launch_bounds__(SPMV_THREADS, SPMV_MINWAVES) void spmv_csr_rowblock
   // (the stencil case) get one lane per row and the reference's summation order
   int tpr = 1;
   while (tpr < MI355X_WAVE && nrows * (tpr * 2) <= SPMV_THREADS) tpr *= 2;
-  if (nnz <= 16 * nrows) tpr = 1;
+  if (nnz <= SPMV_SEQ_AVG * nrows) tpr = 1;
 
   // Every load below is unconditional (see the idx8 kernel further down for why): lanes past the last row re-read
   // the last row's extent, lanes past the last pair re-read the block's first pair.
@@ -184,17 +227,7 @@ __global__ __launch_bounds__(SPMV_THREADS, SPMV_MINWAVES) void spmv_csr_rowblock
   // ---- per-row sums out of LDS -------------------------------------------
   const int rs = r < nrows ? a0 - k0 : 0, re = r < nrows ? a1 - k0 : 0;
   if (tpr == 1) {
-    if (r < nrows) {
-      double sum = ADD ? ysum : 0.0;
-      for (int k = rs; k < re; k += 8) {          // 8 LDS reads in flight; added in column order
-        double t[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) t[j] = prod[(k + j < re) ? k + j : re - 1];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { const double u = sum + t[j]; sum = (k + j < re) ? u : sum; }
-      }
-      yout[orow] = sum;
-    }
+    if (r < nrows) yout[orow] = row_sum_lds(prod, rs, re, ADD ? ysum : 0.0, pairsum);
   } else {
     double sum = 0.0;
     if (r < nrows) for (int k = rs + sub; k < re; k += tpr) sum += prod[k];
@@ -219,7 +252,7 @@ template <bool ADD, bool DOT>
 __global__ __launch_bounds__(SPMV_THREADS, SPMV_MINWAVES) void spmv_csr_rowblock_idx8_kernel(
     const int2 *__restrict__ rowblk, int nblocks, const int *__restrict__ ai, const unsigned char *__restrict__ idx8,
     const int *__restrict__ offtab_g, int ntab, const double *__restrict__ aa, const double *__restrict__ x,
-    const double *yin, double *yout, double *__restrict__ dotpart) {
+    const double *yin, double *yout, double *__restrict__ dotpart, int pairsum) {
   __shared__ double prod[SPMV_BLOCK_NNZ];
   __shared__ unsigned char rowof[SPMV_BLOCK_NNZ];
   __shared__ int offtab[256];
@@ -271,7 +304,7 @@ __global__ __launch_bounds__(SPMV_THREADS, SPMV_MINWAVES) void spmv_csr_rowblock
 
   int tpr = 1;
   while (tpr < MI355X_WAVE && nrows * (tpr * 2) <= SPMV_THREADS) tpr *= 2;
-  if (nnz <= 16 * nrows) tpr = 1;
+  if (nnz <= SPMV_SEQ_AVG * nrows) tpr = 1;
   const int r = tid / tpr, sub = tid & (tpr - 1);
   const int rc = r < nrows ? r : nrows - 1;
   const int a0 = ai[r0 + rc], a1 = ai[r0 + rc + 1];
@@ -323,14 +356,7 @@ __global__ __launch_bounds__(SPMV_THREADS, SPMV_MINWAVES) void spmv_csr_rowblock
   double yval = 0.0;             // this lane's row result (lanes without a row: 0)
   if (tpr == 1) {
     if (r < nrows) {
-      double sum = ADD ? ysum : 0.0;
-      for (int k = rs; k < re; k += 8) {          // 8 LDS reads in flight; added in column order
-        double t[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) t[j] = prod[(k + j < re) ? k + j : re - 1];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { const double u = sum + t[j]; sum = (k + j < re) ? u : sum; }
-      }
+      const double sum = row_sum_lds(prod, rs, re, ADD ? ysum : 0.0, pairsum);
       yout[r0 + r] = sum;
       yval = sum;
     }
@@ -353,6 +379,111 @@ __global__ __launch_bounds__(SPMV_THREADS, SPMV_MINWAVES) void spmv_csr_rowblock
       for (int w = 1; w < SPMV_THREADS / MI355X_WAVE; ++w) t += wsum[w];
       dotpart[lb] = t;
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Grouped-row variant: the MI355X form of the reference's inodes (Mat_CheckInode inode.c:3964-4034,
+// MatMult_SeqAIJ_Inode inode.c:392-578).  Consecutive rows with one and the same column pattern -- the dof rows of
+// one node of a finite-element matrix -- form a group whose column list is stored ONCE (gj); the value array is the
+// untouched CSR `a`.  A 3-dof matrix streams 8 + 4/3 bytes per nonzero instead of 12.  Work layout as above: row
+// blocks of whole groups (<= 256 rows, <= 2046 nonzeros, <= SPMV_GJ_CAP shared column indices), values streamed with
+// coalesced 16-byte loads, the block's column lists staged in LDS by one coalesced load, and the column of nonzero k
+// looked up as gjs[rbase[row(k)] + k] with row(k) from the LDS marker array the row-owning lanes write (a per-nonzero
+// 16-bit marker that saves one LDS level was measured 5 % slower: 0.252 against 0.239 ms on the FEM stand-in).  Row sums as in
+// the other kernels (pairsum: the inode routine's two-at-a-time order, so the result carries the reference's bits).
+template <bool ADD>
+__global__ __launch_bounds__(SPMV_THREADS, SPMV_MINWAVES) void spmv_csr_rowblock_inode_kernel(
+    const int4 *__restrict__ rowblk, int nblocks, const int *__restrict__ ai, const int *__restrict__ goff,
+    const int *__restrict__ gj, const double *__restrict__ aa, const double *__restrict__ x, const double *yin, double *yout,
+    int pairsum) {
+  __shared__ double prod[SPMV_BLOCK_NNZ];
+  __shared__ int gjs[SPMV_GJ_CAP + 2];               // +2: parking slots for the halves of a pair outside the block
+  __shared__ int rbase[SPMV_BLOCK_ROWS];             // per row: its nonzero e of the block has column gjs[rbase + e]
+  __shared__ unsigned char rowof[SPMV_BLOCK_NNZ];    // per nonzero of the block: its row (written by the lanes that own the row)
+  static_assert(SPMV_THREADS == 256, "two index pairs per lane cover SPMV_GJ_CAP entries for 256 lanes");
+  static_assert(SPMV_GJ_CAP + 2 <= 4 * SPMV_THREADS, "index staging: two int2 loads per lane");
+#if SPMV_REMAP == 2
+  const int xcd = blockIdx.x % MI355X_NXCD;
+  const int slot = blockIdx.x / MI355X_NXCD;
+  const int lb = ((slot / SPMV_CH) * MI355X_NXCD + xcd) * SPMV_CH + (slot % SPMV_CH);
+#else
+  const int lb = blockIdx.x;
+#endif
+  if (lb >= nblocks) return;
+  const int4 b0 = rowblk[lb];
+  const int4 b1 = rowblk[lb + 1];
+  const int r0 = b0.x, r1 = b1.x, k0 = b0.y, k1 = b1.y, g0 = b0.z, g1 = b1.z;
+  const int nnz = k1 - k0;
+  const int nrows = r1 - r0;
+  const int tid = threadIdx.x;
+  if (nnz == 0) {               // only empty rows
+    if (tid < nrows) yout[r0 + tid] = ADD ? yin[r0 + tid] : 0.0;
+    return;
+  }
+  int tpr = 1;
+  while (tpr < MI355X_WAVE && nrows * (tpr * 2) <= SPMV_THREADS) tpr *= 2;
+  if (nnz <= SPMV_SEQ_AVG * nrows) tpr = 1;
+  const int r = tid / tpr, sub = tid & (tpr - 1);
+  const int rc = r < nrows ? r : nrows - 1;
+  const int a0 = ai[r0 + rc], a1 = ai[r0 + rc + 1];
+  const int go = goff[r0 + rc];
+  double ysum = 0.0;
+  if (ADD) ysum = yin[r0 + rc];
+  // this lane's slices of the value stream and of the block's shared column lists; every load unconditional
+  constexpr int PAIRS = SPMV_BLOCK_NNZ / (2 * SPMV_THREADS);
+  const int ka = k0 & ~1, ga = g0 & ~1;
+  v2d v[PAIRS];
+  v2i gv[2];
+#pragma unroll
+  for (int p = 0; p < PAIRS; ++p) {
+    const int k = ka + 2 * tid + p * 2 * SPMV_THREADS;
+    const int kk = (k < k1) ? k : ka;
+    v[p] = SPMV_LOAD(reinterpret_cast<const v2d *>(aa + kk));
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int g = ga + 2 * tid + q * 2 * SPMV_THREADS;
+    const int gg = (g < g1) ? g : ga;
+    gv[q] = SPMV_LOAD(reinterpret_cast<const v2i *>(gj + gg));
+  }
+  const int rs = r < nrows ? a0 - k0 : 0, re = r < nrows ? a1 - k0 : 0;
+  for (int k = rs + sub; k < re; k += tpr) rowof[k] = (unsigned char)r;
+  if (r < nrows && sub == 0) rbase[r] = (go - g0) - rs;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int g = ga + 2 * tid + q * 2 * SPMV_THREADS;
+    gjs[(g >= g0 && g < g1) ? g - g0 : SPMV_GJ_CAP] = gv[q].x;
+    gjs[(g + 1 < g1) ? g + 1 - g0 : SPMV_GJ_CAP + 1] = gv[q].y;
+  }
+  __syncthreads();
+  double xa[PAIRS], xb[PAIRS];
+#pragma unroll
+  for (int p = 0; p < PAIRS; ++p) {
+    const int k = ka + 2 * tid + p * 2 * SPMV_THREADS;
+    const bool in = k < k1;
+    const bool v0 = in && k >= k0, v1 = in && (k + 1 < k1);
+    const int kk = in ? k : ka;
+    const int e0 = kk + (v0 ? 0 : (in ? 1 : (k0 & 1))) - k0;   // an element of this block to take the column from
+    const int e1 = kk + (v1 ? 1 : (in ? 0 : (k0 & 1))) - k0;
+    xa[p] = x[gjs[rbase[rowof[e0]] + e0]];
+    xb[p] = x[gjs[rbase[rowof[e1]] + e1]];
+  }
+#pragma unroll
+  for (int p = 0; p < PAIRS; ++p) {
+    const int k = ka + 2 * tid + p * 2 * SPMV_THREADS;
+    const double pa = v[p].x * xa[p], pb = v[p].y * xb[p];
+    prod[(k >= k0 && k < k1) ? k - k0 : SPMV_BLOCK_NNZ - 1] = pa;
+    prod[(k + 1 < k1) ? k + 1 - k0 : SPMV_BLOCK_NNZ - 1] = pb;
+  }
+  __syncthreads();
+  if (tpr == 1) {
+    if (r < nrows) yout[r0 + r] = row_sum_lds(prod, rs, re, ADD ? ysum : 0.0, pairsum);
+  } else {
+    double sum = 0.0;
+    if (r < nrows) for (int k = rs + sub; k < re; k += tpr) sum += prod[k];
+    for (int off = tpr >> 1; off > 0; off >>= 1) sum += __shfl_down(sum, off, MI355X_WAVE);
+    if (r < nrows && sub == 0) yout[r0 + r] = ADD ? (ysum + sum) : sum;
   }
 }
 
@@ -524,6 +655,18 @@ static int launch_spmv(mi355x_handle_t h, mi355x_spmv_plan_t p, const int *ai, c
   if (p->nblocks == 0) return 0;
   const bool vec = mi355x_aligned16(aa) && ((((uintptr_t)aj) & 7u) == 0);
   const bool cprow = p->d_rows != nullptr;
+  if (p->d_gj && !cprow && mi355x_aligned16(aa)) {
+#if SPMV_REMAP == 2
+    const int perg = MI355X_NXCD * SPMV_CH;
+    const int gg = ((p->nblocks + perg - 1) / perg) * perg;
+#else
+    const int gg = p->nblocks;
+#endif
+    hipLaunchKernelGGL((spmv_csr_rowblock_inode_kernel<ADD>), dim3(gg), dim3(SPMV_THREADS), 0, h->stream, p->d_rowblk4, p->nblocks,
+                       ai, p->d_goff, p->d_gj, aa, x, yin, yout, p->pairsum);
+    MI355X_LAUNCH_CHECK();
+    return 0;
+  }
   if (p->d_idx8 && !cprow && mi355x_aligned16(aa)) {
 #if SPMV_REMAP == 2
     const int per8 = MI355X_NXCD * SPMV_CH;
@@ -532,7 +675,7 @@ static int launch_spmv(mi355x_handle_t h, mi355x_spmv_plan_t p, const int *ai, c
     const int g8 = p->nblocks;
 #endif
     hipLaunchKernelGGL((spmv_csr_rowblock_idx8_kernel<ADD, false>), dim3(g8), dim3(SPMV_THREADS), 0, h->stream, p->d_rowblk,
-                       p->nblocks, ai, p->d_idx8, p->d_offtab, p->ntab, aa, x, yin, yout, (double *)nullptr);
+                       p->nblocks, ai, p->d_idx8, p->d_offtab, p->ntab, aa, x, yin, yout, (double *)nullptr, p->pairsum);
     MI355X_LAUNCH_CHECK();
     return 0;
   }
@@ -544,7 +687,7 @@ static int launch_spmv(mi355x_handle_t h, mi355x_spmv_plan_t p, const int *ai, c
 #endif
 #define SPMV_GO(C, V)                                                                                               \
   hipLaunchKernelGGL((spmv_csr_rowblock_kernel<ADD, C, V>), grid, block, 0, h->stream, p->d_rowblk, p->nblocks,    \
-                     p->chunk, ai, aj, aa, x, yin, yout, p->d_rows)
+                     p->chunk, ai, aj, aa, x, yin, yout, p->d_rows, p->pairsum)
   if (cprow) { if (vec) SPMV_GO(true, true); else SPMV_GO(true, false); }
   else       { if (vec) SPMV_GO(false, true); else SPMV_GO(false, false); }
 #undef SPMV_GO
@@ -565,6 +708,12 @@ int mi355x_spmv_plan_create(mi355x_handle_t h, int nrows, const int *ai_host, co
   p->ntab = 0;
   p->nlong = 0;
   p->d_dotpart = nullptr;
+  p->pairsum = 0;
+  p->d_rowblk4 = nullptr;
+  p->d_goff = nullptr;
+  p->d_gj = nullptr;
+  p->ngroups = 0;
+  p->ngj = 0;
   std::vector<int2> rb;
   rb.reserve((size_t)nrows / 128 + 2);
   rb.push_back(make_int2(0, ai_host[0]));
@@ -635,6 +784,88 @@ int mi355x_spmv_plan_compress_indices(mi355x_handle_t h, mi355x_spmv_plan_t p, c
   return 0;
 }
 
+// Row grouping (the analysis half of the reference's inode machinery).  The caller passes the node sizes the
+// reference's Mat_CheckInode finds (ns[nnodes], consecutive rows with identical column lists, at most `limit` rows
+// each; inode.c:3981-3998) -- the host library computes them with the reference's loop so that they can be compared
+// with it.  This routine stores one column list per group and rebuilds the row blocks from whole groups.  It leaves
+// the plan as it is (returns 0) when grouping would not pay (shared indices > 2/3 of the nonzeros), when a row has
+// more than SPMV_GJ_CAP entries, or for compressed-row / index-compressed plans.
+int mi355x_spmv_plan_group_rows(mi355x_handle_t h, mi355x_spmv_plan_t p, const int *ai_host, const int *aj_host, int nnodes,
+                                const int *ns) {
+  if (!p || p->d_rows || p->d_idx8 || p->d_gj || p->nrows == 0 || nnodes <= 0) return 0;
+  const int m = p->nrows;
+  const long nnz = ai_host[m];
+  // groups: a node whose rows together exceed the LDS stage is cut into smaller groups
+  std::vector<int> gstart;          // first row of each group (+ m at the end)
+  gstart.reserve((size_t)nnodes + 1);
+  long ngj = 0;
+  int row = 0;
+  for (int g = 0; g < nnodes; ++g) {
+    const int nc = ai_host[row + 1] - ai_host[row];
+    if (nc > SPMV_GJ_CAP) return 0;
+    int left = ns[g];
+    if (left < 1 || row + left > m) return (int)hipErrorInvalidValue;
+    int per = left;
+    while ((long)per * nc > SPMV_BLOCK_CAP) --per;          // nc <= SPMV_GJ_CAP: per >= 2
+    while (left > 0) {
+      const int take = left < per ? left : per;
+      gstart.push_back(row);
+      ngj += nc;
+      row += take;
+      left -= take;
+    }
+  }
+  if (row != m) return (int)hipErrorInvalidValue;
+  gstart.push_back(m);
+  if (3 * ngj > 2 * nnz) return 0;                            // not enough shared structure to pay for the lookups
+  const int ngroups = (int)gstart.size() - 1;
+  std::vector<int> goff((size_t)m), gjh((size_t)(ngj > 0 ? ngj : 1));
+  std::vector<int4> rb;
+  rb.reserve((size_t)m / 64 + 2);
+  rb.push_back(make_int4(0, ai_host[0], 0, 0));
+  long gpos = 0;
+  int brows = 0, bnnz = 0, bgj = 0;
+  for (int g = 0; g < ngroups; ++g) {
+    const int ra = gstart[g], rbn = gstart[g + 1];
+    const int nc = ai_host[ra + 1] - ai_host[ra];
+    const int gn = (rbn - ra) * nc;
+    if (brows + (rbn - ra) > SPMV_BLOCK_ROWS || bnnz + gn > SPMV_BLOCK_CAP || bgj + nc > SPMV_GJ_CAP) {
+      rb.push_back(make_int4(ra, ai_host[ra], (int)gpos, 0));
+      brows = bnnz = bgj = 0;
+    }
+    for (int r = ra; r < rbn; ++r) goff[(size_t)r] = (int)gpos;
+    for (int c = 0; c < nc; ++c) gjh[(size_t)(gpos + c)] = aj_host[ai_host[ra] + c];
+    gpos += nc;
+    brows += rbn - ra; bnnz += gn; bgj += nc;
+  }
+  rb.push_back(make_int4(m, ai_host[m], (int)gpos, 0));
+  MI355X_TRY(hipMalloc((void **)&p->d_rowblk4, sizeof(int4) * rb.size()));
+  MI355X_TRY(hipMalloc((void **)&p->d_goff, sizeof(int) * (size_t)m));
+  MI355X_TRY(hipMalloc((void **)&p->d_gj, sizeof(int) * (size_t)(ngj > 0 ? ngj : 1) + 16));   // +16: the last pair load may straddle the end
+  MI355X_TRY(hipMemcpyAsync(p->d_rowblk4, rb.data(), sizeof(int4) * rb.size(), hipMemcpyHostToDevice, h->stream));
+  MI355X_TRY(hipMemcpyAsync(p->d_goff, goff.data(), sizeof(int) * (size_t)m, hipMemcpyHostToDevice, h->stream));
+  MI355X_TRY(hipMemcpyAsync(p->d_gj, gjh.data(), sizeof(int) * (size_t)ngj, hipMemcpyHostToDevice, h->stream));
+  MI355X_TRY(hipStreamSynchronize(h->stream));
+  p->nblocks = (int)rb.size() - 1;
+  p->chunk = (p->nblocks + MI355X_NXCD - 1) / MI355X_NXCD;
+  p->nlong = 0;
+  p->ngroups = ngroups;
+  p->ngj = ngj;
+  return 0;
+}
+
+int mi355x_spmv_plan_set_pairsum(mi355x_spmv_plan_t p, int on) {
+  if (p) p->pairsum = on ? 1 : 0;
+  return 0;
+}
+
+int mi355x_spmv_plan_group_info(mi355x_spmv_plan_t p, int *ngroups, long *nshared_indices, int *pairsum) {
+  if (ngroups) *ngroups = p->d_gj ? p->ngroups : 0;
+  if (nshared_indices) *nshared_indices = p->d_gj ? p->ngj : 0;
+  if (pairsum) *pairsum = p->pairsum;
+  return 0;
+}
+
 int mi355x_spmv_plan_destroy(mi355x_spmv_plan_t p) {
   if (!p) return 0;
   hipFree(p->d_rowblk);
@@ -642,6 +873,9 @@ int mi355x_spmv_plan_destroy(mi355x_spmv_plan_t p) {
   if (p->d_offtab) hipFree(p->d_offtab);
   if (p->d_rows) hipFree(p->d_rows);
   if (p->d_dotpart) hipFree(p->d_dotpart);
+  if (p->d_rowblk4) hipFree(p->d_rowblk4);
+  if (p->d_goff) hipFree(p->d_goff);
+  if (p->d_gj) hipFree(p->d_gj);
   delete p;
   return 0;
 }
@@ -680,7 +914,7 @@ int mi355x_spmv_csr_dot(mi355x_handle_t h, mi355x_spmv_plan_t p, const int *ai, 
   const int g8 = p->nblocks;
 #endif
   hipLaunchKernelGGL((spmv_csr_rowblock_idx8_kernel<false, true>), dim3(g8), dim3(SPMV_THREADS), 0, h->stream, p->d_rowblk,
-                     p->nblocks, ai, p->d_idx8, p->d_offtab, p->ntab, aa, x, (const double *)nullptr, y, p->d_dotpart);
+                     p->nblocks, ai, p->d_idx8, p->d_offtab, p->ntab, aa, x, (const double *)nullptr, y, p->d_dotpart, p->pairsum);
   MI355X_LAUNCH_CHECK();
   return 0;
 }

@@ -10,12 +10,14 @@
 #define CHUNKSIZE 15   /* aij.h: rows grow by this many slots when preallocation is exceeded */
 
 /* ---------------------------------------------------------------- host container */
+static PetscErrorCode device_free(Mat A);
 static PetscErrorCode seqaij_prealloc(Mat A, PetscInt nz, const PetscInt *nnz) {
   PetscErrorCode ierr;
   Mat_SeqAIJ *a = SA(A);
   PetscInt m = a->m;
   if (nz == PETSC_DEFAULT || nz == PETSC_DECIDE) nz = 5;   /* aij.c MatSeqAIJSetPreallocation_SeqAIJ */
   if (nz < 0) SETERRQ(A->comm, PETSC_ERR_ARG_OUTOFRANGE, "nz cannot be less than 0: value %d", nz);
+  device_free(A);   /* a new pattern is coming: the mirror, plan, index dictionary, transpose and batch map go with the old one */
   free(a->i); free(a->j); free(a->a); free(a->ilen); free(a->imax);
   ierr = PetscMalloc(sizeof(PetscInt) * (size_t)(m + 1), &a->i);CHKERRQ(ierr);
   ierr = PetscMalloc(sizeof(PetscInt) * (size_t)PetscMax(m, 1), &a->ilen);CHKERRQ(ierr);
@@ -99,6 +101,40 @@ static PetscErrorCode seqaij_compact(Mat_SeqAIJ *a) {
   return 0;
 }
 
+/* Mat_CheckInode (src/mat/impls/aij/seq/inode.c:3964-4034): consecutive rows with identical column lists form a node of
+ * at most `limit` rows (-mat_inode_limit, default 5, inode2.c:85-99); with more than 0.8 m nodes -- or -mat_no_inode -- the
+ * matrix keeps the plain routines (inode_count = 0). */
+static PetscErrorCode seqaij_check_inode(Mat A) {
+  PetscErrorCode ierr;
+  Mat_SeqAIJ *a = SA(A);
+  PetscInt m = a->m, limit = 5, i = 0, node_count = 0, *ns;
+  PetscBool set; char buf[16];
+  free(a->inode_size); a->inode_size = NULL; a->inode_count = 0;
+  ierr = PetscOptionsGetString(NULL, "-mat_no_inode", buf, sizeof(buf), &set);CHKERRQ(ierr);
+  if (set || !m) return 0;
+  ierr = PetscOptionsGetInt(NULL, "-mat_inode_limit", &limit, &set);CHKERRQ(ierr);
+  if (limit < 1) limit = 1;
+  if (limit > 5) limit = 5;
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)(m + 1), &ns);CHKERRQ(ierr);
+  const PetscInt *idx = a->j, *ii = a->i;
+  while (i < m) {
+    const PetscInt nzx = ii[i + 1] - ii[i];
+    const PetscInt *idy = idx;
+    PetscInt j, blk_size;
+    for (j = i + 1, blk_size = 1; j < m && blk_size < limit; ++j, ++blk_size) {
+      if (ii[j + 1] - ii[j] != nzx) break;
+      idy += nzx;
+      if (memcmp(idx, idy, sizeof(PetscInt) * (size_t)nzx)) break;
+    }
+    ns[node_count++] = blk_size;
+    idx += (size_t)blk_size * nzx;
+    i = j;
+  }
+  if (node_count > .8 * m) { free(ns); return 0; }
+  a->inode_size = ns; a->inode_count = node_count;
+  return 0;
+}
+
 /* ---------------------------------------------------------------- device mirror */
 static PetscErrorCode device_free(Mat A) {
   Mat_SeqAIJHIP *d = SD(A);
@@ -116,9 +152,10 @@ static PetscErrorCode device_free(Mat A) {
   if (d->bm_segslot) mi355x_free(d->bm_segslot);
   if (d->bm_v) mi355x_free(d->bm_v);
   const PetscInt nup = d->n_uploads;
+  const PetscBool cprow = d->cprow;
   memset(d, 0, sizeof(*d));
   d->uploaded_state = -1; d->t_state = -1; d->pattern_nz = -1;
-  d->n_uploads = nup;
+  d->n_uploads = nup; d->cprow = cprow;   /* a count and a request: they outlive the arrays */
   return 0;
 }
 
@@ -134,9 +171,7 @@ PetscErrorCode MatSeqAIJHIPUpload(Mat A) {
   if (!a->compact) SETERRQ(A->comm, PETSC_ERR_ARG_WRONGSTATE, "matrix must be assembled before it is sent to the GPU");
   PetscBool same_pattern = (PetscBool)(d->d_a && d->plan && d->pattern_nz == a->nz);   /* entries are never removed: same nz == same pattern */
   if (!same_pattern) {
-    PetscBool keepcprow = d->cprow;
     device_free(A);
-    d->cprow = keepcprow;
     PetscInt m = a->m, nrows = m;
     const PetscInt *ip = a->i; PetscInt *ci = NULL, *ridx = NULL;
     /* compressed rows when >= 60% of the rows are empty (Mat_CheckCompressedRow ratio, compressedrow.c:28;
@@ -153,8 +188,9 @@ PetscErrorCode MatSeqAIJHIPUpload(Mat A) {
       ip = ci;
     }
     CHKHIP(mi355x_malloc((void **)&d->d_i, sizeof(PetscInt) * (size_t)(nrows + 1)));
-    CHKHIP(mi355x_malloc((void **)&d->d_j, sizeof(PetscInt) * (size_t)PetscMax(a->nz, 1)));
-    CHKHIP(mi355x_malloc((void **)&d->d_a, sizeof(PetscScalar) * (size_t)PetscMax(a->nz, 1)));
+    /* +16 B: the SpMV kernels read aligned pairs and the pair holding the last element may extend past it (mi355x_kernels.h) */
+    CHKHIP(mi355x_malloc((void **)&d->d_j, sizeof(PetscInt) * (size_t)PetscMax(a->nz, 1) + 16));
+    CHKHIP(mi355x_malloc((void **)&d->d_a, sizeof(PetscScalar) * (size_t)PetscMax(a->nz, 1) + 16));
     CHKHIP(mi355x_memcpy_h2d(dc->h, d->d_i, ip, sizeof(PetscInt) * (size_t)(nrows + 1)));
     CHKHIP(mi355x_memcpy_h2d(dc->h, d->d_j, a->j, sizeof(PetscInt) * (size_t)a->nz));
     if (a->bs <= 1) {
@@ -164,6 +200,16 @@ PetscErrorCode MatSeqAIJHIPUpload(Mat A) {
        * when the matrix uses <= 256 distinct (col - row) offsets; plain CSR otherwise */
       ierr = PetscOptionsGetInt(NULL, "-mat_hipmi355x_index_compression", &ic, &set);CHKERRQ(ierr);
       if (ic && !use_cprow) CHKHIP(mi355x_spmv_plan_compress_indices(dc->h, d->plan, a->i, a->j));
+      /* inodes: when the reference's Mat_CheckInode would switch this matrix to MatMult_SeqAIJ_Inode, the row sums take
+       * that routine's two-at-a-time order (same bits), and -- unless the 1-byte index dictionary already applies --
+       * the rows of a node share one stored column list (mi355x_spmv_plan_group_rows) */
+      ierr = seqaij_check_inode(A);CHKERRQ(ierr);
+      if (a->inode_count) {
+        int ntab = 0;
+        CHKHIP(mi355x_spmv_plan_set_pairsum(d->plan, 1));
+        CHKHIP(mi355x_spmv_plan_is_compressed(d->plan, &ntab));
+        if (!ntab && !use_cprow) CHKHIP(mi355x_spmv_plan_group_rows(dc->h, d->plan, a->i, a->j, a->inode_count, a->inode_size));
+      }
     }
     else {   /* BAIJ: the plan partitions the VALUE stream, i.e. the block-row pointer scaled by bs*bs */
       PetscInt *sc, bs2 = a->bs * a->bs;
@@ -179,7 +225,7 @@ PetscErrorCode MatSeqAIJHIPUpload(Mat A) {
     if (!use_cprow) d->cprow = PETSC_FALSE;
   }
   size_t vals = (size_t)a->nz * (size_t)(a->bs > 1 ? a->bs * a->bs : 1);
-  if (a->bs > 1 && !same_pattern) { mi355x_free(d->d_a); CHKHIP(mi355x_malloc((void **)&d->d_a, sizeof(PetscScalar) * PetscMax(vals, 1))); }
+  if (a->bs > 1 && !same_pattern) { mi355x_free(d->d_a); CHKHIP(mi355x_malloc((void **)&d->d_a, sizeof(PetscScalar) * PetscMax(vals, 1) + 16)); }
   CHKHIP(mi355x_memcpy_h2d(dc->h, d->d_a, a->a, sizeof(PetscScalar) * vals));
   CHKHIP(mi355x_handle_synchronize(dc->h));
   d->n_uploads++;
@@ -212,8 +258,8 @@ static PetscErrorCode upload_transpose(Mat A) {
     for (PetscInt k = a->i[r]; k < a->i[r + 1]; k++) { PetscInt p = next[a->j[k]]++; tj[p] = r; ta[p] = a->a[k]; }
   if (d->t_i) { mi355x_free(d->t_i); mi355x_free(d->t_j); mi355x_free(d->t_a); mi355x_spmv_plan_destroy(d->t_plan); d->t_plan = NULL; }
   CHKHIP(mi355x_malloc((void **)&d->t_i, sizeof(PetscInt) * (size_t)(n + 1)));
-  CHKHIP(mi355x_malloc((void **)&d->t_j, sizeof(PetscInt) * (size_t)PetscMax(nz, 1)));
-  CHKHIP(mi355x_malloc((void **)&d->t_a, sizeof(PetscScalar) * (size_t)PetscMax(nz, 1)));
+  CHKHIP(mi355x_malloc((void **)&d->t_j, sizeof(PetscInt) * (size_t)PetscMax(nz, 1) + 16));
+  CHKHIP(mi355x_malloc((void **)&d->t_a, sizeof(PetscScalar) * (size_t)PetscMax(nz, 1) + 16));
   CHKHIP(mi355x_memcpy_h2d(dc->h, d->t_i, ti, sizeof(PetscInt) * (size_t)(n + 1)));
   CHKHIP(mi355x_memcpy_h2d(dc->h, d->t_j, tj, sizeof(PetscInt) * (size_t)nz));
   CHKHIP(mi355x_memcpy_h2d(dc->h, d->t_a, ta, sizeof(PetscScalar) * (size_t)nz));
@@ -401,6 +447,28 @@ PetscErrorCode MatHIPMI355XGetIndexCompression(Mat A, PetscInt *noffsets) {
   ierr = MatSeqAIJHIPUpload(A);CHKERRQ(ierr);
   if (SD(A)->plan && SA(A)->bs <= 1) CHKHIP(mi355x_spmv_plan_is_compressed(SD(A)->plan, &ntab));
   *noffsets = ntab;
+  return 0;
+}
+
+/* row grouping of the SpMV plan: number of nodes Mat_CheckInode found (0: plain routines), groups the device plan stores
+ * one column list for (0: the plan streams per-nonzero indices), and the shared indices stored */
+PetscErrorCode MatHIPMI355XGetInodeInfo(Mat A, PetscInt *nodes, PetscInt *groups, PetscInt *shared_indices) {
+  PetscErrorCode ierr; int ng = 0; long ngj = 0;
+  if (nodes) *nodes = 0;
+  if (groups) *groups = 0;
+  if (shared_indices) *shared_indices = 0;
+  if (!A) return 0;
+  if (A->ops->mult != MatMult_SeqAIJHIP) {
+    Mat Ad = NULL;
+    if (!strcmp(A->type_name, MATMPIAIJHIPMI355X)) { ierr = MatMPIAIJGetSeqAIJ(A, &Ad, NULL, NULL);CHKERRQ(ierr); }
+    if (!Ad || Ad->ops->mult != MatMult_SeqAIJHIP) return 0;
+    A = Ad;
+  }
+  ierr = MatSeqAIJHIPUpload(A);CHKERRQ(ierr);
+  if (SD(A)->plan && SA(A)->bs <= 1) CHKHIP(mi355x_spmv_plan_group_info(SD(A)->plan, &ng, &ngj, NULL));
+  if (nodes) *nodes = SA(A)->inode_count;
+  if (groups) *groups = ng;
+  if (shared_indices) *shared_indices = (PetscInt)ngj;
   return 0;
 }
 
@@ -606,7 +674,7 @@ PetscErrorCode MatGetVecs_HIPMI355X(Mat A, Vec *right, Vec *left) { return MatGe
 static PetscErrorCode MatDestroy_SeqAIJHIP(Mat A) {   /* free the mirror and zero spptr first, aijcusp.cu:584-586 */
   Mat_SeqAIJ *a = SA(A);
   if (SD(A)) { device_free(A); free(A->spptr); A->spptr = NULL; }
-  if (a) { free(a->i); free(a->j); free(a->a); free(a->ilen); free(a->imax); free(a); A->data = NULL; }
+  if (a) { free(a->i); free(a->j); free(a->a); free(a->ilen); free(a->imax); free(a->inode_size); free(a); A->data = NULL; }
   return 0;
 }
 
@@ -645,6 +713,17 @@ static PetscErrorCode adopt_csr(Mat B, PetscInt nrows, PetscInt bs, const PetscI
   PetscInt nz = i[nrows];
   size_t vals = (size_t)nz * (size_t)(bs > 1 ? bs * bs : 1);
   if (i[0] != 0) SETERRQ(B->comm, PETSC_ERR_ARG_OUTOFRANGE, "i (row indices) must start with 0");
+  for (PetscInt r = 0; r < nrows; r++) if (i[r + 1] < i[r]) SETERRQ(B->comm, PETSC_ERR_ARG_OUTOFRANGE, "Negative row length in i (row indices) row = %d length = %d", r, i[r + 1] - i[r]);
+  {   /* column indices in range and ascending within each row (the kernels gather x[col] unchecked) */
+    const PetscInt ncols = bs > 1 ? s->n / bs : s->n;
+    for (PetscInt r = 0; r < nrows; r++) for (PetscInt k = i[r]; k < i[r + 1]; k++) {
+      if (j[k] < 0 || j[k] >= ncols) SETERRQ(B->comm, PETSC_ERR_ARG_OUTOFRANGE, "Column index %d out of range [0,%d) in row %d", j[k], ncols, r);
+      if (k > i[r] && j[k] <= j[k - 1]) SETERRQ(B->comm, PETSC_ERR_ARG_WRONG, "Column indices of row %d are not sorted and unique", r);
+    }
+  }
+  device_free(B);   /* the matrix may have been used before (MatLoad into a used Mat): nothing of the old pattern survives */
+  free(s->i); free(s->j); free(s->a); free(s->ilen); free(s->imax);
+  s->i = s->j = s->ilen = s->imax = NULL; s->a = NULL;
   ierr = PetscMalloc(sizeof(PetscInt) * (size_t)(nrows + 1), &s->i);CHKERRQ(ierr);
   ierr = PetscMalloc(sizeof(PetscInt) * (size_t)PetscMax(nz, 1), &s->j);CHKERRQ(ierr);
   ierr = PetscMalloc(sizeof(PetscScalar) * PetscMax(vals, 1), &s->a);CHKERRQ(ierr);
@@ -656,7 +735,6 @@ static PetscErrorCode adopt_csr(Mat B, PetscInt nrows, PetscInt bs, const PetscI
   s->nonzerorows = 0;
   for (PetscInt r = 0; r < nrows; r++) {
     s->ilen[r] = s->imax[r] = i[r + 1] - i[r];
-    if (s->ilen[r] < 0) SETERRQ(B->comm, PETSC_ERR_ARG_OUTOFRANGE, "Negative row length in i (row indices) row = %d length = %d", r, s->ilen[r]);
     s->nonzerorows += (s->ilen[r] > 0);
   }
   s->nz = s->maxnz = nz; s->compact = PETSC_TRUE;

@@ -52,18 +52,21 @@ PetscErrorCode PetscViewerDestroy(PetscViewer *viewer) {
 extern PetscErrorCode MatSeqAIJSetCSR_Private(Mat, PetscInt, const PetscInt *, const PetscInt *, const PetscScalar *);
 extern PetscErrorCode MatMPIAIJSetCSR_Private(Mat, PetscInt, const PetscInt *, const PetscInt *, const PetscScalar *);
 
-PetscErrorCode MatLoad(Mat A, PetscViewer viewer) {
+/* the validated part of MatLoad: everything that can fail after the first allocation, so that the caller frees once */
+static PetscErrorCode matload_body(Mat A, PetscViewer viewer, long base, const PetscInt header[4], PetscInt *rowlens,
+                                   PetscInt **li_, PetscInt **lj_, PetscScalar **la_) {
   PetscErrorCode ierr;
-  PetscInt header[4], M, N, *rowlens, *li, *lj; PetscScalar *la;
-  if (!A || !viewer) SETERRQ(0, PETSC_ERR_ARG_NULL, "Null argument");
-  if (viewer->mode != FILE_MODE_READ) SETERRQ(A->comm, PETSC_ERR_ARG_WRONG, "viewer not opened for reading");
-  long base = ftell(viewer->f);
-  ierr = read_ints(viewer->f, header, 4);CHKERRQ(ierr);
-  if (header[0] != MAT_FILE_CLASSID) SETERRQ(A->comm, 79 /* PETSC_ERR_FILE_UNEXPECTED */, "not matrix object");
-  M = header[1]; N = header[2];
-  if (header[3] < 0) SETERRQ(A->comm, 79, "Matrix stored in special format on disk, cannot load as SeqAIJ");
-  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)PetscMax(M, 1), &rowlens);CHKERRQ(ierr);
+  const PetscInt M = header[1], N = header[2], nz = header[3];
+  PetscInt *li, *lj; PetscScalar *la;
   ierr = read_ints(viewer->f, rowlens, (size_t)M);CHKERRQ(ierr);
+  {   /* aij.c:4125: the row lengths must add up to the header's nonzero count (and none may be negative) */
+    long sum = 0;
+    for (PetscInt r = 0; r < M; r++) {
+      if (rowlens[r] < 0 || rowlens[r] > N) SETERRQ(A->comm, 79, "Inconsistant matrix data in file: row %d has length %d", r, rowlens[r]);
+      sum += rowlens[r];
+    }
+    if (sum != (long)nz) SETERRQ(A->comm, 66, "Inconsistant matrix data in file. no-nonzeros = %d, sum-row-lengths = %ld", nz, sum);
+  }
   if (!A->type_name[0]) {
     if (A->m_req == -1 && A->M_req == -1) { ierr = MatSetSizes(A, PETSC_DECIDE, PETSC_DECIDE, M, N);CHKERRQ(ierr); }   /* applies a type chosen earlier */
     if (!A->type_name[0]) { ierr = MatSetType(A, MATAIJHIPMI355X);CHKERRQ(ierr); }
@@ -73,22 +76,43 @@ PetscErrorCode MatLoad(Mat A, PetscViewer viewer) {
   long before = 0, mine = 0;
   for (PetscInt r = 0; r < rs; r++) before += rowlens[r];
   for (PetscInt r = rs; r < re; r++) mine += rowlens[r];
-  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)(m + 1), &li);CHKERRQ(ierr);
-  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)PetscMax(mine, 1), &lj);CHKERRQ(ierr);
-  ierr = PetscMalloc(sizeof(PetscScalar) * (size_t)PetscMax(mine, 1), &la);CHKERRQ(ierr);
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)(m + 1), li_);CHKERRQ(ierr);
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)PetscMax(mine, 1), lj_);CHKERRQ(ierr);
+  ierr = PetscMalloc(sizeof(PetscScalar) * (size_t)PetscMax(mine, 1), la_);CHKERRQ(ierr);
+  li = *li_; lj = *lj_; la = *la_;
   li[0] = 0;
   for (PetscInt r = 0; r < m; r++) li[r + 1] = li[r] + rowlens[rs + r];
-  long cols0 = base + 16 + 4L * M, vals0 = cols0 + 4L * header[3];
-  fseek(viewer->f, cols0 + 4L * before, SEEK_SET);
+  long cols0 = base + 16 + 4L * M, vals0 = cols0 + 4L * nz;
+  if (fseek(viewer->f, cols0 + 4L * before, SEEK_SET)) SETERRQ(A->comm, 66, "Cannot seek to the column indices");
   ierr = read_ints(viewer->f, lj, (size_t)mine);CHKERRQ(ierr);
-  fseek(viewer->f, vals0 + 8L * before, SEEK_SET);
+  /* the kernels gather x[col] unchecked: a file whose columns are out of range or unsorted never reaches them */
+  for (PetscInt r = 0; r < m; r++) for (PetscInt k = li[r]; k < li[r + 1]; k++) {
+    if (lj[k] < 0 || lj[k] >= N) SETERRQ(A->comm, 66, "Inconsistant matrix data in file: column %d of row %d is outside [0,%d)", lj[k], rs + r, N);
+    if (k > li[r] && lj[k] <= lj[k - 1]) SETERRQ(A->comm, 66, "Inconsistant matrix data in file: columns of row %d are not increasing", rs + r);
+  }
+  if (fseek(viewer->f, vals0 + 8L * before, SEEK_SET)) SETERRQ(A->comm, 66, "Cannot seek to the values");
   ierr = read_scalars(viewer->f, la, (size_t)mine);CHKERRQ(ierr);
-  fseek(viewer->f, vals0 + 8L * header[3], SEEK_SET);   /* leave the file positioned after the matrix */
+  if (fseek(viewer->f, vals0 + 8L * nz, SEEK_SET)) SETERRQ(A->comm, 66, "Cannot seek past the matrix");   /* leave the file positioned after the matrix */
   if (!strcmp(A->type_name, MATSEQAIJHIPMI355X)) { ierr = MatSeqAIJSetCSR_Private(A, m, li, lj, la);CHKERRQ(ierr); }
   else if (!strcmp(A->type_name, MATMPIAIJHIPMI355X)) { ierr = MatMPIAIJSetCSR_Private(A, m, li, lj, la);CHKERRQ(ierr); }
   else SETERRQ(A->comm, PETSC_ERR_SUP, "MatLoad for type %s", A->type_name);
-  free(rowlens); free(li); free(lj); free(la);
   return 0;
+}
+
+PetscErrorCode MatLoad(Mat A, PetscViewer viewer) {
+  PetscErrorCode ierr;
+  PetscInt header[4], *rowlens = NULL, *li = NULL, *lj = NULL; PetscScalar *la = NULL;
+  if (!A || !viewer) SETERRQ(0, PETSC_ERR_ARG_NULL, "Null argument");
+  if (viewer->mode != FILE_MODE_READ) SETERRQ(A->comm, PETSC_ERR_ARG_WRONG, "viewer not opened for reading");
+  long base = ftell(viewer->f);
+  ierr = read_ints(viewer->f, header, 4);CHKERRQ(ierr);
+  if (header[0] != MAT_FILE_CLASSID) SETERRQ(A->comm, 79 /* PETSC_ERR_FILE_UNEXPECTED */, "not matrix object");
+  if (header[3] < 0) SETERRQ(A->comm, 79, "Matrix stored in special format on disk, cannot load as SeqAIJ");
+  if (header[1] < 0 || header[2] < 0) SETERRQ(A->comm, 66 /* PETSC_ERR_FILE_READ */, "Inconsistant matrix data in file: sizes %d x %d", header[1], header[2]);
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)PetscMax(header[1], 1), &rowlens);CHKERRQ(ierr);
+  ierr = matload_body(A, viewer, base, header, rowlens, &li, &lj, &la);
+  free(rowlens); free(li); free(lj); free(la);
+  return ierr;
 }
 
 PetscErrorCode MatView(Mat A, PetscViewer viewer) {

@@ -215,6 +215,7 @@ typedef struct {
   PetscInt bs;              /* block size (BAIJ reuse: i,j index blocks, a holds bs*bs per block) */
   PetscBool compact;        /* rows are packed (after assembly) */
   PetscInt nonzerorows;
+  PetscInt inode_count, *inode_size;   /* Mat_SeqAIJ_Inode node_count / size (aij.h:99-115); 0 / NULL: plain routines */
 } Mat_SeqAIJ;
 
 /* device mirror */

@@ -113,6 +113,17 @@ def spmv_inode(ai, aj, aa, x):
     return y
 
 
+def matmult(ai, aj, aa, x, z=None):
+    """MatMult (z None) / MatMultAdd as the reference DISPATCHES them for a seqaij matrix: the inode routines when
+    Mat_CheckInode keeps them, the plain loops otherwise.  Returns (y, number of nodes or 0)."""
+    m = ai.size - 1
+    y = np.zeros(m)
+    ns = np.zeros(m + 1, dtype=np.int32)
+    lib().orc_matmult_seqaij.restype = C.c_int
+    nodes = lib().orc_matmult_seqaij(C.c_int(m), I(ai), I(aj), D(aa), D(x), D(z) if z is not None else None, D(y), I(ns))
+    return y, nodes
+
+
 def spmv_add(ai, aj, aa, x, y):
     m = ai.size - 1
     z = np.zeros(m)

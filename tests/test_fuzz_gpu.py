@@ -83,11 +83,17 @@ def test_spmv_random_shapes(dev, seed):
     dai = dev.put(ai); daj = dev.put(aj if aj.size else np.zeros(2, np.int32)); daa = dev.put(aa if aa.size else np.zeros(2))
     dx = dev.put(x)
     y0 = np.random.default_rng(seed).standard_normal(m)
-    ref = orc.spmv(ai, aj, aa, x)
-    refadd = orc.spmv_add(ai, aj, aa, x, y0)
+    # the reference's dispatch: inode routines (pair summation) when Mat_CheckInode keeps them, plain loops otherwise;
+    # the plan gets the same decision and, where it pays, the grouped-row form
+    ref, nodes = orc.matmult(ai, aj, aa, x)
+    refadd = orc.matmult(ai, aj, aa, x, y0)[0]
+    ns = np.ascontiguousarray(orc.check_inode(ai, aj)[1], dtype=np.int32)
     for compress in (False, True):
         plan = C.c_void_p()
         dev.chk(k.mi355x_spmv_plan_create(dev.h, m, ai.ctypes.data, None, C.byref(plan)))
+        dev.chk(k.mi355x_spmv_plan_set_pairsum(plan, 1 if nodes else 0))
+        if nodes and not compress and aj.size:
+            dev.chk(k.mi355x_spmv_plan_group_rows(dev.h, plan, ai.ctypes.data, aj.ctypes.data, nodes, ns.ctypes.data))
         nt = C.c_int(0)
         if compress:
             dev.chk(k.mi355x_spmv_plan_compress_indices(dev.h, plan, ai.ctypes.data, (aj if aj.size else np.zeros(2, np.int32)).ctypes.data))

@@ -193,7 +193,7 @@ def test_mat_ex5_golden(P, name, rect, mtype):
     yy = np.arange(n, dtype=np.float64)
     y.set_array(yy)
     L.MatMult(A.h, y.h, w.h)
-    assert np.array_equal(bits(w.array()), bits(orc.spmv(ai2, aj2, aa2, yy)))
+    assert np.array_equal(bits(w.array()), bits(orc.matmult(ai2, aj2, aa2, yy)[0]))
 
 
 def test_mat_p7_and_transpose_bitexact(P):
@@ -205,18 +205,18 @@ def test_mat_p7_and_transpose_bitexact(P):
     x = np.sin(0.37 * np.arange(n)) + 1.0
     vx, vy, vz = V(P, x), V(P, np.zeros(n)), V(P, rnd(n, 3))
     L.MatMult(A.h, vx.h, vy.h)
-    assert np.array_equal(bits(vy.array()), bits(orc.spmv(ai, aj, aa, x)))
+    assert np.array_equal(bits(vy.array()), bits(orc.matmult(ai, aj, aa, x)[0]))
     L.MatMultTranspose(A.h, vx.h, vy.h)
     assert np.array_equal(bits(vy.array()), bits(orc.spmv_t(ai, aj, aa, x, n)))
     z = vz.array()
     L.MatMultTransposeAdd(A.h, vx.h, vz.h, vy.h)
     assert np.array_equal(bits(vy.array()), bits(orc.spmv_t_add(ai, aj, aa, x, z, n)))
     L.MatMultAdd(A.h, vx.h, vz.h, vz.h)            # in place
-    assert np.array_equal(bits(vz.array()), bits(orc.spmv_add(ai, aj, aa, x, z)))
+    assert np.array_equal(bits(vz.array()), bits(orc.matmult(ai, aj, aa, x, z)[0]))
     # value-only update: MatScale bumps the state, only `a` is re-sent
     L.MatScale(A.h, -2.0)
     L.MatMult(A.h, vx.h, vy.h)
-    assert np.array_equal(bits(vy.array()), bits(orc.spmv(ai, aj, -2.0 * aa, x)))
+    assert np.array_equal(bits(vy.array()), bits(orc.matmult(ai, aj, -2.0 * aa, x)[0]))
     fl = C.c_double(); L.PetscGetFlops(C.byref(fl)); assert fl.value > 0
 
 
@@ -887,7 +887,7 @@ def test_value_updates_on_the_device_copy(P):
         L.MatDiagonalScale(A.h, vl.h, vr.h)
         ref = orc.diagonal_scale(ai, aj, aa, l, r)
         A.mult(vx, vy)
-        assert np.array_equal(bits(vy.array()), bits(orc.spmv(ai, aj, ref, x)))
+        assert np.array_equal(bits(vy.array()), bits(orc.matmult(ai, aj, ref, x)[0]))
         L.MatMultTranspose(A.h, vx.h, vy.h)
         assert np.allclose(vy.array(), orc.spmv_t(ai, aj, ref, x, n), rtol=0, atol=1e-12)
         L.MatDiagonalScale(A.h, None, vr.h)
@@ -897,7 +897,7 @@ def test_value_updates_on_the_device_copy(P):
         L.MatScale(A.h, -0.37)
         ref = -0.37 * ref
         A.mult(vx, vy)
-        assert np.array_equal(bits(vy.array()), bits(orc.spmv(ai, aj, ref, x)))
+        assert np.array_equal(bits(vy.array()), bits(orc.matmult(ai, aj, ref, x)[0]))
         d = vx.duplicate(); L.MatGetDiagonal(A.h, d.h)
         assert np.array_equal(bits(d.array()), bits(orc.get_diagonal(ai, aj, ref)))
         L.MatZeroEntries(A.h)
@@ -1082,7 +1082,7 @@ def test_pattern_change_after_device_use(P):
     S = sp.csr_matrix(S); S.sort_indices()
     si, sj, sa = S.indptr.astype(np.int32), S.indices.astype(np.int32), S.data.astype(np.float64)
     A.mult(vx, vy)
-    assert np.array_equal(bits(vy.array()), bits(orc.spmv(si, sj, sa, x)))
+    assert np.array_equal(bits(vy.array()), bits(orc.matmult(si, sj, sa, x)[0]))
     L.MatMultTranspose(A.h, vx.h, vy.h)
     assert np.allclose(vy.array(), orc.spmv_t(si, sj, sa, x, n), rtol=0, atol=1e-12)
     # batch assembly on the NEW pattern, touching one of the new entries
@@ -1097,3 +1097,142 @@ def test_pattern_change_after_device_use(P):
     S = sp.csr_matrix(S); S.sort_indices()
     A.mult(vx, vy)
     assert np.allclose(vy.array(), orc.spmv(S.indptr.astype(np.int32), S.indices.astype(np.int32), S.data.astype(np.float64), x), rtol=0, atol=1e-13)
+
+
+def multidof_stencil(m, n, dof, seed):
+    """2-D 5-point node stencil with dof x dof coupling, point-wise AIJ: rows of 3*dof..5*dof entries (<= 16 for dof <= 3)"""
+    bi, bj, _ = pb.lap2d(m, n)
+    rng = np.random.default_rng(seed)
+    return pb.expand_blocks(bi, bj, rng.standard_normal((bj.size, dof, dof)))
+
+
+def set_options(L, s):
+    L.PetscOptionsClear()
+    if s:
+        L.PetscOptionsInsertString(s.encode())
+
+
+def test_inode_matrices_carry_the_reference_dispatch(P):
+    """SURVEY 8(a5).  A seqaij matrix whose rows repeat their pattern (several dof per node) is run by the reference
+    through MatMult_SeqAIJ_Inode, which sums two products at a time.  The HIP type makes the same decision with the same
+    loop (Mat_CheckInode, node sizes identical to the oracle's), groups the rows on the device, and for short rows
+    reproduces THAT routine bit for bit; -mat_no_inode restores MatMult_SeqAIJ's order, also bit for bit."""
+    L = P.lib()
+    for dof in (2, 3):
+        ai, aj, aa = multidof_stencil(23, 19, dof, 5 + dof)
+        m = ai.size - 1
+        x = rnd(m, 21); z = rnd(m, 22)
+        nodes_ref, ns_ref = orc.check_inode(ai, aj)
+        assert nodes_ref == m // dof
+        for opt, inode in (("", True), ("-mat_no_inode", False), ("-mat_inode_limit 1", False), ("-mat_hipmi355x_index_compression 0", True)):
+            set_options(L, opt)
+            A = P.Mat.from_csr(ai, aj, aa)
+            vx, vy, vz = V(P, x), V(P, np.zeros(m)), V(P, z)
+            A.mult(vx, vy)
+            nodes, groups, shared = C.c_int(), C.c_int(), C.c_int()
+            L.MatHIPMI355XGetInodeInfo(A.h, C.byref(nodes), C.byref(groups), C.byref(shared))
+            set_options(L, "")
+            ref = orc.spmv_inode(ai, aj, aa, x) if inode else orc.spmv(ai, aj, aa, x)
+            assert nodes.value == (nodes_ref if inode else 0)
+            if opt == "-mat_hipmi355x_index_compression 0":     # no offset dictionary: the rows of a node share one column list
+                assert groups.value == nodes_ref and shared.value * dof == aj.size
+            assert np.array_equal(bits(vy.array()), bits(ref))
+            L.MatMultAdd(A.h, vx.h, vz.h, vy.h)
+            refadd = orc.matmult(ai, aj, aa, x, z)[0] if inode else orc.spmv_add(ai, aj, aa, x, z)
+            assert np.array_equal(bits(vy.array()), bits(refadd))
+        assert not np.array_equal(bits(orc.spmv_inode(ai, aj, aa, x)), bits(orc.spmv(ai, aj, aa, x)))   # the two orders do differ
+
+
+def test_fem_like_config4_shape_small(P):
+    """BASELINE configs[3] stand-in at test size (tests/problems.py gen_fem3: 3 dof per node, hexahedral flange mesh,
+    RCM-ordered): grouped-row kernel vs the reference's dispatch (rows of ~60-81 entries: several lanes per row,
+    BASELINE.md tolerance), GMRES(30) + block Jacobi histories vs the oracle"""
+    L = P.lib()
+    ai, aj, aa = pb.gen_fem3(14, 14, 8)
+    m = ai.size - 1
+    x = rnd(m, 31)
+    scale = np.zeros(m); np.add.at(scale, np.repeat(np.arange(m), np.diff(ai)), np.abs(aa * x[aj]))
+    A = P.Mat.from_csr(ai, aj, aa)
+    vx, vy = V(P, x), V(P, np.zeros(m))
+    A.mult(vx, vy)
+    nodes, groups, shared = C.c_int(), C.c_int(), C.c_int()
+    L.MatHIPMI355XGetInodeInfo(A.h, C.byref(nodes), C.byref(groups), C.byref(shared))
+    nodes_ref, _ = orc.check_inode(ai, aj)
+    assert nodes.value == nodes_ref == m // 3 and groups.value == nodes_ref and shared.value * 3 == aj.size
+    ref, used = orc.matmult(ai, aj, aa, x)
+    assert used == nodes_ref
+    assert np.all(np.abs(vy.array() - ref) <= 1e-12 * scale)
+    b = orc.spmv(ai, aj, aa, np.ones(m))
+    xh, h, its, reason = solve(P, ai, aj, aa, b, "gmres", "bjacobi", opts="-sub_pc_type jacobi", rtol=1e-8)
+    xr, hr, itsr, rr = orc.ksp_solve(ai, aj, aa, b, ksp="gmres", pc="bjacobi", blocks=[0, m], sub_ksp="preonly", sub_pc="jacobi", rtol=1e-8)
+    assert its == itsr and reason == rr
+    assert np.allclose(h, hr, rtol=1e-8, atol=0)
+    assert np.linalg.norm(xh - 1.0) < 1e-6 * np.sqrt(m)
+
+
+def test_same_nonzero_count_different_pattern(P):
+    """a matrix that has been used on the device is re-preallocated and re-filled with ANOTHER pattern of the same
+    nonzero count (and: MatLoad-style adoption of new arrays into a used Mat): nothing of the old mirror may survive"""
+    L = P.lib()
+    n = 300
+    rng = np.random.default_rng(9)
+
+    def pattern(seed):
+        r = np.random.default_rng(seed)
+        cols = [np.sort(r.choice(n, size=5, replace=False)).astype(np.int32) for _ in range(n)]
+        ai = np.arange(0, 5 * n + 1, 5, dtype=np.int32)
+        return ai, np.concatenate(cols), r.standard_normal(5 * n)
+
+    def fill(A, ai, aj, aa):
+        for r in range(n):
+            rr = np.array([r], np.int32); cols = aj[ai[r]:ai[r + 1]].copy(); vals = aa[ai[r]:ai[r + 1]].copy()
+            L.MatSetValues(A.h, 1, rr.ctypes.data_as(C.c_void_p), cols.size, cols.ctypes.data_as(C.c_void_p), vals.ctypes.data_as(C.c_void_p), 1)
+        L.MatAssemblyBegin(A.h, 0); L.MatAssemblyEnd(A.h, 0)
+
+    x = rng.standard_normal(n); vx = V(P, x); vy = V(P, np.zeros(n))
+    A = P.Mat(); L.MatCreate(L.COMM_SELF, C.byref(A.h))
+    L.MatSetSizes(A.h, n, n, n, n); L.MatSetType(A.h, b"seqaijhipmi355x")
+    L.MatSeqAIJSetPreallocation(A.h, 5, None)
+    p1 = pattern(1); fill(A, *p1)
+    A.mult(vx, vy); L.MatMultTranspose(A.h, vx.h, vy.h)
+    assert np.allclose(vy.array(), orc.spmv_t(*p1, x, n), rtol=0, atol=1e-12)
+    L.MatSeqAIJSetPreallocation(A.h, 5, None)          # same nz per row, then other columns
+    p2 = pattern(2); fill(A, *p2)
+    assert not np.array_equal(p1[1], p2[1])
+    A.mult(vx, vy)
+    assert np.array_equal(bits(vy.array()), bits(orc.matmult(*p2, x)[0]))
+    L.MatMultTranspose(A.h, vx.h, vy.h)
+    assert np.allclose(vy.array(), orc.spmv_t(*p2, x, n), rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("which", ["fem", "irr"])
+def test_config4_full_size_properties(P, which):
+    """BASELINE configs[3] at full size (~1.5 M rows, ~1.15e8 nonzeros: the FEM-like and the IRR stand-ins for Flan_1565,
+    tests/problems.py): (1) sampled rows of y = A x against a host dot product of the same row, BASELINE.md tolerance;
+    (2) the grouped-row plan and the plain plan (-mat_no_inode) are two different kernels over the same matrix and must
+    agree to that tolerance everywhere; (3) linearity A(2x) == 2 A x bit for bit (scaling by 2 is exact)."""
+    L = P.lib()
+    ai, aj, aa = pb.gen_fem3() if which == "fem" else pb.gen_irr()
+    m = ai.size - 1
+    x = np.sin(0.37 * np.arange(m)) + 1.0
+    vx, vy = V(P, x), V(P, np.zeros(m))
+    A = P.Mat.from_csr(ai, aj, aa)
+    A.mult(vx, vy)
+    y = vy.array()
+    nodes = C.c_int(); L.MatHIPMI355XGetInodeInfo(A.h, C.byref(nodes), None, None)
+    assert (nodes.value == m // 3) if which == "fem" else (nodes.value == 0)
+    rows = np.random.default_rng(3).integers(0, m, 4000)
+    for r in rows:
+        k0, k1 = ai[r], ai[r + 1]
+        t = aa[k0:k1] * x[aj[k0:k1]]
+        assert abs(y[r] - t.sum()) <= 1e-12 * np.abs(t).sum()
+    L.VecScale(vx.h, 2.0)
+    A.mult(vx, vy)
+    assert np.array_equal(bits(vy.array()), bits(2.0 * y))
+    if which == "fem":
+        set_options(L, "-mat_no_inode")
+        B = P.Mat.from_csr(ai, aj, aa)
+        B.mult(vx, vy)
+        set_options(L, "")
+        absrow = np.zeros(m); np.add.at(absrow, np.repeat(np.arange(m), np.diff(ai)), np.abs(aa * x[aj]))
+        assert np.all(np.abs(vy.array() - 2.0 * y) <= 2e-12 * absrow)

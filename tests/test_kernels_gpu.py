@@ -203,11 +203,20 @@ def random_csr(m, n, rowlen, seed, sort=True):
     return ai, aj, aa
 
 
-def run_spmv(dev, ai, aj, aa, x, y0=None, rows=None, compress=False):
+def run_spmv(dev, ai, aj, aa, x, y0=None, rows=None, compress=False, group=False, pairsum=None):
     k = dev.k
     dai, daj, daa = upload_csr(dev, ai, aj, aa)
     dx = dev.put(x)
     plan = make_plan(dev, ai, rows)
+    if group:       # node sizes as Mat_CheckInode finds them (the oracle's restatement), then the device-side grouping
+        nodes, ns = orc.check_inode(ai, aj)
+        ns = np.ascontiguousarray(ns, dtype=np.int32)
+        dev.chk(k.mi355x_spmv_plan_group_rows(dev.h, plan, ai.ctypes.data, aj.ctypes.data, nodes, ns.ctypes.data))
+        ng, ngj = C.c_int(), C.c_long()
+        k.mi355x_spmv_plan_group_info(plan, C.byref(ng), C.byref(ngj), None)
+        run_spmv.last_groups = (nodes, ng.value, ngj.value)
+    if pairsum is not None:
+        dev.chk(k.mi355x_spmv_plan_set_pairsum(plan, int(pairsum)))
     if compress:
         dev.chk(k.mi355x_spmv_plan_compress_indices(dev.h, plan, ai.ctypes.data, aj.ctypes.data))
         nt = C.c_int()
@@ -358,6 +367,74 @@ def test_spmv_irregular(dev):
     got = run_spmv(dev, ai, aj, aa, x, y0=y0)
     ref = orc.spmv_add(ai, aj, aa, x, y0)
     assert np.all(np.abs(got - ref) <= 1e-12 * np.maximum(scale + np.abs(y0), 1e-300))
+
+
+def grouped_csr(nnodes, ncols, seed, maxdof=5, maxlen=40, empty=0.05):
+    """rows in runs of 1..maxdof sharing one random column list (what a multi-dof FEM matrix looks like to Mat_CheckInode)"""
+    rng = np.random.default_rng(seed)
+    ai = [0]; aj = []
+    for _ in range(nnodes):
+        dof = int(rng.integers(1, maxdof + 1))
+        ln = 0 if rng.random() < empty else int(rng.integers(1, maxlen + 1))
+        cols = np.sort(rng.choice(ncols, size=min(ln, ncols), replace=False))
+        for _ in range(dof):
+            aj.extend(cols.tolist()); ai.append(len(aj))
+    ai = np.array(ai, dtype=np.int32); aj = np.array(aj, dtype=np.int32)
+    return ai, aj, rng.standard_normal(aj.size)
+
+
+@pytest.mark.parametrize("shape", ["groups16", "fem3", "long"])
+def test_spmv_grouped_rows(dev, shape):
+    """the inode form (mi355x_spmv_plan_group_rows): one stored column list per group of identical rows.  Row blocks of
+    short rows (<= 16 nonzeros per row on average: one lane per row) carry the bits of MatMult_SeqAIJ_Inode with the pair
+    summation and those of MatMult_SeqAIJ with the plain one -- MatMult and MatMultAdd; longer rows are summed by
+    several lanes + a tree and agree within BASELINE.md's 1e-12 * sum|a_ij x_j|"""
+    import problems as pb
+    if shape == "groups16":
+        ai, aj, aa = grouped_csr(6000, 3000, 71, maxlen=16)     # groups of 1..5 rows, rows of 0..16 entries
+    elif shape == "fem3":
+        ai, aj, aa = pb.gen_fem3(12, 12, 7)                     # 3 dof per node, ~60 nonzeros per row
+    else:
+        ai, aj, aa = grouped_csr(300, 5000, 72, maxdof=4, maxlen=950, empty=0.0)   # rows up to the shared-index cap (960)
+    m = ai.size - 1
+    ncols = int(aj.max()) + 1 if aj.size else 1
+    x = rnd(max(ncols, m), 73)
+    y0 = rnd(m, 74)
+    exact = shape == "groups16"
+    scale = np.zeros(m); np.add.at(scale, np.repeat(np.arange(m), np.diff(ai)), np.abs(aa * x[aj]))
+    for pairsum, ref, ref_add in ((1, orc.spmv_inode(ai, aj, aa, x), orc.matmult(ai, aj, aa, x, y0)[0]),
+                                  (0, orc.spmv(ai, aj, aa, x), orc.spmv_add(ai, aj, aa, x, y0))):
+        got = run_spmv(dev, ai, aj, aa, x, group=True, pairsum=pairsum)
+        nodes, ng, ngj = run_spmv.last_groups
+        assert nodes > 0 and ng >= nodes and 3 * ngj <= 2 * aj.size     # grouped, and it pays
+        got_add = run_spmv(dev, ai, aj, aa, x, y0=y0, group=True, pairsum=pairsum)
+        if exact:
+            assert_bitexact(got, ref)
+            assert_bitexact(got_add, ref_add)
+        else:
+            assert np.all(np.abs(got - ref) <= 1e-12 * np.maximum(scale, 1e-300))
+            assert np.all(np.abs(got_add - ref_add) <= 1e-12 * np.maximum(scale + np.abs(y0), 1e-300))
+    if exact:   # the ungrouped kernels with pair summation: same bits (index-compressed / compressed-row plans of such matrices)
+        assert_bitexact(run_spmv(dev, ai, aj, aa, x, pairsum=1), orc.spmv_inode(ai, aj, aa, x))
+        assert_bitexact(run_spmv(dev, ai, aj, aa, x, y0=y0, pairsum=1), orc.matmult(ai, aj, aa, x, y0)[0])
+
+
+def test_spmv_grouping_declines_when_it_would_not_pay(dev):
+    ai, aj, aa = orc.gen_p7(9, 8, 7)                            # no two rows share a pattern
+    x = rnd(ai.size - 1, 75)
+    nodes, ns = orc.check_inode(ai, aj)
+    assert nodes == 0
+    ns1 = np.ones(ai.size - 1, dtype=np.int32)
+    k = dev.k
+    plan = make_plan(dev, ai)
+    dev.chk(k.mi355x_spmv_plan_group_rows(dev.h, plan, ai.ctypes.data, aj.ctypes.data, ai.size - 1, ns1.ctypes.data))
+    ng = C.c_int(-1)
+    k.mi355x_spmv_plan_group_info(plan, C.byref(ng), None, None)
+    assert ng.value == 0                                        # singleton groups share nothing: plan left alone
+    bad = np.array([2, 2], dtype=np.int32)                      # node sizes that do not add up to m
+    assert k.mi355x_spmv_plan_group_rows(dev.h, plan, ai.ctypes.data, aj.ctypes.data, 2, bad.ctypes.data) != 0
+    dev.chk(k.mi355x_spmv_plan_destroy(plan))
+    assert_bitexact(run_spmv(dev, ai, aj, aa, x), orc.spmv(ai, aj, aa, x))
 
 
 def test_spmv_compressed_rows(dev):

@@ -49,6 +49,8 @@ def main():
         ai, aj, aa = cached("fem", problems.gen_fem3)
     n = ai.size - 1
     print("%s: n=%d nnz=%d (%.1f/row, max %d) ready in %.1fs" % (which, n, aj.size, aj.size / n, np.diff(ai).max(), time.time() - t0), flush=True)
+    if os.environ.get("PETSC_OPTIONS_EXTRA"):
+        L.PetscOptionsInsertString(os.environ["PETSC_OPTIONS_EXTRA"].encode())
     A = P.Mat.from_csr(ai, aj, aa)
     x = P.Vec.from_array(np.sin(0.37 * np.arange(n)) + 1.0, comm=L.COMM_SELF)
     y = x.duplicate()
@@ -56,7 +58,9 @@ def main():
     A.mult(x, y)
     y.array()
     print("first MatMult (analysis + upload) %.2fs" % (time.time() - t0), flush=True)
-    info = getattr(L, "MatHIPMI355XGetFormat", None)
+    nodes, groups, shared = C.c_int(), C.c_int(), C.c_int()
+    L.MatHIPMI355XGetInodeInfo(A.h, C.byref(nodes), C.byref(groups), C.byref(shared))
+    print("  inode check: %d nodes; device plan: %d groups, %d shared column indices (%.2f per nonzero)" % (nodes.value, groups.value, shared.value, shared.value / max(aj.size, 1)), flush=True)
     B = 12 * aj.size + 4 * (n + 1) + 16 * n
     L.MatHIPMI355XSetTiming(A.h, 1)
     for _ in range(reps):

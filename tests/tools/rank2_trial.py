@@ -35,8 +35,8 @@ def main():
     A.mult(x, y)
     # MatMult_MPIAIJ order (mpiaij.c:1111-1114): diagonal block first, then += off-diagonal block * ghost values
     pc = orc.mpiaij_split(rank * mloc, (rank + 1) * mloc, rank * mloc, (rank + 1) * mloc, gi, gj, ga)
-    ref = orc.spmv(pc["ad_i"], pc["ad_j"], pc["ad_a"], xg[rank * mloc:(rank + 1) * mloc])
-    ref = orc.spmv_add(pc["bo_i"], pc["bo_j"], pc["bo_a"], xg[pc["garray"]].copy(), ref)
+    ref = orc.matmult(pc["ad_i"], pc["ad_j"], pc["ad_a"], xg[rank * mloc:(rank + 1) * mloc])[0]
+    ref = orc.matmult(pc["bo_i"], pc["bo_j"], pc["bo_a"], xg[pc["garray"]].copy(), ref)[0]
     ok1 = np.array_equal(y.array().view(np.uint64), ref.view(np.uint64))
     L.MatMultTranspose(A.h, x.h, y.h)
     reft = orc.spmv_t(gi, gj, ga, xg, N)[rank * mloc:(rank + 1) * mloc]
@@ -74,9 +74,9 @@ def main():
     B.mult(vx, vy)
     pcs = [orc.mpiaij_split(int(rng_[q]), int(rng_[q + 1]), int(rng_[q]), int(rng_[q + 1]), si, sj, sa) for q in range(world)]
     me = pcs[rank]
-    ref = orc.spmv(me["ad_i"], me["ad_j"], me["ad_a"], xi[rs:re_].copy())
+    ref = orc.matmult(me["ad_i"], me["ad_j"], me["ad_a"], xi[rs:re_].copy())[0]
     if me["garray"].size:
-        ref = orc.spmv_add(me["bo_i"], me["bo_j"], me["bo_a"], xi[me["garray"]].copy(), ref)
+        ref = orc.matmult(me["bo_i"], me["bo_j"], me["bo_a"], xi[me["garray"]].copy(), ref)[0]
     ok5 = np.array_equal(vy.array().view(np.uint64), ref.view(np.uint64))
     L.MatMultTranspose(B.h, vx.h, vy.h)
     reft = orc.spmv_t(me["ad_i"], me["ad_j"], me["ad_a"], xi[rs:re_].copy(), re_ - rs)
@@ -97,11 +97,11 @@ def main():
     L.MatScale(B.h, -0.37)
     B.mult(vx, vy)
     ad = -0.37 * orc.diagonal_scale(me["ad_i"], me["ad_j"], me["ad_a"], lg[rs:re_].copy(), rg[rs:re_].copy())
-    ref = orc.spmv(me["ad_i"], me["ad_j"], ad, xi[rs:re_].copy())
+    ref = orc.matmult(me["ad_i"], me["ad_j"], ad, xi[rs:re_].copy())[0]
     if me["garray"].size:
         bo = orc.diagonal_scale(me["bo_i"], me["bo_j"], me["bo_a"], lg[rs:re_].copy(), None)
         bo = -0.37 * orc.diagonal_scale(me["bo_i"], me["bo_j"], bo, None, rg[me["garray"]].copy())
-        ref = orc.spmv_add(me["bo_i"], me["bo_j"], bo, xi[me["garray"]].copy(), ref)
+        ref = orc.matmult(me["bo_i"], me["bo_j"], bo, xi[me["garray"]].copy(), ref)[0]
     ok7 = np.array_equal(vy.array().view(np.uint64), ref.view(np.uint64))
     print("rank %d/%d: MatDiagonalScale + MatScale then MatMult bitexact=%s" % (rank, world, ok7), flush=True)
     ok1 = ok1 and ok5 and ok6
