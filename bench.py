@@ -140,7 +140,13 @@ def main():
     noff = C.c_int(0)
     L.MatHIPMI355XGetIndexCompression(timed, C.byref(noff))
     kernel_name = ("spmv_csr_rowblock_idx8_kernel (CSR + 1-byte offset-dictionary column indices, %d offsets; 'achieved' uses the CSR algorithmic bytes)" % noff.value) if noff.value else "spmv_csr_rowblock_kernel"
-    staged = world > 1 and PD.last_transport != "rccl"
+    if world > 1:
+        tr = PD.transport_report(comm)                   # asked of the C library: what the halo and the reductions travelled over
+    else:
+        tr = {"transport": "single", "rccl_ranks": 0, "rccl_communicators": 0}
+    staged = world > 1 and tr["transport"] != "rccl"
+    if world > 1 and not staged:
+        assert tr["rccl_ranks"] == world, "RCCL reports %d ranks, launched %d" % (tr["rccl_ranks"], world)
     out = {
         "metric": "KSP CG+Jacobi iterations/s x unknowns (3-D 7-pt Poisson, %d^3 rows per GPU); ksp_its_per_sec and spmv_gbps are BASELINE.json's two quantities" % n,
         "value": round(value, 3), "unit": "Mdof-it/s",
@@ -149,7 +155,8 @@ def main():
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "3D 7-pt Poisson P7(%d,%d,%d) = %d rows, %s, KSPCG + PCJACOBI, b = A*1, x0 = 0, exactly K iterations"
                    % (nx, ny, nz, unknowns, "MatSeqAIJ on 1 GPU" if world == 1 else "MatMPIAIJ in %d z-slabs, %s" % (world, "HOST-STAGED halo and reductions (one-GPU rehearsal, not a measurement)" if staged else "RCCL halo")),
-                   "rows_per_gpu": mloc, "nnz_per_gpu": nnz_loc, "parallelism": "row-block dp%d" % world},
+                   "rows_per_gpu": mloc, "nnz_per_gpu": nnz_loc, "parallelism": "row-block dp%d" % world,
+                   "transport": tr["transport"], "rccl_ranks": tr["rccl_ranks"], "rccl_communicators": tr["rccl_communicators"]},
         "ksp_its_per_sec": round(its_per_s, 2),
         "spmv_gbps": round(spmv_gbps_one * world, 1),
         "ksp_gbps": round(cg_bytes * its_per_s * world / 1e9, 1),
@@ -165,8 +172,17 @@ def main():
     # FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE x2 on gfx950, calibration in profiles/r01_fetch_calibration.md)
     try:
         import csv
+        import hashlib
         fs = ws = None
-        with open(os.path.join(ROOT, "profiles", "r01_bench_pmc_summary.csv")) as f:
+        src_hash = hashlib.sha256(open(os.path.join(ROOT, "petsc-dev_amd", "csrc", "spmv_csr.hip"), "rb").read()).hexdigest()[:16]
+        pmc_csv = os.path.join(ROOT, "profiles", "bench_pmc_summary.csv")
+        # the counters are only quoted while they describe THIS kernel: the summary's first line carries the hash of the
+        # kernel source it was collected with (tests/tools/pmc_summary.py --stamp); a stale file is ignored
+        head = open(pmc_csv).readline()
+        if ("spmv_csr.hip sha256/16 = " + src_hash) not in head:
+            raise RuntimeError("stale PMC summary")
+        with open(pmc_csv) as f:
+            f.readline()
             for row in csv.DictReader(f):
                 if "spmv_csr_rowblock" in row["kernel"] and "<true" not in row["kernel"]:   # the y = A x instantiation
                     if row["counter"] == "FETCH_SIZE":
@@ -176,7 +192,7 @@ def main():
         if fs is not None and ws is not None and n == 256 and world == 1:
             out["roofline"]["traffic"] = int((2.0 * fs + ws) * 1024)
             out["roofline"]["kernel"] = kernel_name.replace("'achieved' uses the CSR algorithmic bytes", "'achieved' uses the CSR algorithmic bytes, 'traffic' is what the kernel actually moved")
-            out["roofline"]["traffic_source"] = "profiles/r01_bench_pmc_summary.csv (rocprofv3 --pmc, separate passes; bytes per launch)"
+            out["roofline"]["traffic_source"] = "profiles/bench_pmc_summary.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of this command with this kernel source; bytes per launch)"
     except Exception:
         pass
 

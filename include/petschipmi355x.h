@@ -129,6 +129,10 @@ PetscErrorCode PetscCommSetExchange(MPI_Comm comm, PetscCommExchangeFn fn);
 PetscErrorCode PetscCommSetWorld(MPI_Comm comm);
 /* attach the RCCL communicator (mi355x_comm.h) used for device-side halo exchange and reductions */
 PetscErrorCode PetscCommSetDeviceComm(MPI_Comm comm, void *mi355x_comm);
+/* one communicator per HIP stream: `reduce` serves the all-reduces queued on the compute stream, `halo` the grouped
+ * send/recv (and split-phase all-reduces) queued on the halo stream, so that RCCL does not serialise the two */
+PetscErrorCode PetscCommSetDeviceComms(MPI_Comm comm, void *reduce, void *halo);
+PetscErrorCode PetscCommGetDeviceTransport(MPI_Comm comm, int *kind /*0 single,1 RCCL,2 host-staged*/, int *nranks, int *distinct_halo_comm);
 PetscErrorCode PetscCommDestroy(MPI_Comm *comm);
 PetscErrorCode MPI_Comm_rank(MPI_Comm comm, PetscMPIInt *rank);
 PetscErrorCode MPI_Comm_size(MPI_Comm comm, PetscMPIInt *size);

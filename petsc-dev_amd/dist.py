@@ -140,37 +140,48 @@ def torch_comm(device_comm=True):
     L.PetscCommSetWorld(comm)
     if device_comm and size > 1:
         k = P.load_kernels()
-        uid = C.create_string_buffer(128)
-        if rank == 0:
-            rc = k.mi355x_comm_get_unique_id(uid)
-            if rc:
-                raise RuntimeError("ncclGetUniqueId failed: %s" % k.mi355x_comm_error_string(rc).decode())
-        obj = [uid.raw]
-        dist.broadcast_object_list(obj, src=0)
         ndev = C.c_int()
         k.mi355x_device_count(C.byref(ndev))
         dev = int(os.environ.get("LOCAL_RANK", "0")) % max(ndev.value, 1)
         rc = k.mi355x_set_device(dev)
         if rc:
             raise RuntimeError("hipSetDevice(%d) failed: %s" % (dev, k.mi355x_error_string(rc).decode()))
-        dcomm = C.c_void_p()
-        rc = k.mi355x_comm_init_rank(C.byref(dcomm), size, rank, obj[0])
-        why = "" if rc == 0 else "ncclCommInitRank: %s" % k.mi355x_comm_error_string(rc).decode()
-        if rc == 0:
-            why = _rccl_self_test(k, dcomm, rank, size)
-        # every rank must take the same transport: agree over gloo
-        ok = torch.tensor([0 if why else 1], dtype=torch.int32)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if int(ok[0]) == 1:
-            L.PetscCommSetDeviceComm(comm, dcomm)
+        # TWO communicators over the same ranks, one per HIP stream: RCCL runs the operations of one communicator one
+        # after the other in issue order whatever streams they are given, so the halo exchange (halo stream) and the
+        # scalar all-reduces (compute stream) each get their own.  Every rank issues its operations in the same
+        # program order (the solvers are SPMD), which is what concurrent use of two communicators requires.
+        dcomms, why = [], ""
+        for which in ("reductions", "halo"):
+            uid = C.create_string_buffer(128)
+            if rank == 0:
+                rc = k.mi355x_comm_get_unique_id(uid)
+                if rc:
+                    raise RuntimeError("ncclGetUniqueId failed: %s" % k.mi355x_comm_error_string(rc).decode())
+            obj = [uid.raw]
+            dist.broadcast_object_list(obj, src=0)
+            dcomm = C.c_void_p()
+            rc = k.mi355x_comm_init_rank(C.byref(dcomm), size, rank, obj[0])
+            if rc:
+                why = why or "ncclCommInitRank (%s): %s" % (which, k.mi355x_comm_error_string(rc).decode())
+            else:
+                dcomms.append(dcomm)
+                why = why or _rccl_self_test(k, dcomm, rank, size)
+            # every rank must take the same transport (and leave this loop together): agree over gloo
+            ok = torch.tensor([0 if why else 1], dtype=torch.int32)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok[0]) != 1:
+                why = why or "another rank failed"
+                break
+        if not why:
+            L.PetscCommSetDeviceComms(comm, dcomms[0], dcomms[1])
             transport = "rccl"
         else:
             # LOUD: the halo and the reductions then travel device -> host -> gloo -> host -> device (the reference's own
             # CUSP arrangement); still the GPU compute path, but not the transport this library is built for
             print("[petsc-hipmi355x] rank %d: RCCL communicator unusable (%s); ALL ranks fall back to the host-staged transport"
-                  % (rank, why or "another rank failed"), file=sys.stderr, flush=True)
-            if rc == 0:
-                k.mi355x_comm_destroy(dcomm)
+                  % (rank, why), file=sys.stderr, flush=True)
+            for d in dcomms:
+                k.mi355x_comm_destroy(d)
             transport = "host-staged"
     elif size > 1:
         transport = "host-staged"
@@ -179,3 +190,13 @@ def torch_comm(device_comm=True):
     global last_transport
     last_transport = transport
     return comm
+
+
+def transport_report(comm):
+    """What the device-side collectives of `comm` really travel over, asked of the C library (not of this module's
+    bookkeeping): {"transport": "single"|"rccl"|"host-staged", "rccl_ranks": n RCCL reports, "rccl_communicators": 1|2}"""
+    L = P.lib()
+    kind, nranks, distinct = C.c_int(), C.c_int(), C.c_int()
+    L.PetscCommGetDeviceTransport(comm, C.byref(kind), C.byref(nranks), C.byref(distinct))
+    return {"transport": ("single", "rccl", "host-staged")[kind.value], "rccl_ranks": nranks.value,
+            "rccl_communicators": (2 if distinct.value else 1) if kind.value == 1 else 0}

@@ -178,8 +178,9 @@ static PetscErrorCode PCApply_BJacobi(PC pc, Vec x, Vec y) {
   ierr = VecHIPGetWrite(y, &dy);CHKERRQ(ierr);
   bx->dev = (PetscScalar *)dx; bx->valid = VALID_DEVICE; PetscObjectStateIncrease(bj->x);
   by->dev = dy; by->valid = VALID_DEVICE; PetscObjectStateIncrease(bj->y);
-  ierr = KSPSolve(bj->ksp, bj->x, bj->y);CHKERRQ(ierr);
-  bx->dev = sx; bx->valid = vx; by->dev = sy; by->valid = vy;
+  ierr = KSPSolve(bj->ksp, bj->x, bj->y);
+  bx->dev = sx; bx->valid = vx; by->dev = sy; by->valid = vy;   /* the aliases come off first, also when the sub-solve failed: the work vectors own sx / sy */
+  CHKERRQ(ierr);
   ierr = VecHIPRestoreWrite(y);CHKERRQ(ierr);
   PetscObjectStateIncrease(y);   /* y changed through the alias: cached norms are stale (VecRestoreArray does this in bjacobi.c:758) */
   return 0;

@@ -38,7 +38,11 @@ struct _p_PetscComm {
   PetscCommAllreduceFn allreduce;
   PetscCommBarrierFn barrier;
   PetscCommExchangeFn exchange;
-  mi355x_comm_t dcomm;     /* RCCL communicator for device buffers */
+  /* RCCL communicators for device buffers, one per HIP stream (operations of one communicator are serialised by RCCL
+   * in issue order whatever stream they are given, so the halo and the reductions would not overlap on one):
+   * dcomm carries what is queued on the compute stream (all-reduces of dots / norms), dcomm_halo what is queued on
+   * the halo stream (grouped ncclSend/ncclRecv of VecScatter, the split-phase all-reduce of comb.c's Begin/End) */
+  mi355x_comm_t dcomm, dcomm_halo;
 };
 
 /* ---- device context of this process (one GPU, two streams) ---- */
@@ -165,6 +169,7 @@ struct _p_VecScatter {
   int ready_marked;           /* ev_packed already recorded by VecScatterMarkReady */
   /* every rank's request list (kept from set-up) for the host-staged transport */
   PetscScalar *h_send, *h_recv;   /* host staging buffers of the host-staged transport */
+  PetscScalar *d_local_tmp;       /* device staging of the local (self) part, local_n doubles */
 };
 PetscErrorCode VecScatterMarkReady(VecScatter ctx, Vec x);
 PetscErrorCode VecScatterCreate_PtoS_MPIAIJ(MPI_Comm comm, PetscLayout *xmap, PetscInt ec, const PetscInt *garray, VecScatter *ctx);

@@ -45,13 +45,30 @@ PetscErrorCode PetscCommCreate(int rank, int size, void *ctx, PetscCommAllgather
   struct _p_PetscComm *c;
   if (size > 1 && (!ag || !ar)) SETERRQ(0, PETSC_ERR_ARG_NULL, "a communicator of size %d needs allgather and allreduce callbacks", size);
   ierr = PetscMalloc(sizeof(*c), &c);CHKERRQ(ierr);
-  c->rank = rank; c->size = size; c->ctx = ctx; c->allgather = ag; c->allreduce = ar; c->barrier = bar; c->exchange = NULL; c->dcomm = NULL;
+  c->rank = rank; c->size = size; c->ctx = ctx; c->allgather = ag; c->allreduce = ar; c->barrier = bar; c->exchange = NULL; c->dcomm = NULL; c->dcomm_halo = NULL;
   *comm = c;
   return 0;
 }
 PetscErrorCode PetscCommSetExchange(MPI_Comm comm, PetscCommExchangeFn fn) { comm->exchange = fn; return 0; }
 PetscErrorCode PetscCommSetWorld(MPI_Comm comm) { PETSC_COMM_WORLD = comm ? comm : &comm_self; return 0; }
-PetscErrorCode PetscCommSetDeviceComm(MPI_Comm comm, void *dcomm) { comm->dcomm = (mi355x_comm_t)dcomm; return 0; }
+PetscErrorCode PetscCommSetDeviceComm(MPI_Comm comm, void *dcomm) { comm->dcomm = comm->dcomm_halo = (mi355x_comm_t)dcomm; return 0; }
+/* two communicators over the same ranks: `reduce` for the compute stream, `halo` for the halo stream */
+PetscErrorCode PetscCommSetDeviceComms(MPI_Comm comm, void *reduce, void *halo) {
+  if ((reduce == NULL) != (halo == NULL)) SETERRQ(comm, PETSC_ERR_ARG_WRONG, "both RCCL communicators or none");
+  comm->dcomm = (mi355x_comm_t)reduce; comm->dcomm_halo = (mi355x_comm_t)halo;
+  return 0;
+}
+/* what the device-side collectives of this communicator travel over: 0 = one rank, nothing to exchange; 1 = RCCL
+ * (nranks = the size RCCL reports for the reduction communicator, distinct = 1 when the halo has a communicator of its
+ * own); 2 = host-staged (several ranks, no RCCL communicator attached) */
+PetscErrorCode PetscCommGetDeviceTransport(MPI_Comm comm, int *kind, int *nranks, int *distinct) {
+  int r = 0, n = 0;
+  *kind = comm->dcomm ? 1 : (comm->size > 1 ? 2 : 0);
+  if (comm->dcomm) CHKHIP(mi355x_comm_rank(comm->dcomm, &r, &n));
+  if (nranks) *nranks = n;
+  if (distinct) *distinct = (comm->dcomm && comm->dcomm_halo != comm->dcomm) ? 1 : 0;
+  return 0;
+}
 PetscErrorCode PetscCommDestroy(MPI_Comm *comm) {
   if (*comm && *comm != &comm_self) { if (PETSC_COMM_WORLD == *comm) PETSC_COMM_WORLD = &comm_self; free(*comm); }
   *comm = NULL;

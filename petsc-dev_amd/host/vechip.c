@@ -563,7 +563,7 @@ PetscErrorCode PetscCommSplitReductionBegin(MPI_Comm comm) {
     if (!sr.ev) CHKHIP(mi355x_event_create(&sr.ev));
     CHKHIP(mi355x_event_record(sr.ev, dc->h));                    /* the reductions queued so far */
     CHKHIP(mi355x_handle_wait_event(dc->hcomm, sr.ev));
-    CHKHIP(mi355x_comm_allreduce_sum(x->comm->dcomm, dc->hcomm, ds, (size_t)sr.n));
+    CHKHIP(mi355x_comm_allreduce_sum(x->comm->dcomm_halo, dc->hcomm, ds, (size_t)sr.n));   /* halo stream: its own communicator */
     CHKHIP(mi355x_handle_publish_at(dc->hcomm, ds, sr.n, SR_HOST0));   /* lands in the HALO handle's pinned scratch */
   } else {
     CHKHIP(mi355x_handle_publish_at(dc->h, ds, sr.n, SR_HOST0));

@@ -114,6 +114,7 @@ static PetscErrorCode scatter_device_setup(VecScatter ctx, PetscDeviceCtx *dc) {
       CHKHIP(mi355x_memcpy_h2d(dc->h, s[k]->d_local_slots, s[k]->local_slots, sizeof(PetscInt) * (size_t)s[k]->local_n));
     }
   }
+  if (ctx->to.local_n > 0) CHKHIP(mi355x_malloc((void **)&ctx->d_local_tmp, sizeof(PetscScalar) * (size_t)ctx->to.local_n));
   CHKHIP(mi355x_handle_synchronize(dc->h));
   CHKHIP(mi355x_event_create(&ctx->ev_packed));
   CHKHIP(mi355x_event_create(&ctx->ev_done));
@@ -133,8 +134,8 @@ static PetscErrorCode neighbour_exchange(VecScatter ctx, PetscDeviceCtx *dc, Pet
   if (comm->dcomm) {
     int rc = 0, rc_end;
     CHKHIP(mi355x_comm_group_start());
-    for (PetscInt i = 0; i < nr && !rc; i++) rc = mi355x_comm_recv(comm->dcomm, dc->hcomm, rdst[i], (size_t)rcnt[i], rprocs[i]);
-    for (PetscInt i = 0; i < ns && !rc; i++) rc = mi355x_comm_send(comm->dcomm, dc->hcomm, ssrc[i], (size_t)scnt[i], sprocs[i]);
+    for (PetscInt i = 0; i < nr && !rc; i++) rc = mi355x_comm_recv(comm->dcomm_halo, dc->hcomm, rdst[i], (size_t)rcnt[i], rprocs[i]);
+    for (PetscInt i = 0; i < ns && !rc; i++) rc = mi355x_comm_send(comm->dcomm_halo, dc->hcomm, ssrc[i], (size_t)scnt[i], sprocs[i]);
     rc_end = mi355x_comm_group_end();                       /* always closed, also after a failed post */
     CHKHIP(rc);
     CHKHIP(rc_end);
@@ -180,14 +181,21 @@ PetscErrorCode VecScatterMarkReady(VecScatter ctx, Vec x) {
 }
 
 /* FORWARD/INSERT: x (parallel) -> y (= lvec, sequential).  REVERSE/ADD: x (= lvec) -> y (parallel), +=. */
+static PetscErrorCode scatter_begin(VecScatter ctx, Vec x, Vec y, InsertMode addv, ScatterMode mode);
 PetscErrorCode VecScatterBegin(VecScatter ctx, Vec x, Vec y, InsertMode addv, ScatterMode mode) {
   PetscErrorCode ierr;
-  PetscDeviceCtx *dc;
   if (!ctx) SETERRQ(0, PETSC_ERR_ARG_NULL, "Null VecScatter");
   if (ctx->inuse) SETERRQ(ctx->comm, PETSC_ERR_ARG_WRONGSTATE, " Scatter ctx already in use");   /* vscat.c:1637 */
   if (!((mode == SCATTER_FORWARD && addv == INSERT_VALUES) || (mode == SCATTER_REVERSE && addv == ADD_VALUES)))
     SETERRQ(ctx->comm, PETSC_ERR_SUP, "only FORWARD/INSERT and REVERSE/ADD (the MatMult[Transpose]_MPIAIJ uses) are ported");
-  ctx->inuse = PETSC_TRUE;
+  ierr = scatter_begin(ctx, x, y, addv, mode);CHKERRQ(ierr);
+  ctx->inuse = PETSC_TRUE;                                  /* only a Begin that succeeded leaves the scatter in use */
+  return 0;
+}
+static PetscErrorCode scatter_begin(VecScatter ctx, Vec x, Vec y, InsertMode addv, ScatterMode mode) {
+  PetscErrorCode ierr;
+  PetscDeviceCtx *dc;
+  (void)addv;
   if (ctx->to.n == 0 && ctx->from.n == 0 && ctx->to.local_n == 0) return 0;
   ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
   ierr = scatter_device_setup(ctx, dc);CHKERRQ(ierr);
@@ -218,13 +226,9 @@ PetscErrorCode VecScatterBegin(VecScatter ctx, Vec x, Vec y, InsertMode addv, Sc
       ierr = neighbour_exchange(ctx, dc, from->n, from->procs, rdst, rcnt, to->n, to->procs, ssrc, scnt);CHKERRQ(ierr);
     }
     if (from->n && !from->contiq) CHKHIP(mi355x_unpack_insert(dc->hcomm, (size_t)from->starts[from->n], from->d_indices, from->d_values, dy));   /* UnPack_1 */
-    if (to->local_n) {   /* Scatter_1, vpscat.c:538 */
-      PetscScalar *tmp = mi355x_handle_device_scratch(dc->hcomm);
-      for (PetscInt o = 0; o < to->local_n; o += 64) {
-        PetscInt c = PetscMin(64, to->local_n - o);
-        CHKHIP(mi355x_pack(dc->hcomm, (size_t)c, to->d_local_slots + o, dx, tmp));
-        CHKHIP(mi355x_unpack_insert(dc->hcomm, (size_t)c, from->d_local_slots + o, tmp, dy));
-      }
+    if (to->local_n) {   /* Scatter_1, vpscat.c:538; staged through the scatter's own buffer */
+      CHKHIP(mi355x_pack(dc->hcomm, (size_t)to->local_n, to->d_local_slots, dx, ctx->d_local_tmp));
+      CHKHIP(mi355x_unpack_insert(dc->hcomm, (size_t)to->local_n, from->d_local_slots, ctx->d_local_tmp, dy));
     }
     CHKHIP(mi355x_event_record(ctx->ev_done, dc->hcomm));
   } else {
@@ -275,13 +279,9 @@ PetscErrorCode VecScatterEnd(VecScatter ctx, Vec x, Vec y, InsertMode addv, Scat
     }
     if (to->local_n) {
       const PetscScalar *dx;
-      PetscScalar *tmp = mi355x_handle_device_scratch(dc->h);
       ierr = VecHIPGetRead(x, &dx);CHKERRQ(ierr);
-      for (PetscInt o = 0; o < to->local_n; o += 64) {
-        PetscInt c = PetscMin(64, to->local_n - o);
-        CHKHIP(mi355x_pack(dc->h, (size_t)c, from->d_local_slots + o, dx, tmp));
-        CHKHIP(mi355x_unpack_add(dc->h, (size_t)c, to->d_local_slots + o, tmp, dy));
-      }
+      CHKHIP(mi355x_pack(dc->h, (size_t)to->local_n, from->d_local_slots, dx, ctx->d_local_tmp));
+      CHKHIP(mi355x_unpack_add(dc->h, (size_t)to->local_n, to->d_local_slots, ctx->d_local_tmp, dy));
     }
   }
   ierr = VecHIPRestoreWrite(y);CHKERRQ(ierr);
@@ -299,6 +299,7 @@ PetscErrorCode VecScatterDestroy(VecScatter *pctx) {
     if (s[k]->d_values) mi355x_free(s[k]->d_values);
     if (s[k]->d_local_slots) mi355x_free(s[k]->d_local_slots);
   }
+  if (ctx->d_local_tmp) mi355x_free(ctx->d_local_tmp);
   if (ctx->ev_packed) mi355x_event_destroy(ctx->ev_packed);
   if (ctx->ev_done) mi355x_event_destroy(ctx->ev_done);
   free(ctx->h_send); free(ctx->h_recv);

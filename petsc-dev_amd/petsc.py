@@ -14,7 +14,7 @@ P = C.POINTER
 # name -> argtypes; all return PetscErrorCode (int)
 _SIG = {
     "PetscHIPMI355XInitialize": [i32], "PetscHIPMI355XFinalize": [], "PetscHIPMI355XRegisterAll": [],
-    "PetscCommCreate": [i32, i32, vp, vp, vp, vp, P(vp)], "PetscCommSetWorld": [vp], "PetscCommSetExchange": [vp, vp], "PetscCommSetDeviceComm": [vp, vp],
+    "PetscCommCreate": [i32, i32, vp, vp, vp, vp, P(vp)], "PetscCommSetWorld": [vp], "PetscCommSetExchange": [vp, vp], "PetscCommSetDeviceComm": [vp, vp], "PetscCommSetDeviceComms": [vp, vp, vp], "PetscCommGetDeviceTransport": [vp, P(i32), P(i32), P(i32)],
     "PetscCommDestroy": [P(vp)], "PetscGetFlops": [P(dbl)],
     "PetscOptionsInsertString": [C.c_char_p], "PetscOptionsSetValue": [C.c_char_p, C.c_char_p], "PetscOptionsClear": [],
     "VecCreate": [vp, P(vp)], "VecSetSizes": [vp, i32, i32], "VecSetType": [vp, C.c_char_p], "VecSetFromOptions": [vp],

@@ -364,11 +364,19 @@ def test_device_collectives_on_a_one_rank_rccl_communicator(P):
     dcomm = C.c_void_p()
     rc = k.mi355x_comm_init_rank(C.byref(dcomm), 1, 0, uid.raw)
     assert rc == 0, k.mi355x_comm_error_string(rc).decode()
-    L.PetscCommSetDeviceComm(comm, dcomm)
+    # as the launcher arranges it: a second communicator for what is queued on the halo stream
+    uid2 = C.create_string_buffer(128)
+    assert k.mi355x_comm_get_unique_id(uid2) == 0
+    hcomm = C.c_void_p()
+    rc = k.mi355x_comm_init_rank(C.byref(hcomm), 1, 0, uid2.raw)
+    assert rc == 0, k.mi355x_comm_error_string(rc).decode()
+    assert PD.transport_report(comm) == {"transport": "single", "rccl_ranks": 0, "rccl_communicators": 0}
+    L.PetscCommSetDeviceComms(comm, dcomm, hcomm)
+    assert PD.transport_report(comm) == {"transport": "rccl", "rccl_ranks": 1, "rccl_communicators": 2}
     try:
         # the launcher's self test: one all-reduce and one grouped ncclSend/ncclRecv (to itself on one rank) through the
         # C wrappers of include/mi355x_comm.h
-        assert PD._rccl_self_test(k, dcomm, 0, 1) == ""
+        assert PD._rccl_self_test(k, dcomm, 0, 1) == "" and PD._rccl_self_test(k, hcomm, 0, 1) == ""
         ai, aj, aa = pb.lap2d(33, 29)
         n = ai.size - 1
         b = orc.spmv(ai, aj, aa, np.cos(0.3 * np.arange(n)))
@@ -391,6 +399,7 @@ def test_device_collectives_on_a_one_rank_rccl_communicator(P):
     finally:
         L.PetscCommSetDeviceComm(comm, None)
         k.mi355x_comm_destroy(dcomm)
+        k.mi355x_comm_destroy(hcomm)
 
 
 @pytest.mark.parametrize("pc", ["jacobi", "none", "ilu"])

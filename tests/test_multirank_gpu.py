@@ -24,6 +24,7 @@ def test_mpiaij_two_ranks_one_gpu(built, nranks):
     out = r.stdout + r.stderr
     assert r.returncode == 0, out[-3000:]
     for k in range(nranks):
+        assert "rank %d/%d: transport=host-staged rccl_ranks=0 rccl_communicators=0" % (k, nranks) in out, out[-3000:]
         assert "rank %d/%d: MatMult bitexact=True MatMultTranspose=True norm=True" % (k, nranks) in out, out[-3000:]
         assert "rank %d/%d: irregular MatMult bitexact=True MatMultTranspose bitexact=True" % (k, nranks) in out, out[-3000:]
         assert "rank %d/%d: MatDiagonalScale + MatScale then MatMult bitexact=True" % (k, nranks) in out, out[-3000:]
@@ -49,4 +50,5 @@ def test_bench_two_ranks_rehearsal(built, wide):
     assert d["n_gpus"] == 2 and d["steps"] == 6 and d["warmup"] == 2 and d["scaling"] == "weak"
     assert d["config"]["rows_per_gpu"] == 40 ** 3 and d["value"] > 0 and d["roofline"]["avg_launch_ms"] > 0
     assert "idx8" in d["roofline"]["kernel"]
+    assert d["config"]["transport"] == "host-staged" and "HOST-STAGED" in d["config"]["workload"]
     assert ("P7(80,80,20)" if wide else "P7(40,40,80)") in d["config"]["workload"]

@@ -22,6 +22,8 @@ def main():
     L = P.lib()
     staged = os.environ.get("MI355X_STAGED", "0") == "1"   # several ranks on one GPU: RCCL refuses, use the host-staged transport
     comm = PD.torch_comm(device_comm=not staged)
+    tr = PD.transport_report(comm)
+    print("rank %d/%d: transport=%s rccl_ranks=%d rccl_communicators=%d" % (rank, world, tr["transport"], tr["rccl_ranks"], tr["rccl_communicators"]), flush=True)
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 16
     nx, ny, nz = n, n, n * world
     mloc = n ** 3
