@@ -228,6 +228,19 @@ int mi355x_ilu0_lower_level(mi355x_handle_t h, int nrows, const int *rows, const
 int mi355x_ilu0_upper_level(mi355x_handle_t h, int nrows, const int *rows, const int *bj, const double *ba,
                             const int *bdiag, double *x);
 
+/* The same two solves WITHOUT a kernel boundary per level: one launch per triangular solve, rows sorted by level and
+ * stored as sliced ELL (one wavefront per 64 rows), dependencies handed over through the solution values themselves
+ * (a sentinel bit pattern means "not computed yet"; write-through stores, polling loads).  Same one-lane-per-row,
+ * column-order arithmetic: same bits.  plan_create: lev[i] = dependency level of row i (every level non-empty), row i's
+ * off-diagonal entries are cj/cv[rp[i] .. rp[i]+rl[i]), dinv != NULL (inverted diagonal per row) marks the upper solve.
+ * apply: y = U^-1 L^-1 b; returns non-zero without launching if an earlier application timed out on a dependency. */
+typedef struct mi355x_trisolve_plan_s *mi355x_trisolve_plan_t;
+int mi355x_trisolve_plan_create(mi355x_handle_t h, int n, int nlev, const int *lev, const int *rp, const int *rl, const int *cj,
+                                const double *cv, const double *dinv, mi355x_trisolve_plan_t *plan);
+int mi355x_trisolve_plan_destroy(mi355x_trisolve_plan_t plan);
+int mi355x_trisolve_apply(mi355x_handle_t h, mi355x_trisolve_plan_t lower, mi355x_trisolve_plan_t upper, const double *b, double *y);
+int mi355x_trisolve_aborted(mi355x_trisolve_plan_t plan, int *aborted);
+
 /* ---- halo pack / unpack (VecScatter) ---------------------------------- */
 /* Pack_1    src/vec/vec/utils/vpscat.c:493   buf[k] = x[idx[k]] */
 int mi355x_pack(mi355x_handle_t h, size_t n, const int *idx, const double *x, double *buf);

@@ -269,7 +269,8 @@ PetscErrorCode PCSetUp(PC pc);
 PetscErrorCode PCApply(PC pc, Vec x, Vec y);
 PetscErrorCode PCSetFromOptions(PC pc);
 PetscErrorCode PCDestroy(PC *pc);
-PetscErrorCode PCILUGetLevels_HIPMI355X(PC pc, PetscInt *nlevL, PetscInt *nlevU);   /* launches per triangular solve */
+PetscErrorCode PCILUGetLevels_HIPMI355X(PC pc, PetscInt *nlevL, PetscInt *nlevU);   /* dependency levels of the two triangular solves */
+PetscErrorCode PCILUGetSolver_HIPMI355X(PC pc, PetscInt *syncfree, PetscInt *aborted);   /* 1: two-launch sync-free solves (-pc_factor_hipmi355x_trisolve syncfree, default above 16 levels); 0: one launch per level */
 PetscErrorCode PCBJacobiGetSubKSP(PC pc, PetscInt *n_local, PetscInt *first_local, KSP **ksp);
 
 /* ---- KSP (include/petscksp.h) ---------------------------------------------------------------- */

@@ -4,6 +4,10 @@
 // Rows of one level are independent; one lane per row subtracts its products in column order, exactly the
 // order of PetscSparseDenseMinusDot (aij.h:337-339), so every x[i] carries the reference's bits.
 #include "common.hpp"
+#include <vector>
+#include <algorithm>
+#include <string.h>
+#include <stdlib.h>
 
 __global__ __launch_bounds__(MI355X_BLOCK) void ilu0_lower_level_kernel(int nrows, const int *__restrict__ rows,
                                                                        const int *__restrict__ bi,
@@ -48,6 +52,272 @@ int mi355x_ilu0_upper_level(mi355x_handle_t h, int nrows, const int *rows, const
   hipLaunchKernelGGL(ilu0_upper_level_kernel, dim3((nrows + MI355X_BLOCK - 1) / MI355X_BLOCK), dim3(MI355X_BLOCK), 0,
                      h->stream, nrows, rows, bj, ba, bdiag, x);
   MI355X_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// Sync-free ("point-to-point") triangular solves: ONE launch per solve instead of one per dependency level.
+//
+// Layout built once on the host (mi355x_trisolve_plan_create): the rows of a factor are sorted by dependency level
+// (ties: longer rows first) and stored in slices of 64 consecutive positions, column-major inside a slice
+// (sliced ELL, C = one wavefront): entry q of the row at position t = 64 s + lane sits at ptr[s] + 64 q + lane, so a
+// wavefront's q-th entries are one coalesced 512-byte load.  Column indices are POSITIONS in the same order, and the
+// solution is kept in that order too (w[t]), so that a wavefront stores 64 consecutive doubles.
+//
+// Hand-off: w is initialised with a sentinel bit pattern; the lane that owns position t stores w[t] once, with a
+// write-through (sc1) 8-byte store, and a consumer polls the value itself with sc1 loads until it is not the sentinel
+// (data-tagged granule, MI355X_MICROARCH.md "handoff-1to1": no flag, no fence; an aligned 8-byte store is not torn).
+// Workgroups pull chunks of 4 slices in position order from 8 interleaved queues (chunk c belongs to queue c % 8); a
+// chunk only depends on earlier positions, every queue hands its chunks out in increasing order, and the grid is
+// sized to be fully resident, so the smallest unfinished chunk never waits for anything unfinished: every wait ends.
+// A slice that spans several levels (small levels) walks them in sub-steps: the lanes of a later level poll what the
+// lanes of an earlier level of the same wavefront have already stored.
+// Arithmetic: one lane per row, products subtracted in column order -- MatSolve_SeqAIJ_NaturalOrdering's bits
+// (aijfact.c:3126-3172), as in the level kernels above.
+// Every spin is bounded: a lane that gives up raises *abort_flag (pinned host memory) and all spinners drain.
+#define TRI_SENTINEL 0xFFF8DEADBEEFCAFEull
+#define TRI_QUEUES 8
+#define TRI_QSTRIDE 16          // queue counters 64 bytes apart
+#define TRI_SPIN_LIMIT (1 << 19)   // x ~1 us per poll once backed off: gives up after ~0.5 s
+
+struct mi355x_trisolve_plan_s {
+  int n, nslices, nchunks, upper;
+  int *d_ptr;        // nslices + 1 entry offsets (multiples of 64)
+  int *d_info;       // per position: (row length << 8) | sub-step inside the slice; padding positions: 0
+  int *d_row;        // per position: the row it holds, -1 for padding
+  int *d_col;        // sliced-ELL column POSITIONS
+  double *d_val;     // sliced-ELL values
+  double *d_dinv;    // upper: inverted diagonal per position
+  unsigned char *d_nsub;   // sub-steps per slice
+  int *d_pos;        // per row: its position (for the other solve's gather of this solve's result)
+  double *d_w;       // solution in position order, 64 * nslices doubles
+  unsigned int *d_queue;   // TRI_QUEUES counters
+  int *abort_flag;   // pinned + mapped
+  int grid, sleep_cap;
+};
+
+__device__ __forceinline__ double tri_poll(const double *p, int *abort_flag, int sleep_cap) {
+  double v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  int spins = 0;
+  while (__double_as_longlong(v) == (long long)TRI_SENTINEL) {
+    // back off: a wavefront far ahead of the solve's front must not flood the L2 with polls (thousands of spinning
+    // wavefronts slowed the producers 3x); the wait grows from 128 clocks by 128 per poll up to sleep_cap x 128
+    { const int k = spins < sleep_cap ? spins + 1 : sleep_cap;
+      for (int z = 0; z < k; ++z) __builtin_amdgcn_s_sleep(2); }
+    if ((++spins & 255) == 0) {
+      if (spins > TRI_SPIN_LIMIT || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) {
+        __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        break;
+      }
+    }
+    v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  return v;
+}
+
+// UPPER == false: w[t] = b[row] - L(row,:) w          (b in natural order)
+// UPPER == true : w[t] = (src[spos[row]] - U(row,:) w) * dinv[t] ;  y[row] = w[t]   (src = the lower solve's w)
+// `reset`: the OTHER solve's w, returned to the sentinel for its next run -- lower: reset[t] (coalesced; the upper
+// solve of the previous application is complete), upper: src[spos[row]] right after it has been read (only this lane
+// reads that entry).  other_queue: the other solve's queue counters, zeroed by workgroup 0.
+template <bool UPPER>
+__global__ __launch_bounds__(MI355X_BLOCK) void trisolve_syncfree_kernel(
+    int nslices, int nchunks, const int *__restrict__ ptr, const int *__restrict__ info, const int *__restrict__ rowof,
+    const int *__restrict__ col, const double *__restrict__ val, const double *__restrict__ dinv,
+    const unsigned char *__restrict__ nsub, const double *src, const int *__restrict__ spos, double *w, double *y,
+    double *reset, unsigned int *queue, unsigned int *other_queue, int *abort_flag, int sleep_cap) {
+  __shared__ int chunk_s[2];
+  const int tid = threadIdx.x, lane = tid & (MI355X_WAVE - 1), wave = tid / MI355X_WAVE;
+  if (blockIdx.x == 0 && tid < TRI_QUEUES) other_queue[tid * TRI_QSTRIDE] = 0u;
+  const int q = blockIdx.x % TRI_QUEUES;
+  for (int it = 0;; ++it) {
+    if (tid == 0) {
+      const unsigned int k = __hip_atomic_fetch_add(queue + q * TRI_QSTRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      chunk_s[it & 1] = (int)(k * TRI_QUEUES + q);
+    }
+    __syncthreads();                       // (the slot written two iterations ago is free again: one barrier per iteration)
+    const int chunk = chunk_s[it & 1];
+    if (chunk >= nchunks || chunk < 0) break;
+    const int s = chunk * (MI355X_BLOCK / MI355X_WAVE) + wave;
+    if (s >= nslices) continue;
+    const int t = s * MI355X_WAVE + lane;
+    const int base = ptr[s], slen = (ptr[s + 1] - base) / MI355X_WAVE;
+    const int inf = info[t], row = rowof[t];
+    const int mylen = inf >> 8, mysub = inf & 255;
+    const int ns = nsub[s];
+    double sum = 0.0;
+    if (row >= 0) {
+      if (UPPER) { const int p = spos[row]; sum = src[p]; reset[p] = __longlong_as_double((long long)TRI_SENTINEL); }
+      else sum = src[row];
+    }
+    if (!UPPER) reset[t] = __longlong_as_double((long long)TRI_SENTINEL);
+    const double di = UPPER ? dinv[t] : 1.0;
+    for (int step = 0; step < ns; ++step) {
+      if (row >= 0 && mysub == step) {
+        // entries in batches of 8: the loads of a batch are issued together, consumed in column order
+        for (int q0 = 0; q0 < mylen; q0 += 8) {
+          int c[8]; double a[8], v[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int qq = (q0 + j < mylen) ? q0 + j : q0;
+            c[j] = col[base + qq * MI355X_WAVE + lane];
+            a[j] = val[base + qq * MI355X_WAVE + lane];
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            v[j] = 0.0;
+            if (q0 + j < mylen) v[j] = __hip_atomic_load(w + c[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            if (q0 + j < mylen) {
+              double xv = v[j];
+              if (__double_as_longlong(xv) == (long long)TRI_SENTINEL) xv = tri_poll(w + c[j], abort_flag, sleep_cap);
+              sum -= a[j] * xv;
+            }
+          }
+        }
+        const double r = UPPER ? sum * di : sum;
+        __hip_atomic_store(w + t, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (UPPER) y[row] = r;
+      }
+    }
+    (void)slen;
+  }
+}
+
+extern "C" {
+
+// Host analysis + upload.  n rows; lev[i] = dependency level of row i (0-based, every level non-empty); len(i) and
+// the entries of row i come from (rp, cj, cv): row i's off-diagonal entries are cj/cv[rp[i] .. rp[i] + rl[i]).
+// dinv_host != NULL marks the upper solve (inverted diagonals per row).
+int mi355x_trisolve_plan_create(mi355x_handle_t h, int n, int nlev, const int *lev, const int *rp, const int *rl, const int *cj,
+                                const double *cv, const double *dinv_host, mi355x_trisolve_plan_t *out) {
+  mi355x_trisolve_plan_s *p = new mi355x_trisolve_plan_s();
+  memset(p, 0, sizeof(*p));
+  p->n = n; p->upper = dinv_host != nullptr;
+  const int W = MI355X_WAVE;
+  p->nslices = (n + W - 1) / W;
+  p->nchunks = (p->nslices + 3) / 4;
+  // positions: by level, longer rows first inside a level (stable in the row number)
+  std::vector<int> order((size_t)n), levptr((size_t)nlev + 1, 0);
+  for (int i = 0; i < n; ++i) levptr[(size_t)lev[i] + 1]++;
+  for (int l = 0; l < nlev; ++l) levptr[(size_t)l + 1] += levptr[(size_t)l];
+  { std::vector<int> next(levptr.begin(), levptr.end() - 1);
+    for (int i = 0; i < n; ++i) order[(size_t)next[(size_t)lev[i]]++] = i; }
+  for (int l = 0; l < nlev; ++l)
+    std::stable_sort(order.begin() + levptr[(size_t)l], order.begin() + levptr[(size_t)l + 1], [&](int a, int b) { return rl[a] > rl[b]; });
+  const size_t np = (size_t)p->nslices * W;
+  std::vector<int> pos((size_t)(n > 0 ? n : 1)), info(np > 0 ? np : 1, 0), rowof(np > 0 ? np : 1, -1), ptr((size_t)p->nslices + 1, 0);
+  std::vector<unsigned char> nsub((size_t)(p->nslices > 0 ? p->nslices : 1), 1);
+  std::vector<double> dinv(np > 0 ? np : 1, 1.0);
+  for (int t = 0; t < n; ++t) pos[(size_t)order[(size_t)t]] = t;
+  long total = 0;
+  for (int s = 0; s < p->nslices; ++s) {
+    int mx = 0;
+    const int l0 = lev[order[(size_t)s * W]];
+    for (int j = 0; j < W && (size_t)s * W + j < (size_t)n; ++j) {
+      const int t = s * W + j, i = order[(size_t)t];
+      const int sub = lev[i] - l0;
+      if (sub < 0 || sub > 255) { delete p; return (int)hipErrorInvalidValue; }
+      info[(size_t)t] = (rl[i] << 8) | sub;
+      rowof[(size_t)t] = i;
+      if (dinv_host) dinv[(size_t)t] = dinv_host[i];
+      if (rl[i] > mx) mx = rl[i];
+      if (sub + 1 > nsub[(size_t)s]) nsub[(size_t)s] = (unsigned char)(sub + 1);
+    }
+    ptr[(size_t)s] = (int)total;
+    total += (long)mx * W;
+    if (total > 2147483000L) { delete p; return (int)hipErrorInvalidValue; }
+  }
+  ptr[(size_t)p->nslices] = (int)total;
+  std::vector<int> col((size_t)(total > 0 ? total : 1), 0);
+  std::vector<double> val((size_t)(total > 0 ? total : 1), 0.0);
+  for (int t = 0; t < n; ++t) {
+    const int i = order[(size_t)t], s = t / W, lane = t % W;
+    for (int q = 0; q < rl[i]; ++q) {
+      const int dep = cj[rp[i] + q];
+      if (pos[(size_t)dep] >= t) { delete p; return (int)hipErrorInvalidValue; }   // a dependency must come earlier
+      col[(size_t)ptr[(size_t)s] + (size_t)q * W + lane] = pos[(size_t)dep];
+      val[(size_t)ptr[(size_t)s] + (size_t)q * W + lane] = cv[rp[i] + q];
+    }
+  }
+#define TRI_UP(dst, vec, T) do { MI355X_TRY(hipMalloc((void **)&(dst), sizeof(T) * (vec).size())); \
+    MI355X_TRY(hipMemcpyAsync((dst), (vec).data(), sizeof(T) * (vec).size(), hipMemcpyHostToDevice, h->stream)); } while (0)
+  TRI_UP(p->d_ptr, ptr, int); TRI_UP(p->d_info, info, int); TRI_UP(p->d_row, rowof, int); TRI_UP(p->d_col, col, int);
+  TRI_UP(p->d_val, val, double); TRI_UP(p->d_nsub, nsub, unsigned char); TRI_UP(p->d_pos, pos, int);
+  if (dinv_host) TRI_UP(p->d_dinv, dinv, double);
+#undef TRI_UP
+  MI355X_TRY(hipMalloc((void **)&p->d_w, sizeof(double) * (np > 0 ? np : 1)));
+  { std::vector<unsigned long long> sent(np > 0 ? np : 1, TRI_SENTINEL);
+    MI355X_TRY(hipMemcpyAsync(p->d_w, sent.data(), sizeof(double) * sent.size(), hipMemcpyHostToDevice, h->stream));
+    MI355X_TRY(hipStreamSynchronize(h->stream)); }
+  MI355X_TRY(hipMalloc((void **)&p->d_queue, sizeof(unsigned int) * TRI_QUEUES * TRI_QSTRIDE));
+  MI355X_TRY(hipMemsetAsync(p->d_queue, 0, sizeof(unsigned int) * TRI_QUEUES * TRI_QSTRIDE, h->stream));
+  MI355X_TRY(hipHostMalloc((void **)&p->abort_flag, 64, hipHostMallocMapped | hipHostMallocCoherent));
+  *p->abort_flag = 0;
+  // fully resident grid: the occupancy the runtime reports, at most 4 workgroups per CU (MI355X_MICROARCH.md:
+  // the query can over-report by one; 4 of 256 threads is well inside what this kernel's registers admit)
+  int dev = 0, ncu = 256, per_cu = 0;
+  hipDeviceProp_t prop;
+  MI355X_TRY(hipGetDevice(&dev));
+  MI355X_TRY(hipGetDeviceProperties(&prop, dev));
+  ncu = prop.multiProcessorCount;
+  MI355X_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trisolve_syncfree_kernel<true>, MI355X_BLOCK, 0));
+  if (per_cu > 4) per_cu = 4;
+  if (per_cu < 1) { delete p; return (int)hipErrorInvalidValue; }
+  p->grid = ncu * per_cu;
+  // ... and no larger than a few levels' worth of chunks: workgroups further ahead of the front could only spin
+  { const char *e = getenv("MI355X_TRISOLVE_AHEAD");      // development knobs; the defaults are the measured best
+    const long ahead = e ? atol(e) : 4;
+    const long per_level = ((long)p->nchunks + nlev - 1) / (nlev > 0 ? nlev : 1);
+    long g = ahead * per_level;
+    if (g < TRI_QUEUES) g = TRI_QUEUES;
+    if (g < p->grid) p->grid = (int)g; }
+  if (p->grid > p->nchunks) p->grid = p->nchunks > 0 ? p->nchunks : 1;
+  if (p->grid >= TRI_QUEUES) p->grid -= p->grid % TRI_QUEUES;    // every queue gets the same number of pullers
+  // poll back-off cap (x 128 clocks): the more wavefronts wait, the gentler they must poll (P7(256), 344 workgroups:
+  // cap 2 -> 8.1 ms, cap 8 -> 2.9 ms; P7(128), 88 workgroups: cap 2 -> 1.04 ms, cap 8 -> 1.14 ms per application)
+  { const char *e = getenv("MI355X_TRISOLVE_SLEEP"); p->sleep_cap = e ? atoi(e) : (p->grid <= 128 ? 2 : 8); if (p->sleep_cap < 1) p->sleep_cap = 1; }
+  MI355X_TRY(hipStreamSynchronize(h->stream));
+  *out = p;
+  return 0;
+}
+
+int mi355x_trisolve_plan_destroy(mi355x_trisolve_plan_t p) {
+  if (!p) return 0;
+  (void)hipFree(p->d_ptr); (void)hipFree(p->d_info); (void)hipFree(p->d_row); (void)hipFree(p->d_col); (void)hipFree(p->d_val);
+  (void)hipFree(p->d_nsub); (void)hipFree(p->d_pos); (void)hipFree(p->d_w); (void)hipFree(p->d_queue);
+  if (p->d_dinv) (void)hipFree(p->d_dinv);
+  if (p->abort_flag) (void)hipHostFree(p->abort_flag);
+  delete p;
+  return 0;
+}
+
+// One ILU(0) application y = U^-1 L^-1 b: two launches (lower, upper).  Returns hipErrorLaunchFailure if an EARLIER
+// application on these plans gave up waiting (the flag lives in pinned memory; the caller then uses the level kernels).
+int mi355x_trisolve_apply(mi355x_handle_t h, mi355x_trisolve_plan_t lo, mi355x_trisolve_plan_t up, const double *b, double *y) {
+  if (!lo || !up || lo->n != up->n || lo->upper || !up->upper) return (int)hipErrorInvalidValue;
+  if (*lo->abort_flag || *up->abort_flag) return (int)hipErrorLaunchFailure;
+  if (lo->n == 0) return 0;
+  // with fewer chunks than queues some queues have no puller: chunk c is then only served through queue c % 8 ...
+  // so tiny systems use ONE workgroup per queue that exists (grid >= min(nchunks, 8) is guaranteed by plan_create)
+  const int glo = lo->grid < TRI_QUEUES ? TRI_QUEUES : lo->grid, gup = up->grid < TRI_QUEUES ? TRI_QUEUES : up->grid;
+  hipLaunchKernelGGL((trisolve_syncfree_kernel<false>), dim3(glo), dim3(MI355X_BLOCK), 0, h->stream, lo->nslices, lo->nchunks,
+                     lo->d_ptr, lo->d_info, lo->d_row, lo->d_col, lo->d_val, (const double *)nullptr, lo->d_nsub, b,
+                     (const int *)nullptr, lo->d_w, (double *)nullptr, up->d_w, lo->d_queue, up->d_queue, lo->abort_flag, lo->sleep_cap);
+  MI355X_LAUNCH_CHECK();
+  hipLaunchKernelGGL((trisolve_syncfree_kernel<true>), dim3(gup), dim3(MI355X_BLOCK), 0, h->stream, up->nslices, up->nchunks,
+                     up->d_ptr, up->d_info, up->d_row, up->d_col, up->d_val, up->d_dinv, up->d_nsub, lo->d_w, lo->d_pos,
+                     up->d_w, y, lo->d_w, up->d_queue, lo->d_queue, up->abort_flag, up->sleep_cap);
+  MI355X_LAUNCH_CHECK();
+  return 0;
+}
+
+int mi355x_trisolve_aborted(mi355x_trisolve_plan_t p, int *aborted) {
+  *aborted = p && p->abort_flag ? *p->abort_flag : 0;
   return 0;
 }
 

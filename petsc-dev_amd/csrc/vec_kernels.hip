@@ -269,12 +269,20 @@ __global__ __launch_bounds__(MI355X_BLOCK) void reduce_kernel(F f, size_t n, int
     return;
   }
   block_reduce_store<NOUT, MODE, true>(acc, partials + (size_t)blockIdx.x * NOUT, lds);
-  // Publish: the partials were stored write-through by lanes of wavefront 0; once those stores have left
-  // (vmcnt(0)) lane 0 takes a ticket.  The workgroup that draws the last ticket acquires (invalidates its
-  // CU's L1) and reads every partial with sc1 loads.
+  // Publish: the partials were stored write-through (sc1) by lanes of wavefront 0; once those stores have left
+  // (vmcnt(0)) lane 0 of the SAME wavefront takes a ticket with a relaxed agent-scope add.  The workgroup that draws
+  // the last ticket acquires (invalidates its CU's L1) and reads every partial with sc1 loads.  This is the
+  // write-through form of the hand-off MI355X_MICROARCH.md lists as valid on gfx950 ("sc1 slab stores need no release
+  // fence -> every storing wave s_waitcnt vmcnt(0) -> one lane's relaxed agent fetch_add; the reducer acquires");
+  // it is a property of this ISA, not of the HIP memory model.  -DMI355X_REDUCE_RELEASE=1 builds the model-conformant
+  // form (agent-scope release fence before the ticket: an L2 write-back per workgroup, dot 0.044 -> 0.106 ms at n = 2^24).
   if (threadIdx.x < MI355X_WAVE) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (threadIdx.x == 0) {
+#if defined(MI355X_REDUCE_RELEASE) && MI355X_REDUCE_RELEASE
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
       unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       int last = (t == gridDim.x - 1);
       if (last) {

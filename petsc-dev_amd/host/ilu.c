@@ -4,7 +4,11 @@
  *            natural ordering, on the HOST copy of the matrix -- as the reference's own GPU back end does
  *            (src/mat/impls/aij/seq/seqcusparse/aijcusparse.cu:192-445 factors on the CPU and solves on the GPU);
  *            then a dependency-level analysis of L and U and one upload.
- *   apply  : MatSolve_SeqAIJ_NaturalOrdering (aijfact.c:3126) as level-scheduled device kernels, one launch per level. */
+ *   apply  : MatSolve_SeqAIJ_NaturalOrdering (aijfact.c:3126) on the device, one lane per row in column order (same bits):
+ *            by default two launches, one per triangular solve, with point-to-point hand-off of the solution values
+ *            between wavefronts (mi355x_trisolve_*, csrc/trisolve.hip); -pc_factor_hipmi355x_trisolve level selects the
+ *            level-scheduled kernels, one launch per dependency level (replayed from a hipGraph), which also serve
+ *            systems with few levels and as the fall-back. */
 #include "petscimpl.h"
 
 typedef struct {
@@ -16,6 +20,7 @@ typedef struct {
   PetscScalar *d_work;                                   /* fixed in-place buffer the captured graph works on */
   void *graph;                                           /* hipGraphExec of the nlevL + nlevU level launches */
   int graph_tried;
+  mi355x_trisolve_plan_t tri_lo, tri_up;                 /* sync-free solves (NULL: level launches) */
   int factored_state;
 } PC_ILU;
 
@@ -29,6 +34,8 @@ static PetscErrorCode ilu_free(PC_ILU *f) {
   if (f->d_rowsU) mi355x_free(f->d_rowsU);
   if (f->d_work) mi355x_free(f->d_work);
   if (f->graph) mi355x_graph_destroy(f->graph);
+  if (f->tri_lo) mi355x_trisolve_plan_destroy(f->tri_lo);
+  if (f->tri_up) mi355x_trisolve_plan_destroy(f->tri_up);
   memset(f, 0, sizeof(*f));
   f->factored_state = -1;
   return 0;
@@ -120,8 +127,9 @@ static PetscErrorCode PCSetUp_ILU(PC pc) {
   }
   free(rtmp); free(adiag);
   /* dependency levels: a row may start once the rows it references are done */
-  PetscInt *lev, *rowsL, *rowsU;
+  PetscInt *lev, *levU, *rowsL, *rowsU;
   ierr = PetscMalloc(sizeof(PetscInt) * (size_t)PetscMax(n, 1), &lev);CHKERRQ(ierr);
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)PetscMax(n, 1), &levU);CHKERRQ(ierr);
   f->nlevL = 0;
   for (PetscInt i = 0; i < n; i++) {
     PetscInt l = 0;
@@ -132,12 +140,36 @@ static PetscErrorCode PCSetUp_ILU(PC pc) {
   f->nlevU = 0;
   for (PetscInt i = n - 1; i >= 0; i--) {
     PetscInt l = 0, s0 = bdiag[i + 1] + 1, nz = bdiag[i] - bdiag[i + 1] - 1;
-    for (PetscInt q = 0; q < nz; q++) l = PetscMax(l, lev[bj[s0 + q]] + 1);
-    lev[i] = l; f->nlevU = PetscMax(f->nlevU, l + 1);
+    for (PetscInt q = 0; q < nz; q++) l = PetscMax(l, levU[bj[s0 + q]] + 1);
+    levU[i] = l; f->nlevU = PetscMax(f->nlevU, l + 1);
   }
-  ierr = level_order(n, lev, f->nlevU, &f->levptrU, &rowsU);CHKERRQ(ierr);
-  free(lev);
+  ierr = level_order(n, levU, f->nlevU, &f->levptrU, &rowsU);CHKERRQ(ierr);
   ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
+  {   /* sync-free solves: worth it as soon as the level launches would be a launch-bound chain */
+    char mode[32] = "syncfree"; PetscBool set;
+    ierr = PetscOptionsGetString(pc->prefix, "-pc_factor_hipmi355x_trisolve", mode, sizeof(mode), &set);CHKERRQ(ierr);
+    if (strcmp(mode, "syncfree") && strcmp(mode, "level")) SETERRQ(pc->comm, PETSC_ERR_ARG_WRONG, "-pc_factor_hipmi355x_trisolve <syncfree|level>, got %s", mode);
+    if (!strcmp(mode, "syncfree") && n > 0 && (f->nlevL + f->nlevU > 16 || set)) {
+      PetscInt *rpU, *rlU, *rlL; PetscScalar *dinv;
+      ierr = PetscMalloc(sizeof(PetscInt) * (size_t)n, &rpU);CHKERRQ(ierr);
+      ierr = PetscMalloc(sizeof(PetscInt) * (size_t)n, &rlU);CHKERRQ(ierr);
+      ierr = PetscMalloc(sizeof(PetscInt) * (size_t)n, &rlL);CHKERRQ(ierr);
+      ierr = PetscMalloc(sizeof(PetscScalar) * (size_t)n, &dinv);CHKERRQ(ierr);
+      for (PetscInt i = 0; i < n; i++) {
+        rlL[i] = bi[i + 1] - bi[i];
+        rpU[i] = bdiag[i + 1] + 1; rlU[i] = bdiag[i] - bdiag[i + 1] - 1; dinv[i] = ba[bdiag[i]];
+      }
+      int rc = mi355x_trisolve_plan_create(dc->h, n, f->nlevL, lev, bi, rlL, bj, ba, NULL, &f->tri_lo);
+      if (!rc) rc = mi355x_trisolve_plan_create(dc->h, n, f->nlevU, levU, rpU, rlU, bj, ba, dinv, &f->tri_up);
+      free(rpU); free(rlU); free(rlL); free(dinv);
+      if (rc) {   /* e.g. a factor too large for 32-bit sliced-ELL offsets: the level kernels serve */
+        if (f->tri_lo) mi355x_trisolve_plan_destroy(f->tri_lo);
+        if (f->tri_up) mi355x_trisolve_plan_destroy(f->tri_up);
+        f->tri_lo = f->tri_up = NULL;
+      }
+    }
+  }
+  free(lev); free(levU);
   CHKHIP(mi355x_malloc((void **)&f->d_bi, sizeof(PetscInt) * (size_t)(n + 1)));
   CHKHIP(mi355x_malloc((void **)&f->d_bj, sizeof(PetscInt) * (size_t)(f->nz + 1)));
   CHKHIP(mi355x_malloc((void **)&f->d_bdiag, sizeof(PetscInt) * (size_t)(n + 1)));
@@ -166,6 +198,19 @@ static PetscErrorCode PCApply_ILU(PC pc, Vec x, Vec y) {   /* PCApply_ILU -> Mat
   /* The level launches are a launch-bound inner loop (766 + 766 kernels for P7(256)): with more than a handful of
    * levels they are captured once into a hipGraph that works in place on a fixed buffer and replayed per
    * application (copy in, one graph launch, copy out).  Same kernels, same order, same bits. */
+  if (f->tri_lo) {
+    int rc = mi355x_trisolve_apply(dc->h, f->tri_lo, f->tri_up, db, dx);
+    if (rc == 719) {   /* hipErrorLaunchFailure: an earlier application gave up on a dependency (its result was unusable) */
+      mi355x_trisolve_plan_destroy(f->tri_lo); mi355x_trisolve_plan_destroy(f->tri_up);
+      f->tri_lo = f->tri_up = NULL;
+      SETERRQ(pc->comm, PETSC_ERR_LIB, "sync-free triangular solve timed out in an earlier application; the level-scheduled solves are used from now on");
+    }
+    CHKHIP(rc);
+    ierr = VecHIPRestoreWrite(y);CHKERRQ(ierr);
+    PetscObjectStateIncrease(y);
+    ierr = PetscLogFlops(2.0 * f->nz - f->n);CHKERRQ(ierr);
+    return 0;
+  }
   if (!f->graph_tried && f->nlevL + f->nlevU > 16) {
     f->graph_tried = 1;
     if (!mi355x_malloc((void **)&f->d_work, sizeof(PetscScalar) * (size_t)PetscMax(f->n, 1)) && !mi355x_graph_capture_begin(dc->h)) {
@@ -208,6 +253,22 @@ PetscErrorCode PCCreate_ILU(PC pc) {
   f->factored_state = -1;
   pc->data = f;
   pc->ops->setup = PCSetUp_ILU; pc->ops->apply = PCApply_ILU; pc->ops->destroy = PCDestroy_ILU;
+  return 0;
+}
+
+/* 1 when PCApply runs the sync-free solves (two launches), 0 for the level-scheduled kernels; *aborted: a dependency wait gave up */
+PetscErrorCode PCILUGetSolver_HIPMI355X(PC pc, PetscInt *syncfree, PetscInt *aborted) {
+  if (strcmp(pc->type_name, "ilu")) SETERRQ(pc->comm, PETSC_ERR_ARG_WRONG, "not a PCILU");
+  PC_ILU *f = (PC_ILU *)pc->data;
+  int a = 0, b = 0;
+  if (syncfree) *syncfree = f->tri_lo ? 1 : 0;
+  if (f->tri_lo) {
+    PetscDeviceCtx *dc;
+    PetscErrorCode ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
+    CHKHIP(mi355x_handle_synchronize(dc->h));      /* the flag of everything queued so far */
+    mi355x_trisolve_aborted(f->tri_lo, &a); mi355x_trisolve_aborted(f->tri_up, &b);
+  }
+  if (aborted) *aborted = a || b;
   return 0;
 }
 

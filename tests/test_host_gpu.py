@@ -667,23 +667,34 @@ def test_ilu0_apply_bitexact_and_golden(P):
     MatSolve_SeqAIJ_NaturalOrdering bit for bit (one lane per row, products subtracted in column order), and with NO
     -pc_type option a one-rank solve picks ILU like the reference: ex2 -m 5 -n 5 refine_always == ex2_1.out."""
     L = P.lib()
-    # the third case has 31 + 31 levels: above 16 the level launches run as a captured hipGraph (same bits)
-    for ai, aj, aa in (pb.lap2d(9, 7), P.gen_poisson7(7, 6, 5), P.gen_poisson7(12, 11, 10)):
-        n = ai.size - 1
-        aa = aa * (1.0 + 0.05 * np.sin(np.arange(aa.size)))
-        A = P.Mat.from_csr(ai, aj, aa)
-        pc = C.c_void_p()
-        k = P.KSP(comm=L.COMM_SELF); k.set_operators(A); L.KSPGetPC(k.h, C.byref(pc)); L.PCSetType(pc, b"ilu")
-        bvec = rnd(n, 77)
-        vb, vx = V(P, bvec), V(P, np.zeros(n))
-        L.raw("PCSetUp")(pc); L.raw("PCApply")(pc, vb.h, vx.h)
-        ref = orc.ilu0_solve(orc.ilu0_factor(ai, aj, aa), bvec)
-        assert np.array_equal(bits(vx.array()), bits(ref))
-        L.raw("PCApply")(pc, vb.h, vx.h)            # replay
-        assert np.array_equal(bits(vx.array()), bits(ref))
-        nl, nu = C.c_int(), C.c_int()
-        L.PCILUGetLevels_HIPMI355X(pc, C.byref(nl), C.byref(nu))
-        assert nl.value == nu.value and nl.value > 1
+    # the third case has 31 + 31 levels: above 16 the solves run sync-free (two launches), or -- with
+    # -pc_factor_hipmi355x_trisolve level -- as one launch per level replayed from a captured hipGraph: same bits
+    for mode in ("", "-pc_factor_hipmi355x_trisolve level", "-pc_factor_hipmi355x_trisolve syncfree"):
+        for ai, aj, aa in (pb.lap2d(9, 7), P.gen_poisson7(7, 6, 5), P.gen_poisson7(12, 11, 10)):
+            n = ai.size - 1
+            aa = aa * (1.0 + 0.05 * np.sin(np.arange(aa.size)))
+            A = P.Mat.from_csr(ai, aj, aa)
+            pc = C.c_void_p()
+            k = P.KSP(comm=L.COMM_SELF); k.set_operators(A); L.KSPGetPC(k.h, C.byref(pc)); L.PCSetType(pc, b"ilu")
+            bvec = rnd(n, 77)
+            vb, vx = V(P, bvec), V(P, np.zeros(n))
+            set_options(L, mode)
+            L.raw("PCSetUp")(pc)
+            set_options(L, "")
+            L.raw("PCApply")(pc, vb.h, vx.h)
+            ref = orc.ilu0_solve(orc.ilu0_factor(ai, aj, aa), bvec)
+            assert np.array_equal(bits(vx.array()), bits(ref))
+            for rep in range(3):                        # replays: the sentinel of the hand-off buffers is restored every time
+                b2 = rnd(n, 78 + rep); vb.set_array(b2)
+                L.raw("PCApply")(pc, vb.h, vx.h)
+                assert np.array_equal(bits(vx.array()), bits(orc.ilu0_solve(orc.ilu0_factor(ai, aj, aa), b2)))
+            nl, nu = C.c_int(), C.c_int()
+            L.PCILUGetLevels_HIPMI355X(pc, C.byref(nl), C.byref(nu))
+            assert nl.value == nu.value and nl.value > 1
+            sf, ab = C.c_int(), C.c_int()
+            L.PCILUGetSolver_HIPMI355X(pc, C.byref(sf), C.byref(ab))
+            assert ab.value == 0
+            assert sf.value == (1 if (mode.endswith("syncfree") or (mode == "" and nl.value + nu.value > 16)) else 0)
     ai, aj, aa = pb.lap2d(5, 5)
     u = np.ones(25)
     b = orc.spmv(ai, aj, aa, u)
@@ -698,6 +709,44 @@ def test_ilu0_apply_bitexact_and_golden(P):
     L.PetscOptionsClear()
     pb.check_monitor(k.history(), gold)
     assert k.its == 4 and "%.5g" % np.linalg.norm(vx.array() - u) in ("0.0003927", "0.00039270")
+
+
+@pytest.mark.parametrize("shape", ["fem3", "irr", "deep", "p7"])
+def test_ilu0_syncfree_solves_on_irregular_factors(P, shape):
+    """the sync-free triangular solves on factors whose levels are ragged: slices that span many levels (in-wavefront
+    sub-steps), rows of very different lengths in one slice, hundreds of dependencies per row, more levels than slices;
+    bit-exact against MatSolve_SeqAIJ_NaturalOrdering's restatement, applied several times"""
+    L = P.lib()
+    if shape == "fem3":
+        ai, aj, aa = pb.gen_fem3(10, 10, 6)
+    elif shape == "irr":
+        ai, aj, aa = pb.gen_irr(n=6000, mean=40.0, seed=4)
+    elif shape == "deep":      # tridiagonal + a few long-range entries: n levels of one row each
+        n = 3000
+        import scipy.sparse as sp
+        S = sp.diags([-np.ones(n - 1), 4.0 * np.ones(n), -np.ones(n - 1)], [-1, 0, 1]).tolil()
+        for r in range(50, n, 97):
+            S[r, r - 50] = -0.5; S[r - 50, r] = -0.25
+        ai, aj, aa = pb.csr(S)
+    else:
+        ai, aj, aa = P.gen_poisson7(40, 33, 21)
+    n = ai.size - 1
+    A = P.Mat.from_csr(ai, aj, aa)
+    pc = C.c_void_p()
+    k = P.KSP(comm=L.COMM_SELF); k.set_operators(A); L.KSPGetPC(k.h, C.byref(pc)); L.PCSetType(pc, b"ilu")
+    set_options(L, "-pc_factor_hipmi355x_trisolve syncfree")
+    L.raw("PCSetUp")(pc)
+    set_options(L, "")
+    f = orc.ilu0_factor(ai, aj, aa)
+    vb, vx = V(P, np.zeros(n)), V(P, np.zeros(n))
+    for rep in range(3):
+        b = rnd(n, 90 + rep)
+        vb.set_array(b)
+        L.raw("PCApply")(pc, vb.h, vx.h)
+        assert np.array_equal(bits(vx.array()), bits(orc.ilu0_solve(f, b)))
+    sf, ab = C.c_int(), C.c_int()
+    L.PCILUGetSolver_HIPMI355X(pc, C.byref(sf), C.byref(ab))
+    assert sf.value == 1 and ab.value == 0
 
 
 def test_ksp_bjacobi_single_block_golden(P):
