@@ -219,6 +219,12 @@ int mi355x_spmv_bsr(mi355x_handle_t h, int mbs, int bs, const int *ai, const int
 int mi355x_spmv_bsr_planned(mi355x_handle_t h, mi355x_spmv_plan_t plan, int bs, const int *ai, const int *aj,
                             const double *aa, const double *x, double *y);
 
+/* bs = 4 on the matrix cores (v_mfma_f64_4x4x4_4b_f64 as a fused multiply + 4-lane reduction; BASELINE configs[4]); one
+ * wavefront per block row, no analysis.  variant 0: 16-byte loads (8 blocks per step), 1: 8-byte loads (4 per step).
+ * FMA arithmetic and a tree over the four block columns: agrees with MatMult_SeqBAIJ_4 (baij2.c:387) to rounding. */
+int mi355x_spmv_bsr4_mfma(mi355x_handle_t h, int mbs, int variant, const int *ai, const int *aj, const double *aa,
+                          const double *x, double *y);
+
 /* ---- ILU(0) triangular solves ---------------------------- */
 /* MatSolve_SeqAIJ_NaturalOrdering  src/mat/impls/aij/seq/aijfact.c:3126-3172 on the factor layout of :1628-1700,
  * one launch per dependency level; `rows` lists the rows of the level (device array).  Lower: x[i] = b[i] - L(i,:)x

@@ -231,6 +231,7 @@ typedef struct {
   int uploaded_state;        /* Mat state at last upload (compare state instead of valid_GPU_matrix) */
   /* compressed-row form for mostly-empty blocks (src/mat/utils/compressedrow.c:28) */
   PetscBool cprow;            /* compressed-row form requested (off-diagonal block) */
+  PetscBool baij4_mfma;       /* BAIJ bs = 4: MatMult on the matrix cores (mi355x_spmv_bsr4_mfma) */
   PetscInt pattern_nz;        /* nz of the pattern the mirror was built for (-1: none) */
   /* cached explicit transpose for MatMultTranspose */
   PetscInt *t_i, *t_j; PetscScalar *t_a; mi355x_spmv_plan_t t_plan; int t_state;

@@ -220,21 +220,75 @@ def test_mat_p7_and_transpose_bitexact(P):
     fl = C.c_double(); L.PetscGetFlops(C.byref(fl)); assert fl.value > 0
 
 
-def test_baij_matmult(P):
+@pytest.mark.parametrize("bs,opt", [(3, ""), (4, ""), (4, "-mat_hipmi355x_baij4 fma"), (2, ""), (5, "")])
+def test_baij_matmult(P, bs, opt):
+    """MatMult_SeqBAIJ_N / _3 / _4 (baij2.c:331-436,981): bs = 4 runs on the matrix cores by default
+    (-mat_hipmi355x_baij4 fma selects the row-block FMA kernel); BASELINE.md tolerance against the oracle's restatement"""
     L = P.lib()
     rng = np.random.default_rng(4)
-    mbs, bs = 300, 3
+    mbs = 300
     import scipy.sparse as sp
     S = sp.random(mbs, mbs, density=0.05, random_state=5, format="csr") + sp.eye(mbs, format="csr")
     S = sp.csr_matrix(S); S.sort_indices()
     bi, bj = S.indptr.astype(np.int32), S.indices.astype(np.int32)
     ba = rng.standard_normal(bj.size * bs * bs)
+    set_options(L, opt)
     A = P.Mat.from_bsr(bs, bi, bj, ba)
     x = rnd(mbs * bs, 6)
     vx, vy = V(P, x), V(P, np.zeros(mbs * bs))
     L.MatMult(A.h, vx.h, vy.h)
+    set_options(L, "")
     ref = orc.spmv_bsr(bs, bi, bj, ba, x)
     assert np.allclose(vy.array(), ref, rtol=0, atol=1e-12 * 50)
+
+
+def test_config5_full_size_baij_equals_aij(P):
+    """BASELINE configs[4] at full size: the 27-point, 3-dof elasticity shape on 128^3 nodes (6.3 M rows, 5.6e7 blocks)
+    stored as BAIJ bs = 3, as BAIJ zero-padded to bs = 4 (matrix-core kernel and FMA kernel) and as point-wise AIJ (5.1e8
+    nonzeros: the reference's inode matrix).  The reference's own check for BAIJ (src/mat/examples/tests/ex48.c: the
+    BAIJ product equals the AIJ product of the same matrix) at BASELINE.md's tolerance, plus sampled rows against a
+    host dot product."""
+    L = P.lib()
+    nn, bs = 128, 3
+    import sys as _sys
+    _sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+    from bench_configs import gen_baij27
+    bi, bj, ba3 = gen_baij27(nn, bs=3)
+    mbs, nnzb = bi.size - 1, bj.size
+    blocks_cr = ba3.reshape(nnzb, 3, 3)                      # [blk][col][row]
+    x3 = np.sin(0.1 * np.arange(mbs * 3))
+    vx3, vy3 = V(P, x3), V(P, np.zeros(mbs * 3))
+    A3 = P.Mat.from_bsr(3, bi, bj, ba3)
+    A3.mult(vx3, vy3)
+    y3 = vy3.array()
+    # sampled block rows against the host
+    absrow = None
+    for br in np.random.default_rng(8).integers(0, mbs, 300):
+        blk = slice(bi[br], bi[br + 1])
+        t = blocks_cr[blk] * x3.reshape(mbs, 3)[bj[blk]][:, :, None]     # [blk][col][row] products
+        assert np.all(np.abs(y3[3 * br:3 * br + 3] - t.sum(axis=(0, 1))) <= 1e-12 * np.abs(t).sum(axis=(0, 1)))
+    # padded to 4x4: both bs = 4 kernels
+    b4 = np.zeros((nnzb, 4, 4)); b4[:, :3, :3] = blocks_cr
+    x4 = np.zeros((mbs, 4)); x4[:, :3] = x3.reshape(mbs, 3)
+    scale = np.abs(y3).max()
+    for opt in ("", "-mat_hipmi355x_baij4 fma"):
+        set_options(L, opt)
+        A4 = P.Mat.from_bsr(4, bi, bj, b4.ravel())
+        vx4, vy4 = V(P, x4.ravel()), V(P, np.zeros(mbs * 4))
+        A4.mult(vx4, vy4)
+        set_options(L, "")
+        y4 = vy4.array().reshape(mbs, 4)
+        assert np.all(y4[:, 3] == 0.0)
+        assert np.max(np.abs(y4[:, :3].ravel() - y3)) <= 1e-12 * 81 * scale
+        del A4, vx4, vy4
+    del b4
+    # the same operator point-wise (AIJ): 81 nonzeros per row, 135 distinct offsets, rows of a node share their pattern
+    ai, aj, aa = pb.expand_blocks(bi, bj, np.ascontiguousarray(blocks_cr.transpose(0, 2, 1)))
+    A = P.Mat.from_csr(ai, aj, aa)
+    A.mult(vx3, vy3)
+    nodes = C.c_int(); L.MatHIPMI355XGetInodeInfo(A.h, C.byref(nodes), None, None)
+    assert nodes.value == mbs
+    assert np.max(np.abs(vy3.array() - y3)) <= 1e-12 * 81 * scale
 
 
 def test_elasticity_aij_vs_inode_and_baij(P):

@@ -491,6 +491,44 @@ def test_spmv_bsr(dev, bs):
         assert np.allclose(dev.get(dy, mbs * bs), ref, rtol=0, atol=1e-12 * 30 * bs * 10)
 
 
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("shape", ["ragged", "stencil", "wide"])
+def test_spmv_bsr4_mfma(dev, variant, shape):
+    """bs = 4 on the matrix cores (v_mfma_f64_4x4x4_4b_f64 as multiply + 4-lane reduction): exact on small-integer data
+    (every lane map right: any swapped row, column or block shows up as an integer difference), BASELINE.md tolerance
+    on random data; block rows of 0 .. 70 blocks incl. counts that are not multiples of the 4 / 8 blocks per step"""
+    bs = 4
+    if shape == "ragged":
+        mbs, nbs = 700, 900
+        ai, aj, _ = random_csr(mbs, nbs, lambda rng, m: rng.integers(0, 40, m), 301)
+    elif shape == "stencil":
+        import problems as pb
+        (_, _, _), (ai, aj, _) = pb.elasticity_like(7, 6, 5, dof=1)
+        mbs = nbs = ai.size - 1
+    else:
+        mbs, nbs = 64, 400
+        ai, aj, _ = random_csr(mbs, nbs, lambda rng, m: np.where(np.arange(m) % 5 == 0, 70, rng.integers(1, 9, m)), 302)
+    rng = np.random.default_rng(303)
+    dx_host = rng.integers(-3, 4, nbs * bs).astype(np.float64)
+    for exact in (True, False):
+        aa = rng.integers(-4, 5, aj.size * 16).astype(np.float64) if exact else rnd(aj.size * 16, 304)
+        x = dx_host if exact else rnd(nbs * bs, 305)
+        dai, daj, daa = upload_csr(dev, ai, aj, aa)
+        dx = dev.put(x); dy = dev.put(np.full(mbs * bs, 7.0))
+        dev.chk(dev.k.mi355x_spmv_bsr4_mfma(dev.h, mbs, variant, dai, daj, daa, dx, dy))
+        got = dev.get(dy, mbs * bs)
+        ref = orc.spmv_bsr(bs, ai, aj, aa, x)
+        if exact:
+            assert np.array_equal(got, ref)
+        else:
+            blk_row = np.repeat(np.arange(mbs), np.diff(ai))
+            absx = np.abs(aa.reshape(-1, 4, 4)) * np.abs(x.reshape(-1, 4)[aj])[:, :, None]      # [blk][col][row]
+            scale = np.zeros((mbs, 4)); np.add.at(scale, blk_row, absx.sum(axis=1))
+            assert np.all(np.abs(got - ref) <= 1e-12 * np.maximum(scale.ravel(), 1e-300))
+        for q in (dai, daj, daa, dx, dy):
+            dev.free(q)
+
+
 def test_spmv_bsr_wide_block_row(dev):
     """a block row wider than the LDS stage (> 2046 values) takes the whole-workgroup path"""
     bs, mbs, nbs = 3, 40, 600
