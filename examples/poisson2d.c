@@ -11,6 +11,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include "petschipmi355x.h"
+#include "petscmini_mpinames.h"   /* MPI_Comm spelling on the harness */
 
 #define CHK(call) do { PetscErrorCode e_ = (call); if (e_) { fprintf(stderr, "error %d: %s\n", (int)e_, PetscGetLastErrorMessage()); return 1; } } while (0)
 

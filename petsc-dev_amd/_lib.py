@@ -3,7 +3,7 @@ there is no fallback path of any kind."""
 import ctypes as C
 import os
 
-from ._build import kernels_lib_path, host_lib_path
+from ._build import kernels_lib_path, host_lib_path, harness_lib_path
 
 vp = C.c_void_p
 sz = C.c_size_t
@@ -141,11 +141,26 @@ def load_kernels():
     return _kernels
 
 
+_harness = None
+
+
+def load_harness():
+    """dlopen harness/libpetscharness.so (the stand-in PETSc; RTLD_GLOBAL so the plugin resolves against it)."""
+    global _harness
+    if _harness is None:
+        path = harness_lib_path()
+        if not os.path.exists(path):
+            raise RuntimeError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'`" % path)
+        _harness = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    return _harness
+
+
 def load_host():
-    """dlopen host/libpetschipmi355x.so; signatures are declared by petsc-dev_amd/petsc.py."""
+    """dlopen host/libpetschipmi355x.so (the plugin); signatures are declared by petsc-dev_amd/petsc.py."""
     global _host
     if _host is None:
         load_kernels()
+        load_harness()
         path = host_lib_path()
         if not os.path.exists(path):
             raise RuntimeError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'`" % path)

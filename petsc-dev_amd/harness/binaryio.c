@@ -10,7 +10,7 @@
 #define MAT_FILE_CLASSID 1211216
 #define VEC_FILE_CLASSID 1211214
 
-struct _p_PetscViewer { MPI_Comm comm; FILE *f; int mode; };
+struct _p_PetscViewer { PetscComm comm; FILE *f; int mode; };
 
 static uint32_t bswap32(uint32_t v) { return (v >> 24) | ((v >> 8) & 0xff00u) | ((v << 8) & 0xff0000u) | (v << 24); }
 static uint64_t bswap64(uint64_t v) { return ((uint64_t)bswap32((uint32_t)v) << 32) | bswap32((uint32_t)(v >> 32)); }
@@ -35,7 +35,7 @@ static PetscErrorCode write_scalars(FILE *f, const PetscScalar *p, size_t n) {
   return 0;
 }
 
-PetscErrorCode PetscViewerBinaryOpen(MPI_Comm comm, const char name[], PetscFileMode mode, PetscViewer *viewer) {
+PetscErrorCode PetscViewerBinaryOpen(PetscComm comm, const char name[], PetscFileMode mode, PetscViewer *viewer) {
   PetscViewer v;
   PetscErrorCode ierr = PetscMalloc(sizeof(*v), &v);CHKERRQ(ierr);
   v->comm = comm; v->mode = (int)mode;
@@ -49,8 +49,8 @@ PetscErrorCode PetscViewerDestroy(PetscViewer *viewer) {
   return 0;
 }
 
-extern PetscErrorCode MatSeqAIJSetCSR_Private(Mat, PetscInt, const PetscInt *, const PetscInt *, const PetscScalar *);
-extern PetscErrorCode MatMPIAIJSetCSR_Private(Mat, PetscInt, const PetscInt *, const PetscInt *, const PetscScalar *);
+extern PetscErrorCode MatSeqAIJSetPreallocationCSR(Mat, const PetscInt[], const PetscInt[], const PetscScalar[]);
+extern PetscErrorCode MatMPIAIJSetPreallocationCSR(Mat, const PetscInt[], const PetscInt[], const PetscScalar[]);
 
 /* the validated part of MatLoad: everything that can fail after the first allocation, so that the caller frees once */
 static PetscErrorCode matload_body(Mat A, PetscViewer viewer, long base, const PetscInt header[4], PetscInt *rowlens,
@@ -69,7 +69,7 @@ static PetscErrorCode matload_body(Mat A, PetscViewer viewer, long base, const P
   }
   if (!A->type_name[0]) {
     if (A->m_req == -1 && A->M_req == -1) { ierr = MatSetSizes(A, PETSC_DECIDE, PETSC_DECIDE, M, N);CHKERRQ(ierr); }   /* applies a type chosen earlier */
-    if (!A->type_name[0]) { ierr = MatSetType(A, MATAIJHIPMI355X);CHKERRQ(ierr); }
+    if (!A->type_name[0]) { ierr = MatSetType(A, MATAIJ);CHKERRQ(ierr); }
   }
   if (A->rmap->N != M || A->cmap->N != N) SETERRQ(A->comm, 79, "Matrix in file of different length (%d,%d) than the input matrix (%d,%d)", M, N, A->rmap->N, A->cmap->N);
   PetscInt rs = A->rmap->rstart, re = A->rmap->rend, m = re - rs;
@@ -93,9 +93,14 @@ static PetscErrorCode matload_body(Mat A, PetscViewer viewer, long base, const P
   if (fseek(viewer->f, vals0 + 8L * before, SEEK_SET)) SETERRQ(A->comm, 66, "Cannot seek to the values");
   ierr = read_scalars(viewer->f, la, (size_t)mine);CHKERRQ(ierr);
   if (fseek(viewer->f, vals0 + 8L * nz, SEEK_SET)) SETERRQ(A->comm, 66, "Cannot seek past the matrix");   /* leave the file positioned after the matrix */
-  if (!strcmp(A->type_name, MATSEQAIJHIPMI355X)) { ierr = MatSeqAIJSetCSR_Private(A, m, li, lj, la);CHKERRQ(ierr); }
-  else if (!strcmp(A->type_name, MATMPIAIJHIPMI355X)) { ierr = MatMPIAIJSetCSR_Private(A, m, li, lj, la);CHKERRQ(ierr); }
-  else SETERRQ(A->comm, PETSC_ERR_SUP, "MatLoad for type %s", A->type_name);
+  {   /* MatLoad_SeqAIJ / MatLoad_MPIAIJ hand the rows to the type (aij.c:4140, mpiaij.c:3560): whichever CSR setter it composed */
+    PetscVoidFunction fs, fm;
+    ierr = PetscObjectQueryFunction((PetscObject)A, "MatSeqAIJSetPreallocationCSR_C", &fs);CHKERRQ(ierr);
+    ierr = PetscObjectQueryFunction((PetscObject)A, "MatMPIAIJSetPreallocationCSR_C", &fm);CHKERRQ(ierr);
+    if (fs) { ierr = MatSeqAIJSetPreallocationCSR(A, li, lj, la);CHKERRQ(ierr); }
+    else if (fm) { ierr = MatMPIAIJSetPreallocationCSR(A, li, lj, la);CHKERRQ(ierr); }
+    else SETERRQ(A->comm, PETSC_ERR_SUP, "MatLoad for type %s", A->type_name);
+  }
   return 0;
 }
 
@@ -118,9 +123,10 @@ PetscErrorCode MatLoad(Mat A, PetscViewer viewer) {
 PetscErrorCode MatView(Mat A, PetscViewer viewer) {
   PetscErrorCode ierr;
   if (!A || !viewer) SETERRQ(0, PETSC_ERR_ARG_NULL, "Null argument");
-  if (strcmp(A->type_name, MATSEQAIJHIPMI355X)) SETERRQ(A->comm, PETSC_ERR_SUP, "binary MatView is ported for the sequential AIJ type only");
-  PetscInt m; const PetscInt *ai, *aj; const PetscScalar *aa;
-  ierr = MatSeqAIJGetArrays(A, &m, &ai, &aj, &aa);CHKERRQ(ierr);
+  PetscInt m; const PetscInt *ai, *aj; const PetscScalar *aa; PetscVoidFunction f;
+  ierr = PetscObjectQueryFunction((PetscObject)A, "MatSeqAIJGetArrays_C", &f);CHKERRQ(ierr);   /* MatView_SeqAIJ_Binary reads the type's CSR arrays */
+  if (!f) SETERRQ(A->comm, PETSC_ERR_SUP, "binary MatView is ported for the sequential AIJ type only");
+  ierr = ((PetscErrorCode (*)(Mat, PetscInt *, const PetscInt **, const PetscInt **, const PetscScalar **))f)(A, &m, &ai, &aj, &aa);CHKERRQ(ierr);
   PetscInt header[4] = {MAT_FILE_CLASSID, m, A->cmap->N, ai[m]}, *rl;
   ierr = PetscMalloc(sizeof(PetscInt) * (size_t)PetscMax(m, 1), &rl);CHKERRQ(ierr);
   for (PetscInt r = 0; r < m; r++) rl[r] = ai[r + 1] - ai[r];
@@ -140,7 +146,7 @@ PetscErrorCode VecLoad(Vec v, PetscViewer viewer) {   /* src/vec/vec/utils/vecio
   ierr = read_ints(viewer->f, header, 2);CHKERRQ(ierr);
   if (header[0] != VEC_FILE_CLASSID) SETERRQ(v->comm, 79, "Not vector next in file");
   if (!v->map) { ierr = VecSetSizes(v, PETSC_DECIDE, header[1]);CHKERRQ(ierr); }
-  if (!v->type_name[0]) { ierr = VecSetType(v, VECHIPMI355X);CHKERRQ(ierr); }
+  if (!v->type_name[0]) { ierr = VecSetType(v, VECSTANDARD);CHKERRQ(ierr); }
   if (v->map->N != header[1]) SETERRQ(v->comm, 79, "Vector in file different length (%d) then input vector (%d)", header[1], v->map->N);
   PetscScalar *a;
   ierr = VecGetArray(v, &a);CHKERRQ(ierr);

@@ -6,7 +6,7 @@
  * -1 at +-1, +-nx, +-nx*ny truncated at the faces -- the 3-D analogue of the 5-point stencil loop in
  * src/ksp/ksp/examples/tutorials/ex2.c:96-103.  Rows [rstart,rend), global column indices ascending.
  * Pass aj = aa = NULL to count.  Returns nnz through *nnz_out. */
-PetscErrorCode PetscHIPMI355XGenPoisson7(PetscInt nx, PetscInt ny, PetscInt nz, long rstart, long rend, PetscInt *ai, PetscInt *aj, PetscScalar *aa, long *nnz_out) {
+PetscErrorCode PetscMiniGenPoisson7(PetscInt nx, PetscInt ny, PetscInt nz, long rstart, long rend, PetscInt *ai, PetscInt *aj, PetscScalar *aa, long *nnz_out) {
   long nnz = 0;
   const long plane = (long)nx * ny;
   if ((long)nx * ny * nz > 2147483647L) SETERRQ(0, PETSC_ERR_ARG_OUTOFRANGE, "grid %d x %d x %d exceeds 32-bit PetscInt", nx, ny, nz);

@@ -1,4 +1,11 @@
-/* The three Krylov methods of the north star, as host-side drivers over the Vec/Mat function
+/* HARNESS file: a restatement of the reference's cg.c / gmres.c / borthog2.c / bcgs.c / groppcg.c for boxes without PETSc
+ * (the GPU test box).  In a PETSc tree this file is NOT used: the reference's own KSPSolve_CG / _GMRES / _BCGS run over
+ * the plugin's Vec/Mat types unchanged.  It is not part of the product library (libpetschipmi355x.so)
+ * and links against nothing device-specific; what it adds to the reference's sequences -- the fused forms -- it
+ * reaches only through methods a Vec/Mat type may compose ("VecKrylovFusedOps_C", "MatMultTDotBegin_C"), and it falls
+ * back to the op-by-op sequence when they are absent.
+ *
+ * The three Krylov methods of the north star, as host-side drivers over the Vec/Mat function
  * tables.  Operation sequences follow the reference exactly (so iteration counts and residual
  * histories are comparable): KSPSolve_CG src/ksp/ksp/impls/cg/cg.c:92-286, KSPSolve_GMRES /
  * KSPGMRESCycle src/ksp/ksp/impls/gmres/gmres.c:118-409 with classical Gram-Schmidt
@@ -6,6 +13,20 @@
  * Per CG iteration on the device: 1 SpMV, 1 pointwise mult, 2 dots, 1 norm, 2 axpy, 1 aypx; the only
  * host<->device traffic is the three 8-byte reduction results. */
 #include "petscimpl.h"
+
+/* the fused kernels of the vectors' type, or NULL */
+static const VecKrylovFusedOps *fused_ops(Vec x) {
+  PetscVoidFunction f = NULL;
+  if (PetscObjectQueryFunction((PetscObject)x, "VecKrylovFusedOps_C", &f) || !f) return NULL;
+  return ((VecKrylovFusedOpsGetFn)f)();
+}
+static PetscErrorCode mat_mult_tdot_begin(Mat A, Vec x, Vec y, PetscBool *ok) {
+  PetscVoidFunction f = NULL;
+  *ok = PETSC_FALSE;
+  PetscErrorCode ierr = PetscObjectQueryFunction((PetscObject)A, "MatMultTDotBegin_C", &f);CHKERRQ(ierr);
+  if (f) { ierr = ((MatMultTDotBeginFn)f)(A, x, y, ok);CHKERRQ(ierr); }
+  return 0;
+}
 
 /* ================================================================== CG */
 typedef struct { PetscBool singlereduction; PetscInt fused; } KSP_CG;   /* cgimpl.h; fused: 0/1/2, see KSPSolve_CG */
@@ -46,13 +67,14 @@ static PetscErrorCode KSPSolve_CG(KSP ksp) {
    *     levels to rounding (1e-15 relative per step), not bit for bit; measured gain 1-2 % (the separate dot reads p
    *     and the just-written w largely out of the Infinity Cache), so it is an option, not the default;
    *  0: the reference's op-by-op sequence. */
-  const PetscInt flevel = single ? 0 : ((KSP_CG *)ksp->data)->fused;
+  const VecKrylovFusedOps *F = fused_ops(X);
+  const PetscInt flevel = (single || !F) ? 0 : ((KSP_CG *)ksp->data)->fused;
   const PetscBool fused = (PetscBool)(flevel > 0);
   Vec D = NULL;
   PetscBool devscalar = PETSC_FALSE, front_queued = PETSC_FALSE, fusedpc = PETSC_FALSE;   /* fusedpc: PCJACOBI (D) or PCNONE (D == NULL, z = r) */
   if (fused) {
     ierr = PCJacobiGetInverseDiagonal_Private(ksp->pc, &D);CHKERRQ(ierr);
-    if (D || PCIsNone_Private(ksp->pc)) { ierr = VecCGUpdateCheck_HIPMI355X(X, R, Z, P, W, D, &fusedpc);CHKERRQ(ierr); }
+    if (D || PCIsNone_Private(ksp->pc)) { ierr = F->cg_update_check(X, R, Z, P, W, D, &fusedpc);CHKERRQ(ierr); }
     devscalar = (PetscBool)(fusedpc && flevel > 1);
   }
 
@@ -111,10 +133,10 @@ static PetscErrorCode KSPSolve_CG(KSP ksp) {
       else { b = beta / betaold; ierr = VecAYPX(P, b, Z);CHKERRQ(ierr); }   /* p <- z + b*p */
       dpiold = dpi;
       if (!single || !i) {
-        if (devscalar && flevel > 3) { ierr = MatMultTDotBegin_HIPMI355X(Amat, P, W, &dpi_on_device);CHKERRQ(ierr); }   /* both at once */
+        if (devscalar && flevel > 3) { ierr = mat_mult_tdot_begin(Amat, P, W, &dpi_on_device);CHKERRQ(ierr); }   /* both at once */
         if (!dpi_on_device) {
           ierr = KSP_MatMult(ksp, Amat, P, W);CHKERRQ(ierr);       /* w <- Ap */
-          if (devscalar) { ierr = VecTDotBegin_HIPMI355X(P, W, &dpi_on_device);CHKERRQ(ierr); }
+          if (devscalar) { ierr = F->tdot_begin(P, W, &dpi_on_device);CHKERRQ(ierr); }
           if (!dpi_on_device) { ierr = VecTDot(P, W, &dpi);CHKERRQ(ierr); }   /* dpi <- p'w */
         }
       } else {                                                      /* cg.c:200-203: recurrences instead of a product and a dot */
@@ -128,26 +150,26 @@ static PetscErrorCode KSPSolve_CG(KSP ksp) {
     if (dpi_on_device) {
       /* the update kernel applies the tests below to dpi itself and touches nothing if one fires; dpi comes back
        * with the sums, and the host takes the same exits */
-      ierr = VecCGUpdateDevBegin_HIPMI355X(X, R, Z, P, W, D, beta, dpiold, (PetscBool)(i > 0));CHKERRQ(ierr);
+      ierr = F->cg_update_dev_begin(X, R, Z, P, W, D, beta, dpiold, (PetscBool)(i > 0));CHKERRQ(ierr);
       if (flevel > 2 && i + 1 < ksp->max_it && (nt == KSP_NORM_NONE || dp > 10.0 * ksp->ttol)) {
         /* front half of iteration i+1 (beta of this iteration is its betaold) */
         PetscBool ok = PETSC_FALSE;
-        ierr = VecAYPXDev_HIPMI355X(P, beta, Z);CHKERRQ(ierr);
-        if (flevel > 3) { ierr = MatMultTDotBegin_HIPMI355X(Amat, P, W, &ok);CHKERRQ(ierr); }
+        ierr = F->aypx_dev(P, beta, Z);CHKERRQ(ierr);
+        if (flevel > 3) { ierr = mat_mult_tdot_begin(Amat, P, W, &ok);CHKERRQ(ierr); }
         if (!ok) {
           ierr = KSP_MatMult(ksp, Amat, P, W);CHKERRQ(ierr);
-          ierr = VecTDotBegin_HIPMI355X(P, W, &ok);CHKERRQ(ierr);
+          ierr = F->tdot_begin(P, W, &ok);CHKERRQ(ierr);
           if (!ok) SETERRQ(ksp->comm, PETSC_ERR_PLIB, "split dot refused after it had been accepted");
         }
         front_queued = PETSC_TRUE;
       }
-      ierr = VecCGUpdateDevEnd_HIPMI355X(X, &zz, &zr, &rr, &dpi);CHKERRQ(ierr);
+      ierr = F->cg_update_dev_end(X, &zz, &zr, &rr, &dpi);CHKERRQ(ierr);
       have_sums = PETSC_TRUE;
     }
     if (PetscIsInfOrNanScalar(dpi)) SETERRQ(ksp->comm, PETSC_ERR_FP, "Infinite or not-a-number generated in dot product");
     if ((dpi == 0.0) || ((i > 0) && (dpi * dpiold <= 0.0))) { ksp->reason = KSP_DIVERGED_INDEFINITE_MAT; break; }
     a = beta / dpi;
-    if (!have_sums && fusedpc) { ierr = VecCGUpdate_HIPMI355X(X, R, Z, P, W, D, a, &zz, &zr, &rr, &have_sums);CHKERRQ(ierr); }
+    if (!have_sums && fusedpc) { ierr = F->cg_update(X, R, Z, P, W, D, a, &zz, &zr, &rr, &have_sums);CHKERRQ(ierr); }
     if (have_sums) {
       /* z = B r is already there whatever the norm type (the reference applies the PC before or after the test,
        * cg.c:233-268: same z either way), and so is the next beta */
@@ -537,10 +559,11 @@ static PetscErrorCode KSPSolve_BCGS(KSP ksp) {
   Vec D = NULL;
   PetscBool fusedpc = PETSC_FALSE, have_rho = PETSC_FALSE, done;
   char t_[16]; PetscBool set;
+  const VecKrylovFusedOps *F = fused_ops(X);
 
   if (ksp->pc_side == PC_RIGHT) SETERRQ(ksp->comm, PETSC_ERR_SUP, "right-preconditioned BiCGStab is outside the ported path");
   ierr = PetscOptionsGetString(ksp->prefix, "-ksp_bcgs_fused", t_, sizeof(t_), &set);CHKERRQ(ierr);
-  if (!set || (strcmp(t_, "0") && strcmp(t_, "false"))) {
+  if (F && (!set || (strcmp(t_, "0") && strcmp(t_, "false")))) {
     ierr = PCJacobiGetInverseDiagonal_Private(ksp->pc, &D);CHKERRQ(ierr);
     fusedpc = (PetscBool)(D != NULL || PCIsNone_Private(ksp->pc));
   }
@@ -566,7 +589,7 @@ static PetscErrorCode KSPSolve_BCGS(KSP ksp) {
     done = PETSC_FALSE;
     if (fusedpc) {                                               /* v <- K p and (v,rp) */
       ierr = KSP_MatMult(ksp, Amat, P, T);CHKERRQ(ierr);
-      ierr = VecPMultDot_HIPMI355X(V, T, D, RP, &d1, &done);CHKERRQ(ierr);
+      ierr = F->pmult_dot(V, T, D, RP, &d1, &done);CHKERRQ(ierr);
       if (!done) { ierr = KSP_PCApply(ksp, T, V);CHKERRQ(ierr); }
     } else { ierr = KSP_PCApplyBAorAB(ksp, P, V, T);CHKERRQ(ierr); }
     if (!done) { ierr = VecDot(V, RP, &d1);CHKERRQ(ierr); }
@@ -576,7 +599,7 @@ static PetscErrorCode KSPSolve_BCGS(KSP ksp) {
     done = PETSC_FALSE;
     if (fusedpc) {                                               /* t <- K s and (s,t), (t,t) */
       ierr = KSP_MatMult(ksp, Amat, S, R);CHKERRQ(ierr);
-      ierr = VecPMultDotNorm2_HIPMI355X(T, R, D, S, &d1, &d2, &done);CHKERRQ(ierr);
+      ierr = F->pmult_dotnorm2(T, R, D, S, &d1, &d2, &done);CHKERRQ(ierr);
       if (!done) { ierr = KSP_PCApply(ksp, R, T);CHKERRQ(ierr); }
     } else { ierr = KSP_PCApplyBAorAB(ksp, S, T, R);CHKERRQ(ierr); }
     if (!done) { ierr = VecDotNorm2(S, T, &d1, &d2);CHKERRQ(ierr); }
@@ -596,7 +619,7 @@ static PetscErrorCode KSPSolve_BCGS(KSP ksp) {
     done = PETSC_FALSE;
     if (fusedpc) {                                               /* x, r, (r,r) and the next (r,rp) in one sweep */
       PetscScalar rr, rhonext;
-      ierr = VecBCGSUpdate_HIPMI355X(X, R, P, S, T, RP, alpha, omega, &rr, &rhonext, &done);CHKERRQ(ierr);
+      ierr = F->bcgs_update(X, R, P, S, T, RP, alpha, omega, &rr, &rhonext, &done);CHKERRQ(ierr);
       if (done) { dp = nonorm ? 0.0 : PetscSqrtReal(rr); rhoold = rho; rho = rhonext; have_rho = PETSC_TRUE; }
     }
     if (!done) {

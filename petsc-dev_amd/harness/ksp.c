@@ -8,9 +8,10 @@ static const char *ksp_reason_name(KSPConvergedReason r);
 
 #define KSPValid(k) do { if (!(k)) SETERRQ(0, PETSC_ERR_ARG_NULL, "Null KSP"); } while (0)
 
-PetscErrorCode KSPCreate(MPI_Comm comm, KSP *inksp) {   /* itcreate.c:640-700 */
+PetscErrorCode KSPCreate(PetscComm comm, KSP *inksp) {   /* itcreate.c:640-700 */
   PetscErrorCode ierr;
   KSP ksp;
+  ierr = PetscMiniInitialize();CHKERRQ(ierr);
   ierr = PetscMalloc(sizeof(*ksp), &ksp);CHKERRQ(ierr);
   memset(ksp, 0, sizeof(*ksp));
   ksp->comm = comm;
@@ -21,14 +22,22 @@ PetscErrorCode KSPCreate(MPI_Comm comm, KSP *inksp) {   /* itcreate.c:640-700 */
   return 0;
 }
 
-static struct { const char *name; PetscErrorCode (*fn)(KSP); } ksp_types[] = {
-  {KSPCG, KSPCreate_CG}, {KSPGROPPCG, KSPCreate_GROPPCG}, {KSPGMRES, KSPCreate_GMRES}, {KSPBCGS, KSPCreate_BCGS}, {KSPPREONLY, KSPCreate_PREONLY}, {NULL, NULL}};
+#define MAXKSPTYPES 16
+static struct { char name[32]; PetscErrorCode (*fn)(KSP); } ksp_types[MAXKSPTYPES + 1];
+static int n_ksp_types = 0;
+PetscErrorCode KSPRegister(const char *name, PetscErrorCode (*fn)(KSP)) {   /* src/ksp/ksp/interface/itregis.c */
+  for (int i = 0; i < n_ksp_types; i++) if (!strcmp(ksp_types[i].name, name)) { ksp_types[i].fn = fn; return 0; }
+  if (n_ksp_types >= MAXKSPTYPES) SETERRQ(0, PETSC_ERR_PLIB, "KSP type table full");
+  snprintf(ksp_types[n_ksp_types].name, 32, "%s", name);
+  ksp_types[n_ksp_types++].fn = fn;
+  return 0;
+}
 
 PetscErrorCode KSPSetType(KSP ksp, KSPType type) {
   PetscErrorCode ierr;
   KSPValid(ksp);
   if (!strcmp(ksp->type_name, type)) return 0;
-  for (int i = 0; ksp_types[i].name; i++) {
+  for (int i = 0; i < n_ksp_types; i++) {
     if (!strcmp(ksp_types[i].name, type)) {
       if (ksp->ops->destroy) { ierr = (*ksp->ops->destroy)(ksp);CHKERRQ(ierr); }
       if (ksp->work) { ierr = VecDestroyVecs(ksp->nwork, &ksp->work);CHKERRQ(ierr); ksp->nwork = 0; }

@@ -3,6 +3,7 @@
 #include "petscimpl.h"
 
 #define MAXTYPES 16
+typedef PetscErrorCode (*MatCreateFn)(Mat);
 static struct { char name[32]; MatCreateFn fn; } mat_types[MAXTYPES];
 static int n_mat_types = 0;
 
@@ -18,7 +19,7 @@ PetscErrorCode MatRegister(const char *name, MatCreateFn fn) {
 #define MatTypeSet(A, arg) do { MatValid(A, arg); if (!(A)->data) SETERRQ((A)->comm, PETSC_ERR_ARG_TYPENOTSET, "Mat type not set: Parameter # %d", arg); } while (0)
 #define MatAssembled(A) do { if (!(A)->assembled) SETERRQ((A)->comm, PETSC_ERR_ARG_WRONGSTATE, "Not for unassembled matrix"); } while (0)
 
-PetscErrorCode MatCreate(MPI_Comm comm, Mat *A) {
+PetscErrorCode MatCreate(PetscComm comm, Mat *A) {
   Mat B;
   PetscErrorCode ierr = PetscMalloc(sizeof(*B), &B);CHKERRQ(ierr);
   memset(B, 0, sizeof(*B));
@@ -48,6 +49,7 @@ PetscErrorCode MatSetType(Mat A, MatType type) {
     if (!strcmp(mat_types[i].name, type)) {
       if (A->ops->destroy) { ierr = (*A->ops->destroy)(A);CHKERRQ(ierr); }   /* matreg.c:68-71 */
       memset(A->ops, 0, sizeof(A->ops));
+      ierr = PetscObjectListDestroy_Private((PetscObject)A);CHKERRQ(ierr);
       A->data = NULL; A->spptr = NULL;
       if (!A->rmap) {
         if (A->m_req == -1 && A->M_req == -1) {   /* sizes not known yet (e.g. MatSetType, then MatLoad): remember the choice */
@@ -67,10 +69,7 @@ PetscErrorCode MatSetFromOptions(Mat A) {
   char t[64];
   PetscBool set;
   PetscErrorCode ierr = PetscOptionsGetString(NULL, "-mat_type", t, sizeof(t), &set);CHKERRQ(ierr);
-  if (!set) snprintf(t, sizeof(t), "%s", MATAIJHIPMI355X);
-  if (!strcmp(t, "aij")) snprintf(t, sizeof(t), "%s", MATAIJHIPMI355X);
-  else if (!strcmp(t, "seqaij")) snprintf(t, sizeof(t), "%s", MATSEQAIJHIPMI355X);
-  else if (!strcmp(t, "mpiaij")) snprintf(t, sizeof(t), "%s", MATMPIAIJHIPMI355X);
+  if (!set) snprintf(t, sizeof(t), "%s", MATAIJ);   /* matrix.c MatSetFromOptions: the default type is aij */
   return MatSetType(A, t);
 }
 PetscErrorCode MatGetType(Mat A, MatType *type) { MatValid(A, 1); *type = A->type_name; return 0; }
@@ -123,7 +122,7 @@ PetscErrorCode MatDestroy(Mat *A) {
   if ((*A)->ops->destroy) { ierr = (*(*A)->ops->destroy)(*A);CHKERRQ(ierr); }
   ierr = PetscLayoutDestroy(&(*A)->rmap);CHKERRQ(ierr);
   ierr = PetscLayoutDestroy(&(*A)->cmap);CHKERRQ(ierr);
-  if ((*A)->time_ev) { for (PetscInt k = 0; k < 2 * (*A)->time_cap; k++) mi355x_event_destroy((*A)->time_ev[k]); free((*A)->time_ev); }
+  ierr = PetscObjectListDestroy_Private((PetscObject)*A);CHKERRQ(ierr);
   free(*A); *A = NULL;
   return 0;
 }
@@ -216,35 +215,75 @@ PetscErrorCode MatZeroEntries(Mat A) {
   return 0;
 }
 
-/* ---- per-launch device timing used by bench.py (hipEvent pairs on the compute stream) ---- */
-PetscErrorCode MatHIPMI355XSetTiming(Mat A, PetscBool on) {
+/* ---- type-specific methods reached through composed functions, as in the reference (PetscTryMethod / PetscUseMethod,
+ * e.g. MatSeqAIJSetPreallocation aij.c:3435, MatMPIAIJSetPreallocation mpiaij.c:4274, MatGetDiagonalBlock matrix.c) ---- */
+PetscErrorCode MatSeqAIJSetPreallocation(Mat A, PetscInt nz, const PetscInt nnz[]) {
+  PetscVoidFunction f;
   MatValid(A, 1);
-  A->timing = on; A->time_n = 0; A->time_ms = 0.0;
-  if (on && !A->time_ev) {
-    A->time_cap = 4096;
-    PetscErrorCode ierr = PetscMalloc(sizeof(mi355x_event_t) * 2 * (size_t)A->time_cap, &A->time_ev);CHKERRQ(ierr);
-    for (PetscInt k = 0; k < 2 * A->time_cap; k++) CHKHIP(mi355x_event_create(&A->time_ev[k]));
-  }
+  PetscErrorCode ierr = PetscObjectQueryFunction((PetscObject)A, "MatSeqAIJSetPreallocation_C", &f);CHKERRQ(ierr);
+  if (f) { ierr = ((PetscErrorCode (*)(Mat, PetscInt, const PetscInt[]))f)(A, nz, nnz);CHKERRQ(ierr); }
   return 0;
 }
-PetscErrorCode MatTimingBegin(Mat A, mi355x_handle_t h) {
-  if (A->timing && A->time_n < A->time_cap) CHKHIP(mi355x_event_record(A->time_ev[2 * A->time_n], h));
-  return 0;
-}
-PetscErrorCode MatTimingEnd(Mat A, mi355x_handle_t h) {
-  if (A->timing && A->time_n < A->time_cap) { CHKHIP(mi355x_event_record(A->time_ev[2 * A->time_n + 1], h)); A->time_n++; }
-  return 0;
-}
-PetscErrorCode MatHIPMI355XGetTiming(Mat A, PetscInt *nlaunches, PetscLogDouble *total_ms) {
+PetscErrorCode MatMPIAIJSetPreallocation(Mat A, PetscInt d_nz, const PetscInt d_nnz[], PetscInt o_nz, const PetscInt o_nnz[]) {
+  PetscVoidFunction f;
   MatValid(A, 1);
-  double tot = 0.0;
-  for (PetscInt k = 0; k < A->time_n; k++) {
-    float ms = 0.f;
-    CHKHIP(mi355x_event_synchronize(A->time_ev[2 * k + 1]));
-    CHKHIP(mi355x_event_elapsed_ms(A->time_ev[2 * k], A->time_ev[2 * k + 1], &ms));
-    tot += ms;
-  }
-  if (nlaunches) *nlaunches = A->time_n;
-  if (total_ms) *total_ms = tot;
+  PetscErrorCode ierr = PetscObjectQueryFunction((PetscObject)A, "MatMPIAIJSetPreallocation_C", &f);CHKERRQ(ierr);
+  if (f) { ierr = ((PetscErrorCode (*)(Mat, PetscInt, const PetscInt[], PetscInt, const PetscInt[]))f)(A, d_nz, d_nnz, o_nz, o_nnz);CHKERRQ(ierr); }
+  return 0;
+}
+/* MatSeqAIJSetPreallocationCSR / MatMPIAIJSetPreallocationCSR (aij.c:3795, mpiaij.c:3960): copy a CSR description in */
+PetscErrorCode MatSeqAIJSetPreallocationCSR(Mat A, const PetscInt i[], const PetscInt j[], const PetscScalar v[]) {
+  PetscVoidFunction f;
+  MatValid(A, 1);
+  PetscErrorCode ierr = PetscObjectQueryFunction((PetscObject)A, "MatSeqAIJSetPreallocationCSR_C", &f);CHKERRQ(ierr);
+  if (!f) SETERRQ(A->comm, PETSC_ERR_SUP, "Mat type %s cannot be filled from CSR arrays", A->type_name);
+  ierr = ((PetscErrorCode (*)(Mat, const PetscInt[], const PetscInt[], const PetscScalar[]))f)(A, i, j, v);CHKERRQ(ierr);
+  return 0;
+}
+PetscErrorCode MatMPIAIJSetPreallocationCSR(Mat A, const PetscInt i[], const PetscInt j[], const PetscScalar v[]) {
+  PetscVoidFunction f;
+  MatValid(A, 1);
+  PetscErrorCode ierr = PetscObjectQueryFunction((PetscObject)A, "MatMPIAIJSetPreallocationCSR_C", &f);CHKERRQ(ierr);
+  if (!f) SETERRQ(A->comm, PETSC_ERR_SUP, "Mat type %s cannot be filled from CSR arrays", A->type_name);
+  ierr = ((PetscErrorCode (*)(Mat, const PetscInt[], const PetscInt[], const PetscScalar[]))f)(A, i, j, v);CHKERRQ(ierr);
+  return 0;
+}
+PetscErrorCode MatGetDiagonalBlock(Mat A, Mat *a) {   /* matrix.c MatGetDiagonalBlock: "MatGetDiagonalBlock_C", or A itself on one process */
+  PetscVoidFunction f;
+  MatTypeSet(A, 1);
+  PetscErrorCode ierr = PetscObjectQueryFunction((PetscObject)A, "MatGetDiagonalBlock_C", &f);CHKERRQ(ierr);
+  if (f) { ierr = ((PetscErrorCode (*)(Mat, Mat *))f)(A, a);CHKERRQ(ierr); return 0; }
+  if (A->comm->size == 1) { *a = A; return 0; }
+  SETERRQ(A->comm, PETSC_ERR_SUP, "Cannot get diagonal part for this matrix");
+}
+/* MatCreateSeqAIJWithArrays (aij.c:3845), MatCreateMPIAIJWithArrays (mpiaij.c:4046), MatCreateSeqBAIJWithArrays
+ * (baij.c): here the arrays are copied (the sequential reference routines alias them) */
+PetscErrorCode MatCreateSeqAIJWithArrays(PetscComm comm, PetscInt m, PetscInt n, PetscInt i[], PetscInt j[], PetscScalar a[], Mat *mat) {
+  PetscErrorCode ierr;
+  ierr = MatCreate(comm, mat);CHKERRQ(ierr);
+  ierr = MatSetSizes(*mat, m, n, m, n);CHKERRQ(ierr);
+  ierr = MatSetType(*mat, MATSEQAIJ);CHKERRQ(ierr);
+  ierr = MatSeqAIJSetPreallocationCSR(*mat, i, j, a);CHKERRQ(ierr);
+  return 0;
+}
+PetscErrorCode MatCreateMPIAIJWithArrays(PetscComm comm, PetscInt m, PetscInt n, PetscInt M, PetscInt N, const PetscInt i[], const PetscInt j[], const PetscScalar a[], Mat *mat) {
+  PetscErrorCode ierr;
+  if (i[0]) SETERRQ(comm, PETSC_ERR_ARG_OUTOFRANGE, "i (row indices) must start with 0");
+  if (m < 0) SETERRQ(comm, PETSC_ERR_ARG_OUTOFRANGE, "local number of rows (m) cannot be PETSC_DECIDE, or negative");
+  ierr = MatCreate(comm, mat);CHKERRQ(ierr);
+  ierr = MatSetSizes(*mat, m, n, M, N);CHKERRQ(ierr);
+  ierr = MatSetType(*mat, MATMPIAIJ);CHKERRQ(ierr);
+  ierr = MatMPIAIJSetPreallocationCSR(*mat, i, j, a);CHKERRQ(ierr);
+  return 0;
+}
+PetscErrorCode MatCreateSeqBAIJWithArrays(PetscComm comm, PetscInt bs, PetscInt m, PetscInt n, PetscInt i[], PetscInt j[], PetscScalar a[], Mat *mat) {
+  PetscErrorCode ierr; PetscVoidFunction f;
+  if (bs < 1 || m % bs || n % bs) SETERRQ(comm, PETSC_ERR_ARG_SIZ, "block size %d must divide the local sizes %d, %d", bs, m, n);
+  ierr = MatCreate(comm, mat);CHKERRQ(ierr);
+  ierr = MatSetSizes(*mat, m, n, m, n);CHKERRQ(ierr);
+  ierr = MatSetType(*mat, MATSEQBAIJ);CHKERRQ(ierr);
+  ierr = PetscObjectQueryFunction((PetscObject)*mat, "MatSeqBAIJSetPreallocationCSR_C", &f);CHKERRQ(ierr);
+  if (!f) SETERRQ(comm, PETSC_ERR_SUP, "Mat type %s cannot be filled from block CSR arrays", (*mat)->type_name);
+  ierr = ((PetscErrorCode (*)(Mat, PetscInt, const PetscInt[], const PetscInt[], const PetscScalar[]))f)(*mat, bs, i, j, a);CHKERRQ(ierr);
   return 0;
 }

@@ -3,22 +3,51 @@
  * per rank (src/ksp/pc/impls/bjacobi/bjacobi.c:738-761,858-923). */
 #include "petscimpl.h"
 
-PetscErrorCode PCCreate(MPI_Comm comm, PC *newpc) {
+PetscErrorCode PCCreate(PetscComm comm, PC *newpc) {
   PC pc;
-  PetscErrorCode ierr = PetscMalloc(sizeof(*pc), &pc);CHKERRQ(ierr);
+  PetscErrorCode ierr = PetscMiniInitialize();CHKERRQ(ierr);
+  ierr = PetscMalloc(sizeof(*pc), &pc);CHKERRQ(ierr);
   memset(pc, 0, sizeof(*pc));
   pc->comm = comm;
   *newpc = pc;
   return 0;
 }
-static struct { const char *name; PetscErrorCode (*fn)(PC); } pc_types[] = {
-  {PCNONE, PCCreate_None}, {PCJACOBI, PCCreate_Jacobi}, {PCBJACOBI, PCCreate_BJacobi}, {PCILU, PCCreate_ILU}, {NULL, NULL}};
+#define MAXPCTYPES 16
+static struct { char name[32]; PetscErrorCode (*fn)(PC); } pc_types[MAXPCTYPES + 1];
+static int n_pc_types = 0;
+PetscErrorCode PCRegister(const char *name, PetscErrorCode (*fn)(PC)) {   /* src/ksp/pc/interface/pcregis.c */
+  for (int i = 0; i < n_pc_types; i++) if (!strcmp(pc_types[i].name, name)) { pc_types[i].fn = fn; return 0; }
+  if (n_pc_types >= MAXPCTYPES) SETERRQ(0, PETSC_ERR_PLIB, "PC type table full");
+  snprintf(pc_types[n_pc_types].name, 32, "%s", name);
+  pc_types[n_pc_types++].fn = fn;
+  return 0;
+}
+static PetscBool pc_type_registered(const char *name) {
+  for (int i = 0; i < n_pc_types; i++) if (!strcmp(pc_types[i].name, name)) return PETSC_TRUE;
+  return PETSC_FALSE;
+}
+/* the harness's own types: KSPRegisterAll / PCRegisterAll (itregis.c, pcregis.c), for the types restated here */
+PetscErrorCode PetscMiniInitialize(void) {
+  static int done = 0;
+  PetscErrorCode ierr;
+  if (done) return 0;
+  done = 1;
+  ierr = PCRegister(PCNONE, PCCreate_None);CHKERRQ(ierr);
+  ierr = PCRegister(PCJACOBI, PCCreate_Jacobi);CHKERRQ(ierr);
+  ierr = PCRegister(PCBJACOBI, PCCreate_BJacobi);CHKERRQ(ierr);
+  ierr = KSPRegister(KSPCG, KSPCreate_CG);CHKERRQ(ierr);
+  ierr = KSPRegister(KSPGROPPCG, KSPCreate_GROPPCG);CHKERRQ(ierr);
+  ierr = KSPRegister(KSPGMRES, KSPCreate_GMRES);CHKERRQ(ierr);
+  ierr = KSPRegister(KSPBCGS, KSPCreate_BCGS);CHKERRQ(ierr);
+  ierr = KSPRegister(KSPPREONLY, KSPCreate_PREONLY);CHKERRQ(ierr);
+  return 0;
+}
 
 PetscErrorCode PCSetType(PC pc, PCType type) {
   PetscErrorCode ierr;
   if (!pc) SETERRQ(0, PETSC_ERR_ARG_NULL, "Null PC");
   if (!strcmp(pc->type_name, type)) return 0;
-  for (int i = 0; pc_types[i].name; i++) {
+  for (int i = 0; i < n_pc_types; i++) {
     if (!strcmp(pc_types[i].name, type)) {
       if (pc->ops->destroy) { ierr = (*pc->ops->destroy)(pc);CHKERRQ(ierr); }
       memset(pc->ops, 0, sizeof(pc->ops));
@@ -28,7 +57,7 @@ PetscErrorCode PCSetType(PC pc, PCType type) {
       return 0;
     }
   }
-  SETERRQ(pc->comm, PETSC_ERR_ARG_UNKNOWN_TYPE, "Unable to find requested PC type %s (ported: none, jacobi, bjacobi, ilu)", type);
+  SETERRQ(pc->comm, PETSC_ERR_ARG_UNKNOWN_TYPE, "Unable to find requested PC type %s", type);
 }
 PetscErrorCode PCGetType(PC pc, PCType *type) { *type = pc->type_name; return 0; }
 PetscErrorCode PCSetOperators(PC pc, Mat Amat, Mat Pmat, MatStructure flag) {
@@ -51,10 +80,10 @@ PetscErrorCode PCSetUp(PC pc) {   /* precon.c:~800 */
   if (pc->setupcalled > 1) return 0;
   if (!pc->mat) SETERRQ(pc->comm, PETSC_ERR_ARG_WRONGSTATE, "Matrix must be set first");
   if (!pc->type_name[0]) {
-    /* PCGetDefaultType_Private (precon.c:14-53): ILU on one process (when the matrix can be factored, i.e.
-     * sequential AIJ here), block Jacobi on several */
+    /* PCGetDefaultType_Private (precon.c:14-53): ILU on one process when the matrix can be factored (here: an ILU
+     * has been registered and the matrix is a sequential AIJ type), block Jacobi on several */
     if (pc->comm->size > 1) { ierr = PCSetType(pc, PCBJACOBI);CHKERRQ(ierr); }
-    else { ierr = PCSetType(pc, !strcmp(pc->pmat->type_name, MATSEQAIJHIPMI355X) ? PCILU : PCJACOBI);CHKERRQ(ierr); }
+    else { ierr = PCSetType(pc, (pc_type_registered(PCILU) && !strncmp(pc->pmat->type_name, MATSEQAIJ, 6)) ? PCILU : PCJACOBI);CHKERRQ(ierr); }
   }
   if (pc->ops->setup) { ierr = (*pc->ops->setup)(pc);CHKERRQ(ierr); }
   pc->setupcalled = 2;
@@ -74,6 +103,7 @@ PetscErrorCode PCDestroy(PC *ppc) {
   PC pc = *ppc;
   if (!pc) return 0;
   if (pc->ops->destroy) { ierr = (*pc->ops->destroy)(pc);CHKERRQ(ierr); }
+  ierr = PetscObjectListDestroy_Private((PetscObject)pc);CHKERRQ(ierr);
   free(pc); *ppc = NULL;
   return 0;
 }
@@ -85,20 +115,25 @@ PetscErrorCode PCCreate_None(PC pc) { pc->ops->apply = PCApply_None; return 0; }
 /* ---------------------------------------------------------------- PCJACOBI */
 typedef struct { Vec diag; } PC_Jacobi;
 
-/* PCSetUp_Jacobi, jacobi.c:125-198: MatGetDiagonal -> VecReciprocal -> zeros replaced by 1.  The
- * reference does the last step in a host loop over VecGetArray (forcing a D2H/H2D round trip for a
- * GPU vector); d = (d == 0) ? 1 : 1/d is one device kernel here (same values: VecReciprocal leaves
- * zeros as zeros, the loop then sets them to 1). */
+/* PCSetUp_Jacobi, jacobi.c:125-198: MatGetDiagonal -> VecReciprocal -> zeros replaced by 1 in a host loop over
+ * VecGetArray (jacobi.c:182-190).  A vector type may offer the last two steps as one method of its own,
+ * "VecJacobiInvert_C" (d = (d == 0) ? 1 : 1/d, same values), which spares an accelerator type the host round trip. */
 static PetscErrorCode PCSetUp_Jacobi(PC pc) {
   PetscErrorCode ierr;
   PC_Jacobi *jac = (PC_Jacobi *)pc->data;
-  PetscScalar *d; PetscDeviceCtx *dc;
+  PetscVoidFunction f;
   if (!jac->diag) { ierr = MatGetVecs(pc->pmat, &jac->diag, NULL);CHKERRQ(ierr); }
   ierr = MatGetDiagonal(pc->pmat, jac->diag);CHKERRQ(ierr);
-  ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
-  ierr = VecHIPMI355XGetArray(jac->diag, &d);CHKERRQ(ierr);
-  CHKHIP(mi355x_vec_jacobi_invert(dc->h, (size_t)jac->diag->map->n, d, NULL));
-  ierr = VecHIPMI355XRestoreArray(jac->diag, &d);CHKERRQ(ierr);
+  ierr = PetscObjectQueryFunction((PetscObject)jac->diag, "VecJacobiInvert_C", &f);CHKERRQ(ierr);
+  if (f) { ierr = ((PetscErrorCode (*)(Vec))f)(jac->diag);CHKERRQ(ierr); PetscObjectStateIncrease(jac->diag); }
+  else {
+    PetscScalar *x; PetscInt n;
+    ierr = VecReciprocal(jac->diag);CHKERRQ(ierr);
+    ierr = VecGetLocalSize(jac->diag, &n);CHKERRQ(ierr);
+    ierr = VecGetArray(jac->diag, &x);CHKERRQ(ierr);
+    for (PetscInt i = 0; i < n; i++) if (x[i] == 0.0) x[i] = 1.0;
+    ierr = VecRestoreArray(jac->diag, &x);CHKERRQ(ierr);
+  }
   return 0;
 }
 static PetscErrorCode PCApply_Jacobi(PC pc, Vec x, Vec y) {   /* jacobi.c:266-277 */
@@ -136,8 +171,6 @@ typedef struct {
   Mat block;
 } PC_BJacobi;
 
-extern PetscErrorCode MatMPIAIJGetSeqAIJ(Mat, Mat *, Mat *, const PetscInt **);
-
 static PetscErrorCode PCSetUp_BJacobi(PC pc) {   /* PCSetUp_BJacobi_Singleblock, bjacobi.c:858-923 */
   PetscErrorCode ierr;
   PC_BJacobi *bj = (PC_BJacobi *)pc->data;
@@ -145,8 +178,7 @@ static PetscErrorCode PCSetUp_BJacobi(PC pc) {   /* PCSetUp_BJacobi_Singleblock,
   snprintf(prefix, sizeof(prefix), "%s", pc->prefix);
   ierr = PetscOptionsGetInt(prefix, "-pc_bjacobi_blocks", &nb, &set);CHKERRQ(ierr);
   if (set && nb != pc->comm->size) SETERRQ(pc->comm, PETSC_ERR_SUP, "%d blocks on %d processes: only one block per process (PCSetUp_BJacobi_Singleblock) is on the ported path", nb, pc->comm->size);
-  if (!strcmp(pc->pmat->type_name, MATMPIAIJHIPMI355X)) { ierr = MatMPIAIJGetSeqAIJ(pc->pmat, &bj->block, NULL, NULL);CHKERRQ(ierr); }   /* MatGetDiagonalBlock */
-  else bj->block = pc->pmat;
+  ierr = MatGetDiagonalBlock(pc->pmat, &bj->block);CHKERRQ(ierr);
   if (!bj->ksp) {
     PC subpc;
     ierr = KSPCreate(PETSC_COMM_SELF, &bj->ksp);CHKERRQ(ierr);
@@ -154,10 +186,9 @@ static PetscErrorCode PCSetUp_BJacobi(PC pc) {   /* PCSetUp_BJacobi_Singleblock,
     snprintf(prefix, sizeof(prefix), "%ssub_", pc->prefix);
     ierr = KSPSetOptionsPrefix(bj->ksp, prefix);CHKERRQ(ierr);
     ierr = KSPGetPC(bj->ksp, &subpc);CHKERRQ(ierr);
-    /* the sub-PC defaults to ILU(0) like the reference's (precon.c:14-53, PCSetUp of the sub-KSP) */
-    ierr = PCSetType(subpc, PCILU);CHKERRQ(ierr);
-    ierr = VecCreateSeqHIPMI355X(PETSC_COMM_SELF, bj->block->rmap->n, &bj->x);CHKERRQ(ierr);
-    ierr = VecCreateSeqHIPMI355X(PETSC_COMM_SELF, bj->block->rmap->n, &bj->y);CHKERRQ(ierr);
+    /* the sub-PC's type is left unset: PCSetUp picks the default (ILU(0) on a sequential AIJ block, precon.c:14-53) */
+    (void)subpc;
+    ierr = MatGetVecs(bj->block, &bj->x, &bj->y);CHKERRQ(ierr);
   }
   ierr = KSPSetOperators(bj->ksp, bj->block, bj->block, SAME_NONZERO_PATTERN);CHKERRQ(ierr);
   ierr = KSPSetFromOptions(bj->ksp);CHKERRQ(ierr);
@@ -165,23 +196,39 @@ static PetscErrorCode PCSetUp_BJacobi(PC pc) {   /* PCSetUp_BJacobi_Singleblock,
   return 0;
 }
 
-/* PCApply_BJacobi_Singleblock, bjacobi.c:738-761.  The reference aliases the parallel vectors' HOST
- * arrays into sequential work vectors (VecGetArray + VecPlaceArray), which drags a GPU vector through
- * the host on every application.  Here the aliasing is done on the DEVICE pointers. */
+/* PCApply_BJacobi_Singleblock, bjacobi.c:738-761: the parallel vectors' local arrays are placed into the sequential
+ * work vectors (VecGetArray + VecPlaceArray), the sub-KSP solves, the arrays are reset.  A vector type whose data does
+ * not live on the host may offer the same aliasing as a method of its own ("VecShareArrayBegin_C" / "VecShareArrayEnd_C":
+ * sub takes parent's storage; write != 0 for the output vector), which avoids a host round trip per application. */
+typedef PetscErrorCode (*VecShareFn)(Vec sub, Vec parent, PetscBool write);
 static PetscErrorCode PCApply_BJacobi(PC pc, Vec x, Vec y) {
-  PetscErrorCode ierr;
+  PetscErrorCode ierr, ierr2;
   PC_BJacobi *bj = (PC_BJacobi *)pc->data;
-  Vec_HIPMI355X *bx = (Vec_HIPMI355X *)bj->x->data, *by = (Vec_HIPMI355X *)bj->y->data;
-  const PetscScalar *dx; PetscScalar *dy, *sx = bx->dev, *sy = by->dev;
-  int vx = bx->valid, vy = by->valid;
-  ierr = VecHIPGetRead(x, &dx);CHKERRQ(ierr);
-  ierr = VecHIPGetWrite(y, &dy);CHKERRQ(ierr);
-  bx->dev = (PetscScalar *)dx; bx->valid = VALID_DEVICE; PetscObjectStateIncrease(bj->x);
-  by->dev = dy; by->valid = VALID_DEVICE; PetscObjectStateIncrease(bj->y);
-  ierr = KSPSolve(bj->ksp, bj->x, bj->y);
-  bx->dev = sx; bx->valid = vx; by->dev = sy; by->valid = vy;   /* the aliases come off first, also when the sub-solve failed: the work vectors own sx / sy */
-  CHKERRQ(ierr);
-  ierr = VecHIPRestoreWrite(y);CHKERRQ(ierr);
+  PetscVoidFunction fb, fe;
+  ierr = PetscObjectQueryFunction((PetscObject)bj->x, "VecShareArrayBegin_C", &fb);CHKERRQ(ierr);
+  ierr = PetscObjectQueryFunction((PetscObject)bj->x, "VecShareArrayEnd_C", &fe);CHKERRQ(ierr);
+  if (fb && fe) {
+    ierr = ((VecShareFn)fb)(bj->x, x, PETSC_FALSE);CHKERRQ(ierr);
+    ierr = ((VecShareFn)fb)(bj->y, y, PETSC_TRUE);
+    if (ierr) { ((VecShareFn)fe)(bj->x, x, PETSC_FALSE); CHKERRQ(ierr); }
+    ierr = KSPSolve(bj->ksp, bj->x, bj->y);
+    /* the aliases come off first, also when the sub-solve failed: the work vectors own their storage again */
+    ierr2 = ((VecShareFn)fe)(bj->x, x, PETSC_FALSE);
+    if (!ierr2) ierr2 = ((VecShareFn)fe)(bj->y, y, PETSC_TRUE);
+    CHKERRQ(ierr); CHKERRQ(ierr2);
+  } else {
+    const PetscScalar *xa; PetscScalar *ya;
+    ierr = VecGetArrayRead(x, &xa);CHKERRQ(ierr);
+    ierr = VecGetArray(y, &ya);CHKERRQ(ierr);
+    ierr = VecPlaceArray(bj->x, xa);CHKERRQ(ierr);
+    ierr = VecPlaceArray(bj->y, ya);CHKERRQ(ierr);
+    ierr = KSPSolve(bj->ksp, bj->x, bj->y);
+    ierr2 = VecResetArray(bj->x);
+    if (!ierr2) ierr2 = VecResetArray(bj->y);
+    CHKERRQ(ierr); CHKERRQ(ierr2);
+    ierr = VecRestoreArrayRead(x, &xa);CHKERRQ(ierr);
+    ierr = VecRestoreArray(y, &ya);CHKERRQ(ierr);
+  }
   PetscObjectStateIncrease(y);   /* y changed through the alias: cached norms are stale (VecRestoreArray does this in bjacobi.c:758) */
   return 0;
 }

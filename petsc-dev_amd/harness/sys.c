@@ -1,4 +1,4 @@
-/* Runtime support the HIPMI355X types need from "Sys": error codes with a traceback string
+/* Harness "Sys": error codes with a traceback string
  * (src/sys/error/err.c), the communicator stand-in, row-block layouts (src/vec/vec/impls/mpi/pmap.c),
  * a string options database (src/sys/objects/options.c) and the flop counter (include/petsclog.h). */
 #include "petscimpl.h"
@@ -32,90 +32,72 @@ static PetscLogDouble total_flops = 0.0;
 PetscErrorCode PetscLogFlops(PetscLogDouble f) { total_flops += f; return 0; }
 PetscErrorCode PetscGetFlops(PetscLogDouble *f) { *f = total_flops; return 0; }
 
-const char *PetscHIPMI355XVersion(void) { return "petsc-hipmi355x 0.1 (gfx950)"; }
-
 /* ---------------------------------------------------------------- communicator */
-static struct _p_PetscComm comm_self = {0, 1, NULL, NULL, NULL, NULL, NULL, NULL};
-MPI_Comm PETSC_COMM_SELF = &comm_self;
-MPI_Comm PETSC_COMM_WORLD = &comm_self;
+static struct _p_PetscComm comm_self = {0, 1, NULL, NULL, NULL, NULL, NULL, {NULL, NULL}};
+PetscComm PETSC_COMM_SELF = &comm_self;
+PetscComm PETSC_COMM_WORLD = &comm_self;
 
 PetscErrorCode PetscCommCreate(int rank, int size, void *ctx, PetscCommAllgatherFn ag, PetscCommAllreduceFn ar,
-                               PetscCommBarrierFn bar, MPI_Comm *comm) {
+                               PetscCommBarrierFn bar, PetscComm *comm) {
   PetscErrorCode ierr;
   struct _p_PetscComm *c;
   if (size > 1 && (!ag || !ar)) SETERRQ(0, PETSC_ERR_ARG_NULL, "a communicator of size %d needs allgather and allreduce callbacks", size);
   ierr = PetscMalloc(sizeof(*c), &c);CHKERRQ(ierr);
-  c->rank = rank; c->size = size; c->ctx = ctx; c->allgather = ag; c->allreduce = ar; c->barrier = bar; c->exchange = NULL; c->dcomm = NULL; c->dcomm_halo = NULL;
+  c->rank = rank; c->size = size; c->ctx = ctx; c->allgather = ag; c->allreduce = ar; c->barrier = bar; c->exchange = NULL; c->plugin[0] = c->plugin[1] = NULL;
   *comm = c;
   return 0;
 }
-PetscErrorCode PetscCommSetExchange(MPI_Comm comm, PetscCommExchangeFn fn) { comm->exchange = fn; return 0; }
-PetscErrorCode PetscCommSetWorld(MPI_Comm comm) { PETSC_COMM_WORLD = comm ? comm : &comm_self; return 0; }
-PetscErrorCode PetscCommSetDeviceComm(MPI_Comm comm, void *dcomm) { comm->dcomm = comm->dcomm_halo = (mi355x_comm_t)dcomm; return 0; }
-/* two communicators over the same ranks: `reduce` for the compute stream, `halo` for the halo stream */
-PetscErrorCode PetscCommSetDeviceComms(MPI_Comm comm, void *reduce, void *halo) {
-  if ((reduce == NULL) != (halo == NULL)) SETERRQ(comm, PETSC_ERR_ARG_WRONG, "both RCCL communicators or none");
-  comm->dcomm = (mi355x_comm_t)reduce; comm->dcomm_halo = (mi355x_comm_t)halo;
+PetscErrorCode PetscCommSetExchange(PetscComm comm, PetscCommExchangeFn fn) { comm->exchange = fn; return 0; }
+PetscErrorCode PetscCommSetWorld(PetscComm comm) { PETSC_COMM_WORLD = comm ? comm : &comm_self; return 0; }
+PetscErrorCode PetscCommSetPluginData(PetscComm comm, int slot, void *data) {
+  if (slot < 0 || slot > 1) SETERRQ(comm, PETSC_ERR_ARG_OUTOFRANGE, "slot %d", slot);
+  comm->plugin[slot] = data;
   return 0;
 }
-/* what the device-side collectives of this communicator travel over: 0 = one rank, nothing to exchange; 1 = RCCL
- * (nranks = the size RCCL reports for the reduction communicator, distinct = 1 when the halo has a communicator of its
- * own); 2 = host-staged (several ranks, no RCCL communicator attached) */
-PetscErrorCode PetscCommGetDeviceTransport(MPI_Comm comm, int *kind, int *nranks, int *distinct) {
-  int r = 0, n = 0;
-  *kind = comm->dcomm ? 1 : (comm->size > 1 ? 2 : 0);
-  if (comm->dcomm) CHKHIP(mi355x_comm_rank(comm->dcomm, &r, &n));
-  if (nranks) *nranks = n;
-  if (distinct) *distinct = (comm->dcomm && comm->dcomm_halo != comm->dcomm) ? 1 : 0;
+PetscErrorCode PetscCommGetPluginData(PetscComm comm, int slot, void **data) {
+  if (slot < 0 || slot > 1) SETERRQ(comm, PETSC_ERR_ARG_OUTOFRANGE, "slot %d", slot);
+  *data = comm->plugin[slot];
   return 0;
 }
-PetscErrorCode PetscCommDestroy(MPI_Comm *comm) {
+PetscErrorCode PetscCommDestroy(PetscComm *comm) {
   if (*comm && *comm != &comm_self) { if (PETSC_COMM_WORLD == *comm) PETSC_COMM_WORLD = &comm_self; free(*comm); }
   *comm = NULL;
   return 0;
 }
-PetscErrorCode MPI_Comm_rank(MPI_Comm comm, PetscMPIInt *rank) { *rank = comm->rank; return 0; }
-PetscErrorCode MPI_Comm_size(MPI_Comm comm, PetscMPIInt *size) { *size = comm->size; return 0; }
+PetscErrorCode PetscCommRank(PetscComm comm, PetscMPIInt *rank) { *rank = comm->rank; return 0; }
+PetscErrorCode PetscCommSize(PetscComm comm, PetscMPIInt *size) { *size = comm->size; return 0; }
 
-/* ---------------------------------------------------------------- device */
-static PetscDeviceCtx devctx = {0, -1, NULL, NULL};
-static int requested_device = -1;
-
-PetscErrorCode PetscDeviceGet(PetscDeviceCtx **ctx) {
-  if (!devctx.initialized) {
-    int n = 0, dev = requested_device;
-    int rc = mi355x_device_count(&n);
-    if (rc || n < 1) SETERRQ(0, PETSC_ERR_LIB, "no gfx950 device is available to the HIPMI355X types (hip rc=%d, devices=%d); there is no CPU path", rc, n);
-    if (dev < 0) {
-      const char *lr = getenv("LOCAL_RANK");
-      dev = lr ? atoi(lr) % n : 0;
-    }
-    CHKHIP(mi355x_set_device(dev));
-    CHKHIP(mi355x_handle_create(&devctx.h));
-    CHKHIP(mi355x_handle_create(&devctx.hcomm));
-    devctx.device = dev;
-    devctx.initialized = 1;
-  }
-  *ctx = &devctx;
+/* ---------------------------------------------------------------- composed functions (src/sys/objects/inherit.c) */
+PetscErrorCode PetscObjectComposeFunction(PetscObject obj, const char name[], PetscVoidFunction fn) {
+  PetscErrorCode ierr;
+  struct _n_PetscFList *e;
+  if (!obj) SETERRQ(0, PETSC_ERR_ARG_NULL, "Null Object");
+  for (e = obj->qlist; e; e = e->next) if (!strcmp(e->name, name)) { e->fn = fn; return 0; }
+  ierr = PetscMalloc(sizeof(*e), &e);CHKERRQ(ierr);
+  snprintf(e->name, sizeof(e->name), "%s", name);
+  e->fn = fn; e->next = obj->qlist; obj->qlist = e;
   return 0;
 }
-
-PetscErrorCode PetscHIPMI355XInitialize(int device) {
-  requested_device = device;
-  return PetscHIPMI355XRegisterAll();
+PetscErrorCode PetscObjectQueryFunction(PetscObject obj, const char name[], PetscVoidFunction *fn) {
+  *fn = NULL;
+  if (!obj) return 0;
+  for (struct _n_PetscFList *e = obj->qlist; e; e = e->next) if (!strcmp(e->name, name)) { *fn = e->fn; return 0; }
+  return 0;
 }
-PetscErrorCode PetscHIPMI355XFinalize(void) {
-  if (devctx.initialized) {
-    mi355x_handle_destroy(devctx.h);
-    mi355x_handle_destroy(devctx.hcomm);
-    devctx.initialized = 0;
-  }
+PetscErrorCode PetscObjectListDestroy_Private(PetscObject obj) {
+  struct _n_PetscFList *e = obj->qlist;
+  while (e) { struct _n_PetscFList *n = e->next; free(e); e = n; }
+  obj->qlist = NULL;
+  return 0;
+}
+PetscErrorCode PetscObjectChangeTypeName(PetscObject obj, const char type_name[]) {
+  snprintf(obj->type_name, sizeof(obj->type_name), "%s", type_name ? type_name : "");
   return 0;
 }
 
 /* ---------------------------------------------------------------- layout */
 /* PetscSplitOwnership, src/sys/utils/psplit.c: n = N/size + ((N % size) > rank) */
-PetscErrorCode PetscSplitOwnership(MPI_Comm comm, PetscInt *n, PetscInt *N) {
+PetscErrorCode PetscSplitOwnership(PetscComm comm, PetscInt *n, PetscInt *N) {
   if (*N == PETSC_DECIDE && *n == PETSC_DECIDE) SETERRQ(comm, PETSC_ERR_ARG_INCOMP, "Both n and N cannot be PETSC_DECIDE");
   if (*N == PETSC_DECIDE) {
     PetscInt s = *n;
@@ -128,9 +110,9 @@ PetscErrorCode PetscSplitOwnership(MPI_Comm comm, PetscInt *n, PetscInt *N) {
 }
 
 /* PetscLayoutSetUp, src/vec/vec/impls/mpi/pmap.c: gather every rank's n, prefix-sum into range[] */
-PetscErrorCode PetscLayoutCreateSetUp(MPI_Comm comm, PetscInt n, PetscInt N, PetscLayout **map) {
+PetscErrorCode PetscLayoutCreateSetUp(PetscComm comm, PetscInt n, PetscInt N, PetscLayout *map) {
   PetscErrorCode ierr;
-  PetscLayout *m;
+  PetscLayout m;
   ierr = PetscSplitOwnership(comm, &n, &N);CHKERRQ(ierr);
   ierr = PetscMalloc(sizeof(*m), &m);CHKERRQ(ierr);
   ierr = PetscMalloc(sizeof(PetscInt) * (size_t)(comm->size + 1), &m->range);CHKERRQ(ierr);
@@ -148,8 +130,8 @@ PetscErrorCode PetscLayoutCreateSetUp(MPI_Comm comm, PetscInt n, PetscInt N, Pet
   *map = m;
   return 0;
 }
-PetscErrorCode PetscLayoutReference(PetscLayout *in, PetscLayout **out) { in->refcnt++; *out = in; return 0; }
-PetscErrorCode PetscLayoutDestroy(PetscLayout **map) {
+PetscErrorCode PetscLayoutReference(PetscLayout in, PetscLayout *out) { in->refcnt++; *out = in; return 0; }
+PetscErrorCode PetscLayoutDestroy(PetscLayout *map) {
   if (*map && --(*map)->refcnt == 0) { free((*map)->range); free(*map); }
   *map = NULL;
   return 0;

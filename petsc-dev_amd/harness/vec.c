@@ -3,6 +3,7 @@
 #include "petscimpl.h"
 
 #define MAXTYPES 16
+typedef PetscErrorCode (*VecCreateFn)(Vec);
 static struct { char name[32]; VecCreateFn fn; } vec_types[MAXTYPES];
 static int n_vec_types = 0;
 
@@ -20,7 +21,7 @@ PetscErrorCode VecRegister(const char *name, VecCreateFn fn) {
     if ((x)->map->N != (y)->map->N) SETERRQ((x)->comm, PETSC_ERR_ARG_INCOMP, "Incompatible vector global lengths %d != %d", (x)->map->N, (y)->map->N); \
     if ((x)->map->n != (y)->map->n) SETERRQ((x)->comm, PETSC_ERR_ARG_INCOMP, "Incompatible vector local lengths %d != %d", (x)->map->n, (y)->map->n); } while (0)
 
-PetscErrorCode VecCreate(MPI_Comm comm, Vec *vec) {
+PetscErrorCode VecCreate(PetscComm comm, Vec *vec) {
   PetscErrorCode ierr;
   Vec v;
   ierr = PetscMalloc(sizeof(*v), &v);CHKERRQ(ierr);
@@ -49,7 +50,8 @@ PetscErrorCode VecSetType(Vec v, VecType type) {
     if (!strcmp(vec_types[i].name, type)) {
       if (v->ops->destroy) { ierr = (*v->ops->destroy)(v);CHKERRQ(ierr); }
       memset(v->ops, 0, sizeof(v->ops));
-      v->data = NULL;
+      ierr = PetscObjectListDestroy_Private((PetscObject)v);CHKERRQ(ierr);
+      v->data = NULL; v->petscnative = PETSC_FALSE;
       ierr = (*vec_types[i].fn)(v);CHKERRQ(ierr);
       return 0;
     }
@@ -61,11 +63,7 @@ PetscErrorCode VecSetFromOptions(Vec v) {
   char t[64];
   PetscBool set;
   PetscErrorCode ierr = PetscOptionsGetString(NULL, "-vec_type", t, sizeof(t), &set);CHKERRQ(ierr);
-  if (!set) snprintf(t, sizeof(t), "%s", VECHIPMI355X);
-  /* the reference's names select the HIPMI355X implementation of the same shape */
-  if (!strcmp(t, "seq")) snprintf(t, sizeof(t), "%s", VECSEQHIPMI355X);
-  else if (!strcmp(t, "mpi")) snprintf(t, sizeof(t), "%s", VECMPIHIPMI355X);
-  else if (!strcmp(t, "standard")) snprintf(t, sizeof(t), "%s", VECHIPMI355X);
+  if (!set) snprintf(t, sizeof(t), "%s", VECSTANDARD);   /* vector.c VecSetFromOptions: standard = seq on one process, mpi on several */
   return VecSetType(v, t);
 }
 PetscErrorCode VecGetType(Vec v, VecType *type) { VecValid(v, 1); *type = v->type_name; return 0; }
@@ -94,6 +92,7 @@ PetscErrorCode VecDestroy(Vec *v) {
   if (!*v) return 0;
   if ((*v)->ops->destroy) { ierr = (*(*v)->ops->destroy)(*v);CHKERRQ(ierr); }
   ierr = PetscLayoutDestroy(&(*v)->map);CHKERRQ(ierr);
+  ierr = PetscObjectListDestroy_Private((PetscObject)*v);CHKERRQ(ierr);
   free(*v); *v = NULL;
   return 0;
 }
@@ -123,8 +122,14 @@ PetscErrorCode VecRestoreArray(Vec v, PetscScalar **a) {
   PetscObjectStateIncrease(v);
   return 0;
 }
-PetscErrorCode VecGetArrayRead(Vec v, const PetscScalar **a) { VecTypeSet(v, 1); PetscErrorCode ierr = (*v->ops->getarrayread)(v, a);CHKERRQ(ierr); return 0; }
-PetscErrorCode VecRestoreArrayRead(Vec v, const PetscScalar **a) { VecTypeSet(v, 1); if (a) *a = NULL; return 0; }
+/* the read-only pair takes the same two slots (vecimpl.h:369-400); only VecRestoreArray bumps the state */
+PetscErrorCode VecGetArrayRead(Vec v, const PetscScalar **a) { VecTypeSet(v, 1); PetscErrorCode ierr = (*v->ops->getarray)(v, (PetscScalar **)a);CHKERRQ(ierr); return 0; }
+PetscErrorCode VecRestoreArrayRead(Vec v, const PetscScalar **a) {
+  VecTypeSet(v, 1);
+  PetscErrorCode ierr = (*v->ops->restorearray)(v, (PetscScalar **)a);CHKERRQ(ierr);
+  if (a) *a = NULL;
+  return 0;
+}
 PetscErrorCode VecPlaceArray(Vec v, const PetscScalar *a) {
   VecTypeSet(v, 1);
   PetscErrorCode ierr = (*v->ops->placearray)(v, a);CHKERRQ(ierr);
@@ -283,5 +288,61 @@ PetscErrorCode VecDotNorm2(Vec s, Vec t, PetscScalar *dp, PetscReal *nm) {   /* 
   PetscScalar n2;
   PetscErrorCode ierr = (*s->ops->dotnorm2)(s, t, dp, &n2);CHKERRQ(ierr);
   *nm = n2;
+  return 0;
+}
+
+
+/* ---- split-phase reductions (src/vec/vec/utils/comb.c:402-721).  The reference queues the local parts and starts one
+ * MPI_Iallreduce in PetscCommSplitReductionBegin; here a vector type may provide the three phases itself
+ * ("VecSplitReductionOps_C": its Begin launches the local reduction, the communicator-wide Begin starts the
+ * all-reduce, its End delivers); without it Begin simply performs the whole reduction and End hands the value back. */
+typedef struct {
+  PetscErrorCode (*dot_begin)(Vec, Vec, PetscScalar *);
+  PetscErrorCode (*dot_end)(Vec, Vec, PetscScalar *);
+  PetscErrorCode (*norm_begin)(Vec, NormType, PetscReal *);
+  PetscErrorCode (*norm_end)(Vec, NormType, PetscReal *);
+  PetscErrorCode (*comm_begin)(PetscComm);
+} VecSplitReductionOps;
+static const VecSplitReductionOps *split_ops(Vec x) {
+  PetscVoidFunction f = NULL;
+  if (PetscObjectQueryFunction((PetscObject)x, "VecSplitReductionOps_C", &f) || !f) return NULL;
+  return ((const VecSplitReductionOps *(*)(void))f)();
+}
+#define SR_MAX 32
+static struct { PetscScalar val[SR_MAX]; int n, next; const VecSplitReductionOps *ops; } sr_host = {{0}, 0, 0, NULL};
+PetscErrorCode VecDotBegin(Vec x, Vec y, PetscScalar *result) {
+  VecTypeSet(x, 1); VecTypeSet(y, 2); VecSameSize(x, y);
+  const VecSplitReductionOps *o = split_ops(x);
+  if (o) { sr_host.ops = o; return o->dot_begin(x, y, result); }
+  if (sr_host.n >= SR_MAX) SETERRQ(x->comm, PETSC_ERR_SUP, "more than %d split reductions in flight", SR_MAX);
+  PetscErrorCode ierr = VecDot(x, y, &sr_host.val[sr_host.n++]);CHKERRQ(ierr);
+  return 0;
+}
+PetscErrorCode VecDotEnd(Vec x, Vec y, PetscScalar *result) {
+  const VecSplitReductionOps *o = split_ops(x);
+  if (o) return o->dot_end(x, y, result);
+  if (sr_host.next >= sr_host.n) SETERRQ(x->comm, PETSC_ERR_ORDER, "VecxxxEnd() without a matching VecxxxBegin()");
+  *result = sr_host.val[sr_host.next++];
+  if (sr_host.next == sr_host.n) sr_host.next = sr_host.n = 0;
+  return 0;
+}
+PetscErrorCode VecNormBegin(Vec x, NormType type, PetscReal *result) {
+  VecTypeSet(x, 1);
+  const VecSplitReductionOps *o = split_ops(x);
+  if (o) { sr_host.ops = o; return o->norm_begin(x, type, result); }
+  if (sr_host.n >= SR_MAX) SETERRQ(x->comm, PETSC_ERR_SUP, "more than %d split reductions in flight", SR_MAX);
+  PetscErrorCode ierr = VecNorm(x, type, &sr_host.val[sr_host.n++]);CHKERRQ(ierr);
+  return 0;
+}
+PetscErrorCode VecNormEnd(Vec x, NormType type, PetscReal *result) {
+  const VecSplitReductionOps *o = split_ops(x);
+  if (o) return o->norm_end(x, type, result);
+  if (sr_host.next >= sr_host.n) SETERRQ(x->comm, PETSC_ERR_ORDER, "VecxxxEnd() without a matching VecxxxBegin()");
+  *result = sr_host.val[sr_host.next++];
+  if (sr_host.next == sr_host.n) sr_host.next = sr_host.n = 0;
+  return 0;
+}
+PetscErrorCode PetscCommSplitReductionBegin(PetscComm comm) {
+  if (sr_host.ops && sr_host.ops->comm_begin) return sr_host.ops->comm_begin(comm);
   return 0;
 }

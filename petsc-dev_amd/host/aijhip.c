@@ -3,7 +3,7 @@
  * MatAssemblyEnd_SeqAIJ aij.c:~860) plus the device mirror and the ops the reference's GPU subclass
  * overrides (MatCreate_SeqAIJCUSP, src/mat/impls/aij/seq/seqcusp/aijcusp.cu:657-681): mult, multadd,
  * multtranspose[add], getdiagonal, assemblyend, getvecs, destroy. */
-#include "petscimpl.h"
+#include "hipmi355ximpl.h"
 
 #define SA(A) ((Mat_SeqAIJ *)(A)->data)
 #define SD(A) ((Mat_SeqAIJHIP *)(A)->spptr)
@@ -152,10 +152,12 @@ static PetscErrorCode device_free(Mat A) {
   if (d->bm_segslot) mi355x_free(d->bm_segslot);
   if (d->bm_v) mi355x_free(d->bm_v);
   const PetscInt nup = d->n_uploads;
-  const PetscBool cprow = d->cprow;
+  const PetscBool cprow = d->cprow, timing = d->timing;
+  const PetscInt tn = d->time_n, tcap = d->time_cap; mi355x_event_t *tev = d->time_ev;
   memset(d, 0, sizeof(*d));
   d->uploaded_state = -1; d->t_state = -1; d->pattern_nz = -1;
   d->n_uploads = nup; d->cprow = cprow;   /* a count and a request: they outlive the arrays */
+  d->timing = timing; d->time_n = tn; d->time_cap = tcap; d->time_ev = tev;
   return 0;
 }
 
@@ -490,7 +492,7 @@ PetscErrorCode MatMultTDotBegin_HIPMI355X(Mat A, Vec xx, Vec yy, PetscBool *ok) 
   Mat_SeqAIJ *a = SA(A); Mat_SeqAIJHIP *d = SD(A);
   const PetscScalar *x; PetscScalar *y; PetscDeviceCtx *dc; int ntab = 0;
   if (a->bs > 1 || d->cprow || a->m != a->n || xx == yy) return 0;
-  if (xx->map->n != a->n || yy->map->n != a->m || (xx->comm->size > 1 && !xx->comm->dcomm)) return 0;
+  if (xx->map->n != a->n || yy->map->n != a->m || (HipCommSize(xx->comm) > 1 && !HipCommDevice(xx->comm))) return 0;
   ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
   ierr = MatSeqAIJHIPUpload(A);CHKERRQ(ierr);
   if (!d->plan) return 0;
@@ -505,7 +507,7 @@ PetscErrorCode MatMultTDotBegin_HIPMI355X(Mat A, Vec xx, Vec yy, PetscBool *ok) 
   ierr = MatTimingEnd(A, dc->h);CHKERRQ(ierr);
   double *slot = mi355x_handle_device_scratch(dc->h) + PETSC_HIP_DPI_SLOT;
   CHKHIP(mi355x_spmv_dot_finish(dc->h, d->plan, slot));
-  if (xx->comm->dcomm) CHKHIP(mi355x_comm_allreduce_sum(xx->comm->dcomm, dc->h, slot, 1));
+  if (HipCommDevice(xx->comm)) CHKHIP(mi355x_comm_allreduce_sum(HipCommDevice(xx->comm), dc->h, slot, 1));
   ierr = VecHIPRestoreWrite(yy);CHKERRQ(ierr);
   PetscObjectStateIncrease(yy);
   ierr = PetscLogFlops(2.0 * a->nz - a->nonzerorows + 2.0 * a->m - 1);CHKERRQ(ierr);
@@ -681,15 +683,27 @@ PetscErrorCode MatGetVecs_HIPMI355X(Mat A, Vec *right, Vec *left) { return MatGe
 
 static PetscErrorCode MatDestroy_SeqAIJHIP(Mat A) {   /* free the mirror and zero spptr first, aijcusp.cu:584-586 */
   Mat_SeqAIJ *a = SA(A);
-  if (SD(A)) { device_free(A); free(A->spptr); A->spptr = NULL; }
+  if (SD(A)) {
+    Mat_SeqAIJHIP *d = SD(A);
+    device_free(A);
+    if (d->time_ev) { for (PetscInt k = 0; k < 2 * d->time_cap; k++) mi355x_event_destroy(d->time_ev[k]); free(d->time_ev); }
+    free(A->spptr); A->spptr = NULL;
+  }
   if (a) { free(a->i); free(a->j); free(a->a); free(a->ilen); free(a->imax); free(a->inode_size); free(a); A->data = NULL; }
   return 0;
 }
 
+static PetscErrorCode MatSeqAIJSetPreallocation_SeqAIJHIP(Mat A, PetscInt nz, const PetscInt nnz[]) { return seqaij_prealloc(A, nz, nnz); }
+static PetscErrorCode MatSeqAIJSetPreallocationCSR_SeqAIJHIP(Mat B, const PetscInt *i, const PetscInt *j, const PetscScalar *a);
+static PetscErrorCode MatSeqBAIJSetPreallocationCSR_SeqBAIJHIP(Mat B, PetscInt bs, const PetscInt *i, const PetscInt *j, const PetscScalar *a);
+
+/* MatCreate_SeqAIJCUSP (aijcusp.cu:657-681) fills, after the parent constructor, the slots mult, multadd, multtranspose,
+ * multtransposeadd, assemblyend, destroy, getvecs, setvaluesbatch; the container and its assembly are this file's too
+ * (host/aijhip.c) on the harness, the parent MATSEQAIJ's inside a PETSc tree. */
 static PetscErrorCode create_common(Mat B, const char *tname, PetscInt bs) {
   PetscErrorCode ierr;
   Mat_SeqAIJ *a; Mat_SeqAIJHIP *d;
-  if (B->comm->size > 1) SETERRQ(B->comm, PETSC_ERR_ARG_WRONG, "Comm must be of size 1");
+  if (HipCommSize(HipObjComm(B)) > 1) SETERRQ(HipObjComm(B), PETSC_ERR_ARG_WRONG, "Comm must be of size 1");
   ierr = PetscMalloc(sizeof(*a), &a);CHKERRQ(ierr);
   memset(a, 0, sizeof(*a));
   ierr = PetscMalloc(sizeof(*d), &d);CHKERRQ(ierr);
@@ -697,22 +711,33 @@ static PetscErrorCode create_common(Mat B, const char *tname, PetscInt bs) {
   d->uploaded_state = -1; d->t_state = -1; d->pattern_nz = -1;
   a->m = B->rmap->n; a->n = B->cmap->n; a->bs = bs;
   B->data = a; B->spptr = d;
-  snprintf(B->type_name, sizeof(B->type_name), "%s", tname);
-  MatOps *o = B->ops;
-  o->setvalues = MatSetValues_SeqAIJHIP; o->mult = MatMult_SeqAIJHIP; o->multadd = MatMultAdd_SeqAIJHIP;
-  o->multtranspose = MatMultTranspose_SeqAIJHIP; o->multtransposeadd = MatMultTransposeAdd_SeqAIJHIP;
-  o->getdiagonal = MatGetDiagonal_SeqAIJHIP; o->assemblyend = MatAssemblyEnd_SeqAIJHIP; o->zeroentries = MatZeroEntries_SeqAIJHIP;
-  o->setup = MatSetUp_SeqAIJHIP; o->scale = MatScale_SeqAIJHIP; o->diagonalscale = MatDiagonalScale_SeqAIJHIP; o->setvaluesbatch = MatSetValuesBatch_SeqAIJHIP; o->destroy = MatDestroy_SeqAIJHIP; o->getvecs = MatGetVecs_HIP;
+  ierr = PetscObjectChangeTypeName((PetscObject)B, tname);CHKERRQ(ierr);
+  B->ops->setvalues = MatSetValues_SeqAIJHIP;
+  B->ops->mult = MatMult_SeqAIJHIP;
+  B->ops->multadd = MatMultAdd_SeqAIJHIP;
+  B->ops->multtranspose = MatMultTranspose_SeqAIJHIP;
+  B->ops->multtransposeadd = MatMultTransposeAdd_SeqAIJHIP;
+  B->ops->getdiagonal = MatGetDiagonal_SeqAIJHIP;
+  B->ops->assemblyend = MatAssemblyEnd_SeqAIJHIP;
+  B->ops->zeroentries = MatZeroEntries_SeqAIJHIP;
+  B->ops->setup = MatSetUp_SeqAIJHIP;
+  B->ops->scale = MatScale_SeqAIJHIP;
+  B->ops->diagonalscale = MatDiagonalScale_SeqAIJHIP;
+  B->ops->setvaluesbatch = MatSetValuesBatch_SeqAIJHIP;
+  B->ops->destroy = MatDestroy_SeqAIJHIP;
+  B->ops->getvecs = MatGetVecs_HIP;
+  ierr = PetscObjectComposeFunction((PetscObject)B, "MatSeqAIJGetArrays_C", (PetscVoidFunction)MatSeqAIJGetArrays);CHKERRQ(ierr);
+  ierr = PetscObjectComposeFunction((PetscObject)B, "MatMultTDotBegin_C", (PetscVoidFunction)MatMultTDotBegin_HIPMI355X);CHKERRQ(ierr);
+  if (bs == 1) {
+    ierr = PetscObjectComposeFunction((PetscObject)B, "MatSeqAIJSetPreallocation_C", (PetscVoidFunction)MatSeqAIJSetPreallocation_SeqAIJHIP);CHKERRQ(ierr);
+    ierr = PetscObjectComposeFunction((PetscObject)B, "MatSeqAIJSetPreallocationCSR_C", (PetscVoidFunction)MatSeqAIJSetPreallocationCSR_SeqAIJHIP);CHKERRQ(ierr);
+  } else {
+    ierr = PetscObjectComposeFunction((PetscObject)B, "MatSeqBAIJSetPreallocationCSR_C", (PetscVoidFunction)MatSeqBAIJSetPreallocationCSR_SeqBAIJHIP);CHKERRQ(ierr);
+  }
   return 0;
 }
 PetscErrorCode MatCreate_SeqAIJHIPMI355X(Mat B) { return create_common(B, MATSEQAIJHIPMI355X, 1); }
 PetscErrorCode MatCreate_SeqBAIJHIPMI355X(Mat B) { return create_common(B, MATSEQBAIJHIPMI355X, 0); }
-
-PetscErrorCode MatSeqAIJSetPreallocation(Mat A, PetscInt nz, const PetscInt nnz[]) {
-  /* a no-op for other types, like the composed "MatSeqAIJSetPreallocation_C" lookup (aij.c:3908) */
-  if (!A || strcmp(A->type_name, MATSEQAIJHIPMI355X)) return 0;
-  return seqaij_prealloc(A, nz, nnz);
-}
 
 /* MatCreateSeqAIJWithArrays (aij.c): the arrays are copied (the reference aliases them) */
 static PetscErrorCode adopt_csr(Mat B, PetscInt nrows, PetscInt bs, const PetscInt *i, const PetscInt *j, const PetscScalar *a) {
@@ -747,27 +772,17 @@ static PetscErrorCode adopt_csr(Mat B, PetscInt nrows, PetscInt bs, const PetscI
   }
   s->nz = s->maxnz = nz; s->compact = PETSC_TRUE;
   if (bs > 1) { s->m = nrows; s->bs = bs; }
-  B->preallocated = PETSC_TRUE; B->assembled = PETSC_TRUE; B->was_assembled = PETSC_TRUE; B->state++;
+  B->preallocated = PETSC_TRUE; B->assembled = PETSC_TRUE; B->was_assembled = PETSC_TRUE; PetscObjectStateIncrease(B);
   return 0;
 }
-PetscErrorCode MatSeqAIJSetCSR_Private(Mat B, PetscInt m, const PetscInt *i, const PetscInt *j, const PetscScalar *a) { return adopt_csr(B, m, 1, i, j, a); }
-PetscErrorCode MatCreateSeqAIJWithArrays(MPI_Comm comm, PetscInt m, PetscInt n, PetscInt i[], PetscInt j[], PetscScalar a[], Mat *mat) {
+/* "MatSeqAIJSetPreallocationCSR_C" (aij.c:3795) and its BAIJ analogue (baij.c): m, n are point sizes; i, j index blocks */
+static PetscErrorCode MatSeqAIJSetPreallocationCSR_SeqAIJHIP(Mat B, const PetscInt *i, const PetscInt *j, const PetscScalar *a) { return adopt_csr(B, B->rmap->n, 1, i, j, a); }
+static PetscErrorCode MatSeqBAIJSetPreallocationCSR_SeqBAIJHIP(Mat B, PetscInt bs, const PetscInt *i, const PetscInt *j, const PetscScalar *a) {
   PetscErrorCode ierr;
-  ierr = MatCreate(comm, mat);CHKERRQ(ierr);
-  ierr = MatSetSizes(*mat, m, n, m, n);CHKERRQ(ierr);
-  ierr = MatSetType(*mat, MATSEQAIJHIPMI355X);CHKERRQ(ierr);
-  ierr = adopt_csr(*mat, m, 1, i, j, a);CHKERRQ(ierr);
-  return 0;
-}
-/* MatCreateSeqBAIJWithArrays (src/mat/impls/baij/seq/baij.c): m, n are point sizes; i, j index blocks */
-PetscErrorCode MatCreateSeqBAIJWithArrays(MPI_Comm comm, PetscInt bs, PetscInt m, PetscInt n, PetscInt i[], PetscInt j[], PetscScalar a[], Mat *mat) {
-  PetscErrorCode ierr;
-  if (bs < 1 || m % bs || n % bs) SETERRQ(comm, PETSC_ERR_ARG_SIZ, "block size %d must divide the local sizes %d, %d", bs, m, n);
-  ierr = MatCreate(comm, mat);CHKERRQ(ierr);
-  ierr = MatSetSizes(*mat, m, n, m, n);CHKERRQ(ierr);
-  ierr = MatSetType(*mat, MATSEQBAIJHIPMI355X);CHKERRQ(ierr);
-  ierr = adopt_csr(*mat, m / bs, bs, i, j, a);CHKERRQ(ierr);
-  if (bs == 1) SA(*mat)->bs = 1;
+  if (bs < 1 || B->rmap->n % bs || B->cmap->n % bs) SETERRQ(HipObjComm(B), PETSC_ERR_ARG_SIZ, "block size %d must divide the local sizes %d, %d", bs, B->rmap->n, B->cmap->n);
+  SA(B)->bs = bs;                       /* the column check of adopt_csr counts block columns */
+  ierr = adopt_csr(B, B->rmap->n / bs, bs, i, j, a);CHKERRQ(ierr);
+  if (bs == 1) SA(B)->bs = 1;
   return 0;
 }
 PetscErrorCode MatSeqAIJGetArrays(Mat A, PetscInt *m, const PetscInt **i, const PetscInt **j, const PetscScalar **a) {
@@ -777,5 +792,42 @@ PetscErrorCode MatSeqAIJGetArrays(Mat A, PetscInt *m, const PetscInt **i, const 
   if (i) *i = s->i;
   if (j) *j = s->j;
   if (a) *a = s->a;
+  return 0;
+}
+
+/* ---- per-launch device timing used by bench.py (hipEvent pairs on the compute stream) ---- */
+PetscErrorCode MatHIPMI355XSetTiming(Mat A, PetscBool on) {
+  if (!A || A->ops->mult != MatMult_SeqAIJHIP) SETERRQ(A ? HipObjComm(A) : 0, PETSC_ERR_ARG_WRONG, "sequential HIPMI355X matrix expected");
+  Mat_SeqAIJHIP *d = SD(A);
+  d->timing = on; d->time_n = 0;
+  if (on && !d->time_ev) {
+    d->time_cap = 4096;
+    PetscErrorCode ierr = PetscMalloc(sizeof(mi355x_event_t) * 2 * (size_t)d->time_cap, &d->time_ev);CHKERRQ(ierr);
+    for (PetscInt k = 0; k < 2 * d->time_cap; k++) CHKHIP(mi355x_event_create(&d->time_ev[k]));
+  }
+  return 0;
+}
+PetscErrorCode MatTimingBegin(Mat A, mi355x_handle_t h) {
+  Mat_SeqAIJHIP *d = SD(A);
+  if (d->timing && d->time_n < d->time_cap) CHKHIP(mi355x_event_record(d->time_ev[2 * d->time_n], h));
+  return 0;
+}
+PetscErrorCode MatTimingEnd(Mat A, mi355x_handle_t h) {
+  Mat_SeqAIJHIP *d = SD(A);
+  if (d->timing && d->time_n < d->time_cap) { CHKHIP(mi355x_event_record(d->time_ev[2 * d->time_n + 1], h)); d->time_n++; }
+  return 0;
+}
+PetscErrorCode MatHIPMI355XGetTiming(Mat A, PetscInt *nlaunches, PetscLogDouble *total_ms) {
+  if (!A || A->ops->mult != MatMult_SeqAIJHIP) SETERRQ(A ? HipObjComm(A) : 0, PETSC_ERR_ARG_WRONG, "sequential HIPMI355X matrix expected");
+  Mat_SeqAIJHIP *d = SD(A);
+  double tot = 0.0;
+  for (PetscInt k = 0; k < d->time_n; k++) {
+    float ms = 0.f;
+    CHKHIP(mi355x_event_synchronize(d->time_ev[2 * k + 1]));
+    CHKHIP(mi355x_event_elapsed_ms(d->time_ev[2 * k], d->time_ev[2 * k + 1], &ms));
+    tot += ms;
+  }
+  if (nlaunches) *nlaunches = d->time_n;
+  if (total_ms) *total_ms = tot;
   return 0;
 }

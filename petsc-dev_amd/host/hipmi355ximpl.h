@@ -1,0 +1,154 @@
+/* Private header of the PLUGIN (libpetschipmi355x.so): the HIPMI355X Vec/Mat/PC implementations.
+ *
+ * Object model: in a PETSc tree (PETSCHIPMI355X_WITH_PETSC, integration/petsc-3.3/) PETSc's own private headers; on a box
+ * without PETSc the harness's stand-ins (petsc-dev_amd/harness/petscimpl.h), which keep the reference's names for the
+ * header fields (hdr.comm, hdr.type_name, hdr.state), the layouts (map->n, rmap, cmap), data / spptr, the flags
+ * (petscnative, assembled, preallocated) and every function-table slot the types fill, so that the sources in this
+ * directory compile against either.  What differs between the two is collected in the HIPOBJ_* / HipComm* names below. */
+#ifndef HIPMI355XIMPL_H
+#define HIPMI355XIMPL_H
+#include "petschipmi355x.h"
+#if defined(PETSCHIPMI355X_WITH_PETSC)
+#include "hipmi355x_petsc33.h"          /* integration/petsc-3.3/: real petsc-private headers + the names below over MPI */
+#else
+#include "../harness/petscimpl.h"
+#define MPI_Comm PetscComm               /* the plugin's sources use PETSc's spelling */
+/* ---- what the plugin needs from "Sys" beyond the public API (all of it exists in libpetsc under these names) ---- */
+#define HipCommSize(comm) ((comm)->size)
+#define HipCommRank(comm) ((comm)->rank)
+/* host collectives of the reference's set-up phase (MPI_Allgather / MPI_Allreduce / persistent send-recv pairs) */
+#define HipCommAllgather(comm, sbuf, nbytes, rbuf) ((comm)->allgather((comm)->ctx, (sbuf), (nbytes), (rbuf)))
+#define HipCommAllreduce(comm, buf, count, is_double, op) ((comm)->allreduce((comm)->ctx, (buf), (count), (is_double), (op)))
+#define HipCommHasExchange(comm) ((comm)->exchange != NULL)
+#define HipCommExchange(comm, ns, sp, sb, sbytes, nr, rp, rb, rbytes) ((comm)->exchange((comm)->ctx, (ns), (sp), (sb), (sbytes), (nr), (rp), (rb), (rbytes)))
+/* the RCCL communicators hung on the communicator: slot 0 reductions (compute stream), slot 1 halo (halo stream) */
+#define HipCommDevice(comm) ((mi355x_comm_t)(comm)->plugin[0])
+#define HipCommDeviceHalo(comm) ((mi355x_comm_t)(comm)->plugin[1])
+#define HipObjComm(obj) (((PetscObject)(obj))->comm)
+#define HipObjTypeName(obj) (((PetscObject)(obj))->type_name)
+#define HipObjPrefix(obj) (((PetscObject)(obj))->prefix)
+#define HipObjState(obj) (((PetscObject)(obj))->state)
+#endif
+#include "mi355x_kernels.h"
+#include "mi355x_comm.h"
+
+/* map a kernel-library (hipError_t) failure to PETSC_ERR_LIB like CHKERRCUSP, cuspvecimpl.h:79 */
+#define CHKHIP(e) do { int e__ = (e); if (e__) return PetscError(__LINE__, __func__, __FILE__, PETSC_ERR_LIB, "HIP/RCCL error %d: %s", e__, mi355x_comm_error_string(e__)); } while (0)
+
+/* ---- device context of this process (one GPU, two streams) ---- */
+typedef struct {
+  int initialized, device;
+  mi355x_handle_t h;        /* compute stream */
+  mi355x_handle_t hcomm;    /* halo stream ("second HIP stream" of the north star) */
+} PetscDeviceCtx;
+PetscErrorCode PetscDeviceGet(PetscDeviceCtx **ctx);   /* lazily creates handles; PETSC_ERR_LIB without a GPU */
+
+/* ---- Vec ---- */
+/* coherence flags, as PETSC_CUSP_UNALLOCATED/CPU/GPU/BOTH (include/petsc-private/vecimpl.h) */
+enum { VALID_NONE = 0, VALID_HOST = 1, VALID_DEVICE = 2, VALID_BOTH = 3 };
+typedef struct {
+  PetscScalar *host;        /* host mirror, allocated on first host access; FIRST member, as VECHEADER (vecimpl.h:446-449) */
+  PetscScalar *dev;         /* HBM */
+  int valid;
+  PetscScalar *placed_save; /* VecPlaceArray */
+  int host_owned;
+  PetscScalar *alias_save; int alias_valid;   /* "VecShareArrayBegin_C": the storage this vector owns while it borrows another's */
+} Vec_HIPMI355X;
+
+PetscErrorCode VecCreate_SeqHIPMI355X(Vec v);
+PetscErrorCode VecCreate_MPIHIPMI355X(Vec v);
+PetscErrorCode VecCreate_HIPMI355X(Vec v);
+PetscErrorCode VecCreateSeqHIPMI355X(MPI_Comm comm, PetscInt n, Vec *v);
+/* device pointers with coherence (analogue of VecCUSPGetArrayRead/Write, cuspvecimpl.h:95-150) */
+PetscErrorCode VecHIPGetRead(Vec v, const PetscScalar **d);
+PetscErrorCode VecHIPGetWrite(Vec v, PetscScalar **d);       /* contents will be overwritten */
+PetscErrorCode VecHIPGetReadWrite(Vec v, PetscScalar **d);
+PetscErrorCode VecHIPRestoreWrite(Vec v);                    /* device newer; state++ */
+#define PETSC_HIP_DPI_SLOT 8   /* device scratch slot holding p'w between the dot (or the SpMV by-product) and the CG update */
+PetscErrorCode MatMultTDotBegin_HIPMI355X(Mat A, Vec x, Vec y, PetscBool *ok);   /* y = A x, x'y left on the device */
+
+/* ---- VecScatter (VecScatter_MPI_General, include/petsc-private/vecimpl.h:509-555) ---- */
+typedef struct {
+  PetscInt n;                 /* number of neighbours */
+  PetscInt *procs, *starts, *indices;
+  PetscInt *d_indices;        /* device copy */
+  PetscScalar *d_values;      /* device message buffer */
+  PetscBool contiq;           /* indices contiguous: exchange in place (vpscat.c:1951-1960) */
+  PetscInt local_n;
+  PetscInt *local_slots, *d_local_slots;
+} VecScatterSide;
+#if !defined(PETSCHIPMI355X_WITH_PETSC)
+struct _p_VecScatter {
+#else
+struct _p_VecScatter_HIPMI355X {          /* hangs off the reference's VecScatter->spptr (vecimpl.h:539-555) */
+#endif
+  MPI_Comm comm;
+  VecScatterSide to, from;
+  PetscBool inuse;            /* guard, vscat.c:1637 */
+  mi355x_event_t ev_packed, ev_done;
+  int device_ready;
+  int ready_marked;           /* ev_packed already recorded by VecScatterMarkReady */
+  PetscScalar *h_send, *h_recv;   /* host staging buffers of the host-staged transport */
+  PetscScalar *d_local_tmp;       /* device staging of the local (self) part, local_n doubles */
+};
+PetscErrorCode VecScatterMarkReady(VecScatter ctx, Vec x);
+PetscErrorCode VecScatterCreate_PtoS_MPIAIJ(MPI_Comm comm, PetscLayout xmap, PetscInt ec, const PetscInt *garray, VecScatter *ctx);
+
+/* ---- Mat ---- */
+/* host CSR container: the part of Mat_SeqAIJ the path needs (src/mat/impls/aij/seq/aij.h:10-39,99-115), same member
+ * names.  With a real PETSc the parent type MATSEQAIJ owns it (aij.h) and the assembly code of aijhip.c is not built. */
+typedef struct {
+  PetscInt m, n;            /* local rows / columns */
+  PetscInt *i, *j;          /* row pointer / column index */
+  PetscScalar *a;
+  PetscInt *ilen, *imax;    /* used / allocated per row during assembly */
+  PetscInt nz, maxnz;
+  PetscInt bs;              /* block size (BAIJ reuse: i,j index blocks, a holds bs*bs per block) */
+  PetscBool compact;        /* rows are packed (after assembly) */
+  PetscInt nonzerorows;
+  PetscInt inode_count, *inode_size;   /* Mat_SeqAIJ_Inode node_count / size (aij.h:99-115); 0 / NULL: plain routines */
+} Mat_SeqAIJ;
+
+/* device mirror */
+typedef struct {
+  PetscInt *d_i, *d_j;
+  PetscScalar *d_a;
+  mi355x_spmv_plan_t plan;
+  int uploaded_state;        /* Mat state at last upload (compare state instead of valid_GPU_matrix) */
+  /* compressed-row form for mostly-empty blocks (src/mat/utils/compressedrow.c:28) */
+  PetscBool cprow;            /* compressed-row form requested (off-diagonal block) */
+  PetscBool baij4_mfma;       /* BAIJ bs = 4: MatMult on the matrix cores (mi355x_spmv_bsr4_mfma) */
+  PetscInt pattern_nz;        /* nz of the pattern the mirror was built for (-1: none) */
+  /* cached explicit transpose for MatMultTranspose */
+  PetscInt *t_i, *t_j; PetscScalar *t_a; mi355x_spmv_plan_t t_plan; int t_state;
+  PetscInt n_uploads;        /* value uploads so far */
+  /* MatSetValuesBatch map for one connectivity (rows array): contributions grouped by nonzero, in call order */
+  PetscInt bm_nb, bm_bs, bm_nseg; unsigned long long bm_hash; size_t bm_T, bm_vcap;
+  PetscInt *bm_order, *bm_segptr, *bm_segslot;   /* device */
+  PetscScalar *bm_v;                             /* device staging of the element values */
+  /* per-launch device timing for bench.py (hipEvent pairs on the compute stream) */
+  PetscBool timing; PetscInt time_n, time_cap; mi355x_event_t *time_ev;
+} Mat_SeqAIJHIP;
+
+/* Mat_MPIAIJ, src/mat/impls/aij/mpi/mpiaij.h:35-77 */
+typedef struct {
+  Mat A, B;                 /* diagonal / off-diagonal blocks (SeqAIJHIPMI355X) */
+  PetscInt *garray, ec;
+  Vec lvec;
+  VecScatter Mvctx;
+  PetscInt rstart, rend, cstart, cend;
+} Mat_MPIAIJ;
+
+PetscErrorCode MatCreate_SeqAIJHIPMI355X(Mat);
+PetscErrorCode MatCreate_MPIAIJHIPMI355X(Mat);
+PetscErrorCode MatCreate_AIJHIPMI355X(Mat);
+PetscErrorCode MatCreate_SeqBAIJHIPMI355X(Mat);
+PetscErrorCode MatSeqAIJHIPUpload(Mat A);
+PetscErrorCode MatSeqAIJHIPSetCompressedRow(Mat A, PetscBool flg);
+PetscErrorCode MatSetUpMultiply_MPIAIJ(Mat mat);
+PetscErrorCode MatTimingBegin(Mat A, mi355x_handle_t h);
+PetscErrorCode MatTimingEnd(Mat A, mi355x_handle_t h);
+PetscErrorCode MatGetVecs_HIPMI355X(Mat A, Vec *right, Vec *left);
+PetscErrorCode PCCreate_ILU_HIPMI355X(PC);
+
+#endif

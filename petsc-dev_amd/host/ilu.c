@@ -9,7 +9,7 @@
  *            between wavefronts (mi355x_trisolve_*, csrc/trisolve.hip); -pc_factor_hipmi355x_trisolve level selects the
  *            level-scheduled kernels, one launch per dependency level (replayed from a hipGraph), which also serve
  *            systems with few levels and as the fall-back. */
-#include "petscimpl.h"
+#include "hipmi355ximpl.h"
 
 typedef struct {
   PetscInt n, nz;
@@ -246,7 +246,7 @@ static PetscErrorCode PCDestroy_ILU(PC pc) {
   return 0;
 }
 
-PetscErrorCode PCCreate_ILU(PC pc) {
+PetscErrorCode PCCreate_ILU_HIPMI355X(PC pc) {
   PC_ILU *f;
   PetscErrorCode ierr = PetscMalloc(sizeof(*f), &f);CHKERRQ(ierr);
   memset(f, 0, sizeof(*f));

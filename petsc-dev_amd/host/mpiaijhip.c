@@ -2,10 +2,9 @@
  * src/mat/impls/aij/mpi/mpiaij.c:1102-1238 and mmaij.c:9-161; the GPU subclass role of
  * src/mat/impls/aij/mpi/mpicusp/mpiaijcusp.cu:85-112,204-235.  A (diagonal block, local columns)
  * and B (off-diagonal block, columns compacted through garray) are MATSEQAIJHIPMI355X. */
-#include "petscimpl.h"
+#include "hipmi355ximpl.h"
 
 #define MA(A) ((Mat_MPIAIJ *)(A)->data)
-extern PetscErrorCode MatGetVecs_HIPMI355X(Mat A, Vec *right, Vec *left);
 
 static PetscErrorCode make_block(Mat parent, PetscInt m, PetscInt n, Mat *blk) {
   PetscErrorCode ierr;
@@ -16,9 +15,10 @@ static PetscErrorCode make_block(Mat parent, PetscInt m, PetscInt n, Mat *blk) {
   return 0;
 }
 
-PetscErrorCode MatMPIAIJSetPreallocation(Mat A, PetscInt d_nz, const PetscInt d_nnz[], PetscInt o_nz, const PetscInt o_nnz[]) {
+/* "MatMPIAIJSetPreallocation_C" (MatMPIAIJSetPreallocation_MPIAIJ, mpiaij.c; recomposed by the GPU subclass as in
+ * mpiaijcusp.cu:36-46,213-215) */
+static PetscErrorCode MatMPIAIJSetPreallocation_MPIAIJHIP(Mat A, PetscInt d_nz, const PetscInt d_nnz[], PetscInt o_nz, const PetscInt o_nnz[]) {
   PetscErrorCode ierr;
-  if (!A || strcmp(A->type_name, MATMPIAIJHIPMI355X)) return 0;   /* composed-function no-op for other types */
   Mat_MPIAIJ *a = MA(A);
   if (d_nz == PETSC_DEFAULT || d_nz == PETSC_DECIDE) d_nz = 5;     /* mpiaij.c MatMPIAIJSetPreallocation_MPIAIJ */
   if (o_nz == PETSC_DEFAULT || o_nz == PETSC_DECIDE) o_nz = 2;
@@ -31,7 +31,7 @@ PetscErrorCode MatMPIAIJSetPreallocation(Mat A, PetscInt d_nz, const PetscInt d_
   A->preallocated = PETSC_TRUE;
   return 0;
 }
-static PetscErrorCode MatSetUp_MPIAIJHIP(Mat A) { return MatMPIAIJSetPreallocation(A, PETSC_DEFAULT, NULL, PETSC_DEFAULT, NULL); }
+static PetscErrorCode MatSetUp_MPIAIJHIP(Mat A) { return MatMPIAIJSetPreallocation_MPIAIJHIP(A, PETSC_DEFAULT, NULL, PETSC_DEFAULT, NULL); }
 
 static int cmp_int(const void *a, const void *b) { PetscInt x = *(const PetscInt *)a, y = *(const PetscInt *)b; return (x > y) - (x < y); }
 
@@ -197,6 +197,9 @@ static PetscErrorCode MatDestroy_MPIAIJHIP(Mat A) {
   return 0;
 }
 
+static PetscErrorCode MatMPIAIJSetPreallocationCSR_MPIAIJHIP(Mat A, const PetscInt i[], const PetscInt j[], const PetscScalar a[]);
+static PetscErrorCode MatGetDiagonalBlock_MPIAIJHIP(Mat A, Mat *a) { *a = MA(A)->A; return 0; }   /* MatGetDiagonalBlock_MPIAIJ, mpiaij.c */
+
 PetscErrorCode MatCreate_MPIAIJHIPMI355X(Mat B) {   /* MatCreate_MPIAIJCUSP, mpiaijcusp.cu:204-235 */
   PetscErrorCode ierr;
   Mat_MPIAIJ *a;
@@ -204,40 +207,40 @@ PetscErrorCode MatCreate_MPIAIJHIPMI355X(Mat B) {   /* MatCreate_MPIAIJCUSP, mpi
   memset(a, 0, sizeof(*a));
   a->rstart = B->rmap->rstart; a->rend = B->rmap->rend; a->cstart = B->cmap->rstart; a->cend = B->cmap->rend;
   B->data = a;
-  snprintf(B->type_name, sizeof(B->type_name), "%s", MATMPIAIJHIPMI355X);
-  MatOps *o = B->ops;
-  o->setvalues = MatSetValues_MPIAIJHIP; o->mult = MatMult_MPIAIJHIP; o->multadd = MatMultAdd_MPIAIJHIP;
-  o->multtranspose = MatMultTranspose_MPIAIJHIP; o->multtransposeadd = MatMultTransposeAdd_MPIAIJHIP;
-  o->getdiagonal = MatGetDiagonal_MPIAIJHIP; o->assemblyend = MatAssemblyEnd_MPIAIJHIP; o->zeroentries = MatZeroEntries_MPIAIJHIP;
-  o->setup = MatSetUp_MPIAIJHIP; o->scale = MatScale_MPIAIJHIP; o->diagonalscale = MatDiagonalScale_MPIAIJHIP; o->destroy = MatDestroy_MPIAIJHIP; o->getvecs = MatGetVecs_HIPMI355X;
+  ierr = PetscObjectChangeTypeName((PetscObject)B, MATMPIAIJHIPMI355X);CHKERRQ(ierr);
+  B->ops->setvalues = MatSetValues_MPIAIJHIP;
+  B->ops->mult = MatMult_MPIAIJHIP;
+  B->ops->multadd = MatMultAdd_MPIAIJHIP;
+  B->ops->multtranspose = MatMultTranspose_MPIAIJHIP;
+  B->ops->multtransposeadd = MatMultTransposeAdd_MPIAIJHIP;
+  B->ops->getdiagonal = MatGetDiagonal_MPIAIJHIP;
+  B->ops->assemblyend = MatAssemblyEnd_MPIAIJHIP;
+  B->ops->zeroentries = MatZeroEntries_MPIAIJHIP;
+  B->ops->setup = MatSetUp_MPIAIJHIP;
+  B->ops->scale = MatScale_MPIAIJHIP;
+  B->ops->diagonalscale = MatDiagonalScale_MPIAIJHIP;
+  B->ops->destroy = MatDestroy_MPIAIJHIP;
+  B->ops->getvecs = MatGetVecs_HIPMI355X;
+  ierr = PetscObjectComposeFunction((PetscObject)B, "MatMPIAIJSetPreallocation_C", (PetscVoidFunction)MatMPIAIJSetPreallocation_MPIAIJHIP);CHKERRQ(ierr);
+  ierr = PetscObjectComposeFunction((PetscObject)B, "MatMPIAIJSetPreallocationCSR_C", (PetscVoidFunction)MatMPIAIJSetPreallocationCSR_MPIAIJHIP);CHKERRQ(ierr);
+  ierr = PetscObjectComposeFunction((PetscObject)B, "MatGetDiagonalBlock_C", (PetscVoidFunction)MatGetDiagonalBlock_MPIAIJHIP);CHKERRQ(ierr);
   return 0;
 }
 /* base name "aijhipmi355x" -> seq or mpi by communicator size (MatRegisterBaseName, matreg.c:161-180) */
 PetscErrorCode MatCreate_AIJHIPMI355X(Mat B) {
-  return (B->comm->size == 1) ? MatCreate_SeqAIJHIPMI355X(B) : MatCreate_MPIAIJHIPMI355X(B);
+  return (HipCommSize(B->comm) == 1) ? MatCreate_SeqAIJHIPMI355X(B) : MatCreate_MPIAIJHIPMI355X(B);
 }
 
-/* MatCreateMPIAIJWithArrays (mpiaij.c; via MatMPIAIJSetPreallocationCSR): i/j/a hold this rank's rows with
- * global, ascending column indices.  The split is the column test of MatSetValues_MPIAIJ done in bulk. */
-PetscErrorCode MatMPIAIJSetCSR_Private(Mat A, PetscInt m, const PetscInt i[], const PetscInt j[], const PetscScalar a[]);
-PetscErrorCode MatCreateMPIAIJWithArrays(MPI_Comm comm, PetscInt m, PetscInt n, PetscInt M, PetscInt N, const PetscInt i[], const PetscInt j[], const PetscScalar a[], Mat *mat) {
+/* "MatMPIAIJSetPreallocationCSR_C" (MatMPIAIJSetPreallocationCSR_MPIAIJ, mpiaij.c:3900-3960): fills the matrix from this
+ * rank's rows in CSR form, global ascending column indices.  The split is the column test of MatSetValues_MPIAIJ in bulk. */
+static PetscErrorCode MatMPIAIJSetPreallocationCSR_MPIAIJHIP(Mat A, const PetscInt i[], const PetscInt j[], const PetscScalar a[]) {
   PetscErrorCode ierr;
-  Mat A;
-  if (i[0]) SETERRQ(comm, PETSC_ERR_ARG_OUTOFRANGE, "i (row indices) must start with 0");
-  if (m < 0) SETERRQ(comm, PETSC_ERR_ARG_OUTOFRANGE, "local number of rows (m) cannot be PETSC_DECIDE, or negative");
-  ierr = MatCreate(comm, &A);CHKERRQ(ierr);
-  ierr = MatSetSizes(A, m, n, M, N);CHKERRQ(ierr);
-  ierr = MatSetType(A, MATMPIAIJHIPMI355X);CHKERRQ(ierr);
-  ierr = MatMPIAIJSetCSR_Private(A, m, i, j, a);CHKERRQ(ierr);
-  *mat = A;
-  return 0;
-}
-
-/* fills an (empty) MATMPIAIJHIPMI355X from this rank's rows in CSR form (MatMPIAIJSetPreallocationCSR, mpiaij.c) */
-PetscErrorCode MatMPIAIJSetCSR_Private(Mat A, PetscInt m, const PetscInt i[], const PetscInt j[], const PetscScalar a[]) {
-  PetscErrorCode ierr;
-  if (m != A->rmap->n) SETERRQ(A->comm, PETSC_ERR_ARG_SIZ, "local row count %d does not match the layout %d", m, A->rmap->n);
+  const PetscInt m = A->rmap->n;
+  MPI_Comm comm = HipObjComm(A);
   Mat_MPIAIJ *aij = MA(A);
+  (void)comm;
+  if (i[0]) SETERRQ(comm, PETSC_ERR_ARG_OUTOFRANGE, "i (row indices) must start with 0");
+  if (aij->A) { ierr = MatDestroy(&aij->A);CHKERRQ(ierr); ierr = MatDestroy(&aij->B);CHKERRQ(ierr); }
   PetscInt cs = aij->cstart, ce = aij->cend, nd = 0, no = 0;
   for (PetscInt k = 0; k < i[m]; k++) { if (j[k] >= cs && j[k] < ce) nd++; else no++; }
   PetscInt *di, *dj, *oi, *oj; PetscScalar *da, *oa;
@@ -257,12 +260,14 @@ PetscErrorCode MatMPIAIJSetCSR_Private(Mat A, PetscInt m, const PetscInt i[], co
     }
     di[r + 1] = nd; oi[r + 1] = no;
   }
-  ierr = MatCreateSeqAIJWithArrays(PETSC_COMM_SELF, m, A->cmap->n, di, dj, da, &aij->A);CHKERRQ(ierr);
-  ierr = MatCreateSeqAIJWithArrays(PETSC_COMM_SELF, m, A->cmap->N, oi, oj, oa, &aij->B);CHKERRQ(ierr);
+  ierr = make_block(A, m, A->cmap->n, &aij->A);CHKERRQ(ierr);
+  ierr = MatSeqAIJSetPreallocationCSR(aij->A, di, dj, da);CHKERRQ(ierr);
+  ierr = make_block(A, m, A->cmap->N, &aij->B);CHKERRQ(ierr);
+  ierr = MatSeqAIJSetPreallocationCSR(aij->B, oi, oj, oa);CHKERRQ(ierr);
   free(di); free(dj); free(da); free(oi); free(oj); free(oa);
   A->preallocated = PETSC_TRUE;
   ierr = MatSetUpMultiply_MPIAIJ(A);CHKERRQ(ierr);
-  A->assembled = PETSC_TRUE; A->was_assembled = PETSC_TRUE; A->state++;
+  A->assembled = PETSC_TRUE; A->was_assembled = PETSC_TRUE; PetscObjectStateIncrease(A);
   return 0;
 }
 
@@ -278,17 +283,5 @@ PetscErrorCode MatMPIAIJGetScatter(Mat A, VecScatter *ctx, Vec *lvec, PetscInt *
   if (ctx) *ctx = MA(A)->Mvctx;
   if (lvec) *lvec = MA(A)->lvec;
   if (ec) *ec = MA(A)->ec;
-  return 0;
-}
-
-PetscErrorCode PetscHIPMI355XRegisterAll(void) {
-  PetscErrorCode ierr;
-  ierr = VecRegister(VECSEQHIPMI355X, VecCreate_SeqHIPMI355X);CHKERRQ(ierr);
-  ierr = VecRegister(VECMPIHIPMI355X, VecCreate_MPIHIPMI355X);CHKERRQ(ierr);
-  ierr = VecRegister(VECHIPMI355X, VecCreate_HIPMI355X);CHKERRQ(ierr);
-  ierr = MatRegister(MATSEQAIJHIPMI355X, MatCreate_SeqAIJHIPMI355X);CHKERRQ(ierr);
-  ierr = MatRegister(MATMPIAIJHIPMI355X, MatCreate_MPIAIJHIPMI355X);CHKERRQ(ierr);
-  ierr = MatRegister(MATAIJHIPMI355X, MatCreate_AIJHIPMI355X);CHKERRQ(ierr);
-  ierr = MatRegister(MATSEQBAIJHIPMI355X, MatCreate_SeqBAIJHIPMI355X);CHKERRQ(ierr);
   return 0;
 }

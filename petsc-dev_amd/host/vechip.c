@@ -5,9 +5,10 @@
  * cuspvecimpl.h:95-150.  Reductions: device two-level tree -> (RCCL all-reduce when the
  * communicator has more than one rank, replacing MPI_Allreduce of pbvec.c:16,30 / pvec2.c:20,62-80)
  * -> pinned host scalar -> one stream synchronise. */
-#include "petscimpl.h"
+#include "hipmi355ximpl.h"
 
 #define VH(v) ((Vec_HIPMI355X *)(v)->data)
+PetscErrorCode VecCGUpdateCheck_HIPMI355X(Vec x, Vec r, Vec z, Vec p, Vec w, Vec d, PetscBool *ok);
 
 static PetscErrorCode dev_alloc(Vec v) {
   Vec_HIPMI355X *s = VH(v);
@@ -87,11 +88,6 @@ static PetscErrorCode VecGetArray_HIP(Vec v, PetscScalar **a) {
   return 0;
 }
 static PetscErrorCode VecRestoreArray_HIP(Vec v, PetscScalar **a) { if (a) *a = NULL; VH(v)->valid = VALID_HOST; return 0; }
-static PetscErrorCode VecGetArrayRead_HIP(Vec v, const PetscScalar **a) {
-  PetscErrorCode ierr = to_host(v);CHKERRQ(ierr);
-  *a = VH(v)->host;
-  return 0;
-}
 /* VecPlaceArray_SeqCUSP (veccusp.cu): adopt a host array; the device copy is refreshed on next use */
 static PetscErrorCode VecPlaceArray_HIP(Vec v, const PetscScalar *a) {
   Vec_HIPMI355X *s = VH(v);
@@ -250,8 +246,8 @@ static PetscErrorCode VecMAXPY_HIP(Vec y, PetscInt nv, const PetscScalar *alpha,
  * over RCCL on the same stream, copied to the pinned scratch, and only then do we synchronise. */
 /* A communicator with an RCCL communicator attached reduces on the device (also a one-rank one: the tests use that
  * to run this path on a single GPU); several ranks without one use the host-staged transport. */
-#define DEVICE_COLLECTIVES(x) ((x)->comm->dcomm != NULL)
-#define HOST_STAGED(x) ((x)->comm->size > 1 && !(x)->comm->dcomm)
+#define DEVICE_COLLECTIVES(x) (HipCommDevice((x)->comm) != NULL)
+#define HOST_STAGED(x) (HipCommSize((x)->comm) > 1 && !HipCommDevice((x)->comm))
 static PetscErrorCode reduce_target(Vec x, PetscDeviceCtx *dc, double **out) {
   *out = DEVICE_COLLECTIVES(x) ? mi355x_handle_device_scratch(dc->h) : mi355x_handle_host_scratch(dc->h);
   return 0;
@@ -265,13 +261,13 @@ static PetscErrorCode reduce_finish2(Vec x, PetscDeviceCtx *dc, int nsum, int co
      * reduction followed by a host all-reduce (mpicusp.cu:32-113); used by the shared-GPU rehearsal tests */
     CHKHIP(mi355x_handle_synchronize(dc->h));
     for (int j = 0; j < count; j++) result[j] = hs[j];
-    if (x->comm->allreduce(x->comm->ctx, result, nsum, 1, is_max ? 1 : 0)) SETERRQ(x->comm, PETSC_ERR_LIB, "allreduce failed");
+    if (HipCommAllreduce(x->comm, result, nsum, 1, is_max ? 1 : 0)) SETERRQ(x->comm, PETSC_ERR_LIB, "allreduce failed");
     return 0;
   }
   if (DEVICE_COLLECTIVES(x)) {
     double *ds = mi355x_handle_device_scratch(dc->h);
-    if (is_max) CHKHIP(mi355x_comm_allreduce_max(x->comm->dcomm, dc->h, ds, (size_t)nsum));
-    else CHKHIP(mi355x_comm_allreduce_sum(x->comm->dcomm, dc->h, ds, (size_t)nsum));
+    if (is_max) CHKHIP(mi355x_comm_allreduce_max(HipCommDevice(x->comm), dc->h, ds, (size_t)nsum));
+    else CHKHIP(mi355x_comm_allreduce_sum(HipCommDevice(x->comm), dc->h, ds, (size_t)nsum));
     /* device -> pinned host by a tiny kernel on the same stream that also stores the completion number the host
      * polls: no stream synchronisation, and kernels queued behind it do not delay the result */
     CHKHIP(mi355x_handle_publish(dc->h, ds, count));
@@ -386,7 +382,7 @@ PetscErrorCode VecTDotBegin_HIPMI355X(Vec x, Vec y, PetscBool *ok) {
   ierr = VecHIPGetRead(y, &dy);CHKERRQ(ierr);
   ds = mi355x_handle_device_scratch(dc->h) + DPI_SLOT;
   CHKHIP(mi355x_vec_dot(dc->h, N_(x), dx, dy, ds));
-  if (DEVICE_COLLECTIVES(x)) CHKHIP(mi355x_comm_allreduce_sum(x->comm->dcomm, dc->h, ds, 1));
+  if (DEVICE_COLLECTIVES(x)) CHKHIP(mi355x_comm_allreduce_sum(HipCommDevice(x->comm), dc->h, ds, 1));
   if (x->map->n > 0) { ierr = PetscLogFlops(2.0 * x->map->n - 1);CHKERRQ(ierr); }
   *ok = PETSC_TRUE;
   return 0;
@@ -411,7 +407,7 @@ PetscErrorCode VecCGUpdateDevBegin_HIPMI355X(Vec x, Vec r, Vec z, Vec p, Vec w, 
   VecHIPRestoreWrite(x); VecHIPRestoreWrite(r); VecHIPRestoreWrite(z);
   PetscObjectStateIncrease(x); PetscObjectStateIncrease(r); PetscObjectStateIncrease(z);
   if (DEVICE_COLLECTIVES(x)) {
-    CHKHIP(mi355x_comm_allreduce_sum(x->comm->dcomm, dc->h, ds, 3));
+    CHKHIP(mi355x_comm_allreduce_sum(HipCommDevice(x->comm), dc->h, ds, 3));
     CHKHIP(mi355x_handle_publish(dc->h, ds, 4));
   }
   ierr = PetscLogFlops(9.0 * x->map->n);CHKERRQ(ierr);
@@ -530,7 +526,7 @@ static PetscErrorCode sr_queue(Vec x, int kind, const PetscScalar *dx, const Pet
   sr.kind[sr.n++] = kind; sr.owner = x;
   return 0;
 }
-PetscErrorCode VecDotBegin(Vec x, Vec y, PetscScalar *result) {
+static PetscErrorCode VecDotBegin_HIP(Vec x, Vec y, PetscScalar *result) {
   PetscErrorCode ierr; const PetscScalar *dx, *dy;
   (void)result;
   CheckHIP(x); CheckHIP(y);
@@ -541,7 +537,7 @@ PetscErrorCode VecDotBegin(Vec x, Vec y, PetscScalar *result) {
   if (x->map->n > 0) { ierr = PetscLogFlops(2.0 * x->map->n - 1);CHKERRQ(ierr); }
   return 0;
 }
-PetscErrorCode VecNormBegin(Vec x, NormType type, PetscReal *result) {
+static PetscErrorCode VecNormBegin_HIP(Vec x, NormType type, PetscReal *result) {
   PetscErrorCode ierr; const PetscScalar *dx;
   (void)result;
   CheckHIP(x);
@@ -551,7 +547,7 @@ PetscErrorCode VecNormBegin(Vec x, NormType type, PetscReal *result) {
   ierr = PetscLogFlops(PetscMax(2.0 * x->map->n - 1, 0.0));CHKERRQ(ierr);
   return 0;
 }
-PetscErrorCode PetscCommSplitReductionBegin(MPI_Comm comm) {
+static PetscErrorCode PetscCommSplitReductionBegin_HIP(MPI_Comm comm) {
   PetscErrorCode ierr; DEVCTX;
   (void)comm;
   if (!sr.n || sr.started) return 0;
@@ -563,7 +559,7 @@ PetscErrorCode PetscCommSplitReductionBegin(MPI_Comm comm) {
     if (!sr.ev) CHKHIP(mi355x_event_create(&sr.ev));
     CHKHIP(mi355x_event_record(sr.ev, dc->h));                    /* the reductions queued so far */
     CHKHIP(mi355x_handle_wait_event(dc->hcomm, sr.ev));
-    CHKHIP(mi355x_comm_allreduce_sum(x->comm->dcomm_halo, dc->hcomm, ds, (size_t)sr.n));   /* halo stream: its own communicator */
+    CHKHIP(mi355x_comm_allreduce_sum(HipCommDeviceHalo(x->comm), dc->hcomm, ds, (size_t)sr.n));   /* halo stream: its own communicator */
     CHKHIP(mi355x_handle_publish_at(dc->hcomm, ds, sr.n, SR_HOST0));   /* lands in the HALO handle's pinned scratch */
   } else {
     CHKHIP(mi355x_handle_publish_at(dc->h, ds, sr.n, SR_HOST0));
@@ -580,7 +576,7 @@ static PetscErrorCode sr_fetch(Vec x) {
       CHKHIP(mi355x_handle_synchronize(dc->h));
       const double *hs = mi355x_handle_host_scratch(dc->h) + SR_HOST0;
       for (int j = 0; j < sr.n; j++) sr.val[j] = hs[j];
-      if (o->comm->allreduce(o->comm->ctx, sr.val, sr.n, 1, 0)) SETERRQ(o->comm, PETSC_ERR_LIB, "allreduce failed");
+      if (HipCommAllreduce(o->comm, sr.val, sr.n, 1, 0)) SETERRQ(o->comm, PETSC_ERR_LIB, "allreduce failed");
     } else {
       mi355x_handle_t hh = DEVICE_COLLECTIVES(o) ? dc->hcomm : dc->h;
       CHKHIP(mi355x_handle_wait_result(hh));
@@ -599,8 +595,8 @@ static PetscErrorCode sr_take(Vec x, int kind, PetscScalar *out) {
   if (sr.fetched == sr.n) { sr.n = 0; sr.started = 0; sr.fetched = 0; sr.owner = NULL; }
   return 0;
 }
-PetscErrorCode VecDotEnd(Vec x, Vec y, PetscScalar *result) { (void)y; return sr_take(x, 0, result); }
-PetscErrorCode VecNormEnd(Vec x, NormType type, PetscReal *result) {
+static PetscErrorCode VecDotEnd_HIP(Vec x, Vec y, PetscScalar *result) { (void)y; return sr_take(x, 0, result); }
+static PetscErrorCode VecNormEnd_HIP(Vec x, NormType type, PetscReal *result) {
   PetscScalar v;
   (void)type;
   PetscErrorCode ierr = sr_take(x, 1, &v);CHKERRQ(ierr);
@@ -612,6 +608,7 @@ static PetscErrorCode VecDestroy_HIP(Vec v) {
   Vec_HIPMI355X *s = VH(v);
   if (!s) return 0;
   if (s->placed_save) { s->host = s->placed_save; s->placed_save = NULL; }
+  if (s->alias_save) { s->dev = s->alias_save; s->alias_save = NULL; }   /* never free storage borrowed from another vector */
   if (s->dev) mi355x_free(s->dev);
   if (s->host && s->host_owned) free(s->host);
   free(s);
@@ -619,42 +616,124 @@ static PetscErrorCode VecDestroy_HIP(Vec v) {
   return 0;
 }
 
-static PetscErrorCode VecDuplicate_HIP(Vec v, Vec *newv) {
+static PetscErrorCode VecDuplicate_HIP(Vec v, Vec *newv) {   /* VecDuplicate_SeqCUSP / _MPICUSP: same type, same layout */
   PetscErrorCode ierr;
   Vec w;
-  ierr = VecCreate(v->comm, &w);CHKERRQ(ierr);
+  ierr = VecCreate(HipObjComm(v), &w);CHKERRQ(ierr);
   ierr = PetscLayoutReference(v->map, &w->map);CHKERRQ(ierr);
-  ierr = (*v->ops->create)(w);CHKERRQ(ierr);
+  ierr = VecSetType(w, HipObjTypeName(v));CHKERRQ(ierr);
   *newv = w;
   return 0;
 }
 
-static PetscErrorCode VecCreate_HIP_common(Vec v, const char *tname, VecCreateFn self) {
+/* ---- methods beyond the function table, offered by name (PetscObjectComposeFunction) ---- */
+/* "VecJacobiInvert_C": d = (d == 0) ? 1 : 1/d on the device (PCSetUp_Jacobi's host loop, jacobi.c:182-190) */
+static PetscErrorCode VecJacobiInvert_HIP(Vec d) {
+  PetscErrorCode ierr; PetscScalar *dd; PetscDeviceCtx *dc;
+  ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
+  ierr = VecHIPGetReadWrite(d, &dd);CHKERRQ(ierr);
+  CHKHIP(mi355x_vec_jacobi_invert(dc->h, (size_t)d->map->n, dd, NULL));
+  return VecHIPRestoreWrite(d);
+}
+/* "VecShareArrayBegin_C" / "VecShareArrayEnd_C": sub borrows parent's DEVICE storage (PCApply_BJacobi_Singleblock's
+ * VecPlaceArray of host arrays, bjacobi.c:738-761, without the host round trip) */
+static PetscErrorCode VecShareArrayBegin_HIP(Vec sub, Vec parent, PetscBool write) {
+  PetscErrorCode ierr;
+  Vec_HIPMI355X *s = VH(sub);
+  PetscScalar *dp;
+  if (!parent->data || !strstr(HipObjTypeName(parent), "hipmi355x")) SETERRQ(HipObjComm(sub), PETSC_ERR_ARG_NOTSAMETYPE, "cannot share the storage of a %s vector", HipObjTypeName(parent));
+  if (s->alias_save) SETERRQ(HipObjComm(sub), PETSC_ERR_ARG_WRONGSTATE, "vector already shares another vector's storage");
+  if (sub->map->n != parent->map->n) SETERRQ(HipObjComm(sub), PETSC_ERR_ARG_SIZ, "local sizes %d and %d differ", sub->map->n, parent->map->n);
+  if (write) { ierr = VecHIPGetWrite(parent, &dp);CHKERRQ(ierr); }
+  else { const PetscScalar *cp; ierr = VecHIPGetRead(parent, &cp);CHKERRQ(ierr); dp = (PetscScalar *)cp; }
+  ierr = VecHIPGetWrite(sub, &s->alias_save);CHKERRQ(ierr);      /* makes sure sub owns device storage to come back to */
+  s->alias_valid = s->valid;
+  s->dev = dp; s->valid = VALID_DEVICE;
+  PetscObjectStateIncrease(sub);
+  return 0;
+}
+static PetscErrorCode VecShareArrayEnd_HIP(Vec sub, Vec parent, PetscBool write) {
+  Vec_HIPMI355X *s = VH(sub);
+  if (!s->alias_save) return 0;
+  s->dev = s->alias_save; s->valid = s->alias_valid; s->alias_save = NULL;
+  PetscObjectStateIncrease(sub);
+  if (write) return VecHIPRestoreWrite(parent);
+  return 0;
+}
+/* "VecKrylovFusedOps_C": the fused sweeps of KSPSolve_CG / KSPSolve_BCGS, bit-identical to the calls they replace */
+static const VecKrylovFusedOps *VecKrylovFusedOps_HIP(void) {
+  static const VecKrylovFusedOps ops = {
+    VecCGUpdate_HIPMI355X, VecCGUpdateCheck_HIPMI355X, VecTDotBegin_HIPMI355X, VecCGUpdateDevBegin_HIPMI355X, VecCGUpdateDevEnd_HIPMI355X,
+    VecAYPXDev_HIPMI355X, VecPMultDot_HIPMI355X, VecPMultDotNorm2_HIPMI355X, VecBCGSUpdate_HIPMI355X};
+  return &ops;
+}
+/* "VecSplitReductionOps_C": VecDotBegin/End, VecNormBegin/End, PetscCommSplitReductionBegin (comb.c:402-721) with the
+ * all-reduce on the halo stream */
+typedef struct {
+  PetscErrorCode (*dot_begin)(Vec, Vec, PetscScalar *);
+  PetscErrorCode (*dot_end)(Vec, Vec, PetscScalar *);
+  PetscErrorCode (*norm_begin)(Vec, NormType, PetscReal *);
+  PetscErrorCode (*norm_end)(Vec, NormType, PetscReal *);
+  PetscErrorCode (*comm_begin)(MPI_Comm);
+} VecSplitReductionOps;
+static const VecSplitReductionOps *VecSplitReductionOps_HIP(void) {
+  static const VecSplitReductionOps ops = {VecDotBegin_HIP, VecDotEnd_HIP, VecNormBegin_HIP, VecNormEnd_HIP, PetscCommSplitReductionBegin_HIP};
+  return &ops;
+}
+
+/* the common part of VecCreate_SeqCUSP (veccusp.cu:1905-1947) / VecCreate_MPICUSP (mpicusp.cu:179-230): the function-table
+ * slots those constructors override, and petscnative = PETSC_FALSE so that VecGetArray / VecRestoreArray of user code come
+ * through ops->getarray / restorearray (vecimpl.h:375-434) */
+static PetscErrorCode VecCreate_HIP_common(Vec v, const char *tname) {
   PetscErrorCode ierr;
   Vec_HIPMI355X *s;
   ierr = PetscMalloc(sizeof(*s), &s);CHKERRQ(ierr);
   memset(s, 0, sizeof(*s));
   v->data = s;
-  snprintf(v->type_name, sizeof(v->type_name), "%s", tname);
-  VecOps *o = v->ops;
-  o->duplicate = VecDuplicate_HIP; o->dot = VecDot_HIP; o->tdot = VecDot_HIP; o->mdot = VecMDot_HIP; o->mtdot = VecMDot_HIP;
-  o->norm = VecNorm_HIP; o->scale = VecScale_HIP; o->copy = VecCopy_HIP; o->set = VecSet_HIP; o->swap = VecSwap_HIP;
-  o->axpy = VecAXPY_HIP; o->axpby = VecAXPBY_HIP; o->maxpy = VecMAXPY_HIP; o->aypx = VecAYPX_HIP; o->waxpy = VecWAXPY_HIP;
-  o->axpbypcz = VecAXPBYPCZ_HIP; o->pointwisemult = VecPointwiseMult_HIP; o->pointwisedivide = VecPointwiseDivide_HIP;
-  o->setvalues = VecSetValues_HIP; o->getarray = VecGetArray_HIP; o->restorearray = VecRestoreArray_HIP;
-  o->getarrayread = VecGetArrayRead_HIP; o->placearray = VecPlaceArray_HIP; o->resetarray = VecResetArray_HIP;
-  o->destroy = VecDestroy_HIP; o->reciprocal = VecReciprocal_HIP; o->dotnorm2 = VecDotNorm2_HIP; o->create = self;
+  v->petscnative = PETSC_FALSE;
+  ierr = PetscObjectChangeTypeName((PetscObject)v, tname);CHKERRQ(ierr);
+  v->ops->duplicate = VecDuplicate_HIP;
+  v->ops->dot = VecDot_HIP;
+  v->ops->tdot = VecDot_HIP;
+  v->ops->mdot = VecMDot_HIP;
+  v->ops->mtdot = VecMDot_HIP;
+  v->ops->norm = VecNorm_HIP;
+  v->ops->scale = VecScale_HIP;
+  v->ops->copy = VecCopy_HIP;
+  v->ops->set = VecSet_HIP;
+  v->ops->swap = VecSwap_HIP;
+  v->ops->axpy = VecAXPY_HIP;
+  v->ops->axpby = VecAXPBY_HIP;
+  v->ops->maxpy = VecMAXPY_HIP;
+  v->ops->aypx = VecAYPX_HIP;
+  v->ops->waxpy = VecWAXPY_HIP;
+  v->ops->axpbypcz = VecAXPBYPCZ_HIP;
+  v->ops->pointwisemult = VecPointwiseMult_HIP;
+  v->ops->pointwisedivide = VecPointwiseDivide_HIP;
+  v->ops->setvalues = VecSetValues_HIP;
+  v->ops->getarray = VecGetArray_HIP;
+  v->ops->restorearray = VecRestoreArray_HIP;
+  v->ops->placearray = VecPlaceArray_HIP;
+  v->ops->resetarray = VecResetArray_HIP;
+  v->ops->destroy = VecDestroy_HIP;
+  v->ops->reciprocal = VecReciprocal_HIP;
+  v->ops->dotnorm2 = VecDotNorm2_HIP;
+  ierr = PetscObjectComposeFunction((PetscObject)v, "VecJacobiInvert_C", (PetscVoidFunction)VecJacobiInvert_HIP);CHKERRQ(ierr);
+  ierr = PetscObjectComposeFunction((PetscObject)v, "VecShareArrayBegin_C", (PetscVoidFunction)VecShareArrayBegin_HIP);CHKERRQ(ierr);
+  ierr = PetscObjectComposeFunction((PetscObject)v, "VecShareArrayEnd_C", (PetscVoidFunction)VecShareArrayEnd_HIP);CHKERRQ(ierr);
+  ierr = PetscObjectComposeFunction((PetscObject)v, "VecKrylovFusedOps_C", (PetscVoidFunction)VecKrylovFusedOps_HIP);CHKERRQ(ierr);
+  ierr = PetscObjectComposeFunction((PetscObject)v, "VecSplitReductionOps_C", (PetscVoidFunction)VecSplitReductionOps_HIP);CHKERRQ(ierr);
   return 0;
 }
 
 PetscErrorCode VecCreate_SeqHIPMI355X(Vec v) {
-  if (v->comm->size > 1) SETERRQ(v->comm, PETSC_ERR_ARG_WRONG, "Cannot create VECSEQHIPMI355X on more than one process");
-  return VecCreate_HIP_common(v, VECSEQHIPMI355X, VecCreate_SeqHIPMI355X);
+  if (HipCommSize(v->comm) > 1) SETERRQ(v->comm, PETSC_ERR_ARG_WRONG, "Cannot create VECSEQHIPMI355X on more than one process");
+  return VecCreate_HIP_common(v, VECSEQHIPMI355X);
 }
-PetscErrorCode VecCreate_MPIHIPMI355X(Vec v) { return VecCreate_HIP_common(v, VECMPIHIPMI355X, VecCreate_MPIHIPMI355X); }
+PetscErrorCode VecCreate_MPIHIPMI355X(Vec v) { return VecCreate_HIP_common(v, VECMPIHIPMI355X); }
 /* size dispatch, as VecCreate_CUSP mpicusp.cu:232-246 */
 PetscErrorCode VecCreate_HIPMI355X(Vec v) {
-  return (v->comm->size == 1) ? VecCreate_SeqHIPMI355X(v) : VecCreate_MPIHIPMI355X(v);
+  return (HipCommSize(v->comm) == 1) ? VecCreate_SeqHIPMI355X(v) : VecCreate_MPIHIPMI355X(v);
 }
 PetscErrorCode VecCreateSeqHIPMI355X(MPI_Comm comm, PetscInt n, Vec *v) {
   PetscErrorCode ierr;

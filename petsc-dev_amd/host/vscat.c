@@ -5,7 +5,7 @@
  * (vpscat.h:14-233: pack, persistent MPI_Start, MPI_Waitany, unpack) by
  *     device pack kernel -> RCCL grouped send/recv over xGMI on the halo stream -> device unpack,
  * ordered against the compute stream with two HIP events so the diagonal-block SpMV overlaps it. */
-#include "petscimpl.h"
+#include "hipmi355ximpl.h"
 
 static int owner_of(int size, const PetscInt *range, PetscInt idx) {   /* vpscat.c:1762-1772 */
   for (int j = 0; j < size; j++) if (idx < range[j + 1]) return j;
@@ -17,17 +17,17 @@ static PetscBool is_contiguous(const PetscInt *idx, PetscInt n) {
   return PETSC_TRUE;
 }
 
-PetscErrorCode VecScatterCreate_PtoS_MPIAIJ(MPI_Comm comm, PetscLayout *xmap, PetscInt ec, const PetscInt *garray, VecScatter *out) {
+PetscErrorCode VecScatterCreate_PtoS_MPIAIJ(MPI_Comm comm, PetscLayout xmap, PetscInt ec, const PetscInt *garray, VecScatter *out) {
   PetscErrorCode ierr;
   VecScatter ctx;
-  int size = comm->size, rank = comm->rank;
+  int size = HipCommSize(comm), rank = HipCommRank(comm);
   PetscInt *ecs, maxec = 0, *all = NULL;
   ierr = PetscMalloc(sizeof(*ctx), &ctx);CHKERRQ(ierr);
   memset(ctx, 0, sizeof(*ctx));
   ctx->comm = comm;
   ierr = PetscMalloc(sizeof(PetscInt) * (size_t)size, &ecs);CHKERRQ(ierr);
   if (size > 1) {
-    if (comm->allgather(comm->ctx, &ec, (int)sizeof(PetscInt), ecs)) SETERRQ(comm, PETSC_ERR_LIB, "allgather failed");
+    if (HipCommAllgather(comm, &ec, (int)sizeof(PetscInt), ecs)) SETERRQ(comm, PETSC_ERR_LIB, "allgather failed");
   } else ecs[0] = ec;
   for (int p = 0; p < size; p++) maxec = PetscMax(maxec, ecs[p]);
   if (size > 1 && maxec > 0) {
@@ -36,7 +36,7 @@ PetscErrorCode VecScatterCreate_PtoS_MPIAIJ(MPI_Comm comm, PetscLayout *xmap, Pe
     memset(mine, 0, sizeof(PetscInt) * (size_t)maxec);
     memcpy(mine, garray, sizeof(PetscInt) * (size_t)ec);
     ierr = PetscMalloc(sizeof(PetscInt) * (size_t)maxec * (size_t)size, &all);CHKERRQ(ierr);
-    if (comm->allgather(comm->ctx, mine, (int)(sizeof(PetscInt) * (size_t)maxec), all)) SETERRQ(comm, PETSC_ERR_LIB, "allgather failed");
+    if (HipCommAllgather(comm, mine, (int)(sizeof(PetscInt) * (size_t)maxec), all)) SETERRQ(comm, PETSC_ERR_LIB, "allgather failed");
     free(mine);
   }
   /* ---- "from" (receive) side: owners ascending, slots in order of appearance (vpscat.c:1871-1885) ---- */
@@ -131,17 +131,17 @@ static PetscErrorCode neighbour_exchange(VecScatter ctx, PetscDeviceCtx *dc, Pet
                                          PetscInt ns, const PetscInt *sprocs, const PetscScalar *const *ssrc, const PetscInt *scnt) {
   PetscErrorCode ierr;
   MPI_Comm comm = ctx->comm;
-  if (comm->dcomm) {
+  if (HipCommDevice(comm)) {
     int rc = 0, rc_end;
     CHKHIP(mi355x_comm_group_start());
-    for (PetscInt i = 0; i < nr && !rc; i++) rc = mi355x_comm_recv(comm->dcomm_halo, dc->hcomm, rdst[i], (size_t)rcnt[i], rprocs[i]);
-    for (PetscInt i = 0; i < ns && !rc; i++) rc = mi355x_comm_send(comm->dcomm_halo, dc->hcomm, ssrc[i], (size_t)scnt[i], sprocs[i]);
+    for (PetscInt i = 0; i < nr && !rc; i++) rc = mi355x_comm_recv(HipCommDeviceHalo(comm), dc->hcomm, rdst[i], (size_t)rcnt[i], rprocs[i]);
+    for (PetscInt i = 0; i < ns && !rc; i++) rc = mi355x_comm_send(HipCommDeviceHalo(comm), dc->hcomm, ssrc[i], (size_t)scnt[i], sprocs[i]);
     rc_end = mi355x_comm_group_end();                       /* always closed, also after a failed post */
     CHKHIP(rc);
     CHKHIP(rc_end);
     return 0;
   }
-  if (!comm->exchange) SETERRQ(comm, PETSC_ERR_ORDER, "parallel scatter needs PetscCommSetDeviceComm() (RCCL) or PetscCommSetExchange() (host-staged)");
+  if (!HipCommHasExchange(comm)) SETERRQ(comm, PETSC_ERR_ORDER, "parallel scatter needs PetscCommSetDeviceComm() (RCCL) or PetscCommSetExchange() (host-staged)");
   size_t stot = 0, rtot = 0;
   for (PetscInt i = 0; i < ns; i++) stot += (size_t)scnt[i];
   for (PetscInt i = 0; i < nr; i++) rtot += (size_t)rcnt[i];
@@ -158,7 +158,7 @@ static PetscErrorCode neighbour_exchange(VecScatter ctx, PetscDeviceCtx *dc, Pet
   off = 0;
   for (PetscInt i = 0; i < nr; i++) { rb[i] = ctx->h_recv + off; rp[i] = rprocs[i]; rbytes[i] = (int)(sizeof(PetscScalar) * (size_t)rcnt[i]); off += (size_t)rcnt[i]; }
   CHKHIP(mi355x_handle_synchronize(dc->hcomm));
-  if (comm->exchange(comm->ctx, (int)ns, sp, sb, sbytes, (int)nr, rp, rb, rbytes)) SETERRQ(comm, PETSC_ERR_LIB, "host exchange failed");
+  if (HipCommExchange(comm, (int)ns, sp, sb, sbytes, (int)nr, rp, rb, rbytes)) SETERRQ(comm, PETSC_ERR_LIB, "host exchange failed");
   for (PetscInt i = 0; i < nr; i++) CHKHIP(mi355x_memcpy_h2d(dc->hcomm, rdst[i], rb[i], (size_t)rbytes[i]));
   CHKHIP(mi355x_handle_synchronize(dc->hcomm));   /* the staging buffer is pageable and reused */
   return 0;

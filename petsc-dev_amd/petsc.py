@@ -1,4 +1,6 @@
-"""Thin ctypes front end of host/libpetschipmi355x.so (include/petschipmi355x.h) for tests and bench.py.
+"""Thin ctypes front end of the two C libraries above the kernel library -- harness/libpetscharness.so (the stand-in
+PETSc object model, include/petscmini.h) and host/libpetschipmi355x.so (the HIPMI355X plugin, include/petschipmi355x.h)
+-- for tests and bench.py.
 
 No arithmetic happens here: every call goes straight to the C host library, which dispatches through
 the Vec/Mat function tables to the HIP kernels.  Errors raise PetscError with the C traceback text."""
@@ -6,7 +8,7 @@ import ctypes as C
 
 import numpy as np
 
-from ._lib import load_host, load_kernels
+from ._lib import load_host, load_harness, load_kernels
 
 vp, i32, dbl = C.c_void_p, C.c_int, C.c_double
 P = C.POINTER
@@ -47,7 +49,7 @@ _SIG = {
     "MatMPIAIJGetScatter": [vp, P(vp), P(vp), P(i32)],
     "MatHIPMI355XSetTiming": [vp, i32], "MatHIPMI355XGetTiming": [vp, P(i32), P(dbl)],
     "MatHIPMI355XGetIndexCompression": [vp, P(i32)], "MatHIPMI355XGetInodeInfo": [vp, P(i32), P(i32), P(i32)], "MatHIPMI355XGetUploadCount": [vp, P(i32)],
-    "PetscHIPMI355XGenPoisson7": [i32, i32, i32, C.c_long, C.c_long, vp, vp, vp, P(C.c_long)],
+    "PetscMiniGenPoisson7": [i32, i32, i32, C.c_long, C.c_long, vp, vp, vp, P(C.c_long)],
     "PetscViewerBinaryOpen": [vp, C.c_char_p, i32, P(vp)], "PetscViewerDestroy": [P(vp)],
     "MatLoad": [vp, vp], "MatView": [vp, vp], "VecLoad": [vp, vp], "VecView": [vp, vp],
     "PCSetType": [vp, C.c_char_p], "PCILUGetLevels_HIPMI355X": [vp, P(i32), P(i32)], "PCILUGetSolver_HIPMI355X": [vp, P(i32), P(i32)], "PCBJacobiGetSubKSP": [vp, P(i32), P(i32), P(vp)],
@@ -58,6 +60,11 @@ _SIG = {
     "KSPGetConvergedReason": [vp, P(i32)], "KSPSetResidualHistory": [vp, vp, i32, i32],
     "KSPGetResidualHistory": [vp, P(vp), P(i32)], "KSPDestroy": [P(vp)],
 }
+
+# names exported by the plugin library; everything else in _SIG lives in the harness
+_PLUGIN = {n for n in _SIG if "HIPMI355X" in n} | {
+    "PetscCommSetDeviceComm", "PetscCommSetDeviceComms", "PetscCommGetDeviceTransport", "VecScatterBegin", "VecScatterEnd",
+    "VecScatterGetLists", "MatSeqAIJGetArrays", "MatMPIAIJGetSeqAIJ", "MatMPIAIJGetScatter"}
 
 INSERT_VALUES, ADD_VALUES = 1, 2
 SCATTER_FORWARD, SCATTER_REVERSE = 0, 1
@@ -77,33 +84,41 @@ class Lib:
 
     def __init__(self):
         load_kernels()
-        self._l = load_host()
-        self._l.PetscGetLastErrorMessage.restype = C.c_char_p
-        self._l.PetscHIPMI355XVersion.restype = C.c_char_p
+        self._h = load_harness()       # object model: VecCreate, MatMult, KSPSolve, ...
+        self._p = load_host()          # plugin: type constructors, PetscHIPMI355X*, introspection
+        self._h.PetscGetLastErrorMessage.restype = C.c_char_p
+        self._p.PetscHIPMI355XVersion.restype = C.c_char_p
         for name, args in _SIG.items():
-            fn = getattr(self._l, name)
+            fn = self._sym(name)
             fn.argtypes = args
             fn.restype = i32
-        self.COMM_SELF = vp.in_dll(self._l, "PETSC_COMM_SELF")
-        self.chk(self._l.PetscHIPMI355XInitialize(-1))
+        self.COMM_SELF = vp.in_dll(self._h, "PETSC_COMM_SELF")
+        self.chk(self._p.PetscHIPMI355XInitialize(-1))
+
+    def _sym(self, name):
+        """a function of the plugin or of the harness (each name is exported by exactly one of them)"""
+        try:
+            return getattr(self._p, name) if name in _PLUGIN else getattr(self._h, name)
+        except AttributeError:
+            return getattr(self._h, name) if name in _PLUGIN else getattr(self._p, name)
 
     @property
     def COMM_WORLD(self):
-        return vp.in_dll(self._l, "PETSC_COMM_WORLD")
+        return vp.in_dll(self._h, "PETSC_COMM_WORLD")
 
     def chk(self, rc):
         if rc:
-            raise PetscError(rc, self._l.PetscGetLastErrorMessage().decode(errors="replace"))
+            raise PetscError(rc, self._h.PetscGetLastErrorMessage().decode(errors="replace"))
 
     def __getattr__(self, name):
-        fn = getattr(self._l, name)
+        fn = self._sym(name)
 
         def call(*a):
             self.chk(fn(*a))
         return call
 
     def raw(self, name):
-        return getattr(self._l, name)
+        return self._sym(name)
 
 
 _lib = None
@@ -326,9 +341,9 @@ def gen_poisson7(nx, ny, nz, rstart=0, rend=None):
     if rend is None:
         rend = nx * ny * nz
     nnz = C.c_long()
-    L.PetscHIPMI355XGenPoisson7(nx, ny, nz, rstart, rend, None, None, None, C.byref(nnz))
+    L.PetscMiniGenPoisson7(nx, ny, nz, rstart, rend, None, None, None, C.byref(nnz))
     ai = np.zeros(rend - rstart + 1, dtype=np.int32)
     aj = np.zeros(nnz.value, dtype=np.int32)
     aa = np.zeros(nnz.value)
-    L.PetscHIPMI355XGenPoisson7(nx, ny, nz, rstart, rend, _ptr(ai), _ptr(aj), _ptr(aa), C.byref(nnz))
+    L.PetscMiniGenPoisson7(nx, ny, nz, rstart, rend, _ptr(ai), _ptr(aj), _ptr(aa), C.byref(nnz))
     return ai, aj, aa

@@ -29,13 +29,34 @@ def test_kernel_library_exports(built):
             assert hasattr(lib, n), "%s declared in %s but not exported" % (n, h)
 
 
-def test_host_library_exports(built):
-    built.load_kernels()
-    lib = C.CDLL(built.host_lib_path())
-    names = declared("petschipmi355x.h")
+def test_harness_and_plugin_library_exports(built):
+    """the harness (stand-in PETSc object model) exports what include/petscmini.h declares and loads ON ITS OWN: it has
+    no reference into the plugin or the kernel library.  The plugin exports what include/petschipmi355x.h declares."""
+    import subprocess
+    harness = C.CDLL(built.harness_lib_path(), mode=C.RTLD_GLOBAL)      # before anything else is loaded: must resolve alone
+    names = declared("petscmini.h")
     assert len(names) > 100
     for n in sorted(names):
-        assert hasattr(lib, n), "%s declared in petschipmi355x.h but not exported" % n
+        assert hasattr(harness, n), "%s declared in petscmini.h but not exported by the harness" % n
+    und = subprocess.run(["nm", "-D", "--undefined-only", built.harness_lib_path()], capture_output=True, text=True, check=True).stdout
+    assert "mi355x_" not in und and "HIPMI355X" not in und and "hip" not in und.lower().replace("ship", ""), und
+    built.load_kernels()
+    plugin = C.CDLL(built.host_lib_path())
+    names = declared("petschipmi355x.h")
+    assert len(names) > 15
+    for n in sorted(names):
+        assert hasattr(plugin, n), "%s declared in petschipmi355x.h but not exported by the plugin" % n
+    # what the plugin takes from the object model are PETSc's own entry points (plus the three harness spellings of
+    # PetscError / PetscMalloc / communicator attributes): the list a port to a real PETSc has to satisfy
+    und = subprocess.run(["nm", "-D", "--undefined-only", built.host_lib_path()], capture_output=True, text=True, check=True).stdout
+    wanted = {l.split()[-1] for l in und.splitlines() if l.split() and re.match(r"(Petsc|Vec|Mat|KSP|PC|PETSC_)", l.split()[-1])}
+    allowed = {"MatAssemblyBegin", "MatAssemblyEnd", "MatCreate", "MatDestroy", "MatDiagonalScale", "MatRegister", "MatScale",
+               "MatSeqAIJSetPreallocation", "MatSeqAIJSetPreallocationCSR", "MatSetSizes", "MatSetType", "MatSetValues", "MatZeroEntries",
+               "PCRegister", "PETSC_COMM_SELF", "PetscCommSetPluginData", "PetscCommSplitReductionBegin", "PetscError", "PetscLayoutCreateSetUp",
+               "PetscLayoutDestroy", "PetscLayoutReference", "PetscLogFlops", "PetscMallocFn", "PetscObjectChangeTypeName",
+               "PetscObjectComposeFunction", "PetscOptionsGetInt", "PetscOptionsGetString", "VecCreate", "VecDestroy", "VecGetArray",
+               "VecGetArrayRead", "VecRegister", "VecRestoreArray", "VecRestoreArrayRead", "VecSetSizes", "VecSetType"}
+    assert wanted <= allowed, sorted(wanted - allowed)
 
 
 def test_no_cpu_fallback(built):
