@@ -140,11 +140,13 @@ PetscErrorCode PetscOptionsClear(void);
  * type-specific methods such as "MatSeqAIJSetPreallocation_C" are looked up by name on the object. */
 typedef struct _p_PetscObject *PetscObject;
 typedef void (*PetscVoidFunction)(void);
-PetscErrorCode VecRegister(const char *sname, PetscErrorCode (*create)(Vec));
-PetscErrorCode MatRegister(const char *sname, PetscErrorCode (*create)(Mat));
-PetscErrorCode PCRegister(const char *sname, PetscErrorCode (*create)(PC));
-PetscErrorCode KSPRegister(const char *sname, PetscErrorCode (*create)(KSP));
-PetscErrorCode PetscObjectComposeFunction(PetscObject obj, const char name[], PetscVoidFunction fn);
+/* signatures of the reference (petscvec.h:314, petscmat.h:176, petscpc.h, petscksp.h, petscsys.h:1360): `path` and the
+ * function's own name serve dynamic loading there and are ignored here */
+PetscErrorCode VecRegister(const char sname[], const char path[], const char name[], PetscErrorCode (*create)(Vec));
+PetscErrorCode MatRegister(const char sname[], const char path[], const char name[], PetscErrorCode (*create)(Mat));
+PetscErrorCode PCRegister(const char sname[], const char path[], const char name[], PetscErrorCode (*create)(PC));
+PetscErrorCode KSPRegister(const char sname[], const char path[], const char name[], PetscErrorCode (*create)(KSP));
+PetscErrorCode PetscObjectComposeFunction(PetscObject obj, const char name[], const char fname[], PetscVoidFunction fn);
 PetscErrorCode PetscObjectQueryFunction(PetscObject obj, const char name[], PetscVoidFunction *fn);
 PetscErrorCode PetscObjectChangeTypeName(PetscObject obj, const char type_name[]);
 

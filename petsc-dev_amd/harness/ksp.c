@@ -25,7 +25,8 @@ PetscErrorCode KSPCreate(PetscComm comm, KSP *inksp) {   /* itcreate.c:640-700 *
 #define MAXKSPTYPES 16
 static struct { char name[32]; PetscErrorCode (*fn)(KSP); } ksp_types[MAXKSPTYPES + 1];
 static int n_ksp_types = 0;
-PetscErrorCode KSPRegister(const char *name, PetscErrorCode (*fn)(KSP)) {   /* src/ksp/ksp/interface/itregis.c */
+PetscErrorCode KSPRegister(const char name[], const char path[], const char fname[], PetscErrorCode (*fn)(KSP)) {   /* src/ksp/ksp/interface/itregis.c */
+  (void)path; (void)fname;
   for (int i = 0; i < n_ksp_types; i++) if (!strcmp(ksp_types[i].name, name)) { ksp_types[i].fn = fn; return 0; }
   if (n_ksp_types >= MAXKSPTYPES) SETERRQ(0, PETSC_ERR_PLIB, "KSP type table full");
   snprintf(ksp_types[n_ksp_types].name, 32, "%s", name);

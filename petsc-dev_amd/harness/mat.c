@@ -7,7 +7,8 @@ typedef PetscErrorCode (*MatCreateFn)(Mat);
 static struct { char name[32]; MatCreateFn fn; } mat_types[MAXTYPES];
 static int n_mat_types = 0;
 
-PetscErrorCode MatRegister(const char *name, MatCreateFn fn) {
+PetscErrorCode MatRegister(const char name[], const char path[], const char fname[], MatCreateFn fn) {
+  (void)path; (void)fname;
   for (int i = 0; i < n_mat_types; i++) if (!strcmp(mat_types[i].name, name)) { mat_types[i].fn = fn; return 0; }
   if (n_mat_types >= MAXTYPES) SETERRQ(0, PETSC_ERR_PLIB, "Mat type table full");
   snprintf(mat_types[n_mat_types].name, 32, "%s", name);

@@ -15,7 +15,8 @@ PetscErrorCode PCCreate(PetscComm comm, PC *newpc) {
 #define MAXPCTYPES 16
 static struct { char name[32]; PetscErrorCode (*fn)(PC); } pc_types[MAXPCTYPES + 1];
 static int n_pc_types = 0;
-PetscErrorCode PCRegister(const char *name, PetscErrorCode (*fn)(PC)) {   /* src/ksp/pc/interface/pcregis.c */
+PetscErrorCode PCRegister(const char name[], const char path[], const char fname[], PetscErrorCode (*fn)(PC)) {   /* src/ksp/pc/interface/pcregis.c */
+  (void)path; (void)fname;
   for (int i = 0; i < n_pc_types; i++) if (!strcmp(pc_types[i].name, name)) { pc_types[i].fn = fn; return 0; }
   if (n_pc_types >= MAXPCTYPES) SETERRQ(0, PETSC_ERR_PLIB, "PC type table full");
   snprintf(pc_types[n_pc_types].name, 32, "%s", name);
@@ -32,14 +33,14 @@ PetscErrorCode PetscMiniInitialize(void) {
   PetscErrorCode ierr;
   if (done) return 0;
   done = 1;
-  ierr = PCRegister(PCNONE, PCCreate_None);CHKERRQ(ierr);
-  ierr = PCRegister(PCJACOBI, PCCreate_Jacobi);CHKERRQ(ierr);
-  ierr = PCRegister(PCBJACOBI, PCCreate_BJacobi);CHKERRQ(ierr);
-  ierr = KSPRegister(KSPCG, KSPCreate_CG);CHKERRQ(ierr);
-  ierr = KSPRegister(KSPGROPPCG, KSPCreate_GROPPCG);CHKERRQ(ierr);
-  ierr = KSPRegister(KSPGMRES, KSPCreate_GMRES);CHKERRQ(ierr);
-  ierr = KSPRegister(KSPBCGS, KSPCreate_BCGS);CHKERRQ(ierr);
-  ierr = KSPRegister(KSPPREONLY, KSPCreate_PREONLY);CHKERRQ(ierr);
+  ierr = PCRegister(PCNONE, 0, "PCCreate_None", PCCreate_None);CHKERRQ(ierr);
+  ierr = PCRegister(PCJACOBI, 0, "PCCreate_Jacobi", PCCreate_Jacobi);CHKERRQ(ierr);
+  ierr = PCRegister(PCBJACOBI, 0, "PCCreate_BJacobi", PCCreate_BJacobi);CHKERRQ(ierr);
+  ierr = KSPRegister(KSPCG, 0, "KSPCreate_CG", KSPCreate_CG);CHKERRQ(ierr);
+  ierr = KSPRegister(KSPGROPPCG, 0, "KSPCreate_GROPPCG", KSPCreate_GROPPCG);CHKERRQ(ierr);
+  ierr = KSPRegister(KSPGMRES, 0, "KSPCreate_GMRES", KSPCreate_GMRES);CHKERRQ(ierr);
+  ierr = KSPRegister(KSPBCGS, 0, "KSPCreate_BCGS", KSPCreate_BCGS);CHKERRQ(ierr);
+  ierr = KSPRegister(KSPPREONLY, 0, "KSPCreate_PREONLY", KSPCreate_PREONLY);CHKERRQ(ierr);
   return 0;
 }
 

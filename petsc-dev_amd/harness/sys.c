@@ -68,7 +68,8 @@ PetscErrorCode PetscCommRank(PetscComm comm, PetscMPIInt *rank) { *rank = comm->
 PetscErrorCode PetscCommSize(PetscComm comm, PetscMPIInt *size) { *size = comm->size; return 0; }
 
 /* ---------------------------------------------------------------- composed functions (src/sys/objects/inherit.c) */
-PetscErrorCode PetscObjectComposeFunction(PetscObject obj, const char name[], PetscVoidFunction fn) {
+PetscErrorCode PetscObjectComposeFunction(PetscObject obj, const char name[], const char fname[], PetscVoidFunction fn) {
+  (void)fname;
   PetscErrorCode ierr;
   struct _n_PetscFList *e;
   if (!obj) SETERRQ(0, PETSC_ERR_ARG_NULL, "Null Object");

@@ -7,7 +7,8 @@ typedef PetscErrorCode (*VecCreateFn)(Vec);
 static struct { char name[32]; VecCreateFn fn; } vec_types[MAXTYPES];
 static int n_vec_types = 0;
 
-PetscErrorCode VecRegister(const char *name, VecCreateFn fn) {
+PetscErrorCode VecRegister(const char name[], const char path[], const char fname[], VecCreateFn fn) {
+  (void)path; (void)fname;
   for (int i = 0; i < n_vec_types; i++) if (!strcmp(vec_types[i].name, name)) { vec_types[i].fn = fn; return 0; }
   if (n_vec_types >= MAXTYPES) SETERRQ(0, PETSC_ERR_PLIB, "Vec type table full");
   snprintf(vec_types[n_vec_types].name, 32, "%s", name);

@@ -1,31 +1,34 @@
 /* MATSEQAIJHIPMI355X (and MATSEQBAIJHIPMI355X): host CSR container for assembly (the part of
- * Mat_SeqAIJ the path needs: src/mat/impls/aij/seq/aij.h:10-39,99-115; MatSetValues_SeqAIJ aij.c:~330,
+ * HipAIJ the path needs: src/mat/impls/aij/seq/aij.h:10-39,99-115; MatSetValues_SeqAIJ aij.c:~330,
  * MatAssemblyEnd_SeqAIJ aij.c:~860) plus the device mirror and the ops the reference's GPU subclass
  * overrides (MatCreate_SeqAIJCUSP, src/mat/impls/aij/seq/seqcusp/aijcusp.cu:657-681): mult, multadd,
  * multtranspose[add], getdiagonal, assemblyend, getvecs, destroy. */
 #include "hipmi355ximpl.h"
 
-#define SA(A) ((Mat_SeqAIJ *)(A)->data)
+/* the host CSR container: this file's own on the harness, a view of the parent MATSEQAIJ's arrays inside a PETSc tree */
+#define SA(A) HipAIJGet(A)
 #define SD(A) ((Mat_SeqAIJHIP *)(A)->spptr)
+PetscErrorCode MatSeqAIJGetArrays(Mat A, PetscInt *m, const PetscInt **i, const PetscInt **j, const PetscScalar **a);
 #define CHUNKSIZE 15   /* aij.h: rows grow by this many slots when preallocation is exceeded */
 
+#if !defined(PETSCHIPMI355X_WITH_PETSC)   /* inside a PETSc tree the parent type MATSEQAIJ owns the container and its assembly (aij.c) */
 /* ---------------------------------------------------------------- host container */
 static PetscErrorCode device_free(Mat A);
 static PetscErrorCode seqaij_prealloc(Mat A, PetscInt nz, const PetscInt *nnz) {
   PetscErrorCode ierr;
-  Mat_SeqAIJ *a = SA(A);
+  HipAIJ *a = SA(A);
   PetscInt m = a->m;
   if (nz == PETSC_DEFAULT || nz == PETSC_DECIDE) nz = 5;   /* aij.c MatSeqAIJSetPreallocation_SeqAIJ */
-  if (nz < 0) SETERRQ(A->comm, PETSC_ERR_ARG_OUTOFRANGE, "nz cannot be less than 0: value %d", nz);
+  if (nz < 0) SETERRQ(HipObjComm(A), PETSC_ERR_ARG_OUTOFRANGE, "nz cannot be less than 0: value %d", nz);
   device_free(A);   /* a new pattern is coming: the mirror, plan, index dictionary, transpose and batch map go with the old one */
-  free(a->i); free(a->j); free(a->a); free(a->ilen); free(a->imax);
+  HipFree(a->i); HipFree(a->j); HipFree(a->a); HipFree(a->ilen); HipFree(a->imax);
   ierr = PetscMalloc(sizeof(PetscInt) * (size_t)(m + 1), &a->i);CHKERRQ(ierr);
   ierr = PetscMalloc(sizeof(PetscInt) * (size_t)PetscMax(m, 1), &a->ilen);CHKERRQ(ierr);
   ierr = PetscMalloc(sizeof(PetscInt) * (size_t)PetscMax(m, 1), &a->imax);CHKERRQ(ierr);
   a->i[0] = 0;
   for (PetscInt r = 0; r < m; r++) {
     PetscInt c = nnz ? nnz[r] : nz;
-    if (c < 0) SETERRQ(A->comm, PETSC_ERR_ARG_OUTOFRANGE, "nnz cannot be less than 0: local row %d value %d", r, c);
+    if (c < 0) SETERRQ(HipObjComm(A), PETSC_ERR_ARG_OUTOFRANGE, "nnz cannot be less than 0: local row %d value %d", r, c);
     a->imax[r] = c; a->ilen[r] = 0; a->i[r + 1] = a->i[r] + c;
   }
   a->maxnz = a->i[m];
@@ -37,7 +40,7 @@ static PetscErrorCode seqaij_prealloc(Mat A, PetscInt nz, const PetscInt *nnz) {
 }
 
 /* grow row r by CHUNKSIZE slots (MatSeqXAIJReallocateAIJ, aij.h) */
-static PetscErrorCode seqaij_grow(Mat_SeqAIJ *a, PetscInt r) {
+static PetscErrorCode seqaij_grow(HipAIJ *a, PetscInt r) {
   PetscErrorCode ierr;
   PetscInt m = a->m, add = CHUNKSIZE, newmax = a->i[m] + add;
   PetscInt *nj; PetscScalar *na;
@@ -51,13 +54,13 @@ static PetscErrorCode seqaij_grow(Mat_SeqAIJ *a, PetscInt r) {
   memcpy(na + a->i[r + 1] + add, a->a + a->i[r + 1], sizeof(PetscScalar) * (size_t)tail);
   for (PetscInt q = r + 1; q <= m; q++) a->i[q] += add;
   a->imax[r] += add;
-  free(a->j); free(a->a);
+  HipFree(a->j); HipFree(a->a);
   a->j = nj; a->a = na; a->maxnz = newmax;
   return 0;
 }
 
 /* one entry of MatSetValues_SeqAIJ: sorted insertion into the row, INSERT or ADD on a hit */
-static PetscErrorCode seqaij_set(Mat_SeqAIJ *a, PetscInt r, PetscInt c, PetscScalar v, InsertMode mode, PetscBool *newnz) {
+static PetscErrorCode seqaij_set(HipAIJ *a, PetscInt r, PetscInt c, PetscScalar v, InsertMode mode, PetscBool *newnz) {
   PetscErrorCode ierr;
   PetscInt *rp = a->j + a->i[r], n = a->ilen[r], lo = 0, hi = n;
   PetscScalar *ap = a->a + a->i[r];
@@ -80,7 +83,7 @@ static PetscErrorCode seqaij_set(Mat_SeqAIJ *a, PetscInt r, PetscInt c, PetscSca
 }
 
 /* MatAssemblyEnd_SeqAIJ (aij.c:~860-930): squeeze out the unused slots of every row */
-static PetscErrorCode seqaij_compact(Mat_SeqAIJ *a) {
+static PetscErrorCode seqaij_compact(HipAIJ *a) {
   PetscInt m = a->m, shift = 0;
   a->nonzerorows = 0;
   for (PetscInt r = 0; r < m; r++) {
@@ -101,15 +104,19 @@ static PetscErrorCode seqaij_compact(Mat_SeqAIJ *a) {
   return 0;
 }
 
+#else
+static PetscErrorCode device_free(Mat A);
+#endif
+
 /* Mat_CheckInode (src/mat/impls/aij/seq/inode.c:3964-4034): consecutive rows with identical column lists form a node of
  * at most `limit` rows (-mat_inode_limit, default 5, inode2.c:85-99); with more than 0.8 m nodes -- or -mat_no_inode -- the
  * matrix keeps the plain routines (inode_count = 0). */
 static PetscErrorCode seqaij_check_inode(Mat A) {
   PetscErrorCode ierr;
-  Mat_SeqAIJ *a = SA(A);
+  HipAIJ *a = SA(A);
   PetscInt m = a->m, limit = 5, i = 0, node_count = 0, *ns;
   PetscBool set; char buf[16];
-  free(a->inode_size); a->inode_size = NULL; a->inode_count = 0;
+  HipFree(a->inode_size); a->inode_size = NULL; a->inode_count = 0;
   ierr = PetscOptionsGetString(NULL, "-mat_no_inode", buf, sizeof(buf), &set);CHKERRQ(ierr);
   if (set || !m) return 0;
   ierr = PetscOptionsGetInt(NULL, "-mat_inode_limit", &limit, &set);CHKERRQ(ierr);
@@ -130,7 +137,7 @@ static PetscErrorCode seqaij_check_inode(Mat A) {
     idx += (size_t)blk_size * nzx;
     i = j;
   }
-  if (node_count > .8 * m) { free(ns); return 0; }
+  if (node_count > .8 * m) { HipFree(ns); return 0; }
   a->inode_size = ns; a->inode_count = node_count;
   return 0;
 }
@@ -165,12 +172,12 @@ static PetscErrorCode device_free(Mat A) {
  * reference, a value-only change (same pattern) re-sends only `a`. */
 PetscErrorCode MatSeqAIJHIPUpload(Mat A) {
   PetscErrorCode ierr;
-  Mat_SeqAIJ *a = SA(A);
+  HipAIJ *a = SA(A);
   Mat_SeqAIJHIP *d = SD(A);
   PetscDeviceCtx *dc;
-  if (d->uploaded_state == A->state && d->d_a) return 0;
+  if (d->uploaded_state == HipObjState(A) && d->d_a) return 0;
   ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
-  if (!a->compact) SETERRQ(A->comm, PETSC_ERR_ARG_WRONGSTATE, "matrix must be assembled before it is sent to the GPU");
+  if (!a->compact) SETERRQ(HipObjComm(A), PETSC_ERR_ARG_WRONGSTATE, "matrix must be assembled before it is sent to the GPU");
   PetscBool same_pattern = (PetscBool)(d->d_a && d->plan && d->pattern_nz == a->nz);   /* entries are never removed: same nz == same pattern */
   if (!same_pattern) {
     device_free(A);
@@ -219,17 +226,17 @@ PetscErrorCode MatSeqAIJHIPUpload(Mat A) {
                            * nodes, 27 blocks per row: 1.295 ms against 1.402 ms for the row-block FMA kernel) */
         char kind[16] = "mfma"; PetscBool set;
         ierr = PetscOptionsGetString(NULL, "-mat_hipmi355x_baij4", kind, sizeof(kind), &set);CHKERRQ(ierr);
-        if (strcmp(kind, "mfma") && strcmp(kind, "fma")) SETERRQ(A->comm, PETSC_ERR_ARG_WRONG, "-mat_hipmi355x_baij4 <mfma|fma>, got %s", kind);
+        if (strcmp(kind, "mfma") && strcmp(kind, "fma")) SETERRQ(HipObjComm(A), PETSC_ERR_ARG_WRONG, "-mat_hipmi355x_baij4 <mfma|fma>, got %s", kind);
         d->baij4_mfma = (PetscBool)!strcmp(kind, "mfma");
       }
-      if ((double)a->nz * bs2 > 2147483000.0) SETERRQ(A->comm, PETSC_ERR_ARG_OUTOFRANGE, "BAIJ matrix too large for 32-bit value offsets");
+      if ((double)a->nz * bs2 > 2147483000.0) SETERRQ(HipObjComm(A), PETSC_ERR_ARG_OUTOFRANGE, "BAIJ matrix too large for 32-bit value offsets");
       ierr = PetscMalloc(sizeof(PetscInt) * (size_t)(nrows + 1), &sc);CHKERRQ(ierr);
       for (PetscInt r = 0; r <= nrows; r++) sc[r] = a->i[r] * bs2;
       CHKHIP(mi355x_spmv_plan_create(dc->h, nrows, sc, NULL, &d->plan));
-      free(sc);
+      HipFree(sc);
     }
     CHKHIP(mi355x_handle_synchronize(dc->h));
-    free(ci); free(ridx);
+    HipFree(ci); HipFree(ridx);
     d->pattern_nz = a->nz;
     if (!use_cprow) d->cprow = PETSC_FALSE;
   }
@@ -238,7 +245,7 @@ PetscErrorCode MatSeqAIJHIPUpload(Mat A) {
   CHKHIP(mi355x_memcpy_h2d(dc->h, d->d_a, a->a, sizeof(PetscScalar) * vals));
   CHKHIP(mi355x_handle_synchronize(dc->h));
   d->n_uploads++;
-  d->uploaded_state = A->state;
+  d->uploaded_state = HipObjState(A);
   return 0;
 }
 
@@ -248,10 +255,10 @@ PetscErrorCode MatSeqAIJHIPSetCompressedRow(Mat A, PetscBool flg) { SD(A)->cprow
  * MatMultTransposeAdd_SeqAIJ's scatter loop adds them in, aij.c:1100-1112) */
 static PetscErrorCode upload_transpose(Mat A) {
   PetscErrorCode ierr;
-  Mat_SeqAIJ *a = SA(A);
+  HipAIJ *a = SA(A);
   Mat_SeqAIJHIP *d = SD(A);
   PetscDeviceCtx *dc;
-  if (d->t_state == A->state && d->t_a) return 0;
+  if (d->t_state == HipObjState(A) && d->t_a) return 0;
   ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
   PetscInt m = a->m, n = a->n, nz = a->nz;
   PetscInt *ti, *tj, *next; PetscScalar *ta;
@@ -274,33 +281,35 @@ static PetscErrorCode upload_transpose(Mat A) {
   CHKHIP(mi355x_memcpy_h2d(dc->h, d->t_a, ta, sizeof(PetscScalar) * (size_t)nz));
   CHKHIP(mi355x_spmv_plan_create(dc->h, n, ti, NULL, &d->t_plan));
   CHKHIP(mi355x_handle_synchronize(dc->h));
-  free(ti); free(tj); free(ta); free(next);
-  d->t_state = A->state;
+  HipFree(ti); HipFree(tj); HipFree(ta); HipFree(next);
+  d->t_state = HipObjState(A);
   return 0;
 }
 
 /* ---------------------------------------------------------------- ops */
+#if !defined(PETSCHIPMI355X_WITH_PETSC)   /* the parent MATSEQAIJ's job inside a PETSc tree */
 static PetscErrorCode MatSetUp_SeqAIJHIP(Mat A) { return seqaij_prealloc(A, PETSC_DEFAULT, NULL); }
 
 static PetscErrorCode MatSetValues_SeqAIJHIP(Mat A, PetscInt m, const PetscInt im[], PetscInt n, const PetscInt in[], const PetscScalar v[], InsertMode is) {
   PetscErrorCode ierr;
-  Mat_SeqAIJ *a = SA(A);
+  HipAIJ *a = SA(A);
   /* a host-side insertion: whatever the device-side updates stamped (MatSetValuesBatch, MatScale, ... look one state
    * bump ahead), the device copy is stale from here on */
   SD(A)->uploaded_state = -1;
   for (PetscInt k = 0; k < m; k++) {
     PetscInt row = im[k];
     if (row < 0) continue;
-    if (row >= a->m) SETERRQ(A->comm, PETSC_ERR_ARG_OUTOFRANGE, "Row too large: row %d max %d", row, a->m - 1);
+    if (row >= a->m) SETERRQ(HipObjComm(A), PETSC_ERR_ARG_OUTOFRANGE, "Row too large: row %d max %d", row, a->m - 1);
     for (PetscInt l = 0; l < n; l++) {
       if (in[l] < 0) continue;
-      if (in[l] >= a->n) SETERRQ(A->comm, PETSC_ERR_ARG_OUTOFRANGE, "Column too large: col %d max %d", in[l], a->n - 1);
+      if (in[l] >= a->n) SETERRQ(HipObjComm(A), PETSC_ERR_ARG_OUTOFRANGE, "Column too large: col %d max %d", in[l], a->n - 1);
       ierr = seqaij_set(a, row, in[l], v[k * n + l], is, NULL);CHKERRQ(ierr);   /* row-oriented values, aij.c roworiented */
     }
   }
   return 0;
 }
 
+#endif
 /* MatSetValuesBatch (matrix.c:1698; the reference's GPU version aijAssemble.cu:157 sorts and reduces a COO list on every
  * call): nb square blocks of bs x bs values, rows[] = their row = column indices, ADD_VALUES.  With an assembled matrix
  * whose pattern already holds every (row, col) pair -- the re-assembly of a time step or Newton iteration -- the values
@@ -315,7 +324,7 @@ static unsigned long long fnv1a(const void *p, size_t nbytes) {
 }
 static PetscErrorCode batch_map_build(Mat A, PetscInt nb, PetscInt bs, const PetscInt rows[], PetscBool *ok) {
   PetscErrorCode ierr;
-  Mat_SeqAIJ *a = SA(A); Mat_SeqAIJHIP *d = SD(A);
+  HipAIJ *a = SA(A); Mat_SeqAIJHIP *d = SD(A);
   PetscDeviceCtx *dc;
   const size_t T = (size_t)nb * (size_t)bs * (size_t)bs;
   PetscInt *slot = NULL, *count = NULL, *order = NULL, *segptr = NULL, *segslot = NULL;
@@ -329,16 +338,16 @@ static PetscErrorCode batch_map_build(Mat A, PetscInt nb, PetscInt bs, const Pet
     const PetscInt *rb = rows + (size_t)b * bs;
     for (PetscInt i = 0; i < bs; i++) {
       const PetscInt row = rb[i];
-      if (row >= a->m) { free(slot); free(count); SETERRQ(A->comm, PETSC_ERR_ARG_OUTOFRANGE, "Row too large: row %d max %d", row, a->m - 1); }
+      if (row >= a->m) { HipFree(slot); HipFree(count); SETERRQ(HipObjComm(A), PETSC_ERR_ARG_OUTOFRANGE, "Row too large: row %d max %d", row, a->m - 1); }
       for (PetscInt j = 0; j < bs; j++) {
         const size_t t = ((size_t)b * bs + i) * bs + j;
         const PetscInt col = rb[j];
         slot[t] = -1;
         if (row < 0 || col < 0) continue;                     /* MatSetValues ignores negative indices */
-        if (col >= a->n) { free(slot); free(count); SETERRQ(A->comm, PETSC_ERR_ARG_OUTOFRANGE, "Column too large: col %d max %d", col, a->n - 1); }
+        if (col >= a->n) { HipFree(slot); HipFree(count); SETERRQ(HipObjComm(A), PETSC_ERR_ARG_OUTOFRANGE, "Column too large: col %d max %d", col, a->n - 1); }
         PetscInt k = a->i[row];
         for (; k < a->i[row + 1]; k++) if (a->j[k] == col) break;
-        if (k == a->i[row + 1]) { free(slot); free(count); return 0; }   /* a new nonzero: not a pure value re-assembly */
+        if (k == a->i[row + 1]) { HipFree(slot); HipFree(count); return 0; }   /* a new nonzero: not a pure value re-assembly */
         slot[t] = k; count[k + 1]++; used++;
       }
     }
@@ -365,7 +374,7 @@ static PetscErrorCode batch_map_build(Mat A, PetscInt nb, PetscInt bs, const Pet
   CHKHIP(mi355x_memcpy_h2d(dc->h, d->bm_segptr, segptr, sizeof(PetscInt) * (size_t)(nseg + 1)));
   CHKHIP(mi355x_memcpy_h2d(dc->h, d->bm_segslot, segslot, sizeof(PetscInt) * (size_t)nseg));
   CHKHIP(mi355x_handle_synchronize(dc->h));
-  free(slot); free(count); free(order); free(segptr); free(segslot);
+  HipFree(slot); HipFree(count); HipFree(order); HipFree(segptr); HipFree(segslot);
   d->bm_nb = nb; d->bm_bs = bs; d->bm_nseg = nseg; d->bm_T = T;
   d->bm_hash = fnv1a(rows, sizeof(PetscInt) * (size_t)nb * (size_t)bs);
   *ok = PETSC_TRUE;
@@ -373,7 +382,7 @@ static PetscErrorCode batch_map_build(Mat A, PetscInt nb, PetscInt bs, const Pet
 }
 static PetscErrorCode MatSetValuesBatch_SeqAIJHIP(Mat A, PetscInt nb, PetscInt bs, PetscInt rows[], const PetscScalar v[]) {
   PetscErrorCode ierr;
-  Mat_SeqAIJ *a = SA(A); Mat_SeqAIJHIP *d = SD(A);
+  HipAIJ *a = SA(A); Mat_SeqAIJHIP *d = SD(A);
   PetscBool ok = PETSC_FALSE;
   if (a->bs <= 1 && a->compact && A->assembled && nb > 0 && bs > 0 && !d->cprow) {
     ierr = MatSeqAIJHIPUpload(A);CHKERRQ(ierr);               /* device values current before they are added to */
@@ -399,12 +408,13 @@ static PetscErrorCode MatSetValuesBatch_SeqAIJHIP(Mat A, PetscInt nb, PetscInt b
   CHKHIP(mi355x_handle_synchronize(dc->h));                    /* v and a->a are pageable host memory */
   /* MatSetValuesBatch's wrapper leaves the state alone and the MatAssemblyEnd that has to follow bumps it once: the
    * device copy is stamped with that state, so the assembly does not trigger an upload */
-  d->uploaded_state = A->state + 1;
+  d->uploaded_state = HipObjState(A) + 1;
   d->t_state = -1;
   ierr = PetscLogFlops((PetscLogDouble)d->bm_T);CHKERRQ(ierr);
   return 0;
 }
 
+#if !defined(PETSCHIPMI355X_WITH_PETSC)   /* the parent MATSEQAIJ's job inside a PETSc tree */
 static PetscErrorCode MatAssemblyEnd_SeqAIJHIP(Mat A, MatAssemblyType mode) {
   if (mode == MAT_FLUSH_ASSEMBLY) return 0;
   /* (the reference re-installs ops->mult here because the inode check may have replaced it,
@@ -412,9 +422,10 @@ static PetscErrorCode MatAssemblyEnd_SeqAIJHIP(Mat A, MatAssemblyType mode) {
   return seqaij_compact(SA(A));
 }
 
+#endif
 static PetscErrorCode MatMult_SeqAIJHIP(Mat A, Vec xx, Vec yy) {   /* MatMult_SeqAIJCUSP aijcusp.cu:349 */
   PetscErrorCode ierr;
-  Mat_SeqAIJ *a = SA(A); Mat_SeqAIJHIP *d = SD(A);
+  HipAIJ *a = SA(A); Mat_SeqAIJHIP *d = SD(A);
   const PetscScalar *x; PetscScalar *y; PetscDeviceCtx *dc;
   ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
   ierr = MatSeqAIJHIPUpload(A);CHKERRQ(ierr);
@@ -438,7 +449,7 @@ static PetscErrorCode MatMult_SeqAIJHIP(Mat A, Vec xx, Vec yy) {   /* MatMult_Se
  * unchanged pattern must not add to it) */
 PetscErrorCode MatHIPMI355XGetUploadCount(Mat A, PetscInt *n) {
   *n = 0;
-  if (!A || A->ops->mult != MatMult_SeqAIJHIP) SETERRQ(A ? A->comm : 0, PETSC_ERR_ARG_WRONG, "sequential HIPMI355X matrix expected");
+  if (!A || A->ops->mult != MatMult_SeqAIJHIP) SETERRQ(A ? HipObjComm(A) : 0, PETSC_ERR_ARG_WRONG, "sequential HIPMI355X matrix expected");
   *n = SD(A)->n_uploads;
   return 0;
 }
@@ -450,7 +461,7 @@ PetscErrorCode MatHIPMI355XGetIndexCompression(Mat A, PetscInt *noffsets) {
   if (!A) return 0;
   if (A->ops->mult != MatMult_SeqAIJHIP) {
     Mat Ad = NULL;
-    if (!strcmp(A->type_name, MATMPIAIJHIPMI355X)) { ierr = MatMPIAIJGetSeqAIJ(A, &Ad, NULL, NULL);CHKERRQ(ierr); }
+    if (!strcmp(HipObjTypeName(A), MATMPIAIJHIPMI355X)) { ierr = MatMPIAIJGetSeqAIJ(A, &Ad, NULL, NULL);CHKERRQ(ierr); }
     if (!Ad || Ad->ops->mult != MatMult_SeqAIJHIP) return 0;
     A = Ad;
   }
@@ -470,7 +481,7 @@ PetscErrorCode MatHIPMI355XGetInodeInfo(Mat A, PetscInt *nodes, PetscInt *groups
   if (!A) return 0;
   if (A->ops->mult != MatMult_SeqAIJHIP) {
     Mat Ad = NULL;
-    if (!strcmp(A->type_name, MATMPIAIJHIPMI355X)) { ierr = MatMPIAIJGetSeqAIJ(A, &Ad, NULL, NULL);CHKERRQ(ierr); }
+    if (!strcmp(HipObjTypeName(A), MATMPIAIJHIPMI355X)) { ierr = MatMPIAIJGetSeqAIJ(A, &Ad, NULL, NULL);CHKERRQ(ierr); }
     if (!Ad || Ad->ops->mult != MatMult_SeqAIJHIP) return 0;
     A = Ad;
   }
@@ -489,10 +500,10 @@ PetscErrorCode MatMultTDotBegin_HIPMI355X(Mat A, Vec xx, Vec yy, PetscBool *ok) 
   PetscErrorCode ierr;
   *ok = PETSC_FALSE;
   if (!A || A->ops->mult != MatMult_SeqAIJHIP) return 0;
-  Mat_SeqAIJ *a = SA(A); Mat_SeqAIJHIP *d = SD(A);
+  HipAIJ *a = SA(A); Mat_SeqAIJHIP *d = SD(A);
   const PetscScalar *x; PetscScalar *y; PetscDeviceCtx *dc; int ntab = 0;
   if (a->bs > 1 || d->cprow || a->m != a->n || xx == yy) return 0;
-  if (xx->map->n != a->n || yy->map->n != a->m || (HipCommSize(xx->comm) > 1 && !HipCommDevice(xx->comm))) return 0;
+  if (xx->map->n != a->n || yy->map->n != a->m || (HipCommSize(HipObjComm(xx)) > 1 && !HipCommDevice(HipObjComm(xx)))) return 0;
   ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
   ierr = MatSeqAIJHIPUpload(A);CHKERRQ(ierr);
   if (!d->plan) return 0;
@@ -507,9 +518,9 @@ PetscErrorCode MatMultTDotBegin_HIPMI355X(Mat A, Vec xx, Vec yy, PetscBool *ok) 
   ierr = MatTimingEnd(A, dc->h);CHKERRQ(ierr);
   double *slot = mi355x_handle_device_scratch(dc->h) + PETSC_HIP_DPI_SLOT;
   CHKHIP(mi355x_spmv_dot_finish(dc->h, d->plan, slot));
-  if (HipCommDevice(xx->comm)) CHKHIP(mi355x_comm_allreduce_sum(HipCommDevice(xx->comm), dc->h, slot, 1));
+  if (HipCommDevice(HipObjComm(xx))) CHKHIP(mi355x_comm_allreduce_sum(HipCommDevice(HipObjComm(xx)), dc->h, slot, 1));
   ierr = VecHIPRestoreWrite(yy);CHKERRQ(ierr);
-  PetscObjectStateIncrease(yy);
+  HipStateIncrease(yy);
   ierr = PetscLogFlops(2.0 * a->nz - a->nonzerorows + 2.0 * a->m - 1);CHKERRQ(ierr);
   *ok = PETSC_TRUE;
   return 0;
@@ -517,9 +528,9 @@ PetscErrorCode MatMultTDotBegin_HIPMI355X(Mat A, Vec xx, Vec yy, PetscBool *ok) 
 
 static PetscErrorCode MatMultAdd_SeqAIJHIP(Mat A, Vec xx, Vec yy, Vec zz) {   /* MatMultAdd_SeqAIJCUSP aijcusp.cu:405 */
   PetscErrorCode ierr;
-  Mat_SeqAIJ *a = SA(A); Mat_SeqAIJHIP *d = SD(A);
+  HipAIJ *a = SA(A); Mat_SeqAIJHIP *d = SD(A);
   const PetscScalar *x, *y; PetscScalar *z; PetscDeviceCtx *dc;
-  if (a->bs > 1) SETERRQ(A->comm, PETSC_ERR_SUP, "MatMultAdd for the BAIJ type is outside the ported path");
+  if (a->bs > 1) SETERRQ(HipObjComm(A), PETSC_ERR_SUP, "MatMultAdd for the BAIJ type is outside the ported path");
   ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
   ierr = MatSeqAIJHIPUpload(A);CHKERRQ(ierr);
   ierr = VecHIPGetRead(xx, &x);CHKERRQ(ierr);
@@ -539,9 +550,9 @@ static PetscErrorCode MatMultAdd_SeqAIJHIP(Mat A, Vec xx, Vec yy, Vec zz) {   /*
 
 static PetscErrorCode MatMultTransposeAdd_SeqAIJHIP(Mat A, Vec xx, Vec zz, Vec yy) {   /* aij.c:1078: yy = zz + A^T xx */
   PetscErrorCode ierr;
-  Mat_SeqAIJ *a = SA(A); Mat_SeqAIJHIP *d = SD(A);
+  HipAIJ *a = SA(A); Mat_SeqAIJHIP *d = SD(A);
   const PetscScalar *x, *z; PetscScalar *y; PetscDeviceCtx *dc;
-  if (a->bs > 1) SETERRQ(A->comm, PETSC_ERR_SUP, "MatMultTranspose for the BAIJ type is outside the ported path");
+  if (a->bs > 1) SETERRQ(HipObjComm(A), PETSC_ERR_SUP, "MatMultTranspose for the BAIJ type is outside the ported path");
   ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
   ierr = upload_transpose(A);CHKERRQ(ierr);
   ierr = VecHIPGetRead(xx, &x);CHKERRQ(ierr);
@@ -554,9 +565,9 @@ static PetscErrorCode MatMultTransposeAdd_SeqAIJHIP(Mat A, Vec xx, Vec zz, Vec y
 }
 static PetscErrorCode MatMultTranspose_SeqAIJHIP(Mat A, Vec xx, Vec yy) {   /* aij.c:1124: VecSet(yy,0); Add */
   PetscErrorCode ierr;
-  Mat_SeqAIJ *a = SA(A); Mat_SeqAIJHIP *d = SD(A);
+  HipAIJ *a = SA(A); Mat_SeqAIJHIP *d = SD(A);
   const PetscScalar *x; PetscScalar *y; PetscDeviceCtx *dc;
-  if (a->bs > 1) SETERRQ(A->comm, PETSC_ERR_SUP, "MatMultTranspose for the BAIJ type is outside the ported path");
+  if (a->bs > 1) SETERRQ(HipObjComm(A), PETSC_ERR_SUP, "MatMultTranspose for the BAIJ type is outside the ported path");
   ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
   ierr = upload_transpose(A);CHKERRQ(ierr);
   ierr = VecHIPGetRead(xx, &x);CHKERRQ(ierr);
@@ -570,15 +581,15 @@ static PetscErrorCode MatMultTranspose_SeqAIJHIP(Mat A, Vec xx, Vec yy) {   /* a
 
 static PetscErrorCode MatGetDiagonal_SeqAIJHIP(Mat A, Vec v) {   /* aij.c:1040 */
   PetscErrorCode ierr;
-  Mat_SeqAIJ *a = SA(A); Mat_SeqAIJHIP *d = SD(A);
+  HipAIJ *a = SA(A); Mat_SeqAIJHIP *d = SD(A);
   PetscScalar *dv; PetscDeviceCtx *dc;
-  if (v->map->n != a->m) SETERRQ(A->comm, PETSC_ERR_ARG_SIZ, "Nonconforming matrix and vector");
+  if (v->map->n != A->rmap->n) SETERRQ(HipObjComm(A), PETSC_ERR_ARG_SIZ, "Nonconforming matrix and vector");
   if (a->bs > 1 || d->cprow) {   /* host route for the rarely used shapes */
     PetscScalar *h;
     ierr = VecGetArray(v, &h);CHKERRQ(ierr);
     if (a->bs > 1) {
-      PetscInt bs = a->bs, mbs = a->m / bs;
-      for (PetscInt r = 0; r < a->m; r++) h[r] = 0.0;
+      PetscInt bs = a->bs, mbs = a->m;                 /* BAIJ: a->m counts block rows */
+      for (PetscInt r = 0; r < mbs * bs; r++) h[r] = 0.0;
       for (PetscInt br = 0; br < mbs; br++) for (PetscInt k = a->i[br]; k < a->i[br + 1]; k++) if (a->j[k] == br)
         for (PetscInt q = 0; q < bs; q++) h[br * bs + q] = a->a[(size_t)k * bs * bs + q * bs + q];
     } else {
@@ -599,11 +610,11 @@ static PetscErrorCode MatGetDiagonal_SeqAIJHIP(Mat A, Vec v) {   /* aij.c:1040 *
  * the device copy is stamped with that future state.  The cached transpose is dropped. */
 static PetscBool device_values_current(Mat A) {
   Mat_SeqAIJHIP *d = SD(A);
-  return (PetscBool)(d->d_a && d->uploaded_state == A->state && SA(A)->bs <= 1);
+  return (PetscBool)(d->d_a && d->uploaded_state == HipObjState(A) && SA(A)->bs <= 1);
 }
 static PetscErrorCode MatScale_SeqAIJHIP(Mat A, PetscScalar alpha) {   /* MatScale_SeqAIJ: dscal on a->a */
   PetscErrorCode ierr;
-  Mat_SeqAIJ *a = SA(A); Mat_SeqAIJHIP *d = SD(A);
+  HipAIJ *a = SA(A); Mat_SeqAIJHIP *d = SD(A);
   size_t vals = (size_t)a->nz * (size_t)(a->bs > 1 ? a->bs * a->bs : 1);
   const PetscBool on_device = (PetscBool)(device_values_current(A) && alpha != 0.0);   /* alpha == 0: signs of zero, take the upload */
   for (size_t k = 0; k < vals; k++) a->a[k] = alpha * a->a[k];
@@ -611,14 +622,14 @@ static PetscErrorCode MatScale_SeqAIJHIP(Mat A, PetscScalar alpha) {   /* MatSca
     PetscDeviceCtx *dc;
     ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
     CHKHIP(mi355x_vec_scale(dc->h, vals, alpha, d->d_a));
-    d->uploaded_state = A->state + 1;
+    d->uploaded_state = HipObjState(A) + 1;
     d->t_state = -1;
   }
   return PetscLogFlops((PetscLogDouble)vals);
 }
 static PetscErrorCode MatZeroEntries_SeqAIJHIP(Mat A) {
   PetscErrorCode ierr;
-  Mat_SeqAIJ *a = SA(A); Mat_SeqAIJHIP *d = SD(A);
+  HipAIJ *a = SA(A); Mat_SeqAIJHIP *d = SD(A);
   size_t vals = (size_t)(a->compact ? a->nz : a->maxnz) * (size_t)(a->bs > 1 ? a->bs * a->bs : 1);
   const PetscBool on_device = (PetscBool)(device_values_current(A) && a->compact);
   memset(a->a, 0, sizeof(PetscScalar) * vals);
@@ -626,7 +637,7 @@ static PetscErrorCode MatZeroEntries_SeqAIJHIP(Mat A) {
     PetscDeviceCtx *dc;
     ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
     CHKHIP(mi355x_memset(dc->h, d->d_a, 0, sizeof(PetscScalar) * vals));
-    d->uploaded_state = A->state + 1;
+    d->uploaded_state = HipObjState(A) + 1;
     d->t_state = -1;
   }
   return 0;
@@ -634,12 +645,12 @@ static PetscErrorCode MatZeroEntries_SeqAIJHIP(Mat A) {
 /* MatDiagonalScale_SeqAIJ, aij.c:2055-2092: left scaling pass, then right scaling pass ((a*l)*r) */
 static PetscErrorCode MatDiagonalScale_SeqAIJHIP(Mat A, Vec ll, Vec rr) {
   PetscErrorCode ierr;
-  Mat_SeqAIJ *a = SA(A); Mat_SeqAIJHIP *d = SD(A);
+  HipAIJ *a = SA(A); Mat_SeqAIJHIP *d = SD(A);
   const PetscScalar *l = NULL, *r = NULL;
-  if (a->bs > 1) SETERRQ(A->comm, PETSC_ERR_SUP, "MatDiagonalScale for the BAIJ type is outside the ported path");
-  if (!a->compact) SETERRQ(A->comm, PETSC_ERR_ARG_WRONGSTATE, "matrix must be assembled");
-  if (ll && ll->map->n != a->m) SETERRQ(A->comm, PETSC_ERR_ARG_SIZ, "Left scaling vector wrong length");
-  if (rr && rr->map->n != a->n) SETERRQ(A->comm, PETSC_ERR_ARG_SIZ, "Right scaling vector wrong length");
+  if (a->bs > 1) SETERRQ(HipObjComm(A), PETSC_ERR_SUP, "MatDiagonalScale for the BAIJ type is outside the ported path");
+  if (!a->compact) SETERRQ(HipObjComm(A), PETSC_ERR_ARG_WRONGSTATE, "matrix must be assembled");
+  if (ll && ll->map->n != a->m) SETERRQ(HipObjComm(A), PETSC_ERR_ARG_SIZ, "Left scaling vector wrong length");
+  if (rr && rr->map->n != a->n) SETERRQ(HipObjComm(A), PETSC_ERR_ARG_SIZ, "Right scaling vector wrong length");
   const PetscBool on_device = (PetscBool)(device_values_current(A) && !d->cprow);
   if (on_device) {   /* device pointers first: fetching the host arrays below must not be what makes them stale */
     const PetscScalar *dl = NULL, *dr = NULL; PetscDeviceCtx *dc;
@@ -647,7 +658,7 @@ static PetscErrorCode MatDiagonalScale_SeqAIJHIP(Mat A, Vec ll, Vec rr) {
     if (ll) { ierr = VecHIPGetRead(ll, &dl);CHKERRQ(ierr); }
     if (rr) { ierr = VecHIPGetRead(rr, &dr);CHKERRQ(ierr); }
     CHKHIP(mi355x_csr_diagonal_scale(dc->h, a->m, d->d_i, d->d_j, d->d_a, dl, dr));
-    d->uploaded_state = A->state + 1;
+    d->uploaded_state = HipObjState(A) + 1;
     d->t_state = -1;
   }
   if (ll) {
@@ -668,12 +679,12 @@ static PetscErrorCode MatDiagonalScale_SeqAIJHIP(Mat A, Vec ll, Vec rr) {
 static PetscErrorCode MatGetVecs_HIP(Mat A, Vec *right, Vec *left) {   /* MatGetVecs_SeqAIJCUSP aijcusp.cu:324-345 */
   PetscErrorCode ierr;
   if (right) {
-    ierr = VecCreate(A->comm, right);CHKERRQ(ierr);
+    ierr = VecCreate(HipObjComm(A), right);CHKERRQ(ierr);
     ierr = VecSetSizes(*right, A->cmap->n, A->cmap->N);CHKERRQ(ierr);
     ierr = VecSetType(*right, VECHIPMI355X);CHKERRQ(ierr);
   }
   if (left) {
-    ierr = VecCreate(A->comm, left);CHKERRQ(ierr);
+    ierr = VecCreate(HipObjComm(A), left);CHKERRQ(ierr);
     ierr = VecSetSizes(*left, A->rmap->n, A->rmap->N);CHKERRQ(ierr);
     ierr = VecSetType(*left, VECHIPMI355X);CHKERRQ(ierr);
   }
@@ -681,18 +692,23 @@ static PetscErrorCode MatGetVecs_HIP(Mat A, Vec *right, Vec *left) {   /* MatGet
 }
 PetscErrorCode MatGetVecs_HIPMI355X(Mat A, Vec *right, Vec *left) { return MatGetVecs_HIP(A, right, left); }
 
+#if !defined(PETSCHIPMI355X_WITH_PETSC)   /* the parent MATSEQAIJ's job inside a PETSc tree */
 static PetscErrorCode MatDestroy_SeqAIJHIP(Mat A) {   /* free the mirror and zero spptr first, aijcusp.cu:584-586 */
-  Mat_SeqAIJ *a = SA(A);
+  HipAIJ *a = SA(A);
   if (SD(A)) {
     Mat_SeqAIJHIP *d = SD(A);
     device_free(A);
-    if (d->time_ev) { for (PetscInt k = 0; k < 2 * d->time_cap; k++) mi355x_event_destroy(d->time_ev[k]); free(d->time_ev); }
-    free(A->spptr); A->spptr = NULL;
+    if (d->time_ev) { for (PetscInt k = 0; k < 2 * d->time_cap; k++) mi355x_event_destroy(d->time_ev[k]); HipFree(d->time_ev); }
+    HipFree(A->spptr); A->spptr = NULL;
   }
-  if (a) { free(a->i); free(a->j); free(a->a); free(a->ilen); free(a->imax); free(a->inode_size); free(a); A->data = NULL; }
+  if (a) { HipFree(a->i); HipFree(a->j); HipFree(a->a); HipFree(a->ilen); HipFree(a->imax); HipFree(a->inode_size); HipFree(a); A->data = NULL; }
   return 0;
 }
 
+#endif
+#if defined(PETSCHIPMI355X_WITH_PETSC)
+#include "aijhipmi355x_ctor.h"    /* integration/petsc-3.3/: the constructor as a subclass of the reference's MATSEQAIJ */
+#else
 static PetscErrorCode MatSeqAIJSetPreallocation_SeqAIJHIP(Mat A, PetscInt nz, const PetscInt nnz[]) { return seqaij_prealloc(A, nz, nnz); }
 static PetscErrorCode MatSeqAIJSetPreallocationCSR_SeqAIJHIP(Mat B, const PetscInt *i, const PetscInt *j, const PetscScalar *a);
 static PetscErrorCode MatSeqBAIJSetPreallocationCSR_SeqBAIJHIP(Mat B, PetscInt bs, const PetscInt *i, const PetscInt *j, const PetscScalar *a);
@@ -702,7 +718,7 @@ static PetscErrorCode MatSeqBAIJSetPreallocationCSR_SeqBAIJHIP(Mat B, PetscInt b
  * (host/aijhip.c) on the harness, the parent MATSEQAIJ's inside a PETSc tree. */
 static PetscErrorCode create_common(Mat B, const char *tname, PetscInt bs) {
   PetscErrorCode ierr;
-  Mat_SeqAIJ *a; Mat_SeqAIJHIP *d;
+  HipAIJ *a; Mat_SeqAIJHIP *d;
   if (HipCommSize(HipObjComm(B)) > 1) SETERRQ(HipObjComm(B), PETSC_ERR_ARG_WRONG, "Comm must be of size 1");
   ierr = PetscMalloc(sizeof(*a), &a);CHKERRQ(ierr);
   memset(a, 0, sizeof(*a));
@@ -726,13 +742,13 @@ static PetscErrorCode create_common(Mat B, const char *tname, PetscInt bs) {
   B->ops->setvaluesbatch = MatSetValuesBatch_SeqAIJHIP;
   B->ops->destroy = MatDestroy_SeqAIJHIP;
   B->ops->getvecs = MatGetVecs_HIP;
-  ierr = PetscObjectComposeFunction((PetscObject)B, "MatSeqAIJGetArrays_C", (PetscVoidFunction)MatSeqAIJGetArrays);CHKERRQ(ierr);
-  ierr = PetscObjectComposeFunction((PetscObject)B, "MatMultTDotBegin_C", (PetscVoidFunction)MatMultTDotBegin_HIPMI355X);CHKERRQ(ierr);
+  ierr = PetscObjectComposeFunction((PetscObject)B, "MatSeqAIJGetArrays_C", "MatSeqAIJGetArrays", (PetscVoidFunction)MatSeqAIJGetArrays);CHKERRQ(ierr);
+  ierr = PetscObjectComposeFunction((PetscObject)B, "MatMultTDotBegin_C", "MatMultTDotBegin_HIPMI355X", (PetscVoidFunction)MatMultTDotBegin_HIPMI355X);CHKERRQ(ierr);
   if (bs == 1) {
-    ierr = PetscObjectComposeFunction((PetscObject)B, "MatSeqAIJSetPreallocation_C", (PetscVoidFunction)MatSeqAIJSetPreallocation_SeqAIJHIP);CHKERRQ(ierr);
-    ierr = PetscObjectComposeFunction((PetscObject)B, "MatSeqAIJSetPreallocationCSR_C", (PetscVoidFunction)MatSeqAIJSetPreallocationCSR_SeqAIJHIP);CHKERRQ(ierr);
+    ierr = PetscObjectComposeFunction((PetscObject)B, "MatSeqAIJSetPreallocation_C", "MatSeqAIJSetPreallocation_SeqAIJHIP", (PetscVoidFunction)MatSeqAIJSetPreallocation_SeqAIJHIP);CHKERRQ(ierr);
+    ierr = PetscObjectComposeFunction((PetscObject)B, "MatSeqAIJSetPreallocationCSR_C", "MatSeqAIJSetPreallocationCSR_SeqAIJHIP", (PetscVoidFunction)MatSeqAIJSetPreallocationCSR_SeqAIJHIP);CHKERRQ(ierr);
   } else {
-    ierr = PetscObjectComposeFunction((PetscObject)B, "MatSeqBAIJSetPreallocationCSR_C", (PetscVoidFunction)MatSeqBAIJSetPreallocationCSR_SeqBAIJHIP);CHKERRQ(ierr);
+    ierr = PetscObjectComposeFunction((PetscObject)B, "MatSeqBAIJSetPreallocationCSR_C", "MatSeqBAIJSetPreallocationCSR_SeqBAIJHIP", (PetscVoidFunction)MatSeqBAIJSetPreallocationCSR_SeqBAIJHIP);CHKERRQ(ierr);
   }
   return 0;
 }
@@ -742,20 +758,20 @@ PetscErrorCode MatCreate_SeqBAIJHIPMI355X(Mat B) { return create_common(B, MATSE
 /* MatCreateSeqAIJWithArrays (aij.c): the arrays are copied (the reference aliases them) */
 static PetscErrorCode adopt_csr(Mat B, PetscInt nrows, PetscInt bs, const PetscInt *i, const PetscInt *j, const PetscScalar *a) {
   PetscErrorCode ierr;
-  Mat_SeqAIJ *s = SA(B);
+  HipAIJ *s = SA(B);
   PetscInt nz = i[nrows];
   size_t vals = (size_t)nz * (size_t)(bs > 1 ? bs * bs : 1);
-  if (i[0] != 0) SETERRQ(B->comm, PETSC_ERR_ARG_OUTOFRANGE, "i (row indices) must start with 0");
-  for (PetscInt r = 0; r < nrows; r++) if (i[r + 1] < i[r]) SETERRQ(B->comm, PETSC_ERR_ARG_OUTOFRANGE, "Negative row length in i (row indices) row = %d length = %d", r, i[r + 1] - i[r]);
+  if (i[0] != 0) SETERRQ(HipObjComm(B), PETSC_ERR_ARG_OUTOFRANGE, "i (row indices) must start with 0");
+  for (PetscInt r = 0; r < nrows; r++) if (i[r + 1] < i[r]) SETERRQ(HipObjComm(B), PETSC_ERR_ARG_OUTOFRANGE, "Negative row length in i (row indices) row = %d length = %d", r, i[r + 1] - i[r]);
   {   /* column indices in range and ascending within each row (the kernels gather x[col] unchecked) */
     const PetscInt ncols = bs > 1 ? s->n / bs : s->n;
     for (PetscInt r = 0; r < nrows; r++) for (PetscInt k = i[r]; k < i[r + 1]; k++) {
-      if (j[k] < 0 || j[k] >= ncols) SETERRQ(B->comm, PETSC_ERR_ARG_OUTOFRANGE, "Column index %d out of range [0,%d) in row %d", j[k], ncols, r);
-      if (k > i[r] && j[k] <= j[k - 1]) SETERRQ(B->comm, PETSC_ERR_ARG_WRONG, "Column indices of row %d are not sorted and unique", r);
+      if (j[k] < 0 || j[k] >= ncols) SETERRQ(HipObjComm(B), PETSC_ERR_ARG_OUTOFRANGE, "Column index %d out of range [0,%d) in row %d", j[k], ncols, r);
+      if (k > i[r] && j[k] <= j[k - 1]) SETERRQ(HipObjComm(B), PETSC_ERR_ARG_WRONG, "Column indices of row %d are not sorted and unique", r);
     }
   }
   device_free(B);   /* the matrix may have been used before (MatLoad into a used Mat): nothing of the old pattern survives */
-  free(s->i); free(s->j); free(s->a); free(s->ilen); free(s->imax);
+  HipFree(s->i); HipFree(s->j); HipFree(s->a); HipFree(s->ilen); HipFree(s->imax);
   s->i = s->j = s->ilen = s->imax = NULL; s->a = NULL;
   ierr = PetscMalloc(sizeof(PetscInt) * (size_t)(nrows + 1), &s->i);CHKERRQ(ierr);
   ierr = PetscMalloc(sizeof(PetscInt) * (size_t)PetscMax(nz, 1), &s->j);CHKERRQ(ierr);
@@ -772,7 +788,7 @@ static PetscErrorCode adopt_csr(Mat B, PetscInt nrows, PetscInt bs, const PetscI
   }
   s->nz = s->maxnz = nz; s->compact = PETSC_TRUE;
   if (bs > 1) { s->m = nrows; s->bs = bs; }
-  B->preallocated = PETSC_TRUE; B->assembled = PETSC_TRUE; B->was_assembled = PETSC_TRUE; PetscObjectStateIncrease(B);
+  B->preallocated = PETSC_TRUE; B->assembled = PETSC_TRUE; B->was_assembled = PETSC_TRUE; HipStateIncrease(B);
   return 0;
 }
 /* "MatSeqAIJSetPreallocationCSR_C" (aij.c:3795) and its BAIJ analogue (baij.c): m, n are point sizes; i, j index blocks */
@@ -785,9 +801,11 @@ static PetscErrorCode MatSeqBAIJSetPreallocationCSR_SeqBAIJHIP(Mat B, PetscInt b
   if (bs == 1) SA(B)->bs = 1;
   return 0;
 }
+#endif
+
 PetscErrorCode MatSeqAIJGetArrays(Mat A, PetscInt *m, const PetscInt **i, const PetscInt **j, const PetscScalar **a) {
-  if (!A || !A->data || (strcmp(A->type_name, MATSEQAIJHIPMI355X) && strcmp(A->type_name, MATSEQBAIJHIPMI355X))) SETERRQ(0, PETSC_ERR_ARG_WRONG, "not a SeqAIJHIPMI355X matrix");
-  Mat_SeqAIJ *s = SA(A);
+  if (!A || !A->data || (strcmp(HipObjTypeName(A), MATSEQAIJHIPMI355X) && strcmp(HipObjTypeName(A), MATSEQBAIJHIPMI355X))) SETERRQ(0, PETSC_ERR_ARG_WRONG, "not a SeqAIJHIPMI355X matrix");
+  HipAIJ *s = SA(A);
   if (m) *m = s->m;
   if (i) *i = s->i;
   if (j) *j = s->j;

@@ -28,6 +28,8 @@
 #define HipObjTypeName(obj) (((PetscObject)(obj))->type_name)
 #define HipObjPrefix(obj) (((PetscObject)(obj))->prefix)
 #define HipObjState(obj) (((PetscObject)(obj))->state)
+#define HipStateIncrease(obj) PetscObjectStateIncrease(obj)
+#define HipFree(p) free(p)
 #endif
 #include "mi355x_kernels.h"
 #include "mi355x_comm.h"
@@ -77,10 +79,14 @@ typedef struct {
   PetscInt local_n;
   PetscInt *local_slots, *d_local_slots;
 } VecScatterSide;
+/* the plugin's own scatter context: device index lists, message buffers, events.  On the harness it IS the VecScatter
+ * (there is no other); inside a PETSc tree it lives beside the reference's Mvctx, which MatMult no longer uses. */
 #if !defined(PETSCHIPMI355X_WITH_PETSC)
+typedef struct _p_VecScatter *HipScatter;
 struct _p_VecScatter {
 #else
-struct _p_VecScatter_HIPMI355X {          /* hangs off the reference's VecScatter->spptr (vecimpl.h:539-555) */
+typedef struct _p_HipScatter *HipScatter;
+struct _p_HipScatter {
 #endif
   MPI_Comm comm;
   VecScatterSide to, from;
@@ -91,12 +97,20 @@ struct _p_VecScatter_HIPMI355X {          /* hangs off the reference's VecScatte
   PetscScalar *h_send, *h_recv;   /* host staging buffers of the host-staged transport */
   PetscScalar *d_local_tmp;       /* device staging of the local (self) part, local_n doubles */
 };
-PetscErrorCode VecScatterMarkReady(VecScatter ctx, Vec x);
-PetscErrorCode VecScatterCreate_PtoS_MPIAIJ(MPI_Comm comm, PetscLayout xmap, PetscInt ec, const PetscInt *garray, VecScatter *ctx);
+PetscErrorCode HipScatterCreate_PtoS_MPIAIJ(MPI_Comm comm, PetscLayout xmap, PetscInt ec, const PetscInt *garray, HipScatter *ctx);
+PetscErrorCode HipScatterMarkReady(HipScatter ctx, Vec x);
+PetscErrorCode HipScatterBegin(HipScatter ctx, Vec x, Vec y, InsertMode addv, ScatterMode mode);
+PetscErrorCode HipScatterEnd(HipScatter ctx, Vec x, Vec y, InsertMode addv, ScatterMode mode);
+PetscErrorCode HipScatterDestroy(HipScatter *ctx);
+PetscErrorCode HipScatterGetLists(HipScatter ctx, PetscInt *nrecv, const PetscInt **rprocs, const PetscInt **rstarts, const PetscInt **rindices,
+                                  PetscInt *nsend, const PetscInt **sprocs, const PetscInt **sstarts, const PetscInt **sindices,
+                                  PetscInt *nlocal, const PetscInt **lto, const PetscInt **lfrom);
 
 /* ---- Mat ---- */
 /* host CSR container: the part of Mat_SeqAIJ the path needs (src/mat/impls/aij/seq/aij.h:10-39,99-115), same member
- * names.  With a real PETSc the parent type MATSEQAIJ owns it (aij.h) and the assembly code of aijhip.c is not built. */
+ * names.  On the harness it IS the container (A->data) and aijhip.c assembles into it; inside a PETSc tree the parent
+ * type MATSEQAIJ owns the container (aij.h) and this struct is a VIEW of its arrays, refreshed at MatAssemblyEnd and
+ * kept in the device mirror (integration/petsc-3.3/aijhipmi355x.c) -- the kernels' callers read the same fields. */
 typedef struct {
   PetscInt m, n;            /* local rows / columns */
   PetscInt *i, *j;          /* row pointer / column index */
@@ -107,7 +121,7 @@ typedef struct {
   PetscBool compact;        /* rows are packed (after assembly) */
   PetscInt nonzerorows;
   PetscInt inode_count, *inode_size;   /* Mat_SeqAIJ_Inode node_count / size (aij.h:99-115); 0 / NULL: plain routines */
-} Mat_SeqAIJ;
+} HipAIJ;
 
 /* device mirror */
 typedef struct {
@@ -128,16 +142,31 @@ typedef struct {
   PetscScalar *bm_v;                             /* device staging of the element values */
   /* per-launch device timing for bench.py (hipEvent pairs on the compute stream) */
   PetscBool timing; PetscInt time_n, time_cap; mi355x_event_t *time_ev;
+#if defined(PETSCHIPMI355X_WITH_PETSC)
+  HipAIJ view;               /* of the parent's Mat_SeqAIJ */
+#endif
 } Mat_SeqAIJHIP;
+#if defined(PETSCHIPMI355X_WITH_PETSC)
+#define HipAIJGet(A) (&((Mat_SeqAIJHIP *)(A)->spptr)->view)
+#else
+#define HipAIJGet(A) ((HipAIJ *)(A)->data)
+#endif
 
-/* Mat_MPIAIJ, src/mat/impls/aij/mpi/mpiaij.h:35-77 */
+/* the members of Mat_MPIAIJ the path needs (src/mat/impls/aij/mpi/mpiaij.h:35-77), same names, with the plugin's scatter
+ * in place of Mvctx.  On the harness it IS the container (A->data); inside a PETSc tree the parent MATMPIAIJ owns the
+ * container and this struct hangs off A->spptr with A, B, garray aliasing the parent's after each assembly. */
 typedef struct {
   Mat A, B;                 /* diagonal / off-diagonal blocks (SeqAIJHIPMI355X) */
   PetscInt *garray, ec;
   Vec lvec;
-  VecScatter Mvctx;
+  HipScatter hscat;
   PetscInt rstart, rend, cstart, cend;
-} Mat_MPIAIJ;
+} HipMPIAIJ;
+#if defined(PETSCHIPMI355X_WITH_PETSC)
+#define HipMPIAIJGet(A) ((HipMPIAIJ *)(A)->spptr)
+#else
+#define HipMPIAIJGet(A) ((HipMPIAIJ *)(A)->data)
+#endif
 
 PetscErrorCode MatCreate_SeqAIJHIPMI355X(Mat);
 PetscErrorCode MatCreate_MPIAIJHIPMI355X(Mat);

@@ -34,24 +34,27 @@ PetscErrorCode PetscHIPMI355XRegisterAll(void) {
   static int done = 0;
   if (done) return 0;
   done = 1;
-  ierr = VecRegister(VECSEQHIPMI355X, VecCreate_SeqHIPMI355X);CHKERRQ(ierr);
-  ierr = VecRegister(VECMPIHIPMI355X, VecCreate_MPIHIPMI355X);CHKERRQ(ierr);
-  ierr = VecRegister(VECHIPMI355X, VecCreate_HIPMI355X);CHKERRQ(ierr);
-  ierr = MatRegister(MATSEQAIJHIPMI355X, MatCreate_SeqAIJHIPMI355X);CHKERRQ(ierr);
-  ierr = MatRegister(MATMPIAIJHIPMI355X, MatCreate_MPIAIJHIPMI355X);CHKERRQ(ierr);
-  ierr = MatRegister(MATAIJHIPMI355X, MatCreate_AIJHIPMI355X);CHKERRQ(ierr);
-  ierr = MatRegister(MATSEQBAIJHIPMI355X, MatCreate_SeqBAIJHIPMI355X);CHKERRQ(ierr);
+  ierr = VecRegister(VECSEQHIPMI355X, 0, "VecCreate_SeqHIPMI355X", VecCreate_SeqHIPMI355X);CHKERRQ(ierr);
+  ierr = VecRegister(VECMPIHIPMI355X, 0, "VecCreate_MPIHIPMI355X", VecCreate_MPIHIPMI355X);CHKERRQ(ierr);
+  ierr = VecRegister(VECHIPMI355X, 0, "VecCreate_HIPMI355X", VecCreate_HIPMI355X);CHKERRQ(ierr);
+  ierr = MatRegister(MATSEQAIJHIPMI355X, 0, "MatCreate_SeqAIJHIPMI355X", MatCreate_SeqAIJHIPMI355X);CHKERRQ(ierr);
+  ierr = MatRegister(MATMPIAIJHIPMI355X, 0, "MatCreate_MPIAIJHIPMI355X", MatCreate_MPIAIJHIPMI355X);CHKERRQ(ierr);
+  ierr = MatRegister(MATAIJHIPMI355X, 0, "MatCreate_AIJHIPMI355X", MatCreate_AIJHIPMI355X);CHKERRQ(ierr);
+  ierr = MatRegister(MATSEQBAIJHIPMI355X, 0, "MatCreate_SeqBAIJHIPMI355X", MatCreate_SeqBAIJHIPMI355X);CHKERRQ(ierr);
 #if !defined(PETSCHIPMI355X_WITH_PETSC)
   /* the harness has no CPU types: the reference's generic names select the HIPMI355X implementation of the same shape
    * (with a real PETSc they keep meaning the CPU types, and -vec_type hipmi355x -mat_type aijhipmi355x select these) */
-  ierr = VecRegister(VECSEQ, VecCreate_SeqHIPMI355X);CHKERRQ(ierr);
-  ierr = VecRegister(VECMPI, VecCreate_MPIHIPMI355X);CHKERRQ(ierr);
-  ierr = VecRegister(VECSTANDARD, VecCreate_HIPMI355X);CHKERRQ(ierr);
-  ierr = MatRegister(MATSEQAIJ, MatCreate_SeqAIJHIPMI355X);CHKERRQ(ierr);
-  ierr = MatRegister(MATMPIAIJ, MatCreate_MPIAIJHIPMI355X);CHKERRQ(ierr);
-  ierr = MatRegister(MATAIJ, MatCreate_AIJHIPMI355X);CHKERRQ(ierr);
-  ierr = MatRegister(MATSEQBAIJ, MatCreate_SeqBAIJHIPMI355X);CHKERRQ(ierr);
-  ierr = PCRegister(PCILU, PCCreate_ILU_HIPMI355X);CHKERRQ(ierr);
+  ierr = VecRegister(VECSEQ, 0, "VecCreate_SeqHIPMI355X", VecCreate_SeqHIPMI355X);CHKERRQ(ierr);
+  ierr = VecRegister(VECMPI, 0, "VecCreate_MPIHIPMI355X", VecCreate_MPIHIPMI355X);CHKERRQ(ierr);
+  ierr = VecRegister(VECSTANDARD, 0, "VecCreate_HIPMI355X", VecCreate_HIPMI355X);CHKERRQ(ierr);
+  ierr = MatRegister(MATSEQAIJ, 0, "MatCreate_SeqAIJHIPMI355X", MatCreate_SeqAIJHIPMI355X);CHKERRQ(ierr);
+  ierr = MatRegister(MATMPIAIJ, 0, "MatCreate_MPIAIJHIPMI355X", MatCreate_MPIAIJHIPMI355X);CHKERRQ(ierr);
+  ierr = MatRegister(MATAIJ, 0, "MatCreate_AIJHIPMI355X", MatCreate_AIJHIPMI355X);CHKERRQ(ierr);
+  ierr = MatRegister(MATSEQBAIJ, 0, "MatCreate_SeqBAIJHIPMI355X", MatCreate_SeqBAIJHIPMI355X);CHKERRQ(ierr);
+  ierr = PCRegister(PCILU, 0, "PCCreate_ILU_HIPMI355X", PCCreate_ILU_HIPMI355X);CHKERRQ(ierr);
+#else
+  /* PETSc's own PCILU keeps its name (host MatSolve); the device-side ILU(0) apply is offered next to it */
+  ierr = PCRegister("iluhipmi355x", 0, "PCCreate_ILU_HIPMI355X", PCCreate_ILU_HIPMI355X);CHKERRQ(ierr);
 #endif
   return 0;
 }

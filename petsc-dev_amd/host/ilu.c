@@ -25,7 +25,7 @@ typedef struct {
 } PC_ILU;
 
 static PetscErrorCode ilu_free(PC_ILU *f) {
-  free(f->bi); free(f->bj); free(f->bdiag); free(f->ba); free(f->levptrL); free(f->levptrU);
+  HipFree(f->bi); HipFree(f->bj); HipFree(f->bdiag); HipFree(f->ba); HipFree(f->levptrL); HipFree(f->levptrU);
   if (f->d_bi) mi355x_free(f->d_bi);
   if (f->d_bj) mi355x_free(f->d_bj);
   if (f->d_bdiag) mi355x_free(f->d_bdiag);
@@ -53,7 +53,7 @@ static PetscErrorCode level_order(PetscInt n, const PetscInt *lev, PetscInt nlev
   for (PetscInt l = 0; l < nlev; l++) ptr[l + 1] += ptr[l];
   memcpy(next, ptr, sizeof(PetscInt) * (size_t)(nlev + 1));
   for (PetscInt i = 0; i < n; i++) rows[next[lev[i]]++] = i;
-  free(next);
+  HipFree(next);
   *ptr_out = ptr; *rows_out = rows;
   return 0;
 }
@@ -64,10 +64,10 @@ static PetscErrorCode PCSetUp_ILU(PC pc) {
   Mat A = pc->pmat;
   PetscInt n; const PetscInt *ai, *aj; const PetscScalar *aa;
   PetscDeviceCtx *dc;
-  if (strcmp(A->type_name, MATSEQAIJHIPMI355X)) SETERRQ(pc->comm, PETSC_ERR_SUP, "PCILU needs a sequential AIJ matrix (use -pc_type bjacobi -sub_pc_type ilu in parallel); got %s", A->type_name);
-  if (f->factored_state == A->state && f->d_ba) return 0;
+  if (strcmp(HipObjTypeName(A), MATSEQAIJHIPMI355X)) SETERRQ(HipObjComm(pc), PETSC_ERR_SUP, "PCILU needs a sequential AIJ matrix (use -pc_type bjacobi -sub_pc_type ilu in parallel); got %s", HipObjTypeName(A));
+  if (f->factored_state == HipObjState(A) && f->d_ba) return 0;
   ierr = MatSeqAIJGetArrays(A, &n, &ai, &aj, &aa);CHKERRQ(ierr);
-  if (A->rmap->n != A->cmap->n) SETERRQ(pc->comm, PETSC_ERR_ARG_WRONG, "Must be square matrix, rows %d columns %d", A->rmap->n, A->cmap->n);
+  if (A->rmap->n != A->cmap->n) SETERRQ(HipObjComm(pc), PETSC_ERR_ARG_WRONG, "Must be square matrix, rows %d columns %d", A->rmap->n, A->cmap->n);
   ierr = ilu_free(f);CHKERRQ(ierr);
   f->n = n; f->nz = ai[n];
   PetscInt *adiag;
@@ -75,7 +75,7 @@ static PetscErrorCode PCSetUp_ILU(PC pc) {
   for (PetscInt i = 0; i < n; i++) {
     adiag[i] = -1;
     for (PetscInt q = ai[i]; q < ai[i + 1]; q++) if (aj[q] == i) { adiag[i] = q; break; }
-    if (adiag[i] < 0) SETERRQ(pc->comm, PETSC_ERR_ARG_WRONGSTATE, "Matrix is missing diagonal entry %d", i);
+    if (adiag[i] < 0) SETERRQ(HipObjComm(pc), PETSC_ERR_ARG_WRONGSTATE, "Matrix is missing diagonal entry %d", i);
   }
   ierr = PetscMalloc(sizeof(PetscInt) * (size_t)(n + 1), &f->bi);CHKERRQ(ierr);
   ierr = PetscMalloc(sizeof(PetscInt) * (size_t)(f->nz + 1), &f->bj);CHKERRQ(ierr);
@@ -122,10 +122,10 @@ static PetscErrorCode PCSetUp_ILU(PC pc) {
     for (PetscInt j = 0; j < nzl; j++) { ba[bi[i] + j] = rtmp[bj[bi[i] + j]]; rs += PetscAbsScalar(ba[bi[i] + j]); }
     for (PetscInt j = 0; j < nzu - 1; j++) { ba[bdiag[i + 1] + 1 + j] = rtmp[bj[bdiag[i + 1] + 1 + j]]; rs += PetscAbsScalar(ba[bdiag[i + 1] + 1 + j]); }
     /* MatPivotCheck: the reference would shift (MAT_SHIFT_NONZERO); a shift-free factorisation is what is ported */
-    if (PetscAbsScalar(rtmp[i]) <= zeropivot * rs) { free(rtmp); free(adiag); SETERRQ(pc->comm, 71 /* PETSC_ERR_MAT_LU_ZRPVT */, "Zero pivot row %d value %g tolerance %g * rs %g (pivot shifting is outside the ported path)", i, PetscAbsScalar(rtmp[i]), zeropivot, rs); }
+    if (PetscAbsScalar(rtmp[i]) <= zeropivot * rs) { HipFree(rtmp); HipFree(adiag); SETERRQ(HipObjComm(pc), 71 /* PETSC_ERR_MAT_LU_ZRPVT */, "Zero pivot row %d value %g tolerance %g * rs %g (pivot shifting is outside the ported path)", i, PetscAbsScalar(rtmp[i]), zeropivot, rs); }
     ba[bdiag[i]] = 1.0 / rtmp[i];
   }
-  free(rtmp); free(adiag);
+  HipFree(rtmp); HipFree(adiag);
   /* dependency levels: a row may start once the rows it references are done */
   PetscInt *lev, *levU, *rowsL, *rowsU;
   ierr = PetscMalloc(sizeof(PetscInt) * (size_t)PetscMax(n, 1), &lev);CHKERRQ(ierr);
@@ -147,8 +147,8 @@ static PetscErrorCode PCSetUp_ILU(PC pc) {
   ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
   {   /* sync-free solves: worth it as soon as the level launches would be a launch-bound chain */
     char mode[32] = "syncfree"; PetscBool set;
-    ierr = PetscOptionsGetString(pc->prefix, "-pc_factor_hipmi355x_trisolve", mode, sizeof(mode), &set);CHKERRQ(ierr);
-    if (strcmp(mode, "syncfree") && strcmp(mode, "level")) SETERRQ(pc->comm, PETSC_ERR_ARG_WRONG, "-pc_factor_hipmi355x_trisolve <syncfree|level>, got %s", mode);
+    ierr = PetscOptionsGetString(HipObjPrefix(pc), "-pc_factor_hipmi355x_trisolve", mode, sizeof(mode), &set);CHKERRQ(ierr);
+    if (strcmp(mode, "syncfree") && strcmp(mode, "level")) SETERRQ(HipObjComm(pc), PETSC_ERR_ARG_WRONG, "-pc_factor_hipmi355x_trisolve <syncfree|level>, got %s", mode);
     if (!strcmp(mode, "syncfree") && n > 0 && (f->nlevL + f->nlevU > 16 || set)) {
       PetscInt *rpU, *rlU, *rlL; PetscScalar *dinv;
       ierr = PetscMalloc(sizeof(PetscInt) * (size_t)n, &rpU);CHKERRQ(ierr);
@@ -161,7 +161,7 @@ static PetscErrorCode PCSetUp_ILU(PC pc) {
       }
       int rc = mi355x_trisolve_plan_create(dc->h, n, f->nlevL, lev, bi, rlL, bj, ba, NULL, &f->tri_lo);
       if (!rc) rc = mi355x_trisolve_plan_create(dc->h, n, f->nlevU, levU, rpU, rlU, bj, ba, dinv, &f->tri_up);
-      free(rpU); free(rlU); free(rlL); free(dinv);
+      HipFree(rpU); HipFree(rlU); HipFree(rlL); HipFree(dinv);
       if (rc) {   /* e.g. a factor too large for 32-bit sliced-ELL offsets: the level kernels serve */
         if (f->tri_lo) mi355x_trisolve_plan_destroy(f->tri_lo);
         if (f->tri_up) mi355x_trisolve_plan_destroy(f->tri_up);
@@ -169,7 +169,7 @@ static PetscErrorCode PCSetUp_ILU(PC pc) {
       }
     }
   }
-  free(lev); free(levU);
+  HipFree(lev); HipFree(levU);
   CHKHIP(mi355x_malloc((void **)&f->d_bi, sizeof(PetscInt) * (size_t)(n + 1)));
   CHKHIP(mi355x_malloc((void **)&f->d_bj, sizeof(PetscInt) * (size_t)(f->nz + 1)));
   CHKHIP(mi355x_malloc((void **)&f->d_bdiag, sizeof(PetscInt) * (size_t)(n + 1)));
@@ -183,8 +183,8 @@ static PetscErrorCode PCSetUp_ILU(PC pc) {
   CHKHIP(mi355x_memcpy_h2d(dc->h, f->d_rowsL, rowsL, sizeof(PetscInt) * (size_t)n));
   CHKHIP(mi355x_memcpy_h2d(dc->h, f->d_rowsU, rowsU, sizeof(PetscInt) * (size_t)n));
   CHKHIP(mi355x_handle_synchronize(dc->h));
-  free(rowsL); free(rowsU);
-  f->factored_state = A->state;
+  HipFree(rowsL); HipFree(rowsU);
+  f->factored_state = HipObjState(A);
   return 0;
 }
 
@@ -203,11 +203,11 @@ static PetscErrorCode PCApply_ILU(PC pc, Vec x, Vec y) {   /* PCApply_ILU -> Mat
     if (rc == 719) {   /* hipErrorLaunchFailure: an earlier application gave up on a dependency (its result was unusable) */
       mi355x_trisolve_plan_destroy(f->tri_lo); mi355x_trisolve_plan_destroy(f->tri_up);
       f->tri_lo = f->tri_up = NULL;
-      SETERRQ(pc->comm, PETSC_ERR_LIB, "sync-free triangular solve timed out in an earlier application; the level-scheduled solves are used from now on");
+      SETERRQ(HipObjComm(pc), PETSC_ERR_LIB, "sync-free triangular solve timed out in an earlier application; the level-scheduled solves are used from now on");
     }
     CHKHIP(rc);
     ierr = VecHIPRestoreWrite(y);CHKERRQ(ierr);
-    PetscObjectStateIncrease(y);
+    HipStateIncrease(y);
     ierr = PetscLogFlops(2.0 * f->nz - f->n);CHKERRQ(ierr);
     return 0;
   }
@@ -235,14 +235,14 @@ static PetscErrorCode PCApply_ILU(PC pc, Vec x, Vec y) {   /* PCApply_ILU -> Mat
       CHKHIP(mi355x_ilu0_upper_level(dc->h, f->levptrU[l + 1] - f->levptrU[l], f->d_rowsU + f->levptrU[l], f->d_bj, f->d_ba, f->d_bdiag, dx));
   }
   ierr = VecHIPRestoreWrite(y);CHKERRQ(ierr);
-  PetscObjectStateIncrease(y);
+  HipStateIncrease(y);
   ierr = PetscLogFlops(2.0 * f->nz - f->n);CHKERRQ(ierr);
   return 0;
 }
 
 static PetscErrorCode PCDestroy_ILU(PC pc) {
   PC_ILU *f = (PC_ILU *)pc->data;
-  if (f) { ilu_free(f); free(f); pc->data = NULL; }
+  if (f) { ilu_free(f); HipFree(f); pc->data = NULL; }
   return 0;
 }
 
@@ -258,7 +258,7 @@ PetscErrorCode PCCreate_ILU_HIPMI355X(PC pc) {
 
 /* 1 when PCApply runs the sync-free solves (two launches), 0 for the level-scheduled kernels; *aborted: a dependency wait gave up */
 PetscErrorCode PCILUGetSolver_HIPMI355X(PC pc, PetscInt *syncfree, PetscInt *aborted) {
-  if (strcmp(pc->type_name, "ilu")) SETERRQ(pc->comm, PETSC_ERR_ARG_WRONG, "not a PCILU");
+  if (strcmp(HipObjTypeName(pc), "ilu")) SETERRQ(HipObjComm(pc), PETSC_ERR_ARG_WRONG, "not a PCILU");
   PC_ILU *f = (PC_ILU *)pc->data;
   int a = 0, b = 0;
   if (syncfree) *syncfree = f->tri_lo ? 1 : 0;
@@ -274,7 +274,7 @@ PetscErrorCode PCILUGetSolver_HIPMI355X(PC pc, PetscInt *syncfree, PetscInt *abo
 
 /* levels of the two triangular solves (for tests / DESIGN.md) */
 PetscErrorCode PCILUGetLevels_HIPMI355X(PC pc, PetscInt *nlevL, PetscInt *nlevU) {
-  if (strcmp(pc->type_name, "ilu")) SETERRQ(pc->comm, PETSC_ERR_ARG_WRONG, "not a PCILU");
+  if (strcmp(HipObjTypeName(pc), "ilu")) SETERRQ(HipObjComm(pc), PETSC_ERR_ARG_WRONG, "not a PCILU");
   PC_ILU *f = (PC_ILU *)pc->data;
   if (nlevL) *nlevL = f->nlevL;
   if (nlevU) *nlevU = f->nlevU;

@@ -4,8 +4,9 @@
  * and B (off-diagonal block, columns compacted through garray) are MATSEQAIJHIPMI355X. */
 #include "hipmi355ximpl.h"
 
-#define MA(A) ((Mat_MPIAIJ *)(A)->data)
+#define MA(A) HipMPIAIJGet(A)
 
+#if !defined(PETSCHIPMI355X_WITH_PETSC)   /* container, assembly and MatSetUpMultiply are the parent MATMPIAIJ's inside a PETSc tree */
 static PetscErrorCode make_block(Mat parent, PetscInt m, PetscInt n, Mat *blk) {
   PetscErrorCode ierr;
   (void)parent;
@@ -19,7 +20,7 @@ static PetscErrorCode make_block(Mat parent, PetscInt m, PetscInt n, Mat *blk) {
  * mpiaijcusp.cu:36-46,213-215) */
 static PetscErrorCode MatMPIAIJSetPreallocation_MPIAIJHIP(Mat A, PetscInt d_nz, const PetscInt d_nnz[], PetscInt o_nz, const PetscInt o_nnz[]) {
   PetscErrorCode ierr;
-  Mat_MPIAIJ *a = MA(A);
+  HipMPIAIJ *a = MA(A);
   if (d_nz == PETSC_DEFAULT || d_nz == PETSC_DECIDE) d_nz = 5;     /* mpiaij.c MatMPIAIJSetPreallocation_MPIAIJ */
   if (o_nz == PETSC_DEFAULT || o_nz == PETSC_DECIDE) o_nz = 2;
   if (!a->A) {
@@ -38,15 +39,15 @@ static int cmp_int(const void *a, const void *b) { PetscInt x = *(const PetscInt
 /* MatSetValues_MPIAIJ, mpiaij.c:517-560: locally owned rows only (the reference stashes the rest) */
 static PetscErrorCode MatSetValues_MPIAIJHIP(Mat A, PetscInt m, const PetscInt im[], PetscInt n, const PetscInt in[], const PetscScalar v[], InsertMode addv) {
   PetscErrorCode ierr;
-  Mat_MPIAIJ *a = MA(A);
+  HipMPIAIJ *a = MA(A);
   for (PetscInt i = 0; i < m; i++) {
     if (im[i] < 0) continue;
-    if (im[i] < a->rstart || im[i] >= a->rend) SETERRQ(A->comm, PETSC_ERR_SUP, "row %d is not owned by this process [%d,%d): off-process MatSetValues is outside the ported path", im[i], a->rstart, a->rend);
+    if (im[i] < a->rstart || im[i] >= a->rend) SETERRQ(HipObjComm(A), PETSC_ERR_SUP, "row %d is not owned by this process [%d,%d): off-process MatSetValues is outside the ported path", im[i], a->rstart, a->rend);
     PetscInt row = im[i] - a->rstart;
     for (PetscInt j = 0; j < n; j++) {
       PetscInt col = in[j];
       if (col < 0) continue;
-      if (col >= A->cmap->N) SETERRQ(A->comm, PETSC_ERR_ARG_OUTOFRANGE, "Column too large: col %d max %d", col, A->cmap->N - 1);
+      if (col >= A->cmap->N) SETERRQ(HipObjComm(A), PETSC_ERR_ARG_OUTOFRANGE, "Column too large: col %d max %d", col, A->cmap->N - 1);
       if (col >= a->cstart && col < a->cend) {
         PetscInt lc = col - a->cstart;
         ierr = MatSetValues(a->A, 1, &row, 1, &lc, &v[i * n + j], addv);CHKERRQ(ierr);
@@ -54,7 +55,7 @@ static PetscErrorCode MatSetValues_MPIAIJHIP(Mat A, PetscInt m, const PetscInt i
         PetscInt bc = col;
         if (a->garray) {   /* assembled before: B's columns are compacted (colmap lookup, mpiaij.c:540-550) */
           PetscInt *p = (PetscInt *)bsearch(&col, a->garray, (size_t)a->ec, sizeof(PetscInt), cmp_int);
-          if (!p) SETERRQ(A->comm, PETSC_ERR_SUP, "new off-diagonal column %d after assembly (MatDisAssemble_MPIAIJ, mmaij.c:170) is outside the ported path", col);
+          if (!p) SETERRQ(HipObjComm(A), PETSC_ERR_SUP, "new off-diagonal column %d after assembly (MatDisAssemble_MPIAIJ, mmaij.c:170) is outside the ported path", col);
           bc = (PetscInt)(p - a->garray);
         }
         ierr = MatSetValues(a->B, 1, &row, 1, &bc, &v[i * n + j], addv);CHKERRQ(ierr);
@@ -67,8 +68,8 @@ static PetscErrorCode MatSetValues_MPIAIJHIP(Mat A, PetscInt m, const PetscInt i
 /* MatSetUpMultiply_MPIAIJ, mmaij.c:9-161 */
 PetscErrorCode MatSetUpMultiply_MPIAIJ(Mat mat) {
   PetscErrorCode ierr;
-  Mat_MPIAIJ *aij = MA(mat);
-  Mat_SeqAIJ *B = (Mat_SeqAIJ *)aij->B->data;
+  HipMPIAIJ *aij = MA(mat);
+  HipAIJ *B = HipAIJGet(aij->B);
   PetscInt nzB = B->nz, ec = 0, *garray, *tmp;
   /* garray = sorted distinct global columns of B (mmaij.c:27-50) */
   ierr = PetscMalloc(sizeof(PetscInt) * (size_t)PetscMax(nzB, 1), &tmp);CHKERRQ(ierr);
@@ -77,7 +78,7 @@ PetscErrorCode MatSetUpMultiply_MPIAIJ(Mat mat) {
   for (PetscInt k = 0; k < nzB; k++) if (k == 0 || tmp[k] != tmp[k - 1]) tmp[ec++] = tmp[k];
   ierr = PetscMalloc(sizeof(PetscInt) * (size_t)(ec + 1), &garray);CHKERRQ(ierr);
   memcpy(garray, tmp, sizeof(PetscInt) * (size_t)ec);
-  free(tmp);
+  HipFree(tmp);
   /* compact out the extra columns in B (mmaij.c:56-63) */
   for (PetscInt k = 0; k < nzB; k++) {
     PetscInt *p = (PetscInt *)bsearch(&B->j[k], garray, (size_t)ec, sizeof(PetscInt), cmp_int);
@@ -86,11 +87,11 @@ PetscErrorCode MatSetUpMultiply_MPIAIJ(Mat mat) {
   B->n = ec;
   ierr = PetscLayoutDestroy(&aij->B->cmap);CHKERRQ(ierr);
   ierr = PetscLayoutCreateSetUp(PETSC_COMM_SELF, ec, ec, &aij->B->cmap);CHKERRQ(ierr);
-  aij->B->state++;
+  HipStateIncrease(aij->B);
   /* local vector that is used to scatter into (mmaij.c:102) */
   ierr = VecCreateSeqHIPMI355X(PETSC_COMM_SELF, ec, &aij->lvec);CHKERRQ(ierr);
   /* generate the scatter context (mmaij.c:131-148) */
-  ierr = VecScatterCreate_PtoS_MPIAIJ(mat->comm, mat->cmap, ec, garray, &aij->Mvctx);CHKERRQ(ierr);
+  ierr = HipScatterCreate_PtoS_MPIAIJ(HipObjComm(mat), mat->cmap, ec, garray, &aij->hscat);CHKERRQ(ierr);
   aij->garray = garray; aij->ec = ec;
   ierr = MatSeqAIJHIPSetCompressedRow(aij->B, PETSC_TRUE);CHKERRQ(ierr);
   return 0;
@@ -98,7 +99,7 @@ PetscErrorCode MatSetUpMultiply_MPIAIJ(Mat mat) {
 
 static PetscErrorCode MatAssemblyEnd_MPIAIJHIP(Mat A, MatAssemblyType mode) {   /* mpiaij.c:650-720 */
   PetscErrorCode ierr;
-  Mat_MPIAIJ *a = MA(A);
+  HipMPIAIJ *a = MA(A);
   if (mode == MAT_FLUSH_ASSEMBLY) return 0;
   ierr = MatAssemblyBegin(a->A, mode);CHKERRQ(ierr);
   ierr = MatAssemblyEnd(a->A, mode);CHKERRQ(ierr);
@@ -108,49 +109,51 @@ static PetscErrorCode MatAssemblyEnd_MPIAIJHIP(Mat A, MatAssemblyType mode) {   
   return 0;
 }
 
+#endif
+
 static PetscErrorCode MatMult_MPIAIJHIP(Mat A, Vec xx, Vec yy) {   /* mpiaij.c:1102-1116 */
   PetscErrorCode ierr;
-  Mat_MPIAIJ *a = MA(A);
-  if (xx->map->n != A->cmap->n) SETERRQ(A->comm, PETSC_ERR_ARG_SIZ, "Incompatible partition of A (%d) and xx (%d)", A->cmap->n, xx->map->n);
+  HipMPIAIJ *a = MA(A);
+  if (xx->map->n != A->cmap->n) SETERRQ(HipObjComm(A), PETSC_ERR_ARG_SIZ, "Incompatible partition of A (%d) and xx (%d)", A->cmap->n, xx->map->n);
   /* Same dependences as the reference's Begin / mult / End sequence, but the diagonal-block SpMV is queued before
    * the host spends its ~tens of microseconds enqueueing the RCCL group: "x is final" is marked first. */
-  ierr = VecScatterMarkReady(a->Mvctx, xx);CHKERRQ(ierr);
+  ierr = HipScatterMarkReady(a->hscat, xx);CHKERRQ(ierr);
   ierr = (*a->A->ops->mult)(a->A, xx, yy);CHKERRQ(ierr);                                         /* compute stream */
-  ierr = VecScatterBegin(a->Mvctx, xx, a->lvec, INSERT_VALUES, SCATTER_FORWARD);CHKERRQ(ierr);   /* halo stream, overlaps */
-  ierr = VecScatterEnd(a->Mvctx, xx, a->lvec, INSERT_VALUES, SCATTER_FORWARD);CHKERRQ(ierr);
+  ierr = HipScatterBegin(a->hscat, xx, a->lvec, INSERT_VALUES, SCATTER_FORWARD);CHKERRQ(ierr);   /* halo stream, overlaps */
+  ierr = HipScatterEnd(a->hscat, xx, a->lvec, INSERT_VALUES, SCATTER_FORWARD);CHKERRQ(ierr);
   ierr = (*a->B->ops->multadd)(a->B, a->lvec, yy, yy);CHKERRQ(ierr);
   return 0;
 }
 static PetscErrorCode MatMultAdd_MPIAIJHIP(Mat A, Vec xx, Vec yy, Vec zz) {   /* mpiaij.c:1132-1143 */
   PetscErrorCode ierr;
-  Mat_MPIAIJ *a = MA(A);
-  ierr = VecScatterBegin(a->Mvctx, xx, a->lvec, INSERT_VALUES, SCATTER_FORWARD);CHKERRQ(ierr);
+  HipMPIAIJ *a = MA(A);
+  ierr = HipScatterBegin(a->hscat, xx, a->lvec, INSERT_VALUES, SCATTER_FORWARD);CHKERRQ(ierr);
   ierr = (*a->A->ops->multadd)(a->A, xx, yy, zz);CHKERRQ(ierr);
-  ierr = VecScatterEnd(a->Mvctx, xx, a->lvec, INSERT_VALUES, SCATTER_FORWARD);CHKERRQ(ierr);
+  ierr = HipScatterEnd(a->hscat, xx, a->lvec, INSERT_VALUES, SCATTER_FORWARD);CHKERRQ(ierr);
   ierr = (*a->B->ops->multadd)(a->B, a->lvec, zz, zz);CHKERRQ(ierr);
   return 0;
 }
 static PetscErrorCode MatMultTranspose_MPIAIJHIP(Mat A, Vec xx, Vec yy) {   /* mpiaij.c:1147-1174, !merged branch */
   PetscErrorCode ierr;
-  Mat_MPIAIJ *a = MA(A);
+  HipMPIAIJ *a = MA(A);
   ierr = (*a->B->ops->multtranspose)(a->B, xx, a->lvec);CHKERRQ(ierr);
-  ierr = VecScatterBegin(a->Mvctx, a->lvec, yy, ADD_VALUES, SCATTER_REVERSE);CHKERRQ(ierr);
+  ierr = HipScatterBegin(a->hscat, a->lvec, yy, ADD_VALUES, SCATTER_REVERSE);CHKERRQ(ierr);
   ierr = (*a->A->ops->multtranspose)(a->A, xx, yy);CHKERRQ(ierr);
-  ierr = VecScatterEnd(a->Mvctx, a->lvec, yy, ADD_VALUES, SCATTER_REVERSE);CHKERRQ(ierr);
+  ierr = HipScatterEnd(a->hscat, a->lvec, yy, ADD_VALUES, SCATTER_REVERSE);CHKERRQ(ierr);
   return 0;
 }
 static PetscErrorCode MatMultTransposeAdd_MPIAIJHIP(Mat A, Vec xx, Vec yy, Vec zz) {   /* mpiaij.c:1223-1238 */
   PetscErrorCode ierr;
-  Mat_MPIAIJ *a = MA(A);
+  HipMPIAIJ *a = MA(A);
   ierr = (*a->B->ops->multtranspose)(a->B, xx, a->lvec);CHKERRQ(ierr);
-  ierr = VecScatterBegin(a->Mvctx, a->lvec, zz, ADD_VALUES, SCATTER_REVERSE);CHKERRQ(ierr);
+  ierr = HipScatterBegin(a->hscat, a->lvec, zz, ADD_VALUES, SCATTER_REVERSE);CHKERRQ(ierr);
   ierr = (*a->A->ops->multtransposeadd)(a->A, xx, yy, zz);CHKERRQ(ierr);
-  ierr = VecScatterEnd(a->Mvctx, a->lvec, zz, ADD_VALUES, SCATTER_REVERSE);CHKERRQ(ierr);
+  ierr = HipScatterEnd(a->hscat, a->lvec, zz, ADD_VALUES, SCATTER_REVERSE);CHKERRQ(ierr);
   return 0;
 }
 static PetscErrorCode MatGetDiagonal_MPIAIJHIP(Mat A, Vec v) {   /* mpiaij.c:1246-1256 */
-  if (A->rmap->N != A->cmap->N) SETERRQ(A->comm, PETSC_ERR_SUP, "Supports only square matrix where A->A is diag block");
-  if (A->rmap->rstart != A->cmap->rstart || A->rmap->rend != A->cmap->rend) SETERRQ(A->comm, PETSC_ERR_ARG_SIZ, "row partition must equal col partition");
+  if (A->rmap->N != A->cmap->N) SETERRQ(HipObjComm(A), PETSC_ERR_SUP, "Supports only square matrix where A->A is diag block");
+  if (A->rmap->rstart != A->cmap->rstart || A->rmap->rend != A->cmap->rend) SETERRQ(HipObjComm(A), PETSC_ERR_ARG_SIZ, "row partition must equal col partition");
   return (*MA(A)->A->ops->getdiagonal)(MA(A)->A, v);
 }
 static PetscErrorCode MatScale_MPIAIJHIP(Mat A, PetscScalar aa) {
@@ -162,18 +165,18 @@ static PetscErrorCode MatScale_MPIAIJHIP(Mat A, PetscScalar aa) {
 /* MatDiagonalScale_MPIAIJ, mpiaij.c:2183-2213: the right vector's ghost values come through the MatMult scatter */
 static PetscErrorCode MatDiagonalScale_MPIAIJHIP(Mat A, Vec ll, Vec rr) {
   PetscErrorCode ierr;
-  Mat_MPIAIJ *aij = MA(A);
+  HipMPIAIJ *aij = MA(A);
   if (rr) {
-    if (rr->map->n != A->cmap->n) SETERRQ(A->comm, PETSC_ERR_ARG_SIZ, "right vector non-conforming local size");
-    ierr = VecScatterBegin(aij->Mvctx, rr, aij->lvec, INSERT_VALUES, SCATTER_FORWARD);CHKERRQ(ierr);
+    if (rr->map->n != A->cmap->n) SETERRQ(HipObjComm(A), PETSC_ERR_ARG_SIZ, "right vector non-conforming local size");
+    ierr = HipScatterBegin(aij->hscat, rr, aij->lvec, INSERT_VALUES, SCATTER_FORWARD);CHKERRQ(ierr);
   }
   if (ll) {
-    if (ll->map->n != A->rmap->n) SETERRQ(A->comm, PETSC_ERR_ARG_SIZ, "left vector non-conforming local size");
+    if (ll->map->n != A->rmap->n) SETERRQ(HipObjComm(A), PETSC_ERR_ARG_SIZ, "left vector non-conforming local size");
     ierr = MatDiagonalScale(aij->B, ll, NULL);CHKERRQ(ierr);
   }
   ierr = MatDiagonalScale(aij->A, ll, rr);CHKERRQ(ierr);
   if (rr) {
-    ierr = VecScatterEnd(aij->Mvctx, rr, aij->lvec, INSERT_VALUES, SCATTER_FORWARD);CHKERRQ(ierr);
+    ierr = HipScatterEnd(aij->hscat, rr, aij->lvec, INSERT_VALUES, SCATTER_FORWARD);CHKERRQ(ierr);
     ierr = MatDiagonalScale(aij->B, NULL, aij->lvec);CHKERRQ(ierr);
   }
   return 0;
@@ -184,16 +187,19 @@ static PetscErrorCode MatZeroEntries_MPIAIJHIP(Mat A) {
   ierr = MatZeroEntries(MA(A)->B);CHKERRQ(ierr);
   return 0;
 }
+#if defined(PETSCHIPMI355X_WITH_PETSC)
+#include "mpiaijhipmi355x_ctor.h"   /* integration/petsc-3.3/: the constructor as a subclass of the reference's MATMPIAIJ */
+#else
 static PetscErrorCode MatDestroy_MPIAIJHIP(Mat A) {
   PetscErrorCode ierr;
-  Mat_MPIAIJ *a = MA(A);
+  HipMPIAIJ *a = MA(A);
   if (!a) return 0;
   ierr = MatDestroy(&a->A);CHKERRQ(ierr);
   ierr = MatDestroy(&a->B);CHKERRQ(ierr);
   ierr = VecDestroy(&a->lvec);CHKERRQ(ierr);
-  ierr = VecScatterDestroy(&a->Mvctx);CHKERRQ(ierr);
-  free(a->garray);
-  free(a); A->data = NULL;
+  ierr = HipScatterDestroy(&a->hscat);CHKERRQ(ierr);
+  HipFree(a->garray);
+  HipFree(a); A->data = NULL;
   return 0;
 }
 
@@ -202,7 +208,7 @@ static PetscErrorCode MatGetDiagonalBlock_MPIAIJHIP(Mat A, Mat *a) { *a = MA(A)-
 
 PetscErrorCode MatCreate_MPIAIJHIPMI355X(Mat B) {   /* MatCreate_MPIAIJCUSP, mpiaijcusp.cu:204-235 */
   PetscErrorCode ierr;
-  Mat_MPIAIJ *a;
+  HipMPIAIJ *a;
   ierr = PetscMalloc(sizeof(*a), &a);CHKERRQ(ierr);
   memset(a, 0, sizeof(*a));
   a->rstart = B->rmap->rstart; a->rend = B->rmap->rend; a->cstart = B->cmap->rstart; a->cend = B->cmap->rend;
@@ -221,23 +227,26 @@ PetscErrorCode MatCreate_MPIAIJHIPMI355X(Mat B) {   /* MatCreate_MPIAIJCUSP, mpi
   B->ops->diagonalscale = MatDiagonalScale_MPIAIJHIP;
   B->ops->destroy = MatDestroy_MPIAIJHIP;
   B->ops->getvecs = MatGetVecs_HIPMI355X;
-  ierr = PetscObjectComposeFunction((PetscObject)B, "MatMPIAIJSetPreallocation_C", (PetscVoidFunction)MatMPIAIJSetPreallocation_MPIAIJHIP);CHKERRQ(ierr);
-  ierr = PetscObjectComposeFunction((PetscObject)B, "MatMPIAIJSetPreallocationCSR_C", (PetscVoidFunction)MatMPIAIJSetPreallocationCSR_MPIAIJHIP);CHKERRQ(ierr);
-  ierr = PetscObjectComposeFunction((PetscObject)B, "MatGetDiagonalBlock_C", (PetscVoidFunction)MatGetDiagonalBlock_MPIAIJHIP);CHKERRQ(ierr);
+  ierr = PetscObjectComposeFunction((PetscObject)B, "MatMPIAIJSetPreallocation_C", "MatMPIAIJSetPreallocation_MPIAIJHIP", (PetscVoidFunction)MatMPIAIJSetPreallocation_MPIAIJHIP);CHKERRQ(ierr);
+  ierr = PetscObjectComposeFunction((PetscObject)B, "MatMPIAIJSetPreallocationCSR_C", "MatMPIAIJSetPreallocationCSR_MPIAIJHIP", (PetscVoidFunction)MatMPIAIJSetPreallocationCSR_MPIAIJHIP);CHKERRQ(ierr);
+  ierr = PetscObjectComposeFunction((PetscObject)B, "MatGetDiagonalBlock_C", "MatGetDiagonalBlock_MPIAIJHIP", (PetscVoidFunction)MatGetDiagonalBlock_MPIAIJHIP);CHKERRQ(ierr);
   return 0;
 }
+#endif
+
 /* base name "aijhipmi355x" -> seq or mpi by communicator size (MatRegisterBaseName, matreg.c:161-180) */
 PetscErrorCode MatCreate_AIJHIPMI355X(Mat B) {
-  return (HipCommSize(B->comm) == 1) ? MatCreate_SeqAIJHIPMI355X(B) : MatCreate_MPIAIJHIPMI355X(B);
+  return (HipCommSize(HipObjComm(B)) == 1) ? MatCreate_SeqAIJHIPMI355X(B) : MatCreate_MPIAIJHIPMI355X(B);
 }
 
+#if !defined(PETSCHIPMI355X_WITH_PETSC)
 /* "MatMPIAIJSetPreallocationCSR_C" (MatMPIAIJSetPreallocationCSR_MPIAIJ, mpiaij.c:3900-3960): fills the matrix from this
  * rank's rows in CSR form, global ascending column indices.  The split is the column test of MatSetValues_MPIAIJ in bulk. */
 static PetscErrorCode MatMPIAIJSetPreallocationCSR_MPIAIJHIP(Mat A, const PetscInt i[], const PetscInt j[], const PetscScalar a[]) {
   PetscErrorCode ierr;
   const PetscInt m = A->rmap->n;
   MPI_Comm comm = HipObjComm(A);
-  Mat_MPIAIJ *aij = MA(A);
+  HipMPIAIJ *aij = MA(A);
   (void)comm;
   if (i[0]) SETERRQ(comm, PETSC_ERR_ARG_OUTOFRANGE, "i (row indices) must start with 0");
   if (aij->A) { ierr = MatDestroy(&aij->A);CHKERRQ(ierr); ierr = MatDestroy(&aij->B);CHKERRQ(ierr); }
@@ -264,23 +273,25 @@ static PetscErrorCode MatMPIAIJSetPreallocationCSR_MPIAIJHIP(Mat A, const PetscI
   ierr = MatSeqAIJSetPreallocationCSR(aij->A, di, dj, da);CHKERRQ(ierr);
   ierr = make_block(A, m, A->cmap->N, &aij->B);CHKERRQ(ierr);
   ierr = MatSeqAIJSetPreallocationCSR(aij->B, oi, oj, oa);CHKERRQ(ierr);
-  free(di); free(dj); free(da); free(oi); free(oj); free(oa);
+  HipFree(di); HipFree(dj); HipFree(da); HipFree(oi); HipFree(oj); HipFree(oa);
   A->preallocated = PETSC_TRUE;
   ierr = MatSetUpMultiply_MPIAIJ(A);CHKERRQ(ierr);
-  A->assembled = PETSC_TRUE; A->was_assembled = PETSC_TRUE; PetscObjectStateIncrease(A);
+  A->assembled = PETSC_TRUE; A->was_assembled = PETSC_TRUE; HipStateIncrease(A);
   return 0;
 }
 
+#endif
+
 PetscErrorCode MatMPIAIJGetSeqAIJ(Mat A, Mat *Ad, Mat *Ao, const PetscInt **garray) {   /* mpiaij.c MatMPIAIJGetSeqAIJ */
-  if (!A || strcmp(A->type_name, MATMPIAIJHIPMI355X)) SETERRQ(0, PETSC_ERR_ARG_WRONG, "not an MPIAIJHIPMI355X matrix");
+  if (!A || strcmp(HipObjTypeName(A), MATMPIAIJHIPMI355X)) SETERRQ(0, PETSC_ERR_ARG_WRONG, "not an MPIAIJHIPMI355X matrix");
   if (Ad) *Ad = MA(A)->A;
   if (Ao) *Ao = MA(A)->B;
   if (garray) *garray = MA(A)->garray;
   return 0;
 }
 PetscErrorCode MatMPIAIJGetScatter(Mat A, VecScatter *ctx, Vec *lvec, PetscInt *ec) {
-  if (!A || strcmp(A->type_name, MATMPIAIJHIPMI355X)) SETERRQ(0, PETSC_ERR_ARG_WRONG, "not an MPIAIJHIPMI355X matrix");
-  if (ctx) *ctx = MA(A)->Mvctx;
+  if (!A || strcmp(HipObjTypeName(A), MATMPIAIJHIPMI355X)) SETERRQ(0, PETSC_ERR_ARG_WRONG, "not an MPIAIJHIPMI355X matrix");
+  if (ctx) *ctx = (VecScatter)MA(A)->hscat;
   if (lvec) *lvec = MA(A)->lvec;
   if (ec) *ec = MA(A)->ec;
   return 0;

@@ -74,11 +74,11 @@ PetscErrorCode VecHIPGetReadWrite(Vec v, PetscScalar **d) {
 }
 PetscErrorCode VecHIPRestoreWrite(Vec v) { VH(v)->valid = VALID_DEVICE; return 0; }
 
-static int is_hip(Vec v) { return v && v->data && strstr(v->type_name, "hipmi355x") != NULL; }
+static int is_hip(Vec v) { return v && v->data && strstr(HipObjTypeName(v), "hipmi355x") != NULL; }
 #define CheckHIP(v) do { if (!is_hip(v)) SETERRQ((v)->comm, PETSC_ERR_ARG_NOTSAMETYPE, "vector of type %s mixed with a HIPMI355X vector", (v)->type_name); } while (0)
 
 PetscErrorCode VecHIPMI355XGetArray(Vec v, PetscScalar **d) { CheckHIP(v); return VecHIPGetReadWrite(v, d); }
-PetscErrorCode VecHIPMI355XRestoreArray(Vec v, PetscScalar **d) { if (d) *d = NULL; VecHIPRestoreWrite(v); PetscObjectStateIncrease(v); return 0; }
+PetscErrorCode VecHIPMI355XRestoreArray(Vec v, PetscScalar **d) { if (d) *d = NULL; VecHIPRestoreWrite(v); HipStateIncrease(v); return 0; }
 PetscErrorCode VecHIPMI355XGetArrayRead(Vec v, const PetscScalar **d) { CheckHIP(v); return VecHIPGetRead(v, d); }
 
 /* ---- host access ---- */
@@ -91,7 +91,7 @@ static PetscErrorCode VecRestoreArray_HIP(Vec v, PetscScalar **a) { if (a) *a = 
 /* VecPlaceArray_SeqCUSP (veccusp.cu): adopt a host array; the device copy is refreshed on next use */
 static PetscErrorCode VecPlaceArray_HIP(Vec v, const PetscScalar *a) {
   Vec_HIPMI355X *s = VH(v);
-  if (s->placed_save) SETERRQ(v->comm, PETSC_ERR_ARG_WRONGSTATE, "VecPlaceArray() was already called on this vector, without a call to VecResetArray()");
+  if (s->placed_save) SETERRQ(HipObjComm(v), PETSC_ERR_ARG_WRONGSTATE, "VecPlaceArray() was already called on this vector, without a call to VecResetArray()");
   PetscErrorCode ierr = to_host(v);CHKERRQ(ierr);
   s->placed_save = s->host;
   s->host = (PetscScalar *)a;
@@ -111,7 +111,7 @@ static PetscErrorCode VecSetValues_HIP(Vec v, PetscInt ni, const PetscInt ix[], 
   PetscErrorCode ierr = VecGetArray_HIP(v, &a);CHKERRQ(ierr);
   for (PetscInt k = 0; k < ni; k++) {
     if (ix[k] < 0) continue;
-    if (ix[k] < v->map->rstart || ix[k] >= v->map->rend) SETERRQ(v->comm, PETSC_ERR_SUP, "off-process VecSetValues (index %d outside [%d,%d)) is outside the ported path", ix[k], v->map->rstart, v->map->rend);
+    if (ix[k] < v->map->rstart || ix[k] >= v->map->rend) SETERRQ(HipObjComm(v), PETSC_ERR_SUP, "off-process VecSetValues (index %d outside [%d,%d)) is outside the ported path", ix[k], v->map->rstart, v->map->rend);
     if (mode == INSERT_VALUES) a[ix[k] - v->map->rstart] = y[k];
     else a[ix[k] - v->map->rstart] += y[k];
   }
@@ -235,7 +235,7 @@ static PetscErrorCode VecMAXPY_HIP(Vec y, PetscInt nv, const PetscScalar *alpha,
   for (PetscInt j = 0; j < nv; j++) { CheckHIP(x[j]); ierr = VecHIPGetRead(x[j], &tab[j]);CHKERRQ(ierr); }
   ierr = VecHIPGetReadWrite(y, &dy);CHKERRQ(ierr);
   CHKHIP(mi355x_vec_maxpy(dc->h, N_(y), nv, alpha, tab, dy));
-  free(tab);
+  HipFree(tab);
   ierr = PetscLogFlops(nv * 2.0 * y->map->n);CHKERRQ(ierr);
   return VecHIPRestoreWrite(y);
 }
@@ -246,8 +246,9 @@ static PetscErrorCode VecMAXPY_HIP(Vec y, PetscInt nv, const PetscScalar *alpha,
  * over RCCL on the same stream, copied to the pinned scratch, and only then do we synchronise. */
 /* A communicator with an RCCL communicator attached reduces on the device (also a one-rank one: the tests use that
  * to run this path on a single GPU); several ranks without one use the host-staged transport. */
-#define DEVICE_COLLECTIVES(x) (HipCommDevice((x)->comm) != NULL)
-#define HOST_STAGED(x) (HipCommSize((x)->comm) > 1 && !HipCommDevice((x)->comm))
+static int hip_local_only = 0;   /* ops->dot_local / norm_local / mdot_local: this rank's part only (comb.c:402-721) */
+#define DEVICE_COLLECTIVES(x) (!hip_local_only && HipCommDevice(HipObjComm(x)) != NULL)
+#define HOST_STAGED(x) (!hip_local_only && HipCommSize(HipObjComm(x)) > 1 && !HipCommDevice(HipObjComm(x)))
 static PetscErrorCode reduce_target(Vec x, PetscDeviceCtx *dc, double **out) {
   *out = DEVICE_COLLECTIVES(x) ? mi355x_handle_device_scratch(dc->h) : mi355x_handle_host_scratch(dc->h);
   return 0;
@@ -261,13 +262,13 @@ static PetscErrorCode reduce_finish2(Vec x, PetscDeviceCtx *dc, int nsum, int co
      * reduction followed by a host all-reduce (mpicusp.cu:32-113); used by the shared-GPU rehearsal tests */
     CHKHIP(mi355x_handle_synchronize(dc->h));
     for (int j = 0; j < count; j++) result[j] = hs[j];
-    if (HipCommAllreduce(x->comm, result, nsum, 1, is_max ? 1 : 0)) SETERRQ(x->comm, PETSC_ERR_LIB, "allreduce failed");
+    if (HipCommAllreduce(HipObjComm(x), result, nsum, 1, is_max ? 1 : 0)) SETERRQ(HipObjComm(x), PETSC_ERR_LIB, "allreduce failed");
     return 0;
   }
   if (DEVICE_COLLECTIVES(x)) {
     double *ds = mi355x_handle_device_scratch(dc->h);
-    if (is_max) CHKHIP(mi355x_comm_allreduce_max(HipCommDevice(x->comm), dc->h, ds, (size_t)nsum));
-    else CHKHIP(mi355x_comm_allreduce_sum(HipCommDevice(x->comm), dc->h, ds, (size_t)nsum));
+    if (is_max) CHKHIP(mi355x_comm_allreduce_max(HipCommDevice(HipObjComm(x)), dc->h, ds, (size_t)nsum));
+    else CHKHIP(mi355x_comm_allreduce_sum(HipCommDevice(HipObjComm(x)), dc->h, ds, (size_t)nsum));
     /* device -> pinned host by a tiny kernel on the same stream that also stores the completion number the host
      * polls: no stream synchronisation, and kernels queued behind it do not delay the result */
     CHKHIP(mi355x_handle_publish(dc->h, ds, count));
@@ -361,7 +362,7 @@ PetscErrorCode VecCGUpdate_HIPMI355X(Vec x, Vec r, Vec z, Vec p, Vec w, Vec d, P
   ierr = reduce_target(x, dc, &out);CHKERRQ(ierr);
   CHKHIP(mi355x_vec_cg_update(dc->h, N_(x), a, dp_, dw, dd, dx, dr, dz, out));
   VecHIPRestoreWrite(x); VecHIPRestoreWrite(r); VecHIPRestoreWrite(z);
-  PetscObjectStateIncrease(x); PetscObjectStateIncrease(r); PetscObjectStateIncrease(z);
+  HipStateIncrease(x); HipStateIncrease(r); HipStateIncrease(z);
   ierr = reduce_finish(x, dc, 3, 0, res);CHKERRQ(ierr);
   *zz = res[0]; *zr = res[1]; *rr = res[2];
   ierr = PetscLogFlops(9.0 * x->map->n);CHKERRQ(ierr);   /* 2n + 2n + n + 2n + 2n */
@@ -382,7 +383,7 @@ PetscErrorCode VecTDotBegin_HIPMI355X(Vec x, Vec y, PetscBool *ok) {
   ierr = VecHIPGetRead(y, &dy);CHKERRQ(ierr);
   ds = mi355x_handle_device_scratch(dc->h) + DPI_SLOT;
   CHKHIP(mi355x_vec_dot(dc->h, N_(x), dx, dy, ds));
-  if (DEVICE_COLLECTIVES(x)) CHKHIP(mi355x_comm_allreduce_sum(HipCommDevice(x->comm), dc->h, ds, 1));
+  if (DEVICE_COLLECTIVES(x)) CHKHIP(mi355x_comm_allreduce_sum(HipCommDevice(HipObjComm(x)), dc->h, ds, 1));
   if (x->map->n > 0) { ierr = PetscLogFlops(2.0 * x->map->n - 1);CHKERRQ(ierr); }
   *ok = PETSC_TRUE;
   return 0;
@@ -405,9 +406,9 @@ PetscErrorCode VecCGUpdateDevBegin_HIPMI355X(Vec x, Vec r, Vec z, Vec p, Vec w, 
   CHKHIP(mi355x_vec_cg_update_dev(dc->h, N_(x), beta, ds + DPI_SLOT, dpiold, (int)check_sign, dp_, dw, dd, dx, dr, dz, ds,
                                   DEVICE_COLLECTIVES(x) ? 0 : 1));
   VecHIPRestoreWrite(x); VecHIPRestoreWrite(r); VecHIPRestoreWrite(z);
-  PetscObjectStateIncrease(x); PetscObjectStateIncrease(r); PetscObjectStateIncrease(z);
+  HipStateIncrease(x); HipStateIncrease(r); HipStateIncrease(z);
   if (DEVICE_COLLECTIVES(x)) {
-    CHKHIP(mi355x_comm_allreduce_sum(HipCommDevice(x->comm), dc->h, ds, 3));
+    CHKHIP(mi355x_comm_allreduce_sum(HipCommDevice(HipObjComm(x)), dc->h, ds, 3));
     CHKHIP(mi355x_handle_publish(dc->h, ds, 4));
   }
   ierr = PetscLogFlops(9.0 * x->map->n);CHKERRQ(ierr);
@@ -429,7 +430,7 @@ PetscErrorCode VecAYPXDev_HIPMI355X(Vec p, PetscScalar den, Vec z) {
   ierr = VecHIPGetReadWrite(p, &dp_);CHKERRQ(ierr);
   CHKHIP(mi355x_vec_aypx_dev(dc->h, N_(p), mi355x_handle_device_scratch(dc->h) + 1, den, dz, dp_));
   VecHIPRestoreWrite(p);
-  PetscObjectStateIncrease(p);
+  HipStateIncrease(p);
   ierr = PetscLogFlops(2.0 * p->map->n);CHKERRQ(ierr);
   return 0;
 }
@@ -461,7 +462,7 @@ PetscErrorCode VecPMultDot_HIPMI355X(Vec w, Vec x, Vec d, Vec y, PetscScalar *va
   ierr = VecHIPGetWrite(w, &dw);CHKERRQ(ierr);
   ierr = reduce_target(w, dc, &out);CHKERRQ(ierr);
   CHKHIP(mi355x_vec_pmult_dot(dc->h, N_(w), dx, dd, dy, dw, out));
-  VecHIPRestoreWrite(w); PetscObjectStateIncrease(w);
+  VecHIPRestoreWrite(w); HipStateIncrease(w);
   ierr = reduce_finish(w, dc, 1, 0, val);CHKERRQ(ierr);
   ierr = PetscLogFlops(3.0 * w->map->n);CHKERRQ(ierr);
   *done = PETSC_TRUE;
@@ -477,7 +478,7 @@ PetscErrorCode VecPMultDotNorm2_HIPMI355X(Vec w, Vec x, Vec d, Vec s_, PetscScal
   ierr = VecHIPGetWrite(w, &dw);CHKERRQ(ierr);
   ierr = reduce_target(w, dc, &out);CHKERRQ(ierr);
   CHKHIP(mi355x_vec_pmult_dotnorm2(dc->h, N_(w), dx, dd, dsv, dw, out));
-  VecHIPRestoreWrite(w); PetscObjectStateIncrease(w);
+  VecHIPRestoreWrite(w); HipStateIncrease(w);
   ierr = reduce_finish(w, dc, 2, 0, res);CHKERRQ(ierr);
   *dp = res[0]; *nm = res[1];
   ierr = PetscLogFlops(5.0 * w->map->n);CHKERRQ(ierr);
@@ -498,7 +499,7 @@ PetscErrorCode VecBCGSUpdate_HIPMI355X(Vec x, Vec r, Vec p, Vec s_, Vec t, Vec r
   ierr = reduce_target(x, dc, &out);CHKERRQ(ierr);
   CHKHIP(mi355x_vec_bcgs_update(dc->h, N_(x), alpha, omega, dp_, dsv, dt, drp, dx, dr, out));
   VecHIPRestoreWrite(x); VecHIPRestoreWrite(r);
-  PetscObjectStateIncrease(x); PetscObjectStateIncrease(r);
+  HipStateIncrease(x); HipStateIncrease(r);
   ierr = reduce_finish(x, dc, 2, 0, res);CHKERRQ(ierr);
   *rr = res[0]; *rho = res[1];
   ierr = PetscLogFlops(10.0 * x->map->n);CHKERRQ(ierr);
@@ -518,8 +519,8 @@ PetscErrorCode VecBCGSUpdate_HIPMI355X(Vec x, Vec r, Vec p, Vec s_, Vec t, Vec r
 static struct { int n, started, fetched; int kind[SR_MAX]; PetscScalar val[SR_MAX]; Vec owner; mi355x_event_t ev; } sr;
 static PetscErrorCode sr_queue(Vec x, int kind, const PetscScalar *dx, const PetscScalar *dy) {
   PetscErrorCode ierr; DEVCTX;
-  if (sr.started) SETERRQ(x->comm, PETSC_ERR_ORDER, "Called VecxxxBegin() in a different order or number of times than VecxxxEnd(): a split reduction is still pending");
-  if (sr.n >= SR_MAX) SETERRQ(x->comm, PETSC_ERR_SUP, "at most %d reductions per split phase", SR_MAX);
+  if (sr.started) SETERRQ(HipObjComm(x), PETSC_ERR_ORDER, "Called VecxxxBegin() in a different order or number of times than VecxxxEnd(): a split reduction is still pending");
+  if (sr.n >= SR_MAX) SETERRQ(HipObjComm(x), PETSC_ERR_SUP, "at most %d reductions per split phase", SR_MAX);
   double *slot = HOST_STAGED(x) ? mi355x_handle_host_scratch(dc->h) + SR_HOST0 + sr.n : mi355x_handle_device_scratch(dc->h) + SR_SLOT0 + sr.n;
   if (kind == 0) CHKHIP(mi355x_vec_dot(dc->h, N_(x), dx, dy, slot));
   else CHKHIP(mi355x_vec_norm(dc->h, N_(x), 1, dx, slot));
@@ -530,7 +531,7 @@ static PetscErrorCode VecDotBegin_HIP(Vec x, Vec y, PetscScalar *result) {
   PetscErrorCode ierr; const PetscScalar *dx, *dy;
   (void)result;
   CheckHIP(x); CheckHIP(y);
-  if (x->map->n != y->map->n) SETERRQ(x->comm, PETSC_ERR_ARG_INCOMP, "Incompatible vector local lengths");
+  if (x->map->n != y->map->n) SETERRQ(HipObjComm(x), PETSC_ERR_ARG_INCOMP, "Incompatible vector local lengths");
   ierr = VecHIPGetRead(x, &dx);CHKERRQ(ierr);
   ierr = VecHIPGetRead(y, &dy);CHKERRQ(ierr);
   ierr = sr_queue(x, 0, dx, dy);CHKERRQ(ierr);
@@ -541,7 +542,7 @@ static PetscErrorCode VecNormBegin_HIP(Vec x, NormType type, PetscReal *result) 
   PetscErrorCode ierr; const PetscScalar *dx;
   (void)result;
   CheckHIP(x);
-  if (type != NORM_2) SETERRQ(x->comm, PETSC_ERR_SUP, "split-phase norms: NORM_2 only");
+  if (type != NORM_2) SETERRQ(HipObjComm(x), PETSC_ERR_SUP, "split-phase norms: NORM_2 only");
   ierr = VecHIPGetRead(x, &dx);CHKERRQ(ierr);
   ierr = sr_queue(x, 1, dx, NULL);CHKERRQ(ierr);
   ierr = PetscLogFlops(PetscMax(2.0 * x->map->n - 1, 0.0));CHKERRQ(ierr);
@@ -559,7 +560,7 @@ static PetscErrorCode PetscCommSplitReductionBegin_HIP(MPI_Comm comm) {
     if (!sr.ev) CHKHIP(mi355x_event_create(&sr.ev));
     CHKHIP(mi355x_event_record(sr.ev, dc->h));                    /* the reductions queued so far */
     CHKHIP(mi355x_handle_wait_event(dc->hcomm, sr.ev));
-    CHKHIP(mi355x_comm_allreduce_sum(HipCommDeviceHalo(x->comm), dc->hcomm, ds, (size_t)sr.n));   /* halo stream: its own communicator */
+    CHKHIP(mi355x_comm_allreduce_sum(HipCommDeviceHalo(HipObjComm(x)), dc->hcomm, ds, (size_t)sr.n));   /* halo stream: its own communicator */
     CHKHIP(mi355x_handle_publish_at(dc->hcomm, ds, sr.n, SR_HOST0));   /* lands in the HALO handle's pinned scratch */
   } else {
     CHKHIP(mi355x_handle_publish_at(dc->h, ds, sr.n, SR_HOST0));
@@ -568,15 +569,15 @@ static PetscErrorCode PetscCommSplitReductionBegin_HIP(MPI_Comm comm) {
 }
 static PetscErrorCode sr_fetch(Vec x) {
   PetscErrorCode ierr; DEVCTX;
-  if (!sr.n) SETERRQ(x->comm, PETSC_ERR_ORDER, "VecxxxEnd() without a matching VecxxxBegin()");
-  if (!sr.started) { ierr = PetscCommSplitReductionBegin(x->comm);CHKERRQ(ierr); }
+  if (!sr.n) SETERRQ(HipObjComm(x), PETSC_ERR_ORDER, "VecxxxEnd() without a matching VecxxxBegin()");
+  if (!sr.started) { ierr = PetscCommSplitReductionBegin(HipObjComm(x));CHKERRQ(ierr); }
   if (sr.fetched == 0) {
     Vec o = sr.owner;
     if (HOST_STAGED(o)) {
       CHKHIP(mi355x_handle_synchronize(dc->h));
       const double *hs = mi355x_handle_host_scratch(dc->h) + SR_HOST0;
       for (int j = 0; j < sr.n; j++) sr.val[j] = hs[j];
-      if (HipCommAllreduce(o->comm, sr.val, sr.n, 1, 0)) SETERRQ(o->comm, PETSC_ERR_LIB, "allreduce failed");
+      if (HipCommAllreduce(HipObjComm(o), sr.val, sr.n, 1, 0)) SETERRQ(HipObjComm(o), PETSC_ERR_LIB, "allreduce failed");
     } else {
       mi355x_handle_t hh = DEVICE_COLLECTIVES(o) ? dc->hcomm : dc->h;
       CHKHIP(mi355x_handle_wait_result(hh));
@@ -590,7 +591,7 @@ static PetscErrorCode sr_fetch(Vec x) {
 }
 static PetscErrorCode sr_take(Vec x, int kind, PetscScalar *out) {
   PetscErrorCode ierr = sr_fetch(x);CHKERRQ(ierr);
-  if (sr.fetched >= sr.n || sr.kind[sr.fetched] != kind) SETERRQ(x->comm, PETSC_ERR_ORDER, "Called VecxxxEnd() in a different order or number of times than VecxxxBegin()");
+  if (sr.fetched >= sr.n || sr.kind[sr.fetched] != kind) SETERRQ(HipObjComm(x), PETSC_ERR_ORDER, "Called VecxxxEnd() in a different order or number of times than VecxxxBegin()");
   *out = sr.val[sr.fetched++];
   if (sr.fetched == sr.n) { sr.n = 0; sr.started = 0; sr.fetched = 0; sr.owner = NULL; }
   return 0;
@@ -604,14 +605,24 @@ static PetscErrorCode VecNormEnd_HIP(Vec x, NormType type, PetscReal *result) {
   return 0;
 }
 
+/* the *_local slots of struct _VecOps (vecimpl.h:262-266): the same device reductions without the step across ranks;
+ * NORM_2 returns the root of the local sum, as VecNorm_Seq does for VecNormBegin (comb.c squares it again) */
+static PetscErrorCode VecDot_HIP_local(Vec x, Vec y, PetscScalar *val) { hip_local_only = 1; PetscErrorCode ierr = VecDot_HIP(x, y, val); hip_local_only = 0; return ierr; }
+static PetscErrorCode VecMDot_HIP_local(Vec x, PetscInt nv, const Vec y[], PetscScalar *val) { hip_local_only = 1; PetscErrorCode ierr = VecMDot_HIP(x, nv, y, val); hip_local_only = 0; return ierr; }
+static PetscErrorCode VecNorm_HIP_local(Vec x, NormType type, PetscReal *val) { hip_local_only = 1; PetscErrorCode ierr = VecNorm_HIP(x, type, val); hip_local_only = 0; return ierr; }
+
+#if defined(PETSCHIPMI355X_WITH_PETSC)
+#include "vechipmi355x_ctor.h"      /* integration/petsc-3.3/: the slots PETSc's real struct _VecOps needs beyond the numerical ones */
+#endif
+
 static PetscErrorCode VecDestroy_HIP(Vec v) {
   Vec_HIPMI355X *s = VH(v);
   if (!s) return 0;
   if (s->placed_save) { s->host = s->placed_save; s->placed_save = NULL; }
   if (s->alias_save) { s->dev = s->alias_save; s->alias_save = NULL; }   /* never free storage borrowed from another vector */
   if (s->dev) mi355x_free(s->dev);
-  if (s->host && s->host_owned) free(s->host);
-  free(s);
+  if (s->host && s->host_owned) HipFree(s->host);
+  HipFree(s);
   v->data = NULL;
   return 0;
 }
@@ -649,14 +660,14 @@ static PetscErrorCode VecShareArrayBegin_HIP(Vec sub, Vec parent, PetscBool writ
   ierr = VecHIPGetWrite(sub, &s->alias_save);CHKERRQ(ierr);      /* makes sure sub owns device storage to come back to */
   s->alias_valid = s->valid;
   s->dev = dp; s->valid = VALID_DEVICE;
-  PetscObjectStateIncrease(sub);
+  HipStateIncrease(sub);
   return 0;
 }
 static PetscErrorCode VecShareArrayEnd_HIP(Vec sub, Vec parent, PetscBool write) {
   Vec_HIPMI355X *s = VH(sub);
   if (!s->alias_save) return 0;
   s->dev = s->alias_save; s->valid = s->alias_valid; s->alias_save = NULL;
-  PetscObjectStateIncrease(sub);
+  HipStateIncrease(sub);
   if (write) return VecHIPRestoreWrite(parent);
   return 0;
 }
@@ -687,6 +698,11 @@ static const VecSplitReductionOps *VecSplitReductionOps_HIP(void) {
 static PetscErrorCode VecCreate_HIP_common(Vec v, const char *tname) {
   PetscErrorCode ierr;
   Vec_HIPMI355X *s;
+  (void)VecDot_HIP_local; (void)VecMDot_HIP_local; (void)VecNorm_HIP_local;
+#if defined(PETSCHIPMI355X_WITH_PETSC)
+  ierr = PetscMemzero(v->ops, sizeof(struct _VecOps));CHKERRQ(ierr);
+  ierr = VecCreate_HIP_petsc33(v, (PetscBool)!strcmp(tname, VECMPIHIPMI355X));CHKERRQ(ierr);
+#endif
   ierr = PetscMalloc(sizeof(*s), &s);CHKERRQ(ierr);
   memset(s, 0, sizeof(*s));
   v->data = s;
@@ -718,22 +734,22 @@ static PetscErrorCode VecCreate_HIP_common(Vec v, const char *tname) {
   v->ops->destroy = VecDestroy_HIP;
   v->ops->reciprocal = VecReciprocal_HIP;
   v->ops->dotnorm2 = VecDotNorm2_HIP;
-  ierr = PetscObjectComposeFunction((PetscObject)v, "VecJacobiInvert_C", (PetscVoidFunction)VecJacobiInvert_HIP);CHKERRQ(ierr);
-  ierr = PetscObjectComposeFunction((PetscObject)v, "VecShareArrayBegin_C", (PetscVoidFunction)VecShareArrayBegin_HIP);CHKERRQ(ierr);
-  ierr = PetscObjectComposeFunction((PetscObject)v, "VecShareArrayEnd_C", (PetscVoidFunction)VecShareArrayEnd_HIP);CHKERRQ(ierr);
-  ierr = PetscObjectComposeFunction((PetscObject)v, "VecKrylovFusedOps_C", (PetscVoidFunction)VecKrylovFusedOps_HIP);CHKERRQ(ierr);
-  ierr = PetscObjectComposeFunction((PetscObject)v, "VecSplitReductionOps_C", (PetscVoidFunction)VecSplitReductionOps_HIP);CHKERRQ(ierr);
+  ierr = PetscObjectComposeFunction((PetscObject)v, "VecJacobiInvert_C", "VecJacobiInvert_HIP", (PetscVoidFunction)VecJacobiInvert_HIP);CHKERRQ(ierr);
+  ierr = PetscObjectComposeFunction((PetscObject)v, "VecShareArrayBegin_C", "VecShareArrayBegin_HIP", (PetscVoidFunction)VecShareArrayBegin_HIP);CHKERRQ(ierr);
+  ierr = PetscObjectComposeFunction((PetscObject)v, "VecShareArrayEnd_C", "VecShareArrayEnd_HIP", (PetscVoidFunction)VecShareArrayEnd_HIP);CHKERRQ(ierr);
+  ierr = PetscObjectComposeFunction((PetscObject)v, "VecKrylovFusedOps_C", "VecKrylovFusedOps_HIP", (PetscVoidFunction)VecKrylovFusedOps_HIP);CHKERRQ(ierr);
+  ierr = PetscObjectComposeFunction((PetscObject)v, "VecSplitReductionOps_C", "VecSplitReductionOps_HIP", (PetscVoidFunction)VecSplitReductionOps_HIP);CHKERRQ(ierr);
   return 0;
 }
 
 PetscErrorCode VecCreate_SeqHIPMI355X(Vec v) {
-  if (HipCommSize(v->comm) > 1) SETERRQ(v->comm, PETSC_ERR_ARG_WRONG, "Cannot create VECSEQHIPMI355X on more than one process");
+  if (HipCommSize(HipObjComm(v)) > 1) SETERRQ(HipObjComm(v), PETSC_ERR_ARG_WRONG, "Cannot create VECSEQHIPMI355X on more than one process");
   return VecCreate_HIP_common(v, VECSEQHIPMI355X);
 }
 PetscErrorCode VecCreate_MPIHIPMI355X(Vec v) { return VecCreate_HIP_common(v, VECMPIHIPMI355X); }
 /* size dispatch, as VecCreate_CUSP mpicusp.cu:232-246 */
 PetscErrorCode VecCreate_HIPMI355X(Vec v) {
-  return (HipCommSize(v->comm) == 1) ? VecCreate_SeqHIPMI355X(v) : VecCreate_MPIHIPMI355X(v);
+  return (HipCommSize(HipObjComm(v)) == 1) ? VecCreate_SeqHIPMI355X(v) : VecCreate_MPIHIPMI355X(v);
 }
 PetscErrorCode VecCreateSeqHIPMI355X(MPI_Comm comm, PetscInt n, Vec *v) {
   PetscErrorCode ierr;

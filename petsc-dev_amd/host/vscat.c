@@ -1,7 +1,7 @@
-/* VecScatter, parallel -> sequential "general" form: the halo exchange of MatMult_MPIAIJ.
+/* HipScatter, parallel -> sequential "general" form: the halo exchange of MatMult_MPIAIJ.
  * Set-up restates VecScatterCreate_PtoS (src/vec/vec/utils/vpscat.c:1730-1924) with the index-list
  * exchange done by one all-gather of every rank's request list instead of Isend/Irecv pairs (same
- * resulting to/from lists, bit for bit).  Begin/End replace VecScatterBegin_1/End_1
+ * resulting to/from lists, bit for bit).  Begin/End replace HipScatterBegin_1/End_1
  * (vpscat.h:14-233: pack, persistent MPI_Start, MPI_Waitany, unpack) by
  *     device pack kernel -> RCCL grouped send/recv over xGMI on the halo stream -> device unpack,
  * ordered against the compute stream with two HIP events so the diagonal-block SpMV overlaps it. */
@@ -17,9 +17,9 @@ static PetscBool is_contiguous(const PetscInt *idx, PetscInt n) {
   return PETSC_TRUE;
 }
 
-PetscErrorCode VecScatterCreate_PtoS_MPIAIJ(MPI_Comm comm, PetscLayout xmap, PetscInt ec, const PetscInt *garray, VecScatter *out) {
+PetscErrorCode HipScatterCreate_PtoS_MPIAIJ(MPI_Comm comm, PetscLayout xmap, PetscInt ec, const PetscInt *garray, HipScatter *out) {
   PetscErrorCode ierr;
-  VecScatter ctx;
+  HipScatter ctx;
   int size = HipCommSize(comm), rank = HipCommRank(comm);
   PetscInt *ecs, maxec = 0, *all = NULL;
   ierr = PetscMalloc(sizeof(*ctx), &ctx);CHKERRQ(ierr);
@@ -37,7 +37,7 @@ PetscErrorCode VecScatterCreate_PtoS_MPIAIJ(MPI_Comm comm, PetscLayout xmap, Pet
     memcpy(mine, garray, sizeof(PetscInt) * (size_t)ec);
     ierr = PetscMalloc(sizeof(PetscInt) * (size_t)maxec * (size_t)size, &all);CHKERRQ(ierr);
     if (HipCommAllgather(comm, mine, (int)(sizeof(PetscInt) * (size_t)maxec), all)) SETERRQ(comm, PETSC_ERR_LIB, "allgather failed");
-    free(mine);
+    HipFree(mine);
   }
   /* ---- "from" (receive) side: owners ascending, slots in order of appearance (vpscat.c:1871-1885) ---- */
   VecScatterSide *from = &ctx->from, *to = &ctx->to;
@@ -78,7 +78,7 @@ PetscErrorCode VecScatterCreate_PtoS_MPIAIJ(MPI_Comm comm, PetscLayout xmap, Pet
       if (gq[i] >= xmap->range[rank] && gq[i] < xmap->range[rank + 1]) { to->indices[cnt++] = gq[i] - xmap->range[rank]; have = PETSC_TRUE; }
     if (have) { to->procs[to->n++] = q; to->starts[to->n] = cnt; }
   }
-  free(all); free(ecs);
+  HipFree(all); HipFree(ecs);
   /* contiguity (the to->contiq / from->contiq special case, vpscat.c:1951-1960), here per side */
   from->contiq = PETSC_TRUE;
   for (PetscInt i = 0; i < from->n; i++) if (!is_contiguous(from->indices + from->starts[i], from->starts[i + 1] - from->starts[i])) from->contiq = PETSC_FALSE;
@@ -88,10 +88,10 @@ PetscErrorCode VecScatterCreate_PtoS_MPIAIJ(MPI_Comm comm, PetscLayout xmap, Pet
   return 0;
 }
 
-PetscErrorCode VecScatterGetLists(VecScatter ctx, PetscInt *nrecv, const PetscInt **rprocs, const PetscInt **rstarts, const PetscInt **rindices,
+PetscErrorCode HipScatterGetLists(HipScatter ctx, PetscInt *nrecv, const PetscInt **rprocs, const PetscInt **rstarts, const PetscInt **rindices,
                                   PetscInt *nsend, const PetscInt **sprocs, const PetscInt **sstarts, const PetscInt **sindices,
                                   PetscInt *nlocal, const PetscInt **lto, const PetscInt **lfrom) {
-  if (!ctx) SETERRQ(0, PETSC_ERR_ARG_NULL, "Null VecScatter");
+  if (!ctx) SETERRQ(0, PETSC_ERR_ARG_NULL, "Null HipScatter");
   *nrecv = ctx->from.n; *rprocs = ctx->from.procs; *rstarts = ctx->from.starts; *rindices = ctx->from.indices;
   *nsend = ctx->to.n; *sprocs = ctx->to.procs; *sstarts = ctx->to.starts; *sindices = ctx->to.indices;
   *nlocal = ctx->to.local_n; *lto = ctx->to.local_slots; *lfrom = ctx->from.local_slots;
@@ -99,7 +99,7 @@ PetscErrorCode VecScatterGetLists(VecScatter ctx, PetscInt *nrecv, const PetscIn
 }
 
 /* one-time index upload (VecScatterInitializeForGPU, src/vec/vec/utils/veccusp/vscatcusp.c:29-112) */
-static PetscErrorCode scatter_device_setup(VecScatter ctx, PetscDeviceCtx *dc) {
+static PetscErrorCode scatter_device_setup(HipScatter ctx, PetscDeviceCtx *dc) {
   if (ctx->device_ready) return 0;
   VecScatterSide *s[2] = {&ctx->to, &ctx->from};
   for (int k = 0; k < 2; k++) {
@@ -127,7 +127,7 @@ static PetscErrorCode scatter_device_setup(VecScatter ctx, PetscDeviceCtx *dc) {
  * rehearsal tests) the same buffers travel device -> host -> launcher-supplied exchange -> host -> device, the
  * arrangement of the reference's own CUSP path (vpscat.h:56-61,226-230); everything around the transport --
  * pack, contiguity shortcuts, offsets, unpack order -- is shared. */
-static PetscErrorCode neighbour_exchange(VecScatter ctx, PetscDeviceCtx *dc, PetscInt nr, const PetscInt *rprocs, PetscScalar *const *rdst, const PetscInt *rcnt,
+static PetscErrorCode neighbour_exchange(HipScatter ctx, PetscDeviceCtx *dc, PetscInt nr, const PetscInt *rprocs, PetscScalar *const *rdst, const PetscInt *rcnt,
                                          PetscInt ns, const PetscInt *sprocs, const PetscScalar *const *ssrc, const PetscInt *scnt) {
   PetscErrorCode ierr;
   MPI_Comm comm = ctx->comm;
@@ -165,9 +165,9 @@ static PetscErrorCode neighbour_exchange(VecScatter ctx, PetscDeviceCtx *dc, Pet
 }
 
 /* Records "the source vector is final" on the compute stream NOW, so that the caller may queue independent work
- * (the diagonal-block SpMV) on the compute stream before VecScatterBegin spends host time enqueueing the RCCL
+ * (the diagonal-block SpMV) on the compute stream before HipScatterBegin spends host time enqueueing the RCCL
  * operations: the halo stream still only waits for what preceded this point. */
-PetscErrorCode VecScatterMarkReady(VecScatter ctx, Vec x) {
+PetscErrorCode HipScatterMarkReady(HipScatter ctx, Vec x) {
   PetscErrorCode ierr;
   PetscDeviceCtx *dc;
   const PetscScalar *dx;
@@ -181,10 +181,10 @@ PetscErrorCode VecScatterMarkReady(VecScatter ctx, Vec x) {
 }
 
 /* FORWARD/INSERT: x (parallel) -> y (= lvec, sequential).  REVERSE/ADD: x (= lvec) -> y (parallel), +=. */
-static PetscErrorCode scatter_begin(VecScatter ctx, Vec x, Vec y, InsertMode addv, ScatterMode mode);
-PetscErrorCode VecScatterBegin(VecScatter ctx, Vec x, Vec y, InsertMode addv, ScatterMode mode) {
+static PetscErrorCode scatter_begin(HipScatter ctx, Vec x, Vec y, InsertMode addv, ScatterMode mode);
+PetscErrorCode HipScatterBegin(HipScatter ctx, Vec x, Vec y, InsertMode addv, ScatterMode mode) {
   PetscErrorCode ierr;
-  if (!ctx) SETERRQ(0, PETSC_ERR_ARG_NULL, "Null VecScatter");
+  if (!ctx) SETERRQ(0, PETSC_ERR_ARG_NULL, "Null HipScatter");
   if (ctx->inuse) SETERRQ(ctx->comm, PETSC_ERR_ARG_WRONGSTATE, " Scatter ctx already in use");   /* vscat.c:1637 */
   if (!((mode == SCATTER_FORWARD && addv == INSERT_VALUES) || (mode == SCATTER_REVERSE && addv == ADD_VALUES)))
     SETERRQ(ctx->comm, PETSC_ERR_SUP, "only FORWARD/INSERT and REVERSE/ADD (the MatMult[Transpose]_MPIAIJ uses) are ported");
@@ -192,7 +192,7 @@ PetscErrorCode VecScatterBegin(VecScatter ctx, Vec x, Vec y, InsertMode addv, Sc
   ctx->inuse = PETSC_TRUE;                                  /* only a Begin that succeeded leaves the scatter in use */
   return 0;
 }
-static PetscErrorCode scatter_begin(VecScatter ctx, Vec x, Vec y, InsertMode addv, ScatterMode mode) {
+static PetscErrorCode scatter_begin(HipScatter ctx, Vec x, Vec y, InsertMode addv, ScatterMode mode) {
   PetscErrorCode ierr;
   PetscDeviceCtx *dc;
   (void)addv;
@@ -257,10 +257,10 @@ static PetscErrorCode scatter_begin(VecScatter ctx, Vec x, Vec y, InsertMode add
   return 0;
 }
 
-PetscErrorCode VecScatterEnd(VecScatter ctx, Vec x, Vec y, InsertMode addv, ScatterMode mode) {
+PetscErrorCode HipScatterEnd(HipScatter ctx, Vec x, Vec y, InsertMode addv, ScatterMode mode) {
   PetscErrorCode ierr;
   PetscDeviceCtx *dc;
-  if (!ctx) SETERRQ(0, PETSC_ERR_ARG_NULL, "Null VecScatter");
+  if (!ctx) SETERRQ(0, PETSC_ERR_ARG_NULL, "Null HipScatter");
   ctx->inuse = PETSC_FALSE;
   if (ctx->to.n == 0 && ctx->from.n == 0 && ctx->to.local_n == 0) return 0;
   ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
@@ -285,16 +285,16 @@ PetscErrorCode VecScatterEnd(VecScatter ctx, Vec x, Vec y, InsertMode addv, Scat
     }
   }
   ierr = VecHIPRestoreWrite(y);CHKERRQ(ierr);
-  PetscObjectStateIncrease(y);
+  HipStateIncrease(y);
   return 0;
 }
 
-PetscErrorCode VecScatterDestroy(VecScatter *pctx) {
-  VecScatter ctx = *pctx;
+PetscErrorCode HipScatterDestroy(HipScatter *pctx) {
+  HipScatter ctx = *pctx;
   if (!ctx) return 0;
   VecScatterSide *s[2] = {&ctx->to, &ctx->from};
   for (int k = 0; k < 2; k++) {
-    free(s[k]->procs); free(s[k]->starts); free(s[k]->indices); free(s[k]->local_slots);
+    HipFree(s[k]->procs); HipFree(s[k]->starts); HipFree(s[k]->indices); HipFree(s[k]->local_slots);
     if (s[k]->d_indices) mi355x_free(s[k]->d_indices);
     if (s[k]->d_values) mi355x_free(s[k]->d_values);
     if (s[k]->d_local_slots) mi355x_free(s[k]->d_local_slots);
@@ -302,8 +302,20 @@ PetscErrorCode VecScatterDestroy(VecScatter *pctx) {
   if (ctx->d_local_tmp) mi355x_free(ctx->d_local_tmp);
   if (ctx->ev_packed) mi355x_event_destroy(ctx->ev_packed);
   if (ctx->ev_done) mi355x_event_destroy(ctx->ev_done);
-  free(ctx->h_send); free(ctx->h_recv);
-  free(ctx);
+  HipFree(ctx->h_send); HipFree(ctx->h_recv);
+  HipFree(ctx);
   *pctx = NULL;
   return 0;
+}
+
+#if !defined(PETSCHIPMI355X_WITH_PETSC)
+/* PETSc's names for the same calls: on the harness this scatter is the only VecScatter there is */
+PetscErrorCode VecScatterBegin(VecScatter ctx, Vec x, Vec y, InsertMode addv, ScatterMode mode) { return HipScatterBegin(ctx, x, y, addv, mode); }
+PetscErrorCode VecScatterEnd(VecScatter ctx, Vec x, Vec y, InsertMode addv, ScatterMode mode) { return HipScatterEnd(ctx, x, y, addv, mode); }
+PetscErrorCode VecScatterDestroy(VecScatter *ctx) { return HipScatterDestroy(ctx); }
+#endif
+PetscErrorCode VecScatterGetLists(VecScatter ctx, PetscInt *nrecv, const PetscInt **rprocs, const PetscInt **rstarts, const PetscInt **rindices,
+                                  PetscInt *nsend, const PetscInt **sprocs, const PetscInt **sstarts, const PetscInt **sindices,
+                                  PetscInt *nlocal, const PetscInt **lto, const PetscInt **lfrom) {
+  return HipScatterGetLists((HipScatter)ctx, nrecv, rprocs, rstarts, rindices, nsend, sprocs, sstarts, sindices, nlocal, lto, lfrom);
 }

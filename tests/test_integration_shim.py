@@ -1,0 +1,184 @@
+"""The drop-in boundary, checked against the reference's OWN headers (runs where /root/reference exists; skipped on the
+GPU box).  The plugin (petsc-dev_amd/host/*.c + integration/petsc-3.3/*_ctor.h) is written once for two object models: the
+harness (petsc-dev_amd/harness/petscimpl.h) and PETSc 3.3's real private headers.  What makes that possible -- and what a
+maintainer relies on when building it inside a PETSc tree -- is asserted here:
+  * every function-table slot of the harness's struct _VecOps / _MatOps exists in the reference's struct with the
+    identical C signature (include/petsc-private/vecimpl.h:221-294, matimpl.h:17-188);
+  * every slot any plugin source assigns (v->ops->X = / B->ops->X =) exists in the reference's struct;
+  * the object and container members the sources touch exist in the reference's structs under the same names;
+  * the PETSc functions the plugin calls have the reference's signatures (registration, composed functions, parent
+    constructors, generic Vec slots)."""
+import glob
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "include", "petsc-private")), reason="reference tree not present")
+
+
+def read(path):
+    return open(path).read()
+
+
+def strip_comments(t):
+    t = re.sub(r"/\*.*?\*/", " ", t, flags=re.S)
+    return re.sub(r"//[^\n]*", " ", t)
+
+
+def struct_body(text, name):
+    m = re.search(r"struct\s+%s\s*\{" % re.escape(name), text)
+    assert m, name
+    depth, i = 1, m.end()
+    while depth:
+        depth += {"{": 1, "}": -1}.get(text[i], 0)
+        i += 1
+    return text[m.end():i - 1]
+
+
+def norm_sig(ret, params):
+    """'PetscErrorCode', 'Vec x , const Vec y[], PetscErrorCode (*f)(Vec)' -> canonical type list, parameter names dropped"""
+    # split on commas that are not inside parentheses (function-pointer parameters carry their own lists)
+    parts, depth, cur = [], 0, ""
+    for ch in params:
+        depth += {"(": 1, ")": -1}.get(ch, 0)
+        if ch == "," and depth == 0:
+            parts.append(cur); cur = ""
+        else:
+            cur += ch
+    parts.append(cur)
+    out = []
+    for p in parts:
+        p = re.sub(r"\s+", " ", p.strip())
+        if not p or p == "void":
+            continue
+        if "(" in p:                                   # function pointer: drop the pointer's own name
+            p = re.sub(r"\(\s*(\*+)\s*\w*\s*\)", r"(\1)", p, count=1)
+        else:
+            idents = [t for t in re.findall(r"[A-Za-z_]\w*", p) if t not in ("const", "struct", "unsigned", "volatile")]
+            if len(idents) >= 2:                       # a type and a name: the name goes
+                k = p.rfind(idents[-1])
+                p = p[:k] + p[k + len(idents[-1]):]
+        p = p.replace(" ", "").replace("[]", "*")      # T x[] and T *x are the same parameter type
+        out.append(p)
+    return re.sub(r"\s+", "", ret) + "(" + ",".join(out) + ")"
+
+
+def slots(body):
+    """{slot: normalised signature} of a function-table struct body"""
+    res = {}
+    for m in re.finditer(r"([A-Za-z_][\w\s\*]*?)\(\s*\*\s*([a-z_0-9]+)\s*\)\s*\(([^;]*)\)\s*;", body):
+        res[m.group(2)] = norm_sig(m.group(1), m.group(3))
+    return res
+
+
+REF_VEC = strip_comments(read(os.path.join(REF, "include/petsc-private/vecimpl.h"))) if os.path.isdir(REF) else ""
+REF_MAT = strip_comments(read(os.path.join(REF, "include/petsc-private/matimpl.h"))) if os.path.isdir(REF) else ""
+HARNESS = strip_comments(read(os.path.join(ROOT, "petsc-dev_amd/harness/petscimpl.h")))
+PLUGIN_SOURCES = sorted(glob.glob(os.path.join(ROOT, "petsc-dev_amd/host/*.c")) + glob.glob(os.path.join(ROOT, "integration/petsc-3.3/*.h")) +
+                        glob.glob(os.path.join(ROOT, "integration/petsc-3.3/*.c")))
+
+
+@pytest.mark.parametrize("struct,ref_text", [("_VecOps", "vec"), ("_MatOps", "mat")])
+def test_harness_function_tables_have_the_reference_signatures(struct, ref_text):
+    ref = slots(struct_body(REF_VEC if ref_text == "vec" else REF_MAT, struct))
+    mine = slots(struct_body(HARNESS, struct))
+    assert len(ref) > 60 and len(mine) >= 15
+    for name, sig in mine.items():
+        assert name in ref, "slot %s of the harness's struct %s does not exist in the reference" % (name, struct)
+        assert sig == ref[name], "slot %s: harness %s, reference %s" % (name, sig, ref[name])
+
+
+def test_every_slot_the_plugin_assigns_exists_in_the_reference_tables():
+    vec_ref = slots(struct_body(REF_VEC, "_VecOps"))
+    mat_ref = slots(struct_body(REF_MAT, "_MatOps"))
+    seen_vec, seen_mat = set(), set()
+    for path in PLUGIN_SOURCES:
+        txt = strip_comments(read(path))
+        for var, slot in re.findall(r"\b(\w+)->ops->([a-z_0-9]+)\s*=[^=]", txt):
+            if var in ("v", "vv", "V"):
+                assert slot in vec_ref, "%s assigns Vec slot %s, which struct _VecOps of the reference does not have" % (os.path.basename(path), slot)
+                seen_vec.add(slot)
+            elif var in ("B", "A"):
+                assert slot in mat_ref, "%s assigns Mat slot %s, which struct _MatOps of the reference does not have" % (os.path.basename(path), slot)
+                seen_mat.add(slot)
+            else:
+                assert var == "pc", (path, var, slot)
+    # the slots the reference's own GPU subclasses override are all there (veccusp.cu:1915-1941, aijcusp.cu:665-676)
+    assert {"dot", "norm", "tdot", "scale", "copy", "set", "swap", "axpy", "axpby", "axpbypcz", "pointwisemult", "pointwisedivide",
+            "maxpy", "mdot", "aypx", "waxpy", "dotnorm2", "placearray", "resetarray", "destroy", "duplicate",
+            "dot_local", "tdot_local", "norm_local", "mdot_local", "getarray", "restorearray"} <= seen_vec
+    assert {"mult", "multadd", "multtranspose", "multtransposeadd", "assemblyend", "destroy", "getvecs", "setvaluesbatch"} <= seen_mat
+
+
+def test_object_and_container_members_exist_in_the_reference():
+    pv = struct_body(REF_VEC, "_p_Vec")
+    for member in ("map", "data", "petscnative", "array_gotten"):
+        assert re.search(r"\b%s\b" % member, pv), member
+    assert "PETSCHEADER(struct _VecOps)" in re.sub(r"\s+", "", pv).replace("PETSCHEADER(struct_VecOps)", "PETSCHEADER(struct _VecOps)")
+    pm = struct_body(REF_MAT, "_p_Mat")
+    for member in ("rmap", "cmap", "data", "spptr", "assembled", "was_assembled", "preallocated"):
+        assert re.search(r"\b%s\b" % member, pm), member
+    hdr = strip_comments(read(os.path.join(REF, "include/petsc-private/petscimpl.h")))
+    obj = hdr[hdr.index("typedef struct _p_PetscObject {"):hdr.index("} _p_PetscObject;")]
+    for member in ("comm", "type_name", "state", "prefix", "qlist"):
+        assert re.search(r"\b%s\b" % member, obj), member
+    assert re.search(r"#define\s+PETSCHEADER\(ObjectOps\)\s*\\\s*_p_PetscObject\s+hdr;\s*\\\s*ObjectOps\s+\*ops", hdr)
+    lay = strip_comments(read(os.path.join(REF, "include/petsc-private/vecimpl.h")))
+    body = struct_body(lay, "_n_PetscLayout")
+    for member in ("n", "N", "rstart", "rend", "range"):
+        assert re.search(r"\b%s\b" % member, body), member
+    aij = strip_comments(read(os.path.join(REF, "src/mat/impls/aij/seq/aij.h")))
+    for member in ("*i", "*j", "*ilen", "*imax", "nz", "maxnz", "*a;"):        # SEQAIJHEADER members the view aliases
+        assert member in aij, member
+    assert re.search(r"PetscBool\s+use;", aij) and "node_count" in aij and "Mat_SeqAIJ_Inode inode" in aij
+    mpi = struct_body(strip_comments(read(os.path.join(REF, "src/mat/impls/aij/mpi/mpiaij.h"))), "").strip() if False else strip_comments(read(os.path.join(REF, "src/mat/impls/aij/mpi/mpiaij.h")))
+    for member in (r"Mat\s+A,B;", r"\*garray;", r"Vec\s+lvec;", r"VecScatter\s+Mvctx;"):
+        assert re.search(member, mpi), member
+
+
+def test_petsc_functions_the_plugin_calls_have_the_reference_signatures():
+    def decl(header, name):
+        t = strip_comments(read(os.path.join(REF, header)))
+        m = re.search(r"PetscErrorCode\s+%s\s*\(([^;{]*)\)\s*;" % re.escape(name), t)
+        assert m, (header, name)
+        return norm_sig("PetscErrorCode", m.group(1))
+
+    mini = strip_comments(read(os.path.join(ROOT, "include/petscmini.h")))
+
+    def mine(name):
+        m = re.search(r"PetscErrorCode\s+%s\s*\(([^;{]*)\)\s*;" % re.escape(name), mini)
+        assert m, name
+        return norm_sig("PetscErrorCode", m.group(1))
+
+    for header, name in (("include/petscvec.h", "VecRegister"), ("include/petscmat.h", "MatRegister"), ("include/petscpc.h", "PCRegister"),
+                         ("include/petscksp.h", "KSPRegister"), ("include/petscsys.h", "PetscObjectComposeFunction"),
+                         ("include/petscsys.h", "PetscObjectQueryFunction"), ("include/petscsys.h", "PetscObjectChangeTypeName"),
+                         ("include/petscmat.h", "MatSeqAIJSetPreallocation"), ("include/petscmat.h", "MatMPIAIJSetPreallocation"),
+                         ("include/petscmat.h", "MatSeqAIJSetPreallocationCSR"), ("include/petscmat.h", "MatMPIAIJSetPreallocationCSR"),
+                         ("include/petscmat.h", "MatGetDiagonalBlock"), ("include/petscmat.h", "MatSetValuesBatch"),
+                         ("include/petscvec.h", "VecDotBegin"), ("include/petscvec.h", "VecNormEnd")):
+        ref = decl(header, name)
+        got = mine(name)
+        ref = ref.replace("void(*)(void)", "PetscVoidFunction").replace("void(**)(void)", "PetscVoidFunction*")
+        assert got == ref, "%s: harness %s, reference %s" % (name, got, ref)
+    # parent constructors and generic slots the *_ctor.h fragments call: declared (non-static) in the reference's tree
+    for header, name in (("src/mat/impls/aij/seq/aij.h", "MatCreate_SeqAIJ"), ("src/mat/impls/aij/mpi/mpiaij.h", "MatCreate_MPIAIJ"),
+                         ("src/vec/vec/impls/dvecimpl.h", "VecGetSize_Seq"), ("src/vec/vec/impls/dvecimpl.h", "VecView_Seq"),
+                         ("src/vec/vec/impls/mpi/pvecimpl.h", "VecGetSize_MPI"), ("src/vec/vec/impls/mpi/pvecimpl.h", "VecView_MPI"),
+                         ("include/petsc-private/vecimpl.h", "VecDuplicateVecs_Default"), ("include/petsc-private/vecimpl.h", "VecDestroyVecs_Default"),
+                         ("include/petsc-private/vecimpl.h", "VecLoad_Default"), ("include/petsc-private/vecimpl.h", "PetscLayoutReference")):
+        decl(header, name)
+    frag = "".join(read(p) for p in PLUGIN_SOURCES if p.endswith("_ctor.h"))
+    for name in ("MatCreate_SeqAIJ", "MatCreate_MPIAIJ", "VecGetSize_Seq", "VecView_MPI", "VecDuplicateVecs_Default", "VecLoad_Default"):
+        assert name + "(" in frag or name + ";" in frag or "= " + name in frag, name
+
+
+def test_public_headers_define_no_mpi_names():
+    """include/petschipmi355x.h and include/petscmini.h can be included next to <mpi.h>: they declare no MPI_ identifier
+    (the MPI spellings for harness example programs live in the opt-in petscmini_mpinames.h)"""
+    for h in ("petschipmi355x.h", "petscmini.h", "mi355x_kernels.h", "mi355x_comm.h"):
+        t = strip_comments(read(os.path.join(ROOT, "include", h)))
+        assert not re.search(r"\bMPI_\w+", t), h
