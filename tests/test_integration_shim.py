@@ -173,7 +173,7 @@ def test_petsc_functions_the_plugin_calls_have_the_reference_signatures():
         decl(header, name)
     frag = "".join(read(p) for p in PLUGIN_SOURCES if p.endswith("_ctor.h"))
     for name in ("MatCreate_SeqAIJ", "MatCreate_MPIAIJ", "VecGetSize_Seq", "VecView_MPI", "VecDuplicateVecs_Default", "VecLoad_Default"):
-        assert name + "(" in frag or name + ";" in frag or "= " + name in frag, name
+        assert re.search(r"\b%s\b" % name, frag), name
 
 
 def test_public_headers_define_no_mpi_names():
