@@ -225,6 +225,10 @@ int mi355x_spmv_bsr_planned(mi355x_handle_t h, mi355x_spmv_plan_t plan, int bs, 
 int mi355x_spmv_bsr4_mfma(mi355x_handle_t h, int mbs, int variant, const int *ai, const int *aj, const double *aa,
                           const double *x, double *y);
 
+/* PCApply_PBJacobi_N  src/ksp/pc/impls/pbjacobi/pbjacobi.c:20-200   y_i = D_i^-1 x_i, idiag = mbs inverted bs x bs blocks
+ * (column-major, as MatInvertBlockDiagonal_SeqBAIJ baij.c:13 leaves them); the reference's left-to-right row sums */
+int mi355x_pbjacobi_apply(mi355x_handle_t h, int mbs, int bs, const double *idiag, const double *x, double *y);
+
 /* ---- ILU(0) triangular solves ---------------------------- */
 /* MatSolve_SeqAIJ_NaturalOrdering  src/mat/impls/aij/seq/aijfact.c:3126-3172 on the factor layout of :1628-1700,
  * one launch per dependency level; `rows` lists the rows of the level (device array).  Lower: x[i] = b[i] - L(i,:)x

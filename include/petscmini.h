@@ -101,6 +101,7 @@ typedef const char *PCType;
 #define PCNONE     "none"
 #define PCJACOBI   "jacobi"
 #define PCBJACOBI  "bjacobi"
+#define PCPBJACOBI "pbjacobi"  /* point-block Jacobi (src/ksp/pc/impls/pbjacobi/pbjacobi.c), SURVEY 8f.4 */
 #define PCILU      "ilu"       /* ILU(0), natural ordering, sequential AIJ */
 
 /* ---- Sys ----------------------------------------------------------------------------------- */

@@ -28,6 +28,7 @@ typedef struct solver_s {
   int max_it, restart, refine_always, guess_nonzero, cg_single;
   int norm_type;   /* KSPNormType: 0 none, 1 preconditioned (default), 2 unpreconditioned, 3 natural (petscksp.h) */
   int pc_right;    /* PC_RIGHT (GMRES only): A B y = b, x = B y; the norm is then the unpreconditioned one */
+  int pb_bs;       /* PCPBJACOBI block size */
   int n;
   int inode;       /* -1: not checked yet; 1: Mat_CheckInode keeps the inode routines for this matrix; 0: plain */
   const int *ai, *aj;
@@ -145,6 +146,15 @@ static void pc_setup(solver *s) {
     orc_csr_get_diagonal(s->n, s->ai, s->aj, s->aa, s->idiag);   /* MatGetDiagonal */
     orc_vec_reciprocal((size_t)s->n, s->idiag);                   /* VecReciprocal */
     for (int i = 0; i < s->n; i++) if (s->idiag[i] == 0.0) s->idiag[i] = 1.0;
+  } else if (s->pc_type == ORC_PC_PBJACOBI) {
+    /* PCSetUp_PBJacobi (pbjacobi.c:228-275) -> MatInvertBlockDiagonal: the bs x bs diagonal blocks, column-major, inverted.
+     * The blocks are read out of the point CSR (entries a BAIJ matrix stores as explicit zeros are zero here too). */
+    const int bs = s->pb_bs > 0 ? s->pb_bs : 1, mbs = s->n / bs;
+    s->idiag = (double *)calloc((size_t)mbs * bs * bs + 1, sizeof(double));
+    for (int i = 0; i < s->n; i++)
+      for (int k = s->ai[i]; k < s->ai[i + 1]; k++)
+        if (s->aj[k] / bs == i / bs) s->idiag[(size_t)(i / bs) * bs * bs + (i % bs) + (size_t)(s->aj[k] % bs) * bs] = s->aa[k];
+    for (int i = 0; i < mbs; i++) orc_block_inverse(bs, s->idiag + (size_t)i * bs * bs);
   } else if (s->pc_type == ORC_PC_BJACOBI) {
     /* PCSetUp_BJacobi_*: sub-KSP on each diagonal block (bjacobi.c:858-923; MatGetSubMatrices of
      * the contiguous diagonal blocks) */
@@ -189,6 +199,7 @@ static void pc_apply(solver *s, const double *x, double *y) {
   if (s->pc_type == ORC_PC_NONE) orc_vec_copy((size_t)s->n, x, y);
   else if (s->pc_type == ORC_PC_JACOBI) orc_vec_pointwise_mult((size_t)s->n, x, s->idiag, y);
   else if (s->pc_type == ORC_PC_ILU) orc_ilu0_solve(s->n, s->fi, s->fj, s->fdiag, s->fa, x, y);   /* PCApply_ILU -> MatSolve */
+  else if (s->pc_type == ORC_PC_PBJACOBI) orc_pbjacobi_apply(s->n / (s->pb_bs > 0 ? s->pb_bs : 1), s->pb_bs > 0 ? s->pb_bs : 1, s->idiag, x, y);
   else {
     for (int k = 0; k < s->nblocks; k++) {
       solver *t = &s->sub[k];
@@ -574,6 +585,7 @@ int orc_ksp_solve(const orc_ksp_opts *o, int n, const int *ai, const int *aj, co
   S.ksp_type = o->ksp_type; S.pc_type = o->pc_type;
   S.rtol = o->rtol; S.abstol = o->abstol; S.dtol = o->dtol; S.max_it = o->max_it;
   S.restart = o->restart; S.refine_always = o->refine_always; S.guess_nonzero = o->guess_nonzero; S.cg_single = o->cg_single; S.norm_type = o->norm_type; S.pc_right = (o->pc_right && o->ksp_type == ORC_KSP_GMRES);
+  S.pb_bs = o->pb_bs;
   S.n = n; S.ai = ai; S.aj = aj; S.aa = aa; S.inode = -1;
   S.nblocks = o->nblocks; S.blk = o->blk;
   S.hist = hist; S.hist_cap = hist_cap; S.nhist = 0;

@@ -58,6 +58,10 @@ void orc_csr_get_diagonal(int m, const int *ai, const int *aj, const double *aa,
 int  orc_check_inode(int m, const int *ai, const int *aj, int limit, int *ns);
 void orc_spmv_csr_inode(int m, const int *ai, const int *aj, const double *aa, const double *x, double *y);
 void orc_spmv_csr_inode_add(int m, const int *ai, const int *aj, const double *aa, const double *x, const double *z, double *y);
+/* point-block Jacobi: pbjacobi.c, baij.c:13-160, dgefa*.c / dgedi.c */
+int  orc_block_inverse(int n, double *a);
+int  orc_bsr_invert_block_diagonal(int mbs, int bs, const int *ai, const int *aj, const double *aa, double *idiag);
+void orc_pbjacobi_apply(int mbs, int bs, const double *idiag, const double *x, double *y);
 int  orc_matmult_seqaij(int m, const int *ai, const int *aj, const double *aa, const double *x, const double *z, double *y, int *ns_work);
 /* explicit transpose, rows of A^T listing contributions in increasing original-row order */
 void orc_csr_transpose(int m, int n, const int *ai, const int *aj, const double *aa, int *ti, int *tj, double *ta);
@@ -85,7 +89,7 @@ void orc_scatter_create(int size, int rank, const int *ranges, const int *const 
 
 /* ---- KSP (src/ksp/ksp/impls/{cg/cg.c:92, gmres/gmres.c:118-409 + borthog2.c:35, bcgs/bcgs.c:43}) ---- */
 enum { ORC_KSP_CG = 0, ORC_KSP_GMRES = 1, ORC_KSP_BCGS = 2, ORC_KSP_PREONLY = 3, ORC_KSP_GROPPCG = 4 };
-enum { ORC_PC_NONE = 0, ORC_PC_JACOBI = 1, ORC_PC_BJACOBI = 2, ORC_PC_ILU = 3 };
+enum { ORC_PC_NONE = 0, ORC_PC_JACOBI = 1, ORC_PC_BJACOBI = 2, ORC_PC_ILU = 3, ORC_PC_PBJACOBI = 4 };
 /* ILU(0), natural ordering (src/mat/impls/aij/seq/aijfact.c:1628 symbolic, :461 numeric, :3126 solve); bi[n+1], bj/ba[nz+1], bdiag[n+1] */
 int  orc_ilu0_factor(int n, const int *ai, const int *aj, const double *aa, int *bi, int *bj, int *bdiag, double *ba);
 void orc_ilu0_solve(int n, const int *bi, const int *bj, const int *bdiag, const double *ba, const double *b, double *x);
@@ -104,6 +108,7 @@ typedef struct {
   int sub_max_it;
   int cg_single;          /* -ksp_cg_single_reduction (cg.c:116-122,200-203,263-270) */
   int norm_type;          /* KSPNormType for CG (cg.c:136-161): 0 none, 1 preconditioned (default), 2 unpreconditioned, 3 natural */
+  int pb_bs;              /* PCPBJACOBI: the matrix's block size (pbjacobi.c:240: taken from the Mat); n % pb_bs == 0 */
   int pc_right;           /* -ksp_pc_side right (GMRES): KSPInitialResidual itres.c:55-64, PCApplyBAorAB precon.c:617, gmres.c:343-346 */
 } orc_ksp_opts;
 void orc_ksp_default_opts(orc_ksp_opts *o);

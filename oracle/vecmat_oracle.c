@@ -310,3 +310,73 @@ int orc_matmult_seqaij(int m, const int *ai, const int *aj, const double *aa, co
   else       { if (z) orc_spmv_csr_add(m, ai, aj, aa, x, z, y); else orc_spmv_csr(m, ai, aj, aa, x, y); }
   return nodes;
 }
+
+
+/* ---- point-block Jacobi: src/ksp/pc/impls/pbjacobi/pbjacobi.c ----
+ * PetscKernel_A_gets_inverse_A_N (src/mat/impls/baij/seq/dgefa.c, dgefa2.c .. dgefa7.c, dgedi.c): LINPACK dgefa (Gaussian
+ * elimination with partial pivoting, multipliers stored negated) followed by dgedi (inverse(U), then inverse(U)*inverse(L),
+ * column interchanges undone), on a column-major n x n block, in place; no shift.  Returns the 0-based zero-pivot row + 1, or 0. */
+int orc_block_inverse(int n, double *a) {
+  int ipvt[16];
+  double work[16];
+  if (n < 1 || n > 16) return -1;
+#define A_(i, j) a[(i) + (j) * n]
+  for (int k = 0; k < n - 1; k++) {
+    int l = k;
+    double max = fabs(A_(k, k));
+    for (int i = k + 1; i < n; i++) { const double t = fabs(A_(i, k)); if (t > max) { max = t; l = i; } }
+    ipvt[k] = l;
+    if (A_(l, k) == 0.0) return k + 1;
+    if (l != k) { const double t = A_(l, k); A_(l, k) = A_(k, k); A_(k, k) = t; }
+    { const double t = -1. / A_(k, k); for (int i = k + 1; i < n; i++) A_(i, k) *= t; }
+    for (int j = k + 1; j < n; j++) {
+      const double t = A_(l, j);
+      if (l != k) { A_(l, j) = A_(k, j); A_(k, j) = t; }
+      for (int i = k + 1; i < n; i++) A_(i, j) += t * A_(i, k);
+    }
+  }
+  ipvt[n - 1] = n - 1;
+  if (A_(n - 1, n - 1) == 0.0) return n;
+  for (int k = 0; k < n; k++) {                 /* inverse(U) */
+    A_(k, k) = 1.0 / A_(k, k);
+    { const double t = -A_(k, k); for (int i = 0; i < k; i++) A_(i, k) *= t; }
+    for (int j = k + 1; j < n; j++) {
+      const double t = A_(k, j);
+      A_(k, j) = 0.0;
+      for (int i = 0; i <= k; i++) A_(i, j) += t * A_(i, k);
+    }
+  }
+  for (int kb = 1; kb < n; kb++) {              /* inverse(U) * inverse(L) */
+    const int k = n - 1 - kb;
+    for (int i = k + 1; i < n; i++) { work[i] = A_(i, k); A_(i, k) = 0.0; }
+    for (int j = k + 1; j < n; j++) { const double t = work[j]; for (int i = 0; i < n; i++) A_(i, k) += t * A_(i, j); }
+    const int l = ipvt[k];
+    if (l != k) for (int i = 0; i < n; i++) { const double t = A_(i, k); A_(i, k) = A_(i, l); A_(i, l) = t; }
+  }
+#undef A_
+  return 0;
+}
+/* MatInvertBlockDiagonal_SeqBAIJ (baij.c:13-160): the diagonal block of every block row, inverted; blocks column-major */
+int orc_bsr_invert_block_diagonal(int mbs, int bs, const int *ai, const int *aj, const double *aa, double *idiag) {
+  const int bs2 = bs * bs;
+  for (int i = 0; i < mbs; i++) {
+    int found = 0;
+    for (int k = ai[i]; k < ai[i + 1]; k++) if (aj[k] == i) { memcpy(idiag + (size_t)i * bs2, aa + (size_t)k * bs2, sizeof(double) * (size_t)bs2); found = 1; break; }
+    if (!found) return -(i + 1);
+    const int z = orc_block_inverse(bs, idiag + (size_t)i * bs2);
+    if (z) return i * bs + z;
+  }
+  return 0;
+}
+/* PCApply_PBJacobi_N (pbjacobi.c:20-200): y_i = D_i^-1 x_i, every row the left-to-right sum d[r]*x0 + d[r+bs]*x1 + ... */
+void orc_pbjacobi_apply(int mbs, int bs, const double *idiag, const double *x, double *y) {
+  const int bs2 = bs * bs;
+  for (int i = 0; i < mbs; i++) {
+    const double *d = idiag + (size_t)i * bs2, *xx = x + (size_t)i * bs;
+    for (int r = 0; r < bs; r++) {
+      double sum = d[r] * xx[0];
+      for (int c = 1; c < bs; c++) sum += d[r + c * bs] * xx[c];
+      y[(size_t)i * bs + r] = sum;
+    }
+  }
+}

@@ -72,6 +72,7 @@ KERNEL_API = {
     "mi355x_handle_publish": [vp, vp, i32],
     "mi355x_handle_publish_at": [vp, vp, i32, i32],
     "mi355x_vec_cg_update_dev": [vp, sz, dbl, vp, dbl, i32, vp, vp, vp, vp, vp, vp, vp, i32],
+    "mi355x_pbjacobi_apply": [vp, i32, i32, vp, vp, vp],
     "mi355x_spmv_bsr4_mfma": [vp, i32, i32, vp, vp, vp, vp, vp],
     "mi355x_trisolve_plan_create": [vp, i32, i32, vp, vp, vp, vp, vp, vp, C.POINTER(vp)],
     "mi355x_trisolve_plan_destroy": [vp],

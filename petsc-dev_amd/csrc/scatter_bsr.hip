@@ -188,6 +188,22 @@ __global__ __launch_bounds__(MI355X_BLOCK) void bsr4_mfma_kernel(int mbs, const 
   }
 }
 
+// PCApply_PBJacobi_N (src/ksp/pc/impls/pbjacobi/pbjacobi.c:20-200): y_i = D_i^-1 x_i with the inverted bs x bs diagonal blocks
+// stored column-major, one lane per point row, the row's products added left to right (d[r] x0 + d[r+bs] x1 + ...): the
+// reference's expression order, same bits.  (8 bs + 16) B per point row: HBM-bound.
+__global__ __launch_bounds__(MI355X_BLOCK) void pbjacobi_apply_kernel(long n, int bs, const double *__restrict__ idiag,
+                                                                     const double *__restrict__ x, double *__restrict__ y) {
+  const long stride = (long)gridDim.x * MI355X_BLOCK;
+  for (long row = (long)blockIdx.x * MI355X_BLOCK + threadIdx.x; row < n; row += stride) {
+    const long blk = row / bs;
+    const int r = (int)(row - blk * bs);
+    const double *d = idiag + blk * bs * bs + r, *xx = x + blk * bs;
+    double sum = d[0] * xx[0];
+    for (int c = 1; c < bs; ++c) sum += d[(long)c * bs] * xx[c];
+    y[row] = sum;
+  }
+}
+
 template <int BS>
 static int launch_bsr(mi355x_handle_t h, int mbs, const int *ai, const int *aj, const double *aa, const double *x,
                       double *y) {
@@ -235,6 +251,15 @@ int mi355x_spmv_bsr(mi355x_handle_t h, int mbs, int bs, const int *ai, const int
     case 8: return launch_bsr<8>(h, mbs, ai, aj, aa, x, y);
     default: return (int)hipErrorInvalidValue;
   }
+}
+
+int mi355x_pbjacobi_apply(mi355x_handle_t h, int mbs, int bs, const double *idiag, const double *x, double *y) {
+  if (mbs <= 0) return 0;
+  if (bs < 1) return (int)hipErrorInvalidValue;
+  const long n = (long)mbs * bs;
+  hipLaunchKernelGGL(pbjacobi_apply_kernel, dim3(mi355x_grid_for((size_t)n, 4)), dim3(MI355X_BLOCK), 0, h->stream, n, bs, idiag, x, y);
+  MI355X_LAUNCH_CHECK();
+  return 0;
 }
 
 // MatMult_SeqBAIJ_4 on the matrix cores; variant 0: 16-byte loads, 8 blocks per step; 1: 8-byte loads, 4 blocks per step;

@@ -124,6 +124,23 @@ def matmult(ai, aj, aa, x, z=None):
     return y, nodes
 
 
+def pbjacobi_setup(bs, bi, bj, ba):
+    """inverted diagonal blocks (MatInvertBlockDiagonal_SeqBAIJ), column-major, mbs x bs x bs"""
+    mbs = bi.size - 1
+    idiag = np.zeros(mbs * bs * bs)
+    lib().orc_bsr_invert_block_diagonal.restype = C.c_int
+    rc = lib().orc_bsr_invert_block_diagonal(C.c_int(mbs), C.c_int(bs), I(bi), I(bj), D(ba), D(idiag))
+    assert rc == 0, rc
+    return idiag
+
+
+def pbjacobi_apply(bs, idiag, x):
+    mbs = idiag.size // (bs * bs)
+    y = np.zeros(mbs * bs)
+    lib().orc_pbjacobi_apply(C.c_int(mbs), C.c_int(bs), D(idiag), D(x), D(y))
+    return y
+
+
 def spmv_add(ai, aj, aa, x, y):
     m = ai.size - 1
     z = np.zeros(m)
@@ -245,11 +262,11 @@ class KspOpts(C.Structure):
                 ("dtol", C.c_double), ("max_it", C.c_int), ("restart", C.c_int), ("refine_always", C.c_int),
                 ("guess_nonzero", C.c_int), ("nblocks", C.c_int), ("blk", pi), ("sub_ksp_type", C.c_int),
                 ("sub_pc_type", C.c_int), ("sub_rtol", C.c_double), ("sub_abstol", C.c_double),
-                ("sub_dtol", C.c_double), ("sub_max_it", C.c_int), ("cg_single", C.c_int), ("norm_type", C.c_int), ("pc_right", C.c_int)]
+                ("sub_dtol", C.c_double), ("sub_max_it", C.c_int), ("cg_single", C.c_int), ("norm_type", C.c_int), ("pb_bs", C.c_int), ("pc_right", C.c_int)]
 
 
 KSP = dict(cg=0, gmres=1, bcgs=2, preonly=3, groppcg=4)
-PC = dict(none=0, jacobi=1, bjacobi=2, ilu=3)
+PC = dict(none=0, jacobi=1, bjacobi=2, ilu=3, pbjacobi=4)
 
 
 def ksp_solve(ai, aj, aa, b, ksp="gmres", pc="none", x0=None, blocks=None, sub_ksp="preonly", sub_pc="jacobi", **kw):

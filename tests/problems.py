@@ -166,6 +166,24 @@ def elasticity_like(nx, ny, nz, dof=3, seed=3):
     return (np.array(ai, dtype=np.int32), np.array(aj, dtype=np.int32), np.array(aa)), (bi, bj, ba)
 
 
+def spd_blocks(nx, ny, nz, dof=3, seed=3):
+    """A symmetric positive definite dof-per-node operator whose diagonal blocks are dense and badly point-scaled (the case
+    point-block Jacobi is for): sym(elasticity_like) + blockdiag(c_node * K), K = I + 0.9 (J - I) (eigenvalues 0.1 .. ),
+    c_node large enough for definiteness.  Returns point CSR and block CSR (blocks column-major)."""
+    import scipy.sparse as sp
+    (ai, aj, aa), (bi, bj, _) = elasticity_like(nx, ny, nz, dof, seed)
+    n = ai.size - 1
+    M = sp.csr_matrix((aa, aj, ai), shape=(n, n))
+    S = sp.csr_matrix(M + M.T)
+    r = np.asarray(abs(S).sum(1)).ravel().reshape(-1, dof).max(1)           # per node
+    K = np.eye(dof) + 0.9 * (np.ones((dof, dof)) - np.eye(dof))
+    S = sp.csr_matrix(S + sp.block_diag([10.0 * (c + 1.0) * K for c in r], format="csr"))
+    S.sort_indices()
+    B = sp.bsr_matrix(S, blocksize=(dof, dof)); B.sort_indices()
+    ba = np.ascontiguousarray(B.data.transpose(0, 2, 1)).ravel()
+    return (S.indptr.astype(np.int32), S.indices.astype(np.int32), S.data.copy()), (B.indptr.astype(np.int32), B.indices.astype(np.int32), ba)
+
+
 def gen_irr(n=1564794, mean=73.0, seed=12345):
     """SURVEY 8(d) config 4 stand-in 'IRR': log-normal row lengths clipped to [3,400], columns banded +-50 000 with
     20 % uniform long-range entries, diagonally dominant values.  (A random pattern: no FEM matrix looks like this;

@@ -242,6 +242,52 @@ def test_baij_matmult(P, bs, opt):
     assert np.allclose(vy.array(), ref, rtol=0, atol=1e-12 * 50)
 
 
+@pytest.mark.parametrize("bs", [2, 3, 4, 5])
+def test_pbjacobi_on_baij(P, bs):
+    """PCPBJACOBI on the BAIJ type (pbjacobi.c + MatInvertBlockDiagonal_SeqBAIJ baij.c:13): PCApply equals the
+    restatement bit for bit (-ksp_type preonly: x = B b), and CG + PCPBJACOBI walks the restatement's residual history
+    (the BAIJ product differs from the point-wise one in summation order: BASELINE.md tolerance)."""
+    L = P.lib()
+    (ai, aj, aa), (bi, bj, ba) = pb.spd_blocks(7, 6, 5, dof=bs)
+    n = ai.size - 1
+    b = np.cos(0.1 * np.arange(n))
+    idiag = orc.pbjacobi_setup(bs, bi, bj, ba)
+
+    def run(ksp, **tol):
+        A = P.Mat.from_bsr(bs, bi, bj, ba)
+        vb, vx = V(P, b), V(P, np.zeros(n))
+        k = P.KSP(comm=L.COMM_SELF); k.set_operators(A)
+        set_options(L, "-ksp_type %s -pc_type pbjacobi" % ksp)
+        if tol:
+            k.set_tolerances(**tol)
+        k.set_from_options(); set_options(L, "")
+        k.record_history()
+        k.solve(vb, vx)
+        return vx.array(), k.history(), k.its, k.reason
+
+    x, _, _, _ = run("preonly")
+    assert np.array_equal(x.view(np.uint64), orc.pbjacobi_apply(bs, idiag, b).view(np.uint64))
+    x, h, its, reason = run("cg", rtol=1e-10)
+    xo, ho, ito, ro = orc.ksp_solve(ai, aj, aa, b, ksp="cg", pc="pbjacobi", pb_bs=bs, rtol=1e-10)
+    assert (its, reason) == (ito, ro) and reason > 0
+    assert np.allclose(h, ho, rtol=1e-8, atol=0) and np.allclose(x, xo, rtol=1e-9, atol=1e-12)
+
+
+def test_pbjacobi_zero_pivot_and_wrong_type_are_errors(P):
+    """MatInvertBlockDiagonal's zero-pivot error reaches KSPSetUp; a missing diagonal block too"""
+    L = P.lib()
+    bs = 2
+    bi = np.array([0, 1, 2], dtype=np.int32)
+    for bj, ba in ((np.array([0, 1], dtype=np.int32), np.array([1., 1, 1, 1, 2, 0, 0, 2])),      # first block singular
+                   (np.array([1, 1], dtype=np.int32), np.array([2., 0, 0, 2, 2, 0, 0, 2]))):     # block row 0 has no diagonal block
+        A = P.Mat.from_bsr(bs, bi, bj, ba)
+        k = P.KSP(comm=L.COMM_SELF); k.set_operators(A)
+        set_options(L, "-ksp_type preonly -pc_type pbjacobi"); k.set_from_options(); set_options(L, "")
+        vb, vx = V(P, np.ones(4)), V(P, np.zeros(4))
+        with pytest.raises(P.PetscError):
+            k.solve(vb, vx)
+
+
 def test_config5_full_size_baij_equals_aij(P):
     """BASELINE configs[4] at full size: the 27-point, 3-dof elasticity shape on 128^3 nodes (6.3 M rows, 5.6e7 blocks)
     stored as BAIJ bs = 3, as BAIJ zero-padded to bs = 4 (matrix-core kernel and FMA kernel) and as point-wise AIJ (5.1e8

@@ -2,6 +2,7 @@
 src/mat/examples/tests/output and src/ksp/ksp/examples/{tests,tutorials}/output) and to the reference run
 recorded in SURVEY.md 8(c)/(d).  Residual norms are compared as the 6-significant-digit text
 -ksp_monitor_short prints."""
+import ctypes as C
 import os
 
 import numpy as np
@@ -223,3 +224,49 @@ def test_threaded_cpu_baseline_matches_the_sequential_oracle():
         assert t >= 0.0
         assert np.linalg.norm(x - xs) <= 1e-12 * np.linalg.norm(xs)
         assert abs(rn - hs[25]) <= 1e-10 * hs[0]
+
+
+@pytest.mark.parametrize("bs", [1, 2, 3, 4, 5, 6, 7, 9])
+def test_block_inverse_and_pbjacobi_restatement(bs):
+    """PetscKernel_A_gets_inverse_A_N (dgefa*.c / dgedi.c: LINPACK, partial pivoting) and PCApply_PBJacobi_N (pbjacobi.c):
+    the inverse agrees with LAPACK's to rounding (also when the leading entry is zero and rows must be interchanged), a
+    singular block reports its zero pivot, and the apply is the column-major block times the vector."""
+    rng = np.random.default_rng(bs)
+    mbs = 40
+    blocks = rng.standard_normal((mbs, bs, bs)) + 3.0 * np.eye(bs)
+    if bs > 1:
+        blocks[0, 0, 0] = 0.0                                   # forces an interchange in the first column
+        blocks[1] = blocks[1][::-1].copy()                      # anti-diagonal dominant: interchanges in every column
+    bi = np.arange(mbs + 1, dtype=np.int32); bj = np.arange(mbs, dtype=np.int32)
+    ba = np.ascontiguousarray(blocks.transpose(0, 2, 1)).reshape(-1)   # column-major blocks
+    idiag = orc.pbjacobi_setup(bs, bi, bj, ba)
+    inv = idiag.reshape(mbs, bs, bs).transpose(0, 2, 1)
+    for b in range(mbs):
+        assert np.allclose(inv[b] @ blocks[b], np.eye(bs), rtol=0, atol=1e-11 * np.linalg.cond(blocks[b]))
+    x = rng.standard_normal(mbs * bs)
+    y = orc.pbjacobi_apply(bs, idiag, x)
+    assert np.allclose(y, np.einsum("brc,bc->br", inv, x.reshape(mbs, bs)).reshape(-1), rtol=1e-13, atol=1e-13)
+    if bs > 1:
+        sing = np.ones((bs, bs)).reshape(-1)                    # rank one: the second pivot is exactly zero
+        assert orc.lib().orc_block_inverse(C.c_int(bs), orc.D(sing)) == 2
+
+
+def test_pbjacobi_with_block_size_one_is_jacobi():
+    """bs = 1: dgedi's 1.0 / a and the single product d * x are PCJacobi's VecReciprocal and VecPointwiseMult: same bits."""
+    ai, aj, aa = pb.lap2d(12, 9)
+    aa = aa * (1.0 + 0.1 * np.cos(np.arange(aa.size)))
+    b = np.sin(np.arange(ai.size - 1.0))
+    xj, hj, itj, rj = orc.ksp_solve(ai, aj, aa, b, ksp="cg", pc="jacobi", rtol=1e-9)
+    xp, hp, itp, rp = orc.ksp_solve(ai, aj, aa, b, ksp="cg", pc="pbjacobi", pb_bs=1, rtol=1e-9)
+    assert itj == itp and rj == rp and np.array_equal(xj.view(np.uint64), xp.view(np.uint64)) and np.array_equal(hj, hp)
+
+
+def test_pbjacobi_preconditions_a_block_system():
+    """CG + PCPBJACOBI on a 3-dof SPD operator converges in fewer iterations than CG + PCJACOBI and to the same solution."""
+    (ai, aj, aa), _ = pb.spd_blocks(6, 5, 4)
+    n = ai.size - 1
+    b = np.cos(0.1 * np.arange(n))
+    xj, _, itj, rj = orc.ksp_solve(ai, aj, aa, b, ksp="cg", pc="jacobi", rtol=1e-10)
+    xp, _, itp, rp = orc.ksp_solve(ai, aj, aa, b, ksp="cg", pc="pbjacobi", pb_bs=3, rtol=1e-10)
+    assert rj > 0 and rp > 0 and itp < itj, (itp, itj)
+    assert np.allclose(xj, xp, rtol=1e-7, atol=1e-9)
