@@ -150,6 +150,11 @@ int mi355x_vec_bcgs_update(mi355x_handle_t h, size_t n, double alpha, double ome
                            const double *rp, double *x, double *r, double *out);
 /* VecMDot_Seq         src/vec/vec/impls/seq/dvec2.c:146     out[j] = sum_i x_i y_j,i , j<nv ; x read once per 16 y's */
 int mi355x_vec_mdot(mi355x_handle_t h, size_t n, int nv, const double *x, const double *const *y, double *out);
+/* KSPGMRESCycle fusions (gmres.c:118-209, borthog2.c:60-66): x += sum_j sign*coef_dev[j]*y_j in VecMAXPY_Seq's grouping with
+ * sum x_new^2 from the same sweep (bits of VecMAXPY + VecNorm); x *= 1/sqrt(*norm2_dev) with VecNormalize's special cases */
+int mi355x_vec_maxpy_dev_norm2(mi355x_handle_t h, size_t n, int nv, const double *coef_dev, double sign, const double *const *y,
+                               double *x, double *out);
+int mi355x_vec_scale_rnorm_dev(mi355x_handle_t h, size_t n, const double *norm2_dev, double *x);
 /* VecSum / VecMax helpers are not on the Krylov path and are not provided. */
 
 /* ---- CSR SpMV (MatMult_SeqAIJ family) --------------------------------- */
@@ -195,6 +200,9 @@ int mi355x_spmv_dot_finish(mi355x_handle_t h, mi355x_spmv_plan_t plan, double *o
 /* MatMultAdd_SeqAIJ   src/mat/impls/aij/seq/aij.c:1291   z[r] = y[r] + sum_k ... (sum starts from y[r]);
  * z may alias y.  With a compressed-row plan only the listed rows are touched (z must alias y
  * or already hold y, as aij.c:1314-1316 arranges). */
+/* y = d .* (A x): MatMult + PCApply_Jacobi's VecPointwiseMult (jacobi.c:266) in one kernel, bits of the two calls */
+int mi355x_spmv_csr_scaled(mi355x_handle_t h, mi355x_spmv_plan_t plan, const int *ai, const int *aj, const double *aa,
+                           const double *x, const double *d, double *y);
 int mi355x_spmv_csr_add(mi355x_handle_t h, mi355x_spmv_plan_t plan, const int *ai, const int *aj,
                         const double *aa, const double *x, const double *y, double *z);
 /* MatMultTranspose[Add]_SeqAIJ  src/mat/impls/aij/seq/aij.c:1078-1135 is served by the same two

@@ -18,6 +18,7 @@
 #else
 #include "petscmini.h"
 #endif
+#include "petsckrylovfused.h"   /* fused-kernel tables the types compose ("VecKrylovFusedOps_C", "MatMultTDotBegin_C", "MatMultDiagonalScale_C") */
 #ifdef __cplusplus
 extern "C" {
 #endif

@@ -82,6 +82,7 @@ PetscErrorCode MatCreate_SeqAIJHIPMI355X(Mat B) {
   B->ops->destroy          = MatDestroy_SeqAIJHIPMI355X;
   B->ops->getvecs          = MatGetVecs_HIP;
   ierr = PetscObjectComposeFunction((PetscObject)B, "MatMultTDotBegin_C", "MatMultTDotBegin_HIPMI355X", (PetscVoidFunction)MatMultTDotBegin_HIPMI355X);CHKERRQ(ierr);
+  ierr = PetscObjectComposeFunction((PetscObject)B, "MatMultDiagonalScale_C", "MatMultDiagonalScale_HIPMI355X", (PetscVoidFunction)MatMultDiagonalScale_HIPMI355X);CHKERRQ(ierr);
   ierr = PetscObjectChangeTypeName((PetscObject)B, MATSEQAIJHIPMI355X);CHKERRQ(ierr);
   PetscFunctionReturn(0);
 }

@@ -64,6 +64,8 @@ KERNEL_API = {
     "mi355x_vec_norm": [vp, sz, i32, vp, vp],
     "mi355x_vec_dotnorm2": [vp, sz, vp, vp, vp],
     "mi355x_vec_mdot": [vp, sz, i32, vp, C.POINTER(vp), vp],
+    "mi355x_vec_maxpy_dev_norm2": [vp, sz, i32, vp, C.c_double, C.POINTER(vp), vp, vp],
+    "mi355x_vec_scale_rnorm_dev": [vp, sz, vp, vp],
     "mi355x_vec_cg_update": [vp, sz, dbl, vp, vp, vp, vp, vp, vp, vp],
     "mi355x_vec_aypx_dev": [vp, sz, vp, dbl, vp, vp],
     "mi355x_vec_pmult_dot": [vp, sz, vp, vp, vp, vp, vp],
@@ -88,6 +90,7 @@ KERNEL_API = {
     "mi355x_spmv_plan_info": [vp, pi32, pi32, C.POINTER(sz)],
     "mi355x_spmv_csr": [vp, vp, vp, vp, vp, vp, vp],
     "mi355x_spmv_csr_add": [vp, vp, vp, vp, vp, vp, vp, vp],
+    "mi355x_spmv_csr_scaled": [vp, vp, vp, vp, vp, vp, vp, vp],
     "mi355x_spmv_csr_dot": [vp, vp, vp, vp, vp, vp, vp],
     "mi355x_spmv_dot_finish": [vp, vp, vp],
     "mi355x_csr_get_diagonal": [vp, i32, vp, vp, vp, vp],

@@ -107,7 +107,14 @@ __device__ __forceinline__ double row_sum_lds(const double *prod, int rs, int re
   return sum;
 }
 
-template <bool ADD, bool CPROW, bool VEC>
+// How a row's sum reaches y.  ADD == 0: y = A x.  ADD == 1: y = yin + A x (MatMultAdd).  ADD == 2: y = yin .* (A x), yin being a
+// diagonal scaling (PCApply_Jacobi's VecPointwiseMult fused into the product: same bits as the two separate sweeps).
+template <int ADD> __device__ __forceinline__ double spmv_out(double yv, double t) { return ADD == 1 ? yv + t : (ADD == 2 ? yv * t : t); }
+template <int ADD> __device__ __forceinline__ double spmv_empty(double yv) { return ADD == 1 ? yv : (ADD == 2 ? yv * 0.0 : 0.0); }
+// same, for a sum that was started from yv when ADD == 1
+template <int ADD> __device__ __forceinline__ double spmv_fin(double yv, double s) { return ADD == 2 ? yv * s : s; }
+
+template <int ADD, bool CPROW, bool VEC>
 __global__ __launch_bounds__(SPMV_THREADS, SPMV_MINWAVES) void spmv_csr_rowblock_kernel(
     const int2 *__restrict__ rowblk, int nblocks, int chunk, const int *__restrict__ ai, const int *__restrict__ aj,
     const double *__restrict__ aa, const double *__restrict__ x, const double *yin, double *yout,
@@ -157,14 +164,14 @@ __global__ __launch_bounds__(SPMV_THREADS, SPMV_MINWAVES) void spmv_csr_rowblock
 #pragma unroll
       for (int w = 1; w < SPMV_THREADS / MI355X_WAVE; ++w) t += wsum[w];
       const int orow = CPROW ? rows[r0] : r0;
-      yout[orow] = ADD ? (yin[orow] + t) : t;
+      yout[orow] = spmv_out<ADD>(ADD ? yin[orow] : 0.0, t);
     }
     return;
   }
   if (nnz == 0) {   // only empty rows
     if (tid < nrows) {
       const int orow = CPROW ? rows[r0 + tid] : r0 + tid;
-      yout[orow] = ADD ? yin[orow] : 0.0;
+      yout[orow] = spmv_empty<ADD>(ADD ? yin[orow] : 0.0);
     }
     return;
   }
@@ -227,12 +234,12 @@ __global__ __launch_bounds__(SPMV_THREADS, SPMV_MINWAVES) void spmv_csr_rowblock
   // ---- per-row sums out of LDS -------------------------------------------
   const int rs = r < nrows ? a0 - k0 : 0, re = r < nrows ? a1 - k0 : 0;
   if (tpr == 1) {
-    if (r < nrows) yout[orow] = row_sum_lds(prod, rs, re, ADD ? ysum : 0.0, pairsum);
+    if (r < nrows) yout[orow] = spmv_fin<ADD>(ysum, row_sum_lds(prod, rs, re, ADD == 1 ? ysum : 0.0, pairsum));
   } else {
     double sum = 0.0;
     if (r < nrows) for (int k = rs + sub; k < re; k += tpr) sum += prod[k];
     for (int off = tpr >> 1; off > 0; off >>= 1) sum += __shfl_down(sum, off, MI355X_WAVE);
-    if (r < nrows && sub == 0) yout[orow] = ADD ? (ysum + sum) : sum;
+    if (r < nrows && sub == 0) yout[orow] = spmv_out<ADD>(ysum, sum);
   }
 }
 
@@ -248,7 +255,7 @@ __global__ __launch_bounds__(SPMV_THREADS, SPMV_MINWAVES) void spmv_csr_rowblock
 // boundary is loaded whole (an aligned 16-byte access cannot leave the page its first half lies in) and the element
 // outside the block is simply not written to LDS.  With no control flow between the loads the compiler keeps all of
 // them in flight behind a single s_waitcnt; the earlier predicated form serialised them pair by pair.
-template <bool ADD, bool DOT>
+template <int ADD, bool DOT>
 __global__ __launch_bounds__(SPMV_THREADS, SPMV_MINWAVES) void spmv_csr_rowblock_idx8_kernel(
     const int2 *__restrict__ rowblk, int nblocks, const int *__restrict__ ai, const unsigned char *__restrict__ idx8,
     const int *__restrict__ offtab_g, int ntab, const double *__restrict__ aa, const double *__restrict__ x,
@@ -258,7 +265,7 @@ __global__ __launch_bounds__(SPMV_THREADS, SPMV_MINWAVES) void spmv_csr_rowblock
   __shared__ int offtab[256];
   __shared__ double wsum[SPMV_THREADS / MI355X_WAVE];
   static_assert(SPMV_THREADS == 256 || SPMV_THREADS == 128 || SPMV_THREADS == 512, "the offset table is staged 256 / SPMV_THREADS entries per lane");
-  static_assert(!(DOT && ADD), "the x'y by-product is provided for y = A x only");
+  static_assert(!(DOT && ADD != 0), "the x'y by-product is provided for y = A x only");
 #if SPMV_REMAP == 2
   const int xcd = blockIdx.x % MI355X_NXCD;
   const int slot = blockIdx.x / MI355X_NXCD;
@@ -290,14 +297,14 @@ __global__ __launch_bounds__(SPMV_THREADS, SPMV_MINWAVES) void spmv_csr_rowblock
       double t = wsum[0];
 #pragma unroll
       for (int w = 1; w < SPMV_THREADS / MI355X_WAVE; ++w) t += wsum[w];
-      const double yv = ADD ? (yin[r0] + t) : t;
+      const double yv = spmv_out<ADD>(ADD ? yin[r0] : 0.0, t);
       yout[r0] = yv;
       if (DOT) dotpart[lb] = yv * x[r0];
     }
     return;
   }
   if (nnz == 0) {               // only empty rows
-    if (tid < nrows) yout[r0 + tid] = ADD ? yin[r0 + tid] : 0.0;
+    if (tid < nrows) yout[r0 + tid] = spmv_empty<ADD>(ADD ? yin[r0 + tid] : 0.0);
     if (DOT && tid == 0) dotpart[lb] = 0.0;
     return;
   }
@@ -356,7 +363,7 @@ __global__ __launch_bounds__(SPMV_THREADS, SPMV_MINWAVES) void spmv_csr_rowblock
   double yval = 0.0;             // this lane's row result (lanes without a row: 0)
   if (tpr == 1) {
     if (r < nrows) {
-      const double sum = row_sum_lds(prod, rs, re, ADD ? ysum : 0.0, pairsum);
+      const double sum = spmv_fin<ADD>(ysum, row_sum_lds(prod, rs, re, ADD == 1 ? ysum : 0.0, pairsum));
       yout[r0 + r] = sum;
       yval = sum;
     }
@@ -364,7 +371,7 @@ __global__ __launch_bounds__(SPMV_THREADS, SPMV_MINWAVES) void spmv_csr_rowblock
     double sum = 0.0;
     if (r < nrows) for (int k = rs + sub; k < re; k += tpr) sum += prod[k];
     for (int off = tpr >> 1; off > 0; off >>= 1) sum += __shfl_down(sum, off, MI355X_WAVE);
-    if (r < nrows && sub == 0) { yval = ADD ? (ysum + sum) : sum; yout[r0 + r] = yval; }
+    if (r < nrows && sub == 0) { yval = spmv_out<ADD>(ysum, sum); yout[r0 + r] = yval; }
   }
   if (DOT) {
     // x'y by-product: this block's sum of x_r y_r in a fixed order (lanes -> wavefront tree -> 4 wavefronts in order);
@@ -392,7 +399,7 @@ __global__ __launch_bounds__(SPMV_THREADS, SPMV_MINWAVES) void spmv_csr_rowblock
 // looked up as gjs[rbase[row(k)] + k] with row(k) from the LDS marker array the row-owning lanes write (a per-nonzero
 // 16-bit marker that saves one LDS level was measured 5 % slower: 0.252 against 0.239 ms on the FEM stand-in).  Row sums as in
 // the other kernels (pairsum: the inode routine's two-at-a-time order, so the result carries the reference's bits).
-template <bool ADD>
+template <int ADD>
 __global__ __launch_bounds__(SPMV_THREADS, SPMV_MINWAVES) void spmv_csr_rowblock_inode_kernel(
     const int4 *__restrict__ rowblk, int nblocks, const int *__restrict__ ai, const int *__restrict__ goff,
     const int *__restrict__ gj, const double *__restrict__ aa, const double *__restrict__ x, const double *yin, double *yout,
@@ -418,7 +425,7 @@ __global__ __launch_bounds__(SPMV_THREADS, SPMV_MINWAVES) void spmv_csr_rowblock
   const int nrows = r1 - r0;
   const int tid = threadIdx.x;
   if (nnz == 0) {               // only empty rows
-    if (tid < nrows) yout[r0 + tid] = ADD ? yin[r0 + tid] : 0.0;
+    if (tid < nrows) yout[r0 + tid] = spmv_empty<ADD>(ADD ? yin[r0 + tid] : 0.0);
     return;
   }
   int tpr = 1;
@@ -478,12 +485,12 @@ __global__ __launch_bounds__(SPMV_THREADS, SPMV_MINWAVES) void spmv_csr_rowblock
   }
   __syncthreads();
   if (tpr == 1) {
-    if (r < nrows) yout[r0 + r] = row_sum_lds(prod, rs, re, ADD ? ysum : 0.0, pairsum);
+    if (r < nrows) yout[r0 + r] = spmv_fin<ADD>(ysum, row_sum_lds(prod, rs, re, ADD == 1 ? ysum : 0.0, pairsum));
   } else {
     double sum = 0.0;
     if (r < nrows) for (int k = rs + sub; k < re; k += tpr) sum += prod[k];
     for (int off = tpr >> 1; off > 0; off >>= 1) sum += __shfl_down(sum, off, MI355X_WAVE);
-    if (r < nrows && sub == 0) yout[r0 + r] = ADD ? (ysum + sum) : sum;
+    if (r < nrows && sub == 0) yout[r0 + r] = spmv_out<ADD>(ysum, sum);
   }
 }
 
@@ -649,7 +656,7 @@ __global__ __launch_bounds__(MI355X_BLOCK) void csr_diag_kernel(int m, const int
   d[r] = v;
 }
 
-template <bool ADD>
+template <int ADD>
 static int launch_spmv(mi355x_handle_t h, mi355x_spmv_plan_t p, const int *ai, const int *aj, const double *aa,
                        const double *x, const double *yin, double *yout) {
   if (p->nblocks == 0) return 0;
@@ -894,7 +901,13 @@ int mi355x_spmv_plan_info(mi355x_spmv_plan_t p, int *nblocks, int *nlong, size_t
 
 int mi355x_spmv_csr(mi355x_handle_t h, mi355x_spmv_plan_t plan, const int *ai, const int *aj, const double *aa,
                     const double *x, double *y) {
-  return launch_spmv<false>(h, plan, ai, aj, aa, x, nullptr, y);
+  return launch_spmv<0>(h, plan, ai, aj, aa, x, nullptr, y);
+}
+
+// y = d .* (A x): MatMult followed by PCApply_Jacobi's VecPointwiseMult (jacobi.c:266) in the product's epilogue
+int mi355x_spmv_csr_scaled(mi355x_handle_t h, mi355x_spmv_plan_t plan, const int *ai, const int *aj, const double *aa,
+                           const double *x, const double *d, double *y) {
+  return launch_spmv<2>(h, plan, ai, aj, aa, x, d, y);
 }
 
 // y = A x and x'y from one pass over the matrix (KSPSolve_CG's w = A p, dpi = p'w): every row block leaves its sum of
@@ -913,7 +926,7 @@ int mi355x_spmv_csr_dot(mi355x_handle_t h, mi355x_spmv_plan_t p, const int *ai, 
 #else
   const int g8 = p->nblocks;
 #endif
-  hipLaunchKernelGGL((spmv_csr_rowblock_idx8_kernel<false, true>), dim3(g8), dim3(SPMV_THREADS), 0, h->stream, p->d_rowblk,
+  hipLaunchKernelGGL((spmv_csr_rowblock_idx8_kernel<0, true>), dim3(g8), dim3(SPMV_THREADS), 0, h->stream, p->d_rowblk,
                      p->nblocks, ai, p->d_idx8, p->d_offtab, p->ntab, aa, x, (const double *)nullptr, y, p->d_dotpart, p->pairsum);
   MI355X_LAUNCH_CHECK();
   return 0;
@@ -927,7 +940,7 @@ int mi355x_spmv_dot_finish(mi355x_handle_t h, mi355x_spmv_plan_t p, double *out)
 
 int mi355x_spmv_csr_add(mi355x_handle_t h, mi355x_spmv_plan_t plan, const int *ai, const int *aj, const double *aa,
                         const double *x, const double *y, double *z) {
-  return launch_spmv<true>(h, plan, ai, aj, aa, x, y, z);
+  return launch_spmv<1>(h, plan, ai, aj, aa, x, y, z);
 }
 
 int mi355x_spmv_bsr_planned(mi355x_handle_t h, mi355x_spmv_plan_t p, int bs, const int *ai, const int *aj,

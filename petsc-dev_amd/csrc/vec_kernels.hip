@@ -632,6 +632,88 @@ struct MDotF {
   }
 };
 
+
+// ---- fused forms for KSPGMRESCycle (gmres.c:118-209) ------------------------------------------------------------------
+// The Gram-Schmidt update x += sum_j (-h_j) y_j (VecMAXPY of borthog2.c:64 with the coefficients VecMDot has just left in
+// device memory, negated as borthog2.c:63 does) and Sum x_new^2 (the VecNorm inside gmres.c:146's VecNormalize) in ONE
+// sweep: the grouping of maxpy_elem (= petscaxpy.h:101-110) and the per-lane order of SumSqF, so x and the norm carry the
+// bits of the separate calls.  Up to 32 vectors per sweep.
+template <int G0, int NG4>
+struct MaxpyNormF {
+  static constexpr int NV = G0 + 4 * NG4;
+  const double *y[NV];
+  const double *adev;   // coefficients in device memory ...
+  double sign;          // ... times +-1
+  double *x;
+  double a[NV];
+  __device__ __forceinline__ void prologue(size_t, double (&)[1]) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) a[j] = sign * adev[j];   // (-1) * h: the bits of -h
+  }
+  template <int NOUT_>
+  __device__ __forceinline__ void sweep(size_t tid, size_t stride, size_t n2, double (&acc)[NOUT_]) const {
+    for (size_t i = tid; i < n2; i += stride) accum2(i, acc);
+  }
+  __device__ __forceinline__ void accum1(size_t i, double (&acc)[1]) const {
+    double v[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) v[j] = y[j][i];
+    const double xv = maxpy_elem<G0, NG4>(x[i], a, v);
+    x[i] = xv;
+    acc[0] += xv * xv;
+  }
+  __device__ __forceinline__ void accum2(size_t i, double (&acc)[1]) const {
+    double2 yv[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) yv[j] = reinterpret_cast<const double2 *>(y[j])[i];
+    double2 xv = reinterpret_cast<double2 *>(x)[i];
+    double lo[NV], hi[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) { lo[j] = yv[j].x; hi[j] = yv[j].y; }
+    xv.x = maxpy_elem<G0, NG4>(xv.x, a, lo);
+    xv.y = maxpy_elem<G0, NG4>(xv.y, a, hi);
+    reinterpret_cast<double2 *>(x)[i] = xv;
+    acc[0] += xv.x * xv.x;
+    acc[0] += xv.y * xv.y;
+  }
+};
+template <int G0, int NG4> struct has_prologue<MaxpyNormF<G0, NG4>> { static constexpr bool value = true; };
+
+template <int G0, int NG4>
+static int launch_maxpy_norm(mi355x_handle_t h, size_t n, const double *adev, double sign, const double *const *y, double *x, double *out) {
+  MaxpyNormF<G0, NG4> f;
+  int vec_ok = mi355x_aligned16(x);
+  for (int j = 0; j < G0 + 4 * NG4; ++j) { f.y[j] = y[j]; vec_ok = vec_ok && mi355x_aligned16(y[j]); }
+  f.adev = adev; f.sign = sign; f.x = x;
+  return launch_reduce<1, RED_SUM>(h, f, n, vec_ok, out);
+}
+
+// x *= 1/sqrt(*norm2) with the cases of VecNormalize (rvector.c:308-314: a zero norm leaves x alone, so does a norm of one)
+// and of VecScale_Seq (bvec1.c:183: alpha == 0 sets zero); sqrt and the division are IEEE-exact on the device as on the host
+__global__ __launch_bounds__(MI355X_BLOCK) void scale_rnorm_dev_kernel(const double *norm2, double *x, size_t n, int vec_ok) {
+  const double nrm = sqrt(*norm2);
+  if (nrm == 0.0 || nrm == 1.0) return;
+  const double alpha = 1.0 / nrm;
+  if (alpha == 1.0) return;
+  const size_t tid = (size_t)blockIdx.x * MI355X_BLOCK + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * MI355X_BLOCK;
+  if (vec_ok) {
+    const size_t n2 = n >> 1;
+    double2 *x2 = reinterpret_cast<double2 *>(x);
+    size_t i = tid;
+    for (; i + stride < n2; i += 2 * stride) {
+      double2 v0 = x2[i], v1 = x2[i + stride];
+      v0.x = alpha == 0.0 ? 0.0 : v0.x * alpha; v0.y = alpha == 0.0 ? 0.0 : v0.y * alpha;
+      v1.x = alpha == 0.0 ? 0.0 : v1.x * alpha; v1.y = alpha == 0.0 ? 0.0 : v1.y * alpha;
+      x2[i] = v0; x2[i + stride] = v1;
+    }
+    if (i < n2) { double2 v = x2[i]; v.x = alpha == 0.0 ? 0.0 : v.x * alpha; v.y = alpha == 0.0 ? 0.0 : v.y * alpha; x2[i] = v; }
+    if ((n & 1) && tid == 0) x[n - 1] = alpha == 0.0 ? 0.0 : x[n - 1] * alpha;
+  } else {
+    for (size_t i = tid; i < n; i += stride) x[i] = alpha == 0.0 ? 0.0 : x[i] * alpha;
+  }
+}
+
 template <int NV>
 static int launch_mdot(mi355x_handle_t h, size_t n, const double *x, const double *const *y, double *out) {
   MDotF<NV> f;
@@ -813,17 +895,58 @@ int mi355x_vec_bcgs_update(mi355x_handle_t h, size_t n, double alpha, double ome
   int v = mi355x_aligned16(p) && mi355x_aligned16(s) && mi355x_aligned16(t) && mi355x_aligned16(rp) && mi355x_aligned16(x) && mi355x_aligned16(r);
   return launch_reduce<2, RED_SUM>(h, f, n, v, out);
 }
+
+// borthog2.c:63-64 + the norm of gmres.c:146: x += sum_j sign * coef_dev[j] * y_j, *out = sum x_new^2 (out: device or the
+// handle's pinned scratch); coef_dev must not be written while this runs
+int mi355x_vec_maxpy_dev_norm2(mi355x_handle_t h, size_t n, int nv, const double *coef_dev, double sign, const double *const *y,
+                               double *x, double *out) {
+  if (nv <= 0) return mi355x_vec_norm(h, n, 2, x, out);
+  if (n == 0) return launch_reduce<1, RED_SUM>(h, SumSqF{x}, n, 1, out);
+  int pos = 0;
+  const int rem = nv & 3;
+  while (pos < nv) {
+    const int g0 = (pos == 0 && rem) ? rem : 4;
+    int ng4 = (nv - pos - g0) / 4;
+    if (ng4 > 7) ng4 = 7;
+    const int cnt = g0 + 4 * ng4;
+    const bool last = pos + cnt == nv;
+    // an earlier sweep's sum is of no use: it goes to the last device scratch slot
+    double *o = last ? out : h->dev_scratch + (MI355X_SCRATCH_DOUBLES - 1);
+    int rc = 0;
+#define MN_CASE(G, N4) case (G) * 10 + (N4): rc = launch_maxpy_norm<G, N4>(h, n, coef_dev + pos, sign, y + pos, x, o); break
+#define MN_ROW(G) MN_CASE(G, 0); MN_CASE(G, 1); MN_CASE(G, 2); MN_CASE(G, 3); MN_CASE(G, 4); MN_CASE(G, 5); MN_CASE(G, 6); MN_CASE(G, 7)
+    switch (g0 * 10 + ng4) {
+      MN_ROW(1); MN_ROW(2); MN_ROW(3); MN_ROW(4);
+      default: return (int)hipErrorInvalidValue;
+    }
+#undef MN_ROW
+#undef MN_CASE
+    if (rc) return rc;
+    pos += cnt;
+  }
+  return 0;
+}
+int mi355x_vec_scale_rnorm_dev(mi355x_handle_t h, size_t n, const double *norm2_dev, double *x) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(scale_rnorm_dev_kernel, dim3(mi355x_grid_for(n, 4)), dim3(MI355X_BLOCK), 0, h->stream, norm2_dev, x, n, mi355x_aligned16(x));
+  MI355X_LAUNCH_CHECK();
+  return 0;
+}
 int mi355x_vec_mdot(mi355x_handle_t h, size_t n, int nv, const double *x, const double *const *y, double *out) {
   int pos = 0;
-  while (pos < nv) {   // up to 16 vectors per pass over x
+  static int width = 0;   // vectors per pass over x: MI355X_MDOT_WIDTH (16 or 32)
+  if (!width) { const char *e = getenv("MI355X_MDOT_WIDTH"); width = (e && atoi(e) == 32) ? 32 : 16; }
+  while (pos < nv) {
     int left = nv - pos;
-    int cnt = left > 16 ? 16 : left;
-    if (left > 16 && left < 24) cnt = (left + 1) / 2;   // two passes of similar width instead of 16 + a few
+    int cnt = left > width ? width : left;
+    if (width == 16 && left > 16 && left < 24) cnt = (left + 1) / 2;   // two passes of similar width instead of 16 + a few
     int rc;
     switch (cnt) {
 #define MDOT_CASE(N) case N: rc = launch_mdot<N>(h, n, x, y + pos, out + pos); break
       MDOT_CASE(1); MDOT_CASE(2); MDOT_CASE(3); MDOT_CASE(4); MDOT_CASE(5); MDOT_CASE(6); MDOT_CASE(7); MDOT_CASE(8);
       MDOT_CASE(9); MDOT_CASE(10); MDOT_CASE(11); MDOT_CASE(12); MDOT_CASE(13); MDOT_CASE(14); MDOT_CASE(15); MDOT_CASE(16);
+      MDOT_CASE(17); MDOT_CASE(18); MDOT_CASE(19); MDOT_CASE(20); MDOT_CASE(21); MDOT_CASE(22); MDOT_CASE(23); MDOT_CASE(24);
+      MDOT_CASE(25); MDOT_CASE(26); MDOT_CASE(27); MDOT_CASE(28); MDOT_CASE(29); MDOT_CASE(30); MDOT_CASE(31); MDOT_CASE(32);
 #undef MDOT_CASE
       default: return (int)hipErrorInvalidValue;
     }

@@ -20,6 +20,13 @@ static const VecKrylovFusedOps *fused_ops(Vec x) {
   if (PetscObjectQueryFunction((PetscObject)x, "VecKrylovFusedOps_C", &f) || !f) return NULL;
   return ((VecKrylovFusedOpsGetFn)f)();
 }
+static PetscErrorCode mat_mult_diagonal_scale(Mat A, Vec d, Vec x, Vec y, PetscBool *ok) {
+  PetscVoidFunction f = NULL;
+  *ok = PETSC_FALSE;
+  PetscErrorCode ierr = PetscObjectQueryFunction((PetscObject)A, "MatMultDiagonalScale_C", &f);CHKERRQ(ierr);
+  if (f) { ierr = ((MatMultDiagonalScaleFn)f)(A, d, x, y, ok);CHKERRQ(ierr); }
+  return 0;
+}
 static PetscErrorCode mat_mult_tdot_begin(Mat A, Vec x, Vec y, PetscBool *ok) {
   PetscVoidFunction f = NULL;
   *ok = PETSC_FALSE;
@@ -329,6 +336,7 @@ typedef struct {
   Vec *vecs;      /* [0]=TEMP, [1]=TEMP_MATOP, [2+k]=VV(k) */
   PetscInt nvecs;
   PetscInt it;
+  PetscBool fused;   /* -ksp_gmres_fused: use the types' fused kernels when they have them (not a reference option) */
 } KSP_GMRES;
 #define GM ((KSP_GMRES *)ksp->data)
 #define HH(a, b) (g->hh + (size_t)(b) * (size_t)(g->max_k + 2) + (a))      /* gmresimpl.h */
@@ -360,6 +368,8 @@ static PetscErrorCode KSPSetFromOptions_GMRES(KSP ksp) {
     else if (!strcmp(t, "refine_never")) GM->cgstype = KSP_GMRES_CGS_REFINE_NEVER;
     else SETERRQ(ksp->comm, PETSC_ERR_ARG_UNKNOWN_TYPE, "Unknown refinement type %s", t);
   }
+  ierr = PetscOptionsGetString(ksp->prefix, "-ksp_gmres_fused", t, sizeof(t), &set);CHKERRQ(ierr);
+  if (set) GM->fused = (PetscBool)(strcmp(t, "0") && strcmp(t, "false"));
   return 0;
 }
 
@@ -467,7 +477,11 @@ static PetscErrorCode gmres_cycle(PetscInt *itcount, KSP ksp) {
   KSP_GMRES *g = GM;
   PetscReal res_norm, res, hapbnd, tt;
   PetscInt it = 0, max_k = g->max_k;
-  PetscBool hapend = PETSC_FALSE;
+  PetscBool hapend = PETSC_FALSE, done;
+  const VecKrylovFusedOps *F = g->fused ? fused_ops(VEC_VV(0)) : NULL;
+  Vec Dj = NULL;
+  if (F && !F->gmres_orthog_normalize) F = NULL;
+  if (g->fused && ksp->pc_side == PC_LEFT) { ierr = PCJacobiGetInverseDiagonal_Private(ksp->pc, &Dj);CHKERRQ(ierr); }
 
   ierr = VecNormalize(VEC_VV(0), &res_norm);CHKERRQ(ierr);
   res = res_norm;
@@ -481,9 +495,21 @@ static PetscErrorCode gmres_cycle(PetscInt *itcount, KSP ksp) {
   while (!ksp->reason && it < max_k && ksp->its < ksp->max_it) {
     if (it) { KSPLogResidualHistory(ksp, res); ierr = KSPMonitor(ksp, ksp->its, res);CHKERRQ(ierr); }
     g->it = it - 1;
-    ierr = KSP_PCApplyBAorAB(ksp, VEC_VV(it), VEC_VV(1 + it), VEC_TEMP_MATOP);CHKERRQ(ierr);
-    ierr = gmres_orthog(ksp, it);CHKERRQ(ierr);                    /* update hessenberg matrix and do Gram-Schmidt */
-    ierr = VecNormalize(VEC_VV(it + 1), &tt);CHKERRQ(ierr);       /* vv(i+1) . vv(i+1) */
+    /* -ksp_gmres_fused (default on; 0: the reference's op-by-op sequence).  Left PCJACOBI: the product and the diagonal scaling
+     * in one kernel; no refinement: MDot, MAXPY + norm, scale with the scalars on the device and one host wait.  Same bits. */
+    done = PETSC_FALSE;
+    if (Dj) { ierr = mat_mult_diagonal_scale(ksp->pc->mat, Dj, VEC_VV(it), VEC_VV(1 + it), &done);CHKERRQ(ierr); }
+    if (!done) { ierr = KSP_PCApplyBAorAB(ksp, VEC_VV(it), VEC_VV(1 + it), VEC_TEMP_MATOP);CHKERRQ(ierr); }
+    done = PETSC_FALSE;
+    if (F && g->cgstype == KSP_GMRES_CGS_REFINE_NEVER) {
+      PetscScalar *hh = HH(0, it), *hes = HES(0, it), *lhh = g->lhh;
+      ierr = F->gmres_orthog_normalize(VEC_VV(it + 1), it + 1, &VEC_VV(0), lhh, &tt, &done);CHKERRQ(ierr);
+      if (done) for (PetscInt j = 0; j <= it; j++) { hh[j] = 0.0; hes[j] = 0.0; lhh[j] = -lhh[j]; hh[j] -= lhh[j]; hes[j] -= lhh[j]; }   /* borthog2.c:52-66 */
+    }
+    if (!done) {
+      ierr = gmres_orthog(ksp, it);CHKERRQ(ierr);                  /* update hessenberg matrix and do Gram-Schmidt */
+      ierr = VecNormalize(VEC_VV(it + 1), &tt);CHKERRQ(ierr);     /* vv(i+1) . vv(i+1) */
+    }
     *HH(it + 1, it) = tt;
     *HES(it + 1, it) = tt;
     hapbnd = PetscAbsScalar(tt / g->grs[it]);                      /* happy breakdown test */
@@ -536,7 +562,7 @@ PetscErrorCode KSPCreate_GMRES(KSP ksp) {   /* gmres.c KSPCreate_GMRES: restart 
   KSP_GMRES *g;
   PetscErrorCode ierr = PetscMalloc(sizeof(*g), &g);CHKERRQ(ierr);
   memset(g, 0, sizeof(*g));
-  g->max_k = 30; g->haptol = 1.0e-30; g->cgstype = KSP_GMRES_CGS_REFINE_NEVER;
+  g->max_k = 30; g->haptol = 1.0e-30; g->cgstype = KSP_GMRES_CGS_REFINE_NEVER; g->fused = PETSC_TRUE;
   ksp->data = g;
   ksp->ops->setup = KSPSetUp_GMRES; ksp->ops->solve = KSPSolve_GMRES; ksp->ops->destroy = KSPDestroy_GMRES;
   ksp->ops->setfromoptions = KSPSetFromOptions_GMRES;

@@ -194,22 +194,6 @@ PetscErrorCode PCCreate_None(PC), PCCreate_Jacobi(PC), PCCreate_BJacobi(PC);
 PetscBool PCIsNone_Private(PC pc);
 PetscErrorCode PCJacobiGetInverseDiagonal_Private(PC pc, Vec *d);   /* NULL unless pc is a set-up PCJACOBI */
 
-/* ---- optional, type-specific methods the drivers look up by name (PetscObjectQueryFunction), never link against ----
- * "VecKrylovFusedOps_C" on a Vec returns a table of fused Krylov kernels (several BLAS-1 calls of KSPSolve_CG / _BCGS in
- * one sweep, results bit-identical to the separate calls); absent -> the drivers run the reference's op-by-op sequence.
- * "MatMultTDotBegin_C" on a Mat: y = A x with x'y left on the device for the fused CG update. */
-typedef struct {
-  PetscErrorCode (*cg_update)(Vec x, Vec r, Vec z, Vec p, Vec w, Vec d, PetscScalar a, PetscScalar *zz, PetscScalar *zr, PetscScalar *rr, PetscBool *done);
-  PetscErrorCode (*cg_update_check)(Vec x, Vec r, Vec z, Vec p, Vec w, Vec d, PetscBool *ok);
-  PetscErrorCode (*tdot_begin)(Vec x, Vec y, PetscBool *ok);
-  PetscErrorCode (*cg_update_dev_begin)(Vec x, Vec r, Vec z, Vec p, Vec w, Vec d, PetscScalar beta, PetscScalar dpiold, PetscBool check_sign);
-  PetscErrorCode (*cg_update_dev_end)(Vec x, PetscScalar *zz, PetscScalar *zr, PetscScalar *rr, PetscScalar *dpi);
-  PetscErrorCode (*aypx_dev)(Vec p, PetscScalar den, Vec z);
-  PetscErrorCode (*pmult_dot)(Vec w, Vec x, Vec d, Vec y, PetscScalar *val, PetscBool *done);
-  PetscErrorCode (*pmult_dotnorm2)(Vec w, Vec x, Vec d, Vec s, PetscScalar *dp, PetscReal *nm, PetscBool *done);
-  PetscErrorCode (*bcgs_update)(Vec x, Vec r, Vec p, Vec s, Vec t, Vec rp, PetscScalar alpha, PetscScalar omega, PetscScalar *rr, PetscScalar *rho, PetscBool *done);
-} VecKrylovFusedOps;
-typedef const VecKrylovFusedOps *(*VecKrylovFusedOpsGetFn)(void);
-typedef PetscErrorCode (*MatMultTDotBeginFn)(Mat A, Vec x, Vec y, PetscBool *ok);
+#include "petsckrylovfused.h"   /* the optional fused-kernel tables a Vec / Mat type may compose */
 
 #endif

@@ -526,6 +526,31 @@ PetscErrorCode MatMultTDotBegin_HIPMI355X(Mat A, Vec xx, Vec yy, PetscBool *ok) 
   return 0;
 }
 
+/* "MatMultDiagonalScale_C": y = d .* (A x), i.e. MatMult followed by PCApply_Jacobi's VecPointwiseMult(y, w, d) (jacobi.c:266)
+ * with the scaling in the product's epilogue: the intermediate vector is neither written nor read.  Same bits as the two calls. */
+PetscErrorCode MatMultDiagonalScale_HIPMI355X(Mat A, Vec dd, Vec xx, Vec yy, PetscBool *ok) {
+  PetscErrorCode ierr;
+  *ok = PETSC_FALSE;
+  if (!A || A->ops->mult != MatMult_SeqAIJHIP) return 0;
+  HipAIJ *a = SA(A); Mat_SeqAIJHIP *d = SD(A);
+  const PetscScalar *x, *dg; PetscScalar *y; PetscDeviceCtx *dc;
+  if (a->bs > 1 || xx == yy || dd == yy || xx->map->n != a->n || yy->map->n != a->m || dd->map->n != a->m) return 0;
+  ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
+  ierr = MatSeqAIJHIPUpload(A);CHKERRQ(ierr);
+  if (!d->plan || d->cprow) return 0;
+  ierr = VecHIPGetRead(xx, &x);CHKERRQ(ierr);
+  ierr = VecHIPGetRead(dd, &dg);CHKERRQ(ierr);
+  ierr = VecHIPGetWrite(yy, &y);CHKERRQ(ierr);
+  ierr = MatTimingBegin(A, dc->h);CHKERRQ(ierr);
+  CHKHIP(mi355x_spmv_csr_scaled(dc->h, d->plan, d->d_i, d->d_j, d->d_a, x, dg, y));
+  ierr = MatTimingEnd(A, dc->h);CHKERRQ(ierr);
+  ierr = VecHIPRestoreWrite(yy);CHKERRQ(ierr);
+  HipStateIncrease(yy);
+  ierr = PetscLogFlops(2.0 * a->nz - a->nonzerorows + a->m);CHKERRQ(ierr);
+  *ok = PETSC_TRUE;
+  return 0;
+}
+
 static PetscErrorCode MatMultAdd_SeqAIJHIP(Mat A, Vec xx, Vec yy, Vec zz) {   /* MatMultAdd_SeqAIJCUSP aijcusp.cu:405 */
   PetscErrorCode ierr;
   HipAIJ *a = SA(A); Mat_SeqAIJHIP *d = SD(A);
@@ -744,6 +769,7 @@ static PetscErrorCode create_common(Mat B, const char *tname, PetscInt bs) {
   B->ops->getvecs = MatGetVecs_HIP;
   ierr = PetscObjectComposeFunction((PetscObject)B, "MatSeqAIJGetArrays_C", "MatSeqAIJGetArrays", (PetscVoidFunction)MatSeqAIJGetArrays);CHKERRQ(ierr);
   ierr = PetscObjectComposeFunction((PetscObject)B, "MatMultTDotBegin_C", "MatMultTDotBegin_HIPMI355X", (PetscVoidFunction)MatMultTDotBegin_HIPMI355X);CHKERRQ(ierr);
+  ierr = PetscObjectComposeFunction((PetscObject)B, "MatMultDiagonalScale_C", "MatMultDiagonalScale_HIPMI355X", (PetscVoidFunction)MatMultDiagonalScale_HIPMI355X);CHKERRQ(ierr);
   if (bs == 1) {
     ierr = PetscObjectComposeFunction((PetscObject)B, "MatSeqAIJSetPreallocation_C", "MatSeqAIJSetPreallocation_SeqAIJHIP", (PetscVoidFunction)MatSeqAIJSetPreallocation_SeqAIJHIP);CHKERRQ(ierr);
     ierr = PetscObjectComposeFunction((PetscObject)B, "MatSeqAIJSetPreallocationCSR_C", "MatSeqAIJSetPreallocationCSR_SeqAIJHIP", (PetscVoidFunction)MatSeqAIJSetPreallocationCSR_SeqAIJHIP);CHKERRQ(ierr);

@@ -68,6 +68,7 @@ PetscErrorCode VecHIPGetReadWrite(Vec v, PetscScalar **d);
 PetscErrorCode VecHIPRestoreWrite(Vec v);                    /* device newer; state++ */
 #define PETSC_HIP_DPI_SLOT 8   /* device scratch slot holding p'w between the dot (or the SpMV by-product) and the CG update */
 PetscErrorCode MatMultTDotBegin_HIPMI355X(Mat A, Vec x, Vec y, PetscBool *ok);   /* y = A x, x'y left on the device */
+PetscErrorCode MatMultDiagonalScale_HIPMI355X(Mat A, Vec d, Vec x, Vec y, PetscBool *ok);   /* y = d .* (A x) */
 
 /* ---- VecScatter (VecScatter_MPI_General, include/petsc-private/vecimpl.h:509-555) ---- */
 typedef struct {

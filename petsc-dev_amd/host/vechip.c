@@ -671,11 +671,40 @@ static PetscErrorCode VecShareArrayEnd_HIP(Vec sub, Vec parent, PetscBool write)
   if (write) return VecHIPRestoreWrite(parent);
   return 0;
 }
+/* KSPGMRESClassicalGramSchmidtOrthogonalization without refinement (borthog2.c:60-66) followed by gmres.c:146's VecNormalize,
+ * with the scalars staying on the device: VecMDot leaves <w, V_j> in device scratch (all-reduced there over RCCL when the
+ * communicator has one), one sweep does w -= sum_j h_j V_j AND sum w^2 (mi355x_vec_maxpy_dev_norm2: VecMAXPY's grouping, VecNorm's
+ * order), a tiny kernel hands h and |w|^2 to the host, and w *= 1/|w| reads |w|^2 from device memory while the host already
+ * has its numbers.  One host wait per Krylov step instead of three; 2 nv + 5 vector passes instead of 2 nv + 6. */
+PetscErrorCode VecGMRESOrthogNormalize_HIPMI355X(Vec w, PetscInt nv, const Vec V[], PetscScalar *dots, PetscReal *nrm, PetscBool *done) {
+  PetscErrorCode ierr; const double *tab[32]; PetscScalar *dw; double *ds; DEVCTX;
+  *done = PETSC_FALSE;
+  if (!is_hip(w) || nv < 1 || nv > 32 || HOST_STAGED(w)) return 0;
+  for (PetscInt j = 0; j < nv; j++) if (!is_hip(V[j]) || V[j] == w || V[j]->map->n != w->map->n) return 0;
+  for (PetscInt j = 0; j < nv; j++) { ierr = VecHIPGetRead(V[j], &tab[j]);CHKERRQ(ierr); }
+  ierr = VecHIPGetReadWrite(w, &dw);CHKERRQ(ierr);
+  ds = mi355x_handle_device_scratch(dc->h);
+  CHKHIP(mi355x_vec_mdot(dc->h, N_(w), (int)nv, dw, tab, ds));
+  if (DEVICE_COLLECTIVES(w)) CHKHIP(mi355x_comm_allreduce_sum(HipCommDevice(HipObjComm(w)), dc->h, ds, (size_t)nv));
+  CHKHIP(mi355x_vec_maxpy_dev_norm2(dc->h, N_(w), (int)nv, ds, -1.0, tab, dw, ds + nv));
+  if (DEVICE_COLLECTIVES(w)) CHKHIP(mi355x_comm_allreduce_sum(HipCommDevice(HipObjComm(w)), dc->h, ds + nv, 1));
+  CHKHIP(mi355x_handle_publish(dc->h, ds, (int)nv + 1));
+  CHKHIP(mi355x_vec_scale_rnorm_dev(dc->h, N_(w), ds + nv, dw));
+  VecHIPRestoreWrite(w);
+  HipStateIncrease(w);
+  CHKHIP(mi355x_handle_wait_result(dc->h));
+  const double *hs = mi355x_handle_host_scratch(dc->h);
+  for (PetscInt j = 0; j < nv; j++) dots[j] = hs[j];
+  *nrm = PetscSqrtReal(hs[nv]);                                 /* pvec2.c:62-64: the square is reduced, then the root */
+  ierr = PetscLogFlops(PetscMax(nv * (2.0 * w->map->n - 1), 0.0) + 2.0 * nv * w->map->n + PetscMax(2.0 * w->map->n - 1, 0.0) + w->map->n);CHKERRQ(ierr);
+  *done = PETSC_TRUE;
+  return 0;
+}
 /* "VecKrylovFusedOps_C": the fused sweeps of KSPSolve_CG / KSPSolve_BCGS, bit-identical to the calls they replace */
 static const VecKrylovFusedOps *VecKrylovFusedOps_HIP(void) {
   static const VecKrylovFusedOps ops = {
     VecCGUpdate_HIPMI355X, VecCGUpdateCheck_HIPMI355X, VecTDotBegin_HIPMI355X, VecCGUpdateDevBegin_HIPMI355X, VecCGUpdateDevEnd_HIPMI355X,
-    VecAYPXDev_HIPMI355X, VecPMultDot_HIPMI355X, VecPMultDotNorm2_HIPMI355X, VecBCGSUpdate_HIPMI355X};
+    VecAYPXDev_HIPMI355X, VecPMultDot_HIPMI355X, VecPMultDotNorm2_HIPMI355X, VecBCGSUpdate_HIPMI355X, VecGMRESOrthogNormalize_HIPMI355X};
   return &ops;
 }
 /* "VecSplitReductionOps_C": VecDotBegin/End, VecNormBegin/End, PetscCommSplitReductionBegin (comb.c:402-721) with the

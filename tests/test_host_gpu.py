@@ -242,6 +242,26 @@ def test_baij_matmult(P, bs, opt):
     assert np.allclose(vy.array(), ref, rtol=0, atol=1e-12 * 50)
 
 
+@pytest.mark.parametrize("pc,opts", [("jacobi", ""), ("none", ""), ("ilu", ""), ("jacobi", "-ksp_gmres_restart 7"), ("jacobi", "-ksp_gmres_restart 40"),
+                                     ("jacobi", "-ksp_pc_side right"), ("jacobi", "-ksp_gmres_cgs_refinement_type refine_always")])
+def test_gmres_fused_equals_op_by_op_bit_for_bit(P, pc, opts):
+    """-ksp_gmres_fused (default): SpMV with PCJACOBI's scaling in its epilogue, MDot -> MAXPY + norm -> scale with the
+    scalars on the device.  Every residual norm and the solution carry the bits of the reference's op-by-op sequence
+    (-ksp_gmres_fused 0), for restarts below / above the 32-vector sweep, other PCs, right preconditioning, refinement."""
+    ai, aj, aa = orc.gen_p7(14, 12, 10)
+    aa = aa * (1.0 + 0.2 * np.sin(np.arange(aa.size)))          # nonsymmetric values
+    n = ai.size - 1
+    b = np.cos(0.37 * np.arange(n))
+    x1, h1, it1, r1 = solve(P, ai, aj, aa, b, "gmres", pc, opts=opts, rtol=1e-11)
+    x0, h0, it0, r0 = solve(P, ai, aj, aa, b, "gmres", pc, opts=opts + " -ksp_gmres_fused 0", rtol=1e-11)
+    assert (it1, r1) == (it0, r0) and r1 > 0 and it1 > 8
+    assert np.array_equal(h1.view(np.uint64), h0.view(np.uint64))
+    assert np.array_equal(x1.view(np.uint64), x0.view(np.uint64))
+    if pc == "jacobi" and not opts:                                # and both are the oracle's walk
+        xo, ho, ito, ro = orc.ksp_solve(ai, aj, aa, b, ksp="gmres", pc="jacobi", rtol=1e-11)
+        assert ito == it1 and np.array_equal(ho.view(np.uint64), h1.view(np.uint64))
+
+
 @pytest.mark.parametrize("bs", [2, 3, 4, 5])
 def test_pbjacobi_on_baij(P, bs):
     """PCPBJACOBI on the BAIJ type (pbjacobi.c + MatInvertBlockDiagonal_SeqBAIJ baij.c:13): PCApply equals the

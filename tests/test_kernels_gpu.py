@@ -119,6 +119,57 @@ def test_maxpy_bitexact(dev, n, nv):
         dev.free(p)
 
 
+@pytest.mark.parametrize("n", [1, 2, 255, 4097, 70001, 1 << 20])
+@pytest.mark.parametrize("nv", [1, 2, 3, 4, 5, 8, 15, 16, 17, 29, 30, 31, 32])
+def test_gmres_fused_sweeps_carry_the_bits_of_the_separate_calls(dev, n, nv):
+    """mi355x_vec_maxpy_dev_norm2 == VecMAXPY (coefficients negated as borthog2.c:63) + VecNorm's sum of squares;
+    mi355x_vec_scale_rnorm_dev == VecNormalize's VecScale(1/norm) (rvector.c:308-314)"""
+    if n > 70001 and nv not in (3, 17, 30):
+        pytest.skip("large size covered for nv = 3, 17, 30")
+    k = dev.k
+    x = rnd(n, 10)
+    ys = [rnd(n, 100 + j) for j in range(nv)]
+    h = rnd(nv, 11)
+    dx, dx2 = dev.put(x), dev.put(x)
+    dys = [dev.put(v) for v in ys]
+    tab = dev.ptr_table(dys)
+    dh = dev.put(h)
+    out = dev.alloc(16)
+    # separate calls: host coefficients -h, then the norm
+    mh = -h
+    dev.chk(k.mi355x_vec_maxpy(dev.h, n, nv, mh.ctypes.data_as(C.POINTER(C.c_double)), tab, dx))
+    dev.chk(k.mi355x_vec_norm(dev.h, n, 2, dx, dev.host_scratch()))
+    ref_n2 = dev.scalar_out()[0]
+    ref_x = dev.get(dx, n)
+    # fused
+    dev.chk(k.mi355x_vec_maxpy_dev_norm2(dev.h, n, nv, dh, -1.0, tab, dx2, out))
+    dev.sync()
+    got_n2 = dev.get(out, 1)
+    assert_bitexact(dev.get(dx2, n), ref_x)
+    assert_bitexact(got_n2, np.array([ref_n2]))
+    dev.chk(k.mi355x_vec_scale_rnorm_dev(dev.h, n, out, dx2))
+    dev.sync()
+    assert_bitexact(dev.get(dx2, n), ref_x * (1.0 / np.sqrt(ref_n2)))
+    for p in [dx, dx2, dh, out] + dys:
+        dev.free(p)
+
+
+def test_scale_rnorm_dev_special_cases(dev):
+    """a zero norm and a norm of exactly one leave the vector alone (rvector.c:309-311)"""
+    k = dev.k
+    x = rnd(1001, 5)
+    dx = dev.put(x)
+    for n2 in (0.0, 1.0):
+        dn = dev.put(np.array([n2]))
+        dev.chk(k.mi355x_vec_scale_rnorm_dev(dev.h, x.size, dn, dx)); dev.sync()
+        assert_bitexact(dev.get(dx, x.size), x)
+        dev.free(dn)
+    dn = dev.put(np.array([4.0]))
+    dev.chk(k.mi355x_vec_scale_rnorm_dev(dev.h, x.size, dn, dx)); dev.sync()
+    assert_bitexact(dev.get(dx, x.size), x * 0.5)
+    dev.free(dn); dev.free(dx)
+
+
 @pytest.mark.parametrize("n", SIZES)
 def test_reductions(dev, n):
     k = dev.k
@@ -203,7 +254,7 @@ def random_csr(m, n, rowlen, seed, sort=True):
     return ai, aj, aa
 
 
-def run_spmv(dev, ai, aj, aa, x, y0=None, rows=None, compress=False, group=False, pairsum=None):
+def run_spmv(dev, ai, aj, aa, x, y0=None, rows=None, compress=False, group=False, pairsum=None, dscale=None):
     k = dev.k
     dai, daj, daa = upload_csr(dev, ai, aj, aa)
     dx = dev.put(x)
@@ -222,7 +273,13 @@ def run_spmv(dev, ai, aj, aa, x, y0=None, rows=None, compress=False, group=False
         nt = C.c_int()
         k.mi355x_spmv_plan_is_compressed(plan, C.byref(nt))
         run_spmv.last_ntab = nt.value
-    if y0 is None:
+    if dscale is not None:                                       # y = d .* (A x) in the product's epilogue
+        m_out = ai.size - 1
+        dy = dev.put(np.full(m_out, 7.0))
+        dd = dev.put(dscale)
+        dev.chk(k.mi355x_spmv_csr_scaled(dev.h, plan, dai, daj, daa, dx, dd, dy))
+        dev.sync(); dev.free(dd)
+    elif y0 is None:
         m_out = ai.size - 1
         dy = dev.put(np.full(m_out, 7.0))
         dev.chk(k.mi355x_spmv_csr(dev.h, plan, dai, daj, daa, dx, dy))
@@ -417,6 +474,32 @@ def test_spmv_grouped_rows(dev, shape):
     if exact:   # the ungrouped kernels with pair summation: same bits (index-compressed / compressed-row plans of such matrices)
         assert_bitexact(run_spmv(dev, ai, aj, aa, x, pairsum=1), orc.spmv_inode(ai, aj, aa, x))
         assert_bitexact(run_spmv(dev, ai, aj, aa, x, y0=y0, pairsum=1), orc.matmult(ai, aj, aa, x, y0)[0])
+
+
+@pytest.mark.parametrize("shape", ["stencil", "irregular", "groups16", "fem3", "longrow", "emptyrows"])
+def test_spmv_with_diagonal_scaling_epilogue(dev, shape):
+    """mi355x_spmv_csr_scaled: y = d .* (A x) is the product followed by PCApply_Jacobi's VecPointwiseMult (jacobi.c:266),
+    bit for bit, in every SpMV kernel (plain, index-compressed, grouped rows, long row, rows without entries)"""
+    import problems as pb
+    kw = {}
+    if shape == "stencil":
+        ai, aj, aa = orc.gen_p7(13, 11, 9); kw = dict(compress=True)
+    elif shape == "irregular":
+        ai, aj, aa = random_csr(3000, 3000, lambda rng, m: rng.integers(0, 40, m), 81)
+    elif shape == "groups16":
+        ai, aj, aa = grouped_csr(6000, 3000, 71, maxlen=16); kw = dict(group=True, pairsum=1)
+    elif shape == "fem3":
+        ai, aj, aa = pb.gen_fem3(10, 9, 6); kw = dict(group=True, pairsum=1)
+    elif shape == "longrow":
+        ai, aj, aa = random_csr(40, 9000, lambda rng, m: np.where(np.arange(m) == 7, 6000, rng.integers(0, 9, m)), 82)
+    else:
+        ai, aj, aa = random_csr(2000, 2000, lambda rng, m: np.where(rng.random(m) < 0.7, 0, rng.integers(1, 9, m)), 83)
+    m = ai.size - 1
+    ncols = int(aj.max()) + 1 if aj.size else 1
+    x = rnd(max(ncols, m), 84)
+    d = rnd(m, 85)
+    plain = run_spmv(dev, ai, aj, aa, x, **kw)
+    assert_bitexact(run_spmv(dev, ai, aj, aa, x, dscale=d, **kw), plain * d)
 
 
 def test_spmv_grouping_declines_when_it_would_not_pay(dev):
