@@ -11,6 +11,7 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 120
     extra = sys.argv[3] if len(sys.argv) > 3 else ""
+    only = sys.argv[4].split(",") if len(sys.argv) > 4 else None      # e.g. gmres:jacobi,cg:none
     import petsc_dev_amd as pda
     from petsc_dev_amd import petsc as P
     L = P.lib()
@@ -22,6 +23,8 @@ def main():
     b, x = u.duplicate(), u.duplicate()
     A.mult(u, b)
     for ksp_t, pc_t in (("cg", "jacobi"), ("groppcg", "jacobi"), ("gmres", "jacobi"), ("bcgs", "jacobi"), ("cg", "none"), ("gmres", "none")):
+        if only and ("%s:%s" % (ksp_t, pc_t)) not in only:
+            continue
         ksp = P.KSP(comm=L.COMM_SELF)
         ksp.set_operators(A)
         L.PetscOptionsClear()
