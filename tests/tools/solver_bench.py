@@ -30,7 +30,7 @@ def main():
         L.PetscOptionsClear()
         L.PetscOptionsInsertString(("-ksp_type %s -pc_type %s %s" % (ksp_t, pc_t, extra)).encode())
         ksp.set_from_options()
-        ksp.set_tolerances(rtol=0.0, abstol=1e-300, dtol=1e300, max_it=10)
+        ksp.set_tolerances(rtol=0.0, abstol=1e-300, dtol=1e300, max_it=40)
         L.VecSet(x.h, 0.0); ksp.solve(b, x)
         ksp.set_tolerances(rtol=0.0, abstol=1e-300, dtol=1e300, max_it=steps)
         L.VecSet(x.h, 0.0)
