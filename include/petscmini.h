@@ -97,6 +97,7 @@ typedef const char *PCType;
 #define KSPGMRES   "gmres"
 #define KSPBCGS    "bcgs"
 #define KSPPREONLY "preonly"
+#define KSPPIPECG  "pipecg"    /* pipelined CG (src/ksp/ksp/impls/cg/pipecg/pipecg.c), SURVEY 8f.4 */
 #define KSPGROPPCG "groppcg"   /* Gropp's overlapped CG (src/ksp/ksp/impls/cg/groppcg/groppcg.c), SURVEY 8f.4 */
 #define PCNONE     "none"
 #define PCJACOBI   "jacobi"

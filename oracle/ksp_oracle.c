@@ -333,6 +333,60 @@ static void solve_cg(solver *s, const double *B, double *X) {
   free(R);
 }
 
+/* ---- KSPSolve_PIPECG, src/ksp/ksp/impls/cg/pipecg/pipecg.c:49-205 (split-phase reductions are immediate here); the branch
+ * structure of its reductions is kept as it is: gamma is refreshed every iteration only with the natural norm or none ---- */
+static void solve_pipecg(solver *sv, const double *B, double *X) {
+  size_t n = (size_t)sv->n;
+  const int nt = sv->norm_type;
+  double *M = (double *)malloc(9 * n * sizeof(double)), *Z = M + n, *P = Z + n, *N = P + n, *W = N + n, *Q = W + n, *U = Q + n, *R = U + n, *S = R + n;
+  double alpha = 0.0, beta = 0.0, gamma = 0.0, gammaold = 0.0, delta = 0.0, dp = 0.0;
+  int i;
+  sv->its = 0;
+  if (sv->guess_nonzero) { mat_mult(sv, X, R); orc_vec_aypx(n, -1.0, B, R); }
+  else orc_vec_copy(n, B, R);
+  pc_apply(sv, R, U);
+  if (nt == 1) { orc_vec_norm(n, 1, U, &dp); mat_mult(sv, U, W); }
+  else if (nt == 2) { orc_vec_norm(n, 1, R, &dp); mat_mult(sv, U, W); }
+  else if (nt == 3) { gamma = orc_vec_dot(n, R, U); mat_mult(sv, U, W); dp = sqrt(fabs(gamma)); }
+  else { mat_mult(sv, U, W); dp = 0.0; }
+  monitor(sv, dp);
+  converged(sv, 0, dp, B);
+  if (sv->reason) { free(M); return; }
+  i = 0;
+  do {
+    if (i > 0 && nt == 2) orc_vec_norm(n, 1, R, &dp);
+    else if (i > 0 && nt == 1) orc_vec_norm(n, 1, U, &dp);
+    else if (!(i == 0 && nt == 3)) gamma = orc_vec_dot(n, R, U);
+    delta = orc_vec_dot(n, W, U);
+    pc_apply(sv, W, M);
+    mat_mult(sv, M, N);
+    if (i > 0) {
+      if (nt == 3) dp = sqrt(fabs(gamma));
+      else if (nt == 0) dp = 0.0;
+      monitor(sv, dp);
+      converged(sv, i, dp, B);
+      if (sv->reason) break;
+    }
+    if (i == 0) {
+      alpha = gamma / delta;
+      orc_vec_copy(n, N, Z); orc_vec_copy(n, M, Q); orc_vec_copy(n, U, P); orc_vec_copy(n, W, S);
+    } else {
+      beta = gamma / gammaold;
+      alpha = gamma / (delta - beta / alpha * gamma);
+      orc_vec_aypx(n, beta, N, Z); orc_vec_aypx(n, beta, M, Q); orc_vec_aypx(n, beta, U, P); orc_vec_aypx(n, beta, W, S);
+    }
+    orc_vec_axpy(n, alpha, P, X);
+    orc_vec_axpy(n, -alpha, Q, U);
+    orc_vec_axpy(n, -alpha, Z, W);
+    orc_vec_axpy(n, -alpha, S, R);
+    gammaold = gamma;
+    i++;
+    sv->its = i;
+  } while (i < sv->max_it);
+  if (i >= sv->max_it) sv->reason = R_DIVERGED_ITS;
+  free(M);
+}
+
 /* ---- KSPSolve_GROPPCG, src/ksp/ksp/impls/cg/groppcg/groppcg.c:40-175 (split-phase reductions are immediate here) ---- */
 static void solve_groppcg(solver *sv, const double *B, double *X) {
   size_t n = (size_t)sv->n;
@@ -570,6 +624,7 @@ static int solve(solver *s, const double *b, double *x) {
   switch (s->ksp_type) {
   case ORC_KSP_CG: solve_cg(s, b, x); break;
   case ORC_KSP_GROPPCG: solve_groppcg(s, b, x); break;
+  case ORC_KSP_PIPECG: solve_pipecg(s, b, x); break;
   case ORC_KSP_GMRES: solve_gmres(s, b, x); break;
   case ORC_KSP_BCGS: solve_bcgs(s, b, x); break;
   case ORC_KSP_PREONLY: pc_apply(s, b, x); s->its = 1; s->reason = R_CONVERGED_ITS; break;

@@ -88,7 +88,7 @@ void orc_scatter_create(int size, int rank, const int *ranges, const int *const 
                         int *nlocal, int *lto, int *lfrom);
 
 /* ---- KSP (src/ksp/ksp/impls/{cg/cg.c:92, gmres/gmres.c:118-409 + borthog2.c:35, bcgs/bcgs.c:43}) ---- */
-enum { ORC_KSP_CG = 0, ORC_KSP_GMRES = 1, ORC_KSP_BCGS = 2, ORC_KSP_PREONLY = 3, ORC_KSP_GROPPCG = 4 };
+enum { ORC_KSP_CG = 0, ORC_KSP_GMRES = 1, ORC_KSP_BCGS = 2, ORC_KSP_PREONLY = 3, ORC_KSP_GROPPCG = 4, ORC_KSP_PIPECG = 5 };
 enum { ORC_PC_NONE = 0, ORC_PC_JACOBI = 1, ORC_PC_BJACOBI = 2, ORC_PC_ILU = 3, ORC_PC_PBJACOBI = 4 };
 /* ILU(0), natural ordering (src/mat/impls/aij/seq/aijfact.c:1628 symbolic, :461 numeric, :3126 solve); bi[n+1], bj/ba[nz+1], bdiag[n+1] */
 int  orc_ilu0_factor(int n, const int *ai, const int *aj, const double *aa, int *bi, int *bj, int *bdiag, double *ba);

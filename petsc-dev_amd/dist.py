@@ -165,12 +165,18 @@ def torch_comm(device_comm=True):
                 why = why or "ncclCommInitRank (%s): %s" % (which, k.mi355x_comm_error_string(rc).decode())
             else:
                 dcomms.append(dcomm)
-                why = why or _rccl_self_test(k, dcomm, rank, size)
-            # every rank must take the same transport (and leave this loop together): agree over gloo
+            # every rank must take the same transport, and no rank may enter a collective of a communicator another rank
+            # failed to join: agree over gloo after the initialisation, then again after the self test
             ok = torch.tensor([0 if why else 1], dtype=torch.int32)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if int(ok[0]) != 1:
-                why = why or "another rank failed"
+                why = why or "another rank failed in ncclCommInitRank"
+                break
+            why = _rccl_self_test(k, dcomm, rank, size)
+            ok = torch.tensor([0 if why else 1], dtype=torch.int32)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok[0]) != 1:
+                why = why or "another rank failed the RCCL self test"
                 break
         if not why:
             L.PetscCommSetDeviceComms(comm, dcomms[0], dcomms[1])

@@ -327,6 +327,112 @@ static PetscErrorCode KSPSolve_GROPPCG(KSP ksp) {
 }
 PetscErrorCode KSPCreate_GROPPCG(KSP ksp) { ksp->ops->setup = KSPSetUp_GROPPCG; ksp->ops->solve = KSPSolve_GROPPCG; return 0; }
 
+/* ================================================================== PIPECG
+ * Pipelined CG of Ghysels & Vanroose (src/ksp/ksp/impls/cg/pipecg/pipecg.c:49-205): ONE split-phase reduction per
+ * iteration -- {norm or (r,u), (w,u)} -- overlapped with m = B w and n = A m; nine work vectors, four extra recurrences.
+ * Restated as this snapshot has it, including the branch structure of its reductions (pipecg.c:124-131,138-145): with the
+ * preconditioned or the unpreconditioned norm gamma = (r,u) is reduced in iteration 0 only and the recurrence then runs with
+ * beta = 1; the natural norm and KSP_NORM_NONE refresh gamma every iteration and are the forms that converge like KSPCG. */
+static PetscErrorCode KSPSetUp_PIPECG(KSP ksp) { return KSPDefaultGetWork(ksp, 9); }
+static PetscErrorCode KSPSolve_PIPECG(KSP ksp) {
+  PetscErrorCode ierr;
+  PetscInt i;
+  PetscScalar alpha = 0.0, beta = 0.0, gamma = 0.0, gammaold = 0.0, delta = 0.0;
+  PetscReal dp = 0.0;
+  Vec X = ksp->vec_sol, B = ksp->vec_rhs, M = ksp->work[0], Z = ksp->work[1], P = ksp->work[2], N = ksp->work[3], W = ksp->work[4],
+      Q = ksp->work[5], U = ksp->work[6], R = ksp->work[7], S = ksp->work[8];
+  Mat Amat = ksp->pc->mat;
+  const KSPNormType nt = ksp->normtype;
+
+  ksp->its = 0;
+  if (!ksp->guess_zero) {
+    ierr = KSP_MatMult(ksp, Amat, X, R);CHKERRQ(ierr);
+    ierr = VecAYPX(R, -1.0, B);CHKERRQ(ierr);
+  } else { ierr = VecCopy(B, R);CHKERRQ(ierr); }
+  ierr = KSP_PCApply(ksp, R, U);CHKERRQ(ierr);
+  switch (nt) {
+  case KSP_NORM_PRECONDITIONED:
+    ierr = VecNormBegin(U, NORM_2, &dp);CHKERRQ(ierr);
+    ierr = PetscCommSplitReductionBegin(U->comm);CHKERRQ(ierr);
+    ierr = KSP_MatMult(ksp, Amat, U, W);CHKERRQ(ierr);
+    ierr = VecNormEnd(U, NORM_2, &dp);CHKERRQ(ierr);
+    break;
+  case KSP_NORM_UNPRECONDITIONED:
+    ierr = VecNormBegin(R, NORM_2, &dp);CHKERRQ(ierr);
+    ierr = PetscCommSplitReductionBegin(R->comm);CHKERRQ(ierr);
+    ierr = KSP_MatMult(ksp, Amat, U, W);CHKERRQ(ierr);
+    ierr = VecNormEnd(R, NORM_2, &dp);CHKERRQ(ierr);
+    break;
+  case KSP_NORM_NATURAL:
+    ierr = VecDotBegin(R, U, &gamma);CHKERRQ(ierr);
+    ierr = PetscCommSplitReductionBegin(R->comm);CHKERRQ(ierr);
+    ierr = KSP_MatMult(ksp, Amat, U, W);CHKERRQ(ierr);
+    ierr = VecDotEnd(R, U, &gamma);CHKERRQ(ierr);
+    if (PetscIsInfOrNanScalar(gamma)) SETERRQ(ksp->comm, PETSC_ERR_FP, "Infinite or not-a-number generated in dot product");
+    dp = PetscSqrtReal(PetscAbsScalar(gamma));
+    break;
+  case KSP_NORM_NONE:
+    ierr = KSP_MatMult(ksp, Amat, U, W);CHKERRQ(ierr);
+    dp = 0.0;
+    break;
+  default: SETERRQ(ksp->comm, PETSC_ERR_SUP, "norm type %d", (int)nt);
+  }
+  KSPLogResidualHistory(ksp, dp);
+  ierr = KSPMonitor(ksp, 0, dp);CHKERRQ(ierr);
+  ksp->rnorm = dp;
+  ierr = KSPDefaultConverged(ksp, 0, dp, &ksp->reason);CHKERRQ(ierr);
+  if (ksp->reason) return 0;
+
+  i = 0;
+  do {
+    const int red = (i > 0 && nt == KSP_NORM_UNPRECONDITIONED) ? 1 : (i > 0 && nt == KSP_NORM_PRECONDITIONED) ? 2 : !(i == 0 && nt == KSP_NORM_NATURAL) ? 3 : 0;
+    if (red == 1) { ierr = VecNormBegin(R, NORM_2, &dp);CHKERRQ(ierr); }
+    else if (red == 2) { ierr = VecNormBegin(U, NORM_2, &dp);CHKERRQ(ierr); }
+    else if (red == 3) { ierr = VecDotBegin(R, U, &gamma);CHKERRQ(ierr); }
+    ierr = VecDotBegin(W, U, &delta);CHKERRQ(ierr);
+    ierr = PetscCommSplitReductionBegin(R->comm);CHKERRQ(ierr);
+    ierr = KSP_PCApply(ksp, W, M);CHKERRQ(ierr);                 /* the overlapped work: m = B w, n = A m */
+    ierr = KSP_MatMult(ksp, Amat, M, N);CHKERRQ(ierr);
+    if (red == 1) { ierr = VecNormEnd(R, NORM_2, &dp);CHKERRQ(ierr); }
+    else if (red == 2) { ierr = VecNormEnd(U, NORM_2, &dp);CHKERRQ(ierr); }
+    else if (red == 3) { ierr = VecDotEnd(R, U, &gamma);CHKERRQ(ierr); }
+    ierr = VecDotEnd(W, U, &delta);CHKERRQ(ierr);
+    if (i > 0) {
+      if (nt == KSP_NORM_NATURAL) dp = PetscSqrtReal(PetscAbsScalar(gamma));
+      else if (nt == KSP_NORM_NONE) dp = 0.0;
+      ksp->rnorm = dp;
+      KSPLogResidualHistory(ksp, dp);
+      ierr = KSPMonitor(ksp, i, dp);CHKERRQ(ierr);
+      ierr = KSPDefaultConverged(ksp, i, dp, &ksp->reason);CHKERRQ(ierr);
+      if (ksp->reason) break;
+    }
+    if (i == 0) {
+      alpha = gamma / delta;
+      ierr = VecCopy(N, Z);CHKERRQ(ierr);
+      ierr = VecCopy(M, Q);CHKERRQ(ierr);
+      ierr = VecCopy(U, P);CHKERRQ(ierr);
+      ierr = VecCopy(W, S);CHKERRQ(ierr);
+    } else {
+      beta = gamma / gammaold;
+      alpha = gamma / (delta - beta / alpha * gamma);
+      ierr = VecAYPX(Z, beta, N);CHKERRQ(ierr);
+      ierr = VecAYPX(Q, beta, M);CHKERRQ(ierr);
+      ierr = VecAYPX(P, beta, U);CHKERRQ(ierr);
+      ierr = VecAYPX(S, beta, W);CHKERRQ(ierr);
+    }
+    ierr = VecAXPY(X, alpha, P);CHKERRQ(ierr);
+    ierr = VecAXPY(U, -alpha, Q);CHKERRQ(ierr);
+    ierr = VecAXPY(W, -alpha, Z);CHKERRQ(ierr);
+    ierr = VecAXPY(R, -alpha, S);CHKERRQ(ierr);
+    gammaold = gamma;
+    i++;
+    ksp->its = i;
+  } while (i < ksp->max_it);
+  if (i >= ksp->max_it) ksp->reason = KSP_DIVERGED_ITS;
+  return 0;
+}
+PetscErrorCode KSPCreate_PIPECG(KSP ksp) { ksp->ops->setup = KSPSetUp_PIPECG; ksp->ops->solve = KSPSolve_PIPECG; return 0; }
+
 /* ================================================================== GMRES(m) */
 typedef struct {
   PetscInt max_k;

@@ -160,9 +160,9 @@ PetscErrorCode KSPSetUp(KSP ksp) {   /* itfunc.c:175 */
       SETERRQ(ksp->comm, PETSC_ERR_SUP, "KSPGMRES: the norm follows the side (left: preconditioned, right: unpreconditioned)");
   } else {
     /* KSPSetNormType (itcreate.c:196-205): every norm with KSPCG; BiCGStab: preconditioned or none */
-    if (ksp->normtype != KSP_NORM_PRECONDITIONED && ksp->normtype != KSP_NORM_NONE && strcmp(ksp->type_name, KSPCG) && strcmp(ksp->type_name, KSPGROPPCG))
+    if (ksp->normtype != KSP_NORM_PRECONDITIONED && ksp->normtype != KSP_NORM_NONE && strcmp(ksp->type_name, KSPCG) && strcmp(ksp->type_name, KSPGROPPCG) && strcmp(ksp->type_name, KSPPIPECG))
       SETERRQ(ksp->comm, PETSC_ERR_SUP, "KSP %s: only the preconditioned residual norm is on the ported path (unpreconditioned/natural: KSPCG)", ksp->type_name);
-    if (ksp->normtype == KSP_NORM_NONE && strcmp(ksp->type_name, KSPCG) && strcmp(ksp->type_name, KSPGROPPCG) && strcmp(ksp->type_name, KSPBCGS) && strcmp(ksp->type_name, KSPPREONLY))
+    if (ksp->normtype == KSP_NORM_NONE && strcmp(ksp->type_name, KSPCG) && strcmp(ksp->type_name, KSPGROPPCG) && strcmp(ksp->type_name, KSPPIPECG) && strcmp(ksp->type_name, KSPBCGS) && strcmp(ksp->type_name, KSPPREONLY))
       SETERRQ(ksp->comm, PETSC_ERR_SUP, "KSP %s with KSP_NORM_NONE is outside the ported path", ksp->type_name);
   }
   ierr = PCSetUp(ksp->pc);CHKERRQ(ierr);

@@ -38,6 +38,7 @@ PetscErrorCode PetscMiniInitialize(void) {
   ierr = PCRegister(PCBJACOBI, 0, "PCCreate_BJacobi", PCCreate_BJacobi);CHKERRQ(ierr);
   ierr = KSPRegister(KSPCG, 0, "KSPCreate_CG", KSPCreate_CG);CHKERRQ(ierr);
   ierr = KSPRegister(KSPGROPPCG, 0, "KSPCreate_GROPPCG", KSPCreate_GROPPCG);CHKERRQ(ierr);
+  ierr = KSPRegister(KSPPIPECG, 0, "KSPCreate_PIPECG", KSPCreate_PIPECG);CHKERRQ(ierr);
   ierr = KSPRegister(KSPGMRES, 0, "KSPCreate_GMRES", KSPCreate_GMRES);CHKERRQ(ierr);
   ierr = KSPRegister(KSPBCGS, 0, "KSPCreate_BCGS", KSPCreate_BCGS);CHKERRQ(ierr);
   ierr = KSPRegister(KSPPREONLY, 0, "KSPCreate_PREONLY", KSPCreate_PREONLY);CHKERRQ(ierr);

@@ -189,7 +189,7 @@ PetscErrorCode KSPInitialResidual(KSP ksp, Vec vsoln, Vec vt1, Vec vt2, Vec vres
 PetscErrorCode KSP_MatMult(KSP ksp, Mat A, Vec x, Vec y);
 PetscErrorCode KSP_PCApply(KSP ksp, Vec x, Vec y);
 PetscErrorCode KSP_PCApplyBAorAB(KSP ksp, Vec x, Vec y, Vec w);
-PetscErrorCode KSPCreate_CG(KSP), KSPCreate_GROPPCG(KSP), KSPCreate_GMRES(KSP), KSPCreate_BCGS(KSP), KSPCreate_PREONLY(KSP);
+PetscErrorCode KSPCreate_CG(KSP), KSPCreate_GROPPCG(KSP), KSPCreate_PIPECG(KSP), KSPCreate_GMRES(KSP), KSPCreate_BCGS(KSP), KSPCreate_PREONLY(KSP);
 PetscErrorCode PCCreate_None(PC), PCCreate_Jacobi(PC), PCCreate_BJacobi(PC);
 PetscBool PCIsNone_Private(PC pc);
 PetscErrorCode PCJacobiGetInverseDiagonal_Private(PC pc, Vec *d);   /* NULL unless pc is a set-up PCJACOBI */

@@ -265,7 +265,7 @@ class KspOpts(C.Structure):
                 ("sub_dtol", C.c_double), ("sub_max_it", C.c_int), ("cg_single", C.c_int), ("norm_type", C.c_int), ("pb_bs", C.c_int), ("pc_right", C.c_int)]
 
 
-KSP = dict(cg=0, gmres=1, bcgs=2, preonly=3, groppcg=4)
+KSP = dict(cg=0, gmres=1, bcgs=2, preonly=3, groppcg=4, pipecg=5)
 PC = dict(none=0, jacobi=1, bjacobi=2, ilu=3, pbjacobi=4)
 
 

@@ -699,6 +699,33 @@ def test_ksp_groppcg(P, norm):
     assert r1.value == u.dot(v) and r2.value == u.norm()
 
 
+@pytest.mark.parametrize("norm", ["natural", "none", "preconditioned", "unpreconditioned"])
+def test_ksp_pipecg(P, norm):
+    """KSPPIPECG (pipecg.c:49-205) as this snapshot has it: history against the oracle's restatement for every norm type.
+    With the natural norm (and none) it is CG -- same solution and iteration count as KSPCG; with the (un)preconditioned norm
+    the reference reduces gamma = (r,u) in iteration 0 only (pipecg.c:124-131) and the recurrence runs with beta = 1: the
+    port reproduces that walk too, for the first iterations (it does not converge)."""
+    ai, aj, aa = pb.lap2d(37, 31)
+    n = ai.size - 1
+    d = 1.0 + 0.5 * np.sin(np.arange(n))
+    rows = np.repeat(np.arange(n), np.diff(ai))
+    aa = aa * d[rows] * d[aj]
+    b = orc.spmv(ai, aj, aa, np.cos(0.3 * np.arange(n)))
+    nt = dict(none=0, preconditioned=1, unpreconditioned=2, natural=3)[norm]
+    works = norm in ("natural", "none")
+    kw = dict(rtol=1e-8, max_it=(41 if norm == "none" else 500) if works else 12)
+    for pc in ("jacobi", "none"):
+        x, h, its, reason = solve(P, ai, aj, aa, b, "pipecg", pc, opts="-ksp_norm_type " + norm, **kw)
+        xr, hr, itsr, rr = orc.ksp_solve(ai, aj, aa, b, ksp="pipecg", pc=pc, norm_type=nt, **kw)
+        assert reason == rr and abs(its - itsr) <= (1 if works else 0)
+        k = min(len(h), len(hr))
+        assert np.allclose(h[:k], hr[:k], rtol=1e-6 if works else 1e-9, atol=1e-14 * max(hr[0], 1e-300))
+        assert np.linalg.norm(x - xr) <= 1e-6 * np.linalg.norm(xr)
+        if norm == "natural":
+            xc, hc, itsc, rc = solve(P, ai, aj, aa, b, "cg", pc, opts="-ksp_norm_type natural", **kw)
+            assert rc == reason and np.linalg.norm(x - xc) <= 1e-6 * np.linalg.norm(xc) and abs(its - itsc) <= 2
+
+
 def test_ksp_cg_single_reduction(P):
     """-ksp_cg_single_reduction (cg.c:116-122,200-203,263-270): two reductions per iteration instead of
     three (VecMDot(2) for delta and beta), A*p by recurrence; same op sequence as the oracle's restatement"""

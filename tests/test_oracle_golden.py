@@ -270,3 +270,22 @@ def test_pbjacobi_preconditions_a_block_system():
     xp, _, itp, rp = orc.ksp_solve(ai, aj, aa, b, ksp="cg", pc="pbjacobi", pb_bs=3, rtol=1e-10)
     assert rj > 0 and rp > 0 and itp < itj, (itp, itj)
     assert np.allclose(xj, xp, rtol=1e-7, atol=1e-9)
+
+
+def test_pipecg_restatement_is_cg_with_the_natural_norm():
+    """KSPSolve_PIPECG (pipecg.c:49-205): with the natural norm (gamma refreshed every iteration) it spans CG's Krylov space --
+    same iteration count +-1 and solution as the CG restatement pinned by pc/tests ex2_1.out; on that golden's own problem
+    (tridiagonal n = 10, PCNONE) it prints CG's natural-norm residuals to 6 digits"""
+    ai, aj, aa = pb.tridiag(10)
+    b = orc.spmv(ai, aj, aa, np.ones(10))
+    xc, hc, itc, rc = orc.ksp_solve(ai, aj, aa, b, ksp="cg", pc="none", norm_type=3)
+    xp, hp, itp, rp = orc.ksp_solve(ai, aj, aa, b, ksp="pipecg", pc="none", norm_type=3)
+    assert rc == rp and itc == itp and np.allclose(hp, hc, rtol=1e-6) and np.linalg.norm(xp - 1.0) < 1e-12
+    ai, aj, aa = pb.lap2d(23, 19)
+    b = np.cos(0.2 * np.arange(ai.size - 1))
+    xc, hc, itc, rc = orc.ksp_solve(ai, aj, aa, b, ksp="cg", pc="jacobi", norm_type=3, rtol=1e-9)
+    xp, hp, itp, rp = orc.ksp_solve(ai, aj, aa, b, ksp="pipecg", pc="jacobi", norm_type=3, rtol=1e-9)
+    assert rc == rp and abs(itc - itp) <= 1 and np.allclose(xp, xc, rtol=1e-7, atol=1e-10)
+    # the snapshot's quirk: with the preconditioned norm gamma is reduced once; the walk does not converge
+    xq, hq, itq, rq = orc.ksp_solve(ai, aj, aa, b, ksp="pipecg", pc="jacobi", norm_type=1, rtol=1e-9, max_it=200)
+    assert rq < 0
