@@ -11,9 +11,10 @@ from petsc_dev_amd import petsc as P
 import orc
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 L = P.lib(); k = pda.load_kernels()
-ai, aj, aa = P.gen_poisson7(n, n, n)
+dims = [int(v) for v in os.environ.get("ILU_BENCH_DIMS", "%d,%d,%d" % (n, n, n)).split(",")]   # e.g. 16,16,4096: few rows per level
+ai, aj, aa = P.gen_poisson7(*dims)
 A = P.Mat.from_csr(ai, aj, aa)
-N = n ** 3
+N = dims[0] * dims[1] * dims[2]
 b = P.Vec.from_array(np.sin(0.1 * np.arange(N)), comm=L.COMM_SELF); x = b.duplicate()
 ksp = P.KSP(comm=L.COMM_SELF); ksp.set_operators(A)
 pc = C.c_void_p(); L.KSPGetPC(ksp.h, C.byref(pc)); L.PCSetType(pc, b"ilu")
