@@ -53,6 +53,8 @@ def main():
     else:
         comm = L.COMM_SELF
 
+    if args.ksp_opts:                        # before the matrix exists: -mat_* options are read when it is first used
+        L.PetscOptionsInsertString(args.ksp_opts.encode())
     n = args.n
     nx, ny, nz = n, n, n * world            # z-slabs: rank r owns planes [r*n, (r+1)*n)
     if args.wide_planes or (world == 8 and n == 256):
@@ -79,7 +81,6 @@ def main():
     ksp.set_type("cg")
     ksp.set_pc_type("jacobi")
     if args.ksp_opts:
-        L.PetscOptionsInsertString(args.ksp_opts.encode())
         ksp.set_from_options()
 
     # the dominant kernel: SpMV of the (diagonal block of the) matrix
@@ -139,7 +140,14 @@ def main():
     cg_bytes = spmv_bytes + 136 * mloc                                   # unfused CG+Jacobi op sequence
     noff = C.c_int(0)
     L.MatHIPMI355XGetIndexCompression(timed, C.byref(noff))
-    kernel_name = ("spmv_csr_rowblock_idx8_kernel (CSR + 1-byte offset-dictionary column indices, %d offsets; 'achieved' uses the CSR algorithmic bytes)" % noff.value) if noff.value else "spmv_csr_rowblock_kernel"
+    npat = C.c_int()
+    L.MatHIPMI355XGetRowPatterns(timed, C.byref(npat))
+    if npat.value:
+        kernel_name = "spmv_csr_rowblock_pat_kernel (CSR values + a %d-entry row-pattern dictionary: 2 index bytes per row; 'achieved' uses the CSR algorithmic bytes)" % npat.value
+    elif noff.value:
+        kernel_name = "spmv_csr_rowblock_idx8_kernel (CSR + 1-byte offset-dictionary column indices, %d offsets; 'achieved' uses the CSR algorithmic bytes)" % noff.value
+    else:
+        kernel_name = "spmv_csr_rowblock_kernel"
     if world > 1:
         tr = PD.transport_report(comm)                   # asked of the C library: what the halo and the reductions travelled over
     else:
@@ -184,7 +192,7 @@ def main():
         with open(pmc_csv) as f:
             f.readline()
             for row in csv.DictReader(f):
-                if "spmv_csr_rowblock" in row["kernel"] and "kernel<0," in row["kernel"]:   # the y = A x instantiation (ADD == 0)
+                if "spmv_csr_rowblock" in row["kernel"] and ("kernel<0," in row["kernel"] or "kernel<0>" in row["kernel"]):   # the y = A x instantiation (ADD == 0)
                     if row["counter"] == "FETCH_SIZE":
                         fs = float(row["avg_value_KB"])
                     elif row["counter"] == "WRITE_SIZE":

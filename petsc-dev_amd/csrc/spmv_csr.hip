@@ -19,6 +19,7 @@
 //   * variants: offset-dictionary index compression (1 byte per nonzero instead of 4), an
 //     x'y by-product for CG, and the BCSR form of the same structure.
 #include "common.hpp"
+#include <map>
 #include <vector>
 #include <stdlib.h>
 
@@ -65,6 +66,11 @@ struct mi355x_spmv_plan_s {
   unsigned char *d_idx8;
   int *d_offtab;
   int ntab;
+  // row patterns (stencil matrices): the offset lists of the rows come from a small dictionary; per row the start of its
+  // list in the table (2 bytes per ROW instead of 1 byte per nonzero)
+  unsigned short *d_prow;
+  int *d_pattab;       // SPMV_PAT_CAP ints
+  int npat, use_pat;
   double *d_dotpart;   // per-row-block x'y values of mi355x_spmv_csr_dot (allocated on first use)
   // rows summed the way MatMult_SeqAIJ_Inode does (two products at a time, inode.c:392-578): set when the reference's
   // Mat_CheckInode would switch this matrix to its inode routines
@@ -390,6 +396,93 @@ __global__ __launch_bounds__(SPMV_THREADS, SPMV_MINWAVES) void spmv_csr_rowblock
 }
 
 // ---------------------------------------------------------------------------------------------
+// Row-pattern variant for stencil matrices.  When the rows' offset lists (col - row, in column order) come from a small
+// dictionary -- 27 lists of <= 7 offsets for the 7-point operator on a box: interior rows and the boundary cases -- the
+// analysis stores, per ROW, where its list starts in a table (2 bytes) and nothing per nonzero: the kernel streams the values
+// (8 B per nonzero) and 6 bytes per row.  Work layout: the block's values go to LDS with coalesced 16-byte loads; after ONE
+// barrier lane r owns row r and gathers x[row + offset_q] itself -- for a fixed q the lanes of a wavefront read
+// consecutive x entries (the rows are consecutive, the offsets equal), so the gathers are coalesced, which the per-nonzero
+// layouts above cannot offer -- multiplies with the staged values and adds in column order (or two at a time, pairsum):
+// the arithmetic and order of the other kernels, same bits.  No row markers, no per-nonzero index stream, one barrier less.
+#define SPMV_PAT_CAP 512
+template <int ADD>
+__global__ __launch_bounds__(SPMV_THREADS, SPMV_MINWAVES) void spmv_csr_rowblock_pat_kernel(
+    const int2 *__restrict__ rowblk, int nblocks, const int *__restrict__ ai, const unsigned short *__restrict__ prow,
+    const int *__restrict__ pattab_g, const double *__restrict__ aa, const double *__restrict__ x, const double *yin, double *yout,
+    int pairsum) {
+  __shared__ double vs[SPMV_BLOCK_NNZ];
+  __shared__ int pattab[SPMV_PAT_CAP];
+  static_assert(SPMV_THREADS == 256 && SPMV_BLOCK_ROWS <= SPMV_THREADS, "one lane per row of the block");
+#if SPMV_REMAP == 2
+  const int xcd = blockIdx.x % MI355X_NXCD;
+  const int slot = blockIdx.x / MI355X_NXCD;
+  const int lb = ((slot / SPMV_CH) * MI355X_NXCD + xcd) * SPMV_CH + (slot % SPMV_CH);
+#else
+  const int lb = blockIdx.x;
+#endif
+  if (lb >= nblocks) return;
+  const int2 b0 = rowblk[lb];
+  const int2 b1 = rowblk[lb + 1];
+  const int r0 = b0.x, r1 = b1.x, k0 = b0.y, k1 = b1.y;
+  const int nrows = r1 - r0;
+  const int tid = threadIdx.x;
+  const int t0 = pattab_g[tid], t1 = pattab_g[tid + SPMV_THREADS];     // SPMV_PAT_CAP initialised entries
+  if (k1 == k0) {               // only empty rows
+    if (tid < nrows) yout[r0 + tid] = spmv_empty<ADD>(ADD ? yin[r0 + tid] : 0.0);
+    return;
+  }
+  const int rc = tid < nrows ? tid : nrows - 1;
+  const int a0 = ai[r0 + rc], a1 = ai[r0 + rc + 1];
+  const int pst = prow[r0 + rc];
+  double ysum = 0.0;
+  if (ADD) ysum = yin[r0 + rc];
+  constexpr int PAIRS = SPMV_BLOCK_NNZ / (2 * SPMV_THREADS);
+  const int ka = k0 & ~1;
+  v2d v[PAIRS];
+#pragma unroll
+  for (int p = 0; p < PAIRS; ++p) {      // every load unconditional, see the idx8 kernel
+    const int k = ka + 2 * tid + p * 2 * SPMV_THREADS;
+    const int kk = (k < k1) ? k : ka;
+    v[p] = SPMV_LOAD(reinterpret_cast<const v2d *>(aa + kk));
+  }
+  pattab[tid] = t0;
+  pattab[tid + SPMV_THREADS] = t1;
+#pragma unroll
+  for (int p = 0; p < PAIRS; ++p) {
+    const int k = ka + 2 * tid + p * 2 * SPMV_THREADS;
+    vs[(k >= k0 && k < k1) ? k - k0 : SPMV_BLOCK_NNZ - 1] = v[p].x;     // elements outside the block: the spare last slot
+    vs[(k + 1 < k1) ? k + 1 - k0 : SPMV_BLOCK_NNZ - 1] = v[p].y;
+  }
+  __syncthreads();
+  if (tid >= nrows) return;
+  const int rs = a0 - k0, len = a1 - a0;
+  const long xbase = (long)r0 + tid;
+  double sum = (ADD == 1) ? ysum : 0.0;
+  for (int q0 = 0; q0 < len; q0 += 8) {
+    double xv[8], av[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int qq = (q0 + j < len) ? q0 + j : len - 1;
+      xv[j] = x[xbase + pattab[pst + qq]];
+      av[j] = vs[rs + qq];
+    }
+    if (!pairsum) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const double u = sum + av[j] * xv[j]; sum = (q0 + j < len) ? u : sum; }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; j += 2) {
+        const double pa = av[j] * xv[j], pb = av[j + 1] * xv[j + 1];
+        const double inc = (q0 + j + 1 < len) ? pa + pb : pa;
+        const double u = sum + inc;
+        sum = (q0 + j < len) ? u : sum;
+      }
+    }
+  }
+  yout[r0 + tid] = spmv_fin<ADD>(ysum, sum);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Grouped-row variant: the MI355X form of the reference's inodes (Mat_CheckInode inode.c:3964-4034,
 // MatMult_SeqAIJ_Inode inode.c:392-578).  Consecutive rows with one and the same column pattern -- the dof rows of
 // one node of a finite-element matrix -- form a group whose column list is stored ONCE (gj); the value array is the
@@ -674,6 +767,18 @@ static int launch_spmv(mi355x_handle_t h, mi355x_spmv_plan_t p, const int *ai, c
     MI355X_LAUNCH_CHECK();
     return 0;
   }
+  if (p->d_prow && p->use_pat && !cprow && mi355x_aligned16(aa)) {
+#if SPMV_REMAP == 2
+    const int perp = MI355X_NXCD * SPMV_CH;
+    const int gp = ((p->nblocks + perp - 1) / perp) * perp;
+#else
+    const int gp = p->nblocks;
+#endif
+    hipLaunchKernelGGL((spmv_csr_rowblock_pat_kernel<ADD>), dim3(gp), dim3(SPMV_THREADS), 0, h->stream, p->d_rowblk, p->nblocks,
+                       ai, p->d_prow, p->d_pattab, aa, x, yin, yout, p->pairsum);
+    MI355X_LAUNCH_CHECK();
+    return 0;
+  }
   if (p->d_idx8 && !cprow && mi355x_aligned16(aa)) {
 #if SPMV_REMAP == 2
     const int per8 = MI355X_NXCD * SPMV_CH;
@@ -713,6 +818,7 @@ int mi355x_spmv_plan_create(mi355x_handle_t h, int nrows, const int *ai_host, co
   p->d_idx8 = nullptr;
   p->d_offtab = nullptr;
   p->ntab = 0;
+  p->d_prow = nullptr; p->d_pattab = nullptr; p->npat = 0; p->use_pat = 1;
   p->nlong = 0;
   p->d_dotpart = nullptr;
   p->pairsum = 0;
@@ -788,6 +894,53 @@ int mi355x_spmv_plan_compress_indices(mi355x_handle_t h, mi355x_spmv_plan_t p, c
   MI355X_TRY(hipMemcpyAsync(p->d_offtab, tab, sizeof(int) * (size_t)ntab, hipMemcpyHostToDevice, h->stream));
   MI355X_TRY(hipStreamSynchronize(h->stream));
   p->ntab = ntab;
+  // row patterns: the rows' slot lists as a dictionary of at most SPMV_PAT_CAP table entries in all (stencil operators: a
+  // handful of lists); rows too long for the row block's one-lane-per-row sums (> SPMV_BLOCK_CAP never happens here) or a
+  // table that would not fit leave the plan at the per-nonzero bytes
+  {
+    std::map<std::vector<unsigned char>, int> dict;
+    std::vector<unsigned short> prow((size_t)m);
+    std::vector<int> ptab;
+    std::vector<unsigned char> cur, prev;
+    int prev_start = -1;
+    bool ok = true;
+    for (int r = 0; r < m && ok; ++r) {
+      const int len = ai_host[r + 1] - ai_host[r];
+      if (len > SPMV_BLOCK_CAP) { ok = false; break; }
+      cur.assign(idx.begin() + ai_host[r], idx.begin() + ai_host[r + 1]);
+      int start;
+      if (prev_start >= 0 && cur == prev) start = prev_start;
+      else {
+        auto it = dict.find(cur);
+        if (it != dict.end()) start = it->second;
+        else {
+          start = (int)ptab.size();
+          if (start + len > SPMV_PAT_CAP) { ok = false; break; }
+          for (int q = 0; q < len; ++q) ptab.push_back(tab[cur[(size_t)q]]);
+          dict.emplace(cur, start);
+        }
+        prev = cur; prev_start = start;
+      }
+      prow[(size_t)r] = (unsigned short)start;
+    }
+    if (ok) {
+      ptab.resize(SPMV_PAT_CAP, 0);
+      MI355X_TRY(hipMalloc((void **)&p->d_prow, sizeof(unsigned short) * (size_t)m + 16));
+      MI355X_TRY(hipMalloc((void **)&p->d_pattab, sizeof(int) * SPMV_PAT_CAP));
+      MI355X_TRY(hipMemcpyAsync(p->d_prow, prow.data(), sizeof(unsigned short) * (size_t)m, hipMemcpyHostToDevice, h->stream));
+      MI355X_TRY(hipMemcpyAsync(p->d_pattab, ptab.data(), sizeof(int) * SPMV_PAT_CAP, hipMemcpyHostToDevice, h->stream));
+      MI355X_TRY(hipStreamSynchronize(h->stream));
+      p->npat = (int)dict.size();
+    }
+  }
+  return 0;
+}
+
+// A/B switch for the row-pattern kernel (on by default when the analysis found a dictionary); *npat: its size, 0 if none
+int mi355x_spmv_plan_use_patterns(mi355x_spmv_plan_t p, int on, int *npat) {
+  if (!p) return (int)hipErrorInvalidValue;
+  if (on >= 0) p->use_pat = on ? 1 : 0;
+  if (npat) *npat = p->d_prow ? p->npat : 0;
   return 0;
 }
 
@@ -878,6 +1031,8 @@ int mi355x_spmv_plan_destroy(mi355x_spmv_plan_t p) {
   hipFree(p->d_rowblk);
   if (p->d_idx8) hipFree(p->d_idx8);
   if (p->d_offtab) hipFree(p->d_offtab);
+  if (p->d_prow) hipFree(p->d_prow);
+  if (p->d_pattab) hipFree(p->d_pattab);
   if (p->d_rows) hipFree(p->d_rows);
   if (p->d_dotpart) hipFree(p->d_dotpart);
   if (p->d_rowblk4) hipFree(p->d_rowblk4);

@@ -208,7 +208,14 @@ PetscErrorCode MatSeqAIJHIPUpload(Mat A) {
       /* -mat_hipmi355x_index_compression <0|1> (default 1): one byte per nonzero instead of a 4-byte column index
        * when the matrix uses <= 256 distinct (col - row) offsets; plain CSR otherwise */
       ierr = PetscOptionsGetInt(NULL, "-mat_hipmi355x_index_compression", &ic, &set);CHKERRQ(ierr);
-      if (ic && !use_cprow) CHKHIP(mi355x_spmv_plan_compress_indices(dc->h, d->plan, a->i, a->j));
+      if (ic && !use_cprow) {
+        PetscInt rp = 1;
+        CHKHIP(mi355x_spmv_plan_compress_indices(dc->h, d->plan, a->i, a->j));
+        /* -mat_hipmi355x_row_patterns <0|1> (default 1): stencil matrices whose rows' offset lists come from a small dictionary
+         * stream 2 bytes per ROW instead of 1 byte per nonzero (spmv_csr_rowblock_pat_kernel); same bits */
+        ierr = PetscOptionsGetInt(NULL, "-mat_hipmi355x_row_patterns", &rp, &set);CHKERRQ(ierr);
+        CHKHIP(mi355x_spmv_plan_use_patterns(d->plan, rp ? 1 : 0, NULL));
+      }
       /* inodes: when the reference's Mat_CheckInode would switch this matrix to MatMult_SeqAIJ_Inode, the row sums take
        * that routine's two-at-a-time order (same bits), and -- unless the 1-byte index dictionary already applies --
        * the rows of a node share one stored column list (mi355x_spmv_plan_group_rows) */
@@ -468,6 +475,28 @@ PetscErrorCode MatHIPMI355XGetIndexCompression(Mat A, PetscInt *noffsets) {
   ierr = MatSeqAIJHIPUpload(A);CHKERRQ(ierr);
   if (SD(A)->plan && SA(A)->bs <= 1) CHKHIP(mi355x_spmv_plan_is_compressed(SD(A)->plan, &ntab));
   *noffsets = ntab;
+  return 0;
+}
+
+/* size of the row-pattern dictionary the SpMV plan runs with (0: none, or switched off) */
+PetscErrorCode MatHIPMI355XGetRowPatterns(Mat A, PetscInt *npat) {
+  PetscErrorCode ierr; int np_ = 0;
+  *npat = 0;
+  if (!A) return 0;
+  if (A->ops->mult != MatMult_SeqAIJHIP) {
+    Mat Ad = NULL;
+    if (!strcmp(HipObjTypeName(A), MATMPIAIJHIPMI355X)) { ierr = MatMPIAIJGetSeqAIJ(A, &Ad, NULL, NULL);CHKERRQ(ierr); }
+    if (!Ad || Ad->ops->mult != MatMult_SeqAIJHIP) return 0;
+    A = Ad;
+  }
+  ierr = MatSeqAIJHIPUpload(A);CHKERRQ(ierr);
+  if (SD(A)->plan && SA(A)->bs <= 1) {
+    PetscInt rp = 1; PetscBool set;
+    CHKHIP(mi355x_spmv_plan_use_patterns(SD(A)->plan, -1, &np_));
+    ierr = PetscOptionsGetInt(NULL, "-mat_hipmi355x_row_patterns", &rp, &set);CHKERRQ(ierr);
+    if (!rp) np_ = 0;
+  }
+  *npat = np_;
   return 0;
 }
 

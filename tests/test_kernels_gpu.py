@@ -254,7 +254,7 @@ def random_csr(m, n, rowlen, seed, sort=True):
     return ai, aj, aa
 
 
-def run_spmv(dev, ai, aj, aa, x, y0=None, rows=None, compress=False, group=False, pairsum=None, dscale=None):
+def run_spmv(dev, ai, aj, aa, x, y0=None, rows=None, compress=False, group=False, pairsum=None, dscale=None, patterns=None):
     k = dev.k
     dai, daj, daa = upload_csr(dev, ai, aj, aa)
     dx = dev.put(x)
@@ -273,6 +273,9 @@ def run_spmv(dev, ai, aj, aa, x, y0=None, rows=None, compress=False, group=False
         nt = C.c_int()
         k.mi355x_spmv_plan_is_compressed(plan, C.byref(nt))
         run_spmv.last_ntab = nt.value
+        npat = C.c_int()                       # row-pattern kernel: patterns=False forces the per-nonzero (idx8) kernel
+        dev.chk(k.mi355x_spmv_plan_use_patterns(plan, -1 if patterns is None else int(patterns), C.byref(npat)))
+        run_spmv.last_npat = npat.value
     if dscale is not None:                                       # y = d .* (A x) in the product's epilogue
         m_out = ai.size - 1
         dy = dev.put(np.full(m_out, 7.0))
@@ -311,11 +314,46 @@ def test_spmv_index_compression_bitexact(dev, dims):
     aa = aa * (1.0 + 0.01 * np.cos(np.arange(aa.size)))
     n = ai.size - 1
     x = np.sin(0.37 * np.arange(n)) + 1.0
-    got = run_spmv(dev, ai, aj, aa, x, compress=True)
-    assert run_spmv.last_ntab == 7
-    assert_bitexact(got, orc.spmv(ai, aj, aa, x))
     y0 = rnd(n, 51)
+    for patterns in (False, True):             # the per-nonzero byte kernel, then the row-pattern kernel (2 bytes per row)
+        got = run_spmv(dev, ai, aj, aa, x, compress=True, patterns=patterns)
+        assert run_spmv.last_ntab == 7 and 1 <= run_spmv.last_npat <= 27
+        assert_bitexact(got, orc.spmv(ai, aj, aa, x))
+        assert_bitexact(run_spmv(dev, ai, aj, aa, x, y0=y0, compress=True, patterns=patterns), orc.spmv_add(ai, aj, aa, x, y0))
+        assert_bitexact(run_spmv(dev, ai, aj, aa, x, compress=True, patterns=patterns, pairsum=1), orc.spmv_inode(ai, aj, aa, x))
+
+
+def test_spmv_row_patterns_other_shapes(dev):
+    """row-pattern analysis: a 2-D 9-point stencil with empty rows sprinkled in and rows of 0..9 entries (dictionary), a banded
+    matrix whose boundary rows need more table than there is (declined: per-nonzero bytes), and the ex5 rectangular shape"""
+    import scipy.sparse as sp
+    nx, ny = 37, 29
+    n = nx * ny
+    rows, cols = [], []
+    for j in range(ny):
+        for i in range(nx):
+            r = i + nx * j
+            if r % 11 == 5:
+                continue                                   # a row without entries
+            for dj in (-1, 0, 1):
+                for di in (-1, 0, 1):
+                    if 0 <= i + di < nx and 0 <= j + dj < ny:
+                        rows.append(r); cols.append(i + di + nx * (j + dj))
+    A = sp.csr_matrix((rnd(len(rows), 60), (rows, cols)), shape=(n, n)); A.sort_indices()
+    ai, aj, aa = A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.copy()
+    x = rnd(n, 61); y0 = rnd(n, 62); d = rnd(n, 63)
+    got = run_spmv(dev, ai, aj, aa, x, compress=True)
+    assert run_spmv.last_ntab == 9 and run_spmv.last_npat >= 9
+    assert_bitexact(got, orc.spmv(ai, aj, aa, x))
     assert_bitexact(run_spmv(dev, ai, aj, aa, x, y0=y0, compress=True), orc.spmv_add(ai, aj, aa, x, y0))
+    assert_bitexact(run_spmv(dev, ai, aj, aa, x, dscale=d, compress=True), orc.spmv(ai, aj, aa, x) * d)
+    # banded, 81 offsets: 81 boundary lists of 41..80 offsets do not fit the table -> no dictionary, idx8 kernel
+    nb = 3000
+    rows_ = [np.arange(max(0, r - 40), min(nb, r + 41)) for r in range(nb)]
+    aib = np.concatenate(([0], np.cumsum([c.size for c in rows_]))).astype(np.int32)
+    ajb = np.concatenate(rows_).astype(np.int32)
+    run_spmv(dev, aib, ajb, rnd(ajb.size, 64), rnd(nb, 65), compress=True)
+    assert run_spmv.last_ntab == 81 and run_spmv.last_npat == 0
 
 
 def test_spmv_index_compression_other_shapes(dev):
@@ -476,14 +514,16 @@ def test_spmv_grouped_rows(dev, shape):
         assert_bitexact(run_spmv(dev, ai, aj, aa, x, y0=y0, pairsum=1), orc.matmult(ai, aj, aa, x, y0)[0])
 
 
-@pytest.mark.parametrize("shape", ["stencil", "irregular", "groups16", "fem3", "longrow", "emptyrows"])
+@pytest.mark.parametrize("shape", ["stencil", "stencil_patterns", "irregular", "groups16", "fem3", "longrow", "emptyrows"])
 def test_spmv_with_diagonal_scaling_epilogue(dev, shape):
     """mi355x_spmv_csr_scaled: y = d .* (A x) is the product followed by PCApply_Jacobi's VecPointwiseMult (jacobi.c:266),
     bit for bit, in every SpMV kernel (plain, index-compressed, grouped rows, long row, rows without entries)"""
     import problems as pb
     kw = {}
     if shape == "stencil":
-        ai, aj, aa = orc.gen_p7(13, 11, 9); kw = dict(compress=True)
+        ai, aj, aa = orc.gen_p7(13, 11, 9); kw = dict(compress=True, patterns=False)
+    elif shape == "stencil_patterns":
+        ai, aj, aa = orc.gen_p7(13, 11, 9); kw = dict(compress=True, patterns=True)
     elif shape == "irregular":
         ai, aj, aa = random_csr(3000, 3000, lambda rng, m: rng.integers(0, 40, m), 81)
     elif shape == "groups16":
