@@ -143,7 +143,7 @@ def main():
     npat = C.c_int()
     L.MatHIPMI355XGetRowPatterns(timed, C.byref(npat))
     if npat.value:
-        kernel_name = "spmv_csr_rowblock_pat_kernel (CSR values + a %d-entry row-pattern dictionary: 2 index bytes per row; 'achieved' uses the CSR algorithmic bytes)" % npat.value
+        kernel_name = "spmv_csr_rowblock_pat_kernel (CSR values + a %d-list row-pattern dictionary: one 4-byte word per row instead of column indices and row pointer; 'achieved' uses the CSR algorithmic bytes)" % npat.value
     elif noff.value:
         kernel_name = "spmv_csr_rowblock_idx8_kernel (CSR + 1-byte offset-dictionary column indices, %d offsets; 'achieved' uses the CSR algorithmic bytes)" % noff.value
     else:

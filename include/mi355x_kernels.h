@@ -170,7 +170,7 @@ int mi355x_spmv_plan_destroy(mi355x_spmv_plan_t plan);
  * (col - row) -- stencil operators -- one byte per nonzero is stored next to the CSR arrays and the SpMV
  * kernels stream val + 1 B instead of val + 4 B col.  Same arithmetic, same bits; no-op otherwise. */
 int mi355x_spmv_plan_compress_indices(mi355x_handle_t h, mi355x_spmv_plan_t plan, const int *ai_host, const int *aj_host);
-/* row-pattern kernel (stencil matrices: 2 bytes per row instead of 1 byte per nonzero; found by mi355x_spmv_plan_compress_indices):
+/* row-pattern kernel (stencil matrices: 4 bytes per row instead of 1 byte per nonzero + the row pointer; found by mi355x_spmv_plan_compress_indices):
  * on = 0/1 switches it, on < 0 only asks; *npat = size of the dictionary, 0 when the plan has none */
 int mi355x_spmv_plan_use_patterns(mi355x_spmv_plan_t p, int on, int *npat);
 int mi355x_spmv_plan_is_compressed(mi355x_spmv_plan_t plan, int *ntab);

@@ -68,7 +68,7 @@ struct mi355x_spmv_plan_s {
   int ntab;
   // row patterns (stencil matrices): the offset lists of the rows come from a small dictionary; per row the start of its
   // list in the table (2 bytes per ROW instead of 1 byte per nonzero)
-  unsigned short *d_prow;
+  unsigned int *d_prow;
   int *d_pattab;       // SPMV_PAT_CAP ints
   int npat, use_pat;
   double *d_dotpart;   // per-row-block x'y values of mi355x_spmv_csr_dot (allocated on first use)
@@ -398,8 +398,9 @@ __global__ __launch_bounds__(SPMV_THREADS, SPMV_MINWAVES) void spmv_csr_rowblock
 // ---------------------------------------------------------------------------------------------
 // Row-pattern variant for stencil matrices.  When the rows' offset lists (col - row, in column order) come from a small
 // dictionary -- 27 lists of <= 7 offsets for the 7-point operator on a box: interior rows and the boundary cases -- the
-// analysis stores, per ROW, where its list starts in a table (2 bytes) and nothing per nonzero: the kernel streams the values
-// (8 B per nonzero) and 6 bytes per row.  Work layout: the block's values go to LDS with coalesced 16-byte loads; after ONE
+// analysis stores, per ROW, one 4-byte word -- where its list starts in a table, and the row's first nonzero relative to its row
+// block -- and nothing per nonzero: the kernel streams the values (8 B per nonzero) and 4 bytes per row; the row pointer is
+// not read at all (a table entry carries its list's length).  Work layout: the block's values go to LDS with coalesced 16-byte loads; after ONE
 // barrier lane r owns row r and gathers x[row + offset_q] itself -- for a fixed q the lanes of a wavefront read
 // consecutive x entries (the rows are consecutive, the offsets equal), so the gathers are coalesced, which the per-nonzero
 // layouts above cannot offer -- multiplies with the staged values and adds in column order (or two at a time, pairsum):
@@ -407,7 +408,7 @@ __global__ __launch_bounds__(SPMV_THREADS, SPMV_MINWAVES) void spmv_csr_rowblock
 #define SPMV_PAT_CAP 512
 template <int ADD>
 __global__ __launch_bounds__(SPMV_THREADS, SPMV_MINWAVES) void spmv_csr_rowblock_pat_kernel(
-    const int2 *__restrict__ rowblk, int nblocks, const int *__restrict__ ai, const unsigned short *__restrict__ prow,
+    const int2 *__restrict__ rowblk, int nblocks, const unsigned int *__restrict__ prow,
     const int *__restrict__ pattab_g, const double *__restrict__ aa, const double *__restrict__ x, const double *yin, double *yout,
     int pairsum) {
   __shared__ double vs[SPMV_BLOCK_NNZ];
@@ -432,8 +433,8 @@ __global__ __launch_bounds__(SPMV_THREADS, SPMV_MINWAVES) void spmv_csr_rowblock
     return;
   }
   const int rc = tid < nrows ? tid : nrows - 1;
-  const int a0 = ai[r0 + rc], a1 = ai[r0 + rc + 1];
-  const int pst = prow[r0 + rc];
+  const unsigned int pw = prow[r0 + rc];          // {where the row's list starts in the table : 16, its first nonzero in the block : 16}
+  const int pst = (int)(pw & 0xffffu), rs = (int)(pw >> 16);
   double ysum = 0.0;
   if (ADD) ysum = yin[r0 + rc];
   constexpr int PAIRS = SPMV_BLOCK_NNZ / (2 * SPMV_THREADS);
@@ -455,7 +456,7 @@ __global__ __launch_bounds__(SPMV_THREADS, SPMV_MINWAVES) void spmv_csr_rowblock
   }
   __syncthreads();
   if (tid >= nrows) return;
-  const int rs = a0 - k0, len = a1 - a0;
+  const int len = pattab[pst];                     // table entry: {length, offsets ...}
   const long xbase = (long)r0 + tid;
   double sum = (ADD == 1) ? ysum : 0.0;
   for (int q0 = 0; q0 < len; q0 += 8) {
@@ -463,7 +464,7 @@ __global__ __launch_bounds__(SPMV_THREADS, SPMV_MINWAVES) void spmv_csr_rowblock
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int qq = (q0 + j < len) ? q0 + j : len - 1;
-      xv[j] = x[xbase + pattab[pst + qq]];
+      xv[j] = x[xbase + pattab[pst + 1 + qq]];
       av[j] = vs[rs + qq];
     }
     if (!pairsum) {
@@ -775,7 +776,7 @@ static int launch_spmv(mi355x_handle_t h, mi355x_spmv_plan_t p, const int *ai, c
     const int gp = p->nblocks;
 #endif
     hipLaunchKernelGGL((spmv_csr_rowblock_pat_kernel<ADD>), dim3(gp), dim3(SPMV_THREADS), 0, h->stream, p->d_rowblk, p->nblocks,
-                       ai, p->d_prow, p->d_pattab, aa, x, yin, yout, p->pairsum);
+                       p->d_prow, p->d_pattab, aa, x, yin, yout, p->pairsum);
     MI355X_LAUNCH_CHECK();
     return 0;
   }
@@ -899,14 +900,20 @@ int mi355x_spmv_plan_compress_indices(mi355x_handle_t h, mi355x_spmv_plan_t p, c
   // table that would not fit leave the plan at the per-nonzero bytes
   {
     std::map<std::vector<unsigned char>, int> dict;
-    std::vector<unsigned short> prow((size_t)m);
+    std::vector<unsigned int> prow((size_t)m);
     std::vector<int> ptab;
     std::vector<unsigned char> cur, prev;
     int prev_start = -1;
     bool ok = true;
+    // first nonzero of every row block (the rows carry their offset from it in 16 bits: a block holds <= 2046 nonzeros)
+    std::vector<int2> blk((size_t)p->nblocks + 1);
+    MI355X_TRY(hipMemcpy(blk.data(), p->d_rowblk, sizeof(int2) * ((size_t)p->nblocks + 1), hipMemcpyDeviceToHost));
+    int b = 0;
     for (int r = 0; r < m && ok; ++r) {
+      while (b + 1 <= p->nblocks && blk[(size_t)b + 1].x <= r) ++b;      // the block that holds row r
       const int len = ai_host[r + 1] - ai_host[r];
-      if (len > SPMV_BLOCK_CAP) { ok = false; break; }
+      const int rs = ai_host[r] - blk[(size_t)b].y;
+      if (len > SPMV_BLOCK_CAP || rs < 0 || rs > 0xffff) { ok = false; break; }
       cur.assign(idx.begin() + ai_host[r], idx.begin() + ai_host[r + 1]);
       int start;
       if (prev_start >= 0 && cur == prev) start = prev_start;
@@ -915,19 +922,20 @@ int mi355x_spmv_plan_compress_indices(mi355x_handle_t h, mi355x_spmv_plan_t p, c
         if (it != dict.end()) start = it->second;
         else {
           start = (int)ptab.size();
-          if (start + len > SPMV_PAT_CAP) { ok = false; break; }
+          if (start + 1 + len > SPMV_PAT_CAP) { ok = false; break; }
+          ptab.push_back(len);                                            // table entry: {length, offsets ...}
           for (int q = 0; q < len; ++q) ptab.push_back(tab[cur[(size_t)q]]);
           dict.emplace(cur, start);
         }
         prev = cur; prev_start = start;
       }
-      prow[(size_t)r] = (unsigned short)start;
+      prow[(size_t)r] = (unsigned int)start | ((unsigned int)rs << 16);
     }
     if (ok) {
       ptab.resize(SPMV_PAT_CAP, 0);
-      MI355X_TRY(hipMalloc((void **)&p->d_prow, sizeof(unsigned short) * (size_t)m + 16));
+      MI355X_TRY(hipMalloc((void **)&p->d_prow, sizeof(unsigned int) * (size_t)m + 16));
       MI355X_TRY(hipMalloc((void **)&p->d_pattab, sizeof(int) * SPMV_PAT_CAP));
-      MI355X_TRY(hipMemcpyAsync(p->d_prow, prow.data(), sizeof(unsigned short) * (size_t)m, hipMemcpyHostToDevice, h->stream));
+      MI355X_TRY(hipMemcpyAsync(p->d_prow, prow.data(), sizeof(unsigned int) * (size_t)m, hipMemcpyHostToDevice, h->stream));
       MI355X_TRY(hipMemcpyAsync(p->d_pattab, ptab.data(), sizeof(int) * SPMV_PAT_CAP, hipMemcpyHostToDevice, h->stream));
       MI355X_TRY(hipStreamSynchronize(h->stream));
       p->npat = (int)dict.size();

@@ -212,7 +212,7 @@ PetscErrorCode MatSeqAIJHIPUpload(Mat A) {
         PetscInt rp = 1;
         CHKHIP(mi355x_spmv_plan_compress_indices(dc->h, d->plan, a->i, a->j));
         /* -mat_hipmi355x_row_patterns <0|1> (default 1): stencil matrices whose rows' offset lists come from a small dictionary
-         * stream 2 bytes per ROW instead of 1 byte per nonzero (spmv_csr_rowblock_pat_kernel); same bits */
+         * stream 4 bytes per ROW instead of 1 byte per nonzero + the row pointer (spmv_csr_rowblock_pat_kernel); same bits */
         ierr = PetscOptionsGetInt(NULL, "-mat_hipmi355x_row_patterns", &rp, &set);CHKERRQ(ierr);
         CHKHIP(mi355x_spmv_plan_use_patterns(d->plan, rp ? 1 : 0, NULL));
       }
