@@ -720,9 +720,13 @@ static PetscErrorCode KSPSolve_BCGS(KSP ksp) {
     ierr = VecAXPBYPCZ(P, 1.0, -omegaold * beta, beta, R, V);CHKERRQ(ierr);   /* p <- r - omega*beta*v + beta*p */
     done = PETSC_FALSE;
     if (fusedpc) {                                               /* v <- K p and (v,rp) */
-      ierr = KSP_MatMult(ksp, Amat, P, T);CHKERRQ(ierr);
-      ierr = F->pmult_dot(V, T, D, RP, &d1, &done);CHKERRQ(ierr);
-      if (!done) { ierr = KSP_PCApply(ksp, T, V);CHKERRQ(ierr); }
+      PetscBool scaled = PETSC_FALSE;                            /* PCJACOBI: the scaling in the product's epilogue, then a plain dot */
+      if (D) { ierr = mat_mult_diagonal_scale(Amat, D, P, V, &scaled);CHKERRQ(ierr); }
+      if (!scaled) {
+        ierr = KSP_MatMult(ksp, Amat, P, T);CHKERRQ(ierr);
+        ierr = F->pmult_dot(V, T, D, RP, &d1, &done);CHKERRQ(ierr);
+        if (!done) { ierr = KSP_PCApply(ksp, T, V);CHKERRQ(ierr); }
+      }
     } else { ierr = KSP_PCApplyBAorAB(ksp, P, V, T);CHKERRQ(ierr); }
     if (!done) { ierr = VecDot(V, RP, &d1);CHKERRQ(ierr); }
     if (d1 == 0.0) SETERRQ(ksp->comm, PETSC_ERR_PLIB, "Divide by zero");
@@ -730,9 +734,13 @@ static PetscErrorCode KSPSolve_BCGS(KSP ksp) {
     ierr = VecWAXPY(S, -alpha, V, R);CHKERRQ(ierr);              /* s <- r - a v */
     done = PETSC_FALSE;
     if (fusedpc) {                                               /* t <- K s and (s,t), (t,t) */
-      ierr = KSP_MatMult(ksp, Amat, S, R);CHKERRQ(ierr);
-      ierr = F->pmult_dotnorm2(T, R, D, S, &d1, &d2, &done);CHKERRQ(ierr);
-      if (!done) { ierr = KSP_PCApply(ksp, R, T);CHKERRQ(ierr); }
+      PetscBool scaled = PETSC_FALSE;
+      if (D) { ierr = mat_mult_diagonal_scale(Amat, D, S, T, &scaled);CHKERRQ(ierr); }
+      if (!scaled) {
+        ierr = KSP_MatMult(ksp, Amat, S, R);CHKERRQ(ierr);
+        ierr = F->pmult_dotnorm2(T, R, D, S, &d1, &d2, &done);CHKERRQ(ierr);
+        if (!done) { ierr = KSP_PCApply(ksp, R, T);CHKERRQ(ierr); }
+      }
     } else { ierr = KSP_PCApplyBAorAB(ksp, S, T, R);CHKERRQ(ierr); }
     if (!done) { ierr = VecDotNorm2(S, T, &d1, &d2);CHKERRQ(ierr); }
     if (d2 == 0.0) {

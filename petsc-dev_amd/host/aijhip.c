@@ -287,6 +287,15 @@ static PetscErrorCode upload_transpose(Mat A) {
   CHKHIP(mi355x_memcpy_h2d(dc->h, d->t_j, tj, sizeof(PetscInt) * (size_t)nz));
   CHKHIP(mi355x_memcpy_h2d(dc->h, d->t_a, ta, sizeof(PetscScalar) * (size_t)nz));
   CHKHIP(mi355x_spmv_plan_create(dc->h, n, ti, NULL, &d->t_plan));
+  { /* the transpose of a stencil matrix is a stencil matrix: same index compression / row patterns as the matrix itself */
+    PetscInt ic = 1, rp = 1; PetscBool set;
+    ierr = PetscOptionsGetInt(NULL, "-mat_hipmi355x_index_compression", &ic, &set);CHKERRQ(ierr);
+    ierr = PetscOptionsGetInt(NULL, "-mat_hipmi355x_row_patterns", &rp, &set);CHKERRQ(ierr);
+    if (ic) {
+      CHKHIP(mi355x_spmv_plan_compress_indices(dc->h, d->t_plan, ti, tj));
+      CHKHIP(mi355x_spmv_plan_use_patterns(d->t_plan, rp ? 1 : 0, NULL));
+    }
+  }
   CHKHIP(mi355x_handle_synchronize(dc->h));
   HipFree(ti); HipFree(tj); HipFree(ta); HipFree(next);
   d->t_state = HipObjState(A);
