@@ -106,7 +106,11 @@ __global__ __launch_bounds__(MI355X_BLOCK) void bsr4_mfma_kernel(int mbs, const 
                                                                 const double *__restrict__ aa, const double *__restrict__ x,
                                                                 double *__restrict__ y) {
   const int lane = threadIdx.x & (MI355X_WAVE - 1);
-  const int br0 = (blockIdx.x * (MI355X_BLOCK / MI355X_WAVE) + (threadIdx.x >> 6)) * ROWS;
+  // workgroups b, b+8, .. share an XCD: give each XCD runs of 32 consecutive workgroups (128 block rows), so that a block
+  // column's x entries are pulled into one L2 instead of eight (the map of the CSR kernels, spmv_csr.hip)
+  const int xcd = blockIdx.x % MI355X_NXCD, slot = blockIdx.x / MI355X_NXCD;
+  const int wg = ((slot / 32) * MI355X_NXCD + xcd) * 32 + (slot % 32);
+  const int br0 = (wg * (MI355X_BLOCK / MI355X_WAVE) + (threadIdx.x >> 6)) * ROWS;
   if (br0 >= mbs) return;
   constexpr int BPS = WIDE ? 8 : 4;           // blocks per step
   constexpr int STEPS = 4;                    // steps in flight
@@ -270,7 +274,8 @@ int mi355x_spmv_bsr4_mfma(mi355x_handle_t h, int mbs, int variant, const int *ai
   if (mbs <= 0) return 0;
   if (!mi355x_aligned16(aa) || !mi355x_aligned16(y)) return (int)hipErrorInvalidValue;
   const int wpb = MI355X_BLOCK / MI355X_WAVE;
-  const int grid = (mbs + wpb - 1) / wpb;
+  const int per = MI355X_NXCD * 32;                                   // whole runs for every XCD (bsr4_mfma_kernel's workgroup map)
+  const int grid = (((mbs + wpb - 1) / wpb + per - 1) / per) * per;
   if (variant == 0) hipLaunchKernelGGL((bsr4_mfma_kernel<true, 1>), dim3(grid), dim3(MI355X_BLOCK), 0, h->stream, mbs, ai, aj, aa, x, y);
   else hipLaunchKernelGGL((bsr4_mfma_kernel<false, 1>), dim3(grid), dim3(MI355X_BLOCK), 0, h->stream, mbs, ai, aj, aa, x, y);
   MI355X_LAUNCH_CHECK();

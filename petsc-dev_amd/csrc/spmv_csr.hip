@@ -603,7 +603,15 @@ __global__ __launch_bounds__(SPMV_THREADS) void bsr_rowblock_kernel(const int2 *
   __shared__ double prod[SPMV_BLOCK_NNZ];
   __shared__ int ajs[SPMV_BLOCK_NNZ / 4 + 1];   // block columns of the row block (bs >= 2: at most NNZ/4 blocks)
   constexpr int BS2 = BS * BS;
+  // interleaved block -> XCD map of the CSR kernels: each XCD walks runs of consecutive row blocks, so a block column's x
+  // entries are pulled into ONE XCD's L2 instead of all eight (PMC at 128^3 nodes: 4.75 GB fetched for 4.35 GB without it)
+#if SPMV_REMAP == 2
+  const int xcd = blockIdx.x % MI355X_NXCD;
+  const int slot = blockIdx.x / MI355X_NXCD;
+  const int lb = ((slot / SPMV_CH) * MI355X_NXCD + xcd) * SPMV_CH + (slot % SPMV_CH);
+#else
   const int lb = blockIdx.x;
+#endif
   if (lb >= nblocks) return;
   const int2 b0 = rowblk[lb];
   const int2 b1 = rowblk[lb + 1];
@@ -1109,7 +1117,12 @@ int mi355x_spmv_csr_add(mi355x_handle_t h, mi355x_spmv_plan_t plan, const int *a
 int mi355x_spmv_bsr_planned(mi355x_handle_t h, mi355x_spmv_plan_t p, int bs, const int *ai, const int *aj,
                             const double *aa, const double *x, double *y) {
   if (p->nblocks == 0) return 0;
+#if SPMV_REMAP == 2
+  const int perb = MI355X_NXCD * SPMV_CH;
+  dim3 grid(((p->nblocks + perb - 1) / perb) * perb), block(SPMV_THREADS);
+#else
   dim3 grid(p->nblocks), block(SPMV_THREADS);
+#endif
 #define BSR_GO(B) hipLaunchKernelGGL((bsr_rowblock_kernel<B>), grid, block, 0, h->stream, p->d_rowblk, p->nblocks, ai, aj, aa, x, y)
   switch (bs) {
     case 2: BSR_GO(2); break;
