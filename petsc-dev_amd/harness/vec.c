@@ -111,8 +111,16 @@ PetscErrorCode VecSetValues(Vec v, PetscInt ni, const PetscInt ix[], const Petsc
   PetscObjectStateIncrease(v);
   return 0;
 }
-PetscErrorCode VecAssemblyBegin(Vec v) { VecTypeSet(v, 1); return 0; }
-PetscErrorCode VecAssemblyEnd(Vec v) { VecTypeSet(v, 1); return 0; }
+PetscErrorCode VecAssemblyBegin(Vec v) {   /* vector.c:145 */
+  VecTypeSet(v, 1);
+  if (v->ops->assemblybegin) { PetscErrorCode ierr = (*v->ops->assemblybegin)(v);CHKERRQ(ierr); }
+  return 0;
+}
+PetscErrorCode VecAssemblyEnd(Vec v) {
+  VecTypeSet(v, 1);
+  if (v->ops->assemblyend) { PetscErrorCode ierr = (*v->ops->assemblyend)(v);CHKERRQ(ierr); }
+  return 0;
+}
 
 /* host access goes through ops->getarray/restorearray, the petscnative == PETSC_FALSE route of
  * include/petsc-private/vecimpl.h:375-385,409-419,430-434 */

@@ -45,6 +45,14 @@ typedef struct {
 } PetscDeviceCtx;
 PetscErrorCode PetscDeviceGet(PetscDeviceCtx **ctx);   /* lazily creates handles; PETSC_ERR_LIB without a GPU */
 
+/* ---- off-process entries set with VecSetValues / MatSetValues (harness flavour; inside a PETSc tree the parent classes stash:
+ * src/vec/vec/utils/vecstash.c, src/mat/utils/matstash.c).  Entries wait here until the assembly, which hands every rank the
+ * entries of all ranks in RANK order (the reference processes messages in arrival order). ---- */
+typedef struct { PetscInt n, cap, *i, *j; PetscScalar *v; int mode; /* 0 unset, else InsertMode */ } HipStash;
+PetscErrorCode HipStashAdd(HipStash *s, PetscInt i, PetscInt j, PetscScalar v, int mode);
+PetscErrorCode HipStashExchange(MPI_Comm comm, HipStash *s, PetscInt *nrecv, PetscInt **ri, PetscInt **rj, PetscScalar **rv, int *mode);
+void HipStashFree(HipStash *s);
+
 /* ---- Vec ---- */
 /* coherence flags, as PETSC_CUSP_UNALLOCATED/CPU/GPU/BOTH (include/petsc-private/vecimpl.h) */
 enum { VALID_NONE = 0, VALID_HOST = 1, VALID_DEVICE = 2, VALID_BOTH = 3 };
@@ -55,6 +63,7 @@ typedef struct {
   PetscScalar *placed_save; /* VecPlaceArray */
   int host_owned;
   PetscScalar *alias_save; int alias_valid;   /* "VecShareArrayBegin_C": the storage this vector owns while it borrows another's */
+  HipStash stash;           /* off-process VecSetValues (harness flavour) */
 } Vec_HIPMI355X;
 
 PetscErrorCode VecCreate_SeqHIPMI355X(Vec v);
@@ -162,6 +171,7 @@ typedef struct {
   Vec lvec;
   HipScatter hscat;
   PetscInt rstart, rend, cstart, cend;
+  HipStash stash;           /* off-process MatSetValues (harness flavour) */
 } HipMPIAIJ;
 #if defined(PETSCHIPMI355X_WITH_PETSC)
 #define HipMPIAIJGet(A) ((HipMPIAIJ *)(A)->spptr)

@@ -102,3 +102,73 @@ PetscErrorCode PetscCommGetDeviceTransport(MPI_Comm comm, int *kind, int *nranks
   return 0;
 }
 #endif
+
+/* ---------------------------------------------------------------- stash of off-process entries */
+PetscErrorCode HipStashAdd(HipStash *s, PetscInt i, PetscInt j, PetscScalar v, int mode) {
+  PetscErrorCode ierr;
+  if (s->mode && s->mode != mode) SETERRQ(0, PETSC_ERR_ARG_WRONGSTATE, "Cannot mix add values and insert values");   /* matrix.c:1010 */
+  s->mode = mode;
+  if (s->n == s->cap) {
+    const PetscInt ncap = s->cap ? 2 * s->cap : 1024;
+    PetscInt *ni, *nj; PetscScalar *nv;
+    ierr = PetscMalloc(sizeof(PetscInt) * (size_t)ncap, &ni);CHKERRQ(ierr);
+    ierr = PetscMalloc(sizeof(PetscInt) * (size_t)ncap, &nj);CHKERRQ(ierr);
+    ierr = PetscMalloc(sizeof(PetscScalar) * (size_t)ncap, &nv);CHKERRQ(ierr);
+    if (s->n) { memcpy(ni, s->i, sizeof(PetscInt) * (size_t)s->n); memcpy(nj, s->j, sizeof(PetscInt) * (size_t)s->n); memcpy(nv, s->v, sizeof(PetscScalar) * (size_t)s->n); }
+    HipFree(s->i); HipFree(s->j); HipFree(s->v);
+    s->i = ni; s->j = nj; s->v = nv; s->cap = ncap;
+  }
+  s->i[s->n] = i; s->j[s->n] = j; s->v[s->n] = v; s->n++;
+  return 0;
+}
+void HipStashFree(HipStash *s) { HipFree(s->i); HipFree(s->j); HipFree(s->v); memset(s, 0, sizeof(*s)); }
+
+/* Collective.  Every rank receives the stashed entries of ALL ranks, rank after rank, each rank's in the order they were set
+ * (the owner picks out its rows); the stash is emptied.  *mode: the InsertMode the ranks used (0: nobody stashed); ranks
+ * that inserted while others added are an error, as MatAssemblyBegin_MPIAIJ's MPI_BOR test (mpiaij.c:598-603). */
+PetscErrorCode HipStashExchange(MPI_Comm comm, HipStash *s, PetscInt *nrecv, PetscInt **ri, PetscInt **rj, PetscScalar **rv, int *mode) {
+  PetscErrorCode ierr;
+  const int size = HipCommSize(comm);
+  PetscInt hdr[2], *hdrs, maxn = 0, total = 0;
+  *nrecv = 0; *ri = NULL; *rj = NULL; *rv = NULL; *mode = s->mode;
+  if (size == 1) { s->n = 0; s->mode = 0; return 0; }
+  hdr[0] = s->n; hdr[1] = s->mode;
+  ierr = PetscMalloc(sizeof(PetscInt) * 2 * (size_t)size, &hdrs);CHKERRQ(ierr);
+  if (HipCommAllgather(comm, hdr, (int)sizeof(hdr), hdrs)) SETERRQ(comm, PETSC_ERR_LIB, "allgather failed");
+  for (int r = 0; r < size; r++) {
+    if (hdrs[2 * r] > maxn) maxn = hdrs[2 * r];
+    total += hdrs[2 * r];
+    if (hdrs[2 * r + 1]) {
+      if (*mode && *mode != (int)hdrs[2 * r + 1]) { HipFree(hdrs); SETERRQ(comm, PETSC_ERR_ARG_WRONGSTATE, "Some processors inserted others added"); }
+      *mode = (int)hdrs[2 * r + 1];
+    }
+  }
+  if (maxn) {
+    const size_t rec = 2 * sizeof(PetscInt) + sizeof(PetscScalar);
+    char *mine, *all;
+    ierr = PetscMalloc(rec * (size_t)maxn, &mine);CHKERRQ(ierr);
+    ierr = PetscMalloc(rec * (size_t)maxn * (size_t)size, &all);CHKERRQ(ierr);
+    memset(mine, 0, rec * (size_t)maxn);
+    memcpy(mine, s->i, sizeof(PetscInt) * (size_t)s->n);
+    memcpy(mine + sizeof(PetscInt) * (size_t)maxn, s->j, sizeof(PetscInt) * (size_t)s->n);
+    memcpy(mine + 2 * sizeof(PetscInt) * (size_t)maxn, s->v, sizeof(PetscScalar) * (size_t)s->n);
+    if (HipCommAllgather(comm, mine, (int)(rec * (size_t)maxn), all)) SETERRQ(comm, PETSC_ERR_LIB, "allgather failed");
+    ierr = PetscMalloc(sizeof(PetscInt) * (size_t)PetscMax(total, 1), ri);CHKERRQ(ierr);
+    ierr = PetscMalloc(sizeof(PetscInt) * (size_t)PetscMax(total, 1), rj);CHKERRQ(ierr);
+    ierr = PetscMalloc(sizeof(PetscScalar) * (size_t)PetscMax(total, 1), rv);CHKERRQ(ierr);
+    PetscInt k = 0;
+    for (int r = 0; r < size; r++) {
+      const char *blk = all + rec * (size_t)maxn * (size_t)r;
+      const PetscInt cnt = hdrs[2 * r];
+      memcpy(*ri + k, blk, sizeof(PetscInt) * (size_t)cnt);
+      memcpy(*rj + k, blk + sizeof(PetscInt) * (size_t)maxn, sizeof(PetscInt) * (size_t)cnt);
+      memcpy(*rv + k, blk + 2 * sizeof(PetscInt) * (size_t)maxn, sizeof(PetscScalar) * (size_t)cnt);
+      k += cnt;
+    }
+    *nrecv = total;
+    HipFree(mine); HipFree(all);
+  }
+  HipFree(hdrs);
+  s->n = 0; s->mode = 0;
+  return 0;
+}

@@ -36,13 +36,22 @@ static PetscErrorCode MatSetUp_MPIAIJHIP(Mat A) { return MatMPIAIJSetPreallocati
 
 static int cmp_int(const void *a, const void *b) { PetscInt x = *(const PetscInt *)a, y = *(const PetscInt *)b; return (x > y) - (x < y); }
 
-/* MatSetValues_MPIAIJ, mpiaij.c:517-560: locally owned rows only (the reference stashes the rest) */
+/* MatSetValues_MPIAIJ, mpiaij.c:517-560: locally owned rows go into A / B; rows of other processes are stashed until the
+ * assembly (mpiaij.c:552-558, matstash.c), unless MAT_NO_OFF_PROC_ENTRIES-like behaviour is asked with nothing */
 static PetscErrorCode MatSetValues_MPIAIJHIP(Mat A, PetscInt m, const PetscInt im[], PetscInt n, const PetscInt in[], const PetscScalar v[], InsertMode addv) {
   PetscErrorCode ierr;
   HipMPIAIJ *a = MA(A);
   for (PetscInt i = 0; i < m; i++) {
     if (im[i] < 0) continue;
-    if (im[i] < a->rstart || im[i] >= a->rend) SETERRQ(HipObjComm(A), PETSC_ERR_SUP, "row %d is not owned by this process [%d,%d): off-process MatSetValues is outside the ported path", im[i], a->rstart, a->rend);
+    if (im[i] >= A->rmap->N) SETERRQ(HipObjComm(A), PETSC_ERR_ARG_OUTOFRANGE, "Row too large: row %d max %d", im[i], A->rmap->N - 1);
+    if (im[i] < a->rstart || im[i] >= a->rend) {
+      for (PetscInt j = 0; j < n; j++) {
+        if (in[j] < 0) continue;
+        if (in[j] >= A->cmap->N) SETERRQ(HipObjComm(A), PETSC_ERR_ARG_OUTOFRANGE, "Column too large: col %d max %d", in[j], A->cmap->N - 1);
+        ierr = HipStashAdd(&a->stash, im[i], in[j], v[i * n + j], (int)addv);CHKERRQ(ierr);
+      }
+      continue;
+    }
     PetscInt row = im[i] - a->rstart;
     for (PetscInt j = 0; j < n; j++) {
       PetscInt col = in[j];
@@ -97,9 +106,20 @@ PetscErrorCode MatSetUpMultiply_MPIAIJ(Mat mat) {
   return 0;
 }
 
-static PetscErrorCode MatAssemblyEnd_MPIAIJHIP(Mat A, MatAssemblyType mode) {   /* mpiaij.c:650-720 */
+static PetscErrorCode MatAssemblyEnd_MPIAIJHIP(Mat A, MatAssemblyType mode) {   /* mpiaij.c:590-720 */
   PetscErrorCode ierr;
   HipMPIAIJ *a = MA(A);
+  {   /* the stashed off-process entries reach their owners (MatAssemblyBegin/End_MPIAIJ: MatStashScatterBegin .. GetMesg),
+       * rank after rank and in the order they were set */
+    PetscInt nr, *ri, *rj; PetscScalar *rv; int smode;
+    ierr = HipStashExchange(HipObjComm(A), &a->stash, &nr, &ri, &rj, &rv, &smode);CHKERRQ(ierr);
+    for (PetscInt k = 0; k < nr; k++) {
+      if (ri[k] < a->rstart || ri[k] >= a->rend) continue;
+      ierr = MatSetValues_MPIAIJHIP(A, 1, &ri[k], 1, &rj[k], &rv[k], (InsertMode)smode);
+      if (ierr) { HipFree(ri); HipFree(rj); HipFree(rv); CHKERRQ(ierr); }
+    }
+    HipFree(ri); HipFree(rj); HipFree(rv);
+  }
   if (mode == MAT_FLUSH_ASSEMBLY) return 0;
   ierr = MatAssemblyBegin(a->A, mode);CHKERRQ(ierr);
   ierr = MatAssemblyEnd(a->A, mode);CHKERRQ(ierr);
@@ -199,6 +219,7 @@ static PetscErrorCode MatDestroy_MPIAIJHIP(Mat A) {
   ierr = VecDestroy(&a->lvec);CHKERRQ(ierr);
   ierr = HipScatterDestroy(&a->hscat);CHKERRQ(ierr);
   HipFree(a->garray);
+  HipStashFree(&a->stash);
   HipFree(a); A->data = NULL;
   return 0;
 }

@@ -111,11 +111,35 @@ static PetscErrorCode VecSetValues_HIP(Vec v, PetscInt ni, const PetscInt ix[], 
   PetscErrorCode ierr = VecGetArray_HIP(v, &a);CHKERRQ(ierr);
   for (PetscInt k = 0; k < ni; k++) {
     if (ix[k] < 0) continue;
-    if (ix[k] < v->map->rstart || ix[k] >= v->map->rend) SETERRQ(HipObjComm(v), PETSC_ERR_SUP, "off-process VecSetValues (index %d outside [%d,%d)) is outside the ported path", ix[k], v->map->rstart, v->map->rend);
+    if (ix[k] >= v->map->N) { VecRestoreArray_HIP(v, NULL); SETERRQ(HipObjComm(v), PETSC_ERR_ARG_OUTOFRANGE, "Out of range index value %d maximum %d", ix[k], v->map->N); }
+    if (ix[k] < v->map->rstart || ix[k] >= v->map->rend) {   /* VecSetValues_MPI (pdvec.c): stashed until VecAssemblyBegin */
+      ierr = HipStashAdd(&VH(v)->stash, ix[k], 0, y[k], (int)mode);
+      if (ierr) { VecRestoreArray_HIP(v, NULL); CHKERRQ(ierr); }
+      continue;
+    }
     if (mode == INSERT_VALUES) a[ix[k] - v->map->rstart] = y[k];
     else a[ix[k] - v->map->rstart] += y[k];
   }
   return VecRestoreArray_HIP(v, NULL);
+}
+
+/* VecAssemblyBegin_MPI / End_MPI (pdvec.c): the stashed off-process entries reach their owners, rank after rank */
+static PetscErrorCode VecAssemblyBegin_HIP(Vec v) {
+  PetscErrorCode ierr;
+  PetscInt nr, *ri, *rj; PetscScalar *rv, *a = NULL; int smode;
+  ierr = HipStashExchange(HipObjComm(v), &VH(v)->stash, &nr, &ri, &rj, &rv, &smode);CHKERRQ(ierr);
+  if (nr) {
+    ierr = VecGetArray_HIP(v, &a);CHKERRQ(ierr);
+    for (PetscInt k = 0; k < nr; k++) {
+      if (ri[k] < v->map->rstart || ri[k] >= v->map->rend) continue;
+      if (smode == (int)INSERT_VALUES) a[ri[k] - v->map->rstart] = rv[k];
+      else a[ri[k] - v->map->rstart] += rv[k];
+    }
+    ierr = VecRestoreArray_HIP(v, NULL);CHKERRQ(ierr);
+    HipStateIncrease(v);
+  }
+  HipFree(ri); HipFree(rj); HipFree(rv);
+  return 0;
 }
 
 /* ---- element-wise ops ---- */
@@ -622,6 +646,7 @@ static PetscErrorCode VecDestroy_HIP(Vec v) {
   if (s->alias_save) { s->dev = s->alias_save; s->alias_save = NULL; }   /* never free storage borrowed from another vector */
   if (s->dev) mi355x_free(s->dev);
   if (s->host && s->host_owned) HipFree(s->host);
+  HipStashFree(&s->stash);
   HipFree(s);
   v->data = NULL;
   return 0;
@@ -756,6 +781,7 @@ static PetscErrorCode VecCreate_HIP_common(Vec v, const char *tname) {
   v->ops->pointwisemult = VecPointwiseMult_HIP;
   v->ops->pointwisedivide = VecPointwiseDivide_HIP;
   v->ops->setvalues = VecSetValues_HIP;
+  v->ops->assemblybegin = VecAssemblyBegin_HIP;
   v->ops->getarray = VecGetArray_HIP;
   v->ops->restorearray = VecRestoreArray_HIP;
   v->ops->placearray = VecPlaceArray_HIP;

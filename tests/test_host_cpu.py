@@ -228,6 +228,83 @@ def test_mpiaij_setup_irregular(built, size):
     check_mpiaij_setup(P, size, ai, aj, aa, ranges, via_setvalues=True)
 
 
+@pytest.mark.parametrize("size", [2, 3, 4])
+def test_off_process_setvalues_are_stashed_and_assembled(built, size):
+    """MatSetValues / VecSetValues into rows owned by OTHER ranks (mpiaij.c:552-558, matstash.c; pdvec.c): a 1-D chain of
+    2-node elements dealt round-robin to the ranks, so most contributions are off-process; after assembly every rank's
+    diagonal / off-diagonal blocks, garray and scatter lists equal the oracle's split of the globally summed matrix, the
+    load vector equals the sum too (both orders of contributions are rank order: compared exactly with that order), and mixing
+    INSERT on one rank with ADD on another is the reference's error."""
+    from petsc_dev_amd import petsc as P
+    from fakempi import FakeWorld
+    L = P.lib()
+    N = 41
+    ne = N - 1
+    ke = np.array([[2.0, -1.0], [-1.0, 2.0]])
+    rng = np.random.default_rng(3)
+    scale = 1.0 + rng.random(ne)
+    fe = rng.standard_normal((ne, 2))
+    ranges = np.array([0] + list(np.cumsum([N // size + (N % size > r) for r in range(size)])), dtype=np.int32)
+    owner_of_elem = [e % size for e in range(ne)]
+
+    # expected sums, in the order the entries reach a row: the owner's own contributions as they are set, then the stashed
+    # ones rank after rank, each rank's in its element order
+    dense = np.zeros((N, N)); load = np.zeros(N)
+    for row_owner in range(size):
+        lo, hi = int(ranges[row_owner]), int(ranges[row_owner + 1])
+        # local first (set order), then every rank's stash in rank order (the owner's own stash is empty for its rows)
+        order = [row_owner] + [r for r in range(size) if r != row_owner]
+        for src in order:
+            for e in range(ne):
+                if owner_of_elem[e] != src:
+                    continue
+                for a in range(2):
+                    if lo <= e + a < hi:
+                        load[e + a] += fe[e, a]
+                        for b in range(2):
+                            dense[e + a, e + b] += scale[e] * ke[a, b]
+    import scipy.sparse as sp
+    S = sp.csr_matrix(dense); S.sort_indices()
+    ai, aj, aa = S.indptr.astype(np.int32), S.indices.astype(np.int32), S.data.copy()
+
+    def work(rank, comm):
+        rs, re_ = int(ranges[rank]), int(ranges[rank + 1])
+        A = P.Mat()
+        L.MatCreate(comm, C.byref(A.h)); L.MatSetSizes(A.h, re_ - rs, re_ - rs, N, N); L.MatSetType(A.h, b"aijhipmi355x")
+        L.MatMPIAIJSetPreallocation(A.h, 3, None, 2, None)
+        v = P.Vec.create(re_ - rs, N=N, comm=comm)
+        for e in range(ne):
+            if owner_of_elem[e] != rank:
+                continue
+            idx = np.array([e, e + 1], dtype=np.int32)
+            vals = (scale[e] * ke).ravel().copy()
+            L.MatSetValues(A.h, 2, idx.ctypes.data_as(C.c_void_p), 2, idx.ctypes.data_as(C.c_void_p), vals.ctypes.data_as(C.c_void_p), P.ADD_VALUES)
+            L.VecSetValues(v.h, 2, idx.ctypes.data_as(C.c_void_p), fe[e].copy().ctypes.data_as(C.c_void_p), P.ADD_VALUES)
+        L.MatAssemblyBegin(A.h, P.MAT_FINAL_ASSEMBLY); L.MatAssemblyEnd(A.h, P.MAT_FINAL_ASSEMBLY)
+        L.VecAssemblyBegin(v.h); L.VecAssemblyEnd(v.h)
+        out = mpiaij_pieces(P, A.h), v.array().copy()
+        A.destroy()
+        return out
+
+    got = FakeWorld(size).run(work)
+    check_against_oracle(size, [g[0] for g in got], ai, aj, aa, ranges)
+    assert np.array_equal(np.concatenate([g[1] for g in got]), load)
+
+    def mixed(rank, comm):
+        rs, re_ = int(ranges[rank]), int(ranges[rank + 1])
+        v = P.Vec.create(re_ - rs, N=N, comm=comm)
+        other = np.array([int(ranges[(rank + 1) % size])], dtype=np.int32)          # a row of the next rank
+        one = np.ones(1)
+        L.VecSetValues(v.h, 1, other.ctypes.data_as(C.c_void_p), one.ctypes.data_as(C.c_void_p), P.INSERT_VALUES if rank == 0 else P.ADD_VALUES)
+        try:
+            L.VecAssemblyBegin(v.h)
+        except P.PetscError as e:
+            return e.code
+        return 0
+
+    assert set(FakeWorld(size).run(mixed)) == {73}         # PETSC_ERR_ARG_WRONGSTATE on every rank
+
+
 def test_ex5_np3_layout(built):
     """src/mat/examples/tests/ex5.c on 3 ranks (golden ex5_23.out): 8x8 dense rows, PETSC_DECIDE split 3/3/2"""
     from petsc_dev_amd import petsc as P
