@@ -41,6 +41,7 @@ void   orc_vec_pointwise_mult(size_t n, const double *x, const double *y, double
 void   orc_vec_pointwise_divide(size_t n, const double *x, const double *y, double *w);  /* bvec2.c:298 */
 void   orc_vec_reciprocal(size_t n, double *x);                                          /* vinv.c VecReciprocal_Default */
 void   orc_vec_maxpy(size_t n, int nv, const double *alpha, const double *const *y, double *x); /* dvec2.c:836 */
+void   orc_set_device_reduction_order(int on);   /* test aid: reductions in the HIP kernels' summation tree instead of the reference's loop */
 double orc_vec_dot(size_t n, const double *x, const double *y);                          /* bvec1.c:57,122 */
 void   orc_vec_mdot(size_t n, int nv, const double *x, const double *const *y, double *z); /* dvec2.c:146 */
 /* type: 0 NORM_1, 1 NORM_2, 2 FROBENIUS, 3 INFINITY, 4 NORM_1_AND_2 (out[0],out[1]) */

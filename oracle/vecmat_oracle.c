@@ -104,7 +104,57 @@ void orc_vec_maxpy(size_t n, int nv, const double *alpha, const double *const *y
 }
 
 /* VecDot_Seq/VecTDot_Seq, src/vec/vec/impls/seq/bvec1.c:57,122: ddot_, netlib order (left to right) */
+/* ---- the device's summation order (test aid).  The reference adds the terms of a dot product one after the other (BLAS
+ * ddot / the loops of dvec2.c); the HIP reductions add the same terms in a fixed tree (csrc/vec_kernels.hip reduce_kernel:
+ * min(ceil(n/4096),1024) workgroups of 256 lanes, lane t of the grid takes the element pairs t, t+T, t+2T, ... in order,
+ * a shuffle-down tree over each wavefront, the four wavefronts in order, then one workgroup adds the per-workgroup sums the
+ * same way).  With orc_set_device_reduction_order(1) the oracle's reductions use that tree on the same terms, so that a whole
+ * Krylov solve can be compared with the HIP path bit for bit: whatever differs then is not summation order. ---- */
+static int dev_order = 0;
+void orc_set_device_reduction_order(int on) { dev_order = on; }
+typedef double (*orc_term_fn)(const double *a, const double *b, size_t i);
+static double term_mul(const double *a, const double *b, size_t i) { return a[i] * b[i]; }
+static double term_abs(const double *a, const double *b, size_t i) { (void)b; return fabs(a[i]); }
+static double tree64(double *v) {
+  for (int off = 32; off > 0; off >>= 1) for (int l = 0; l < off; l++) v[l] = v[l] + v[l + off];
+  return v[0];
+}
+static double block256(double *lanes) {
+  double w0 = tree64(lanes), w1 = tree64(lanes + 64), w2 = tree64(lanes + 128), w3 = tree64(lanes + 192);
+  double s = w0; s = s + w1; s = s + w2; s = s + w3;
+  return s;
+}
+static double dev_reduce(size_t n, orc_term_fn f, const double *a, const double *b) {
+  size_t grid = (n + 4095) / 4096;
+  if (grid < 1) grid = 1;
+  if (grid > 1024) grid = 1024;
+  const size_t T = grid * 256, n2 = n >> 1;
+  double *partial = (double *)malloc(sizeof(double) * grid), lanes[256], res;
+  for (size_t blk = 0; blk < grid; blk++) {
+    for (size_t t = 0; t < 256; t++) {
+      const size_t tid = blk * 256 + t;
+      double acc = 0.0;
+      for (size_t i = tid; i < n2; i += T) { acc = acc + f(a, b, 2 * i); acc = acc + f(a, b, 2 * i + 1); }
+      if ((n & 1) && tid == 0) acc = acc + f(a, b, n - 1);
+      lanes[t] = acc;
+    }
+    partial[blk] = block256(lanes);
+  }
+  if (grid == 1) res = partial[0];
+  else {
+    for (size_t t = 0; t < 256; t++) {
+      double acc = 0.0;
+      for (size_t blk = t; blk < grid; blk += 256) acc = acc + partial[blk];
+      lanes[t] = acc;
+    }
+    res = block256(lanes);
+  }
+  free(partial);
+  return res;
+}
+
 double orc_vec_dot(size_t n, const double *x, const double *y) {
+  if (dev_order) return dev_reduce(n, term_mul, x, y);
   double s = 0.0;
   for (size_t i = 0; i < n; i++) s = s + x[i] * y[i];
   return s;
@@ -130,7 +180,7 @@ static double mdot_one(size_t n, const double *x, const double *y) {
   return sum;
 }
 void orc_vec_mdot(size_t n, int nv, const double *x, const double *const *y, double *z) {
-  for (int j = 0; j < nv; j++) z[j] = mdot_one(n, x, y[j]);
+  for (int j = 0; j < nv; j++) z[j] = dev_order ? dev_reduce(n, term_mul, x, y[j]) : mdot_one(n, x, y[j]);
 }
 
 /* VecNorm_Seq, src/vec/vec/impls/seq/bvec2.c:605-642 */
@@ -147,6 +197,7 @@ void orc_vec_norm(size_t n, int type, const double *x, double *out) {
     out[0] = max;
   } else if (type == 0) {
     double s = 0.0;
+    if (dev_order) { out[0] = dev_reduce(n, term_abs, x, x); return; }
     for (i = 0; i < n; i++) s = s + fabs(x[i]);   /* dasum */
     out[0] = s;
   } else if (type == 4) {
@@ -158,6 +209,7 @@ void orc_vec_norm(size_t n, int type, const double *x, double *out) {
 /* VecDotNorm2 default branch, src/vec/vec/utils/vinv.c:1222-1234 */
 void orc_vec_dotnorm2(size_t n, const double *s, const double *t, double *dp, double *nm) {
   double dpx = 0.0, nmx = 0.0;
+  if (dev_order) { *dp = dev_reduce(n, term_mul, s, t); *nm = dev_reduce(n, term_mul, t, t); return; }
   for (size_t i = 0; i < n; i++) { dpx += s[i] * t[i]; nmx += t[i] * t[i]; }
   *dp = dpx; *nm = nmx;
 }

@@ -124,6 +124,16 @@ def matmult(ai, aj, aa, x, z=None):
     return y, nodes
 
 
+class device_reduction_order:
+    """with orc.device_reduction_order(): the oracle's dots / norms use the HIP reduction tree (same terms, same order), so a
+    whole solve can be compared with the HIP path bit for bit"""
+    def __enter__(self):
+        lib().orc_set_device_reduction_order(C.c_int(1))
+
+    def __exit__(self, *a):
+        lib().orc_set_device_reduction_order(C.c_int(0))
+
+
 def pbjacobi_setup(bs, bi, bj, ba):
     """inverted diagonal blocks (MatInvertBlockDiagonal_SeqBAIJ), column-major, mbs x bs x bs"""
     mbs = bi.size - 1

@@ -262,6 +262,37 @@ def test_gmres_fused_equals_op_by_op_bit_for_bit(P, pc, opts):
         assert abs(ito - it1) <= 1 and np.allclose(ho[:50], h1[:50], rtol=1e-9, atol=0)
 
 
+@pytest.mark.parametrize("ksp,pc,opts", [("cg", "jacobi", ""), ("cg", "none", ""), ("cg", "jacobi", "-ksp_cg_fused 0"), ("gmres", "jacobi", ""),
+                                        ("gmres", "ilu", ""), ("gmres", "none", "-ksp_gmres_restart 9"), ("bcgs", "jacobi", ""), ("bcgs", "none", ""),
+                                        ("groppcg", "jacobi", ""), ("cg", "jacobi", "-ksp_norm_type natural")])
+def test_whole_solves_equal_the_oracle_bit_for_bit_in_the_device_summation_order(P, ksp, pc, opts):
+    """The parity tolerances elsewhere in this file exist for ONE reason: the reference adds the terms of a dot product one
+    after the other, the HIP reductions add the same terms in a tree.  With the oracle's reductions switched to that tree
+    (orc.device_reduction_order(): same terms, restated order) every residual norm of the history, the iteration count, the
+    reason and the solution of a whole Krylov solve are bit-identical between the HIP path and the oracle -- CG, GMRES,
+    BiCGStab, GROPPCG, with Jacobi / ILU(0) / none, fused or op by op.  On two operators: 3-D 7-point (row-pattern SpMV
+    kernel) and a nonsymmetric variable-coefficient one (BiCGStab's recurrences amplify any last-bit difference: none left)."""
+    norm = 3 if "natural" in opts else 1
+    for which in ("p7", "nonsym"):
+        ai, aj, aa = orc.gen_p7(17, 15, 13)
+        if which == "nonsym":
+            aa = aa * (1.0 + 0.3 * np.sin(0.7 * np.arange(aa.size)))
+            if ksp in ("cg", "groppcg"):
+                continue
+        n = ai.size - 1
+        b = np.cos(0.37 * np.arange(n)) + 0.1
+        kw = dict(rtol=1e-10, max_it=300)
+        x, h, its, reason = solve(P, ai, aj, aa, b, ksp, pc, opts=opts, **kw)
+        okw = {}
+        if "-ksp_gmres_restart" in opts:
+            okw["restart"] = 9
+        with orc.device_reduction_order():
+            xo, ho, ito, ro = orc.ksp_solve(ai, aj, aa, b, ksp=ksp, pc=pc, norm_type=norm, **kw, **okw)
+        assert (its, reason) == (ito, ro) and its > 5
+        assert np.array_equal(h.view(np.uint64), ho.view(np.uint64)), (which, np.max(np.abs(h - ho) / ho))
+        assert np.array_equal(x.view(np.uint64), xo.view(np.uint64))
+
+
 @pytest.mark.parametrize("bs", [2, 3, 4, 5])
 def test_pbjacobi_on_baij(P, bs):
     """PCPBJACOBI on the BAIJ type (pbjacobi.c + MatInvertBlockDiagonal_SeqBAIJ baij.c:13): PCApply equals the

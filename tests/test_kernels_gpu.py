@@ -170,6 +170,34 @@ def test_scale_rnorm_dev_special_cases(dev):
     dev.free(dn); dev.free(dx)
 
 
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 257, 4095, 4097, 70001, 1 << 20, 5000001])
+def test_reductions_equal_the_oracle_in_the_device_summation_order(dev, n):
+    """orc.device_reduction_order() restates reduce_kernel's tree (per-lane strided pair sums -> shuffle-down tree -> four
+    wavefronts in order -> one workgroup over the per-workgroup sums): dot, norms, dot+norm2 and MDot are then bit-identical"""
+    k = dev.k
+    x, y = rnd(n, 20), rnd(n, 21)
+    ys = [rnd(n, 200 + j) for j in range(5)]
+    dx, dy = dev.put(x), dev.put(y)
+    dys = [dev.put(v) for v in ys]
+    with orc.device_reduction_order():
+        ref_dot = orc.vec_dot(x, y)
+        ref_n2 = orc.vec_norm(x, 1); ref_n1 = orc.vec_norm(x, 0)      # oracle types: 0 = NORM_1, 1 = NORM_2
+        ref_dn = orc.vec_dotnorm2(x, y)
+        ref_md = orc.vec_mdot(x, ys)
+    dev.chk(k.mi355x_vec_dot(dev.h, n, dx, dy, dev.host_scratch()))
+    assert_bitexact(dev.scalar_out(1), np.array([ref_dot]))
+    dev.chk(k.mi355x_vec_norm(dev.h, n, 2, dx, dev.host_scratch()))
+    assert_bitexact(np.sqrt(dev.scalar_out(1)), np.array([ref_n2]))
+    dev.chk(k.mi355x_vec_norm(dev.h, n, 0, dx, dev.host_scratch()))
+    assert_bitexact(dev.scalar_out(1), np.array([ref_n1]))
+    dev.chk(k.mi355x_vec_dotnorm2(dev.h, n, dx, dy, dev.host_scratch()))
+    assert_bitexact(dev.scalar_out(2), np.array(ref_dn))
+    dev.chk(k.mi355x_vec_mdot(dev.h, n, 5, dx, dev.ptr_table(dys), dev.host_scratch()))
+    assert_bitexact(dev.scalar_out(5), np.array(ref_md))
+    for p in [dx, dy] + dys:
+        dev.free(p)
+
+
 @pytest.mark.parametrize("n", SIZES)
 def test_reductions(dev, n):
     k = dev.k
