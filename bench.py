@@ -172,6 +172,8 @@ def main():
         "ksp_gbps_basis": "SURVEY 8(d) algorithmic bytes of the reference's op-by-op iteration (SpMV + 17 vector passes); the fused CG update moves 13 passes",
         "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": round(spmv_gbps_one, 1), "peak": 8000.0,
                      "unit": "GB/s", "frac": round(spmv_gbps_one / 8000.0, 4), "traffic": None,
+                     "basis": "achieved/frac price the launch in the reference CSR's bytes (SURVEY 8d: 12 B per nonzero + 4 B per row + x + y); "
+                              "a kernel that streams fewer index bytes can exceed 1.0 on that basis -- traffic / traffic_frac are the bytes it really moved",
                      "algorithmic_bytes_per_launch": spmv_bytes, "avg_launch_ms": round(spmv_ms, 5), "launches_timed": nl.value},
         "setup_s": round(setup_s, 2),
     }
