@@ -818,6 +818,18 @@ def test_ksp_golden_ex4_and_ex5_two_systems(P):
         assert np.linalg.norm(vx.array() - u) < 1e-4 * np.linalg.norm(u)
 
 
+@pytest.mark.parametrize("name,rtol,fused", [("ex1_1.out", 1e-5, 1), ("ex23_1.out", 1e-7, 1), ("ex23_1.out", 1e-7, 0)])
+def test_ksp_golden_ex1_ex23_happy_breakdown(P, name, rtol, fused):
+    """tutorials ex1.c / ex23.c vs output/ex1_1.out, ex23_1.out on the HIP path: GMRES + PCJACOBI on the tridiagonal n = 10
+    system ends in its happy-breakdown branch after 5 steps ('< 1.e-11'), fused or op by op"""
+    ai, aj, aa = pb.tridiag(10)
+    b = orc.spmv(ai, aj, aa, np.ones(10))
+    gold = pb.parse_monitor(os.path.join(G, "ksp_tutorials", name))[0]
+    x, h, its, reason = solve(P, ai, aj, aa, b, "gmres", "jacobi", opts="-ksp_gmres_cgs_refinement_type refine_always -ksp_gmres_fused %d" % fused, rtol=rtol)
+    pb.check_monitor(h, gold)
+    assert its == 5 and reason > 0 and np.linalg.norm(x - 1.0) <= 1e-11
+
+
 def test_ksp_golden_ex3_ex2f_ex9(P):
     (ai, aj, aa), b, u0, ustar = pb.ex3_fem(5)
     gold = pb.parse_monitor(os.path.join(G, "ksp_tests", "ex3_1.out"))[0]

@@ -83,6 +83,20 @@ def test_pc_tests_ex2_cg_golden():
     assert its == 5 and reason == 2 and np.linalg.norm(x - 1.0) <= 1e-14   # the example prints the error only above 1e-14
 
 
+@pytest.mark.parametrize("name,rtol", [("ex1_1.out", 1e-5), ("ex23_1.out", 1e-7), ("ex23_2.out", 1e-7)])
+def test_tutorial_ex1_ex23_gmres_jacobi_happy_breakdown(name, rtol):
+    """src/ksp/ksp/examples/tutorials/ex1.c and ex23.c (1 and 3 ranks), -ksp_monitor_short refine_always (makefile:295,862,868)
+    vs output/ex1_1.out, ex23_1.out, ex23_2.out: tridiagonal n = 10, GMRES(30) + PCJACOBI, b = A*1.  The Krylov space is
+    exhausted after n/2 = 5 steps: the last line is '< 1.e-11' and the solve ends through GMRES's happy-breakdown branch
+    (gmres.c:171-178,200-203).  The examples print the error only when it exceeds 1e-11: it must not."""
+    ai, aj, aa = pb.tridiag(10)
+    b = orc.spmv(ai, aj, aa, np.ones(10))
+    gold = pb.parse_monitor(os.path.join(G, "ksp_tutorials", name))[0]
+    x, h, its, reason = orc.ksp_solve(ai, aj, aa, b, ksp="gmres", pc="jacobi", refine_always=1, rtol=rtol)
+    pb.check_monitor(h, gold)
+    assert its == 5 and reason > 0 and np.linalg.norm(x - 1.0) <= 1e-11
+
+
 def test_ksp_tests_ex4_golden():
     """src/ksp/ksp/examples/tests/ex4.c -m 5 -pc_type jacobi refine_always (makefile:197) vs output/ex4_1.out: the
     Q1 Laplacian of ex3.c assembled sequentially (MatZeroRows boundary rows, non-zero initial guess)"""
