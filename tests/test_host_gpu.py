@@ -196,6 +196,45 @@ def test_mat_ex5_golden(P, name, rect, mtype):
     assert np.array_equal(bits(w.array()), bits(orc.matmult(ai2, aj2, aa2, yy)[0]))
 
 
+@pytest.mark.parametrize("name,mtype", [("ex5_31.out", "aij"), ("ex5_32.out", "baij")])
+def test_mat_ex5_diagonalscale_golden_aij_and_baij(P, name, mtype):
+    """src/mat/examples/tests/ex5.c -test_diagonalscale with -mat_type mpiaij / mpibaij on one rank (makefile:796-804) vs
+    output/ex5_31.out, ex5_32.out: MatMult, MatMultTranspose, MatGetDiagonal and the matrix after MatDiagonalScale(C, x, y),
+    every printed number.  ex5_32.out is the one output the reference holds for the BAIJ type on this path (block size 1:
+    MatMult_SeqBAIJ_1); it equals the AIJ output, as the BAIJ type here equals the AIJ type at block size 1."""
+    import re
+    L = P.lib()
+    ai, aj, aa, m, n = pb.ex5_mat(8, rect=0, alpha=1.0)
+    A = P.Mat.from_csr(ai, aj, aa, ncols=n) if mtype == "aij" else P.Mat.from_bsr(1, ai, aj, aa)
+    L.MatScale(A.h, 0.1)
+    text = open(os.path.join(G, name)).read()
+    gold = pb.parse_vecview(os.path.join(G, name))
+    fmt = lambda v: np.array([float("%g" % t) for t in v])  # noqa: E731
+    y = V(P, np.arange(n, dtype=np.float64)); x = V(P, np.zeros(m))
+    L.MatMult(A.h, y.h, x.h)
+    assert np.array_equal(fmt(x.array()), gold[0])
+    x.set_array(np.arange(m, dtype=np.float64))
+    L.MatMultTranspose(A.h, x.h, y.h)
+    assert np.array_equal(fmt(y.array()), gold[1])
+    L.VecSet(x.h, 1.0)
+    L.MatGetDiagonal(A.h, x.h)
+    assert np.array_equal(fmt(x.array()), gold[2])
+    y.set_array(np.arange(1, n + 1, dtype=np.float64))
+    L.MatDiagonalScale(A.h, x.h, y.h)
+    # the two MatView blocks of the golden: before and after the scaling
+    views = text.split("Matrix Object:")[1:]
+    assert len(views) == 2
+    want = np.array([[float(v) for _, v in re.findall(r"\((\d+), ([-0-9.e+]+)\)", line)] for line in views[1].splitlines() if line.startswith("row ")])
+    m_, i_, j_, a_ = C.c_int(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+    L.MatSeqAIJGetArrays(A.h, C.byref(m_), C.byref(i_), C.byref(j_), C.byref(a_))
+    vals = np.ctypeslib.as_array(C.cast(a_, C.POINTER(C.c_double)), (m * n,)).reshape(m, n)
+    assert np.array_equal(fmt(vals.ravel()).reshape(m, n), want)
+    # and the device copy was scaled side by side: the product with ones equals the row sums of the printed matrix
+    ones = V(P, np.ones(n)); r = V(P, np.zeros(m))
+    L.MatMult(A.h, ones.h, r.h)
+    assert np.allclose(r.array(), vals.sum(1), rtol=1e-14)
+
+
 def test_mat_p7_and_transpose_bitexact(P):
     L = P.lib()
     ai, aj, aa = P.gen_poisson7(20, 17, 13)
