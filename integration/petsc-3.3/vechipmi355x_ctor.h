@@ -8,7 +8,7 @@
 #include <../src/vec/vec/impls/dvecimpl.h>       /* VecGetSize_Seq, VecView_Seq */
 #include <../src/vec/vec/impls/mpi/pvecimpl.h>   /* VecGetSize_MPI, VecView_MPI */
 
-static PetscErrorCode VecAssemblyNoop_HIP(Vec v) { (void)v; return 0; }   /* off-process VecSetValues is refused, nothing to flush */
+static PetscErrorCode VecAssemblyNoop_HIP(Vec v) { (void)v; return 0; }   /* VecAssemblyBegin_HIP (vechip.c) has delivered the stash already */
 
 static PetscErrorCode VecCreate_HIP_petsc33(Vec v, PetscBool mpi) {
   PetscFunctionBegin;
@@ -18,7 +18,7 @@ static PetscErrorCode VecCreate_HIP_petsc33(Vec v, PetscBool mpi) {
   v->ops->getlocalsize  = VecGetSize_Seq;
   v->ops->view          = mpi ? VecView_MPI : VecView_Seq;     /* read through VecGetArrayRead -> ops->getarray (petscnative == PETSC_FALSE) */
   v->ops->load          = VecLoad_Default;
-  v->ops->assemblybegin = VecAssemblyNoop_HIP;
+  v->ops->assemblybegin = VecAssemblyBegin_HIP;               /* off-process VecSetValues: the type's own stash (it carries no Vec_MPI) */
   v->ops->assemblyend   = VecAssemblyNoop_HIP;
   v->ops->dot_local     = VecDot_HIP_local;                    /* the split-phase reductions of comb.c use the _local slots */
   v->ops->tdot_local    = VecDot_HIP_local;
