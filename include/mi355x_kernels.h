@@ -258,6 +258,10 @@ int mi355x_ilu0_upper_level(mi355x_handle_t h, int nrows, const int *rows, const
 typedef struct mi355x_trisolve_plan_s *mi355x_trisolve_plan_t;
 int mi355x_trisolve_plan_create(mi355x_handle_t h, int n, int nlev, const int *lev, const int *rp, const int *rl, const int *cj,
                                 const double *cv, const double *dinv, mi355x_trisolve_plan_t *plan);
+/* by_level != 0: rows summed in the order of their dependencies' levels instead of column order (factors of inode matrices;
+ * tolerance instead of bit-exactness against MatSolve_SeqAIJ_NaturalOrdering), large levels on slice boundaries */
+int mi355x_trisolve_plan_create_ordered(mi355x_handle_t h, int n, int nlev, const int *lev, const int *rp, const int *rl, const int *cj,
+                                        const double *cv, const double *dinv, int by_level, mi355x_trisolve_plan_t *plan);
 int mi355x_trisolve_plan_destroy(mi355x_trisolve_plan_t plan);
 int mi355x_trisolve_apply(mi355x_handle_t h, mi355x_trisolve_plan_t lower, mi355x_trisolve_plan_t upper, const double *b, double *y);
 int mi355x_trisolve_aborted(mi355x_trisolve_plan_t plan, int *aborted);

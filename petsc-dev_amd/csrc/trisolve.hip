@@ -80,6 +80,7 @@ int mi355x_ilu0_upper_level(mi355x_handle_t h, int nrows, const int *rows, const
 #define TRI_SENTINEL 0xFFF8DEADBEEFCAFEull
 #define TRI_QUEUES 8
 #define TRI_QSTRIDE 16          // queue counters 64 bytes apart
+#define TRI_ALIGN_MIN 32        // by_level plans: levels of at least this many rows start on a slice boundary
 #define TRI_SPIN_LIMIT (1 << 19)   // x ~1 us per poll once backed off: gives up after ~0.5 s
 
 struct mi355x_trisolve_plan_s {
@@ -127,10 +128,14 @@ __global__ __launch_bounds__(MI355X_BLOCK) void trisolve_syncfree_kernel(
     int nslices, int nchunks, const int *__restrict__ ptr, const int *__restrict__ info, const int *__restrict__ rowof,
     const int *__restrict__ col, const double *__restrict__ val, const double *__restrict__ dinv,
     const unsigned char *__restrict__ nsub, const double *src, const int *__restrict__ spos, double *w, double *y,
-    double *reset, unsigned int *queue, unsigned int *other_queue, int *abort_flag, int sleep_cap) {
+    double *reset, int reset_n, unsigned int *queue, unsigned int *other_queue, int *abort_flag, int sleep_cap) {
   __shared__ int chunk_s[2];
   const int tid = threadIdx.x, lane = tid & (MI355X_WAVE - 1), wave = tid / MI355X_WAVE;
   if (blockIdx.x == 0 && tid < TRI_QUEUES) other_queue[tid * TRI_QSTRIDE] = 0u;
+  if (!UPPER) {   // the other solve's vector may be longer than this one's (its own level padding): the tail is re-armed here
+    for (long i = (long)nslices * MI355X_WAVE + (long)blockIdx.x * MI355X_BLOCK + tid; i < reset_n; i += (long)gridDim.x * MI355X_BLOCK)
+      reset[i] = __longlong_as_double((long long)TRI_SENTINEL);
+  }
   const int q = blockIdx.x % TRI_QUEUES;
   for (int it = 0;; ++it) {
     if (tid == 0) {
@@ -152,7 +157,7 @@ __global__ __launch_bounds__(MI355X_BLOCK) void trisolve_syncfree_kernel(
       if (UPPER) { const int p = spos[row]; sum = src[p]; reset[p] = __longlong_as_double((long long)TRI_SENTINEL); }
       else sum = src[row];
     }
-    if (!UPPER) reset[t] = __longlong_as_double((long long)TRI_SENTINEL);
+    if (!UPPER && t < reset_n) reset[t] = __longlong_as_double((long long)TRI_SENTINEL);
     const double di = UPPER ? dinv[t] : 1.0;
     for (int step = 0; step < ns; ++step) {
       if (row >= 0 && mysub == step) {
@@ -193,14 +198,18 @@ extern "C" {
 // Host analysis + upload.  n rows; lev[i] = dependency level of row i (0-based, every level non-empty); len(i) and
 // the entries of row i come from (rp, cj, cv): row i's off-diagonal entries are cj/cv[rp[i] .. rp[i] + rl[i]).
 // dinv_host != NULL marks the upper solve (inverted diagonals per row).
-int mi355x_trisolve_plan_create(mi355x_handle_t h, int n, int nlev, const int *lev, const int *rp, const int *rl, const int *cj,
-                                const double *cv, const double *dinv_host, mi355x_trisolve_plan_t *out) {
+// by_level != 0: every row's entries are stored -- and therefore summed -- in the order of their dependencies' levels (oldest
+// first, column order among equals) instead of column order, and a level of TRI_ALIGN_MIN rows or more starts on a slice
+// boundary.  A row then waits only on its LAST entries, after everything older has been consumed, and a wavefront does not
+// hold rows of two large levels.  For factors of matrices with inodes (3-dof FEM: ~38 entries per row, recent dependencies
+// in the middle of the column order) the reference itself runs another routine with another order (MatSolve_SeqAIJ_Inode,
+// inode.c); results then agree with the natural-ordering loop to rounding, not bit for bit.  Deterministic either way.
+int mi355x_trisolve_plan_create_ordered(mi355x_handle_t h, int n, int nlev, const int *lev, const int *rp, const int *rl, const int *cj,
+                                        const double *cv, const double *dinv_host, int by_level, mi355x_trisolve_plan_t *out) {
   mi355x_trisolve_plan_s *p = new mi355x_trisolve_plan_s();
   memset(p, 0, sizeof(*p));
   p->n = n; p->upper = dinv_host != nullptr;
   const int W = MI355X_WAVE;
-  p->nslices = (n + W - 1) / W;
-  p->nchunks = (p->nslices + 3) / 4;
   // positions: by level, longer rows first inside a level (stable in the row number)
   std::vector<int> order((size_t)n), levptr((size_t)nlev + 1, 0);
   for (int i = 0; i < n; ++i) levptr[(size_t)lev[i] + 1]++;
@@ -209,22 +218,33 @@ int mi355x_trisolve_plan_create(mi355x_handle_t h, int n, int nlev, const int *l
     for (int i = 0; i < n; ++i) order[(size_t)next[(size_t)lev[i]]++] = i; }
   for (int l = 0; l < nlev; ++l)
     std::stable_sort(order.begin() + levptr[(size_t)l], order.begin() + levptr[(size_t)l + 1], [&](int a, int b) { return rl[a] > rl[b]; });
+  std::vector<long> tpos((size_t)(n > 0 ? n : 1));
+  long cur = 0;
+  for (int l = 0; l < nlev; ++l) {
+    const int sz = levptr[(size_t)l + 1] - levptr[(size_t)l];
+    if (by_level && sz >= TRI_ALIGN_MIN && (cur % W)) cur += W - cur % W;     // padding positions: no row, never read
+    for (int t = levptr[(size_t)l]; t < levptr[(size_t)l + 1]; ++t) tpos[(size_t)t] = cur++;
+  }
+  if (cur > 2147483000L) { delete p; return (int)hipErrorInvalidValue; }
+  p->nslices = (int)((cur + W - 1) / W);
+  p->nchunks = (p->nslices + 3) / 4;
   const size_t np = (size_t)p->nslices * W;
   std::vector<int> pos((size_t)(n > 0 ? n : 1)), info(np > 0 ? np : 1, 0), rowof(np > 0 ? np : 1, -1), ptr((size_t)p->nslices + 1, 0);
   std::vector<unsigned char> nsub((size_t)(p->nslices > 0 ? p->nslices : 1), 1);
   std::vector<double> dinv(np > 0 ? np : 1, 1.0);
-  for (int t = 0; t < n; ++t) pos[(size_t)order[(size_t)t]] = t;
+  for (int t = 0; t < n; ++t) { pos[(size_t)order[(size_t)t]] = (int)tpos[(size_t)t]; rowof[(size_t)tpos[(size_t)t]] = order[(size_t)t]; }
   long total = 0;
   for (int s = 0; s < p->nslices; ++s) {
-    int mx = 0;
-    const int l0 = lev[order[(size_t)s * W]];
-    for (int j = 0; j < W && (size_t)s * W + j < (size_t)n; ++j) {
-      const int t = s * W + j, i = order[(size_t)t];
+    int mx = 0, l0 = -1;
+    for (int j = 0; j < W; ++j) {
+      const size_t P = (size_t)s * W + j;
+      const int i = rowof[P];
+      if (i < 0) continue;
+      if (l0 < 0) l0 = lev[i];                   // positions are in level order: the slice's first row has its lowest level
       const int sub = lev[i] - l0;
       if (sub < 0 || sub > 255) { delete p; return (int)hipErrorInvalidValue; }
-      info[(size_t)t] = (rl[i] << 8) | sub;
-      rowof[(size_t)t] = i;
-      if (dinv_host) dinv[(size_t)t] = dinv_host[i];
+      info[P] = (rl[i] << 8) | sub;
+      if (dinv_host) dinv[P] = dinv_host[i];
       if (rl[i] > mx) mx = rl[i];
       if (sub + 1 > nsub[(size_t)s]) nsub[(size_t)s] = (unsigned char)(sub + 1);
     }
@@ -235,13 +255,18 @@ int mi355x_trisolve_plan_create(mi355x_handle_t h, int n, int nlev, const int *l
   ptr[(size_t)p->nslices] = (int)total;
   std::vector<int> col((size_t)(total > 0 ? total : 1), 0);
   std::vector<double> val((size_t)(total > 0 ? total : 1), 0.0);
+  std::vector<int> perm;
   for (int t = 0; t < n; ++t) {
-    const int i = order[(size_t)t], s = t / W, lane = t % W;
+    const int i = order[(size_t)t], P = (int)tpos[(size_t)t], s = P / W, lane = P % W;
+    perm.resize((size_t)rl[i]);
+    for (int q = 0; q < rl[i]; ++q) perm[(size_t)q] = q;
+    if (by_level) std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return lev[cj[rp[i] + a]] < lev[cj[rp[i] + b]]; });
     for (int q = 0; q < rl[i]; ++q) {
-      const int dep = cj[rp[i] + q];
-      if (pos[(size_t)dep] >= t) { delete p; return (int)hipErrorInvalidValue; }   // a dependency must come earlier
+      const int src_q = perm[(size_t)q];
+      const int dep = cj[rp[i] + src_q];
+      if (pos[(size_t)dep] >= P) { delete p; return (int)hipErrorInvalidValue; }   // a dependency must come earlier
       col[(size_t)ptr[(size_t)s] + (size_t)q * W + lane] = pos[(size_t)dep];
-      val[(size_t)ptr[(size_t)s] + (size_t)q * W + lane] = cv[rp[i] + q];
+      val[(size_t)ptr[(size_t)s] + (size_t)q * W + lane] = cv[rp[i] + src_q];
     }
   }
 #define TRI_UP(dst, vec, T) do { MI355X_TRY(hipMalloc((void **)&(dst), sizeof(T) * (vec).size())); \
@@ -286,6 +311,11 @@ int mi355x_trisolve_plan_create(mi355x_handle_t h, int n, int nlev, const int *l
   return 0;
 }
 
+int mi355x_trisolve_plan_create(mi355x_handle_t h, int n, int nlev, const int *lev, const int *rp, const int *rl, const int *cj,
+                                const double *cv, const double *dinv_host, mi355x_trisolve_plan_t *out) {
+  return mi355x_trisolve_plan_create_ordered(h, n, nlev, lev, rp, rl, cj, cv, dinv_host, 0, out);
+}
+
 int mi355x_trisolve_plan_destroy(mi355x_trisolve_plan_t p) {
   if (!p) return 0;
   (void)hipFree(p->d_ptr); (void)hipFree(p->d_info); (void)hipFree(p->d_row); (void)hipFree(p->d_col); (void)hipFree(p->d_val);
@@ -307,11 +337,11 @@ int mi355x_trisolve_apply(mi355x_handle_t h, mi355x_trisolve_plan_t lo, mi355x_t
   const int glo = lo->grid < TRI_QUEUES ? TRI_QUEUES : lo->grid, gup = up->grid < TRI_QUEUES ? TRI_QUEUES : up->grid;
   hipLaunchKernelGGL((trisolve_syncfree_kernel<false>), dim3(glo), dim3(MI355X_BLOCK), 0, h->stream, lo->nslices, lo->nchunks,
                      lo->d_ptr, lo->d_info, lo->d_row, lo->d_col, lo->d_val, (const double *)nullptr, lo->d_nsub, b,
-                     (const int *)nullptr, lo->d_w, (double *)nullptr, up->d_w, lo->d_queue, up->d_queue, lo->abort_flag, lo->sleep_cap);
+                     (const int *)nullptr, lo->d_w, (double *)nullptr, up->d_w, up->nslices * MI355X_WAVE, lo->d_queue, up->d_queue, lo->abort_flag, lo->sleep_cap);
   MI355X_LAUNCH_CHECK();
   hipLaunchKernelGGL((trisolve_syncfree_kernel<true>), dim3(gup), dim3(MI355X_BLOCK), 0, h->stream, up->nslices, up->nchunks,
                      up->d_ptr, up->d_info, up->d_row, up->d_col, up->d_val, up->d_dinv, up->d_nsub, lo->d_w, lo->d_pos,
-                     up->d_w, y, lo->d_w, up->d_queue, lo->d_queue, up->abort_flag, up->sleep_cap);
+                     up->d_w, y, lo->d_w, 0, up->d_queue, lo->d_queue, up->abort_flag, up->sleep_cap);
   MI355X_LAUNCH_CHECK();
   return 0;
 }

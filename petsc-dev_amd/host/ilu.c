@@ -21,6 +21,7 @@ typedef struct {
   void *graph;                                           /* hipGraphExec of the nlevL + nlevU level launches */
   int graph_tried;
   mi355x_trisolve_plan_t tri_lo, tri_up;                 /* sync-free solves (NULL: level launches) */
+  int by_level;                                          /* rows summed in dependency-level order (inode matrices) instead of column order */
   int factored_state;
 } PC_ILU;
 
@@ -159,8 +160,19 @@ static PetscErrorCode PCSetUp_ILU(PC pc) {
         rlL[i] = bi[i + 1] - bi[i];
         rpU[i] = bdiag[i + 1] + 1; rlU[i] = bdiag[i] - bdiag[i + 1] - 1; dinv[i] = ba[bdiag[i]];
       }
-      int rc = mi355x_trisolve_plan_create(dc->h, n, f->nlevL, lev, bi, rlL, bj, ba, NULL, &f->tri_lo);
-      if (!rc) rc = mi355x_trisolve_plan_create(dc->h, n, f->nlevU, levU, rpU, rlU, bj, ba, dinv, &f->tri_up);
+      /* -pc_factor_hipmi355x_trisolve_order <column|level>.  column: every row is summed in column order, the bits of
+       * MatSolve_SeqAIJ_NaturalOrdering.  level: in the order of its dependencies' levels (a row then waits on its last
+       * entries only) -- the default where the reference does not run the natural-ordering routine either: a matrix with
+       * inodes, whose factor it solves with MatSolve_SeqAIJ_Inode (inode.c; MatLUFactorNumeric_SeqAIJ_Inode installs it),
+       * in yet another order.  There the two agree to rounding. */
+      char ord[32] = ""; PetscInt nodes = 0; int by_level;
+      ierr = PetscOptionsGetString(HipObjPrefix(pc), "-pc_factor_hipmi355x_trisolve_order", ord, sizeof(ord), &set);CHKERRQ(ierr);
+      if (set && strcmp(ord, "column") && strcmp(ord, "level")) SETERRQ(HipObjComm(pc), PETSC_ERR_ARG_WRONG, "-pc_factor_hipmi355x_trisolve_order <column|level>, got %s", ord);
+      ierr = MatHIPMI355XGetInodeInfo(A, &nodes, NULL, NULL);CHKERRQ(ierr);
+      by_level = set ? !strcmp(ord, "level") : (nodes > 0);
+      f->by_level = by_level;
+      int rc = mi355x_trisolve_plan_create_ordered(dc->h, n, f->nlevL, lev, bi, rlL, bj, ba, NULL, by_level, &f->tri_lo);
+      if (!rc) rc = mi355x_trisolve_plan_create_ordered(dc->h, n, f->nlevU, levU, rpU, rlU, bj, ba, dinv, by_level, &f->tri_up);
       HipFree(rpU); HipFree(rlU); HipFree(rlL); HipFree(dinv);
       if (rc) {   /* e.g. a factor too large for 32-bit sliced-ELL offsets: the level kernels serve */
         if (f->tri_lo) mi355x_trisolve_plan_destroy(f->tri_lo);
