@@ -97,6 +97,7 @@ struct mi355x_trisolve_plan_s {
   unsigned int *d_queue;   // TRI_QUEUES counters
   int *abort_flag;   // pinned + mapped
   int grid, sleep_cap;
+  int by_level;      // rows in dependency-level order, levels on slice boundaries
 };
 
 __device__ __forceinline__ double tri_poll(const double *p, int *abort_flag, int sleep_cap) {
@@ -123,6 +124,16 @@ __device__ __forceinline__ double tri_poll(const double *p, int *abort_flag, int
 // `reset`: the OTHER solve's w, returned to the sentinel for its next run -- lower: reset[t] (coalesced; the upper
 // solve of the previous application is complete), upper: src[spos[row]] right after it has been read (only this lane
 // reads that entry).  other_queue: the other solve's queue counters, zeroed by workgroup 0.
+#ifdef MI355X_TRI_TRACE
+// development build (csrc/variants/build_tri_trace.sh): lane 0 of every wavefront leaves four timestamps per slice (100 MHz
+// wall clock): slice start, last batch's entries looked at, last dependency arrived, result stored
+__device__ long long *tri_trace_buf = nullptr;
+extern "C" int mi355x_trisolve_debug_trace(long long *dev_buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(tri_trace_buf), &dev_buf, sizeof(dev_buf)); }
+#define TRI_STAMP(k) do { if (tri_trace_buf && lane == 0) tri_trace_buf[(UPPER ? 8000000L : 0L) + (long)s * 4 + (k)] = wall_clock64(); } while (0)
+#else
+#define TRI_STAMP(k) do { } while (0)
+#endif
+
 template <bool UPPER>
 __global__ __launch_bounds__(MI355X_BLOCK) void trisolve_syncfree_kernel(
     int nslices, int nchunks, const int *__restrict__ ptr, const int *__restrict__ info, const int *__restrict__ rowof,
@@ -159,9 +170,10 @@ __global__ __launch_bounds__(MI355X_BLOCK) void trisolve_syncfree_kernel(
     }
     if (!UPPER && t < reset_n) reset[t] = __longlong_as_double((long long)TRI_SENTINEL);
     const double di = UPPER ? dinv[t] : 1.0;
+    TRI_STAMP(0);
     for (int step = 0; step < ns; ++step) {
       if (row >= 0 && mysub == step) {
-        // entries in batches of 8: the loads of a batch are issued together, consumed in column order
+        // entries in batches of 8: the loads of a batch are issued together, consumed in stored order
         for (int q0 = 0; q0 < mylen; q0 += 8) {
           int c[8]; double a[8], v[8];
 #pragma unroll
@@ -175,6 +187,7 @@ __global__ __launch_bounds__(MI355X_BLOCK) void trisolve_syncfree_kernel(
             v[j] = 0.0;
             if (q0 + j < mylen) v[j] = __hip_atomic_load(w + c[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
+          if (q0 + 8 >= mylen) TRI_STAMP(1);
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             if (q0 + j < mylen) {
@@ -184,8 +197,10 @@ __global__ __launch_bounds__(MI355X_BLOCK) void trisolve_syncfree_kernel(
             }
           }
         }
+        TRI_STAMP(2);
         const double r = UPPER ? sum * di : sum;
         __hip_atomic_store(w + t, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        TRI_STAMP(3);
         if (UPPER) y[row] = r;
       }
     }
@@ -291,6 +306,7 @@ int mi355x_trisolve_plan_create_ordered(mi355x_handle_t h, int n, int nlev, cons
   MI355X_TRY(hipGetDeviceProperties(&prop, dev));
   ncu = prop.multiProcessorCount;
   MI355X_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trisolve_syncfree_kernel<true>, MI355X_BLOCK, 0));
+  p->by_level = by_level;
   if (per_cu > 4) per_cu = 4;
   if (per_cu < 1) { delete p; return (int)hipErrorInvalidValue; }
   p->grid = ncu * per_cu;
@@ -335,14 +351,20 @@ int mi355x_trisolve_apply(mi355x_handle_t h, mi355x_trisolve_plan_t lo, mi355x_t
   // with fewer chunks than queues some queues have no puller: chunk c is then only served through queue c % 8 ...
   // so tiny systems use ONE workgroup per queue that exists (grid >= min(nchunks, 8) is guaranteed by plan_create)
   const int glo = lo->grid < TRI_QUEUES ? TRI_QUEUES : lo->grid, gup = up->grid < TRI_QUEUES ? TRI_QUEUES : up->grid;
-  hipLaunchKernelGGL((trisolve_syncfree_kernel<false>), dim3(glo), dim3(MI355X_BLOCK), 0, h->stream, lo->nslices, lo->nchunks,
-                     lo->d_ptr, lo->d_info, lo->d_row, lo->d_col, lo->d_val, (const double *)nullptr, lo->d_nsub, b,
-                     (const int *)nullptr, lo->d_w, (double *)nullptr, up->d_w, up->nslices * MI355X_WAVE, lo->d_queue, up->d_queue, lo->abort_flag, lo->sleep_cap);
-  MI355X_LAUNCH_CHECK();
-  hipLaunchKernelGGL((trisolve_syncfree_kernel<true>), dim3(gup), dim3(MI355X_BLOCK), 0, h->stream, up->nslices, up->nchunks,
-                     up->d_ptr, up->d_info, up->d_row, up->d_col, up->d_val, up->d_dinv, up->d_nsub, lo->d_w, lo->d_pos,
-                     up->d_w, y, lo->d_w, 0, up->d_queue, lo->d_queue, up->abort_flag, up->sleep_cap);
-  MI355X_LAUNCH_CHECK();
+#define TRI_GO()                                                                                                                 \
+  do {                                                                                                                            \
+    hipLaunchKernelGGL((trisolve_syncfree_kernel<false>), dim3(glo), dim3(MI355X_BLOCK), 0, h->stream, lo->nslices, lo->nchunks, \
+                       lo->d_ptr, lo->d_info, lo->d_row, lo->d_col, lo->d_val, (const double *)nullptr, lo->d_nsub, b,          \
+                       (const int *)nullptr, lo->d_w, (double *)nullptr, up->d_w, up->nslices * MI355X_WAVE, lo->d_queue, up->d_queue, lo->abort_flag, lo->sleep_cap); \
+    MI355X_LAUNCH_CHECK();                                                                                                        \
+    hipLaunchKernelGGL((trisolve_syncfree_kernel<true>), dim3(gup), dim3(MI355X_BLOCK), 0, h->stream, up->nslices, up->nchunks,  \
+                       up->d_ptr, up->d_info, up->d_row, up->d_col, up->d_val, up->d_dinv, up->d_nsub, lo->d_w, lo->d_pos,       \
+                       up->d_w, y, lo->d_w, 0, up->d_queue, lo->d_queue, up->abort_flag, up->sleep_cap);                        \
+    MI355X_LAUNCH_CHECK();                                                                                                        \
+  } while (0)
+  if (lo->by_level != up->by_level) return (int)hipErrorInvalidValue;
+  TRI_GO();
+#undef TRI_GO
   return 0;
 }
 
