@@ -106,7 +106,7 @@ void orc_vec_maxpy(size_t n, int nv, const double *alpha, const double *const *y
 /* VecDot_Seq/VecTDot_Seq, src/vec/vec/impls/seq/bvec1.c:57,122: ddot_, netlib order (left to right) */
 /* ---- the device's summation order (test aid).  The reference adds the terms of a dot product one after the other (BLAS
  * ddot / the loops of dvec2.c); the HIP reductions add the same terms in a fixed tree (csrc/vec_kernels.hip reduce_kernel:
- * min(ceil(n/4096),1024) workgroups of 256 lanes, lane t of the grid takes the element pairs t, t+T, t+2T, ... in order,
+ * min(ceil(n/4096),512) workgroups of 256 lanes, lane t of the grid takes the element pairs t, t+T, t+2T, ... in order,
  * a shuffle-down tree over each wavefront, the four wavefronts in order, then one workgroup adds the per-workgroup sums the
  * same way).  With orc_set_device_reduction_order(1) the oracle's reductions use that tree on the same terms, so that a whole
  * Krylov solve can be compared with the HIP path bit for bit: whatever differs then is not summation order. ---- */
@@ -127,7 +127,7 @@ static double block256(double *lanes) {
 static double dev_reduce(size_t n, orc_term_fn f, const double *a, const double *b) {
   size_t grid = (n + 4095) / 4096;
   if (grid < 1) grid = 1;
-  if (grid > 1024) grid = 1024;
+  if (grid > 512) grid = 512;           /* MI355X_REDUCE_GRID_CAP, csrc/common.hpp */
   const size_t T = grid * 256, n2 = n >> 1;
   double *partial = (double *)malloc(sizeof(double) * grid), lanes[256], res;
   for (size_t blk = 0; blk < grid; blk++) {

@@ -9,6 +9,7 @@
 #define MI355X_BLOCK 256          // 4 wavefronts per workgroup, one per SIMD
 #define MI355X_NXCD 8             // XCDs (each with a private 4 MiB L2)
 #define MI355X_MAX_GRID 2048      // 256 CUs x 8 resident 256-thread workgroups
+#define MI355X_REDUCE_GRID_CAP 512   // workgroups of a reduction launch (vec_kernels.hip launch_reduce)
 #define MI355X_MAX_RED 32         // max simultaneous reduction outputs (MDot chunk)
 #define MI355X_SCRATCH_DOUBLES 64
 

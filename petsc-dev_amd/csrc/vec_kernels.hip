@@ -1,7 +1,7 @@
 // Vec BLAS-1 kernels for gfx950.  All of them are HBM-bound streams: 16-byte
 // (double2) loads/stores per lane and a grid-stride loop; element-wise kernels run
 // <= 2048 workgroups (256 CUs x 8 resident 256-thread workgroups) with two double2
-// iterations in flight per lane, reductions <= 1024 workgroups with four.  Compiled with -ffp-contract=off so
+// iterations in flight per lane, reductions <= 512 workgroups with four.  Compiled with -ffp-contract=off so
 // a*x+y is a rounded multiply then a rounded add, as in the reference's C loops
 // (src/vec/vec/impls/seq/{bvec1,bvec2,dvec2}.c).
 #include "common.hpp"
@@ -316,7 +316,10 @@ __global__ __launch_bounds__(MI355X_BLOCK) void reduce_kernel(F f, size_t n, int
 template <int NOUT, int MODE, class F>
 static int launch_reduce(mi355x_handle_t h, F f, size_t n, int vec_ok, double *out, bool also_to_host = false) {
   int grid = mi355x_grid_for(n, 16);
-  if (grid > 1024) grid = 1024;   // 4 workgroups per CU; the last one sums <= 1024 partials
+  // at most 512 workgroups, 2 per CU (measured on the CG iteration at n = 2^24, one box, same process order: 256 -> 0.541 ms,
+  // 384 -> 0.535, 512 -> 0.523, 768 -> 0.529, 1024 -> 0.534, 2048 -> 0.536); the last one sums <= 512 partials.  The oracle's
+  // device-order emulation (oracle/vecmat_oracle.c dev_reduce) restates this geometry: change both together.
+  if (grid > MI355X_REDUCE_GRID_CAP) grid = MI355X_REDUCE_GRID_CAP;
   // a result that goes to the handle's pinned scratch is followed by a completion number (mi355x_handle_wait_result)
   unsigned long long *hs = nullptr, seq = 0;
   double *host_copy = nullptr;
