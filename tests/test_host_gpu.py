@@ -303,7 +303,9 @@ def test_gmres_fused_equals_op_by_op_bit_for_bit(P, pc, opts):
 
 @pytest.mark.parametrize("ksp,pc,opts", [("cg", "jacobi", ""), ("cg", "none", ""), ("cg", "jacobi", "-ksp_cg_fused 0"), ("gmres", "jacobi", ""),
                                         ("gmres", "ilu", ""), ("gmres", "none", "-ksp_gmres_restart 9"), ("bcgs", "jacobi", ""), ("bcgs", "none", ""),
-                                        ("groppcg", "jacobi", ""), ("cg", "jacobi", "-ksp_norm_type natural")])
+                                        ("groppcg", "jacobi", ""), ("cg", "jacobi", "-ksp_norm_type natural"),
+                                        ("gmres", "jacobi", "-ksp_gmres_cgs_refinement_type refine_always"), ("pipecg", "jacobi", "-ksp_norm_type natural"),
+                                        ("gmres", "jacobi", "-ksp_gmres_fused 0"), ("bcgs", "jacobi", "-ksp_bcgs_fused 0")])
 def test_whole_solves_equal_the_oracle_bit_for_bit_in_the_device_summation_order(P, ksp, pc, opts):
     """The parity tolerances elsewhere in this file exist for ONE reason: the reference adds the terms of a dot product one
     after the other, the HIP reductions add the same terms in a tree.  With the oracle's reductions switched to that tree
@@ -316,7 +318,7 @@ def test_whole_solves_equal_the_oracle_bit_for_bit_in_the_device_summation_order
         ai, aj, aa = orc.gen_p7(17, 15, 13)
         if which == "nonsym":
             aa = aa * (1.0 + 0.3 * np.sin(0.7 * np.arange(aa.size)))
-            if ksp in ("cg", "groppcg"):
+            if ksp in ("cg", "groppcg", "pipecg"):
                 continue
         n = ai.size - 1
         b = np.cos(0.37 * np.arange(n)) + 0.1
@@ -325,11 +327,26 @@ def test_whole_solves_equal_the_oracle_bit_for_bit_in_the_device_summation_order
         okw = {}
         if "-ksp_gmres_restart" in opts:
             okw["restart"] = 9
+        if "refine_always" in opts:
+            okw["refine_always"] = 1
         with orc.device_reduction_order():
             xo, ho, ito, ro = orc.ksp_solve(ai, aj, aa, b, ksp=ksp, pc=pc, norm_type=norm, **kw, **okw)
         assert (its, reason) == (ito, ro) and its > 5
         assert np.array_equal(h.view(np.uint64), ho.view(np.uint64)), (which, np.max(np.abs(h - ho) / ho))
         assert np.array_equal(x.view(np.uint64), xo.view(np.uint64))
+
+
+def test_config1_cg_jacobi_equals_the_oracle_bit_for_bit_in_the_device_summation_order(P):
+    """BASELINE.json configs[0] (ex2 -m 100 -n 100, CG + Jacobi, 160 iterations): all 161 residual norms and the solution,
+    bit for bit, with the oracle's reductions in the device order"""
+    ai, aj, aa = pb.lap2d(100, 100)
+    b = orc.spmv(ai, aj, aa, np.ones(10000))
+    rtol = 1e-2 / (101 * 101)                                     # ex2.c: KSPSetTolerances(ksp, 1.e-2/((m+1)*(n+1)), 1.e-50, ...)
+    x, h, its, reason = solve(P, ai, aj, aa, b, "cg", "jacobi", rtol=rtol, abstol=1e-50)
+    with orc.device_reduction_order():
+        xo, ho, ito, ro = orc.ksp_solve(ai, aj, aa, b, ksp="cg", pc="jacobi", rtol=rtol, abstol=1e-50)
+    assert (its, reason) == (ito, ro) and its == 160
+    assert np.array_equal(h.view(np.uint64), ho.view(np.uint64)) and np.array_equal(x.view(np.uint64), xo.view(np.uint64))
 
 
 @pytest.mark.parametrize("bs", [2, 3, 4, 5])
