@@ -166,67 +166,130 @@ PetscErrorCode PCCreate_Jacobi(PC pc) {
   return 0;
 }
 
-/* ---------------------------------------------------------------- PCBJACOBI, one block per rank */
+/* ---------------------------------------------------------------- PCBJACOBI: one block per rank (PCSetUp_BJacobi_Singleblock,
+ * bjacobi.c:858-923) or several local blocks (PCSetUp_BJacobi_Multiblock, bjacobi.c:1060-1230); blocks that span ranks
+ * (-pc_bjacobi_blocks < size: the multiproc case) are outside the ported path */
 typedef struct {
-  KSP ksp;        /* sub-KSP on the local diagonal block, options prefix "sub_" */
-  Vec x, y;       /* sequential work vectors */
-  Mat block;
+  PetscInt nloc;            /* local blocks */
+  PetscInt *starts;         /* nloc + 1 local row offsets */
+  KSP *ksp;                 /* one sub-KSP per block, options prefix "sub_" */
+  Vec *x, *y;               /* sequential work vectors per block */
+  Mat *block;               /* nloc == 1: the diagonal block itself (not owned); else extracted copies (owned) */
+  PetscBool owns_blocks;
 } PC_BJacobi;
+typedef PetscErrorCode (*MatSeqAIJGetArraysFn)(Mat, PetscInt *, const PetscInt **, const PetscInt **, const PetscScalar **);
 
-static PetscErrorCode PCSetUp_BJacobi(PC pc) {   /* PCSetUp_BJacobi_Singleblock, bjacobi.c:858-923 */
+/* the [s, e) x [s, e) diagonal block of a sequential AIJ matrix, as a matrix of the same type (MatGetSubMatrices with the
+ * contiguous index sets of bjacobi.c:1115-1130) */
+static PetscErrorCode extract_diagonal_block(Mat A, PetscInt s, PetscInt e, Mat *sub) {
   PetscErrorCode ierr;
-  PC_BJacobi *bj = (PC_BJacobi *)pc->data;
-  PetscInt nb; PetscBool set; char prefix[80];
-  snprintf(prefix, sizeof(prefix), "%s", pc->prefix);
-  ierr = PetscOptionsGetInt(prefix, "-pc_bjacobi_blocks", &nb, &set);CHKERRQ(ierr);
-  if (set && nb != pc->comm->size) SETERRQ(pc->comm, PETSC_ERR_SUP, "%d blocks on %d processes: only one block per process (PCSetUp_BJacobi_Singleblock) is on the ported path", nb, pc->comm->size);
-  ierr = MatGetDiagonalBlock(pc->pmat, &bj->block);CHKERRQ(ierr);
-  if (!bj->ksp) {
-    PC subpc;
-    ierr = KSPCreate(PETSC_COMM_SELF, &bj->ksp);CHKERRQ(ierr);
-    ierr = KSPSetType(bj->ksp, KSPPREONLY);CHKERRQ(ierr);
-    snprintf(prefix, sizeof(prefix), "%ssub_", pc->prefix);
-    ierr = KSPSetOptionsPrefix(bj->ksp, prefix);CHKERRQ(ierr);
-    ierr = KSPGetPC(bj->ksp, &subpc);CHKERRQ(ierr);
-    /* the sub-PC's type is left unset: PCSetUp picks the default (ILU(0) on a sequential AIJ block, precon.c:14-53) */
-    (void)subpc;
-    ierr = MatGetVecs(bj->block, &bj->x, &bj->y);CHKERRQ(ierr);
+  PetscVoidFunction f = NULL;
+  PetscInt m; const PetscInt *ai, *aj; const PetscScalar *aa;
+  ierr = PetscObjectQueryFunction((PetscObject)A, "MatSeqAIJGetArrays_C", &f);CHKERRQ(ierr);
+  if (!f) SETERRQ(A->comm, PETSC_ERR_SUP, "several block-Jacobi blocks per process need a sequential AIJ diagonal block, got %s", A->type_name);
+  ierr = ((MatSeqAIJGetArraysFn)f)(A, &m, &ai, &aj, &aa);CHKERRQ(ierr);
+  if (A->rmap->n != m) SETERRQ(A->comm, PETSC_ERR_SUP, "several block-Jacobi blocks per process are ported for block size 1");
+  PetscInt nz = 0, *si, *sj; PetscScalar *sa;
+  for (PetscInt r = s; r < e; r++) for (PetscInt k = ai[r]; k < ai[r + 1]; k++) if (aj[k] >= s && aj[k] < e) nz++;
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)(e - s + 1), &si);CHKERRQ(ierr);
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)PetscMax(nz, 1), &sj);CHKERRQ(ierr);
+  ierr = PetscMalloc(sizeof(PetscScalar) * (size_t)PetscMax(nz, 1), &sa);CHKERRQ(ierr);
+  nz = 0; si[0] = 0;
+  for (PetscInt r = s; r < e; r++) {
+    for (PetscInt k = ai[r]; k < ai[r + 1]; k++) if (aj[k] >= s && aj[k] < e) { sj[nz] = aj[k] - s; sa[nz] = aa[k]; nz++; }
+    si[r - s + 1] = nz;
   }
-  ierr = KSPSetOperators(bj->ksp, bj->block, bj->block, SAME_NONZERO_PATTERN);CHKERRQ(ierr);
-  ierr = KSPSetFromOptions(bj->ksp);CHKERRQ(ierr);
-  ierr = KSPSetUp(bj->ksp);CHKERRQ(ierr);
+  ierr = MatCreateSeqAIJWithArrays(PETSC_COMM_SELF, e - s, e - s, si, sj, sa, sub);   /* the arrays are copied */
+  free(si); free(sj); free(sa);
+  CHKERRQ(ierr);
   return 0;
 }
 
-/* PCApply_BJacobi_Singleblock, bjacobi.c:738-761: the parallel vectors' local arrays are placed into the sequential
- * work vectors (VecGetArray + VecPlaceArray), the sub-KSP solves, the arrays are reset.  A vector type whose data does
- * not live on the host may offer the same aliasing as a method of its own ("VecShareArrayBegin_C" / "VecShareArrayEnd_C":
- * sub takes parent's storage; write != 0 for the output vector), which avoids a host round trip per application. */
-typedef PetscErrorCode (*VecShareFn)(Vec sub, Vec parent, PetscBool write);
+static PetscErrorCode PCSetUp_BJacobi(PC pc) {
+  PetscErrorCode ierr;
+  PC_BJacobi *bj = (PC_BJacobi *)pc->data;
+  PetscInt nb = pc->comm->size; PetscBool set; char prefix[80];
+  Mat diag;
+  snprintf(prefix, sizeof(prefix), "%s", pc->prefix);
+  ierr = PetscOptionsGetInt(prefix, "-pc_bjacobi_blocks", &nb, &set);CHKERRQ(ierr);
+  if (!set) nb = pc->comm->size;
+  if (nb < pc->comm->size) SETERRQ(pc->comm, PETSC_ERR_SUP, "%d blocks on %d processes: blocks that span processes (PCSetUp_BJacobi_Multiproc) are outside the ported path", nb, pc->comm->size);
+  /* bjacobi.c:118-150: the blocks are dealt evenly to the ranks, a rank's rows evenly to its blocks */
+  const PetscInt nloc = nb / pc->comm->size + ((nb % pc->comm->size) > pc->comm->rank ? 1 : 0);
+  ierr = MatGetDiagonalBlock(pc->pmat, &diag);CHKERRQ(ierr);
+  const PetscInt M = diag->rmap->n;
+  if (nloc > 1 && nloc > M && M > 0) SETERRQ(pc->comm, PETSC_ERR_ARG_OUTOFRANGE, "more block-Jacobi blocks (%d) than local rows (%d)", nloc, M);
+  if (bj->ksp && bj->nloc != nloc) SETERRQ(pc->comm, PETSC_ERR_SUP, "the number of block-Jacobi blocks cannot change after set-up");
+  if (!bj->ksp) {
+    bj->nloc = nloc;
+    ierr = PetscMalloc(sizeof(PetscInt) * (size_t)(nloc + 1), &bj->starts);CHKERRQ(ierr);
+    ierr = PetscMalloc(sizeof(KSP) * (size_t)nloc, &bj->ksp);CHKERRQ(ierr);
+    ierr = PetscMalloc(sizeof(Vec) * (size_t)nloc, &bj->x);CHKERRQ(ierr);
+    ierr = PetscMalloc(sizeof(Vec) * (size_t)nloc, &bj->y);CHKERRQ(ierr);
+    ierr = PetscMalloc(sizeof(Mat) * (size_t)nloc, &bj->block);CHKERRQ(ierr);
+    memset(bj->ksp, 0, sizeof(KSP) * (size_t)nloc); memset(bj->x, 0, sizeof(Vec) * (size_t)nloc);
+    memset(bj->y, 0, sizeof(Vec) * (size_t)nloc); memset(bj->block, 0, sizeof(Mat) * (size_t)nloc);
+    bj->starts[0] = 0;
+    for (PetscInt i = 0; i < nloc; i++) bj->starts[i + 1] = bj->starts[i] + M / nloc + ((M % nloc) > i ? 1 : 0);
+    bj->owns_blocks = (PetscBool)(nloc > 1);
+  }
+  for (PetscInt i = 0; i < nloc; i++) {
+    if (nloc == 1) bj->block[0] = diag;
+    else {
+      if (bj->block[i]) { ierr = MatDestroy(&bj->block[i]);CHKERRQ(ierr); }     /* values may have changed: extract again */
+      ierr = extract_diagonal_block(diag, bj->starts[i], bj->starts[i + 1], &bj->block[i]);CHKERRQ(ierr);
+    }
+    if (!bj->ksp[i]) {
+      ierr = KSPCreate(PETSC_COMM_SELF, &bj->ksp[i]);CHKERRQ(ierr);
+      ierr = KSPSetType(bj->ksp[i], KSPPREONLY);CHKERRQ(ierr);
+      snprintf(prefix, sizeof(prefix), "%ssub_", pc->prefix);
+      ierr = KSPSetOptionsPrefix(bj->ksp[i], prefix);CHKERRQ(ierr);
+      /* the sub-PC's type is left unset: PCSetUp picks the default (ILU(0) on a sequential AIJ block, precon.c:14-53) */
+      ierr = MatGetVecs(bj->block[i], &bj->x[i], &bj->y[i]);CHKERRQ(ierr);
+    }
+    ierr = KSPSetOperators(bj->ksp[i], bj->block[i], bj->block[i], SAME_NONZERO_PATTERN);CHKERRQ(ierr);
+    ierr = KSPSetFromOptions(bj->ksp[i]);CHKERRQ(ierr);
+    ierr = KSPSetUp(bj->ksp[i]);CHKERRQ(ierr);
+  }
+  return 0;
+}
+
+/* PCApply_BJacobi_Singleblock / _Multiblock, bjacobi.c:738-761,1140-1180: the local arrays of the parallel vectors are placed
+ * into the sequential work vectors of each block (VecGetArray + VecPlaceArray at the block's offset), the sub-KSP solves, the
+ * arrays are reset.  A vector type whose data does not live on the host may offer the same aliasing as a method of its own
+ * ("VecShareSubArrayBegin_C" / "VecShareSubArrayEnd_C": sub takes parent's storage from an offset on; write != 0 for the
+ * output vector), which avoids a host round trip per application. */
+typedef PetscErrorCode (*VecShareSubFn)(Vec sub, Vec parent, PetscInt offset, PetscBool write);
 static PetscErrorCode PCApply_BJacobi(PC pc, Vec x, Vec y) {
   PetscErrorCode ierr, ierr2;
   PC_BJacobi *bj = (PC_BJacobi *)pc->data;
   PetscVoidFunction fb, fe;
-  ierr = PetscObjectQueryFunction((PetscObject)bj->x, "VecShareArrayBegin_C", &fb);CHKERRQ(ierr);
-  ierr = PetscObjectQueryFunction((PetscObject)bj->x, "VecShareArrayEnd_C", &fe);CHKERRQ(ierr);
+  ierr = PetscObjectQueryFunction((PetscObject)bj->x[0], "VecShareSubArrayBegin_C", &fb);CHKERRQ(ierr);
+  ierr = PetscObjectQueryFunction((PetscObject)bj->x[0], "VecShareSubArrayEnd_C", &fe);CHKERRQ(ierr);
   if (fb && fe) {
-    ierr = ((VecShareFn)fb)(bj->x, x, PETSC_FALSE);CHKERRQ(ierr);
-    ierr = ((VecShareFn)fb)(bj->y, y, PETSC_TRUE);
-    if (ierr) { ((VecShareFn)fe)(bj->x, x, PETSC_FALSE); CHKERRQ(ierr); }
-    ierr = KSPSolve(bj->ksp, bj->x, bj->y);
-    /* the aliases come off first, also when the sub-solve failed: the work vectors own their storage again */
-    ierr2 = ((VecShareFn)fe)(bj->x, x, PETSC_FALSE);
-    if (!ierr2) ierr2 = ((VecShareFn)fe)(bj->y, y, PETSC_TRUE);
-    CHKERRQ(ierr); CHKERRQ(ierr2);
+    for (PetscInt i = 0; i < bj->nloc; i++) {
+      const PetscInt off = bj->starts[i];
+      ierr = ((VecShareSubFn)fb)(bj->x[i], x, off, PETSC_FALSE);CHKERRQ(ierr);
+      ierr = ((VecShareSubFn)fb)(bj->y[i], y, off, PETSC_TRUE);
+      if (ierr) { ((VecShareSubFn)fe)(bj->x[i], x, off, PETSC_FALSE); CHKERRQ(ierr); }
+      ierr = KSPSolve(bj->ksp[i], bj->x[i], bj->y[i]);
+      /* the aliases come off first, also when the sub-solve failed: the work vectors own their storage again */
+      ierr2 = ((VecShareSubFn)fe)(bj->x[i], x, off, PETSC_FALSE);
+      if (!ierr2) ierr2 = ((VecShareSubFn)fe)(bj->y[i], y, off, PETSC_TRUE);
+      CHKERRQ(ierr); CHKERRQ(ierr2);
+    }
   } else {
     const PetscScalar *xa; PetscScalar *ya;
     ierr = VecGetArrayRead(x, &xa);CHKERRQ(ierr);
     ierr = VecGetArray(y, &ya);CHKERRQ(ierr);
-    ierr = VecPlaceArray(bj->x, xa);CHKERRQ(ierr);
-    ierr = VecPlaceArray(bj->y, ya);CHKERRQ(ierr);
-    ierr = KSPSolve(bj->ksp, bj->x, bj->y);
-    ierr2 = VecResetArray(bj->x);
-    if (!ierr2) ierr2 = VecResetArray(bj->y);
+    ierr = 0; ierr2 = 0;
+    for (PetscInt i = 0; i < bj->nloc && !ierr && !ierr2; i++) {
+      ierr = VecPlaceArray(bj->x[i], xa + bj->starts[i]);
+      if (!ierr) ierr = VecPlaceArray(bj->y[i], ya + bj->starts[i]);
+      if (!ierr) ierr = KSPSolve(bj->ksp[i], bj->x[i], bj->y[i]);
+      ierr2 = VecResetArray(bj->x[i]);
+      if (!ierr2) ierr2 = VecResetArray(bj->y[i]);
+    }
     CHKERRQ(ierr); CHKERRQ(ierr2);
     ierr = VecRestoreArrayRead(x, &xa);CHKERRQ(ierr);
     ierr = VecRestoreArray(y, &ya);CHKERRQ(ierr);
@@ -238,9 +301,13 @@ static PetscErrorCode PCDestroy_BJacobi(PC pc) {
   PetscErrorCode ierr;
   PC_BJacobi *bj = (PC_BJacobi *)pc->data;
   if (!bj) return 0;
-  ierr = KSPDestroy(&bj->ksp);CHKERRQ(ierr);
-  ierr = VecDestroy(&bj->x);CHKERRQ(ierr);
-  ierr = VecDestroy(&bj->y);CHKERRQ(ierr);
+  for (PetscInt i = 0; i < bj->nloc && bj->ksp; i++) {
+    ierr = KSPDestroy(&bj->ksp[i]);CHKERRQ(ierr);
+    ierr = VecDestroy(&bj->x[i]);CHKERRQ(ierr);
+    ierr = VecDestroy(&bj->y[i]);CHKERRQ(ierr);
+    if (bj->owns_blocks && bj->block[i]) { ierr = MatDestroy(&bj->block[i]);CHKERRQ(ierr); }
+  }
+  free(bj->starts); free(bj->ksp); free(bj->x); free(bj->y); free(bj->block);
   free(bj); pc->data = NULL;
   return 0;
 }
@@ -248,9 +315,16 @@ PetscErrorCode PCBJacobiGetSubKSP(PC pc, PetscInt *n_local, PetscInt *first_loca
   if (strcmp(pc->type_name, PCBJACOBI)) SETERRQ(pc->comm, PETSC_ERR_ARG_WRONG, "Cannot get subsolvers for this preconditioner");
   PC_BJacobi *bj = (PC_BJacobi *)pc->data;
   if (!bj->ksp) SETERRQ(pc->comm, PETSC_ERR_ARG_WRONGSTATE, "Must call KSPSetUp() or PCSetUp() first");
-  if (n_local) *n_local = 1;
-  if (first_local) *first_local = pc->comm->rank;
-  if (ksp) *ksp = &bj->ksp;
+  if (n_local) *n_local = bj->nloc;
+  if (first_local) {   /* blocks are numbered rank after rank (bjacobi.c PCBJacobiGetSubKSP_BJacobi) */
+    PetscInt nb = pc->comm->size; PetscBool set;
+    PetscOptionsGetInt(pc->prefix, "-pc_bjacobi_blocks", &nb, &set);
+    if (!set) nb = pc->comm->size;
+    PetscInt first = 0;
+    for (int r = 0; r < pc->comm->rank; r++) first += nb / pc->comm->size + ((nb % pc->comm->size) > r ? 1 : 0);
+    *first_local = first;
+  }
+  if (ksp) *ksp = bj->ksp;
   return 0;
 }
 PetscErrorCode PCCreate_BJacobi(PC pc) {

@@ -673,29 +673,37 @@ static PetscErrorCode VecJacobiInvert_HIP(Vec d) {
 }
 /* "VecShareArrayBegin_C" / "VecShareArrayEnd_C": sub borrows parent's DEVICE storage (PCApply_BJacobi_Singleblock's
  * VecPlaceArray of host arrays, bjacobi.c:738-761, without the host round trip) */
-static PetscErrorCode VecShareArrayBegin_HIP(Vec sub, Vec parent, PetscBool write) {
+static PetscErrorCode VecShareSubArrayBegin_HIP(Vec sub, Vec parent, PetscInt offset, PetscBool write) {
   PetscErrorCode ierr;
   Vec_HIPMI355X *s = VH(sub);
   PetscScalar *dp;
   if (!parent->data || !strstr(HipObjTypeName(parent), "hipmi355x")) SETERRQ(HipObjComm(sub), PETSC_ERR_ARG_NOTSAMETYPE, "cannot share the storage of a %s vector", HipObjTypeName(parent));
   if (s->alias_save) SETERRQ(HipObjComm(sub), PETSC_ERR_ARG_WRONGSTATE, "vector already shares another vector's storage");
-  if (sub->map->n != parent->map->n) SETERRQ(HipObjComm(sub), PETSC_ERR_ARG_SIZ, "local sizes %d and %d differ", sub->map->n, parent->map->n);
-  if (write) { ierr = VecHIPGetWrite(parent, &dp);CHKERRQ(ierr); }
+  if (offset < 0 || offset + sub->map->n > parent->map->n) SETERRQ(HipObjComm(sub), PETSC_ERR_ARG_SIZ, "%d entries from offset %d do not fit a vector of local size %d", sub->map->n, offset, parent->map->n);
+  /* a block's output slice: the parent keeps what the other blocks have written (read-write access), unless the slice is all of it */
+  if (write && offset == 0 && sub->map->n == parent->map->n) { ierr = VecHIPGetWrite(parent, &dp);CHKERRQ(ierr); }
+  else if (write) { ierr = VecHIPGetReadWrite(parent, &dp);CHKERRQ(ierr); }
   else { const PetscScalar *cp; ierr = VecHIPGetRead(parent, &cp);CHKERRQ(ierr); dp = (PetscScalar *)cp; }
   ierr = VecHIPGetWrite(sub, &s->alias_save);CHKERRQ(ierr);      /* makes sure sub owns device storage to come back to */
   s->alias_valid = s->valid;
-  s->dev = dp; s->valid = VALID_DEVICE;
+  s->dev = dp + offset; s->valid = VALID_DEVICE;
   HipStateIncrease(sub);
   return 0;
 }
-static PetscErrorCode VecShareArrayEnd_HIP(Vec sub, Vec parent, PetscBool write) {
+static PetscErrorCode VecShareSubArrayEnd_HIP(Vec sub, Vec parent, PetscInt offset, PetscBool write) {
   Vec_HIPMI355X *s = VH(sub);
+  (void)offset;
   if (!s->alias_save) return 0;
   s->dev = s->alias_save; s->valid = s->alias_valid; s->alias_save = NULL;
   HipStateIncrease(sub);
   if (write) return VecHIPRestoreWrite(parent);
   return 0;
 }
+static PetscErrorCode VecShareArrayBegin_HIP(Vec sub, Vec parent, PetscBool write) {
+  if (sub->map->n != parent->map->n) SETERRQ(HipObjComm(sub), PETSC_ERR_ARG_SIZ, "local sizes %d and %d differ", sub->map->n, parent->map->n);
+  return VecShareSubArrayBegin_HIP(sub, parent, 0, write);
+}
+static PetscErrorCode VecShareArrayEnd_HIP(Vec sub, Vec parent, PetscBool write) { return VecShareSubArrayEnd_HIP(sub, parent, 0, write); }
 /* KSPGMRESClassicalGramSchmidtOrthogonalization without refinement (borthog2.c:60-66) followed by gmres.c:146's VecNormalize,
  * with the scalars staying on the device: VecMDot leaves <w, V_j> in device scratch (all-reduced there over RCCL when the
  * communicator has one), one sweep does w -= sum_j h_j V_j AND sum w^2 (mi355x_vec_maxpy_dev_norm2: VecMAXPY's grouping, VecNorm's
@@ -792,6 +800,8 @@ static PetscErrorCode VecCreate_HIP_common(Vec v, const char *tname) {
   ierr = PetscObjectComposeFunction((PetscObject)v, "VecJacobiInvert_C", "VecJacobiInvert_HIP", (PetscVoidFunction)VecJacobiInvert_HIP);CHKERRQ(ierr);
   ierr = PetscObjectComposeFunction((PetscObject)v, "VecShareArrayBegin_C", "VecShareArrayBegin_HIP", (PetscVoidFunction)VecShareArrayBegin_HIP);CHKERRQ(ierr);
   ierr = PetscObjectComposeFunction((PetscObject)v, "VecShareArrayEnd_C", "VecShareArrayEnd_HIP", (PetscVoidFunction)VecShareArrayEnd_HIP);CHKERRQ(ierr);
+  ierr = PetscObjectComposeFunction((PetscObject)v, "VecShareSubArrayBegin_C", "VecShareSubArrayBegin_HIP", (PetscVoidFunction)VecShareSubArrayBegin_HIP);CHKERRQ(ierr);
+  ierr = PetscObjectComposeFunction((PetscObject)v, "VecShareSubArrayEnd_C", "VecShareSubArrayEnd_HIP", (PetscVoidFunction)VecShareSubArrayEnd_HIP);CHKERRQ(ierr);
   ierr = PetscObjectComposeFunction((PetscObject)v, "VecKrylovFusedOps_C", "VecKrylovFusedOps_HIP", (PetscVoidFunction)VecKrylovFusedOps_HIP);CHKERRQ(ierr);
   ierr = PetscObjectComposeFunction((PetscObject)v, "VecSplitReductionOps_C", "VecSplitReductionOps_HIP", (PetscVoidFunction)VecSplitReductionOps_HIP);CHKERRQ(ierr);
   return 0;

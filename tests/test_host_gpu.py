@@ -1012,6 +1012,40 @@ def test_ilu0_syncfree_solves_on_irregular_factors(P, shape):
         assert np.array_equal(bits(vx.array()), bits(first))
 
 
+@pytest.mark.parametrize("name,nblocks,err,nits", [("ex2_bjacobi_2.out", 2, "0.000496964", 4), ("ex2_bjacobi_3.out", 4, "0.000404746", 7)])
+def test_ksp_bjacobi_several_local_blocks_golden(P, name, nblocks, err, nits):
+    """ex2_bjacobi_2.out / ex2_bjacobi_3.out (tutorials makefile:355,360: 4 ranks, 2 and 4 blocks of 28 / 14 rows, inexact
+    GMRES + Jacobi sub-solves) reproduced on ONE rank with -pc_bjacobi_blocks 2 / 4: PCSetUp_BJacobi_Multiblock's even split
+    gives the same blocks; sub-vectors alias slices of the device vectors ("VecShareSubArrayBegin_C")"""
+    ai, aj, aa = pb.lap2d(8, 7)
+    u = np.ones(56)
+    b = orc.spmv(ai, aj, aa, u)
+    gold = pb.parse_monitor(os.path.join(G, "ksp_tutorials", name))[0]
+    x, h, its, reason = solve(P, ai, aj, aa, b, "gmres", "bjacobi", opts="-pc_bjacobi_blocks %d -sub_pc_type jacobi -sub_ksp_type gmres" % nblocks,
+                              rtol=1e-2 / 72, abstol=1e-50)
+    pb.check_monitor(h, gold)
+    assert its == nits and "%g" % np.linalg.norm(x - u) == err
+
+
+@pytest.mark.parametrize("nblocks,sub", [(4, "-sub_pc_type ilu"), (7, "-sub_pc_type jacobi"), (3, "-sub_ksp_type gmres -sub_pc_type jacobi -sub_ksp_rtol 1e-3")])
+def test_ksp_bjacobi_several_local_blocks_equal_the_oracle_bit_for_bit(P, nblocks, sub):
+    """GMRES + block Jacobi with several blocks on one rank (uneven split: 2210 rows), ILU(0) / Jacobi / inexact GMRES sub-solves:
+    history and solution equal the oracle's block-Jacobi restatement bit for bit under the device summation order"""
+    ai, aj, aa = orc.gen_p7(17, 13, 10)
+    aa = aa * (1.0 + 0.3 * np.sin(0.7 * np.arange(aa.size)))
+    n = ai.size - 1
+    b = np.cos(0.37 * np.arange(n)) + 0.1
+    x, h, its, reason = solve(P, ai, aj, aa, b, "gmres", "bjacobi", opts="-pc_bjacobi_blocks %d %s" % (nblocks, sub), rtol=1e-10, max_it=300)
+    starts = [0]
+    for i in range(nblocks):
+        starts.append(starts[-1] + n // nblocks + (1 if (n % nblocks) > i else 0))
+    okw = dict(sub_ksp="gmres", sub_pc="jacobi", sub_rtol=1e-3) if "gmres" in sub else dict(sub_ksp="preonly", sub_pc="ilu" if "ilu" in sub else "jacobi")
+    with orc.device_reduction_order():
+        xo, ho, ito, ro = orc.ksp_solve(ai, aj, aa, b, ksp="gmres", pc="bjacobi", blocks=starts, rtol=1e-10, max_it=300, **okw)
+    assert (its, reason) == (ito, ro) and its > 5
+    assert np.array_equal(h.view(np.uint64), ho.view(np.uint64)) and np.array_equal(x.view(np.uint64), xo.view(np.uint64))
+
+
 def test_ksp_bjacobi_single_block_golden(P):
     """ex2_bjacobi.out: one block, sub-KSP GMRES + Jacobi (-sub_ksp_type gmres -sub_pc_type jacobi); device-side aliasing
     of the work vectors instead of the reference's host VecPlaceArray round trip"""

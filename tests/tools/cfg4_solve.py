@@ -16,6 +16,7 @@ import problems as pb  # noqa: E402
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "fem"
     sub = sys.argv[2] if len(sys.argv) > 2 else "ilu"
+    nblocks = int(sys.argv[3]) if len(sys.argv) > 3 else 1          # -pc_bjacobi_blocks on the one rank
     import petsc_dev_amd as pda
     from petsc_dev_amd import petsc as P
     L = P.lib(); k = pda.load_kernels()
@@ -29,18 +30,18 @@ def main():
     A.mult(x, b)
     ksp = P.KSP(comm=L.COMM_SELF)
     ksp.set_operators(A); ksp.set_type("gmres")
-    if sub == "ilu":      # one rank: block Jacobi with one block and ILU(0) inside IS PCILU (the reference's default on one rank)
+    if sub == "ilu" and nblocks == 1:      # one rank: block Jacobi with one block and ILU(0) inside IS PCILU (the reference's default on one rank)
         ksp.set_pc_type("ilu")
     else:
         ksp.set_pc_type("bjacobi")
-        L.PetscOptionsClear(); L.PetscOptionsInsertString(("-sub_pc_type %s" % sub).encode())
+        L.PetscOptionsClear(); L.PetscOptionsInsertString(("-sub_pc_type %s -pc_bjacobi_blocks %d" % (sub, nblocks)).encode())
     ksp.set_from_options()
     ksp.set_tolerances(rtol=0.0, abstol=1e-300, dtol=1e300, max_it=35)
     t0 = time.time()
     ksp.solve(b, u)                 # PCSetUp (factorisation, level analysis, upload) happens here
     k.mi355x_device_synchronize()
     print("set-up + 35 warm-up iterations: %.2f s" % (time.time() - t0), flush=True)
-    if sub == "ilu":
+    if sub == "ilu" and nblocks == 1:
         pc = C.c_void_p(); L.KSPGetPC(ksp.h, C.byref(pc))
         nl, nu = C.c_int(), C.c_int(); L.PCILUGetLevels_HIPMI355X(pc, C.byref(nl), C.byref(nu))
         for _ in range(3):
@@ -60,7 +61,7 @@ def main():
     ksp.solve(b, u)
     k.mi355x_device_synchronize()
     dt = time.perf_counter() - t0
-    print("%s GMRES(30) + bjacobi(%s): %d its in %.3f s = %.1f it/s (%.3f ms per iteration)" % (which, sub, ksp.its, dt, ksp.its / dt, dt / ksp.its * 1e3), flush=True)
+    print("%s GMRES(30) + bjacobi(%s, %d block%s): %d its in %.3f s = %.1f it/s (%.3f ms per iteration)" % (which, sub, nblocks, "" if nblocks == 1 else "s", ksp.its, dt, ksp.its / dt, dt / ksp.its * 1e3), flush=True)
     ksp.set_tolerances(rtol=1e-8, abstol=1e-50, dtol=1e5, max_it=2000)
     L.VecSet(u.h, 0.0)
     t0 = time.perf_counter()
