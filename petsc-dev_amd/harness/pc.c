@@ -176,6 +176,7 @@ typedef struct {
   Vec *x, *y;               /* sequential work vectors per block */
   Mat *block;               /* nloc == 1: the diagonal block itself (not owned); else extracted copies (owned) */
   PetscBool owns_blocks;
+  PetscBool merged;         /* several blocks, every sub-solver KSPPREONLY + PCILU: ONE solver over the block-diagonal matrix */
 } PC_BJacobi;
 typedef PetscErrorCode (*MatSeqAIJGetArraysFn)(Mat, PetscInt *, const PetscInt **, const PetscInt **, const PetscScalar **);
 
@@ -200,6 +201,33 @@ static PetscErrorCode extract_diagonal_block(Mat A, PetscInt s, PetscInt e, Mat 
     si[r - s + 1] = nz;
   }
   ierr = MatCreateSeqAIJWithArrays(PETSC_COMM_SELF, e - s, e - s, si, sj, sa, sub);   /* the arrays are copied */
+  free(si); free(sj); free(sa);
+  CHKERRQ(ierr);
+  return 0;
+}
+
+/* the matrix with every coupling between different blocks dropped.  Its ILU(0) factors are the blocks' ILU(0) factors side by
+ * side (nothing couples them), and one triangular solve over it does all blocks' solves at once -- their dependency levels
+ * overlap -- with each block's arithmetic unchanged: what the reference computes block after block (bjacobi.c:1140-1180) */
+static PetscErrorCode extract_block_diagonal(Mat A, PetscInt nloc, const PetscInt *starts, Mat *sub) {
+  PetscErrorCode ierr;
+  PetscVoidFunction f = NULL;
+  PetscInt m; const PetscInt *ai, *aj; const PetscScalar *aa;
+  ierr = PetscObjectQueryFunction((PetscObject)A, "MatSeqAIJGetArrays_C", &f);CHKERRQ(ierr);
+  if (!f) SETERRQ(A->comm, PETSC_ERR_SUP, "several block-Jacobi blocks per process need a sequential AIJ diagonal block, got %s", A->type_name);
+  ierr = ((MatSeqAIJGetArraysFn)f)(A, &m, &ai, &aj, &aa);CHKERRQ(ierr);
+  if (A->rmap->n != m) SETERRQ(A->comm, PETSC_ERR_SUP, "several block-Jacobi blocks per process are ported for block size 1");
+  PetscInt nz = 0, *si, *sj; PetscScalar *sa;
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)(m + 1), &si);CHKERRQ(ierr);
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)PetscMax(ai[m], 1), &sj);CHKERRQ(ierr);
+  ierr = PetscMalloc(sizeof(PetscScalar) * (size_t)PetscMax(ai[m], 1), &sa);CHKERRQ(ierr);
+  si[0] = 0;
+  for (PetscInt b = 0; b < nloc; b++)
+    for (PetscInt r = starts[b]; r < starts[b + 1]; r++) {
+      for (PetscInt k = ai[r]; k < ai[r + 1]; k++) if (aj[k] >= starts[b] && aj[k] < starts[b + 1]) { sj[nz] = aj[k]; sa[nz] = aa[k]; nz++; }
+      si[r + 1] = nz;
+    }
+  ierr = MatCreateSeqAIJWithArrays(PETSC_COMM_SELF, m, m, si, sj, sa, sub);
   free(si); free(sj); free(sa);
   CHKERRQ(ierr);
   return 0;
@@ -232,12 +260,22 @@ static PetscErrorCode PCSetUp_BJacobi(PC pc) {
     bj->starts[0] = 0;
     for (PetscInt i = 0; i < nloc; i++) bj->starts[i + 1] = bj->starts[i] + M / nloc + ((M % nloc) > i ? 1 : 0);
     bj->owns_blocks = (PetscBool)(nloc > 1);
+    if (nloc > 1) {   /* all sub-solvers "apply ILU(0) once" (the defaults): one solver over the block-diagonal matrix */
+      char kt[32] = "", pt[32] = "", mg[16] = ""; PetscBool ks, ps, ms;
+      snprintf(prefix, sizeof(prefix), "%ssub_", pc->prefix);
+      ierr = PetscOptionsGetString(prefix, "-ksp_type", kt, sizeof(kt), &ks);CHKERRQ(ierr);
+      ierr = PetscOptionsGetString(prefix, "-pc_type", pt, sizeof(pt), &ps);CHKERRQ(ierr);
+      ierr = PetscOptionsGetString(pc->prefix, "-pc_bjacobi_merge_blocks", mg, sizeof(mg), &ms);CHKERRQ(ierr);   /* 0: block after block */
+      bj->merged = (PetscBool)((!ks || !strcmp(kt, KSPPREONLY)) && (!ps || !strcmp(pt, PCILU)) && !(ms && (!strcmp(mg, "0") || !strcmp(mg, "false"))));
+    }
   }
-  for (PetscInt i = 0; i < nloc; i++) {
+  const PetscInt nsolvers = bj->merged ? 1 : nloc;
+  for (PetscInt i = 0; i < nsolvers; i++) {
     if (nloc == 1) bj->block[0] = diag;
     else {
       if (bj->block[i]) { ierr = MatDestroy(&bj->block[i]);CHKERRQ(ierr); }     /* values may have changed: extract again */
-      ierr = extract_diagonal_block(diag, bj->starts[i], bj->starts[i + 1], &bj->block[i]);CHKERRQ(ierr);
+      if (bj->merged) { ierr = extract_block_diagonal(diag, nloc, bj->starts, &bj->block[0]);CHKERRQ(ierr); }
+      else { ierr = extract_diagonal_block(diag, bj->starts[i], bj->starts[i + 1], &bj->block[i]);CHKERRQ(ierr); }
     }
     if (!bj->ksp[i]) {
       ierr = KSPCreate(PETSC_COMM_SELF, &bj->ksp[i]);CHKERRQ(ierr);
@@ -251,6 +289,7 @@ static PetscErrorCode PCSetUp_BJacobi(PC pc) {
     ierr = KSPSetFromOptions(bj->ksp[i]);CHKERRQ(ierr);
     ierr = KSPSetUp(bj->ksp[i]);CHKERRQ(ierr);
   }
+  if (bj->merged) for (PetscInt i = 1; i < nloc; i++) bj->ksp[i] = bj->ksp[0];   /* PCBJacobiGetSubKSP: every block answers with the one solver */
   return 0;
 }
 
@@ -266,9 +305,10 @@ static PetscErrorCode PCApply_BJacobi(PC pc, Vec x, Vec y) {
   PetscVoidFunction fb, fe;
   ierr = PetscObjectQueryFunction((PetscObject)bj->x[0], "VecShareSubArrayBegin_C", &fb);CHKERRQ(ierr);
   ierr = PetscObjectQueryFunction((PetscObject)bj->x[0], "VecShareSubArrayEnd_C", &fe);CHKERRQ(ierr);
+  const PetscInt nsolvers = bj->merged ? 1 : bj->nloc;
   if (fb && fe) {
-    for (PetscInt i = 0; i < bj->nloc; i++) {
-      const PetscInt off = bj->starts[i];
+    for (PetscInt i = 0; i < nsolvers; i++) {
+      const PetscInt off = bj->merged ? 0 : bj->starts[i];
       ierr = ((VecShareSubFn)fb)(bj->x[i], x, off, PETSC_FALSE);CHKERRQ(ierr);
       ierr = ((VecShareSubFn)fb)(bj->y[i], y, off, PETSC_TRUE);
       if (ierr) { ((VecShareSubFn)fe)(bj->x[i], x, off, PETSC_FALSE); CHKERRQ(ierr); }
@@ -283,9 +323,10 @@ static PetscErrorCode PCApply_BJacobi(PC pc, Vec x, Vec y) {
     ierr = VecGetArrayRead(x, &xa);CHKERRQ(ierr);
     ierr = VecGetArray(y, &ya);CHKERRQ(ierr);
     ierr = 0; ierr2 = 0;
-    for (PetscInt i = 0; i < bj->nloc && !ierr && !ierr2; i++) {
-      ierr = VecPlaceArray(bj->x[i], xa + bj->starts[i]);
-      if (!ierr) ierr = VecPlaceArray(bj->y[i], ya + bj->starts[i]);
+    for (PetscInt i = 0; i < nsolvers && !ierr && !ierr2; i++) {
+      const PetscInt off = bj->merged ? 0 : bj->starts[i];
+      ierr = VecPlaceArray(bj->x[i], xa + off);
+      if (!ierr) ierr = VecPlaceArray(bj->y[i], ya + off);
       if (!ierr) ierr = KSPSolve(bj->ksp[i], bj->x[i], bj->y[i]);
       ierr2 = VecResetArray(bj->x[i]);
       if (!ierr2) ierr2 = VecResetArray(bj->y[i]);
@@ -301,7 +342,7 @@ static PetscErrorCode PCDestroy_BJacobi(PC pc) {
   PetscErrorCode ierr;
   PC_BJacobi *bj = (PC_BJacobi *)pc->data;
   if (!bj) return 0;
-  for (PetscInt i = 0; i < bj->nloc && bj->ksp; i++) {
+  for (PetscInt i = 0; i < (bj->merged ? 1 : bj->nloc) && bj->ksp; i++) {
     ierr = KSPDestroy(&bj->ksp[i]);CHKERRQ(ierr);
     ierr = VecDestroy(&bj->x[i]);CHKERRQ(ierr);
     ierr = VecDestroy(&bj->y[i]);CHKERRQ(ierr);

@@ -1027,10 +1027,12 @@ def test_ksp_bjacobi_several_local_blocks_golden(P, name, nblocks, err, nits):
     assert its == nits and "%g" % np.linalg.norm(x - u) == err
 
 
-@pytest.mark.parametrize("nblocks,sub", [(4, "-sub_pc_type ilu"), (7, "-sub_pc_type jacobi"), (3, "-sub_ksp_type gmres -sub_pc_type jacobi -sub_ksp_rtol 1e-3")])
+@pytest.mark.parametrize("nblocks,sub", [(4, "-sub_pc_type ilu"), (4, "-sub_pc_type ilu -pc_bjacobi_merge_blocks 0"), (5, ""), (7, "-sub_pc_type jacobi"), (3, "-sub_ksp_type gmres -sub_pc_type jacobi -sub_ksp_rtol 1e-3")])
 def test_ksp_bjacobi_several_local_blocks_equal_the_oracle_bit_for_bit(P, nblocks, sub):
     """GMRES + block Jacobi with several blocks on one rank (uneven split: 2210 rows), ILU(0) / Jacobi / inexact GMRES sub-solves:
-    history and solution equal the oracle's block-Jacobi restatement bit for bit under the device summation order"""
+    history and solution equal the oracle's block-Jacobi restatement bit for bit under the device summation order -- also when
+    the ILU(0) blocks are solved as ONE triangular solve over the block-diagonal matrix (the default for preonly + ILU
+    sub-solvers; -pc_bjacobi_merge_blocks 0: block after block)"""
     ai, aj, aa = orc.gen_p7(17, 13, 10)
     aa = aa * (1.0 + 0.3 * np.sin(0.7 * np.arange(aa.size)))
     n = ai.size - 1
@@ -1039,7 +1041,7 @@ def test_ksp_bjacobi_several_local_blocks_equal_the_oracle_bit_for_bit(P, nblock
     starts = [0]
     for i in range(nblocks):
         starts.append(starts[-1] + n // nblocks + (1 if (n % nblocks) > i else 0))
-    okw = dict(sub_ksp="gmres", sub_pc="jacobi", sub_rtol=1e-3) if "gmres" in sub else dict(sub_ksp="preonly", sub_pc="ilu" if "ilu" in sub else "jacobi")
+    okw = dict(sub_ksp="gmres", sub_pc="jacobi", sub_rtol=1e-3) if "gmres" in sub else dict(sub_ksp="preonly", sub_pc="jacobi" if "jacobi" in sub else "ilu")
     with orc.device_reduction_order():
         xo, ho, ito, ro = orc.ksp_solve(ai, aj, aa, b, ksp="gmres", pc="bjacobi", blocks=starts, rtol=1e-10, max_it=300, **okw)
     assert (its, reason) == (ito, ro) and its > 5
