@@ -1037,13 +1037,13 @@ def test_ksp_bjacobi_several_local_blocks_equal_the_oracle_bit_for_bit(P, nblock
     aa = aa * (1.0 + 0.3 * np.sin(0.7 * np.arange(aa.size)))
     n = ai.size - 1
     b = np.cos(0.37 * np.arange(n)) + 0.1
-    x, h, its, reason = solve(P, ai, aj, aa, b, "gmres", "bjacobi", opts="-pc_bjacobi_blocks %d %s" % (nblocks, sub), rtol=1e-10, max_it=300)
+    x, h, its, reason = solve(P, ai, aj, aa, b, "gmres", "bjacobi", opts="-pc_bjacobi_blocks %d %s" % (nblocks, sub), rtol=1e-10, max_it=60)
     starts = [0]
     for i in range(nblocks):
         starts.append(starts[-1] + n // nblocks + (1 if (n % nblocks) > i else 0))
-    okw = dict(sub_ksp="gmres", sub_pc="jacobi", sub_rtol=1e-3) if "gmres" in sub else dict(sub_ksp="preonly", sub_pc="jacobi" if "jacobi" in sub else "ilu")
+    okw = dict(sub_ksp="gmres", sub_pc="jacobi", sub_rtol=1e-3) if "gmres" in sub else dict(sub_ksp="preonly", sub_pc="jacobi" if "-sub_pc_type jacobi" in sub else "ilu")
     with orc.device_reduction_order():
-        xo, ho, ito, ro = orc.ksp_solve(ai, aj, aa, b, ksp="gmres", pc="bjacobi", blocks=starts, rtol=1e-10, max_it=300, **okw)
+        xo, ho, ito, ro = orc.ksp_solve(ai, aj, aa, b, ksp="gmres", pc="bjacobi", blocks=starts, rtol=1e-10, max_it=60, **okw)
     assert (its, reason) == (ito, ro) and its > 5
     assert np.array_equal(h.view(np.uint64), ho.view(np.uint64)) and np.array_equal(x.view(np.uint64), xo.view(np.uint64))
 
