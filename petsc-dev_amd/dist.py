@@ -143,22 +143,31 @@ def torch_comm(device_comm=True):
         ndev = C.c_int()
         k.mi355x_device_count(C.byref(ndev))
         dev = int(os.environ.get("LOCAL_RANK", "0")) % max(ndev.value, 1)
+        dcomms, why = [], ""
         rc = k.mi355x_set_device(dev)
-        if rc:
-            raise RuntimeError("hipSetDevice(%d) failed: %s" % (dev, k.mi355x_error_string(rc).decode()))
+        if rc:   # no exception here: the other ranks are about to enter a broadcast and must not be left waiting
+            why = "hipSetDevice(%d) failed: %s" % (dev, k.mi355x_error_string(rc).decode())
         # TWO communicators over the same ranks, one per HIP stream: RCCL runs the operations of one communicator one
         # after the other in issue order whatever streams they are given, so the halo exchange (halo stream) and the
         # scalar all-reduces (compute stream) each get their own.  Every rank issues its operations in the same
         # program order (the solvers are SPMD), which is what concurrent use of two communicators requires.
-        dcomms, why = [], ""
         for which in ("reductions", "halo"):
             uid = C.create_string_buffer(128)
+            have_id = True
             if rank == 0:
-                rc = k.mi355x_comm_get_unique_id(uid)
+                rc = k.mi355x_comm_get_unique_id(uid) if not why else 1
                 if rc:
-                    raise RuntimeError("ncclGetUniqueId failed: %s" % k.mi355x_comm_error_string(rc).decode())
-            obj = [uid.raw]
+                    have_id = False
+                    why = why or "ncclGetUniqueId failed: %s" % k.mi355x_comm_error_string(rc).decode()
+            obj = [uid.raw if have_id else b""]
             dist.broadcast_object_list(obj, src=0)
+            if not obj[0]:
+                why = why or "rank 0 could not create an RCCL unique id"
+            ok = torch.tensor([0 if why else 1], dtype=torch.int32)      # everybody continues, or nobody
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok[0]) != 1:
+                why = why or "another rank failed before ncclCommInitRank"
+                break
             dcomm = C.c_void_p()
             rc = k.mi355x_comm_init_rank(C.byref(dcomm), size, rank, obj[0])
             if rc:
