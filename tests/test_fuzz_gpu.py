@@ -3,6 +3,7 @@ the oracle: row-length mixes that put row-block boundaries at odd/even offsets, 
 single-row and single-entry matrices, rows that span the LDS stage, banded patterns that compress and random ones that
 do not.  Short rows (<= 16 per row on average in a block) must match bit for bit, the others to 1e-12 * sum|a x|."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -24,8 +25,11 @@ def bits(a):
     return np.ascontiguousarray(a).view(np.uint64)
 
 
+FUZZ_OFFSET = int(os.environ.get("FUZZ_OFFSET", "0"))   # extended runs: FUZZ_OFFSET=100000 python -m pytest tests/test_fuzz_gpu.py
+
+
 def make_case(seed):
-    rng = np.random.default_rng(1000 + seed)
+    rng = np.random.default_rng(1000 + seed + FUZZ_OFFSET)
     kind = seed % 8
     m = int(rng.integers(1, 6000))
     n = m if kind in (0, 1, 2, 3) else int(rng.integers(1, 6000))
@@ -124,7 +128,7 @@ def test_spmv_random_shapes(dev, seed):
 @pytest.mark.parametrize("seed", range(16))
 def test_bsr_random_shapes(dev, seed):
     k = dev.k
-    rng = np.random.default_rng(3000 + seed)
+    rng = np.random.default_rng(3000 + seed + FUZZ_OFFSET)
     bs = int(rng.integers(2, 9))
     mbs = int(rng.integers(1, 1200)); nbs = int(rng.integers(1, 1200))
     maxb = [1, 3, 10, 40, 300][seed % 5]
@@ -166,7 +170,7 @@ def test_ksp_random_small_systems(P, seed):
     """every solver x preconditioner of the path on small random diagonally dominant systems (sizes 1..700, also
     n = 1 and n = 2, symmetric for CG) against the oracle: same convergence reason, iteration count within +-1
     (BiCGStab: +-max(2, 20 %)), histories to 1e-6 while the residual is above 1e-4 of its start, same solution."""
-    rng = np.random.default_rng(5000 + seed)
+    rng = np.random.default_rng(5000 + seed + FUZZ_OFFSET)
     ksp = ["cg", "gmres", "bcgs"][seed % 3]
     pc = ["none", "jacobi", "bjacobi", "ilu"][(seed // 3) % 4]
     n = [1, 2, 3, 17, 64, 257, 700][seed % 7]
