@@ -5,9 +5,11 @@
 A step = one CG iteration of the reference's KSPSolve_CG op sequence over the HIPMI355X Vec/Mat types:
 1 SpMV (MatMult_SeqAIJ / MatMult_MPIAIJ with RCCL halo), 1 Jacobi apply, 2 dots, 1 norm, 2 axpy, 1 aypx.
 value = iterations/s x global unknowns (aggregates over ranks under weak scaling); ksp_its_per_sec and
-spmv_gbps carry BASELINE.json's two quantities as absolute numbers.  roofline: the SpMV kernel, timed
-with HIP events on the compute stream inside the timed solve.  cpu_baseline: the oracle's C
-restatement of the same solve on one host core, bounded sample (rank 0, N=1 only).
+spmv_gbps carry BASELINE.json's two quantities as absolute numbers.  The two kernels that make up three quarters of an
+iteration -- the SpMV and the fused CG update -- are both timed with HIP events on the compute stream inside the timed solve
+(roofline_spmv, roofline_cg_update); roofline is whichever of the two took longer.  csr_streaming: the same solve with
+the matrix's value array streamed (value patterns switched off), measured in the same run.  cpu_baseline: the oracle's
+C restatement of the same solve on the host cores, bounded sample (rank 0, N=1 only).
 """
 import argparse
 import ctypes as C
@@ -101,34 +103,39 @@ def main():
             dist.barrier()
 
     k = pda.load_kernels()
-    # warm-up: W untimed iterations (also uploads the matrix, builds the Jacobi diagonal)
-    ksp.set_tolerances(rtol=0.0, abstol=1e-300, dtol=1e300, max_it=max(args.warmup, 1))
-    ksp.solve(b, x)
-    k.mi355x_device_synchronize()
-    L.MatHIPMI355XSetTiming(timed, 0 if os.environ.get("BENCH_NO_SPMV_EVENTS") else 1)   # (development: cost of the event pairs)
-    ksp.set_tolerances(rtol=0.0, abstol=1e-300, dtol=1e300, max_it=args.steps)
-    barrier()
-    k.mi355x_device_synchronize()
-    t0 = time.perf_counter()
-    ksp.solve(b, x)
-    k.mi355x_device_synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
-    its = ksp.its
-    nl, tms = C.c_int(), C.c_double()
-    L.MatHIPMI355XGetTiming(timed, C.byref(nl), C.byref(tms))
-    L.MatHIPMI355XSetTiming(timed, 0)
-    if dist is not None:
-        import torch
-        t = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t[0])
-        s = torch.tensor([tms.value / max(nl.value, 1)], dtype=torch.float64)
-        dist.all_reduce(s, op=dist.ReduceOp.MAX)
-        spmv_ms = float(s[0])
-    else:
+
+    def timed_solve():
+        """W untimed iterations (the first call also uploads the matrix and builds the Jacobi diagonal), then exactly K timed ones"""
+        ksp.set_tolerances(rtol=0.0, abstol=1e-300, dtol=1e300, max_it=max(args.warmup, 1))
+        ksp.solve(b, x)
+        k.mi355x_device_synchronize()
+        ev = 0 if os.environ.get("BENCH_NO_SPMV_EVENTS") else 1                      # (development: cost of the event pairs)
+        L.MatHIPMI355XSetTiming(timed, ev)
+        L.VecHIPMI355XSetCGUpdateTiming(ev)
+        ksp.set_tolerances(rtol=0.0, abstol=1e-300, dtol=1e300, max_it=args.steps)
+        barrier()
+        k.mi355x_device_synchronize()
+        t0 = time.perf_counter()
+        ksp.solve(b, x)
+        k.mi355x_device_synchronize()
+        barrier()
+        dt = time.perf_counter() - t0
+        assert ksp.its == args.steps, "solver stopped after %d of %d iterations (reason %d)" % (ksp.its, args.steps, ksp.reason)
+        nl, tms, nu, ums = C.c_int(), C.c_double(), C.c_int(), C.c_double()
+        L.MatHIPMI355XGetTiming(timed, C.byref(nl), C.byref(tms))
+        L.VecHIPMI355XGetCGUpdateTiming(C.byref(nu), C.byref(ums))
+        L.MatHIPMI355XSetTiming(timed, 0)
+        L.VecHIPMI355XSetCGUpdateTiming(0)
         spmv_ms = tms.value / max(nl.value, 1)
-    assert its == args.steps, "solver stopped after %d of %d iterations (reason %d)" % (its, args.steps, ksp.reason)
+        upd_ms = ums.value / max(nu.value, 1)
+        if dist is not None:
+            import torch
+            t = torch.tensor([dt, spmv_ms, upd_ms], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt, spmv_ms, upd_ms = float(t[0]), float(t[1]), float(t[2])
+        return dt, spmv_ms, nl.value, upd_ms, nu.value
+
+    dt, spmv_ms, spmv_launches, upd_ms, upd_launches = timed_solve()
 
     its_per_s = args.steps / dt
     unknowns = mloc * world
@@ -142,7 +149,20 @@ def main():
     L.MatHIPMI355XGetIndexCompression(timed, C.byref(noff))
     npat = C.c_int()
     L.MatHIPMI355XGetRowPatterns(timed, C.byref(npat))
-    if npat.value:
+    nvpat = C.c_int()
+    L.MatHIPMI355XGetValuePatterns(timed, C.byref(nvpat))
+
+    def streamed_kernel_name():
+        if npat.value:
+            return "spmv_csr_rowblock_pat_kernel (CSR values + a %d-list row-pattern dictionary: one 4-byte word per row instead of column indices and row pointer; 'achieved' uses the CSR algorithmic bytes)" % npat.value
+        if noff.value:
+            return "spmv_csr_rowblock_idx8_kernel (CSR + 1-byte offset-dictionary column indices, %d offsets; 'achieved' uses the CSR algorithmic bytes)" % noff.value
+        return "spmv_csr_rowblock_kernel"
+
+    if nvpat.value:
+        kernel_name = ("spmv_csr_valpat_kernel (constant-coefficient operator: %d distinct rows {offsets, values} in a dictionary, 2 bytes per row, "
+                       "the value array is not read; 'achieved' uses the CSR algorithmic bytes)" % nvpat.value)
+    elif npat.value:
         kernel_name = "spmv_csr_rowblock_pat_kernel (CSR values + a %d-list row-pattern dictionary: one 4-byte word per row instead of column indices and row pointer; 'achieved' uses the CSR algorithmic bytes)" % npat.value
     elif noff.value:
         kernel_name = "spmv_csr_rowblock_idx8_kernel (CSR + 1-byte offset-dictionary column indices, %d offsets; 'achieved' uses the CSR algorithmic bytes)" % noff.value
@@ -170,50 +190,88 @@ def main():
         "ksp_gbps": round(cg_bytes * its_per_s * world / 1e9, 1),
         "ksp_hbm_frac": round(cg_bytes * its_per_s / 8e12, 4),
         "ksp_gbps_basis": "SURVEY 8(d) algorithmic bytes of the reference's op-by-op iteration (SpMV + 17 vector passes); the fused CG update moves 13 passes",
-        "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": round(spmv_gbps_one, 1), "peak": 8000.0,
-                     "unit": "GB/s", "frac": round(spmv_gbps_one / 8000.0, 4), "traffic": None,
-                     "basis": "achieved/frac price the launch in the reference CSR's bytes (SURVEY 8d: 12 B per nonzero + 4 B per row + x + y); "
-                              "a kernel that streams fewer index bytes can exceed 1.0 on that basis -- traffic / traffic_frac are the bytes it really moved",
-                     "algorithmic_bytes_per_launch": spmv_bytes, "avg_launch_ms": round(spmv_ms, 5), "launches_timed": nl.value},
         "setup_s": round(setup_s, 2),
     }
+    BASIS = ("achieved/frac price the launch in the reference's bytes (SURVEY 8d: 12 B per nonzero + 4 B per row + x + y for the CSR "
+             "product; the op-by-op vector passes for the update); a kernel that moves fewer bytes than the reference's sequence can "
+             "exceed 1.0 on that basis -- traffic / traffic_frac are the bytes it really moved")
+    # the SpMV (the kernel SURVEY 8d prices) ...
+    r_spmv = {"bound": "hbm", "kernel": kernel_name, "achieved": round(spmv_gbps_one, 1), "peak": 8000.0,
+              "unit": "GB/s", "frac": round(spmv_gbps_one / 8000.0, 4), "traffic": None, "basis": BASIS,
+              "algorithmic_bytes_per_launch": spmv_bytes, "avg_launch_ms": round(spmv_ms, 5), "launches_timed": spmv_launches}
+    if nvpat.value:
+        r_spmv["limiter"] = ("not HBM: with the value array out of the way the launch moves ~0.31 GB (x once, y once, 2 B per row) and is bound "
+                             "by the CUs' L1 / instruction issue on the x gathers (DESIGN.md section 4); traffic_frac says how far from the memory roof it runs")
+    # ... and the fused CG update (VecAXPY, VecAXPY, PCApply_Jacobi, VecNorm, VecTDot of cg.c:206-232 in one sweep): the
+    # reference's five operations make 12 vector passes, the kernel 8 (reads x p r w d, writes x r z)
+    upd_bytes = 12 * 8 * mloc
+    upd_gbps = upd_bytes / (upd_ms * 1e-3) / 1e9 if upd_ms > 0 else 0.0
+    r_upd = {"bound": "hbm", "kernel": "reduce_kernel<4, 0, CGUpdateDevF> (x += a p, r -= a w, z = r .* d, z'z, z'r, r'r in one sweep; 'achieved' uses the "
+                                       "12 vector passes of the reference's five operations, the kernel makes 8)",
+             "achieved": round(upd_gbps, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(upd_gbps / 8000.0, 4), "traffic": None, "basis": BASIS,
+             "algorithmic_bytes_per_launch": upd_bytes, "avg_launch_ms": round(upd_ms, 5), "launches_timed": upd_launches}
 
-    # HBM traffic of the same kernel from the committed rocprofv3 PMC passes of this command (separate
+    # HBM traffic of the two kernels from the committed rocprofv3 PMC passes of this command (separate
     # FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE x2 on gfx950, calibration in profiles/r01_fetch_calibration.md)
     try:
         import csv
         import hashlib
-        fs = ws = None
-        src_hash = hashlib.sha256(open(os.path.join(ROOT, "petsc-dev_amd", "csrc", "spmv_csr.hip"), "rb").read()).hexdigest()[:16]
+        cnt = {}
         pmc_csv = os.path.join(ROOT, "profiles", "bench_pmc_summary.csv")
-        # the counters are only quoted while they describe THIS kernel: the summary's first line carries the hash of the
-        # kernel source it was collected with (tests/tools/pmc_summary.py --stamp); a stale file is ignored
+        # the counters are only quoted while they describe THESE kernels: the summary's first line carries the hashes of the
+        # kernel sources it was collected with (tests/tools/pmc_summary.py --stamp); a stale file is ignored
         head = open(pmc_csv).readline()
-        if ("spmv_csr.hip sha256/16 = " + src_hash) not in head:
-            raise RuntimeError("stale PMC summary")
+        for src in ("spmv_csr.hip", "vec_kernels.hip"):
+            h16 = hashlib.sha256(open(os.path.join(ROOT, "petsc-dev_amd", "csrc", src), "rb").read()).hexdigest()[:16]
+            if ("%s sha256/16 = %s" % (src, h16)) not in head:
+                raise RuntimeError("stale PMC summary")
+        spmv_tag = "spmv_csr_valpat_kernel<0>" if nvpat.value else "spmv_csr_rowblock"
         with open(pmc_csv) as f:
             f.readline()
             for row in csv.DictReader(f):
-                if "spmv_csr_rowblock" in row["kernel"] and ("kernel<0," in row["kernel"] or "kernel<0>" in row["kernel"]):   # the y = A x instantiation (ADD == 0)
-                    if row["counter"] == "FETCH_SIZE":
-                        fs = float(row["avg_value_KB"])
-                    elif row["counter"] == "WRITE_SIZE":
-                        ws = float(row["avg_value_KB"])
-        if fs is not None and ws is not None and n == 256 and world == 1:
-            out["roofline"]["traffic"] = int((2.0 * fs + ws) * 1024)
-            # what the kernel really moved per second (the index-compressed stream is smaller than CSR's): frac uses the CSR
-            # algorithmic bytes as the contract asks, traffic_frac the measured bytes
-            out["roofline"]["traffic_gbps"] = round(out["roofline"]["traffic"] / (out["roofline"]["avg_launch_ms"] * 1e-3) / 1e9, 1)
-            out["roofline"]["traffic_frac"] = round(out["roofline"]["traffic_gbps"] / 8000.0, 4)
-            # the whole iteration in bytes really moved: the SpMV's measured traffic + the 13 vector passes of the fused CG
-            # iteration (AYPX 3, dot 2, fused update 8), next to ksp_gbps / ksp_hbm_frac which price the reference's op-by-op bytes
-            moved = out["roofline"]["traffic"] + 13 * 8 * mloc
-            out["ksp_moved_gbps"] = round(moved / (out["ms_per_step"] * 1e-3) / 1e9, 1)
-            out["ksp_moved_frac"] = round(out["ksp_moved_gbps"] / 8000.0, 4)
-            out["roofline"]["kernel"] = kernel_name.replace("'achieved' uses the CSR algorithmic bytes", "'achieved' uses the CSR algorithmic bytes, 'traffic' is what the kernel actually moved")
-            out["roofline"]["traffic_source"] = "profiles/bench_pmc_summary.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of this command with this kernel source; bytes per launch)"
+                kn = row["kernel"]
+                if spmv_tag in kn and ("kernel<0," in kn or "kernel<0>" in kn):                # the y = A x instantiation (ADD == 0)
+                    cnt[("spmv", row["counter"])] = float(row["avg_value_KB"])
+                elif "CGUpdateDevF" in kn:
+                    cnt[("upd", row["counter"])] = float(row["avg_value_KB"])
+        src_note = "profiles/bench_pmc_summary.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of this command with this kernel source; bytes per launch)"
+        if n == 256 and world == 1:
+            for key, r in (("spmv", r_spmv), ("upd", r_upd)):
+                if (key, "FETCH_SIZE") in cnt and (key, "WRITE_SIZE") in cnt and r["avg_launch_ms"] > 0:
+                    r["traffic"] = int((2.0 * cnt[(key, "FETCH_SIZE")] + cnt[(key, "WRITE_SIZE")]) * 1024)
+                    # what the kernel really moved per second: frac uses the reference's algorithmic bytes as the contract asks,
+                    # traffic_frac the measured bytes
+                    r["traffic_gbps"] = round(r["traffic"] / (r["avg_launch_ms"] * 1e-3) / 1e9, 1)
+                    r["traffic_frac"] = round(r["traffic_gbps"] / 8000.0, 4)
+                    r["kernel"] = r["kernel"].replace("'achieved' uses the", "'traffic' is what the kernel actually moved, 'achieved' uses the")
+                    r["traffic_source"] = src_note
+            if r_spmv["traffic"] is not None:
+                # the whole iteration in bytes really moved: the SpMV's measured traffic + the 13 vector passes of the fused CG
+                # iteration (AYPX 3, dot 2, fused update 8), next to ksp_gbps / ksp_hbm_frac which price the reference's op-by-op bytes
+                moved = r_spmv["traffic"] + 13 * 8 * mloc
+                out["ksp_moved_gbps"] = round(moved / (out["ms_per_step"] * 1e-3) / 1e9, 1)
+                out["ksp_moved_frac"] = round(out["ksp_moved_gbps"] / 8000.0, 4)
     except Exception:
         pass
+    # roofline = the dominant kernel of the step: whichever of the two took longer per launch (one launch of each per step)
+    dom = r_upd if upd_ms > spmv_ms else r_spmv
+    out["roofline"] = dict(dom)
+    out["roofline"]["dominant"] = ("the fused CG update: %.4f ms per step against %.4f ms for the SpMV" % (upd_ms, spmv_ms)) if dom is r_upd else \
+                                  ("the SpMV: %.4f ms per step against %.4f ms for the fused CG update" % (spmv_ms, upd_ms))
+    out["roofline_spmv"] = r_spmv
+    out["roofline_cg_update"] = r_upd
+
+    # the same solve with the value array streamed (value patterns off): what the path does for an operator with varying
+    # coefficients, and the configuration BASELINE.json's spmv_gbps is defined on; same matrix, same run
+    if nvpat.value and world == 1:
+        L.MatHIPMI355XSetValuePatterns(timed, 0)
+        dt2, spmv_ms2, _, upd_ms2, _ = timed_solve()
+        L.MatHIPMI355XSetValuePatterns(timed, 1)
+        g2 = spmv_bytes / (spmv_ms2 * 1e-3) / 1e9
+        out["csr_streaming"] = {"what": "the same %d iterations with -mat_hipmi355x_value_patterns 0: the SpMV streams the value array (%s)" % (args.steps, streamed_kernel_name().split(" (")[0]),
+                                "ksp_its_per_sec": round(args.steps / dt2, 2), "value": round(args.steps / dt2 * unknowns / 1e6, 3),
+                                "ms_per_step": round(dt2 / args.steps * 1e3, 5), "spmv_avg_launch_ms": round(spmv_ms2, 5),
+                                "spmv_gbps": round(g2, 1), "spmv_frac": round(g2 / 8000.0, 4), "cg_update_avg_launch_ms": round(upd_ms2, 5)}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import orc

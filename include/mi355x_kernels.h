@@ -173,6 +173,16 @@ int mi355x_spmv_plan_compress_indices(mi355x_handle_t h, mi355x_spmv_plan_t plan
 /* row-pattern kernel (stencil matrices: 4 bytes per row instead of 1 byte per nonzero + the row pointer; found by mi355x_spmv_plan_compress_indices):
  * on = 0/1 switches it, on < 0 only asks; *npat = size of the dictionary, 0 when the plan has none */
 int mi355x_spmv_plan_use_patterns(mi355x_spmv_plan_t p, int on, int *npat);
+/* value patterns (constant-coefficient operators: whole rows -- offsets AND values, bit for bit -- taken from a table of
+ * <= 512 entries; 2 bytes per row, the value array is not read).  _value_patterns derives the table from the host copy of
+ * the values that are (about to be) on the device and must be called again after every upload; _drop_ after any change of
+ * the device values that did not go through it; _use_: on = 0/1 switches, on < 0 only asks.  *nvpat = distinct rows, 0 =
+ * not in use (varying coefficients, compressed-row plan, switched off).  Replaces nothing in the reference: the reference
+ * streams MatMult_SeqAIJ's a[] (aij.c:1225); the result carries the same bits. */
+int mi355x_spmv_plan_value_patterns(mi355x_handle_t h, mi355x_spmv_plan_t p, const int *ai_host, const int *aj_host,
+                                    const double *aa_host, int *nvpat);
+int mi355x_spmv_plan_drop_value_patterns(mi355x_spmv_plan_t p);
+int mi355x_spmv_plan_use_value_patterns(mi355x_spmv_plan_t p, int on, int *nvpat);
 int mi355x_spmv_plan_is_compressed(mi355x_spmv_plan_t plan, int *ntab);
 /* Optional analysis step for matrices with repeated row patterns (finite elements with several dof per node): the
  * MI355X form of the reference's inodes.  ns[nnodes] are the node sizes Mat_CheckInode finds (src/mat/impls/aij/seq/

@@ -76,6 +76,10 @@ PetscErrorCode MatHIPMI355XGetTiming(Mat A, PetscInt *nlaunches, PetscLogDouble 
 PetscErrorCode MatHIPMI355XGetUploadCount(Mat A, PetscInt *n);   /* value uploads host -> device of a sequential matrix so far */
 PetscErrorCode MatHIPMI355XGetInodeInfo(Mat A, PetscInt *nodes, PetscInt *groups, PetscInt *shared_indices);   /* Mat_CheckInode's node count; groups / column indices the device plan stores once per group */
 PetscErrorCode MatHIPMI355XGetRowPatterns(Mat A, PetscInt *npat);   /* 0: none; else the size of the row-pattern dictionary the SpMV runs with */
+PetscErrorCode MatHIPMI355XSetValuePatterns(Mat A, PetscBool on);   /* A/B switch for one matrix until its next upload (the option -mat_hipmi355x_value_patterns decides at every upload) */
+PetscErrorCode VecHIPMI355XSetCGUpdateTiming(PetscBool on);   /* hipEvent pairs around the fused CG update (bench.py's roofline for that kernel) */
+PetscErrorCode VecHIPMI355XGetCGUpdateTiming(PetscInt *nlaunches, PetscLogDouble *total_ms);
+PetscErrorCode MatHIPMI355XGetValuePatterns(Mat A, PetscInt *nvpat);   /* 0: the SpMV streams the values; else the number of distinct rows (offsets + values) of the dictionary it runs from */
 PetscErrorCode MatHIPMI355XGetIndexCompression(Mat A, PetscInt *noffsets);   /* 0: plain CSR indices; else #offsets of the 1-byte dictionary */
 PetscErrorCode PCILUGetLevels_HIPMI355X(PC pc, PetscInt *nlevL, PetscInt *nlevU);   /* dependency levels of the two triangular solves */
 PetscErrorCode PCILUGetSolver_HIPMI355X(PC pc, PetscInt *syncfree, PetscInt *aborted);   /* 1: two-launch sync-free solves (-pc_factor_hipmi355x_trisolve syncfree, default above 16 levels); 0: one launch per level */

@@ -85,6 +85,9 @@ KERNEL_API = {
     "mi355x_spmv_plan_destroy": [vp],
     "mi355x_spmv_plan_compress_indices": [vp, vp, vp, vp],
     "mi355x_spmv_plan_use_patterns": [vp, i32, vp],
+    "mi355x_spmv_plan_value_patterns": [vp, vp, vp, vp, vp, vp],
+    "mi355x_spmv_plan_drop_value_patterns": [vp],
+    "mi355x_spmv_plan_use_value_patterns": [vp, i32, vp],
     "mi355x_spmv_plan_is_compressed": [vp, pi32],
     "mi355x_spmv_plan_group_rows": [vp, vp, vp, vp, i32, vp],
     "mi355x_spmv_plan_set_pairsum": [vp, i32],

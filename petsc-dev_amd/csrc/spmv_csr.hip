@@ -22,6 +22,7 @@
 #include <map>
 #include <vector>
 #include <stdlib.h>
+#include <string.h>
 
 // tuning knobs (the defaults are the measured best on MI355X for the 7-point operator)
 #ifndef SPMV_THREADS
@@ -71,6 +72,12 @@ struct mi355x_spmv_plan_s {
   unsigned int *d_prow;
   int *d_pattab;       // SPMV_PAT_CAP ints
   int npat, use_pat;
+  // value patterns (constant-coefficient operators): rows whose offsets AND values repeat; per row 2 bytes, the values
+  // live in the table.  Valid only for the values they were derived from (mi355x_spmv_plan_value_patterns / _drop_)
+  unsigned short *d_vrow;
+  int *d_vpattab;      // SPMV_PAT_CAP ints   {length, offsets ...}
+  double *d_vpatval;   // SPMV_PAT_CAP doubles, value q of an entry at the index of its offset q
+  int nvpat, vtablen, vpat_valid, use_vpat;
   double *d_dotpart;   // per-row-block x'y values of mi355x_spmv_csr_dot (allocated on first use)
   // rows summed the way MatMult_SeqAIJ_Inode does (two products at a time, inode.c:392-578): set when the reference's
   // Mat_CheckInode would switch this matrix to its inode routines
@@ -484,6 +491,134 @@ __global__ __launch_bounds__(SPMV_THREADS, SPMV_MINWAVES) void spmv_csr_rowblock
 }
 
 // ---------------------------------------------------------------------------------------------
+// Value-pattern variant for constant-coefficient operators (value indexing in the sense of CSR-VI, taken per row).  When
+// whole rows repeat -- the same offsets AND bit-for-bit the same values: the 27 row kinds of the 7-point operator on a
+// box, any stencil with constant coefficients -- the analysis keeps ONE copy of each distinct row {length, offsets, values}
+// in a table of at most SPMV_PAT_CAP entries and 2 bytes per ROW saying which; the value array is not read at all.  The
+// kernel streams 2 B + y per row and gathers x (coalesced: consecutive lanes own consecutive rows, see the row-pattern
+// kernel); products and their order are those of the other kernels, so the result carries the same bits.  The table
+// describes the values it was derived from: every path that changes values on the device drops it
+// (mi355x_spmv_plan_drop_value_patterns), every upload derives it again.
+// What bounds it (rocprofv3 counters, P7(256)): HBM traffic is the ideal 0.31 GB, but every 8-byte-per-lane gather costs the
+// CU's L1 ~17 tag cycles, so the texture addresser, not memory, was busy.  Hence TWO adjacent rows per lane: rows r, r+1
+// with one and the same table entry -- the rule in a stencil -- read x[r + off], x[r + 1 + off] as ONE 16-byte load per
+// offset (8-byte aligned: global loads need no more), half the gather instructions for the same data; a pair whose rows
+// differ (a boundary) takes the one-row path twice.
+#ifndef SPMV_VPAT_PP
+#define SPMV_VPAT_PP 2        // row pairs per lane
+#endif
+#ifndef SPMV_VPAT_MAP
+#define SPMV_VPAT_MAP 2       // 0: dispatch order; 1: each XCD walks a contiguous eighth of the rows; 2: runs of SPMV_CH blocks round-robin
+#endif
+#define SPMV_VPAT_ROWS (2 * SPMV_VPAT_PP * SPMV_THREADS)      // rows per workgroup
+typedef double v2du __attribute__((ext_vector_type(2), aligned(8)));
+
+// one row out of the table, the other kernels' arithmetic and order
+__device__ __forceinline__ double vpat_row(const int *pattab, const double *patval, int ps, long row, const double *__restrict__ x,
+                                           double sum, int pairsum) {
+  const int len = pattab[ps];                      // table entry: {length, offsets ...}; values at the offsets' indices
+  for (int q0 = 0; q0 < len; q0 += 8) {
+    double xv[8], av[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int qq = (q0 + i < len) ? q0 + i : len - 1;
+      xv[i] = x[row + pattab[ps + 1 + qq]];
+      av[i] = patval[ps + 1 + qq];
+    }
+    if (!pairsum) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { const double u = sum + av[i] * xv[i]; sum = (q0 + i < len) ? u : sum; }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; i += 2) {
+        const double pa = av[i] * xv[i], pb = av[i + 1] * xv[i + 1];
+        const double inc = (q0 + i + 1 < len) ? pa + pb : pa;
+        const double u = sum + inc;
+        sum = (q0 + i < len) ? u : sum;
+      }
+    }
+  }
+  return sum;
+}
+
+template <int ADD>
+__global__ __launch_bounds__(SPMV_THREADS) void spmv_csr_valpat_kernel(
+    int nrows, int nblocks, int chunk, const unsigned short *__restrict__ vrow, const int *__restrict__ pattab_g,
+    const double *__restrict__ patval_g, int tablen, const double *__restrict__ x, const double *yin, double *yout, int pairsum) {
+  __shared__ int pattab[SPMV_PAT_CAP];
+  __shared__ double patval[SPMV_PAT_CAP];
+#if SPMV_VPAT_MAP == 1
+  const int lb = (int)(blockIdx.x % MI355X_NXCD) * chunk + (int)(blockIdx.x / MI355X_NXCD);
+  if (blockIdx.x / MI355X_NXCD >= (unsigned)chunk || lb >= nblocks) return;
+#elif SPMV_VPAT_MAP == 2
+  const int xcd = blockIdx.x % MI355X_NXCD;
+  const int slot = blockIdx.x / MI355X_NXCD;
+  const int lb = ((slot / SPMV_CH) * MI355X_NXCD + xcd) * SPMV_CH + (slot % SPMV_CH);
+  if (lb >= nblocks) return;
+#else
+  const int lb = blockIdx.x;
+  if (lb >= nblocks) return;
+#endif
+  const int tid = threadIdx.x;
+  for (int t = tid; t < tablen; t += SPMV_THREADS) { pattab[t] = pattab_g[t]; patval[t] = patval_g[t]; }
+  const long rbase = (long)lb * SPMV_VPAT_ROWS + 2 * tid;
+  unsigned int w2[SPMV_VPAT_PP];
+  v2du yv[SPMV_VPAT_PP];
+#pragma unroll
+  for (int p = 0; p < SPMV_VPAT_PP; ++p) {
+    const long row = rbase + (long)p * 2 * SPMV_THREADS;
+    const long rc = row < nrows ? row : 0;         // row is even: the two 16-bit words of rows row, row + 1 are one aligned 32-bit word
+    w2[p] = *reinterpret_cast<const unsigned int *>(vrow + rc);        // (vrow has 16 bytes of slack behind row nrows - 1)
+    yv[p].x = ADD ? yin[rc] : 0.0;
+    yv[p].y = (ADD && rc + 1 < nrows) ? yin[rc + 1] : 0.0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int p = 0; p < SPMV_VPAT_PP; ++p) {
+    const long row = rbase + (long)p * 2 * SPMV_THREADS;
+    if (row >= nrows) break;
+    const int ps0 = (int)(w2[p] & 0xffffu), ps1 = (int)(w2[p] >> 16);
+    const bool two = row + 1 < nrows;
+    double s0 = (ADD == 1) ? yv[p].x : 0.0, s1 = (ADD == 1) ? yv[p].y : 0.0;
+    if (two && ps0 == ps1) {
+      const int len = pattab[ps0];
+      for (int q0 = 0; q0 < len; q0 += 8) {
+        v2du xv[8];
+        double av[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int qq = (q0 + i < len) ? q0 + i : len - 1;
+          xv[i] = *reinterpret_cast<const v2du *>(x + row + pattab[ps0 + 1 + qq]);
+          av[i] = patval[ps0 + 1 + qq];
+        }
+        if (!pairsum) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const double u0 = s0 + av[i] * xv[i].x, u1 = s1 + av[i] * xv[i].y;
+            s0 = (q0 + i < len) ? u0 : s0; s1 = (q0 + i < len) ? u1 : s1;
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; i += 2) {
+            const double pa0 = av[i] * xv[i].x, pb0 = av[i + 1] * xv[i + 1].x, pa1 = av[i] * xv[i].y, pb1 = av[i + 1] * xv[i + 1].y;
+            const double u0 = s0 + ((q0 + i + 1 < len) ? pa0 + pb0 : pa0), u1 = s1 + ((q0 + i + 1 < len) ? pa1 + pb1 : pa1);
+            s0 = (q0 + i < len) ? u0 : s0; s1 = (q0 + i < len) ? u1 : s1;
+          }
+        }
+      }
+    } else {
+      s0 = vpat_row(pattab, patval, ps0, row, x, s0, pairsum);
+      if (two) s1 = vpat_row(pattab, patval, ps1, row + 1, x, s1, pairsum);
+    }
+    if (two) {
+      v2du out;
+      out.x = spmv_fin<ADD>(yv[p].x, s0); out.y = spmv_fin<ADD>(yv[p].y, s1);
+      *reinterpret_cast<v2du *>(yout + row) = out;
+    } else yout[row] = spmv_fin<ADD>(yv[p].x, s0);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Grouped-row variant: the MI355X form of the reference's inodes (Mat_CheckInode inode.c:3964-4034,
 // MatMult_SeqAIJ_Inode inode.c:392-578).  Consecutive rows with one and the same column pattern -- the dof rows of
 // one node of a finite-element matrix -- form a group whose column list is stored ONCE (gj); the value array is the
@@ -764,6 +899,23 @@ static int launch_spmv(mi355x_handle_t h, mi355x_spmv_plan_t p, const int *ai, c
   if (p->nblocks == 0) return 0;
   const bool vec = mi355x_aligned16(aa) && ((((uintptr_t)aj) & 7u) == 0);
   const bool cprow = p->d_rows != nullptr;
+  if (p->vpat_valid && p->use_vpat && !cprow) {
+    const int per_wg = SPMV_VPAT_ROWS;
+    const int nb = (p->nrows + per_wg - 1) / per_wg;
+    const int chunkv = (nb + MI355X_NXCD - 1) / MI355X_NXCD;
+#if SPMV_VPAT_MAP == 1
+    const int gv = chunkv * MI355X_NXCD;
+#elif SPMV_VPAT_MAP == 2
+    const int perv = MI355X_NXCD * SPMV_CH;
+    const int gv = ((nb + perv - 1) / perv) * perv;
+#else
+    const int gv = nb;
+#endif
+    hipLaunchKernelGGL((spmv_csr_valpat_kernel<ADD>), dim3(gv), dim3(SPMV_THREADS), 0, h->stream, p->nrows, nb, chunkv, p->d_vrow,
+                       p->d_vpattab, p->d_vpatval, p->vtablen, x, yin, yout, p->pairsum);
+    MI355X_LAUNCH_CHECK();
+    return 0;
+  }
   if (p->d_gj && !cprow && mi355x_aligned16(aa)) {
 #if SPMV_REMAP == 2
     const int perg = MI355X_NXCD * SPMV_CH;
@@ -828,6 +980,7 @@ int mi355x_spmv_plan_create(mi355x_handle_t h, int nrows, const int *ai_host, co
   p->d_offtab = nullptr;
   p->ntab = 0;
   p->d_prow = nullptr; p->d_pattab = nullptr; p->npat = 0; p->use_pat = 1;
+  p->d_vrow = nullptr; p->d_vpattab = nullptr; p->d_vpatval = nullptr; p->nvpat = 0; p->vtablen = 0; p->vpat_valid = 0; p->use_vpat = 1;
   p->nlong = 0;
   p->d_dotpart = nullptr;
   p->pairsum = 0;
@@ -960,6 +1113,74 @@ int mi355x_spmv_plan_use_patterns(mi355x_spmv_plan_t p, int on, int *npat) {
   return 0;
 }
 
+// Value-pattern analysis (see spmv_csr_valpat_kernel): one table entry per distinct row {length, offsets, values},
+// values compared bit for bit.  Gives up as soon as the table would exceed SPMV_PAT_CAP entries -- after a few dozen
+// rows for a matrix with varying coefficients -- and then leaves the plan as it was.  To be called with the values that
+// are (about to be) on the device, after every change of them.  *nvpat: distinct rows found, 0 when not applicable.
+int mi355x_spmv_plan_value_patterns(mi355x_handle_t h, mi355x_spmv_plan_t p, const int *ai_host, const int *aj_host,
+                                    const double *aa_host, int *nvpat) {
+  if (nvpat) *nvpat = 0;
+  if (!p) return (int)hipErrorInvalidValue;
+  p->vpat_valid = 0;
+  if (p->d_rows || p->nrows == 0 || !p->use_vpat) return 0;
+  const int m = p->nrows;
+  std::vector<unsigned short> vrow((size_t)m);
+  std::vector<int> ptab;
+  std::vector<double> pval;
+  std::vector<int> starts;                         // the entries, in order of first appearance
+  ptab.reserve(SPMV_PAT_CAP); pval.reserve(SPMV_PAT_CAP);
+  auto same = [&](int s, int r, int len) {
+    if (ptab[(size_t)s] != len) return false;
+    const int k0 = ai_host[r];
+    for (int q = 0; q < len; ++q) if (aj_host[k0 + q] - r != ptab[(size_t)s + 1 + q]) return false;
+    return len == 0 || memcmp(aa_host + k0, pval.data() + s + 1, sizeof(double) * (size_t)len) == 0;
+  };
+  int prev = -1;
+  for (int r = 0; r < m; ++r) {
+    const int len = ai_host[r + 1] - ai_host[r];
+    int start = -1;
+    if (prev >= 0 && same(prev, r, len)) start = prev;
+    else for (size_t e = 0; e < starts.size(); ++e) if (same(starts[e], r, len)) { start = starts[e]; break; }
+    if (start < 0) {
+      start = (int)ptab.size();
+      if (start + 1 + len > SPMV_PAT_CAP) return 0;                  // not a constant-coefficient operator
+      ptab.push_back(len); pval.push_back(0.0);
+      for (int q = 0; q < len; ++q) { ptab.push_back(aj_host[ai_host[r] + q] - r); pval.push_back(aa_host[ai_host[r] + q]); }
+      starts.push_back(start);
+    }
+    prev = start;
+    vrow[(size_t)r] = (unsigned short)start;
+  }
+  if (!p->d_vrow) {
+    MI355X_TRY(hipMalloc((void **)&p->d_vrow, sizeof(unsigned short) * (size_t)m + 16));
+    MI355X_TRY(hipMalloc((void **)&p->d_vpattab, sizeof(int) * SPMV_PAT_CAP));
+    MI355X_TRY(hipMalloc((void **)&p->d_vpatval, sizeof(double) * SPMV_PAT_CAP));
+  }
+  MI355X_TRY(hipMemcpyAsync(p->d_vrow, vrow.data(), sizeof(unsigned short) * (size_t)m, hipMemcpyHostToDevice, h->stream));
+  MI355X_TRY(hipMemcpyAsync(p->d_vpattab, ptab.data(), sizeof(int) * ptab.size(), hipMemcpyHostToDevice, h->stream));
+  MI355X_TRY(hipMemcpyAsync(p->d_vpatval, pval.data(), sizeof(double) * pval.size(), hipMemcpyHostToDevice, h->stream));
+  MI355X_TRY(hipStreamSynchronize(h->stream));   // the vectors are locals
+  p->vtablen = (int)ptab.size();
+  p->nvpat = (int)starts.size();
+  p->vpat_valid = 1;
+  if (nvpat) *nvpat = p->nvpat;
+  return 0;
+}
+
+// the values on the device no longer are the ones the table was derived from
+int mi355x_spmv_plan_drop_value_patterns(mi355x_spmv_plan_t p) {
+  if (p) p->vpat_valid = 0;
+  return 0;
+}
+
+// A/B switch (on by default); on < 0 only queries.  *nvpat: size of the dictionary in use, 0 if none
+int mi355x_spmv_plan_use_value_patterns(mi355x_spmv_plan_t p, int on, int *nvpat) {
+  if (!p) return (int)hipErrorInvalidValue;
+  if (on >= 0) { p->use_vpat = on ? 1 : 0; if (!on) p->vpat_valid = 0; }
+  if (nvpat) *nvpat = p->vpat_valid ? p->nvpat : 0;
+  return 0;
+}
+
 // Row grouping (the analysis half of the reference's inode machinery).  The caller passes the node sizes the
 // reference's Mat_CheckInode finds (ns[nnodes], consecutive rows with identical column lists, at most `limit` rows
 // each; inode.c:3981-3998) -- the host library computes them with the reference's loop so that they can be compared
@@ -1049,6 +1270,9 @@ int mi355x_spmv_plan_destroy(mi355x_spmv_plan_t p) {
   if (p->d_offtab) hipFree(p->d_offtab);
   if (p->d_prow) hipFree(p->d_prow);
   if (p->d_pattab) hipFree(p->d_pattab);
+  if (p->d_vrow) hipFree(p->d_vrow);
+  if (p->d_vpattab) hipFree(p->d_vpattab);
+  if (p->d_vpatval) hipFree(p->d_vpatval);
   if (p->d_rows) hipFree(p->d_rows);
   if (p->d_dotpart) hipFree(p->d_dotpart);
   if (p->d_rowblk4) hipFree(p->d_rowblk4);

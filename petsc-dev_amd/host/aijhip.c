@@ -14,6 +14,7 @@ PetscErrorCode MatSeqAIJGetArrays(Mat A, PetscInt *m, const PetscInt **i, const 
 #if !defined(PETSCHIPMI355X_WITH_PETSC)   /* inside a PETSc tree the parent type MATSEQAIJ owns the container and its assembly (aij.c) */
 /* ---------------------------------------------------------------- host container */
 static PetscErrorCode device_free(Mat A);
+static PetscBool device_values_current(Mat A);
 static PetscErrorCode seqaij_prealloc(Mat A, PetscInt nz, const PetscInt *nnz) {
   PetscErrorCode ierr;
   HipAIJ *a = SA(A);
@@ -250,6 +251,15 @@ PetscErrorCode MatSeqAIJHIPUpload(Mat A) {
   size_t vals = (size_t)a->nz * (size_t)(a->bs > 1 ? a->bs * a->bs : 1);
   if (a->bs > 1 && !same_pattern) { mi355x_free(d->d_a); CHKHIP(mi355x_malloc((void **)&d->d_a, sizeof(PetscScalar) * PetscMax(vals, 1) + 16)); }
   CHKHIP(mi355x_memcpy_h2d(dc->h, d->d_a, a->a, sizeof(PetscScalar) * vals));
+  if (a->bs <= 1 && d->plan) {
+    /* -mat_hipmi355x_value_patterns <0|1> (default 1): constant-coefficient operators -- whole rows, offsets and values,
+     * from a dictionary of <= 512 entries -- run a kernel that reads 2 bytes per row and no values (spmv_csr_valpat_kernel);
+     * same bits.  The dictionary belongs to THESE values: derived again on every upload, dropped by every device-side change. */
+    PetscInt vp = 1; PetscBool set;
+    ierr = PetscOptionsGetInt(NULL, "-mat_hipmi355x_value_patterns", &vp, &set);CHKERRQ(ierr);
+    CHKHIP(mi355x_spmv_plan_use_value_patterns(d->plan, vp ? 1 : 0, NULL));
+    if (vp) CHKHIP(mi355x_spmv_plan_value_patterns(dc->h, d->plan, a->i, a->j, a->a, NULL));
+  }
   CHKHIP(mi355x_handle_synchronize(dc->h));
   d->n_uploads++;
   d->uploaded_state = HipObjState(A);
@@ -426,6 +436,7 @@ static PetscErrorCode MatSetValuesBatch_SeqAIJHIP(Mat A, PetscInt nb, PetscInt b
    * device copy is stamped with that state, so the assembly does not trigger an upload */
   d->uploaded_state = HipObjState(A) + 1;
   d->t_state = -1;
+  CHKHIP(mi355x_spmv_plan_drop_value_patterns(d->plan));
   ierr = PetscLogFlops((PetscLogDouble)d->bm_T);CHKERRQ(ierr);
   return 0;
 }
@@ -506,6 +517,43 @@ PetscErrorCode MatHIPMI355XGetRowPatterns(Mat A, PetscInt *npat) {
     if (!rp) np_ = 0;
   }
   *npat = np_;
+  return 0;
+}
+
+/* size of the value-pattern dictionary the SpMV runs with right now (0: none -- varying coefficients, switched off, or
+ * dropped by a device-side change of the values since the last upload) */
+PetscErrorCode MatHIPMI355XGetValuePatterns(Mat A, PetscInt *nvpat) {
+  PetscErrorCode ierr; int nv = 0;
+  *nvpat = 0;
+  if (!A) return 0;
+  if (A->ops->mult != MatMult_SeqAIJHIP) {
+    Mat Ad = NULL;
+    if (!strcmp(HipObjTypeName(A), MATMPIAIJHIPMI355X)) { ierr = MatMPIAIJGetSeqAIJ(A, &Ad, NULL, NULL);CHKERRQ(ierr); }
+    if (!Ad || Ad->ops->mult != MatMult_SeqAIJHIP) return 0;
+    A = Ad;
+  }
+  ierr = MatSeqAIJHIPUpload(A);CHKERRQ(ierr);
+  if (SD(A)->plan && SA(A)->bs <= 1) CHKHIP(mi355x_spmv_plan_use_value_patterns(SD(A)->plan, -1, &nv));
+  *nvpat = nv;
+  return 0;
+}
+
+/* A/B switch for one matrix (the option -mat_hipmi355x_value_patterns is read at every upload; this overrides it until
+ * the next upload): off -> the SpMV streams the value array again; on -> the dictionary is derived from the host copy now */
+PetscErrorCode MatHIPMI355XSetValuePatterns(Mat A, PetscBool on) {
+  PetscErrorCode ierr; PetscDeviceCtx *dc;
+  if (!A) return 0;
+  if (A->ops->mult != MatMult_SeqAIJHIP) {
+    Mat Ad = NULL;
+    if (!strcmp(HipObjTypeName(A), MATMPIAIJHIPMI355X)) { ierr = MatMPIAIJGetSeqAIJ(A, &Ad, NULL, NULL);CHKERRQ(ierr); }
+    if (!Ad || Ad->ops->mult != MatMult_SeqAIJHIP) SETERRQ(HipObjComm(A), PETSC_ERR_ARG_WRONG, "HIPMI355X AIJ matrix expected");
+    A = Ad;
+  }
+  ierr = MatSeqAIJHIPUpload(A);CHKERRQ(ierr);
+  if (!SD(A)->plan || SA(A)->bs > 1) return 0;
+  ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
+  CHKHIP(mi355x_spmv_plan_use_value_patterns(SD(A)->plan, on ? 1 : 0, NULL));
+  if (on && device_values_current(A)) CHKHIP(mi355x_spmv_plan_value_patterns(dc->h, SD(A)->plan, SA(A)->i, SA(A)->j, SA(A)->a, NULL));
   return 0;
 }
 
@@ -687,6 +735,7 @@ static PetscErrorCode MatScale_SeqAIJHIP(Mat A, PetscScalar alpha) {   /* MatSca
     CHKHIP(mi355x_vec_scale(dc->h, vals, alpha, d->d_a));
     d->uploaded_state = HipObjState(A) + 1;
     d->t_state = -1;
+    CHKHIP(mi355x_spmv_plan_drop_value_patterns(d->plan));
   }
   return PetscLogFlops((PetscLogDouble)vals);
 }
@@ -702,6 +751,7 @@ static PetscErrorCode MatZeroEntries_SeqAIJHIP(Mat A) {
     CHKHIP(mi355x_memset(dc->h, d->d_a, 0, sizeof(PetscScalar) * vals));
     d->uploaded_state = HipObjState(A) + 1;
     d->t_state = -1;
+    CHKHIP(mi355x_spmv_plan_drop_value_patterns(d->plan));
   }
   return 0;
 }
@@ -723,6 +773,7 @@ static PetscErrorCode MatDiagonalScale_SeqAIJHIP(Mat A, Vec ll, Vec rr) {
     CHKHIP(mi355x_csr_diagonal_scale(dc->h, a->m, d->d_i, d->d_j, d->d_a, dl, dr));
     d->uploaded_state = HipObjState(A) + 1;
     d->t_state = -1;
+    CHKHIP(mi355x_spmv_plan_drop_value_patterns(d->plan));
   }
   if (ll) {
     ierr = VecGetArrayRead(ll, &l);CHKERRQ(ierr);

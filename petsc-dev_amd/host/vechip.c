@@ -365,6 +365,33 @@ static PetscErrorCode VecDotNorm2_HIP(Vec s, Vec t, PetscScalar *dp, PetscScalar
   return 0;
 }
 
+/* per-launch device timing of the fused CG update for bench.py (hipEvent pairs on the compute stream, like
+ * MatHIPMI355XSetTiming for the product) */
+static struct { PetscBool on; PetscInt n, cap; mi355x_event_t *ev; } cgu_time;
+PetscErrorCode VecHIPMI355XSetCGUpdateTiming(PetscBool on) {
+  cgu_time.on = on; cgu_time.n = 0;
+  if (on && !cgu_time.ev) {
+    cgu_time.cap = 4096;
+    PetscErrorCode ierr = PetscMalloc(sizeof(mi355x_event_t) * 2 * (size_t)cgu_time.cap, &cgu_time.ev);CHKERRQ(ierr);
+    for (PetscInt k = 0; k < 2 * cgu_time.cap; k++) CHKHIP(mi355x_event_create(&cgu_time.ev[k]));
+  }
+  return 0;
+}
+PetscErrorCode VecHIPMI355XGetCGUpdateTiming(PetscInt *nlaunches, PetscLogDouble *total_ms) {
+  double tot = 0.0;
+  for (PetscInt k = 0; k < cgu_time.n; k++) {
+    float ms = 0.f;
+    CHKHIP(mi355x_event_synchronize(cgu_time.ev[2 * k + 1]));
+    CHKHIP(mi355x_event_elapsed_ms(cgu_time.ev[2 * k], cgu_time.ev[2 * k + 1], &ms));
+    tot += ms;
+  }
+  if (nlaunches) *nlaunches = cgu_time.n;
+  if (total_ms) *total_ms = tot;
+  return 0;
+}
+#define CGU_TIME_BEGIN(h) do { if (cgu_time.on && cgu_time.n < cgu_time.cap) CHKHIP(mi355x_event_record(cgu_time.ev[2 * cgu_time.n], h)); } while (0)
+#define CGU_TIME_END(h)   do { if (cgu_time.on && cgu_time.n < cgu_time.cap) { CHKHIP(mi355x_event_record(cgu_time.ev[2 * cgu_time.n + 1], h)); cgu_time.n++; } } while (0)
+
 /* Fused CG update for HIPMI355X vectors (KSPSolve_CG cg.c:206-232 with a Jacobi PCApply in the middle):
  * x += a p; r -= a w; z = r .* d; *zz = z'z, *zr = z'r in one sweep and one reduction (one all-reduce of two
  * doubles on several ranks instead of two of one).  Results carry the bits of the separate VecAXPY, VecAXPY,
@@ -384,7 +411,9 @@ PetscErrorCode VecCGUpdate_HIPMI355X(Vec x, Vec r, Vec z, Vec p, Vec w, Vec d, P
   ierr = VecHIPGetReadWrite(r, &dr);CHKERRQ(ierr);
   ierr = VecHIPGetWrite(z, &dz);CHKERRQ(ierr);
   ierr = reduce_target(x, dc, &out);CHKERRQ(ierr);
+  CGU_TIME_BEGIN(dc->h);
   CHKHIP(mi355x_vec_cg_update(dc->h, N_(x), a, dp_, dw, dd, dx, dr, dz, out));
+  CGU_TIME_END(dc->h);
   VecHIPRestoreWrite(x); VecHIPRestoreWrite(r); VecHIPRestoreWrite(z);
   HipStateIncrease(x); HipStateIncrease(r); HipStateIncrease(z);
   ierr = reduce_finish(x, dc, 3, 0, res);CHKERRQ(ierr);
@@ -427,8 +456,10 @@ PetscErrorCode VecCGUpdateDevBegin_HIPMI355X(Vec x, Vec r, Vec z, Vec p, Vec w, 
   else { ierr = VecHIPGetWrite(z, &dz);CHKERRQ(ierr); }
   ds = mi355x_handle_device_scratch(dc->h);
   /* one rank: the finishing workgroup hands the sums to the host itself; several: all-reduce first, then publish */
+  CGU_TIME_BEGIN(dc->h);
   CHKHIP(mi355x_vec_cg_update_dev(dc->h, N_(x), beta, ds + DPI_SLOT, dpiold, (int)check_sign, dp_, dw, dd, dx, dr, dz, ds,
                                   DEVICE_COLLECTIVES(x) ? 0 : 1));
+  CGU_TIME_END(dc->h);
   VecHIPRestoreWrite(x); VecHIPRestoreWrite(r); VecHIPRestoreWrite(z);
   HipStateIncrease(x); HipStateIncrease(r); HipStateIncrease(z);
   if (DEVICE_COLLECTIVES(x)) {

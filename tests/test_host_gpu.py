@@ -1266,6 +1266,64 @@ def test_value_updates_on_the_device_copy(P):
         A.destroy()
 
 
+def test_value_patterns_follow_the_values(P):
+    """-mat_hipmi355x_value_patterns (default on): a constant-coefficient operator runs from the row dictionary (27 kinds
+    of rows for the 7-point box); every device-side change of the values (MatScale, MatDiagonalScale, MatZeroEntries) drops
+    it, the products stay bit-identical to the oracle's throughout, and the next upload derives it again.  With the option
+    off the dictionary is never built."""
+    L = P.lib()
+    ai, aj, aa = orc.gen_p7(12, 11, 10)
+    n = ai.size - 1
+    x = np.cos(0.3 * np.arange(n)); l = 1.0 + 0.5 * np.cos(np.arange(n))
+    vx = V(P, x); vy = V(P, np.zeros(n)); vl = V(P, l)
+    nv = C.c_int()
+
+    def count(A):
+        L.MatHIPMI355XGetValuePatterns(A.h, C.byref(nv)); return nv.value
+
+    def check(A, vals):
+        A.mult(vx, vy)
+        assert np.array_equal(bits(vy.array()), bits(orc.matmult(ai, aj, vals, x)[0]))
+        L.MatMultAdd(A.h, vx.h, vl.h, vy.h)
+        assert np.array_equal(bits(vy.array()), bits(orc.spmv_add(ai, aj, vals, x, l)))
+
+    A = P.Mat.from_csr(ai, aj, aa)
+    check(A, aa)
+    assert count(A) == 27
+    L.MatScale(A.h, 0.5)                                   # on the device: the dictionary describes the old values
+    assert count(A) == 0
+    check(A, 0.5 * aa)
+    L.MatDiagonalScale(A.h, vl.h, None)
+    ref = orc.diagonal_scale(ai, aj, 0.5 * aa, l, None)
+    assert count(A) == 0
+    check(A, ref)
+    # new values into the same pattern from the host: one upload, dictionary derived again
+    L.MatZeroEntries(A.h)
+    assert count(A) == 0
+    for r in range(n):
+        cols = np.ascontiguousarray(aj[ai[r]:ai[r + 1]]); v = np.ascontiguousarray(3.0 * aa[ai[r]:ai[r + 1]])
+        rr = np.array([r], np.int32)
+        L.MatSetValues(A.h, 1, rr.ctypes.data_as(C.c_void_p), cols.size, cols.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p), 1)
+    L.MatAssemblyBegin(A.h, 0); L.MatAssemblyEnd(A.h, 0)
+    check(A, 3.0 * aa)
+    assert count(A) == 27
+    # varying coefficients into the same pattern: refused, values streamed
+    L.MatDiagonalScale(A.h, vl.h, None)                    # device side
+    A2 = P.Mat.from_csr(ai, aj, orc.diagonal_scale(ai, aj, 3.0 * aa, l, None))      # the same values through an upload
+    check(A2, orc.diagonal_scale(ai, aj, 3.0 * aa, l, None))
+    assert count(A2) == 0 and count(A) == 0
+    A.destroy(); A2.destroy()
+    # switched off
+    L.PetscOptionsSetValue(b"-mat_hipmi355x_value_patterns", b"0")
+    try:
+        B = P.Mat.from_csr(ai, aj, aa)
+        check(B, aa)
+        assert count(B) == 0
+        B.destroy()
+    finally:
+        L.PetscOptionsClear()
+
+
 def test_setvaluesbatch_device_assembly(P):
     """MatSetValuesBatch (matrix.c:1698): first assembly goes through the reference's loop of MatSetValues; every later
     one with the same connectivity is a device-side value assembly through the cached map -- bit-identical to the

@@ -282,7 +282,7 @@ def random_csr(m, n, rowlen, seed, sort=True):
     return ai, aj, aa
 
 
-def run_spmv(dev, ai, aj, aa, x, y0=None, rows=None, compress=False, group=False, pairsum=None, dscale=None, patterns=None):
+def run_spmv(dev, ai, aj, aa, x, y0=None, rows=None, compress=False, group=False, pairsum=None, dscale=None, patterns=None, values=False):
     k = dev.k
     dai, daj, daa = upload_csr(dev, ai, aj, aa)
     dx = dev.put(x)
@@ -304,6 +304,14 @@ def run_spmv(dev, ai, aj, aa, x, y0=None, rows=None, compress=False, group=False
         npat = C.c_int()                       # row-pattern kernel: patterns=False forces the per-nonzero (idx8) kernel
         dev.chk(k.mi355x_spmv_plan_use_patterns(plan, -1 if patterns is None else int(patterns), C.byref(npat)))
         run_spmv.last_npat = npat.value
+    if values:      # value patterns: whole rows (offsets + values) from a dictionary, the device value array is not read
+        nv = C.c_int()
+        aa_h = np.ascontiguousarray(aa, dtype=np.float64)
+        dev.chk(k.mi355x_spmv_plan_value_patterns(dev.h, plan, ai.ctypes.data, aj.ctypes.data, aa_h.ctypes.data, C.byref(nv)))
+        run_spmv.last_nvpat = nv.value
+        if nv.value:                       # prove it: poison the device values the other kernels would stream
+            dev.free(daa)
+            daa = dev.put(np.full(max(aa.size, 1) + 2, np.nan))
     if dscale is not None:                                       # y = d .* (A x) in the product's epilogue
         m_out = ai.size - 1
         dy = dev.put(np.full(m_out, 7.0))
@@ -349,6 +357,89 @@ def test_spmv_index_compression_bitexact(dev, dims):
         assert_bitexact(got, orc.spmv(ai, aj, aa, x))
         assert_bitexact(run_spmv(dev, ai, aj, aa, x, y0=y0, compress=True, patterns=patterns), orc.spmv_add(ai, aj, aa, x, y0))
         assert_bitexact(run_spmv(dev, ai, aj, aa, x, compress=True, patterns=patterns, pairsum=1), orc.spmv_inode(ai, aj, aa, x))
+
+
+@pytest.mark.parametrize("dims", [(5, 4, 3), (33, 17, 9), (64, 64, 40), (1, 1, 1), (700, 3, 1)])
+def test_spmv_value_patterns_bitexact(dev, dims):
+    """constant-coefficient operator: whole rows (offsets and values) come from the dictionary, the value array is not read
+    (it is NaN on the device here); y = Ax, y = y0 + Ax, y = d .* (Ax) and the inode summation order carry the oracle's bits"""
+    ai, aj, aa = orc.gen_p7(*dims)
+    n = ai.size - 1
+    x = np.sin(0.37 * np.arange(n)) + 1.0
+    y0 = rnd(n, 70); d = rnd(n, 71)
+    got = run_spmv(dev, ai, aj, aa, x, values=True)
+    assert 1 <= run_spmv.last_nvpat <= 27
+    assert_bitexact(got, orc.spmv(ai, aj, aa, x))
+    assert_bitexact(run_spmv(dev, ai, aj, aa, x, y0=y0, values=True), orc.spmv_add(ai, aj, aa, x, y0))
+    assert_bitexact(run_spmv(dev, ai, aj, aa, x, dscale=d, values=True), orc.spmv(ai, aj, aa, x) * d)
+    assert_bitexact(run_spmv(dev, ai, aj, aa, x, values=True, pairsum=1), orc.spmv_inode(ai, aj, aa, x))
+    # the same with the other analyses present: value patterns take precedence over index compression / row patterns
+    assert_bitexact(run_spmv(dev, ai, aj, aa, x, compress=True, values=True), orc.spmv(ai, aj, aa, x))
+
+
+def test_spmv_value_patterns_shapes_and_refusals(dev):
+    """a 9-point stencil with two coefficient regions, stored zeros of either sign (compared as bits, so two entries) and
+    empty rows; varying coefficients and compressed-row plans are refused and the value array is streamed as before;
+    dropping the dictionary returns to the streamed values"""
+    import scipy.sparse as sp
+    nx, ny = 41, 23
+    n = nx * ny
+    rows, cols, vals = [], [], []
+    for j in range(ny):
+        for i in range(nx):
+            r = i + nx * j
+            if r % 13 == 7:
+                continue                                   # a row without entries
+            for dj in (-1, 0, 1):
+                for di in (-1, 0, 1):
+                    if 0 <= i + di < nx and 0 <= j + dj < ny:
+                        rows.append(r); cols.append(i + di + nx * (j + dj))
+                        c = 8.0 if (di == 0 and dj == 0) else (-1.0 if (di == 0 or dj == 0) else -0.5)
+                        vals.append(c * (3.0 if j >= ny // 2 else 1.0))
+    A = sp.csr_matrix((vals, (rows, cols)), shape=(n, n)); A.sort_indices()
+    ai, aj, aa = A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.copy()
+    aa[ai[5]] = -0.0; aa[ai[6]] = 0.0                     # rows 5 and 6: same offsets, values differ in the sign of a zero
+    x = rnd(n, 72)
+    got = run_spmv(dev, ai, aj, aa, x, values=True)
+    kinds = {(tuple(aj[ai[r]:ai[r + 1]] - r), aa[ai[r]:ai[r + 1]].tobytes()) for r in range(n)}
+    assert run_spmv.last_nvpat == len(kinds) and len(kinds) >= 12
+    assert_bitexact(got, orc.spmv(ai, aj, aa, x))
+    # varying coefficients: refused after a few rows, the kernel streams the values
+    aav = aa * (1.0 + 0.01 * np.cos(np.arange(aa.size)))
+    got = run_spmv(dev, ai, aj, aav, x, values=True)
+    assert run_spmv.last_nvpat == 0
+    assert_bitexact(got, orc.spmv(ai, aj, aav, x))
+    # switched off / dropped: back to the value stream
+    k = dev.k
+    ai7, aj7, aa7 = orc.gen_p7(9, 8, 7)
+    n7 = ai7.size - 1
+    x7 = rnd(n7, 73)
+    dai, daj, daa = upload_csr(dev, ai7, aj7, aa7 * 2.0)     # device values are TWICE the ones the dictionary is derived from
+    dx = dev.put(x7); dy = dev.put(np.zeros(n7))
+    plan = make_plan(dev, ai7, None)
+    nv = C.c_int()
+    dev.chk(k.mi355x_spmv_plan_value_patterns(dev.h, plan, ai7.ctypes.data, aj7.ctypes.data, aa7.ctypes.data, C.byref(nv)))
+    assert nv.value > 0
+    dev.chk(k.mi355x_spmv_csr(dev.h, plan, dai, daj, daa, dx, dy))
+    assert_bitexact(dev.get(dy, n7), orc.spmv(ai7, aj7, aa7, x7))               # dictionary
+    dev.chk(k.mi355x_spmv_plan_drop_value_patterns(plan))
+    dev.chk(k.mi355x_spmv_plan_use_value_patterns(plan, -1, C.byref(nv)))
+    assert nv.value == 0
+    dev.chk(k.mi355x_spmv_csr(dev.h, plan, dai, daj, daa, dx, dy))
+    assert_bitexact(dev.get(dy, n7), orc.spmv(ai7, aj7, aa7 * 2.0, x7))         # streamed device values
+    dev.chk(k.mi355x_spmv_plan_use_value_patterns(plan, 0, None))               # switched off: the analysis declines
+    dev.chk(k.mi355x_spmv_plan_value_patterns(dev.h, plan, ai7.ctypes.data, aj7.ctypes.data, aa7.ctypes.data, C.byref(nv)))
+    assert nv.value == 0
+    dev.chk(k.mi355x_spmv_plan_destroy(plan))
+    for p in (dai, daj, daa, dx, dy):
+        dev.free(p)
+    # compressed-row plan: not applicable
+    rows_nz = np.flatnonzero(np.diff(ai) > 0).astype(np.int32)
+    aic = np.concatenate(([0], np.cumsum(np.diff(ai)[rows_nz]))).astype(np.int32)
+    planc = make_plan(dev, aic, rows_nz)
+    dev.chk(k.mi355x_spmv_plan_value_patterns(dev.h, planc, ai.ctypes.data, aj.ctypes.data, aa.ctypes.data, C.byref(nv)))
+    assert nv.value == 0
+    dev.chk(k.mi355x_spmv_plan_destroy(planc))
 
 
 def test_spmv_row_patterns_other_shapes(dev):

@@ -49,6 +49,7 @@ def test_bench_two_ranks_rehearsal(built, wide):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 6 and d["warmup"] == 2 and d["scaling"] == "weak"
     assert d["config"]["rows_per_gpu"] == 40 ** 3 and d["value"] > 0 and d["roofline"]["avg_launch_ms"] > 0
-    assert "pat_kernel" in d["roofline"]["kernel"]     # the diagonal block of the slab runs the row-pattern kernel
+    assert "valpat_kernel" in d["roofline_spmv"]["kernel"]     # the diagonal block of the slab (constant coefficients) runs from the row dictionary
+    assert d["roofline_spmv"]["avg_launch_ms"] > 0 and d["roofline_cg_update"]["avg_launch_ms"] > 0 and d["roofline_cg_update"]["launches_timed"] == 6
     assert d["config"]["transport"] == "host-staged" and "HOST-STAGED" in d["config"]["workload"]
     assert ("P7(80,80,20)" if wide else "P7(40,40,80)") in d["config"]["workload"]

@@ -19,11 +19,11 @@ NOTES = {"FETCH_SIZE": "FETCH_SIZE reads 1/2 of the fetched bytes on gfx950 (cal
 
 def main():
     args = sys.argv[1:]
-    if args and args[0] == "--stamp":     # first line: hash of the kernel source the counters were collected with (bench.py checks it)
+    if args and args[0] == "--stamp":     # first line: hashes of the kernel sources the counters were collected with (bench.py checks them)
         import hashlib
         root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-        h = hashlib.sha256(open(os.path.join(root, "petsc-dev_amd", "csrc", "spmv_csr.hip"), "rb").read()).hexdigest()[:16]
-        print("# spmv_csr.hip sha256/16 = %s" % h)
+        print("# " + "; ".join("%s sha256/16 = %s" % (src, hashlib.sha256(open(os.path.join(root, "petsc-dev_amd", "csrc", src), "rb").read()).hexdigest()[:16])
+                               for src in ("spmv_csr.hip", "vec_kernels.hip")))
         args = args[1:]
     w = csv.writer(sys.stdout)
     w.writerow(["counter", "kernel", "dispatches", "avg_value_KB", "note"])
