@@ -499,31 +499,31 @@ __global__ __launch_bounds__(SPMV_THREADS, SPMV_MINWAVES) void spmv_csr_rowblock
 // kernel); products and their order are those of the other kernels, so the result carries the same bits.  The table
 // describes the values it was derived from: every path that changes values on the device drops it
 // (mi355x_spmv_plan_drop_value_patterns), every upload derives it again.
-// What bounds it (rocprofv3 counters, P7(256)): HBM traffic is the ideal 0.31 GB, but every 8-byte-per-lane gather costs the
-// CU's L1 ~17 tag cycles, so the texture addresser, not memory, was busy.  Hence TWO adjacent rows per lane: rows r, r+1
-// with one and the same table entry -- the rule in a stencil -- read x[r + off], x[r + 1 + off] as ONE 16-byte load per
-// offset (8-byte aligned: global loads need no more), half the gather instructions for the same data; a pair whose rows
-// differ (a boundary) takes the one-row path twice.
-#ifndef SPMV_VPAT_PP
-#define SPMV_VPAT_PP 2        // row pairs per lane
+// What bounds it is not memory: rocprofv3 counts 0.31 GB per launch on P7(256), the ideal (x once, y once, 2 B per row), at
+// 2.8 TB/s.  The launch is a latency chain -- row word -> table -> gathers -> store -- run by as many wavefronts as a CU holds:
+// probe builds take 0.046 ms with every global access removed and 0.02-0.04 ms more for each of the three phases.  Per nonzero
+// the work is therefore kept minimal (table entries padded to a multiple of 8 slots and holding BYTE offsets, a gather's
+// address = the uniform base of x + one 32-bit add, no index clamped; stores after all of a lane's rows, because loads and
+// stores share one in-order completion counter).  Measured and not kept, all within +-10 % of this form or slower: an LDS copy
+// of the x window around the block's rows for the near offsets, all of a lane's gathers issued before any is used, two
+// adjacent rows per lane with 16-byte gathers, wavefront tiles of 512 rows with one 16-byte word load per lane, a persistent
+// grid walking the rows, an XCD-contiguous block map, wavefront-uniform table entries through scalar registers.
+#ifndef SPMV_VPAT_RPL
+#define SPMV_VPAT_RPL 4       // rows per lane (inside the CG iteration on P7(256): 1 -> 0.127 ms, 2 -> 0.116, 4 -> 0.106, 8 -> 0.107)
 #endif
-#ifndef SPMV_VPAT_MAP
-#define SPMV_VPAT_MAP 2       // 0: dispatch order; 1: each XCD walks a contiguous eighth of the rows; 2: runs of SPMV_CH blocks round-robin
-#endif
-#define SPMV_VPAT_ROWS (2 * SPMV_VPAT_PP * SPMV_THREADS)      // rows per workgroup
-typedef double v2du __attribute__((ext_vector_type(2), aligned(8)));
+#define SPMV_VPAT_ROWS (SPMV_VPAT_RPL * SPMV_THREADS)      // rows per workgroup
+#define SPMV_VPAT_MAXROWS (1 << 28)                        // 32-bit byte offsets into x
 
-// one row out of the table, the other kernels' arithmetic and order
-__device__ __forceinline__ double vpat_row(const int *pattab, const double *patval, int ps, long row, const double *__restrict__ x,
+// one row out of the table, the other kernels' arithmetic and order; rb8 = 8 * row, xb = x as bytes
+__device__ __forceinline__ double vpat_row(const int *pattab, const double *patval, int ps, unsigned int rb8, const char *__restrict__ xb,
                                            double sum, int pairsum) {
-  const int len = pattab[ps];                      // table entry: {length, offsets ...}; values at the offsets' indices
+  const int len = pattab[ps];                      // table entry: {length, byte offsets ... (padded to 8 k slots)}; values at the offsets' indices
   for (int q0 = 0; q0 < len; q0 += 8) {
     double xv[8], av[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int qq = (q0 + i < len) ? q0 + i : len - 1;
-      xv[i] = x[row + pattab[ps + 1 + qq]];
-      av[i] = patval[ps + 1 + qq];
+    for (int i = 0; i < 8; ++i) {                  // a pad slot repeats the entry's first offset: a valid address, its product is not used
+      xv[i] = *reinterpret_cast<const double *>(xb + (unsigned int)(rb8 + (unsigned int)pattab[ps + 1 + q0 + i]));
+      av[i] = patval[ps + 1 + q0 + i];
     }
     if (!pairsum) {
 #pragma unroll
@@ -543,78 +543,37 @@ __device__ __forceinline__ double vpat_row(const int *pattab, const double *patv
 
 template <int ADD>
 __global__ __launch_bounds__(SPMV_THREADS) void spmv_csr_valpat_kernel(
-    int nrows, int nblocks, int chunk, const unsigned short *__restrict__ vrow, const int *__restrict__ pattab_g,
-    const double *__restrict__ patval_g, int tablen, const double *__restrict__ x, const double *yin, double *yout, int pairsum) {
+    int nrows, const unsigned short *__restrict__ vrow, const int *__restrict__ pattab_g, const double *__restrict__ patval_g, int tablen,
+    const double *__restrict__ x, const double *yin, double *yout, int pairsum) {
   __shared__ int pattab[SPMV_PAT_CAP];
   __shared__ double patval[SPMV_PAT_CAP];
-#if SPMV_VPAT_MAP == 1
-  const int lb = (int)(blockIdx.x % MI355X_NXCD) * chunk + (int)(blockIdx.x / MI355X_NXCD);
-  if (blockIdx.x / MI355X_NXCD >= (unsigned)chunk || lb >= nblocks) return;
-#elif SPMV_VPAT_MAP == 2
-  const int xcd = blockIdx.x % MI355X_NXCD;
-  const int slot = blockIdx.x / MI355X_NXCD;
-  const int lb = ((slot / SPMV_CH) * MI355X_NXCD + xcd) * SPMV_CH + (slot % SPMV_CH);
-  if (lb >= nblocks) return;
-#else
-  const int lb = blockIdx.x;
-  if (lb >= nblocks) return;
-#endif
   const int tid = threadIdx.x;
   for (int t = tid; t < tablen; t += SPMV_THREADS) { pattab[t] = pattab_g[t]; patval[t] = patval_g[t]; }
-  const long rbase = (long)lb * SPMV_VPAT_ROWS + 2 * tid;
-  unsigned int w2[SPMV_VPAT_PP];
-  v2du yv[SPMV_VPAT_PP];
+  const long rbase = (long)blockIdx.x * SPMV_VPAT_ROWS + tid;          // the grid covers the rows exactly: no block without one
+  int pst[SPMV_VPAT_RPL];
+  double yv[SPMV_VPAT_RPL];
 #pragma unroll
-  for (int p = 0; p < SPMV_VPAT_PP; ++p) {
-    const long row = rbase + (long)p * 2 * SPMV_THREADS;
-    const long rc = row < nrows ? row : 0;         // row is even: the two 16-bit words of rows row, row + 1 are one aligned 32-bit word
-    w2[p] = *reinterpret_cast<const unsigned int *>(vrow + rc);        // (vrow has 16 bytes of slack behind row nrows - 1)
-    yv[p].x = ADD ? yin[rc] : 0.0;
-    yv[p].y = (ADD && rc + 1 < nrows) ? yin[rc + 1] : 0.0;
+  for (int j = 0; j < SPMV_VPAT_RPL; ++j) {
+    const long row = rbase + (long)j * SPMV_THREADS;
+    const long rc = row < nrows ? row : (long)nrows - 1;
+    pst[j] = vrow[rc];
+    yv[j] = ADD ? yin[rc] : 0.0;
   }
   __syncthreads();
+  const char *xb = reinterpret_cast<const char *>(x);
+  // the stores wait until every row of the lane has its sum: loads and stores share one in-order completion counter on this
+  // ISA, so a store issued between two rows' gathers would put its acknowledgement (an HBM round trip) on the second row's path
+  double res[SPMV_VPAT_RPL];
 #pragma unroll
-  for (int p = 0; p < SPMV_VPAT_PP; ++p) {
-    const long row = rbase + (long)p * 2 * SPMV_THREADS;
-    if (row >= nrows) break;
-    const int ps0 = (int)(w2[p] & 0xffffu), ps1 = (int)(w2[p] >> 16);
-    const bool two = row + 1 < nrows;
-    double s0 = (ADD == 1) ? yv[p].x : 0.0, s1 = (ADD == 1) ? yv[p].y : 0.0;
-    if (two && ps0 == ps1) {
-      const int len = pattab[ps0];
-      for (int q0 = 0; q0 < len; q0 += 8) {
-        v2du xv[8];
-        double av[8];
+  for (int j = 0; j < SPMV_VPAT_RPL; ++j) {
+    const long row = rbase + (long)j * SPMV_THREADS;
+    res[j] = 0.0;
+    if (row < nrows) res[j] = spmv_fin<ADD>(yv[j], vpat_row(pattab, patval, pst[j], (unsigned int)row * 8u, xb, (ADD == 1) ? yv[j] : 0.0, pairsum));
+  }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int qq = (q0 + i < len) ? q0 + i : len - 1;
-          xv[i] = *reinterpret_cast<const v2du *>(x + row + pattab[ps0 + 1 + qq]);
-          av[i] = patval[ps0 + 1 + qq];
-        }
-        if (!pairsum) {
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const double u0 = s0 + av[i] * xv[i].x, u1 = s1 + av[i] * xv[i].y;
-            s0 = (q0 + i < len) ? u0 : s0; s1 = (q0 + i < len) ? u1 : s1;
-          }
-        } else {
-#pragma unroll
-          for (int i = 0; i < 8; i += 2) {
-            const double pa0 = av[i] * xv[i].x, pb0 = av[i + 1] * xv[i + 1].x, pa1 = av[i] * xv[i].y, pb1 = av[i + 1] * xv[i + 1].y;
-            const double u0 = s0 + ((q0 + i + 1 < len) ? pa0 + pb0 : pa0), u1 = s1 + ((q0 + i + 1 < len) ? pa1 + pb1 : pa1);
-            s0 = (q0 + i < len) ? u0 : s0; s1 = (q0 + i < len) ? u1 : s1;
-          }
-        }
-      }
-    } else {
-      s0 = vpat_row(pattab, patval, ps0, row, x, s0, pairsum);
-      if (two) s1 = vpat_row(pattab, patval, ps1, row + 1, x, s1, pairsum);
-    }
-    if (two) {
-      v2du out;
-      out.x = spmv_fin<ADD>(yv[p].x, s0); out.y = spmv_fin<ADD>(yv[p].y, s1);
-      *reinterpret_cast<v2du *>(yout + row) = out;
-    } else yout[row] = spmv_fin<ADD>(yv[p].x, s0);
+  for (int j = 0; j < SPMV_VPAT_RPL; ++j) {
+    const long row = rbase + (long)j * SPMV_THREADS;
+    if (row < nrows) yout[row] = res[j];
   }
 }
 
@@ -900,19 +859,9 @@ static int launch_spmv(mi355x_handle_t h, mi355x_spmv_plan_t p, const int *ai, c
   const bool vec = mi355x_aligned16(aa) && ((((uintptr_t)aj) & 7u) == 0);
   const bool cprow = p->d_rows != nullptr;
   if (p->vpat_valid && p->use_vpat && !cprow) {
-    const int per_wg = SPMV_VPAT_ROWS;
-    const int nb = (p->nrows + per_wg - 1) / per_wg;
-    const int chunkv = (nb + MI355X_NXCD - 1) / MI355X_NXCD;
-#if SPMV_VPAT_MAP == 1
-    const int gv = chunkv * MI355X_NXCD;
-#elif SPMV_VPAT_MAP == 2
-    const int perv = MI355X_NXCD * SPMV_CH;
-    const int gv = ((nb + perv - 1) / perv) * perv;
-#else
-    const int gv = nb;
-#endif
-    hipLaunchKernelGGL((spmv_csr_valpat_kernel<ADD>), dim3(gv), dim3(SPMV_THREADS), 0, h->stream, p->nrows, nb, chunkv, p->d_vrow,
-                       p->d_vpattab, p->d_vpatval, p->vtablen, x, yin, yout, p->pairsum);
+    const int nb = (p->nrows + SPMV_VPAT_ROWS - 1) / SPMV_VPAT_ROWS;
+    hipLaunchKernelGGL((spmv_csr_valpat_kernel<ADD>), dim3(nb), dim3(SPMV_THREADS), 0, h->stream, p->nrows, p->d_vrow, p->d_vpattab,
+                       p->d_vpatval, p->vtablen, x, yin, yout, p->pairsum);
     MI355X_LAUNCH_CHECK();
     return 0;
   }
@@ -1129,12 +1078,15 @@ int mi355x_spmv_plan_value_patterns(mi355x_handle_t h, mi355x_spmv_plan_t p, con
   std::vector<double> pval;
   std::vector<int> starts;                         // the entries, in order of first appearance
   ptab.reserve(SPMV_PAT_CAP); pval.reserve(SPMV_PAT_CAP);
+  // table entry: {length, byte offsets of the columns relative to the row ..., padded to a multiple of 8 slots with copies of the
+  // first offset}; values at the offsets' indices (pads 0.0, never used in a sum)
   auto same = [&](int s, int r, int len) {
     if (ptab[(size_t)s] != len) return false;
     const int k0 = ai_host[r];
-    for (int q = 0; q < len; ++q) if (aj_host[k0 + q] - r != ptab[(size_t)s + 1 + q]) return false;
+    for (int q = 0; q < len; ++q) if ((aj_host[k0 + q] - r) * 8 != ptab[(size_t)s + 1 + q]) return false;
     return len == 0 || memcmp(aa_host + k0, pval.data() + s + 1, sizeof(double) * (size_t)len) == 0;
   };
+  if (m > SPMV_VPAT_MAXROWS) return 0;              // byte offsets into x are 32-bit
   int prev = -1;
   for (int r = 0; r < m; ++r) {
     const int len = ai_host[r + 1] - ai_host[r];
@@ -1142,10 +1094,16 @@ int mi355x_spmv_plan_value_patterns(mi355x_handle_t h, mi355x_spmv_plan_t p, con
     if (prev >= 0 && same(prev, r, len)) start = prev;
     else for (size_t e = 0; e < starts.size(); ++e) if (same(starts[e], r, len)) { start = starts[e]; break; }
     if (start < 0) {
+      const int slots = (len + 7) / 8 * 8;
       start = (int)ptab.size();
-      if (start + 1 + len > SPMV_PAT_CAP) return 0;                  // not a constant-coefficient operator
+      if (start + 1 + slots > SPMV_PAT_CAP) return 0;                // not a constant-coefficient operator
       ptab.push_back(len); pval.push_back(0.0);
-      for (int q = 0; q < len; ++q) { ptab.push_back(aj_host[ai_host[r] + q] - r); pval.push_back(aa_host[ai_host[r] + q]); }
+      for (int q = 0; q < slots; ++q) {
+        const int col = aj_host[ai_host[r] + (q < len ? q : 0)];
+        if (col >= SPMV_VPAT_MAXROWS) return 0;
+        ptab.push_back((col - r) * 8);
+        pval.push_back(q < len ? aa_host[ai_host[r] + q] : 0.0);
+      }
       starts.push_back(start);
     }
     prev = start;
