@@ -17,6 +17,8 @@ def main():
     L = P.lib()
     k = pda.load_kernels()
     ai, aj, aa = P.gen_poisson7(n, n, n)
+    if extra:                                # -mat_* options are read when the matrix is first used
+        L.PetscOptionsInsertString(extra.encode())
     A = P.Mat.from_csr(ai, aj, aa)
     N = n ** 3
     u = P.Vec.create(N, comm=L.COMM_SELF); L.VecSet(u.h, 1.0)
