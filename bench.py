@@ -200,8 +200,8 @@ def main():
               "unit": "GB/s", "frac": round(spmv_gbps_one / 8000.0, 4), "traffic": None, "basis": BASIS,
               "algorithmic_bytes_per_launch": spmv_bytes, "avg_launch_ms": round(spmv_ms, 5), "launches_timed": spmv_launches}
     if nvpat.value:
-        r_spmv["limiter"] = ("not HBM: with the value array out of the way the launch moves ~0.31 GB (x once, y once, 2 B per row) and is bound "
-                             "by the CUs' L1 / instruction issue on the x gathers (DESIGN.md section 4); traffic_frac says how far from the memory roof it runs")
+        r_spmv["limiter"] = ("not HBM: with the value array out of the way the launch moves ~0.36 GB (ideal 0.30: x once, y once, 2 B per row) and is bound "
+                             "by the latency chain row word -> table -> gathers -> store at full occupancy (DESIGN.md section 4, 'Value patterns'); traffic_frac says how far from the memory roof it runs")
     # ... and the fused CG update (VecAXPY, VecAXPY, PCApply_Jacobi, VecNorm, VecTDot of cg.c:206-232 in one sweep): the
     # reference's five operations make 12 vector passes, the kernel 8 (reads x p r w d, writes x r z)
     upd_bytes = 12 * 8 * mloc

@@ -499,8 +499,8 @@ __global__ __launch_bounds__(SPMV_THREADS, SPMV_MINWAVES) void spmv_csr_rowblock
 // kernel); products and their order are those of the other kernels, so the result carries the same bits.  The table
 // describes the values it was derived from: every path that changes values on the device drops it
 // (mi355x_spmv_plan_drop_value_patterns), every upload derives it again.
-// What bounds it is not memory: rocprofv3 counts 0.31 GB per launch on P7(256), the ideal (x once, y once, 2 B per row), at
-// 2.8 TB/s.  The launch is a latency chain -- row word -> table -> gathers -> store -- run by as many wavefronts as a CU holds:
+// What bounds it is not memory: rocprofv3 counts 0.36 GB per launch on P7(256) (ideal 0.30: x once, y once, 2 B per row; x is
+// fetched 1.45 times, neighbouring planes by more than one XCD's L2) at 3.3 TB/s.  The launch is a latency chain -- row word -> table -> gathers -> store -- run by as many wavefronts as a CU holds:
 // probe builds take 0.046 ms with every global access removed and 0.02-0.04 ms more for each of the three phases.  Per nonzero
 // the work is therefore kept minimal (table entries padded to a multiple of 8 slots and holding BYTE offsets, a gather's
 // address = the uniform base of x + one 32-bit add, no index clamped; stores after all of a lane's rows, because loads and
