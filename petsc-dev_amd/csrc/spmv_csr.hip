@@ -521,8 +521,9 @@ __device__ __forceinline__ double vpat_row(const int *pattab, const double *patv
   for (int q0 = 0; q0 < len; q0 += 8) {
     double xv[8], av[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {                  // a pad slot repeats the entry's first offset: a valid address, its product is not used
-      xv[i] = *reinterpret_cast<const double *>(xb + (unsigned int)(rb8 + (unsigned int)pattab[ps + 1 + q0 + i]));
+    for (int i = 0; i < 8; ++i) {                  // the gathers are what the launch pays for (texture addresser 76 % busy): a slot beyond
+      xv[i] = 0.0;                                 // the row's length is not loaded -- and not issued at all when no lane of the wavefront needs it
+      if (q0 + i < len) xv[i] = *reinterpret_cast<const double *>(xb + (unsigned int)(rb8 + (unsigned int)pattab[ps + 1 + q0 + i]));
       av[i] = patval[ps + 1 + q0 + i];
     }
     if (!pairsum) {
