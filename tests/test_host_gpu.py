@@ -336,6 +336,27 @@ def test_whole_solves_equal_the_oracle_bit_for_bit_in_the_device_summation_order
         assert np.array_equal(x.view(np.uint64), xo.view(np.uint64))
 
 
+@pytest.mark.parametrize("ksp,pc", [("cg", "jacobi"), ("cg", "none"), ("gmres", "jacobi"), ("bcgs", "jacobi"), ("gmres", "ilu"), ("groppcg", "jacobi")])
+def test_value_patterns_leave_every_bit_of_a_solve_alone(P, ksp, pc):
+    """the product run from the row dictionary (default) against the same solve with the value array streamed
+    (-mat_hipmi355x_value_patterns 0): every residual norm and the solution, bit for bit -- 3-D 7-point and 2-D 5-point operators"""
+    for (ai, aj, aa) in (orc.gen_p7(19, 16, 14), pb.lap2d(37, 29)):
+        n = ai.size - 1
+        b = np.cos(0.21 * np.arange(n)) + 0.3
+        runs = [solve(P, ai, aj, aa, b, ksp, pc, opts=o, rtol=1e-10) for o in ("", "-mat_hipmi355x_value_patterns 0")]
+        (x0, h0, its0, r0), (x1, h1, its1, r1) = runs
+        assert (its0, r0) == (its1, r1) and its0 > 10
+        assert np.array_equal(h0.view(np.uint64), h1.view(np.uint64)) and np.array_equal(x0.view(np.uint64), x1.view(np.uint64))
+    # and the default really is the dictionary, the option really the streamed values
+    L = P.lib(); nv = C.c_int()
+    A = P.Mat.from_csr(*orc.gen_p7(6, 5, 4)); L.MatHIPMI355XGetValuePatterns(A.h, C.byref(nv)); assert nv.value > 0; A.destroy()
+    L.PetscOptionsSetValue(b"-mat_hipmi355x_value_patterns", b"0")
+    try:
+        A = P.Mat.from_csr(*orc.gen_p7(6, 5, 4)); L.MatHIPMI355XGetValuePatterns(A.h, C.byref(nv)); assert nv.value == 0; A.destroy()
+    finally:
+        L.PetscOptionsClear()
+
+
 def test_config1_cg_jacobi_equals_the_oracle_bit_for_bit_in_the_device_summation_order(P):
     """BASELINE.json configs[0] (ex2 -m 100 -n 100, CG + Jacobi, 160 iterations): all 161 residual norms and the solution,
     bit for bit, with the oracle's reductions in the device order"""
