@@ -272,6 +272,11 @@ int mi355x_trisolve_plan_create(mi355x_handle_t h, int n, int nlev, const int *l
  * tolerance instead of bit-exactness against MatSolve_SeqAIJ_NaturalOrdering), large levels on slice boundaries */
 int mi355x_trisolve_plan_create_ordered(mi355x_handle_t h, int n, int nlev, const int *lev, const int *rp, const int *rl, const int *cj,
                                         const double *cv, const double *dinv, int by_level, mi355x_trisolve_plan_t *plan);
+/* upper solve of an incomplete Cholesky factor U^T D U: right-hand side entry i is multiplied by rscale[i] (= 1/D(i)) before row
+ * i's sum starts -- the x[i] = xi * (1/D(i)) between the two sweeps of MatSolve_SeqSBAIJ_1_NaturalOrdering (sbaijfact2.c:1977-2015);
+ * entries in the caller's order */
+int mi355x_trisolve_plan_create_scaled(mi355x_handle_t h, int n, int nlev, const int *lev, const int *rp, const int *rl, const int *cj,
+                                       const double *cv, const double *dinv, const double *rscale, mi355x_trisolve_plan_t *plan);
 int mi355x_trisolve_plan_destroy(mi355x_trisolve_plan_t plan);
 int mi355x_trisolve_apply(mi355x_handle_t h, mi355x_trisolve_plan_t lower, mi355x_trisolve_plan_t upper, const double *b, double *y);
 int mi355x_trisolve_aborted(mi355x_trisolve_plan_t plan, int *aborted);

@@ -104,6 +104,7 @@ typedef const char *PCType;
 #define PCBJACOBI  "bjacobi"
 #define PCPBJACOBI "pbjacobi"  /* point-block Jacobi (src/ksp/pc/impls/pbjacobi/pbjacobi.c), SURVEY 8f.4 */
 #define PCILU      "ilu"       /* ILU(0), natural ordering, sequential AIJ */
+#define PCICC      "icc"       /* ICC(0), natural ordering, sequential AIJ */
 
 /* ---- Sys ----------------------------------------------------------------------------------- */
 extern PetscComm PETSC_COMM_SELF, PETSC_COMM_WORLD;

@@ -132,9 +132,111 @@ void orc_ilu0_solve(int n, const int *bi, const int *bj, const int *bdiag, const
   }
 }
 
+/* ---- ICC(0), natural ordering: MatICCFactorSymbolic_SeqAIJ (levels 0: the pattern of A's upper triangle, diagonal LAST in its
+ * row, aijfact.c:2405-2600) and MatCholeskyFactorNumeric_SeqAIJ (aijfact.c:2076-2230) with PCICC's defaults (icc.c:189-200:
+ * MAT_SHIFT_POSITIVE_DEFINITE, zeropivot 100 eps).  Row k of the factor ends up holding  -U(k,j)/D(k)-style multipliers: the
+ * reference overwrites U(i,k) by uikdi = -U(i,k) * (1/D(i)) when row i is added into row k, and that is what the solve reads. ---- */
+int orc_icc0_count(int n, const int *ai, const int *aj) {
+  int nz = 0;
+  for (int i = 0; i < n; i++) { nz++; for (int q = ai[i]; q < ai[i + 1]; q++) if (aj[q] > i) nz++; }
+  return nz;
+}
+int orc_icc0_factor(int n, const int *ai, const int *aj, const double *aa, int *ui, int *uj, double *ua) {
+  /* symbolic: strictly upper entries of row k in column order, then the diagonal slot */
+  int nz = 0;
+  ui[0] = 0;
+  for (int k = 0; k < n; k++) {
+    for (int q = ai[k]; q < ai[k + 1]; q++) if (aj[q] > k) uj[nz++] = aj[q];
+    uj[nz++] = k;
+    ui[k + 1] = nz;
+  }
+  const double zeropivot = 100.0 * 2.220446049250313e-16;
+  double shift_top = zeropivot, shift_amount = 0.0, shift_fraction = 0.0, shift_lo = 0.0, shift_hi = 1.0;
+  int nshift = 0;
+  const int nshift_max = 5;
+  for (int i = 0; i < n; i++) {            /* max over the rows of sum|a_ij| - |a_ii| - Re(a_ii): what makes the matrix diagonally dominant */
+    double d = 0.0, rs;
+    for (int q = ai[i]; q < ai[i + 1]; q++) if (aj[q] == i) d = aa[q];
+    rs = -fabs(d) - d;
+    for (int q = ai[i]; q < ai[i + 1]; q++) rs += fabs(aa[q]);
+    if (rs > shift_top) shift_top = rs;
+  }
+  shift_top *= 1.1;
+  double *rtmp = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+  int *il = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1)), *c2r = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+  int newshift;
+  do {
+    newshift = 0;
+    for (int i = 0; i < n; i++) c2r[i] = n;      /* c2r[col]: head of the list of earlier rows with an entry in column col still to be applied */
+    if (n) il[0] = 0;                            /* il[i]: first entry of row i not yet consumed */
+    for (int k = 0; k < n; k++) {
+      const int diagk = ui[k + 1] - 1;
+      for (int q = ui[k]; q < ui[k + 1]; q++) rtmp[uj[q]] = 0.0;
+      { int w = ui[k];                           /* the unfactored row's upper part; the factor's slots are zeroed as they are claimed */
+        for (int q = ai[k]; q < ai[k + 1]; q++) if (aj[q] >= k) { rtmp[aj[q]] = aa[q]; ua[w++] = 0.0; } }
+      rtmp[k] += shift_amount;
+      double dk = rtmp[k];
+      int i = c2r[k];
+      while (i < k) {
+        const int nexti = c2r[i], ili = il[i];
+        const double uikdi = -ua[ili] * ua[ui[i + 1] - 1];
+        dk += uikdi * ua[ili];
+        ua[ili] = uikdi;
+        const int jmin = ili + 1, jmax = ui[i + 1] - 1;      /* the rest of row i, without its diagonal slot */
+        if (jmin < jmax) {
+          for (int q = jmin; q < jmax; q++) rtmp[uj[q]] += uikdi * ua[q];
+          il[i] = jmin;
+          const int j = uj[jmin]; c2r[i] = c2r[j]; c2r[j] = i;
+        }
+        i = nexti;
+      }
+      double rs = 0.0;
+      if (ui[k] < diagk) {
+        for (int q = ui[k]; q < diagk; q++) { ua[q] = rtmp[uj[q]]; rs += fabs(ua[q]); }
+        il[k] = ui[k];
+        const int j = uj[ui[k]]; c2r[k] = c2r[j]; c2r[j] = k;
+      }
+      if (dk <= zeropivot * rs) {                /* MatPivotCheck_pd (matimpl.h:532-553): bisect the shift towards diagonal dominance */
+        if (nshift == nshift_max) shift_fraction = shift_hi;
+        else { shift_lo = shift_fraction; shift_fraction = (shift_hi + shift_lo) / 2.; }
+        shift_amount = shift_fraction * shift_top;
+        nshift++;
+        newshift = 1;
+        if (nshift > nshift_max + 1) { free(rtmp); free(il); free(c2r); return -1; }
+        break;
+      }
+      ua[diagk] = 1.0 / dk;
+    }
+  } while (newshift);
+  free(rtmp); free(il); free(c2r);
+  return nshift;
+}
+void orc_icc0_solve(int n, const int *ui, const int *uj, const double *ua, const double *b, double *x) {
+  for (int i = 0; i < n; i++) x[i] = b[i];
+  for (int i = 0; i < n; i++) {                  /* U^T D y = b: column sweep, then the row's own entry times 1/D(i) */
+    const int nz = ui[i + 1] - ui[i] - 1;
+    const double xi = x[i];
+    for (int q = 0; q < nz; q++) x[uj[ui[i] + q]] += ua[ui[i] + q] * xi;
+    x[i] = xi * ua[ui[i] + nz];
+  }
+  for (int i = n - 2; i >= 0; i--) {             /* U x = y: the row's entries from its last off-diagonal one backwards */
+    const int nz = ui[i + 1] - ui[i] - 1;
+    double xi = x[i];
+    for (int q = nz - 1; q >= 0; q--) xi += ua[ui[i] + q] * x[uj[ui[i] + q]];
+    x[i] = xi;
+  }
+}
+
 /* ---- PC ---- */
 static void pc_setup(solver *s) {
-  if (s->pc_type == ORC_PC_ILU) {
+  if (s->pc_type == ORC_PC_ICC) {
+    int nz = orc_icc0_count(s->n, s->ai, s->aj);
+    s->fi = (int *)malloc(sizeof(int) * (size_t)(s->n + 1));
+    s->fj = (int *)malloc(sizeof(int) * (size_t)(nz + 1));
+    s->fdiag = NULL;
+    s->fa = (double *)calloc((size_t)nz + 1, sizeof(double));
+    orc_icc0_factor(s->n, s->ai, s->aj, s->aa, s->fi, s->fj, s->fa);
+  } else if (s->pc_type == ORC_PC_ILU) {
     int nz = s->ai[s->n];
     s->fi = (int *)malloc(sizeof(int) * (size_t)(s->n + 1));
     s->fj = (int *)malloc(sizeof(int) * (size_t)(nz + 1));
@@ -199,6 +301,7 @@ static void pc_apply(solver *s, const double *x, double *y) {
   if (s->pc_type == ORC_PC_NONE) orc_vec_copy((size_t)s->n, x, y);
   else if (s->pc_type == ORC_PC_JACOBI) orc_vec_pointwise_mult((size_t)s->n, x, s->idiag, y);
   else if (s->pc_type == ORC_PC_ILU) orc_ilu0_solve(s->n, s->fi, s->fj, s->fdiag, s->fa, x, y);   /* PCApply_ILU -> MatSolve */
+  else if (s->pc_type == ORC_PC_ICC) orc_icc0_solve(s->n, s->fi, s->fj, s->fa, x, y);               /* PCApply_ICC (icc.c:65) -> MatSolve */
   else if (s->pc_type == ORC_PC_PBJACOBI) orc_pbjacobi_apply(s->n / (s->pb_bs > 0 ? s->pb_bs : 1), s->pb_bs > 0 ? s->pb_bs : 1, s->idiag, x, y);
   else {
     for (int k = 0; k < s->nblocks; k++) {

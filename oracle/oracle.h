@@ -90,10 +90,18 @@ void orc_scatter_create(int size, int rank, const int *ranges, const int *const 
 
 /* ---- KSP (src/ksp/ksp/impls/{cg/cg.c:92, gmres/gmres.c:118-409 + borthog2.c:35, bcgs/bcgs.c:43}) ---- */
 enum { ORC_KSP_CG = 0, ORC_KSP_GMRES = 1, ORC_KSP_BCGS = 2, ORC_KSP_PREONLY = 3, ORC_KSP_GROPPCG = 4, ORC_KSP_PIPECG = 5 };
-enum { ORC_PC_NONE = 0, ORC_PC_JACOBI = 1, ORC_PC_BJACOBI = 2, ORC_PC_ILU = 3, ORC_PC_PBJACOBI = 4 };
+enum { ORC_PC_NONE = 0, ORC_PC_JACOBI = 1, ORC_PC_BJACOBI = 2, ORC_PC_ILU = 3, ORC_PC_PBJACOBI = 4, ORC_PC_ICC = 5 };
 /* ILU(0), natural ordering (src/mat/impls/aij/seq/aijfact.c:1628 symbolic, :461 numeric, :3126 solve); bi[n+1], bj/ba[nz+1], bdiag[n+1] */
 int  orc_ilu0_factor(int n, const int *ai, const int *aj, const double *aa, int *bi, int *bj, int *bdiag, double *ba);
 void orc_ilu0_solve(int n, const int *bi, const int *bj, const int *bdiag, const double *ba, const double *b, double *x);
+/* ICC(0), natural ordering, of the upper triangle of a sequential AIJ matrix (MatICCFactorSymbolic_SeqAIJ with levels 0 +
+ * MatCholeskyFactorNumeric_SeqAIJ, aijfact.c:2076-2230,2405-2600): ui[n+1], uj/ua[nnz of the upper triangle incl. diagonal]; row k holds
+ * its off-diagonal entries (stored NEGATED and scaled, as the reference leaves them) in column order and then 1/D(k).  Returns the number
+ * of positive-definite shifts the factorisation needed (MatPivotCheck_pd), < 0 on failure.  orc_icc0_count: entries of the factor. */
+int  orc_icc0_count(int n, const int *ai, const int *aj);
+int  orc_icc0_factor(int n, const int *ai, const int *aj, const double *aa, int *ui, int *uj, double *ua);
+/* MatSolve_SeqSBAIJ_1_NaturalOrdering (sbaijfact2.c:1977-2015): U^T D sweep forward, U sweep backward */
+void orc_icc0_solve(int n, const int *ui, const int *uj, const double *ua, const double *b, double *x);
 typedef struct {
   int ksp_type, pc_type;
   double rtol, abstol, dtol;

@@ -78,6 +78,7 @@ KERNEL_API = {
     "mi355x_spmv_bsr4_mfma": [vp, i32, i32, vp, vp, vp, vp, vp],
     "mi355x_trisolve_plan_create": [vp, i32, i32, vp, vp, vp, vp, vp, vp, C.POINTER(vp)],
     "mi355x_trisolve_plan_create_ordered": [vp, i32, i32, vp, vp, vp, vp, vp, vp, i32, C.POINTER(vp)],
+    "mi355x_trisolve_plan_create_scaled": [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, C.POINTER(vp)],
     "mi355x_trisolve_plan_destroy": [vp],
     "mi355x_trisolve_apply": [vp, vp, vp, vp, vp],
     "mi355x_trisolve_aborted": [vp, pi32],

@@ -91,6 +91,7 @@ struct mi355x_trisolve_plan_s {
   int *d_col;        // sliced-ELL column POSITIONS
   double *d_val;     // sliced-ELL values
   double *d_dinv;    // upper: inverted diagonal per position
+  double *d_rscale;  // upper, optional: factor applied to the right-hand side entry before the row's sum starts (ICC: D^-1 between the two solves)
   unsigned char *d_nsub;   // sub-steps per slice
   int *d_pos;        // per row: its position (for the other solve's gather of this solve's result)
   double *d_w;       // solution in position order, 64 * nslices doubles
@@ -139,7 +140,8 @@ __global__ __launch_bounds__(MI355X_BLOCK) void trisolve_syncfree_kernel(
     int nslices, int nchunks, const int *__restrict__ ptr, const int *__restrict__ info, const int *__restrict__ rowof,
     const int *__restrict__ col, const double *__restrict__ val, const double *__restrict__ dinv,
     const unsigned char *__restrict__ nsub, const double *src, const int *__restrict__ spos, double *w, double *y,
-    double *reset, int reset_n, unsigned int *queue, unsigned int *other_queue, int *abort_flag, int sleep_cap) {
+    double *reset, int reset_n, unsigned int *queue, unsigned int *other_queue, int *abort_flag, int sleep_cap,
+    const double *__restrict__ rscale) {
   __shared__ int chunk_s[2];
   const int tid = threadIdx.x, lane = tid & (MI355X_WAVE - 1), wave = tid / MI355X_WAVE;
   if (blockIdx.x == 0 && tid < TRI_QUEUES) other_queue[tid * TRI_QSTRIDE] = 0u;
@@ -165,7 +167,12 @@ __global__ __launch_bounds__(MI355X_BLOCK) void trisolve_syncfree_kernel(
     const int ns = nsub[s];
     double sum = 0.0;
     if (row >= 0) {
-      if (UPPER) { const int p = spos[row]; sum = src[p]; reset[p] = __longlong_as_double((long long)TRI_SENTINEL); }
+      if (UPPER) {
+        const int p = spos[row];
+        sum = src[p];
+        if (rscale) sum = sum * rscale[t];          // MatSolve_SeqSBAIJ_1_NaturalOrdering: x[i] = xi * (1/D(i)) between the two sweeps
+        reset[p] = __longlong_as_double((long long)TRI_SENTINEL);
+      }
       else sum = src[row];
     }
     if (!UPPER && t < reset_n) reset[t] = __longlong_as_double((long long)TRI_SENTINEL);
@@ -219,8 +226,9 @@ extern "C" {
 // hold rows of two large levels.  For factors of matrices with inodes (3-dof FEM: ~38 entries per row, recent dependencies
 // in the middle of the column order) the reference itself runs another routine with another order (MatSolve_SeqAIJ_Inode,
 // inode.c); results then agree with the natural-ordering loop to rounding, not bit for bit.  Deterministic either way.
-int mi355x_trisolve_plan_create_ordered(mi355x_handle_t h, int n, int nlev, const int *lev, const int *rp, const int *rl, const int *cj,
-                                        const double *cv, const double *dinv_host, int by_level, mi355x_trisolve_plan_t *out) {
+static int trisolve_plan_create_impl(mi355x_handle_t h, int n, int nlev, const int *lev, const int *rp, const int *rl, const int *cj,
+                                     const double *cv, const double *dinv_host, const double *rscale_host, int by_level,
+                                     mi355x_trisolve_plan_t *out) {
   mi355x_trisolve_plan_s *p = new mi355x_trisolve_plan_s();
   memset(p, 0, sizeof(*p));
   p->n = n; p->upper = dinv_host != nullptr;
@@ -246,7 +254,7 @@ int mi355x_trisolve_plan_create_ordered(mi355x_handle_t h, int n, int nlev, cons
   const size_t np = (size_t)p->nslices * W;
   std::vector<int> pos((size_t)(n > 0 ? n : 1)), info(np > 0 ? np : 1, 0), rowof(np > 0 ? np : 1, -1), ptr((size_t)p->nslices + 1, 0);
   std::vector<unsigned char> nsub((size_t)(p->nslices > 0 ? p->nslices : 1), 1);
-  std::vector<double> dinv(np > 0 ? np : 1, 1.0);
+  std::vector<double> dinv(np > 0 ? np : 1, 1.0), rsc(np > 0 ? np : 1, 1.0);
   for (int t = 0; t < n; ++t) { pos[(size_t)order[(size_t)t]] = (int)tpos[(size_t)t]; rowof[(size_t)tpos[(size_t)t]] = order[(size_t)t]; }
   long total = 0;
   for (int s = 0; s < p->nslices; ++s) {
@@ -260,6 +268,7 @@ int mi355x_trisolve_plan_create_ordered(mi355x_handle_t h, int n, int nlev, cons
       if (sub < 0 || sub > 255) { delete p; return (int)hipErrorInvalidValue; }
       info[P] = (rl[i] << 8) | sub;
       if (dinv_host) dinv[P] = dinv_host[i];
+      if (rscale_host) rsc[P] = rscale_host[i];
       if (rl[i] > mx) mx = rl[i];
       if (sub + 1 > nsub[(size_t)s]) nsub[(size_t)s] = (unsigned char)(sub + 1);
     }
@@ -289,6 +298,7 @@ int mi355x_trisolve_plan_create_ordered(mi355x_handle_t h, int n, int nlev, cons
   TRI_UP(p->d_ptr, ptr, int); TRI_UP(p->d_info, info, int); TRI_UP(p->d_row, rowof, int); TRI_UP(p->d_col, col, int);
   TRI_UP(p->d_val, val, double); TRI_UP(p->d_nsub, nsub, unsigned char); TRI_UP(p->d_pos, pos, int);
   if (dinv_host) TRI_UP(p->d_dinv, dinv, double);
+  if (dinv_host && rscale_host) TRI_UP(p->d_rscale, rsc, double);
 #undef TRI_UP
   MI355X_TRY(hipMalloc((void **)&p->d_w, sizeof(double) * (np > 0 ? np : 1)));
   { std::vector<unsigned long long> sent(np > 0 ? np : 1, TRI_SENTINEL);
@@ -327,6 +337,19 @@ int mi355x_trisolve_plan_create_ordered(mi355x_handle_t h, int n, int nlev, cons
   return 0;
 }
 
+int mi355x_trisolve_plan_create_ordered(mi355x_handle_t h, int n, int nlev, const int *lev, const int *rp, const int *rl, const int *cj,
+                                        const double *cv, const double *dinv_host, int by_level, mi355x_trisolve_plan_t *out) {
+  return trisolve_plan_create_impl(h, n, nlev, lev, rp, rl, cj, cv, dinv_host, nullptr, by_level, out);
+}
+
+// upper solve whose right-hand side entry i is multiplied by rscale_host[i] before row i's sum starts: the D^-1 between the
+// U^T and the U sweep of an incomplete Cholesky factor (MatSolve_SeqSBAIJ_1_NaturalOrdering, sbaijfact2.c:1977-2015)
+int mi355x_trisolve_plan_create_scaled(mi355x_handle_t h, int n, int nlev, const int *lev, const int *rp, const int *rl, const int *cj,
+                                       const double *cv, const double *dinv_host, const double *rscale_host, mi355x_trisolve_plan_t *out) {
+  if (!dinv_host || !rscale_host) return (int)hipErrorInvalidValue;
+  return trisolve_plan_create_impl(h, n, nlev, lev, rp, rl, cj, cv, dinv_host, rscale_host, 0, out);
+}
+
 int mi355x_trisolve_plan_create(mi355x_handle_t h, int n, int nlev, const int *lev, const int *rp, const int *rl, const int *cj,
                                 const double *cv, const double *dinv_host, mi355x_trisolve_plan_t *out) {
   return mi355x_trisolve_plan_create_ordered(h, n, nlev, lev, rp, rl, cj, cv, dinv_host, 0, out);
@@ -337,6 +360,7 @@ int mi355x_trisolve_plan_destroy(mi355x_trisolve_plan_t p) {
   (void)hipFree(p->d_ptr); (void)hipFree(p->d_info); (void)hipFree(p->d_row); (void)hipFree(p->d_col); (void)hipFree(p->d_val);
   (void)hipFree(p->d_nsub); (void)hipFree(p->d_pos); (void)hipFree(p->d_w); (void)hipFree(p->d_queue);
   if (p->d_dinv) (void)hipFree(p->d_dinv);
+  if (p->d_rscale) (void)hipFree(p->d_rscale);
   if (p->abort_flag) (void)hipHostFree(p->abort_flag);
   delete p;
   return 0;
@@ -355,11 +379,12 @@ int mi355x_trisolve_apply(mi355x_handle_t h, mi355x_trisolve_plan_t lo, mi355x_t
   do {                                                                                                                            \
     hipLaunchKernelGGL((trisolve_syncfree_kernel<false>), dim3(glo), dim3(MI355X_BLOCK), 0, h->stream, lo->nslices, lo->nchunks, \
                        lo->d_ptr, lo->d_info, lo->d_row, lo->d_col, lo->d_val, (const double *)nullptr, lo->d_nsub, b,          \
-                       (const int *)nullptr, lo->d_w, (double *)nullptr, up->d_w, up->nslices * MI355X_WAVE, lo->d_queue, up->d_queue, lo->abort_flag, lo->sleep_cap); \
+                       (const int *)nullptr, lo->d_w, (double *)nullptr, up->d_w, up->nslices * MI355X_WAVE, lo->d_queue, up->d_queue, lo->abort_flag, lo->sleep_cap, \
+                       (const double *)nullptr); \
     MI355X_LAUNCH_CHECK();                                                                                                        \
     hipLaunchKernelGGL((trisolve_syncfree_kernel<true>), dim3(gup), dim3(MI355X_BLOCK), 0, h->stream, up->nslices, up->nchunks,  \
                        up->d_ptr, up->d_info, up->d_row, up->d_col, up->d_val, up->d_dinv, up->d_nsub, lo->d_w, lo->d_pos,       \
-                       up->d_w, y, lo->d_w, 0, up->d_queue, lo->d_queue, up->abort_flag, up->sleep_cap);                        \
+                       up->d_w, y, lo->d_w, 0, up->d_queue, lo->d_queue, up->abort_flag, up->sleep_cap, (const double *)up->d_rscale); \
     MI355X_LAUNCH_CHECK();                                                                                                        \
   } while (0)
   if (lo->by_level != up->by_level) return (int)hipErrorInvalidValue;

@@ -190,6 +190,7 @@ PetscErrorCode MatTimingBegin(Mat A, mi355x_handle_t h);
 PetscErrorCode MatTimingEnd(Mat A, mi355x_handle_t h);
 PetscErrorCode MatGetVecs_HIPMI355X(Mat A, Vec *right, Vec *left);
 PetscErrorCode PCCreate_ILU_HIPMI355X(PC);
+PetscErrorCode PCCreate_ICC_HIPMI355X(PC);
 PetscErrorCode PCCreate_PBJacobi_HIPMI355X(PC);
 
 #endif

@@ -53,10 +53,12 @@ PetscErrorCode PetscHIPMI355XRegisterAll(void) {
   ierr = MatRegister(MATSEQBAIJ, 0, "MatCreate_SeqBAIJHIPMI355X", MatCreate_SeqBAIJHIPMI355X);CHKERRQ(ierr);
   ierr = PCRegister(PCILU, 0, "PCCreate_ILU_HIPMI355X", PCCreate_ILU_HIPMI355X);CHKERRQ(ierr);
   ierr = PCRegister(PCPBJACOBI, 0, "PCCreate_PBJacobi_HIPMI355X", PCCreate_PBJacobi_HIPMI355X);CHKERRQ(ierr);
+  ierr = PCRegister(PCICC, 0, "PCCreate_ICC_HIPMI355X", PCCreate_ICC_HIPMI355X);CHKERRQ(ierr);
 #else
   ierr = PCRegister("pbjacobihipmi355x", 0, "PCCreate_PBJacobi_HIPMI355X", PCCreate_PBJacobi_HIPMI355X);CHKERRQ(ierr);
   /* PETSc's own PCILU keeps its name (host MatSolve); the device-side ILU(0) apply is offered next to it */
   ierr = PCRegister("iluhipmi355x", 0, "PCCreate_ILU_HIPMI355X", PCCreate_ILU_HIPMI355X);CHKERRQ(ierr);
+  ierr = PCRegister("icchipmi355x", 0, "PCCreate_ICC_HIPMI355X", PCCreate_ICC_HIPMI355X);CHKERRQ(ierr);
 #endif
   return 0;
 }

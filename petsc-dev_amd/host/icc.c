@@ -1,0 +1,209 @@
+/* PCICC with zero fill on a sequential AIJ block (SURVEY 8f.1 names ILU(0)/ICC(0)): the incomplete Cholesky factorisation the
+ * reference offers for symmetric positive definite systems, i.e. the natural partner of KSPCG under PCBJACOBI.
+ *   set-up : MatICCFactorSymbolic_SeqAIJ with levels 0 and natural ordering (the pattern of A's upper triangle, the diagonal last in
+ *            its row, src/mat/impls/aij/seq/aijfact.c:2405-2600) + MatCholeskyFactorNumeric_SeqAIJ (aijfact.c:2076-2230) with
+ *            PCICC's defaults (src/ksp/pc/impls/factor/icc/icc.c:189-200: MAT_SHIFT_POSITIVE_DEFINITE, zeropivot 100 eps), on the
+ *            HOST copy of the matrix -- as for PCILU (host/ilu.c) -- then the two triangular systems in row form and one upload.
+ *   apply  : MatSolve_SeqSBAIJ_1_NaturalOrdering (src/mat/impls/sbaij/seq/sbaijfact2.c:1977-2015) on the device with the sync-free
+ *            solves of csrc/trisolve.hip.  The reference sweeps U^T by COLUMNS (x[col] += v * x_i for the entries of row i, rows in
+ *            ascending order): entry (i, c) therefore reaches x[c] after every earlier row's -- which is the order a row-oriented
+ *            solve with L = U^T adds them in.  x[c] += v t is the bits of x[c] -= (-v) t, so the plans hold the negated values; the
+ *            1/D(i) between the two sweeps is the upper solve's right-hand-side factor; its rows are stored last entry first, as the
+ *            reference's backward loop reads them.  Same bits as the host loop. */
+#include "hipmi355ximpl.h"
+
+typedef struct {
+  PetscInt n, nz, nlevL, nlevU, nshift;
+  mi355x_trisolve_plan_t tri_lo, tri_up;
+  int factored_state;
+} PC_ICC;
+
+static PetscErrorCode icc_free(PC_ICC *f) {
+  if (f->tri_lo) mi355x_trisolve_plan_destroy(f->tri_lo);
+  if (f->tri_up) mi355x_trisolve_plan_destroy(f->tri_up);
+  memset(f, 0, sizeof(*f));
+  f->factored_state = -1;
+  return 0;
+}
+
+static PetscErrorCode PCSetUp_ICC(PC pc) {
+  PetscErrorCode ierr;
+  PC_ICC *f = (PC_ICC *)pc->data;
+  Mat A = pc->pmat;
+  PetscInt n; const PetscInt *ai, *aj; const PetscScalar *aa;
+  PetscDeviceCtx *dc;
+  if (strcmp(HipObjTypeName(A), MATSEQAIJHIPMI355X)) SETERRQ(HipObjComm(pc), PETSC_ERR_SUP, "PCICC needs a sequential AIJ matrix (use -pc_type bjacobi -sub_pc_type icc in parallel); got %s", HipObjTypeName(A));
+  if (f->factored_state == HipObjState(A) && f->tri_lo) return 0;
+  ierr = MatSeqAIJGetArrays(A, &n, &ai, &aj, &aa);CHKERRQ(ierr);
+  if (A->rmap->n != A->cmap->n) SETERRQ(HipObjComm(pc), PETSC_ERR_ARG_WRONG, "Must be square matrix, rows %d columns %d", A->rmap->n, A->cmap->n);
+  ierr = icc_free(f);CHKERRQ(ierr);
+  f->n = n;
+  if (!n) { f->factored_state = HipObjState(A); return 0; }
+
+  /* ---- symbolic: row k = its strictly upper entries in column order, then the diagonal slot ---- */
+  PetscInt *ui, *uj, nz = 0; PetscScalar *ua;
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)(n + 1), &ui);CHKERRQ(ierr);
+  for (PetscInt k = 0; k < n; k++) {
+    PetscBool hasd = PETSC_FALSE;
+    for (PetscInt q = ai[k]; q < ai[k + 1]; q++) { if (aj[q] > k) nz++; else if (aj[q] == k) hasd = PETSC_TRUE; }
+    if (!hasd) { HipFree(ui); SETERRQ(HipObjComm(pc), PETSC_ERR_ARG_WRONGSTATE, "Matrix is missing diagonal entry %d", k); }
+    nz++;
+  }
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)nz, &uj);CHKERRQ(ierr);
+  ierr = PetscMalloc(sizeof(PetscScalar) * (size_t)nz, &ua);CHKERRQ(ierr);
+  f->nz = nz; nz = 0; ui[0] = 0;
+  for (PetscInt k = 0; k < n; k++) {
+    for (PetscInt q = ai[k]; q < ai[k + 1]; q++) if (aj[q] > k) uj[nz++] = aj[q];
+    uj[nz++] = k;
+    ui[k + 1] = nz;
+  }
+
+  /* ---- numeric, left-looking over the rows; the shift of MatPivotCheck_pd (matimpl.h:532-553) restarts it ---- */
+  const PetscReal zeropivot = 100.0 * 2.220446049250313e-16;
+  PetscReal shift_top = zeropivot, shift_amount = 0.0, shift_fraction = 0.0, shift_lo = 0.0, shift_hi = 1.0;
+  const PetscInt nshift_max = 5;
+  for (PetscInt i = 0; i < n; i++) {
+    PetscScalar d = 0.0; PetscReal rs;
+    for (PetscInt q = ai[i]; q < ai[i + 1]; q++) if (aj[q] == i) d = aa[q];
+    rs = -PetscAbsScalar(d) - d;
+    for (PetscInt q = ai[i]; q < ai[i + 1]; q++) rs += PetscAbsScalar(aa[q]);
+    if (rs > shift_top) shift_top = rs;
+  }
+  shift_top *= 1.1;
+  PetscScalar *work; PetscInt *first, *list;
+  ierr = PetscMalloc(sizeof(PetscScalar) * (size_t)n, &work);CHKERRQ(ierr);
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)n, &first);CHKERRQ(ierr);   /* first[i]: first entry of row i not yet folded into a later row */
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)n, &list);CHKERRQ(ierr);    /* list[c]: chain of the earlier rows whose next entry is in column c */
+  PetscBool again;
+  do {
+    again = PETSC_FALSE;
+    for (PetscInt i = 0; i < n; i++) list[i] = n;
+    first[0] = 0;
+    for (PetscInt k = 0; k < n; k++) {
+      const PetscInt dslot = ui[k + 1] - 1;
+      for (PetscInt q = ui[k]; q <= dslot; q++) { work[uj[q]] = 0.0; ua[q] = 0.0; }
+      for (PetscInt q = ai[k]; q < ai[k + 1]; q++) if (aj[q] >= k) work[aj[q]] = aa[q];
+      work[k] += shift_amount;
+      PetscScalar dk = work[k];
+      for (PetscInt i = list[k]; i < k;) {
+        const PetscInt nexti = list[i], at = first[i];
+        const PetscScalar m = -ua[at] * ua[ui[i + 1] - 1];     /* -U(i,k)/D(i): what the solve multiplies with */
+        dk += m * ua[at];
+        ua[at] = m;
+        if (at + 1 < ui[i + 1] - 1) {
+          for (PetscInt q = at + 1; q < ui[i + 1] - 1; q++) work[uj[q]] += m * ua[q];
+          first[i] = at + 1;
+          const PetscInt c = uj[at + 1]; list[i] = list[c]; list[c] = i;
+        }
+        i = nexti;
+      }
+      PetscReal rs = 0.0;
+      if (ui[k] < dslot) {
+        for (PetscInt q = ui[k]; q < dslot; q++) { ua[q] = work[uj[q]]; rs += PetscAbsScalar(ua[q]); }
+        first[k] = ui[k];
+        const PetscInt c = uj[ui[k]]; list[k] = list[c]; list[c] = k;
+      }
+      if (dk <= zeropivot * rs) {
+        if (f->nshift == nshift_max) shift_fraction = shift_hi;
+        else { shift_lo = shift_fraction; shift_fraction = (shift_hi + shift_lo) / 2.; }
+        shift_amount = shift_fraction * shift_top;
+        f->nshift++;
+        if (f->nshift > nshift_max + 1) { HipFree(work); HipFree(first); HipFree(list); HipFree(ui); HipFree(uj); HipFree(ua); SETERRQ(HipObjComm(pc), 71 /* PETSC_ERR_MAT_LU_ZRPVT */, "ICC(0): no positive pivot in row %d even with the full diagonal shift", k); }
+        again = PETSC_TRUE;
+        break;
+      }
+      ua[dslot] = 1.0 / dk;
+    }
+  } while (again);
+  HipFree(work); HipFree(first); HipFree(list);
+
+  /* ---- the two triangular systems in row form, negated values ---- */
+  const PetscInt noff = f->nz - n;
+  PetscInt *lp, *ll, *lj, *up, *ul, *uc, *levL, *levU; PetscScalar *lv, *uv, *ones, *dinv;
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)(n + 1), &lp);CHKERRQ(ierr);
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)n, &ll);CHKERRQ(ierr);
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)PetscMax(noff, 1), &lj);CHKERRQ(ierr);
+  ierr = PetscMalloc(sizeof(PetscScalar) * (size_t)PetscMax(noff, 1), &lv);CHKERRQ(ierr);
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)n, &up);CHKERRQ(ierr);
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)n, &ul);CHKERRQ(ierr);
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)PetscMax(noff, 1), &uc);CHKERRQ(ierr);
+  ierr = PetscMalloc(sizeof(PetscScalar) * (size_t)PetscMax(noff, 1), &uv);CHKERRQ(ierr);
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)n, &levL);CHKERRQ(ierr);
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)n, &levU);CHKERRQ(ierr);
+  ierr = PetscMalloc(sizeof(PetscScalar) * (size_t)n, &ones);CHKERRQ(ierr);
+  ierr = PetscMalloc(sizeof(PetscScalar) * (size_t)n, &dinv);CHKERRQ(ierr);
+  memset(lp, 0, sizeof(PetscInt) * (size_t)(n + 1));
+  for (PetscInt i = 0; i < n; i++) for (PetscInt q = ui[i]; q < ui[i + 1] - 1; q++) lp[uj[q] + 1]++;
+  for (PetscInt c = 0; c < n; c++) { ll[c] = 0; lp[c + 1] += lp[c]; }
+  for (PetscInt i = 0; i < n; i++)                      /* rows in ascending order: row c of U^T lists its entries in the order the column sweep adds them */
+    for (PetscInt q = ui[i]; q < ui[i + 1] - 1; q++) { const PetscInt c = uj[q], at = lp[c] + ll[c]++; lj[at] = i; lv[at] = -ua[q]; }
+  f->nlevL = 0;
+  for (PetscInt c = 0; c < n; c++) {
+    PetscInt l = 0;
+    for (PetscInt q = lp[c]; q < lp[c] + ll[c]; q++) l = PetscMax(l, levL[lj[q]] + 1);
+    levL[c] = l; f->nlevL = PetscMax(f->nlevL, l + 1);
+  }
+  f->nlevU = 0;
+  { PetscInt w = 0;
+    for (PetscInt i = 0; i < n; i++) {                  /* the backward loop reads a row from its last off-diagonal entry to its first */
+      up[i] = w; ul[i] = ui[i + 1] - 1 - ui[i];
+      for (PetscInt q = ui[i + 1] - 2; q >= ui[i]; q--) { uc[w] = uj[q]; uv[w] = -ua[q]; w++; }
+      ones[i] = 1.0; dinv[i] = ua[ui[i + 1] - 1];
+    } }
+  for (PetscInt i = n - 1; i >= 0; i--) {
+    PetscInt l = 0;
+    for (PetscInt q = ui[i]; q < ui[i + 1] - 1; q++) l = PetscMax(l, levU[uj[q]] + 1);
+    levU[i] = l; f->nlevU = PetscMax(f->nlevU, l + 1);
+  }
+  ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
+  int rc = mi355x_trisolve_plan_create_ordered(dc->h, n, f->nlevL, levL, lp, ll, lj, lv, NULL, 0, &f->tri_lo);
+  if (!rc) rc = mi355x_trisolve_plan_create_scaled(dc->h, n, f->nlevU, levU, up, ul, uc, uv, ones, dinv, &f->tri_up);
+  HipFree(lp); HipFree(ll); HipFree(lj); HipFree(lv); HipFree(up); HipFree(ul); HipFree(uc); HipFree(uv);
+  HipFree(levL); HipFree(levU); HipFree(ones); HipFree(dinv); HipFree(ui); HipFree(uj); HipFree(ua);
+  if (rc) { icc_free(f); CHKHIP(rc); }
+  f->factored_state = HipObjState(A);
+  return 0;
+}
+
+static PetscErrorCode PCApply_ICC(PC pc, Vec x, Vec y) {   /* PCApply_ICC (icc.c:65) -> MatSolve(fact, x, y) */
+  PetscErrorCode ierr;
+  PC_ICC *f = (PC_ICC *)pc->data;
+  const PetscScalar *db; PetscScalar *dx; PetscDeviceCtx *dc;
+  if (!f->n) return 0;
+  ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
+  ierr = VecHIPGetRead(x, &db);CHKERRQ(ierr);
+  ierr = VecHIPGetWrite(y, &dx);CHKERRQ(ierr);
+  int rc = mi355x_trisolve_apply(dc->h, f->tri_lo, f->tri_up, db, dx);
+  if (rc == 719) SETERRQ(HipObjComm(pc), PETSC_ERR_LIB, "sync-free triangular solve timed out in an earlier application");
+  CHKHIP(rc);
+  ierr = VecHIPRestoreWrite(y);CHKERRQ(ierr);
+  HipStateIncrease(y);
+  ierr = PetscLogFlops(4.0 * f->nz - 3.0 * f->n);CHKERRQ(ierr);
+  return 0;
+}
+
+static PetscErrorCode PCDestroy_ICC(PC pc) {
+  PC_ICC *f = (PC_ICC *)pc->data;
+  if (f) { icc_free(f); HipFree(f); pc->data = NULL; }
+  return 0;
+}
+
+PetscErrorCode PCCreate_ICC_HIPMI355X(PC pc) {
+  PC_ICC *f;
+  PetscErrorCode ierr = PetscMalloc(sizeof(*f), &f);CHKERRQ(ierr);
+  memset(f, 0, sizeof(*f));
+  f->factored_state = -1;
+  pc->data = f;
+  pc->ops->setup = PCSetUp_ICC; pc->ops->apply = PCApply_ICC; pc->ops->destroy = PCDestroy_ICC;
+  return 0;
+}
+
+/* dependency levels of the two sweeps and the number of positive-definite shifts the factorisation took (for tests / DESIGN.md) */
+PetscErrorCode PCICCGetInfo_HIPMI355X(PC pc, PetscInt *nlevL, PetscInt *nlevU, PetscInt *nshift) {
+  if (strcmp(HipObjTypeName(pc), "icc") && strcmp(HipObjTypeName(pc), "icchipmi355x")) SETERRQ(HipObjComm(pc), PETSC_ERR_ARG_WRONG, "not a PCICC");
+  PC_ICC *f = (PC_ICC *)pc->data;
+  if (nlevL) *nlevL = f->nlevL;
+  if (nlevU) *nlevU = f->nlevU;
+  if (nshift) *nshift = f->nshift;
+  return 0;
+}

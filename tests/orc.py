@@ -266,6 +266,23 @@ def ilu0_solve(f, b):
     return x
 
 
+def icc0_factor(ai, aj, aa):
+    """(ui, uj, ua), number of positive-definite shifts the factorisation needed"""
+    n = ai.size - 1
+    nz = lib().orc_icc0_count(C.c_int(n), I(ai), I(aj))
+    ui = np.zeros(n + 1, dtype=np.int32); uj = np.zeros(nz + 1, dtype=np.int32); ua = np.zeros(nz + 1)
+    rc = lib().orc_icc0_factor(C.c_int(n), I(ai), I(aj), D(aa), I(ui), I(uj), D(ua))
+    assert rc >= 0
+    return (ui, uj, ua), rc
+
+
+def icc0_solve(f, b):
+    ui, uj, ua = f
+    x = np.zeros(b.size)
+    lib().orc_icc0_solve(C.c_int(b.size), I(ui), I(uj), D(ua), D(b), D(x))
+    return x
+
+
 # ---- KSP ----
 class KspOpts(C.Structure):
     _fields_ = [("ksp_type", C.c_int), ("pc_type", C.c_int), ("rtol", C.c_double), ("abstol", C.c_double),
@@ -276,7 +293,7 @@ class KspOpts(C.Structure):
 
 
 KSP = dict(cg=0, gmres=1, bcgs=2, preonly=3, groppcg=4, pipecg=5)
-PC = dict(none=0, jacobi=1, bjacobi=2, ilu=3, pbjacobi=4)
+PC = dict(none=0, jacobi=1, bjacobi=2, ilu=3, pbjacobi=4, icc=5)
 
 
 def ksp_solve(ai, aj, aa, b, ksp="gmres", pc="none", x0=None, blocks=None, sub_ksp="preonly", sub_pc="jacobi", **kw):

@@ -19,6 +19,30 @@ def lap2d(m, n):
     return csr(sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(N, N)))
 
 
+def ex32(M=8):
+    """src/ksp/ksp/examples/tests/ex32.c with -dof 1 (ComputeMatrix :133-215, the symmetrisation in main :59-63, ComputeRHS :117-129):
+    M^3 grid, boundary rows hold only their diagonal, interior rows the 7-point operator scaled by the mesh widths, then
+    A <- 0.5 (A + A^T) (so an interior-boundary coupling is halved and mirrored); b = 1/(M-1)^3 everywhere"""
+    H = 1.0 / (M - 1)
+    d = 2.0 * (H * H / H + H * H / H + H * H / H)
+    nb = -(H * H / H)
+    N = M ** 3
+    idx = lambda i, j, k: i + M * (j + M * k)
+    rows, cols, vals = [], [], []
+    for k in range(M):
+        for j in range(M):
+            for i in range(M):
+                r = idx(i, j, k)
+                rows.append(r); cols.append(r); vals.append(d)
+                if not (i in (0, M - 1) or j in (0, M - 1) or k in (0, M - 1)):
+                    for (a, b_, c) in ((i - 1, j, k), (i + 1, j, k), (i, j - 1, k), (i, j + 1, k), (i, j, k - 1), (i, j, k + 1)):
+                        rows.append(r); cols.append(idx(a, b_, c)); vals.append(nb)
+    A = sp.csr_matrix((vals, (rows, cols)), shape=(N, N))
+    A = ((A + A.T) * 0.5).tocsr()
+    A.sort_indices()
+    return csr(A), np.full(N, 1.0 / ((M - 1) ** 3))
+
+
 def tridiag(n=10):
     """src/ksp/pc/examples/tests/ex2.c:33-47: tridiagonal (-1, 2, -1), n = 10, seqaij"""
     A = sp.diags([-np.ones(n - 1), 2.0 * np.ones(n), -np.ones(n - 1)], [-1, 0, 1])

@@ -929,6 +929,55 @@ def test_ksp_golden_ex3_ex2f_ex9(P):
         assert np.linalg.norm(x - u) < 1e-4
 
 
+def test_icc0_apply_bitexact_and_golden(P):
+    """SURVEY 8f.1 names ILU(0)/ICC(0): PCICC (zero fill, natural ordering).  The device solve reproduces
+    MatSolve_SeqSBAIJ_1_NaturalOrdering bit for bit (U^T sweep as the row form that adds in the same order, D^-1 in between, U sweep
+    with the rows read last entry first), replays included; a matrix that needs MatPivotCheck_pd's diagonal shift takes the same
+    number of shifts as the oracle; ksp/tests/ex32.c -ksp_type cg -pc_type icc (natural ordering, levels 0) prints output/ex32_5.out's
+    first block; and CG + block Jacobi(ICC) converges like the oracle's"""
+    L = P.lib()
+    cases = [pb.lap2d(9, 7), P.gen_poisson7(7, 6, 5), P.gen_poisson7(12, 11, 10), pb.ex32()[0]]
+    # symmetric, varying coefficients (scaled symmetrically), and one that is NOT diagonally dominant enough: shifts
+    ai, aj, aa = P.gen_poisson7(8, 7, 6)
+    s_ = 1.0 + 0.3 * np.sin(np.arange(ai.size - 1))
+    rows = np.repeat(np.arange(ai.size - 1), np.diff(ai))
+    cases.append((ai, aj, aa * s_[rows] * s_[aj]))
+    ai2, aj2, aa2 = pb.lap2d(8, 8)
+    aa2 = aa2.copy(); aa2[aj2 == np.repeat(np.arange(ai2.size - 1), np.diff(ai2))] = 1.5      # diagonal 1.5 against four -1: indefinite
+    cases.append((ai2, aj2, aa2))
+    for ci, (ai, aj, aa) in enumerate(cases):
+        n = ai.size - 1
+        A = P.Mat.from_csr(ai, aj, aa)
+        pc = C.c_void_p()
+        k = P.KSP(comm=L.COMM_SELF); k.set_operators(A); L.KSPGetPC(k.h, C.byref(pc)); L.PCSetType(pc, b"icc")
+        L.raw("PCSetUp")(pc)
+        f, nshift = orc.icc0_factor(ai, aj, aa)
+        nl, nu, ns = C.c_int(), C.c_int(), C.c_int()
+        L.PCICCGetInfo_HIPMI355X(pc, C.byref(nl), C.byref(nu), C.byref(ns))
+        assert ns.value == nshift and (nshift > 0) == (ci == len(cases) - 1) and nl.value == nu.value and nl.value > 1
+        vb, vx = V(P, np.zeros(n)), V(P, np.zeros(n))
+        for rep in range(3):                            # replays: the sentinel of the hand-off buffers is restored every time
+            b2 = rnd(n, 90 + rep); vb.set_array(b2)
+            L.raw("PCApply")(pc, vb.h, vx.h)
+            assert np.array_equal(bits(vx.array()), bits(orc.icc0_solve(f, b2)))
+    (ai, aj, aa), b = pb.ex32()
+    gold = pb.parse_monitor(os.path.join(G, "ksp_tests", "ex32_5.out"))[0]
+    x, h, its, reason = solve(P, ai, aj, aa, b, "cg", "icc")
+    pb.check_monitor(h, gold)
+    xo, ho, itso, ro = orc.ksp_solve(ai, aj, aa, b, ksp="cg", pc="icc")
+    assert (its, reason) == (itso, ro) and np.allclose(x, xo, rtol=1e-12, atol=1e-15)
+    # the SPD default under block Jacobi: several ICC(0) blocks per process
+    ai, aj, aa = P.gen_poisson7(10, 9, 8)
+    n = ai.size - 1
+    b = orc.spmv(ai, aj, aa, np.ones(n))
+    x, h, its, reason = solve(P, ai, aj, aa, b, "cg", "bjacobi", opts="-pc_bjacobi_blocks 4 -sub_pc_type icc", rtol=1e-8)
+    blocks = [0, n // 4, n // 2, 3 * n // 4, n]
+    blocks = [0] + [sum([(n // 4) + (1 if i < n % 4 else 0) for i in range(j + 1)]) for j in range(4)]
+    xo, ho, itso, ro = orc.ksp_solve(ai, aj, aa, b, ksp="cg", pc="bjacobi", blocks=blocks, sub_pc="icc", rtol=1e-8)
+    assert reason == ro == 2 and abs(its - itso) <= 1 and np.allclose(h[:min(len(h), len(ho))], ho[:min(len(h), len(ho))], rtol=1e-8)
+    assert np.linalg.norm(x - 1.0) < 1e-6 * np.sqrt(n)
+
+
 def test_ilu0_apply_bitexact_and_golden(P):
     """PCILU (ILU(0), natural ordering).  The level-scheduled device solve reproduces
     MatSolve_SeqAIJ_NaturalOrdering bit for bit (one lane per row, products subtracted in column order), and with NO

@@ -303,3 +303,39 @@ def test_pipecg_restatement_is_cg_with_the_natural_norm():
     # the snapshot's quirk: with the preconditioned norm gamma is reduced once; the walk does not converge
     xq, hq, itq, rq = orc.ksp_solve(ai, aj, aa, b, ksp="pipecg", pc="jacobi", norm_type=1, rtol=1e-9, max_it=200)
     assert rq < 0
+
+
+def test_ex32_cg_icc0_golden_and_factor_properties():
+    """ksp/tests/ex32.c -dof 1 -ksp_type cg -pc_type icc -pc_factor_mat_ordering_type natural -mat_type aij -pc_factor_levels 0
+    (makefile runex32_testset5, first case) vs output/ex32_5.out: pins the oracle's ICC(0) -- MatICCFactorSymbolic_SeqAIJ /
+    MatCholeskyFactorNumeric_SeqAIJ / MatSolve_SeqSBAIJ_1_NaturalOrdering.  Plus what the factor has to satisfy: U^T D U agrees with A on
+    A's pattern (zero fill), the preconditioner is symmetric, and a matrix that is not diagonally dominant takes the reference's
+    positive-definite shifts and still yields a positive diagonal"""
+    (ai, aj, aa), b = pb.ex32()
+    gold = pb.parse_monitor(os.path.join(G, "ksp_tests", "ex32_5.out"))[0]
+    x, h, its, reason = orc.ksp_solve(ai, aj, aa, b, ksp="cg", pc="icc")
+    pb.check_monitor(h, gold)
+    import scipy.sparse as sp
+    for ai, aj, aa in (pb.lap2d(7, 6), orc.gen_p7(5, 4, 3)):
+        n = ai.size - 1
+        (ui, uj, ua), ns = orc.icc0_factor(ai, aj, aa)
+        assert ns == 0
+        # rebuild U (unit diagonal) and D from the stored multipliers: stored off-diagonal = -U(i,j), stored diagonal = 1/D(i)
+        U = sp.lil_matrix((n, n)); D = np.zeros(n)
+        for i in range(n):
+            D[i] = 1.0 / ua[ui[i + 1] - 1]
+            U[i, i] = 1.0
+            for q in range(ui[i], ui[i + 1] - 1):
+                U[i, uj[q]] = -ua[q]
+        U = U.tocsr()
+        R = (U.T @ sp.diags(D) @ U).tocsr()
+        A = sp.csr_matrix((aa, aj, ai), shape=(n, n))
+        mask = A.copy(); mask.data[:] = 1.0
+        assert abs((R.multiply(mask) - A)).max() < 1e-13          # exact on the pattern of A, fill dropped
+        e = np.eye(n)
+        M = np.column_stack([orc.icc0_solve((ui, uj, ua), e[:, j].copy()) for j in range(n)])
+        assert np.allclose(M, M.T, rtol=0, atol=1e-14) and np.allclose(M, np.linalg.inv(R.toarray()), rtol=1e-10, atol=1e-12)
+    ai, aj, aa = pb.lap2d(8, 8)
+    aa = aa.copy(); aa[aj == np.repeat(np.arange(ai.size - 1), np.diff(ai))] = 1.5
+    (ui, uj, ua), ns = orc.icc0_factor(ai, aj, aa)
+    assert 1 <= ns <= 6 and np.all(ua[ui[1:] - 1] > 0)
