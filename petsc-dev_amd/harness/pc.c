@@ -266,7 +266,8 @@ static PetscErrorCode PCSetUp_BJacobi(PC pc) {
       ierr = PetscOptionsGetString(prefix, "-ksp_type", kt, sizeof(kt), &ks);CHKERRQ(ierr);
       ierr = PetscOptionsGetString(prefix, "-pc_type", pt, sizeof(pt), &ps);CHKERRQ(ierr);
       ierr = PetscOptionsGetString(pc->prefix, "-pc_bjacobi_merge_blocks", mg, sizeof(mg), &ms);CHKERRQ(ierr);   /* 0: block after block */
-      bj->merged = (PetscBool)((!ks || !strcmp(kt, KSPPREONLY)) && (!ps || !strcmp(pt, PCILU)) && !(ms && (!strcmp(mg, "0") || !strcmp(mg, "false"))));
+      /* ILU(0), or ICC(0) when the type can factor the blocks of a block-diagonal matrix independently ("PCFactorSetIndependentBlocks_C", asked below) */
+      bj->merged = (PetscBool)((!ks || !strcmp(kt, KSPPREONLY)) && (!ps || !strcmp(pt, PCILU) || !strcmp(pt, PCICC)) && !(ms && (!strcmp(mg, "0") || !strcmp(mg, "false"))));
     }
   }
   const PetscInt nsolvers = bj->merged ? 1 : nloc;
@@ -287,6 +288,12 @@ static PetscErrorCode PCSetUp_BJacobi(PC pc) {
     }
     ierr = KSPSetOperators(bj->ksp[i], bj->block[i], bj->block[i], SAME_NONZERO_PATTERN);CHKERRQ(ierr);
     ierr = KSPSetFromOptions(bj->ksp[i]);CHKERRQ(ierr);
+    if (bj->merged) {   /* a factorisation with a shift strategy (ICC) must treat the blocks as the separate matrices they stand for */
+      PetscVoidFunction fb = NULL;
+      ierr = PetscObjectQueryFunction((PetscObject)bj->ksp[i]->pc, "PCFactorSetIndependentBlocks_C", &fb);CHKERRQ(ierr);
+      if (fb) { ierr = ((PetscErrorCode (*)(PC, PetscInt, const PetscInt *))fb)(bj->ksp[i]->pc, nloc, bj->starts);CHKERRQ(ierr); }
+      else if (!strcmp(bj->ksp[i]->pc->type_name, PCICC)) SETERRQ(pc->comm, PETSC_ERR_SUP, "this PCICC cannot factor independent blocks: use -pc_bjacobi_merge_blocks 0");
+    }
     ierr = KSPSetUp(bj->ksp[i]);CHKERRQ(ierr);
   }
   if (bj->merged) for (PetscInt i = 1; i < nloc; i++) bj->ksp[i] = bj->ksp[0];   /* PCBJacobiGetSubKSP: every block answers with the one solver */

@@ -16,12 +16,31 @@ typedef struct {
   PetscInt n, nz, nlevL, nlevU, nshift;
   mi355x_trisolve_plan_t tri_lo, tri_up;
   int factored_state;
+  /* "PCFactorSetIndependentBlocks_C": the matrix is block diagonal with these row ranges and stands for that many separate
+   * matrices (block Jacobi solving all its ICC(0) blocks as one system): each range is factored as the reference factors a
+   * matrix of its own -- its own shift loop -- so the result is the blocks' factors side by side also when a block needs shifts */
+  PetscInt nblk, *blk;
 } PC_ICC;
 
 static PetscErrorCode icc_free(PC_ICC *f) {
+  PetscInt nblk = f->nblk, *blk = f->blk;
   if (f->tri_lo) mi355x_trisolve_plan_destroy(f->tri_lo);
   if (f->tri_up) mi355x_trisolve_plan_destroy(f->tri_up);
   memset(f, 0, sizeof(*f));
+  f->factored_state = -1;
+  f->nblk = nblk; f->blk = blk;
+  return 0;
+}
+
+static PetscErrorCode PCFactorSetIndependentBlocks_ICC(PC pc, PetscInt nblk, const PetscInt *starts) {
+  PC_ICC *f = (PC_ICC *)pc->data;
+  PetscErrorCode ierr;
+  HipFree(f->blk); f->blk = NULL; f->nblk = 0;
+  if (nblk > 0) {
+    ierr = PetscMalloc(sizeof(PetscInt) * (size_t)(nblk + 1), &f->blk);CHKERRQ(ierr);
+    memcpy(f->blk, starts, sizeof(PetscInt) * (size_t)(nblk + 1));
+    f->nblk = nblk;
+  }
   f->factored_state = -1;
   return 0;
 }
@@ -58,63 +77,74 @@ static PetscErrorCode PCSetUp_ICC(PC pc) {
     ui[k + 1] = nz;
   }
 
-  /* ---- numeric, left-looking over the rows; the shift of MatPivotCheck_pd (matimpl.h:532-553) restarts it ---- */
+  /* ---- numeric, left-looking over the rows; the shift of MatPivotCheck_pd (matimpl.h:532-553) restarts it.  One pass per
+   * independent block (one block = the whole matrix unless "PCFactorSetIndependentBlocks_C" said otherwise) ---- */
   const PetscReal zeropivot = 100.0 * 2.220446049250313e-16;
-  PetscReal shift_top = zeropivot, shift_amount = 0.0, shift_fraction = 0.0, shift_lo = 0.0, shift_hi = 1.0;
   const PetscInt nshift_max = 5;
-  for (PetscInt i = 0; i < n; i++) {
-    PetscScalar d = 0.0; PetscReal rs;
-    for (PetscInt q = ai[i]; q < ai[i + 1]; q++) if (aj[q] == i) d = aa[q];
-    rs = -PetscAbsScalar(d) - d;
-    for (PetscInt q = ai[i]; q < ai[i + 1]; q++) rs += PetscAbsScalar(aa[q]);
-    if (rs > shift_top) shift_top = rs;
-  }
-  shift_top *= 1.1;
   PetscScalar *work; PetscInt *first, *list;
   ierr = PetscMalloc(sizeof(PetscScalar) * (size_t)n, &work);CHKERRQ(ierr);
   ierr = PetscMalloc(sizeof(PetscInt) * (size_t)n, &first);CHKERRQ(ierr);   /* first[i]: first entry of row i not yet folded into a later row */
   ierr = PetscMalloc(sizeof(PetscInt) * (size_t)n, &list);CHKERRQ(ierr);    /* list[c]: chain of the earlier rows whose next entry is in column c */
-  PetscBool again;
-  do {
-    again = PETSC_FALSE;
-    for (PetscInt i = 0; i < n; i++) list[i] = n;
-    first[0] = 0;
-    for (PetscInt k = 0; k < n; k++) {
-      const PetscInt dslot = ui[k + 1] - 1;
-      for (PetscInt q = ui[k]; q <= dslot; q++) { work[uj[q]] = 0.0; ua[q] = 0.0; }
-      for (PetscInt q = ai[k]; q < ai[k + 1]; q++) if (aj[q] >= k) work[aj[q]] = aa[q];
-      work[k] += shift_amount;
-      PetscScalar dk = work[k];
-      for (PetscInt i = list[k]; i < k;) {
-        const PetscInt nexti = list[i], at = first[i];
-        const PetscScalar m = -ua[at] * ua[ui[i + 1] - 1];     /* -U(i,k)/D(i): what the solve multiplies with */
-        dk += m * ua[at];
-        ua[at] = m;
-        if (at + 1 < ui[i + 1] - 1) {
-          for (PetscInt q = at + 1; q < ui[i + 1] - 1; q++) work[uj[q]] += m * ua[q];
-          first[i] = at + 1;
-          const PetscInt c = uj[at + 1]; list[i] = list[c]; list[c] = i;
-        }
-        i = nexti;
-      }
-      PetscReal rs = 0.0;
-      if (ui[k] < dslot) {
-        for (PetscInt q = ui[k]; q < dslot; q++) { ua[q] = work[uj[q]]; rs += PetscAbsScalar(ua[q]); }
-        first[k] = ui[k];
-        const PetscInt c = uj[ui[k]]; list[k] = list[c]; list[c] = k;
-      }
-      if (dk <= zeropivot * rs) {
-        if (f->nshift == nshift_max) shift_fraction = shift_hi;
-        else { shift_lo = shift_fraction; shift_fraction = (shift_hi + shift_lo) / 2.; }
-        shift_amount = shift_fraction * shift_top;
-        f->nshift++;
-        if (f->nshift > nshift_max + 1) { HipFree(work); HipFree(first); HipFree(list); HipFree(ui); HipFree(uj); HipFree(ua); SETERRQ(HipObjComm(pc), 71 /* PETSC_ERR_MAT_LU_ZRPVT */, "ICC(0): no positive pivot in row %d even with the full diagonal shift", k); }
-        again = PETSC_TRUE;
-        break;
-      }
-      ua[dslot] = 1.0 / dk;
+  const PetscInt whole[2] = {0, n};
+  const PetscInt nblk = (f->nblk > 0 && f->blk[f->nblk] == n) ? f->nblk : 1, *blk = (f->nblk > 0 && f->blk[f->nblk] == n) ? f->blk : whole;
+  for (PetscInt bb = 0; bb < nblk; bb++) {
+    const PetscInt r0 = blk[bb], r1 = blk[bb + 1];
+    for (PetscInt k = r0; k < r1; k++)
+      for (PetscInt q = ui[k]; q < ui[k + 1]; q++)
+        if (uj[q] >= r1) { HipFree(work); HipFree(first); HipFree(list); HipFree(ui); HipFree(uj); HipFree(ua); SETERRQ(HipObjComm(pc), PETSC_ERR_ARG_WRONG, "row %d couples to column %d outside its independent block", k, uj[q]); }
+    PetscReal shift_top = zeropivot, shift_amount = 0.0, shift_fraction = 0.0, shift_lo = 0.0, shift_hi = 1.0;
+    PetscInt nshift = 0;
+    for (PetscInt i = r0; i < r1; i++) {
+      PetscScalar d = 0.0; PetscReal rs;
+      for (PetscInt q = ai[i]; q < ai[i + 1]; q++) if (aj[q] == i) d = aa[q];
+      rs = -PetscAbsScalar(d) - d;
+      for (PetscInt q = ai[i]; q < ai[i + 1]; q++) rs += PetscAbsScalar(aa[q]);
+      if (rs > shift_top) shift_top = rs;
     }
-  } while (again);
+    shift_top *= 1.1;
+    PetscBool again;
+    do {
+      again = PETSC_FALSE;
+      for (PetscInt i = r0; i < r1; i++) list[i] = n;
+      if (r0 < r1) first[r0] = ui[r0];
+      for (PetscInt k = r0; k < r1; k++) {
+        const PetscInt dslot = ui[k + 1] - 1;
+        for (PetscInt q = ui[k]; q <= dslot; q++) { work[uj[q]] = 0.0; ua[q] = 0.0; }
+        for (PetscInt q = ai[k]; q < ai[k + 1]; q++) if (aj[q] >= k) work[aj[q]] = aa[q];
+        work[k] += shift_amount;
+        PetscScalar dk = work[k];
+        for (PetscInt i = list[k]; i < k;) {
+          const PetscInt nexti = list[i], at = first[i];
+          const PetscScalar m = -ua[at] * ua[ui[i + 1] - 1];     /* -U(i,k)/D(i): what the solve multiplies with */
+          dk += m * ua[at];
+          ua[at] = m;
+          if (at + 1 < ui[i + 1] - 1) {
+            for (PetscInt q = at + 1; q < ui[i + 1] - 1; q++) work[uj[q]] += m * ua[q];
+            first[i] = at + 1;
+            const PetscInt c = uj[at + 1]; list[i] = list[c]; list[c] = i;
+          }
+          i = nexti;
+        }
+        PetscReal rs = 0.0;
+        if (ui[k] < dslot) {
+          for (PetscInt q = ui[k]; q < dslot; q++) { ua[q] = work[uj[q]]; rs += PetscAbsScalar(ua[q]); }
+          first[k] = ui[k];
+          const PetscInt c = uj[ui[k]]; list[k] = list[c]; list[c] = k;
+        }
+        if (dk <= zeropivot * rs) {
+          if (nshift == nshift_max) shift_fraction = shift_hi;
+          else { shift_lo = shift_fraction; shift_fraction = (shift_hi + shift_lo) / 2.; }
+          shift_amount = shift_fraction * shift_top;
+          nshift++;
+          if (nshift > nshift_max + 1) { HipFree(work); HipFree(first); HipFree(list); HipFree(ui); HipFree(uj); HipFree(ua); SETERRQ(HipObjComm(pc), 71 /* PETSC_ERR_MAT_LU_ZRPVT */, "ICC(0): no positive pivot in row %d even with the full diagonal shift", k); }
+          again = PETSC_TRUE;
+          break;
+        }
+        ua[dslot] = 1.0 / dk;
+      }
+    } while (again);
+    f->nshift = PetscMax(f->nshift, nshift);
+  }
   HipFree(work); HipFree(first); HipFree(list);
 
   /* ---- the two triangular systems in row form, negated values ---- */
@@ -184,7 +214,8 @@ static PetscErrorCode PCApply_ICC(PC pc, Vec x, Vec y) {   /* PCApply_ICC (icc.c
 
 static PetscErrorCode PCDestroy_ICC(PC pc) {
   PC_ICC *f = (PC_ICC *)pc->data;
-  if (f) { icc_free(f); HipFree(f); pc->data = NULL; }
+  if (f) { icc_free(f); HipFree(f->blk); HipFree(f); pc->data = NULL; }
+  (void)PetscObjectComposeFunction((PetscObject)pc, "PCFactorSetIndependentBlocks_C", "", (PetscVoidFunction)NULL);
   return 0;
 }
 
@@ -195,6 +226,7 @@ PetscErrorCode PCCreate_ICC_HIPMI355X(PC pc) {
   f->factored_state = -1;
   pc->data = f;
   pc->ops->setup = PCSetUp_ICC; pc->ops->apply = PCApply_ICC; pc->ops->destroy = PCDestroy_ICC;
+  ierr = PetscObjectComposeFunction((PetscObject)pc, "PCFactorSetIndependentBlocks_C", "PCFactorSetIndependentBlocks_ICC", (PetscVoidFunction)PCFactorSetIndependentBlocks_ICC);CHKERRQ(ierr);
   return 0;
 }
 

@@ -976,6 +976,20 @@ def test_icc0_apply_bitexact_and_golden(P):
     xo, ho, itso, ro = orc.ksp_solve(ai, aj, aa, b, ksp="cg", pc="bjacobi", blocks=blocks, sub_pc="icc", rtol=1e-8)
     assert reason == ro == 2 and abs(its - itso) <= 1 and np.allclose(h[:min(len(h), len(ho))], ho[:min(len(h), len(ho))], rtol=1e-8)
     assert np.linalg.norm(x - 1.0) < 1e-6 * np.sqrt(n)
+    # the blocks solved as ONE block-diagonal system (default) against block after block (-pc_bjacobi_merge_blocks 0): same bits,
+    # also when one block needs the positive-definite shift and the others do not (each block keeps its own shift loop)
+    ai, aj, aa = pb.lap2d(16, 8)
+    n = ai.size - 1
+    aa = aa.copy()
+    rows = np.repeat(np.arange(n), np.diff(ai))
+    aa[(aj == rows) & (rows >= 3 * n // 4)] = 1.5          # the last quarter of the rows: not diagonally dominant
+    b = np.cos(0.3 * np.arange(n)) + 0.2
+    runs = [solve(P, ai, aj, aa, b, "gmres", "bjacobi", opts="-pc_bjacobi_blocks 4 -sub_pc_type icc " + o, rtol=1e-9) for o in ("", "-pc_bjacobi_merge_blocks 0")]
+    assert runs[0][2] == runs[1][2] and runs[0][2] > 3 and runs[0][3] == runs[1][3] == 2
+    assert np.array_equal(bits(runs[0][1]), bits(runs[1][1])) and np.array_equal(bits(runs[0][0]), bits(runs[1][0]))
+    blocks = [0, n // 4, n // 2, 3 * n // 4, n]
+    xo, ho, itso, ro = orc.ksp_solve(ai, aj, aa, b, ksp="gmres", pc="bjacobi", blocks=blocks, sub_pc="icc", rtol=1e-9)
+    assert itso == runs[0][2] and np.allclose(runs[0][1], ho, rtol=1e-7) and np.allclose(runs[0][0], xo, rtol=1e-9, atol=1e-12)
 
 
 def test_ilu0_apply_bitexact_and_golden(P):
