@@ -35,15 +35,19 @@ if n <= 128:
     print("oracle (1 core) solve %.3f ms ; bit-exact: %s" % (tc * 1e3, np.array_equal(x.array().view(np.uint64), ref.view(np.uint64))), flush=True)
 u = P.Vec.create(N, comm=L.COMM_SELF); L.VecSet(u.h, 1.0)
 A.mult(u, b)
-for pct in ("icc", "jacobi"):
+cases = [("icc", "-pc_type icc"), ("jacobi", "-pc_type jacobi")]
+for nb in [int(v) for v in os.environ.get("ICC_BENCH_BLOCKS", "64,4096").split(",") if v]:      # several ICC(0) blocks on the one rank, solved as one system
+    cases.append(("bjacobi/icc x%d" % nb, "-pc_type bjacobi -pc_bjacobi_blocks %d -sub_pc_type icc" % nb))
+for pct, popt in cases:
     ks = P.KSP(comm=L.COMM_SELF); ks.set_operators(A)
-    L.PetscOptionsClear(); L.PetscOptionsInsertString(("-ksp_type cg -pc_type %s" % pct).encode())
-    ks.set_from_options(); L.PetscOptionsClear()
+    L.PetscOptionsClear(); L.PetscOptionsInsertString(("-ksp_type cg " + popt).encode())
+    ks.set_from_options()
     ks.set_tolerances(rtol=1e-8, abstol=1e-50, dtol=1e5, max_it=20000)
-    L.VecSet(x.h, 0.0); ks.solve(b, x)            # includes the set-up
+    L.VecSet(x.h, 0.0); ks.solve(b, x)            # includes the set-up (block Jacobi reads its options there)
+    L.PetscOptionsClear()
     L.VecSet(x.h, 0.0)
     k.mi355x_device_synchronize(); t0 = time.perf_counter()
     ks.solve(b, x)
     k.mi355x_device_synchronize(); dt = time.perf_counter() - t0
     err = np.abs(x.array() - 1.0).max()
-    print("CG + %-6s: %5d iterations to rtol 1e-8 in %8.2f ms (%.3f ms per iteration), max error %.2e" % (pct, ks.its, dt * 1e3, dt * 1e3 / max(ks.its, 1), err), flush=True)
+    print("CG + %-18s: %5d iterations to rtol 1e-8 in %8.2f ms (%.3f ms per iteration), max error %.2e" % (pct, ks.its, dt * 1e3, dt * 1e3 / max(ks.its, 1), err), flush=True)
