@@ -82,6 +82,7 @@ PetscErrorCode VecHIPMI355XGetCGUpdateTiming(PetscInt *nlaunches, PetscLogDouble
 PetscErrorCode MatHIPMI355XGetValuePatterns(Mat A, PetscInt *nvpat);   /* 0: the SpMV streams the values; else the number of distinct rows (offsets + values) of the dictionary it runs from */
 PetscErrorCode MatHIPMI355XGetIndexCompression(Mat A, PetscInt *noffsets);   /* 0: plain CSR indices; else #offsets of the 1-byte dictionary */
 PetscErrorCode PCICCGetInfo_HIPMI355X(PC pc, PetscInt *nlevL, PetscInt *nlevU, PetscInt *nshift);   /* levels of the two sweeps of ICC(0); positive-definite shifts the factorisation took */
+PetscErrorCode PCILUGetShiftCount_HIPMI355X(PC pc, PetscInt *nshift);   /* restarts of ILU(0) with a larger diagonal shift (MAT_SHIFT_NONZERO, PCILU's default) */
 PetscErrorCode PCILUGetLevels_HIPMI355X(PC pc, PetscInt *nlevL, PetscInt *nlevU);   /* dependency levels of the two triangular solves */
 PetscErrorCode PCILUGetSolver_HIPMI355X(PC pc, PetscInt *syncfree, PetscInt *aborted);   /* 1: two-launch sync-free solves (-pc_factor_hipmi355x_trisolve syncfree, default above 16 levels); 0: one launch per level */
 

@@ -63,6 +63,12 @@ static int solve(solver *s, const double *b, double *x);
 /* MatILUFactorSymbolic_SeqAIJ_ilu0 (:1628-1700): L rows forward (columns < i), then the U rows stored from the
  * last row backwards, each followed by its diagonal slot; bdiag[i] = position of the (inverted) diagonal. */
 int orc_ilu0_factor(int n, const int *ai, const int *aj, const double *aa, int *bi, int *bj, int *bdiag, double *ba) {
+  return orc_ilu0_factor_shift(n, ai, aj, aa, bi, bj, bdiag, ba, NULL);
+}
+/* ... with PCILU's default shift (ilu.c:387-389: MAT_SHIFT_NONZERO, shiftamount = zeropivot = 100 eps): a pivot with
+ * |pivot| <= zeropivot * (sum of the row's other factor entries) restarts the factorisation with the diagonal shifted by
+ * shiftamount, then twice that, ... (MatPivotCheck_nz, matimpl.h:512-528; aijfact.c:507-592).  *nshift: restarts taken. */
+int orc_ilu0_factor_shift(int n, const int *ai, const int *aj, const double *aa, int *bi, int *bj, int *bdiag, double *ba, int *nshift_out) {
   int k = 0;
   int *adiag = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
   for (int i = 0; i < n; i++) {
@@ -83,8 +89,13 @@ int orc_ilu0_factor(int n, const int *ai, const int *aj, const double *aa, int *
     bj[k++] = i;
     bdiag[i] = bdiag[i + 1] + nz + 1;
   }
-  /* MatLUFactorNumeric_SeqAIJ (:461-620), identity permutations, no shift needed */
+  /* MatLUFactorNumeric_SeqAIJ (:461-620), identity permutations */
   double *rtmp = (double *)calloc((size_t)n + 1, sizeof(double));
+  const double zeropivot = 100.0 * 2.220446049250313e-16, shiftamount = 100.0 * 2.220446049250313e-16;
+  double shift_amount = 0.0;
+  int nshift = 0, again;
+  do {
+  again = 0;
   for (int i = 0; i < n; i++) {
     int nz = bi[i + 1] - bi[i];
     const int *bjtmp = bj + bi[i];
@@ -93,6 +104,8 @@ int orc_ilu0_factor(int n, const int *ai, const int *aj, const double *aa, int *
     bjtmp = bj + bdiag[i + 1] + 1;
     for (int j = 0; j < nz; j++) rtmp[bjtmp[j]] = 0.0;
     for (int q = ai[i]; q < ai[i + 1]; q++) rtmp[aj[q]] = aa[q];
+    rtmp[i] += shift_amount;
+    double rs = 0.0;
     const int nzL = bi[i + 1] - bi[i];
     for (int kk = 0; kk < nzL; kk++) {
       const int row = bj[bi[i] + kk];
@@ -106,12 +119,21 @@ int orc_ilu0_factor(int n, const int *ai, const int *aj, const double *aa, int *
         for (int j = 0; j < nzu; j++) rtmp[pj[j]] -= multiplier * pv[j];
       }
     }
-    for (int j = 0; j < nzL; j++) ba[bi[i] + j] = rtmp[bj[bi[i] + j]];
+    for (int j = 0; j < nzL; j++) { ba[bi[i] + j] = rtmp[bj[bi[i] + j]]; rs += fabs(ba[bi[i] + j]); }
     nz = bdiag[i] - bdiag[i + 1] - 1;
-    for (int j = 0; j < nz; j++) ba[bdiag[i + 1] + 1 + j] = rtmp[bj[bdiag[i + 1] + 1 + j]];
+    for (int j = 0; j < nz; j++) { ba[bdiag[i + 1] + 1 + j] = rtmp[bj[bdiag[i + 1] + 1 + j]]; rs += fabs(ba[bdiag[i + 1] + 1 + j]); }
+    if (fabs(rtmp[i]) <= zeropivot * rs) {     /* MatPivotCheck_nz */
+      shift_amount = nshift ? shift_amount * 2.0 : shiftamount;
+      nshift++;
+      if (nshift > 80) { free(rtmp); free(adiag); return 2; }
+      again = 1;
+      break;
+    }
     ba[bdiag[i]] = 1.0 / rtmp[i];   /* inverted diagonal */
   }
+  } while (again);
   free(rtmp); free(adiag);
+  if (nshift_out) *nshift_out = nshift;
   return 0;
 }
 

@@ -93,6 +93,7 @@ enum { ORC_KSP_CG = 0, ORC_KSP_GMRES = 1, ORC_KSP_BCGS = 2, ORC_KSP_PREONLY = 3,
 enum { ORC_PC_NONE = 0, ORC_PC_JACOBI = 1, ORC_PC_BJACOBI = 2, ORC_PC_ILU = 3, ORC_PC_PBJACOBI = 4, ORC_PC_ICC = 5 };
 /* ILU(0), natural ordering (src/mat/impls/aij/seq/aijfact.c:1628 symbolic, :461 numeric, :3126 solve); bi[n+1], bj/ba[nz+1], bdiag[n+1] */
 int  orc_ilu0_factor(int n, const int *ai, const int *aj, const double *aa, int *bi, int *bj, int *bdiag, double *ba);
+int  orc_ilu0_factor_shift(int n, const int *ai, const int *aj, const double *aa, int *bi, int *bj, int *bdiag, double *ba, int *nshift);   /* same; *nshift = restarts MatPivotCheck_nz asked for */
 void orc_ilu0_solve(int n, const int *bi, const int *bj, const int *bdiag, const double *ba, const double *b, double *x);
 /* ICC(0), natural ordering, of the upper triangle of a sequential AIJ matrix (MatICCFactorSymbolic_SeqAIJ with levels 0 +
  * MatCholeskyFactorNumeric_SeqAIJ, aijfact.c:2076-2230,2405-2600): ui[n+1], uj/ua[nnz of the upper triangle incl. diagonal]; row k holds

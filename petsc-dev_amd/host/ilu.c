@@ -22,6 +22,7 @@ typedef struct {
   int graph_tried;
   mi355x_trisolve_plan_t tri_lo, tri_up;                 /* sync-free solves (NULL: level launches) */
   int by_level;                                          /* rows summed in dependency-level order (inode matrices) instead of column order */
+  PetscInt nshift;                                       /* restarts of the factorisation MatPivotCheck_nz asked for */
   int factored_state;
 } PC_ILU;
 
@@ -101,31 +102,44 @@ static PetscErrorCode PCSetUp_ILU(PC pc) {
   /* numeric (aijfact.c:505-570): row by row with a dense work row; pivots are stored inverted */
   PetscScalar *rtmp;
   ierr = PetscMalloc(sizeof(PetscScalar) * (size_t)(n + 1), &rtmp);CHKERRQ(ierr);
-  const PetscReal zeropivot = 100.0 * 2.220446049250313e-16;   /* ilu.c:389 */
-  for (PetscInt i = 0; i < n; i++) {
-    PetscInt nzl = bi[i + 1] - bi[i], nzu = bdiag[i] - bdiag[i + 1];
-    PetscReal rs = 0.0;
-    for (PetscInt j = 0; j < nzl; j++) rtmp[bj[bi[i] + j]] = 0.0;
-    for (PetscInt j = 0; j < nzu; j++) rtmp[bj[bdiag[i + 1] + 1 + j]] = 0.0;
-    for (PetscInt q = ai[i]; q < ai[i + 1]; q++) rtmp[aj[q]] = aa[q];
-    for (PetscInt kk = 0; kk < nzl; kk++) {
-      const PetscInt row = bj[bi[i] + kk];
-      PetscScalar *pc_ = rtmp + row;
-      if (*pc_ != 0.0) {
-        const PetscScalar multiplier = *pc_ * ba[bdiag[row]];
-        *pc_ = multiplier;
-        const PetscInt *pj = bj + bdiag[row + 1] + 1;
-        const PetscScalar *pv = ba + bdiag[row + 1] + 1;
-        const PetscInt nz = bdiag[row] - bdiag[row + 1] - 1;
-        for (PetscInt j = 0; j < nz; j++) rtmp[pj[j]] -= multiplier * pv[j];
+  const PetscReal zeropivot = 100.0 * 2.220446049250313e-16, shiftamount = 100.0 * 2.220446049250313e-16;   /* ilu.c:388-389 */
+  PetscReal shift_amount = 0.0;
+  PetscBool again;
+  f->nshift = 0;
+  do {   /* MAT_SHIFT_NONZERO, PCILU's default on a SeqAIJ matrix (ilu.c:387): a pivot that fails MatPivotCheck_nz (matimpl.h:512-528)
+          * restarts the factorisation with the diagonal shifted by shiftamount, then by twice that, ... (aijfact.c:507-592) */
+    again = PETSC_FALSE;
+    for (PetscInt i = 0; i < n; i++) {
+      PetscInt nzl = bi[i + 1] - bi[i], nzu = bdiag[i] - bdiag[i + 1];
+      PetscReal rs = 0.0;
+      for (PetscInt j = 0; j < nzl; j++) rtmp[bj[bi[i] + j]] = 0.0;
+      for (PetscInt j = 0; j < nzu; j++) rtmp[bj[bdiag[i + 1] + 1 + j]] = 0.0;
+      for (PetscInt q = ai[i]; q < ai[i + 1]; q++) rtmp[aj[q]] = aa[q];
+      rtmp[i] += shift_amount;
+      for (PetscInt kk = 0; kk < nzl; kk++) {
+        const PetscInt row = bj[bi[i] + kk];
+        PetscScalar *pc_ = rtmp + row;
+        if (*pc_ != 0.0) {
+          const PetscScalar multiplier = *pc_ * ba[bdiag[row]];
+          *pc_ = multiplier;
+          const PetscInt *pj = bj + bdiag[row + 1] + 1;
+          const PetscScalar *pv = ba + bdiag[row + 1] + 1;
+          const PetscInt nz = bdiag[row] - bdiag[row + 1] - 1;
+          for (PetscInt j = 0; j < nz; j++) rtmp[pj[j]] -= multiplier * pv[j];
+        }
       }
+      for (PetscInt j = 0; j < nzl; j++) { ba[bi[i] + j] = rtmp[bj[bi[i] + j]]; rs += PetscAbsScalar(ba[bi[i] + j]); }
+      for (PetscInt j = 0; j < nzu - 1; j++) { ba[bdiag[i + 1] + 1 + j] = rtmp[bj[bdiag[i + 1] + 1 + j]]; rs += PetscAbsScalar(ba[bdiag[i + 1] + 1 + j]); }
+      if (PetscAbsScalar(rtmp[i]) <= zeropivot * rs) {
+        shift_amount = f->nshift ? shift_amount * 2.0 : shiftamount;
+        f->nshift++;
+        if (f->nshift > 80) { HipFree(rtmp); HipFree(adiag); SETERRQ(HipObjComm(pc), 71 /* PETSC_ERR_MAT_LU_ZRPVT */, "Zero pivot row %d value %g: still there after %d diagonal shifts", i, PetscAbsScalar(rtmp[i]), f->nshift); }
+        again = PETSC_TRUE;
+        break;
+      }
+      ba[bdiag[i]] = 1.0 / rtmp[i];
     }
-    for (PetscInt j = 0; j < nzl; j++) { ba[bi[i] + j] = rtmp[bj[bi[i] + j]]; rs += PetscAbsScalar(ba[bi[i] + j]); }
-    for (PetscInt j = 0; j < nzu - 1; j++) { ba[bdiag[i + 1] + 1 + j] = rtmp[bj[bdiag[i + 1] + 1 + j]]; rs += PetscAbsScalar(ba[bdiag[i + 1] + 1 + j]); }
-    /* MatPivotCheck: the reference would shift (MAT_SHIFT_NONZERO); a shift-free factorisation is what is ported */
-    if (PetscAbsScalar(rtmp[i]) <= zeropivot * rs) { HipFree(rtmp); HipFree(adiag); SETERRQ(HipObjComm(pc), 71 /* PETSC_ERR_MAT_LU_ZRPVT */, "Zero pivot row %d value %g tolerance %g * rs %g (pivot shifting is outside the ported path)", i, PetscAbsScalar(rtmp[i]), zeropivot, rs); }
-    ba[bdiag[i]] = 1.0 / rtmp[i];
-  }
+  } while (again);
   HipFree(rtmp); HipFree(adiag);
   /* dependency levels: a row may start once the rows it references are done */
   PetscInt *lev, *levU, *rowsL, *rowsU;
@@ -281,6 +295,13 @@ PetscErrorCode PCILUGetSolver_HIPMI355X(PC pc, PetscInt *syncfree, PetscInt *abo
     mi355x_trisolve_aborted(f->tri_lo, &a); mi355x_trisolve_aborted(f->tri_up, &b);
   }
   if (aborted) *aborted = a || b;
+  return 0;
+}
+
+/* restarts of the factorisation with a larger diagonal shift (MAT_SHIFT_NONZERO); 0 for every matrix whose pivots pass */
+PetscErrorCode PCILUGetShiftCount_HIPMI355X(PC pc, PetscInt *nshift) {
+  if (strcmp(HipObjTypeName(pc), "ilu") && strcmp(HipObjTypeName(pc), "iluhipmi355x")) SETERRQ(HipObjComm(pc), PETSC_ERR_ARG_WRONG, "not a PCILU");
+  *nshift = ((PC_ILU *)pc->data)->nshift;
   return 0;
 }
 

@@ -259,6 +259,18 @@ def ilu0_factor(ai, aj, aa):
     return bi, bj, bd, ba
 
 
+def ilu0_factor_shift(ai, aj, aa):
+    """(factor, restarts of the factorisation MatPivotCheck_nz asked for)"""
+    n = ai.size - 1
+    nz = int(ai[-1])
+    bi = np.zeros(n + 1, dtype=np.int32); bj = np.zeros(nz + 1, dtype=np.int32)
+    bd = np.zeros(n + 1, dtype=np.int32); ba = np.zeros(nz + 1)
+    ns = C.c_int()
+    rc = lib().orc_ilu0_factor_shift(C.c_int(n), I(ai), I(aj), D(aa), I(bi), I(bj), I(bd), D(ba), C.byref(ns))
+    assert rc == 0
+    return (bi, bj, bd, ba), ns.value
+
+
 def ilu0_solve(f, b):
     bi, bj, bd, ba = f
     x = np.zeros(b.size)

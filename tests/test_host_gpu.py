@@ -1025,6 +1025,20 @@ def test_ilu0_apply_bitexact_and_golden(P):
             L.PCILUGetSolver_HIPMI355X(pc, C.byref(sf), C.byref(ab))
             assert ab.value == 0
             assert sf.value == (1 if (mode.endswith("syncfree") or (mode == "" and nl.value + nu.value > 16)) else 0)
+    # a zero pivot: PCILU's default MAT_SHIFT_NONZERO restarts the factorisation with a shifted diagonal, as many times as the oracle's
+    import scipy.sparse as sp
+    T = sp.diags([np.ones(39), np.ones(40), np.ones(39)], [-1, 0, 1]).tocsr(); T.sort_indices()
+    ai, aj, aa = T.indptr.astype(np.int32), T.indices.astype(np.int32), T.data.copy()
+    A = P.Mat.from_csr(ai, aj, aa)
+    pc = C.c_void_p()
+    k = P.KSP(comm=L.COMM_SELF); k.set_operators(A); L.KSPGetPC(k.h, C.byref(pc)); L.PCSetType(pc, b"ilu")
+    L.raw("PCSetUp")(pc)
+    f, ns_o = orc.ilu0_factor_shift(ai, aj, aa)
+    ns = C.c_int(); L.PCILUGetShiftCount_HIPMI355X(pc, C.byref(ns))
+    assert ns.value == ns_o and ns_o >= 1
+    bvec = rnd(40, 81); vb, vx = V(P, bvec), V(P, np.zeros(40))
+    L.raw("PCApply")(pc, vb.h, vx.h)
+    assert np.array_equal(bits(vx.array()), bits(orc.ilu0_solve(f, bvec)))
     ai, aj, aa = pb.lap2d(5, 5)
     u = np.ones(25)
     b = orc.spmv(ai, aj, aa, u)

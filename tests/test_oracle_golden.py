@@ -339,3 +339,41 @@ def test_ex32_cg_icc0_golden_and_factor_properties():
     aa = aa.copy(); aa[aj == np.repeat(np.arange(ai.size - 1), np.diff(ai))] = 1.5
     (ui, uj, ua), ns = orc.icc0_factor(ai, aj, aa)
     assert 1 <= ns <= 6 and np.all(ua[ui[1:] - 1] > 0)
+
+
+def test_ilu0_nonzero_shift_restarts_like_the_reference():
+    """PCILU's default MAT_SHIFT_NONZERO (ilu.c:387-389, MatPivotCheck_nz): tridiag(1, 1, 1) has a zero second pivot; the
+    factorisation restarts with the diagonal shifted by 100 eps, 200 eps, ... until every pivot passes |pivot| > 100 eps * (row sum of the
+    factor's off-diagonal entries); a matrix whose pivots pass is factored exactly as before (no shift, same bits)"""
+    import scipy.sparse as sp
+    n = 12
+    A = sp.diags([np.ones(n - 1), np.ones(n), np.ones(n - 1)], [-1, 0, 1]).tocsr(); A.sort_indices()
+    ai, aj, aa = A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.copy()
+    f, ns = orc.ilu0_factor_shift(ai, aj, aa)
+    assert ns >= 1
+    # ILU(0) of a tridiagonal matrix is its LU without pivoting: an independent dense restatement of the rule gives the same number
+    # of restarts and the same pivots
+    zp = 100.0 * 2.220446049250313e-16
+    shift, tries = 0.0, 0
+    while True:
+        M = A.toarray() + shift * np.eye(n)
+        ok = True
+        for i in range(n):
+            for kk in range(i):
+                if M[i, kk] != 0.0:
+                    m = M[i, kk] / M[kk, kk]
+                    M[i, kk] = m
+                    M[i, kk + 1:] -= m * M[kk, kk + 1:]
+            rs = np.abs(M[i, :i]).sum() + np.abs(M[i, i + 1:]).sum()
+            if abs(M[i, i]) <= zp * rs:
+                shift = zp if tries == 0 else 2.0 * shift
+                tries += 1
+                ok = False
+                break
+        if ok:
+            break
+    bi, bj, bd, ba = f
+    assert tries == ns and np.allclose(1.0 / ba[bd[:n]], np.diag(M), rtol=1e-12, atol=0)
+    ai, aj, aa = pb.lap2d(6, 5)
+    f0, ns0 = orc.ilu0_factor_shift(ai, aj, aa)
+    assert ns0 == 0 and all(np.array_equal(u, v) for u, v in zip(f0, orc.ilu0_factor(ai, aj, aa)))
