@@ -288,8 +288,10 @@ static PetscErrorCode PCSetUp_BJacobi(PC pc) {
     }
     ierr = KSPSetOperators(bj->ksp[i], bj->block[i], bj->block[i], SAME_NONZERO_PATTERN);CHKERRQ(ierr);
     ierr = KSPSetFromOptions(bj->ksp[i]);CHKERRQ(ierr);
-    if (bj->merged) {   /* a factorisation with a shift strategy (ICC) must treat the blocks as the separate matrices they stand for */
+    if (bj->merged) {   /* a factorisation with a shift strategy must treat the blocks as the separate matrices they stand for */
       PetscVoidFunction fb = NULL;
+      PC sub = bj->ksp[i]->pc;
+      if (!sub->type_name[0] && pc_type_registered(PCILU) && !strncmp(bj->block[i]->type_name, MATSEQAIJ, 6)) { ierr = PCSetType(sub, PCILU);CHKERRQ(ierr); }   /* the default PCSetUp would pick (precon.c:14-53), now, so that it can be asked */
       ierr = PetscObjectQueryFunction((PetscObject)bj->ksp[i]->pc, "PCFactorSetIndependentBlocks_C", &fb);CHKERRQ(ierr);
       if (fb) { ierr = ((PetscErrorCode (*)(PC, PetscInt, const PetscInt *))fb)(bj->ksp[i]->pc, nloc, bj->starts);CHKERRQ(ierr); }
       else if (!strcmp(bj->ksp[i]->pc->type_name, PCICC)) SETERRQ(pc->comm, PETSC_ERR_SUP, "this PCICC cannot factor independent blocks: use -pc_bjacobi_merge_blocks 0");

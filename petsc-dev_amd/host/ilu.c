@@ -22,8 +22,9 @@ typedef struct {
   int graph_tried;
   mi355x_trisolve_plan_t tri_lo, tri_up;                 /* sync-free solves (NULL: level launches) */
   int by_level;                                          /* rows summed in dependency-level order (inode matrices) instead of column order */
-  PetscInt nshift;                                       /* restarts of the factorisation MatPivotCheck_nz asked for */
+  PetscInt nshift;                                       /* restarts of the factorisation MatPivotCheck_nz asked for (largest count over the blocks) */
   int factored_state;
+  PetscInt nblk, *blk;                                   /* "PCFactorSetIndependentBlocks_C": the matrix stands for that many separate matrices (row ranges), each with its own shift loop */
 } PC_ILU;
 
 static PetscErrorCode ilu_free(PC_ILU *f) {
@@ -38,7 +39,24 @@ static PetscErrorCode ilu_free(PC_ILU *f) {
   if (f->graph) mi355x_graph_destroy(f->graph);
   if (f->tri_lo) mi355x_trisolve_plan_destroy(f->tri_lo);
   if (f->tri_up) mi355x_trisolve_plan_destroy(f->tri_up);
-  memset(f, 0, sizeof(*f));
+  { PetscInt nblk = f->nblk, *blk = f->blk;
+    memset(f, 0, sizeof(*f));
+    f->nblk = nblk; f->blk = blk; }
+  f->factored_state = -1;
+  return 0;
+}
+
+/* block Jacobi solving all its ILU(0) blocks as one block-diagonal system: every block is factored as the reference factors a
+ * matrix of its own (its own restarts), so the result is the blocks' factors side by side also when one block needs a shift */
+static PetscErrorCode PCFactorSetIndependentBlocks_ILU(PC pc, PetscInt nblk, const PetscInt *starts) {
+  PC_ILU *f = (PC_ILU *)pc->data;
+  PetscErrorCode ierr;
+  HipFree(f->blk); f->blk = NULL; f->nblk = 0;
+  if (nblk > 0) {
+    ierr = PetscMalloc(sizeof(PetscInt) * (size_t)(nblk + 1), &f->blk);CHKERRQ(ierr);
+    memcpy(f->blk, starts, sizeof(PetscInt) * (size_t)(nblk + 1));
+    f->nblk = nblk;
+  }
   f->factored_state = -1;
   return 0;
 }
@@ -103,43 +121,53 @@ static PetscErrorCode PCSetUp_ILU(PC pc) {
   PetscScalar *rtmp;
   ierr = PetscMalloc(sizeof(PetscScalar) * (size_t)(n + 1), &rtmp);CHKERRQ(ierr);
   const PetscReal zeropivot = 100.0 * 2.220446049250313e-16, shiftamount = 100.0 * 2.220446049250313e-16;   /* ilu.c:388-389 */
-  PetscReal shift_amount = 0.0;
-  PetscBool again;
   f->nshift = 0;
-  do {   /* MAT_SHIFT_NONZERO, PCILU's default on a SeqAIJ matrix (ilu.c:387): a pivot that fails MatPivotCheck_nz (matimpl.h:512-528)
-          * restarts the factorisation with the diagonal shifted by shiftamount, then by twice that, ... (aijfact.c:507-592) */
-    again = PETSC_FALSE;
-    for (PetscInt i = 0; i < n; i++) {
-      PetscInt nzl = bi[i + 1] - bi[i], nzu = bdiag[i] - bdiag[i + 1];
-      PetscReal rs = 0.0;
-      for (PetscInt j = 0; j < nzl; j++) rtmp[bj[bi[i] + j]] = 0.0;
-      for (PetscInt j = 0; j < nzu; j++) rtmp[bj[bdiag[i + 1] + 1 + j]] = 0.0;
-      for (PetscInt q = ai[i]; q < ai[i + 1]; q++) rtmp[aj[q]] = aa[q];
-      rtmp[i] += shift_amount;
-      for (PetscInt kk = 0; kk < nzl; kk++) {
-        const PetscInt row = bj[bi[i] + kk];
-        PetscScalar *pc_ = rtmp + row;
-        if (*pc_ != 0.0) {
-          const PetscScalar multiplier = *pc_ * ba[bdiag[row]];
-          *pc_ = multiplier;
-          const PetscInt *pj = bj + bdiag[row + 1] + 1;
-          const PetscScalar *pv = ba + bdiag[row + 1] + 1;
-          const PetscInt nz = bdiag[row] - bdiag[row + 1] - 1;
-          for (PetscInt j = 0; j < nz; j++) rtmp[pj[j]] -= multiplier * pv[j];
-        }
-      }
-      for (PetscInt j = 0; j < nzl; j++) { ba[bi[i] + j] = rtmp[bj[bi[i] + j]]; rs += PetscAbsScalar(ba[bi[i] + j]); }
-      for (PetscInt j = 0; j < nzu - 1; j++) { ba[bdiag[i + 1] + 1 + j] = rtmp[bj[bdiag[i + 1] + 1 + j]]; rs += PetscAbsScalar(ba[bdiag[i + 1] + 1 + j]); }
-      if (PetscAbsScalar(rtmp[i]) <= zeropivot * rs) {
-        shift_amount = f->nshift ? shift_amount * 2.0 : shiftamount;
-        f->nshift++;
-        if (f->nshift > 80) { HipFree(rtmp); HipFree(adiag); SETERRQ(HipObjComm(pc), 71 /* PETSC_ERR_MAT_LU_ZRPVT */, "Zero pivot row %d value %g: still there after %d diagonal shifts", i, PetscAbsScalar(rtmp[i]), f->nshift); }
-        again = PETSC_TRUE;
-        break;
-      }
-      ba[bdiag[i]] = 1.0 / rtmp[i];
+  const PetscInt whole[2] = {0, n};
+  const PetscInt nblk = (f->nblk > 0 && f->blk[f->nblk] == n) ? f->nblk : 1, *blk = (f->nblk > 0 && f->blk[f->nblk] == n) ? f->blk : whole;
+  for (PetscInt bb = 0; bb < nblk; bb++) {
+    const PetscInt r0 = blk[bb], r1 = blk[bb + 1];
+    for (PetscInt i = r0; i < r1; i++) {
+      if (ai[i] < ai[i + 1] && (aj[ai[i]] < r0 || aj[ai[i + 1] - 1] >= r1)) { HipFree(rtmp); HipFree(adiag); SETERRQ(HipObjComm(pc), PETSC_ERR_ARG_WRONG, "row %d couples to a column outside its independent block", i); }
     }
-  } while (again);
+    PetscReal shift_amount = 0.0;
+    PetscInt nshift = 0;
+    PetscBool again;
+    do {   /* MAT_SHIFT_NONZERO, PCILU's default on a SeqAIJ matrix (ilu.c:387): a pivot that fails MatPivotCheck_nz (matimpl.h:512-528)
+            * restarts the factorisation with the diagonal shifted by shiftamount, then by twice that, ... (aijfact.c:507-592) */
+      again = PETSC_FALSE;
+      for (PetscInt i = r0; i < r1; i++) {
+        PetscInt nzl = bi[i + 1] - bi[i], nzu = bdiag[i] - bdiag[i + 1];
+        PetscReal rs = 0.0;
+        for (PetscInt j = 0; j < nzl; j++) rtmp[bj[bi[i] + j]] = 0.0;
+        for (PetscInt j = 0; j < nzu; j++) rtmp[bj[bdiag[i + 1] + 1 + j]] = 0.0;
+        for (PetscInt q = ai[i]; q < ai[i + 1]; q++) rtmp[aj[q]] = aa[q];
+        rtmp[i] += shift_amount;
+        for (PetscInt kk = 0; kk < nzl; kk++) {
+          const PetscInt row = bj[bi[i] + kk];
+          PetscScalar *pc_ = rtmp + row;
+          if (*pc_ != 0.0) {
+            const PetscScalar multiplier = *pc_ * ba[bdiag[row]];
+            *pc_ = multiplier;
+            const PetscInt *pj = bj + bdiag[row + 1] + 1;
+            const PetscScalar *pv = ba + bdiag[row + 1] + 1;
+            const PetscInt nz = bdiag[row] - bdiag[row + 1] - 1;
+            for (PetscInt j = 0; j < nz; j++) rtmp[pj[j]] -= multiplier * pv[j];
+          }
+        }
+        for (PetscInt j = 0; j < nzl; j++) { ba[bi[i] + j] = rtmp[bj[bi[i] + j]]; rs += PetscAbsScalar(ba[bi[i] + j]); }
+        for (PetscInt j = 0; j < nzu - 1; j++) { ba[bdiag[i + 1] + 1 + j] = rtmp[bj[bdiag[i + 1] + 1 + j]]; rs += PetscAbsScalar(ba[bdiag[i + 1] + 1 + j]); }
+        if (PetscAbsScalar(rtmp[i]) <= zeropivot * rs) {
+          shift_amount = nshift ? shift_amount * 2.0 : shiftamount;
+          nshift++;
+          if (nshift > 80) { HipFree(rtmp); HipFree(adiag); SETERRQ(HipObjComm(pc), 71 /* PETSC_ERR_MAT_LU_ZRPVT */, "Zero pivot row %d value %g: still there after %d diagonal shifts", i, PetscAbsScalar(rtmp[i]), nshift); }
+          again = PETSC_TRUE;
+          break;
+        }
+        ba[bdiag[i]] = 1.0 / rtmp[i];
+      }
+    } while (again);
+    f->nshift = PetscMax(f->nshift, nshift);
+  }
   HipFree(rtmp); HipFree(adiag);
   /* dependency levels: a row may start once the rows it references are done */
   PetscInt *lev, *levU, *rowsL, *rowsU;
@@ -268,7 +296,8 @@ static PetscErrorCode PCApply_ILU(PC pc, Vec x, Vec y) {   /* PCApply_ILU -> Mat
 
 static PetscErrorCode PCDestroy_ILU(PC pc) {
   PC_ILU *f = (PC_ILU *)pc->data;
-  if (f) { ilu_free(f); HipFree(f); pc->data = NULL; }
+  if (f) { ilu_free(f); HipFree(f->blk); HipFree(f); pc->data = NULL; }
+  (void)PetscObjectComposeFunction((PetscObject)pc, "PCFactorSetIndependentBlocks_C", "", (PetscVoidFunction)NULL);
   return 0;
 }
 
@@ -279,6 +308,7 @@ PetscErrorCode PCCreate_ILU_HIPMI355X(PC pc) {
   f->factored_state = -1;
   pc->data = f;
   pc->ops->setup = PCSetUp_ILU; pc->ops->apply = PCApply_ILU; pc->ops->destroy = PCDestroy_ILU;
+  ierr = PetscObjectComposeFunction((PetscObject)pc, "PCFactorSetIndependentBlocks_C", "PCFactorSetIndependentBlocks_ILU", (PetscVoidFunction)PCFactorSetIndependentBlocks_ILU);CHKERRQ(ierr);
   return 0;
 }
 

@@ -990,6 +990,17 @@ def test_icc0_apply_bitexact_and_golden(P):
     blocks = [0, n // 4, n // 2, 3 * n // 4, n]
     xo, ho, itso, ro = orc.ksp_solve(ai, aj, aa, b, ksp="gmres", pc="bjacobi", blocks=blocks, sub_pc="icc", rtol=1e-9)
     assert itso == runs[0][2] and np.allclose(runs[0][1], ho, rtol=1e-7) and np.allclose(runs[0][0], xo, rtol=1e-9, atol=1e-12)
+    # the same for ILU(0) blocks with the nonzero shift: one block has a zero pivot (tridiag(1,1,1) rows), the others do not
+    import scipy.sparse as sp
+    T = sp.block_diag([sp.diags([-np.ones(19), 4.0 * np.ones(20), -np.ones(19)], [-1, 0, 1]), sp.diags([np.ones(19), np.ones(20), np.ones(19)], [-1, 0, 1]),
+                       sp.diags([-np.ones(19), 3.0 * np.ones(20), -np.ones(19)], [-1, 0, 1])]).tolil()
+    T[19, 20] = T[20, 19] = 0.25; T[39, 40] = T[40, 39] = 0.25      # couplings between the blocks (dropped by block Jacobi)
+    T = T.tocsr(); T.sort_indices()
+    ai, aj, aa = T.indptr.astype(np.int32), T.indices.astype(np.int32), T.data.copy()
+    b = np.cos(0.3 * np.arange(60)) + 0.2
+    runs = [solve(P, ai, aj, aa, b, "gmres", "bjacobi", opts="-pc_bjacobi_blocks 3 " + o, rtol=1e-9, max_it=40) for o in ("", "-pc_bjacobi_merge_blocks 0", "-sub_pc_type ilu")]
+    for r in runs[1:]:
+        assert r[2] == runs[0][2] and np.array_equal(bits(r[1]), bits(runs[0][1])) and np.array_equal(bits(r[0]), bits(runs[0][0]))
 
 
 def test_ilu0_apply_bitexact_and_golden(P):
