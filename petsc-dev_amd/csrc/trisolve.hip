@@ -6,6 +6,8 @@
 #include "common.hpp"
 #include <vector>
 #include <algorithm>
+#include <thread>
+#include <atomic>
 #include <string.h>
 #include <stdlib.h>
 
@@ -239,8 +241,26 @@ static int trisolve_plan_create_impl(mi355x_handle_t h, int n, int nlev, const i
   for (int l = 0; l < nlev; ++l) levptr[(size_t)l + 1] += levptr[(size_t)l];
   { std::vector<int> next(levptr.begin(), levptr.end() - 1);
     for (int i = 0; i < n; ++i) order[(size_t)next[(size_t)lev[i]]++] = i; }
-  for (int l = 0; l < nlev; ++l)
-    std::stable_sort(order.begin() + levptr[(size_t)l], order.begin() + levptr[(size_t)l + 1], [&](int a, int b) { return rl[a] > rl[b]; });
+  // (longer rows first inside a level, stable in the row number: a counting sort over the row lengths when they are few -- the
+  // factors of a stencil operator have 0..3 entries per row -- instead of a comparison sort of 16.7 M rows)
+  { int maxlen = 0;
+    for (int i = 0; i < n; ++i) if (rl[i] > maxlen) maxlen = rl[i];
+    if (maxlen <= 4096) {
+      std::vector<int> cnt((size_t)maxlen + 2), tmp;
+      for (int l = 0; l < nlev; ++l) {
+        const int a = levptr[(size_t)l], b = levptr[(size_t)l + 1];
+        if (b - a < 2) continue;
+        std::fill(cnt.begin(), cnt.end(), 0);
+        for (int t = a; t < b; ++t) cnt[(size_t)(maxlen - rl[order[(size_t)t]]) + 1]++;      // bucket 0 = the longest rows
+        for (int q = 0; q <= maxlen; ++q) cnt[(size_t)q + 1] += cnt[(size_t)q];
+        tmp.assign(order.begin() + a, order.begin() + b);
+        for (int t = 0; t < b - a; ++t) order[(size_t)a + (size_t)cnt[(size_t)(maxlen - rl[tmp[(size_t)t]])]++] = tmp[(size_t)t];
+      }
+    } else {
+      for (int l = 0; l < nlev; ++l)
+        std::stable_sort(order.begin() + levptr[(size_t)l], order.begin() + levptr[(size_t)l + 1], [&](int a, int b) { return rl[a] > rl[b]; });
+    }
+  }
   std::vector<long> tpos((size_t)(n > 0 ? n : 1));
   long cur = 0;
   for (int l = 0; l < nlev; ++l) {
@@ -279,20 +299,34 @@ static int trisolve_plan_create_impl(mi355x_handle_t h, int n, int nlev, const i
   ptr[(size_t)p->nslices] = (int)total;
   std::vector<int> col((size_t)(total > 0 ? total : 1), 0);
   std::vector<double> val((size_t)(total > 0 ? total : 1), 0.0);
-  std::vector<int> perm;
-  for (int t = 0; t < n; ++t) {
-    const int i = order[(size_t)t], P = (int)tpos[(size_t)t], s = P / W, lane = P % W;
-    perm.resize((size_t)rl[i]);
-    for (int q = 0; q < rl[i]; ++q) perm[(size_t)q] = q;
-    if (by_level) std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return lev[cj[rp[i] + a]] < lev[cj[rp[i] + b]]; });
-    for (int q = 0; q < rl[i]; ++q) {
-      const int src_q = perm[(size_t)q];
-      const int dep = cj[rp[i] + src_q];
-      if (pos[(size_t)dep] >= P) { delete p; return (int)hipErrorInvalidValue; }   // a dependency must come earlier
-      col[(size_t)ptr[(size_t)s] + (size_t)q * W + lane] = pos[(size_t)dep];
-      val[(size_t)ptr[(size_t)s] + (size_t)q * W + lane] = cv[rp[i] + src_q];
+  // every row writes its own slots of the sliced ELL arrays: host threads take contiguous ranges of positions
+  { std::atomic<int> bad(0);
+    auto fill = [&](int t0, int t1) {
+      std::vector<int> perm;
+      for (int t = t0; t < t1 && !bad.load(std::memory_order_relaxed); ++t) {
+        const int i = order[(size_t)t], P = (int)tpos[(size_t)t], s = P / W, lane = P % W;
+        perm.resize((size_t)rl[i]);
+        for (int q = 0; q < rl[i]; ++q) perm[(size_t)q] = q;
+        if (by_level) std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return lev[cj[rp[i] + a]] < lev[cj[rp[i] + b]]; });
+        for (int q = 0; q < rl[i]; ++q) {
+          const int src_q = perm[(size_t)q];
+          const int dep = cj[rp[i] + src_q];
+          if (pos[(size_t)dep] >= P) { bad.store(1); break; }   // a dependency must come earlier
+          col[(size_t)ptr[(size_t)s] + (size_t)q * W + lane] = pos[(size_t)dep];
+          val[(size_t)ptr[(size_t)s] + (size_t)q * W + lane] = cv[rp[i] + src_q];
+        }
+      }
+    };
+    unsigned hc = std::thread::hardware_concurrency();
+    int nth = (int)(hc > 8 ? 8 : (hc < 1 ? 1 : hc));
+    if (n < 200000) nth = 1;
+    if (nth == 1) fill(0, n);
+    else {
+      std::vector<std::thread> th;
+      for (int k = 0; k < nth; ++k) th.emplace_back(fill, (int)((long)n * k / nth), (int)((long)n * (k + 1) / nth));
+      for (auto &t : th) t.join();
     }
-  }
+    if (bad.load()) { delete p; return (int)hipErrorInvalidValue; } }
 #define TRI_UP(dst, vec, T) do { MI355X_TRY(hipMalloc((void **)&(dst), sizeof(T) * (vec).size())); \
     MI355X_TRY(hipMemcpyAsync((dst), (vec).data(), sizeof(T) * (vec).size(), hipMemcpyHostToDevice, h->stream)); } while (0)
   TRI_UP(p->d_ptr, ptr, int); TRI_UP(p->d_info, info, int); TRI_UP(p->d_row, rowof, int); TRI_UP(p->d_col, col, int);
