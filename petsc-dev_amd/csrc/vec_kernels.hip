@@ -201,6 +201,20 @@ __device__ __forceinline__ void publish_to_host(unsigned long long *host_seq, un
   }
 }
 
+// Streaming accesses for operands nobody reads again soon.  In a CG iteration x and r are touched by the update sweep only and z
+// by the AYPX that follows it only; loaded / stored non-temporally they stop evicting p, w and z from the L2 / Infinity Cache,
+// which the neighbouring kernels re-read (measured on P7(256): fused update 0.183 -> 0.166 ms, whole iteration 0.414 -> 0.374 ms;
+// the same treatment of w and the Jacobi diagonal gained nothing).  Same values, same bits.
+typedef double vk_v2d __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double2 nt_load2(const double2 *p) {
+  const vk_v2d t = __builtin_nontemporal_load(reinterpret_cast<const vk_v2d *>(p));
+  double2 r; r.x = t.x; r.y = t.y; return r;
+}
+__device__ __forceinline__ void nt_store2(double2 *p, double2 v) {
+  vk_v2d t; t.x = v.x; t.y = v.y;
+  __builtin_nontemporal_store(t, reinterpret_cast<vk_v2d *>(p));
+}
+
 // y = x + (num/den) y with the scalar's numerator still in device memory (KSPSolve_CG: b = beta_new/beta_old, beta_new
 // being the z'r the previous kernel on the stream has just reduced).  VecAYPX_Seq's special case alpha == 0 -> copy
 // (dvec2.c:980) is kept; alpha == +-1 need no special form (x + 1*y and x + (-1)*y are the bits of x + y and x - y).
@@ -215,14 +229,14 @@ __global__ __launch_bounds__(MI355X_BLOCK) void aypx_dev_kernel(const double *nu
     double2 *y2 = reinterpret_cast<double2 *>(y);
     size_t i = tid;
     for (; i + stride < n2; i += 2 * stride) {
-      double2 xv0 = x2[i], xv1 = x2[i + stride], yv0 = y2[i], yv1 = y2[i + stride], r0, r1;
+      double2 xv0 = nt_load2(x2 + i), xv1 = nt_load2(x2 + i + stride), yv0 = y2[i], yv1 = y2[i + stride], r0, r1;   // x = z: its last reader (see nt_load2)
       r0.x = copy ? xv0.x : xv0.x + alpha * yv0.x; r0.y = copy ? xv0.y : xv0.y + alpha * yv0.y;
       r1.x = copy ? xv1.x : xv1.x + alpha * yv1.x; r1.y = copy ? xv1.y : xv1.y + alpha * yv1.y;
       y2[i] = r0;
       y2[i + stride] = r1;
     }
     if (i < n2) {
-      double2 xv = x2[i], yv = y2[i], r;
+      double2 xv = nt_load2(x2 + i), yv = y2[i], r;
       r.x = copy ? xv.x : xv.x + alpha * yv.x; r.y = copy ? xv.y : xv.y + alpha * yv.y;
       y2[i] = r;
     }
@@ -441,19 +455,19 @@ struct CGUpdateF {
       double2 *x2 = reinterpret_cast<double2 *>(x), *r2 = reinterpret_cast<double2 *>(r), *z2 = reinterpret_cast<double2 *>(z);
       const double2 one2 = {1.0, 1.0};
       double2 pv0 = p2[i], pv1 = p2[i + stride], wv0 = w2[i], wv1 = w2[i + stride], dv0 = d ? d2[i] : one2, dv1 = d ? d2[i + stride] : one2;
-      double2 xv0 = x2[i], xv1 = x2[i + stride], rv0 = r2[i], rv1 = r2[i + stride], zv0, zv1;
+      double2 xv0 = nt_load2(x2 + i), xv1 = nt_load2(x2 + i + stride), rv0 = nt_load2(r2 + i), rv1 = nt_load2(r2 + i + stride), zv0, zv1;
       step(pv0.x, wv0.x, dv0.x, xv0.x, rv0.x, zv0.x, acc); step(pv0.y, wv0.y, dv0.y, xv0.y, rv0.y, zv0.y, acc);
       step(pv1.x, wv1.x, dv1.x, xv1.x, rv1.x, zv1.x, acc); step(pv1.y, wv1.y, dv1.y, xv1.y, rv1.y, zv1.y, acc);
-      x2[i] = xv0; r2[i] = rv0; z2[i] = zv0;
-      x2[i + stride] = xv1; r2[i + stride] = rv1; z2[i + stride] = zv1;
+      nt_store2(x2 + i, xv0); nt_store2(r2 + i, rv0); z2[i] = zv0;
+      nt_store2(x2 + i + stride, xv1); nt_store2(r2 + i + stride, rv1); z2[i + stride] = zv1;
     }
     for (; i < n2; i += stride) {
       const double2 one2 = {1.0, 1.0};
       double2 pv = reinterpret_cast<const double2 *>(p)[i], wv = reinterpret_cast<const double2 *>(w)[i];
       double2 dv = d ? reinterpret_cast<const double2 *>(d)[i] : one2;
-      double2 xv = reinterpret_cast<double2 *>(x)[i], rv = reinterpret_cast<double2 *>(r)[i], zv;
+      double2 xv = nt_load2(reinterpret_cast<double2 *>(x) + i), rv = nt_load2(reinterpret_cast<double2 *>(r) + i), zv;
       step(pv.x, wv.x, dv.x, xv.x, rv.x, zv.x, acc); step(pv.y, wv.y, dv.y, xv.y, rv.y, zv.y, acc);
-      reinterpret_cast<double2 *>(x)[i] = xv; reinterpret_cast<double2 *>(r)[i] = rv; reinterpret_cast<double2 *>(z)[i] = zv;
+      nt_store2(reinterpret_cast<double2 *>(x) + i, xv); nt_store2(reinterpret_cast<double2 *>(r) + i, rv); reinterpret_cast<double2 *>(z)[i] = zv;
     }
   }
   __device__ __forceinline__ void step(double pv, double wv, double dv, double &xv, double &rv, double &zv, double (&acc)[3]) const {
@@ -512,16 +526,16 @@ struct CGUpdateDevF {
     size_t i = tid;
     for (; i + stride < n2; i += 2 * stride) {
       double2 pv0 = p2[i], pv1 = p2[i + stride], wv0 = w2[i], wv1 = w2[i + stride], dv0 = d ? d2[i] : one2, dv1 = d ? d2[i + stride] : one2;
-      double2 xv0 = x2[i], xv1 = x2[i + stride], rv0 = r2[i], rv1 = r2[i + stride], zv0, zv1;
+      double2 xv0 = nt_load2(x2 + i), xv1 = nt_load2(x2 + i + stride), rv0 = nt_load2(r2 + i), rv1 = nt_load2(r2 + i + stride), zv0, zv1;
       step(a, pv0.x, wv0.x, dv0.x, xv0.x, rv0.x, zv0.x, acc); step(a, pv0.y, wv0.y, dv0.y, xv0.y, rv0.y, zv0.y, acc);
       step(a, pv1.x, wv1.x, dv1.x, xv1.x, rv1.x, zv1.x, acc); step(a, pv1.y, wv1.y, dv1.y, xv1.y, rv1.y, zv1.y, acc);
-      x2[i] = xv0; r2[i] = rv0; z2[i] = zv0;
-      x2[i + stride] = xv1; r2[i + stride] = rv1; z2[i + stride] = zv1;
+      nt_store2(x2 + i, xv0); nt_store2(r2 + i, rv0); z2[i] = zv0;
+      nt_store2(x2 + i + stride, xv1); nt_store2(r2 + i + stride, rv1); z2[i + stride] = zv1;
     }
     for (; i < n2; i += stride) {
-      double2 pv = p2[i], wv = w2[i], dv = d ? d2[i] : one2, xv = x2[i], rv = r2[i], zv;
+      double2 pv = p2[i], wv = w2[i], dv = d ? d2[i] : one2, xv = nt_load2(x2 + i), rv = nt_load2(r2 + i), zv;
       step(a, pv.x, wv.x, dv.x, xv.x, rv.x, zv.x, acc); step(a, pv.y, wv.y, dv.y, xv.y, rv.y, zv.y, acc);
-      x2[i] = xv; r2[i] = rv; z2[i] = zv;
+      nt_store2(x2 + i, xv); nt_store2(r2 + i, rv); z2[i] = zv;
     }
   }
   __device__ void accum1(size_t i, double (&acc)[4]) const {
