@@ -612,12 +612,13 @@ struct BcgsUpdateF {
     x[i] = xv; r[i] = rv;
   }
   __device__ void accum2(size_t i, double (&a)[2]) const {
-    double2 pv = reinterpret_cast<const double2 *>(p)[i], sv = reinterpret_cast<const double2 *>(s)[i];
-    double2 tv = reinterpret_cast<const double2 *>(t)[i], qv = reinterpret_cast<const double2 *>(rp)[i];
-    double2 xv = reinterpret_cast<double2 *>(x)[i], rv;
+    // x is touched here only, s and t have their last reader here: streaming accesses (see nt_load2)
+    double2 pv = reinterpret_cast<const double2 *>(p)[i], sv = nt_load2(reinterpret_cast<const double2 *>(s) + i);
+    double2 tv = nt_load2(reinterpret_cast<const double2 *>(t) + i), qv = reinterpret_cast<const double2 *>(rp)[i];
+    double2 xv = nt_load2(reinterpret_cast<double2 *>(x) + i), rv;
     one(pv.x, sv.x, tv.x, qv.x, xv.x, rv.x, a);
     one(pv.y, sv.y, tv.y, qv.y, xv.y, rv.y, a);
-    reinterpret_cast<double2 *>(x)[i] = xv;
+    nt_store2(reinterpret_cast<double2 *>(x) + i, xv);
     reinterpret_cast<double2 *>(r)[i] = rv;
   }
 };
