@@ -6,6 +6,26 @@
 // (src/vec/vec/impls/seq/{bvec1,bvec2,dvec2}.c).
 #include "common.hpp"
 
+// Streaming accesses for operands nobody reads again soon.  In a CG iteration x and r are touched by the update sweep only and z
+// by the AYPX that follows it only; loaded / stored non-temporally they stop evicting p, w and z from the L2 / Infinity Cache,
+// which the neighbouring kernels re-read (measured on P7(256): fused update 0.183 -> 0.166 ms, whole iteration 0.414 -> 0.374 ms;
+// the same treatment of w and the Jacobi diagonal gained nothing).  Same values, same bits.
+typedef double vk_v2d __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double2 nt_load2(const double2 *p) {
+  const vk_v2d t = __builtin_nontemporal_load(reinterpret_cast<const vk_v2d *>(p));
+  double2 r; r.x = t.x; r.y = t.y; return r;
+}
+__device__ __forceinline__ void nt_store2(double2 *p, double2 v) {
+  vk_v2d t; t.x = v.x; t.y = v.y;
+  __builtin_nontemporal_store(t, reinterpret_cast<vk_v2d *>(p));
+}
+// Gram-Schmidt sweeps (VecMDot, VecMAXPY and their fused forms): when the nv basis vectors of a sweep are larger than the caches
+// they are pure streams, and loaded non-temporally they leave the ONE vector the sweep shares with its neighbours (w: written by
+// the product, read by MDot, read and written by MAXPY, scaled, gathered by the next product) in the L2 / Infinity Cache:
+// GMRES(30)+Jacobi on P7(256) 1.045 -> 0.955 ms per iteration.  A basis that fits (P7(64): 16 x 2 MB) must stay cacheable:
+// there the hint costs 20 %.  Threshold: half of the 256 MiB Infinity Cache.
+static inline int gs_streams(size_t n, int nv) { return (size_t)nv * n * sizeof(double) > ((size_t)128 << 20); }
+
 // ------------------------------------------------------------------------
 // element-wise map:  out[i] = op(a[i], b[i], c[i])   (inputs may alias out)
 // ------------------------------------------------------------------------
@@ -99,6 +119,7 @@ __global__ __launch_bounds__(MI355X_BLOCK) void swap_kernel(double *x, double *y
 struct MaxpyArgs {
   const double *y[32];
   double a[32];
+  int nt;
 };
 
 template <int G>
@@ -130,8 +151,13 @@ __global__ __launch_bounds__(MI355X_BLOCK) void maxpy_kernel(MaxpyArgs args, dou
     double2 *x2 = reinterpret_cast<double2 *>(x);
     for (size_t i = tid; i < n2; i += stride) {
       double2 yv[NV];
+      if (args.nt) {                               // see gs_streams()
 #pragma unroll
-      for (int j = 0; j < NV; ++j) yv[j] = reinterpret_cast<const double2 *>(args.y[j])[i];
+        for (int j = 0; j < NV; ++j) yv[j] = nt_load2(reinterpret_cast<const double2 *>(args.y[j]) + i);
+      } else {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) yv[j] = reinterpret_cast<const double2 *>(args.y[j])[i];
+      }
       double2 xv = x2[i];
       double lo[NV], hi[NV];
 #pragma unroll
@@ -199,20 +225,6 @@ __device__ __forceinline__ void publish_to_host(unsigned long long *host_seq, un
     __threadfence_system();
     __hip_atomic_store(host_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
-}
-
-// Streaming accesses for operands nobody reads again soon.  In a CG iteration x and r are touched by the update sweep only and z
-// by the AYPX that follows it only; loaded / stored non-temporally they stop evicting p, w and z from the L2 / Infinity Cache,
-// which the neighbouring kernels re-read (measured on P7(256): fused update 0.183 -> 0.166 ms, whole iteration 0.414 -> 0.374 ms;
-// the same treatment of w and the Jacobi diagonal gained nothing).  Same values, same bits.
-typedef double vk_v2d __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ double2 nt_load2(const double2 *p) {
-  const vk_v2d t = __builtin_nontemporal_load(reinterpret_cast<const vk_v2d *>(p));
-  double2 r; r.x = t.x; r.y = t.y; return r;
-}
-__device__ __forceinline__ void nt_store2(double2 *p, double2 v) {
-  vk_v2d t; t.x = v.x; t.y = v.y;
-  __builtin_nontemporal_store(t, reinterpret_cast<vk_v2d *>(p));
 }
 
 // y = x + (num/den) y with the scalar's numerator still in device memory (KSPSolve_CG: b = beta_new/beta_old, beta_new
@@ -627,6 +639,7 @@ template <int NV>
 struct MDotF {
   const double *x;
   const double *y[NV];
+  int nt;
   template <int NOUT_>
   __device__ __forceinline__ void sweep(size_t tid, size_t stride, size_t n2, double (&a)[NOUT_]) const {
     size_t i = tid;
@@ -641,8 +654,13 @@ struct MDotF {
   __device__ void accum2(size_t i, double (&a)[NV]) const {
     double2 xv = reinterpret_cast<const double2 *>(x)[i];
     double2 yv[NV];
+    if (nt) {                                      // basis larger than the caches: see gs_streams()
 #pragma unroll
-    for (int j = 0; j < NV; ++j) yv[j] = reinterpret_cast<const double2 *>(y[j])[i];
+      for (int j = 0; j < NV; ++j) yv[j] = nt_load2(reinterpret_cast<const double2 *>(y[j]) + i);
+    } else {
+#pragma unroll
+      for (int j = 0; j < NV; ++j) yv[j] = reinterpret_cast<const double2 *>(y[j])[i];
+    }
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
       a[j] += xv.x * yv[j].x;
@@ -661,6 +679,7 @@ template <int G0, int NG4>
 struct MaxpyNormF {
   static constexpr int NV = G0 + 4 * NG4;
   const double *y[NV];
+  int nt;
   const double *adev;   // coefficients in device memory ...
   double sign;          // ... times +-1
   double *x;
@@ -683,8 +702,13 @@ struct MaxpyNormF {
   }
   __device__ __forceinline__ void accum2(size_t i, double (&acc)[1]) const {
     double2 yv[NV];
+    if (nt) {                                      // basis larger than the caches: see gs_streams()
 #pragma unroll
-    for (int j = 0; j < NV; ++j) yv[j] = reinterpret_cast<const double2 *>(y[j])[i];
+      for (int j = 0; j < NV; ++j) yv[j] = nt_load2(reinterpret_cast<const double2 *>(y[j]) + i);
+    } else {
+#pragma unroll
+      for (int j = 0; j < NV; ++j) yv[j] = reinterpret_cast<const double2 *>(y[j])[i];
+    }
     double2 xv = reinterpret_cast<double2 *>(x)[i];
     double lo[NV], hi[NV];
 #pragma unroll
@@ -704,6 +728,7 @@ static int launch_maxpy_norm(mi355x_handle_t h, size_t n, const double *adev, do
   int vec_ok = mi355x_aligned16(x);
   for (int j = 0; j < G0 + 4 * NG4; ++j) { f.y[j] = y[j]; vec_ok = vec_ok && mi355x_aligned16(y[j]); }
   f.adev = adev; f.sign = sign; f.x = x;
+  f.nt = gs_streams(n, G0 + 4 * NG4);
   return launch_reduce<1, RED_SUM>(h, f, n, vec_ok, out);
 }
 
@@ -737,6 +762,7 @@ template <int NV>
 static int launch_mdot(mi355x_handle_t h, size_t n, const double *x, const double *const *y, double *out) {
   MDotF<NV> f;
   f.x = x;
+  f.nt = gs_streams(n, NV);
   int vec_ok = mi355x_aligned16(x);
   for (int j = 0; j < NV; ++j) {
     f.y[j] = y[j];
@@ -850,6 +876,7 @@ int mi355x_vec_maxpy(mi355x_handle_t h, size_t n, int nv, const double *alpha, c
       args.a[j] = (j < cnt) ? alpha[pos + j] : 0.0;
       if (j < cnt) vec_ok = vec_ok && mi355x_aligned16(y[pos + j]);
     }
+    args.nt = gs_streams(n, cnt);
     int rc = 0;
 #define MAXPY_CASE(G, N4) case (G) * 10 + (N4): rc = launch_maxpy<G, N4>(h, args, x, n, vec_ok); break
 #define MAXPY_ROW(G) MAXPY_CASE(G, 0); MAXPY_CASE(G, 1); MAXPY_CASE(G, 2); MAXPY_CASE(G, 3); MAXPY_CASE(G, 4); MAXPY_CASE(G, 5); MAXPY_CASE(G, 6); MAXPY_CASE(G, 7)
