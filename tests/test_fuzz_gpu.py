@@ -249,3 +249,68 @@ def test_repeated_solves_are_bitwise_reproducible(P, ksp, pc):
             ref = got
         else:
             assert got[:2] == ref[:2] and np.array_equal(got[2], ref[2]) and np.array_equal(got[3], ref[3]), "run %d differs" % rep
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_spmv_fuzz_value_patterns(dev, seed):
+    """constant-coefficient operators of random shape: a handful of row kinds {offsets, values} -- some with more than 8 entries,
+    empty ones, stored zeros of either sign, rectangular shapes -- dealt to the rows in runs or at random; the product from the row
+    dictionary (the value array on the device is NaN) carries the oracle's bits for y = Ax, y += Ax, y = d .* Ax and the inode
+    summation order; one more kind than the table holds and the analysis declines"""
+    k = dev.k
+    rng = np.random.default_rng(7000 + seed + FUZZ_OFFSET)
+    m = int(rng.integers(1, 5000))
+    n = m if seed % 3 else int(rng.integers(max(1, m // 2), 2 * m + 2))
+    nk = int(rng.integers(1, 30))
+    kinds = []
+    for _ in range(nk):
+        ln = int(rng.choice([0, 1, 2, 3, 5, 7, 8, 9, 13, 27]))
+        offs = np.unique(rng.integers(-min(n, 300), min(n, 300) + 1, ln))
+        vals = rng.standard_normal(offs.size)
+        if offs.size and rng.random() < 0.3:
+            vals[int(rng.integers(0, offs.size))] = 0.0 if rng.random() < 0.5 else -0.0
+        kinds.append((offs, vals))
+    if seed % 2:
+        which = rng.integers(0, nk, m)
+    else:                                   # runs of one kind, as the planes of a stencil give them
+        which = np.repeat(rng.integers(0, nk, m // 50 + 1), 50)[:m]
+    rows, vals = [], []
+    for r in range(m):
+        offs, v = kinds[int(which[r])]
+        c = r + offs
+        keep = (c >= 0) & (c < n)           # clipping at the boundary makes further kinds: the dictionary holds them too
+        rows.append(c[keep]); vals.append(v[keep])
+    lens = np.array([c.size for c in rows])
+    ai = np.concatenate(([0], np.cumsum(lens))).astype(np.int32)
+    aj = (np.concatenate(rows) if lens.sum() else np.zeros(0)).astype(np.int32)
+    aa = (np.concatenate(vals) if lens.sum() else np.zeros(0)).astype(np.float64)
+    x = rng.standard_normal(n); y0 = rng.standard_normal(m); d = rng.standard_normal(m)
+    distinct = {(tuple((aj[ai[r]:ai[r + 1]] - r).tolist()), aa[ai[r]:ai[r + 1]].tobytes()) for r in range(m)}
+    slots = sum(1 + (len(o) + 7) // 8 * 8 for o, _ in distinct)
+    dai, daj = dev.put(ai), dev.put(aj if aj.size else np.zeros(1, np.int32))
+    daa = dev.put(np.full(max(aa.size, 1) + 2, np.nan))
+    dx, dy = dev.put(x), dev.put(y0)
+    dd = dev.put(d)
+    plan = C.c_void_p()
+    dev.chk(k.mi355x_spmv_plan_create(dev.h, m, ai.ctypes.data, None, C.byref(plan)))
+    nv = C.c_int()
+    aa_h = np.ascontiguousarray(aa if aa.size else np.zeros(1))
+    dev.chk(k.mi355x_spmv_plan_value_patterns(dev.h, plan, ai.ctypes.data, aj.ctypes.data, aa_h.ctypes.data, C.byref(nv)))
+    if slots > 512:
+        assert nv.value == 0                # more table than there is: declined, the value array would be streamed
+    else:
+        assert nv.value == len(distinct)
+        dz = dev.alloc(8 * m)
+        dev.chk(k.mi355x_spmv_csr(dev.h, plan, dai, daj, daa, dx, dz))
+        assert np.array_equal(bits(dev.get(dz, m)), bits(orc.spmv(ai, aj, aa, x)))
+        dev.chk(k.mi355x_spmv_csr_add(dev.h, plan, dai, daj, daa, dx, dy, dz))
+        assert np.array_equal(bits(dev.get(dz, m)), bits(orc.spmv_add(ai, aj, aa, x, y0)))
+        dev.chk(k.mi355x_spmv_csr_scaled(dev.h, plan, dai, daj, daa, dx, dd, dz))
+        assert np.array_equal(bits(dev.get(dz, m)), bits(orc.spmv(ai, aj, aa, x) * d))
+        dev.chk(k.mi355x_spmv_plan_set_pairsum(plan, 1))
+        dev.chk(k.mi355x_spmv_csr(dev.h, plan, dai, daj, daa, dx, dz))
+        assert np.array_equal(bits(dev.get(dz, m)), bits(orc.spmv_inode(ai, aj, aa, x)))
+        dev.free(dz)
+    dev.chk(k.mi355x_spmv_plan_destroy(plan))
+    for p in (dai, daj, daa, dx, dy, dd):
+        dev.free(p)
