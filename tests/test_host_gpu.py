@@ -1003,6 +1003,48 @@ def test_icc0_apply_bitexact_and_golden(P):
         assert r[2] == runs[0][2] and np.array_equal(bits(r[1]), bits(runs[0][1])) and np.array_equal(bits(r[0]), bits(runs[0][0]))
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_factor_fuzz_ilu0_icc0(P, seed):
+    """random symmetric sparsity patterns (random density, a band plus scattered entries, sometimes empty off-diagonal rows) with diagonals
+    from strongly dominant to not dominant at all: ILU(0) and ICC(0) on the device take the oracle's number of shifts and apply
+    with its bits"""
+    import scipy.sparse as sp
+    L = P.lib()
+    rng = np.random.default_rng(9000 + seed)
+    n = int(rng.integers(2, 2500))
+    R = sp.random(n, n, density=min(1.0, float(rng.uniform(1.0, 6.0)) / n), random_state=int(rng.integers(1 << 30)), data_rvs=rng.standard_normal)
+    B = sp.diags([rng.standard_normal(n - 1)], [1]) if seed % 2 else sp.csr_matrix((n, n))
+    S = (R + R.T + B + B.T).tolil()
+    S.setdiag(0.0)
+    S = S.tocsr(); S.eliminate_zeros()
+    rowsum = np.asarray(abs(S).sum(axis=1)).ravel()
+    dom = [2.0, 1.05, 0.7, 0.3][seed % 4]                      # < 1: not diagonally dominant -> pivot shifts
+    A = (S + sp.diags(dom * rowsum + (0.5 if seed % 3 else 0.0) + 1e-3)).tocsr(); A.sort_indices()
+    ai, aj, aa = A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.copy()
+    bvec = rng.standard_normal(n)
+    for pct in ("icc", "ilu"):
+        Am = P.Mat.from_csr(ai, aj, aa)
+        pc = C.c_void_p()
+        k = P.KSP(comm=L.COMM_SELF); k.set_operators(Am); L.KSPGetPC(k.h, C.byref(pc)); L.PCSetType(pc, pct.encode())
+        set_options(L, "-pc_factor_hipmi355x_trisolve syncfree")
+        L.raw("PCSetUp")(pc)
+        set_options(L, "")
+        vb, vx = V(P, bvec), V(P, np.zeros(n))
+        L.raw("PCApply")(pc, vb.h, vx.h)
+        ns = C.c_int()
+        if pct == "icc":
+            f, nso = orc.icc0_factor(ai, aj, aa)
+            ref = orc.icc0_solve(f, bvec)
+            L.PCICCGetInfo_HIPMI355X(pc, None, None, C.byref(ns))
+        else:
+            f, nso = orc.ilu0_factor_shift(ai, aj, aa)
+            ref = orc.ilu0_solve(f, bvec)
+            L.PCILUGetShiftCount_HIPMI355X(pc, C.byref(ns))
+        assert ns.value == nso
+        assert np.array_equal(bits(vx.array()), bits(ref)), (pct, seed, n)
+        Am.destroy()
+
+
 def test_ilu0_apply_bitexact_and_golden(P):
     """PCILU (ILU(0), natural ordering).  The level-scheduled device solve reproduces
     MatSolve_SeqAIJ_NaturalOrdering bit for bit (one lane per row, products subtracted in column order), and with NO
