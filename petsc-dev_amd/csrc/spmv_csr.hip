@@ -558,7 +558,7 @@ __global__ __launch_bounds__(SPMV_THREADS) void spmv_csr_valpat_kernel(
     const long row = rbase + (long)j * SPMV_THREADS;
     const long rc = row < nrows ? row : (long)nrows - 1;
     pst[j] = vrow[rc];
-    yv[j] = ADD ? yin[rc] : 0.0;
+    yv[j] = ADD == 2 ? __builtin_nontemporal_load(yin + rc) : (ADD ? yin[rc] : 0.0);   // ADD == 2: the Jacobi diagonal, a stream read once per product
   }
   __syncthreads();
   const char *xb = reinterpret_cast<const char *>(x);

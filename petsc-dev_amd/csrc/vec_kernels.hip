@@ -8,8 +8,9 @@
 
 // Streaming accesses for operands nobody reads again soon.  In a CG iteration x and r are touched by the update sweep only and z
 // by the AYPX that follows it only; loaded / stored non-temporally they stop evicting p, w and z from the L2 / Infinity Cache,
-// which the neighbouring kernels re-read (measured on P7(256): fused update 0.183 -> 0.166 ms, whole iteration 0.414 -> 0.374 ms;
-// the same treatment of w and the Jacobi diagonal gained nothing).  Same values, same bits.
+// which the neighbouring kernels re-read (measured on P7(256): fused update 0.183 -> 0.166 ms, whole iteration 0.414 -> 0.374 ms).
+// The Jacobi diagonal, read once per iteration by the update alone, is a stream of the same kind (+3 % more); w, read here for the
+// last time but still cached from the dot before, is better left alone.  Same values, same bits.
 typedef double vk_v2d __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ double2 nt_load2(const double2 *p) {
   const vk_v2d t = __builtin_nontemporal_load(reinterpret_cast<const vk_v2d *>(p));
@@ -466,7 +467,7 @@ struct CGUpdateF {
       const double2 *d2 = reinterpret_cast<const double2 *>(d);
       double2 *x2 = reinterpret_cast<double2 *>(x), *r2 = reinterpret_cast<double2 *>(r), *z2 = reinterpret_cast<double2 *>(z);
       const double2 one2 = {1.0, 1.0};
-      double2 pv0 = p2[i], pv1 = p2[i + stride], wv0 = w2[i], wv1 = w2[i + stride], dv0 = d ? d2[i] : one2, dv1 = d ? d2[i + stride] : one2;
+      double2 pv0 = p2[i], pv1 = p2[i + stride], wv0 = w2[i], wv1 = w2[i + stride], dv0 = d ? nt_load2(d2 + i) : one2, dv1 = d ? nt_load2(d2 + i + stride) : one2;
       double2 xv0 = nt_load2(x2 + i), xv1 = nt_load2(x2 + i + stride), rv0 = nt_load2(r2 + i), rv1 = nt_load2(r2 + i + stride), zv0, zv1;
       step(pv0.x, wv0.x, dv0.x, xv0.x, rv0.x, zv0.x, acc); step(pv0.y, wv0.y, dv0.y, xv0.y, rv0.y, zv0.y, acc);
       step(pv1.x, wv1.x, dv1.x, xv1.x, rv1.x, zv1.x, acc); step(pv1.y, wv1.y, dv1.y, xv1.y, rv1.y, zv1.y, acc);
@@ -476,7 +477,7 @@ struct CGUpdateF {
     for (; i < n2; i += stride) {
       const double2 one2 = {1.0, 1.0};
       double2 pv = reinterpret_cast<const double2 *>(p)[i], wv = reinterpret_cast<const double2 *>(w)[i];
-      double2 dv = d ? reinterpret_cast<const double2 *>(d)[i] : one2;
+      double2 dv = d ? nt_load2(reinterpret_cast<const double2 *>(d) + i) : one2;
       double2 xv = nt_load2(reinterpret_cast<double2 *>(x) + i), rv = nt_load2(reinterpret_cast<double2 *>(r) + i), zv;
       step(pv.x, wv.x, dv.x, xv.x, rv.x, zv.x, acc); step(pv.y, wv.y, dv.y, xv.y, rv.y, zv.y, acc);
       nt_store2(reinterpret_cast<double2 *>(x) + i, xv); nt_store2(reinterpret_cast<double2 *>(r) + i, rv); reinterpret_cast<double2 *>(z)[i] = zv;
@@ -537,7 +538,7 @@ struct CGUpdateDevF {
     double2 *x2 = reinterpret_cast<double2 *>(x), *r2 = reinterpret_cast<double2 *>(r), *z2 = reinterpret_cast<double2 *>(z);
     size_t i = tid;
     for (; i + stride < n2; i += 2 * stride) {
-      double2 pv0 = p2[i], pv1 = p2[i + stride], wv0 = w2[i], wv1 = w2[i + stride], dv0 = d ? d2[i] : one2, dv1 = d ? d2[i + stride] : one2;
+      double2 pv0 = p2[i], pv1 = p2[i + stride], wv0 = w2[i], wv1 = w2[i + stride], dv0 = d ? nt_load2(d2 + i) : one2, dv1 = d ? nt_load2(d2 + i + stride) : one2;
       double2 xv0 = nt_load2(x2 + i), xv1 = nt_load2(x2 + i + stride), rv0 = nt_load2(r2 + i), rv1 = nt_load2(r2 + i + stride), zv0, zv1;
       step(a, pv0.x, wv0.x, dv0.x, xv0.x, rv0.x, zv0.x, acc); step(a, pv0.y, wv0.y, dv0.y, xv0.y, rv0.y, zv0.y, acc);
       step(a, pv1.x, wv1.x, dv1.x, xv1.x, rv1.x, zv1.x, acc); step(a, pv1.y, wv1.y, dv1.y, xv1.y, rv1.y, zv1.y, acc);
@@ -545,7 +546,7 @@ struct CGUpdateDevF {
       nt_store2(x2 + i + stride, xv1); nt_store2(r2 + i + stride, rv1); z2[i + stride] = zv1;
     }
     for (; i < n2; i += stride) {
-      double2 pv = p2[i], wv = w2[i], dv = d ? d2[i] : one2, xv = nt_load2(x2 + i), rv = nt_load2(r2 + i), zv;
+      double2 pv = p2[i], wv = w2[i], dv = d ? nt_load2(d2 + i) : one2, xv = nt_load2(x2 + i), rv = nt_load2(r2 + i), zv;
       step(a, pv.x, wv.x, dv.x, xv.x, rv.x, zv.x, acc); step(a, pv.y, wv.y, dv.y, xv.y, rv.y, zv.y, acc);
       nt_store2(x2 + i, xv); nt_store2(r2 + i, rv); z2[i] = zv;
     }
