@@ -22,8 +22,8 @@ PetscErrorCode HipCommGetData(MPI_Comm comm, HipCommData *out) {
   HipCommData d;
   int flag;
   PetscFunctionBegin;
-  if (keyval == MPI_KEYVAL_INVALID) { ierr = MPI_Comm_create_keyval(MPI_COMM_NULL_COPY_FN, delete_fn, &keyval, NULL);CHKERRQ(ierr); }
-  ierr = MPI_Comm_get_attr(comm, keyval, &d, &flag);CHKERRQ(ierr);
+  if (keyval == MPI_KEYVAL_INVALID) { ierr = MPI_Keyval_create(MPI_NULL_COPY_FN, delete_fn, &keyval, NULL);CHKERRQ(ierr);   /* the MPI-1 spelling tagm.c uses (src/sys/objects/tagm.c:141); MPIUNI has no other */ }
+  ierr = MPI_Attr_get(comm, keyval, &d, &flag);CHKERRQ(ierr);
   if (!flag) {
     d = (HipCommData)calloc(1, sizeof(*d));
     ierr = MPI_Comm_size(comm, &d->size);CHKERRQ(ierr);
@@ -49,7 +49,7 @@ PetscErrorCode HipCommGetData(MPI_Comm comm, HipCommData *out) {
         if (c[1]) mi355x_comm_destroy((mi355x_comm_t)c[1]);
       }
     }
-    ierr = MPI_Comm_set_attr(comm, keyval, d);CHKERRQ(ierr);
+    ierr = MPI_Attr_put(comm, keyval, d);CHKERRQ(ierr);
   }
   *out = d;
   PetscFunctionReturn(0);
@@ -73,7 +73,7 @@ int HipCommExchange(MPI_Comm comm, int ns, const int *speers, void *const *sbufs
                     int nr, const int *rpeers, void *const *rbufs, const int *rbytes) {
   MPI_Request req[128];
   int n = 0, rc = MPI_SUCCESS;
-  if (ns + nr > 128) return MPI_ERR_COUNT;
+  if (ns + nr > 128) return MPI_ERR_OTHER;
   for (int i = 0; i < nr && rc == MPI_SUCCESS; i++) rc = MPI_Irecv(rbufs[i], rbytes[i], MPI_BYTE, rpeers[i], 7351, comm, &req[n++]);
   for (int i = 0; i < ns && rc == MPI_SUCCESS; i++) rc = MPI_Isend(sbufs[i], sbytes[i], MPI_BYTE, speers[i], 7351, comm, &req[n++]);
   if (rc == MPI_SUCCESS) rc = MPI_Waitall(n, req, MPI_STATUSES_IGNORE);

@@ -9,12 +9,12 @@
 #define SA(A) HipAIJGet(A)
 #define SD(A) ((Mat_SeqAIJHIP *)(A)->spptr)
 PetscErrorCode MatSeqAIJGetArrays(Mat A, PetscInt *m, const PetscInt **i, const PetscInt **j, const PetscScalar **a);
-#define CHUNKSIZE 15   /* aij.h: rows grow by this many slots when preallocation is exceeded */
+static PetscErrorCode device_free(Mat A);
+static PetscBool device_values_current(Mat A);
 
 #if !defined(PETSCHIPMI355X_WITH_PETSC)   /* inside a PETSc tree the parent type MATSEQAIJ owns the container and its assembly (aij.c) */
 /* ---------------------------------------------------------------- host container */
-static PetscErrorCode device_free(Mat A);
-static PetscBool device_values_current(Mat A);
+#define CHUNKSIZE 15   /* aij.h: rows grow by this many slots when preallocation is exceeded */
 static PetscErrorCode seqaij_prealloc(Mat A, PetscInt nz, const PetscInt *nnz) {
   PetscErrorCode ierr;
   HipAIJ *a = SA(A);

@@ -35,7 +35,7 @@
 #include "mi355x_comm.h"
 
 /* map a kernel-library (hipError_t) failure to PETSC_ERR_LIB like CHKERRCUSP, cuspvecimpl.h:79 */
-#define CHKHIP(e) do { int e__ = (e); if (e__) return PetscError(__LINE__, __func__, __FILE__, PETSC_ERR_LIB, "HIP/RCCL error %d: %s", e__, mi355x_comm_error_string(e__)); } while (0)
+#define CHKHIP(e) do { int e__ = (e); if (e__) SETERRQ(PETSC_COMM_SELF, PETSC_ERR_LIB, "HIP/RCCL error %d: %s", e__, mi355x_comm_error_string(e__)); } while (0)
 
 /* ---- device context of this process (one GPU, two streams) ---- */
 typedef struct {

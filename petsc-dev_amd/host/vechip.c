@@ -75,7 +75,7 @@ PetscErrorCode VecHIPGetReadWrite(Vec v, PetscScalar **d) {
 PetscErrorCode VecHIPRestoreWrite(Vec v) { VH(v)->valid = VALID_DEVICE; return 0; }
 
 static int is_hip(Vec v) { return v && v->data && strstr(HipObjTypeName(v), "hipmi355x") != NULL; }
-#define CheckHIP(v) do { if (!is_hip(v)) SETERRQ((v)->comm, PETSC_ERR_ARG_NOTSAMETYPE, "vector of type %s mixed with a HIPMI355X vector", (v)->type_name); } while (0)
+#define CheckHIP(v) do { if (!is_hip(v)) SETERRQ(HipObjComm(v), PETSC_ERR_ARG_NOTSAMETYPE, "vector of type %s mixed with a HIPMI355X vector", HipObjTypeName(v)); } while (0)
 
 PetscErrorCode VecHIPMI355XGetArray(Vec v, PetscScalar **d) { CheckHIP(v); return VecHIPGetReadWrite(v, d); }
 PetscErrorCode VecHIPMI355XRestoreArray(Vec v, PetscScalar **d) { if (d) *d = NULL; VecHIPRestoreWrite(v); HipStateIncrease(v); return 0; }

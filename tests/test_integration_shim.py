@@ -182,3 +182,23 @@ def test_public_headers_define_no_mpi_names():
     for h in ("petschipmi355x.h", "petscmini.h", "mi355x_kernels.h", "mi355x_comm.h"):
         t = strip_comments(read(os.path.join(ROOT, "include", h)))
         assert not re.search(r"\bMPI_\w+", t), h
+
+
+PETSC_FLAVOUR_SOURCES = sorted(glob.glob(os.path.join(ROOT, "petsc-dev_amd/host/*.c")) + glob.glob(os.path.join(ROOT, "integration/petsc-3.3/*.c")))
+
+
+@pytest.mark.parametrize("src", PETSC_FLAVOUR_SOURCES, ids=[os.path.basename(s) for s in PETSC_FLAVOUR_SOURCES])
+def test_petsc_flavour_compiles_against_the_reference_headers(src):
+    """gcc -fsyntax-only -DPETSCHIPMI355X_WITH_PETSC over every plug-in source against /root/reference/include: macro bodies
+    (CHKHIP, SETERRQ), member accesses and prototypes are checked by the compiler, not by regular expressions.
+    tests/petsc33_syntax/petscconf.h is a compile aid for OUR sources (the reference's headers include a configure-generated
+    petscconf.h); nothing of the reference is built, no object is produced."""
+    import subprocess
+    cmd = ["gcc", "-fsyntax-only", "-std=gnu11", "-Wall", "-Wno-comment", "-Wno-unused",
+           "-Werror=implicit-function-declaration", "-Werror=incompatible-pointer-types", "-Werror=int-conversion",
+           "-DPETSCHIPMI355X_WITH_PETSC",
+           "-I" + os.path.join(ROOT, "tests/petsc33_syntax"), "-I" + os.path.join(REF, "include"), "-I" + os.path.join(REF, "include/mpiuni"), "-I" + REF,
+           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "petsc-dev_amd/host"), "-I" + os.path.join(ROOT, "integration/petsc-3.3"), src]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    own = [l for l in r.stderr.splitlines() if ("error" in l or "warning" in l) and REF not in l.split(":")[0]]
+    assert r.returncode == 0 and not own, r.stderr[-4000:]
