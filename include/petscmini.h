@@ -61,7 +61,9 @@ typedef enum { NORM_1 = 0, NORM_2 = 1, NORM_FROBENIUS = 2, NORM_INFINITY = 3, NO
 typedef enum { MAT_FLUSH_ASSEMBLY = 1, MAT_FINAL_ASSEMBLY = 0 } MatAssemblyType;               /* petscmat.h:347 */
 typedef enum { DIFFERENT_NONZERO_PATTERN, SUBSET_NONZERO_PATTERN, SAME_NONZERO_PATTERN, SAME_PRECONDITIONER } MatStructure;
 typedef enum { PC_SIDE_DEFAULT = -1, PC_LEFT, PC_RIGHT, PC_SYMMETRIC } PCSide;
+#define PC_SIDE_MAX 3    /* PC_SYMMETRIC + 1, petscpc.h:96 */
 typedef enum { KSP_NORM_DEFAULT = -1, KSP_NORM_NONE = 0, KSP_NORM_PRECONDITIONED = 1, KSP_NORM_UNPRECONDITIONED = 2, KSP_NORM_NATURAL = 3 } KSPNormType;
+#define KSP_NORM_MAX 4   /* KSP_NORM_NATURAL + 1, petscksp.h:349 */
 typedef enum { KSP_GMRES_CGS_REFINE_NEVER, KSP_GMRES_CGS_REFINE_IFNEEDED, KSP_GMRES_CGS_REFINE_ALWAYS } KSPGMRESCGSRefinementType;
 typedef enum { /* petscksp.h:403-430 */
   KSP_CONVERGED_RTOL_NORMAL = 1, KSP_CONVERGED_ATOL_NORMAL = 9, KSP_CONVERGED_RTOL = 2, KSP_CONVERGED_ATOL = 3,
@@ -252,6 +254,7 @@ PetscErrorCode PCCreate(PetscComm comm, PC *pc);
 PetscErrorCode PCSetType(PC pc, PCType type);
 PetscErrorCode PCGetType(PC pc, PCType *type);
 PetscErrorCode PCSetOperators(PC pc, Mat Amat, Mat Pmat, MatStructure flag);
+PetscErrorCode PCGetOperators(PC pc, Mat *Amat, Mat *Pmat, MatStructure *flag);
 PetscErrorCode PCSetUp(PC pc);
 PetscErrorCode PCApply(PC pc, Vec x, Vec y);
 PetscErrorCode PCSetFromOptions(PC pc);

@@ -13,7 +13,7 @@
 #include <petsc-private/vecimpl.h>     /* struct _p_Vec, struct _VecOps, PetscLayout, VecGetArray hooks (vecimpl.h:221-294,339-434) */
 #include <petsc-private/matimpl.h>     /* struct _p_Mat, struct _MatOps (matimpl.h:17-188,300-330) */
 #include <petsc-private/pcimpl.h>
-#include <petscksp.h>
+#include <petsc-private/kspimpl.h>    /* struct _p_KSP, KSPDefaultGetWork, KSPLogResidualHistory, KSP_MatMult / KSP_PCApply (kspimpl.h:8-110,131-191): host/kspfused.c */
 
 /* variadic SETERRQ: PETSc 3.3 spells the argument count (SETERRQ1..8, petscerror.h:120-212); PetscError itself is variadic */
 #undef SETERRQ

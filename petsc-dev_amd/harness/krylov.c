@@ -1,42 +1,17 @@
-/* HARNESS file: a restatement of the reference's cg.c / gmres.c / borthog2.c / bcgs.c / groppcg.c for boxes without PETSc
- * (the GPU test box).  In a PETSc tree this file is NOT used: the reference's own KSPSolve_CG / _GMRES / _BCGS run over
- * the plugin's Vec/Mat types unchanged.  It is not part of the product library (libpetschipmi355x.so)
- * and links against nothing device-specific; what it adds to the reference's sequences -- the fused forms -- it
- * reaches only through methods a Vec/Mat type may compose ("VecKrylovFusedOps_C", "MatMultTDotBegin_C"), and it falls
- * back to the op-by-op sequence when they are absent.
+/* HARNESS file: a plain restatement of the reference's cg.c / gmres.c / borthog2.c / bcgs.c / groppcg.c / pipecg.c for boxes
+ * without PETSc (the GPU test box) -- the op-by-op sequences an UNCHANGED PETSc program drives over the plug-in's Vec/Mat types
+ * (SURVEY 8a25).  In a PETSc tree this file is NOT used: the reference's own KSPSolve_CG / _GMRES / _BCGS take its place.  It is
+ * not part of the product library (libpetschipmi355x.so), links against nothing device-specific and knows no fused kernel:
+ * the plug-in's own solvers are separate KSP types (KSPCGHIPMI355X, KSPGMRESHIPMI355X, KSPBCGSHIPMI355X; host/kspfused.c),
+ * registered through KSPRegister like any third-party KSP.
  *
- * The three Krylov methods of the north star, as host-side drivers over the Vec/Mat function
- * tables.  Operation sequences follow the reference exactly (so iteration counts and residual
- * histories are comparable): KSPSolve_CG src/ksp/ksp/impls/cg/cg.c:92-286, KSPSolve_GMRES /
- * KSPGMRESCycle src/ksp/ksp/impls/gmres/gmres.c:118-409 with classical Gram-Schmidt
- * src/ksp/ksp/impls/gmres/borthog2.c:35-119, KSPSolve_BCGS src/ksp/ksp/impls/bcgs/bcgs.c:43-160.
- * Per CG iteration on the device: 1 SpMV, 1 pointwise mult, 2 dots, 1 norm, 2 axpy, 1 aypx; the only
- * host<->device traffic is the three 8-byte reduction results. */
+ * Operation sequences follow the reference exactly (so iteration counts and residual histories are comparable):
+ * KSPSolve_CG src/ksp/ksp/impls/cg/cg.c:92-286, KSPSolve_GMRES / KSPGMRESCycle src/ksp/ksp/impls/gmres/gmres.c:118-409 with
+ * classical Gram-Schmidt src/ksp/ksp/impls/gmres/borthog2.c:35-119, KSPSolve_BCGS src/ksp/ksp/impls/bcgs/bcgs.c:43-160. */
 #include "petscimpl.h"
 
-/* the fused kernels of the vectors' type, or NULL */
-static const VecKrylovFusedOps *fused_ops(Vec x) {
-  PetscVoidFunction f = NULL;
-  if (PetscObjectQueryFunction((PetscObject)x, "VecKrylovFusedOps_C", &f) || !f) return NULL;
-  return ((VecKrylovFusedOpsGetFn)f)();
-}
-static PetscErrorCode mat_mult_diagonal_scale(Mat A, Vec d, Vec x, Vec y, PetscBool *ok) {
-  PetscVoidFunction f = NULL;
-  *ok = PETSC_FALSE;
-  PetscErrorCode ierr = PetscObjectQueryFunction((PetscObject)A, "MatMultDiagonalScale_C", &f);CHKERRQ(ierr);
-  if (f) { ierr = ((MatMultDiagonalScaleFn)f)(A, d, x, y, ok);CHKERRQ(ierr); }
-  return 0;
-}
-static PetscErrorCode mat_mult_tdot_begin(Mat A, Vec x, Vec y, PetscBool *ok) {
-  PetscVoidFunction f = NULL;
-  *ok = PETSC_FALSE;
-  PetscErrorCode ierr = PetscObjectQueryFunction((PetscObject)A, "MatMultTDotBegin_C", &f);CHKERRQ(ierr);
-  if (f) { ierr = ((MatMultTDotBeginFn)f)(A, x, y, ok);CHKERRQ(ierr); }
-  return 0;
-}
-
 /* ================================================================== CG */
-typedef struct { PetscBool singlereduction; PetscInt fused; } KSP_CG;   /* cgimpl.h; fused: 0/1/2, see KSPSolve_CG */
+typedef struct { PetscBool singlereduction; } KSP_CG;   /* cgimpl.h */
 static PetscErrorCode KSPSetUp_CG(KSP ksp) {   /* cg.c:50-80 (no eigenvalue work): 3 work vectors, 5 with -ksp_cg_single_reduction */
   return KSPDefaultGetWork(ksp, ((KSP_CG *)ksp->data)->singlereduction ? 5 : 3);
 }
@@ -44,8 +19,6 @@ static PetscErrorCode KSPSetFromOptions_CG(KSP ksp) {   /* cg.c:330-345 */
   char t[16]; PetscBool set;
   PetscErrorCode ierr = PetscOptionsGetString(ksp->prefix, "-ksp_cg_single_reduction", t, sizeof(t), &set);CHKERRQ(ierr);
   if (set) ((KSP_CG *)ksp->data)->singlereduction = (PetscBool)(strcmp(t, "0") && strcmp(t, "false"));
-  ierr = PetscOptionsGetString(ksp->prefix, "-ksp_cg_fused", t, sizeof(t), &set);CHKERRQ(ierr);
-  if (set) ((KSP_CG *)ksp->data)->fused = (!strcmp(t, "0") || !strcmp(t, "false")) ? 0 : ((!strcmp(t, "1") || !strcmp(t, "true")) ? 1 : (!strcmp(t, "2") ? 2 : (!strcmp(t, "4") ? 4 : 3)));
   return 0;
 }
 static PetscErrorCode KSPDestroy_CG(KSP ksp) { free(ksp->data); ksp->data = NULL; return 0; }
@@ -59,31 +32,6 @@ static PetscErrorCode KSPSolve_CG(KSP ksp) {
   Vec X = ksp->vec_sol, B = ksp->vec_rhs, R = ksp->work[0], Z = ksp->work[1], P = ksp->work[2];
   Vec S = single ? ksp->work[3] : NULL, W = single ? ksp->work[4] : Z;   /* cg.c:116-122 */
   Mat Amat = ksp->pc->mat;
-  /* Fused forms, -ksp_cg_fused <0|1|2|3|4> (default 3); iterates and history carry the same bits at every level:
-   *  1: with PCJACOBI (or PCNONE) the two AXPYs, the PCApply, the norm and the dot of cg.c:206-232 are one sweep
-   *     (VecCGUpdate_HIPMI355X); with any other PC the norm and the dot share one VecDotNorm2 reduction;
-   *  2: as 1, and with PCJACOBI dpi = p'w stays on the device, where the update forms a = beta/dpi itself: one host
-   *     synchronisation per iteration instead of two (VecTDotBegin_HIPMI355X / VecCGUpdateDev_HIPMI355X);
-   *  3: as 2, and while the host waits for the sums of iteration i (its convergence test) the device already runs
-   *     the front half of iteration i+1 -- p = z + b p with b = beta_new/beta formed on the device
-   *     (VecAYPXDev_HIPMI355X), w = A p, p'w -- so the host round trip is off the device's critical path.  If the
-   *     test then ends the solve, only the work vectors P and Z(=W) have been touched; not done for the last
-   *     permitted iteration, nor when the residual is within 10x of its target;
-   *  4: as 3, and on one rank p'w is a by-product of the SpMV pass itself (MatMultTDotBegin_HIPMI355X: the separate
-   *     16n-byte dot pass disappears).  Its summation tree differs from VecTDot's, so iterates agree with the other
-   *     levels to rounding (1e-15 relative per step), not bit for bit; measured gain 1-2 % (the separate dot reads p
-   *     and the just-written w largely out of the Infinity Cache), so it is an option, not the default;
-   *  0: the reference's op-by-op sequence. */
-  const VecKrylovFusedOps *F = fused_ops(X);
-  const PetscInt flevel = (single || !F) ? 0 : ((KSP_CG *)ksp->data)->fused;
-  const PetscBool fused = (PetscBool)(flevel > 0);
-  Vec D = NULL;
-  PetscBool devscalar = PETSC_FALSE, front_queued = PETSC_FALSE, fusedpc = PETSC_FALSE;   /* fusedpc: PCJACOBI (D) or PCNONE (D == NULL, z = r) */
-  if (fused) {
-    ierr = PCJacobiGetInverseDiagonal_Private(ksp->pc, &D);CHKERRQ(ierr);
-    if (D || PCIsNone_Private(ksp->pc)) { ierr = F->cg_update_check(X, R, Z, P, W, D, &fusedpc);CHKERRQ(ierr); }
-    devscalar = (PetscBool)(fusedpc && flevel > 1);
-  }
 
   const KSPNormType nt = ksp->normtype;   /* cg.c:136-161,233-260: which norm the convergence test sees */
   ksp->its = 0;
@@ -112,7 +60,7 @@ static PetscErrorCode KSPSolve_CG(KSP ksp) {
   KSPLogResidualHistory(ksp, dp);
   ierr = KSPMonitor(ksp, 0, dp);CHKERRQ(ierr);
   ksp->rnorm = dp;
-  ierr = KSPDefaultConverged(ksp, 0, dp, &ksp->reason);CHKERRQ(ierr);
+  ierr = (*ksp->converged)(ksp, 0, dp, &ksp->reason, ksp->cnvP);CHKERRQ(ierr);
   if (ksp->reason) return 0;
   if (nt != KSP_NORM_PRECONDITIONED && nt != KSP_NORM_NATURAL) { ierr = KSP_PCApply(ksp, R, Z);CHKERRQ(ierr); }
   if (nt != KSP_NORM_NATURAL) {
@@ -129,118 +77,75 @@ static PetscErrorCode KSPSolve_CG(KSP ksp) {
     ksp->its = i + 1;
     if (beta == 0.0) { ksp->reason = KSP_CONVERGED_ATOL; break; }
     else if ((i > 0) && (beta * betaold < 0.0)) { ksp->reason = KSP_DIVERGED_INDEFINITE_PC; break; }
-    PetscBool dpi_on_device = PETSC_FALSE;
-    if (front_queued) {          /* p, w = A p and p'w of this iteration were queued behind the previous update */
-      b = beta / betaold;
-      dpiold = dpi;
-      dpi_on_device = PETSC_TRUE;
-      front_queued = PETSC_FALSE;
-    } else {
-      if (!i) { ierr = VecCopy(Z, P);CHKERRQ(ierr); b = 0.0; }     /* p <- z */
-      else { b = beta / betaold; ierr = VecAYPX(P, b, Z);CHKERRQ(ierr); }   /* p <- z + b*p */
-      dpiold = dpi;
-      if (!single || !i) {
-        if (devscalar && flevel > 3) { ierr = mat_mult_tdot_begin(Amat, P, W, &dpi_on_device);CHKERRQ(ierr); }   /* both at once */
-        if (!dpi_on_device) {
-          ierr = KSP_MatMult(ksp, Amat, P, W);CHKERRQ(ierr);       /* w <- Ap */
-          if (devscalar) { ierr = F->tdot_begin(P, W, &dpi_on_device);CHKERRQ(ierr); }
-          if (!dpi_on_device) { ierr = VecTDot(P, W, &dpi);CHKERRQ(ierr); }   /* dpi <- p'w */
-        }
-      } else {                                                      /* cg.c:200-203: recurrences instead of a product and a dot */
-        ierr = VecAYPX(W, beta / betaold, S);CHKERRQ(ierr);        /* w <- Ap */
-        dpi = delta - beta * beta * dpiold / (betaold * betaold);  /* dpi <- p'w */
-      }
+    if (!i) { ierr = VecCopy(Z, P);CHKERRQ(ierr); b = 0.0; }       /* p <- z */
+    else { b = beta / betaold; ierr = VecAYPX(P, b, Z);CHKERRQ(ierr); }   /* p <- z + b*p */
+    dpiold = dpi;
+    if (!single || !i) {
+      ierr = KSP_MatMult(ksp, Amat, P, W);CHKERRQ(ierr);           /* w <- Ap */
+      ierr = VecTDot(P, W, &dpi);CHKERRQ(ierr);                    /* dpi <- p'w */
+    } else {                                                        /* cg.c:200-203: recurrences instead of a product and a dot */
+      ierr = VecAYPX(W, beta / betaold, S);CHKERRQ(ierr);          /* w <- Ap */
+      dpi = delta - beta * beta * dpiold / (betaold * betaold);    /* dpi <- p'w */
     }
     betaold = beta;
-    PetscBool have_sums = PETSC_FALSE;                             /* z, z'z, z'r, r'r all produced by one fused sweep */
-    PetscScalar zz = 0.0, zr = 0.0, rr = 0.0;
-    if (dpi_on_device) {
-      /* the update kernel applies the tests below to dpi itself and touches nothing if one fires; dpi comes back
-       * with the sums, and the host takes the same exits */
-      ierr = F->cg_update_dev_begin(X, R, Z, P, W, D, beta, dpiold, (PetscBool)(i > 0));CHKERRQ(ierr);
-      if (flevel > 2 && i + 1 < ksp->max_it && (nt == KSP_NORM_NONE || dp > 10.0 * ksp->ttol)) {
-        /* front half of iteration i+1 (beta of this iteration is its betaold) */
-        PetscBool ok = PETSC_FALSE;
-        ierr = F->aypx_dev(P, beta, Z);CHKERRQ(ierr);
-        if (flevel > 3) { ierr = mat_mult_tdot_begin(Amat, P, W, &ok);CHKERRQ(ierr); }
-        if (!ok) {
-          ierr = KSP_MatMult(ksp, Amat, P, W);CHKERRQ(ierr);
-          ierr = F->tdot_begin(P, W, &ok);CHKERRQ(ierr);
-          if (!ok) SETERRQ(ksp->comm, PETSC_ERR_PLIB, "split dot refused after it had been accepted");
-        }
-        front_queued = PETSC_TRUE;
-      }
-      ierr = F->cg_update_dev_end(X, &zz, &zr, &rr, &dpi);CHKERRQ(ierr);
-      have_sums = PETSC_TRUE;
-    }
     if (PetscIsInfOrNanScalar(dpi)) SETERRQ(ksp->comm, PETSC_ERR_FP, "Infinite or not-a-number generated in dot product");
     if ((dpi == 0.0) || ((i > 0) && (dpi * dpiold <= 0.0))) { ksp->reason = KSP_DIVERGED_INDEFINITE_MAT; break; }
     a = beta / dpi;
-    if (!have_sums && fusedpc) { ierr = F->cg_update(X, R, Z, P, W, D, a, &zz, &zr, &rr, &have_sums);CHKERRQ(ierr); }
-    if (have_sums) {
-      /* z = B r is already there whatever the norm type (the reference applies the PC before or after the test,
-       * cg.c:233-268: same z either way), and so is the next beta */
-      if (nt == KSP_NORM_PRECONDITIONED) dp = PetscSqrtReal(zz);   /* the square is reduced, then rooted (pvec2.c:62-64) */
-      else if (nt == KSP_NORM_UNPRECONDITIONED) dp = PetscSqrtReal(rr);
-      else if (nt == KSP_NORM_NATURAL) {
-        if (PetscIsInfOrNanScalar(zr)) SETERRQ(ksp->comm, PETSC_ERR_FP, "Infinite or not-a-number generated in dot product");
-        dp = PetscSqrtReal(PetscAbsScalar(zr));
-      } else dp = 0.0;
-    } else {
-      ierr = VecAXPY(X, a, P);CHKERRQ(ierr);                     /* x <- x + ap */
-      ierr = VecAXPY(R, -a, W);CHKERRQ(ierr);                    /* r <- r - aw */
-      if (nt == KSP_NORM_PRECONDITIONED) {
-        ierr = KSP_PCApply(ksp, R, Z);CHKERRQ(ierr);             /* z <- Br */
-        if (single) { ierr = KSP_MatMult(ksp, Amat, Z, S);CHKERRQ(ierr); }   /* cg.c:217-219 */
-        if (fused) { PetscReal n2; ierr = VecDotNorm2(R, Z, &zr, &n2);CHKERRQ(ierr); dp = PetscSqrtReal(n2); have_sums = PETSC_TRUE; }   /* norm and next beta share a reduction */
-        else { ierr = VecNorm(Z, NORM_2, &dp);CHKERRQ(ierr); }
-      } else if (nt == KSP_NORM_UNPRECONDITIONED) {
-        ierr = VecNorm(R, NORM_2, &dp);CHKERRQ(ierr);
-      } else if (nt == KSP_NORM_NATURAL) {
-        ierr = KSP_PCApply(ksp, R, Z);CHKERRQ(ierr);
-        if (single) {
-          PetscScalar tmp[2]; Vec vecs[2];
-          vecs[0] = S; vecs[1] = R;
-          ierr = KSP_MatMult(ksp, Amat, Z, S);CHKERRQ(ierr);
-          ierr = VecMDot(Z, 2, vecs, tmp);CHKERRQ(ierr);
-          delta = tmp[0]; beta = tmp[1];
-        } else { ierr = VecTDot(Z, R, &beta);CHKERRQ(ierr); }
-        if (PetscIsInfOrNanScalar(beta)) SETERRQ(ksp->comm, PETSC_ERR_FP, "Infinite or not-a-number generated in dot product");
-        dp = PetscSqrtReal(PetscAbsScalar(beta));
-      } else dp = 0.0;
-    }
+    ierr = VecAXPY(X, a, P);CHKERRQ(ierr);                         /* x <- x + ap */
+    ierr = VecAXPY(R, -a, W);CHKERRQ(ierr);                        /* r <- r - aw */
+    if (nt == KSP_NORM_PRECONDITIONED) {
+      ierr = KSP_PCApply(ksp, R, Z);CHKERRQ(ierr);                 /* z <- Br */
+      if (single) { ierr = KSP_MatMult(ksp, Amat, Z, S);CHKERRQ(ierr); }   /* cg.c:217-219 */
+      ierr = VecNorm(Z, NORM_2, &dp);CHKERRQ(ierr);
+    } else if (nt == KSP_NORM_UNPRECONDITIONED) {
+      ierr = VecNorm(R, NORM_2, &dp);CHKERRQ(ierr);
+    } else if (nt == KSP_NORM_NATURAL) {
+      ierr = KSP_PCApply(ksp, R, Z);CHKERRQ(ierr);
+      if (single) {
+        PetscScalar tmp[2]; Vec vecs[2];
+        vecs[0] = S; vecs[1] = R;
+        ierr = KSP_MatMult(ksp, Amat, Z, S);CHKERRQ(ierr);
+        ierr = VecMDot(Z, 2, vecs, tmp);CHKERRQ(ierr);
+        delta = tmp[0]; beta = tmp[1];
+      } else { ierr = VecTDot(Z, R, &beta);CHKERRQ(ierr); }
+      if (PetscIsInfOrNanScalar(beta)) SETERRQ(ksp->comm, PETSC_ERR_FP, "Infinite or not-a-number generated in dot product");
+      dp = PetscSqrtReal(PetscAbsScalar(beta));
+    } else dp = 0.0;
     ksp->rnorm = dp;
     KSPLogResidualHistory(ksp, dp);
     ierr = KSPMonitor(ksp, i + 1, dp);CHKERRQ(ierr);
-    ierr = KSPDefaultConverged(ksp, i + 1, dp, &ksp->reason);CHKERRQ(ierr);
+    ierr = (*ksp->converged)(ksp, i + 1, dp, &ksp->reason, ksp->cnvP);CHKERRQ(ierr);
     if (ksp->reason) break;
-    if (have_sums) beta = zr;                                      /* beta <- z'*r, from the fused sweep */
-    else {
-      if (nt != KSP_NORM_PRECONDITIONED && nt != KSP_NORM_NATURAL) {
-        ierr = KSP_PCApply(ksp, R, Z);CHKERRQ(ierr);             /* z <- Br */
-        if (single) { ierr = KSP_MatMult(ksp, Amat, Z, S);CHKERRQ(ierr); }
-      }
-      if (nt != KSP_NORM_NATURAL) {
-        if (single) {                                             /* cg.c:263-270: one VecMDot(2) = one reduction for delta and beta */
-          PetscScalar tmp[2]; Vec vecs[2];
-          vecs[0] = S; vecs[1] = R;
-          ierr = VecMDot(Z, 2, vecs, tmp);CHKERRQ(ierr);
-          delta = tmp[0]; beta = tmp[1];
-        } else { ierr = VecTDot(Z, R, &beta);CHKERRQ(ierr); }    /* beta <- z'*r */
-      }
+    if (nt != KSP_NORM_PRECONDITIONED && nt != KSP_NORM_NATURAL) {
+      ierr = KSP_PCApply(ksp, R, Z);CHKERRQ(ierr);                 /* z <- Br */
+      if (single) { ierr = KSP_MatMult(ksp, Amat, Z, S);CHKERRQ(ierr); }
     }
-    if (PetscIsInfOrNanScalar(beta)) SETERRQ(ksp->comm, PETSC_ERR_FP, "Infinite or not-a-number generated in dot product");
+    if (nt != KSP_NORM_NATURAL) {
+      if (single) {                                                 /* cg.c:263-270: one VecMDot(2) = one reduction for delta and beta */
+        PetscScalar tmp[2]; Vec vecs[2];
+        vecs[0] = S; vecs[1] = R;
+        ierr = VecMDot(Z, 2, vecs, tmp);CHKERRQ(ierr);
+        delta = tmp[0]; beta = tmp[1];
+      } else { ierr = VecTDot(Z, R, &beta);CHKERRQ(ierr); }        /* beta <- z'*r */
+      if (PetscIsInfOrNanScalar(beta)) SETERRQ(ksp->comm, PETSC_ERR_FP, "Infinite or not-a-number generated in dot product");
+    }
     i++;
   } while (i < ksp->max_it);
   if (i >= ksp->max_it) ksp->reason = KSP_DIVERGED_ITS;
   return 0;
 }
+static void cg_family_norms(KSP ksp, PetscInt pref) {   /* cg.c:439-442, groppcg.c:170-173, pipecg.c:199-202 */
+  ksp->normsupporttable[KSP_NORM_PRECONDITIONED][PC_LEFT] = pref;
+  ksp->normsupporttable[KSP_NORM_UNPRECONDITIONED][PC_LEFT] = 1;
+  ksp->normsupporttable[KSP_NORM_NATURAL][PC_LEFT] = 1;
+  ksp->normsupporttable[KSP_NORM_NONE][PC_LEFT] = 1;
+}
 PetscErrorCode KSPCreate_CG(KSP ksp) {
   KSP_CG *cg;
   PetscErrorCode ierr = PetscMalloc(sizeof(*cg), &cg);CHKERRQ(ierr);
   cg->singlereduction = PETSC_FALSE;
-  cg->fused = 3;
   ksp->data = cg;
+  cg_family_norms(ksp, 2);
   ksp->ops->setup = KSPSetUp_CG; ksp->ops->solve = KSPSolve_CG; ksp->ops->setfromoptions = KSPSetFromOptions_CG; ksp->ops->destroy = KSPDestroy_CG;
   return 0;
 }
@@ -285,7 +190,7 @@ static PetscErrorCode KSPSolve_GROPPCG(KSP ksp) {
   KSPLogResidualHistory(ksp, dp);
   ierr = KSPMonitor(ksp, 0, dp);CHKERRQ(ierr);
   ksp->rnorm = dp;
-  ierr = KSPDefaultConverged(ksp, 0, dp, &ksp->reason);CHKERRQ(ierr);
+  ierr = (*ksp->converged)(ksp, 0, dp, &ksp->reason, ksp->cnvP);CHKERRQ(ierr);
   if (ksp->reason) return 0;
 
   i = 0;
@@ -315,7 +220,7 @@ static PetscErrorCode KSPSolve_GROPPCG(KSP ksp) {
     ksp->rnorm = dp;
     KSPLogResidualHistory(ksp, dp);
     ierr = KSPMonitor(ksp, i, dp);CHKERRQ(ierr);
-    ierr = KSPDefaultConverged(ksp, i, dp, &ksp->reason);CHKERRQ(ierr);
+    ierr = (*ksp->converged)(ksp, i, dp, &ksp->reason, ksp->cnvP);CHKERRQ(ierr);
     if (ksp->reason) break;
     beta = gammaNew / gamma;
     gamma = gammaNew;
@@ -325,7 +230,7 @@ static PetscErrorCode KSPSolve_GROPPCG(KSP ksp) {
   if (i >= ksp->max_it && !ksp->reason) ksp->reason = KSP_DIVERGED_ITS;
   return 0;
 }
-PetscErrorCode KSPCreate_GROPPCG(KSP ksp) { ksp->ops->setup = KSPSetUp_GROPPCG; ksp->ops->solve = KSPSolve_GROPPCG; return 0; }
+PetscErrorCode KSPCreate_GROPPCG(KSP ksp) { cg_family_norms(ksp, 1); ksp->ops->setup = KSPSetUp_GROPPCG; ksp->ops->solve = KSPSolve_GROPPCG; return 0; }
 
 /* ================================================================== PIPECG
  * Pipelined CG of Ghysels & Vanroose (src/ksp/ksp/impls/cg/pipecg/pipecg.c:49-205): ONE split-phase reduction per
@@ -380,7 +285,7 @@ static PetscErrorCode KSPSolve_PIPECG(KSP ksp) {
   KSPLogResidualHistory(ksp, dp);
   ierr = KSPMonitor(ksp, 0, dp);CHKERRQ(ierr);
   ksp->rnorm = dp;
-  ierr = KSPDefaultConverged(ksp, 0, dp, &ksp->reason);CHKERRQ(ierr);
+  ierr = (*ksp->converged)(ksp, 0, dp, &ksp->reason, ksp->cnvP);CHKERRQ(ierr);
   if (ksp->reason) return 0;
 
   i = 0;
@@ -403,7 +308,7 @@ static PetscErrorCode KSPSolve_PIPECG(KSP ksp) {
       ksp->rnorm = dp;
       KSPLogResidualHistory(ksp, dp);
       ierr = KSPMonitor(ksp, i, dp);CHKERRQ(ierr);
-      ierr = KSPDefaultConverged(ksp, i, dp, &ksp->reason);CHKERRQ(ierr);
+      ierr = (*ksp->converged)(ksp, i, dp, &ksp->reason, ksp->cnvP);CHKERRQ(ierr);
       if (ksp->reason) break;
     }
     if (i == 0) {
@@ -431,7 +336,7 @@ static PetscErrorCode KSPSolve_PIPECG(KSP ksp) {
   if (i >= ksp->max_it) ksp->reason = KSP_DIVERGED_ITS;
   return 0;
 }
-PetscErrorCode KSPCreate_PIPECG(KSP ksp) { ksp->ops->setup = KSPSetUp_PIPECG; ksp->ops->solve = KSPSolve_PIPECG; return 0; }
+PetscErrorCode KSPCreate_PIPECG(KSP ksp) { cg_family_norms(ksp, 1); ksp->ops->setup = KSPSetUp_PIPECG; ksp->ops->solve = KSPSolve_PIPECG; return 0; }
 
 /* ================================================================== GMRES(m) */
 typedef struct {
@@ -442,7 +347,6 @@ typedef struct {
   Vec *vecs;      /* [0]=TEMP, [1]=TEMP_MATOP, [2+k]=VV(k) */
   PetscInt nvecs;
   PetscInt it;
-  PetscBool fused;   /* -ksp_gmres_fused: use the types' fused kernels when they have them (not a reference option) */
 } KSP_GMRES;
 #define GM ((KSP_GMRES *)ksp->data)
 #define HH(a, b) (g->hh + (size_t)(b) * (size_t)(g->max_k + 2) + (a))      /* gmresimpl.h */
@@ -451,15 +355,13 @@ typedef struct {
 #define VEC_TEMP_MATOP g->vecs[1]
 #define VEC_VV(i) g->vecs[2 + (i)]
 
-PetscErrorCode KSPGMRESSetRestart(KSP ksp, PetscInt restart) {
-  if (strcmp(ksp->type_name, KSPGMRES)) return 0;
+static PetscErrorCode KSPGMRESSetRestart_GMRES(KSP ksp, PetscInt restart) {   /* gmres.c:752-770 */
   if (restart < 1) SETERRQ(ksp->comm, PETSC_ERR_ARG_OUTOFRANGE, "Restart must be positive");
   if (ksp->setupcalled) SETERRQ(ksp->comm, PETSC_ERR_ORDER, "Must call KSPGMRESSetRestart() before KSPSetUp()");
   GM->max_k = restart;
   return 0;
 }
-PetscErrorCode KSPGMRESSetCGSRefinementType(KSP ksp, KSPGMRESCGSRefinementType type) {
-  if (strcmp(ksp->type_name, KSPGMRES)) return 0;
+static PetscErrorCode KSPGMRESSetCGSRefinementType_GMRES(KSP ksp, KSPGMRESCGSRefinementType type) {
   GM->cgstype = type;
   return 0;
 }
@@ -474,8 +376,6 @@ static PetscErrorCode KSPSetFromOptions_GMRES(KSP ksp) {
     else if (!strcmp(t, "refine_never")) GM->cgstype = KSP_GMRES_CGS_REFINE_NEVER;
     else SETERRQ(ksp->comm, PETSC_ERR_ARG_UNKNOWN_TYPE, "Unknown refinement type %s", t);
   }
-  ierr = PetscOptionsGetString(ksp->prefix, "-ksp_gmres_fused", t, sizeof(t), &set);CHKERRQ(ierr);
-  if (set) GM->fused = (PetscBool)(strcmp(t, "0") && strcmp(t, "false"));
   return 0;
 }
 
@@ -583,11 +483,7 @@ static PetscErrorCode gmres_cycle(PetscInt *itcount, KSP ksp) {
   KSP_GMRES *g = GM;
   PetscReal res_norm, res, hapbnd, tt;
   PetscInt it = 0, max_k = g->max_k;
-  PetscBool hapend = PETSC_FALSE, done;
-  const VecKrylovFusedOps *F = g->fused ? fused_ops(VEC_VV(0)) : NULL;
-  Vec Dj = NULL;
-  if (F && !F->gmres_orthog_normalize) F = NULL;
-  if (g->fused && ksp->pc_side == PC_LEFT) { ierr = PCJacobiGetInverseDiagonal_Private(ksp->pc, &Dj);CHKERRQ(ierr); }
+  PetscBool hapend = PETSC_FALSE;
 
   ierr = VecNormalize(VEC_VV(0), &res_norm);CHKERRQ(ierr);
   res = res_norm;
@@ -597,25 +493,13 @@ static PetscErrorCode gmres_cycle(PetscInt *itcount, KSP ksp) {
   KSPLogResidualHistory(ksp, res);
   ierr = KSPMonitor(ksp, ksp->its, res);CHKERRQ(ierr);
   if (!res) { if (itcount) *itcount = 0; ksp->reason = KSP_CONVERGED_ATOL; return 0; }
-  ierr = KSPDefaultConverged(ksp, ksp->its, res, &ksp->reason);CHKERRQ(ierr);
+  ierr = (*ksp->converged)(ksp, ksp->its, res, &ksp->reason, ksp->cnvP);CHKERRQ(ierr);
   while (!ksp->reason && it < max_k && ksp->its < ksp->max_it) {
     if (it) { KSPLogResidualHistory(ksp, res); ierr = KSPMonitor(ksp, ksp->its, res);CHKERRQ(ierr); }
     g->it = it - 1;
-    /* -ksp_gmres_fused (default on; 0: the reference's op-by-op sequence).  Left PCJACOBI: the product and the diagonal scaling
-     * in one kernel; no refinement: MDot, MAXPY + norm, scale with the scalars on the device and one host wait.  Same bits. */
-    done = PETSC_FALSE;
-    if (Dj) { ierr = mat_mult_diagonal_scale(ksp->pc->mat, Dj, VEC_VV(it), VEC_VV(1 + it), &done);CHKERRQ(ierr); }
-    if (!done) { ierr = KSP_PCApplyBAorAB(ksp, VEC_VV(it), VEC_VV(1 + it), VEC_TEMP_MATOP);CHKERRQ(ierr); }
-    done = PETSC_FALSE;
-    if (F && g->cgstype == KSP_GMRES_CGS_REFINE_NEVER) {
-      PetscScalar *hh = HH(0, it), *hes = HES(0, it), *lhh = g->lhh;
-      ierr = F->gmres_orthog_normalize(VEC_VV(it + 1), it + 1, &VEC_VV(0), lhh, &tt, &done);CHKERRQ(ierr);
-      if (done) for (PetscInt j = 0; j <= it; j++) { hh[j] = 0.0; hes[j] = 0.0; lhh[j] = -lhh[j]; hh[j] -= lhh[j]; hes[j] -= lhh[j]; }   /* borthog2.c:52-66 */
-    }
-    if (!done) {
-      ierr = gmres_orthog(ksp, it);CHKERRQ(ierr);                  /* update hessenberg matrix and do Gram-Schmidt */
-      ierr = VecNormalize(VEC_VV(it + 1), &tt);CHKERRQ(ierr);     /* vv(i+1) . vv(i+1) */
-    }
+    ierr = KSP_PCApplyBAorAB(ksp, VEC_VV(it), VEC_VV(1 + it), VEC_TEMP_MATOP);CHKERRQ(ierr);
+    ierr = gmres_orthog(ksp, it);CHKERRQ(ierr);                    /* update hessenberg matrix and do Gram-Schmidt */
+    ierr = VecNormalize(VEC_VV(it + 1), &tt);CHKERRQ(ierr);       /* vv(i+1) . vv(i+1) */
     *HH(it + 1, it) = tt;
     *HES(it + 1, it) = tt;
     hapbnd = PetscAbsScalar(tt / g->grs[it]);                      /* happy breakdown test */
@@ -627,7 +511,7 @@ static PetscErrorCode gmres_cycle(PetscInt *itcount, KSP ksp) {
     ksp->its++;
     ksp->rnorm = res;
     if (ksp->reason) break;
-    ierr = KSPDefaultConverged(ksp, ksp->its, res, &ksp->reason);CHKERRQ(ierr);
+    ierr = (*ksp->converged)(ksp, ksp->its, res, &ksp->reason, ksp->cnvP);CHKERRQ(ierr);
     if (hapend) {
       if (!ksp->reason) SETERRQ(ksp->comm, PETSC_ERR_PLIB, "You reached the happy break down, but convergence was not indicated. Residual norm = %g", res);
       break;
@@ -662,43 +546,35 @@ static PetscErrorCode KSPDestroy_GMRES(KSP ksp) {
   free(g->hh); free(g->hes); free(g->grs); free(g->cc); free(g->ss); free(g->lhh); free(g->nrs);
   if (g->vecs) { PetscErrorCode ierr = VecDestroyVecs(g->nvecs, &g->vecs);CHKERRQ(ierr); }
   free(g); ksp->data = NULL;
+  (void)PetscObjectComposeFunction((PetscObject)ksp, "KSPGMRESSetRestart_C", "", (PetscVoidFunction)NULL);   /* gmres.c:288-291 */
+  (void)PetscObjectComposeFunction((PetscObject)ksp, "KSPGMRESSetCGSRefinementType_C", "", (PetscVoidFunction)NULL);
   return 0;
 }
 PetscErrorCode KSPCreate_GMRES(KSP ksp) {   /* gmres.c KSPCreate_GMRES: restart 30, haptol 1e-30, refine never */
   KSP_GMRES *g;
   PetscErrorCode ierr = PetscMalloc(sizeof(*g), &g);CHKERRQ(ierr);
   memset(g, 0, sizeof(*g));
-  g->max_k = 30; g->haptol = 1.0e-30; g->cgstype = KSP_GMRES_CGS_REFINE_NEVER; g->fused = PETSC_TRUE;
+  g->max_k = 30; g->haptol = 1.0e-30; g->cgstype = KSP_GMRES_CGS_REFINE_NEVER;
   ksp->data = g;
+  ksp->normsupporttable[KSP_NORM_PRECONDITIONED][PC_LEFT] = 2;      /* gmres.c:909-910 */
+  ksp->normsupporttable[KSP_NORM_UNPRECONDITIONED][PC_RIGHT] = 1;
   ksp->ops->setup = KSPSetUp_GMRES; ksp->ops->solve = KSPSolve_GMRES; ksp->ops->destroy = KSPDestroy_GMRES;
   ksp->ops->setfromoptions = KSPSetFromOptions_GMRES;
+  ierr = PetscObjectComposeFunction((PetscObject)ksp, "KSPGMRESSetRestart_C", "KSPGMRESSetRestart_GMRES", (PetscVoidFunction)KSPGMRESSetRestart_GMRES);CHKERRQ(ierr);   /* gmres.c:931-942 */
+  ierr = PetscObjectComposeFunction((PetscObject)ksp, "KSPGMRESSetCGSRefinementType_C", "KSPGMRESSetCGSRefinementType_GMRES", (PetscVoidFunction)KSPGMRESSetCGSRefinementType_GMRES);CHKERRQ(ierr);
   return 0;
 }
 
 /* ================================================================== BiCGStab */
 static PetscErrorCode KSPSetUp_BCGS(KSP ksp) { return KSPDefaultGetWork(ksp, 6); }   /* bcgs.c:13 */
 
-/* -ksp_bcgs_fused <bool> (default true): with left PCJACOBI / PCNONE the PCApply is fused with the dot(s) that follow it
- * and the x/r update with the norm and the NEXT iteration's rho (VecPMultDot, VecPMultDotNorm2, VecBCGSUpdate in
- * vechip.c): 22 vector passes and 3 reductions per iteration instead of 27 and 4, identical bits. */
 static PetscErrorCode KSPSolve_BCGS(KSP ksp) {
   PetscErrorCode ierr;
   PetscInt i;
   PetscScalar rho = 0.0, rhoold, alpha, beta, omega, omegaold, d1;
   PetscReal dp = 0.0, d2;
   Vec X = ksp->vec_sol, B = ksp->vec_rhs, R = ksp->work[0], RP = ksp->work[1], V = ksp->work[2], T = ksp->work[3], S = ksp->work[4], P = ksp->work[5];
-  Mat Amat = ksp->pc->mat;
-  Vec D = NULL;
-  PetscBool fusedpc = PETSC_FALSE, have_rho = PETSC_FALSE, done;
-  char t_[16]; PetscBool set;
-  const VecKrylovFusedOps *F = fused_ops(X);
 
-  if (ksp->pc_side == PC_RIGHT) SETERRQ(ksp->comm, PETSC_ERR_SUP, "right-preconditioned BiCGStab is outside the ported path");
-  ierr = PetscOptionsGetString(ksp->prefix, "-ksp_bcgs_fused", t_, sizeof(t_), &set);CHKERRQ(ierr);
-  if (F && (!set || (strcmp(t_, "0") && strcmp(t_, "false")))) {
-    ierr = PCJacobiGetInverseDiagonal_Private(ksp->pc, &D);CHKERRQ(ierr);
-    fusedpc = (PetscBool)(D != NULL || PCIsNone_Private(ksp->pc));
-  }
   const PetscBool nonorm = (PetscBool)(ksp->normtype == KSP_NORM_NONE);   /* bcgs.c:76,131: smoother use, no norms, KSPSkipConverged */
   ierr = KSPInitialResidual(ksp, X, V, T, R, B);CHKERRQ(ierr);   /* initial preconditioned residual */
   if (!nonorm) { ierr = VecNorm(R, NORM_2, &dp);CHKERRQ(ierr); }
@@ -706,7 +582,7 @@ static PetscErrorCode KSPSolve_BCGS(KSP ksp) {
   ksp->rnorm = dp;
   KSPLogResidualHistory(ksp, dp);
   ierr = KSPMonitor(ksp, 0, dp);CHKERRQ(ierr);
-  ierr = KSPDefaultConverged(ksp, 0, dp, &ksp->reason);CHKERRQ(ierr);
+  ierr = (*ksp->converged)(ksp, 0, dp, &ksp->reason, ksp->cnvP);CHKERRQ(ierr);
   if (ksp->reason) return 0;
   ierr = VecCopy(R, RP);CHKERRQ(ierr);                           /* rp == r */
   rhoold = 1.0; alpha = 1.0; omegaold = 1.0;
@@ -714,35 +590,16 @@ static PetscErrorCode KSPSolve_BCGS(KSP ksp) {
   ierr = VecSet(V, 0.0);CHKERRQ(ierr);
   i = 0;
   do {
-    if (!have_rho) { ierr = VecDot(R, RP, &rho);CHKERRQ(ierr); }  /* rho <- (r,rp) */
-    have_rho = PETSC_FALSE;
+    ierr = VecDot(R, RP, &rho);CHKERRQ(ierr);                    /* rho <- (r,rp) */
     beta = (rho / rhoold) * (alpha / omegaold);
     ierr = VecAXPBYPCZ(P, 1.0, -omegaold * beta, beta, R, V);CHKERRQ(ierr);   /* p <- r - omega*beta*v + beta*p */
-    done = PETSC_FALSE;
-    if (fusedpc) {                                               /* v <- K p and (v,rp) */
-      PetscBool scaled = PETSC_FALSE;                            /* PCJACOBI: the scaling in the product's epilogue, then a plain dot */
-      if (D) { ierr = mat_mult_diagonal_scale(Amat, D, P, V, &scaled);CHKERRQ(ierr); }
-      if (!scaled) {
-        ierr = KSP_MatMult(ksp, Amat, P, T);CHKERRQ(ierr);
-        ierr = F->pmult_dot(V, T, D, RP, &d1, &done);CHKERRQ(ierr);
-        if (!done) { ierr = KSP_PCApply(ksp, T, V);CHKERRQ(ierr); }
-      }
-    } else { ierr = KSP_PCApplyBAorAB(ksp, P, V, T);CHKERRQ(ierr); }
-    if (!done) { ierr = VecDot(V, RP, &d1);CHKERRQ(ierr); }
+    ierr = KSP_PCApplyBAorAB(ksp, P, V, T);CHKERRQ(ierr);        /* v <- K p */
+    ierr = VecDot(V, RP, &d1);CHKERRQ(ierr);
     if (d1 == 0.0) SETERRQ(ksp->comm, PETSC_ERR_PLIB, "Divide by zero");
     alpha = rho / d1;
     ierr = VecWAXPY(S, -alpha, V, R);CHKERRQ(ierr);              /* s <- r - a v */
-    done = PETSC_FALSE;
-    if (fusedpc) {                                               /* t <- K s and (s,t), (t,t) */
-      PetscBool scaled = PETSC_FALSE;
-      if (D) { ierr = mat_mult_diagonal_scale(Amat, D, S, T, &scaled);CHKERRQ(ierr); }
-      if (!scaled) {
-        ierr = KSP_MatMult(ksp, Amat, S, R);CHKERRQ(ierr);
-        ierr = F->pmult_dotnorm2(T, R, D, S, &d1, &d2, &done);CHKERRQ(ierr);
-        if (!done) { ierr = KSP_PCApply(ksp, R, T);CHKERRQ(ierr); }
-      }
-    } else { ierr = KSP_PCApplyBAorAB(ksp, S, T, R);CHKERRQ(ierr); }
-    if (!done) { ierr = VecDotNorm2(S, T, &d1, &d2);CHKERRQ(ierr); }
+    ierr = KSP_PCApplyBAorAB(ksp, S, T, R);CHKERRQ(ierr);        /* t <- K s */
+    ierr = VecDotNorm2(S, T, &d1, &d2);CHKERRQ(ierr);
     if (d2 == 0.0) {
       /* t is 0: if s is 0 too, alpha p may be the solution */
       ierr = VecDot(S, S, &d1);CHKERRQ(ierr);
@@ -756,29 +613,25 @@ static PetscErrorCode KSPSolve_BCGS(KSP ksp) {
       break;
     }
     omega = d1 / d2;                                             /* w <- (t's)/(t't) */
-    done = PETSC_FALSE;
-    if (fusedpc) {                                               /* x, r, (r,r) and the next (r,rp) in one sweep */
-      PetscScalar rr, rhonext;
-      ierr = F->bcgs_update(X, R, P, S, T, RP, alpha, omega, &rr, &rhonext, &done);CHKERRQ(ierr);
-      if (done) { dp = nonorm ? 0.0 : PetscSqrtReal(rr); rhoold = rho; rho = rhonext; have_rho = PETSC_TRUE; }
-    }
-    if (!done) {
-      ierr = VecAXPBYPCZ(X, alpha, omega, 1.0, P, S);CHKERRQ(ierr);/* x <- alpha*p + omega*s + x */
-      ierr = VecWAXPY(R, -omega, T, S);CHKERRQ(ierr);            /* r <- s - w t */
-      if (!nonorm) { ierr = VecNorm(R, NORM_2, &dp);CHKERRQ(ierr); }
-      rhoold = rho;
-    }
+    ierr = VecAXPBYPCZ(X, alpha, omega, 1.0, P, S);CHKERRQ(ierr);/* x <- alpha*p + omega*s + x */
+    ierr = VecWAXPY(R, -omega, T, S);CHKERRQ(ierr);              /* r <- s - w t */
+    if (!nonorm) { ierr = VecNorm(R, NORM_2, &dp);CHKERRQ(ierr); }
+    rhoold = rho;
     omegaold = omega;
     ksp->its++;
     ksp->rnorm = dp;
     KSPLogResidualHistory(ksp, dp);
     ierr = KSPMonitor(ksp, i + 1, dp);CHKERRQ(ierr);
-    ierr = KSPDefaultConverged(ksp, i + 1, dp, &ksp->reason);CHKERRQ(ierr);
+    ierr = (*ksp->converged)(ksp, i + 1, dp, &ksp->reason, ksp->cnvP);CHKERRQ(ierr);
     if (ksp->reason) break;
-    if ((have_rho ? rhoold : rho) == 0.0) { ksp->reason = KSP_DIVERGED_BREAKDOWN; break; }   /* bcgs.c:146: the rho this iteration used */
+    if (rho == 0.0) { ksp->reason = KSP_DIVERGED_BREAKDOWN; break; }   /* bcgs.c:146 */
     i++;
   } while (i < ksp->max_it);
   if (i >= ksp->max_it) ksp->reason = KSP_DIVERGED_ITS;
   return 0;
 }
-PetscErrorCode KSPCreate_BCGS(KSP ksp) { ksp->ops->setup = KSPSetUp_BCGS; ksp->ops->solve = KSPSolve_BCGS; return 0; }
+PetscErrorCode KSPCreate_BCGS(KSP ksp) {   /* bcgs.c:246 (left preconditioning only on the ported path) */
+  ksp->normsupporttable[KSP_NORM_PRECONDITIONED][PC_LEFT] = 2;
+  ksp->ops->setup = KSPSetUp_BCGS; ksp->ops->solve = KSPSolve_BCGS;
+  return 0;
+}

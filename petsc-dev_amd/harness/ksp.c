@@ -18,7 +18,43 @@ PetscErrorCode KSPCreate(PetscComm comm, KSP *inksp) {   /* itcreate.c:640-700 *
   ksp->max_it = 10000; ksp->pc_side = PC_SIDE_DEFAULT; ksp->rtol = 1.e-5; ksp->abstol = 1.e-50; ksp->divtol = 1.e4;
   ksp->chknorm = -1; ksp->normtype = KSP_NORM_DEFAULT; ksp->rnorm = 0.0; ksp->its = 0; ksp->guess_zero = PETSC_TRUE;
   ksp->reason = KSP_CONVERGED_ITERATING;
+  ksp->converged = KSPDefaultConverged;
   *inksp = ksp;
+  return 0;
+}
+
+/* KSPSetSupportedNorm / KSPNormSupportTableReset_Private, itcreate.c:309-372: every KSPCreate_XXX declares the (norm, side)
+ * pairs it can run with a preference; KSP_NORM_NONE is supported by every type unless it says otherwise */
+PetscErrorCode KSPSetSupportedNorm(KSP ksp, KSPNormType normtype, PCSide pcside, PetscInt priority) {
+  KSPValid(ksp);
+  ksp->normsupporttable[normtype][pcside] = priority;
+  return 0;
+}
+static void ksp_norm_table_reset(KSP ksp) {
+  memset(ksp->normsupporttable, 0, sizeof(ksp->normsupporttable));
+  ksp->normsupporttable[KSP_NORM_NONE][PC_LEFT] = 1;
+  ksp->normsupporttable[KSP_NORM_NONE][PC_RIGHT] = 1;
+}
+static const char *const norm_names[] = {"NONE", "PRECONDITIONED", "UNPRECONDITIONED", "NATURAL"}, *const side_names[] = {"LEFT", "RIGHT", "SYMMETRIC"};
+/* KSPSetUpNorms_Private, itcreate.c:341-372: the best supported pair among those the user's choices leave open */
+static PetscErrorCode ksp_setup_norms(KSP ksp) {
+  PetscInt best = 0, ibest = 0, jbest = 0;
+  for (PetscInt i = 0; i < KSP_NORM_MAX; i++)
+    for (PetscInt j = 0; j < PC_SIDE_MAX; j++) {
+      if (ksp->normtype != KSP_NORM_DEFAULT && (PetscInt)ksp->normtype != i) continue;
+      if (ksp->pc_side != PC_SIDE_DEFAULT && (PetscInt)ksp->pc_side != j) continue;
+      if (ksp->normsupporttable[i][j] <= best) continue;
+      if (ksp->normtype == KSP_NORM_DEFAULT && i == KSP_NORM_NONE && ksp->normsupporttable[i][j] <= 1) continue;   /* no norm is never the silent default (preonly asks for it with 2) */
+      best = ksp->normsupporttable[i][j]; ibest = i; jbest = j;
+    }
+  if (best < 1) {
+    if (ksp->normtype == KSP_NORM_DEFAULT && ksp->pc_side == PC_SIDE_DEFAULT) SETERRQ(ksp->comm, PETSC_ERR_PLIB, "The %s KSP implementation did not call KSPSetSupportedNorm()", ksp->type_name);
+    if (ksp->normtype == KSP_NORM_DEFAULT) SETERRQ(ksp->comm, PETSC_ERR_SUP, "KSP %s does not support %s", ksp->type_name, side_names[ksp->pc_side]);
+    if (ksp->pc_side == PC_SIDE_DEFAULT) SETERRQ(ksp->comm, PETSC_ERR_SUP, "KSP %s does not support %s", ksp->type_name, norm_names[ksp->normtype]);
+    SETERRQ(ksp->comm, PETSC_ERR_SUP, "KSP %s does not support %s with %s", ksp->type_name, norm_names[ksp->normtype], side_names[ksp->pc_side]);
+  }
+  ksp->normtype = (KSPNormType)ibest;
+  ksp->pc_side = (PCSide)jbest;
   return 0;
 }
 
@@ -44,8 +80,9 @@ PetscErrorCode KSPSetType(KSP ksp, KSPType type) {
       if (ksp->work) { ierr = VecDestroyVecs(ksp->nwork, &ksp->work);CHKERRQ(ierr); ksp->nwork = 0; }
       memset(ksp->ops, 0, sizeof(ksp->ops));
       ksp->data = NULL; ksp->setupcalled = 0;
-      ierr = (*ksp_types[i].fn)(ksp);CHKERRQ(ierr);
+      ksp_norm_table_reset(ksp);
       snprintf(ksp->type_name, sizeof(ksp->type_name), "%s", type);
+      ierr = (*ksp_types[i].fn)(ksp);CHKERRQ(ierr);
       return 0;
     }
   }
@@ -74,12 +111,35 @@ PetscErrorCode KSPSetTolerances(KSP ksp, PetscReal rtol, PetscReal abstol, Petsc
   return 0;
 }
 PetscErrorCode KSPSetInitialGuessNonzero(KSP ksp, PetscBool flg) { KSPValid(ksp); ksp->guess_zero = (PetscBool)!flg; return 0; }
-PetscErrorCode KSPSetNormType(KSP ksp, KSPNormType t) { KSPValid(ksp); ksp->normtype = t; return 0; }
+PetscErrorCode KSPSetNormType(KSP ksp, KSPNormType t) {   /* itcreate.c:221-235: no norm -> the test that only counts iterations */
+  KSPValid(ksp);
+  ksp->normtype = t;
+  if (t == KSP_NORM_NONE) ksp->converged = KSPSkipConverged;
+  else if (ksp->converged == KSPSkipConverged) ksp->converged = KSPDefaultConverged;
+  if (ksp->setupcalled == 2) ksp->setupcalled = 1;   /* have KSPSetUp look at the combination again */
+  return 0;
+}
 PetscErrorCode KSPSetPCSide(KSP ksp, PCSide side) {   /* itcreate.c KSPSetPCSide */
   KSPValid(ksp);
   if (side != PC_LEFT && side != PC_RIGHT) SETERRQ(ksp->comm, PETSC_ERR_SUP, "only left and right preconditioning are on the ported path");
   ksp->pc_side = side;
   if (ksp->setupcalled == 2) ksp->setupcalled = 1;
+  return 0;
+}
+/* KSPGMRESSetRestart / KSPGMRESSetCGSRefinementType, gmres.c:730,798: PetscTryMethod -- whatever KSP type composed the
+ * method answers, any other type ignores the call */
+PetscErrorCode KSPGMRESSetRestart(KSP ksp, PetscInt restart) {
+  PetscVoidFunction f = NULL;
+  KSPValid(ksp);
+  PetscErrorCode ierr = PetscObjectQueryFunction((PetscObject)ksp, "KSPGMRESSetRestart_C", &f);CHKERRQ(ierr);
+  if (f) { ierr = ((PetscErrorCode (*)(KSP, PetscInt))f)(ksp, restart);CHKERRQ(ierr); }
+  return 0;
+}
+PetscErrorCode KSPGMRESSetCGSRefinementType(KSP ksp, KSPGMRESCGSRefinementType type) {
+  PetscVoidFunction f = NULL;
+  KSPValid(ksp);
+  PetscErrorCode ierr = PetscObjectQueryFunction((PetscObject)ksp, "KSPGMRESSetCGSRefinementType_C", &f);CHKERRQ(ierr);
+  if (f) { ierr = ((PetscErrorCode (*)(KSP, KSPGMRESCGSRefinementType))f)(ksp, type);CHKERRQ(ierr); }
   return 0;
 }
 PetscErrorCode KSPSetOptionsPrefix(KSP ksp, const char prefix[]) {
@@ -115,12 +175,13 @@ PetscErrorCode KSPSetFromOptions(KSP ksp) {   /* itcl.c KSPSetFromOptions, the o
   }
   ierr = PetscOptionsGetString(ksp->prefix, "-ksp_norm_type", t, sizeof(t), &set);CHKERRQ(ierr);   /* itcl.c: KSPNormTypes[] */
   if (set) {
-    if (!strcmp(t, "none")) ksp->normtype = KSP_NORM_NONE;
-    else if (!strcmp(t, "preconditioned")) ksp->normtype = KSP_NORM_PRECONDITIONED;
-    else if (!strcmp(t, "unpreconditioned")) ksp->normtype = KSP_NORM_UNPRECONDITIONED;
-    else if (!strcmp(t, "natural")) ksp->normtype = KSP_NORM_NATURAL;
+    KSPNormType nt;
+    if (!strcmp(t, "none")) nt = KSP_NORM_NONE;
+    else if (!strcmp(t, "preconditioned")) nt = KSP_NORM_PRECONDITIONED;
+    else if (!strcmp(t, "unpreconditioned")) nt = KSP_NORM_UNPRECONDITIONED;
+    else if (!strcmp(t, "natural")) nt = KSP_NORM_NATURAL;
     else SETERRQ(ksp->comm, PETSC_ERR_ARG_UNKNOWN_TYPE, "Unknown norm type %s", t);
-    ksp->setupcalled = ksp->setupcalled == 2 ? 1 : ksp->setupcalled;   /* have KSPSetUp look at the combination again */
+    ierr = KSPSetNormType(ksp, nt);CHKERRQ(ierr);
   }
   if (ksp->ops->setfromoptions) { ierr = (*ksp->ops->setfromoptions)(ksp);CHKERRQ(ierr); }
   return 0;
@@ -148,23 +209,8 @@ PetscErrorCode KSPSetUp(KSP ksp) {   /* itfunc.c:175 */
   if (ksp->setupcalled == 2) return 0;
   if (!ksp->pc || !ksp->pc->mat) SETERRQ(ksp->comm, PETSC_ERR_ARG_WRONGSTATE, "Matrix must be set first");
   if (!ksp->setupcalled) { ierr = (*ksp->ops->setup)(ksp);CHKERRQ(ierr); }
-  /* norm type / side defaults (KSPSetUpNorms_Private, itcreate.c): left PC + preconditioned norm; right PC (GMRES
-   * only here) goes with the unpreconditioned norm, which is what its recurrence produces */
-  if (ksp->pc_side == PC_SIDE_DEFAULT) ksp->pc_side = PC_LEFT;
-  if (ksp->pc_side == PC_RIGHT && strcmp(ksp->type_name, KSPGMRES))
-    SETERRQ(ksp->comm, PETSC_ERR_SUP, "KSP %s with right preconditioning is outside the ported path (KSPGMRES has it)", ksp->type_name);
-  if (ksp->normtype == KSP_NORM_DEFAULT)
-    ksp->normtype = !strcmp(ksp->type_name, KSPPREONLY) ? KSP_NORM_NONE : (ksp->pc_side == PC_RIGHT ? KSP_NORM_UNPRECONDITIONED : KSP_NORM_PRECONDITIONED);
-  if (!strcmp(ksp->type_name, KSPGMRES)) {
-    if (ksp->normtype != (ksp->pc_side == PC_RIGHT ? KSP_NORM_UNPRECONDITIONED : KSP_NORM_PRECONDITIONED))
-      SETERRQ(ksp->comm, PETSC_ERR_SUP, "KSPGMRES: the norm follows the side (left: preconditioned, right: unpreconditioned)");
-  } else {
-    /* KSPSetNormType (itcreate.c:196-205): every norm with KSPCG; BiCGStab: preconditioned or none */
-    if (ksp->normtype != KSP_NORM_PRECONDITIONED && ksp->normtype != KSP_NORM_NONE && strcmp(ksp->type_name, KSPCG) && strcmp(ksp->type_name, KSPGROPPCG) && strcmp(ksp->type_name, KSPPIPECG))
-      SETERRQ(ksp->comm, PETSC_ERR_SUP, "KSP %s: only the preconditioned residual norm is on the ported path (unpreconditioned/natural: KSPCG)", ksp->type_name);
-    if (ksp->normtype == KSP_NORM_NONE && strcmp(ksp->type_name, KSPCG) && strcmp(ksp->type_name, KSPGROPPCG) && strcmp(ksp->type_name, KSPPIPECG) && strcmp(ksp->type_name, KSPBCGS) && strcmp(ksp->type_name, KSPPREONLY))
-      SETERRQ(ksp->comm, PETSC_ERR_SUP, "KSP %s with KSP_NORM_NONE is outside the ported path", ksp->type_name);
-  }
+  ierr = ksp_setup_norms(ksp);CHKERRQ(ierr);   /* itfunc.c:225 */
+  if (ksp->normtype == KSP_NORM_NONE) ksp->converged = KSPSkipConverged;
   ierr = PCSetUp(ksp->pc);CHKERRQ(ierr);
   ksp->setupcalled = 2;
   return 0;
@@ -253,6 +299,7 @@ PetscErrorCode KSPDestroy(KSP *pksp) {
   if (ksp->ops->destroy) { ierr = (*ksp->ops->destroy)(ksp);CHKERRQ(ierr); }
   if (ksp->work) { ierr = VecDestroyVecs(ksp->nwork, &ksp->work);CHKERRQ(ierr); }
   ierr = PCDestroy(&ksp->pc);CHKERRQ(ierr);
+  ierr = PetscObjectListDestroy_Private((PetscObject)ksp);CHKERRQ(ierr);
   free(ksp->res_hist_alloc);
   free(ksp); *pksp = NULL;
   return 0;
@@ -290,12 +337,17 @@ PetscErrorCode KSPInitialResidual(KSP ksp, Vec vsoln, Vec vt1, Vec vt2, Vec vres
   return 0;
 }
 
-/* KSPDefaultConverged, iterativ.c:702-783; with KSP_NORM_NONE the test installed by KSPSetNormType is
- * KSPSkipConverged (itcreate.c:228-229, iterativ.c:536-544): iterate until max_it, then KSP_CONVERGED_ITS */
-PetscErrorCode KSPDefaultConverged(KSP ksp, PetscInt n, PetscReal rnorm, KSPConvergedReason *reason) {
+/* KSPSkipConverged, iterativ.c:536-544: what KSPSetNormType(KSP_NORM_NONE) installs -- iterate until max_it */
+PetscErrorCode KSPSkipConverged(KSP ksp, PetscInt n, PetscReal rnorm, KSPConvergedReason *reason, void *ctx) {
+  (void)rnorm; (void)ctx;
+  *reason = (n >= ksp->max_it) ? KSP_CONVERGED_ITS : KSP_CONVERGED_ITERATING;
+  return 0;
+}
+/* KSPDefaultConverged, iterativ.c:702-783 */
+PetscErrorCode KSPDefaultConverged(KSP ksp, PetscInt n, PetscReal rnorm, KSPConvergedReason *reason, void *ctx) {
   PetscErrorCode ierr;
+  (void)ctx;
   *reason = KSP_CONVERGED_ITERATING;
-  if (ksp->normtype == KSP_NORM_NONE) { if (n >= ksp->max_it) *reason = KSP_CONVERGED_ITS; return 0; }
   if (!n) {
     if (!ksp->guess_zero) {
       PetscReal snorm = 0.0;
@@ -331,4 +383,8 @@ static PetscErrorCode KSPSolve_PREONLY(KSP ksp) {
   ksp->reason = KSP_CONVERGED_ITS;
   return 0;
 }
-PetscErrorCode KSPCreate_PREONLY(KSP ksp) { ksp->ops->setup = KSPSetUp_PREONLY; ksp->ops->solve = KSPSolve_PREONLY; return 0; }
+PetscErrorCode KSPCreate_PREONLY(KSP ksp) {   /* preonly.c:55-56 */
+  ksp->ops->setup = KSPSetUp_PREONLY; ksp->ops->solve = KSPSolve_PREONLY;
+  ksp->normsupporttable[KSP_NORM_NONE][PC_LEFT] = 2; ksp->normsupporttable[KSP_NORM_NONE][PC_RIGHT] = 1;
+  return 0;
+}

@@ -69,6 +69,13 @@ PetscErrorCode PCSetOperators(PC pc, Mat Amat, Mat Pmat, MatStructure flag) {
   if (pc->setupcalled == 2) pc->setupcalled = 1;
   return 0;
 }
+PetscErrorCode PCGetOperators(PC pc, Mat *Amat, Mat *Pmat, MatStructure *flag) {   /* precon.c PCGetOperators */
+  if (!pc) SETERRQ(0, PETSC_ERR_ARG_NULL, "Null PC");
+  if (Amat) *Amat = pc->mat;
+  if (Pmat) *Pmat = pc->pmat;
+  if (flag) *flag = SAME_NONZERO_PATTERN;
+  return 0;
+}
 PetscErrorCode PCSetFromOptions(PC pc) {
   PetscErrorCode ierr; char t[64]; PetscBool set;
   ierr = PetscOptionsGetString(pc->prefix, "-pc_type", t, sizeof(t), &set);CHKERRQ(ierr);
@@ -142,16 +149,6 @@ static PetscErrorCode PCApply_Jacobi(PC pc, Vec x, Vec y) {   /* jacobi.c:266-27
   PC_Jacobi *jac = (PC_Jacobi *)pc->data;
   return VecPointwiseMult(y, x, jac->diag);
 }
-/* for the fused CG update (krylov.c): the vector PCApply_Jacobi multiplies by, or NULL when pc is another type */
-PetscErrorCode PCJacobiGetInverseDiagonal_Private(PC pc, Vec *d) {
-  PetscErrorCode ierr;
-  *d = NULL;
-  if (!pc || pc->ops->apply != PCApply_Jacobi) return 0;
-  if (pc->setupcalled < 2) { ierr = PCSetUp(pc);CHKERRQ(ierr); }
-  *d = ((PC_Jacobi *)pc->data)->diag;
-  return 0;
-}
-PetscBool PCIsNone_Private(PC pc) { return (PetscBool)(pc && pc->ops->apply == PCApply_None); }
 static PetscErrorCode PCDestroy_Jacobi(PC pc) {
   PC_Jacobi *jac = (PC_Jacobi *)pc->data;
   if (jac) { PetscErrorCode ierr = VecDestroy(&jac->diag);CHKERRQ(ierr); free(jac); pc->data = NULL; }

@@ -174,6 +174,9 @@ struct _p_KSP {
   PetscBool guess_zero;
   KSPNormType normtype;
   PCSide pc_side;
+  PetscInt normsupporttable[KSP_NORM_MAX][PC_SIDE_MAX];   /* KSPSetSupportedNorm (kspimpl.h:52, itcreate.c:309-372) */
+  PetscErrorCode (*converged)(KSP, PetscInt, PetscReal, KSPConvergedReason *, void *);   /* kspimpl.h:87 */
+  void *cnvP;
   KSPConvergedReason reason;
   int setupcalled;
   PetscReal *res_hist; PetscInt res_hist_len, res_hist_max; PetscBool res_hist_reset; PetscReal *res_hist_alloc;
@@ -181,7 +184,9 @@ struct _p_KSP {
   PetscBool printreason;   /* -ksp_converged_reason */
   void *data;
 };
-PetscErrorCode KSPDefaultConverged(KSP ksp, PetscInt n, PetscReal rnorm, KSPConvergedReason *reason);
+PetscErrorCode KSPDefaultConverged(KSP ksp, PetscInt n, PetscReal rnorm, KSPConvergedReason *reason, void *ctx);   /* iterativ.c:702 */
+PetscErrorCode KSPSkipConverged(KSP ksp, PetscInt n, PetscReal rnorm, KSPConvergedReason *reason, void *ctx);      /* iterativ.c:536 */
+PetscErrorCode KSPSetSupportedNorm(KSP ksp, KSPNormType normtype, PCSide pcside, PetscInt priority);               /* itcreate.c:309 */
 PetscErrorCode KSPMonitor(KSP ksp, PetscInt it, PetscReal rnorm);
 PetscErrorCode KSPLogResidualHistory(KSP ksp, PetscReal norm);
 PetscErrorCode KSPDefaultGetWork(KSP ksp, PetscInt nw);
@@ -191,8 +196,6 @@ PetscErrorCode KSP_PCApply(KSP ksp, Vec x, Vec y);
 PetscErrorCode KSP_PCApplyBAorAB(KSP ksp, Vec x, Vec y, Vec w);
 PetscErrorCode KSPCreate_CG(KSP), KSPCreate_GROPPCG(KSP), KSPCreate_PIPECG(KSP), KSPCreate_GMRES(KSP), KSPCreate_BCGS(KSP), KSPCreate_PREONLY(KSP);
 PetscErrorCode PCCreate_None(PC), PCCreate_Jacobi(PC), PCCreate_BJacobi(PC);
-PetscBool PCIsNone_Private(PC pc);
-PetscErrorCode PCJacobiGetInverseDiagonal_Private(PC pc, Vec *d);   /* NULL unless pc is a set-up PCJACOBI */
 
 #include "petsckrylovfused.h"   /* the optional fused-kernel tables a Vec / Mat type may compose */
 

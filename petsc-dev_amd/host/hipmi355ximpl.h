@@ -192,5 +192,8 @@ PetscErrorCode MatGetVecs_HIPMI355X(Mat A, Vec *right, Vec *left);
 PetscErrorCode PCCreate_ILU_HIPMI355X(PC);
 PetscErrorCode PCCreate_ICC_HIPMI355X(PC);
 PetscErrorCode PCCreate_PBJacobi_HIPMI355X(PC);
+PetscErrorCode KSPCreate_CGHIPMI355X(KSP);
+PetscErrorCode KSPCreate_GMRESHIPMI355X(KSP);
+PetscErrorCode KSPCreate_BCGSHIPMI355X(KSP);
 
 #endif

@@ -41,6 +41,10 @@ PetscErrorCode PetscHIPMI355XRegisterAll(void) {
   ierr = MatRegister(MATMPIAIJHIPMI355X, 0, "MatCreate_MPIAIJHIPMI355X", MatCreate_MPIAIJHIPMI355X);CHKERRQ(ierr);
   ierr = MatRegister(MATAIJHIPMI355X, 0, "MatCreate_AIJHIPMI355X", MatCreate_AIJHIPMI355X);CHKERRQ(ierr);
   ierr = MatRegister(MATSEQBAIJHIPMI355X, 0, "MatCreate_SeqBAIJHIPMI355X", MatCreate_SeqBAIJHIPMI355X);CHKERRQ(ierr);
+  /* the plug-in's solvers are KSP types of their own; KSPCG / KSPGMRES / KSPBCGS stay whatever the object model has */
+  ierr = KSPRegister(KSPCGHIPMI355X, 0, "KSPCreate_CGHIPMI355X", KSPCreate_CGHIPMI355X);CHKERRQ(ierr);
+  ierr = KSPRegister(KSPGMRESHIPMI355X, 0, "KSPCreate_GMRESHIPMI355X", KSPCreate_GMRESHIPMI355X);CHKERRQ(ierr);
+  ierr = KSPRegister(KSPBCGSHIPMI355X, 0, "KSPCreate_BCGSHIPMI355X", KSPCreate_BCGSHIPMI355X);CHKERRQ(ierr);
 #if !defined(PETSCHIPMI355X_WITH_PETSC)
   /* the harness has no CPU types: the reference's generic names select the HIPMI355X implementation of the same shape
    * (with a real PETSc they keep meaning the CPU types, and -vec_type hipmi355x -mat_type aijhipmi355x select these) */

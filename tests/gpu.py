@@ -6,6 +6,20 @@ import numpy as np
 import petsc_dev_amd as pda
 
 
+# The plug-in's own solvers are KSP types of their own (petsc-dev_amd/host/kspfused.c); "cg" / "gmres" / "bcgs" are the harness's
+# plain restatement of the reference's KSPSolve_* (what an unchanged PETSc program drives over the same Vec/Mat ops).
+PRODUCT_KSP = {"cg": "cghipmi355x", "gmres": "gmreshipmi355x", "bcgs": "bcgshipmi355x"}
+_PLAIN_MARKS = {"cg": ("-ksp_cg_fused 0", "-ksp_cg_single_reduction"), "gmres": ("-ksp_gmres_fused 0",), "bcgs": ("-ksp_bcgs_fused 0",)}
+
+
+def ksp_type_for(ksp, opts=""):
+    """the product's solver for a method, unless the options ask for the reference's op-by-op sequence (-ksp_*_fused 0,
+    -ksp_cg_single_reduction): then the plain type, which is the independent restatement the product is compared with"""
+    if ksp in PRODUCT_KSP and not any(m in opts for m in _PLAIN_MARKS[ksp]):
+        return PRODUCT_KSP[ksp]
+    return ksp
+
+
 class Dev:
     def __init__(self):
         self.k = pda.load_kernels()

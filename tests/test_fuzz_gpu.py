@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 import orc
+from gpu import ksp_type_for
 
 pytestmark = pytest.mark.gpu
 
@@ -203,7 +204,7 @@ def test_ksp_random_small_systems(P, seed):
     k = P.KSP(comm=L.COMM_SELF)
     k.set_operators(Am)
     L.PetscOptionsClear()
-    L.PetscOptionsInsertString(("-ksp_type %s -pc_type %s -ksp_gmres_restart 12" % (ksp, pc)).encode())
+    L.PetscOptionsInsertString(("-ksp_type %s -pc_type %s -ksp_gmres_restart 12" % (ksp_type_for(ksp), pc)).encode())
     k.set_tolerances(rtol=1e-9, max_it=400)
     k.set_from_options()
     k.record_history()
@@ -239,7 +240,7 @@ def test_repeated_solves_are_bitwise_reproducible(P, ksp, pc):
         k = P.KSP(comm=L.COMM_SELF)
         k.set_operators(A)
         L.PetscOptionsClear()
-        L.PetscOptionsInsertString(("-ksp_type %s -pc_type %s -ksp_gmres_restart 10" % (ksp, pc)).encode())
+        L.PetscOptionsInsertString(("-ksp_type %s -pc_type %s -ksp_gmres_restart 10" % (ksp_type_for(ksp), pc)).encode())
         k.set_tolerances(rtol=1e-6, max_it=60)
         k.set_from_options(); k.record_history()
         k.solve(vb, vx)

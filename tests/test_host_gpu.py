@@ -14,6 +14,7 @@ import pytest
 
 import orc
 import problems as pb
+from gpu import ksp_type_for
 
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -498,7 +499,7 @@ def solve(P, ai, aj, aa, b, ksp, pc, x0=None, opts="", comm=None, mpi=False, **t
     k = P.KSP(comm=comm)
     k.set_operators(A)
     L.PetscOptionsClear()
-    L.PetscOptionsInsertString(("-ksp_type %s -pc_type %s %s" % (ksp, pc, opts)).encode())
+    L.PetscOptionsInsertString(("-ksp_type %s -pc_type %s %s" % (ksp_type_for(ksp, opts), pc, opts)).encode())
     if tol:
         k.set_tolerances(**tol)
     k.set_from_options()
@@ -1282,7 +1283,7 @@ def test_cg_jacobi_full_size_properties(P):
         x = one.duplicate(); L.VecSet(x.h, 0.0)
         k = P.KSP(comm=L.COMM_SELF)
         k.set_operators(A)
-        L.PetscOptionsClear(); L.PetscOptionsInsertString(("-ksp_type cg -pc_type jacobi " + opts).encode())
+        L.PetscOptionsClear(); L.PetscOptionsInsertString(("-ksp_type %s -pc_type jacobi %s" % (ksp_type_for("cg", opts), opts)).encode())
         k.set_tolerances(rtol=1e-8, max_it=5000)
         k.set_from_options()
         k.record_history()

@@ -81,11 +81,14 @@ PLUGIN_SOURCES = sorted(glob.glob(os.path.join(ROOT, "petsc-dev_amd/host/*.c")) 
                         glob.glob(os.path.join(ROOT, "integration/petsc-3.3/*.c")))
 
 
-@pytest.mark.parametrize("struct,ref_text", [("_VecOps", "vec"), ("_MatOps", "mat")])
+@pytest.mark.parametrize("struct,ref_text", [("_VecOps", "vec"), ("_MatOps", "mat"), ("_KSPOps", "ksp"), ("_PCOps", "pc")])
 def test_harness_function_tables_have_the_reference_signatures(struct, ref_text):
-    ref = slots(struct_body(REF_VEC if ref_text == "vec" else REF_MAT, struct))
+    ref_src = {"vec": REF_VEC, "mat": REF_MAT,
+               "ksp": strip_comments(read(os.path.join(REF, "include/petsc-private/kspimpl.h"))),
+               "pc": strip_comments(read(os.path.join(REF, "include/petsc-private/pcimpl.h")))}[ref_text]
+    ref = slots(struct_body(ref_src, struct))
     mine = slots(struct_body(HARNESS, struct))
-    assert len(ref) > 60 and len(mine) >= 15
+    assert (len(ref) > 60 and len(mine) >= 15) if ref_text in ("vec", "mat") else (len(ref) >= 10 and len(mine) >= 4)
     for name, sig in mine.items():
         assert name in ref, "slot %s of the harness's struct %s does not exist in the reference" % (name, struct)
         assert sig == ref[name], "slot %s: harness %s, reference %s" % (name, sig, ref[name])
@@ -94,6 +97,8 @@ def test_harness_function_tables_have_the_reference_signatures(struct, ref_text)
 def test_every_slot_the_plugin_assigns_exists_in_the_reference_tables():
     vec_ref = slots(struct_body(REF_VEC, "_VecOps"))
     mat_ref = slots(struct_body(REF_MAT, "_MatOps"))
+    ksp_ref = slots(struct_body(strip_comments(read(os.path.join(REF, "include/petsc-private/kspimpl.h"))), "_KSPOps"))
+    pc_ref = slots(struct_body(strip_comments(read(os.path.join(REF, "include/petsc-private/pcimpl.h"))), "_PCOps"))
     seen_vec, seen_mat = set(), set()
     for path in PLUGIN_SOURCES:
         txt = strip_comments(read(path))
@@ -104,8 +109,11 @@ def test_every_slot_the_plugin_assigns_exists_in_the_reference_tables():
             elif var in ("B", "A"):
                 assert slot in mat_ref, "%s assigns Mat slot %s, which struct _MatOps of the reference does not have" % (os.path.basename(path), slot)
                 seen_mat.add(slot)
+            elif var == "ksp":
+                assert slot in ksp_ref, "%s assigns KSP slot %s, which struct _KSPOps of the reference does not have" % (os.path.basename(path), slot)
             else:
                 assert var == "pc", (path, var, slot)
+                assert slot in pc_ref, "%s assigns PC slot %s, which struct _PCOps of the reference does not have" % (os.path.basename(path), slot)
     # the slots the reference's own GPU subclasses override are all there (veccusp.cu:1915-1941, aijcusp.cu:665-676)
     assert {"dot", "norm", "tdot", "scale", "copy", "set", "swap", "axpy", "axpby", "axpbypcz", "pointwisemult", "pointwisedivide",
             "maxpy", "mdot", "aypx", "waxpy", "dotnorm2", "placearray", "resetarray", "destroy", "duplicate",

@@ -80,7 +80,7 @@ def main():
         t = tms.value / nl.value * 1e-3
         print("IRR spmv: %.3f ms  %.1f GB/s algorithmic (%.3f of 8 TB/s)" % (t * 1e3, B / t / 1e9, B / t / 8e12), flush=True)
         ksp = P.KSP(comm=L.COMM_SELF)
-        ksp.set_operators(A); ksp.set_type("gmres"); ksp.set_pc_type("bjacobi")
+        ksp.set_operators(A); ksp.set_type("gmreshipmi355x"); ksp.set_pc_type("bjacobi")
         L.PetscOptionsClear(); L.PetscOptionsInsertString(b"-sub_pc_type jacobi")   # all-device sub-solve
         ksp.set_from_options()
         ksp.set_tolerances(rtol=0.0, abstol=1e-300, dtol=1e300, max_it=10)

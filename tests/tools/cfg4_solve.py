@@ -29,7 +29,7 @@ def main():
     b = x.duplicate(); u = x.duplicate()
     A.mult(x, b)
     ksp = P.KSP(comm=L.COMM_SELF)
-    ksp.set_operators(A); ksp.set_type("gmres")
+    ksp.set_operators(A); ksp.set_type("gmreshipmi355x")
     if sub == "ilu" and nblocks == 1:      # one rank: block Jacobi with one block and ILU(0) inside IS PCILU (the reference's default on one rank)
         ksp.set_pc_type("ilu")
     else:

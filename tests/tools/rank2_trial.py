@@ -46,7 +46,7 @@ def main():
     nrm = x.norm()
     ok3 = abs(nrm - np.linalg.norm(xg)) <= 1e-12 * nrm
     b = x.duplicate(); u = x.duplicate(); L.VecSet(u.h, 1.0); A.mult(u, b)
-    k = P.KSP(comm=comm); k.set_operators(A); k.set_type("cg"); k.set_pc_type("jacobi"); k.set_tolerances(rtol=1e-8); k.record_history()
+    k = P.KSP(comm=comm); k.set_operators(A); k.set_type("cghipmi355x"); k.set_pc_type("jacobi"); k.set_tolerances(rtol=1e-8); k.record_history()
     sol = x.duplicate()
     k.solve(b, sol)
     xr, hr, itsr, rr = orc.ksp_solve(gi, gj, ga, orc.spmv(gi, gj, ga, np.ones(N)), ksp="cg", pc="jacobi", rtol=1e-8)

@@ -7,6 +7,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 
 
+PRODUCT = {"cg": "cghipmi355x", "gmres": "gmreshipmi355x", "bcgs": "bcgshipmi355x"}   # the plug-in's own solvers; "-ksp_*_fused 0" selects the plain types
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 120
@@ -30,7 +33,7 @@ def main():
         ksp = P.KSP(comm=L.COMM_SELF)
         ksp.set_operators(A)
         L.PetscOptionsClear()
-        L.PetscOptionsInsertString(("-ksp_type %s -pc_type %s %s" % (ksp_t, pc_t, extra)).encode())
+        L.PetscOptionsInsertString(("-ksp_type %s -pc_type %s %s" % (PRODUCT.get(ksp_t, ksp_t) if "fused 0" not in extra else ksp_t, pc_t, extra)).encode())
         ksp.set_from_options()
         ksp.set_tolerances(rtol=0.0, abstol=1e-300, dtol=1e300, max_it=40)
         L.VecSet(x.h, 0.0); ksp.solve(b, x)
