@@ -2,14 +2,23 @@
 """bench.py -- KSP CG + Jacobi on the 3-D 7-point Poisson operator, 256^3 rows per GPU
 (BASELINE.json configs[1] at N=1; configs[2] = 512^3 in 8 z-slabs at N=8; weak scaling in between).
 
-A step = one CG iteration of the reference's KSPSolve_CG op sequence over the HIPMI355X Vec/Mat types:
+A step = one CG iteration (the reference's KSPSolve_CG recurrence, cg.c:180-281) over the HIPMI355X Vec/Mat types:
 1 SpMV (MatMult_SeqAIJ / MatMult_MPIAIJ with RCCL halo), 1 Jacobi apply, 2 dots, 1 norm, 2 axpy, 1 aypx.
-value = iterations/s x global unknowns (aggregates over ranks under weak scaling); ksp_its_per_sec and
-spmv_gbps carry BASELINE.json's two quantities as absolute numbers.  The two kernels that make up three quarters of an
-iteration -- the SpMV and the fused CG update -- are both timed with HIP events on the compute stream inside the timed solve
-(roofline_spmv, roofline_cg_update); roofline is whichever of the two took longer.  csr_streaming: the same solve with
-the matrix's value array streamed (value patterns switched off), measured in the same run.  cpu_baseline: the oracle's
-C restatement of the same solve on the host cores, bounded sample (rank 0, N=1 only).
+
+Three configurations of the same solve are timed in the same run (N=1; on several GPUs only the first):
+  headline          -ksp_type cghipmi355x (the plug-in's registered CG, fused sweeps), the matrix's VALUE ARRAY STREAMED
+                    (-mat_hipmi355x_value_patterns 0): what every matrix gets, constant coefficients or not.  value,
+                    ms_per_step, roofline, spmv_gbps, ksp_* describe THIS leg.
+  value_patterns    the same solver with the library's default for this matrix: P7 has constant coefficients, its rows come
+                    from a 27-entry dictionary and the product does not read the value array (bit-identical results).
+  op_by_op          -ksp_type cg: the plain restatement of PETSc's own KSPSolve_CG, one kernel per Vec/Mat call -- what an
+                    UNCHANGED PETSc program drives over the same types (value array streamed).
+
+Every fraction in the line is BYTES MOVED / time / 8 TB/s: PMC-measured bytes per launch (profiles/bench_pmc_summary.csv,
+quoted only while its stamp matches the kernel sources) or, failing that, the kernel's own byte model.  What the same time
+would be worth in the reference's algorithmic bytes (CSR 12 B/nnz + ..., 17 vector passes) is reported
+separately as effective_gbps_vs_reference_bytes and never as a fraction of the roof.
+cpu_baseline: the oracle's C restatement of the same solve on the host cores, bounded sample (rank 0, N=1 only).
 """
 import argparse
 import ctypes as C
@@ -22,6 +31,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
+PEAK_GBPS = 8000.0          # MI355X HBM3E (MI355X_MICROARCH.md)
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -33,6 +44,7 @@ def main():
     ap.add_argument("--cpu-its", type=int, default=20)
     ap.add_argument("--wide-planes", action="store_true", help="development: (2n)x(2n)x(n/4) rows per GPU instead of n^3 (N=8 is then the cube P7(2n))")
     ap.add_argument("--ksp-opts", default="", help="extra options-database string (development: e.g. '-ksp_cg_fused 2')")
+    ap.add_argument("--headline-only", action="store_true", help="development: skip the value_patterns and op_by_op legs")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -78,14 +90,16 @@ def main():
     A.mult(u, b)                                         # b = A * 1
     setup_s = time.time() - t0
 
-    ksp = P.KSP(comm=comm)
-    ksp.set_operators(A)
-    ksp.set_type("cg")
-    ksp.set_pc_type("jacobi")
-    if args.ksp_opts:
-        ksp.set_from_options()
+    def make_ksp(ksp_type):
+        k_ = P.KSP(comm=comm)
+        k_.set_operators(A)
+        k_.set_type(ksp_type)
+        k_.set_pc_type("jacobi")
+        if args.ksp_opts:
+            k_.set_from_options()
+        return k_
 
-    # the dominant kernel: SpMV of the (diagonal block of the) matrix
+    # the kernel the matrix part of a step runs: SpMV of the (diagonal block of the) matrix
     if world > 1:
         Ad = C.c_void_p()
         L.MatMPIAIJGetSeqAIJ(A.h, C.byref(Ad), None, None)
@@ -96,7 +110,7 @@ def main():
     else:
         nnz_k = nnz_loc
         timed = A.h
-    spmv_bytes = 12 * nnz_k + 4 * (mloc + 1) + 8 * mloc + 8 * mloc
+    spmv_ref_bytes = 12 * nnz_k + 4 * (mloc + 1) + 8 * mloc + 8 * mloc     # the reference CSR's algorithmic bytes
 
     def barrier():
         if dist is not None:
@@ -104,7 +118,7 @@ def main():
 
     k = pda.load_kernels()
 
-    def timed_solve():
+    def timed_solve(ksp):
         """W untimed iterations (the first call also uploads the matrix and builds the Jacobi diagonal), then exactly K timed ones"""
         ksp.set_tolerances(rtol=0.0, abstol=1e-300, dtol=1e300, max_it=max(args.warmup, 1))
         ksp.solve(b, x)
@@ -133,41 +147,97 @@ def main():
             t = torch.tensor([dt, spmv_ms, upd_ms], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt, spmv_ms, upd_ms = float(t[0]), float(t[1]), float(t[2])
-        return dt, spmv_ms, nl.value, upd_ms, nu.value
+        return {"dt": dt, "spmv_ms": spmv_ms, "spmv_launches": nl.value, "upd_ms": upd_ms, "upd_launches": nu.value}
 
-    dt, spmv_ms, spmv_launches, upd_ms, upd_launches = timed_solve()
-
-    its_per_s = args.steps / dt
-    unknowns = mloc * world
-    value = its_per_s * unknowns / 1e6
-    if os.environ.get("BENCH_NO_SPMV_EVENTS"):
-        print("no-events run: %.5f ms/step" % (dt / args.steps * 1e3), flush=True)
-        return
-    spmv_gbps_one = spmv_bytes / (spmv_ms * 1e-3) / 1e9
-    cg_bytes = spmv_bytes + 136 * mloc                                   # unfused CG+Jacobi op sequence
-    noff = C.c_int(0)
+    # ---- which SpMV kernel the analysis chose for this matrix, and what each one moves per launch (its own byte model) ----
+    noff, npat, nvpat = C.c_int(0), C.c_int(0), C.c_int(0)
+    L.MatHIPMI355XSetValuePatterns(timed, 1)
+    ksp_fused = make_ksp("cghipmi355x")
+    ksp_fused.set_tolerances(rtol=0.0, abstol=1e-300, dtol=1e300, max_it=1)
+    ksp_fused.solve(b, x)                                # first use: upload + analysis
     L.MatHIPMI355XGetIndexCompression(timed, C.byref(noff))
-    npat = C.c_int()
     L.MatHIPMI355XGetRowPatterns(timed, C.byref(npat))
-    nvpat = C.c_int()
     L.MatHIPMI355XGetValuePatterns(timed, C.byref(nvpat))
 
-    def streamed_kernel_name():
+    def spmv_kernel(value_patterns):
+        """(kernel name for the JSON, tag in rocprofv3's kernel names, modelled bytes moved per launch: matrix stream + x once + y once)"""
+        vec = 8 * mloc + 8 * mloc
+        if value_patterns and nvpat.value:
+            return ("spmv_csr_valpat_kernel (%d distinct rows {offsets, values} in a dictionary, 2 bytes per row; the value array is not read)" % nvpat.value,
+                    "spmv_csr_valpat_kernel<0>", 2 * mloc + vec)
         if npat.value:
-            return "spmv_csr_rowblock_pat_kernel (CSR values + a %d-list row-pattern dictionary: one 4-byte word per row instead of column indices and row pointer; 'achieved' uses the CSR algorithmic bytes)" % npat.value
+            return ("spmv_csr_rowblock_pat_kernel (CSR values + a %d-list row-pattern dictionary: 8 B per nonzero + one 4-byte word per row)" % npat.value,
+                    "spmv_csr_rowblock_pat_kernel<0>", 8 * nnz_k + 4 * mloc + vec)
         if noff.value:
-            return "spmv_csr_rowblock_idx8_kernel (CSR + 1-byte offset-dictionary column indices, %d offsets; 'achieved' uses the CSR algorithmic bytes)" % noff.value
-        return "spmv_csr_rowblock_kernel"
+            return ("spmv_csr_rowblock_idx8_kernel (CSR values + 1-byte offset-dictionary column indices, %d offsets)" % noff.value,
+                    "spmv_csr_rowblock_idx8_kernel<0,", 9 * nnz_k + 4 * (mloc + 1) + vec)
+        return ("spmv_csr_rowblock_kernel (plain CSR)", "spmv_csr_rowblock_kernel<0,", 12 * nnz_k + 4 * (mloc + 1) + vec)
 
-    if nvpat.value:
-        kernel_name = ("spmv_csr_valpat_kernel (constant-coefficient operator: %d distinct rows {offsets, values} in a dictionary, 2 bytes per row, "
-                       "the value array is not read; 'achieved' uses the CSR algorithmic bytes)" % nvpat.value)
-    elif npat.value:
-        kernel_name = "spmv_csr_rowblock_pat_kernel (CSR values + a %d-list row-pattern dictionary: one 4-byte word per row instead of column indices and row pointer; 'achieved' uses the CSR algorithmic bytes)" % npat.value
-    elif noff.value:
-        kernel_name = "spmv_csr_rowblock_idx8_kernel (CSR + 1-byte offset-dictionary column indices, %d offsets; 'achieved' uses the CSR algorithmic bytes)" % noff.value
-    else:
-        kernel_name = "spmv_csr_rowblock_kernel"
+    # ---- PMC-measured bytes per launch, while the committed summary describes THESE kernel sources ----
+    pmc = {}
+    pmc_note = None
+    try:
+        import csv
+        import hashlib
+        pmc_csv = os.path.join(ROOT, "profiles", "bench_pmc_summary.csv")
+        head = open(pmc_csv).readline()
+        for src in ("spmv_csr.hip", "vec_kernels.hip"):
+            h16 = hashlib.sha256(open(os.path.join(ROOT, "petsc-dev_amd", "csrc", src), "rb").read()).hexdigest()[:16]
+            if ("%s sha256/16 = %s" % (src, h16)) not in head:
+                raise RuntimeError("stale PMC summary")
+        if n == 256 and world == 1:
+            with open(pmc_csv) as f:
+                f.readline()
+                for row in csv.DictReader(f):
+                    pmc[(row["kernel"], row["counter"])] = float(row["avg_value_KB"])
+            pmc_note = ("profiles/bench_pmc_summary.csv: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of this command with these "
+                        "kernel sources; bytes per launch = 2 x FETCH_SIZE (gfx950 counts 64-B units as 32) + WRITE_SIZE")
+    except Exception:
+        pmc = {}
+
+    def pmc_bytes(tag):
+        f = [v for (kn, c), v in pmc.items() if tag in kn and c == "FETCH_SIZE"]
+        w = [v for (kn, c), v in pmc.items() if tag in kn and c == "WRITE_SIZE"]
+        return int((2.0 * f[0] + w[0]) * 1024) if len(f) == 1 and len(w) == 1 else None
+
+    def kernel_roofline(name, tag, model_bytes, ref_bytes, ms, launches):
+        """one kernel against the HBM roof in bytes it MOVED (PMC if stamped, else its byte model)"""
+        measured = pmc_bytes(tag)
+        moved = measured if measured is not None else model_bytes
+        gbps = moved / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        return {"bound": "hbm", "kernel": name, "achieved": round(gbps, 1), "peak": PEAK_GBPS, "unit": "GB/s", "frac": round(gbps / PEAK_GBPS, 4),
+                "traffic": measured, "bytes_moved_per_launch": moved, "bytes_moved_basis": "pmc" if measured is not None else "kernel byte model",
+                "bytes_model_per_launch": model_bytes, "avg_launch_ms": round(ms, 5), "launches_timed": launches,
+                "reference_algorithmic_bytes_per_launch": ref_bytes,
+                "effective_gbps_vs_reference_bytes": round(ref_bytes / (ms * 1e-3) / 1e9, 1) if ms > 0 else 0.0,
+                **({"traffic_source": pmc_note} if measured is not None else {})}
+
+    def leg(ksp, value_patterns, vec_passes, what):
+        """time one configuration; its/s, and the step / its two main kernels in bytes moved"""
+        L.MatHIPMI355XSetValuePatterns(timed, 1 if value_patterns else 0)
+        t = timed_solve(ksp)
+        its = args.steps / t["dt"]
+        name, tag, model = spmv_kernel(value_patterns)
+        r_spmv = kernel_roofline(name, tag, model, spmv_ref_bytes, t["spmv_ms"], t["spmv_launches"])
+        step_moved = r_spmv["bytes_moved_per_launch"] + vec_passes * 8 * mloc
+        out = {"what": what, "ksp_its_per_sec": round(its, 2), "value": round(its * mloc * world / 1e6, 3), "ms_per_step": round(t["dt"] / args.steps * 1e3, 5),
+               "vector_passes_per_step": vec_passes, "bytes_moved_per_step": step_moved,
+               "ksp_gbps": round(step_moved * its * world / 1e9, 1), "ksp_hbm_frac": round(step_moved * its / 1e9 / PEAK_GBPS, 4),
+               "spmv": r_spmv}
+        if t["upd_launches"]:
+            # fused CG update: x += a p, r -= a w, z = d .* r, z'z, z'r, r'r in one sweep = 8 vector passes (reads x p r w d, writes x r z);
+            # the reference's five calls (VecAXPY x2, PCApply_Jacobi, VecNorm, VecTDot; cg.c:206-232) make 12
+            out["cg_update"] = kernel_roofline("reduce_kernel<4, 0, CGUpdateDevF> (fused CG update, 8 vector passes)", "CGUpdateDevF", 8 * 8 * mloc, 12 * 8 * mloc,
+                                               t["upd_ms"], t["upd_launches"])
+        return out, t
+
+    # ---- leg 1, the headline: registered fused CG, value array streamed ----
+    head, th = leg(ksp_fused, False, 13, "-ksp_type cghipmi355x -mat_hipmi355x_value_patterns 0: fused CG sweeps, the SpMV streams the value array")
+    if os.environ.get("BENCH_NO_SPMV_EVENTS"):
+        print("no-events run: %.5f ms/step" % head["ms_per_step"], flush=True)
+        return
+    its_per_s = head["ksp_its_per_sec"]
+    unknowns = mloc * world
     if world > 1:
         tr = PD.transport_report(comm)                   # asked of the C library: what the halo and the reductions travelled over
     else:
@@ -175,103 +245,54 @@ def main():
     staged = world > 1 and tr["transport"] != "rccl"
     if world > 1 and not staged:
         assert tr["rccl_ranks"] == world, "RCCL reports %d ranks, launched %d" % (tr["rccl_ranks"], world)
+    cg_ref_bytes = spmv_ref_bytes + 136 * mloc           # the reference's unfused CG+Jacobi iteration (SpMV + 17 vector passes)
     out = {
         "metric": "KSP CG+Jacobi iterations/s x unknowns (3-D 7-pt Poisson, %d^3 rows per GPU); ksp_its_per_sec and spmv_gbps are BASELINE.json's two quantities" % n,
-        "value": round(value, 3), "unit": "Mdof-it/s",
+        "value": head["value"], "unit": "Mdof-it/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(dt / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "3D 7-pt Poisson P7(%d,%d,%d) = %d rows, %s, KSPCG + PCJACOBI, b = A*1, x0 = 0, exactly K iterations"
+        "config": {"workload": "3D 7-pt Poisson P7(%d,%d,%d) = %d rows, %s, CG + PCJACOBI (-ksp_type cghipmi355x), value array streamed, b = A*1, x0 = 0, exactly K iterations"
                    % (nx, ny, nz, unknowns, "MatSeqAIJ on 1 GPU" if world == 1 else "MatMPIAIJ in %d z-slabs, %s" % (world, "HOST-STAGED halo and reductions (one-GPU rehearsal, not a measurement)" if staged else "RCCL halo")),
                    "rows_per_gpu": mloc, "nnz_per_gpu": nnz_loc, "parallelism": "row-block dp%d" % world,
                    "transport": tr["transport"], "rccl_ranks": tr["rccl_ranks"], "rccl_communicators": tr["rccl_communicators"]},
-        "ksp_its_per_sec": round(its_per_s, 2),
-        "spmv_gbps": round(spmv_gbps_one * world, 1),
-        "ksp_gbps": round(cg_bytes * its_per_s * world / 1e9, 1),
-        "ksp_hbm_frac": round(cg_bytes * its_per_s / 8e12, 4),
-        "ksp_gbps_basis": "SURVEY 8(d) algorithmic bytes of the reference's op-by-op iteration (SpMV + 17 vector passes); the fused CG update moves 13 passes",
+        "ksp_its_per_sec": its_per_s,
+        "spmv_gbps": round(head["spmv"]["achieved"] * world, 1),
+        "spmv_gbps_basis": "bytes the SpMV kernel moved (%s) / its average launch time inside the timed solve, summed over GPUs" % head["spmv"]["bytes_moved_basis"],
+        "ksp_gbps": head["ksp_gbps"], "ksp_hbm_frac": head["ksp_hbm_frac"],
+        "ksp_gbps_basis": "bytes moved per step = SpMV (as above) + 13 vector passes of the fused iteration (AYPX 3, dot 2, fused update 8)",
+        "effective_gbps_vs_reference_bytes": {"spmv": round(head["spmv"]["effective_gbps_vs_reference_bytes"] * world, 1),
+                                              "ksp": round(cg_ref_bytes * its_per_s * world / 1e9, 1),
+                                              "what": "the same times priced in the REFERENCE's algorithmic bytes (SURVEY 8d: CSR 12 B/nnz + 4 B/row + x + y = %d B per SpMV; "
+                                                      "SpMV + 17 vector passes = %d B per op-by-op iteration); not a fraction of any roof" % (spmv_ref_bytes, cg_ref_bytes)},
         "setup_s": round(setup_s, 2),
     }
-    BASIS = ("achieved/frac price the launch in the reference's bytes (SURVEY 8d: 12 B per nonzero + 4 B per row + x + y for the CSR "
-             "product; the op-by-op vector passes for the update); a kernel that moves fewer bytes than the reference's sequence can "
-             "exceed 1.0 on that basis -- traffic / traffic_frac are the bytes it really moved")
-    # the SpMV (the kernel SURVEY 8d prices) ...
-    r_spmv = {"bound": "hbm", "kernel": kernel_name, "achieved": round(spmv_gbps_one, 1), "peak": 8000.0,
-              "unit": "GB/s", "frac": round(spmv_gbps_one / 8000.0, 4), "traffic": None, "basis": BASIS,
-              "algorithmic_bytes_per_launch": spmv_bytes, "avg_launch_ms": round(spmv_ms, 5), "launches_timed": spmv_launches}
-    if nvpat.value:
-        r_spmv["limiter"] = ("not HBM: with the value array out of the way the launch moves ~0.36 GB (ideal 0.30: x once, y once, 2 B per row) and is bound "
-                             "by the latency chain row word -> table -> gathers -> store at full occupancy (DESIGN.md section 4, 'Value patterns'); traffic_frac says how far from the memory roof it runs")
-    # ... and the fused CG update (VecAXPY, VecAXPY, PCApply_Jacobi, VecNorm, VecTDot of cg.c:206-232 in one sweep): the
-    # reference's five operations make 12 vector passes, the kernel 8 (reads x p r w d, writes x r z)
-    upd_bytes = 12 * 8 * mloc
-    upd_gbps = upd_bytes / (upd_ms * 1e-3) / 1e9 if upd_ms > 0 else 0.0
-    r_upd = {"bound": "hbm", "kernel": "reduce_kernel<4, 0, CGUpdateDevF> (x += a p, r -= a w, z = r .* d, z'z, z'r, r'r in one sweep; 'achieved' uses the "
-                                       "12 vector passes of the reference's five operations, the kernel makes 8)",
-             "achieved": round(upd_gbps, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(upd_gbps / 8000.0, 4), "traffic": None, "basis": BASIS,
-             "algorithmic_bytes_per_launch": upd_bytes, "avg_launch_ms": round(upd_ms, 5), "launches_timed": upd_launches}
+    # roofline = the dominant kernel of the headline step: whichever of the SpMV and the fused update took longer per launch
+    upd = head.get("cg_update")
+    dom_is_upd = bool(upd) and upd["avg_launch_ms"] > head["spmv"]["avg_launch_ms"]
+    out["roofline"] = dict(upd if dom_is_upd else head["spmv"])
+    out["roofline"]["dominant"] = "%s: %.4f ms per step against %.4f ms for %s" % (
+        ("the fused CG update", upd["avg_launch_ms"], head["spmv"]["avg_launch_ms"], "the SpMV") if dom_is_upd else
+        ("the SpMV", head["spmv"]["avg_launch_ms"], upd["avg_launch_ms"] if upd else 0.0, "the fused CG update"))
+    out["roofline_spmv"] = head["spmv"]
+    if upd:
+        out["roofline_cg_update"] = upd
+    out["legs"] = {"headline": {kk: vv for kk, vv in head.items() if kk not in ("spmv", "cg_update")}}
 
-    # HBM traffic of the two kernels from the committed rocprofv3 PMC passes of this command (separate
-    # FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE x2 on gfx950, calibration in profiles/r01_fetch_calibration.md)
-    try:
-        import csv
-        import hashlib
-        cnt = {}
-        pmc_csv = os.path.join(ROOT, "profiles", "bench_pmc_summary.csv")
-        # the counters are only quoted while they describe THESE kernels: the summary's first line carries the hashes of the
-        # kernel sources it was collected with (tests/tools/pmc_summary.py --stamp); a stale file is ignored
-        head = open(pmc_csv).readline()
-        for src in ("spmv_csr.hip", "vec_kernels.hip"):
-            h16 = hashlib.sha256(open(os.path.join(ROOT, "petsc-dev_amd", "csrc", src), "rb").read()).hexdigest()[:16]
-            if ("%s sha256/16 = %s" % (src, h16)) not in head:
-                raise RuntimeError("stale PMC summary")
-        spmv_tag = "spmv_csr_valpat_kernel<0>" if nvpat.value else "spmv_csr_rowblock"
-        with open(pmc_csv) as f:
-            f.readline()
-            for row in csv.DictReader(f):
-                kn = row["kernel"]
-                if spmv_tag in kn and ("kernel<0," in kn or "kernel<0>" in kn):                # the y = A x instantiation (ADD == 0)
-                    cnt[("spmv", row["counter"])] = float(row["avg_value_KB"])
-                elif "CGUpdateDevF" in kn:
-                    cnt[("upd", row["counter"])] = float(row["avg_value_KB"])
-        src_note = "profiles/bench_pmc_summary.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of this command with this kernel source; bytes per launch)"
-        if n == 256 and world == 1:
-            for key, r in (("spmv", r_spmv), ("upd", r_upd)):
-                if (key, "FETCH_SIZE") in cnt and (key, "WRITE_SIZE") in cnt and r["avg_launch_ms"] > 0:
-                    r["traffic"] = int((2.0 * cnt[(key, "FETCH_SIZE")] + cnt[(key, "WRITE_SIZE")]) * 1024)
-                    # what the kernel really moved per second: frac uses the reference's algorithmic bytes as the contract asks,
-                    # traffic_frac the measured bytes
-                    r["traffic_gbps"] = round(r["traffic"] / (r["avg_launch_ms"] * 1e-3) / 1e9, 1)
-                    r["traffic_frac"] = round(r["traffic_gbps"] / 8000.0, 4)
-                    r["kernel"] = r["kernel"].replace("'achieved' uses the", "'traffic' is what the kernel actually moved, 'achieved' uses the")
-                    r["traffic_source"] = src_note
-            if r_spmv["traffic"] is not None:
-                # the whole iteration in bytes really moved: the SpMV's measured traffic + the 13 vector passes of the fused CG
-                # iteration (AYPX 3, dot 2, fused update 8), next to ksp_gbps / ksp_hbm_frac which price the reference's op-by-op bytes
-                moved = r_spmv["traffic"] + 13 * 8 * mloc
-                out["ksp_moved_gbps"] = round(moved / (out["ms_per_step"] * 1e-3) / 1e9, 1)
-                out["ksp_moved_frac"] = round(out["ksp_moved_gbps"] / 8000.0, 4)
-    except Exception:
-        pass
-    # roofline = the dominant kernel of the step: whichever of the two took longer per launch (one launch of each per step)
-    dom = r_upd if upd_ms > spmv_ms else r_spmv
-    out["roofline"] = dict(dom)
-    out["roofline"]["dominant"] = ("the fused CG update: %.4f ms per step against %.4f ms for the SpMV" % (upd_ms, spmv_ms)) if dom is r_upd else \
-                                  ("the SpMV: %.4f ms per step against %.4f ms for the fused CG update" % (spmv_ms, upd_ms))
-    out["roofline_spmv"] = r_spmv
-    out["roofline_cg_update"] = r_upd
-
-    # the same solve with the value array streamed (value patterns off): what the path does for an operator with varying
-    # coefficients, and the configuration BASELINE.json's spmv_gbps is defined on; same matrix, same run
-    if nvpat.value and world == 1:
-        L.MatHIPMI355XSetValuePatterns(timed, 0)
-        dt2, spmv_ms2, _, upd_ms2, _ = timed_solve()
+    if world == 1 and not args.headline_only:
+        # ---- leg 2: the library's default for THIS matrix (constant coefficients: rows from a dictionary) ----
+        if nvpat.value:
+            vp, _ = leg(ksp_fused, True, 13, "-ksp_type cghipmi355x, value patterns on (library default; P7 is a constant-coefficient operator): the SpMV does not read the value array; bit-identical results")
+            out["legs"]["value_patterns"] = vp
+        # ---- leg 3: what an unchanged PETSc program drives: KSPSolve_CG op by op (VecAYPX, MatMult, VecTDot, VecAXPY x2, PCApply, VecNorm, VecTDot) ----
+        ksp_plain = make_ksp("cg")
+        ob, _ = leg(ksp_plain, False, 17, "-ksp_type cg: the plain KSPSolve_CG sequence, one kernel per Vec/Mat call (17 vector passes), value array streamed")
+        if nvpat.value:
+            L.MatHIPMI355XSetValuePatterns(timed, 1)
+            t2 = timed_solve(ksp_plain)
+            ob["ksp_its_per_sec_with_value_patterns"] = round(args.steps / t2["dt"], 2)
+        out["legs"]["op_by_op"] = ob
         L.MatHIPMI355XSetValuePatterns(timed, 1)
-        g2 = spmv_bytes / (spmv_ms2 * 1e-3) / 1e9
-        out["csr_streaming"] = {"what": "the same %d iterations with -mat_hipmi355x_value_patterns 0: the SpMV streams the value array (%s)" % (args.steps, streamed_kernel_name().split(" (")[0]),
-                                "ksp_its_per_sec": round(args.steps / dt2, 2), "value": round(args.steps / dt2 * unknowns / 1e6, 3),
-                                "ms_per_step": round(dt2 / args.steps * 1e3, 5), "spmv_avg_launch_ms": round(spmv_ms2, 5),
-                                "spmv_gbps": round(g2, 1), "spmv_frac": round(g2 / 8000.0, 4), "cg_update_avg_launch_ms": round(upd_ms2, 5)}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import orc

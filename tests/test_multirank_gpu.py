@@ -49,7 +49,8 @@ def test_bench_two_ranks_rehearsal(built, wide):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 6 and d["warmup"] == 2 and d["scaling"] == "weak"
     assert d["config"]["rows_per_gpu"] == 40 ** 3 and d["value"] > 0 and d["roofline"]["avg_launch_ms"] > 0
-    assert "valpat_kernel" in d["roofline_spmv"]["kernel"]     # the diagonal block of the slab (constant coefficients) runs from the row dictionary
+    assert "rowblock_pat_kernel" in d["roofline_spmv"]["kernel"]     # the headline streams the value array of the slab's diagonal block (row-pattern kernel)
+    assert "cghipmi355x" in d["config"]["workload"] and 0 < d["roofline"]["frac"] < 1 and 0 < d["ksp_hbm_frac"] < 1
     assert d["roofline_spmv"]["avg_launch_ms"] > 0 and d["roofline_cg_update"]["avg_launch_ms"] > 0 and d["roofline_cg_update"]["launches_timed"] == 6
     assert d["config"]["transport"] == "host-staged" and "HOST-STAGED" in d["config"]["workload"]
     assert ("P7(80,80,20)" if wide else "P7(40,40,80)") in d["config"]["workload"]
