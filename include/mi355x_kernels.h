@@ -280,6 +280,12 @@ int mi355x_trisolve_plan_create_scaled(mi355x_handle_t h, int n, int nlev, const
 int mi355x_trisolve_plan_destroy(mi355x_trisolve_plan_t plan);
 int mi355x_trisolve_apply(mi355x_handle_t h, mi355x_trisolve_plan_t lower, mi355x_trisolve_plan_t upper, const double *b, double *y);
 int mi355x_trisolve_aborted(mi355x_trisolve_plan_t plan, int *aborted);
+/* the same application over the same plans with one launch per dependency level and no hand-off between wavefronts (same
+ * per-row order of the products: same bits): what a caller falls back to after a sync-free application gave up, whatever the
+ * factor (ILU(0), ICC(0)); does not consult or change the abort flags */
+int mi355x_trisolve_apply_levels(mi355x_handle_t h, mi355x_trisolve_plan_t lower, mi355x_trisolve_plan_t upper, const double *b, double *y);
+/* development / tests: raise a plan's abort flag as a dependency wait that gave up would */
+int mi355x_trisolve_debug_set_aborted(mi355x_trisolve_plan_t plan, int value);
 
 /* ---- halo pack / unpack (VecScatter) ---------------------------------- */
 /* Pack_1    src/vec/vec/utils/vpscat.c:493   buf[k] = x[idx[k]] */

@@ -60,6 +60,21 @@ typedef enum { SCATTER_FORWARD = 0, SCATTER_REVERSE = 1 } ScatterMode;          
 typedef enum { NORM_1 = 0, NORM_2 = 1, NORM_FROBENIUS = 2, NORM_INFINITY = 3, NORM_1_AND_2 = 4 } NormType; /* petscvec.h:155 */
 typedef enum { MAT_FLUSH_ASSEMBLY = 1, MAT_FINAL_ASSEMBLY = 0 } MatAssemblyType;               /* petscmat.h:347 */
 typedef enum { DIFFERENT_NONZERO_PATTERN, SUBSET_NONZERO_PATTERN, SAME_NONZERO_PATTERN, SAME_PRECONDITIONER } MatStructure;
+/* matrix factorisation interface (include/petscmat.h:100-131,1042-1088): the factored matrix is a Mat of its own, obtained from the
+ * operator with MatGetFactor, filled by a symbolic and a numeric call, applied with MatSolve */
+typedef enum { MAT_FACTOR_NONE, MAT_FACTOR_LU, MAT_FACTOR_CHOLESKY, MAT_FACTOR_ILU, MAT_FACTOR_ICC, MAT_FACTOR_ILUDT } MatFactorType;
+typedef enum { MAT_SHIFT_NONE, MAT_SHIFT_NONZERO, MAT_SHIFT_POSITIVE_DEFINITE, MAT_SHIFT_INBLOCKS } MatFactorShiftType;
+typedef struct {
+  PetscReal diagonal_fill, usedt, dt, dtcol, dtcount;
+  PetscReal fill;            /* expected fill */
+  PetscReal levels;          /* ICC/ILU(levels) */
+  PetscReal pivotinblocks;
+  PetscReal zeropivot;       /* pivot is called zero if less than this */
+  PetscReal shifttype;       /* MatFactorShiftType, stored as a real (petscmat.h:1072) */
+  PetscReal shiftamount;
+} MatFactorInfo;
+#define MatSolverPackage char *
+#define MATSOLVERPETSC "petsc"
 typedef enum { PC_SIDE_DEFAULT = -1, PC_LEFT, PC_RIGHT, PC_SYMMETRIC } PCSide;
 #define PC_SIDE_MAX 3    /* PC_SYMMETRIC + 1, petscpc.h:96 */
 typedef enum { KSP_NORM_DEFAULT = -1, KSP_NORM_NONE = 0, KSP_NORM_PRECONDITIONED = 1, KSP_NORM_UNPRECONDITIONED = 2, KSP_NORM_NATURAL = 3 } KSPNormType;
@@ -80,6 +95,7 @@ typedef struct _p_VecScatter *VecScatter;
 typedef struct _p_KSP        *KSP;
 typedef struct _p_PC         *PC;
 typedef struct _p_PetscViewer *PetscViewer;
+typedef struct _p_IS         *IS;           /* index set: only ever NULL here (the natural ordering) */
 typedef enum { FILE_MODE_READ, FILE_MODE_WRITE } PetscFileMode;
 typedef const char *VecType;
 typedef const char *MatType;
@@ -236,6 +252,16 @@ PetscErrorCode MatMultTransposeAdd(Mat A, Vec x, Vec y, Vec z);
 PetscErrorCode MatGetDiagonal(Mat A, Vec d);
 PetscErrorCode MatScale(Mat A, PetscScalar a);
 PetscErrorCode MatZeroEntries(Mat A);
+PetscErrorCode MatSetOptionsPrefix(Mat A, const char prefix[]);
+/* matrix.c:3937-4010 (MatGetFactor looks "MatGetFactor_<package>_C" up on the operator), 2766-3144 (symbolic / numeric), 3196 (MatSolve) */
+PetscErrorCode MatFactorInfoInitialize(MatFactorInfo *info);
+PetscErrorCode MatGetFactor(Mat mat, const MatSolverPackage type, MatFactorType ftype, Mat *f);
+PetscErrorCode MatGetFactorAvailable(Mat mat, const MatSolverPackage type, MatFactorType ftype, PetscBool *flg);
+PetscErrorCode MatILUFactorSymbolic(Mat fact, Mat mat, IS row, IS col, const MatFactorInfo *info);
+PetscErrorCode MatLUFactorNumeric(Mat fact, Mat mat, const MatFactorInfo *info);
+PetscErrorCode MatICCFactorSymbolic(Mat fact, Mat mat, IS perm, const MatFactorInfo *info);
+PetscErrorCode MatCholeskyFactorNumeric(Mat fact, Mat mat, const MatFactorInfo *info);
+PetscErrorCode MatSolve(Mat mat, Vec b, Vec x);
 PetscErrorCode MatDiagonalScale(Mat A, Vec l, Vec r);   /* A <- diag(l) A diag(r); l or r may be NULL (aij.c:2055, mpiaij.c:2183) */
 /* ---- binary IO (PETSc binary format, big-endian; src/mat/impls/aij/seq/aij.c:4093-4157, src/vec/vec/utils/vecio.c) ---- */
 PetscErrorCode PetscViewerBinaryOpen(PetscComm comm, const char name[], PetscFileMode mode, PetscViewer *viewer);
@@ -259,6 +285,7 @@ PetscErrorCode PCSetUp(PC pc);
 PetscErrorCode PCApply(PC pc, Vec x, Vec y);
 PetscErrorCode PCSetFromOptions(PC pc);
 PetscErrorCode PCDestroy(PC *pc);
+PetscErrorCode PCFactorGetMatrix(PC pc, Mat *mat);   /* the factored matrix of a PCILU / PCICC (precon.c PCFactorGetMatrix) */
 PetscErrorCode PCBJacobiGetSubKSP(PC pc, PetscInt *n_local, PetscInt *first_local, KSP **ksp);
 
 /* ---- KSP (include/petscksp.h) ---------------------------------------------------------------- */

@@ -83,6 +83,9 @@ PetscErrorCode MatCreate_SeqAIJHIPMI355X(Mat B) {
   B->ops->getvecs          = MatGetVecs_HIP;
   ierr = PetscObjectComposeFunction((PetscObject)B, "MatMultTDotBegin_C", "MatMultTDotBegin_HIPMI355X", (PetscVoidFunction)MatMultTDotBegin_HIPMI355X);CHKERRQ(ierr);
   ierr = PetscObjectComposeFunction((PetscObject)B, "MatMultDiagonalScale_C", "MatMultDiagonalScale_HIPMI355X", (PetscVoidFunction)MatMultDiagonalScale_HIPMI355X);CHKERRQ(ierr);
+  /* PETSc's own PCILU / PCICC / PCBJACOBI ask MatGetFactor(A, "petsc", ...): answered with a factored matrix whose ops->solve is the
+   * device triangular solve (host/ilu.c), as MatCreate_SeqAIJCUSPARSE overloads the same name (aijcusparse.cu:837-840) */
+  ierr = PetscObjectComposeFunction((PetscObject)B, "MatGetFactor_petsc_C", "MatGetFactor_seqaijhipmi355x_petsc", (PetscVoidFunction)MatGetFactor_seqaijhipmi355x_petsc);CHKERRQ(ierr);
   ierr = PetscObjectChangeTypeName((PetscObject)B, MATSEQAIJHIPMI355X);CHKERRQ(ierr);
   PetscFunctionReturn(0);
 }

@@ -101,6 +101,8 @@ struct mi355x_trisolve_plan_s {
   int *abort_flag;   // pinned + mapped
   int grid, sleep_cap;
   int by_level;      // rows in dependency-level order, levels on slice boundaries
+  int nlev;
+  int *levpos;       // host, 2 * nlev: first and one-past-last position of every dependency level (level-by-level fall-back)
 };
 
 __device__ __forceinline__ double tri_poll(const double *p, int *abort_flag, int sleep_cap) {
@@ -217,6 +219,31 @@ __global__ __launch_bounds__(MI355X_BLOCK) void trisolve_syncfree_kernel(
   }
 }
 
+extern "C" int mi355x_trisolve_plan_destroy(mi355x_trisolve_plan_t p);
+
+// The same rows, one dependency level per launch, no polling: what an application falls back to after a sync-free solve gave
+// up (bounded spins), and the reference point the sync-free kernels are measured against.  Same layout, same per-row
+// order of the products, same bits.
+template <bool UPPER>
+__global__ __launch_bounds__(MI355X_BLOCK) void trisolve_level_kernel(int p0, int p1, const int *__restrict__ ptr, const int *__restrict__ info,
+                                                                      const int *__restrict__ rowof, const int *__restrict__ col,
+                                                                      const double *__restrict__ val, const double *__restrict__ dinv,
+                                                                      const double *src, const int *__restrict__ spos, double *w, double *y,
+                                                                      const double *__restrict__ rscale) {
+  const int t = p0 + blockIdx.x * MI355X_BLOCK + threadIdx.x;
+  if (t >= p1) return;
+  const int row = rowof[t];
+  if (row < 0) return;
+  const int s = t / MI355X_WAVE, lane = t % MI355X_WAVE, base = ptr[s], mylen = info[t] >> 8;
+  double sum;
+  if (UPPER) { sum = src[spos[row]]; if (rscale) sum = sum * rscale[t]; }
+  else sum = src[row];
+  for (int q = 0; q < mylen; ++q) sum -= val[base + q * MI355X_WAVE + lane] * w[col[base + q * MI355X_WAVE + lane]];
+  const double r = UPPER ? sum * dinv[t] : sum;
+  w[t] = r;
+  if (UPPER) y[row] = r;
+}
+
 extern "C" {
 
 // Host analysis + upload.  n rows; lev[i] = dependency level of row i (0-based, every level non-empty); len(i) and
@@ -228,11 +255,12 @@ extern "C" {
 // hold rows of two large levels.  For factors of matrices with inodes (3-dof FEM: ~38 entries per row, recent dependencies
 // in the middle of the column order) the reference itself runs another routine with another order (MatSolve_SeqAIJ_Inode,
 // inode.c); results then agree with the natural-ordering loop to rounding, not bit for bit.  Deterministic either way.
-static int trisolve_plan_create_impl(mi355x_handle_t h, int n, int nlev, const int *lev, const int *rp, const int *rl, const int *cj,
-                                     const double *cv, const double *dinv_host, const double *rscale_host, int by_level,
-                                     mi355x_trisolve_plan_t *out) {
-  mi355x_trisolve_plan_s *p = new mi355x_trisolve_plan_s();
-  memset(p, 0, sizeof(*p));
+// every failure leaves through TRI_TRY / TRI_FAIL: pending copies out of the local vectors are drained first, and the caller
+// (trisolve_plan_create_impl) hands the half-built plan to mi355x_trisolve_plan_destroy
+#define TRI_TRY(expr) do { const int e__ = (int)(expr); if (e__) { (void)hipStreamSynchronize(h->stream); return e__; } } while (0)
+#define TRI_FAIL() do { (void)hipStreamSynchronize(h->stream); return (int)hipErrorInvalidValue; } while (0)
+static int trisolve_plan_fill(mi355x_handle_t h, mi355x_trisolve_plan_s *p, int n, int nlev, const int *lev, const int *rp, const int *rl, const int *cj,
+                              const double *cv, const double *dinv_host, const double *rscale_host, int by_level) {
   p->n = n; p->upper = dinv_host != nullptr;
   const int W = MI355X_WAVE;
   // positions: by level, longer rows first inside a level (stable in the row number)
@@ -268,7 +296,14 @@ static int trisolve_plan_create_impl(mi355x_handle_t h, int n, int nlev, const i
     if (by_level && sz >= TRI_ALIGN_MIN && (cur % W)) cur += W - cur % W;     // padding positions: no row, never read
     for (int t = levptr[(size_t)l]; t < levptr[(size_t)l + 1]; ++t) tpos[(size_t)t] = cur++;
   }
-  if (cur > 2147483000L) { delete p; return (int)hipErrorInvalidValue; }
+  if (cur > 2147483000L) TRI_FAIL();
+  p->nlev = nlev;
+  p->levpos = (int *)malloc(sizeof(int) * 2 * (size_t)(nlev > 0 ? nlev : 1));
+  if (!p->levpos) TRI_FAIL();
+  for (int l = 0; l < nlev; ++l) {
+    p->levpos[2 * l] = (int)tpos[(size_t)levptr[(size_t)l]];
+    p->levpos[2 * l + 1] = (int)tpos[(size_t)levptr[(size_t)l + 1] - 1] + 1;
+  }
   p->nslices = (int)((cur + W - 1) / W);
   p->nchunks = (p->nslices + 3) / 4;
   const size_t np = (size_t)p->nslices * W;
@@ -285,7 +320,7 @@ static int trisolve_plan_create_impl(mi355x_handle_t h, int n, int nlev, const i
       if (i < 0) continue;
       if (l0 < 0) l0 = lev[i];                   // positions are in level order: the slice's first row has its lowest level
       const int sub = lev[i] - l0;
-      if (sub < 0 || sub > 255) { delete p; return (int)hipErrorInvalidValue; }
+      if (sub < 0 || sub > 255) TRI_FAIL();
       info[P] = (rl[i] << 8) | sub;
       if (dinv_host) dinv[P] = dinv_host[i];
       if (rscale_host) rsc[P] = rscale_host[i];
@@ -294,7 +329,7 @@ static int trisolve_plan_create_impl(mi355x_handle_t h, int n, int nlev, const i
     }
     ptr[(size_t)s] = (int)total;
     total += (long)mx * W;
-    if (total > 2147483000L) { delete p; return (int)hipErrorInvalidValue; }
+    if (total > 2147483000L) TRI_FAIL();
   }
   ptr[(size_t)p->nslices] = (int)total;
   std::vector<int> col((size_t)(total > 0 ? total : 1), 0);
@@ -326,33 +361,33 @@ static int trisolve_plan_create_impl(mi355x_handle_t h, int n, int nlev, const i
       for (int k = 0; k < nth; ++k) th.emplace_back(fill, (int)((long)n * k / nth), (int)((long)n * (k + 1) / nth));
       for (auto &t : th) t.join();
     }
-    if (bad.load()) { delete p; return (int)hipErrorInvalidValue; } }
-#define TRI_UP(dst, vec, T) do { MI355X_TRY(hipMalloc((void **)&(dst), sizeof(T) * (vec).size())); \
-    MI355X_TRY(hipMemcpyAsync((dst), (vec).data(), sizeof(T) * (vec).size(), hipMemcpyHostToDevice, h->stream)); } while (0)
+    if (bad.load()) TRI_FAIL(); }
+#define TRI_UP(dst, vec, T) do { TRI_TRY(hipMalloc((void **)&(dst), sizeof(T) * (vec).size())); \
+    TRI_TRY(hipMemcpyAsync((dst), (vec).data(), sizeof(T) * (vec).size(), hipMemcpyHostToDevice, h->stream)); } while (0)
   TRI_UP(p->d_ptr, ptr, int); TRI_UP(p->d_info, info, int); TRI_UP(p->d_row, rowof, int); TRI_UP(p->d_col, col, int);
   TRI_UP(p->d_val, val, double); TRI_UP(p->d_nsub, nsub, unsigned char); TRI_UP(p->d_pos, pos, int);
   if (dinv_host) TRI_UP(p->d_dinv, dinv, double);
   if (dinv_host && rscale_host) TRI_UP(p->d_rscale, rsc, double);
 #undef TRI_UP
-  MI355X_TRY(hipMalloc((void **)&p->d_w, sizeof(double) * (np > 0 ? np : 1)));
+  TRI_TRY(hipMalloc((void **)&p->d_w, sizeof(double) * (np > 0 ? np : 1)));
   { std::vector<unsigned long long> sent(np > 0 ? np : 1, TRI_SENTINEL);
-    MI355X_TRY(hipMemcpyAsync(p->d_w, sent.data(), sizeof(double) * sent.size(), hipMemcpyHostToDevice, h->stream));
-    MI355X_TRY(hipStreamSynchronize(h->stream)); }
-  MI355X_TRY(hipMalloc((void **)&p->d_queue, sizeof(unsigned int) * TRI_QUEUES * TRI_QSTRIDE));
-  MI355X_TRY(hipMemsetAsync(p->d_queue, 0, sizeof(unsigned int) * TRI_QUEUES * TRI_QSTRIDE, h->stream));
-  MI355X_TRY(hipHostMalloc((void **)&p->abort_flag, 64, hipHostMallocMapped | hipHostMallocCoherent));
+    TRI_TRY(hipMemcpyAsync(p->d_w, sent.data(), sizeof(double) * sent.size(), hipMemcpyHostToDevice, h->stream));
+    TRI_TRY(hipStreamSynchronize(h->stream)); }
+  TRI_TRY(hipMalloc((void **)&p->d_queue, sizeof(unsigned int) * TRI_QUEUES * TRI_QSTRIDE));
+  TRI_TRY(hipMemsetAsync(p->d_queue, 0, sizeof(unsigned int) * TRI_QUEUES * TRI_QSTRIDE, h->stream));
+  TRI_TRY(hipHostMalloc((void **)&p->abort_flag, 64, hipHostMallocMapped | hipHostMallocCoherent));
   *p->abort_flag = 0;
   // fully resident grid: the occupancy the runtime reports, at most 4 workgroups per CU (MI355X_MICROARCH.md:
   // the query can over-report by one; 4 of 256 threads is well inside what this kernel's registers admit)
   int dev = 0, ncu = 256, per_cu = 0;
   hipDeviceProp_t prop;
-  MI355X_TRY(hipGetDevice(&dev));
-  MI355X_TRY(hipGetDeviceProperties(&prop, dev));
+  TRI_TRY(hipGetDevice(&dev));
+  TRI_TRY(hipGetDeviceProperties(&prop, dev));
   ncu = prop.multiProcessorCount;
-  MI355X_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trisolve_syncfree_kernel<true>, MI355X_BLOCK, 0));
+  TRI_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trisolve_syncfree_kernel<true>, MI355X_BLOCK, 0));
   p->by_level = by_level;
   if (per_cu > 4) per_cu = 4;
-  if (per_cu < 1) { delete p; return (int)hipErrorInvalidValue; }
+  if (per_cu < 1) TRI_FAIL();
   p->grid = ncu * per_cu;
   // ... and no larger than a few levels' worth of chunks: workgroups further ahead of the front could only spin
   { const char *e = getenv("MI355X_TRISOLVE_AHEAD");      // development knobs; the defaults are the measured best
@@ -366,7 +401,20 @@ static int trisolve_plan_create_impl(mi355x_handle_t h, int n, int nlev, const i
   // poll back-off cap (x 128 clocks): the more wavefronts wait, the gentler they must poll (P7(256), 344 workgroups:
   // cap 2 -> 8.1 ms, cap 8 -> 2.9 ms; P7(128), 88 workgroups: cap 2 -> 1.04 ms, cap 8 -> 1.14 ms per application)
   { const char *e = getenv("MI355X_TRISOLVE_SLEEP"); p->sleep_cap = e ? atoi(e) : (p->grid <= 128 ? 2 : 8); if (p->sleep_cap < 1) p->sleep_cap = 1; }
-  MI355X_TRY(hipStreamSynchronize(h->stream));
+  TRI_TRY(hipStreamSynchronize(h->stream));
+  return 0;
+}
+#undef TRI_TRY
+#undef TRI_FAIL
+
+static int trisolve_plan_create_impl(mi355x_handle_t h, int n, int nlev, const int *lev, const int *rp, const int *rl, const int *cj,
+                                     const double *cv, const double *dinv_host, const double *rscale_host, int by_level,
+                                     mi355x_trisolve_plan_t *out) {
+  mi355x_trisolve_plan_s *p = new mi355x_trisolve_plan_s();
+  memset(p, 0, sizeof(*p));
+  *out = nullptr;
+  const int rc = trisolve_plan_fill(h, p, n, nlev, lev, rp, rl, cj, cv, dinv_host, rscale_host, by_level);
+  if (rc) { mi355x_trisolve_plan_destroy(p); return rc; }     // one cleanup path: nothing allocated so far survives a failure
   *out = p;
   return 0;
 }
@@ -396,6 +444,7 @@ int mi355x_trisolve_plan_destroy(mi355x_trisolve_plan_t p) {
   if (p->d_dinv) (void)hipFree(p->d_dinv);
   if (p->d_rscale) (void)hipFree(p->d_rscale);
   if (p->abort_flag) (void)hipHostFree(p->abort_flag);
+  free(p->levpos);
   delete p;
   return 0;
 }
@@ -424,6 +473,34 @@ int mi355x_trisolve_apply(mi355x_handle_t h, mi355x_trisolve_plan_t lo, mi355x_t
   if (lo->by_level != up->by_level) return (int)hipErrorInvalidValue;
   TRI_GO();
 #undef TRI_GO
+  return 0;
+}
+
+// y = U^-1 L^-1 b over the same plans, one launch per dependency level (nlevL + nlevU launches), no hand-off between
+// wavefronts: usable after an abort (the flags are not consulted, nothing is left armed or disarmed for the sync-free form)
+int mi355x_trisolve_apply_levels(mi355x_handle_t h, mi355x_trisolve_plan_t lo, mi355x_trisolve_plan_t up, const double *b, double *y) {
+  if (!lo || !up || lo->n != up->n || lo->upper || !up->upper) return (int)hipErrorInvalidValue;
+  if (lo->n == 0) return 0;
+  for (int l = 0; l < lo->nlev; ++l) {
+    const int p0 = lo->levpos[2 * l], p1 = lo->levpos[2 * l + 1];
+    hipLaunchKernelGGL((trisolve_level_kernel<false>), dim3((p1 - p0 + MI355X_BLOCK - 1) / MI355X_BLOCK), dim3(MI355X_BLOCK), 0, h->stream, p0, p1,
+                       lo->d_ptr, lo->d_info, lo->d_row, lo->d_col, lo->d_val, (const double *)nullptr, b, (const int *)nullptr, lo->d_w,
+                       (double *)nullptr, (const double *)nullptr);
+    MI355X_LAUNCH_CHECK();
+  }
+  for (int l = 0; l < up->nlev; ++l) {
+    const int p0 = up->levpos[2 * l], p1 = up->levpos[2 * l + 1];
+    hipLaunchKernelGGL((trisolve_level_kernel<true>), dim3((p1 - p0 + MI355X_BLOCK - 1) / MI355X_BLOCK), dim3(MI355X_BLOCK), 0, h->stream, p0, p1,
+                       up->d_ptr, up->d_info, up->d_row, up->d_col, up->d_val, up->d_dinv, lo->d_w, lo->d_pos, up->d_w, y,
+                       (const double *)up->d_rscale);
+    MI355X_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+int mi355x_trisolve_debug_set_aborted(mi355x_trisolve_plan_t p, int value) {
+  if (!p || !p->abort_flag) return (int)hipErrorInvalidValue;
+  *p->abort_flag = value;
   return 0;
 }
 

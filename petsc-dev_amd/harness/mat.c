@@ -73,6 +73,7 @@ PetscErrorCode MatSetFromOptions(Mat A) {
   if (!set) snprintf(t, sizeof(t), "%s", MATAIJ);   /* matrix.c MatSetFromOptions: the default type is aij */
   return MatSetType(A, t);
 }
+PetscErrorCode MatSetOptionsPrefix(Mat A, const char prefix[]) { MatValid(A, 1); snprintf(A->prefix, sizeof(A->prefix), "%s", prefix ? prefix : ""); return 0; }
 PetscErrorCode MatGetType(Mat A, MatType *type) { MatValid(A, 1); *type = A->type_name; return 0; }
 PetscErrorCode MatSetUp(Mat A) {
   MatTypeSet(A, 1);
@@ -286,5 +287,76 @@ PetscErrorCode MatCreateSeqBAIJWithArrays(PetscComm comm, PetscInt bs, PetscInt 
   ierr = PetscObjectQueryFunction((PetscObject)*mat, "MatSeqBAIJSetPreallocationCSR_C", &f);CHKERRQ(ierr);
   if (!f) SETERRQ(comm, PETSC_ERR_SUP, "Mat type %s cannot be filled from block CSR arrays", (*mat)->type_name);
   ierr = ((PetscErrorCode (*)(Mat, PetscInt, const PetscInt[], const PetscInt[], const PetscScalar[]))f)(*mat, bs, i, j, a);CHKERRQ(ierr);
+  return 0;
+}
+
+/* ---- factorisation interface (matrix.c) ---- */
+PetscErrorCode MatFactorInfoInitialize(MatFactorInfo *info) { memset(info, 0, sizeof(*info)); return 0; }   /* matrix.c:2633 */
+/* MatGetFactor, matrix.c:3937-3975: the operator's TYPE says which factorisations a solver package offers for it, through a
+ * method composed under "MatGetFactor_<package>_C" */
+PetscErrorCode MatGetFactor(Mat mat, const MatSolverPackage type, MatFactorType ftype, Mat *f) {
+  PetscErrorCode ierr;
+  char name[96];
+  PetscVoidFunction conv = NULL;
+  MatTypeSet(mat, 1);
+  if (mat->factortype) SETERRQ(mat->comm, PETSC_ERR_ARG_WRONGSTATE, "Not for factored matrix");
+  snprintf(name, sizeof(name), "MatGetFactor_%s_C", type);
+  ierr = PetscObjectQueryFunction((PetscObject)mat, name, &conv);CHKERRQ(ierr);
+  if (!conv) SETERRQ(mat->comm, PETSC_ERR_SUP, "Matrix format %s does not have a solver package %s. Perhaps you must ./configure with --download-%s", mat->type_name, type, type);
+  ierr = ((PetscErrorCode (*)(Mat, MatFactorType, Mat *))conv)(mat, ftype, f);CHKERRQ(ierr);
+  return 0;
+}
+PetscErrorCode MatGetFactorAvailable(Mat mat, const MatSolverPackage type, MatFactorType ftype, PetscBool *flg) {   /* matrix.c:3996 */
+  PetscErrorCode ierr;
+  char name[96];
+  PetscVoidFunction conv = NULL;
+  MatValid(mat, 1);
+  *flg = PETSC_FALSE;
+  snprintf(name, sizeof(name), "MatGetFactorAvailable_%s_C", type);
+  ierr = PetscObjectQueryFunction((PetscObject)mat, name, &conv);CHKERRQ(ierr);
+  if (conv) { ierr = ((PetscErrorCode (*)(Mat, MatFactorType, PetscBool *))conv)(mat, ftype, flg);CHKERRQ(ierr); }
+  return 0;
+}
+#define FactorPair(fact, mat) do { MatValid(fact, 1); MatTypeSet(mat, 2); MatAssembled(mat); \
+  if ((mat)->rmap->N != (mat)->cmap->N) SETERRQ((mat)->comm, PETSC_ERR_ARG_WRONG, "matrix must be square"); } while (0)
+PetscErrorCode MatILUFactorSymbolic(Mat fact, Mat mat, IS row, IS col, const MatFactorInfo *info) {   /* matrix.c:5905 */
+  FactorPair(fact, mat);
+  if (info->levels < 0) SETERRQ(mat->comm, PETSC_ERR_ARG_OUTOFRANGE, "Levels of fill negative %d", (int)info->levels);
+  if (!fact->ops->ilufactorsymbolic) SETERRQ(mat->comm, PETSC_ERR_SUP, "Matrix type %s symbolic ILU", mat->type_name);
+  PetscErrorCode ierr = (*fact->ops->ilufactorsymbolic)(fact, mat, row, col, info);CHKERRQ(ierr);
+  return 0;
+}
+PetscErrorCode MatLUFactorNumeric(Mat fact, Mat mat, const MatFactorInfo *info) {   /* matrix.c:2815 */
+  FactorPair(fact, mat);
+  if (!fact->ops->lufactornumeric) SETERRQ(mat->comm, PETSC_ERR_SUP, "Mat type %s numeric LU", mat->type_name);
+  PetscErrorCode ierr = (*fact->ops->lufactornumeric)(fact, mat, info);CHKERRQ(ierr);
+  fact->state++;
+  return 0;
+}
+PetscErrorCode MatICCFactorSymbolic(Mat fact, Mat mat, IS perm, const MatFactorInfo *info) {   /* matrix.c:5968 */
+  FactorPair(fact, mat);
+  if (info->levels < 0) SETERRQ(mat->comm, PETSC_ERR_ARG_OUTOFRANGE, "Levels negative %d", (int)info->levels);
+  if (!fact->ops->iccfactorsymbolic) SETERRQ(mat->comm, PETSC_ERR_SUP, "Matrix type %s symbolic ICC", mat->type_name);
+  PetscErrorCode ierr = (*fact->ops->iccfactorsymbolic)(fact, mat, perm, info);CHKERRQ(ierr);
+  return 0;
+}
+PetscErrorCode MatCholeskyFactorNumeric(Mat fact, Mat mat, const MatFactorInfo *info) {   /* matrix.c:2957 */
+  FactorPair(fact, mat);
+  if (!fact->ops->choleskyfactornumeric) SETERRQ(mat->comm, PETSC_ERR_SUP, "Mat type %s numeric factor Cholesky", mat->type_name);
+  PetscErrorCode ierr = (*fact->ops->choleskyfactornumeric)(fact, mat, info);CHKERRQ(ierr);
+  fact->state++;
+  return 0;
+}
+PetscErrorCode MatSolve(Mat mat, Vec b, Vec x) {   /* matrix.c:3196-3225 */
+  PetscErrorCode ierr;
+  MatValid(mat, 1);
+  if (x == b) SETERRQ(mat->comm, PETSC_ERR_ARG_IDN, "x and b must be different vectors");
+  if (!mat->factortype) SETERRQ(mat->comm, PETSC_ERR_ARG_WRONGSTATE, "Unfactored matrix");
+  if (mat->cmap->N != x->map->N) SETERRQ(mat->comm, PETSC_ERR_ARG_SIZ, "Mat mat,Vec x: global dim %d %d", mat->cmap->N, x->map->N);
+  if (mat->rmap->N != b->map->N) SETERRQ(mat->comm, PETSC_ERR_ARG_SIZ, "Mat mat,Vec b: global dim %d %d", mat->rmap->N, b->map->N);
+  if (!mat->rmap->N && !mat->cmap->N) return 0;
+  if (!mat->ops->solve) SETERRQ(mat->comm, PETSC_ERR_SUP, "Mat type %s", mat->type_name);
+  ierr = (*mat->ops->solve)(mat, b, x);CHKERRQ(ierr);
+  PetscObjectStateIncrease(x);
   return 0;
 }

@@ -23,9 +23,11 @@ PetscErrorCode PCRegister(const char name[], const char path[], const char fname
   pc_types[n_pc_types++].fn = fn;
   return 0;
 }
-static PetscBool pc_type_registered(const char *name) {
-  for (int i = 0; i < n_pc_types; i++) if (!strcmp(pc_types[i].name, name)) return PETSC_TRUE;
-  return PETSC_FALSE;
+/* can this operator be ILU-factored by the default package?  (PCGetDefaultType_Private asks MatGetFactorAvailable, precon.c:24-33) */
+static PetscBool mat_has_ilu(Mat A) {
+  PetscBool flg = PETSC_FALSE;
+  if (MatGetFactorAvailable(A, MATSOLVERPETSC, MAT_FACTOR_ILU, &flg)) return PETSC_FALSE;
+  return flg;
 }
 /* the harness's own types: KSPRegisterAll / PCRegisterAll (itregis.c, pcregis.c), for the types restated here */
 PetscErrorCode PetscMiniInitialize(void) {
@@ -36,6 +38,8 @@ PetscErrorCode PetscMiniInitialize(void) {
   ierr = PCRegister(PCNONE, 0, "PCCreate_None", PCCreate_None);CHKERRQ(ierr);
   ierr = PCRegister(PCJACOBI, 0, "PCCreate_Jacobi", PCCreate_Jacobi);CHKERRQ(ierr);
   ierr = PCRegister(PCBJACOBI, 0, "PCCreate_BJacobi", PCCreate_BJacobi);CHKERRQ(ierr);
+  ierr = PCRegister(PCILU, 0, "PCCreate_ILU", PCCreate_ILU);CHKERRQ(ierr);      /* pcfactor.c: control flow only; the factored matrix comes from the operator's type */
+  ierr = PCRegister(PCICC, 0, "PCCreate_ICC", PCCreate_ICC);CHKERRQ(ierr);
   ierr = KSPRegister(KSPCG, 0, "KSPCreate_CG", KSPCreate_CG);CHKERRQ(ierr);
   ierr = KSPRegister(KSPGROPPCG, 0, "KSPCreate_GROPPCG", KSPCreate_GROPPCG);CHKERRQ(ierr);
   ierr = KSPRegister(KSPPIPECG, 0, "KSPCreate_PIPECG", KSPCreate_PIPECG);CHKERRQ(ierr);
@@ -89,10 +93,9 @@ PetscErrorCode PCSetUp(PC pc) {   /* precon.c:~800 */
   if (pc->setupcalled > 1) return 0;
   if (!pc->mat) SETERRQ(pc->comm, PETSC_ERR_ARG_WRONGSTATE, "Matrix must be set first");
   if (!pc->type_name[0]) {
-    /* PCGetDefaultType_Private (precon.c:14-53): ILU on one process when the matrix can be factored (here: an ILU
-     * has been registered and the matrix is a sequential AIJ type), block Jacobi on several */
+    /* PCGetDefaultType_Private (precon.c:14-53): ILU on one process when the matrix can be factored, block Jacobi on several */
     if (pc->comm->size > 1) { ierr = PCSetType(pc, PCBJACOBI);CHKERRQ(ierr); }
-    else { ierr = PCSetType(pc, (pc_type_registered(PCILU) && !strncmp(pc->pmat->type_name, MATSEQAIJ, 6)) ? PCILU : PCJACOBI);CHKERRQ(ierr); }
+    else { ierr = PCSetType(pc, mat_has_ilu(pc->pmat) ? PCILU : PCJACOBI);CHKERRQ(ierr); }
   }
   if (pc->ops->setup) { ierr = (*pc->ops->setup)(pc);CHKERRQ(ierr); }
   pc->setupcalled = 2;
@@ -288,7 +291,7 @@ static PetscErrorCode PCSetUp_BJacobi(PC pc) {
     if (bj->merged) {   /* a factorisation with a shift strategy must treat the blocks as the separate matrices they stand for */
       PetscVoidFunction fb = NULL;
       PC sub = bj->ksp[i]->pc;
-      if (!sub->type_name[0] && pc_type_registered(PCILU) && !strncmp(bj->block[i]->type_name, MATSEQAIJ, 6)) { ierr = PCSetType(sub, PCILU);CHKERRQ(ierr); }   /* the default PCSetUp would pick (precon.c:14-53), now, so that it can be asked */
+      if (!sub->type_name[0] && mat_has_ilu(bj->block[i])) { ierr = PCSetType(sub, PCILU);CHKERRQ(ierr); }   /* the default PCSetUp would pick (precon.c:14-53), now, so that it can be asked */
       ierr = PetscObjectQueryFunction((PetscObject)bj->ksp[i]->pc, "PCFactorSetIndependentBlocks_C", &fb);CHKERRQ(ierr);
       if (fb) { ierr = ((PetscErrorCode (*)(PC, PetscInt, const PetscInt *))fb)(bj->ksp[i]->pc, nloc, bj->starts);CHKERRQ(ierr); }
       else if (!strcmp(bj->ksp[i]->pc->type_name, PCICC)) SETERRQ(pc->comm, PETSC_ERR_SUP, "this PCICC cannot factor independent blocks: use -pc_bjacobi_merge_blocks 0");

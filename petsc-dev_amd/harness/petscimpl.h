@@ -129,6 +129,12 @@ struct _MatOps {
   PetscErrorCode (*destroy)(Mat);                        /* slot 60 */
   PetscErrorCode (*getvecs)(Mat, Vec *, Vec *);          /* slot 88 */
   PetscErrorCode (*setvaluesbatch)(Mat, PetscInt, PetscInt, PetscInt[], const PetscScalar[]);
+  /* the factorisation slots PCILU / PCICC drive (matimpl.h: solve 8, lufactornumeric 30/..., ilufactorsymbolic, iccfactorsymbolic) */
+  PetscErrorCode (*solve)(Mat, Vec, Vec);
+  PetscErrorCode (*lufactornumeric)(Mat, Mat, const MatFactorInfo *);
+  PetscErrorCode (*choleskyfactornumeric)(Mat, Mat, const MatFactorInfo *);
+  PetscErrorCode (*ilufactorsymbolic)(Mat, Mat, IS, IS, const MatFactorInfo *);
+  PetscErrorCode (*iccfactorsymbolic)(Mat, Mat, IS, const MatFactorInfo *);
 };
 typedef struct _MatOps MatOps;
 
@@ -138,6 +144,7 @@ struct _p_Mat {
   PetscLayout rmap, cmap;
   PetscInt m_req, n_req, M_req, N_req;   /* MatSetSizes arguments */
   PetscBool assembled, was_assembled, preallocated;
+  MatFactorType factortype;   /* MAT_FACTOR_NONE for an operator (matimpl.h:306) */
   void *data;
   void *spptr;        /* for the implementation's accelerator mirror, as Mat->spptr (matimpl.h:323) */
 };
@@ -148,6 +155,7 @@ struct _PCOps {
   PetscErrorCode (*apply)(PC, Vec, Vec);
   PetscErrorCode (*setfromoptions)(PC);
   PetscErrorCode (*destroy)(PC);
+  PetscErrorCode (*getfactoredmatrix)(PC, Mat *);
 };
 typedef struct _PCOps PCOps;
 struct _p_PC {
@@ -195,7 +203,7 @@ PetscErrorCode KSP_MatMult(KSP ksp, Mat A, Vec x, Vec y);
 PetscErrorCode KSP_PCApply(KSP ksp, Vec x, Vec y);
 PetscErrorCode KSP_PCApplyBAorAB(KSP ksp, Vec x, Vec y, Vec w);
 PetscErrorCode KSPCreate_CG(KSP), KSPCreate_GROPPCG(KSP), KSPCreate_PIPECG(KSP), KSPCreate_GMRES(KSP), KSPCreate_BCGS(KSP), KSPCreate_PREONLY(KSP);
-PetscErrorCode PCCreate_None(PC), PCCreate_Jacobi(PC), PCCreate_BJacobi(PC);
+PetscErrorCode PCCreate_None(PC), PCCreate_Jacobi(PC), PCCreate_BJacobi(PC), PCCreate_ILU(PC), PCCreate_ICC(PC);
 
 #include "petsckrylovfused.h"   /* the optional fused-kernel tables a Vec / Mat type may compose */
 

@@ -811,6 +811,7 @@ static PetscErrorCode MatDestroy_SeqAIJHIP(Mat A) {   /* free the mirror and zer
   HipAIJ *a = SA(A);
   if (SD(A)) {
     Mat_SeqAIJHIP *d = SD(A);
+    (void)HipTriFactorsDestroy(&d->tri);    /* a factored matrix: its triangular factors */
     device_free(A);
     if (d->time_ev) { for (PetscInt k = 0; k < 2 * d->time_cap; k++) mi355x_event_destroy(d->time_ev[k]); HipFree(d->time_ev); }
     HipFree(A->spptr); A->spptr = NULL;
@@ -860,6 +861,10 @@ static PetscErrorCode create_common(Mat B, const char *tname, PetscInt bs) {
   ierr = PetscObjectComposeFunction((PetscObject)B, "MatMultTDotBegin_C", "MatMultTDotBegin_HIPMI355X", (PetscVoidFunction)MatMultTDotBegin_HIPMI355X);CHKERRQ(ierr);
   ierr = PetscObjectComposeFunction((PetscObject)B, "MatMultDiagonalScale_C", "MatMultDiagonalScale_HIPMI355X", (PetscVoidFunction)MatMultDiagonalScale_HIPMI355X);CHKERRQ(ierr);
   if (bs == 1) {
+    /* ILU(0) / ICC(0) of this type: the factored matrix carries the device triangular solves behind ops->solve (host/ilu.c), as
+     * MatCreate_SeqAIJCUSPARSE overloads "MatGetFactor_petsc_C" (aijcusparse.cu:837-840) */
+    ierr = PetscObjectComposeFunction((PetscObject)B, "MatGetFactor_petsc_C", "MatGetFactor_seqaijhipmi355x_petsc", (PetscVoidFunction)MatGetFactor_seqaijhipmi355x_petsc);CHKERRQ(ierr);
+    ierr = PetscObjectComposeFunction((PetscObject)B, "MatGetFactorAvailable_petsc_C", "MatGetFactorAvailable_seqaijhipmi355x_petsc", (PetscVoidFunction)MatGetFactorAvailable_seqaijhipmi355x_petsc);CHKERRQ(ierr);
     ierr = PetscObjectComposeFunction((PetscObject)B, "MatSeqAIJSetPreallocation_C", "MatSeqAIJSetPreallocation_SeqAIJHIP", (PetscVoidFunction)MatSeqAIJSetPreallocation_SeqAIJHIP);CHKERRQ(ierr);
     ierr = PetscObjectComposeFunction((PetscObject)B, "MatSeqAIJSetPreallocationCSR_C", "MatSeqAIJSetPreallocationCSR_SeqAIJHIP", (PetscVoidFunction)MatSeqAIJSetPreallocationCSR_SeqAIJHIP);CHKERRQ(ierr);
   } else {

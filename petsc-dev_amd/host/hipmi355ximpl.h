@@ -133,6 +133,33 @@ typedef struct {
   PetscInt inode_count, *inode_size;   /* Mat_SeqAIJ_Inode node_count / size (aij.h:99-115); 0 / NULL: plain routines */
 } HipAIJ;
 
+/* ---- factored matrices: what MatGetFactor(A, "petsc", MAT_FACTOR_ILU | MAT_FACTOR_ICC, &F) hangs on F (host/ilu.c, host/icc.c;
+ * the role of Mat_SeqAIJCUSPARSETriFactors, src/mat/impls/aij/seq/seqcusparse/cusparsematimpl.h) ---- */
+typedef struct {
+  MatFactorType kind;                                      /* MAT_FACTOR_ILU or MAT_FACTOR_ICC */
+  PetscInt n, nz;
+  PetscInt *bi, *bj, *bdiag; PetscScalar *ba;              /* ILU(0): host factor in the reference's L / reversed-U layout (aijfact.c:1628-1700) */
+  PetscBool owns_host;                                     /* harness: ours; inside PETSc: the arrays of F's own Mat_SeqAIJ */
+  PetscInt *d_bi, *d_bj, *d_bdiag; PetscScalar *d_ba;      /* device copies for the level-scheduled ILU kernels */
+  PetscInt nlevL, nlevU, *levptrL, *levptrU;               /* dependency levels (host) */
+  PetscInt *d_rowsL, *d_rowsU;                             /* rows ordered by level (device) */
+  PetscScalar *d_work; void *graph; int graph_tried;       /* hipGraph of the level launches working in place on d_work */
+  mi355x_trisolve_plan_t tri_lo, tri_up;                   /* sync-free solves (NULL: level launches) */
+  int by_level;                                            /* rows summed in dependency-level order (inode matrices) instead of column order */
+  int use_levels, aborted;                                 /* a sync-free application gave up: the same plans run level by level from now on */
+  PetscInt nshift;                                         /* restarts / shifts the factorisation took (largest count over the blocks) */
+  int factored_state; void *factored_of;                   /* operator and operator state of the last numeric factorisation */
+  PetscInt nblk, *blk;                                     /* "MatFactorSetIndependentBlocks_C": the matrix stands for that many separate matrices (row ranges) */
+  PetscErrorCode (*parent_destroy)(Mat);                   /* inside PETSc: the parent factor matrix's destroy */
+} HipTriFactors;
+PetscErrorCode HipTriFactorsDestroy(HipTriFactors **f);
+PetscErrorCode HipTriFactorsApply(Mat F, HipTriFactors *f, Vec b, Vec x, PetscLogDouble flops);
+PetscErrorCode HipTriWatchCheck(void);                     /* at every host wait: did a sync-free solve queued earlier give up? */
+void HipTriWatchAdd(HipTriFactors *f);
+PetscErrorCode MatICCFactorSymbolic_SeqAIJHIP(Mat F, Mat A, IS perm, const MatFactorInfo *info);
+PetscErrorCode MatGetFactor_seqaijhipmi355x_petsc(Mat A, MatFactorType ftype, Mat *B);
+PetscErrorCode MatGetFactorAvailable_seqaijhipmi355x_petsc(Mat A, MatFactorType ftype, PetscBool *flg);
+
 /* device mirror */
 typedef struct {
   PetscInt *d_i, *d_j;
@@ -154,8 +181,17 @@ typedef struct {
   PetscBool timing; PetscInt time_n, time_cap; mi355x_event_t *time_ev;
 #if defined(PETSCHIPMI355X_WITH_PETSC)
   HipAIJ view;               /* of the parent's Mat_SeqAIJ */
+#else
+  HipTriFactors *tri;        /* a factored matrix (A->factortype != MAT_FACTOR_NONE): its triangular factors on the device */
 #endif
 } Mat_SeqAIJHIP;
+/* where a factored matrix keeps its device-side factors: inside PETSc the factor is the PARENT's matrix (MATSEQAIJ for ILU, MATSEQSBAIJ
+ * for ICC, from MatGetFactor_seqaij_petsc) whose spptr is free; on the harness it is a matrix of this type */
+#if defined(PETSCHIPMI355X_WITH_PETSC)
+#define HipTriGet(F) ((HipTriFactors *)(F)->spptr)
+#else
+#define HipTriGet(F) (((Mat_SeqAIJHIP *)(F)->spptr)->tri)
+#endif
 #if defined(PETSCHIPMI355X_WITH_PETSC)
 #define HipAIJGet(A) (&((Mat_SeqAIJHIP *)(A)->spptr)->view)
 #else
@@ -189,8 +225,6 @@ PetscErrorCode MatSetUpMultiply_MPIAIJ(Mat mat);
 PetscErrorCode MatTimingBegin(Mat A, mi355x_handle_t h);
 PetscErrorCode MatTimingEnd(Mat A, mi355x_handle_t h);
 PetscErrorCode MatGetVecs_HIPMI355X(Mat A, Vec *right, Vec *left);
-PetscErrorCode PCCreate_ILU_HIPMI355X(PC);
-PetscErrorCode PCCreate_ICC_HIPMI355X(PC);
 PetscErrorCode PCCreate_PBJacobi_HIPMI355X(PC);
 PetscErrorCode KSPCreate_CGHIPMI355X(KSP);
 PetscErrorCode KSPCreate_GMRESHIPMI355X(KSP);

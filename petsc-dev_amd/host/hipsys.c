@@ -55,15 +55,12 @@ PetscErrorCode PetscHIPMI355XRegisterAll(void) {
   ierr = MatRegister(MATMPIAIJ, 0, "MatCreate_MPIAIJHIPMI355X", MatCreate_MPIAIJHIPMI355X);CHKERRQ(ierr);
   ierr = MatRegister(MATAIJ, 0, "MatCreate_AIJHIPMI355X", MatCreate_AIJHIPMI355X);CHKERRQ(ierr);
   ierr = MatRegister(MATSEQBAIJ, 0, "MatCreate_SeqBAIJHIPMI355X", MatCreate_SeqBAIJHIPMI355X);CHKERRQ(ierr);
-  ierr = PCRegister(PCILU, 0, "PCCreate_ILU_HIPMI355X", PCCreate_ILU_HIPMI355X);CHKERRQ(ierr);
   ierr = PCRegister(PCPBJACOBI, 0, "PCCreate_PBJacobi_HIPMI355X", PCCreate_PBJacobi_HIPMI355X);CHKERRQ(ierr);
-  ierr = PCRegister(PCICC, 0, "PCCreate_ICC_HIPMI355X", PCCreate_ICC_HIPMI355X);CHKERRQ(ierr);
 #else
   ierr = PCRegister("pbjacobihipmi355x", 0, "PCCreate_PBJacobi_HIPMI355X", PCCreate_PBJacobi_HIPMI355X);CHKERRQ(ierr);
-  /* PETSc's own PCILU keeps its name (host MatSolve); the device-side ILU(0) apply is offered next to it */
-  ierr = PCRegister("iluhipmi355x", 0, "PCCreate_ILU_HIPMI355X", PCCreate_ILU_HIPMI355X);CHKERRQ(ierr);
-  ierr = PCRegister("icchipmi355x", 0, "PCCreate_ICC_HIPMI355X", PCCreate_ICC_HIPMI355X);CHKERRQ(ierr);
 #endif
+  /* PCILU / PCICC are NOT registered by this library: the object model's own (PETSc's; the harness's pcfactor.c) reach the
+   * device solves through MatGetFactor -> "MatGetFactor_petsc_C", composed on every MATSEQAIJHIPMI355X (host/ilu.c) */
   return 0;
 }
 

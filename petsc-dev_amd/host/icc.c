@@ -1,63 +1,41 @@
-/* PCICC with zero fill on a sequential AIJ block (SURVEY 8f.1 names ILU(0)/ICC(0)): the incomplete Cholesky factorisation the
- * reference offers for symmetric positive definite systems, i.e. the natural partner of KSPCG under PCBJACOBI.
- *   set-up : MatICCFactorSymbolic_SeqAIJ with levels 0 and natural ordering (the pattern of A's upper triangle, the diagonal last in
- *            its row, src/mat/impls/aij/seq/aijfact.c:2405-2600) + MatCholeskyFactorNumeric_SeqAIJ (aijfact.c:2076-2230) with
- *            PCICC's defaults (src/ksp/pc/impls/factor/icc/icc.c:189-200: MAT_SHIFT_POSITIVE_DEFINITE, zeropivot 100 eps), on the
- *            HOST copy of the matrix -- as for PCILU (host/ilu.c) -- then the two triangular systems in row form and one upload.
- *   apply  : MatSolve_SeqSBAIJ_1_NaturalOrdering (src/mat/impls/sbaij/seq/sbaijfact2.c:1977-2015) on the device with the sync-free
- *            solves of csrc/trisolve.hip.  The reference sweeps U^T by COLUMNS (x[col] += v * x_i for the entries of row i, rows in
- *            ascending order): entry (i, c) therefore reaches x[c] after every earlier row's -- which is the order a row-oriented
- *            solve with L = U^T adds them in.  x[c] += v t is the bits of x[c] -= (-v) t, so the plans hold the negated values; the
- *            1/D(i) between the two sweeps is the upper solve's right-hand-side factor; its rows are stored last entry first, as the
- *            reference's backward loop reads them.  Same bits as the host loop. */
+/* Factored matrices of MATSEQAIJHIPMI355X, ICC(0) part (SURVEY 8f.1 names ILU(0)/ICC(0)): the incomplete Cholesky factorisation the
+ * reference offers for symmetric positive definite systems, i.e. the natural partner of KSPCG under PCBJACOBI.  Reached through
+ * MatGetFactor(A, "petsc", MAT_FACTOR_ICC, &F) -> MatICCFactorSymbolic -> MatCholeskyFactorNumeric -> MatSolve (ilu.c has the
+ * MatGetFactor side), i.e. by an unchanged PCICC.
+ *   numeric : MatICCFactorSymbolic_SeqAIJ with levels 0 and natural ordering (the pattern of A's upper triangle, the diagonal last in
+ *             its row, src/mat/impls/aij/seq/aijfact.c:2405-2600) + MatCholeskyFactorNumeric_SeqAIJ (aijfact.c:2076-2230) with
+ *             PCICC's defaults (src/ksp/pc/impls/factor/icc/icc.c:189-200: MAT_SHIFT_POSITIVE_DEFINITE, zeropivot 100 eps), on the
+ *             HOST copy of the matrix: the parent class's routines inside a PETSc tree, their restatement below on the harness;
+ *             then the two triangular systems in row form and one upload.
+ *   solve   : MatSolve_SeqSBAIJ_1_NaturalOrdering (src/mat/impls/sbaij/seq/sbaijfact2.c:1977-2015) on the device with the sync-free
+ *             solves of csrc/trisolve.hip.  The reference sweeps U^T by COLUMNS (x[col] += v * x_i for the entries of row i, rows in
+ *             ascending order): entry (i, c) therefore reaches x[c] after every earlier row's -- which is the order a row-oriented
+ *             solve with L = U^T adds them in.  x[c] += v t is the bits of x[c] -= (-v) t, so the plans hold the negated values; the
+ *             1/D(i) between the two sweeps is the upper solve's right-hand-side factor; its rows are stored last entry first, as the
+ *             reference's backward loop reads them.  Same bits as the host loop. */
 #include "hipmi355ximpl.h"
+#if defined(PETSCHIPMI355X_WITH_PETSC)
+#include <../src/mat/impls/aij/seq/aij.h>
+#include <../src/mat/impls/sbaij/seq/sbaij.h>
+#endif
 
-typedef struct {
-  PetscInt n, nz, nlevL, nlevU, nshift;
-  mi355x_trisolve_plan_t tri_lo, tri_up;
-  int factored_state;
-  /* "PCFactorSetIndependentBlocks_C": the matrix is block diagonal with these row ranges and stands for that many separate
-   * matrices (block Jacobi solving all its ICC(0) blocks as one system): each range is factored as the reference factors a
-   * matrix of its own -- its own shift loop -- so the result is the blocks' factors side by side also when a block needs shifts */
-  PetscInt nblk, *blk;
-} PC_ICC;
-
-static PetscErrorCode icc_free(PC_ICC *f) {
-  PetscInt nblk = f->nblk, *blk = f->blk;
-  if (f->tri_lo) mi355x_trisolve_plan_destroy(f->tri_lo);
-  if (f->tri_up) mi355x_trisolve_plan_destroy(f->tri_up);
-  memset(f, 0, sizeof(*f));
-  f->factored_state = -1;
-  f->nblk = nblk; f->blk = blk;
-  return 0;
+static PetscErrorCode MatSolve_SeqAIJHIP_ICC(Mat F, Vec b, Vec x) {   /* PCApply_ICC (icc.c:65) -> MatSolve(fact, x, y) */
+  HipTriFactors *f = HipTriGet(F);
+  return HipTriFactorsApply(F, f, b, x, 4.0 * f->nz - 3.0 * f->n);
 }
 
-static PetscErrorCode PCFactorSetIndependentBlocks_ICC(PC pc, PetscInt nblk, const PetscInt *starts) {
-  PC_ICC *f = (PC_ICC *)pc->data;
-  PetscErrorCode ierr;
-  HipFree(f->blk); f->blk = NULL; f->nblk = 0;
-  if (nblk > 0) {
-    ierr = PetscMalloc(sizeof(PetscInt) * (size_t)(nblk + 1), &f->blk);CHKERRQ(ierr);
-    memcpy(f->blk, starts, sizeof(PetscInt) * (size_t)(nblk + 1));
-    f->nblk = nblk;
-  }
-  f->factored_state = -1;
-  return 0;
-}
+static PetscErrorCode icc0_plans(Mat F, PetscInt n, const PetscInt *ui, const PetscInt *uj, const PetscScalar *ua);
 
-static PetscErrorCode PCSetUp_ICC(PC pc) {
+#if !defined(PETSCHIPMI355X_WITH_PETSC)
+/* MatICCFactorSymbolic_SeqAIJ (levels 0, natural ordering) + MatCholeskyFactorNumeric_SeqAIJ restated for the harness; inside a
+ * PETSc tree the parent's routines run instead and leave the same arrays in F's Mat_SeqSBAIJ */
+static PetscErrorCode icc0_factor_host(Mat F, Mat A, const MatFactorInfo *info) {
   PetscErrorCode ierr;
-  PC_ICC *f = (PC_ICC *)pc->data;
-  Mat A = pc->pmat;
+  HipTriFactors *f = HipTriGet(F);
   PetscInt n; const PetscInt *ai, *aj; const PetscScalar *aa;
-  PetscDeviceCtx *dc;
-  if (strcmp(HipObjTypeName(A), MATSEQAIJHIPMI355X)) SETERRQ(HipObjComm(pc), PETSC_ERR_SUP, "PCICC needs a sequential AIJ matrix (use -pc_type bjacobi -sub_pc_type icc in parallel); got %s", HipObjTypeName(A));
-  if (f->factored_state == HipObjState(A) && f->tri_lo) return 0;
   ierr = MatSeqAIJGetArrays(A, &n, &ai, &aj, &aa);CHKERRQ(ierr);
-  if (A->rmap->n != A->cmap->n) SETERRQ(HipObjComm(pc), PETSC_ERR_ARG_WRONG, "Must be square matrix, rows %d columns %d", A->rmap->n, A->cmap->n);
-  ierr = icc_free(f);CHKERRQ(ierr);
   f->n = n;
-  if (!n) { f->factored_state = HipObjState(A); return 0; }
+  if (!n) return 0;
 
   /* ---- symbolic: row k = its strictly upper entries in column order, then the diagonal slot ---- */
   PetscInt *ui, *uj, nz = 0; PetscScalar *ua;
@@ -65,7 +43,7 @@ static PetscErrorCode PCSetUp_ICC(PC pc) {
   for (PetscInt k = 0; k < n; k++) {
     PetscBool hasd = PETSC_FALSE;
     for (PetscInt q = ai[k]; q < ai[k + 1]; q++) { if (aj[q] > k) nz++; else if (aj[q] == k) hasd = PETSC_TRUE; }
-    if (!hasd) { HipFree(ui); SETERRQ(HipObjComm(pc), PETSC_ERR_ARG_WRONGSTATE, "Matrix is missing diagonal entry %d", k); }
+    if (!hasd) { HipFree(ui); SETERRQ(HipObjComm(A), PETSC_ERR_ARG_WRONGSTATE, "Matrix is missing diagonal entry %d", k); }
     nz++;
   }
   ierr = PetscMalloc(sizeof(PetscInt) * (size_t)nz, &uj);CHKERRQ(ierr);
@@ -79,7 +57,8 @@ static PetscErrorCode PCSetUp_ICC(PC pc) {
 
   /* ---- numeric, left-looking over the rows; the shift of MatPivotCheck_pd (matimpl.h:532-553) restarts it.  One pass per
    * independent block (one block = the whole matrix unless "PCFactorSetIndependentBlocks_C" said otherwise) ---- */
-  const PetscReal zeropivot = 100.0 * 2.220446049250313e-16;
+  const PetscReal zeropivot = info->zeropivot;
+  const PetscBool shift_pd = (PetscBool)(info->shifttype == (PetscReal)MAT_SHIFT_POSITIVE_DEFINITE);
   const PetscInt nshift_max = 5;
   PetscScalar *work; PetscInt *first, *list;
   ierr = PetscMalloc(sizeof(PetscScalar) * (size_t)n, &work);CHKERRQ(ierr);
@@ -91,7 +70,7 @@ static PetscErrorCode PCSetUp_ICC(PC pc) {
     const PetscInt r0 = blk[bb], r1 = blk[bb + 1];
     for (PetscInt k = r0; k < r1; k++)
       for (PetscInt q = ui[k]; q < ui[k + 1]; q++)
-        if (uj[q] >= r1) { HipFree(work); HipFree(first); HipFree(list); HipFree(ui); HipFree(uj); HipFree(ua); SETERRQ(HipObjComm(pc), PETSC_ERR_ARG_WRONG, "row %d couples to column %d outside its independent block", k, uj[q]); }
+        if (uj[q] >= r1) { HipFree(work); HipFree(first); HipFree(list); HipFree(ui); HipFree(uj); HipFree(ua); SETERRQ(HipObjComm(A), PETSC_ERR_ARG_WRONG, "row %d couples to column %d outside its independent block", k, uj[q]); }
     PetscReal shift_top = zeropivot, shift_amount = 0.0, shift_fraction = 0.0, shift_lo = 0.0, shift_hi = 1.0;
     PetscInt nshift = 0;
     for (PetscInt i = r0; i < r1; i++) {
@@ -132,11 +111,12 @@ static PetscErrorCode PCSetUp_ICC(PC pc) {
           const PetscInt c = uj[ui[k]]; list[k] = list[c]; list[c] = k;
         }
         if (dk <= zeropivot * rs) {
+          if (!shift_pd) { HipFree(work); HipFree(first); HipFree(list); HipFree(ui); HipFree(uj); HipFree(ua); SETERRQ(HipObjComm(A), 72 /* PETSC_ERR_MAT_CH_ZRPVT */, "Zero pivot row %d value %g tolerance %g", k, (double)dk, (double)(zeropivot * rs)); }
           if (nshift == nshift_max) shift_fraction = shift_hi;
           else { shift_lo = shift_fraction; shift_fraction = (shift_hi + shift_lo) / 2.; }
           shift_amount = shift_fraction * shift_top;
           nshift++;
-          if (nshift > nshift_max + 1) { HipFree(work); HipFree(first); HipFree(list); HipFree(ui); HipFree(uj); HipFree(ua); SETERRQ(HipObjComm(pc), 71 /* PETSC_ERR_MAT_LU_ZRPVT */, "ICC(0): no positive pivot in row %d even with the full diagonal shift", k); }
+          if (nshift > nshift_max + 1) { HipFree(work); HipFree(first); HipFree(list); HipFree(ui); HipFree(uj); HipFree(ua); SETERRQ(HipObjComm(A), 71 /* PETSC_ERR_MAT_LU_ZRPVT */, "ICC(0): no positive pivot in row %d even with the full diagonal shift", k); }
           again = PETSC_TRUE;
           break;
         }
@@ -146,8 +126,20 @@ static PetscErrorCode PCSetUp_ICC(PC pc) {
     f->nshift = PetscMax(f->nshift, nshift);
   }
   HipFree(work); HipFree(first); HipFree(list);
+  ierr = icc0_plans(F, n, ui, uj, ua);
+  HipFree(ui); HipFree(uj); HipFree(ua);
+  CHKERRQ(ierr);
+  return 0;
+}
+#endif
 
-  /* ---- the two triangular systems in row form, negated values ---- */
+/* the two triangular systems in row form, negated values, from the factor U (rows: strictly upper entries, then the inverted
+ * diagonal) in the reference's layout; dependency levels; the sync-free plans */
+static PetscErrorCode icc0_plans(Mat F, PetscInt n, const PetscInt *ui, const PetscInt *uj, const PetscScalar *ua) {
+  PetscErrorCode ierr;
+  HipTriFactors *f = HipTriGet(F);
+  PetscDeviceCtx *dc;
+  f->nz = ui[n];
   const PetscInt noff = f->nz - n;
   PetscInt *lp, *ll, *lj, *up, *ul, *uc, *levL, *levU; PetscScalar *lv, *uv, *ones, *dinv;
   ierr = PetscMalloc(sizeof(PetscInt) * (size_t)(n + 1), &lp);CHKERRQ(ierr);
@@ -189,53 +181,48 @@ static PetscErrorCode PCSetUp_ICC(PC pc) {
   int rc = mi355x_trisolve_plan_create_ordered(dc->h, n, f->nlevL, levL, lp, ll, lj, lv, NULL, 0, &f->tri_lo);
   if (!rc) rc = mi355x_trisolve_plan_create_scaled(dc->h, n, f->nlevU, levU, up, ul, uc, uv, ones, dinv, &f->tri_up);
   HipFree(lp); HipFree(ll); HipFree(lj); HipFree(lv); HipFree(up); HipFree(ul); HipFree(uc); HipFree(uv);
-  HipFree(levL); HipFree(levU); HipFree(ones); HipFree(dinv); HipFree(ui); HipFree(uj); HipFree(ua);
-  if (rc) { icc_free(f); CHKHIP(rc); }
-  f->factored_state = HipObjState(A);
-  return 0;
-}
-
-static PetscErrorCode PCApply_ICC(PC pc, Vec x, Vec y) {   /* PCApply_ICC (icc.c:65) -> MatSolve(fact, x, y) */
-  PetscErrorCode ierr;
-  PC_ICC *f = (PC_ICC *)pc->data;
-  const PetscScalar *db; PetscScalar *dx; PetscDeviceCtx *dc;
-  if (!f->n) return 0;
-  ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
-  ierr = VecHIPGetRead(x, &db);CHKERRQ(ierr);
-  ierr = VecHIPGetWrite(y, &dx);CHKERRQ(ierr);
-  int rc = mi355x_trisolve_apply(dc->h, f->tri_lo, f->tri_up, db, dx);
-  if (rc == 719) SETERRQ(HipObjComm(pc), PETSC_ERR_LIB, "sync-free triangular solve timed out in an earlier application");
+  HipFree(levL); HipFree(levU); HipFree(ones); HipFree(dinv);
   CHKHIP(rc);
-  ierr = VecHIPRestoreWrite(y);CHKERRQ(ierr);
-  HipStateIncrease(y);
-  ierr = PetscLogFlops(4.0 * f->nz - 3.0 * f->n);CHKERRQ(ierr);
   return 0;
 }
 
-static PetscErrorCode PCDestroy_ICC(PC pc) {
-  PC_ICC *f = (PC_ICC *)pc->data;
-  if (f) { icc_free(f); HipFree(f->blk); HipFree(f); pc->data = NULL; }
-  (void)PetscObjectComposeFunction((PetscObject)pc, "PCFactorSetIndependentBlocks_C", "", (PetscVoidFunction)NULL);
+static PetscErrorCode MatCholeskyFactorNumeric_SeqAIJHIP(Mat F, Mat A, const MatFactorInfo *info) {
+  PetscErrorCode ierr;
+  HipTriFactors *f = HipTriGet(F);
+  if (A->rmap->n != A->cmap->n) SETERRQ(HipObjComm(A), PETSC_ERR_ARG_WRONG, "Must be square matrix, rows %d columns %d", A->rmap->n, A->cmap->n);
+  if (f->factored_state == HipObjState(A) && f->factored_of == (void *)A && (f->tri_lo || !A->rmap->n)) return 0;
+  if (f->tri_lo) mi355x_trisolve_plan_destroy(f->tri_lo);
+  if (f->tri_up) mi355x_trisolve_plan_destroy(f->tri_up);
+  f->tri_lo = f->tri_up = NULL; f->use_levels = 0; f->nshift = 0; f->nlevL = f->nlevU = 0; f->factored_state = -1;
+#if defined(PETSCHIPMI355X_WITH_PETSC)
+  ierr = MatCholeskyFactorNumeric_SeqAIJ(F, A, info);CHKERRQ(ierr);     /* the parent's factorisation into F's own Mat_SeqSBAIJ (aijfact.c:2076) */
+  { Mat_SeqSBAIJ *b = (Mat_SeqSBAIJ *)F->data;
+    f->n = A->rmap->n;
+    if (f->n) { ierr = icc0_plans(F, f->n, b->i, b->j, b->a);CHKERRQ(ierr); } }
+#else
+  ierr = icc0_factor_host(F, A, info);CHKERRQ(ierr);
+#endif
+  if (f->tri_lo) HipTriWatchAdd(f);
+  F->ops->solve = MatSolve_SeqAIJHIP_ICC;
+  f->factored_state = HipObjState(A); f->factored_of = (void *)A;
   return 0;
 }
 
-PetscErrorCode PCCreate_ICC_HIPMI355X(PC pc) {
-  PC_ICC *f;
-  PetscErrorCode ierr = PetscMalloc(sizeof(*f), &f);CHKERRQ(ierr);
-  memset(f, 0, sizeof(*f));
-  f->factored_state = -1;
-  pc->data = f;
-  pc->ops->setup = PCSetUp_ICC; pc->ops->apply = PCApply_ICC; pc->ops->destroy = PCDestroy_ICC;
-  ierr = PetscObjectComposeFunction((PetscObject)pc, "PCFactorSetIndependentBlocks_C", "PCFactorSetIndependentBlocks_ICC", (PetscVoidFunction)PCFactorSetIndependentBlocks_ICC);CHKERRQ(ierr);
+PetscErrorCode MatICCFactorSymbolic_SeqAIJHIP(Mat F, Mat A, IS perm, const MatFactorInfo *info) {
+  PetscErrorCode ierr;
+  if (info->levels != 0.0) SETERRQ(HipObjComm(A), PETSC_ERR_SUP, "ICC(%d): only zero fill is on the ported path", (int)info->levels);
+  if (strcmp(HipObjTypeName(A), MATSEQAIJHIPMI355X)) SETERRQ(HipObjComm(A), PETSC_ERR_SUP, "ICC on the device needs a sequential AIJ matrix of this type (use -pc_type bjacobi -sub_pc_type icc in parallel); got %s", HipObjTypeName(A));
+#if defined(PETSCHIPMI355X_WITH_PETSC)
+  { PetscBool id = PETSC_TRUE;
+    if (perm) { ierr = ISIdentity(perm, &id);CHKERRQ(ierr); }
+    if (!id) SETERRQ(HipObjComm(A), PETSC_ERR_SUP, "ICC on the device: natural ordering only (-pc_factor_mat_ordering_type natural)");
+    ierr = MatICCFactorSymbolic_SeqAIJ(F, A, perm, info);CHKERRQ(ierr); }
+#else
+  if (perm) SETERRQ(HipObjComm(A), PETSC_ERR_SUP, "ICC: natural ordering only");
+  ierr = 0; (void)ierr;
+#endif
+  HipTriGet(F)->factored_state = -1;
+  F->ops->choleskyfactornumeric = MatCholeskyFactorNumeric_SeqAIJHIP;
   return 0;
 }
 
-/* dependency levels of the two sweeps and the number of positive-definite shifts the factorisation took (for tests / DESIGN.md) */
-PetscErrorCode PCICCGetInfo_HIPMI355X(PC pc, PetscInt *nlevL, PetscInt *nlevU, PetscInt *nshift) {
-  if (strcmp(HipObjTypeName(pc), "icc") && strcmp(HipObjTypeName(pc), "icchipmi355x")) SETERRQ(HipObjComm(pc), PETSC_ERR_ARG_WRONG, "not a PCICC");
-  PC_ICC *f = (PC_ICC *)pc->data;
-  if (nlevL) *nlevL = f->nlevL;
-  if (nlevU) *nlevU = f->nlevU;
-  if (nshift) *nshift = f->nshift;
-  return 0;
-}

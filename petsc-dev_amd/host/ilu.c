@@ -1,34 +1,65 @@
-/* PCILU with zero fill on a sequential AIJ block: the reference's default preconditioner on one rank
- * and its default sub-preconditioner under PCBJACOBI (src/ksp/pc/interface/precon.c:14-53).
- *   set-up : MatILUFactorSymbolic_SeqAIJ_ilu0 + MatLUFactorNumeric_SeqAIJ (src/mat/impls/aij/seq/aijfact.c:1628, :461),
- *            natural ordering, on the HOST copy of the matrix -- as the reference's own GPU back end does
- *            (src/mat/impls/aij/seq/seqcusparse/aijcusparse.cu:192-445 factors on the CPU and solves on the GPU);
- *            then a dependency-level analysis of L and U and one upload.
- *   apply  : MatSolve_SeqAIJ_NaturalOrdering (aijfact.c:3126) on the device, one lane per row in column order (same bits):
- *            by default two launches, one per triangular solve, with point-to-point hand-off of the solution values
- *            between wavefronts (mi355x_trisolve_*, csrc/trisolve.hip); -pc_factor_hipmi355x_trisolve level selects the
- *            level-scheduled kernels, one launch per dependency level (replayed from a hipGraph), which also serve
- *            systems with few levels and as the fall-back. */
+/* Factored matrices of MATSEQAIJHIPMI355X, ILU(0) part, behind the reference's own factorisation interface:
+ *
+ *   MatGetFactor(A, "petsc", MAT_FACTOR_ILU | MAT_FACTOR_ICC, &F)      "MatGetFactor_petsc_C" composed on every matrix of the type
+ *   MatILUFactorSymbolic(F, A, ...) / MatICCFactorSymbolic(F, A, ...)   F->ops->ilufactorsymbolic / iccfactorsymbolic
+ *   MatLUFactorNumeric(F, A, info) / MatCholeskyFactorNumeric(F, A, info)
+ *   MatSolve(F, b, x)                                                   F->ops->solve  = the device triangular solves
+ *
+ * so that an UNCHANGED PCILU / PCICC / PCBJACOBI (PETSc's own inside a PETSc tree, the harness's pcfactor.c on a box without
+ * PETSc) reaches the device solves -- how the reference's GPU back end does it (MatGetFactor_seqaij_cusparse,
+ * MatLUFactorNumeric_SeqAIJCUSPARSE installing MatSolve_SeqAIJCUSPARSE, src/mat/impls/aij/seq/seqcusparse/aijcusparse.cu:57-75,
+ * 175-200,358-445), and like it the factorisation itself runs on the host copy of the matrix.
+ *
+ *   numeric : MatILUFactorSymbolic_SeqAIJ_ilu0 + MatLUFactorNumeric_SeqAIJ (src/mat/impls/aij/seq/aijfact.c:1628, :461), natural
+ *             ordering.  Inside a PETSc tree those routines themselves (the parent class's); on the harness their restatement
+ *             below.  Then a dependency-level analysis of L and U and one upload.
+ *   solve   : MatSolve_SeqAIJ_NaturalOrdering (aijfact.c:3126) on the device, one lane per row in column order (same bits): by
+ *             default two launches, one per triangular solve, with point-to-point hand-off of the solution values between
+ *             wavefronts (mi355x_trisolve_*, csrc/trisolve.hip); -pc_factor_hipmi355x_trisolve level selects the level-scheduled
+ *             kernels, one launch per dependency level (replayed from a hipGraph), which also serve systems with few levels. */
 #include "hipmi355ximpl.h"
+#if defined(PETSCHIPMI355X_WITH_PETSC)
+#include <../src/mat/impls/aij/seq/aij.h>
+EXTERN_C_BEGIN
+extern PetscErrorCode MatGetFactor_seqaij_petsc(Mat, MatFactorType, Mat *);
+EXTERN_C_END
+#endif
 
-typedef struct {
-  PetscInt n, nz;
-  PetscInt *bi, *bj, *bdiag; PetscScalar *ba;            /* host factors */
-  PetscInt *d_bi, *d_bj, *d_bdiag; PetscScalar *d_ba;    /* device copies */
-  PetscInt nlevL, nlevU, *levptrL, *levptrU;             /* level pointers (host) */
-  PetscInt *d_rowsL, *d_rowsU;                           /* rows ordered by level (device) */
-  PetscScalar *d_work;                                   /* fixed in-place buffer the captured graph works on */
-  void *graph;                                           /* hipGraphExec of the nlevL + nlevU level launches */
-  int graph_tried;
-  mi355x_trisolve_plan_t tri_lo, tri_up;                 /* sync-free solves (NULL: level launches) */
-  int by_level;                                          /* rows summed in dependency-level order (inode matrices) instead of column order */
-  PetscInt nshift;                                       /* restarts of the factorisation MatPivotCheck_nz asked for (largest count over the blocks) */
-  int factored_state;
-  PetscInt nblk, *blk;                                   /* "PCFactorSetIndependentBlocks_C": the matrix stands for that many separate matrices (row ranges), each with its own shift loop */
-} PC_ILU;
+/* ---------------------------------------------------------------- sync-free solves that gave up: noticed at the next host wait
+ * A dependency wait of the sync-free kernels is bounded; a lane that gives up raises a flag in pinned host memory and the
+ * application's result is unusable.  The flag cannot be read before the kernels have run, so every factored matrix with
+ * sync-free plans is on a watch list, and every host wait the solvers already perform (reduction results, VecGetArray:
+ * HipTriWatchCheck, called from vechip.c) looks at the flags: the first wait after an abort returns PETSC_ERR_LIB instead of
+ * numbers computed from a poisoned vector, and the factor is switched to the level-by-level form of the same plans for every
+ * later application (MatSolve below), ILU(0) and ICC(0) alike. */
+#define TRI_WATCH_MAX 64
+static HipTriFactors *tri_watch[TRI_WATCH_MAX];
+void HipTriWatchAdd(HipTriFactors *f) {
+  for (int i = 0; i < TRI_WATCH_MAX; i++) if (tri_watch[i] == f) return;
+  for (int i = 0; i < TRI_WATCH_MAX; i++) if (!tri_watch[i]) { tri_watch[i] = f; return; }
+}
+static void tri_watch_remove(HipTriFactors *f) { for (int i = 0; i < TRI_WATCH_MAX; i++) if (tri_watch[i] == f) tri_watch[i] = NULL; }
+PetscErrorCode HipTriWatchCheck(void) {
+  for (int i = 0; i < TRI_WATCH_MAX; i++) {
+    HipTriFactors *f = tri_watch[i];
+    int a = 0, b = 0;
+    if (!f || !f->tri_lo || f->use_levels) continue;
+    mi355x_trisolve_aborted(f->tri_lo, &a); mi355x_trisolve_aborted(f->tri_up, &b);
+    if (a || b) {
+      f->use_levels = 1; f->aborted = 1;
+      SETERRQ(PETSC_COMM_SELF, PETSC_ERR_LIB, "a sync-free triangular solve gave up waiting for a dependency: results computed since that MatSolve are invalid; "
+                                              "later applications of this factor use one launch per dependency level");
+    }
+  }
+  return 0;
+}
 
-static PetscErrorCode ilu_free(PC_ILU *f) {
-  HipFree(f->bi); HipFree(f->bj); HipFree(f->bdiag); HipFree(f->ba); HipFree(f->levptrL); HipFree(f->levptrU);
+PetscErrorCode HipTriFactorsDestroy(HipTriFactors **pf) {
+  HipTriFactors *f = *pf;
+  if (!f) return 0;
+  tri_watch_remove(f);
+  if (f->owns_host) { HipFree(f->bi); HipFree(f->bj); HipFree(f->bdiag); HipFree(f->ba); }
+  HipFree(f->levptrL); HipFree(f->levptrU); HipFree(f->blk);
   if (f->d_bi) mi355x_free(f->d_bi);
   if (f->d_bj) mi355x_free(f->d_bj);
   if (f->d_bdiag) mi355x_free(f->d_bdiag);
@@ -39,18 +70,38 @@ static PetscErrorCode ilu_free(PC_ILU *f) {
   if (f->graph) mi355x_graph_destroy(f->graph);
   if (f->tri_lo) mi355x_trisolve_plan_destroy(f->tri_lo);
   if (f->tri_up) mi355x_trisolve_plan_destroy(f->tri_up);
-  { PetscInt nblk = f->nblk, *blk = f->blk;
-    memset(f, 0, sizeof(*f));
-    f->nblk = nblk; f->blk = blk; }
-  f->factored_state = -1;
+  HipFree(f);
+  *pf = NULL;
   return 0;
 }
+/* forget one numeric factorisation (the symbolic choices, the block list and the watch slot stay) */
+static void tri_reset_numeric(HipTriFactors *f) {
+  if (f->owns_host) { HipFree(f->bi); HipFree(f->bj); HipFree(f->bdiag); HipFree(f->ba); }
+  f->bi = f->bj = f->bdiag = NULL; f->ba = NULL;
+  HipFree(f->levptrL); HipFree(f->levptrU); f->levptrL = f->levptrU = NULL;
+  if (f->d_bi) mi355x_free(f->d_bi);
+  if (f->d_bj) mi355x_free(f->d_bj);
+  if (f->d_bdiag) mi355x_free(f->d_bdiag);
+  if (f->d_ba) mi355x_free(f->d_ba);
+  if (f->d_rowsL) mi355x_free(f->d_rowsL);
+  if (f->d_rowsU) mi355x_free(f->d_rowsU);
+  if (f->d_work) mi355x_free(f->d_work);
+  if (f->graph) mi355x_graph_destroy(f->graph);
+  if (f->tri_lo) mi355x_trisolve_plan_destroy(f->tri_lo);
+  if (f->tri_up) mi355x_trisolve_plan_destroy(f->tri_up);
+  f->d_bi = f->d_bj = f->d_bdiag = f->d_rowsL = f->d_rowsU = NULL; f->d_ba = f->d_work = NULL;
+  f->graph = NULL; f->graph_tried = 0; f->tri_lo = f->tri_up = NULL;
+  f->use_levels = 0; f->nshift = 0; f->nlevL = f->nlevU = 0;
+  f->factored_state = -1;
+}
 
-/* block Jacobi solving all its ILU(0) blocks as one block-diagonal system: every block is factored as the reference factors a
- * matrix of its own (its own restarts), so the result is the blocks' factors side by side also when one block needs a shift */
-static PetscErrorCode PCFactorSetIndependentBlocks_ILU(PC pc, PetscInt nblk, const PetscInt *starts) {
-  PC_ILU *f = (PC_ILU *)pc->data;
+/* block Jacobi solving all its ILU(0) / ICC(0) blocks as one block-diagonal system ("MatFactorSetIndependentBlocks_C", asked for
+ * by the harness's PCILU / PCICC): every block is factored as the reference factors a matrix of its own (its own shift loop), so
+ * the result is the blocks' factors side by side also when one block needs a shift */
+static PetscErrorCode MatFactorSetIndependentBlocks_SeqAIJHIP(Mat F, PetscInt nblk, const PetscInt *starts) {
+  HipTriFactors *f = HipTriGet(F);
   PetscErrorCode ierr;
+  if (f->nblk == nblk && (!nblk || !memcmp(f->blk, starts, sizeof(PetscInt) * (size_t)(nblk + 1)))) return 0;
   HipFree(f->blk); f->blk = NULL; f->nblk = 0;
   if (nblk > 0) {
     ierr = PetscMalloc(sizeof(PetscInt) * (size_t)(nblk + 1), &f->blk);CHKERRQ(ierr);
@@ -78,31 +129,40 @@ static PetscErrorCode level_order(PetscInt n, const PetscInt *lev, PetscInt nlev
   return 0;
 }
 
-static PetscErrorCode PCSetUp_ILU(PC pc) {
+static PetscErrorCode natural_ordering_only(Mat A, IS row, IS col, const MatFactorInfo *info, const char *what) {
+  if (info->levels != 0.0) SETERRQ(HipObjComm(A), PETSC_ERR_SUP, "%s(%d): only zero fill is on the ported path", what, (int)info->levels);
+#if defined(PETSCHIPMI355X_WITH_PETSC)
+  { PetscErrorCode ierr; PetscBool id = PETSC_TRUE;
+    if (row) { ierr = ISIdentity(row, &id);CHKERRQ(ierr); if (!id) SETERRQ(HipObjComm(A), PETSC_ERR_SUP, "%s on the device: natural ordering only (-pc_factor_mat_ordering_type natural)", what); }
+    if (col) { ierr = ISIdentity(col, &id);CHKERRQ(ierr); if (!id) SETERRQ(HipObjComm(A), PETSC_ERR_SUP, "%s on the device: natural ordering only (-pc_factor_mat_ordering_type natural)", what); } }
+#else
+  if (row || col) SETERRQ(HipObjComm(A), PETSC_ERR_SUP, "%s: natural ordering only", what);
+#endif
+  return 0;
+}
+
+#if !defined(PETSCHIPMI355X_WITH_PETSC)
+/* MatILUFactorSymbolic_SeqAIJ_ilu0 + MatLUFactorNumeric_SeqAIJ restated for the harness (inside a PETSc tree the parent's
+ * routines run instead): the pattern of A, L part forward, U part from the last row backwards (aijfact.c:1660-1685); row by row
+ * with a dense work row, pivots stored inverted (aijfact.c:505-570); MatPivotCheck_nz's restarts (matimpl.h:512-528) */
+static PetscErrorCode ilu0_factor_host(Mat F, Mat A, const MatFactorInfo *info) {
   PetscErrorCode ierr;
-  PC_ILU *f = (PC_ILU *)pc->data;
-  Mat A = pc->pmat;
+  HipTriFactors *f = HipTriGet(F);
   PetscInt n; const PetscInt *ai, *aj; const PetscScalar *aa;
-  PetscDeviceCtx *dc;
-  if (strcmp(HipObjTypeName(A), MATSEQAIJHIPMI355X)) SETERRQ(HipObjComm(pc), PETSC_ERR_SUP, "PCILU needs a sequential AIJ matrix (use -pc_type bjacobi -sub_pc_type ilu in parallel); got %s", HipObjTypeName(A));
-  if (f->factored_state == HipObjState(A) && f->d_ba) return 0;
   ierr = MatSeqAIJGetArrays(A, &n, &ai, &aj, &aa);CHKERRQ(ierr);
-  if (A->rmap->n != A->cmap->n) SETERRQ(HipObjComm(pc), PETSC_ERR_ARG_WRONG, "Must be square matrix, rows %d columns %d", A->rmap->n, A->cmap->n);
-  ierr = ilu_free(f);CHKERRQ(ierr);
-  f->n = n; f->nz = ai[n];
+  f->n = n; f->nz = ai[n]; f->owns_host = PETSC_TRUE;
   PetscInt *adiag;
   ierr = PetscMalloc(sizeof(PetscInt) * (size_t)PetscMax(n, 1), &adiag);CHKERRQ(ierr);
   for (PetscInt i = 0; i < n; i++) {
     adiag[i] = -1;
     for (PetscInt q = ai[i]; q < ai[i + 1]; q++) if (aj[q] == i) { adiag[i] = q; break; }
-    if (adiag[i] < 0) SETERRQ(HipObjComm(pc), PETSC_ERR_ARG_WRONGSTATE, "Matrix is missing diagonal entry %d", i);
+    if (adiag[i] < 0) { HipFree(adiag); SETERRQ(HipObjComm(A), PETSC_ERR_ARG_WRONGSTATE, "Matrix is missing diagonal entry %d", i); }
   }
   ierr = PetscMalloc(sizeof(PetscInt) * (size_t)(n + 1), &f->bi);CHKERRQ(ierr);
   ierr = PetscMalloc(sizeof(PetscInt) * (size_t)(f->nz + 1), &f->bj);CHKERRQ(ierr);
   ierr = PetscMalloc(sizeof(PetscInt) * (size_t)(n + 1), &f->bdiag);CHKERRQ(ierr);
   ierr = PetscMalloc(sizeof(PetscScalar) * (size_t)(f->nz + 1), &f->ba);CHKERRQ(ierr);
   memset(f->ba, 0, sizeof(PetscScalar) * (size_t)(f->nz + 1));
-  /* symbolic: the pattern of A, L part forward, U part from the last row backwards (aijfact.c:1660-1685) */
   PetscInt k = 0, *bi = f->bi, *bj = f->bj, *bdiag = f->bdiag; PetscScalar *ba = f->ba;
   bi[0] = 0;
   for (PetscInt i = 0; i < n; i++) {
@@ -117,23 +177,23 @@ static PetscErrorCode PCSetUp_ILU(PC pc) {
     bj[k++] = i;
     bdiag[i] = bdiag[i + 1] + nzu + 1;
   }
-  /* numeric (aijfact.c:505-570): row by row with a dense work row; pivots are stored inverted */
   PetscScalar *rtmp;
   ierr = PetscMalloc(sizeof(PetscScalar) * (size_t)(n + 1), &rtmp);CHKERRQ(ierr);
-  const PetscReal zeropivot = 100.0 * 2.220446049250313e-16, shiftamount = 100.0 * 2.220446049250313e-16;   /* ilu.c:388-389 */
+  const PetscReal zeropivot = info->zeropivot, shiftamount = info->shiftamount;
+  const PetscBool shift_nz = (PetscBool)(info->shifttype == (PetscReal)MAT_SHIFT_NONZERO);
   f->nshift = 0;
   const PetscInt whole[2] = {0, n};
   const PetscInt nblk = (f->nblk > 0 && f->blk[f->nblk] == n) ? f->nblk : 1, *blk = (f->nblk > 0 && f->blk[f->nblk] == n) ? f->blk : whole;
   for (PetscInt bb = 0; bb < nblk; bb++) {
     const PetscInt r0 = blk[bb], r1 = blk[bb + 1];
     for (PetscInt i = r0; i < r1; i++) {
-      if (ai[i] < ai[i + 1] && (aj[ai[i]] < r0 || aj[ai[i + 1] - 1] >= r1)) { HipFree(rtmp); HipFree(adiag); SETERRQ(HipObjComm(pc), PETSC_ERR_ARG_WRONG, "row %d couples to a column outside its independent block", i); }
+      if (ai[i] < ai[i + 1] && (aj[ai[i]] < r0 || aj[ai[i + 1] - 1] >= r1)) { HipFree(rtmp); HipFree(adiag); SETERRQ(HipObjComm(A), PETSC_ERR_ARG_WRONG, "row %d couples to a column outside its independent block", i); }
     }
     PetscReal shift_amount = 0.0;
     PetscInt nshift = 0;
     PetscBool again;
-    do {   /* MAT_SHIFT_NONZERO, PCILU's default on a SeqAIJ matrix (ilu.c:387): a pivot that fails MatPivotCheck_nz (matimpl.h:512-528)
-            * restarts the factorisation with the diagonal shifted by shiftamount, then by twice that, ... (aijfact.c:507-592) */
+    do {   /* MAT_SHIFT_NONZERO, PCILU's default on a SeqAIJ matrix (ilu.c:387): a pivot that fails MatPivotCheck_nz restarts the
+            * factorisation with the diagonal shifted by shiftamount, then by twice that, ... (aijfact.c:507-592) */
       again = PETSC_FALSE;
       for (PetscInt i = r0; i < r1; i++) {
         PetscInt nzl = bi[i + 1] - bi[i], nzu = bdiag[i] - bdiag[i + 1];
@@ -157,9 +217,10 @@ static PetscErrorCode PCSetUp_ILU(PC pc) {
         for (PetscInt j = 0; j < nzl; j++) { ba[bi[i] + j] = rtmp[bj[bi[i] + j]]; rs += PetscAbsScalar(ba[bi[i] + j]); }
         for (PetscInt j = 0; j < nzu - 1; j++) { ba[bdiag[i + 1] + 1 + j] = rtmp[bj[bdiag[i + 1] + 1 + j]]; rs += PetscAbsScalar(ba[bdiag[i + 1] + 1 + j]); }
         if (PetscAbsScalar(rtmp[i]) <= zeropivot * rs) {
+          if (!shift_nz) { HipFree(rtmp); HipFree(adiag); SETERRQ(HipObjComm(A), 71 /* PETSC_ERR_MAT_LU_ZRPVT */, "Zero pivot row %d value %g tolerance %g", i, PetscAbsScalar(rtmp[i]), zeropivot * rs); }
           shift_amount = nshift ? shift_amount * 2.0 : shiftamount;
           nshift++;
-          if (nshift > 80) { HipFree(rtmp); HipFree(adiag); SETERRQ(HipObjComm(pc), 71 /* PETSC_ERR_MAT_LU_ZRPVT */, "Zero pivot row %d value %g: still there after %d diagonal shifts", i, PetscAbsScalar(rtmp[i]), nshift); }
+          if (nshift > 80) { HipFree(rtmp); HipFree(adiag); SETERRQ(HipObjComm(A), 71 /* PETSC_ERR_MAT_LU_ZRPVT */, "Zero pivot row %d value %g: still there after %d diagonal shifts", i, PetscAbsScalar(rtmp[i]), nshift); }
           again = PETSC_TRUE;
           break;
         }
@@ -169,12 +230,22 @@ static PetscErrorCode PCSetUp_ILU(PC pc) {
     f->nshift = PetscMax(f->nshift, nshift);
   }
   HipFree(rtmp); HipFree(adiag);
-  /* dependency levels: a row may start once the rows it references are done */
+  return 0;
+}
+#endif
+
+/* dependency levels of the two triangular factors, the sync-free plans, the level lists: everything MatSolve needs, from the
+ * host factor in f->bi / bj / bdiag / ba (the reference's layout, whoever computed it) */
+static PetscErrorCode ilu0_analyse_and_upload(Mat F, Mat A) {
+  PetscErrorCode ierr;
+  HipTriFactors *f = HipTriGet(F);
+  const PetscInt n = f->n, *bi = f->bi, *bj = f->bj, *bdiag = f->bdiag; const PetscScalar *ba = f->ba;
+  PetscDeviceCtx *dc;
   PetscInt *lev, *levU, *rowsL, *rowsU;
   ierr = PetscMalloc(sizeof(PetscInt) * (size_t)PetscMax(n, 1), &lev);CHKERRQ(ierr);
   ierr = PetscMalloc(sizeof(PetscInt) * (size_t)PetscMax(n, 1), &levU);CHKERRQ(ierr);
   f->nlevL = 0;
-  for (PetscInt i = 0; i < n; i++) {
+  for (PetscInt i = 0; i < n; i++) {          /* a row may start once the rows it references are done */
     PetscInt l = 0;
     for (PetscInt q = bi[i]; q < bi[i + 1]; q++) l = PetscMax(l, lev[bj[q]] + 1);
     lev[i] = l; f->nlevL = PetscMax(f->nlevL, l + 1);
@@ -190,8 +261,8 @@ static PetscErrorCode PCSetUp_ILU(PC pc) {
   ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
   {   /* sync-free solves: worth it as soon as the level launches would be a launch-bound chain */
     char mode[32] = "syncfree"; PetscBool set;
-    ierr = PetscOptionsGetString(HipObjPrefix(pc), "-pc_factor_hipmi355x_trisolve", mode, sizeof(mode), &set);CHKERRQ(ierr);
-    if (strcmp(mode, "syncfree") && strcmp(mode, "level")) SETERRQ(HipObjComm(pc), PETSC_ERR_ARG_WRONG, "-pc_factor_hipmi355x_trisolve <syncfree|level>, got %s", mode);
+    ierr = PetscOptionsGetString(HipObjPrefix(F), "-pc_factor_hipmi355x_trisolve", mode, sizeof(mode), &set);CHKERRQ(ierr);
+    if (strcmp(mode, "syncfree") && strcmp(mode, "level")) SETERRQ(HipObjComm(F), PETSC_ERR_ARG_WRONG, "-pc_factor_hipmi355x_trisolve <syncfree|level>, got %s", mode);
     if (!strcmp(mode, "syncfree") && n > 0 && (f->nlevL + f->nlevU > 16 || set)) {
       PetscInt *rpU, *rlU, *rlL; PetscScalar *dinv;
       ierr = PetscMalloc(sizeof(PetscInt) * (size_t)n, &rpU);CHKERRQ(ierr);
@@ -208,8 +279,8 @@ static PetscErrorCode PCSetUp_ILU(PC pc) {
        * inodes, whose factor it solves with MatSolve_SeqAIJ_Inode (inode.c; MatLUFactorNumeric_SeqAIJ_Inode installs it),
        * in yet another order.  There the two agree to rounding. */
       char ord[32] = ""; PetscInt nodes = 0; int by_level;
-      ierr = PetscOptionsGetString(HipObjPrefix(pc), "-pc_factor_hipmi355x_trisolve_order", ord, sizeof(ord), &set);CHKERRQ(ierr);
-      if (set && strcmp(ord, "column") && strcmp(ord, "level")) SETERRQ(HipObjComm(pc), PETSC_ERR_ARG_WRONG, "-pc_factor_hipmi355x_trisolve_order <column|level>, got %s", ord);
+      ierr = PetscOptionsGetString(HipObjPrefix(F), "-pc_factor_hipmi355x_trisolve_order", ord, sizeof(ord), &set);CHKERRQ(ierr);
+      if (set && strcmp(ord, "column") && strcmp(ord, "level")) SETERRQ(HipObjComm(F), PETSC_ERR_ARG_WRONG, "-pc_factor_hipmi355x_trisolve_order <column|level>, got %s", ord);
       ierr = MatHIPMI355XGetInodeInfo(A, &nodes, NULL, NULL);CHKERRQ(ierr);
       by_level = set ? !strcmp(ord, "level") : (nodes > 0);
       f->by_level = by_level;
@@ -220,51 +291,98 @@ static PetscErrorCode PCSetUp_ILU(PC pc) {
         if (f->tri_lo) mi355x_trisolve_plan_destroy(f->tri_lo);
         if (f->tri_up) mi355x_trisolve_plan_destroy(f->tri_up);
         f->tri_lo = f->tri_up = NULL;
-      }
+      } else HipTriWatchAdd(f);
     }
   }
   HipFree(lev); HipFree(levU);
-  CHKHIP(mi355x_malloc((void **)&f->d_bi, sizeof(PetscInt) * (size_t)(n + 1)));
-  CHKHIP(mi355x_malloc((void **)&f->d_bj, sizeof(PetscInt) * (size_t)(f->nz + 1)));
-  CHKHIP(mi355x_malloc((void **)&f->d_bdiag, sizeof(PetscInt) * (size_t)(n + 1)));
-  CHKHIP(mi355x_malloc((void **)&f->d_ba, sizeof(PetscScalar) * (size_t)(f->nz + 1)));
-  CHKHIP(mi355x_malloc((void **)&f->d_rowsL, sizeof(PetscInt) * (size_t)PetscMax(n, 1)));
-  CHKHIP(mi355x_malloc((void **)&f->d_rowsU, sizeof(PetscInt) * (size_t)PetscMax(n, 1)));
-  CHKHIP(mi355x_memcpy_h2d(dc->h, f->d_bi, bi, sizeof(PetscInt) * (size_t)(n + 1)));
-  CHKHIP(mi355x_memcpy_h2d(dc->h, f->d_bj, bj, sizeof(PetscInt) * (size_t)(f->nz + 1)));
-  CHKHIP(mi355x_memcpy_h2d(dc->h, f->d_bdiag, bdiag, sizeof(PetscInt) * (size_t)(n + 1)));
-  CHKHIP(mi355x_memcpy_h2d(dc->h, f->d_ba, ba, sizeof(PetscScalar) * (size_t)(f->nz + 1)));
-  CHKHIP(mi355x_memcpy_h2d(dc->h, f->d_rowsL, rowsL, sizeof(PetscInt) * (size_t)n));
-  CHKHIP(mi355x_memcpy_h2d(dc->h, f->d_rowsU, rowsU, sizeof(PetscInt) * (size_t)n));
-  CHKHIP(mi355x_handle_synchronize(dc->h));
+  if (!f->tri_lo) {   /* the level-scheduled kernels work on the reference's layout itself */
+    CHKHIP(mi355x_malloc((void **)&f->d_bi, sizeof(PetscInt) * (size_t)(n + 1)));
+    CHKHIP(mi355x_malloc((void **)&f->d_bj, sizeof(PetscInt) * (size_t)(f->nz + 1)));
+    CHKHIP(mi355x_malloc((void **)&f->d_bdiag, sizeof(PetscInt) * (size_t)(n + 1)));
+    CHKHIP(mi355x_malloc((void **)&f->d_ba, sizeof(PetscScalar) * (size_t)(f->nz + 1)));
+    CHKHIP(mi355x_malloc((void **)&f->d_rowsL, sizeof(PetscInt) * (size_t)PetscMax(n, 1)));
+    CHKHIP(mi355x_malloc((void **)&f->d_rowsU, sizeof(PetscInt) * (size_t)PetscMax(n, 1)));
+    CHKHIP(mi355x_memcpy_h2d(dc->h, f->d_bi, bi, sizeof(PetscInt) * (size_t)(n + 1)));
+    CHKHIP(mi355x_memcpy_h2d(dc->h, f->d_bj, bj, sizeof(PetscInt) * (size_t)(f->nz + 1)));
+    CHKHIP(mi355x_memcpy_h2d(dc->h, f->d_bdiag, bdiag, sizeof(PetscInt) * (size_t)(n + 1)));
+    CHKHIP(mi355x_memcpy_h2d(dc->h, f->d_ba, ba, sizeof(PetscScalar) * (size_t)(f->nz + 1)));
+    CHKHIP(mi355x_memcpy_h2d(dc->h, f->d_rowsL, rowsL, sizeof(PetscInt) * (size_t)n));
+    CHKHIP(mi355x_memcpy_h2d(dc->h, f->d_rowsU, rowsU, sizeof(PetscInt) * (size_t)n));
+    CHKHIP(mi355x_handle_synchronize(dc->h));
+  }
   HipFree(rowsL); HipFree(rowsU);
-  f->factored_state = HipObjState(A);
   return 0;
 }
 
-static PetscErrorCode PCApply_ILU(PC pc, Vec x, Vec y) {   /* PCApply_ILU -> MatSolve(fact, x, y) */
+static PetscErrorCode MatSolve_SeqAIJHIP_ILU(Mat F, Vec b, Vec x);
+
+static PetscErrorCode MatLUFactorNumeric_SeqAIJHIP(Mat F, Mat A, const MatFactorInfo *info) {   /* MatLUFactorNumeric_SeqAIJCUSPARSE, aijcusparse.cu:358-376 */
   PetscErrorCode ierr;
-  PC_ILU *f = (PC_ILU *)pc->data;
+  HipTriFactors *f = HipTriGet(F);
+  if (A->rmap->n != A->cmap->n) SETERRQ(HipObjComm(A), PETSC_ERR_ARG_WRONG, "Must be square matrix, rows %d columns %d", A->rmap->n, A->cmap->n);
+  if (f->factored_state == HipObjState(A) && f->factored_of == (void *)A && (f->tri_lo || f->d_ba)) return 0;   /* same operator, same values: nothing to redo */
+  tri_reset_numeric(f);
+#if defined(PETSCHIPMI355X_WITH_PETSC)
+  ierr = MatLUFactorNumeric_SeqAIJ(F, A, info);CHKERRQ(ierr);            /* the parent's factorisation into F's own Mat_SeqAIJ */
+  { Mat_SeqAIJ *b = (Mat_SeqAIJ *)F->data;
+    f->n = A->rmap->n; f->nz = b->nz; f->bi = b->i; f->bj = b->j; f->bdiag = b->diag; f->ba = b->a; f->owns_host = PETSC_FALSE; }
+#else
+  ierr = ilu0_factor_host(F, A, info);CHKERRQ(ierr);
+#endif
+  ierr = ilu0_analyse_and_upload(F, A);CHKERRQ(ierr);
+  F->ops->solve = MatSolve_SeqAIJHIP_ILU;                                 /* aijcusparse.cu:372-373 */
+  f->factored_state = HipObjState(A); f->factored_of = (void *)A;
+  return 0;
+}
+
+static PetscErrorCode MatILUFactorSymbolic_SeqAIJHIP(Mat F, Mat A, IS row, IS col, const MatFactorInfo *info) {   /* aijcusparse.cu:175-186 */
+  PetscErrorCode ierr = natural_ordering_only(A, row, col, info, "ILU");CHKERRQ(ierr);
+  if (strcmp(HipObjTypeName(A), MATSEQAIJHIPMI355X)) SETERRQ(HipObjComm(A), PETSC_ERR_SUP, "ILU on the device needs a sequential AIJ matrix of this type (use -pc_type bjacobi -sub_pc_type ilu in parallel); got %s", HipObjTypeName(A));
+#if defined(PETSCHIPMI355X_WITH_PETSC)
+  ierr = MatILUFactorSymbolic_SeqAIJ(F, A, row, col, info);CHKERRQ(ierr);
+#endif
+  HipTriGet(F)->factored_state = -1;
+  F->ops->lufactornumeric = MatLUFactorNumeric_SeqAIJHIP;
+  return 0;
+}
+
+/* y = U^-1 L^-1 b through whatever the analysis prepared.  After a sync-free application gave up (HipTriWatchCheck), the same
+ * plans run level by level. */
+PetscErrorCode HipTriFactorsApply(Mat F, HipTriFactors *f, Vec b, Vec x, PetscLogDouble flops) {
+  PetscErrorCode ierr;
   const PetscScalar *db; PetscScalar *dx; PetscDeviceCtx *dc;
+  int rc;
+  if (!f->n) return 0;
   ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
-  ierr = VecHIPGetRead(x, &db);CHKERRQ(ierr);
-  ierr = VecHIPGetWrite(y, &dx);CHKERRQ(ierr);
-  /* The level launches are a launch-bound inner loop (766 + 766 kernels for P7(256)): with more than a handful of
-   * levels they are captured once into a hipGraph that works in place on a fixed buffer and replayed per
-   * application (copy in, one graph launch, copy out).  Same kernels, same order, same bits. */
-  if (f->tri_lo) {
-    int rc = mi355x_trisolve_apply(dc->h, f->tri_lo, f->tri_up, db, dx);
-    if (rc == 719) {   /* hipErrorLaunchFailure: an earlier application gave up on a dependency (its result was unusable) */
-      mi355x_trisolve_plan_destroy(f->tri_lo); mi355x_trisolve_plan_destroy(f->tri_up);
-      f->tri_lo = f->tri_up = NULL;
-      SETERRQ(HipObjComm(pc), PETSC_ERR_LIB, "sync-free triangular solve timed out in an earlier application; the level-scheduled solves are used from now on");
+  ierr = VecHIPGetRead(b, &db);CHKERRQ(ierr);
+  ierr = VecHIPGetWrite(x, &dx);CHKERRQ(ierr);
+  if (f->use_levels) rc = mi355x_trisolve_apply_levels(dc->h, f->tri_lo, f->tri_up, db, dx);
+  else {
+    rc = mi355x_trisolve_apply(dc->h, f->tri_lo, f->tri_up, db, dx);
+    if (rc == 719) {   /* hipErrorLaunchFailure: an earlier application gave up and no host wait has noticed yet: this one runs level by level */
+      f->use_levels = 1; f->aborted = 1;
+      rc = mi355x_trisolve_apply_levels(dc->h, f->tri_lo, f->tri_up, db, dx);
     }
-    CHKHIP(rc);
-    ierr = VecHIPRestoreWrite(y);CHKERRQ(ierr);
-    HipStateIncrease(y);
-    ierr = PetscLogFlops(2.0 * f->nz - f->n);CHKERRQ(ierr);
-    return 0;
   }
+  ierr = VecHIPRestoreWrite(x);CHKERRQ(ierr);      /* also on the error path: x is not left in write state */
+  HipStateIncrease(x);
+  CHKHIP(rc);
+  ierr = PetscLogFlops(flops);CHKERRQ(ierr);
+  (void)F;
+  return 0;
+}
+
+static PetscErrorCode MatSolve_SeqAIJHIP_ILU(Mat F, Vec b, Vec x) {   /* MatSolve_SeqAIJCUSPARSE_NaturalOrdering, aijcusparse.cu:419-445 */
+  PetscErrorCode ierr;
+  HipTriFactors *f = HipTriGet(F);
+  const PetscScalar *db; PetscScalar *dx; PetscDeviceCtx *dc;
+  if (f->tri_lo) return HipTriFactorsApply(F, f, b, x, 2.0 * f->nz - f->n);
+  ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
+  ierr = VecHIPGetRead(b, &db);CHKERRQ(ierr);
+  ierr = VecHIPGetWrite(x, &dx);CHKERRQ(ierr);
+  /* The level launches are a launch-bound inner loop (766 + 766 kernels for P7(256)): with more than a handful of levels they
+   * are captured once into a hipGraph that works in place on a fixed buffer and replayed per application (copy in, one graph
+   * launch, copy out).  Same kernels, same order, same bits. */
   if (!f->graph_tried && f->nlevL + f->nlevU > 16) {
     f->graph_tried = 1;
     if (!mi355x_malloc((void **)&f->d_work, sizeof(PetscScalar) * (size_t)PetscMax(f->n, 1)) && !mi355x_graph_capture_begin(dc->h)) {
@@ -278,68 +396,121 @@ static PetscErrorCode PCApply_ILU(PC pc, Vec x, Vec y) {   /* PCApply_ILU -> Mat
       f->graph = g;
     }
   }
+  int rc = 0;
   if (f->graph) {
-    CHKHIP(mi355x_vec_copy(dc->h, (size_t)f->n, db, f->d_work));
-    CHKHIP(mi355x_graph_launch(dc->h, f->graph));
-    CHKHIP(mi355x_vec_copy(dc->h, (size_t)f->n, f->d_work, dx));
+    rc = mi355x_vec_copy(dc->h, (size_t)f->n, db, f->d_work);
+    if (!rc) rc = mi355x_graph_launch(dc->h, f->graph);
+    if (!rc) rc = mi355x_vec_copy(dc->h, (size_t)f->n, f->d_work, dx);
   } else {
-    for (PetscInt l = 0; l < f->nlevL; l++)
-      CHKHIP(mi355x_ilu0_lower_level(dc->h, f->levptrL[l + 1] - f->levptrL[l], f->d_rowsL + f->levptrL[l], f->d_bi, f->d_bj, f->d_ba, db, dx));
-    for (PetscInt l = 0; l < f->nlevU; l++)
-      CHKHIP(mi355x_ilu0_upper_level(dc->h, f->levptrU[l + 1] - f->levptrU[l], f->d_rowsU + f->levptrU[l], f->d_bj, f->d_ba, f->d_bdiag, dx));
+    for (PetscInt l = 0; l < f->nlevL && !rc; l++)
+      rc = mi355x_ilu0_lower_level(dc->h, f->levptrL[l + 1] - f->levptrL[l], f->d_rowsL + f->levptrL[l], f->d_bi, f->d_bj, f->d_ba, db, dx);
+    for (PetscInt l = 0; l < f->nlevU && !rc; l++)
+      rc = mi355x_ilu0_upper_level(dc->h, f->levptrU[l + 1] - f->levptrU[l], f->d_rowsU + f->levptrU[l], f->d_bj, f->d_ba, f->d_bdiag, dx);
   }
-  ierr = VecHIPRestoreWrite(y);CHKERRQ(ierr);
-  HipStateIncrease(y);
+  ierr = VecHIPRestoreWrite(x);CHKERRQ(ierr);
+  HipStateIncrease(x);
+  CHKHIP(rc);
   ierr = PetscLogFlops(2.0 * f->nz - f->n);CHKERRQ(ierr);
   return 0;
 }
 
-static PetscErrorCode PCDestroy_ILU(PC pc) {
-  PC_ILU *f = (PC_ILU *)pc->data;
-  if (f) { ilu_free(f); HipFree(f->blk); HipFree(f); pc->data = NULL; }
-  (void)PetscObjectComposeFunction((PetscObject)pc, "PCFactorSetIndependentBlocks_C", "", (PetscVoidFunction)NULL);
+/* ---------------------------------------------------------------- MatGetFactor */
+#if defined(PETSCHIPMI355X_WITH_PETSC)
+static PetscErrorCode MatDestroy_Factor_SeqAIJHIP(Mat F) {   /* the factor's device state first, spptr zeroed, then the parent's destroy (aijcusp.cu:584-586) */
+  HipTriFactors *f = HipTriGet(F);
+  PetscErrorCode (*parent)(Mat) = f ? f->parent_destroy : NULL;
+  PetscErrorCode ierr = HipTriFactorsDestroy(&f);CHKERRQ(ierr);
+  F->spptr = 0;
+  if (parent) { ierr = (*parent)(F);CHKERRQ(ierr); }
   return 0;
 }
+#endif
 
-PetscErrorCode PCCreate_ILU_HIPMI355X(PC pc) {
-  PC_ILU *f;
-  PetscErrorCode ierr = PetscMalloc(sizeof(*f), &f);CHKERRQ(ierr);
+PetscErrorCode MatGetFactor_seqaijhipmi355x_petsc(Mat A, MatFactorType ftype, Mat *B) {   /* MatGetFactor_seqaij_cusparse, aijcusparse.cu:57-75 */
+  PetscErrorCode ierr;
+  HipTriFactors *f;
+  if (ftype != MAT_FACTOR_ILU && ftype != MAT_FACTOR_ICC) SETERRQ(PETSC_COMM_SELF, PETSC_ERR_SUP, "Factor type not supported for HIPMI355X matrix types (ILU(0) and ICC(0) are)");
+  ierr = PetscMalloc(sizeof(*f), &f);CHKERRQ(ierr);
   memset(f, 0, sizeof(*f));
-  f->factored_state = -1;
-  pc->data = f;
-  pc->ops->setup = PCSetUp_ILU; pc->ops->apply = PCApply_ILU; pc->ops->destroy = PCDestroy_ILU;
-  ierr = PetscObjectComposeFunction((PetscObject)pc, "PCFactorSetIndependentBlocks_C", "PCFactorSetIndependentBlocks_ILU", (PetscVoidFunction)PCFactorSetIndependentBlocks_ILU);CHKERRQ(ierr);
+  f->kind = ftype; f->factored_state = -1;
+#if defined(PETSCHIPMI355X_WITH_PETSC)
+  ierr = MatGetFactor_seqaij_petsc(A, ftype, B);CHKERRQ(ierr);           /* the parent's factor matrix (MATSEQAIJ / MATSEQSBAIJ) with its host routines */
+  f->parent_destroy = (*B)->ops->destroy;
+  (*B)->spptr = f;
+  (*B)->ops->destroy = MatDestroy_Factor_SeqAIJHIP;
+#else
+  { const PetscInt n = A->rmap->n;
+    ierr = MatCreate(HipObjComm(A), B);CHKERRQ(ierr);
+    ierr = MatSetSizes(*B, n, n, n, n);CHKERRQ(ierr);
+    ierr = MatSetType(*B, MATSEQAIJHIPMI355X);CHKERRQ(ierr);
+    ((Mat_SeqAIJHIP *)(*B)->spptr)->tri = f; }
+#endif
+  (*B)->ops->ilufactorsymbolic = MatILUFactorSymbolic_SeqAIJHIP;
+  (*B)->ops->iccfactorsymbolic = MatICCFactorSymbolic_SeqAIJHIP;
+  (*B)->factortype = ftype;
+  ierr = PetscObjectComposeFunction((PetscObject)*B, "MatFactorSetIndependentBlocks_C", "MatFactorSetIndependentBlocks_SeqAIJHIP", (PetscVoidFunction)MatFactorSetIndependentBlocks_SeqAIJHIP);CHKERRQ(ierr);
+  return 0;
+}
+PetscErrorCode MatGetFactorAvailable_seqaijhipmi355x_petsc(Mat A, MatFactorType ftype, PetscBool *flg) {   /* MatGetFactorAvailable_seqaij_petsc, aijfact.c:97 */
+  (void)A;
+  *flg = (PetscBool)(ftype == MAT_FACTOR_ILU || ftype == MAT_FACTOR_ICC);
   return 0;
 }
 
-/* 1 when PCApply runs the sync-free solves (two launches), 0 for the level-scheduled kernels; *aborted: a dependency wait gave up */
+/* ---------------------------------------------------------------- introspection (tests / DESIGN.md), through the PC's public face */
+static PetscErrorCode pc_factors(PC pc, MatFactorType kind, HipTriFactors **f) {
+  PetscErrorCode ierr;
+  Mat F = NULL;
+  ierr = PCFactorGetMatrix(pc, &F);CHKERRQ(ierr);
+  if (!F || !F->factortype || !HipTriGet(F) || HipTriGet(F)->kind != kind) SETERRQ(HipObjComm(pc), PETSC_ERR_ARG_WRONG, "not a set-up %s over a HIPMI355X factored matrix", kind == MAT_FACTOR_ILU ? "PCILU" : "PCICC");
+  *f = HipTriGet(F);
+  return 0;
+}
+/* 1 when MatSolve runs the sync-free solves (two launches), 0 for the level-scheduled kernels; *aborted: a dependency wait gave up */
 PetscErrorCode PCILUGetSolver_HIPMI355X(PC pc, PetscInt *syncfree, PetscInt *aborted) {
-  if (strcmp(HipObjTypeName(pc), "ilu")) SETERRQ(HipObjComm(pc), PETSC_ERR_ARG_WRONG, "not a PCILU");
-  PC_ILU *f = (PC_ILU *)pc->data;
+  HipTriFactors *f;
+  PetscErrorCode ierr = pc_factors(pc, MAT_FACTOR_ILU, &f);CHKERRQ(ierr);
   int a = 0, b = 0;
-  if (syncfree) *syncfree = f->tri_lo ? 1 : 0;
+  if (syncfree) *syncfree = (f->tri_lo && !f->use_levels) ? 1 : 0;
   if (f->tri_lo) {
     PetscDeviceCtx *dc;
-    PetscErrorCode ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
+    ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
     CHKHIP(mi355x_handle_synchronize(dc->h));      /* the flag of everything queued so far */
     mi355x_trisolve_aborted(f->tri_lo, &a); mi355x_trisolve_aborted(f->tri_up, &b);
   }
-  if (aborted) *aborted = a || b;
+  if (aborted) *aborted = a || b || f->aborted;
   return 0;
 }
-
 /* restarts of the factorisation with a larger diagonal shift (MAT_SHIFT_NONZERO); 0 for every matrix whose pivots pass */
 PetscErrorCode PCILUGetShiftCount_HIPMI355X(PC pc, PetscInt *nshift) {
-  if (strcmp(HipObjTypeName(pc), "ilu") && strcmp(HipObjTypeName(pc), "iluhipmi355x")) SETERRQ(HipObjComm(pc), PETSC_ERR_ARG_WRONG, "not a PCILU");
-  *nshift = ((PC_ILU *)pc->data)->nshift;
+  HipTriFactors *f;
+  PetscErrorCode ierr = pc_factors(pc, MAT_FACTOR_ILU, &f);CHKERRQ(ierr);
+  *nshift = f->nshift;
   return 0;
 }
-
-/* levels of the two triangular solves (for tests / DESIGN.md) */
+/* levels of the two triangular solves */
 PetscErrorCode PCILUGetLevels_HIPMI355X(PC pc, PetscInt *nlevL, PetscInt *nlevU) {
-  if (strcmp(HipObjTypeName(pc), "ilu")) SETERRQ(HipObjComm(pc), PETSC_ERR_ARG_WRONG, "not a PCILU");
-  PC_ILU *f = (PC_ILU *)pc->data;
+  HipTriFactors *f;
+  PetscErrorCode ierr = pc_factors(pc, MAT_FACTOR_ILU, &f);CHKERRQ(ierr);
   if (nlevL) *nlevL = f->nlevL;
   if (nlevU) *nlevU = f->nlevU;
+  return 0;
+}
+/* dependency levels of the two sweeps and the number of positive-definite shifts the factorisation took */
+PetscErrorCode PCICCGetInfo_HIPMI355X(PC pc, PetscInt *nlevL, PetscInt *nlevU, PetscInt *nshift) {
+  HipTriFactors *f;
+  PetscErrorCode ierr = pc_factors(pc, MAT_FACTOR_ICC, &f);CHKERRQ(ierr);
+  if (nlevL) *nlevL = f->nlevL;
+  if (nlevU) *nlevU = f->nlevU;
+  if (nshift) *nshift = f->nshift;
+  return 0;
+}
+/* tests: make the next host wait see an aborted sync-free solve on this PC's factor */
+PetscErrorCode PCFactorDebugSetAborted_HIPMI355X(PC pc) {
+  PetscErrorCode ierr;
+  Mat F = NULL;
+  ierr = PCFactorGetMatrix(pc, &F);CHKERRQ(ierr);
+  if (!F || !HipTriGet(F) || !HipTriGet(F)->tri_lo) SETERRQ(HipObjComm(pc), PETSC_ERR_ARG_WRONGSTATE, "no sync-free plans");
+  CHKHIP(mi355x_trisolve_debug_set_aborted(HipTriGet(F)->tri_lo, 1));
   return 0;
 }

@@ -52,6 +52,7 @@ static PetscErrorCode to_host(Vec v) {   /* VecCUSPCopyFromGPU, veccusp.cu:173 *
     ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
     CHKHIP(mi355x_memcpy_d2h(dc->h, s->host, s->dev, sizeof(PetscScalar) * (size_t)v->map->n));
     CHKHIP(mi355x_handle_synchronize(dc->h));
+    ierr = HipTriWatchCheck();CHKERRQ(ierr);     /* did a sync-free triangular solve queued before this copy give up?  (host/ilu.c) */
     s->valid = VALID_BOTH;
   }
   return 0;
@@ -285,6 +286,7 @@ static PetscErrorCode reduce_finish2(Vec x, PetscDeviceCtx *dc, int nsum, int co
     /* host-staged transport (no RCCL communicator attached): the reference's own arrangement, a device
      * reduction followed by a host all-reduce (mpicusp.cu:32-113); used by the shared-GPU rehearsal tests */
     CHKHIP(mi355x_handle_synchronize(dc->h));
+    { PetscErrorCode e_ = HipTriWatchCheck();CHKERRQ(e_); }
     for (int j = 0; j < count; j++) result[j] = hs[j];
     if (HipCommAllreduce(HipObjComm(x), result, nsum, 1, is_max ? 1 : 0)) SETERRQ(HipObjComm(x), PETSC_ERR_LIB, "allreduce failed");
     return 0;
@@ -296,11 +298,11 @@ static PetscErrorCode reduce_finish2(Vec x, PetscDeviceCtx *dc, int nsum, int co
     /* device -> pinned host by a tiny kernel on the same stream that also stores the completion number the host
      * polls: no stream synchronisation, and kernels queued behind it do not delay the result */
     CHKHIP(mi355x_handle_publish(dc->h, ds, count));
-    CHKHIP(mi355x_handle_wait_result(dc->h));
+    CHKHIP(mi355x_handle_wait_result(dc->h)); { PetscErrorCode e_ = HipTriWatchCheck();CHKERRQ(e_); }
   } else {
     /* one rank: the reduction kernel wrote the result and then a completion number to pinned memory; polling that
      * word is cheaper than a stream synchronisation and lets the next launches go out at once */
-    CHKHIP(mi355x_handle_wait_result(dc->h));
+    CHKHIP(mi355x_handle_wait_result(dc->h)); { PetscErrorCode e_ = HipTriWatchCheck();CHKERRQ(e_); }
   }
   for (int j = 0; j < count; j++) result[j] = hs[j];
   return 0;
@@ -472,7 +474,7 @@ PetscErrorCode VecCGUpdateDevBegin_HIPMI355X(Vec x, Vec r, Vec z, Vec p, Vec w, 
 PetscErrorCode VecCGUpdateDevEnd_HIPMI355X(Vec x, PetscScalar *zz, PetscScalar *zr, PetscScalar *rr, PetscScalar *dpi) {
   PetscErrorCode ierr; DEVCTX;
   (void)x;
-  CHKHIP(mi355x_handle_wait_result(dc->h));
+  CHKHIP(mi355x_handle_wait_result(dc->h)); { PetscErrorCode e_ = HipTriWatchCheck();CHKERRQ(e_); }
   const double *hs = mi355x_handle_host_scratch(dc->h);
   *zz = hs[0]; *zr = hs[1]; *rr = hs[2]; *dpi = hs[3];
   return 0;
@@ -635,7 +637,7 @@ static PetscErrorCode sr_fetch(Vec x) {
       if (HipCommAllreduce(HipObjComm(o), sr.val, sr.n, 1, 0)) SETERRQ(HipObjComm(o), PETSC_ERR_LIB, "allreduce failed");
     } else {
       mi355x_handle_t hh = DEVICE_COLLECTIVES(o) ? dc->hcomm : dc->h;
-      CHKHIP(mi355x_handle_wait_result(hh));
+      CHKHIP(mi355x_handle_wait_result(hh)); { PetscErrorCode e_ = HipTriWatchCheck();CHKERRQ(e_); }
       const double *hs = mi355x_handle_host_scratch(hh) + SR_HOST0;
       for (int j = 0; j < sr.n; j++) sr.val[j] = hs[j];
       /* the slots may be rewritten by the next phase only after the all-reduce that read them has finished */
@@ -756,7 +758,7 @@ PetscErrorCode VecGMRESOrthogNormalize_HIPMI355X(Vec w, PetscInt nv, const Vec V
   CHKHIP(mi355x_vec_scale_rnorm_dev(dc->h, N_(w), ds + nv, dw));
   VecHIPRestoreWrite(w);
   HipStateIncrease(w);
-  CHKHIP(mi355x_handle_wait_result(dc->h));
+  CHKHIP(mi355x_handle_wait_result(dc->h)); { PetscErrorCode e_ = HipTriWatchCheck();CHKERRQ(e_); }
   const double *hs = mi355x_handle_host_scratch(dc->h);
   for (PetscInt j = 0; j < nv; j++) dots[j] = hs[j];
   *nrm = PetscSqrtReal(hs[nv]);                                 /* pvec2.c:62-64: the square is reduced, then the root */

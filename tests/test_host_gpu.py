@@ -1046,6 +1046,60 @@ def test_factor_fuzz_ilu0_icc0(P, seed):
         Am.destroy()
 
 
+@pytest.mark.parametrize("pct", ["ilu", "icc"])
+def test_syncfree_solve_that_gave_up_is_noticed_at_the_next_host_wait(P, pct):
+    """A dependency wait of the sync-free triangular solves is bounded; when one gives up the application's result is unusable.
+    The abort flag (pinned host memory) is looked at by every host wait the solvers perform: the first reduction / VecGetArray
+    after it raises PETSC_ERR_LIB instead of returning numbers computed from a poisoned vector, and the factor then runs the
+    same plans one dependency level per launch -- same bits, ILU(0) and ICC(0) alike.  An application queued while the flag is
+    up and nobody has waited yet falls back by itself."""
+    L = P.lib()
+    ai, aj, aa = P.gen_poisson7(12, 11, 10)
+    n = ai.size - 1
+    aa = aa * (1.0 + 0.05 * np.sin(np.arange(aa.size))) if pct == "ilu" else aa
+    A = P.Mat.from_csr(ai, aj, aa)
+    pc = C.c_void_p()
+    k = P.KSP(comm=L.COMM_SELF); k.set_operators(A); L.KSPGetPC(k.h, C.byref(pc)); L.PCSetType(pc, pct.encode())
+    set_options(L, "-pc_factor_hipmi355x_trisolve syncfree")
+    L.raw("PCSetUp")(pc)
+    set_options(L, "")
+    bvec = rnd(n, 5); vb, vx = V(P, bvec), V(P, np.zeros(n))
+    L.raw("PCApply")(pc, vb.h, vx.h)
+    good = bits(vx.array()).copy()
+    ref = orc.ilu0_solve(orc.ilu0_factor(ai, aj, aa), bvec) if pct == "ilu" else orc.icc0_solve(orc.icc0_factor(ai, aj, aa)[0], bvec)
+    assert np.array_equal(good, bits(ref))
+    # (1) the flag goes up after an application was queued: the next host wait reports it
+    L.raw("PCApply")(pc, vb.h, vx.h)
+    L.PCFactorDebugSetAborted_HIPMI355X(pc)
+    with pytest.raises(P.PetscError) as e:
+        vx.norm()
+    assert e.value.code == 76 and "gave up" in str(e.value)
+    # (2) from now on: level by level over the same plans, same bits; the PC says so
+    for rep in range(2):
+        L.raw("PCApply")(pc, vb.h, vx.h)
+        assert np.array_equal(bits(vx.array()), good)
+    if pct == "ilu":
+        sf, ab = C.c_int(), C.c_int()
+        L.PCILUGetSolver_HIPMI355X(pc, C.byref(sf), C.byref(ab))
+        assert (sf.value, ab.value) == (0, 1)
+    # (3) a whole solve on the fallen-back factor converges to the oracle's iterates
+    x, h, its, reason = (None,) * 4
+    k.set_type("gmreshipmi355x" if pct == "ilu" else "cghipmi355x"); k.set_tolerances(rtol=1e-9); k.record_history()
+    vx2 = V(P, np.zeros(n)); k.solve(vb, vx2)
+    xo, ho, ito, ro = orc.ksp_solve(ai, aj, aa, bvec, ksp="gmres" if pct == "ilu" else "cg", pc=pct, rtol=1e-9)
+    assert (k.its, k.reason) == (ito, ro) and np.allclose(k.history(), ho, rtol=1e-8, atol=0)
+    # (4) a fresh factor whose flag is raised BEFORE anything waited: the application itself takes the level path
+    A2 = P.Mat.from_csr(ai, aj, aa)
+    pc2 = C.c_void_p()
+    k2 = P.KSP(comm=L.COMM_SELF); k2.set_operators(A2); L.KSPGetPC(k2.h, C.byref(pc2)); L.PCSetType(pc2, pct.encode())
+    set_options(L, "-pc_factor_hipmi355x_trisolve syncfree")
+    L.raw("PCSetUp")(pc2)
+    set_options(L, "")
+    L.PCFactorDebugSetAborted_HIPMI355X(pc2)
+    L.raw("PCApply")(pc2, vb.h, vx.h)
+    assert np.array_equal(bits(vx.array()), good)
+
+
 def test_ilu0_apply_bitexact_and_golden(P):
     """PCILU (ILU(0), natural ordering).  The level-scheduled device solve reproduces
     MatSolve_SeqAIJ_NaturalOrdering bit for bit (one lane per row, products subtracted in column order), and with NO

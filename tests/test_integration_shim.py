@@ -102,11 +102,11 @@ def test_every_slot_the_plugin_assigns_exists_in_the_reference_tables():
     seen_vec, seen_mat = set(), set()
     for path in PLUGIN_SOURCES:
         txt = strip_comments(read(path))
-        for var, slot in re.findall(r"\b(\w+)->ops->([a-z_0-9]+)\s*=[^=]", txt):
+        for var, slot in re.findall(r"(\(\*B\)|\b\w+)->ops->([a-z_0-9]+)\s*=[^=]", txt):
             if var in ("v", "vv", "V"):
                 assert slot in vec_ref, "%s assigns Vec slot %s, which struct _VecOps of the reference does not have" % (os.path.basename(path), slot)
                 seen_vec.add(slot)
-            elif var in ("B", "A"):
+            elif var in ("B", "A", "F", "(*B)"):
                 assert slot in mat_ref, "%s assigns Mat slot %s, which struct _MatOps of the reference does not have" % (os.path.basename(path), slot)
                 seen_mat.add(slot)
             elif var == "ksp":
