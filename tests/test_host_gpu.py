@@ -1857,3 +1857,44 @@ def test_config4_full_size_properties(P, which):
         set_options(L, "")
         absrow = np.zeros(m); np.add.at(absrow, np.repeat(np.arange(m), np.diff(ai)), np.abs(aa * x[aj]))
         assert np.all(np.abs(vy.array() - 2.0 * y) <= 2e-12 * absrow)
+
+
+@pytest.mark.parametrize("sub", ["jacobi", "ilu"])
+def test_config4_full_size_gmres_bjacobi_solve(P, sub):
+    """BASELINE configs[3] END TO END at full size on the FEM-like stand-in for Flan_1565 (1.53 M rows, 1.18e8 nonzeros, 3 dof per
+    node: tests/problems.py): KSPGMRES(30) + PCBJACOBI with one block per rank and (a) the all-device Jacobi sub-PC, (b) the
+    reference's default sub-solver, preonly + ILU(0) (bjacobi.c:738-923 -> PCILU -> MatGetFactor -> the device triangular solves).
+    Properties that do not need an oracle run of this size: the solve converges to rtol 1e-8 with KSP_CONVERGED_RTOL; the residual
+    norm GMRES reports from its recurrence equals the recomputed ||B (b - A x)||; the error against the known solution is at the
+    level the tolerance implies; and the plug-in's fused solver (-ksp_type gmreshipmi355x) walks the bits of the plain restatement
+    of KSPSolve_GMRES (-ksp_type gmres) over the same operators -- every residual norm and every entry of x."""
+    L = P.lib()
+    ai, aj, aa = pb.gen_fem3()
+    n = ai.size - 1
+    A = P.Mat.from_csr(ai, aj, aa)
+    u = P.Vec.create(n, comm=L.COMM_SELF); L.VecSet(u.h, 1.0)
+    b = u.duplicate(); A.mult(u, b)
+    runs = []
+    for ktype in ("gmreshipmi355x", "gmres"):
+        x = u.duplicate(); L.VecSet(x.h, 0.0)
+        k = P.KSP(comm=L.COMM_SELF)
+        k.set_operators(A)
+        set_options(L, "-ksp_type %s -pc_type bjacobi -sub_pc_type %s" % (ktype, sub))
+        k.set_tolerances(rtol=1e-8, abstol=1e-50, dtol=1e5, max_it=500)
+        k.set_from_options(); k.record_history()
+        set_options(L, "")
+        k.solve(b, x)
+        runs.append((k.its, k.reason, k.history().copy(), x, k))
+    (its, reason, h, x, k), (its0, reason0, h0, x0, _) = runs
+    assert reason == reason0 == 2 and its == its0 and 5 < its < 200
+    assert h[-1] <= 1e-8 * h[0] and np.all(np.diff(h) <= 1e-6 * h[:-1])         # GMRES: the residual never grows (a restart re-measures it)
+    assert np.array_equal(bits(h), bits(h0))
+    xa = x.array()
+    assert np.array_equal(bits(xa), bits(x0.array()))
+    assert np.linalg.norm(xa - 1.0) / np.sqrt(n) < 1e-7
+    # true preconditioned residual B (b - A x) against the recurrence's last value (left preconditioning, preconditioned norm)
+    r = u.duplicate(); z = u.duplicate()
+    A.mult(x, r); L.VecAYPX(r.h, -1.0, b.h)
+    pc = C.c_void_p(); L.KSPGetPC(k.h, C.byref(pc))
+    L.raw("PCApply")(pc, r.h, z.h)
+    assert abs(z.norm() - h[-1]) <= 1e-3 * h[-1] + 1e-12 * h[0]

@@ -32,6 +32,26 @@ def test_mpiaij_two_ranks_one_gpu(built, nranks):
             assert "rank %d/2: golden ex2_2.out (GMRES + bjacobi + ILU(0), 2 ranks) its=7 ok=True" % k in out, out[-3000:]
 
 
+def test_mpiaij_four_ranks_in_the_partition_of_configs2(built):
+    """BASELINE.json configs[2] (P7(512) in 8 z-slabs over RCCL) rehearsed in ITS partition shape on the one GPU a box has:
+    planes twice as wide, a quarter as many per rank (P7(2n, 2n, n/4 * ranks)), so that interior ranks exchange a plane with
+    TWO neighbours and the edge ranks with one -- over the host-staged transport, with FOUR ranks (the GPU boxes admit at most
+    six processes on a card, and the test runner and the launcher are two of them; the 8-rank partition itself is checked on the
+    CPU by test_distributed_gloo.py, and over RCCL by test_rccl_multigpu.py where eight GPUs exist).  Every rank: MatMult and MatMultTranspose bit-exact against the
+    MPIAIJ-ordered oracle, norms, CG + Jacobi history against the oracle."""
+    nranks = 4
+    env = dict(os.environ, MI355X_STAGED="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks),
+           "--master-addr", "127.0.0.1", "--master-port", "29527", os.path.join(ROOT, "tests", "tools", "rank2_trial.py"), "8", "cfg3"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0, out[-3000:]
+    for k in range(nranks):
+        assert "rank %d/%d: transport=host-staged rccl_ranks=0 rccl_communicators=0" % (k, nranks) in out, out[-3000:]
+        assert "rank %d/%d: MatMult bitexact=True MatMultTranspose=True norm=True" % (k, nranks) in out, out[-3000:]
+        assert "rank %d/%d: irregular MatMult bitexact=True MatMultTranspose bitexact=True" % (k, nranks) in out, out[-3000:]
+
+
 @pytest.mark.parametrize("wide", [False, True])
 def test_bench_two_ranks_rehearsal(built, wide):
     """bench.py's N>1 flow (torch.distributed.run launch, z-slab MatMPIAIJ, max-over-ranks timing, one JSON line from

@@ -31,11 +31,12 @@ def launch(nranks, script, *args, port):
     return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
 
 
-@pytest.mark.parametrize("nranks", [2, 3, 4])
+@pytest.mark.parametrize("nranks", [2, 3, 4, 8])
 def test_mpiaij_over_rccl(built, nranks):
     if ndevices() < nranks:
         pytest.skip("needs %d GPUs, %d visible" % (nranks, ndevices()))
-    r = launch(nranks, os.path.join(ROOT, "tests", "tools", "rank2_trial.py"), "12", port=29540 + nranks)
+    # 8 ranks: the partition shape of BASELINE.json configs[2] (wide planes, interior ranks with two neighbours)
+    r = launch(nranks, os.path.join(ROOT, "tests", "tools", "rank2_trial.py"), *(("8", "cfg3") if nranks == 8 else ("12",)), port=29540 + nranks)
     out = r.stdout + r.stderr
     assert r.returncode == 0, out[-3000:]
     assert "host-staged" not in out, out[-3000:]    # a silent fallback is a failure here

@@ -22,6 +22,10 @@ def main():
     from test_host_cpu import mpiaij_pieces, check_against_oracle
     comm = PD.torch_comm(device_comm=False)
     nx, ny, n = 7, 5, 4
+    if len(sys.argv) > 1 and sys.argv[1] == "cfg3":
+        # BASELINE.json configs[2]'s partition at reduced size: P7(2k, 2k, k/4 * world) in z-slabs of k/4 planes of (2k)^2 rows
+        # (k = 256: P7(512) on 8 ranks, 64 planes of 512^2 per rank, 262 144 ghosts per neighbour); here k = 8
+        nx, ny, n = 16, 16, 2
     nz = n * world
     mloc = nx * ny * n
     ai, aj, aa = P.gen_poisson7(nx, ny, nz, rank * mloc, (rank + 1) * mloc)
@@ -43,6 +47,10 @@ def main():
     M = P.i32(); N = P.i32()
     P.lib().MatGetSize(A.h, M, N)
     assert M.value == mloc * world and N.value == mloc * world
+    if len(sys.argv) > 1 and sys.argv[1] == "cfg3":       # interior ranks: two z-neighbours, one plane of ghosts from each; edge ranks: one
+        nb = 1 if rank in (0, world - 1) else 2
+        assert garray.size == nb * nx * ny and lists["sprocs"].size == nb and lists["rprocs"].size == nb, (rank, garray.size)
+        assert int(oi[-1]) == nb * nx * ny                 # B_o: one entry per ghost column (524 288 / 262 144 at full size)
     print("rank %d/%d: MPIAIJ set-up matches the oracle (ec=%d, %d send / %d recv neighbours)" % (rank, world, garray.size, lists["sprocs"].size, lists["rprocs"].size), flush=True)
     dist.barrier()
     dist.destroy_process_group()

@@ -26,7 +26,11 @@ def main():
     print("rank %d/%d: transport=%s rccl_ranks=%d rccl_communicators=%d" % (rank, world, tr["transport"], tr["rccl_ranks"], tr["rccl_communicators"]), flush=True)
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 16
     nx, ny, nz = n, n, n * world
-    mloc = n ** 3
+    if len(sys.argv) > 2 and sys.argv[2] == "cfg3":
+        # the slab shape of BASELINE.json configs[2] (P7(512) on 8 ranks = 64 planes of 512^2 rows per rank) at reduced size:
+        # planes twice as wide, a quarter as many per rank -- P7(2n, 2n, n/4 * world); interior ranks have two z-neighbours
+        nx, ny, nz = 2 * n, 2 * n, (n // 4) * world
+    mloc = nx * ny * (nz // world)
     ai, aj, aa = P.gen_poisson7(nx, ny, nz, rank * mloc, (rank + 1) * mloc)
     A = P.Mat.from_csr_mpi(ai, aj, aa, mloc, mloc * world, mloc * world, comm=comm)
     gi, gj, ga = orc.gen_p7(nx, ny, nz)
@@ -43,6 +47,19 @@ def main():
     L.MatMultTranspose(A.h, x.h, y.h)
     reft = orc.spmv_t(gi, gj, ga, xg, N)[rank * mloc:(rank + 1) * mloc]
     ok2 = np.allclose(y.array(), reft, rtol=1e-13, atol=1e-13)
+    # ... and bit for bit against MatMultTranspose_MPIAIJ's own order (mpiaij.c:1147-1174): A_d^T x, then the neighbours' B_o^T x
+    # pieces added through the reverse scatter, owner after owner in rank order
+    pcs_ = [orc.mpiaij_split(q * mloc, (q + 1) * mloc, q * mloc, (q + 1) * mloc, gi, gj, ga) for q in range(world)]
+    rt = orc.spmv_t(pcs_[rank]["ad_i"], pcs_[rank]["ad_j"], pcs_[rank]["ad_a"], xg[rank * mloc:(rank + 1) * mloc].copy(), mloc)
+    for q in range(world):
+        if q == rank or not pcs_[q]["garray"].size:
+            continue
+        lv = orc.spmv_t(pcs_[q]["bo_i"], pcs_[q]["bo_j"], pcs_[q]["bo_a"], xg[q * mloc:(q + 1) * mloc].copy(), pcs_[q]["garray"].size)
+        mine = (pcs_[q]["garray"] >= rank * mloc) & (pcs_[q]["garray"] < (rank + 1) * mloc)
+        for i_ in np.nonzero(mine)[0]:
+            g = int(pcs_[q]["garray"][i_]) - rank * mloc
+            rt[g] = rt[g] + lv[i_]
+    ok2 = ok2 and np.array_equal(y.array().view(np.uint64), rt.view(np.uint64))
     nrm = x.norm()
     ok3 = abs(nrm - np.linalg.norm(xg)) <= 1e-12 * nrm
     b = x.duplicate(); u = x.duplicate(); L.VecSet(u.h, 1.0); A.mult(u, b)
