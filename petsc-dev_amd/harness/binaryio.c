@@ -85,13 +85,25 @@ static PetscErrorCode matload_body(Mat A, PetscViewer viewer, long base, const P
   long cols0 = base + 16 + 4L * M, vals0 = cols0 + 4L * nz;
   if (fseek(viewer->f, cols0 + 4L * before, SEEK_SET)) SETERRQ(A->comm, 66, "Cannot seek to the column indices");
   ierr = read_ints(viewer->f, lj, (size_t)mine);CHKERRQ(ierr);
-  /* the kernels gather x[col] unchecked: a file whose columns are out of range or unsorted never reaches them */
-  for (PetscInt r = 0; r < m; r++) for (PetscInt k = li[r]; k < li[r + 1]; k++) {
+  /* the kernels gather x[col] unchecked: a file whose columns are out of range never reaches them */
+  for (PetscInt r = 0; r < m; r++) for (PetscInt k = li[r]; k < li[r + 1]; k++)
     if (lj[k] < 0 || lj[k] >= N) SETERRQ(A->comm, 66, "Inconsistant matrix data in file: column %d of row %d is outside [0,%d)", lj[k], rs + r, N);
-    if (k > li[r] && lj[k] <= lj[k - 1]) SETERRQ(A->comm, 66, "Inconsistant matrix data in file: columns of row %d are not increasing", rs + r);
-  }
   if (fseek(viewer->f, vals0 + 8L * before, SEEK_SET)) SETERRQ(A->comm, 66, "Cannot seek to the values");
   ierr = read_scalars(viewer->f, la, (size_t)mine);CHKERRQ(ierr);
+  /* MatLoad_SeqAIJ accepts rows whose columns are not in increasing order (aij.c:4093-4157 stores what the file holds); the CSR
+   * setters and the kernels here want them sorted, so such a row is sorted with its values (stable insertion: rows are short); a
+   * column that appears twice in a row has no meaning in an AIJ file */
+  for (PetscInt r = 0; r < m; r++) {
+    for (PetscInt k = li[r] + 1; k < li[r + 1]; k++) {
+      if (lj[k] > lj[k - 1]) continue;
+      const PetscInt c = lj[k]; const PetscScalar v = la[k];
+      PetscInt q = k;
+      while (q > li[r] && lj[q - 1] > c) { lj[q] = lj[q - 1]; la[q] = la[q - 1]; q--; }
+      lj[q] = c; la[q] = v;
+    }
+    for (PetscInt k = li[r] + 1; k < li[r + 1]; k++)
+      if (lj[k] == lj[k - 1]) SETERRQ(A->comm, 66, "Inconsistant matrix data in file: column %d appears twice in row %d", lj[k], rs + r);
+  }
   if (fseek(viewer->f, vals0 + 8L * nz, SEEK_SET)) SETERRQ(A->comm, 66, "Cannot seek past the matrix");   /* leave the file positioned after the matrix */
   {   /* MatLoad_SeqAIJ / MatLoad_MPIAIJ hand the rows to the type (aij.c:4140, mpiaij.c:3560): whichever CSR setter it composed */
     PetscVoidFunction fs, fm;
@@ -127,6 +139,32 @@ PetscErrorCode MatView(Mat A, PetscViewer viewer) {
   ierr = PetscObjectQueryFunction((PetscObject)A, "MatSeqAIJGetArrays_C", &f);CHKERRQ(ierr);   /* MatView_SeqAIJ_Binary reads the type's CSR arrays */
   if (!f) SETERRQ(A->comm, PETSC_ERR_SUP, "binary MatView is ported for the sequential AIJ type only");
   ierr = ((PetscErrorCode (*)(Mat, PetscInt *, const PetscInt **, const PetscInt **, const PetscScalar **))f)(A, &m, &ai, &aj, &aa);CHKERRQ(ierr);
+  if (m > 0 && A->rmap->n != m) {
+    /* a blocked type (i, j index bs x bs blocks, stored column-major): MatView_SeqBAIJ_Binary (baij.c:1068-1130) writes the POINT rows
+     * -- header {M, N, nnzb bs^2}, every point row's length, its columns bs j + l, its values a[bs^2 k + l bs + r] */
+    const PetscInt bs = A->rmap->n / m, bs2 = bs * bs;
+    if (bs * m != A->rmap->n || bs < 2) SETERRQ(A->comm, PETSC_ERR_PLIB, "block rows %d do not divide %d rows", m, A->rmap->n);
+    const size_t pnz = (size_t)ai[m] * (size_t)bs2;
+    PetscInt hdr[4] = {MAT_FILE_CLASSID, A->rmap->n, A->cmap->N, (PetscInt)pnz}, *prl, *pj; PetscScalar *pa;
+    if (pnz > 2147483647u) SETERRQ(A->comm, PETSC_ERR_SUP, "matrix too large for the binary format's 32-bit nonzero count");
+    ierr = PetscMalloc(sizeof(PetscInt) * (size_t)A->rmap->n, &prl);CHKERRQ(ierr);
+    ierr = PetscMalloc(sizeof(PetscInt) * PetscMax(pnz, 1), &pj);CHKERRQ(ierr);
+    ierr = PetscMalloc(sizeof(PetscScalar) * PetscMax(pnz, 1), &pa);CHKERRQ(ierr);
+    size_t w = 0;
+    for (PetscInt I = 0; I < m; I++)
+      for (PetscInt r = 0; r < bs; r++) {
+        prl[I * bs + r] = bs * (ai[I + 1] - ai[I]);
+        for (PetscInt k = ai[I]; k < ai[I + 1]; k++)
+          for (PetscInt l = 0; l < bs; l++) { pj[w] = bs * aj[k] + l; pa[w] = aa[(size_t)bs2 * (size_t)k + (size_t)l * bs + r]; w++; }
+      }
+    ierr = write_ints(viewer->f, hdr, 4);
+    if (!ierr) ierr = write_ints(viewer->f, prl, (size_t)A->rmap->n);
+    if (!ierr) ierr = write_ints(viewer->f, pj, pnz);
+    if (!ierr) ierr = write_scalars(viewer->f, pa, pnz);
+    free(prl); free(pj); free(pa);
+    CHKERRQ(ierr);
+    return 0;
+  }
   PetscInt header[4] = {MAT_FILE_CLASSID, m, A->cmap->N, ai[m]}, *rl;
   ierr = PetscMalloc(sizeof(PetscInt) * (size_t)PetscMax(m, 1), &rl);CHKERRQ(ierr);
   for (PetscInt r = 0; r < m; r++) rl[r] = ai[r + 1] - ai[r];

@@ -382,6 +382,60 @@ def test_matload_reference_datafiles(built, tmp_path):
         assert vec.size == M
 
 
+def test_matload_sorts_unsorted_rows_and_matview_expands_blocks(built, tmp_path):
+    """MatLoad_SeqAIJ takes a file whose rows list their columns in any order (aij.c:4093-4157): such rows are sorted, values
+    following their columns, instead of being refused.  MatView of a blocked (BAIJ) matrix writes the POINT rows, as
+    MatView_SeqBAIJ_Binary does (baij.c:1068-1130) -- loading the file back as AIJ gives the expanded matrix."""
+    from petsc_dev_amd import petsc as P
+    L = P.lib()
+    path = os.path.join(ROOT, "tests", "golden", "matrices", "spd-real-int32-float64")
+    raw = bytearray(open(path, "rb").read())
+    M, N, nz = (int(v) for v in np.frombuffer(bytes(raw[4:16]), dtype=">i4"))
+    rl = np.frombuffer(bytes(raw[16:16 + 4 * M]), dtype=">i4").astype(np.int64)
+    c0, v0 = 16 + 4 * M, 16 + 4 * M + 4 * nz
+    cols = np.frombuffer(bytes(raw[c0:c0 + 4 * nz]), dtype=">i4").copy()
+    vals = np.frombuffer(bytes(raw[v0:v0 + 8 * nz]), dtype=">f8").copy()
+    ptr = np.concatenate([[0], np.cumsum(rl)])
+    rng = np.random.default_rng(5)
+    sc, sv = cols.copy(), vals.copy()
+    for r in range(M):                                              # every row in a random order
+        perm = rng.permutation(int(rl[r])) + ptr[r]
+        sc[ptr[r]:ptr[r + 1]] = cols[perm]; sv[ptr[r]:ptr[r + 1]] = vals[perm]
+    shuffled = bytearray(raw)
+    shuffled[c0:c0 + 4 * nz] = sc.astype(">i4").tobytes(); shuffled[v0:v0 + 8 * nz] = sv.astype(">f8").tobytes()
+    f = str(tmp_path / "shuffled"); open(f, "wb").write(bytes(shuffled))
+    viewer = C.c_void_p(); A = C.c_void_p()
+    L.PetscViewerBinaryOpen(L.COMM_SELF, f.encode(), 0, C.byref(viewer))
+    L.MatCreate(L.COMM_SELF, C.byref(A))
+    L.MatLoad(A, viewer)
+    ai, aj, aa = seq_arrays(P, A)
+    assert np.array_equal(np.diff(ai), rl) and np.array_equal(aj, cols.astype(np.int32)) and np.array_equal(aa, vals.astype(np.float64))
+    L.PetscViewerDestroy(C.byref(viewer)); L.MatDestroy(C.byref(A))
+    # BAIJ: 3 block rows of 2 x 2 blocks, column-major inside a block
+    bs, bi, bj = 2, np.array([0, 2, 3, 5], dtype=np.int32), np.array([0, 2, 1, 0, 2], dtype=np.int32)
+    ba = np.arange(1.0, 1.0 + 5 * 4)
+    Bm = P.Mat.from_bsr(bs, bi, bj, ba)
+    out = str(tmp_path / "baij")
+    w = C.c_void_p()
+    L.PetscViewerBinaryOpen(L.COMM_SELF, out.encode(), 1, C.byref(w))
+    L.MatView(Bm.h, w)
+    L.PetscViewerDestroy(C.byref(w))
+    dense = np.zeros((6, 6))
+    for I in range(3):
+        for k in range(bi[I], bi[I + 1]):
+            dense[2 * I:2 * I + 2, 2 * bj[k]:2 * bj[k] + 2] = ba[4 * k:4 * k + 4].reshape(2, 2).T      # column-major blocks
+    viewer = C.c_void_p(); A = C.c_void_p()
+    L.PetscViewerBinaryOpen(L.COMM_SELF, out.encode(), 0, C.byref(viewer))
+    L.MatCreate(L.COMM_SELF, C.byref(A))
+    L.MatLoad(A, viewer)
+    ai, aj, aa = seq_arrays(P, A)
+    got = np.zeros((6, 6))
+    for r in range(6):
+        got[r, aj[ai[r]:ai[r + 1]]] = aa[ai[r]:ai[r + 1]]
+    assert ai[-1] == 20 and np.array_equal(got, dense)
+    L.PetscViewerDestroy(C.byref(viewer)); L.MatDestroy(C.byref(A))
+
+
 def test_matload_rejects_inconsistent_files(built, tmp_path):
     """a truncated or inconsistent binary file is an error (the reference: 'Inconsistant matrix data in file',
     aij.c:4125), never a matrix whose column indices would send the SpMV gathers out of bounds"""

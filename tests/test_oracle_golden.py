@@ -121,6 +121,24 @@ def test_tutorial_ex5_two_systems_golden(size, name, rtol):
         assert np.linalg.norm(x - u) < 1e-4 * np.linalg.norm(u)
 
 
+def test_tutorial_ex5_5_and_ex2_5_default_pc_on_two_ranks_golden():
+    """tutorials/makefile:340 (runex2_5: -n 2 ./ex2 -m 5 -n 5 refine_always, default PC) and :423 (runex5_5: -n 2 ./ex5 refine_always,
+    default PC, default tolerances) vs output/ex2_5.out, ex5_5.out: the reference's DEFAULT preconditioner on two ranks -- block
+    Jacobi with ILU(0) in each rank's block -- on two more systems (ex5: two solves, the second after re-assembly with other
+    values).  ex5_5.out prints the error norm and the iteration count of each solve; ex2_5.out is ex2_2.out's run with a viewer
+    option (the makefile diffs it against ex2_2.out)."""
+    assert open(os.path.join(G, "ksp_tutorials", "ex2_5.out")).read() == open(os.path.join(G, "ksp_tutorials", "ex2_2.out")).read()
+    want = [l.split() for l in open(os.path.join(G, "ksp_tutorials", "ex5_5.out")).read().splitlines() if l.startswith("Norm of error")]
+    want = [(w[3].rstrip(","), int(w[5])) for w in want]
+    assert want == [("0.00121238", 7), ("0.000322889", 6)]
+    for second in (False, True):
+        (ai, aj, aa), u = pb.ex5_tutorial(2, second)
+        n = ai.size - 1
+        b = orc.spmv(ai, aj, aa, u)
+        x, h, its, reason = orc.ksp_solve(ai, aj, aa, b, ksp="gmres", pc="bjacobi", blocks=[0, n // 2, n], sub_ksp="preonly", sub_pc="ilu", refine_always=1)
+        assert ("%g" % np.linalg.norm(x - u), its) == want[1 if second else 0]
+
+
 def test_config1_cg_jacobi_regression_record():
     """NOT a pin (the numbers come from SURVEY.md 8(c)'s probe build, which used a hand-written petscconf.h): a
     regression record of BASELINE configs[0], ex2 -m 100 -n 100 -ksp_type cg -pc_type jacobi -> 160 iterations,

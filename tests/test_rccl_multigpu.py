@@ -47,6 +47,7 @@ def test_mpiaij_over_rccl(built, nranks):
         assert "rank %d/%d: MatDiagonalScale + MatScale then MatMult bitexact=True" % (k, nranks) in out, out[-3000:]
         if nranks == 2:   # the reference's own 2-rank golden, default preconditioner (block Jacobi + ILU(0))
             assert "rank %d/2: golden ex2_2.out (GMRES + bjacobi + ILU(0), 2 ranks) its=7 ok=True" % k in out, out[-3000:]
+            assert "rank %d/2: golden ex5_5.out (two systems, GMRES + bjacobi + ILU(0), 2 ranks) ok=True" % k in out, out[-3000:]
 
 
 def test_bench_two_gpus_over_rccl(built):

@@ -147,6 +147,41 @@ def main():
         okg = ke.its == 7 and "%.5g" % xe.norm() in ("0.00029235", "0.00029234")
         print("rank %d/%d: golden ex2_2.out (GMRES + bjacobi + ILU(0), 2 ranks) its=%d ok=%s" % (rank, world, ke.its, okg), flush=True)
         ok1 = ok1 and okg
+        # ---- ex5_5.out (tutorials/makefile:423: -n 2 ./ex5 -ksp_gmres_cgs_refinement_type refine_always): two systems with ONE KSP
+        # and the default PC; the second after MatZeroEntries + re-assembly into the same pattern -> ILU(0) re-factored in both
+        # blocks.  The file prints "Norm of error <%G>, Iterations <its>" per solve.
+        import ctypes as C
+        lines5 = [l.split() for l in open(os.path.join(ROOT, "tests", "golden", "ksp_tutorials", "ex5_5.out")).read().splitlines() if l.startswith("Norm of error")]
+        (g5, u5) = pb.ex5_tutorial(2, False)
+        n5 = g5[0].size - 1; h5 = n5 // 2
+        r0_, r1_ = (0, h5) if rank == 0 else (h5, n5)
+        def local(g):
+            gi_, gj_, ga_ = g
+            return (gi_[r0_:r1_ + 1] - gi_[r0_]).astype(np.int32), gj_[gi_[r0_]:gi_[r1_]].copy(), ga_[gi_[r0_]:gi_[r1_]].copy()
+        li5, lj5, la5 = local(g5)
+        F = P.Mat.from_csr_mpi(li5, lj5, la5, r1_ - r0_, n5, n5, comm=comm)
+        uf = P.Vec.from_array(u5[r0_:r1_], comm=comm, N=n5); bf, xf = uf.duplicate(), uf.duplicate()
+        kf = P.KSP(comm=comm); kf.set_operators(F)
+        L.PetscOptionsClear(); L.PetscOptionsInsertString(b"-ksp_gmres_cgs_refinement_type refine_always")
+        kf.set_from_options()
+        L.PetscOptionsClear()
+        ok5_ = True
+        for second in (False, True):
+            if second:
+                _, _, la52 = local(pb.ex5_tutorial(2, True)[0])
+                L.MatZeroEntries(F.h)
+                rows5 = np.repeat(np.arange(r0_, r1_, dtype=np.int32), np.diff(li5))
+                for r_, c_, v_ in zip(rows5, lj5, la52):        # the example's loop of MatSetValues(ADD_VALUES)
+                    L.MatSetValues(F.h, 1, C.byref(C.c_int(int(r_))), 1, C.byref(C.c_int(int(c_))), C.byref(C.c_double(float(v_))), P.ADD_VALUES)
+                L.MatAssemblyBegin(F.h, P.MAT_FINAL_ASSEMBLY); L.MatAssemblyEnd(F.h, P.MAT_FINAL_ASSEMBLY)
+                kf.set_operators(F)
+            F.mult(uf, bf)
+            kf.solve(bf, xf)
+            L.VecAXPY(xf.h, -1.0, uf.h)
+            want = lines5[1 if second else 0]
+            ok5_ = ok5_ and ("%g" % xf.norm()) == want[3].rstrip(",") and kf.its == int(want[5])
+        print("rank %d/%d: golden ex5_5.out (two systems, GMRES + bjacobi + ILU(0), 2 ranks) ok=%s" % (rank, world, ok5_), flush=True)
+        ok1 = ok1 and ok5_
     print("rank %d/%d: MatMult bitexact=%s MatMultTranspose=%s norm=%s CG its=%d (oracle %d) hist=%s" % (rank, world, ok1, ok2, ok3, k.its, itsr, ok4), flush=True)
     dist.barrier()
     dist.destroy_process_group()
