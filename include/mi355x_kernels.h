@@ -277,6 +277,14 @@ int mi355x_trisolve_plan_create_ordered(mi355x_handle_t h, int n, int nlev, cons
  * entries in the caller's order */
 int mi355x_trisolve_plan_create_scaled(mi355x_handle_t h, int n, int nlev, const int *lev, const int *rp, const int *rl, const int *cj,
                                        const double *cv, const double *dinv, const double *rscale, mi355x_trisolve_plan_t *plan);
+/* node-blocked plans for the factor of a matrix with inodes (MatSolve_SeqAIJ_Inode, src/mat/impls/aij/seq/inode.c:2327-2760): the
+ * n rows form nnodes nodes of 1..5 consecutive rows (nstart[nnodes + 1]) whose factor rows share one column list and are coupled by a
+ * dense triangle; nodelev[u] = dependency level of node u among the nodes.  Row-level arrays as above, in the reference's stored order.
+ * One lane per node; the reference routine's summation order (shared columns two at a time, then the couplings inside the node):
+ * bit for bit MatSolve_SeqAIJ_Inode with by_level == 0.  Returns hipErrorInvalidValue for a factor without that shape.  Lower and
+ * upper plan of an application must both be node plans of the same partition. */
+int mi355x_trisolve_plan_create_nodes(mi355x_handle_t h, int n, int nnodes, const int *nstart, int nlev, const int *nodelev, const int *rp, const int *rl,
+                                      const int *cj, const double *cv, const double *dinv, int by_level, mi355x_trisolve_plan_t *plan);
 int mi355x_trisolve_plan_destroy(mi355x_trisolve_plan_t plan);
 int mi355x_trisolve_apply(mi355x_handle_t h, mi355x_trisolve_plan_t lower, mi355x_trisolve_plan_t upper, const double *b, double *y);
 int mi355x_trisolve_aborted(mi355x_trisolve_plan_t plan, int *aborted);

@@ -88,6 +88,7 @@ PetscErrorCode MatHIPMI355XGetIndexCompression(Mat A, PetscInt *noffsets);   /* 
 PetscErrorCode PCICCGetInfo_HIPMI355X(PC pc, PetscInt *nlevL, PetscInt *nlevU, PetscInt *nshift);   /* levels of the two sweeps of ICC(0); positive-definite shifts the factorisation took */
 PetscErrorCode PCILUGetShiftCount_HIPMI355X(PC pc, PetscInt *nshift);   /* restarts of ILU(0) with a larger diagonal shift (MAT_SHIFT_NONZERO, PCILU's default) */
 PetscErrorCode PCILUGetLevels_HIPMI355X(PC pc, PetscInt *nlevL, PetscInt *nlevU);   /* dependency levels of the two triangular solves */
+PetscErrorCode PCILUGetNodeInfo_HIPMI355X(PC pc, PetscInt *nodes, PetscInt *nlevL, PetscInt *nlevU);   /* node-blocked triangular solves (factor of a matrix with inodes): nodes in the plans (0: row-granular), dependency levels over nodes */
 PetscErrorCode PCFactorDebugSetAborted_HIPMI355X(PC pc);   /* tests: raise the "a dependency wait gave up" flag of this PC's sync-free plans */
 PetscErrorCode PCILUGetSolver_HIPMI355X(PC pc, PetscInt *syncfree, PetscInt *aborted);   /* 1: two-launch sync-free solves (-pc_factor_hipmi355x_trisolve syncfree, default above 16 levels); 0: one launch per level */
 

@@ -154,6 +154,57 @@ void orc_ilu0_solve(int n, const int *bi, const int *bj, const int *bdiag, const
   }
 }
 
+/* MatSolve_SeqAIJ_Inode (src/mat/impls/aij/seq/inode.c:2327-2760), natural ordering: what the reference runs on the ILU factor of
+ * a matrix with inodes (MatLUFactorNumeric_SeqAIJ_Inode installs it, inode.c:1310-1320) -- e.g. every 3-dof FEM matrix.  ns[] = the
+ * node sizes (1..5) of the FACTOR (the nodes of A: consecutive rows with identical column lists).  Per node: every row's sum runs over
+ * the columns of the node's FIRST row (lower) / LAST row (upper) two products at a time -- sum -= v[j] t0 + v[j+1] t1, the two
+ * products added to each other first -- an odd last column alone; THEN the couplings inside the node, row after row.  Written as
+ * one loop over the node size: cases 1..5 of the reference are this loop unrolled. */
+void orc_ilu0_solve_inode(int n, int nnodes, const int *ns, const int *bi, const int *bj, const int *bdiag, const double *ba, const double *b, double *x) {
+  double sum[5];
+  int row = 0;
+  for (int i = 0; i < nnodes; i++) {                      /* forward solve the lower triangular */
+    const int nsz = ns[i], nz = bi[row + 1] - bi[row];
+    const int *vi = bj + bi[row];
+    int j;
+    for (int k = 0; k < nsz; k++) sum[k] = b[row + k];
+    for (j = 0; j < nz - 1; j += 2) {
+      const double t0 = x[vi[j]], t1 = x[vi[j + 1]];
+      for (int k = 0; k < nsz; k++) { const double *v = ba + bi[row + k]; sum[k] -= v[j] * t0 + v[j + 1] * t1; }
+    }
+    if (j == nz - 1) {
+      const double t0 = x[vi[j]];
+      for (int k = 0; k < nsz; k++) { const double *v = ba + bi[row + k]; sum[k] -= v[j] * t0; }
+    }
+    for (int k = 1; k < nsz; k++) { const double *v = ba + bi[row + k]; for (int l = 0; l < k; l++) sum[k] -= v[nz + l] * sum[l]; }
+    for (int k = 0; k < nsz; k++) x[row + k] = sum[k];
+    row += nsz;
+  }
+  row = n - 1;
+  for (int i = nnodes - 1; i >= 0; i--) {                 /* backward solve the upper triangular */
+    const int nsz = ns[i], nz = bdiag[row] - bdiag[row + 1] - 1;
+    const int *vi = bj + bdiag[row + 1] + 1;
+    int j;
+    /* sum[k] belongs to row - k; its stored row starts k entries earlier than the shared columns (the k later rows of the node) */
+    for (int k = 0; k < nsz; k++) sum[k] = x[row - k];
+    for (j = 0; j < nz - 1; j += 2) {
+      const double t0 = x[vi[j]], t1 = x[vi[j + 1]];
+      for (int k = 0; k < nsz; k++) { const double *v = ba + bdiag[row - k + 1] + 1; sum[k] -= v[j + k] * t0 + v[j + k + 1] * t1; }
+    }
+    if (j == nz - 1) {
+      const double t0 = x[vi[j]];
+      for (int k = 0; k < nsz; k++) { const double *v = ba + bdiag[row - k + 1] + 1; sum[k] -= v[j + k] * t0; }
+    }
+    for (int k = 0; k < nsz; k++) {
+      const double *v = ba + bdiag[row - k + 1] + 1;
+      /* couplings to the later rows of the node, nearest LAST: v[k-1] is row's column, v[0] is row-k+1's (inode.c:2580-2760) */
+      for (int l = 0; l < k; l++) sum[k] -= v[k - 1 - l] * x[row - l];
+      x[row - k] = sum[k] * v[nz + k];
+    }
+    row -= nsz;
+  }
+}
+
 /* ---- ICC(0), natural ordering: MatICCFactorSymbolic_SeqAIJ (levels 0: the pattern of A's upper triangle, diagonal LAST in its
  * row, aijfact.c:2405-2600) and MatCholeskyFactorNumeric_SeqAIJ (aijfact.c:2076-2230) with PCICC's defaults (icc.c:189-200:
  * MAT_SHIFT_POSITIVE_DEFINITE, zeropivot 100 eps).  Row k of the factor ends up holding  -U(k,j)/D(k)-style multipliers: the

@@ -95,6 +95,8 @@ enum { ORC_PC_NONE = 0, ORC_PC_JACOBI = 1, ORC_PC_BJACOBI = 2, ORC_PC_ILU = 3, O
 int  orc_ilu0_factor(int n, const int *ai, const int *aj, const double *aa, int *bi, int *bj, int *bdiag, double *ba);
 int  orc_ilu0_factor_shift(int n, const int *ai, const int *aj, const double *aa, int *bi, int *bj, int *bdiag, double *ba, int *nshift);   /* same; *nshift = restarts MatPivotCheck_nz asked for */
 void orc_ilu0_solve(int n, const int *bi, const int *bj, const int *bdiag, const double *ba, const double *b, double *x);
+/* MatSolve_SeqAIJ_Inode (inode.c:2327-2760): the factor of a matrix with inodes; ns[] node sizes (orc_check_inode of A) */
+void orc_ilu0_solve_inode(int n, int nnodes, const int *ns, const int *bi, const int *bj, const int *bdiag, const double *ba, const double *b, double *x);
 /* ICC(0), natural ordering, of the upper triangle of a sequential AIJ matrix (MatICCFactorSymbolic_SeqAIJ with levels 0 +
  * MatCholeskyFactorNumeric_SeqAIJ, aijfact.c:2076-2230,2405-2600): ui[n+1], uj/ua[nnz of the upper triangle incl. diagonal]; row k holds
  * its off-diagonal entries (stored NEGATED and scaled, as the reference leaves them) in column order and then 1/D(k).  Returns the number

@@ -103,6 +103,12 @@ struct mi355x_trisolve_plan_s {
   int by_level;      // rows in dependency-level order, levels on slice boundaries
   int nlev;
   int *levpos;       // host, 2 * nlev: first and one-past-last position of every dependency level (level-by-level fall-back)
+  // node plans (nb > 1): a position holds a NODE -- up to nb consecutive rows with one shared column list (the inodes of the
+  // reference, Mat_CheckInode); d_row = the node's first row, d_col = SLOTS (k * np + position) of the shared columns, d_val = nb
+  // values per shared column, d_din = the couplings inside the node and (upper) the inverted diagonals, d_w = nb * np slots
+  int nb, np;
+  unsigned char *d_nsz;    // per position: rows in the node
+  double *d_din;           // [nb (nb - 1) / 2 + nb][np]
 };
 
 __device__ __forceinline__ double tri_poll(const double *p, int *abort_flag, int sleep_cap) {
@@ -217,6 +223,172 @@ __global__ __launch_bounds__(MI355X_BLOCK) void trisolve_syncfree_kernel(
     }
     (void)slen;
   }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Node-blocked sync-free solves: the MI355X form of MatSolve_SeqAIJ_Inode (src/mat/impls/aij/seq/inode.c:2327-2760), the routine
+// the reference runs on the ILU factor of a matrix with inodes (every 3-dof FEM matrix).  A position of the sliced layout holds a
+// NODE: nsz <= NB consecutive rows whose factor rows share one column list (the first row's in L, the last row's in U) and are
+// coupled to each other by a dense triangle.  One lane owns a node: it walks the shared columns ONCE -- one index, one gather /
+// poll of the solution value, NB values per column -- then solves the nsz x nsz triangle in registers.  Against the row-granular
+// kernel above: dependency levels / nsz (a node's rows were nsz consecutive levels), index traffic and polls / nsz.
+// Summation order = the reference routine's: every row's sum takes the shared columns two at a time,
+// sum -= v[j] t0 + v[j+1] t1 (the two products added to each other first), an odd last column alone, then the couplings inside the
+// node row after row -- bit for bit MatSolve_SeqAIJ_Inode while the columns are stored in column order (by_level = 0).
+// The index / value loads of the NEXT batch of columns are issued before the current batch's polls: they do not depend on any
+// solution value, and behind the polls they would add a memory round trip per batch to the dependency chain.
+template <int NB, bool UPPER, bool POLL>
+__device__ __forceinline__ void tri_node_solve(const int t, const int lane, const int np, const int base, const int ncol, const int row0, const int nsz,
+                                               const int *__restrict__ col, const double *__restrict__ val, const double *__restrict__ din,
+                                               const double *src, const int *__restrict__ spos, double *w, double *y, double *reset,
+                                               int *abort_flag, const int sleep_cap) {
+  constexpr int B = NB <= 3 ? 8 : 4;           // columns per batch (registers: 2 batches x (1 + NB) words per column)
+  constexpr int NT = NB * (NB - 1) / 2;
+  double sum[NB];
+#pragma unroll
+  for (int k = 0; k < NB; ++k) {
+    sum[k] = 0.0;
+    if (k < nsz) {
+      if (UPPER) {                             // sum[k] belongs to the node's row nsz - 1 - k (k = distance from the LAST row, as the reference counts)
+        const int p = spos[row0 + nsz - 1 - k];
+        sum[k] = src[p];
+        if (POLL) reset[p] = __longlong_as_double((long long)TRI_SENTINEL);
+      } else sum[k] = src[row0 + k];
+    }
+  }
+  const double *vbase = val + (size_t)base * NB + lane;
+  const int *cbase = col + base + lane;
+  int cA[B]; double aA[B * NB];
+#pragma unroll
+  for (int j = 0; j < B; ++j) {
+    const int qq = j < ncol ? j : 0;
+    cA[j] = ncol > 0 ? cbase[qq * MI355X_WAVE] : 0;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) aA[j * NB + k] = ncol > 0 ? vbase[(size_t)(qq * NB + k) * MI355X_WAVE] : 0.0;
+  }
+  for (int q0 = 0; q0 < ncol; q0 += B) {
+    int cN[B]; double aN[B * NB];
+    const bool more = q0 + B < ncol;
+#pragma unroll
+    for (int j = 0; j < B; ++j) {              // the next batch's indices and values: in flight while this batch waits for its dependencies
+      const int qq = (q0 + B + j < ncol) ? q0 + B + j : q0;
+      cN[j] = more ? cbase[qq * MI355X_WAVE] : 0;
+#pragma unroll
+      for (int k = 0; k < NB; ++k) aN[j * NB + k] = more ? vbase[(size_t)(qq * NB + k) * MI355X_WAVE] : 0.0;
+    }
+    double v[B];
+#pragma unroll
+    for (int j = 0; j < B; ++j) {
+      v[j] = 0.0;
+      if (q0 + j < ncol) v[j] = POLL ? __hip_atomic_load(w + cA[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : w[cA[j]];
+    }
+#pragma unroll
+    for (int j = 0; j < B; j += 2) {
+      if (q0 + j < ncol) {
+        double x0 = v[j];
+        if (POLL && __double_as_longlong(x0) == (long long)TRI_SENTINEL) x0 = tri_poll(w + cA[j], abort_flag, sleep_cap);
+        if (q0 + j + 1 < ncol) {
+          double x1 = v[j + 1];
+          if (POLL && __double_as_longlong(x1) == (long long)TRI_SENTINEL) x1 = tri_poll(w + cA[j + 1], abort_flag, sleep_cap);
+#pragma unroll
+          for (int k = 0; k < NB; ++k) sum[k] -= aA[j * NB + k] * x0 + aA[(j + 1) * NB + k] * x1;
+        } else {
+#pragma unroll
+          for (int k = 0; k < NB; ++k) sum[k] -= aA[j * NB + k] * x0;
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < B; ++j) {
+      cA[j] = cN[j];
+#pragma unroll
+      for (int k = 0; k < NB; ++k) aA[j * NB + k] = aN[j * NB + k];
+    }
+  }
+  // the couplings inside the node
+  if (!UPPER) {
+#pragma unroll
+    for (int k = 1; k < NB; ++k) {
+      if (k < nsz) {
+#pragma unroll
+        for (int l = 0; l < k; ++l) sum[k] -= din[(size_t)(k * (k - 1) / 2 + l) * np + t] * sum[l];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NB; ++k)
+      if (k < nsz) {
+        if (POLL) __hip_atomic_store(w + (size_t)k * np + t, sum[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else w[(size_t)k * np + t] = sum[k];
+      }
+  } else {
+    double xr[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+      xr[k] = 0.0;
+      if (k < nsz) {
+#pragma unroll
+        for (int l = 0; l < k; ++l) sum[k] -= din[(size_t)(k * (k - 1) / 2 + (k - 1 - l)) * np + t] * xr[l];   // nearest row last (inode.c:2604-2610)
+        xr[k] = sum[k] * din[(size_t)(NT + k) * np + t];
+        const int kk = nsz - 1 - k;            // the row's slot counts from the node's FIRST row
+        if (POLL) __hip_atomic_store(w + (size_t)kk * np + t, xr[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else w[(size_t)kk * np + t] = xr[k];
+        y[row0 + kk] = xr[k];
+      }
+    }
+  }
+}
+
+template <int NB, bool UPPER>
+__global__ __launch_bounds__(MI355X_BLOCK) void trisolve_node_kernel(
+    int nslices, int nchunks, int np, const int *__restrict__ ptr, const int *__restrict__ info, const int *__restrict__ rowof,
+    const unsigned char *__restrict__ nszof, const int *__restrict__ col, const double *__restrict__ val, const double *__restrict__ din,
+    const unsigned char *__restrict__ nsub, const double *src, const int *__restrict__ spos, double *w, double *y,
+    double *reset, int reset_n, unsigned int *queue, unsigned int *other_queue, int *abort_flag, int sleep_cap) {
+  __shared__ int chunk_s[2];
+  const int tid = threadIdx.x, lane = tid & (MI355X_WAVE - 1), wave = tid / MI355X_WAVE;
+  if (blockIdx.x == 0 && tid < TRI_QUEUES) other_queue[tid * TRI_QSTRIDE] = 0u;
+  if (!UPPER) {   // the upper solve's slots beyond this plan's own positions are re-armed here
+    for (long i = (long)NB * np + (long)blockIdx.x * MI355X_BLOCK + tid; i < reset_n; i += (long)gridDim.x * MI355X_BLOCK)
+      reset[i] = __longlong_as_double((long long)TRI_SENTINEL);
+  }
+  const int q = blockIdx.x % TRI_QUEUES;
+  for (int it = 0;; ++it) {
+    if (tid == 0) {
+      const unsigned int k = __hip_atomic_fetch_add(queue + q * TRI_QSTRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      chunk_s[it & 1] = (int)(k * TRI_QUEUES + q);
+    }
+    __syncthreads();
+    const int chunk = chunk_s[it & 1];
+    if (chunk >= nchunks || chunk < 0) break;
+    const int s = chunk * (MI355X_BLOCK / MI355X_WAVE) + wave;
+    if (s >= nslices) continue;
+    const int t = s * MI355X_WAVE + lane;
+    const int inf = info[t], row0 = rowof[t], nsz = nszof[t];
+    const int ncol = inf >> 8, mysub = inf & 255;
+    const int ns = nsub[s];
+    if (!UPPER) {   // re-arm the other (upper) solve's slots of this position: its previous application is complete
+#pragma unroll
+      for (int k = 0; k < NB; ++k) { const long i = (long)k * np + t; if (i < reset_n) reset[i] = __longlong_as_double((long long)TRI_SENTINEL); }
+    }
+    for (int step = 0; step < ns; ++step)
+      if (row0 >= 0 && mysub == step)
+        tri_node_solve<NB, UPPER, true>(t, lane, np, ptr[s], ncol, row0, nsz, col, val, din, src, spos, w, y, reset, abort_flag, sleep_cap);
+  }
+}
+
+template <int NB, bool UPPER>
+__global__ __launch_bounds__(MI355X_BLOCK) void trisolve_node_level_kernel(int p0, int p1, int np, const int *__restrict__ ptr, const int *__restrict__ info,
+                                                                           const int *__restrict__ rowof, const unsigned char *__restrict__ nszof,
+                                                                           const int *__restrict__ col, const double *__restrict__ val,
+                                                                           const double *__restrict__ din, const double *src,
+                                                                           const int *__restrict__ spos, double *w, double *y) {
+  const int t = p0 + blockIdx.x * MI355X_BLOCK + threadIdx.x;
+  if (t >= p1) return;
+  const int row0 = rowof[t];
+  if (row0 < 0) return;
+  tri_node_solve<NB, UPPER, false>(t, t % MI355X_WAVE, np, ptr[t / MI355X_WAVE], info[t] >> 8, row0, nszof[t], col, val, din, src, spos, w, y,
+                                   (double *)nullptr, (int *)nullptr, 0);
 }
 
 extern "C" int mi355x_trisolve_plan_destroy(mi355x_trisolve_plan_t p);
@@ -419,6 +591,228 @@ static int trisolve_plan_create_impl(mi355x_handle_t h, int n, int nlev, const i
   return 0;
 }
 
+
+// ---- node plans: host analysis ----
+// n rows in nnodes nodes (nstart[u] .. nstart[u + 1] the rows of node u, sizes 1 .. 5); nodelev[u] its dependency level among the
+// nodes (every level non-empty).  Row-level factor as for the row plans: row i's off-diagonal entries cj/cv[rp[i] .. rp[i] + rl[i])
+// in the reference's stored order -- lower: the shared columns (those of the node's first row), then the node's own earlier rows;
+// upper: the node's own later rows, then the shared columns (those of the node's last row).  A factor whose rows do not have that
+// shape is refused (hipErrorInvalidValue): the caller keeps the row-granular plan.
+#define TRI_TRY(expr) do { const int e__ = (int)(expr); if (e__) { (void)hipStreamSynchronize(h->stream); return e__; } } while (0)
+#define TRI_FAIL() do { (void)hipStreamSynchronize(h->stream); return (int)hipErrorInvalidValue; } while (0)
+static int trisolve_plan_fill_nodes(mi355x_handle_t h, mi355x_trisolve_plan_s *p, int n, int nnodes, const int *nstart, int nlev, const int *nodelev,
+                                    const int *rp, const int *rl, const int *cj, const double *cv, const double *dinv_host, int by_level) {
+  const int W = MI355X_WAVE;
+  const bool upper = dinv_host != nullptr;
+  p->n = n; p->upper = upper; p->by_level = by_level; p->nlev = nlev;
+  int NB = 1;
+  for (int u = 0; u < nnodes; ++u) { const int z = nstart[u + 1] - nstart[u]; if (z < 1 || z > 5) TRI_FAIL(); if (z > NB) NB = z; }
+  if (NB < 2) TRI_FAIL();
+  p->nb = NB;
+  std::vector<int> nodeof((size_t)(n > 0 ? n : 1));
+  for (int u = 0; u < nnodes; ++u) for (int r = nstart[u]; r < nstart[u + 1]; ++r) nodeof[(size_t)r] = u;
+  // shape check + shared column counts
+  std::vector<int> nsh((size_t)nnodes);
+  for (int u = 0; u < nnodes; ++u) {
+    const int r0 = nstart[u], z = nstart[u + 1] - r0, rL = r0 + z - 1;
+    const int sh = upper ? rl[rL] : rl[r0];
+    nsh[(size_t)u] = sh;
+    const int *shared = upper ? cj + rp[rL] : cj + rp[r0];
+    for (int k = 0; k < z; ++k) {
+      const int r = upper ? rL - k : r0 + k;
+      if (rl[r] != sh + k) TRI_FAIL();
+      const int *mine = cj + rp[r] + (upper ? k : 0);              // where this row's copy of the shared list starts
+      for (int q = 0; q < sh; ++q) if (mine[q] != shared[q]) TRI_FAIL();
+      for (int l = 0; l < k; ++l) {                                // the k couplings inside the node
+        const int c = upper ? cj[rp[r] + l] : cj[rp[r] + sh + l];
+        if (c != (upper ? r + 1 + l : r0 + l)) TRI_FAIL();
+      }
+    }
+    for (int q = 0; q < sh; ++q) if (nodeof[(size_t)shared[q]] == u) TRI_FAIL();
+  }
+  // positions: nodes by level, more shared columns first inside a level (stable)
+  std::vector<int> order((size_t)nnodes), levptr((size_t)nlev + 1, 0);
+  for (int u = 0; u < nnodes; ++u) { if (nodelev[u] < 0 || nodelev[u] >= nlev) TRI_FAIL(); levptr[(size_t)nodelev[u] + 1]++; }
+  for (int l = 0; l < nlev; ++l) levptr[(size_t)l + 1] += levptr[(size_t)l];
+  { std::vector<int> next(levptr.begin(), levptr.end() - 1);
+    for (int u = 0; u < nnodes; ++u) order[(size_t)next[(size_t)nodelev[u]]++] = u; }
+  for (int l = 0; l < nlev; ++l)
+    std::stable_sort(order.begin() + levptr[(size_t)l], order.begin() + levptr[(size_t)l + 1], [&](int a, int b) { return nsh[(size_t)a] > nsh[(size_t)b]; });
+  std::vector<long> tpos((size_t)(nnodes > 0 ? nnodes : 1));
+  long cur = 0;
+  for (int l = 0; l < nlev; ++l) {
+    const int sz = levptr[(size_t)l + 1] - levptr[(size_t)l];
+    if (sz < 1) TRI_FAIL();
+    if (by_level && sz >= TRI_ALIGN_MIN && (cur % W)) cur += W - cur % W;
+    for (int t = levptr[(size_t)l]; t < levptr[(size_t)l + 1]; ++t) tpos[(size_t)t] = cur++;
+  }
+  if (cur * NB > 2147483000L) TRI_FAIL();
+  p->levpos = (int *)malloc(sizeof(int) * 2 * (size_t)(nlev > 0 ? nlev : 1));
+  if (!p->levpos) TRI_FAIL();
+  for (int l = 0; l < nlev; ++l) {
+    p->levpos[2 * l] = (int)tpos[(size_t)levptr[(size_t)l]];
+    p->levpos[2 * l + 1] = (int)tpos[(size_t)levptr[(size_t)l + 1] - 1] + 1;
+  }
+  p->nslices = (int)((cur + W - 1) / W);
+  p->nchunks = (p->nslices + 3) / 4;
+  const size_t np = (size_t)p->nslices * W;
+  p->np = (int)np;
+  const int NT = NB * (NB - 1) / 2, ND = NT + NB;
+  std::vector<int> posn((size_t)(nnodes > 0 ? nnodes : 1)), slot((size_t)(n > 0 ? n : 1)), info(np > 0 ? np : 1, 0), rowof(np > 0 ? np : 1, -1),
+      ptr((size_t)p->nslices + 1, 0);
+  std::vector<unsigned char> nsub((size_t)(p->nslices > 0 ? p->nslices : 1), 1), nszv(np > 0 ? np : 1, 0);
+  std::vector<double> din((np > 0 ? np : 1) * (size_t)ND, 0.0);
+  for (int t = 0; t < nnodes; ++t) {
+    const int u = order[(size_t)t]; const long P = tpos[(size_t)t];
+    posn[(size_t)u] = (int)P; rowof[(size_t)P] = nstart[u]; nszv[(size_t)P] = (unsigned char)(nstart[u + 1] - nstart[u]);
+    for (int r = nstart[u]; r < nstart[u + 1]; ++r) slot[(size_t)r] = (int)((size_t)(r - nstart[u]) * np + (size_t)P);
+  }
+  long total = 0;
+  for (int s = 0; s < p->nslices; ++s) {
+    int mx = 0, l0 = -1;
+    for (int j = 0; j < W; ++j) {
+      const size_t P = (size_t)s * W + j;
+      if (rowof[P] < 0) continue;
+      const int u = nodeof[(size_t)rowof[P]];
+      if (l0 < 0) l0 = nodelev[u];
+      const int sub = nodelev[u] - l0;
+      if (sub < 0 || sub > 255) TRI_FAIL();
+      info[P] = (nsh[(size_t)u] << 8) | sub;
+      if (nsh[(size_t)u] > mx) mx = nsh[(size_t)u];
+      if (sub + 1 > nsub[(size_t)s]) nsub[(size_t)s] = (unsigned char)(sub + 1);
+    }
+    ptr[(size_t)s] = (int)total;
+    total += (long)mx * W;
+    if (total * NB > 2147483000L) TRI_FAIL();
+  }
+  ptr[(size_t)p->nslices] = (int)total;
+  std::vector<int> col((size_t)(total > 0 ? total : 1), 0);
+  std::vector<double> val((size_t)(total > 0 ? total : 1) * NB, 0.0);
+  { std::atomic<int> bad(0);
+    auto fill = [&](int t0, int t1) {
+      std::vector<int> perm;
+      for (int t = t0; t < t1 && !bad.load(std::memory_order_relaxed); ++t) {
+        const int u = order[(size_t)t], P = (int)tpos[(size_t)t], s = P / W, lane = P % W;
+        const int r0 = nstart[u], z = nstart[u + 1] - r0, rL = r0 + z - 1, sh = nsh[(size_t)u];
+        const int *shared = upper ? cj + rp[rL] : cj + rp[r0];
+        perm.resize((size_t)sh);
+        for (int q = 0; q < sh; ++q) perm[(size_t)q] = q;
+        if (by_level) std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return nodelev[nodeof[(size_t)shared[a]]] < nodelev[nodeof[(size_t)shared[b]]]; });
+        for (int q = 0; q < sh; ++q) {
+          const int sq = perm[(size_t)q], dep = shared[sq];
+          if (posn[(size_t)nodeof[(size_t)dep]] >= P) { bad.store(1); break; }        // a dependency must come earlier
+          col[(size_t)ptr[(size_t)s] + (size_t)q * W + lane] = slot[(size_t)dep];
+          for (int k = 0; k < z; ++k) {
+            const int r = upper ? rL - k : r0 + k;
+            val[(size_t)ptr[(size_t)s] * NB + ((size_t)q * NB + k) * W + lane] = cv[rp[r] + (upper ? k : 0) + sq];
+          }
+        }
+        for (int k = 0; k < z; ++k) {
+          const int r = upper ? rL - k : r0 + k;
+          for (int l = 0; l < k; ++l) din[(size_t)(k * (k - 1) / 2 + l) * np + P] = cv[rp[r] + (upper ? l : sh + l)];
+          if (upper) din[(size_t)(NT + k) * np + P] = dinv_host[r];
+        }
+      }
+    };
+    unsigned hc = std::thread::hardware_concurrency();
+    int nth = (int)(hc > 8 ? 8 : (hc < 1 ? 1 : hc));
+    if (nnodes < 100000) nth = 1;
+    if (nth == 1) fill(0, nnodes);
+    else {
+      std::vector<std::thread> th;
+      for (int k = 0; k < nth; ++k) th.emplace_back(fill, (int)((long)nnodes * k / nth), (int)((long)nnodes * (k + 1) / nth));
+      for (auto &t : th) t.join();
+    }
+    if (bad.load()) TRI_FAIL(); }
+#define TRI_UP(dst, vec, T) do { TRI_TRY(hipMalloc((void **)&(dst), sizeof(T) * (vec).size())); \
+    TRI_TRY(hipMemcpyAsync((dst), (vec).data(), sizeof(T) * (vec).size(), hipMemcpyHostToDevice, h->stream)); } while (0)
+  TRI_UP(p->d_ptr, ptr, int); TRI_UP(p->d_info, info, int); TRI_UP(p->d_row, rowof, int); TRI_UP(p->d_col, col, int);
+  TRI_UP(p->d_val, val, double); TRI_UP(p->d_nsub, nsub, unsigned char); TRI_UP(p->d_pos, slot, int);
+  TRI_UP(p->d_nsz, nszv, unsigned char); TRI_UP(p->d_din, din, double);
+#undef TRI_UP
+  const size_t nw = (np > 0 ? np : 1) * (size_t)NB;
+  TRI_TRY(hipMalloc((void **)&p->d_w, sizeof(double) * nw));
+  { std::vector<unsigned long long> sent(nw, TRI_SENTINEL);
+    TRI_TRY(hipMemcpyAsync(p->d_w, sent.data(), sizeof(double) * sent.size(), hipMemcpyHostToDevice, h->stream));
+    TRI_TRY(hipStreamSynchronize(h->stream)); }
+  TRI_TRY(hipMalloc((void **)&p->d_queue, sizeof(unsigned int) * TRI_QUEUES * TRI_QSTRIDE));
+  TRI_TRY(hipMemsetAsync(p->d_queue, 0, sizeof(unsigned int) * TRI_QUEUES * TRI_QSTRIDE, h->stream));
+  TRI_TRY(hipHostMalloc((void **)&p->abort_flag, 64, hipHostMallocMapped | hipHostMallocCoherent));
+  *p->abort_flag = 0;
+  int dev = 0;
+  hipDeviceProp_t prop;
+  TRI_TRY(hipGetDevice(&dev));
+  TRI_TRY(hipGetDeviceProperties(&prop, dev));
+  p->grid = prop.multiProcessorCount * 2;            // register-heavy kernel: two workgroups per CU are resident for every NB
+  { const char *e = getenv("MI355X_TRISOLVE_AHEAD");
+    const long ahead = e ? atol(e) : 4;
+    const long per_level = ((long)p->nchunks + nlev - 1) / (nlev > 0 ? nlev : 1);
+    long g = ahead * per_level;
+    if (g < TRI_QUEUES) g = TRI_QUEUES;
+    if (g < p->grid) p->grid = (int)g; }
+  if (p->grid > p->nchunks) p->grid = p->nchunks > 0 ? p->nchunks : 1;
+  if (p->grid >= TRI_QUEUES) p->grid -= p->grid % TRI_QUEUES;
+  { const char *e = getenv("MI355X_TRISOLVE_SLEEP"); p->sleep_cap = e ? atoi(e) : (p->grid <= 128 ? 2 : 8); if (p->sleep_cap < 1) p->sleep_cap = 1; }
+  TRI_TRY(hipStreamSynchronize(h->stream));
+  return 0;
+}
+#undef TRI_TRY
+#undef TRI_FAIL
+
+int mi355x_trisolve_plan_create_nodes(mi355x_handle_t h, int n, int nnodes, const int *nstart, int nlev, const int *nodelev, const int *rp, const int *rl,
+                                      const int *cj, const double *cv, const double *dinv_host, int by_level, mi355x_trisolve_plan_t *out) {
+  mi355x_trisolve_plan_s *p = new mi355x_trisolve_plan_s();
+  memset(p, 0, sizeof(*p));
+  *out = nullptr;
+  const int rc = trisolve_plan_fill_nodes(h, p, n, nnodes, nstart, nlev, nodelev, rp, rl, cj, cv, dinv_host, by_level);
+  if (rc) { mi355x_trisolve_plan_destroy(p); return rc; }
+  *out = p;
+  return 0;
+}
+
+}  // extern "C"
+
+template <int NB>
+static int tri_node_go(mi355x_handle_t h, mi355x_trisolve_plan_t lo, mi355x_trisolve_plan_t up, const double *b, double *y, bool levels) {
+  if (!levels) {
+    const int glo = lo->grid < TRI_QUEUES ? TRI_QUEUES : lo->grid, gup = up->grid < TRI_QUEUES ? TRI_QUEUES : up->grid;
+    hipLaunchKernelGGL((trisolve_node_kernel<NB, false>), dim3(glo), dim3(MI355X_BLOCK), 0, h->stream, lo->nslices, lo->nchunks, lo->np, lo->d_ptr, lo->d_info,
+                       lo->d_row, lo->d_nsz, lo->d_col, lo->d_val, lo->d_din, lo->d_nsub, b, (const int *)nullptr, lo->d_w, (double *)nullptr, up->d_w,
+                       up->np * NB, lo->d_queue, up->d_queue, lo->abort_flag, lo->sleep_cap);
+    MI355X_LAUNCH_CHECK();
+    hipLaunchKernelGGL((trisolve_node_kernel<NB, true>), dim3(gup), dim3(MI355X_BLOCK), 0, h->stream, up->nslices, up->nchunks, up->np, up->d_ptr, up->d_info,
+                       up->d_row, up->d_nsz, up->d_col, up->d_val, up->d_din, up->d_nsub, lo->d_w, lo->d_pos, up->d_w, y, lo->d_w, 0, up->d_queue,
+                       lo->d_queue, up->abort_flag, up->sleep_cap);
+    MI355X_LAUNCH_CHECK();
+    return 0;
+  }
+  for (int l = 0; l < lo->nlev; ++l) {
+    const int p0 = lo->levpos[2 * l], p1 = lo->levpos[2 * l + 1];
+    hipLaunchKernelGGL((trisolve_node_level_kernel<NB, false>), dim3((p1 - p0 + MI355X_BLOCK - 1) / MI355X_BLOCK), dim3(MI355X_BLOCK), 0, h->stream, p0, p1, lo->np,
+                       lo->d_ptr, lo->d_info, lo->d_row, lo->d_nsz, lo->d_col, lo->d_val, lo->d_din, b, (const int *)nullptr, lo->d_w, (double *)nullptr);
+    MI355X_LAUNCH_CHECK();
+  }
+  for (int l = 0; l < up->nlev; ++l) {
+    const int p0 = up->levpos[2 * l], p1 = up->levpos[2 * l + 1];
+    hipLaunchKernelGGL((trisolve_node_level_kernel<NB, true>), dim3((p1 - p0 + MI355X_BLOCK - 1) / MI355X_BLOCK), dim3(MI355X_BLOCK), 0, h->stream, p0, p1, up->np,
+                       up->d_ptr, up->d_info, up->d_row, up->d_nsz, up->d_col, up->d_val, up->d_din, lo->d_w, lo->d_pos, up->d_w, y);
+    MI355X_LAUNCH_CHECK();
+  }
+  return 0;
+}
+static int tri_node_dispatch(mi355x_handle_t h, mi355x_trisolve_plan_t lo, mi355x_trisolve_plan_t up, const double *b, double *y, bool levels) {
+  if (lo->nb != up->nb) return (int)hipErrorInvalidValue;
+  switch (lo->nb) {
+  case 2: return tri_node_go<2>(h, lo, up, b, y, levels);
+  case 3: return tri_node_go<3>(h, lo, up, b, y, levels);
+  case 4: return tri_node_go<4>(h, lo, up, b, y, levels);
+  case 5: return tri_node_go<5>(h, lo, up, b, y, levels);
+  default: return (int)hipErrorInvalidValue;
+  }
+}
+
+extern "C" {
+
 int mi355x_trisolve_plan_create_ordered(mi355x_handle_t h, int n, int nlev, const int *lev, const int *rp, const int *rl, const int *cj,
                                         const double *cv, const double *dinv_host, int by_level, mi355x_trisolve_plan_t *out) {
   return trisolve_plan_create_impl(h, n, nlev, lev, rp, rl, cj, cv, dinv_host, nullptr, by_level, out);
@@ -443,6 +837,8 @@ int mi355x_trisolve_plan_destroy(mi355x_trisolve_plan_t p) {
   (void)hipFree(p->d_nsub); (void)hipFree(p->d_pos); (void)hipFree(p->d_w); (void)hipFree(p->d_queue);
   if (p->d_dinv) (void)hipFree(p->d_dinv);
   if (p->d_rscale) (void)hipFree(p->d_rscale);
+  if (p->d_nsz) (void)hipFree(p->d_nsz);
+  if (p->d_din) (void)hipFree(p->d_din);
   if (p->abort_flag) (void)hipHostFree(p->abort_flag);
   free(p->levpos);
   delete p;
@@ -455,6 +851,7 @@ int mi355x_trisolve_apply(mi355x_handle_t h, mi355x_trisolve_plan_t lo, mi355x_t
   if (!lo || !up || lo->n != up->n || lo->upper || !up->upper) return (int)hipErrorInvalidValue;
   if (*lo->abort_flag || *up->abort_flag) return (int)hipErrorLaunchFailure;
   if (lo->n == 0) return 0;
+  if (lo->nb > 1 || up->nb > 1) return tri_node_dispatch(h, lo, up, b, y, false);
   // with fewer chunks than queues some queues have no puller: chunk c is then only served through queue c % 8 ...
   // so tiny systems use ONE workgroup per queue that exists (grid >= min(nchunks, 8) is guaranteed by plan_create)
   const int glo = lo->grid < TRI_QUEUES ? TRI_QUEUES : lo->grid, gup = up->grid < TRI_QUEUES ? TRI_QUEUES : up->grid;
@@ -481,6 +878,7 @@ int mi355x_trisolve_apply(mi355x_handle_t h, mi355x_trisolve_plan_t lo, mi355x_t
 int mi355x_trisolve_apply_levels(mi355x_handle_t h, mi355x_trisolve_plan_t lo, mi355x_trisolve_plan_t up, const double *b, double *y) {
   if (!lo || !up || lo->n != up->n || lo->upper || !up->upper) return (int)hipErrorInvalidValue;
   if (lo->n == 0) return 0;
+  if (lo->nb > 1 || up->nb > 1) return tri_node_dispatch(h, lo, up, b, y, true);
   for (int l = 0; l < lo->nlev; ++l) {
     const int p0 = lo->levpos[2 * l], p1 = lo->levpos[2 * l + 1];
     hipLaunchKernelGGL((trisolve_level_kernel<false>), dim3((p1 - p0 + MI355X_BLOCK - 1) / MI355X_BLOCK), dim3(MI355X_BLOCK), 0, h->stream, p0, p1,

@@ -559,6 +559,17 @@ PetscErrorCode MatHIPMI355XSetValuePatterns(Mat A, PetscBool on) {
 
 /* row grouping of the SpMV plan: number of nodes Mat_CheckInode found (0: plain routines), groups the device plan stores
  * one column list for (0: the plan streams per-nonzero indices), and the shared indices stored */
+/* the nodes Mat_CheckInode finds (consecutive rows with identical column lists): count and sizes, NULL / 0 when the matrix keeps the
+ * plain routines.  For the factorisations (host/ilu.c): the reference solves the factor of such a matrix node by node */
+PetscErrorCode MatSeqAIJHIPGetInodes(Mat A, PetscInt *count, const PetscInt **sizes) {
+  PetscErrorCode ierr;
+  *count = 0; *sizes = NULL;
+  if (!A || A->ops->mult != MatMult_SeqAIJHIP) return 0;
+  ierr = MatSeqAIJHIPUpload(A);CHKERRQ(ierr);          /* runs Mat_CheckInode's restatement on the current pattern */
+  *count = SA(A)->inode_count; *sizes = SA(A)->inode_size;
+  return 0;
+}
+
 PetscErrorCode MatHIPMI355XGetInodeInfo(Mat A, PetscInt *nodes, PetscInt *groups, PetscInt *shared_indices) {
   PetscErrorCode ierr; int ng = 0; long ngj = 0;
   if (nodes) *nodes = 0;

@@ -146,6 +146,7 @@ typedef struct {
   PetscScalar *d_work; void *graph; int graph_tried;       /* hipGraph of the level launches working in place on d_work */
   mi355x_trisolve_plan_t tri_lo, tri_up;                   /* sync-free solves (NULL: level launches) */
   int by_level;                                            /* rows summed in dependency-level order (inode matrices) instead of column order */
+  PetscInt nodes, nlevL_nodes, nlevU_nodes;                /* node-blocked plans (the factor of a matrix with inodes): nodes and their levels; 0: row-granular */
   int use_levels, aborted;                                 /* a sync-free application gave up: the same plans run level by level from now on */
   PetscInt nshift;                                         /* restarts / shifts the factorisation took (largest count over the blocks) */
   int factored_state; void *factored_of;                   /* operator and operator state of the last numeric factorisation */
@@ -220,6 +221,7 @@ PetscErrorCode MatCreate_MPIAIJHIPMI355X(Mat);
 PetscErrorCode MatCreate_AIJHIPMI355X(Mat);
 PetscErrorCode MatCreate_SeqBAIJHIPMI355X(Mat);
 PetscErrorCode MatSeqAIJHIPUpload(Mat A);
+PetscErrorCode MatSeqAIJHIPGetInodes(Mat A, PetscInt *count, const PetscInt **sizes);
 PetscErrorCode MatSeqAIJHIPSetCompressedRow(Mat A, PetscBool flg);
 PetscErrorCode MatSetUpMultiply_MPIAIJ(Mat mat);
 PetscErrorCode MatTimingBegin(Mat A, mi355x_handle_t h);

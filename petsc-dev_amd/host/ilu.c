@@ -278,14 +278,54 @@ static PetscErrorCode ilu0_analyse_and_upload(Mat F, Mat A) {
        * entries only) -- the default where the reference does not run the natural-ordering routine either: a matrix with
        * inodes, whose factor it solves with MatSolve_SeqAIJ_Inode (inode.c; MatLUFactorNumeric_SeqAIJ_Inode installs it),
        * in yet another order.  There the two agree to rounding. */
-      char ord[32] = ""; PetscInt nodes = 0; int by_level;
+      char ord[32] = "", nodeopt[16] = ""; PetscInt nodes = 0; const PetscInt *nsizes = NULL; int by_level, rc = 1; PetscBool nset;
       ierr = PetscOptionsGetString(HipObjPrefix(F), "-pc_factor_hipmi355x_trisolve_order", ord, sizeof(ord), &set);CHKERRQ(ierr);
       if (set && strcmp(ord, "column") && strcmp(ord, "level")) SETERRQ(HipObjComm(F), PETSC_ERR_ARG_WRONG, "-pc_factor_hipmi355x_trisolve_order <column|level>, got %s", ord);
-      ierr = MatHIPMI355XGetInodeInfo(A, &nodes, NULL, NULL);CHKERRQ(ierr);
-      by_level = set ? !strcmp(ord, "level") : (nodes > 0);
-      f->by_level = by_level;
-      int rc = mi355x_trisolve_plan_create_ordered(dc->h, n, f->nlevL, lev, bi, rlL, bj, ba, NULL, by_level, &f->tri_lo);
-      if (!rc) rc = mi355x_trisolve_plan_create_ordered(dc->h, n, f->nlevU, levU, rpU, rlU, bj, ba, dinv, by_level, &f->tri_up);
+      ierr = MatSeqAIJHIPGetInodes(A, &nodes, &nsizes);CHKERRQ(ierr);
+      ierr = PetscOptionsGetString(HipObjPrefix(F), "-pc_factor_hipmi355x_trisolve_nodes", nodeopt, sizeof(nodeopt), &nset);CHKERRQ(ierr);
+      f->nodes = 0;
+      if (nodes > 0 && !(nset && (!strcmp(nodeopt, "0") || !strcmp(nodeopt, "false")))) {
+        /* The factor of a matrix with inodes: the reference solves it node by node (MatSolve_SeqAIJ_Inode, inode.c:2327-2760;
+         * MatLUFactorNumeric_SeqAIJ_Inode installs it), and so does the device: one lane per NODE, dependency levels over nodes
+         * (a node's rows were consecutive levels of the row-granular analysis), the shared column list walked once per node in
+         * the reference routine's order -- column order, two columns at a time: its bits -- or, with
+         * -pc_factor_hipmi355x_trisolve_order level, oldest dependency first (agreement to rounding).
+         * -pc_factor_hipmi355x_trisolve_nodes 0 keeps the row-granular plans. */
+        PetscInt *nstart, *nodeof, *nlevL, *nlevU, nlL = 0, nlU = 0;
+        ierr = PetscMalloc(sizeof(PetscInt) * (size_t)(nodes + 1), &nstart);CHKERRQ(ierr);
+        ierr = PetscMalloc(sizeof(PetscInt) * (size_t)n, &nodeof);CHKERRQ(ierr);
+        ierr = PetscMalloc(sizeof(PetscInt) * (size_t)nodes, &nlevL);CHKERRQ(ierr);
+        ierr = PetscMalloc(sizeof(PetscInt) * (size_t)nodes, &nlevU);CHKERRQ(ierr);
+        nstart[0] = 0;
+        for (PetscInt u = 0; u < nodes; u++) { nstart[u + 1] = nstart[u] + nsizes[u]; for (PetscInt r = nstart[u]; r < nstart[u + 1] && r < n; r++) nodeof[r] = u; }
+        if (nstart[nodes] == n) {
+          for (PetscInt u = 0; u < nodes; u++) {                     /* a node may start once the nodes its FIRST row references are done */
+            PetscInt l = 0; const PetscInt r0 = nstart[u];
+            for (PetscInt q = bi[r0]; q < bi[r0 + 1]; q++) l = PetscMax(l, nlevL[nodeof[bj[q]]] + 1);
+            nlevL[u] = l; nlL = PetscMax(nlL, l + 1);
+          }
+          for (PetscInt u = nodes - 1; u >= 0; u--) {                /* upper: the columns of the node's LAST row */
+            PetscInt l = 0; const PetscInt rL = nstart[u + 1] - 1;
+            for (PetscInt q = 0; q < rlU[rL]; q++) l = PetscMax(l, nlevU[nodeof[bj[rpU[rL] + q]]] + 1);
+            nlevU[u] = l; nlU = PetscMax(nlU, l + 1);
+          }
+          by_level = set ? !strcmp(ord, "level") : 0;
+          rc = mi355x_trisolve_plan_create_nodes(dc->h, n, nodes, nstart, nlL, nlevL, bi, rlL, bj, ba, NULL, by_level, &f->tri_lo);
+          if (!rc) rc = mi355x_trisolve_plan_create_nodes(dc->h, n, nodes, nstart, nlU, nlevU, rpU, rlU, bj, ba, dinv, by_level, &f->tri_up);
+          if (rc) {   /* not the shape of an inode factor after all: row-granular plans below */
+            if (f->tri_lo) mi355x_trisolve_plan_destroy(f->tri_lo);
+            if (f->tri_up) mi355x_trisolve_plan_destroy(f->tri_up);
+            f->tri_lo = f->tri_up = NULL;
+          } else { f->nodes = nodes; f->nlevL_nodes = nlL; f->nlevU_nodes = nlU; f->by_level = by_level; }
+        }
+        HipFree(nstart); HipFree(nodeof); HipFree(nlevL); HipFree(nlevU);
+      }
+      if (rc) {
+        by_level = set ? !strcmp(ord, "level") : (nodes > 0);
+        f->by_level = by_level;
+        rc = mi355x_trisolve_plan_create_ordered(dc->h, n, f->nlevL, lev, bi, rlL, bj, ba, NULL, by_level, &f->tri_lo);
+        if (!rc) rc = mi355x_trisolve_plan_create_ordered(dc->h, n, f->nlevU, levU, rpU, rlU, bj, ba, dinv, by_level, &f->tri_up);
+      }
       HipFree(rpU); HipFree(rlU); HipFree(rlL); HipFree(dinv);
       if (rc) {   /* e.g. a factor too large for 32-bit sliced-ELL offsets: the level kernels serve */
         if (f->tri_lo) mi355x_trisolve_plan_destroy(f->tri_lo);
@@ -486,6 +526,15 @@ PetscErrorCode PCILUGetShiftCount_HIPMI355X(PC pc, PetscInt *nshift) {
   HipTriFactors *f;
   PetscErrorCode ierr = pc_factors(pc, MAT_FACTOR_ILU, &f);CHKERRQ(ierr);
   *nshift = f->nshift;
+  return 0;
+}
+/* node-blocked solves: the number of nodes the plans hold (0: row-granular) and the dependency levels over nodes */
+PetscErrorCode PCILUGetNodeInfo_HIPMI355X(PC pc, PetscInt *nodes, PetscInt *nlevL, PetscInt *nlevU) {
+  HipTriFactors *f;
+  PetscErrorCode ierr = pc_factors(pc, MAT_FACTOR_ILU, &f);CHKERRQ(ierr);
+  if (nodes) *nodes = f->nodes;
+  if (nlevL) *nlevL = f->nlevL_nodes;
+  if (nlevU) *nlevU = f->nlevU_nodes;
   return 0;
 }
 /* levels of the two triangular solves */

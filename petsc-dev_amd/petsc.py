@@ -52,7 +52,7 @@ _SIG = {
     "PetscMiniGenPoisson7": [i32, i32, i32, C.c_long, C.c_long, vp, vp, vp, P(C.c_long)],
     "PetscViewerBinaryOpen": [vp, C.c_char_p, i32, P(vp)], "PetscViewerDestroy": [P(vp)],
     "MatLoad": [vp, vp], "MatView": [vp, vp], "VecLoad": [vp, vp], "VecView": [vp, vp],
-    "PCSetType": [vp, C.c_char_p], "PCILUGetLevels_HIPMI355X": [vp, P(i32), P(i32)], "PCILUGetShiftCount_HIPMI355X": [vp, P(i32)], "PCICCGetInfo_HIPMI355X": [vp, P(i32), P(i32), P(i32)], "PCILUGetSolver_HIPMI355X": [vp, P(i32), P(i32)], "PCFactorDebugSetAborted_HIPMI355X": [vp], "PCFactorGetMatrix": [vp, P(vp)], "MatSolve": [vp, vp, vp], "PCBJacobiGetSubKSP": [vp, P(i32), P(i32), P(vp)],
+    "PCSetType": [vp, C.c_char_p], "PCILUGetLevels_HIPMI355X": [vp, P(i32), P(i32)], "PCILUGetShiftCount_HIPMI355X": [vp, P(i32)], "PCICCGetInfo_HIPMI355X": [vp, P(i32), P(i32), P(i32)], "PCILUGetSolver_HIPMI355X": [vp, P(i32), P(i32)], "PCFactorDebugSetAborted_HIPMI355X": [vp], "PCILUGetNodeInfo_HIPMI355X": [vp, P(i32), P(i32), P(i32)], "PCFactorGetMatrix": [vp, P(vp)], "MatSolve": [vp, vp, vp], "PCBJacobiGetSubKSP": [vp, P(i32), P(i32), P(vp)],
     "KSPCreate": [vp, P(vp)], "KSPSetType": [vp, C.c_char_p], "KSPSetOperators": [vp, vp, vp, i32], "KSPGetPC": [vp, P(vp)],
     "KSPSetTolerances": [vp, dbl, dbl, dbl, i32], "KSPSetNormType": [vp, i32], "KSPSetPCSide": [vp, i32], "KSPSetInitialGuessNonzero": [vp, i32], "KSPSetOptionsPrefix": [vp, C.c_char_p],
     "KSPSetFromOptions": [vp], "KSPGMRESSetRestart": [vp, i32], "KSPGMRESSetCGSRefinementType": [vp, i32],

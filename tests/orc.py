@@ -278,6 +278,16 @@ def ilu0_solve(f, b):
     return x
 
 
+def ilu0_solve_inode(f, ns, b):
+    """MatSolve_SeqAIJ_Inode: the triangular solves the reference runs on the factor of a matrix whose rows form nodes `ns`"""
+    bi, bj, bd, ba = f
+    ns = np.ascontiguousarray(ns, dtype=np.int32)
+    assert int(ns.sum()) == b.size
+    x = np.zeros(b.size)
+    lib().orc_ilu0_solve_inode(C.c_int(b.size), C.c_int(ns.size), I(ns), I(bi), I(bj), I(bd), D(ba), D(b), D(x))
+    return x
+
+
 def icc0_factor(ai, aj, aa):
     """(ui, uj, ua), number of positive-definite shifts the factorisation needed"""
     n = ai.size - 1

@@ -1191,31 +1191,90 @@ def test_ilu0_syncfree_solves_on_irregular_factors(P, shape):
     set_options(L, "")
     f = orc.ilu0_factor(ai, aj, aa)
     vb, vx = V(P, np.zeros(n)), V(P, np.zeros(n))
-    nodes = orc.check_inode(ai, aj)[0]
+    nodes, ns = orc.check_inode(ai, aj)
     for rep in range(3):
         b = rnd(n, 90 + rep)
         vb.set_array(b)
         L.raw("PCApply")(pc, vb.h, vx.h)
-        ref = orc.ilu0_solve(f, b)
-        if nodes:      # the reference solves such a factor with MatSolve_SeqAIJ_Inode, not the natural-ordering loop; rows are
-            assert np.linalg.norm(vx.array() - ref) <= 1e-13 * np.linalg.norm(ref)     # summed in dependency-level order here
-            first = vx.array().copy() if rep == 0 else first
-        else:
-            assert np.array_equal(bits(vx.array()), bits(ref))
+        # a factor with inodes: the reference solves it with MatSolve_SeqAIJ_Inode (node by node, two columns at a time), and so
+        # does the device (node-blocked plans); otherwise the natural-ordering loop
+        ref = orc.ilu0_solve_inode(f, ns, b) if nodes else orc.ilu0_solve(f, b)
+        assert np.array_equal(bits(vx.array()), bits(ref))
     sf, ab = C.c_int(), C.c_int()
     L.PCILUGetSolver_HIPMI355X(pc, C.byref(sf), C.byref(ab))
     assert sf.value == 1 and ab.value == 0
-    if nodes:          # column order on request: the natural-ordering loop's bits; and the level order is reproducible
-        k2 = P.KSP(comm=L.COMM_SELF); k2.set_operators(A); pc2 = C.c_void_p(); L.KSPGetPC(k2.h, C.byref(pc2)); L.PCSetType(pc2, b"ilu")
-        set_options(L, "-pc_factor_hipmi355x_trisolve syncfree -pc_factor_hipmi355x_trisolve_order column")
-        L.raw("PCSetUp")(pc2)
-        set_options(L, "")
-        b = rnd(n, 92); vb.set_array(b)
-        L.raw("PCApply")(pc2, vb.h, vx.h)
-        assert np.array_equal(bits(vx.array()), bits(orc.ilu0_solve(f, b)))
-        b = rnd(n, 90); vb.set_array(b)
+    nn, nlL, nlU = C.c_int(), C.c_int(), C.c_int()
+    L.PCILUGetNodeInfo_HIPMI355X(pc, C.byref(nn), C.byref(nlL), C.byref(nlU))
+    assert nn.value == nodes
+    if nodes:
+        rl, ru = C.c_int(), C.c_int(); L.PCILUGetLevels_HIPMI355X(pc, C.byref(rl), C.byref(ru))
+        assert 0 < nlL.value < rl.value and 0 < nlU.value < ru.value          # levels over nodes: fewer than over rows
+        # row-granular plans on request: column order = the natural-ordering loop's bits; level order agrees to rounding
+        for opts, exact in (("-pc_factor_hipmi355x_trisolve_nodes 0 -pc_factor_hipmi355x_trisolve_order column", True),
+                            ("-pc_factor_hipmi355x_trisolve_nodes 0", False), ("-pc_factor_hipmi355x_trisolve_order level", False)):
+            k2 = P.KSP(comm=L.COMM_SELF); k2.set_operators(A); pc2 = C.c_void_p(); L.KSPGetPC(k2.h, C.byref(pc2)); L.PCSetType(pc2, b"ilu")
+            set_options(L, "-pc_factor_hipmi355x_trisolve syncfree " + opts)
+            L.raw("PCSetUp")(pc2)
+            set_options(L, "")
+            b = rnd(n, 92); vb.set_array(b)
+            L.raw("PCApply")(pc2, vb.h, vx.h)
+            ref = orc.ilu0_solve(f, b)
+            if exact:
+                assert np.array_equal(bits(vx.array()), bits(ref))
+            else:
+                assert np.linalg.norm(vx.array() - ref) <= 1e-13 * np.linalg.norm(ref)
+                first = vx.array().copy()
+                L.raw("PCApply")(pc2, vb.h, vx.h)                                # deterministic
+                assert np.array_equal(bits(vx.array()), bits(first))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_ilu0_node_blocked_solves_carry_the_bits_of_the_inode_routine(P, seed):
+    """MatSolve_SeqAIJ_Inode on the device: factors of matrices whose rows form nodes of 1..5 rows (a random node graph, every node a
+    dense block of dofs: what a FEM matrix with a varying number of dofs per node looks like).  The node-blocked sync-free plans walk
+    a node's shared column list once, two columns at a time, then solve the node's triangle -- the reference routine's order (inode.c:
+    2327-2760), restated in the oracle: same bits, several applications; the level-by-level fall-back over the same plans too."""
+    import scipy.sparse as sp
+    L = P.lib()
+    rng = np.random.default_rng(300 + seed)
+    nn = int(rng.integers(40, 900))
+    maxdof = [3, 5, 2, 4, 5, 3][seed]
+    dof = rng.integers(1, maxdof + 1, nn) if seed % 2 else np.full(nn, maxdof)
+    G = sp.random(nn, nn, density=min(1.0, float(rng.uniform(2.0, 7.0)) / nn), random_state=int(rng.integers(1 << 30)), format="csr")
+    G = ((G + G.T + sp.diags([np.ones(nn - 1)], [1]) + sp.diags([np.ones(nn - 1)], [-1]) + sp.eye(nn)) != 0).tocsr()      # symmetric pattern, a path so that levels are deep
+    start = np.concatenate([[0], np.cumsum(dof)])
+    n = int(start[-1])
+    rows, cols = [], []
+    for u in range(nn):
+        nb = G.indices[G.indptr[u]:G.indptr[u + 1]]
+        cc = np.concatenate([np.arange(start[v], start[v + 1]) for v in sorted(nb)])
+        for r in range(start[u], start[u + 1]):
+            rows.append(np.full(cc.size, r)); cols.append(cc)
+    rows = np.concatenate(rows); cols = np.concatenate(cols)
+    vals = -rng.random(rows.size)
+    A_ = sp.csr_matrix((vals, (rows, cols)), shape=(n, n)); A_.sort_indices()
+    rs = np.asarray(abs(A_).sum(axis=1)).ravel()
+    A_ = (A_ + sp.diags(rs + 1.0)).tocsr(); A_.sort_indices()
+    ai, aj, aa = A_.indptr.astype(np.int32), A_.indices.astype(np.int32), A_.data.copy()
+    nodes, ns = orc.check_inode(ai, aj)
+    assert nodes > 0 and ns.max() <= 5
+    A = P.Mat.from_csr(ai, aj, aa)
+    pc = C.c_void_p()
+    k = P.KSP(comm=L.COMM_SELF); k.set_operators(A); L.KSPGetPC(k.h, C.byref(pc)); L.PCSetType(pc, b"ilu")
+    set_options(L, "-pc_factor_hipmi355x_trisolve syncfree")
+    L.raw("PCSetUp")(pc)
+    set_options(L, "")
+    got = C.c_int(); L.PCILUGetNodeInfo_HIPMI355X(pc, C.byref(got), None, None)
+    assert got.value == nodes
+    f = orc.ilu0_factor(ai, aj, aa)
+    vb, vx = V(P, np.zeros(n)), V(P, np.zeros(n))
+    for rep in range(3):
+        b = rnd(n, 500 + rep); vb.set_array(b)
         L.raw("PCApply")(pc, vb.h, vx.h)
-        assert np.array_equal(bits(vx.array()), bits(first))
+        assert np.array_equal(bits(vx.array()), bits(orc.ilu0_solve_inode(f, ns, b))), (seed, rep)
+    L.PCFactorDebugSetAborted_HIPMI355X(pc)          # the same plans, one launch per node level
+    L.raw("PCApply")(pc, vb.h, vx.h)
+    assert np.array_equal(bits(vx.array()), bits(orc.ilu0_solve_inode(f, ns, b)))
 
 
 @pytest.mark.parametrize("name,nblocks,err,nits", [("ex2_bjacobi_2.out", 2, "0.000496964", 4), ("ex2_bjacobi_3.out", 4, "0.000404746", 7)])
