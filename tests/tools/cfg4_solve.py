@@ -30,11 +30,14 @@ def main():
     A.mult(x, b)
     ksp = P.KSP(comm=L.COMM_SELF)
     ksp.set_operators(A); ksp.set_type("gmreshipmi355x")
+    extra = os.environ.get("CFG4_OPTS", "")   # e.g. "-pc_factor_hipmi355x_trisolve_order level" or "-pc_factor_hipmi355x_trisolve_nodes 0"
+    L.PetscOptionsClear()
     if sub == "ilu" and nblocks == 1:      # one rank: block Jacobi with one block and ILU(0) inside IS PCILU (the reference's default on one rank)
         ksp.set_pc_type("ilu")
+        L.PetscOptionsInsertString(extra.encode())
     else:
         ksp.set_pc_type("bjacobi")
-        L.PetscOptionsClear(); L.PetscOptionsInsertString(("-sub_pc_type %s -pc_bjacobi_blocks %d" % (sub, nblocks)).encode())
+        L.PetscOptionsInsertString(("-sub_pc_type %s -pc_bjacobi_blocks %d %s" % (sub, nblocks, extra)).encode())
     ksp.set_from_options()
     ksp.set_tolerances(rtol=0.0, abstol=1e-300, dtol=1e300, max_it=35)
     t0 = time.time()
@@ -44,6 +47,8 @@ def main():
     if sub == "ilu" and nblocks == 1:
         pc = C.c_void_p(); L.KSPGetPC(ksp.h, C.byref(pc))
         nl, nu = C.c_int(), C.c_int(); L.PCILUGetLevels_HIPMI355X(pc, C.byref(nl), C.byref(nu))
+        nn, nnl, nnu = C.c_int(), C.c_int(), C.c_int(); L.PCILUGetNodeInfo_HIPMI355X(pc, C.byref(nn), C.byref(nnl), C.byref(nnu))
+        print("ILU(0) plans: %s" % ("node-blocked, %d nodes, node levels L=%d U=%d" % (nn.value, nnl.value, nnu.value) if nn.value else "row-granular"), flush=True)
         for _ in range(3):
             L.raw("PCApply")(pc, b.h, u.h)
         k.mi355x_device_synchronize()
