@@ -238,6 +238,13 @@ __global__ __launch_bounds__(MI355X_BLOCK) void trisolve_syncfree_kernel(
 // node row after row -- bit for bit MatSolve_SeqAIJ_Inode while the columns are stored in column order (by_level = 0).
 // The index / value loads of the NEXT batch of columns are issued before the current batch's polls: they do not depend on any
 // solution value, and behind the polls they would add a memory round trip per batch to the dependency chain.
+#ifdef MI355X_TRI_TRACE
+// trace build: lane 0 of every wavefront leaves eight timestamps per slice: start, after each of the first five batches, last
+// dependency consumed, results stored
+#define TRI_NSTAMP(k) do { if (POLL && tri_trace_buf && lane == 0) tri_trace_buf[(UPPER ? 8000000L : 0L) + (long)(t / MI355X_WAVE) * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define TRI_NSTAMP(k) do { } while (0)
+#endif
 template <int NB, bool UPPER, bool POLL>
 __device__ __forceinline__ void tri_node_solve(const int t, const int lane, const int np, const int base, const int ncol, const int row0, const int nsz,
                                                const int *__restrict__ col, const double *__restrict__ val, const double *__restrict__ din,
@@ -259,6 +266,11 @@ __device__ __forceinline__ void tri_node_solve(const int t, const int lane, cons
   }
   const double *vbase = val + (size_t)base * NB + lane;
   const int *cbase = col + base + lane;
+  TRI_NSTAMP(0);
+  // the node's own triangle (and inverted diagonals): requested now, needed after the last dependency has arrived
+  double dn[NT + (UPPER ? NB : 0) + 1];
+#pragma unroll
+  for (int e = 0; e < NT + (UPPER ? NB : 0); ++e) dn[e] = din[(size_t)e * np + t];
   int cA[B]; double aA[B * NB];
 #pragma unroll
   for (int j = 0; j < B; ++j) {
@@ -268,29 +280,40 @@ __device__ __forceinline__ void tri_node_solve(const int t, const int lane, cons
     for (int k = 0; k < NB; ++k) aA[j * NB + k] = ncol > 0 ? vbase[(size_t)(qq * NB + k) * MI355X_WAVE] : 0.0;
   }
   for (int q0 = 0; q0 < ncol; q0 += B) {
-    int cN[B]; double aN[B * NB];
-    const bool more = q0 + B < ncol;
-#pragma unroll
-    for (int j = 0; j < B; ++j) {              // the next batch's indices and values: in flight while this batch waits for its dependencies
-      const int qq = (q0 + B + j < ncol) ? q0 + B + j : q0;
-      cN[j] = more ? cbase[qq * MI355X_WAVE] : 0;
-#pragma unroll
-      for (int k = 0; k < NB; ++k) aN[j * NB + k] = more ? vbase[(size_t)(qq * NB + k) * MI355X_WAVE] : 0.0;
-    }
     double v[B];
 #pragma unroll
     for (int j = 0; j < B; ++j) {
       v[j] = 0.0;
       if (q0 + j < ncol) v[j] = POLL ? __hip_atomic_load(w + cA[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : w[cA[j]];
     }
+    // the next batch's indices and values go out BEHIND this batch's gathers (loads return in issue order: the gathers must not
+    // queue behind a round trip to HBM) and are in flight while this batch waits for its dependencies
+    int cN[B]; double aN[B * NB];
+    const bool more = q0 + B < ncol;
+#pragma unroll
+    for (int j = 0; j < B; ++j) {
+      const int qq = (q0 + B + j < ncol) ? q0 + B + j : q0;
+      cN[j] = more ? cbase[qq * MI355X_WAVE] : 0;
+#pragma unroll
+      for (int k = 0; k < NB; ++k) aN[j * NB + k] = more ? vbase[(size_t)(qq * NB + k) * MI355X_WAVE] : 0.0;
+    }
+    // A value that was not there yet is polled for; when it arrives, the batch's other pending values are requested again
+    // TOGETHER (one round trip): the rows of a node are stored by one lane at one time, and a poll per value would put a
+    // memory round trip per value on the dependency chain
+#define TRI_REFRESH(from)                                                                                              \
+  do {                                                                                                                 \
+    _Pragma("unroll") for (int jj = (from); jj < B; ++jj)                                                              \
+      if (q0 + jj < ncol && __double_as_longlong(v[jj]) == (long long)TRI_SENTINEL)                                    \
+        v[jj] = __hip_atomic_load(w + cA[jj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                             \
+  } while (0)
 #pragma unroll
     for (int j = 0; j < B; j += 2) {
       if (q0 + j < ncol) {
         double x0 = v[j];
-        if (POLL && __double_as_longlong(x0) == (long long)TRI_SENTINEL) x0 = tri_poll(w + cA[j], abort_flag, sleep_cap);
+        if (POLL && __double_as_longlong(x0) == (long long)TRI_SENTINEL) { x0 = tri_poll(w + cA[j], abort_flag, sleep_cap); TRI_REFRESH(j + 1); }
         if (q0 + j + 1 < ncol) {
           double x1 = v[j + 1];
-          if (POLL && __double_as_longlong(x1) == (long long)TRI_SENTINEL) x1 = tri_poll(w + cA[j + 1], abort_flag, sleep_cap);
+          if (POLL && __double_as_longlong(x1) == (long long)TRI_SENTINEL) { x1 = tri_poll(w + cA[j + 1], abort_flag, sleep_cap); TRI_REFRESH(j + 2); }
 #pragma unroll
           for (int k = 0; k < NB; ++k) sum[k] -= aA[j * NB + k] * x0 + aA[(j + 1) * NB + k] * x1;
         } else {
@@ -299,20 +322,23 @@ __device__ __forceinline__ void tri_node_solve(const int t, const int lane, cons
         }
       }
     }
+#undef TRI_REFRESH
 #pragma unroll
     for (int j = 0; j < B; ++j) {
       cA[j] = cN[j];
 #pragma unroll
       for (int k = 0; k < NB; ++k) aA[j * NB + k] = aN[j * NB + k];
     }
+    if (q0 / B < 5) TRI_NSTAMP(1 + q0 / B);
   }
+  TRI_NSTAMP(6);
   // the couplings inside the node
   if (!UPPER) {
 #pragma unroll
     for (int k = 1; k < NB; ++k) {
       if (k < nsz) {
 #pragma unroll
-        for (int l = 0; l < k; ++l) sum[k] -= din[(size_t)(k * (k - 1) / 2 + l) * np + t] * sum[l];
+        for (int l = 0; l < k; ++l) sum[k] -= dn[k * (k - 1) / 2 + l] * sum[l];
       }
     }
 #pragma unroll
@@ -328,8 +354,8 @@ __device__ __forceinline__ void tri_node_solve(const int t, const int lane, cons
       xr[k] = 0.0;
       if (k < nsz) {
 #pragma unroll
-        for (int l = 0; l < k; ++l) sum[k] -= din[(size_t)(k * (k - 1) / 2 + (k - 1 - l)) * np + t] * xr[l];   // nearest row last (inode.c:2604-2610)
-        xr[k] = sum[k] * din[(size_t)(NT + k) * np + t];
+        for (int l = 0; l < k; ++l) sum[k] -= dn[k * (k - 1) / 2 + (k - 1 - l)] * xr[l];   // nearest row last (inode.c:2604-2610)
+        xr[k] = sum[k] * dn[NT + k];
         const int kk = nsz - 1 - k;            // the row's slot counts from the node's FIRST row
         if (POLL) __hip_atomic_store(w + (size_t)kk * np + t, xr[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else w[(size_t)kk * np + t] = xr[k];
@@ -337,6 +363,7 @@ __device__ __forceinline__ void tri_node_solve(const int t, const int lane, cons
       }
     }
   }
+  TRI_NSTAMP(7);
 }
 
 template <int NB, bool UPPER>
