@@ -250,7 +250,13 @@ __device__ __forceinline__ void tri_node_solve(const int t, const int lane, cons
                                                const int *__restrict__ col, const double *__restrict__ val, const double *__restrict__ din,
                                                const double *src, const int *__restrict__ spos, double *w, double *y, double *reset,
                                                int *abort_flag, const int sleep_cap) {
-  constexpr int B = NB <= 3 ? 8 : 4;           // columns per batch (registers: 2 batches x (1 + NB) words per column)
+#ifndef TRI_NODE_B
+#define TRI_NODE_B 8
+#endif
+#ifndef TRI_NODE_ALIGN_END
+#define TRI_NODE_ALIGN_END 0       // measured on the FEM stand-in (profiles/r03_tri_variants.log): end-aligned batches 40 / 71 ms against 29 / 48
+#endif
+  constexpr int B = NB <= 3 ? TRI_NODE_B : 4;  // columns per batch (registers: 2 batches x (1 + NB) words per column)
   constexpr int NT = NB * (NB - 1) / 2;
   double sum[NB];
 #pragma unroll
@@ -271,20 +277,24 @@ __device__ __forceinline__ void tri_node_solve(const int t, const int lane, cons
   double dn[NT + (UPPER ? NB : 0) + 1];
 #pragma unroll
   for (int e = 0; e < NT + (UPPER ? NB : 0); ++e) dn[e] = din[(size_t)e * np + t];
+  // TRI_NODE_ALIGN_END (development variant, off): batches aligned to the END of the column list -- the first batch is the short one,
+  // the last batch holds the B newest columns; the offset is even, so that the pairs (0,1), (2,3), ... of the reference's summation
+  // stay pairs.
+  const int qstart = TRI_NODE_ALIGN_END ? -(((B - ncol % B) % B) & ~1) : 0;
   int cA[B]; double aA[B * NB];
 #pragma unroll
   for (int j = 0; j < B; ++j) {
-    const int qq = j < ncol ? j : 0;
+    const int q = qstart + j, qq = (q >= 0 && q < ncol) ? q : 0;
     cA[j] = ncol > 0 ? cbase[qq * MI355X_WAVE] : 0;
 #pragma unroll
     for (int k = 0; k < NB; ++k) aA[j * NB + k] = ncol > 0 ? vbase[(size_t)(qq * NB + k) * MI355X_WAVE] : 0.0;
   }
-  for (int q0 = 0; q0 < ncol; q0 += B) {
+  for (int q0 = qstart; q0 < ncol; q0 += B) {
     double v[B];
 #pragma unroll
     for (int j = 0; j < B; ++j) {
       v[j] = 0.0;
-      if (q0 + j < ncol) v[j] = POLL ? __hip_atomic_load(w + cA[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : w[cA[j]];
+      if (q0 + j >= 0 && q0 + j < ncol) v[j] = POLL ? __hip_atomic_load(w + cA[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : w[cA[j]];
     }
     // the next batch's indices and values go out BEHIND this batch's gathers (loads return in issue order: the gathers must not
     // queue behind a round trip to HBM) and are in flight while this batch waits for its dependencies
@@ -292,7 +302,7 @@ __device__ __forceinline__ void tri_node_solve(const int t, const int lane, cons
     const bool more = q0 + B < ncol;
 #pragma unroll
     for (int j = 0; j < B; ++j) {
-      const int qq = (q0 + B + j < ncol) ? q0 + B + j : q0;
+      const int qn = q0 + B + j, qq = (qn >= 0 && qn < ncol) ? qn : 0;      // (an index outside the list re-reads entry 0: never out of bounds)
       cN[j] = more ? cbase[qq * MI355X_WAVE] : 0;
 #pragma unroll
       for (int k = 0; k < NB; ++k) aN[j * NB + k] = more ? vbase[(size_t)(qq * NB + k) * MI355X_WAVE] : 0.0;
@@ -303,12 +313,12 @@ __device__ __forceinline__ void tri_node_solve(const int t, const int lane, cons
 #define TRI_REFRESH(from)                                                                                              \
   do {                                                                                                                 \
     _Pragma("unroll") for (int jj = (from); jj < B; ++jj)                                                              \
-      if (q0 + jj < ncol && __double_as_longlong(v[jj]) == (long long)TRI_SENTINEL)                                    \
+      if (q0 + jj >= 0 && q0 + jj < ncol && __double_as_longlong(v[jj]) == (long long)TRI_SENTINEL)                    \
         v[jj] = __hip_atomic_load(w + cA[jj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                             \
   } while (0)
 #pragma unroll
     for (int j = 0; j < B; j += 2) {
-      if (q0 + j < ncol) {
+      if (q0 + j >= 0 && q0 + j < ncol) {
         double x0 = v[j];
         if (POLL && __double_as_longlong(x0) == (long long)TRI_SENTINEL) { x0 = tri_poll(w + cA[j], abort_flag, sleep_cap); TRI_REFRESH(j + 1); }
         if (q0 + j + 1 < ncol) {
@@ -329,7 +339,7 @@ __device__ __forceinline__ void tri_node_solve(const int t, const int lane, cons
 #pragma unroll
       for (int k = 0; k < NB; ++k) aA[j * NB + k] = aN[j * NB + k];
     }
-    if (q0 / B < 5) TRI_NSTAMP(1 + q0 / B);
+    if ((q0 - qstart) / B < 5) TRI_NSTAMP(1 + (q0 - qstart) / B);
   }
   TRI_NSTAMP(6);
   // the couplings inside the node

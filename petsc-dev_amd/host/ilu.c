@@ -287,9 +287,10 @@ static PetscErrorCode ilu0_analyse_and_upload(Mat F, Mat A) {
       if (nodes > 0 && !(nset && (!strcmp(nodeopt, "0") || !strcmp(nodeopt, "false")))) {
         /* The factor of a matrix with inodes: the reference solves it node by node (MatSolve_SeqAIJ_Inode, inode.c:2327-2760;
          * MatLUFactorNumeric_SeqAIJ_Inode installs it), and so does the device: one lane per NODE, dependency levels over nodes
-         * (a node's rows were consecutive levels of the row-granular analysis), the shared column list walked once per node in
-         * the reference routine's order -- column order, two columns at a time: its bits -- or, with
-         * -pc_factor_hipmi355x_trisolve_order level, oldest dependency first (agreement to rounding).
+         * (a node's rows were consecutive levels of the row-granular analysis), the shared column list walked once per node, two
+         * columns at a time as the reference routine does.  -pc_factor_hipmi355x_trisolve_order column: in column order -- the
+         * reference routine's bits; level (the default for such factors, as for the row-granular plans): oldest dependency
+         * first -- agreement to rounding, 1.6x faster on the FEM stand-in (profiles/r03_ilu_fem_nodes.log).
          * -pc_factor_hipmi355x_trisolve_nodes 0 keeps the row-granular plans. */
         PetscInt *nstart, *nodeof, *nlevL, *nlevU, nlL = 0, nlU = 0;
         ierr = PetscMalloc(sizeof(PetscInt) * (size_t)(nodes + 1), &nstart);CHKERRQ(ierr);
@@ -309,7 +310,7 @@ static PetscErrorCode ilu0_analyse_and_upload(Mat F, Mat A) {
             for (PetscInt q = 0; q < rlU[rL]; q++) l = PetscMax(l, nlevU[nodeof[bj[rpU[rL] + q]]] + 1);
             nlevU[u] = l; nlU = PetscMax(nlU, l + 1);
           }
-          by_level = set ? !strcmp(ord, "level") : 0;
+          by_level = set ? !strcmp(ord, "level") : 1;
           rc = mi355x_trisolve_plan_create_nodes(dc->h, n, nodes, nstart, nlL, nlevL, bi, rlL, bj, ba, NULL, by_level, &f->tri_lo);
           if (!rc) rc = mi355x_trisolve_plan_create_nodes(dc->h, n, nodes, nstart, nlU, nlevU, rpU, rlU, bj, ba, dinv, by_level, &f->tri_up);
           if (rc) {   /* not the shape of an inode factor after all: row-granular plans below */

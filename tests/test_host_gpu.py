@@ -1197,9 +1197,13 @@ def test_ilu0_syncfree_solves_on_irregular_factors(P, shape):
         vb.set_array(b)
         L.raw("PCApply")(pc, vb.h, vx.h)
         # a factor with inodes: the reference solves it with MatSolve_SeqAIJ_Inode (node by node, two columns at a time), and so
-        # does the device (node-blocked plans); otherwise the natural-ordering loop
-        ref = orc.ilu0_solve_inode(f, ns, b) if nodes else orc.ilu0_solve(f, b)
-        assert np.array_equal(bits(vx.array()), bits(ref))
+        # does the device (node-blocked plans) -- by default with every node's columns in dependency-level order (rounding apart),
+        # in the routine's own order on request (below); otherwise the natural-ordering loop, bit for bit
+        if nodes:
+            ref = orc.ilu0_solve_inode(f, ns, b)
+            assert np.linalg.norm(vx.array() - ref) <= 1e-13 * np.linalg.norm(ref)
+        else:
+            assert np.array_equal(bits(vx.array()), bits(orc.ilu0_solve(f, b)))
     sf, ab = C.c_int(), C.c_int()
     L.PCILUGetSolver_HIPMI355X(pc, C.byref(sf), C.byref(ab))
     assert sf.value == 1 and ab.value == 0
@@ -1210,7 +1214,8 @@ def test_ilu0_syncfree_solves_on_irregular_factors(P, shape):
         rl, ru = C.c_int(), C.c_int(); L.PCILUGetLevels_HIPMI355X(pc, C.byref(rl), C.byref(ru))
         assert 0 < nlL.value < rl.value and 0 < nlU.value < ru.value          # levels over nodes: fewer than over rows
         # row-granular plans on request: column order = the natural-ordering loop's bits; level order agrees to rounding
-        for opts, exact in (("-pc_factor_hipmi355x_trisolve_nodes 0 -pc_factor_hipmi355x_trisolve_order column", True),
+        for opts, exact in (("-pc_factor_hipmi355x_trisolve_nodes 0 -pc_factor_hipmi355x_trisolve_order column", "natural"),
+                            ("-pc_factor_hipmi355x_trisolve_order column", "inode"),
                             ("-pc_factor_hipmi355x_trisolve_nodes 0", False), ("-pc_factor_hipmi355x_trisolve_order level", False)):
             k2 = P.KSP(comm=L.COMM_SELF); k2.set_operators(A); pc2 = C.c_void_p(); L.KSPGetPC(k2.h, C.byref(pc2)); L.PCSetType(pc2, b"ilu")
             set_options(L, "-pc_factor_hipmi355x_trisolve syncfree " + opts)
@@ -1218,7 +1223,7 @@ def test_ilu0_syncfree_solves_on_irregular_factors(P, shape):
             set_options(L, "")
             b = rnd(n, 92); vb.set_array(b)
             L.raw("PCApply")(pc2, vb.h, vx.h)
-            ref = orc.ilu0_solve(f, b)
+            ref = orc.ilu0_solve_inode(f, ns, b) if exact == "inode" else orc.ilu0_solve(f, b)
             if exact:
                 assert np.array_equal(bits(vx.array()), bits(ref))
             else:
@@ -1261,7 +1266,7 @@ def test_ilu0_node_blocked_solves_carry_the_bits_of_the_inode_routine(P, seed):
     A = P.Mat.from_csr(ai, aj, aa)
     pc = C.c_void_p()
     k = P.KSP(comm=L.COMM_SELF); k.set_operators(A); L.KSPGetPC(k.h, C.byref(pc)); L.PCSetType(pc, b"ilu")
-    set_options(L, "-pc_factor_hipmi355x_trisolve syncfree")
+    set_options(L, "-pc_factor_hipmi355x_trisolve syncfree -pc_factor_hipmi355x_trisolve_order column")
     L.raw("PCSetUp")(pc)
     set_options(L, "")
     got = C.c_int(); L.PCILUGetNodeInfo_HIPMI355X(pc, C.byref(got), None, None)

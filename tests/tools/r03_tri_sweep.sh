@@ -1,3 +1,4 @@
-FEM_OPTS="-pc_factor_hipmi355x_trisolve_order level" python tests/tools/fem_ilu_apply.py 2>&1 | tail -1
-FEM_OPTS="" python tests/tools/fem_ilu_apply.py 2>&1 | tail -1
-bash petsc-dev_amd/csrc/variants/build_tri_trace.sh && MI355X_KERNELS_LIB=$PWD/petsc-dev_amd/csrc/variants/libmi355x_kernels_tritrace.so python tests/tools/tri_trace_nodes.py 2>&1 | head -12
+set -e
+python -m pytest tests/test_host_gpu.py -m gpu -x -q -k "ilu0 or node_blocked or gave_up" 2>&1 | tail -3
+V=petsc-dev_amd/csrc/variants
+for o in "-pc_factor_hipmi355x_trisolve_order level" ""; do FEM_OPTS="$o" python tests/tools/fem_ilu_apply.py 2>&1 | tail -1; done
