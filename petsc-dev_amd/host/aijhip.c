@@ -155,16 +155,24 @@ static PetscErrorCode device_free(Mat A) {
   if (d->t_j) mi355x_free(d->t_j);
   if (d->t_a) mi355x_free(d->t_a);
   if (d->t_plan) mi355x_spmv_plan_destroy(d->t_plan);
+  if (d->t_perm) mi355x_free(d->t_perm);
   if (d->bm_order) mi355x_free(d->bm_order);
   if (d->bm_segptr) mi355x_free(d->bm_segptr);
   if (d->bm_segslot) mi355x_free(d->bm_segslot);
   if (d->bm_v) mi355x_free(d->bm_v);
-  const PetscInt nup = d->n_uploads;
+  const PetscInt nup = d->n_uploads, tb = d->t_builds, tr = d->t_refreshes;
+#if !defined(PETSCHIPMI355X_WITH_PETSC)
+  HipTriFactors *tri = d->tri;
+#endif
   const PetscBool cprow = d->cprow, timing = d->timing;
   const PetscInt tn = d->time_n, tcap = d->time_cap; mi355x_event_t *tev = d->time_ev;
   memset(d, 0, sizeof(*d));
   d->uploaded_state = -1; d->t_state = -1; d->pattern_nz = -1;
   d->n_uploads = nup; d->cprow = cprow;   /* a count and a request: they outlive the arrays */
+  d->t_builds = tb; d->t_refreshes = tr;
+#if !defined(PETSCHIPMI355X_WITH_PETSC)
+  d->tri = tri;
+#endif
   d->timing = timing; d->time_n = tn; d->time_cap = tcap; d->time_ev = tev;
   return 0;
 }
@@ -277,19 +285,34 @@ static PetscErrorCode upload_transpose(Mat A) {
   PetscDeviceCtx *dc;
   if (d->t_state == HipObjState(A) && d->t_a) return 0;
   ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
+  if (d->t_a && d->t_perm && d->t_pattern_nz == a->nz && d->pattern_nz == a->nz) {
+    /* only the VALUES changed since the transpose was built (a time step, a Newton iteration, MatScale / MatDiagonalScale /
+     * MatSetValuesBatch on the device copy): A^T's values are the matrix's values in another order, and that order -- the
+     * permutation of the counting sort below -- is on the device.  One gather kernel over the current device values; nothing
+     * is rebuilt on the host, nothing crosses PCIe beyond what MatSeqAIJHIPUpload needs for the matrix itself. */
+    ierr = MatSeqAIJHIPUpload(A);CHKERRQ(ierr);
+    CHKHIP(mi355x_pack(dc->h, (size_t)a->nz, d->t_perm, d->d_a, d->t_a));
+    d->t_state = HipObjState(A);
+    d->t_refreshes++;
+    return 0;
+  }
   PetscInt m = a->m, n = a->n, nz = a->nz;
-  PetscInt *ti, *tj, *next; PetscScalar *ta;
+  PetscInt *ti, *tj, *next, *perm; PetscScalar *ta;
   ierr = PetscMalloc(sizeof(PetscInt) * (size_t)(n + 1), &ti);CHKERRQ(ierr);
   ierr = PetscMalloc(sizeof(PetscInt) * (size_t)PetscMax(nz, 1), &tj);CHKERRQ(ierr);
   ierr = PetscMalloc(sizeof(PetscScalar) * (size_t)PetscMax(nz, 1), &ta);CHKERRQ(ierr);
   ierr = PetscMalloc(sizeof(PetscInt) * (size_t)PetscMax(n, 1), &next);CHKERRQ(ierr);
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)PetscMax(nz, 1), &perm);CHKERRQ(ierr);
   memset(ti, 0, sizeof(PetscInt) * (size_t)(n + 1));
   for (PetscInt k = 0; k < nz; k++) ti[a->j[k] + 1]++;
   for (PetscInt c = 0; c < n; c++) ti[c + 1] += ti[c];
   for (PetscInt c = 0; c < n; c++) next[c] = ti[c];
   for (PetscInt r = 0; r < m; r++)
-    for (PetscInt k = a->i[r]; k < a->i[r + 1]; k++) { PetscInt p = next[a->j[k]]++; tj[p] = r; ta[p] = a->a[k]; }
+    for (PetscInt k = a->i[r]; k < a->i[r + 1]; k++) { PetscInt p = next[a->j[k]]++; tj[p] = r; ta[p] = a->a[k]; perm[p] = k; }
   if (d->t_i) { mi355x_free(d->t_i); mi355x_free(d->t_j); mi355x_free(d->t_a); mi355x_spmv_plan_destroy(d->t_plan); d->t_plan = NULL; }
+  if (d->t_perm) { mi355x_free(d->t_perm); d->t_perm = NULL; }
+  CHKHIP(mi355x_malloc((void **)&d->t_perm, sizeof(PetscInt) * (size_t)PetscMax(nz, 1)));
+  CHKHIP(mi355x_memcpy_h2d(dc->h, d->t_perm, perm, sizeof(PetscInt) * (size_t)nz));
   CHKHIP(mi355x_malloc((void **)&d->t_i, sizeof(PetscInt) * (size_t)(n + 1)));
   CHKHIP(mi355x_malloc((void **)&d->t_j, sizeof(PetscInt) * (size_t)PetscMax(nz, 1) + 16));
   CHKHIP(mi355x_malloc((void **)&d->t_a, sizeof(PetscScalar) * (size_t)PetscMax(nz, 1) + 16));
@@ -307,8 +330,10 @@ static PetscErrorCode upload_transpose(Mat A) {
     }
   }
   CHKHIP(mi355x_handle_synchronize(dc->h));
-  HipFree(ti); HipFree(tj); HipFree(ta); HipFree(next);
+  HipFree(ti); HipFree(tj); HipFree(ta); HipFree(next); HipFree(perm);
   d->t_state = HipObjState(A);
+  d->t_pattern_nz = nz;
+  d->t_builds++;
   return 0;
 }
 
@@ -559,6 +584,15 @@ PetscErrorCode MatHIPMI355XSetValuePatterns(Mat A, PetscBool on) {
 
 /* row grouping of the SpMV plan: number of nodes Mat_CheckInode found (0: plain routines), groups the device plan stores
  * one column list for (0: the plan streams per-nonzero indices), and the shared indices stored */
+/* host builds of the explicit transpose / device-side value refreshes of it so far (tests: a time-stepping caller of
+ * MatMultTranspose must not go back to the host for A^T) */
+PetscErrorCode MatHIPMI355XGetTransposeCounts(Mat A, PetscInt *builds, PetscInt *refreshes) {
+  if (!A || A->ops->mult != MatMult_SeqAIJHIP) SETERRQ(HipObjComm(A), PETSC_ERR_ARG_WRONG, "not a sequential HIPMI355X AIJ matrix");
+  if (builds) *builds = SD(A)->t_builds;
+  if (refreshes) *refreshes = SD(A)->t_refreshes;
+  return 0;
+}
+
 /* the nodes Mat_CheckInode finds (consecutive rows with identical column lists): count and sizes, NULL / 0 when the matrix keeps the
  * plain routines.  For the factorisations (host/ilu.c): the reference solves the factor of such a matrix node by node */
 PetscErrorCode MatSeqAIJHIPGetInodes(Mat A, PetscInt *count, const PetscInt **sizes) {

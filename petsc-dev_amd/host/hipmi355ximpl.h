@@ -173,6 +173,8 @@ typedef struct {
   PetscInt pattern_nz;        /* nz of the pattern the mirror was built for (-1: none) */
   /* cached explicit transpose for MatMultTranspose */
   PetscInt *t_i, *t_j; PetscScalar *t_a; mi355x_spmv_plan_t t_plan; int t_state;
+  PetscInt *t_perm, t_pattern_nz;   /* device: position in A^T -> position in A (values follow by one gather when only values change) */
+  PetscInt t_builds, t_refreshes;   /* host builds / device refreshes so far */
   PetscInt n_uploads;        /* value uploads so far */
   /* MatSetValuesBatch map for one connectivity (rows array): contributions grouped by nonzero, in call order */
   PetscInt bm_nb, bm_bs, bm_nseg; unsigned long long bm_hash; size_t bm_T, bm_vcap;

@@ -1732,6 +1732,57 @@ def test_time_step_loop_with_device_side_value_updates(P, pc):
         assert g[1:] == r_[1:] and g[2] == 2 and np.array_equal(g[0], r_[0])
 
 
+def test_time_step_loop_with_a_transpose_product_stays_on_the_device(P):
+    """MatMultTranspose in a time-step loop (aij.c:1078-1135): the explicit A^T behind it is built ONCE on the host; when only the
+    values change -- on the device (MatScale, MatDiagonalScale, MatZeroEntries + MatSetValuesBatch) or by a same-pattern
+    re-assembly from the host -- its values are refreshed by one gather over the device copy through the permutation kept
+    from the build.  Every step: the bits of the oracle's transpose product on the current values; host builds stay at 1, and the
+    device-side updates cause no upload of the matrix either."""
+    L = P.lib()
+    ai, aj, aa = orc.gen_p7(11, 9, 7)
+    aa = aa * (1.0 + 0.3 * np.sin(np.arange(aa.size)))                 # nonsymmetric values: A^T x != A x
+    n = ai.size - 1
+    A = P.Mat.from_csr(ai, aj, aa)
+    x = np.cos(0.21 * np.arange(n)); vx, vy, vz = V(P, x), V(P, np.zeros(n)), V(P, np.sin(0.1 * np.arange(n)))
+    cur = aa.copy()
+
+    def check():
+        L.MatMultTranspose(A.h, vx.h, vy.h)
+        assert np.array_equal(bits(vy.array()), bits(orc.spmv_t(ai, aj, cur, x, n)))
+        L.MatMultTransposeAdd(A.h, vx.h, vz.h, vy.h)
+        assert np.array_equal(bits(vy.array()), bits(orc.spmv_t_add(ai, aj, cur, x, vz.array(), n)))
+
+    def counts():
+        b_, r_, u_ = C.c_int(), C.c_int(), C.c_int()
+        L.MatHIPMI355XGetTransposeCounts(A.h, C.byref(b_), C.byref(r_)); L.MatHIPMI355XGetUploadCount(A.h, C.byref(u_))
+        return b_.value, r_.value, u_.value
+
+    check()
+    assert counts()[:2] == (1, 0)
+    up0 = counts()[2]
+    rows = np.repeat(np.arange(n), np.diff(ai))
+    dl = 1.0 + 0.4 * np.cos(np.arange(n)); dr = 2.0 - 0.3 * np.sin(0.5 * np.arange(n))
+    vl, vr = V(P, dl), V(P, dr)
+    for step in range(4):
+        if step % 2 == 0:
+            L.MatScale(A.h, 1.25 + step); cur = (1.25 + step) * cur                                   # device copy scaled in place
+        else:
+            L.MatDiagonalScale(A.h, vl.h, vr.h); cur = (cur * dl[rows]) * dr[aj]                       # (a l) r, aij.c:2055-2092
+        check()
+        assert counts() == (1, step + 1, up0)                          # no host rebuild of A^T, no upload of the matrix
+    # a same-pattern re-assembly from the host: one upload of the VALUES, A^T follows on the device
+    new = aa * (2.0 + np.cos(np.arange(aa.size)))
+    L.MatZeroEntries(A.h)
+    for r in range(n):
+        cols = aj[ai[r]:ai[r + 1]].copy(); vals = new[ai[r]:ai[r + 1]].copy(); rr = np.array([r], dtype=np.int32)
+        L.MatSetValues(A.h, 1, rr.ctypes.data_as(C.c_void_p), cols.size, cols.ctypes.data_as(C.c_void_p), vals.ctypes.data_as(C.c_void_p), 2)
+    L.MatAssemblyBegin(A.h, 0); L.MatAssemblyEnd(A.h, 0)
+    cur = new.copy()
+    check()
+    b_, r_, u_ = counts()
+    assert (b_, r_) == (1, 5) and u_ == up0 + 1
+
+
 def test_pattern_change_after_device_use(P):
     """new nonzeros inserted after the matrix has been used on the device (and after a device-side batch assembly has
     cached its map): plan, index dictionary, transpose cache and batch map are rebuilt; MatMult / MatMultTranspose equal
