@@ -239,6 +239,10 @@ int mi355x_spmv_bsr(mi355x_handle_t h, int mbs, int bs, const int *ai, const int
  * (it then partitions by VALUES); aligned 16-byte loads need aa 16-byte aligned */
 int mi355x_spmv_bsr_planned(mi355x_handle_t h, mi355x_spmv_plan_t plan, int bs, const int *ai, const int *aj,
                             const double *aa, const double *x, double *y);
+/* the same product with the row-block kernel's form chosen by the caller (development / A-B runs): x_in_lds != 0 stages the x
+ * entries of the row block's block columns in LDS once per block instead of gathering them once per value */
+int mi355x_spmv_bsr_planned_form(mi355x_handle_t h, mi355x_spmv_plan_t plan, int bs, int x_in_lds, const int *ai, const int *aj,
+                                 const double *aa, const double *x, double *y);
 
 /* bs = 4 on the matrix cores (v_mfma_f64_4x4x4_4b_f64 as a fused multiply + 4-lane reduction; BASELINE configs[4]); one
  * wavefront per block row, no analysis.  variant 0: 16-byte loads (8 blocks per step), 1: 8-byte loads (4 per step).

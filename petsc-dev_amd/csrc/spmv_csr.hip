@@ -690,13 +690,20 @@ __global__ __launch_bounds__(SPMV_THREADS, SPMV_MINWAVES) void spmv_csr_rowblock
 // looks the block column up once per value (e / bs^2), multiplies by x[col*bs + c] and parks the
 // products in LDS; point row (br, r) then owns the LDS entries s + bs*j + r, j < nblocks*bs
 // (blocks are column-major, baij.h:13-30) and is summed by 1..64 lanes + a shuffle tree.
-template <int BS>
+// XLDS: the x entries of the row block's block columns are staged in LDS ONCE per block (bs doubles per stored block, requested
+// together with the value stream, before the barrier) and the products read them from there: bs^2 values share bs staged entries,
+// so the global gathers drop from one per value to one per bs values, and none of them sits behind the barrier.
+#ifndef MI355X_BSR_XLDS_DEFAULT
+#define MI355X_BSR_XLDS_DEFAULT 1   // measured at 128^3 nodes (profiles/r03_cfg5.log): bs = 3 0.781 -> 0.728 ms, bs = 4 1.420 -> 1.290 ms; same bits
+#endif
+template <int BS, bool XLDS>
 __global__ __launch_bounds__(SPMV_THREADS) void bsr_rowblock_kernel(const int2 *__restrict__ rowblk, int nblocks,
                                                                    const int *__restrict__ ai, const int *__restrict__ aj,
                                                                    const double *__restrict__ aa,
                                                                    const double *__restrict__ x, double *__restrict__ y) {
   __shared__ double prod[SPMV_BLOCK_NNZ];
-  __shared__ int ajs[SPMV_BLOCK_NNZ / 4 + 1];   // block columns of the row block (bs >= 2: at most NNZ/4 blocks)
+  __shared__ int ajs[XLDS ? 1 : SPMV_BLOCK_NNZ / 4 + 1];   // block columns of the row block (bs >= 2: at most NNZ/4 blocks)
+  __shared__ double xs[XLDS ? (SPMV_BLOCK_NNZ / (BS * BS) + 1) * BS : 1];   // XLDS: x[bs * col .. + bs) of every stored block
   constexpr int BS2 = BS * BS;
   // interleaved block -> XCD map of the CSR kernels: each XCD walks runs of consecutive row blocks, so a block column's x
   // entries are pulled into ONE XCD's L2 instead of all eight (PMC at 128^3 nodes: 4.75 GB fetched for 4.35 GB without it)
@@ -746,15 +753,30 @@ __global__ __launch_bounds__(SPMV_THREADS) void bsr_rowblock_kernel(const int2 *
   // block columns of this row block: one coalesced load into LDS instead of a global gather per value (a block's bs^2
   // values share one entry); k0 is a multiple of bs^2 because row blocks start at block-row boundaries
   const int kb0 = k0 / BS2, nblk = (k1 - k0) / BS2;
-  for (int b = tid; b < nblk; b += SPMV_THREADS) ajs[b] = aj[kb0 + b];
   constexpr int PAIRS = SPMV_BLOCK_NNZ / (2 * SPMV_THREADS);
   const int ka = k0 & ~1;
   v2d vv[PAIRS];
+  if (XLDS) {
+    // the value stream first (it is the long pole), then one block column per lane and its bs x entries
 #pragma unroll
-  for (int p = 0; p < PAIRS; ++p) {
-    const int k = ka + 2 * tid + p * 2 * SPMV_THREADS;
-    const int kk = (k < k1) ? k : ka;
-    vv[p] = SPMV_LOAD(reinterpret_cast<const v2d *>(aa + kk));
+    for (int p = 0; p < PAIRS; ++p) {
+      const int k = ka + 2 * tid + p * 2 * SPMV_THREADS;
+      const int kk = (k < k1) ? k : ka;
+      vv[p] = SPMV_LOAD(reinterpret_cast<const v2d *>(aa + kk));
+    }
+    for (int b = tid; b < nblk; b += SPMV_THREADS) {
+      const long c = (long)aj[kb0 + b] * BS;
+#pragma unroll
+      for (int q = 0; q < BS; ++q) xs[b * BS + q] = x[c + q];
+    }
+  } else {
+    for (int b = tid; b < nblk; b += SPMV_THREADS) ajs[b] = aj[kb0 + b];
+#pragma unroll
+    for (int p = 0; p < PAIRS; ++p) {
+      const int k = ka + 2 * tid + p * 2 * SPMV_THREADS;
+      const int kk = (k < k1) ? k : ka;
+      vv[p] = SPMV_LOAD(reinterpret_cast<const v2d *>(aa + kk));
+    }
   }
   __syncthreads();
   double xa[PAIRS], xb[PAIRS];
@@ -768,8 +790,13 @@ __global__ __launch_bounds__(SPMV_THREADS) void bsr_rowblock_kernel(const int2 *
     const int f0 = kk + (v0 ? 0 : (in ? 1 : (k0 & 1))) - k0;
     const int f1 = kk + (v1 ? 1 : (in ? 0 : (k0 & 1))) - k0;
     const int blk0 = f0 / BS2, blk1 = f1 / BS2;
-    xa[p] = x[(long)ajs[blk0] * BS + (f0 - blk0 * BS2) / BS];
-    xb[p] = x[(long)ajs[blk1] * BS + (f1 - blk1 * BS2) / BS];
+    if (XLDS) {
+      xa[p] = xs[blk0 * BS + (f0 - blk0 * BS2) / BS];
+      xb[p] = xs[blk1 * BS + (f1 - blk1 * BS2) / BS];
+    } else {
+      xa[p] = x[(long)ajs[blk0] * BS + (f0 - blk0 * BS2) / BS];
+      xb[p] = x[(long)ajs[blk1] * BS + (f1 - blk1 * BS2) / BS];
+    }
   }
 #pragma unroll
   for (int p = 0; p < PAIRS; ++p) {
@@ -1297,8 +1324,8 @@ int mi355x_spmv_csr_add(mi355x_handle_t h, mi355x_spmv_plan_t plan, const int *a
   return launch_spmv<1>(h, plan, ai, aj, aa, x, y, z);
 }
 
-int mi355x_spmv_bsr_planned(mi355x_handle_t h, mi355x_spmv_plan_t p, int bs, const int *ai, const int *aj,
-                            const double *aa, const double *x, double *y) {
+static int spmv_bsr_planned_impl(mi355x_handle_t h, mi355x_spmv_plan_t p, int bs, const int *ai, const int *aj,
+                                 const double *aa, const double *x, double *y, bool xlds) {
   if (p->nblocks == 0) return 0;
 #if SPMV_REMAP == 2
   const int perb = MI355X_NXCD * SPMV_CH;
@@ -1306,7 +1333,8 @@ int mi355x_spmv_bsr_planned(mi355x_handle_t h, mi355x_spmv_plan_t p, int bs, con
 #else
   dim3 grid(p->nblocks), block(SPMV_THREADS);
 #endif
-#define BSR_GO(B) hipLaunchKernelGGL((bsr_rowblock_kernel<B>), grid, block, 0, h->stream, p->d_rowblk, p->nblocks, ai, aj, aa, x, y)
+#define BSR_GO(B) do { if (xlds) hipLaunchKernelGGL((bsr_rowblock_kernel<B, true>), grid, block, 0, h->stream, p->d_rowblk, p->nblocks, ai, aj, aa, x, y); \
+                       else hipLaunchKernelGGL((bsr_rowblock_kernel<B, false>), grid, block, 0, h->stream, p->d_rowblk, p->nblocks, ai, aj, aa, x, y); } while (0)
   switch (bs) {
     case 2: BSR_GO(2); break;
     case 3: BSR_GO(3); break;
@@ -1320,6 +1348,15 @@ int mi355x_spmv_bsr_planned(mi355x_handle_t h, mi355x_spmv_plan_t p, int bs, con
 #undef BSR_GO
   MI355X_LAUNCH_CHECK();
   return 0;
+}
+// development / A-B entry points: the two forms of the row-block BCSR kernel side by side (tests/tools/cfg5_baij.py)
+int mi355x_spmv_bsr_planned_form(mi355x_handle_t h, mi355x_spmv_plan_t p, int bs, int x_in_lds, const int *ai, const int *aj,
+                                 const double *aa, const double *x, double *y) {
+  return spmv_bsr_planned_impl(h, p, bs, ai, aj, aa, x, y, x_in_lds != 0);
+}
+int mi355x_spmv_bsr_planned(mi355x_handle_t h, mi355x_spmv_plan_t p, int bs, const int *ai, const int *aj,
+                            const double *aa, const double *x, double *y) {
+  return spmv_bsr_planned_impl(h, p, bs, ai, aj, aa, x, y, MI355X_BSR_XLDS_DEFAULT != 0);
 }
 
 int mi355x_csr_assemble(mi355x_handle_t h, int nseg, const int *segptr, const int *segslot, const int *order, const double *v, double *aa) {

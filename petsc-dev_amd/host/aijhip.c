@@ -238,9 +238,10 @@ PetscErrorCode MatSeqAIJHIPUpload(Mat A) {
     }
     else {   /* BAIJ: the plan partitions the VALUE stream, i.e. the block-row pointer scaled by bs*bs */
       PetscInt *sc, bs2 = a->bs * a->bs;
-      if (a->bs == 4) {   /* -mat_hipmi355x_baij4 <mfma|fma>: bs = 4 runs on the matrix cores unless told otherwise (measured at 128^3
-                           * nodes, 27 blocks per row: 1.295 ms against 1.402 ms for the row-block FMA kernel) */
-        char kind[16] = "mfma"; PetscBool set;
+      if (a->bs == 4) {   /* -mat_hipmi355x_baij4 <fma|mfma>: the row-block FMA kernel (x staged in LDS: 1.290 ms at 128^3 nodes, 27 blocks
+                           * per row) or the matrix cores (v_mfma_f64_4x4x4: 1.349 ms; it was the faster one, 1.295 against 1.402, while
+                           * the FMA kernel gathered x once per value) */
+        char kind[16] = "fma"; PetscBool set;
         ierr = PetscOptionsGetString(NULL, "-mat_hipmi355x_baij4", kind, sizeof(kind), &set);CHKERRQ(ierr);
         if (strcmp(kind, "mfma") && strcmp(kind, "fma")) SETERRQ(HipObjComm(A), PETSC_ERR_ARG_WRONG, "-mat_hipmi355x_baij4 <mfma|fma>, got %s", kind);
         d->baij4_mfma = (PetscBool)!strcmp(kind, "mfma");
@@ -285,7 +286,7 @@ static PetscErrorCode upload_transpose(Mat A) {
   PetscDeviceCtx *dc;
   if (d->t_state == HipObjState(A) && d->t_a) return 0;
   ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
-  if (d->t_a && d->t_perm && d->t_pattern_nz == a->nz && d->pattern_nz == a->nz) {
+  if (d->t_a && d->t_perm && d->t_pattern_nz == a->nz && (d->pattern_nz == a->nz || d->pattern_nz == -1)) {   /* (-1: no device copy of A yet; the upload below makes one) */
     /* only the VALUES changed since the transpose was built (a time step, a Newton iteration, MatScale / MatDiagonalScale /
      * MatSetValuesBatch on the device copy): A^T's values are the matrix's values in another order, and that order -- the
      * permutation of the counting sort below -- is on the device.  One gather kernel over the current device values; nothing

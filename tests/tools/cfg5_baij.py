@@ -1,5 +1,6 @@
 """Config-5 probe (BASELINE.json configs[4]: BCSR 3-D elasticity, 128^3 nodes, 3 dof per node): the same operator as
   bs3      BAIJ bs = 3, row-block streaming FMA kernel          (MatMult_SeqBAIJ_3, baij2.c:331)
+  bs3x/g   the same kernel with x staged in LDS once per block / gathered once per value (A-B of the two forms; bs4x likewise)
   bs4      zero-padded to 4x4 blocks, row-block streaming FMA   (MatMult_SeqBAIJ_4, baij2.c:387)
   bs4mfma  zero-padded to 4x4 blocks, matrix cores, 16-B loads  (v_mfma_f64_4x4x4_4b_f64)
   bs4mfma8 ... 8-B loads
@@ -48,7 +49,10 @@ def main():
         plans[bs] = p
     variants = {
         "bs3": (3, lambda: k.mi355x_spmv_bsr_planned(dev.h, plans[3], 3, dbi, dbj, da3, dx3, dy3)),
+        "bs3x": (3, lambda: k.mi355x_spmv_bsr_planned_form(dev.h, plans[3], 3, 1, dbi, dbj, da3, dx3, dy3)),
+        "bs3g": (3, lambda: k.mi355x_spmv_bsr_planned_form(dev.h, plans[3], 3, 0, dbi, dbj, da3, dx3, dy3)),
         "bs4": (4, lambda: k.mi355x_spmv_bsr_planned(dev.h, plans[4], 4, dbi, dbj, da4, dx4, dy4)),
+        "bs4x": (4, lambda: k.mi355x_spmv_bsr_planned_form(dev.h, plans[4], 4, 1, dbi, dbj, da4, dx4, dy4)),
         "bs4mfma": (4, lambda: k.mi355x_spmv_bsr4_mfma(dev.h, mbs, 0, dbi, dbj, da4, dx4, dy4)),
         "bs4mfma8": (4, lambda: k.mi355x_spmv_bsr4_mfma(dev.h, mbs, 1, dbi, dbj, da4, dx4, dy4)),
         "wave3": (3, lambda: k.mi355x_spmv_bsr(dev.h, mbs, 3, dbi, dbj, da3, dx3, dy3)),
