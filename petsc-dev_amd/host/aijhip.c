@@ -286,12 +286,14 @@ static PetscErrorCode upload_transpose(Mat A) {
   PetscDeviceCtx *dc;
   if (d->t_state == HipObjState(A) && d->t_a) return 0;
   ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
-  if (d->t_a && d->t_perm && d->t_pattern_nz == a->nz && (d->pattern_nz == a->nz || d->pattern_nz == -1)) {   /* (-1: no device copy of A yet; the upload below makes one) */
+  /* the device copy of A first: building it discards everything that belonged to an older pattern, a cached transpose included
+   * (device_free), so it must not happen between the check below and the use of the cached arrays */
+  ierr = MatSeqAIJHIPUpload(A);CHKERRQ(ierr);
+  if (d->t_a && d->t_perm && d->t_pattern_nz == a->nz && d->pattern_nz == a->nz) {
     /* only the VALUES changed since the transpose was built (a time step, a Newton iteration, MatScale / MatDiagonalScale /
      * MatSetValuesBatch on the device copy): A^T's values are the matrix's values in another order, and that order -- the
      * permutation of the counting sort below -- is on the device.  One gather kernel over the current device values; nothing
-     * is rebuilt on the host, nothing crosses PCIe beyond what MatSeqAIJHIPUpload needs for the matrix itself. */
-    ierr = MatSeqAIJHIPUpload(A);CHKERRQ(ierr);
+     * is rebuilt on the host, nothing crosses PCIe beyond what MatSeqAIJHIPUpload needed for the matrix itself. */
     CHKHIP(mi355x_pack(dc->h, (size_t)a->nz, d->t_perm, d->d_a, d->t_a));
     d->t_state = HipObjState(A);
     d->t_refreshes++;
