@@ -142,6 +142,112 @@ static PetscErrorCode natural_ordering_only(Mat A, IS row, IS col, const MatFact
 }
 
 #if !defined(PETSCHIPMI355X_WITH_PETSC)
+#include <pthread.h>
+#include <unistd.h>
+/* one pass of the numeric ILU(0) over the rows [r0, r1) of an independent block with a given diagonal shift, rows taken level by
+ * level (dependency levels of L) and a level's rows dealt to the threads */
+typedef struct {
+  const PetscInt *ai, *aj; const PetscScalar *aa;
+  const PetscInt *bi, *bj, *bdiag; PetscScalar *ba;
+  PetscInt n, r0, r1, nlev, *levptr, *rows;
+  PetscReal zeropivot, shift_amount;
+  int nth;
+  PetscScalar **rtmp;                 /* a dense work row per thread */
+  volatile PetscInt fail_row; volatile PetscReal fail_value;
+  pthread_barrier_t bar; pthread_mutex_t mtx;
+} IluPass;
+typedef struct { IluPass *p; int tid; } IluArg;
+
+/* row i of MatLUFactorNumeric_SeqAIJ (aijfact.c:505-570): dense work row, multipliers in column order, the pivot stored inverted;
+ * returns 1 when the pivot fails MatPivotCheck_nz (matimpl.h:512-528) */
+static int ilu0_factor_row(const IluPass *p, PetscScalar *rtmp, PetscInt i, PetscReal *badval) {
+  const PetscInt *ai = p->ai, *aj = p->aj, *bi = p->bi, *bj = p->bj, *bdiag = p->bdiag; const PetscScalar *aa = p->aa; PetscScalar *ba = p->ba;
+  PetscInt nzl = bi[i + 1] - bi[i], nzu = bdiag[i] - bdiag[i + 1];
+  PetscReal rs = 0.0;
+  for (PetscInt j = 0; j < nzl; j++) rtmp[bj[bi[i] + j]] = 0.0;
+  for (PetscInt j = 0; j < nzu; j++) rtmp[bj[bdiag[i + 1] + 1 + j]] = 0.0;
+  for (PetscInt q = ai[i]; q < ai[i + 1]; q++) rtmp[aj[q]] = aa[q];
+  rtmp[i] += p->shift_amount;
+  for (PetscInt kk = 0; kk < nzl; kk++) {
+    const PetscInt row = bj[bi[i] + kk];
+    PetscScalar *pc_ = rtmp + row;
+    if (*pc_ != 0.0) {
+      const PetscScalar multiplier = *pc_ * ba[bdiag[row]];
+      *pc_ = multiplier;
+      const PetscInt *pj = bj + bdiag[row + 1] + 1;
+      const PetscScalar *pv = ba + bdiag[row + 1] + 1;
+      const PetscInt nz = bdiag[row] - bdiag[row + 1] - 1;
+      for (PetscInt j = 0; j < nz; j++) rtmp[pj[j]] -= multiplier * pv[j];
+    }
+  }
+  for (PetscInt j = 0; j < nzl; j++) { ba[bi[i] + j] = rtmp[bj[bi[i] + j]]; rs += PetscAbsScalar(ba[bi[i] + j]); }
+  for (PetscInt j = 0; j < nzu - 1; j++) { ba[bdiag[i + 1] + 1 + j] = rtmp[bj[bdiag[i + 1] + 1 + j]]; rs += PetscAbsScalar(ba[bdiag[i + 1] + 1 + j]); }
+  if (PetscAbsScalar(rtmp[i]) <= p->zeropivot * rs) { *badval = PetscAbsScalar(rtmp[i]); return 1; }
+  ba[bdiag[i]] = 1.0 / rtmp[i];
+  return 0;
+}
+static void *ilu0_worker(void *arg_) {
+  IluArg *arg = (IluArg *)arg_;
+  IluPass *p = arg->p;
+  PetscScalar *rtmp = p->rtmp[arg->tid];
+  for (PetscInt l = 0; l < p->nlev; l++) {
+    const PetscInt a = p->levptr[l], b = p->levptr[l + 1], cnt = b - a;
+    const PetscInt lo = a + (PetscInt)((long)cnt * arg->tid / p->nth), hi = a + (PetscInt)((long)cnt * (arg->tid + 1) / p->nth);
+    for (PetscInt t = lo; t < hi; t++) {
+      const PetscInt i = p->rows[t];
+      PetscReal bad;
+      if (i < p->r0 || i >= p->r1) continue;
+      if (ilu0_factor_row(p, rtmp, i, &bad)) {
+        pthread_mutex_lock(&p->mtx);
+        if (p->fail_row < 0 || i < p->fail_row) { p->fail_row = i; p->fail_value = bad; }
+        pthread_mutex_unlock(&p->mtx);
+        break;
+      }
+    }
+    if (p->nth > 1) pthread_barrier_wait(&p->bar);
+    if (p->fail_row >= 0) break;           /* read after the barrier: every thread sees the same answer and leaves together */
+    if (p->nth > 1) pthread_barrier_wait(&p->bar);
+  }
+  return NULL;
+}
+static PetscErrorCode ilu0_run_pass(IluPass *p) {
+  IluArg args[64]; pthread_t th[64];
+  for (int t = 0; t < p->nth; t++) { args[t].p = p; args[t].tid = t; }
+  pthread_mutex_init(&p->mtx, NULL);
+  if (p->nth == 1) { ilu0_worker(&args[0]); pthread_mutex_destroy(&p->mtx); return 0; }
+  if (pthread_barrier_init(&p->bar, NULL, (unsigned)p->nth)) return PETSC_ERR_LIB;
+  int started = 0;
+  for (int t = 1; t < p->nth; t++) { if (pthread_create(&th[t], NULL, ilu0_worker, &args[t])) break; started = t; }
+  if (started != p->nth - 1) {            /* could not start them all: the ones running would wait at the barrier for ever -- not reachable without them */
+    for (int t = 1; t <= started; t++) pthread_cancel(th[t]);
+    for (int t = 1; t <= started; t++) pthread_join(th[t], NULL);
+    pthread_barrier_destroy(&p->bar); pthread_mutex_destroy(&p->mtx);
+    return PETSC_ERR_LIB;
+  }
+  ilu0_worker(&args[0]);
+  for (int t = 1; t < p->nth; t++) pthread_join(th[t], NULL);
+  pthread_barrier_destroy(&p->bar); pthread_mutex_destroy(&p->mtx);
+  return 0;
+}
+/* dependency levels of L (a row may be factored once the rows its L part names are), rows listed level by level */
+static PetscErrorCode ilu0_levels_host(PetscInt n, const PetscInt *bi, const PetscInt *bj, PetscInt *nlev_out, PetscInt **levptr_out, PetscInt **rows_out) {
+  PetscErrorCode ierr;
+  PetscInt *lev, nlev = 0;
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)PetscMax(n, 1), &lev);CHKERRQ(ierr);
+  for (PetscInt i = 0; i < n; i++) {
+    PetscInt l = 0;
+    for (PetscInt q = bi[i]; q < bi[i + 1]; q++) l = PetscMax(l, lev[bj[q]] + 1);
+    lev[i] = l; nlev = PetscMax(nlev, l + 1);
+  }
+  ierr = level_order(n, lev, nlev, levptr_out, rows_out);
+  HipFree(lev);
+  CHKERRQ(ierr);
+  *nlev_out = nlev;
+  return 0;
+}
+#endif
+
+#if !defined(PETSCHIPMI355X_WITH_PETSC)
 /* MatILUFactorSymbolic_SeqAIJ_ilu0 + MatLUFactorNumeric_SeqAIJ restated for the harness (inside a PETSc tree the parent's
  * routines run instead): the pattern of A, L part forward, U part from the last row backwards (aijfact.c:1660-1685); row by row
  * with a dense work row, pivots stored inverted (aijfact.c:505-570); MatPivotCheck_nz's restarts (matimpl.h:512-528) */
@@ -177,59 +283,50 @@ static PetscErrorCode ilu0_factor_host(Mat F, Mat A, const MatFactorInfo *info) 
     bj[k++] = i;
     bdiag[i] = bdiag[i + 1] + nzu + 1;
   }
-  PetscScalar *rtmp;
-  ierr = PetscMalloc(sizeof(PetscScalar) * (size_t)(n + 1), &rtmp);CHKERRQ(ierr);
   const PetscReal zeropivot = info->zeropivot, shiftamount = info->shiftamount;
   const PetscBool shift_nz = (PetscBool)(info->shifttype == (PetscReal)MAT_SHIFT_NONZERO);
   f->nshift = 0;
   const PetscInt whole[2] = {0, n};
   const PetscInt nblk = (f->nblk > 0 && f->blk[f->nblk] == n) ? f->nblk : 1, *blk = (f->nblk > 0 && f->blk[f->nblk] == n) ? f->blk : whole;
+  for (PetscInt bb = 0; bb < nblk; bb++)
+    for (PetscInt i = blk[bb]; i < blk[bb + 1]; i++)
+      if (ai[i] < ai[i + 1] && (aj[ai[i]] < blk[bb] || aj[ai[i + 1] - 1] >= blk[bb + 1])) { HipFree(adiag); SETERRQ(HipObjComm(A), PETSC_ERR_ARG_WRONG, "row %d couples to a column outside its independent block", i); }
+  /* Rows of one dependency level of L do not read each other: a level's rows are factored by several host threads, one barrier per
+   * level.  Every row's own arithmetic is the sequential loop's (ilu0_factor_row), so the factor carries the same bits whatever
+   * the thread count; a pivot that fails MatPivotCheck_nz anywhere ends the pass for everybody and the block restarts shifted. */
+  IluPass ps;
+  memset(&ps, 0, sizeof(ps));
+  ps.ai = ai; ps.aj = aj; ps.aa = aa; ps.bi = bi; ps.bj = bj; ps.bdiag = bdiag; ps.ba = ba; ps.zeropivot = zeropivot; ps.n = n;
+  { PetscInt nth = 1; PetscBool set; long hw = sysconf(_SC_NPROCESSORS_ONLN);
+    if (n >= 200000) nth = (PetscInt)(hw > 16 ? 16 : (hw < 1 ? 1 : hw));
+    ierr = PetscOptionsGetInt(NULL, "-mat_factor_hipmi355x_threads", &nth, &set);CHKERRQ(ierr);
+    if (nth < 1) nth = 1;
+    if (nth > 64) nth = 64;
+    ps.nth = (int)nth; }
+  ierr = ilu0_levels_host(n, bi, bj, &ps.nlev, &ps.levptr, &ps.rows);
+  if (ierr) { HipFree(adiag); CHKERRQ(ierr); }
+  ierr = PetscMalloc(sizeof(PetscScalar *) * (size_t)ps.nth, &ps.rtmp);CHKERRQ(ierr);
+  for (int t = 0; t < ps.nth; t++) { ps.rtmp[t] = (PetscScalar *)calloc((size_t)n + 1, sizeof(PetscScalar)); if (!ps.rtmp[t]) SETERRQ(HipObjComm(A), PETSC_ERR_MEM, "out of memory"); }
   for (PetscInt bb = 0; bb < nblk; bb++) {
-    const PetscInt r0 = blk[bb], r1 = blk[bb + 1];
-    for (PetscInt i = r0; i < r1; i++) {
-      if (ai[i] < ai[i + 1] && (aj[ai[i]] < r0 || aj[ai[i + 1] - 1] >= r1)) { HipFree(rtmp); HipFree(adiag); SETERRQ(HipObjComm(A), PETSC_ERR_ARG_WRONG, "row %d couples to a column outside its independent block", i); }
-    }
-    PetscReal shift_amount = 0.0;
     PetscInt nshift = 0;
-    PetscBool again;
-    do {   /* MAT_SHIFT_NONZERO, PCILU's default on a SeqAIJ matrix (ilu.c:387): a pivot that fails MatPivotCheck_nz restarts the
-            * factorisation with the diagonal shifted by shiftamount, then by twice that, ... (aijfact.c:507-592) */
-      again = PETSC_FALSE;
-      for (PetscInt i = r0; i < r1; i++) {
-        PetscInt nzl = bi[i + 1] - bi[i], nzu = bdiag[i] - bdiag[i + 1];
-        PetscReal rs = 0.0;
-        for (PetscInt j = 0; j < nzl; j++) rtmp[bj[bi[i] + j]] = 0.0;
-        for (PetscInt j = 0; j < nzu; j++) rtmp[bj[bdiag[i + 1] + 1 + j]] = 0.0;
-        for (PetscInt q = ai[i]; q < ai[i + 1]; q++) rtmp[aj[q]] = aa[q];
-        rtmp[i] += shift_amount;
-        for (PetscInt kk = 0; kk < nzl; kk++) {
-          const PetscInt row = bj[bi[i] + kk];
-          PetscScalar *pc_ = rtmp + row;
-          if (*pc_ != 0.0) {
-            const PetscScalar multiplier = *pc_ * ba[bdiag[row]];
-            *pc_ = multiplier;
-            const PetscInt *pj = bj + bdiag[row + 1] + 1;
-            const PetscScalar *pv = ba + bdiag[row + 1] + 1;
-            const PetscInt nz = bdiag[row] - bdiag[row + 1] - 1;
-            for (PetscInt j = 0; j < nz; j++) rtmp[pj[j]] -= multiplier * pv[j];
-          }
-        }
-        for (PetscInt j = 0; j < nzl; j++) { ba[bi[i] + j] = rtmp[bj[bi[i] + j]]; rs += PetscAbsScalar(ba[bi[i] + j]); }
-        for (PetscInt j = 0; j < nzu - 1; j++) { ba[bdiag[i + 1] + 1 + j] = rtmp[bj[bdiag[i + 1] + 1 + j]]; rs += PetscAbsScalar(ba[bdiag[i + 1] + 1 + j]); }
-        if (PetscAbsScalar(rtmp[i]) <= zeropivot * rs) {
-          if (!shift_nz) { HipFree(rtmp); HipFree(adiag); SETERRQ(HipObjComm(A), 71 /* PETSC_ERR_MAT_LU_ZRPVT */, "Zero pivot row %d value %g tolerance %g", i, PetscAbsScalar(rtmp[i]), zeropivot * rs); }
-          shift_amount = nshift ? shift_amount * 2.0 : shiftamount;
-          nshift++;
-          if (nshift > 80) { HipFree(rtmp); HipFree(adiag); SETERRQ(HipObjComm(A), 71 /* PETSC_ERR_MAT_LU_ZRPVT */, "Zero pivot row %d value %g: still there after %d diagonal shifts", i, PetscAbsScalar(rtmp[i]), nshift); }
-          again = PETSC_TRUE;
-          break;
-        }
-        ba[bdiag[i]] = 1.0 / rtmp[i];
-      }
-    } while (again);
+    ps.r0 = blk[bb]; ps.r1 = blk[bb + 1]; ps.shift_amount = 0.0;
+    for (;;) {   /* MAT_SHIFT_NONZERO, PCILU's default on a SeqAIJ matrix (ilu.c:387): a pivot that fails MatPivotCheck_nz restarts the
+                  * factorisation with the diagonal shifted by shiftamount, then by twice that, ... (aijfact.c:507-592) */
+      ps.fail_row = -1;
+      ierr = ilu0_run_pass(&ps);
+      if (ierr) break;
+      if (ps.fail_row < 0) break;
+      if (!shift_nz) { ierr = PETSC_ERR_ARG_WRONG; break; }
+      ps.shift_amount = nshift ? ps.shift_amount * 2.0 : shiftamount;
+      nshift++;
+      if (nshift > 80) { ierr = PETSC_ERR_ARG_WRONG; break; }
+    }
+    if (ierr) break;
     f->nshift = PetscMax(f->nshift, nshift);
   }
-  HipFree(rtmp); HipFree(adiag);
+  for (int t = 0; t < ps.nth; t++) free(ps.rtmp[t]);
+  HipFree(ps.rtmp); HipFree(ps.levptr); HipFree(ps.rows); HipFree(adiag);
+  if (ierr) SETERRQ(HipObjComm(A), 71 /* PETSC_ERR_MAT_LU_ZRPVT */, "Zero pivot row %d value %g%s", ps.fail_row, ps.fail_value, shift_nz ? ": still there after 80 diagonal shifts" : "");
   return 0;
 }
 #endif

@@ -1100,6 +1100,34 @@ def test_syncfree_solve_that_gave_up_is_noticed_at_the_next_host_wait(P, pct):
     assert np.array_equal(bits(vx.array()), good)
 
 
+@pytest.mark.parametrize("nth", [1, 3, 8])
+def test_ilu0_threaded_factorisation_carries_the_same_bits(P, nth):
+    """The host ILU(0) factorisation deals the rows of a dependency level of L to several threads (-mat_factor_hipmi355x_threads;
+    by default for 200 000 rows and more).  Every row's arithmetic is the sequential loop's, so the factor -- seen through one
+    application -- carries the oracle's bits for any thread count, also when MatPivotCheck_nz makes the passes restart with a
+    shifted diagonal (as many restarts as the oracle takes), and also for independent blocks with different shifts."""
+    import scipy.sparse as sp
+    L = P.lib()
+    cases = [P.gen_poisson7(23, 17, 11), pb.gen_fem3(7, 6, 5)]
+    T = sp.diags([np.ones(299), np.ones(300), np.ones(299)], [-1, 0, 1]).tocsr(); T.sort_indices()      # zero pivots: shifts
+    cases.append((T.indptr.astype(np.int32), T.indices.astype(np.int32), T.data.copy()))
+    for ai, aj, aa in cases:
+        n = ai.size - 1
+        aa = aa * (1.0 + 0.03 * np.cos(np.arange(aa.size))) if n != 300 else aa
+        A = P.Mat.from_csr(ai, aj, aa)
+        pc = C.c_void_p()
+        k = P.KSP(comm=L.COMM_SELF); k.set_operators(A); L.KSPGetPC(k.h, C.byref(pc)); L.PCSetType(pc, b"ilu")
+        set_options(L, "-mat_factor_hipmi355x_threads %d -pc_factor_hipmi355x_trisolve_nodes 0 -pc_factor_hipmi355x_trisolve_order column" % nth)
+        L.raw("PCSetUp")(pc)
+        set_options(L, "")
+        f, ns_o = orc.ilu0_factor_shift(ai, aj, aa)
+        ns = C.c_int(); L.PCILUGetShiftCount_HIPMI355X(pc, C.byref(ns))
+        assert ns.value == ns_o and (ns_o >= 1) == (n == 300)
+        b = rnd(n, 11); vb, vx = V(P, b), V(P, np.zeros(n))
+        L.raw("PCApply")(pc, vb.h, vx.h)
+        assert np.array_equal(bits(vx.array()), bits(orc.ilu0_solve(f, b))), (n, nth)
+
+
 def test_ilu0_apply_bitexact_and_golden(P):
     """PCILU (ILU(0), natural ordering).  The level-scheduled device solve reproduces
     MatSolve_SeqAIJ_NaturalOrdering bit for bit (one lane per row, products subtracted in column order), and with NO
