@@ -29,6 +29,24 @@ static PetscErrorCode hipaij_refresh_view(Mat A) {
   PetscFunctionReturn(0);
 }
 
+/* lazily, from MatSeqAIJHIPUpload: the parent's container may have been filled or replaced without this type's MatAssemblyEnd
+ * (MatDuplicate_SeqAIJ, MatCopy_SeqAIJ, MatConvert, MatDuplicateNoCreate_SeqAIJ set assembled themselves).  New arrays or another
+ * nonzero count: the pattern is not the one the device copy was built for -- rebuild; same arrays: the object state decides. */
+static PetscErrorCode hipaij_refresh_view_if_stale(Mat A) {
+  Mat_SeqAIJ *aij = (Mat_SeqAIJ *)A->data;
+  HipAIJ *v = HipAIJGet(A);
+  PetscErrorCode ierr;
+  PetscFunctionBegin;
+  if (!A->assembled) PetscFunctionReturn(0);
+  if (v->i != aij->i || v->j != aij->j || v->a != aij->a || v->nz != aij->nz || !v->compact) {
+    const PetscBool new_pattern = (PetscBool)(v->i != aij->i || v->j != aij->j || v->nz != aij->nz);
+    ierr = hipaij_refresh_view(A);CHKERRQ(ierr);
+    SD(A)->uploaded_state = -1;
+    if (new_pattern) SD(A)->pattern_nz = -1;
+  }
+  PetscFunctionReturn(0);
+}
+
 static PetscErrorCode MatAssemblyEnd_SeqAIJHIPMI355X(Mat A, MatAssemblyType mode) {   /* MatAssemblyEnd_SeqAIJCUSP, aijcusp.cu:452-470 */
   PetscErrorCode ierr;
   PetscFunctionBegin;

@@ -179,11 +179,19 @@ static PetscErrorCode device_free(Mat A) {
 
 /* MatCUSPCopyToGPU (aijcusp.cu:126-253): H2D of i, j, a when the host copy is newer.  Unlike the
  * reference, a value-only change (same pattern) re-sends only `a`. */
+#if defined(PETSCHIPMI355X_WITH_PETSC)
+static PetscErrorCode hipaij_refresh_view_if_stale(Mat A);   /* integration/petsc-3.3/aijhipmi355x_ctor.h */
+#endif
 PetscErrorCode MatSeqAIJHIPUpload(Mat A) {
   PetscErrorCode ierr;
   HipAIJ *a = SA(A);
   Mat_SeqAIJHIP *d = SD(A);
   PetscDeviceCtx *dc;
+#if defined(PETSCHIPMI355X_WITH_PETSC)
+  /* the parent class fills or replaces its arrays on paths that never pass this type's MatAssemblyEnd (MatDuplicate_SeqAIJ,
+   * MatCopy, MatConvert set assembled = TRUE themselves): the view of them is checked before every use */
+  ierr = hipaij_refresh_view_if_stale(A);CHKERRQ(ierr);
+#endif
   if (d->uploaded_state == HipObjState(A) && d->d_a) return 0;
   ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
   if (!a->compact) SETERRQ(HipObjComm(A), PETSC_ERR_ARG_WRONGSTATE, "matrix must be assembled before it is sent to the GPU");

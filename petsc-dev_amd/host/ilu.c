@@ -454,9 +454,12 @@ static PetscErrorCode ilu0_analyse_and_upload(Mat F, Mat A) {
 
 static PetscErrorCode MatSolve_SeqAIJHIP_ILU(Mat F, Vec b, Vec x);
 
+#include <time.h>
+static double wall_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
 static PetscErrorCode MatLUFactorNumeric_SeqAIJHIP(Mat F, Mat A, const MatFactorInfo *info) {   /* MatLUFactorNumeric_SeqAIJCUSPARSE, aijcusparse.cu:358-376 */
   PetscErrorCode ierr;
   HipTriFactors *f = HipTriGet(F);
+  const double t0 = wall_s();
   if (A->rmap->n != A->cmap->n) SETERRQ(HipObjComm(A), PETSC_ERR_ARG_WRONG, "Must be square matrix, rows %d columns %d", A->rmap->n, A->cmap->n);
   if (f->factored_state == HipObjState(A) && f->factored_of == (void *)A && (f->tri_lo || f->d_ba)) return 0;   /* same operator, same values: nothing to redo */
   tri_reset_numeric(f);
@@ -467,7 +470,9 @@ static PetscErrorCode MatLUFactorNumeric_SeqAIJHIP(Mat F, Mat A, const MatFactor
 #else
   ierr = ilu0_factor_host(F, A, info);CHKERRQ(ierr);
 #endif
+  const double t1 = wall_s();
   ierr = ilu0_analyse_and_upload(F, A);CHKERRQ(ierr);
+  if (getenv("PETSC_HIPMI355X_SETUP_TIMING")) fprintf(stderr, "[hipmi355x] ILU(0) n=%d: host factorisation %.3f s, level analysis + plans + upload %.3f s\n", (int)f->n, t1 - t0, wall_s() - t1);
   F->ops->solve = MatSolve_SeqAIJHIP_ILU;                                 /* aijcusparse.cu:372-373 */
   f->factored_state = HipObjState(A); f->factored_of = (void *)A;
   return 0;
