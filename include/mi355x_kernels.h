@@ -286,9 +286,12 @@ int mi355x_trisolve_plan_create_scaled(mi355x_handle_t h, int n, int nlev, const
  * dense triangle; nodelev[u] = dependency level of node u among the nodes.  Row-level arrays as above, in the reference's stored order.
  * One lane per node; the reference routine's summation order (shared columns two at a time, then the couplings inside the node):
  * bit for bit MatSolve_SeqAIJ_Inode with by_level == 0.  Returns hipErrorInvalidValue for a factor without that shape.  Lower and
- * upper plan of an application must both be node plans of the same partition. */
+ * upper plan of an application must both be node plans of the same partition and the same block_columns.
+ * block_columns != 0: additionally every node has the same number of rows (<= 4) and every shared column list is a run of WHOLE
+ * dependency nodes (a FEM matrix with a fixed number of dofs per node): one list entry and one contiguous gather per dependency node
+ * -- fewer, larger batches; same column sequence, same bits.  hipErrorInvalidValue when the factor is not of that kind. */
 int mi355x_trisolve_plan_create_nodes(mi355x_handle_t h, int n, int nnodes, const int *nstart, int nlev, const int *nodelev, const int *rp, const int *rl,
-                                      const int *cj, const double *cv, const double *dinv, int by_level, mi355x_trisolve_plan_t *plan);
+                                      const int *cj, const double *cv, const double *dinv, int by_level, int block_columns, mi355x_trisolve_plan_t *plan);
 int mi355x_trisolve_plan_destroy(mi355x_trisolve_plan_t plan);
 int mi355x_trisolve_apply(mi355x_handle_t h, mi355x_trisolve_plan_t lower, mi355x_trisolve_plan_t upper, const double *b, double *y);
 int mi355x_trisolve_aborted(mi355x_trisolve_plan_t plan, int *aborted);

@@ -107,6 +107,9 @@ struct mi355x_trisolve_plan_s {
   // reference, Mat_CheckInode); d_row = the node's first row, d_col = SLOTS (k * np + position) of the shared columns, d_val = nb
   // values per shared column, d_din = the couplings inside the node and (upper) the inverted diagonals, d_w = nb * np slots
   int nb, np;
+  int spw;                 // node plans: slices (waves) per workgroup
+  int split, ring, maxcol; // split-role kernel (loader + solver wavefront per workgroup): on, batches in the LDS ring, widest slice
+  int blkcols;             // the shared lists hold whole dependency nodes: one list entry per node, solution stored node by node
   unsigned char *d_nsz;    // per position: rows in the node
   double *d_din;           // [nb (nb - 1) / 2 + nb][np]
 };
@@ -245,18 +248,20 @@ __global__ __launch_bounds__(MI355X_BLOCK) void trisolve_syncfree_kernel(
 #else
 #define TRI_NSTAMP(k) do { } while (0)
 #endif
-template <int NB, bool UPPER, bool POLL>
-__device__ __forceinline__ void tri_node_solve(const int t, const int lane, const int np, const int base, const int ncol, const int row0, const int nsz,
+template <int NB, bool UPPER, bool POLL, bool BLK>
+__device__ __forceinline__ void tri_node_solve(const int t, const int lane, const int np, const int base, const int off, const int ncol, const int row0, const int nsz,
                                                const int *__restrict__ col, const double *__restrict__ val, const double *__restrict__ din,
                                                const double *src, const int *__restrict__ spos, double *w, double *y, double *reset,
                                                int *abort_flag, const int sleep_cap) {
 #ifndef TRI_NODE_B
 #define TRI_NODE_B 8
 #endif
-#ifndef TRI_NODE_ALIGN_END
-#define TRI_NODE_ALIGN_END 0       // measured on the FEM stand-in (profiles/r03_tri_variants.log): end-aligned batches 40 / 71 ms against 29 / 48
-#endif
-  constexpr int B = NB <= 3 ? TRI_NODE_B : 4;  // columns per batch (registers: 2 batches x (1 + NB) words per column)
+  // BLK (block columns): the shared list consists of WHOLE dependency nodes, all nodes have NB rows.  The list then stores one
+  // entry per dependency NODE (its position), the solution lives node by node (w[position * NB + row]) so that a dependency's
+  // NB values are one contiguous gather, and a batch is a few whole nodes: 4.5 batches of 8 columns become 3 batches of 4
+  // nodes on a 3-dof FEM factor -- fewer memory round trips on the dependency chain.  Same column sequence, same pairs, same bits.
+  constexpr int B = BLK ? (NB == 2 ? 8 : (NB == 3 ? 12 : (NB == 4 ? 8 : 10))) : (NB <= 3 ? TRI_NODE_B : 4);  // columns per batch
+  constexpr int CB = BLK ? B / NB : B;         // list entries per batch
   constexpr int NT = NB * (NB - 1) / 2;
   double sum[NB];
 #pragma unroll
@@ -270,22 +275,25 @@ __device__ __forceinline__ void tri_node_solve(const int t, const int lane, cons
       } else sum[k] = src[row0 + k];
     }
   }
-  const double *vbase = val + (size_t)base * NB + lane;
-  const int *cbase = col + base + lane;
+  // (without block columns a lane's list sits at the END of the slice's slots, trisolve_plan_fill_nodes: `off` slots of padding first)
+  const double *vbase = val + ((size_t)base + (size_t)off * MI355X_WAVE) * NB + lane;
+  const int *cbase = col + (BLK ? base / NB : base + off * MI355X_WAVE) + lane;
+#define TRI_XADDR(cX, j) (BLK ? w + (size_t)cX[(j) / NB] * NB + ((j) % NB) : w + cX[(j)])
   TRI_NSTAMP(0);
   // the node's own triangle (and inverted diagonals): requested now, needed after the last dependency has arrived
   double dn[NT + (UPPER ? NB : 0) + 1];
 #pragma unroll
   for (int e = 0; e < NT + (UPPER ? NB : 0); ++e) dn[e] = din[(size_t)e * np + t];
-  // TRI_NODE_ALIGN_END (development variant, off): batches aligned to the END of the column list -- the first batch is the short one,
-  // the last batch holds the B newest columns; the offset is even, so that the pairs (0,1), (2,3), ... of the reference's summation
-  // stay pairs.
-  const int qstart = TRI_NODE_ALIGN_END ? -(((B - ncol % B) % B) & ~1) : 0;
-  int cA[B]; double aA[B * NB];
+  constexpr int qstart = 0;
+  int cA[CB]; double aA[B * NB];
+#pragma unroll
+  for (int j = 0; j < CB; ++j) {
+    const int q = BLK ? j * NB : qstart + j, qq = (q >= 0 && q < ncol) ? q : 0;
+    cA[j] = ncol > 0 ? cbase[(BLK ? qq / NB : qq) * MI355X_WAVE] : 0;
+  }
 #pragma unroll
   for (int j = 0; j < B; ++j) {
     const int q = qstart + j, qq = (q >= 0 && q < ncol) ? q : 0;
-    cA[j] = ncol > 0 ? cbase[qq * MI355X_WAVE] : 0;
 #pragma unroll
     for (int k = 0; k < NB; ++k) aA[j * NB + k] = ncol > 0 ? vbase[(size_t)(qq * NB + k) * MI355X_WAVE] : 0.0;
   }
@@ -294,16 +302,20 @@ __device__ __forceinline__ void tri_node_solve(const int t, const int lane, cons
 #pragma unroll
     for (int j = 0; j < B; ++j) {
       v[j] = 0.0;
-      if (q0 + j >= 0 && q0 + j < ncol) v[j] = POLL ? __hip_atomic_load(w + cA[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : w[cA[j]];
+      if (q0 + j >= 0 && q0 + j < ncol) v[j] = POLL ? __hip_atomic_load(TRI_XADDR(cA, j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *TRI_XADDR(cA, j);
     }
     // the next batch's indices and values go out BEHIND this batch's gathers (loads return in issue order: the gathers must not
     // queue behind a round trip to HBM) and are in flight while this batch waits for its dependencies
-    int cN[B]; double aN[B * NB];
+    int cN[CB]; double aN[B * NB];
     const bool more = q0 + B < ncol;
 #pragma unroll
+    for (int j = 0; j < CB; ++j) {
+      const int qn = q0 + B + (BLK ? j * NB : j), qq = (qn >= 0 && qn < ncol) ? qn : 0;   // (an index outside the list re-reads entry 0: never out of bounds)
+      cN[j] = more ? cbase[(BLK ? qq / NB : qq) * MI355X_WAVE] : 0;
+    }
+#pragma unroll
     for (int j = 0; j < B; ++j) {
-      const int qn = q0 + B + j, qq = (qn >= 0 && qn < ncol) ? qn : 0;      // (an index outside the list re-reads entry 0: never out of bounds)
-      cN[j] = more ? cbase[qq * MI355X_WAVE] : 0;
+      const int qn = q0 + B + j, qq = (qn >= 0 && qn < ncol) ? qn : 0;
 #pragma unroll
       for (int k = 0; k < NB; ++k) aN[j * NB + k] = more ? vbase[(size_t)(qq * NB + k) * MI355X_WAVE] : 0.0;
     }
@@ -314,16 +326,16 @@ __device__ __forceinline__ void tri_node_solve(const int t, const int lane, cons
   do {                                                                                                                 \
     _Pragma("unroll") for (int jj = (from); jj < B; ++jj)                                                              \
       if (q0 + jj >= 0 && q0 + jj < ncol && __double_as_longlong(v[jj]) == (long long)TRI_SENTINEL)                    \
-        v[jj] = __hip_atomic_load(w + cA[jj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                             \
+        v[jj] = __hip_atomic_load(TRI_XADDR(cA, jj), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                      \
   } while (0)
 #pragma unroll
     for (int j = 0; j < B; j += 2) {
       if (q0 + j >= 0 && q0 + j < ncol) {
         double x0 = v[j];
-        if (POLL && __double_as_longlong(x0) == (long long)TRI_SENTINEL) { x0 = tri_poll(w + cA[j], abort_flag, sleep_cap); TRI_REFRESH(j + 1); }
+        if (POLL && __double_as_longlong(x0) == (long long)TRI_SENTINEL) { x0 = tri_poll(TRI_XADDR(cA, j), abort_flag, sleep_cap); TRI_REFRESH(j + 1); }
         if (q0 + j + 1 < ncol) {
           double x1 = v[j + 1];
-          if (POLL && __double_as_longlong(x1) == (long long)TRI_SENTINEL) { x1 = tri_poll(w + cA[j + 1], abort_flag, sleep_cap); TRI_REFRESH(j + 2); }
+          if (POLL && __double_as_longlong(x1) == (long long)TRI_SENTINEL) { x1 = tri_poll(TRI_XADDR(cA, j + 1), abort_flag, sleep_cap); TRI_REFRESH(j + 2); }
 #pragma unroll
           for (int k = 0; k < NB; ++k) sum[k] -= aA[j * NB + k] * x0 + aA[(j + 1) * NB + k] * x1;
         } else {
@@ -334,8 +346,9 @@ __device__ __forceinline__ void tri_node_solve(const int t, const int lane, cons
     }
 #undef TRI_REFRESH
 #pragma unroll
+    for (int j = 0; j < CB; ++j) cA[j] = cN[j];
+#pragma unroll
     for (int j = 0; j < B; ++j) {
-      cA[j] = cN[j];
 #pragma unroll
       for (int k = 0; k < NB; ++k) aA[j * NB + k] = aN[j * NB + k];
     }
@@ -354,8 +367,9 @@ __device__ __forceinline__ void tri_node_solve(const int t, const int lane, cons
 #pragma unroll
     for (int k = 0; k < NB; ++k)
       if (k < nsz) {
-        if (POLL) __hip_atomic_store(w + (size_t)k * np + t, sum[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else w[(size_t)k * np + t] = sum[k];
+        double *dst = BLK ? w + (size_t)t * NB + k : w + (size_t)k * np + t;
+        if (POLL) __hip_atomic_store(dst, sum[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else *dst = sum[k];
       }
   } else {
     double xr[NB];
@@ -367,16 +381,18 @@ __device__ __forceinline__ void tri_node_solve(const int t, const int lane, cons
         for (int l = 0; l < k; ++l) sum[k] -= dn[k * (k - 1) / 2 + (k - 1 - l)] * xr[l];   // nearest row last (inode.c:2604-2610)
         xr[k] = sum[k] * dn[NT + k];
         const int kk = nsz - 1 - k;            // the row's slot counts from the node's FIRST row
-        if (POLL) __hip_atomic_store(w + (size_t)kk * np + t, xr[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else w[(size_t)kk * np + t] = xr[k];
+        double *dst = BLK ? w + (size_t)t * NB + kk : w + (size_t)kk * np + t;
+        if (POLL) __hip_atomic_store(dst, xr[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else *dst = xr[k];
         y[row0 + kk] = xr[k];
       }
     }
   }
   TRI_NSTAMP(7);
+#undef TRI_XADDR
 }
 
-template <int NB, bool UPPER>
+template <int NB, bool UPPER, bool BLK>
 __global__ __launch_bounds__(MI355X_BLOCK) void trisolve_node_kernel(
     int nslices, int nchunks, int np, const int *__restrict__ ptr, const int *__restrict__ info, const int *__restrict__ rowof,
     const unsigned char *__restrict__ nszof, const int *__restrict__ col, const double *__restrict__ val, const double *__restrict__ din,
@@ -386,7 +402,7 @@ __global__ __launch_bounds__(MI355X_BLOCK) void trisolve_node_kernel(
   const int tid = threadIdx.x, lane = tid & (MI355X_WAVE - 1), wave = tid / MI355X_WAVE;
   if (blockIdx.x == 0 && tid < TRI_QUEUES) other_queue[tid * TRI_QSTRIDE] = 0u;
   if (!UPPER) {   // the upper solve's slots beyond this plan's own positions are re-armed here
-    for (long i = (long)NB * np + (long)blockIdx.x * MI355X_BLOCK + tid; i < reset_n; i += (long)gridDim.x * MI355X_BLOCK)
+    for (long i = (long)NB * np + (long)blockIdx.x * blockDim.x + tid; i < reset_n; i += (long)gridDim.x * blockDim.x)
       reset[i] = __longlong_as_double((long long)TRI_SENTINEL);
   }
   const int q = blockIdx.x % TRI_QUEUES;
@@ -398,7 +414,7 @@ __global__ __launch_bounds__(MI355X_BLOCK) void trisolve_node_kernel(
     __syncthreads();
     const int chunk = chunk_s[it & 1];
     if (chunk >= nchunks || chunk < 0) break;
-    const int s = chunk * (MI355X_BLOCK / MI355X_WAVE) + wave;
+    const int s = chunk * (int)(blockDim.x / MI355X_WAVE) + wave;
     if (s >= nslices) continue;
     const int t = s * MI355X_WAVE + lane;
     const int inf = info[t], row0 = rowof[t], nsz = nszof[t];
@@ -406,15 +422,303 @@ __global__ __launch_bounds__(MI355X_BLOCK) void trisolve_node_kernel(
     const int ns = nsub[s];
     if (!UPPER) {   // re-arm the other (upper) solve's slots of this position: its previous application is complete
 #pragma unroll
-      for (int k = 0; k < NB; ++k) { const long i = (long)k * np + t; if (i < reset_n) reset[i] = __longlong_as_double((long long)TRI_SENTINEL); }
+      for (int k = 0; k < NB; ++k) { const long i = BLK ? (long)t * NB + k : (long)k * np + t; if (i < reset_n) reset[i] = __longlong_as_double((long long)TRI_SENTINEL); }
     }
     for (int step = 0; step < ns; ++step)
       if (row0 >= 0 && mysub == step)
-        tri_node_solve<NB, UPPER, true>(t, lane, np, ptr[s], ncol, row0, nsz, col, val, din, src, spos, w, y, reset, abort_flag, sleep_cap);
+        tri_node_solve<NB, UPPER, true, BLK>(t, lane, np, ptr[s], BLK ? 0 : (((ptr[s + 1] - ptr[s]) / MI355X_WAVE - ncol) & ~1), ncol, row0, nsz, col, val, din, src, spos, w, y,
+                                             reset, abort_flag, sleep_cap);
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Split-role form of the node-blocked sync-free solve.  A wavefront's vector-memory operations return in issue order, so in the
+// kernel above every poll of a solution value waits behind the index / value loads issued before it -- a round trip to HBM under
+// load (2-3 us measured, profiles/r03_tri_variants.log) per batch of columns, on the dependency chain.  Here a workgroup is two
+// wavefronts: the LOADER dequeues slices and streams their headers, indices and values from HBM into a ring of batches in LDS,
+// running ahead; the SOLVER's only vector-memory operations are the gathers / polls of solution values and its result stores, so
+// a poll costs one L2 / fabric round trip (0.3-0.6 us, tests/tools/probe/handoff_probe.hip).  Same plan arrays, same column
+// sequence, same pairs, same triangle: same bits as tri_node_solve.  Slices with dependent sub-steps (small levels packed into one
+// slice) are solved by the solver with tri_node_solve itself.
+// LDS: [64 B counters][2 headers][R batch stages]; counters: 0 headers produced, 1 headers consumed, 2 batches produced,
+// 3 batches consumed (monotonic; each has one writer).  LDS operations of a wavefront execute in order: data, s_waitcnt, counter.
+template <int NB> struct TriSplitGeom {
+  static constexpr int B = NB <= 3 ? 8 : 4;                     // columns per batch (as tri_node_solve without block columns)
+  static constexpr int NT = NB * (NB - 1) / 2, ND = NT + NB;
+  static constexpr int HB = 64 + 3 * 256 + (NB + ND) * 512;     // header bytes: meta, info / first row / rows per lane, right-hand sides, triangle
+  static constexpr int SB = B * 256 + B * NB * 512;             // stage bytes: B index rows, B * NB value rows
+};
+#define TRI_LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+// wait until the LDS counter reaches `need`; bounded like every other wait of these kernels: a wavefront that gives up raises the
+// abort flag and leaves, its partner's waits then run out the same way, and the application falls back to the level-by-level kernels
+__device__ __forceinline__ bool tri_lds_wait(volatile int *c, const int need, int *abort_flag) {
+  int spins = 0;
+  while (*c < need) {
+    __builtin_amdgcn_s_sleep(1);
+    if (++spins > (1 << 25)) { __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return false; }
+  }
+  asm volatile("" ::: "memory");
+  return true;
+}
+
+template <int NB, bool UPPER>
+__device__ __forceinline__ void tri_split_loader(unsigned char *lds, const int lane, const int nslices, const int np, const int R,
+                                                 const int *__restrict__ ptr, const int *__restrict__ info, const int *__restrict__ rowof,
+                                                 const unsigned char *__restrict__ nszof, const int *__restrict__ col, const double *__restrict__ val,
+                                                 const double *__restrict__ din, const unsigned char *__restrict__ nsub, const double *src,
+                                                 const int *__restrict__ spos, double *reset, const int reset_n, unsigned int *queue, int *abort_flag) {
+  using G = TriSplitGeom<NB>;
+  constexpr int B = G::B, NT = G::NT;
+  volatile int *ctl = (volatile int *)lds;
+  const int q = blockIdx.x % TRI_QUEUES;
+  int hp = 0, bp = 0;
+  for (;;) {
+    unsigned int k = 0;
+    if (lane == 0) k = __hip_atomic_fetch_add(queue + q * TRI_QSTRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    k = (unsigned int)__builtin_amdgcn_readfirstlane((int)k);
+    long sl = (long)k * TRI_QUEUES + q;
+    const int s = sl < nslices ? (int)sl : -1;
+    if (!tri_lds_wait(ctl + 1, hp - 1, abort_flag)) return;
+    unsigned char *H = lds + 64 + (hp & 1) * G::HB;
+    int *Hm = (int *)H, *Hi = (int *)(H + 64);
+    double *Hd = (double *)(H + 64 + 3 * 256);
+    if (s < 0) {
+      if (lane == 0) Hm[0] = -1;
+      TRI_LDS_FENCE();
+      ctl[0] = ++hp;
+      break;
+    }
+    const int t = s * MI355X_WAVE + lane;
+    const int base = ptr[s], maxcol = (ptr[s + 1] - base) / MI355X_WAVE, ns = nsub[s];
+    const int nbatch = ns == 1 ? (maxcol + B - 1) / B : 0;
+    if (!UPPER) {   // re-arm the other (upper) solve's slots of this position: its previous application is complete
+#pragma unroll
+      for (int kk = 0; kk < NB; ++kk) { const long i = (long)kk * np + t; if (i < reset_n) reset[i] = __longlong_as_double((long long)TRI_SENTINEL); }
+    }
+    if (ns == 1) {
+      const int inf = info[t], row0 = rowof[t], nsz = nszof[t];
+      double sum[NB], dn[NT + NB];
+#pragma unroll
+      for (int kk = 0; kk < NB; ++kk) {
+        sum[kk] = 0.0;
+        if (row0 >= 0 && kk < nsz) {
+          if (UPPER) {
+            const int p = spos[row0 + nsz - 1 - kk];
+            sum[kk] = src[p];
+            reset[p] = __longlong_as_double((long long)TRI_SENTINEL);
+          } else sum[kk] = src[row0 + kk];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < NT + (UPPER ? NB : 0); ++e) dn[e] = din[(size_t)e * np + t];
+      Hi[lane] = inf; Hi[64 + lane] = row0; Hi[128 + lane] = nsz;
+#pragma unroll
+      for (int kk = 0; kk < NB; ++kk) Hd[kk * 64 + lane] = sum[kk];
+#pragma unroll
+      for (int e = 0; e < NT + (UPPER ? NB : 0); ++e) Hd[(NB + e) * 64 + lane] = dn[e];
+    }
+    if (lane == 0) { Hm[0] = s; Hm[1] = ns; Hm[2] = nbatch; Hm[3] = maxcol; }
+    TRI_LDS_FENCE();
+    ctl[0] = ++hp;
+    if (nbatch == 0) continue;
+    // the slice's batches, the loads of batch i + 1 in flight while batch i goes to LDS
+    const int pad = nbatch * B - maxcol;
+    const int *cbase = col + base + lane;
+    const double *vbase = val + (size_t)base * NB + lane;
+    int cA[B], cB[B]; double aA[B * NB], aB[B * NB];
+#define TRI_LD_BATCH(i, cX, aX)                                                                                          \
+  do {                                                                                                                   \
+    _Pragma("unroll") for (int j = 0; j < B; ++j) {                                                                      \
+      const int qq = (i) * B + j - pad;               /* the slot: batches are aligned to the END of the slice's slots */  \
+      cX[j] = qq >= 0 ? cbase[(size_t)qq * MI355X_WAVE] : 0;                                                             \
+      _Pragma("unroll") for (int kk = 0; kk < NB; ++kk) aX[j * NB + kk] = qq >= 0 ? vbase[(size_t)(qq * NB + kk) * MI355X_WAVE] : 0.0; \
+    }                                                                                                                    \
+  } while (0)
+#define TRI_PUT_BATCH(cX, aX)                                                                                            \
+  do {                                                                                                                   \
+    if (!tri_lds_wait(ctl + 3, bp - R + 1, abort_flag)) return;                                                          \
+    unsigned char *S = lds + 64 + 2 * G::HB + (size_t)(bp % R) * G::SB;                                                  \
+    int *Si = (int *)S; double *Sv = (double *)(S + B * 256);                                                            \
+    _Pragma("unroll") for (int j = 0; j < B; ++j) Si[j * 64 + lane] = cX[j];                                             \
+    _Pragma("unroll") for (int j = 0; j < B * NB; ++j) Sv[j * 64 + lane] = aX[j];                                        \
+    TRI_LDS_FENCE();                                                                                                     \
+    ctl[2] = ++bp;                                                                                                       \
+  } while (0)
+    TRI_LD_BATCH(0, cA, aA);
+    for (int i = 0; i < nbatch; i += 2) {
+      if (i + 1 < nbatch) TRI_LD_BATCH(i + 1, cB, aB);
+      TRI_PUT_BATCH(cA, aA);
+      if (i + 1 < nbatch) {
+        if (i + 2 < nbatch) TRI_LD_BATCH(i + 2, cA, aA);
+        TRI_PUT_BATCH(cB, aB);
+      }
+    }
+#undef TRI_LD_BATCH
+#undef TRI_PUT_BATCH
   }
 }
 
 template <int NB, bool UPPER>
+__device__ __forceinline__ void tri_split_solver(unsigned char *lds, const int lane, const int np, const int R, const int *__restrict__ ptr,
+                                                 const int *__restrict__ info, const int *__restrict__ rowof, const unsigned char *__restrict__ nszof,
+                                                 const int *__restrict__ col, const double *__restrict__ val, const double *__restrict__ din,
+                                                 const double *src, const int *__restrict__ spos, double *w, double *y, double *reset,
+                                                 int *abort_flag, const int sleep_cap) {
+  using G = TriSplitGeom<NB>;
+  constexpr int B = G::B, NT = G::NT;
+  volatile int *ctl = (volatile int *)lds;
+  int hb = 0, bb = 0;
+  for (;;) {
+    if (!tri_lds_wait(ctl + 0, hb + 1, abort_flag)) return;
+    const unsigned char *H = lds + 64 + (hb & 1) * G::HB;
+    const int *Hm = (const int *)H, *Hi = (const int *)(H + 64);
+    const double *Hd = (const double *)(H + 64 + 3 * 256);
+    const int s = Hm[0];
+    if (s < 0) break;
+    const int ns = Hm[1], nbatch = Hm[2], width = Hm[3];
+    const int t = s * MI355X_WAVE + lane;
+    if (ns != 1) {   // dependent sub-steps inside the slice: the one-wavefront routine, step by step
+      TRI_LDS_FENCE();
+      ctl[1] = ++hb;
+      const int inf = info[t], row0 = rowof[t], nsz = nszof[t];
+      const int ncol = inf >> 8, mysub = inf & 255;
+      for (int step = 0; step < ns; ++step)
+        if (row0 >= 0 && mysub == step)
+          tri_node_solve<NB, UPPER, true, false>(t, lane, np, ptr[s], ((ptr[s + 1] - ptr[s]) / MI355X_WAVE - ncol) & ~1, ncol, row0, nsz, col, val, din, src, spos, w, y, reset,
+                                                 abort_flag, sleep_cap);
+      continue;
+    }
+    const int inf = Hi[lane], row0 = Hi[64 + lane], nsz = Hi[128 + lane];
+    double sum[NB], dn[NT + NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) sum[k] = Hd[k * 64 + lane];
+#pragma unroll
+    for (int e = 0; e < NT + (UPPER ? NB : 0); ++e) dn[e] = Hd[(NB + e) * 64 + lane];
+    TRI_LDS_FENCE();
+    ctl[1] = ++hb;
+    const int ncol = row0 >= 0 ? inf >> 8 : 0;
+    // this lane's column q sits in slot q + (width - ncol & ~1); batch i, entry j is slot i B + j - (nbatch B - width): the last
+    // batch holds the newest dependencies of every lane
+    const int shift = nbatch * B - width + ((width - ncol) & ~1);
+    int cA[B], cB[B]; double vA[B], vB[B];
+#ifdef MI355X_TRI_TRACE
+#define TRI_SSTAMP(k) do { if (tri_trace_buf && lane == 0) tri_trace_buf[(UPPER ? 8000000L : 0L) + (long)s * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define TRI_SSTAMP(k) do { } while (0)
+#endif
+    TRI_SSTAMP(0);
+    // gathers of batch i: its indices out of LDS, one request per column of this lane
+#define TRI_GATHER(i, cX, vX)                                                                                            \
+  do {                                                                                                                   \
+    if (!tri_lds_wait(ctl + 2, bb + (i) + 1, abort_flag)) return;                                                        \
+    const int *Si = (const int *)(lds + 64 + 2 * G::HB + (size_t)((bb + (i)) % R) * G::SB);                              \
+    _Pragma("unroll") for (int j = 0; j < B; ++j) {                                                                      \
+      cX[j] = Si[j * 64 + lane];                                                                                         \
+      vX[j] = 0.0;                                                                                                       \
+      if ((i) * B + j >= shift && (i) * B + j - shift < ncol) vX[j] = __hip_atomic_load(w + cX[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          \
+    }                                                                                                                    \
+  } while (0)
+    // batch i into the sums, two columns at a time
+#define TRI_CONSUME(i, cX, vX)                                                                                           \
+  do {                                                                                                                   \
+    const double *Sv = (const double *)(lds + 64 + 2 * G::HB + (size_t)((bb + (i)) % R) * G::SB + B * 256);              \
+    const int q0 = (i) * B - shift;                                                                                              \
+    /* values that were not there yet: ALL of the batch's pending values are requested again together, round after round   \
+     * (one memory round trip per round, however many of them are pending; bounded as tri_poll is) */                      \
+    bool pend = false;                                                                                                   \
+    _Pragma("unroll") for (int j = 0; j < B; ++j) pend = pend || (q0 + j >= 0 && q0 + j < ncol && __double_as_longlong(vX[j]) == (long long)TRI_SENTINEL); \
+    for (int spins = 0; pend;) {                                                                                         \
+      { const int kz = spins < sleep_cap ? spins + 1 : sleep_cap;                                                        \
+        for (int z = 0; z < kz; ++z) __builtin_amdgcn_s_sleep(2); }                                                      \
+      if ((++spins & 255) == 0) {                                                                                        \
+        if (spins > TRI_SPIN_LIMIT || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) {      \
+          __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);                                \
+          break;                                                                                                         \
+        }                                                                                                                \
+      }                                                                                                                  \
+      _Pragma("unroll") for (int j = 0; j < B; ++j)                                                                      \
+        if (q0 + j >= 0 && q0 + j < ncol && __double_as_longlong(vX[j]) == (long long)TRI_SENTINEL)                                     \
+          vX[j] = __hip_atomic_load(w + cX[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                              \
+      pend = false;                                                                                                      \
+      _Pragma("unroll") for (int j = 0; j < B; ++j) pend = pend || (q0 + j >= 0 && q0 + j < ncol && __double_as_longlong(vX[j]) == (long long)TRI_SENTINEL); \
+    }                                                                                                                    \
+    _Pragma("unroll") for (int j = 0; j < B; j += 2) {                                                                   \
+      if (q0 + j >= 0 && q0 + j + 1 < ncol) {                                                                                           \
+        _Pragma("unroll") for (int k = 0; k < NB; ++k) sum[k] -= Sv[(j * NB + k) * 64 + lane] * vX[j] + Sv[((j + 1) * NB + k) * 64 + lane] * vX[j + 1]; \
+      } else if (q0 + j >= 0 && q0 + j < ncol) {                                                                                        \
+        _Pragma("unroll") for (int k = 0; k < NB; ++k) sum[k] -= Sv[(j * NB + k) * 64 + lane] * vX[j];                   \
+      }                                                                                                                  \
+    }                                                                                                                    \
+    TRI_LDS_FENCE();                                                                                                     \
+    ctl[3] = bb + (i) + 1;                                                                                               \
+    if ((i) < 5) TRI_SSTAMP(1 + (i));                                                                                    \
+  } while (0)
+    if (nbatch > 0) TRI_GATHER(0, cA, vA);
+    for (int i = 0; i < nbatch; i += 2) {
+      if (i + 1 < nbatch) TRI_GATHER(i + 1, cB, vB);
+      TRI_CONSUME(i, cA, vA);
+      if (i + 1 < nbatch) {
+        if (i + 2 < nbatch) TRI_GATHER(i + 2, cA, vA);
+        TRI_CONSUME(i + 1, cB, vB);
+      }
+    }
+#undef TRI_GATHER
+#undef TRI_CONSUME
+    bb += nbatch;
+    TRI_SSTAMP(6);
+    // the couplings inside the node (as tri_node_solve)
+    if (row0 < 0) {
+    } else if (!UPPER) {
+#pragma unroll
+      for (int k = 1; k < NB; ++k) {
+        if (k < nsz) {
+#pragma unroll
+          for (int l = 0; l < k; ++l) sum[k] -= dn[k * (k - 1) / 2 + l] * sum[l];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < NB; ++k)
+        if (k < nsz) __hip_atomic_store(w + (size_t)k * np + t, sum[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      double xr[NB];
+#pragma unroll
+      for (int k = 0; k < NB; ++k) {
+        xr[k] = 0.0;
+        if (k < nsz) {
+#pragma unroll
+          for (int l = 0; l < k; ++l) sum[k] -= dn[k * (k - 1) / 2 + (k - 1 - l)] * xr[l];
+          xr[k] = sum[k] * dn[NT + k];
+          const int kk = nsz - 1 - k;
+          __hip_atomic_store(w + (size_t)kk * np + t, xr[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          y[row0 + kk] = xr[k];
+        }
+      }
+    }
+    TRI_SSTAMP(7);
+  }
+}
+
+template <int NB, bool UPPER>
+__global__ __launch_bounds__(2 * MI355X_WAVE) void trisolve_node_split_kernel(
+    int nslices, int np, int R, const int *__restrict__ ptr, const int *__restrict__ info, const int *__restrict__ rowof,
+    const unsigned char *__restrict__ nszof, const int *__restrict__ col, const double *__restrict__ val, const double *__restrict__ din,
+    const unsigned char *__restrict__ nsub, const double *src, const int *__restrict__ spos, double *w, double *y,
+    double *reset, int reset_n, unsigned int *queue, unsigned int *other_queue, int *abort_flag, int sleep_cap) {
+  extern __shared__ __align__(16) unsigned char tri_split_lds[];
+  const int tid = threadIdx.x, lane = tid & (MI355X_WAVE - 1), wave = tid / MI355X_WAVE;
+  if (tid < 16) ((int *)tri_split_lds)[tid] = 0;
+  if (blockIdx.x == 0 && tid < TRI_QUEUES) other_queue[tid * TRI_QSTRIDE] = 0u;
+  if (!UPPER) {   // the upper solve's slots beyond this plan's own positions are re-armed here
+    for (long i = (long)NB * np + (long)blockIdx.x * blockDim.x + tid; i < reset_n; i += (long)gridDim.x * blockDim.x)
+      reset[i] = __longlong_as_double((long long)TRI_SENTINEL);
+  }
+  __syncthreads();
+  if (wave == 1) tri_split_loader<NB, UPPER>(tri_split_lds, lane, nslices, np, R, ptr, info, rowof, nszof, col, val, din, nsub, src, spos, reset, reset_n, queue, abort_flag);
+  else tri_split_solver<NB, UPPER>(tri_split_lds, lane, np, R, ptr, info, rowof, nszof, col, val, din, src, spos, w, y, reset, abort_flag, sleep_cap);
+}
+
+template <int NB, bool UPPER, bool BLK>
 __global__ __launch_bounds__(MI355X_BLOCK) void trisolve_node_level_kernel(int p0, int p1, int np, const int *__restrict__ ptr, const int *__restrict__ info,
                                                                            const int *__restrict__ rowof, const unsigned char *__restrict__ nszof,
                                                                            const int *__restrict__ col, const double *__restrict__ val,
@@ -424,7 +728,8 @@ __global__ __launch_bounds__(MI355X_BLOCK) void trisolve_node_level_kernel(int p
   if (t >= p1) return;
   const int row0 = rowof[t];
   if (row0 < 0) return;
-  tri_node_solve<NB, UPPER, false>(t, t % MI355X_WAVE, np, ptr[t / MI355X_WAVE], info[t] >> 8, row0, nszof[t], col, val, din, src, spos, w, y,
+  const int sl = t / MI355X_WAVE, nc = info[t] >> 8;
+  tri_node_solve<NB, UPPER, false, BLK>(t, t % MI355X_WAVE, np, ptr[sl], BLK ? 0 : (((ptr[sl + 1] - ptr[sl]) / MI355X_WAVE - nc) & ~1), nc, row0, nszof[t], col, val, din, src, spos, w, y,
                                    (double *)nullptr, (int *)nullptr, 0);
 }
 
@@ -638,14 +943,18 @@ static int trisolve_plan_create_impl(mi355x_handle_t h, int n, int nlev, const i
 #define TRI_TRY(expr) do { const int e__ = (int)(expr); if (e__) { (void)hipStreamSynchronize(h->stream); return e__; } } while (0)
 #define TRI_FAIL() do { (void)hipStreamSynchronize(h->stream); return (int)hipErrorInvalidValue; } while (0)
 static int trisolve_plan_fill_nodes(mi355x_handle_t h, mi355x_trisolve_plan_s *p, int n, int nnodes, const int *nstart, int nlev, const int *nodelev,
-                                    const int *rp, const int *rl, const int *cj, const double *cv, const double *dinv_host, int by_level) {
+                                    const int *rp, const int *rl, const int *cj, const double *cv, const double *dinv_host, int by_level, int blk) {
   const int W = MI355X_WAVE;
   const bool upper = dinv_host != nullptr;
   p->n = n; p->upper = upper; p->by_level = by_level; p->nlev = nlev;
   int NB = 1;
   for (int u = 0; u < nnodes; ++u) { const int z = nstart[u + 1] - nstart[u]; if (z < 1 || z > 5) TRI_FAIL(); if (z > NB) NB = z; }
   if (NB < 2) TRI_FAIL();
-  p->nb = NB;
+  p->nb = NB; p->blkcols = blk ? 1 : 0;
+  if (blk) {   // block columns: every node has NB rows (NB <= 4), every shared list is a run of WHOLE dependency nodes (checked below)
+    if (NB > 4) TRI_FAIL();
+    for (int u = 0; u < nnodes; ++u) if (nstart[u + 1] - nstart[u] != NB) TRI_FAIL();
+  }
   std::vector<int> nodeof((size_t)(n > 0 ? n : 1));
   for (int u = 0; u < nnodes; ++u) for (int r = nstart[u]; r < nstart[u + 1]; ++r) nodeof[(size_t)r] = u;
   // shape check + shared column counts
@@ -666,6 +975,10 @@ static int trisolve_plan_fill_nodes(mi355x_handle_t h, mi355x_trisolve_plan_s *p
       }
     }
     for (int q = 0; q < sh; ++q) if (nodeof[(size_t)shared[q]] == u) TRI_FAIL();
+    if (blk) {
+      if (sh % NB) TRI_FAIL();
+      for (int q = 0; q < sh; ++q) if (shared[q] != nstart[nodeof[(size_t)shared[q - q % NB]]] + q % NB) TRI_FAIL();
+    }
   }
   // positions: nodes by level, more shared columns first inside a level (stable)
   std::vector<int> order((size_t)nnodes), levptr((size_t)nlev + 1, 0);
@@ -680,7 +993,9 @@ static int trisolve_plan_fill_nodes(mi355x_handle_t h, mi355x_trisolve_plan_s *p
   for (int l = 0; l < nlev; ++l) {
     const int sz = levptr[(size_t)l + 1] - levptr[(size_t)l];
     if (sz < 1) TRI_FAIL();
-    if (by_level && sz >= TRI_ALIGN_MIN && (cur % W)) cur += W - cur % W;
+    // a level of TRI_ALIGN_MIN nodes or more starts on a slice boundary, whatever the order of the columns inside the lists
+    // (positions do not enter the sums): such slices have no dependent sub-steps and take the batched path of the split-role kernels
+    if (sz >= TRI_ALIGN_MIN && (cur % W)) cur += W - cur % W;
     for (int t = levptr[(size_t)l]; t < levptr[(size_t)l + 1]; ++t) tpos[(size_t)t] = cur++;
   }
   if (cur * NB > 2147483000L) TRI_FAIL();
@@ -691,7 +1006,9 @@ static int trisolve_plan_fill_nodes(mi355x_handle_t h, mi355x_trisolve_plan_s *p
     p->levpos[2 * l + 1] = (int)tpos[(size_t)levptr[(size_t)l + 1] - 1] + 1;
   }
   p->nslices = (int)((cur + W - 1) / W);
-  p->nchunks = (p->nslices + 3) / 4;
+  { const char *e = getenv("MI355X_TRISOLVE_NODE_WAVES"); p->spw = e ? atoi(e) : 4; if (p->spw != 1 && p->spw != 2 && p->spw != 4) p->spw = 4; }
+  { const char *e = getenv("MI355X_TRISOLVE_SPLIT"); p->split = blk ? 0 : (e ? atoi(e) != 0 : 1); if (p->split) p->spw = 1; }
+  p->nchunks = (p->nslices + p->spw - 1) / p->spw;
   const size_t np = (size_t)p->nslices * W;
   p->np = (int)np;
   const int NT = NB * (NB - 1) / 2, ND = NT + NB;
@@ -702,7 +1019,7 @@ static int trisolve_plan_fill_nodes(mi355x_handle_t h, mi355x_trisolve_plan_s *p
   for (int t = 0; t < nnodes; ++t) {
     const int u = order[(size_t)t]; const long P = tpos[(size_t)t];
     posn[(size_t)u] = (int)P; rowof[(size_t)P] = nstart[u]; nszv[(size_t)P] = (unsigned char)(nstart[u + 1] - nstart[u]);
-    for (int r = nstart[u]; r < nstart[u + 1]; ++r) slot[(size_t)r] = (int)((size_t)(r - nstart[u]) * np + (size_t)P);
+    for (int r = nstart[u]; r < nstart[u + 1]; ++r) slot[(size_t)r] = blk ? (int)((size_t)P * NB + (size_t)(r - nstart[u])) : (int)((size_t)(r - nstart[u]) * np + (size_t)P);
   }
   long total = 0;
   for (int s = 0; s < p->nslices; ++s) {
@@ -718,12 +1035,17 @@ static int trisolve_plan_fill_nodes(mi355x_handle_t h, mi355x_trisolve_plan_s *p
       if (nsh[(size_t)u] > mx) mx = nsh[(size_t)u];
       if (sub + 1 > nsub[(size_t)s]) nsub[(size_t)s] = (unsigned char)(sub + 1);
     }
+    // without block columns the slice is an even number of slots wide and every lane's list ENDS at the slice's last pair of slots
+    // (an even number of padding slots first: the pairs of the reference's summation stay pairs): the newest dependencies of all
+    // lanes then sit in the slice's last batch, whatever the lengths of their lists
+    if (!blk) mx = (mx + 1) & ~1;
     ptr[(size_t)s] = (int)total;
     total += (long)mx * W;
+    if (mx > p->maxcol) p->maxcol = mx;
     if (total * NB > 2147483000L) TRI_FAIL();
   }
   ptr[(size_t)p->nslices] = (int)total;
-  std::vector<int> col((size_t)(total > 0 ? total : 1), 0);
+  std::vector<int> col((size_t)(total > 0 ? total : 1) / (blk ? NB : 1) + 1, 0);     // blk: one entry per dependency node
   std::vector<double> val((size_t)(total > 0 ? total : 1) * NB, 0.0);
   { std::atomic<int> bad(0);
     auto fill = [&](int t0, int t1) {
@@ -732,16 +1054,19 @@ static int trisolve_plan_fill_nodes(mi355x_handle_t h, mi355x_trisolve_plan_s *p
         const int u = order[(size_t)t], P = (int)tpos[(size_t)t], s = P / W, lane = P % W;
         const int r0 = nstart[u], z = nstart[u + 1] - r0, rL = r0 + z - 1, sh = nsh[(size_t)u];
         const int *shared = upper ? cj + rp[rL] : cj + rp[r0];
+        const int off = blk ? 0 : ((ptr[(size_t)s + 1] - ptr[(size_t)s]) / W - sh) & ~1;
         perm.resize((size_t)sh);
         for (int q = 0; q < sh; ++q) perm[(size_t)q] = q;
+        // (stable, and the columns of one dependency node share a level: whole nodes stay together and in their own order)
         if (by_level) std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return nodelev[nodeof[(size_t)shared[a]]] < nodelev[nodeof[(size_t)shared[b]]]; });
         for (int q = 0; q < sh; ++q) {
           const int sq = perm[(size_t)q], dep = shared[sq];
           if (posn[(size_t)nodeof[(size_t)dep]] >= P) { bad.store(1); break; }        // a dependency must come earlier
-          col[(size_t)ptr[(size_t)s] + (size_t)q * W + lane] = slot[(size_t)dep];
+          if (blk) { if (q % NB == 0) col[(size_t)ptr[(size_t)s] / NB + (size_t)(q / NB) * W + lane] = posn[(size_t)nodeof[(size_t)dep]]; }
+          else col[(size_t)ptr[(size_t)s] + (size_t)(off + q) * W + lane] = slot[(size_t)dep];
           for (int k = 0; k < z; ++k) {
             const int r = upper ? rL - k : r0 + k;
-            val[(size_t)ptr[(size_t)s] * NB + ((size_t)q * NB + k) * W + lane] = cv[rp[r] + (upper ? k : 0) + sq];
+            val[(size_t)ptr[(size_t)s] * NB + ((size_t)(off + q) * NB + k) * W + lane] = cv[rp[r] + (upper ? k : 0) + sq];
           }
         }
         for (int k = 0; k < z; ++k) {
@@ -780,9 +1105,9 @@ static int trisolve_plan_fill_nodes(mi355x_handle_t h, mi355x_trisolve_plan_s *p
   hipDeviceProp_t prop;
   TRI_TRY(hipGetDevice(&dev));
   TRI_TRY(hipGetDeviceProperties(&prop, dev));
-  p->grid = prop.multiProcessorCount * 2;            // register-heavy kernel: two workgroups per CU are resident for every NB
+  p->grid = prop.multiProcessorCount;                // register-heavy kernels (up to 254 VGPRs): one workgroup per CU is resident for every NB
   { const char *e = getenv("MI355X_TRISOLVE_AHEAD");
-    const long ahead = e ? atol(e) : 4;
+    const long ahead = e ? atol(e) : (p->split ? 16 : 4);      // (split-role kernels: profiles/r03_tri_variants.log, 21.9 ms at 4, 19.2 at 16, 19.1 at 64)
     const long per_level = ((long)p->nchunks + nlev - 1) / (nlev > 0 ? nlev : 1);
     long g = ahead * per_level;
     if (g < TRI_QUEUES) g = TRI_QUEUES;
@@ -797,11 +1122,11 @@ static int trisolve_plan_fill_nodes(mi355x_handle_t h, mi355x_trisolve_plan_s *p
 #undef TRI_FAIL
 
 int mi355x_trisolve_plan_create_nodes(mi355x_handle_t h, int n, int nnodes, const int *nstart, int nlev, const int *nodelev, const int *rp, const int *rl,
-                                      const int *cj, const double *cv, const double *dinv_host, int by_level, mi355x_trisolve_plan_t *out) {
+                                      const int *cj, const double *cv, const double *dinv_host, int by_level, int block_columns, mi355x_trisolve_plan_t *out) {
   mi355x_trisolve_plan_s *p = new mi355x_trisolve_plan_s();
   memset(p, 0, sizeof(*p));
   *out = nullptr;
-  const int rc = trisolve_plan_fill_nodes(h, p, n, nnodes, nstart, nlev, nodelev, rp, rl, cj, cv, dinv_host, by_level);
+  const int rc = trisolve_plan_fill_nodes(h, p, n, nnodes, nstart, nlev, nodelev, rp, rl, cj, cv, dinv_host, by_level, block_columns);
   if (rc) { mi355x_trisolve_plan_destroy(p); return rc; }
   *out = p;
   return 0;
@@ -809,15 +1134,39 @@ int mi355x_trisolve_plan_create_nodes(mi355x_handle_t h, int n, int nnodes, cons
 
 }  // extern "C"
 
-template <int NB>
+template <int NB, bool BLK>
 static int tri_node_go(mi355x_handle_t h, mi355x_trisolve_plan_t lo, mi355x_trisolve_plan_t up, const double *b, double *y, bool levels) {
-  if (!levels) {
+  if (!levels && !BLK && lo->split && up->split) {
+    // split-role kernels: the LDS ring holds a whole slice's batches (and a spare one) where that fits
+    using G = TriSplitGeom<NB>;
     const int glo = lo->grid < TRI_QUEUES ? TRI_QUEUES : lo->grid, gup = up->grid < TRI_QUEUES ? TRI_QUEUES : up->grid;
-    hipLaunchKernelGGL((trisolve_node_kernel<NB, false>), dim3(glo), dim3(MI355X_BLOCK), 0, h->stream, lo->nslices, lo->nchunks, lo->np, lo->d_ptr, lo->d_info,
+    const int rmax = (int)((150 * 1024 - 64 - 2 * G::HB) / G::SB);
+    auto ring = [&](int maxcol) { int r = (maxcol + G::B - 1) / G::B + 1; if (r < 3) r = 3; if (r > rmax) r = rmax; return r; };
+    const int rlo = ring(lo->maxcol), rup = ring(up->maxcol);
+    const size_t blo = 64 + 2 * (size_t)G::HB + (size_t)rlo * G::SB, bup = 64 + 2 * (size_t)G::HB + (size_t)rup * G::SB;
+    static bool attr_set = false;     // (per NB: this function is a template)
+    if (!attr_set) {
+      MI355X_TRY(hipFuncSetAttribute((const void *)trisolve_node_split_kernel<NB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+      MI355X_TRY(hipFuncSetAttribute((const void *)trisolve_node_split_kernel<NB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((trisolve_node_split_kernel<NB, false>), dim3(glo), dim3(2 * MI355X_WAVE), blo, h->stream, lo->nslices, lo->np, rlo, lo->d_ptr, lo->d_info,
                        lo->d_row, lo->d_nsz, lo->d_col, lo->d_val, lo->d_din, lo->d_nsub, b, (const int *)nullptr, lo->d_w, (double *)nullptr, up->d_w,
                        up->np * NB, lo->d_queue, up->d_queue, lo->abort_flag, lo->sleep_cap);
     MI355X_LAUNCH_CHECK();
-    hipLaunchKernelGGL((trisolve_node_kernel<NB, true>), dim3(gup), dim3(MI355X_BLOCK), 0, h->stream, up->nslices, up->nchunks, up->np, up->d_ptr, up->d_info,
+    hipLaunchKernelGGL((trisolve_node_split_kernel<NB, true>), dim3(gup), dim3(2 * MI355X_WAVE), bup, h->stream, up->nslices, up->np, rup, up->d_ptr, up->d_info,
+                       up->d_row, up->d_nsz, up->d_col, up->d_val, up->d_din, up->d_nsub, lo->d_w, lo->d_pos, up->d_w, y, lo->d_w, 0, up->d_queue,
+                       lo->d_queue, up->abort_flag, up->sleep_cap);
+    MI355X_LAUNCH_CHECK();
+    return 0;
+  }
+  if (!levels) {
+    const int glo = lo->grid < TRI_QUEUES ? TRI_QUEUES : lo->grid, gup = up->grid < TRI_QUEUES ? TRI_QUEUES : up->grid;
+    hipLaunchKernelGGL((trisolve_node_kernel<NB, false, BLK>), dim3(glo), dim3(lo->spw * MI355X_WAVE), 0, h->stream, lo->nslices, lo->nchunks, lo->np, lo->d_ptr, lo->d_info,
+                       lo->d_row, lo->d_nsz, lo->d_col, lo->d_val, lo->d_din, lo->d_nsub, b, (const int *)nullptr, lo->d_w, (double *)nullptr, up->d_w,
+                       up->np * NB, lo->d_queue, up->d_queue, lo->abort_flag, lo->sleep_cap);
+    MI355X_LAUNCH_CHECK();
+    hipLaunchKernelGGL((trisolve_node_kernel<NB, true, BLK>), dim3(gup), dim3(up->spw * MI355X_WAVE), 0, h->stream, up->nslices, up->nchunks, up->np, up->d_ptr, up->d_info,
                        up->d_row, up->d_nsz, up->d_col, up->d_val, up->d_din, up->d_nsub, lo->d_w, lo->d_pos, up->d_w, y, lo->d_w, 0, up->d_queue,
                        lo->d_queue, up->abort_flag, up->sleep_cap);
     MI355X_LAUNCH_CHECK();
@@ -825,25 +1174,33 @@ static int tri_node_go(mi355x_handle_t h, mi355x_trisolve_plan_t lo, mi355x_tris
   }
   for (int l = 0; l < lo->nlev; ++l) {
     const int p0 = lo->levpos[2 * l], p1 = lo->levpos[2 * l + 1];
-    hipLaunchKernelGGL((trisolve_node_level_kernel<NB, false>), dim3((p1 - p0 + MI355X_BLOCK - 1) / MI355X_BLOCK), dim3(MI355X_BLOCK), 0, h->stream, p0, p1, lo->np,
+    hipLaunchKernelGGL((trisolve_node_level_kernel<NB, false, BLK>), dim3((p1 - p0 + MI355X_BLOCK - 1) / MI355X_BLOCK), dim3(MI355X_BLOCK), 0, h->stream, p0, p1, lo->np,
                        lo->d_ptr, lo->d_info, lo->d_row, lo->d_nsz, lo->d_col, lo->d_val, lo->d_din, b, (const int *)nullptr, lo->d_w, (double *)nullptr);
     MI355X_LAUNCH_CHECK();
   }
   for (int l = 0; l < up->nlev; ++l) {
     const int p0 = up->levpos[2 * l], p1 = up->levpos[2 * l + 1];
-    hipLaunchKernelGGL((trisolve_node_level_kernel<NB, true>), dim3((p1 - p0 + MI355X_BLOCK - 1) / MI355X_BLOCK), dim3(MI355X_BLOCK), 0, h->stream, p0, p1, up->np,
+    hipLaunchKernelGGL((trisolve_node_level_kernel<NB, true, BLK>), dim3((p1 - p0 + MI355X_BLOCK - 1) / MI355X_BLOCK), dim3(MI355X_BLOCK), 0, h->stream, p0, p1, up->np,
                        up->d_ptr, up->d_info, up->d_row, up->d_nsz, up->d_col, up->d_val, up->d_din, lo->d_w, lo->d_pos, up->d_w, y);
     MI355X_LAUNCH_CHECK();
   }
   return 0;
 }
 static int tri_node_dispatch(mi355x_handle_t h, mi355x_trisolve_plan_t lo, mi355x_trisolve_plan_t up, const double *b, double *y, bool levels) {
-  if (lo->nb != up->nb) return (int)hipErrorInvalidValue;
+  if (lo->nb != up->nb || lo->blkcols != up->blkcols) return (int)hipErrorInvalidValue;
+  if (lo->blkcols) {
+    switch (lo->nb) {
+    case 2: return tri_node_go<2, true>(h, lo, up, b, y, levels);
+    case 3: return tri_node_go<3, true>(h, lo, up, b, y, levels);
+    case 4: return tri_node_go<4, true>(h, lo, up, b, y, levels);
+    default: return (int)hipErrorInvalidValue;
+    }
+  }
   switch (lo->nb) {
-  case 2: return tri_node_go<2>(h, lo, up, b, y, levels);
-  case 3: return tri_node_go<3>(h, lo, up, b, y, levels);
-  case 4: return tri_node_go<4>(h, lo, up, b, y, levels);
-  case 5: return tri_node_go<5>(h, lo, up, b, y, levels);
+  case 2: return tri_node_go<2, false>(h, lo, up, b, y, levels);
+  case 3: return tri_node_go<3, false>(h, lo, up, b, y, levels);
+  case 4: return tri_node_go<4, false>(h, lo, up, b, y, levels);
+  case 5: return tri_node_go<5, false>(h, lo, up, b, y, levels);
   default: return (int)hipErrorInvalidValue;
   }
 }

@@ -146,6 +146,7 @@ typedef struct {
   PetscScalar *d_work; void *graph; int graph_tried;       /* hipGraph of the level launches working in place on d_work */
   mi355x_trisolve_plan_t tri_lo, tri_up;                   /* sync-free solves (NULL: level launches) */
   int by_level;                                            /* rows summed in dependency-level order (inode matrices) instead of column order */
+  int block_columns;                                       /* node plans whose columns are whole dependency nodes */
   PetscInt nodes, nlevL_nodes, nlevU_nodes;                /* node-blocked plans (the factor of a matrix with inodes): nodes and their levels; 0: row-granular */
   int use_levels, aborted;                                 /* a sync-free application gave up: the same plans run level by level from now on */
   PetscInt nshift;                                         /* restarts / shifts the factorisation took (largest count over the blocks) */

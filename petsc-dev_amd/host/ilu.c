@@ -408,13 +408,18 @@ static PetscErrorCode ilu0_analyse_and_upload(Mat F, Mat A) {
             nlevU[u] = l; nlU = PetscMax(nlU, l + 1);
           }
           by_level = set ? !strcmp(ord, "level") : 1;
-          rc = mi355x_trisolve_plan_create_nodes(dc->h, n, nodes, nstart, nlL, nlevL, bi, rlL, bj, ba, NULL, by_level, &f->tri_lo);
-          if (!rc) rc = mi355x_trisolve_plan_create_nodes(dc->h, n, nodes, nstart, nlU, nlevU, rpU, rlU, bj, ba, dinv, by_level, &f->tri_up);
-          if (rc) {   /* not the shape of an inode factor after all: row-granular plans below */
-            if (f->tri_lo) mi355x_trisolve_plan_destroy(f->tri_lo);
+          /* on request first with whole dependency nodes as columns (a fixed number of dofs per node: one gather per dependency
+           * node; measured no faster, so not the default), then the general node plans, then (below) row by row */
+          PetscInt bc = 0; PetscBool bset;
+          ierr = PetscOptionsGetInt(HipObjPrefix(F), "-pc_factor_hipmi355x_trisolve_block_columns", &bc, &bset);CHKERRQ(ierr);
+          for (int blk = bc ? 1 : 0; blk >= 0; blk--) {
+            rc = mi355x_trisolve_plan_create_nodes(dc->h, n, nodes, nstart, nlL, nlevL, bi, rlL, bj, ba, NULL, by_level, blk, &f->tri_lo);
+            if (!rc) rc = mi355x_trisolve_plan_create_nodes(dc->h, n, nodes, nstart, nlU, nlevU, rpU, rlU, bj, ba, dinv, by_level, blk, &f->tri_up);
+            if (!rc) { f->nodes = nodes; f->nlevL_nodes = nlL; f->nlevU_nodes = nlU; f->by_level = by_level; f->block_columns = blk; break; }
+            if (f->tri_lo) mi355x_trisolve_plan_destroy(f->tri_lo);      /* not of that shape: the next, more general form */
             if (f->tri_up) mi355x_trisolve_plan_destroy(f->tri_up);
             f->tri_lo = f->tri_up = NULL;
-          } else { f->nodes = nodes; f->nlevL_nodes = nlL; f->nlevU_nodes = nlU; f->by_level = by_level; }
+          }
         }
         HipFree(nstart); HipFree(nodeof); HipFree(nlevL); HipFree(nlevU);
       }
@@ -635,7 +640,7 @@ PetscErrorCode PCILUGetShiftCount_HIPMI355X(PC pc, PetscInt *nshift) {
 PetscErrorCode PCILUGetNodeInfo_HIPMI355X(PC pc, PetscInt *nodes, PetscInt *nlevL, PetscInt *nlevU) {
   HipTriFactors *f;
   PetscErrorCode ierr = pc_factors(pc, MAT_FACTOR_ILU, &f);CHKERRQ(ierr);
-  if (nodes) *nodes = f->nodes;
+  if (nodes) *nodes = f->nodes ? (f->block_columns ? -f->nodes : f->nodes) : 0;   /* negative: block-column plans */
   if (nlevL) *nlevL = f->nlevL_nodes;
   if (nlevU) *nlevU = f->nlevU_nodes;
   return 0;

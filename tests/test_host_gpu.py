@@ -1237,13 +1237,14 @@ def test_ilu0_syncfree_solves_on_irregular_factors(P, shape):
     assert sf.value == 1 and ab.value == 0
     nn, nlL, nlU = C.c_int(), C.c_int(), C.c_int()
     L.PCILUGetNodeInfo_HIPMI355X(pc, C.byref(nn), C.byref(nlL), C.byref(nlU))
-    assert nn.value == nodes
+    assert abs(nn.value) == nodes                      # (negative: the node plans whose columns are whole dependency nodes)
     if nodes:
         rl, ru = C.c_int(), C.c_int(); L.PCILUGetLevels_HIPMI355X(pc, C.byref(rl), C.byref(ru))
         assert 0 < nlL.value < rl.value and 0 < nlU.value < ru.value          # levels over nodes: fewer than over rows
         # row-granular plans on request: column order = the natural-ordering loop's bits; level order agrees to rounding
         for opts, exact in (("-pc_factor_hipmi355x_trisolve_nodes 0 -pc_factor_hipmi355x_trisolve_order column", "natural"),
                             ("-pc_factor_hipmi355x_trisolve_order column", "inode"),
+                            ("-pc_factor_hipmi355x_trisolve_order column -pc_factor_hipmi355x_trisolve_block_columns 1", "inode"),
                             ("-pc_factor_hipmi355x_trisolve_nodes 0", False), ("-pc_factor_hipmi355x_trisolve_order level", False)):
             k2 = P.KSP(comm=L.COMM_SELF); k2.set_operators(A); pc2 = C.c_void_p(); L.KSPGetPC(k2.h, C.byref(pc2)); L.PCSetType(pc2, b"ilu")
             set_options(L, "-pc_factor_hipmi355x_trisolve syncfree " + opts)
@@ -1261,8 +1262,9 @@ def test_ilu0_syncfree_solves_on_irregular_factors(P, shape):
                 assert np.array_equal(bits(vx.array()), bits(first))
 
 
+@pytest.mark.parametrize("form", ["split", "onewave", "blockcols"])
 @pytest.mark.parametrize("seed", range(6))
-def test_ilu0_node_blocked_solves_carry_the_bits_of_the_inode_routine(P, seed):
+def test_ilu0_node_blocked_solves_carry_the_bits_of_the_inode_routine(P, seed, form, monkeypatch):
     """MatSolve_SeqAIJ_Inode on the device: factors of matrices whose rows form nodes of 1..5 rows (a random node graph, every node a
     dense block of dofs: what a FEM matrix with a varying number of dofs per node looks like).  The node-blocked sync-free plans walk
     a node's shared column list once, two columns at a time, then solve the node's triangle -- the reference routine's order (inode.c:
@@ -1294,11 +1296,17 @@ def test_ilu0_node_blocked_solves_carry_the_bits_of_the_inode_routine(P, seed):
     A = P.Mat.from_csr(ai, aj, aa)
     pc = C.c_void_p()
     k = P.KSP(comm=L.COMM_SELF); k.set_operators(A); L.KSPGetPC(k.h, C.byref(pc)); L.PCSetType(pc, b"ilu")
-    set_options(L, "-pc_factor_hipmi355x_trisolve syncfree -pc_factor_hipmi355x_trisolve_order column")
+    # the three kernel forms over the same plans: loader + solver wavefront per workgroup (the default), one wavefront doing both
+    # (MI355X_TRISOLVE_SPLIT=0, read when the plan is made), whole dependency nodes as columns (on request)
+    blockcols = 1 if form == "blockcols" else 0
+    monkeypatch.setenv("MI355X_TRISOLVE_SPLIT", "0" if form == "onewave" else "1")
+    set_options(L, "-pc_factor_hipmi355x_trisolve syncfree -pc_factor_hipmi355x_trisolve_order column -pc_factor_hipmi355x_trisolve_block_columns %d" % blockcols)
     L.raw("PCSetUp")(pc)
     set_options(L, "")
     got = C.c_int(); L.PCILUGetNodeInfo_HIPMI355X(pc, C.byref(got), None, None)
-    assert got.value == nodes
+    assert abs(got.value) == nodes
+    uniform = bool(np.all(dof == dof[0])) and dof[0] <= 4 and bool(np.all(ns == dof[0]))
+    assert (got.value < 0) == (uniform and blockcols == 1)      # on request, with a fixed number of dofs per node: whole dependency nodes as columns
     f = orc.ilu0_factor(ai, aj, aa)
     vb, vx = V(P, np.zeros(n)), V(P, np.zeros(n))
     for rep in range(3):
@@ -1308,6 +1316,43 @@ def test_ilu0_node_blocked_solves_carry_the_bits_of_the_inode_routine(P, seed):
     L.PCFactorDebugSetAborted_HIPMI355X(pc)          # the same plans, one launch per node level
     L.raw("PCApply")(pc, vb.h, vx.h)
     assert np.array_equal(bits(vx.array()), bits(orc.ilu0_solve_inode(f, ns, b)))
+
+
+@pytest.mark.parametrize("dof,order", [(3, "column"), (3, "level"), (2, "column"), (4, "column"), (5, "column"), (5, "level")])
+def test_ilu0_split_role_solves_on_fem_factors(P, dof, order):
+    """The batched path of the split-role node kernels (a loader and a solver wavefront per workgroup, the slice's indices and
+    values through a ring in LDS, batches aligned to the END of every lane's column list): FEM-like factors with `dof` rows per
+    node, wide dependency levels (slices without dependent sub-steps), five and more batches per slice.  Columns in column order =
+    MatSolve_SeqAIJ_Inode's bits (inode.c:2327-2760); in dependency-level order to rounding, and deterministic."""
+    L = P.lib()
+    ai, aj, aa = pb.gen_fem3(ex=60, ey=50, ez=10, dof=dof, seed=40 + dof) if dof == 3 else pb.gen_fem3(ex=40, ey=36, ez=12, dof=dof, seed=40 + dof)
+    n = ai.size - 1
+    nodes, ns = orc.check_inode(ai, aj)
+    assert nodes > 0 and ns.max() == dof
+    A = P.Mat.from_csr(ai, aj, aa)
+    pc = C.c_void_p()
+    k = P.KSP(comm=L.COMM_SELF); k.set_operators(A); L.KSPGetPC(k.h, C.byref(pc)); L.PCSetType(pc, b"ilu")
+    set_options(L, "-pc_factor_hipmi355x_trisolve syncfree -pc_factor_hipmi355x_trisolve_order %s" % order)
+    L.raw("PCSetUp")(pc)
+    set_options(L, "")
+    got, nlL, nlU = C.c_int(), C.c_int(), C.c_int(); L.PCILUGetNodeInfo_HIPMI355X(pc, C.byref(got), C.byref(nlL), C.byref(nlU))
+    assert got.value == nodes and nodes / nlL.value > 20          # wide levels: about half of them fill whole slices
+    f = orc.ilu0_factor(ai, aj, aa)
+    vb, vx = V(P, np.zeros(n)), V(P, np.zeros(n))
+    for rep in range(3):
+        b = rnd(n, 700 + rep); vb.set_array(b)
+        L.raw("PCApply")(pc, vb.h, vx.h)
+        ref = orc.ilu0_solve_inode(f, ns, b)
+        if order == "column":
+            assert np.array_equal(bits(vx.array()), bits(ref)), (dof, rep)
+        else:
+            assert np.linalg.norm(vx.array() - ref) <= 1e-13 * np.linalg.norm(ref)
+            first = vx.array().copy()
+            L.raw("PCApply")(pc, vb.h, vx.h)
+            assert np.array_equal(bits(vx.array()), bits(first))
+    sf, ab = C.c_int(), C.c_int()
+    L.PCILUGetSolver_HIPMI355X(pc, C.byref(sf), C.byref(ab))
+    assert sf.value == 1 and ab.value == 0
 
 
 @pytest.mark.parametrize("name,nblocks,err,nits", [("ex2_bjacobi_2.out", 2, "0.000496964", 4), ("ex2_bjacobi_3.out", 4, "0.000404746", 7)])

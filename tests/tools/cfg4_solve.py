@@ -48,7 +48,7 @@ def main():
         pc = C.c_void_p(); L.KSPGetPC(ksp.h, C.byref(pc))
         nl, nu = C.c_int(), C.c_int(); L.PCILUGetLevels_HIPMI355X(pc, C.byref(nl), C.byref(nu))
         nn, nnl, nnu = C.c_int(), C.c_int(), C.c_int(); L.PCILUGetNodeInfo_HIPMI355X(pc, C.byref(nn), C.byref(nnl), C.byref(nnu))
-        print("ILU(0) plans: %s" % ("node-blocked, %d nodes, node levels L=%d U=%d" % (nn.value, nnl.value, nnu.value) if nn.value else "row-granular"), flush=True)
+        print("ILU(0) plans: %s" % ("node-blocked%s, %d nodes, node levels L=%d U=%d" % (" (whole dependency nodes as columns)" if nn.value < 0 else "", abs(nn.value), nnl.value, nnu.value) if nn.value else "row-granular"), flush=True)
         for _ in range(3):
             L.raw("PCApply")(pc, b.h, u.h)
         k.mi355x_device_synchronize()

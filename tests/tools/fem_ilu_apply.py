@@ -39,7 +39,7 @@ def main():
     sf, ab = C.c_int(), C.c_int(); L.PCILUGetSolver_HIPMI355X(pc, C.byref(sf), C.byref(ab))
     lev = (nnl.value + nnu.value) if nn.value else (nl.value + nu.value)
     print("fem %s n=%d: set-up %.2f s; %s, %d levels; PCApply %.3f ms = %.2f us per level; aborted=%d  [%s lib=%s ahead=%s sleep=%s]"
-          % ("x".join(map(str, dims)), n, tset, "node plans (%d nodes)" % nn.value if nn.value else "row plans", lev, t * 1e3, t * 1e6 / max(lev, 1), ab.value,
+          % ("x".join(map(str, dims)), n, tset, ("node plans (%d nodes%s)" % (abs(nn.value), ", block columns" if nn.value < 0 else "")) if nn.value else "row plans", lev, t * 1e3, t * 1e6 / max(lev, 1), ab.value,
              os.environ.get("FEM_OPTS", ""), os.path.basename(os.environ.get("MI355X_KERNELS_LIB", "default")), os.environ.get("MI355X_TRISOLVE_AHEAD", "-"), os.environ.get("MI355X_TRISOLVE_SLEEP", "-")), flush=True)
 
 

@@ -38,6 +38,21 @@ def main():
     k.mi355x_device_synchronize()
     t = np.zeros(nslots, dtype=np.int64)
     k.mi355x_memcpy_d2h(h, t.ctypes.data, buf, 8 * nslots); k.mi355x_handle_synchronize(h)
+    raw = t[:8000000].reshape(-1, 8).astype(np.float64) * 0.01     # the lower solve, slice by slice
+    s0 = int(os.environ.get("TRACE_SLICE", "4000"))
+    base = raw[s0:s0 + 24][raw[s0:s0 + 24, 0] > 0][:, 0].min()
+    print("slices %d.. in slice order (us, relative): start b0 b1 b2 b3 b4 lastdep stored" % s0)
+    for i in range(s0, s0 + 24):
+        print("  %6d: " % i + "  ".join("%8.2f" % (v - base if v > 0 else -1) for v in raw[i]))
+    # how far ahead of the solve's front does a slice start?  (slices before it that are not stored yet when it starts)
+    ok = raw[:, 7] > 0
+    ns_ = int(np.nonzero(ok)[0].max()) + 1
+    st, en = raw[:ns_, 0], raw[:ns_, 7]
+    depth = []
+    for i in range(2000, min(ns_, 7000), 37):
+        lo_ = max(0, i - 600)
+        depth.append(int(np.sum(en[lo_:i] > st[i])))
+    print("slices before a slice that are still unfinished when it starts: median %d, 10%% %d, 90%% %d" % (np.median(depth), np.percentile(depth, 10), np.percentile(depth, 90)))
     t = t[:8000000].reshape(-1, 8)                     # the lower solve
     t = t[t[:, 7] > 0].astype(np.float64) * 0.01      # 100 MHz -> microseconds
     t -= t[:, 0].min()
