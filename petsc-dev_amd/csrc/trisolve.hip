@@ -8,6 +8,8 @@
 #include <algorithm>
 #include <thread>
 #include <atomic>
+#include <chrono>
+#include <memory>
 #include <string.h>
 #include <stdlib.h>
 
@@ -946,6 +948,11 @@ static int trisolve_plan_fill_nodes(mi355x_handle_t h, mi355x_trisolve_plan_s *p
                                     const int *rp, const int *rl, const int *cj, const double *cv, const double *dinv_host, int by_level, int blk) {
   const int W = MI355X_WAVE;
   const bool upper = dinv_host != nullptr;
+  // MI355X_TRISOLVE_TIMING: where the set-up time of a plan goes (stderr)
+  const bool timing = getenv("MI355X_TRISOLVE_TIMING") != nullptr;
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double tlast = now();
+  auto tick = [&](const char *what) { if (timing) { const double t = now(); fprintf(stderr, "[mi355x trisolve plan %s] %-28s %.3f s\n", upper ? "U" : "L", what, t - tlast); tlast = t; } };
   p->n = n; p->upper = upper; p->by_level = by_level; p->nlev = nlev;
   int NB = 1;
   for (int u = 0; u < nnodes; ++u) { const int z = nstart[u + 1] - nstart[u]; if (z < 1 || z > 5) TRI_FAIL(); if (z > NB) NB = z; }
@@ -959,27 +966,41 @@ static int trisolve_plan_fill_nodes(mi355x_handle_t h, mi355x_trisolve_plan_s *p
   for (int u = 0; u < nnodes; ++u) for (int r = nstart[u]; r < nstart[u + 1]; ++r) nodeof[(size_t)r] = u;
   // shape check + shared column counts
   std::vector<int> nsh((size_t)nnodes);
-  for (int u = 0; u < nnodes; ++u) {
-    const int r0 = nstart[u], z = nstart[u + 1] - r0, rL = r0 + z - 1;
-    const int sh = upper ? rl[rL] : rl[r0];
-    nsh[(size_t)u] = sh;
-    const int *shared = upper ? cj + rp[rL] : cj + rp[r0];
-    for (int k = 0; k < z; ++k) {
-      const int r = upper ? rL - k : r0 + k;
-      if (rl[r] != sh + k) TRI_FAIL();
-      const int *mine = cj + rp[r] + (upper ? k : 0);              // where this row's copy of the shared list starts
-      for (int q = 0; q < sh; ++q) if (mine[q] != shared[q]) TRI_FAIL();
-      for (int l = 0; l < k; ++l) {                                // the k couplings inside the node
-        const int c = upper ? cj[rp[r] + l] : cj[rp[r] + sh + l];
-        if (c != (upper ? r + 1 + l : r0 + l)) TRI_FAIL();
+  { std::atomic<int> bad(0);
+    auto check = [&](int u0, int u1) {
+      for (int u = u0; u < u1 && !bad.load(std::memory_order_relaxed); ++u) {
+        const int r0 = nstart[u], z = nstart[u + 1] - r0, rL = r0 + z - 1;
+        const int sh = upper ? rl[rL] : rl[r0];
+        nsh[(size_t)u] = sh;
+        const int *shared = upper ? cj + rp[rL] : cj + rp[r0];
+        for (int k = 0; k < z; ++k) {
+          const int r = upper ? rL - k : r0 + k;
+          if (rl[r] != sh + k) { bad.store(1); return; }
+          const int *mine = cj + rp[r] + (upper ? k : 0);              // where this row's copy of the shared list starts
+          for (int q = 0; q < sh; ++q) if (mine[q] != shared[q]) { bad.store(1); return; }
+          for (int l = 0; l < k; ++l) {                                // the k couplings inside the node
+            const int c = upper ? cj[rp[r] + l] : cj[rp[r] + sh + l];
+            if (c != (upper ? r + 1 + l : r0 + l)) { bad.store(1); return; }
+          }
+        }
+        for (int q = 0; q < sh; ++q) if (nodeof[(size_t)shared[q]] == u) { bad.store(1); return; }
+        if (blk) {
+          if (sh % NB) { bad.store(1); return; }
+          for (int q = 0; q < sh; ++q) if (shared[q] != nstart[nodeof[(size_t)shared[q - q % NB]]] + q % NB) { bad.store(1); return; }
+        }
       }
+    };
+    unsigned hc = std::thread::hardware_concurrency();
+    int nth = (int)(hc > 8 ? 8 : (hc < 1 ? 1 : hc));
+    if (nnodes < 100000) nth = 1;
+    if (nth == 1) check(0, nnodes);
+    else {
+      std::vector<std::thread> th;
+      for (int k = 0; k < nth; ++k) th.emplace_back(check, (int)((long)nnodes * k / nth), (int)((long)nnodes * (k + 1) / nth));
+      for (auto &t : th) t.join();
     }
-    for (int q = 0; q < sh; ++q) if (nodeof[(size_t)shared[q]] == u) TRI_FAIL();
-    if (blk) {
-      if (sh % NB) TRI_FAIL();
-      for (int q = 0; q < sh; ++q) if (shared[q] != nstart[nodeof[(size_t)shared[q - q % NB]]] + q % NB) TRI_FAIL();
-    }
-  }
+    if (bad.load()) TRI_FAIL(); }
+  tick("shape check");
   // positions: nodes by level, more shared columns first inside a level (stable)
   std::vector<int> order((size_t)nnodes), levptr((size_t)nlev + 1, 0);
   for (int u = 0; u < nnodes; ++u) { if (nodelev[u] < 0 || nodelev[u] >= nlev) TRI_FAIL(); levptr[(size_t)nodelev[u] + 1]++; }
@@ -999,6 +1020,7 @@ static int trisolve_plan_fill_nodes(mi355x_handle_t h, mi355x_trisolve_plan_s *p
     for (int t = levptr[(size_t)l]; t < levptr[(size_t)l + 1]; ++t) tpos[(size_t)t] = cur++;
   }
   if (cur * NB > 2147483000L) TRI_FAIL();
+  tick("positions");
   p->levpos = (int *)malloc(sizeof(int) * 2 * (size_t)(nlev > 0 ? nlev : 1));
   if (!p->levpos) TRI_FAIL();
   for (int l = 0; l < nlev; ++l) {
@@ -1046,7 +1068,12 @@ static int trisolve_plan_fill_nodes(mi355x_handle_t h, mi355x_trisolve_plan_s *p
   }
   ptr[(size_t)p->nslices] = (int)total;
   std::vector<int> col((size_t)(total > 0 ? total : 1) / (blk ? NB : 1) + 1, 0);     // blk: one entry per dependency node
-  std::vector<double> val((size_t)(total > 0 ? total : 1) * NB, 0.0);
+  // (zero pages from the allocator, first touched by the fill threads: a memset of the ~0.5 GB here cost 0.13 s)
+  const size_t nval = (size_t)(total > 0 ? total : 1) * NB;
+  std::unique_ptr<double, decltype(&free)> val_mem((double *)calloc(nval, sizeof(double)), &free);
+  if (!val_mem) TRI_FAIL();
+  double *val = val_mem.get();
+  tick("slice layout + allocation");
   { std::atomic<int> bad(0);
     auto fill = [&](int t0, int t1) {
       std::vector<int> perm;
@@ -1086,13 +1113,18 @@ static int trisolve_plan_fill_nodes(mi355x_handle_t h, mi355x_trisolve_plan_s *p
       for (auto &t : th) t.join();
     }
     if (bad.load()) TRI_FAIL(); }
+  tick("fill");
 #define TRI_UP(dst, vec, T) do { TRI_TRY(hipMalloc((void **)&(dst), sizeof(T) * (vec).size())); \
     TRI_TRY(hipMemcpyAsync((dst), (vec).data(), sizeof(T) * (vec).size(), hipMemcpyHostToDevice, h->stream)); } while (0)
   TRI_UP(p->d_ptr, ptr, int); TRI_UP(p->d_info, info, int); TRI_UP(p->d_row, rowof, int); TRI_UP(p->d_col, col, int);
-  TRI_UP(p->d_val, val, double); TRI_UP(p->d_nsub, nsub, unsigned char); TRI_UP(p->d_pos, slot, int);
+  TRI_TRY(hipMalloc((void **)&p->d_val, sizeof(double) * nval));
+  TRI_TRY(hipMemcpyAsync(p->d_val, val, sizeof(double) * nval, hipMemcpyHostToDevice, h->stream));
+  TRI_UP(p->d_nsub, nsub, unsigned char); TRI_UP(p->d_pos, slot, int);
   TRI_UP(p->d_nsz, nszv, unsigned char); TRI_UP(p->d_din, din, double);
 #undef TRI_UP
   const size_t nw = (np > 0 ? np : 1) * (size_t)NB;
+  TRI_TRY(hipStreamSynchronize(h->stream));
+  tick("upload");
   TRI_TRY(hipMalloc((void **)&p->d_w, sizeof(double) * nw));
   { std::vector<unsigned long long> sent(nw, TRI_SENTINEL);
     TRI_TRY(hipMemcpyAsync(p->d_w, sent.data(), sizeof(double) * sent.size(), hipMemcpyHostToDevice, h->stream));
@@ -1116,6 +1148,7 @@ static int trisolve_plan_fill_nodes(mi355x_handle_t h, mi355x_trisolve_plan_s *p
   if (p->grid >= TRI_QUEUES) p->grid -= p->grid % TRI_QUEUES;
   { const char *e = getenv("MI355X_TRISOLVE_SLEEP"); p->sleep_cap = e ? atoi(e) : (p->grid <= 128 ? 2 : 8); if (p->sleep_cap < 1) p->sleep_cap = 1; }
   TRI_TRY(hipStreamSynchronize(h->stream));
+  tick("solution slots, queues");
   return 0;
 }
 #undef TRI_TRY
@@ -1129,6 +1162,28 @@ int mi355x_trisolve_plan_create_nodes(mi355x_handle_t h, int n, int nnodes, cons
   const int rc = trisolve_plan_fill_nodes(h, p, n, nnodes, nstart, nlev, nodelev, rp, rl, cj, cv, dinv_host, by_level, block_columns);
   if (rc) { mi355x_trisolve_plan_destroy(p); return rc; }
   *out = p;
+  return 0;
+}
+
+int mi355x_trisolve_plan_create_nodes_pair(mi355x_handle_t h, int n, int nnodes, const int *nstart, int by_level, int block_columns,
+                                           int nlev_lo, const int *nodelev_lo, const int *rp_lo, const int *rl_lo,
+                                           int nlev_up, const int *nodelev_up, const int *rp_up, const int *rl_up,
+                                           const int *cj, const double *cv, const double *dinv, mi355x_trisolve_plan_t *lower, mi355x_trisolve_plan_t *upper) {
+  *lower = *upper = nullptr;
+  if (!dinv) return (int)hipErrorInvalidValue;
+  int dev = 0;
+  MI355X_TRY(hipGetDevice(&dev));
+  mi355x_trisolve_plan_t lo = nullptr, up = nullptr;
+  int rc_lo = 0, rc_up = 0;
+  std::thread tl([&] { (void)hipSetDevice(dev); rc_lo = mi355x_trisolve_plan_create_nodes(h, n, nnodes, nstart, nlev_lo, nodelev_lo, rp_lo, rl_lo, cj, cv, nullptr, by_level, block_columns, &lo); });
+  rc_up = mi355x_trisolve_plan_create_nodes(h, n, nnodes, nstart, nlev_up, nodelev_up, rp_up, rl_up, cj, cv, dinv, by_level, block_columns, &up);
+  tl.join();
+  if (rc_lo || rc_up) {
+    if (lo) mi355x_trisolve_plan_destroy(lo);
+    if (up) mi355x_trisolve_plan_destroy(up);
+    return rc_lo ? rc_lo : rc_up;
+  }
+  *lower = lo; *upper = up;
   return 0;
 }
 

@@ -141,6 +141,10 @@ static PetscErrorCode natural_ordering_only(Mat A, IS row, IS col, const MatFact
   return 0;
 }
 
+#include <time.h>
+static double wall_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
+#define SETUP_TICK(what) do { if (getenv("PETSC_HIPMI355X_SETUP_TIMING")) { const double t__ = wall_s(); fprintf(stderr, "[hipmi355x]   %-34s %.3f s\n", what, t__ - tick0); tick0 = t__; } } while (0)
+
 #if !defined(PETSCHIPMI355X_WITH_PETSC)
 #include <pthread.h>
 #include <unistd.h>
@@ -153,8 +157,10 @@ typedef struct {
   PetscReal zeropivot, shift_amount;
   int nth;
   PetscScalar **rtmp;                 /* a dense work row per thread */
-  volatile PetscInt fail_row; volatile PetscReal fail_value;
-  pthread_barrier_t bar; pthread_mutex_t mtx;
+  volatile PetscInt fail_row, fail_level; volatile PetscReal fail_value;
+  volatile int go;                    /* the gate the threads start at: 1 go, -1 leave (not all of them could be created) */
+  volatile int bar_count, bar_sense;  /* sense-reversing barrier: the levels are short (tens of microseconds), a futex sleep per level costs more */
+  pthread_mutex_t mtx;
 } IluPass;
 typedef struct { IluPass *p; int tid; } IluArg;
 
@@ -186,10 +192,19 @@ static int ilu0_factor_row(const IluPass *p, PetscScalar *rtmp, PetscInt i, Pets
   ba[bdiag[i]] = 1.0 / rtmp[i];
   return 0;
 }
+#include <sched.h>
+static void ilu0_barrier(IluPass *p, int *sense) {
+  *sense = !*sense;
+  if (__sync_add_and_fetch(&p->bar_count, 1) == p->nth) { p->bar_count = 0; __sync_synchronize(); p->bar_sense = *sense; }
+  else { int spins = 0; while (p->bar_sense != *sense) { if (++spins > 4000) { sched_yield(); spins = 0; } } }
+  __sync_synchronize();
+}
 static void *ilu0_worker(void *arg_) {
   IluArg *arg = (IluArg *)arg_;
   IluPass *p = arg->p;
   PetscScalar *rtmp = p->rtmp[arg->tid];
+  int sense = 0;
+  if (p->nth > 1 && arg->tid > 0) { while (p->go == 0) sched_yield(); if (p->go < 0) return NULL; }
   for (PetscInt l = 0; l < p->nlev; l++) {
     const PetscInt a = p->levptr[l], b = p->levptr[l + 1], cnt = b - a;
     const PetscInt lo = a + (PetscInt)((long)cnt * arg->tid / p->nth), hi = a + (PetscInt)((long)cnt * (arg->tid + 1) / p->nth);
@@ -200,13 +215,15 @@ static void *ilu0_worker(void *arg_) {
       if (ilu0_factor_row(p, rtmp, i, &bad)) {
         pthread_mutex_lock(&p->mtx);
         if (p->fail_row < 0 || i < p->fail_row) { p->fail_row = i; p->fail_value = bad; }
+        if (p->fail_level < 0 || l < p->fail_level) p->fail_level = l;
         pthread_mutex_unlock(&p->mtx);
         break;
       }
     }
-    if (p->nth > 1) pthread_barrier_wait(&p->bar);
-    if (p->fail_row >= 0) break;           /* read after the barrier: every thread sees the same answer and leaves together */
-    if (p->nth > 1) pthread_barrier_wait(&p->bar);
+    if (p->nth > 1) ilu0_barrier(p, &sense);
+    /* one barrier per level: a thread that is already in level l + 1 may record a failure there before a slower thread has looked
+     * at level l's outcome; that thread goes on to level l + 1 like everybody else and they all leave after ITS barrier */
+    if (p->fail_level >= 0 && p->fail_level <= l) break;
   }
   return NULL;
 }
@@ -215,18 +232,19 @@ static PetscErrorCode ilu0_run_pass(IluPass *p) {
   for (int t = 0; t < p->nth; t++) { args[t].p = p; args[t].tid = t; }
   pthread_mutex_init(&p->mtx, NULL);
   if (p->nth == 1) { ilu0_worker(&args[0]); pthread_mutex_destroy(&p->mtx); return 0; }
-  if (pthread_barrier_init(&p->bar, NULL, (unsigned)p->nth)) return PETSC_ERR_LIB;
+  p->bar_count = 0; p->bar_sense = 0; p->go = 0;
   int started = 0;
   for (int t = 1; t < p->nth; t++) { if (pthread_create(&th[t], NULL, ilu0_worker, &args[t])) break; started = t; }
-  if (started != p->nth - 1) {            /* could not start them all: the ones running would wait at the barrier for ever -- not reachable without them */
-    for (int t = 1; t <= started; t++) pthread_cancel(th[t]);
+  if (started != p->nth - 1) {            /* could not start them all: the ones that did are still at the gate and leave from there */
+    p->go = -1;
     for (int t = 1; t <= started; t++) pthread_join(th[t], NULL);
-    pthread_barrier_destroy(&p->bar); pthread_mutex_destroy(&p->mtx);
+    pthread_mutex_destroy(&p->mtx);
     return PETSC_ERR_LIB;
   }
+  p->go = 1;
   ilu0_worker(&args[0]);
   for (int t = 1; t < p->nth; t++) pthread_join(th[t], NULL);
-  pthread_barrier_destroy(&p->bar); pthread_mutex_destroy(&p->mtx);
+  pthread_mutex_destroy(&p->mtx);
   return 0;
 }
 /* dependency levels of L (a row may be factored once the rows its L part names are), rows listed level by level */
@@ -255,6 +273,7 @@ static PetscErrorCode ilu0_factor_host(Mat F, Mat A, const MatFactorInfo *info) 
   PetscErrorCode ierr;
   HipTriFactors *f = HipTriGet(F);
   PetscInt n; const PetscInt *ai, *aj; const PetscScalar *aa;
+  double tick0 = wall_s();
   ierr = MatSeqAIJGetArrays(A, &n, &ai, &aj, &aa);CHKERRQ(ierr);
   f->n = n; f->nz = ai[n]; f->owns_host = PETSC_TRUE;
   PetscInt *adiag;
@@ -268,7 +287,8 @@ static PetscErrorCode ilu0_factor_host(Mat F, Mat A, const MatFactorInfo *info) 
   ierr = PetscMalloc(sizeof(PetscInt) * (size_t)(f->nz + 1), &f->bj);CHKERRQ(ierr);
   ierr = PetscMalloc(sizeof(PetscInt) * (size_t)(n + 1), &f->bdiag);CHKERRQ(ierr);
   ierr = PetscMalloc(sizeof(PetscScalar) * (size_t)(f->nz + 1), &f->ba);CHKERRQ(ierr);
-  memset(f->ba, 0, sizeof(PetscScalar) * (size_t)(f->nz + 1));
+  SETUP_TICK("factor: diagonal positions");
+  f->ba[f->nz] = 0.0;                      /* (every other entry is written by the numeric pass) */
   PetscInt k = 0, *bi = f->bi, *bj = f->bj, *bdiag = f->bdiag; PetscScalar *ba = f->ba;
   bi[0] = 0;
   for (PetscInt i = 0; i < n; i++) {
@@ -283,6 +303,7 @@ static PetscErrorCode ilu0_factor_host(Mat F, Mat A, const MatFactorInfo *info) 
     bj[k++] = i;
     bdiag[i] = bdiag[i + 1] + nzu + 1;
   }
+  SETUP_TICK("factor: pattern of L and U");
   const PetscReal zeropivot = info->zeropivot, shiftamount = info->shiftamount;
   const PetscBool shift_nz = (PetscBool)(info->shifttype == (PetscReal)MAT_SHIFT_NONZERO);
   f->nshift = 0;
@@ -305,6 +326,7 @@ static PetscErrorCode ilu0_factor_host(Mat F, Mat A, const MatFactorInfo *info) 
     ps.nth = (int)nth; }
   ierr = ilu0_levels_host(n, bi, bj, &ps.nlev, &ps.levptr, &ps.rows);
   if (ierr) { HipFree(adiag); CHKERRQ(ierr); }
+  SETUP_TICK("factor: levels of L");
   ierr = PetscMalloc(sizeof(PetscScalar *) * (size_t)ps.nth, &ps.rtmp);CHKERRQ(ierr);
   for (int t = 0; t < ps.nth; t++) { ps.rtmp[t] = (PetscScalar *)calloc((size_t)n + 1, sizeof(PetscScalar)); if (!ps.rtmp[t]) SETERRQ(HipObjComm(A), PETSC_ERR_MEM, "out of memory"); }
   for (PetscInt bb = 0; bb < nblk; bb++) {
@@ -312,7 +334,7 @@ static PetscErrorCode ilu0_factor_host(Mat F, Mat A, const MatFactorInfo *info) 
     ps.r0 = blk[bb]; ps.r1 = blk[bb + 1]; ps.shift_amount = 0.0;
     for (;;) {   /* MAT_SHIFT_NONZERO, PCILU's default on a SeqAIJ matrix (ilu.c:387): a pivot that fails MatPivotCheck_nz restarts the
                   * factorisation with the diagonal shifted by shiftamount, then by twice that, ... (aijfact.c:507-592) */
-      ps.fail_row = -1;
+      ps.fail_row = -1; ps.fail_level = -1;
       ierr = ilu0_run_pass(&ps);
       if (ierr) break;
       if (ps.fail_row < 0) break;
@@ -324,6 +346,7 @@ static PetscErrorCode ilu0_factor_host(Mat F, Mat A, const MatFactorInfo *info) 
     if (ierr) break;
     f->nshift = PetscMax(f->nshift, nshift);
   }
+  SETUP_TICK("factor: numeric passes");
   for (int t = 0; t < ps.nth; t++) free(ps.rtmp[t]);
   HipFree(ps.rtmp); HipFree(ps.levptr); HipFree(ps.rows); HipFree(adiag);
   if (ierr) SETERRQ(HipObjComm(A), 71 /* PETSC_ERR_MAT_LU_ZRPVT */, "Zero pivot row %d value %g%s", ps.fail_row, ps.fail_value, shift_nz ? ": still there after 80 diagonal shifts" : "");
@@ -339,6 +362,7 @@ static PetscErrorCode ilu0_analyse_and_upload(Mat F, Mat A) {
   const PetscInt n = f->n, *bi = f->bi, *bj = f->bj, *bdiag = f->bdiag; const PetscScalar *ba = f->ba;
   PetscDeviceCtx *dc;
   PetscInt *lev, *levU, *rowsL, *rowsU;
+  const double ta0 = wall_s();
   ierr = PetscMalloc(sizeof(PetscInt) * (size_t)PetscMax(n, 1), &lev);CHKERRQ(ierr);
   ierr = PetscMalloc(sizeof(PetscInt) * (size_t)PetscMax(n, 1), &levU);CHKERRQ(ierr);
   f->nlevL = 0;
@@ -355,6 +379,7 @@ static PetscErrorCode ilu0_analyse_and_upload(Mat F, Mat A) {
     levU[i] = l; f->nlevU = PetscMax(f->nlevU, l + 1);
   }
   ierr = level_order(n, levU, f->nlevU, &f->levptrU, &rowsU);CHKERRQ(ierr);
+  if (getenv("PETSC_HIPMI355X_SETUP_TIMING")) fprintf(stderr, "[hipmi355x] ILU(0): row levels %.3f s\n", wall_s() - ta0);
   ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
   {   /* sync-free solves: worth it as soon as the level launches would be a launch-bound chain */
     char mode[32] = "syncfree"; PetscBool set;
@@ -379,6 +404,7 @@ static PetscErrorCode ilu0_analyse_and_upload(Mat F, Mat A) {
       ierr = PetscOptionsGetString(HipObjPrefix(F), "-pc_factor_hipmi355x_trisolve_order", ord, sizeof(ord), &set);CHKERRQ(ierr);
       if (set && strcmp(ord, "column") && strcmp(ord, "level")) SETERRQ(HipObjComm(F), PETSC_ERR_ARG_WRONG, "-pc_factor_hipmi355x_trisolve_order <column|level>, got %s", ord);
       ierr = MatSeqAIJHIPGetInodes(A, &nodes, &nsizes);CHKERRQ(ierr);
+      if (getenv("PETSC_HIPMI355X_SETUP_TIMING")) fprintf(stderr, "[hipmi355x] ILU(0): ... row arrays + inode query at %.3f s\n", wall_s() - ta0);
       ierr = PetscOptionsGetString(HipObjPrefix(F), "-pc_factor_hipmi355x_trisolve_nodes", nodeopt, sizeof(nodeopt), &nset);CHKERRQ(ierr);
       f->nodes = 0;
       if (nodes > 0 && !(nset && (!strcmp(nodeopt, "0") || !strcmp(nodeopt, "false")))) {
@@ -408,13 +434,13 @@ static PetscErrorCode ilu0_analyse_and_upload(Mat F, Mat A) {
             nlevU[u] = l; nlU = PetscMax(nlU, l + 1);
           }
           by_level = set ? !strcmp(ord, "level") : 1;
+          if (getenv("PETSC_HIPMI355X_SETUP_TIMING")) fprintf(stderr, "[hipmi355x] ILU(0): ... node levels at %.3f s\n", wall_s() - ta0);
           /* on request first with whole dependency nodes as columns (a fixed number of dofs per node: one gather per dependency
            * node; measured no faster, so not the default), then the general node plans, then (below) row by row */
           PetscInt bc = 0; PetscBool bset;
           ierr = PetscOptionsGetInt(HipObjPrefix(F), "-pc_factor_hipmi355x_trisolve_block_columns", &bc, &bset);CHKERRQ(ierr);
           for (int blk = bc ? 1 : 0; blk >= 0; blk--) {
-            rc = mi355x_trisolve_plan_create_nodes(dc->h, n, nodes, nstart, nlL, nlevL, bi, rlL, bj, ba, NULL, by_level, blk, &f->tri_lo);
-            if (!rc) rc = mi355x_trisolve_plan_create_nodes(dc->h, n, nodes, nstart, nlU, nlevU, rpU, rlU, bj, ba, dinv, by_level, blk, &f->tri_up);
+            rc = mi355x_trisolve_plan_create_nodes_pair(dc->h, n, nodes, nstart, by_level, blk, nlL, nlevL, bi, rlL, nlU, nlevU, rpU, rlU, bj, ba, dinv, &f->tri_lo, &f->tri_up);
             if (!rc) { f->nodes = nodes; f->nlevL_nodes = nlL; f->nlevU_nodes = nlU; f->by_level = by_level; f->block_columns = blk; break; }
             if (f->tri_lo) mi355x_trisolve_plan_destroy(f->tri_lo);      /* not of that shape: the next, more general form */
             if (f->tri_up) mi355x_trisolve_plan_destroy(f->tri_up);
@@ -430,6 +456,7 @@ static PetscErrorCode ilu0_analyse_and_upload(Mat F, Mat A) {
         if (!rc) rc = mi355x_trisolve_plan_create_ordered(dc->h, n, f->nlevU, levU, rpU, rlU, bj, ba, dinv, by_level, &f->tri_up);
       }
       HipFree(rpU); HipFree(rlU); HipFree(rlL); HipFree(dinv);
+      if (getenv("PETSC_HIPMI355X_SETUP_TIMING")) fprintf(stderr, "[hipmi355x] ILU(0): ... plans made at %.3f s\n", wall_s() - ta0);
       if (rc) {   /* e.g. a factor too large for 32-bit sliced-ELL offsets: the level kernels serve */
         if (f->tri_lo) mi355x_trisolve_plan_destroy(f->tri_lo);
         if (f->tri_up) mi355x_trisolve_plan_destroy(f->tri_up);
@@ -459,8 +486,6 @@ static PetscErrorCode ilu0_analyse_and_upload(Mat F, Mat A) {
 
 static PetscErrorCode MatSolve_SeqAIJHIP_ILU(Mat F, Vec b, Vec x);
 
-#include <time.h>
-static double wall_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
 static PetscErrorCode MatLUFactorNumeric_SeqAIJHIP(Mat F, Mat A, const MatFactorInfo *info) {   /* MatLUFactorNumeric_SeqAIJCUSPARSE, aijcusparse.cu:358-376 */
   PetscErrorCode ierr;
   HipTriFactors *f = HipTriGet(F);
