@@ -292,6 +292,13 @@ int mi355x_trisolve_plan_create_scaled(mi355x_handle_t h, int n, int nlev, const
  * -- fewer, larger batches; same column sequence, same bits.  hipErrorInvalidValue when the factor is not of that kind. */
 int mi355x_trisolve_plan_create_nodes(mi355x_handle_t h, int n, int nnodes, const int *nstart, int nlev, const int *nodelev, const int *rp, const int *rl,
                                       const int *cj, const double *cv, const double *dinv, int by_level, int block_columns, mi355x_trisolve_plan_t *plan);
+/* the lower and the upper row-granular plan of one factor, built side by side (two host threads): the arguments of
+ * mi355x_trisolve_plan_create_ordered for the lower plan, of ..._create_ordered / ..._create_scaled (rscale_up != NULL) for the upper
+ * one; on failure neither plan is returned */
+int mi355x_trisolve_plan_create_pair(mi355x_handle_t h, int n, int by_level,
+                                     int nlev_lo, const int *lev_lo, const int *rp_lo, const int *rl_lo, const int *cj_lo, const double *cv_lo,
+                                     int nlev_up, const int *lev_up, const int *rp_up, const int *rl_up, const int *cj_up, const double *cv_up,
+                                     const double *dinv_up, const double *rscale_up, mi355x_trisolve_plan_t *lower, mi355x_trisolve_plan_t *upper);
 /* the lower and the upper node plan of one factor, built side by side (two host threads: the analyses are independent): arguments as
  * above, once per factor; on failure neither plan is returned */
 int mi355x_trisolve_plan_create_nodes_pair(mi355x_handle_t h, int n, int nnodes, const int *nstart, int by_level, int block_columns,

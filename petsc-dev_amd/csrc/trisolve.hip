@@ -760,6 +760,30 @@ __global__ __launch_bounds__(MI355X_BLOCK) void trisolve_level_kernel(int p0, in
   if (UPPER) y[row] = r;
 }
 
+// a host array that is not initialised on allocation (zeroed = true: zero pages from the allocator), and a loop over [0, n) dealt
+// to a few host threads in contiguous ranges (one thread below `grain` items per thread)
+template <class T> struct HostBuf {
+  T *p; size_t n;
+  explicit HostBuf(size_t n_, bool zeroed = false) : p((T *)(zeroed ? calloc(n_ ? n_ : 1, sizeof(T)) : malloc((n_ ? n_ : 1) * sizeof(T)))), n(n_) {}
+  ~HostBuf() { free(p); }
+  HostBuf(const HostBuf &) = delete;
+  HostBuf &operator=(const HostBuf &) = delete;
+  T &operator[](size_t i) { return p[i]; }
+  const T &operator[](size_t i) const { return p[i]; }
+  size_t size() const { return n; }
+  T *data() { return p; }
+};
+template <class F> static void host_parallel_for(long n, long grain, F f) {
+  unsigned hc = std::thread::hardware_concurrency();
+  long nth = (long)(hc > 8 ? 8 : (hc < 1 ? 1 : hc));
+  if (nth > n / (grain > 0 ? grain : 1)) nth = n / (grain > 0 ? grain : 1);
+  if (nth <= 1) { f(0L, n); return; }
+  std::vector<std::thread> th;
+  for (long k = 1; k < nth; ++k) th.emplace_back(f, n * k / nth, n * (k + 1) / nth);
+  f(0L, n / nth);
+  for (auto &t : th) t.join();
+}
+
 extern "C" {
 
 // Host analysis + upload.  n rows; lev[i] = dependency level of row i (0-based, every level non-empty); len(i) and
@@ -779,6 +803,10 @@ static int trisolve_plan_fill(mi355x_handle_t h, mi355x_trisolve_plan_s *p, int 
                               const double *cv, const double *dinv_host, const double *rscale_host, int by_level) {
   p->n = n; p->upper = dinv_host != nullptr;
   const int W = MI355X_WAVE;
+  const bool timing = getenv("MI355X_TRISOLVE_TIMING") != nullptr, upper = dinv_host != nullptr;
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double tlast = now();
+  auto tick = [&](const char *what) { if (timing) { const double t = now(); fprintf(stderr, "[mi355x trisolve plan %s] %-28s %.3f s\n", upper ? "U" : "L", what, t - tlast); tlast = t; } };
   // positions: by level, longer rows first inside a level (stable in the row number)
   std::vector<int> order((size_t)n), levptr((size_t)nlev + 1, 0);
   for (int i = 0; i < n; ++i) levptr[(size_t)lev[i] + 1]++;
@@ -805,6 +833,7 @@ static int trisolve_plan_fill(mi355x_handle_t h, mi355x_trisolve_plan_s *p, int 
         std::stable_sort(order.begin() + levptr[(size_t)l], order.begin() + levptr[(size_t)l + 1], [&](int a, int b) { return rl[a] > rl[b]; });
     }
   }
+  tick("rows by level and length");
   std::vector<long> tpos((size_t)(n > 0 ? n : 1));
   long cur = 0;
   for (int l = 0; l < nlev; ++l) {
@@ -823,33 +852,50 @@ static int trisolve_plan_fill(mi355x_handle_t h, mi355x_trisolve_plan_s *p, int 
   p->nslices = (int)((cur + W - 1) / W);
   p->nchunks = (p->nslices + 3) / 4;
   const size_t np = (size_t)p->nslices * W;
-  std::vector<int> pos((size_t)(n > 0 ? n : 1)), info(np > 0 ? np : 1, 0), rowof(np > 0 ? np : 1, -1), ptr((size_t)p->nslices + 1, 0);
-  std::vector<unsigned char> nsub((size_t)(p->nslices > 0 ? p->nslices : 1), 1);
-  std::vector<double> dinv(np > 0 ? np : 1, 1.0), rsc(np > 0 ? np : 1, 1.0);
-  for (int t = 0; t < n; ++t) { pos[(size_t)order[(size_t)t]] = (int)tpos[(size_t)t]; rowof[(size_t)tpos[(size_t)t]] = order[(size_t)t]; }
+  // (host arrays without an initialising pass of their own: every entry is written below, by several threads)
+  const size_t npa = np > 0 ? np : 1;
+  HostBuf<int> pos((size_t)(n > 0 ? n : 1)), info(npa), rowof(npa), ptr((size_t)p->nslices + 1), slicemax((size_t)(p->nslices > 0 ? p->nslices : 1));
+  HostBuf<unsigned char> nsub((size_t)(p->nslices > 0 ? p->nslices : 1));
+  HostBuf<double> dinv(npa), rsc(npa);
+  if (!pos.p || !info.p || !rowof.p || !ptr.p || !slicemax.p || !nsub.p || !dinv.p || !rsc.p) TRI_FAIL();
+  host_parallel_for((long)npa, 1 << 20, [&](long a, long b) { for (long P = a; P < b; ++P) { rowof[(size_t)P] = -1; info[(size_t)P] = 0; dinv[(size_t)P] = 1.0; rsc[(size_t)P] = 1.0; } });
+  host_parallel_for((long)n, 1 << 20, [&](long a, long b) { for (long t = a; t < b; ++t) { pos[(size_t)order[(size_t)t]] = (int)tpos[(size_t)t]; rowof[(size_t)tpos[(size_t)t]] = order[(size_t)t]; } });
+  tick("positions");
+  std::atomic<int> badslice(0);
+  host_parallel_for((long)p->nslices, 1 << 14, [&](long s0, long s1) {
+    for (long s = s0; s < s1; ++s) {
+      int mx = 0, l0 = -1, ns = 1;
+      for (int j = 0; j < W; ++j) {
+        const size_t P = (size_t)s * W + j;
+        const int i = rowof[P];
+        if (i < 0) continue;
+        if (l0 < 0) l0 = lev[i];                   // positions are in level order: the slice's first row has its lowest level
+        const int sub = lev[i] - l0;
+        if (sub < 0 || sub > 255) { badslice.store(1); return; }
+        info[P] = (rl[i] << 8) | sub;
+        if (dinv_host) dinv[P] = dinv_host[i];
+        if (rscale_host) rsc[P] = rscale_host[i];
+        if (rl[i] > mx) mx = rl[i];
+        if (sub + 1 > ns) ns = sub + 1;
+      }
+      slicemax[(size_t)s] = mx; nsub[(size_t)s] = (unsigned char)ns;
+    }
+  });
+  if (badslice.load()) TRI_FAIL();
   long total = 0;
   for (int s = 0; s < p->nslices; ++s) {
-    int mx = 0, l0 = -1;
-    for (int j = 0; j < W; ++j) {
-      const size_t P = (size_t)s * W + j;
-      const int i = rowof[P];
-      if (i < 0) continue;
-      if (l0 < 0) l0 = lev[i];                   // positions are in level order: the slice's first row has its lowest level
-      const int sub = lev[i] - l0;
-      if (sub < 0 || sub > 255) TRI_FAIL();
-      info[P] = (rl[i] << 8) | sub;
-      if (dinv_host) dinv[P] = dinv_host[i];
-      if (rscale_host) rsc[P] = rscale_host[i];
-      if (rl[i] > mx) mx = rl[i];
-      if (sub + 1 > nsub[(size_t)s]) nsub[(size_t)s] = (unsigned char)(sub + 1);
-    }
     ptr[(size_t)s] = (int)total;
-    total += (long)mx * W;
+    total += (long)slicemax[(size_t)s] * W;
     if (total > 2147483000L) TRI_FAIL();
   }
   ptr[(size_t)p->nslices] = (int)total;
-  std::vector<int> col((size_t)(total > 0 ? total : 1), 0);
-  std::vector<double> val((size_t)(total > 0 ? total : 1), 0.0);
+  tick("slice layout");
+  // (zero pages from the allocator for the sliced ELL arrays, first touched by the fill threads)
+  const size_t ntot = (size_t)(total > 0 ? total : 1);
+  HostBuf<int> col(ntot, true);
+  HostBuf<double> val(ntot, true);
+  if (!col.p || !val.p) TRI_FAIL();
+  tick("allocation");
   // every row writes its own slots of the sliced ELL arrays: host threads take contiguous ranges of positions
   { std::atomic<int> bad(0);
     auto fill = [&](int t0, int t1) {
@@ -878,6 +924,7 @@ static int trisolve_plan_fill(mi355x_handle_t h, mi355x_trisolve_plan_s *p, int 
       for (auto &t : th) t.join();
     }
     if (bad.load()) TRI_FAIL(); }
+  tick("fill");
 #define TRI_UP(dst, vec, T) do { TRI_TRY(hipMalloc((void **)&(dst), sizeof(T) * (vec).size())); \
     TRI_TRY(hipMemcpyAsync((dst), (vec).data(), sizeof(T) * (vec).size(), hipMemcpyHostToDevice, h->stream)); } while (0)
   TRI_UP(p->d_ptr, ptr, int); TRI_UP(p->d_info, info, int); TRI_UP(p->d_row, rowof, int); TRI_UP(p->d_col, col, int);
@@ -885,6 +932,8 @@ static int trisolve_plan_fill(mi355x_handle_t h, mi355x_trisolve_plan_s *p, int 
   if (dinv_host) TRI_UP(p->d_dinv, dinv, double);
   if (dinv_host && rscale_host) TRI_UP(p->d_rscale, rsc, double);
 #undef TRI_UP
+  TRI_TRY(hipStreamSynchronize(h->stream));
+  tick("upload");
   TRI_TRY(hipMalloc((void **)&p->d_w, sizeof(double) * (np > 0 ? np : 1)));
   { std::vector<unsigned long long> sent(np > 0 ? np : 1, TRI_SENTINEL);
     TRI_TRY(hipMemcpyAsync(p->d_w, sent.data(), sizeof(double) * sent.size(), hipMemcpyHostToDevice, h->stream));
@@ -1162,6 +1211,28 @@ int mi355x_trisolve_plan_create_nodes(mi355x_handle_t h, int n, int nnodes, cons
   const int rc = trisolve_plan_fill_nodes(h, p, n, nnodes, nstart, nlev, nodelev, rp, rl, cj, cv, dinv_host, by_level, block_columns);
   if (rc) { mi355x_trisolve_plan_destroy(p); return rc; }
   *out = p;
+  return 0;
+}
+
+int mi355x_trisolve_plan_create_pair(mi355x_handle_t h, int n, int by_level,
+                                     int nlev_lo, const int *lev_lo, const int *rp_lo, const int *rl_lo, const int *cj_lo, const double *cv_lo,
+                                     int nlev_up, const int *lev_up, const int *rp_up, const int *rl_up, const int *cj_up, const double *cv_up,
+                                     const double *dinv_up, const double *rscale_up, mi355x_trisolve_plan_t *lower, mi355x_trisolve_plan_t *upper) {
+  *lower = *upper = nullptr;
+  if (!dinv_up) return (int)hipErrorInvalidValue;
+  int dev = 0;
+  MI355X_TRY(hipGetDevice(&dev));
+  mi355x_trisolve_plan_t lo = nullptr, up = nullptr;
+  int rc_lo = 0, rc_up = 0;
+  std::thread tl([&] { (void)hipSetDevice(dev); rc_lo = trisolve_plan_create_impl(h, n, nlev_lo, lev_lo, rp_lo, rl_lo, cj_lo, cv_lo, nullptr, nullptr, by_level, &lo); });
+  rc_up = trisolve_plan_create_impl(h, n, nlev_up, lev_up, rp_up, rl_up, cj_up, cv_up, dinv_up, rscale_up, rscale_up ? 0 : by_level, &up);
+  tl.join();
+  if (rc_lo || rc_up) {
+    if (lo) mi355x_trisolve_plan_destroy(lo);
+    if (up) mi355x_trisolve_plan_destroy(up);
+    return rc_lo ? rc_lo : rc_up;
+  }
+  *lower = lo; *upper = up;
   return 0;
 }
 

@@ -25,6 +25,9 @@ static PetscErrorCode MatSolve_SeqAIJHIP_ICC(Mat F, Vec b, Vec x) {   /* PCApply
 }
 
 static PetscErrorCode icc0_plans(Mat F, PetscInt n, const PetscInt *ui, const PetscInt *uj, const PetscScalar *ua);
+#include <time.h>
+static double icc_wall_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
+#define ICC_TICK(what) do { if (getenv("PETSC_HIPMI355X_SETUP_TIMING")) { const double t__ = icc_wall_s(); fprintf(stderr, "[hipmi355x]   %-34s %.3f s\n", what, t__ - tick0); tick0 = t__; } } while (0)
 
 #if !defined(PETSCHIPMI355X_WITH_PETSC)
 /* MatICCFactorSymbolic_SeqAIJ (levels 0, natural ordering) + MatCholeskyFactorNumeric_SeqAIJ restated for the harness; inside a
@@ -33,6 +36,7 @@ static PetscErrorCode icc0_factor_host(Mat F, Mat A, const MatFactorInfo *info) 
   PetscErrorCode ierr;
   HipTriFactors *f = HipTriGet(F);
   PetscInt n; const PetscInt *ai, *aj; const PetscScalar *aa;
+  double tick0 = icc_wall_s();
   ierr = MatSeqAIJGetArrays(A, &n, &ai, &aj, &aa);CHKERRQ(ierr);
   f->n = n;
   if (!n) return 0;
@@ -55,6 +59,7 @@ static PetscErrorCode icc0_factor_host(Mat F, Mat A, const MatFactorInfo *info) 
     ui[k + 1] = nz;
   }
 
+  ICC_TICK("icc: pattern of U");
   /* ---- numeric, left-looking over the rows; the shift of MatPivotCheck_pd (matimpl.h:532-553) restarts it.  One pass per
    * independent block (one block = the whole matrix unless "PCFactorSetIndependentBlocks_C" said otherwise) ---- */
   const PetscReal zeropivot = info->zeropivot;
@@ -126,7 +131,9 @@ static PetscErrorCode icc0_factor_host(Mat F, Mat A, const MatFactorInfo *info) 
     f->nshift = PetscMax(f->nshift, nshift);
   }
   HipFree(work); HipFree(first); HipFree(list);
+  ICC_TICK("icc: numeric");
   ierr = icc0_plans(F, n, ui, uj, ua);
+  ICC_TICK("icc: plans");
   HipFree(ui); HipFree(uj); HipFree(ua);
   CHKERRQ(ierr);
   return 0;
@@ -178,8 +185,7 @@ static PetscErrorCode icc0_plans(Mat F, PetscInt n, const PetscInt *ui, const Pe
     levU[i] = l; f->nlevU = PetscMax(f->nlevU, l + 1);
   }
   ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
-  int rc = mi355x_trisolve_plan_create_ordered(dc->h, n, f->nlevL, levL, lp, ll, lj, lv, NULL, 0, &f->tri_lo);
-  if (!rc) rc = mi355x_trisolve_plan_create_scaled(dc->h, n, f->nlevU, levU, up, ul, uc, uv, ones, dinv, &f->tri_up);
+  int rc = mi355x_trisolve_plan_create_pair(dc->h, n, 0, f->nlevL, levL, lp, ll, lj, lv, f->nlevU, levU, up, ul, uc, uv, ones, dinv, &f->tri_lo, &f->tri_up);
   HipFree(lp); HipFree(ll); HipFree(lj); HipFree(lv); HipFree(up); HipFree(ul); HipFree(uc); HipFree(uv);
   HipFree(levL); HipFree(levU); HipFree(ones); HipFree(dinv);
   CHKHIP(rc);

@@ -452,8 +452,7 @@ static PetscErrorCode ilu0_analyse_and_upload(Mat F, Mat A) {
       if (rc) {
         by_level = set ? !strcmp(ord, "level") : (nodes > 0);
         f->by_level = by_level;
-        rc = mi355x_trisolve_plan_create_ordered(dc->h, n, f->nlevL, lev, bi, rlL, bj, ba, NULL, by_level, &f->tri_lo);
-        if (!rc) rc = mi355x_trisolve_plan_create_ordered(dc->h, n, f->nlevU, levU, rpU, rlU, bj, ba, dinv, by_level, &f->tri_up);
+        rc = mi355x_trisolve_plan_create_pair(dc->h, n, by_level, f->nlevL, lev, bi, rlL, bj, ba, f->nlevU, levU, rpU, rlU, bj, ba, dinv, NULL, &f->tri_lo, &f->tri_up);
       }
       HipFree(rpU); HipFree(rlU); HipFree(rlL); HipFree(dinv);
       if (getenv("PETSC_HIPMI355X_SETUP_TIMING")) fprintf(stderr, "[hipmi355x] ILU(0): ... plans made at %.3f s\n", wall_s() - ta0);
