@@ -10,7 +10,7 @@ Three configurations of the same solve are timed in the same run (N=1; on severa
                     (-mat_hipmi355x_value_patterns 0): what every matrix gets, constant coefficients or not.  value,
                     ms_per_step, roofline, spmv_gbps, ksp_* describe THIS leg.
   value_patterns    the same solver with the library's default for this matrix: P7 has constant coefficients, its rows come
-                    from a 27-entry dictionary and the product does not read the value array (bit-identical results).
+                    from a 27-entry dictionary and the product does not read the value array (the product carries the same bits).
   op_by_op          -ksp_type cg: the plain restatement of PETSc's own KSPSolve_CG, one kernel per Vec/Mat call -- what an
                     UNCHANGED PETSc program drives over the same types (value array streamed).
 
@@ -159,15 +159,17 @@ def main():
     L.MatHIPMI355XGetRowPatterns(timed, C.byref(npat))
     L.MatHIPMI355XGetValuePatterns(timed, C.byref(nvpat))
 
-    def spmv_kernel(value_patterns):
+    def spmv_kernel(value_patterns, with_dot):
         """(kernel name for the JSON, tag in rocprofv3's kernel names, modelled bytes moved per launch: matrix stream + x once + y once)"""
         vec = 8 * mloc + 8 * mloc
+        inst = "<0, true>" if with_dot else "<0, false>"          # the instance that also leaves p'w (the registered CG on one GPU) / the plain product
+        also = "; p'w from the same pass" if with_dot else ""
         if value_patterns and nvpat.value:
-            return ("spmv_csr_valpat_kernel (%d distinct rows {offsets, values} in a dictionary, 2 bytes per row; the value array is not read)" % nvpat.value,
-                    "spmv_csr_valpat_kernel<0>", 2 * mloc + vec)
+            return ("spmv_csr_valpat_kernel (%d distinct rows {offsets, values} in a dictionary, 2 bytes per row; the value array is not read%s)" % (nvpat.value, also),
+                    "spmv_csr_valpat_kernel" + inst, 2 * mloc + vec)
         if npat.value:
-            return ("spmv_csr_rowblock_pat_kernel (CSR values + a %d-list row-pattern dictionary: 8 B per nonzero + one 4-byte word per row)" % npat.value,
-                    "spmv_csr_rowblock_pat_kernel<0>", 8 * nnz_k + 4 * mloc + vec)
+            return ("spmv_csr_rowblock_pat_kernel (CSR values + a %d-list row-pattern dictionary: 8 B per nonzero + one 4-byte word per row%s)" % (npat.value, also),
+                    "spmv_csr_rowblock_pat_kernel" + inst, 8 * nnz_k + 4 * mloc + vec)
         if noff.value:
             return ("spmv_csr_rowblock_idx8_kernel (CSR values + 1-byte offset-dictionary column indices, %d offsets)" % noff.value,
                     "spmv_csr_rowblock_idx8_kernel<0,", 9 * nnz_k + 4 * (mloc + 1) + vec)
@@ -212,12 +214,12 @@ def main():
                 "effective_gbps_vs_reference_bytes": round(ref_bytes / (ms * 1e-3) / 1e9, 1) if ms > 0 else 0.0,
                 **({"traffic_source": pmc_note} if measured is not None else {})}
 
-    def leg(ksp, value_patterns, vec_passes, what):
+    def leg(ksp, value_patterns, vec_passes, what, with_dot=False):
         """time one configuration; its/s, and the step / its two main kernels in bytes moved"""
         L.MatHIPMI355XSetValuePatterns(timed, 1 if value_patterns else 0)
         t = timed_solve(ksp)
         its = args.steps / t["dt"]
-        name, tag, model = spmv_kernel(value_patterns)
+        name, tag, model = spmv_kernel(value_patterns, with_dot)
         r_spmv = kernel_roofline(name, tag, model, spmv_ref_bytes, t["spmv_ms"], t["spmv_launches"])
         step_moved = r_spmv["bytes_moved_per_launch"] + vec_passes * 8 * mloc
         out = {"what": what, "ksp_its_per_sec": round(its, 2), "value": round(its * mloc * world / 1e6, 3), "ms_per_step": round(t["dt"] / args.steps * 1e3, 5),
@@ -232,7 +234,12 @@ def main():
         return out, t
 
     # ---- leg 1, the headline: registered fused CG, value array streamed ----
-    head, th = leg(ksp_fused, False, 13, "-ksp_type cghipmi355x -mat_hipmi355x_value_patterns 0: fused CG sweeps, the SpMV streams the value array")
+    # the registered CG (-ksp_cg_fused 4, its default): on one GPU p'w comes out of the SpMV pass -> AYPX 3 + fused update 8 = 11 vector
+    # passes beside the SpMV; on a parallel matrix p'w is its own reduction (2 more passes)
+    fused_dot = world == 1
+    fused_passes = 11 if fused_dot else 13
+    head, th = leg(ksp_fused, False, fused_passes, "-ksp_type cghipmi355x -mat_hipmi355x_value_patterns 0: fused CG sweeps, the SpMV streams the value array"
+                   + (" and leaves p'w" if fused_dot else ""), fused_dot)
     if os.environ.get("BENCH_NO_SPMV_EVENTS"):
         print("no-events run: %.5f ms/step" % head["ms_per_step"], flush=True)
         return
@@ -260,7 +267,7 @@ def main():
         "spmv_gbps": round(head["spmv"]["achieved"] * world, 1),
         "spmv_gbps_basis": "bytes the SpMV kernel moved (%s) / its average launch time inside the timed solve, summed over GPUs" % head["spmv"]["bytes_moved_basis"],
         "ksp_gbps": head["ksp_gbps"], "ksp_hbm_frac": head["ksp_hbm_frac"],
-        "ksp_gbps_basis": "bytes moved per step = SpMV (as above) + 13 vector passes of the fused iteration (AYPX 3, dot 2, fused update 8)",
+        "ksp_gbps_basis": "bytes moved per step = SpMV (as above) + %d vector passes of the fused iteration (AYPX 3, fused update 8%s)" % (fused_passes, "" if fused_dot else ", dot 2"),
         "effective_gbps_vs_reference_bytes": {"spmv": round(head["spmv"]["effective_gbps_vs_reference_bytes"] * world, 1),
                                               "ksp": round(cg_ref_bytes * its_per_s * world / 1e9, 1),
                                               "what": "the same times priced in the REFERENCE's algorithmic bytes (SURVEY 8d: CSR 12 B/nnz + 4 B/row + x + y = %d B per SpMV; "
@@ -282,7 +289,8 @@ def main():
     if world == 1 and not args.headline_only:
         # ---- leg 2: the library's default for THIS matrix (constant coefficients: rows from a dictionary) ----
         if nvpat.value:
-            vp, _ = leg(ksp_fused, True, 13, "-ksp_type cghipmi355x, value patterns on (library default; P7 is a constant-coefficient operator): the SpMV does not read the value array; bit-identical results")
+            vp, _ = leg(ksp_fused, True, fused_passes, "-ksp_type cghipmi355x, value patterns on (library default; P7 is a constant-coefficient operator): the SpMV does not read the value array; "
+                        "the same products bit for bit, p'w summed per workgroup (iterates agree with the headline's to rounding)", fused_dot)
             out["legs"]["value_patterns"] = vp
         # ---- leg 3: what an unchanged PETSc program drives: KSPSolve_CG op by op (VecAYPX, MatMult, VecTDot, VecAXPY x2, PCApply, VecNorm, VecTDot) ----
         ksp_plain = make_ksp("cg")

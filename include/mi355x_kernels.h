@@ -184,6 +184,8 @@ int mi355x_spmv_plan_value_patterns(mi355x_handle_t h, mi355x_spmv_plan_t p, con
 int mi355x_spmv_plan_drop_value_patterns(mi355x_spmv_plan_t p);
 int mi355x_spmv_plan_use_value_patterns(mi355x_spmv_plan_t p, int on, int *nvpat);
 int mi355x_spmv_plan_is_compressed(mi355x_spmv_plan_t plan, int *ntab);
+/* 1 when mi355x_spmv_csr_dot would run on this plan with this value array (hipErrorNotSupported otherwise) */
+int mi355x_spmv_plan_dot_available(mi355x_spmv_plan_t plan, const double *a, int *yes);
 /* Optional analysis step for matrices with repeated row patterns (finite elements with several dof per node): the
  * MI355X form of the reference's inodes.  ns[nnodes] are the node sizes Mat_CheckInode finds (src/mat/impls/aij/seq/
  * inode.c:3981-3998: consecutive rows with identical column lists, <= limit rows per node).  Each group's column list is
@@ -205,8 +207,9 @@ int mi355x_spmv_csr(mi355x_handle_t h, mi355x_spmv_plan_t plan, const int *ai, c
                     const double *aa, const double *x, double *y);
 /* y = A x and sum_r x_r y_r from ONE pass over the matrix (KSPSolve_CG: w = A p, dpi = p'w; cg.c:190-191): the SpMV
  * leaves one value per row block in the plan, mi355x_spmv_dot_finish adds them in block order into out[0] (device-
- * accessible).  Square matrices with an index-compressed plan only: mi355x_spmv_csr_dot returns hipErrorNotSupported
- * (801) otherwise and does nothing.  y carries the bits of mi355x_spmv_csr; the dot uses a fixed tree. */
+ * accessible).  Square matrices whose plan runs one of the row-block kernels with per-block sums (value patterns, row patterns,
+ * 8-bit column offsets: mi355x_spmv_plan_dot_available): mi355x_spmv_csr_dot returns hipErrorNotSupported (801) otherwise and does
+ * nothing.  y carries the bits of mi355x_spmv_csr; the dot uses a fixed tree. */
 int mi355x_spmv_csr_dot(mi355x_handle_t h, mi355x_spmv_plan_t plan, const int *ai, const int *aj, const double *aa,
                         const double *x, double *y);
 int mi355x_spmv_dot_finish(mi355x_handle_t h, mi355x_spmv_plan_t plan, double *out);

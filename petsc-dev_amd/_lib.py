@@ -90,6 +90,7 @@ KERNEL_API = {
     "mi355x_spmv_plan_drop_value_patterns": [vp],
     "mi355x_spmv_plan_use_value_patterns": [vp, i32, vp],
     "mi355x_spmv_plan_is_compressed": [vp, pi32],
+    "mi355x_spmv_plan_dot_available": [vp, vp, pi32],
     "mi355x_spmv_plan_group_rows": [vp, vp, vp, vp, i32, vp],
     "mi355x_spmv_plan_set_pairsum": [vp, i32],
     "mi355x_spmv_plan_group_info": [vp, pi32, C.POINTER(C.c_long), pi32],

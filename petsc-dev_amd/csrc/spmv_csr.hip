@@ -79,6 +79,7 @@ struct mi355x_spmv_plan_s {
   double *d_vpatval;   // SPMV_PAT_CAP doubles, value q of an entry at the index of its offset q
   int nvpat, vtablen, vpat_valid, use_vpat;
   double *d_dotpart;   // per-row-block x'y values of mi355x_spmv_csr_dot (allocated on first use)
+  int ndotpart;        // how many of them the last mi355x_spmv_csr_dot wrote
   // rows summed the way MatMult_SeqAIJ_Inode does (two products at a time, inode.c:392-578): set when the reference's
   // Mat_CheckInode would switch this matrix to its inode routines
   int pairsum;
@@ -413,13 +414,16 @@ __global__ __launch_bounds__(SPMV_THREADS, SPMV_MINWAVES) void spmv_csr_rowblock
 // layouts above cannot offer -- multiplies with the staged values and adds in column order (or two at a time, pairsum):
 // the arithmetic and order of the other kernels, same bits.  No row markers, no per-nonzero index stream, one barrier less.
 #define SPMV_PAT_CAP 512
-template <int ADD>
+// DOT: the block also leaves the sum of x_r y_r over its rows in dotpart[block] (square matrix; KSPSolve_CG's p'w from the pass that
+// makes w = A p): lanes in row order, a fixed tree -- deterministic; mi355x_spmv_dot_finish adds the blocks' values in block order.
+template <int ADD, bool DOT>
 __global__ __launch_bounds__(SPMV_THREADS, SPMV_MINWAVES) void spmv_csr_rowblock_pat_kernel(
     const int2 *__restrict__ rowblk, int nblocks, const unsigned int *__restrict__ prow,
     const int *__restrict__ pattab_g, const double *__restrict__ aa, const double *__restrict__ x, const double *yin, double *yout,
-    int pairsum) {
+    double *__restrict__ dotpart, int pairsum) {
   __shared__ double vs[SPMV_BLOCK_NNZ];
   __shared__ int pattab[SPMV_PAT_CAP];
+  __shared__ double wdot[DOT ? SPMV_THREADS / MI355X_WAVE : 1];
   static_assert(SPMV_THREADS == 256 && SPMV_BLOCK_ROWS <= SPMV_THREADS, "one lane per row of the block");
 #if SPMV_REMAP == 2
   const int xcd = blockIdx.x % MI355X_NXCD;
@@ -437,6 +441,7 @@ __global__ __launch_bounds__(SPMV_THREADS, SPMV_MINWAVES) void spmv_csr_rowblock
   const int t0 = pattab_g[tid], t1 = pattab_g[tid + SPMV_THREADS];     // SPMV_PAT_CAP initialised entries
   if (k1 == k0) {               // only empty rows
     if (tid < nrows) yout[r0 + tid] = spmv_empty<ADD>(ADD ? yin[r0 + tid] : 0.0);
+    if (DOT && tid == 0) dotpart[lb] = 0.0;
     return;
   }
   const int rc = tid < nrows ? tid : nrows - 1;
@@ -462,9 +467,9 @@ __global__ __launch_bounds__(SPMV_THREADS, SPMV_MINWAVES) void spmv_csr_rowblock
     vs[(k + 1 < k1) ? k + 1 - k0 : SPMV_BLOCK_NNZ - 1] = v[p].y;
   }
   __syncthreads();
-  if (tid >= nrows) return;
-  const int len = pattab[pst];                     // table entry: {length, offsets ...}
-  const long xbase = (long)r0 + tid;
+  if (!DOT && tid >= nrows) return;
+  const int len = tid < nrows ? pattab[pst] : 0;   // table entry: {length, offsets ...}
+  const long xbase = (long)r0 + rc;
   double sum = (ADD == 1) ? ysum : 0.0;
   for (int q0 = 0; q0 < len; q0 += 8) {
     double xv[8], av[8];
@@ -487,7 +492,19 @@ __global__ __launch_bounds__(SPMV_THREADS, SPMV_MINWAVES) void spmv_csr_rowblock
       }
     }
   }
-  yout[r0 + tid] = spmv_fin<ADD>(ysum, sum);
+  const double yv = spmv_fin<ADD>(ysum, sum);
+  if (tid < nrows) yout[r0 + tid] = yv;
+  if (DOT) {
+    const double c = wave_sum(tid < nrows ? yv * x[xbase] : 0.0);
+    if ((tid & (MI355X_WAVE - 1)) == 0) wdot[tid / MI355X_WAVE] = c;
+    __syncthreads();
+    if (tid == 0) {
+      double t = wdot[0];
+#pragma unroll
+      for (int w = 1; w < SPMV_THREADS / MI355X_WAVE; ++w) t += wdot[w];
+      dotpart[lb] = t;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -542,12 +559,13 @@ __device__ __forceinline__ double vpat_row(const int *pattab, const double *patv
   return sum;
 }
 
-template <int ADD>
+template <int ADD, bool DOT>
 __global__ __launch_bounds__(SPMV_THREADS) void spmv_csr_valpat_kernel(
     int nrows, const unsigned short *__restrict__ vrow, const int *__restrict__ pattab_g, const double *__restrict__ patval_g, int tablen,
-    const double *__restrict__ x, const double *yin, double *yout, int pairsum) {
+    const double *__restrict__ x, const double *yin, double *yout, double *__restrict__ dotpart, int pairsum) {
   __shared__ int pattab[SPMV_PAT_CAP];
   __shared__ double patval[SPMV_PAT_CAP];
+  __shared__ double wdot[DOT ? SPMV_THREADS / MI355X_WAVE : 1];
   const int tid = threadIdx.x;
   for (int t = tid; t < tablen; t += SPMV_THREADS) { pattab[t] = pattab_g[t]; patval[t] = patval_g[t]; }
   const long rbase = (long)blockIdx.x * SPMV_VPAT_ROWS + tid;          // the grid covers the rows exactly: no block without one
@@ -575,6 +593,23 @@ __global__ __launch_bounds__(SPMV_THREADS) void spmv_csr_valpat_kernel(
   for (int j = 0; j < SPMV_VPAT_RPL; ++j) {
     const long row = rbase + (long)j * SPMV_THREADS;
     if (row < nrows) yout[row] = res[j];
+  }
+  if (DOT) {   // x_r y_r over the workgroup's rows: a lane's rows in order, then the fixed tree of the other kernels
+    double c = 0.0;
+#pragma unroll
+    for (int j = 0; j < SPMV_VPAT_RPL; ++j) {
+      const long row = rbase + (long)j * SPMV_THREADS;
+      if (row < nrows) c += res[j] * x[row];
+    }
+    c = wave_sum(c);
+    if ((tid & (MI355X_WAVE - 1)) == 0) wdot[tid / MI355X_WAVE] = c;
+    __syncthreads();
+    if (tid == 0) {
+      double t = wdot[0];
+#pragma unroll
+      for (int w = 1; w < SPMV_THREADS / MI355X_WAVE; ++w) t += wdot[w];
+      dotpart[blockIdx.x] = t;
+    }
   }
 }
 
@@ -827,8 +862,17 @@ __global__ __launch_bounds__(SPMV_THREADS) void bsr_rowblock_kernel(const int2 *
 // sum of the per-row-block x'y values in block order: 1024 lanes stride over them, fixed tree
 __global__ __launch_bounds__(1024) void dot_partials_kernel(const double *__restrict__ part, int n, double *out) {
   __shared__ double lds[1024 / MI355X_WAVE];
-  double s = 0.0;
-  for (int i = threadIdx.x; i < n; i += 1024) s += part[i];
+  // eight loads in flight per lane (one dependent load per step took 22 us for the 57 K values of P7(256)); a fixed order of
+  // additions whatever n is: lane t owns values t, t + 1024, ..., added eight accumulators wide, the accumulators in a fixed tree
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0, a5 = 0.0, a6 = 0.0, a7 = 0.0;
+  int i = threadIdx.x;
+  for (; i + 7 * 1024 < n; i += 8 * 1024) {
+    const double v0 = part[i], v1 = part[i + 1024], v2 = part[i + 2 * 1024], v3 = part[i + 3 * 1024];
+    const double v4 = part[i + 4 * 1024], v5 = part[i + 5 * 1024], v6 = part[i + 6 * 1024], v7 = part[i + 7 * 1024];
+    a0 += v0; a1 += v1; a2 += v2; a3 += v3; a4 += v4; a5 += v5; a6 += v6; a7 += v7;
+  }
+  for (; i < n; i += 1024) a0 += part[i];
+  double s = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
   s = wave_sum(s);
   if ((threadIdx.x & (MI355X_WAVE - 1)) == 0) lds[threadIdx.x / MI355X_WAVE] = s;
   __syncthreads();
@@ -888,8 +932,8 @@ static int launch_spmv(mi355x_handle_t h, mi355x_spmv_plan_t p, const int *ai, c
   const bool cprow = p->d_rows != nullptr;
   if (p->vpat_valid && p->use_vpat && !cprow) {
     const int nb = (p->nrows + SPMV_VPAT_ROWS - 1) / SPMV_VPAT_ROWS;
-    hipLaunchKernelGGL((spmv_csr_valpat_kernel<ADD>), dim3(nb), dim3(SPMV_THREADS), 0, h->stream, p->nrows, p->d_vrow, p->d_vpattab,
-                       p->d_vpatval, p->vtablen, x, yin, yout, p->pairsum);
+    hipLaunchKernelGGL((spmv_csr_valpat_kernel<ADD, false>), dim3(nb), dim3(SPMV_THREADS), 0, h->stream, p->nrows, p->d_vrow, p->d_vpattab,
+                       p->d_vpatval, p->vtablen, x, yin, yout, (double *)nullptr, p->pairsum);
     MI355X_LAUNCH_CHECK();
     return 0;
   }
@@ -912,8 +956,8 @@ static int launch_spmv(mi355x_handle_t h, mi355x_spmv_plan_t p, const int *ai, c
 #else
     const int gp = p->nblocks;
 #endif
-    hipLaunchKernelGGL((spmv_csr_rowblock_pat_kernel<ADD>), dim3(gp), dim3(SPMV_THREADS), 0, h->stream, p->d_rowblk, p->nblocks,
-                       p->d_prow, p->d_pattab, aa, x, yin, yout, p->pairsum);
+    hipLaunchKernelGGL((spmv_csr_rowblock_pat_kernel<ADD, false>), dim3(gp), dim3(SPMV_THREADS), 0, h->stream, p->d_rowblk, p->nblocks,
+                       p->d_prow, p->d_pattab, aa, x, yin, yout, (double *)nullptr, p->pairsum);
     MI355X_LAUNCH_CHECK();
     return 0;
   }
@@ -1273,6 +1317,14 @@ int mi355x_spmv_plan_is_compressed(mi355x_spmv_plan_t p, int *ntab) {
   return 0;
 }
 
+// would mi355x_spmv_csr_dot run on this plan with this value array?
+int mi355x_spmv_plan_dot_available(mi355x_spmv_plan_t p, const double *aa, int *yes) {
+  const bool vpat = p->vpat_valid && p->use_vpat && !p->d_rows;
+  const bool pat = p->d_prow && p->use_pat && !p->d_rows && mi355x_aligned16(aa);
+  if (yes) *yes = (vpat || pat || (p->d_idx8 && !p->d_rows && mi355x_aligned16(aa))) ? 1 : 0;
+  return 0;
+}
+
 int mi355x_spmv_plan_info(mi355x_spmv_plan_t p, int *nblocks, int *nlong, size_t *workspace_bytes) {
   if (nblocks) *nblocks = p->nblocks;
   if (nlong) *nlong = p->nlong;
@@ -1298,23 +1350,39 @@ int mi355x_spmv_csr_scaled(mi355x_handle_t h, mi355x_spmv_plan_t plan, const int
 int mi355x_spmv_csr_dot(mi355x_handle_t h, mi355x_spmv_plan_t p, const int *ai, const int *aj, const double *aa,
                         const double *x, double *y) {
   (void)aj;
-  if (!p->d_idx8 || p->d_rows || !mi355x_aligned16(aa)) return (int)hipErrorNotSupported;
+  // the same choice of kernel as mi355x_spmv_csr makes (value patterns, row patterns, 8-bit offsets), each with the per-block sums
+  const bool vpat = p->vpat_valid && p->use_vpat && !p->d_rows;
+  const bool pat = p->d_prow && p->use_pat && !p->d_rows && mi355x_aligned16(aa);
+  if (!vpat && !pat && (!p->d_idx8 || p->d_rows || !mi355x_aligned16(aa))) return (int)hipErrorNotSupported;
   if (p->nblocks == 0) return 0;
-  if (!p->d_dotpart) MI355X_TRY(hipMalloc((void **)&p->d_dotpart, sizeof(double) * (size_t)p->nblocks));
+  const int nvb = (p->nrows + SPMV_VPAT_ROWS - 1) / SPMV_VPAT_ROWS;
+  { const size_t need = (size_t)(p->nblocks > nvb ? p->nblocks : nvb);
+    if (!p->d_dotpart) MI355X_TRY(hipMalloc((void **)&p->d_dotpart, sizeof(double) * need)); }
 #if SPMV_REMAP == 2
   const int per8 = MI355X_NXCD * SPMV_CH;
   const int g8 = ((p->nblocks + per8 - 1) / per8) * per8;
 #else
   const int g8 = p->nblocks;
 #endif
-  hipLaunchKernelGGL((spmv_csr_rowblock_idx8_kernel<0, true>), dim3(g8), dim3(SPMV_THREADS), 0, h->stream, p->d_rowblk,
-                     p->nblocks, ai, p->d_idx8, p->d_offtab, p->ntab, aa, x, (const double *)nullptr, y, p->d_dotpart, p->pairsum);
+  if (vpat) {
+    hipLaunchKernelGGL((spmv_csr_valpat_kernel<0, true>), dim3(nvb), dim3(SPMV_THREADS), 0, h->stream, p->nrows, p->d_vrow, p->d_vpattab,
+                       p->d_vpatval, p->vtablen, x, (const double *)nullptr, y, p->d_dotpart, p->pairsum);
+    p->ndotpart = nvb;
+  } else if (pat) {
+    hipLaunchKernelGGL((spmv_csr_rowblock_pat_kernel<0, true>), dim3(g8), dim3(SPMV_THREADS), 0, h->stream, p->d_rowblk, p->nblocks,
+                       p->d_prow, p->d_pattab, aa, x, (const double *)nullptr, y, p->d_dotpart, p->pairsum);
+    p->ndotpart = p->nblocks;
+  } else {
+    hipLaunchKernelGGL((spmv_csr_rowblock_idx8_kernel<0, true>), dim3(g8), dim3(SPMV_THREADS), 0, h->stream, p->d_rowblk,
+                       p->nblocks, ai, p->d_idx8, p->d_offtab, p->ntab, aa, x, (const double *)nullptr, y, p->d_dotpart, p->pairsum);
+    p->ndotpart = p->nblocks;
+  }
   MI355X_LAUNCH_CHECK();
   return 0;
 }
 int mi355x_spmv_dot_finish(mi355x_handle_t h, mi355x_spmv_plan_t p, double *out) {
-  if (p->nblocks == 0 || !p->d_dotpart) { MI355X_TRY(hipMemsetAsync(out, 0, sizeof(double), h->stream)); return 0; }
-  hipLaunchKernelGGL(dot_partials_kernel, dim3(1), dim3(1024), 0, h->stream, p->d_dotpart, p->nblocks, out);
+  if (p->nblocks == 0 || !p->d_dotpart || p->ndotpart <= 0) { MI355X_TRY(hipMemsetAsync(out, 0, sizeof(double), h->stream)); return 0; }
+  hipLaunchKernelGGL(dot_partials_kernel, dim3(1), dim3(1024), 0, h->stream, p->d_dotpart, p->ndotpart, out);
   MI355X_LAUNCH_CHECK();
   return 0;
 }

@@ -637,7 +637,8 @@ PetscErrorCode MatHIPMI355XGetInodeInfo(Mat A, PetscInt *nodes, PetscInt *groups
 
 /* w = A p with dpi = p'w as a by-product of the same pass (KSPSolve_CG cg.c:190-191); dpi is left in the device
  * scratch slot the fused CG update reads (all-reduced there when the vectors' communicator has an RCCL communicator).
- * *ok = PETSC_FALSE and nothing done unless A is a square, sequential, index-compressed AIJ matrix of this type. */
+ * *ok = PETSC_FALSE and nothing done unless A is a square, sequential AIJ matrix of this type whose product kernel is one of the
+ * row-block kernels that also leave the per-block sums (value patterns, row patterns, 8-bit column offsets). */
 PetscErrorCode MatMultTDotBegin_HIPMI355X(Mat A, Vec xx, Vec yy, PetscBool *ok) {
   PetscErrorCode ierr;
   *ok = PETSC_FALSE;
@@ -649,14 +650,12 @@ PetscErrorCode MatMultTDotBegin_HIPMI355X(Mat A, Vec xx, Vec yy, PetscBool *ok) 
   ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
   ierr = MatSeqAIJHIPUpload(A);CHKERRQ(ierr);
   if (!d->plan) return 0;
-  CHKHIP(mi355x_spmv_plan_is_compressed(d->plan, &ntab));
+  CHKHIP(mi355x_spmv_plan_dot_available(d->plan, d->d_a, &ntab));   /* a plan whose kernel also leaves the per-block sums: patterns or 8-bit offsets */
   if (!ntab) return 0;
   ierr = VecHIPGetRead(xx, &x);CHKERRQ(ierr);
   ierr = VecHIPGetWrite(yy, &y);CHKERRQ(ierr);
   ierr = MatTimingBegin(A, dc->h);CHKERRQ(ierr);
-  int rc = mi355x_spmv_csr_dot(dc->h, d->plan, d->d_i, d->d_j, d->d_a, x, y);
-  if (rc == 801) return 0;   /* hipErrorNotSupported: nothing was launched */
-  CHKHIP(rc);
+  CHKHIP(mi355x_spmv_csr_dot(dc->h, d->plan, d->d_i, d->d_j, d->d_a, x, y));
   ierr = MatTimingEnd(A, dc->h);CHKERRQ(ierr);
   double *slot = mi355x_handle_device_scratch(dc->h) + PETSC_HIP_DPI_SLOT;
   CHKHIP(mi355x_spmv_dot_finish(dc->h, d->plan, slot));

@@ -82,7 +82,7 @@ static PetscErrorCode report(KSP ksp, PetscInt it, PetscReal rn) {   /* what eve
 }
 
 /* ================================================================================================ CG
- * -ksp_cg_fused <0..4> (default 3); iterates and history carry the same bits at levels 0..3:
+ * -ksp_cg_fused <0..4> (default 4); iterates and history carry the same bits at levels 0..3:
  *  0  every step through the public Vec / Mat / PC calls (what KSPCG does);
  *  1  with PCJACOBI or PCNONE the five calls between the two reductions of an iteration -- x += a p, r -= a w, z = B r, |z|,
  *     z'r (cg.c:206-232) -- are ONE sweep returning z'z, z'r and r'r; any other PC: norm and dot share one VecDotNorm2;
@@ -91,7 +91,8 @@ static PetscErrorCode report(KSP ksp, PetscInt it, PetscReal rn) {   /* what eve
  *  3  as 2, and while the host waits for the sums of iteration i the device already runs p = z + b p (b formed on the device),
  *     w = A p and p'w of iteration i+1.  If the convergence test ends the solve only work vectors have been touched.  Not done
  *     for the last permitted iteration nor within 10x of the target;
- *  4  as 3 with p'w produced by the SpMV pass itself (another summation tree: agrees to rounding, not bit for bit). */
+ *  4  as 3 with p'w produced by the SpMV pass itself (another summation tree: agrees with the other levels to rounding, not bit for
+ *     bit; deterministic).  Sequential AIJ matrices whose product kernel leaves per-block sums ("MatMultTDotBegin_C"); level 3 otherwise. */
 typedef struct { PetscInt level; Vec dinv; } KSP_CGHIP;
 
 static PetscErrorCode KSPSetUp_CGHIP(KSP ksp) { return KSPDefaultGetWork(ksp, 3); }
@@ -228,7 +229,7 @@ static PetscErrorCode KSPSolve_CGHIP(KSP ksp) {
 PetscErrorCode KSPCreate_CGHIPMI355X(KSP ksp) {
   KSP_CGHIP *cg;
   PetscErrorCode ierr = PetscMalloc(sizeof(*cg), &cg);CHKERRQ(ierr);
-  cg->level = 3; cg->dinv = NULL;
+  cg->level = 4; cg->dinv = NULL;
   ksp->data = cg;
   ierr = KSPSetSupportedNorm(ksp, KSP_NORM_PRECONDITIONED, PC_LEFT, 2);CHKERRQ(ierr);    /* the four of KSPCG, cg.c:439-442 */
   ierr = KSPSetSupportedNorm(ksp, KSP_NORM_UNPRECONDITIONED, PC_LEFT, 1);CHKERRQ(ierr);

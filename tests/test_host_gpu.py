@@ -302,9 +302,9 @@ def test_gmres_fused_equals_op_by_op_bit_for_bit(P, pc, opts):
         assert abs(ito - it1) <= 1 and np.allclose(ho[:50], h1[:50], rtol=1e-9, atol=0)
 
 
-@pytest.mark.parametrize("ksp,pc,opts", [("cg", "jacobi", ""), ("cg", "none", ""), ("cg", "jacobi", "-ksp_cg_fused 0"), ("gmres", "jacobi", ""),
+@pytest.mark.parametrize("ksp,pc,opts", [("cg", "jacobi", "-ksp_cg_fused 3"), ("cg", "none", "-ksp_cg_fused 3"), ("cg", "jacobi", "-ksp_cg_fused 0"), ("gmres", "jacobi", ""),
                                         ("gmres", "ilu", ""), ("gmres", "none", "-ksp_gmres_restart 9"), ("bcgs", "jacobi", ""), ("bcgs", "none", ""),
-                                        ("groppcg", "jacobi", ""), ("cg", "jacobi", "-ksp_norm_type natural"),
+                                        ("groppcg", "jacobi", ""), ("cg", "jacobi", "-ksp_norm_type natural -ksp_cg_fused 3"),
                                         ("gmres", "jacobi", "-ksp_gmres_cgs_refinement_type refine_always"), ("pipecg", "jacobi", "-ksp_norm_type natural"),
                                         ("gmres", "jacobi", "-ksp_gmres_fused 0"), ("bcgs", "jacobi", "-ksp_bcgs_fused 0")])
 def test_whole_solves_equal_the_oracle_bit_for_bit_in_the_device_summation_order(P, ksp, pc, opts):
@@ -340,14 +340,20 @@ def test_whole_solves_equal_the_oracle_bit_for_bit_in_the_device_summation_order
 @pytest.mark.parametrize("ksp,pc", [("cg", "jacobi"), ("cg", "none"), ("gmres", "jacobi"), ("bcgs", "jacobi"), ("gmres", "ilu"), ("groppcg", "jacobi")])
 def test_value_patterns_leave_every_bit_of_a_solve_alone(P, ksp, pc):
     """the product run from the row dictionary (default) against the same solve with the value array streamed
-    (-mat_hipmi355x_value_patterns 0): every residual norm and the solution, bit for bit -- 3-D 7-point and 2-D 5-point operators"""
+    (-mat_hipmi355x_value_patterns 0): every residual norm and the solution, bit for bit -- 3-D 7-point and 2-D 5-point operators
+    (CG at -ksp_cg_fused 3: its default forms p'w inside the SpMV pass, where the two kernels sum in different trees)"""
     for (ai, aj, aa) in (orc.gen_p7(19, 16, 14), pb.lap2d(37, 29)):
         n = ai.size - 1
         b = np.cos(0.21 * np.arange(n)) + 0.3
-        runs = [solve(P, ai, aj, aa, b, ksp, pc, opts=o, rtol=1e-10) for o in ("", "-mat_hipmi355x_value_patterns 0")]
+        lv = "-ksp_cg_fused 3 " if ksp == "cg" else ""
+        runs = [solve(P, ai, aj, aa, b, ksp, pc, opts=lv + o, rtol=1e-10) for o in ("", "-mat_hipmi355x_value_patterns 0")]
         (x0, h0, its0, r0), (x1, h1, its1, r1) = runs
         assert (its0, r0) == (its1, r1) and its0 > 10
         assert np.array_equal(h0.view(np.uint64), h1.view(np.uint64)) and np.array_equal(x0.view(np.uint64), x1.view(np.uint64))
+        if ksp == "cg":    # CG's default takes p'w out of the SpMV pass, per workgroup: the two kernels' trees differ, the products do not
+            (x4, h4, its4, r4), (x5, h5, its5, r5) = [solve(P, ai, aj, aa, b, ksp, pc, opts=o, rtol=1e-10) for o in ("", "-mat_hipmi355x_value_patterns 0")]
+            assert r4 == r5 == r0 and abs(its4 - its0) <= 1 and abs(its5 - its0) <= 1
+            assert np.linalg.norm(x4 - x0) <= 1e-8 * np.linalg.norm(x0) and np.linalg.norm(x5 - x0) <= 1e-8 * np.linalg.norm(x0)
     # and the default really is the dictionary, the option really the streamed values
     L = P.lib(); nv = C.c_int()
     A = P.Mat.from_csr(*orc.gen_p7(6, 5, 4)); L.MatHIPMI355XGetValuePatterns(A.h, C.byref(nv)); assert nv.value > 0; A.destroy()
@@ -364,7 +370,9 @@ def test_config1_cg_jacobi_equals_the_oracle_bit_for_bit_in_the_device_summation
     ai, aj, aa = pb.lap2d(100, 100)
     b = orc.spmv(ai, aj, aa, np.ones(10000))
     rtol = 1e-2 / (101 * 101)                                     # ex2.c: KSPSetTolerances(ksp, 1.e-2/((m+1)*(n+1)), 1.e-50, ...)
-    x, h, its, reason = solve(P, ai, aj, aa, b, "cg", "jacobi", rtol=rtol, abstol=1e-50)
+    x, h, its, reason = solve(P, ai, aj, aa, b, "cg", "jacobi", rtol=rtol, abstol=1e-50, opts="-ksp_cg_fused 3")
+    x4, h4, its4, reason4 = solve(P, ai, aj, aa, b, "cg", "jacobi", rtol=rtol, abstol=1e-50)      # the default: p'w out of the SpMV pass
+    assert (its4, reason4) == (its, reason) and np.allclose(h4, h, rtol=1e-9, atol=0) and np.linalg.norm(x4 - x) <= 1e-9 * np.linalg.norm(x)
     with orc.device_reduction_order():
         xo, ho, ito, ro = orc.ksp_solve(ai, aj, aa, b, ksp="cg", pc="jacobi", rtol=rtol, abstol=1e-50)
     assert (its, reason) == (ito, ro) and its == 160
@@ -541,11 +549,12 @@ def test_ksp_cg_fused_forms_are_bit_identical(P, pc):
         assert itsf == itsu and rf == ru
         assert np.array_equal(bits(hf), bits(hu))
         assert np.array_equal(bits(xf), bits(xu))
-    xd, hd, itsd, rd = solve(P, ai, aj, aa, b, "cg", pc, rtol=1e-9)            # default = level 3
-    assert itsd == itsu and np.array_equal(bits(hd), bits(hu)) and np.array_equal(bits(xd), bits(xu))
-    # level 4: p'w is a by-product of the SpMV pass, summed in another order -> agreement to rounding
-    for level in ("4",):
-        xf, hf, itsf, rf = solve(P, ai, aj, aa, b, "cg", pc, opts="-ksp_cg_fused " + level, rtol=1e-9)
+    # level 4 (the default): p'w is a by-product of the SpMV pass, summed in another order -> agreement to rounding
+    x4 = None
+    for opts4 in ("-ksp_cg_fused 4", ""):
+        xf, hf, itsf, rf = solve(P, ai, aj, aa, b, "cg", pc, opts=opts4, rtol=1e-9)
+        assert x4 is None or np.array_equal(bits(xf), bits(x4))               # the default IS level 4; deterministic
+        x4 = xf
         assert abs(itsf - itsu) <= 1 and rf == ru
         k_ = min(len(hf), len(hu))
         assert np.allclose(hf[:k_], hu[:k_], rtol=1e-9, atol=0)
@@ -616,13 +625,14 @@ def test_device_collectives_on_a_one_rank_rccl_communicator(P):
         assert x.dot(y) == xc.dot(yc)
         # groppcg: its split-phase all-reduce travels on the HALO stream and is published from the halo handle
         for ksp, pc in (("cg", "jacobi"), ("cg", "none"), ("gmres", "jacobi"), ("bcgs", "jacobi"), ("groppcg", "jacobi"), ("groppcg", "bjacobi")):
-            ref = solve(P, ai, aj, aa, b, ksp, pc, rtol=1e-9)
-            got = solve(P, ai, aj, aa, b, ksp, pc, rtol=1e-9, comm=comm)
+            o = "-ksp_cg_fused 3" if ksp == "cg" else ""      # (level 4 takes p'w out of the sequential SpMV pass; a parallel matrix runs level 3)
+            ref = solve(P, ai, aj, aa, b, ksp, pc, rtol=1e-9, opts=o)
+            got = solve(P, ai, aj, aa, b, ksp, pc, rtol=1e-9, comm=comm, opts=o)
             assert got[2:] == ref[2:]
             assert np.array_equal(bits(got[1]), bits(ref[1])) and np.array_equal(bits(got[0]), bits(ref[0]))
             # the same through a MATMPIAIJ on that communicator (MatMult_MPIAIJ's stream choreography, parallel Vec
             # type, the queued-ahead CG front half over it); everything is in the diagonal block, so same bits again
-            got = solve(P, ai, aj, aa, b, ksp, pc, rtol=1e-9, comm=comm, mpi=True)
+            got = solve(P, ai, aj, aa, b, ksp, pc, rtol=1e-9, comm=comm, mpi=True, opts=o)
             assert got[2:] == ref[2:]
             assert np.array_equal(bits(got[1]), bits(ref[1])) and np.array_equal(bits(got[0]), bits(ref[0]))
     finally:
@@ -653,7 +663,7 @@ def test_ksp_bcgs_fused_forms_are_bit_identical(P, pc):
 @pytest.mark.parametrize("pc", ["jacobi", "ilu"])
 def test_ksp_cg_norm_types(P, norm, pc):
     """KSPSolve_CG's four norm types (cg.c:136-161,233-260; -ksp_norm_type): the history against the oracle's
-    restatement, and the fused default against the op-by-op sequence bit for bit (the fused sweep also returns r'r,
+    restatement, and the fused sweeps (level 3) against the op-by-op sequence bit for bit (the fused sweep also returns r'r,
     so every norm comes out of the same reduction).  KSP_NORM_NONE runs to max_it and ends KSP_CONVERGED_ITS (4)."""
     ai, aj, aa = pb.lap2d(33, 29)
     n = ai.size - 1
@@ -663,8 +673,10 @@ def test_ksp_cg_norm_types(P, norm, pc):
     b = orc.spmv(ai, aj, aa, np.cos(0.3 * np.arange(n)))
     kw = dict(rtol=1e-8, max_it=37 if norm == "none" else 500)
     o = "-ksp_norm_type " + norm
-    xf, hf, itsf, rf = solve(P, ai, aj, aa, b, "cg", pc, opts=o, **kw)
+    xf, hf, itsf, rf = solve(P, ai, aj, aa, b, "cg", pc, opts=o + " -ksp_cg_fused 3", **kw)
     xu, hu, itsu, ru = solve(P, ai, aj, aa, b, "cg", pc, opts=o + " -ksp_cg_fused 0", **kw)
+    xd, hd, itsd, rd = solve(P, ai, aj, aa, b, "cg", pc, opts=o, **kw)          # the default (level 4: p'w out of the SpMV pass): to rounding
+    assert rd == ru and abs(itsd - itsu) <= 1 and np.linalg.norm(xd - xu) <= 1e-7 * np.linalg.norm(xu)
     nt = dict(none=0, preconditioned=1, unpreconditioned=2, natural=3)[norm]
     xr, hr, itsr, rr = orc.ksp_solve(ai, aj, aa, b, ksp="cg", pc=pc, norm_type=nt, **kw)
     assert itsf == itsu and rf == ru and np.array_equal(bits(hf), bits(hu)) and np.array_equal(bits(xf), bits(xu))
@@ -850,7 +862,7 @@ def test_ksp_cg_single_reduction(P):
     assert np.linalg.norm(x - 1.0) < 1e-6
 
 
-@pytest.mark.parametrize("fused", [0, 1, 3])
+@pytest.mark.parametrize("fused", [0, 1, 3, 4])
 def test_ksp_cg_pc_tests_ex2_golden(P, fused):
     """src/ksp/pc/examples/tests/ex2.c -ksp_type cg -ksp_monitor_short vs output/ex2_1.out (the reference's own CG
     golden: tridiagonal n = 10, PCNONE, 5 iterations) on the HIP path, op-by-op and fused forms"""
@@ -1460,8 +1472,8 @@ def test_p7_full_size_properties(P):
 def test_cg_jacobi_full_size_properties(P):
     """KSPCG + PCJACOBI at BASELINE.json's full size (P7(256)) through size-independent properties: the solve of
     A x = A*1 converges to the vector of ones, the reported (preconditioned) residual norm equals the recomputed
-    ||D^-1 (b - A x)|| to 1e-6, and the fused default and the op-by-op sequence (-ksp_cg_fused 0) produce the same
-    iteration count, the same history bits and the same x bits at this size too."""
+    ||D^-1 (b - A x)|| to 1e-6, and the fused sweeps (level 3) and the op-by-op sequence (-ksp_cg_fused 0) produce the same
+    iteration count, the same history bits and the same x bits at this size too; the default (level 4) agrees to rounding."""
     L = P.lib()
     n = 256
     ai, aj, aa = P.gen_poisson7(n, n, n)
@@ -1470,7 +1482,7 @@ def test_cg_jacobi_full_size_properties(P):
     one = P.Vec.create(N, comm=L.COMM_SELF); L.VecSet(one.h, 1.0)
     b = one.duplicate(); A.mult(one, b)
     outs = []
-    for opts in ("", "-ksp_cg_fused 0"):
+    for opts in ("-ksp_cg_fused 3", "-ksp_cg_fused 0", ""):
         x = one.duplicate(); L.VecSet(x.h, 0.0)
         k = P.KSP(comm=L.COMM_SELF)
         k.set_operators(A)
@@ -1481,7 +1493,9 @@ def test_cg_jacobi_full_size_properties(P):
         k.solve(b, x)
         L.PetscOptionsClear()
         outs.append((k.its, k.reason, k.history().copy(), x))
-    (its, reason, h, x), (its0, reason0, h0, x0) = outs
+    (its, reason, h, x), (its0, reason0, h0, x0), (its4, reason4, h4, x4) = outs
+    assert reason4 == 2 and abs(its4 - its0) <= 2 and np.max(np.abs(x4.array() - 1.0)) < 1e-4     # the default (level 4): to rounding
+    del x4
     assert reason == reason0 == 2 and its == its0 and 200 < its < 2000
     assert np.array_equal(bits(h), bits(h0))
     xa = x.array()

@@ -554,6 +554,32 @@ def test_spmv_with_dot_byproduct(dev):
         for q in (dai, daj, daa, dx, dy, dy2, dout):
             dev.free(q)
         assert ci != 0 or nt.value == 7
+    # the same by-product out of the pattern kernels: row patterns (case 0 above has them: values streamed, offsets from a dictionary)
+    # and value patterns (constant coefficients: the value array is not read; several rows per lane, ragged last workgroup)
+    for dims in ((33, 17, 9), (40, 40, 3)):
+        ai, aj, aa = orc.gen_p7(*dims)
+        m = ai.size - 1
+        x = rnd(m, 90)
+        dai, daj, daa = upload_csr(dev, ai, aj, aa)
+        dx = dev.put(x); dy = dev.put(np.full(m, 7.0)); dy2 = dev.put(np.full(m, 9.0)); dout = dev.alloc(64)
+        plan = make_plan(dev, ai, None)
+        nv = C.c_int()
+        dev.chk(k.mi355x_spmv_plan_value_patterns(dev.h, plan, ai.ctypes.data, aj.ctypes.data, aa.ctypes.data, C.byref(nv)))
+        assert nv.value > 0
+        yes = C.c_int(); dev.chk(k.mi355x_spmv_plan_dot_available(plan, daa, C.byref(yes))); assert yes.value == 1
+        dev.chk(k.mi355x_spmv_csr_dot(dev.h, plan, dai, daj, daa, dx, dy))
+        dev.chk(k.mi355x_spmv_dot_finish(dev.h, plan, dout))
+        dev.chk(k.mi355x_spmv_csr(dev.h, plan, dai, daj, daa, dx, dy2))
+        y, y2 = dev.get(dy, m), dev.get(dy2, m)
+        assert_bitexact(y, y2); assert_bitexact(y, orc.spmv(ai, aj, aa, x))
+        got = dev.get(dout, 1)[0]
+        assert abs(got - orc.vec_dot(x, y)) <= 1e-13 * np.sum(np.abs(x * y)), (dims, got)
+        dev.chk(k.mi355x_spmv_csr_dot(dev.h, plan, dai, daj, daa, dx, dy))        # deterministic
+        dev.chk(k.mi355x_spmv_dot_finish(dev.h, plan, dout))
+        assert dev.get(dout, 1)[0] == got
+        dev.chk(k.mi355x_spmv_plan_destroy(plan))
+        for q in (dai, daj, daa, dx, dy, dy2, dout):
+            dev.free(q)
 
 
 def test_spmv_short_rows_bitexact(dev):
