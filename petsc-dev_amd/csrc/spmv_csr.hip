@@ -21,6 +21,8 @@
 #include "common.hpp"
 #include <map>
 #include <vector>
+#include <thread>
+#include <functional>
 #include <stdlib.h>
 #include <string.h>
 
@@ -1145,41 +1147,80 @@ int mi355x_spmv_plan_value_patterns(mi355x_handle_t h, mi355x_spmv_plan_t p, con
   p->vpat_valid = 0;
   if (p->d_rows || p->nrows == 0 || !p->use_vpat) return 0;
   const int m = p->nrows;
-  std::vector<unsigned short> vrow((size_t)m);
-  std::vector<int> ptab;
-  std::vector<double> pval;
-  std::vector<int> starts;                         // the entries, in order of first appearance
-  ptab.reserve(SPMV_PAT_CAP); pval.reserve(SPMV_PAT_CAP);
-  // table entry: {length, byte offsets of the columns relative to the row ..., padded to a multiple of 8 slots with copies of the
-  // first offset}; values at the offsets' indices (pads 0.0, never used in a sum)
-  auto same = [&](int s, int r, int len) {
-    if (ptab[(size_t)s] != len) return false;
-    const int k0 = ai_host[r];
-    for (int q = 0; q < len; ++q) if ((aj_host[k0 + q] - r) * 8 != ptab[(size_t)s + 1 + q]) return false;
-    return len == 0 || memcmp(aa_host + k0, pval.data() + s + 1, sizeof(double) * (size_t)len) == 0;
-  };
   if (m > SPMV_VPAT_MAXROWS) return 0;              // byte offsets into x are 32-bit
-  int prev = -1;
-  for (int r = 0; r < m; ++r) {
-    const int len = ai_host[r + 1] - ai_host[r];
-    int start = -1;
-    if (prev >= 0 && same(prev, r, len)) start = prev;
-    else for (size_t e = 0; e < starts.size(); ++e) if (same(starts[e], r, len)) { start = starts[e]; break; }
-    if (start < 0) {
-      const int slots = (len + 7) / 8 * 8;
-      start = (int)ptab.size();
-      if (start + 1 + slots > SPMV_PAT_CAP) return 0;                // not a constant-coefficient operator
-      ptab.push_back(len); pval.push_back(0.0);
-      for (int q = 0; q < slots; ++q) {
-        const int col = aj_host[ai_host[r] + (q < len ? q : 0)];
-        if (col >= SPMV_VPAT_MAXROWS) return 0;
-        ptab.push_back((col - r) * 8);
-        pval.push_back(q < len ? aa_host[ai_host[r] + q] : 0.0);
+  std::vector<unsigned short> vrow((size_t)m);
+  // table entry: {length, byte offsets of the columns relative to the row ..., padded to a multiple of 8 slots with copies of the
+  // first offset}; values at the offsets' indices (pads 0.0, never used in a sum).  Entries in order of first appearance.
+  // The rows are analysed in contiguous chunks by a few host threads, each with a dictionary of its own (a pass over 0.94 GB of
+  // values on one thread cost 0.2 s at every upload of P7(256)); the chunks' dictionaries are then merged in chunk order -- the
+  // merged table is the one a single pass over all rows builds -- and the rows' entries renumbered.
+  struct Dict { std::vector<int> ptab; std::vector<double> pval; std::vector<int> starts; bool ok = true; };
+  auto analyse = [&](int r0, int r1, Dict &d) {
+    d.ptab.reserve(SPMV_PAT_CAP); d.pval.reserve(SPMV_PAT_CAP);
+    auto same = [&](int s_, int r, int len) {
+      if (d.ptab[(size_t)s_] != len) return false;
+      const int k0 = ai_host[r];
+      for (int q = 0; q < len; ++q) if ((aj_host[k0 + q] - r) * 8 != d.ptab[(size_t)s_ + 1 + q]) return false;
+      return len == 0 || memcmp(aa_host + k0, d.pval.data() + s_ + 1, sizeof(double) * (size_t)len) == 0;
+    };
+    int prev = -1;
+    for (int r = r0; r < r1; ++r) {
+      const int len = ai_host[r + 1] - ai_host[r];
+      int start = -1;
+      if (prev >= 0 && same(prev, r, len)) start = prev;
+      else for (size_t e = 0; e < d.starts.size(); ++e) if (same(d.starts[e], r, len)) { start = d.starts[e]; break; }
+      if (start < 0) {
+        const int slots = (len + 7) / 8 * 8;
+        start = (int)d.ptab.size();
+        if (start + 1 + slots > SPMV_PAT_CAP) { d.ok = false; return; }      // not a constant-coefficient operator
+        d.ptab.push_back(len); d.pval.push_back(0.0);
+        for (int q = 0; q < slots; ++q) {
+          const int col = aj_host[ai_host[r] + (q < len ? q : 0)];
+          if (col >= SPMV_VPAT_MAXROWS) { d.ok = false; return; }
+          d.ptab.push_back((col - r) * 8);
+          d.pval.push_back(q < len ? aa_host[ai_host[r] + q] : 0.0);
+        }
+        d.starts.push_back(start);
       }
-      starts.push_back(start);
+      prev = start;
+      vrow[(size_t)r] = (unsigned short)start;
     }
-    prev = start;
-    vrow[(size_t)r] = (unsigned short)start;
+  };
+  unsigned hc = std::thread::hardware_concurrency();
+  int nth = (int)(hc > 8 ? 8 : (hc < 1 ? 1 : hc));
+  if (m < 400000) nth = 1;
+  std::vector<Dict> dicts((size_t)nth);
+  if (nth == 1) analyse(0, m, dicts[0]);
+  else {
+    std::vector<std::thread> th;
+    for (int k = 0; k < nth; ++k) th.emplace_back(analyse, (int)((long)m * k / nth), (int)((long)m * (k + 1) / nth), std::ref(dicts[(size_t)k]));
+    for (auto &t : th) t.join();
+  }
+  for (auto &d : dicts) if (!d.ok) return 0;
+  std::vector<int> ptab(std::move(dicts[0].ptab)), starts(std::move(dicts[0].starts));
+  std::vector<double> pval(std::move(dicts[0].pval));
+  for (int k = 1; k < nth; ++k) {
+    const Dict &d = dicts[(size_t)k];
+    std::vector<int> to((size_t)SPMV_PAT_CAP, -1);             // this chunk's entry (by its start) -> the merged table's
+    for (size_t e = 0; e < d.starts.size(); ++e) {
+      const int ls = d.starts[e], len = d.ptab[(size_t)ls], slots = (len + 7) / 8 * 8;
+      int g = -1;
+      for (size_t f = 0; f < starts.size() && g < 0; ++f) {
+        const int gs = starts[f];
+        if (ptab[(size_t)gs] == len && memcmp(&ptab[(size_t)gs + 1], &d.ptab[(size_t)ls + 1], sizeof(int) * (size_t)len) == 0 &&
+            (len == 0 || memcmp(&pval[(size_t)gs + 1], &d.pval[(size_t)ls + 1], sizeof(double) * (size_t)len) == 0)) g = gs;
+      }
+      if (g < 0) {
+        g = (int)ptab.size();
+        if (g + 1 + slots > SPMV_PAT_CAP) return 0;
+        ptab.insert(ptab.end(), d.ptab.begin() + ls, d.ptab.begin() + ls + 1 + slots);
+        pval.insert(pval.end(), d.pval.begin() + ls, d.pval.begin() + ls + 1 + slots);
+        starts.push_back(g);
+      }
+      to[(size_t)ls] = g;
+    }
+    const int r0 = (int)((long)m * k / nth), r1 = (int)((long)m * (k + 1) / nth);
+    for (int r = r0; r < r1; ++r) vrow[(size_t)r] = (unsigned short)to[(size_t)vrow[(size_t)r]];
   }
   if (!p->d_vrow) {
     MI355X_TRY(hipMalloc((void **)&p->d_vrow, sizeof(unsigned short) * (size_t)m + 16));

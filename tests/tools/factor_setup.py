@@ -28,7 +28,8 @@ def main():
     n = ai.size - 1
     A = P.Mat.from_csr(ai, aj, aa)
     b = P.Vec.from_array(np.sin(0.1 * np.arange(n)), comm=L.COMM_SELF); x = b.duplicate()
-    A.mult(b, x); k.mi355x_device_synchronize()
+    t0 = time.time(); A.mult(b, x); k.mi355x_device_synchronize()
+    print("first product (upload of the matrix, analysis of its pattern and values, SpMV plan): %.3f s" % (time.time() - t0), flush=True)
     ksp = P.KSP(comm=L.COMM_SELF); ksp.set_operators(A)
     pc = C.c_void_p(); L.KSPGetPC(ksp.h, C.byref(pc)); L.PCSetType(pc, pct.encode())
     L.PetscOptionsInsertString(os.environ.get("FEM_OPTS", "").encode())
