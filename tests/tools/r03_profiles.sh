@@ -31,6 +31,10 @@ pmc bench "FETCH_SIZE WRITE_SIZE" --stamp python3 $R/bench.py --steps 10 --warmu
 python3 $T/fem_ilu_apply.py > $O/ilu_fem.log 2>&1 || exit 1
 stats ilu_fem python3 $T/fem_ilu_apply.py || exit 1
 pmc ilu_fem "FETCH_SIZE WRITE_SIZE" python3 $T/fem_ilu_apply.py
+# config 4 end to end on the FEM stand-in: GMRES(30) + ILU(0) (level order = the default, then the reference's inode order), set-up cost
+python3 $T/cfg4_solve.py fem ilu > $O/cfg4_fem_ilu.log 2>&1 || exit 1
+CFG4_OPTS="-pc_factor_hipmi355x_trisolve_order column" python3 $T/cfg4_solve.py fem ilu > $O/cfg4_fem_ilu_column.log 2>&1 || exit 1
+for a in "p7:256 ilu" "p7:256 icc" "fem ilu" "fem icc"; do PETSC_HIPMI355X_SETUP_TIMING=1 python3 $T/factor_setup.py $a; done > $O/factor_setup.log 2>&1 || exit 1
 # config 5 (BAIJ): the two forms of the row-block kernel, traffic and texture / L1 counters
 stats cfg5 python3 $T/cfg5_baij.py 128 3 bs3x,bs3g,bs4x,bs4mfma || exit 1
 pmc cfg5 "FETCH_SIZE WRITE_SIZE TA_BUSY_avr TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_LATENCY_sum TA_FLAT_READ_WAVEFRONTS_sum SQ_WAIT_INST_ANY SQ_WAVE_CYCLES" python3 $T/cfg5_baij.py 128 2 bs3x,bs3g
