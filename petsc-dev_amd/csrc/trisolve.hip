@@ -254,7 +254,7 @@ template <int NB, bool UPPER, bool POLL, bool BLK>
 __device__ __forceinline__ void tri_node_solve(const int t, const int lane, const int np, const int base, const int off, const int ncol, const int row0, const int nsz,
                                                const int *__restrict__ col, const double *__restrict__ val, const double *__restrict__ din,
                                                const double *src, const int *__restrict__ spos, double *w, double *y, double *reset,
-                                               int *abort_flag, const int sleep_cap) {
+                                               int *abort_flag, const int sleep_cap, const double *__restrict__ rscale) {
 #ifndef TRI_NODE_B
 #define TRI_NODE_B 8
 #endif
@@ -273,6 +273,7 @@ __device__ __forceinline__ void tri_node_solve(const int t, const int lane, cons
       if (UPPER) {                             // sum[k] belongs to the node's row nsz - 1 - k (k = distance from the LAST row, as the reference counts)
         const int p = spos[row0 + nsz - 1 - k];
         sum[k] = src[p];
+        if (rscale) sum[k] = sum[k] * rscale[t];      // single-row plans of an incomplete Cholesky factor: D^-1 between the two sweeps
         if (POLL) reset[p] = __longlong_as_double((long long)TRI_SENTINEL);
       } else sum[k] = src[row0 + k];
     }
@@ -338,8 +339,11 @@ __device__ __forceinline__ void tri_node_solve(const int t, const int lane, cons
         if (q0 + j + 1 < ncol) {
           double x1 = v[j + 1];
           if (POLL && __double_as_longlong(x1) == (long long)TRI_SENTINEL) { x1 = tri_poll(TRI_XADDR(cA, j + 1), abort_flag, sleep_cap); TRI_REFRESH(j + 2); }
+          if (NB == 1) { sum[0] -= aA[j] * x0; sum[0] -= aA[j + 1] * x1; }     // single rows: one product after the other (aijfact.c:3126)
+          else {
 #pragma unroll
-          for (int k = 0; k < NB; ++k) sum[k] -= aA[j * NB + k] * x0 + aA[(j + 1) * NB + k] * x1;
+            for (int k = 0; k < NB; ++k) sum[k] -= aA[j * NB + k] * x0 + aA[(j + 1) * NB + k] * x1;
+          }
         } else {
 #pragma unroll
           for (int k = 0; k < NB; ++k) sum[k] -= aA[j * NB + k] * x0;
@@ -399,7 +403,7 @@ __global__ __launch_bounds__(MI355X_BLOCK) void trisolve_node_kernel(
     int nslices, int nchunks, int np, const int *__restrict__ ptr, const int *__restrict__ info, const int *__restrict__ rowof,
     const unsigned char *__restrict__ nszof, const int *__restrict__ col, const double *__restrict__ val, const double *__restrict__ din,
     const unsigned char *__restrict__ nsub, const double *src, const int *__restrict__ spos, double *w, double *y,
-    double *reset, int reset_n, unsigned int *queue, unsigned int *other_queue, int *abort_flag, int sleep_cap) {
+    double *reset, int reset_n, unsigned int *queue, unsigned int *other_queue, int *abort_flag, int sleep_cap, const double *__restrict__ rscale) {
   __shared__ int chunk_s[2];
   const int tid = threadIdx.x, lane = tid & (MI355X_WAVE - 1), wave = tid / MI355X_WAVE;
   if (blockIdx.x == 0 && tid < TRI_QUEUES) other_queue[tid * TRI_QSTRIDE] = 0u;
@@ -429,7 +433,7 @@ __global__ __launch_bounds__(MI355X_BLOCK) void trisolve_node_kernel(
     for (int step = 0; step < ns; ++step)
       if (row0 >= 0 && mysub == step)
         tri_node_solve<NB, UPPER, true, BLK>(t, lane, np, ptr[s], BLK ? 0 : (((ptr[s + 1] - ptr[s]) / MI355X_WAVE - ncol) & ~1), ncol, row0, nsz, col, val, din, src, spos, w, y,
-                                             reset, abort_flag, sleep_cap);
+                                             reset, abort_flag, sleep_cap, rscale);
   }
 }
 
@@ -469,7 +473,8 @@ __device__ __forceinline__ void tri_split_loader(unsigned char *lds, const int l
                                                  const int *__restrict__ ptr, const int *__restrict__ info, const int *__restrict__ rowof,
                                                  const unsigned char *__restrict__ nszof, const int *__restrict__ col, const double *__restrict__ val,
                                                  const double *__restrict__ din, const unsigned char *__restrict__ nsub, const double *src,
-                                                 const int *__restrict__ spos, double *reset, const int reset_n, unsigned int *queue, int *abort_flag) {
+                                                 const int *__restrict__ spos, double *reset, const int reset_n, unsigned int *queue, int *abort_flag,
+                                                 const double *__restrict__ rscale) {
   using G = TriSplitGeom<NB>;
   constexpr int B = G::B, NT = G::NT;
   volatile int *ctl = (volatile int *)lds;
@@ -508,6 +513,7 @@ __device__ __forceinline__ void tri_split_loader(unsigned char *lds, const int l
           if (UPPER) {
             const int p = spos[row0 + nsz - 1 - kk];
             sum[kk] = src[p];
+            if (rscale) sum[kk] = sum[kk] * rscale[t];
             reset[p] = __longlong_as_double((long long)TRI_SENTINEL);
           } else sum[kk] = src[row0 + kk];
         }
@@ -566,7 +572,7 @@ __device__ __forceinline__ void tri_split_solver(unsigned char *lds, const int l
                                                  const int *__restrict__ info, const int *__restrict__ rowof, const unsigned char *__restrict__ nszof,
                                                  const int *__restrict__ col, const double *__restrict__ val, const double *__restrict__ din,
                                                  const double *src, const int *__restrict__ spos, double *w, double *y, double *reset,
-                                                 int *abort_flag, const int sleep_cap) {
+                                                 int *abort_flag, const int sleep_cap, const double *__restrict__ rscale) {
   using G = TriSplitGeom<NB>;
   constexpr int B = G::B, NT = G::NT;
   volatile int *ctl = (volatile int *)lds;
@@ -588,7 +594,7 @@ __device__ __forceinline__ void tri_split_solver(unsigned char *lds, const int l
       for (int step = 0; step < ns; ++step)
         if (row0 >= 0 && mysub == step)
           tri_node_solve<NB, UPPER, true, false>(t, lane, np, ptr[s], ((ptr[s + 1] - ptr[s]) / MI355X_WAVE - ncol) & ~1, ncol, row0, nsz, col, val, din, src, spos, w, y, reset,
-                                                 abort_flag, sleep_cap);
+                                                 abort_flag, sleep_cap, rscale);
       continue;
     }
     const int inf = Hi[lane], row0 = Hi[64 + lane], nsz = Hi[128 + lane];
@@ -647,7 +653,8 @@ __device__ __forceinline__ void tri_split_solver(unsigned char *lds, const int l
     }                                                                                                                    \
     _Pragma("unroll") for (int j = 0; j < B; j += 2) {                                                                   \
       if (q0 + j >= 0 && q0 + j + 1 < ncol) {                                                                                           \
-        _Pragma("unroll") for (int k = 0; k < NB; ++k) sum[k] -= Sv[(j * NB + k) * 64 + lane] * vX[j] + Sv[((j + 1) * NB + k) * 64 + lane] * vX[j + 1]; \
+        if (NB == 1) { sum[0] -= Sv[j * 64 + lane] * vX[j]; sum[0] -= Sv[(j + 1) * 64 + lane] * vX[j + 1]; }                             \
+        else { _Pragma("unroll") for (int k = 0; k < NB; ++k) sum[k] -= Sv[(j * NB + k) * 64 + lane] * vX[j] + Sv[((j + 1) * NB + k) * 64 + lane] * vX[j + 1]; } \
       } else if (q0 + j >= 0 && q0 + j < ncol) {                                                                                        \
         _Pragma("unroll") for (int k = 0; k < NB; ++k) sum[k] -= Sv[(j * NB + k) * 64 + lane] * vX[j];                   \
       }                                                                                                                  \
@@ -706,7 +713,7 @@ __global__ __launch_bounds__(2 * MI355X_WAVE) void trisolve_node_split_kernel(
     int nslices, int np, int R, const int *__restrict__ ptr, const int *__restrict__ info, const int *__restrict__ rowof,
     const unsigned char *__restrict__ nszof, const int *__restrict__ col, const double *__restrict__ val, const double *__restrict__ din,
     const unsigned char *__restrict__ nsub, const double *src, const int *__restrict__ spos, double *w, double *y,
-    double *reset, int reset_n, unsigned int *queue, unsigned int *other_queue, int *abort_flag, int sleep_cap) {
+    double *reset, int reset_n, unsigned int *queue, unsigned int *other_queue, int *abort_flag, int sleep_cap, const double *__restrict__ rscale) {
   extern __shared__ __align__(16) unsigned char tri_split_lds[];
   const int tid = threadIdx.x, lane = tid & (MI355X_WAVE - 1), wave = tid / MI355X_WAVE;
   if (tid < 16) ((int *)tri_split_lds)[tid] = 0;
@@ -716,8 +723,8 @@ __global__ __launch_bounds__(2 * MI355X_WAVE) void trisolve_node_split_kernel(
       reset[i] = __longlong_as_double((long long)TRI_SENTINEL);
   }
   __syncthreads();
-  if (wave == 1) tri_split_loader<NB, UPPER>(tri_split_lds, lane, nslices, np, R, ptr, info, rowof, nszof, col, val, din, nsub, src, spos, reset, reset_n, queue, abort_flag);
-  else tri_split_solver<NB, UPPER>(tri_split_lds, lane, np, R, ptr, info, rowof, nszof, col, val, din, src, spos, w, y, reset, abort_flag, sleep_cap);
+  if (wave == 1) tri_split_loader<NB, UPPER>(tri_split_lds, lane, nslices, np, R, ptr, info, rowof, nszof, col, val, din, nsub, src, spos, reset, reset_n, queue, abort_flag, rscale);
+  else tri_split_solver<NB, UPPER>(tri_split_lds, lane, np, R, ptr, info, rowof, nszof, col, val, din, src, spos, w, y, reset, abort_flag, sleep_cap, rscale);
 }
 
 template <int NB, bool UPPER, bool BLK>
@@ -725,14 +732,14 @@ __global__ __launch_bounds__(MI355X_BLOCK) void trisolve_node_level_kernel(int p
                                                                            const int *__restrict__ rowof, const unsigned char *__restrict__ nszof,
                                                                            const int *__restrict__ col, const double *__restrict__ val,
                                                                            const double *__restrict__ din, const double *src,
-                                                                           const int *__restrict__ spos, double *w, double *y) {
+                                                                           const int *__restrict__ spos, double *w, double *y, const double *__restrict__ rscale) {
   const int t = p0 + blockIdx.x * MI355X_BLOCK + threadIdx.x;
   if (t >= p1) return;
   const int row0 = rowof[t];
   if (row0 < 0) return;
   const int sl = t / MI355X_WAVE, nc = info[t] >> 8;
   tri_node_solve<NB, UPPER, false, BLK>(t, t % MI355X_WAVE, np, ptr[sl], BLK ? 0 : (((ptr[sl + 1] - ptr[sl]) / MI355X_WAVE - nc) & ~1), nc, row0, nszof[t], col, val, din, src, spos, w, y,
-                                   (double *)nullptr, (int *)nullptr, 0);
+                                   (double *)nullptr, (int *)nullptr, 0, rscale);
 }
 
 extern "C" int mi355x_trisolve_plan_destroy(mi355x_trisolve_plan_t p);
@@ -972,13 +979,22 @@ static int trisolve_plan_fill(mi355x_handle_t h, mi355x_trisolve_plan_s *p, int 
 #undef TRI_TRY
 #undef TRI_FAIL
 
+static int trisolve_plan_fill_nodes(mi355x_handle_t h, mi355x_trisolve_plan_s *p, int n, int nnodes, const int *nstart_in, int nlev, const int *nodelev,
+                                    const int *rp, const int *rl, const int *cj, const double *cv, const double *dinv_host, int by_level, int blk,
+                                    const double *rscale_host, int singles);
 static int trisolve_plan_create_impl(mi355x_handle_t h, int n, int nlev, const int *lev, const int *rp, const int *rl, const int *cj,
                                      const double *cv, const double *dinv_host, const double *rscale_host, int by_level,
-                                     mi355x_trisolve_plan_t *out) {
+                                     mi355x_trisolve_plan_t *out, bool singles = false) {
   mi355x_trisolve_plan_s *p = new mi355x_trisolve_plan_s();
   memset(p, 0, sizeof(*p));
   *out = nullptr;
-  const int rc = trisolve_plan_fill(h, p, n, nlev, lev, rp, rl, cj, cv, dinv_host, rscale_host, by_level);
+  // Deep, narrow dependency graphs (the factor of an unstructured matrix: hundreds of rows per level, thousands of levels) are a
+  // chain of hand-offs: they run through the split-role kernels of the node plans with every row a node of its own (a loader and a
+  // solver wavefront per workgroup, lists end-aligned; same column order, one product after the other: the same bits).  Wide levels
+  // (a stencil operator: tens of thousands of rows per level) are throughput-bound and keep the one-wavefront-per-slice kernel.
+  // The choice is made for the two plans of a factor together (mi355x_trisolve_plan_create_pair).
+  const int rc = singles ? trisolve_plan_fill_nodes(h, p, n, n, nullptr, nlev, lev, rp, rl, cj, cv, dinv_host, by_level, 0, rscale_host, 1)
+                         : trisolve_plan_fill(h, p, n, nlev, lev, rp, rl, cj, cv, dinv_host, rscale_host, by_level);
   if (rc) { mi355x_trisolve_plan_destroy(p); return rc; }     // one cleanup path: nothing allocated so far survives a failure
   *out = p;
   return 0;
@@ -993,8 +1009,18 @@ static int trisolve_plan_create_impl(mi355x_handle_t h, int n, int nlev, const i
 // shape is refused (hipErrorInvalidValue): the caller keeps the row-granular plan.
 #define TRI_TRY(expr) do { const int e__ = (int)(expr); if (e__) { (void)hipStreamSynchronize(h->stream); return e__; } } while (0)
 #define TRI_FAIL() do { (void)hipStreamSynchronize(h->stream); return (int)hipErrorInvalidValue; } while (0)
-static int trisolve_plan_fill_nodes(mi355x_handle_t h, mi355x_trisolve_plan_s *p, int n, int nnodes, const int *nstart, int nlev, const int *nodelev,
-                                    const int *rp, const int *rl, const int *cj, const double *cv, const double *dinv_host, int by_level, int blk) {
+// singles != 0: every row is a node of its own (nstart may be NULL) -- the row-granular solves (MatSolve_SeqAIJ_NaturalOrdering, one
+// product after the other) through the same layout and kernels; rscale_host as in trisolve_plan_fill
+static int trisolve_plan_fill_nodes(mi355x_handle_t h, mi355x_trisolve_plan_s *p, int n, int nnodes, const int *nstart_in, int nlev, const int *nodelev,
+                                    const int *rp, const int *rl, const int *cj, const double *cv, const double *dinv_host, int by_level, int blk,
+                                    const double *rscale_host, int singles) {
+  std::vector<int> nstart_own;
+  if (!nstart_in) {
+    if (!singles || nnodes != n) return (int)hipErrorInvalidValue;
+    nstart_own.resize((size_t)n + 1);
+    for (int i = 0; i <= n; ++i) nstart_own[(size_t)i] = i;
+  }
+  const int *nstart = nstart_in ? nstart_in : nstart_own.data();
   const int W = MI355X_WAVE;
   const bool upper = dinv_host != nullptr;
   // MI355X_TRISOLVE_TIMING: where the set-up time of a plan goes (stderr)
@@ -1005,7 +1031,8 @@ static int trisolve_plan_fill_nodes(mi355x_handle_t h, mi355x_trisolve_plan_s *p
   p->n = n; p->upper = upper; p->by_level = by_level; p->nlev = nlev;
   int NB = 1;
   for (int u = 0; u < nnodes; ++u) { const int z = nstart[u + 1] - nstart[u]; if (z < 1 || z > 5) TRI_FAIL(); if (z > NB) NB = z; }
-  if (NB < 2) TRI_FAIL();
+  if (NB < 2 && !singles) TRI_FAIL();
+  if (singles && (NB != 1 || blk)) TRI_FAIL();
   p->nb = NB; p->blkcols = blk ? 1 : 0;
   if (blk) {   // block columns: every node has NB rows (NB <= 4), every shared list is a run of WHOLE dependency nodes (checked below)
     if (NB > 4) TRI_FAIL();
@@ -1170,6 +1197,12 @@ static int trisolve_plan_fill_nodes(mi355x_handle_t h, mi355x_trisolve_plan_s *p
   TRI_TRY(hipMemcpyAsync(p->d_val, val, sizeof(double) * nval, hipMemcpyHostToDevice, h->stream));
   TRI_UP(p->d_nsub, nsub, unsigned char); TRI_UP(p->d_pos, slot, int);
   TRI_UP(p->d_nsz, nszv, unsigned char); TRI_UP(p->d_din, din, double);
+  std::vector<double> rsc;
+  if (rscale_host && singles && upper) {
+    rsc.assign(np > 0 ? np : 1, 1.0);
+    for (size_t P = 0; P < np; ++P) if (rowof[P] >= 0) rsc[P] = rscale_host[rowof[P]];
+    TRI_UP(p->d_rscale, rsc, double);
+  }
 #undef TRI_UP
   const size_t nw = (np > 0 ? np : 1) * (size_t)NB;
   TRI_TRY(hipStreamSynchronize(h->stream));
@@ -1208,7 +1241,7 @@ int mi355x_trisolve_plan_create_nodes(mi355x_handle_t h, int n, int nnodes, cons
   mi355x_trisolve_plan_s *p = new mi355x_trisolve_plan_s();
   memset(p, 0, sizeof(*p));
   *out = nullptr;
-  const int rc = trisolve_plan_fill_nodes(h, p, n, nnodes, nstart, nlev, nodelev, rp, rl, cj, cv, dinv_host, by_level, block_columns);
+  const int rc = trisolve_plan_fill_nodes(h, p, n, nnodes, nstart, nlev, nodelev, rp, rl, cj, cv, dinv_host, by_level, block_columns, nullptr, 0);
   if (rc) { mi355x_trisolve_plan_destroy(p); return rc; }
   *out = p;
   return 0;
@@ -1224,8 +1257,15 @@ int mi355x_trisolve_plan_create_pair(mi355x_handle_t h, int n, int by_level,
   MI355X_TRY(hipGetDevice(&dev));
   mi355x_trisolve_plan_t lo = nullptr, up = nullptr;
   int rc_lo = 0, rc_up = 0;
-  std::thread tl([&] { (void)hipSetDevice(dev); rc_lo = trisolve_plan_create_impl(h, n, nlev_lo, lev_lo, rp_lo, rl_lo, cj_lo, cv_lo, nullptr, nullptr, by_level, &lo); });
-  rc_up = trisolve_plan_create_impl(h, n, nlev_up, lev_up, rp_up, rl_up, cj_up, cv_up, dinv_up, rscale_up, rscale_up ? 0 : by_level, &up);
+  // MI355X_TRISOLVE_SPLIT=0 / MI355X_TRISOLVE_SPLIT_ROWS=<rows per level> move the switch between the two kernel families (default:
+  // fewer than 4096 rows per dependency level -> split-role kernels, every row a node of its own)
+  bool singles = false;
+  { const char *e = getenv("MI355X_TRISOLVE_SPLIT"), *w = getenv("MI355X_TRISOLVE_SPLIT_ROWS");
+    const long width = w ? atol(w) : 4096;
+    const int nl = nlev_lo > nlev_up ? nlev_lo : nlev_up;
+    singles = !(e && atoi(e) == 0) && nl > 0 && n >= 64 && (long)n / nl < width; }
+  std::thread tl([&] { (void)hipSetDevice(dev); rc_lo = trisolve_plan_create_impl(h, n, nlev_lo, lev_lo, rp_lo, rl_lo, cj_lo, cv_lo, nullptr, nullptr, by_level, &lo, singles); });
+  rc_up = trisolve_plan_create_impl(h, n, nlev_up, lev_up, rp_up, rl_up, cj_up, cv_up, dinv_up, rscale_up, rscale_up ? 0 : by_level, &up, singles);
   tl.join();
   if (rc_lo || rc_up) {
     if (lo) mi355x_trisolve_plan_destroy(lo);
@@ -1278,11 +1318,11 @@ static int tri_node_go(mi355x_handle_t h, mi355x_trisolve_plan_t lo, mi355x_tris
     }
     hipLaunchKernelGGL((trisolve_node_split_kernel<NB, false>), dim3(glo), dim3(2 * MI355X_WAVE), blo, h->stream, lo->nslices, lo->np, rlo, lo->d_ptr, lo->d_info,
                        lo->d_row, lo->d_nsz, lo->d_col, lo->d_val, lo->d_din, lo->d_nsub, b, (const int *)nullptr, lo->d_w, (double *)nullptr, up->d_w,
-                       up->np * NB, lo->d_queue, up->d_queue, lo->abort_flag, lo->sleep_cap);
+                       up->np * NB, lo->d_queue, up->d_queue, lo->abort_flag, lo->sleep_cap, (const double *)nullptr);
     MI355X_LAUNCH_CHECK();
     hipLaunchKernelGGL((trisolve_node_split_kernel<NB, true>), dim3(gup), dim3(2 * MI355X_WAVE), bup, h->stream, up->nslices, up->np, rup, up->d_ptr, up->d_info,
                        up->d_row, up->d_nsz, up->d_col, up->d_val, up->d_din, up->d_nsub, lo->d_w, lo->d_pos, up->d_w, y, lo->d_w, 0, up->d_queue,
-                       lo->d_queue, up->abort_flag, up->sleep_cap);
+                       lo->d_queue, up->abort_flag, up->sleep_cap, (const double *)up->d_rscale);
     MI355X_LAUNCH_CHECK();
     return 0;
   }
@@ -1290,24 +1330,24 @@ static int tri_node_go(mi355x_handle_t h, mi355x_trisolve_plan_t lo, mi355x_tris
     const int glo = lo->grid < TRI_QUEUES ? TRI_QUEUES : lo->grid, gup = up->grid < TRI_QUEUES ? TRI_QUEUES : up->grid;
     hipLaunchKernelGGL((trisolve_node_kernel<NB, false, BLK>), dim3(glo), dim3(lo->spw * MI355X_WAVE), 0, h->stream, lo->nslices, lo->nchunks, lo->np, lo->d_ptr, lo->d_info,
                        lo->d_row, lo->d_nsz, lo->d_col, lo->d_val, lo->d_din, lo->d_nsub, b, (const int *)nullptr, lo->d_w, (double *)nullptr, up->d_w,
-                       up->np * NB, lo->d_queue, up->d_queue, lo->abort_flag, lo->sleep_cap);
+                       up->np * NB, lo->d_queue, up->d_queue, lo->abort_flag, lo->sleep_cap, (const double *)nullptr);
     MI355X_LAUNCH_CHECK();
     hipLaunchKernelGGL((trisolve_node_kernel<NB, true, BLK>), dim3(gup), dim3(up->spw * MI355X_WAVE), 0, h->stream, up->nslices, up->nchunks, up->np, up->d_ptr, up->d_info,
                        up->d_row, up->d_nsz, up->d_col, up->d_val, up->d_din, up->d_nsub, lo->d_w, lo->d_pos, up->d_w, y, lo->d_w, 0, up->d_queue,
-                       lo->d_queue, up->abort_flag, up->sleep_cap);
+                       lo->d_queue, up->abort_flag, up->sleep_cap, (const double *)up->d_rscale);
     MI355X_LAUNCH_CHECK();
     return 0;
   }
   for (int l = 0; l < lo->nlev; ++l) {
     const int p0 = lo->levpos[2 * l], p1 = lo->levpos[2 * l + 1];
     hipLaunchKernelGGL((trisolve_node_level_kernel<NB, false, BLK>), dim3((p1 - p0 + MI355X_BLOCK - 1) / MI355X_BLOCK), dim3(MI355X_BLOCK), 0, h->stream, p0, p1, lo->np,
-                       lo->d_ptr, lo->d_info, lo->d_row, lo->d_nsz, lo->d_col, lo->d_val, lo->d_din, b, (const int *)nullptr, lo->d_w, (double *)nullptr);
+                       lo->d_ptr, lo->d_info, lo->d_row, lo->d_nsz, lo->d_col, lo->d_val, lo->d_din, b, (const int *)nullptr, lo->d_w, (double *)nullptr, (const double *)nullptr);
     MI355X_LAUNCH_CHECK();
   }
   for (int l = 0; l < up->nlev; ++l) {
     const int p0 = up->levpos[2 * l], p1 = up->levpos[2 * l + 1];
     hipLaunchKernelGGL((trisolve_node_level_kernel<NB, true, BLK>), dim3((p1 - p0 + MI355X_BLOCK - 1) / MI355X_BLOCK), dim3(MI355X_BLOCK), 0, h->stream, p0, p1, up->np,
-                       up->d_ptr, up->d_info, up->d_row, up->d_nsz, up->d_col, up->d_val, up->d_din, lo->d_w, lo->d_pos, up->d_w, y);
+                       up->d_ptr, up->d_info, up->d_row, up->d_nsz, up->d_col, up->d_val, up->d_din, lo->d_w, lo->d_pos, up->d_w, y, (const double *)up->d_rscale);
     MI355X_LAUNCH_CHECK();
   }
   return 0;
@@ -1323,6 +1363,7 @@ static int tri_node_dispatch(mi355x_handle_t h, mi355x_trisolve_plan_t lo, mi355
     }
   }
   switch (lo->nb) {
+  case 1: return tri_node_go<1, false>(h, lo, up, b, y, levels);
   case 2: return tri_node_go<2, false>(h, lo, up, b, y, levels);
   case 3: return tri_node_go<3, false>(h, lo, up, b, y, levels);
   case 4: return tri_node_go<4, false>(h, lo, up, b, y, levels);
@@ -1371,7 +1412,7 @@ int mi355x_trisolve_apply(mi355x_handle_t h, mi355x_trisolve_plan_t lo, mi355x_t
   if (!lo || !up || lo->n != up->n || lo->upper || !up->upper) return (int)hipErrorInvalidValue;
   if (*lo->abort_flag || *up->abort_flag) return (int)hipErrorLaunchFailure;
   if (lo->n == 0) return 0;
-  if (lo->nb > 1 || up->nb > 1) return tri_node_dispatch(h, lo, up, b, y, false);
+  if (lo->nb >= 1 || up->nb >= 1) return tri_node_dispatch(h, lo, up, b, y, false);
   // with fewer chunks than queues some queues have no puller: chunk c is then only served through queue c % 8 ...
   // so tiny systems use ONE workgroup per queue that exists (grid >= min(nchunks, 8) is guaranteed by plan_create)
   const int glo = lo->grid < TRI_QUEUES ? TRI_QUEUES : lo->grid, gup = up->grid < TRI_QUEUES ? TRI_QUEUES : up->grid;
@@ -1398,7 +1439,7 @@ int mi355x_trisolve_apply(mi355x_handle_t h, mi355x_trisolve_plan_t lo, mi355x_t
 int mi355x_trisolve_apply_levels(mi355x_handle_t h, mi355x_trisolve_plan_t lo, mi355x_trisolve_plan_t up, const double *b, double *y) {
   if (!lo || !up || lo->n != up->n || lo->upper || !up->upper) return (int)hipErrorInvalidValue;
   if (lo->n == 0) return 0;
-  if (lo->nb > 1 || up->nb > 1) return tri_node_dispatch(h, lo, up, b, y, true);
+  if (lo->nb >= 1 || up->nb >= 1) return tri_node_dispatch(h, lo, up, b, y, true);
   for (int l = 0; l < lo->nlev; ++l) {
     const int p0 = lo->levpos[2 * l], p1 = lo->levpos[2 * l + 1];
     hipLaunchKernelGGL((trisolve_level_kernel<false>), dim3((p1 - p0 + MI355X_BLOCK - 1) / MI355X_BLOCK), dim3(MI355X_BLOCK), 0, h->stream, p0, p1,
