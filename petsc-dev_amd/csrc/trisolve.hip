@@ -456,6 +456,12 @@ template <int NB> struct TriSplitGeom {
   static constexpr int SB = B * 256 + B * NB * 512;             // stage bytes: B index rows, B * NB value rows
 };
 #define TRI_LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#ifndef TRI_LOOKAHEAD
+// batches the solver's gathers run ahead of its products.  0: a batch's values are requested when the batch is due -- a value
+// requested early is mostly a stale sentinel that costs a poll round later (FEM stand-in, profiles/r03_tri_variants.log: 13.9 ms
+// at 0, 19.3 at 1, 22.7 at 3; in the inode routine's column order 30.0 / 35.5 / 44.7)
+#define TRI_LOOKAHEAD 0
+#endif
 // wait until the LDS counter reaches `need`; bounded like every other wait of these kernels: a wavefront that gives up raises the
 // abort flag and leaves, its partner's waits then run out the same way, and the application falls back to the level-by-level kernels
 __device__ __forceinline__ bool tri_lds_wait(volatile int *c, const int need, int *abort_flag) {
@@ -610,6 +616,9 @@ __device__ __forceinline__ void tri_split_solver(unsigned char *lds, const int l
     // batch holds the newest dependencies of every lane
     const int shift = nbatch * B - width + ((width - ncol) & ~1);
     int cA[B], cB[B]; double vA[B], vB[B];
+#if TRI_LOOKAHEAD == 3
+    int cC[B], cD[B]; double vC[B], vD[B];
+#endif
 #ifdef MI355X_TRI_TRACE
 #define TRI_SSTAMP(k) do { if (tri_trace_buf && lane == 0) tri_trace_buf[(UPPER ? 8000000L : 0L) + (long)s * 8 + (k)] = wall_clock64(); } while (0)
 #else
@@ -663,6 +672,22 @@ __device__ __forceinline__ void tri_split_solver(unsigned char *lds, const int l
     ctl[3] = bb + (i) + 1;                                                                                               \
     if ((i) < 5) TRI_SSTAMP(1 + (i));                                                                                    \
   } while (0)
+#if TRI_LOOKAHEAD == 3
+    // the gathers run three batches ahead of the products: behind a wait for a dependency the following batches' values (older
+    // dependencies in column order) are then already in registers
+    if (nbatch > 0) TRI_GATHER(0, cA, vA);
+    if (nbatch > 1) TRI_GATHER(1, cB, vB);
+    if (nbatch > 2) TRI_GATHER(2, cC, vC);
+    for (int i = 0; i < nbatch; i += 4) {
+      if (i + 3 < nbatch) TRI_GATHER(i + 3, cD, vD);
+      TRI_CONSUME(i, cA, vA);
+      if (i + 1 < nbatch) { if (i + 4 < nbatch) TRI_GATHER(i + 4, cA, vA); TRI_CONSUME(i + 1, cB, vB); }
+      if (i + 2 < nbatch) { if (i + 5 < nbatch) TRI_GATHER(i + 5, cB, vB); TRI_CONSUME(i + 2, cC, vC); }
+      if (i + 3 < nbatch) { if (i + 6 < nbatch) TRI_GATHER(i + 6, cC, vC); TRI_CONSUME(i + 3, cD, vD); }
+    }
+#elif TRI_LOOKAHEAD == 0
+    for (int i = 0; i < nbatch; ++i) { TRI_GATHER(i, cA, vA); TRI_CONSUME(i, cA, vA); }
+#else
     if (nbatch > 0) TRI_GATHER(0, cA, vA);
     for (int i = 0; i < nbatch; i += 2) {
       if (i + 1 < nbatch) TRI_GATHER(i + 1, cB, vB);
@@ -672,6 +697,7 @@ __device__ __forceinline__ void tri_split_solver(unsigned char *lds, const int l
         TRI_CONSUME(i + 1, cB, vB);
       }
     }
+#endif
 #undef TRI_GATHER
 #undef TRI_CONSUME
     bb += nbatch;
@@ -1307,7 +1333,7 @@ static int tri_node_go(mi355x_handle_t h, mi355x_trisolve_plan_t lo, mi355x_tris
     using G = TriSplitGeom<NB>;
     const int glo = lo->grid < TRI_QUEUES ? TRI_QUEUES : lo->grid, gup = up->grid < TRI_QUEUES ? TRI_QUEUES : up->grid;
     const int rmax = (int)((150 * 1024 - 64 - 2 * G::HB) / G::SB);
-    auto ring = [&](int maxcol) { int r = (maxcol + G::B - 1) / G::B + 1; if (r < 3) r = 3; if (r > rmax) r = rmax; return r; };
+    auto ring = [&](int maxcol) { int r = (maxcol + G::B - 1) / G::B + 1; if (r < TRI_LOOKAHEAD + 3) r = TRI_LOOKAHEAD + 3; if (r > rmax) r = rmax; return r; };
     const int rlo = ring(lo->maxcol), rup = ring(up->maxcol);
     const size_t blo = 64 + 2 * (size_t)G::HB + (size_t)rlo * G::SB, bup = 64 + 2 * (size_t)G::HB + (size_t)rup * G::SB;
     static bool attr_set = false;     // (per NB: this function is a template)
