@@ -36,6 +36,28 @@ static PetscErrorCode MatSetUp_MPIAIJHIP(Mat A) { return MatMPIAIJSetPreallocati
 
 static int cmp_int(const void *a, const void *b) { PetscInt x = *(const PetscInt *)a, y = *(const PetscInt *)b; return (x > y) - (x < y); }
 
+/* MatDisAssemble_MPIAIJ, mmaij.c:170-231: an entry in an off-diagonal column the assembled matrix does not have yet.  The
+ * off-diagonal block goes back to GLOBAL column numbers (the reference builds a full-width B and re-inserts every row; garray is
+ * increasing, so mapping the stored indices through it keeps every row sorted), the local work vector, the scatter and garray
+ * are discarded; the next final assembly builds them again (MatSetUpMultiply_MPIAIJ) -- on every process, see MatAssemblyEnd */
+static PetscErrorCode MatDisAssemble_MPIAIJHIP(Mat A) {
+  PetscErrorCode ierr;
+  HipMPIAIJ *a = MA(A);
+  if (!a->garray) return 0;
+  HipAIJ *B = HipAIJGet(a->B);
+  for (PetscInt r = 0; r < B->m; r++)
+    for (PetscInt k = B->i[r]; k < B->i[r] + B->ilen[r]; k++) B->j[k] = a->garray[B->j[k]];
+  B->n = A->cmap->N;
+  ierr = PetscLayoutDestroy(&a->B->cmap);CHKERRQ(ierr);
+  ierr = PetscLayoutCreateSetUp(PETSC_COMM_SELF, A->cmap->N, A->cmap->N, &a->B->cmap);CHKERRQ(ierr);
+  ierr = VecDestroy(&a->lvec);CHKERRQ(ierr);
+  ierr = HipScatterDestroy(&a->hscat);CHKERRQ(ierr);
+  HipFree(a->garray); a->garray = NULL; a->ec = 0;
+  ierr = MatSeqAIJHIPSetCompressedRow(a->B, PETSC_FALSE);CHKERRQ(ierr);      /* (and: the device copy of B belongs to the old columns) */
+  HipStateIncrease(a->B);
+  return 0;
+}
+
 /* MatSetValues_MPIAIJ, mpiaij.c:517-560: locally owned rows go into A / B; rows of other processes are stashed until the
  * assembly (mpiaij.c:552-558, matstash.c), unless MAT_NO_OFF_PROC_ENTRIES-like behaviour is asked with nothing */
 static PetscErrorCode MatSetValues_MPIAIJHIP(Mat A, PetscInt m, const PetscInt im[], PetscInt n, const PetscInt in[], const PetscScalar v[], InsertMode addv) {
@@ -64,8 +86,8 @@ static PetscErrorCode MatSetValues_MPIAIJHIP(Mat A, PetscInt m, const PetscInt i
         PetscInt bc = col;
         if (a->garray) {   /* assembled before: B's columns are compacted (colmap lookup, mpiaij.c:540-550) */
           PetscInt *p = (PetscInt *)bsearch(&col, a->garray, (size_t)a->ec, sizeof(PetscInt), cmp_int);
-          if (!p) SETERRQ(HipObjComm(A), PETSC_ERR_SUP, "new off-diagonal column %d after assembly (MatDisAssemble_MPIAIJ, mmaij.c:170) is outside the ported path", col);
-          bc = (PetscInt)(p - a->garray);
+          if (p) bc = (PetscInt)(p - a->garray);
+          else { ierr = MatDisAssemble_MPIAIJHIP(A);CHKERRQ(ierr); }            /* mpiaij.c:545-549: from here on B takes global columns */
         }
         ierr = MatSetValues(a->B, 1, &row, 1, &bc, &v[i * n + j], addv);CHKERRQ(ierr);
       }
@@ -125,6 +147,12 @@ static PetscErrorCode MatAssemblyEnd_MPIAIJHIP(Mat A, MatAssemblyType mode) {   
   ierr = MatAssemblyEnd(a->A, mode);CHKERRQ(ierr);
   ierr = MatAssemblyBegin(a->B, mode);CHKERRQ(ierr);
   ierr = MatAssemblyEnd(a->B, mode);CHKERRQ(ierr);
+  /* if one process has disassembled, all of them must (the scatter is rebuilt collectively): mpiaij.c:694-700 */
+  if (A->was_assembled) {
+    double dis = a->garray ? 0.0 : 1.0;
+    if (HipCommAllreduce(HipObjComm(A), &dis, 1, 1, 0)) SETERRQ(HipObjComm(A), PETSC_ERR_LIB, "allreduce failed");
+    if (dis > 0.0 && a->garray) { ierr = MatDisAssemble_MPIAIJHIP(A);CHKERRQ(ierr); }
+  }
   if (!a->garray) { ierr = MatSetUpMultiply_MPIAIJ(A);CHKERRQ(ierr); }   /* mpiaij.c:701-703 */
   return 0;
 }

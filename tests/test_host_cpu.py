@@ -235,6 +235,51 @@ def test_mpiaij_setup_irregular(built, size):
     check_mpiaij_setup(P, size, ai, aj, aa, ranges, via_setvalues=True)
 
 
+@pytest.mark.parametrize("size", [2, 3])
+def test_new_off_diagonal_columns_after_assembly_disassemble_and_reassemble(built, size):
+    """MatDisAssemble_MPIAIJ (mmaij.c:170): an assembled MPIAIJ matrix receives entries in off-diagonal columns it does not have yet --
+    on ONE rank only, some of them set by another rank (stashed).  The off-diagonal block goes back to global column numbers, the next
+    final assembly rebuilds garray, the compacted block, the work vector and the scatter on EVERY rank (mpiaij.c:694-703): all
+    integer pieces equal the oracle's split of the modified global matrix, values too."""
+    from petsc_dev_amd import petsc as P
+    from fakempi import FakeWorld
+    import scipy.sparse as sp
+    L = P.lib()
+    N = 60
+    A0 = sp.diags([np.full(N - 1, -1.0), np.full(N, 4.0), np.full(N - 1, -1.0)], [-1, 0, 1], format="csr")
+    ai, aj, aa = A0.indptr.astype(np.int32), A0.indices.astype(np.int32), A0.data.astype(np.float64)
+    ranges = np.array([0] + list(np.cumsum([N // size + (N % size > r) for r in range(size)])), dtype=np.int32)
+    # new entries: rows of rank 0, columns owned by the LAST rank (not in rank 0's garray); one of them set by rank 1 (off-process)
+    new = [(1, N - 2, 0.5, 0), (3, N - 5, 0.25, 0), (2, N - 3, -0.75, 1), (1, N - 2, 0.125, 0)]     # (row, col, value, setting rank); the last repeats a position (ADD)
+    dense = A0.toarray()
+    for r, c, v, _ in new:
+        dense[r, c] += v
+    A1 = sp.csr_matrix(dense); A1.sort_indices()
+    bi, bj, ba = A1.indptr.astype(np.int32), A1.indices.astype(np.int32), A1.data.astype(np.float64)
+
+    def work(rank, comm):
+        A = build_local(P, comm, ai, aj, aa, int(ranges[rank]), int(ranges[rank + 1]), N)
+        before = mpiaij_pieces(P, A.h)
+        for r, c, v, who in new:
+            if who == rank:
+                L.MatSetValues(A.h, 1, (C.c_int * 1)(r), 1, (C.c_int * 1)(c), (C.c_double * 1)(v), P.ADD_VALUES)
+        L.MatAssemblyBegin(A.h, P.MAT_FINAL_ASSEMBLY)
+        L.MatAssemblyEnd(A.h, P.MAT_FINAL_ASSEMBLY)
+        out = mpiaij_pieces(P, A.h)
+        # and once more without anything new: nothing is rebuilt, nothing changes
+        L.MatAssemblyBegin(A.h, P.MAT_FINAL_ASSEMBLY)
+        L.MatAssemblyEnd(A.h, P.MAT_FINAL_ASSEMBLY)
+        again = mpiaij_pieces(P, A.h)
+        assert np.array_equal(again[2], out[2]) and np.array_equal(again[1][1], out[1][1])
+        A.destroy()
+        return before, out
+
+    res = FakeWorld(size).run(work)
+    check_against_oracle(size, [r[0] for r in res], ai, aj, aa, ranges)
+    check_against_oracle(size, [r[1] for r in res], bi, bj, ba, ranges)
+    assert res[0][1][2].size == res[0][0][2].size + 3          # rank 0's garray grew by the three new columns
+
+
 @pytest.mark.parametrize("size", [2, 3, 4])
 def test_off_process_setvalues_are_stashed_and_assembled(built, size):
     """MatSetValues / VecSetValues into rows owned by OTHER ranks (mpiaij.c:552-558, matstash.c; pdvec.c): a 1-D chain of
