@@ -2064,6 +2064,45 @@ def test_config4_full_size_properties(P, which):
         assert np.all(np.abs(vy.array() - 2.0 * y) <= 2e-12 * absrow)
 
 
+def test_config4_full_size_ilu0_application_carries_the_reference_bits(P):
+    """The ILU(0) application of BASELINE configs[3] at FULL size (FEM-like stand-in for Flan_1565: 1.53 M rows, 509 728 nodes of 3
+    rows, 2 x 2144 node levels) against the oracle's restatements of the two reference routines, bit for bit: node plans with
+    the columns in column order = MatSolve_SeqAIJ_Inode (inode.c:2327-2760; what the reference runs on this factor), row-granular
+    plans in column order = MatSolve_SeqAIJ_NaturalOrdering (aijfact.c:3126); the defaults (columns in dependency-level order, node
+    plans and row plans) to 1e-13 and deterministic.  All through the split-role sync-free kernels; no application gives up."""
+    L = P.lib()
+    ai, aj, aa = pb.gen_fem3()
+    n = ai.size - 1
+    nodes, ns = orc.check_inode(ai, aj)
+    f = orc.ilu0_factor(ai, aj, aa)
+    bvec = np.cos(0.1 * np.arange(n)) + 0.01 * np.sin(np.arange(n))
+    ref_inode = orc.ilu0_solve_inode(f, ns, bvec)
+    ref_nat = orc.ilu0_solve(f, bvec)
+    A = P.Mat.from_csr(ai, aj, aa)
+    vb, vx = V(P, bvec), V(P, np.zeros(n))
+    for opts, ref, exact in (("-pc_factor_hipmi355x_trisolve_order column", ref_inode, True), ("-pc_factor_hipmi355x_trisolve_nodes 0 -pc_factor_hipmi355x_trisolve_order column", ref_nat, True),
+                             ("", ref_inode, False), ("-pc_factor_hipmi355x_trisolve_nodes 0", ref_nat, False)):
+        pc = C.c_void_p()
+        k = P.KSP(comm=L.COMM_SELF); k.set_operators(A); L.KSPGetPC(k.h, C.byref(pc)); L.PCSetType(pc, b"ilu")
+        set_options(L, opts)
+        L.raw("PCSetUp")(pc)
+        set_options(L, "")
+        got = C.c_int(); L.PCILUGetNodeInfo_HIPMI355X(pc, C.byref(got), None, None)
+        assert got.value == (0 if "nodes 0" in opts else nodes)
+        L.raw("PCApply")(pc, vb.h, vx.h)
+        xa = vx.array().copy()
+        if exact:
+            assert np.array_equal(bits(xa), bits(ref)), opts
+        else:
+            assert np.linalg.norm(xa - ref) <= 1e-13 * np.linalg.norm(ref)
+        L.raw("PCApply")(pc, vb.h, vx.h)
+        assert np.array_equal(bits(vx.array()), bits(xa))              # deterministic
+        sf, ab = C.c_int(), C.c_int()
+        L.PCILUGetSolver_HIPMI355X(pc, C.byref(sf), C.byref(ab))
+        assert sf.value == 1 and ab.value == 0
+        del k
+
+
 @pytest.mark.parametrize("sub", ["jacobi", "ilu"])
 def test_config4_full_size_gmres_bjacobi_solve(P, sub):
     """BASELINE configs[3] END TO END at full size on the FEM-like stand-in for Flan_1565 (1.53 M rows, 1.18e8 nonzeros, 3 dof per
