@@ -105,6 +105,7 @@ struct _p_HipScatter {
   int device_ready;
   int ready_marked;           /* ev_packed already recorded by VecScatterMarkReady */
   PetscScalar *h_send, *h_recv;   /* host staging buffers of the host-staged transport */
+  void *nbr_work;                 /* per-neighbour work arrays of an exchange (pointers, counts, ranks, byte counts): sized for max(to.n, from.n) */
   PetscScalar *d_local_tmp;       /* device staging of the local (self) part, local_n doubles */
 };
 PetscErrorCode HipScatterCreate_PtoS_MPIAIJ(MPI_Comm comm, PetscLayout xmap, PetscInt ec, const PetscInt *garray, HipScatter *ctx);

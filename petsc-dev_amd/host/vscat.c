@@ -147,8 +147,10 @@ static PetscErrorCode neighbour_exchange(HipScatter ctx, PetscDeviceCtx *dc, Pet
   for (PetscInt i = 0; i < nr; i++) rtot += (size_t)rcnt[i];
   if (!ctx->h_send) { ierr = PetscMalloc(sizeof(PetscScalar) * PetscMax((size_t)ctx->to.starts[ctx->to.n] + (size_t)ctx->from.starts[ctx->from.n], 1), &ctx->h_send);CHKERRQ(ierr); }
   if (!ctx->h_recv) { ierr = PetscMalloc(sizeof(PetscScalar) * PetscMax((size_t)ctx->to.starts[ctx->to.n] + (size_t)ctx->from.starts[ctx->from.n], 1), &ctx->h_recv);CHKERRQ(ierr); }
-  void *sb[64], *rb[64]; int sp[64], rp[64], sbytes[64], rbytes[64];
-  if (ns > 64 || nr > 64) SETERRQ(comm, PETSC_ERR_SUP, "host-staged transport supports at most 64 neighbours");
+  /* per-neighbour arrays out of the scatter's work block (scatter_nbr_work: 10 arrays of max(to.n, from.n) entries; 4..9 are ours) */
+  const size_t nmax = (size_t)PetscMax(PetscMax(ctx->to.n, ctx->from.n), 1);
+  void **sb = (void **)ctx->nbr_work + 4 * nmax, **rb = sb + nmax;
+  int *sp = (int *)(rb + nmax), *rp = sp + nmax, *sbytes = rp + nmax, *rbytes = sbytes + nmax;
   size_t off = 0;
   for (PetscInt i = 0; i < ns; i++) {
     CHKHIP(mi355x_memcpy_d2h(dc->hcomm, ctx->h_send + off, ssrc[i], sizeof(PetscScalar) * (size_t)scnt[i]));
@@ -199,8 +201,12 @@ static PetscErrorCode scatter_begin(HipScatter ctx, Vec x, Vec y, InsertMode add
   if (ctx->to.n == 0 && ctx->from.n == 0 && ctx->to.local_n == 0) return 0;
   ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
   ierr = scatter_device_setup(ctx, dc);CHKERRQ(ierr);
-  PetscScalar *rdst[64]; const PetscScalar *ssrc[64]; PetscInt rcnt[64], scnt[64];
-  if (ctx->to.n > 64 || ctx->from.n > 64) SETERRQ(ctx->comm, PETSC_ERR_SUP, "more than 64 neighbours");
+  /* any number of neighbours: the per-neighbour arrays live in a work block of the scatter (8-byte slots; arrays 0..3 here, 4..9
+   * in neighbour_exchange) */
+  const size_t nmax = (size_t)PetscMax(PetscMax(ctx->to.n, ctx->from.n), 1);
+  if (!ctx->nbr_work) { ierr = PetscMalloc(sizeof(void *) * 10 * nmax, &ctx->nbr_work);CHKERRQ(ierr); }
+  PetscScalar **rdst = (PetscScalar **)ctx->nbr_work; const PetscScalar **ssrc = (const PetscScalar **)ctx->nbr_work + nmax;
+  PetscInt *rcnt = (PetscInt *)((void **)ctx->nbr_work + 2 * nmax), *scnt = (PetscInt *)((void **)ctx->nbr_work + 3 * nmax);
   VecScatterSide *to = &ctx->to, *from = &ctx->from;
   if (mode == SCATTER_FORWARD) {
     const PetscScalar *dx; PetscScalar *dy;
@@ -302,7 +308,7 @@ PetscErrorCode HipScatterDestroy(HipScatter *pctx) {
   if (ctx->d_local_tmp) mi355x_free(ctx->d_local_tmp);
   if (ctx->ev_packed) mi355x_event_destroy(ctx->ev_packed);
   if (ctx->ev_done) mi355x_event_destroy(ctx->ev_done);
-  HipFree(ctx->h_send); HipFree(ctx->h_recv);
+  HipFree(ctx->h_send); HipFree(ctx->h_recv); HipFree(ctx->nbr_work);
   HipFree(ctx);
   *pctx = NULL;
   return 0;
