@@ -311,6 +311,11 @@ int mi355x_trisolve_plan_create_nodes_pair(mi355x_handle_t h, int n, int nnodes,
 int mi355x_trisolve_plan_destroy(mi355x_trisolve_plan_t plan);
 int mi355x_trisolve_apply(mi355x_handle_t h, mi355x_trisolve_plan_t lower, mi355x_trisolve_plan_t upper, const double *b, double *y);
 int mi355x_trisolve_aborted(mi355x_trisolve_plan_t plan, int *aborted);
+/* tests: one array of a row plan copied back (which: 0 slice offsets, 1 (length, sub-step) words, 2 position -> row, 3 / 4 sliced-ELL
+ * column positions / values, 5 inverted diagonals, 6 right-hand-side scales, 7 sub-steps per slice, 8 row -> position, 9 level
+ * extents); *bytes = its size, copied when it fits cap_bytes.  Row plans in column order are laid out on the device
+ * (csrc/trisolve_build.hip); MI355X_TRISOLVE_BUILD=host in the environment keeps the host threads' route: the same arrays. */
+int mi355x_trisolve_debug_get(mi355x_trisolve_plan_t plan, int which, void *out, size_t cap_bytes, size_t *bytes);
 /* the same application over the same plans with one launch per dependency level and no hand-off between wavefronts (same
  * per-row order of the products: same bits): what a caller falls back to after a sync-free application gave up, whatever the
  * factor (ILU(0), ICC(0)); does not consult or change the abort flags */

@@ -82,6 +82,7 @@ KERNEL_API = {
     "mi355x_trisolve_plan_destroy": [vp],
     "mi355x_trisolve_apply": [vp, vp, vp, vp, vp],
     "mi355x_trisolve_aborted": [vp, pi32],
+    "mi355x_trisolve_debug_get": [vp, i32, vp, sz, C.POINTER(sz)],
     "mi355x_spmv_plan_create": [vp, i32, vp, vp, C.POINTER(vp)],
     "mi355x_spmv_plan_destroy": [vp],
     "mi355x_spmv_plan_compress_indices": [vp, vp, vp, vp],

@@ -81,40 +81,7 @@ int mi355x_ilu0_upper_level(mi355x_handle_t h, int nrows, const int *rows, const
 // Arithmetic: one lane per row, products subtracted in column order -- MatSolve_SeqAIJ_NaturalOrdering's bits
 // (aijfact.c:3126-3172), as in the level kernels above.
 // Every spin is bounded: a lane that gives up raises *abort_flag (pinned host memory) and all spinners drain.
-#define TRI_SENTINEL 0xFFF8DEADBEEFCAFEull
-#define TRI_QUEUES 8
-#define TRI_QSTRIDE 16          // queue counters 64 bytes apart
-#define TRI_ALIGN_MIN 32        // by_level plans: levels of at least this many rows start on a slice boundary
-#define TRI_SPIN_LIMIT (1 << 19)   // x ~1 us per poll once backed off: gives up after ~0.5 s
-
-struct mi355x_trisolve_plan_s {
-  int n, nslices, nchunks, upper;
-  int *d_ptr;        // nslices + 1 entry offsets (multiples of 64)
-  int *d_info;       // per position: (row length << 8) | sub-step inside the slice; padding positions: 0
-  int *d_row;        // per position: the row it holds, -1 for padding
-  int *d_col;        // sliced-ELL column POSITIONS
-  double *d_val;     // sliced-ELL values
-  double *d_dinv;    // upper: inverted diagonal per position
-  double *d_rscale;  // upper, optional: factor applied to the right-hand side entry before the row's sum starts (ICC: D^-1 between the two solves)
-  unsigned char *d_nsub;   // sub-steps per slice
-  int *d_pos;        // per row: its position (for the other solve's gather of this solve's result)
-  double *d_w;       // solution in position order, 64 * nslices doubles
-  unsigned int *d_queue;   // TRI_QUEUES counters
-  int *abort_flag;   // pinned + mapped
-  int grid, sleep_cap;
-  int by_level;      // rows in dependency-level order, levels on slice boundaries
-  int nlev;
-  int *levpos;       // host, 2 * nlev: first and one-past-last position of every dependency level (level-by-level fall-back)
-  // node plans (nb > 1): a position holds a NODE -- up to nb consecutive rows with one shared column list (the inodes of the
-  // reference, Mat_CheckInode); d_row = the node's first row, d_col = SLOTS (k * np + position) of the shared columns, d_val = nb
-  // values per shared column, d_din = the couplings inside the node and (upper) the inverted diagonals, d_w = nb * np slots
-  int nb, np;
-  int spw;                 // node plans: slices (waves) per workgroup
-  int split, ring, maxcol; // split-role kernel (loader + solver wavefront per workgroup): on, batches in the LDS ring, widest slice
-  int blkcols;             // the shared lists hold whole dependency nodes: one list entry per node, solution stored node by node
-  unsigned char *d_nsz;    // per position: rows in the node
-  double *d_din;           // [nb (nb - 1) / 2 + nb][np]
-};
+#include "trisolve_plan.hpp"
 
 __device__ __forceinline__ double tri_poll(const double *p, int *abort_flag, int sleep_cap) {
   double v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -817,6 +784,48 @@ template <class F> static void host_parallel_for(long n, long grain, F f) {
   for (auto &t : th) t.join();
 }
 
+__global__ __launch_bounds__(MI355X_BLOCK) void tri_arm_kernel(size_t n, double *w) {
+  for (size_t i = (size_t)blockIdx.x * MI355X_BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * MI355X_BLOCK) w[i] = __longlong_as_double((long long)TRI_SENTINEL);
+}
+
+// What a row plan needs beside its sliced-ELL arrays (p->nslices, p->nchunks set): the solution vector armed with the sentinel,
+// the queue counters, the abort flag in pinned memory, the launch geometry.
+int trisolve_plan_finish(mi355x_handle_t h, mi355x_trisolve_plan_s *p, int nlev, int by_level) {
+  const size_t np = (size_t)p->nslices * MI355X_WAVE, npa = np > 0 ? np : 1;
+  MI355X_TRY(hipMalloc((void **)&p->d_w, sizeof(double) * npa));
+  hipLaunchKernelGGL(tri_arm_kernel, dim3(mi355x_grid_for(npa, 4)), dim3(MI355X_BLOCK), 0, h->stream, npa, p->d_w);
+  MI355X_LAUNCH_CHECK();
+  MI355X_TRY(hipMalloc((void **)&p->d_queue, sizeof(unsigned int) * TRI_QUEUES * TRI_QSTRIDE));
+  MI355X_TRY(hipMemsetAsync(p->d_queue, 0, sizeof(unsigned int) * TRI_QUEUES * TRI_QSTRIDE, h->stream));
+  MI355X_TRY(hipHostMalloc((void **)&p->abort_flag, 64, hipHostMallocMapped | hipHostMallocCoherent));
+  *p->abort_flag = 0;
+  // fully resident grid: the occupancy the runtime reports, at most 4 workgroups per CU (MI355X_MICROARCH.md:
+  // the query can over-report by one; 4 of 256 threads is well inside what this kernel's registers admit)
+  int dev = 0, ncu = 256, per_cu = 0;
+  hipDeviceProp_t prop;
+  MI355X_TRY(hipGetDevice(&dev));
+  MI355X_TRY(hipGetDeviceProperties(&prop, dev));
+  ncu = prop.multiProcessorCount;
+  MI355X_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trisolve_syncfree_kernel<true>, MI355X_BLOCK, 0));
+  p->by_level = by_level;
+  if (per_cu > 4) per_cu = 4;
+  if (per_cu < 1) return (int)hipErrorInvalidValue;
+  p->grid = ncu * per_cu;
+  // ... and no larger than a few levels' worth of chunks: workgroups further ahead of the front could only spin
+  { const char *e = getenv("MI355X_TRISOLVE_AHEAD");      // development knobs; the defaults are the measured best
+    const long ahead = e ? atol(e) : 4;
+    const long per_level = ((long)p->nchunks + nlev - 1) / (nlev > 0 ? nlev : 1);
+    long g = ahead * per_level;
+    if (g < TRI_QUEUES) g = TRI_QUEUES;
+    if (g < p->grid) p->grid = (int)g; }
+  if (p->grid > p->nchunks) p->grid = p->nchunks > 0 ? p->nchunks : 1;
+  if (p->grid >= TRI_QUEUES) p->grid -= p->grid % TRI_QUEUES;    // every queue gets the same number of pullers
+  // poll back-off cap (x 128 clocks): the more wavefronts wait, the gentler they must poll (P7(256), 344 workgroups:
+  // cap 2 -> 8.1 ms, cap 8 -> 2.9 ms; P7(128), 88 workgroups: cap 2 -> 1.04 ms, cap 8 -> 1.14 ms per application)
+  { const char *e = getenv("MI355X_TRISOLVE_SLEEP"); p->sleep_cap = e ? atoi(e) : (p->grid <= 128 ? 2 : 8); if (p->sleep_cap < 1) p->sleep_cap = 1; }
+  return 0;
+}
+
 extern "C" {
 
 // Host analysis + upload.  n rows; lev[i] = dependency level of row i (0-based, every level non-empty); len(i) and
@@ -967,38 +976,7 @@ static int trisolve_plan_fill(mi355x_handle_t h, mi355x_trisolve_plan_s *p, int 
 #undef TRI_UP
   TRI_TRY(hipStreamSynchronize(h->stream));
   tick("upload");
-  TRI_TRY(hipMalloc((void **)&p->d_w, sizeof(double) * (np > 0 ? np : 1)));
-  { std::vector<unsigned long long> sent(np > 0 ? np : 1, TRI_SENTINEL);
-    TRI_TRY(hipMemcpyAsync(p->d_w, sent.data(), sizeof(double) * sent.size(), hipMemcpyHostToDevice, h->stream));
-    TRI_TRY(hipStreamSynchronize(h->stream)); }
-  TRI_TRY(hipMalloc((void **)&p->d_queue, sizeof(unsigned int) * TRI_QUEUES * TRI_QSTRIDE));
-  TRI_TRY(hipMemsetAsync(p->d_queue, 0, sizeof(unsigned int) * TRI_QUEUES * TRI_QSTRIDE, h->stream));
-  TRI_TRY(hipHostMalloc((void **)&p->abort_flag, 64, hipHostMallocMapped | hipHostMallocCoherent));
-  *p->abort_flag = 0;
-  // fully resident grid: the occupancy the runtime reports, at most 4 workgroups per CU (MI355X_MICROARCH.md:
-  // the query can over-report by one; 4 of 256 threads is well inside what this kernel's registers admit)
-  int dev = 0, ncu = 256, per_cu = 0;
-  hipDeviceProp_t prop;
-  TRI_TRY(hipGetDevice(&dev));
-  TRI_TRY(hipGetDeviceProperties(&prop, dev));
-  ncu = prop.multiProcessorCount;
-  TRI_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trisolve_syncfree_kernel<true>, MI355X_BLOCK, 0));
-  p->by_level = by_level;
-  if (per_cu > 4) per_cu = 4;
-  if (per_cu < 1) TRI_FAIL();
-  p->grid = ncu * per_cu;
-  // ... and no larger than a few levels' worth of chunks: workgroups further ahead of the front could only spin
-  { const char *e = getenv("MI355X_TRISOLVE_AHEAD");      // development knobs; the defaults are the measured best
-    const long ahead = e ? atol(e) : 4;
-    const long per_level = ((long)p->nchunks + nlev - 1) / (nlev > 0 ? nlev : 1);
-    long g = ahead * per_level;
-    if (g < TRI_QUEUES) g = TRI_QUEUES;
-    if (g < p->grid) p->grid = (int)g; }
-  if (p->grid > p->nchunks) p->grid = p->nchunks > 0 ? p->nchunks : 1;
-  if (p->grid >= TRI_QUEUES) p->grid -= p->grid % TRI_QUEUES;    // every queue gets the same number of pullers
-  // poll back-off cap (x 128 clocks): the more wavefronts wait, the gentler they must poll (P7(256), 344 workgroups:
-  // cap 2 -> 8.1 ms, cap 8 -> 2.9 ms; P7(128), 88 workgroups: cap 2 -> 1.04 ms, cap 8 -> 1.14 ms per application)
-  { const char *e = getenv("MI355X_TRISOLVE_SLEEP"); p->sleep_cap = e ? atoi(e) : (p->grid <= 128 ? 2 : 8); if (p->sleep_cap < 1) p->sleep_cap = 1; }
+  TRI_TRY(trisolve_plan_finish(h, p, nlev, by_level));
   TRI_TRY(hipStreamSynchronize(h->stream));
   return 0;
 }
@@ -1019,8 +997,14 @@ static int trisolve_plan_create_impl(mi355x_handle_t h, int n, int nlev, const i
   // solver wavefront per workgroup, lists end-aligned; same column order, one product after the other: the same bits).  Wide levels
   // (a stencil operator: tens of thousands of rows per level) are throughput-bound and keep the one-wavefront-per-slice kernel.
   // The choice is made for the two plans of a factor together (mi355x_trisolve_plan_create_pair).
+  // Row plans in column order are laid out ON THE DEVICE (trisolve_build.hip: the factor's arrays go up as they are, a radix sort
+  // orders the rows, kernels write the sliced-ELL arrays); MI355X_TRISOLVE_BUILD=host keeps the host threads' route, which also
+  // serves the orders the device route does not build (dependencies oldest first, node plans).  Same plan either way, bit for bit.
+  const char *bm = getenv("MI355X_TRISOLVE_BUILD");
+  const bool on_device = !singles && !by_level && n > 0 && !(bm && !strcmp(bm, "host"));
   const int rc = singles ? trisolve_plan_fill_nodes(h, p, n, n, nullptr, nlev, lev, rp, rl, cj, cv, dinv_host, by_level, 0, rscale_host, 1)
-                         : trisolve_plan_fill(h, p, n, nlev, lev, rp, rl, cj, cv, dinv_host, rscale_host, by_level);
+                 : on_device ? trisolve_plan_fill_device(h, p, n, nlev, lev, rp, rl, cj, cv, dinv_host, rscale_host, by_level)
+                             : trisolve_plan_fill(h, p, n, nlev, lev, rp, rl, cj, cv, dinv_host, rscale_host, by_level);
   if (rc) { mi355x_trisolve_plan_destroy(p); return rc; }     // one cleanup path: nothing allocated so far survives a failure
   *out = p;
   return 0;
@@ -1479,6 +1463,36 @@ int mi355x_trisolve_apply_levels(mi355x_handle_t h, mi355x_trisolve_plan_t lo, m
                        up->d_ptr, up->d_info, up->d_row, up->d_col, up->d_val, up->d_dinv, lo->d_w, lo->d_pos, up->d_w, y,
                        (const double *)up->d_rscale);
     MI355X_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+// tests: one array of a ROW plan back on the host.  which: 0 slice offsets (nslices + 1 ints), 1 (length, sub-step) words, 2 position -> row,
+// 3 sliced-ELL column positions, 4 sliced-ELL values, 5 inverted diagonals, 6 right-hand-side scales, 7 sub-steps per slice, 8 row ->
+// position, 9 first / one-past-last position of every level (host array).  *bytes = the array's size; copied when it fits cap_bytes.
+int mi355x_trisolve_debug_get(mi355x_trisolve_plan_t p, int which, void *out, size_t cap_bytes, size_t *bytes) {
+  if (!p || p->nb >= 1) return (int)hipErrorInvalidValue;
+  const size_t np = (size_t)p->nslices * MI355X_WAVE;
+  int total = 0;
+  if (p->nslices > 0) MI355X_TRY(hipMemcpy(&total, p->d_ptr + p->nslices, sizeof(int), hipMemcpyDeviceToHost));
+  const void *src = nullptr; size_t nb = 0; bool host = false;
+  switch (which) {
+  case 0: src = p->d_ptr; nb = sizeof(int) * ((size_t)p->nslices + 1); break;
+  case 1: src = p->d_info; nb = sizeof(int) * np; break;
+  case 2: src = p->d_row; nb = sizeof(int) * np; break;
+  case 3: src = p->d_col; nb = sizeof(int) * (size_t)total; break;
+  case 4: src = p->d_val; nb = sizeof(double) * (size_t)total; break;
+  case 5: src = p->d_dinv; nb = p->d_dinv ? sizeof(double) * np : 0; break;
+  case 6: src = p->d_rscale; nb = p->d_rscale ? sizeof(double) * np : 0; break;
+  case 7: src = p->d_nsub; nb = (size_t)p->nslices; break;
+  case 8: src = p->d_pos; nb = sizeof(int) * (size_t)p->n; break;
+  case 9: src = p->levpos; nb = sizeof(int) * 2 * (size_t)p->nlev; host = true; break;
+  default: return (int)hipErrorInvalidValue;
+  }
+  *bytes = nb;
+  if (nb && nb <= cap_bytes) {
+    if (host) memcpy(out, src, nb);
+    else MI355X_TRY(hipMemcpy(out, src, nb, hipMemcpyDeviceToHost));
   }
   return 0;
 }

@@ -143,6 +143,7 @@ typedef struct {
   PetscBool owns_host;                                     /* harness: ours; inside PETSc: the arrays of F's own Mat_SeqAIJ */
   PetscInt *d_bi, *d_bj, *d_bdiag; PetscScalar *d_ba;      /* device copies for the level-scheduled ILU kernels */
   PetscInt nlevL, nlevU, *levptrL, *levptrU;               /* dependency levels (host) */
+  PetscInt *rlevL, *rlevU;                                 /* level of every row of L / U, left by the host factorisation for the solves' analysis (else NULL) */
   PetscInt *d_rowsL, *d_rowsU;                             /* rows ordered by level (device) */
   PetscScalar *d_work; void *graph; int graph_tried;       /* hipGraph of the level launches working in place on d_work */
   mi355x_trisolve_plan_t tri_lo, tri_up;                   /* sync-free solves (NULL: level launches) */

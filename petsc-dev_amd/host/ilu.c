@@ -59,7 +59,7 @@ PetscErrorCode HipTriFactorsDestroy(HipTriFactors **pf) {
   if (!f) return 0;
   tri_watch_remove(f);
   if (f->owns_host) { HipFree(f->bi); HipFree(f->bj); HipFree(f->bdiag); HipFree(f->ba); }
-  HipFree(f->levptrL); HipFree(f->levptrU); HipFree(f->blk);
+  HipFree(f->levptrL); HipFree(f->levptrU); HipFree(f->blk); HipFree(f->rlevL); HipFree(f->rlevU);
   if (f->d_bi) mi355x_free(f->d_bi);
   if (f->d_bj) mi355x_free(f->d_bj);
   if (f->d_bdiag) mi355x_free(f->d_bdiag);
@@ -79,6 +79,7 @@ static void tri_reset_numeric(HipTriFactors *f) {
   if (f->owns_host) { HipFree(f->bi); HipFree(f->bj); HipFree(f->bdiag); HipFree(f->ba); }
   f->bi = f->bj = f->bdiag = NULL; f->ba = NULL;
   HipFree(f->levptrL); HipFree(f->levptrU); f->levptrL = f->levptrU = NULL;
+  HipFree(f->rlevL); HipFree(f->rlevU); f->rlevL = f->rlevU = NULL;
   if (f->d_bi) mi355x_free(f->d_bi);
   if (f->d_bj) mi355x_free(f->d_bj);
   if (f->d_bdiag) mi355x_free(f->d_bdiag);
@@ -145,9 +146,61 @@ static PetscErrorCode natural_ordering_only(Mat A, IS row, IS col, const MatFact
 static double wall_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
 #define SETUP_TICK(what) do { if (getenv("PETSC_HIPMI355X_SETUP_TIMING")) { const double t__ = wall_s(); fprintf(stderr, "[hipmi355x]   %-34s %.3f s\n", what, t__ - tick0); tick0 = t__; } } while (0)
 
-#if !defined(PETSCHIPMI355X_WITH_PETSC)
 #include <pthread.h>
 #include <unistd.h>
+/* the set-up's bulk loops over rows (16.7 M of them for P7(256)) on host threads: contiguous ranges, nothing shared */
+typedef void (*HipRangeFn)(void *ctx, PetscInt lo, PetscInt hi);
+typedef struct { HipRangeFn fn; void *ctx; PetscInt lo, hi; } HipRangeArg;
+static void *hip_range_thread(void *a_) { HipRangeArg *a = (HipRangeArg *)a_; a->fn(a->ctx, a->lo, a->hi); return NULL; }
+static void hip_parallel_ranges(PetscInt n, HipRangeFn fn, void *ctx) {
+  HipRangeArg args[16]; pthread_t th[16]; int started[16];
+  long hw = sysconf(_SC_NPROCESSORS_ONLN);
+  int nth = (int)(hw > 16 ? 16 : (hw < 1 ? 1 : hw));
+  if (n < 200000) nth = 1;
+  for (int t = 0; t < nth; t++) { args[t].fn = fn; args[t].ctx = ctx; args[t].lo = (PetscInt)((long)n * t / nth); args[t].hi = (PetscInt)((long)n * (t + 1) / nth); }
+  for (int t = 1; t < nth; t++) started[t] = !pthread_create(&th[t], NULL, hip_range_thread, &args[t]);
+  fn(ctx, args[0].lo, args[0].hi);
+  for (int t = 1; t < nth; t++) { if (started[t]) pthread_join(th[t], NULL); else fn(ctx, args[t].lo, args[t].hi); }
+}
+
+/* dependency levels of the rows of L (a row may start once the rows its L part names are done) and of U (backwards), from the
+ * factor's pattern in the reference's layout; each is a sequential recurrence, the two run side by side */
+typedef struct { PetscInt n; const PetscInt *bi, *bj, *bdiag; PetscInt *lev, nlev; } RowLevArg;
+static void *row_levels_L(void *a_) {
+  RowLevArg *a = (RowLevArg *)a_; const PetscInt *bi = a->bi, *bj = a->bj; PetscInt *lev = a->lev, nlev = 0;
+  for (PetscInt i = 0; i < a->n; i++) {
+    PetscInt l = 0;
+    for (PetscInt q = bi[i]; q < bi[i + 1]; q++) l = PetscMax(l, lev[bj[q]] + 1);
+    lev[i] = l; nlev = PetscMax(nlev, l + 1);
+  }
+  a->nlev = nlev;
+  return NULL;
+}
+static void *row_levels_U(void *a_) {
+  RowLevArg *a = (RowLevArg *)a_; const PetscInt *bj = a->bj, *bdiag = a->bdiag; PetscInt *lev = a->lev, nlev = 0;
+  for (PetscInt i = a->n - 1; i >= 0; i--) {
+    PetscInt l = 0; const PetscInt s0 = bdiag[i + 1] + 1, nz = bdiag[i] - bdiag[i + 1] - 1;
+    for (PetscInt q = 0; q < nz; q++) l = PetscMax(l, lev[bj[s0 + q]] + 1);
+    lev[i] = l; nlev = PetscMax(nlev, l + 1);
+  }
+  a->nlev = nlev;
+  return NULL;
+}
+static PetscErrorCode ilu0_row_levels(PetscInt n, const PetscInt *bi, const PetscInt *bj, const PetscInt *bdiag, PetscInt **levL, PetscInt *nlevL, PetscInt **levU, PetscInt *nlevU) {
+  PetscErrorCode ierr;
+  RowLevArg aL = {n, bi, bj, bdiag, NULL, 0}, aU = {n, bi, bj, bdiag, NULL, 0};
+  pthread_t th; int side = 0;
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)PetscMax(n, 1), &aL.lev);CHKERRQ(ierr);
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)PetscMax(n, 1), &aU.lev);CHKERRQ(ierr);
+  if (n >= 200000) side = !pthread_create(&th, NULL, row_levels_L, &aL);
+  if (!side) row_levels_L(&aL);
+  row_levels_U(&aU);
+  if (side) pthread_join(th, NULL);
+  *levL = aL.lev; *nlevL = aL.nlev; *levU = aU.lev; *nlevU = aU.nlev;
+  return 0;
+}
+
+#if !defined(PETSCHIPMI355X_WITH_PETSC)
 /* one pass of the numeric ILU(0) over the rows [r0, r1) of an independent block with a given diagonal shift, rows taken level by
  * level (dependency levels of L) and a level's rows dealt to the threads */
 typedef struct {
@@ -247,25 +300,30 @@ static PetscErrorCode ilu0_run_pass(IluPass *p) {
   pthread_mutex_destroy(&p->mtx);
   return 0;
 }
-/* dependency levels of L (a row may be factored once the rows its L part names are), rows listed level by level */
-static PetscErrorCode ilu0_levels_host(PetscInt n, const PetscInt *bi, const PetscInt *bj, PetscInt *nlev_out, PetscInt **levptr_out, PetscInt **rows_out) {
-  PetscErrorCode ierr;
-  PetscInt *lev, nlev = 0;
-  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)PetscMax(n, 1), &lev);CHKERRQ(ierr);
-  for (PetscInt i = 0; i < n; i++) {
-    PetscInt l = 0;
-    for (PetscInt q = bi[i]; q < bi[i + 1]; q++) l = PetscMax(l, lev[bj[q]] + 1);
-    lev[i] = l; nlev = PetscMax(nlev, l + 1);
-  }
-  ierr = level_order(n, lev, nlev, levptr_out, rows_out);
-  HipFree(lev);
-  CHKERRQ(ierr);
-  *nlev_out = nlev;
-  return 0;
-}
 #endif
 
 #if !defined(PETSCHIPMI355X_WITH_PETSC)
+typedef struct { const PetscInt *ai, *aj; PetscInt *adiag, *bi, *bj, *bdiag; volatile PetscInt missing; } IluSym;
+static void ilu0_sym_diag(void *c_, PetscInt lo, PetscInt hi) {
+  IluSym *c = (IluSym *)c_;
+  for (PetscInt i = lo; i < hi; i++) {
+    PetscInt d = -1;
+    for (PetscInt q = c->ai[i]; q < c->ai[i + 1]; q++) if (c->aj[q] == i) { d = q; break; }
+    c->adiag[i] = d;
+    if (d < 0) c->missing = i;             /* (the caller looks for the first such row) */
+  }
+}
+/* the pattern of A, L part forward, U part from the last row backwards with the diagonal at each row's end (aijfact.c:1660-1685) */
+static void ilu0_sym_pattern(void *c_, PetscInt lo, PetscInt hi) {
+  IluSym *c = (IluSym *)c_;
+  for (PetscInt i = lo; i < hi; i++) {
+    const PetscInt nzl = c->adiag[i] - c->ai[i], nzu = c->ai[i + 1] - c->adiag[i] - 1;
+    PetscInt *l = c->bj + c->bi[i], *u = c->bj + c->bdiag[i + 1] + 1;
+    for (PetscInt j = 0; j < nzl; j++) l[j] = c->aj[c->ai[i] + j];
+    for (PetscInt j = 0; j < nzu; j++) u[j] = c->aj[c->adiag[i] + 1 + j];
+    u[nzu] = i;
+  }
+}
 /* MatILUFactorSymbolic_SeqAIJ_ilu0 + MatLUFactorNumeric_SeqAIJ restated for the harness (inside a PETSc tree the parent's
  * routines run instead): the pattern of A, L part forward, U part from the last row backwards (aijfact.c:1660-1685); row by row
  * with a dense work row, pivots stored inverted (aijfact.c:505-570); MatPivotCheck_nz's restarts (matimpl.h:512-528) */
@@ -278,31 +336,28 @@ static PetscErrorCode ilu0_factor_host(Mat F, Mat A, const MatFactorInfo *info) 
   f->n = n; f->nz = ai[n]; f->owns_host = PETSC_TRUE;
   PetscInt *adiag;
   ierr = PetscMalloc(sizeof(PetscInt) * (size_t)PetscMax(n, 1), &adiag);CHKERRQ(ierr);
-  for (PetscInt i = 0; i < n; i++) {
-    adiag[i] = -1;
-    for (PetscInt q = ai[i]; q < ai[i + 1]; q++) if (aj[q] == i) { adiag[i] = q; break; }
-    if (adiag[i] < 0) { HipFree(adiag); SETERRQ(HipObjComm(A), PETSC_ERR_ARG_WRONGSTATE, "Matrix is missing diagonal entry %d", i); }
-  }
+  { IluSym sy = {ai, aj, adiag, NULL, NULL, NULL, -1};
+    hip_parallel_ranges(n, ilu0_sym_diag, &sy);
+    if (sy.missing >= 0) {
+      PetscInt first = 0;
+      while (first < n && adiag[first] >= 0) first++;
+      HipFree(adiag);
+      SETERRQ(HipObjComm(A), PETSC_ERR_ARG_WRONGSTATE, "Matrix is missing diagonal entry %d", first);
+    } }
   ierr = PetscMalloc(sizeof(PetscInt) * (size_t)(n + 1), &f->bi);CHKERRQ(ierr);
   ierr = PetscMalloc(sizeof(PetscInt) * (size_t)(f->nz + 1), &f->bj);CHKERRQ(ierr);
   ierr = PetscMalloc(sizeof(PetscInt) * (size_t)(n + 1), &f->bdiag);CHKERRQ(ierr);
   ierr = PetscMalloc(sizeof(PetscScalar) * (size_t)(f->nz + 1), &f->ba);CHKERRQ(ierr);
   SETUP_TICK("factor: diagonal positions");
   f->ba[f->nz] = 0.0;                      /* (every other entry is written by the numeric pass) */
-  PetscInt k = 0, *bi = f->bi, *bj = f->bj, *bdiag = f->bdiag; PetscScalar *ba = f->ba;
+  PetscInt *bi = f->bi, *bj = f->bj, *bdiag = f->bdiag; PetscScalar *ba = f->ba;
+  /* the two pointer arrays are running sums (one light sequential pass each); the column copies are per row, on host threads */
   bi[0] = 0;
-  for (PetscInt i = 0; i < n; i++) {
-    PetscInt nzl = adiag[i] - ai[i];
-    bi[i + 1] = bi[i] + nzl;
-    for (PetscInt j = 0; j < nzl; j++) bj[k++] = aj[ai[i] + j];
-  }
+  for (PetscInt i = 0; i < n; i++) bi[i + 1] = bi[i] + (adiag[i] - ai[i]);
   bdiag[n] = bi[n] - 1;
-  for (PetscInt i = n - 1; i >= 0; i--) {
-    PetscInt nzu = ai[i + 1] - adiag[i] - 1;
-    for (PetscInt j = 0; j < nzu; j++) bj[k++] = aj[adiag[i] + 1 + j];
-    bj[k++] = i;
-    bdiag[i] = bdiag[i + 1] + nzu + 1;
-  }
+  for (PetscInt i = n - 1; i >= 0; i--) bdiag[i] = bdiag[i + 1] + (ai[i + 1] - adiag[i] - 1) + 1;
+  { IluSym sy = {ai, aj, adiag, bi, bj, bdiag, -1};
+    hip_parallel_ranges(n, ilu0_sym_pattern, &sy); }
   SETUP_TICK("factor: pattern of L and U");
   const PetscReal zeropivot = info->zeropivot, shiftamount = info->shiftamount;
   const PetscBool shift_nz = (PetscBool)(info->shifttype == (PetscReal)MAT_SHIFT_NONZERO);
@@ -324,9 +379,12 @@ static PetscErrorCode ilu0_factor_host(Mat F, Mat A, const MatFactorInfo *info) 
     if (nth < 1) nth = 1;
     if (nth > 64) nth = 64;
     ps.nth = (int)nth; }
-  ierr = ilu0_levels_host(n, bi, bj, &ps.nlev, &ps.levptr, &ps.rows);
+  /* levels of L (the threaded passes below take a level's rows together) and of U, kept for the solves' analysis */
+  HipFree(f->rlevL); HipFree(f->rlevU); f->rlevL = f->rlevU = NULL;
+  ierr = ilu0_row_levels(n, bi, bj, bdiag, &f->rlevL, &f->nlevL, &f->rlevU, &f->nlevU);
+  if (!ierr) { ps.nlev = f->nlevL; ierr = level_order(n, f->rlevL, f->nlevL, &ps.levptr, &ps.rows); }
   if (ierr) { HipFree(adiag); CHKERRQ(ierr); }
-  SETUP_TICK("factor: levels of L");
+  SETUP_TICK("factor: levels of L and U");
   ierr = PetscMalloc(sizeof(PetscScalar *) * (size_t)ps.nth, &ps.rtmp);CHKERRQ(ierr);
   for (int t = 0; t < ps.nth; t++) { ps.rtmp[t] = (PetscScalar *)calloc((size_t)n + 1, sizeof(PetscScalar)); if (!ps.rtmp[t]) SETERRQ(HipObjComm(A), PETSC_ERR_MEM, "out of memory"); }
   for (PetscInt bb = 0; bb < nblk; bb++) {
@@ -349,11 +407,20 @@ static PetscErrorCode ilu0_factor_host(Mat F, Mat A, const MatFactorInfo *info) 
   SETUP_TICK("factor: numeric passes");
   for (int t = 0; t < ps.nth; t++) free(ps.rtmp[t]);
   HipFree(ps.rtmp); HipFree(ps.levptr); HipFree(ps.rows); HipFree(adiag);
+  SETUP_TICK("factor: work arrays released");
   if (ierr) SETERRQ(HipObjComm(A), 71 /* PETSC_ERR_MAT_LU_ZRPVT */, "Zero pivot row %d value %g%s", ps.fail_row, ps.fail_value, shift_nz ? ": still there after 80 diagonal shifts" : "");
   return 0;
 }
 #endif
 
+typedef struct { const PetscInt *bi, *bdiag; const PetscScalar *ba; PetscInt *rlL, *rpU, *rlU; PetscScalar *dinv; } RowArr;
+static void ilu0_row_arrays(void *c_, PetscInt lo, PetscInt hi) {
+  RowArr *c = (RowArr *)c_;
+  for (PetscInt i = lo; i < hi; i++) {
+    c->rlL[i] = c->bi[i + 1] - c->bi[i];
+    c->rpU[i] = c->bdiag[i + 1] + 1; c->rlU[i] = c->bdiag[i] - c->bdiag[i + 1] - 1; c->dinv[i] = c->ba[c->bdiag[i]];
+  }
+}
 /* dependency levels of the two triangular factors, the sync-free plans, the level lists: everything MatSolve needs, from the
  * host factor in f->bi / bj / bdiag / ba (the reference's layout, whoever computed it) */
 static PetscErrorCode ilu0_analyse_and_upload(Mat F, Mat A) {
@@ -361,24 +428,10 @@ static PetscErrorCode ilu0_analyse_and_upload(Mat F, Mat A) {
   HipTriFactors *f = HipTriGet(F);
   const PetscInt n = f->n, *bi = f->bi, *bj = f->bj, *bdiag = f->bdiag; const PetscScalar *ba = f->ba;
   PetscDeviceCtx *dc;
-  PetscInt *lev, *levU, *rowsL, *rowsU;
+  PetscInt *lev, *levU, *rowsL = NULL, *rowsU = NULL;
   const double ta0 = wall_s();
-  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)PetscMax(n, 1), &lev);CHKERRQ(ierr);
-  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)PetscMax(n, 1), &levU);CHKERRQ(ierr);
-  f->nlevL = 0;
-  for (PetscInt i = 0; i < n; i++) {          /* a row may start once the rows it references are done */
-    PetscInt l = 0;
-    for (PetscInt q = bi[i]; q < bi[i + 1]; q++) l = PetscMax(l, lev[bj[q]] + 1);
-    lev[i] = l; f->nlevL = PetscMax(f->nlevL, l + 1);
-  }
-  ierr = level_order(n, lev, f->nlevL, &f->levptrL, &rowsL);CHKERRQ(ierr);
-  f->nlevU = 0;
-  for (PetscInt i = n - 1; i >= 0; i--) {
-    PetscInt l = 0, s0 = bdiag[i + 1] + 1, nz = bdiag[i] - bdiag[i + 1] - 1;
-    for (PetscInt q = 0; q < nz; q++) l = PetscMax(l, levU[bj[s0 + q]] + 1);
-    levU[i] = l; f->nlevU = PetscMax(f->nlevU, l + 1);
-  }
-  ierr = level_order(n, levU, f->nlevU, &f->levptrU, &rowsU);CHKERRQ(ierr);
+  if (f->rlevL && f->rlevU) { lev = f->rlevL; levU = f->rlevU; f->rlevL = f->rlevU = NULL; }   /* the host factorisation's own analysis */
+  else { ierr = ilu0_row_levels(n, bi, bj, bdiag, &lev, &f->nlevL, &levU, &f->nlevU);CHKERRQ(ierr); }
   if (getenv("PETSC_HIPMI355X_SETUP_TIMING")) fprintf(stderr, "[hipmi355x] ILU(0): row levels %.3f s\n", wall_s() - ta0);
   ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
   {   /* sync-free solves: worth it as soon as the level launches would be a launch-bound chain */
@@ -391,10 +444,8 @@ static PetscErrorCode ilu0_analyse_and_upload(Mat F, Mat A) {
       ierr = PetscMalloc(sizeof(PetscInt) * (size_t)n, &rlU);CHKERRQ(ierr);
       ierr = PetscMalloc(sizeof(PetscInt) * (size_t)n, &rlL);CHKERRQ(ierr);
       ierr = PetscMalloc(sizeof(PetscScalar) * (size_t)n, &dinv);CHKERRQ(ierr);
-      for (PetscInt i = 0; i < n; i++) {
-        rlL[i] = bi[i + 1] - bi[i];
-        rpU[i] = bdiag[i + 1] + 1; rlU[i] = bdiag[i] - bdiag[i + 1] - 1; dinv[i] = ba[bdiag[i]];
-      }
+      { RowArr ra = {bi, bdiag, ba, rlL, rpU, rlU, dinv};
+        hip_parallel_ranges(n, ilu0_row_arrays, &ra); }
       /* -pc_factor_hipmi355x_trisolve_order <column|level>.  column: every row is summed in column order, the bits of
        * MatSolve_SeqAIJ_NaturalOrdering.  level: in the order of its dependencies' levels (a row then waits on its last
        * entries only) -- the default where the reference does not run the natural-ordering routine either: a matrix with
@@ -463,8 +514,9 @@ static PetscErrorCode ilu0_analyse_and_upload(Mat F, Mat A) {
       } else HipTriWatchAdd(f);
     }
   }
-  HipFree(lev); HipFree(levU);
-  if (!f->tri_lo) {   /* the level-scheduled kernels work on the reference's layout itself */
+  if (!f->tri_lo) {   /* the level-scheduled kernels work on the reference's layout itself, rows listed level by level */
+    ierr = level_order(n, lev, f->nlevL, &f->levptrL, &rowsL);CHKERRQ(ierr);
+    ierr = level_order(n, levU, f->nlevU, &f->levptrU, &rowsU);CHKERRQ(ierr);
     CHKHIP(mi355x_malloc((void **)&f->d_bi, sizeof(PetscInt) * (size_t)(n + 1)));
     CHKHIP(mi355x_malloc((void **)&f->d_bj, sizeof(PetscInt) * (size_t)(f->nz + 1)));
     CHKHIP(mi355x_malloc((void **)&f->d_bdiag, sizeof(PetscInt) * (size_t)(n + 1)));
@@ -479,7 +531,7 @@ static PetscErrorCode ilu0_analyse_and_upload(Mat F, Mat A) {
     CHKHIP(mi355x_memcpy_h2d(dc->h, f->d_rowsU, rowsU, sizeof(PetscInt) * (size_t)n));
     CHKHIP(mi355x_handle_synchronize(dc->h));
   }
-  HipFree(rowsL); HipFree(rowsU);
+  HipFree(rowsL); HipFree(rowsU); HipFree(lev); HipFree(levU);
   return 0;
 }
 

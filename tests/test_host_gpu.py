@@ -1016,16 +1016,19 @@ def test_icc0_apply_bitexact_and_golden(P):
         assert r[2] == runs[0][2] and np.array_equal(bits(r[1]), bits(runs[0][1])) and np.array_equal(bits(r[0]), bits(runs[0][0]))
 
 
-@pytest.mark.parametrize("kernels", ["split", "onewave"])
+@pytest.mark.parametrize("kernels", ["split", "onewave", "onewave_hostbuild"])
 @pytest.mark.parametrize("seed", range(12))
 def test_factor_fuzz_ilu0_icc0(P, seed, kernels, monkeypatch):
     """random symmetric sparsity patterns (random density, a band plus scattered entries, sometimes empty off-diagonal rows) with diagonals
     from strongly dominant to not dominant at all: ILU(0) and ICC(0) on the device take the oracle's number of shifts and apply
     with its bits -- through both families of sync-free kernels: narrow dependency levels run the split-role kernels with every row a
-    node of its own (the default here), MI355X_TRISOLVE_SPLIT=0 keeps the one-wavefront-per-slice kernels that wide levels use"""
+    node of its own (the default here), MI355X_TRISOLVE_SPLIT=0 keeps the one-wavefront-per-slice kernels that wide levels use,
+    their plans laid out on the device (csrc/trisolve_build.hip: radix sort + fill kernels) or, MI355X_TRISOLVE_BUILD=host, by the
+    host threads: the same plan, the same bits"""
     import scipy.sparse as sp
     L = P.lib()
     monkeypatch.setenv("MI355X_TRISOLVE_SPLIT", "1" if kernels == "split" else "0")
+    monkeypatch.setenv("MI355X_TRISOLVE_BUILD", "host" if kernels == "onewave_hostbuild" else "device")
     rng = np.random.default_rng(9000 + seed)
     n = int(rng.integers(2, 2500))
     R = sp.random(n, n, density=min(1.0, float(rng.uniform(1.0, 6.0)) / n), random_state=int(rng.integers(1 << 30)), data_rvs=rng.standard_normal)

@@ -986,3 +986,110 @@ def test_bcgs_fused_kernels_match_separate_kernels_bitwise(dev, n):
         assert_bitexact(dev.get(x2, n), dev.get(x1, n)); assert_bitexact(dev.get(r2, n), dev.get(r1, n))
     for q in (dx, dd, dy, ds, w1, w2, dp, dt, drp, x1, x2, r1, r2):
         dev.free(q)
+
+
+def _tri_levels(n, rp, rl, cj):
+    lev = np.zeros(n, dtype=np.int32)
+    for i in range(n):
+        d = cj[rp[i]:rp[i] + rl[i]]
+        lev[i] = (lev[d].max() + 1) if d.size else 0
+    return lev
+
+
+def _tri_plan_arrays(dev, plan):
+    out = []
+    for which, dt in ((0, np.int32), (1, np.int32), (2, np.int32), (3, np.int32), (4, np.uint64), (5, np.uint64), (6, np.uint64), (7, np.uint8), (8, np.int32), (9, np.int32)):
+        nb = C.c_size_t()
+        dev.chk(dev.k.mi355x_trisolve_debug_get(plan, which, None, 0, C.byref(nb)))
+        a = np.empty(nb.value // np.dtype(dt).itemsize, dtype=dt)
+        if a.nbytes:
+            dev.chk(dev.k.mi355x_trisolve_debug_get(plan, which, a.ctypes.data, a.nbytes, C.byref(nb)))
+        out.append(a)
+    return out
+
+
+@pytest.mark.parametrize("shape", ["wide", "ragged", "chain", "tiny", "empty_rows"])
+@pytest.mark.parametrize("kind", ["lower", "upper", "upper_scaled"])
+def test_trisolve_row_plans_built_on_the_device_equal_the_host_built_plans(dev, shape, kind, monkeypatch):
+    """csrc/trisolve_build.hip lays a row plan out on the device (radix sort of the rows by (level, longer first), positions,
+    per-slice words, scan of the slice widths, fill kernel); MI355X_TRISOLVE_BUILD=host is the host threads' route.  Every array of
+    the plan -- slice offsets, (length, sub-step) words, position <-> row maps, sliced-ELL column positions and values, diagonals,
+    scales, sub-steps, level extents -- must be identical, padding included; the entries may sit anywhere inside the caller's
+    column / value arrays (the device route uploads only the range the rows name)."""
+    k = dev.k
+    rng = np.random.default_rng(hash((shape, kind)) % (1 << 31))
+    n = {"wide": 40000, "ragged": 9000, "chain": 700, "tiny": 5, "empty_rows": 3000}[shape]
+    # strictly lower-triangular dependency structure (for an upper solve the caller hands over reversed roles; the plan only needs
+    # "dependencies come earlier in level order", so a lower structure serves both kinds here)
+    rl = np.zeros(n, dtype=np.int32)
+    cols = []
+    for i in range(n):
+        if shape == "wide":
+            cand = sorted(c for c in (i - 7000, i - 200, i - 1) if c >= 0 and not (c == i - 1 and i % 200 == 0))   # a 3-D stencil's lower part
+        elif shape == "ragged":
+            m = int(rng.integers(0, 40)) if i % 11 else 0
+            cand = sorted(set(int(c) for c in rng.integers(max(0, i - 3000), max(i, 1), size=m) if c < i)) if i else []
+        elif shape == "chain":
+            cand = [i - 1] if i and i % 3 else ([i - 2] if i > 1 else [])
+        elif shape == "tiny":
+            cand = list(range(i))
+        else:
+            cand = [] if i % 2 else sorted(set(int(c) for c in rng.integers(0, max(i, 1), size=3) if c < i))
+        rl[i] = len(cand); cols.append(cand)
+    pad = 17                                                  # the rows' entries do not start at the arrays' first element
+    rp = (pad + np.concatenate(([0], np.cumsum(rl)[:-1]))).astype(np.int32)
+    nz = int(rl.sum())
+    cj = np.full(pad + nz + 5, -7, dtype=np.int32)            # entries no row names hold an invalid column: never looked at
+    cv = np.full(pad + nz + 5, np.nan)
+    for i in range(n):
+        cj[rp[i]:rp[i] + rl[i]] = cols[i]
+    cv[pad:pad + nz] = rng.standard_normal(nz)
+    lev = _tri_levels(n, rp, rl, cj)
+    nlev = int(lev.max()) + 1
+    dinv = rng.standard_normal(n) if kind != "lower" else None
+    rsc = rng.standard_normal(n) if kind == "upper_scaled" else None
+    plans = {}
+    for route in ("host", "device"):
+        monkeypatch.setenv("MI355X_TRISOLVE_BUILD", route)
+        monkeypatch.setenv("MI355X_TRISOLVE_SPLIT", "0")
+        pl = C.c_void_p()
+        if rsc is not None:
+            dev.chk(k.mi355x_trisolve_plan_create_scaled(dev.h, n, nlev, lev.ctypes.data, rp.ctypes.data, rl.ctypes.data, cj.ctypes.data, cv.ctypes.data,
+                                                         dinv.ctypes.data, rsc.ctypes.data, C.byref(pl)))
+        else:
+            dev.chk(k.mi355x_trisolve_plan_create(dev.h, n, nlev, lev.ctypes.data, rp.ctypes.data, rl.ctypes.data, cj.ctypes.data, cv.ctypes.data,
+                                                  dinv.ctypes.data if dinv is not None else None, C.byref(pl)))
+        plans[route] = _tri_plan_arrays(dev, pl)
+        k.mi355x_trisolve_plan_destroy(pl)
+    names = ["ptr", "info", "row", "col", "val", "dinv", "rscale", "nsub", "pos", "levpos"]
+    for name, a, b in zip(names, plans["host"], plans["device"]):
+        assert a.shape == b.shape and np.array_equal(a, b), name
+    assert plans["host"][3].size > 0 or shape == "tiny" or nz == 0
+
+
+def test_trisolve_device_built_plan_rejects_what_the_host_route_rejects(dev, monkeypatch):
+    """a column index outside the matrix, a dependency that does not come earlier, a level without rows: an error code from either
+    route, no fault"""
+    k = dev.k
+    n = 300
+    rl = np.ones(n, dtype=np.int32); rl[0] = 0
+    rp = np.arange(n, dtype=np.int32) - 1; rp[0] = 0
+    cj = np.arange(n - 1, dtype=np.int32)                     # row i depends on row i - 1
+    cv = np.ones(n - 1)
+    lev = np.arange(n, dtype=np.int32)
+    monkeypatch.setenv("MI355X_TRISOLVE_SPLIT", "0")
+    for route in ("host", "device"):
+        monkeypatch.setenv("MI355X_TRISOLVE_BUILD", route)
+        pl = C.c_void_p()
+        # a chain of 300 levels in slices of 64: a slice spans more than 255 levels?  no -- 64 rows per slice, 64 sub-steps: accepted
+        assert k.mi355x_trisolve_plan_create(dev.h, n, n, lev.ctypes.data, rp.ctypes.data, rl.ctypes.data, cj.ctypes.data, cv.ctypes.data, None, C.byref(pl)) == 0
+        k.mi355x_trisolve_plan_destroy(pl)
+        bad_lev = lev.copy(); bad_lev[10] = 5                 # row 10 would run before row 9, which it depends on (and level 10 is empty)
+        assert k.mi355x_trisolve_plan_create(dev.h, n, n, bad_lev.ctypes.data, rp.ctypes.data, rl.ctypes.data, cj.ctypes.data, cv.ctypes.data, None, C.byref(pl)) != 0
+    monkeypatch.setenv("MI355X_TRISOLVE_BUILD", "device")
+    pl = C.c_void_p()
+    bad_cj = cj.copy(); bad_cj[50] = n + 5
+    assert k.mi355x_trisolve_plan_create(dev.h, n, n, lev.ctypes.data, rp.ctypes.data, rl.ctypes.data, bad_cj.ctypes.data, cv.ctypes.data, None, C.byref(pl)) != 0
+    bad_cj = cj.copy(); bad_cj[50] = -3
+    assert k.mi355x_trisolve_plan_create(dev.h, n, n, lev.ctypes.data, rp.ctypes.data, rl.ctypes.data, bad_cj.ctypes.data, cv.ctypes.data, None, C.byref(pl)) != 0
+    dev.sync()
