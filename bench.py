@@ -32,6 +32,9 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 PEAK_GBPS = 8000.0          # MI355X HBM3E (MI355X_MICROARCH.md)
+# the pool's host driver only does dmabuf IPC: without this RCCL's peer-memory set-up between the ranks' GPUs fails
+# (hipIpcGetMemHandle: invalid argument); must be in the environment before the HIP runtime starts
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 
 def main():
