@@ -20,6 +20,8 @@
 //     x'y by-product for CG, and the BCSR form of the same structure.
 #include "common.hpp"
 #include <map>
+#include <array>
+#include <memory>
 #include <vector>
 #include <thread>
 #include <functional>
@@ -1044,6 +1046,18 @@ int mi355x_spmv_plan_create(mi355x_handle_t h, int nrows, const int *ai_host, co
   return 0;
 }
 
+// host threads of the pattern analyses: up to `cap`, one below 400 000 rows; MI355X_ANALYSIS_THREADS=<n> in the environment
+// forces a count (tests: the merge of the chunks' tables on small matrices), never more than one thread per row
+static int analysis_threads(int m, int cap) {
+  unsigned hc = std::thread::hardware_concurrency();
+  int nth = (int)(hc > (unsigned)cap ? (unsigned)cap : (hc < 1 ? 1u : hc));
+  if (m < 400000) nth = 1;
+  const char *e = getenv("MI355X_ANALYSIS_THREADS");
+  if (e && atoi(e) > 0) nth = atoi(e) > 64 ? 64 : atoi(e);
+  if (nth > m) nth = m > 0 ? m : 1;
+  return nth;
+}
+
 // Offset-dictionary analysis: idx8[k] = position of (aj[k] - row) in a table of <= 256 distinct offsets.
 // Returns 0 and leaves the plan uncompressed when the matrix has more distinct offsets.
 int mi355x_spmv_plan_compress_indices(mi355x_handle_t h, mi355x_spmv_plan_t p, const int *ai_host, const int *aj_host) {
@@ -1051,78 +1065,147 @@ int mi355x_spmv_plan_compress_indices(mi355x_handle_t h, mi355x_spmv_plan_t p, c
   if (SPMV_BLOCK_ROWS > 256) return 0;   // row markers are bytes
   const int m = p->nrows;
   const long nnz = ai_host[m];
-  std::vector<unsigned char> idx((size_t)(nnz > 0 ? nnz : 1));
+  // The rows are analysed in contiguous chunks by host threads (one pass over the column indices of P7(256) on one thread: 0.3 s
+  // before the first product): every chunk collects its offsets / its rows' slot lists in order of first appearance, the chunks'
+  // tables are merged in chunk order -- which gives the table of a single pass over all rows -- and the chunks renumber their part.
+  int nth = analysis_threads(m, 16);
+  auto chunk_lo = [&](int k) { return (int)((long)m * k / nth); };
+  auto run_chunks = [&](auto fn) {
+    if (nth == 1) { fn(0); return; }
+    std::vector<std::thread> th;
+    for (int k = 1; k < nth; ++k) th.emplace_back(fn, k);
+    fn(0);
+    for (auto &t : th) t.join();
+  };
+  std::unique_ptr<unsigned char[]> idx(new unsigned char[(size_t)(nnz > 0 ? nnz : 1)]);
+  struct OffTab { int tab[256]; int n = 0; bool ok = true; };
+  std::vector<OffTab> lt((size_t)nth);
+  run_chunks([&](int k) {
+    OffTab &t = lt[(size_t)k];
+    int last = 0;      // (offsets of a stencil matrix repeat row after row, so the slot after the previous one is tried first)
+    for (int r = chunk_lo(k); r < chunk_lo(k + 1); ++r) {
+      for (int q = ai_host[r]; q < ai_host[r + 1]; ++q) {
+        const int off = aj_host[q] - r;
+        int slot = -1;
+        if (t.n && t.tab[last] == off) slot = last;
+        else for (int e = 0; e < t.n; ++e) if (t.tab[e] == off) { slot = e; break; }
+        if (slot < 0) {
+          if (t.n == 256) { t.ok = false; return; }   // too many distinct offsets: keep plain CSR
+          t.tab[t.n] = off;
+          slot = t.n++;
+        }
+        idx[(size_t)q] = (unsigned char)slot;
+        last = (slot + 1 < t.n) ? slot + 1 : 0;
+      }
+    }
+  });
+  for (auto &t : lt) if (!t.ok) return 0;
   int tab[256];
   int ntab = 0;
-  // small open-addressing map offset -> slot (offsets of a stencil matrix repeat row after row, so the
-  // previous row's slots are tried first)
-  int last = 0;
-  for (int r = 0; r < m; ++r) {
-    for (int k = ai_host[r]; k < ai_host[r + 1]; ++k) {
-      const int off = aj_host[k] - r;
-      int slot = -1;
-      if (ntab && tab[last] == off) slot = last;
-      else for (int t = 0; t < ntab; ++t) if (tab[t] == off) { slot = t; break; }
-      if (slot < 0) {
-        if (ntab == 256) return 0;   // too many distinct offsets: keep plain CSR
-        tab[ntab] = off;
-        slot = ntab++;
-      }
-      idx[(size_t)k] = (unsigned char)slot;
-      last = (slot + 1 < ntab) ? slot + 1 : 0;
+  std::vector<std::array<unsigned char, 256>> remap((size_t)nth);
+  std::vector<char> identity((size_t)nth, 1);
+  for (int k = 0; k < nth; ++k) {
+    for (int e = 0; e < lt[(size_t)k].n; ++e) {
+      int g = -1;
+      for (int f = 0; f < ntab; ++f) if (tab[f] == lt[(size_t)k].tab[e]) { g = f; break; }
+      if (g < 0) { if (ntab == 256) return 0; tab[ntab] = lt[(size_t)k].tab[e]; g = ntab++; }
+      remap[(size_t)k][(size_t)e] = (unsigned char)g;
+      if (g != e) identity[(size_t)k] = 0;
     }
   }
+  run_chunks([&](int k) {
+    if (identity[(size_t)k]) return;
+    const unsigned char *mp = remap[(size_t)k].data();
+    for (long q = ai_host[chunk_lo(k)]; q < ai_host[chunk_lo(k + 1)]; ++q) idx[(size_t)q] = mp[idx[(size_t)q]];
+  });
   MI355X_TRY(hipMalloc((void **)&p->d_idx8, (size_t)(nnz > 0 ? nnz : 1) + 16));
   MI355X_TRY(hipMalloc((void **)&p->d_offtab, sizeof(int) * 256));
   MI355X_TRY(hipMemsetAsync(p->d_offtab, 0, sizeof(int) * 256, h->stream));
-  MI355X_TRY(hipMemcpyAsync(p->d_idx8, idx.data(), (size_t)nnz, hipMemcpyHostToDevice, h->stream));
+  MI355X_TRY(hipMemcpyAsync(p->d_idx8, idx.get(), (size_t)nnz, hipMemcpyHostToDevice, h->stream));
   MI355X_TRY(hipMemcpyAsync(p->d_offtab, tab, sizeof(int) * (size_t)ntab, hipMemcpyHostToDevice, h->stream));
-  MI355X_TRY(hipStreamSynchronize(h->stream));
   p->ntab = ntab;
   // row patterns: the rows' slot lists as a dictionary of at most SPMV_PAT_CAP table entries in all (stencil operators: a
   // handful of lists); rows too long for the row block's one-lane-per-row sums (> SPMV_BLOCK_CAP never happens here) or a
   // table that would not fit leave the plan at the per-nonzero bytes
   {
-    std::map<std::vector<unsigned char>, int> dict;
-    std::vector<unsigned int> prow((size_t)m);
-    std::vector<int> ptab;
-    std::vector<unsigned char> cur, prev;
-    int prev_start = -1;
-    bool ok = true;
     // first nonzero of every row block (the rows carry their offset from it in 16 bits: a block holds <= 2046 nonzeros)
     std::vector<int2> blk((size_t)p->nblocks + 1);
-    MI355X_TRY(hipMemcpy(blk.data(), p->d_rowblk, sizeof(int2) * ((size_t)p->nblocks + 1), hipMemcpyDeviceToHost));
-    int b = 0;
-    for (int r = 0; r < m && ok; ++r) {
-      while (b + 1 <= p->nblocks && blk[(size_t)b + 1].x <= r) ++b;      // the block that holds row r
-      const int len = ai_host[r + 1] - ai_host[r];
-      const int rs = ai_host[r] - blk[(size_t)b].y;
-      if (len > SPMV_BLOCK_CAP || rs < 0 || rs > 0xffff) { ok = false; break; }
-      cur.assign(idx.begin() + ai_host[r], idx.begin() + ai_host[r + 1]);
-      int start;
-      if (prev_start >= 0 && cur == prev) start = prev_start;
-      else {
-        auto it = dict.find(cur);
-        if (it != dict.end()) start = it->second;
+    MI355X_TRY(hipMemcpyAsync(blk.data(), p->d_rowblk, sizeof(int2) * ((size_t)p->nblocks + 1), hipMemcpyDeviceToHost, h->stream));
+    MI355X_TRY(hipStreamSynchronize(h->stream));          // (also: idx and tab have left the host)
+    std::unique_ptr<unsigned int[]> prow(new unsigned int[(size_t)m]);
+    struct PatDict { std::vector<int> ptab; std::vector<int> starts; std::vector<std::vector<unsigned char>> keys; bool ok = true; };
+    std::vector<PatDict> pd((size_t)nth);
+    run_chunks([&](int k) {
+      PatDict &d = pd[(size_t)k];
+      std::map<std::vector<unsigned char>, int> dict;
+      std::vector<unsigned char> cur, prev;
+      int prev_start = -1;
+      const int r0 = chunk_lo(k), r1 = chunk_lo(k + 1);
+      int b = 0;
+      { int lo = 0, hi = p->nblocks;                       // the block that holds row r0: the last one starting at or before it
+        while (lo < hi) { const int mid = (lo + hi + 1) / 2; if (blk[(size_t)mid].x <= r0) lo = mid; else hi = mid - 1; }
+        b = lo; }
+      for (int r = r0; r < r1; ++r) {
+        while (b + 1 <= p->nblocks && blk[(size_t)b + 1].x <= r) ++b;
+        const int len = ai_host[r + 1] - ai_host[r];
+        const int rs = ai_host[r] - blk[(size_t)b].y;
+        if (len > SPMV_BLOCK_CAP || rs < 0 || rs > 0xffff) { d.ok = false; return; }
+        cur.assign(idx.get() + ai_host[r], idx.get() + ai_host[r + 1]);
+        int start;
+        if (prev_start >= 0 && cur == prev) start = prev_start;
         else {
-          start = (int)ptab.size();
-          if (start + 1 + len > SPMV_PAT_CAP) { ok = false; break; }
-          ptab.push_back(len);                                            // table entry: {length, offsets ...}
-          for (int q = 0; q < len; ++q) ptab.push_back(tab[cur[(size_t)q]]);
-          dict.emplace(cur, start);
+          auto it = dict.find(cur);
+          if (it != dict.end()) start = it->second;
+          else {
+            start = (int)d.ptab.size();
+            if (start + 1 + len > SPMV_PAT_CAP) { d.ok = false; return; }
+            d.ptab.push_back(len);                                          // table entry: {length, offsets ...}
+            for (int q = 0; q < len; ++q) d.ptab.push_back(tab[cur[(size_t)q]]);
+            dict.emplace(cur, start);
+            d.starts.push_back(start); d.keys.push_back(cur);
+          }
+          prev = cur; prev_start = start;
         }
-        prev = cur; prev_start = start;
+        prow[(size_t)r] = (unsigned int)start | ((unsigned int)rs << 16);
       }
-      prow[(size_t)r] = (unsigned int)start | ((unsigned int)rs << 16);
+    });
+    bool ok = true;
+    for (auto &d : pd) ok = ok && d.ok;
+    std::vector<int> ptab;
+    std::map<std::vector<unsigned char>, int> gdict;
+    std::vector<std::vector<int>> to((size_t)nth);
+    std::vector<char> same((size_t)nth, 1);
+    for (int k = 0; k < nth && ok; ++k) {
+      const PatDict &d = pd[(size_t)k];
+      to[(size_t)k].assign((size_t)SPMV_PAT_CAP, -1);
+      for (size_t e = 0; e < d.starts.size() && ok; ++e) {
+        const int ls = d.starts[e], len = d.ptab[(size_t)ls];
+        int g;
+        auto it = gdict.find(d.keys[e]);
+        if (it != gdict.end()) g = it->second;
+        else {
+          g = (int)ptab.size();
+          if (g + 1 + len > SPMV_PAT_CAP) { ok = false; break; }
+          ptab.insert(ptab.end(), d.ptab.begin() + ls, d.ptab.begin() + ls + 1 + len);
+          gdict.emplace(d.keys[e], g);
+        }
+        to[(size_t)k][(size_t)ls] = g;
+        if (g != ls) same[(size_t)k] = 0;
+      }
     }
     if (ok) {
+      run_chunks([&](int k) {
+        if (same[(size_t)k]) return;
+        const int *t = to[(size_t)k].data();
+        for (int r = chunk_lo(k); r < chunk_lo(k + 1); ++r) prow[(size_t)r] = (prow[(size_t)r] & 0xffff0000u) | (unsigned int)t[prow[(size_t)r] & 0xffffu];
+      });
       ptab.resize(SPMV_PAT_CAP, 0);
       MI355X_TRY(hipMalloc((void **)&p->d_prow, sizeof(unsigned int) * (size_t)m + 16));
       MI355X_TRY(hipMalloc((void **)&p->d_pattab, sizeof(int) * SPMV_PAT_CAP));
-      MI355X_TRY(hipMemcpyAsync(p->d_prow, prow.data(), sizeof(unsigned int) * (size_t)m, hipMemcpyHostToDevice, h->stream));
+      MI355X_TRY(hipMemcpyAsync(p->d_prow, prow.get(), sizeof(unsigned int) * (size_t)m, hipMemcpyHostToDevice, h->stream));
       MI355X_TRY(hipMemcpyAsync(p->d_pattab, ptab.data(), sizeof(int) * SPMV_PAT_CAP, hipMemcpyHostToDevice, h->stream));
       MI355X_TRY(hipStreamSynchronize(h->stream));
-      p->npat = (int)dict.size();
+      p->npat = (int)gdict.size();
     }
   }
   return 0;
@@ -1186,9 +1269,7 @@ int mi355x_spmv_plan_value_patterns(mi355x_handle_t h, mi355x_spmv_plan_t p, con
       vrow[(size_t)r] = (unsigned short)start;
     }
   };
-  unsigned hc = std::thread::hardware_concurrency();
-  int nth = (int)(hc > 8 ? 8 : (hc < 1 ? 1 : hc));
-  if (m < 400000) nth = 1;
+  const int nth = analysis_threads(m, 8);
   std::vector<Dict> dicts((size_t)nth);
   if (nth == 1) analyse(0, m, dicts[0]);
   else {

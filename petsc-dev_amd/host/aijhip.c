@@ -4,6 +4,7 @@
  * overrides (MatCreate_SeqAIJCUSP, src/mat/impls/aij/seq/seqcusp/aijcusp.cu:657-681): mult, multadd,
  * multtranspose[add], getdiagonal, assemblyend, getvecs, destroy. */
 #include "hipmi355ximpl.h"
+#include <time.h>
 
 /* the host CSR container: this file's own on the harness, a view of the parent MATSEQAIJ's arrays inside a PETSc tree */
 #define SA(A) HipAIJGet(A)
@@ -112,6 +113,14 @@ static PetscErrorCode device_free(Mat A);
 /* Mat_CheckInode (src/mat/impls/aij/seq/inode.c:3964-4034): consecutive rows with identical column lists form a node of
  * at most `limit` rows (-mat_inode_limit, default 5, inode2.c:85-99); with more than 0.8 m nodes -- or -mat_no_inode -- the
  * matrix keeps the plain routines (inode_count = 0). */
+typedef struct { const PetscInt *ii, *jj; unsigned char *same; PetscInt m; } InodeCmp;
+static void inode_compare_rows(void *c_, PetscInt lo, PetscInt hi) {     /* same[r]: row r + 1 has row r's column list */
+  InodeCmp *c = (InodeCmp *)c_;
+  for (PetscInt r = lo; r < hi; r++) {
+    const PetscInt nzx = c->ii[r + 1] - c->ii[r];
+    c->same[r] = (unsigned char)(r + 1 < c->m && c->ii[r + 2] - c->ii[r + 1] == nzx && !memcmp(c->jj + c->ii[r], c->jj + c->ii[r + 1], sizeof(PetscInt) * (size_t)nzx));
+  }
+}
 static PetscErrorCode seqaij_check_inode(Mat A) {
   PetscErrorCode ierr;
   HipAIJ *a = SA(A);
@@ -124,20 +133,19 @@ static PetscErrorCode seqaij_check_inode(Mat A) {
   if (limit < 1) limit = 1;
   if (limit > 5) limit = 5;
   ierr = PetscMalloc(sizeof(PetscInt) * (size_t)(m + 1), &ns);CHKERRQ(ierr);
-  const PetscInt *idx = a->j, *ii = a->i;
+  /* the comparisons (row r + 1 against row r: "the same list as the node's first row" is transitive) are the pass over the
+   * column indices and run on host threads; the greedy grouping of the reference's loop then reads one byte per row */
+  unsigned char *same;
+  ierr = PetscMalloc((size_t)m + 1, &same);CHKERRQ(ierr);
+  { InodeCmp ic = {a->i, a->j, same, m};
+    HipParallelRanges(m, inode_compare_rows, &ic); }
   while (i < m) {
-    const PetscInt nzx = ii[i + 1] - ii[i];
-    const PetscInt *idy = idx;
     PetscInt j, blk_size;
-    for (j = i + 1, blk_size = 1; j < m && blk_size < limit; ++j, ++blk_size) {
-      if (ii[j + 1] - ii[j] != nzx) break;
-      idy += nzx;
-      if (memcmp(idx, idy, sizeof(PetscInt) * (size_t)nzx)) break;
-    }
+    for (j = i + 1, blk_size = 1; j < m && blk_size < limit; ++j, ++blk_size) if (!same[j - 1]) break;
     ns[node_count++] = blk_size;
-    idx += (size_t)blk_size * nzx;
     i = j;
   }
+  HipFree(same);
   if (node_count > .8 * m) { HipFree(ns); return 0; }
   a->inode_size = ns; a->inode_count = node_count;
   return 0;
@@ -194,6 +202,12 @@ PetscErrorCode MatSeqAIJHIPUpload(Mat A) {
 #endif
   if (d->uploaded_state == HipObjState(A) && d->d_a) return 0;
   ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
+  const int up_timing = getenv("PETSC_HIPMI355X_SETUP_TIMING") != NULL;
+  double up_t0 = 0.0;
+#define UP_TICK(what) do { if (up_timing) { struct timespec ts__; (void)mi355x_handle_synchronize(dc->h); clock_gettime(CLOCK_MONOTONIC, &ts__); const double t__ = (double)ts__.tv_sec + 1e-9 * (double)ts__.tv_nsec; \
+    if (up_t0 > 0.0) { fprintf(stderr, "[hipmi355x]   upload: %-30s %.3f s\n", what, t__ - up_t0); } \
+    up_t0 = t__; } } while (0)
+  UP_TICK("");
   if (!a->compact) SETERRQ(HipObjComm(A), PETSC_ERR_ARG_WRONGSTATE, "matrix must be assembled before it is sent to the GPU");
   PetscBool same_pattern = (PetscBool)(d->d_a && d->plan && d->pattern_nz == a->nz);   /* entries are never removed: same nz == same pattern */
   if (!same_pattern) {
@@ -219,9 +233,11 @@ PetscErrorCode MatSeqAIJHIPUpload(Mat A) {
     CHKHIP(mi355x_malloc((void **)&d->d_a, sizeof(PetscScalar) * (size_t)PetscMax(a->nz, 1) + 16));
     CHKHIP(mi355x_memcpy_h2d(dc->h, d->d_i, ip, sizeof(PetscInt) * (size_t)(nrows + 1)));
     CHKHIP(mi355x_memcpy_h2d(dc->h, d->d_j, a->j, sizeof(PetscInt) * (size_t)a->nz));
+    UP_TICK("row pointer and columns up");
     if (a->bs <= 1) {
       PetscInt ic = 1; PetscBool set;
       CHKHIP(mi355x_spmv_plan_create(dc->h, nrows, ip, use_cprow ? ridx : NULL, &d->plan));
+      UP_TICK("row-block plan");
       /* -mat_hipmi355x_index_compression <0|1> (default 1): one byte per nonzero instead of a 4-byte column index
        * when the matrix uses <= 256 distinct (col - row) offsets; plain CSR otherwise */
       ierr = PetscOptionsGetInt(NULL, "-mat_hipmi355x_index_compression", &ic, &set);CHKERRQ(ierr);
@@ -232,11 +248,13 @@ PetscErrorCode MatSeqAIJHIPUpload(Mat A) {
          * stream 4 bytes per ROW instead of 1 byte per nonzero + the row pointer (spmv_csr_rowblock_pat_kernel); same bits */
         ierr = PetscOptionsGetInt(NULL, "-mat_hipmi355x_row_patterns", &rp, &set);CHKERRQ(ierr);
         CHKHIP(mi355x_spmv_plan_use_patterns(d->plan, rp ? 1 : 0, NULL));
+        UP_TICK("offset / row-pattern dictionaries");
       }
       /* inodes: when the reference's Mat_CheckInode would switch this matrix to MatMult_SeqAIJ_Inode, the row sums take
        * that routine's two-at-a-time order (same bits), and -- unless the 1-byte index dictionary already applies --
        * the rows of a node share one stored column list (mi355x_spmv_plan_group_rows) */
       ierr = seqaij_check_inode(A);CHKERRQ(ierr);
+      UP_TICK("inode check");
       if (a->inode_count) {
         int ntab = 0;
         CHKHIP(mi355x_spmv_plan_set_pairsum(d->plan, 1));
@@ -267,7 +285,9 @@ PetscErrorCode MatSeqAIJHIPUpload(Mat A) {
   }
   size_t vals = (size_t)a->nz * (size_t)(a->bs > 1 ? a->bs * a->bs : 1);
   if (a->bs > 1 && !same_pattern) { mi355x_free(d->d_a); CHKHIP(mi355x_malloc((void **)&d->d_a, sizeof(PetscScalar) * PetscMax(vals, 1) + 16)); }
+  UP_TICK("(grouped rows, bookkeeping)");
   CHKHIP(mi355x_memcpy_h2d(dc->h, d->d_a, a->a, sizeof(PetscScalar) * vals));
+  UP_TICK("values up");
   if (a->bs <= 1 && d->plan) {
     /* -mat_hipmi355x_value_patterns <0|1> (default 1): constant-coefficient operators -- whole rows, offsets and values,
      * from a dictionary of <= 512 entries -- run a kernel that reads 2 bytes per row and no values (spmv_csr_valpat_kernel);
@@ -278,6 +298,8 @@ PetscErrorCode MatSeqAIJHIPUpload(Mat A) {
     if (vp) CHKHIP(mi355x_spmv_plan_value_patterns(dc->h, d->plan, a->i, a->j, a->a, NULL));
   }
   CHKHIP(mi355x_handle_synchronize(dc->h));
+  UP_TICK("value-pattern analysis");
+#undef UP_TICK
   d->n_uploads++;
   d->uploaded_state = HipObjState(A);
   return 0;

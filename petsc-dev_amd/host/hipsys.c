@@ -28,6 +28,24 @@ PetscErrorCode PetscDeviceGet(PetscDeviceCtx **ctx) {
   return 0;
 }
 
+/* ---------------------------------------------------------------- host threads for the set-up passes */
+#include <pthread.h>
+#include <unistd.h>
+/* the set-up's bulk loops over rows (16.7 M of them for P7(256)) on host threads: contiguous ranges, nothing shared */
+typedef struct { HipRangeFn fn; void *ctx; PetscInt lo, hi; } HipRangeArg;
+static void *hip_range_thread(void *a_) { HipRangeArg *a = (HipRangeArg *)a_; a->fn(a->ctx, a->lo, a->hi); return NULL; }
+void HipParallelRanges(PetscInt n, HipRangeFn fn, void *ctx) {
+  HipRangeArg args[16]; pthread_t th[16]; int started[16];
+  long hw = sysconf(_SC_NPROCESSORS_ONLN);
+  int nth = (int)(hw > 16 ? 16 : (hw < 1 ? 1 : hw));
+  if (n < 200000) nth = 1;
+  for (int t = 0; t < nth; t++) { args[t].fn = fn; args[t].ctx = ctx; args[t].lo = (PetscInt)((long)n * t / nth); args[t].hi = (PetscInt)((long)n * (t + 1) / nth); }
+  for (int t = 1; t < nth; t++) started[t] = !pthread_create(&th[t], NULL, hip_range_thread, &args[t]);
+  fn(ctx, args[0].lo, args[0].hi);
+  for (int t = 1; t < nth; t++) { if (started[t]) pthread_join(th[t], NULL); else fn(ctx, args[t].lo, args[t].hi); }
+}
+
+
 /* ---------------------------------------------------------------- registration */
 PetscErrorCode PetscHIPMI355XRegisterAll(void) {
   PetscErrorCode ierr;

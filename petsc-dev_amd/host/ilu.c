@@ -148,21 +148,6 @@ static double wall_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, 
 
 #include <pthread.h>
 #include <unistd.h>
-/* the set-up's bulk loops over rows (16.7 M of them for P7(256)) on host threads: contiguous ranges, nothing shared */
-typedef void (*HipRangeFn)(void *ctx, PetscInt lo, PetscInt hi);
-typedef struct { HipRangeFn fn; void *ctx; PetscInt lo, hi; } HipRangeArg;
-static void *hip_range_thread(void *a_) { HipRangeArg *a = (HipRangeArg *)a_; a->fn(a->ctx, a->lo, a->hi); return NULL; }
-static void hip_parallel_ranges(PetscInt n, HipRangeFn fn, void *ctx) {
-  HipRangeArg args[16]; pthread_t th[16]; int started[16];
-  long hw = sysconf(_SC_NPROCESSORS_ONLN);
-  int nth = (int)(hw > 16 ? 16 : (hw < 1 ? 1 : hw));
-  if (n < 200000) nth = 1;
-  for (int t = 0; t < nth; t++) { args[t].fn = fn; args[t].ctx = ctx; args[t].lo = (PetscInt)((long)n * t / nth); args[t].hi = (PetscInt)((long)n * (t + 1) / nth); }
-  for (int t = 1; t < nth; t++) started[t] = !pthread_create(&th[t], NULL, hip_range_thread, &args[t]);
-  fn(ctx, args[0].lo, args[0].hi);
-  for (int t = 1; t < nth; t++) { if (started[t]) pthread_join(th[t], NULL); else fn(ctx, args[t].lo, args[t].hi); }
-}
-
 /* dependency levels of the rows of L (a row may start once the rows its L part names are done) and of U (backwards), from the
  * factor's pattern in the reference's layout; each is a sequential recurrence, the two run side by side */
 typedef struct { PetscInt n; const PetscInt *bi, *bj, *bdiag; PetscInt *lev, nlev; } RowLevArg;
@@ -338,7 +323,7 @@ static PetscErrorCode ilu0_factor_host(Mat F, Mat A, const MatFactorInfo *info) 
   PetscInt *adiag;
   ierr = PetscMalloc(sizeof(PetscInt) * (size_t)PetscMax(n, 1), &adiag);CHKERRQ(ierr);
   { IluSym sy = {ai, aj, adiag, NULL, NULL, NULL, -1};
-    hip_parallel_ranges(n, ilu0_sym_diag, &sy);
+    HipParallelRanges(n, ilu0_sym_diag, &sy);
     if (sy.missing >= 0) {
       PetscInt first = 0;
       while (first < n && adiag[first] >= 0) first++;
@@ -358,7 +343,7 @@ static PetscErrorCode ilu0_factor_host(Mat F, Mat A, const MatFactorInfo *info) 
   bdiag[n] = bi[n] - 1;
   for (PetscInt i = n - 1; i >= 0; i--) bdiag[i] = bdiag[i + 1] + (ai[i + 1] - adiag[i] - 1) + 1;
   { IluSym sy = {ai, aj, adiag, bi, bj, bdiag, -1};
-    hip_parallel_ranges(n, ilu0_sym_pattern, &sy); }
+    HipParallelRanges(n, ilu0_sym_pattern, &sy); }
   SETUP_TICK("factor: pattern of L and U");
   const PetscReal zeropivot = info->zeropivot, shiftamount = info->shiftamount;
   const PetscBool shift_nz = (PetscBool)(info->shifttype == (PetscReal)MAT_SHIFT_NONZERO);
@@ -453,7 +438,7 @@ static PetscErrorCode ilu0_analyse_and_upload(Mat F, Mat A) {
       ierr = PetscMalloc(sizeof(PetscInt) * (size_t)n, &rlL);CHKERRQ(ierr);
       ierr = PetscMalloc(sizeof(PetscScalar) * (size_t)n, &dinv);CHKERRQ(ierr);
       { RowArr ra = {bi, bdiag, ba, rlL, rpU, rlU, dinv};
-        hip_parallel_ranges(n, ilu0_row_arrays, &ra); }
+        HipParallelRanges(n, ilu0_row_arrays, &ra); }
       /* -pc_factor_hipmi355x_trisolve_order <column|level>.  column: every row is summed in column order, the bits of
        * MatSolve_SeqAIJ_NaturalOrdering.  level: in the order of its dependencies' levels (a row then waits on its last
        * entries only) -- the default where the reference does not run the natural-ordering routine either: a matrix with

@@ -343,9 +343,12 @@ def test_spmv_p7_bitexact(dev, dims):
     assert_bitexact(run_spmv(dev, ai, aj, aa, x, y0=y0), orc.spmv_add(ai, aj, aa, x, y0))
 
 
+@pytest.mark.parametrize("threads", [1, 5])
 @pytest.mark.parametrize("dims", [(5, 4, 3), (33, 17, 9), (64, 64, 40)])
-def test_spmv_index_compression_bitexact(dev, dims):
-    """offset-dictionary index compression (col = row + table[idx8]): same bits as the plain kernel and the oracle"""
+def test_spmv_index_compression_bitexact(dev, dims, threads, monkeypatch):
+    """offset-dictionary index compression (col = row + table[idx8]): same bits as the plain kernel and the oracle; the analysis
+    in chunks of rows on several host threads (tables merged in chunk order, as for large matrices) finds the same dictionaries"""
+    monkeypatch.setenv("MI355X_ANALYSIS_THREADS", str(threads))
     ai, aj, aa = orc.gen_p7(*dims)
     aa = aa * (1.0 + 0.01 * np.cos(np.arange(aa.size)))
     n = ai.size - 1
@@ -359,10 +362,13 @@ def test_spmv_index_compression_bitexact(dev, dims):
         assert_bitexact(run_spmv(dev, ai, aj, aa, x, compress=True, patterns=patterns, pairsum=1), orc.spmv_inode(ai, aj, aa, x))
 
 
+@pytest.mark.parametrize("threads", [1, 3])
 @pytest.mark.parametrize("dims", [(5, 4, 3), (33, 17, 9), (64, 64, 40), (1, 1, 1), (700, 3, 1)])
-def test_spmv_value_patterns_bitexact(dev, dims):
+def test_spmv_value_patterns_bitexact(dev, dims, threads, monkeypatch):
     """constant-coefficient operator: whole rows (offsets and values) come from the dictionary, the value array is not read
-    (it is NaN on the device here); y = Ax, y = y0 + Ax, y = d .* (Ax) and the inode summation order carry the oracle's bits"""
+    (it is NaN on the device here); y = Ax, y = y0 + Ax, y = d .* (Ax) and the inode summation order carry the oracle's bits;
+    one host thread or the chunked analysis"""
+    monkeypatch.setenv("MI355X_ANALYSIS_THREADS", str(threads))
     ai, aj, aa = orc.gen_p7(*dims)
     n = ai.size - 1
     x = np.sin(0.37 * np.arange(n)) + 1.0

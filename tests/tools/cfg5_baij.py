@@ -89,6 +89,24 @@ def main():
         print("%-9s bs=%d  median %.4f ms (min %.4f)  %.0f GB/s of its own %.3f GB = %.3f of 8 TB/s ; as bs=3 bytes: %.3f" %
               (name, bs, np.median(t), t.min(), B / np.median(t) / 1e6, B / 1e9, B / np.median(t) / 1e6 / 8000,
                ((72 + 4) * nnzb + 4 * (mbs + 1) + 48 * mbs) / np.median(t) / 1e6 / 8000), flush=True)
+    # what the same process streams from the same 4 GB value array with nothing else to do: a read-only pass (sum of squares) and a copy of its first half onto its second (read + write, same total bytes)
+    nval = nnzb * 9
+    out = dev.host_scratch()                        # the handle's pinned result slot (what the reductions write)
+    half = nval // 2
+    for label, fn, nbytes in (("read-only stream (VecNorm kernel over the bs=3 value array)", lambda: k.mi355x_vec_norm(dev.h, nval, 1, da3, out), 8 * nval),
+                              ("copy stream (first half of the value array onto the bs=4 array)", lambda: k.mi355x_vec_copy(dev.h, half, da3, da4), 16 * half)):
+        ts = []
+        for r in range(rounds):
+            fn(); fn()
+            k.mi355x_event_record(e0, dev.h)
+            for _ in range(10):
+                fn()
+            k.mi355x_event_record(e1, dev.h)
+            k.mi355x_event_synchronize(e1)
+            ms = C.c_float(); k.mi355x_event_elapsed_ms(e0, e1, C.byref(ms))
+            ts.append(ms.value / 10)
+        t = np.median(np.array(ts))
+        print("%-70s %.4f ms  %.0f GB/s = %.3f of 8 TB/s" % (label, t, nbytes / t / 1e6, nbytes / t / 1e6 / 8000), flush=True)
 
 
 if __name__ == "__main__":
