@@ -326,10 +326,11 @@ int mi355x_trisolve_debug_set_aborted(mi355x_trisolve_plan_t plan, int value);
 /* ---- halo pack / unpack (VecScatter) ---------------------------------- */
 /* Pack_1    src/vec/vec/utils/vpscat.c:493   buf[k] = x[idx[k]] */
 int mi355x_pack(mi355x_handle_t h, size_t n, const int *idx, const double *x, double *buf);
-/* UnPack_1  src/vec/vec/utils/vpscat.c:503   INSERT: y[idx[k]] = buf[k]; ADD: y[idx[k]] += buf[k]
- * (idx == NULL means contiguous: y[k]).  ADD requires idx entries to be distinct within one call. */
+/* UnPack_1  src/vec/vec/utils/vpscat.c:503-534   INSERT: y[idx[k]] = buf[k]; ADD: y[idx[k]] += buf[k]; MAX: y[idx[k]] =
+ * PetscMax(y[idx[k]], buf[k]) (idx == NULL means contiguous: y[k]).  ADD / MAX require idx entries to be distinct within one call. */
 int mi355x_unpack_insert(mi355x_handle_t h, size_t n, const int *idx, const double *buf, double *y);
 int mi355x_unpack_add(mi355x_handle_t h, size_t n, const int *idx, const double *buf, double *y);
+int mi355x_unpack_max(mi355x_handle_t h, size_t n, const int *idx, const double *buf, double *y);
 
 /* ---- measurement ------------------------------------------------------- */
 /* STREAM-style copy (pattern: src/benchmarks/streams/CUDAVersion.cu) for the achievable-bandwidth line */

@@ -112,6 +112,7 @@ KERNEL_API = {
     "mi355x_pack": [vp, sz, vp, vp, vp],
     "mi355x_unpack_insert": [vp, sz, vp, vp, vp],
     "mi355x_unpack_add": [vp, sz, vp, vp, vp],
+    "mi355x_unpack_max": [vp, sz, vp, vp, vp],
     "mi355x_stream_triad": [vp, sz, dbl, vp, vp, vp],
     # mi355x_comm.h
     "mi355x_comm_get_unique_id": [C.c_char_p],

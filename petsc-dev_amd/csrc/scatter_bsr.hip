@@ -8,14 +8,16 @@ __global__ __launch_bounds__(MI355X_BLOCK) void pack_kernel(size_t n, const int 
   for (size_t k = (size_t)blockIdx.x * MI355X_BLOCK + threadIdx.x; k < n; k += stride) buf[k] = x[idx[k]];
 }
 
-template <bool ADD>
+// UnPack_1 (vpscat.c:503-534): MODE 0 INSERT_VALUES, 1 ADD_VALUES, 2 MAX_VALUES (PetscMax(y, v) = (y < v) ? v : y, petscmath.h)
+template <int MODE>
 __global__ __launch_bounds__(MI355X_BLOCK) void unpack_kernel(size_t n, const int *__restrict__ idx,
                                                              const double *__restrict__ buf, double *y) {
   const size_t stride = (size_t)gridDim.x * MI355X_BLOCK;
   for (size_t k = (size_t)blockIdx.x * MI355X_BLOCK + threadIdx.x; k < n; k += stride) {
     const size_t dst = idx ? (size_t)idx[k] : k;
-    if (ADD) y[dst] = y[dst] + buf[k];
-    else     y[dst] = buf[k];
+    if (MODE == 1) y[dst] = y[dst] + buf[k];
+    else if (MODE == 2) { const double a = y[dst], b = buf[k]; y[dst] = (a < b) ? b : a; }
+    else y[dst] = buf[k];
   }
 }
 
@@ -228,14 +230,22 @@ int mi355x_pack(mi355x_handle_t h, size_t n, const int *idx, const double *x, do
 }
 int mi355x_unpack_insert(mi355x_handle_t h, size_t n, const int *idx, const double *buf, double *y) {
   if (!n) return 0;
-  hipLaunchKernelGGL((unpack_kernel<false>), dim3(mi355x_grid_for(n, 4)), dim3(MI355X_BLOCK), 0, h->stream, n, idx,
+  hipLaunchKernelGGL((unpack_kernel<0>), dim3(mi355x_grid_for(n, 4)), dim3(MI355X_BLOCK), 0, h->stream, n, idx,
                      buf, y);
   MI355X_LAUNCH_CHECK();
   return 0;
 }
 int mi355x_unpack_add(mi355x_handle_t h, size_t n, const int *idx, const double *buf, double *y) {
   if (!n) return 0;
-  hipLaunchKernelGGL((unpack_kernel<true>), dim3(mi355x_grid_for(n, 4)), dim3(MI355X_BLOCK), 0, h->stream, n, idx,
+  hipLaunchKernelGGL((unpack_kernel<1>), dim3(mi355x_grid_for(n, 4)), dim3(MI355X_BLOCK), 0, h->stream, n, idx,
+                     buf, y);
+  MI355X_LAUNCH_CHECK();
+  return 0;
+}
+
+int mi355x_unpack_max(mi355x_handle_t h, size_t n, const int *idx, const double *buf, double *y) {
+  if (!n) return 0;
+  hipLaunchKernelGGL((unpack_kernel<2>), dim3(mi355x_grid_for(n, 4)), dim3(MI355X_BLOCK), 0, h->stream, n, idx,
                      buf, y);
   MI355X_LAUNCH_CHECK();
   return 0;

@@ -182,14 +182,18 @@ PetscErrorCode HipScatterMarkReady(HipScatter ctx, Vec x) {
   return 0;
 }
 
-/* FORWARD/INSERT: x (parallel) -> y (= lvec, sequential).  REVERSE/ADD: x (= lvec) -> y (parallel), +=. */
+/* FORWARD: x (parallel) -> y (= lvec, sequential); REVERSE: x (= lvec) -> y (parallel).  INSERT_VALUES, ADD_VALUES and MAX_VALUES in
+ * either direction (UnPack_1's three forms, vpscat.c:503-534); MatMult_MPIAIJ uses FORWARD/INSERT, the transpose REVERSE/ADD. */
+static int unpack_mode(mi355x_handle_t h, InsertMode addv, size_t n, const PetscInt *idx, const PetscScalar *buf, PetscScalar *y) {
+  return addv == ADD_VALUES ? mi355x_unpack_add(h, n, idx, buf, y) : addv == MAX_VALUES ? mi355x_unpack_max(h, n, idx, buf, y) : mi355x_unpack_insert(h, n, idx, buf, y);
+}
 static PetscErrorCode scatter_begin(HipScatter ctx, Vec x, Vec y, InsertMode addv, ScatterMode mode);
 PetscErrorCode HipScatterBegin(HipScatter ctx, Vec x, Vec y, InsertMode addv, ScatterMode mode) {
   PetscErrorCode ierr;
   if (!ctx) SETERRQ(0, PETSC_ERR_ARG_NULL, "Null HipScatter");
   if (ctx->inuse) SETERRQ(ctx->comm, PETSC_ERR_ARG_WRONGSTATE, " Scatter ctx already in use");   /* vscat.c:1637 */
-  if (!((mode == SCATTER_FORWARD && addv == INSERT_VALUES) || (mode == SCATTER_REVERSE && addv == ADD_VALUES)))
-    SETERRQ(ctx->comm, PETSC_ERR_SUP, "only FORWARD/INSERT and REVERSE/ADD (the MatMult[Transpose]_MPIAIJ uses) are ported");
+  if (addv != INSERT_VALUES && addv != ADD_VALUES && addv != MAX_VALUES) SETERRQ(ctx->comm, PETSC_ERR_ARG_WRONG, "Cannot handle insert mode %d", (int)addv);   /* vpscat.c:530 */
+  if (mode != SCATTER_FORWARD && mode != SCATTER_REVERSE) SETERRQ(ctx->comm, PETSC_ERR_SUP, "SCATTER_LOCAL forms are not ported");
   ierr = scatter_begin(ctx, x, y, addv, mode);CHKERRQ(ierr);
   ctx->inuse = PETSC_TRUE;                                  /* only a Begin that succeeded leaves the scatter in use */
   return 0;
@@ -197,7 +201,6 @@ PetscErrorCode HipScatterBegin(HipScatter ctx, Vec x, Vec y, InsertMode addv, Sc
 static PetscErrorCode scatter_begin(HipScatter ctx, Vec x, Vec y, InsertMode addv, ScatterMode mode) {
   PetscErrorCode ierr;
   PetscDeviceCtx *dc;
-  (void)addv;
   if (ctx->to.n == 0 && ctx->from.n == 0 && ctx->to.local_n == 0) return 0;
   ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
   ierr = scatter_device_setup(ctx, dc);CHKERRQ(ierr);
@@ -222,7 +225,7 @@ static PetscErrorCode scatter_begin(HipScatter ctx, Vec x, Vec y, InsertMode add
       for (PetscInt i = 0; i < from->n; i++) {
         PetscInt s = from->starts[i];
         rcnt[i] = from->starts[i + 1] - s;
-        rdst[i] = from->contiq ? dy + from->indices[s] : from->d_values + s;
+        rdst[i] = (from->contiq && addv == INSERT_VALUES) ? dy + from->indices[s] : from->d_values + s;   /* in place only when the values replace */
       }
       for (PetscInt i = 0; i < to->n; i++) {
         PetscInt s = to->starts[i];
@@ -231,10 +234,10 @@ static PetscErrorCode scatter_begin(HipScatter ctx, Vec x, Vec y, InsertMode add
       }
       ierr = neighbour_exchange(ctx, dc, from->n, from->procs, rdst, rcnt, to->n, to->procs, ssrc, scnt);CHKERRQ(ierr);
     }
-    if (from->n && !from->contiq) CHKHIP(mi355x_unpack_insert(dc->hcomm, (size_t)from->starts[from->n], from->d_indices, from->d_values, dy));   /* UnPack_1 */
+    if (from->n && !(from->contiq && addv == INSERT_VALUES)) CHKHIP(unpack_mode(dc->hcomm, addv, (size_t)from->starts[from->n], from->d_indices, from->d_values, dy));   /* UnPack_1 */
     if (to->local_n) {   /* Scatter_1, vpscat.c:538; staged through the scatter's own buffer */
       CHKHIP(mi355x_pack(dc->hcomm, (size_t)to->local_n, to->d_local_slots, dx, ctx->d_local_tmp));
-      CHKHIP(mi355x_unpack_insert(dc->hcomm, (size_t)to->local_n, from->d_local_slots, ctx->d_local_tmp, dy));
+      CHKHIP(unpack_mode(dc->hcomm, addv, (size_t)to->local_n, from->d_local_slots, ctx->d_local_tmp, dy));
     }
     CHKHIP(mi355x_event_record(ctx->ev_done, dc->hcomm));
   } else {
@@ -273,7 +276,7 @@ PetscErrorCode HipScatterEnd(HipScatter ctx, Vec x, Vec y, InsertMode addv, Scat
   /* the compute stream resumes after the halo stream's work (replaces MPI_Waitany, vpscat.h:210) */
   CHKHIP(mi355x_handle_wait_event(dc->h, ctx->ev_done));
   if (mode == SCATTER_REVERSE) {
-    /* y[idx] += received, one neighbour after the other in rank order: the additions happen here,
+    /* y[idx] (+)= received, one neighbour after the other in rank order: the updates happen here,
      * after the local transpose product, as mpiaij.c:1162-1164 assumes; the order is fixed (the
      * reference's is arrival order unless -vecscatter_reproduce, vpscat.h:206-208) */
     PetscScalar *dy;
@@ -281,13 +284,13 @@ PetscErrorCode HipScatterEnd(HipScatter ctx, Vec x, Vec y, InsertMode addv, Scat
     ierr = VecHIPGetReadWrite(y, &dy);CHKERRQ(ierr);
     for (PetscInt i = 0; i < to->n; i++) {
       PetscInt s = to->starts[i], c = to->starts[i + 1] - s;
-      CHKHIP(mi355x_unpack_add(dc->h, (size_t)c, to->d_indices + s, to->d_values + s, dy));
+      CHKHIP(unpack_mode(dc->h, addv, (size_t)c, to->d_indices + s, to->d_values + s, dy));
     }
     if (to->local_n) {
       const PetscScalar *dx;
       ierr = VecHIPGetRead(x, &dx);CHKERRQ(ierr);
       CHKHIP(mi355x_pack(dc->h, (size_t)to->local_n, from->d_local_slots, dx, ctx->d_local_tmp));
-      CHKHIP(mi355x_unpack_add(dc->h, (size_t)to->local_n, to->d_local_slots, ctx->d_local_tmp, dy));
+      CHKHIP(unpack_mode(dc->h, addv, (size_t)to->local_n, to->d_local_slots, ctx->d_local_tmp, dy));
     }
   }
   ierr = VecHIPRestoreWrite(y);CHKERRQ(ierr);

@@ -110,6 +110,44 @@ def main():
                 reft[g - rs] = reft[g - rs] + lv[i_]
     ok6 = np.array_equal(vy.array().view(np.uint64), reft.view(np.uint64))
     print("rank %d/%d: irregular MatMult bitexact=%s MatMultTranspose bitexact=%s" % (rank, world, ok5, ok6), flush=True)
+    # ---- the matrix's VecScatter by itself, every InsertMode in both directions (UnPack_1's INSERT / ADD / MAX, vpscat.c:503-534):
+    # forward: ghost slot i receives x[garray[i]] from its owner; reverse: owned entry g receives, neighbour after neighbour in rank
+    # order, what every rank holds in its ghost slot for g.  Bit for bit (max and a single addition per step are exact operations
+    # in a fixed order).
+    import ctypes as C
+    sc, lvh, ecn = C.c_void_p(), C.c_void_p(), C.c_int()
+    L.MatMPIAIJGetScatter(B.h, C.byref(sc), C.byref(lvh), C.byref(ecn))
+    lvec = P.Vec(lvh, own=False)
+    ghost = lambda q: np.cos(0.1 * pcs[q]["garray"] + q) * (1.0 + q)       # what rank q holds in its ghost slots (reverse direction)
+    l0 = np.sin(0.2 * np.arange(me["garray"].size)) * 0.9                   # ghost slots before a forward scatter
+    y0 = np.sin(0.05 * np.arange(rs, re_)) * 0.8                            # owned entries before a reverse scatter
+    ok8 = ecn.value == me["garray"].size
+    INSERT, ADD, MAX = 1, 2, 3
+    for mode in (INSERT, ADD, MAX):
+        if me["garray"].size:
+            lvec.set_array(l0)
+        vx.set_array(xi[rs:re_])
+        L.VecScatterBegin(sc, vx.h, lvec.h, mode, 0)
+        L.VecScatterEnd(sc, vx.h, lvec.h, mode, 0)
+        got = lvec.array()
+        inc = xi[me["garray"]]
+        want = inc if mode == INSERT else (l0 + inc if mode == ADD else np.where(l0 < inc, inc, l0))
+        ok8 = ok8 and np.array_equal(got.view(np.uint64), np.ascontiguousarray(want).view(np.uint64))
+        if me["garray"].size:
+            lvec.set_array(ghost(rank))
+        vy.set_array(y0)
+        L.VecScatterBegin(sc, lvec.h, vy.h, mode, 1)
+        L.VecScatterEnd(sc, lvec.h, vy.h, mode, 1)
+        want = y0.copy()
+        for q in range(world):
+            if q == rank:
+                continue
+            gq, vq = pcs[q]["garray"], ghost(q)
+            for i_ in np.nonzero((gq >= rs) & (gq < re_))[0]:
+                g = int(gq[i_]) - rs
+                want[g] = vq[i_] if mode == INSERT else (want[g] + vq[i_] if mode == ADD else (vq[i_] if want[g] < vq[i_] else want[g]))
+        ok8 = ok8 and np.array_equal(vy.array().view(np.uint64), want.view(np.uint64))
+    print("rank %d/%d: VecScatter INSERT / ADD / MAX, forward and reverse, bitexact=%s" % (rank, world, ok8), flush=True)
     # MatDiagonalScale_MPIAIJ (mpiaij.c:2183): left vector by rows, right vector's ghost values through the MatMult
     # scatter; the device copies of both blocks are updated in place.  Then MatScale.  Against the scaled oracle pieces.
     lg = 1.0 + 0.5 * np.cos(np.arange(NI)); rg = 2.0 + np.sin(0.7 * np.arange(NI))
