@@ -2106,6 +2106,38 @@ def test_config4_full_size_ilu0_application_carries_the_reference_bits(P):
         del k
 
 
+@pytest.mark.parametrize("pct", ["ilu", "icc"])
+def test_p7_full_size_factor_plans_built_on_the_device(P, pct, monkeypatch):
+    """ILU(0) / ICC(0) on P7(256) (BASELINE configs[1]'s operator, 16.7 M rows; wide dependency levels: the one-wavefront-per-slice
+    kernels): the sync-free plans laid out on the device (csrc/trisolve_build.hip, the default) and by the host threads
+    (MI355X_TRISOLVE_BUILD=host) give the same application bit for bit, and that is the oracle's MatSolve restatement's."""
+    L = P.lib()
+    m = 256
+    ai, aj, aa = P.gen_poisson7(m, m, m)
+    n = ai.size - 1
+    bvec = np.cos(0.1 * np.arange(n)) + 0.01 * np.sin(np.arange(n))
+    A = P.Mat.from_csr(ai, aj, aa)
+    vb, vx = V(P, bvec), V(P, np.zeros(n))
+    got = {}
+    for route in ("device", "host"):
+        monkeypatch.setenv("MI355X_TRISOLVE_BUILD", route)
+        pc = C.c_void_p()
+        k = P.KSP(comm=L.COMM_SELF); k.set_operators(A); L.KSPGetPC(k.h, C.byref(pc)); L.PCSetType(pc, pct.encode())
+        L.raw("PCSetUp")(pc)
+        L.raw("PCApply")(pc, vb.h, vx.h)
+        got[route] = vx.array().copy()
+        L.raw("PCApply")(pc, vb.h, vx.h)
+        assert np.array_equal(bits(vx.array()), bits(got[route]))      # deterministic, and the plans re-arm themselves
+        if pct == "ilu":
+            sf, ab = C.c_int(), C.c_int()
+            L.PCILUGetSolver_HIPMI355X(pc, C.byref(sf), C.byref(ab))
+            assert sf.value == 1 and ab.value == 0
+        del k
+    assert np.array_equal(bits(got["device"]), bits(got["host"]))
+    ref = orc.ilu0_solve(orc.ilu0_factor(ai, aj, aa), bvec) if pct == "ilu" else orc.icc0_solve(orc.icc0_factor(ai, aj, aa)[0], bvec)
+    assert np.array_equal(bits(got["device"]), bits(ref))
+
+
 @pytest.mark.parametrize("sub", ["jacobi", "ilu"])
 def test_config4_full_size_gmres_bjacobi_solve(P, sub):
     """BASELINE configs[3] END TO END at full size on the FEM-like stand-in for Flan_1565 (1.53 M rows, 1.18e8 nonzeros, 3 dof per
