@@ -30,6 +30,24 @@ static double icc_wall_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTON
 #define ICC_TICK(what) do { if (getenv("PETSC_HIPMI355X_SETUP_TIMING")) { const double t__ = icc_wall_s(); fprintf(stderr, "[hipmi355x]   %-34s %.3f s\n", what, t__ - tick0); tick0 = t__; } } while (0)
 
 #if !defined(PETSCHIPMI355X_WITH_PETSC)
+typedef struct { const PetscInt *ai, *aj; PetscInt *ui, *uj; volatile PetscInt missing; } IccSym;
+static void icc0_sym_count(void *c_, PetscInt lo, PetscInt hi) {   /* ui[k + 1] = strictly upper entries of row k + the diagonal slot; -1: no diagonal entry */
+  IccSym *c = (IccSym *)c_;
+  for (PetscInt k = lo; k < hi; k++) {
+    PetscInt cnt = 1; PetscBool hasd = PETSC_FALSE;
+    for (PetscInt q = c->ai[k]; q < c->ai[k + 1]; q++) { if (c->aj[q] > k) cnt++; else if (c->aj[q] == k) hasd = PETSC_TRUE; }
+    c->ui[k + 1] = hasd ? cnt : -1;
+    if (!hasd) c->missing = k;
+  }
+}
+static void icc0_sym_fill(void *c_, PetscInt lo, PetscInt hi) {    /* row k = its strictly upper entries in column order, then the diagonal slot */
+  IccSym *c = (IccSym *)c_;
+  for (PetscInt k = lo; k < hi; k++) {
+    PetscInt w = c->ui[k];
+    for (PetscInt q = c->ai[k]; q < c->ai[k + 1]; q++) if (c->aj[q] > k) c->uj[w++] = c->aj[q];
+    c->uj[w] = k;
+  }
+}
 /* MatICCFactorSymbolic_SeqAIJ (levels 0, natural ordering) + MatCholeskyFactorNumeric_SeqAIJ restated for the harness; inside a
  * PETSc tree the parent's routines run instead and leave the same arrays in F's Mat_SeqSBAIJ */
 static PetscErrorCode icc0_factor_host(Mat F, Mat A, const MatFactorInfo *info) {
@@ -44,20 +62,22 @@ static PetscErrorCode icc0_factor_host(Mat F, Mat A, const MatFactorInfo *info) 
   /* ---- symbolic: row k = its strictly upper entries in column order, then the diagonal slot ---- */
   PetscInt *ui, *uj, nz = 0; PetscScalar *ua;
   ierr = PetscMalloc(sizeof(PetscInt) * (size_t)(n + 1), &ui);CHKERRQ(ierr);
-  for (PetscInt k = 0; k < n; k++) {
-    PetscBool hasd = PETSC_FALSE;
-    for (PetscInt q = ai[k]; q < ai[k + 1]; q++) { if (aj[q] > k) nz++; else if (aj[q] == k) hasd = PETSC_TRUE; }
-    if (!hasd) { HipFree(ui); SETERRQ(HipObjComm(A), PETSC_ERR_ARG_WRONGSTATE, "Matrix is missing diagonal entry %d", k); }
-    nz++;
-  }
-  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)nz, &uj);CHKERRQ(ierr);
-  ierr = PetscMalloc(sizeof(PetscScalar) * (size_t)nz, &ua);CHKERRQ(ierr);
-  f->nz = nz; nz = 0; ui[0] = 0;
-  for (PetscInt k = 0; k < n; k++) {
-    for (PetscInt q = ai[k]; q < ai[k + 1]; q++) if (aj[q] > k) uj[nz++] = aj[q];
-    uj[nz++] = k;
-    ui[k + 1] = nz;
-  }
+  { IccSym sy = {ai, aj, ui, NULL, -1};                    /* per-row counts and copies on host threads, the running sum in between */
+    HipParallelRanges(n, icc0_sym_count, &sy);
+    if (sy.missing >= 0) {
+      PetscInt first = 0;
+      while (first < n && ui[first + 1] >= 0) first++;
+      HipFree(ui);
+      SETERRQ(HipObjComm(A), PETSC_ERR_ARG_WRONGSTATE, "Matrix is missing diagonal entry %d", first);
+    }
+    ui[0] = 0;
+    for (PetscInt k = 0; k < n; k++) ui[k + 1] += ui[k];
+    nz = ui[n];
+    ierr = PetscMalloc(sizeof(PetscInt) * (size_t)nz, &uj);CHKERRQ(ierr);
+    ierr = PetscMalloc(sizeof(PetscScalar) * (size_t)nz, &ua);CHKERRQ(ierr);
+    f->nz = nz;
+    sy.uj = uj;
+    HipParallelRanges(n, icc0_sym_fill, &sy); }
 
   ICC_TICK("icc: pattern of U");
   /* ---- numeric, left-looking over the rows; the shift of MatPivotCheck_pd (matimpl.h:532-553) restarts it.  One pass per
@@ -140,6 +160,45 @@ static PetscErrorCode icc0_factor_host(Mat F, Mat A, const MatFactorInfo *info) 
 }
 #endif
 
+#include <pthread.h>
+typedef struct { PetscInt n; const PetscInt *ui, *uj; const PetscScalar *ua; PetscInt *lp, *ll, *lj; PetscScalar *lv; PetscInt *up, *ul, *uc; PetscScalar *uv, *ones, *dinv; PetscInt *levU, nlevU; } IccT;
+static void icc0_count_columns(void *c_, PetscInt lo, PetscInt hi) {          /* lp[c + 1] = entries in column c, for the columns [lo, hi) */
+  IccT *t = (IccT *)c_;
+  for (PetscInt i = 0; i < hi && i < t->n; i++) {
+    const PetscInt q0 = t->ui[i], q1 = t->ui[i + 1] - 1;                      /* strictly upper entries: columns > i (in any order) */
+    for (PetscInt q = q0; q < q1; q++) { const PetscInt c = t->uj[q]; if (c >= lo && c < hi) t->lp[c + 1]++; }
+  }
+}
+static void icc0_fill_columns(void *c_, PetscInt lo, PetscInt hi) {
+  IccT *t = (IccT *)c_;
+  for (PetscInt i = 0; i < hi && i < t->n; i++) {
+    const PetscInt q0 = t->ui[i], q1 = t->ui[i + 1] - 1;
+    for (PetscInt q = q0; q < q1; q++) {
+      const PetscInt c = t->uj[q];
+      if (c >= lo && c < hi) { const PetscInt at = t->lp[c] + t->ll[c]++; t->lj[at] = i; t->lv[at] = -t->ua[q]; }
+    }
+  }
+}
+static void icc0_upper_rows(void *c_, PetscInt lo, PetscInt hi) {
+  IccT *t = (IccT *)c_;
+  for (PetscInt i = lo; i < hi; i++) {
+    PetscInt w = t->ui[i] - i;                                                /* every earlier row left its diagonal slot behind */
+    t->up[i] = w; t->ul[i] = t->ui[i + 1] - 1 - t->ui[i];
+    for (PetscInt q = t->ui[i + 1] - 2; q >= t->ui[i]; q--) { t->uc[w] = t->uj[q]; t->uv[w] = -t->ua[q]; w++; }
+    t->ones[i] = 1.0; t->dinv[i] = t->ua[t->ui[i + 1] - 1];
+  }
+}
+static void *icc0_levels_U(void *c_) {
+  IccT *t = (IccT *)c_; PetscInt nlev = 0;
+  for (PetscInt i = t->n - 1; i >= 0; i--) {
+    PetscInt l = 0;
+    for (PetscInt q = t->ui[i]; q < t->ui[i + 1] - 1; q++) l = PetscMax(l, t->levU[t->uj[q]] + 1);
+    t->levU[i] = l; nlev = PetscMax(nlev, l + 1);
+  }
+  t->nlevU = nlev;
+  return NULL;
+}
+
 /* the two triangular systems in row form, negated values, from the factor U (rows: strictly upper entries, then the inverted
  * diagonal) in the reference's layout; dependency levels; the sync-free plans */
 static PetscErrorCode icc0_plans(Mat F, PetscInt n, const PetscInt *ui, const PetscInt *uj, const PetscScalar *ua) {
@@ -161,29 +220,25 @@ static PetscErrorCode icc0_plans(Mat F, PetscInt n, const PetscInt *ui, const Pe
   ierr = PetscMalloc(sizeof(PetscInt) * (size_t)n, &levU);CHKERRQ(ierr);
   ierr = PetscMalloc(sizeof(PetscScalar) * (size_t)n, &ones);CHKERRQ(ierr);
   ierr = PetscMalloc(sizeof(PetscScalar) * (size_t)n, &dinv);CHKERRQ(ierr);
+  /* U^T by COLUMN RANGES on host threads: a thread owns the columns [lo, hi), walks the rows in ascending order (so that row c of
+   * U^T lists its entries in the order the column sweep adds them) and takes the entries whose column is its own.  The levels of U (a backward recurrence over U's own rows) are
+   * computed beside it, those of U^T (forward, over the transposed rows) after it. */
+  IccT tr = {n, ui, uj, ua, lp, ll, lj, lv, up, ul, uc, uv, ones, dinv, levU, 0};
+  pthread_t thU; int sideU = 0;
+  if (n >= 200000) sideU = !pthread_create(&thU, NULL, icc0_levels_U, &tr);
   memset(lp, 0, sizeof(PetscInt) * (size_t)(n + 1));
-  for (PetscInt i = 0; i < n; i++) for (PetscInt q = ui[i]; q < ui[i + 1] - 1; q++) lp[uj[q] + 1]++;
+  HipParallelRanges(n, icc0_count_columns, &tr);
   for (PetscInt c = 0; c < n; c++) { ll[c] = 0; lp[c + 1] += lp[c]; }
-  for (PetscInt i = 0; i < n; i++)                      /* rows in ascending order: row c of U^T lists its entries in the order the column sweep adds them */
-    for (PetscInt q = ui[i]; q < ui[i + 1] - 1; q++) { const PetscInt c = uj[q], at = lp[c] + ll[c]++; lj[at] = i; lv[at] = -ua[q]; }
+  HipParallelRanges(n, icc0_fill_columns, &tr);
   f->nlevL = 0;
   for (PetscInt c = 0; c < n; c++) {
     PetscInt l = 0;
     for (PetscInt q = lp[c]; q < lp[c] + ll[c]; q++) l = PetscMax(l, levL[lj[q]] + 1);
     levL[c] = l; f->nlevL = PetscMax(f->nlevL, l + 1);
   }
-  f->nlevU = 0;
-  { PetscInt w = 0;
-    for (PetscInt i = 0; i < n; i++) {                  /* the backward loop reads a row from its last off-diagonal entry to its first */
-      up[i] = w; ul[i] = ui[i + 1] - 1 - ui[i];
-      for (PetscInt q = ui[i + 1] - 2; q >= ui[i]; q--) { uc[w] = uj[q]; uv[w] = -ua[q]; w++; }
-      ones[i] = 1.0; dinv[i] = ua[ui[i + 1] - 1];
-    } }
-  for (PetscInt i = n - 1; i >= 0; i--) {
-    PetscInt l = 0;
-    for (PetscInt q = ui[i]; q < ui[i + 1] - 1; q++) l = PetscMax(l, levU[uj[q]] + 1);
-    levU[i] = l; f->nlevU = PetscMax(f->nlevU, l + 1);
-  }
+  HipParallelRanges(n, icc0_upper_rows, &tr);             /* the backward loop reads a row from its last off-diagonal entry to its first */
+  if (sideU) pthread_join(thU, NULL); else icc0_levels_U(&tr);
+  f->nlevU = tr.nlevU;
   ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
   int rc = mi355x_trisolve_plan_create_pair(dc->h, n, 0, f->nlevL, levL, lp, ll, lj, lv, f->nlevU, levU, up, ul, uc, uv, ones, dinv, &f->tri_lo, &f->tri_up);
   HipFree(lp); HipFree(ll); HipFree(lj); HipFree(lv); HipFree(up); HipFree(ul); HipFree(uc); HipFree(uv);
