@@ -416,8 +416,19 @@ __global__ __launch_bounds__(MI355X_BLOCK) void trisolve_node_kernel(
 // slice) are solved by the solver with tri_node_solve itself.
 // LDS: [64 B counters][2 headers][R batch stages]; counters: 0 headers produced, 1 headers consumed, 2 batches produced,
 // 3 batches consumed (monotonic; each has one writer).  LDS operations of a wavefront execute in order: data, s_waitcnt, counter.
+// A solved value becomes visible to the polling wavefronts.  All XCDs: an agent-scope store (written through to the memory side,
+// 0.54 us to a poller on another XCD).  One XCD (every participating workgroup runs on the same XCD, see the kernel): the XCD's L2 is
+// the point of coherence for all of them, a workgroup-scope store reaches it and an agent-scope load reads it there: 0.27 us
+// (tests/tools/probe/handoff_probe.hip, profiles/r03_tri_variants.log).
+__device__ __forceinline__ void tri_publish(double *p, const double v, const int one_xcd) {
+  if (one_xcd) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 template <int NB> struct TriSplitGeom {
-  static constexpr int B = NB <= 3 ? 8 : 4;                     // columns per batch (as tri_node_solve without block columns)
+#ifndef TRI_SPLIT_B
+#define TRI_SPLIT_B 8
+#endif
+  static constexpr int B = NB <= 3 ? TRI_SPLIT_B : 4;           // columns per batch (as tri_node_solve without block columns)
   static constexpr int NT = NB * (NB - 1) / 2, ND = NT + NB;
   static constexpr int HB = 64 + 3 * 256 + (NB + ND) * 512;     // header bytes: meta, info / first row / rows per lane, right-hand sides, triangle
   static constexpr int SB = B * 256 + B * NB * 512;             // stage bytes: B index rows, B * NB value rows
@@ -447,11 +458,10 @@ __device__ __forceinline__ void tri_split_loader(unsigned char *lds, const int l
                                                  const unsigned char *__restrict__ nszof, const int *__restrict__ col, const double *__restrict__ val,
                                                  const double *__restrict__ din, const unsigned char *__restrict__ nsub, const double *src,
                                                  const int *__restrict__ spos, double *reset, const int reset_n, unsigned int *queue, int *abort_flag,
-                                                 const double *__restrict__ rscale) {
+                                                 const double *__restrict__ rscale, const int q) {
   using G = TriSplitGeom<NB>;
   constexpr int B = G::B, NT = G::NT;
   volatile int *ctl = (volatile int *)lds;
-  const int q = blockIdx.x % TRI_QUEUES;
   int hp = 0, bp = 0;
   for (;;) {
     unsigned int k = 0;
@@ -545,7 +555,7 @@ __device__ __forceinline__ void tri_split_solver(unsigned char *lds, const int l
                                                  const int *__restrict__ info, const int *__restrict__ rowof, const unsigned char *__restrict__ nszof,
                                                  const int *__restrict__ col, const double *__restrict__ val, const double *__restrict__ din,
                                                  const double *src, const int *__restrict__ spos, double *w, double *y, double *reset,
-                                                 int *abort_flag, const int sleep_cap, const double *__restrict__ rscale) {
+                                                 int *abort_flag, const int sleep_cap, const double *__restrict__ rscale, const int one_xcd) {
   using G = TriSplitGeom<NB>;
   constexpr int B = G::B, NT = G::NT;
   volatile int *ctl = (volatile int *)lds;
@@ -681,7 +691,7 @@ __device__ __forceinline__ void tri_split_solver(unsigned char *lds, const int l
       }
 #pragma unroll
       for (int k = 0; k < NB; ++k)
-        if (k < nsz) __hip_atomic_store(w + (size_t)k * np + t, sum[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (k < nsz) tri_publish(w + (size_t)k * np + t, sum[k], one_xcd);
     } else {
       double xr[NB];
 #pragma unroll
@@ -692,7 +702,7 @@ __device__ __forceinline__ void tri_split_solver(unsigned char *lds, const int l
           for (int l = 0; l < k; ++l) sum[k] -= dn[k * (k - 1) / 2 + (k - 1 - l)] * xr[l];
           xr[k] = sum[k] * dn[NT + k];
           const int kk = nsz - 1 - k;
-          __hip_atomic_store(w + (size_t)kk * np + t, xr[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          tri_publish(w + (size_t)kk * np + t, xr[k], one_xcd);
           y[row0 + kk] = xr[k];
         }
       }
@@ -706,18 +716,40 @@ __global__ __launch_bounds__(2 * MI355X_WAVE) void trisolve_node_split_kernel(
     int nslices, int np, int R, const int *__restrict__ ptr, const int *__restrict__ info, const int *__restrict__ rowof,
     const unsigned char *__restrict__ nszof, const int *__restrict__ col, const double *__restrict__ val, const double *__restrict__ din,
     const unsigned char *__restrict__ nsub, const double *src, const int *__restrict__ spos, double *w, double *y,
-    double *reset, int reset_n, unsigned int *queue, unsigned int *other_queue, int *abort_flag, int sleep_cap, const double *__restrict__ rscale) {
+    double *reset, int reset_n, unsigned int *queue, unsigned int *other_queue, int *abort_flag, int sleep_cap, const double *__restrict__ rscale,
+    int one_xcd) {
   extern __shared__ __align__(16) unsigned char tri_split_lds[];
   const int tid = threadIdx.x, lane = tid & (MI355X_WAVE - 1), wave = tid / MI355X_WAVE;
   if (tid < 16) ((int *)tri_split_lds)[tid] = 0;
   if (blockIdx.x == 0 && tid < TRI_QUEUES) other_queue[tid * TRI_QSTRIDE] = 0u;
+  if (blockIdx.x == 0 && tid == 0) { other_queue[TRI_XCD_WORD] = 0xffffffffu; other_queue[TRI_XCD_WORD + 1] = 0u; }
   if (!UPPER) {   // the upper solve's slots beyond this plan's own positions are re-armed here
     for (long i = (long)NB * np + (long)blockIdx.x * blockDim.x + tid; i < reset_n; i += (long)gridDim.x * blockDim.x)
       reset[i] = __longlong_as_double((long long)TRI_SENTINEL);
   }
   __syncthreads();
-  if (wave == 1) tri_split_loader<NB, UPPER>(tri_split_lds, lane, nslices, np, R, ptr, info, rowof, nszof, col, val, din, nsub, src, spos, reset, reset_n, queue, abort_flag, rscale);
-  else tri_split_solver<NB, UPPER>(tri_split_lds, lane, np, R, ptr, info, rowof, nszof, col, val, din, src, spos, w, y, reset, abort_flag, sleep_cap, rscale);
+  int q = blockIdx.x % TRI_QUEUES;
+  if (one_xcd) {
+    // ONE XCD: the dependency chain of a factor with narrow levels is a chain of hand-offs, and a hand-off inside one XCD (through
+    // its L2) takes half the time of one across XCDs (through the memory side).  The launch holds 8 x the workgroups the plan asks
+    // for; the XCD of the first workgroup to arrive is the one that solves, workgroups of the other XCDs leave at once; the ones that
+    // stay take tickets, which deal them to the queues.  (Bandwidth: these solves move ~1 GB in ~6 ms, a fraction of one XCD's share.)
+    int *me = (int *)tri_split_lds + 8;
+    if (tid == 0) {
+      unsigned int xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      xcc &= 15u;
+      const unsigned int lead = atomicCAS(queue + TRI_XCD_WORD, 0xffffffffu, xcc);
+      const int in = lead == 0xffffffffu || lead == xcc;
+      me[0] = in;
+      me[1] = in ? (int)(atomicAdd(queue + TRI_XCD_WORD + 1, 1u) % TRI_QUEUES) : 0;
+    }
+    __syncthreads();
+    if (!me[0]) return;
+    q = me[1];
+  }
+  if (wave == 1) tri_split_loader<NB, UPPER>(tri_split_lds, lane, nslices, np, R, ptr, info, rowof, nszof, col, val, din, nsub, src, spos, reset, reset_n, queue, abort_flag, rscale, q);
+  else tri_split_solver<NB, UPPER>(tri_split_lds, lane, np, R, ptr, info, rowof, nszof, col, val, din, src, spos, w, y, reset, abort_flag, sleep_cap, rscale, one_xcd);
 }
 
 template <int NB, bool UPPER, bool BLK>
@@ -795,8 +827,9 @@ int trisolve_plan_finish(mi355x_handle_t h, mi355x_trisolve_plan_s *p, int nlev,
   MI355X_TRY(hipMalloc((void **)&p->d_w, sizeof(double) * npa));
   hipLaunchKernelGGL(tri_arm_kernel, dim3(mi355x_grid_for(npa, 4)), dim3(MI355X_BLOCK), 0, h->stream, npa, p->d_w);
   MI355X_LAUNCH_CHECK();
-  MI355X_TRY(hipMalloc((void **)&p->d_queue, sizeof(unsigned int) * TRI_QUEUES * TRI_QSTRIDE));
-  MI355X_TRY(hipMemsetAsync(p->d_queue, 0, sizeof(unsigned int) * TRI_QUEUES * TRI_QSTRIDE, h->stream));
+  MI355X_TRY(hipMalloc((void **)&p->d_queue, sizeof(unsigned int) * (TRI_QUEUES * TRI_QSTRIDE + 32)));
+  MI355X_TRY(hipMemsetAsync(p->d_queue, 0, sizeof(unsigned int) * (TRI_QUEUES * TRI_QSTRIDE + 32), h->stream));
+  MI355X_TRY(hipMemsetAsync(p->d_queue + TRI_XCD_WORD, 0xFF, sizeof(unsigned int), h->stream));
   MI355X_TRY(hipHostMalloc((void **)&p->abort_flag, 64, hipHostMallocMapped | hipHostMallocCoherent));
   *p->abort_flag = 0;
   // fully resident grid: the occupancy the runtime reports, at most 4 workgroups per CU (MI355X_MICROARCH.md:
@@ -1116,6 +1149,7 @@ static int trisolve_plan_fill_nodes(mi355x_handle_t h, mi355x_trisolve_plan_s *p
   p->nslices = (int)((cur + W - 1) / W);
   { const char *e = getenv("MI355X_TRISOLVE_NODE_WAVES"); p->spw = e ? atoi(e) : 4; if (p->spw != 1 && p->spw != 2 && p->spw != 4) p->spw = 4; }
   { const char *e = getenv("MI355X_TRISOLVE_SPLIT"); p->split = blk ? 0 : (e ? atoi(e) != 0 : 1); if (p->split) p->spw = 1; }
+  { const char *e = getenv("MI355X_TRISOLVE_ONE_XCD"); p->one_xcd = p->split && (e ? atoi(e) != 0 : TRI_ONE_XCD_DEFAULT); }
   p->nchunks = (p->nslices + p->spw - 1) / p->spw;
   const size_t np = (size_t)p->nslices * W;
   p->np = (int)np;
@@ -1221,8 +1255,9 @@ static int trisolve_plan_fill_nodes(mi355x_handle_t h, mi355x_trisolve_plan_s *p
   { std::vector<unsigned long long> sent(nw, TRI_SENTINEL);
     TRI_TRY(hipMemcpyAsync(p->d_w, sent.data(), sizeof(double) * sent.size(), hipMemcpyHostToDevice, h->stream));
     TRI_TRY(hipStreamSynchronize(h->stream)); }
-  TRI_TRY(hipMalloc((void **)&p->d_queue, sizeof(unsigned int) * TRI_QUEUES * TRI_QSTRIDE));
-  TRI_TRY(hipMemsetAsync(p->d_queue, 0, sizeof(unsigned int) * TRI_QUEUES * TRI_QSTRIDE, h->stream));
+  TRI_TRY(hipMalloc((void **)&p->d_queue, sizeof(unsigned int) * (TRI_QUEUES * TRI_QSTRIDE + 32)));
+  TRI_TRY(hipMemsetAsync(p->d_queue, 0, sizeof(unsigned int) * (TRI_QUEUES * TRI_QSTRIDE + 32), h->stream));
+  TRI_TRY(hipMemsetAsync(p->d_queue + TRI_XCD_WORD, 0xFF, sizeof(unsigned int), h->stream));
   TRI_TRY(hipHostMalloc((void **)&p->abort_flag, 64, hipHostMallocMapped | hipHostMallocCoherent));
   *p->abort_flag = 0;
   int dev = 0;
@@ -1326,13 +1361,15 @@ static int tri_node_go(mi355x_handle_t h, mi355x_trisolve_plan_t lo, mi355x_tris
       MI355X_TRY(hipFuncSetAttribute((const void *)trisolve_node_split_kernel<NB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
       attr_set = true;
     }
-    hipLaunchKernelGGL((trisolve_node_split_kernel<NB, false>), dim3(glo), dim3(2 * MI355X_WAVE), blo, h->stream, lo->nslices, lo->np, rlo, lo->d_ptr, lo->d_info,
+    // one-XCD form (see the kernel): 8 x the workgroups, those of seven XCDs leave at once
+    const int xlo = lo->one_xcd && glo >= 2 * TRI_QUEUES, xup = up->one_xcd && gup >= 2 * TRI_QUEUES;
+    hipLaunchKernelGGL((trisolve_node_split_kernel<NB, false>), dim3(xlo ? glo * MI355X_NXCD : glo), dim3(2 * MI355X_WAVE), blo, h->stream, lo->nslices, lo->np, rlo, lo->d_ptr, lo->d_info,
                        lo->d_row, lo->d_nsz, lo->d_col, lo->d_val, lo->d_din, lo->d_nsub, b, (const int *)nullptr, lo->d_w, (double *)nullptr, up->d_w,
-                       up->np * NB, lo->d_queue, up->d_queue, lo->abort_flag, lo->sleep_cap, (const double *)nullptr);
+                       up->np * NB, lo->d_queue, up->d_queue, lo->abort_flag, lo->sleep_cap, (const double *)nullptr, xlo);
     MI355X_LAUNCH_CHECK();
-    hipLaunchKernelGGL((trisolve_node_split_kernel<NB, true>), dim3(gup), dim3(2 * MI355X_WAVE), bup, h->stream, up->nslices, up->np, rup, up->d_ptr, up->d_info,
+    hipLaunchKernelGGL((trisolve_node_split_kernel<NB, true>), dim3(xup ? gup * MI355X_NXCD : gup), dim3(2 * MI355X_WAVE), bup, h->stream, up->nslices, up->np, rup, up->d_ptr, up->d_info,
                        up->d_row, up->d_nsz, up->d_col, up->d_val, up->d_din, up->d_nsub, lo->d_w, lo->d_pos, up->d_w, y, lo->d_w, 0, up->d_queue,
-                       lo->d_queue, up->abort_flag, up->sleep_cap, (const double *)up->d_rscale);
+                       lo->d_queue, up->abort_flag, up->sleep_cap, (const double *)up->d_rscale, xup);
     MI355X_LAUNCH_CHECK();
     return 0;
   }

@@ -8,6 +8,10 @@
 #define TRI_QSTRIDE 16          // queue counters 64 bytes apart
 #define TRI_ALIGN_MIN 32        // by_level plans: levels of at least this many rows start on a slice boundary
 #define TRI_SPIN_LIMIT (1 << 19)   // x ~1 us per poll once backed off: gives up after ~0.5 s
+#define TRI_XCD_WORD (TRI_QUEUES * TRI_QSTRIDE)   // behind the queue counters: [0] the XCD that solves (0xffffffff: not chosen yet), [1] tickets
+#ifndef TRI_ONE_XCD_DEFAULT
+#define TRI_ONE_XCD_DEFAULT 0
+#endif
 
 struct mi355x_trisolve_plan_s {
   int n, nslices, nchunks, upper;
@@ -33,6 +37,7 @@ struct mi355x_trisolve_plan_s {
   int nb, np;
   int spw;                 // node plans: slices (waves) per workgroup
   int split, ring, maxcol; // split-role kernel (loader + solver wavefront per workgroup): on, batches in the LDS ring, widest slice
+  int one_xcd;             // split-role kernels: all participating workgroups on one XCD (hand-offs through its L2)
   int blkcols;             // the shared lists hold whole dependency nodes: one list entry per node, solution stored node by node
   unsigned char *d_nsz;    // per position: rows in the node
   double *d_din;           // [nb (nb - 1) / 2 + nb][np]

@@ -3,4 +3,4 @@
 cd "$(dirname "$0")/.." || exit 1
 name=$1; shift
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -I../../include "$@" -c trisolve.hip -o variants/trisolve_$name.o 2>/dev/null || exit 1
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o variants/libmi355x_kernels_$name.so runtime.o vec_kernels.o spmv_csr.o scatter_bsr.o variants/trisolve_$name.o comm_rccl.o -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o variants/libmi355x_kernels_$name.so runtime.o vec_kernels.o spmv_csr.o scatter_bsr.o variants/trisolve_$name.o trisolve_build.o comm_rccl.o -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
