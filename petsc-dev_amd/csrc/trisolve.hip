@@ -117,6 +117,9 @@ extern "C" int mi355x_trisolve_debug_trace(long long *dev_buf) { return (int)hip
 #define TRI_STAMP(k) do { } while (0)
 #endif
 
+#ifndef TRI_POLL_TOGETHER
+#define TRI_POLL_TOGETHER 1
+#endif
 template <bool UPPER>
 __global__ __launch_bounds__(MI355X_BLOCK) void trisolve_syncfree_kernel(
     int nslices, int nchunks, const int *__restrict__ ptr, const int *__restrict__ info, const int *__restrict__ rowof,
@@ -177,6 +180,34 @@ __global__ __launch_bounds__(MI355X_BLOCK) void trisolve_syncfree_kernel(
             if (q0 + j < mylen) v[j] = __hip_atomic_load(w + c[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
           if (q0 + 8 >= mylen) TRI_STAMP(1);
+#if TRI_POLL_TOGETHER
+          // values that were not there yet: ALL of the batch's pending values are requested again together, round after round -- one
+          // memory round trip per round however many are pending (a row's dependencies of the previous level complete at about the
+          // same time: polled one after the other, each of them cost a round trip of its own ON the dependency chain: P7(256),
+          // 3 entries per row, 2.8 ms per application that way); backed off and bounded as tri_poll is
+          { bool pend = false;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pend = pend || (q0 + j < mylen && __double_as_longlong(v[j]) == (long long)TRI_SENTINEL);
+            for (int spins = 0; pend;) {
+              { const int kz = spins < sleep_cap ? spins + 1 : sleep_cap;
+                for (int z = 0; z < kz; ++z) __builtin_amdgcn_s_sleep(2); }
+              if ((++spins & 255) == 0) {
+                if (spins > TRI_SPIN_LIMIT || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) {
+                  __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                  break;
+                }
+              }
+#pragma unroll
+              for (int j = 0; j < 8; ++j)
+                if (q0 + j < mylen && __double_as_longlong(v[j]) == (long long)TRI_SENTINEL) v[j] = __hip_atomic_load(w + c[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              pend = false;
+#pragma unroll
+              for (int j = 0; j < 8; ++j) pend = pend || (q0 + j < mylen && __double_as_longlong(v[j]) == (long long)TRI_SENTINEL);
+            } }
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (q0 + j < mylen) sum -= a[j] * v[j];
+#else
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             if (q0 + j < mylen) {
@@ -185,6 +216,7 @@ __global__ __launch_bounds__(MI355X_BLOCK) void trisolve_syncfree_kernel(
               sum -= a[j] * xv;
             }
           }
+#endif
         }
         TRI_STAMP(2);
         const double r = UPPER ? sum * di : sum;
@@ -853,9 +885,10 @@ int trisolve_plan_finish(mi355x_handle_t h, mi355x_trisolve_plan_s *p, int nlev,
     if (g < p->grid) p->grid = (int)g; }
   if (p->grid > p->nchunks) p->grid = p->nchunks > 0 ? p->nchunks : 1;
   if (p->grid >= TRI_QUEUES) p->grid -= p->grid % TRI_QUEUES;    // every queue gets the same number of pullers
-  // poll back-off cap (x 128 clocks): the more wavefronts wait, the gentler they must poll (P7(256), 344 workgroups:
-  // cap 2 -> 8.1 ms, cap 8 -> 2.9 ms; P7(128), 88 workgroups: cap 2 -> 1.04 ms, cap 8 -> 1.14 ms per application)
-  { const char *e = getenv("MI355X_TRISOLVE_SLEEP"); p->sleep_cap = e ? atoi(e) : (p->grid <= 128 ? 2 : 8); if (p->sleep_cap < 1) p->sleep_cap = 1; }
+  // poll back-off cap (x 128 clocks).  With a row's pending values polled together (one round trip per round) P7(256), 344
+  // workgroups: cap 1 2.66 ms, 2 2.67, 4 2.76, 8 2.83 per application (polled one after the other: 8.1 ms at cap 2, 2.9 at cap 8:
+  // the polls flooded the L2); P7(128), 88 workgroups: cap 2 1.04 ms, cap 8 1.14
+  { const char *e = getenv("MI355X_TRISOLVE_SLEEP"); p->sleep_cap = e ? atoi(e) : 2; if (p->sleep_cap < 1) p->sleep_cap = 1; }
   return 0;
 }
 
