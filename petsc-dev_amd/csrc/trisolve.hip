@@ -184,7 +184,8 @@ __global__ __launch_bounds__(MI355X_BLOCK) void trisolve_syncfree_kernel(
           // values that were not there yet: ALL of the batch's pending values are requested again together, round after round -- one
           // memory round trip per round however many are pending (a row's dependencies of the previous level complete at about the
           // same time: polled one after the other, each of them cost a round trip of its own ON the dependency chain: P7(256),
-          // 3 entries per row, 2.8 ms per application that way); backed off and bounded as tri_poll is
+          // 3 entries per row, 2.83 ms per application that way, 2.67 so); backed off and bounded as tri_poll is.  Two probes in
+          // flight half a round trip apart were measured too: 3.1-3.5 ms -- more poll traffic slows the producers down
           { bool pend = false;
 #pragma unroll
             for (int j = 0; j < 8; ++j) pend = pend || (q0 + j < mylen && __double_as_longlong(v[j]) == (long long)TRI_SENTINEL);

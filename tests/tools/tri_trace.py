@@ -17,7 +17,10 @@ def main():
     import petsc_dev_amd as pda
     from petsc_dev_amd import petsc as P
     L = P.lib(); k = pda.load_kernels()
-    ai, aj, aa = pb.gen_fem3() if which == "fem" else P.gen_poisson7(16, 16, 4096)
+    if which.startswith("p7:"):
+        m = int(which.split(":")[1]); ai, aj, aa = P.gen_poisson7(m, m, m)
+    else:
+        ai, aj, aa = pb.gen_fem3() if which == "fem" else P.gen_poisson7(16, 16, 4096)
     n = ai.size - 1
     A = P.Mat.from_csr(ai, aj, aa)
     b = P.Vec.create(n, comm=L.COMM_SELF); L.VecSet(b.h, 1.0); u = b.duplicate()
