@@ -1014,7 +1014,7 @@ def _tri_plan_arrays(dev, plan):
     return out
 
 
-@pytest.mark.parametrize("shape", ["wide", "ragged", "chain", "tiny", "empty_rows"])
+@pytest.mark.parametrize("shape", ["wide", "ragged", "chain", "tiny", "empty_rows", "n1", "n64", "n65", "longrow", "deepchain"])
 @pytest.mark.parametrize("kind", ["lower", "upper", "upper_scaled"])
 def test_trisolve_row_plans_built_on_the_device_equal_the_host_built_plans(dev, shape, kind, monkeypatch):
     """csrc/trisolve_build.hip lays a row plan out on the device (radix sort of the rows by (level, longer first), positions,
@@ -1024,7 +1024,7 @@ def test_trisolve_row_plans_built_on_the_device_equal_the_host_built_plans(dev, 
     column / value arrays (the device route uploads only the range the rows name)."""
     k = dev.k
     rng = np.random.default_rng(hash((shape, kind)) % (1 << 31))
-    n = {"wide": 40000, "ragged": 9000, "chain": 700, "tiny": 5, "empty_rows": 3000}[shape]
+    n = {"wide": 40000, "ragged": 9000, "chain": 700, "tiny": 5, "empty_rows": 3000, "n1": 1, "n64": 64, "n65": 65, "longrow": 4000, "deepchain": 70000}[shape]
     # strictly lower-triangular dependency structure (for an upper solve the caller hands over reversed roles; the plan only needs
     # "dependencies come earlier in level order", so a lower structure serves both kinds here)
     rl = np.zeros(n, dtype=np.int32)
@@ -1035,8 +1035,12 @@ def test_trisolve_row_plans_built_on_the_device_equal_the_host_built_plans(dev, 
         elif shape == "ragged":
             m = int(rng.integers(0, 40)) if i % 11 else 0
             cand = sorted(set(int(c) for c in rng.integers(max(0, i - 3000), max(i, 1), size=m) if c < i)) if i else []
-        elif shape == "chain":
+        elif shape in ("chain", "deepchain"):
             cand = [i - 1] if i and i % 3 else ([i - 2] if i > 1 else [])
+        elif shape in ("n1", "n64", "n65"):
+            cand = [c for c in (i - 1, i - 9) if c >= 0 and i % 4]
+        elif shape == "longrow":                            # a few rows with thousands of entries among short ones
+            cand = list(range(0, i, 1 if i in (1500, 3999) else max(i, 1))) if i in (1500, 3999) else ([i - 1] if i % 2 else [])
         elif shape == "tiny":
             cand = list(range(i))
         else:
