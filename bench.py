@@ -11,8 +11,9 @@ Three configurations of the same solve are timed in the same run (N=1; on severa
                     ms_per_step, roofline, spmv_gbps, ksp_* describe THIS leg.
   value_patterns    the same solver with the library's default for this matrix: P7 has constant coefficients, its rows come
                     from a 27-entry dictionary and the product does not read the value array (the product carries the same bits).
-  op_by_op          -ksp_type cg: the plain restatement of PETSc's own KSPSolve_CG, one kernel per Vec/Mat call -- what an
-                    UNCHANGED PETSc program drives over the same types (value array streamed).
+  op_by_op          -ksp_type cg: the plain restatement of PETSc's own KSPSolve_CG -- what an UNCHANGED PETSc program drives over
+                    the same types (value array streamed).  The Vec type recognises the update calls of that sequence and runs
+                    them as one fused sweep (same bits); ksp_its_per_sec_every_call_its_own_kernel: with that switched off.
 
 Every fraction in the line is BYTES MOVED / time / 8 TB/s: PMC-measured bytes per launch (profiles/bench_pmc_summary.csv,
 quoted only while its stamp matches the kernel sources) or, failing that, the kernel's own byte model.  What the same time
@@ -296,12 +297,23 @@ def main():
                         "the same products bit for bit, p'w summed per workgroup (iterates agree with the headline's to rounding)", fused_dot)
             out["legs"]["value_patterns"] = vp
         # ---- leg 3: what an unchanged PETSc program drives: KSPSolve_CG op by op (VecAYPX, MatMult, VecTDot, VecAXPY x2, PCApply, VecNorm, VecTDot) ----
+        # The Vec type notes KSPSolve_CG's update calls instead of launching them one by one and runs them as the fused sweep when the norm
+        # is asked for (host/vechip.c, "deferred element-wise operations"; same bits): SpMV + AYPX 3 + TDot(p,w) 2 + sweep 8 = 13 vector
+        # passes.  With -vec_hipmi355x_defer 0 every call is a kernel of its own: 17 passes.
         ksp_plain = make_ksp("cg")
-        ob, _ = leg(ksp_plain, False, 17, "-ksp_type cg: the plain KSPSolve_CG sequence, one kernel per Vec/Mat call (17 vector passes), value array streamed")
+        setdef = L.raw("VecHIPMI355XSetDeferral")
+        setdef(1)
+        ob, _ = leg(ksp_plain, False, 13, "-ksp_type cg: the plain KSPSolve_CG call sequence of an unchanged program (value array streamed); the Vec type recognises its "
+                    "update calls (VecAXPY x2, PCApply_Jacobi, VecNorm, VecTDot) and runs them as one fused sweep: SpMV + 13 vector passes")
+        setdef(0)
+        t1 = timed_solve(ksp_plain)
+        ob["ksp_its_per_sec_every_call_its_own_kernel"] = round(args.steps / t1["dt"], 2)      # -vec_hipmi355x_defer 0: 17 vector passes
+        setdef(1)
         if nvpat.value:
             L.MatHIPMI355XSetValuePatterns(timed, 1)
             t2 = timed_solve(ksp_plain)
             ob["ksp_its_per_sec_with_value_patterns"] = round(args.steps / t2["dt"], 2)
+        setdef(-1)
         out["legs"]["op_by_op"] = ob
         L.MatHIPMI355XSetValuePatterns(timed, 1)
 

@@ -56,6 +56,11 @@ PetscErrorCode PetscCommGetDeviceTransport(PetscComm comm, int *kind /*0 single,
 
 /* PETSc names the harness does not implement because only the plugin's MPIAIJ type needs them */
 /* VecScatter, parallel -> sequential general: the MPIAIJ halo (src/vec/vec/utils/vpscat.c, vpscat.h) */
+/* Runs the element-wise operations the Vec type has noted but not launched yet (host/vechip.c, "deferred element-wise operations":
+ * an unchanged KSPSolve_CG's update sequence is recognised and run as one fused sweep; -vec_hipmi355x_defer 0 switches the noting
+ * off).  Every access to a vector's storage does this by itself; the call exists for timing code. */
+PetscErrorCode VecHIPMI355XFlushDeferred(void);
+PetscErrorCode VecHIPMI355XSetDeferral(PetscInt on);   /* 1 / 0; negative: back to what -vec_hipmi355x_defer says */
 PetscErrorCode VecScatterBegin(VecScatter ctx, Vec x, Vec y, InsertMode addv, ScatterMode mode);
 PetscErrorCode VecScatterEnd(VecScatter ctx, Vec x, Vec y, InsertMode addv, ScatterMode mode);
 PetscErrorCode VecScatterDestroy(VecScatter *ctx);

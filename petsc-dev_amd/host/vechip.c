@@ -58,17 +58,31 @@ static PetscErrorCode to_host(Vec v) {   /* VecCUSPCopyFromGPU, veccusp.cu:173 *
   return 0;
 }
 
+/* ---- deferred CG sweep (the queue and what it is for: further down, "deferred element-wise operations") ---- */
+static struct {
+  int n, busy;                      /* pending operations (0..3); busy: the queue is being run, everything executes at once */
+  Vec x, p; PetscScalar a;          /* 1: x += a p */
+  Vec r, w;                         /* 2: r += (-a) w */
+  Vec z, m1, m2;                    /* 3: z = m1 .* m2, one of them r, the other the diagonal d */
+  Vec cz, cr; long sz, sr; PetscScalar zr; int have;   /* z'r left by the fused sweep, valid while z and r keep these states */
+} dq;
+static PetscErrorCode deferred_flush(void);
+#define FLUSH_DEFERRED() do { if (dq.n && !dq.busy) { PetscErrorCode e__ = deferred_flush();CHKERRQ(e__); } } while (0)
+
 PetscErrorCode VecHIPGetRead(Vec v, const PetscScalar **d) {
+  FLUSH_DEFERRED();
   PetscErrorCode ierr = to_device(v);CHKERRQ(ierr);
   *d = VH(v)->dev;
   return 0;
 }
 PetscErrorCode VecHIPGetWrite(Vec v, PetscScalar **d) {
+  FLUSH_DEFERRED();
   PetscErrorCode ierr = dev_alloc(v);CHKERRQ(ierr);
   *d = VH(v)->dev;
   return 0;
 }
 PetscErrorCode VecHIPGetReadWrite(Vec v, PetscScalar **d) {
+  FLUSH_DEFERRED();
   PetscErrorCode ierr = to_device(v);CHKERRQ(ierr);
   *d = VH(v)->dev;
   return 0;
@@ -84,6 +98,7 @@ PetscErrorCode VecHIPMI355XGetArrayRead(Vec v, const PetscScalar **d) { CheckHIP
 
 /* ---- host access ---- */
 static PetscErrorCode VecGetArray_HIP(Vec v, PetscScalar **a) {
+  FLUSH_DEFERRED();
   PetscErrorCode ierr = to_host(v);CHKERRQ(ierr);
   *a = VH(v)->host;
   return 0;
@@ -93,6 +108,7 @@ static PetscErrorCode VecRestoreArray_HIP(Vec v, PetscScalar **a) { if (a) *a = 
 static PetscErrorCode VecPlaceArray_HIP(Vec v, const PetscScalar *a) {
   Vec_HIPMI355X *s = VH(v);
   if (s->placed_save) SETERRQ(HipObjComm(v), PETSC_ERR_ARG_WRONGSTATE, "VecPlaceArray() was already called on this vector, without a call to VecResetArray()");
+  FLUSH_DEFERRED();
   PetscErrorCode ierr = to_host(v);CHKERRQ(ierr);
   s->placed_save = s->host;
   s->host = (PetscScalar *)a;
@@ -102,6 +118,7 @@ static PetscErrorCode VecPlaceArray_HIP(Vec v, const PetscScalar *a) {
 static PetscErrorCode VecResetArray_HIP(Vec v) {
   Vec_HIPMI355X *s = VH(v);
   if (!s->placed_save) return 0;
+  FLUSH_DEFERRED();
   s->host = s->placed_save;
   s->placed_save = NULL;
   s->valid = VALID_HOST;
@@ -177,10 +194,75 @@ static PetscErrorCode VecScale_HIP(Vec x, PetscScalar alpha) {
   ierr = PetscLogFlops((PetscLogDouble)x->map->n);CHKERRQ(ierr);
   return VecHIPRestoreWrite(x);
 }
+/* ---- deferred element-wise operations: the CG sweep of an UNCHANGED KSPSolve_CG ----------------------------------------------
+ * PETSc's KSPSolve_CG (cg.c:206-232) updates with five calls -- VecAXPY(X,a,P); VecAXPY(R,-a,W); PCApply (Jacobi:
+ * VecPointwiseMult(Z,R,D), jacobi.c:266-277); VecNorm(Z); VecTDot(Z,R) -- i.e. five kernels, 17 vector passes and two host waits
+ * where the fused sweep (mi355x_vec_cg_update, the kernel of the registered cghipmi355x type) makes 8 passes and one wait with the
+ * same bits.  An unchanged program never calls the fused entry point, so the TYPE recognises the sequence: a VecAXPY is not launched
+ * at once but noted; a second one with the negated scalar on other vectors, then a VecPointwiseMult reading the second one's result,
+ * extend the note; a VecNorm_2 / VecDot / VecTDot of the product then runs the whole note as ONE fused sweep, and the z'r it
+ * leaves answers the VecTDot(Z,R) that follows without a kernel (kept per object state of z and r).  Anything else -- any access
+ * to any vector's storage (VecHIPGetRead / Write, VecGetArray: every operation of this file and every Mat / PC / scatter routine
+ * goes through them), a vector being destroyed, an operation that does not continue the pattern -- first runs what is noted, in
+ * order, with the ordinary kernels: the same results as without the note.  -vec_hipmi355x_defer 0 switches it off. */
+static int defer_on = -1;
+static int defer_enabled(void) {
+  if (defer_on < 0) { PetscInt v = 1; PetscBool set; if (PetscOptionsGetInt(NULL, "-vec_hipmi355x_defer", &v, &set)) v = 1; defer_on = v ? 1 : 0; }
+  return defer_on;
+}
+static PetscErrorCode VecAXPY_HIP_now(Vec y, PetscScalar alpha, Vec x);
+static PetscErrorCode VecPointwiseMult_HIP_now(Vec w, Vec x, Vec y);
+PetscErrorCode VecCGUpdate_HIPMI355X(Vec x, Vec r, Vec z, Vec p, Vec w, Vec d, PetscScalar a, PetscScalar *zz, PetscScalar *zr, PetscScalar *rr, PetscBool *done);
+static PetscErrorCode deferred_flush(void) {
+  PetscErrorCode ierr;
+  if (!dq.n || dq.busy) return 0;
+  const int n = dq.n;
+  dq.n = 0; dq.busy = 1;
+  ierr = VecAXPY_HIP_now(dq.x, dq.a, dq.p);
+  if (!ierr && n >= 2) ierr = VecAXPY_HIP_now(dq.r, -dq.a, dq.w);
+  if (!ierr && n >= 3) ierr = VecPointwiseMult_HIP_now(dq.z, dq.m1, dq.m2);
+  dq.busy = 0;
+  CHKERRQ(ierr);
+  return 0;
+}
+PetscErrorCode VecHIPMI355XFlushDeferred(void) { return deferred_flush(); }
+/* on: 1 / 0; negative: as the options database says (-vec_hipmi355x_defer, read again at the next operation) */
+PetscErrorCode VecHIPMI355XSetDeferral(PetscInt on) {
+  PetscErrorCode ierr = deferred_flush();CHKERRQ(ierr);
+  defer_on = on < 0 ? -1 : (on ? 1 : 0);
+  dq.have = 0;
+  return 0;
+}
+/* the note holds the whole sweep and `v` is its product: run it fused.  *zz, *zr = z'z, z'r (over all ranks); *done = PETSC_FALSE:
+ * not possible with these vectors (then the note has been run with the ordinary kernels and the caller goes on as usual) */
+static PetscErrorCode deferred_sweep(PetscScalar *zz, PetscScalar *zr, PetscBool *done) {
+  PetscErrorCode ierr;
+  PetscScalar rr;
+  Vec x = dq.x, p = dq.p, r = dq.r, w = dq.w, z = dq.z, d = dq.m1 == dq.r ? dq.m2 : dq.m1;
+  const PetscScalar a = dq.a;
+  *done = PETSC_FALSE;
+  dq.busy = 1;                                        /* the accessors inside must not run the note */
+  ierr = VecCGUpdate_HIPMI355X(x, r, z, p, w, d, a, zz, zr, &rr, done);
+  dq.busy = 0;
+  CHKERRQ(ierr);
+  if (!*done) return deferred_flush();
+  dq.n = 0;
+  dq.cz = z; dq.cr = r; dq.sz = (long)HipObjState(z); dq.sr = (long)HipObjState(r); dq.zr = *zr; dq.have = 1;
+  return 0;
+}
 static PetscErrorCode VecAXPY_HIP(Vec y, PetscScalar alpha, Vec x) {
-  PetscErrorCode ierr; const PetscScalar *dx; PetscScalar *dy; DEVCTX;
   CheckHIP(x);
   if (alpha == 0.0) return 0;
+  if (defer_enabled() && !dq.busy && x != y && is_hip(y) && x->map->n == y->map->n) {
+    if (dq.n == 1 && alpha == -dq.a && y != dq.x && y != dq.p && x != dq.x && x->map->n == dq.x->map->n) { dq.r = y; dq.w = x; dq.n = 2; return 0; }
+    FLUSH_DEFERRED();
+    dq.x = y; dq.p = x; dq.a = alpha; dq.n = 1;
+    return 0;
+  }
+  return VecAXPY_HIP_now(y, alpha, x);
+}
+static PetscErrorCode VecAXPY_HIP_now(Vec y, PetscScalar alpha, Vec x) {
+  PetscErrorCode ierr; const PetscScalar *dx; PetscScalar *dy; DEVCTX;
   ierr = VecHIPGetRead(x, &dx);CHKERRQ(ierr);
   ierr = VecHIPGetReadWrite(y, &dy);CHKERRQ(ierr);
   CHKHIP(mi355x_vec_axpy(dc->h, N_(y), alpha, dx, dy));
@@ -226,8 +308,18 @@ static PetscErrorCode VecAXPBYPCZ_HIP(Vec z, PetscScalar alpha, PetscScalar beta
   return VecHIPRestoreWrite(z);
 }
 static PetscErrorCode VecPointwiseMult_HIP(Vec w, Vec x, Vec y) {
-  PetscErrorCode ierr; const PetscScalar *dx, *dy; PetscScalar *dw; DEVCTX;
   CheckHIP(x); CheckHIP(y);
+  if (dq.n == 2 && !dq.busy && is_hip(w) && (x == dq.r) != (y == dq.r)) {
+    Vec d = x == dq.r ? y : x;
+    if (w != dq.x && w != dq.r && w != dq.p && w != d && d != dq.x && d != dq.r && w->map->n == dq.r->map->n && d->map->n == dq.r->map->n) {
+      dq.z = w; dq.m1 = x; dq.m2 = y; dq.n = 3;
+      return 0;
+    }
+  }
+  return VecPointwiseMult_HIP_now(w, x, y);
+}
+static PetscErrorCode VecPointwiseMult_HIP_now(Vec w, Vec x, Vec y) {
+  PetscErrorCode ierr; const PetscScalar *dx, *dy; PetscScalar *dw; DEVCTX;
   ierr = VecHIPGetRead(x, &dx);CHKERRQ(ierr);
   ierr = VecHIPGetRead(y, &dy);CHKERRQ(ierr);
   if (w == x || w == y) { ierr = VecHIPGetReadWrite(w, &dw);CHKERRQ(ierr); }
@@ -314,6 +406,16 @@ static PetscErrorCode reduce_finish(Vec x, PetscDeviceCtx *dc, int count, int is
 static PetscErrorCode VecDot_HIP(Vec x, Vec y, PetscScalar *val) {
   PetscErrorCode ierr; const PetscScalar *dx, *dy; double *out; DEVCTX;
   CheckHIP(y);
+  if (!hip_local_only && !dq.busy) {
+    if (dq.n == 3 && ((x == dq.z && y == dq.r) || (x == dq.r && y == dq.z))) {   /* natural norm: the sweep's product is first asked for as z'r */
+      PetscScalar zz, zr; PetscBool done;
+      ierr = deferred_sweep(&zz, &zr, &done);CHKERRQ(ierr);
+      if (done) { *val = zr; return 0; }
+    } else if (!dq.n && dq.have && ((x == dq.cz && y == dq.cr) || (x == dq.cr && y == dq.cz)) && (long)HipObjState(dq.cz) == dq.sz && (long)HipObjState(dq.cr) == dq.sr) {
+      *val = dq.zr;                                   /* left by the fused sweep that answered VecNorm(z) */
+      return 0;
+    }
+  }
   ierr = VecHIPGetRead(x, &dx);CHKERRQ(ierr);
   ierr = VecHIPGetRead(y, &dy);CHKERRQ(ierr);
   ierr = reduce_target(x, dc, &out);CHKERRQ(ierr);
@@ -338,6 +440,11 @@ static PetscErrorCode VecMDot_HIP(Vec x, PetscInt nv, const Vec y[], PetscScalar
 }
 static PetscErrorCode VecNorm_HIP(Vec x, NormType type, PetscReal *val) {
   PetscErrorCode ierr; const PetscScalar *dx; double *out; PetscScalar r[2]; DEVCTX;
+  if (dq.n == 3 && !dq.busy && !hip_local_only && type == NORM_2 && x == dq.z) {
+    PetscScalar zz, zr; PetscBool done;
+    ierr = deferred_sweep(&zz, &zr, &done);CHKERRQ(ierr);
+    if (done) { *val = PetscSqrtReal(zz); return 0; }
+  }
   ierr = VecHIPGetRead(x, &dx);CHKERRQ(ierr);
   ierr = reduce_target(x, dc, &out);CHKERRQ(ierr);
   CHKHIP(mi355x_vec_norm(dc->h, N_(x), (int)type, dx, out));
@@ -675,6 +782,8 @@ static PetscErrorCode VecNorm_HIP_local(Vec x, NormType type, PetscReal *val) { 
 static PetscErrorCode VecDestroy_HIP(Vec v) {
   Vec_HIPMI355X *s = VH(v);
   if (!s) return 0;
+  FLUSH_DEFERRED();                                  /* a pending operation may name this vector */
+  if (dq.cz == v || dq.cr == v) dq.have = 0;
   if (s->placed_save) { s->host = s->placed_save; s->placed_save = NULL; }
   if (s->alias_save) { s->dev = s->alias_save; s->alias_save = NULL; }   /* never free storage borrowed from another vector */
   if (s->dev) mi355x_free(s->dev);
@@ -727,6 +836,7 @@ static PetscErrorCode VecShareSubArrayEnd_HIP(Vec sub, Vec parent, PetscInt offs
   Vec_HIPMI355X *s = VH(sub);
   (void)offset;
   if (!s->alias_save) return 0;
+  FLUSH_DEFERRED();                                  /* an operation pending on the borrowed storage runs before it goes back */
   s->dev = s->alias_save; s->valid = s->alias_valid; s->alias_save = NULL;
   HipStateIncrease(sub);
   if (write) return VecHIPRestoreWrite(parent);

@@ -2177,3 +2177,111 @@ def test_config4_full_size_gmres_bjacobi_solve(P, sub):
     pc = C.c_void_p(); L.KSPGetPC(k.h, C.byref(pc))
     L.raw("PCApply")(pc, r.h, z.h)
     assert abs(z.norm() - h[-1]) <= 1e-3 * h[-1] + 1e-12 * h[0]
+
+
+def _deferral(P, on):
+    P.lib().raw("VecHIPMI355XSetDeferral")(on)
+
+
+@pytest.mark.parametrize("norm", ["preconditioned", "natural", "unpreconditioned"])
+@pytest.mark.parametrize("pc", ["jacobi", "none", "ilu"])
+def test_unchanged_ksp_cg_runs_the_fused_sweep_with_the_same_bits(P, pc, norm):
+    """The plain KSPSolve_CG (what an unchanged PETSc program drives: VecAXPY, VecAXPY, PCApply, VecNorm, VecTDot one after the other)
+    over vectors that note element-wise operations instead of launching them (host/vechip.c): with PCJACOBI the five calls become ONE
+    fused sweep per iteration -- counted -- and the VecTDot(Z,R) behind it is answered without a kernel; iterates, residual history,
+    iteration count and reason are bit for bit those of the same solve with the noting switched off, whatever the PC or norm type."""
+    L = P.lib()
+    ai, aj, aa = pb.lap2d(37, 29)
+    n = ai.size - 1
+    b = orc.spmv(ai, aj, aa, np.cos(0.3 * np.arange(n)))
+    opts = "-ksp_cg_fused 0 -ksp_norm_type " + norm
+    runs = {}
+    for on in (0, 1):
+        _deferral(P, on)
+        L.VecHIPMI355XSetCGUpdateTiming(1)
+        runs[on] = solve(P, ai, aj, aa, b, "cg", pc, opts=opts, rtol=1e-9)
+        nl = C.c_int(); L.VecHIPMI355XGetCGUpdateTiming(C.byref(nl), None)
+        L.VecHIPMI355XSetCGUpdateTiming(0)
+        runs[on] = runs[on] + (nl.value,)
+    _deferral(P, -1)
+    (x0, h0, its0, r0, n0), (x1, h1, its1, r1, n1) = runs[0], runs[1]
+    assert r0 == r1 == 2 and its0 == its1 > 20
+    assert np.array_equal(bits(h0), bits(h1)) and np.array_equal(bits(x0), bits(x1))
+    assert n0 == 0                                              # the plain type by itself never calls the fused sweep
+    if pc == "jacobi" and norm != "unpreconditioned":           # (unpreconditioned: VecNorm(R) sits between the AXPYs and the PCApply)
+        assert its1 - 1 <= n1 <= its1 + 1
+    else:
+        assert n1 == 0
+
+
+def test_deferred_vector_operations_are_transparent(P):
+    """Noted-but-not-launched operations never show: every scenario (the whole CG pattern, prefixes of it read early, operand
+    aliasing that must not extend the note, another norm type, swapped dot operands, a change of r between the sweep and the dot it
+    would answer, a vector destroyed while named by the note, host access) gives the bits of the same calls with the noting off."""
+    L = P.lib()
+    n = 5000
+    rng = np.random.default_rng(77)
+    base = {k: rng.standard_normal(n) for k in "xprwzd"}
+    a = 0.37
+
+    def run(scn):
+        v = {k: P.Vec.from_array(base[k], comm=L.COMM_SELF) for k in "xprwzd"}
+        out = []
+        val = C.c_double()
+
+        def nrm(vec, t=2):
+            r = (C.c_double * 2)(); L.VecNorm(vec.h, t, r); return r[0]
+
+        def dot(u, w_):
+            L.VecTDot(u.h, w_.h, C.byref(val)); return val.value
+        if scn == "full":
+            L.VecAXPY(v["x"].h, a, v["p"].h); L.VecAXPY(v["r"].h, -a, v["w"].h); L.VecPointwiseMult(v["z"].h, v["r"].h, v["d"].h)
+            out += [nrm(v["z"]), dot(v["z"], v["r"]), dot(v["z"], v["r"])]
+        elif scn == "full_swapped_operands":
+            L.VecAXPY(v["x"].h, a, v["p"].h); L.VecAXPY(v["r"].h, -a, v["w"].h); L.VecPointwiseMult(v["z"].h, v["d"].h, v["r"].h)
+            out += [dot(v["r"], v["z"]), nrm(v["z"])]
+        elif scn == "one_then_read":
+            L.VecAXPY(v["x"].h, a, v["p"].h); out += [nrm(v["x"])]
+        elif scn == "two_then_read":
+            L.VecAXPY(v["x"].h, a, v["p"].h); L.VecAXPY(v["r"].h, -a, v["w"].h); out += [dot(v["r"], v["x"])]
+        elif scn == "second_reads_first":
+            L.VecAXPY(v["x"].h, a, v["p"].h); L.VecAXPY(v["r"].h, -a, v["x"].h)
+        elif scn == "second_writes_first":
+            L.VecAXPY(v["x"].h, a, v["p"].h); L.VecAXPY(v["x"].h, -a, v["w"].h)
+        elif scn == "not_negated":
+            L.VecAXPY(v["x"].h, a, v["p"].h); L.VecAXPY(v["r"].h, a, v["w"].h); L.VecPointwiseMult(v["z"].h, v["r"].h, v["d"].h); out += [nrm(v["z"])]
+        elif scn == "product_overwrites_p":
+            L.VecAXPY(v["x"].h, a, v["p"].h); L.VecAXPY(v["r"].h, -a, v["w"].h); L.VecPointwiseMult(v["p"].h, v["r"].h, v["d"].h); out += [nrm(v["p"])]
+        elif scn == "product_into_w":                              # cg.c:122 keeps A p in Z: z may be w
+            L.VecAXPY(v["x"].h, a, v["p"].h); L.VecAXPY(v["r"].h, -a, v["w"].h); L.VecPointwiseMult(v["w"].h, v["r"].h, v["d"].h); out += [nrm(v["w"]), dot(v["w"], v["r"])]
+        elif scn == "norm_1":
+            L.VecAXPY(v["x"].h, a, v["p"].h); L.VecAXPY(v["r"].h, -a, v["w"].h); L.VecPointwiseMult(v["z"].h, v["r"].h, v["d"].h); out += [nrm(v["z"], 0), nrm(v["z"], 3)]
+        elif scn == "r_changes_before_the_dot":
+            L.VecAXPY(v["x"].h, a, v["p"].h); L.VecAXPY(v["r"].h, -a, v["w"].h); L.VecPointwiseMult(v["z"].h, v["r"].h, v["d"].h)
+            out += [nrm(v["z"])]; L.VecScale(v["r"].h, 1.5); out += [dot(v["z"], v["r"])]
+        elif scn == "destroy_while_noted":
+            L.VecAXPY(v["x"].h, a, v["p"].h); L.VecAXPY(v["r"].h, -a, v["w"].h); L.VecPointwiseMult(v["z"].h, v["r"].h, v["d"].h)
+            v["d"].destroy(); v["d"].h = C.c_void_p(); v["p"].destroy(); v["p"].h = C.c_void_p()
+        elif scn == "host_access":
+            L.VecAXPY(v["x"].h, a, v["p"].h); L.VecAXPY(v["r"].h, -a, v["w"].h)
+            v["w"].set_array(base["z"]); L.VecAXPY(v["r"].h, 2.0, v["w"].h)
+        elif scn == "zero_alpha":
+            L.VecAXPY(v["x"].h, 0.0, v["p"].h); L.VecAXPY(v["r"].h, -0.0, v["w"].h); L.VecAXPY(v["x"].h, a, v["p"].h)
+        arrays = [v[k].array() for k in "xprwzd" if v[k].h]
+        return out, arrays
+
+    scenarios = ["full", "full_swapped_operands", "one_then_read", "two_then_read", "second_reads_first", "second_writes_first", "not_negated",
+                 "product_overwrites_p", "product_into_w", "norm_1", "r_changes_before_the_dot", "destroy_while_noted", "host_access", "zero_alpha"]
+    for scn in scenarios:
+        _deferral(P, 0); o0, a0 = run(scn)
+        _deferral(P, 1); o1, a1 = run(scn)
+        assert np.array_equal(bits(np.array(o0)), bits(np.array(o1))), scn
+        assert len(a0) == len(a1) and all(np.array_equal(bits(u), bits(w_)) for u, w_ in zip(a0, a1)), scn
+    _deferral(P, -1)
+    # and the reference values of the whole pattern
+    _deferral(P, 1); o1, a1 = run("full"); _deferral(P, -1)
+    x = base["x"].copy(); orc.vec_axpy(x, a, base["p"])
+    r = base["r"].copy(); orc.vec_axpy(r, -a, base["w"])
+    z = np.zeros(n); orc.vec_pointwise_mult(z, r, base["d"])
+    assert np.array_equal(bits(a1[0]), bits(x)) and np.array_equal(bits(a1[2]), bits(r)) and np.array_equal(bits(a1[4]), bits(z))
+    assert abs(o1[0] - np.linalg.norm(z)) <= 1e-13 * np.linalg.norm(z) and o1[1] == o1[2] and abs(o1[1] - z @ r) <= 1e-13 * np.sum(np.abs(z * r))
