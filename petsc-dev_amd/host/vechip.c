@@ -170,9 +170,15 @@ static PetscErrorCode VecSet_HIP(Vec x, PetscScalar alpha) {
   CHKHIP(mi355x_vec_set(dc->h, N_(x), alpha, d));
   return VecHIPRestoreWrite(x);
 }
+static PetscErrorCode VecCopy_HIP_now(Vec x, Vec y);
 static PetscErrorCode VecCopy_HIP(Vec x, Vec y) {
-  PetscErrorCode ierr; const PetscScalar *dx; PetscScalar *dy; DEVCTX;
   CheckHIP(y);
+  /* PCApply_None (src/ksp/pc/impls/none/none.c: VecCopy(x, y)) as the third operation of the noted CG sweep: z = r */
+  if (dq.n == 2 && !dq.busy && x == dq.r && y != dq.x && y != dq.r && y != dq.p && y->map->n == x->map->n) { dq.z = y; dq.m1 = x; dq.m2 = NULL; dq.n = 3; return 0; }
+  return VecCopy_HIP_now(x, y);
+}
+static PetscErrorCode VecCopy_HIP_now(Vec x, Vec y) {
+  PetscErrorCode ierr; const PetscScalar *dx; PetscScalar *dy; DEVCTX;
   ierr = VecHIPGetRead(x, &dx);CHKERRQ(ierr);
   ierr = VecHIPGetWrite(y, &dy);CHKERRQ(ierr);
   CHKHIP(mi355x_vec_copy(dc->h, N_(x), dx, dy));
@@ -220,7 +226,7 @@ static PetscErrorCode deferred_flush(void) {
   dq.n = 0; dq.busy = 1;
   ierr = VecAXPY_HIP_now(dq.x, dq.a, dq.p);
   if (!ierr && n >= 2) ierr = VecAXPY_HIP_now(dq.r, -dq.a, dq.w);
-  if (!ierr && n >= 3) ierr = VecPointwiseMult_HIP_now(dq.z, dq.m1, dq.m2);
+  if (!ierr && n >= 3) ierr = dq.m2 ? VecPointwiseMult_HIP_now(dq.z, dq.m1, dq.m2) : VecCopy_HIP_now(dq.m1, dq.z);
   dq.busy = 0;
   CHKERRQ(ierr);
   return 0;
@@ -238,7 +244,7 @@ PetscErrorCode VecHIPMI355XSetDeferral(PetscInt on) {
 static PetscErrorCode deferred_sweep(PetscScalar *zz, PetscScalar *zr, PetscBool *done) {
   PetscErrorCode ierr;
   PetscScalar rr;
-  Vec x = dq.x, p = dq.p, r = dq.r, w = dq.w, z = dq.z, d = dq.m1 == dq.r ? dq.m2 : dq.m1;
+  Vec x = dq.x, p = dq.p, r = dq.r, w = dq.w, z = dq.z, d = dq.m1 == dq.r ? dq.m2 : dq.m1;     /* d == NULL: the copy of PCNONE */
   const PetscScalar a = dq.a;
   *done = PETSC_FALSE;
   dq.busy = 1;                                        /* the accessors inside must not run the note */

@@ -2208,7 +2208,7 @@ def test_unchanged_ksp_cg_runs_the_fused_sweep_with_the_same_bits(P, pc, norm):
     assert r0 == r1 == 2 and its0 == its1 > 20
     assert np.array_equal(bits(h0), bits(h1)) and np.array_equal(bits(x0), bits(x1))
     assert n0 == 0                                              # the plain type by itself never calls the fused sweep
-    if pc == "jacobi" and norm != "unpreconditioned":           # (unpreconditioned: VecNorm(R) sits between the AXPYs and the PCApply)
+    if pc in ("jacobi", "none") and norm != "unpreconditioned":  # (PCNONE's VecCopy is the third operation then; unpreconditioned: VecNorm(R) sits between the AXPYs and the PCApply)
         assert its1 - 1 <= n1 <= its1 + 1
     else:
         assert n1 == 0
@@ -2240,6 +2240,10 @@ def test_deferred_vector_operations_are_transparent(P):
         elif scn == "full_swapped_operands":
             L.VecAXPY(v["x"].h, a, v["p"].h); L.VecAXPY(v["r"].h, -a, v["w"].h); L.VecPointwiseMult(v["z"].h, v["d"].h, v["r"].h)
             out += [dot(v["r"], v["z"]), nrm(v["z"])]
+        elif scn == "copy_as_third":                               # PCApply_None
+            L.VecAXPY(v["x"].h, a, v["p"].h); L.VecAXPY(v["r"].h, -a, v["w"].h); L.VecCopy(v["r"].h, v["z"].h); out += [nrm(v["z"]), dot(v["z"], v["r"])]
+        elif scn == "copy_elsewhere":
+            L.VecAXPY(v["x"].h, a, v["p"].h); L.VecAXPY(v["r"].h, -a, v["w"].h); L.VecCopy(v["x"].h, v["z"].h); out += [nrm(v["z"])]
         elif scn == "one_then_read":
             L.VecAXPY(v["x"].h, a, v["p"].h); out += [nrm(v["x"])]
         elif scn == "two_then_read":
@@ -2270,7 +2274,7 @@ def test_deferred_vector_operations_are_transparent(P):
         arrays = [v[k].array() for k in "xprwzd" if v[k].h]
         return out, arrays
 
-    scenarios = ["full", "full_swapped_operands", "one_then_read", "two_then_read", "second_reads_first", "second_writes_first", "not_negated",
+    scenarios = ["full", "full_swapped_operands", "copy_as_third", "copy_elsewhere", "one_then_read", "two_then_read", "second_reads_first", "second_writes_first", "not_negated",
                  "product_overwrites_p", "product_into_w", "norm_1", "r_changes_before_the_dot", "destroy_while_noted", "host_access", "zero_alpha"]
     for scn in scenarios:
         _deferral(P, 0); o0, a0 = run(scn)
