@@ -69,6 +69,18 @@ def main():
     xr, hr, itsr, rr = orc.ksp_solve(gi, gj, ga, orc.spmv(gi, gj, ga, np.ones(N)), ksp="cg", pc="jacobi", rtol=1e-8)
     h = k.history()
     ok4 = abs(k.its - itsr) <= 1 and np.allclose(h[:min(len(h), len(hr))], hr[:min(len(h), len(hr))], rtol=1e-6)
+    # the plain KSPSolve_CG sequence of an unchanged program over PARALLEL vectors: its update calls noted and run as one fused sweep
+    # (one reduction of three values across the ranks) == every call a kernel and a reduction of its own, bit for bit
+    hist = {}
+    for on in (0, 1):
+        L.raw("VecHIPMI355XSetDeferral")(on)
+        kp = P.KSP(comm=comm); kp.set_operators(A); kp.set_type("cg"); kp.set_pc_type("jacobi"); kp.set_tolerances(rtol=1e-8); kp.record_history()
+        L.VecSet(sol.h, 0.0)
+        kp.solve(b, sol)
+        hist[on] = (kp.history().copy(), kp.its, sol.array().copy())
+    L.raw("VecHIPMI355XSetDeferral")(-1)
+    ok9 = hist[0][1] == hist[1][1] and np.array_equal(hist[0][0].view(np.uint64), hist[1][0].view(np.uint64)) and np.array_equal(hist[0][2].view(np.uint64), hist[1][2].view(np.uint64))
+    print("rank %d/%d: plain KSPSolve_CG with the update calls deferred == launched one by one: %s (its %d)" % (rank, world, ok9, hist[1][1]), flush=True)
     # Gropp's CG over the same operator: split-phase reductions across the ranks (staged: host all-reduce at the End)
     kg = P.KSP(comm=comm); kg.set_operators(A); kg.set_type("groppcg"); kg.set_pc_type("jacobi"); kg.set_tolerances(rtol=1e-8); kg.record_history()
     L.VecSet(sol.h, 0.0)
