@@ -59,12 +59,13 @@ static PetscErrorCode to_host(Vec v) {   /* VecCUSPCopyFromGPU, veccusp.cu:173 *
 }
 
 /* ---- deferred CG sweep (the queue and what it is for: further down, "deferred element-wise operations") ---- */
+enum { DQ_AXPY = 1, DQ_PMULT, DQ_COPY, DQ_AXPBYPCZ, DQ_WAXPY };
+typedef struct { int kind; Vec o, a, b; PetscScalar s1, s2, s3; } DqOp;   /* o: the vector written; a, b: read; the call's scalars */
 static struct {
-  int n, busy;                      /* pending operations (0..3); busy: the queue is being run, everything executes at once */
-  Vec x, p; PetscScalar a;          /* 1: x += a p */
-  Vec r, w;                         /* 2: r += (-a) w */
-  Vec z, m1, m2;                    /* 3: z = m1 .* m2, one of them r, the other the diagonal d */
-  Vec cz, cr; long sz, sr; PetscScalar zr; int have;   /* z'r left by the fused sweep, valid while z and r keep these states */
+  int n, busy;                      /* noted operations (0..3), a prefix of one of the patterns below; busy: the note is being run */
+  DqOp op[3];
+  Vec ca, cb; long sa, sb; PetscScalar cval; int have;   /* a dot product (ca, cb) left by a fused sweep, valid while both keep these states */
+  Vec la[4], lb[4]; int lpos;       /* operands of the last few VecDot / VecTDot calls (BiCGStab: (r, rp) of the iteration's start names the partner the fused update needs) */
 } dq;
 static PetscErrorCode deferred_flush(void);
 #define FLUSH_DEFERRED() do { if (dq.n && !dq.busy) { PetscErrorCode e__ = deferred_flush();CHKERRQ(e__); } } while (0)
@@ -174,7 +175,10 @@ static PetscErrorCode VecCopy_HIP_now(Vec x, Vec y);
 static PetscErrorCode VecCopy_HIP(Vec x, Vec y) {
   CheckHIP(y);
   /* PCApply_None (src/ksp/pc/impls/none/none.c: VecCopy(x, y)) as the third operation of the noted CG sweep: z = r */
-  if (dq.n == 2 && !dq.busy && x == dq.r && y != dq.x && y != dq.r && y != dq.p && y->map->n == x->map->n) { dq.z = y; dq.m1 = x; dq.m2 = NULL; dq.n = 3; return 0; }
+  if (dq.n == 2 && !dq.busy && dq.op[0].kind == DQ_AXPY && x == dq.op[1].o && y != dq.op[0].o && y != dq.op[1].o && y != dq.op[0].a && is_hip(y) && y->map->n == x->map->n) {
+    dq.op[2].kind = DQ_COPY; dq.op[2].o = y; dq.op[2].a = x; dq.op[2].b = NULL; dq.n = 3;
+    return 0;
+  }
   return VecCopy_HIP_now(x, y);
 }
 static PetscErrorCode VecCopy_HIP_now(Vec x, Vec y) {
@@ -218,15 +222,30 @@ static int defer_enabled(void) {
 }
 static PetscErrorCode VecAXPY_HIP_now(Vec y, PetscScalar alpha, Vec x);
 static PetscErrorCode VecPointwiseMult_HIP_now(Vec w, Vec x, Vec y);
+static PetscErrorCode VecAXPBYPCZ_HIP_now(Vec z, PetscScalar alpha, PetscScalar beta, PetscScalar gamma, Vec x, Vec y);
+static PetscErrorCode VecWAXPY_HIP_now(Vec w, PetscScalar alpha, Vec x, Vec y);
 PetscErrorCode VecCGUpdate_HIPMI355X(Vec x, Vec r, Vec z, Vec p, Vec w, Vec d, PetscScalar a, PetscScalar *zz, PetscScalar *zr, PetscScalar *rr, PetscBool *done);
+PetscErrorCode VecPMultDot_HIPMI355X(Vec w, Vec x, Vec d, Vec y, PetscScalar *val, PetscBool *done);
+PetscErrorCode VecPMultDotNorm2_HIPMI355X(Vec w, Vec x, Vec d, Vec s_, PetscScalar *dp, PetscReal *nm, PetscBool *done);
+PetscErrorCode VecBCGSUpdate_HIPMI355X(Vec x, Vec r, Vec p, Vec s_, Vec t, Vec rp, PetscScalar alpha, PetscScalar omega, PetscScalar *rr, PetscScalar *rho, PetscBool *done);
+static PetscErrorCode dq_run(const DqOp *o) {
+  switch (o->kind) {
+  case DQ_AXPY: return VecAXPY_HIP_now(o->o, o->s1, o->a);
+  case DQ_PMULT: return VecPointwiseMult_HIP_now(o->o, o->a, o->b);
+  case DQ_COPY: return VecCopy_HIP_now(o->a, o->o);
+  case DQ_AXPBYPCZ: return VecAXPBYPCZ_HIP_now(o->o, o->s1, o->s2, o->s3, o->a, o->b);
+  case DQ_WAXPY: return VecWAXPY_HIP_now(o->o, o->s1, o->a, o->b);
+  default: return 0;
+  }
+}
 static PetscErrorCode deferred_flush(void) {
-  PetscErrorCode ierr;
+  PetscErrorCode ierr = 0;
   if (!dq.n || dq.busy) return 0;
   const int n = dq.n;
+  DqOp ops[3];
+  for (int k = 0; k < n; k++) ops[k] = dq.op[k];
   dq.n = 0; dq.busy = 1;
-  ierr = VecAXPY_HIP_now(dq.x, dq.a, dq.p);
-  if (!ierr && n >= 2) ierr = VecAXPY_HIP_now(dq.r, -dq.a, dq.w);
-  if (!ierr && n >= 3) ierr = dq.m2 ? VecPointwiseMult_HIP_now(dq.z, dq.m1, dq.m2) : VecCopy_HIP_now(dq.m1, dq.z);
+  for (int k = 0; k < n && !ierr; k++) ierr = dq_run(&ops[k]);
   dq.busy = 0;
   CHKERRQ(ierr);
   return 0;
@@ -236,16 +255,25 @@ PetscErrorCode VecHIPMI355XFlushDeferred(void) { return deferred_flush(); }
 PetscErrorCode VecHIPMI355XSetDeferral(PetscInt on) {
   PetscErrorCode ierr = deferred_flush();CHKERRQ(ierr);
   defer_on = on < 0 ? -1 : (on ? 1 : 0);
-  dq.have = 0;
+  dq.have = 0; memset(dq.la, 0, sizeof(dq.la)); memset(dq.lb, 0, sizeof(dq.lb));
   return 0;
 }
-/* the note holds the whole sweep and `v` is its product: run it fused.  *zz, *zr = z'z, z'r (over all ranks); *done = PETSC_FALSE:
- * not possible with these vectors (then the note has been run with the ordinary kernels and the caller goes on as usual) */
+static void dq_keep(Vec a, Vec b, PetscScalar v) { dq.ca = a; dq.cb = b; dq.sa = (long)HipObjState(a); dq.sb = (long)HipObjState(b); dq.cval = v; dq.have = 1; }
+static int dq_kept(Vec x, Vec y, PetscScalar *v) {
+  if (!dq.have || !((x == dq.ca && y == dq.cb) || (x == dq.cb && y == dq.ca))) return 0;
+  if ((long)HipObjState(dq.ca) != dq.sa || (long)HipObjState(dq.cb) != dq.sb) return 0;
+  *v = dq.cval;
+  return 1;
+}
+/* the note holds the whole CG sweep: run it fused.  *zz, *zr = z'z, z'r (over all ranks); *done = PETSC_FALSE: not possible with these
+ * vectors (then the note has been run with the ordinary kernels and the caller goes on as usual) */
+static int dq_is_cg_sweep(void) { return dq.n == 3 && dq.op[0].kind == DQ_AXPY; }
 static PetscErrorCode deferred_sweep(PetscScalar *zz, PetscScalar *zr, PetscBool *done) {
   PetscErrorCode ierr;
   PetscScalar rr;
-  Vec x = dq.x, p = dq.p, r = dq.r, w = dq.w, z = dq.z, d = dq.m1 == dq.r ? dq.m2 : dq.m1;     /* d == NULL: the copy of PCNONE */
-  const PetscScalar a = dq.a;
+  Vec x = dq.op[0].o, p = dq.op[0].a, r = dq.op[1].o, w = dq.op[1].a, z = dq.op[2].o;
+  Vec d = dq.op[2].kind == DQ_COPY ? NULL : (dq.op[2].a == r ? dq.op[2].b : dq.op[2].a);       /* NULL: the copy of PCNONE */
+  const PetscScalar a = dq.op[0].s1;
   *done = PETSC_FALSE;
   dq.busy = 1;                                        /* the accessors inside must not run the note */
   ierr = VecCGUpdate_HIPMI355X(x, r, z, p, w, d, a, zz, zr, &rr, done);
@@ -253,16 +281,38 @@ static PetscErrorCode deferred_sweep(PetscScalar *zz, PetscScalar *zr, PetscBool
   CHKERRQ(ierr);
   if (!*done) return deferred_flush();
   dq.n = 0;
-  dq.cz = z; dq.cr = r; dq.sz = (long)HipObjState(z); dq.sr = (long)HipObjState(r); dq.zr = *zr; dq.have = 1;
+  dq_keep(z, r, *zr);
+  return 0;
+}
+/* BiCGStab (bcgs.c:100-125): VecAXPBYPCZ(X, alpha, omega, 1, P, S); VecWAXPY(R, -omega, T, S) noted, and VecNorm(R) or VecDot(R, RP)
+ * asks: x += alpha p + omega s, r = s - omega t, r'r and (r, rp) in one sweep; rp: the other operand of that VecDot, or -- when the
+ * norm asks first -- of the last VecDot this vector r was in (the (r, rp) of the previous iteration); (r, rp) is kept for the VecDot */
+static int dq_is_bcgs_update(void) { return dq.n == 2 && dq.op[0].kind == DQ_AXPBYPCZ && dq.op[1].kind == DQ_WAXPY; }
+static PetscErrorCode deferred_bcgs_update(Vec rp, PetscScalar *rr, PetscScalar *rho, PetscBool *done) {
+  PetscErrorCode ierr;
+  Vec x = dq.op[0].o, p = dq.op[0].a, s_ = dq.op[0].b, r = dq.op[1].o, t = dq.op[1].a;
+  const PetscScalar alpha = dq.op[0].s1, omega = dq.op[0].s2;
+  *done = PETSC_FALSE;
+  if (!rp || !is_hip(rp)) return deferred_flush();
+  dq.busy = 1;
+  ierr = VecBCGSUpdate_HIPMI355X(x, r, p, s_, t, rp, alpha, omega, rr, rho, done);
+  dq.busy = 0;
+  CHKERRQ(ierr);
+  if (!*done) return deferred_flush();
+  dq.n = 0;
+  dq_keep(r, rp, *rho);
   return 0;
 }
 static PetscErrorCode VecAXPY_HIP(Vec y, PetscScalar alpha, Vec x) {
   CheckHIP(x);
   if (alpha == 0.0) return 0;
   if (defer_enabled() && !dq.busy && x != y && is_hip(y) && x->map->n == y->map->n) {
-    if (dq.n == 1 && alpha == -dq.a && y != dq.x && y != dq.p && x != dq.x && x->map->n == dq.x->map->n) { dq.r = y; dq.w = x; dq.n = 2; return 0; }
+    if (dq.n == 1 && dq.op[0].kind == DQ_AXPY && alpha == -dq.op[0].s1 && y != dq.op[0].o && y != dq.op[0].a && x != dq.op[0].o && x->map->n == dq.op[0].o->map->n) {
+      dq.op[1].kind = DQ_AXPY; dq.op[1].o = y; dq.op[1].a = x; dq.op[1].b = NULL; dq.op[1].s1 = alpha; dq.n = 2;
+      return 0;
+    }
     FLUSH_DEFERRED();
-    dq.x = y; dq.p = x; dq.a = alpha; dq.n = 1;
+    dq.op[0].kind = DQ_AXPY; dq.op[0].o = y; dq.op[0].a = x; dq.op[0].b = NULL; dq.op[0].s1 = alpha; dq.n = 1;
     return 0;
   }
   return VecAXPY_HIP_now(y, alpha, x);
@@ -294,8 +344,17 @@ static PetscErrorCode VecAXPBY_HIP(Vec y, PetscScalar alpha, PetscScalar beta, V
   return VecHIPRestoreWrite(y);
 }
 static PetscErrorCode VecWAXPY_HIP(Vec w, PetscScalar alpha, Vec x, Vec y) {
-  PetscErrorCode ierr; const PetscScalar *dx, *dy; PetscScalar *dw; DEVCTX;
   CheckHIP(x); CheckHIP(y);
+  /* BiCGStab's r = s - omega t behind the noted x = alpha p + omega s + x */
+  if (dq.n == 1 && !dq.busy && dq.op[0].kind == DQ_AXPBYPCZ && alpha == -dq.op[0].s2 && y == dq.op[0].b && is_hip(w) && w != x && w != y &&
+      w != dq.op[0].o && w != dq.op[0].a && x != dq.op[0].o && w->map->n == y->map->n && x->map->n == y->map->n) {
+    dq.op[1].kind = DQ_WAXPY; dq.op[1].o = w; dq.op[1].a = x; dq.op[1].b = y; dq.op[1].s1 = alpha; dq.n = 2;
+    return 0;
+  }
+  return VecWAXPY_HIP_now(w, alpha, x, y);
+}
+static PetscErrorCode VecWAXPY_HIP_now(Vec w, PetscScalar alpha, Vec x, Vec y) {
+  PetscErrorCode ierr; const PetscScalar *dx, *dy; PetscScalar *dw; DEVCTX;
   ierr = VecHIPGetRead(x, &dx);CHKERRQ(ierr);
   ierr = VecHIPGetRead(y, &dy);CHKERRQ(ierr);
   ierr = VecHIPGetWrite(w, &dw);CHKERRQ(ierr);
@@ -304,8 +363,16 @@ static PetscErrorCode VecWAXPY_HIP(Vec w, PetscScalar alpha, Vec x, Vec y) {
   return VecHIPRestoreWrite(w);
 }
 static PetscErrorCode VecAXPBYPCZ_HIP(Vec z, PetscScalar alpha, PetscScalar beta, PetscScalar gamma, Vec x, Vec y) {
-  PetscErrorCode ierr; const PetscScalar *dx, *dy; PetscScalar *dz; DEVCTX;
   CheckHIP(x); CheckHIP(y);
+  if (defer_enabled() && !dq.busy && gamma == 1.0 && is_hip(z) && z != x && z != y && x != y && x->map->n == z->map->n && y->map->n == z->map->n) {
+    FLUSH_DEFERRED();                                /* BiCGStab's x = alpha p + omega s + x: the first operation of its update */
+    dq.op[0].kind = DQ_AXPBYPCZ; dq.op[0].o = z; dq.op[0].a = x; dq.op[0].b = y; dq.op[0].s1 = alpha; dq.op[0].s2 = beta; dq.op[0].s3 = gamma; dq.n = 1;
+    return 0;
+  }
+  return VecAXPBYPCZ_HIP_now(z, alpha, beta, gamma, x, y);
+}
+static PetscErrorCode VecAXPBYPCZ_HIP_now(Vec z, PetscScalar alpha, PetscScalar beta, PetscScalar gamma, Vec x, Vec y) {
+  PetscErrorCode ierr; const PetscScalar *dx, *dy; PetscScalar *dz; DEVCTX;
   ierr = VecHIPGetRead(x, &dx);CHKERRQ(ierr);
   ierr = VecHIPGetRead(y, &dy);CHKERRQ(ierr);
   ierr = VecHIPGetReadWrite(z, &dz);CHKERRQ(ierr);
@@ -315,12 +382,17 @@ static PetscErrorCode VecAXPBYPCZ_HIP(Vec z, PetscScalar alpha, PetscScalar beta
 }
 static PetscErrorCode VecPointwiseMult_HIP(Vec w, Vec x, Vec y) {
   CheckHIP(x); CheckHIP(y);
-  if (dq.n == 2 && !dq.busy && is_hip(w) && (x == dq.r) != (y == dq.r)) {
-    Vec d = x == dq.r ? y : x;
-    if (w != dq.x && w != dq.r && w != dq.p && w != d && d != dq.x && d != dq.r && w->map->n == dq.r->map->n && d->map->n == dq.r->map->n) {
-      dq.z = w; dq.m1 = x; dq.m2 = y; dq.n = 3;
+  if (dq.n == 2 && !dq.busy && dq.op[0].kind == DQ_AXPY && is_hip(w) && (x == dq.op[1].o) != (y == dq.op[1].o)) {   /* the CG sweep's z = r .* d */
+    Vec r = dq.op[1].o, d = x == r ? y : x;
+    if (w != dq.op[0].o && w != r && w != dq.op[0].a && w != d && d != dq.op[0].o && d != r && w->map->n == r->map->n && d->map->n == r->map->n) {
+      dq.op[2].kind = DQ_PMULT; dq.op[2].o = w; dq.op[2].a = x; dq.op[2].b = y; dq.n = 3;
       return 0;
     }
+  }
+  if (defer_enabled() && !dq.busy && is_hip(w) && w != x && w != y && x->map->n == w->map->n && y->map->n == w->map->n) {
+    FLUSH_DEFERRED();                                /* a product by itself (PCApply_Jacobi): a VecDot / VecDotNorm2 of it may follow (BiCGStab) */
+    dq.op[0].kind = DQ_PMULT; dq.op[0].o = w; dq.op[0].a = x; dq.op[0].b = y; dq.n = 1;
+    return 0;
   }
   return VecPointwiseMult_HIP_now(w, x, y);
 }
@@ -413,12 +485,23 @@ static PetscErrorCode VecDot_HIP(Vec x, Vec y, PetscScalar *val) {
   PetscErrorCode ierr; const PetscScalar *dx, *dy; double *out; DEVCTX;
   CheckHIP(y);
   if (!hip_local_only && !dq.busy) {
-    if (dq.n == 3 && ((x == dq.z && y == dq.r) || (x == dq.r && y == dq.z))) {   /* natural norm: the sweep's product is first asked for as z'r */
-      PetscScalar zz, zr; PetscBool done;
-      ierr = deferred_sweep(&zz, &zr, &done);CHKERRQ(ierr);
-      if (done) { *val = zr; return 0; }
-    } else if (!dq.n && dq.have && ((x == dq.cz && y == dq.cr) || (x == dq.cr && y == dq.cz)) && (long)HipObjState(dq.cz) == dq.sz && (long)HipObjState(dq.cr) == dq.sr) {
-      *val = dq.zr;                                   /* left by the fused sweep that answered VecNorm(z) */
+    PetscBool done = PETSC_FALSE; PetscScalar u, v;
+    if (x != y) { dq.la[dq.lpos & 3] = x; dq.lb[dq.lpos & 3] = y; dq.lpos++; }
+    if (dq_is_cg_sweep() && ((x == dq.op[2].o && y == dq.op[1].o) || (x == dq.op[1].o && y == dq.op[2].o))) {   /* natural norm: the sweep's product is first asked for as z'r */
+      ierr = deferred_sweep(&u, &v, &done);CHKERRQ(ierr);
+      if (done) { *val = v; return 0; }
+    } else if (dq_is_bcgs_update() && x != y && (x == dq.op[1].o || y == dq.op[1].o)) {                          /* BiCGStab without a norm: (r, rp) asks */
+      ierr = deferred_bcgs_update(x == dq.op[1].o ? y : x, &u, &v, &done);CHKERRQ(ierr);
+      if (done) { *val = v; return 0; }
+    } else if (dq.n == 1 && dq.op[0].kind == DQ_PMULT && x != y && (x == dq.op[0].o || y == dq.op[0].o)) {       /* (K p, rp) right behind the Jacobi product */
+      const DqOp o = dq.op[0];
+      dq.busy = 1;
+      ierr = VecPMultDot_HIPMI355X(o.o, o.a, o.b, x == o.o ? y : x, &v, &done);
+      dq.busy = 0;
+      CHKERRQ(ierr);
+      if (done) { dq.n = 0; *val = v; return 0; }
+    } else if (!dq.n && dq_kept(x, y, &v)) {          /* left by the fused sweep that answered the VecNorm before */
+      *val = v;
       return 0;
     }
   }
@@ -446,10 +529,20 @@ static PetscErrorCode VecMDot_HIP(Vec x, PetscInt nv, const Vec y[], PetscScalar
 }
 static PetscErrorCode VecNorm_HIP(Vec x, NormType type, PetscReal *val) {
   PetscErrorCode ierr; const PetscScalar *dx; double *out; PetscScalar r[2]; DEVCTX;
-  if (dq.n == 3 && !dq.busy && !hip_local_only && type == NORM_2 && x == dq.z) {
-    PetscScalar zz, zr; PetscBool done;
-    ierr = deferred_sweep(&zz, &zr, &done);CHKERRQ(ierr);
-    if (done) { *val = PetscSqrtReal(zz); return 0; }
+  if (!dq.busy && !hip_local_only && type == NORM_2) {
+    PetscBool done = PETSC_FALSE; PetscScalar u, v;
+    if (dq_is_cg_sweep() && x == dq.op[2].o) {
+      ierr = deferred_sweep(&u, &v, &done);CHKERRQ(ierr);
+      if (done) { *val = PetscSqrtReal(u); return 0; }
+    } else if (dq_is_bcgs_update() && x == dq.op[1].o) {
+      Vec rp = NULL;
+      for (int k = 1; k <= 4 && !rp; k++) {           /* the newest product this r was in */
+        const int q = (dq.lpos - k) & 3;
+        if (dq.la[q] == x) rp = dq.lb[q]; else if (dq.lb[q] == x) rp = dq.la[q];
+      }
+      ierr = deferred_bcgs_update(rp, &u, &v, &done);CHKERRQ(ierr);
+      if (done) { *val = PetscSqrtReal(u); return 0; }
+    }
   }
   ierr = VecHIPGetRead(x, &dx);CHKERRQ(ierr);
   ierr = reduce_target(x, dc, &out);CHKERRQ(ierr);
@@ -470,6 +563,14 @@ static PetscErrorCode VecNorm_HIP(Vec x, NormType type, PetscReal *val) {
 static PetscErrorCode VecDotNorm2_HIP(Vec s, Vec t, PetscScalar *dp, PetscScalar *nm) {
   PetscErrorCode ierr; const PetscScalar *ds_, *dt; double *out; PetscScalar r[2]; DEVCTX;
   CheckHIP(t);
+  if (dq.n == 1 && !dq.busy && !hip_local_only && dq.op[0].kind == DQ_PMULT && t == dq.op[0].o && s != t) {   /* BiCGStab: (s, t), (t, t) right behind t = K s */
+    const DqOp o = dq.op[0]; PetscBool done = PETSC_FALSE; PetscReal nrm2;
+    dq.busy = 1;
+    ierr = VecPMultDotNorm2_HIPMI355X(o.o, o.a, o.b, s, dp, &nrm2, &done);
+    dq.busy = 0;
+    CHKERRQ(ierr);
+    if (done) { dq.n = 0; *nm = nrm2; return 0; }
+  }
   ierr = VecHIPGetRead(s, &ds_);CHKERRQ(ierr);
   ierr = VecHIPGetRead(t, &dt);CHKERRQ(ierr);
   ierr = reduce_target(s, dc, &out);CHKERRQ(ierr);
@@ -789,7 +890,8 @@ static PetscErrorCode VecDestroy_HIP(Vec v) {
   Vec_HIPMI355X *s = VH(v);
   if (!s) return 0;
   FLUSH_DEFERRED();                                  /* a pending operation may name this vector */
-  if (dq.cz == v || dq.cr == v) dq.have = 0;
+  if (dq.ca == v || dq.cb == v) dq.have = 0;
+  for (int k = 0; k < 4; k++) if (dq.la[k] == v || dq.lb[k] == v) dq.la[k] = dq.lb[k] = NULL;
   if (s->placed_save) { s->host = s->placed_save; s->placed_save = NULL; }
   if (s->alias_save) { s->dev = s->alias_save; s->alias_save = NULL; }   /* never free storage borrowed from another vector */
   if (s->dev) mi355x_free(s->dev);

@@ -2214,6 +2214,29 @@ def test_unchanged_ksp_cg_runs_the_fused_sweep_with_the_same_bits(P, pc, norm):
         assert n1 == 0
 
 
+@pytest.mark.parametrize("norm", ["preconditioned", "none"])
+@pytest.mark.parametrize("ksp", ["bcgs", "gmres"])
+@pytest.mark.parametrize("pc", ["jacobi", "none", "ilu"])
+def test_unchanged_bcgs_and_gmres_keep_their_bits_under_the_noted_operations(P, ksp, pc, norm):
+    """KSPSolve_BCGS's calls as an unchanged program makes them: the Jacobi products are noted and run inside the VecDot / VecDotNorm2
+    that follows, VecAXPBYPCZ(X, ...) + VecWAXPY(R, ...) run inside VecNorm(R) (or, without a norm, inside VecDot(R, RP)) together with
+    (r, rp); GMRES only sees its lone products and updates noted and run at the next access.  Iterates and histories are bit for bit
+    those of the same solve with the noting off."""
+    ai, aj, aa = pb.lap2d(31, 23)
+    aa = aa * (1.0 + 0.3 * np.sin(0.7 * np.arange(aa.size)))            # non-symmetric values
+    n = ai.size - 1
+    b = orc.spmv(ai, aj, aa, np.cos(0.3 * np.arange(n)))
+    opts = "-ksp_bcgs_fused 0 -ksp_gmres_fused 0 -ksp_norm_type " + norm + (" -ksp_max_it 40" if norm == "none" else "")
+    runs = {}
+    for on in (0, 1):
+        _deferral(P, on)
+        runs[on] = solve(P, ai, aj, aa, b, ksp, pc, opts=opts, rtol=1e-9)
+    _deferral(P, -1)
+    (x0, h0, its0, r0), (x1, h1, its1, r1) = runs[0], runs[1]
+    assert r0 == r1 and its0 == its1 > 5
+    assert np.array_equal(bits(h0), bits(h1)) and np.array_equal(bits(x0), bits(x1))
+
+
 def test_deferred_vector_operations_are_transparent(P):
     """Noted-but-not-launched operations never show: every scenario (the whole CG pattern, prefixes of it read early, operand
     aliasing that must not extend the note, another norm type, swapped dot operands, a change of r between the sweep and the dot it
@@ -2240,6 +2263,29 @@ def test_deferred_vector_operations_are_transparent(P):
         elif scn == "full_swapped_operands":
             L.VecAXPY(v["x"].h, a, v["p"].h); L.VecAXPY(v["r"].h, -a, v["w"].h); L.VecPointwiseMult(v["z"].h, v["d"].h, v["r"].h)
             out += [dot(v["r"], v["z"]), nrm(v["z"])]
+        elif scn == "bcgs_update_norm_first":                      # VecDot(R, RP) of the previous iteration names rp, then the update, norm, dot
+            out += [dot(v["r"], v["d"])]
+            L.VecAXPBYPCZ(v["x"].h, a, 0.7, 1.0, v["p"].h, v["z"].h); L.VecWAXPY(v["r"].h, -0.7, v["w"].h, v["z"].h)
+            out += [nrm(v["r"]), dot(v["r"], v["d"])]
+        elif scn == "bcgs_update_dot_first":
+            L.VecAXPBYPCZ(v["x"].h, a, 0.7, 1.0, v["p"].h, v["z"].h); L.VecWAXPY(v["r"].h, -0.7, v["w"].h, v["z"].h)
+            out += [dot(v["d"], v["r"]), nrm(v["r"])]
+        elif scn == "bcgs_update_unknown_partner":
+            L.VecAXPBYPCZ(v["x"].h, a, 0.7, 1.0, v["p"].h, v["z"].h); L.VecWAXPY(v["r"].h, -0.7, v["w"].h, v["z"].h)
+            out += [nrm(v["r"])]
+        elif scn == "bcgs_update_broken":                          # another omega, another s: not the pattern
+            L.VecAXPBYPCZ(v["x"].h, a, 0.7, 1.0, v["p"].h, v["z"].h); L.VecWAXPY(v["r"].h, -0.6, v["w"].h, v["z"].h); out += [nrm(v["r"])]
+            L.VecAXPBYPCZ(v["x"].h, a, 0.7, 1.0, v["p"].h, v["z"].h); L.VecWAXPY(v["r"].h, -0.7, v["w"].h, v["d"].h); out += [nrm(v["r"])]
+            L.VecAXPBYPCZ(v["x"].h, a, 0.7, 0.5, v["p"].h, v["z"].h); L.VecWAXPY(v["r"].h, -0.7, v["w"].h, v["z"].h); out += [nrm(v["r"])]
+        elif scn == "product_then_dot":
+            L.VecPointwiseMult(v["z"].h, v["w"].h, v["d"].h); out += [dot(v["z"], v["r"])]
+            L.VecPointwiseMult(v["z"].h, v["d"].h, v["p"].h); out += [dot(v["x"], v["z"])]
+        elif scn == "product_then_dotnorm2":
+            L.VecPointwiseMult(v["z"].h, v["w"].h, v["d"].h)
+            dp, nm2 = C.c_double(), C.c_double(); L.raw("VecDotNorm2")(v["r"].h, v["z"].h, C.byref(dp), C.byref(nm2)); out += [dp.value, nm2.value]
+        elif scn == "product_then_other":
+            L.VecPointwiseMult(v["z"].h, v["w"].h, v["d"].h); out += [dot(v["x"], v["r"]), nrm(v["z"])]
+            L.VecPointwiseMult(v["z"].h, v["z"].h, v["d"].h); out += [dot(v["z"], v["r"])]
         elif scn == "copy_as_third":                               # PCApply_None
             L.VecAXPY(v["x"].h, a, v["p"].h); L.VecAXPY(v["r"].h, -a, v["w"].h); L.VecCopy(v["r"].h, v["z"].h); out += [nrm(v["z"]), dot(v["z"], v["r"])]
         elif scn == "copy_elsewhere":
@@ -2274,7 +2320,8 @@ def test_deferred_vector_operations_are_transparent(P):
         arrays = [v[k].array() for k in "xprwzd" if v[k].h]
         return out, arrays
 
-    scenarios = ["full", "full_swapped_operands", "copy_as_third", "copy_elsewhere", "one_then_read", "two_then_read", "second_reads_first", "second_writes_first", "not_negated",
+    scenarios = ["full", "full_swapped_operands", "bcgs_update_norm_first", "bcgs_update_dot_first", "bcgs_update_unknown_partner", "bcgs_update_broken",
+                 "product_then_dot", "product_then_dotnorm2", "product_then_other", "copy_as_third", "copy_elsewhere", "one_then_read", "two_then_read", "second_reads_first", "second_writes_first", "not_negated",
                  "product_overwrites_p", "product_into_w", "norm_1", "r_changes_before_the_dot", "destroy_while_noted", "host_access", "zero_alpha"]
     for scn in scenarios:
         _deferral(P, 0); o0, a0 = run(scn)
