@@ -41,6 +41,9 @@ pmc cfg5 "FETCH_SIZE WRITE_SIZE TA_BUSY_avr TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE
 # GMRES(30) kernel budget with the registered solver, and the other solvers' iteration times
 python3 $T/solver_bench.py 256 120 "-mat_hipmi355x_value_patterns 0" > $O/solver_bench_value_streamed.log 2>&1 || exit 1
 python3 $T/solver_bench.py 256 120 > $O/solver_bench_value_patterns.log 2>&1 || exit 1
+# the plain KSP types = the call sequences of an unchanged PETSc program, with the Vec type's noted operations (default) and without
+{ echo "== plain types, -vec_hipmi355x_defer 1 (default)"; python3 $T/solver_bench.py 256 120 "-mat_hipmi355x_value_patterns 0 -ksp_cg_fused 0 -ksp_gmres_fused 0 -ksp_bcgs_fused 0" cg:jacobi,gmres:jacobi,bcgs:jacobi,cg:none;
+  echo "== plain types, -vec_hipmi355x_defer 0 (every call a kernel of its own)"; python3 $T/solver_bench.py 256 120 "-mat_hipmi355x_value_patterns 0 -ksp_cg_fused 0 -ksp_gmres_fused 0 -ksp_bcgs_fused 0 -vec_hipmi355x_defer 0" cg:jacobi,gmres:jacobi,bcgs:jacobi,cg:none; } > $O/solver_bench_unchanged_program.log 2>&1 || exit 1
 stats gmres python3 $T/solver_bench.py 256 120 "-mat_hipmi355x_value_patterns 0" gmres:jacobi || exit 1
 # last, so that the JSON reads the freshly stamped counters
 cp $O/bench_pmc_summary.csv $R/profiles/bench_pmc_summary.csv
