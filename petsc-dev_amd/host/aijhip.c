@@ -264,10 +264,10 @@ PetscErrorCode MatSeqAIJHIPUpload(Mat A) {
     }
     else {   /* BAIJ: the plan partitions the VALUE stream, i.e. the block-row pointer scaled by bs*bs */
       PetscInt *sc, bs2 = a->bs * a->bs;
-      if (a->bs == 4) {   /* -mat_hipmi355x_baij4 <fma|mfma>: the row-block FMA kernel (x staged in LDS: 1.290 ms at 128^3 nodes, 27 blocks
-                           * per row) or the matrix cores (v_mfma_f64_4x4x4: 1.349 ms; it was the faster one, 1.295 against 1.402, while
-                           * the FMA kernel gathered x once per value) */
-        char kind[16] = "fma"; PetscBool set;
+      if (a->bs == 4) {   /* -mat_hipmi355x_baij4 <mfma|fma>: the matrix cores (v_mfma_f64_4x4x4, 16-byte loads: 1.22-1.28 ms at 128^3 nodes, 27
+                           * blocks per row; the default -- BASELINE configs[4]'s "MFMA 4x4 tile path") or the row-block FMA kernel with x staged
+                           * in LDS (1.25-1.32 ms in the same processes, three boxes: profiles/r03_cfg5.log) */
+        char kind[16] = "mfma"; PetscBool set;
         ierr = PetscOptionsGetString(NULL, "-mat_hipmi355x_baij4", kind, sizeof(kind), &set);CHKERRQ(ierr);
         if (strcmp(kind, "mfma") && strcmp(kind, "fma")) SETERRQ(HipObjComm(A), PETSC_ERR_ARG_WRONG, "-mat_hipmi355x_baij4 <mfma|fma>, got %s", kind);
         d->baij4_mfma = (PetscBool)!strcmp(kind, "mfma");
@@ -517,7 +517,7 @@ static PetscErrorCode MatMult_SeqAIJHIP(Mat A, Vec xx, Vec yy) {   /* MatMult_Se
   ierr = VecHIPGetRead(xx, &x);CHKERRQ(ierr);
   ierr = VecHIPGetWrite(yy, &y);CHKERRQ(ierr);
   ierr = MatTimingBegin(A, dc->h);CHKERRQ(ierr);
-  if (a->bs == 4 && d->baij4_mfma) CHKHIP(mi355x_spmv_bsr4_mfma(dc->h, a->m, 0, d->d_i, d->d_j, d->d_a, x, y));   /* matrix cores: MatMult_SeqBAIJ_4 */
+  if (a->bs == 4 && d->baij4_mfma && !(((size_t)y) & 15)) CHKHIP(mi355x_spmv_bsr4_mfma(dc->h, a->m, 0, d->d_i, d->d_j, d->d_a, x, y));   /* matrix cores: MatMult_SeqBAIJ_4 (16-byte stores of y; a vector borrowing storage at an odd offset takes the FMA kernel) */
   else if (a->bs > 1) CHKHIP(mi355x_spmv_bsr_planned(dc->h, d->plan, a->bs, d->d_i, d->d_j, d->d_a, x, y));
   else {
     if (d->cprow) CHKHIP(mi355x_vec_set(dc->h, (size_t)a->m, 0.0, y));   /* rows without entries */

@@ -260,10 +260,10 @@ def test_mat_p7_and_transpose_bitexact(P):
     fl = C.c_double(); L.PetscGetFlops(C.byref(fl)); assert fl.value > 0
 
 
-@pytest.mark.parametrize("bs,opt", [(3, ""), (4, ""), (4, "-mat_hipmi355x_baij4 mfma"), (2, ""), (5, "")])
+@pytest.mark.parametrize("bs,opt", [(3, ""), (4, ""), (4, "-mat_hipmi355x_baij4 fma"), (2, ""), (5, "")])
 def test_baij_matmult(P, bs, opt):
-    """MatMult_SeqBAIJ_N / _3 / _4 (baij2.c:331-436,981); bs = 4: the row-block FMA kernel by default, -mat_hipmi355x_baij4 mfma
-    selects the matrix cores; BASELINE.md tolerance against the oracle's restatement"""
+    """MatMult_SeqBAIJ_N / _3 / _4 (baij2.c:331-436,981); bs = 4: the matrix cores by default, -mat_hipmi355x_baij4 fma
+    selects the row-block FMA kernel; BASELINE.md tolerance against the oracle's restatement"""
     L = P.lib()
     rng = np.random.default_rng(4)
     mbs = 300
@@ -454,7 +454,7 @@ def test_config5_full_size_baij_equals_aij(P):
     b4 = np.zeros((nnzb, 4, 4)); b4[:, :3, :3] = blocks_cr
     x4 = np.zeros((mbs, 4)); x4[:, :3] = x3.reshape(mbs, 3)
     scale = np.abs(y3).max()
-    for opt in ("", "-mat_hipmi355x_baij4 mfma"):
+    for opt in ("", "-mat_hipmi355x_baij4 fma"):
         set_options(L, opt)
         A4 = P.Mat.from_bsr(4, bi, bj, b4.ravel())
         vx4, vy4 = V(P, x4.ravel()), V(P, np.zeros(mbs * 4))
