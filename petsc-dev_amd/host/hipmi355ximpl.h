@@ -160,6 +160,9 @@ PetscErrorCode HipTriFactorsDestroy(HipTriFactors **f);
 PetscErrorCode HipTriFactorsApply(Mat F, HipTriFactors *f, Vec b, Vec x, PetscLogDouble flops);
 typedef void (*HipRangeFn)(void *ctx, PetscInt lo, PetscInt hi);
 void HipParallelRanges(PetscInt n, HipRangeFn fn, void *ctx);   /* fn over contiguous parts of [0, n) on up to 16 host threads (hipsys.c); one thread below 200 000 */
+PetscErrorCode VecHIPMI355XFlushDeferred(void);                /* host/vechip.c: run the noted element-wise operations */
+PetscErrorCode VecHIPMI355XSetDeferral(PetscInt on);
+void HipFactorJoinHelpers(void);                              /* host/ilu.c: the thread that returns the factorisation's work arrays */
 PetscErrorCode HipTriWatchCheck(void);                     /* at every host wait: did a sync-free solve queued earlier give up? */
 void HipTriWatchAdd(HipTriFactors *f);
 PetscErrorCode MatICCFactorSymbolic_SeqAIJHIP(Mat F, Mat A, IS perm, const MatFactorInfo *info);

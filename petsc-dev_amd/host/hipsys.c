@@ -87,6 +87,8 @@ PetscErrorCode PetscHIPMI355XInitialize(int device) {
   return PetscHIPMI355XRegisterAll();
 }
 PetscErrorCode PetscHIPMI355XFinalize(void) {
+  HipFactorJoinHelpers();
+  (void)VecHIPMI355XFlushDeferred();
   if (devctx.initialized) {
     mi355x_handle_destroy(devctx.h);
     mi355x_handle_destroy(devctx.hcomm);

@@ -148,6 +148,9 @@ static double wall_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, 
 
 #include <pthread.h>
 #include <unistd.h>
+/* the host factorisation hands its work arrays to a thread that returns them to the system; at most one such thread: it is joined before the next one starts and by PetscHIPMI355XFinalize (never left running behind the library) */
+static pthread_t release_th; static int release_running = 0;
+void HipFactorJoinHelpers(void) { if (release_running) { pthread_join(release_th, NULL); release_running = 0; } }
 /* dependency levels of the rows of L (a row may start once the rows its L part names are done) and of U (backwards), from the
  * factor's pattern in the reference's layout; each is a sequential recurrence, the two run side by side */
 typedef struct { PetscInt n; const PetscInt *bi, *bj, *bdiag; PetscInt *lev, nlev; } RowLevArg;
@@ -392,12 +395,13 @@ static PetscErrorCode ilu0_factor_host(Mat F, Mat A, const MatFactorInfo *info) 
   }
   SETUP_TICK("factor: numeric passes");
   /* returning 16 dense work rows (2 GB of touched pages at 16.7 M rows) to the system takes 0.12 s: off the caller's path */
-  { void **junk = (void **)malloc(sizeof(void *) * (size_t)(ps.nth + 4)); pthread_t th; int k = 0;
+  { void **junk = (void **)malloc(sizeof(void *) * (size_t)(ps.nth + 4)); int k = 0;
     if (junk) {
       for (int t = 0; t < ps.nth; t++) junk[k++] = ps.rtmp[t];
       junk[k++] = ps.levptr; junk[k++] = ps.rows; junk[k++] = adiag; junk[k] = NULL;
-      if (n < 200000 || pthread_create(&th, NULL, ilu0_release_thread, junk)) ilu0_release_thread(junk);
-      else pthread_detach(th);
+      HipFactorJoinHelpers();
+      if (n < 200000 || pthread_create(&release_th, NULL, ilu0_release_thread, junk)) ilu0_release_thread(junk);
+      else release_running = 1;
     } else { for (int t = 0; t < ps.nth; t++) free(ps.rtmp[t]); HipFree(ps.levptr); HipFree(ps.rows); HipFree(adiag); }
     HipFree(ps.rtmp); }
   SETUP_TICK("factor: work arrays released");
