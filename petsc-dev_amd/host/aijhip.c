@@ -155,6 +155,7 @@ static PetscErrorCode seqaij_check_inode(Mat A) {
 static PetscErrorCode device_free(Mat A) {
   Mat_SeqAIJHIP *d = SD(A);
   if (!d) return 0;
+  { PetscErrorCode ierr = VecHIPProductMatrixChanges(A);CHKERRQ(ierr); }   /* a noted product of this matrix runs while its arrays exist */
   if (d->d_i) mi355x_free(d->d_i);
   if (d->d_j) mi355x_free(d->d_j);
   if (d->d_a) mi355x_free(d->d_a);
@@ -201,6 +202,7 @@ PetscErrorCode MatSeqAIJHIPUpload(Mat A) {
   ierr = hipaij_refresh_view_if_stale(A);CHKERRQ(ierr);
 #endif
   if (d->uploaded_state == HipObjState(A) && d->d_a) return 0;
+  ierr = VecHIPProductMatrixChanges(A);CHKERRQ(ierr);      /* (the device copy still holds the values the noted product was asked with) */
   ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
   const int up_timing = getenv("PETSC_HIPMI355X_SETUP_TIMING") != NULL;
   double up_t0 = 0.0;
@@ -487,6 +489,7 @@ static PetscErrorCode MatSetValuesBatch_SeqAIJHIP(Mat A, PetscInt nb, PetscInt b
     d->bm_vcap = d->bm_T;
   }
   CHKHIP(mi355x_memcpy_h2d(dc->h, d->bm_v, v, sizeof(PetscScalar) * d->bm_T));
+  { PetscErrorCode e__ = VecHIPProductMatrixChanges(A);CHKERRQ(e__); }
   CHKHIP(mi355x_csr_assemble(dc->h, d->bm_nseg, d->bm_segptr, d->bm_segslot, d->bm_order, d->bm_v, d->d_a));
   CHKHIP(mi355x_memcpy_d2h(dc->h, a->a, d->d_a, sizeof(PetscScalar) * (size_t)a->nz));   /* host mirror follows */
   CHKHIP(mi355x_handle_synchronize(dc->h));                    /* v and a->a are pageable host memory */
@@ -508,12 +511,26 @@ static PetscErrorCode MatAssemblyEnd_SeqAIJHIP(Mat A, MatAssemblyType mode) {
 }
 
 #endif
+static PetscErrorCode MatMult_SeqAIJHIP_device(Mat A, Vec xx, Vec yy);
+PetscErrorCode MatMultDiagonalScale_HIPMI355X(Mat A, Vec dd, Vec xx, Vec yy, PetscBool *ok);
 static PetscErrorCode MatMult_SeqAIJHIP(Mat A, Vec xx, Vec yy) {   /* MatMult_SeqAIJCUSP aijcusp.cu:349 */
+  PetscErrorCode ierr = MatSeqAIJHIPUpload(A);CHKERRQ(ierr);       /* from here on the device copy holds the values of THIS call */
+  /* a point-wise AIJ matrix on one rank: the product is noted with the Vec type (host/vechip.c, "a noted product"): if PCApply_Jacobi
+   * follows, the two become one kernel and the work vector in between is never written; anything else runs the product as it is.
+   * Whatever changes the device copy afterwards (a new upload, MatScale / MatDiagonalScale / assembly on the device, the matrix going
+   * away) first lets a noted product of this matrix run (VecHIPProductMatrixChanges). */
+  if (SA(A)->bs <= 1 && !SD(A)->cprow) {
+    PetscBool noted = PETSC_FALSE;
+    ierr = VecHIPNoteProduct(A, xx, yy, MatMult_SeqAIJHIP_device, MatMultDiagonalScale_HIPMI355X, &noted);CHKERRQ(ierr);
+    if (noted) return 0;
+  }
+  return MatMult_SeqAIJHIP_device(A, xx, yy);
+}
+static PetscErrorCode MatMult_SeqAIJHIP_device(Mat A, Vec xx, Vec yy) {   /* y = A x with the device copy as it is */
   PetscErrorCode ierr;
   HipAIJ *a = SA(A); Mat_SeqAIJHIP *d = SD(A);
   const PetscScalar *x; PetscScalar *y; PetscDeviceCtx *dc;
   ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
-  ierr = MatSeqAIJHIPUpload(A);CHKERRQ(ierr);
   ierr = VecHIPGetRead(xx, &x);CHKERRQ(ierr);
   ierr = VecHIPGetWrite(yy, &y);CHKERRQ(ierr);
   ierr = MatTimingBegin(A, dc->h);CHKERRQ(ierr);
@@ -809,6 +826,7 @@ static PetscErrorCode MatScale_SeqAIJHIP(Mat A, PetscScalar alpha) {   /* MatSca
   if (on_device) {
     PetscDeviceCtx *dc;
     ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
+    { PetscErrorCode e__ = VecHIPProductMatrixChanges(A);CHKERRQ(e__); }
     CHKHIP(mi355x_vec_scale(dc->h, vals, alpha, d->d_a));
     d->uploaded_state = HipObjState(A) + 1;
     d->t_state = -1;
@@ -825,6 +843,7 @@ static PetscErrorCode MatZeroEntries_SeqAIJHIP(Mat A) {
   if (on_device) {
     PetscDeviceCtx *dc;
     ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
+    { PetscErrorCode e__ = VecHIPProductMatrixChanges(A);CHKERRQ(e__); }
     CHKHIP(mi355x_memset(dc->h, d->d_a, 0, sizeof(PetscScalar) * vals));
     d->uploaded_state = HipObjState(A) + 1;
     d->t_state = -1;
@@ -847,6 +866,7 @@ static PetscErrorCode MatDiagonalScale_SeqAIJHIP(Mat A, Vec ll, Vec rr) {
     ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
     if (ll) { ierr = VecHIPGetRead(ll, &dl);CHKERRQ(ierr); }
     if (rr) { ierr = VecHIPGetRead(rr, &dr);CHKERRQ(ierr); }
+    { PetscErrorCode e__ = VecHIPProductMatrixChanges(A);CHKERRQ(e__); }
     CHKHIP(mi355x_csr_diagonal_scale(dc->h, a->m, d->d_i, d->d_j, d->d_a, dl, dr));
     d->uploaded_state = HipObjState(A) + 1;
     d->t_state = -1;

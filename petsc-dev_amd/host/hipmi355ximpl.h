@@ -160,6 +160,10 @@ PetscErrorCode HipTriFactorsDestroy(HipTriFactors **f);
 PetscErrorCode HipTriFactorsApply(Mat F, HipTriFactors *f, Vec b, Vec x, PetscLogDouble flops);
 typedef void (*HipRangeFn)(void *ctx, PetscInt lo, PetscInt hi);
 void HipParallelRanges(PetscInt n, HipRangeFn fn, void *ctx);   /* fn over contiguous parts of [0, n) on up to 16 host threads (hipsys.c); one thread below 200 000 */
+typedef PetscErrorCode (*HipProductNowFn)(Mat A, Vec x, Vec t);                           /* t = A x, launched now */
+typedef PetscErrorCode (*HipProductScaledFn)(Mat A, Vec d, Vec x, Vec w, PetscBool *ok);   /* w = d .* (A x) in one kernel */
+PetscErrorCode VecHIPNoteProduct(Mat A, Vec x, Vec t, HipProductNowFn now, HipProductScaledFn scaled, PetscBool *noted);   /* host/vechip.c, "a noted product" */
+PetscErrorCode VecHIPProductMatrixChanges(Mat A);              /* to be called before A's device values change or go away */
 PetscErrorCode VecHIPMI355XFlushDeferred(void);                /* host/vechip.c: run the noted element-wise operations */
 PetscErrorCode VecHIPMI355XSetDeferral(PetscInt on);
 void HipFactorJoinHelpers(void);                              /* host/ilu.c: the thread that returns the factorisation's work arrays */

@@ -67,23 +67,36 @@ static struct {
   Vec ca, cb; long sa, sb; PetscScalar cval; int have;   /* a dot product (ca, cb) left by a fused sweep, valid while both keep these states */
   Vec la[4], lb[4]; int lpos;       /* operands of the last few VecDot / VecTDot calls (BiCGStab: (r, rp) of the iteration's start names the partner the fused update needs) */
 } dq;
+/* a product noted by the Mat type (MatMult of a sequential AIJ matrix, "a noted product" below).  pp: t = A x noted, nothing launched.
+ * pl: d .* (A x) has been launched into another vector and t itself is still unwritten (written only if somebody needs it). */
+typedef struct { int on; Mat A; long astate; Vec x, t; HipProductNowFn now; HipProductScaledFn scaled; } PendingProduct;
+static PendingProduct pp, pl;
+static int pp_busy;
+static PetscErrorCode product_run(PendingProduct *q);
 static PetscErrorCode deferred_flush(void);
-#define FLUSH_DEFERRED() do { if (dq.n && !dq.busy) { PetscErrorCode e__ = deferred_flush();CHKERRQ(e__); } } while (0)
+#define FLUSH_DEFERRED() do { if ((dq.n && !dq.busy) || (pp.on && !pp_busy)) { PetscErrorCode e__ = deferred_flush();CHKERRQ(e__); } } while (0)
+/* the unwritten t of pl: a reader gets it written first; a writer of t makes it dead; a writer of x gets it written first */
+#define PP_READ(v)  do { if (pl.on && !pp_busy && (v) == pl.t) { PetscErrorCode e__ = product_run(&pl);CHKERRQ(e__); } } while (0)
+#define PP_WRITE(v) do { if (pl.on && !pp_busy) { if ((v) == pl.t) pl.on = 0; else if ((v) == pl.x) { PetscErrorCode e__ = product_run(&pl);CHKERRQ(e__); } } } while (0)
+#define PP_RW(v)    do { if (pl.on && !pp_busy && ((v) == pl.t || (v) == pl.x)) { PetscErrorCode e__ = product_run(&pl);CHKERRQ(e__); } } while (0)
 
 PetscErrorCode VecHIPGetRead(Vec v, const PetscScalar **d) {
   FLUSH_DEFERRED();
+  PP_READ(v);
   PetscErrorCode ierr = to_device(v);CHKERRQ(ierr);
   *d = VH(v)->dev;
   return 0;
 }
 PetscErrorCode VecHIPGetWrite(Vec v, PetscScalar **d) {
   FLUSH_DEFERRED();
+  PP_WRITE(v);
   PetscErrorCode ierr = dev_alloc(v);CHKERRQ(ierr);
   *d = VH(v)->dev;
   return 0;
 }
 PetscErrorCode VecHIPGetReadWrite(Vec v, PetscScalar **d) {
   FLUSH_DEFERRED();
+  PP_RW(v);
   PetscErrorCode ierr = to_device(v);CHKERRQ(ierr);
   *d = VH(v)->dev;
   return 0;
@@ -100,6 +113,7 @@ PetscErrorCode VecHIPMI355XGetArrayRead(Vec v, const PetscScalar **d) { CheckHIP
 /* ---- host access ---- */
 static PetscErrorCode VecGetArray_HIP(Vec v, PetscScalar **a) {
   FLUSH_DEFERRED();
+  PP_RW(v);
   PetscErrorCode ierr = to_host(v);CHKERRQ(ierr);
   *a = VH(v)->host;
   return 0;
@@ -110,6 +124,7 @@ static PetscErrorCode VecPlaceArray_HIP(Vec v, const PetscScalar *a) {
   Vec_HIPMI355X *s = VH(v);
   if (s->placed_save) SETERRQ(HipObjComm(v), PETSC_ERR_ARG_WRONGSTATE, "VecPlaceArray() was already called on this vector, without a call to VecResetArray()");
   FLUSH_DEFERRED();
+  PP_RW(v);
   PetscErrorCode ierr = to_host(v);CHKERRQ(ierr);
   s->placed_save = s->host;
   s->host = (PetscScalar *)a;
@@ -120,6 +135,7 @@ static PetscErrorCode VecResetArray_HIP(Vec v) {
   Vec_HIPMI355X *s = VH(v);
   if (!s->placed_save) return 0;
   FLUSH_DEFERRED();
+  PP_RW(v);
   s->host = s->placed_save;
   s->placed_save = NULL;
   s->valid = VALID_HOST;
@@ -238,8 +254,50 @@ static PetscErrorCode dq_run(const DqOp *o) {
   default: return 0;
   }
 }
+/* ---- a noted product.  KSP_PCApplyBAorAB with left preconditioning is MatMult(A, x, T) followed by PCApply(T -> V) with a work
+ * vector T nobody reads again (kspimpl.h; GMRES and BiCGStab do it once / twice per iteration).  MatMult of a sequential AIJ matrix is
+ * therefore NOTED instead of launched; when PCApply_Jacobi's VecPointwiseMult(V, T, D) follows, V = D .* (A x) is one kernel with the
+ * scaling in the product's epilogue (MatMultDiagonalScale, same bits) and T stays unwritten: any reader of T, any writer of x, a change
+ * of A's device values, storage changing hands (VecShareArray) gets T = A x written first (MatMult's own kernel); a writer of T (the
+ * next MatMult into the same work vector) simply makes it dead.  Anything else after the note runs the product as MatMult would have. */
+static PetscErrorCode product_run(PendingProduct *q) {
+  PetscErrorCode ierr;
+  if (!q->on || pp_busy) return 0;
+  const PendingProduct r = *q;
+  q->on = 0; pp_busy = 1;
+  ierr = (*r.now)(r.A, r.x, r.t);
+  pp_busy = 0;
+  CHKERRQ(ierr);
+  return 0;
+}
+/* a vector is about to be written by something that does not pass the accessors' checks (pp_busy): the unwritten t is dead if it is
+ * this vector, and is written first if its source is */
+static PetscErrorCode product_before_write(Vec w) {
+  if (!pl.on) return 0;
+  if (w == pl.t) { pl.on = 0; return 0; }
+  if (w == pl.x) return product_run(&pl);
+  return 0;
+}
+PetscErrorCode VecHIPNoteProduct(Mat A, Vec x, Vec t, HipProductNowFn now, HipProductScaledFn scaled, PetscBool *noted) {
+  PetscErrorCode ierr;
+  *noted = PETSC_FALSE;
+  if (!defer_enabled() || pp_busy || dq.busy || !is_hip(x) || !is_hip(t) || x == t || HipCommSize(HipObjComm(x)) > 1) return 0;
+  FLUSH_DEFERRED();                                   /* noted operations (they may write x) and an older noted product run first */
+  ierr = product_before_write(t);CHKERRQ(ierr);       /* this product will write t */
+  pp.on = 1; pp.A = A; pp.astate = (long)HipObjState(A); pp.x = x; pp.t = t; pp.now = now; pp.scaled = scaled;
+  *noted = PETSC_TRUE;
+  return 0;
+}
+PetscErrorCode VecHIPProductMatrixChanges(Mat A) {    /* A's device values are about to change or go away */
+  PetscErrorCode ierr;
+  if (pp_busy) return 0;
+  if (pp.on && pp.A == A) { ierr = product_run(&pp);CHKERRQ(ierr); }
+  if (pl.on && pl.A == A) { ierr = product_run(&pl);CHKERRQ(ierr); }
+  return 0;
+}
 static PetscErrorCode deferred_flush(void) {
   PetscErrorCode ierr = 0;
+  if (pp.on && !pp_busy) { ierr = product_run(&pp);CHKERRQ(ierr); }
   if (!dq.n || dq.busy) return 0;
   const int n = dq.n;
   DqOp ops[3];
@@ -250,10 +308,11 @@ static PetscErrorCode deferred_flush(void) {
   CHKERRQ(ierr);
   return 0;
 }
-PetscErrorCode VecHIPMI355XFlushDeferred(void) { return deferred_flush(); }
+PetscErrorCode VecHIPMI355XFlushDeferred(void) { PetscErrorCode ierr = deferred_flush();CHKERRQ(ierr); return product_run(&pl); }
 /* on: 1 / 0; negative: as the options database says (-vec_hipmi355x_defer, read again at the next operation) */
 PetscErrorCode VecHIPMI355XSetDeferral(PetscInt on) {
   PetscErrorCode ierr = deferred_flush();CHKERRQ(ierr);
+  ierr = product_run(&pl);CHKERRQ(ierr);
   defer_on = on < 0 ? -1 : (on ? 1 : 0);
   dq.have = 0; memset(dq.la, 0, sizeof(dq.la)); memset(dq.lb, 0, sizeof(dq.lb));
   return 0;
@@ -382,6 +441,23 @@ static PetscErrorCode VecAXPBYPCZ_HIP_now(Vec z, PetscScalar alpha, PetscScalar 
 }
 static PetscErrorCode VecPointwiseMult_HIP(Vec w, Vec x, Vec y) {
   CheckHIP(x); CheckHIP(y);
+  if (pp.on && !pp_busy && !dq.busy && is_hip(w) && (x == pp.t) != (y == pp.t)) {   /* PCApply_Jacobi right behind a noted MatMult */
+    Vec d = x == pp.t ? y : x;
+    if (w != pp.t && w != pp.x && w != d && d != pp.x && pp.scaled && (long)HipObjState(pp.A) == pp.astate) {   /* (the matrix has not been touched since) */
+      PetscBool ok = PETSC_FALSE;
+      PetscErrorCode ierr = product_before_write(w);CHKERRQ(ierr);      /* an older unwritten work vector: dead if it is w */
+      if (pl.on && d == pl.t) { ierr = product_run(&pl);CHKERRQ(ierr); }   /* (read as the diagonal: never in practice) */
+      pp_busy = 1;
+      ierr = (*pp.scaled)(pp.A, d, pp.x, w, &ok);
+      pp_busy = 0;
+      CHKERRQ(ierr);
+      if (ok) {
+        if (pl.on) { ierr = product_run(&pl);CHKERRQ(ierr); }          /* one unwritten work vector at a time */
+        pl = pp; pp.on = 0;
+        return 0;
+      }
+    }
+  }
   if (dq.n == 2 && !dq.busy && dq.op[0].kind == DQ_AXPY && is_hip(w) && (x == dq.op[1].o) != (y == dq.op[1].o)) {   /* the CG sweep's z = r .* d */
     Vec r = dq.op[1].o, d = x == r ? y : x;
     if (w != dq.op[0].o && w != r && w != dq.op[0].a && w != d && d != dq.op[0].o && d != r && w->map->n == r->map->n && d->map->n == r->map->n) {
@@ -890,6 +966,7 @@ static PetscErrorCode VecDestroy_HIP(Vec v) {
   Vec_HIPMI355X *s = VH(v);
   if (!s) return 0;
   FLUSH_DEFERRED();                                  /* a pending operation may name this vector */
+  if (pl.on && !pp_busy) { if (v == pl.t) pl.on = 0; else if (v == pl.x) { PetscErrorCode e__ = product_run(&pl);CHKERRQ(e__); } }
   if (dq.ca == v || dq.cb == v) dq.have = 0;
   for (int k = 0; k < 4; k++) if (dq.la[k] == v || dq.lb[k] == v) dq.la[k] = dq.lb[k] = NULL;
   if (s->placed_save) { s->host = s->placed_save; s->placed_save = NULL; }
@@ -928,6 +1005,8 @@ static PetscErrorCode VecShareSubArrayBegin_HIP(Vec sub, Vec parent, PetscInt of
   Vec_HIPMI355X *s = VH(sub);
   PetscScalar *dp;
   if (!parent->data || !strstr(HipObjTypeName(parent), "hipmi355x")) SETERRQ(HipObjComm(sub), PETSC_ERR_ARG_NOTSAMETYPE, "cannot share the storage of a %s vector", HipObjTypeName(parent));
+  FLUSH_DEFERRED();
+  if (pl.on && !pp_busy) { PetscErrorCode e__ = product_run(&pl);CHKERRQ(e__); }   /* storage changes hands: nothing stays unwritten across it */
   if (s->alias_save) SETERRQ(HipObjComm(sub), PETSC_ERR_ARG_WRONGSTATE, "vector already shares another vector's storage");
   if (offset < 0 || offset + sub->map->n > parent->map->n) SETERRQ(HipObjComm(sub), PETSC_ERR_ARG_SIZ, "%d entries from offset %d do not fit a vector of local size %d", sub->map->n, offset, parent->map->n);
   /* a block's output slice: the parent keeps what the other blocks have written (read-write access), unless the slice is all of it */
@@ -945,6 +1024,7 @@ static PetscErrorCode VecShareSubArrayEnd_HIP(Vec sub, Vec parent, PetscInt offs
   (void)offset;
   if (!s->alias_save) return 0;
   FLUSH_DEFERRED();                                  /* an operation pending on the borrowed storage runs before it goes back */
+  if (pl.on && !pp_busy) { PetscErrorCode e__ = product_run(&pl);CHKERRQ(e__); }
   s->dev = s->alias_save; s->valid = s->alias_valid; s->alias_save = NULL;
   HipStateIncrease(sub);
   if (write) return VecHIPRestoreWrite(parent);

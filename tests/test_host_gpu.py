@@ -2336,3 +2336,81 @@ def test_deferred_vector_operations_are_transparent(P):
     z = np.zeros(n); orc.vec_pointwise_mult(z, r, base["d"])
     assert np.array_equal(bits(a1[0]), bits(x)) and np.array_equal(bits(a1[2]), bits(r)) and np.array_equal(bits(a1[4]), bits(z))
     assert abs(o1[0] - np.linalg.norm(z)) <= 1e-13 * np.linalg.norm(z) and o1[1] == o1[2] and abs(o1[1] - z @ r) <= 1e-13 * np.sum(np.abs(z * r))
+
+
+def test_noted_products_are_transparent(P):
+    """MatMult of a sequential AIJ matrix is noted, not launched; a Jacobi product right behind it makes ONE kernel of the two and
+    leaves the work vector unwritten until somebody reads it.  Every way the sequence can go on -- the work vector read later, the
+    source vector or the matrix changed first, the work vector overwritten or combined into, vectors destroyed, a product that is
+    not followed by the pattern -- gives the bits of the same calls with the noting off."""
+    L = P.lib()
+    ai, aj, aa = pb.lap2d(23, 19)
+    aa = aa * (1.0 + 0.2 * np.sin(np.arange(aa.size)))
+    n = ai.size - 1
+    rng = np.random.default_rng(5)
+    base = {k: rng.standard_normal(n) for k in "xtwdzy"}
+
+    def run(scn):
+        A = P.Mat.from_csr(ai, aj, aa)
+        v = {k: P.Vec.from_array(base[k], comm=L.COMM_SELF) for k in "xtwdzy"}
+        out = []
+        val = C.c_double()
+
+        def dot(u, w_):
+            L.VecTDot(u.h, w_.h, C.byref(val)); return val.value
+        L.MatMult(A.h, v["x"].h, v["t"].h)
+        if scn == "read_t_later":
+            L.VecPointwiseMult(v["w"].h, v["t"].h, v["d"].h); out += [dot(v["w"], v["y"])]
+        elif scn == "operands_swapped":
+            L.VecPointwiseMult(v["w"].h, v["d"].h, v["t"].h)
+        elif scn == "x_changes_first":
+            L.VecPointwiseMult(v["w"].h, v["t"].h, v["d"].h); L.VecScale(v["x"].h, 1.7)
+        elif scn == "x_set_first":
+            L.VecPointwiseMult(v["w"].h, v["t"].h, v["d"].h); L.VecSet(v["x"].h, 3.0)
+        elif scn == "x_host_access":
+            L.VecPointwiseMult(v["w"].h, v["t"].h, v["d"].h); v["x"].set_array(base["z"])
+        elif scn == "t_overwritten_by_the_next_product":
+            L.VecPointwiseMult(v["w"].h, v["t"].h, v["d"].h); L.MatMult(A.h, v["z"].h, v["t"].h); L.VecPointwiseMult(v["y"].h, v["t"].h, v["d"].h)
+        elif scn == "t_overwritten_by_a_copy":
+            L.VecPointwiseMult(v["w"].h, v["t"].h, v["d"].h); L.VecCopy(v["z"].h, v["t"].h)
+        elif scn == "t_combined_into":
+            L.VecPointwiseMult(v["w"].h, v["t"].h, v["d"].h); L.VecAXPY(v["t"].h, 0.3, v["z"].h); L.VecAXPY(v["y"].h, 0.5, v["t"].h)
+        elif scn == "matrix_scaled_first":
+            L.VecPointwiseMult(v["w"].h, v["t"].h, v["d"].h); L.MatScale(A.h, 2.5); L.MatMult(A.h, v["x"].h, v["z"].h)
+        elif scn == "matrix_scaled_before_the_product_runs":
+            L.MatScale(A.h, 2.5)
+        elif scn == "matrix_diagonal_scaled_first":
+            L.VecPointwiseMult(v["w"].h, v["t"].h, v["d"].h); L.MatDiagonalScale(A.h, v["d"].h, v["y"].h)
+        elif scn == "x_destroyed":
+            L.VecPointwiseMult(v["w"].h, v["t"].h, v["d"].h); v["x"].destroy(); v["x"].h = C.c_void_p()
+        elif scn == "t_destroyed":
+            L.VecPointwiseMult(v["w"].h, v["t"].h, v["d"].h); v["t"].destroy(); v["t"].h = C.c_void_p()
+        elif scn == "matrix_destroyed":
+            L.VecPointwiseMult(v["w"].h, v["t"].h, v["d"].h); A.destroy(); A.h = C.c_void_p()
+        elif scn == "no_pattern_dot":
+            out += [dot(v["t"], v["y"])]
+        elif scn == "product_into_the_source":
+            L.VecPointwiseMult(v["x"].h, v["t"].h, v["d"].h)
+        elif scn == "product_by_itself":
+            L.VecPointwiseMult(v["w"].h, v["t"].h, v["t"].h)
+        elif scn == "another_product_not_t":
+            L.VecPointwiseMult(v["w"].h, v["z"].h, v["d"].h)
+        elif scn == "transpose_next":
+            L.VecPointwiseMult(v["w"].h, v["t"].h, v["d"].h); L.MatMultTranspose(A.h, v["t"].h, v["z"].h)
+        arrays = [v[k].array() for k in "xtwdzy" if v[k].h]
+        return out, arrays
+
+    scenarios = ["read_t_later", "operands_swapped", "x_changes_first", "x_set_first", "x_host_access", "t_overwritten_by_the_next_product", "t_overwritten_by_a_copy",
+                 "t_combined_into", "matrix_scaled_first", "matrix_scaled_before_the_product_runs", "matrix_diagonal_scaled_first", "x_destroyed", "t_destroyed",
+                 "matrix_destroyed", "no_pattern_dot", "product_into_the_source", "product_by_itself", "another_product_not_t", "transpose_next"]
+    for scn in scenarios:
+        _deferral(P, 0); o0, a0 = run(scn)
+        _deferral(P, 1); o1, a1 = run(scn)
+        assert np.array_equal(bits(np.array(o0)), bits(np.array(o1))), scn
+        assert len(a0) == len(a1) and all(np.array_equal(bits(u), bits(w_)) for u, w_ in zip(a0, a1)), scn
+    _deferral(P, -1)
+    # against the oracle: w = d .* (A x), t = A x
+    _deferral(P, 1); o1, a1 = run("read_t_later"); _deferral(P, -1)
+    t_ref = orc.spmv(ai, aj, aa, base["x"])
+    w_ref = np.zeros(n); orc.vec_pointwise_mult(w_ref, t_ref, base["d"])
+    assert np.array_equal(bits(a1[1]), bits(t_ref)) and np.array_equal(bits(a1[2]), bits(w_ref))
