@@ -2414,3 +2414,24 @@ def test_noted_products_are_transparent(P):
     t_ref = orc.spmv(ai, aj, aa, base["x"])
     w_ref = np.zeros(n); orc.vec_pointwise_mult(w_ref, t_ref, base["d"])
     assert np.array_equal(bits(a1[1]), bits(t_ref)) and np.array_equal(bits(a1[2]), bits(w_ref))
+
+
+def test_noting_follows_the_options_database(P):
+    """-vec_hipmi355x_defer <0|1> (read when the next operation asks; default 1) switches the noted operations: the plain CG calls run
+    the fused sweep once per iteration with it, never without it; same bits."""
+    L = P.lib()
+    ai, aj, aa = pb.lap2d(19, 17)
+    b = orc.spmv(ai, aj, aa, np.cos(0.3 * np.arange(ai.size - 1)))
+    res = {}
+    for opt in ("-vec_hipmi355x_defer 0", "-vec_hipmi355x_defer 1", ""):
+        L.VecHIPMI355XSetCGUpdateTiming(1)
+        L.PetscOptionsClear(); L.PetscOptionsInsertString(opt.encode())
+        _deferral(P, -1)                                   # "as the options database says": asked again at the next operation, inside solve()
+        x, h, its, r = solve(P, ai, aj, aa, b, "cg", "jacobi", opts="-ksp_cg_fused 0 " + opt, rtol=1e-9)
+        nl = C.c_int(); L.VecHIPMI355XGetCGUpdateTiming(C.byref(nl), None)
+        L.VecHIPMI355XSetCGUpdateTiming(0)
+        res[opt] = (bits(x).copy(), bits(h).copy(), its, nl.value)
+    _deferral(P, -1)
+    assert res["-vec_hipmi355x_defer 0"][3] == 0 and res["-vec_hipmi355x_defer 1"][3] >= res["-vec_hipmi355x_defer 1"][2] - 1 and res[""][3] == res["-vec_hipmi355x_defer 1"][3]
+    for k in ("-vec_hipmi355x_defer 1", ""):
+        assert np.array_equal(res[k][0], res["-vec_hipmi355x_defer 0"][0]) and np.array_equal(res[k][1], res["-vec_hipmi355x_defer 0"][1])
