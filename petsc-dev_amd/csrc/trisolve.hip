@@ -458,10 +458,13 @@ __device__ __forceinline__ void tri_publish(double *p, const double v, const int
   else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 template <int NB> struct TriSplitGeom {
-#ifndef TRI_SPLIT_B
-#define TRI_SPLIT_B 8
+#ifndef TRI_SPLIT_B3
+#define TRI_SPLIT_B3 16
 #endif
-  static constexpr int B = NB <= 3 ? TRI_SPLIT_B : 4;           // columns per batch (as tri_node_solve without block columns)
+  // columns per batch.  Nodes of 3 rows (3-dof FEM): 16 -- a node's newest dependencies (several nodes x 3 columns) then sit in ONE batch:
+  // FEM stand-in 14.0 -> 13.4 ms in level order, 30.4 -> 26.0 ms in the reference routine's column order (with the one-XCD form below);
+  // single rows: 8 (16: ICC(0) 35 -> 43 ms, row-granular ILU(0) 28 -> 40 ms); wider nodes: 4 (registers)
+  static constexpr int B = NB == 3 ? TRI_SPLIT_B3 : (NB <= 2 ? 8 : 4);
   static constexpr int NT = NB * (NB - 1) / 2, ND = NT + NB;
   static constexpr int HB = 64 + 3 * 256 + (NB + ND) * 512;     // header bytes: meta, info / first row / rows per lane, right-hand sides, triangle
   static constexpr int SB = B * 256 + B * NB * 512;             // stage bytes: B index rows, B * NB value rows
@@ -1183,7 +1186,8 @@ static int trisolve_plan_fill_nodes(mi355x_handle_t h, mi355x_trisolve_plan_s *p
   p->nslices = (int)((cur + W - 1) / W);
   { const char *e = getenv("MI355X_TRISOLVE_NODE_WAVES"); p->spw = e ? atoi(e) : 4; if (p->spw != 1 && p->spw != 2 && p->spw != 4) p->spw = 4; }
   { const char *e = getenv("MI355X_TRISOLVE_SPLIT"); p->split = blk ? 0 : (e ? atoi(e) != 0 : 1); if (p->split) p->spw = 1; }
-  { const char *e = getenv("MI355X_TRISOLVE_ONE_XCD"); p->one_xcd = p->split && (e ? atoi(e) != 0 : TRI_ONE_XCD_DEFAULT); }
+  // one-XCD form (trisolve_node_split_kernel): on for plans of 3-row nodes, where it was measured to gain (single-row plans lose 4 %)
+  { const char *e = getenv("MI355X_TRISOLVE_ONE_XCD"); p->one_xcd = p->split && (e ? atoi(e) != 0 : (p->nb == 3)); }
   p->nchunks = (p->nslices + p->spw - 1) / p->spw;
   const size_t np = (size_t)p->nslices * W;
   p->np = (int)np;

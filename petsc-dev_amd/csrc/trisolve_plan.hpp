@@ -9,9 +9,7 @@
 #define TRI_ALIGN_MIN 32        // by_level plans: levels of at least this many rows start on a slice boundary
 #define TRI_SPIN_LIMIT (1 << 19)   // x ~1 us per poll once backed off: gives up after ~0.5 s
 #define TRI_XCD_WORD (TRI_QUEUES * TRI_QSTRIDE)   // behind the queue counters: [0] the XCD that solves (0xffffffff: not chosen yet), [1] tickets
-#ifndef TRI_ONE_XCD_DEFAULT
-#define TRI_ONE_XCD_DEFAULT 0
-#endif
+
 
 struct mi355x_trisolve_plan_s {
   int n, nslices, nchunks, upper;
