@@ -464,7 +464,10 @@ template <int NB> struct TriSplitGeom {
   // columns per batch.  Nodes of 3 rows (3-dof FEM): 16 -- a node's newest dependencies (several nodes x 3 columns) then sit in ONE batch:
   // FEM stand-in 14.0 -> 13.4 ms in level order, 30.4 -> 26.0 ms in the reference routine's column order (with the one-XCD form below);
   // single rows: 8 (16: ICC(0) 35 -> 43 ms, row-granular ILU(0) 28 -> 40 ms); wider nodes: 4 (registers)
-  static constexpr int B = NB == 3 ? TRI_SPLIT_B3 : (NB <= 2 ? 8 : 4);
+#ifndef TRI_SPLIT_B1
+#define TRI_SPLIT_B1 8
+#endif
+  static constexpr int B = NB == 3 ? TRI_SPLIT_B3 : (NB == 1 ? TRI_SPLIT_B1 : (NB == 2 ? 8 : 4));
   static constexpr int NT = NB * (NB - 1) / 2, ND = NT + NB;
   static constexpr int HB = 64 + 3 * 256 + (NB + ND) * 512;     // header bytes: meta, info / first row / rows per lane, right-hand sides, triangle
   static constexpr int SB = B * 256 + B * NB * 512;             // stage bytes: B index rows, B * NB value rows
