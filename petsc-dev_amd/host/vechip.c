@@ -59,12 +59,13 @@ static PetscErrorCode to_host(Vec v) {   /* VecCUSPCopyFromGPU, veccusp.cu:173 *
 }
 
 /* ---- deferred CG sweep (the queue and what it is for: further down, "deferred element-wise operations") ---- */
-enum { DQ_AXPY = 1, DQ_PMULT, DQ_COPY, DQ_AXPBYPCZ, DQ_WAXPY };
+enum { DQ_AXPY = 1, DQ_PMULT, DQ_COPY, DQ_AXPBYPCZ, DQ_WAXPY, DQ_MAXPY };
 typedef struct { int kind; Vec o, a, b; PetscScalar s1, s2, s3; } DqOp;   /* o: the vector written; a, b: read; the call's scalars */
 static struct {
   int n, busy;                      /* noted operations (0..3), a prefix of one of the patterns below; busy: the note is being run */
   DqOp op[3];
   Vec ca, cb; long sa, sb; PetscScalar cval; int have;   /* a dot product (ca, cb) left by a fused sweep, valid while both keep these states */
+  PetscInt mnv; PetscScalar malpha[32]; Vec mx[32];   /* DQ_MAXPY (op[0].o += sum malpha[j] mx[j]): GMRES's update, run inside the VecNorm behind it */
   Vec la[4], lb[4]; int lpos;       /* operands of the last few VecDot / VecTDot calls (BiCGStab: (r, rp) of the iteration's start names the partner the fused update needs) */
 } dq;
 /* a product noted by the Mat type (MatMult of a sequential AIJ matrix, "a noted product" below).  pp: t = A x noted, nothing launched.
@@ -240,6 +241,7 @@ static PetscErrorCode VecAXPY_HIP_now(Vec y, PetscScalar alpha, Vec x);
 static PetscErrorCode VecPointwiseMult_HIP_now(Vec w, Vec x, Vec y);
 static PetscErrorCode VecAXPBYPCZ_HIP_now(Vec z, PetscScalar alpha, PetscScalar beta, PetscScalar gamma, Vec x, Vec y);
 static PetscErrorCode VecWAXPY_HIP_now(Vec w, PetscScalar alpha, Vec x, Vec y);
+static PetscErrorCode VecMAXPY_HIP_now(Vec y, PetscInt nv, const PetscScalar *alpha, Vec *x);
 PetscErrorCode VecCGUpdate_HIPMI355X(Vec x, Vec r, Vec z, Vec p, Vec w, Vec d, PetscScalar a, PetscScalar *zz, PetscScalar *zr, PetscScalar *rr, PetscBool *done);
 PetscErrorCode VecPMultDot_HIPMI355X(Vec w, Vec x, Vec d, Vec y, PetscScalar *val, PetscBool *done);
 PetscErrorCode VecPMultDotNorm2_HIPMI355X(Vec w, Vec x, Vec d, Vec s_, PetscScalar *dp, PetscReal *nm, PetscBool *done);
@@ -251,6 +253,7 @@ static PetscErrorCode dq_run(const DqOp *o) {
   case DQ_COPY: return VecCopy_HIP_now(o->a, o->o);
   case DQ_AXPBYPCZ: return VecAXPBYPCZ_HIP_now(o->o, o->s1, o->s2, o->s3, o->a, o->b);
   case DQ_WAXPY: return VecWAXPY_HIP_now(o->o, o->s1, o->a, o->b);
+  case DQ_MAXPY: return VecMAXPY_HIP_now(o->o, dq.mnv, dq.malpha, dq.mx);
   default: return 0;
   }
 }
@@ -500,6 +503,22 @@ static PetscErrorCode VecReciprocal_HIP(Vec x) {
   return VecHIPRestoreWrite(x);
 }
 static PetscErrorCode VecMAXPY_HIP(Vec y, PetscInt nv, const PetscScalar *alpha, Vec *x) {
+  /* KSPGMRESClassicalGramSchmidtOrthogonalization's VecMAXPY(w, -h) (borthog2.c:60-66) is followed by VecNormalize = VecNorm + VecScale
+   * (gmres.c:146): noted, it runs inside that VecNorm -- one sweep for the update and the sum of squares, same bits */
+  if (defer_enabled() && !dq.busy && !pp_busy && nv >= 1 && nv <= 32 && is_hip(y)) {
+    PetscBool ok = PETSC_TRUE;
+    for (PetscInt j = 0; j < nv && ok; j++) ok = (PetscBool)(is_hip(x[j]) && x[j] != y && x[j]->map->n == y->map->n);
+    if (ok) {
+      FLUSH_DEFERRED();
+      dq.op[0].kind = DQ_MAXPY; dq.op[0].o = y; dq.op[0].a = dq.op[0].b = NULL; dq.mnv = nv;
+      for (PetscInt j = 0; j < nv; j++) { dq.malpha[j] = alpha[j]; dq.mx[j] = x[j]; }
+      dq.n = 1;
+      return 0;
+    }
+  }
+  return VecMAXPY_HIP_now(y, nv, alpha, x);
+}
+static PetscErrorCode VecMAXPY_HIP_now(Vec y, PetscInt nv, const PetscScalar *alpha, Vec *x) {
   PetscErrorCode ierr; PetscScalar *dy; DEVCTX;
   const double **tab;
   ierr = PetscMalloc(sizeof(double *) * (size_t)nv, &tab);CHKERRQ(ierr);
@@ -603,12 +622,43 @@ static PetscErrorCode VecMDot_HIP(Vec x, PetscInt nv, const Vec y[], PetscScalar
   ierr = PetscLogFlops(PetscMax(nv * (2.0 * x->map->n - 1), 0.0));CHKERRQ(ierr);
   return 0;
 }
+/* the noted MAXPY and the sum of squares of its result in one sweep (mi355x_vec_maxpy_dev_norm2: VecMAXPY_Seq's grouping, VecNorm's order);
+ * the coefficients go to the device through a pinned staging buffer, in stream order */
+static PetscErrorCode deferred_maxpy_norm(PetscScalar *sumsq, PetscBool *done) {
+  PetscErrorCode ierr; DEVCTX;
+  static double *stage = NULL, *dcoef = NULL;
+  const double *tab[32]; PetscScalar *dy; double *out;
+  Vec y = dq.op[0].o; const PetscInt nv = dq.mnv;
+  *done = PETSC_FALSE;
+  if (!stage) {
+    if (mi355x_host_malloc((void **)&stage, sizeof(double) * 32) || mi355x_malloc((void **)&dcoef, sizeof(double) * 32)) { stage = NULL; return deferred_flush(); }
+  }
+  dq.busy = 1;
+  ierr = 0;
+  for (PetscInt j = 0; j < nv && !ierr; j++) { stage[j] = dq.malpha[j]; ierr = VecHIPGetRead(dq.mx[j], &tab[j]); }
+  if (!ierr) ierr = VecHIPGetReadWrite(y, &dy);
+  dq.busy = 0;
+  CHKERRQ(ierr);
+  dq.n = 0;
+  CHKHIP(mi355x_memcpy_h2d(dc->h, dcoef, stage, sizeof(double) * (size_t)nv));
+  ierr = reduce_target(y, dc, &out);CHKERRQ(ierr);
+  CHKHIP(mi355x_vec_maxpy_dev_norm2(dc->h, N_(y), (int)nv, dcoef, 1.0, tab, dy, out));
+  VecHIPRestoreWrite(y);
+  HipStateIncrease(y);
+  ierr = reduce_finish(y, dc, 1, 0, sumsq);CHKERRQ(ierr);
+  ierr = PetscLogFlops(nv * 2.0 * y->map->n + PetscMax(2.0 * y->map->n - 1, 0.0));CHKERRQ(ierr);
+  *done = PETSC_TRUE;
+  return 0;
+}
 static PetscErrorCode VecNorm_HIP(Vec x, NormType type, PetscReal *val) {
   PetscErrorCode ierr; const PetscScalar *dx; double *out; PetscScalar r[2]; DEVCTX;
   if (!dq.busy && !hip_local_only && type == NORM_2) {
     PetscBool done = PETSC_FALSE; PetscScalar u, v;
     if (dq_is_cg_sweep() && x == dq.op[2].o) {
       ierr = deferred_sweep(&u, &v, &done);CHKERRQ(ierr);
+      if (done) { *val = PetscSqrtReal(u); return 0; }
+    } else if (dq.n == 1 && dq.op[0].kind == DQ_MAXPY && x == dq.op[0].o) {
+      ierr = deferred_maxpy_norm(&u, &done);CHKERRQ(ierr);
       if (done) { *val = PetscSqrtReal(u); return 0; }
     } else if (dq_is_bcgs_update() && x == dq.op[1].o) {
       Vec rp = NULL;

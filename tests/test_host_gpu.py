@@ -2286,6 +2286,13 @@ def test_deferred_vector_operations_are_transparent(P):
         elif scn == "product_then_other":
             L.VecPointwiseMult(v["z"].h, v["w"].h, v["d"].h); out += [dot(v["x"], v["r"]), nrm(v["z"])]
             L.VecPointwiseMult(v["z"].h, v["z"].h, v["d"].h); out += [dot(v["z"], v["r"])]
+        elif scn in ("maxpy_norm", "maxpy_then_dot", "maxpy_norm1"):  # GMRES: VecMAXPY(w, -h, V) then VecNormalize(w)
+            vs = [v[k] for k in "prwd"]
+            al = np.array([0.3, -1.7, 0.01, 2.5])
+            tabv = (C.c_void_p * 4)(*[u.h.value for u in vs])
+            L.VecMAXPY(v["z"].h, 4, al.ctypes.data_as(C.c_void_p), tabv)
+            out += [nrm(v["z"])] if scn == "maxpy_norm" else ([dot(v["z"], v["x"])] if scn == "maxpy_then_dot" else [nrm(v["z"], 0)])
+            L.VecScale(v["z"].h, 1.0 / 3.0)
         elif scn == "copy_as_third":                               # PCApply_None
             L.VecAXPY(v["x"].h, a, v["p"].h); L.VecAXPY(v["r"].h, -a, v["w"].h); L.VecCopy(v["r"].h, v["z"].h); out += [nrm(v["z"]), dot(v["z"], v["r"])]
         elif scn == "copy_elsewhere":
@@ -2321,7 +2328,7 @@ def test_deferred_vector_operations_are_transparent(P):
         return out, arrays
 
     scenarios = ["full", "full_swapped_operands", "bcgs_update_norm_first", "bcgs_update_dot_first", "bcgs_update_unknown_partner", "bcgs_update_broken",
-                 "product_then_dot", "product_then_dotnorm2", "product_then_other", "copy_as_third", "copy_elsewhere", "one_then_read", "two_then_read", "second_reads_first", "second_writes_first", "not_negated",
+                 "product_then_dot", "product_then_dotnorm2", "product_then_other", "maxpy_norm", "maxpy_then_dot", "maxpy_norm1", "copy_as_third", "copy_elsewhere", "one_then_read", "two_then_read", "second_reads_first", "second_writes_first", "not_negated",
                  "product_overwrites_p", "product_into_w", "norm_1", "r_changes_before_the_dot", "destroy_while_noted", "host_access", "zero_alpha"]
     for scn in scenarios:
         _deferral(P, 0); o0, a0 = run(scn)
