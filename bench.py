@@ -218,7 +218,7 @@ def main():
                 "effective_gbps_vs_reference_bytes": round(ref_bytes / (ms * 1e-3) / 1e9, 1) if ms > 0 else 0.0,
                 **({"traffic_source": pmc_note} if measured is not None else {})}
 
-    def leg(ksp, value_patterns, vec_passes, what, with_dot=False):
+    def leg(ksp, value_patterns, vec_passes, what, with_dot=False, host_scalar_update=False):
         """time one configuration; its/s, and the step / its two main kernels in bytes moved"""
         L.MatHIPMI355XSetValuePatterns(timed, 1 if value_patterns else 0)
         t = timed_solve(ksp)
@@ -233,7 +233,10 @@ def main():
         if t["upd_launches"]:
             # fused CG update: x += a p, r -= a w, z = d .* r, z'z, z'r, r'r in one sweep = 8 vector passes (reads x p r w d, writes x r z);
             # the reference's five calls (VecAXPY x2, PCApply_Jacobi, VecNorm, VecTDot; cg.c:206-232) make 12
-            out["cg_update"] = kernel_roofline("reduce_kernel<4, 0, CGUpdateDevF> (fused CG update, 8 vector passes)", "CGUpdateDevF", 8 * 8 * mloc, 12 * 8 * mloc,
+            # (the registered solver's sweep takes its step length from device memory: CGUpdateDevF; the sweep the Vec type runs for the
+            # plain KSPSolve_CG gets it from the host with the call: CGUpdateF; the same 8 passes)
+            kname, ktag = (("reduce_kernel<3, 0, CGUpdateF>", "CGUpdateF>") if host_scalar_update else ("reduce_kernel<4, 0, CGUpdateDevF>", "CGUpdateDevF"))
+            out["cg_update"] = kernel_roofline(kname + " (fused CG update, 8 vector passes)", ktag, 8 * 8 * mloc, 12 * 8 * mloc,
                                                t["upd_ms"], t["upd_launches"])
         return out, t
 
@@ -304,7 +307,7 @@ def main():
         setdef = L.raw("VecHIPMI355XSetDeferral")
         setdef(1)
         ob, _ = leg(ksp_plain, False, 13, "-ksp_type cg: the plain KSPSolve_CG call sequence of an unchanged program (value array streamed); the Vec type recognises its "
-                    "update calls (VecAXPY x2, PCApply_Jacobi, VecNorm, VecTDot) and runs them as one fused sweep: SpMV + 13 vector passes")
+                    "update calls (VecAXPY x2, PCApply_Jacobi, VecNorm, VecTDot) and runs them as one fused sweep: SpMV + 13 vector passes", host_scalar_update=True)
         setdef(0)
         t1 = timed_solve(ksp_plain)
         ob["ksp_its_per_sec_every_call_its_own_kernel"] = round(args.steps / t1["dt"], 2)      # -vec_hipmi355x_defer 0: 17 vector passes
