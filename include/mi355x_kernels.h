@@ -37,6 +37,10 @@ int  mi355x_get_device(int *dev);
 int  mi355x_device_name(char *buf, size_t len);
 int  mi355x_device_synchronize(void);
 int  mi355x_mem_info(size_t *free_bytes, size_t *total_bytes);   /* hipMemGetInfo of the current device */
+/* host threads THIS process may use for the set-up passes (pattern analyses, factorisation, plan construction), at most cap:
+ * the CPUs of its affinity mask, cut to the cgroup's CPU quota, shared among the ranks torchrun started on this node
+ * (LOCAL_WORLD_SIZE); MI355X_HOST_THREADS=<n> in the environment overrides.  Never less than 1. */
+int  mi355x_host_threads(int cap);
 
 int  mi355x_handle_create(mi355x_handle_t *h);
 int  mi355x_handle_destroy(mi355x_handle_t h);

@@ -53,6 +53,9 @@ const char    *PetscHIPMI355XVersion(void);
 PetscErrorCode PetscCommSetDeviceComm(PetscComm comm, void *mi355x_comm);
 PetscErrorCode PetscCommSetDeviceComms(PetscComm comm, void *reduce, void *halo);
 PetscErrorCode PetscCommGetDeviceTransport(PetscComm comm, int *kind /*0 single,1 RCCL,2 host-staged*/, int *nranks, int *distinct_halo_comm);
+/* bench.py: microseconds per one-double ncclAllReduce on the compute stream's communicator (what VecDot_MPI / VecNorm_MPI's
+ * MPI_Allreduce, pbvec.c:9-35, pvec2.c:46-83, became), synchronised after each / queued back to back.  Collective; zeros without RCCL. */
+PetscErrorCode PetscCommDeviceAllreduceLatency(PetscComm comm, PetscInt reps, PetscLogDouble *sync_each_us, PetscLogDouble *back_to_back_us);
 
 /* PETSc names the harness does not implement because only the plugin's MPIAIJ type needs them */
 /* VecScatter, parallel -> sequential general: the MPIAIJ halo (src/vec/vec/utils/vpscat.c, vpscat.h) */
@@ -82,6 +85,12 @@ PetscErrorCode MatMPIAIJGetScatter(Mat A, VecScatter *ctx, Vec *lvec, PetscInt *
 /* per-MatMult device timing (HIP events on the compute stream around the SpMV launches) for bench.py */
 PetscErrorCode MatHIPMI355XSetTiming(Mat A, PetscBool on);
 PetscErrorCode MatHIPMI355XGetTiming(Mat A, PetscInt *nlaunches, PetscLogDouble *total_ms);
+/* the same for a MATMPIAIJHIPMI355X matrix's MatMult (mpiaij.c:1102-1116): event pairs around the diagonal-block product (compute
+ * stream) AND around the halo exchange (halo stream; VecScatterBegin_1/End_1, vpscat.h:14-233): busy time of the halo stream, how much of
+ * it lies inside the diagonal product, how long the compute stream waits for it afterwards; bytes this rank sends per product, to how many ranks */
+PetscErrorCode MatMPIAIJHIPMI355XSetHaloTiming(Mat A, PetscBool on);
+PetscErrorCode MatMPIAIJHIPMI355XGetHaloTiming(Mat A, PetscInt *nproducts, PetscLogDouble *halo_ms, PetscLogDouble *overlap_ms, PetscLogDouble *exposed_ms,
+                                               PetscLogDouble *send_bytes, PetscInt *neighbours);
 PetscErrorCode MatHIPMI355XGetUploadCount(Mat A, PetscInt *n);   /* value uploads host -> device of a sequential matrix so far */
 PetscErrorCode MatHIPMI355XGetTransposeCounts(Mat A, PetscInt *host_builds, PetscInt *device_refreshes);   /* of the cached explicit A^T behind MatMultTranspose */
 PetscErrorCode MatHIPMI355XGetInodeInfo(Mat A, PetscInt *nodes, PetscInt *groups, PetscInt *shared_indices);   /* Mat_CheckInode's node count; groups / column indices the device plan stores once per group */

@@ -2,6 +2,9 @@
 // reduction workspace), memory, events.  Everything returns hipError_t as int.
 #include "common.hpp"
 #include <string.h>
+#include <sched.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 extern "C" {
 
@@ -23,6 +26,26 @@ int mi355x_device_name(char *buf, size_t len) {
 }
 int mi355x_device_synchronize(void) { MI355X_TRY(hipDeviceSynchronize()); return 0; }
 int mi355x_mem_info(size_t *free_bytes, size_t *total_bytes) { MI355X_TRY(hipMemGetInfo(free_bytes, total_bytes)); return 0; }
+
+int mi355x_host_threads(int cap) {
+  const char *e = getenv("MI355X_HOST_THREADS");
+  if (e && atoi(e) > 0) return atoi(e) > 64 ? 64 : atoi(e);
+  long n = 1;
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof(set), &set) == 0 && CPU_COUNT(&set) > 0) n = CPU_COUNT(&set);
+  if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {          // cgroup v2 quota of this container: "<quota> <period>" or "max <period>"
+    char q[32]; long period = 0;
+    if (fscanf(f, "%31s %ld", q, &period) == 2 && strcmp(q, "max") && period > 0) {
+      long share = (atol(q) + period - 1) / period;
+      if (share >= 1 && share < n) n = share;
+    }
+    fclose(f);
+  }
+  const char *lw = getenv("LOCAL_WORLD_SIZE");                    // ranks torchrun started on this node share its cores
+  if (lw && atoi(lw) > 1) n /= atoi(lw);
+  if (n > cap) n = cap;
+  return n < 1 ? 1 : (int)n;
+}
 
 int mi355x_handle_create(mi355x_handle_t *out) {
   mi355x_handle_s *h = new mi355x_handle_s();

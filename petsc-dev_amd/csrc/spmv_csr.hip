@@ -1049,8 +1049,7 @@ int mi355x_spmv_plan_create(mi355x_handle_t h, int nrows, const int *ai_host, co
 // host threads of the pattern analyses: up to `cap`, one below 400 000 rows; MI355X_ANALYSIS_THREADS=<n> in the environment
 // forces a count (tests: the merge of the chunks' tables on small matrices), never more than one thread per row
 static int analysis_threads(int m, int cap) {
-  unsigned hc = std::thread::hardware_concurrency();
-  int nth = (int)(hc > (unsigned)cap ? (unsigned)cap : (hc < 1 ? 1u : hc));
+  int nth = mi355x_host_threads(cap);
   if (m < 400000) nth = 1;
   const char *e = getenv("MI355X_ANALYSIS_THREADS");
   if (e && atoi(e) > 0) nth = atoi(e) > 64 ? 64 : atoi(e);

@@ -845,8 +845,7 @@ template <class T> struct HostBuf {
   T *data() { return p; }
 };
 template <class F> static void host_parallel_for(long n, long grain, F f) {
-  unsigned hc = std::thread::hardware_concurrency();
-  long nth = (long)(hc > 8 ? 8 : (hc < 1 ? 1 : hc));
+  long nth = mi355x_host_threads(8);
   if (nth > n / (grain > 0 ? grain : 1)) nth = n / (grain > 0 ? grain : 1);
   if (nth <= 1) { f(0L, n); return; }
   std::vector<std::thread> th;
@@ -1029,8 +1028,7 @@ static int trisolve_plan_fill(mi355x_handle_t h, mi355x_trisolve_plan_s *p, int 
         }
       }
     };
-    unsigned hc = std::thread::hardware_concurrency();
-    int nth = (int)(hc > 8 ? 8 : (hc < 1 ? 1 : hc));
+    int nth = mi355x_host_threads(8);
     if (n < 200000) nth = 1;
     if (nth == 1) fill(0, n);
     else {
@@ -1149,8 +1147,7 @@ static int trisolve_plan_fill_nodes(mi355x_handle_t h, mi355x_trisolve_plan_s *p
         }
       }
     };
-    unsigned hc = std::thread::hardware_concurrency();
-    int nth = (int)(hc > 8 ? 8 : (hc < 1 ? 1 : hc));
+    int nth = mi355x_host_threads(8);
     if (nnodes < 100000) nth = 1;
     if (nth == 1) check(0, nnodes);
     else {
@@ -1264,8 +1261,7 @@ static int trisolve_plan_fill_nodes(mi355x_handle_t h, mi355x_trisolve_plan_s *p
         }
       }
     };
-    unsigned hc = std::thread::hardware_concurrency();
-    int nth = (int)(hc > 8 ? 8 : (hc < 1 ? 1 : hc));
+    int nth = mi355x_host_threads(8);
     if (nnodes < 100000) nth = 1;
     if (nth == 1) fill(0, nnodes);
     else {

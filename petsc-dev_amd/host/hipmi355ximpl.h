@@ -107,12 +107,16 @@ struct _p_HipScatter {
   PetscScalar *h_send, *h_recv;   /* host staging buffers of the host-staged transport */
   void *nbr_work;                 /* per-neighbour work arrays of an exchange (pointers, counts, ranks, byte counts): sized for max(to.n, from.n) */
   PetscScalar *d_local_tmp;       /* device staging of the local (self) part, local_n doubles */
+  /* per-exchange device timing for bench.py: event pairs on the HALO stream around each forward exchange (first operation after the
+   * wait on "x is final" .. last operation before "halo done") */
+  PetscBool timing; PetscInt time_n, time_cap; mi355x_event_t *time_ev;
 };
 PetscErrorCode HipScatterCreate_PtoS_MPIAIJ(MPI_Comm comm, PetscLayout xmap, PetscInt ec, const PetscInt *garray, HipScatter *ctx);
 PetscErrorCode HipScatterMarkReady(HipScatter ctx, Vec x);
 PetscErrorCode HipScatterBegin(HipScatter ctx, Vec x, Vec y, InsertMode addv, ScatterMode mode);
 PetscErrorCode HipScatterEnd(HipScatter ctx, Vec x, Vec y, InsertMode addv, ScatterMode mode);
 PetscErrorCode HipScatterDestroy(HipScatter *ctx);
+PetscErrorCode HipScatterSetTiming(HipScatter ctx, PetscBool on);
 PetscErrorCode HipScatterGetLists(HipScatter ctx, PetscInt *nrecv, const PetscInt **rprocs, const PetscInt **rstarts, const PetscInt **rindices,
                                   PetscInt *nsend, const PetscInt **sprocs, const PetscInt **sstarts, const PetscInt **sindices,
                                   PetscInt *nlocal, const PetscInt **lto, const PetscInt **lfrom);
@@ -160,6 +164,7 @@ PetscErrorCode HipTriFactorsDestroy(HipTriFactors **f);
 PetscErrorCode HipTriFactorsApply(Mat F, HipTriFactors *f, Vec b, Vec x, PetscLogDouble flops);
 typedef void (*HipRangeFn)(void *ctx, PetscInt lo, PetscInt hi);
 void HipParallelRanges(PetscInt n, HipRangeFn fn, void *ctx);   /* fn over contiguous parts of [0, n) on up to 16 host threads (hipsys.c); one thread below 200 000 */
+int HipHostThreads(int cap);                                    /* host threads this RANK may use for set-up passes: affinity mask, cgroup quota, ranks on the node (hipsys.c) */
 typedef PetscErrorCode (*HipProductNowFn)(Mat A, Vec x, Vec t);                           /* t = A x, launched now */
 typedef PetscErrorCode (*HipProductScaledFn)(Mat A, Vec d, Vec x, Vec w, PetscBool *ok);   /* w = d .* (A x) in one kernel */
 PetscErrorCode VecHIPNoteProduct(Mat A, Vec x, Vec t, HipProductNowFn now, HipProductScaledFn scaled, PetscBool *noted);   /* host/vechip.c, "a noted product" */

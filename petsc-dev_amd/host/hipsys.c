@@ -2,6 +2,7 @@
  * (The role of src/sys/objects/init.c:614 PetscOptionsCheckInitial's CUSP part and src/vec/vec/interface/dlregisvec.c
  * in the reference.) */
 #include "hipmi355ximpl.h"
+#include <time.h>
 
 const char *PetscHIPMI355XVersion(void) { return "petsc-hipmi355x 0.2 (gfx950)"; }
 
@@ -34,10 +35,12 @@ PetscErrorCode PetscDeviceGet(PetscDeviceCtx **ctx) {
 /* the set-up's bulk loops over rows (16.7 M of them for P7(256)) on host threads: contiguous ranges, nothing shared */
 typedef struct { HipRangeFn fn; void *ctx; PetscInt lo, hi; } HipRangeArg;
 static void *hip_range_thread(void *a_) { HipRangeArg *a = (HipRangeArg *)a_; a->fn(a->ctx, a->lo, a->hi); return NULL; }
+/* the affinity mask's CPUs, cut to the cgroup quota and shared among the ranks of this node (mi355x_host_threads): eight ranks of a
+ * node do not start 8 x 16 spinning threads */
+int HipHostThreads(int cap) { return mi355x_host_threads(cap); }
 void HipParallelRanges(PetscInt n, HipRangeFn fn, void *ctx) {
   HipRangeArg args[16]; pthread_t th[16]; int started[16];
-  long hw = sysconf(_SC_NPROCESSORS_ONLN);
-  int nth = (int)(hw > 16 ? 16 : (hw < 1 ? 1 : hw));
+  int nth = HipHostThreads(16);
   if (n < 200000) nth = 1;
   for (int t = 0; t < nth; t++) { args[t].fn = fn; args[t].ctx = ctx; args[t].lo = (PetscInt)((long)n * t / nth); args[t].hi = (PetscInt)((long)n * (t + 1) / nth); }
   for (int t = 1; t < nth; t++) started[t] = !pthread_create(&th[t], NULL, hip_range_thread, &args[t]);
@@ -122,6 +125,33 @@ PetscErrorCode PetscCommGetDeviceTransport(MPI_Comm comm, int *kind, int *nranks
   if (HipCommDevice(comm)) CHKHIP(mi355x_comm_rank(HipCommDevice(comm), &r, &n));
   if (nranks) *nranks = n;
   if (distinct) *distinct = (HipCommDevice(comm) && HipCommDeviceHalo(comm) != HipCommDevice(comm)) ? 1 : 0;
+  return 0;
+}
+/* bench.py: what ONE scalar all-reduce of the solvers costs on this communicator (VecDot_MPI / VecNorm_MPI's MPI_Allreduce,
+ * pbvec.c:9-35, pvec2.c:46-83, here ncclAllReduce of one double on the compute stream): reps reductions with a stream
+ * synchronise after each (sync_each_us: what a solver that reads every result on the host pays) and reps queued back to back
+ * (back_to_back_us: the device-side cost per reduction).  Collective.  Zeros without RCCL communicators. */
+PetscErrorCode PetscCommDeviceAllreduceLatency(MPI_Comm comm, PetscInt reps, PetscLogDouble *sync_each_us, PetscLogDouble *back_to_back_us) {
+  PetscErrorCode ierr;
+  PetscDeviceCtx *dc;
+  struct timespec t0, t1;
+  *sync_each_us = 0.0; *back_to_back_us = 0.0;
+  if (!HipCommDevice(comm) || reps < 1) return 0;
+  ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
+  double *ds = mi355x_handle_device_scratch(dc->h) + 16;
+  const double one = 1.0;
+  CHKHIP(mi355x_memcpy_h2d(dc->h, ds, &one, sizeof(one)));
+  for (int w = 0; w < 5; w++) CHKHIP(mi355x_comm_allreduce_max(HipCommDevice(comm), dc->h, ds, 1));
+  CHKHIP(mi355x_handle_synchronize(dc->h));
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  for (PetscInt r = 0; r < reps; r++) { CHKHIP(mi355x_comm_allreduce_max(HipCommDevice(comm), dc->h, ds, 1)); CHKHIP(mi355x_handle_synchronize(dc->h)); }
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  *sync_each_us = ((double)(t1.tv_sec - t0.tv_sec) * 1e9 + (double)(t1.tv_nsec - t0.tv_nsec)) / 1e3 / (double)reps;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  for (PetscInt r = 0; r < reps; r++) CHKHIP(mi355x_comm_allreduce_max(HipCommDevice(comm), dc->h, ds, 1));
+  CHKHIP(mi355x_handle_synchronize(dc->h));
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  *back_to_back_us = ((double)(t1.tv_sec - t0.tv_sec) * 1e9 + (double)(t1.tv_nsec - t0.tv_nsec)) / 1e3 / (double)reps;
   return 0;
 }
 #endif

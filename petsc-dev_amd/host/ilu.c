@@ -32,15 +32,23 @@ EXTERN_C_END
  * HipTriWatchCheck, called from vechip.c) looks at the flags: the first wait after an abort returns PETSC_ERR_LIB instead of
  * numbers computed from a poisoned vector, and the factor is switched to the level-by-level form of the same plans for every
  * later application (MatSolve below), ILU(0) and ICC(0) alike. */
-#define TRI_WATCH_MAX 64
-static HipTriFactors *tri_watch[TRI_WATCH_MAX];
+static HipTriFactors **tri_watch = NULL;
+static int tri_watch_cap = 0;
+/* the list grows with the number of live factors (multigrid levels, fieldsplit blocks, many KSPs); a factor that cannot be put on
+ * it (out of memory) never runs the sync-free kernels unwatched: it takes the level launches */
 void HipTriWatchAdd(HipTriFactors *f) {
-  for (int i = 0; i < TRI_WATCH_MAX; i++) if (tri_watch[i] == f) return;
-  for (int i = 0; i < TRI_WATCH_MAX; i++) if (!tri_watch[i]) { tri_watch[i] = f; return; }
+  for (int i = 0; i < tri_watch_cap; i++) if (tri_watch[i] == f) return;
+  for (int i = 0; i < tri_watch_cap; i++) if (!tri_watch[i]) { tri_watch[i] = f; return; }
+  const int ncap = tri_watch_cap ? 2 * tri_watch_cap : 64;
+  HipTriFactors **nw = (HipTriFactors **)realloc(tri_watch, sizeof(*nw) * (size_t)ncap);
+  if (!nw) { f->use_levels = 1; return; }
+  memset(nw + tri_watch_cap, 0, sizeof(*nw) * (size_t)(ncap - tri_watch_cap));
+  nw[tri_watch_cap] = f;
+  tri_watch = nw; tri_watch_cap = ncap;
 }
-static void tri_watch_remove(HipTriFactors *f) { for (int i = 0; i < TRI_WATCH_MAX; i++) if (tri_watch[i] == f) tri_watch[i] = NULL; }
+static void tri_watch_remove(HipTriFactors *f) { for (int i = 0; i < tri_watch_cap; i++) if (tri_watch[i] == f) tri_watch[i] = NULL; }
 PetscErrorCode HipTriWatchCheck(void) {
-  for (int i = 0; i < TRI_WATCH_MAX; i++) {
+  for (int i = 0; i < tri_watch_cap; i++) {
     HipTriFactors *f = tri_watch[i];
     int a = 0, b = 0;
     if (!f || !f->tri_lo || f->use_levels) continue;
@@ -200,6 +208,7 @@ typedef struct {
   PetscScalar **rtmp;                 /* a dense work row per thread */
   volatile PetscInt fail_row, fail_level; volatile PetscReal fail_value;
   volatile int go;                    /* the gate the threads start at: 1 go, -1 leave (not all of them could be created) */
+  int oversubscribed;                 /* more threads than cores of this rank */
   volatile int bar_count, bar_sense;  /* sense-reversing barrier: the levels are short (tens of microseconds), a futex sleep per level costs more */
   pthread_mutex_t mtx;
 } IluPass;
@@ -237,7 +246,9 @@ static int ilu0_factor_row(const IluPass *p, PetscScalar *rtmp, PetscInt i, Pets
 static void ilu0_barrier(IluPass *p, int *sense) {
   *sense = !*sense;
   if (__sync_add_and_fetch(&p->bar_count, 1) == p->nth) { p->bar_count = 0; __sync_synchronize(); p->bar_sense = *sense; }
-  else { int spins = 0; while (p->bar_sense != *sense) { if (++spins > 4000) { sched_yield(); spins = 0; } } }
+  else {   /* more threads than this rank's cores (an explicit -mat_factor_hipmi355x_threads): give the core away at once instead of spinning */
+    const int limit = p->oversubscribed ? 1 : 4000;
+    int spins = 0; while (p->bar_sense != *sense) { if (++spins > limit) { sched_yield(); spins = 0; } } }
   __sync_synchronize();
 }
 static void *ilu0_worker(void *arg_) {
@@ -362,12 +373,12 @@ static PetscErrorCode ilu0_factor_host(Mat F, Mat A, const MatFactorInfo *info) 
   IluPass ps;
   memset(&ps, 0, sizeof(ps));
   ps.ai = ai; ps.aj = aj; ps.aa = aa; ps.bi = bi; ps.bj = bj; ps.bdiag = bdiag; ps.ba = ba; ps.zeropivot = zeropivot; ps.n = n;
-  { PetscInt nth = 1; PetscBool set; long hw = sysconf(_SC_NPROCESSORS_ONLN);
-    if (n >= 200000) nth = (PetscInt)(hw > 16 ? 16 : (hw < 1 ? 1 : hw));
+  { PetscInt nth = 1; PetscBool set;
+    if (n >= 200000) nth = (PetscInt)HipHostThreads(16);
     ierr = PetscOptionsGetInt(NULL, "-mat_factor_hipmi355x_threads", &nth, &set);CHKERRQ(ierr);
     if (nth < 1) nth = 1;
     if (nth > 64) nth = 64;
-    ps.nth = (int)nth; }
+    ps.nth = (int)nth; ps.oversubscribed = nth > (PetscInt)HipHostThreads(64); }
   /* levels of L (the threaded passes below take a level's rows together) and of U, kept for the solves' analysis */
   HipFree(f->rlevL); HipFree(f->rlevU); f->rlevL = f->rlevU = NULL;
   ierr = ilu0_row_levels(n, bi, bj, bdiag, &f->rlevL, &f->nlevL, &f->rlevU, &f->nlevU);

@@ -345,3 +345,49 @@ PetscErrorCode MatMPIAIJGetScatter(Mat A, VecScatter *ctx, Vec *lvec, PetscInt *
   if (ec) *ec = MA(A)->ec;
   return 0;
 }
+
+/* ---- bench.py: how the halo exchange of MatMult_MPIAIJ (mpiaij.c:1102-1116; VecScatterBegin_1/End_1, vpscat.h:14-233) sits beside the
+ * diagonal-block product.  Event pairs: the diagonal product on the compute stream (MatHIPMI355XSetTiming of the diagonal block) and
+ * the exchange on the halo stream (HipScatterSetTiming), one pair of each per MatMult.  Reported over the products timed so far:
+ *   halo_ms     sum of the halo stream's busy spans (pack, grouped send/recv, unpack)
+ *   overlap_ms  the part of those spans inside the diagonal product's span
+ *   exposed_ms  what the compute stream waits for after its diagonal product has ended (halo end - product end, where positive)
+ *   send_bytes  bytes this rank sends per product, neighbours: to how many ranks ---- */
+PetscErrorCode MatMPIAIJHIPMI355XSetHaloTiming(Mat A, PetscBool on) {
+  PetscErrorCode ierr;
+  if (!A || strcmp(HipObjTypeName(A), MATMPIAIJHIPMI355X)) SETERRQ(0, PETSC_ERR_ARG_WRONG, "not an MPIAIJHIPMI355X matrix");
+  ierr = MatHIPMI355XSetTiming(MA(A)->A, on);CHKERRQ(ierr);
+  if (MA(A)->hscat) { ierr = HipScatterSetTiming(MA(A)->hscat, on);CHKERRQ(ierr); }
+  return 0;
+}
+PetscErrorCode MatMPIAIJHIPMI355XGetHaloTiming(Mat A, PetscInt *nproducts, PetscLogDouble *halo_ms, PetscLogDouble *overlap_ms, PetscLogDouble *exposed_ms,
+                                               PetscLogDouble *send_bytes, PetscInt *neighbours) {
+  if (!A || strcmp(HipObjTypeName(A), MATMPIAIJHIPMI355X)) SETERRQ(0, PETSC_ERR_ARG_WRONG, "not an MPIAIJHIPMI355X matrix");
+  HipScatter sc = MA(A)->hscat;
+  Mat_SeqAIJHIP *d = (Mat_SeqAIJHIP *)MA(A)->A->spptr;
+  double halo = 0.0, over = 0.0, expo = 0.0;
+  PetscInt n = 0;
+  if (sc && d && sc->time_ev && d->time_ev) {
+    n = PetscMin(sc->time_n, d->time_n);
+    for (PetscInt k = 0; k < n; k++) {
+      mi355x_event_t s0 = d->time_ev[2 * k], s1 = d->time_ev[2 * k + 1], h0 = sc->time_ev[2 * k], h1 = sc->time_ev[2 * k + 1];
+      float ts1 = 0.f, th0 = 0.f, th1 = 0.f;     /* all measured from the start of the diagonal product */
+      CHKHIP(mi355x_event_synchronize(s1));
+      CHKHIP(mi355x_event_synchronize(h1));
+      CHKHIP(mi355x_event_elapsed_ms(s0, s1, &ts1));
+      CHKHIP(mi355x_event_elapsed_ms(s0, h0, &th0));
+      CHKHIP(mi355x_event_elapsed_ms(s0, h1, &th1));
+      const double lo = th0 > 0.f ? th0 : 0.0, hi = th1 < ts1 ? th1 : ts1;
+      halo += (double)th1 - (double)th0;
+      if (hi > lo) over += hi - lo;
+      if (th1 > ts1) expo += (double)th1 - (double)ts1;
+    }
+  }
+  if (nproducts) *nproducts = n;
+  if (halo_ms) *halo_ms = halo;
+  if (overlap_ms) *overlap_ms = over;
+  if (exposed_ms) *exposed_ms = expo;
+  if (send_bytes) *send_bytes = sc ? (double)sizeof(PetscScalar) * (double)sc->to.starts[sc->to.n] : 0.0;
+  if (neighbours) *neighbours = sc ? sc->to.n : 0;
+  return 0;
+}

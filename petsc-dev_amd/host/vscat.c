@@ -219,6 +219,8 @@ static PetscErrorCode scatter_begin(HipScatter ctx, Vec x, Vec y, InsertMode add
     if (!ctx->ready_marked) CHKHIP(mi355x_event_record(ctx->ev_packed, dc->h));
     ctx->ready_marked = 0;
     CHKHIP(mi355x_handle_wait_event(dc->hcomm, ctx->ev_packed));
+    const PetscBool timed = (PetscBool)(ctx->timing && ctx->time_n < ctx->time_cap);
+    if (timed) CHKHIP(mi355x_event_record(ctx->time_ev[2 * ctx->time_n], dc->hcomm));
     PetscInt nsend = to->starts[to->n];
     if (nsend && !to->contiq) CHKHIP(mi355x_pack(dc->hcomm, (size_t)nsend, to->d_indices, dx, to->d_values));   /* Pack_1 */
     if (to->n || from->n) {
@@ -239,6 +241,7 @@ static PetscErrorCode scatter_begin(HipScatter ctx, Vec x, Vec y, InsertMode add
       CHKHIP(mi355x_pack(dc->hcomm, (size_t)to->local_n, to->d_local_slots, dx, ctx->d_local_tmp));
       CHKHIP(unpack_mode(dc->hcomm, addv, (size_t)to->local_n, from->d_local_slots, ctx->d_local_tmp, dy));
     }
+    if (timed) { CHKHIP(mi355x_event_record(ctx->time_ev[2 * ctx->time_n + 1], dc->hcomm)); ctx->time_n++; }
     CHKHIP(mi355x_event_record(ctx->ev_done, dc->hcomm));
   } else {
     const PetscScalar *dx; PetscScalar *dy;
@@ -298,9 +301,24 @@ PetscErrorCode HipScatterEnd(HipScatter ctx, Vec x, Vec y, InsertMode addv, Scat
   return 0;
 }
 
+/* bench.py: an event pair on the halo stream around every forward exchange from now on (on), read by the MPIAIJ matrix that owns the
+ * scatter (MatMPIAIJHIPMI355XGetHaloTiming) */
+PetscErrorCode HipScatterSetTiming(HipScatter ctx, PetscBool on) {
+  if (!ctx) SETERRQ(0, PETSC_ERR_ARG_NULL, "Null HipScatter");
+  ctx->timing = on; ctx->time_n = 0;
+  if (on && !ctx->time_ev) {
+    ctx->time_cap = 4096;
+    PetscErrorCode ierr = PetscMalloc(sizeof(mi355x_event_t) * 2 * (size_t)ctx->time_cap, &ctx->time_ev);CHKERRQ(ierr);
+    memset(ctx->time_ev, 0, sizeof(mi355x_event_t) * 2 * (size_t)ctx->time_cap);
+    for (PetscInt k = 0; k < 2 * ctx->time_cap; k++) CHKHIP(mi355x_event_create(&ctx->time_ev[k]));
+  }
+  return 0;
+}
+
 PetscErrorCode HipScatterDestroy(HipScatter *pctx) {
   HipScatter ctx = *pctx;
   if (!ctx) return 0;
+  if (ctx->time_ev) { for (PetscInt k = 0; k < 2 * ctx->time_cap; k++) if (ctx->time_ev[k]) mi355x_event_destroy(ctx->time_ev[k]); HipFree(ctx->time_ev); }
   VecScatterSide *s[2] = {&ctx->to, &ctx->from};
   for (int k = 0; k < 2; k++) {
     HipFree(s[k]->procs); HipFree(s[k]->starts); HipFree(s[k]->indices); HipFree(s[k]->local_slots);

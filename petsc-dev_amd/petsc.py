@@ -48,6 +48,8 @@ _SIG = {
     "MatSeqAIJGetArrays": [vp, P(i32), P(vp), P(vp), P(vp)], "MatMPIAIJGetSeqAIJ": [vp, P(vp), P(vp), P(vp)],
     "MatMPIAIJGetScatter": [vp, P(vp), P(vp), P(i32)],
     "MatHIPMI355XSetTiming": [vp, i32], "MatHIPMI355XGetTiming": [vp, P(i32), P(dbl)],
+    "MatMPIAIJHIPMI355XSetHaloTiming": [vp, i32], "MatMPIAIJHIPMI355XGetHaloTiming": [vp, P(i32), P(dbl), P(dbl), P(dbl), P(dbl), P(i32)],
+    "PetscCommDeviceAllreduceLatency": [vp, i32, P(dbl), P(dbl)],
     "MatHIPMI355XGetIndexCompression": [vp, P(i32)], "MatHIPMI355XGetRowPatterns": [vp, P(i32)], "MatHIPMI355XGetValuePatterns": [vp, P(i32)], "MatHIPMI355XSetValuePatterns": [vp, i32], "VecHIPMI355XSetCGUpdateTiming": [i32], "VecHIPMI355XGetCGUpdateTiming": [P(i32), P(dbl)], "MatHIPMI355XGetInodeInfo": [vp, P(i32), P(i32), P(i32)], "MatHIPMI355XGetUploadCount": [vp, P(i32)], "MatHIPMI355XGetTransposeCounts": [vp, P(i32), P(i32)],
     "PetscMiniGenPoisson7": [i32, i32, i32, C.c_long, C.c_long, vp, vp, vp, P(C.c_long)],
     "PetscViewerBinaryOpen": [vp, C.c_char_p, i32, P(vp)], "PetscViewerDestroy": [P(vp)],
@@ -63,7 +65,7 @@ _SIG = {
 
 # names exported by the plugin library; everything else in _SIG lives in the harness
 _PLUGIN = {n for n in _SIG if "HIPMI355X" in n} | {
-    "PetscCommSetDeviceComm", "PetscCommSetDeviceComms", "PetscCommGetDeviceTransport", "VecScatterBegin", "VecScatterEnd",
+    "PetscCommSetDeviceComm", "PetscCommSetDeviceComms", "PetscCommGetDeviceTransport", "PetscCommDeviceAllreduceLatency", "VecScatterBegin", "VecScatterEnd",
     "VecScatterGetLists", "MatSeqAIJGetArrays", "MatMPIAIJGetSeqAIJ", "MatMPIAIJGetScatter"}
 
 INSERT_VALUES, ADD_VALUES = 1, 2

@@ -34,3 +34,24 @@ def test_mpiaij_setup_gloo_eight_ranks_in_the_partition_of_configs2(built):
     for k in range(world):
         nb = 1 if k in (0, world - 1) else 2
         assert "rank %d/%d: MPIAIJ set-up matches the oracle (ec=%d, %d send / %d recv neighbours)" % (k, world, nb * 256, nb, nb) in out, out[-3000:]
+
+
+def test_bench_gpus_2_started_plainly_never_reports_one_gpu(built):
+    """`python bench.py --gpus 2` (no torch.distributed.run around it: the shape of the driver's N=1 command with another N) must
+    start two ranks itself or fail; it must never fall through to the one-GPU path and print an n_gpus: 1 line.  Here there is no
+    GPU: the two ranks start (gloo rendezvous on 127.0.0.1), find no device and exit non-zero; the parent relays that."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MI355X_STAGED")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--grid-n", "8", "--steps", "1", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0, (r.stdout + r.stderr)[-2000:]
+    assert "starting 2 ranks" in r.stderr
+    for line in r.stdout.splitlines():
+        if line.startswith("{"):
+            assert json.loads(line).get("n_gpus") != 1, line[:300]
+    # and a world size that contradicts --gpus is refused, not reinterpreted
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--grid-n", "8"],
+                       env=dict(env, WORLD_SIZE="2", RANK="0"), capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "WORLD_SIZE=2 but --gpus 4" in (r.stdout + r.stderr)

@@ -1449,17 +1449,36 @@ def test_ksp_vs_oracle_p7(P, ksp, pc):
     assert np.linalg.norm(x - xr) <= 1e-6 * np.linalg.norm(xr)
 
 
-def test_p7_full_size_properties(P):
+def _which_spmv(P, A):
+    """(row-pattern dictionary size, value-pattern dictionary size) of an uploaded sequential matrix: which SpMV kernel it runs"""
+    import ctypes as C
+    npat, nvpat = C.c_int(), C.c_int()
+    P.lib().MatHIPMI355XGetRowPatterns(A.h, C.byref(npat))
+    P.lib().MatHIPMI355XGetValuePatterns(A.h, C.byref(nvpat))
+    return npat.value, nvpat.value
+
+
+@pytest.mark.parametrize("value_patterns", ["default", "0"])
+def test_p7_full_size_properties(P, value_patterns):
     """BASELINE.json configs[1] at full size (P7(256): 16.8M rows) through size-independent properties:
-    A*1 is the boundary indicator pattern (row sums), linearity A(ax+by) = aAx + bAy, symmetry <Ax,y> = <x,Ay>."""
+    A*1 is the boundary indicator pattern (row sums), linearity A(ax+by) = aAx + bAy, symmetry <Ax,y> = <x,Ay>.
+    Both SpMV kernels this operator can get: the library default (value patterns: spmv_csr_valpat_kernel) and, with
+    -mat_hipmi355x_value_patterns 0, the kernel bench.py's headline and `roofline` quote (spmv_csr_rowblock_pat_kernel, the
+    value array streamed) -- and the two products agree bit for bit."""
     L = P.lib()
     n = 256
     ai, aj, aa = P.gen_poisson7(n, n, n)
+    L.PetscOptionsClear()
+    if value_patterns == "0":
+        L.PetscOptionsInsertString(b"-mat_hipmi355x_value_patterns 0")
     A = P.Mat.from_csr(ai, aj, aa)
     N = n ** 3
     one = P.Vec.create(N, comm=L.COMM_SELF); L.VecSet(one.h, 1.0)
     r = one.duplicate()
     A.mult(one, r)
+    L.PetscOptionsClear()
+    npat, nvpat = _which_spmv(P, A)
+    assert (nvpat == 0 and npat > 0) if value_patterns == "0" else nvpat > 0, (npat, nvpat)
     rs = r.array()
     expect = 6.0 - np.diff(ai) + 1.0                  # 6 - (#neighbours) ; row has 1 + #neighbours entries
     assert np.array_equal(rs, expect)
@@ -1473,26 +1492,40 @@ def test_p7_full_size_properties(P):
     L.VecAXPY(aw.h, -2.5, ax.h); L.VecAXPY(aw.h, -1.0, ay.h)
     assert aw.norm() <= 1e-12 * ax.norm()
     assert abs(ax.dot(y) - x.dot(ay)) <= 1e-12 * ax.norm() * y.norm()
+    if value_patterns == "0":
+        # the same matrix object switched to the other kernel: the product carries the same bits
+        axv = ax.array().copy()
+        L.MatHIPMI355XSetValuePatterns(A.h, 1)
+        A.mult(x, ax)
+        assert _which_spmv(P, A)[1] > 0
+        assert np.array_equal(bits(ax.array()), bits(axv))
 
 
-def test_cg_jacobi_full_size_properties(P):
+@pytest.mark.parametrize("value_patterns", ["default", "0"])
+def test_cg_jacobi_full_size_properties(P, value_patterns):
     """KSPCG + PCJACOBI at BASELINE.json's full size (P7(256)) through size-independent properties: the solve of
     A x = A*1 converges to the vector of ones, the reported (preconditioned) residual norm equals the recomputed
     ||D^-1 (b - A x)|| to 1e-6, and the fused sweeps (level 3) and the op-by-op sequence (-ksp_cg_fused 0) produce the same
-    iteration count, the same history bits and the same x bits at this size too; the default (level 4) agrees to rounding."""
+    iteration count, the same history bits and the same x bits at this size too; the default (level 4) agrees to rounding.
+    value_patterns "0": the value array streamed -- bench.py's headline configuration, whose level-4 solve runs
+    spmv_csr_rowblock_pat_kernel<0, true> (the product that also leaves p'w, the kernel `roofline` quotes)."""
     L = P.lib()
     n = 256
     ai, aj, aa = P.gen_poisson7(n, n, n)
+    vp_opt = "-mat_hipmi355x_value_patterns 0" if value_patterns == "0" else ""
+    L.PetscOptionsClear(); L.PetscOptionsInsertString(vp_opt.encode())
     A = P.Mat.from_csr(ai, aj, aa)
     N = n ** 3
     one = P.Vec.create(N, comm=L.COMM_SELF); L.VecSet(one.h, 1.0)
     b = one.duplicate(); A.mult(one, b)
+    npat, nvpat = _which_spmv(P, A)
+    assert (nvpat == 0 and npat > 0) if value_patterns == "0" else nvpat > 0, (npat, nvpat)
     outs = []
     for opts in ("-ksp_cg_fused 3", "-ksp_cg_fused 0", ""):
         x = one.duplicate(); L.VecSet(x.h, 0.0)
         k = P.KSP(comm=L.COMM_SELF)
         k.set_operators(A)
-        L.PetscOptionsClear(); L.PetscOptionsInsertString(("-ksp_type %s -pc_type jacobi %s" % (ksp_type_for("cg", opts), opts)).encode())
+        L.PetscOptionsClear(); L.PetscOptionsInsertString(("-ksp_type %s -pc_type jacobi %s %s" % (ksp_type_for("cg", opts), opts, vp_opt)).encode())
         k.set_tolerances(rtol=1e-8, max_it=5000)
         k.set_from_options()
         k.record_history()
@@ -1500,7 +1533,9 @@ def test_cg_jacobi_full_size_properties(P):
         L.PetscOptionsClear()
         outs.append((k.its, k.reason, k.history().copy(), x))
     (its, reason, h, x), (its0, reason0, h0, x0), (its4, reason4, h4, x4) = outs
+    assert _which_spmv(P, A) == (npat, nvpat)                                                      # no re-upload switched the kernel under the solves
     assert reason4 == 2 and abs(its4 - its0) <= 2 and np.max(np.abs(x4.array() - 1.0)) < 1e-4     # the default (level 4): to rounding
+    assert np.allclose(h4[:50], h0[:50], rtol=1e-9, atol=0)                                        # and so does the head of its residual history
     del x4
     assert reason == reason0 == 2 and its == its0 and 200 < its < 2000
     assert np.array_equal(bits(h), bits(h0))

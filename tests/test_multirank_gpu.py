@@ -77,3 +77,32 @@ def test_bench_two_ranks_rehearsal(built, wide):
     assert d["roofline_spmv"]["avg_launch_ms"] > 0 and d["roofline_cg_update"]["avg_launch_ms"] > 0 and d["roofline_cg_update"]["launches_timed"] == 6
     assert d["config"]["transport"] == "host-staged" and "HOST-STAGED" in d["config"]["workload"]
     assert ("P7(80,80,20)" if wide else "P7(40,40,80)") in d["config"]["workload"]
+
+
+def test_bench_started_plainly_with_gpus_2_starts_two_ranks(built):
+    """`python3 bench.py --gpus 2` with NO launcher around it (the shape of the driver's bench command): the process starts the two
+    ranks itself before touching the GPU, relays rank 0's line and reports n_gpus == 2 -- never the one-GPU path.  Two ranks on the
+    one card of this box: the host-staged rehearsal transport has to be asked for (MI355X_STAGED=1); without it the run refuses."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(MI355X_STAGED="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--grid-n", "40"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["transport"] == "host-staged" and "HOST-STAGED" in d["config"]["workload"] and "P7(40,40,80)" in d["config"]["workload"]
+    mg = d["multi_gpu"]                               # the exchange step's own figures
+    assert mg["halo_bytes_per_neighbour_per_spmv"] == 8 * 40 * 40 and mg["halo_neighbours_busiest_rank"] == 1 and mg["spmv_products_timed"] == 6
+    assert mg["halo_stream_busy_ms_per_spmv"] > 0 and 0.0 <= mg["halo_overlap_frac"] <= 1.0 and mg["halo_exposed_ms_per_spmv"] >= 0
+    assert len(mg["halo_ms_per_rank"]) == 2 and mg["transport"] == "host-staged"
+    s = d["strong"]                                   # the strong-scaling point rides along: the cube P7(80) in two slabs
+    assert s["scaling"] == "strong" and s["n_gpus"] == 2 and s["rows_total"] == 80 ** 3 and s["rows_per_gpu"] == 80 ** 3 // 2 and s["value"] > 0
+    assert s["multi_gpu"]["halo_bytes_per_neighbour_per_spmv"] == 8 * 80 * 80
+    # not asked for: two ranks on one card are refused, with no line at all
+    env.pop("MI355X_STAGED")
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")], (r.stdout + r.stderr)[-2000:]
+    assert "MI355X_STAGED=1" in (r.stdout + r.stderr)
