@@ -101,6 +101,18 @@ KERNEL_API = {
     "mi355x_spmv_csr_scaled": [vp, vp, vp, vp, vp, vp, vp, vp],
     "mi355x_spmv_csr_dot": [vp, vp, vp, vp, vp, vp, vp],
     "mi355x_spmv_dot_finish": [vp, vp, vp],
+    "mi355x_spmv_tiled_probe": [i32, vp, vp, C.POINTER(dbl)],
+    "mi355x_spmv_tiled_build": [i32, i32, vp, vp, i32, C.POINTER(vp)],
+    "mi355x_spmv_tiled_info": [vp, C.POINTER(C.c_long), C.POINTER(C.c_long), pi32, pi32, pi32],
+    "mi355x_spmv_tiled_geometry": [pi32, pi32, pi32, pi32, pi32],
+    "mi355x_spmv_tiled_upload": [vp, vp, vp],
+    "mi355x_spmv_tiled_refresh_values": [vp, vp, vp],
+    "mi355x_spmv_tiled": [vp, vp, vp, vp, vp],
+    "mi355x_spmv_tiled_parts": [vp, vp, vp, vp, vp, i32],
+    "mi355x_spmv_tiled_debug_get": [vp, i32, vp, sz, C.POINTER(sz)],
+    "mi355x_spmv_tiled_drop_host": [vp],
+    "mi355x_spmv_tiled_destroy": [vp],
+    "mi355x_host_threads": [i32],
     "mi355x_csr_get_diagonal": [vp, i32, vp, vp, vp, vp],
     "mi355x_csr_diagonal_scale": [vp, i32, vp, vp, vp, vp, vp],
     "mi355x_csr_assemble": [vp, i32, vp, vp, vp, vp, vp],

@@ -165,6 +165,7 @@ static PetscErrorCode device_free(Mat A) {
   if (d->t_a) mi355x_free(d->t_a);
   if (d->t_plan) mi355x_spmv_plan_destroy(d->t_plan);
   if (d->t_perm) mi355x_free(d->t_perm);
+  if (d->tiled) mi355x_spmv_tiled_destroy(d->tiled);
   if (d->bm_order) mi355x_free(d->bm_order);
   if (d->bm_segptr) mi355x_free(d->bm_segptr);
   if (d->bm_segslot) mi355x_free(d->bm_segslot);
@@ -263,6 +264,34 @@ PetscErrorCode MatSeqAIJHIPUpload(Mat A) {
         CHKHIP(mi355x_spmv_plan_is_compressed(d->plan, &ntab));
         if (!ntab && !use_cprow) CHKHIP(mi355x_spmv_plan_group_rows(dc->h, d->plan, a->i, a->j, a->inode_count, a->inode_size));
       }
+      /* -mat_hipmi355x_tiled <-1|0|1> (default -1 = decide): the column-tiled product (csrc/spmv_tiled.hip).  A matrix that got neither
+       * an offset dictionary nor grouped rows gathers x once per nonzero; when a sample of its 32-row groups shows those gathers
+       * landing on lines of x of their own (> 0.5 line per nonzero: rows that share no columns with their neighbours -- the
+       * irregular matrices of BASELINE configs[3]) and it is large enough for x to leave the L2 (>= 2^17 columns), the product is
+       * re-cut into row panels x column tiles with the tiles of x staged in LDS; kept only if at least half of the nonzeros fall into
+       * pairs worth staging.  -mat_hipmi355x_tiled_stage_min <n> (default 1024): entries a (panel, tile) pair needs to be staged. */
+      {
+        PetscInt tl = -1, smin = 0; PetscBool set; int ntab = 0, ng = 0; long ngj = 0;
+        ierr = PetscOptionsGetInt(NULL, "-mat_hipmi355x_tiled", &tl, &set);CHKERRQ(ierr);
+        ierr = PetscOptionsGetInt(NULL, "-mat_hipmi355x_tiled_stage_min", &smin, &set);CHKERRQ(ierr);
+        CHKHIP(mi355x_spmv_plan_is_compressed(d->plan, &ntab));
+        CHKHIP(mi355x_spmv_plan_group_info(d->plan, &ng, &ngj, NULL));
+        if (tl != 0 && !use_cprow && !ntab && !ng && a->nz > 0) {
+          PetscBool want = (PetscBool)(tl > 0);
+          if (tl < 0 && a->n >= (1 << 17) && a->nz >= (1 << 22)) {
+            double lpn = 0.0;
+            CHKHIP(mi355x_spmv_tiled_probe(a->m, a->i, a->j, &lpn));
+            want = (PetscBool)(lpn > 0.5);
+          }
+          if (want) {
+            long staged = 0, rest = 0;
+            CHKHIP(mi355x_spmv_tiled_build(a->m, a->n, a->i, a->j, (int)smin, &d->tiled));
+            CHKHIP(mi355x_spmv_tiled_info(d->tiled, &staged, &rest, NULL, NULL, NULL));
+            if (tl < 0 && 2 * staged < (long)a->nz) { mi355x_spmv_tiled_destroy(d->tiled); d->tiled = NULL; }
+          }
+          UP_TICK("column-tiled layout");
+        }
+      }
     }
     else {   /* BAIJ: the plan partitions the VALUE stream, i.e. the block-row pointer scaled by bs*bs */
       PetscInt *sc, bs2 = a->bs * a->bs;
@@ -290,6 +319,12 @@ PetscErrorCode MatSeqAIJHIPUpload(Mat A) {
   UP_TICK("(grouped rows, bookkeeping)");
   CHKHIP(mi355x_memcpy_h2d(dc->h, d->d_a, a->a, sizeof(PetscScalar) * vals));
   UP_TICK("values up");
+  if (d->tiled) {
+    if (!same_pattern) { CHKHIP(mi355x_spmv_tiled_upload(dc->h, d->tiled, d->d_a)); CHKHIP(mi355x_spmv_tiled_drop_host(d->tiled)); }
+    else CHKHIP(mi355x_spmv_tiled_refresh_values(dc->h, d->tiled, d->d_a));
+    d->tiled_fresh = PETSC_TRUE;
+    UP_TICK("column-tiled values");
+  }
   if (a->bs <= 1 && d->plan) {
     /* -mat_hipmi355x_value_patterns <0|1> (default 1): constant-coefficient operators -- whole rows, offsets and values,
      * from a dictionary of <= 512 entries -- run a kernel that reads 2 bytes per row and no values (spmv_csr_valpat_kernel);
@@ -496,7 +531,7 @@ static PetscErrorCode MatSetValuesBatch_SeqAIJHIP(Mat A, PetscInt nb, PetscInt b
   /* MatSetValuesBatch's wrapper leaves the state alone and the MatAssemblyEnd that has to follow bumps it once: the
    * device copy is stamped with that state, so the assembly does not trigger an upload */
   d->uploaded_state = HipObjState(A) + 1;
-  d->t_state = -1;
+  d->t_state = -1; d->tiled_fresh = PETSC_FALSE;
   CHKHIP(mi355x_spmv_plan_drop_value_patterns(d->plan));
   ierr = PetscLogFlops((PetscLogDouble)d->bm_T);CHKERRQ(ierr);
   return 0;
@@ -513,6 +548,13 @@ static PetscErrorCode MatAssemblyEnd_SeqAIJHIP(Mat A, MatAssemblyType mode) {
 #endif
 static PetscErrorCode MatMult_SeqAIJHIP_device(Mat A, Vec xx, Vec yy);
 PetscErrorCode MatMultDiagonalScale_HIPMI355X(Mat A, Vec dd, Vec xx, Vec yy, PetscBool *ok);
+/* the column-tiled form keeps its own copy of the values in its own order: after a device-side change of d_a (MatScale,
+ * MatDiagonalScale, MatZeroEntries, MatSetValuesBatch on the device copy) one gather brings it up to date, when it is next used */
+static PetscErrorCode tiled_values_current(Mat A, PetscDeviceCtx *dc) {
+  Mat_SeqAIJHIP *d = SD(A);
+  if (d->tiled && !d->tiled_fresh) { CHKHIP(mi355x_spmv_tiled_refresh_values(dc->h, d->tiled, d->d_a)); d->tiled_fresh = PETSC_TRUE; }
+  return 0;
+}
 static PetscErrorCode MatMult_SeqAIJHIP(Mat A, Vec xx, Vec yy) {   /* MatMult_SeqAIJCUSP aijcusp.cu:349 */
   PetscErrorCode ierr = MatSeqAIJHIPUpload(A);CHKERRQ(ierr);       /* from here on the device copy holds the values of THIS call */
   /* a point-wise AIJ matrix on one rank: the product is noted with the Vec type (host/vechip.c, "a noted product"): if PCApply_Jacobi
@@ -537,8 +579,12 @@ static PetscErrorCode MatMult_SeqAIJHIP_device(Mat A, Vec xx, Vec yy) {   /* y =
   if (a->bs == 4 && d->baij4_mfma && !(((size_t)y) & 15)) CHKHIP(mi355x_spmv_bsr4_mfma(dc->h, a->m, 0, d->d_i, d->d_j, d->d_a, x, y));   /* matrix cores: MatMult_SeqBAIJ_4 (16-byte stores of y; a vector borrowing storage at an odd offset takes the FMA kernel) */
   else if (a->bs > 1) CHKHIP(mi355x_spmv_bsr_planned(dc->h, d->plan, a->bs, d->d_i, d->d_j, d->d_a, x, y));
   else {
-    if (d->cprow) CHKHIP(mi355x_vec_set(dc->h, (size_t)a->m, 0.0, y));   /* rows without entries */
-    CHKHIP(mi355x_spmv_csr(dc->h, d->plan, d->d_i, d->d_j, d->d_a, x, y));
+    int rc = 801;
+    if (d->tiled) { ierr = tiled_values_current(A, dc);CHKERRQ(ierr); rc = mi355x_spmv_tiled(dc->h, d->tiled, x, NULL, y); if (rc && rc != 801) CHKHIP(rc); }
+    if (rc) {                                                            /* no tiled form, or an x it cannot take (storage borrowed at an odd offset) */
+      if (d->cprow) CHKHIP(mi355x_vec_set(dc->h, (size_t)a->m, 0.0, y));   /* rows without entries */
+      CHKHIP(mi355x_spmv_csr(dc->h, d->plan, d->d_i, d->d_j, d->d_a, x, y));
+    }
   }
   ierr = MatTimingEnd(A, dc->h);CHKERRQ(ierr);
   ierr = VecHIPRestoreWrite(yy);CHKERRQ(ierr);
@@ -570,6 +616,18 @@ PetscErrorCode MatHIPMI355XGetIndexCompression(Mat A, PetscInt *noffsets) {
   ierr = MatSeqAIJHIPUpload(A);CHKERRQ(ierr);
   if (SD(A)->plan && SA(A)->bs <= 1) CHKHIP(mi355x_spmv_plan_is_compressed(SD(A)->plan, &ntab));
   *noffsets = ntab;
+  return 0;
+}
+
+/* the column-tiled form of a sequential matrix's product, if the analysis chose it: nonzeros that gather from LDS tiles / that stay in
+ * the CSR remainder (both 0: the row-block kernels run) */
+PetscErrorCode MatHIPMI355XGetTiledInfo(Mat A, PetscInt *staged, PetscInt *remainder) {
+  PetscErrorCode ierr; long s_ = 0, r_ = 0;
+  *staged = 0; *remainder = 0;
+  if (!A || A->ops->mult != MatMult_SeqAIJHIP) return 0;
+  ierr = MatSeqAIJHIPUpload(A);CHKERRQ(ierr);
+  if (SD(A)->tiled) CHKHIP(mi355x_spmv_tiled_info(SD(A)->tiled, &s_, &r_, NULL, NULL, NULL));
+  *staged = (PetscInt)s_; *remainder = (PetscInt)r_;
   return 0;
 }
 
@@ -717,7 +775,7 @@ PetscErrorCode MatMultDiagonalScale_HIPMI355X(Mat A, Vec dd, Vec xx, Vec yy, Pet
   if (a->bs > 1 || xx == yy || dd == yy || xx->map->n != a->n || yy->map->n != a->m || dd->map->n != a->m) return 0;
   ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
   ierr = MatSeqAIJHIPUpload(A);CHKERRQ(ierr);
-  if (!d->plan || d->cprow) return 0;
+  if (!d->plan || d->cprow || d->tiled) return 0;         /* (the column-tiled product has no scaling epilogue: the two calls stay two) */
   ierr = VecHIPGetRead(xx, &x);CHKERRQ(ierr);
   ierr = VecHIPGetRead(dd, &dg);CHKERRQ(ierr);
   ierr = VecHIPGetWrite(yy, &y);CHKERRQ(ierr);
@@ -746,7 +804,9 @@ static PetscErrorCode MatMultAdd_SeqAIJHIP(Mat A, Vec xx, Vec yy, Vec zz) {   /*
     if (d->cprow) { CHKHIP(mi355x_vec_copy(dc->h, (size_t)a->m, y, z)); y = z; }   /* aij.c:1314-1316 */
   }
   ierr = MatTimingBegin(A, dc->h);CHKERRQ(ierr);
-  CHKHIP(mi355x_spmv_csr_add(dc->h, d->plan, d->d_i, d->d_j, d->d_a, x, y, z));
+  { int rc = 801;
+    if (d->tiled) { ierr = tiled_values_current(A, dc);CHKERRQ(ierr); rc = mi355x_spmv_tiled(dc->h, d->tiled, x, y, z); if (rc && rc != 801) CHKHIP(rc); }
+    if (rc) CHKHIP(mi355x_spmv_csr_add(dc->h, d->plan, d->d_i, d->d_j, d->d_a, x, y, z)); }
   ierr = MatTimingEnd(A, dc->h);CHKERRQ(ierr);
   ierr = VecHIPRestoreWrite(zz);CHKERRQ(ierr);
   ierr = PetscLogFlops(2.0 * a->nz);CHKERRQ(ierr);
@@ -829,7 +889,7 @@ static PetscErrorCode MatScale_SeqAIJHIP(Mat A, PetscScalar alpha) {   /* MatSca
     { PetscErrorCode e__ = VecHIPProductMatrixChanges(A);CHKERRQ(e__); }
     CHKHIP(mi355x_vec_scale(dc->h, vals, alpha, d->d_a));
     d->uploaded_state = HipObjState(A) + 1;
-    d->t_state = -1;
+    d->t_state = -1; d->tiled_fresh = PETSC_FALSE;
     CHKHIP(mi355x_spmv_plan_drop_value_patterns(d->plan));
   }
   return PetscLogFlops((PetscLogDouble)vals);
@@ -846,7 +906,7 @@ static PetscErrorCode MatZeroEntries_SeqAIJHIP(Mat A) {
     { PetscErrorCode e__ = VecHIPProductMatrixChanges(A);CHKERRQ(e__); }
     CHKHIP(mi355x_memset(dc->h, d->d_a, 0, sizeof(PetscScalar) * vals));
     d->uploaded_state = HipObjState(A) + 1;
-    d->t_state = -1;
+    d->t_state = -1; d->tiled_fresh = PETSC_FALSE;
     CHKHIP(mi355x_spmv_plan_drop_value_patterns(d->plan));
   }
   return 0;
@@ -869,7 +929,7 @@ static PetscErrorCode MatDiagonalScale_SeqAIJHIP(Mat A, Vec ll, Vec rr) {
     { PetscErrorCode e__ = VecHIPProductMatrixChanges(A);CHKERRQ(e__); }
     CHKHIP(mi355x_csr_diagonal_scale(dc->h, a->m, d->d_i, d->d_j, d->d_a, dl, dr));
     d->uploaded_state = HipObjState(A) + 1;
-    d->t_state = -1;
+    d->t_state = -1; d->tiled_fresh = PETSC_FALSE;
     CHKHIP(mi355x_spmv_plan_drop_value_patterns(d->plan));
   }
   if (ll) {

@@ -197,6 +197,9 @@ typedef struct {
   PetscInt bm_nb, bm_bs, bm_nseg; unsigned long long bm_hash; size_t bm_T, bm_vcap;
   PetscInt *bm_order, *bm_segptr, *bm_segslot;   /* device */
   PetscScalar *bm_v;                             /* device staging of the element values */
+  /* column-tiled form of the product (csrc/spmv_tiled.hip: x staged in LDS) for matrices whose gathers miss the caches; NULL: the
+   * row-block kernels.  tiled_fresh: its values are those of d_a */
+  mi355x_spmv_tiled_t tiled; PetscBool tiled_fresh;
   /* per-launch device timing for bench.py (hipEvent pairs on the compute stream) */
   PetscBool timing; PetscInt time_n, time_cap; mi355x_event_t *time_ev;
 #if defined(PETSCHIPMI355X_WITH_PETSC)

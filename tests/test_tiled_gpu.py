@@ -1,0 +1,174 @@
+"""The column-tiled SpMV (csrc/spmv_tiled.hip: x tiles staged in LDS) on the GPU, through the C ABI and through MatMult:
+the staged part bit for bit against the host reading of the layout (tests/tiled.py: the kernel's own order), the whole
+product against the oracle's MatMult_SeqAIJ (aij.c:1225-1285) within 1e-12 * sum |a_ij x_j| (a row's staged products are
+added in column order, the remainder's after them: another order than the reference's, hence a tolerance), MatMultAdd, value
+refreshes after device-side changes, and the choice the Mat type makes."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import orc
+import tiled
+from test_tiled_cpu import random_csr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev(built):
+    from gpu import Dev
+    d = Dev()
+    yield d
+    d.free_all()
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint64)
+
+
+def run_case(dev, ai, aj, aa, n, stage_min, seed=0):
+    k = dev.k
+    m = ai.size - 1
+    plan = tiled.build(k, ai, aj, n, stage_min)
+    try:
+        rowof = np.repeat(np.arange(m), np.diff(ai))
+        x = np.sin(0.37 * np.arange(n)) + 1.0
+        yin = np.random.default_rng(seed).standard_normal(m)
+        # what the kernel must produce for the staged part, from the host copy of the layout (before the upload drops nothing: the
+        # host copy lives until _drop_host)
+        (rows, cols, pos), _ = tiled.walk(k, plan, m)
+        near = np.zeros(m); near_add = yin.copy()
+        for r, c, q in zip(rows, cols, pos):
+            near[r] = near[r] + aa[q] * x[c]
+            near_add[r] = near_add[r] + aa[q] * x[c]
+        inf = tiled.info(k, plan)
+        daa = dev.put(np.concatenate((aa, [0.0, 0.0])))
+        dx, dyin = dev.put(x), dev.put(yin)
+        dy = dev.alloc(8 * max(m, 2))
+        dev.chk(k.mi355x_spmv_tiled_upload(dev.h, plan, daa))
+        # staged part alone: the kernel's order is the layout's order
+        dev.chk(k.mi355x_spmv_tiled_parts(dev.h, plan, dx, None, dy, 1))
+        assert np.array_equal(bits(dev.get(dy, m)), bits(near))
+        dev.chk(k.mi355x_spmv_tiled_parts(dev.h, plan, dx, dyin, dy, 1))
+        assert np.array_equal(bits(dev.get(dy, m)), bits(near_add))
+        # the whole product against the oracle
+        scale = np.zeros(m)
+        np.add.at(scale, rowof, np.abs(aa * x[aj]))
+        ref = orc.spmv(ai, aj, aa, x) if m else np.zeros(0)
+        dev.chk(k.mi355x_spmv_tiled(dev.h, plan, dx, None, dy))
+        y = dev.get(dy, m)
+        assert np.all(np.abs(y - ref) <= 1e-12 * scale + 1e-300)
+        if inf["remainder"] == 0:
+            assert np.array_equal(bits(y), bits(ref))          # one stream in column order from 0: the reference's bits
+        refadd = orc.spmv_add(ai, aj, aa, x, yin) if m else np.zeros(0)
+        dev.chk(k.mi355x_spmv_tiled(dev.h, plan, dx, dyin, dy))
+        assert np.all(np.abs(dev.get(dy, m) - refadd) <= 1e-12 * (scale + np.abs(yin)) + 1e-300)
+        dev.chk(k.mi355x_spmv_tiled(dev.h, plan, dx, dyin, dyin))                     # in place
+        assert np.all(np.abs(dev.get(dyin, m) - refadd) <= 1e-12 * (scale + np.abs(yin)) + 1e-300)
+        # an x the kernel cannot take (8-byte aligned only): refused, nothing launched
+        if n > 2:
+            dxo = C.c_void_p(dx.value + 8)
+            assert k.mi355x_spmv_tiled(dev.h, plan, dxo, None, dy) == 801
+        # new values under the same pattern
+        aa2 = aa * 1.7 - 0.3
+        dev.chk(k.mi355x_memcpy_h2d(dev.h, daa, aa2.ctypes.data, aa2.nbytes))
+        dev.chk(k.mi355x_spmv_tiled_refresh_values(dev.h, plan, daa))
+        dev.chk(k.mi355x_spmv_tiled(dev.h, plan, dx, None, dy))
+        ref2 = orc.spmv(ai, aj, aa2, x) if m else np.zeros(0)
+        scale2 = np.zeros(m)
+        np.add.at(scale2, rowof, np.abs(aa2 * x[aj]))
+        assert np.all(np.abs(dev.get(dy, m) - ref2) <= 1e-12 * scale2 + 1e-300)
+        return inf
+    finally:
+        k.mi355x_spmv_tiled_destroy(plan)
+        dev.free_all()
+
+
+def test_tiled_spmv_matches_its_layout_bitwise_and_the_oracle(dev):
+    rng = np.random.default_rng(15)
+    g = tiled.geometry(dev.k)
+    m = 2 * g["panel"] + 333
+    n = 5 * g["tw"] + 77
+    lens = np.clip(np.exp(rng.normal(3.2, 0.7, m)), 0, 300).astype(int)
+    lens[::23] = 0
+    ai, aj, aa = random_csr(rng, m, n, lens, band=6000, far_frac=0.2)
+    inf = run_case(dev, ai, aj, aa, n, stage_min=3000)
+    assert inf["staged"] > 0 and inf["remainder"] > 0
+    run_case(dev, ai, aj, aa, n, stage_min=1)                    # everything staged
+    run_case(dev, ai, aj, aa, n, stage_min=10 ** 9)              # everything remainder
+
+
+def test_tiled_spmv_long_rows_and_degenerate_shapes(dev):
+    rng = np.random.default_rng(16)
+    g = tiled.geometry(dev.k)
+    m, n = 300, g["tw"] + 500
+    lens = np.full(m, 5); lens[7] = 1800; lens[8] = 700; lens[130] = 513; lens[299] = 3000
+    ai, aj, aa = random_csr(rng, m, n, lens, band=n, far_frac=0.0)
+    run_case(dev, ai, aj, aa, n, stage_min=1)
+    run_case(dev, np.array([0, 1], np.int32), np.array([0], np.int32), np.array([2.5]), 1, stage_min=1)
+    run_case(dev, np.zeros(50, np.int32), np.zeros(0, np.int32), np.zeros(0), 10, stage_min=1)
+    m, n = g["panel"], 2 * g["tw"]
+    ai, aj, aa = random_csr(rng, m, n, np.full(m, 6), band=2000, far_frac=0.1)
+    run_case(dev, ai, aj, aa, n, stage_min=32)
+
+
+def test_mat_type_chooses_the_tiled_product_and_keeps_it_current(built):
+    """Through MatMult: -mat_hipmi355x_tiled 1 forces the column-tiled product on a small matrix, the default (decide) leaves small
+    matrices and stencils alone; MatScale / MatDiagonalScale on the device copy reach the tiled values; MatMultAdd uses it too."""
+    from petsc_dev_amd import petsc as P
+    L = P.lib()
+    rng = np.random.default_rng(17)
+    m = n = 30000
+    ai, aj, aa = random_csr(rng, m, n, np.clip(np.exp(rng.normal(3.0, 0.6, m)), 1, 200).astype(int), band=5000, far_frac=0.2)
+    rowof = np.repeat(np.arange(m), np.diff(ai))
+    xh = np.cos(0.3 * np.arange(n)) + 0.5
+
+    def tol(a):
+        s = np.zeros(m)
+        np.add.at(s, rowof, np.abs(a * xh[aj]))
+        return 1e-12 * s + 1e-300
+
+    L.PetscOptionsClear()
+    A0 = P.Mat.from_csr(ai, aj, aa)
+    x = P.Vec.from_array(xh, comm=L.COMM_SELF)
+    y = x.duplicate()
+    A0.mult(x, y)
+    st, rm = C.c_int(), C.c_int()
+    L.MatHIPMI355XGetTiledInfo(A0.h, C.byref(st), C.byref(rm))
+    assert st.value == 0 and rm.value == 0                       # too small for the analysis to bother
+    y0 = y.array().copy()
+    L.PetscOptionsInsertString(b"-mat_hipmi355x_tiled 1 -mat_hipmi355x_tiled_stage_min 500")
+    A = P.Mat.from_csr(ai, aj, aa)
+    A.mult(x, y)
+    L.PetscOptionsClear()
+    L.MatHIPMI355XGetTiledInfo(A.h, C.byref(st), C.byref(rm))
+    assert st.value > 0 and st.value + rm.value == aj.size
+    ref = orc.spmv(ai, aj, aa, xh)
+    assert np.all(np.abs(y.array() - ref) <= tol(aa)) and np.all(np.abs(y0 - ref) <= tol(aa))
+    # device-side value changes
+    L.MatScale(A.h, -2.5)
+    d = P.Vec.from_array(1.0 + 0.1 * np.sin(np.arange(n)), comm=L.COMM_SELF)
+    L.MatDiagonalScale(A.h, d.h, d.h)
+    A.mult(x, y)
+    dh = d.array()
+    aa2 = ((aa * -2.5) * dh[rowof]) * dh[aj]
+    assert np.all(np.abs(y.array() - orc.spmv(ai, aj, aa2, xh)) <= tol(aa2))
+    n_up = C.c_int()
+    L.MatHIPMI355XGetUploadCount(A.h, C.byref(n_up))
+    assert n_up.value == 1                                       # nothing went back over PCIe for it
+    # MatMultAdd
+    z = P.Vec.from_array(np.sin(np.arange(m) * 0.01), comm=L.COMM_SELF)
+    w = z.duplicate()
+    L.MatMultAdd(A.h, x.h, z.h, w.h)
+    refadd = orc.spmv_add(ai, aj, aa2, xh, z.array())
+    assert np.all(np.abs(w.array() - refadd) <= tol(aa2) + 1e-12 * np.abs(z.array()))
+    # a 7-point stencil never takes it, forced or not (it has an offset dictionary)
+    L.PetscOptionsInsertString(b"-mat_hipmi355x_tiled 1")
+    ai7, aj7, aa7 = P.gen_poisson7(20, 20, 20)
+    A7 = P.Mat.from_csr(ai7, aj7, aa7)
+    x7 = P.Vec.from_array(np.ones(8000), comm=L.COMM_SELF); y7 = x7.duplicate()
+    A7.mult(x7, y7)
+    L.PetscOptionsClear()
+    L.MatHIPMI355XGetTiledInfo(A7.h, C.byref(st), C.byref(rm))
+    assert st.value == 0 and rm.value == 0
