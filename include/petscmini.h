@@ -59,6 +59,7 @@ typedef enum { NOT_SET_VALUES, INSERT_VALUES, ADD_VALUES, MAX_VALUES } InsertMod
 typedef enum { SCATTER_FORWARD = 0, SCATTER_REVERSE = 1 } ScatterMode;                         /* petscvec.h:42 */
 typedef enum { NORM_1 = 0, NORM_2 = 1, NORM_FROBENIUS = 2, NORM_INFINITY = 3, NORM_1_AND_2 = 4 } NormType; /* petscvec.h:155 */
 typedef enum { MAT_FLUSH_ASSEMBLY = 1, MAT_FINAL_ASSEMBLY = 0 } MatAssemblyType;               /* petscmat.h:347 */
+typedef enum { MAT_DO_NOT_COPY_VALUES, MAT_COPY_VALUES, MAT_SHARE_NONZERO_PATTERN } MatDuplicateOption;   /* petscmat.h:440 */
 typedef enum { DIFFERENT_NONZERO_PATTERN, SUBSET_NONZERO_PATTERN, SAME_NONZERO_PATTERN, SAME_PRECONDITIONER } MatStructure;
 /* matrix factorisation interface (include/petscmat.h:100-131,1042-1088): the factored matrix is a Mat of its own, obtained from the
  * operator with MatGetFactor, filled by a symbolic and a numeric call, applied with MatSolve */
@@ -193,6 +194,7 @@ PetscErrorCode VecGetArrayRead(Vec v, const PetscScalar **a);
 PetscErrorCode VecRestoreArrayRead(Vec v, const PetscScalar **a);
 PetscErrorCode VecPlaceArray(Vec v, const PetscScalar *a);
 PetscErrorCode VecResetArray(Vec v);
+PetscErrorCode VecReplaceArray(Vec v, const PetscScalar *a);   /* rvector.c:1610: the vector takes ownership of a (allocated with PetscMalloc) */
 PetscErrorCode VecSet(Vec x, PetscScalar alpha);
 PetscErrorCode VecCopy(Vec x, Vec y);
 PetscErrorCode VecSwap(Vec x, Vec y);
@@ -223,7 +225,8 @@ PetscErrorCode PetscCommSplitReductionBegin(PetscComm comm);
 PetscErrorCode MatCreate(PetscComm comm, Mat *A);
 PetscErrorCode MatSetSizes(Mat A, PetscInt m, PetscInt n, PetscInt M, PetscInt N);
 PetscErrorCode MatSetType(Mat A, MatType type);
-PetscErrorCode MatSetFromOptions(Mat A);                      /* -mat_type */
+PetscErrorCode MatSetFromOptions(Mat A);                      /* -mat_type, then the type's own options (ops->setfromoptions, gcreate.c:167-205) */
+PetscErrorCode MatDuplicate(Mat A, MatDuplicateOption op, Mat *B);   /* matrix.c:4023 */
 PetscErrorCode MatGetType(Mat A, MatType *type);
 PetscErrorCode MatSetUp(Mat A);
 PetscErrorCode MatSeqAIJSetPreallocation(Mat A, PetscInt nz, const PetscInt nnz[]);

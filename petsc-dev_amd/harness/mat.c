@@ -70,8 +70,24 @@ PetscErrorCode MatSetFromOptions(Mat A) {
   char t[64];
   PetscBool set;
   PetscErrorCode ierr = PetscOptionsGetString(NULL, "-mat_type", t, sizeof(t), &set);CHKERRQ(ierr);
-  if (!set) snprintf(t, sizeof(t), "%s", MATAIJ);   /* matrix.c MatSetFromOptions: the default type is aij */
-  return MatSetType(A, t);
+  if (set || (!A->type_name[0] && !A->pending_type[0])) {                    /* gcreate.c:188-193: -mat_type, else the default type (aij) for a matrix without one */
+    if (!set) snprintf(t, sizeof(t), "%s", MATAIJ);
+    ierr = MatSetType(A, t);CHKERRQ(ierr);
+  }
+  if (A->ops->setfromoptions) { ierr = (*A->ops->setfromoptions)(A);CHKERRQ(ierr); }   /* gcreate.c:201-203 */
+  return 0;
+}
+/* MatDuplicate, matrix.c:4023-4055 */
+PetscErrorCode MatDuplicate(Mat A, MatDuplicateOption op, Mat *M) {
+  PetscErrorCode ierr;
+  MatTypeSet(A, 1);
+  if (!A->assembled) SETERRQ(A->comm, PETSC_ERR_ARG_WRONGSTATE, "Not for unassembled matrix");
+  if (A->factortype) SETERRQ(A->comm, PETSC_ERR_ARG_WRONGSTATE, "Not for factored matrix");
+  *M = NULL;
+  if (!A->ops->duplicate) SETERRQ(A->comm, PETSC_ERR_SUP, "Not written for this matrix type");
+  ierr = (*A->ops->duplicate)(A, op, M);CHKERRQ(ierr);
+  PetscObjectStateIncrease(*M);
+  return 0;
 }
 PetscErrorCode MatSetOptionsPrefix(Mat A, const char prefix[]) { MatValid(A, 1); snprintf(A->prefix, sizeof(A->prefix), "%s", prefix ? prefix : ""); return 0; }
 PetscErrorCode MatGetType(Mat A, MatType *type) { MatValid(A, 1); *type = A->type_name; return 0; }

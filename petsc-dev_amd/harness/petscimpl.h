@@ -95,6 +95,7 @@ struct _VecOps {
   PetscErrorCode (*getarray)(Vec, PetscScalar **);
   PetscErrorCode (*restorearray)(Vec, PetscScalar **);
   PetscErrorCode (*placearray)(Vec, const PetscScalar *);
+  PetscErrorCode (*replacearray)(Vec, const PetscScalar *);   /* vecimpl.h:259 */
   PetscErrorCode (*resetarray)(Vec);
   PetscErrorCode (*destroy)(Vec);
   PetscErrorCode (*reciprocal)(Vec);
@@ -126,6 +127,8 @@ struct _MatOps {
   PetscErrorCode (*zeroentries)(Mat);                    /* slot 23 */
   PetscErrorCode (*setup)(Mat);                          /* slot 29 */
   PetscErrorCode (*scale)(Mat, PetscScalar);
+  PetscErrorCode (*duplicate)(Mat, MatDuplicateOption, Mat *);   /* slot 34 */
+  PetscErrorCode (*setfromoptions)(Mat);                 /* slot 76 */
   PetscErrorCode (*destroy)(Mat);                        /* slot 60 */
   PetscErrorCode (*getvecs)(Mat, Vec *, Vec *);          /* slot 88 */
   PetscErrorCode (*setvaluesbatch)(Mat, PetscInt, PetscInt, PetscInt[], const PetscScalar[]);

@@ -145,6 +145,13 @@ PetscErrorCode VecPlaceArray(Vec v, const PetscScalar *a) {
   PetscObjectStateIncrease(v);
   return 0;
 }
+PetscErrorCode VecReplaceArray(Vec v, const PetscScalar *a) {   /* rvector.c:1610-1628 */
+  VecTypeSet(v, 1);
+  if (!v->ops->replacearray) SETERRQ(v->comm, PETSC_ERR_SUP, "Cannot replace array in this type of vector");
+  PetscErrorCode ierr = (*v->ops->replacearray)(v, a);CHKERRQ(ierr);
+  PetscObjectStateIncrease(v);
+  return 0;
+}
 PetscErrorCode VecResetArray(Vec v) {
   VecTypeSet(v, 1);
   PetscErrorCode ierr = (*v->ops->resetarray)(v);CHKERRQ(ierr);

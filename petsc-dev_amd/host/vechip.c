@@ -132,6 +132,19 @@ static PetscErrorCode VecPlaceArray_HIP(Vec v, const PetscScalar *a) {
   s->valid = VALID_HOST;
   return 0;
 }
+/* VecReplaceArray_Seq (dvec2.c:1159-1168): the vector's own host array is freed and `a` takes its place for good -- the vector
+ * owns it from now on (allocated with PetscMalloc, as the reference requires) -- and holds the current values */
+static PetscErrorCode VecReplaceArray_HIP(Vec v, const PetscScalar *a) {
+  Vec_HIPMI355X *s = VH(v);
+  FLUSH_DEFERRED();
+  PP_RW(v);
+  if (s->placed_save) { if (s->host_owned) HipFree(s->placed_save); s->placed_save = NULL; }   /* the saved array was the one this vector allocated */
+  else if (s->host && s->host_owned) HipFree(s->host);
+  s->host = (PetscScalar *)a;
+  s->host_owned = 1;
+  s->valid = VALID_HOST;
+  return 0;
+}
 static PetscErrorCode VecResetArray_HIP(Vec v) {
   Vec_HIPMI355X *s = VH(v);
   if (!s->placed_save) return 0;
@@ -1174,6 +1187,7 @@ static PetscErrorCode VecCreate_HIP_common(Vec v, const char *tname) {
   v->ops->getarray = VecGetArray_HIP;
   v->ops->restorearray = VecRestoreArray_HIP;
   v->ops->placearray = VecPlaceArray_HIP;
+  v->ops->replacearray = VecReplaceArray_HIP;
   v->ops->resetarray = VecResetArray_HIP;
   v->ops->destroy = VecDestroy_HIP;
   v->ops->reciprocal = VecReciprocal_HIP;

@@ -179,12 +179,50 @@ template <int NR, int NW> static void shape(const char *name, size_t n) {
   run<3, NR, NW, 4, 256, 1, 1>(name, "XCD eighths, tiles in turn U=4, 2048 wg, nt", n, 2048);
 }
 
+// second table: segments dealt to MORE workgroups than are resident (between "flat" and "one segment per resident workgroup"), and the
+// non-temporal forms the first table left out
+template <int NR, int NW> static void shape2(const char *name, size_t n) {
+  run<1, NR, NW, 4, 256, 0, 0>(name, "flat U=4 T=256", n, 0);
+  run<1, NR, NW, 4, 256, 1, 1>(name, "flat U=4 T=256 nt loads+stores", n, 0);
+  run<1, NR, NW, 2, 256, 1, 1>(name, "flat U=2 T=256 nt loads+stores", n, 0);
+  run<1, NR, NW, 8, 256, 1, 1>(name, "flat U=8 T=256 nt loads+stores", n, 0);
+  run<1, NR, NW, 1, 256, 1, 1>(name, "flat U=1 T=256 nt loads+stores", n, 0);
+  for (int g : {4096, 8192, 16384, 32768}) {
+    char buf[96];
+    snprintf(buf, sizeof buf, "segment per workgroup U=4, %d wg", g);
+    run<2, NR, NW, 4, 256, 0, 0>(name, buf, n, g);
+    snprintf(buf, sizeof buf, "segment per workgroup U=4, %d wg, nt", g);
+    run<2, NR, NW, 4, 256, 1, 1>(name, buf, n, g);
+  }
+  run<2, NR, NW, 2, 256, 1, 1>(name, "segment per workgroup U=2, 8192 wg, nt", n, 8192);
+  run<2, NR, NW, 8, 256, 1, 1>(name, "segment per workgroup U=8, 8192 wg, nt", n, 8192);
+}
+
 int main(int argc, char **argv) {
   const size_t nmax = (size_t)1 << 27;
   cap2 = nmax / 2;
   for (int j = 0; j < 7; ++j) { CK(hipMalloc(&bufs[j], 8 * nmax + 64)); CK(hipMemset(bufs[j], 0, 8 * nmax)); }
   hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
   printf("device %s, %d CUs\n", prop.name, prop.multiProcessorCount);
+  if (argc > 1 && std::string(argv[1]) == "2") {
+    for (size_t n : {(size_t)1 << 22, (size_t)1 << 24, (size_t)1 << 27}) {
+      shape2<1, 1>("copy", n);
+      shape2<2, 1>("aypx", n);
+      shape2<5, 3>("cgupd", n);
+      run_read<1, 2, 4, 256, 0>("flat U=4", n, 0);
+      run_read<1, 2, 4, 256, 1>("flat U=4 nt", n, 0);
+      run_read<1, 2, 8, 256, 1>("flat U=8 nt", n, 0);
+      for (int g : {2048, 4096, 8192, 16384}) {
+        char buf[96];
+        snprintf(buf, sizeof buf, "segment U=4, %d wg", g); run_read<2, 2, 4, 256, 0>(buf, n, g);
+        snprintf(buf, sizeof buf, "segment U=4, %d wg, nt", g); run_read<2, 2, 4, 256, 1>(buf, n, g);
+      }
+      run_read<2, 2, 8, 256, 1>("segment U=8, 4096 wg, nt", n, 4096);
+      run_read<2, 1, 4, 256, 1>("segment U=4, 4096 wg, nt", n, 4096);
+      run_read<2, 1, 4, 256, 0>("segment U=4, 4096 wg", n, 4096);
+    }
+    return 0;
+  }
   for (size_t n : {(size_t)1 << 24, (size_t)1 << 27}) {
     shape<1, 1>("copy", n);
     shape<2, 1>("aypx", n);
