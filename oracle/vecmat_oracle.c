@@ -125,17 +125,23 @@ static double block256(double *lanes) {
   return s;
 }
 static double dev_reduce(size_t n, orc_term_fn f, const double *a, const double *b) {
-  size_t grid = (n + 4095) / 4096;
+  /* csrc/vec_kernels.hip reduce_kernel / launch_reduce: tiles of 1024 pairs (MI355X_TILE2), one workgroup per tile up to 8192
+   * workgroups (MI355X_REDUCE_GRID_CAP), beyond that contiguous runs of tiles; lane t of a workgroup meets its run's pairs
+   * s0 + t, s0 + t + 256, ... in that order */
+  const size_t n2 = n >> 1, ntiles = (n2 + 1023) / 1024;
+  size_t grid = ntiles;
   if (grid < 1) grid = 1;
-  if (grid > 512) grid = 512;           /* MI355X_REDUCE_GRID_CAP, csrc/common.hpp */
-  const size_t T = grid * 256, n2 = n >> 1;
+  if (grid > 8192) grid = 8192;
+  const size_t per = (ntiles + grid - 1) / grid;
   double *partial = (double *)malloc(sizeof(double) * grid), lanes[256], res;
   for (size_t blk = 0; blk < grid; blk++) {
+    size_t s0 = blk * per * 1024, s1 = s0 + per * 1024;
+    if (s0 > n2) s0 = n2;
+    if (s1 > n2) s1 = n2;
     for (size_t t = 0; t < 256; t++) {
-      const size_t tid = blk * 256 + t;
       double acc = 0.0;
-      for (size_t i = tid; i < n2; i += T) { acc = acc + f(a, b, 2 * i); acc = acc + f(a, b, 2 * i + 1); }
-      if ((n & 1) && tid == 0) acc = acc + f(a, b, n - 1);
+      for (size_t i = s0 + t; i < s1; i += 256) { acc = acc + f(a, b, 2 * i); acc = acc + f(a, b, 2 * i + 1); }
+      if ((n & 1) && blk == 0 && t == 0) acc = acc + f(a, b, n - 1);
       lanes[t] = acc;
     }
     partial[blk] = block256(lanes);

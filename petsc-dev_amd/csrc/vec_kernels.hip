@@ -1,9 +1,13 @@
-// Vec BLAS-1 kernels for gfx950.  All of them are HBM-bound streams: 16-byte
-// (double2) loads/stores per lane and a grid-stride loop; element-wise kernels run
-// <= 2048 workgroups (256 CUs x 8 resident 256-thread workgroups) with two double2
-// iterations in flight per lane, reductions <= 512 workgroups with four.  Compiled with -ffp-contract=off so
-// a*x+y is a rounded multiply then a rounded add, as in the reference's C loops
-// (src/vec/vec/impls/seq/{bvec1,bvec2,dvec2}.c).
+// Vec BLAS-1 kernels for gfx950.  All of them are HBM-bound streams of 16-byte (double2) loads / stores per lane.
+// How the index space is dealt to workgroups decides the rate (profiles/r04_stream_probe*.log, n = 2^27 doubles per vector, beyond the
+// 256 MiB Infinity Cache): a grid-stride loop over 2048 resident workgroups copies at 4.9 TB/s, ONE CONTIGUOUS TILE PER WORKGROUP
+// ("flat": as many workgroups as tiles, the dispatcher hands out the next tile when a workgroup retires, so the tiles in flight
+// form one compact window that slides through memory) at 6.0, with non-temporal accesses at 6.3-6.7; inside the cache (2^24) 7.7 ->
+// 7.8-8.4 and the non-temporal hint costs 20 %.  So: element-wise kernels take one tile of 256 x 2 double2 per workgroup;
+// reductions, whose workgroup count bounds the last workgroup's pass over the partials, take contiguous runs of tiles of 256 x 4
+// double2, one run each for <= 8192 workgroups (one tile each up to n = 2^24); vectors that cannot live in the cache (>= 256 MiB)
+// are streamed non-temporally.  Compiled with -ffp-contract=off so a*x+y is a rounded multiply then a rounded add, as in the
+// reference's C loops (src/vec/vec/impls/seq/{bvec1,bvec2,dvec2}.c).
 #include "common.hpp"
 
 // Streaming accesses for operands nobody reads again soon.  In a CG iteration x and r are touched by the update sweep only and z
@@ -30,30 +34,38 @@ static inline int gs_streams(size_t n, int nv) { return (size_t)nv * n * sizeof(
 // ------------------------------------------------------------------------
 // element-wise map:  out[i] = op(a[i], b[i], c[i])   (inputs may alias out)
 // ------------------------------------------------------------------------
-template <int NIN, class Op>
+// big: vectors of >= 256 MiB cannot be cache-resident between two kernels: stream them (measured: +5-12 % there, -20 % inside the cache)
+static inline int vec_streams(size_t n) { return n * sizeof(double) >= ((size_t)256 << 20); }
+template <bool NT> __device__ __forceinline__ double2 ld2(const double2 *p) { return NT ? nt_load2(p) : *p; }
+template <bool NT> __device__ __forceinline__ void st2(double2 *p, double2 v) { if (NT) nt_store2(p, v); else *p = v; }
+// the same choice at run time (a functor member, uniform over the launch)
+__device__ __forceinline__ double2 ldq(const double2 *p, int nt) { return nt ? nt_load2(p) : *p; }
+__device__ __forceinline__ void stq(double2 *p, double2 v, int nt) { if (nt) nt_store2(p, v); else *p = v; }
+
+// vec_ok: workgroup b owns the tile [b * MI355X_MAP_TILE2, (b + 1) * MI355X_MAP_TILE2) of double2's, lane t its entries t and t + 256
+template <int NIN, class Op, bool NT>
 __global__ __launch_bounds__(MI355X_BLOCK) void map_kernel(Op op, const double *a, const double *b, const double *c,
                                                           double *out, size_t n, int vec_ok) {
   const size_t tid = (size_t)blockIdx.x * MI355X_BLOCK + threadIdx.x;
-  const size_t stride = (size_t)gridDim.x * MI355X_BLOCK;
   if (vec_ok) {
     const size_t n2 = n >> 1;
     const double2 *a2 = reinterpret_cast<const double2 *>(a);
     const double2 *b2 = reinterpret_cast<const double2 *>(b);
     const double2 *c2 = reinterpret_cast<const double2 *>(c);
     double2 *o2 = reinterpret_cast<double2 *>(out);
-    size_t i = tid;
-    for (; i + stride < n2; i += 2 * stride) {
+    const size_t stride = MI355X_BLOCK;
+    const size_t i = (size_t)blockIdx.x * MI355X_MAP_TILE2 + threadIdx.x;
+    if (i + stride < n2) {
       double2 av0 = {0, 0}, bv0 = {0, 0}, cv0 = {0, 0}, av1 = {0, 0}, bv1 = {0, 0}, cv1 = {0, 0};
-      if (NIN >= 1) { av0 = a2[i]; av1 = a2[i + stride]; }
-      if (NIN >= 2) { bv0 = b2[i]; bv1 = b2[i + stride]; }
-      if (NIN >= 3) { cv0 = c2[i]; cv1 = c2[i + stride]; }
+      if (NIN >= 1) { av0 = ld2<NT>(a2 + i); av1 = ld2<NT>(a2 + i + stride); }
+      if (NIN >= 2) { bv0 = ld2<NT>(b2 + i); bv1 = ld2<NT>(b2 + i + stride); }
+      if (NIN >= 3) { cv0 = ld2<NT>(c2 + i); cv1 = ld2<NT>(c2 + i + stride); }
       double2 r0, r1;
       r0.x = op(av0.x, bv0.x, cv0.x); r0.y = op(av0.y, bv0.y, cv0.y);
       r1.x = op(av1.x, bv1.x, cv1.x); r1.y = op(av1.y, bv1.y, cv1.y);
-      o2[i] = r0;
-      o2[i + stride] = r1;
-    }
-    if (i < n2) {
+      st2<NT>(o2 + i, r0);
+      st2<NT>(o2 + i + stride, r1);
+    } else if (i < n2) {
       double2 av = {0, 0}, bv = {0, 0}, cv = {0, 0};
       if (NIN >= 1) av = a2[i];
       if (NIN >= 2) bv = b2[i];
@@ -67,18 +79,26 @@ __global__ __launch_bounds__(MI355X_BLOCK) void map_kernel(Op op, const double *
       out[k] = op(NIN >= 1 ? a[k] : 0.0, NIN >= 2 ? b[k] : 0.0, NIN >= 3 ? c[k] : 0.0);
     }
   } else {
+    const size_t stride = (size_t)gridDim.x * MI355X_BLOCK;
     for (size_t i = tid; i < n; i += stride)
       out[i] = op(NIN >= 1 ? a[i] : 0.0, NIN >= 2 ? b[i] : 0.0, NIN >= 3 ? c[i] : 0.0);
   }
 }
 
+// workgroups of an element-wise launch: one per tile of MI355X_MAP_TILE2 double2's (an unaligned view takes the scalar grid-stride loop)
+static inline unsigned int map_grid(size_t n, int vec_ok) {
+  if (!vec_ok) return (unsigned int)mi355x_grid_for(n, 4);
+  const size_t n2 = n >> 1, nt = (n2 + MI355X_MAP_TILE2 - 1) / MI355X_MAP_TILE2;
+  return (unsigned int)(nt ? nt : 1);
+}
 template <int NIN, class Op>
 static int launch_map(mi355x_handle_t h, Op op, const double *a, const double *b, const double *c, double *out, size_t n) {
   if (n == 0) return 0;
   int vec_ok = mi355x_aligned16(out) && (NIN < 1 || mi355x_aligned16(a)) && (NIN < 2 || mi355x_aligned16(b)) &&
                (NIN < 3 || mi355x_aligned16(c));
-  int grid = mi355x_grid_for(n, 4);
-  hipLaunchKernelGGL((map_kernel<NIN, Op>), dim3(grid), dim3(MI355X_BLOCK), 0, h->stream, op, a, b, c, out, n, vec_ok);
+  const unsigned int grid = map_grid(n, vec_ok);
+  if (vec_streams(n)) hipLaunchKernelGGL((map_kernel<NIN, Op, true>), dim3(grid), dim3(MI355X_BLOCK), 0, h->stream, op, a, b, c, out, n, vec_ok);
+  else hipLaunchKernelGGL((map_kernel<NIN, Op, false>), dim3(grid), dim3(MI355X_BLOCK), 0, h->stream, op, a, b, c, out, n, vec_ok);
   MI355X_LAUNCH_CHECK();
   return 0;
 }
@@ -150,7 +170,8 @@ __global__ __launch_bounds__(MI355X_BLOCK) void maxpy_kernel(MaxpyArgs args, dou
   if (vec_ok) {
     const size_t n2 = n >> 1;
     double2 *x2 = reinterpret_cast<double2 *>(x);
-    for (size_t i = tid; i < n2; i += stride) {
+    const size_t i = tid;                            // one double2 of every stream per lane, one contiguous tile per workgroup (grid = all tiles)
+    if (i < n2) {
       double2 yv[NV];
       if (args.nt) {                               // see gs_streams()
 #pragma unroll
@@ -186,7 +207,8 @@ __global__ __launch_bounds__(MI355X_BLOCK) void maxpy_kernel(MaxpyArgs args, dou
 
 template <int G0, int NG4>
 static int launch_maxpy(mi355x_handle_t h, const MaxpyArgs &args, double *x, size_t n, int vec_ok) {
-  int grid = mi355x_grid_for(n, 2);
+  const size_t nt2 = ((n >> 1) + MI355X_BLOCK - 1) / MI355X_BLOCK;
+  const unsigned int grid = vec_ok ? (unsigned int)(nt2 ? nt2 : 1) : (unsigned int)mi355x_grid_for(n, 2);
   hipLaunchKernelGGL((maxpy_kernel<G0, NG4>), dim3(grid), dim3(MI355X_BLOCK), 0, h->stream, args, x, n, vec_ok);
   MI355X_LAUNCH_CHECK();
   return 0;
@@ -231,30 +253,31 @@ __device__ __forceinline__ void publish_to_host(unsigned long long *host_seq, un
 // y = x + (num/den) y with the scalar's numerator still in device memory (KSPSolve_CG: b = beta_new/beta_old, beta_new
 // being the z'r the previous kernel on the stream has just reduced).  VecAYPX_Seq's special case alpha == 0 -> copy
 // (dvec2.c:980) is kept; alpha == +-1 need no special form (x + 1*y and x + (-1)*y are the bits of x + y and x - y).
+template <bool NT>
 __global__ __launch_bounds__(MI355X_BLOCK) void aypx_dev_kernel(const double *num, double den, const double *x, double *y, size_t n, int vec_ok) {
   const double alpha = *num / den;
   const bool copy = (alpha == 0.0);
   const size_t tid = (size_t)blockIdx.x * MI355X_BLOCK + threadIdx.x;
-  const size_t stride = (size_t)gridDim.x * MI355X_BLOCK;
-  if (vec_ok) {
+  if (vec_ok) {                                    // one tile of MI355X_MAP_TILE2 double2's per workgroup (see map_kernel)
     const size_t n2 = n >> 1;
     const double2 *x2 = reinterpret_cast<const double2 *>(x);
     double2 *y2 = reinterpret_cast<double2 *>(y);
-    size_t i = tid;
-    for (; i + stride < n2; i += 2 * stride) {
-      double2 xv0 = nt_load2(x2 + i), xv1 = nt_load2(x2 + i + stride), yv0 = y2[i], yv1 = y2[i + stride], r0, r1;   // x = z: its last reader (see nt_load2)
+    const size_t stride = MI355X_BLOCK;
+    const size_t i = (size_t)blockIdx.x * MI355X_MAP_TILE2 + threadIdx.x;
+    if (i + stride < n2) {
+      double2 xv0 = nt_load2(x2 + i), xv1 = nt_load2(x2 + i + stride), yv0 = ld2<NT>(y2 + i), yv1 = ld2<NT>(y2 + i + stride), r0, r1;   // x = z: its last reader (see nt_load2)
       r0.x = copy ? xv0.x : xv0.x + alpha * yv0.x; r0.y = copy ? xv0.y : xv0.y + alpha * yv0.y;
       r1.x = copy ? xv1.x : xv1.x + alpha * yv1.x; r1.y = copy ? xv1.y : xv1.y + alpha * yv1.y;
-      y2[i] = r0;
-      y2[i + stride] = r1;
-    }
-    if (i < n2) {
+      st2<NT>(y2 + i, r0);
+      st2<NT>(y2 + i + stride, r1);
+    } else if (i < n2) {
       double2 xv = nt_load2(x2 + i), yv = y2[i], r;
       r.x = copy ? xv.x : xv.x + alpha * yv.x; r.y = copy ? xv.y : xv.y + alpha * yv.y;
       y2[i] = r;
     }
     if ((n & 1) && tid == 0) y[n - 1] = copy ? x[n - 1] : x[n - 1] + alpha * y[n - 1];
   } else {
+    const size_t stride = (size_t)gridDim.x * MI355X_BLOCK;
     for (size_t i = tid; i < n; i += stride) y[i] = copy ? x[i] : x[i] + alpha * y[i];
   }
 }
@@ -278,16 +301,24 @@ __global__ __launch_bounds__(MI355X_BLOCK) void reduce_kernel(F f, size_t n, int
   __shared__ double lds[MI355X_BLOCK / MI355X_WAVE][NOUT];
   __shared__ int is_last;
   const size_t tid = (size_t)blockIdx.x * MI355X_BLOCK + threadIdx.x;
-  const size_t stride = (size_t)gridDim.x * MI355X_BLOCK;
   double acc[NOUT];
 #pragma unroll
   for (int j = 0; j < NOUT; ++j) acc[j] = 0.0;
   if constexpr (has_prologue<F>::value) f.prologue(tid, acc);
   if (vec_ok) {
+    // workgroup b owns a contiguous run of tiles of MI355X_TILE2 double2's: [s0, s1); lane t meets s0 + t, s0 + t + 256, ... in that
+    // order (the functors' sweeps take a first index, a step and an end).  The oracle's device-order emulation
+    // (oracle/vecmat_oracle.c dev_reduce) restates this geometry: change both together.
     const size_t n2 = n >> 1;
-    f.template sweep<NOUT>(tid, stride, n2, acc);
+    const size_t ntiles = (n2 + MI355X_TILE2 - 1) / MI355X_TILE2;
+    const size_t per = (ntiles + gridDim.x - 1) / gridDim.x;
+    size_t s0 = (size_t)blockIdx.x * per * MI355X_TILE2, s1 = s0 + per * MI355X_TILE2;
+    if (s0 > n2) s0 = n2;
+    if (s1 > n2) s1 = n2;
+    f.template sweep<NOUT>(s0 + threadIdx.x, (size_t)MI355X_BLOCK, s1, acc);
     if ((n & 1) && tid == 0) f.accum1(n - 1, acc);
   } else {
+    const size_t stride = (size_t)gridDim.x * MI355X_BLOCK;
     for (size_t i = tid; i < n; i += stride) f.accum1(i, acc);
   }
   if (gridDim.x == 1) {  // single workgroup: no hand-off needed
@@ -342,11 +373,11 @@ __global__ __launch_bounds__(MI355X_BLOCK) void reduce_kernel(F f, size_t n, int
 
 template <int NOUT, int MODE, class F>
 static int launch_reduce(mi355x_handle_t h, F f, size_t n, int vec_ok, double *out, bool also_to_host = false) {
-  int grid = mi355x_grid_for(n, 16);
-  // at most 512 workgroups, 2 per CU (measured on the CG iteration at n = 2^24, one box, same process order: 256 -> 0.541 ms,
-  // 384 -> 0.535, 512 -> 0.523, 768 -> 0.529, 1024 -> 0.534, 2048 -> 0.536); the last one sums <= 512 partials.  The oracle's
-  // device-order emulation (oracle/vecmat_oracle.c dev_reduce) restates this geometry: change both together.
-  if (grid > MI355X_REDUCE_GRID_CAP) grid = MI355X_REDUCE_GRID_CAP;
+  // one workgroup per tile of MI355X_TILE2 double2's, at most MI355X_REDUCE_GRID_CAP of them (then contiguous runs of tiles each); the
+  // last one to finish sums that many partials.  The oracle's device-order emulation (oracle/vecmat_oracle.c dev_reduce) restates
+  // this geometry: change both together.
+  size_t ntiles = ((n >> 1) + MI355X_TILE2 - 1) / MI355X_TILE2;
+  int grid = (int)(ntiles < 1 ? 1 : (ntiles > MI355X_REDUCE_GRID_CAP ? MI355X_REDUCE_GRID_CAP : ntiles));
   // a result that goes to the handle's pinned scratch is followed by a completion number (mi355x_handle_wait_result)
   unsigned long long *hs = nullptr, seq = 0;
   double *host_copy = nullptr;
@@ -375,11 +406,12 @@ static int launch_reduce(mi355x_handle_t h, F f, size_t n, int vec_ok, double *o
 
 struct DotF {
   const double *x, *y;
+  int nt = 0;                  // vectors too large for the cache: streamed (vec_streams)
   DEFAULT_SWEEP()
   __device__ void accum2x4(size_t i, size_t st, double (&a)[1]) const {
     const double2 *x2 = reinterpret_cast<const double2 *>(x), *y2 = reinterpret_cast<const double2 *>(y);
-    double2 xv0 = x2[i], xv1 = x2[i + st], xv2 = x2[i + 2 * st], xv3 = x2[i + 3 * st];
-    double2 yv0 = y2[i], yv1 = y2[i + st], yv2 = y2[i + 2 * st], yv3 = y2[i + 3 * st];
+    double2 xv0 = ldq(x2 + i, nt), xv1 = ldq(x2 + i + st, nt), xv2 = ldq(x2 + i + 2 * st, nt), xv3 = ldq(x2 + i + 3 * st, nt);
+    double2 yv0 = ldq(y2 + i, nt), yv1 = ldq(y2 + i + st, nt), yv2 = ldq(y2 + i + 2 * st, nt), yv3 = ldq(y2 + i + 3 * st, nt);
     a[0] += xv0.x * yv0.x; a[0] += xv0.y * yv0.y; a[0] += xv1.x * yv1.x; a[0] += xv1.y * yv1.y;
     a[0] += xv2.x * yv2.x; a[0] += xv2.y * yv2.y; a[0] += xv3.x * yv3.x; a[0] += xv3.y * yv3.y;
   }
@@ -392,10 +424,11 @@ struct DotF {
 };
 struct SumSqF {
   const double *x;
+  int nt = 0;
   DEFAULT_SWEEP()
   __device__ void accum2x4(size_t i, size_t st, double (&a)[1]) const {
     const double2 *x2 = reinterpret_cast<const double2 *>(x);
-    double2 v0 = x2[i], v1 = x2[i + st], v2 = x2[i + 2 * st], v3 = x2[i + 3 * st];
+    double2 v0 = ldq(x2 + i, nt), v1 = ldq(x2 + i + st, nt), v2 = ldq(x2 + i + 2 * st, nt), v3 = ldq(x2 + i + 3 * st, nt);
     a[0] += v0.x * v0.x; a[0] += v0.y * v0.y; a[0] += v1.x * v1.x; a[0] += v1.y * v1.y;
     a[0] += v2.x * v2.x; a[0] += v2.y * v2.y; a[0] += v3.x * v3.x; a[0] += v3.y * v3.y;
   }
@@ -459,6 +492,7 @@ struct CGUpdateF {
   double a, ma;
   const double *p, *w, *d;
   double *x, *r, *z;
+  int big = 0;                 // vectors too large for the cache: p, w and z are streams as well (vec_streams)
   template <int NOUT_>
   __device__ __forceinline__ void sweep(size_t tid, size_t stride, size_t n2, double (&acc)[NOUT_]) const {
     size_t i = tid;
@@ -467,12 +501,12 @@ struct CGUpdateF {
       const double2 *d2 = reinterpret_cast<const double2 *>(d);
       double2 *x2 = reinterpret_cast<double2 *>(x), *r2 = reinterpret_cast<double2 *>(r), *z2 = reinterpret_cast<double2 *>(z);
       const double2 one2 = {1.0, 1.0};
-      double2 pv0 = p2[i], pv1 = p2[i + stride], wv0 = w2[i], wv1 = w2[i + stride], dv0 = d ? nt_load2(d2 + i) : one2, dv1 = d ? nt_load2(d2 + i + stride) : one2;
+      double2 pv0 = ldq(p2 + i, big), pv1 = ldq(p2 + i + stride, big), wv0 = ldq(w2 + i, big), wv1 = ldq(w2 + i + stride, big), dv0 = d ? nt_load2(d2 + i) : one2, dv1 = d ? nt_load2(d2 + i + stride) : one2;
       double2 xv0 = nt_load2(x2 + i), xv1 = nt_load2(x2 + i + stride), rv0 = nt_load2(r2 + i), rv1 = nt_load2(r2 + i + stride), zv0, zv1;
       step(pv0.x, wv0.x, dv0.x, xv0.x, rv0.x, zv0.x, acc); step(pv0.y, wv0.y, dv0.y, xv0.y, rv0.y, zv0.y, acc);
       step(pv1.x, wv1.x, dv1.x, xv1.x, rv1.x, zv1.x, acc); step(pv1.y, wv1.y, dv1.y, xv1.y, rv1.y, zv1.y, acc);
-      nt_store2(x2 + i, xv0); nt_store2(r2 + i, rv0); z2[i] = zv0;
-      nt_store2(x2 + i + stride, xv1); nt_store2(r2 + i + stride, rv1); z2[i + stride] = zv1;
+      nt_store2(x2 + i, xv0); nt_store2(r2 + i, rv0); stq(z2 + i, zv0, big);
+      nt_store2(x2 + i + stride, xv1); nt_store2(r2 + i + stride, rv1); stq(z2 + i + stride, zv1, big);
     }
     for (; i < n2; i += stride) {
       const double2 one2 = {1.0, 1.0};
@@ -509,6 +543,7 @@ struct CGUpdateDevF {
   const double *dpi_ptr;
   const double *p, *w, *d;
   double *x, *r, *z;
+  int big = 0;                 // see CGUpdateF
   __device__ __forceinline__ bool scalars(double &a) const {
     const double dpi = *dpi_ptr;
     const bool bad = !(dpi == dpi) || fabs(dpi) == __builtin_huge_val() || dpi == 0.0 || (check_sign && dpi * dpiold <= 0.0);
@@ -538,12 +573,12 @@ struct CGUpdateDevF {
     double2 *x2 = reinterpret_cast<double2 *>(x), *r2 = reinterpret_cast<double2 *>(r), *z2 = reinterpret_cast<double2 *>(z);
     size_t i = tid;
     for (; i + stride < n2; i += 2 * stride) {
-      double2 pv0 = p2[i], pv1 = p2[i + stride], wv0 = w2[i], wv1 = w2[i + stride], dv0 = d ? nt_load2(d2 + i) : one2, dv1 = d ? nt_load2(d2 + i + stride) : one2;
+      double2 pv0 = ldq(p2 + i, big), pv1 = ldq(p2 + i + stride, big), wv0 = ldq(w2 + i, big), wv1 = ldq(w2 + i + stride, big), dv0 = d ? nt_load2(d2 + i) : one2, dv1 = d ? nt_load2(d2 + i + stride) : one2;
       double2 xv0 = nt_load2(x2 + i), xv1 = nt_load2(x2 + i + stride), rv0 = nt_load2(r2 + i), rv1 = nt_load2(r2 + i + stride), zv0, zv1;
       step(a, pv0.x, wv0.x, dv0.x, xv0.x, rv0.x, zv0.x, acc); step(a, pv0.y, wv0.y, dv0.y, xv0.y, rv0.y, zv0.y, acc);
       step(a, pv1.x, wv1.x, dv1.x, xv1.x, rv1.x, zv1.x, acc); step(a, pv1.y, wv1.y, dv1.y, xv1.y, rv1.y, zv1.y, acc);
-      nt_store2(x2 + i, xv0); nt_store2(r2 + i, rv0); z2[i] = zv0;
-      nt_store2(x2 + i + stride, xv1); nt_store2(r2 + i + stride, rv1); z2[i + stride] = zv1;
+      nt_store2(x2 + i, xv0); nt_store2(r2 + i, rv0); stq(z2 + i, zv0, big);
+      nt_store2(x2 + i + stride, xv1); nt_store2(r2 + i + stride, rv1); stq(z2 + i + stride, zv1, big);
     }
     for (; i < n2; i += stride) {
       double2 pv = p2[i], wv = w2[i], dv = d ? nt_load2(d2 + i) : one2, xv = nt_load2(x2 + i), rv = nt_load2(r2 + i), zv;
@@ -741,20 +776,20 @@ __global__ __launch_bounds__(MI355X_BLOCK) void scale_rnorm_dev_kernel(const dou
   const double alpha = 1.0 / nrm;
   if (alpha == 1.0) return;
   const size_t tid = (size_t)blockIdx.x * MI355X_BLOCK + threadIdx.x;
-  const size_t stride = (size_t)gridDim.x * MI355X_BLOCK;
-  if (vec_ok) {
+  if (vec_ok) {                                    // one tile of MI355X_MAP_TILE2 double2's per workgroup (see map_kernel)
     const size_t n2 = n >> 1;
     double2 *x2 = reinterpret_cast<double2 *>(x);
-    size_t i = tid;
-    for (; i + stride < n2; i += 2 * stride) {
+    const size_t stride = MI355X_BLOCK;
+    const size_t i = (size_t)blockIdx.x * MI355X_MAP_TILE2 + threadIdx.x;
+    if (i + stride < n2) {
       double2 v0 = x2[i], v1 = x2[i + stride];
       v0.x = alpha == 0.0 ? 0.0 : v0.x * alpha; v0.y = alpha == 0.0 ? 0.0 : v0.y * alpha;
       v1.x = alpha == 0.0 ? 0.0 : v1.x * alpha; v1.y = alpha == 0.0 ? 0.0 : v1.y * alpha;
       x2[i] = v0; x2[i + stride] = v1;
-    }
-    if (i < n2) { double2 v = x2[i]; v.x = alpha == 0.0 ? 0.0 : v.x * alpha; v.y = alpha == 0.0 ? 0.0 : v.y * alpha; x2[i] = v; }
+    } else if (i < n2) { double2 v = x2[i]; v.x = alpha == 0.0 ? 0.0 : v.x * alpha; v.y = alpha == 0.0 ? 0.0 : v.y * alpha; x2[i] = v; }
     if ((n & 1) && tid == 0) x[n - 1] = alpha == 0.0 ? 0.0 : x[n - 1] * alpha;
   } else {
+    const size_t stride = (size_t)gridDim.x * MI355X_BLOCK;
     for (size_t i = tid; i < n; i += stride) x[i] = alpha == 0.0 ? 0.0 : x[i] * alpha;
   }
 }
@@ -807,7 +842,8 @@ int mi355x_vec_aypx(mi355x_handle_t h, size_t n, double alpha, const double *x, 
 int mi355x_vec_aypx_dev(mi355x_handle_t h, size_t n, const double *num_dev, double den, const double *x, double *y) {
   if (n == 0) return 0;
   int vec_ok = mi355x_aligned16(x) && mi355x_aligned16(y);
-  hipLaunchKernelGGL(aypx_dev_kernel, dim3(mi355x_grid_for(n, 4)), dim3(MI355X_BLOCK), 0, h->stream, num_dev, den, x, y, n, vec_ok);
+  if (vec_streams(n)) hipLaunchKernelGGL(aypx_dev_kernel<true>, dim3(map_grid(n, vec_ok)), dim3(MI355X_BLOCK), 0, h->stream, num_dev, den, x, y, n, vec_ok);
+  else hipLaunchKernelGGL(aypx_dev_kernel<false>, dim3(map_grid(n, vec_ok)), dim3(MI355X_BLOCK), 0, h->stream, num_dev, den, x, y, n, vec_ok);
   MI355X_LAUNCH_CHECK();
   return 0;
 }
@@ -895,6 +931,7 @@ int mi355x_vec_maxpy(mi355x_handle_t h, size_t n, int nv, const double *alpha, c
 
 int mi355x_vec_dot(mi355x_handle_t h, size_t n, const double *x, const double *y, double *out) {
   DotF f{x, y};
+  f.nt = vec_streams(n);
   return launch_reduce<1, RED_SUM>(h, f, n, mi355x_aligned16(x) && mi355x_aligned16(y), out);
 }
 int mi355x_vec_norm(mi355x_handle_t h, size_t n, int type, const double *x, double *out) {
@@ -902,7 +939,7 @@ int mi355x_vec_norm(mi355x_handle_t h, size_t n, int type, const double *x, doub
   switch (type) {
     case 0: return launch_reduce<1, RED_SUM>(h, SumAbsF{x}, n, v, out);
     case 1:
-    case 2: return launch_reduce<1, RED_SUM>(h, SumSqF{x}, n, v, out);
+    case 2: return launch_reduce<1, RED_SUM>(h, SumSqF{x, vec_streams(n)}, n, v, out);
     case 3: return launch_reduce<1, RED_MAX>(h, MaxAbsF{x}, n, v, out);
     case 4: return launch_reduce<2, RED_SUM>(h, Norm12F{x}, n, v, out);
     default: return (int)hipErrorInvalidValue;
@@ -915,6 +952,7 @@ int mi355x_vec_dotnorm2(mi355x_handle_t h, size_t n, const double *s, const doub
 int mi355x_vec_cg_update(mi355x_handle_t h, size_t n, double a, const double *p, const double *w, const double *d,
                          double *x, double *r, double *z, double *out) {
   CGUpdateF f{a, -a, p, w, d, x, r, z};
+  f.big = vec_streams(n);
   int v = mi355x_aligned16(p) && mi355x_aligned16(w) && mi355x_aligned16(d) && mi355x_aligned16(x) && mi355x_aligned16(r) &&
           mi355x_aligned16(z);   /* d == NULL (identity preconditioner) counts as aligned */
   return launch_reduce<3, RED_SUM>(h, f, n, v, out);
@@ -923,6 +961,7 @@ int mi355x_vec_cg_update_dev(mi355x_handle_t h, size_t n, double beta, const dou
                              const double *p, const double *w, const double *d, double *x, double *r, double *z, double *out,
                              int also_to_host) {
   CGUpdateDevF f{beta, dpiold, check_sign, dpi_dev, p, w, d, x, r, z};
+  f.big = vec_streams(n);
   int v = mi355x_aligned16(p) && mi355x_aligned16(w) && mi355x_aligned16(d) && mi355x_aligned16(x) && mi355x_aligned16(r) &&
           mi355x_aligned16(z);   /* d == NULL (identity preconditioner) counts as aligned */
   return launch_reduce<4, RED_SUM>(h, f, n, v, out, also_to_host != 0);
@@ -974,7 +1013,7 @@ int mi355x_vec_maxpy_dev_norm2(mi355x_handle_t h, size_t n, int nv, const double
 }
 int mi355x_vec_scale_rnorm_dev(mi355x_handle_t h, size_t n, const double *norm2_dev, double *x) {
   if (n == 0) return 0;
-  hipLaunchKernelGGL(scale_rnorm_dev_kernel, dim3(mi355x_grid_for(n, 4)), dim3(MI355X_BLOCK), 0, h->stream, norm2_dev, x, n, mi355x_aligned16(x));
+  hipLaunchKernelGGL(scale_rnorm_dev_kernel, dim3(map_grid(n, mi355x_aligned16(x))), dim3(MI355X_BLOCK), 0, h->stream, norm2_dev, x, n, mi355x_aligned16(x));
   MI355X_LAUNCH_CHECK();
   return 0;
 }

@@ -1,15 +1,15 @@
 """Reading the column-tiled SpMV layout (csrc/spmv_tiled.hip) back on the host: the tests' restatement of what the kernel does with
-the arrays the builder leaves -- which entries a chunk holds, in which lane's registers, which row they are added into and in which
-order.  Test infrastructure: numpy / Python loops over small matrices."""
+the arrays the builder leaves -- which entries a (wavefront, tile) stream holds, which lane meets them at which step, which row they
+are added into and in which order.  Test infrastructure: numpy / Python loops over small matrices."""
 import ctypes as C
 
 import numpy as np
 
 
 def geometry(k):
-    g = [C.c_int() for _ in range(5)]
+    g = [C.c_int() for _ in range(4)]
     k.mi355x_spmv_tiled_geometry(*[C.byref(v) for v in g])
-    return dict(zip(("panel", "tw", "waves", "rpl", "ch"), [v.value for v in g]))
+    return dict(zip(("panel", "tw", "waves", "rounds"), [v.value for v in g]))
 
 
 def build(k, ai, aj, n, stage_min):
@@ -31,49 +31,54 @@ def get(k, plan, which, dtype):
 
 
 def info(k, plan):
-    a, b = C.c_long(), C.c_long()
-    p, q, c = C.c_int(), C.c_int(), C.c_int()
-    k.mi355x_spmv_tiled_info(plan, C.byref(a), C.byref(b), C.byref(p), C.byref(q), C.byref(c))
-    return {"staged": a.value, "remainder": b.value, "panels": p.value, "pairs": q.value, "chunks": c.value}
+    a, b, s = C.c_long(), C.c_long(), C.c_long()
+    p, q = C.c_int(), C.c_int()
+    k.mi355x_spmv_tiled_info(plan, C.byref(a), C.byref(b), C.byref(p), C.byref(q), C.byref(s))
+    return {"staged": a.value, "remainder": b.value, "panels": p.value, "pairs": q.value, "steps": s.value}
 
 
 def walk(k, plan, m):
-    """Every staged entry as (row, column, position in the CSR value array), in the order the kernel adds a row's products, plus the
-    remainder's CSR (far_i, far_j, far_perm)."""
+    """Every staged entry as (row, column, position in the CSR value array) in storage order -- for one row that is the order its lane
+    adds the products in -- plus the remainder's CSR (far_i, far_j, far_perm).  Checks the jagged-diagonal invariants on the way: a
+    round's rows are sorted by count (so a step's active lanes are 0 .. n - 1), every row of a wavefront appears at most once per tile."""
     g = geometry(k)
-    sub = 64 * g["rpl"]
-    pt_ptr, pt_tile, pt_chunk0 = get(k, plan, 0, np.int32), get(k, plan, 1, np.int32), get(k, plan, 2, np.int32)
-    chunk_e0, perm = get(k, plan, 3, np.int32), get(k, plan, 4, np.int32)
-    lcol = get(k, plan, 5, np.uint16).reshape(-1, 64, 8)
-    cend = get(k, plan, 6, np.uint16).reshape(-1, 64, g["rpl"])
+    W, R = g["waves"], g["rounds"]
+    sub = 64 * R
+    pt_ptr, pt_tile, wt_e0 = get(k, plan, 0, np.int32), get(k, plan, 1, np.int32), get(k, plan, 2, np.int32)
+    desc = get(k, plan, 3, np.uint32).reshape(-1, 64, R)
+    perm, lcol = get(k, plan, 4, np.int32), get(k, plan, 5, np.uint16)
     far = get(k, plan, 7, np.int32), get(k, plan, 8, np.int32), get(k, plan, 9, np.int32)
     rows, cols, pos = [], [], []
-    npanels = pt_ptr.size - 1
-    for p in range(npanels):
+    steps = 0
+    for p in range(pt_ptr.size - 1):
         last_tile = -1
         for pt in range(pt_ptr[p], pt_ptr[p + 1]):
             t = int(pt_tile[pt])
             assert t > last_tile, "a panel's staged tiles ascend"
             last_tile = t
-            for w in range(g["waves"]):
-                for c in range(pt_chunk0[pt * g["waves"] + w], pt_chunk0[pt * g["waves"] + w + 1]):
-                    e0 = int(chunk_e0[c])
-                    assert e0 % 2 == 0
-                    start = 0
-                    for rl in range(sub):
-                        end = int(cend[c, rl & 63, rl >> 6])
-                        assert start <= end <= g["ch"], (start, end)
-                        for kk in range(start, end):
-                            pi = kk >> 1
-                            lc = int(lcol[c, pi & 63, 2 * (pi >> 6) + (kk & 1)])
-                            rows.append(p * g["panel"] + w * sub + rl)
-                            cols.append(t * g["tw"] + lc)
-                            pos.append(int(perm[e0 + kk]))
-                        start = end
-                    ne = start
-                    assert ne > 0 and chunk_e0[c + 1] - e0 == ne + (ne & 1)
-                    if ne & 1:
-                        assert perm[e0 + ne] == -1                      # padding to an even count
+            for w in range(W):
+                off = int(wt_e0[pt * W + w])
+                seen_rows = set()
+                for a in range(R):
+                    cnt = (desc[pt * W + w, :, a] & 0xffffff).astype(np.int64)
+                    rl = (desc[pt * W + w, :, a] >> 24).astype(np.int64)
+                    assert np.all(cnt[:-1] >= cnt[1:]), "rows of a round sorted by count"
+                    if a:
+                        assert cnt[0] <= (desc[pt * W + w, 63, a - 1] & 0xffffff), "rounds in rank order"
+                    for l in range(64):
+                        if cnt[l]:
+                            assert int(rl[l]) not in seen_rows and rl[l] < sub
+                            seen_rows.add(int(rl[l]))
+                    for j in range(int(cnt[0])):
+                        nact = int(np.sum(cnt > j))
+                        steps += 1
+                        for l in range(nact):
+                            rows.append(p * g["panel"] + w * sub + int(rl[l]))
+                            cols.append(t * g["tw"] + int(lcol[off + l]))
+                            pos.append(int(perm[off + l]))
+                        off += nact
+                assert off == wt_e0[pt * W + w + 1]
+    assert steps == info(k, plan)["steps"]
     return (np.array(rows, dtype=np.int64), np.array(cols, dtype=np.int64), np.array(pos, dtype=np.int64)), far
 
 
