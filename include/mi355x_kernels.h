@@ -275,6 +275,9 @@ int mi355x_spmv_bsr(mi355x_handle_t h, int mbs, int bs, const int *ai, const int
  * (it then partitions by VALUES); aligned 16-byte loads need aa 16-byte aligned */
 int mi355x_spmv_bsr_planned(mi355x_handle_t h, mi355x_spmv_plan_t plan, int bs, const int *ai, const int *aj,
                             const double *aa, const double *x, double *y);
+/* MatMultAdd_SeqBAIJ_3/_4/_N  src/mat/impls/baij/seq/baij2.c:1168-1480   z = y + A x with the same kernel; z may alias y */
+int mi355x_spmv_bsr_planned_add(mi355x_handle_t h, mi355x_spmv_plan_t plan, int bs, const int *ai, const int *aj,
+                                const double *aa, const double *x, const double *y, double *z);
 /* the same product with the row-block kernel's form chosen by the caller (development / A-B runs): x_in_lds != 0 stages the x
  * entries of the row block's block columns in LDS once per block instead of gathering them once per value */
 int mi355x_spmv_bsr_planned_form(mi355x_handle_t h, mi355x_spmv_plan_t plan, int bs, int x_in_lds, const int *ai, const int *aj,

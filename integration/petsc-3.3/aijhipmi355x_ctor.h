@@ -32,11 +32,13 @@ static PetscErrorCode hipaij_refresh_view(Mat A) {
 /* lazily, from MatSeqAIJHIPUpload: the parent's container may have been filled or replaced without this type's MatAssemblyEnd
  * (MatDuplicate_SeqAIJ, MatCopy_SeqAIJ, MatConvert, MatDuplicateNoCreate_SeqAIJ set assembled themselves).  New arrays or another
  * nonzero count: the pattern is not the one the device copy was built for -- rebuild; same arrays: the object state decides. */
+static PetscErrorCode hipbaij_refresh_view_if_stale(Mat A);   /* baijhipmi355x_ctor.h: the same for a matrix whose parent is MATSEQBAIJ */
 static PetscErrorCode hipaij_refresh_view_if_stale(Mat A) {
   Mat_SeqAIJ *aij = (Mat_SeqAIJ *)A->data;
   HipAIJ *v = HipAIJGet(A);
   PetscErrorCode ierr;
   PetscFunctionBegin;
+  if (SD(A)->baij_parent) { ierr = hipbaij_refresh_view_if_stale(A);CHKERRQ(ierr); PetscFunctionReturn(0); }
   if (!A->assembled) PetscFunctionReturn(0);
   if (v->i != aij->i || v->j != aij->j || v->a != aij->a || v->nz != aij->nz || !v->compact) {
     const PetscBool new_pattern = (PetscBool)(v->i != aij->i || v->j != aij->j || v->nz != aij->nz);
@@ -96,6 +98,9 @@ PetscErrorCode MatCreate_SeqAIJHIPMI355X(Mat B) {
   B->ops->zeroentries      = MatZeroEntries_SeqAIJHIP;
   B->ops->diagonalscale    = MatDiagonalScale_SeqAIJHIP;
   B->ops->setvaluesbatch   = MatSetValuesBatch_SeqAIJHIP;
+  B->ops->setfromoptions   = MatSetFromOptions_SeqAIJHIP;  /* the type's -mat_hipmi355x_* options under the matrix's prefix (slot 76); MatSetFromOptions_SeqAIJ has none of its own in 3.3 */
+  /* ops->duplicate stays MatDuplicate_SeqAIJ (aij.c:3964): it creates the new matrix with MatSetType(type_name), i.e. through THIS
+   * constructor, and fills the parent's container; the view is refreshed when the copy is first used (hipaij_refresh_view_if_stale) */
   B->ops->assemblyend      = MatAssemblyEnd_SeqAIJHIPMI355X;
   B->ops->destroy          = MatDestroy_SeqAIJHIPMI355X;
   B->ops->getvecs          = MatGetVecs_HIP;

@@ -1,0 +1,111 @@
+/* Source fragment, included by petsc-dev_amd/host/aijhip.c when built inside a PETSc 3.3 tree (after aijhipmi355x_ctor.h; it needs
+ * that file's static ops in scope).  MATSEQBAIJHIPMI355X as a subclass of MATSEQBAIJ: the parent constructor first
+ * (MatCreate_SeqBAIJ, src/mat/impls/baij/seq/baij.c:3296), then the slots of the product path are overridden -- mult
+ * (MatMult_SeqBAIJ_3/_4/_N, baij2.c:331-436,981), multadd (MatMultAdd_SeqBAIJ_3/_4/_N, baij2.c:1168-1480) -- plus assemblyend,
+ * destroy and getvecs; the device mirror hangs off B->spptr; the type name is changed last.  Everything else -- MatSetValuesBlocked,
+ * preallocation ("MatSeqBAIJSetPreallocation_C"), MatScale, MatDiagonalScale, MatZeroEntries, MatGetDiagonal, the transpose products
+ * (MatMultTranspose_SeqBAIJ, baij2.c:1579), the factorisations -- stays the parent's: those routines work on the parent's container
+ * (through VecGetArray for vectors of the HIPMI355X type: ops->getarray brings the values to the host) and bump the object state, which
+ * is what tells this type to send the values to the device again.
+ * The parent owns the block CSR container (Mat_SeqBAIJ, baij.h:13-30: i, j over blocks, a = bs x bs column-major blocks); the kernels'
+ * callers read it through the same view (HipAIJ) as the AIJ type, with m counting block rows and bs the block size. */
+#include <../src/mat/impls/baij/seq/baij.h>
+
+EXTERN_C_BEGIN
+extern PetscErrorCode MatCreate_SeqBAIJ(Mat);
+EXTERN_C_END
+
+static HipAIJParentOps seqbaij_parent;
+
+static PetscErrorCode hipbaij_refresh_view(Mat A) {
+  Mat_SeqBAIJ *b = (Mat_SeqBAIJ *)A->data;
+  HipAIJ *v = HipAIJGet(A);
+  PetscFunctionBegin;
+  v->m = b->mbs; v->n = A->cmap->n;
+  v->i = b->i; v->j = b->j; v->a = b->a; v->ilen = b->ilen; v->imax = b->imax;
+  v->nz = b->nz; v->maxnz = b->maxnz; v->bs = A->rmap->bs;
+  v->compact = A->assembled;                       /* MatAssemblyEnd_SeqBAIJ has squeezed the block rows (baij.c:2262-2340) */
+  v->nonzerorows = 0;
+  for (PetscInt r = 0; r < b->mbs; r++) v->nonzerorows += (b->i[r + 1] > b->i[r]);
+  PetscFunctionReturn(0);
+}
+
+/* (called from hipaij_refresh_view_if_stale for matrices whose parent is MATSEQBAIJ) */
+static PetscErrorCode hipbaij_refresh_view_if_stale(Mat A) {
+  Mat_SeqBAIJ *b = (Mat_SeqBAIJ *)A->data;
+  HipAIJ *v = HipAIJGet(A);
+  PetscErrorCode ierr;
+  PetscFunctionBegin;
+  if (!A->assembled) PetscFunctionReturn(0);
+  if (v->i != b->i || v->j != b->j || v->a != b->a || v->nz != b->nz || v->bs != A->rmap->bs || !v->compact) {
+    const PetscBool new_pattern = (PetscBool)(v->i != b->i || v->j != b->j || v->nz != b->nz || v->bs != A->rmap->bs);
+    ierr = hipbaij_refresh_view(A);CHKERRQ(ierr);
+    SD(A)->uploaded_state = -1;
+    if (new_pattern) SD(A)->pattern_nz = -1;
+  }
+  PetscFunctionReturn(0);
+}
+
+static PetscErrorCode MatAssemblyEnd_SeqBAIJHIPMI355X(Mat A, MatAssemblyType mode) {
+  PetscErrorCode ierr;
+  PetscFunctionBegin;
+  ierr = (*seqbaij_parent.assemblyend)(A, mode);CHKERRQ(ierr);
+  if (mode == MAT_FLUSH_ASSEMBLY) PetscFunctionReturn(0);
+  A->assembled = PETSC_TRUE;                       /* matrix.c sets it after this slot returns; the view wants it now */
+  ierr = hipbaij_refresh_view(A);CHKERRQ(ierr);
+  /* MatAssemblyEnd_SeqBAIJ installs the block-size specialised CPU products (MatSeqBAIJSetNumericFactorization / the switch in
+   * MatSeqBAIJSetPreallocation_SeqBAIJ, baij.c:3080-3170, assigns ops->mult = MatMult_SeqBAIJ_3 ... at preallocation): this type's go back in */
+  A->ops->mult    = MatMult_SeqAIJHIP;
+  A->ops->multadd = MatMultAdd_SeqAIJHIP;
+  SD(A)->uploaded_state = -1;
+  PetscFunctionReturn(0);
+}
+
+static PetscErrorCode MatDestroy_SeqBAIJHIPMI355X(Mat A) {   /* mirror first, spptr zeroed, then the parent (as aijcusp.cu:575-590 does for AIJ) */
+  PetscErrorCode ierr;
+  PetscFunctionBegin;
+  if (SD(A)) {
+    Mat_SeqAIJHIP *d = SD(A);
+    device_free(A);
+    if (d->time_ev) { for (PetscInt k = 0; k < 2 * d->time_cap; k++) mi355x_event_destroy(d->time_ev[k]); HipFree(d->time_ev); }
+    ierr = PetscFree(A->spptr);CHKERRQ(ierr);
+    A->spptr = 0;
+  }
+  ierr = (*seqbaij_parent.destroy)(A);CHKERRQ(ierr);
+  PetscFunctionReturn(0);
+}
+
+/* "MatSeqBAIJSetPreallocation_C" of the parent assigns the block-size specialised ops->mult / multadd (baij.c:3120-3170): this type
+ * wraps it and puts its own back, as MatMPIAIJSetPreallocation is wrapped by the MPIAIJ subclass (mpiaijcusp.cu:36-46) */
+static PetscErrorCode (*seqbaij_parent_prealloc)(Mat, PetscInt, PetscInt, PetscInt *) = 0;
+EXTERN_C_BEGIN
+static PetscErrorCode MatSeqBAIJSetPreallocation_SeqBAIJHIPMI355X(Mat B, PetscInt bs, PetscInt nz, PetscInt *nnz) {
+  PetscErrorCode ierr;
+  PetscFunctionBegin;
+  ierr = (*seqbaij_parent_prealloc)(B, bs, nz, nnz);CHKERRQ(ierr);
+  B->ops->mult    = MatMult_SeqAIJHIP;
+  B->ops->multadd = MatMultAdd_SeqAIJHIP;
+  PetscFunctionReturn(0);
+}
+PetscErrorCode MatCreate_SeqBAIJHIPMI355X(Mat B) {
+  PetscErrorCode ierr;
+  Mat_SeqAIJHIP *d;
+  PetscFunctionBegin;
+  ierr = MatCreate_SeqBAIJ(B);CHKERRQ(ierr);
+  seqbaij_parent.assemblyend = B->ops->assemblyend;
+  seqbaij_parent.destroy = B->ops->destroy;
+  ierr = PetscObjectQueryFunction((PetscObject)B, "MatSeqBAIJSetPreallocation_C", (void (**)(void))&seqbaij_parent_prealloc);CHKERRQ(ierr);
+  ierr = PetscNewLog(B, Mat_SeqAIJHIP, &d);CHKERRQ(ierr);
+  d->uploaded_state = -1; d->t_state = -1; d->pattern_nz = -1;
+  d->baij_parent = PETSC_TRUE;
+  B->spptr = d;
+  B->ops->mult        = MatMult_SeqAIJHIP;            /* bs > 1: mi355x_spmv_bsr_planned / mi355x_spmv_bsr4_mfma (-mat_hipmi355x_baij4) */
+  B->ops->multadd     = MatMultAdd_SeqAIJHIP;
+  B->ops->assemblyend = MatAssemblyEnd_SeqBAIJHIPMI355X;
+  B->ops->destroy     = MatDestroy_SeqBAIJHIPMI355X;
+  B->ops->getvecs     = MatGetVecs_HIP;
+  ierr = PetscObjectComposeFunction((PetscObject)B, "MatSeqBAIJSetPreallocation_C", "MatSeqBAIJSetPreallocation_SeqBAIJHIPMI355X", (PetscVoidFunction)MatSeqBAIJSetPreallocation_SeqBAIJHIPMI355X);CHKERRQ(ierr);
+  ierr = PetscObjectChangeTypeName((PetscObject)B, MATSEQBAIJHIPMI355X);CHKERRQ(ierr);
+  PetscFunctionReturn(0);
+}
+EXTERN_C_END

@@ -118,6 +118,7 @@ KERNEL_API = {
     "mi355x_csr_assemble": [vp, i32, vp, vp, vp, vp, vp],
     "mi355x_spmv_bsr": [vp, i32, i32, vp, vp, vp, vp, vp],
     "mi355x_spmv_bsr_planned": [vp, vp, i32, vp, vp, vp, vp, vp],
+    "mi355x_spmv_bsr_planned_add": [vp, vp, i32, vp, vp, vp, vp, vp, vp],
     "mi355x_spmv_bsr_planned_form": [vp, vp, i32, i32, vp, vp, vp, vp, vp],
     "mi355x_ilu0_lower_level": [vp, i32, vp, vp, vp, vp, vp, vp],
     "mi355x_ilu0_upper_level": [vp, i32, vp, vp, vp, vp, vp],

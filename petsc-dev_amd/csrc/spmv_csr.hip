@@ -739,7 +739,8 @@ template <int BS, bool XLDS>
 __global__ __launch_bounds__(SPMV_THREADS) void bsr_rowblock_kernel(const int2 *__restrict__ rowblk, int nblocks,
                                                                    const int *__restrict__ ai, const int *__restrict__ aj,
                                                                    const double *__restrict__ aa,
-                                                                   const double *__restrict__ x, double *__restrict__ y) {
+                                                                   const double *__restrict__ x, const double *yin, double *y) {
+  // yin != NULL: y = yin + A x (MatMultAdd_SeqBAIJ_N, baij2.c:1168-1480; y may alias yin: every point row is read and written by one lane)
   __shared__ double prod[SPMV_BLOCK_NNZ];
   __shared__ int ajs[XLDS ? 1 : SPMV_BLOCK_NNZ / 4 + 1];   // block columns of the row block (bs >= 2: at most NNZ/4 blocks)
   __shared__ double xs[XLDS ? (SPMV_BLOCK_NNZ / (BS * BS) + 1) * BS : 1];   // XLDS: x[bs * col .. + bs) of every stored block
@@ -774,11 +775,11 @@ __global__ __launch_bounds__(SPMV_THREADS) void bsr_rowblock_kernel(const int2 *
 #pragma unroll
     for (int r = 0; r < BS; ++r) { double v = wave_sum(acc[r]); if ((tid & 63) == 0) part[tid / 64][r] = v; }
     __syncthreads();
-    if (tid < BS) { double t = part[0][tid]; for (int w = 1; w < SPMV_THREADS / MI355X_WAVE; ++w) t += part[w][tid]; y[(long)r0 * BS + tid] = t; }
+    if (tid < BS) { double t = part[0][tid]; for (int w = 1; w < SPMV_THREADS / MI355X_WAVE; ++w) t += part[w][tid]; y[(long)r0 * BS + tid] = yin ? yin[(long)r0 * BS + tid] + t : t; }
     return;
   }
   if (k1 == k0) {   // only empty block rows
-    if (tid < nv) y[(long)r0 * BS + tid] = 0.0;
+    if (tid < nv) y[(long)r0 * BS + tid] = yin ? yin[(long)r0 * BS + tid] : 0.0;
     return;
   }
   int tpr = 1;
@@ -850,7 +851,7 @@ __global__ __launch_bounds__(SPMV_THREADS) void bsr_rowblock_kernel(const int2 *
   double sum = 0.0;
   for (int j = sub; j < cnt; j += tpr) sum += prod[s + BS * j + rr_];
   for (int off = tpr >> 1; off > 0; off >>= 1) sum += __shfl_down(sum, off, MI355X_WAVE);
-  if (v < nv && sub == 0) y[(long)br * BS + rr_] = sum;
+  if (v < nv && sub == 0) y[(long)br * BS + rr_] = yin ? yin[(long)br * BS + rr_] + sum : sum;
   // block rows with very few blocks: the row block can hold more point rows than the workgroup has lanes
   // (<= 256 block rows x bs); the remaining ones are summed the same way, one lane per point row (tpr is 1 here)
   for (int v2 = tid + SPMV_THREADS; v2 < nv; v2 += SPMV_THREADS) {
@@ -859,7 +860,7 @@ __global__ __launch_bounds__(SPMV_THREADS) void bsr_rowblock_kernel(const int2 *
     const int s2 = b0_ * BS2 - k0, cnt2 = (b1_ - b0_) * BS;
     double sum2 = 0.0;
     for (int j = 0; j < cnt2; ++j) sum2 += prod[s2 + BS * j + rr2];
-    y[(long)br2 * BS + rr2] = sum2;
+    y[(long)br2 * BS + rr2] = yin ? yin[(long)br2 * BS + rr2] + sum2 : sum2;
   }
 }
 
@@ -1514,7 +1515,7 @@ int mi355x_spmv_csr_add(mi355x_handle_t h, mi355x_spmv_plan_t plan, const int *a
 }
 
 static int spmv_bsr_planned_impl(mi355x_handle_t h, mi355x_spmv_plan_t p, int bs, const int *ai, const int *aj,
-                                 const double *aa, const double *x, double *y, bool xlds) {
+                                 const double *aa, const double *x, const double *yin, double *y, bool xlds) {
   if (p->nblocks == 0) return 0;
 #if SPMV_REMAP == 2
   const int perb = MI355X_NXCD * SPMV_CH;
@@ -1522,8 +1523,8 @@ static int spmv_bsr_planned_impl(mi355x_handle_t h, mi355x_spmv_plan_t p, int bs
 #else
   dim3 grid(p->nblocks), block(SPMV_THREADS);
 #endif
-#define BSR_GO(B) do { if (xlds) hipLaunchKernelGGL((bsr_rowblock_kernel<B, true>), grid, block, 0, h->stream, p->d_rowblk, p->nblocks, ai, aj, aa, x, y); \
-                       else hipLaunchKernelGGL((bsr_rowblock_kernel<B, false>), grid, block, 0, h->stream, p->d_rowblk, p->nblocks, ai, aj, aa, x, y); } while (0)
+#define BSR_GO(B) do { if (xlds) hipLaunchKernelGGL((bsr_rowblock_kernel<B, true>), grid, block, 0, h->stream, p->d_rowblk, p->nblocks, ai, aj, aa, x, yin, y); \
+                       else hipLaunchKernelGGL((bsr_rowblock_kernel<B, false>), grid, block, 0, h->stream, p->d_rowblk, p->nblocks, ai, aj, aa, x, yin, y); } while (0)
   switch (bs) {
     case 2: BSR_GO(2); break;
     case 3: BSR_GO(3); break;
@@ -1541,11 +1542,16 @@ static int spmv_bsr_planned_impl(mi355x_handle_t h, mi355x_spmv_plan_t p, int bs
 // development / A-B entry points: the two forms of the row-block BCSR kernel side by side (tests/tools/cfg5_baij.py)
 int mi355x_spmv_bsr_planned_form(mi355x_handle_t h, mi355x_spmv_plan_t p, int bs, int x_in_lds, const int *ai, const int *aj,
                                  const double *aa, const double *x, double *y) {
-  return spmv_bsr_planned_impl(h, p, bs, ai, aj, aa, x, y, x_in_lds != 0);
+  return spmv_bsr_planned_impl(h, p, bs, ai, aj, aa, x, nullptr, y, x_in_lds != 0);
 }
 int mi355x_spmv_bsr_planned(mi355x_handle_t h, mi355x_spmv_plan_t p, int bs, const int *ai, const int *aj,
                             const double *aa, const double *x, double *y) {
-  return spmv_bsr_planned_impl(h, p, bs, ai, aj, aa, x, y, MI355X_BSR_XLDS_DEFAULT != 0);
+  return spmv_bsr_planned_impl(h, p, bs, ai, aj, aa, x, nullptr, y, MI355X_BSR_XLDS_DEFAULT != 0);
+}
+// z = y + A x (MatMultAdd_SeqBAIJ_N, baij2.c:1168-1480); z may alias y
+int mi355x_spmv_bsr_planned_add(mi355x_handle_t h, mi355x_spmv_plan_t p, int bs, const int *ai, const int *aj,
+                                const double *aa, const double *x, const double *y, double *z) {
+  return spmv_bsr_planned_impl(h, p, bs, ai, aj, aa, x, y, z, MI355X_BSR_XLDS_DEFAULT != 0);
 }
 
 int mi355x_csr_assemble(mi355x_handle_t h, int nseg, const int *segptr, const int *segslot, const int *order, const double *v, double *aa) {

@@ -151,6 +151,34 @@ static PetscErrorCode seqaij_check_inode(Mat A) {
   return 0;
 }
 
+/* ---------------------------------------------------------------- the type's options
+ * -mat_hipmi355x_index_compression, _row_patterns, _value_patterns, _tiled, _tiled_stage_min.  MatSetFromOptions (ops->setfromoptions,
+ * slot 76, matimpl.h:110; gcreate.c:201-203) reads them under the matrix's own options prefix and keeps them with the matrix; a matrix
+ * that was never asked falls back to the global database when its device copy is built (blocks of an MPIAIJ matrix, matrices created
+ * by MatCreateSeqAIJWithArrays and used at once). */
+enum { HOPT_IC = 0, HOPT_RP, HOPT_VP, HOPT_TILED, HOPT_TILED_SMIN, HOPT_N };
+static const char *const hopt_name[HOPT_N] = {"-mat_hipmi355x_index_compression", "-mat_hipmi355x_row_patterns", "-mat_hipmi355x_value_patterns",
+                                              "-mat_hipmi355x_tiled", "-mat_hipmi355x_tiled_stage_min"};
+static PetscErrorCode hip_mat_option(Mat A, int which, PetscInt *val) {
+  Mat_SeqAIJHIP *d = SD(A);
+  PetscBool set;
+  if (d->opt_set[which]) { *val = d->opt[which]; return 0; }
+  return PetscOptionsGetInt(NULL, hopt_name[which], val, &set);
+}
+static PetscErrorCode MatSetFromOptions_SeqAIJHIP(Mat A) {
+  PetscErrorCode ierr;
+  Mat_SeqAIJHIP *d = SD(A);
+  for (int k = 0; k < HOPT_N; k++) {
+    PetscInt v = 0; PetscBool set = PETSC_FALSE;
+    ierr = PetscOptionsGetInt(HipObjPrefix(A), hopt_name[k], &v, &set);CHKERRQ(ierr);
+    if (set && (!d->opt_set[k] || d->opt[k] != v)) {
+      d->opt[k] = v; d->opt_set[k] = PETSC_TRUE;
+      d->uploaded_state = -1; d->pattern_nz = -1;            /* the analyses run again with the new choice */
+    }
+  }
+  return 0;
+}
+
 /* ---------------------------------------------------------------- device mirror */
 static PetscErrorCode device_free(Mat A) {
   Mat_SeqAIJHIP *d = SD(A);
@@ -176,7 +204,10 @@ static PetscErrorCode device_free(Mat A) {
 #endif
   const PetscBool cprow = d->cprow, timing = d->timing;
   const PetscInt tn = d->time_n, tcap = d->time_cap; mi355x_event_t *tev = d->time_ev;
+  PetscInt opt[8]; PetscBool opt_set[8];
+  memcpy(opt, d->opt, sizeof(opt)); memcpy(opt_set, d->opt_set, sizeof(opt_set));
   memset(d, 0, sizeof(*d));
+  memcpy(d->opt, opt, sizeof(opt)); memcpy(d->opt_set, opt_set, sizeof(opt_set));   /* what MatSetFromOptions was told outlives the arrays */
   d->uploaded_state = -1; d->t_state = -1; d->pattern_nz = -1;
   d->n_uploads = nup; d->cprow = cprow;   /* a count and a request: they outlive the arrays */
   d->t_builds = tb; d->t_refreshes = tr;
@@ -238,18 +269,18 @@ PetscErrorCode MatSeqAIJHIPUpload(Mat A) {
     CHKHIP(mi355x_memcpy_h2d(dc->h, d->d_j, a->j, sizeof(PetscInt) * (size_t)a->nz));
     UP_TICK("row pointer and columns up");
     if (a->bs <= 1) {
-      PetscInt ic = 1; PetscBool set;
+      PetscInt ic = 1;
       CHKHIP(mi355x_spmv_plan_create(dc->h, nrows, ip, use_cprow ? ridx : NULL, &d->plan));
       UP_TICK("row-block plan");
       /* -mat_hipmi355x_index_compression <0|1> (default 1): one byte per nonzero instead of a 4-byte column index
        * when the matrix uses <= 256 distinct (col - row) offsets; plain CSR otherwise */
-      ierr = PetscOptionsGetInt(NULL, "-mat_hipmi355x_index_compression", &ic, &set);CHKERRQ(ierr);
+      ierr = hip_mat_option(A, HOPT_IC, &ic);CHKERRQ(ierr);
       if (ic && !use_cprow) {
         PetscInt rp = 1;
         CHKHIP(mi355x_spmv_plan_compress_indices(dc->h, d->plan, a->i, a->j));
         /* -mat_hipmi355x_row_patterns <0|1> (default 1): stencil matrices whose rows' offset lists come from a small dictionary
          * stream 4 bytes per ROW instead of 1 byte per nonzero + the row pointer (spmv_csr_rowblock_pat_kernel); same bits */
-        ierr = PetscOptionsGetInt(NULL, "-mat_hipmi355x_row_patterns", &rp, &set);CHKERRQ(ierr);
+        ierr = hip_mat_option(A, HOPT_RP, &rp);CHKERRQ(ierr);
         CHKHIP(mi355x_spmv_plan_use_patterns(d->plan, rp ? 1 : 0, NULL));
         UP_TICK("offset / row-pattern dictionaries");
       }
@@ -271,9 +302,9 @@ PetscErrorCode MatSeqAIJHIPUpload(Mat A) {
        * re-cut into row panels x column tiles with the tiles of x staged in LDS; kept only if at least half of the nonzeros fall into
        * pairs worth staging.  -mat_hipmi355x_tiled_stage_min <n> (default 1024): entries a (panel, tile) pair needs to be staged. */
       {
-        PetscInt tl = -1, smin = 0; PetscBool set; int ntab = 0, ng = 0; long ngj = 0;
-        ierr = PetscOptionsGetInt(NULL, "-mat_hipmi355x_tiled", &tl, &set);CHKERRQ(ierr);
-        ierr = PetscOptionsGetInt(NULL, "-mat_hipmi355x_tiled_stage_min", &smin, &set);CHKERRQ(ierr);
+        PetscInt tl = -1, smin = 0; int ntab = 0, ng = 0; long ngj = 0;
+        ierr = hip_mat_option(A, HOPT_TILED, &tl);CHKERRQ(ierr);
+        ierr = hip_mat_option(A, HOPT_TILED_SMIN, &smin);CHKERRQ(ierr);
         CHKHIP(mi355x_spmv_plan_is_compressed(d->plan, &ntab));
         CHKHIP(mi355x_spmv_plan_group_info(d->plan, &ng, &ngj, NULL));
         if (tl != 0 && !use_cprow && !ntab && !ng && a->nz > 0) {
@@ -329,8 +360,8 @@ PetscErrorCode MatSeqAIJHIPUpload(Mat A) {
     /* -mat_hipmi355x_value_patterns <0|1> (default 1): constant-coefficient operators -- whole rows, offsets and values,
      * from a dictionary of <= 512 entries -- run a kernel that reads 2 bytes per row and no values (spmv_csr_valpat_kernel);
      * same bits.  The dictionary belongs to THESE values: derived again on every upload, dropped by every device-side change. */
-    PetscInt vp = 1; PetscBool set;
-    ierr = PetscOptionsGetInt(NULL, "-mat_hipmi355x_value_patterns", &vp, &set);CHKERRQ(ierr);
+    PetscInt vp = 1;
+    ierr = hip_mat_option(A, HOPT_VP, &vp);CHKERRQ(ierr);
     CHKHIP(mi355x_spmv_plan_use_value_patterns(d->plan, vp ? 1 : 0, NULL));
     if (vp) CHKHIP(mi355x_spmv_plan_value_patterns(dc->h, d->plan, a->i, a->j, a->a, NULL));
   }
@@ -391,9 +422,9 @@ static PetscErrorCode upload_transpose(Mat A) {
   CHKHIP(mi355x_memcpy_h2d(dc->h, d->t_a, ta, sizeof(PetscScalar) * (size_t)nz));
   CHKHIP(mi355x_spmv_plan_create(dc->h, n, ti, NULL, &d->t_plan));
   { /* the transpose of a stencil matrix is a stencil matrix: same index compression / row patterns as the matrix itself */
-    PetscInt ic = 1, rp = 1; PetscBool set;
-    ierr = PetscOptionsGetInt(NULL, "-mat_hipmi355x_index_compression", &ic, &set);CHKERRQ(ierr);
-    ierr = PetscOptionsGetInt(NULL, "-mat_hipmi355x_row_patterns", &rp, &set);CHKERRQ(ierr);
+    PetscInt ic = 1, rp = 1;
+    ierr = hip_mat_option(A, HOPT_IC, &ic);CHKERRQ(ierr);
+    ierr = hip_mat_option(A, HOPT_RP, &rp);CHKERRQ(ierr);
     if (ic) {
       CHKHIP(mi355x_spmv_plan_compress_indices(dc->h, d->t_plan, ti, tj));
       CHKHIP(mi355x_spmv_plan_use_patterns(d->t_plan, rp ? 1 : 0, NULL));
@@ -644,9 +675,9 @@ PetscErrorCode MatHIPMI355XGetRowPatterns(Mat A, PetscInt *npat) {
   }
   ierr = MatSeqAIJHIPUpload(A);CHKERRQ(ierr);
   if (SD(A)->plan && SA(A)->bs <= 1) {
-    PetscInt rp = 1; PetscBool set;
+    PetscInt rp = 1;
     CHKHIP(mi355x_spmv_plan_use_patterns(SD(A)->plan, -1, &np_));
-    ierr = PetscOptionsGetInt(NULL, "-mat_hipmi355x_row_patterns", &rp, &set);CHKERRQ(ierr);
+    ierr = hip_mat_option(A, HOPT_RP, &rp);CHKERRQ(ierr);
     if (!rp) np_ = 0;
   }
   *npat = np_;
@@ -793,9 +824,18 @@ static PetscErrorCode MatMultAdd_SeqAIJHIP(Mat A, Vec xx, Vec yy, Vec zz) {   /*
   PetscErrorCode ierr;
   HipAIJ *a = SA(A); Mat_SeqAIJHIP *d = SD(A);
   const PetscScalar *x, *y; PetscScalar *z; PetscDeviceCtx *dc;
-  if (a->bs > 1) SETERRQ(HipObjComm(A), PETSC_ERR_SUP, "MatMultAdd for the BAIJ type is outside the ported path");
   ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
   ierr = MatSeqAIJHIPUpload(A);CHKERRQ(ierr);
+  if (a->bs > 1) {   /* MatMultAdd_SeqBAIJ_3/_4/_N (baij2.c:1168-1480): the row-block kernel with y as the sums' start */
+    ierr = VecHIPGetRead(xx, &x);CHKERRQ(ierr);
+    if (zz == yy) { ierr = VecHIPGetReadWrite(zz, &z);CHKERRQ(ierr); y = z; }
+    else { ierr = VecHIPGetRead(yy, &y);CHKERRQ(ierr); ierr = VecHIPGetWrite(zz, &z);CHKERRQ(ierr); }
+    ierr = MatTimingBegin(A, dc->h);CHKERRQ(ierr);
+    CHKHIP(mi355x_spmv_bsr_planned_add(dc->h, d->plan, a->bs, d->d_i, d->d_j, d->d_a, x, y, z));
+    ierr = MatTimingEnd(A, dc->h);CHKERRQ(ierr);
+    ierr = VecHIPRestoreWrite(zz);CHKERRQ(ierr);
+    return PetscLogFlops(2.0 * a->bs * a->bs * a->nz);                   /* baij2.c: 2 bs^2 nz */
+  }
   ierr = VecHIPGetRead(xx, &x);CHKERRQ(ierr);
   if (zz == yy) { ierr = VecHIPGetReadWrite(zz, &z);CHKERRQ(ierr); y = z; }
   else {
@@ -916,8 +956,37 @@ static PetscErrorCode MatDiagonalScale_SeqAIJHIP(Mat A, Vec ll, Vec rr) {
   PetscErrorCode ierr;
   HipAIJ *a = SA(A); Mat_SeqAIJHIP *d = SD(A);
   const PetscScalar *l = NULL, *r = NULL;
-  if (a->bs > 1) SETERRQ(HipObjComm(A), PETSC_ERR_SUP, "MatDiagonalScale for the BAIJ type is outside the ported path");
   if (!a->compact) SETERRQ(HipObjComm(A), PETSC_ERR_ARG_WRONGSTATE, "matrix must be assembled");
+  if (a->bs > 1) {   /* MatDiagonalScale_SeqBAIJ, baij2.c:2026-2084: blocks column-major, v[r + c bs] *= l[row bs + r], then *= r[col bs + c]; on the
+                      * host copy (a set-up operation of this type); the wrapper's state bump sends the values to the device at the next use */
+    const PetscInt bs = a->bs, bs2 = bs * bs, mbs = a->m;
+    if (ll && ll->map->n != mbs * bs) SETERRQ(HipObjComm(A), PETSC_ERR_ARG_SIZ, "Left scaling vector wrong length");
+    if (rr && rr->map->n != a->n) SETERRQ(HipObjComm(A), PETSC_ERR_ARG_SIZ, "Right scaling vector wrong length");
+    if (ll) {
+      ierr = VecGetArrayRead(ll, &l);CHKERRQ(ierr);
+      for (PetscInt i = 0; i < mbs; i++) {
+        const PetscScalar *li = l + (size_t)i * bs;
+        PetscScalar *v = a->a + (size_t)bs2 * a->i[i];
+        for (PetscInt j = a->i[i]; j < a->i[i + 1]; j++) for (PetscInt k = 0; k < bs2; k++) (*v++) *= li[k % bs];
+      }
+      ierr = VecRestoreArrayRead(ll, &l);CHKERRQ(ierr);
+      ierr = PetscLogFlops((PetscLogDouble)a->nz);CHKERRQ(ierr);       /* (the reference logs the block count, baij2.c:2060) */
+    }
+    if (rr) {
+      ierr = VecGetArrayRead(rr, &r);CHKERRQ(ierr);
+      for (PetscInt i = 0; i < mbs; i++) {
+        PetscScalar *v = a->a + (size_t)bs2 * a->i[i];
+        for (PetscInt j = a->i[i]; j < a->i[i + 1]; j++) {
+          const PetscScalar *ri = r + (size_t)bs * a->j[j];
+          for (PetscInt k = 0; k < bs; k++) { const PetscScalar x = ri[k]; for (PetscInt t = 0; t < bs; t++) v[t] *= x; v += bs; }
+        }
+      }
+      ierr = VecRestoreArrayRead(rr, &r);CHKERRQ(ierr);
+      ierr = PetscLogFlops((PetscLogDouble)a->nz);CHKERRQ(ierr);
+    }
+    d->uploaded_state = -1;
+    return 0;
+  }
   if (ll && ll->map->n != a->m) SETERRQ(HipObjComm(A), PETSC_ERR_ARG_SIZ, "Left scaling vector wrong length");
   if (rr && rr->map->n != a->n) SETERRQ(HipObjComm(A), PETSC_ERR_ARG_SIZ, "Right scaling vector wrong length");
   const PetscBool on_device = (PetscBool)(device_values_current(A) && !d->cprow);
@@ -980,10 +1049,12 @@ static PetscErrorCode MatDestroy_SeqAIJHIP(Mat A) {   /* free the mirror and zer
 #endif
 #if defined(PETSCHIPMI355X_WITH_PETSC)
 #include "aijhipmi355x_ctor.h"    /* integration/petsc-3.3/: the constructor as a subclass of the reference's MATSEQAIJ */
+#include "baijhipmi355x_ctor.h"   /* ... and MATSEQBAIJHIPMI355X as a subclass of MATSEQBAIJ */
 #else
 static PetscErrorCode MatSeqAIJSetPreallocation_SeqAIJHIP(Mat A, PetscInt nz, const PetscInt nnz[]) { return seqaij_prealloc(A, nz, nnz); }
 static PetscErrorCode MatSeqAIJSetPreallocationCSR_SeqAIJHIP(Mat B, const PetscInt *i, const PetscInt *j, const PetscScalar *a);
 static PetscErrorCode MatSeqBAIJSetPreallocationCSR_SeqBAIJHIP(Mat B, PetscInt bs, const PetscInt *i, const PetscInt *j, const PetscScalar *a);
+static PetscErrorCode MatDuplicate_SeqAIJHIP(Mat A, MatDuplicateOption op, Mat *M);
 
 /* MatCreate_SeqAIJCUSP (aijcusp.cu:657-681) fills, after the parent constructor, the slots mult, multadd, multtranspose,
  * multtransposeadd, assemblyend, destroy, getvecs, setvaluesbatch; the container and its assembly are this file's too
@@ -1012,6 +1083,8 @@ static PetscErrorCode create_common(Mat B, const char *tname, PetscInt bs) {
   B->ops->scale = MatScale_SeqAIJHIP;
   B->ops->diagonalscale = MatDiagonalScale_SeqAIJHIP;
   B->ops->setvaluesbatch = MatSetValuesBatch_SeqAIJHIP;
+  B->ops->duplicate = MatDuplicate_SeqAIJHIP;
+  B->ops->setfromoptions = MatSetFromOptions_SeqAIJHIP;
   B->ops->destroy = MatDestroy_SeqAIJHIP;
   B->ops->getvecs = MatGetVecs_HIP;
   ierr = PetscObjectComposeFunction((PetscObject)B, "MatSeqAIJGetArrays_C", "MatSeqAIJGetArrays", (PetscVoidFunction)MatSeqAIJGetArrays);CHKERRQ(ierr);
@@ -1029,10 +1102,29 @@ static PetscErrorCode create_common(Mat B, const char *tname, PetscInt bs) {
   }
   return 0;
 }
+/* MatDuplicate_SeqAIJ (aij.c:3964) / MatDuplicate_SeqBAIJ (baij.c:2874): same type, same layouts, the pattern copied, the values copied
+ * (MAT_COPY_VALUES) or zero; MAT_SHARE_NONZERO_PATTERN copies the pattern as well (the harness container has no shared arrays).  The
+ * type's options go along. */
+static PetscErrorCode adopt_csr(Mat B, PetscInt nrows, PetscInt bs, const PetscInt *i, const PetscInt *j, const PetscScalar *a);
+static PetscErrorCode MatDuplicate_SeqAIJHIP(Mat A, MatDuplicateOption op, Mat *M) {
+  PetscErrorCode ierr;
+  HipAIJ *a = SA(A);
+  Mat B;
+  if (!a->compact) SETERRQ(HipObjComm(A), PETSC_ERR_ARG_WRONGSTATE, "Not for unassembled matrix");
+  ierr = MatCreate(HipObjComm(A), &B);CHKERRQ(ierr);
+  ierr = MatSetSizes(B, A->rmap->n, A->cmap->n, A->rmap->n, A->cmap->n);CHKERRQ(ierr);
+  ierr = MatSetType(B, HipObjTypeName(A));CHKERRQ(ierr);
+  ierr = adopt_csr(B, a->m, a->bs > 1 ? a->bs : 1, a->i, a->j, a->a);CHKERRQ(ierr);
+  if (op != MAT_COPY_VALUES) memset(SA(B)->a, 0, sizeof(PetscScalar) * (size_t)a->nz * (size_t)(a->bs > 1 ? a->bs * a->bs : 1));
+  memcpy(SD(B)->opt, SD(A)->opt, sizeof(SD(A)->opt)); memcpy(SD(B)->opt_set, SD(A)->opt_set, sizeof(SD(A)->opt_set));
+  SD(B)->cprow = SD(A)->cprow;
+  *M = B;
+  return 0;
+}
 PetscErrorCode MatCreate_SeqAIJHIPMI355X(Mat B) { return create_common(B, MATSEQAIJHIPMI355X, 1); }
 PetscErrorCode MatCreate_SeqBAIJHIPMI355X(Mat B) { return create_common(B, MATSEQBAIJHIPMI355X, 0); }
 
-/* MatCreateSeqAIJWithArrays (aij.c): the arrays are copied (the reference aliases them) */
+/* MatCreateSeqAIJWithArrays (aij.c): the arrays are copied (the reference aliases them); i, j, a may be the matrix's own (MatDuplicate) */
 static PetscErrorCode adopt_csr(Mat B, PetscInt nrows, PetscInt bs, const PetscInt *i, const PetscInt *j, const PetscScalar *a) {
   PetscErrorCode ierr;
   HipAIJ *s = SA(B);

@@ -200,10 +200,12 @@ typedef struct {
   /* column-tiled form of the product (csrc/spmv_tiled.hip: x staged in LDS) for matrices whose gathers miss the caches; NULL: the
    * row-block kernels.  tiled_fresh: its values are those of d_a */
   mi355x_spmv_tiled_t tiled; PetscBool tiled_fresh;
+  PetscInt opt[8]; PetscBool opt_set[8];   /* the type's options as MatSetFromOptions read them under the matrix's prefix (host/aijhip.c) */
   /* per-launch device timing for bench.py (hipEvent pairs on the compute stream) */
   PetscBool timing; PetscInt time_n, time_cap; mi355x_event_t *time_ev;
 #if defined(PETSCHIPMI355X_WITH_PETSC)
-  HipAIJ view;               /* of the parent's Mat_SeqAIJ */
+  HipAIJ view;               /* of the parent's Mat_SeqAIJ (or Mat_SeqBAIJ: baij_parent) */
+  PetscBool baij_parent;
 #else
   HipTriFactors *tri;        /* a factored matrix (A->factortype != MAT_FACTOR_NONE): its triangular factors on the device */
 #endif
