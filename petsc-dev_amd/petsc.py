@@ -24,7 +24,7 @@ _SIG = {
     "VecGetLocalSize": [vp, P(i32)], "VecGetOwnershipRange": [vp, P(i32), P(i32)],
     "VecSetValues": [vp, i32, vp, vp, i32], "VecAssemblyBegin": [vp], "VecAssemblyEnd": [vp],
     "VecGetArray": [vp, P(vp)], "VecRestoreArray": [vp, P(vp)], "VecGetArrayRead": [vp, P(vp)], "VecRestoreArrayRead": [vp, P(vp)],
-    "VecPlaceArray": [vp, vp], "VecResetArray": [vp],
+    "VecPlaceArray": [vp, vp], "VecResetArray": [vp], "VecReplaceArray": [vp, vp], "PetscMallocFn": [C.c_size_t, P(vp)],
     "VecHIPMI355XGetArray": [vp, P(vp)], "VecHIPMI355XRestoreArray": [vp, P(vp)], "VecHIPMI355XGetArrayRead": [vp, P(vp)],
     "VecSet": [vp, dbl], "VecCopy": [vp, vp], "VecSwap": [vp, vp], "VecScale": [vp, dbl], "VecAXPY": [vp, dbl, vp],
     "VecAYPX": [vp, dbl, vp], "VecAXPBY": [vp, dbl, dbl, vp], "VecWAXPY": [vp, dbl, vp, vp],
@@ -43,7 +43,7 @@ _SIG = {
     "MatCreateSeqBAIJWithArrays": [vp, i32, i32, i32, vp, vp, vp, P(vp)],
     "MatDestroy": [P(vp)], "MatGetSize": [vp, P(i32), P(i32)], "MatGetLocalSize": [vp, P(i32), P(i32)],
     "MatGetOwnershipRange": [vp, P(i32), P(i32)], "MatGetVecs": [vp, P(vp), P(vp)],
-    "MatDiagonalScale": [vp, vp, vp], "MatSetValuesBatch": [vp, i32, i32, vp, vp], "MatMult": [vp, vp, vp], "MatMultAdd": [vp, vp, vp, vp], "MatMultTranspose": [vp, vp, vp],
+    "MatDuplicate": [vp, i32, P(vp)], "MatSetOptionsPrefix": [vp, C.c_char_p], "MatDiagonalScale": [vp, vp, vp], "MatSetValuesBatch": [vp, i32, i32, vp, vp], "MatMult": [vp, vp, vp], "MatMultAdd": [vp, vp, vp, vp], "MatMultTranspose": [vp, vp, vp],
     "MatMultTransposeAdd": [vp, vp, vp, vp], "MatGetDiagonal": [vp, vp], "MatScale": [vp, dbl], "MatZeroEntries": [vp],
     "MatSeqAIJGetArrays": [vp, P(i32), P(vp), P(vp), P(vp)], "MatMPIAIJGetSeqAIJ": [vp, P(vp), P(vp), P(vp)],
     "MatMPIAIJGetScatter": [vp, P(vp), P(vp), P(i32)],

@@ -580,3 +580,54 @@ def test_matrixmarket_converter(built, tmp_path):
         assert np.array_equal(ai, ref.indptr) and np.array_equal(aj, ref.indices) and np.array_equal(aa, ref.data), name
     r = subprocess.run([exe, "-fin", str(tmp_path / "missing.mtx"), "-fout", "x"], capture_output=True, text=True, timeout=60)
     assert r.returncode != 0
+
+
+def test_mat_duplicate_setfromoptions_and_vec_replacearray_slots(built):
+    """Table slots SURVEY 8(b) lists that the types fill besides the products: Mat duplicate (matimpl.h:60; MatDuplicate_SeqAIJ
+    aij.c:3964, _SeqBAIJ baij.c:2874), Mat setfromoptions (matimpl.h:110: the type's own options, read under the matrix's prefix),
+    Vec replacearray (vecimpl.h:259; VecReplaceArray_Seq dvec2.c:1159).  Host-side behaviour only (no device needed)."""
+    import ctypes as C
+    from petsc_dev_amd import petsc as P
+    L = P.lib()
+    ai, aj, aa = P.gen_poisson7(5, 4, 3)
+    A = P.Mat.from_csr(ai, aj, aa)
+
+    def arrays(M):
+        m, i_, j_, a_ = C.c_int(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        L.MatSeqAIJGetArrays(M, C.byref(m), C.byref(i_), C.byref(j_), C.byref(a_))
+        ii = np.ctypeslib.as_array(C.cast(i_, C.POINTER(C.c_int)), (m.value + 1,)).copy()
+        jj = np.ctypeslib.as_array(C.cast(j_, C.POINTER(C.c_int)), (ii[-1],)).copy()
+        vv = np.ctypeslib.as_array(C.cast(a_, C.POINTER(C.c_double)), (ii[-1],)).copy()
+        return ii, jj, vv, a_.value
+
+    for op, expect_vals in ((1, aa), (0, np.zeros_like(aa)), (2, np.zeros_like(aa))):     # MAT_COPY_VALUES, MAT_DO_NOT_COPY_VALUES, MAT_SHARE_NONZERO_PATTERN
+        Bh = C.c_void_p()
+        L.MatDuplicate(A.h, op, C.byref(Bh))
+        B = P.Mat(Bh)
+        t = C.c_char_p()
+        L.MatGetType(B.h, C.byref(t))
+        assert t.value == b"seqaijhipmi355x"
+        ii, jj, vv, addr = arrays(B.h)
+        assert np.array_equal(ii, ai) and np.array_equal(jj, aj) and np.array_equal(vv, expect_vals)
+        assert addr != arrays(A.h)[3]                       # its own storage
+    # the type's options, under the matrix's prefix, through MatSetFromOptions (ops->setfromoptions)
+    L.PetscOptionsClear()
+    L.PetscOptionsInsertString(b"-fine_mat_hipmi355x_value_patterns 0 -mat_hipmi355x_value_patterns 1")
+    L.MatSetOptionsPrefix(A.h, b"fine_")
+    L.MatSetFromOptions(A.h)
+    t = C.c_char_p()
+    L.MatGetType(A.h, C.byref(t))
+    assert t.value == b"seqaijhipmi355x"                    # no -mat_type: the type it has stays (gcreate.c:188-193)
+    L.PetscOptionsClear()
+    # Vec replacearray: the vector takes the array over for good
+    v = P.Vec.create(6, comm=L.COMM_SELF)
+    p = C.c_void_p()
+    L.PetscMallocFn(6 * 8, C.byref(p))
+    src = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_double)), (6,))
+    src[:] = [1.5, -2.0, 3.25, 0.0, 7.0, -1.0]
+    L.VecReplaceArray(v.h, p)
+    q = C.c_void_p()
+    L.VecGetArray(v.h, C.byref(q))
+    assert q.value == p.value
+    L.VecRestoreArray(v.h, C.byref(q))
+    del v                                                   # frees the adopted array with the vector

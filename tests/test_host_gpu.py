@@ -280,6 +280,32 @@ def test_baij_matmult(P, bs, opt):
     set_options(L, "")
     ref = orc.spmv_bsr(bs, bi, bj, ba, x)
     assert np.allclose(vy.array(), ref, rtol=0, atol=1e-12 * 50)
+    # MatMultAdd_SeqBAIJ_3/_4/_N (baij2.c:1168-1480): z = y + A x, separate z and in place
+    y0 = rnd(mbs * bs, 7)
+    vz, vw = V(P, y0), V(P, np.zeros(mbs * bs))
+    L.MatMultAdd(A.h, vx.h, vz.h, vw.h)
+    assert np.allclose(vw.array(), y0 + ref, rtol=0, atol=1e-12 * 50)
+    L.MatMultAdd(A.h, vx.h, vz.h, vz.h)
+    assert np.allclose(vz.array(), y0 + ref, rtol=0, atol=1e-12 * 50)
+    # MatDiagonalScale_SeqBAIJ (baij2.c:2026-2084) and MatScale, then the product again; and a duplicate of the scaled matrix
+    l, r = 1.0 + 0.1 * rnd(mbs * bs, 8), 1.0 + 0.1 * rnd(mbs * bs, 9)
+    vl, vr = V(P, l), V(P, r)
+    L.MatDiagonalScale(A.h, vl.h, vr.h)
+    L.MatScale(A.h, -0.5)
+    blk_row = np.repeat(np.arange(mbs), np.diff(bi))
+    ba2 = ba.reshape(-1, bs, bs).copy()                      # [block][column][row]: column-major blocks
+    for c in range(bs):
+        for rr in range(bs):
+            ba2[:, c, rr] = ((ba2[:, c, rr] * l[blk_row * bs + rr]) * r[bj * bs + c]) * -0.5
+    ref2 = orc.spmv_bsr(bs, bi, bj, ba2.reshape(-1), x)
+    L.MatMult(A.h, vx.h, vy.h)
+    assert np.allclose(vy.array(), ref2, rtol=0, atol=1e-12 * 50)
+    import ctypes as C
+    Bh = C.c_void_p()
+    L.MatDuplicate(A.h, 1, C.byref(Bh))
+    B = P.Mat(Bh)
+    L.MatMult(B.h, vx.h, vw.h)
+    assert np.array_equal(vw.array().view(np.uint64), vy.array().view(np.uint64))
 
 
 @pytest.mark.parametrize("pc,opts", [("jacobi", ""), ("none", ""), ("ilu", ""), ("jacobi", "-ksp_gmres_restart 7"), ("jacobi", "-ksp_gmres_restart 40"),

@@ -210,3 +210,69 @@ def test_petsc_flavour_compiles_against_the_reference_headers(src):
     r = subprocess.run(cmd, capture_output=True, text=True)
     own = [l for l in r.stderr.splitlines() if ("error" in l or "warning" in l) and REF not in l.split(":")[0]]
     assert r.returncode == 0 and not own, r.stderr[-4000:]
+
+
+def test_petsc_flavour_links_every_symbol_resolves():
+    """The PETSc flavour of the plug-in compiled to OBJECTS (gcc -c -DPETSCHIPMI355X_WITH_PETSC against the reference's headers) and its
+    undefined symbols resolved: every one must be defined by the flavour's own objects, exported by libmi355x_kernels.so, a C library
+    / pthread / math name, an MPI entry point (mpiuni or a real MPI provides it), or DEFINED -- a function body or a variable definition,
+    not a mere declaration -- somewhere under /root/reference/src.  -fsyntax-only cannot see a constructor that is registered but does
+    not exist in this flavour; this does.  Nothing of the reference is compiled: its sources are only searched as text."""
+    import subprocess
+    import tempfile
+    objs = []
+    with tempfile.TemporaryDirectory() as tmp:
+        for src in PETSC_FLAVOUR_SOURCES:
+            o = os.path.join(tmp, os.path.basename(src) + ".o")
+            cmd = ["gcc", "-c", "-O0", "-std=gnu11", "-w", "-fPIC", "-DPETSCHIPMI355X_WITH_PETSC",
+                   "-I" + os.path.join(ROOT, "tests/petsc33_syntax"), "-I" + os.path.join(REF, "include"), "-I" + os.path.join(REF, "include/mpiuni"), "-I" + REF,
+                   "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "petsc-dev_amd/host"), "-I" + os.path.join(ROOT, "integration/petsc-3.3"), src, "-o", o]
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            assert r.returncode == 0, r.stderr[-3000:]
+            objs.append(o)
+        nm = subprocess.run(["nm"] + objs, capture_output=True, text=True, check=True).stdout
+    defined, undefined = set(), set()
+    for line in nm.splitlines():
+        parts = line.split()
+        if len(parts) == 2 and parts[0] == "U":
+            undefined.add(parts[1])
+        elif len(parts) == 3 and parts[1] in "TDBRVWCGS":
+            defined.add(parts[2])
+    undefined -= defined
+    import petsc_dev_amd as pda
+    kn = subprocess.run(["nm", "-D", "--defined-only", pda.kernels_lib_path()], capture_output=True, text=True, check=True).stdout
+    kernel_syms = {l.split()[-1] for l in kn.splitlines() if l.split()}
+    libc = {"malloc", "free", "calloc", "realloc", "memcpy", "memset", "memmove", "memcmp", "strcmp", "strncmp", "strlen", "strcpy", "strncpy", "snprintf", "sprintf", "fprintf",
+            "printf", "puts", "fputs", "fwrite", "stderr", "stdout", "getenv", "atoi", "atol", "atof", "strtol", "qsort", "bsearch", "sqrt", "fabs", "clock_gettime", "sched_yield",
+            "sysconf", "abort", "__stack_chk_fail", "_GLOBAL_OFFSET_TABLE_", "__isnan", "__isinf", "isnan", "isinf", "__assert_fail", "usleep", "nanosleep", "time", "strstr", "strchr",
+            "__sync_synchronize"}
+    left = sorted(s_ for s_ in undefined if s_ not in kernel_syms and s_ not in libc and not s_.startswith("pthread_") and not s_.startswith("MPI_") and not s_.startswith("MPIUNI_")
+                  and not s_.startswith("Petsc_MPI_") and not s_.startswith("__sync_") and not s_.startswith("__atomic_"))
+    # what remains must be DEFINED in the reference's sources (libpetsc provides it at link time)
+    assert left, "the flavour calls nothing of PETSc?"
+    ref_text = {}
+    missing = []
+    import glob as _glob
+    src_files = [f for f in _glob.glob(os.path.join(REF, "src", "**", "*.c"), recursive=True) if "/examples/" not in f and "/ftn-" not in f and "/f90-" not in f]
+    blob = {}
+    for name in left:
+        pat_fn = re.compile(r"^\s*(?:PetscErrorCode|void|int|PetscBool|PetscInt|const\s+char\s*\*|MPI_Comm)\s+(?:PETSCMAT_DLLEXPORT\s+|PETSC_DLLEXPORT\s+)?%s\s*\([^;{]*\)\s*\{" % re.escape(name), re.M)
+        pat_var = re.compile(r"^\s*(?:PETSC_EXTERN\s+)?(?!extern)[A-Za-z_][\w\s\*]*\(?\s*\*?\s*\b%s\b\s*\)?\s*(?:\([^;{]*\)\s*)?(?:=|;|\[)" % re.escape(name), re.M)
+        found = False
+        for f in src_files:
+            if f not in blob:
+                try:
+                    blob[f] = open(f, errors="replace").read()
+                except OSError:
+                    blob[f] = ""
+            t = blob[f]
+            if name in t and (pat_fn.search(t) or pat_var.search(t)):
+                found = True
+                break
+        if not found:
+            missing.append(name)
+    assert not missing, "undefined in the PETSc flavour and defined nowhere under %s/src: %s" % (REF, missing)
+    # the constructors hipsys.c registers are the flavour's own
+    for name in ("MatCreate_SeqAIJHIPMI355X", "MatCreate_SeqBAIJHIPMI355X", "MatCreate_MPIAIJHIPMI355X", "VecCreate_SeqHIPMI355X", "VecCreate_MPIHIPMI355X",
+                 "KSPCreate_CGHIPMI355X", "PCCreate_PBJacobi_HIPMI355X"):
+        assert name in defined, name
