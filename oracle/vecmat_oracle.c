@@ -125,22 +125,30 @@ static double block256(double *lanes) {
   return s;
 }
 static double dev_reduce(size_t n, orc_term_fn f, const double *a, const double *b) {
-  /* csrc/vec_kernels.hip reduce_kernel / launch_reduce: tiles of 1024 pairs (MI355X_TILE2), one workgroup per tile up to 8192
-   * workgroups (MI355X_REDUCE_GRID_CAP), beyond that contiguous runs of tiles; lane t of a workgroup meets its run's pairs
-   * s0 + t, s0 + t + 256, ... in that order */
-  const size_t n2 = n >> 1, ntiles = (n2 + 1023) / 1024;
-  size_t grid = ntiles;
-  if (grid < 1) grid = 1;
-  if (grid > 8192) grid = 8192;
-  const size_t per = (ntiles + grid - 1) / grid;
+  /* csrc/vec_kernels.hip reduce_kernel / launch_reduce.  Vectors below 256 MiB: <= 512 workgroups (MI355X_REDUCE_GRID_CAP), grid-stride:
+   * lane t of workgroup b meets the pairs b * 256 + t, + grid * 256, ...  Vectors of 256 MiB and more: tiles of 1024 pairs
+   * (MI355X_TILE2) in contiguous runs, one run for each of <= 4096 workgroups (MI355X_REDUCE_GRID_CAP_BIG); lane t of a workgroup meets
+   * its run's pairs s0 + t, s0 + t + 256, ... */
+  const size_t n2 = n >> 1;
+  const int runs = n * sizeof(double) >= ((size_t)256 << 20);
+  size_t grid, per = 0;
+  if (runs) {
+    const size_t ntiles = (n2 + 1023) / 1024;
+    grid = ntiles > 4096 ? 4096 : ntiles;
+    per = (ntiles + grid - 1) / grid;
+  } else {
+    grid = (n + 4095) / 4096;
+    if (grid < 1) grid = 1;
+    if (grid > 512) grid = 512;
+  }
   double *partial = (double *)malloc(sizeof(double) * grid), lanes[256], res;
   for (size_t blk = 0; blk < grid; blk++) {
-    size_t s0 = blk * per * 1024, s1 = s0 + per * 1024;
-    if (s0 > n2) s0 = n2;
-    if (s1 > n2) s1 = n2;
+    size_t first, step, end;
+    if (runs) { first = blk * per * 1024; end = first + per * 1024; if (first > n2) first = n2; if (end > n2) end = n2; step = 256; }
+    else { first = blk * 256; end = n2; step = grid * 256; }
     for (size_t t = 0; t < 256; t++) {
       double acc = 0.0;
-      for (size_t i = s0 + t; i < s1; i += 256) { acc = acc + f(a, b, 2 * i); acc = acc + f(a, b, 2 * i + 1); }
+      for (size_t i = first + t; i < end; i += step) { acc = acc + f(a, b, 2 * i); acc = acc + f(a, b, 2 * i + 1); }
       if ((n & 1) && blk == 0 && t == 0) acc = acc + f(a, b, n - 1);
       lanes[t] = acc;
     }

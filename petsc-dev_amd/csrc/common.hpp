@@ -9,7 +9,8 @@
 #define MI355X_BLOCK 256          // 4 wavefronts per workgroup, one per SIMD
 #define MI355X_NXCD 8             // XCDs (each with a private 4 MiB L2)
 #define MI355X_MAX_GRID 2048      // 256 CUs x 8 resident 256-thread workgroups
-#define MI355X_REDUCE_GRID_CAP 8192  // workgroups of a reduction launch (vec_kernels.hip launch_reduce): one 16 KB tile per stream each up to n = 2^24
+#define MI355X_REDUCE_GRID_CAP 512   // workgroups of a reduction launch over vectors that fit the Infinity Cache (vec_kernels.hip launch_reduce): grid-stride
+#define MI355X_REDUCE_GRID_CAP_BIG 4096   // ... over vectors of >= 256 MiB: contiguous runs of tiles, one run per workgroup
 #define MI355X_TILE2 1024            // double2's of a reduction tile: 256 lanes x 4 (vec_kernels.hip)
 #define MI355X_MAP_TILE2 512         // double2's of an element-wise tile: 256 lanes x 2
 #define MI355X_MAX_RED 32         // max simultaneous reduction outputs (MDot chunk)
@@ -29,7 +30,7 @@
 
 struct mi355x_handle_s {
   hipStream_t stream;
-  double *partials;           // MI355X_REDUCE_GRID_CAP * MI355X_MAX_RED doubles (HBM)
+  double *partials;           // MI355X_REDUCE_GRID_CAP_BIG * MI355X_MAX_RED doubles (HBM)
   unsigned int *ticket;       // arrival counter for the single-launch reductions
   double *host_scratch;       // pinned + mapped, MI355X_SCRATCH_DOUBLES
   double *dev_scratch;        // HBM, MI355X_SCRATCH_DOUBLES

@@ -51,7 +51,7 @@ int mi355x_handle_create(mi355x_handle_t *out) {
   mi355x_handle_s *h = new mi355x_handle_s();
   memset(h, 0, sizeof(*h));
   MI355X_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-  MI355X_TRY(hipMalloc((void **)&h->partials, sizeof(double) * MI355X_REDUCE_GRID_CAP * MI355X_MAX_RED));
+  MI355X_TRY(hipMalloc((void **)&h->partials, sizeof(double) * MI355X_REDUCE_GRID_CAP_BIG * MI355X_MAX_RED));
   MI355X_TRY(hipMalloc((void **)&h->ticket, 256));
   MI355X_TRY(hipMemset(h->ticket, 0, 256));
   // +1 slot: the completion sequence word that lets the host poll instead of synchronising the stream

@@ -8,18 +8,19 @@
 // word-granular random access, so the product is re-cut so that the gathers go there.
 //
 // Layout (built once per nonzero pattern on host threads, values refreshed on the device through a permutation):
-//   * rows in PANELS of TL_WAVES * TL_SUB rows, one workgroup per panel; columns in TILES of TL_TW (8192) entries of x = 64 KB of LDS;
+//   * rows in PANELS of TL_PANEL = 2048 rows, one workgroup per panel; columns in TILES of TL_TW (8192) entries of x = 64 KB of LDS;
 //   * a (panel, tile) pair with at least `stage_min` entries is STAGED: the workgroup loads that tile of x into LDS once and all of the
 //     panel's entries in it gather from there.  The panel walks its staged tiles in ascending order.  Entries of pairs too thin to
 //     stage (the long-range fifth) stay in a CSR remainder that the row-block kernel adds afterwards (mi355x_spmv_csr_add) -- the split
 //     of MatMult_MPIAIJ's diagonal / off-diagonal blocks, inside one GPU;
-//   * inside a workgroup every wavefront owns TL_SUB = 256 rows and, per staged tile, ONE LANE PER ROW: the wavefront's rows with entries
-//     in the tile are sorted by their number of entries there (descending) and dealt to the lanes rank by rank, 64 per round (TL_RPL = 4
-//     rounds).  A round is stored as jagged diagonals: step j holds entry j of every row of the round that has more than j entries --
-//     the rows being sorted, those are lanes 0 .. n_j - 1 -- so a step is ONE coalesced load of n_j values and n_j 2-byte in-tile column
-//     numbers with no padding, n_j comes out of a ballot of the lanes' own counts, and a lane meets its row's entries in column order:
-//     x from the LDS tile, multiply, add to the row's running sum.  No product stage, no cross-lane traffic, no barrier except at a tile
-//     switch.  The running sums of the wavefront's 256 rows live in LDS between tiles (the row <-> lane assignment changes with the tile);
+//   * per staged tile, ONE LANE PER ROW: the panel's rows with entries in the tile are sorted by their number of entries there
+//     (descending) and cut into ROUNDS of 64 consecutive ranks -- rows of (nearly) equal length -- dealt to the workgroup's wavefronts in
+//     turn (TL_RPL = 4 rounds each).  A round is stored as jagged diagonals: step j holds entry j of every row of the round that has more
+//     than j entries -- the rows being sorted, those are lanes 0 .. n_j - 1 -- so a step is ONE coalesced load of n_j values and n_j
+//     2-byte in-tile column numbers with no padding, n_j comes out of a ballot of the lanes' own counts, and a lane meets its row's
+//     entries in column order: x from the LDS tile, multiply, add to the row's running sum.  No product stage, no cross-lane traffic,
+//     no barrier except at a tile switch.  The running sums of the panel's rows live in LDS between tiles (the row <-> lane assignment
+//     changes with the tile);
 //   * per (wavefront, tile) one 16-byte word per lane says which rows it serves and how many entries each has: ~0.9 B per entry on the
 //     stand-in; with 8 B values and 2 B columns 10.9 B per entry instead of CSR's 12 + 4 per row.
 // Arithmetic: a*x rounded, then added (-ffp-contract=off); a row's staged products are added one after the other in column order
@@ -31,14 +32,16 @@
 #include <thread>
 #include <vector>
 #include <string.h>
+#include <stdlib.h>
 
 #define TL_TW 8192            // columns of x per tile (64 KB of LDS)
 #ifndef TL_WAVES
 #define TL_WAVES 8            // wavefronts per workgroup
 #endif
 #define TL_RPL 4              // rounds per (wavefront, tile): rows per lane
-#define TL_SUB (64 * TL_RPL)              // rows per wavefront
-#define TL_PANEL (TL_WAVES * TL_SUB)      // rows per workgroup
+#define TL_PANEL (TL_WAVES * 64 * TL_RPL)  // rows per workgroup: every row of the panel is some lane's in some round, whatever the tile
+#define TL_CNT_BITS 16                     // a descriptor word: (row of the panel << 16) | entries of the row in the tile (<= TL_TW)
+static_assert(TL_TW < (1 << TL_CNT_BITS) && TL_PANEL <= (1 << (32 - TL_CNT_BITS)), "descriptor word");
 #ifndef TL_U
 #define TL_U 8                // steps whose loads a lane issues together
 #endif
@@ -53,7 +56,7 @@ struct tl_host {
   std::vector<int> pt_ptr;        // [npanels + 1] -> staged (panel, tile) pairs
   std::vector<int> pt_tile;       // [npt] tile number
   std::vector<int> wt_e0;         // [npt * TL_WAVES + 1] first entry of (pair, wavefront) in val / lcol / perm
-  std::vector<unsigned int> desc; // [npt * TL_WAVES][64][TL_RPL]: round a of lane l serves row (word >> 24) of the wavefront with (word & 0xffffff) entries
+  std::vector<unsigned int> desc; // [npt * TL_WAVES][64][TL_RPL]: in its round a, lane l of the wavefront serves row (word >> 16) of the panel, which has (word & 0xffff) entries in the tile
   std::vector<int> perm;          // [nnz_near] entry -> position in the CSR value array
   std::vector<unsigned short> lcol;   // [nnz_near] column - tile * TL_TW
   std::vector<int> far_i, far_j, far_perm;   // CSR remainder over all m rows, global columns
@@ -94,36 +97,36 @@ static void build_panel(int p, int m, int n, const int *ai, const int *aj, int s
   std::sort(touched.begin(), touched.end());
   for (int r = r0; r < r1; ++r) cur[r - r0] = ai[r];
   std::vector<RowSeg> segs;
-  segs.reserve(TL_SUB);
+  segs.reserve(TL_PANEL);
   for (int t : touched) {
     const bool staged = cnt[t] >= stage_min;
     cnt[t] = 0;
     if (!staged) continue;
     const int clo = t * TL_TW, chi = clo + TL_TW;
     o.pt_tile.push_back(t);
+    // the panel's rows with entries in this tile, longest first (ties: lower row first)
+    segs.clear();
+    for (int rl = 0; rl < r1 - r0; ++rl) {
+      const int r = r0 + rl;
+      int k = cur[rl];
+      const int kend = ai[r + 1];
+      while (k < kend && aj[k] < clo) ++k;                 // entries of thinner tiles in between: the remainder's
+      const int kb = k;
+      while (k < kend && aj[k] < chi) ++k;
+      cur[rl] = k;
+      if (k > kb) segs.push_back({rl, kb, k - kb});
+    }
+    std::stable_sort(segs.begin(), segs.end(), [](const RowSeg &a, const RowSeg &b) { return a.cnt > b.cnt; });
+    // rounds of 64 consecutive ranks; round g goes to wavefront g % TL_WAVES as its round g / TL_WAVES
     for (int w = 0; w < TL_WAVES; ++w) {
-      const int s0 = r0 + w * TL_SUB;
-      segs.clear();
-      for (int rl = 0; rl < TL_SUB; ++rl) {
-        const int r = s0 + rl;
-        if (r >= r1) break;
-        int k = cur[r - r0];
-        const int kend = ai[r + 1];
-        while (k < kend && aj[k] < clo) ++k;                 // entries of thinner tiles in between: the remainder's
-        const int kb = k;
-        while (k < kend && aj[k] < chi) ++k;
-        cur[r - r0] = k;
-        if (k > kb) segs.push_back({rl, kb, k - kb});
-      }
-      // longest rows first (ties: lower row first), 64 per round
-      std::stable_sort(segs.begin(), segs.end(), [](const RowSeg &a, const RowSeg &b) { return a.cnt > b.cnt; });
       const size_t dbase = o.desc.size();
       o.desc.resize(dbase + 64 * TL_RPL, 0u);
       int ne = 0;
       for (int a = 0; a < TL_RPL; ++a) {
-        const size_t lo = (size_t)a * 64, hi = std::min(segs.size(), lo + 64);
+        const size_t g = (size_t)a * TL_WAVES + w;
+        const size_t lo = g * 64, hi = std::min(segs.size(), lo + 64);
         if (lo >= hi) break;
-        for (size_t q = lo; q < hi; ++q) o.desc[dbase + (q - lo) * TL_RPL + a] = ((unsigned int)segs[q].rl << 24) | (unsigned int)segs[q].cnt;
+        for (size_t q = lo; q < hi; ++q) o.desc[dbase + (q - lo) * TL_RPL + a] = ((unsigned int)segs[q].rl << TL_CNT_BITS) | (unsigned int)segs[q].cnt;
         const int maxc = segs[lo].cnt;
         for (int j = 0; j < maxc; ++j)
           for (size_t q = lo; q < hi && segs[q].cnt > j; ++q) {
@@ -282,7 +285,7 @@ __global__ __launch_bounds__(256) void tl_gather_values_kernel(const int *__rest
   for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < n; k += stride) val[k] = aa[perm[k]];
 }
 
-template <int ADD>
+template <int ADD, int U>
 __global__ __launch_bounds__(TL_WAVES * 64) void spmv_tiled_kernel(
     int npanels, int chunkx, const int *__restrict__ pt_ptr, const int *__restrict__ pt_tile, const int *__restrict__ wt_e0,
     const unsigned int *__restrict__ desc, const double *__restrict__ val, const unsigned short *__restrict__ lcol,
@@ -290,19 +293,15 @@ __global__ __launch_bounds__(TL_WAVES * 64) void spmv_tiled_kernel(
   extern __shared__ __attribute__((aligned(16))) double tl_lds[];
   double *xt = tl_lds;                                   // TL_TW doubles: the tile of x
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  double *accw = tl_lds + TL_TW + w * TL_SUB;            // running sums of this wavefront's rows
+  double *acc = tl_lds + TL_TW;                          // running sums of the panel's rows
 
   // each XCD walks a contiguous eighth of the panels: neighbouring panels stage the same tiles, out of the same L2
   const int xcd = blockIdx.x % MI355X_NXCD, slot = blockIdx.x / MI355X_NXCD;
   const int p = xcd * chunkx + slot;
   if (slot >= chunkx || p >= npanels) return;
 
-  const int row0 = p * TL_PANEL + w * TL_SUB;
-#pragma unroll
-  for (int a = 0; a < TL_RPL; ++a) {
-    const int r = row0 + a * 64 + lane;
-    accw[a * 64 + lane] = (ADD && r < m) ? yin[r] : 0.0;
-  }
+  const int row0 = p * TL_PANEL;
+  for (int rl = tid; rl < TL_PANEL; rl += TL_WAVES * 64) acc[rl] = (ADD && row0 + rl < m) ? yin[row0 + rl] : 0.0;
 
   const int pt0 = pt_ptr[p], pt1 = pt_ptr[p + 1];
   for (int pt = pt0; pt < pt1; ++pt) {
@@ -322,14 +321,14 @@ __global__ __launch_bounds__(TL_WAVES * 64) void spmv_tiled_kernel(
     __syncthreads();
 #pragma unroll
     for (int a = 0; a < TL_RPL; ++a) {
-      const int cnt = (int)(d[a] & 0xffffffu), rl = (int)(d[a] >> 24);
+      const int cnt = (int)(d[a] & ((1u << TL_CNT_BITS) - 1)), rl = (int)(d[a] >> TL_CNT_BITS);
       const int maxc = __builtin_amdgcn_readfirstlane(cnt);          // rows sorted by count: lane 0 has the round's longest
       if (maxc == 0) break;                                           // (wave-uniform) no rows left for this and the later rounds
-      double sum = cnt ? accw[rl] : 0.0;
-      for (int j0 = 0; j0 < maxc; j0 += TL_U) {
-        double v[TL_U]; unsigned short c[TL_U]; bool on[TL_U];
+      double sum = cnt ? acc[rl] : 0.0;
+      for (int j0 = 0; j0 < maxc; j0 += U) {
+        double v[U]; unsigned short c[U]; bool on[U];
 #pragma unroll
-        for (int u = 0; u < TL_U; ++u) {                              // step j0 + u: entry j0 + u of every row that has one, lanes 0 .. n - 1
+        for (int u = 0; u < U; ++u) {                              // step j0 + u: entry j0 + u of every row that has one, lanes 0 .. n - 1
           on[u] = j0 + u < cnt;
           const int nact = __popcll(__ballot(on[u]));
           const int idx = off + (on[u] ? lane : 0);                   // every load unconditional (idle lanes re-read the step's first entry; the arrays carry slack)
@@ -338,17 +337,13 @@ __global__ __launch_bounds__(TL_WAVES * 64) void spmv_tiled_kernel(
           off += nact;
         }
 #pragma unroll
-        for (int u = 0; u < TL_U; ++u) { const double xv = xt[c[u]]; const double s2 = sum + v[u] * xv; sum = on[u] ? s2 : sum; }
+        for (int u = 0; u < U; ++u) { const double xv = xt[c[u]]; const double s2 = sum + v[u] * xv; sum = on[u] ? s2 : sum; }
       }
-      if (cnt) accw[rl] = sum;
+      if (cnt) acc[rl] = sum;
     }
   }
   __syncthreads();
-#pragma unroll
-  for (int a = 0; a < TL_RPL; ++a) {
-    const int r = row0 + a * 64 + lane;
-    if (r < m) yout[r] = accw[a * 64 + lane];
-  }
+  for (int rl = tid; rl < TL_PANEL; rl += TL_WAVES * 64) if (row0 + rl < m) yout[row0 + rl] = acc[rl];
 }
 
 extern "C" {
@@ -394,22 +389,24 @@ int mi355x_spmv_tiled_refresh_values(mi355x_handle_t h, mi355x_spmv_tiled_t P, c
 int mi355x_spmv_tiled_parts(mi355x_handle_t h, mi355x_spmv_tiled_t P, const double *x, const double *yin, double *yout, int which) {
   if (!mi355x_aligned16(x)) return (int)hipErrorNotSupported;
   if (P->m == 0) return 0;
-  const size_t lds = sizeof(double) * (TL_TW + TL_WAVES * TL_SUB);
-  static bool attr_set = false;
-  if (!attr_set) {
-    MI355X_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(spmv_tiled_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    MI355X_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(spmv_tiled_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
+  const size_t lds = sizeof(double) * (TL_TW + TL_PANEL);
+  static int U = 0;                 // steps whose loads a lane issues together: 8, or MI355X_TILED_U=16 (development)
+  if (!U) {
+    const char *e = getenv("MI355X_TILED_U");
+    U = (e && atoi(e) == 16) ? 16 : TL_U;
+    MI355X_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(spmv_tiled_kernel<0, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    MI355X_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(spmv_tiled_kernel<1, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    MI355X_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(spmv_tiled_kernel<0, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    MI355X_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(spmv_tiled_kernel<1, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
   const int chunkx = (P->npanels + MI355X_NXCD - 1) / MI355X_NXCD;
   const int grid = chunkx * MI355X_NXCD;
   if (which != 2) {
-    if (yin)
-      hipLaunchKernelGGL((spmv_tiled_kernel<1>), dim3(grid), dim3(TL_WAVES * 64), lds, h->stream, P->npanels, chunkx, P->d_pt_ptr, P->d_pt_tile, P->d_wt_e0,
-                         P->d_desc, P->d_val, P->d_lcol, x, yin, yout, P->m, P->n);
-    else
-      hipLaunchKernelGGL((spmv_tiled_kernel<0>), dim3(grid), dim3(TL_WAVES * 64), lds, h->stream, P->npanels, chunkx, P->d_pt_ptr, P->d_pt_tile, P->d_wt_e0,
-                         P->d_desc, P->d_val, P->d_lcol, x, (const double *)nullptr, yout, P->m, P->n);
+#define TL_GO(A_, U_, YIN) hipLaunchKernelGGL((spmv_tiled_kernel<A_, U_>), dim3(grid), dim3(TL_WAVES * 64), lds, h->stream, P->npanels, chunkx, P->d_pt_ptr, P->d_pt_tile, \
+                                              P->d_wt_e0, P->d_desc, P->d_val, P->d_lcol, x, YIN, yout, P->m, P->n)
+    if (yin) { if (U == 16) TL_GO(1, 16, yin); else TL_GO(1, 8, yin); }
+    else { if (U == 16) TL_GO(0, 16, (const double *)nullptr); else TL_GO(0, 8, (const double *)nullptr); }
+#undef TL_GO
     MI355X_LAUNCH_CHECK();
   }
   if (which != 1 && P->nnz_far > 0) return mi355x_spmv_csr_add(h, P->far_plan, P->d_far_i, P->d_far_j, P->d_far_a, x, yout, yout);

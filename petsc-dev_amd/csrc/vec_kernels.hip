@@ -4,9 +4,10 @@
 // ("flat": as many workgroups as tiles, the dispatcher hands out the next tile when a workgroup retires, so the tiles in flight
 // form one compact window that slides through memory) at 6.0, with non-temporal accesses at 6.3-6.7; inside the cache (2^24) 7.7 ->
 // 7.8-8.4 and the non-temporal hint costs 20 %.  So: element-wise kernels take one tile of 256 x 2 double2 per workgroup;
-// reductions, whose workgroup count bounds the last workgroup's pass over the partials, take contiguous runs of tiles of 256 x 4
-// double2, one run each for <= 8192 workgroups (one tile each up to n = 2^24); vectors that cannot live in the cache (>= 256 MiB)
-// are streamed non-temporally.  Compiled with -ffp-contract=off so a*x+y is a rounded multiply then a rounded add, as in the
+// reductions, whose workgroup count is also the number of partials the last workgroup has to add, keep <= 512 grid-striding
+// workgroups for vectors that fit the cache (inside the cache the geometry makes no difference to a pure reader) and take contiguous
+// runs of tiles of 256 x 4 double2, one run each for <= 4096 workgroups, for vectors of >= 256 MiB; those are also streamed
+// non-temporally.  Compiled with -ffp-contract=off so a*x+y is a rounded multiply then a rounded add, as in the
 // reference's C loops (src/vec/vec/impls/seq/{bvec1,bvec2,dvec2}.c).
 #include "common.hpp"
 
@@ -294,7 +295,12 @@ __global__ void publish_kernel(const double *src, double *host_dst, int count, u
 template <class F> struct has_prologue { static constexpr bool value = false; };
 
 // F::accum(i2 or i, acc): adds element contributions
-template <int NOUT, int MODE, class F>
+// RUNS == false: grid-stride (lane t of workgroup b meets double2's b * 256 + t, + grid * 256, ...): vectors that live in the caches.
+// RUNS == true: workgroup b owns a contiguous run of tiles of MI355X_TILE2 double2's, [s0, s1), and lane t meets s0 + t, s0 + t + 256,
+// ...: vectors of >= 256 MiB, where one compact window of tiles in flight streams 6.0-7.0 TB/s and 512 strided workgroups 4.9-6.1
+// (profiles/r04_stream_probe*.log).  The functors' sweeps take a first index, a step and an end, so they serve both.  The oracle's
+// device-order emulation (oracle/vecmat_oracle.c dev_reduce) restates both geometries and the size that separates them: change together.
+template <int NOUT, int MODE, class F, bool RUNS>
 __global__ __launch_bounds__(MI355X_BLOCK) void reduce_kernel(F f, size_t n, int vec_ok, double *partials,
                                                              unsigned int *ticket, double *out, double *host_copy,
                                                              unsigned long long *host_seq, unsigned long long seq) {
@@ -306,16 +312,17 @@ __global__ __launch_bounds__(MI355X_BLOCK) void reduce_kernel(F f, size_t n, int
   for (int j = 0; j < NOUT; ++j) acc[j] = 0.0;
   if constexpr (has_prologue<F>::value) f.prologue(tid, acc);
   if (vec_ok) {
-    // workgroup b owns a contiguous run of tiles of MI355X_TILE2 double2's: [s0, s1); lane t meets s0 + t, s0 + t + 256, ... in that
-    // order (the functors' sweeps take a first index, a step and an end).  The oracle's device-order emulation
-    // (oracle/vecmat_oracle.c dev_reduce) restates this geometry: change both together.
     const size_t n2 = n >> 1;
-    const size_t ntiles = (n2 + MI355X_TILE2 - 1) / MI355X_TILE2;
-    const size_t per = (ntiles + gridDim.x - 1) / gridDim.x;
-    size_t s0 = (size_t)blockIdx.x * per * MI355X_TILE2, s1 = s0 + per * MI355X_TILE2;
-    if (s0 > n2) s0 = n2;
-    if (s1 > n2) s1 = n2;
-    f.template sweep<NOUT>(s0 + threadIdx.x, (size_t)MI355X_BLOCK, s1, acc);
+    if (RUNS) {
+      const size_t ntiles = (n2 + MI355X_TILE2 - 1) / MI355X_TILE2;
+      const size_t per = (ntiles + gridDim.x - 1) / gridDim.x;
+      size_t s0 = (size_t)blockIdx.x * per * MI355X_TILE2, s1 = s0 + per * MI355X_TILE2;
+      if (s0 > n2) s0 = n2;
+      if (s1 > n2) s1 = n2;
+      f.template sweep<NOUT>(s0 + threadIdx.x, (size_t)MI355X_BLOCK, s1, acc);
+    } else {
+      f.template sweep<NOUT>(tid, (size_t)gridDim.x * MI355X_BLOCK, n2, acc);
+    }
     if ((n & 1) && tid == 0) f.accum1(n - 1, acc);
   } else {
     const size_t stride = (size_t)gridDim.x * MI355X_BLOCK;
@@ -356,11 +363,21 @@ __global__ __launch_bounds__(MI355X_BLOCK) void reduce_kernel(F f, size_t n, int
   // last-arriving workgroup: sum the per-workgroup partials in workgroup order
 #pragma unroll
   for (int j = 0; j < NOUT; ++j) acc[j] = 0.0;
-  for (unsigned int b = threadIdx.x; b < gridDim.x; b += MI355X_BLOCK) {
+  // (a lane's partials b = t, t + 256, ... are added in that order; up to four workgroups' worth requested together)
+  for (unsigned int b0 = threadIdx.x; b0 < gridDim.x; b0 += 4 * MI355X_BLOCK) {
+    double v[4][NOUT];
 #pragma unroll
-    for (int j = 0; j < NOUT; ++j) {
-      double v = __hip_atomic_load(partials + (size_t)b * NOUT + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      acc[j] = (MODE == RED_MAX) ? nanmax(acc[j], v) : acc[j] + v;
+    for (int u = 0; u < 4; ++u) {
+      const unsigned int b = b0 + u * MI355X_BLOCK;
+#pragma unroll
+      for (int j = 0; j < NOUT; ++j) v[u][j] = __hip_atomic_load(partials + (size_t)(b < gridDim.x ? b : b0) * NOUT + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (b0 + u * MI355X_BLOCK < gridDim.x) {
+#pragma unroll
+        for (int j = 0; j < NOUT; ++j) acc[j] = (MODE == RED_MAX) ? nanmax(acc[j], v[u][j]) : acc[j] + v[u][j];
+      }
     }
   }
   __syncthreads();
@@ -373,11 +390,19 @@ __global__ __launch_bounds__(MI355X_BLOCK) void reduce_kernel(F f, size_t n, int
 
 template <int NOUT, int MODE, class F>
 static int launch_reduce(mi355x_handle_t h, F f, size_t n, int vec_ok, double *out, bool also_to_host = false) {
-  // one workgroup per tile of MI355X_TILE2 double2's, at most MI355X_REDUCE_GRID_CAP of them (then contiguous runs of tiles each); the
-  // last one to finish sums that many partials.  The oracle's device-order emulation (oracle/vecmat_oracle.c dev_reduce) restates
-  // this geometry: change both together.
-  size_t ntiles = ((n >> 1) + MI355X_TILE2 - 1) / MI355X_TILE2;
-  int grid = (int)(ntiles < 1 ? 1 : (ntiles > MI355X_REDUCE_GRID_CAP ? MI355X_REDUCE_GRID_CAP : ntiles));
+  // vectors that fit the caches: at most 512 workgroups, 2 per CU (measured on the CG iteration at n = 2^24, one box, same process
+  // order: 256 -> 0.541 ms, 384 -> 0.535, 512 -> 0.523, 768 -> 0.529, 1024 -> 0.534, 2048 -> 0.536; 8192 with one tile each: 0.56),
+  // grid-stride; the last one sums <= 512 partials.  Vectors of >= 256 MiB: contiguous runs of tiles for <= 4096 workgroups.  The
+  // oracle's device-order emulation (oracle/vecmat_oracle.c dev_reduce) restates both: change together.
+  const bool runs = vec_streams(n) != 0;
+  int grid;
+  if (runs) {
+    const size_t ntiles = ((n >> 1) + MI355X_TILE2 - 1) / MI355X_TILE2;
+    grid = (int)(ntiles > MI355X_REDUCE_GRID_CAP_BIG ? MI355X_REDUCE_GRID_CAP_BIG : ntiles);
+  } else {
+    grid = mi355x_grid_for(n, 16);
+    if (grid > MI355X_REDUCE_GRID_CAP) grid = MI355X_REDUCE_GRID_CAP;
+  }
   // a result that goes to the handle's pinned scratch is followed by a completion number (mi355x_handle_wait_result)
   unsigned long long *hs = nullptr, seq = 0;
   double *host_copy = nullptr;
@@ -389,8 +414,10 @@ static int launch_reduce(mi355x_handle_t h, F f, size_t n, int vec_ok, double *o
     seq = ++h->seq;
     host_copy = h->host_scratch;
   }
-  hipLaunchKernelGGL((reduce_kernel<NOUT, MODE, F>), dim3(grid), dim3(MI355X_BLOCK), 0, h->stream, f, n, vec_ok,
-                     h->partials, h->ticket, out, host_copy, hs, seq);
+  if (runs) hipLaunchKernelGGL((reduce_kernel<NOUT, MODE, F, true>), dim3(grid), dim3(MI355X_BLOCK), 0, h->stream, f, n, vec_ok,
+                               h->partials, h->ticket, out, host_copy, hs, seq);
+  else hipLaunchKernelGGL((reduce_kernel<NOUT, MODE, F, false>), dim3(grid), dim3(MI355X_BLOCK), 0, h->stream, f, n, vec_ok,
+                          h->partials, h->ticket, out, host_copy, hs, seq);
   MI355X_LAUNCH_CHECK();
   return 0;
 }

@@ -170,10 +170,12 @@ def test_scale_rnorm_dev_special_cases(dev):
     dev.free(dn); dev.free(dx)
 
 
-@pytest.mark.parametrize("n", [1, 2, 63, 64, 257, 4095, 4097, 70001, 1 << 20, 5000001])
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 257, 4095, 4097, 70001, 1 << 20, 5000001, (1 << 25) + 3, (1 << 25) + (1 << 23) + 2048 + 1])
 def test_reductions_equal_the_oracle_in_the_device_summation_order(dev, n):
     """orc.device_reduction_order() restates reduce_kernel's tree (per-lane strided pair sums -> shuffle-down tree -> four
-    wavefronts in order -> one workgroup over the per-workgroup sums): dot, norms, dot+norm2 and MDot are then bit-identical"""
+    wavefronts in order -> one workgroup over the per-workgroup sums): dot, norms, dot+norm2 and MDot are then bit-identical.
+    The two largest sizes are vectors of >= 256 MiB: the geometry of contiguous runs of tiles (one / several tiles per workgroup)
+    and streaming loads."""
     k = dev.k
     x, y = rnd(n, 20), rnd(n, 21)
     ys = [rnd(n, 200 + j) for j in range(5)]
@@ -196,6 +198,41 @@ def test_reductions_equal_the_oracle_in_the_device_summation_order(dev, n):
     assert_bitexact(dev.scalar_out(5), np.array(ref_md))
     for p in [dx, dy] + dys:
         dev.free(p)
+
+
+def test_elementwise_and_fused_update_streaming_forms_bitexact(dev):
+    """Vectors of >= 256 MiB take the non-temporal forms of the element-wise kernels and of the fused CG update (one tile per
+    workgroup; contiguous runs of tiles): the same bits as the reference's loops / as the separate calls."""
+    k = dev.k
+    n = (1 << 25) + 7
+    x, y, z = rnd(n, 31), rnd(n, 32), rnd(n, 33)
+    dx, dy, dz = dev.put(x), dev.put(y), dev.put(z)
+    dw = dev.alloc(8 * n)
+    dev.chk(k.mi355x_vec_axpy(dev.h, n, 0.37, dx, dy))
+    r = y.copy(); orc.vec_axpy(r, 0.37, x); assert_bitexact(dev.get(dy, n), r); y = r
+    dev.chk(k.mi355x_vec_aypx(dev.h, n, -1.25, dx, dy))
+    r = y.copy(); orc.vec_aypx(r, -1.25, x); assert_bitexact(dev.get(dy, n), r); y = r
+    dev.chk(k.mi355x_vec_waxpy(dev.h, n, 2.0, dx, dy, dw))
+    r = np.zeros(n); orc.vec_waxpy(r, 2.0, x, y); assert_bitexact(dev.get(dw, n), r)
+    dev.chk(k.mi355x_vec_pointwise_mult(dev.h, n, dx, dy, dw))
+    assert_bitexact(dev.get(dw, n), x * y)
+    dev.chk(k.mi355x_vec_copy(dev.h, n, dx, dw))
+    assert_bitexact(dev.get(dw, n), x)
+    # fused CG update against the separate calls (x += a p; r -= a w; z = r .* d; sums in the device order)
+    p_, w_, d_ = rnd(n, 34), rnd(n, 35), 1.0 + 0.1 * rnd(n, 36)
+    dp, dwv, dd = dev.put(p_), dev.put(w_), dev.put(d_)
+    xs, rs = x.copy(), z.copy()
+    dev.chk(k.mi355x_memcpy_h2d(dev.h, dz, rs.ctypes.data, rs.nbytes))
+    dzz = dev.alloc(8 * n)
+    dev.chk(k.mi355x_vec_cg_update(dev.h, n, 0.61, dp, dwv, dd, dx, dz, dzz, dev.host_scratch()))
+    sums = dev.scalar_out(3)
+    orc.vec_axpy(xs, 0.61, p_); orc.vec_axpy(rs, -0.61, w_)
+    zs = rs * d_
+    assert_bitexact(dev.get(dx, n), xs); assert_bitexact(dev.get(dz, n), rs); assert_bitexact(dev.get(dzz, n), zs)
+    with orc.device_reduction_order():
+        ref = np.array([orc.vec_dot(zs, zs), orc.vec_dot(zs, rs), orc.vec_dot(rs, rs)])
+    assert_bitexact(sums, ref)
+    dev.free_all()
 
 
 @pytest.mark.parametrize("n", SIZES)

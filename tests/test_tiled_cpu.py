@@ -88,7 +88,7 @@ def test_tiled_layout_rows_longer_than_a_chunk_and_degenerate_shapes(k):
     lens = np.full(m, 5); lens[7] = 1800; lens[8] = 700; lens[130] = 513; lens[299] = 3000
     ai, aj, aa = random_csr(rng, m, n, lens, band=n, far_frac=0.0)
     inf = check(k, ai, aj, aa, n, stage_min=1, expect_all_staged=True)
-    assert inf["steps"] >= 2000
+    assert inf["steps"] >= 1000
     # one row, one column; no rows at all; a matrix without entries
     check(k, np.array([0, 1], np.int32), np.array([0], np.int32), np.array([2.5]), 1, stage_min=1, expect_all_staged=True)
     check(k, np.array([0], np.int32), np.zeros(0, np.int32), np.zeros(0), 10, stage_min=1)

@@ -39,11 +39,11 @@ def info(k, plan):
 
 def walk(k, plan, m):
     """Every staged entry as (row, column, position in the CSR value array) in storage order -- for one row that is the order its lane
-    adds the products in -- plus the remainder's CSR (far_i, far_j, far_perm).  Checks the jagged-diagonal invariants on the way: a
-    round's rows are sorted by count (so a step's active lanes are 0 .. n - 1), every row of a wavefront appears at most once per tile."""
+    adds the products in -- plus the remainder's CSR (far_i, far_j, far_perm).  Checks the jagged-diagonal invariants on the way: per
+    (panel, tile) the rows are sorted by count over ALL rounds (round g = a * waves + w is wavefront w's round a), so a step's active
+    lanes are 0 .. n - 1, and every row of the panel appears at most once per tile."""
     g = geometry(k)
     W, R = g["waves"], g["rounds"]
-    sub = 64 * R
     pt_ptr, pt_tile, wt_e0 = get(k, plan, 0, np.int32), get(k, plan, 1, np.int32), get(k, plan, 2, np.int32)
     desc = get(k, plan, 3, np.uint32).reshape(-1, 64, R)
     perm, lcol = get(k, plan, 4, np.int32), get(k, plan, 5, np.uint16)
@@ -56,28 +56,28 @@ def walk(k, plan, m):
             t = int(pt_tile[pt])
             assert t > last_tile, "a panel's staged tiles ascend"
             last_tile = t
+            seen_rows = set()
+            ranked = np.zeros(W * R * 64, dtype=np.int64)
             for w in range(W):
                 off = int(wt_e0[pt * W + w])
-                seen_rows = set()
                 for a in range(R):
-                    cnt = (desc[pt * W + w, :, a] & 0xffffff).astype(np.int64)
-                    rl = (desc[pt * W + w, :, a] >> 24).astype(np.int64)
-                    assert np.all(cnt[:-1] >= cnt[1:]), "rows of a round sorted by count"
-                    if a:
-                        assert cnt[0] <= (desc[pt * W + w, 63, a - 1] & 0xffffff), "rounds in rank order"
+                    cnt = (desc[pt * W + w, :, a] & 0xffff).astype(np.int64)
+                    rl = (desc[pt * W + w, :, a] >> 16).astype(np.int64)
+                    ranked[(a * W + w) * 64:(a * W + w) * 64 + 64] = cnt
                     for l in range(64):
                         if cnt[l]:
-                            assert int(rl[l]) not in seen_rows and rl[l] < sub
+                            assert int(rl[l]) not in seen_rows and rl[l] < g["panel"]
                             seen_rows.add(int(rl[l]))
                     for j in range(int(cnt[0])):
                         nact = int(np.sum(cnt > j))
                         steps += 1
                         for l in range(nact):
-                            rows.append(p * g["panel"] + w * sub + int(rl[l]))
+                            rows.append(p * g["panel"] + int(rl[l]))
                             cols.append(t * g["tw"] + int(lcol[off + l]))
                             pos.append(int(perm[off + l]))
                         off += nact
                 assert off == wt_e0[pt * W + w + 1]
+            assert np.all(ranked[:-1] >= ranked[1:]), "the panel's rows sorted by count across the rounds"
     assert steps == info(k, plan)["steps"]
     return (np.array(rows, dtype=np.int64), np.array(cols, dtype=np.int64), np.array(pos, dtype=np.int64)), far
 
