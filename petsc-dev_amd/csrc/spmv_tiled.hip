@@ -40,6 +40,8 @@
 #endif
 #define TL_RPL 4              // rounds per (wavefront, tile): rows per lane
 #define TL_PANEL (TL_WAVES * 64 * TL_RPL)  // rows per workgroup: every row of the panel is some lane's in some round, whatever the tile
+#define TL_MAX_PASS 16                     // column ranges of the remainder
+#define TL_PASS_BYTES (3u << 20)           // ... each covering <= 3 MiB of x: it stays in one XCD's 4 MiB L2 next to the streams passing through
 #define TL_CNT_BITS 16                     // a descriptor word: (row of the panel << 16) | entries of the row in the tile (<= TL_TW)
 static_assert(TL_TW < (1 << TL_CNT_BITS) && TL_PANEL <= (1 << (32 - TL_CNT_BITS)), "descriptor word");
 #ifndef TL_U
@@ -59,7 +61,8 @@ struct tl_host {
   std::vector<unsigned int> desc; // [npt * TL_WAVES][64][TL_RPL]: in its round a, lane l of the wavefront serves row (word >> 16) of the panel, which has (word & 0xffff) entries in the tile
   std::vector<int> perm;          // [nnz_near] entry -> position in the CSR value array
   std::vector<unsigned short> lcol;   // [nnz_near] column - tile * TL_TW
-  std::vector<int> far_i, far_j, far_perm;   // CSR remainder over all m rows, global columns
+  int npass = 1;                  // the remainder is cut into column ranges applied one after the other (x of one range stays in every XCD's L2)
+  std::vector<int> far_i, far_j, far_perm;   // CSR remainder, pass-major: far_i[q * (m + 1) + r] .. [.. + r + 1] = row r's entries of pass q in far_j / far_perm (absolute positions), global columns
 };
 
 struct mi355x_spmv_tiled_s {
@@ -70,9 +73,11 @@ struct mi355x_spmv_tiled_s {
   unsigned int *d_desc;
   unsigned short *d_lcol;
   double *d_val;
+  int npass;
+  long nfar_store;               // entries of the remainder's arrays (nnz_far + padding between passes)
   int *d_far_i, *d_far_j, *d_far_perm;
   double *d_far_a;
-  mi355x_spmv_plan_t far_plan;
+  mi355x_spmv_plan_t far_plan[TL_MAX_PASS];
 };
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -210,28 +215,55 @@ int mi355x_spmv_tiled_build(int m, int n, const int *ai, const int *aj, int stag
   }
   H->pt_ptr[(size_t)H->npanels] = (int)H->pt_tile.size();
   H->wt_e0.push_back((int)e);
-  // remainder: every entry no stream took, rows in order (a second walk with the same staging decisions)
-  H->far_i.assign((size_t)m + 1, 0);
-  H->nnz_far = H->nnz - H->nnz_near;
-  H->far_j.reserve((size_t)H->nnz_far); H->far_perm.reserve((size_t)H->nnz_far);
+  // remainder: every entry no stream took (a second walk with the same staging decisions), cut into column ranges of <= 3 MiB of x that
+  // are applied one after the other: the gathers of one pass then hit the L2 of whichever XCD issues them instead of going out to the
+  // Infinity Cache for every one (the remainder is what is scattered over all of x).  Within a pass rows in order, columns ascending;
+  // a row's remainder products are still added in column order, pass after pass.
   {
-    std::vector<char> staged((size_t)ntiles + 1, 0);
-    for (int p = 0; p < H->npanels; ++p) {
-      for (int i = H->pt_ptr[(size_t)p]; i < H->pt_ptr[(size_t)p + 1]; ++i) staged[(size_t)H->pt_tile[(size_t)i]] = 1;
-      const int r0 = p * TL_PANEL, r1 = std::min(m, r0 + TL_PANEL);
-      for (int r = r0; r < r1; ++r) {
-        for (int k = ai[r]; k < ai[r + 1]; ++k) if (!staged[(size_t)(aj[k] / TL_TW)]) { H->far_j.push_back(aj[k]); H->far_perm.push_back(k); }
-        H->far_i[(size_t)r + 1] = (int)H->far_j.size();
-      }
-      for (int i = H->pt_ptr[(size_t)p]; i < H->pt_ptr[(size_t)p + 1]; ++i) staged[(size_t)H->pt_tile[(size_t)i]] = 0;
-    }
+    int np = (int)(((size_t)n * sizeof(double) + TL_PASS_BYTES - 1) / TL_PASS_BYTES);
+    const char *e_ = getenv("MI355X_TILED_FAR_PASSES");
+    if (e_ && atoi(e_) > 0) np = atoi(e_);
+    if (np < 1) np = 1;
+    if (np > TL_MAX_PASS) np = TL_MAX_PASS;
+    H->npass = np;
   }
-  if ((long)H->far_j.size() != H->nnz_far || e != H->nnz_near) { delete H; return (int)hipErrorUnknown; }
+  const int colsper = (n + H->npass - 1) / H->npass > 0 ? (n + H->npass - 1) / H->npass : 1;
+  H->nnz_far = H->nnz - H->nnz_near;
+  H->far_i.assign((size_t)H->npass * ((size_t)m + 1), 0);
+  H->far_j.assign((size_t)H->nnz_far, 0); H->far_perm.assign((size_t)H->nnz_far, 0);
+  {
+    // count per (pass, row), prefix over pass-major order, fill
+    std::vector<char> staged((size_t)ntiles + 1, 0);
+    std::vector<int> cntpr((size_t)H->npass * (size_t)(m > 0 ? m : 1), 0);
+    auto for_far = [&](auto &&fn) {
+      for (int p = 0; p < H->npanels; ++p) {
+        for (int i = H->pt_ptr[(size_t)p]; i < H->pt_ptr[(size_t)p + 1]; ++i) staged[(size_t)H->pt_tile[(size_t)i]] = 1;
+        const int r0 = p * TL_PANEL, r1 = std::min(m, r0 + TL_PANEL);
+        for (int r = r0; r < r1; ++r)
+          for (int k = ai[r]; k < ai[r + 1]; ++k) if (!staged[(size_t)(aj[k] / TL_TW)]) fn(r, k, aj[k] / colsper);
+        for (int i = H->pt_ptr[(size_t)p]; i < H->pt_ptr[(size_t)p + 1]; ++i) staged[(size_t)H->pt_tile[(size_t)i]] = 0;
+      }
+    };
+    long nfar = 0;
+    for_far([&](int r, int, int q) { cntpr[(size_t)q * m + r]++; ++nfar; });
+    if (nfar != H->nnz_far) { delete H; return (int)hipErrorUnknown; }
+    long run = 0;
+    for (int q = 0; q < H->npass; ++q) {
+      for (int r = 0; r < m; ++r) { H->far_i[(size_t)q * (m + 1) + r] = (int)run; run += cntpr[(size_t)q * m + r]; }
+      H->far_i[(size_t)q * (m + 1) + m] = (int)run;
+      if (run & 1) ++run;                          // every pass starts on an even entry (the row-block kernel's 16-byte value loads)
+    }
+    H->far_j.assign((size_t)run, 0); H->far_perm.assign((size_t)run, -1);
+    std::vector<int> nextpr((size_t)H->npass * (size_t)(m > 0 ? m : 1));
+    for (int q = 0; q < H->npass; ++q) for (int r = 0; r < m; ++r) nextpr[(size_t)q * m + r] = H->far_i[(size_t)q * (m + 1) + r];
+    for_far([&](int r, int k, int q) { const int pos = nextpr[(size_t)q * m + r]++; H->far_j[(size_t)pos] = aj[k]; H->far_perm[(size_t)pos] = k; });
+  }
+  if (e != H->nnz_near) { delete H; return (int)hipErrorUnknown; }
   mi355x_spmv_tiled_s *P = new mi355x_spmv_tiled_s();
   memset(P, 0, sizeof(*P));
   P->host = H;
   P->m = m; P->n = n; P->npanels = H->npanels; P->npt = (int)H->pt_tile.size();
-  P->nnz_near = H->nnz_near; P->nnz_far = H->nnz_far; P->nsteps = H->nsteps;
+  P->nnz_near = H->nnz_near; P->nnz_far = H->nnz_far; P->nsteps = H->nsteps; P->npass = H->npass;
   *out = P;
   return 0;
 }
@@ -282,7 +314,7 @@ int mi355x_spmv_tiled_drop_host(mi355x_spmv_tiled_t P) { delete P->host; P->host
 // val[k] = aa[perm[k]]: the layout's values out of the CSR array that is on the device anyway
 __global__ __launch_bounds__(256) void tl_gather_values_kernel(const int *__restrict__ perm, const double *__restrict__ aa, double *__restrict__ val, long n) {
   const long stride = (long)gridDim.x * 256;
-  for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < n; k += stride) val[k] = aa[perm[k]];
+  for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < n; k += stride) { const int q = perm[k]; val[k] = q >= 0 ? aa[q] : 0.0; }   // (-1: padding between the remainder's passes)
 }
 
 template <int ADD, int U>
@@ -365,8 +397,15 @@ int mi355x_spmv_tiled_upload(mi355x_handle_t h, mi355x_spmv_tiled_t P, const dou
       (rc = up((void **)&P->d_far_perm, H->far_perm.data(), H->far_perm.size() * 4)))
     return rc;
   MI355X_TRY(hipMalloc((void **)&P->d_val, sizeof(double) * (size_t)(P->nnz_near > 0 ? P->nnz_near : 1) + 64));
-  MI355X_TRY(hipMalloc((void **)&P->d_far_a, sizeof(double) * (size_t)(P->nnz_far > 0 ? P->nnz_far : 1) + 64));
-  if (P->nnz_far > 0) { rc = mi355x_spmv_plan_create(h, P->m, H->far_i.data(), nullptr, &P->far_plan); if (rc) return rc; }
+  P->nfar_store = (long)H->far_perm.size();
+  MI355X_TRY(hipMalloc((void **)&P->d_far_a, sizeof(double) * (size_t)(P->nfar_store > 0 ? P->nfar_store : 1) + 64));
+  if (P->nnz_far > 0)
+    for (int q = 0; q < P->npass; ++q) {
+      const int *fi = H->far_i.data() + (size_t)q * ((size_t)P->m + 1);
+      if (fi[P->m] == fi[0]) continue;                                    // nothing in this column range
+      rc = mi355x_spmv_plan_create(h, P->m, fi, nullptr, &P->far_plan[q]);
+      if (rc) return rc;
+    }
   MI355X_TRY(hipStreamSynchronize(h->stream));
   return mi355x_spmv_tiled_refresh_values(h, P, aa_dev);
 }
@@ -378,7 +417,7 @@ int mi355x_spmv_tiled_refresh_values(mi355x_handle_t h, mi355x_spmv_tiled_t P, c
     MI355X_LAUNCH_CHECK();
   }
   if (P->nnz_far > 0) {
-    hipLaunchKernelGGL(tl_gather_values_kernel, dim3(mi355x_grid_for((size_t)P->nnz_far, 4)), dim3(256), 0, h->stream, P->d_far_perm, aa_dev, P->d_far_a, P->nnz_far);
+    hipLaunchKernelGGL(tl_gather_values_kernel, dim3(mi355x_grid_for((size_t)P->nfar_store, 4)), dim3(256), 0, h->stream, P->d_far_perm, aa_dev, P->d_far_a, P->nfar_store);
     MI355X_LAUNCH_CHECK();
   }
   return 0;
@@ -409,7 +448,12 @@ int mi355x_spmv_tiled_parts(mi355x_handle_t h, mi355x_spmv_tiled_t P, const doub
 #undef TL_GO
     MI355X_LAUNCH_CHECK();
   }
-  if (which != 1 && P->nnz_far > 0) return mi355x_spmv_csr_add(h, P->far_plan, P->d_far_i, P->d_far_j, P->d_far_a, x, yout, yout);
+  if (which != 1 && P->nnz_far > 0)
+    for (int q = 0; q < P->npass; ++q) {
+      if (!P->far_plan[q]) continue;
+      const int rc = mi355x_spmv_csr_add(h, P->far_plan[q], P->d_far_i + (size_t)q * ((size_t)P->m + 1), P->d_far_j, P->d_far_a, x, yout, yout);
+      if (rc) return rc;
+    }
   return 0;
 }
 int mi355x_spmv_tiled(mi355x_handle_t h, mi355x_spmv_tiled_t P, const double *x, const double *yin, double *yout) {
@@ -421,7 +465,7 @@ int mi355x_spmv_tiled_destroy(mi355x_spmv_tiled_t P) {
   delete P->host;
   void *ptrs[] = {P->d_pt_ptr, P->d_pt_tile, P->d_wt_e0, P->d_desc, P->d_perm, P->d_lcol, P->d_val, P->d_far_i, P->d_far_j, P->d_far_perm, P->d_far_a};
   for (void *q : ptrs) if (q) hipFree(q);
-  if (P->far_plan) mi355x_spmv_plan_destroy(P->far_plan);
+  for (int q = 0; q < TL_MAX_PASS; ++q) if (P->far_plan[q]) mi355x_spmv_plan_destroy(P->far_plan[q]);
   delete P;
   return 0;
 }

@@ -32,7 +32,8 @@ def check(k, ai, aj, aa, n, stage_min, expect_all_staged=False, expect_none_stag
     try:
         inf = tiled.info(k, plan)
         assert inf["staged"] + inf["remainder"] == aj.size
-        (rows, cols, pos), (fi, fj, fp) = tiled.walk(k, plan, m)
+        (rows, cols, pos), far = tiled.walk(k, plan, m)
+        fr, fj, fp = tiled.remainder(far, m)
         assert rows.size == inf["staged"] and fj.size == inf["remainder"]
         if expect_all_staged:
             assert inf["remainder"] == 0
@@ -45,7 +46,7 @@ def check(k, ai, aj, aa, n, stage_min, expect_all_staged=False, expect_none_stag
         assert np.all(seen == 1)
         rowof = np.repeat(np.arange(m), np.diff(ai))
         assert np.array_equal(rowof[pos], rows) and np.array_equal(aj[pos], cols)
-        assert np.array_equal(aj[fp], fj) and np.array_equal(rowof[fp], np.repeat(np.arange(m), np.diff(fi)))
+        assert np.array_equal(aj[fp], fj) and np.array_equal(rowof[fp], fr)
         # a row's staged entries are met in ascending column order (= ascending CSR position)
         order = np.lexsort((np.arange(rows.size), rows))
         pr, pp = rows[order], pos[order]
@@ -65,7 +66,11 @@ def check(k, ai, aj, aa, n, stage_min, expect_all_staged=False, expect_none_stag
         k.mi355x_spmv_tiled_destroy(plan)
 
 
-def test_tiled_layout_holds_every_nonzero_once_and_in_column_order(k):
+@pytest.mark.parametrize("passes", ["", "3"])
+def test_tiled_layout_holds_every_nonzero_once_and_in_column_order(k, passes, monkeypatch):
+    """(passes: the remainder cut into that many column ranges; default = by the size of x, one for these sizes)"""
+    if passes:
+        monkeypatch.setenv("MI355X_TILED_FAR_PASSES", passes)
     rng = np.random.default_rng(5)
     g = tiled.geometry(k)
     assert g["tw"] == 8192 and g["rounds"] == 4 and g["panel"] == g["waves"] * 64 * g["rounds"]

@@ -85,7 +85,11 @@ def run_case(dev, ai, aj, aa, n, stage_min, seed=0):
         dev.free_all()
 
 
-def test_tiled_spmv_matches_its_layout_bitwise_and_the_oracle(dev):
+@pytest.mark.parametrize("passes", ["", "3"])
+def test_tiled_spmv_matches_its_layout_bitwise_and_the_oracle(dev, passes, monkeypatch):
+    """(passes: the remainder cut into that many column ranges, applied one after the other)"""
+    if passes:
+        monkeypatch.setenv("MI355X_TILED_FAR_PASSES", passes)
     rng = np.random.default_rng(15)
     g = tiled.geometry(dev.k)
     m = 2 * g["panel"] + 333

@@ -82,13 +82,32 @@ def walk(k, plan, m):
     return (np.array(rows, dtype=np.int64), np.array(cols, dtype=np.int64), np.array(pos, dtype=np.int64)), far
 
 
+def remainder(far, m):
+    """the remainder's entries as (row, column, position in the CSR value array), pass after pass (the remainder is cut into column
+    ranges applied one after the other), rows in order inside a pass: the order its products reach a row's sum"""
+    fi, fj, fp = far
+    npass = fi.size // (m + 1) if m + 1 else 0
+    rows, cols, pos = [], [], []
+    lastcol = {}
+    for q in range(npass):
+        base = q * (m + 1)
+        assert fi[base] % 2 == 0, "a pass starts on an even entry"
+        for r in range(m):
+            for kk in range(fi[base + r], fi[base + r + 1]):
+                assert fp[kk] >= 0
+                assert lastcol.get(r, -1) < fj[kk], "a row's remainder entries ascend in column, pass after pass"
+                lastcol[r] = int(fj[kk])
+                rows.append(r); cols.append(int(fj[kk])); pos.append(int(fp[kk]))
+    return np.array(rows, dtype=np.int64), np.array(cols, dtype=np.int64), np.array(pos, dtype=np.int64)
+
+
 def apply(k, plan, m, aa, x, yin=None):
-    """y = (yin or 0) + A x from the layout, in the kernel's order: a row's staged products in stream order, then its remainder in CSR order"""
-    (rows, cols, pos), (fi, fj, fp) = walk(k, plan, m)
+    """y = (yin or 0) + A x from the layout, in the kernel's order: a row's staged products in stream order, then its remainder pass after pass"""
+    (rows, cols, pos), far = walk(k, plan, m)
     y = np.zeros(m) if yin is None else yin.astype(np.float64).copy()
     for r, c, q in zip(rows, cols, pos):
         y[r] = y[r] + aa[q] * x[c]
-    for r in range(m):
-        for kk in range(fi[r], fi[r + 1]):
-            y[r] = y[r] + aa[fp[kk]] * x[fj[kk]]
+    fr, fc, fq = remainder(far, m)
+    for r, c, q in zip(fr, fc, fq):
+        y[r] = y[r] + aa[q] * x[c]
     return y
