@@ -258,6 +258,7 @@ __device__ __forceinline__ void tri_node_solve(const int t, const int lane, cons
 #ifndef TRI_NODE_B
 #define TRI_NODE_B 8
 #endif
+  static_assert(TRI_NODE_B >= 2 && TRI_NODE_B % 2 == 0 && TRI_NODE_B <= 16, "TRI_NODE_B: an even number of columns per batch (the inode routine's pairs), at most 16 (registers)");
   // BLK (block columns): the shared list consists of WHOLE dependency nodes, all nodes have NB rows.  The list then stores one
   // entry per dependency NODE (its position), the solution lives node by node (w[position * NB + row]) so that a dependency's
   // NB values are one contiguous gather, and a batch is a few whole nodes: 4.5 batches of 8 columns become 3 batches of 4
@@ -454,8 +455,11 @@ __global__ __launch_bounds__(MI355X_BLOCK) void trisolve_node_kernel(
 // the point of coherence for all of them, a workgroup-scope store reaches it and an agent-scope load reads it there: 0.27 us
 // (tests/tools/probe/handoff_probe.hip, profiles/r03_tri_variants.log).
 __device__ __forceinline__ void tri_publish(double *p, const double v, const int one_xcd) {
-  if (one_xcd) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // agent scope always: a solution value is polled by OTHER workgroups, and only an agent-scope store is visible to them by the memory
+  // model.  (Round 3 stored with workgroup scope in the one-XCD form -- the line then stays in the XCD's L2, 13.4 instead of 14.0 ms on
+  // the FEM stand-in -- which is correct only as long as L1 writes through and every poller shares that L2: not kept.)
+  (void)one_xcd;
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 template <int NB> struct TriSplitGeom {
 #ifndef TRI_SPLIT_B3
@@ -471,7 +475,11 @@ template <int NB> struct TriSplitGeom {
   static constexpr int NT = NB * (NB - 1) / 2, ND = NT + NB;
   static constexpr int HB = 64 + 3 * 256 + (NB + ND) * 512;     // header bytes: meta, info / first row / rows per lane, right-hand sides, triangle
   static constexpr int SB = B * 256 + B * NB * 512;             // stage bytes: B index rows, B * NB value rows
+  // legal ranges of the build knobs (csrc/variants/build_tri.sh passes arbitrary -D options: a variant outside them must not build):
+  // pairs of the inode summation stay pairs (even batches), and the smallest ring -- look-ahead + 3 batches -- fits the LDS asked for
+  static_assert(B >= 2 && B % 2 == 0 && B <= 32, "TRI_SPLIT_B*: an even number of columns per batch, at most 32");
 };
+#define TRI_SPLIT_LDS_BYTES (150 * 1024)
 #define TRI_LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #ifndef TRI_LOOKAHEAD
 // batches the solver's gathers run ahead of its products.  0: a batch's values are requested when the batch is due -- a value
@@ -479,6 +487,13 @@ template <int NB> struct TriSplitGeom {
 // at 0, 19.3 at 1, 22.7 at 3; in the inode routine's column order 30.0 / 35.5 / 44.7)
 #define TRI_LOOKAHEAD 0
 #endif
+static_assert(TRI_LOOKAHEAD >= 0 && TRI_LOOKAHEAD <= 8, "TRI_LOOKAHEAD: 0..8 batches");
+static_assert(64 + 2 * TriSplitGeom<1>::HB + (TRI_LOOKAHEAD + 3) * TriSplitGeom<1>::SB <= TRI_SPLIT_LDS_BYTES &&
+              64 + 2 * TriSplitGeom<2>::HB + (TRI_LOOKAHEAD + 3) * TriSplitGeom<2>::SB <= TRI_SPLIT_LDS_BYTES &&
+              64 + 2 * TriSplitGeom<3>::HB + (TRI_LOOKAHEAD + 3) * TriSplitGeom<3>::SB <= TRI_SPLIT_LDS_BYTES &&
+              64 + 2 * TriSplitGeom<4>::HB + (TRI_LOOKAHEAD + 3) * TriSplitGeom<4>::SB <= TRI_SPLIT_LDS_BYTES &&
+              64 + 2 * TriSplitGeom<5>::HB + (TRI_LOOKAHEAD + 3) * TriSplitGeom<5>::SB <= TRI_SPLIT_LDS_BYTES,
+              "the smallest batch ring of the split-role kernels (look-ahead + 3 batches) must fit the LDS they ask for");
 // wait until the LDS counter reaches `need`; bounded like every other wait of these kernels: a wavefront that gives up raises the
 // abort flag and leaves, its partner's waits then run out the same way, and the application falls back to the level-by-level kernels
 __device__ __forceinline__ bool tri_lds_wait(volatile int *c, const int need, int *abort_flag) {
@@ -1186,8 +1201,11 @@ static int trisolve_plan_fill_nodes(mi355x_handle_t h, mi355x_trisolve_plan_s *p
   p->nslices = (int)((cur + W - 1) / W);
   { const char *e = getenv("MI355X_TRISOLVE_NODE_WAVES"); p->spw = e ? atoi(e) : 4; if (p->spw != 1 && p->spw != 2 && p->spw != 4) p->spw = 4; }
   { const char *e = getenv("MI355X_TRISOLVE_SPLIT"); p->split = blk ? 0 : (e ? atoi(e) != 0 : 1); if (p->split) p->spw = 1; }
-  // one-XCD form (trisolve_node_split_kernel): on for plans of 3-row nodes, where it was measured to gain (single-row plans lose 4 %)
-  { const char *e = getenv("MI355X_TRISOLVE_ONE_XCD"); p->one_xcd = p->split && (e ? atoi(e) != 0 : (p->nb == 3)); }
+  // one-XCD form (trisolve_node_split_kernel): OFF unless MI355X_TRISOLVE_ONE_XCD=1 asks for it (development).  Its workgroups are
+  // dealt to the queues by ticket, so a queue is served only if at least TRI_QUEUES workgroups land on the elected XCD; the launch
+  // asks for 8 x 2 x TRI_QUEUES or more, but placement is the dispatcher's: a plan that relies on it would turn an unlucky placement
+  // into bounded spins and an aborted solve.
+  { const char *e = getenv("MI355X_TRISOLVE_ONE_XCD"); p->one_xcd = p->split && e && atoi(e) != 0; }
   p->nchunks = (p->nslices + p->spw - 1) / p->spw;
   const size_t np = (size_t)p->nslices * W;
   p->np = (int)np;
@@ -1388,15 +1406,23 @@ static int tri_node_go(mi355x_handle_t h, mi355x_trisolve_plan_t lo, mi355x_tris
     // split-role kernels: the LDS ring holds a whole slice's batches (and a spare one) where that fits
     using G = TriSplitGeom<NB>;
     const int glo = lo->grid < TRI_QUEUES ? TRI_QUEUES : lo->grid, gup = up->grid < TRI_QUEUES ? TRI_QUEUES : up->grid;
-    const int rmax = (int)((150 * 1024 - 64 - 2 * G::HB) / G::SB);
+    const int rmax = (int)((TRI_SPLIT_LDS_BYTES - 64 - 2 * G::HB) / G::SB);
     auto ring = [&](int maxcol) { int r = (maxcol + G::B - 1) / G::B + 1; if (r < TRI_LOOKAHEAD + 3) r = TRI_LOOKAHEAD + 3; if (r > rmax) r = rmax; return r; };
     const int rlo = ring(lo->maxcol), rup = ring(up->maxcol);
     const size_t blo = 64 + 2 * (size_t)G::HB + (size_t)rlo * G::SB, bup = 64 + 2 * (size_t)G::HB + (size_t)rup * G::SB;
-    static bool attr_set = false;     // (per NB: this function is a template)
-    if (!attr_set) {
-      MI355X_TRY(hipFuncSetAttribute((const void *)trisolve_node_split_kernel<NB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-      MI355X_TRY(hipFuncSetAttribute((const void *)trisolve_node_split_kernel<NB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-      attr_set = true;
+    static int attr_dev = -2;         // the device the attribute was set on (per NB: this function is a template); -1: it refused
+    {
+      int dev = -1;
+      MI355X_TRY(hipGetDevice(&dev));
+      if (attr_dev != dev && attr_dev != -1) {
+        if (hipFuncSetAttribute((const void *)trisolve_node_split_kernel<NB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, TRI_SPLIT_LDS_BYTES) != hipSuccess ||
+            hipFuncSetAttribute((const void *)trisolve_node_split_kernel<NB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, TRI_SPLIT_LDS_BYTES) != hipSuccess) {
+          (void)hipGetLastError();
+          attr_dev = -1;
+        } else attr_dev = dev;
+      }
+      // a device that does not give a workgroup that much LDS: the same plans one launch per dependency level (same bits), not a failed MatSolve
+      if (attr_dev == -1) return tri_node_go<NB, BLK>(h, lo, up, b, y, true);
     }
     // one-XCD form (see the kernel): 8 x the workgroups, those of seven XCDs leave at once
     const int xlo = lo->one_xcd && glo >= 2 * TRI_QUEUES, xup = up->one_xcd && gup >= 2 * TRI_QUEUES;

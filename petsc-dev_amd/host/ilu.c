@@ -594,6 +594,10 @@ PetscErrorCode HipTriFactorsApply(Mat F, HipTriFactors *f, Vec b, Vec x, PetscLo
     if (rc == 719) {   /* hipErrorLaunchFailure: an earlier application gave up and no host wait has noticed yet: this one runs level by level */
       f->use_levels = 1; f->aborted = 1;
       rc = mi355x_trisolve_apply_levels(dc->h, f->tri_lo, f->tri_up, db, dx);
+    } else if (rc == 1 || rc == 701 || rc == 720) {   /* hipErrorInvalidValue / LaunchOutOfResources / cooperative too large: the sync-free kernels could not be launched on this
+                                                        * device (LDS, registers): nothing ran, so the same plans serve one launch per level from now on */
+      f->use_levels = 1;
+      rc = mi355x_trisolve_apply_levels(dc->h, f->tri_lo, f->tri_up, db, dx);
     }
   }
   ierr = VecHIPRestoreWrite(x);CHKERRQ(ierr);      /* also on the error path: x is not left in write state */
