@@ -240,7 +240,7 @@ int mi355x_csr_get_diagonal(mi355x_handle_t h, int m, const int *ai, const int *
 
 /* ---- column-tiled CSR SpMV: x staged in LDS (csrc/spmv_tiled.hip) ------ */
 /* For matrices whose x gathers miss the caches (rows that pick columns from a wide window without neighbouring rows sharing them):
- * MatMult_SeqAIJ / MatMultAdd_SeqAIJ (aij.c:1225, 1291) re-cut into row panels x column tiles of 8192 entries of x; a (panel, tile)
+ * MatMult_SeqAIJ / MatMultAdd_SeqAIJ (aij.c:1225, 1291) re-cut into row panels x column tiles of 4096 entries of x; a (panel, tile)
  * pair with >= stage_min entries gathers from a copy of that tile in LDS (one lane per row, jagged diagonals of the rows sorted by
  * their length in the tile), the thin pairs' entries stay in a CSR remainder added by the row-block kernel afterwards.  Products of a
  * row's staged entries are added in column order, then the remainder's: agrees with the reference to rounding (<= 1e-12 * sum

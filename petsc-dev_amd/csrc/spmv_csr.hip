@@ -497,7 +497,11 @@ __global__ __launch_bounds__(SPMV_THREADS, SPMV_MINWAVES) void spmv_csr_rowblock
     }
   }
   const double yv = spmv_fin<ADD>(ysum, sum);
+#if defined(SPMV_NT_Y) && SPMV_NT_Y
+  if (tid < nrows) __builtin_nontemporal_store(yv, yout + r0 + tid);
+#else
   if (tid < nrows) yout[r0 + tid] = yv;
+#endif
   if (DOT) {
     const double c = wave_sum(tid < nrows ? yv * x[xbase] : 0.0);
     if ((tid & (MI355X_WAVE - 1)) == 0) wdot[tid / MI355X_WAVE] = c;

@@ -8,7 +8,8 @@
 // word-granular random access, so the product is re-cut so that the gathers go there.
 //
 // Layout (built once per nonzero pattern on host threads, values refreshed on the device through a permutation):
-//   * rows in PANELS of TL_PANEL = 2048 rows, one workgroup per panel; columns in TILES of TL_TW (8192) entries of x = 64 KB of LDS;
+//   * rows in PANELS of TL_PANEL = 2048 rows, one workgroup per panel; columns in TILES of TL_TW (4096) entries of x = 32 KB of LDS, two of
+//     them resident (the next tile arrives while the current one is gathered from);
 //   * a (panel, tile) pair with at least `stage_min` entries is STAGED: the workgroup loads that tile of x into LDS once and all of the
 //     panel's entries in it gather from there.  The panel walks its staged tiles in ascending order.  Entries of pairs too thin to
 //     stage (the long-range fifth) stay in a CSR remainder that the row-block kernel adds afterwards (mi355x_spmv_csr_add) -- the split
@@ -33,8 +34,11 @@
 #include <vector>
 #include <string.h>
 #include <stdlib.h>
+#include <stdio.h>
 
-#define TL_TW 8192            // columns of x per tile (64 KB of LDS)
+#ifndef TL_TW
+#define TL_TW 4096            // columns of x per tile (32 KB of LDS; two buffers)
+#endif
 #ifndef TL_WAVES
 #define TL_WAVES 8            // wavefronts per workgroup
 #endif
@@ -325,7 +329,7 @@ __global__ __launch_bounds__(TL_WAVES * 64) void spmv_tiled_kernel(
   extern __shared__ __attribute__((aligned(16))) double tl_lds[];
   double *xt = tl_lds;                                   // TL_TW doubles: the tile of x
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  double *acc = tl_lds + TL_TW;                          // running sums of the panel's rows
+  double *acc = tl_lds + 2 * TL_TW;                      // running sums of the panel's rows
 
   // each XCD walks a contiguous eighth of the panels: neighbouring panels stage the same tiles, out of the same L2
   const int xcd = blockIdx.x % MI355X_NXCD, slot = blockIdx.x / MI355X_NXCD;
@@ -335,22 +339,35 @@ __global__ __launch_bounds__(TL_WAVES * 64) void spmv_tiled_kernel(
   const int row0 = p * TL_PANEL;
   for (int rl = tid; rl < TL_PANEL; rl += TL_WAVES * 64) acc[rl] = (ADD && row0 + rl < m) ? yin[row0 + rl] : 0.0;
 
+  // Two tile buffers: while the workgroup gathers from one, every thread holds its share of the NEXT staged tile in registers (requested
+  // at the start of the tile, written to the other buffer at its end): the tile switch costs one barrier and no exposed load.
+  constexpr int TPT = TL_TW / 2 / (TL_WAVES * 64);      // double2's of a tile per thread
+  static_assert(TPT * 2 * TL_WAVES * 64 == TL_TW, "a tile is a whole number of double2's per thread");
   const int pt0 = pt_ptr[p], pt1 = pt_ptr[p + 1];
+  tl_v2d nx[TPT];
+  auto tile_request = [&](int t) {                       // the thread's double2's i = tid + k * threads of tile t (clamped inside x)
+    const size_t base = (size_t)t * TL_TW;
+    const int ncol = (n - (long)base) < TL_TW ? (int)(n - (long)base) : TL_TW;
+    const tl_v2d *xs = reinterpret_cast<const tl_v2d *>(x + base);
+#pragma unroll
+    for (int k = 0; k < TPT; ++k) {
+      const int i = tid + k * TL_WAVES * 64;
+      nx[k] = xs[i < (ncol >> 1) ? i : 0];
+      if ((ncol & 1) && i == (ncol >> 1)) nx[k].x = x[base + ncol - 1];     // the last column of an odd-sized last tile
+    }
+  };
+  auto tile_store = [&](double *buf) {
+#pragma unroll
+    for (int k = 0; k < TPT; ++k) reinterpret_cast<tl_v2d *>(buf)[tid + k * TL_WAVES * 64] = nx[k];
+  };
+  if (pt0 < pt1) { tile_request(pt_tile[pt0]); tile_store(xt); }
+  __syncthreads();                                       // first tile in place, the sums' first stores done
   for (int pt = pt0; pt < pt1; ++pt) {
-    const int t = pt_tile[pt];
-    // this lane's rows and counts in the tile, and where the wavefront's entries start: requested before the tile is loaded
+    const double *xc = xt + ((pt - pt0) & 1) * TL_TW;
+    // this lane's rows and counts in the tile, and where the wavefront's entries start
     const tl_u4 d = __builtin_nontemporal_load(reinterpret_cast<const tl_u4 *>(desc + ((size_t)pt * TL_WAVES + w) * (64 * TL_RPL)) + lane);
     int off = wt_e0[pt * TL_WAVES + w];
-    __syncthreads();                                     // the previous tile is not read any more (and the sums' first stores are done)
-    {
-      const size_t base = (size_t)t * TL_TW;
-      const int ncol = (n - (long)base) < TL_TW ? (int)(n - (long)base) : TL_TW;
-      const tl_v2d *xs = reinterpret_cast<const tl_v2d *>(x + base);
-      tl_v2d *xd = reinterpret_cast<tl_v2d *>(xt);
-      for (int i = tid; i < (ncol >> 1); i += TL_WAVES * 64) xd[i] = xs[i];
-      if ((ncol & 1) && tid == 0) xt[ncol - 1] = x[base + ncol - 1];
-    }
-    __syncthreads();
+    if (pt + 1 < pt1) tile_request(pt_tile[pt + 1]);
 #pragma unroll
     for (int a = 0; a < TL_RPL; ++a) {
       const int cnt = (int)(d[a] & ((1u << TL_CNT_BITS) - 1)), rl = (int)(d[a] >> TL_CNT_BITS);
@@ -369,10 +386,12 @@ __global__ __launch_bounds__(TL_WAVES * 64) void spmv_tiled_kernel(
           off += nact;
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) { const double xv = xt[c[u]]; const double s2 = sum + v[u] * xv; sum = on[u] ? s2 : sum; }
+        for (int u = 0; u < U; ++u) { const double xv = xc[c[u]]; const double s2 = sum + v[u] * xv; sum = on[u] ? s2 : sum; }
       }
       if (cnt) acc[rl] = sum;
     }
+    if (pt + 1 < pt1) tile_store(xt + (((pt - pt0) & 1) ^ 1) * TL_TW);
+    __syncthreads();                                     // nobody reads this tile any more; the next one is complete
   }
   __syncthreads();
   for (int rl = tid; rl < TL_PANEL; rl += TL_WAVES * 64) if (row0 + rl < m) yout[row0 + rl] = acc[rl];
@@ -428,9 +447,14 @@ int mi355x_spmv_tiled_refresh_values(mi355x_handle_t h, mi355x_spmv_tiled_t P, c
 int mi355x_spmv_tiled_parts(mi355x_handle_t h, mi355x_spmv_tiled_t P, const double *x, const double *yin, double *yout, int which) {
   if (!mi355x_aligned16(x)) return (int)hipErrorNotSupported;
   if (P->m == 0) return 0;
-  const size_t lds = sizeof(double) * (TL_TW + TL_PANEL);
+  const size_t lds = sizeof(double) * (2 * TL_TW + TL_PANEL);
   static int U = 0;                 // steps whose loads a lane issues together: 8, or MI355X_TILED_U=16 (development)
   if (!U) {
+    if (getenv("MI355X_TILED_DEBUG")) {
+      int nb = 0;
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, spmv_tiled_kernel<0, 8>, TL_WAVES * 64, lds);
+      fprintf(stderr, "[mi355x tiled] tile %d columns, %d wavefronts per workgroup, %zu B of LDS: %d workgroups per CU\n", TL_TW, TL_WAVES, lds, nb);
+    }
     const char *e = getenv("MI355X_TILED_U");
     U = (e && atoi(e) == 16) ? 16 : TL_U;
     MI355X_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(spmv_tiled_kernel<0, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
