@@ -76,6 +76,7 @@ struct mi355x_spmv_plan_s {
   unsigned int *d_prow;
   int *d_pattab;       // SPMV_PAT_CAP ints
   int npat, use_pat;
+  int ch;              // run length (row blocks) of the row-pattern kernel's block -> XCD map, from the operator's largest offset
   // value patterns (constant-coefficient operators): rows whose offsets AND values repeat; per row 2 bytes, the values
   // live in the table.  Valid only for the values they were derived from (mi355x_spmv_plan_value_patterns / _drop_)
   unsigned short *d_vrow;
@@ -424,7 +425,7 @@ template <int ADD, bool DOT>
 __global__ __launch_bounds__(SPMV_THREADS, SPMV_MINWAVES) void spmv_csr_rowblock_pat_kernel(
     const int2 *__restrict__ rowblk, int nblocks, const unsigned int *__restrict__ prow,
     const int *__restrict__ pattab_g, const double *__restrict__ aa, const double *__restrict__ x, const double *yin, double *yout,
-    double *__restrict__ dotpart, int pairsum) {
+    double *__restrict__ dotpart, int pairsum, int ch) {
   __shared__ double vs[SPMV_BLOCK_NNZ];
   __shared__ int pattab[SPMV_PAT_CAP];
   __shared__ double wdot[DOT ? SPMV_THREADS / MI355X_WAVE : 1];
@@ -432,7 +433,7 @@ __global__ __launch_bounds__(SPMV_THREADS, SPMV_MINWAVES) void spmv_csr_rowblock
 #if SPMV_REMAP == 2
   const int xcd = blockIdx.x % MI355X_NXCD;
   const int slot = blockIdx.x / MI355X_NXCD;
-  const int lb = ((slot / SPMV_CH) * MI355X_NXCD + xcd) * SPMV_CH + (slot % SPMV_CH);
+  const int lb = ((slot / ch) * MI355X_NXCD + xcd) * ch + (slot % ch);     // runs of ch row blocks, see mi355x_spmv_plan_compress_indices
 #else
   const int lb = blockIdx.x;
 #endif
@@ -960,13 +961,13 @@ static int launch_spmv(mi355x_handle_t h, mi355x_spmv_plan_t p, const int *ai, c
   }
   if (p->d_prow && p->use_pat && !cprow && mi355x_aligned16(aa)) {
 #if SPMV_REMAP == 2
-    const int perp = MI355X_NXCD * SPMV_CH;
+    const int perp = MI355X_NXCD * p->ch;
     const int gp = ((p->nblocks + perp - 1) / perp) * perp;
 #else
     const int gp = p->nblocks;
 #endif
     hipLaunchKernelGGL((spmv_csr_rowblock_pat_kernel<ADD, false>), dim3(gp), dim3(SPMV_THREADS), 0, h->stream, p->d_rowblk, p->nblocks,
-                       p->d_prow, p->d_pattab, aa, x, yin, yout, (double *)nullptr, p->pairsum);
+                       p->d_prow, p->d_pattab, aa, x, yin, yout, (double *)nullptr, p->pairsum, p->ch);
     MI355X_LAUNCH_CHECK();
     return 0;
   }
@@ -1009,7 +1010,7 @@ int mi355x_spmv_plan_create(mi355x_handle_t h, int nrows, const int *ai_host, co
   p->d_idx8 = nullptr;
   p->d_offtab = nullptr;
   p->ntab = 0;
-  p->d_prow = nullptr; p->d_pattab = nullptr; p->npat = 0; p->use_pat = 1;
+  p->d_prow = nullptr; p->d_pattab = nullptr; p->npat = 0; p->use_pat = 1; p->ch = SPMV_CH;
   p->d_vrow = nullptr; p->d_vpattab = nullptr; p->d_vpatval = nullptr; p->nvpat = 0; p->vtablen = 0; p->vpat_valid = 0; p->use_vpat = 1;
   p->nlong = 0;
   p->d_dotpart = nullptr;
@@ -1128,6 +1129,21 @@ int mi355x_spmv_plan_compress_indices(mi355x_handle_t h, mi355x_spmv_plan_t p, c
   MI355X_TRY(hipMemcpyAsync(p->d_idx8, idx.get(), (size_t)nnz, hipMemcpyHostToDevice, h->stream));
   MI355X_TRY(hipMemcpyAsync(p->d_offtab, tab, sizeof(int) * (size_t)ntab, hipMemcpyHostToDevice, h->stream));
   p->ntab = ntab;
+  // Run length of the block -> XCD map for this operator.  XCD x owns runs of `ch` consecutive row blocks, dealt round-robin, so the
+  // rows a run covers come back to the SAME XCD every 8 * ch blocks.  With 8 * ch * 256 rows = the operator's largest offset (the plane
+  // of a 3-D stencil) the x entries a row reads at that offset were fetched into this XCD's own L2 when it worked on the plane before:
+  // P7(256) ch = 32 (the value tuned by hand in round 2), P7(512) ch = 128: 1.96 -> 1.77 ms per product there
+  // (profiles/r04_spmv_map_sweep.log); any other ch leaves those gathers to the Infinity Cache.  MI355X_SPMV_CH=<n> overrides.
+  {
+    long maxoff = 0;
+    for (int e = 0; e < ntab; ++e) { const long o = tab[e] < 0 ? -(long)tab[e] : (long)tab[e]; if (o > maxoff) maxoff = o; }
+    long ch = (maxoff + (long)MI355X_NXCD * SPMV_BLOCK_ROWS / 2) / ((long)MI355X_NXCD * SPMV_BLOCK_ROWS);
+    if (ch < 8) ch = 8;
+    if (ch > 1024) ch = 1024;
+    const char *e_ = getenv("MI355X_SPMV_CH");
+    if (e_ && atoi(e_) > 0) ch = atoi(e_);
+    p->ch = (int)ch;
+  }
   // row patterns: the rows' slot lists as a dictionary of at most SPMV_PAT_CAP table entries in all (stencil operators: a
   // handful of lists); rows too long for the row block's one-lane-per-row sums (> SPMV_BLOCK_CAP never happens here) or a
   // table that would not fit leave the plan at the per-nonzero bytes
@@ -1495,8 +1511,10 @@ int mi355x_spmv_csr_dot(mi355x_handle_t h, mi355x_spmv_plan_t p, const int *ai, 
                        p->d_vpatval, p->vtablen, x, (const double *)nullptr, y, p->d_dotpart, p->pairsum);
     p->ndotpart = nvb;
   } else if (pat) {
-    hipLaunchKernelGGL((spmv_csr_rowblock_pat_kernel<0, true>), dim3(g8), dim3(SPMV_THREADS), 0, h->stream, p->d_rowblk, p->nblocks,
-                       p->d_prow, p->d_pattab, aa, x, (const double *)nullptr, y, p->d_dotpart, p->pairsum);
+    const int perp = MI355X_NXCD * p->ch;
+    const int gp = SPMV_REMAP == 2 ? ((p->nblocks + perp - 1) / perp) * perp : p->nblocks;
+    hipLaunchKernelGGL((spmv_csr_rowblock_pat_kernel<0, true>), dim3(gp), dim3(SPMV_THREADS), 0, h->stream, p->d_rowblk, p->nblocks,
+                       p->d_prow, p->d_pattab, aa, x, (const double *)nullptr, y, p->d_dotpart, p->pairsum, p->ch);
     p->ndotpart = p->nblocks;
   } else {
     hipLaunchKernelGGL((spmv_csr_rowblock_idx8_kernel<0, true>), dim3(g8), dim3(SPMV_THREADS), 0, h->stream, p->d_rowblk,
