@@ -21,7 +21,9 @@ def main():
     from petsc_dev_amd import petsc as P
     L = P.lib(); k = pda.load_kernels()
     t0 = time.time()
-    ai, aj, aa = pb.gen_fem3() if which == "fem" else pb.gen_irr()
+    sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
+    from cfg4_spmv import cached                    # the generated CSR is kept under $CFG4_CACHE (default /tmp) between the tools of one run
+    ai, aj, aa = cached(which, pb.gen_fem3 if which == "fem" else pb.gen_irr)
     n = ai.size - 1
     print("%s: n=%d nnz=%d (%.1f/row) generated in %.1fs" % (which, n, aj.size, aj.size / n, time.time() - t0), flush=True)
     A = P.Mat.from_csr(ai, aj, aa)
