@@ -63,6 +63,9 @@ struct tl_host {
   std::vector<int> pt_tile;       // [npt] tile number
   std::vector<int> wt_e0;         // [npt * TL_WAVES + 1] first entry of (pair, wavefront) in val / lcol / perm
   std::vector<unsigned int> desc; // [npt * TL_WAVES][64][TL_RPL]: in its round a, lane l of the wavefront serves row (word >> 16) of the panel, which has (word & 0xffff) entries in the tile
+  std::vector<int> wt_s0;         // [npt * TL_WAVES + 1] first step word of (pair, wavefront) in `steps` (a multiple of TL_U)
+  std::vector<unsigned short> steps;   // one word per jagged diagonal, a wavefront's steps of one tile padded to a multiple of TL_U:
+                                       // (round << 8) | active lanes (1..64; 0 = padding)
   std::vector<int> perm;          // [nnz_near] entry -> position in the CSR value array
   std::vector<unsigned short> lcol;   // [nnz_near] column - tile * TL_TW
   int npass = 1;                  // the remainder is cut into column ranges applied one after the other (x of one range stays in every XCD's L2)
@@ -73,9 +76,9 @@ struct mi355x_spmv_tiled_s {
   tl_host *host;                  // kept until _drop_host (tests read it back)
   int m, n, npanels, npt;
   long nnz_near, nnz_far, nsteps;
-  int *d_pt_ptr, *d_pt_tile, *d_wt_e0, *d_perm;
+  int *d_pt_ptr, *d_pt_tile, *d_wt_e0, *d_wt_s0, *d_perm;
   unsigned int *d_desc;
-  unsigned short *d_lcol;
+  unsigned short *d_lcol, *d_steps;
   double *d_val;
   int npass;
   long nfar_store;               // entries of the remainder's arrays (nnz_far + padding between passes)
@@ -89,10 +92,10 @@ struct mi355x_spmv_tiled_s {
 // ---------------------------------------------------------------------------------------------------------------------------------
 namespace {
 struct PanelOut {
-  std::vector<int> pt_tile, wt_ne, perm;
+  std::vector<int> pt_tile, wt_ne, wt_ns, perm;
   std::vector<unsigned int> desc;
-  std::vector<unsigned short> lcol;
-  long near = 0, steps = 0;
+  std::vector<unsigned short> lcol, steps;
+  long near = 0, nsteps = 0;
 };
 struct RowSeg { int rl, k0, cnt; };
 
@@ -130,23 +133,29 @@ static void build_panel(int p, int m, int n, const int *ai, const int *aj, int s
     for (int w = 0; w < TL_WAVES; ++w) {
       const size_t dbase = o.desc.size();
       o.desc.resize(dbase + 64 * TL_RPL, 0u);
-      int ne = 0;
+      int ne = 0, ns = 0;
       for (int a = 0; a < TL_RPL; ++a) {
         const size_t g = (size_t)a * TL_WAVES + w;
         const size_t lo = g * 64, hi = std::min(segs.size(), lo + 64);
         if (lo >= hi) break;
         for (size_t q = lo; q < hi; ++q) o.desc[dbase + (q - lo) * TL_RPL + a] = ((unsigned int)segs[q].rl << TL_CNT_BITS) | (unsigned int)segs[q].cnt;
         const int maxc = segs[lo].cnt;
-        for (int j = 0; j < maxc; ++j)
+        for (int j = 0; j < maxc; ++j) {
+          int nact = 0;
           for (size_t q = lo; q < hi && segs[q].cnt > j; ++q) {
             const int k = segs[q].k0 + j;
             o.perm.push_back(k);
             o.lcol.push_back((unsigned short)(aj[k] - clo));
-            ++ne;
+            ++ne; ++nact;
           }
-        o.steps += maxc;
+          o.steps.push_back((unsigned short)((a << 8) | nact));
+          ++ns;
+        }
+        o.nsteps += maxc;
       }
+      while (ns % TL_U) { o.steps.push_back(0); ++ns; }
       o.wt_ne.push_back(ne);
+      o.wt_ns.push_back(ns);
       o.near += ne;
     }
   }
@@ -202,16 +211,19 @@ int mi355x_spmv_tiled_build(int m, int n, const int *ai, const int *aj, int stag
   }
   // concatenate in panel order
   size_t npt = 0, nval = 0;
-  for (auto &o : po) { npt += o.pt_tile.size(); nval += o.perm.size(); H->nnz_near += o.near; H->nsteps += o.steps; }
+  for (auto &o : po) { npt += o.pt_tile.size(); nval += o.perm.size(); H->nnz_near += o.near; H->nsteps += o.nsteps; }
   H->pt_ptr.resize((size_t)H->npanels + 1);
   H->pt_tile.reserve(npt); H->wt_e0.reserve(npt * TL_WAVES + 1); H->desc.reserve(npt * TL_WAVES * 64 * TL_RPL);
   H->perm.reserve(nval); H->lcol.reserve(nval + 8);
-  long e = 0;
+  long e = 0, sw = 0;
   for (int p = 0; p < H->npanels; ++p) {
     PanelOut &o = po[(size_t)p];
     H->pt_ptr[(size_t)p] = (int)H->pt_tile.size();
     H->pt_tile.insert(H->pt_tile.end(), o.pt_tile.begin(), o.pt_tile.end());
     for (int ne : o.wt_ne) { H->wt_e0.push_back((int)e); e += ne; }
+    for (int ns : o.wt_ns) { H->wt_s0.push_back((int)sw); sw += ns; }
+    H->steps.insert(H->steps.end(), o.steps.begin(), o.steps.end());
+    std::vector<unsigned short>().swap(o.steps);
     H->desc.insert(H->desc.end(), o.desc.begin(), o.desc.end());
     H->perm.insert(H->perm.end(), o.perm.begin(), o.perm.end());
     H->lcol.insert(H->lcol.end(), o.lcol.begin(), o.lcol.end());
@@ -219,6 +231,7 @@ int mi355x_spmv_tiled_build(int m, int n, const int *ai, const int *aj, int stag
   }
   H->pt_ptr[(size_t)H->npanels] = (int)H->pt_tile.size();
   H->wt_e0.push_back((int)e);
+  H->wt_s0.push_back((int)sw);
   // remainder: every entry no stream took (a second walk with the same staging decisions), cut into column ranges of <= 3 MiB of x that
   // are applied one after the other: the gathers of one pass then hit the L2 of whichever XCD issues them instead of going out to the
   // Infinity Cache for every one (the remainder is what is scattered over all of x).  Within a pass rows in order, columns ascending;
@@ -286,7 +299,7 @@ int mi355x_spmv_tiled_geometry(int *panel_rows, int *tile_cols, int *waves, int 
   return 0;
 }
 
-// tests: one host array of the layout (which: 0 pt_ptr, 1 pt_tile, 2 wt_e0, 3 desc, 4 perm, 5 lcol, 7 far_i, 8 far_j, 9 far_perm);
+// tests: one host array of the layout (which: 0 pt_ptr, 1 pt_tile, 2 wt_e0, 3 desc, 4 perm, 5 lcol, 6 steps, 7 far_i, 8 far_j, 9 far_perm, 10 wt_s0);
 // available until mi355x_spmv_tiled_drop_host
 int mi355x_spmv_tiled_debug_get(mi355x_spmv_tiled_t P, int which, void *out, size_t cap_bytes, size_t *bytes) {
   if (!P->host) return (int)hipErrorInvalidValue;
@@ -299,6 +312,8 @@ int mi355x_spmv_tiled_debug_get(mi355x_spmv_tiled_t P, int which, void *out, siz
     case 3: src = H->desc.data(); nb = H->desc.size() * 4; break;
     case 4: src = H->perm.data(); nb = H->perm.size() * 4; break;
     case 5: src = H->lcol.data(); nb = H->lcol.size() * 2; break;
+    case 6: src = H->steps.data(); nb = H->steps.size() * 2; break;
+    case 10: src = H->wt_s0.data(); nb = H->wt_s0.size() * 4; break;
     case 7: src = H->far_i.data(); nb = H->far_i.size() * 4; break;
     case 8: src = H->far_j.data(); nb = H->far_j.size() * 4; break;
     case 9: src = H->far_perm.data(); nb = H->far_perm.size() * 4; break;
@@ -321,15 +336,53 @@ __global__ __launch_bounds__(256) void tl_gather_values_kernel(const int *__rest
   for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < n; k += stride) { const int q = perm[k]; val[k] = q >= 0 ? aa[q] : 0.0; }   // (-1: padding between the remainder's passes)
 }
 
-template <int ADD, int U>
-__global__ __launch_bounds__(TL_WAVES * 64) void spmv_tiled_kernel(
+// One workgroup = TL_WAVES gathering wavefronts + ONE loader wavefront.  The loader brings the panel's next staged tile of x into the
+// idle one of two LDS buffers while the others gather from the current one: a tile switch is one barrier, no load on anybody's path.
+// A gathering wavefront walks its steps of the tile in groups of TL_U (one 16-byte word of step descriptors per group, the same for
+// all lanes: round and active-lane count of each step) and keeps TWO groups' loads in flight: the next group is requested before the
+// current one is consumed.  A lane's four running sums (one per round) live in registers during a tile and in LDS between tiles.
+typedef unsigned short tl_us8 __attribute__((ext_vector_type(8)));
+
+struct tl_group { double v[TL_U]; unsigned short c[TL_U]; tl_us8 w; };
+
+__device__ __forceinline__ void tl_issue(tl_group &g, const unsigned short *__restrict__ steps, int sw, int &off, const int lane,
+                                         const double *__restrict__ val, const unsigned short *__restrict__ lcol) {
+  g.w = *reinterpret_cast<const tl_us8 *>(steps + sw);             // uniform address: one scalar load
+#pragma unroll
+  for (int u = 0; u < TL_U; ++u) {
+    const int nact = g.w[u] & 0xff;                                  // lanes 0 .. nact - 1 take part in this step (0: padding)
+    const int idx = off + (lane < nact ? lane : 0);                  // every load unconditional (idle lanes re-read the step's first entry; the arrays carry slack)
+    g.v[u] = __builtin_nontemporal_load(val + idx);
+    g.c[u] = __builtin_nontemporal_load(lcol + idx);
+    off += nact;
+  }
+}
+__device__ __forceinline__ void tl_consume(const tl_group &g, const double *xc, const int lane, double (&sum)[TL_RPL]) {
+#pragma unroll
+  for (int u = 0; u < TL_U; ++u) {
+    const int nact = g.w[u] & 0xff, a = g.w[u] >> 8;                 // both wave-uniform
+    const double p = g.v[u] * xc[g.c[u]];
+    if (lane < nact) {
+      if (a == 0) sum[0] = sum[0] + p;
+      else if (a == 1) sum[1] = sum[1] + p;
+      else if (a == 2) sum[2] = sum[2] + p;
+      else sum[3] = sum[3] + p;
+    }
+  }
+}
+static_assert(TL_RPL == 4 && TL_U == 8, "tl_consume / the step words are written for four rounds and groups of eight steps");
+
+template <int ADD>
+__global__ __launch_bounds__((TL_WAVES + 1) * 64) void spmv_tiled_kernel(
     int npanels, int chunkx, const int *__restrict__ pt_ptr, const int *__restrict__ pt_tile, const int *__restrict__ wt_e0,
-    const unsigned int *__restrict__ desc, const double *__restrict__ val, const unsigned short *__restrict__ lcol,
+    const int *__restrict__ wt_s0, const unsigned short *__restrict__ steps, const unsigned int *__restrict__ desc,
+    const double *__restrict__ val, const unsigned short *__restrict__ lcol,
     const double *__restrict__ x, const double *yin, double *yout, int m, int n) {
   extern __shared__ __attribute__((aligned(16))) double tl_lds[];
-  double *xt = tl_lds;                                   // TL_TW doubles: the tile of x
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  double *xt = tl_lds;                                   // 2 x TL_TW doubles: two tiles of x
   double *acc = tl_lds + 2 * TL_TW;                      // running sums of the panel's rows
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int NT = (TL_WAVES + 1) * 64;
 
   // each XCD walks a contiguous eighth of the panels: neighbouring panels stage the same tiles, out of the same L2
   const int xcd = blockIdx.x % MI355X_NXCD, slot = blockIdx.x / MI355X_NXCD;
@@ -337,64 +390,81 @@ __global__ __launch_bounds__(TL_WAVES * 64) void spmv_tiled_kernel(
   if (slot >= chunkx || p >= npanels) return;
 
   const int row0 = p * TL_PANEL;
-  for (int rl = tid; rl < TL_PANEL; rl += TL_WAVES * 64) acc[rl] = (ADD && row0 + rl < m) ? yin[row0 + rl] : 0.0;
+  for (int rl = tid; rl < TL_PANEL; rl += NT) acc[rl] = (ADD && row0 + rl < m) ? yin[row0 + rl] : 0.0;
 
-  // Two tile buffers: while the workgroup gathers from one, every thread holds its share of the NEXT staged tile in registers (requested
-  // at the start of the tile, written to the other buffer at its end): the tile switch costs one barrier and no exposed load.
-  constexpr int TPT = TL_TW / 2 / (TL_WAVES * 64);      // double2's of a tile per thread
-  static_assert(TPT * 2 * TL_WAVES * 64 == TL_TW, "a tile is a whole number of double2's per thread");
   const int pt0 = pt_ptr[p], pt1 = pt_ptr[p + 1];
-  tl_v2d nx[TPT];
-  auto tile_request = [&](int t) {                       // the thread's double2's i = tid + k * threads of tile t (clamped inside x)
+  // a tile into a buffer: whole double2's inside x, then the last column of an odd-sized last tile
+  auto tile_tail = [&](int t, double *buf) {
+    const size_t base = (size_t)t * TL_TW;
+    const long left = (long)n - (long)base;
+    if (left < TL_TW && (left & 1) && lane == 0) buf[left - 1] = x[base + left - 1];
+  };
+  if (pt0 < pt1) {                                       // the first tile: everybody
+    const int t = pt_tile[pt0];
     const size_t base = (size_t)t * TL_TW;
     const int ncol = (n - (long)base) < TL_TW ? (int)(n - (long)base) : TL_TW;
     const tl_v2d *xs = reinterpret_cast<const tl_v2d *>(x + base);
-#pragma unroll
-    for (int k = 0; k < TPT; ++k) {
-      const int i = tid + k * TL_WAVES * 64;
-      nx[k] = xs[i < (ncol >> 1) ? i : 0];
-      if ((ncol & 1) && i == (ncol >> 1)) nx[k].x = x[base + ncol - 1];     // the last column of an odd-sized last tile
-    }
-  };
-  auto tile_store = [&](double *buf) {
-#pragma unroll
-    for (int k = 0; k < TPT; ++k) reinterpret_cast<tl_v2d *>(buf)[tid + k * TL_WAVES * 64] = nx[k];
-  };
-  if (pt0 < pt1) { tile_request(pt_tile[pt0]); tile_store(xt); }
+    for (int i = tid; i < (ncol >> 1); i += NT) reinterpret_cast<tl_v2d *>(xt)[i] = xs[i];
+    if (w == 0) tile_tail(t, xt);
+  }
   __syncthreads();                                       // first tile in place, the sums' first stores done
-  for (int pt = pt0; pt < pt1; ++pt) {
-    const double *xc = xt + ((pt - pt0) & 1) * TL_TW;
-    // this lane's rows and counts in the tile, and where the wavefront's entries start
-    const tl_u4 d = __builtin_nontemporal_load(reinterpret_cast<const tl_u4 *>(desc + ((size_t)pt * TL_WAVES + w) * (64 * TL_RPL)) + lane);
-    int off = wt_e0[pt * TL_WAVES + w];
-    if (pt + 1 < pt1) tile_request(pt_tile[pt + 1]);
+
+  if (w == TL_WAVES) {
+    // ---- the loader: tile pt + 1 into the other buffer while the others gather from tile pt ----
+    constexpr int LB = 16;                               // 16-byte loads in flight: 1 KB each, two batches of 16 KB per 4096-column tile
+    for (int pt = pt0; pt < pt1; ++pt) {
+      if (pt + 1 < pt1) {
+        const int t = pt_tile[pt + 1];
+        double *buf = xt + (((pt - pt0) & 1) ^ 1) * TL_TW;
+        const size_t base = (size_t)t * TL_TW;
+        const int ncol = (n - (long)base) < TL_TW ? (int)(n - (long)base) : TL_TW;
+        const int n2 = ncol >> 1;
+        const tl_v2d *xs = reinterpret_cast<const tl_v2d *>(x + base);
+        for (int i0 = 0; i0 < n2; i0 += LB * 64) {
+          tl_v2d r[LB];
 #pragma unroll
-    for (int a = 0; a < TL_RPL; ++a) {
-      const int cnt = (int)(d[a] & ((1u << TL_CNT_BITS) - 1)), rl = (int)(d[a] >> TL_CNT_BITS);
-      const int maxc = __builtin_amdgcn_readfirstlane(cnt);          // rows sorted by count: lane 0 has the round's longest
-      if (maxc == 0) break;                                           // (wave-uniform) no rows left for this and the later rounds
-      double sum = cnt ? acc[rl] : 0.0;
-      for (int j0 = 0; j0 < maxc; j0 += U) {
-        double v[U]; unsigned short c[U]; bool on[U];
+          for (int k = 0; k < LB; ++k) { const int i = i0 + k * 64 + lane; r[k] = xs[i < n2 ? i : 0]; }
 #pragma unroll
-        for (int u = 0; u < U; ++u) {                              // step j0 + u: entry j0 + u of every row that has one, lanes 0 .. n - 1
-          on[u] = j0 + u < cnt;
-          const int nact = __popcll(__ballot(on[u]));
-          const int idx = off + (on[u] ? lane : 0);                   // every load unconditional (idle lanes re-read the step's first entry; the arrays carry slack)
-          v[u] = __builtin_nontemporal_load(val + idx);
-          c[u] = __builtin_nontemporal_load(lcol + idx);
-          off += nact;
+          for (int k = 0; k < LB; ++k) { const int i = i0 + k * 64 + lane; if (i < n2) reinterpret_cast<tl_v2d *>(buf)[i] = r[k]; }
         }
-#pragma unroll
-        for (int u = 0; u < U; ++u) { const double xv = xc[c[u]]; const double s2 = sum + v[u] * xv; sum = on[u] ? s2 : sum; }
+        tile_tail(t, buf);
       }
-      if (cnt) acc[rl] = sum;
+      __syncthreads();                                   // (the gathering wavefronts' end-of-tile barrier)
     }
-    if (pt + 1 < pt1) tile_store(xt + (((pt - pt0) & 1) ^ 1) * TL_TW);
-    __syncthreads();                                     // nobody reads this tile any more; the next one is complete
+  } else {
+    // ---- a gathering wavefront ----
+    // (a tile's row words are requested one tile ahead: nothing but the group in flight stands between a tile's start and its first products)
+    tl_u4 dnext = {0u, 0u, 0u, 0u};
+    if (pt0 < pt1) dnext = __builtin_nontemporal_load(reinterpret_cast<const tl_u4 *>(desc + ((size_t)pt0 * TL_WAVES + w) * (64 * TL_RPL)) + lane);
+    for (int pt = pt0; pt < pt1; ++pt) {
+      const double *xc = xt + ((pt - pt0) & 1) * TL_TW;
+      const int iw = pt * TL_WAVES + w;
+      const tl_u4 d = dnext;
+      if (pt + 1 < pt1) dnext = __builtin_nontemporal_load(reinterpret_cast<const tl_u4 *>(desc + ((size_t)iw + TL_WAVES) * (64 * TL_RPL)) + lane);
+      int off = wt_e0[iw];
+      const int s0 = wt_s0[iw], s1 = wt_s0[iw + 1];
+      tl_group ga, gb;
+      if (s0 < s1) tl_issue(ga, steps, s0, off, lane, val, lcol);
+      int rl[TL_RPL]; bool has[TL_RPL]; double sum[TL_RPL];
+#pragma unroll
+      for (int a = 0; a < TL_RPL; ++a) {
+        has[a] = (d[a] & ((1u << TL_CNT_BITS) - 1)) != 0;
+        rl[a] = (int)(d[a] >> TL_CNT_BITS);
+        sum[a] = has[a] ? acc[rl[a]] : 0.0;
+      }
+      for (int sw = s0; sw < s1; sw += 2 * TL_U) {       // two groups per trip: the other one's loads are in flight while one is consumed
+        if (sw + TL_U < s1) tl_issue(gb, steps, sw + TL_U, off, lane, val, lcol);
+        tl_consume(ga, xc, lane, sum);
+        if (sw + 2 * TL_U < s1) tl_issue(ga, steps, sw + 2 * TL_U, off, lane, val, lcol);
+        if (sw + TL_U < s1) tl_consume(gb, xc, lane, sum);
+      }
+#pragma unroll
+      for (int a = 0; a < TL_RPL; ++a) if (has[a]) acc[rl[a]] = sum[a];
+      __syncthreads();                                   // nobody reads this tile any more; the loader has completed the next one
+    }
   }
   __syncthreads();
-  for (int rl = tid; rl < TL_PANEL; rl += TL_WAVES * 64) if (row0 + rl < m) yout[row0 + rl] = acc[rl];
+  for (int rl = tid; rl < TL_PANEL; rl += NT) if (row0 + rl < m) yout[row0 + rl] = acc[rl];
 }
 
 extern "C" {
@@ -411,6 +481,7 @@ int mi355x_spmv_tiled_upload(mi355x_handle_t h, mi355x_spmv_tiled_t P, const dou
   int rc;
   if ((rc = up((void **)&P->d_pt_ptr, H->pt_ptr.data(), H->pt_ptr.size() * 4)) || (rc = up((void **)&P->d_pt_tile, H->pt_tile.data(), H->pt_tile.size() * 4)) ||
       (rc = up((void **)&P->d_wt_e0, H->wt_e0.data(), H->wt_e0.size() * 4)) || (rc = up((void **)&P->d_desc, H->desc.data(), H->desc.size() * 4)) ||
+      (rc = up((void **)&P->d_wt_s0, H->wt_s0.data(), H->wt_s0.size() * 4)) || (rc = up((void **)&P->d_steps, H->steps.data(), H->steps.size() * 2)) ||
       (rc = up((void **)&P->d_perm, H->perm.data(), H->perm.size() * 4)) || (rc = up((void **)&P->d_lcol, H->lcol.data(), H->lcol.size() * 2)) ||
       (rc = up((void **)&P->d_far_i, H->far_i.data(), H->far_i.size() * 4)) || (rc = up((void **)&P->d_far_j, H->far_j.data(), H->far_j.size() * 4)) ||
       (rc = up((void **)&P->d_far_perm, H->far_perm.data(), H->far_perm.size() * 4)))
@@ -448,27 +519,23 @@ int mi355x_spmv_tiled_parts(mi355x_handle_t h, mi355x_spmv_tiled_t P, const doub
   if (!mi355x_aligned16(x)) return (int)hipErrorNotSupported;
   if (P->m == 0) return 0;
   const size_t lds = sizeof(double) * (2 * TL_TW + TL_PANEL);
-  static int U = 0;                 // steps whose loads a lane issues together: 8, or MI355X_TILED_U=16 (development)
-  if (!U) {
+  static bool attr_set = false;
+  if (!attr_set) {
     if (getenv("MI355X_TILED_DEBUG")) {
       int nb = 0;
-      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, spmv_tiled_kernel<0, 8>, TL_WAVES * 64, lds);
-      fprintf(stderr, "[mi355x tiled] tile %d columns, %d wavefronts per workgroup, %zu B of LDS: %d workgroups per CU\n", TL_TW, TL_WAVES, lds, nb);
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, spmv_tiled_kernel<0>, (TL_WAVES + 1) * 64, lds);
+      fprintf(stderr, "[mi355x tiled] tile %d columns, %d + 1 wavefronts per workgroup, %zu B of LDS: %d workgroups per CU\n", TL_TW, TL_WAVES, lds, nb);
     }
-    const char *e = getenv("MI355X_TILED_U");
-    U = (e && atoi(e) == 16) ? 16 : TL_U;
-    MI355X_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(spmv_tiled_kernel<0, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    MI355X_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(spmv_tiled_kernel<1, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    MI355X_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(spmv_tiled_kernel<0, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    MI355X_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(spmv_tiled_kernel<1, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    MI355X_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(spmv_tiled_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    MI355X_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(spmv_tiled_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
   }
   const int chunkx = (P->npanels + MI355X_NXCD - 1) / MI355X_NXCD;
   const int grid = chunkx * MI355X_NXCD;
   if (which != 2) {
-#define TL_GO(A_, U_, YIN) hipLaunchKernelGGL((spmv_tiled_kernel<A_, U_>), dim3(grid), dim3(TL_WAVES * 64), lds, h->stream, P->npanels, chunkx, P->d_pt_ptr, P->d_pt_tile, \
-                                              P->d_wt_e0, P->d_desc, P->d_val, P->d_lcol, x, YIN, yout, P->m, P->n)
-    if (yin) { if (U == 16) TL_GO(1, 16, yin); else TL_GO(1, 8, yin); }
-    else { if (U == 16) TL_GO(0, 16, (const double *)nullptr); else TL_GO(0, 8, (const double *)nullptr); }
+#define TL_GO(A_, YIN) hipLaunchKernelGGL((spmv_tiled_kernel<A_>), dim3(grid), dim3((TL_WAVES + 1) * 64), lds, h->stream, P->npanels, chunkx, P->d_pt_ptr, P->d_pt_tile, \
+                                          P->d_wt_e0, P->d_wt_s0, P->d_steps, P->d_desc, P->d_val, P->d_lcol, x, YIN, yout, P->m, P->n)
+    if (yin) TL_GO(1, yin); else TL_GO(0, (const double *)nullptr);
 #undef TL_GO
     MI355X_LAUNCH_CHECK();
   }
@@ -487,7 +554,7 @@ int mi355x_spmv_tiled(mi355x_handle_t h, mi355x_spmv_tiled_t P, const double *x,
 int mi355x_spmv_tiled_destroy(mi355x_spmv_tiled_t P) {
   if (!P) return 0;
   delete P->host;
-  void *ptrs[] = {P->d_pt_ptr, P->d_pt_tile, P->d_wt_e0, P->d_desc, P->d_perm, P->d_lcol, P->d_val, P->d_far_i, P->d_far_j, P->d_far_perm, P->d_far_a};
+  void *ptrs[] = {P->d_pt_ptr, P->d_pt_tile, P->d_wt_e0, P->d_wt_s0, P->d_steps, P->d_desc, P->d_perm, P->d_lcol, P->d_val, P->d_far_i, P->d_far_j, P->d_far_perm, P->d_far_a};
   for (void *q : ptrs) if (q) hipFree(q);
   for (int q = 0; q < TL_MAX_PASS; ++q) if (P->far_plan[q]) mi355x_spmv_plan_destroy(P->far_plan[q]);
   delete P;

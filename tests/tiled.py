@@ -47,6 +47,7 @@ def walk(k, plan, m):
     pt_ptr, pt_tile, wt_e0 = get(k, plan, 0, np.int32), get(k, plan, 1, np.int32), get(k, plan, 2, np.int32)
     desc = get(k, plan, 3, np.uint32).reshape(-1, 64, R)
     perm, lcol = get(k, plan, 4, np.int32), get(k, plan, 5, np.uint16)
+    stepw, wt_s0 = get(k, plan, 6, np.uint16), get(k, plan, 10, np.int32)
     far = get(k, plan, 7, np.int32), get(k, plan, 8, np.int32), get(k, plan, 9, np.int32)
     rows, cols, pos = [], [], []
     steps = 0
@@ -60,6 +61,8 @@ def walk(k, plan, m):
             ranked = np.zeros(W * R * 64, dtype=np.int64)
             for w in range(W):
                 off = int(wt_e0[pt * W + w])
+                sw = int(wt_s0[pt * W + w])
+                assert sw % 8 == 0 and wt_s0[pt * W + w + 1] % 8 == 0, "a wavefront's step words start on a group boundary"
                 for a in range(R):
                     cnt = (desc[pt * W + w, :, a] & 0xffff).astype(np.int64)
                     rl = (desc[pt * W + w, :, a] >> 16).astype(np.int64)
@@ -70,6 +73,8 @@ def walk(k, plan, m):
                             seen_rows.add(int(rl[l]))
                     for j in range(int(cnt[0])):
                         nact = int(np.sum(cnt > j))
+                        assert stepw[sw] == (a << 8) | nact, "the step word the kernel reads: round and active lanes"
+                        sw += 1
                         steps += 1
                         for l in range(nact):
                             rows.append(p * g["panel"] + int(rl[l]))
@@ -77,6 +82,7 @@ def walk(k, plan, m):
                             pos.append(int(perm[off + l]))
                         off += nact
                 assert off == wt_e0[pt * W + w + 1]
+                assert np.all(stepw[sw:wt_s0[pt * W + w + 1]] == 0) and wt_s0[pt * W + w + 1] - sw < 8, "padding words to the next group boundary"
             assert np.all(ranked[:-1] >= ranked[1:]), "the panel's rows sorted by count across the rounds"
     assert steps == info(k, plan)["steps"]
     return (np.array(rows, dtype=np.int64), np.array(cols, dtype=np.int64), np.array(pos, dtype=np.int64)), far
