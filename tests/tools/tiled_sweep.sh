@@ -1,10 +1,9 @@
 #!/bin/bash
-# A/B of the column-tiled SpMV's build knobs and remainder passes on the IRR stand-in (one box, one process per variant)
+# A/B of the column-tiled SpMV's build knobs on the IRR stand-in (one box, one process per variant)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 export CFG4_CACHE=/tmp MI355X_TILED_DEBUG=1
 V=$R/petsc-dev_amd/csrc/variants
-run() { echo "== $1"; shift; timeout -k 10 300 env "$@" python3 $R/tests/tools/tiled_probe.py irr 1024 2>&1 | grep -v "^irr\|lines of x"; }
+run() { echo "== $1"; shift; timeout -k 10 300 env "$@" python3 $R/tests/tools/tiled_probe.py irr 1024 2>&1 | grep -v "^irr\|lines of x\|^row-block"; }
 run "default build" A=1
-for q in 2 3; do run "remainder in $q passes" MI355X_TILED_FAR_PASSES=$q; done
-run "U = 16" MI355X_TILED_U=16
-for v in tw8192 tw2048 w16 w16tw2048; do run "variant $v" MI355X_KERNELS_LIB=$V/libmi355x_kernels_$v.so; done
+run "panels of 2048 rows (764: the last round of workgroup slots half empty)" MI355X_TILED_PANELS=764
+for v in ${VARIANTS:-u8g2 tw2048}; do run "variant $v" MI355X_KERNELS_LIB=$V/libmi355x_kernels_$v.so; done
