@@ -240,12 +240,12 @@ int mi355x_csr_get_diagonal(mi355x_handle_t h, int m, const int *ai, const int *
 
 /* ---- column-tiled CSR SpMV: x staged in LDS (csrc/spmv_tiled.hip) ------ */
 /* For matrices whose x gathers miss the caches (rows that pick columns from a wide window without neighbouring rows sharing them):
- * MatMult_SeqAIJ / MatMultAdd_SeqAIJ (aij.c:1225, 1291) re-cut into row panels (<= 2048 rows, equal shares of the nonzeros) x column
- * tiles of 4096 entries of x; a (panel, tile)
- * pair with >= stage_min entries gathers from a copy of that tile in LDS (one lane per row, jagged diagonals of the rows sorted by
- * their length in the tile), the thin pairs' entries stay in a CSR remainder added by the row-block kernel afterwards.  Products of a
- * row's staged entries are added in column order, then the remainder's: agrees with the reference to rounding (<= 1e-12 * sum
- * |a_ij x_j|; bit for bit when nothing is left to the remainder), reproducible.
+ * MatMult_SeqAIJ / MatMultAdd_SeqAIJ (aij.c:1225, 1291) re-cut into row panels (<= 2047 rows, equal shares of the nonzeros) x column
+ * tiles of 4096 entries of x; a (panel, tile) pair with >= stage_min entries gathers from a copy of that tile in LDS and adds into row
+ * sums that live in LDS too (12-byte entries in dense blocks of 128, two per lane, ds_add_f64), the thin pairs' entries stay in a CSR
+ * remainder added by the row-block kernel afterwards.  Products of a row's staged entries are added in column order, then the
+ * remainder's: agrees with the reference to rounding (<= 1e-12 * sum |a_ij x_j|; bit for bit when nothing is left to the
+ * remainder), reproducible.
  *   _probe    fraction of sampled gathers that touch a 128-byte line of x nothing else in their 32-row group touches (host only)
  *   _build    the layout from the host CSR pattern (host only: no device call); stage_min <= 0: 1024
  *   _upload   tables to the device; values gathered from the CSR value array that is on the device (aa_dev)
@@ -254,16 +254,16 @@ int mi355x_csr_get_diagonal(mi355x_handle_t h, int m, const int *ai, const int *
 typedef struct mi355x_spmv_tiled_s *mi355x_spmv_tiled_t;
 int mi355x_spmv_tiled_probe(int m, const int *ai_host, const int *aj_host, double *lines_per_nonzero);
 int mi355x_spmv_tiled_build(int m, int n, const int *ai_host, const int *aj_host, int stage_min, mi355x_spmv_tiled_t *plan);
-/* nsteps: jagged diagonals (one coalesced load of <= 64 entries each) over all wavefronts */
-int mi355x_spmv_tiled_info(mi355x_spmv_tiled_t plan, long *nnz_staged, long *nnz_remainder, int *npanels, int *npairs, long *nsteps);
-int mi355x_spmv_tiled_geometry(int *panel_rows, int *tile_cols, int *waves, int *rounds, int *group_steps, int *trip_steps);
+/* nblocks: 128-entry blocks stored over all wavefronts (nnz_staged / (128 nblocks): the share that is not padding) */
+int mi355x_spmv_tiled_info(mi355x_spmv_tiled_t plan, long *nnz_staged, long *nnz_remainder, int *npanels, int *npairs, long *nblocks);
+int mi355x_spmv_tiled_geometry(int *panel_rows, int *tile_cols, int *waves, int *block_entries);
 int mi355x_spmv_tiled_upload(mi355x_handle_t h, mi355x_spmv_tiled_t plan, const double *aa_dev);
 int mi355x_spmv_tiled_refresh_values(mi355x_handle_t h, mi355x_spmv_tiled_t plan, const double *aa_dev);
 int mi355x_spmv_tiled(mi355x_handle_t h, mi355x_spmv_tiled_t plan, const double *x, const double *yin, double *yout);
 /* development: which = 1 the staged part only, 2 the remainder only (their separate cost), 0 both */
 int mi355x_spmv_tiled_parts(mi355x_handle_t h, mi355x_spmv_tiled_t plan, const double *x, const double *yin, double *yout, int which);
-/* tests: one host array of the layout (0 pt_ptr, 1 pt_tile, 2 pw_e0, 3 desc, 4 perm, 5 lcol, 6 steps, 7 far_i, 8 far_j, 9 far_perm,
- * 10 pw_s0, 11 prow) until _drop_host releases the host copy */
+/* tests: one host array of the layout (0 pt_ptr, 1 pt_tile, 2 pw_e0, 3 word, 4 perm, 7 far_i, 8 far_j, 9 far_perm, 10 wrow, 11 prow)
+ * until _drop_host releases the host copy */
 int mi355x_spmv_tiled_debug_get(mi355x_spmv_tiled_t plan, int which, void *out, size_t cap_bytes, size_t *bytes);
 int mi355x_spmv_tiled_drop_host(mi355x_spmv_tiled_t plan);
 int mi355x_spmv_tiled_destroy(mi355x_spmv_tiled_t plan);

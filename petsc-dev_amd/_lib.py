@@ -104,7 +104,7 @@ KERNEL_API = {
     "mi355x_spmv_tiled_probe": [i32, vp, vp, C.POINTER(dbl)],
     "mi355x_spmv_tiled_build": [i32, i32, vp, vp, i32, C.POINTER(vp)],
     "mi355x_spmv_tiled_info": [vp, C.POINTER(C.c_long), C.POINTER(C.c_long), pi32, pi32, C.POINTER(C.c_long)],
-    "mi355x_spmv_tiled_geometry": [pi32, pi32, pi32, pi32, pi32, pi32],
+    "mi355x_spmv_tiled_geometry": [pi32, pi32, pi32, pi32],
     "mi355x_spmv_tiled_upload": [vp, vp, vp],
     "mi355x_spmv_tiled_refresh_values": [vp, vp, vp],
     "mi355x_spmv_tiled": [vp, vp, vp, vp, vp],

@@ -5,28 +5,32 @@
 // without neighbouring rows sharing them (the irregular stand-in of BASELINE configs[3]: 73 entries per row, +-50 000 band, a fifth of the
 // entries anywhere) every gather is an L1 miss that moves a whole cache line out of L2 for 8 useful bytes: 120 M L1->L2 requests for 112 M
 // nonzeros, 2.5x the algorithmic bytes on the fabric, 0.23 of the HBM roof (profiles/r02_cfg4_irr*).  LDS is the one on-chip memory with
-// word-granular random access, so the product is re-cut so that the gathers go there.
+// word-granular random access, so the product is re-cut so that the gathers -- and the row sums -- live there.
 //
 // Layout (built once per nonzero pattern on host threads, values refreshed on the device through a permutation):
-//   * rows in PANELS of TL_PANEL = 2048 rows, one workgroup per panel; columns in TILES of TL_TW (4096) entries of x = 32 KB of LDS, two of
-//     them resident (the next tile arrives while the current one is gathered from);
-//   * a (panel, tile) pair with at least `stage_min` entries is STAGED: the workgroup loads that tile of x into LDS once and all of the
-//     panel's entries in it gather from there.  The panel walks its staged tiles in ascending order.  Entries of pairs too thin to
-//     stage (the long-range fifth) stay in a CSR remainder that the row-block kernel adds afterwards (mi355x_spmv_csr_add) -- the split
-//     of MatMult_MPIAIJ's diagonal / off-diagonal blocks, inside one GPU;
-//   * per staged tile, ONE LANE PER ROW: the panel's rows with entries in the tile are sorted by their number of entries there
-//     (descending) and cut into ROUNDS of 64 consecutive ranks -- rows of (nearly) equal length -- dealt to the workgroup's wavefronts in
-//     turn (TL_RPL = 4 rounds each).  A round is stored as jagged diagonals: step j holds entry j of every row of the round that has more
-//     than j entries -- the rows being sorted, those are lanes 0 .. n_j - 1 -- so a step is ONE coalesced load of n_j values and n_j
-//     2-byte in-tile column numbers with no padding, n_j comes out of a ballot of the lanes' own counts, and a lane meets its row's
-//     entries in column order: x from the LDS tile, multiply, add to the row's running sum.  No product stage, no cross-lane traffic,
-//     no barrier except at a tile switch.  The running sums of the panel's rows live in LDS between tiles (the row <-> lane assignment
-//     changes with the tile);
-//   * per (wavefront, tile) one 16-byte word per lane says which rows it serves and how many entries each has: ~0.9 B per entry on the
-//     stand-in; with 8 B values and 2 B columns 10.9 B per entry instead of CSR's 12 + 4 per row.
-// Arithmetic: a*x rounded, then added (-ffp-contract=off); a row's staged products are added one after the other in column order
-// starting from 0 (or y), the remainder after them (that part's rows of more than 16 entries by a tree): agrees with the reference to
-// rounding (tests: <= 1e-12 * sum |a_ij x_j|), bit for bit when nothing is left to the remainder, and run-to-run identical.
+//   * rows in PANELS of <= TL_PANEL = 6143 rows holding equal shares of the nonzeros, one workgroup per panel; columns in TILES of TL_TW
+//     (2048) entries of x = 16 KB of LDS, two of them resident (a loader wavefront brings the next tile while the current one is
+//     gathered from); the panel's row sums are 6144 doubles of LDS for the whole kernel;
+//   * a (panel, tile) pair with at least `stage_min` entries is STAGED: all of the panel's entries in that tile gather x from LDS.  The
+//     panel walks its staged tiles in ascending order.  Entries of pairs too thin to stage (the long-range fifth) stay in a CSR
+//     remainder that the row-block kernel adds afterwards (mi355x_spmv_csr_add) -- the split of MatMult_MPIAIJ's diagonal /
+//     off-diagonal blocks, inside one GPU;
+//   * the panel's rows are dealt to the workgroup's TL_WAVES gathering wavefronts in contiguous ranges of equal nonzeros: a row's sum
+//     is only ever touched by its wavefront.  A wavefront's entries of one staged tile, in CSR order (rows ascending, columns
+//     ascending), are cut into BLOCKS of 128 padded with zeros that go to a spare accumulator; its blocks of all the panel's tiles
+//     follow each other without a gap.  An entry is 12 bytes: the value and one 32-bit word (row of the panel << 16 | column in the
+//     tile; bit 15 of a block's first word: the block opens the next tile);
+//   * the kernel keeps TL_NG blocks' loads in flight per wavefront, across tile switches.  A block is TWO full-width loads (16 bytes of
+//     values, 8 bytes of words per lane: two entries) and per entry one LDS read of x, one multiply and one ds_add_f64 into the row's
+//     sum: no sorting, no descriptors, no per-row bookkeeping -- 10 instructions per entry and lane where the jagged-diagonal forms of
+//     this file's history took 50 and were bound by the wavefronts' own instruction streams (profiles/r04_tiled_*: 0.30 ms whatever
+//     the pipelining), while the memory system gives this access pattern 6.8 TB/s (profiles/r04_dense_atomic_probe.log).
+// Arithmetic: a*x rounded, then added (-ffp-contract=off).  Entry q of a block is stored at position 2 (q mod 64) + q div 64: lane l's
+// pair is entries l and 64 + l, so the block's first ds_add_f64 instruction adds entries 0..63 and the second 64..127, and lanes of one
+// instruction that meet on one accumulator are added in ascending lane order (measured: dense_atomic_probe; asserted by the GPU tests'
+// bitwise comparison with the layout's order): a row's staged products are added one after the other in column order starting from 0
+// (or y), the remainder after them (that part's rows of more than 16 entries by a tree): agrees with the reference to rounding (tests:
+// <= 1e-12 * sum |a_ij x_j|), bit for bit when nothing is left to the remainder, and run-to-run identical.
 #include "common.hpp"
 #include <algorithm>
 #include <atomic>
@@ -37,52 +41,43 @@
 #include <stdio.h>
 
 #ifndef TL_TW
-#define TL_TW 4096            // columns of x per tile (32 KB of LDS; two buffers)
+#define TL_TW 2048            // columns of x per tile (16 KB of LDS; two buffers)
 #endif
 #ifndef TL_WAVES
 #define TL_WAVES 8            // gathering wavefronts per workgroup
 #endif
-#define TL_RPL 4              // rounds per (wavefront, tile): rows per lane
-#define TL_PANEL (TL_WAVES * 64 * TL_RPL)  // most rows a workgroup takes: every row of the panel is some lane's in some round, whatever the tile
+#ifndef TL_NG
+#define TL_NG 4               // blocks in flight per wavefront
+#endif
+#ifndef TL_SLOTS
+#define TL_SLOTS 6144                      // row sums in LDS (48 KB): the panel's rows and one spare for the padding.  With the two tiles 80 KB: two
+#endif                                     // workgroups fit a CU.  (Entries per (panel, tile) pair -- what a tile switch and a block's padding are paid
+                                           // from -- go with rows x columns: 6144 x 2048 holds 1.5x those of 2048 x 4096 in the same LDS and moves
+                                           // a third of the x tiles: 0.19 ms against 0.26 on the stand-in, profiles/r04_tiled_sweep5.log)
+#define TL_PANEL (TL_SLOTS - 1)            // most rows a workgroup takes
+#define TL_BLOCK 128                       // entries per block: two per lane
 #define TL_MAX_PASS 16                     // column ranges of the remainder
 #define TL_PASS_BYTES (3u << 20)           // ... each covering <= 3 MiB of x: it stays in one XCD's 4 MiB L2 next to the streams passing through
-#define TL_CNT_BITS 16                     // a descriptor word: (row of the panel << 16) | entries of the row in the tile (<= TL_TW)
-static_assert(TL_TW < (1 << TL_CNT_BITS) && TL_PANEL <= (1 << (32 - TL_CNT_BITS)), "descriptor word");
-#ifndef TL_U
-#define TL_U 4                // steps per group: the loads a lane issues together
-#endif
-#ifndef TL_NG
-#define TL_NG 3               // groups in flight per wavefront
-#endif
-#define TL_TRIPW (TL_NG * TL_U / 2)        // 32-bit words of step descriptors per trip of the kernel's loop (two steps per word)
-static_assert((TL_U == 4 || TL_U == 8) && TL_TRIPW <= 64, "step words: a group is 2 or 4 whole 32-bit words, a trip's words one per lane");
-#define TL_STEP_NEWTILE 0x8000u            // step word: first step of the wavefront's first group in the panel's next staged tile
-#define TL_STEP_ROUNDEND 0x4000u           // ... last step of a round: the lanes' rows are complete for this tile, the next round's rows follow
-#define TL_LDS_BYTES (8 * (2 * TL_TW + TL_PANEL))
+#define TL_WORD_NEWTILE 0x8000u            // a block's first word: the block opens the panel's next staged tile
+static_assert(TL_TW <= 0x8000 && TL_SLOTS <= 0x10000 && TL_TW % 128 == 0, "entry word: row << 16 | flag << 15 | column in the tile; a tile is whole 1 KB loads");
+#define TL_LDS_BYTES (8 * (2 * TL_TW + TL_SLOTS))
 #define TL_NCU 256
-#define TL_WG_PER_CU ((160 * 1024 / TL_LDS_BYTES) < (32 / (TL_WAVES + 1)) ? (160 * 1024 / TL_LDS_BYTES) : (32 / (TL_WAVES + 1)))
-static_assert(TL_WG_PER_CU >= 1, "one workgroup must fit a CU");
+static_assert(TL_LDS_BYTES <= 160 * 1024 && (TL_WAVES + 1) * 64 <= 1024, "one workgroup must fit a CU");
 
 typedef double tl_v2d __attribute__((ext_vector_type(2)));
-typedef unsigned int tl_u4 __attribute__((ext_vector_type(4)));
+typedef unsigned int tl_v2u __attribute__((ext_vector_type(2)));
 
 // what the builder leaves (host) and the plan holds (device); all offsets fit 32 bits (nnz < 2^31 as in the CSR arrays)
 struct tl_host {
   int m = 0, n = 0, npanels = 0;
-  long nnz = 0, nnz_near = 0, nnz_far = 0, nsteps = 0;
-  std::vector<int> prow;          // [npanels + 1] first row of a panel (<= TL_PANEL rows each, cut so that the panels hold equal shares of the nonzeros)
+  long nnz = 0, nnz_near = 0, nnz_far = 0, nstore = 0;
+  std::vector<int> prow;          // [npanels + 1] first row of a panel
+  std::vector<int> wrow;          // [npanels * (TL_WAVES + 1)] first row (of the matrix) of a wavefront's range inside its panel; the last one = the panel's end
   std::vector<int> pt_ptr;        // [npanels + 1] -> staged (panel, tile) pairs
   std::vector<int> pt_tile;       // [npt] tile number
-  // a wavefront's stream runs through ALL staged tiles of its panel without a gap: (panel, wavefront)-major, tiles ascending inside
-  std::vector<int> pw_e0;         // [npanels * TL_WAVES + 1] first entry of (panel, wavefront) in val / lcol / perm
-  std::vector<int> pw_s0;         // [npanels * TL_WAVES + 1] first step word of (panel, wavefront) in `steps` (a multiple of TL_U)
-  std::vector<unsigned int> desc; // [(pt_ptr[p] * TL_WAVES + w * ntiles(p) + i)][64][TL_RPL]: in tile i of the panel, in its round a, lane l of wavefront w serves row (word >> 16) of the panel, which has (word & 0xffff) entries in the tile
-  std::vector<unsigned short> steps;   // one word per jagged diagonal: active lanes (1..64; 0 = padding), TL_STEP_ROUNDEND on a round's last
-                                       // step (a tile's rounds follow each other, 0 .. 3, empty ones last and absent); a wavefront's steps of
-                                       // one tile are padded to whole groups of TL_U (at least one group per tile) and the first word of the
-                                       // tile's first group carries TL_STEP_NEWTILE
-  std::vector<int> perm;          // [nnz_near] entry -> position in the CSR value array
-  std::vector<unsigned short> lcol;   // [nnz_near] column - tile * TL_TW
+  std::vector<int> pw_e0;         // [npanels * TL_WAVES + 1] first stored entry of (panel, wavefront): a multiple of TL_BLOCK
+  std::vector<int> perm;          // [nstore] stored entry -> position in the CSR value array, -1: padding (value 0)
+  std::vector<unsigned int> word; // [nstore] row of the panel << 16 | column - tile * TL_TW (padding: TL_PANEL << 16); TL_WORD_NEWTILE on the first stored word of a tile's first block
   int npass = 1;                  // the remainder is cut into column ranges applied one after the other (x of one range stays in every XCD's L2)
   std::vector<int> far_i, far_j, far_perm;   // CSR remainder, pass-major: far_i[q * (m + 1) + r] .. [.. + r + 1] = row r's entries of pass q in far_j / far_perm (absolute positions), global columns
 };
@@ -90,10 +85,9 @@ struct tl_host {
 struct mi355x_spmv_tiled_s {
   tl_host *host;                  // kept until _drop_host (tests read it back)
   int m, n, npanels, npt;
-  long nnz_near, nnz_far, nsteps;
-  int *d_prow, *d_pt_ptr, *d_pt_tile, *d_pw_e0, *d_pw_s0, *d_perm;
-  unsigned int *d_desc;
-  unsigned short *d_lcol, *d_steps;
+  long nnz_near, nnz_far, nstore;
+  int *d_prow, *d_pt_ptr, *d_pt_tile, *d_pw_e0, *d_perm;
+  unsigned int *d_word;
   double *d_val;
   int npass;
   long nfar_store;               // entries of the remainder's arrays (nnz_far + padding between passes)
@@ -109,71 +103,67 @@ namespace {
 struct PanelOut {
   std::vector<int> pt_tile;
   std::vector<int> perm[TL_WAVES];
-  std::vector<unsigned int> desc[TL_WAVES];
-  std::vector<unsigned short> lcol[TL_WAVES], steps[TL_WAVES];
-  long near = 0, nsteps = 0;
+  std::vector<unsigned int> word[TL_WAVES];
+  int wrow[TL_WAVES + 1];
+  long near = 0;
 };
-struct RowSeg { int rl, k0, cnt; };
 
-// one panel (rows r0 .. r1 - 1): which tiles are staged, then per (wavefront, staged tile) the rounds of jagged diagonals
-static void build_panel(int r0, int r1, int n, const int *ai, const int *aj, int stage_min, std::vector<int> &cnt, std::vector<int> &touched,
+// position of a block's entry q (CSR order) in storage: lane q mod 64 holds entries q and q + 64 side by side
+static inline int tl_slot(int q) { return 2 * (q & 63) + (q >> 6); }
+
+// one panel (rows r0 .. r1 - 1): its wavefronts' row ranges, which tiles are staged, then per (wavefront, staged tile) the blocks
+static void build_panel(int r0, int r1, const int *ai, const int *aj, int stage_min, std::vector<int> &cnt, std::vector<int> &touched,
                         std::vector<int> &cur, PanelOut &o) {
-  (void)n;
+  // wavefront ranges: equal shares of the panel's nonzeros
+  {
+    const long base = ai[r0], tot = (long)ai[r1] - base;
+    o.wrow[0] = r0;
+    for (int w = 1; w < TL_WAVES; ++w) {
+      int r;
+      if (tot > 0) r = (int)(std::lower_bound(ai + r0, ai + r1 + 1, base + (tot * w + TL_WAVES - 1) / TL_WAVES, [](int v, long t) { return (long)v < t; }) - ai);
+      else r = r0 + (int)(((long)(r1 - r0) * w) / TL_WAVES);
+      if (r < o.wrow[w - 1]) r = o.wrow[w - 1];
+      if (r > r1) r = r1;
+      o.wrow[w] = r;
+    }
+    o.wrow[TL_WAVES] = r1;
+  }
   touched.clear();
   for (int r = r0; r < r1; ++r)
     for (int k = ai[r]; k < ai[r + 1]; ++k) { const int t = aj[k] / TL_TW; if (cnt[t]++ == 0) touched.push_back(t); }
   std::sort(touched.begin(), touched.end());
   for (int r = r0; r < r1; ++r) cur[r - r0] = ai[r];
-  std::vector<RowSeg> segs;
-  segs.reserve(TL_PANEL);
+  std::vector<int> kk;                                     // one (wavefront, tile)'s entries in CSR order
   for (int t : touched) {
     const bool staged = cnt[t] >= stage_min;
     cnt[t] = 0;
     if (!staged) continue;
     const int clo = t * TL_TW, chi = clo + TL_TW;
     o.pt_tile.push_back(t);
-    // the panel's rows with entries in this tile, longest first (ties: lower row first)
-    segs.clear();
-    for (int rl = 0; rl < r1 - r0; ++rl) {
-      const int r = r0 + rl;
-      int k = cur[rl];
-      const int kend = ai[r + 1];
-      while (k < kend && aj[k] < clo) ++k;                 // entries of thinner tiles in between: the remainder's
-      const int kb = k;
-      while (k < kend && aj[k] < chi) ++k;
-      cur[rl] = k;
-      if (k > kb) segs.push_back({rl, kb, k - kb});
-    }
-    std::stable_sort(segs.begin(), segs.end(), [](const RowSeg &a, const RowSeg &b) { return a.cnt > b.cnt; });
-    // rounds of 64 consecutive ranks; round g goes to wavefront g % TL_WAVES as its round g / TL_WAVES
     for (int w = 0; w < TL_WAVES; ++w) {
-      std::vector<unsigned int> &D = o.desc[w];
-      std::vector<unsigned short> &S = o.steps[w];
-      const size_t dbase = D.size(), sbase = S.size();
-      D.resize(dbase + 64 * TL_RPL, 0u);
-      int ns = 0;
-      for (int a = 0; a < TL_RPL; ++a) {
-        const size_t g = (size_t)a * TL_WAVES + w;
-        const size_t lo = g * 64, hi = std::min(segs.size(), lo + 64);
-        if (lo >= hi) break;
-        for (size_t q = lo; q < hi; ++q) D[dbase + (q - lo) * TL_RPL + a] = ((unsigned int)segs[q].rl << TL_CNT_BITS) | (unsigned int)segs[q].cnt;
-        const int maxc = segs[lo].cnt;
-        for (int j = 0; j < maxc; ++j) {
-          int nact = 0;
-          for (size_t q = lo; q < hi && segs[q].cnt > j; ++q) {
-            const int k = segs[q].k0 + j;
-            o.perm[w].push_back(k);
-            o.lcol[w].push_back((unsigned short)(aj[k] - clo));
-            ++nact;
-          }
-          S.push_back((unsigned short)(nact | (j + 1 == maxc ? TL_STEP_ROUNDEND : 0u)));
-          ++ns;
-          o.near += nact;
-        }
-        o.nsteps += maxc;
+      kk.clear();
+      for (int r = o.wrow[w]; r < o.wrow[w + 1]; ++r) {
+        int k = cur[r - r0];
+        const int kend = ai[r + 1];
+        while (k < kend && aj[k] < clo) ++k;               // entries of thinner tiles in between: the remainder's
+        while (k < kend && aj[k] < chi) kk.push_back(k++);
+        cur[r - r0] = k;
       }
-      if (ns == 0 || ns % TL_U) do { S.push_back(0); ++ns; } while (ns % TL_U);   // whole groups, and at least one per tile (the wavefront meets every tile switch)
-      S[sbase] = (unsigned short)(S[sbase] | TL_STEP_NEWTILE);
+      const int nreal = (int)kk.size();
+      const int nb = nreal ? (nreal + TL_BLOCK - 1) / TL_BLOCK : 1;     // at least one block per tile: the wavefront meets every tile switch
+      const size_t base = o.perm[w].size();
+      o.perm[w].resize(base + (size_t)nb * TL_BLOCK, -1);
+      o.word[w].resize(base + (size_t)nb * TL_BLOCK, (unsigned int)TL_PANEL << 16);
+      int r = o.wrow[w];
+      for (int q = 0; q < nreal; ++q) {
+        const int k = kk[(size_t)q];
+        while (ai[r + 1] <= k) ++r;
+        const size_t pos = base + (size_t)(q / TL_BLOCK) * TL_BLOCK + (size_t)tl_slot(q % TL_BLOCK);
+        o.perm[w][pos] = k;
+        o.word[w][pos] = ((unsigned int)(r - r0) << 16) | (unsigned int)(aj[k] - clo);
+      }
+      o.word[w][base] |= TL_WORD_NEWTILE;
+      o.near += nreal;
     }
   }
 }
@@ -209,29 +199,43 @@ int mi355x_spmv_tiled_build(int m, int n, const int *ai, const int *aj, int stag
   if (stage_min <= 0) stage_min = 1024;
   tl_host *H = new tl_host();
   H->m = m; H->n = n; H->nnz = m ? ai[m] : 0;
-  // panels: equal shares of the nonzeros (<= TL_PANEL rows each), and a whole number of rounds of the chip's workgroup slots when the
-  // matrix is large enough to fill them more than once -- a last round that fills a fraction of the slots costs as much as a full one
+  // panels: equal shares of the nonzeros (<= TL_PANEL rows each), and the same number on every CU when there are more than CUs -- the
+  // product runs at the rate of the CU with the most panels (306 panels on 256 CUs cost what 512 do: profiles/r04_tiled_sweep5.log)
   {
-    const int slots = TL_NCU * TL_WG_PER_CU;
+    const int slots = TL_NCU;
     long np = ((long)m + TL_PANEL - 1) / TL_PANEL;
     if (np > slots) np = (np + slots - 1) / slots * slots;
     const char *e_ = getenv("MI355X_TILED_PANELS");
-    if (e_ && atol(e_) > 0) np = atol(e_);
+    const bool forced = e_ && atol(e_) > 0;
+    if (forced) np = atol(e_);
     if (np < 1) np = 1;
-    H->prow.push_back(0);
-    int r = 0;
-    for (long p = 0; r < m; ++p) {
-      int end;
-      if (H->nnz > 0 && p + 1 < np) {
-        const long target = (long)(((__int128)H->nnz * (p + 1) + np - 1) / np);      // nonzeros the first p + 1 panels should hold
-        end = (int)(std::lower_bound(ai + r, ai + m + 1, target, [](int v, long t) { return (long)v < t; }) - ai);
-      } else end = (H->nnz > 0) ? m : (int)std::min<long>(m, ((long)m * (p + 1) + np - 1) / np);
-      if (end <= r) end = r + 1;
-      if (end > r + TL_PANEL) end = r + TL_PANEL;
-      if (end > m) end = m;
-      H->prow.push_back(end);
-      r = end;
-    }
+    // the smallest bound on a panel's nonzeros with which the rows fit np panels of <= TL_PANEL rows (greedy cuts, bisection on the
+    // bound); rows too sparse for that (the row cap binds): another panel per CU
+    auto cut = [&](long bound, std::vector<int> *outv) -> long {
+      long cnt = 0;
+      int r = 0;
+      if (outv) { outv->clear(); outv->push_back(0); }
+      while (r < m) {
+        int end = (int)(std::upper_bound(ai + r, ai + m + 1, (long)ai[r] + bound, [](long t, int v) { return t < (long)v; }) - ai) - 1;   // last end with ai[end] - ai[r] <= bound
+        if (end <= r) end = r + 1;                         // (a row heavier than the bound: a panel of its own)
+        if (end > r + TL_PANEL) end = r + TL_PANEL;
+        if (end > m) end = m;
+        if (outv) outv->push_back(end);
+        r = end;
+        ++cnt;
+      }
+      return cnt;
+    };
+    if (m > 0) {
+      while (!forced && cut(H->nnz + 1, nullptr) > np) np += (np >= slots) ? slots : 1;
+      long lo = H->nnz / np, hi = H->nnz + 1;              // cut(hi) <= np holds (or the count is forced: the best the row cap allows)
+      if (lo < 1) lo = 1;
+      while (lo < hi) {
+        const long mid = lo + (hi - lo) / 2;
+        if (cut(mid, nullptr) <= np) hi = mid; else lo = mid + 1;
+      }
+      cut(hi, &H->prow);
+    } else H->prow.push_back(0);
     H->npanels = (int)H->prow.size() - 1;
   }
   const int ntiles = (n + TL_TW - 1) / TL_TW;
@@ -244,7 +248,7 @@ int mi355x_spmv_tiled_build(int m, int n, const int *ai, const int *aj, int stag
     auto work = [&]() {
       std::vector<int> cnt((size_t)ntiles + 1, 0), touched, cur((size_t)TL_PANEL, 0);
       for (int p = next.fetch_add(1); p < H->npanels; p = next.fetch_add(1))
-        build_panel(H->prow[(size_t)p], H->prow[(size_t)p + 1], n, ai, aj, stage_min, cnt, touched, cur, po[(size_t)p]);
+        build_panel(H->prow[(size_t)p], H->prow[(size_t)p + 1], ai, aj, stage_min, cnt, touched, cur, po[(size_t)p]);
     };
     std::vector<std::thread> th;
     for (int t = 1; t < nth; ++t) th.emplace_back(work);
@@ -252,34 +256,31 @@ int mi355x_spmv_tiled_build(int m, int n, const int *ai, const int *aj, int stag
     for (auto &t : th) t.join();
   }
   // concatenate: panel after panel, inside a panel wavefront after wavefront
-  size_t npt = 0, nval = 0, nsw = 0;
+  size_t npt = 0, nst = 0;
   for (auto &o : po) {
-    npt += o.pt_tile.size(); H->nnz_near += o.near; H->nsteps += o.nsteps;
-    for (int w = 0; w < TL_WAVES; ++w) { nval += o.perm[w].size(); nsw += o.steps[w].size(); }
+    npt += o.pt_tile.size(); H->nnz_near += o.near;
+    for (int w = 0; w < TL_WAVES; ++w) nst += o.perm[w].size();
   }
+  if (nst >= (size_t)1 << 31) { delete H; return (int)hipErrorInvalidValue; }
   H->pt_ptr.resize((size_t)H->npanels + 1);
-  H->pt_tile.reserve(npt); H->pw_e0.reserve((size_t)H->npanels * TL_WAVES + 1); H->pw_s0.reserve((size_t)H->npanels * TL_WAVES + 1);
-  H->desc.reserve(npt * TL_WAVES * 64 * TL_RPL); H->perm.reserve(nval); H->lcol.reserve(nval + 8); H->steps.reserve(nsw + 8);
-  long e = 0, sw = 0;
+  H->pt_tile.reserve(npt); H->pw_e0.reserve((size_t)H->npanels * TL_WAVES + 1); H->wrow.reserve((size_t)H->npanels * (TL_WAVES + 1));
+  H->perm.reserve(nst); H->word.reserve(nst);
+  long e = 0;
   for (int p = 0; p < H->npanels; ++p) {
     PanelOut &o = po[(size_t)p];
     H->pt_ptr[(size_t)p] = (int)H->pt_tile.size();
     H->pt_tile.insert(H->pt_tile.end(), o.pt_tile.begin(), o.pt_tile.end());
+    H->wrow.insert(H->wrow.end(), o.wrow, o.wrow + TL_WAVES + 1);
     for (int w = 0; w < TL_WAVES; ++w) {
       H->pw_e0.push_back((int)e); e += (long)o.perm[w].size();
-      while (o.steps[w].size() % (TL_NG * TL_U)) o.steps[w].push_back(0);       // whole trips of the kernel's loop
-      H->pw_s0.push_back((int)sw); sw += (long)o.steps[w].size();
-      H->steps.insert(H->steps.end(), o.steps[w].begin(), o.steps[w].end());
-      H->desc.insert(H->desc.end(), o.desc[w].begin(), o.desc[w].end());
       H->perm.insert(H->perm.end(), o.perm[w].begin(), o.perm[w].end());
-      H->lcol.insert(H->lcol.end(), o.lcol[w].begin(), o.lcol[w].end());
-      std::vector<unsigned short>().swap(o.steps[w]); std::vector<int>().swap(o.perm[w]);
-      std::vector<unsigned short>().swap(o.lcol[w]); std::vector<unsigned int>().swap(o.desc[w]);
+      H->word.insert(H->word.end(), o.word[w].begin(), o.word[w].end());
+      std::vector<int>().swap(o.perm[w]); std::vector<unsigned int>().swap(o.word[w]);
     }
   }
   H->pt_ptr[(size_t)H->npanels] = (int)H->pt_tile.size();
   H->pw_e0.push_back((int)e);
-  H->pw_s0.push_back((int)sw);
+  H->nstore = e;
   // remainder: every entry no stream took (a second walk with the same staging decisions), cut into column ranges of <= 3 MiB of x that
   // are applied one after the other: the gathers of one pass then hit the L2 of whichever XCD issues them instead of going out to the
   // Infinity Cache for every one (the remainder is what is scattered over all of x).  Within a pass rows in order, columns ascending;
@@ -323,31 +324,31 @@ int mi355x_spmv_tiled_build(int m, int n, const int *ai, const int *aj, int stag
     for (int q = 0; q < H->npass; ++q) for (int r = 0; r < m; ++r) nextpr[(size_t)q * m + r] = H->far_i[(size_t)q * (m + 1) + r];
     for_far([&](int r, int k, int q) { const int pos = nextpr[(size_t)q * m + r]++; H->far_j[(size_t)pos] = aj[k]; H->far_perm[(size_t)pos] = k; });
   }
-  if (e != H->nnz_near) { delete H; return (int)hipErrorUnknown; }
+  if (e != H->nstore) { delete H; return (int)hipErrorUnknown; }
   mi355x_spmv_tiled_s *P = new mi355x_spmv_tiled_s();
   memset(P, 0, sizeof(*P));
   P->host = H;
   P->m = m; P->n = n; P->npanels = H->npanels; P->npt = (int)H->pt_tile.size();
-  P->nnz_near = H->nnz_near; P->nnz_far = H->nnz_far; P->nsteps = H->nsteps; P->npass = H->npass;
+  P->nnz_near = H->nnz_near; P->nnz_far = H->nnz_far; P->nstore = H->nstore; P->npass = H->npass;
   *out = P;
   return 0;
 }
 
-// nsteps: jagged diagonals over all wavefronts (nnz_staged / nsteps = lanes busy per load, of 64)
-int mi355x_spmv_tiled_info(mi355x_spmv_tiled_t P, long *nnz_staged, long *nnz_remainder, int *npanels, int *npairs, long *nsteps) {
+// nblocks: 128-entry blocks over all wavefronts (nnz_staged / (128 nblocks) = the share of the stored entries that are not padding)
+int mi355x_spmv_tiled_info(mi355x_spmv_tiled_t P, long *nnz_staged, long *nnz_remainder, int *npanels, int *npairs, long *nblocks) {
   if (nnz_staged) *nnz_staged = P->nnz_near;
   if (nnz_remainder) *nnz_remainder = P->nnz_far;
   if (npanels) *npanels = P->npanels;
   if (npairs) *npairs = P->npt;
-  if (nsteps) *nsteps = P->nsteps;
+  if (nblocks) *nblocks = P->nstore / TL_BLOCK;
   return 0;
 }
-int mi355x_spmv_tiled_geometry(int *panel_rows, int *tile_cols, int *waves, int *rounds, int *group_steps, int *trip_steps) {
-  *panel_rows = TL_PANEL; *tile_cols = TL_TW; *waves = TL_WAVES; *rounds = TL_RPL; *group_steps = TL_U; *trip_steps = TL_NG * TL_U;
+int mi355x_spmv_tiled_geometry(int *panel_rows, int *tile_cols, int *waves, int *block_entries) {
+  *panel_rows = TL_PANEL; *tile_cols = TL_TW; *waves = TL_WAVES; *block_entries = TL_BLOCK;
   return 0;
 }
 
-// tests: one host array of the layout (which: 0 pt_ptr, 1 pt_tile, 2 pw_e0, 3 desc, 4 perm, 5 lcol, 6 steps, 7 far_i, 8 far_j, 9 far_perm, 10 pw_s0, 11 prow);
+// tests: one host array of the layout (which: 0 pt_ptr, 1 pt_tile, 2 pw_e0, 3 word, 4 perm, 7 far_i, 8 far_j, 9 far_perm, 10 wrow, 11 prow);
 // available until mi355x_spmv_tiled_drop_host
 int mi355x_spmv_tiled_debug_get(mi355x_spmv_tiled_t P, int which, void *out, size_t cap_bytes, size_t *bytes) {
   if (!P->host) return (int)hipErrorInvalidValue;
@@ -357,15 +358,13 @@ int mi355x_spmv_tiled_debug_get(mi355x_spmv_tiled_t P, int which, void *out, siz
     case 0: src = H->pt_ptr.data(); nb = H->pt_ptr.size() * 4; break;
     case 1: src = H->pt_tile.data(); nb = H->pt_tile.size() * 4; break;
     case 2: src = H->pw_e0.data(); nb = H->pw_e0.size() * 4; break;
-    case 3: src = H->desc.data(); nb = H->desc.size() * 4; break;
+    case 3: src = H->word.data(); nb = H->word.size() * 4; break;
     case 4: src = H->perm.data(); nb = H->perm.size() * 4; break;
-    case 5: src = H->lcol.data(); nb = H->lcol.size() * 2; break;
-    case 6: src = H->steps.data(); nb = H->steps.size() * 2; break;
-    case 10: src = H->pw_s0.data(); nb = H->pw_s0.size() * 4; break;
-    case 11: src = H->prow.data(); nb = H->prow.size() * 4; break;
     case 7: src = H->far_i.data(); nb = H->far_i.size() * 4; break;
     case 8: src = H->far_j.data(); nb = H->far_j.size() * 4; break;
     case 9: src = H->far_perm.data(); nb = H->far_perm.size() * 4; break;
+    case 10: src = H->wrow.data(); nb = H->wrow.size() * 4; break;
+    case 11: src = H->prow.data(); nb = H->prow.size() * 4; break;
     default: return (int)hipErrorInvalidValue;
   }
   *bytes = nb;
@@ -386,80 +385,29 @@ __global__ __launch_bounds__(256) void tl_gather_values_kernel(const int *__rest
 }
 
 // One workgroup = TL_WAVES gathering wavefronts + ONE loader wavefront.  The loader brings the panel's next staged tile of x into the
-// idle one of two LDS buffers while the others gather from the current one: a tile switch is one barrier, no load on anybody's path.
-// A gathering wavefront's stream runs through all the panel's tiles without a gap and it keeps TL_NG groups of TL_U steps' loads in
-// flight ACROSS the tile switches (the value / column loads do not depend on the tile of x, only their use does): the barrier costs the
-// skew between the wavefronts, not a drained pipeline.  The step words (round and active-lane count of each step, wave-uniform) come
-// through a vector load one trip ahead, one 32-bit word per lane, and are read out with readlane: they return in order with the value
-// loads and never sit between an LDS read and its use.  A lane's four running sums (one per round) live in registers during a tile and
-// in LDS between tiles.
-struct tl_group { double v[TL_U]; unsigned short c[TL_U]; unsigned int w[TL_U / 2]; tl_u4 d; };   // d: the row words of the tile the group opens (if it opens one)
+// idle one of two LDS buffers while the others gather from the current one: a tile switch is one barrier, no load on anybody's path
+// (the row sums need no barrier: a row belongs to one wavefront).  A gathering wavefront keeps TL_NG blocks' loads in flight, across
+// the tile switches -- the loads do not depend on the tile of x, only their use does.  Every load is issued on every path (past the
+// stream's end: the last block again), so that the number of loads in flight is the same wherever the code is: a conditional issue
+// makes the compiler wait for the younger blocks' loads too, and the pipeline is one block deep whatever the source says.
+struct tl_blk { tl_v2d v; tl_v2u c; };
 
-__device__ __forceinline__ unsigned int tl_stepword(const tl_group &g, int u) { return (g.w[u >> 1] >> ((u & 1) * 16)) & 0xffffu; }
-
-// group k of the trip whose words are in wv (lane j: word j of the trip)
-// (the row words of a tile travel with the group that opens it: a value loaded long before its use and carried through the loop in a
-//  register of its own makes the compiler wait for everything issued since, whenever that register is copied)
-__device__ __forceinline__ void tl_issue(tl_group &g, const unsigned int wv, const int k, int &off, const int lane,
-                                         const double *__restrict__ val, const unsigned short *__restrict__ lcol, const tl_u4 *&dq) {
-#pragma unroll
-  for (int i = 0; i < TL_U / 2; ++i) g.w[i] = (unsigned int)__builtin_amdgcn_readlane((int)wv, k * (TL_U / 2) + i);
-  if (g.w[0] & TL_STEP_NEWTILE) { g.d = __builtin_nontemporal_load(dq); dq += 64; }
-  else g.d = tl_u4{0u, 0u, 0u, 0u};
-#pragma unroll
-  for (int u = 0; u < TL_U; ++u) {
-    const int nact = (int)(tl_stepword(g, u) & 0x7fu);               // lanes 0 .. nact - 1 take part in this step (0: padding)
-    const int idx = off + (lane < nact ? lane : 0);                  // every load unconditional (idle lanes re-read the step's first entry; the arrays carry slack)
-    g.v[u] = __builtin_nontemporal_load(val + idx);
-    g.c[u] = __builtin_nontemporal_load(lcol + idx);
-    off += nact;
-  }
-}
-// One group: the LDS reads go out together, then step after step  s += a * x  for the lanes the step has (the others add -0.0, the one
-// addend that leaves every double -- both zeros included -- as it is: no branch, the compiler's wait counts stay exact).  At a round's
-// last step the lanes' rows are complete for this tile: the sum goes back to LDS and the next round's row, sum and count move up.
-struct tl_rows { unsigned int d[TL_RPL]; double q[TL_RPL]; };    // d[0] / q[0]: the current round's row word and running sum
-__device__ __forceinline__ void tl_consume(const tl_group &g, const double *xc, double *acc, const int lane, tl_rows &r) {
-  double xv[TL_U];
-#pragma unroll
-  for (int u = 0; u < TL_U; ++u) {
-#ifdef TL_EXP_NOGATHER
-    xv[u] = (double)g.c[u];
-#else
-    xv[u] = xc[g.c[u]];
-#endif
-  }
-#pragma unroll
-  for (int u = 0; u < TL_U; ++u) {
-    const unsigned int sw = tl_stepword(g, u);
-    const int nact = (int)(sw & 0x7fu);                              // wave-uniform
-    const double p = g.v[u] * xv[u];
-    r.q[0] = r.q[0] + (lane < nact ? p : -0.0);
-    if (sw & TL_STEP_ROUNDEND) {                                     // wave-uniform
-      if (r.d[0] & ((1u << TL_CNT_BITS) - 1)) acc[r.d[0] >> TL_CNT_BITS] = r.q[0];
-#pragma unroll
-      for (int a = 0; a + 1 < TL_RPL; ++a) { r.d[a] = r.d[a + 1]; r.q[a] = r.q[a + 1]; }
-      r.d[TL_RPL - 1] = 0u;
-    }
-  }
-}
-static_assert(TL_RPL == 4, "the row words of a (wavefront, tile) are one 16-byte load per lane");
+__device__ __forceinline__ void tl_lds_add(double *p, double v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }   // ds_add_f64
 
 #ifdef TL_PROFILE
-// development build: per panel {start, end (100 MHz wall clock), hardware id (XCC << 32 | HW_ID), then core cycles of wavefront 0: in tile-switch barriers,
-// in tl_consume, in tl_issue, whole gather loop; of the loader: loading tiles}
+// development build: per panel {start, end (100 MHz wall clock), hardware id (XCC << 32 | HW_ID), core cycles wavefront 0 spent in tile-switch barriers,
+// the loader: cycles from a tile's first load to its arrival, cycles at the barriers, wavefront 0: cycles of its whole gather loop}
 __device__ unsigned long long tl_prof_buf[8 * 8192];
 #endif
 
 template <int ADD>
 __global__ __launch_bounds__((TL_WAVES + 1) * 64) void spmv_tiled_kernel(
     int npanels, int chunkx, const int *__restrict__ prow, const int *__restrict__ pt_ptr, const int *__restrict__ pt_tile,
-    const int *__restrict__ pw_e0, const int *__restrict__ pw_s0, const unsigned short *__restrict__ steps, const unsigned int *__restrict__ desc,
-    const double *__restrict__ val, const unsigned short *__restrict__ lcol,
+    const int *__restrict__ pw_e0, const tl_v2d *__restrict__ val, const tl_v2u *__restrict__ word,
     const double *__restrict__ x, const double *yin, double *yout, int n) {
   extern __shared__ __attribute__((aligned(16))) double tl_lds[];
   double *xt = tl_lds;                                   // 2 x TL_TW doubles: two tiles of x
-  double *acc = tl_lds + 2 * TL_TW;                      // running sums of the panel's rows
+  double *acc = tl_lds + 2 * TL_TW;                      // the panel's row sums, and the padding's
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   constexpr int NT = (TL_WAVES + 1) * 64;
 
@@ -467,12 +415,12 @@ __global__ __launch_bounds__((TL_WAVES + 1) * 64) void spmv_tiled_kernel(
   const int xcd = blockIdx.x % MI355X_NXCD, slot = blockIdx.x / MI355X_NXCD;
   const int p = xcd * chunkx + slot;
   if (slot >= chunkx || p >= npanels) return;
-
 #ifdef TL_PROFILE
-  unsigned long long prof_t0 = __builtin_amdgcn_s_memrealtime(), prof_bar = 0, prof_con = 0, prof_iss = 0, prof_loop = 0, prof_ld = 0;
+  unsigned long long prof_t0 = __builtin_amdgcn_s_memrealtime(), prof_bar = 0, prof_ld = 0, prof_lbar = 0, prof_loop = 0;
 #endif
+
   const int row0 = prow[p], nrow = prow[p + 1] - row0;
-  for (int rl = tid; rl < nrow; rl += NT) acc[rl] = ADD ? yin[row0 + rl] : 0.0;
+  for (int rl = tid; rl < TL_SLOTS; rl += NT) acc[rl] = (ADD && rl < nrow) ? yin[row0 + rl] : 0.0;
 
   const int pt0 = pt_ptr[p], ntp = pt_ptr[p + 1] - pt0;
   // a tile into a buffer: whole double2's inside x, then the last column of an odd-sized last tile
@@ -493,12 +441,11 @@ __global__ __launch_bounds__((TL_WAVES + 1) * 64) void spmv_tiled_kernel(
   if (w == TL_WAVES) {
     __syncthreads();                                     // first tile in place, the sums' first stores done
     // ---- the loader: tile i + 1 into the other buffer while the others gather from tile i ----
-    constexpr int LB = 16;                               // 16-byte loads in flight: 1 KB each, two batches of 16 KB per 4096-column tile
+    // (straight into LDS -- global_load_lds_dwordx4: lane l's 16 bytes land at the instruction's LDS base + 16 l -- so the whole tile is
+    //  in flight at once without a register: one memory round trip per tile.  Through registers, 16 loads at a time, a 4096-column tile
+    //  took two round trips behind the gathering wavefronts' loads in the CU's queue, 4.5 us, and the gathering wavefronts spent 60% of
+    //  the kernel at the tile-switch barrier waiting for it: profiles/r04_tiled_prof_v7a.log)
     for (int i = 0; i + 1 < ntp; ++i) {
-#ifdef TL_EXP_NOLOAD
-      __syncthreads();
-      continue;
-#endif
 #ifdef TL_PROFILE
       const unsigned long long pq0 = __builtin_readcyclecounter();
 #endif
@@ -508,89 +455,71 @@ __global__ __launch_bounds__((TL_WAVES + 1) * 64) void spmv_tiled_kernel(
       const int ncol = (n - (long)base) < TL_TW ? (int)(n - (long)base) : TL_TW;
       const int n2 = ncol >> 1;
       const tl_v2d *xs = reinterpret_cast<const tl_v2d *>(x + base);
-      for (int i0 = 0; i0 < n2; i0 += LB * 64) {
-        tl_v2d r[LB];
 #pragma unroll
-        for (int k = 0; k < LB; ++k) { const int j = i0 + k * 64 + lane; r[k] = xs[j < n2 ? j : 0]; }
-#pragma unroll
-        for (int k = 0; k < LB; ++k) { const int j = i0 + k * 64 + lane; if (j < n2) reinterpret_cast<tl_v2d *>(buf)[j] = r[k]; }
+      for (int k = 0; k < TL_TW / 128; ++k) {
+        if (k * 64 < n2) {                               // (a short last tile: whole instructions past its end are skipped, lanes past it re-read its first pair into columns nobody gathers)
+          const int j = k * 64 + lane;
+          __builtin_amdgcn_global_load_lds(xs + (j < n2 ? j : 0), (__attribute__((address_space(3))) void *)(buf + k * 128), 16, 0, 0);
+        }
       }
+      __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): the tile is in LDS
       tile_tail(t, buf);
 #ifdef TL_PROFILE
-      __builtin_amdgcn_s_waitcnt(0);
-      prof_ld += __builtin_readcyclecounter() - pq0;
+      const unsigned long long pq1 = __builtin_readcyclecounter();
+      prof_ld += pq1 - pq0;
 #endif
-#ifndef TL_EXP_NOBARRIER
       __syncthreads();                                   // (the gathering wavefronts' switch to tile i + 1)
+#ifdef TL_PROFILE
+      prof_lbar += __builtin_readcyclecounter() - pq1;
 #endif
     }
   } else {
     // ---- a gathering wavefront ----
-    // (the stream is padded to whole trips of TL_NG groups and every load below is issued on every path -- past the stream's end into
-    //  padding words that say "no lanes" -- so that the loads in flight are the same number wherever the code is: a conditional issue
-    //  makes the compiler wait for the younger groups' loads too, and the pipeline is one group deep whatever the source says)
     const int ipw = p * TL_WAVES + w;
-    int off = pw_e0[ipw];
-    const int s0 = pw_s0[ipw];
-    const int ntrips = (pw_s0[ipw + 1] - s0) / (TL_NG * TL_U);
-    const unsigned int *sw32 = reinterpret_cast<const unsigned int *>(steps + s0);       // (s0 a multiple of TL_U: 8- or 16-byte aligned)
-    const int wl = lane < TL_TRIPW ? lane : TL_TRIPW - 1;
-    const tl_u4 *dq = reinterpret_cast<const tl_u4 *>(desc + ((size_t)pt0 * TL_WAVES + (size_t)w * ntp) * (64 * TL_RPL)) + lane;   // the next tile's row words: + 64 per tile
-    if (ntrips == 0) {                                   // no staged tile in this panel (true for all its wavefronts alike)
+    const int e0 = pw_e0[ipw];
+    const int nblocks = (pw_e0[ipw + 1] - e0) / TL_BLOCK;
+    const tl_v2d *vq = val + (e0 >> 1) + lane;           // + 64 per block
+    const tl_v2u *cq = word + (e0 >> 1) + lane;
+    if (nblocks == 0) {                                  // no staged tile in this panel (true for all its wavefronts alike)
       __syncthreads();
     } else {
-      tl_group grp[TL_NG];
-      unsigned int wv = sw32[wl], wvn = sw32[TL_TRIPW + wl];
-      if (ntrips < 2) wvn = 0u;                          // (what was read lies in the next stream or the array's slack)
+      tl_blk blk[TL_NG];
 #pragma unroll
-      for (int k = 0; k < TL_NG; ++k) tl_issue(grp[k], wv, k, off, lane, val, lcol, dq);
+      for (int k = 0; k < TL_NG; ++k) {
+        const size_t o = (size_t)(k < nblocks ? k : nblocks - 1) * 64;
+        blk[k].v = __builtin_nontemporal_load(vq + o); blk[k].c = __builtin_nontemporal_load(cq + o);
+      }
       __syncthreads();                                   // first tile in place, the sums' first stores done
-
       int it = -1;                                       // the tile being gathered from (index among the panel's staged tiles)
       const double *xc = xt;
-      tl_rows r;
-#pragma unroll
-      for (int a = 0; a < TL_RPL; ++a) { r.d[a] = 0u; r.q[a] = 0.0; }
-      auto tile_switch = [&](const tl_u4 d) {
-#ifdef TL_PROFILE
-        const unsigned long long pb0 = __builtin_readcyclecounter();
-#endif
-#ifndef TL_EXP_NOBARRIER
-        if (it >= 0) __syncthreads();                    // nobody reads tile `it` any more, every row's sum is back in LDS; the loader has completed the next tile
-#endif
-#ifdef TL_PROFILE
-        prof_bar += __builtin_readcyclecounter() - pb0;
-#endif
-        ++it;
-        xc = xt + (it & 1) * TL_TW;
-#pragma unroll
-        for (int a = 0; a < TL_RPL; ++a) {
-          r.d[a] = d[a];
-          r.q[a] = (d[a] & ((1u << TL_CNT_BITS) - 1)) ? acc[d[a] >> TL_CNT_BITS] : 0.0;
-        }
-      };
 #ifdef TL_PROFILE
       const unsigned long long pl0 = __builtin_readcyclecounter();
 #endif
-      for (int t = 0; t < ntrips; ++t) {
-        unsigned int wvnn = sw32[(t + 2) * TL_TRIPW + wl];   // the words of the trip after next
-        if (t + 2 >= ntrips) wvnn = 0u;
+      for (int b = 0; b < nblocks; b += TL_NG) {
 #pragma unroll
         for (int k = 0; k < TL_NG; ++k) {
-          if (grp[k].w[0] & TL_STEP_NEWTILE) tile_switch(grp[k].d);
+          if (b + k < nblocks) {
+            const unsigned int c0 = blk[k].c.x, c1 = blk[k].c.y;
+            if ((unsigned int)__builtin_amdgcn_readfirstlane((int)c0) & TL_WORD_NEWTILE) {
 #ifdef TL_PROFILE
-          const unsigned long long pc0 = __builtin_readcyclecounter();
+              const unsigned long long pb0 = __builtin_readcyclecounter();
 #endif
-          tl_consume(grp[k], xc, acc, lane, r);
+              if (it >= 0) __syncthreads();              // nobody reads tile `it` any more; the loader has completed the next one
 #ifdef TL_PROFILE
-          const unsigned long long pc1 = __builtin_readcyclecounter();
+              prof_bar += __builtin_readcyclecounter() - pb0;
 #endif
-          tl_issue(grp[k], wvn, k, off, lane, val, lcol, dq);   // (the last trip: words of zeros, loads nobody uses)
-#ifdef TL_PROFILE
-          prof_con += pc1 - pc0; prof_iss += __builtin_readcyclecounter() - pc1;
-#endif
+              ++it;
+              xc = xt + (it & 1) * TL_TW;
+            }
+            const double x0 = xc[c0 & (TL_WORD_NEWTILE - 1u)], x1 = xc[c1 & (TL_WORD_NEWTILE - 1u)];
+            const double p0 = blk[k].v.x * x0, p1 = blk[k].v.y * x1;
+            tl_lds_add(acc + (c0 >> 16), p0);            // entries 0 .. 63 of the block, ascending with the lane
+            tl_lds_add(acc + (c1 >> 16), p1);            // entries 64 .. 127
+          }
+          const int nb = b + k + TL_NG;
+          const size_t o = (size_t)(nb < nblocks ? nb : nblocks - 1) * 64;
+          blk[k].v = __builtin_nontemporal_load(vq + o); blk[k].c = __builtin_nontemporal_load(cq + o);
         }
-        wvn = wvnn;
       }
 #ifdef TL_PROFILE
       prof_loop = __builtin_readcyclecounter() - pl0;
@@ -604,9 +533,9 @@ __global__ __launch_bounds__((TL_WAVES + 1) * 64) void spmv_tiled_kernel(
     tl_prof_buf[8 * p + 0] = prof_t0;
     tl_prof_buf[8 * p + 1] = __builtin_amdgcn_s_memrealtime();
     tl_prof_buf[8 * p + 2] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) | (unsigned int)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
-    tl_prof_buf[8 * p + 3] = prof_bar; tl_prof_buf[8 * p + 4] = prof_con; tl_prof_buf[8 * p + 5] = prof_iss; tl_prof_buf[8 * p + 6] = prof_loop;
+    tl_prof_buf[8 * p + 3] = prof_bar; tl_prof_buf[8 * p + 6] = prof_loop;
   }
-  if (tid == TL_WAVES * 64 && p < 8192) tl_prof_buf[8 * p + 7] = prof_ld;
+  if (tid == TL_WAVES * 64 && p < 8192) { tl_prof_buf[8 * p + 4] = prof_ld; tl_prof_buf[8 * p + 5] = prof_lbar; }
 #endif
 }
 
@@ -617,20 +546,18 @@ int mi355x_spmv_tiled_upload(mi355x_handle_t h, mi355x_spmv_tiled_t P, const dou
   tl_host *H = P->host;
   if (!H) return (int)hipErrorInvalidValue;
   auto up = [&](void **d, const void *src, size_t nbytes) -> int {
-    MI355X_TRY(hipMalloc(d, (nbytes ? nbytes : 1) + 1024));          // slack: the kernel's unconditional loads run past a stream's end (idle lanes, step words two trips ahead)
+    MI355X_TRY(hipMalloc(d, (nbytes ? nbytes : 1) + 1024));
     if (nbytes) MI355X_TRY(hipMemcpyAsync(*d, src, nbytes, hipMemcpyHostToDevice, h->stream));
     return 0;
   };
   int rc;
   if ((rc = up((void **)&P->d_pt_ptr, H->pt_ptr.data(), H->pt_ptr.size() * 4)) || (rc = up((void **)&P->d_pt_tile, H->pt_tile.data(), H->pt_tile.size() * 4)) ||
-      (rc = up((void **)&P->d_prow, H->prow.data(), H->prow.size() * 4)) ||
-      (rc = up((void **)&P->d_pw_e0, H->pw_e0.data(), H->pw_e0.size() * 4)) || (rc = up((void **)&P->d_desc, H->desc.data(), H->desc.size() * 4)) ||
-      (rc = up((void **)&P->d_pw_s0, H->pw_s0.data(), H->pw_s0.size() * 4)) || (rc = up((void **)&P->d_steps, H->steps.data(), H->steps.size() * 2)) ||
-      (rc = up((void **)&P->d_perm, H->perm.data(), H->perm.size() * 4)) || (rc = up((void **)&P->d_lcol, H->lcol.data(), H->lcol.size() * 2)) ||
+      (rc = up((void **)&P->d_prow, H->prow.data(), H->prow.size() * 4)) || (rc = up((void **)&P->d_pw_e0, H->pw_e0.data(), H->pw_e0.size() * 4)) ||
+      (rc = up((void **)&P->d_perm, H->perm.data(), H->perm.size() * 4)) || (rc = up((void **)&P->d_word, H->word.data(), H->word.size() * 4)) ||
       (rc = up((void **)&P->d_far_i, H->far_i.data(), H->far_i.size() * 4)) || (rc = up((void **)&P->d_far_j, H->far_j.data(), H->far_j.size() * 4)) ||
       (rc = up((void **)&P->d_far_perm, H->far_perm.data(), H->far_perm.size() * 4)))
     return rc;
-  MI355X_TRY(hipMalloc((void **)&P->d_val, sizeof(double) * (size_t)(P->nnz_near > 0 ? P->nnz_near : 1) + 64));
+  MI355X_TRY(hipMalloc((void **)&P->d_val, sizeof(double) * (size_t)(P->nstore > 0 ? P->nstore : 1) + 1024));
   P->nfar_store = (long)H->far_perm.size();
   MI355X_TRY(hipMalloc((void **)&P->d_far_a, sizeof(double) * (size_t)(P->nfar_store > 0 ? P->nfar_store : 1) + 64));
   if (P->nnz_far > 0)
@@ -646,8 +573,8 @@ int mi355x_spmv_tiled_upload(mi355x_handle_t h, mi355x_spmv_tiled_t P, const dou
 
 // the CSR values on the device changed (same pattern): one gather per part
 int mi355x_spmv_tiled_refresh_values(mi355x_handle_t h, mi355x_spmv_tiled_t P, const double *aa_dev) {
-  if (P->nnz_near > 0) {
-    hipLaunchKernelGGL(tl_gather_values_kernel, dim3(mi355x_grid_for((size_t)P->nnz_near, 4)), dim3(256), 0, h->stream, P->d_perm, aa_dev, P->d_val, P->nnz_near);
+  if (P->nstore > 0) {
+    hipLaunchKernelGGL(tl_gather_values_kernel, dim3(mi355x_grid_for((size_t)P->nstore, 4)), dim3(256), 0, h->stream, P->d_perm, aa_dev, P->d_val, P->nstore);
     MI355X_LAUNCH_CHECK();
   }
   if (P->nnz_far > 0) {
@@ -658,7 +585,9 @@ int mi355x_spmv_tiled_refresh_values(mi355x_handle_t h, mi355x_spmv_tiled_t P, c
 }
 
 // y = A x (yin == NULL) or yout = yin + A x (yout may alias yin).  x must be 16-byte aligned (hipErrorNotSupported otherwise: the caller
-// takes the row-block kernel).  which: 0 both parts, 1 the staged part only, 2 the remainder only (development: their separate cost)
+// takes the row-block kernel).  which: 0 both parts, 1 the staged part only, 2 the remainder only (development: their separate cost).
+// (The remainder on a stream of its own beside the staged kernel was tried -- the one bound by the fabric between L2 and the CUs, the
+//  other by HBM and LDS -- and gained nothing: profiles/r04_tiled_sweep7.log.)
 int mi355x_spmv_tiled_parts(mi355x_handle_t h, mi355x_spmv_tiled_t P, const double *x, const double *yin, double *yout, int which) {
   if (!mi355x_aligned16(x)) return (int)hipErrorNotSupported;
   if (P->m == 0) return 0;
@@ -668,7 +597,7 @@ int mi355x_spmv_tiled_parts(mi355x_handle_t h, mi355x_spmv_tiled_t P, const doub
     if (getenv("MI355X_TILED_DEBUG")) {
       int nb = 0;
       (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, spmv_tiled_kernel<0>, (TL_WAVES + 1) * 64, lds);
-      fprintf(stderr, "[mi355x tiled] tile %d columns, %d + 1 wavefronts per workgroup, %d groups of %d steps in flight, %zu B of LDS: %d workgroups per CU (layout cut for %d)\n", TL_TW, TL_WAVES, TL_NG, TL_U, lds, nb, TL_WG_PER_CU);
+      fprintf(stderr, "[mi355x tiled] tile %d columns, panel <= %d rows, %d + 1 wavefronts per workgroup, %d blocks of %d entries in flight, %zu B of LDS: %d workgroups per CU\n", TL_TW, TL_PANEL, TL_WAVES, TL_NG, TL_BLOCK, lds, nb);
     }
     MI355X_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(spmv_tiled_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     MI355X_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(spmv_tiled_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -678,7 +607,7 @@ int mi355x_spmv_tiled_parts(mi355x_handle_t h, mi355x_spmv_tiled_t P, const doub
   const int grid = chunkx * MI355X_NXCD;
   if (which != 2) {
 #define TL_GO(A_, YIN) hipLaunchKernelGGL((spmv_tiled_kernel<A_>), dim3(grid), dim3((TL_WAVES + 1) * 64), lds, h->stream, P->npanels, chunkx, P->d_prow, P->d_pt_ptr, \
-                                          P->d_pt_tile, P->d_pw_e0, P->d_pw_s0, P->d_steps, P->d_desc, P->d_val, P->d_lcol, x, YIN, yout, P->n)
+                                          P->d_pt_tile, P->d_pw_e0, reinterpret_cast<const tl_v2d *>(P->d_val), reinterpret_cast<const tl_v2u *>(P->d_word), x, YIN, yout, P->n)
     if (yin) TL_GO(1, yin); else TL_GO(0, (const double *)nullptr);
 #undef TL_GO
     MI355X_LAUNCH_CHECK();
@@ -706,7 +635,7 @@ int mi355x_spmv_tiled(mi355x_handle_t h, mi355x_spmv_tiled_t P, const double *x,
 int mi355x_spmv_tiled_destroy(mi355x_spmv_tiled_t P) {
   if (!P) return 0;
   delete P->host;
-  void *ptrs[] = {P->d_prow, P->d_pt_ptr, P->d_pt_tile, P->d_pw_e0, P->d_pw_s0, P->d_steps, P->d_desc, P->d_perm, P->d_lcol, P->d_val, P->d_far_i, P->d_far_j, P->d_far_perm, P->d_far_a};
+  void *ptrs[] = {P->d_prow, P->d_pt_ptr, P->d_pt_tile, P->d_pw_e0, P->d_perm, P->d_word, P->d_val, P->d_far_i, P->d_far_j, P->d_far_perm, P->d_far_a};
   for (void *q : ptrs) if (q) hipFree(q);
   for (int q = 0; q < TL_MAX_PASS; ++q) if (P->far_plan[q]) mi355x_spmv_plan_destroy(P->far_plan[q]);
   delete P;

@@ -73,7 +73,7 @@ def test_tiled_layout_holds_every_nonzero_once_and_in_column_order(k, passes, mo
         monkeypatch.setenv("MI355X_TILED_FAR_PASSES", passes)
     rng = np.random.default_rng(5)
     g = tiled.geometry(k)
-    assert g["tw"] in (2048, 4096, 8192) and g["rounds"] == 4 and g["panel"] == g["waves"] * 64 * g["rounds"]
+    assert g["tw"] % 128 == 0 and g["block"] == 128 and g["panel"] < 65536
     m = g["panel"] + 700                               # a full panel and a ragged one
     n = 3 * g["tw"] + 1234                             # ragged last tile
     lens = np.clip(np.exp(rng.normal(3.0, 0.7, m)), 0, 200).astype(int)
@@ -88,12 +88,12 @@ def test_tiled_layout_holds_every_nonzero_once_and_in_column_order(k, passes, mo
 def test_tiled_layout_rows_longer_than_a_chunk_and_degenerate_shapes(k):
     rng = np.random.default_rng(6)
     g = tiled.geometry(k)
-    # rows with many entries in one tile beside short ones: long jagged diagonals with one active lane
+    # rows with many entries in one tile beside short ones: a wavefront's range of the panel may be one row, or none
     m, n = 300, g["tw"] + 500
     lens = np.full(m, 5); lens[7] = 1800; lens[8] = 700; lens[130] = 513; lens[299] = 3000
     ai, aj, aa = random_csr(rng, m, n, lens, band=n, far_frac=0.0)
     inf = check(k, ai, aj, aa, n, stage_min=1, expect_all_staged=True)
-    assert inf["steps"] >= 1000
+    assert inf["blocks"] * 128 >= inf["staged"] > 3000
     # one row, one column; no rows at all; a matrix without entries
     check(k, np.array([0, 1], np.int32), np.array([0], np.int32), np.array([2.5]), 1, stage_min=1, expect_all_staged=True)
     check(k, np.array([0], np.int32), np.zeros(0, np.int32), np.zeros(0), 10, stage_min=1)

@@ -7,9 +7,9 @@ import numpy as np
 
 
 def geometry(k):
-    g = [C.c_int() for _ in range(6)]
+    g = [C.c_int() for _ in range(4)]
     k.mi355x_spmv_tiled_geometry(*[C.byref(v) for v in g])
-    return dict(zip(("panel", "tw", "waves", "rounds", "group", "trip"), [v.value for v in g]))
+    return dict(zip(("panel", "tw", "waves", "block"), [v.value for v in g]))
 
 
 def build(k, ai, aj, n, stage_min):
@@ -34,79 +34,67 @@ def info(k, plan):
     a, b, s = C.c_long(), C.c_long(), C.c_long()
     p, q = C.c_int(), C.c_int()
     k.mi355x_spmv_tiled_info(plan, C.byref(a), C.byref(b), C.byref(p), C.byref(q), C.byref(s))
-    return {"staged": a.value, "remainder": b.value, "panels": p.value, "pairs": q.value, "steps": s.value}
+    return {"staged": a.value, "remainder": b.value, "panels": p.value, "pairs": q.value, "blocks": s.value}
 
 
-NEWTILE, ROUNDEND = 0x8000, 0x4000
+NEWTILE = 0x8000
 
 
 def walk(k, plan, m):
     """Every staged entry as (row, column, position in the CSR value array), panel after panel, inside a panel tile after tile, inside
-    a tile in storage order -- for one row that is the order its lane adds the products in -- plus the remainder's CSR (far_i, far_j,
-    far_perm).  A wavefront's stream runs through all staged tiles of its panel: its step words and entries are contiguous, a tile's
-    steps padded to whole groups (at least one), the first word of a tile's first group flagged.  Checks the jagged-diagonal
-    invariants on the way: per (panel, tile) the rows are sorted by count over ALL rounds (round g = a * waves + w is wavefront w's
-    round a), so a step's active lanes are 0 .. n - 1, and every row of the panel appears at most once per tile."""
+    a tile wavefront after wavefront, inside a wavefront's blocks in the order the kernel adds them (entry q of a block is stored at
+    2 (q mod 64) + q div 64: the first ds_add_f64 of a block takes entries 0..63 in lane order, the second 64..127) -- for one row
+    that is the order its products are added in -- plus the remainder's CSR (far_i, far_j, far_perm).  Checks on the way: a wavefront's
+    stream holds one flagged run of blocks per staged tile of its panel, its rows stay inside its range of the panel, a (wavefront,
+    tile)'s entries are in CSR order and only its last block is padded (value position -1, the spare accumulator's row)."""
     g = geometry(k)
-    W, R, U = g["waves"], g["rounds"], g["group"]
+    W, B = g["waves"], g["block"]
     pt_ptr, pt_tile, pw_e0 = get(k, plan, 0, np.int32), get(k, plan, 1, np.int32), get(k, plan, 2, np.int32)
-    desc = get(k, plan, 3, np.uint32).reshape(-1, 64, R)
-    perm, lcol = get(k, plan, 4, np.int32), get(k, plan, 5, np.uint16)
-    stepw, pw_s0, prow = get(k, plan, 6, np.uint16), get(k, plan, 10, np.int32), get(k, plan, 11, np.int32)
+    word, perm = get(k, plan, 3, np.uint32), get(k, plan, 4, np.int32)
+    wrow, prow = get(k, plan, 10, np.int32).reshape(-1, W + 1), get(k, plan, 11, np.int32)
     far = get(k, plan, 7, np.int32), get(k, plan, 8, np.int32), get(k, plan, 9, np.int32)
     assert prow[0] == 0 and prow[-1] == m and prow.size == pt_ptr.size and np.all(np.diff(prow) > 0) and np.all(np.diff(prow) <= g["panel"])
-    assert pw_e0.size == (prow.size - 1) * W + 1 and pw_s0.size == pw_e0.size
+    assert pw_e0.size == (prow.size - 1) * W + 1 and wrow.shape[0] == prow.size - 1 and word.size == perm.size == pw_e0[-1]
+    assert np.all(pw_e0 % B == 0)
+    slot = np.array([2 * (q % 64) + q // 64 for q in range(B)])
     rows, cols, pos = [], [], []
-    steps = 0
+    nblocks = 0
     for p in range(pt_ptr.size - 1):
         ntp = int(pt_ptr[p + 1] - pt_ptr[p])
-        nrow = int(prow[p + 1] - prow[p])
-        off = [int(pw_e0[p * W + w]) for w in range(W)]           # each wavefront's cursor in its own stream
-        sw = [int(pw_s0[p * W + w]) for w in range(W)]
-        assert all(v % g["trip"] == 0 for v in sw), "a wavefront's step words start on a trip boundary"
+        assert wrow[p, 0] == prow[p] and wrow[p, W] == prow[p + 1] and np.all(np.diff(wrow[p]) >= 0)
+        runs = []                                                   # per wavefront: its blocks' starts, one run per tile
+        for w in range(W):
+            starts = np.arange(pw_e0[p * W + w], pw_e0[p * W + w + 1], B)
+            flagged = [int(b) for b in starts if word[b] & NEWTILE]
+            assert len(flagged) == ntp and (ntp == 0 or flagged[0] == starts[0]), "one flagged block per staged tile, the stream opens with one"
+            ends = flagged[1:] + [int(pw_e0[p * W + w + 1])]
+            runs.append([np.arange(f, e, B) for f, e in zip(flagged, ends)])
+            nblocks += starts.size
         last_tile = -1
         for i in range(ntp):
             t = int(pt_tile[pt_ptr[p] + i])
             assert t > last_tile, "a panel's staged tiles ascend"
             last_tile = t
-            seen_rows = set()
-            ranked = np.zeros(W * R * 64, dtype=np.int64)
             for w in range(W):
-                d = desc[pt_ptr[p] * W + w * ntp + i]
-                first = True
-                for a in range(R):
-                    cnt = (d[:, a] & 0xffff).astype(np.int64)
-                    rl = (d[:, a] >> 16).astype(np.int64)
-                    ranked[(a * W + w) * 64:(a * W + w) * 64 + 64] = cnt
-                    assert a == 0 or cnt[0] == 0 or (d[0, a - 1] & 0xffff) > 0, "a wavefront's empty rounds come last"
-                    for l in range(64):
-                        if cnt[l]:
-                            assert int(rl[l]) not in seen_rows and rl[l] < nrow
-                            seen_rows.add(int(rl[l]))
-                    for j in range(int(cnt[0])):
-                        nact = int(np.sum(cnt > j))
-                        assert stepw[sw[w]] == (nact | (ROUNDEND if j + 1 == int(cnt[0]) else 0) | (NEWTILE if first else 0)), \
-                            "the step word the kernel reads: active lanes, last step of the round, tile switch"
-                        first = False
-                        sw[w] += 1
-                        steps += 1
-                        for l in range(nact):
-                            rows.append(int(prow[p]) + int(rl[l]))
-                            cols.append(t * g["tw"] + int(lcol[off[w] + l]))
-                            pos.append(int(perm[off[w] + l]))
-                        off[w] += nact
-                if first:                                         # nothing of this tile for this wavefront: one group of padding, flagged
-                    assert stepw[sw[w]] == NEWTILE
-                    sw[w] += 1
-                npad = (-sw[w]) % U
-                assert np.all(stepw[sw[w]:sw[w] + npad] == 0), "padding words to the next group boundary"
-                sw[w] += npad
-            assert np.all(ranked[:-1] >= ranked[1:]), "the panel's rows sorted by count across the rounds"
-        for w in range(W):
-            end = int(pw_s0[p * W + w + 1])
-            assert off[w] == pw_e0[p * W + w + 1] and end % g["trip"] == 0 and 0 <= end - sw[w] < g["trip"] and np.all(stepw[sw[w]:end] == 0), \
-                "a wavefront's stream ends on a whole trip of the kernel's loop, padded with empty steps"
-    assert steps == info(k, plan)["steps"]
+                prev = (-1, -1)
+                done = False
+                for b0 in runs[w][i]:
+                    for q in range(B):
+                        s = int(b0 + slot[q])
+                        wd = int(word[s])
+                        if q:
+                            assert not wd & NEWTILE, "only a block's first stored word carries the flag"
+                        if perm[s] < 0:
+                            assert (wd >> 16) == g["panel"] and (wd & 0x7fff) == 0, "padding goes to the spare accumulator"
+                            done = True
+                            continue
+                        assert not done and b0 == runs[w][i][-1] or not done, "padding only at the end of a (wavefront, tile)'s last block"
+                        r, c = int(prow[p]) + (wd >> 16), t * g["tw"] + (wd & 0x7fff)
+                        assert wrow[p, w] <= r < wrow[p, w + 1] and (wd & 0x7fff) < g["tw"]
+                        assert (r, c) > prev, "CSR order inside a (wavefront, tile)"
+                        prev = (r, c)
+                        rows.append(r); cols.append(c); pos.append(int(perm[s]))
+    assert nblocks == info(k, plan)["blocks"]
     return (np.array(rows, dtype=np.int64), np.array(cols, dtype=np.int64), np.array(pos, dtype=np.int64)), far
 
 

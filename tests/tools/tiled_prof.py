@@ -29,9 +29,9 @@ def main():
     print("sum of durations / span = %.1f workgroups active on average (512 slots)" % (dur.sum() / t1.max()))
     bar = a[:, 3].astype(np.float64) / 2400.0                              # us at 2.4 GHz
     print("wavefront 0 in tile-switch barriers: median %.1f us of %.1f (%.0f%%)" % (np.median(bar), np.median(dur), 100 * np.median(bar / dur)))
-    for name, col in (("tl_consume", 4), ("tl_issue", 5), ("gather loop", 6), ("loader: loading tiles", 7)):
+    for name, col in (("loader: a tile's loads, first issue to arrival (sum over the tiles)", 4), ("loader: at the barriers", 5), ("wavefront 0: its gather loop", 6)):
         v = a[:, col].astype(np.float64) / 2400.0
-        print("  %-24s median %.1f us (%.0f%% of the workgroup's time)" % (name, np.median(v), 100 * np.median(v / dur)))
+        print("  %-72s median %.1f us (%.0f%% of the workgroup's time)" % (name, np.median(v), 100 * np.median(v / dur)))
     first = t0 < 10.0
     print("workgroups started in the first 10 us: %d, duration median %.1f; the others: %d, median %.1f" % (first.sum(), np.median(dur[first]), (~first).sum(), np.median(dur[~first])))
     edges = np.linspace(0, t1.max(), 21)

@@ -5,5 +5,6 @@ export CFG4_CACHE=/tmp MI355X_TILED_DEBUG=1
 V=$R/petsc-dev_amd/csrc/variants
 run() { echo "== $1"; shift; timeout -k 10 300 env "$@" python3 $R/tests/tools/tiled_probe.py irr 1024 2>&1 | grep -v "^irr\|lines of x\|^row-block"; }
 run "default build" A=1
-run "panels of 2048 rows (764: the last round of workgroup slots half empty)" MI355X_TILED_PANELS=764
-for v in ${VARIANTS:-u8g2 tw2048}; do run "variant $v" MI355X_KERNELS_LIB=$V/libmi355x_kernels_$v.so; done
+run "the remainder after the staged part, not beside it" MI355X_TILED_OVERLAP=0
+for q in ${PASSES:-2 3 8}; do run "remainder in $q passes" MI355X_TILED_FAR_PASSES=$q; done
+for v in ${VARIANTS:-w4 w6}; do run "variant $v" MI355X_KERNELS_LIB=$V/libmi355x_kernels_$v.so; done
