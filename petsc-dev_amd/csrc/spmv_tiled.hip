@@ -25,6 +25,9 @@
 //     sum: no sorting, no descriptors, no per-row bookkeeping -- 10 instructions per entry and lane where the jagged-diagonal forms of
 //     this file's history took 50 and were bound by the wavefronts' own instruction streams (profiles/r04_tiled_*: 0.30 ms whatever
 //     the pipelining), while the memory system gives this access pattern 6.8 TB/s (profiles/r04_dense_atomic_probe.log).
+//     At 12 bytes the staged part moves 1.2 GB in 0.19 ms: HBM's rate.  10-byte entries (a 16-bit word: column, 3-bit row step, rows
+//     rebuilt by two 64-lane prefix sums per block) were built, pass the same tests and are slower, 0.207 ms: the prefix sums'
+//     instructions cost more than the bytes save (profiles/r04_tiled_10byte_entries.log).
 // Arithmetic: a*x rounded, then added (-ffp-contract=off).  Entry q of a block is stored at position 2 (q mod 64) + q div 64: lane l's
 // pair is entries l and 64 + l, so the block's first ds_add_f64 instruction adds entries 0..63 and the second 64..127, and lanes of one
 // instruction that meet on one accumulator are added in ascending lane order (measured: dense_atomic_probe; asserted by the GPU tests'
@@ -442,9 +445,10 @@ __global__ __launch_bounds__((TL_WAVES + 1) * 64) void spmv_tiled_kernel(
     __syncthreads();                                     // first tile in place, the sums' first stores done
     // ---- the loader: tile i + 1 into the other buffer while the others gather from tile i ----
     // (straight into LDS -- global_load_lds_dwordx4: lane l's 16 bytes land at the instruction's LDS base + 16 l -- so the whole tile is
-    //  in flight at once without a register: one memory round trip per tile.  Through registers, 16 loads at a time, a 4096-column tile
-    //  took two round trips behind the gathering wavefronts' loads in the CU's queue, 4.5 us, and the gathering wavefronts spent 60% of
-    //  the kernel at the tile-switch barrier waiting for it: profiles/r04_tiled_prof_v7a.log)
+    //  in flight at once without a register: one memory round trip per tile, and the kernel needs 40 VGPRs instead of 78.  Through
+    //  registers, 16 loads at a time, a 4096-column tile took two round trips behind the gathering wavefronts' loads in the CU's queue
+    //  and the gathering wavefronts waited at the tile switch for most of the kernel; timeline of the present form, from the
+    //  TL_PROFILE build: profiles/r04_tiled_prof_v7.log)
     for (int i = 0; i + 1 < ntp; ++i) {
 #ifdef TL_PROFILE
       const unsigned long long pq0 = __builtin_readcyclecounter();
@@ -586,8 +590,9 @@ int mi355x_spmv_tiled_refresh_values(mi355x_handle_t h, mi355x_spmv_tiled_t P, c
 
 // y = A x (yin == NULL) or yout = yin + A x (yout may alias yin).  x must be 16-byte aligned (hipErrorNotSupported otherwise: the caller
 // takes the row-block kernel).  which: 0 both parts, 1 the staged part only, 2 the remainder only (development: their separate cost).
-// (The remainder on a stream of its own beside the staged kernel was tried -- the one bound by the fabric between L2 and the CUs, the
-//  other by HBM and LDS -- and gained nothing: profiles/r04_tiled_sweep7.log.)
+// (The remainder on a stream of its own beside the staged kernel -- the one bound by L2 requests, one per gather, the other by HBM --
+//  gains 6-10 % with two wholly independent streams and nothing once the fork, the join and the final addition are paid:
+//  profiles/r04_tiled_overlap_probe.log, r04_tiled_sweep7.log.)
 int mi355x_spmv_tiled_parts(mi355x_handle_t h, mi355x_spmv_tiled_t P, const double *x, const double *yin, double *yout, int which) {
   if (!mi355x_aligned16(x)) return (int)hipErrorNotSupported;
   if (P->m == 0) return 0;
