@@ -117,3 +117,49 @@ def test_tiled_probe_tells_scattered_gathers_from_shared_ones(k):
     ai, aj, aa = P.gen_poisson7(32, 32, 32)
     k.mi355x_spmv_tiled_probe(ai.size - 1, ai.ctypes.data, aj.ctypes.data, C.byref(v))
     assert v.value < 0.2
+
+
+def test_tiled_panels_hold_equal_shares_of_the_nonzeros(k, monkeypatch):
+    """mi355x_spmv_tiled_build's row panels: never more rows than the geometry allows, the smallest bound on a panel's nonzeros that fits
+    the panel count (greedy cuts, bisection), a multiple of 256 panels when the rows do not fit 256, the count forced by
+    MI355X_TILED_PANELS for experiments; the wavefronts' row ranges inside a panel are equal shares too."""
+    rng = np.random.default_rng(21)
+    g = tiled.geometry(k)
+    m = 3 * g["panel"] + 1000
+    lens = rng.integers(3, 9, m)
+    lens[: m // 5] = 1                                   # a sparse head: its panels hit the row cap, the others make up for it
+    ai = np.concatenate(([0], np.cumsum(lens))).astype(np.int32)
+    n = 4 * g["tw"]
+    off = np.arange(ai[-1]) - np.repeat(ai[:-1], lens)
+    aj = ((np.repeat(np.arange(m), lens) // 7 + off * 5) % n).astype(np.int32)
+    aj = np.concatenate([np.sort(aj[ai[r]:ai[r + 1]]) for r in range(m)]).astype(np.int32)
+    for r in range(m):                                   # distinct columns inside a row (offsets of 5 are distinct below n)
+        assert np.all(np.diff(aj[ai[r]:ai[r + 1]]) > 0)
+    for forced in (None, 9, 40):
+        if forced:
+            monkeypatch.setenv("MI355X_TILED_PANELS", str(forced))
+        plan = tiled.build(k, ai, aj, n, 10 ** 9)
+        try:
+            prow = tiled.get(k, plan, 11, np.int32)
+            wrow = tiled.get(k, plan, 10, np.int32).reshape(-1, g["waves"] + 1)
+            np_ = prow.size - 1
+            assert prow[0] == 0 and prow[-1] == m and np.all(np.diff(prow) >= 1) and np.all(np.diff(prow) <= g["panel"])
+            if forced:
+                assert np_ == forced
+            else:
+                assert np_ == 4                            # ceil(m / panel): fewer than 256, nothing to round
+            nz = np.diff(ai[prow]).astype(np.int64)
+            capped = np.diff(prow) == g["panel"]
+            # no panel holds more than the bound; a smaller bound would need more panels: check by re-cutting greedily with max(nz) - 1
+            bound = nz.max() - 1
+            cnt, r = 0, 0
+            while r < m:
+                e = int(np.searchsorted(ai, ai[r] + bound, side="right")) - 1
+                e = min(max(e, r + 1), r + g["panel"], m)
+                r = e; cnt += 1
+            assert cnt > np_ or np.all(capped | (nz <= bound)), "the bound is the smallest that fits"
+            assert np.all(wrow[:, 0] == prow[:-1]) and np.all(wrow[:, -1] == prow[1:]) and np.all(np.diff(wrow, axis=1) >= 0)
+            wnz = np.diff(ai[wrow], axis=1)
+            assert np.all(wnz.max(axis=1) <= nz / g["waves"] + lens.max() + 1), "a wavefront's share exceeds the mean by less than one row"
+        finally:
+            k.mi355x_spmv_tiled_destroy(plan)

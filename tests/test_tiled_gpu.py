@@ -117,6 +117,39 @@ def test_tiled_spmv_long_rows_and_degenerate_shapes(dev):
     run_case(dev, ai, aj, aa, n, stage_min=32)
 
 
+def test_tiled_spmv_many_lanes_on_one_row_sum_and_non_finite_x_outside_the_pattern(dev):
+    """(1) A row with hundreds of entries in one tile: every ds_add_f64 instruction of its blocks has all 64 lanes on ONE accumulator;
+    values of mixed magnitude, so that any order but ascending lanes would round differently (run_case compares bit for bit with the
+    layout's order and, everything being staged, with the oracle).  (2) Padding multiplies 0 by x at the tile's first column: an Inf
+    there that no row references must not reach any y (the padding's products go to the spare accumulator)."""
+    rng = np.random.default_rng(18)
+    g = tiled.geometry(dev.k)
+    m, n = 500, 2 * g["tw"]
+    lens = np.full(m, 4); lens[3] = 900; lens[250] = 700; lens[499] = 1300
+    ai, aj, aa = random_csr(rng, m, n, lens, band=n, far_frac=0.0)
+    aa = aa * 10.0 ** rng.integers(-8, 9, aa.size)
+    run_case(dev, ai, aj, aa, n, stage_min=1)
+    # (2)
+    k = dev.k
+    keep = (aj != 0) & (aj != g["tw"])                              # nobody references the first column of either tile
+    rowof = np.repeat(np.arange(m), np.diff(ai))
+    ai2 = np.concatenate(([0], np.cumsum(np.bincount(rowof[keep], minlength=m)))).astype(np.int32)
+    aj2, aa2 = aj[keep].astype(np.int32), aa[keep]
+    x = np.cos(0.11 * np.arange(n)) + 2.0
+    x[0] = np.inf; x[g["tw"]] = -np.inf
+    plan = tiled.build(k, ai2, aj2, n, 1)
+    try:
+        daa = dev.put(np.concatenate((aa2, [0.0, 0.0])))
+        dx, dy = dev.put(x), dev.alloc(8 * m)
+        dev.chk(k.mi355x_spmv_tiled_upload(dev.h, plan, daa))
+        dev.chk(k.mi355x_spmv_tiled(dev.h, plan, dx, None, dy))
+        y = dev.get(dy, m)
+        xs = x.copy(); xs[0] = 0.0; xs[g["tw"]] = 0.0
+        assert np.all(np.isfinite(y)) and np.array_equal(bits(y), bits(orc.spmv(ai2, aj2, aa2, xs)))
+    finally:
+        k.mi355x_spmv_tiled_destroy(plan)
+
+
 def test_mat_type_chooses_the_tiled_product_and_keeps_it_current(built):
     """Through MatMult: -mat_hipmi355x_tiled 1 forces the column-tiled product on a small matrix, the default (decide) leaves small
     matrices and stencils alone; MatScale / MatDiagonalScale on the device copy reach the tiled values; MatMultAdd uses it too."""
