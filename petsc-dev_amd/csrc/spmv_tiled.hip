@@ -12,14 +12,16 @@
 //     (2048) entries of x = 16 KB of LDS, two of them resident (a loader wavefront brings the next tile while the current one is
 //     gathered from); the panel's row sums are 6144 doubles of LDS for the whole kernel;
 //   * a (panel, tile) pair with at least `stage_min` entries is STAGED: all of the panel's entries in that tile gather x from LDS.  The
-//     panel walks its staged tiles in ascending order.  Entries of pairs too thin to stage (the long-range fifth) stay in a CSR
-//     remainder that the row-block kernel adds afterwards (mi355x_spmv_csr_add) -- the split of MatMult_MPIAIJ's diagonal /
-//     off-diagonal blocks, inside one GPU;
-//   * the panel's rows are dealt to the workgroup's TL_WAVES gathering wavefronts in contiguous ranges of equal nonzeros: a row's sum
+//     panel walks its staged tiles in ascending order.  Entries of pairs too thin to stage (the long-range fifth: the REMAINDER) follow
+//     in the same streams, grouped by WINDOWS of 2^18 columns (2 MiB of x) in ascending order: their x comes from global memory, one
+//     L2 request per entry, and all workgroups reach the same window at about the same time, so those requests hit the XCD's L2 --
+//     the split of MatMult_MPIAIJ's diagonal / off-diagonal blocks, inside one GPU and inside one kernel;
+//   * the panel's rows are dealt to the workgroup's TL_WAVES (4) gathering wavefronts in contiguous ranges of equal nonzeros: a row's sum
 //     is only ever touched by its wavefront.  A wavefront's entries of one staged tile, in CSR order (rows ascending, columns
 //     ascending), are cut into BLOCKS of 128 padded with zeros that go to a spare accumulator; its blocks of all the panel's tiles
-//     follow each other without a gap.  An entry is 12 bytes: the value and one 32-bit word (row of the panel << 16 | column in the
-//     tile; bit 15 of a block's first word: the block opens the next tile);
+//     follow each other without a gap, then its blocks of the remainder, window after window.  An entry is 12 bytes: the value and
+//     one 32-bit word (staged: row of the panel << 16 | column in the tile, bit 15 of a block's first word: the block opens the next
+//     tile; remainder: row << 18 | column in the window, bit 31: the block opens the wavefront's next window);
 //   * the kernel keeps TL_NG blocks' loads in flight per wavefront, across tile switches.  A block is TWO full-width loads (16 bytes of
 //     values, 8 bytes of words per lane: two entries) and per entry one LDS read of x, one multiply and one ds_add_f64 into the row's
 //     sum: no sorting, no descriptors, no per-row bookkeeping -- 10 instructions per entry and lane where the jagged-diagonal forms of
@@ -32,8 +34,9 @@
 // pair is entries l and 64 + l, so the block's first ds_add_f64 instruction adds entries 0..63 and the second 64..127, and lanes of one
 // instruction that meet on one accumulator are added in ascending lane order (measured: dense_atomic_probe; asserted by the GPU tests'
 // bitwise comparison with the layout's order): a row's staged products are added one after the other in column order starting from 0
-// (or y), the remainder after them (that part's rows of more than 16 entries by a tree): agrees with the reference to rounding (tests:
-// <= 1e-12 * sum |a_ij x_j|), bit for bit when nothing is left to the remainder, and run-to-run identical.
+// (or y), its remainder products after them, again in column order: agrees with the reference to rounding (tests: <= 1e-12 * sum
+// |a_ij x_j|), bit for bit when nothing (or everything) is left to the remainder, and the whole product is bit for bit what the layout's
+// order gives on the host (run-to-run identical).
 #include "common.hpp"
 #include <algorithm>
 #include <atomic>
@@ -47,10 +50,15 @@
 #define TL_TW 2048            // columns of x per tile (16 KB of LDS; two buffers)
 #endif
 #ifndef TL_WAVES
-#define TL_WAVES 8            // gathering wavefronts per workgroup
-#endif
+#define TL_WAVES 4            // gathering wavefronts per workgroup.  (2 / 3 / 4 / 5 / 6 / 8 / 12 / 15 on the stand-in: the staged part wants >= 4 to keep
+#endif                        // HBM busy -- 0.28 / 0.22 / 0.19 ms, then flat --, the remainder is bound by the CUs' address units (77 % busy, ~3 cycles per
+                              // gathered line) and pays every further wavefront with padding of its runs: 0.140 ms at 4, 0.152 at 8, 0.166 at 15:
+                              // profiles/r04_tiled_sweep10.log, r04_tiled_sweep11.log, r04_tiled_pmc_far.csv)
 #ifndef TL_NG
 #define TL_NG 4               // blocks in flight per wavefront
+#endif
+#ifndef TL_FG
+#define TL_FG 2               // remainder: blocks whose gathers are in flight per wavefront (their stream loads run another TL_FG blocks ahead; 2 / 4 / 6: the same time)
 #endif
 #ifndef TL_SLOTS
 #define TL_SLOTS 6144                      // row sums in LDS (48 KB): the panel's rows and one spare for the padding.  With the two tiles 80 KB: two
@@ -59,10 +67,10 @@
                                            // a third of the x tiles: 0.19 ms against 0.26 on the stand-in, profiles/r04_tiled_sweep5.log)
 #define TL_PANEL (TL_SLOTS - 1)            // most rows a workgroup takes
 #define TL_BLOCK 128                       // entries per block: two per lane
-#define TL_MAX_PASS 16                     // column ranges of the remainder
-#define TL_PASS_BYTES (3u << 20)           // ... each covering <= 3 MiB of x: it stays in one XCD's 4 MiB L2 next to the streams passing through
+#define TL_FW_SHIFT 18                     // a window of the remainder: 2^18 columns = 2 MiB of x, what stays in an XCD's 4 MiB L2 next to the streams passing through
+#define TL_WORD_NEWWIN 0x80000000u         // remainder: a block's first word: the block opens the wavefront's next window
 #define TL_WORD_NEWTILE 0x8000u            // a block's first word: the block opens the panel's next staged tile
-static_assert(TL_TW <= 0x8000 && TL_SLOTS <= 0x10000 && TL_TW % 128 == 0, "entry word: row << 16 | flag << 15 | column in the tile; a tile is whole 1 KB loads");
+static_assert(TL_TW <= 0x8000 && TL_SLOTS <= 0x2000 && TL_TW % 128 == 0, "entry words: row << 16 | flag << 15 | column in the tile; flag << 31 | row << 18 | column in the window; a tile is whole 1 KB loads");
 #define TL_LDS_BYTES (8 * (2 * TL_TW + TL_SLOTS))
 #define TL_NCU 256
 static_assert(TL_LDS_BYTES <= 160 * 1024 && (TL_WAVES + 1) * 64 <= 1024, "one workgroup must fit a CU");
@@ -80,9 +88,11 @@ struct tl_host {
   std::vector<int> pt_tile;       // [npt] tile number
   std::vector<int> pw_e0;         // [npanels * TL_WAVES + 1] first stored entry of (panel, wavefront): a multiple of TL_BLOCK
   std::vector<int> perm;          // [nstore] stored entry -> position in the CSR value array, -1: padding (value 0)
-  std::vector<unsigned int> word; // [nstore] row of the panel << 16 | column - tile * TL_TW (padding: TL_PANEL << 16); TL_WORD_NEWTILE on the first stored word of a tile's first block
-  int npass = 1;                  // the remainder is cut into column ranges applied one after the other (x of one range stays in every XCD's L2)
-  std::vector<int> far_i, far_j, far_perm;   // CSR remainder, pass-major: far_i[q * (m + 1) + r] .. [.. + r + 1] = row r's entries of pass q in far_j / far_perm (absolute positions), global columns
+  std::vector<unsigned int> word; // [nstore] staged: row of the panel << 16 | column - tile * TL_TW (padding: TL_PANEL << 16), TL_WORD_NEWTILE on the first stored word
+                                  // of a tile's first block; remainder: row << 18 | column - (window << 18) (padding: TL_PANEL << 18), TL_WORD_NEWWIN likewise
+  std::vector<int> pw_f0;         // [npanels * TL_WAVES] first stored entry of the wavefront's remainder blocks (its staged blocks come before)
+  std::vector<int> fw_ptr;        // [npanels * TL_WAVES + 1] -> the windows of a wavefront's remainder, ascending (only windows it has entries in)
+  std::vector<int> fw_win;        // window numbers (column >> TL_FW_SHIFT)
 };
 
 struct mi355x_spmv_tiled_s {
@@ -92,11 +102,7 @@ struct mi355x_spmv_tiled_s {
   int *d_prow, *d_pt_ptr, *d_pt_tile, *d_pw_e0, *d_perm;
   unsigned int *d_word;
   double *d_val;
-  int npass;
-  long nfar_store;               // entries of the remainder's arrays (nnz_far + padding between passes)
-  int *d_far_i, *d_far_j, *d_far_perm;
-  double *d_far_a;
-  mi355x_spmv_plan_t far_plan[TL_MAX_PASS];
+  int *d_pw_f0, *d_fw_ptr, *d_fw_win;
 };
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -108,7 +114,9 @@ struct PanelOut {
   std::vector<int> perm[TL_WAVES];
   std::vector<unsigned int> word[TL_WAVES];
   int wrow[TL_WAVES + 1];
-  long near = 0;
+  int nstaged[TL_WAVES];          // stored entries of the wavefront's staged blocks
+  std::vector<int> fwin[TL_WAVES];
+  long near = 0, far = 0;
 };
 
 // position of a block's entry q (CSR order) in storage: lane q mod 64 holds entries q and q + 64 side by side
@@ -116,7 +124,7 @@ static inline int tl_slot(int q) { return 2 * (q & 63) + (q >> 6); }
 
 // one panel (rows r0 .. r1 - 1): its wavefronts' row ranges, which tiles are staged, then per (wavefront, staged tile) the blocks
 static void build_panel(int r0, int r1, const int *ai, const int *aj, int stage_min, std::vector<int> &cnt, std::vector<int> &touched,
-                        std::vector<int> &cur, PanelOut &o) {
+                        std::vector<int> &cur, std::vector<char> &stagedflag, PanelOut &o) {
   // wavefront ranges: equal shares of the panel's nonzeros
   {
     const long base = ai[r0], tot = (long)ai[r1] - base;
@@ -141,6 +149,7 @@ static void build_panel(int r0, int r1, const int *ai, const int *aj, int stage_
     const bool staged = cnt[t] >= stage_min;
     cnt[t] = 0;
     if (!staged) continue;
+    stagedflag[(size_t)t] = 1;
     const int clo = t * TL_TW, chi = clo + TL_TW;
     o.pt_tile.push_back(t);
     for (int w = 0; w < TL_WAVES; ++w) {
@@ -169,6 +178,39 @@ static void build_panel(int r0, int r1, const int *ai, const int *aj, int stage_
       o.near += nreal;
     }
   }
+  // the remainder: per wavefront what no staged tile took, window after window, CSR order inside a window
+  std::vector<std::pair<int, int>> fe;
+  for (int w = 0; w < TL_WAVES; ++w) {
+    o.nstaged[w] = (int)o.perm[w].size();
+    fe.clear();
+    for (int r = o.wrow[w]; r < o.wrow[w + 1]; ++r)
+      for (int k = ai[r]; k < ai[r + 1]; ++k)
+        if (!stagedflag[(size_t)(aj[k] / TL_TW)]) fe.push_back({aj[k] >> TL_FW_SHIFT, k});
+    std::stable_sort(fe.begin(), fe.end(), [](const std::pair<int, int> &a, const std::pair<int, int> &b) { return a.first < b.first; });
+    size_t i = 0;
+    int r = o.wrow[w];
+    while (i < fe.size()) {
+      size_t j = i;
+      while (j < fe.size() && fe[j].first == fe[i].first) ++j;
+      const int win = fe[i].first, nreal = (int)(j - i), nb = (nreal + TL_BLOCK - 1) / TL_BLOCK;
+      const size_t base = o.perm[w].size();
+      o.fwin[w].push_back(win);
+      o.perm[w].resize(base + (size_t)nb * TL_BLOCK, -1);
+      o.word[w].resize(base + (size_t)nb * TL_BLOCK, (unsigned int)TL_PANEL << TL_FW_SHIFT);
+      r = o.wrow[w];
+      for (int q = 0; q < nreal; ++q) {
+        const int k = fe[i + (size_t)q].second;
+        while (ai[r + 1] <= k) ++r;
+        const size_t pos = base + (size_t)(q / TL_BLOCK) * TL_BLOCK + (size_t)tl_slot(q % TL_BLOCK);
+        o.perm[w][pos] = k;
+        o.word[w][pos] = ((unsigned int)(r - r0) << TL_FW_SHIFT) | (unsigned int)(aj[k] - (win << TL_FW_SHIFT));
+      }
+      o.word[w][base] |= TL_WORD_NEWWIN;
+      o.far += nreal;
+      i = j;
+    }
+  }
+  for (int t : o.pt_tile) stagedflag[(size_t)t] = 0;
 }
 }  // namespace
 
@@ -250,8 +292,9 @@ int mi355x_spmv_tiled_build(int m, int n, const int *ai, const int *aj, int stag
     std::atomic<int> next(0);
     auto work = [&]() {
       std::vector<int> cnt((size_t)ntiles + 1, 0), touched, cur((size_t)TL_PANEL, 0);
+      std::vector<char> stagedflag((size_t)ntiles + 1, 0);
       for (int p = next.fetch_add(1); p < H->npanels; p = next.fetch_add(1))
-        build_panel(H->prow[(size_t)p], H->prow[(size_t)p + 1], ai, aj, stage_min, cnt, touched, cur, po[(size_t)p]);
+        build_panel(H->prow[(size_t)p], H->prow[(size_t)p + 1], ai, aj, stage_min, cnt, touched, cur, stagedflag, po[(size_t)p]);
     };
     std::vector<std::thread> th;
     for (int t = 1; t < nth; ++t) th.emplace_back(work);
@@ -261,7 +304,7 @@ int mi355x_spmv_tiled_build(int m, int n, const int *ai, const int *aj, int stag
   // concatenate: panel after panel, inside a panel wavefront after wavefront
   size_t npt = 0, nst = 0;
   for (auto &o : po) {
-    npt += o.pt_tile.size(); H->nnz_near += o.near;
+    npt += o.pt_tile.size(); H->nnz_near += o.near; H->nnz_far += o.far;
     for (int w = 0; w < TL_WAVES; ++w) nst += o.perm[w].size();
   }
   if (nst >= (size_t)1 << 31) { delete H; return (int)hipErrorInvalidValue; }
@@ -275,7 +318,9 @@ int mi355x_spmv_tiled_build(int m, int n, const int *ai, const int *aj, int stag
     H->pt_tile.insert(H->pt_tile.end(), o.pt_tile.begin(), o.pt_tile.end());
     H->wrow.insert(H->wrow.end(), o.wrow, o.wrow + TL_WAVES + 1);
     for (int w = 0; w < TL_WAVES; ++w) {
-      H->pw_e0.push_back((int)e); e += (long)o.perm[w].size();
+      H->pw_e0.push_back((int)e); H->pw_f0.push_back((int)(e + o.nstaged[w])); e += (long)o.perm[w].size();
+      H->fw_ptr.push_back((int)H->fw_win.size());
+      H->fw_win.insert(H->fw_win.end(), o.fwin[w].begin(), o.fwin[w].end());
       H->perm.insert(H->perm.end(), o.perm[w].begin(), o.perm[w].end());
       H->word.insert(H->word.end(), o.word[w].begin(), o.word[w].end());
       std::vector<int>().swap(o.perm[w]); std::vector<unsigned int>().swap(o.word[w]);
@@ -283,56 +328,15 @@ int mi355x_spmv_tiled_build(int m, int n, const int *ai, const int *aj, int stag
   }
   H->pt_ptr[(size_t)H->npanels] = (int)H->pt_tile.size();
   H->pw_e0.push_back((int)e);
+  H->fw_ptr.push_back((int)H->fw_win.size());
   H->nstore = e;
-  // remainder: every entry no stream took (a second walk with the same staging decisions), cut into column ranges of <= 3 MiB of x that
-  // are applied one after the other: the gathers of one pass then hit the L2 of whichever XCD issues them instead of going out to the
-  // Infinity Cache for every one (the remainder is what is scattered over all of x).  Within a pass rows in order, columns ascending;
-  // a row's remainder products are still added in column order, pass after pass.
-  {
-    int np = (int)(((size_t)n * sizeof(double) + TL_PASS_BYTES - 1) / TL_PASS_BYTES);
-    const char *e_ = getenv("MI355X_TILED_FAR_PASSES");
-    if (e_ && atoi(e_) > 0) np = atoi(e_);
-    if (np < 1) np = 1;
-    if (np > TL_MAX_PASS) np = TL_MAX_PASS;
-    H->npass = np;
-  }
-  const int colsper = (n + H->npass - 1) / H->npass > 0 ? (n + H->npass - 1) / H->npass : 1;
-  H->nnz_far = H->nnz - H->nnz_near;
-  H->far_i.assign((size_t)H->npass * ((size_t)m + 1), 0);
-  H->far_j.assign((size_t)H->nnz_far, 0); H->far_perm.assign((size_t)H->nnz_far, 0);
-  {
-    // count per (pass, row), prefix over pass-major order, fill
-    std::vector<char> staged((size_t)ntiles + 1, 0);
-    std::vector<int> cntpr((size_t)H->npass * (size_t)(m > 0 ? m : 1), 0);
-    auto for_far = [&](auto &&fn) {
-      for (int p = 0; p < H->npanels; ++p) {
-        for (int i = H->pt_ptr[(size_t)p]; i < H->pt_ptr[(size_t)p + 1]; ++i) staged[(size_t)H->pt_tile[(size_t)i]] = 1;
-        const int r0 = H->prow[(size_t)p], r1 = H->prow[(size_t)p + 1];
-        for (int r = r0; r < r1; ++r)
-          for (int k = ai[r]; k < ai[r + 1]; ++k) if (!staged[(size_t)(aj[k] / TL_TW)]) fn(r, k, aj[k] / colsper);
-        for (int i = H->pt_ptr[(size_t)p]; i < H->pt_ptr[(size_t)p + 1]; ++i) staged[(size_t)H->pt_tile[(size_t)i]] = 0;
-      }
-    };
-    long nfar = 0;
-    for_far([&](int r, int, int q) { cntpr[(size_t)q * m + r]++; ++nfar; });
-    if (nfar != H->nnz_far) { delete H; return (int)hipErrorUnknown; }
-    long run = 0;
-    for (int q = 0; q < H->npass; ++q) {
-      for (int r = 0; r < m; ++r) { H->far_i[(size_t)q * (m + 1) + r] = (int)run; run += cntpr[(size_t)q * m + r]; }
-      H->far_i[(size_t)q * (m + 1) + m] = (int)run;
-      if (run & 1) ++run;                          // every pass starts on an even entry (the row-block kernel's 16-byte value loads)
-    }
-    H->far_j.assign((size_t)run, 0); H->far_perm.assign((size_t)run, -1);
-    std::vector<int> nextpr((size_t)H->npass * (size_t)(m > 0 ? m : 1));
-    for (int q = 0; q < H->npass; ++q) for (int r = 0; r < m; ++r) nextpr[(size_t)q * m + r] = H->far_i[(size_t)q * (m + 1) + r];
-    for_far([&](int r, int k, int q) { const int pos = nextpr[(size_t)q * m + r]++; H->far_j[(size_t)pos] = aj[k]; H->far_perm[(size_t)pos] = k; });
-  }
+  if (H->nnz_near + H->nnz_far != H->nnz) { delete H; return (int)hipErrorUnknown; }
   if (e != H->nstore) { delete H; return (int)hipErrorUnknown; }
   mi355x_spmv_tiled_s *P = new mi355x_spmv_tiled_s();
   memset(P, 0, sizeof(*P));
   P->host = H;
   P->m = m; P->n = n; P->npanels = H->npanels; P->npt = (int)H->pt_tile.size();
-  P->nnz_near = H->nnz_near; P->nnz_far = H->nnz_far; P->nstore = H->nstore; P->npass = H->npass;
+  P->nnz_near = H->nnz_near; P->nnz_far = H->nnz_far; P->nstore = H->nstore;
   *out = P;
   return 0;
 }
@@ -351,7 +355,7 @@ int mi355x_spmv_tiled_geometry(int *panel_rows, int *tile_cols, int *waves, int 
   return 0;
 }
 
-// tests: one host array of the layout (which: 0 pt_ptr, 1 pt_tile, 2 pw_e0, 3 word, 4 perm, 7 far_i, 8 far_j, 9 far_perm, 10 wrow, 11 prow);
+// tests: one host array of the layout (which: 0 pt_ptr, 1 pt_tile, 2 pw_e0, 3 word, 4 perm, 7 pw_f0, 8 fw_ptr, 9 fw_win, 10 wrow, 11 prow);
 // available until mi355x_spmv_tiled_drop_host
 int mi355x_spmv_tiled_debug_get(mi355x_spmv_tiled_t P, int which, void *out, size_t cap_bytes, size_t *bytes) {
   if (!P->host) return (int)hipErrorInvalidValue;
@@ -363,9 +367,9 @@ int mi355x_spmv_tiled_debug_get(mi355x_spmv_tiled_t P, int which, void *out, siz
     case 2: src = H->pw_e0.data(); nb = H->pw_e0.size() * 4; break;
     case 3: src = H->word.data(); nb = H->word.size() * 4; break;
     case 4: src = H->perm.data(); nb = H->perm.size() * 4; break;
-    case 7: src = H->far_i.data(); nb = H->far_i.size() * 4; break;
-    case 8: src = H->far_j.data(); nb = H->far_j.size() * 4; break;
-    case 9: src = H->far_perm.data(); nb = H->far_perm.size() * 4; break;
+    case 7: src = H->pw_f0.data(); nb = H->pw_f0.size() * 4; break;
+    case 8: src = H->fw_ptr.data(); nb = H->fw_ptr.size() * 4; break;
+    case 9: src = H->fw_win.data(); nb = H->fw_win.size() * 4; break;
     case 10: src = H->wrow.data(); nb = H->wrow.size() * 4; break;
     case 11: src = H->prow.data(); nb = H->prow.size() * 4; break;
     default: return (int)hipErrorInvalidValue;
@@ -393,7 +397,12 @@ __global__ __launch_bounds__(256) void tl_gather_values_kernel(const int *__rest
 // the tile switches -- the loads do not depend on the tile of x, only their use does.  Every load is issued on every path (past the
 // stream's end: the last block again), so that the number of loads in flight is the same wherever the code is: a conditional issue
 // makes the compiler wait for the younger blocks' loads too, and the pipeline is one block deep whatever the source says.
+// After its staged blocks a gathering wavefront walks its remainder blocks: the same 12-byte entries, x gathered from global memory
+// (window base + 18-bit column).  2 TL_FG blocks in a ring: a block's two stream loads go out 2 TL_FG blocks ahead, its two gathers
+// TL_FG blocks ahead (their addresses are the words just arrived), both on every path; no barrier -- a row sum is still its
+// wavefront's own.  (Gathers of 2 / 4 / 8 blocks in flight: 153 / 207 / 187 G gathers/s in profiles/r04_dense_atomic_probe2.log.)
 struct tl_blk { tl_v2d v; tl_v2u c; };
+struct tl_fblk { tl_v2d v; tl_v2u c; double x0, x1; };
 
 __device__ __forceinline__ void tl_lds_add(double *p, double v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }   // ds_add_f64
 
@@ -406,8 +415,9 @@ __device__ unsigned long long tl_prof_buf[8 * 8192];
 template <int ADD>
 __global__ __launch_bounds__((TL_WAVES + 1) * 64) void spmv_tiled_kernel(
     int npanels, int chunkx, const int *__restrict__ prow, const int *__restrict__ pt_ptr, const int *__restrict__ pt_tile,
-    const int *__restrict__ pw_e0, const tl_v2d *__restrict__ val, const tl_v2u *__restrict__ word,
-    const double *__restrict__ x, const double *yin, double *yout, int n) {
+    const int *__restrict__ pw_e0, const int *__restrict__ pw_f0, const int *__restrict__ fw_ptr, const int *__restrict__ fw_win,
+    const tl_v2d *__restrict__ val, const tl_v2u *__restrict__ word,
+    const double *__restrict__ x, const double *yin, double *yout, int n, int phases) {
   extern __shared__ __attribute__((aligned(16))) double tl_lds[];
   double *xt = tl_lds;                                   // 2 x TL_TW doubles: two tiles of x
   double *acc = tl_lds + 2 * TL_TW;                      // the panel's row sums, and the padding's
@@ -425,7 +435,7 @@ __global__ __launch_bounds__((TL_WAVES + 1) * 64) void spmv_tiled_kernel(
   const int row0 = prow[p], nrow = prow[p + 1] - row0;
   for (int rl = tid; rl < TL_SLOTS; rl += NT) acc[rl] = (ADD && rl < nrow) ? yin[row0 + rl] : 0.0;
 
-  const int pt0 = pt_ptr[p], ntp = pt_ptr[p + 1] - pt0;
+  const int pt0 = pt_ptr[p], ntp = (phases & 1) ? pt_ptr[p + 1] - pt0 : 0;     // (phases: 1 the staged tiles, 2 the remainder; development: their separate cost)
   // a tile into a buffer: whole double2's inside x, then the last column of an odd-sized last tile
   auto tile_tail = [&](int t, double *buf) {
     const size_t base = (size_t)t * TL_TW;
@@ -480,8 +490,9 @@ __global__ __launch_bounds__((TL_WAVES + 1) * 64) void spmv_tiled_kernel(
   } else {
     // ---- a gathering wavefront ----
     const int ipw = p * TL_WAVES + w;
-    const int e0 = pw_e0[ipw];
-    const int nblocks = (pw_e0[ipw + 1] - e0) / TL_BLOCK;
+    const int e0 = pw_e0[ipw], f0 = pw_f0[ipw];
+    const int nblocks = (phases & 1) ? (f0 - e0) / TL_BLOCK : 0;
+    const int nfb = (phases & 2) ? (pw_e0[ipw + 1] - f0) / TL_BLOCK : 0;
     const tl_v2d *vq = val + (e0 >> 1) + lane;           // + 64 per block
     const tl_v2u *cq = word + (e0 >> 1) + lane;
     if (nblocks == 0) {                                  // no staged tile in this panel (true for all its wavefronts alike)
@@ -529,6 +540,39 @@ __global__ __launch_bounds__((TL_WAVES + 1) * 64) void spmv_tiled_kernel(
       prof_loop = __builtin_readcyclecounter() - pl0;
 #endif
     }
+    if (nfb > 0) {
+      // ---- the remainder: x from global memory, window after window ----
+      const tl_v2d *vf = val + (f0 >> 1) + lane;
+      const tl_v2u *cf = word + (f0 >> 1) + lane;
+      const int *wl = fw_win + fw_ptr[ipw];              // the wavefront's windows in order
+      int iw = -1;                                       // (the gathers' side: they run two blocks ahead of the sums)
+      const double *xw = x;
+      constexpr int FR = 2 * TL_FG;
+      tl_fblk s[FR];
+      auto stream = [&](tl_fblk &q, int blk) {
+        const size_t o = (size_t)(blk < nfb ? blk : nfb - 1) * 64;
+        q.v = __builtin_nontemporal_load(vf + o); q.c = __builtin_nontemporal_load(cf + o);
+      };
+      auto gather = [&](tl_fblk &q, int blk) {
+        if (blk < nfb && ((unsigned int)__builtin_amdgcn_readfirstlane((int)q.c.x) & TL_WORD_NEWWIN)) { ++iw; xw = x + ((size_t)wl[iw] << TL_FW_SHIFT); }
+        q.x0 = xw[q.c.x & ((1u << TL_FW_SHIFT) - 1u)]; q.x1 = xw[q.c.y & ((1u << TL_FW_SHIFT) - 1u)];
+      };
+#pragma unroll
+      for (int k = 0; k < FR; ++k) stream(s[k], k);
+#pragma unroll
+      for (int k = 0; k < TL_FG; ++k) gather(s[k], k);
+      for (int b = 0; b < nfb; b += FR) {
+#pragma unroll
+        for (int k = 0; k < FR; ++k) {
+          gather(s[(k + TL_FG) % FR], b + k + TL_FG);
+          if (b + k < nfb) {
+            tl_lds_add(acc + ((s[k].c.x >> TL_FW_SHIFT) & (unsigned int)(0x1fff)), s[k].v.x * s[k].x0);
+            tl_lds_add(acc + ((s[k].c.y >> TL_FW_SHIFT) & (unsigned int)(0x1fff)), s[k].v.y * s[k].x1);
+          }
+          stream(s[k], b + k + FR);
+        }
+      }
+    }
   }
   __syncthreads();
   for (int rl = tid; rl < nrow; rl += NT) yout[row0 + rl] = acc[rl];
@@ -545,7 +589,7 @@ __global__ __launch_bounds__((TL_WAVES + 1) * 64) void spmv_tiled_kernel(
 
 extern "C" {
 
-// device part: tables up, values gathered from the CSR value array on the device (aa_dev), remainder with a row-block plan of its own
+// device part: tables up, values gathered from the CSR value array on the device (aa_dev)
 int mi355x_spmv_tiled_upload(mi355x_handle_t h, mi355x_spmv_tiled_t P, const double *aa_dev) {
   tl_host *H = P->host;
   if (!H) return (int)hipErrorInvalidValue;
@@ -558,31 +602,18 @@ int mi355x_spmv_tiled_upload(mi355x_handle_t h, mi355x_spmv_tiled_t P, const dou
   if ((rc = up((void **)&P->d_pt_ptr, H->pt_ptr.data(), H->pt_ptr.size() * 4)) || (rc = up((void **)&P->d_pt_tile, H->pt_tile.data(), H->pt_tile.size() * 4)) ||
       (rc = up((void **)&P->d_prow, H->prow.data(), H->prow.size() * 4)) || (rc = up((void **)&P->d_pw_e0, H->pw_e0.data(), H->pw_e0.size() * 4)) ||
       (rc = up((void **)&P->d_perm, H->perm.data(), H->perm.size() * 4)) || (rc = up((void **)&P->d_word, H->word.data(), H->word.size() * 4)) ||
-      (rc = up((void **)&P->d_far_i, H->far_i.data(), H->far_i.size() * 4)) || (rc = up((void **)&P->d_far_j, H->far_j.data(), H->far_j.size() * 4)) ||
-      (rc = up((void **)&P->d_far_perm, H->far_perm.data(), H->far_perm.size() * 4)))
+      (rc = up((void **)&P->d_pw_f0, H->pw_f0.data(), H->pw_f0.size() * 4)) || (rc = up((void **)&P->d_fw_ptr, H->fw_ptr.data(), H->fw_ptr.size() * 4)) ||
+      (rc = up((void **)&P->d_fw_win, H->fw_win.data(), H->fw_win.size() * 4)))
     return rc;
   MI355X_TRY(hipMalloc((void **)&P->d_val, sizeof(double) * (size_t)(P->nstore > 0 ? P->nstore : 1) + 1024));
-  P->nfar_store = (long)H->far_perm.size();
-  MI355X_TRY(hipMalloc((void **)&P->d_far_a, sizeof(double) * (size_t)(P->nfar_store > 0 ? P->nfar_store : 1) + 64));
-  if (P->nnz_far > 0)
-    for (int q = 0; q < P->npass; ++q) {
-      const int *fi = H->far_i.data() + (size_t)q * ((size_t)P->m + 1);
-      if (fi[P->m] == fi[0]) continue;                                    // nothing in this column range
-      rc = mi355x_spmv_plan_create(h, P->m, fi, nullptr, &P->far_plan[q]);
-      if (rc) return rc;
-    }
   MI355X_TRY(hipStreamSynchronize(h->stream));
   return mi355x_spmv_tiled_refresh_values(h, P, aa_dev);
 }
 
-// the CSR values on the device changed (same pattern): one gather per part
+// the CSR values on the device changed (same pattern): one gather
 int mi355x_spmv_tiled_refresh_values(mi355x_handle_t h, mi355x_spmv_tiled_t P, const double *aa_dev) {
   if (P->nstore > 0) {
     hipLaunchKernelGGL(tl_gather_values_kernel, dim3(mi355x_grid_for((size_t)P->nstore, 4)), dim3(256), 0, h->stream, P->d_perm, aa_dev, P->d_val, P->nstore);
-    MI355X_LAUNCH_CHECK();
-  }
-  if (P->nnz_far > 0) {
-    hipLaunchKernelGGL(tl_gather_values_kernel, dim3(mi355x_grid_for((size_t)P->nfar_store, 4)), dim3(256), 0, h->stream, P->d_far_perm, aa_dev, P->d_far_a, P->nfar_store);
     MI355X_LAUNCH_CHECK();
   }
   return 0;
@@ -590,9 +621,9 @@ int mi355x_spmv_tiled_refresh_values(mi355x_handle_t h, mi355x_spmv_tiled_t P, c
 
 // y = A x (yin == NULL) or yout = yin + A x (yout may alias yin).  x must be 16-byte aligned (hipErrorNotSupported otherwise: the caller
 // takes the row-block kernel).  which: 0 both parts, 1 the staged part only, 2 the remainder only (development: their separate cost).
-// (The remainder on a stream of its own beside the staged kernel -- the one bound by L2 requests, one per gather, the other by HBM --
-//  gains 6-10 % with two wholly independent streams and nothing once the fork, the join and the final addition are paid:
-//  profiles/r04_tiled_overlap_probe.log, r04_tiled_sweep7.log.)
+// (History of the remainder: a CSR of its own added by the row-block kernel in column ranges of 3 MiB of x, four launches and four
+//  read-modify-writes of y, 0.17 ms on the stand-in; on a stream of its own beside the staged kernel: no gain; inside the kernel, as
+//  it is now, 0.14 ms: profiles/r04_tiled_sweep10.log, r04_tiled_sweep11.log; its counters r04_tiled_pmc_far.csv.)
 int mi355x_spmv_tiled_parts(mi355x_handle_t h, mi355x_spmv_tiled_t P, const double *x, const double *yin, double *yout, int which) {
   if (!mi355x_aligned16(x)) return (int)hipErrorNotSupported;
   if (P->m == 0) return 0;
@@ -610,9 +641,10 @@ int mi355x_spmv_tiled_parts(mi355x_handle_t h, mi355x_spmv_tiled_t P, const doub
   }
   const int chunkx = (P->npanels + MI355X_NXCD - 1) / MI355X_NXCD;
   const int grid = chunkx * MI355X_NXCD;
-  if (which != 2) {
+  {
 #define TL_GO(A_, YIN) hipLaunchKernelGGL((spmv_tiled_kernel<A_>), dim3(grid), dim3((TL_WAVES + 1) * 64), lds, h->stream, P->npanels, chunkx, P->d_prow, P->d_pt_ptr, \
-                                          P->d_pt_tile, P->d_pw_e0, reinterpret_cast<const tl_v2d *>(P->d_val), reinterpret_cast<const tl_v2u *>(P->d_word), x, YIN, yout, P->n)
+                                          P->d_pt_tile, P->d_pw_e0, P->d_pw_f0, P->d_fw_ptr, P->d_fw_win, reinterpret_cast<const tl_v2d *>(P->d_val), reinterpret_cast<const tl_v2u *>(P->d_word), x, YIN, yout, P->n, \
+                                          which == 1 ? 1 : which == 2 ? 2 : 3)
     if (yin) TL_GO(1, yin); else TL_GO(0, (const double *)nullptr);
 #undef TL_GO
     MI355X_LAUNCH_CHECK();
@@ -625,12 +657,6 @@ int mi355x_spmv_tiled_parts(mi355x_handle_t h, mi355x_spmv_tiled_t P, const doub
     }
 #endif
   }
-  if (which != 1 && P->nnz_far > 0)
-    for (int q = 0; q < P->npass; ++q) {
-      if (!P->far_plan[q]) continue;
-      const int rc = mi355x_spmv_csr_add(h, P->far_plan[q], P->d_far_i + (size_t)q * ((size_t)P->m + 1), P->d_far_j, P->d_far_a, x, yout, yout);
-      if (rc) return rc;
-    }
   return 0;
 }
 int mi355x_spmv_tiled(mi355x_handle_t h, mi355x_spmv_tiled_t P, const double *x, const double *yin, double *yout) {
@@ -640,9 +666,8 @@ int mi355x_spmv_tiled(mi355x_handle_t h, mi355x_spmv_tiled_t P, const double *x,
 int mi355x_spmv_tiled_destroy(mi355x_spmv_tiled_t P) {
   if (!P) return 0;
   delete P->host;
-  void *ptrs[] = {P->d_prow, P->d_pt_ptr, P->d_pt_tile, P->d_pw_e0, P->d_perm, P->d_word, P->d_val, P->d_far_i, P->d_far_j, P->d_far_perm, P->d_far_a};
+  void *ptrs[] = {P->d_prow, P->d_pt_ptr, P->d_pt_tile, P->d_pw_e0, P->d_pw_f0, P->d_fw_ptr, P->d_fw_win, P->d_perm, P->d_word, P->d_val};
   for (void *q : ptrs) if (q) hipFree(q);
-  for (int q = 0; q < TL_MAX_PASS; ++q) if (P->far_plan[q]) mi355x_spmv_plan_destroy(P->far_plan[q]);
   delete P;
   return 0;
 }

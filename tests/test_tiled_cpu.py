@@ -66,11 +66,7 @@ def check(k, ai, aj, aa, n, stage_min, expect_all_staged=False, expect_none_stag
         k.mi355x_spmv_tiled_destroy(plan)
 
 
-@pytest.mark.parametrize("passes", ["", "3"])
-def test_tiled_layout_holds_every_nonzero_once_and_in_column_order(k, passes, monkeypatch):
-    """(passes: the remainder cut into that many column ranges; default = by the size of x, one for these sizes)"""
-    if passes:
-        monkeypatch.setenv("MI355X_TILED_FAR_PASSES", passes)
+def test_tiled_layout_holds_every_nonzero_once_and_in_column_order(k):
     rng = np.random.default_rng(5)
     g = tiled.geometry(k)
     assert g["tw"] % 128 == 0 and g["block"] == 128 and g["panel"] < 65536

@@ -37,11 +37,15 @@ def run_case(dev, ai, aj, aa, n, stage_min, seed=0):
         yin = np.random.default_rng(seed).standard_normal(m)
         # what the kernel must produce for the staged part, from the host copy of the layout (before the upload drops nothing: the
         # host copy lives until _drop_host)
-        (rows, cols, pos), _ = tiled.walk(k, plan, m)
+        (rows, cols, pos), far = tiled.walk(k, plan, m)
         near = np.zeros(m); near_add = yin.copy()
         for r, c, q in zip(rows, cols, pos):
             near[r] = near[r] + aa[q] * x[c]
             near_add[r] = near_add[r] + aa[q] * x[c]
+        whole, rem_only = near.copy(), np.zeros(m)                 # ... and with the remainder behind it / alone
+        for r, c, q in zip(*far):
+            whole[r] = whole[r] + aa[q] * x[c]
+            rem_only[r] = rem_only[r] + aa[q] * x[c]
         inf = tiled.info(k, plan)
         daa = dev.put(np.concatenate((aa, [0.0, 0.0])))
         dx, dyin = dev.put(x), dev.put(yin)
@@ -56,10 +60,13 @@ def run_case(dev, ai, aj, aa, n, stage_min, seed=0):
         scale = np.zeros(m)
         np.add.at(scale, rowof, np.abs(aa * x[aj]))
         ref = orc.spmv(ai, aj, aa, x) if m else np.zeros(0)
+        dev.chk(k.mi355x_spmv_tiled_parts(dev.h, plan, dx, None, dy, 2))
+        assert np.array_equal(bits(dev.get(dy, m)), bits(rem_only))
         dev.chk(k.mi355x_spmv_tiled(dev.h, plan, dx, None, dy))
         y = dev.get(dy, m)
+        assert np.array_equal(bits(y), bits(whole))               # the whole product: the layout's order, bit for bit
         assert np.all(np.abs(y - ref) <= 1e-12 * scale + 1e-300)
-        if inf["remainder"] == 0:
+        if inf["remainder"] == 0 or inf["staged"] == 0:
             assert np.array_equal(bits(y), bits(ref))          # one stream in column order from 0: the reference's bits
         refadd = orc.spmv_add(ai, aj, aa, x, yin) if m else np.zeros(0)
         dev.chk(k.mi355x_spmv_tiled(dev.h, plan, dx, dyin, dy))
@@ -85,11 +92,7 @@ def run_case(dev, ai, aj, aa, n, stage_min, seed=0):
         dev.free_all()
 
 
-@pytest.mark.parametrize("passes", ["", "3"])
-def test_tiled_spmv_matches_its_layout_bitwise_and_the_oracle(dev, passes, monkeypatch):
-    """(passes: the remainder cut into that many column ranges, applied one after the other)"""
-    if passes:
-        monkeypatch.setenv("MI355X_TILED_FAR_PASSES", passes)
+def test_tiled_spmv_matches_its_layout_bitwise_and_the_oracle(dev):
     rng = np.random.default_rng(15)
     g = tiled.geometry(dev.k)
     m = 2 * g["panel"] + 333

@@ -15,9 +15,10 @@ typedef unsigned int v2u __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ void lds_add(double *p, double v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
-// MODE 0: loads only; 1: + x gather from LDS; 2: + ds_add_f64 into the row accumulators
+// MODE 0: loads only; 1: + x gather from LDS; 2: + ds_add_f64 into the row accumulators; 3: as 2 but x gathered from GLOBAL memory
+// (a window of 2^18 doubles = 2 MiB that all workgroups share: the long-range entries of the product, one L2 request per entry)
 template <int MODE, int U, int W>
-__global__ __launch_bounds__(W * 64) void dense_kernel(const v2d *__restrict__ val, const v2u *__restrict__ idx, long per2, int nblocks, double *out) {
+__global__ __launch_bounds__(W * 64) void dense_kernel(const v2d *__restrict__ val, const v2u *__restrict__ idx, long per2, int nblocks, double *out, const double *__restrict__ xg = nullptr) {
   extern __shared__ double lds[];
   double *xt = lds, *acc = lds + 8192;                       // two 4096-column tiles, then 2048 + 1 accumulators
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -35,11 +36,26 @@ __global__ __launch_bounds__(W * 64) void dense_kernel(const v2d *__restrict__ v
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (MODE == 0) { s0 += v[u].x + v[u].y + (double)(ix[u].x ^ ix[u].y); continue; }
+      if (MODE == 3) continue;
       const double x0 = xt[ix[u].x & 0xffffu], x1 = xt[ix[u].y & 0xffffu];
       const double p0 = v[u].x * x0, p1 = v[u].y * x1;
       if (MODE == 1) { s0 += p0 + p1; continue; }
       lds_add(acc + (ix[u].x >> 16), p0);
       lds_add(acc + (ix[u].y >> 16), p1);
+    }
+    if (MODE == 3) {                                     // the gathers of all U blocks go out together, then the products
+      double g0[U], g1[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        // a pseudo-random column of the window from the word (the probe's words hold 12-bit columns: spread them over 2^18)
+        const unsigned int c0 = (ix[u].x * 2654435761u) >> 14, c1 = (ix[u].y * 2246822519u) >> 14;
+        g0[u] = xg[c0]; g1[u] = xg[c1];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        lds_add(acc + (ix[u].x >> 16), v[u].x * g0[u]);
+        lds_add(acc + (ix[u].y >> 16), v[u].y * g1[u]);
+      }
     }
   }
   __syncthreads();
@@ -47,6 +63,7 @@ __global__ __launch_bounds__(W * 64) void dense_kernel(const v2d *__restrict__ v
   if (s0 == 1.2345e300) out[threadIdx.x] = s0;
 }
 
+static const double *g_xg = nullptr;
 template <int MODE, int U, int W>
 static void run(const char *name, const v2d *val, const v2u *idx, long nent, double *out, int G) {
   const size_t ldsb = 80 * 1024;
@@ -54,10 +71,10 @@ static void run(const char *name, const v2d *val, const v2u *idx, long nent, dou
   const int nblocks = (int)(per2 / 64) / U * U;
   CK(hipFuncSetAttribute(reinterpret_cast<const void *>(dense_kernel<MODE, U, W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((dense_kernel<MODE, U, W>), dim3(G), dim3(W * 64), ldsb, 0, val, idx, per2, nblocks, out);
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((dense_kernel<MODE, U, W>), dim3(G), dim3(W * 64), ldsb, 0, val, idx, per2, nblocks, out, g_xg);
   CK(hipEventRecord(e0));
   const int reps = 10;
-  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((dense_kernel<MODE, U, W>), dim3(G), dim3(W * 64), ldsb, 0, val, idx, per2, nblocks, out);
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((dense_kernel<MODE, U, W>), dim3(G), dim3(W * 64), ldsb, 0, val, idx, per2, nblocks, out, g_xg);
   CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
   float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
   const double entries = (double)G * W * nblocks * 128.0;
@@ -107,5 +124,14 @@ int main() {
   run<2, 4, 8>("+ ds_add_f64 into the row sums, 4 blocks in flight", v, ix, nent, out, 512);
   run<2, 4, 4>("+ ds_add_f64, 4 blocks in flight, 4 wavefronts per workgroup", v, ix, nent, out, 512);
   run<2, 8, 4>("+ ds_add_f64, 8 blocks in flight, 4 wavefronts per workgroup", v, ix, nent, out, 512);
+  {
+    double *xg; CK(hipMalloc(&xg, 8u << 18)); CK(hipMemset(xg, 0, 8u << 18)); g_xg = xg;
+    printf("-- x gathered from a 2 MiB window in global memory instead of LDS (one L2 request per entry), 20 M entries' worth would be 1/5 of these times\n");
+    run<3, 2, 8>("global gathers + ds_add_f64, 2 blocks in flight", v, ix, nent, out, 256);
+    run<3, 4, 8>("global gathers + ds_add_f64, 4 blocks in flight", v, ix, nent, out, 256);
+    run<3, 4, 8>("global gathers + ds_add_f64, 4 blocks in flight", v, ix, nent, out, 512);
+    run<3, 8, 8>("global gathers + ds_add_f64, 8 blocks in flight", v, ix, nent, out, 256);
+    run<3, 4, 15>("global gathers + ds_add_f64, 4 blocks in flight, 15 wavefronts", v, ix, nent, out, 256);
+  }
   return 0;
 }

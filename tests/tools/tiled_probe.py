@@ -48,7 +48,8 @@ def main():
         dev.chk(k.mi355x_spmv_tiled_upload(dev.h, tp, daa))
         k.mi355x_spmv_tiled_drop_host(tp)
         dev.sync()
-        ts = [event_time(k, dev.h, lambda w=w: k.mi355x_spmv_tiled_parts(dev.h, tp, dx, None, dy, w), 20) for w in (0, 1, 2)]
+        only = os.environ.get("TILED_PROBE_WHICH")                # (counters of one part alone: every launch of the process is that part)
+        ts = [event_time(k, dev.h, lambda w=w: k.mi355x_spmv_tiled_parts(dev.h, tp, dx, None, dy, int(only) if only else w), 20) for w in (0, 1, 2)]
         dev.chk(k.mi355x_spmv_tiled(dev.h, tp, dx, None, dy))
         err = np.max(np.abs(dev.get(dy, m) - ref) / (np.abs(ref) + 1.0))
         print("tiled stage_min %6d: build %.2fs staged %.1f%% in %d pairs / %d blocks (%.1f%% of the stored entries are padding) | both %.4f ms = %.3f of 8 TB/s ; staged part %.4f ms ; remainder %.4f ms ; max rel diff vs row-block %.2g"

@@ -5,6 +5,4 @@ export CFG4_CACHE=/tmp MI355X_TILED_DEBUG=1
 V=$R/petsc-dev_amd/csrc/variants
 run() { echo "== $1"; shift; timeout -k 10 300 env "$@" python3 $R/tests/tools/tiled_probe.py irr 1024 2>&1 | grep -v "^irr\|lines of x\|^row-block"; }
 run "default build" A=1
-run "the remainder after the staged part, not beside it" MI355X_TILED_OVERLAP=0
-for q in ${PASSES:-2 3 8}; do run "remainder in $q passes" MI355X_TILED_FAR_PASSES=$q; done
-for v in ${VARIANTS:-w4 w6}; do run "variant $v" MI355X_KERNELS_LIB=$V/libmi355x_kernels_$v.so; done
+for v in ${VARIANTS:-w4 w12}; do run "variant $v" MI355X_KERNELS_LIB=$V/libmi355x_kernels_$v.so; done
