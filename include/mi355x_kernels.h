@@ -240,12 +240,12 @@ int mi355x_csr_get_diagonal(mi355x_handle_t h, int m, const int *ai, const int *
 
 /* ---- column-tiled CSR SpMV: x staged in LDS (csrc/spmv_tiled.hip) ------ */
 /* For matrices whose x gathers miss the caches (rows that pick columns from a wide window without neighbouring rows sharing them):
- * MatMult_SeqAIJ / MatMultAdd_SeqAIJ (aij.c:1225, 1291) re-cut into row panels (<= 2047 rows, equal shares of the nonzeros) x column
- * tiles of 4096 entries of x; a (panel, tile) pair with >= stage_min entries gathers from a copy of that tile in LDS and adds into row
- * sums that live in LDS too (12-byte entries in dense blocks of 128, two per lane, ds_add_f64), the thin pairs' entries stay in a CSR
- * remainder added by the row-block kernel afterwards.  Products of a row's staged entries are added in column order, then the
- * remainder's: agrees with the reference to rounding (<= 1e-12 * sum |a_ij x_j|; bit for bit when nothing is left to the
- * remainder), reproducible.
+ * MatMult_SeqAIJ / MatMultAdd_SeqAIJ (aij.c:1225, 1291) re-cut into row panels (<= 6143 rows, equal shares of the nonzeros) x column
+ * tiles of 2048 entries of x; a (panel, tile) pair with >= stage_min entries gathers from a copy of that tile in LDS and adds into row
+ * sums that live in LDS too (12-byte entries in dense blocks of 128, two per lane, ds_add_f64); the thin pairs' entries (the remainder)
+ * follow in the same streams, grouped by windows of 2^18 columns, their x gathered from global memory -- one kernel, y written once.
+ * Products of a row's staged entries are added in column order, then the remainder's in column order: agrees with the reference to
+ * rounding (<= 1e-12 * sum |a_ij x_j|; bit for bit when nothing or everything is left to the remainder), reproducible.
  *   _probe    fraction of sampled gathers that touch a 128-byte line of x nothing else in their 32-row group touches (host only)
  *   _build    the layout from the host CSR pattern (host only: no device call); stage_min <= 0: 1024
  *   _upload   tables to the device; values gathered from the CSR value array that is on the device (aa_dev)
@@ -262,7 +262,7 @@ int mi355x_spmv_tiled_refresh_values(mi355x_handle_t h, mi355x_spmv_tiled_t plan
 int mi355x_spmv_tiled(mi355x_handle_t h, mi355x_spmv_tiled_t plan, const double *x, const double *yin, double *yout);
 /* development: which = 1 the staged part only, 2 the remainder only (their separate cost), 0 both */
 int mi355x_spmv_tiled_parts(mi355x_handle_t h, mi355x_spmv_tiled_t plan, const double *x, const double *yin, double *yout, int which);
-/* tests: one host array of the layout (0 pt_ptr, 1 pt_tile, 2 pw_e0, 3 word, 4 perm, 7 far_i, 8 far_j, 9 far_perm, 10 wrow, 11 prow)
+/* tests: one host array of the layout (0 pt_ptr, 1 pt_tile, 2 pw_e0, 3 word, 4 perm, 7 pw_f0, 8 fw_ptr, 9 fw_win, 10 wrow, 11 prow)
  * until _drop_host releases the host copy */
 int mi355x_spmv_tiled_debug_get(mi355x_spmv_tiled_t plan, int which, void *out, size_t cap_bytes, size_t *bytes);
 int mi355x_spmv_tiled_drop_host(mi355x_spmv_tiled_t plan);

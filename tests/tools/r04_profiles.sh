@@ -46,7 +46,7 @@ if has irr; then
   PETSC_OPTIONS_EXTRA="-mat_hipmi355x_tiled 0" stats cfg4_irr_rowblock python3 $T/cfg4_spmv.py irr 10 || exit 1
   stats cfg4_irr_tiled python3 $T/cfg4_spmv.py irr 10 || exit 1
   PETSC_OPTIONS_EXTRA="-mat_hipmi355x_tiled 0" pmc cfg4_irr_rowblock "FETCH_SIZE WRITE_SIZE TCP_TCC_READ_REQ_sum TCC_MISS_sum TCC_HIT_sum" python3 $T/cfg4_spmv.py irr 5
-  pmc cfg4_irr_tiled "FETCH_SIZE WRITE_SIZE TCP_TCC_READ_REQ_sum TCC_MISS_sum TCC_HIT_sum SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" python3 $T/cfg4_spmv.py irr 5
+  pmc cfg4_irr_tiled "FETCH_SIZE WRITE_SIZE TCP_TCC_READ_REQ_sum TCC_MISS_sum TCC_HIT_sum SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY TA_BUSY_avr" python3 $T/cfg4_spmv.py irr 5
   python3 $T/cfg4_solve.py irr jacobi > $O/cfg4_irr_solve.log 2>&1
 fi
 if has solvers; then
