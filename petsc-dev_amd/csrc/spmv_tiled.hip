@@ -623,7 +623,10 @@ int mi355x_spmv_tiled_refresh_values(mi355x_handle_t h, mi355x_spmv_tiled_t P, c
 // takes the row-block kernel).  which: 0 both parts, 1 the staged part only, 2 the remainder only (development: their separate cost).
 // (History of the remainder: a CSR of its own added by the row-block kernel in column ranges of 3 MiB of x, four launches and four
 //  read-modify-writes of y, 0.17 ms on the stand-in; on a stream of its own beside the staged kernel: no gain; inside the kernel, as
-//  it is now, 0.14 ms: profiles/r04_tiled_sweep10.log, r04_tiled_sweep11.log; its counters r04_tiled_pmc_far.csv.)
+//  it is now, 0.14 ms: profiles/r04_tiled_sweep10.log, r04_tiled_sweep11.log; its counters r04_tiled_pmc_far.csv.  Both kinds of
+//  blocks in ONE loop, one remainder block per four staged ones -- the staged part bound by HBM, the remainder by the address units --
+//  was built too and passes the same bitwise tests against its own interleaved order: 0.32-0.33 ms against 0.34, whatever the depth of
+//  the rings (profiles/r04_tiled_sweep12.log); not kept: 5 % for a row's products no longer being added in column order.)
 int mi355x_spmv_tiled_parts(mi355x_handle_t h, mi355x_spmv_tiled_t P, const double *x, const double *yin, double *yout, int which) {
   if (!mi355x_aligned16(x)) return (int)hipErrorNotSupported;
   if (P->m == 0) return 0;
