@@ -101,6 +101,8 @@ PetscErrorCode MatCreate_SeqBAIJHIPMI355X(Mat B) {
   B->spptr = d;
   B->ops->mult        = MatMult_SeqAIJHIP;            /* bs > 1: mi355x_spmv_bsr_planned / mi355x_spmv_bsr4_mfma (-mat_hipmi355x_baij4) */
   B->ops->multadd     = MatMultAdd_SeqAIJHIP;
+  B->ops->multtranspose    = MatMultTranspose_SeqAIJHIP;      /* MatMultTranspose_SeqBAIJ / MatMultTransposeAdd_SeqBAIJ, baij2.c:1579, 1740: the block transpose */
+  B->ops->multtransposeadd = MatMultTransposeAdd_SeqAIJHIP;
   B->ops->assemblyend = MatAssemblyEnd_SeqBAIJHIPMI355X;
   B->ops->destroy     = MatDestroy_SeqBAIJHIPMI355X;
   B->ops->getvecs     = MatGetVecs_HIP;

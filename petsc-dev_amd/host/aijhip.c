@@ -387,6 +387,45 @@ static PetscErrorCode upload_transpose(Mat A) {
   /* the device copy of A first: building it discards everything that belonged to an older pattern, a cached transpose included
    * (device_free), so it must not happen between the check below and the use of the cached arrays */
   ierr = MatSeqAIJHIPUpload(A);CHKERRQ(ierr);
+  if (a->bs > 1) {
+    /* BAIJ (MatMultTranspose_SeqBAIJ / MatMultTransposeAdd_SeqBAIJ, baij2.c:1579, 1740): the block transpose -- block rows and columns
+     * exchanged by the same stable counting sort (an output row's contributions in increasing original block row, the order the
+     * reference's scatter loop adds them in), every bs x bs block (column-major, baij.h:13-30) transposed -- built on the host whenever
+     * the matrix moved, then A^T x is the row-block BCSR kernel over it. */
+    PetscInt mbs = a->m, bs = a->bs, bs2 = bs * bs, nbs = a->n / bs, nzb = a->nz;      /* (a->m counts block rows, a->n scalar columns) */
+    PetscInt *ti, *tj, *next, *sc; PetscScalar *ta;
+    ierr = PetscMalloc(sizeof(PetscInt) * (size_t)(nbs + 1), &ti);CHKERRQ(ierr);
+    ierr = PetscMalloc(sizeof(PetscInt) * (size_t)PetscMax(nzb, 1), &tj);CHKERRQ(ierr);
+    ierr = PetscMalloc(sizeof(PetscScalar) * (size_t)PetscMax(nzb, 1) * (size_t)bs2, &ta);CHKERRQ(ierr);
+    ierr = PetscMalloc(sizeof(PetscInt) * (size_t)PetscMax(nbs, 1), &next);CHKERRQ(ierr);
+    memset(ti, 0, sizeof(PetscInt) * (size_t)(nbs + 1));
+    for (PetscInt k = 0; k < nzb; k++) ti[a->j[k] + 1]++;
+    for (PetscInt c = 0; c < nbs; c++) ti[c + 1] += ti[c];
+    for (PetscInt c = 0; c < nbs; c++) next[c] = ti[c];
+    for (PetscInt r = 0; r < mbs; r++)
+      for (PetscInt k = a->i[r]; k < a->i[r + 1]; k++) {
+        PetscInt p = next[a->j[k]]++;
+        const PetscScalar *blk = a->a + (size_t)k * bs2; PetscScalar *tb = ta + (size_t)p * bs2;
+        tj[p] = r;
+        for (PetscInt c = 0; c < bs; c++) for (PetscInt q = 0; q < bs; q++) tb[c * bs + q] = blk[q * bs + c];
+      }
+    if (d->t_i) { mi355x_free(d->t_i); mi355x_free(d->t_j); mi355x_free(d->t_a); mi355x_spmv_plan_destroy(d->t_plan); d->t_plan = NULL; d->t_i = NULL; }
+    CHKHIP(mi355x_malloc((void **)&d->t_i, sizeof(PetscInt) * (size_t)(nbs + 1)));
+    CHKHIP(mi355x_malloc((void **)&d->t_j, sizeof(PetscInt) * (size_t)PetscMax(nzb, 1) + 16));
+    CHKHIP(mi355x_malloc((void **)&d->t_a, sizeof(PetscScalar) * (size_t)PetscMax(nzb, 1) * (size_t)bs2 + 16));
+    CHKHIP(mi355x_memcpy_h2d(dc->h, d->t_i, ti, sizeof(PetscInt) * (size_t)(nbs + 1)));
+    CHKHIP(mi355x_memcpy_h2d(dc->h, d->t_j, tj, sizeof(PetscInt) * (size_t)nzb));
+    CHKHIP(mi355x_memcpy_h2d(dc->h, d->t_a, ta, sizeof(PetscScalar) * (size_t)nzb * (size_t)bs2));
+    ierr = PetscMalloc(sizeof(PetscInt) * (size_t)(nbs + 1), &sc);CHKERRQ(ierr);
+    for (PetscInt c = 0; c <= nbs; c++) sc[c] = ti[c] * bs2;            /* the plan partitions the VALUE stream (as the matrix's own) */
+    CHKHIP(mi355x_spmv_plan_create(dc->h, nbs, sc, NULL, &d->t_plan));
+    CHKHIP(mi355x_handle_synchronize(dc->h));
+    HipFree(ti); HipFree(tj); HipFree(ta); HipFree(next); HipFree(sc);
+    d->t_state = HipObjState(A);
+    d->t_pattern_nz = nzb;
+    d->t_builds++;
+    return 0;
+  }
   if (d->t_a && d->t_perm && d->t_pattern_nz == a->nz && d->pattern_nz == a->nz) {
     /* only the VALUES changed since the transpose was built (a time step, a Newton iteration, MatScale / MatDiagonalScale /
      * MatSetValuesBatch on the device copy): A^T's values are the matrix's values in another order, and that order -- the
@@ -857,13 +896,13 @@ static PetscErrorCode MatMultTransposeAdd_SeqAIJHIP(Mat A, Vec xx, Vec zz, Vec y
   PetscErrorCode ierr;
   HipAIJ *a = SA(A); Mat_SeqAIJHIP *d = SD(A);
   const PetscScalar *x, *z; PetscScalar *y; PetscDeviceCtx *dc;
-  if (a->bs > 1) SETERRQ(HipObjComm(A), PETSC_ERR_SUP, "MatMultTranspose for the BAIJ type is outside the ported path");
   ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
   ierr = upload_transpose(A);CHKERRQ(ierr);
   ierr = VecHIPGetRead(xx, &x);CHKERRQ(ierr);
   if (zz == yy) { ierr = VecHIPGetReadWrite(yy, &y);CHKERRQ(ierr); z = y; }
   else { ierr = VecHIPGetRead(zz, &z);CHKERRQ(ierr); ierr = VecHIPGetWrite(yy, &y);CHKERRQ(ierr); }
-  CHKHIP(mi355x_spmv_csr_add(dc->h, d->t_plan, d->t_i, d->t_j, d->t_a, x, z, y));
+  if (a->bs > 1) CHKHIP(mi355x_spmv_bsr_planned_add(dc->h, d->t_plan, a->bs, d->t_i, d->t_j, d->t_a, x, z, y));   /* MatMultTransposeAdd_SeqBAIJ, baij2.c:1740 */
+  else CHKHIP(mi355x_spmv_csr_add(dc->h, d->t_plan, d->t_i, d->t_j, d->t_a, x, z, y));
   ierr = VecHIPRestoreWrite(yy);CHKERRQ(ierr);
   ierr = PetscLogFlops(2.0 * a->nz);CHKERRQ(ierr);
   return 0;
@@ -872,13 +911,13 @@ static PetscErrorCode MatMultTranspose_SeqAIJHIP(Mat A, Vec xx, Vec yy) {   /* a
   PetscErrorCode ierr;
   HipAIJ *a = SA(A); Mat_SeqAIJHIP *d = SD(A);
   const PetscScalar *x; PetscScalar *y; PetscDeviceCtx *dc;
-  if (a->bs > 1) SETERRQ(HipObjComm(A), PETSC_ERR_SUP, "MatMultTranspose for the BAIJ type is outside the ported path");
   ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
   ierr = upload_transpose(A);CHKERRQ(ierr);
   ierr = VecHIPGetRead(xx, &x);CHKERRQ(ierr);
   ierr = VecHIPGetWrite(yy, &y);CHKERRQ(ierr);
   /* 0 + p1 + p2 ... == p1 + p2 ... bit for bit, so the plain product kernel serves */
-  CHKHIP(mi355x_spmv_csr(dc->h, d->t_plan, d->t_i, d->t_j, d->t_a, x, y));
+  if (a->bs > 1) CHKHIP(mi355x_spmv_bsr_planned(dc->h, d->t_plan, a->bs, d->t_i, d->t_j, d->t_a, x, y));          /* MatMultTranspose_SeqBAIJ, baij2.c:1579 */
+  else CHKHIP(mi355x_spmv_csr(dc->h, d->t_plan, d->t_i, d->t_j, d->t_a, x, y));
   ierr = VecHIPRestoreWrite(yy);CHKERRQ(ierr);
   ierr = PetscLogFlops(2.0 * a->nz);CHKERRQ(ierr);
   return 0;

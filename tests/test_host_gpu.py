@@ -306,6 +306,20 @@ def test_baij_matmult(P, bs, opt):
     B = P.Mat(Bh)
     L.MatMult(B.h, vx.h, vw.h)                           # (the copy reads the options anew: bs = 4 may take the other kernel than A did)
     assert np.allclose(vw.array(), ref2, rtol=0, atol=1e-12 * 50)
+    # MatMultTranspose_SeqBAIJ / MatMultTransposeAdd_SeqBAIJ (baij2.c:1579, 1740) against the scalar matrix's transpose product
+    Sp = sp.bsr_matrix((ba2.transpose(0, 2, 1), bj, bi), shape=(mbs * bs, mbs * bs)).tocsr()   # blocks [column][row] -> [row][column]
+    reft = Sp.T @ x
+    scale = np.abs(Sp.T) @ np.abs(x)
+    L.MatMultTranspose(A.h, vx.h, vy.h)
+    assert np.all(np.abs(vy.array() - reft) <= 1e-12 * scale + 1e-300)
+    vz2 = V(P, y0)
+    L.MatMultTransposeAdd(A.h, vx.h, vz2.h, vw.h)
+    assert np.all(np.abs(vw.array() - (y0 + reft)) <= 1e-12 * (scale + np.abs(y0)) + 1e-300)
+    L.MatMultTransposeAdd(A.h, vx.h, vz2.h, vz2.h)
+    assert np.all(np.abs(vz2.array() - (y0 + reft)) <= 1e-12 * (scale + np.abs(y0)) + 1e-300)
+    L.MatScale(A.h, 2.0)                                 # the block transpose follows the matrix
+    L.MatMultTranspose(A.h, vx.h, vy.h)
+    assert np.all(np.abs(vy.array() - 2.0 * reft) <= 2e-12 * scale + 1e-300)
 
 
 @pytest.mark.parametrize("pc,opts", [("jacobi", ""), ("none", ""), ("ilu", ""), ("jacobi", "-ksp_gmres_restart 7"), ("jacobi", "-ksp_gmres_restart 40"),
