@@ -132,6 +132,7 @@ template <int ADD> __device__ __forceinline__ double spmv_out(double yv, double 
 template <int ADD> __device__ __forceinline__ double spmv_empty(double yv) { return ADD == 1 ? yv : (ADD == 2 ? yv * 0.0 : 0.0); }
 // same, for a sum that was started from yv when ADD == 1
 template <int ADD> __device__ __forceinline__ double spmv_fin(double yv, double s) { return ADD == 2 ? yv * s : s; }
+static inline int spmv_y_streams(long nrows) { return (size_t)nrows * sizeof(double) >= ((size_t)256 << 20); }   // (vec_kernels.hip: vec_streams)
 
 template <int ADD, bool CPROW, bool VEC>
 __global__ __launch_bounds__(SPMV_THREADS, SPMV_MINWAVES) void spmv_csr_rowblock_kernel(
@@ -425,7 +426,7 @@ template <int ADD, bool DOT>
 __global__ __launch_bounds__(SPMV_THREADS, SPMV_MINWAVES) void spmv_csr_rowblock_pat_kernel(
     const int2 *__restrict__ rowblk, int nblocks, const unsigned int *__restrict__ prow,
     const int *__restrict__ pattab_g, const double *__restrict__ aa, const double *__restrict__ x, const double *yin, double *yout,
-    double *__restrict__ dotpart, int pairsum, int ch) {
+    double *__restrict__ dotpart, int pairsum, int ch, int nty) {
   __shared__ double vs[SPMV_BLOCK_NNZ];
   __shared__ int pattab[SPMV_PAT_CAP];
   __shared__ double wdot[DOT ? SPMV_THREADS / MI355X_WAVE : 1];
@@ -498,11 +499,9 @@ __global__ __launch_bounds__(SPMV_THREADS, SPMV_MINWAVES) void spmv_csr_rowblock
     }
   }
   const double yv = spmv_fin<ADD>(ysum, sum);
-#if defined(SPMV_NT_Y) && SPMV_NT_Y
-  if (tid < nrows) __builtin_nontemporal_store(yv, yout + r0 + tid);
-#else
-  if (tid < nrows) yout[r0 + tid] = yv;
-#endif
+  // y beyond the Infinity Cache (vectors of >= 256 MiB) is written once and read by another kernel much later: a non-temporal store
+  // there (+3 % on P7(512), three of three alternations on one box: profiles/r04_spmv_p7_512_ab.log; nothing either way at P7(256))
+  if (tid < nrows) { if (nty) __builtin_nontemporal_store(yv, yout + r0 + tid); else yout[r0 + tid] = yv; }
   if (DOT) {
     const double c = wave_sum(tid < nrows ? yv * x[xbase] : 0.0);
     if ((tid & (MI355X_WAVE - 1)) == 0) wdot[tid / MI355X_WAVE] = c;
@@ -967,7 +966,7 @@ static int launch_spmv(mi355x_handle_t h, mi355x_spmv_plan_t p, const int *ai, c
     const int gp = p->nblocks;
 #endif
     hipLaunchKernelGGL((spmv_csr_rowblock_pat_kernel<ADD, false>), dim3(gp), dim3(SPMV_THREADS), 0, h->stream, p->d_rowblk, p->nblocks,
-                       p->d_prow, p->d_pattab, aa, x, yin, yout, (double *)nullptr, p->pairsum, p->ch);
+                       p->d_prow, p->d_pattab, aa, x, yin, yout, (double *)nullptr, p->pairsum, p->ch, spmv_y_streams(p->nrows));
     MI355X_LAUNCH_CHECK();
     return 0;
   }
@@ -1514,7 +1513,7 @@ int mi355x_spmv_csr_dot(mi355x_handle_t h, mi355x_spmv_plan_t p, const int *ai, 
     const int perp = MI355X_NXCD * p->ch;
     const int gp = SPMV_REMAP == 2 ? ((p->nblocks + perp - 1) / perp) * perp : p->nblocks;
     hipLaunchKernelGGL((spmv_csr_rowblock_pat_kernel<0, true>), dim3(gp), dim3(SPMV_THREADS), 0, h->stream, p->d_rowblk, p->nblocks,
-                       p->d_prow, p->d_pattab, aa, x, (const double *)nullptr, y, p->d_dotpart, p->pairsum, p->ch);
+                       p->d_prow, p->d_pattab, aa, x, (const double *)nullptr, y, p->d_dotpart, p->pairsum, p->ch, spmv_y_streams(p->nrows));
     p->ndotpart = p->nblocks;
   } else {
     hipLaunchKernelGGL((spmv_csr_rowblock_idx8_kernel<0, true>), dim3(g8), dim3(SPMV_THREADS), 0, h->stream, p->d_rowblk,
