@@ -458,6 +458,23 @@ def main():
                                             "what": "one-double ncclAllReduce on the compute stream's communicator, 50 repetitions; the fused CG makes 2 per iteration "
                                                     "(p'w; the update's three sums in one), KSPSolve_CG op by op 3" if not staged else "host-staged transport: not measured"}
         out["multi_gpu"] = mg
+        # ---- self-checks of the N-rank line (every rank asserts; outside the timed region): the parallel product with its halo
+        # exchange applied to 1 must give the operator's row sums on this rank's rows -- a halo that brought the wrong planes, or none,
+        # cannot pass --, and the solve must have reduced the true residual b - A x, recomputed with separate calls
+        ai_, aj_, aa_ = case.csr
+        ychk = case.u.duplicate()
+        case.A.mult(case.u, ychk)
+        rows_ok = torch.tensor([1.0 if np.array_equal(ychk.array(), np.add.reduceat(aa_, ai_[:-1].astype(np.int64))) else 0.0], dtype=torch.float64)
+        dist.all_reduce(rows_ok, op=dist.ReduceOp.MIN)                                     # every rank learns whether ALL passed: rank 0 prints no line otherwise
+        assert rows_ok.item() == 1.0, "A*1 through MatMult_MPIAIJ differs from the operator's row sums on some rank"
+        case.A.mult(case.x, ychk)
+        L.VecAYPX(ychk.h, -1.0, case.b.h)
+        nr_, nb_ = C.c_double(), C.c_double()
+        L.VecNorm(ychk.h, P.NORM_2, C.byref(nr_))                                          # collective
+        L.VecNorm(case.b.h, P.NORM_2, C.byref(nb_))
+        assert nr_.value / nb_.value < 1.0, "the %d-rank solve does not reduce the residual" % world
+        out["checks"] = {"mpiaij_spmv_times_ones_equals_row_sums_on_every_rank": True, "true_residual_after_K_steps": nr_.value / nb_.value}
+        del ychk
 
     if world == 1 and not args.headline_only:
         nvpat = case.nvpat
