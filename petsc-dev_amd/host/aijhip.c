@@ -192,6 +192,7 @@ static PetscErrorCode device_free(Mat A) {
   if (d->t_j) mi355x_free(d->t_j);
   if (d->t_a) mi355x_free(d->t_a);
   if (d->t_plan) mi355x_spmv_plan_destroy(d->t_plan);
+  if (d->t_tiled) { mi355x_spmv_tiled_destroy(d->t_tiled); d->t_tiled = NULL; }
   if (d->t_perm) mi355x_free(d->t_perm);
   if (d->tiled) mi355x_spmv_tiled_destroy(d->tiled);
   if (d->bm_order) mi355x_free(d->bm_order);
@@ -432,6 +433,7 @@ static PetscErrorCode upload_transpose(Mat A) {
      * permutation of the counting sort below -- is on the device.  One gather kernel over the current device values; nothing
      * is rebuilt on the host, nothing crosses PCIe beyond what MatSeqAIJHIPUpload needed for the matrix itself. */
     CHKHIP(mi355x_pack(dc->h, (size_t)a->nz, d->t_perm, d->d_a, d->t_a));
+    if (d->t_tiled) CHKHIP(mi355x_spmv_tiled_refresh_values(dc->h, d->t_tiled, d->t_a));
     d->t_state = HipObjState(A);
     d->t_refreshes++;
     return 0;
@@ -450,6 +452,7 @@ static PetscErrorCode upload_transpose(Mat A) {
   for (PetscInt r = 0; r < m; r++)
     for (PetscInt k = a->i[r]; k < a->i[r + 1]; k++) { PetscInt p = next[a->j[k]]++; tj[p] = r; ta[p] = a->a[k]; perm[p] = k; }
   if (d->t_i) { mi355x_free(d->t_i); mi355x_free(d->t_j); mi355x_free(d->t_a); mi355x_spmv_plan_destroy(d->t_plan); d->t_plan = NULL; }
+  if (d->t_tiled) { mi355x_spmv_tiled_destroy(d->t_tiled); d->t_tiled = NULL; }
   if (d->t_perm) { mi355x_free(d->t_perm); d->t_perm = NULL; }
   CHKHIP(mi355x_malloc((void **)&d->t_perm, sizeof(PetscInt) * (size_t)PetscMax(nz, 1)));
   CHKHIP(mi355x_memcpy_h2d(dc->h, d->t_perm, perm, sizeof(PetscInt) * (size_t)nz));
@@ -470,6 +473,17 @@ static PetscErrorCode upload_transpose(Mat A) {
     }
   }
   CHKHIP(mi355x_handle_synchronize(dc->h));
+  if (d->tiled) {
+    /* the matrix took the column-tiled product (its gathers miss the caches): so do its transpose's, whose rows pick their columns
+     * from the same wide windows.  Same rule: kept if at least half of the nonzeros fall into pairs worth staging. */
+    PetscInt tl = -1, smin = 0; long staged = 0, rest = 0;
+    ierr = hip_mat_option(A, HOPT_TILED, &tl);CHKERRQ(ierr);
+    ierr = hip_mat_option(A, HOPT_TILED_SMIN, &smin);CHKERRQ(ierr);
+    CHKHIP(mi355x_spmv_tiled_build(n, m, ti, tj, (int)smin, &d->t_tiled));
+    CHKHIP(mi355x_spmv_tiled_info(d->t_tiled, &staged, &rest, NULL, NULL, NULL));
+    if (tl < 0 && 2 * staged < (long)nz) { mi355x_spmv_tiled_destroy(d->t_tiled); d->t_tiled = NULL; }
+    else { CHKHIP(mi355x_spmv_tiled_upload(dc->h, d->t_tiled, d->t_a)); CHKHIP(mi355x_spmv_tiled_drop_host(d->t_tiled)); }
+  }
   HipFree(ti); HipFree(tj); HipFree(ta); HipFree(next); HipFree(perm);
   d->t_state = HipObjState(A);
   d->t_pattern_nz = nz;
@@ -902,7 +916,11 @@ static PetscErrorCode MatMultTransposeAdd_SeqAIJHIP(Mat A, Vec xx, Vec zz, Vec y
   if (zz == yy) { ierr = VecHIPGetReadWrite(yy, &y);CHKERRQ(ierr); z = y; }
   else { ierr = VecHIPGetRead(zz, &z);CHKERRQ(ierr); ierr = VecHIPGetWrite(yy, &y);CHKERRQ(ierr); }
   if (a->bs > 1) CHKHIP(mi355x_spmv_bsr_planned_add(dc->h, d->t_plan, a->bs, d->t_i, d->t_j, d->t_a, x, z, y));   /* MatMultTransposeAdd_SeqBAIJ, baij2.c:1740 */
-  else CHKHIP(mi355x_spmv_csr_add(dc->h, d->t_plan, d->t_i, d->t_j, d->t_a, x, z, y));
+  else {
+    int rc = 801;
+    if (d->t_tiled) { rc = mi355x_spmv_tiled(dc->h, d->t_tiled, x, z, y); if (rc && rc != 801) CHKHIP(rc); }
+    if (rc) CHKHIP(mi355x_spmv_csr_add(dc->h, d->t_plan, d->t_i, d->t_j, d->t_a, x, z, y));
+  }
   ierr = VecHIPRestoreWrite(yy);CHKERRQ(ierr);
   ierr = PetscLogFlops(2.0 * a->nz);CHKERRQ(ierr);
   return 0;
@@ -917,7 +935,11 @@ static PetscErrorCode MatMultTranspose_SeqAIJHIP(Mat A, Vec xx, Vec yy) {   /* a
   ierr = VecHIPGetWrite(yy, &y);CHKERRQ(ierr);
   /* 0 + p1 + p2 ... == p1 + p2 ... bit for bit, so the plain product kernel serves */
   if (a->bs > 1) CHKHIP(mi355x_spmv_bsr_planned(dc->h, d->t_plan, a->bs, d->t_i, d->t_j, d->t_a, x, y));          /* MatMultTranspose_SeqBAIJ, baij2.c:1579 */
-  else CHKHIP(mi355x_spmv_csr(dc->h, d->t_plan, d->t_i, d->t_j, d->t_a, x, y));
+  else {
+    int rc = 801;
+    if (d->t_tiled) { rc = mi355x_spmv_tiled(dc->h, d->t_tiled, x, NULL, y); if (rc && rc != 801) CHKHIP(rc); }
+    if (rc) CHKHIP(mi355x_spmv_csr(dc->h, d->t_plan, d->t_i, d->t_j, d->t_a, x, y));
+  }
   ierr = VecHIPRestoreWrite(yy);CHKERRQ(ierr);
   ierr = PetscLogFlops(2.0 * a->nz);CHKERRQ(ierr);
   return 0;

@@ -200,6 +200,7 @@ typedef struct {
   /* column-tiled form of the product (csrc/spmv_tiled.hip: x staged in LDS) for matrices whose gathers miss the caches; NULL: the
    * row-block kernels.  tiled_fresh: its values are those of d_a */
   mi355x_spmv_tiled_t tiled; PetscBool tiled_fresh;
+  mi355x_spmv_tiled_t t_tiled;        /* the column-tiled form of the cached transpose (built when the matrix itself took that form) */
   PetscInt opt[8]; PetscBool opt_set[8];   /* the type's options as MatSetFromOptions read them under the matrix's prefix (host/aijhip.c) */
   /* per-launch device timing for bench.py (hipEvent pairs on the compute stream) */
   PetscBool timing; PetscInt time_n, time_cap; mi355x_event_t *time_ev;

@@ -203,6 +203,25 @@ def test_mat_type_chooses_the_tiled_product_and_keeps_it_current(built):
     L.MatMultAdd(A.h, x.h, z.h, w.h)
     refadd = orc.spmv_add(ai, aj, aa2, xh, z.array())
     assert np.all(np.abs(w.array() - refadd) <= tol(aa2) + 1e-12 * np.abs(z.array()))
+    # the cached transpose of such a matrix takes the column-tiled form too (MatMultTranspose / MatMultTransposeAdd, aij.c:1078, 1124),
+    # and follows a device-side change of the values without a rebuild
+    import scipy.sparse as sp
+    S2 = sp.csr_matrix((aa2, aj, ai), shape=(m, n))
+    xt = P.Vec.from_array(np.sin(0.2 * np.arange(m)) + 0.3, comm=L.COMM_SELF)
+    yt = x.duplicate()
+    L.MatMultTranspose(A.h, xt.h, yt.h)
+    tolt = 1e-12 * (abs(S2).T @ np.abs(xt.array())) + 1e-300
+    assert np.all(np.abs(yt.array() - S2.T @ xt.array()) <= tolt)
+    zt = P.Vec.from_array(np.cos(np.arange(n) * 0.02), comm=L.COMM_SELF)
+    wt = zt.duplicate()
+    L.MatMultTransposeAdd(A.h, xt.h, zt.h, wt.h)
+    assert np.all(np.abs(wt.array() - (zt.array() + S2.T @ xt.array())) <= tolt + 1e-12 * np.abs(zt.array()))
+    L.MatScale(A.h, 0.5)
+    L.MatMultTranspose(A.h, xt.h, yt.h)
+    assert np.all(np.abs(yt.array() - 0.5 * (S2.T @ xt.array())) <= tolt)
+    nb_, nr_ = C.c_int(), C.c_int()
+    L.MatHIPMI355XGetTransposeCounts(A.h, C.byref(nb_), C.byref(nr_))
+    assert nb_.value == 1 and nr_.value >= 1                     # built once, refreshed on the device
     # a 7-point stencil never takes it, forced or not (it has an offset dictionary)
     L.PetscOptionsInsertString(b"-mat_hipmi355x_tiled 1")
     ai7, aj7, aa7 = P.gen_poisson7(20, 20, 20)

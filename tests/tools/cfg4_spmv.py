@@ -70,6 +70,17 @@ def main():
     L.MatHIPMI355XSetTiming(A.h, 0)
     t = tms.value / nl.value * 1e-3
     print("%s MatMult: %.4f ms  %.1f GB/s of CSR-algorithmic bytes (%d B) = %.3f of 8 TB/s" % (which, t * 1e3, B / t / 1e9, B, B / t / 8e12), flush=True)
+    if os.environ.get("CFG4_TRANSPOSE"):                 # the cached transpose's product (wall clock over `reps` products, one host wait at the end)
+        t0 = time.time()
+        L.MatMultTranspose(A.h, x.h, y.h)
+        y.array()
+        print("first MatMultTranspose (transpose built, uploaded) %.2fs" % (time.time() - t0), flush=True)
+        t0 = time.time()
+        for _ in range(reps):
+            L.MatMultTranspose(A.h, x.h, y.h)
+        y.array()
+        tt = (time.time() - t0) / reps
+        print("%s MatMultTranspose: %.4f ms  = %.3f of 8 TB/s (wall clock incl. one read-back of y per %d products)" % (which, tt * 1e3, B / tt / 8e12, reps), flush=True)
     if n <= 200000:
         import orc
         ref = orc.spmv(ai, aj, aa, np.sin(0.37 * np.arange(n)) + 1.0)
