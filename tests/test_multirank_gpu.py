@@ -101,6 +101,8 @@ def test_bench_started_plainly_with_gpus_2_starts_two_ranks(built):
     s = d["strong"]                                   # the strong-scaling point rides along: the cube P7(80) in two slabs
     assert s["scaling"] == "strong" and s["n_gpus"] == 2 and s["rows_total"] == 80 ** 3 and s["rows_per_gpu"] == 80 ** 3 // 2 and s["value"] > 0
     assert s["multi_gpu"]["halo_bytes_per_neighbour_per_spmv"] == 8 * 80 * 80
+    ck = d["checks"]                                  # the N-rank line checks itself: the halo-carrying product against the row sums on every rank
+    assert ck["mpiaij_spmv_times_ones_equals_row_sums_on_every_rank"] is True and 0.0 < ck["true_residual_after_K_steps"] < 1.0
     # not asked for: two ranks on one card are refused, with no line at all
     env.pop("MI355X_STAGED")
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
