@@ -30,6 +30,11 @@
 //     At 12 bytes the staged part moves 1.2 GB in 0.19 ms: HBM's rate.  10-byte entries (a 16-bit word: column, 3-bit row step, rows
 //     rebuilt by two 64-lane prefix sums per block) were built, pass the same tests and are slower, 0.207 ms: the prefix sums'
 //     instructions cost more than the bytes save (profiles/r04_tiled_10byte_entries.log).
+// What the form pays for: lanes of one ds_add_f64 that meet on one accumulator are serialised, so a matrix whose rows have MANY entries
+// in one tile runs badly here (the FEM stand-in, 77 entries per row in a handful of tiles, forced through it: 0.62 ms against 0.25 for
+// the grouped-row kernel, profiles/r04_fem_tiled_try.log).  The Mat type's selection rule does not admit such matrices: more than half
+// a line of x per nonzero in 32-row groups means fewer than 8 entries per row and tile, and matrices with inodes or an offset
+// dictionary keep their kernels (host/aijhip.c).
 // Arithmetic: a*x rounded, then added (-ffp-contract=off).  Entry q of a block is stored at position 2 (q mod 64) + q div 64: lane l's
 // pair is entries l and 64 + l, so the block's first ds_add_f64 instruction adds entries 0..63 and the second 64..127, and lanes of one
 // instruction that meet on one accumulator are added in ascending lane order (measured: dense_atomic_probe; asserted by the GPU tests'
