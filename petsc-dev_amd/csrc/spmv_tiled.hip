@@ -32,7 +32,9 @@
 //     instructions cost more than the bytes save (profiles/r04_tiled_10byte_entries.log).
 // What the form pays for: lanes of one ds_add_f64 that meet on one accumulator are serialised, so a matrix whose rows have MANY entries
 // in one tile runs badly here (the FEM stand-in, 77 entries per row in a handful of tiles, forced through it: 0.62 ms against 0.25 for
-// the grouped-row kernel, profiles/r04_fem_tiled_try.log).  The Mat type's selection rule does not admit such matrices: more than half
+// the grouped-row kernel, profiles/r04_fem_tiled_try.log; with a run ordered "entry j of every row, j = 0, 1, .." instead of row after
+// row, so that the lanes meet on different sums, 0.49 ms -- and the value refresh twice as slow, its gather then jumping rows with
+// every entry: r04_tiled_jorder.log; not kept).  The Mat type's selection rule does not admit such matrices: more than half
 // a line of x per nonzero in 32-row groups means fewer than 8 entries per row and tile, and matrices with inodes or an offset
 // dictionary keep their kernels (host/aijhip.c).
 // Arithmetic: a*x rounded, then added (-ffp-contract=off).  Entry q of a block is stored at position 2 (q mod 64) + q div 64: lane l's
