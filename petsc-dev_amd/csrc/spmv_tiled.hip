@@ -47,6 +47,8 @@
 #include "common.hpp"
 #include <algorithm>
 #include <atomic>
+#include <memory>
+#include <new>
 #include <thread>
 #include <vector>
 #include <string.h>
@@ -245,11 +247,18 @@ int mi355x_spmv_tiled_probe(int m, const int *ai, const int *aj, double *lines_p
 }
 
 // Host part: cut the CSR matrix into staged (panel, tile) streams + remainder.  No device call.  stage_min <= 0: the default (1024).
+static int tl_build_impl(int m, int n, const int *ai, const int *aj, int stage_min, mi355x_spmv_tiled_t *out);
 int mi355x_spmv_tiled_build(int m, int n, const int *ai, const int *aj, int stage_min, mi355x_spmv_tiled_t *out) {
   *out = nullptr;
   if (m < 0 || n < 0) return (int)hipErrorInvalidValue;
+  try { return tl_build_impl(m, n, ai, aj, stage_min, out); }       // (the layout is a few times the CSR arrays in host memory: an allocation that fails must come back as an error code)
+  catch (const std::bad_alloc &) { *out = nullptr; return (int)hipErrorOutOfMemory; }
+  catch (...) { *out = nullptr; return (int)hipErrorUnknown; }
+}
+static int tl_build_impl(int m, int n, const int *ai, const int *aj, int stage_min, mi355x_spmv_tiled_t *out) {
   if (stage_min <= 0) stage_min = 1024;
-  tl_host *H = new tl_host();
+  std::unique_ptr<tl_host> Hown(new tl_host());
+  tl_host *H = Hown.get();
   H->m = m; H->n = n; H->nnz = m ? ai[m] : 0;
   // panels: equal shares of the nonzeros (<= TL_PANEL rows each), and the same number on every CU when there are more than CUs -- the
   // product runs at the rate of the CU with the most panels (306 panels on 256 CUs cost what 512 do: profiles/r04_tiled_sweep5.log)
@@ -296,17 +305,20 @@ int mi355x_spmv_tiled_build(int m, int n, const int *ai, const int *aj, int stag
     int nth = mi355x_host_threads(16);
     if (H->nnz < 2000000) nth = 1;
     if (nth > H->npanels) nth = H->npanels > 0 ? H->npanels : 1;
-    std::atomic<int> next(0);
+    std::atomic<int> next(0), failed(0);
     auto work = [&]() {
-      std::vector<int> cnt((size_t)ntiles + 1, 0), touched, cur((size_t)TL_PANEL, 0);
-      std::vector<char> stagedflag((size_t)ntiles + 1, 0);
-      for (int p = next.fetch_add(1); p < H->npanels; p = next.fetch_add(1))
-        build_panel(H->prow[(size_t)p], H->prow[(size_t)p + 1], ai, aj, stage_min, cnt, touched, cur, stagedflag, po[(size_t)p]);
+      try {
+        std::vector<int> cnt((size_t)ntiles + 1, 0), touched, cur((size_t)TL_PANEL, 0);
+        std::vector<char> stagedflag((size_t)ntiles + 1, 0);
+        for (int p = next.fetch_add(1); p < H->npanels && !failed.load(); p = next.fetch_add(1))
+          build_panel(H->prow[(size_t)p], H->prow[(size_t)p + 1], ai, aj, stage_min, cnt, touched, cur, stagedflag, po[(size_t)p]);
+      } catch (...) { failed.store(1); }                  // (an exception must not leave a thread)
     };
     std::vector<std::thread> th;
     for (int t = 1; t < nth; ++t) th.emplace_back(work);
     work();
     for (auto &t : th) t.join();
+    if (failed.load()) return (int)hipErrorOutOfMemory;
   }
   // concatenate: panel after panel, inside a panel wavefront after wavefront
   size_t npt = 0, nst = 0;
@@ -314,7 +326,7 @@ int mi355x_spmv_tiled_build(int m, int n, const int *ai, const int *aj, int stag
     npt += o.pt_tile.size(); H->nnz_near += o.near; H->nnz_far += o.far;
     for (int w = 0; w < TL_WAVES; ++w) nst += o.perm[w].size();
   }
-  if (nst >= (size_t)1 << 31) { delete H; return (int)hipErrorInvalidValue; }
+  if (nst >= (size_t)1 << 31) return (int)hipErrorInvalidValue;
   H->pt_ptr.resize((size_t)H->npanels + 1);
   H->pt_tile.reserve(npt); H->pw_e0.reserve((size_t)H->npanels * TL_WAVES + 1); H->wrow.reserve((size_t)H->npanels * (TL_WAVES + 1));
   H->perm.reserve(nst); H->word.reserve(nst);
@@ -337,11 +349,11 @@ int mi355x_spmv_tiled_build(int m, int n, const int *ai, const int *aj, int stag
   H->pw_e0.push_back((int)e);
   H->fw_ptr.push_back((int)H->fw_win.size());
   H->nstore = e;
-  if (H->nnz_near + H->nnz_far != H->nnz) { delete H; return (int)hipErrorUnknown; }
-  if (e != H->nstore) { delete H; return (int)hipErrorUnknown; }
+  if (H->nnz_near + H->nnz_far != H->nnz) return (int)hipErrorUnknown;
+  if (e != H->nstore) return (int)hipErrorUnknown;
   mi355x_spmv_tiled_s *P = new mi355x_spmv_tiled_s();
   memset(P, 0, sizeof(*P));
-  P->host = H;
+  P->host = Hown.release();
   P->m = m; P->n = n; P->npanels = H->npanels; P->npt = (int)H->pt_tile.size();
   P->nnz_near = H->nnz_near; P->nnz_far = H->nnz_far; P->nstore = H->nstore;
   *out = P;
