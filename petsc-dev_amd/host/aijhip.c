@@ -317,9 +317,13 @@ PetscErrorCode MatSeqAIJHIPUpload(Mat A) {
           }
           if (want) {
             long staged = 0, rest = 0;
-            CHKHIP(mi355x_spmv_tiled_build(a->m, a->n, a->i, a->j, (int)smin, &d->tiled));
-            CHKHIP(mi355x_spmv_tiled_info(d->tiled, &staged, &rest, NULL, NULL, NULL));
-            if (tl < 0 && 2 * staged < (long)a->nz) { mi355x_spmv_tiled_destroy(d->tiled); d->tiled = NULL; }
+            int rcb = mi355x_spmv_tiled_build(a->m, a->n, a->i, a->j, (int)smin, &d->tiled);
+            if (rcb && tl > 0) CHKHIP(rcb);                                  /* asked for: report; decided here: the row-block kernels serve (e.g. no host memory for the layout) */
+            if (rcb) d->tiled = NULL;
+            else {
+              CHKHIP(mi355x_spmv_tiled_info(d->tiled, &staged, &rest, NULL, NULL, NULL));
+              if (tl < 0 && 2 * staged < (long)a->nz) { mi355x_spmv_tiled_destroy(d->tiled); d->tiled = NULL; }
+            }
           }
           UP_TICK("column-tiled layout");
         }
@@ -479,10 +483,12 @@ static PetscErrorCode upload_transpose(Mat A) {
     PetscInt tl = -1, smin = 0; long staged = 0, rest = 0;
     ierr = hip_mat_option(A, HOPT_TILED, &tl);CHKERRQ(ierr);
     ierr = hip_mat_option(A, HOPT_TILED_SMIN, &smin);CHKERRQ(ierr);
-    CHKHIP(mi355x_spmv_tiled_build(n, m, ti, tj, (int)smin, &d->t_tiled));
-    CHKHIP(mi355x_spmv_tiled_info(d->t_tiled, &staged, &rest, NULL, NULL, NULL));
-    if (tl < 0 && 2 * staged < (long)nz) { mi355x_spmv_tiled_destroy(d->t_tiled); d->t_tiled = NULL; }
-    else { CHKHIP(mi355x_spmv_tiled_upload(dc->h, d->t_tiled, d->t_a)); CHKHIP(mi355x_spmv_tiled_drop_host(d->t_tiled)); }
+    if (mi355x_spmv_tiled_build(n, m, ti, tj, (int)smin, &d->t_tiled)) d->t_tiled = NULL;   /* (the row-block kernel over the cached transpose serves) */
+    else {
+      CHKHIP(mi355x_spmv_tiled_info(d->t_tiled, &staged, &rest, NULL, NULL, NULL));
+      if (tl < 0 && 2 * staged < (long)nz) { mi355x_spmv_tiled_destroy(d->t_tiled); d->t_tiled = NULL; }
+      else { CHKHIP(mi355x_spmv_tiled_upload(dc->h, d->t_tiled, d->t_a)); CHKHIP(mi355x_spmv_tiled_drop_host(d->t_tiled)); }
+    }
   }
   HipFree(ti); HipFree(tj); HipFree(ta); HipFree(next); HipFree(perm);
   d->t_state = HipObjState(A);
