@@ -68,6 +68,7 @@ def parse_args(argv=None):
                     help="which series `value` reports: weak = n^3 rows per GPU (default; the strong point still rides along as `strong`); "
                          "strong = the cube P7(2n) split over the GPUs, nothing else")
     ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling point")
+    ap.add_argument("--no-stream", action="store_true", help="skip the STREAM-style legs (what the memory system gives the library's own copy / triad / read-only kernels)")
     return ap.parse_args(argv)
 
 
@@ -548,6 +549,41 @@ def main():
         out["checks"] = checks
         L.MatHIPMI355XSetValuePatterns(timed, 1)
         del xs, ys, rv
+
+    if world == 1 and not args.no_stream and not args.headline_only:
+        # ---- what the memory system gives plain streams in THIS run (SURVEY 8d "Roofline": achievable copy / triad rate next to the peak):
+        # the library's own VecCopy (1 read, 1 write), VecWAXPY (2 reads, 1 write) and VecDot (2 reads) on vectors of the workload's
+        # size (134 MB each at 256^3: they partly live in the 256 MB Infinity Cache, as the solve's do) and of 1 GiB (nothing cached);
+        # every call a kernel of its own (no noted operations), wall clock over 20 calls between two device synchronisations
+        setdef = L.raw("VecHIPMI355XSetDeferral")
+        setdef(0)
+        stream = {}
+        for label, nn in (("workload_size", mloc), ("1GiB", 1 << 27)):
+            va = P.Vec.create(nn, comm=comm); vb = va.duplicate(); vc = va.duplicate()
+            L.VecSet(va.h, 1.0); L.VecSet(vb.h, 2.0); L.VecSet(vc.h, 0.0)
+            nrm = C.c_double()
+            res = {"n": int(nn)}
+            for name, nbytes, fn in (("copy", 16 * nn, lambda: L.VecCopy(va.h, vc.h)), ("triad", 24 * nn, lambda: L.VecWAXPY(vc.h, 3.0, va.h, vb.h)),
+                                     ("read", 16 * nn, lambda: L.VecDot(va.h, vb.h, C.byref(nrm)))):
+                for _ in range(3):
+                    fn()
+                k.mi355x_device_synchronize()
+                t0 = time.perf_counter()
+                for _ in range(20):
+                    fn()
+                k.mi355x_device_synchronize()
+                res[name + "_gbps"] = round(nbytes * 20 / (time.perf_counter() - t0) / 1e9, 1)
+            stream[label] = res
+            del va, vb, vc
+        setdef(-1)
+        stream["what"] = ("VecCopy / VecWAXPY / VecDot of this library, 20 calls each between device synchronisations; 'read' (the dot) includes one host wait per call "
+                          "(the sum comes back): a lower bound of the read rate")
+        out["stream"] = stream
+        ach = max(stream["workload_size"]["copy_gbps"], stream["workload_size"]["triad_gbps"])
+        for key in ("roofline", "roofline_spmv", "roofline_cg_update"):
+            if key in out and out[key].get("achieved"):
+                out[key]["frac_of_achievable_stream"] = round(out[key]["achieved"] / ach, 4)
+                out[key]["achievable_stream_gbps"] = ach
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import orc
