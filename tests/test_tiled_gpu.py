@@ -231,3 +231,18 @@ def test_mat_type_chooses_the_tiled_product_and_keeps_it_current(built):
     L.PetscOptionsClear()
     L.MatHIPMI355XGetTiledInfo(A7.h, C.byref(st), C.byref(rm))
     assert st.value == 0 and rm.value == 0
+
+
+@pytest.mark.parametrize("seed", [101, 102, 103, 104, 105, 106])
+def test_tiled_spmv_random_shapes(dev, seed):
+    """Shapes the other cases do not reach: fewer rows than wavefronts, one column, columns spanning several windows of the remainder
+    (2^18 columns each), rows that are all remainder beside rows that are all staged, stage_min between the pairs' sizes."""
+    rng = np.random.default_rng(seed)
+    g = tiled.geometry(dev.k)
+    m = int(rng.choice([1, 3, 7, 65, 400, 1500]))
+    n = int(rng.choice([1, 5, g["tw"] - 1, g["tw"] + 3, 3 * g["tw"], (1 << 18) + 5000, (1 << 19) + 17]))
+    lens = np.minimum(rng.integers(0, 40, m), n)
+    if rng.random() < 0.5:
+        lens[rng.integers(0, m)] = min(n, 700)
+    ai, aj, aa = random_csr(rng, m, n, lens, band=int(rng.choice([3, 200, 5000, n])) , far_frac=float(rng.choice([0.0, 0.3, 1.0])))
+    run_case(dev, ai, aj, aa, n, stage_min=int(rng.choice([1, 8, 64, 10 ** 9])), seed=seed)
