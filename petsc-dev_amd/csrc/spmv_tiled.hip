@@ -64,7 +64,7 @@
                               // gathered line) and pays every further wavefront with padding of its runs: 0.140 ms at 4, 0.152 at 8, 0.166 at 15:
                               // profiles/r04_tiled_sweep10.log, r04_tiled_sweep11.log, r04_tiled_pmc_far.csv)
 #ifndef TL_NG
-#define TL_NG 4               // blocks in flight per wavefront
+#define TL_NG 8               // staged blocks in flight per wavefront (with 4 wavefronts: 2 / 4 / 6 / 8 -> 0.267 / 0.191 / 0.184 / 0.185 ms for the staged part, profiles/r04_tiled_sweep13.log)
 #endif
 #ifndef TL_FG
 #define TL_FG 2               // remainder: blocks whose gathers are in flight per wavefront (their stream loads run another TL_FG blocks ahead; 2 / 4 / 6: the same time)
