@@ -94,6 +94,7 @@ PetscErrorCode MatMPIAIJHIPMI355XGetHaloTiming(Mat A, PetscInt *nproducts, Petsc
 PetscErrorCode MatHIPMI355XGetUploadCount(Mat A, PetscInt *n);   /* value uploads host -> device of a sequential matrix so far */
 PetscErrorCode MatHIPMI355XGetTransposeCounts(Mat A, PetscInt *host_builds, PetscInt *device_refreshes);   /* of the cached explicit A^T behind MatMultTranspose */
 PetscErrorCode MatHIPMI355XGetInodeInfo(Mat A, PetscInt *nodes, PetscInt *groups, PetscInt *shared_indices);   /* Mat_CheckInode's node count; groups / column indices the device plan stores once per group */
+PetscErrorCode MatHIPMI355XGetBlockedInfo(Mat A, PetscInt *bs, PetscInt *nblocks);   /* blocked companion of an AIJ matrix whose nodes are complete bs x bs blocks (products by the BAIJ kernel); 0, 0: not in use */
 PetscErrorCode MatHIPMI355XGetTiledInfo(Mat A, PetscInt *staged, PetscInt *remainder);   /* column-tiled product (x tiles in LDS): nonzeros gathering from LDS / left to the row-block kernel; 0, 0: not in use */
 PetscErrorCode MatHIPMI355XGetRowPatterns(Mat A, PetscInt *npat);   /* 0: none; else the size of the row-pattern dictionary the SpMV runs with */
 PetscErrorCode MatHIPMI355XSetValuePatterns(Mat A, PetscBool on);   /* A/B switch for one matrix until its next upload (the option -mat_hipmi355x_value_patterns decides at every upload) */

@@ -156,9 +156,9 @@ static PetscErrorCode seqaij_check_inode(Mat A) {
  * slot 76, matimpl.h:110; gcreate.c:201-203) reads them under the matrix's own options prefix and keeps them with the matrix; a matrix
  * that was never asked falls back to the global database when its device copy is built (blocks of an MPIAIJ matrix, matrices created
  * by MatCreateSeqAIJWithArrays and used at once). */
-enum { HOPT_IC = 0, HOPT_RP, HOPT_VP, HOPT_TILED, HOPT_TILED_SMIN, HOPT_N };
+enum { HOPT_IC = 0, HOPT_RP, HOPT_VP, HOPT_TILED, HOPT_TILED_SMIN, HOPT_BLOCKED, HOPT_N };
 static const char *const hopt_name[HOPT_N] = {"-mat_hipmi355x_index_compression", "-mat_hipmi355x_row_patterns", "-mat_hipmi355x_value_patterns",
-                                              "-mat_hipmi355x_tiled", "-mat_hipmi355x_tiled_stage_min"};
+                                              "-mat_hipmi355x_tiled", "-mat_hipmi355x_tiled_stage_min", "-mat_hipmi355x_blocked"};
 static PetscErrorCode hip_mat_option(Mat A, int which, PetscInt *val) {
   Mat_SeqAIJHIP *d = SD(A);
   PetscBool set;
@@ -195,6 +195,11 @@ static PetscErrorCode device_free(Mat A) {
   if (d->t_tiled) { mi355x_spmv_tiled_destroy(d->t_tiled); d->t_tiled = NULL; }
   if (d->t_perm) mi355x_free(d->t_perm);
   if (d->tiled) mi355x_spmv_tiled_destroy(d->tiled);
+  if (d->b_i) mi355x_free(d->b_i);
+  if (d->b_j) mi355x_free(d->b_j);
+  if (d->b_a) mi355x_free(d->b_a);
+  if (d->b_perm) mi355x_free(d->b_perm);
+  if (d->b_plan) mi355x_spmv_plan_destroy(d->b_plan);
   if (d->bm_order) mi355x_free(d->bm_order);
   if (d->bm_segptr) mi355x_free(d->bm_segptr);
   if (d->bm_segslot) mi355x_free(d->bm_segslot);
@@ -224,6 +229,64 @@ static PetscErrorCode device_free(Mat A) {
 #if defined(PETSCHIPMI355X_WITH_PETSC)
 static PetscErrorCode hipaij_refresh_view_if_stale(Mat A);   /* integration/petsc-3.3/aijhipmi355x_ctor.h */
 #endif
+/* the blocked companion (see MatSeqAIJHIPUpload): BCSR arrays of an AIJ matrix whose nodes are complete bs x bs blocks; leaves d->b_plan
+ * NULL when the matrix is not of that shape */
+static PetscErrorCode blocked_companion_build(Mat A, PetscDeviceCtx *dc) {
+  PetscErrorCode ierr;
+  HipAIJ *a = SA(A); Mat_SeqAIJHIP *d = SD(A);
+  const PetscInt m = a->m, n = a->n, nn = a->inode_count;
+  if (nn <= 0 || !a->inode_size) return 0;
+  const PetscInt bs = a->inode_size[0];
+  if (bs < 2 || bs > 5 || nn * bs != m || n % bs) return 0;
+  for (PetscInt i = 0; i < nn; i++) if (a->inode_size[i] != bs) return 0;
+  /* every node's column list: whole aligned groups of bs consecutive columns (the rows of a node share the list: check its first row) */
+  PetscInt nblk = 0;
+  for (PetscInt i = 0; i < nn; i++) {
+    const PetscInt r = i * bs, k0 = a->i[r], len = a->i[r + 1] - k0;
+    if (len % bs) return 0;
+    for (PetscInt g = 0; g < len; g += bs) {
+      const PetscInt c0 = a->j[k0 + g];
+      if (c0 % bs) return 0;
+      for (PetscInt q = 1; q < bs; q++) if (a->j[k0 + g + q] != c0 + q) return 0;
+    }
+    for (PetscInt q = 1; q < bs; q++) if (a->i[r + q + 1] - a->i[r + q] != len) return 0;     /* (Mat_CheckInode compared the lists themselves) */
+    nblk += len / bs;
+  }
+  if ((double)nblk * bs * bs > 2147483000.0) return 0;
+  PetscInt *bi, *bj, *perm, *sc;
+  const PetscInt bs2 = bs * bs;
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)(nn + 1), &bi);CHKERRQ(ierr);
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)PetscMax(nblk, 1), &bj);CHKERRQ(ierr);
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)PetscMax(nblk, 1) * (size_t)bs2, &perm);CHKERRQ(ierr);
+  ierr = PetscMalloc(sizeof(PetscInt) * (size_t)(nn + 1), &sc);CHKERRQ(ierr);
+  bi[0] = 0;
+  for (PetscInt i = 0, b = 0; i < nn; i++) {
+    const PetscInt r = i * bs, len = a->i[r + 1] - a->i[r];
+    for (PetscInt g = 0; g < len; g += bs, b++) {
+      bj[b] = a->j[a->i[r] + g] / bs;
+      for (PetscInt c = 0; c < bs; c++) for (PetscInt q = 0; q < bs; q++) perm[(size_t)b * bs2 + c * bs + q] = a->i[r + q] + g + c;   /* value (row q, column c) of the block */
+    }
+    bi[i + 1] = bi[i] + len / bs;
+  }
+  for (PetscInt i = 0; i <= nn; i++) sc[i] = bi[i] * bs2;
+  CHKHIP(mi355x_malloc((void **)&d->b_i, sizeof(PetscInt) * (size_t)(nn + 1)));
+  CHKHIP(mi355x_malloc((void **)&d->b_j, sizeof(PetscInt) * (size_t)PetscMax(nblk, 1) + 16));
+  CHKHIP(mi355x_malloc((void **)&d->b_perm, sizeof(PetscInt) * (size_t)PetscMax(nblk, 1) * (size_t)bs2));
+  CHKHIP(mi355x_malloc((void **)&d->b_a, sizeof(PetscScalar) * (size_t)PetscMax(nblk, 1) * (size_t)bs2 + 16));
+  CHKHIP(mi355x_memcpy_h2d(dc->h, d->b_i, bi, sizeof(PetscInt) * (size_t)(nn + 1)));
+  CHKHIP(mi355x_memcpy_h2d(dc->h, d->b_j, bj, sizeof(PetscInt) * (size_t)nblk));
+  CHKHIP(mi355x_memcpy_h2d(dc->h, d->b_perm, perm, sizeof(PetscInt) * (size_t)nblk * (size_t)bs2));
+  CHKHIP(mi355x_spmv_plan_create(dc->h, nn, sc, NULL, &d->b_plan));
+  CHKHIP(mi355x_handle_synchronize(dc->h));
+  HipFree(bi); HipFree(bj); HipFree(perm); HipFree(sc);
+  d->b_bs = bs; d->b_nblocks = nblk; d->b_fresh = PETSC_FALSE;
+  return 0;
+}
+static PetscErrorCode blocked_values_current(Mat A, PetscDeviceCtx *dc) {      /* after a device-side change of d_a: one gather, when next used */
+  Mat_SeqAIJHIP *d = SD(A);
+  if (d->b_plan && !d->b_fresh) { CHKHIP(mi355x_pack(dc->h, (size_t)SA(A)->nz, d->b_perm, d->d_a, d->b_a)); d->b_fresh = PETSC_TRUE; }
+  return 0;
+}
 PetscErrorCode MatSeqAIJHIPUpload(Mat A) {
   PetscErrorCode ierr;
   HipAIJ *a = SA(A);
@@ -296,6 +359,19 @@ PetscErrorCode MatSeqAIJHIPUpload(Mat A) {
         CHKHIP(mi355x_spmv_plan_is_compressed(d->plan, &ntab));
         if (!ntab && !use_cprow) CHKHIP(mi355x_spmv_plan_group_rows(dc->h, d->plan, a->i, a->j, a->inode_count, a->inode_size));
       }
+      /* -mat_hipmi355x_blocked <-1|0|1> (default -1 = decide): the blocked companion.  When every node Mat_CheckInode found has the same
+       * size bs (2..5) and its shared column list is made of whole aligned groups of bs columns -- the 3-dof matrices of FEM codes
+       * assembled into AIJ: every coupling a complete bs x bs block -- the matrix IS a BAIJ matrix, and MatMult_SeqBAIJ_bs's kernel
+       * reads 8 bs^2 + 4 bytes per block where the grouped-row kernel reads 8 bs^2 + 4 bs: BCSR arrays are laid out beside the CSR ones
+       * (block values column-major, baij.h:13-30, as a permutation of d_a kept on the device) and the products take the BCSR row-block
+       * kernel: FEM stand-in 0.245 -> 0.197 ms, the same sums bit for bit (profiles/r04_fem_as_baij.log).  Decided here only for rows
+       * long enough that the grouped-row kernel does not carry the reference's bits anyway (more than 16 nonzeros per row). */
+      if (a->inode_count && !use_cprow) {
+        PetscInt bl = -1;
+        ierr = hip_mat_option(A, HOPT_BLOCKED, &bl);CHKERRQ(ierr);
+        if (bl != 0 && (bl > 0 || (double)a->nz > 16.0 * (double)a->m)) { ierr = blocked_companion_build(A, dc);CHKERRQ(ierr); }
+        UP_TICK("blocked companion");
+      }
       /* -mat_hipmi355x_tiled <-1|0|1> (default -1 = decide): the column-tiled product (csrc/spmv_tiled.hip).  A matrix that got neither
        * an offset dictionary nor grouped rows gathers x once per nonzero; when a sample of its 32-row groups shows those gathers
        * landing on lines of x of their own (> 0.5 line per nonzero: rows that share no columns with their neighbours -- the
@@ -355,6 +431,11 @@ PetscErrorCode MatSeqAIJHIPUpload(Mat A) {
   UP_TICK("(grouped rows, bookkeeping)");
   CHKHIP(mi355x_memcpy_h2d(dc->h, d->d_a, a->a, sizeof(PetscScalar) * vals));
   UP_TICK("values up");
+  if (d->b_plan) {
+    CHKHIP(mi355x_pack(dc->h, (size_t)a->nz, d->b_perm, d->d_a, d->b_a));
+    d->b_fresh = PETSC_TRUE;
+    UP_TICK("blocked companion's values");
+  }
   if (d->tiled) {
     if (!same_pattern) { CHKHIP(mi355x_spmv_tiled_upload(dc->h, d->tiled, d->d_a)); CHKHIP(mi355x_spmv_tiled_drop_host(d->tiled)); }
     else CHKHIP(mi355x_spmv_tiled_refresh_values(dc->h, d->tiled, d->d_a));
@@ -621,7 +702,7 @@ static PetscErrorCode MatSetValuesBatch_SeqAIJHIP(Mat A, PetscInt nb, PetscInt b
   /* MatSetValuesBatch's wrapper leaves the state alone and the MatAssemblyEnd that has to follow bumps it once: the
    * device copy is stamped with that state, so the assembly does not trigger an upload */
   d->uploaded_state = HipObjState(A) + 1;
-  d->t_state = -1; d->tiled_fresh = PETSC_FALSE;
+  d->t_state = -1; d->tiled_fresh = PETSC_FALSE; d->b_fresh = PETSC_FALSE;
   CHKHIP(mi355x_spmv_plan_drop_value_patterns(d->plan));
   ierr = PetscLogFlops((PetscLogDouble)d->bm_T);CHKERRQ(ierr);
   return 0;
@@ -668,6 +749,7 @@ static PetscErrorCode MatMult_SeqAIJHIP_device(Mat A, Vec xx, Vec yy) {   /* y =
   ierr = MatTimingBegin(A, dc->h);CHKERRQ(ierr);
   if (a->bs == 4 && d->baij4_mfma && !(((size_t)y) & 15)) CHKHIP(mi355x_spmv_bsr4_mfma(dc->h, a->m, 0, d->d_i, d->d_j, d->d_a, x, y));   /* matrix cores: MatMult_SeqBAIJ_4 (16-byte stores of y; a vector borrowing storage at an odd offset takes the FMA kernel) */
   else if (a->bs > 1) CHKHIP(mi355x_spmv_bsr_planned(dc->h, d->plan, a->bs, d->d_i, d->d_j, d->d_a, x, y));
+  else if (d->b_plan) { ierr = blocked_values_current(A, dc);CHKERRQ(ierr); CHKHIP(mi355x_spmv_bsr_planned(dc->h, d->b_plan, (int)d->b_bs, d->b_i, d->b_j, d->b_a, x, y)); }   /* the blocked companion */
   else {
     int rc = 801;
     if (d->tiled) { ierr = tiled_values_current(A, dc);CHKERRQ(ierr); rc = mi355x_spmv_tiled(dc->h, d->tiled, x, NULL, y); if (rc && rc != 801) CHKHIP(rc); }
@@ -706,6 +788,14 @@ PetscErrorCode MatHIPMI355XGetIndexCompression(Mat A, PetscInt *noffsets) {
   ierr = MatSeqAIJHIPUpload(A);CHKERRQ(ierr);
   if (SD(A)->plan && SA(A)->bs <= 1) CHKHIP(mi355x_spmv_plan_is_compressed(SD(A)->plan, &ntab));
   *noffsets = ntab;
+  return 0;
+}
+
+/* the blocked companion of a sequential matrix, if the analysis chose it: block size and number of blocks (0, 0: none) */
+PetscErrorCode MatHIPMI355XGetBlockedInfo(Mat A, PetscInt *bs, PetscInt *nblocks) {
+  *bs = 0; *nblocks = 0;
+  if (!A || A->ops->mult != MatMult_SeqAIJHIP) SETERRQ(HipObjComm(A), PETSC_ERR_ARG_WRONG, "not a sequential HIPMI355X AIJ matrix");
+  if (SD(A)->b_plan) { *bs = SD(A)->b_bs; *nblocks = SD(A)->b_nblocks; }
   return 0;
 }
 
@@ -865,7 +955,7 @@ PetscErrorCode MatMultDiagonalScale_HIPMI355X(Mat A, Vec dd, Vec xx, Vec yy, Pet
   if (a->bs > 1 || xx == yy || dd == yy || xx->map->n != a->n || yy->map->n != a->m || dd->map->n != a->m) return 0;
   ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
   ierr = MatSeqAIJHIPUpload(A);CHKERRQ(ierr);
-  if (!d->plan || d->cprow || d->tiled) return 0;         /* (the column-tiled product has no scaling epilogue: the two calls stay two) */
+  if (!d->plan || d->cprow || d->tiled || d->b_plan) return 0;         /* (the column-tiled and the blocked product have no scaling epilogue: the two calls stay two) */
   ierr = VecHIPGetRead(xx, &x);CHKERRQ(ierr);
   ierr = VecHIPGetRead(dd, &dg);CHKERRQ(ierr);
   ierr = VecHIPGetWrite(yy, &y);CHKERRQ(ierr);
@@ -903,7 +993,8 @@ static PetscErrorCode MatMultAdd_SeqAIJHIP(Mat A, Vec xx, Vec yy, Vec zz) {   /*
     if (d->cprow) { CHKHIP(mi355x_vec_copy(dc->h, (size_t)a->m, y, z)); y = z; }   /* aij.c:1314-1316 */
   }
   ierr = MatTimingBegin(A, dc->h);CHKERRQ(ierr);
-  { int rc = 801;
+  if (d->b_plan && !d->cprow) { ierr = blocked_values_current(A, dc);CHKERRQ(ierr); CHKHIP(mi355x_spmv_bsr_planned_add(dc->h, d->b_plan, (int)d->b_bs, d->b_i, d->b_j, d->b_a, x, y, z)); }
+  else { int rc = 801;
     if (d->tiled) { ierr = tiled_values_current(A, dc);CHKERRQ(ierr); rc = mi355x_spmv_tiled(dc->h, d->tiled, x, y, z); if (rc && rc != 801) CHKHIP(rc); }
     if (rc) CHKHIP(mi355x_spmv_csr_add(dc->h, d->plan, d->d_i, d->d_j, d->d_a, x, y, z)); }
   ierr = MatTimingEnd(A, dc->h);CHKERRQ(ierr);
@@ -996,7 +1087,7 @@ static PetscErrorCode MatScale_SeqAIJHIP(Mat A, PetscScalar alpha) {   /* MatSca
     { PetscErrorCode e__ = VecHIPProductMatrixChanges(A);CHKERRQ(e__); }
     CHKHIP(mi355x_vec_scale(dc->h, vals, alpha, d->d_a));
     d->uploaded_state = HipObjState(A) + 1;
-    d->t_state = -1; d->tiled_fresh = PETSC_FALSE;
+    d->t_state = -1; d->tiled_fresh = PETSC_FALSE; d->b_fresh = PETSC_FALSE;
     CHKHIP(mi355x_spmv_plan_drop_value_patterns(d->plan));
   }
   return PetscLogFlops((PetscLogDouble)vals);
@@ -1013,7 +1104,7 @@ static PetscErrorCode MatZeroEntries_SeqAIJHIP(Mat A) {
     { PetscErrorCode e__ = VecHIPProductMatrixChanges(A);CHKERRQ(e__); }
     CHKHIP(mi355x_memset(dc->h, d->d_a, 0, sizeof(PetscScalar) * vals));
     d->uploaded_state = HipObjState(A) + 1;
-    d->t_state = -1; d->tiled_fresh = PETSC_FALSE;
+    d->t_state = -1; d->tiled_fresh = PETSC_FALSE; d->b_fresh = PETSC_FALSE;
     CHKHIP(mi355x_spmv_plan_drop_value_patterns(d->plan));
   }
   return 0;
@@ -1065,7 +1156,7 @@ static PetscErrorCode MatDiagonalScale_SeqAIJHIP(Mat A, Vec ll, Vec rr) {
     { PetscErrorCode e__ = VecHIPProductMatrixChanges(A);CHKERRQ(e__); }
     CHKHIP(mi355x_csr_diagonal_scale(dc->h, a->m, d->d_i, d->d_j, d->d_a, dl, dr));
     d->uploaded_state = HipObjState(A) + 1;
-    d->t_state = -1; d->tiled_fresh = PETSC_FALSE;
+    d->t_state = -1; d->tiled_fresh = PETSC_FALSE; d->b_fresh = PETSC_FALSE;
     CHKHIP(mi355x_spmv_plan_drop_value_patterns(d->plan));
   }
   if (ll) {

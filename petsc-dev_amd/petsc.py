@@ -50,7 +50,7 @@ _SIG = {
     "MatHIPMI355XSetTiming": [vp, i32], "MatHIPMI355XGetTiming": [vp, P(i32), P(dbl)],
     "MatMPIAIJHIPMI355XSetHaloTiming": [vp, i32], "MatMPIAIJHIPMI355XGetHaloTiming": [vp, P(i32), P(dbl), P(dbl), P(dbl), P(dbl), P(i32)],
     "PetscCommDeviceAllreduceLatency": [vp, i32, P(dbl), P(dbl)],
-    "MatHIPMI355XGetIndexCompression": [vp, P(i32)], "MatHIPMI355XGetRowPatterns": [vp, P(i32)], "MatHIPMI355XGetTiledInfo": [vp, P(i32), P(i32)], "MatHIPMI355XGetValuePatterns": [vp, P(i32)], "MatHIPMI355XSetValuePatterns": [vp, i32], "VecHIPMI355XSetCGUpdateTiming": [i32], "VecHIPMI355XGetCGUpdateTiming": [P(i32), P(dbl)], "MatHIPMI355XGetInodeInfo": [vp, P(i32), P(i32), P(i32)], "MatHIPMI355XGetUploadCount": [vp, P(i32)], "MatHIPMI355XGetTransposeCounts": [vp, P(i32), P(i32)],
+    "MatHIPMI355XGetIndexCompression": [vp, P(i32)], "MatHIPMI355XGetRowPatterns": [vp, P(i32)], "MatHIPMI355XGetTiledInfo": [vp, P(i32), P(i32)], "MatHIPMI355XGetBlockedInfo": [vp, P(i32), P(i32)], "MatHIPMI355XGetValuePatterns": [vp, P(i32)], "MatHIPMI355XSetValuePatterns": [vp, i32], "VecHIPMI355XSetCGUpdateTiming": [i32], "VecHIPMI355XGetCGUpdateTiming": [P(i32), P(dbl)], "MatHIPMI355XGetInodeInfo": [vp, P(i32), P(i32), P(i32)], "MatHIPMI355XGetUploadCount": [vp, P(i32)], "MatHIPMI355XGetTransposeCounts": [vp, P(i32), P(i32)],
     "PetscMiniGenPoisson7": [i32, i32, i32, C.c_long, C.c_long, vp, vp, vp, P(C.c_long)],
     "PetscViewerBinaryOpen": [vp, C.c_char_p, i32, P(vp)], "PetscViewerDestroy": [P(vp)],
     "MatLoad": [vp, vp], "MatView": [vp, vp], "VecLoad": [vp, vp], "VecView": [vp, vp],

@@ -2074,6 +2074,70 @@ def test_fem_like_config4_shape_small(P):
     assert np.linalg.norm(xh - 1.0) < 1e-6 * np.sqrt(m)
 
 
+def test_blocked_companion_of_a_three_dof_matrix(P):
+    """An AIJ matrix whose nodes are complete 3 x 3 blocks (gen_fem3: 77 nonzeros per row) is multiplied by the BAIJ row-block kernel
+    over BCSR arrays laid out beside the CSR ones (-mat_hipmi355x_blocked, decided for rows of more than 16 nonzeros): the same sums as
+    the grouped-row kernel bit for bit, MatMultAdd too, device-side value changes reach it by one gather; a matrix with an incomplete
+    block, or with short rows, keeps the grouped-row kernel."""
+    L = P.lib()
+    ai, aj, aa = pb.gen_fem3(14, 14, 8)
+    m = ai.size - 1
+    x = rnd(m, 41); z = rnd(m, 42)
+    rowof = np.repeat(np.arange(m), np.diff(ai))
+    scale = np.zeros(m); np.add.at(scale, rowof, np.abs(aa * x[aj]))
+    bs_, nb_ = C.c_int(), C.c_int()
+    set_options(L, "-mat_hipmi355x_blocked 0")
+    A0 = P.Mat.from_csr(ai, aj, aa)
+    vx, vy0 = V(P, x), V(P, np.zeros(m))
+    A0.mult(vx, vy0)
+    L.MatHIPMI355XGetBlockedInfo(A0.h, C.byref(bs_), C.byref(nb_))
+    assert bs_.value == 0 and nb_.value == 0
+    set_options(L, "")
+    A = P.Mat.from_csr(ai, aj, aa)
+    vy, vz, vw = V(P, np.zeros(m)), V(P, z), V(P, np.zeros(m))
+    A.mult(vx, vy)
+    L.MatHIPMI355XGetBlockedInfo(A.h, C.byref(bs_), C.byref(nb_))
+    assert bs_.value == 3 and nb_.value * 9 == aj.size
+    ref, _ = orc.matmult(ai, aj, aa, x)
+    assert np.all(np.abs(vy.array() - ref) <= 1e-12 * scale)
+    assert np.array_equal(bits(vy.array()), bits(vy0.array()))          # the grouped-row kernel's sums
+    L.MatMultAdd(A.h, vx.h, vz.h, vw.h)
+    L.MatMultAdd(A0.h, vx.h, vz.h, vy0.h)
+    assert np.array_equal(bits(vw.array()), bits(vy0.array()))
+    # values changed on the device: MatScale, MatDiagonalScale
+    dl = V(P, 1.0 + 0.1 * rnd(m, 43))
+    L.MatScale(A.h, -1.5); L.MatDiagonalScale(A.h, dl.h, dl.h)
+    A.mult(vx, vy)
+    aa2 = ((aa * -1.5) * dl.array()[rowof]) * dl.array()[aj]
+    ref2, _ = orc.matmult(ai, aj, aa2, x)
+    assert np.all(np.abs(vy.array() - ref2) <= 1e-12 * 1.5 * 1.3 * scale)
+    n_up = C.c_int()
+    L.MatHIPMI355XGetUploadCount(A.h, C.byref(n_up))
+    assert n_up.value == 1
+    # one entry of one block missing: not a BAIJ matrix any more
+    keep = np.ones(aj.size, bool); keep[ai[5] + 1] = False
+    ai2 = np.concatenate(([0], np.cumsum(np.bincount(rowof[keep], minlength=m)))).astype(np.int32)
+    B = P.Mat.from_csr(ai2, aj[keep].astype(np.int32), aa[keep])
+    vy2 = V(P, np.zeros(m))
+    B.mult(vx, vy2)
+    L.MatHIPMI355XGetBlockedInfo(B.h, C.byref(bs_), C.byref(nb_))
+    assert bs_.value == 0
+    # short rows (2 dof, 5 + 2 neighbours): decided against (the grouped-row kernel carries the reference's bits there); forced: taken
+    ai3, aj3, aa3 = multidof_stencil(23, 19, 2, 7)
+    m3 = ai3.size - 1
+    x3 = rnd(m3, 44)
+    for opt, want in (("", 0), ("-mat_hipmi355x_blocked 1 -mat_hipmi355x_index_compression 0", 2)):
+        set_options(L, opt)
+        A3 = P.Mat.from_csr(ai3, aj3, aa3)
+        v3, w3 = V(P, x3), V(P, np.zeros(m3))
+        A3.mult(v3, w3)
+        set_options(L, "")
+        L.MatHIPMI355XGetBlockedInfo(A3.h, C.byref(bs_), C.byref(nb_))
+        assert bs_.value == want, (opt, bs_.value)
+        s3 = np.zeros(m3); np.add.at(s3, np.repeat(np.arange(m3), np.diff(ai3)), np.abs(aa3 * x3[aj3]))
+        assert np.all(np.abs(w3.array() - orc.spmv(ai3, aj3, aa3, x3)) <= 1e-12 * s3)
+
+
 def test_same_nonzero_count_different_pattern(P):
     """a matrix that has been used on the device is re-preallocated and re-filled with ANOTHER pattern of the same
     nonzero count (and: MatLoad-style adoption of new arrays into a used Mat): nothing of the old mirror may survive"""
