@@ -200,6 +200,11 @@ static PetscErrorCode device_free(Mat A) {
   if (d->b_a) mi355x_free(d->b_a);
   if (d->b_perm) mi355x_free(d->b_perm);
   if (d->b_plan) mi355x_spmv_plan_destroy(d->b_plan);
+  if (d->tb_i) mi355x_free(d->tb_i);
+  if (d->tb_j) mi355x_free(d->tb_j);
+  if (d->tb_a) mi355x_free(d->tb_a);
+  if (d->tb_perm) mi355x_free(d->tb_perm);
+  if (d->tb_plan) mi355x_spmv_plan_destroy(d->tb_plan);
   if (d->bm_order) mi355x_free(d->bm_order);
   if (d->bm_segptr) mi355x_free(d->bm_segptr);
   if (d->bm_segslot) mi355x_free(d->bm_segslot);
@@ -433,7 +438,7 @@ PetscErrorCode MatSeqAIJHIPUpload(Mat A) {
   UP_TICK("values up");
   if (d->b_plan) {
     CHKHIP(mi355x_pack(dc->h, (size_t)a->nz, d->b_perm, d->d_a, d->b_a));
-    d->b_fresh = PETSC_TRUE;
+    d->b_fresh = PETSC_TRUE; d->tb_fresh = PETSC_FALSE;
     UP_TICK("blocked companion's values");
   }
   if (d->tiled) {
@@ -702,7 +707,7 @@ static PetscErrorCode MatSetValuesBatch_SeqAIJHIP(Mat A, PetscInt nb, PetscInt b
   /* MatSetValuesBatch's wrapper leaves the state alone and the MatAssemblyEnd that has to follow bumps it once: the
    * device copy is stamped with that state, so the assembly does not trigger an upload */
   d->uploaded_state = HipObjState(A) + 1;
-  d->t_state = -1; d->tiled_fresh = PETSC_FALSE; d->b_fresh = PETSC_FALSE;
+  d->t_state = -1; d->tiled_fresh = PETSC_FALSE; d->b_fresh = PETSC_FALSE; d->tb_fresh = PETSC_FALSE;
   CHKHIP(mi355x_spmv_plan_drop_value_patterns(d->plan));
   ierr = PetscLogFlops((PetscLogDouble)d->bm_T);CHKERRQ(ierr);
   return 0;
@@ -791,6 +796,51 @@ PetscErrorCode MatHIPMI355XGetIndexCompression(Mat A, PetscInt *noffsets) {
   return 0;
 }
 
+/* the block transpose of the blocked companion (MatMultTranspose / MatMultTransposeAdd of such a matrix): built from the host CSR arrays
+ * at the first transpose product after the pattern changed -- block rows and columns exchanged by a stable counting sort (an output
+ * row's contributions in increasing original block row, the order aij.c:1100-1112 adds them in), every block transposed --, its
+ * values a permutation gather of d_a like the companion's own */
+static PetscErrorCode blocked_transpose_current(Mat A, PetscDeviceCtx *dc) {
+  PetscErrorCode ierr;
+  HipAIJ *a = SA(A); Mat_SeqAIJHIP *d = SD(A);
+  if (!d->b_plan) return 0;
+  if (!d->tb_plan) {
+    const PetscInt bs = d->b_bs, bs2 = bs * bs, nn = a->m / bs, nbs = a->n / bs, nblk = d->b_nblocks;
+    PetscInt *ti, *tj, *next, *perm, *sc;
+    ierr = PetscMalloc(sizeof(PetscInt) * (size_t)(nbs + 1), &ti);CHKERRQ(ierr);
+    ierr = PetscMalloc(sizeof(PetscInt) * (size_t)PetscMax(nblk, 1), &tj);CHKERRQ(ierr);
+    ierr = PetscMalloc(sizeof(PetscInt) * (size_t)PetscMax(nbs, 1), &next);CHKERRQ(ierr);
+    ierr = PetscMalloc(sizeof(PetscInt) * (size_t)PetscMax(nblk, 1) * (size_t)bs2, &perm);CHKERRQ(ierr);
+    ierr = PetscMalloc(sizeof(PetscInt) * (size_t)(nbs + 1), &sc);CHKERRQ(ierr);
+    memset(ti, 0, sizeof(PetscInt) * (size_t)(nbs + 1));
+    for (PetscInt i = 0; i < nn; i++) { const PetscInt r = i * bs; for (PetscInt g = 0; g < a->i[r + 1] - a->i[r]; g += bs) ti[a->j[a->i[r] + g] / bs + 1]++; }
+    for (PetscInt c = 0; c < nbs; c++) ti[c + 1] += ti[c];
+    for (PetscInt c = 0; c < nbs; c++) next[c] = ti[c];
+    for (PetscInt i = 0; i < nn; i++) {
+      const PetscInt r = i * bs, len = a->i[r + 1] - a->i[r];
+      for (PetscInt g = 0; g < len; g += bs) {
+        const PetscInt p = next[a->j[a->i[r] + g] / bs]++;
+        tj[p] = i;
+        /* transposed block, column-major: entry (row qq, column cc) of it is entry (row cc, column qq) of the block */
+        for (PetscInt cc = 0; cc < bs; cc++) for (PetscInt qq = 0; qq < bs; qq++) perm[(size_t)p * bs2 + cc * bs + qq] = a->i[r + cc] + g + qq;
+      }
+    }
+    for (PetscInt c = 0; c <= nbs; c++) sc[c] = ti[c] * bs2;
+    CHKHIP(mi355x_malloc((void **)&d->tb_i, sizeof(PetscInt) * (size_t)(nbs + 1)));
+    CHKHIP(mi355x_malloc((void **)&d->tb_j, sizeof(PetscInt) * (size_t)PetscMax(nblk, 1) + 16));
+    CHKHIP(mi355x_malloc((void **)&d->tb_perm, sizeof(PetscInt) * (size_t)PetscMax(nblk, 1) * (size_t)bs2));
+    CHKHIP(mi355x_malloc((void **)&d->tb_a, sizeof(PetscScalar) * (size_t)PetscMax(nblk, 1) * (size_t)bs2 + 16));
+    CHKHIP(mi355x_memcpy_h2d(dc->h, d->tb_i, ti, sizeof(PetscInt) * (size_t)(nbs + 1)));
+    CHKHIP(mi355x_memcpy_h2d(dc->h, d->tb_j, tj, sizeof(PetscInt) * (size_t)nblk));
+    CHKHIP(mi355x_memcpy_h2d(dc->h, d->tb_perm, perm, sizeof(PetscInt) * (size_t)nblk * (size_t)bs2));
+    CHKHIP(mi355x_spmv_plan_create(dc->h, nbs, sc, NULL, &d->tb_plan));
+    CHKHIP(mi355x_handle_synchronize(dc->h));
+    HipFree(ti); HipFree(tj); HipFree(next); HipFree(perm); HipFree(sc);
+    d->tb_fresh = PETSC_FALSE;
+  }
+  if (!d->tb_fresh) { CHKHIP(mi355x_pack(dc->h, (size_t)a->nz, d->tb_perm, d->d_a, d->tb_a)); d->tb_fresh = PETSC_TRUE; }
+  return 0;
+}
 /* the blocked companion of a sequential matrix, if the analysis chose it: block size and number of blocks (0, 0: none) */
 PetscErrorCode MatHIPMI355XGetBlockedInfo(Mat A, PetscInt *bs, PetscInt *nblocks) {
   *bs = 0; *nblocks = 0;
@@ -1008,6 +1058,16 @@ static PetscErrorCode MatMultTransposeAdd_SeqAIJHIP(Mat A, Vec xx, Vec zz, Vec y
   HipAIJ *a = SA(A); Mat_SeqAIJHIP *d = SD(A);
   const PetscScalar *x, *z; PetscScalar *y; PetscDeviceCtx *dc;
   ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
+  if (a->bs <= 1) { ierr = MatSeqAIJHIPUpload(A);CHKERRQ(ierr); }
+  if (a->bs <= 1 && d->b_plan) {                                      /* the blocked companion's block transpose: no scalar transpose is built */
+    ierr = blocked_transpose_current(A, dc);CHKERRQ(ierr);
+    ierr = VecHIPGetRead(xx, &x);CHKERRQ(ierr);
+    if (zz == yy) { ierr = VecHIPGetReadWrite(yy, &y);CHKERRQ(ierr); z = y; }
+    else { ierr = VecHIPGetRead(zz, &z);CHKERRQ(ierr); ierr = VecHIPGetWrite(yy, &y);CHKERRQ(ierr); }
+    CHKHIP(mi355x_spmv_bsr_planned_add(dc->h, d->tb_plan, (int)d->b_bs, d->tb_i, d->tb_j, d->tb_a, x, z, y));
+    ierr = VecHIPRestoreWrite(yy);CHKERRQ(ierr);
+    return PetscLogFlops(2.0 * a->nz);
+  }
   ierr = upload_transpose(A);CHKERRQ(ierr);
   ierr = VecHIPGetRead(xx, &x);CHKERRQ(ierr);
   if (zz == yy) { ierr = VecHIPGetReadWrite(yy, &y);CHKERRQ(ierr); z = y; }
@@ -1027,6 +1087,15 @@ static PetscErrorCode MatMultTranspose_SeqAIJHIP(Mat A, Vec xx, Vec yy) {   /* a
   HipAIJ *a = SA(A); Mat_SeqAIJHIP *d = SD(A);
   const PetscScalar *x; PetscScalar *y; PetscDeviceCtx *dc;
   ierr = PetscDeviceGet(&dc);CHKERRQ(ierr);
+  if (a->bs <= 1) { ierr = MatSeqAIJHIPUpload(A);CHKERRQ(ierr); }
+  if (a->bs <= 1 && d->b_plan) {
+    ierr = blocked_transpose_current(A, dc);CHKERRQ(ierr);
+    ierr = VecHIPGetRead(xx, &x);CHKERRQ(ierr);
+    ierr = VecHIPGetWrite(yy, &y);CHKERRQ(ierr);
+    CHKHIP(mi355x_spmv_bsr_planned(dc->h, d->tb_plan, (int)d->b_bs, d->tb_i, d->tb_j, d->tb_a, x, y));
+    ierr = VecHIPRestoreWrite(yy);CHKERRQ(ierr);
+    return PetscLogFlops(2.0 * a->nz);
+  }
   ierr = upload_transpose(A);CHKERRQ(ierr);
   ierr = VecHIPGetRead(xx, &x);CHKERRQ(ierr);
   ierr = VecHIPGetWrite(yy, &y);CHKERRQ(ierr);
@@ -1087,7 +1156,7 @@ static PetscErrorCode MatScale_SeqAIJHIP(Mat A, PetscScalar alpha) {   /* MatSca
     { PetscErrorCode e__ = VecHIPProductMatrixChanges(A);CHKERRQ(e__); }
     CHKHIP(mi355x_vec_scale(dc->h, vals, alpha, d->d_a));
     d->uploaded_state = HipObjState(A) + 1;
-    d->t_state = -1; d->tiled_fresh = PETSC_FALSE; d->b_fresh = PETSC_FALSE;
+    d->t_state = -1; d->tiled_fresh = PETSC_FALSE; d->b_fresh = PETSC_FALSE; d->tb_fresh = PETSC_FALSE;
     CHKHIP(mi355x_spmv_plan_drop_value_patterns(d->plan));
   }
   return PetscLogFlops((PetscLogDouble)vals);
@@ -1104,7 +1173,7 @@ static PetscErrorCode MatZeroEntries_SeqAIJHIP(Mat A) {
     { PetscErrorCode e__ = VecHIPProductMatrixChanges(A);CHKERRQ(e__); }
     CHKHIP(mi355x_memset(dc->h, d->d_a, 0, sizeof(PetscScalar) * vals));
     d->uploaded_state = HipObjState(A) + 1;
-    d->t_state = -1; d->tiled_fresh = PETSC_FALSE; d->b_fresh = PETSC_FALSE;
+    d->t_state = -1; d->tiled_fresh = PETSC_FALSE; d->b_fresh = PETSC_FALSE; d->tb_fresh = PETSC_FALSE;
     CHKHIP(mi355x_spmv_plan_drop_value_patterns(d->plan));
   }
   return 0;
@@ -1156,7 +1225,7 @@ static PetscErrorCode MatDiagonalScale_SeqAIJHIP(Mat A, Vec ll, Vec rr) {
     { PetscErrorCode e__ = VecHIPProductMatrixChanges(A);CHKERRQ(e__); }
     CHKHIP(mi355x_csr_diagonal_scale(dc->h, a->m, d->d_i, d->d_j, d->d_a, dl, dr));
     d->uploaded_state = HipObjState(A) + 1;
-    d->t_state = -1; d->tiled_fresh = PETSC_FALSE; d->b_fresh = PETSC_FALSE;
+    d->t_state = -1; d->tiled_fresh = PETSC_FALSE; d->b_fresh = PETSC_FALSE; d->tb_fresh = PETSC_FALSE;
     CHKHIP(mi355x_spmv_plan_drop_value_patterns(d->plan));
   }
   if (ll) {

@@ -204,6 +204,7 @@ typedef struct {
   /* the blocked companion of an AIJ matrix whose nodes are complete bs x bs blocks (3-dof FEM matrices): BCSR arrays on the device, values
    * a permutation gather of d_a, multiplied by the BAIJ row-block kernel (host/aijhip.c, "blocked companion") */
   PetscInt *b_i, *b_j, *b_perm, b_bs, b_nblocks; PetscScalar *b_a; mi355x_spmv_plan_t b_plan; PetscBool b_fresh;
+  PetscInt *tb_i, *tb_j, *tb_perm; PetscScalar *tb_a; mi355x_spmv_plan_t tb_plan; PetscBool tb_fresh;   /* ... and its block transpose, for the transpose products */
   PetscInt opt[8]; PetscBool opt_set[8];   /* the type's options as MatSetFromOptions read them under the matrix's prefix (host/aijhip.c) */
   /* per-launch device timing for bench.py (hipEvent pairs on the compute stream) */
   PetscBool timing; PetscInt time_n, time_cap; mi355x_event_t *time_ev;

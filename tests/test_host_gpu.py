@@ -2114,6 +2114,21 @@ def test_blocked_companion_of_a_three_dof_matrix(P):
     n_up = C.c_int()
     L.MatHIPMI355XGetUploadCount(A.h, C.byref(n_up))
     assert n_up.value == 1
+    # the transpose products take the companion's block transpose (no scalar transpose is built), and follow the device values
+    import scipy.sparse as sp
+    S2 = sp.csr_matrix((aa2, aj, ai), shape=(m, m))
+    tolT = 1e-12 * (abs(S2).T @ np.abs(x)) + 1e-300
+    L.MatMultTranspose(A.h, vx.h, vy.h)
+    assert np.all(np.abs(vy.array() - S2.T @ x) <= tolT)
+    L.MatMultTransposeAdd(A.h, vx.h, vz.h, vw.h)
+    assert np.all(np.abs(vw.array() - (z + S2.T @ x)) <= tolT + 1e-12 * np.abs(z))
+    tb_, tr_ = C.c_int(), C.c_int()
+    L.MatHIPMI355XGetTransposeCounts(A.h, C.byref(tb_), C.byref(tr_))
+    assert tb_.value == 0
+    L.MatScale(A.h, 2.0)
+    L.MatMultTranspose(A.h, vx.h, vy.h)
+    assert np.all(np.abs(vy.array() - 2.0 * (S2.T @ x)) <= 2.0 * tolT)
+    L.MatScale(A.h, 0.5)
     # one entry of one block missing: not a BAIJ matrix any more
     keep = np.ones(aj.size, bool); keep[ai[5] + 1] = False
     ai2 = np.concatenate(([0], np.cumsum(np.bincount(rowof[keep], minlength=m)))).astype(np.int32)
