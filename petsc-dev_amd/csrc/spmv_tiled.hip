@@ -689,7 +689,7 @@ int mi355x_spmv_tiled_destroy(mi355x_spmv_tiled_t P) {
   if (!P) return 0;
   delete P->host;
   void *ptrs[] = {P->d_prow, P->d_pt_ptr, P->d_pt_tile, P->d_pw_e0, P->d_pw_f0, P->d_fw_ptr, P->d_fw_win, P->d_perm, P->d_word, P->d_val};
-  for (void *q : ptrs) if (q) hipFree(q);
+  for (void *q : ptrs) if (q) (void)hipFree(q);
   delete P;
   return 0;
 }
