@@ -118,6 +118,82 @@ def ex9_system(which, t, m=3, n=2):
     return csr(sp.csr_matrix(K)), u
 
 
+def serendipity20_stiffness(E=1.0, nu=0.3):
+    """Stiffness of ONE 20-node serendipity brick as src/ksp/ksp/examples/tests/ex10.c forms it (Elastic20Stiff /
+    paulsetup20 / paulintegrate20, ex10.c:230-533) -- the example's own input data: nodes on the 3 x 3 x 3 lattice of the
+    cube [-1, 3]^3 without face centres and body centre, 3-point Gauss rule with the example's 15-digit abscissae and
+    weights, isotropic material E = 1, nu = 0.3 with engineering shear strains (xx yy zz xy yz zx).  Returned on the
+    lattice's 81 dofs, entries below 1e-8 of the largest dropped, lower triangle averaged with the upper as the example
+    does (the upper one stays as integrated)."""
+    lattice = [g for g in range(27) if g not in (4, 10, 12, 13, 14, 16, 22)]                # the 20 nodes, lattice index = i + 3 j + 9 k
+    ref = np.array([[g % 3 - 1.0, (g // 3) % 3 - 1.0, g // 9 - 1.0] for g in lattice])     # canonical (r, s, t) of each node
+    xyz = 2.0 * ref + 1.0                                                                   # physical coordinates: the cube [-1, 3]^3
+    gx = np.array([-0.774596669241483, 0.0, 0.774596669241483])
+    gw = np.array([0.555555555555555, 0.888888888888888, 0.555555555555555])
+    lam = E / ((1.0 + nu) * (1.0 - 2.0 * nu))
+    Cm = np.zeros((6, 6))
+    Cm[:3, :3] = lam * nu
+    Cm[np.arange(3), np.arange(3)] = lam * (1.0 - nu)
+    Cm[np.arange(3, 6), np.arange(3, 6)] = lam * (0.5 - nu)
+    K = np.zeros((60, 60))
+    for a in range(3):
+        for b_ in range(3):
+            for c in range(3):
+                q = np.array([gx[a], gx[b_], gx[c]])
+                dN = np.zeros((3, 20))                                                      # d N_node / d (r, s, t) at the point
+                for nd in range(20):
+                    o = ref[nd]
+                    mid = [d for d in range(3) if o[d] == 0.0]
+                    if not mid:                                                             # corner: 1/8 prod(1 + q o)(sum q o - 2)
+                        f = 1.0 + q * o
+                        tot = float(np.dot(q, o))
+                        for d in range(3):
+                            e1, e2 = [e for e in range(3) if e != d]
+                            dN[d, nd] = 0.125 * o[d] * f[e1] * f[e2] * (tot - 1.0 + q[d] * o[d])
+                    else:                                                                   # mid-edge along direction z0: 1/4 (1 - q_z0^2) prod over the other two
+                        z0 = mid[0]
+                        e1, e2 = [e for e in range(3) if e != z0]
+                        f1, f2 = 1.0 + q[e1] * o[e1], 1.0 + q[e2] * o[e2]
+                        dN[z0, nd] = -0.5 * q[z0] * f1 * f2
+                        dN[e1, nd] = 0.25 * o[e1] * f2 * (1.0 - q[z0] * q[z0])
+                        dN[e2, nd] = 0.25 * o[e2] * f1 * (1.0 - q[z0] * q[z0])
+                J = dN @ xyz                                                                # J[i, j] = d x_j / d r_i
+                G = np.linalg.solve(J, dN)                                                  # physical gradients of the shape functions
+                B = np.zeros((6, 60))
+                for nd in range(20):
+                    gxx, gyy, gzz = G[:, nd]
+                    B[0, 3 * nd] = gxx; B[1, 3 * nd + 1] = gyy; B[2, 3 * nd + 2] = gzz
+                    B[3, 3 * nd] = gyy; B[3, 3 * nd + 1] = gxx
+                    B[4, 3 * nd + 1] = gzz; B[4, 3 * nd + 2] = gyy
+                    B[5, 3 * nd] = gzz; B[5, 3 * nd + 2] = gxx
+                K += (B.T @ (Cm @ B)) * (np.linalg.det(J) * gw[a] * gw[b_] * gw[c])
+    Ke = np.zeros((81, 81))
+    dofs = np.array([3 * g + d for g in lattice for d in range(3)])
+    Ke[np.ix_(dofs, dofs)] = K
+    Ke[np.abs(Ke) < 1.e-8 * np.abs(Ke).max()] = 0.0
+    low = np.tril_indices(81, -1)
+    Ke[low] = (Ke[low] + Ke.T[low]) / 2.0
+    return Ke
+
+
+def ex10_elasticity():
+    """src/ksp/ksp/examples/tests/ex10.c as its makefile runs it (runex10: default -m 3, halved to ONE brick, 81 lattice dofs):
+    the brick's stiffness added entry by entry AND transposed (AddElement, ex10.c:183-205: A = Ke + Ke^T on the entries that
+    are not zero), the lattice's first plane (27 dofs, clamped) and the dofs no element touches removed (ex10.c:150-166):
+    36 rows, 1200 nonzeros.  u = 0, 1, 2, ...; b = A u.  Returns CSR, b, u."""
+    Ke = serendipity20_stiffness()
+    A = Ke + Ke.T
+    mask = (Ke != 0.0) | (Ke.T != 0.0)
+    keep = [i for i in range(27, 81) if mask[i].any()]
+    A = A[np.ix_(keep, keep)]; mask = mask[np.ix_(keep, keep)]
+    ai = np.concatenate(([0], np.cumsum(mask.sum(axis=1)))).astype(np.int32)
+    aj = np.concatenate([np.nonzero(mask[i])[0] for i in range(len(keep))]).astype(np.int32)
+    aa = np.concatenate([A[i, mask[i]] for i in range(len(keep))]).astype(np.float64)
+    u = np.arange(len(keep), dtype=np.float64)
+    b = np.array([np.dot(aa[ai[i]:ai[i + 1]], u[aj[ai[i]:ai[i + 1]]]) for i in range(len(keep))])
+    return (ai, aj, aa), b, u
+
+
 def parse_monitor(path):
     """'  3 KSP Residual norm 0.146074 ' lines of -ksp_monitor_short -> list of (it, text) groups split at it == 0"""
     solves, cur = [], None

@@ -1249,6 +1249,27 @@ def test_ilu0_apply_bitexact_and_golden(P):
     assert k.its == 4 and "%.5g" % np.linalg.norm(vx.array() - u) in ("0.0003927", "0.00039270")
 
 
+@pytest.mark.parametrize("opts", ["-ksp_cg_fused 0", ""])
+def test_ksp_tests_ex10_cg_ilu0_on_a_matrix_with_inodes_golden(P, opts):
+    """The reference's ksp/examples/tests/ex10 (one 20-node elasticity brick, AIJ with 21 inodes of 1, 2 and 3 rows, KSPCG + the
+    default PCILU) on the HIP path vs output/ex10_1.out: the inode count MatView reports, the ten monitor lines, 9 iterations --
+    through the plain CG call sequence and through the plug-in's own CG."""
+    L = P.lib()
+    (ai, aj, aa), b, u = pb.ex10_elasticity()
+    text = open(os.path.join(G, "ksp_tests", "ex10_1.out")).read()
+    gold = pb.parse_monitor(os.path.join(G, "ksp_tests", "ex10_1.out"))[0]
+    A = P.Mat.from_csr(ai, aj, aa)
+    vu, vb = V(P, u), V(P, np.zeros(u.size))
+    A.mult(vu, vb)                                                   # b = A u as the example forms it (MatMult_SeqAIJ_Inode)
+    nodes, groups, shared = C.c_int(), C.c_int(), C.c_int()
+    L.MatHIPMI355XGetInodeInfo(A.h, C.byref(nodes), C.byref(groups), C.byref(shared))
+    assert "found %d nodes, limit used is 5" % nodes.value in text
+    assert np.all(np.abs(vb.array() - b) <= 1e-13 * np.abs(b).max())
+    x, h, its, reason = solve(P, ai, aj, aa, vb.array(), "cg", "ilu", opts=opts, rtol=1e-10)
+    pb.check_monitor(h, gold)
+    assert its == 9 and reason == 2 and np.linalg.norm(x - u) < 1e-11
+
+
 @pytest.mark.parametrize("shape", ["fem3", "irr", "deep", "p7"])
 def test_ilu0_syncfree_solves_on_irregular_factors(P, shape):
     """the sync-free triangular solves on factors whose levels are ragged: slices that span many levels (in-wavefront

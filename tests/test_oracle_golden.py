@@ -241,6 +241,27 @@ def test_tutorial_ex2_gmres_ilu0():
     assert its == 7 and "%g" % np.linalg.norm(x - u) == "0.000292349"
 
 
+def test_ksp_tests_ex10_cg_ilu0_on_a_matrix_with_inodes_golden():
+    """src/ksp/ksp/examples/tests/ex10.c -matconvert_type seqaij -ksp_monitor_short (makefile:272) vs output/ex10_1.out: one 20-node
+    serendipity brick of linear elasticity, 36 x 36 with 1200 nonzeros stored as AIJ -- 'using I-node routines: found 21 nodes,
+    limit used is 5', nodes of 1, 2 and 3 rows -- 'matrix 1 norm = 34.0627', then KSPCG (rtol 1e-10) with the one-rank default
+    PCILU: ten monitor lines, 9 iterations.  The reference's own golden for MatMult_SeqAIJ_Inode + the ILU(0) routines on a matrix
+    with inodes of mixed sizes under CG."""
+    import scipy.sparse as sp
+    (ai, aj, aa), b, u = pb.ex10_elasticity()
+    m = ai.size - 1
+    text = open(os.path.join(G, "ksp_tests", "ex10_1.out")).read()
+    assert "rows=%d, cols=%d" % (m, m) in text and "total: nonzeros=%d" % aj.size in text
+    nc, ns = orc.check_inode(ai, aj)
+    assert "using I-node routines: found %d nodes, limit used is 5" % nc in text and sorted(set(ns[:nc].tolist())) == [1, 2, 3]
+    assert "matrix 1 norm = %g" % abs(sp.csr_matrix((aa, aj, ai), shape=(m, m))).sum(axis=0).max() in text
+    gold = pb.parse_monitor(os.path.join(G, "ksp_tests", "ex10_1.out"))[0]
+    x, h, its, reason = orc.ksp_solve(ai, aj, aa, b, ksp="cg", pc="ilu", rtol=1e-10)
+    pb.check_monitor(h, gold)
+    assert its == 9 and reason == 2 and "Number of iterations %d" % its in text
+    assert np.linalg.norm(x - u) < 1e-11                    # 'Norm of error 5.85503e-13': rounding, not reproducible digit by digit
+
+
 def test_threaded_cpu_baseline_matches_the_sequential_oracle():
     """bench.py's cpu_baseline loop (one thread per block of rows, partial sums added in rank order -- the reference's
     MPI arrangement inside one process) computes the same CG + Jacobi iterates as the sequential oracle, to the
