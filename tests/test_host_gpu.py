@@ -1249,6 +1249,16 @@ def test_ilu0_apply_bitexact_and_golden(P):
     assert k.its == 4 and "%.5g" % np.linalg.norm(vx.array() - u) in ("0.0003927", "0.00039270")
 
 
+@pytest.mark.parametrize("opts", ["-ksp_gmres_fused 0", ""])
+def test_ksp_tests_ex40_default_gmres_without_a_preconditioner_golden(P, opts):
+    """ksp/examples/tests/ex40 -pc_type none vs output/ex40.out on the HIP path: default GMRES (no refinement step), PCNONE, ex2's 8 x 7
+    operator: 'Norm of error 1.68964e-05 iterations 13' -- plain call sequence and the plug-in's own GMRES."""
+    ai, aj, aa = pb.lap2d(8, 7)
+    u = np.ones(56)
+    x, h, its, reason = solve(P, ai, aj, aa, orc.spmv(ai, aj, aa, u), "gmres", "none", opts=opts, rtol=1e-2 / 72, abstol=1e-50)
+    assert open(os.path.join(G, "ksp_tests", "ex40.out")).read().strip() == "Norm of error %g iterations %d" % (np.linalg.norm(x - u), its)
+
+
 @pytest.mark.parametrize("opts", ["-ksp_cg_fused 0", ""])
 def test_ksp_tests_ex10_cg_ilu0_on_a_matrix_with_inodes_golden(P, opts):
     """The reference's ksp/examples/tests/ex10 (one 20-node elasticity brick, AIJ with 21 inodes of 1, 2 and 3 rows, KSPCG + the

@@ -33,6 +33,8 @@ def test_mpiaij_two_ranks_one_gpu(built, nranks):
         if nranks == 2:   # the reference's own 2-rank golden, default preconditioner (block Jacobi + ILU(0))
             assert "rank %d/2: golden ex2_2.out (GMRES + bjacobi + ILU(0), 2 ranks) its=7 ok=True" % k in out, out[-3000:]
             assert "rank %d/2: golden ex5_5.out (two systems, GMRES + bjacobi + ILU(0), 2 ranks) ok=True" % k in out, out[-3000:]
+            assert "rank %d/2: golden ex16_1.out (four right-hand sides, one KSP, GMRES + bjacobi + ILU(0), 2 ranks) ok=True" % k in out, out[-3000:]
+            assert "rank %d/2: golden ex40.out (default GMRES, PCNONE, 2 ranks) ok=True" % k in out, out[-3000:]
 
 
 def test_mpiaij_four_ranks_in_the_partition_of_configs2(built):

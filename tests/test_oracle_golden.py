@@ -262,6 +262,32 @@ def test_ksp_tests_ex10_cg_ilu0_on_a_matrix_with_inodes_golden():
     assert np.linalg.norm(x - u) < 1e-11                    # 'Norm of error 5.85503e-13': rounding, not reproducible digit by digit
 
 
+def test_tutorial_ex16_four_right_hand_sides_on_two_ranks_golden():
+    """src/ksp/ksp/examples/tutorials/ex16.c -ntimes 4 refine_always on 2 ranks (makefile:839) vs output/ex16_1.out: ONE KSP, the
+    default PC of a 2-rank run (block Jacobi + ILU(0), set up once: SAME_PRECONDITIONER), four systems A x = A (k 1), k = 1..4,
+    on ex2's 8 x 7 grid; per system 'Norm of error <%G> System k: iterations 9'."""
+    ai, aj, aa = pb.lap2d(8, 7)
+    lines = [l.split() for l in open(os.path.join(G, "ksp_tutorials", "ex16_1.out")).read().splitlines()]
+    assert len(lines) == 4
+    for k, want in enumerate(lines, start=1):
+        u = np.full(56, float(k))
+        x, h, its, reason = orc.ksp_solve(ai, aj, aa, orc.spmv(ai, aj, aa, u), ksp="gmres", pc="bjacobi", blocks=[0, 28, 56],
+                                          sub_ksp="preonly", sub_pc="ilu", refine_always=1)
+        assert "%g" % np.linalg.norm(x - u) == want[3] and int(want[5].rstrip(":")) == k and its == int(want[7]) == 9
+
+
+def test_ksp_tests_ex40_gmres_without_refinement_and_without_a_preconditioner_golden():
+    """src/ksp/ksp/examples/tests/ex40.c -pc_type none on 6 ranks (makefile:819) vs output/ex40.out: ex2's 8 x 7 operator, u = 1,
+    rtol 1e-2 / 72, the DEFAULT GMRES -- classical Gram-Schmidt with no refinement step, the one form the other goldens (all
+    refine_always) do not reach -- and PCNONE: 'Norm of error 1.68964e-05 iterations 13'.  (The example stores the operator as
+    MATELEMENTAL, a dense distributed type outside this path; the Krylov sequence over the same operator is what the line pins, and
+    without a preconditioner the rank count enters only through the order of the reductions.)"""
+    ai, aj, aa = pb.lap2d(8, 7)
+    u = np.ones(56)
+    x, h, its, reason = orc.ksp_solve(ai, aj, aa, orc.spmv(ai, aj, aa, u), ksp="gmres", pc="none", rtol=1e-2 / 72, abstol=1e-50)
+    assert open(os.path.join(G, "ksp_tests", "ex40.out")).read().strip() == "Norm of error %g iterations %d" % (np.linalg.norm(x - u), its)
+
+
 def test_threaded_cpu_baseline_matches_the_sequential_oracle():
     """bench.py's cpu_baseline loop (one thread per block of rows, partial sums added in rank order -- the reference's
     MPI arrangement inside one process) computes the same CG + Jacobi iterates as the sequential oracle, to the

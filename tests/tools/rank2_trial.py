@@ -234,6 +234,37 @@ def main():
             ok5_ = ok5_ and ("%g" % xf.norm()) == want[3].rstrip(",") and kf.its == int(want[5])
         print("rank %d/%d: golden ex5_5.out (two systems, GMRES + bjacobi + ILU(0), 2 ranks) ok=%s" % (rank, world, ok5_), flush=True)
         ok1 = ok1 and ok5_
+        # ---- ex16_1.out (tutorials/makefile:839: -n 2 ./ex16 -ntimes 4 refine_always): four right-hand sides through ONE KSP whose
+        # default PC (block Jacobi + ILU(0)) is set up once; and ksp/tests ex40.out (default GMRES, no refinement, PCNONE) on the same
+        # 8 x 7 operator split 28 + 28
+        g16 = pb.lap2d(8, 7)
+        r0_, r1_ = (0, 28) if rank == 0 else (28, 56)
+        li16, lj16, la16 = (g16[0][r0_:r1_ + 1] - g16[0][r0_]).astype(np.int32), g16[1][g16[0][r0_]:g16[0][r1_]].copy(), g16[2][g16[0][r0_]:g16[0][r1_]].copy()
+        H = P.Mat.from_csr_mpi(li16, lj16, la16, 28, 56, 56, comm=comm)
+        uh = P.Vec.create(28, N=56, comm=comm); bh, xh = uh.duplicate(), uh.duplicate()
+        kh = P.KSP(comm=comm); kh.set_operators(H)
+        L.PetscOptionsClear(); L.PetscOptionsInsertString(b"-ksp_gmres_cgs_refinement_type refine_always")
+        kh.set_from_options()
+        L.PetscOptionsClear()
+        ok16 = True
+        for k16, want in enumerate([l.split() for l in open(os.path.join(ROOT, "tests", "golden", "ksp_tutorials", "ex16_1.out")).read().splitlines()], start=1):
+            L.VecSet(uh.h, float(k16))
+            H.mult(uh, bh)
+            kh.solve(bh, xh)
+            L.VecAXPY(xh.h, -1.0, uh.h)
+            ok16 = ok16 and ("%g" % xh.norm()) == want[3] and kh.its == int(want[7])
+        print("rank %d/%d: golden ex16_1.out (four right-hand sides, one KSP, GMRES + bjacobi + ILU(0), 2 ranks) ok=%s" % (rank, world, ok16), flush=True)
+        k40 = P.KSP(comm=comm); k40.set_operators(H)
+        L.PetscOptionsClear(); L.PetscOptionsInsertString(b"-pc_type none")
+        k40.set_tolerances(rtol=1e-2 / 72, abstol=1e-50); k40.set_from_options()
+        L.PetscOptionsClear()
+        L.VecSet(uh.h, 1.0)
+        H.mult(uh, bh)
+        k40.solve(bh, xh)
+        L.VecAXPY(xh.h, -1.0, uh.h)
+        ok40 = open(os.path.join(ROOT, "tests", "golden", "ksp_tests", "ex40.out")).read().strip() == "Norm of error %g iterations %d" % (xh.norm(), k40.its)
+        print("rank %d/%d: golden ex40.out (default GMRES, PCNONE, 2 ranks) ok=%s" % (rank, world, ok40), flush=True)
+        ok1 = ok1 and ok16 and ok40
     print("rank %d/%d: MatMult bitexact=%s MatMultTranspose=%s norm=%s CG its=%d (oracle %d) hist=%s" % (rank, world, ok1, ok2, ok3, k.its, itsr, ok4), flush=True)
     dist.barrier()
     dist.destroy_process_group()
