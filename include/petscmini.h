@@ -285,6 +285,7 @@ PetscErrorCode PCGetType(PC pc, PCType *type);
 PetscErrorCode PCSetOperators(PC pc, Mat Amat, Mat Pmat, MatStructure flag);
 PetscErrorCode PCGetOperators(PC pc, Mat *Amat, Mat *Pmat, MatStructure *flag);
 PetscErrorCode PCSetUp(PC pc);
+PetscErrorCode PCSetUpOnBlocks(PC pc);
 PetscErrorCode PCApply(PC pc, Vec x, Vec y);
 PetscErrorCode PCSetFromOptions(PC pc);
 PetscErrorCode PCDestroy(PC *pc);

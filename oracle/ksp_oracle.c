@@ -825,8 +825,8 @@ int orc_ksp_solve(const orc_ksp_opts *o, int n, const int *ai, const int *aj, co
     for (int k = 0; k < S.nblocks; k++) {
       solver *t = &S.sub[k];
       pc_free(t);   /* sub PC type is set below, redo its set-up */
-      t->ksp_type = o->sub_ksp_type; t->pc_type = o->sub_pc_type; t->norm_type = 1;
-      t->rtol = o->sub_rtol; t->abstol = o->sub_abstol; t->dtol = o->sub_dtol; t->max_it = o->sub_max_it;
+      t->ksp_type = o->blk_ksp_type ? o->blk_ksp_type[k] : o->sub_ksp_type; t->pc_type = o->blk_pc_type ? o->blk_pc_type[k] : o->sub_pc_type; t->norm_type = 1;
+      t->rtol = o->blk_rtol ? o->blk_rtol[k] : o->sub_rtol; t->abstol = o->sub_abstol; t->dtol = o->sub_dtol; t->max_it = o->sub_max_it;
       t->restart = o->restart; t->refine_always = 0;
       pc_setup(t);
     }

@@ -122,6 +122,10 @@ typedef struct {
   int norm_type;          /* KSPNormType for CG (cg.c:136-161): 0 none, 1 preconditioned (default), 2 unpreconditioned, 3 natural */
   int pb_bs;              /* PCPBJACOBI: the matrix's block size (pbjacobi.c:240: taken from the Mat); n % pb_bs == 0 */
   int pc_right;           /* -ksp_pc_side right (GMRES): KSPInitialResidual itres.c:55-64, PCApplyBAorAB precon.c:617, gmres.c:343-346 */
+  /* block Jacobi with sub-solvers set block by block, what a program does through PCBJacobiGetSubKSP (tutorials/ex7.c:173-195): when not
+   * NULL, nblocks entries each, replacing sub_ksp_type / sub_pc_type / sub_rtol for that block */
+  const int *blk_ksp_type, *blk_pc_type;
+  const double *blk_rtol;
 } orc_ksp_opts;
 void orc_ksp_default_opts(orc_ksp_opts *o);
 /* Solves A x = b.  hist[0..] receives the residual norms the monitor would print (hist_cap entries

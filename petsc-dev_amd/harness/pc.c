@@ -101,6 +101,11 @@ PetscErrorCode PCSetUp(PC pc) {   /* precon.c:~800 */
   pc->setupcalled = 2;
   return 0;
 }
+PetscErrorCode PCSetUpOnBlocks(PC pc) {   /* precon.c:857-868 */
+  if (!pc) SETERRQ(0, PETSC_ERR_ARG_NULL, "Null PC");
+  if (!pc->ops->setuponblocks) return 0;
+  return (*pc->ops->setuponblocks)(pc);
+}
 PetscErrorCode PCApply(PC pc, Vec x, Vec y) {   /* precon.c:369-388 */
   PetscErrorCode ierr;
   if (!pc) SETERRQ(0, PETSC_ERR_ARG_NULL, "Null PC");
@@ -296,9 +301,16 @@ static PetscErrorCode PCSetUp_BJacobi(PC pc) {
       if (fb) { ierr = ((PetscErrorCode (*)(PC, PetscInt, const PetscInt *))fb)(bj->ksp[i]->pc, nloc, bj->starts);CHKERRQ(ierr); }
       else if (!strcmp(bj->ksp[i]->pc->type_name, PCICC)) SETERRQ(pc->comm, PETSC_ERR_SUP, "this PCICC cannot factor independent blocks: use -pc_bjacobi_merge_blocks 0");
     }
-    ierr = KSPSetUp(bj->ksp[i]);CHKERRQ(ierr);
+    /* the block solvers themselves are set up by PCSetUpOnBlocks, i.e. at the start of KSPSolve (or at their first application): a program
+     * may still change them through PCBJacobiGetSubKSP after KSPSetUp (tutorials/ex7.c:166-195) */
   }
   if (bj->merged) for (PetscInt i = 1; i < nloc; i++) bj->ksp[i] = bj->ksp[0];   /* PCBJacobiGetSubKSP: every block answers with the one solver */
+  return 0;
+}
+static PetscErrorCode PCSetUpOnBlocks_BJacobi(PC pc) {   /* PCSetUpOnBlocks_BJacobi_Singleblock / _Multiblock, bjacobi.c:726,985 */
+  PC_BJacobi *bj = (PC_BJacobi *)pc->data;
+  const PetscInt nsolvers = bj->merged ? 1 : bj->nloc;
+  for (PetscInt i = 0; i < nsolvers; i++) { PetscErrorCode ierr = KSPSetUp(bj->ksp[i]);CHKERRQ(ierr); }
   return 0;
 }
 
@@ -382,6 +394,6 @@ PetscErrorCode PCCreate_BJacobi(PC pc) {
   PetscErrorCode ierr = PetscMalloc(sizeof(*bj), &bj);CHKERRQ(ierr);
   memset(bj, 0, sizeof(*bj));
   pc->data = bj;
-  pc->ops->setup = PCSetUp_BJacobi; pc->ops->apply = PCApply_BJacobi; pc->ops->destroy = PCDestroy_BJacobi;
+  pc->ops->setup = PCSetUp_BJacobi; pc->ops->apply = PCApply_BJacobi; pc->ops->destroy = PCDestroy_BJacobi; pc->ops->setuponblocks = PCSetUpOnBlocks_BJacobi;
   return 0;
 }

@@ -159,6 +159,7 @@ struct _PCOps {
   PetscErrorCode (*setfromoptions)(PC);
   PetscErrorCode (*destroy)(PC);
   PetscErrorCode (*getfactoredmatrix)(PC, Mat *);
+  PetscErrorCode (*setuponblocks)(PC);     /* PCSetUpOnBlocks, precon.c:857: what KSPSolve asks for after KSPSetUp (itfunc.c:377) */
 };
 typedef struct _PCOps PCOps;
 struct _p_PC {

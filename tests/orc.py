@@ -311,16 +311,23 @@ class KspOpts(C.Structure):
                 ("dtol", C.c_double), ("max_it", C.c_int), ("restart", C.c_int), ("refine_always", C.c_int),
                 ("guess_nonzero", C.c_int), ("nblocks", C.c_int), ("blk", pi), ("sub_ksp_type", C.c_int),
                 ("sub_pc_type", C.c_int), ("sub_rtol", C.c_double), ("sub_abstol", C.c_double),
-                ("sub_dtol", C.c_double), ("sub_max_it", C.c_int), ("cg_single", C.c_int), ("norm_type", C.c_int), ("pb_bs", C.c_int), ("pc_right", C.c_int)]
+                ("sub_dtol", C.c_double), ("sub_max_it", C.c_int), ("cg_single", C.c_int), ("norm_type", C.c_int), ("pb_bs", C.c_int), ("pc_right", C.c_int),
+                ("blk_ksp_type", pi), ("blk_pc_type", pi), ("blk_rtol", C.POINTER(C.c_double))]
 
 
 KSP = dict(cg=0, gmres=1, bcgs=2, preonly=3, groppcg=4, pipecg=5)
 PC = dict(none=0, jacobi=1, bjacobi=2, ilu=3, pbjacobi=4, icc=5)
 
 
-def ksp_solve(ai, aj, aa, b, ksp="gmres", pc="none", x0=None, blocks=None, sub_ksp="preonly", sub_pc="jacobi", **kw):
+def ksp_solve(ai, aj, aa, b, ksp="gmres", pc="none", x0=None, blocks=None, sub_ksp="preonly", sub_pc="jacobi", block_solvers=None, **kw):
+    """block_solvers: [(ksp, pc, rtol), ...] one per block -- sub-solvers set block by block (PCBJacobiGetSubKSP)"""
     o = KspOpts()
     lib().orc_ksp_default_opts(C.byref(o))
+    if block_solvers is not None:
+        bk = np.array([KSP[t[0]] for t in block_solvers], dtype=np.int32)
+        bp = np.array([PC[t[1]] for t in block_solvers], dtype=np.int32)
+        br = np.array([t[2] for t in block_solvers], dtype=np.float64)
+        o.blk_ksp_type = I(bk); o.blk_pc_type = I(bp); o.blk_rtol = br.ctypes.data_as(C.POINTER(C.c_double))
     o.ksp_type = KSP[ksp]; o.pc_type = PC[pc]
     o.sub_ksp_type = KSP[sub_ksp]; o.sub_pc_type = PC[sub_pc]
     for k, v in kw.items():

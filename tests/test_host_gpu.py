@@ -1249,6 +1249,40 @@ def test_ilu0_apply_bitexact_and_golden(P):
     assert k.its == 4 and "%.5g" % np.linalg.norm(vx.array() - u) in ("0.0003927", "0.00039270")
 
 
+def test_tutorial_ex7_block_jacobi_with_a_different_solver_on_every_block_golden(P):
+    """tutorials/ex7 vs output/ex7_1.out on the HIP path, on ONE rank: eight blocks of ten rows (-pc_bjacobi_blocks 8, kept as eight
+    solvers: -pc_bjacobi_merge_blocks 0), every block's KSP customised after KSPSetUp through PCBJacobiGetSubKSP as the example does --
+    blocks 0..3 (the example's rank 0) alternately BiCGStab + PCNONE (rtol 1e-6) and the default ILU(0), blocks 4..7 (its rank 1)
+    GMRES + Jacobi (rtol 1e-7).  Fourteen monitor lines, 'Norm of error 1.09983e-05 iterations 13'."""
+    L = P.lib()
+    ai, aj, aa = pb.lap2d(8, 10)
+    u = np.ones(80)
+    A = P.Mat.from_csr(ai, aj, aa)
+    vb, vx = V(P, orc.spmv(ai, aj, aa, u)), V(P, np.zeros(80))
+    k = P.KSP(comm=L.COMM_SELF); k.set_operators(A)
+    L.PetscOptionsClear()
+    L.PetscOptionsInsertString(b"-pc_type bjacobi -pc_bjacobi_blocks 8 -pc_bjacobi_merge_blocks 0 -ksp_gmres_cgs_refinement_type refine_always")
+    k.set_from_options(); k.record_history()
+    L.KSPSetUp(k.h)
+    pc, nloc, first, sub = C.c_void_p(), C.c_int(), C.c_int(), C.c_void_p()
+    L.KSPGetPC(k.h, C.byref(pc))
+    L.PCBJacobiGetSubKSP(pc, C.byref(nloc), C.byref(first), C.byref(sub))
+    assert (nloc.value, first.value) == (8, 0)
+    subs = C.cast(sub, C.POINTER(C.c_void_p))
+    for i in range(8):
+        spc = C.c_void_p(); L.KSPGetPC(subs[i], C.byref(spc))
+        if i < 4 and i % 2:
+            L.PCSetType(spc, b"ilu")
+        elif i < 4:
+            L.PCSetType(spc, b"none"); L.KSPSetType(subs[i], b"bcgs"); L.KSPSetTolerances(subs[i], 1e-6, P.PETSC_DEFAULT, P.PETSC_DEFAULT, int(P.PETSC_DEFAULT))
+        else:
+            L.PCSetType(spc, b"jacobi"); L.KSPSetType(subs[i], b"gmres"); L.KSPSetTolerances(subs[i], 1e-7, P.PETSC_DEFAULT, P.PETSC_DEFAULT, int(P.PETSC_DEFAULT))
+    k.solve(vb, vx)
+    L.PetscOptionsClear()
+    pb.check_monitor(k.history(), pb.parse_monitor(os.path.join(G, "ksp_tutorials", "ex7_1.out"))[0])
+    assert open(os.path.join(G, "ksp_tutorials", "ex7_1.out")).read().splitlines()[-1] == "Norm of error %g iterations %d" % (np.linalg.norm(vx.array() - u), k.its)
+
+
 @pytest.mark.parametrize("opts", ["-ksp_gmres_fused 0", ""])
 def test_ksp_tests_ex40_default_gmres_without_a_preconditioner_golden(P, opts):
     """ksp/examples/tests/ex40 -pc_type none vs output/ex40.out on the HIP path: default GMRES (no refinement step), PCNONE, ex2's 8 x 7

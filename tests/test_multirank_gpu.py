@@ -35,6 +35,7 @@ def test_mpiaij_two_ranks_one_gpu(built, nranks):
             assert "rank %d/2: golden ex5_5.out (two systems, GMRES + bjacobi + ILU(0), 2 ranks) ok=True" % k in out, out[-3000:]
             assert "rank %d/2: golden ex16_1.out (four right-hand sides, one KSP, GMRES + bjacobi + ILU(0), 2 ranks) ok=True" % k in out, out[-3000:]
             assert "rank %d/2: golden ex40.out (default GMRES, PCNONE, 2 ranks) ok=True" % k in out, out[-3000:]
+            assert "rank %d/2: golden ex7_1.out (block Jacobi, a different solver on every block, 2 ranks) ok=True" % k in out, out[-3000:]
 
 
 def test_mpiaij_four_ranks_in_the_partition_of_configs2(built):

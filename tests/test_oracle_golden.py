@@ -276,6 +276,23 @@ def test_tutorial_ex16_four_right_hand_sides_on_two_ranks_golden():
         assert "%g" % np.linalg.norm(x - u) == want[3] and int(want[5].rstrip(":")) == k and its == int(want[7]) == 9
 
 
+EX7_BLOCK_SOLVERS = [("bcgs", "none", 1e-6) if k % 2 == 0 else ("preonly", "ilu", 1e-5) for k in range(4)] + [("gmres", "jacobi", 1e-7)] * 4
+
+
+def test_tutorial_ex7_block_jacobi_with_a_different_solver_on_every_block_golden():
+    """src/ksp/ksp/examples/tutorials/ex7.c -ksp_monitor_short refine_always on 2 ranks (makefile:433) vs output/ex7_1.out: 8 x 10
+    grid, GMRES + block Jacobi with EIGHT blocks of ten rows (PCBJacobiSetTotalBlocks), the sub-solvers set block by block through
+    PCBJacobiGetSubKSP (ex7.c:173-195) -- rank 0's blocks alternately BiCGStab without a preconditioner (rtol 1e-6) and the default
+    ILU(0) application, rank 1's GMRES + Jacobi (rtol 1e-7).  Fourteen monitor lines and 'Norm of error 1.09983e-05 iterations 13':
+    the reference's golden for BiCGStab, GMRES and ILU(0) as INNER solvers."""
+    ai, aj, aa = pb.lap2d(8, 10)
+    u = np.ones(80)
+    x, h, its, reason = orc.ksp_solve(ai, aj, aa, orc.spmv(ai, aj, aa, u), ksp="gmres", pc="bjacobi", blocks=list(range(0, 81, 10)),
+                                      block_solvers=EX7_BLOCK_SOLVERS, refine_always=1)
+    pb.check_monitor(h, pb.parse_monitor(os.path.join(G, "ksp_tutorials", "ex7_1.out"))[0])
+    assert open(os.path.join(G, "ksp_tutorials", "ex7_1.out")).read().splitlines()[-1] == "Norm of error %g iterations %d" % (np.linalg.norm(x - u), its)
+
+
 def test_ksp_tests_ex40_gmres_without_refinement_and_without_a_preconditioner_golden():
     """src/ksp/ksp/examples/tests/ex40.c -pc_type none on 6 ranks (makefile:819) vs output/ex40.out: ex2's 8 x 7 operator, u = 1,
     rtol 1e-2 / 72, the DEFAULT GMRES -- classical Gram-Schmidt with no refinement step, the one form the other goldens (all

@@ -265,6 +265,41 @@ def main():
         ok40 = open(os.path.join(ROOT, "tests", "golden", "ksp_tests", "ex40.out")).read().strip() == "Norm of error %g iterations %d" % (xh.norm(), k40.its)
         print("rank %d/%d: golden ex40.out (default GMRES, PCNONE, 2 ranks) ok=%s" % (rank, world, ok40), flush=True)
         ok1 = ok1 and ok16 and ok40
+        # ---- ex7_1.out (tutorials/makefile:433: -n 2 ./ex7 -ksp_monitor_short refine_always) as the example runs it: 8 x 10 grid, eight
+        # blocks of ten rows, four per rank, each block's solver set after KSPSetUp through PCBJacobiGetSubKSP -- rank 0 alternately
+        # BiCGStab + PCNONE (rtol 1e-6) and the default ILU(0), rank 1 GMRES + Jacobi (rtol 1e-7)
+        g7 = pb.lap2d(8, 10)
+        r0_, r1_ = (0, 40) if rank == 0 else (40, 80)
+        li7, lj7, la7 = (g7[0][r0_:r1_ + 1] - g7[0][r0_]).astype(np.int32), g7[1][g7[0][r0_]:g7[0][r1_]].copy(), g7[2][g7[0][r0_]:g7[0][r1_]].copy()
+        A7 = P.Mat.from_csr_mpi(li7, lj7, la7, 40, 80, 80, comm=comm)
+        u7 = P.Vec.create(40, N=80, comm=comm); L.VecSet(u7.h, 1.0)
+        b7, x7 = u7.duplicate(), u7.duplicate()
+        A7.mult(u7, b7)
+        k7 = P.KSP(comm=comm); k7.set_operators(A7)
+        L.PetscOptionsClear()
+        L.PetscOptionsInsertString(b"-pc_type bjacobi -pc_bjacobi_blocks 8 -pc_bjacobi_merge_blocks 0 -ksp_gmres_cgs_refinement_type refine_always")
+        k7.set_from_options(); k7.record_history()
+        L.KSPSetUp(k7.h)
+        pc7, nloc7, first7, sub7 = C.c_void_p(), C.c_int(), C.c_int(), C.c_void_p()
+        L.KSPGetPC(k7.h, C.byref(pc7))
+        L.PCBJacobiGetSubKSP(pc7, C.byref(nloc7), C.byref(first7), C.byref(sub7))
+        subs7 = C.cast(sub7, C.POINTER(C.c_void_p))
+        for i7 in range(nloc7.value):
+            spc7 = C.c_void_p(); L.KSPGetPC(subs7[i7], C.byref(spc7))
+            if rank == 0 and i7 % 2:
+                L.PCSetType(spc7, b"ilu")
+            elif rank == 0:
+                L.PCSetType(spc7, b"none"); L.KSPSetType(subs7[i7], b"bcgs"); L.KSPSetTolerances(subs7[i7], 1e-6, P.PETSC_DEFAULT, P.PETSC_DEFAULT, int(P.PETSC_DEFAULT))
+            else:
+                L.PCSetType(spc7, b"jacobi"); L.KSPSetType(subs7[i7], b"gmres"); L.KSPSetTolerances(subs7[i7], 1e-7, P.PETSC_DEFAULT, P.PETSC_DEFAULT, int(P.PETSC_DEFAULT))
+        k7.solve(b7, x7)
+        L.PetscOptionsClear()
+        gold7 = open(os.path.join(ROOT, "tests", "golden", "ksp_tutorials", "ex7_1.out")).read().splitlines()
+        pb.check_monitor(k7.history(), pb.parse_monitor(os.path.join(ROOT, "tests", "golden", "ksp_tutorials", "ex7_1.out"))[0])
+        L.VecAXPY(x7.h, -1.0, u7.h)
+        ok7_ = (nloc7.value, first7.value) == (4, 4 * rank) and gold7[-1] == "Norm of error %g iterations %d" % (x7.norm(), k7.its)
+        print("rank %d/%d: golden ex7_1.out (block Jacobi, a different solver on every block, 2 ranks) ok=%s" % (rank, world, ok7_), flush=True)
+        ok1 = ok1 and ok7_
     print("rank %d/%d: MatMult bitexact=%s MatMultTranspose=%s norm=%s CG its=%d (oracle %d) hist=%s" % (rank, world, ok1, ok2, ok3, k.its, itsr, ok4), flush=True)
     dist.barrier()
     dist.destroy_process_group()
