@@ -30,6 +30,8 @@ def test_mpiaij_two_ranks_one_gpu(built, nranks):
         assert "rank %d/%d: plain KSPSolve_CG with the update calls deferred == launched one by one: True" % (k, nranks) in out, out[-3000:]
         assert "rank %d/%d: VecScatter INSERT / ADD / MAX, forward and reverse, bitexact=True" % (k, nranks) in out, out[-3000:]
         assert "rank %d/%d: MatDiagonalScale + MatScale then MatMult bitexact=True" % (k, nranks) in out, out[-3000:]
+        if nranks == 3:   # the reference's 3-rank golden of mat/tests/ex5 with -test_diagonalscale
+            assert "rank %d/3: golden ex5_33.out (MatMult, MatMultTranspose, MatGetDiagonal, MatDiagonalScale of MPIAIJ, 3 ranks) ok=True" % k in out, out[-3000:]
         if nranks == 2:   # the reference's own 2-rank golden, default preconditioner (block Jacobi + ILU(0))
             assert "rank %d/2: golden ex2_2.out (GMRES + bjacobi + ILU(0), 2 ranks) its=7 ok=True" % k in out, out[-3000:]
             assert "rank %d/2: golden ex5_5.out (two systems, GMRES + bjacobi + ILU(0), 2 ranks) ok=True" % k in out, out[-3000:]

@@ -69,6 +69,28 @@ def test_ex5_mpiaij():
         assert np.array_equal(fmt(out), gold[0])
         assert np.array_equal(fmt(outT), gold[1])
         assert np.array_equal(fmt(orc.get_diagonal(ai, aj, aa)), gold[-1])
+    # ex5_33.out (makefile:806: -n 3 -mat_type mpiaij -test_diagonalscale): the same products, then MatGetDiagonal and
+    # MatDiagonalScale(C, x = the diagonal, y = 1..n) through the pieces -- MatDiagonalScale_MPIAIJ (mpiaij.c:2012-2046) scales the
+    # diagonal block by (l, r local) and the off-diagonal block by (l, r scattered to the ghost columns)
+    import re
+    text = open(os.path.join(G, "ex5_33.out")).read()
+    gold = pb.parse_vecview(os.path.join(G, "ex5_33.out"))
+    views = [np.array([[float(v) for _, v in re.findall(r"\((\d+), ([-0-9.e+]+)\)", line)] for line in blk.splitlines() if line.startswith("row ")])
+             for blk in text.split("Matrix Object:")[1:]]
+    assert len(views) == 2 and np.array_equal(fmt(out), gold[0]) and np.array_equal(fmt(outT), gold[1])
+    diag = orc.get_diagonal(ai, aj, aa)
+    assert np.array_equal(fmt(diag), gold[2])
+    rvec = np.arange(1, n + 1, dtype=np.float64)
+    before, after = np.zeros((m, n)), np.zeros((m, n))
+    for r, p in enumerate(pieces):
+        lo, hi = int(ranges[r]), int(ranges[r + 1])
+        ad = orc.diagonal_scale(p["ad_i"], p["ad_j"], p["ad_a"], diag[lo:hi].copy(), rvec[lo:hi].copy())
+        bo = orc.diagonal_scale(p["bo_i"], p["bo_j"], p["bo_a"], diag[lo:hi].copy(), rvec[p["garray"]].copy())
+        for i in range(hi - lo):
+            sd, so = slice(p["ad_i"][i], p["ad_i"][i + 1]), slice(p["bo_i"][i], p["bo_i"][i + 1])
+            before[lo + i, lo + p["ad_j"][sd]] = p["ad_a"][sd]; before[lo + i, p["garray"][p["bo_j"][so]]] = p["bo_a"][so]
+            after[lo + i, lo + p["ad_j"][sd]] = ad[sd]; after[lo + i, p["garray"][p["bo_j"][so]]] = bo[so]
+    assert np.array_equal(fmt(before.ravel()).reshape(m, n), views[0]) and np.array_equal(fmt(after.ravel()).reshape(m, n), views[1])
 
 
 def test_pc_tests_ex2_cg_golden():

@@ -300,6 +300,41 @@ def main():
         ok7_ = (nloc7.value, first7.value) == (4, 4 * rank) and gold7[-1] == "Norm of error %g iterations %d" % (x7.norm(), k7.its)
         print("rank %d/%d: golden ex7_1.out (block Jacobi, a different solver on every block, 2 ranks) ok=%s" % (rank, world, ok7_), flush=True)
         ok1 = ok1 and ok7_
+    # ---- reference golden on 3 ranks: src/mat/examples/tests/ex5.c -mat_type mpiaij -test_diagonalscale (makefile:806) == output/ex5_33.out:
+    # MatMult, MatMultTranspose, MatGetDiagonal, then MatDiagonalScale(C, x = the diagonal, y = 1..n) -- every printed number; the scaled
+    # matrix is read back column by column through MatMult with unit vectors (one exact product per entry)
+    if world == 3:
+        import re
+        import problems as pb
+        fmt5 = lambda v: np.array([float("%g" % t) for t in v])  # noqa: E731
+        g5i, g5j, g5a, m5, n5 = pb.ex5_mat(8)
+        rng5 = [0, 3, 6, 8]
+        lo5, hi5 = rng5[rank], rng5[rank + 1]
+        C5 = P.Mat.from_csr_mpi((g5i[lo5:hi5 + 1] - g5i[lo5]).astype(np.int32), g5j[g5i[lo5]:g5i[hi5]].copy(), g5a[g5i[lo5]:g5i[hi5]].copy(), hi5 - lo5, m5, n5, comm=comm)
+        text5 = open(os.path.join(ROOT, "tests", "golden", "ex5_33.out")).read()
+        gold5 = pb.parse_vecview(os.path.join(ROOT, "tests", "golden", "ex5_33.out"))
+        views5 = [np.array([[float(v) for _, v in re.findall(r"\((\d+), ([-0-9.e+]+)\)", line)] for line in blk.splitlines() if line.startswith("row ")])
+                  for blk in text5.split("Matrix Object:")[1:]]
+        y5 = P.Vec.from_array(np.arange(lo5, hi5, dtype=np.float64), comm=comm, N=n5); x5 = y5.duplicate()
+        C5.mult(y5, x5)
+        ok33 = np.array_equal(fmt5(x5.array()), gold5[0][lo5:hi5])
+        x5.set_array(np.arange(lo5, hi5, dtype=np.float64))
+        L.MatMultTranspose(C5.h, x5.h, y5.h)
+        ok33 = ok33 and np.array_equal(fmt5(y5.array()), gold5[1][lo5:hi5])
+        L.MatGetDiagonal(C5.h, x5.h)
+        ok33 = ok33 and np.array_equal(fmt5(x5.array()), gold5[2][lo5:hi5])
+        y5.set_array(np.arange(lo5 + 1, hi5 + 1, dtype=np.float64))
+        L.MatDiagonalScale(C5.h, x5.h, y5.h)
+        e5, c5 = y5.duplicate(), x5.duplicate()
+        for j5 in range(n5):
+            unit = np.zeros(hi5 - lo5)
+            if lo5 <= j5 < hi5:
+                unit[j5 - lo5] = 1.0
+            e5.set_array(unit)
+            C5.mult(e5, c5)
+            ok33 = ok33 and np.array_equal(fmt5(c5.array()), views5[1][lo5:hi5, j5])
+        print("rank %d/%d: golden ex5_33.out (MatMult, MatMultTranspose, MatGetDiagonal, MatDiagonalScale of MPIAIJ, 3 ranks) ok=%s" % (rank, world, ok33), flush=True)
+        ok1 = ok1 and ok33
     print("rank %d/%d: MatMult bitexact=%s MatMultTranspose=%s norm=%s CG its=%d (oracle %d) hist=%s" % (rank, world, ok1, ok2, ok3, k.its, itsr, ok4), flush=True)
     dist.barrier()
     dist.destroy_process_group()
