@@ -307,6 +307,7 @@ PetscErrorCode KSPSetFromOptions(KSP ksp);   /* -ksp_type -ksp_rtol -ksp_atol -k
 PetscErrorCode KSPGMRESSetRestart(KSP ksp, PetscInt restart);
 PetscErrorCode KSPGMRESSetCGSRefinementType(KSP ksp, KSPGMRESCGSRefinementType type);
 PetscErrorCode KSPSetUp(KSP ksp);
+PetscErrorCode KSPSetUpOnBlocks(KSP ksp);
 PetscErrorCode KSPSolve(KSP ksp, Vec b, Vec x);
 PetscErrorCode KSPGetIterationNumber(KSP ksp, PetscInt *its);
 PetscErrorCode KSPGetResidualNorm(KSP ksp, PetscReal *rnorm);

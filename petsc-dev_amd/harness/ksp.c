@@ -216,13 +216,21 @@ PetscErrorCode KSPSetUp(KSP ksp) {   /* itfunc.c:175 */
   return 0;
 }
 
+PetscErrorCode KSPSetUpOnBlocks(KSP ksp) {   /* itfunc.c:147-156 */
+  PetscErrorCode ierr;
+  KSPValid(ksp);
+  if (!ksp->pc) return 0;
+  ierr = PCSetUpOnBlocks(ksp->pc);CHKERRQ(ierr);
+  return 0;
+}
+
 PetscErrorCode KSPSolve(KSP ksp, Vec b, Vec x) {   /* itfunc.c:335 */
   PetscErrorCode ierr;
   KSPValid(ksp);
   if (b == x) SETERRQ(ksp->comm, PETSC_ERR_SUP, "in-place solve (b == x) is outside the ported path");
   ksp->vec_rhs = b; ksp->vec_sol = x;
   ierr = KSPSetUp(ksp);CHKERRQ(ierr);
-  ierr = PCSetUpOnBlocks(ksp->pc);CHKERRQ(ierr);                       /* KSPSetUpOnBlocks, itfunc.c:377 */
+  ierr = KSPSetUpOnBlocks(ksp);CHKERRQ(ierr);                          /* itfunc.c:377 */
   if (ksp->guess_zero) { ierr = VecSet(ksp->vec_sol, 0.0);CHKERRQ(ierr); }
   if (ksp->res_hist_reset) ksp->res_hist_len = 0;
   ksp->reason = KSP_CONVERGED_ITERATING;
