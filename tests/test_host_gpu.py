@@ -80,6 +80,22 @@ def test_vec_ops_through_function_table(P):
     assert e.value.code == 75
 
 
+def test_vec_tests_ex18_dot_known_answer(P):
+    """src/vec/vec/examples/tests/ex18.c vs output/ex18_1.out on HIPMI355X vectors: VecDot (and VecTDot, VecMDot's first entry) of
+    the example's two 15-entry vectors, printed with %16.12e"""
+    import ctypes as C
+    from test_oracle_golden import ex18_vectors
+    L = P.lib()
+    xa, ya = ex18_vectors()
+    x, y = V(P, xa), V(P, ya)
+    want = open(os.path.join(G, "vec_tests", "ex18_1.out")).read().strip()
+    assert want == "Vector inner product %16.12e" % x.dot(y)
+    t = C.c_double(); L.VecTDot(x.h, y.h, C.byref(t))
+    tab = (C.c_void_p * 1)(y.h.value); d1 = (C.c_double * 1)()
+    L.VecMDot(x.h, 1, tab, d1)
+    assert want == "Vector inner product %16.12e" % t.value == "Vector inner product %16.12e" % d1[0]
+
+
 def test_vec_tutorial_ex1_golden(P):
     """src/vec/vec/examples/tutorials/ex1.c replayed on HIPMI355X vectors (n = 20): VecSet, Dot, MDot, Scale, Copy, AXPY,
     AYPX, Swap, WAXPY, PointwiseMult, PointwiseDivide, MAXPY and the norms in between, printed as the example prints

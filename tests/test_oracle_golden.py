@@ -327,6 +327,20 @@ def test_ksp_tests_ex40_gmres_without_refinement_and_without_a_preconditioner_go
     assert open(os.path.join(G, "ksp_tests", "ex40.out")).read().strip() == "Norm of error %g iterations %d" % (np.linalg.norm(x - u), its)
 
 
+def ex18_vectors(n=15):
+    """src/vec/vec/examples/tests/ex18.c:20-27: x_i = i + 1 / (i + .35), y_i = x_i + 1.375547826473644376"""
+    i = np.arange(n, dtype=np.float64)
+    x = i + 1.0 / (i + .35)
+    return x, x + 1.375547826473644376
+
+
+def test_vec_tests_ex18_dot_known_answer():
+    """src/vec/vec/examples/tests/ex18.c ('Compares BLAS dots on different machines') vs output/ex18_1.out: VecDot of two 15-entry
+    vectors printed with %16.12e"""
+    x, y = ex18_vectors()
+    assert open(os.path.join(G, "vec_tests", "ex18_1.out")).read().strip() == "Vector inner product %16.12e" % orc.vec_dot(x, y)
+
+
 def test_threaded_cpu_baseline_matches_the_sequential_oracle():
     """bench.py's cpu_baseline loop (one thread per block of rows, partial sums added in rank order -- the reference's
     MPI arrangement inside one process) computes the same CG + Jacobi iterates as the sequential oracle, to the
