@@ -27,6 +27,7 @@ def test_mpiaij_two_ranks_one_gpu(built, nranks):
         assert "rank %d/%d: transport=host-staged rccl_ranks=0 rccl_communicators=0" % (k, nranks) in out, out[-3000:]
         assert "rank %d/%d: MatMult bitexact=True MatMultTranspose=True norm=True" % (k, nranks) in out, out[-3000:]
         assert "rank %d/%d: irregular MatMult bitexact=True MatMultTranspose bitexact=True" % (k, nranks) in out, out[-3000:]
+        assert "rank %d/%d: irregular MatMult through the column-tiled kernel bitexact=True MatMultTranspose bitexact=True" % (k, nranks) in out, out[-3000:]
         assert "rank %d/%d: plain KSPSolve_CG with the update calls deferred == launched one by one: True" % (k, nranks) in out, out[-3000:]
         assert "rank %d/%d: VecScatter INSERT / ADD / MAX, forward and reverse, bitexact=True" % (k, nranks) in out, out[-3000:]
         assert "rank %d/%d: MatDiagonalScale + MatScale then MatMult bitexact=True" % (k, nranks) in out, out[-3000:]

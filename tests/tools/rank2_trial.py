@@ -122,6 +122,18 @@ def main():
                 reft[g - rs] = reft[g - rs] + lv[i_]
     ok6 = np.array_equal(vy.array().view(np.uint64), reft.view(np.uint64))
     print("rank %d/%d: irregular MatMult bitexact=%s MatMultTranspose bitexact=%s" % (rank, world, ok5, ok6), flush=True)
+    # the same matrix with its diagonal block's product (and the cached transpose's) run by the column-tiled kernel, every (panel, tile)
+    # pair staged (-mat_hipmi355x_tiled 1 -mat_hipmi355x_tiled_stage_min 1): a row's products are then added in column order, the reference's
+    L.PetscOptionsClear(); L.PetscOptionsInsertString(b"-mat_hipmi355x_tiled 1 -mat_hipmi355x_tiled_stage_min 1")
+    Bt = P.Mat.from_csr_mpi(li, sj[si[rs]:si[re_]].copy(), sa[si[rs]:si[re_]].copy(), re_ - rs, NI, NI, comm=comm)
+    vx.set_array(xi[rs:re_].copy())
+    Bt.mult(vx, vy)
+    ok5t = np.array_equal(vy.array().view(np.uint64), ref.view(np.uint64))
+    L.MatMultTranspose(Bt.h, vx.h, vy.h)
+    ok6t = np.array_equal(vy.array().view(np.uint64), reft.view(np.uint64))
+    L.PetscOptionsClear()
+    print("rank %d/%d: irregular MatMult through the column-tiled kernel bitexact=%s MatMultTranspose bitexact=%s" % (rank, world, ok5t, ok6t), flush=True)
+    ok5, ok6 = ok5 and ok5t, ok6 and ok6t
     # ---- the matrix's VecScatter by itself, every InsertMode in both directions (UnPack_1's INSERT / ADD / MAX, vpscat.c:503-534):
     # forward: ghost slot i receives x[garray[i]] from its owner; reverse: owned entry g receives, neighbour after neighbour in rank
     # order, what every rank holds in its ghost slot for g.  Bit for bit (max and a single addition per step are exact operations
